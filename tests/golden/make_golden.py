@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the REFERENCE model classes.
+
+Runs only in the development container (needs /root/reference, read-only).  The
+reference's ``<Model>/main.py`` files are imported in place with the stand-in
+``freerec`` of ``_freerec_standin.py`` on ``sys.modules``; nothing of the
+reference's source enters this repository -- only inputs/outputs (``*.npz``).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic):
+  sasrec_bce.npz / sasrec_bpr.npz / sasrec_ce.npz : SASRec/main.py  fit loss, every param grad,
+        recommend_from_full scores, encode() output, masked top-K (Coach.evaluate contract,
+        UniSRec/main.py:400-447)
+  mfbpr.npz    : MF-BPR/main.py   fit loss + table grads + full scores
+  lightgcn.npz : LightGCN/main.py encode/fit (rec_loss, emb_loss) + grads + full scores
+  deepfm.npz   : DeepFM/main.py   logits, loss, grads (train-mode BN), eval sigmoid scores
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _freerec_standin as standin  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_ref(model_dir, modname, overrides):
+    fr, mods = standin.build(argv_defaults=overrides)
+    for k in list(sys.modules):
+        if k == "freerec" or k.startswith("freerec."):
+            del sys.modules[k]
+    sys.modules.update(mods)
+    argv = sys.argv
+    sys.argv = ["main.py"]
+    try:
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, model_dir, "main.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return fr, mod
+
+
+def sd_np(model):
+    return {"param/" + k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()
+            if not v.is_sparse and v.layout == torch.strided}
+
+
+def grads_np(model):
+    return {"grad/" + k: (p.grad.detach().cpu().numpy().copy() if p.grad is not None
+                          else np.zeros(tuple(p.shape), np.float32))
+            for k, p in model.named_parameters()}
+
+
+def make_seqs(g, B, S, N, min_len=1):
+    """Left-padded item sequences (ids +1, 0 = pad), IPos/INeg 0-based, 0 on pads.
+    Row contract: HSTU/sampler.py:54-62 + SASRec/main.py:143-157."""
+    lens = torch.randint(min_len, S, (B,), generator=g)
+    lens[0] = S  # one full-length row
+    lens[1] = 1  # one single-item row
+    seq = torch.zeros(B, S, dtype=torch.long)
+    pos = torch.zeros(B, S, dtype=torch.long)
+    neg = torch.zeros(B, S, dtype=torch.long)
+    for b in range(B):
+        L = int(lens[b])
+        seq[b, S - L:] = torch.randint(0, N, (L,), generator=g) + 1
+        pos[b, S - L:] = torch.randint(0, N, (L,), generator=g)
+        neg[b, S - L:] = torch.randint(0, N, (L,), generator=g)
+    return seq, pos, neg
+
+
+def masked_topk(scores, seen_lists, K):
+    """Coach.evaluate full-ranking contract (UniSRec/main.py:408-414): scores[seen] = -1e23, then top-K."""
+    s = scores.clone()
+    for b, items in enumerate(seen_lists):
+        s[b, torch.as_tensor(items, dtype=torch.long)] = -1e23
+    vals, idx = torch.topk(s, K, dim=1)
+    return s, vals, idx
+
+
+def ragged_np(lists):
+    ptr = np.zeros(len(lists) + 1, np.int64)
+    ptr[1:] = np.cumsum([len(x) for x in lists])
+    flat = np.concatenate([np.asarray(x, np.int64) for x in lists]) if ptr[-1] else np.zeros(0, np.int64)
+    return ptr, flat
+
+
+def gen_sasrec(loss):
+    torch.manual_seed(1)
+    fr, ref = import_ref("SASRec", f"ref_sasrec_{loss}", dict(dropout_rate=0.0, loss=loss))
+    N, B, S = 200, 8, ref.cfg.maxlen
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=40), F("ITEM", "ITEM", "ID", count=N)])
+    model = ref.SASRec(ds)
+    # make biases / LN affine non-trivial so they are actually exercised
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias") or "LN" in n:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    seq, pos, neg = make_seqs(g, B, S, N)
+    data = {model.ISeq: seq, model.IPos: pos, model.INeg: neg}
+    out = {"in/seq": seq.numpy(), "in/pos": pos.numpy(), "in/neg": neg.numpy(),
+           "cfg/N": np.int64(N), "cfg/D": np.int64(ref.cfg.embedding_dim),
+           "cfg/num_blocks": np.int64(ref.cfg.num_blocks)}
+    out.update(sd_np(model))
+    model.train()
+    losses = model(data)
+    losses["rec_loss"].backward()
+    out["out/rec_loss"] = losses["rec_loss"].detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        userEmbds, itemEmbds = model.encode(data)
+        scores = model(data, ranking="full")
+    out["out/userEmbds"] = userEmbds.numpy()
+    out["out/scores"] = scores.numpy()
+    seen = [sorted(set((seq[b][seq[b] > 0] - 1).tolist())) for b in range(B)]
+    sp, si = ragged_np(seen)
+    _, vals, idx = masked_topk(scores, seen, 50)
+    out.update({"in/seen_ptr": sp, "in/seen_idx": si, "out/topk_vals": vals.numpy(), "out/topk_idx": idx.numpy()})
+    np.savez_compressed(os.path.join(HERE, f"sasrec_{loss.lower()}.npz"), **out)
+    print(f"sasrec_{loss.lower()}: loss={float(out['out/rec_loss']):.6f}")
+
+
+def gen_mfbpr():
+    torch.manual_seed(1)
+    fr, ref = import_ref("MF-BPR", "ref_mfbpr", {})
+    U, N, B = 50, 80, 16
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)])
+    model = ref.MF(ds)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():  # std=1e-4 init gives ~ln2 everywhere; spread values so the test is sharp
+        for p in model.parameters():
+            p.copy_(0.3 * torch.randn(p.shape, generator=g))
+    users = torch.randint(0, U, (B, 1), generator=g)
+    users[1] = users[0]  # duplicate user -> colliding scatter-add
+    ipos = torch.randint(0, N, (B, 1), generator=g)
+    ineg = torch.randint(0, N, (B, 1), generator=g)
+    ineg[2] = ipos[3]  # same row hit through both tables' index lists
+    data = {model.User: users, model.IPos: ipos, model.INeg: ineg}
+    out = {"in/users": users.numpy(), "in/pos": ipos.numpy(), "in/neg": ineg.numpy()}
+    out.update(sd_np(model))
+    model.train()
+    loss = model(data)["rec_loss"]
+    loss.backward()
+    out["out/rec_loss"] = loss.detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        model.reset_ranking_buffers()
+        scores = model(data, ranking="full")
+    out["out/scores"] = scores.numpy()
+    np.savez_compressed(os.path.join(HERE, "mfbpr.npz"), **out)
+    print(f"mfbpr: loss={float(loss):.6f}")
+
+
+def sym_norm_adj(U, N, edges):
+    """Bipartite D^-1/2 A D^-1/2 as CSR (no self loops; NGCF/main.py:76-87 adds them explicitly,
+    so the default `to_normalized_adj('sym')` does not)."""
+    n = U + N
+    A = torch.zeros(n, n)
+    for u, i in edges:
+        A[u, U + i] = 1.0
+        A[U + i, u] = 1.0
+    deg = A.sum(1)
+    dinv = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+    A = dinv[:, None] * A * dinv[None, :]
+    return A.to_sparse_csr()
+
+
+def gen_lightgcn():
+    torch.manual_seed(1)
+    U, N, B = 30, 40, 16
+    g = torch.Generator().manual_seed(5)
+    edges = set()
+    while len(edges) < 150:
+        edges.add((int(torch.randint(0, U, (1,), generator=g)), int(torch.randint(0, N, (1,), generator=g))))
+    adj = sym_norm_adj(U, N, sorted(edges))
+    fr, ref = import_ref("LightGCN", "ref_lightgcn", {})
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)], adj=adj)
+    model = ref.LightGCN(ds)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(0.3 * torch.randn(p.shape, generator=g))
+    users = torch.randint(0, U, (B, 1), generator=g)
+    ipos = torch.randint(0, N, (B, 1), generator=g)
+    ineg = torch.randint(0, N, (B, 1), generator=g)
+    data = {model.User: users, model.IPos: ipos, model.INeg: ineg}
+    out = {"in/users": users.numpy(), "in/pos": ipos.numpy(), "in/neg": ineg.numpy(),
+           "in/adj_crow": adj.crow_indices().numpy(), "in/adj_col": adj.col_indices().numpy(),
+           "in/adj_val": adj.values().numpy(), "cfg/num_layers": np.int64(ref.cfg.num_layers),
+           "cfg/weight_decay": np.float64(ref.cfg.weight_decay)}
+    out.update({"param/User.embeddings.weight": model.User.embeddings.weight.detach().numpy().copy(),
+                "param/Item.embeddings.weight": model.Item.embeddings.weight.detach().numpy().copy()})
+    model.train()
+    losses = model(data)
+    # CoachForLightGCN.train_per_epoch (LightGCN/main.py:160)
+    loss = losses["rec_loss"] + ref.cfg.weight_decay * losses["emb_loss"]
+    loss.backward()
+    out["out/rec_loss"] = losses["rec_loss"].detach().numpy()
+    out["out/emb_loss"] = losses["emb_loss"].detach().numpy()
+    out["out/loss"] = loss.detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        ue, ie = model.encode()
+        model.reset_ranking_buffers()
+        scores = model(data, ranking="full")
+    out["out/userEmbds"], out["out/itemEmbds"], out["out/scores"] = ue.numpy(), ie.numpy(), scores.numpy()
+    np.savez_compressed(os.path.join(HERE, "lightgcn.npz"), **out)
+    print(f"lightgcn: rec={float(losses['rec_loss']):.6f} emb={float(losses['emb_loss']):.6f}")
+
+
+def gen_deepfm():
+    torch.manual_seed(1)
+    fr, ref = import_ref("DeepFM", "ref_deepfm",
+                         dict(hidden_dims="32,24,16", batch_norm=True, hidden_dropout_rate=0.0))
+    counts = [23, 41, 7, 7, 2, 3, 2, 9, 17, 29]
+    F = fr.data.fields.Field
+    fields = [F(f"F{i}", "EMBED", *(("USER", "ID") if i == 0 else ("ITEM", "ID") if i == 1 else ()), count=c)
+              for i, c in enumerate(counts)]
+    fields.append(F("LABEL", "LABEL"))
+    ds = fr.data.datasets.RecDataSet(fields)
+    model = ref.DeepFM(ds)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "embeddings" in n:
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    B = 32
+    data = {f: torch.randint(0, f.count, (B, 1), generator=g) for f in model.input_fields}
+    labels = torch.randint(0, 2, (B, 1), generator=g)
+    data[model.Label] = labels
+    out = {"in/x": torch.cat([data[f] for f in model.input_fields], 1).numpy(), "in/labels": labels.numpy(),
+           "cfg/counts": np.asarray(counts, np.int64)}
+    out.update(sd_np(model))
+    model.train()
+    logits = model.encode(data)
+    out["out/train_logits"] = logits.detach().numpy().copy()
+    loss = model.criterion(logits, labels)
+    loss.backward()
+    out["out/rec_loss"] = loss.detach().numpy()
+    out.update(grads_np(model))
+    # running stats were updated by the train-mode forward; save post-step buffers for the eval pass
+    out.update({"post/" + k: v.detach().numpy().copy() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k})
+    # canonical per-field names (the nn.Module aliasing of Field objects yields duplicate state_dict keys)
+    out = {k: v for k, v in out.items() if "input_fields" not in k and "/User." not in k and "/Item." not in k}
+    for i, f in enumerate(model.input_fields):
+        out[f"table/{i}"] = f.embeddings.weight.detach().numpy().copy()
+        out[f"table_lr/{i}"] = f.embeddings_lr.weight.detach().numpy().copy()
+        out[f"gtable/{i}"] = f.embeddings.weight.grad.numpy().copy()
+        out[f"gtable_lr/{i}"] = f.embeddings_lr.weight.grad.numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        out["out/eval_scores"] = model(data, ranking="pool").numpy()
+    np.savez_compressed(os.path.join(HERE, "deepfm.npz"), **out)
+    print(f"deepfm: loss={float(loss):.6f}")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    for loss in ("BCE", "BPR", "CE"):
+        gen_sasrec(loss)
+    gen_mfbpr()
+    gen_lightgcn()
+    gen_deepfm()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,214 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the REFERENCE classes
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import adam, criterions, deepfm, embedding, lightgcn, mf, ranking, sasrec
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+torch.set_num_threads(2)
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def T(a, grad=False):
+    t = torch.from_numpy(np.array(a))
+    return t.requires_grad_(grad) if grad else t
+
+
+# ------------------------------------------------------------------ SASRec
+@pytest.mark.parametrize("loss", ["BCE", "BPR", "CE"])
+def test_sasrec_fit_loss_and_grads(loss):
+    z = load(f"sasrec_{loss.lower()}")
+    P = sasrec.params_from_npz(z, requires_grad=True)
+    L = sasrec.fit(P, T(z["in/seq"]), T(z["in/pos"]), T(z["in/neg"]), loss=loss, num_blocks=int(z["cfg/num_blocks"]))
+    np.testing.assert_allclose(L.item(), float(z["out/rec_loss"]), rtol=2e-6)
+    L.backward()
+    for k in z.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        g = P[name].grad
+        g = torch.zeros_like(P[name]) if g is None else g
+        ref = z[k]
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(g.numpy() - ref).max() <= 2e-5 * scale + 1e-7, name
+
+
+def test_sasrec_encode_scores_topk():
+    z = load("sasrec_bce")
+    P = sasrec.params_from_npz(z)
+    seq = T(z["in/seq"])
+    with torch.no_grad():
+        u, items = sasrec.encode(P, seq, int(z["cfg/num_blocks"]))
+        sc = sasrec.recommend_from_full(P, seq, int(z["cfg/num_blocks"]))
+    np.testing.assert_allclose(u.numpy(), z["out/userEmbds"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(sc.numpy(), z["out/scores"], rtol=1e-4, atol=2e-5)
+    # C oracle (fmaf chain + ties->lowest index) against the reference's torch.topk after scores[seen] = -1e23
+    q = u[:, -1, :].numpy()
+    vals, idx = ranking.score_topk(q, items.numpy(), z["in/seen_ptr"], z["in/seen_idx"], 50)
+    np.testing.assert_array_equal(idx, z["out/topk_idx"])        # bit-exact top-K indices
+    np.testing.assert_allclose(vals, z["out/topk_vals"], rtol=1e-4, atol=2e-5)
+    dense = ranking.score_dense(q, items.numpy())
+    np.testing.assert_allclose(dense, z["out/scores"], rtol=1e-4, atol=2e-5)
+
+
+def test_sasrec_embed_matches_reference_frontend():
+    z = load("sasrec_bce")
+    x = embedding.sasrec_embed(z["param/Item.embeddings.weight"], z["param/Position.weight"], z["in/seq"])
+    E, Pm, seq = T(z["param/Item.embeddings.weight"]), T(z["param/Position.weight"]), T(z["in/seq"])
+    ref = (E[seq] * 8.0 + Pm[None]).masked_fill((seq == 0)[..., None], 0.0)
+    np.testing.assert_array_equal(x, ref.numpy())
+    # dense embedding grad == scatter_add of the upstream rows, padding row zero
+    g = np.random.default_rng(0).standard_normal((8, 50, 64)).astype(np.float32)
+    Eg = T(z["param/Item.embeddings.weight"], True)
+    torch.nn.functional.embedding(seq, Eg, padding_idx=0).backward(T(g))
+    mine = embedding.scatter_add_rows(g, z["in/seq"], 201, padding_idx=0)
+    np.testing.assert_allclose(mine, Eg.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(mine, embedding.scatter_add_rows_fast(g, z["in/seq"], 201, 0))
+    np.testing.assert_array_equal(mine, ranking.scatter_add_rows_c(g, z["in/seq"], 201, 0))
+    np.testing.assert_array_equal(embedding.gather_rows(z["param/Item.embeddings.weight"], z["in/seq"]),
+                                  ranking.gather_rows_c(z["param/Item.embeddings.weight"], z["in/seq"]))
+
+
+# ------------------------------------------------------------------ MF-BPR / LightGCN
+def test_mfbpr():
+    z = load("mfbpr")
+    U, I = T(z["param/User.embeddings.weight"], True), T(z["param/Item.embeddings.weight"], True)
+    users, pos, neg = T(z["in/users"]), T(z["in/pos"]), T(z["in/neg"])
+    L = mf.fit(U, I, users, pos, neg)
+    np.testing.assert_allclose(L.item(), float(z["out/rec_loss"]), rtol=1e-6)
+    L.backward()
+    np.testing.assert_allclose(U.grad.numpy(), z["grad/User.embeddings.weight"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(I.grad.numpy(), z["grad/Item.embeddings.weight"], rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        sc = mf.recommend_from_full(U, I, users)
+    np.testing.assert_allclose(sc.numpy(), z["out/scores"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ranking.score_dense(U.detach().numpy()[z["in/users"][:, 0]], I.detach().numpy()),
+                               z["out/scores"], rtol=1e-5, atol=1e-6)
+
+
+def test_lightgcn():
+    z = load("lightgcn")
+    U, I = T(z["param/User.embeddings.weight"], True), T(z["param/Item.embeddings.weight"], True)
+    crow, col, val = z["in/adj_crow"], z["in/adj_col"], z["in/adj_val"]
+    users, pos, neg = T(z["in/users"]), T(z["in/pos"]), T(z["in/neg"])
+    rec, emb = lightgcn.fit(U, I, crow, col, val, users, pos, neg, int(z["cfg/num_layers"]))
+    np.testing.assert_allclose(rec.item(), float(z["out/rec_loss"]), rtol=2e-6)
+    np.testing.assert_allclose(emb.item(), float(z["out/emb_loss"]), rtol=2e-6)
+    (rec + float(z["cfg/weight_decay"]) * emb).backward()
+    np.testing.assert_allclose(U.grad.numpy(), z["grad/User.embeddings.weight"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(I.grad.numpy(), z["grad/Item.embeddings.weight"], rtol=2e-5, atol=1e-7)
+    with torch.no_grad():
+        ue, ie = lightgcn.encode(U, I, crow, col, val, int(z["cfg/num_layers"]))
+    np.testing.assert_allclose(ue.numpy(), z["out/userEmbds"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ie.numpy(), z["out/itemEmbds"], rtol=1e-5, atol=1e-6)
+
+
+def test_lightgcn_adj_builder_matches_golden_adj():
+    z = load("lightgcn")
+    crow, col, val = z["in/adj_crow"], z["in/adj_col"], z["in/adj_val"]
+    U, N = 30, 40
+    rows = np.repeat(np.arange(U + N), np.diff(crow))
+    m = rows < U
+    c2, k2, v2 = lightgcn.sym_normalized_adj(U, N, rows[m], col[m] - U)
+    np.testing.assert_array_equal(c2, crow)
+    np.testing.assert_array_equal(k2, col)
+    np.testing.assert_allclose(v2, val, rtol=1e-6)
+
+
+# ------------------------------------------------------------------ DeepFM
+def _deepfm_params(z, grad):
+    nf = len(z["cfg/counts"])
+    tables = [T(z[f"table/{i}"], grad) for i in range(nf)]
+    tables_lr = [T(z[f"table_lr/{i}"], grad) for i in range(nf)]
+    mlp = []
+    i = 0
+    while f"param/dnn.{i}.linear.weight" in z.files:
+        mlp.append({k: T(z[f"param/dnn.{i}.{k}"], grad and "running" not in k)
+                    for k in ("linear.weight", "linear.bias", "bn.weight", "bn.bias", "bn.running_mean", "bn.running_var")})
+        i += 1
+    mlp.append({"weight": T(z[f"param/dnn.{i}.weight"], grad), "bias": T(z[f"param/dnn.{i}.bias"], grad)})
+    return tables, tables_lr, T(z["param/fm.lr_layer.bias"], grad), mlp
+
+
+def test_deepfm():
+    z = load("deepfm")
+    tables, tables_lr, lrb, mlp = _deepfm_params(z, True)
+    x, y = T(z["in/x"]), T(z["in/labels"])
+    logits = deepfm.encode(tables, tables_lr, lrb, mlp, x, training=True)
+    np.testing.assert_allclose(logits.detach().numpy(), z["out/train_logits"], rtol=1e-4, atol=1e-5)
+    L = criterions.bce_with_logits(logits, y)
+    np.testing.assert_allclose(L.item(), float(z["out/rec_loss"]), rtol=1e-5)
+    L.backward()
+    for i, t in enumerate(tables):
+        np.testing.assert_allclose(t.grad.numpy(), z[f"gtable/{i}"], rtol=1e-3, atol=2e-6)
+        np.testing.assert_allclose(tables_lr[i].grad.numpy(), z[f"gtable_lr/{i}"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(mlp[0]["linear.weight"].grad.numpy(), z["grad/dnn.0.linear.weight"], rtol=1e-3, atol=2e-6)
+    # eval pass uses the running stats as updated by the train-mode forward
+    for i in range(len(mlp) - 1):
+        mlp[i]["bn.running_mean"] = T(z[f"post/dnn.{i}.bn.running_mean"])
+        mlp[i]["bn.running_var"] = T(z[f"post/dnn.{i}.bn.running_var"])
+    with torch.no_grad():
+        sc = torch.sigmoid(deepfm.encode(tables, tables_lr, lrb, mlp, x, training=False))
+    np.testing.assert_allclose(sc.numpy(), z["out/eval_scores"], rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------ criteria / metrics / adam known answers
+def test_criteria_known_answers():
+    z = torch.zeros(7)
+    assert abs(criterions.bpr_loss(z, z).item() - np.log(2)) < 1e-7          # untrained BPR = ln 2
+    assert abs(criterions.bce_with_logits(z, torch.ones(7)).item() - np.log(2)) < 1e-7
+    assert criterions.regularize_l2([torch.ones(3, 2)]).item() == 3.0
+
+
+def test_metric_known_answers():
+    rng = np.random.default_rng(0)
+    B, N = 64, 300
+    scores = rng.standard_normal((B, N)).astype(np.float32)
+    tgt = rng.integers(0, N, B)
+    targets = np.zeros((B, N), np.float32)
+    targets[np.arange(B), tgt] = 1
+    m = ranking.metrics_dense(scores, targets)
+    np.testing.assert_array_equal(m["HITRATE@1"], m["NDCG@1"])               # one target per user
+    for k in (5, 10, 20, 50):
+        assert (m[f"NDCG@{k}"] <= m[f"HITRATE@{k}"] + 1e-12).all()
+        assert (m[f"NDCG@{k}"] >= m[f"HITRATE@{k}"] / np.log2(k + 1) - 1e-12).all()
+        np.testing.assert_allclose(m[f"RECALL@{k}"], m[f"HITRATE@{k}"])
+        np.testing.assert_allclose(m[f"PRECISION@{k}"], m[f"HITRATE@{k}"] / k)
+    rank = (scores > scores[np.arange(B), tgt][:, None]).sum(1)
+    np.testing.assert_allclose(m["HITRATE@10"], (rank < 10).astype(float))
+    np.testing.assert_allclose(m["NDCG@10"], np.where(rank < 10, 1 / np.log2(rank + 2.0), 0.0))
+    np.testing.assert_allclose(m["MRR@10"], np.where(rank < 10, 1 / (rank + 1.0), 0.0))
+
+
+def test_topk_ties_and_short_catalog():
+    Q = np.ones((2, 4), np.float32)
+    E = np.zeros((6, 4), np.float32)
+    E[[1, 3, 4]] = 1.0          # three-way tie at 4.0, three-way tie at 0.0
+    vals, idx = ranking.score_topk(Q, E, np.array([0, 1, 1]), np.array([3]), 5)
+    np.testing.assert_array_equal(idx[1], [1, 3, 4, 0, 2])                  # ties -> lowest index
+    np.testing.assert_array_equal(idx[0], [1, 4, 0, 2, 5])                  # item 3 masked for user 0
+    vals, idx = ranking.score_topk(Q, E, np.array([0, 5, 5]), np.array([0, 1, 2, 3, 4]), 4)
+    np.testing.assert_array_equal(idx[0], [5, 0, 1, 2])                     # K > #unmasked: masked fill by index
+    assert vals[0, 1] == np.float32(-1e23)
+
+
+def test_adam_matches_torch():
+    rng = np.random.default_rng(1)
+    p0 = rng.standard_normal((50, 8)).astype(np.float32)
+    tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([tp], lr=5e-4, betas=(0.9, 0.999), weight_decay=1e-6)
+    p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for step in range(1, 6):
+        g = rng.standard_normal(p0.shape).astype(np.float32)
+        g[::3] = 0                                       # rows with zero grad still move (dense semantics)
+        tp.grad = torch.from_numpy(g.copy())
+        opt.step()
+        adam.adam_step(p, g, m, v, step, 5e-4, 0.9, 0.999, 1e-8, 1e-6)
+        np.testing.assert_allclose(p, tp.detach().numpy(), rtol=1e-5, atol=1e-7)
