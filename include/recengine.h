@@ -1,0 +1,135 @@
+/* recengine -- C ABI of the MI355X-native embedding-and-scoring engine (librecengine.so).
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json `north_star`: every entry point
+ * replaces one group of aten ops that the reference's model scripts dispatch through PyTorch
+ * (the reference has no native code and no FFI of its own -- SURVEY.md §2b -- so "the reference interface
+ * each one replaces" is the Python call site cited per function, paths relative to MTandHJ/RecBoard).
+ *
+ * Conventions (SURVEY.md §8b "C ABI underneath"):
+ *   - plain pointers + sizes; all pointers are DEVICE pointers unless named `h_*`; no torch types.
+ *   - the CALLER owns every buffer; kernels allocate nothing.  Ops that need scratch take `ws`/`ws_bytes`
+ *     and have a `*_workspace_bytes()` query.
+ *   - stream-ordered on `stream` (a hipStream_t passed as void*); no internal device synchronisation;
+ *     no global mutable state (re-entrant).
+ *   - return 0 on success, a negative RE_E* code otherwise (no exceptions cross the ABI).
+ *   - fp32 data, int64 indices (the reference is fp32/int64 everywhere).
+ *   - out-of-range indices never fault: they read as a zero row / are dropped, and are counted in the
+ *     optional `status` word where an entry point takes one.
+ */
+#ifndef RECENGINE_H
+#define RECENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RE_OK 0
+#define RE_EINVAL (-1)    /* bad argument (null pointer, negative size, unsupported D/K) */
+#define RE_EWORKSPACE (-2) /* workspace too small */
+#define RE_ELAUNCH (-3)   /* hipGetLastError() != hipSuccess after a launch */
+#define RE_EUNSUPPORTED (-4)
+
+#define RE_TOPK_MAX 64          /* K <= 64 (cfg.monitors use K <= 50) */
+#define RE_MASKED_SCORE (-1e23f) /* UniSRec/main.py:413 `scores[seen] = -1e23` */
+
+typedef void* re_stream_t; /* hipStream_t */
+
+int re_abi_version(void);
+const char* re_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K1  embedding row gather.  out[i, :] = W[idx[i], :]   (i < n)
+ * Replaces `nn.Embedding.__call__` / `W[idx]`:  SASRec/main.py:183,200-204; MF-BPR/main.py:84-86;
+ * LightGCN/main.py:91-93,101-103; DeepFM/main.py:59-61,204-206.
+ * HBM-bound: 8 + 8*D algorithmic bytes per looked-up row. */
+int re_gather_rows(const float* W, int64_t R, int64_t D, const int64_t* idx, int64_t n, float* out,
+                   re_stream_t stream);
+
+/* SASRec front end, fused: out[b,s,:] = seq[b,s]==0 ? 0 : dropout(E[seq[b,s]] * scale + P[s])
+ * Replaces SASRec/main.py:181-187 (embedding, `*= D**0.5`, mark_position, embdDropout, masked_fill).
+ * drop_p == 0 disables dropout; otherwise the engine's counter-based mask (stream id 1, element id
+ * (b*S+s)*D+d, see csrc/re_rng.h) scaled by 1/(1-p). */
+int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float* P, const int64_t* seq, int64_t B,
+                    int64_t S, float scale, float drop_p, uint32_t seed, float* out, re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K1b  dense gradient of the gather: dW[r,:] = sum_{i: idx[i]==r} g[i,:], rows == padding_idx skipped,
+ * every other row zero.  dW [R,D] is fully overwritten.  Deterministic (sorted segments, fixed chunking):
+ * two calls on the same input give bit-identical output.
+ * Replaces aten embedding_dense_backward / index_put_(accumulate) reached from `loss.backward()`
+ * (SASRec/main.py:249, MF-BPR/main.py:122).  `scale` multiplies every contribution (SASRec: sqrt(D)). */
+size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
+int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
+                        int64_t padding_idx, float scale, float* dW, void* ws, size_t ws_bytes,
+                        re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K3  fused pair-logit criteria over table rows.
+ *
+ * re_pair_loss_fwd: for every position i < n with valid[i] != 0 (valid may be NULL = all):
+ *      pl = <U[i,:], E[e_off + pos[i], :]>,  nl = <U[i,:], E[e_off + neg[i], :]>
+ *      kind RE_LOSS_BCE: l_i = softplus(-pl) + softplus(nl)     (BCE(pl,1) + BCE(nl,0), SASRec/main.py:208-214)
+ *      kind RE_LOSS_BPR: l_i = softplus(nl - pl)                (SASRec/main.py:215; MF-BPR/main.py:88-91)
+ *   loss[0] = sum_i l_i / M,  M = #valid positions (reduction="mean"); pl/nl are kept in `logits[2n]`
+ *   for the backward.  `count` (int32[1]) receives M.
+ * re_pair_loss_bwd: given dloss (device scalar, may be NULL = 1.0) writes
+ *      dU[i,:] = dpl*E[pos] + dnl*E[neg]   (zero row where !valid)
+ *      gpos[i,:] = dpl*U[i,:], gneg[i,:] = dnl*U[i,:]   (contribution rows for re_scatter_add_rows)
+ * U is [n, D] with row stride ldu (floats) so that userEmbds [B,S,D] can be passed un-compacted:
+ * the boolean-mask compaction of SASRec/main.py:199-204 (a host sync in the reference) is fused away. */
+#define RE_LOSS_BCE 0
+#define RE_LOSS_BPR 1
+size_t re_pair_loss_workspace_bytes(int64_t n);
+int re_pair_loss_fwd(const float* U, int64_t ldu, const float* E, int64_t R, int64_t D, int64_t e_off,
+                     const int64_t* pos, const int64_t* neg, const uint8_t* valid, int64_t n, int kind,
+                     float* logits, float* loss, int32_t* count, void* ws, size_t ws_bytes,
+                     re_stream_t stream);
+int re_pair_loss_bwd(const float* U, int64_t ldu, const float* E, int64_t R, int64_t D, int64_t e_off,
+                     const int64_t* pos, const int64_t* neg, const uint8_t* valid, int64_t n, int kind,
+                     const float* logits, const int32_t* count, const float* dloss, float* dU, int64_t lddu,
+                     float* gpos, float* gneg, re_stream_t stream);
+
+/* MF-BPR / LightGCN triplet form (MF-BPR/main.py:81-93): rows gathered from TWO tables inside the kernel.
+ *      pl = <Ut[users[i]], It[pos[i]]>, nl = <Ut[users[i]], It[neg[i]]>, loss = mean softplus(nl - pl)
+ * bwd writes the three contribution-row sets (for re_scatter_add_rows into dUt / dIt). */
+int re_bpr_triplet_fwd(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D,
+                       const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
+                       float* logits, float* loss, void* ws, size_t ws_bytes, re_stream_t stream);
+int re_bpr_triplet_bwd(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D,
+                       const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
+                       const float* logits, const float* dloss, float* gu, float* gpos, float* gneg,
+                       re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K4  full-catalog scoring.
+ * re_score_dense: out[b,n] = <Q[b,:], E[n,:]>   -- literal drop-in for `recommend_from_full`
+ *   (SASRec/main.py:228 einsum("BD,ND->BN"); MF-BPR/main.py:104; LightGCN/main.py:120).
+ * re_score_topk: the Coach.evaluate contract (freerec, mirrored at UniSRec/main.py:408-414) fused:
+ *   scores -> scores[seen] = -1e23 -> top-K, without materialising B x N.
+ *   vals [B,K] sorted descending, idx [B,K] int64; ties -> lowest item index; if fewer than K items are
+ *   unmasked the tail is filled with masked items (value -1e23) in ascending index order; if K > N the
+ *   remaining slots get (-inf, -1).  seen_ptr[B+1]/seen_idx[nnz] is a CSR of int64 item ids (any order);
+ *   seen_ptr == NULL means retain_seen.
+ * Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32), i.e. a k-ordered fmaf chain per score -- exact fp32.
+ * D must be a multiple of 8 and <= 256; K <= RE_TOPK_MAX. */
+int re_score_dense(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, float* out,
+                   re_stream_t stream);
+size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K);
+int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t D,
+                  const int64_t* seen_ptr, const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx,
+                  void* ws, size_t ws_bytes, re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K10  dense Adam with coupled L2 (torch.optim.Adam semantics, eps 1e-8, no amsgrad), one launch over a flat
+ * parameter arena.  Replaces `self.optimizer.step()` (SASRec/main.py:250; cfg dump
+ * benchmark/Amazon2014Beauty_550_LOU/SASRec.json:254-300).  step is 1-based.  g may alias nothing else. */
+int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, re_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECENGINE_H */

@@ -26,7 +26,7 @@ def rng_u32(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
 
 
 def drop_threshold(p: float) -> int:
-    return int(min(p * 4294967296.0, 4294967295.0))
+    return int(min(float(np.float32(p)) * 4294967296.0, 4294967295.0))  # p is a C float in the ABI
 
 
 def keep_mask(seed: int, stream: int, shape, p: float) -> np.ndarray:

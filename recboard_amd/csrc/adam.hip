@@ -1,0 +1,59 @@
+// K10: dense Adam with coupled L2 weight decay over a flat fp32 parameter arena.  HBM-bound:
+// 16 B read + 12 B written per element.  torch.optim.Adam single-tensor formulation:
+//   g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+#include <math.h>
+
+#include "re_common.h"
+
+__global__ __launch_bounds__(256) void adam_vec4(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                 float4* __restrict__ v, int64_t n4, float b1, float b2, float omb1, float omb2,
+                                                 float step_size, float inv_sqrt_bc2, float eps, float wd) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = p[i], G = g[i], M = m[i], V = v[i];
+#define RE_ADAM1(c)                                        \
+    {                                                      \
+        float gg = G.c + wd * P.c;                         \
+        M.c = b1 * M.c + omb1 * gg;                        \
+        V.c = b2 * V.c + omb2 * gg * gg;                   \
+        float denom = sqrtf(V.c) * inv_sqrt_bc2 + eps;     \
+        P.c = P.c - step_size * (M.c / denom);             \
+    }
+        RE_ADAM1(x) RE_ADAM1(y) RE_ADAM1(z) RE_ADAM1(w)
+#undef RE_ADAM1
+        p[i] = P; m[i] = M; v[i] = V;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_tail(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, int64_t begin, int64_t n, float b1, float b2, float omb1,
+                                                 float omb2, float step_size, float inv_sqrt_bc2, float eps, float wd) {
+    int64_t i = begin + threadIdx.x;
+    if (i >= n) return;
+    float gg = g[i] + wd * p[i];
+    float M = b1 * m[i] + omb1 * gg;
+    float V = b2 * v[i] + omb2 * gg * gg;
+    m[i] = M; v[i] = V;
+    p[i] = p[i] - step_size * (M / (sqrtf(V) * inv_sqrt_bc2 + eps));
+}
+
+extern "C" int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, re_stream_t stream) {
+    if (n == 0) return RE_OK;
+    if (!p || !g || !m || !v || n < 0 || step < 1) return RE_EINVAL;
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+          reinterpret_cast<uintptr_t>(v)) & 15u) != 0)
+        return RE_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const int64_t n4 = n >> 2;
+    if (n4 > 0)
+        hipLaunchKernelGGL(adam_vec4, dim3(re_grid(n4, 256)), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m, (float4*)v, n4,
+                           beta1, beta2, 1.0f - beta1, 1.0f - beta2, step_size, inv_sqrt_bc2, eps, weight_decay);
+    if (n & 3)
+        hipLaunchKernelGGL(adam_tail, dim3(1), dim3(256), 0, s, p, g, m, v, n4 << 2, n, beta1, beta2, 1.0f - beta1, 1.0f - beta2,
+                           step_size, inv_sqrt_bc2, eps, weight_decay);
+    return re_launch_status();
+}

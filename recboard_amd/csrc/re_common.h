@@ -1,0 +1,35 @@
+// Shared helpers for the recengine HIP kernels (gfx950 / CDNA4 only: wave64, no other target).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/recengine.h"
+
+#define RE_WAVE 64
+
+static inline int re_launch_status() {
+    return hipGetLastError() == hipSuccess ? RE_OK : RE_ELAUNCH;
+}
+
+static inline int64_t re_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t re_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// grid size for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, never more than the work
+static inline unsigned re_grid(int64_t work_items, int64_t per_block, int64_t cap = 2048) {
+    int64_t g = re_cdiv(work_items, per_block);
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+__device__ __forceinline__ float re_softplus(float x) {
+    // log(1 + exp(x)), stable: max(x,0) + log1p(exp(-|x|))  (torch.nn.functional.softplus, threshold irrelevant in fp32 here)
+    return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float re_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float re_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,318 @@
+// K1b: dense embedding gradient  dW[r,:] = sum_{i: idx[i]==r} scale * g[i,:]   -- deterministic.
+//
+// Design (cdna_hip_programming.md Appendix B "Scatter / gather / embedding", the atomic-free form):
+// the contribution rows already exist in HBM (`g`, the upstream gradient), so only an inverted index is built:
+//   1. keys = destination row (R for dropped entries: padding_idx / out of range), vals = position i
+//   2. LSD radix sort of (key, val), 8 bits per pass over ceil(log2(R+1)) bits; stable, so inside one
+//      destination the positions stay ascending  -> a fixed summation order.
+//      One wave per 1024-key tile; the in-tile stable rank uses wave64 ballots (8 per key byte) instead of
+//      LDS atomics, per-digit running bases live in LDS.
+//   3. segmented sum over fixed chunks of RE_SEG_CHUNK sorted entries: one lane group (D/4 lanes, float4 each)
+//      per chunk walks its entries in order; runs that lie inside one chunk are written straight to dW, runs
+//      that cross a chunk boundary leave a partial row; a fix-up kernel adds the partials in chunk order.
+//      Hot rows (Zipf head: thousands of contributions) are thereby split across many lane groups
+//      instead of serialising one wave (the skew pitfall of Appendix B).
+// Float atomics would be ~1.3 TB/s of added bytes and run-to-run non-reproducible; this path reads each
+// contribution row exactly once at gather-like rates and is bitwise reproducible.
+//
+// Algorithmic bytes: per contribution 8 (idx) + 4D (row read); per distinct row 4D (write).
+#include "re_common.h"
+
+#define RE_SORT_TILE 1024
+#define RE_SEG_CHUNK 32
+#define RE_FLAG_SLOT0 1u      // chunk's first run continues a run of the previous chunk -> partial in slot 0
+#define RE_FLAG_SLOT1 2u      // chunk's last run starts here and continues into the next chunk -> slot 1
+#define RE_FLAG_CONT 4u       // slot-0 run covers the whole chunk and continues into the next one
+
+// ------------------------------------------------------------------------------------------------ keys
+__global__ __launch_bounds__(256) void scatter_make_keys(const int64_t* __restrict__ idx, int64_t n, int64_t R,
+                                                         int64_t padding_idx, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int64_t r = idx[i];
+        keys[i] = (r == padding_idx || r < 0 || r >= R) ? (uint32_t)R : (uint32_t)r;
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ radix pass
+__global__ __launch_bounds__(64) void radix_hist(const uint32_t* __restrict__ keys, int64_t n, int shift,
+                                                 uint32_t* __restrict__ hist, int64_t T) {
+    __shared__ uint32_t h[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) h[d] = 0;
+    __syncthreads();
+    const int64_t tile = blockIdx.x;
+    const int64_t base = tile * RE_SORT_TILE;
+#pragma unroll 4
+    for (int r = 0; r < RE_SORT_TILE / 64; ++r) {
+        int64_t i = base + r * 64 + lane;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int d = lane; d < 256; d += 64) hist[(int64_t)d * T + tile] = h[d];
+}
+
+// exclusive scan of hist[256*T] (digit-major, tile-minor) by ONE block of 1024 threads
+__global__ __launch_bounds__(1024) void radix_scan(uint32_t* __restrict__ hist, int64_t total) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    // strips of 1024*8 entries; each thread owns 8 consecutive entries of a strip
+    for (int64_t strip = 0; strip < total; strip += 1024 * 8) {
+        uint32_t v[8];
+        uint32_t s = 0;
+        const int64_t b = strip + (int64_t)tid * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (b + j < total) ? hist[b + j] : 0u;
+            s += v[j];
+        }
+        uint32_t inc = s;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        uint32_t run = carry_s + woff + inc - s;
+        __syncthreads();
+        if (tid == 1023) carry_s = run + s;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (b + j < total) hist[b + j] = run;
+            run += v[j];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void radix_scatter(const uint32_t* __restrict__ keys_in,
+                                                    const uint32_t* __restrict__ vals_in, int64_t n, int shift,
+                                                    const uint32_t* __restrict__ hist, int64_t T,
+                                                    uint32_t* __restrict__ keys_out,
+                                                    uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t base[256];
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    for (int d = lane; d < 256; d += 64) base[d] = hist[(int64_t)d * T + tile];
+    __syncthreads();
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < RE_SORT_TILE / 64; ++r) {
+        const int64_t i = tile * RE_SORT_TILE + r * 64 + lane;
+        const bool valid = i < n;
+        uint32_t k = 0, v = 0;
+        if (valid) { k = keys_in[i]; v = vals_in[i]; }
+        const uint32_t d = (k >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = __popcll(peers & lt);
+        uint32_t off = 0;
+        if (valid) off = base[d] + rank;
+        __syncthreads();
+        if (valid && rank == 0) base[d] += __popcll(peers);
+        __syncthreads();
+        if (valid) { keys_out[off] = k; vals_out[off] = v; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ segmented sum
+__device__ __forceinline__ void f4_fma(float4& a, const float4& x, float s) {
+    a.x = fmaf(x.x, s, a.x); a.y = fmaf(x.y, s, a.y); a.z = fmaf(x.z, s, a.z); a.w = fmaf(x.w, s, a.w);
+}
+__device__ __forceinline__ void f4_add(float4& a, const float4& x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
+
+template <int LPR>
+__global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                  const float* __restrict__ g, int64_t n, int64_t D, int64_t R,
+                                                  float scale, float* __restrict__ dW, float* __restrict__ partial,
+                                                  uint32_t* __restrict__ pflags, int64_t nchunks) {
+    const int lir = threadIdx.x % LPR;
+    const int64_t c = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (c >= nchunks) return;
+    const int64_t begin = c * RE_SEG_CHUNK;
+    const int64_t end = (begin + RE_SEG_CHUNK < n) ? begin + RE_SEG_CHUNK : n;
+    const uint32_t NONE = 0xFFFFFFFFu, DROP = (uint32_t)R;
+    const uint32_t prevKey = begin > 0 ? keys[begin - 1] : NONE;
+    const uint32_t nextKey = end < n ? keys[end] : NONE;
+    const int64_t D4 = D >> 2;
+    uint32_t flags = 0;
+    for (int64_t col = lir; col < D4; col += LPR) {
+        uint32_t curKey = keys[begin];
+        bool isHead = true;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t j0 = begin; j0 < end; j0 += 8) {
+            uint32_t k[8];
+            float4 row[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t j = j0 + u;
+                k[u] = j < end ? keys[j] : NONE;
+                row[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < end && k[u] != DROP) row[u] = reinterpret_cast<const float4*>(g + (int64_t)vals[j] * D)[col];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u >= end) break;
+                if (k[u] != curKey) {
+                    // flush a run that ended strictly inside the chunk (cannot be the tail)
+                    if (curKey != DROP) {
+                        if (isHead && curKey == prevKey) {
+                            reinterpret_cast<float4*>(partial + (c * 2 + 0) * D)[col] = acc;
+                            flags |= RE_FLAG_SLOT0;
+                        } else {
+                            reinterpret_cast<float4*>(dW + (int64_t)curKey * D)[col] = acc;
+                        }
+                    }
+                    curKey = k[u];
+                    isHead = false;
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                f4_fma(acc, row[u], scale);
+            }
+        }
+        // flush the tail run
+        if (curKey != DROP) {
+            const bool headOpen = isHead && curKey == prevKey;
+            const bool tailOpen = curKey == nextKey;
+            if (headOpen) {
+                reinterpret_cast<float4*>(partial + (c * 2 + 0) * D)[col] = acc;
+                flags |= RE_FLAG_SLOT0 | (tailOpen ? RE_FLAG_CONT : 0u);
+            } else if (tailOpen) {
+                reinterpret_cast<float4*>(partial + (c * 2 + 1) * D)[col] = acc;
+                flags |= RE_FLAG_SLOT1;
+            } else {
+                reinterpret_cast<float4*>(dW + (int64_t)curKey * D)[col] = acc;
+            }
+        }
+    }
+    if (lir == 0) pflags[c] = flags;
+}
+
+// one lane group per chunk in which a boundary-crossing run STARTS: add the following chunks' slot-0 partials in order
+template <int LPR>
+__global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ keys, int64_t n, int64_t D,
+                                                 float* __restrict__ dW, const float* __restrict__ partial,
+                                                 const uint32_t* __restrict__ pflags, int64_t nchunks) {
+    const int lir = threadIdx.x % LPR;
+    const int64_t c = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (c >= nchunks) return;
+    if (!(pflags[c] & RE_FLAG_SLOT1)) return;
+    const int64_t end = (c * RE_SEG_CHUNK + RE_SEG_CHUNK < n) ? c * RE_SEG_CHUNK + RE_SEG_CHUNK : n;
+    const uint32_t key = keys[end - 1];
+    const int64_t D4 = D >> 2;
+    for (int64_t col = lir; col < D4; col += LPR) {
+        float4 acc = reinterpret_cast<const float4*>(partial + (c * 2 + 1) * D)[col];
+        for (int64_t cc = c + 1; cc < nchunks; ++cc) {
+            const uint32_t f = pflags[cc];
+            if (!(f & RE_FLAG_SLOT0)) break;  // cannot happen for a well-formed chain; keeps the loop bounded
+            f4_add(acc, reinterpret_cast<const float4*>(partial + (cc * 2 + 0) * D)[col]);
+            if (!(f & RE_FLAG_CONT)) break;
+        }
+        reinterpret_cast<float4*>(dW + (int64_t)key * D)[col] = acc;
+    }
+}
+
+// scalar-D fallback (D % 4 != 0: DeepFM D=10 / D=1): one thread per (distinct-run, column) walks its run
+__global__ __launch_bounds__(256) void seg_reduce_scalar(const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ vals,
+                                                         const float* __restrict__ g, int64_t n, int64_t D, int64_t R,
+                                                         float scale, float* __restrict__ dW) {
+    const int64_t total = n * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t j = e / D, d = e - j * D;
+        const uint32_t k = keys[j];
+        if (k == (uint32_t)R) continue;
+        if (j > 0 && keys[j - 1] == k) continue;  // not the first entry of its run
+        float acc = 0.f;
+        for (int64_t t = j; t < n && keys[t] == k; ++t) acc = fmaf(g[(int64_t)vals[t] * D + d], scale, acc);
+        dW[(int64_t)k * D + d] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct ScatterWs {
+    uint32_t *k0, *k1, *v0, *v1, *hist, *pflags;
+    float* partial;
+    int64_t T, nchunks;
+    size_t bytes;
+};
+
+static ScatterWs scatter_ws_layout(void* ws, int64_t n, int64_t D) {
+    ScatterWs w;
+    w.T = re_cdiv(n, RE_SORT_TILE);
+    w.nchunks = re_cdiv(n, RE_SEG_CHUNK);
+    size_t off = 0;
+    char* base = (char*)ws;
+    auto take = [&](size_t bytes) { char* p = base + off; off += re_align(bytes); return p; };
+    w.k0 = (uint32_t*)take((size_t)n * 4);
+    w.k1 = (uint32_t*)take((size_t)n * 4);
+    w.v0 = (uint32_t*)take((size_t)n * 4);
+    w.v1 = (uint32_t*)take((size_t)n * 4);
+    w.hist = (uint32_t*)take((size_t)256 * w.T * 4);
+    w.pflags = (uint32_t*)take((size_t)w.nchunks * 4);
+    w.partial = (float*)take((size_t)w.nchunks * 2 * D * 4);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R) {
+    (void)R;
+    if (n <= 0 || D <= 0) return 256;
+    return scatter_ws_layout(nullptr, n, D).bytes;
+}
+
+extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
+                                   int64_t padding_idx, float scale, float* dW, void* ws, size_t ws_bytes,
+                                   re_stream_t stream) {
+    if (!dW || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
+    if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+    if (n == 0) return RE_OK;
+    if (!g || !idx || !ws) return RE_EINVAL;
+    ScatterWs w = scatter_ws_layout(ws, n, D);
+    if (ws_bytes < w.bytes) return RE_EWORKSPACE;
+
+    hipLaunchKernelGGL(scatter_make_keys, dim3(re_grid(n, 256)), dim3(256), 0, s, idx, n, R, padding_idx, w.k0, w.v0);
+    int bits = 1;
+    while (((int64_t)1 << bits) <= R) ++bits;  // keys take values 0..R
+    uint32_t *ki = w.k0, *vi = w.v0, *ko = w.k1, *vo = w.v1;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(radix_hist, dim3((unsigned)w.T), dim3(64), 0, s, ki, n, shift, w.hist, w.T);
+        hipLaunchKernelGGL(radix_scan, dim3(1), dim3(1024), 0, s, w.hist, (int64_t)256 * w.T);
+        hipLaunchKernelGGL(radix_scatter, dim3((unsigned)w.T), dim3(64), 0, s, ki, vi, n, shift, w.hist, w.T, ko, vo);
+        uint32_t* t;
+        t = ki; ki = ko; ko = t;
+        t = vi; vi = vo; vo = t;
+    }
+    const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u) == 0;
+    if (!vec) {
+        hipLaunchKernelGGL(seg_reduce_scalar, dim3(re_grid(n * D, 256)), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW);
+        return re_launch_status();
+    }
+    const int64_t D4 = D >> 2;
+    if (D4 >= 32) {
+        const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 32);
+        hipLaunchKernelGGL(seg_reduce<32>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks);
+        hipLaunchKernelGGL(seg_fixup<32>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks);
+    } else if (D4 >= 16) {
+        const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 16);
+        hipLaunchKernelGGL(seg_reduce<16>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks);
+        hipLaunchKernelGGL(seg_fixup<16>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks);
+    } else {
+        const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 4);
+        hipLaunchKernelGGL(seg_reduce<4>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks);
+        hipLaunchKernelGGL(seg_fixup<4>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks);
+    }
+    return re_launch_status();
+}

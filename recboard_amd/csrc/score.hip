@@ -1,0 +1,406 @@
+// K4: full-catalog scoring  S = Q . E^T  on the fp32 matrix cores, with the Coach.evaluate epilogue fused
+// (seen-mask + streaming top-K), so the B x N score matrix never exists.          MFMA-bound (fp32).
+//
+// Reference ops replaced: SASRec/main.py:228 einsum("BD,ND->BN"), MF-BPR/main.py:104, LightGCN/main.py:120,
+// then -- in freerec's Coach.evaluate, mirrored at UniSRec/main.py:408-414 -- `scores[seen] = -1e23`, a dense
+// target matrix and one torch.topk per "NAME@K" monitor.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32.  A = 32 items x 2 k, B = 2 k x 32 users, so a lane owns ONE user (its
+// accumulator column) and 16 items (rows).  k is fed in natural order (step s uses k = 2s, 2s+1), which makes
+// every score bit-for-bit the fp32 chain  acc = fmaf(q[k], e[k], acc), k = 0..D-1  -- the C oracle's arithmetic.
+//
+// Data movement per workgroup (256 threads = 4 waves = 4 x 32 users):
+//   * the 128 users' query rows are MFMA-B fragments held in registers for a whole segment (D/2 VGPRs);
+//   * item rows stream HBM/L2 -> registers (coalesced float4, prefetched one stage ahead) -> LDS, de-interleaved
+//     into [even k | odd k] halves with a 16-B row pad so that the A-fragment ds_read_b128s are conflict-free;
+//   * per 32-item tile a wave issues D/2 MFMAs (D=64: 2048 cycles) and then scans its 16 accumulators against
+//     the lane's user threshold (the current K-th best): one v_cmp per register in the common case.
+//   * rare hits go to a per-user binary heap in LDS ([slot][user] layout, conflict-free across lanes); the two
+//     lanes that share a user insert one after the other.  The seen-mask is applied only to hits, through a
+//     per-lane cursor into the user's sorted seen list.
+// Work split: "stream-K" -- the (user block, item stage) units are cut into equal contiguous ranges, one per
+// workgroup (2 workgroups per CU), so the chip is evenly loaded for any B x N; a user block touched by several
+// workgroups gets one partial top-K list per segment, merged by score_topk_merge (bitonic networks on wave64).
+//
+// Algorithmic work: 2*D FLOP per (user, item) pair; bytes lower bound 4D(B+N) + 12BK.
+#include <math.h>
+
+#include "re_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SC_USERS 128   // users per workgroup (4 waves x 32)
+#define SC_TI 64       // items per LDS stage (2 MFMA tiles)
+#define SC_MAX_WGS 512 // 2 per CU on MI355X
+
+__device__ __forceinline__ bool sc_before(float va, int ia, float vb, int ib) {  // a ranks before b
+    return va > vb || (va == vb && ia < ib);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int D, bool TOPK>
+__global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__ Q, const float* __restrict__ E,
+                                                       int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
+                                                       const int64_t* __restrict__ seen_idx, int K,
+                                                       float* __restrict__ part_vals, int* __restrict__ part_idx,
+                                                       int maxseg, int64_t nub, int64_t nst, int64_t upw,
+                                                       float* __restrict__ dense_out) {
+    constexpr int KH = D / 2;            // k values per lane half
+    constexpr int RSF = D + 4;           // LDS row stride in floats (16-B pad)
+    constexpr int F4_PER_STAGE = SC_TI * D / 4;
+    constexpr int PF = F4_PER_STAGE / 256;  // prefetch float4 per thread
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* tile = reinterpret_cast<float*>(smem);
+    float* hv = tile + SC_TI * RSF;
+    int* hi = reinterpret_cast<int*>(hv + (TOPK ? K : 0) * SC_USERS);
+    int* cnt = hi + (TOPK ? K : 0) * SC_USERS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int ul = wid * 32 + c;  // user slot inside the block
+
+    const int64_t units_total = nub * nst;
+    int64_t unit = (int64_t)blockIdx.x * upw;
+    const int64_t unit_end = (unit + upw < units_total) ? unit + upw : units_total;
+
+    while (unit < unit_end) {
+        const int64_t ub = unit / nst;
+        const int64_t st0 = unit - ub * nst;
+        const int64_t st1 = (st0 + (unit_end - unit) < nst) ? st0 + (unit_end - unit) : nst;
+        const int seg = (int)((int64_t)blockIdx.x - (ub * nst) / upw);
+        const int64_t user = ub * SC_USERS + ul;
+
+        // ---- query fragments (MFMA B operand): bq[s] = Q[user][2s + h]
+        float bq[KH];
+        {
+            const float* qrow = Q + user * D;
+            const bool uok = user < B;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) bq[s] = uok ? qrow[2 * s + h] : 0.0f;
+        }
+        float thr = -INFINITY;
+        int64_t sc_cur = 0, sc_end = 0;
+        int next_seen = 0x7FFFFFFF;
+        if (TOPK) {
+            if (h == 0) cnt[ul] = 0;
+            if (seen_ptr && user < B) {
+                sc_cur = seen_ptr[user];
+                sc_end = seen_ptr[user + 1];
+                // first seen id inside this segment
+                const int64_t first_item = st0 * SC_TI;
+                int64_t lo = sc_cur, hi2 = sc_end;
+                while (lo < hi2) {
+                    const int64_t mid = (lo + hi2) >> 1;
+                    if (seen_idx[mid] < first_item) lo = mid + 1; else hi2 = mid;
+                }
+                sc_cur = lo;
+                next_seen = sc_cur < sc_end ? (int)seen_idx[sc_cur] : 0x7FFFFFFF;
+            }
+        }
+
+        // ---- prefetch first stage
+        float4 pf[PF];
+        auto prefetch = [&](int64_t st) {
+            const int64_t item0 = st * SC_TI;
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int f = p * 256 + tid;
+                const int row = f / (D / 4);
+                pf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (item0 + row < N) pf[p] = reinterpret_cast<const float4*>(E + item0 * D)[f];
+            }
+        };
+        prefetch(st0);
+
+        for (int64_t st = st0; st < st1; ++st) {
+            __syncthreads();  // every wave is done reading the previous stage
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int f = p * 256 + tid;
+                const int row = f / (D / 4);
+                const int k0 = (f % (D / 4)) * 4;
+                float* dst = tile + row * RSF + (k0 >> 1);
+                *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);        // even k
+                *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);   // odd k
+            }
+            __syncthreads();
+            if (st + 1 < st1) prefetch(st + 1);
+
+#pragma unroll
+            for (int it = 0; it < SC_TI / 32; ++it) {
+                const int64_t item0 = st * SC_TI + it * 32;
+                if (item0 >= N) break;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                const float* arow = tile + (it * 32 + c) * RSF + h * KH;
+#pragma unroll
+                for (int q = 0; q < KH / 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+                    if (TOPK) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * q + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
+                    } else {  // dense: users on rows, items on lanes -> coalesced row stores
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[4 * q + 0], a.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[4 * q + 1], a.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[4 * q + 2], a.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[4 * q + 3], a.w, acc, 0, 0, 0);
+                    }
+                }
+
+                if (!TOPK) {
+                    const int64_t item = item0 + c;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t urow = ub * SC_USERS + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (urow < B && item < N) dense_out[urow * N + item] = acc[r];
+                    }
+                    continue;
+                }
+
+                // ---- fast filter: one compare per accumulator register against the lane's user threshold
+                unsigned m = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
+                if (__ballot(m != 0) == 0ull) continue;
+
+                // ---- slow path: heap inserts (rare once the heap is warm)
+#pragma unroll 1
+                for (int r = 0; r < 16; ++r) {
+                    bool hit = (m >> r) & 1u;
+                    if (__ballot(hit) == 0ull) continue;
+                    const float v = acc[r];
+                    const int item = (int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    hit = hit && item < N && user < B;
+                    if (hit && item >= next_seen) {  // advance the seen cursor to lower_bound(item)
+                        int64_t lo = sc_cur, hi2 = sc_end;
+                        while (lo < hi2) {
+                            const int64_t mid = (lo + hi2) >> 1;
+                            if (seen_idx[mid] < item) lo = mid + 1; else hi2 = mid;
+                        }
+                        sc_cur = lo;
+                        next_seen = sc_cur < sc_end ? (int)seen_idx[sc_cur] : 0x7FFFFFFF;
+                        if (next_seen == item) hit = false;  // scores[seen] = -1e23 never reaches the top-K
+                    }
+#pragma unroll 1
+                    for (int hh = 0; hh < 2; ++hh) {
+                        if (hit && h == hh) {
+                            const int n_in = cnt[ul];
+                            if (n_in < K) {  // still filling: sift-up insert (root = worst entry)
+                                int p = n_in;
+                                while (p > 0) {
+                                    const int par = (p - 1) >> 1;
+                                    const float pv = hv[par * SC_USERS + ul];
+                                    const int pi = hi[par * SC_USERS + ul];
+                                    if (!sc_before(pv, pi, v, item)) break;  // parent not better than new -> stop
+                                    hv[p * SC_USERS + ul] = pv;
+                                    hi[p * SC_USERS + ul] = pi;
+                                    p = par;
+                                }
+                                hv[p * SC_USERS + ul] = v;
+                                hi[p * SC_USERS + ul] = item;
+                                cnt[ul] = n_in + 1;
+                            } else if (sc_before(v, item, hv[ul], hi[ul])) {  // beats the current worst: replace root
+                                int p = 0;
+                                for (;;) {
+                                    int ch = 2 * p + 1;
+                                    if (ch >= K) break;
+                                    float cv = hv[ch * SC_USERS + ul];
+                                    int ci = hi[ch * SC_USERS + ul];
+                                    if (ch + 1 < K) {
+                                        const float rv = hv[(ch + 1) * SC_USERS + ul];
+                                        const int ri = hi[(ch + 1) * SC_USERS + ul];
+                                        if (sc_before(cv, ci, rv, ri)) { cv = rv; ci = ri; ++ch; }  // pick the WORSE child
+                                    }
+                                    if (!sc_before(v, item, cv, ci)) break;  // new entry is not better than child -> it stays here
+                                    hv[p * SC_USERS + ul] = cv;
+                                    hi[p * SC_USERS + ul] = ci;
+                                    p = ch;
+                                }
+                                hv[p * SC_USERS + ul] = v;
+                                hi[p * SC_USERS + ul] = item;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                thr = (cnt[ul] >= K) ? hv[ul] : -INFINITY;
+            }
+        }
+
+        if (TOPK) {
+            // ---- partial list of this segment: unsorted heap contents, padded with (-inf, -1)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (user < B) {
+                const int n_in = cnt[ul];
+                float* pv = part_vals + (user * maxseg + seg) * K;
+                int* pi = part_idx + (user * maxseg + seg) * K;
+                for (int s = h; s < K; s += 2) {
+                    pv[s] = s < n_in ? hv[s * SC_USERS + ul] : -INFINITY;
+                    pi[s] = s < n_in ? hi[s * SC_USERS + ul] : -1;
+                }
+            }
+        }
+        unit += st1 - st0;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// merge the per-segment partial lists of one user (one wave per user), sort, apply the K > #unmasked fill.
+__device__ __forceinline__ void bitonic_step(float& v, int& i, int j, bool keep_first, int lane) {
+    const float pv = __shfl_xor(v, j, 64);
+    const int pi = __shfl_xor(i, j, 64);
+    const bool take = keep_first ? sc_before(pv, pi, v, i) : sc_before(v, i, pv, pi);
+    if (take) { v = pv; i = pi; }
+    (void)lane;
+}
+
+__device__ __forceinline__ void bitonic_sort64(float& v, int& i, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool lower = (lane & j) == 0;
+            const bool asc = (lane & k) == 0;
+            bitonic_step(v, i, j, lower == asc, lane);
+        }
+}
+
+__global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict__ part_vals, const int* __restrict__ part_idx,
+                                                        int maxseg, int64_t B, int64_t N, int K, int64_t nst, int64_t upw,
+                                                        const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
+                                                        float* __restrict__ vals, int64_t* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t user = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (user >= B) return;
+    const int64_t ub = user / SC_USERS;
+    const int64_t w0 = (ub * nst) / upw, w1 = ((ub + 1) * nst - 1) / upw;
+    const int nseg = (int)(w1 - w0 + 1);
+    const int PAD = 0x7FFFFFFF;
+    float bv = -INFINITY;
+    int bi = PAD;
+    for (int s = 0; s < nseg; ++s) {
+        float v = -INFINITY;
+        int i = PAD;
+        if (lane < K) {
+            v = part_vals[(user * maxseg + s) * K + lane];
+            i = part_idx[(user * maxseg + s) * K + lane];
+            if (i < 0) { i = PAD; v = -INFINITY; }
+        }
+        bitonic_sort64(v, i, lane);
+        // top-64 of the union of two best-first lists: compare lane t with lane 63-t of the other list
+        const float rv = __shfl(v, 63 - lane, 64);
+        const int ri = __shfl(i, 63 - lane, 64);
+        if (sc_before(rv, ri, bv, bi)) { bv = rv; bi = ri; }
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1) bitonic_step(bv, bi, j, (lane & j) == 0, lane);
+    }
+    const int nvalid = __popcll(__ballot(bi != PAD && lane < K));
+    if (lane < K && bi != PAD) {
+        vals[user * K + lane] = bv;
+        idx[user * K + lane] = bi;
+    }
+    if (nvalid < K && lane == 0) {
+        // fewer than K unmasked items: torch.topk would continue into the masked (-1e23) entries;
+        // ties -> lowest index, i.e. the user's seen items in ascending order.
+        int o = nvalid;
+        int64_t last = -1;
+        if (seen_ptr)
+            for (int64_t p = seen_ptr[user]; p < seen_ptr[user + 1] && o < K; ++p) {
+                const int64_t it = seen_idx[p];
+                if (it < 0 || it >= N || it == last) continue;
+                last = it;
+                vals[user * K + o] = RE_MASKED_SCORE;
+                idx[user * K + o] = it;
+                ++o;
+            }
+        for (; o < K; ++o) { vals[user * K + o] = -INFINITY; idx[user * K + o] = -1; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct ScorePlan {
+    int64_t nub, nst, units, upw;
+    int nwg, maxseg;
+};
+
+static ScorePlan score_plan(int64_t B, int64_t N) {
+    ScorePlan p;
+    p.nub = re_cdiv(B, SC_USERS);
+    p.nst = re_cdiv(N, SC_TI);
+    p.units = p.nub * p.nst;
+    int64_t nwg = p.units < SC_MAX_WGS ? p.units : SC_MAX_WGS;
+    if (nwg < 1) nwg = 1;
+    p.upw = re_cdiv(p.units, nwg);
+    p.nwg = (int)re_cdiv(p.units, p.upw);
+    p.maxseg = (int)(re_cdiv(p.nst, p.upw) + 1);
+    return p;
+}
+
+static size_t score_lds_bytes(int D, int K, bool topk) {
+    size_t b = (size_t)SC_TI * (D + 4) * 4;
+    if (topk) b += (size_t)K * SC_USERS * 8 + SC_USERS * 4;
+    return b;
+}
+
+extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K) {
+    (void)D;
+    if (B <= 0 || N <= 0 || K <= 0) return 256;
+    ScorePlan p = score_plan(B, N);
+    return re_align((size_t)p.nub * SC_USERS * p.maxseg * K * 4) * 2 + 256;
+}
+
+template <int D, bool TOPK>
+static int score_launch(const float* Q, const float* E, int64_t B, int64_t N, const int64_t* seen_ptr, const int64_t* seen_idx,
+                        int K, float* pv, int* pi, const ScorePlan& p, float* dense_out, hipStream_t s) {
+    const size_t lds = score_lds_bytes(D, K, TOPK);
+    auto kern = score_kernel<D, TOPK>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RE_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, dense_out);
+    return re_launch_status();
+}
+
+template <bool TOPK>
+static int score_dispatch(int64_t D, const float* Q, const float* E, int64_t B, int64_t N, const int64_t* seen_ptr,
+                          const int64_t* seen_idx, int K, float* pv, int* pi, const ScorePlan& p, float* dense_out, hipStream_t s) {
+    switch (D) {
+        case 32: return score_launch<32, TOPK>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
+        case 64: return score_launch<64, TOPK>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
+        case 128: return score_launch<128, TOPK>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
+        default: return RE_EUNSUPPORTED;
+    }
+}
+
+extern "C" int re_score_dense(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, float* out, re_stream_t stream) {
+    if (B == 0 || N == 0) return RE_OK;
+    if (!Q || !E || !out || B < 0 || N < 0) return RE_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(E) & 15u) != 0 || N >= 0x7FFFFFFFll) return RE_EUNSUPPORTED;
+    ScorePlan p = score_plan(B, N);
+    return score_dispatch<false>(D, Q, E, B, N, nullptr, nullptr, 0, nullptr, nullptr, p, out, (hipStream_t)stream);
+}
+
+extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, const int64_t* seen_ptr,
+                             const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx, void* ws, size_t ws_bytes,
+                             re_stream_t stream) {
+    if (B == 0) return RE_OK;
+    if (!Q || !E || !vals || !idx || !ws || B < 0 || N <= 0 || K <= 0 || K > RE_TOPK_MAX) return RE_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(E) & 15u) != 0 || N >= 0x7FFFFFFFll) return RE_EUNSUPPORTED;
+    if (seen_ptr && !seen_idx) return RE_EINVAL;
+    if (ws_bytes < re_score_topk_workspace_bytes(B, N, D, K)) return RE_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    ScorePlan p = score_plan(B, N);
+    const size_t half = re_align((size_t)p.nub * SC_USERS * p.maxseg * K * 4);
+    float* pv = (float*)ws;
+    int* pi = (int*)((char*)ws + half);
+    int rc = score_dispatch<true>(D, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p, nullptr, s);
+    if (rc != RE_OK) return rc;
+    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, p.maxseg, B, N, (int)K, p.nst, p.upw,
+                       seen_ptr, seen_idx, vals, idx);
+    return re_launch_status();
+}

@@ -1,0 +1,58 @@
+"""ctypes binding of librecengine.so -- the C-ABI drop-in boundary (include/recengine.h).
+
+The product path has NO fallback: if the shared library is missing or a call returns a negative code,
+a RuntimeError is raised.  Nothing here imports `oracle/`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librecengine.so")
+
+_vp, _i64, _i32, _f32, _u32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                    ctypes.c_uint32, ctypes.c_size_t)
+
+# name -> (restype, argtypes); mirrors include/recengine.h one to one
+SIGNATURES = {
+    "re_abi_version": (_i32, []),
+    "re_error_string": (ctypes.c_char_p, [_i32]),
+    "re_gather_rows": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "re_sasrec_embed": (_i32, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _f32, _u32, _vp, _vp]),
+    "re_scatter_add_rows_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "re_scatter_add_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _sz, _vp]),
+    "re_pair_loss_workspace_bytes": (_sz, [_i64]),
+    "re_pair_loss_fwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "re_pair_loss_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "re_bpr_triplet_fwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "re_bpr_triplet_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "re_score_dense": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "re_score_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "re_score_topk": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "re_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
+}
+
+_LIB = None
+
+
+def load():
+    """Load librecengine.so (built by `__graft_entry__.build()` / `make -C recboard_amd/csrc`)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"recengine: {LIB_PATH} not found -- the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C recboard_amd/csrc`.")
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().re_error_string(code).decode()
+        raise RuntimeError(f"recengine: {what} failed: {msg} (code {code})")

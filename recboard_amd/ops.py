@@ -1,0 +1,180 @@
+"""Torch-tensor front end of the C ABI (include/recengine.h): argument checks, buffer allocation, stream plumbing.
+
+PyTorch is used for device memory and streams only; every function here ends in exactly one (or a fixed few)
+`librecengine.so` calls on `torch.cuda.current_stream()`.  CPU tensors are rejected -- there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import lib
+
+LOSS_BCE, LOSS_BPR = 0, 1
+TOPK_MAX = 64
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype, name, contiguous=True):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"recengine: `{name}` must be a tensor on a HIP device (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise TypeError(f"recengine: `{name}` must be {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"recengine: `{name}` must be contiguous")
+    return t
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ K1
+def gather_rows(W: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[..., :] = W[idx[...], :]   (re_gather_rows)."""
+    _req(W, torch.float32, "W")
+    _req(idx, torch.int64, "idx")
+    R, D = W.shape
+    out = torch.empty(idx.shape + (D,), dtype=torch.float32, device=W.device)
+    lib.check(lib.load().re_gather_rows(_p(W), R, D, _p(idx), idx.numel(), _p(out), _stream()), "re_gather_rows")
+    return out
+
+
+def sasrec_embed(E, P, seq, scale, drop_p=0.0, seed=0):
+    """(E[seq]*scale + P[s]) with pad rows zeroed and optional engine dropout (re_sasrec_embed)."""
+    _req(E, torch.float32, "E"); _req(P, torch.float32, "P"); _req(seq, torch.int64, "seq")
+    B, S = seq.shape
+    R, D = E.shape
+    if P.shape[0] < S or P.shape[1] != D:
+        raise ValueError("recengine: position table must be [>=S, D]")
+    out = torch.empty((B, S, D), dtype=torch.float32, device=E.device)
+    lib.check(lib.load().re_sasrec_embed(_p(E), R, D, _p(P), _p(seq), B, S, float(scale), float(drop_p),
+                                         int(seed) & 0xFFFFFFFF, _p(out), _stream()), "re_sasrec_embed")
+    return out
+
+
+def scatter_add_rows(g: torch.Tensor, idx: torch.Tensor, R: int, padding_idx: int = -1, scale: float = 1.0):
+    """Dense [R, D] gradient of gather_rows, deterministic (re_scatter_add_rows)."""
+    _req(g, torch.float32, "g"); _req(idx, torch.int64, "idx")
+    D = g.shape[-1]
+    n = idx.numel()
+    if g.numel() != n * D:
+        raise ValueError("recengine: g must have one row per index")
+    L = lib.load()
+    ws = _ws(L.re_scatter_add_rows_workspace_bytes(n, D, R), g.device)
+    dW = torch.empty((R, D), dtype=torch.float32, device=g.device)
+    lib.check(L.re_scatter_add_rows(_p(g), _p(idx), n, D, R, int(padding_idx), float(scale), _p(dW), _p(ws),
+                                    ws.numel(), _stream()), "re_scatter_add_rows")
+    return dW
+
+
+# ------------------------------------------------------------------------------------------------ K3
+def pair_loss_fwd(U, E, pos, neg, valid, kind, e_off=0):
+    """U [n, D] (rows may be strided), E [R, D]; returns (loss[1], logits[n,2], count int32[1])."""
+    _req(U, torch.float32, "U", contiguous=False); _req(E, torch.float32, "E")
+    _req(pos, torch.int64, "pos"); _req(neg, torch.int64, "neg")
+    if U.dim() != 2 or U.stride(1) != 1:
+        raise ValueError("recengine: U must be [n, D] with unit inner stride")
+    n, D = U.shape
+    if valid is not None:
+        _req(valid, torch.uint8, "valid")
+    L = lib.load()
+    dev = U.device
+    logits = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = _ws(L.re_pair_loss_workspace_bytes(n), dev)
+    lib.check(L.re_pair_loss_fwd(_p(U), U.stride(0), _p(E), E.shape[0], D, e_off, _p(pos), _p(neg), _p(valid), n,
+                                 kind, _p(logits), _p(loss), _p(count), _p(ws), ws.numel(), _stream()),
+              "re_pair_loss_fwd")
+    return loss, logits, count
+
+
+def pair_loss_bwd(U, E, pos, neg, valid, kind, logits, count, dloss, e_off=0):
+    """-> (dU [n,D], gpos [n,D], gneg [n,D]) contribution rows."""
+    n, D = U.shape
+    dev = U.device
+    dU = torch.empty((n, D), dtype=torch.float32, device=dev)
+    gpos = torch.empty((n, D), dtype=torch.float32, device=dev)
+    gneg = torch.empty((n, D), dtype=torch.float32, device=dev)
+    if dloss is not None:
+        _req(dloss, torch.float32, "dloss")
+    lib.check(lib.load().re_pair_loss_bwd(_p(U), U.stride(0), _p(E), E.shape[0], D, e_off, _p(pos), _p(neg), _p(valid),
+                                          n, kind, _p(logits), _p(count), _p(dloss), _p(dU), D, _p(gpos), _p(gneg),
+                                          _stream()), "re_pair_loss_bwd")
+    return dU, gpos, gneg
+
+
+def bpr_triplet_fwd(Ut, It, users, pos, neg):
+    _req(Ut, torch.float32, "Ut"); _req(It, torch.float32, "It")
+    for t, nme in ((users, "users"), (pos, "pos"), (neg, "neg")):
+        _req(t, torch.int64, nme)
+    n = users.numel()
+    if pos.numel() != n or neg.numel() != n:
+        raise ValueError("recengine: one positive and one negative per user row (K = 1)")
+    D = Ut.shape[1]
+    L = lib.load()
+    dev = Ut.device
+    logits = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    ws = _ws(L.re_pair_loss_workspace_bytes(n), dev)
+    lib.check(L.re_bpr_triplet_fwd(_p(Ut), Ut.shape[0], _p(It), It.shape[0], D, _p(users), _p(pos), _p(neg), n,
+                                   _p(logits), _p(loss), _p(ws), ws.numel(), _stream()), "re_bpr_triplet_fwd")
+    return loss, logits
+
+
+def bpr_triplet_bwd(Ut, It, users, pos, neg, logits, dloss):
+    n = users.numel()
+    D = Ut.shape[1]
+    dev = Ut.device
+    gu, gp, gn = (torch.empty((n, D), dtype=torch.float32, device=dev) for _ in range(3))
+    lib.check(lib.load().re_bpr_triplet_bwd(_p(Ut), Ut.shape[0], _p(It), It.shape[0], D, _p(users), _p(pos), _p(neg), n,
+                                            _p(logits), _p(dloss), _p(gu), _p(gp), _p(gn), _stream()),
+              "re_bpr_triplet_bwd")
+    return gu, gp, gn
+
+
+# ------------------------------------------------------------------------------------------------ K4
+def score_dense(Q, E):
+    _req(Q, torch.float32, "Q"); _req(E, torch.float32, "E")
+    B, D = Q.shape
+    N = E.shape[0]
+    out = torch.empty((B, N), dtype=torch.float32, device=Q.device)
+    lib.check(lib.load().re_score_dense(_p(Q), _p(E), B, N, D, _p(out), _stream()), "re_score_dense")
+    return out
+
+
+def score_topk(Q, E, seen_ptr, seen_idx, K):
+    """Fused score + seen-mask + top-K.  seen_ptr int64[B+1], seen_idx int64[nnz] with every user's ids ASCENDING
+    (None/None = retain_seen).  -> (vals f32 [B,K] descending, idx int64 [B,K])."""
+    _req(Q, torch.float32, "Q"); _req(E, torch.float32, "E")
+    B, D = Q.shape
+    N = E.shape[0]
+    if seen_ptr is not None:
+        _req(seen_ptr, torch.int64, "seen_ptr"); _req(seen_idx, torch.int64, "seen_idx")
+        if seen_ptr.numel() != B + 1:
+            raise ValueError("recengine: seen_ptr must have B+1 entries")
+    if not (0 < K <= TOPK_MAX):
+        raise ValueError(f"recengine: K must be in 1..{TOPK_MAX}")
+    L = lib.load()
+    dev = Q.device
+    vals = torch.empty((B, K), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, K), dtype=torch.int64, device=dev)
+    ws = _ws(L.re_score_topk_workspace_bytes(B, N, D, K), dev)
+    lib.check(L.re_score_topk(_p(Q), _p(E), B, N, D, _p(seen_ptr), _p(seen_idx), K, _p(vals), _p(idx), _p(ws),
+                              ws.numel(), _stream()), "re_score_topk")
+    return vals, idx
+
+
+# ------------------------------------------------------------------------------------------------ K10
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nme)
+    lib.check(lib.load().re_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(beta1),
+                                      float(beta2), float(eps), float(weight_decay), _stream()), "re_adam_step")

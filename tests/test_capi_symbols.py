@@ -1,0 +1,40 @@
+"""CPU: the C-ABI library loads and exports every symbol include/recengine.h declares (no compute calls)."""
+import os
+import re
+
+from recboard_amd import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "recengine.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(re_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"librecengine.so does not export {n}"
+        assert n in lib.SIGNATURES, f"recboard_amd/lib.py has no ctypes signature for {n}"
+    assert sorted(lib.SIGNATURES) == names
+    assert L.re_abi_version() == 1
+    assert L.re_error_string(0) == b"ok"
+
+
+def test_workspace_queries_are_pure_host_calls():
+    L = lib.load()
+    assert L.re_scatter_add_rows_workspace_bytes(76800, 64, 12102) > 4 * 76800 * 4
+    assert L.re_score_topk_workspace_bytes(22363, 12101, 64, 50) >= 22363 * 50 * 8
+    assert L.re_pair_loss_workspace_bytes(1000) >= 8192
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    import pytest
+    import torch
+    from recboard_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gather_rows(torch.zeros(4, 8), torch.zeros(3, dtype=torch.long))
