@@ -13,8 +13,7 @@
  *     no global mutable state (re-entrant).
  *   - return 0 on success, a negative RE_E* code otherwise (no exceptions cross the ABI).
  *   - fp32 data, int64 indices (the reference is fp32/int64 everywhere).
- *   - out-of-range indices never fault: they read as a zero row / are dropped, and are counted in the
- *     optional `status` word where an entry point takes one.
+ *   - out-of-range indices never fault: they read as a zero row / are dropped.
  */
 #ifndef RECENGINE_H
 #define RECENGINE_H
@@ -111,7 +110,8 @@ int re_bpr_triplet_bwd(const float* Ut, int64_t RU, const float* It, int64_t RI,
  *   scores -> scores[seen] = -1e23 -> top-K, without materialising B x N.
  *   vals [B,K] sorted descending, idx [B,K] int64; ties -> lowest item index; if fewer than K items are
  *   unmasked the tail is filled with masked items (value -1e23) in ascending index order; if K > N the
- *   remaining slots get (-inf, -1).  seen_ptr[B+1]/seen_idx[nnz] is a CSR of int64 item ids (any order);
+ *   remaining slots get (-inf, -1).  seen_ptr[B+1]/seen_idx[nnz] is a CSR of int64 item ids, ASCENDING inside
+ *   every user's range (duplicates allowed);
  *   seen_ptr == NULL means retain_seen.
  * Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32), i.e. a k-ordered fmaf chain per score -- exact fp32.
  * D must be a multiple of 8 and <= 256; K <= RE_TOPK_MAX. */
@@ -125,9 +125,10 @@ int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t 
 /* ---------------------------------------------------------------------------------------------------------
  * K10  dense Adam with coupled L2 (torch.optim.Adam semantics, eps 1e-8, no amsgrad), one launch over a flat
  * parameter arena.  Replaces `self.optimizer.step()` (SASRec/main.py:250; cfg dump
- * benchmark/Amazon2014Beauty_550_LOU/SASRec.json:254-300).  step is 1-based.  g may alias nothing else. */
-int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr,
-                 float beta1, float beta2, float eps, float weight_decay, re_stream_t stream);
+ * benchmark/Amazon2014Beauty_550_LOU/SASRec.json:254-300).  step is 1-based.  Hyper-parameters are doubles because
+ * torch derives 1-beta and the bias corrections in double precision before rounding to fp32. */
+int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
+                 double beta1, double beta2, double eps, double weight_decay, re_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -36,24 +36,25 @@ __global__ __launch_bounds__(256) void adam_tail(float* __restrict__ p, const fl
     p[i] = p[i] - step_size * (M / (sqrtf(V) * inv_sqrt_bc2 + eps));
 }
 
-extern "C" int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, re_stream_t stream) {
+extern "C" int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr, double beta1,
+                            double beta2, double eps, double weight_decay, re_stream_t stream) {
+    re_clear_error();
     if (n == 0) return RE_OK;
     if (!p || !g || !m || !v || n < 0 || step < 1) return RE_EINVAL;
     if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
           reinterpret_cast<uintptr_t>(v)) & 15u) != 0)
         return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const int64_t n4 = n >> 2;
     if (n4 > 0)
         hipLaunchKernelGGL(adam_vec4, dim3(re_grid(n4, 256)), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m, (float4*)v, n4,
-                           beta1, beta2, 1.0f - beta1, 1.0f - beta2, step_size, inv_sqrt_bc2, eps, weight_decay);
+                           (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), step_size, inv_sqrt_bc2, (float)eps, (float)weight_decay);
     if (n & 3)
-        hipLaunchKernelGGL(adam_tail, dim3(1), dim3(256), 0, s, p, g, m, v, n4 << 2, n, beta1, beta2, 1.0f - beta1, 1.0f - beta2,
-                           step_size, inv_sqrt_bc2, eps, weight_decay);
+        hipLaunchKernelGGL(adam_tail, dim3(1), dim3(256), 0, s, p, g, m, v, n4 << 2, n, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                           (float)(1.0 - beta2), step_size, inv_sqrt_bc2, (float)eps, (float)weight_decay);
     return re_launch_status();
 }

@@ -60,6 +60,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int re_gather_rows(const float* W, int64_t R, int64_t D, const int64_t* idx, int64_t n, float* out,
                               re_stream_t stream) {
+    re_clear_error();
     if (n == 0) return RE_OK;
     if (!W || !idx || !out || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void sasrec_embed_vec4(const float* __restrict
 
 extern "C" int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float* P, const int64_t* seq, int64_t B,
                                int64_t S, float scale, float drop_p, uint32_t seed, float* out, re_stream_t stream) {
+    re_clear_error();
     const int64_t n = B * S;
     if (n == 0) return RE_OK;
     if (!E || !P || !seq || !out || R <= 0 || D <= 0 || B < 0 || S <= 0) return RE_EINVAL;

@@ -186,6 +186,7 @@ static int pair_bwd(const float* Ubase, int64_t ldu, int64_t RU, const int64_t* 
 extern "C" int re_pair_loss_fwd(const float* U, int64_t ldu, const float* E, int64_t R, int64_t D, int64_t e_off,
                                 const int64_t* pos, const int64_t* neg, const uint8_t* valid, int64_t n, int kind,
                                 float* logits, float* loss, int32_t* count, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
     return pair_fwd(U, ldu, n > 0 ? n : 1, nullptr, E, R, D, e_off, pos, neg, valid, n, kind, logits, loss, count, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -193,6 +194,7 @@ extern "C" int re_pair_loss_bwd(const float* U, int64_t ldu, const float* E, int
                                 const int64_t* pos, const int64_t* neg, const uint8_t* valid, int64_t n, int kind,
                                 const float* logits, const int32_t* count, const float* dloss, float* dU, int64_t lddu,
                                 float* gpos, float* gneg, re_stream_t stream) {
+    re_clear_error();
     if (!count) return RE_EINVAL;
     return pair_bwd(U, ldu, n > 0 ? n : 1, nullptr, E, R, D, e_off, pos, neg, valid, n, kind, logits, count, 0, dloss, dU, lddu, gpos, gneg, (hipStream_t)stream);
 }
@@ -200,6 +202,7 @@ extern "C" int re_pair_loss_bwd(const float* U, int64_t ldu, const float* E, int
 extern "C" int re_bpr_triplet_fwd(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D,
                                   const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                                   float* logits, float* loss, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
     if (!users) return RE_EINVAL;
     return pair_fwd(Ut, D, RU, users, It, RI, D, 0, pos, neg, nullptr, n, RE_LOSS_BPR, logits, loss, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -208,6 +211,7 @@ extern "C" int re_bpr_triplet_bwd(const float* Ut, int64_t RU, const float* It, 
                                   const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                                   const float* logits, const float* dloss, float* gu, float* gpos, float* gneg,
                                   re_stream_t stream) {
+    re_clear_error();
     if (!users) return RE_EINVAL;
     return pair_bwd(Ut, D, RU, users, It, RI, D, 0, pos, neg, nullptr, n, RE_LOSS_BPR, logits, nullptr, n, dloss, gu, D, gpos, gneg, (hipStream_t)stream);
 }

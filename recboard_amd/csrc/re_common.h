@@ -7,6 +7,9 @@
 
 #define RE_WAVE 64
 
+// hipGetLastError() is sticky per host thread and other libraries in the process (torch) may leave an error
+// behind: every ABI entry clears it first, so re_launch_status() reports only this call's launches.
+static inline void re_clear_error() { (void)hipGetLastError(); }
 static inline int re_launch_status() {
     return hipGetLastError() == hipSuccess ? RE_OK : RE_ELAUNCH;
 }

@@ -274,6 +274,7 @@ extern "C" size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int6
 extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                                    int64_t padding_idx, float scale, float* dW, void* ws, size_t ws_bytes,
                                    re_stream_t stream) {
+    re_clear_error();
     if (!dW || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
     if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;

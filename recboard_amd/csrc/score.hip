@@ -378,6 +378,7 @@ static int score_dispatch(int64_t D, const float* Q, const float* E, int64_t B, 
 }
 
 extern "C" int re_score_dense(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, float* out, re_stream_t stream) {
+    re_clear_error();
     if (B == 0 || N == 0) return RE_OK;
     if (!Q || !E || !out || B < 0 || N < 0) return RE_EINVAL;
     if ((reinterpret_cast<uintptr_t>(E) & 15u) != 0 || N >= 0x7FFFFFFFll) return RE_EUNSUPPORTED;
@@ -388,6 +389,7 @@ extern "C" int re_score_dense(const float* Q, const float* E, int64_t B, int64_t
 extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, const int64_t* seen_ptr,
                              const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx, void* ws, size_t ws_bytes,
                              re_stream_t stream) {
+    re_clear_error();
     if (B == 0) return RE_OK;
     if (!Q || !E || !vals || !idx || !ws || B < 0 || N <= 0 || K <= 0 || K > RE_TOPK_MAX) return RE_EINVAL;
     if ((reinterpret_cast<uintptr_t>(E) & 15u) != 0 || N >= 0x7FFFFFFFll) return RE_EUNSUPPORTED;

@@ -9,8 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librecengine.so")
 
-_vp, _i64, _i32, _f32, _u32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
-                                    ctypes.c_uint32, ctypes.c_size_t)
+_vp, _i64, _i32, _f32, _u32, _sz, _f64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                          ctypes.c_uint32, ctypes.c_size_t, ctypes.c_double)
 
 # name -> (restype, argtypes); mirrors include/recengine.h one to one
 SIGNATURES = {
@@ -28,7 +28,7 @@ SIGNATURES = {
     "re_score_dense": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "re_score_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_score_topk": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "re_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "re_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _vp]),
 }
 
 _LIB = None
@@ -43,6 +43,10 @@ def load():
         raise RuntimeError(
             f"recengine: {LIB_PATH} not found -- the HIP extension is required (no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C recboard_amd/csrc`.")
+    # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7); it must be the one already mapped when
+    # librecengine.so resolves the same SONAME, otherwise the process ends up with two HIP runtimes and every
+    # launch on a torch stream fails.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
