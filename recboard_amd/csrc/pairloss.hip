@@ -82,12 +82,18 @@ __global__ __launch_bounds__(256) void pair_loss_fwd_k(const float* __restrict__
 
 __global__ __launch_bounds__(64) void pair_loss_finalize(const float* __restrict__ bsum, const int32_t* __restrict__ bcnt,
                                                          int nblocks, float* __restrict__ loss, int32_t* __restrict__ count) {
-    if (threadIdx.x != 0) return;
+    // one wave: lane l sums blocks l, l+64, ... in order, then a fixed shuffle tree -> deterministic
+    const int lane = threadIdx.x;
     float s = 0.f;
     int c = 0;
-    for (int b = 0; b < nblocks; ++b) { s += bsum[b]; c += bcnt[b]; }
-    loss[0] = c > 0 ? s / (float)c : 0.f / 0.f;  // mean over an empty set is NaN, as torch's
-    if (count) count[0] = c;
+    for (int b = lane; b < nblocks; b += 64) { s += bsum[b]; c += bcnt[b]; }
+    s = re_wave_sum(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) {
+        loss[0] = c > 0 ? s / (float)c : 0.f / 0.f;  // mean over an empty set is NaN, as torch's
+        if (count) count[0] = c;
+    }
 }
 
 template <int LPR>

@@ -1,0 +1,240 @@
+"""SASRec on the engine: the host-side mirror of the reference's `SASRec` (SASRec/main.py:53-236) and of the step
+loop in `CoachForSASRec.train_per_epoch` (SASRec/main.py:242-258).
+
+Same parameter names/shapes as the reference's state_dict (`Item.embeddings.weight`, `Position.weight`,
+`attnLayers.l.in_proj_weight`, `fwdLayers.l.conv1.weight` [D,D,1], ...), same method names (`encode`, `fit`,
+`recommend_from_full`) and argument meaning, so the parity tests read like the reference's own code.
+
+MI355X-first layout: every parameter is a view into ONE contiguous fp32 arena in HBM; gradients, and Adam's m/v
+live in arenas of the same layout.  Consequences: the optimizer is a single fused launch (re_adam_step), a
+data-parallel step needs exactly one RCCL all-reduce (the whole gradient arena is one bucket), and checkpoints
+are one tensor.  The arena is padded so every parameter starts 16-byte aligned (float4 access in the kernels).
+
+Hot-path ops are librecengine kernels (recboard_amd/ops.py); there is no CPU fallback.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+
+
+def param_shapes(num_items: int, maxlen: int, D: int, num_blocks: int):
+    """Reference state_dict order (SASRec/main.py:70-111)."""
+    shapes = OrderedDict()
+    shapes["Item.embeddings.weight"] = (num_items + 1, D)  # row 0 = padding (NUM_PADS = 1)
+    shapes["Position.weight"] = (maxlen, D)
+    for l in range(num_blocks):
+        shapes[f"attnLNs.{l}.weight"] = (D,)
+        shapes[f"attnLNs.{l}.bias"] = (D,)
+    for l in range(num_blocks):
+        shapes[f"attnLayers.{l}.in_proj_weight"] = (3 * D, D)
+        shapes[f"attnLayers.{l}.in_proj_bias"] = (3 * D,)
+        shapes[f"attnLayers.{l}.out_proj.weight"] = (D, D)
+        shapes[f"attnLayers.{l}.out_proj.bias"] = (D,)
+    for l in range(num_blocks):
+        shapes[f"fwdLNs.{l}.weight"] = (D,)
+        shapes[f"fwdLNs.{l}.bias"] = (D,)
+    for l in range(num_blocks):
+        shapes[f"fwdLayers.{l}.conv1.weight"] = (D, D, 1)
+        shapes[f"fwdLayers.{l}.conv1.bias"] = (D,)
+        shapes[f"fwdLayers.{l}.conv2.weight"] = (D, D, 1)
+        shapes[f"fwdLayers.{l}.conv2.bias"] = (D,)
+    shapes["lastLN.weight"] = (D,)
+    shapes["lastLN.bias"] = (D,)
+    return shapes
+
+
+class ParamArena:
+    """Named fp32 views into one contiguous device buffer (+ same-layout buffers for grad / Adam state)."""
+
+    def __init__(self, shapes, device):
+        self.shapes = shapes
+        self.offsets = OrderedDict()
+        off = 0
+        for k, shp in shapes.items():
+            self.offsets[k] = off
+            off += (math.prod(shp) + 3) // 4 * 4
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.data)
+        self.m = torch.zeros_like(self.data)
+        self.v = torch.zeros_like(self.data)
+        self.step = 0
+
+    def view(self, buf, k):
+        o = self.offsets[k]
+        return buf[o:o + math.prod(self.shapes[k])].view(self.shapes[k])
+
+    def views(self, buf):
+        return OrderedDict((k, self.view(buf, k)) for k in self.shapes)
+
+
+class _EmbedFn(torch.autograd.Function):
+    """x = E[seq]*sqrt(D) + P[s], pad rows 0 (re_sasrec_embed); backward = deterministic scatter-add into dense dE."""
+
+    @staticmethod
+    def forward(ctx, E, P, seq, scale):
+        ctx.save_for_backward(seq)
+        ctx.R, ctx.scale, ctx.S = E.shape[0], scale, seq.shape[1]
+        return ops.sasrec_embed(E, P, seq, scale)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (seq,) = ctx.saved_tensors
+        gout = gout.contiguous()
+        dE = ops.scatter_add_rows(gout, seq, ctx.R, 0, ctx.scale)
+        dP = (gout * (seq != 0).unsqueeze(-1)).sum(0)
+        return dE, dP, None, None
+
+
+class _PairLossFn(torch.autograd.Function):
+    """mean BCE(pos,1)+BCE(neg,0) / BPR over the valid positions (re_pair_loss_fwd/bwd), item rows = E[1 + id]."""
+
+    @staticmethod
+    def forward(ctx, U, E, pos, neg, valid, rows_pos, rows_neg, kind):
+        U2 = U.reshape(-1, U.shape[-1])
+        loss, logits, count = ops.pair_loss_fwd(U2, E, pos, neg, valid, kind, e_off=1)
+        ctx.save_for_backward(U2, E, pos, neg, valid, rows_pos, rows_neg, logits, count)
+        ctx.kind, ctx.ushape = kind, U.shape
+        return loss.squeeze(0)
+
+    @staticmethod
+    def backward(ctx, gl):
+        U2, E, pos, neg, valid, rows_pos, rows_neg, logits, count = ctx.saved_tensors
+        dU, gp, gn = ops.pair_loss_bwd(U2, E, pos, neg, valid, ctx.kind, logits, count, gl.reshape(1).contiguous(), e_off=1)
+        dE = ops.scatter_add_rows(torch.cat([gp, gn]), torch.cat([rows_pos, rows_neg]), E.shape[0], 0, 1.0)
+        return dU.view(ctx.ushape), dE, None, None, None, None, None, None
+
+
+class SASRecEngine:
+    """SASRec (reference defaults: D=64, 2 blocks, 1 head, maxlen 50) with engine kernels on the hot path."""
+
+    def __init__(self, num_items, maxlen=50, embedding_dim=64, num_blocks=2, dropout_rate=0.0, loss="BCE",
+                 lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1):
+        assert loss in ("BCE", "BPR")
+        self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
+        self.p_drop, self.loss_kind = dropout_rate, loss
+        self.lr, self.wd, self.betas = lr, weight_decay, betas
+        self.device = torch.device(device)
+        self.arena = ParamArena(param_shapes(num_items, maxlen, embedding_dim, num_blocks), self.device)
+        self.training = True
+        self.seed = seed
+        self.params = OrderedDict()
+        for k in self.arena.shapes:
+            p = self.arena.view(self.arena.data, k).requires_grad_(True)
+            self.params[k] = p
+        self.reset_parameters(seed)
+
+    # ---- reference SASRec.reset_parameters (SASRec/main.py:130-141): embeddings + nn.Linear (= out_proj) xavier-normal,
+    #      MHA in_proj xavier-uniform, Conv1d default kaiming-uniform(a=sqrt(5)), LN gamma=1 beta=0, biases 0
+    def reset_parameters(self, seed=1):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        D = self.D
+        with torch.no_grad():
+            for k, p in self.params.items():
+                shp = tuple(p.shape)
+                if k.endswith("embeddings.weight") or k == "Position.weight" or k.endswith("out_proj.weight"):
+                    std = math.sqrt(2.0 / (shp[0] + shp[1]))
+                    w = torch.randn(shp, generator=g) * std
+                elif k.endswith("in_proj_weight"):
+                    bound = math.sqrt(6.0 / (shp[0] + shp[1]))
+                    w = (torch.rand(shp, generator=g) * 2 - 1) * bound
+                elif "conv" in k:
+                    bound = 1.0 / math.sqrt(D)
+                    w = (torch.rand(shp, generator=g) * 2 - 1) * bound
+                elif "LN" in k and k.endswith("weight"):
+                    w = torch.ones(shp)
+                else:
+                    w = torch.zeros(shp)
+                p.copy_(w.to(self.device))
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for k, p in self.params.items():
+                p.copy_(torch.as_tensor(sd[k]).to(self.device).view(p.shape))
+
+    def state_dict(self):
+        return OrderedDict((k, p.detach().clone()) for k, p in self.params.items())
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ---- encoder (aten path; the fused HIP encoder replaces `_blocks`)
+    def _drop(self, x):
+        return torch.nn.functional.dropout(x, self.p_drop, self.training) if self.p_drop > 0 else x
+
+    def _blocks(self, x, pad):
+        P, D, S = self.params, self.D, x.shape[1]
+        F = torch.nn.functional
+        causal = torch.ones(S, S, dtype=torch.bool, device=x.device).triu(1)
+        for l in range(self.L):
+            Wi, bi = P[f"attnLayers.{l}.in_proj_weight"], P[f"attnLayers.{l}.in_proj_bias"]
+            q = F.layer_norm(x, (D,), P[f"attnLNs.{l}.weight"], P[f"attnLNs.{l}.bias"], 1e-8) @ Wi[:D].T + bi[:D]
+            kv = x @ Wi[D:].T + bi[D:]
+            k, v = kv[..., :D], kv[..., D:]
+            att = (q @ k.transpose(1, 2)) / math.sqrt(D)
+            att = self._drop(torch.softmax(att.masked_fill(causal, float("-inf")), -1))
+            x = (att @ v) @ P[f"attnLayers.{l}.out_proj.weight"].T + P[f"attnLayers.{l}.out_proj.bias"] + x
+            y = F.layer_norm(x, (D,), P[f"fwdLNs.{l}.weight"], P[f"fwdLNs.{l}.bias"], 1e-8)
+            h = self._drop(y @ P[f"fwdLayers.{l}.conv1.weight"].squeeze(-1).T + P[f"fwdLayers.{l}.conv1.bias"])
+            o = self._drop(torch.relu(h) @ P[f"fwdLayers.{l}.conv2.weight"].squeeze(-1).T + P[f"fwdLayers.{l}.conv2.bias"])
+            x = (o + y).masked_fill(pad, 0.0)
+        return F.layer_norm(x, (D,), P["lastLN.weight"], P["lastLN.bias"], 1e-8)
+
+    def encode(self, seq):
+        """-> (userEmbds [B,S,D], itemEmbds = E[1:]).  SASRec/main.py:178-193."""
+        E = self.params["Item.embeddings.weight"]
+        x = _EmbedFn.apply(E, self.params["Position.weight"], seq, float(self.D ** 0.5))
+        pad = (seq == 0).unsqueeze(-1)
+        x = self._drop(x)  # pads are zero before and after dropout, as in the reference's order of ops
+        return self._blocks(x, pad), E[1:]
+
+    def fit(self, seq, pos, neg, aux=None):
+        """-> {"rec_loss": scalar}.  SASRec/main.py:195-221 (BCE / BPR)."""
+        u, _ = self.encode(seq)
+        if aux is None:
+            aux = self.batch_aux(seq, pos, neg)
+        valid, rows_pos, rows_neg = aux
+        kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
+        loss = _PairLossFn.apply(u, self.params["Item.embeddings.weight"], pos.reshape(-1), neg.reshape(-1), valid,
+                                 rows_pos, rows_neg, kind)
+        return {"rec_loss": loss}
+
+    @staticmethod
+    def batch_aux(seq, pos, neg):
+        """Per-batch index helpers (belong to batch assembly, not to the step): valid mask as uint8 and the
+        destination rows of the pos/neg gradient contributions (row 0 = padding row, dropped)."""
+        v = (seq != 0).reshape(-1)
+        return (v.to(torch.uint8), torch.where(v, pos.reshape(-1) + 1, 0), torch.where(v, neg.reshape(-1) + 1, 0))
+
+    def recommend_from_full(self, seq):
+        """scores [B, N] = u[:, -1, :] . E[1:]^T  (SASRec/main.py:223-228) -- dense drop-in."""
+        with torch.no_grad():
+            u, items = self.encode(seq)
+            return ops.score_dense(u[:, -1, :].contiguous(), items)
+
+    def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):
+        """Coach.evaluate contract fused (UniSRec/main.py:408-414): masked top-K without the B x N matrix."""
+        with torch.no_grad():
+            u, items = self.encode(seq)
+            return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K)
+
+    # ---- CoachForSASRec.train_per_epoch body (SASRec/main.py:243-250): zero_grad, backward, Adam step
+    def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
+        A = self.arena
+        A.grad.zero_()
+        for k, p in self.params.items():
+            p.grad = A.view(A.grad, k)
+        loss = self.fit(seq, pos, neg, aux)["rec_loss"]
+        loss.backward()
+        if grad_hook is not None:
+            grad_hook(A.grad)  # data parallel: one all-reduce over the whole gradient arena
+        A.step += 1
+        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        return loss.detach()
