@@ -123,6 +123,35 @@ int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t 
                   void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * K6/K7  fused SASRec encoder (D = 64, S <= 64, L <= 4, 1 head): one workgroup per sequence, activations in LDS.
+ * Replaces the per-block aten chain of SASRec/main.py:163-176 (after_one_block), :31-50 (PointWiseFeedForward),
+ * :188-191 (block loop + lastLN): LN -> q/k/v -> causal softmax (pads attended as keys, K/V not layer-normed)
+ * -> out_proj + residual -> LN -> Conv1d(k=1) FFN + residual -> pad mask; all five dropout sites in-kernel
+ * (counter-based masks, csrc/re_rng.h; drop_p = 0 disables them).
+ *   x0 [B,S,D]  = re_sasrec_embed output;  seq [B,S] int64 (0 = pad);  u [B,S,D] = userEmbds (lastLN output).
+ *   block_params: HOST array of 12*L DEVICE pointers, per block in this order:
+ *     attnLNs.weight, attnLNs.bias, in_proj_weight [3D,D], in_proj_bias [3D], out_proj.weight [D,D], out_proj.bias,
+ *     fwdLNs.weight, fwdLNs.bias, conv1.weight [D,D(,1)], conv1.bias, conv2.weight, conv2.bias
+ *   tape: NULL for inference; otherwise re_sasrec_tape_bytes() bytes that receive the activations the backward
+ *   needs (x, q, k, v, P, o, x1, relu(h), LN statistics).
+ * re_sasrec_encoder_bwd: given dU [B,S,D] (gradient w.r.t. u) and the tape of the SAME (drop_p, seed) forward,
+ *   writes dx0 [B,S,D] (gradient w.r.t. x0, for re_scatter_add_rows / the position table) and OVERWRITES the
+ *   parameter gradients: block_grads is a HOST array of 12*L DEVICE pointers in the order above.
+ *   Weight gradients are accumulated per workgroup in registers, written as slabs and reduced in a fixed order
+ *   (deterministic, no float atomics). */
+size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
+int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                          const float* const* block_params, const float* last_w, const float* last_b,
+                          float drop_p, uint32_t seed, float* u, void* tape, size_t tape_bytes,
+                          re_stream_t stream);
+size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
+int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                          const float* const* block_params, const float* last_w, const float* last_b,
+                          float drop_p, uint32_t seed, const void* tape, float* dx0,
+                          float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
+                          size_t ws_bytes, re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * K10  dense Adam with coupled L2 (torch.optim.Adam semantics, eps 1e-8, no amsgrad), one launch over a flat
  * parameter arena.  Replaces `self.optimizer.step()` (SASRec/main.py:250; cfg dump
  * benchmark/Amazon2014Beauty_550_LOU/SASRec.json:254-300).  step is 1-based.  Hyper-parameters are doubles because

@@ -1,0 +1,403 @@
+// K6/K7 backward: one launch per SASRec block (l = L-1 .. 0), one sequence per workgroup iteration, everything in LDS.
+//
+// Gradient of the block of sasrec_fwd.hip (SASRec/main.py:163-176 + :31-50) w.r.t. its input and its 12 parameters,
+// reading the forward's tape (x, q, k, v, P, o, x1, relu(h), LN statistics) instead of recomputing the forward:
+// 16 GEMMs of 64^3 per sequence per block (2 per linear map: dX = dY W and dW += dY^T X).  Layer-normed operands
+// (LN_a(x), LN_f(x1)) are rebuilt from the saved statistics; dropout masks are regenerated from (seed, stream, index).
+//
+// Parameter gradients: each wave keeps its 16x64 strip of the six 64x64 weight gradients in registers (96 VGPRs)
+// across all the sequences its persistent workgroup processes; bias / LayerNorm gradients are per-thread column
+// partials.  At the end every workgroup writes ONE slab (27 648 floats); sasrec_grad_reduce sums the slabs in a
+// fixed order straight into the gradient tensors: deterministic, no float atomics (cdna_hip_programming.md G12).
+//
+// MFMA-bound: 16 GEMMs x 2*64^3 = 8.39 MFLOP per sequence per block.
+#include <math.h>
+
+#include "sasrec_common.h"
+
+#define SB_NMAT 6
+#define SB_NVEC 12
+#define SB_SLAB (SB_NMAT * 4096 + SB_NVEC * 256)
+// matrix slots: 0 Wq 1 Wk 2 Wv 3 Wo 4 W1 5 W2;  vector slots: 0 bq 1 bk 2 bv 3 bo 4 b1 5 b2 6 ga 7 ba 8 gf 9 bf 10 glast 11 blast
+
+template <bool A_KC>
+__device__ __forceinline__ void gemm64_acc(const float* A, const float (&bf)[16], int lane, f32x4 (&acc)[4]) {
+    const int g = lane >> 4, c = lane & 15;
+    float af[4][16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (A_KC) frag_kc(af[t], A + (16 * t + c) * SE_LS + 16 * g);
+        else frag_ks(af[t], A + (16 * g) * SE_LS + 16 * t + c, SE_LS);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
+}
+
+// sum over this thread's 16 rows of one column
+__device__ __forceinline__ float colsum16(const float* tile, int tid) {
+    const int c = tid & 63, r0 = (tid >> 6) * 16;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += tile[(r0 + i) * SE_LS + c];
+    return s;
+}
+// sum over 16 rows of dy * xhat, xhat = (x - mean[row]) * rstd[row]
+__device__ __forceinline__ float colsum16_xhat(const float* dy, const float* x, const float* mean, const float* rstd, int tid) {
+    const int c = tid & 63, r0 = (tid >> 6) * 16;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + i;
+        s = fmaf(dy[r * SE_LS + c], (x[r * SE_LS + c] - mean[r]) * rstd[r], s);
+    }
+    return s;
+}
+// LayerNorm backward for this thread's row slice: dst (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma
+template <bool ACCUM>
+__device__ __forceinline__ void ln_bwd_row(const float* dy, const float* x, float* dst, const float* __restrict__ gamma,
+                                           const float* mean, const float* rstd, int tid) {
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    float d[16], xv[16];
+    frag_kc(d, dy + r * SE_LS + c0);
+    frag_kc(xv, x + r * SE_LS + c0);
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        xv[i] = (xv[i] - mu) * rs;
+        d[i] *= gamma[c0 + i];
+        s1 += d[i];
+        s2 = fmaf(d[i], xv[i], s2);
+    }
+    s1 = quad_sum(s1) * (1.0f / SE_D);
+    s2 = quad_sum(s2) * (1.0f / SE_D);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = rs * (d[i] - s1 - xv[i] * s2);
+        if (ACCUM) dst[r * SE_LS + c0 + i] += v; else dst[r * SE_LS + c0 + i] = v;
+    }
+}
+// y = (x - mean) * rstd * gamma + beta from saved statistics
+__device__ __forceinline__ void ln_apply_row(const float* x, float* dst, const float* __restrict__ gw, const float* __restrict__ gb,
+                                             const float* mean, const float* rstd, int tid) {
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    const float mu = mean[r], rs = rstd[r];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[r * SE_LS + c0 + i] = (x[r * SE_LS + c0 + i] - mu) * rs * gw[c0 + i] + gb[c0 + i];
+}
+
+__device__ __forceinline__ void load_stats(float* s_mean, float* s_rstd, const float* __restrict__ st, int S, int tid) {
+    if (tid < SE_ROWS) {
+        s_mean[tid] = tid < S ? st[2 * tid] : 0.f;
+        s_rstd[tid] = tid < S ? st[2 * tid + 1] : 0.f;
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restrict__ dIn, const int64_t* __restrict__ seq, int B, int S,
+                                                          int l, SasrecBlockParams W, const float* __restrict__ last_w,
+                                                          float drop_scale, uint32_t thresh, uint32_t seed,
+                                                          const float* __restrict__ tape, SasrecTape T,
+                                                          float* __restrict__ dOut, float* __restrict__ slab) {
+    extern __shared__ __align__(16) float lds[];
+    float* b0 = lds;
+    float* b1 = b0 + SE_BUF;
+    float* b2 = b1 + SE_BUF;
+    float* b3 = b2 + SE_BUF;
+    float* b4 = b3 + SE_BUF;
+    float* b5 = b4 + SE_BUF;
+    float* b6 = b5 + SE_BUF;
+    __shared__ float s_mean[SE_ROWS], s_rstd[SE_ROWS];
+    __shared__ int s_pad[SE_ROWS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15, col = 16 * wave + c;
+    const int64_t SD = (int64_t)S * SE_D;
+    const float* tp = tape + (int64_t)l * T.per_block;
+
+    f32x4 accW[SB_NMAT][4];
+#pragma unroll
+    for (int m = 0; m < SB_NMAT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accW[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float accV[SB_NVEC];
+#pragma unroll
+    for (int v = 0; v < SB_NVEC; ++v) accV[v] = 0.f;
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        tile_load(b0, dIn + (int64_t)b * SD, S, tid);
+        if (tid < SE_ROWS) s_pad[tid] = (tid < S) ? (seq[(int64_t)b * S + tid] == 0) : 1;
+        if (FIRST) {
+            tile_load(b1, tape + T.off_XL + (int64_t)b * SD, S, tid);
+            load_stats(s_mean, s_rstd, tape + T.off_SL + (int64_t)b * S * 2, S, tid);
+        }
+        __syncthreads();
+        if (FIRST) {  // u = LN_last(x_L): dgamma/dbeta, then dx_L in place
+            accV[10] += colsum16_xhat(b0, b1, s_mean, s_rstd, tid);
+            accV[11] += colsum16(b0, tid);
+            __syncthreads();
+            ln_bwd_row<false>(b0, b1, b0, last_w, s_mean, s_rstd, tid);
+            __syncthreads();
+        }
+        // ---- pad mask of the block output (x'[pad] = 0) and dO2 = dX' * dropout2 mask
+        tile_load(b1, tp + T.off_HR + (int64_t)b * SD, S, tid);
+        {
+            const int r = tid >> 2, c0 = (tid & 3) * 16;
+            const bool dead = s_pad[r] != 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = dead ? 0.f : b0[r * SE_LS + c0 + i];
+                b0[r * SE_LS + c0 + i] = v;
+                if (thresh) {
+                    const uint32_t e = (uint32_t)((((int64_t)b * S + r) * SE_D) + c0 + i);
+                    v = re_keep(seed, RE_STREAM_FFN2(l), e, thresh) ? v * drop_scale : 0.f;
+                }
+                b2[r * SE_LS + c0 + i] = v;
+            }
+        }
+        __syncthreads();
+        // ---- A. FFN second map: dW2 += dO2^T hr; db2; dH = (dO2 W2) * (hr > 0) * scale
+        {
+            float bf[16];
+            frag_ks(bf, b1 + (16 * g) * SE_LS + col, SE_LS);
+            gemm64_acc<false>(b2, bf, lane, accW[5]);
+            accV[5] += colsum16(b2, tid);
+            wfrag_ks(bf, W.w2, wave, lane);
+            gemm64<true>(b2, bf, lane, [&](int row, float v) {
+                b3[row * SE_LS + col] = (b1[row * SE_LS + col] > 0.f) ? v * drop_scale : 0.f;
+            });
+        }
+        __syncthreads();
+        // ---- B. FFN first map: y = LN_f(x1) rebuilt; dW1 += dH^T y; db1; dY = dH W1 + dX'
+        tile_load(b1, tp + T.off_X1 + (int64_t)b * SD, S, tid);
+        load_stats(s_mean, s_rstd, tp + T.off_SF + (int64_t)b * S * 2, S, tid);
+        __syncthreads();
+        ln_apply_row(b1, b2, W.ln_f_w, W.ln_f_b, s_mean, s_rstd, tid);
+        __syncthreads();
+        {
+            float bf[16];
+            frag_ks(bf, b2 + (16 * g) * SE_LS + col, SE_LS);
+            gemm64_acc<false>(b3, bf, lane, accW[4]);
+            accV[4] += colsum16(b3, tid);
+            wfrag_ks(bf, W.w1, wave, lane);
+            gemm64<true>(b3, bf, lane, [&](int row, float v) { b0[row * SE_LS + col] += v; });
+        }
+        __syncthreads();
+        // ---- C. LN_f backward: dgamma_f, dbeta_f, dX1 (in place in b0)
+        accV[8] += colsum16_xhat(b0, b1, s_mean, s_rstd, tid);
+        accV[9] += colsum16(b0, tid);
+        __syncthreads();
+        ln_bwd_row<false>(b0, b1, b0, W.ln_f_w, s_mean, s_rstd, tid);
+        __syncthreads();
+        // ---- D. out_proj: dWo += dX1^T o; dbo; dO = dX1 Wo
+        tile_load(b2, tp + T.off_O + (int64_t)b * SD, S, tid);
+        __syncthreads();
+        {
+            float bf[16];
+            frag_ks(bf, b2 + (16 * g) * SE_LS + col, SE_LS);
+            gemm64_acc<false>(b0, bf, lane, accW[3]);
+            accV[3] += colsum16(b0, tid);
+            wfrag_ks(bf, W.out_w, wave, lane);
+            gemm64<true>(b0, bf, lane, [&](int row, float v) { b3[row * SE_LS + col] = v; });
+        }
+        __syncthreads();
+        // ---- E. attention: load V, P; Pd = P*mask; dP = (dO V^T)*mask; dV = Pd^T dO; dS = P (dP - rowsum(dP P)) / sqrt(D)
+        tile_load(b1, tp + T.off_V + (int64_t)b * SD, S, tid);
+        {
+            const float* Pg = tp + T.off_P + (int64_t)b * S * S;
+            const int i = tid >> 2, j0 = (tid & 3) * 16;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = j0 + jj;
+                float p = (i < S && j <= i) ? Pg[i * S + j] : 0.f;
+                float m = 1.0f;
+                if (thresh && p != 0.f) {
+                    const uint32_t e = (uint32_t)(((int64_t)b * S + i) * S + j);
+                    m = re_keep(seed, RE_STREAM_ATTN(l), e, thresh) ? drop_scale : 0.f;
+                }
+                b4[i * SE_LS + j] = p;
+                b6[i * SE_LS + j] = p * m;
+            }
+        }
+        __syncthreads();
+        {
+            float bf[16];
+            frag_kc(bf, b1 + (16 * wave + c) * SE_LS + 16 * g);  // B^T = V (k = d contiguous)
+            gemm64<true>(b3, bf, lane, [&](int row, float v) {
+                // grad w.r.t. the pre-dropout probability: scale by the same mask factor Pd/P (0, or 1/(1-p))
+                const float p = b4[row * SE_LS + col];
+                const float pd = b6[row * SE_LS + col];
+                b5[row * SE_LS + col] = (p != 0.f) ? v * (pd / p) : 0.f;
+            });
+            frag_ks(bf, b3 + (16 * g) * SE_LS + col, SE_LS);     // B[k=i][n=d] = dO
+            gemm64<false>(b6, bf, lane, [&](int row, float v) { b2[row * SE_LS + col] = v; });  // dV
+        }
+        __syncthreads();
+        {
+            const int i = tid >> 2, j0 = (tid & 3) * 16;
+            float dp[16], pp[16];
+            frag_kc(dp, b5 + i * SE_LS + j0);
+            frag_kc(pp, b4 + i * SE_LS + j0);
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) s = fmaf(dp[jj], pp[jj], s);
+            s = quad_sum(s);
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) b5[i * SE_LS + j0 + jj] = pp[jj] * (dp[jj] - s) * 0.125f;
+        }
+        // ---- F. dQ = dS K -> b4 ; dK = dS^T Q -> b6
+        tile_load(b3, tp + T.off_Q + (int64_t)b * SD, S, tid);
+        __syncthreads();   // dS complete; V (b1) and P (b4) no longer needed
+        tile_load(b1, tp + T.off_K + (int64_t)b * SD, S, tid);
+        __syncthreads();
+        {
+            float bf[16];
+            frag_ks(bf, b1 + (16 * g) * SE_LS + col, SE_LS);
+            gemm64<true>(b5, bf, lane, [&](int row, float v) { b4[row * SE_LS + col] = v; });
+            frag_ks(bf, b3 + (16 * g) * SE_LS + col, SE_LS);
+            gemm64<false>(b5, bf, lane, [&](int row, float v) { b6[row * SE_LS + col] = v; });
+        }
+        __syncthreads();
+        // ---- G. projections: x, LN_a(x) rebuilt; dWq/dWk/dWv, biases; dA1 = dQ Wq -> b5; dX (b0) += dK Wk + dV Wv
+        tile_load(b1, tp + T.off_X + (int64_t)b * SD, S, tid);
+        load_stats(s_mean, s_rstd, tp + T.off_SA + (int64_t)b * S * 2, S, tid);
+        __syncthreads();
+        ln_apply_row(b1, b3, W.ln_a_w, W.ln_a_b, s_mean, s_rstd, tid);
+        __syncthreads();
+        {
+            float bf[16];
+            frag_ks(bf, b3 + (16 * g) * SE_LS + col, SE_LS);     // LN_a(x)
+            gemm64_acc<false>(b4, bf, lane, accW[0]);
+            frag_ks(bf, b1 + (16 * g) * SE_LS + col, SE_LS);     // x
+            gemm64_acc<false>(b6, bf, lane, accW[1]);
+            gemm64_acc<false>(b2, bf, lane, accW[2]);
+            accV[0] += colsum16(b4, tid);
+            accV[1] += colsum16(b6, tid);
+            accV[2] += colsum16(b2, tid);
+            wfrag_ks(bf, W.in_w, wave, lane);
+            gemm64<true>(b4, bf, lane, [&](int row, float v) { b5[row * SE_LS + col] = v; });
+            wfrag_ks(bf, W.in_w + SE_D * SE_D, wave, lane);
+            gemm64<true>(b6, bf, lane, [&](int row, float v) { b0[row * SE_LS + col] += v; });
+            wfrag_ks(bf, W.in_w + 2 * SE_D * SE_D, wave, lane);
+            gemm64<true>(b2, bf, lane, [&](int row, float v) { b0[row * SE_LS + col] += v; });
+        }
+        __syncthreads();
+        // ---- H. LN_a backward: dgamma_a, dbeta_a; dX += LN_a'(dA1)
+        accV[6] += colsum16_xhat(b5, b1, s_mean, s_rstd, tid);
+        accV[7] += colsum16(b5, tid);
+        ln_bwd_row<true>(b5, b1, b0, W.ln_a_w, s_mean, s_rstd, tid);
+        __syncthreads();
+        tile_store(b0, dOut + (int64_t)b * SD, S, tid);
+    }
+
+    // ---- this workgroup's slab
+    float* sl = slab + (int64_t)blockIdx.x * SB_SLAB;
+#pragma unroll
+    for (int m = 0; m < SB_NMAT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[m * 4096 + (16 * t + 4 * g + j) * SE_D + col] = accW[m][t][j];
+#pragma unroll
+    for (int v = 0; v < SB_NVEC; ++v) sl[SB_NMAT * 4096 + v * 256 + tid] = accV[v];
+}
+
+struct SasrecGradDst {
+    float* p[14];  // ABI order of the 12 block gradients, then g_last_w, g_last_b (may be null)
+};
+
+// out = sum over workgroups (ascending) of the slab entries; one thread per output element
+__global__ __launch_bounds__(256) void sasrec_grad_reduce(const float* __restrict__ slab, int nwg, SasrecGradDst dst, int with_last) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int NM = SB_NMAT * 4096;
+    const int nvec = with_last ? SB_NVEC : SB_NVEC - 2;
+    if (e < NM) {
+        float s = 0.f;
+        for (int w = 0; w < nwg; ++w) s += slab[(int64_t)w * SB_SLAB + e];
+        const int m = e >> 12, off = e & 4095;
+        float* d = (m < 3) ? dst.p[2] + m * 4096 : (m == 3 ? dst.p[4] : (m == 4 ? dst.p[8] : dst.p[10]));
+        d[off] = s;
+    } else if (e < NM + nvec * 64) {
+        const int v = (e - NM) >> 6, cc = (e - NM) & 63;
+        float s = 0.f;
+        for (int w = 0; w < nwg; ++w) {
+            const float* q = slab + (int64_t)w * SB_SLAB + NM + v * 256 + cc;
+            s += ((q[0] + q[64]) + q[128]) + q[192];
+        }
+        float* d;
+        switch (v) {
+            case 0: case 1: case 2: d = dst.p[3] + v * 64; break;
+            case 3: d = dst.p[5]; break;
+            case 4: d = dst.p[9]; break;
+            case 5: d = dst.p[11]; break;
+            case 6: d = dst.p[0]; break;
+            case 7: d = dst.p[1]; break;
+            case 8: d = dst.p[6]; break;
+            case 9: d = dst.p[7]; break;
+            case 10: d = dst.p[12]; break;
+            default: d = dst.p[13]; break;
+        }
+        d[cc] = s;
+    }
+}
+
+#define SB_MAX_WGS 256
+
+extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L) {
+    (void)L;
+    if (B <= 0) return 256;
+    const int64_t nwg = B < SB_MAX_WGS ? B : SB_MAX_WGS;
+    return (size_t)(nwg * SB_SLAB + 2 * B * S * D) * sizeof(float) + 512;
+}
+
+extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                                     const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
+                                     uint32_t seed, const void* tape, float* dx0, float* const* block_grads, float* g_last_w,
+                                     float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (B == 0) return RE_OK;
+    if (!dU || !seq || !tape || !dx0 || !block_params || !block_grads || !g_last_w || !g_last_b || !last_w || !last_b || !ws || B < 0)
+        return RE_EINVAL;
+    if (D != SE_D || S < 1 || S > SE_ROWS || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
+    if (drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
+    if (ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L)) return RE_EWORKSPACE;
+    for (int64_t i = 0; i < 12 * L; ++i)
+        if (!block_params[i] || !block_grads[i]) return RE_EINVAL;
+    const SasrecTape T = sasrec_tape_layout(B, S, D, L);
+    const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
+    const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const int nwg = (int)(B < SB_MAX_WGS ? B : SB_MAX_WGS);
+    float* slab = (float*)ws;
+    float* dxa = slab + (size_t)nwg * SB_SLAB;
+    float* dxb = dxa + (size_t)B * S * D;
+    const size_t ldsb = (size_t)7 * SE_BUF * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    auto kf = sasrec_block_bwd_k<true>;
+    auto kn = sasrec_block_bwd_k<false>;
+    if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+    const float* din = dU;
+    for (int64_t l = L - 1; l >= 0; --l) {
+        const float* const* q = block_params + 12 * l;
+        SasrecBlockParams W{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]};
+        float* dout = (l == 0) ? dx0 : (((L - 1 - l) & 1) ? dxb : dxa);
+        const bool first = (l == L - 1);
+        if (first)
+            hipLaunchKernelGGL(kf, dim3(nwg), dim3(256), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
+                               (const float*)tape, T, dout, slab);
+        else
+            hipLaunchKernelGGL(kn, dim3(nwg), dim3(256), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
+                               (const float*)tape, T, dout, slab);
+        SasrecGradDst dst;
+        for (int i = 0; i < 12; ++i) dst.p[i] = block_grads[12 * l + i];
+        dst.p[12] = g_last_w;
+        dst.p[13] = g_last_b;
+        const int nelem = SB_NMAT * 4096 + SB_NVEC * 64;
+        hipLaunchKernelGGL(sasrec_grad_reduce, dim3((nelem + 255) / 256), dim3(256), 0, s, slab, nwg, dst, first ? 1 : 0);
+        din = dout;
+    }
+    return re_launch_status();
+}

@@ -1,0 +1,147 @@
+// Shared device helpers for the fused SASRec encoder kernels (D = 64, S <= 64; one workgroup = one sequence).
+//
+// All per-sequence activations live in LDS as [64 rows][SE_LS floats] row-major tiles (rows >= S are zero / unused);
+// every product is a 64x64x64 GEMM on v_mfma_f32_16x16x4_f32 (exact fp32), wave w of the 4 waves owning output
+// columns [16w, 16w+16).  The k index of an MFMA step is free as long as A and B agree, so lane group g = lane>>4
+// takes k = 16g + s at step s: a k-contiguous operand fragment is then 16 consecutive floats (4 x ds_read_b128 or
+// 4 x global_load_dwordx4), which is how weights W[out][in] (y = x W^T) and row-major activations are consumed
+// without any transposed copies.
+#pragma once
+#include "re_common.h"
+#include "re_rng.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SE_D 64
+#define SE_ROWS 64
+#define SE_LS 68  // LDS row stride in floats (16-B pad: conflict-free b128 fragment reads)
+#define SE_BUF (SE_ROWS * SE_LS)
+
+struct SasrecBlockParams {
+    const float *ln_a_w, *ln_a_b;   // attnLNs.l
+    const float *in_w, *in_b;       // attnLayers.l.in_proj_{weight,bias}  [3D, D], [3D]
+    const float *out_w, *out_b;     // attnLayers.l.out_proj
+    const float *ln_f_w, *ln_f_b;   // fwdLNs.l
+    const float *w1, *b1, *w2, *b2; // fwdLayers.l.conv{1,2} ([D, D, 1] == [D, D])
+};
+#define SE_MAX_BLOCKS 4
+struct SasrecParams {
+    SasrecBlockParams blk[SE_MAX_BLOCKS];
+    const float *last_w, *last_b;
+};
+
+// ---- tape layout (activations saved by the forward for the backward), all fp32, per block l:
+//   X, Q, K, V, O, X1, HR : [B][S][D]     P : [B][S][S]     stats_a, stats_f : [B][S][2] (mean, rstd)
+// then XL [B][S][D] (input of lastLN) and stats_last [B][S][2].
+struct SasrecTape {
+    int64_t per_block, off_X, off_Q, off_K, off_V, off_O, off_X1, off_HR, off_P, off_SA, off_SF, off_XL, off_SL, total;
+};
+__host__ __device__ inline SasrecTape sasrec_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L) {
+    SasrecTape t;
+    const int64_t act = B * S * D, pp = B * S * S, st = B * S * 2;
+    int64_t o = 0;
+    t.off_X = o; o += act;
+    t.off_Q = o; o += act;
+    t.off_K = o; o += act;
+    t.off_V = o; o += act;
+    t.off_O = o; o += act;
+    t.off_X1 = o; o += act;
+    t.off_HR = o; o += act;
+    t.off_P = o; o += (pp + 3) / 4 * 4;
+    t.off_SA = o; o += st;
+    t.off_SF = o; o += st;
+    t.per_block = o;
+    t.off_XL = L * o;
+    t.off_SL = t.off_XL + act;
+    t.total = t.off_SL + st;
+    return t;
+}
+
+// ---- fragments ------------------------------------------------------------------------------------------
+// k-contiguous: 16 consecutive floats starting at p (16-B aligned)
+__device__ __forceinline__ void frag_kc(float (&f)[16], const float* p) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+        f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+}
+// k-strided: f[s] = p[s * stride]
+__device__ __forceinline__ void frag_ks(float (&f)[16], const float* p, int stride) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) f[s] = p[s * stride];
+}
+
+// C[m][16w + c] = sum_k A[m][k] * B[k][16w + c] for all 64 rows m.
+// A_KC: A is an LDS tile [m][k] (k contiguous); otherwise A is given transposed, i.e. the LDS tile is [k][m].
+// bf[s] = B[k = 16g + s][n = 16w + c] is supplied by the caller.  epi(row, value) is called for the lane's column.
+template <bool A_KC, class Epi>
+__device__ __forceinline__ void gemm64(const float* A, const float (&bf)[16], int lane, Epi epi) {
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 acc[4];
+    float af[4][16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (A_KC) frag_kc(af[t], A + (16 * t + c) * SE_LS + 16 * g);
+        else frag_ks(af[t], A + (16 * g) * SE_LS + 16 * t + c, SE_LS);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi(16 * t + 4 * g + j, acc[t][j]);
+}
+
+// weight fragment for y = x W^T: B[k][n] = W[n][k], W row-major [64][64] in global memory (k contiguous)
+__device__ __forceinline__ void wfrag_kc(float (&bf)[16], const float* W, int wave, int lane) {
+    frag_kc(bf, W + (16 * wave + (lane & 15)) * SE_D + 16 * (lane >> 4));
+}
+// weight fragment for dx = dy W: B[k][n] = W[k][n] (k strided)
+__device__ __forceinline__ void wfrag_ks(float (&bf)[16], const float* W, int wave, int lane) {
+    frag_ks(bf, W + (16 * (lane >> 4)) * SE_D + 16 * wave + (lane & 15), SE_D);
+}
+
+// ---- row-wise helpers: thread tid handles row tid>>2, columns [16*(tid&3), +16) ----------------------------------
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+}
+
+// LayerNorm of one LDS tile row-slice (eps 1e-8, biased variance -- nn.LayerNorm, SASRec/main.py:89,94,106)
+__device__ __forceinline__ void ln_row(const float* src, float* dst, const float* __restrict__ gw, const float* __restrict__ gb,
+                                       int tid, float& mean, float& rstd) {
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    float x[16];
+    frag_kc(x, src + r * SE_LS + c0);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += x[i];
+    mean = quad_sum(s) * (1.0f / SE_D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = x[i] - mean; q = fmaf(d, d, q); }
+    rstd = 1.0f / sqrtf(quad_sum(q) * (1.0f / SE_D) + 1e-8f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[r * SE_LS + c0 + i] = (x[i] - mean) * rstd * gw[c0 + i] + gb[c0 + i];
+}
+
+// copy an LDS tile's first S rows to / from a [S][64] global matrix (coalesced float4)
+__device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ gdst, int S, int tid) {
+    for (int f = tid; f < S * (SE_D / 4); f += 256) {
+        const int r = f >> 4, c4 = f & 15;
+        reinterpret_cast<float4*>(gdst)[f] = *reinterpret_cast<const float4*>(tile + r * SE_LS + 4 * c4);
+    }
+}
+__device__ __forceinline__ void tile_load(float* tile, const float* __restrict__ gsrc, int S, int tid) {
+    for (int f = tid; f < SE_ROWS * (SE_D / 4); f += 256) {
+        const int r = f >> 4, c4 = f & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < S) v = reinterpret_cast<const float4*>(gsrc)[f];
+        *reinterpret_cast<float4*>(tile + r * SE_LS + 4 * c4) = v;
+    }
+}

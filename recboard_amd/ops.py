@@ -172,6 +172,57 @@ def score_topk(Q, E, seen_ptr, seen_idx, K):
     return vals, idx
 
 
+# ------------------------------------------------------------------------------------------------ K6/K7
+BLOCK_PARAM_ORDER = ("attnLNs.{l}.weight", "attnLNs.{l}.bias", "attnLayers.{l}.in_proj_weight", "attnLayers.{l}.in_proj_bias",
+                     "attnLayers.{l}.out_proj.weight", "attnLayers.{l}.out_proj.bias", "fwdLNs.{l}.weight", "fwdLNs.{l}.bias",
+                     "fwdLayers.{l}.conv1.weight", "fwdLayers.{l}.conv1.bias", "fwdLayers.{l}.conv2.weight",
+                     "fwdLayers.{l}.conv2.bias")
+
+
+def _ptr_table(tensors):
+    """HOST array of device pointers (the ABI's `const float* const*`)."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        _req(t, torch.float32, f"param[{i}]")
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def sasrec_block_tensors(named, L):
+    """Flatten a name->tensor mapping (reference state_dict names) into the ABI's 12-per-block order."""
+    return [named[k.format(l=l)] for l in range(L) for k in BLOCK_PARAM_ORDER]
+
+
+def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False):
+    """u = lastLN(blocks(x0)) fused (re_sasrec_encoder_fwd).  -> (u [B,S,D], tape or None)."""
+    _req(x0, torch.float32, "x0"); _req(seq, torch.int64, "seq")
+    B, S, D = x0.shape
+    Lb = lib.load()
+    u = torch.empty_like(x0)
+    tape = None
+    if need_tape:
+        tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=x0.device)
+    tbl = _ptr_table(block_tensors)
+    lib.check(Lb.re_sasrec_encoder_fwd(_p(x0), _p(seq), B, S, D, L, tbl, _p(last_w), _p(last_b), float(drop_p),
+                                       int(seed) & 0xFFFFFFFF, _p(u), _p(tape), 0 if tape is None else tape.numel() * 4,
+                                       _stream()), "re_sasrec_encoder_fwd")
+    return u, tape
+
+
+def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b):
+    """-> dx0 [B,S,D]; OVERWRITES the tensors in block_grads / g_last_* with the parameter gradients."""
+    _req(dU, torch.float32, "dU"); _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape")
+    B, S, D = dU.shape
+    Lb = lib.load()
+    dx0 = torch.empty_like(dU)
+    ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
+    tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
+    lib.check(Lb.re_sasrec_encoder_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
+                                       int(seed) & 0xFFFFFFFF, _p(tape), _p(dx0), tg, _p(g_last_w), _p(g_last_b), _p(ws),
+                                       ws.numel(), _stream()), "re_sasrec_encoder_bwd")
+    return dx0
+
+
 # ------------------------------------------------------------------------------------------------ K10
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
