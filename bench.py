@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
+    ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,12 +133,12 @@ def main():
     from recboard_amd.sasrec import SASRecEngine
     cfg = BEAUTY
     model = SASRecEngine(cfg["items"], cfg["S"], cfg["D"], cfg["L"], dropout_rate=cfg["p_drop"], loss="BCE",
-                         lr=cfg["lr"], weight_decay=cfg["wd"], seed=1)
+                         lr=cfg["lr"], weight_decay=cfg["wd"], seed=1, encoder=args.encoder)
     host_batches = synth_batches(cfg, 8, seed=1 + rank)
     batches = []
     for seq, pos, neg in host_batches:
         t = tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg))
-        batches.append(t + (model.batch_aux(*t),))
+        batches.append(t + ((model.batch_aux_fused(*t) if args.encoder == 'fused' else model.batch_aux(*t)),))
 
     hook = None
     if world > 1:

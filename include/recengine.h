@@ -54,6 +54,14 @@ int re_gather_rows(const float* W, int64_t R, int64_t D, const int64_t* idx, int
 int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float* P, const int64_t* seq, int64_t B,
                     int64_t S, float scale, float drop_p, uint32_t seed, float* out, re_stream_t stream);
 
+/* Backward of re_sasrec_embed, in place on gx [B,S,D]: in = gradient w.r.t. x0 (from re_sasrec_encoder_bwd), out =
+ * contribution rows for re_scatter_add_rows (pad rows zero, the forward's dropout mask re-applied, times `scale`);
+ * dP [S,D] = sum over b of the masked gradient (gradient of the position table, SASRec/main.py:159-161).
+ * Deterministic. */
+size_t re_sasrec_embed_bwd_workspace_bytes(int64_t S, int64_t D);
+int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int64_t S, int64_t D, float scale, float drop_p,
+                        uint32_t seed, float* dP, void* ws, size_t ws_bytes, re_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * K1b  dense gradient of the gather: dW[r,:] = sum_{i: idx[i]==r} g[i,:], rows == padding_idx skipped,
  * every other row zero.  dW [R,D] is fully overwritten.  Deterministic (sorted segments, fixed chunking):

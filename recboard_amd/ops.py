@@ -46,20 +46,34 @@ def gather_rows(W: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def sasrec_embed(E, P, seq, scale, drop_p=0.0, seed=0):
+def sasrec_embed(E, P, seq, scale, drop_p=0.0, seed=0, out=None):
     """(E[seq]*scale + P[s]) with pad rows zeroed and optional engine dropout (re_sasrec_embed)."""
     _req(E, torch.float32, "E"); _req(P, torch.float32, "P"); _req(seq, torch.int64, "seq")
     B, S = seq.shape
     R, D = E.shape
     if P.shape[0] < S or P.shape[1] != D:
         raise ValueError("recengine: position table must be [>=S, D]")
-    out = torch.empty((B, S, D), dtype=torch.float32, device=E.device)
+    if out is None:
+        out = torch.empty((B, S, D), dtype=torch.float32, device=E.device)
     lib.check(lib.load().re_sasrec_embed(_p(E), R, D, _p(P), _p(seq), B, S, float(scale), float(drop_p),
                                          int(seed) & 0xFFFFFFFF, _p(out), _stream()), "re_sasrec_embed")
     return out
 
 
-def scatter_add_rows(g: torch.Tensor, idx: torch.Tensor, R: int, padding_idx: int = -1, scale: float = 1.0):
+def sasrec_embed_bwd(gx, seq, scale, drop_p, seed, dP, ws=None):
+    """In place on gx [B,S,D] (gradient w.r.t. x0 -> scatter contribution rows); writes dP [S,D] (re_sasrec_embed_bwd)."""
+    _req(gx, torch.float32, "gx"); _req(seq, torch.int64, "seq"); _req(dP, torch.float32, "dP")
+    B, S, D = gx.shape
+    L = lib.load()
+    if ws is None:
+        ws = _ws(L.re_sasrec_embed_bwd_workspace_bytes(S, D), gx.device)
+    lib.check(L.re_sasrec_embed_bwd(_p(gx), _p(seq), B, S, D, float(scale), float(drop_p), int(seed) & 0xFFFFFFFF, _p(dP),
+                                    _p(ws), ws.numel(), _stream()), "re_sasrec_embed_bwd")
+    return gx
+
+
+def scatter_add_rows(g: torch.Tensor, idx: torch.Tensor, R: int, padding_idx: int = -1, scale: float = 1.0, out=None,
+                     ws=None):
     """Dense [R, D] gradient of gather_rows, deterministic (re_scatter_add_rows)."""
     _req(g, torch.float32, "g"); _req(idx, torch.int64, "idx")
     D = g.shape[-1]
@@ -67,8 +81,10 @@ def scatter_add_rows(g: torch.Tensor, idx: torch.Tensor, R: int, padding_idx: in
     if g.numel() != n * D:
         raise ValueError("recengine: g must have one row per index")
     L = lib.load()
-    ws = _ws(L.re_scatter_add_rows_workspace_bytes(n, D, R), g.device)
-    dW = torch.empty((R, D), dtype=torch.float32, device=g.device)
+    if ws is None:
+        ws = _ws(L.re_scatter_add_rows_workspace_bytes(n, D, R), g.device)
+    dW = out if out is not None else torch.empty((R, D), dtype=torch.float32, device=g.device)
+    _req(dW, torch.float32, "out")
     lib.check(L.re_scatter_add_rows(_p(g), _p(idx), n, D, R, int(padding_idx), float(scale), _p(dW), _p(ws),
                                     ws.numel(), _stream()), "re_scatter_add_rows")
     return dW
@@ -96,13 +112,16 @@ def pair_loss_fwd(U, E, pos, neg, valid, kind, e_off=0):
     return loss, logits, count
 
 
-def pair_loss_bwd(U, E, pos, neg, valid, kind, logits, count, dloss, e_off=0):
+def pair_loss_bwd(U, E, pos, neg, valid, kind, logits, count, dloss, e_off=0, out=None):
     """-> (dU [n,D], gpos [n,D], gneg [n,D]) contribution rows."""
     n, D = U.shape
     dev = U.device
-    dU = torch.empty((n, D), dtype=torch.float32, device=dev)
-    gpos = torch.empty((n, D), dtype=torch.float32, device=dev)
-    gneg = torch.empty((n, D), dtype=torch.float32, device=dev)
+    if out is not None:
+        dU, gpos, gneg = (_req(t, torch.float32, "out") for t in out)
+    else:
+        dU = torch.empty((n, D), dtype=torch.float32, device=dev)
+        gpos = torch.empty((n, D), dtype=torch.float32, device=dev)
+        gneg = torch.empty((n, D), dtype=torch.float32, device=dev)
     if dloss is not None:
         _req(dloss, torch.float32, "dloss")
     lib.check(lib.load().re_pair_loss_bwd(_p(U), U.stride(0), _p(E), E.shape[0], D, e_off, _p(pos), _p(neg), _p(valid),
@@ -193,14 +212,13 @@ def sasrec_block_tensors(named, L):
     return [named[k.format(l=l)] for l in range(L) for k in BLOCK_PARAM_ORDER]
 
 
-def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False):
+def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None, tape=None):
     """u = lastLN(blocks(x0)) fused (re_sasrec_encoder_fwd).  -> (u [B,S,D], tape or None)."""
     _req(x0, torch.float32, "x0"); _req(seq, torch.int64, "seq")
     B, S, D = x0.shape
     Lb = lib.load()
-    u = torch.empty_like(x0)
-    tape = None
-    if need_tape:
+    u = out if out is not None else torch.empty_like(x0)
+    if need_tape and tape is None:
         tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=x0.device)
     tbl = _ptr_table(block_tensors)
     lib.check(Lb.re_sasrec_encoder_fwd(_p(x0), _p(seq), B, S, D, L, tbl, _p(last_w), _p(last_b), float(drop_p),
@@ -209,13 +227,16 @@ def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, se
     return u, tape
 
 
-def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b):
+def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b,
+                       out=None, ws=None):
     """-> dx0 [B,S,D]; OVERWRITES the tensors in block_grads / g_last_* with the parameter gradients."""
     _req(dU, torch.float32, "dU"); _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape")
     B, S, D = dU.shape
     Lb = lib.load()
-    dx0 = torch.empty_like(dU)
-    ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
+    dx0 = out if out is not None else torch.empty_like(dU)
+    _req(dx0, torch.float32, "out")
+    if ws is None:
+        ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
     tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
     lib.check(Lb.re_sasrec_encoder_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
                                        int(seed) & 0xFFFFFFFF, _p(tape), _p(dx0), tg, _p(g_last_w), _p(g_last_b), _p(ws),

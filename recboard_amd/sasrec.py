@@ -18,6 +18,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops
+from .lib import load as lib_load
 
 
 def param_shapes(num_items: int, maxlen: int, D: int, num_blocks: int):
@@ -112,8 +113,13 @@ class SASRecEngine:
     """SASRec (reference defaults: D=64, 2 blocks, 1 head, maxlen 50) with engine kernels on the hot path."""
 
     def __init__(self, num_items, maxlen=50, embedding_dim=64, num_blocks=2, dropout_rate=0.0, loss="BCE",
-                 lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1):
+                 lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, encoder="fused"):
         assert loss in ("BCE", "BPR")
+        assert encoder in ("fused", "aten")
+        if encoder == "fused" and (embedding_dim != 64 or maxlen > 64 or num_blocks > 4):
+            raise NotImplementedError("fused encoder kernels: D = 64, maxlen <= 64, blocks <= 4 (use encoder='aten')")
+        self.encoder = encoder
+        self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
         self.p_drop, self.loss_kind = dropout_rate, loss
         self.lr, self.wd, self.betas = lr, weight_decay, betas
@@ -187,8 +193,26 @@ class SASRecEngine:
             x = (o + y).masked_fill(pad, 0.0)
         return F.layer_norm(x, (D,), P["lastLN.weight"], P["lastLN.bias"], 1e-8)
 
+    def _block_tensors(self, buf=None):
+        A = self.arena
+        named = self.params if buf is None else A.views(buf)
+        return ops.sasrec_block_tensors({k: v.detach() for k, v in named.items()}, self.L)
+
+    def _step_seed(self):
+        """32-bit dropout seed of the current step (counter-based masks: (seed, stream, element) -> keep bit)."""
+        return (self.seed * 0x9E3779B1 + (self.arena.step + 1) * 0x85EBCA77) & 0xFFFFFFFF
+
     def encode(self, seq):
         """-> (userEmbds [B,S,D], itemEmbds = E[1:]).  SASRec/main.py:178-193."""
+        if self.encoder == "fused" and not torch.is_grad_enabled():
+            P = self.params
+            E = P["Item.embeddings.weight"].detach()
+            p = self.p_drop if self.training else 0.0
+            sd = self._step_seed()
+            x0 = ops.sasrec_embed(E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), p, sd)
+            u, _ = ops.sasrec_encoder_fwd(x0, seq, self._block_tensors(), P["lastLN.weight"].detach(),
+                                          P["lastLN.bias"].detach(), self.L, p, sd)
+            return u, E[1:]
         E = self.params["Item.embeddings.weight"]
         x = _EmbedFn.apply(E, self.params["Position.weight"], seq, float(self.D ** 0.5))
         pad = (seq == 0).unsqueeze(-1)
@@ -225,8 +249,66 @@ class SASRecEngine:
             u, items = self.encode(seq)
             return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K)
 
+    @staticmethod
+    def batch_aux_fused(seq, pos, neg):
+        """As batch_aux, for the fused step: (valid uint8 [B*S], destination rows of all 3*B*S gradient contributions)."""
+        v, rp, rn = SASRecEngine.batch_aux(seq, pos, neg)
+        return v, torch.cat([seq.reshape(-1), rp, rn])
+
+    def _buffers(self, B, S):
+        key = (B, S)
+        if key not in self._bufs:
+            D, dev, L = self.D, self.device, lib_load()
+            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+            u8 = lambda n: torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)  # noqa: E731
+            n3 = 3 * B * S
+            self._bufs[key] = dict(
+                x0=f(B, S, D), u=f(B, S, D), dU=f(B * S, D), contrib=f(n3, D),
+                tape=f(L.re_sasrec_tape_bytes(B, S, D, self.L) // 4),
+                ws_bwd=u8(L.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, self.L)),
+                ws_emb=u8(L.re_sasrec_embed_bwd_workspace_bytes(S, D)),
+                ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
+        return self._bufs[key]
+
+    def train_step_fused(self, seq, pos, neg, aux=None, grad_hook=None):
+        """One training step with every hot-path op a librecengine kernel and no autograd graph:
+        embed -> fused encoder (tape) -> fused pair loss -> loss bwd -> per-block encoder bwd (+ slab reduce)
+        -> embed bwd -> ONE deterministic scatter-add of all 3*B*S item-gradient rows -> fused Adam."""
+        A, P, D = self.arena, self.params, self.D
+        B, S = seq.shape
+        if aux is None:
+            aux = self.batch_aux_fused(seq, pos, neg)
+        valid, rows_all = aux
+        W = self._buffers(B, S)
+        G = A.views(A.grad)
+        p = self.p_drop if self.training else 0.0
+        sd = self._step_seed()
+        E, Ppos = P["Item.embeddings.weight"].detach(), P["Position.weight"].detach()
+        lw, lb = P["lastLN.weight"].detach(), P["lastLN.bias"].detach()
+        bt = self._block_tensors()
+        kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
+        n = B * S
+        ops.sasrec_embed(E, Ppos, seq, float(D ** 0.5), p, sd, out=W["x0"])
+        ops.sasrec_encoder_fwd(W["x0"], seq, bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"])
+        u2 = W["u"].view(n, D)
+        posf, negf = pos.reshape(-1), neg.reshape(-1)
+        loss, logits, count = ops.pair_loss_fwd(u2, E, posf, negf, valid, kind, e_off=1)
+        C = W["contrib"]
+        ops.pair_loss_bwd(u2, E, posf, negf, valid, kind, logits, count, None, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
+        ops.sasrec_encoder_bwd(W["dU"].view(B, S, D), seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad),
+                               G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"])
+        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, G["Position.weight"], ws=W["ws_emb"])
+        ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=G["Item.embeddings.weight"], ws=W["ws_sc"])
+        if grad_hook is not None:
+            grad_hook(A.grad)
+        A.step += 1
+        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        return loss.squeeze(0)
+
     # ---- CoachForSASRec.train_per_epoch body (SASRec/main.py:243-250): zero_grad, backward, Adam step
     def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
+        if self.encoder == "fused":
+            return self.train_step_fused(seq, pos, neg, aux, grad_hook)
         A = self.arena
         A.grad.zero_()
         for k, p in self.params.items():

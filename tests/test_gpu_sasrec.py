@@ -13,6 +13,7 @@ def _engine(z, loss, **kw):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from recboard_amd.sasrec import SASRecEngine
+    kw.setdefault("encoder", "aten")
     m = SASRecEngine(int(z["cfg/N"]), 50, int(z["cfg/D"]), int(z["cfg/num_blocks"]), dropout_rate=0.0, loss=loss, **kw)
     m.load_state_dict({k[6:]: z[k] for k in z.files if k.startswith("param/") and z[k].dtype == np.float32})
     return m
@@ -41,9 +42,10 @@ def test_fit_loss_and_grads_match_reference_golden(loss):
     assert (m.params["Item.embeddings.weight"].grad[0] == 0).all()   # padding row gets no gradient
 
 
-def test_encode_scores_topk_match_reference_golden():
+@pytest.mark.parametrize("encoder", ["aten", "fused"])
+def test_encode_scores_topk_match_reference_golden(encoder):
     z = np.load(os.path.join(G, "sasrec_bce.npz"))
-    m = _engine(z, "BCE").eval()
+    m = _engine(z, "BCE", encoder=encoder).eval()
     seq = dev(z["in/seq"])
     with torch.no_grad():
         u, _ = m.encode(seq)
@@ -55,18 +57,19 @@ def test_encode_scores_topk_match_reference_golden():
     np.testing.assert_allclose(vals.cpu().numpy(), z["out/topk_vals"], rtol=1e-4, atol=2e-5)
 
 
-def test_train_step_matches_oracle_adam_trajectory():
+@pytest.mark.parametrize("encoder,loss", [("aten", "BCE"), ("fused", "BCE"), ("fused", "BPR")])
+def test_train_step_matches_oracle_adam_trajectory(encoder, loss):
     """3 full steps (zero_grad, backward, dense Adam with coupled L2) vs oracle fit + torch.optim.Adam on CPU."""
     from oracle import sasrec as osas
-    z = np.load(os.path.join(G, "sasrec_bce.npz"))
-    m = _engine(z, "BCE", lr=5e-4, weight_decay=1e-6)
+    z = np.load(os.path.join(G, f"sasrec_{loss.lower()}.npz"))
+    m = _engine(z, loss, lr=5e-4, weight_decay=1e-6, encoder=encoder)
     P = osas.params_from_npz(z, requires_grad=True)
     opt = torch.optim.Adam(list(P.values()), lr=5e-4, betas=(0.9, 0.999), weight_decay=1e-6)
     seq, pos, neg = (torch.from_numpy(z[k]) for k in ("in/seq", "in/pos", "in/neg"))
     for step in range(3):
         l_gpu = m.train_step(seq.cuda(), pos.cuda(), neg.cuda())
         opt.zero_grad()
-        l_cpu = osas.fit(P, seq, pos, neg, "BCE", 2)
+        l_cpu = osas.fit(P, seq, pos, neg, loss, 2)
         l_cpu.backward()
         for p in P.values():       # params absent from the graph still take the dense L2 + moment update
             if p.grad is None:
@@ -75,3 +78,30 @@ def test_train_step_matches_oracle_adam_trajectory():
         np.testing.assert_allclose(l_gpu.item(), l_cpu.item(), rtol=2e-5)
     for k, p in m.params.items():
         np.testing.assert_allclose(p.detach().cpu().numpy(), P[k].detach().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)
+
+
+def test_fused_step_grads_match_reference_golden():
+    """fused train step (no autograd): every gradient in the arena vs the reference's loss.backward()."""
+    z = np.load(os.path.join(G, "sasrec_bce.npz"))
+    m = _engine(z, "BCE", lr=0.0, encoder="fused")       # lr 0: parameters stay put, gradients stay in the arena
+    seq, pos, neg = dev(z["in/seq"]), dev(z["in/pos"]), dev(z["in/neg"])
+    L = m.train_step(seq, pos, neg)
+    np.testing.assert_allclose(L.item(), float(z["out/rec_loss"]), rtol=1e-5)
+    Gv = m.arena.views(m.arena.grad)
+    for k in m.params:
+        ref = z["grad/" + k]
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(Gv[k].cpu().numpy() - ref).max()
+        assert err <= 1e-4 * scale + 1e-7, (k, err, scale)
+
+
+def test_fused_step_with_dropout_trains():
+    """dropout 0.5 (benchmark config): loss decreases over steps on a fixed batch, masks differ per step, nothing NaN."""
+    z = np.load(os.path.join(G, "sasrec_bce.npz"))
+    from recboard_amd.sasrec import SASRecEngine
+    m = SASRecEngine(200, 50, 64, 2, dropout_rate=0.5, loss="BCE", lr=1e-3, weight_decay=1e-6, encoder="fused")
+    seq, pos, neg = dev(z["in/seq"]), dev(z["in/pos"]), dev(z["in/neg"])
+    losses = [m.train_step(seq, pos, neg).item() for _ in range(60)]
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-10:]) < np.mean(losses[:10]) - 0.05
+    assert len({round(x, 6) for x in losses[:5]}) == 5
