@@ -33,6 +33,7 @@ __device__ __forceinline__ void gemm64_acc(const float* A, const float (&bf)[16]
     for (int s = 0; s < 16; ++s)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // sum over this thread's 16 rows of one column
@@ -97,7 +98,7 @@ __device__ __forceinline__ void load_stats(float* s_mean, float* s_rstd, const f
 
 template <bool FIRST>
 __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restrict__ dIn, const int64_t* __restrict__ seq, int B, int S,
-                                                          int l, SasrecBlockParams W, const float* __restrict__ last_w,
+                                                          int l, SasrecBlockParams W0, const float* __restrict__ last_w0,
                                                           float drop_scale, uint32_t thresh, uint32_t seed,
                                                           const float* __restrict__ tape, SasrecTape T,
                                                           float* __restrict__ dOut, float* __restrict__ slab) {
@@ -127,6 +128,8 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
     for (int v = 0; v < SB_NVEC; ++v) accV[v] = 0.f;
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const SasrecBlockParams W = se_launder(W0);
+        const float* last_w = se_launder(last_w0);
         __syncthreads();
         tile_load(b0, dIn + (int64_t)b * SD, S, tid);
         if (tid < SE_ROWS) s_pad[tid] = (tid < S) ? (seq[(int64_t)b * S + tid] == 0) : 1;
@@ -309,22 +312,38 @@ struct SasrecGradDst {
     float* p[14];  // ABI order of the 12 block gradients, then g_last_w, g_last_b (may be null)
 };
 
-// out = sum over workgroups (ascending) of the slab entries; one thread per output element
-__global__ __launch_bounds__(256) void sasrec_grad_reduce(const float* __restrict__ slab, int nwg, SasrecGradDst dst, int with_last) {
+// Slab reduction in two fixed-order levels (deterministic): level 1 sums groups of SB_RGROUP slabs with one thread per
+// (group, element) -- SB_RGROUP independent loads in flight per thread, nwg/SB_RGROUP x more threads than elements --
+// level 2 adds the group partials in order and writes the gradient tensors.
+#define SB_RGROUP 16
+__global__ __launch_bounds__(256) void sasrec_slab_partial(const float* __restrict__ slab, int nwg, float* __restrict__ part) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= SB_SLAB) return;
+    const int w0 = blockIdx.y * SB_RGROUP;
+    float v[SB_RGROUP];
+#pragma unroll
+    for (int i = 0; i < SB_RGROUP; ++i) v[i] = (w0 + i < nwg) ? slab[(int64_t)(w0 + i) * SB_SLAB + e] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < SB_RGROUP; ++i) s += v[i];
+    part[(int64_t)blockIdx.y * SB_SLAB + e] = s;
+}
+
+__global__ __launch_bounds__(256) void sasrec_grad_reduce(const float* __restrict__ part, int ngroups, SasrecGradDst dst, int with_last) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int NM = SB_NMAT * 4096;
     const int nvec = with_last ? SB_NVEC : SB_NVEC - 2;
     if (e < NM) {
         float s = 0.f;
-        for (int w = 0; w < nwg; ++w) s += slab[(int64_t)w * SB_SLAB + e];
+        for (int w = 0; w < ngroups; ++w) s += part[(int64_t)w * SB_SLAB + e];
         const int m = e >> 12, off = e & 4095;
         float* d = (m < 3) ? dst.p[2] + m * 4096 : (m == 3 ? dst.p[4] : (m == 4 ? dst.p[8] : dst.p[10]));
         d[off] = s;
     } else if (e < NM + nvec * 64) {
         const int v = (e - NM) >> 6, cc = (e - NM) & 63;
         float s = 0.f;
-        for (int w = 0; w < nwg; ++w) {
-            const float* q = slab + (int64_t)w * SB_SLAB + NM + v * 256 + cc;
+        for (int w = 0; w < ngroups; ++w) {
+            const float* q = part + (int64_t)w * SB_SLAB + NM + v * 256 + cc;
             s += ((q[0] + q[64]) + q[128]) + q[192];
         }
         float* d;
@@ -350,7 +369,8 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
     (void)L;
     if (B <= 0) return 256;
     const int64_t nwg = B < SB_MAX_WGS ? B : SB_MAX_WGS;
-    return (size_t)(nwg * SB_SLAB + 2 * B * S * D) * sizeof(float) + 512;
+    const int64_t ngroups = (nwg + SB_RGROUP - 1) / SB_RGROUP;
+    return (size_t)((nwg + ngroups) * SB_SLAB + 2 * B * S * D) * sizeof(float) + 512;
 }
 
 extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
@@ -370,8 +390,10 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int nwg = (int)(B < SB_MAX_WGS ? B : SB_MAX_WGS);
+    const int ngroups = (nwg + SB_RGROUP - 1) / SB_RGROUP;
     float* slab = (float*)ws;
-    float* dxa = slab + (size_t)nwg * SB_SLAB;
+    float* part = slab + (size_t)nwg * SB_SLAB;
+    float* dxa = part + (size_t)ngroups * SB_SLAB;
     float* dxb = dxa + (size_t)B * S * D;
     const size_t ldsb = (size_t)7 * SE_BUF * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
@@ -396,7 +418,8 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
         dst.p[12] = g_last_w;
         dst.p[13] = g_last_b;
         const int nelem = SB_NMAT * 4096 + SB_NVEC * 64;
-        hipLaunchKernelGGL(sasrec_grad_reduce, dim3((nelem + 255) / 256), dim3(256), 0, s, slab, nwg, dst, first ? 1 : 0);
+        hipLaunchKernelGGL(sasrec_slab_partial, dim3((SB_SLAB + 255) / 256, ngroups), dim3(256), 0, s, slab, nwg, part);
+        hipLaunchKernelGGL(sasrec_grad_reduce, dim3((nelem + 255) / 256), dim3(256), 0, s, part, ngroups, dst, first ? 1 : 0);
         din = dout;
     }
     return re_launch_status();

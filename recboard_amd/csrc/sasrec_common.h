@@ -57,6 +57,23 @@ __host__ __device__ inline SasrecTape sasrec_tape_layout(int64_t B, int64_t S, i
     return t;
 }
 
+// The persistent sequence loop makes every parameter load loop-invariant; hipcc then hoists ~100-200 VGPRs of weight
+// fragments out of the loop and spills.  Laundering the pointers once per iteration keeps the loads inside.
+template <class T>
+__device__ __forceinline__ const T* se_launder(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ SasrecBlockParams se_launder(SasrecBlockParams W) {
+    W.ln_a_w = se_launder(W.ln_a_w); W.ln_a_b = se_launder(W.ln_a_b);
+    W.in_w = se_launder(W.in_w); W.in_b = se_launder(W.in_b);
+    W.out_w = se_launder(W.out_w); W.out_b = se_launder(W.out_b);
+    W.ln_f_w = se_launder(W.ln_f_w); W.ln_f_b = se_launder(W.ln_f_b);
+    W.w1 = se_launder(W.w1); W.b1 = se_launder(W.b1);
+    W.w2 = se_launder(W.w2); W.b2 = se_launder(W.b2);
+    return W;
+}
+
 // ---- fragments ------------------------------------------------------------------------------------------
 // k-contiguous: 16 consecutive floats starting at p (16-B aligned)
 __device__ __forceinline__ void frag_kc(float (&f)[16], const float* p) {
@@ -94,6 +111,7 @@ __device__ __forceinline__ void gemm64(const float* A, const float (&bf)[16], in
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) epi(16 * t + 4 * g + j, acc[t][j]);
+    __builtin_amdgcn_sched_barrier(0);  // keep consecutive GEMMs from interleaving their fragment loads (VGPR pressure)
 }
 
 // weight fragment for y = x W^T: B[k][n] = W[n][k], W row-major [64][64] in global memory (k contiguous)
@@ -138,6 +156,9 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
     }
 }
 __device__ __forceinline__ void tile_load(float* tile, const float* __restrict__ gsrc, int S, int tid) {
+    // pin the global loads below this point: hipcc otherwise hoists the loads of EVERY later phase (they do not depend
+    // on LDS) to the top of the sequence loop and holds 64 VGPRs per tile until its phase arrives.
+    gsrc = se_launder(gsrc);
     for (int f = tid; f < SE_ROWS * (SE_D / 4); f += 256) {
         const int r = f >> 4, c4 = f & 15;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
         __syncthreads();
 
         for (int l = 0; l < L; ++l) {
-            const SasrecBlockParams& W = P.blk[l];
+            const SasrecBlockParams W = se_launder(P.blk[l]);
             float* tp = TRAIN ? tape + (int64_t)l * T.per_block : nullptr;
             // ---- 1. Q-input = LN_a(x)
             {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
         // ---- u = LN_last(x_L)
         {
             float mean, rstd;
-            ln_row(bX, bA, P.last_w, P.last_b, tid, mean, rstd);
+            ln_row(bX, bA, se_launder(P.last_w), se_launder(P.last_b), tid, mean, rstd);
             if (TRAIN) {
                 tile_store(bX, tape + T.off_XL + (int64_t)b * SD, S, tid);
                 if ((tid & 3) == 0 && r_e < S) {

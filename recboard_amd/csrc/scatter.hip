@@ -53,42 +53,30 @@ __global__ __launch_bounds__(64) void radix_hist(const uint32_t* __restrict__ ke
     for (int d = lane; d < 256; d += 64) hist[(int64_t)d * T + tile] = h[d];
 }
 
-// exclusive scan of hist[256*T] (digit-major, tile-minor) by ONE block of 1024 threads
+// exclusive scan of hist[256*T] (digit-major, tile-minor) by ONE block of 1024 threads: each thread owns one
+// contiguous chunk of ceil(total/1024) entries (two passes over its chunk, one block-wide scan of the chunk sums)
 __global__ __launch_bounds__(1024) void radix_scan(uint32_t* __restrict__ hist, int64_t total) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    const int64_t chunk = (total + 1023) / 1024;
+    const int64_t b = (int64_t)tid * chunk;
+    const int64_t e = (b + chunk < total) ? b + chunk : total;
+    uint32_t s = 0;
+    for (int64_t i = b; i < e; ++i) s += hist[i];
+    uint32_t inc = s;  // inclusive wave scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
     __syncthreads();
-    // strips of 1024*8 entries; each thread owns 8 consecutive entries of a strip
-    for (int64_t strip = 0; strip < total; strip += 1024 * 8) {
-        uint32_t v[8];
-        uint32_t s = 0;
-        const int64_t b = strip + (int64_t)tid * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = (b + j < total) ? hist[b + j] : 0u;
-            s += v[j];
-        }
-        uint32_t inc = s;  // inclusive wave scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) wsum[wid] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wsum[w];
-        uint32_t run = carry_s + woff + inc - s;
-        __syncthreads();
-        if (tid == 1023) carry_s = run + s;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (b + j < total) hist[b + j] = run;
-            run += v[j];
-        }
-        __syncthreads();
+    uint32_t run = inc - s;
+    for (int w = 0; w < wid; ++w) run += wsum[w];
+    for (int64_t i = b; i < e; ++i) {
+        const uint32_t v = hist[i];
+        hist[i] = run;
+        run += v;
     }
 }
 
