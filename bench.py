@@ -10,7 +10,8 @@ SURVEY.md §8d C2).  A "step" = one full training step (forward, backward, dense
 in HBM.  `value` = training sequences per second over all GPUs (weak scaling: 512 per GPU).
 The second half of BASELINE's metric -- full-catalog items scored per second -- is measured in the same run, outside
 the timed region, over all 22 363 users x 12 101 items with the fused score+mask+top-K kernel, and reported in
-`items_scored_per_sec` and in the `roofline` object (MFMA-bound kernel).  `roofline_gather` reports the HBM-bound
+`items_scored_per_sec` and `roofline_score` (MFMA-bound).  `roofline` is the dominant kernel of the timed region (the
+per-block encoder backward, MFMA-bound fp32), `roofline_gather` the HBM-bound
 embedding gather.  `cpu_baseline` times the torch-CPU oracle of the same training step on this box's host cores.
 """
 import argparse
@@ -182,6 +183,29 @@ def main():
     }
 
     if rank == 0 and not args.no_extras:
+        # ---------------- dominant kernel of the timed region: the per-block encoder backward (MFMA-bound, fp32)
+        if args.encoder == "fused":
+            seq, pos, neg, aux = batches[0]
+            Bq, Sq, Dq, Lq = cfg["B"], cfg["S"], cfg["D"], cfg["L"]
+            W = model._buffers(Bq, Sq)
+            A = model.arena
+            G = A.views(A.grad)
+            bt, bg = model._block_tensors(), model._block_tensors(A.grad)
+            lw, lb = model.params["lastLN.weight"].detach(), model.params["lastLN.bias"].detach()
+            dU = torch.randn(Bq, Sq, Dq, device="cuda") * 1e-3
+            dx = torch.empty_like(dU)
+
+            def run_bwd():
+                ops.sasrec_encoder_bwd(dU, seq, bt, lw, lb, Lq, cfg["p_drop"], 123, W["tape"], bg, G["lastLN.weight"],
+                                       G["lastLN.bias"], out=dx, ws=W["ws_bwd"])
+            t_bwd = event_time_ms(run_bwd, 30)
+            fl = 16 * 2.0 * 64 ** 3 * Bq * Lq     # 16 GEMMs of 64^3 per sequence per block
+            tfb = fl / (t_bwd * 1e-3) / 1e12
+            line["roofline"] = {"kernel": "sasrec_block_bwd_k (x%d blocks, + slab reduce)" % Lq, "bound": "mfma",
+                                "achieved": round(tfb, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": round(tfb / MFMA_F32_PEAK_TF, 4), "traffic": None, "launch_ms": round(t_bwd / Lq, 4),
+                                "work": f"16 GEMMs x 2*64^3 FLOP x {Bq} sequences = {fl / Lq:.3e} FLOP per block launch "
+                                        f"(64-row padded tiles; S={Sq})"}
         # ---------------- full-catalog evaluation leg: every user x every item, seen-mask + top-50 fused
         U, N, D, K = cfg["users"], cfg["items"], cfg["D"], 50
         rng = np.random.default_rng(7)
@@ -198,7 +222,7 @@ def main():
         flops = 2.0 * D * U * N
         tf = flops / (t_score * 1e-3) / 1e12
         line["items_scored_per_sec"] = round(U * N / (t_score * 1e-3), 1)
-        line["roofline"] = {"kernel": "score_kernel<64,topk> (+merge)", "bound": "mfma", "achieved": round(tf, 2),
+        line["roofline_score"] = {"kernel": "score_kernel<64,topk> (+merge)", "bound": "mfma", "achieved": round(tf, 2),
                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                             "traffic": None, "launch_ms": round(t_score, 4),
                             "work": f"2*D*B*N = {flops:.3e} FLOP per launch (B={U}, N={N}, D={D}, K={K})"}
