@@ -64,13 +64,14 @@ int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int64_t S, int
 
 /* ---------------------------------------------------------------------------------------------------------
  * K1b  dense gradient of the gather: dW[r,:] = sum_{i: idx[i]==r} g[i,:], rows == padding_idx skipped,
- * every other row zero.  dW [R,D] is fully overwritten.  Deterministic (sorted segments, fixed chunking):
+ * every other row zero.  dW [R,D] is fully overwritten (accumulate = 0) or added to (accumulate = 1).
+ * Deterministic (sorted segments, fixed chunking):
  * two calls on the same input give bit-identical output.
  * Replaces aten embedding_dense_backward / index_put_(accumulate) reached from `loss.backward()`
  * (SASRec/main.py:249, MF-BPR/main.py:122).  `scale` multiplies every contribution (SASRec: sqrt(D)). */
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
-                        int64_t padding_idx, float scale, float* dW, void* ws, size_t ws_bytes,
+                        int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,
                         re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -160,12 +161,30 @@ int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_
                           size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * K8  CSR SpMM for LightGCN propagation:  Y = A X (+ beta Z);  if ACC: ACC += acc_scale * Y.
+ * Replaces `self.Adj @ allEmbds` + `avgEmbds += allEmbds / (L+1)` (LightGCN/main.py:81-84) and, Adj being symmetric,
+ * the transposed product of the backward pass.  crow int64[nrows+1], col int64[nnz], val f32[nnz]; X [ncols, D],
+ * Y/Z/ACC [nrows, D]; Y must not alias X.  long_rows[nlong] = ids of the rows with more than 512 non-zeros
+ * (computed once per adjacency; they get a workgroup each).  Fixed summation order => bitwise reproducible.
+ * re_rows_sqnorm: out[0] (+)= scale * sum_i ||W[idx[i],:]||^2  -- `criterion.regularize(rows, "l2")`
+ * (LightGCN/main.py:99-106) with scale = 1/2 / B. */
+int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
+                const int64_t* long_rows, int64_t nlong, const float* X, int64_t D, float* Y, const float* Z,
+                float beta, float* ACC, float acc_scale, re_stream_t stream);
+size_t re_rows_sqnorm_workspace_bytes(void);
+int re_rows_sqnorm(const float* W, int64_t R, int64_t D, const int64_t* idx, int64_t n, float scale, float* out,
+                   int accumulate, void* ws, size_t ws_bytes, re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * K10  dense Adam with coupled L2 (torch.optim.Adam semantics, eps 1e-8, no amsgrad), one launch over a flat
  * parameter arena.  Replaces `self.optimizer.step()` (SASRec/main.py:250; cfg dump
  * benchmark/Amazon2014Beauty_550_LOU/SASRec.json:254-300).  step is 1-based.  Hyper-parameters are doubles because
  * torch derives 1-beta and the bias corrections in double precision before rounding to fp32. */
 int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
                  double beta1, double beta2, double eps, double weight_decay, re_stream_t stream);
+
+/* dst[i] = alpha * src[i]  (LightGCN/main.py:80 `avgEmbds = allEmbds / (L+1)`) */
+int re_scale_copy(float* dst, const float* src, float alpha, int64_t n, re_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -58,3 +58,15 @@ extern "C" int re_adam_step(float* p, const float* g, float* m, float* v, int64_
                            (float)(1.0 - beta2), step_size, inv_sqrt_bc2, (float)eps, (float)weight_decay);
     return re_launch_status();
 }
+
+// dst = alpha * src over a flat fp32 range (LightGCN: avgEmbds = allEmbds / (L+1), LightGCN/main.py:80)
+__global__ __launch_bounds__(256) void scale_copy_k(float* __restrict__ dst, const float* __restrict__ src, float alpha, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = alpha * src[i];
+}
+extern "C" int re_scale_copy(float* dst, const float* src, float alpha, int64_t n, re_stream_t stream) {
+    re_clear_error();
+    if (n == 0) return RE_OK;
+    if (!dst || !src || n < 0) return RE_EINVAL;
+    hipLaunchKernelGGL(scale_copy_k, dim3(re_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, dst, src, alpha, n);
+    return re_launch_status();
+}

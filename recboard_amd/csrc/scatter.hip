@@ -123,7 +123,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                   const float* __restrict__ g, int64_t n, int64_t D, int64_t R,
                                                   float scale, float* __restrict__ dW, float* __restrict__ partial,
-                                                  uint32_t* __restrict__ pflags, int64_t nchunks) {
+                                                  uint32_t* __restrict__ pflags, int64_t nchunks, int accumulate) {
     const int lir = threadIdx.x % LPR;
     const int64_t c = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (c >= nchunks) return;
@@ -158,7 +158,9 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
                             reinterpret_cast<float4*>(partial + (c * 2 + 0) * D)[col] = acc;
                             flags |= RE_FLAG_SLOT0;
                         } else {
-                            reinterpret_cast<float4*>(dW + (int64_t)curKey * D)[col] = acc;
+                            float4* d = reinterpret_cast<float4*>(dW + (int64_t)curKey * D) + col;
+                            if (accumulate) f4_add(acc, *d);
+                            *d = acc;
                         }
                     }
                     curKey = k[u];
@@ -179,7 +181,9 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
                 reinterpret_cast<float4*>(partial + (c * 2 + 1) * D)[col] = acc;
                 flags |= RE_FLAG_SLOT1;
             } else {
-                reinterpret_cast<float4*>(dW + (int64_t)curKey * D)[col] = acc;
+                float4* d = reinterpret_cast<float4*>(dW + (int64_t)curKey * D) + col;
+                if (accumulate) f4_add(acc, *d);
+                *d = acc;
             }
         }
     }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
 template <int LPR>
 __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ keys, int64_t n, int64_t D,
                                                  float* __restrict__ dW, const float* __restrict__ partial,
-                                                 const uint32_t* __restrict__ pflags, int64_t nchunks) {
+                                                 const uint32_t* __restrict__ pflags, int64_t nchunks, int accumulate) {
     const int lir = threadIdx.x % LPR;
     const int64_t c = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (c >= nchunks) return;
@@ -206,7 +210,9 @@ __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ ke
             f4_add(acc, reinterpret_cast<const float4*>(partial + (cc * 2 + 0) * D)[col]);
             if (!(f & RE_FLAG_CONT)) break;
         }
-        reinterpret_cast<float4*>(dW + (int64_t)key * D)[col] = acc;
+        float4* d = reinterpret_cast<float4*>(dW + (int64_t)key * D) + col;
+        if (accumulate) f4_add(acc, *d);
+        *d = acc;
     }
 }
 
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ ke
 __global__ __launch_bounds__(256) void seg_reduce_scalar(const uint32_t* __restrict__ keys,
                                                          const uint32_t* __restrict__ vals,
                                                          const float* __restrict__ g, int64_t n, int64_t D, int64_t R,
-                                                         float scale, float* __restrict__ dW) {
+                                                         float scale, float* __restrict__ dW, int accumulate) {
     const int64_t total = n * D;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t j = e / D, d = e - j * D;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256) void seg_reduce_scalar(const uint32_t* __restr
         if (j > 0 && keys[j - 1] == k) continue;  // not the first entry of its run
         float acc = 0.f;
         for (int64_t t = j; t < n && keys[t] == k; ++t) acc = fmaf(g[(int64_t)vals[t] * D + d], scale, acc);
-        dW[(int64_t)k * D + d] = acc;
+        dW[(int64_t)k * D + d] = (accumulate ? dW[(int64_t)k * D + d] : 0.f) + acc;
     }
 }
 
@@ -260,13 +266,13 @@ extern "C" size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int6
 }
 
 extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
-                                   int64_t padding_idx, float scale, float* dW, void* ws, size_t ws_bytes,
+                                   int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,
                                    re_stream_t stream) {
     re_clear_error();
     if (!dW || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
     if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+    if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
     if (n == 0) return RE_OK;
     if (!g || !idx || !ws) return RE_EINVAL;
     ScatterWs w = scatter_ws_layout(ws, n, D);
@@ -286,22 +292,22 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
     }
     const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u) == 0;
     if (!vec) {
-        hipLaunchKernelGGL(seg_reduce_scalar, dim3(re_grid(n * D, 256)), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW);
+        hipLaunchKernelGGL(seg_reduce_scalar, dim3(re_grid(n * D, 256)), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, accumulate);
         return re_launch_status();
     }
     const int64_t D4 = D >> 2;
     if (D4 >= 32) {
         const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 32);
-        hipLaunchKernelGGL(seg_reduce<32>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks);
-        hipLaunchKernelGGL(seg_fixup<32>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks);
+        hipLaunchKernelGGL(seg_reduce<32>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks, accumulate);
+        hipLaunchKernelGGL(seg_fixup<32>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks, accumulate);
     } else if (D4 >= 16) {
         const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 16);
-        hipLaunchKernelGGL(seg_reduce<16>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks);
-        hipLaunchKernelGGL(seg_fixup<16>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks);
+        hipLaunchKernelGGL(seg_reduce<16>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks, accumulate);
+        hipLaunchKernelGGL(seg_fixup<16>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks, accumulate);
     } else {
         const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 4);
-        hipLaunchKernelGGL(seg_reduce<4>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks);
-        hipLaunchKernelGGL(seg_fixup<4>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks);
+        hipLaunchKernelGGL(seg_reduce<4>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks, accumulate);
+        hipLaunchKernelGGL(seg_fixup<4>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks, accumulate);
     }
     return re_launch_status();
 }

@@ -1,0 +1,170 @@
+// K8: CSR SpMM for LightGCN propagation:  Y = A X (+ beta Z),  optionally  ACC += acc_scale * Y.      HBM / Infinity-Cache bound.
+//
+// Reference: `allEmbds = self.Adj @ allEmbds; avgEmbds += allEmbds / (L+1)` (LightGCN/main.py:81-84), Adj = the
+// symmetric-normalised bipartite adjacency as a CSR tensor (LightGCN/main.py:47-49); aten runs rocSPARSE csrmm plus an
+// elementwise add per layer, and the transposed product in backward.  Adj is symmetric, so backward is the same kernel:
+//   g_l = A g_{l+1} + dAvg / (L+1)        (Z = dAvg, beta = 1/(L+1))
+//
+// Layout: one lane group (D/4 lanes x float4) per output row walks the row's non-zeros four at a time (independent
+// col/val loads, then four independent X-row loads); a row's 256-B X rows are full-line reads.  X (31.5 MB at Yelp
+// sizes) lives in the 256 MB Infinity Cache, so the stream that must come from HBM is (col, val) = 12 B per non-zero.
+// Power-law rows: rows longer than SP_LONG non-zeros are left to a second kernel that gives each one a whole
+// workgroup (16 lane groups, strided non-zeros, fixed-order LDS combine) -- the per-wave skew pitfall of
+// cdna_hip_programming.md Appendix B.  Summation order is fixed => bitwise reproducible.
+//
+// Algorithmic bytes: per non-zero 12 B (+ a 4D-byte X row, cache-resident); per row 8 B crow + 4D B write
+// (+ 4D B for Z, + 8D B for ACC); 2D FLOP per non-zero.
+#include "re_common.h"
+
+#define SP_LONG 512
+
+__device__ __forceinline__ void f4_axpy(float4& a, float s, const float4& x) {
+    a.x = fmaf(s, x.x, a.x); a.y = fmaf(s, x.y, a.y); a.z = fmaf(s, x.z, a.z); a.w = fmaf(s, x.w, a.w);
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col, const float* __restrict__ val,
+                                                  const float* __restrict__ X, int64_t ncols, int64_t D, int64_t c4,
+                                                  int64_t p0, int64_t p1, int64_t step) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t p = p0;
+    for (; p + 3 * step < p1; p += 4 * step) {
+        int64_t cc[4];
+        float vv[4];
+        float4 xr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cc[u] = col[p + u * step]; vv[u] = val[p + u * step]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cc[u] >= 0 && cc[u] < ncols) xr[u] = reinterpret_cast<const float4*>(X + cc[u] * D)[c4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f4_axpy(acc, vv[u], xr[u]);
+    }
+    for (; p < p1; p += step) {
+        const int64_t cc = col[p];
+        if (cc >= 0 && cc < ncols) f4_axpy(acc, val[p], reinterpret_cast<const float4*>(X + cc * D)[c4]);
+    }
+    return acc;
+}
+
+template <int LPR>
+__device__ __forceinline__ void spmm_store(float4 acc, int64_t r, int64_t D, int64_t c4, float* __restrict__ Y,
+                                           const float* __restrict__ Z, float beta, float* __restrict__ ACC, float acc_scale) {
+    if (Z) f4_axpy(acc, beta, reinterpret_cast<const float4*>(Z + r * D)[c4]);
+    reinterpret_cast<float4*>(Y + r * D)[c4] = acc;
+    if (ACC) {
+        float4 a = reinterpret_cast<float4*>(ACC + r * D)[c4];
+        f4_axpy(a, acc_scale, acc);
+        reinterpret_cast<float4*>(ACC + r * D)[c4] = a;
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
+                                                     const float* __restrict__ val, int64_t nrows, int64_t ncols,
+                                                     const float* __restrict__ X, int64_t D, float* __restrict__ Y,
+                                                     const float* __restrict__ Z, float beta, float* __restrict__ ACC,
+                                                     float acc_scale) {
+    const int lir = threadIdx.x % LPR;
+    const int64_t gpb = 256 / LPR;
+    const int64_t D4 = D >> 2;
+    for (int64_t r = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR; r < nrows; r += (int64_t)gridDim.x * gpb) {
+        const int64_t p0 = crow[r], p1 = crow[r + 1];
+        if (p1 - p0 > SP_LONG) continue;  // handled by spmm_csr_long
+        for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
+            const float4 acc = spmm_row_range<LPR>(col, val, X, ncols, D, c4, p0, p1, 1);
+            spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
+        }
+    }
+}
+
+// one workgroup per long row: lane group j takes non-zeros p0 + j, p0 + j + G, ...; partials combined in group order
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__ long_rows, int64_t nlong,
+                                                     const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
+                                                     const float* __restrict__ val, int64_t ncols, const float* __restrict__ X,
+                                                     int64_t D, float* __restrict__ Y, const float* __restrict__ Z, float beta,
+                                                     float* __restrict__ ACC, float acc_scale) {
+    __shared__ float4 part[256];
+    const int lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    constexpr int G = 256 / LPR;
+    const int64_t D4 = D >> 2;
+    for (int64_t i = blockIdx.x; i < nlong; i += gridDim.x) {
+        const int64_t r = long_rows[i];
+        const int64_t p0 = crow[r], p1 = crow[r + 1];
+        for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
+            part[threadIdx.x] = spmm_row_range<LPR>(col, val, X, ncols, D, c4, p0 + grp, p1, G);
+            __syncthreads();
+            if (grp == 0) {
+                float4 acc = part[lir];
+                for (int j = 1; j < G; ++j) {
+                    const float4 q = part[j * LPR + lir];
+                    acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+                }
+                spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
+                           const int64_t* long_rows, int64_t nlong, const float* X, int64_t D, float* Y, const float* Z,
+                           float beta, float* ACC, float acc_scale, re_stream_t stream) {
+    re_clear_error();
+    if (nrows == 0) return RE_OK;
+    if (!crow || !col || !val || !X || !Y || nrows < 0 || ncols <= 0 || D <= 0 || nlong < 0 || (nlong > 0 && !long_rows))
+        return RE_EINVAL;
+    if ((D & 3) || ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Z) |
+                     reinterpret_cast<uintptr_t>(ACC)) & 15u))
+        return RE_EUNSUPPORTED;
+    if (X == Y) return RE_EINVAL;  // not in place
+    hipStream_t s = (hipStream_t)stream;
+    if ((D >> 2) >= 32) {
+        hipLaunchKernelGGL(spmm_csr_rows<32>, dim3(re_grid(nrows, 8, 65536)), dim3(256), 0, s, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+        if (nlong) hipLaunchKernelGGL(spmm_csr_long<32>, dim3(re_grid(nlong, 1, 4096)), dim3(256), 0, s, long_rows, nlong, crow, col, val, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+    } else {
+        hipLaunchKernelGGL(spmm_csr_rows<16>, dim3(re_grid(nrows, 16, 65536)), dim3(256), 0, s, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+        if (nlong) hipLaunchKernelGGL(spmm_csr_long<16>, dim3(re_grid(nlong, 1, 4096)), dim3(256), 0, s, long_rows, nlong, crow, col, val, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+    }
+    return re_launch_status();
+}
+
+// rows' squared L2 norms: out[0] = scale * sum_i ||W[idx[i], :]||^2   (BaseCriterion.regularize(.., "l2") = sum/2,
+// LightGCN/main.py:99-106).  Deterministic: block partials, then one wave adds them in order.
+__global__ __launch_bounds__(256) void rows_sqnorm_k(const float* __restrict__ W, int64_t R, int64_t D, const int64_t* __restrict__ idx,
+                                                     int64_t n, float* __restrict__ bsum) {
+    __shared__ float s_sum[4];
+    float acc = 0.f;
+    const int64_t total = n * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / D, d = e - i * D;
+        const int64_t r = idx[i];
+        if (r >= 0 && r < R) { const float x = W[r * D + d]; acc = fmaf(x, x, acc); }
+    }
+    acc = re_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+}
+__global__ __launch_bounds__(64) void rows_sqnorm_fin(const float* __restrict__ bsum, int nb, float scale, float* __restrict__ out, int accumulate) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 64) s += bsum[b];
+    s = re_wave_sum(s);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s * scale;
+}
+
+extern "C" size_t re_rows_sqnorm_workspace_bytes(void) { return 1024 * sizeof(float); }
+extern "C" int re_rows_sqnorm(const float* W, int64_t R, int64_t D, const int64_t* idx, int64_t n, float scale, float* out,
+                              int accumulate, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!W || !idx || !out || !ws || n < 0 || R <= 0 || D <= 0) return RE_EINVAL;
+    if (ws_bytes < re_rows_sqnorm_workspace_bytes()) return RE_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)re_grid(n * D, 256 * 4, 1024);
+    hipLaunchKernelGGL(rows_sqnorm_k, dim3(nb), dim3(256), 0, s, W, R, D, idx, n, (float*)ws);
+    hipLaunchKernelGGL(rows_sqnorm_fin, dim3(1), dim3(64), 0, s, (const float*)ws, nb, scale, out, accumulate);
+    return re_launch_status();
+}

@@ -1,0 +1,159 @@
+"""MF-BPR and LightGCN on the engine: host-side mirrors of the reference's `MF` (MF-BPR/main.py:25-109) and
+`LightGCN` (LightGCN/main.py:27-125) classes and of their Coach step bodies (MF-BPR/main.py:115-131,
+LightGCN/main.py:156-172).  Same state-dict names (`User.embeddings.weight`, `Item.embeddings.weight`), same method
+names (`encode`, `fit`, `reset_ranking_buffers`, `recommend_from_full`).
+
+Layout: user and item tables are consecutive views of ONE fp32 arena, so LightGCN's `torch.cat((U, I))` is a zero-copy
+view, the optimizer is one launch, and a data-parallel step is one all-reduce.  No autograd graph: forward and backward
+are explicit sequences of librecengine kernels (no CPU fallback).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from .sasrec import ParamArena
+
+
+class MFEngine:
+    """user/item embds -> dot -> BPR  (MF-BPR/main.py)."""
+
+    def __init__(self, num_users, num_items, embedding_dim=64, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1):
+        self.U, self.N, self.D = num_users, num_items, embedding_dim
+        self.lr, self.wd, self.betas = lr, weight_decay, betas
+        self.device = torch.device(device)
+        shapes = OrderedDict([("User.embeddings.weight", (num_users, embedding_dim)),
+                              ("Item.embeddings.weight", (num_items, embedding_dim))])
+        self.arena = ParamArena(shapes, self.device)
+        self.params = self.arena.views(self.arena.data)
+        g = torch.Generator().manual_seed(seed)   # nn.init.normal_(std=1e-4), MF-BPR/main.py:55
+        for p in self.params.values():
+            p.copy_((torch.randn(p.shape, generator=g) * 1e-4).to(self.device))
+        self.ranking_buffer = None
+
+    def load_state_dict(self, sd):
+        for k, p in self.params.items():
+            p.copy_(torch.as_tensor(sd[k]).to(self.device))
+
+    def state_dict(self):
+        return OrderedDict((k, p.clone()) for k, p in self.params.items())
+
+    def encode(self):
+        return self.params["User.embeddings.weight"], self.params["Item.embeddings.weight"]
+
+    def fit(self, users, pos, neg):
+        """-> {"rec_loss"} (forward only).  MF-BPR/main.py:81-93."""
+        Ut, It = self.encode()
+        loss, _ = ops.bpr_triplet_fwd(Ut, It, users.reshape(-1), pos.reshape(-1), neg.reshape(-1))
+        return {"rec_loss": loss.squeeze(0)}
+
+    def train_step(self, users, pos, neg, grad_hook=None):
+        """forward + backward + Adam (MF-BPR/main.py:116-123)."""
+        A = self.arena
+        Ut, It = self.encode()
+        u, p, n = users.reshape(-1), pos.reshape(-1), neg.reshape(-1)
+        loss, logits = ops.bpr_triplet_fwd(Ut, It, u, p, n)
+        gu, gp, gn = ops.bpr_triplet_bwd(Ut, It, u, p, n, logits, None)
+        G = A.views(A.grad)
+        ops.scatter_add_rows(gu, u, self.U, out=G["User.embeddings.weight"])
+        ops.scatter_add_rows(torch.cat([gp, gn]), torch.cat([p, n]), self.N, out=G["Item.embeddings.weight"])
+        if grad_hook is not None:
+            grad_hook(A.grad)
+        A.step += 1
+        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        return loss.squeeze(0)
+
+    # MF-BPR/main.py:95-104
+    def reset_ranking_buffers(self):
+        Ut, It = self.encode()
+        self.ranking_buffer = (Ut.clone(), It.clone())
+
+    def recommend_from_full(self, users):
+        Ub, Ib = self.ranking_buffer
+        return ops.score_dense(ops.gather_rows(Ub, users.reshape(-1)), Ib)
+
+    def recommend_topk(self, users, seen_ptr, seen_idx, K=50):
+        Ub, Ib = self.ranking_buffer
+        return ops.score_topk(ops.gather_rows(Ub, users.reshape(-1)), Ib, seen_ptr, seen_idx, K)
+
+
+class LightGCNEngine(MFEngine):
+    """user/item embds -> L x (Adj @ X) -> layer mean -> dot -> BPR + L2 on the raw rows  (LightGCN/main.py)."""
+
+    def __init__(self, num_users, num_items, adj_crow, adj_col, adj_val, embedding_dim=64, num_layers=3, lr=1e-3,
+                 weight_decay=1e-4, betas=(0.9, 0.999), device="cuda", seed=1):
+        super().__init__(num_users, num_items, embedding_dim, lr, weight_decay, betas, device, seed)
+        self.L = num_layers
+        dev = self.device
+        self.crow = torch.as_tensor(adj_crow, dtype=torch.int64).to(dev).contiguous()
+        self.col = torch.as_tensor(adj_col, dtype=torch.int64).to(dev).contiguous()
+        self.val = torch.as_tensor(adj_val, dtype=torch.float32).to(dev).contiguous()
+        self.long_rows = ops.spmm_plan(self.crow)
+        n = num_users + num_items
+        assert self.crow.numel() == n + 1
+        self.n = n
+        f = lambda: torch.empty((n, embedding_dim), dtype=torch.float32, device=dev)  # noqa: E731
+        self.Xa, self.Xb, self.avg, self.davg, self.Ga = f(), f(), f(), f(), f()
+        self.X0 = self.arena.data[: n * embedding_dim].view(n, embedding_dim)   # zero-copy torch.cat((U, I))
+        self.emb = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def _spmm(self, X, out, **kw):
+        return ops.spmm_csr(self.crow, self.col, self.val, self.long_rows, X, out, **kw)
+
+    def encode(self):
+        """-> (userEmbds, itemEmbds) after propagation.  LightGCN/main.py:77-86."""
+        s = 1.0 / (self.L + 1)
+        ops.scale_copy(self.avg, self.X0, s)
+        src, bufs = self.X0, (self.Xa, self.Xb)
+        for l in range(self.L):
+            dst = bufs[l & 1]
+            self._spmm(src, dst, acc=self.avg, acc_scale=s)
+            src = dst
+        return self.avg[: self.U], self.avg[self.U:]
+
+    def _emb_loss(self, u, p, n):
+        P = self.params
+        sc = 0.5 / u.numel()                      # regularize(.., "l2") / len(users)
+        ops.rows_sqnorm(P["User.embeddings.weight"], u, sc, self.emb)
+        ops.rows_sqnorm(P["Item.embeddings.weight"], p, sc, self.emb, accumulate=True)
+        ops.rows_sqnorm(P["Item.embeddings.weight"], n, sc, self.emb, accumulate=True)
+        return self.emb
+
+    def fit(self, users, pos, neg):
+        """-> {"rec_loss", "emb_loss"} (forward only).  LightGCN/main.py:88-108."""
+        ue, ie = self.encode()
+        u, p, n = users.reshape(-1), pos.reshape(-1), neg.reshape(-1)
+        loss, _ = ops.bpr_triplet_fwd(ue, ie, u, p, n)
+        return {"rec_loss": loss.squeeze(0), "emb_loss": self._emb_loss(u, p, n).clone().squeeze(0)}
+
+    def train_step(self, users, pos, neg, grad_hook=None):
+        """loss = rec + weight_decay * emb; backward through the L propagation layers (Adj symmetric); Adam WITHOUT
+        weight decay (LightGCN/main.py:139-145,160-164)."""
+        A, D, U = self.arena, self.D, self.U
+        ue, ie = self.encode()
+        u, p, n = users.reshape(-1), pos.reshape(-1), neg.reshape(-1)
+        B = u.numel()
+        loss, logits = ops.bpr_triplet_fwd(ue, ie, u, p, n)
+        emb = self._emb_loss(u, p, n)
+        gu, gp, gn = ops.bpr_triplet_bwd(ue, ie, u, p, n, logits, None)
+        rows = torch.cat([u, p + U, n + U])
+        s = 1.0 / (self.L + 1)
+        ops.scatter_add_rows(torch.cat([gu, gp, gn]), rows, self.n, scale=s, out=self.davg)   # d(avg)/(L+1), dense
+        # g_L = davg ; g_l = Adj g_{l+1} + davg ; the last product lands in the gradient arena
+        gX0 = A.grad[: self.n * D].view(self.n, D)
+        src, bufs = self.davg, (self.Ga, self.Xa)
+        for l in range(self.L):
+            dst = gX0 if l == self.L - 1 else bufs[l & 1]
+            self._spmm(src, dst, Z=self.davg, beta=1.0)
+            src = dst
+        # + weight_decay * d(emb_loss): rows of the RAW tables, scaled by wd / B
+        ops.scatter_add_rows(ops.gather_rows(self.X0, rows), rows, self.n, scale=self.wd / B, out=gX0, accumulate=True)
+        if grad_hook is not None:
+            grad_hook(A.grad)
+        A.step += 1
+        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, 0.0)
+        return (loss + self.wd * emb).squeeze(0)
+
+    def reset_ranking_buffers(self):
+        ue, ie = self.encode()
+        self.ranking_buffer = (ue.clone(), ie.clone())

@@ -21,7 +21,7 @@ SIGNATURES = {
     "re_sasrec_embed_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "re_sasrec_embed_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _f32, _f32, _u32, _vp, _vp, _sz, _vp]),
     "re_scatter_add_rows_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "re_scatter_add_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _sz, _vp]),
+    "re_scatter_add_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
     "re_pair_loss_workspace_bytes": (_sz, [_i64]),
     "re_pair_loss_fwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_pair_loss_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -35,6 +35,10 @@ SIGNATURES = {
     "re_sasrec_encoder_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_sasrec_encoder_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _sz, _vp]),
+    "re_spmm_csr": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp]),
+    "re_rows_sqnorm_workspace_bytes": (_sz, []),
+    "re_rows_sqnorm": (_i32, [_vp, _i64, _i64, _vp, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
+    "re_scale_copy": (_i32, [_vp, _vp, _f32, _i64, _vp]),
     "re_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _vp]),
 }
 

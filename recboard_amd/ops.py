@@ -73,7 +73,7 @@ def sasrec_embed_bwd(gx, seq, scale, drop_p, seed, dP, ws=None):
 
 
 def scatter_add_rows(g: torch.Tensor, idx: torch.Tensor, R: int, padding_idx: int = -1, scale: float = 1.0, out=None,
-                     ws=None):
+                     ws=None, accumulate=False):
     """Dense [R, D] gradient of gather_rows, deterministic (re_scatter_add_rows)."""
     _req(g, torch.float32, "g"); _req(idx, torch.int64, "idx")
     D = g.shape[-1]
@@ -85,8 +85,10 @@ def scatter_add_rows(g: torch.Tensor, idx: torch.Tensor, R: int, padding_idx: in
         ws = _ws(L.re_scatter_add_rows_workspace_bytes(n, D, R), g.device)
     dW = out if out is not None else torch.empty((R, D), dtype=torch.float32, device=g.device)
     _req(dW, torch.float32, "out")
-    lib.check(L.re_scatter_add_rows(_p(g), _p(idx), n, D, R, int(padding_idx), float(scale), _p(dW), _p(ws),
-                                    ws.numel(), _stream()), "re_scatter_add_rows")
+    if accumulate and out is None:
+        raise ValueError("recengine: accumulate=True needs `out`")
+    lib.check(L.re_scatter_add_rows(_p(g), _p(idx), n, D, R, int(padding_idx), float(scale), _p(dW), int(bool(accumulate)),
+                                    _p(ws), ws.numel(), _stream()), "re_scatter_add_rows")
     return dW
 
 
@@ -244,9 +246,46 @@ def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, 
     return dx0
 
 
+# ------------------------------------------------------------------------------------------------ K8
+def spmm_plan(crow: torch.Tensor, threshold: int = 512):
+    """Row ids with more than `threshold` non-zeros (once per adjacency; the only host-visible preprocessing)."""
+    deg = crow[1:] - crow[:-1]
+    return torch.nonzero(deg > threshold).reshape(-1).contiguous()
+
+
+def spmm_csr(crow, col, val, long_rows, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0):
+    """out = A @ X (+ beta * Z); acc += acc_scale * out  (re_spmm_csr)."""
+    for t, nme in ((crow, "crow"), (col, "col"), (long_rows, "long_rows")):
+        _req(t, torch.int64, nme)
+    for t, nme in ((val, "val"), (X, "X"), (out, "out")):
+        _req(t, torch.float32, nme)
+    nrows = crow.numel() - 1
+    lib.check(lib.load().re_spmm_csr(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(long_rows), long_rows.numel(), _p(X),
+                                     X.shape[1], _p(out), _p(Z), float(beta), _p(acc), float(acc_scale), _stream()),
+              "re_spmm_csr")
+    return out
+
+
+def rows_sqnorm(W, idx, scale, out, accumulate=False, ws=None):
+    """out[0] (+)= scale * sum_i ||W[idx[i]]||^2  (re_rows_sqnorm)."""
+    _req(W, torch.float32, "W"); _req(idx, torch.int64, "idx"); _req(out, torch.float32, "out")
+    L = lib.load()
+    if ws is None:
+        ws = _ws(L.re_rows_sqnorm_workspace_bytes(), W.device)
+    lib.check(L.re_rows_sqnorm(_p(W), W.shape[0], W.shape[1], _p(idx), idx.numel(), float(scale), _p(out),
+                               int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "re_rows_sqnorm")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ K10
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _req(t, torch.float32, nme)
     lib.check(lib.load().re_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(beta1),
                                       float(beta2), float(eps), float(weight_decay), _stream()), "re_adam_step")
+
+
+def scale_copy(dst, src, alpha):
+    _req(dst, torch.float32, "dst"); _req(src, torch.float32, "src")
+    lib.check(lib.load().re_scale_copy(_p(dst), _p(src), float(alpha), src.numel(), _stream()), "re_scale_copy")
+    return dst

@@ -1,0 +1,127 @@
+"""GPU: MF-BPR / LightGCN engines and the CSR SpMM kernel vs the reference's golden vectors and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from recboard_amd import ops as _ops
+    return _ops
+
+
+def test_mf_engine_matches_reference_golden(ops):
+    from recboard_amd.gen import MFEngine
+    z = np.load(os.path.join(G, "mfbpr.npz"))
+    m = MFEngine(50, 80, 64, lr=0.0)
+    m.load_state_dict({k[6:]: z[k] for k in z.files if k.startswith("param/")})
+    users, pos, neg = dev(z["in/users"]), dev(z["in/pos"]), dev(z["in/neg"])
+    np.testing.assert_allclose(m.fit(users, pos, neg)["rec_loss"].item(), float(z["out/rec_loss"]), rtol=2e-6)
+    loss = m.train_step(users, pos, neg)
+    np.testing.assert_allclose(loss.item(), float(z["out/rec_loss"]), rtol=2e-6)
+    Gv = m.arena.views(m.arena.grad)
+    for k in Gv:
+        np.testing.assert_allclose(Gv[k].cpu().numpy(), z["grad/" + k], rtol=1e-4, atol=1e-7)
+    m.reset_ranking_buffers()
+    np.testing.assert_allclose(m.recommend_from_full(users).cpu().numpy(), z["out/scores"], rtol=1e-4, atol=1e-6)
+
+
+def test_lightgcn_engine_matches_reference_golden(ops):
+    from recboard_amd.gen import LightGCNEngine
+    z = np.load(os.path.join(G, "lightgcn.npz"))
+    wd = float(z["cfg/weight_decay"])
+    m = LightGCNEngine(30, 40, z["in/adj_crow"], z["in/adj_col"], z["in/adj_val"], 64, int(z["cfg/num_layers"]), lr=0.0, weight_decay=wd)
+    m.load_state_dict({k[6:]: z[k] for k in z.files if k.startswith("param/")})
+    users, pos, neg = dev(z["in/users"]), dev(z["in/pos"]), dev(z["in/neg"])
+    ue, ie = m.encode()
+    np.testing.assert_allclose(ue.cpu().numpy(), z["out/userEmbds"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ie.cpu().numpy(), z["out/itemEmbds"], rtol=1e-4, atol=1e-6)
+    f = m.fit(users, pos, neg)
+    np.testing.assert_allclose(f["rec_loss"].item(), float(z["out/rec_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(f["emb_loss"].item(), float(z["out/emb_loss"]), rtol=1e-5)
+    loss = m.train_step(users, pos, neg)
+    np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=1e-5)
+    Gv = m.arena.views(m.arena.grad)
+    for k in Gv:
+        ref = z["grad/" + k]
+        assert np.abs(Gv[k].cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-8, k
+    m.reset_ranking_buffers()
+    np.testing.assert_allclose(m.recommend_from_full(users).cpu().numpy(), z["out/scores"], rtol=1e-4, atol=1e-6)
+
+
+def test_lightgcn_adam_trajectory_vs_oracle(ops):
+    from oracle import lightgcn as olg
+    from recboard_amd.gen import LightGCNEngine
+    z = np.load(os.path.join(G, "lightgcn.npz"))
+    wd = float(z["cfg/weight_decay"])
+    crow, col, val = z["in/adj_crow"], z["in/adj_col"], z["in/adj_val"]
+    m = LightGCNEngine(30, 40, crow, col, val, 64, 3, lr=5e-3, weight_decay=wd)
+    m.load_state_dict({k[6:]: z[k] for k in z.files if k.startswith("param/")})
+    U = torch.from_numpy(z["param/User.embeddings.weight"].copy()).requires_grad_(True)
+    I = torch.from_numpy(z["param/Item.embeddings.weight"].copy()).requires_grad_(True)
+    opt = torch.optim.Adam([U, I], lr=5e-3)     # optimizer built WITHOUT weight decay (LightGCN/main.py:139-145)
+    users, pos, neg = (torch.from_numpy(z[k]) for k in ("in/users", "in/pos", "in/neg"))
+    for _ in range(3):
+        lg = m.train_step(users.cuda(), pos.cuda(), neg.cuda())
+        opt.zero_grad()
+        rec, emb = olg.fit(U, I, crow, col, val, users, pos, neg, 3)
+        (rec + wd * emb).backward()
+        opt.step()
+        np.testing.assert_allclose(lg.item(), (rec + wd * emb).item(), rtol=2e-5)
+    np.testing.assert_allclose(m.params["User.embeddings.weight"].cpu().numpy(), U.detach().numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(m.params["Item.embeddings.weight"].cpu().numpy(), I.detach().numpy(), rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,D,avg_deg,hot", [(500, 64, 8, 0), (3000, 64, 20, 2000), (700, 128, 5, 600)])
+def test_spmm_csr_vs_oracle_with_long_rows(ops, n, D, avg_deg, hot):
+    """random sparse matrix (+ one very long row -> the workgroup-per-row path), beta/Z and ACC epilogues."""
+    from oracle import lightgcn as olg
+    rng = np.random.default_rng(n)
+    rows = rng.integers(0, n, n * avg_deg)
+    cols = rng.integers(0, n, n * avg_deg)
+    if hot:
+        rows = np.concatenate([rows, np.full(hot, 7)])
+        cols = np.concatenate([cols, rng.integers(0, n, hot)])
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    vals = rng.standard_normal(len(rows)).astype(np.float32)
+    crow = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=crow[1:])
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    Z = rng.standard_normal((n, D)).astype(np.float32)
+    acc0 = rng.standard_normal((n, D)).astype(np.float32)
+    ref = olg.spmm_csr(crow, cols, vals, torch.from_numpy(X)).numpy() + 0.5 * Z
+    cr, co, va = dev(crow), dev(cols), dev(vals)
+    plan = ops.spmm_plan(cr)
+    assert plan.numel() == (1 if hot else 0)
+    out = torch.empty(n, D, device="cuda")
+    acc = dev(acc0)
+    ops.spmm_csr(cr, co, va, plan, dev(X), out, Z=dev(Z), beta=0.5, acc=acc, acc_scale=0.25)
+    scale = np.abs(ref).max()
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * scale
+    np.testing.assert_allclose(acc.cpu().numpy(), acc0 + 0.25 * ref, rtol=1e-4, atol=1e-4)
+    out2 = torch.empty_like(out)
+    ops.spmm_csr(cr, co, va, plan, dev(X), out2, Z=dev(Z), beta=0.5)
+    assert torch.equal(out, out2)           # bitwise reproducible
+
+
+def test_scatter_add_accumulate_mode(ops):
+    rng = np.random.default_rng(4)
+    n, D, R = 5000, 64, 300
+    g, idx = dev(rng.standard_normal((n, D)).astype(np.float32)), dev(rng.integers(0, R, n))
+    base = torch.randn(R, D, device="cuda")
+    fresh = ops.scatter_add_rows(g, idx, R)
+    out = base.clone()
+    ops.scatter_add_rows(g, idx, R, out=out, accumulate=True)
+    torch.testing.assert_close(out, base + fresh, rtol=1e-6, atol=1e-5)
