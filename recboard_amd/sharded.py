@@ -1,0 +1,159 @@
+"""Row-sharded embedding table for one node: row r lives on rank r % G as local row r // G.
+
+`mod` placement spreads Zipf-hot rows over all GPUs.  Per step there is ONE exchange per direction:
+    forward   indices out (all_to_all of int64 local row ids) -> owners gather -> rows back (all_to_all of fp32 rows)
+    backward  gradient rows to their owners (all_to_all) -> local deterministic scatter-add into the shard's gradient
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-to-all puts each pair's bytes on its own link, so the
+exchange is bounded by the largest per-pair message, not by a ring.  The table's gradient is never all-reduced.
+
+The local kernels are injected (`local_ops`): the product default is the HIP engine (recboard_amd.ops, GPU only, no
+CPU fallback); the CPU `gloo` tests inject the oracle's gather / scatter-add to exercise the routing logic.
+Full-catalog scoring shards the same way: queries are all-gathered (B*D*4 bytes -- tiny), every rank scores its shard
+with the fused top-K kernel, the G partial lists are all-gathered and merged.
+"""
+import torch
+import torch.distributed as dist
+
+
+class EngineLocalOps:
+    """HIP kernels (recboard_amd.ops).  Requires a GPU; raises otherwise."""
+
+    def gather(self, W, idx):
+        from . import ops
+        return ops.gather_rows(W, idx)
+
+    def scatter_add(self, g, idx, R):
+        from . import ops
+        return ops.scatter_add_rows(g, idx, R)
+
+    def score_topk(self, Q, E, seen_ptr, seen_idx, K):
+        from . import ops
+        return ops.score_topk(Q, E, seen_ptr, seen_idx, K)
+
+
+class Route:
+    """Permutation + split sizes of one lookup, kept for the backward exchange."""
+    __slots__ = ("order", "send_counts", "recv_counts", "recv_local", "n")
+
+
+class ShardedTable:
+    def __init__(self, num_rows, dim, local_ops=None, group=None, device=None, dtype=torch.float32):
+        self.group = group
+        self.G = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.R, self.D = num_rows, dim
+        self.local_rows = (num_rows - self.rank + self.G - 1) // self.G
+        self.ops = local_ops if local_ops is not None else EngineLocalOps()
+        self.device = device
+        self.weight = torch.zeros((self.local_rows, dim), dtype=dtype, device=device)
+
+    # ---- placement
+    def owner(self, idx):
+        return idx % self.G
+
+    def local_index(self, idx):
+        return idx // self.G
+
+    def global_index(self, local, rank=None):
+        return local * self.G + (self.rank if rank is None else rank)
+
+    def init_from_full(self, full):
+        """Test helper: take this rank's rows of a replicated table."""
+        self.weight.copy_(full[self.rank::self.G])
+
+    # ---- exchange
+    def _route(self, idx):
+        flat = idx.reshape(-1)
+        own = self.owner(flat)
+        order = torch.argsort(own, stable=True)
+        send_counts = torch.bincount(own, minlength=self.G)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()       # split sizes are host-side by API
+        send_local = self.local_index(flat[order]).contiguous()
+        recv_local = torch.empty(sum(rc), dtype=flat.dtype, device=flat.device)
+        dist.all_to_all_single(recv_local, send_local, rc, sc, group=self.group)
+        r = Route()
+        r.order, r.send_counts, r.recv_counts, r.recv_local, r.n = order, sc, rc, recv_local, flat.numel()
+        return r
+
+    def lookup(self, idx):
+        """-> (rows [*idx.shape, D], route).  Global `W[idx]` on a table no rank holds entirely."""
+        r = self._route(idx)
+        rows_for_peers = self.ops.gather(self.weight, r.recv_local).reshape(-1, self.D)
+        rows_sorted = torch.empty((r.n, self.D), dtype=self.weight.dtype, device=self.weight.device)
+        dist.all_to_all_single(rows_sorted, rows_for_peers.contiguous(), r.send_counts, r.recv_counts, group=self.group)
+        out = torch.empty_like(rows_sorted)
+        out[r.order] = rows_sorted
+        return out.reshape(tuple(idx.shape) + (self.D,)), r
+
+    def backward(self, grad_rows, route):
+        """Send every gradient row to the owner of its table row; -> dense gradient of THIS rank's shard."""
+        g = grad_rows.reshape(-1, self.D)[route.order].contiguous()
+        recv = torch.empty((sum(route.recv_counts), self.D), dtype=g.dtype, device=g.device)
+        dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
+        return self.ops.scatter_add(recv, route.recv_local, self.local_rows)
+
+    # ---- full-catalog scoring over the sharded catalog
+    def score_topk(self, Q_local, seen_ptr, seen_idx, K):
+        """Q_local [b, D] on every rank; seen CSR in GLOBAL item ids for the local queries.
+        -> (vals [b, K], idx [b, K] global ids), identical to scoring against the unsharded table."""
+        G, dev = self.G, Q_local.device
+        b = Q_local.shape[0]
+        Qs = [torch.empty_like(Q_local) for _ in range(G)]
+        dist.all_gather(Qs, Q_local.contiguous(), group=self.group)
+        ptrs, idxs = self._gather_seen(seen_ptr, seen_idx)
+        outs_v, outs_i = [], []
+        for src in range(G):                 # score every rank's queries against MY shard
+            sp, si = self._seen_for_shard(ptrs[src], idxs[src])
+            v, i = self.ops.score_topk(Qs[src], self.weight, sp, si, min(K, self.local_rows))
+            gi = torch.where(i >= 0, self.global_index(i), i)
+            if v.shape[1] < K:               # shard smaller than K: pad
+                pad = K - v.shape[1]
+                v = torch.cat([v, torch.full((b, pad), float("-inf"), device=dev)], 1)
+                gi = torch.cat([gi, torch.full((b, pad), -1, dtype=gi.dtype, device=dev)], 1)
+            outs_v.append(v)
+            outs_i.append(gi)
+        # every rank ends up with the G partial lists of ITS queries
+        sv, si_ = torch.stack(outs_v).contiguous(), torch.stack(outs_i).contiguous()      # [G, b, K], equal splits
+        pv, pi = torch.empty_like(sv), torch.empty_like(si_)
+        dist.all_to_all_single(pv, sv, group=self.group)
+        dist.all_to_all_single(pi, si_, group=self.group)
+        return merge_topk(pv.permute(1, 0, 2).reshape(b, G * K), pi.permute(1, 0, 2).reshape(b, G * K), K)
+
+    def _gather_seen(self, seen_ptr, seen_idx):
+        G = self.G
+        if seen_ptr is None:
+            return [None] * G, [None] * G
+        n = torch.tensor([seen_idx.numel()], dtype=torch.int64, device=seen_idx.device)
+        ns = [torch.empty_like(n) for _ in range(G)]
+        dist.all_gather(ns, n, group=self.group)
+        ptrs = [torch.empty_like(seen_ptr) for _ in range(G)]
+        dist.all_gather(ptrs, seen_ptr.contiguous(), group=self.group)
+        mx = int(max(int(x) for x in ns))
+        padded = torch.full((mx,), -1, dtype=seen_idx.dtype, device=seen_idx.device)
+        padded[: seen_idx.numel()] = seen_idx
+        idxs = [torch.empty_like(padded) for _ in range(G)]
+        dist.all_gather(idxs, padded, group=self.group)
+        return ptrs, [x[: int(k)] for x, k in zip(idxs, ns)]
+
+    def _seen_for_shard(self, ptr, idx):
+        """Keep the seen ids owned by this rank, as LOCAL ids (ascending order is preserved)."""
+        if ptr is None:
+            return None, None
+        mine = self.owner(idx) == self.rank
+        counts = torch.zeros(ptr.numel() - 1, dtype=torch.int64, device=idx.device)
+        rows = torch.repeat_interleave(torch.arange(ptr.numel() - 1, device=idx.device), ptr[1:] - ptr[:-1])
+        counts.index_add_(0, rows[mine], torch.ones(int(mine.sum()), dtype=torch.int64, device=idx.device))
+        sp = torch.zeros_like(ptr)
+        sp[1:] = torch.cumsum(counts, 0)
+        return sp, self.local_index(idx[mine]).contiguous()
+
+
+def merge_topk(vals, idx, K):
+    """K best of concatenated partial lists [b, G*K]; order = value descending, ties -> lowest index; (-inf, -1) last."""
+    key_idx = torch.where(idx < 0, torch.full_like(idx, torch.iinfo(idx.dtype).max), idx)
+    o1 = torch.argsort(key_idx, dim=1, stable=True)
+    v1, i1 = torch.gather(vals, 1, o1), torch.gather(idx, 1, o1)
+    o2 = torch.argsort(v1, dim=1, descending=True, stable=True)
+    return torch.gather(v1, 1, o2)[:, :K].contiguous(), torch.gather(i1, 1, o2)[:, :K].contiguous()
