@@ -161,6 +161,15 @@ int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_
                           size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Ranking metrics from the sorted top-K list of re_score_topk (freerec.metrics via Coach.evaluate, contract mirrored at
+ * UniSRec/main.py:428-447).  topk_idx [B, Kmax] int64; targets as CSR (tgt_ptr[B+1], tgt_idx) of item ids;
+ * h_ks = HOST array of nk <= 8 cut-offs (each <= Kmax <= 64).
+ * per_user [B, nk, 5] = (HITRATE, PRECISION, RECALL, NDCG, MRR) @ k;  sums [nk*5] (optional) = totals over the B users
+ * in a fixed order (the caller divides by the number of users, as Coach.monitor does with n = batch size). */
+int re_rank_metrics(const int64_t* topk_idx, int64_t B, int64_t Kmax, const int64_t* tgt_ptr, const int64_t* tgt_idx,
+                    const int32_t* h_ks, int32_t nk, float* per_user, float* sums, re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * K8  CSR SpMM for LightGCN propagation:  Y = A X (+ beta Z);  if ACC: ACC += acc_scale * Y.
  * Replaces `self.Adj @ allEmbds` + `avgEmbds += allEmbds / (L+1)` (LightGCN/main.py:81-84) and, Adj being symmetric,
  * the transposed product of the backward pass.  crow int64[nrows+1], col int64[nnz], val f32[nnz]; X [ncols, D],

@@ -289,3 +289,19 @@ def scale_copy(dst, src, alpha):
     _req(dst, torch.float32, "dst"); _req(src, torch.float32, "src")
     lib.check(lib.load().re_scale_copy(_p(dst), _p(src), float(alpha), src.numel(), _stream()), "re_scale_copy")
     return dst
+
+
+METRIC_NAMES = ("HITRATE", "PRECISION", "RECALL", "NDCG", "MRR")
+
+
+def rank_metrics(topk_idx, tgt_ptr, tgt_idx, ks):
+    """-> (per_user [B, nk, 5], sums [nk, 5]) for METRIC_NAMES at every k in `ks` (re_rank_metrics)."""
+    _req(topk_idx, torch.int64, "topk_idx"); _req(tgt_ptr, torch.int64, "tgt_ptr"); _req(tgt_idx, torch.int64, "tgt_idx")
+    B, Kmax = topk_idx.shape
+    ks = [int(k) for k in ks]
+    arr = (ctypes.c_int32 * len(ks))(*ks)
+    per_user = torch.empty((B, len(ks), 5), dtype=torch.float32, device=topk_idx.device)
+    sums = torch.empty((len(ks), 5), dtype=torch.float32, device=topk_idx.device)
+    lib.check(lib.load().re_rank_metrics(_p(topk_idx), B, Kmax, _p(tgt_ptr), _p(tgt_idx), arr, len(ks), _p(per_user), _p(sums),
+                                         _stream()), "re_rank_metrics")
+    return per_user, sums

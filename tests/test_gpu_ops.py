@@ -300,3 +300,47 @@ def test_adam_step_matches_oracle_and_torch(ops):
         adam.adam_step(pr, g, mr, vr, step, 5e-4, 0.9, 0.999, 1e-8, 1e-6)
     np.testing.assert_allclose(p.cpu().numpy(), pr, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(v.cpu().numpy(), vr, rtol=2e-6, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ ranking metrics
+def test_rank_metrics_vs_oracle(ops):
+    from oracle import ranking
+    rng = np.random.default_rng(8)
+    B, N, K = 333, 500, 50
+    scores = rng.standard_normal((B, N)).astype(np.float32)
+    ntg = rng.integers(1, 4, B)
+    tl = [np.sort(rng.choice(N, k, replace=False)) for k in ntg]
+    ptr = np.zeros(B + 1, np.int64)
+    ptr[1:] = np.cumsum(ntg)
+    tidx = np.concatenate(tl).astype(np.int64)
+    order = np.argsort(-scores, axis=1, kind="stable")[:, :K].astype(np.int64)
+    ks = (1, 5, 10, 20, 50)
+    ref = ranking.metrics_from_topk(order, ptr, tidx, ks)
+    per_user, sums = ops.rank_metrics(dev(order), dev(ptr), dev(tidx), ks)
+    for ik, k in enumerate(ks):
+        for j, name in enumerate(ops.METRIC_NAMES):
+            np.testing.assert_allclose(per_user[:, ik, j].cpu().numpy(), ref[f"{name}@{k}"], rtol=1e-5, atol=1e-6, err_msg=f"{name}@{k}")
+            np.testing.assert_allclose(sums[ik, j].item(), ref[f"{name}@{k}"].sum(), rtol=1e-5)
+
+
+def test_evaluator_matches_reference_golden_pipeline(ops):
+    """Coach.evaluate contract end to end on the SASRec golden: scores -> seen mask -> top-50 -> HR/NDCG."""
+    from oracle import ranking
+    from recboard_amd.evaluate import RankingEvaluator
+    z = np.load(os.path.join(G, "sasrec_bce.npz"))
+    q = z["out/userEmbds"][:, -1, :]
+    E = z["param/Item.embeddings.weight"][1:]
+    tgt = np.arange(8) * 7 % 200                     # one held-out target per user (leave-one-out)
+    tp, ti = np.arange(9, dtype=np.int64), tgt.astype(np.int64)
+    ev = RankingEvaluator(["LOSS", "HitRate@1", "HitRate@10", "NDCG@10", "NDCG@50"])
+    _, idx = ops.score_topk(dev(q), dev(E), dev(z["in/seen_ptr"]), dev(z["in/seen_idx"]), ev.kmax)
+    ev.update(idx, dev(tp), dev(ti))
+    got = ev.compute()
+    s = z["out/scores"].copy()
+    for b in range(8):
+        s[b, z["in/seen_idx"][z["in/seen_ptr"][b]:z["in/seen_ptr"][b + 1]]] = -1e23
+    tg = np.zeros_like(s)
+    tg[np.arange(8), tgt] = 1
+    ref = ranking.metrics_dense(s, tg, (1, 10, 50))
+    for k in got:
+        np.testing.assert_allclose(got[k], ref[k].mean(), rtol=1e-5, atol=1e-7, err_msg=k)
