@@ -143,6 +143,12 @@ int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t 
  *     fwdLNs.weight, fwdLNs.bias, conv1.weight [D,D(,1)], conv1.bias, conv2.weight, conv2.bias
  *   tape: NULL for inference; otherwise re_sasrec_tape_bytes() bytes that receive the activations the backward
  *   needs (x, q, k, v, P, o, x1, relu(h), LN statistics).
+ *   order / nshort (both NULL or both set, DEVICE int32): optional length packing.  order[B] lists the sequence
+ *   ids with the `*nshort` "short" ones first -- short = every real token lies in the last 16 positions.  Four short
+ *   sequences share one workgroup iteration (block-diagonal attention; the S-16 leading pad positions enter the
+ *   softmax analytically as one key of multiplicity S-16), the others take one iteration each.  Results are the
+ *   same function of the inputs either way.  In training mode rows of u / dx0 at pad positions in front of a short
+ *   sequence's window are not written (nothing on the path reads them); inference fills them with lastLN.bias.
  * re_sasrec_encoder_bwd: given dU [B,S,D] (gradient w.r.t. u) and the tape of the SAME (drop_p, seed) forward,
  *   writes dx0 [B,S,D] (gradient w.r.t. x0, for re_scatter_add_rows / the position table) and OVERWRITES the
  *   parameter gradients: block_grads is a HOST array of 12*L DEVICE pointers in the order above.
@@ -152,13 +158,13 @@ size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b,
                           float drop_p, uint32_t seed, float* u, void* tape, size_t tape_bytes,
-                          re_stream_t stream);
+                          const int32_t* order, const int32_t* nshort, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b,
                           float drop_p, uint32_t seed, const void* tape, float* dx0,
                           float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
-                          size_t ws_bytes, re_stream_t stream);
+                          size_t ws_bytes, const int32_t* order, const int32_t* nshort, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Ranking metrics from the sorted top-K list of re_score_topk (freerec.metrics via Coach.evaluate, contract mirrored at

@@ -44,6 +44,14 @@ __device__ __forceinline__ float colsum16(const float* tile, int tid) {
     for (int i = 0; i < 16; ++i) s += tile[(r0 + i) * SE_LS + c];
     return s;
 }
+// sum over this thread's 16 rows of w[row] * tile[row][col]
+__device__ __forceinline__ float colsum16_w(const float* tile, const float* w, int tid) {
+    const int c = tid & 63, r0 = (tid >> 6) * 16;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s = fmaf(w[r0 + i], tile[(r0 + i) * SE_LS + c], s);
+    return s;
+}
 // sum over 16 rows of dy * xhat, xhat = (x - mean[row]) * rstd[row]
 __device__ __forceinline__ float colsum16_xhat(const float* dy, const float* x, const float* mean, const float* rstd, int tid) {
     const int c = tid & 63, r0 = (tid >> 6) * 16;
@@ -89,10 +97,11 @@ __device__ __forceinline__ void ln_apply_row(const float* x, float* dst, const f
     for (int i = 0; i < 16; ++i) dst[r * SE_LS + c0 + i] = (x[r * SE_LS + c0 + i] - mu) * rs * gw[c0 + i] + gb[c0 + i];
 }
 
-__device__ __forceinline__ void load_stats(float* s_mean, float* s_rstd, const float* __restrict__ st, int S, int tid) {
+__device__ __forceinline__ void load_stats(float* s_a, float* s_b, const float* __restrict__ st, const int* s_gid, int tid) {
     if (tid < SE_ROWS) {
-        s_mean[tid] = tid < S ? st[2 * tid] : 0.f;
-        s_rstd[tid] = tid < S ? st[2 * tid + 1] : 0.f;
+        const int gid = s_gid[tid];
+        s_a[tid] = gid >= 0 ? st[2 * (int64_t)gid] : 0.f;
+        s_b[tid] = gid >= 0 ? st[2 * (int64_t)gid + 1] : 0.f;
     }
 }
 
@@ -101,7 +110,8 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
                                                           int l, SasrecBlockParams W0, const float* __restrict__ last_w0,
                                                           float drop_scale, uint32_t thresh, uint32_t seed,
                                                           const float* __restrict__ tape, SasrecTape T,
-                                                          float* __restrict__ dOut, float* __restrict__ slab) {
+                                                          float* __restrict__ dOut, float* __restrict__ slab,
+                                                          const int* __restrict__ order, const int* __restrict__ nshort_ptr) {
     extern __shared__ __align__(16) float lds[];
     float* b0 = lds;
     float* b1 = b0 + SE_BUF;
@@ -111,12 +121,13 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
     float* b5 = b4 + SE_BUF;
     float* b6 = b5 + SE_BUF;
     __shared__ float s_mean[SE_ROWS], s_rstd[SE_ROWS];
-    __shared__ int s_pad[SE_ROWS];
+    __shared__ float s_ppad[SE_ROWS], s_w[SE_ROWS], s_cpad[SE_ROWS];   // virtual pad key: prob of one copy, total kept weight, dS
+    __shared__ int s_gid[SE_ROWS], s_grp[SE_ROWS], s_pad[SE_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15, col = 16 * wave + c;
-    const int64_t SD = (int64_t)S * SE_D;
     const float* tp = tape + (int64_t)l * T.per_block;
+    const SeWork WK = se_work(B, nshort_ptr);
 
     f32x4 accW[SB_NMAT][4];
 #pragma unroll
@@ -127,15 +138,16 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
 #pragma unroll
     for (int v = 0; v < SB_NVEC; ++v) accV[v] = 0.f;
 
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int wi = blockIdx.x; wi < WK.total; wi += gridDim.x) {
         const SasrecBlockParams W = se_launder(W0);
         const float* last_w = se_launder(last_w0);
         __syncthreads();
-        tile_load(b0, dIn + (int64_t)b * SD, S, tid);
-        if (tid < SE_ROWS) s_pad[tid] = (tid < S) ? (seq[(int64_t)b * S + tid] == 0) : 1;
+        const int n_out = se_decode(wi, WK, B, S, order, seq, tid, s_gid, s_grp, s_pad);
+        __syncthreads();
+        tile_load(b0, dIn, s_gid, tid);
         if (FIRST) {
-            tile_load(b1, tape + T.off_XL + (int64_t)b * SD, S, tid);
-            load_stats(s_mean, s_rstd, tape + T.off_SL + (int64_t)b * S * 2, S, tid);
+            tile_load(b1, tape + T.off_XL, s_gid, tid);
+            load_stats(s_mean, s_rstd, tape + T.off_SL, s_gid, tid);
         }
         __syncthreads();
         if (FIRST) {  // u = LN_last(x_L): dgamma/dbeta, then dx_L in place
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
             __syncthreads();
         }
         // ---- pad mask of the block output (x'[pad] = 0) and dO2 = dX' * dropout2 mask
-        tile_load(b1, tp + T.off_HR + (int64_t)b * SD, S, tid);
+        tile_load(b1, tp + T.off_HR, s_gid, tid);
         {
             const int r = tid >> 2, c0 = (tid & 3) * 16;
             const bool dead = s_pad[r] != 0;
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
                 float v = dead ? 0.f : b0[r * SE_LS + c0 + i];
                 b0[r * SE_LS + c0 + i] = v;
                 if (thresh) {
-                    const uint32_t e = (uint32_t)((((int64_t)b * S + r) * SE_D) + c0 + i);
+                    const uint32_t e = (uint32_t)((int64_t)s_gid[r] * SE_D + c0 + i);
                     v = re_keep(seed, RE_STREAM_FFN2(l), e, thresh) ? v * drop_scale : 0.f;
                 }
                 b2[r * SE_LS + c0 + i] = v;
@@ -175,8 +187,8 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
         }
         __syncthreads();
         // ---- B. FFN first map: y = LN_f(x1) rebuilt; dW1 += dH^T y; db1; dY = dH W1 + dX'
-        tile_load(b1, tp + T.off_X1 + (int64_t)b * SD, S, tid);
-        load_stats(s_mean, s_rstd, tp + T.off_SF + (int64_t)b * S * 2, S, tid);
+        tile_load(b1, tp + T.off_X1, s_gid, tid);
+        load_stats(s_mean, s_rstd, tp + T.off_SF, s_gid, tid);
         __syncthreads();
         ln_apply_row(b1, b2, W.ln_f_w, W.ln_f_b, s_mean, s_rstd, tid);
         __syncthreads();
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
         ln_bwd_row<false>(b0, b1, b0, W.ln_f_w, s_mean, s_rstd, tid);
         __syncthreads();
         // ---- D. out_proj: dWo += dX1^T o; dbo; dO = dX1 Wo
-        tile_load(b2, tp + T.off_O + (int64_t)b * SD, S, tid);
+        tile_load(b2, tp + T.off_O, s_gid, tid);
         __syncthreads();
         {
             float bf[16];
@@ -208,19 +220,21 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
         }
         __syncthreads();
         // ---- E. attention: load V, P; Pd = P*mask; dP = (dO V^T)*mask; dV = Pd^T dO; dS = P (dP - rowsum(dP P)) / sqrt(D)
-        tile_load(b1, tp + T.off_V + (int64_t)b * SD, S, tid);
+        tile_load(b1, tp + T.off_V, s_gid, tid);
+        load_stats(s_ppad, s_w, tp + T.off_PP, s_gid, tid);   // (p_pad, w) of the virtual out-of-window pad key
         {
-            const float* Pg = tp + T.off_P + (int64_t)b * S * S;
+            const float* Pg = tp + T.off_P;
             const int i = tid >> 2, j0 = (tid & 3) * 16;
+            const int gi = s_gid[i], grp = s_grp[i];
+            const int sbase = gi >= 0 ? (gi / S) * S : 0;
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) {
                 const int j = j0 + jj;
-                float p = (i < S && j <= i) ? Pg[i * S + j] : 0.f;
+                const bool ok = gi >= 0 && j <= i && s_gid[j] >= 0 && s_grp[j] == grp;
+                const int sj = ok ? s_gid[j] - sbase : 0;
+                float p = ok ? Pg[(int64_t)gi * S + sj] : 0.f;
                 float m = 1.0f;
-                if (thresh && p != 0.f) {
-                    const uint32_t e = (uint32_t)(((int64_t)b * S + i) * S + j);
-                    m = re_keep(seed, RE_STREAM_ATTN(l), e, thresh) ? drop_scale : 0.f;
-                }
+                if (thresh && p != 0.f) m = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? drop_scale : 0.f;
                 b4[i * SE_LS + j] = p;
                 b6[i * SE_LS + j] = p * m;
             }
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
             frag_ks(bf, b3 + (16 * g) * SE_LS + col, SE_LS);     // B[k=i][n=d] = dO
             gemm64<false>(b6, bf, lane, [&](int row, float v) { b2[row * SE_LS + col] = v; });  // dV
         }
+        if (n_out > 0) accV[2] += colsum16_w(b3, s_w, tid);     // d b_v through the virtual pad key: sum_i w_i dO_i
         __syncthreads();
         {
             const int i = tid >> 2, j0 = (tid & 3) * 16;
@@ -248,25 +263,39 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) s = fmaf(dp[jj], pp[jj], s);
             s = quad_sum(s);
+            if (n_out > 0) {
+                // virtual pad key: upstream grad of each copy = (dO_i . b_v) * mask; t = dO_i . b_v
+                float t = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) t = fmaf(b3[i * SE_LS + j0 + jj], W.in_b[2 * SE_D + j0 + jj], t);
+                t = quad_sum(t);
+                const float wv = s_w[i], ppad = s_ppad[i];
+                s = fmaf(t, wv, s);                                            // rowdot includes the pad copies
+                if ((tid & 3) == 0) s_cpad[i] = (wv * t - (float)n_out * ppad * s) * 0.125f;   // sum of dS over the copies
+            }
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) b5[i * SE_LS + j0 + jj] = pp[jj] * (dp[jj] - s) * 0.125f;
         }
+        __syncthreads();   // dS complete; dO (b3), V (b1) and P (b4) no longer needed
         // ---- F. dQ = dS K -> b4 ; dK = dS^T Q -> b6
-        tile_load(b3, tp + T.off_Q + (int64_t)b * SD, S, tid);
-        __syncthreads();   // dS complete; V (b1) and P (b4) no longer needed
-        tile_load(b1, tp + T.off_K + (int64_t)b * SD, S, tid);
+        tile_load(b3, tp + T.off_Q, s_gid, tid);
+        tile_load(b1, tp + T.off_K, s_gid, tid);
         __syncthreads();
         {
             float bf[16];
             frag_ks(bf, b1 + (16 * g) * SE_LS + col, SE_LS);
-            gemm64<true>(b5, bf, lane, [&](int row, float v) { b4[row * SE_LS + col] = v; });
+            const float bkc = (n_out > 0) ? W.in_b[SE_D + col] : 0.f;
+            gemm64<true>(b5, bf, lane, [&](int row, float v) {
+                b4[row * SE_LS + col] = (n_out > 0) ? fmaf(s_cpad[row], bkc, v) : v;   // + dS_pad * b_k
+            });
             frag_ks(bf, b3 + (16 * g) * SE_LS + col, SE_LS);
             gemm64<false>(b5, bf, lane, [&](int row, float v) { b6[row * SE_LS + col] = v; });
+            if (n_out > 0) accV[1] += colsum16_w(b3, s_cpad, tid);   // d b_k through the virtual pad key: sum_i dS_pad_i q_i
         }
         __syncthreads();
         // ---- G. projections: x, LN_a(x) rebuilt; dWq/dWk/dWv, biases; dA1 = dQ Wq -> b5; dX (b0) += dK Wk + dV Wv
-        tile_load(b1, tp + T.off_X + (int64_t)b * SD, S, tid);
-        load_stats(s_mean, s_rstd, tp + T.off_SA + (int64_t)b * S * 2, S, tid);
+        tile_load(b1, tp + T.off_X, s_gid, tid);
+        load_stats(s_mean, s_rstd, tp + T.off_SA, s_gid, tid);
         __syncthreads();
         ln_apply_row(b1, b3, W.ln_a_w, W.ln_a_b, s_mean, s_rstd, tid);
         __syncthreads();
@@ -293,7 +322,7 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
         accV[7] += colsum16(b5, tid);
         ln_bwd_row<true>(b5, b1, b0, W.ln_a_w, s_mean, s_rstd, tid);
         __syncthreads();
-        tile_store(b0, dOut + (int64_t)b * SD, S, tid);
+        tile_store(b0, dOut, s_gid, tid);
     }
 
     // ---- this workgroup's slab
@@ -376,13 +405,15 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
 extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                                      const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
                                      uint32_t seed, const void* tape, float* dx0, float* const* block_grads, float* g_last_w,
-                                     float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream) {
+                                     float* g_last_b, void* ws, size_t ws_bytes, const int32_t* order, const int32_t* nshort,
+                                     re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
     if (!dU || !seq || !tape || !dx0 || !block_params || !block_grads || !g_last_w || !g_last_b || !last_w || !last_b || !ws || B < 0)
         return RE_EINVAL;
     if (D != SE_D || S < 1 || S > SE_ROWS || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
     if (drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
+    if ((order == nullptr) != (nshort == nullptr)) return RE_EINVAL;
     if (ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L)) return RE_EWORKSPACE;
     for (int64_t i = 0; i < 12 * L; ++i)
         if (!block_params[i] || !block_grads[i]) return RE_EINVAL;
@@ -409,10 +440,10 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
         const bool first = (l == L - 1);
         if (first)
             hipLaunchKernelGGL(kf, dim3(nwg), dim3(256), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
-                               (const float*)tape, T, dout, slab);
+                               (const float*)tape, T, dout, slab, order, nshort);
         else
             hipLaunchKernelGGL(kn, dim3(nwg), dim3(256), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
-                               (const float*)tape, T, dout, slab);
+                               (const float*)tape, T, dout, slab, order, nshort);
         SasrecGradDst dst;
         for (int i = 0; i < 12; ++i) dst.p[i] = block_grads[12 * l + i];
         dst.p[12] = g_last_w;

@@ -31,10 +31,10 @@ struct SasrecParams {
 };
 
 // ---- tape layout (activations saved by the forward for the backward), all fp32, per block l:
-//   X, Q, K, V, O, X1, HR : [B][S][D]     P : [B][S][S]     stats_a, stats_f : [B][S][2] (mean, rstd)
+//   X, Q, K, V, O, X1, HR : [B][S][D]     P : [B][S][S]     stats_a, stats_f : [B][S][2] (mean, rstd)   PP : [B][S][2]
 // then XL [B][S][D] (input of lastLN) and stats_last [B][S][2].
 struct SasrecTape {
-    int64_t per_block, off_X, off_Q, off_K, off_V, off_O, off_X1, off_HR, off_P, off_SA, off_SF, off_XL, off_SL, total;
+    int64_t per_block, off_X, off_Q, off_K, off_V, off_O, off_X1, off_HR, off_P, off_SA, off_SF, off_PP, off_XL, off_SL, total;
 };
 __host__ __device__ inline SasrecTape sasrec_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L) {
     SasrecTape t;
@@ -50,6 +50,7 @@ __host__ __device__ inline SasrecTape sasrec_tape_layout(int64_t B, int64_t S, i
     t.off_P = o; o += (pp + 3) / 4 * 4;
     t.off_SA = o; o += st;
     t.off_SF = o; o += st;
+    t.off_PP = o; o += st;   // (p_pad, w) of the virtual out-of-window pad key, per query row
     t.per_block = o;
     t.off_XL = L * o;
     t.off_SL = t.off_XL + act;
@@ -148,21 +149,69 @@ __device__ __forceinline__ void ln_row(const float* src, float* dst, const float
     for (int i = 0; i < 16; ++i) dst[r * SE_LS + c0 + i] = (x[i] - mean) * rstd * gw[c0 + i] + gb[c0 + i];
 }
 
-// copy an LDS tile's first S rows to / from a [S][64] global matrix (coalesced float4)
-__device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ gdst, int S, int tid) {
-    for (int f = tid; f < S * (SE_D / 4); f += 256) {
+// ---- work items: which (sequence, position) each of the 64 LDS rows holds ------------------------------------------
+// Sequences are left-padded, so a sequence's real tokens are its LAST len positions.  Two packings:
+//   LONG  : one sequence, row r = position r - (64 - S)                       (any length)
+//   SHORT : four sequences whose real tokens all lie in their last SE_WIN = 16 positions; row tile t = the last 16
+//           positions of sequence t.  Attention is block diagonal (same-tile keys only) and the S - 16 positions in
+//           front of the window -- all pads, i.e. identical keys k = b_k, v = b_v -- enter the softmax analytically as
+//           one virtual key of multiplicity n_out (exactly what the reference computes, SASRec/main.py:163-171: pad
+//           positions are attended; only the summation order differs).
+// The projections / FFN / LayerNorms are row-wise, so they run unchanged on the packed 64 rows: a batch whose
+// sequences are mostly short needs ~4x fewer workgroup iterations (~88 % of tokens are padding).
+#define SE_WIN 16
+struct SeWork {
+    int total, nsw, nshort;
+};
+__device__ __forceinline__ SeWork se_work(int B, const int* __restrict__ nshort_ptr) {
+    SeWork w;
+    w.nshort = nshort_ptr ? nshort_ptr[0] : 0;
+    if (w.nshort < 0) w.nshort = 0;
+    if (w.nshort > B) w.nshort = B;
+    w.nsw = (w.nshort + 3) >> 2;
+    w.total = w.nsw + (B - w.nshort);
+    return w;
+}
+// fills s_gid (global token row b*S+s or -1), s_grp (attention group), s_pad (1 = pad or dummy row); returns n_out
+__device__ __forceinline__ int se_decode(int wi, const SeWork& W, int B, int S, const int* __restrict__ order,
+                                         const int64_t* __restrict__ seq, int tid, int* s_gid, int* s_grp, int* s_pad) {
+    const bool shortw = wi < W.nsw;
+    if (tid < SE_ROWS) {
+        int gid = -1, grp = 0;
+        if (shortw) {
+            const int q = 4 * wi + (tid >> 4);
+            const int s = S - SE_WIN + (tid & 15);
+            grp = tid >> 4;
+            if (q < W.nshort && s >= 0) gid = (order ? order[q] : q) * S + s;
+        } else {
+            const int q = W.nshort + (wi - W.nsw);
+            const int s = tid - (SE_ROWS - S);
+            if (s >= 0) gid = (order ? order[q] : q) * S + s;
+        }
+        s_gid[tid] = gid;
+        s_grp[tid] = grp;
+        s_pad[tid] = (gid < 0) ? 1 : (seq[gid] == 0);
+    }
+    return (shortw && S > SE_WIN) ? S - SE_WIN : 0;
+}
+
+// copy LDS tile rows <-> rows of a [B*S][64] global matrix selected by s_gid (coalesced float4 per row)
+__device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ gdst, const int* s_gid, int tid) {
+    for (int f = tid; f < SE_ROWS * (SE_D / 4); f += 256) {
         const int r = f >> 4, c4 = f & 15;
-        reinterpret_cast<float4*>(gdst)[f] = *reinterpret_cast<const float4*>(tile + r * SE_LS + 4 * c4);
+        const int gid = s_gid[r];
+        if (gid >= 0) reinterpret_cast<float4*>(gdst + (int64_t)gid * SE_D)[c4] = *reinterpret_cast<const float4*>(tile + r * SE_LS + 4 * c4);
     }
 }
-__device__ __forceinline__ void tile_load(float* tile, const float* __restrict__ gsrc, int S, int tid) {
+__device__ __forceinline__ void tile_load(float* tile, const float* __restrict__ gsrc, const int* s_gid, int tid) {
     // pin the global loads below this point: hipcc otherwise hoists the loads of EVERY later phase (they do not depend
     // on LDS) to the top of the sequence loop and holds 64 VGPRs per tile until its phase arrives.
     gsrc = se_launder(gsrc);
     for (int f = tid; f < SE_ROWS * (SE_D / 4); f += 256) {
         const int r = f >> 4, c4 = f & 15;
+        const int gid = s_gid[r];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < S) v = reinterpret_cast<const float4*>(gsrc)[f];
+        if (gid >= 0) v = reinterpret_cast<const float4*>(gsrc + (int64_t)gid * SE_D)[c4];
         *reinterpret_cast<float4*>(tile + r * SE_LS + 4 * c4) = v;
     }
 }

@@ -18,7 +18,9 @@ template <bool TRAIN>
 __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restrict__ x0, const int64_t* __restrict__ seq,
                                                             int B, int S, int L, SasrecParams P, float drop_scale,
                                                             uint32_t thresh, uint32_t seed, float* __restrict__ u,
-                                                            float* __restrict__ tape, SasrecTape T) {
+                                                            float* __restrict__ tape, SasrecTape T,
+                                                            const int* __restrict__ order, const int* __restrict__ nshort_ptr,
+                                                            int fill_pads) {
     extern __shared__ __align__(16) float lds[];
     float* bX = lds;
     float* bA = bX + SE_BUF;
@@ -26,18 +28,20 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
     float* bK = bQ + SE_BUF;
     float* bV = bK + SE_BUF;
     float* bP = bV + SE_BUF;
-    __shared__ int s_pad[SE_ROWS];
+    __shared__ int s_gid[SE_ROWS], s_grp[SE_ROWS], s_pad[SE_ROWS];
+    __shared__ float s_w[SE_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15, col = 16 * wave + c;
     const int r_e = tid >> 2, c0_e = (tid & 3) * 16;  // element-wise mapping
     const float inv_sqrt_d = 0.125f;                  // 1/sqrt(64)
-    const int64_t SD = (int64_t)S * SE_D;
+    const SeWork WK = se_work(B, nshort_ptr);
 
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int wi = blockIdx.x; wi < WK.total; wi += gridDim.x) {
         __syncthreads();
-        tile_load(bX, x0 + (int64_t)b * SD, S, tid);
-        if (tid < SE_ROWS) s_pad[tid] = (tid < S) ? (seq[(int64_t)b * S + tid] == 0) : 1;
+        const int n_out = se_decode(wi, WK, B, S, order, seq, tid, s_gid, s_grp, s_pad);
+        __syncthreads();
+        tile_load(bX, x0, s_gid, tid);
         __syncthreads();
 
         for (int l = 0; l < L; ++l) {
@@ -48,9 +52,9 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                 float mean, rstd;
                 ln_row(bX, bA, W.ln_a_w, W.ln_a_b, tid, mean, rstd);
                 if (TRAIN) {
-                    tile_store(bX, tp + T.off_X + (int64_t)b * SD, S, tid);
-                    if ((tid & 3) == 0 && r_e < S) {
-                        float* st = tp + T.off_SA + ((int64_t)b * S + r_e) * 2;
+                    tile_store(bX, tp + T.off_X, s_gid, tid);
+                    if ((tid & 3) == 0 && s_gid[r_e] >= 0) {
+                        float* st = tp + T.off_SA + (int64_t)s_gid[r_e] * 2;
                         st[0] = mean; st[1] = rstd;
                     }
                 }
@@ -71,9 +75,9 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
             }
             __syncthreads();
             if (TRAIN) {
-                tile_store(bQ, tp + T.off_Q + (int64_t)b * SD, S, tid);
-                tile_store(bK, tp + T.off_K + (int64_t)b * SD, S, tid);
-                tile_store(bV, tp + T.off_V + (int64_t)b * SD, S, tid);
+                tile_store(bQ, tp + T.off_Q, s_gid, tid);
+                tile_store(bK, tp + T.off_K, s_gid, tid);
+                tile_store(bV, tp + T.off_V, s_gid, tid);
             }
             // ---- 3. scores = q k^T / sqrt(D)   (B^T = K, k-contiguous in LDS)
             {
@@ -82,16 +86,29 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                 gemm64<true>(bQ, bf, lane, [&](int row, float v) { bP[row * SE_LS + col] = v * inv_sqrt_d; });
             }
             __syncthreads();
-            // ---- softmax over keys j <= i (causal), rows >= S and columns > i are zero; dropout on the probabilities
+            // ---- softmax over the keys of the same sequence with j <= i (causal; pads ARE keys), plus the virtual
+            //      out-of-window pad key (multiplicity n_out, score q.b_k/sqrt(D), value b_v); dropout on the probabilities
             {
                 const int i = r_e;
+                const int gi = s_gid[i], grp = s_grp[i];
                 float p[16];
                 float mx = -INFINITY;
+                unsigned okm = 0;
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) {
                     const int j = c0_e + jj;
-                    p[jj] = (j <= i && i < S) ? bP[i * SE_LS + j] : -INFINITY;
+                    const bool ok = gi >= 0 && j <= i && s_gid[j] >= 0 && s_grp[j] == grp;
+                    okm |= (ok ? 1u : 0u) << jj;
+                    p[jj] = ok ? bP[i * SE_LS + j] : -INFINITY;
                     mx = fmaxf(mx, p[jj]);
+                }
+                float spad = -INFINITY;
+                if (n_out > 0) {  // wave-uniform
+                    float d = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) d = fmaf(bQ[i * SE_LS + c0_e + jj], W.in_b[SE_D + c0_e + jj], d);
+                    spad = (gi >= 0) ? quad_sum(d) * inv_sqrt_d : -INFINITY;
+                    mx = fmaxf(mx, spad);
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
@@ -102,28 +119,54 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                     sum += p[jj];
                 }
                 sum = quad_sum(sum);
-                const float inv = (i < S) ? 1.0f / sum : 0.f;
+                const float epad = (spad == -INFINITY) ? 0.f : expf(spad - mx);
+                sum += (float)n_out * epad;
+                const float inv = (gi >= 0) ? 1.0f / sum : 0.f;
+                if (n_out > 0) {
+                    const float ppad = epad * inv;
+                    float kept = (float)n_out;
+                    if (thresh && gi >= 0) {  // each of the n_out pad keys has its own dropout bit (element (b, s_i, jj))
+                        int cnt = 0;
+                        for (int jj = (tid & 3); jj < n_out; jj += 4)
+                            cnt += re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + jj), thresh) ? 1 : 0;
+                        cnt += __shfl_xor(cnt, 1, 64);
+                        cnt += __shfl_xor(cnt, 2, 64);
+                        kept = (float)cnt * drop_scale;
+                    }
+                    const float wv = ppad * kept;
+                    if ((tid & 3) == 0) {
+                        s_w[i] = wv;
+                        if (TRAIN && gi >= 0) {
+                            float* pp = tp + T.off_PP + (int64_t)gi * 2;
+                            pp[0] = ppad; pp[1] = wv;
+                        }
+                    }
+                } else if ((tid & 3) == 0) {
+                    s_w[i] = 0.f;
+                }
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) {
                     const int j = c0_e + jj;
                     float pr = p[jj] * inv;
-                    if (TRAIN && i < S && j < S) tp[T.off_P + ((int64_t)b * S + i) * S + j] = pr;
-                    if (thresh && pr != 0.f) {
-                        const uint32_t e = (uint32_t)(((int64_t)b * S + i) * S + j);
-                        pr = re_keep(seed, RE_STREAM_ATTN(l), e, thresh) ? pr * drop_scale : 0.f;
+                    if ((okm >> jj) & 1u) {
+                        const int sj = s_gid[j] - (gi / S) * S;   // position of key j inside the sequence
+                        if (TRAIN) tp[T.off_P + (int64_t)gi * S + sj] = pr;
+                        if (thresh && pr != 0.f)
+                            pr = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? pr * drop_scale : 0.f;
                     }
                     bP[i * SE_LS + j] = pr;
                 }
             }
             __syncthreads();
-            // ---- 4. o = A v   (B[k=j][n=d] = V[j][d]: k strided)
+            // ---- 4. o = A v + w * b_v   (B[k=j][n=d] = V[j][d]: k strided)
             {
                 float bf[16];
                 frag_ks(bf, bV + (16 * g) * SE_LS + col, SE_LS);
-                gemm64<true>(bP, bf, lane, [&](int row, float v) { bA[row * SE_LS + col] = v; });
+                const float bv = W.in_b[2 * SE_D + col];
+                gemm64<true>(bP, bf, lane, [&](int row, float v) { bA[row * SE_LS + col] = fmaf(s_w[row], bv, v); });
             }
             __syncthreads();
-            if (TRAIN) tile_store(bA, tp + T.off_O + (int64_t)b * SD, S, tid);
+            if (TRAIN) tile_store(bA, tp + T.off_O, s_gid, tid);
             // ---- 5. x1 = o Wo^T + bo + x
             {
                 float bf[16];
@@ -137,9 +180,9 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                 float mean, rstd;
                 ln_row(bQ, bK, W.ln_f_w, W.ln_f_b, tid, mean, rstd);
                 if (TRAIN) {
-                    tile_store(bQ, tp + T.off_X1 + (int64_t)b * SD, S, tid);
-                    if ((tid & 3) == 0 && r_e < S) {
-                        float* st = tp + T.off_SF + ((int64_t)b * S + r_e) * 2;
+                    tile_store(bQ, tp + T.off_X1, s_gid, tid);
+                    if ((tid & 3) == 0 && s_gid[r_e] >= 0) {
+                        float* st = tp + T.off_SF + (int64_t)s_gid[r_e] * 2;
                         st[0] = mean; st[1] = rstd;
                     }
                 }
@@ -153,14 +196,14 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                 gemm64<true>(bK, bf, lane, [&](int row, float v) {
                     v += b1;
                     if (thresh) {
-                        const uint32_t e = (uint32_t)((((int64_t)b * S + row) * SE_D) + col);
+                        const uint32_t e = (uint32_t)((int64_t)s_gid[row] * SE_D + col);
                         v = re_keep(seed, RE_STREAM_FFN1(l), e, thresh) ? v * drop_scale : 0.f;
                     }
                     bV[row * SE_LS + col] = fmaxf(v, 0.f);
                 });
             }
             __syncthreads();
-            if (TRAIN) tile_store(bV, tp + T.off_HR + (int64_t)b * SD, S, tid);
+            if (TRAIN) tile_store(bV, tp + T.off_HR, s_gid, tid);
             // ---- 8. x' = dropout2(hr W2^T + b2) + y, pad rows zeroed
             {
                 float bf[16];
@@ -169,7 +212,7 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                 gemm64<true>(bV, bf, lane, [&](int row, float v) {
                     v += b2;
                     if (thresh) {
-                        const uint32_t e = (uint32_t)((((int64_t)b * S + row) * SE_D) + col);
+                        const uint32_t e = (uint32_t)((int64_t)s_gid[row] * SE_D + col);
                         v = re_keep(seed, RE_STREAM_FFN2(l), e, thresh) ? v * drop_scale : 0.f;
                     }
                     v += bK[row * SE_LS + col];
@@ -183,15 +226,27 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
             float mean, rstd;
             ln_row(bX, bA, se_launder(P.last_w), se_launder(P.last_b), tid, mean, rstd);
             if (TRAIN) {
-                tile_store(bX, tape + T.off_XL + (int64_t)b * SD, S, tid);
-                if ((tid & 3) == 0 && r_e < S) {
-                    float* st = tape + T.off_SL + ((int64_t)b * S + r_e) * 2;
+                tile_store(bX, tape + T.off_XL, s_gid, tid);
+                if ((tid & 3) == 0 && s_gid[r_e] >= 0) {
+                    float* st = tape + T.off_SL + (int64_t)s_gid[r_e] * 2;
                     st[0] = mean; st[1] = rstd;
                 }
             }
         }
         __syncthreads();
-        tile_store(bA, u + (int64_t)b * SD, S, tid);
+        tile_store(bA, u, s_gid, tid);
+        if (fill_pads && n_out > 0) {
+            // positions in front of the window are pads: u = LN_last(0) = beta_last (what the reference's encode returns there)
+            for (int f = tid; f < 4 * n_out * (SE_D / 4); f += 256) {
+                const int c4 = f & 15, rr = f >> 4;
+                const int t = rr / n_out, s = rr - t * n_out;
+                const int q = 4 * wi + t;
+                if (q < WK.nshort) {
+                    const int b = order ? order[q] : q;
+                    reinterpret_cast<float4*>(u + ((int64_t)b * S + s) * SE_D)[c4] = reinterpret_cast<const float4*>(P.last_b)[c4];
+                }
+            }
+        }
     }
 }
 
@@ -215,7 +270,8 @@ static bool se_fill_params(SasrecParams& P, const float* const* bp, int64_t L, c
 
 extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                                      const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
-                                     uint32_t seed, float* u, void* tape, size_t tape_bytes, re_stream_t stream) {
+                                     uint32_t seed, float* u, void* tape, size_t tape_bytes, const int32_t* order,
+                                     const int32_t* nshort, re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
     if (!x0 || !seq || !u || B < 0) return RE_EINVAL;
@@ -229,15 +285,16 @@ extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_
     const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const size_t ldsb = (size_t)6 * SE_BUF * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    const int grid = (int)(B < 2048 ? B : 2048);
+    const int grid = (int)(B < 2048 ? B : 2048);  // >= the number of work items (shorts packed 4 per item); idle blocks exit
+    if ((order == nullptr) != (nshort == nullptr)) return RE_EINVAL;
     if (tape) {
         auto k = sasrec_encoder_fwd_k<true>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, order, nshort, 0);
     } else {
         auto k = sasrec_encoder_fwd_k<false>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T, order, nshort, 1);
     }
     return re_launch_status();
 }

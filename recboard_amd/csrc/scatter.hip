@@ -54,15 +54,25 @@ __global__ __launch_bounds__(64) void radix_hist(const uint32_t* __restrict__ ke
 }
 
 // exclusive scan of hist[256*T] (digit-major, tile-minor) by ONE block of 1024 threads: each thread owns one
-// contiguous chunk of ceil(total/1024) entries (two passes over its chunk, one block-wide scan of the chunk sums)
+// contiguous chunk of ceil(total/1024) entries.  Chunks of <= 32 entries (n <= 131 072 keys) are held in registers:
+// all loads are issued before the first use, so the kernel pays one memory latency instead of one per entry.
 __global__ __launch_bounds__(1024) void radix_scan(uint32_t* __restrict__ hist, int64_t total) {
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t chunk = (total + 1023) / 1024;
     const int64_t b = (int64_t)tid * chunk;
     const int64_t e = (b + chunk < total) ? b + chunk : total;
+    const bool small = chunk <= 32;
+    uint32_t v[32];
     uint32_t s = 0;
-    for (int64_t i = b; i < e; ++i) s += hist[i];
+    if (small) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = (b + i < e) ? hist[b + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s += v[i];
+    } else {
+        for (int64_t i = b; i < e; ++i) s += hist[i];
+    }
     uint32_t inc = s;  // inclusive wave scan
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -73,10 +83,18 @@ __global__ __launch_bounds__(1024) void radix_scan(uint32_t* __restrict__ hist, 
     __syncthreads();
     uint32_t run = inc - s;
     for (int w = 0; w < wid; ++w) run += wsum[w];
-    for (int64_t i = b; i < e; ++i) {
-        const uint32_t v = hist[i];
-        hist[i] = run;
-        run += v;
+    if (small) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (b + i < e) hist[b + i] = run;
+            run += v[i];
+        }
+    } else {
+        for (int64_t i = b; i < e; ++i) {
+            const uint32_t x = hist[i];
+            hist[i] = run;
+            run += x;
+        }
     }
 }
 

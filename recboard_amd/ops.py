@@ -214,7 +214,17 @@ def sasrec_block_tensors(named, L):
     return [named[k.format(l=l)] for l in range(L) for k in BLOCK_PARAM_ORDER]
 
 
-def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None, tape=None):
+def seq_packing(seq, window=16):
+    """Length packing for the fused encoder (batch-assembly work, no host sync): -> (order int32[B], nshort int32[1]).
+    `short` = every real token of the left-padded sequence lies in its last `window` positions."""
+    S = seq.shape[1]
+    short = (seq[:, : max(S - window, 0)] != 0).sum(1) == 0
+    order = torch.argsort((~short).to(torch.int8), stable=True).to(torch.int32).contiguous()
+    return order, short.sum().to(torch.int32).reshape(1).contiguous()
+
+
+def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None, tape=None,
+                       packing=None):
     """u = lastLN(blocks(x0)) fused (re_sasrec_encoder_fwd).  -> (u [B,S,D], tape or None)."""
     _req(x0, torch.float32, "x0"); _req(seq, torch.int64, "seq")
     B, S, D = x0.shape
@@ -223,14 +233,17 @@ def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, se
     if need_tape and tape is None:
         tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=x0.device)
     tbl = _ptr_table(block_tensors)
+    order, nshort = packing if packing is not None else (None, None)
+    if order is not None:
+        _req(order, torch.int32, "order"); _req(nshort, torch.int32, "nshort")
     lib.check(Lb.re_sasrec_encoder_fwd(_p(x0), _p(seq), B, S, D, L, tbl, _p(last_w), _p(last_b), float(drop_p),
                                        int(seed) & 0xFFFFFFFF, _p(u), _p(tape), 0 if tape is None else tape.numel() * 4,
-                                       _stream()), "re_sasrec_encoder_fwd")
+                                       _p(order), _p(nshort), _stream()), "re_sasrec_encoder_fwd")
     return u, tape
 
 
 def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b,
-                       out=None, ws=None):
+                       out=None, ws=None, packing=None):
     """-> dx0 [B,S,D]; OVERWRITES the tensors in block_grads / g_last_* with the parameter gradients."""
     _req(dU, torch.float32, "dU"); _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape")
     B, S, D = dU.shape
@@ -240,9 +253,10 @@ def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, 
     if ws is None:
         ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
     tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
+    order, nshort = packing if packing is not None else (None, None)
     lib.check(Lb.re_sasrec_encoder_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
                                        int(seed) & 0xFFFFFFFF, _p(tape), _p(dx0), tg, _p(g_last_w), _p(g_last_b), _p(ws),
-                                       ws.numel(), _stream()), "re_sasrec_encoder_bwd")
+                                       ws.numel(), _p(order), _p(nshort), _stream()), "re_sasrec_encoder_bwd")
     return dx0
 
 

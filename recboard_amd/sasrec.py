@@ -211,7 +211,7 @@ class SASRecEngine:
             sd = self._step_seed()
             x0 = ops.sasrec_embed(E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), p, sd)
             u, _ = ops.sasrec_encoder_fwd(x0, seq, self._block_tensors(), P["lastLN.weight"].detach(),
-                                          P["lastLN.bias"].detach(), self.L, p, sd)
+                                          P["lastLN.bias"].detach(), self.L, p, sd, packing=ops.seq_packing(seq))
             return u, E[1:]
         E = self.params["Item.embeddings.weight"]
         x = _EmbedFn.apply(E, self.params["Position.weight"], seq, float(self.D ** 0.5))
@@ -253,7 +253,7 @@ class SASRecEngine:
     def batch_aux_fused(seq, pos, neg):
         """As batch_aux, for the fused step: (valid uint8 [B*S], destination rows of all 3*B*S gradient contributions)."""
         v, rp, rn = SASRecEngine.batch_aux(seq, pos, neg)
-        return v, torch.cat([seq.reshape(-1), rp, rn])
+        return v, torch.cat([seq.reshape(-1), rp, rn]), ops.seq_packing(seq)
 
     def _buffers(self, B, S):
         key = (B, S)
@@ -278,7 +278,7 @@ class SASRecEngine:
         B, S = seq.shape
         if aux is None:
             aux = self.batch_aux_fused(seq, pos, neg)
-        valid, rows_all = aux
+        valid, rows_all, packing = aux
         W = self._buffers(B, S)
         G = A.views(A.grad)
         p = self.p_drop if self.training else 0.0
@@ -289,14 +289,14 @@ class SASRecEngine:
         kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
         n = B * S
         ops.sasrec_embed(E, Ppos, seq, float(D ** 0.5), p, sd, out=W["x0"])
-        ops.sasrec_encoder_fwd(W["x0"], seq, bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"])
+        ops.sasrec_encoder_fwd(W["x0"], seq, bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"], packing=packing)
         u2 = W["u"].view(n, D)
         posf, negf = pos.reshape(-1), neg.reshape(-1)
         loss, logits, count = ops.pair_loss_fwd(u2, E, posf, negf, valid, kind, e_off=1)
         C = W["contrib"]
         ops.pair_loss_bwd(u2, E, posf, negf, valid, kind, logits, count, None, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
         ops.sasrec_encoder_bwd(W["dU"].view(B, S, D), seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad),
-                               G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"])
+                               G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing)
         ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, G["Position.weight"], ws=W["ws_emb"])
         ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=G["Item.embeddings.weight"], ws=W["ws_sc"])
         if grad_hook is not None:
