@@ -191,6 +191,23 @@ int re_rows_sqnorm(const float* W, int64_t R, int64_t D, const int64_t* idx, int
                    int accumulate, void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * K9  DeepFM multi-field embedding bag (DeepFM/main.py:58-62, :80-85, :204-209).  The F per-field tables are ONE
+ * concatenated table T [rows_total, D] (+ LR vector TL [rows_total]); offsets[F] (device) = first row of each field.
+ *   fwd: E[b,f,:] = T[offsets[f] + x[b,f], :]  (written as [B, F*D], the MLP input)
+ *        fm_lr[b] = 0.5 * sum_d((sum_f E)^2 - sum_f E^2) + sum_f TL[...] + lr_bias[0]
+ *   bwd: gE[b,f,:] = dE_mlp[b,f,:] + dlogit[b] * (sum_f' E[b,f',:] - E[b,f,:]);  gL[b,f] = dlogit[b]
+ *        (contribution rows for re_scatter_add_rows with indices offsets[f] + x[b,f]; dE_mlp may be NULL)
+ * F <= 64, D <= 16 (the reference uses D = 10).
+ * re_bce_logits: loss[0] = mean BCE-with-logits (DeepFM/main.py:214), dlogit[i] = (sigmoid(x_i) - y_i) / n,
+ * dsum[0] (optional) = sum_i dlogit[i] (gradient of the LR bias).  labels are fp32 0/1. */
+int re_fm_bag_fwd(const float* T, const float* TL, const float* lr_bias, const int64_t* offsets, int64_t rows_total,
+                  const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, re_stream_t stream);
+int re_fm_bag_bwd(const float* E, const float* dE_mlp, const float* dlogit, int64_t B, int64_t F, int64_t D, float* gE,
+                  float* gL, re_stream_t stream);
+int re_bce_logits(const float* logits, const float* labels, int64_t n, float* loss, float* dlogit, float* dsum,
+                  re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * K10  dense Adam with coupled L2 (torch.optim.Adam semantics, eps 1e-8, no amsgrad), one launch over a flat
  * parameter arena.  Replaces `self.optimizer.step()` (SASRec/main.py:250; cfg dump
  * benchmark/Amazon2014Beauty_550_LOU/SASRec.json:254-300).  step is 1-based.  Hyper-parameters are doubles because

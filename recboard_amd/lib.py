@@ -39,6 +39,9 @@ SIGNATURES = {
     "re_rows_sqnorm_workspace_bytes": (_sz, []),
     "re_rows_sqnorm": (_i32, [_vp, _i64, _i64, _vp, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
     "re_rank_metrics": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "re_fm_bag_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "re_fm_bag_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "re_bce_logits": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "re_scale_copy": (_i32, [_vp, _vp, _f32, _i64, _vp]),
     "re_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _vp]),
 }

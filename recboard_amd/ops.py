@@ -319,3 +319,41 @@ def rank_metrics(topk_idx, tgt_ptr, tgt_idx, ks):
     lib.check(lib.load().re_rank_metrics(_p(topk_idx), B, Kmax, _p(tgt_ptr), _p(tgt_idx), arr, len(ks), _p(per_user), _p(sums),
                                          _stream()), "re_rank_metrics")
     return per_user, sums
+
+
+# ------------------------------------------------------------------------------------------------ K9
+def fm_bag_fwd(T, TL, lr_bias, offsets, x):
+    """-> (E [B, F*D], fm_lr [B])  (re_fm_bag_fwd)."""
+    _req(T, torch.float32, "T"); _req(TL, torch.float32, "TL"); _req(lr_bias, torch.float32, "lr_bias")
+    _req(offsets, torch.int64, "offsets"); _req(x, torch.int64, "x")
+    B, F = x.shape
+    D = T.shape[1]
+    E = torch.empty((B, F * D), dtype=torch.float32, device=T.device)
+    fm_lr = torch.empty((B,), dtype=torch.float32, device=T.device)
+    lib.check(lib.load().re_fm_bag_fwd(_p(T), _p(TL), _p(lr_bias), _p(offsets), T.shape[0], _p(x), B, F, D, _p(E), _p(fm_lr),
+                                       _stream()), "re_fm_bag_fwd")
+    return E, fm_lr
+
+
+def fm_bag_bwd(E, dE_mlp, dlogit, F, D):
+    """-> (gE [B*F, D], gL [B*F, 1]) contribution rows  (re_fm_bag_bwd)."""
+    _req(E, torch.float32, "E"); _req(dlogit, torch.float32, "dlogit")
+    if dE_mlp is not None:
+        _req(dE_mlp, torch.float32, "dE_mlp")
+    B = E.shape[0]
+    gE = torch.empty((B * F, D), dtype=torch.float32, device=E.device)
+    gL = torch.empty((B * F, 1), dtype=torch.float32, device=E.device)
+    lib.check(lib.load().re_fm_bag_bwd(_p(E), _p(dE_mlp), _p(dlogit), B, F, D, _p(gE), _p(gL), _stream()), "re_fm_bag_bwd")
+    return gE, gL
+
+
+def bce_logits(logits, labels):
+    """-> (loss [1], dlogit [n], dsum [1]): mean BCE-with-logits and its gradient (re_bce_logits)."""
+    _req(logits, torch.float32, "logits"); _req(labels, torch.float32, "labels")
+    n = logits.numel()
+    dev = logits.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dl = torch.empty(n, dtype=torch.float32, device=dev)
+    ds = torch.empty(1, dtype=torch.float32, device=dev)
+    lib.check(lib.load().re_bce_logits(_p(logits), _p(labels), n, _p(loss), _p(dl), _p(ds), _stream()), "re_bce_logits")
+    return loss, dl, ds

@@ -1,0 +1,81 @@
+"""GPU: DeepFM bag / FM / LR / BCE kernels and the DeepFM engine vs the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _engine(z):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from recboard_amd.deepfm import DeepFMEngine
+    counts = z["cfg/counts"].tolist()
+    m = DeepFMEngine(counts, 10, (32, 24, 16), batch_norm=True, hidden_dropout_rate=0.0, lr=1e-3)
+    for f, (t, tl) in enumerate(zip(m.tables(), m.tables_lr())):
+        t.copy_(dev(z[f"table/{f}"]))
+        tl.copy_(dev(z[f"table_lr/{f}"]))
+    m.bias.copy_(dev(z["param/fm.lr_layer.bias"]))
+    sd = {k[len("param/dnn."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/dnn.")}
+    m.dnn.load_state_dict(sd)
+    return m
+
+
+def test_fm_bag_and_bce_kernels_vs_oracle():
+    from oracle import criterions
+    z = np.load(os.path.join(G, "deepfm.npz"))
+    m = _engine(z)
+    from recboard_amd import ops
+    x = dev(z["in/x"])
+    E, fm_lr = ops.fm_bag_fwd(m.T, m.TL.reshape(-1), m.bias, m.offsets, x)
+    tabs = [torch.from_numpy(z[f"table/{f}"]) for f in range(10)]
+    tl = [torch.from_numpy(z[f"table_lr/{f}"]) for f in range(10)]
+    xc = torch.from_numpy(z["in/x"])
+    Er = torch.stack([tabs[f][xc[:, f]] for f in range(10)], 1)
+    np.testing.assert_array_equal(E.cpu().numpy(), Er.flatten(1).numpy())
+    fm = 0.5 * (Er.sum(1) ** 2 - (Er ** 2).sum(1)).sum(-1)
+    lr = torch.stack([tl[f][xc[:, f]] for f in range(10)], 1).sum(1).squeeze(-1) + torch.from_numpy(z["param/fm.lr_layer.bias"])
+    np.testing.assert_allclose(fm_lr.cpu().numpy(), (fm + lr).numpy(), rtol=1e-5, atol=1e-6)
+    logits = torch.randn(32)
+    labels = torch.from_numpy(z["in/labels"]).float().reshape(-1)
+    lg = logits.clone().requires_grad_(True)
+    ref = criterions.bce_with_logits(lg, labels)
+    ref.backward()
+    loss, dl, ds = ops.bce_logits(logits.cuda(), labels.cuda())
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-6)
+    np.testing.assert_allclose(dl.cpu().numpy(), lg.grad.numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(ds.item(), lg.grad.sum().item(), rtol=1e-4, atol=1e-7)
+
+
+def test_deepfm_engine_matches_reference_golden():
+    z = np.load(os.path.join(G, "deepfm.npz"))
+    m = _engine(z).train()
+    x, y = dev(z["in/x"]), dev(z["in/labels"])
+    logits, _, _ = m.encode(x)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), z["out/train_logits"], rtol=1e-4, atol=1e-5)
+    m2 = _engine(z).train()
+    loss = m2.forward_backward(x, y)
+    np.testing.assert_allclose(loss.item(), float(z["out/rec_loss"]), rtol=1e-5)
+    for f, (o, c) in enumerate(zip(m2.offsets.tolist(), m2.counts)):
+        np.testing.assert_allclose(m2.gT[o:o + c].cpu().numpy(), z[f"gtable/{f}"], rtol=1e-3, atol=2e-6)
+        np.testing.assert_allclose(m2.gTL[o:o + c].cpu().numpy(), z[f"gtable_lr/{f}"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(m2.gbias.cpu().numpy(), z["grad/fm.lr_layer.bias"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(m2.dnn[0].linear.weight.grad.cpu().numpy(), z["grad/dnn.0.linear.weight"], rtol=1e-3, atol=2e-6)
+    # eval pass: running stats as updated by the train-mode forward
+    m2.eval()
+    np.testing.assert_allclose(m2.recommend_from_pool(x).cpu().numpy(), z["out/eval_scores"], rtol=1e-4, atol=1e-6)
+
+
+def test_deepfm_train_step_runs_and_learns():
+    z = np.load(os.path.join(G, "deepfm.npz"))
+    m = _engine(z).train()
+    x, y = dev(z["in/x"]), dev(z["in/labels"])
+    losses = [m.train_step(x, y).item() for _ in range(40)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.05
