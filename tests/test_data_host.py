@@ -1,0 +1,56 @@
+"""CPU: host logic of the vectorised samplers / evaluator helpers (row contracts of the reference's datapipes)."""
+import numpy as np
+import torch
+
+from recboard_amd.data import EvalSampler, GenTrainSampler, SeqTrainSampler, SyntheticSeqDataset
+from recboard_amd.evaluate import parse_monitors, ragged_to_csr
+
+
+def test_seq_train_rows_follow_the_reference_contract():
+    ds = SyntheticSeqDataset(200, 60, mean_len=9, seed=2)
+    sp = SeqTrainSampler(ds, maxlen=50, batch_size=64, seed=1)
+    seen_users = []
+    for batch in sp:
+        for r in range(len(batch["User"])):
+            u = int(batch["User"][r])
+            tr = ds.train_seq(u)[-51:]
+            iseq, ipos, ineg = batch["ISeq"][r].numpy(), batch["IPos"][r].numpy(), batch["INeg"][r].numpy()
+            L = len(tr) - 1
+            assert (iseq[:50 - L] == 0).all() and (ipos[:50 - L] == 0).all() and (ineg[:50 - L] == 0).all()   # lpad_ with 0
+            np.testing.assert_array_equal(iseq[50 - L:], tr[:-1] + 1)       # seq[:-1], NUM_PADS offset on ISeq only
+            np.testing.assert_array_equal(ipos[50 - L:], tr[1:])            # seq[1:], 0-based
+            assert not set(ineg[50 - L:].tolist()) & set(ds.train_seq(u).tolist())   # negatives are unseen items
+            seen_users.append(u)
+    assert sorted(seen_users) == sorted(sp.users.tolist())                  # one row per user per epoch
+
+
+def test_gen_train_and_eval_rows():
+    ds = SyntheticSeqDataset(100, 80, mean_len=8, seed=4)
+    gp = GenTrainSampler(ds, 128, seed=1)
+    b = next(iter(gp))
+    assert b["User"].shape == (128, 1) and b["IPos"].shape == (128, 1) and b["INeg"].shape == (128, 1)
+    for u, p, n in zip(b["User"][:, 0].tolist(), b["IPos"][:, 0].tolist(), b["INeg"][:, 0].tolist()):
+        assert p in ds.train_seq(u) and n not in ds.train_seq(u)
+    assert len(gp) == (ds.num_train_interactions() + 127) // 128
+    ev = next(iter(EvalSampler(ds, 50, 32, "test")))
+    u = int(ev["User"][3])
+    assert ev["IUnseen"][3] == [int(ds.test_target(u))]
+    assert ev["ISeen"][3] == sorted(set(ds.seqs[u][:-1].tolist()))          # test: train + valid items are seen
+    assert int(ev["ISeq"][3, -1]) == int(ds.seqs[u][-2]) + 1                # last position is the most recent item
+
+
+def test_evaluator_helpers():
+    assert parse_monitors(["LOSS", "HitRate@10", "ndcg@5"]) == [("HITRATE", 10), ("NDCG", 5)]
+    ptr, idx = ragged_to_csr([[5, 1], [], [3]], "cpu")
+    assert ptr.tolist() == [0, 2, 2, 3] and idx.tolist() == [1, 5, 3]
+
+
+def test_seq_packing_host_semantics():
+    from recboard_amd.ops import seq_packing
+    seq = torch.zeros(5, 50, dtype=torch.long)
+    seq[0, -3:] = 7          # short
+    seq[1, -16:] = 7         # short (exactly the window)
+    seq[2, -17:] = 7         # long
+    seq[3, :] = 7            # long
+    order, nshort = seq_packing(seq)
+    assert int(nshort) == 3 and sorted(order[:3].tolist()) == [0, 1, 4] and sorted(order[3:].tolist()) == [2, 3]
