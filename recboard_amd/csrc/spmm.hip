@@ -8,9 +8,10 @@
 // Layout: one lane group (D/4 lanes x float4) per output row walks the row's non-zeros four at a time (independent
 // col/val loads, then four independent X-row loads); a row's 256-B X rows are full-line reads.  X (31.5 MB at Yelp
 // sizes) lives in the 256 MB Infinity Cache, so the stream that must come from HBM is (col, val) = 12 B per non-zero.
-// Power-law rows: rows longer than SP_LONG non-zeros are left to a second kernel that gives each one a whole
-// workgroup (16 lane groups, strided non-zeros, fixed-order LDS combine) -- the per-wave skew pitfall of
-// cdna_hip_programming.md Appendix B.  Summation order is fixed => bitwise reproducible.
+// Power-law rows: the caller passes the rows in descending-degree order (computed once per adjacency); the first
+// `nlong` of them (more than SP_LONG non-zeros) get a whole workgroup each (16 lane groups, strided non-zeros,
+// fixed-order LDS combine), the rest are walked in that order so the rows sharing a wave have similar lengths -- the
+// per-wave skew pitfall of cdna_hip_programming.md Appendix B.  Summation order is fixed => bitwise reproducible.
 //
 // Algorithmic bytes: per non-zero 12 B (+ a 4D-byte X row, cache-resident); per row 8 B crow + 4D B write
 // (+ 4D B for Z, + 8D B for ACC); 2D FLOP per non-zero.
@@ -62,7 +63,8 @@ __device__ __forceinline__ void spmm_store(float4 acc, int64_t r, int64_t D, int
 }
 
 template <int LPR>
-__global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
+__global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__ row_order, int64_t first,
+                                                     const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
                                                      const float* __restrict__ val, int64_t nrows, int64_t ncols,
                                                      const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                      const float* __restrict__ Z, float beta, float* __restrict__ ACC,
@@ -70,9 +72,11 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__
     const int lir = threadIdx.x % LPR;
     const int64_t gpb = 256 / LPR;
     const int64_t D4 = D >> 2;
-    for (int64_t r = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR; r < nrows; r += (int64_t)gridDim.x * gpb) {
+    // rows are visited in descending-degree order (row_order): the 4 (or 2) rows a wave works on have similar lengths,
+    // and the longest rows start first
+    for (int64_t i = first + (int64_t)blockIdx.x * gpb + threadIdx.x / LPR; i < nrows; i += (int64_t)gridDim.x * gpb) {
+        const int64_t r = row_order ? row_order[i] : i;
         const int64_t p0 = crow[r], p1 = crow[r + 1];
-        if (p1 - p0 > SP_LONG) continue;  // handled by spmm_csr_long
         for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
             const float4 acc = spmm_row_range<LPR>(col, val, X, ncols, D, c4, p0, p1, 1);
             spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
@@ -111,11 +115,11 @@ __global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__
 }
 
 extern "C" int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
-                           const int64_t* long_rows, int64_t nlong, const float* X, int64_t D, float* Y, const float* Z,
+                           const int64_t* row_order, int64_t nlong, const float* X, int64_t D, float* Y, const float* Z,
                            float beta, float* ACC, float acc_scale, re_stream_t stream) {
     re_clear_error();
     if (nrows == 0) return RE_OK;
-    if (!crow || !col || !val || !X || !Y || nrows < 0 || ncols <= 0 || D <= 0 || nlong < 0 || (nlong > 0 && !long_rows))
+    if (!crow || !col || !val || !X || !Y || nrows < 0 || ncols <= 0 || D <= 0 || nlong < 0 || nlong > nrows || (nlong > 0 && !row_order))
         return RE_EINVAL;
     if ((D & 3) || ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Z) |
                      reinterpret_cast<uintptr_t>(ACC)) & 15u))
@@ -123,11 +127,11 @@ extern "C" int re_spmm_csr(const int64_t* crow, const int64_t* col, const float*
     if (X == Y) return RE_EINVAL;  // not in place
     hipStream_t s = (hipStream_t)stream;
     if ((D >> 2) >= 32) {
-        hipLaunchKernelGGL(spmm_csr_rows<32>, dim3(re_grid(nrows, 8, 65536)), dim3(256), 0, s, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
-        if (nlong) hipLaunchKernelGGL(spmm_csr_long<32>, dim3(re_grid(nlong, 1, 4096)), dim3(256), 0, s, long_rows, nlong, crow, col, val, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+        hipLaunchKernelGGL(spmm_csr_rows<32>, dim3(re_grid(nrows - nlong, 8, 65536)), dim3(256), 0, s, row_order, nlong, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+        if (nlong) hipLaunchKernelGGL(spmm_csr_long<32>, dim3(re_grid(nlong, 1, 4096)), dim3(256), 0, s, row_order, nlong, crow, col, val, ncols, X, D, Y, Z, beta, ACC, acc_scale);
     } else {
-        hipLaunchKernelGGL(spmm_csr_rows<16>, dim3(re_grid(nrows, 16, 65536)), dim3(256), 0, s, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
-        if (nlong) hipLaunchKernelGGL(spmm_csr_long<16>, dim3(re_grid(nlong, 1, 4096)), dim3(256), 0, s, long_rows, nlong, crow, col, val, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+        hipLaunchKernelGGL(spmm_csr_rows<16>, dim3(re_grid(nrows - nlong, 16, 65536)), dim3(256), 0, s, row_order, nlong, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+        if (nlong) hipLaunchKernelGGL(spmm_csr_long<16>, dim3(re_grid(nlong, 1, 4096)), dim3(256), 0, s, row_order, nlong, crow, col, val, ncols, X, D, Y, Z, beta, ACC, acc_scale);
     }
     return re_launch_status();
 }

@@ -88,7 +88,7 @@ class LightGCNEngine(MFEngine):
         self.crow = torch.as_tensor(adj_crow, dtype=torch.int64).to(dev).contiguous()
         self.col = torch.as_tensor(adj_col, dtype=torch.int64).to(dev).contiguous()
         self.val = torch.as_tensor(adj_val, dtype=torch.float32).to(dev).contiguous()
-        self.long_rows = ops.spmm_plan(self.crow)
+        self.plan = ops.spmm_plan(self.crow)
         n = num_users + num_items
         assert self.crow.numel() == n + 1
         self.n = n
@@ -98,7 +98,7 @@ class LightGCNEngine(MFEngine):
         self.emb = torch.zeros(1, dtype=torch.float32, device=dev)
 
     def _spmm(self, X, out, **kw):
-        return ops.spmm_csr(self.crow, self.col, self.val, self.long_rows, X, out, **kw)
+        return ops.spmm_csr(self.crow, self.col, self.val, self.plan, X, out, **kw)
 
     def encode(self):
         """-> (userEmbds, itemEmbds) after propagation.  LightGCN/main.py:77-86."""

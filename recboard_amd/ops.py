@@ -262,19 +262,22 @@ def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, 
 
 # ------------------------------------------------------------------------------------------------ K8
 def spmm_plan(crow: torch.Tensor, threshold: int = 512):
-    """Row ids with more than `threshold` non-zeros (once per adjacency; the only host-visible preprocessing)."""
+    """-> (row_order int64[nrows] by descending degree, nlong = #rows with more than `threshold` non-zeros).
+    Once per adjacency; the only host-visible preprocessing."""
     deg = crow[1:] - crow[:-1]
-    return torch.nonzero(deg > threshold).reshape(-1).contiguous()
+    order = torch.argsort(deg, descending=True, stable=True).contiguous()
+    return order, int((deg > threshold).sum())
 
 
-def spmm_csr(crow, col, val, long_rows, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0):
-    """out = A @ X (+ beta * Z); acc += acc_scale * out  (re_spmm_csr)."""
-    for t, nme in ((crow, "crow"), (col, "col"), (long_rows, "long_rows")):
+def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0):
+    """out = A @ X (+ beta * Z); acc += acc_scale * out  (re_spmm_csr).  plan = spmm_plan(crow)."""
+    row_order, nlong = plan
+    for t, nme in ((crow, "crow"), (col, "col"), (row_order, "row_order")):
         _req(t, torch.int64, nme)
     for t, nme in ((val, "val"), (X, "X"), (out, "out")):
         _req(t, torch.float32, nme)
     nrows = crow.numel() - 1
-    lib.check(lib.load().re_spmm_csr(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(long_rows), long_rows.numel(), _p(X),
+    lib.check(lib.load().re_spmm_csr(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(row_order), int(nlong), _p(X),
                                      X.shape[1], _p(out), _p(Z), float(beta), _p(acc), float(acc_scale), _stream()),
               "re_spmm_csr")
     return out
