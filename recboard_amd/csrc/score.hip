@@ -32,13 +32,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SC_USERS 128   // users per workgroup (4 waves x 32)
 #define SC_TI 64       // items per LDS stage (2 MFMA tiles)
 #define SC_MAX_WGS 512 // 2 per CU on MI355X
+#define SC_MIN_SEG 1   // stages (of SC_TI items) per segment, at least (A/B in scripts/tune_score.py: larger is slower)
 
 __device__ __forceinline__ bool sc_before(float va, int ia, float vb, int ib) {  // a ranks before b
     return va > vb || (va == vb && ia < ib);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int D, bool TOPK>
+template <int D, bool TOPK, int POPMODE>   // POPMODE 0: per register, 1: per-lane pop, 2: per tile by hit density
 __global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__ Q, const float* __restrict__ E,
                                                        int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
                                                        const int64_t* __restrict__ seen_idx, int K,
@@ -166,14 +167,34 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__
                 for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
                 if (__ballot(m != 0) == 0ull) continue;
 
-                // ---- slow path: heap inserts (rare once the heap is warm)
+                // ---- slow path: heap inserts.
+                // POP: every lane pops ITS OWN lowest pending hit per iteration (loop count = max over lanes of
+                // popcount(m)); !POP: register after register (loop count = #registers with any hit in the wave).
+                if (user >= B) m = 0;
+                // few lanes with hits (warm lists): walking the registers is cheapest; many (cold lists, iid scores): pop
+                const bool POP = POPMODE == 1 || (POPMODE == 2 && __popcll(__ballot(m != 0)) >= 12);
 #pragma unroll 1
-                for (int r = 0; r < 16; ++r) {
-                    bool hit = (m >> r) & 1u;
-                    if (__ballot(hit) == 0ull) continue;
-                    const float v = acc[r];
+                for (int rr = 0; POP ? (__ballot(m != 0) != 0ull) : (rr < 16); ++rr) {
+                    bool hit;
+                    int r;
+                    float v;
+                    if (POP) {
+                        hit = m != 0;
+                        r = hit ? (__ffs(m) - 1) : 0;
+                        m &= m - 1;
+                        v = acc[0];
+#pragma unroll
+                        for (int q = 1; q < 16; ++q) v = (r == q) ? acc[q] : v;
+                    } else {
+                        r = rr;
+                        hit = (m >> r) & 1u;
+                        if (__ballot(hit) == 0ull) continue;
+                        v = acc[r];
+                    }
                     const int item = (int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    hit = hit && item < N && user < B;
+                    // `>=`: thr may have been raised inside this tile by the partner lane with a HIGHER item id; the
+                    // insert below applies the full (value, lowest-index) rule
+                    hit = hit && item < N && v >= thr;
                     if (hit && item >= next_seen) {  // advance the seen cursor to lower_bound(item)
                         int64_t lo = sc_cur, hi2 = sc_end;
                         while (lo < hi2) {
@@ -226,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                     }
+                    if (POP) thr = (cnt[ul] >= K) ? hv[ul] : -INFINITY;   // later pops of this tile see the tightened threshold
                 }
                 thr = (cnt[ul] >= K) ? hv[ul] : -INFINITY;
             }
@@ -323,6 +345,10 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------
+static int g_score_pop = 2;      // tuning switches (scripts/tune_score.py); not part of the ABI
+static int64_t g_score_minseg = SC_MIN_SEG;
+extern "C" void re_dbg_score_variant(int pop, int64_t minseg) { g_score_pop = pop; g_score_minseg = minseg; }
+
 struct ScorePlan {
     int64_t nub, nst, units, upw;
     int nwg, maxseg;
@@ -333,9 +359,14 @@ static ScorePlan score_plan(int64_t B, int64_t N) {
     p.nub = re_cdiv(B, SC_USERS);
     p.nst = re_cdiv(N, SC_TI);
     p.units = p.nub * p.nst;
-    int64_t nwg = p.units < SC_MAX_WGS ? p.units : SC_MAX_WGS;
-    if (nwg < 1) nwg = 1;
-    p.upw = re_cdiv(p.units, nwg);
+    // Equal unit ranges per workgroup, at most 2 workgroups per CU -- but never fewer than SC_MIN_SEG stages per
+    // segment: every segment re-warms its users' top-K lists (~K(1+ln(T/K)) heap inserts for T items), so slicing a
+    // small catalog over all CUs costs more in warm-ups and list merging than it gains (B=512 x N=12101: 0.58 -> see
+    // scripts/tune_score.py).
+    int64_t upw = re_cdiv(p.units, SC_MAX_WGS);
+    const int64_t min_seg = p.nst < g_score_minseg ? p.nst : g_score_minseg;
+    if (upw < min_seg) upw = min_seg;
+    p.upw = upw;
     p.nwg = (int)re_cdiv(p.units, p.upw);
     p.maxseg = (int)(re_cdiv(p.nst, p.upw) + 1);
     return p;
@@ -354,11 +385,11 @@ extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D,
     return re_align((size_t)p.nub * SC_USERS * p.maxseg * K * 4) * 2 + 256;
 }
 
-template <int D, bool TOPK>
+template <int D, bool TOPK, int POP>
 static int score_launch(const float* Q, const float* E, int64_t B, int64_t N, const int64_t* seen_ptr, const int64_t* seen_idx,
                         int K, float* pv, int* pi, const ScorePlan& p, float* dense_out, hipStream_t s) {
     const size_t lds = score_lds_bytes(D, K, TOPK);
-    auto kern = score_kernel<D, TOPK>;
+    auto kern = score_kernel<D, TOPK, POP>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RE_ELAUNCH;
     }
@@ -370,9 +401,12 @@ template <bool TOPK>
 static int score_dispatch(int64_t D, const float* Q, const float* E, int64_t B, int64_t N, const int64_t* seen_ptr,
                           const int64_t* seen_idx, int K, float* pv, int* pi, const ScorePlan& p, float* dense_out, hipStream_t s) {
     switch (D) {
-        case 32: return score_launch<32, TOPK>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
-        case 64: return score_launch<64, TOPK>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
-        case 128: return score_launch<128, TOPK>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
+        case 32: return score_launch<32, TOPK, 2>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
+        case 64:
+            if (TOPK && g_score_pop == 0) return score_launch<64, TOPK, 0>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
+            if (TOPK && g_score_pop == 1) return score_launch<64, TOPK, 1>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
+            return score_launch<64, TOPK, 2>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
+        case 128: return score_launch<128, TOPK, 2>(Q, E, B, N, seen_ptr, seen_idx, K, pv, pi, p, dense_out, s);
         default: return RE_EUNSUPPORTED;
     }
 }

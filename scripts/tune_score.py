@@ -1,0 +1,34 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recboard_amd import ops, lib
+import ctypes
+L = lib.load(); L.re_dbg_score_variant.argtypes = [ctypes.c_int, ctypes.c_int64]; L.re_dbg_score_variant.restype = None
+U, N, D = 22363, 12101, 64
+g = torch.Generator(device="cuda").manual_seed(1)
+q = torch.randn(U, D, device="cuda", generator=g); E = torch.randn(N, D, device="cuda", generator=g)
+sp = torch.arange(0, U + 1, device="cuda") * 8
+si = torch.sort(torch.randint(0, N, (U, 8), device="cuda", generator=g), 1).values.reshape(-1)
+def t(fn, it=10):
+    for _ in range(2): fn()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True); e0.record()
+    for _ in range(it): fn()
+    e1.record(); e1.synchronize(); return e0.elapsed_time(e1) / it
+
+import bench
+from recboard_amd.sasrec import SASRecEngine
+cfg = bench.BEAUTY
+model = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5).eval()
+import numpy as np
+eval_seq = torch.from_numpy(np.concatenate([b[0] for b in bench.synth_batches(cfg, 44, 99)])[:U]).cuda()
+with torch.no_grad():
+    q2 = torch.cat([model.encode(eval_seq[i:i + 512])[0][:, -1, :] for i in range(0, U, 512)]).contiguous()
+E2 = model.params["Item.embeddings.weight"].detach()[1:]
+for rnd in range(2):
+    for name, (qq, EE) in {"random-normal": (q, E), "bench (LN-encoded q, xavier E)": (q2, E2)}.items():
+        for pop in (0, 1, 2):
+            for minseg in (1,):
+                L.re_dbg_score_variant(pop, minseg)
+                ms = t(lambda: ops.score_topk(qq, EE, sp, si, 50))
+                ms5 = t(lambda: ops.score_topk(qq[:512], EE, sp[:513], si, 50))
+                print(f"{name:32s} pop={pop} minseg={minseg:2d}: full {ms:.3f} ms ({2*D*U*N/ms/1e9:.1f} TF)   B=512: {ms5:.3f} ms")
