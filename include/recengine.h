@@ -179,14 +179,17 @@ int re_rank_metrics(const int64_t* topk_idx, int64_t B, int64_t Kmax, const int6
  * K8  CSR SpMM for LightGCN propagation:  Y = A X (+ beta Z);  if ACC: ACC += acc_scale * Y.
  * Replaces `self.Adj @ allEmbds` + `avgEmbds += allEmbds / (L+1)` (LightGCN/main.py:81-84) and, Adj being symmetric,
  * the transposed product of the backward pass.  crow int64[nrows+1], col int64[nnz], val f32[nnz]; X [ncols, D],
- * Y/Z/ACC [nrows, D]; Y must not alias X.  row_order[nrows] = row ids in descending-degree order (computed once per
- * adjacency; NULL = natural order, then nlong must be 0); its first nlong rows (more than 512 non-zeros) get a
- * workgroup each.  Fixed summation order => bitwise reproducible.
+ * Y/Z/ACC [nrows, D]; Y must not alias X.  Plan (computed once per adjacency, all device arrays): row_order[nrows] =
+ * row ids in descending-degree order (NULL = natural order, then nlong must be 0); its first nlong rows (more than 512
+ * non-zeros) are cut into chunks of 2048 non-zeros: chunk_ptr[nlong+1] = first chunk of each long row,
+ * chunk_row[nchunks] = index (into row_order) of the row a chunk belongs to; ws >= nchunks*D*4 bytes holds the chunk
+ * partials.  Fixed summation order => bitwise reproducible.
  * re_rows_sqnorm: out[0] (+)= scale * sum_i ||W[idx[i],:]||^2  -- `criterion.regularize(rows, "l2")`
  * (LightGCN/main.py:99-106) with scale = 1/2 / B. */
 int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
-                const int64_t* row_order, int64_t nlong, const float* X, int64_t D, float* Y, const float* Z,
-                float beta, float* ACC, float acc_scale, re_stream_t stream);
+                const int64_t* row_order, int64_t nlong, const int32_t* chunk_row, const int64_t* chunk_ptr,
+                int64_t nchunks, const float* X, int64_t D, float* Y, const float* Z, float beta, float* ACC,
+                float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream);
 size_t re_rows_sqnorm_workspace_bytes(void);
 int re_rows_sqnorm(const float* W, int64_t R, int64_t D, const int64_t* idx, int64_t n, float scale, float* out,
                    int accumulate, void* ws, size_t ws_bytes, re_stream_t stream);

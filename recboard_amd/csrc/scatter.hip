@@ -132,12 +132,18 @@ __global__ __launch_bounds__(64) void radix_scatter(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ segmented sum
+// column vectors: float4 (D % 4 == 0, 16-B aligned buffers) or float (any D: DeepFM's D = 10 and D = 1 tables)
 __device__ __forceinline__ void f4_fma(float4& a, const float4& x, float s) {
     a.x = fmaf(x.x, s, a.x); a.y = fmaf(x.y, s, a.y); a.z = fmaf(x.z, s, a.z); a.w = fmaf(x.w, s, a.w);
 }
+__device__ __forceinline__ void f4_fma(float& a, const float& x, float s) { a = fmaf(x, s, a); }
 __device__ __forceinline__ void f4_add(float4& a, const float4& x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
+__device__ __forceinline__ void f4_add(float& a, const float& x) { a += x; }
+template <class V> __device__ __forceinline__ V vzero();
+template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ float vzero<float>() { return 0.f; }
 
-template <int LPR>
+template <int LPR, class V>
 __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                   const float* __restrict__ g, int64_t n, int64_t D, int64_t R,
                                                   float scale, float* __restrict__ dW, float* __restrict__ partial,
@@ -150,21 +156,21 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
     const uint32_t NONE = 0xFFFFFFFFu, DROP = (uint32_t)R;
     const uint32_t prevKey = begin > 0 ? keys[begin - 1] : NONE;
     const uint32_t nextKey = end < n ? keys[end] : NONE;
-    const int64_t D4 = D >> 2;
+    const int64_t D4 = D / (int64_t)(sizeof(V) / sizeof(float));
     uint32_t flags = 0;
     for (int64_t col = lir; col < D4; col += LPR) {
         uint32_t curKey = keys[begin];
         bool isHead = true;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        V acc = vzero<V>();
         for (int64_t j0 = begin; j0 < end; j0 += 8) {
             uint32_t k[8];
-            float4 row[8];
+            V row[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int64_t j = j0 + u;
                 k[u] = j < end ? keys[j] : NONE;
-                row[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j < end && k[u] != DROP) row[u] = reinterpret_cast<const float4*>(g + (int64_t)vals[j] * D)[col];
+                row[u] = vzero<V>();
+                if (j < end && k[u] != DROP) row[u] = reinterpret_cast<const V*>(g + (int64_t)vals[j] * D)[col];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -173,17 +179,17 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
                     // flush a run that ended strictly inside the chunk (cannot be the tail)
                     if (curKey != DROP) {
                         if (isHead && curKey == prevKey) {
-                            reinterpret_cast<float4*>(partial + (c * 2 + 0) * D)[col] = acc;
+                            reinterpret_cast<V*>(partial + (c * 2 + 0) * D)[col] = acc;
                             flags |= RE_FLAG_SLOT0;
                         } else {
-                            float4* d = reinterpret_cast<float4*>(dW + (int64_t)curKey * D) + col;
+                            V* d = reinterpret_cast<V*>(dW + (int64_t)curKey * D) + col;
                             if (accumulate) f4_add(acc, *d);
                             *d = acc;
                         }
                     }
                     curKey = k[u];
                     isHead = false;
-                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc = vzero<V>();
                 }
                 f4_fma(acc, row[u], scale);
             }
@@ -193,13 +199,13 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
             const bool headOpen = isHead && curKey == prevKey;
             const bool tailOpen = curKey == nextKey;
             if (headOpen) {
-                reinterpret_cast<float4*>(partial + (c * 2 + 0) * D)[col] = acc;
+                reinterpret_cast<V*>(partial + (c * 2 + 0) * D)[col] = acc;
                 flags |= RE_FLAG_SLOT0 | (tailOpen ? RE_FLAG_CONT : 0u);
             } else if (tailOpen) {
-                reinterpret_cast<float4*>(partial + (c * 2 + 1) * D)[col] = acc;
+                reinterpret_cast<V*>(partial + (c * 2 + 1) * D)[col] = acc;
                 flags |= RE_FLAG_SLOT1;
             } else {
-                float4* d = reinterpret_cast<float4*>(dW + (int64_t)curKey * D) + col;
+                V* d = reinterpret_cast<V*>(dW + (int64_t)curKey * D) + col;
                 if (accumulate) f4_add(acc, *d);
                 *d = acc;
             }
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
 }
 
 // one lane group per chunk in which a boundary-crossing run STARTS: add the following chunks' slot-0 partials in order
-template <int LPR>
+template <int LPR, class V>
 __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ keys, int64_t n, int64_t D,
                                                  float* __restrict__ dW, const float* __restrict__ partial,
                                                  const uint32_t* __restrict__ pflags, int64_t nchunks, int accumulate) {
@@ -219,35 +225,18 @@ __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ ke
     if (!(pflags[c] & RE_FLAG_SLOT1)) return;
     const int64_t end = (c * RE_SEG_CHUNK + RE_SEG_CHUNK < n) ? c * RE_SEG_CHUNK + RE_SEG_CHUNK : n;
     const uint32_t key = keys[end - 1];
-    const int64_t D4 = D >> 2;
+    const int64_t D4 = D / (int64_t)(sizeof(V) / sizeof(float));
     for (int64_t col = lir; col < D4; col += LPR) {
-        float4 acc = reinterpret_cast<const float4*>(partial + (c * 2 + 1) * D)[col];
+        V acc = reinterpret_cast<const V*>(partial + (c * 2 + 1) * D)[col];
         for (int64_t cc = c + 1; cc < nchunks; ++cc) {
             const uint32_t f = pflags[cc];
             if (!(f & RE_FLAG_SLOT0)) break;  // cannot happen for a well-formed chain; keeps the loop bounded
-            f4_add(acc, reinterpret_cast<const float4*>(partial + (cc * 2 + 0) * D)[col]);
+            f4_add(acc, reinterpret_cast<const V*>(partial + (cc * 2 + 0) * D)[col]);
             if (!(f & RE_FLAG_CONT)) break;
         }
-        float4* d = reinterpret_cast<float4*>(dW + (int64_t)key * D) + col;
+        V* d = reinterpret_cast<V*>(dW + (int64_t)key * D) + col;
         if (accumulate) f4_add(acc, *d);
         *d = acc;
-    }
-}
-
-// scalar-D fallback (D % 4 != 0: DeepFM D=10 / D=1): one thread per (distinct-run, column) walks its run
-__global__ __launch_bounds__(256) void seg_reduce_scalar(const uint32_t* __restrict__ keys,
-                                                         const uint32_t* __restrict__ vals,
-                                                         const float* __restrict__ g, int64_t n, int64_t D, int64_t R,
-                                                         float scale, float* __restrict__ dW, int accumulate) {
-    const int64_t total = n * D;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t j = e / D, d = e - j * D;
-        const uint32_t k = keys[j];
-        if (k == (uint32_t)R) continue;
-        if (j > 0 && keys[j - 1] == k) continue;  // not the first entry of its run
-        float acc = 0.f;
-        for (int64_t t = j; t < n && keys[t] == k; ++t) acc = fmaf(g[(int64_t)vals[t] * D + d], scale, acc);
-        dW[(int64_t)k * D + d] = (accumulate ? dW[(int64_t)k * D + d] : 0.f) + acc;
     }
 }
 
@@ -309,23 +298,22 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
         t = vi; vi = vo; vo = t;
     }
     const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u) == 0;
-    if (!vec) {
-        hipLaunchKernelGGL(seg_reduce_scalar, dim3(re_grid(n * D, 256)), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, accumulate);
-        return re_launch_status();
+#define SEG_LAUNCH(LPRV, VT)                                                                                                       \
+    do {                                                                                                                           \
+        const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / LPRV);                                                            \
+        hipLaunchKernelGGL((seg_reduce<LPRV, VT>), dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks, accumulate); \
+        hipLaunchKernelGGL((seg_fixup<LPRV, VT>), dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks, accumulate); \
+    } while (0)
+    if (vec) {
+        const int64_t D4 = D >> 2;
+        if (D4 >= 32) SEG_LAUNCH(32, float4);
+        else if (D4 >= 16) SEG_LAUNCH(16, float4);
+        else SEG_LAUNCH(4, float4);
+    } else {  // one lane per column (DeepFM: D = 10 -> 16 lanes, 10 active; D = 1 -> 4 lanes), same chunked algorithm
+        if (D > 16) SEG_LAUNCH(32, float);
+        else if (D > 4) SEG_LAUNCH(16, float);
+        else SEG_LAUNCH(4, float);
     }
-    const int64_t D4 = D >> 2;
-    if (D4 >= 32) {
-        const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 32);
-        hipLaunchKernelGGL(seg_reduce<32>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks, accumulate);
-        hipLaunchKernelGGL(seg_fixup<32>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks, accumulate);
-    } else if (D4 >= 16) {
-        const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 16);
-        hipLaunchKernelGGL(seg_reduce<16>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks, accumulate);
-        hipLaunchKernelGGL(seg_fixup<16>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks, accumulate);
-    } else {
-        const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / 4);
-        hipLaunchKernelGGL(seg_reduce<4>, dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks, accumulate);
-        hipLaunchKernelGGL(seg_fixup<4>, dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks, accumulate);
-    }
+#undef SEG_LAUNCH
     return re_launch_status();
 }

@@ -84,20 +84,26 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__
     }
 }
 
-// one workgroup per long row: lane group j takes non-zeros p0 + j, p0 + j + G, ...; partials combined in group order
+// long rows: one workgroup per CHUNK of SP_CHUNK non-zeros (a popular item can have tens of thousands of non-zeros: one
+// workgroup per row would be the tail of the whole launch).  Lane group j takes non-zeros p0 + j, p0 + j + G, ...; the 16
+// group partials are combined in group order -> one partial row per chunk; spmm_csr_long_combine then adds a row's chunk
+// partials in chunk order and applies the epilogue.  Fixed order everywhere => bitwise reproducible.
+#define SP_CHUNK 2048
 template <int LPR>
-__global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__ long_rows, int64_t nlong,
+__global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__ row_order, const int32_t* __restrict__ chunk_row,
+                                                     const int64_t* __restrict__ chunk_ptr, int64_t nchunks,
                                                      const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
                                                      const float* __restrict__ val, int64_t ncols, const float* __restrict__ X,
-                                                     int64_t D, float* __restrict__ Y, const float* __restrict__ Z, float beta,
-                                                     float* __restrict__ ACC, float acc_scale) {
+                                                     int64_t D, float* __restrict__ partial) {
     __shared__ float4 part[256];
     const int lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     constexpr int G = 256 / LPR;
     const int64_t D4 = D >> 2;
-    for (int64_t i = blockIdx.x; i < nlong; i += gridDim.x) {
-        const int64_t r = long_rows[i];
-        const int64_t p0 = crow[r], p1 = crow[r + 1];
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const int li = chunk_row[ch];
+        const int64_t r = row_order[li];
+        const int64_t p0 = crow[r] + (ch - chunk_ptr[li]) * SP_CHUNK;
+        const int64_t p1 = (p0 + SP_CHUNK < crow[r + 1]) ? p0 + SP_CHUNK : crow[r + 1];
         for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
             part[threadIdx.x] = spmm_row_range<LPR>(col, val, X, ncols, D, c4, p0 + grp, p1, G);
             __syncthreads();
@@ -107,32 +113,56 @@ __global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__
                     const float4 q = part[j * LPR + lir];
                     acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
                 }
-                spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
+                reinterpret_cast<float4*>(partial + ch * D)[c4] = acc;
             }
             __syncthreads();
         }
     }
 }
 
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_csr_long_combine(const int64_t* __restrict__ row_order, int64_t nlong,
+                                                             const int64_t* __restrict__ chunk_ptr, const float* __restrict__ partial,
+                                                             int64_t D, float* __restrict__ Y, const float* __restrict__ Z, float beta,
+                                                             float* __restrict__ ACC, float acc_scale) {
+    const int lir = threadIdx.x % LPR;
+    const int64_t li = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (li >= nlong) return;
+    const int64_t r = row_order[li];
+    const int64_t D4 = D >> 2;
+    for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t ch = chunk_ptr[li]; ch < chunk_ptr[li + 1]; ++ch) {
+            const float4 q = reinterpret_cast<const float4*>(partial + ch * D)[c4];
+            acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+        }
+        spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
+    }
+}
+
 extern "C" int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
-                           const int64_t* row_order, int64_t nlong, const float* X, int64_t D, float* Y, const float* Z,
-                           float beta, float* ACC, float acc_scale, re_stream_t stream) {
+                           const int64_t* row_order, int64_t nlong, const int32_t* chunk_row, const int64_t* chunk_ptr,
+                           int64_t nchunks, const float* X, int64_t D, float* Y, const float* Z, float beta, float* ACC,
+                           float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream) {
     re_clear_error();
     if (nrows == 0) return RE_OK;
-    if (!crow || !col || !val || !X || !Y || nrows < 0 || ncols <= 0 || D <= 0 || nlong < 0 || nlong > nrows || (nlong > 0 && !row_order))
-        return RE_EINVAL;
+    if (!crow || !col || !val || !X || !Y || nrows < 0 || ncols <= 0 || D <= 0 || nlong < 0 || nlong > nrows) return RE_EINVAL;
+    if (nlong > 0 && (!row_order || !chunk_row || !chunk_ptr || nchunks < nlong || !ws)) return RE_EINVAL;
+    if (nlong > 0 && ws_bytes < (size_t)nchunks * D * sizeof(float)) return RE_EWORKSPACE;
     if ((D & 3) || ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Z) |
-                     reinterpret_cast<uintptr_t>(ACC)) & 15u))
+                     reinterpret_cast<uintptr_t>(ACC) | reinterpret_cast<uintptr_t>(ws)) & 15u))
         return RE_EUNSUPPORTED;
     if (X == Y) return RE_EINVAL;  // not in place
     hipStream_t s = (hipStream_t)stream;
-    if ((D >> 2) >= 32) {
-        hipLaunchKernelGGL(spmm_csr_rows<32>, dim3(re_grid(nrows - nlong, 8, 65536)), dim3(256), 0, s, row_order, nlong, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
-        if (nlong) hipLaunchKernelGGL(spmm_csr_long<32>, dim3(re_grid(nlong, 1, 4096)), dim3(256), 0, s, row_order, nlong, crow, col, val, ncols, X, D, Y, Z, beta, ACC, acc_scale);
-    } else {
-        hipLaunchKernelGGL(spmm_csr_rows<16>, dim3(re_grid(nrows - nlong, 16, 65536)), dim3(256), 0, s, row_order, nlong, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
-        if (nlong) hipLaunchKernelGGL(spmm_csr_long<16>, dim3(re_grid(nlong, 1, 4096)), dim3(256), 0, s, row_order, nlong, crow, col, val, ncols, X, D, Y, Z, beta, ACC, acc_scale);
-    }
+    float* partial = (float*)ws;
+#define SP_LAUNCH(LPRV)                                                                                                             \
+    do {                                                                                                                            \
+        if (nlong) hipLaunchKernelGGL(spmm_csr_long<LPRV>, dim3(re_grid(nchunks, 1, 65536)), dim3(256), 0, s, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial); \
+        if (nrows > nlong) hipLaunchKernelGGL(spmm_csr_rows<LPRV>, dim3(re_grid(nrows - nlong, 256 / LPRV, 65536)), dim3(256), 0, s, row_order, nlong, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
+        if (nlong) hipLaunchKernelGGL(spmm_csr_long_combine<LPRV>, dim3((unsigned)re_cdiv(nlong, 256 / LPRV)), dim3(256), 0, s, row_order, nlong, chunk_ptr, partial, D, Y, Z, beta, ACC, acc_scale); \
+    } while (0)
+    if ((D >> 2) >= 32) SP_LAUNCH(32); else SP_LAUNCH(16);
+#undef SP_LAUNCH
     return re_launch_status();
 }
 

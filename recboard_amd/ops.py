@@ -261,25 +261,43 @@ def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, 
 
 
 # ------------------------------------------------------------------------------------------------ K8
-def spmm_plan(crow: torch.Tensor, threshold: int = 512):
-    """-> (row_order int64[nrows] by descending degree, nlong = #rows with more than `threshold` non-zeros).
-    Once per adjacency; the only host-visible preprocessing."""
-    deg = crow[1:] - crow[:-1]
-    order = torch.argsort(deg, descending=True, stable=True).contiguous()
-    return order, int((deg > threshold).sum())
+SPMM_LONG, SPMM_CHUNK = 512, 2048
+
+
+class SpmmPlan:
+    """Once per adjacency (the only host-visible preprocessing): rows in descending-degree order; the rows with more than
+    SPMM_LONG non-zeros are cut into chunks of SPMM_CHUNK non-zeros that get a workgroup each."""
+
+    def __init__(self, crow: torch.Tensor, D: int):
+        deg = crow[1:] - crow[:-1]
+        self.row_order = torch.argsort(deg, descending=True, stable=True).contiguous()
+        self.nlong = int((deg > SPMM_LONG).sum())
+        ldeg = deg[self.row_order[: self.nlong]]
+        nch = (ldeg + SPMM_CHUNK - 1) // SPMM_CHUNK
+        self.chunk_ptr = torch.zeros(self.nlong + 1, dtype=torch.int64, device=crow.device)
+        self.chunk_ptr[1:] = torch.cumsum(nch, 0)
+        self.nchunks = int(self.chunk_ptr[-1]) if self.nlong else 0
+        self.chunk_row = torch.repeat_interleave(torch.arange(self.nlong, device=crow.device, dtype=torch.int32), nch).contiguous()
+        self.ws = torch.empty(max(self.nchunks * D, 4), dtype=torch.float32, device=crow.device)
+
+
+def spmm_plan(crow: torch.Tensor, D: int = 64):
+    return SpmmPlan(crow, D)
 
 
 def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0):
-    """out = A @ X (+ beta * Z); acc += acc_scale * out  (re_spmm_csr).  plan = spmm_plan(crow)."""
-    row_order, nlong = plan
-    for t, nme in ((crow, "crow"), (col, "col"), (row_order, "row_order")):
+    """out = A @ X (+ beta * Z); acc += acc_scale * out  (re_spmm_csr).  plan = spmm_plan(crow, D)."""
+    for t, nme in ((crow, "crow"), (col, "col")):
         _req(t, torch.int64, nme)
     for t, nme in ((val, "val"), (X, "X"), (out, "out")):
         _req(t, torch.float32, nme)
     nrows = crow.numel() - 1
-    lib.check(lib.load().re_spmm_csr(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(row_order), int(nlong), _p(X),
-                                     X.shape[1], _p(out), _p(Z), float(beta), _p(acc), float(acc_scale), _stream()),
-              "re_spmm_csr")
+    D = X.shape[1]
+    if plan.ws.numel() < plan.nchunks * D:
+        plan.ws = torch.empty(plan.nchunks * D, dtype=torch.float32, device=X.device)
+    lib.check(lib.load().re_spmm_csr(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(plan.row_order), plan.nlong,
+                                     _p(plan.chunk_row), _p(plan.chunk_ptr), plan.nchunks, _p(X), D, _p(out), _p(Z), float(beta),
+                                     _p(acc), float(acc_scale), _p(plan.ws), plan.ws.numel() * 4, _stream()), "re_spmm_csr")
     return out
 
 

@@ -61,7 +61,7 @@ dt = timeit(lambda: lg.train_step(u, p, n), iters=20, warmup=5)
 t_sp = ev(lambda: lg._spmm(lg.X0, lg.Xa))
 rows = U + N
 bytes_alg = nnz * 12 + rows * (8 + 4 * 64) + nnz * 256   # (col,val) + crow/Y + X rows (cache-resident upper figure)
-print(json.dumps({"config": f"C3 LightGCN Yelp nnz={nnz} long_rows={lg.plan[1]} B=2048", "ms_per_step": round(dt * 1e3, 4),
+print(json.dumps({"config": f"C3 LightGCN Yelp nnz={nnz} long_rows={lg.plan.nlong} chunks={lg.plan.nchunks} B=2048", "ms_per_step": round(dt * 1e3, 4),
                   "triplets_per_s": round(B / dt, 1), "spmm_ms": round(t_sp, 4),
                   "spmm_GBs_incl_X_rows": round(bytes_alg / t_sp / 1e6, 1), "spmm_GBs_hbm_stream": round((nnz * 12 + rows * 264) / t_sp / 1e6, 1),
                   "spmm_GFLOPs": round(2 * 64 * nnz / t_sp / 1e6, 1)}))

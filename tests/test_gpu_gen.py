@@ -83,7 +83,7 @@ def test_lightgcn_adam_trajectory_vs_oracle(ops):
     np.testing.assert_allclose(m.params["Item.embeddings.weight"].cpu().numpy(), I.detach().numpy(), rtol=1e-3, atol=2e-5)
 
 
-@pytest.mark.parametrize("n,D,avg_deg,hot", [(500, 64, 8, 0), (3000, 64, 20, 2000), (700, 128, 5, 600)])
+@pytest.mark.parametrize("n,D,avg_deg,hot", [(500, 64, 8, 0), (3000, 64, 20, 2000), (700, 128, 5, 600), (4000, 64, 6, 9000)])
 def test_spmm_csr_vs_oracle_with_long_rows(ops, n, D, avg_deg, hot):
     """random sparse matrix (+ one very long row -> the workgroup-per-row path), beta/Z and ACC epilogues."""
     from oracle import lightgcn as olg
@@ -103,8 +103,8 @@ def test_spmm_csr_vs_oracle_with_long_rows(ops, n, D, avg_deg, hot):
     acc0 = rng.standard_normal((n, D)).astype(np.float32)
     ref = olg.spmm_csr(crow, cols, vals, torch.from_numpy(X)).numpy() + 0.5 * Z
     cr, co, va = dev(crow), dev(cols), dev(vals)
-    plan = ops.spmm_plan(cr)
-    assert plan[1] == (1 if hot else 0)
+    plan = ops.spmm_plan(cr, D)
+    assert plan.nlong == (1 if hot else 0) and plan.nchunks == (0 if not hot else -(-(int(crow[8] - crow[7])) // 2048))
     out = torch.empty(n, D, device="cuda")
     acc = dev(acc0)
     ops.spmm_csr(cr, co, va, plan, dev(X), out, Z=dev(Z), beta=0.5, acc=acc, acc_scale=0.25)
