@@ -272,6 +272,193 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Variant R ("register lists"): the same MFMA loop, but every LANE keeps its own best-K list of the items IT sees
+// (lane (c,h) sees 16 of every 32 items of user c) -- sorted, in registers (KR values + KR item ids).  Hits are
+// appended to a per-lane FIFO in LDS with plain stores (no atomics: the queue is private to the lane) and folded into
+// the register list in wave-wide drains: round e processes entry e of every lane's queue with ONE branch-free sorted
+// insertion (1 compare + 4 selects per slot), so the cost of a drain is max-over-lanes(queue length) insertions while
+// all 64 lanes work -- instead of one ~440-cycle LDS heap episode per hit with one or two lanes active (the PMC
+// finding of round 1).  A lane's K-th best is a valid lower bound of its user's K-th best, so filtering on it is exact;
+// the two lanes of a user emit two partial lists per segment and score_topk_merge takes the best K of all of them.
+#define SR_QC 16
+template <int D, int KR>
+__global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
+                                                           int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
+                                                           const int64_t* __restrict__ seen_idx, int K,
+                                                           float* __restrict__ part_vals, int* __restrict__ part_idx,
+                                                           int maxseg, int64_t nub, int64_t nst, int64_t upw) {
+    constexpr int KH = D / 2;
+    constexpr int RSF = D + 4;
+    constexpr int F4_PER_STAGE = SC_TI * D / 4;
+    constexpr int PF = F4_PER_STAGE / 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* tile = reinterpret_cast<float*>(smem);
+    float* qv = tile + SC_TI * RSF;                          // [4 waves][SR_QC][64 lanes]
+    int* qi = reinterpret_cast<int*>(qv + 4 * SR_QC * 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int ul = wid * 32 + c;
+    const int NONE = 0x7FFFFFFF;
+    float* myqv = qv + wid * SR_QC * 64 + lane;
+    int* myqi = qi + wid * SR_QC * 64 + lane;
+
+    const int64_t units_total = nub * nst;
+    int64_t unit = (int64_t)blockIdx.x * upw;
+    const int64_t unit_end = (unit + upw < units_total) ? unit + upw : units_total;
+
+    while (unit < unit_end) {
+        const int64_t ub = unit / nst;
+        const int64_t st0 = unit - ub * nst;
+        const int64_t st1 = (st0 + (unit_end - unit) < nst) ? st0 + (unit_end - unit) : nst;
+        const int seg = (int)((int64_t)blockIdx.x - (ub * nst) / upw);
+        const int64_t user = ub * SC_USERS + ul;
+
+        float bq[KH];
+        {
+            const float* qrow = Q + user * D;
+            const bool uok = user < B;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) bq[s] = uok ? qrow[2 * s + h] : 0.0f;
+        }
+        float lv[KR];
+        int li[KR];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) { lv[j] = -INFINITY; li[j] = NONE; }
+        float thr = (user < B) ? -INFINITY : INFINITY;
+        int qn = 0;
+        int64_t sc_cur = 0, sc_end = 0;
+        int ns0 = NONE, ns1 = NONE;
+        if (seen_ptr && user < B) {
+            sc_cur = seen_ptr[user];
+            sc_end = seen_ptr[user + 1];
+            const int64_t first_item = st0 * SC_TI;
+            int64_t lo = sc_cur, hi2 = sc_end;
+            while (lo < hi2) {
+                const int64_t mid = (lo + hi2) >> 1;
+                if (seen_idx[mid] < first_item) lo = mid + 1; else hi2 = mid;
+            }
+            sc_cur = lo;
+            ns0 = sc_cur < sc_end ? (int)seen_idx[sc_cur] : NONE;
+            ns1 = sc_cur + 1 < sc_end ? (int)seen_idx[sc_cur + 1] : NONE;
+        }
+
+        // fold every lane's queue into its register list: round e = entry e of every queue
+        auto drain = [&]() {
+            int rounds = qn;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o, 64));
+            for (int e = 0; e < rounds; ++e) {
+                const bool act = e < qn;
+                const float v = act ? myqv[e * 64] : -INFINITY;
+                const int it = act ? myqi[e * 64] : NONE;
+                // sorted insertion, best first; ties keep the earlier (lower) item id in front: strict >
+                bool cprev = v > lv[KR - 1];
+#pragma unroll
+                for (int j = KR - 1; j >= 1; --j) {
+                    const bool cup = v > lv[j - 1];            // would v also go in front of slot j-1 ?
+                    lv[j] = cprev ? (cup ? lv[j - 1] : v) : lv[j];
+                    li[j] = cprev ? (cup ? li[j - 1] : it) : li[j];
+                    cprev = cup;
+                }
+                lv[0] = cprev ? v : lv[0];
+                li[0] = cprev ? it : li[0];
+            }
+            qn = 0;
+            if (user < B) thr = lv[KR - 1];
+        };
+
+        float4 pf[PF];
+        auto prefetch = [&](int64_t st) {
+            const int64_t item0 = st * SC_TI;
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int f = p * 256 + tid;
+                const int row = f / (D / 4);
+                pf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (item0 + row < N) pf[p] = reinterpret_cast<const float4*>(E + item0 * D)[f];
+            }
+        };
+        prefetch(st0);
+
+        for (int64_t st = st0; st < st1; ++st) {
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int f = p * 256 + tid;
+                const int row = f / (D / 4);
+                const int k0 = (f % (D / 4)) * 4;
+                float* dst = tile + row * RSF + (k0 >> 1);
+                *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);
+                *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
+            }
+            __syncthreads();
+            if (st + 1 < st1) prefetch(st + 1);
+
+#pragma unroll
+            for (int it = 0; it < SC_TI / 32; ++it) {
+                const int64_t item0 = st * SC_TI + it * 32;
+                if (item0 >= N) break;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                const float* arow = tile + (it * 32 + c) * RSF + h * KH;
+#pragma unroll
+                for (int q = 0; q < KH / 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * q + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
+                }
+                unsigned m = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
+                // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with one id prefetched)
+                while (ns0 < (int)item0 + 32) {
+                    const int d = ns0 - (int)item0;
+                    if (d >= 0 && ((d >> 2) & 1) == h) m &= ~(1u << ((d & 3) + 4 * (d >> 3)));
+                    ++sc_cur;
+                    ns0 = ns1;
+                    ns1 = sc_cur + 1 < sc_end ? (int)seen_idx[sc_cur + 1] : NONE;
+                }
+                if (item0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) m &= ~(1u << r);
+                }
+                if (__ballot(m != 0) == 0ull) continue;
+                if (__ballot(qn + (int)__popc(m) > SR_QC) != 0ull) {   // some queue cannot take this tile's hits: drain first
+                    drain();
+                    unsigned m2 = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m2 |= (acc[r] > thr ? 1u : 0u) << r;
+                    m &= m2;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((m >> r) & 1u) {
+                        myqv[qn * 64] = acc[r];
+                        myqi[qn * 64] = (int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        ++qn;
+                    }
+                }
+            }
+        }
+        drain();
+        if (user < B) {
+            float* pv = part_vals + ((user * maxseg + seg) * 2 + h) * K;
+            int* pi = part_idx + ((user * maxseg + seg) * 2 + h) * K;
+#pragma unroll
+            for (int j = 0; j < KR; ++j)
+                if (j < K) { pv[j] = lv[j]; pi[j] = li[j] == NONE ? -1 : li[j]; }
+        }
+        unit += st1 - st0;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // merge the per-segment partial lists of one user (one wave per user), sort, apply the K > #unmasked fill.
 __device__ __forceinline__ void bitonic_step(float& v, int& i, int j, bool keep_first, int lane) {
     const float pv = __shfl_xor(v, j, 64);
@@ -293,7 +480,7 @@ __device__ __forceinline__ void bitonic_sort64(float& v, int& i, int lane) {
 }
 
 __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict__ part_vals, const int* __restrict__ part_idx,
-                                                        int maxseg, int64_t B, int64_t N, int K, int64_t nst, int64_t upw,
+                                                        int maxseg, int lps, int64_t B, int64_t N, int K, int64_t nst, int64_t upw,
                                                         const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
                                                         float* __restrict__ vals, int64_t* __restrict__ idx) {
     const int lane = threadIdx.x & 63;
@@ -301,7 +488,8 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
     if (user >= B) return;
     const int64_t ub = user / SC_USERS;
     const int64_t w0 = (ub * nst) / upw, w1 = ((ub + 1) * nst - 1) / upw;
-    const int nseg = (int)(w1 - w0 + 1);
+    const int nseg = (int)(w1 - w0 + 1) * lps;   // lps partial lists per segment (2 for the register-list variant)
+    maxseg *= lps;
     const int PAD = 0x7FFFFFFF;
     float bv = -INFINITY;
     int bi = PAD;
@@ -345,7 +533,7 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static int g_score_pop = 2;      // tuning switches (scripts/tune_score.py); not part of the ABI
+static int g_score_pop = 3;      // tuning switches (scripts/tune_score.py); not part of the ABI
 static int64_t g_score_minseg = SC_MIN_SEG;
 extern "C" void re_dbg_score_variant(int pop, int64_t minseg) { g_score_pop = pop; g_score_minseg = minseg; }
 
@@ -382,7 +570,7 @@ extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D,
     (void)D;
     if (B <= 0 || N <= 0 || K <= 0) return 256;
     ScorePlan p = score_plan(B, N);
-    return re_align((size_t)p.nub * SC_USERS * p.maxseg * K * 4) * 2 + 256;
+    return re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4) * 2 + 256;   // up to 2 lists per (user, segment)
 }
 
 template <int D, bool TOPK, int POP>
@@ -431,12 +619,24 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
     if (ws_bytes < re_score_topk_workspace_bytes(B, N, D, K)) return RE_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     ScorePlan p = score_plan(B, N);
-    const size_t half = re_align((size_t)p.nub * SC_USERS * p.maxseg * K * 4);
+    const size_t half = re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4);
     float* pv = (float*)ws;
     int* pi = (int*)((char*)ws + half);
-    int rc = score_dispatch<true>(D, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p, nullptr, s);
+    int rc, lps = 1;
+    // register-list variant: many users per launch (its two lists per segment double the merge work, which dominates
+    // when B is small -- A/B in scripts/tune_score.py)
+    if (g_score_pop == 3 && D == 64 && K <= 52 && p.nub >= 16) {
+        lps = 2;
+        const size_t lds = (size_t)SC_TI * (64 + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
+#define SR_LAUNCH(KRV) hipLaunchKernelGGL((score_kernel_reg<64, KRV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw)
+        if (K <= 16) SR_LAUNCH(16); else if (K <= 32) SR_LAUNCH(32); else SR_LAUNCH(52);
+#undef SR_LAUNCH
+        rc = re_launch_status();
+    } else {
+        rc = score_dispatch<true>(D, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p, nullptr, s);
+    }
     if (rc != RE_OK) return rc;
-    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, p.maxseg, B, N, (int)K, p.nst, p.upw,
+    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, p.maxseg, lps, B, N, (int)K, p.nst, p.upw,
                        seen_ptr, seen_idx, vals, idx);
     return re_launch_status();
 }

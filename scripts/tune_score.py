@@ -26,7 +26,7 @@ with torch.no_grad():
 E2 = model.params["Item.embeddings.weight"].detach()[1:]
 for rnd in range(2):
     for name, (qq, EE) in {"random-normal": (q, E), "bench (LN-encoded q, xavier E)": (q2, E2)}.items():
-        for pop in (0, 1, 2):
+        for pop in (0, 2, 3):
             for minseg in (1,):
                 L.re_dbg_score_variant(pop, minseg)
                 ms = t(lambda: ops.score_topk(qq, EE, sp, si, 50))
