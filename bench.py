@@ -253,8 +253,9 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, host_batches)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()            # the other ranks wait for rank 0's extra legs instead of tearing the communicator down
         dist.destroy_process_group()
 
 
