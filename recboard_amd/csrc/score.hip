@@ -280,13 +280,21 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__
 // all 64 lanes work -- instead of one ~440-cycle LDS heap episode per hit with one or two lanes active (the PMC
 // finding of round 1).  A lane's K-th best is a valid lower bound of its user's K-th best, so filtering on it is exact;
 // the two lanes of a user emit two partial lists per segment and score_topk_merge takes the best K of all of them.
-#define SR_QC 16
-template <int D, int KR>
+// VLOG = true ("value lists + log"): the register list holds VALUES only, so an insertion is one v_med3_f32 per slot
+// instead of 1 compare + 4 selects; the (value, item) pairs that passed the lane's threshold are appended to a per-lane
+// log in global memory ([entry][lane] per wave: coalesced), pruned against the current threshold whenever it could
+// overflow (<= KR entries survive a prune, see the tie argument in DESIGN.md), and reduced to the exact best K -- all
+// entries above the lane's K-th value, then the earliest entries equal to it -- at the end of the segment.
+#define SR_QC 24
+#define SR_LOGCAP 128
+__device__ unsigned long long g_sr_counters[4];   // diagnostics (dbg == 3): drains, rounds, appended hits, tiles with hits
+template <int D, int KR, bool VLOG>
 __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
                                                            int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
                                                            const int64_t* __restrict__ seen_idx, int K,
                                                            float* __restrict__ part_vals, int* __restrict__ part_idx,
-                                                           int maxseg, int64_t nub, int64_t nst, int64_t upw) {
+                                                           int maxseg, int64_t nub, int64_t nst, int64_t upw,
+                                                           float* __restrict__ logv_all, int* __restrict__ logi_all, int dbg) {
     constexpr int KH = D / 2;
     constexpr int RSF = D + 4;
     constexpr int F4_PER_STAGE = SC_TI * D / 4;
@@ -302,6 +310,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
     const int NONE = 0x7FFFFFFF;
     float* myqv = qv + wid * SR_QC * 64 + lane;
     int* myqi = qi + wid * SR_QC * 64 + lane;
+    float* logv = VLOG ? logv_all + ((int64_t)blockIdx.x * 4 + wid) * SR_LOGCAP * 64 + lane : nullptr;
+    int* logi = VLOG ? logi_all + ((int64_t)blockIdx.x * 4 + wid) * SR_LOGCAP * 64 + lane : nullptr;
 
     const int64_t units_total = nub * nst;
     int64_t unit = (int64_t)blockIdx.x * upw;
@@ -322,11 +332,13 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
             for (int s = 0; s < KH; ++s) bq[s] = uok ? qrow[2 * s + h] : 0.0f;
         }
         float lv[KR];
-        int li[KR];
+        int li[VLOG ? 1 : KR];
 #pragma unroll
-        for (int j = 0; j < KR; ++j) { lv[j] = -INFINITY; li[j] = NONE; }
-        float thr = (user < B) ? -INFINITY : INFINITY;
-        int qn = 0;
+        for (int j = 0; j < KR; ++j) lv[j] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < (VLOG ? 1 : KR); ++j) li[j] = NONE;
+        float thr = (user < B && dbg != 1) ? -INFINITY : INFINITY;
+        int qn = 0, ln = 0;
         int64_t sc_cur = 0, sc_end = 0;
         int ns0 = NONE, ns1 = NONE;
         if (seen_ptr && user < B) {
@@ -343,29 +355,72 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
             ns1 = sc_cur + 1 < sc_end ? (int)seen_idx[sc_cur + 1] : NONE;
         }
 
+        // log prune: keep the entries that can still be in the best K (value >= the lane's current KR-th best)
+        auto prune = [&](float keep_from) {
+            int w = 0;
+            for (int e = 0; e < SR_LOGCAP; ++e) {
+                if (__ballot(e < ln) == 0ull) break;
+                if (e < ln) {
+                    const float v = logv[e * 64];
+                    const int it = logi[e * 64];
+                    if (v >= keep_from) { logv[w * 64] = v; logi[w * 64] = it; ++w; }
+                }
+            }
+            ln = w;
+        };
         // fold every lane's queue into its register list: round e = entry e of every queue
         auto drain = [&]() {
-            int rounds = qn;
+            int rounds = (dbg == 2) ? 0 : qn;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o, 64));
-            for (int e = 0; e < rounds; ++e) {
+            if (dbg == 3) {
+                if (lane == 0) { atomicAdd(&g_sr_counters[0], 1ull); atomicAdd(&g_sr_counters[1], (unsigned long long)rounds); }
+                atomicAdd(&g_sr_counters[2], (unsigned long long)qn);
+            }
+#pragma unroll 1
+            for (int e = 0; e < rounds; ++e) {   // ONE copy of the insertion code: the kernel must stay inside the I-cache
                 const bool act = e < qn;
-                const float v = act ? myqv[e * 64] : -INFINITY;
+                float v = act ? myqv[e * 64] : -INFINITY;
                 const int it = act ? myqi[e * 64] : NONE;
-                // sorted insertion, best first; ties keep the earlier (lower) item id in front: strict >
-                bool cprev = v > lv[KR - 1];
+                if (VLOG) {
+                    const bool take = v > lv[KR - 1];       // strict: a later item with the K-th value loses the tie
+                    if (take) { logv[ln * 64] = v; logi[ln * 64] = it; ++ln; }
+                    if (!take) v = -INFINITY;
 #pragma unroll
-                for (int j = KR - 1; j >= 1; --j) {
-                    const bool cup = v > lv[j - 1];            // would v also go in front of slot j-1 ?
-                    lv[j] = cprev ? (cup ? lv[j - 1] : v) : lv[j];
-                    li[j] = cprev ? (cup ? li[j - 1] : it) : li[j];
-                    cprev = cup;
+                    for (int j = KR - 1; j >= 1; --j) lv[j] = __builtin_amdgcn_fmed3f(v, lv[j], lv[j - 1]);
+                    lv[0] = fmaxf(v, lv[0]);
+                } else {
+                    // sorted insertion, best first; ties keep the earlier (lower) item id in front: strict >
+                    bool cprev = v > lv[KR - 1];
+#pragma unroll
+                    for (int j = KR - 1; j >= 1; --j) {
+                        const bool cup = v > lv[j - 1];            // would v also go in front of slot j-1 ?
+                        lv[j] = cprev ? (cup ? lv[j - 1] : v) : lv[j];
+                        li[j] = cprev ? (cup ? li[j - 1] : it) : li[j];
+                        cprev = cup;
+                    }
+                    lv[0] = cprev ? v : lv[0];
+                    li[0] = cprev ? it : li[0];
                 }
-                lv[0] = cprev ? v : lv[0];
-                li[0] = cprev ? it : li[0];
             }
             qn = 0;
-            if (user < B) thr = lv[KR - 1];
+            if (user < B && (dbg == 0 || dbg == 3)) {
+                thr = lv[KR - 1];
+                if (!VLOG) {
+                    // The user's K-th best is at least (a) either lane's K-th best and (b) min(a, b) where a, b are the
+                    // two lanes' ceil(K/2)-th bests (K/2 items above a in one half + K/2 above b in the other): (b) is
+                    // close to the true K-th value because the halves are statistically alike -> ~40 % fewer hits.
+                    float mid = lv[0], kth = lv[0];
+#pragma unroll
+                    for (int j = 1; j < KR; ++j) {
+                        mid = (j == (K + 1) / 2 - 1) ? lv[j] : mid;
+                        kth = (j == K - 1) ? lv[j] : kth;
+                    }
+                    const float pmid = __shfl_xor(mid, 32, 64), pkth = __shfl_xor(kth, 32, 64);
+                    thr = fmaxf(fmaxf(kth, pkth), fminf(mid, pmid));
+                }
+            }
+            if (VLOG && __ballot(ln + SR_QC > SR_LOGCAP) != 0ull) prune(lv[KR - 1]);   // room for the next drain
         };
 
         float4 pf[PF];
@@ -381,55 +436,66 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         };
         prefetch(st0);
 
-        for (int64_t st = st0; st < st1; ++st) {
-            __syncthreads();
+        // the stage loop runs one extra, empty iteration (fin) whose only job is the final drain: the drain code then
+        // exists once in the kernel
+        for (int64_t st = st0; st <= st1; ++st) {
+            const bool fin = st == st1;
+            if (!fin) {
+                __syncthreads();
 #pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                const int f = p * 256 + tid;
-                const int row = f / (D / 4);
-                const int k0 = (f % (D / 4)) * 4;
-                float* dst = tile + row * RSF + (k0 >> 1);
-                *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);
-                *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
+                for (int p = 0; p < PF; ++p) {
+                    const int f = p * 256 + tid;
+                    const int row = f / (D / 4);
+                    const int k0 = (f % (D / 4)) * 4;
+                    float* dst = tile + row * RSF + (k0 >> 1);
+                    *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);
+                    *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
+                }
+                __syncthreads();
+                if (st + 1 < st1) prefetch(st + 1);
             }
-            __syncthreads();
-            if (st + 1 < st1) prefetch(st + 1);
-
-#pragma unroll
+#pragma unroll 1
             for (int it = 0; it < SC_TI / 32; ++it) {
                 const int64_t item0 = st * SC_TI + it * 32;
-                if (item0 >= N) break;
                 f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                const float* arow = tile + (it * 32 + c) * RSF + h * KH;
-#pragma unroll
-                for (int q = 0; q < KH / 4; ++q) {
-                    const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * q + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
-                }
                 unsigned m = 0;
+                bool need_drain = fin;
+                if (!fin) {
+                    if (item0 >= N) break;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
-                // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with one id prefetched)
-                while (ns0 < (int)item0 + 32) {
-                    const int d = ns0 - (int)item0;
-                    if (d >= 0 && ((d >> 2) & 1) == h) m &= ~(1u << ((d & 3) + 4 * (d >> 3)));
-                    ++sc_cur;
-                    ns0 = ns1;
-                    ns1 = sc_cur + 1 < sc_end ? (int)seen_idx[sc_cur + 1] : NONE;
-                }
-                if (item0 + 32 > N) {
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    const float* arow = tile + (it * 32 + c) * RSF + h * KH;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if ((int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) m &= ~(1u << r);
+                    for (int q = 0; q < KH / 4; ++q) {
+                        const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * q + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
+                    // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with one id prefetched)
+                    while (ns0 < (int)item0 + 32) {
+                        const int d = ns0 - (int)item0;
+                        if (d >= 0 && ((d >> 2) & 1) == h) m &= ~(1u << ((d & 3) + 4 * (d >> 3)));
+                        ++sc_cur;
+                        ns0 = ns1;
+                        ns1 = sc_cur + 1 < sc_end ? (int)seen_idx[sc_cur + 1] : NONE;
+                    }
+                    if (item0 + 32 > N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if ((int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) m &= ~(1u << r);
+                    }
+                    // Drains are WORKGROUP-wide: the four waves share the stage barriers, so a wave draining alone stalls the
+                    // other three at the next barrier (measured: drain time x ~3); draining together costs one extra barrier
+                    // per tile and keeps the four SIMDs busy at the same time.
+                    need_drain = __syncthreads_or(qn + (int)__popc(m) > SR_QC) != 0;   // some queue cannot take this tile's hits
                 }
-                if (__ballot(m != 0) == 0ull) continue;
-                if (__ballot(qn + (int)__popc(m) > SR_QC) != 0ull) {   // some queue cannot take this tile's hits: drain first
+                if (need_drain) {
                     drain();
+                    if (fin) break;
                     unsigned m2 = 0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m2 |= (acc[r] > thr ? 1u : 0u) << r;
@@ -445,13 +511,30 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 }
             }
         }
-        drain();
         if (user < B) {
             float* pv = part_vals + ((user * maxseg + seg) * 2 + h) * K;
             int* pi = part_idx + ((user * maxseg + seg) * 2 + h) * K;
+            if (VLOG) {
+                // exact best K of the lane: everything above its K-th value, then the earliest entries equal to it
+                float thrK = lv[0];
 #pragma unroll
-            for (int j = 0; j < KR; ++j)
-                if (j < K) { pv[j] = lv[j]; pi[j] = li[j] == NONE ? -1 : li[j]; }
+                for (int j = 1; j < KR; ++j) thrK = (j == K - 1) ? lv[j] : thrK;
+                int ngt = 0;
+                for (int e = 0; e < ln; ++e) ngt += logv[e * 64] > thrK ? 1 : 0;
+                int w = 0, neq = K - ngt;
+                for (int e = 0; e < ln && w < K; ++e) {
+                    const float v = logv[e * 64];
+                    if (v > thrK || (v == thrK && neq > 0)) {
+                        if (v == thrK) --neq;
+                        pv[w] = v; pi[w] = logi[e * 64]; ++w;
+                    }
+                }
+                for (; w < K; ++w) { pv[w] = -INFINITY; pi[w] = -1; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KR; ++j)
+                    if (j < K) { pv[j] = lv[j]; pi[j] = li[j] == NONE ? -1 : li[j]; }
+            }
         }
         unit += st1 - st0;
         __syncthreads();
@@ -480,7 +563,7 @@ __device__ __forceinline__ void bitonic_sort64(float& v, int& i, int lane) {
 }
 
 __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict__ part_vals, const int* __restrict__ part_idx,
-                                                        int maxseg, int lps, int64_t B, int64_t N, int K, int64_t nst, int64_t upw,
+                                                        int maxseg, int lps, int presorted, int64_t B, int64_t N, int K, int64_t nst, int64_t upw,
                                                         const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
                                                         float* __restrict__ vals, int64_t* __restrict__ idx) {
     const int lane = threadIdx.x & 63;
@@ -501,7 +584,7 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
             i = part_idx[(user * maxseg + s) * K + lane];
             if (i < 0) { i = PAD; v = -INFINITY; }
         }
-        bitonic_sort64(v, i, lane);
+        if (!presorted) bitonic_sort64(v, i, lane);   // register-list partials arrive sorted best-first (padding last)
         // top-64 of the union of two best-first lists: compare lane t with lane 63-t of the other list
         const float rv = __shfl(v, 63 - lane, 64);
         const int ri = __shfl(i, 63 - lane, 64);
@@ -535,7 +618,14 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 static int g_score_pop = 3;      // tuning switches (scripts/tune_score.py); not part of the ABI
 static int64_t g_score_minseg = SC_MIN_SEG;
-extern "C" void re_dbg_score_variant(int pop, int64_t minseg) { g_score_pop = pop; g_score_minseg = minseg; }
+static int g_score_vlog = 0;
+static int g_score_dbg = 0;   // diagnostics only (scripts/tune_score.py): 1 = no hits at all, 2 = append but never insert
+extern "C" void re_dbg_score_diag(int mode) { g_score_dbg = mode; }
+extern "C" void re_dbg_score_counters(unsigned long long* out4, int reset) {
+    (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sr_counters), 32);
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sr_counters), z, 32); }
+}
+extern "C" void re_dbg_score_variant(int pop, int64_t minseg) { g_score_vlog = (pop == 4); g_score_pop = (pop == 4) ? 3 : pop; g_score_minseg = minseg; }
 
 struct ScorePlan {
     int64_t nub, nst, units, upw;
@@ -570,7 +660,8 @@ extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D,
     (void)D;
     if (B <= 0 || N <= 0 || K <= 0) return 256;
     ScorePlan p = score_plan(B, N);
-    return re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4) * 2 + 256;   // up to 2 lists per (user, segment)
+    return re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4) * 2      // up to 2 lists per (user, segment)
+           + (size_t)SC_MAX_WGS * 4 * SR_LOGCAP * 64 * 8 + 256;                    // per-lane candidate logs
 }
 
 template <int D, bool TOPK, int POP>
@@ -628,15 +719,18 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
     if (g_score_pop == 3 && D == 64 && K <= 52 && p.nub >= 16) {
         lps = 2;
         const size_t lds = (size_t)SC_TI * (64 + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
-#define SR_LAUNCH(KRV) hipLaunchKernelGGL((score_kernel_reg<64, KRV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw)
-        if (K <= 16) SR_LAUNCH(16); else if (K <= 32) SR_LAUNCH(32); else SR_LAUNCH(52);
+        float* logv = (float*)((char*)ws + 2 * half);
+        int* logi = (int*)(logv + (size_t)SC_MAX_WGS * 4 * SR_LOGCAP * 64);
+#define SR_LAUNCH(KRV, VL) hipLaunchKernelGGL((score_kernel_reg<64, KRV, VL>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, logv, logi, g_score_dbg)
+        if (g_score_vlog) { if (K <= 16) SR_LAUNCH(16, true); else if (K <= 32) SR_LAUNCH(32, true); else SR_LAUNCH(52, true); }
+        else { if (K <= 16) SR_LAUNCH(16, false); else if (K <= 32) SR_LAUNCH(32, false); else SR_LAUNCH(52, false); }
 #undef SR_LAUNCH
         rc = re_launch_status();
     } else {
         rc = score_dispatch<true>(D, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p, nullptr, s);
     }
     if (rc != RE_OK) return rc;
-    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, p.maxseg, lps, B, N, (int)K, p.nst, p.upw,
+    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, p.maxseg, lps, (lps == 2 && !g_score_vlog) ? 1 : 0, B, N, (int)K, p.nst, p.upw,
                        seen_ptr, seen_idx, vals, idx);
     return re_launch_status();
 }

@@ -26,9 +26,27 @@ with torch.no_grad():
 E2 = model.params["Item.embeddings.weight"].detach()[1:]
 for rnd in range(2):
     for name, (qq, EE) in {"random-normal": (q, E), "bench (LN-encoded q, xavier E)": (q2, E2)}.items():
-        for pop in (0, 2, 3):
+        for pop in (2, 3, 4):
             for minseg in (1,):
                 L.re_dbg_score_variant(pop, minseg)
                 ms = t(lambda: ops.score_topk(qq, EE, sp, si, 50))
                 ms5 = t(lambda: ops.score_topk(qq[:512], EE, sp[:513], si, 50))
                 print(f"{name:32s} pop={pop} minseg={minseg:2d}: full {ms:.3f} ms ({2*D*U*N/ms/1e9:.1f} TF)   B=512: {ms5:.3f} ms")
+
+L.re_dbg_score_diag.argtypes = [ctypes.c_int]; L.re_dbg_score_diag.restype = None
+L.re_dbg_score_variant(3, 1)
+for mode, name in ((0, "normal"), (1, "no hits (MFMA loop + filter only)"), (2, "append every score, never insert")):
+    L.re_dbg_score_diag(mode)
+    ms = t(lambda: ops.score_topk(q, E, sp, si, 50))
+    print(f"reg-list diag {name:40s}: {ms:.3f} ms")
+L.re_dbg_score_diag(0)
+
+L.re_dbg_score_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.re_dbg_score_counters.restype = None
+buf = (ctypes.c_ulonglong * 4)()
+L.re_dbg_score_diag(3)
+L.re_dbg_score_counters(buf, 1)
+ops.score_topk(q, E, sp, si, 50); torch.cuda.synchronize()
+L.re_dbg_score_counters(buf, 1)
+nw = 512 * 4
+print(f"one launch: drains/wave {buf[0]/nw:.1f}  rounds/wave {buf[1]/nw:.1f}  hits/lane {buf[2]/nw/64:.1f}  (segments/wave 1; MFMA tiles/wave ~130)")
+L.re_dbg_score_diag(0)
