@@ -219,6 +219,23 @@ int re_bce_logits(const float* logits, const float* labels, int64_t n, float* lo
 int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
                  double beta1, double beta2, double eps, double weight_decay, re_stream_t stream);
 
+/* Cross entropy over materialised logits [M, N] (row stride ld), forward and backward IN PLACE (SASRec --loss CE,
+ * SASRec/main.py:217-219; CrossEntropy4Logits(mean) = F.cross_entropy): row_loss[m] = logsumexp(x_m) - x_m[labels[m]],
+ * loss[0] = mean(row_loss), and logits <- (softmax(x_m) - onehot(labels[m])) / M, the gradient w.r.t. the logits. */
+int re_ce_rows(float* logits, int64_t M, int64_t N, int64_t ld, const int64_t* labels, float* row_loss, float* loss,
+               re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * General fp32 GEMM on the matrix cores: C[M,N] = alpha * op(A)[M,K] op(B)[K,N] + beta * C (+ bias[n]) (+ ReLU).
+ * transX = 0: the operand is stored as op(X) row-major (A: [M,K] lda, B: [K,N] ldb); transX = 1: stored transposed
+ * (A: [K,M] lda, B: [N,K] ldb).  `y = x W^T + b` (nn.Linear, DeepFM/main.py:112-121; SASRec CE logits
+ * SASRec/main.py:217) is transA = 0, transB = 1.  Exact fp32 (k-ordered fmaf chains); long-K skinny products are split
+ * along K into slabs reduced in a fixed order (workspace from re_gemm_f32_workspace_bytes). */
+size_t re_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws,
+                size_t ws_bytes, re_stream_t stream);
+
 /* dst[i] = alpha * src[i]  (LightGCN/main.py:80 `avgEmbds = allEmbds / (L+1)`) */
 int re_scale_copy(float* dst, const float* src, float alpha, int64_t n, re_stream_t stream);
 

@@ -140,3 +140,60 @@ extern "C" int re_bce_logits(const float* logits, const float* labels, int64_t n
     hipLaunchKernelGGL(bce_logits_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, labels, n, loss, dlogit, dsum);
     return re_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Cross entropy over materialised logits, forward + backward in place (SASRec --loss CE, SASRec/main.py:217-219;
+// CrossEntropy4Logits(reduction="mean") = F.cross_entropy).  One workgroup per row: max, sum-exp, then
+//   row_loss[m] = logsumexp(x_m) - x_m[y_m];   x_m <- (softmax(x_m) - onehot(y_m)) * (1 / M)      (the gradient)
+// loss[0] = mean(row_loss) by a second, fixed-order kernel.  [M, N] = 3 000 x 12 101 on the benchmark shapes: 145 MB,
+// read twice and written once.
+__global__ __launch_bounds__(256) void ce_rows_k(float* __restrict__ logits, int64_t N, int64_t ld, const int64_t* __restrict__ labels,
+                                                 float inv_m, float* __restrict__ row_loss) {
+    __shared__ float red[4];
+    float* x = logits + (int64_t)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int64_t i = tid; i < N; i += 256) mx = fmaxf(mx, x[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int64_t i = tid; i < N; i += 256) s += expf(x[i] - mx);
+    s = re_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = ((red[0] + red[1]) + red[2]) + red[3];
+    const int64_t y = labels[blockIdx.x];
+    const bool yok = y >= 0 && y < N;
+    if (tid == 0) row_loss[blockIdx.x] = yok ? (logf(s) + mx - x[y]) : 0.f;
+    __syncthreads();
+    const float inv_s = 1.0f / s;
+    for (int64_t i = tid; i < N; i += 256) {
+        float p = expf(x[i] - mx) * inv_s;
+        if (yok && i == y) p -= 1.0f;
+        x[i] = p * inv_m;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_mean_k(const float* __restrict__ v, int64_t n, float scale, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+    s = re_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (((red[0] + red[1]) + red[2]) + red[3]) * scale;
+}
+
+extern "C" int re_ce_rows(float* logits, int64_t M, int64_t N, int64_t ld, const int64_t* labels, float* row_loss, float* loss,
+                          re_stream_t stream) {
+    re_clear_error();
+    if (!logits || !labels || !row_loss || !loss || M <= 0 || N <= 0 || ld < N) return RE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_rows_k, dim3((unsigned)M), dim3(256), 0, s, logits, N, ld, labels, 1.0f / (float)M, row_loss);
+    hipLaunchKernelGGL(sum_mean_k, dim3(1), dim3(256), 0, s, (const float*)row_loss, M, 1.0f / (float)M, loss);
+    return re_launch_status();
+}

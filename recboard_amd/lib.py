@@ -42,6 +42,9 @@ SIGNATURES = {
     "re_fm_bag_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "re_fm_bag_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "re_bce_logits": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "re_gemm_f32_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "re_gemm_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
+    "re_ce_rows": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "re_scale_copy": (_i32, [_vp, _vp, _f32, _i64, _vp]),
     "re_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _vp]),
 }

@@ -378,3 +378,39 @@ def bce_logits(logits, labels):
     ds = torch.empty(1, dtype=torch.float32, device=dev)
     lib.check(lib.load().re_bce_logits(_p(logits), _p(labels), n, _p(loss), _p(dl), _p(ds), _stream()), "re_bce_logits")
     return loss, dl, ds
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, bias=None, relu=False):
+    """out = alpha * op(A) @ op(B) + beta * out (+ bias) (+ ReLU) on the fp32 matrix cores (re_gemm_f32).
+    A, B: 2-D fp32 with unit inner stride (row stride = leading dimension)."""
+    for t, nme in ((A, "A"), (B, "B")):
+        _req(t, torch.float32, nme, contiguous=False)
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"recengine: `{nme}` must be 2-D with unit inner stride")
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    Kb, N = (B.shape[1], B.shape[0]) if transB else B.shape
+    if K != Kb:
+        raise ValueError(f"recengine: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("recengine: beta != 0 needs `out`")
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _req(out, torch.float32, "out", contiguous=False)
+    if bias is not None:
+        _req(bias, torch.float32, "bias")
+    L = lib.load()
+    ws = _ws(L.re_gemm_f32_workspace_bytes(M, N, K), A.device)
+    lib.check(L.re_gemm_f32(int(transA), int(transB), M, N, K, float(alpha), _p(A), A.stride(0), _p(B), B.stride(0), float(beta),
+                            _p(out), out.stride(0), _p(bias), int(relu), _p(ws), ws.numel(), _stream()), "re_gemm_f32")
+    return out
+
+
+def ce_rows_(logits, labels):
+    """In place: logits [M, N] -> d(mean CE)/d(logits); returns loss [1]  (re_ce_rows)."""
+    _req(logits, torch.float32, "logits"); _req(labels, torch.int64, "labels")
+    M, N = logits.shape
+    row_loss = torch.empty(M, dtype=torch.float32, device=logits.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    lib.check(lib.load().re_ce_rows(_p(logits), M, N, logits.stride(0), _p(labels), _p(row_loss), _p(loss), _stream()), "re_ce_rows")
+    return loss

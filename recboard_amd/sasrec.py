@@ -114,8 +114,10 @@ class SASRecEngine:
 
     def __init__(self, num_items, maxlen=50, embedding_dim=64, num_blocks=2, dropout_rate=0.0, loss="BCE",
                  lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, encoder="fused"):
-        assert loss in ("BCE", "BPR")
+        assert loss in ("BCE", "BPR", "CE")
         assert encoder in ("fused", "aten")
+        if loss == "CE" and encoder != "fused":
+            raise NotImplementedError("loss='CE' is implemented on the fused path only")
         if encoder == "fused" and (embedding_dim != 64 or maxlen > 64 or num_blocks > 4):
             raise NotImplementedError("fused encoder kernels: D = 64, maxlen <= 64, blocks <= 4 (use encoder='aten')")
         self.encoder = encoder
@@ -253,7 +255,8 @@ class SASRecEngine:
     def batch_aux_fused(seq, pos, neg):
         """As batch_aux, for the fused step: (valid uint8 [B*S], destination rows of all 3*B*S gradient contributions)."""
         v, rp, rn = SASRecEngine.batch_aux(seq, pos, neg)
-        return v, torch.cat([seq.reshape(-1), rp, rn]), ops.seq_packing(seq)
+        vidx = torch.nonzero(v).reshape(-1).contiguous()      # valid positions (CE compacts to them; batch assembly, not the step)
+        return v, torch.cat([seq.reshape(-1), rp, rn]), ops.seq_packing(seq), vidx
 
     def _buffers(self, B, S):
         key = (B, S)
@@ -278,7 +281,7 @@ class SASRecEngine:
         B, S = seq.shape
         if aux is None:
             aux = self.batch_aux_fused(seq, pos, neg)
-        valid, rows_all, packing = aux
+        valid, rows_all, packing, vidx = aux
         W = self._buffers(B, S)
         G = A.views(A.grad)
         p = self.p_drop if self.training else 0.0
@@ -292,13 +295,25 @@ class SASRecEngine:
         ops.sasrec_encoder_fwd(W["x0"], seq, bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"], packing=packing)
         u2 = W["u"].view(n, D)
         posf, negf = pos.reshape(-1), neg.reshape(-1)
-        loss, logits, count = ops.pair_loss_fwd(u2, E, posf, negf, valid, kind, e_off=1)
         C = W["contrib"]
-        ops.pair_loss_bwd(u2, E, posf, negf, valid, kind, logits, count, None, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
+        GE = G["Item.embeddings.weight"]
+        if self.loss_kind == "CE":
+            # SASRec/main.py:216-219: logits = u[valid] E[1:]^T, mean CE against IPos -- three fp32 MFMA GEMMs + one row kernel
+            Uv = ops.gather_rows(u2, vidx)                                   # [M, D]
+            logits = ops.gemm(Uv, E[1:], transB=True)                        # [M, N]
+            loss = ops.ce_rows_(logits, posf[vidx].contiguous())             # logits <- d loss / d logits
+            dUv = ops.gemm(logits, E[1:])                                    # [M, D]
+            ops.scatter_add_rows(dUv, vidx, n, out=W["dU"])                  # back to the [B*S, D] layout (pads zero)
+            C[n:].zero_()                                                    # no pos/neg contribution rows in CE mode
+        else:
+            loss, logits, count = ops.pair_loss_fwd(u2, E, posf, negf, valid, kind, e_off=1)
+            ops.pair_loss_bwd(u2, E, posf, negf, valid, kind, logits, count, None, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
         ops.sasrec_encoder_bwd(W["dU"].view(B, S, D), seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad),
                                G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing)
         ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, G["Position.weight"], ws=W["ws_emb"])
-        ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=G["Item.embeddings.weight"], ws=W["ws_sc"])
+        ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])
+        if self.loss_kind == "CE":
+            ops.gemm(logits, Uv, transA=True, beta=1.0, out=GE[1:])          # dE[1:] += dlogits^T u[valid]
         if grad_hook is not None:
             grad_hook(A.grad)
         A.step += 1

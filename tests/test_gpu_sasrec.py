@@ -105,3 +105,18 @@ def test_fused_step_with_dropout_trains():
     assert all(np.isfinite(losses))
     assert np.mean(losses[-10:]) < np.mean(losses[:10]) - 0.05
     assert len({round(x, 6) for x in losses[:5]}) == 5
+
+
+def test_fused_step_ce_loss_matches_reference_golden():
+    """--loss CE (SASRec/main.py:216-219): logits over the whole catalog via the MFMA GEMM, row-wise CE in place."""
+    z = np.load(os.path.join(G, "sasrec_ce.npz"))
+    m = _engine(z, "CE", lr=0.0, encoder="fused")
+    seq, pos, neg = dev(z["in/seq"]), dev(z["in/pos"]), dev(z["in/neg"])
+    L = m.train_step(seq, pos, neg)
+    np.testing.assert_allclose(L.item(), float(z["out/rec_loss"]), rtol=1e-5)
+    Gv = m.arena.views(m.arena.grad)
+    for k in m.params:
+        ref = z["grad/" + k]
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(Gv[k].cpu().numpy() - ref).max()
+        assert err <= 1e-4 * scale + 1e-7, (k, err, scale)
