@@ -236,6 +236,24 @@ int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
                 const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws,
                 size_t ws_bytes, re_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * DeepFM MLPBlock pieces around re_gemm_f32 (DeepFM/main.py:103-124: Linear -> BatchNorm1d -> ReLU -> Dropout):
+ * re_bn_relu_drop_fwd: a = dropout(relu(bn(z))) over z [M, N]; gamma == NULL means "no BatchNorm" (a = dropout(relu(z))).
+ *   training != 0: batch statistics (biased variance), running_mean/var updated with `momentum` (unbiased variance), the
+ *   engine's counter-based dropout mask (element id m*N+n, stream_id); otherwise running statistics, no dropout.
+ *   stats [2N] receives (mean, rstd) for the backward.
+ * re_bn_relu_drop_bwd: given da, writes dz [M, N] (gradient w.r.t. z), dgamma [N], dbeta [N] (for gamma == NULL dbeta is
+ *   the column sum of dz, i.e. the Linear bias gradient).
+ * re_colsum: out[n] = sum_m x[m, n] (bias gradients).  All column reductions are fixed-order (deterministic). */
+int re_bn_relu_drop_fwd(const float* z, int64_t M, int64_t N, const float* gamma, const float* beta, float* run_mean,
+                        float* run_var, int training, float eps, float momentum, float drop_p, uint32_t seed,
+                        uint32_t stream_id, float* stats, float* a, void* ws, size_t ws_bytes, re_stream_t stream);
+int re_bn_relu_drop_bwd(const float* da, const float* a, const float* z, int64_t M, int64_t N, const float* gamma,
+                        const float* stats, float drop_p, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                        re_stream_t stream);
+int re_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, re_stream_t stream);
+size_t re_mlp_workspace_bytes(int64_t N);   /* scratch of the three entry points above (per-chunk column partials) */
+
 /* dst[i] = alpha * src[i]  (LightGCN/main.py:80 `avgEmbds = allEmbds / (L+1)`) */
 int re_scale_copy(float* dst, const float* src, float alpha, int64_t n, re_stream_t stream);
 

@@ -1,0 +1,214 @@
+// DeepFM MLP pieces around the GEMM: BatchNorm1d (training: batch statistics; eval: running statistics) + ReLU + Dropout,
+// forward and backward, and column sums for bias gradients.                                   HBM-bound, [M, N] = 4096 x 400.
+//
+// Reference: MLPBlock.forward = dropout(relu(bn(linear(x))))  (DeepFM/main.py:119-124), nn.BatchNorm1d defaults
+// (eps 1e-5, momentum 0.1, biased variance for normalisation, unbiased for the running estimate).
+// Column statistics: a workgroup owns 64 columns; thread (c, rg) accumulates rows rg, rg+4, ... (coalesced over c), the
+// four row groups are combined in LDS in a fixed order -> deterministic.  Variance is two-pass (mean first).
+#include <math.h>
+
+#include "re_common.h"
+#include "re_rng.h"
+
+// Column reductions over [M, N] run on a (N/64) x ML_CHUNKS grid: block (bx, by) reduces rows [by*rpc, (by+1)*rpc) of 64
+// columns (thread (c, rg) takes rows rg, rg+4, ... of the chunk: coalesced over c), the four row groups are combined in
+// LDS in a fixed order, and a finalize kernel merges the ML_CHUNKS partials per column in chunk order -> deterministic.
+#define ML_CHUNKS 32
+
+template <class F>
+__device__ __forceinline__ void col_reduce2(int64_t M, int64_t N, F f, float& o1, float& o2, bool& owner, int64_t& col,
+                                            int64_t& m_begin, int64_t& m_end) {
+    __shared__ float r1[256], r2[256];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    col = (int64_t)blockIdx.x * 64 + c;
+    const int64_t rpc = (M + gridDim.y - 1) / gridDim.y;
+    m_begin = (int64_t)blockIdx.y * rpc;
+    m_end = (m_begin + rpc < M) ? m_begin + rpc : M;
+    float a = 0.f, b = 0.f;
+    if (col < N)
+        for (int64_t m = m_begin + rg; m < m_end; m += 4) { float x, y; f(m, col, x, y); a += x; b += y; }
+    r1[threadIdx.x] = a; r2[threadIdx.x] = b;
+    __syncthreads();
+    owner = rg == 0 && col < N;
+    if (owner) {
+        o1 = ((r1[c] + r1[64 + c]) + r1[128 + c]) + r1[192 + c];
+        o2 = ((r2[c] + r2[64 + c]) + r2[128 + c]) + r2[192 + c];
+    }
+    __syncthreads();
+}
+
+// partial[by][0][n] = chunk mean, partial[by][1][n] = chunk M2 (sum of squared deviations from the chunk mean)
+__global__ __launch_bounds__(256) void bn_stats_partial_k(const float* __restrict__ z, int64_t M, int64_t N, float* __restrict__ partial) {
+    float s, dummy, q;
+    bool owner;
+    int64_t col, mb, me;
+    __shared__ float s_mean[64];
+    col_reduce2(M, N, [&](int64_t m, int64_t n, float& x, float& y) { x = z[m * N + n]; y = 0.f; }, s, dummy, owner, col, mb, me);
+    const float cnt = (float)(me > mb ? me - mb : 0);
+    if (owner) s_mean[threadIdx.x & 63] = cnt > 0.f ? s / cnt : 0.f;
+    __syncthreads();
+    const float mu = s_mean[threadIdx.x & 63];
+    col_reduce2(M, N, [&](int64_t m, int64_t n, float& x, float& y) { const float d = z[m * N + n] - mu; x = d * d; y = 0.f; }, q, dummy, owner, col, mb, me);
+    if (owner) {
+        partial[((int64_t)blockIdx.y * 2 + 0) * N + col] = mu;
+        partial[((int64_t)blockIdx.y * 2 + 1) * N + col] = q;
+    }
+}
+
+// Chan's parallel-variance merge of the chunk (mean, M2) pairs, in chunk order; then (mean, rstd) + running statistics
+__global__ __launch_bounds__(256) void bn_stats_final_k(const float* __restrict__ partial, int chunks, int64_t M, int64_t N, float eps,
+                                                        float momentum, float* __restrict__ stats, float* __restrict__ run_mean,
+                                                        float* __restrict__ run_var) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int64_t rpc = (M + chunks - 1) / chunks;
+    float mean = 0.f, m2 = 0.f, cnt = 0.f;
+    for (int b = 0; b < chunks; ++b) {
+        const int64_t mb = (int64_t)b * rpc;
+        if (mb >= M) break;
+        const float nb = (float)(((mb + rpc < M) ? mb + rpc : M) - mb);
+        const float mub = partial[((int64_t)b * 2 + 0) * N + n], m2b = partial[((int64_t)b * 2 + 1) * N + n];
+        const float delta = mub - mean, tot = cnt + nb;
+        mean += delta * (nb / tot);
+        m2 += m2b + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+    }
+    const float var = m2 / (float)M;
+    stats[n] = mean;
+    stats[N + n] = 1.0f / sqrtf(var + eps);
+    if (run_mean) {
+        run_mean[n] = (1.f - momentum) * run_mean[n] + momentum * mean;
+        run_var[n] = (1.f - momentum) * run_var[n] + momentum * (M > 1 ? m2 / (float)(M - 1) : var);
+    }
+}
+
+// out1[n] = sum over chunks of partial[b][0][n], out2 likewise (either may be null)
+__global__ __launch_bounds__(256) void col_final_k(const float* __restrict__ partial, int chunks, int64_t N, float* __restrict__ out1,
+                                                   float* __restrict__ out2) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f, b = 0.f;
+    for (int c = 0; c < chunks; ++c) { a += partial[((int64_t)c * 2 + 0) * N + n]; b += partial[((int64_t)c * 2 + 1) * N + n]; }
+    if (out1) out1[n] = a;
+    if (out2) out2[n] = b;
+}
+
+// eval mode: stats from the running estimates
+__global__ __launch_bounds__(256) void bn_stats_eval_k(const float* __restrict__ run_mean, const float* __restrict__ run_var, int64_t N,
+                                                       float eps, float* __restrict__ stats) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n < N) { stats[n] = run_mean[n]; stats[N + n] = 1.0f / sqrtf(run_var[n] + eps); }
+}
+
+// a = dropout(relu((z - mean) * rstd * gamma + beta));   stats == NULL: no BatchNorm (a = dropout(relu(z)))
+__global__ __launch_bounds__(256) void bn_relu_drop_fwd_k(const float* __restrict__ z, int64_t total, int64_t N,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float drop_scale, uint32_t thresh,
+                                                          uint32_t seed, uint32_t stream_id, float* __restrict__ a) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t n = e % N;
+        float v = z[e];
+        if (stats) v = (v - stats[n]) * stats[N + n] * gamma[n] + beta[n];
+        v = fmaxf(v, 0.f);
+        if (thresh) v = re_keep(seed, stream_id, (uint32_t)e, thresh) ? v * drop_scale : 0.f;
+        a[e] = v;
+    }
+}
+
+// backward, pass 1: g = da * dropmask * (a > 0)  (written to dz as scratch); partial sums of g and g*xhat per chunk
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__ da, const float* __restrict__ a, const float* __restrict__ z,
+                                                       int64_t M, int64_t N, const float* __restrict__ stats, float drop_scale,
+                                                       float* __restrict__ dz, float* __restrict__ partial) {
+    float sg, sgx;
+    bool owner;
+    int64_t col, mb, me;
+    col_reduce2(M, N, [&](int64_t m, int64_t n, float& x, float& y) {
+        const int64_t e = m * N + n;
+        const float g = (a[e] > 0.f) ? da[e] * drop_scale : 0.f;   // a > 0 <=> relu active and not dropped
+        dz[e] = g;
+        x = g;
+        y = stats ? g * (z[e] - stats[n]) * stats[N + n] : 0.f;
+    }, sg, sgx, owner, col, mb, me);
+    if (owner) {
+        partial[((int64_t)blockIdx.y * 2 + 0) * N + col] = sg;
+        partial[((int64_t)blockIdx.y * 2 + 1) * N + col] = sgx;
+    }
+}
+
+// backward, pass 2 (BatchNorm only): dz = rstd * gamma * (g - mean(g) - xhat * mean(g * xhat))
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(float* __restrict__ dz, const float* __restrict__ z, int64_t total, int64_t M, int64_t N,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    const float invm = 1.0f / (float)M;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t n = e % N;
+        const float xhat = (z[e] - stats[n]) * stats[N + n];
+        dz[e] = stats[N + n] * gamma[n] * (dz[e] - dbeta[n] * invm - xhat * dgamma[n] * invm);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int64_t M, int64_t N, float* __restrict__ partial) {
+    float s, d;
+    bool owner;
+    int64_t col, mb, me;
+    col_reduce2(M, N, [&](int64_t m, int64_t n, float& a, float& b) { a = x[m * N + n]; b = 0.f; }, s, d, owner, col, mb, me);
+    if (owner) {
+        partial[((int64_t)blockIdx.y * 2 + 0) * N + col] = s;
+        partial[((int64_t)blockIdx.y * 2 + 1) * N + col] = 0.f;
+    }
+}
+
+static int ml_chunks(int64_t M) { return M >= 4 * ML_CHUNKS ? ML_CHUNKS : 1; }
+extern "C" size_t re_mlp_workspace_bytes(int64_t N) { return (size_t)ML_CHUNKS * 2 * N * sizeof(float) + 256; }
+
+extern "C" int re_bn_relu_drop_fwd(const float* z, int64_t M, int64_t N, const float* gamma, const float* beta, float* run_mean,
+                                   float* run_var, int training, float eps, float momentum, float drop_p, uint32_t seed,
+                                   uint32_t stream_id, float* stats, float* a, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!z || !a || M <= 0 || N <= 0) return RE_EINVAL;
+    if (gamma && training && (!ws || ws_bytes < re_mlp_workspace_bytes(N))) return RE_EWORKSPACE;
+    const bool bn = gamma != nullptr;
+    if (bn && (!beta || !stats || !run_mean || !run_var)) return RE_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (bn) {
+        if (training) {
+            const int ch = ml_chunks(M);
+            hipLaunchKernelGGL(bn_stats_partial_k, dim3((unsigned)re_cdiv(N, 64), ch), dim3(256), 0, s, z, M, N, (float*)ws);
+            hipLaunchKernelGGL(bn_stats_final_k, dim3((unsigned)re_cdiv(N, 256)), dim3(256), 0, s, (const float*)ws, ch, M, N, eps, momentum, stats, run_mean, run_var);
+        }
+        else hipLaunchKernelGGL(bn_stats_eval_k, dim3((unsigned)re_cdiv(N, 256)), dim3(256), 0, s, (const float*)run_mean, (const float*)run_var, N, eps, stats);
+    }
+    const uint32_t thresh = (training && drop_p > 0.f) ? re_drop_threshold(drop_p) : 0u;
+    const float ds = thresh ? 1.0f / (1.0f - drop_p) : 1.0f;
+    hipLaunchKernelGGL(bn_relu_drop_fwd_k, dim3(re_grid(M * N, 1024)), dim3(256), 0, s, z, M * N, N, bn ? (const float*)stats : nullptr, gamma, beta, ds,
+                       thresh, seed, stream_id, a);
+    return re_launch_status();
+}
+
+extern "C" int re_bn_relu_drop_bwd(const float* da, const float* a, const float* z, int64_t M, int64_t N, const float* gamma,
+                                   const float* stats, float drop_p, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                   re_stream_t stream) {
+    re_clear_error();
+    if (!da || !a || !z || !dz || !dbeta || M <= 0 || N <= 0) return RE_EINVAL;
+    if (!ws || ws_bytes < re_mlp_workspace_bytes(N)) return RE_EWORKSPACE;
+    const bool bn = gamma != nullptr;
+    if (bn && (!stats || !dgamma)) return RE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const int ch = ml_chunks(M);
+    hipLaunchKernelGGL(bn_bwd_reduce_k, dim3((unsigned)re_cdiv(N, 64), ch), dim3(256), 0, s, da, a, z, M, N, bn ? stats : nullptr, ds, dz, (float*)ws);
+    hipLaunchKernelGGL(col_final_k, dim3((unsigned)re_cdiv(N, 256)), dim3(256), 0, s, (const float*)ws, ch, N, dbeta, bn ? dgamma : nullptr);
+    if (bn) hipLaunchKernelGGL(bn_bwd_apply_k, dim3(re_grid(M * N, 1024)), dim3(256), 0, s, dz, z, M * N, M, N, stats, gamma, (const float*)dgamma, (const float*)dbeta);
+    return re_launch_status();
+}
+
+extern "C" int re_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!x || !out || M <= 0 || N <= 0) return RE_EINVAL;
+    if (!ws || ws_bytes < re_mlp_workspace_bytes(N)) return RE_EWORKSPACE;
+    const int ch = ml_chunks(M);
+    hipLaunchKernelGGL(colsum_k, dim3((unsigned)re_cdiv(N, 64), ch), dim3(256), 0, (hipStream_t)stream, x, M, N, (float*)ws);
+    hipLaunchKernelGGL(col_final_k, dim3((unsigned)re_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, ch, N, out, (float*)nullptr);
+    return re_launch_status();
+}

@@ -1,32 +1,24 @@
 """DeepFM on the engine: host-side mirror of the reference's `DeepFM` (DeepFM/main.py:127-219) and of
-`CoachForDeepFM.train_per_epoch`'s step body (:256-276).
+`CoachForDeepFM.train_per_epoch`'s step body (:256-276).  Every heavy op of the step is a librecengine kernel (what is
+left to torch: adding two [B] vectors, the gradient-norm reduction of the clip, the eval-time sigmoid):
 
-Native (librecengine): the multi-field embedding bag, the FM second-order term, the logistic-regression term, the
-BCE-with-logits criterion and its gradient, the scatter-add of ALL field gradients (one launch per table) and the Adam
-update of the tables.  The F per-field tables are ONE concatenated table (plus one LR vector): `field f, id i` is row
-`offsets[f] + i`.  State-dict access keeps the reference's per-field view (`tables[f]`, `tables_lr[f]`).
+  multi-field embedding bag + FM second-order term + logistic regression   re_fm_bag_fwd / _bwd          (DeepFM/main.py:58-62,80-85,204-206)
+  MLP  Linear -> BatchNorm1d -> ReLU -> Dropout (x3) -> Linear(., 1)       re_gemm_f32 + re_bn_relu_drop_*  (:103-124,151-164)
+  BCELoss4Logits(mean) and its gradient                                     re_bce_logits                 (:214)
+  table gradients                                                           re_scatter_add_rows (one launch per table, all fields)
+  clip_grad_norm_(.., 10) + Adam with the two weight-decay groups           re_rows_sqnorm-style norm + re_adam_step x2   (:187-199,267-268)
 
-STILL ON ATEN THIS ROUND (flagged in DESIGN.md §7): the 3x400 MLP with BatchNorm (DeepFM/main.py:103-124,151-164) and
-its optimizer.  Its input gradient flows back into the native bag backward.
+Layout: ONE parameter arena = [ T (sum count_f x D) | TL (sum count_f) | pad ][ MLP weights, biases, BN affine | LR bias ];
+the first segment is the reference's "embeddings" optimizer group (weight_decay = embedding_decay), the second its
+"other" group -- two Adam launches.  The F per-field tables are one concatenated table: `field f, id i` is row
+`offsets[f] + i`; `tables()` / `tables_lr()` give the reference's per-field views.
 """
+import math
+from collections import OrderedDict
+
 import torch
-import torch.nn as nn
 
 from . import ops
-
-
-class MLPBlock(nn.Module):
-    """Linear -> BatchNorm1d -> ReLU -> Dropout (DeepFM/main.py:103-124)."""
-
-    def __init__(self, i, o, batch_norm, p):
-        super().__init__()
-        self.linear = nn.Linear(i, o)
-        self.bn = nn.BatchNorm1d(o) if batch_norm else nn.Identity()
-        self.act = nn.ReLU()
-        self.dropout = nn.Dropout(p)
-
-    def forward(self, x):
-        return self.dropout(self.act(self.bn(self.linear(x))))
 
 
 class DeepFMEngine:
@@ -35,73 +27,130 @@ class DeepFMEngine:
         self.counts, self.F, self.D = list(counts), len(counts), embedding_dim
         self.device = torch.device(device)
         self.lr, self.emb_decay, self.wd, self.betas = lr, embedding_decay, weight_decay, betas
+        self.bn, self.p_drop, self.seed = batch_norm, hidden_dropout_rate, seed
         off = [0]
         for c in self.counts[:-1]:
             off.append(off[-1] + c)
         self.rows = sum(self.counts)
         self.offsets = torch.tensor(off, dtype=torch.int64, device=self.device)
-        # arena: [T (rows*D) | TL (rows) | lr bias (1)]  -> one Adam launch with weight_decay = embedding_decay.
-        # (the LR bias belongs to the reference's non-embedding group; its decay is applied separately below)
-        nT, nL = self.rows * self.D, self.rows
-        pad = (-(nT + nL)) % 4
-        self.n_arena = nT + nL + pad + 4
-        self.data = torch.zeros(self.n_arena, device=self.device)
-        self.grad, self.m, self.v = (torch.zeros_like(self.data) for _ in range(3))
-        self.T = self.data[:nT].view(self.rows, self.D)
-        self.TL = self.data[nT:nT + nL].view(self.rows, 1)
-        self.bias = self.data[nT + nL + pad:nT + nL + pad + 1]
-        self.gT = self.grad[:nT].view(self.rows, self.D)
-        self.gTL = self.grad[nT:nT + nL].view(self.rows, 1)
-        self.gbias = self.grad[nT + nL + pad:nT + nL + pad + 1]
-        g = torch.Generator().manual_seed(seed)
-        self.T.copy_((torch.randn(self.T.shape, generator=g) * 1e-4).to(self.device))      # nn.init.normal_(std=1e-4), :178
-        self.TL.copy_((torch.randn(self.TL.shape, generator=g) * 1e-4).to(self.device))
         dims = [self.F * self.D] + list(hidden_dims)
-        blocks = [MLPBlock(i, o, batch_norm, hidden_dropout_rate) for i, o in zip(dims[:-1], dims[1:])]
-        blocks.append(nn.Linear(dims[-1], 1))
-        self.dnn = nn.Sequential(*blocks).to(self.device)
-        for mod in self.dnn.modules():
-            if isinstance(mod, nn.Linear):
-                nn.init.xavier_normal_(mod.weight)
-                nn.init.constant_(mod.bias, 0.0)
-        self.mlp_opt = torch.optim.Adam(self.dnn.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)
+        self.dims = dims
+        shapes = OrderedDict()
+        shapes["T"] = (self.rows, self.D)
+        shapes["TL"] = (self.rows, 1)
+        self.n_emb = sum((math.prod(s) + 3) // 4 * 4 for s in shapes.values())          # embeddings group ends here
+        for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+            shapes[f"dnn.{i}.linear.weight"] = (b, a)
+            shapes[f"dnn.{i}.linear.bias"] = (b,)
+            if batch_norm:
+                shapes[f"dnn.{i}.bn.weight"] = (b,)
+                shapes[f"dnn.{i}.bn.bias"] = (b,)
+        nl = len(dims) - 1
+        shapes[f"dnn.{nl}.weight"] = (1, dims[-1])
+        shapes[f"dnn.{nl}.bias"] = (1,)
+        shapes["fm.lr_layer.bias"] = (1,)
+        self.shapes, self.nl = shapes, nl
+        self.off = OrderedDict()
+        o = 0
+        for k, shp in shapes.items():
+            self.off[k] = o
+            o += (math.prod(shp) + 3) // 4 * 4
+        self.numel = o
+        self.data = torch.zeros(o, device=self.device)
+        self.grad, self.m, self.v = (torch.zeros_like(self.data) for _ in range(3))
+        self.P = self._views(self.data)
+        self.G = self._views(self.grad)
+        self.T, self.TL, self.bias = self.P["T"], self.P["TL"], self.P["fm.lr_layer.bias"]
+        self.gT, self.gTL, self.gbias = self.G["T"], self.G["TL"], self.G["fm.lr_layer.bias"]
+        self.running = {}
+        if batch_norm:
+            for i, b in enumerate(dims[1:]):
+                self.running[i] = (torch.zeros(b, device=self.device), torch.ones(b, device=self.device))
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():   # DeepFM.reset_parameters (DeepFM/main.py:172-182)
+            for k, p in self.P.items():
+                if k in ("T", "TL"):
+                    p.copy_((torch.randn(p.shape, generator=g) * 1e-4).to(self.device))
+                elif k.endswith("linear.weight") or k == f"dnn.{nl}.weight":
+                    std = math.sqrt(2.0 / (p.shape[0] + p.shape[1]))
+                    p.copy_((torch.randn(p.shape, generator=g) * std).to(self.device))
+                elif k.endswith("bn.weight"):
+                    p.fill_(1.0)
         self.step = 0
         self.training = True
 
-    # ---- per-field views (reference state-dict granularity)
+    def _views(self, buf):
+        return OrderedDict((k, buf[o:o + math.prod(self.shapes[k])].view(self.shapes[k])) for k, o in self.off.items())
+
+    # ---- per-field views (reference state-dict granularity) and state-dict loading
     def tables(self):
         return [self.T[o:o + c] for o, c in zip(self.offsets.tolist(), self.counts)]
 
     def tables_lr(self):
         return [self.TL[o:o + c] for o, c in zip(self.offsets.tolist(), self.counts)]
 
+    def load_dnn_state_dict(self, sd):
+        """`dnn.*` entries of the reference state_dict (incl. BatchNorm running statistics)."""
+        for k, p in self.P.items():
+            if k.startswith("dnn."):
+                p.copy_(torch.as_tensor(sd[k[4:]]).to(self.device).view(p.shape))
+        for i in self.running:
+            self.running[i][0].copy_(torch.as_tensor(sd[f"{i}.bn.running_mean"]).to(self.device))
+            self.running[i][1].copy_(torch.as_tensor(sd[f"{i}.bn.running_var"]).to(self.device))
+
     def train(self, mode=True):
         self.training = mode
-        self.dnn.train(mode)
         return self
 
     def eval(self):
         return self.train(False)
 
+    def _step_seed(self):
+        return (self.seed * 0x9E3779B1 + (self.step + 1) * 0x85EBCA77) & 0xFFFFFFFF
+
+    # ---- forward: keeps what the backward needs in `tape`
     def encode(self, x):
-        """-> (logits [B, 1], E leaf [B, F*D], fm_lr [B]).  DeepFM/main.py:201-209."""
+        """-> (logits [B], tape).  DeepFM/main.py:201-209."""
+        P = self.P
         E, fm_lr = ops.fm_bag_fwd(self.T, self.TL.reshape(-1), self.bias, self.offsets, x)
-        E.requires_grad_(self.training)
-        logits = fm_lr.unsqueeze(1) + self.dnn(E)
-        return logits, E, fm_lr
+        tape = {"E": E, "layers": []}
+        h, sd = E, self._step_seed()
+        for i in range(self.nl):
+            z = ops.gemm(h, P[f"dnn.{i}.linear.weight"], transB=True, bias=P[f"dnn.{i}.linear.bias"])
+            rm, rv = self.running[i] if self.bn else (None, None)
+            a, stats = ops.bn_relu_drop_fwd(z, P.get(f"dnn.{i}.bn.weight"), P.get(f"dnn.{i}.bn.bias"), rm, rv, self.training,
+                                            self.p_drop, sd, stream_id=100 + i)
+            tape["layers"].append((h, z, a, stats))
+            h = a
+        dnn = ops.gemm(h, P[f"dnn.{self.nl}.weight"], transB=True, bias=P[f"dnn.{self.nl}.bias"])   # [B, 1]
+        tape["h_last"] = h
+        logits = fm_lr + dnn.reshape(-1)      # lr + fm + dnn  (elementwise add of two [B] vectors)
+        return logits, tape
 
     def recommend_from_pool(self, x):
-        with torch.no_grad():
-            return torch.sigmoid(self.encode(x)[0])
+        """sigmoid(logits) [B, 1]  (DeepFM/main.py:217-219)."""
+        return torch.sigmoid(self.encode(x)[0]).unsqueeze(1)
 
     def forward_backward(self, x, labels):
-        """loss + every gradient (tables in self.grad, MLP in .grad of its parameters).  DeepFM/main.py:211-215,264-266."""
-        logits, E, _ = self.encode(x)
-        loss, dlogit, dsum = ops.bce_logits(logits.detach().reshape(-1).contiguous(), labels.reshape(-1).to(torch.float32).contiguous())
-        for p in self.dnn.parameters():
-            p.grad = None
-        logits.backward(dlogit.unsqueeze(1))                 # MLP (aten): parameter grads + dE
-        gE, gL = ops.fm_bag_bwd(E.detach(), E.grad.contiguous(), dlogit, self.F, self.D)
+        """loss + every gradient into the gradient arena.  DeepFM/main.py:211-215, 264-266."""
+        P, G = self.P, self.G
+        logits, tape = self.encode(x)
+        loss, dlogit, dsum = ops.bce_logits(logits.contiguous(), labels.reshape(-1).to(torch.float32).contiguous())
+        dl = dlogit.unsqueeze(1)                                                       # [B, 1]
+        nl = self.nl
+        # final Linear(., 1):  dW = dl^T h,  db = sum dl,  dh = dl W
+        ops.gemm(dl, tape["h_last"], transA=True, out=G[f"dnn.{nl}.weight"])
+        G[f"dnn.{nl}.bias"].copy_(dsum)
+        da = ops.gemm(dl, P[f"dnn.{nl}.weight"])
+        for i in reversed(range(nl)):
+            h, z, a, stats = tape["layers"][i]
+            dz, _, _ = ops.bn_relu_drop_bwd(da, a, z, P.get(f"dnn.{i}.bn.weight"), stats, self.p_drop if self.training else 0.0,
+                                            dgamma=G.get(f"dnn.{i}.bn.weight"), dbeta=G[f"dnn.{i}.bn.bias"] if self.bn else G[f"dnn.{i}.linear.bias"])
+            ops.gemm(dz, h, transA=True, out=G[f"dnn.{i}.linear.weight"])             # dW = dz^T x
+            if self.bn:
+                ops.colsum(dz, out=G[f"dnn.{i}.linear.bias"])                          # (= 0 up to rounding behind a BatchNorm)
+            da = ops.gemm(dz, P[f"dnn.{i}.linear.weight"])                             # dx = dz W
+        gE, gL = ops.fm_bag_bwd(tape["E"], da, dlogit, self.F, self.D)
         rows = (x + self.offsets.unsqueeze(0)).reshape(-1)
         ops.scatter_add_rows(gE, rows, self.rows, out=self.gT)
         ops.scatter_add_rows(gL, rows, self.rows, out=self.gTL)
@@ -109,17 +158,13 @@ class DeepFMEngine:
         return loss.squeeze(0)
 
     def train_step(self, x, labels, max_norm=10.0):
-        """forward, backward, clip_grad_norm_(.., 10), Adam with the two weight-decay groups (DeepFM/main.py:187-199,264-268)."""
+        """forward, backward, clip_grad_norm_(.., 10), Adam with the reference's two groups (DeepFM/main.py:187-199, 264-268)."""
         loss = self.forward_backward(x, labels)
-        mg = [p.grad for p in self.dnn.parameters()]
-        total = torch.sqrt(self.grad.pow(2).sum() + sum(g.pow(2).sum() for g in mg))
-        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        self.grad.mul_(coef)
-        for g in mg:
-            g.mul_(coef)
+        total = torch.sqrt(self.grad.pow(2).sum())
+        self.grad.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
         self.step += 1
-        # the LR bias is in the reference's non-embedding group (weight_decay, not embedding_decay): pre-compensate
-        self.gbias.add_((self.wd - self.emb_decay) * self.bias)
-        ops.adam_step(self.data, self.grad, self.m, self.v, self.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.emb_decay)
-        self.mlp_opt.step()
+        ne = self.n_emb
+        b1, b2 = self.betas
+        ops.adam_step(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], self.step, self.lr, b1, b2, 1e-8, self.emb_decay)
+        ops.adam_step(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], self.step, self.lr, b1, b2, 1e-8, self.wd)
         return loss

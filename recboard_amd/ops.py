@@ -414,3 +414,45 @@ def ce_rows_(logits, labels):
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
     lib.check(lib.load().re_ce_rows(_p(logits), M, N, logits.stride(0), _p(labels), _p(row_loss), _p(loss), _stream()), "re_ce_rows")
     return loss
+
+
+# ------------------------------------------------------------------------------------------------ MLP pieces
+def bn_relu_drop_fwd(z, gamma, beta, run_mean, run_var, training, drop_p=0.0, seed=0, stream_id=100, eps=1e-5, momentum=0.1):
+    """-> (a, stats): a = dropout(relu(bn(z)))  (re_bn_relu_drop_fwd); gamma None = no BatchNorm."""
+    _req(z, torch.float32, "z")
+    M, N = z.shape
+    a = torch.empty_like(z)
+    stats = torch.empty(2 * N, dtype=torch.float32, device=z.device) if gamma is not None else None
+    L = lib.load()
+    ws = _ws(L.re_mlp_workspace_bytes(N), z.device)
+    lib.check(L.re_bn_relu_drop_fwd(_p(z), M, N, _p(gamma), _p(beta), _p(run_mean), _p(run_var), int(bool(training)),
+                                    float(eps), float(momentum), float(drop_p), int(seed) & 0xFFFFFFFF, int(stream_id),
+                                    _p(stats), _p(a), _p(ws), ws.numel(), _stream()), "re_bn_relu_drop_fwd")
+    return a, stats
+
+
+def bn_relu_drop_bwd(da, a, z, gamma, stats, drop_p, dgamma=None, dbeta=None):
+    """-> (dz, dgamma, dbeta)  (re_bn_relu_drop_bwd)."""
+    _req(da, torch.float32, "da")
+    M, N = z.shape
+    dz = torch.empty_like(z)
+    if dbeta is None:
+        dbeta = torch.empty(N, dtype=torch.float32, device=z.device)
+    if gamma is not None and dgamma is None:
+        dgamma = torch.empty(N, dtype=torch.float32, device=z.device)
+    L = lib.load()
+    ws = _ws(L.re_mlp_workspace_bytes(N), z.device)
+    lib.check(L.re_bn_relu_drop_bwd(_p(da), _p(a), _p(z), M, N, _p(gamma), _p(stats), float(drop_p), _p(dz), _p(dgamma),
+                                    _p(dbeta), _p(ws), ws.numel(), _stream()), "re_bn_relu_drop_bwd")
+    return dz, dgamma, dbeta
+
+
+def colsum(x, out=None):
+    _req(x, torch.float32, "x")
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    L = lib.load()
+    ws = _ws(L.re_mlp_workspace_bytes(N), x.device)
+    lib.check(L.re_colsum(_p(x), M, N, _p(out), _p(ws), ws.numel(), _stream()), "re_colsum")
+    return out

@@ -23,8 +23,7 @@ def _engine(z):
         t.copy_(dev(z[f"table/{f}"]))
         tl.copy_(dev(z[f"table_lr/{f}"]))
     m.bias.copy_(dev(z["param/fm.lr_layer.bias"]))
-    sd = {k[len("param/dnn."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/dnn.")}
-    m.dnn.load_state_dict(sd)
+    m.load_dnn_state_dict({k[len("param/dnn."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/dnn.")})
     return m
 
 
@@ -58,8 +57,8 @@ def test_deepfm_engine_matches_reference_golden():
     z = np.load(os.path.join(G, "deepfm.npz"))
     m = _engine(z).train()
     x, y = dev(z["in/x"]), dev(z["in/labels"])
-    logits, _, _ = m.encode(x)
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), z["out/train_logits"], rtol=1e-4, atol=1e-5)
+    logits, _ = m.encode(x)
+    np.testing.assert_allclose(logits.cpu().numpy(), z["out/train_logits"].reshape(-1), rtol=1e-4, atol=1e-5)
     m2 = _engine(z).train()
     loss = m2.forward_backward(x, y)
     np.testing.assert_allclose(loss.item(), float(z["out/rec_loss"]), rtol=1e-5)
@@ -67,7 +66,14 @@ def test_deepfm_engine_matches_reference_golden():
         np.testing.assert_allclose(m2.gT[o:o + c].cpu().numpy(), z[f"gtable/{f}"], rtol=1e-3, atol=2e-6)
         np.testing.assert_allclose(m2.gTL[o:o + c].cpu().numpy(), z[f"gtable_lr/{f}"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(m2.gbias.cpu().numpy(), z["grad/fm.lr_layer.bias"], rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(m2.dnn[0].linear.weight.grad.cpu().numpy(), z["grad/dnn.0.linear.weight"], rtol=1e-3, atol=2e-6)
+    for k in z.files:          # every MLP gradient: Linear weights/biases, BatchNorm affine
+        if k.startswith("grad/dnn."):
+            ref = z[k]
+            got = m2.G[k[5:]].cpu().numpy().reshape(ref.shape)
+            assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-3) + 1e-7, k
+    for i in range(3):         # running statistics updated like nn.BatchNorm1d (momentum 0.1, unbiased variance)
+        np.testing.assert_allclose(m2.running[i][0].cpu().numpy(), z[f"post/dnn.{i}.bn.running_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(m2.running[i][1].cpu().numpy(), z[f"post/dnn.{i}.bn.running_var"], rtol=1e-4, atol=1e-6)
     # eval pass: running stats as updated by the train-mode forward
     m2.eval()
     np.testing.assert_allclose(m2.recommend_from_pool(x).cpu().numpy(), z["out/eval_scores"], rtol=1e-4, atol=1e-6)
