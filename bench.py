@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
     ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,9 +148,32 @@ def main():
             dist.all_reduce(garena)
             garena.mul_(1.0 / world)
 
-    def step(i):
+    use_graph = args.encoder == "fused" and not args.no_graph
+    blobs = [model.pack_batch(*b[:3]) for b in batches] if use_graph else None
+
+    def step_eager(i):
         seq, pos, neg, aux = batches[i % len(batches)]
         return model.train_step(seq, pos, neg, aux, grad_hook=hook)
+
+    def step_graph(i):
+        return model.train_step_graph(blobs[i % len(blobs)], cfg["B"], cfg["S"], grad_hook=hook)
+
+    step = step_eager
+    if use_graph:
+        try:   # capture happens on the first call; the eager launch path is the same kernels one by one
+            step_graph(0)
+            torch.cuda.synchronize()
+            step = step_graph
+        except Exception as e:  # noqa: BLE001
+            if world == 1:
+                raise
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            use_graph = False
+    if dist is not None:   # every rank must take the same path (the collectives differ otherwise)
+        flag = torch.tensor([1 if use_graph else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_graph = bool(flag.item())
+        step = step_graph if use_graph else step_eager
 
     for i in range(args.warmup):
         step(i)
@@ -178,6 +202,7 @@ def main():
         "config": {"workload": "SASRec d=64 L=2 maxlen=50 BCE dropout=0.5 Adam on Amazon2014Beauty_550_LOU shapes "
                                "(12101 items, 22363 users), B=512 per GPU",
                    "global_batch": world * cfg["B"], "seq_len": cfg["S"],
+                   "launch": "one hipGraph replay + one staging launch per step" if use_graph else "eager (one launch per kernel)",
                    "parallelism": f"dp{world} (replicated 3 MB table, one gradient-arena all-reduce per step)"},
         "final_loss": round(float(loss), 5),
     }

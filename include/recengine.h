@@ -50,9 +50,12 @@ int re_gather_rows(const float* W, int64_t R, int64_t D, const int64_t* idx, int
 /* SASRec front end, fused: out[b,s,:] = seq[b,s]==0 ? 0 : dropout(E[seq[b,s]] * scale + P[s])
  * Replaces SASRec/main.py:181-187 (embedding, `*= D**0.5`, mark_position, embdDropout, masked_fill).
  * drop_p == 0 disables dropout; otherwise the engine's counter-based mask (stream id 1, element id
- * (b*S+s)*D+d, see csrc/re_rng.h) scaled by 1/(1-p). */
+ * (b*S+s)*D+d, see csrc/re_rng.h) scaled by 1/(1-p).  Every dropout entry point takes the seed twice: `seed` by value
+ * and `seed_dev` (DEVICE uint32[1], may be NULL); the effective seed is seed ^ *seed_dev, so a step captured in a hipGraph
+ * can be replayed with a fresh per-step seed uploaded to device memory. */
 int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float* P, const int64_t* seq, int64_t B,
-                    int64_t S, float scale, float drop_p, uint32_t seed, float* out, re_stream_t stream);
+                    int64_t S, float scale, float drop_p, uint32_t seed, const uint32_t* seed_dev, float* out,
+                    re_stream_t stream);
 
 /* Backward of re_sasrec_embed, in place on gx [B,S,D]: in = gradient w.r.t. x0 (from re_sasrec_encoder_bwd), out =
  * contribution rows for re_scatter_add_rows (pad rows zero, the forward's dropout mask re-applied, times `scale`);
@@ -60,7 +63,7 @@ int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float* P, const 
  * Deterministic. */
 size_t re_sasrec_embed_bwd_workspace_bytes(int64_t S, int64_t D);
 int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int64_t S, int64_t D, float scale, float drop_p,
-                        uint32_t seed, float* dP, void* ws, size_t ws_bytes, re_stream_t stream);
+                        uint32_t seed, const uint32_t* seed_dev, float* dP, void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K1b  dense gradient of the gather: dW[r,:] = sum_{i: idx[i]==r} g[i,:], rows == padding_idx skipped,
@@ -157,12 +160,12 @@ int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t 
 size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b,
-                          float drop_p, uint32_t seed, float* u, void* tape, size_t tape_bytes,
+                          float drop_p, uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, size_t tape_bytes,
                           const int32_t* order, const int32_t* nshort, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b,
-                          float drop_p, uint32_t seed, const void* tape, float* dx0,
+                          float drop_p, uint32_t seed, const uint32_t* seed_dev, const void* tape, float* dx0,
                           float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
                           size_t ws_bytes, const int32_t* order, const int32_t* nshort, re_stream_t stream);
 
@@ -216,6 +219,16 @@ int re_bce_logits(const float* logits, const float* labels, int64_t n, float* lo
  * parameter arena.  Replaces `self.optimizer.step()` (SASRec/main.py:250; cfg dump
  * benchmark/Amazon2014Beauty_550_LOU/SASRec.json:254-300).  step is 1-based.  Hyper-parameters are doubles because
  * torch derives 1-beta and the bias corrections in double precision before rounding to fp32. */
+/* hipGraph-friendly variant of re_adam_step: hyper (DEVICE float[2]) = { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) };
+ * n must be a multiple of 4. */
+int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1,
+                     double beta2, double eps, double weight_decay, re_stream_t stream);
+/* Prepares a captured step for replay in ONE launch: dst[0:nbytes] = src[0:nbytes] (the step's packed batch -> the static
+ * buffer the hipGraph reads; nbytes and both pointers multiples of 16) and state (DEVICE uint32[4]) = { seed, 0,
+ * bits(lr / (1 - beta1^step)), bits(1 / sqrt(1 - beta2^step)) } -- state doubles as `seed_dev` of the dropout entry points
+ * and, from word 2, as `hyper` of re_adam_step_dev. */
+int re_step_stage(void* dst, const void* src, size_t nbytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
+                  double beta1, double beta2, re_stream_t stream);
 int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
                  double beta1, double beta2, double eps, double weight_decay, re_stream_t stream);
 

@@ -36,6 +36,42 @@ __global__ __launch_bounds__(256) void adam_tail(float* __restrict__ p, const fl
     p[i] = p[i] - step_size * (M / (sqrtf(V) * inv_sqrt_bc2 + eps));
 }
 
+// hipGraph-friendly variant: the two step-dependent scalars come from device memory (hyper[0] = lr / (1 - beta1^t),
+// hyper[1] = 1 / sqrt(1 - beta2^t)), so a captured step can be replayed with a fresh 8-byte upload per step.
+__global__ __launch_bounds__(256) void adam_vec4_dev(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                     float4* __restrict__ v, int64_t n4, float b1, float b2, float omb1, float omb2,
+                                                     const float* __restrict__ hyper, float eps, float wd) {
+    const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = p[i], G = g[i], M = m[i], V = v[i];
+#define RE_ADAM1(c)                                        \
+    {                                                      \
+        float gg = G.c + wd * P.c;                         \
+        M.c = b1 * M.c + omb1 * gg;                        \
+        V.c = b2 * V.c + omb2 * gg * gg;                   \
+        float denom = sqrtf(V.c) * inv_sqrt_bc2 + eps;     \
+        P.c = P.c - step_size * (M.c / denom);             \
+    }
+        RE_ADAM1(x) RE_ADAM1(y) RE_ADAM1(z) RE_ADAM1(w)
+#undef RE_ADAM1
+        p[i] = P; m[i] = M; v[i] = V;
+    }
+}
+
+extern "C" int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1, double beta2,
+                                double eps, double weight_decay, re_stream_t stream) {
+    re_clear_error();
+    if (n == 0) return RE_OK;
+    if (!p || !g || !m || !v || !hyper || n < 0) return RE_EINVAL;
+    if ((n & 3) || ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v)) & 15u) != 0)
+        return RE_EUNSUPPORTED;
+    hipLaunchKernelGGL(adam_vec4_dev, dim3(re_grid(n >> 2, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g, (float4*)m,
+                       (float4*)v, n >> 2, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), hyper, (float)eps,
+                       (float)weight_decay);
+    return re_launch_status();
+}
+
 extern "C" int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr, double beta1,
                             double beta2, double eps, double weight_decay, re_stream_t stream) {
     re_clear_error();
@@ -56,6 +92,32 @@ extern "C" int re_adam_step(float* p, const float* g, float* m, float* v, int64_
     if (n & 3)
         hipLaunchKernelGGL(adam_tail, dim3(1), dim3(256), 0, s, p, g, m, v, n4 << 2, n, (float)beta1, (float)beta2, (float)(1.0 - beta1),
                            (float)(1.0 - beta2), step_size, inv_sqrt_bc2, (float)eps, (float)weight_decay);
+    return re_launch_status();
+}
+
+// One launch that prepares a captured (hipGraph) step for replay: copies the step's packed batch into the static buffer the
+// graph reads (16-byte words) and writes the step scalars { seed, 0, lr/(1-b1^t), 1/sqrt(1-b2^t) } where the captured
+// kernels look for them.  The scalars are computed on the host exactly as in re_adam_step.
+__global__ __launch_bounds__(256) void step_stage_k(uint4* __restrict__ dst, const uint4* __restrict__ src, int64_t n16,
+                                                    uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && state) {
+        state[0] = seed;
+        state[1] = 0u;
+        state[2] = __float_as_uint(step_size);
+        state[3] = __float_as_uint(inv_sqrt_bc2);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int re_step_stage(void* dst, const void* src, size_t nbytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
+                             double beta1, double beta2, re_stream_t stream) {
+    re_clear_error();
+    if ((nbytes && (!dst || !src)) || step < 1) return RE_EINVAL;
+    if ((nbytes & 15u) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u)) return RE_EUNSUPPORTED;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const int64_t n16 = (int64_t)(nbytes >> 4);
+    hipLaunchKernelGGL(step_stage_k, dim3(re_grid(n16 > 0 ? n16 : 1, 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)dst, (const uint4*)src,
+                       n16, state, seed, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
     return re_launch_status();
 }
 

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void sasrec_embed_vec4(const float* __restrict
                                                          const float* __restrict__ P,
                                                          const int64_t* __restrict__ seq, int64_t n, int64_t S,
                                                          float scale, float drop_scale, uint32_t thresh,
-                                                         uint32_t seed, float* __restrict__ out) {
+                                                         uint32_t seed, float* __restrict__ out,
+                                                         const uint32_t* __restrict__ seed_dev) {
+    if (seed_dev) seed ^= seed_dev[0];   // per-step seed kept in device memory (hipGraph replays)
     const int lane_in_row = threadIdx.x % LPR;
     const int64_t groups_per_block = 256 / LPR;
     const int64_t group = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / LPR;
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(256) void sasrec_embed_vec4(const float* __restrict
 }
 
 extern "C" int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float* P, const int64_t* seq, int64_t B,
-                               int64_t S, float scale, float drop_p, uint32_t seed, float* out, re_stream_t stream) {
+                               int64_t S, float scale, float drop_p, uint32_t seed, const uint32_t* seed_dev, float* out,
+                               re_stream_t stream) {
     re_clear_error();
     const int64_t n = B * S;
     if (n == 0) return RE_OK;
@@ -161,9 +164,9 @@ extern "C" int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float
     const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     if ((D >> 2) >= 32)
-        hipLaunchKernelGGL(sasrec_embed_vec4<32>, dim3(re_grid(n, 8 * RE_GATHER_ILP)), dim3(256), 0, s, E, R, D, P, seq, n, S, scale, ds, thresh, seed, out);
+        hipLaunchKernelGGL(sasrec_embed_vec4<32>, dim3(re_grid(n, 8 * RE_GATHER_ILP)), dim3(256), 0, s, E, R, D, P, seq, n, S, scale, ds, thresh, seed, out, seed_dev);
     else
-        hipLaunchKernelGGL(sasrec_embed_vec4<16>, dim3(re_grid(n, 16 * RE_GATHER_ILP)), dim3(256), 0, s, E, R, D, P, seq, n, S, scale, ds, thresh, seed, out);
+        hipLaunchKernelGGL(sasrec_embed_vec4<16>, dim3(re_grid(n, 16 * RE_GATHER_ILP)), dim3(256), 0, s, E, R, D, P, seq, n, S, scale, ds, thresh, seed, out, seed_dev);
     return re_launch_status();
 }
 
@@ -177,7 +180,8 @@ extern "C" int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float
 
 __global__ __launch_bounds__(256) void sasrec_embed_bwd_k(float* __restrict__ gx, const int64_t* __restrict__ seq, int B, int S,
                                                           int D, float scale, float drop_scale, uint32_t thresh, uint32_t seed,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, const uint32_t* __restrict__ seed_dev) {
+    if (seed_dev) seed ^= seed_dev[0];
     const int nf4 = S * D / 4, d4n = D / 4;
     float4 acc[EB_SLOTS];
 #pragma unroll
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void sasrec_embed_bwd_reduce(const float* __re
 extern "C" size_t re_sasrec_embed_bwd_workspace_bytes(int64_t S, int64_t D) { return (size_t)EB_WGS * S * D * sizeof(float) + 256; }
 
 extern "C" int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int64_t S, int64_t D, float scale, float drop_p,
-                                   uint32_t seed, float* dP, void* ws, size_t ws_bytes, re_stream_t stream) {
+                                   uint32_t seed, const uint32_t* seed_dev, float* dP, void* ws, size_t ws_bytes, re_stream_t stream) {
     re_clear_error();
     if (!gx || !seq || !dP || !ws || B < 0 || S <= 0 || D <= 0) return RE_EINVAL;
     if ((D & 3) || S * D / 4 > 256 * EB_SLOTS || !aligned16(gx) || !aligned16(dP)) return RE_EUNSUPPORTED;
@@ -230,7 +234,7 @@ extern "C" int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int
     const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int nwg = (int)(B < EB_WGS ? (B > 0 ? B : 1) : EB_WGS);
-    hipLaunchKernelGGL(sasrec_embed_bwd_k, dim3(nwg), dim3(256), 0, s, gx, seq, (int)B, (int)S, (int)D, scale, ds, thresh, seed, (float*)ws);
+    hipLaunchKernelGGL(sasrec_embed_bwd_k, dim3(nwg), dim3(256), 0, s, gx, seq, (int)B, (int)S, (int)D, scale, ds, thresh, seed, (float*)ws, seed_dev);
     const int n = (int)(S * D);
     hipLaunchKernelGGL(sasrec_embed_bwd_reduce, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)ws, nwg, n, dP);
     return re_launch_status();

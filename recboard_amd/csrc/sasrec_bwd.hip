@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
                                                           float drop_scale, uint32_t thresh, uint32_t seed,
                                                           const float* __restrict__ tape, SasrecTape T,
                                                           float* __restrict__ dOut, float* __restrict__ slab,
-                                                          const int* __restrict__ order, const int* __restrict__ nshort_ptr) {
+                                                          const int* __restrict__ order, const int* __restrict__ nshort_ptr,
+                                                          const uint32_t* __restrict__ seed_dev) {
+    if (seed_dev) seed ^= seed_dev[0];   // per-step seed kept in device memory (hipGraph replays)
     extern __shared__ __align__(16) float lds[];
     float* b0 = lds;
     float* b1 = b0 + SE_BUF;
@@ -404,7 +406,8 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
 
 extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                                      const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
-                                     uint32_t seed, const void* tape, float* dx0, float* const* block_grads, float* g_last_w,
+                                     uint32_t seed, const uint32_t* seed_dev, const void* tape, float* dx0, float* const* block_grads,
+                                     float* g_last_w,
                                      float* g_last_b, void* ws, size_t ws_bytes, const int32_t* order, const int32_t* nshort,
                                      re_stream_t stream) {
     re_clear_error();
@@ -430,8 +433,12 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     hipStream_t s = (hipStream_t)stream;
     auto kf = sasrec_block_bwd_k<true>;
     auto kn = sasrec_block_bwd_k<false>;
-    if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+    static bool attr_done = false;   // benign race: the attribute is idempotent; kept out of captured regions after the first call
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        attr_done = true;
+    }
     const float* din = dU;
     for (int64_t l = L - 1; l >= 0; --l) {
         const float* const* q = block_params + 12 * l;
@@ -440,10 +447,10 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
         const bool first = (l == L - 1);
         if (first)
             hipLaunchKernelGGL(kf, dim3(nwg), dim3(256), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
-                               (const float*)tape, T, dout, slab, order, nshort);
+                               (const float*)tape, T, dout, slab, order, nshort, seed_dev);
         else
             hipLaunchKernelGGL(kn, dim3(nwg), dim3(256), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
-                               (const float*)tape, T, dout, slab, order, nshort);
+                               (const float*)tape, T, dout, slab, order, nshort, seed_dev);
         SasrecGradDst dst;
         for (int i = 0; i < 12; ++i) dst.p[i] = block_grads[12 * l + i];
         dst.p[12] = g_last_w;

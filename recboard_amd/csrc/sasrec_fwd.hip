@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                                                             uint32_t thresh, uint32_t seed, float* __restrict__ u,
                                                             float* __restrict__ tape, SasrecTape T,
                                                             const int* __restrict__ order, const int* __restrict__ nshort_ptr,
-                                                            int fill_pads) {
+                                                            int fill_pads, const uint32_t* __restrict__ seed_dev) {
+    if (seed_dev) seed ^= seed_dev[0];   // per-step seed kept in device memory (hipGraph replays)
     extern __shared__ __align__(16) float lds[];
     float* bX = lds;
     float* bA = bX + SE_BUF;
@@ -270,8 +271,8 @@ static bool se_fill_params(SasrecParams& P, const float* const* bp, int64_t L, c
 
 extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                                      const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
-                                     uint32_t seed, float* u, void* tape, size_t tape_bytes, const int32_t* order,
-                                     const int32_t* nshort, re_stream_t stream) {
+                                     uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, size_t tape_bytes,
+                                     const int32_t* order, const int32_t* nshort, re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
     if (!x0 || !seq || !u || B < 0) return RE_EINVAL;
@@ -287,14 +288,21 @@ extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)(B < 2048 ? B : 2048);  // >= the number of work items (shorts packed 4 per item); idle blocks exit
     if ((order == nullptr) != (nshort == nullptr)) return RE_EINVAL;
+    static bool attr_done[2] = {false, false};   // benign race: the attribute is idempotent
     if (tape) {
         auto k = sasrec_encoder_fwd_k<true>;
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, order, nshort, 0);
+        if (!attr_done[1]) {
+            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+            attr_done[1] = true;
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, order, nshort, 0, seed_dev);
     } else {
         auto k = sasrec_encoder_fwd_k<false>;
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T, order, nshort, 1);
+        if (!attr_done[0]) {
+            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+            attr_done[0] = true;
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T, order, nshort, 1, seed_dev);
     }
     return re_launch_status();
 }

@@ -19,7 +19,7 @@
 #include "re_common.h"
 
 #define RE_SORT_TILE 1024
-#define RE_SEG_CHUNK 32
+#define RE_SEG_CHUNK 16
 #define RE_FLAG_SLOT0 1u      // chunk's first run continues a run of the previous chunk -> partial in slot 0
 #define RE_FLAG_SLOT1 2u      // chunk's last run starts here and continues into the next chunk -> slot 1
 #define RE_FLAG_CONT 4u       // slot-0 run covers the whole chunk and continues into the next one
@@ -131,6 +131,144 @@ __global__ __launch_bounds__(64) void radix_scatter(const uint32_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused small-n sort
+// n <= RE_FUSED_MAX_TILES * 1024 keys (a training batch: 76 800 contributions at SASRec/Beauty, 160 k at DeepFM/Criteo):
+// the generic pipeline above is 1 + 3 launches per pass, each a latency-bound 64-thread tile walk.  Here a pass is ONE
+// launch.  Tiles are 1024 keys on 256 threads (4 keys per lane, all loaded before the first ranking round); the scan
+// kernel is folded into the scatter kernel (thread d sums column d of the [T x 256] tile histogram: everything below its
+// tile, and the column total; one block scan over the totals gives the digit bases); the NEXT pass's tile histogram is
+// built by the scatter itself with integer atomics on the tile its output lands in (integer counts: deterministic).
+// The first pass reads idx directly (no key/val arrays yet) and its histogram kernel also zero-fills dW and the later
+// passes' histograms.  Launches: 1 + passes (+ 2 for the segmented sum), vs 2 + 3 * passes (+ 2).
+#define RE_FUSED_MAX_TILES 512
+
+__device__ __forceinline__ uint32_t sc_key(int64_t r, int64_t R, int64_t padding_idx) {
+    return (r == padding_idx || r < 0 || r >= R) ? (uint32_t)R : (uint32_t)r;
+}
+
+__global__ __launch_bounds__(256) void sc_hist0(const int64_t* __restrict__ idx, int64_t n, int64_t R, int64_t padding_idx,
+                                                uint32_t* __restrict__ hist0, uint32_t* __restrict__ zero_u32, int64_t zero_words,
+                                                float* __restrict__ zero_f32, int64_t zero_floats, int64_t zero_vec, int T) {
+    __shared__ uint32_t h[256];
+    const int tid = threadIdx.x;
+    // zero fills that the later kernels rely on (independent of the histogram; blocks >= T exist only for this)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < zero_words; i += (int64_t)gridDim.x * 256) zero_u32[i] = 0u;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < zero_vec; i += (int64_t)gridDim.x * 256) reinterpret_cast<float4*>(zero_f32)[i] = z;
+    for (int64_t i = zero_vec * 4 + (int64_t)blockIdx.x * 256 + tid; i < zero_floats; i += (int64_t)gridDim.x * 256) zero_f32[i] = 0.f;
+    if ((int)blockIdx.x >= T) return;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RE_SORT_TILE;
+    int64_t r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = base + q * 256 + tid;
+        r[q] = i < n ? idx[i] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (base + q * 256 + tid < n) atomicAdd(&h[sc_key(r[q], R, padding_idx) & 255u], 1u);
+    __syncthreads();
+    hist0[(int64_t)blockIdx.x * 256 + tid] = h[tid];
+}
+
+// FIRST: keys come from idx (vals = position).  hist_next != nullptr: count the next pass's digits per OUTPUT tile.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void sc_scatter(const int64_t* __restrict__ idx, int64_t R, int64_t padding_idx,
+                                                  const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n,
+                                                  int shift, const uint32_t* __restrict__ hist, int T,
+                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                  uint32_t* __restrict__ hist_next, int shift_next) {
+    __shared__ uint32_t base[4][256];   // per wave: running output offset of each digit
+    __shared__ uint32_t wcnt[4][256];   // per wave: digit counts of its 256-key strip
+    __shared__ uint32_t wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    // ---- this block's digit bases: thread d owns digit d
+    uint32_t below = 0, total = 0;
+    {
+        const uint32_t* col = hist + tid;
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = col[(int64_t)(t + u) * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                total += x[u];
+                if (t + u < tile) below += x[u];
+            }
+        }
+        for (; t < T; ++t) {
+            const uint32_t x = col[(int64_t)t * 256];
+            total += x;
+            if (t < tile) below += x;
+        }
+    }
+    uint32_t inc = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    // ---- load this wave's strip (4 rounds of 64 keys) and count its digits
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+    uint32_t k[4], v[4];
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = (int64_t)tile * RE_SORT_TILE + wave * 256 + r * 64 + lane;
+        ok[r] = i < n;
+        k[r] = 0; v[r] = 0;
+        if (ok[r]) {
+            if (FIRST) { k[r] = sc_key(idx[i], R, padding_idx); v[r] = (uint32_t)i; }
+            else { k[r] = keys_in[i]; v[r] = vals_in[i]; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (ok[r]) atomicAdd(&wcnt[wave][(k[r] >> shift) & 255u], 1u);
+    __syncthreads();
+    {
+        uint32_t run = inc - total + below;
+        for (int w = 0; w < wave; ++w) run += wtot[w];
+        // run = first output slot of digit `tid` for this tile; split it over the 4 strips in order
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            base[w][tid] = run;
+            run += wcnt[w][tid];
+        }
+    }
+    __syncthreads();
+    // ---- stable ranking, wave-private: 4 rounds of 64 keys
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t d = (k[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(ok[r]);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = __popcll(peers & lt);
+        uint32_t off = 0;
+        if (ok[r]) off = base[wave][d] + rank;
+        __syncthreads();
+        if (ok[r] && rank == 0) base[wave][d] += __popcll(peers);
+        __syncthreads();
+        if (ok[r]) {
+            keys_out[off] = k[r];
+            vals_out[off] = v[r];
+            if (hist_next) atomicAdd(&hist_next[(int64_t)(off >> 10) * 256 + ((k[r] >> shift_next) & 255u)], 1u);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ segmented sum
 // column vectors: float4 (D % 4 == 0, 16-B aligned buffers) or float (any D: DeepFM's D = 10 and D = 1 tables)
 __device__ __forceinline__ void f4_fma(float4& a, const float4& x, float s) {
@@ -162,18 +300,18 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
         uint32_t curKey = keys[begin];
         bool isHead = true;
         V acc = vzero<V>();
-        for (int64_t j0 = begin; j0 < end; j0 += 8) {
-            uint32_t k[8];
-            V row[8];
+        for (int64_t j0 = begin; j0 < end; j0 += RE_SEG_CHUNK) {   // (one trip: every load of the chunk is in flight at once)
+            uint32_t k[RE_SEG_CHUNK];
+            V row[RE_SEG_CHUNK];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RE_SEG_CHUNK; ++u) {
                 const int64_t j = j0 + u;
                 k[u] = j < end ? keys[j] : NONE;
                 row[u] = vzero<V>();
                 if (j < end && k[u] != DROP) row[u] = reinterpret_cast<const V*>(g + (int64_t)vals[j] * D)[col];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RE_SEG_CHUNK; ++u) {
                 if (j0 + u >= end) break;
                 if (k[u] != curKey) {
                     // flush a run that ended strictly inside the chunk (cannot be the tail)
@@ -214,29 +352,118 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
     if (lir == 0) pflags[c] = flags;
 }
 
-// one lane group per chunk in which a boundary-crossing run STARTS: add the following chunks' slot-0 partials in order
+// one lane group per chunk in which a boundary-crossing run STARTS: add the following chunks' slot-0 partials in order.
+// Chains of up to 8 links (the common case) are finished by their lane group alone.  A longer chain -- a hot row: a Zipf-head
+// item, a low-cardinality DeepFM field -- is handed to the whole block: its links are split into G = 256/LPR contiguous
+// ranges summed concurrently (each in link order), and the G range sums are added in range order.  The summation tree is a
+// fixed function of the sorted keys, so the result stays bitwise reproducible.
 template <int LPR, class V>
 __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ keys, int64_t n, int64_t D,
                                                  float* __restrict__ dW, const float* __restrict__ partial,
                                                  const uint32_t* __restrict__ pflags, int64_t nchunks, int accumulate) {
-    const int lir = threadIdx.x % LPR;
-    const int64_t c = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
-    if (c >= nchunks) return;
-    if (!(pflags[c] & RE_FLAG_SLOT1)) return;
-    const int64_t end = (c * RE_SEG_CHUNK + RE_SEG_CHUNK < n) ? c * RE_SEG_CHUNK + RE_SEG_CHUNK : n;
-    const uint32_t key = keys[end - 1];
+    constexpr int G = 256 / LPR;
+    __shared__ int64_t long_c[G];
+    __shared__ int n_long;
+    __shared__ unsigned long long chain_end;
+    __shared__ V red[G][LPR];
+    const int lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const int64_t D4 = D / (int64_t)(sizeof(V) / sizeof(float));
-    for (int64_t col = lir; col < D4; col += LPR) {
-        V acc = reinterpret_cast<const V*>(partial + (c * 2 + 1) * D)[col];
-        for (int64_t cc = c + 1; cc < nchunks; ++cc) {
-            const uint32_t f = pflags[cc];
-            if (!(f & RE_FLAG_SLOT0)) break;  // cannot happen for a well-formed chain; keeps the loop bounded
-            f4_add(acc, reinterpret_cast<const V*>(partial + (cc * 2 + 0) * D)[col]);
-            if (!(f & RE_FLAG_CONT)) break;
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * G + grp;
+    if (c < nchunks && (pflags[c] & RE_FLAG_SLOT1)) {
+        const int64_t end = (c * RE_SEG_CHUNK + RE_SEG_CHUNK < n) ? c * RE_SEG_CHUNK + RE_SEG_CHUNK : n;
+        const uint32_t key = keys[end - 1];
+        bool is_long = false;
+        for (int64_t col = lir; col < D4 && !is_long; col += LPR) {
+            V acc = reinterpret_cast<const V*>(partial + (c * 2 + 1) * D)[col];
+            bool open = true;
+            uint32_t f[8];
+            V part[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {   // 8 links of the chain, loads issued together
+                const int64_t cc = (c + 1 + u < nchunks) ? c + 1 + u : nchunks - 1;
+                f[u] = (c + 1 + u < nchunks) ? pflags[cc] : 0u;
+                part[u] = reinterpret_cast<const V*>(partial + (cc * 2 + 0) * D)[col];   // (valid memory; used only on the chain)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (!open) break;
+                if (!(f[u] & RE_FLAG_SLOT0)) { open = false; break; }  // cannot happen for a well-formed chain
+                f4_add(acc, part[u]);
+                if (!(f[u] & RE_FLAG_CONT)) open = false;
+            }
+            if (open && c + 9 < nchunks) { is_long = true; break; }   // (uniform over the lane group: depends on flags only)
+            V* d = reinterpret_cast<V*>(dW + (int64_t)key * D) + col;
+            if (accumulate) f4_add(acc, *d);
+            *d = acc;
         }
-        V* d = reinterpret_cast<V*>(dW + (int64_t)key * D) + col;
-        if (accumulate) f4_add(acc, *d);
-        *d = acc;
+        if (is_long && lir == 0) long_c[atomicAdd(&n_long, 1)] = c;
+    }
+    __syncthreads();
+    const int nl = n_long;
+    for (int l = 0; l < nl; ++l) {
+        // deterministic pick: the l-th smallest registered chunk (registration order is not deterministic)
+        int64_t lc = 0;
+        {
+            int64_t prev = -1;
+            for (int q = 0; q <= l; ++q) {
+                int64_t best = INT64_MAX;
+                for (int i = 0; i < nl; ++i)
+                    if (long_c[i] > prev && long_c[i] < best) best = long_c[i];
+                prev = best;
+            }
+            lc = prev;
+        }
+        // ---- where the chain ends: the first link without CONT
+        if (threadIdx.x == 0) chain_end = ~0ull;
+        __syncthreads();
+        for (int64_t j0 = lc + 1; j0 < nchunks; j0 += 256) {
+            const int64_t cc = j0 + threadIdx.x;
+            if (cc < nchunks) {
+                const uint32_t f = pflags[cc];
+                if (!(f & RE_FLAG_CONT) || !(f & RE_FLAG_SLOT0)) atomicMin(&chain_end, (unsigned long long)cc);
+            }
+            __syncthreads();
+            if (chain_end != ~0ull) break;
+            __syncthreads();
+        }
+        __syncthreads();
+        int64_t last = (chain_end == ~0ull) ? nchunks - 1 : (int64_t)chain_end;   // last link (inclusive)
+        if (!(pflags[last] & RE_FLAG_SLOT0)) --last;                               // malformed chain guard
+        const int64_t m = last - lc;                                               // links lc+1 .. last
+        const int64_t per = (m + G - 1) / G;
+        const int64_t lo = lc + 1 + (int64_t)grp * per;
+        const int64_t hi = (lo + per < last + 1) ? lo + per : last + 1;
+        const int64_t end = (lc * RE_SEG_CHUNK + RE_SEG_CHUNK < n) ? lc * RE_SEG_CHUNK + RE_SEG_CHUNK : n;
+        const uint32_t key = keys[end - 1];
+        for (int64_t col0 = 0; col0 < D4; col0 += LPR) {
+            const int64_t col = col0 + lir;
+            V acc = vzero<V>();
+            if (col < D4) {
+                for (int64_t c0 = lo; c0 < hi; c0 += 8) {
+                    V part[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t cc = (c0 + u < hi) ? c0 + u : hi - 1;
+                        part[u] = reinterpret_cast<const V*>(partial + (cc * 2 + 0) * D)[col];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (c0 + u < hi) f4_add(acc, part[u]);
+                }
+            }
+            red[grp][lir] = acc;
+            __syncthreads();
+            if (grp == 0 && col < D4) {
+                V tot = reinterpret_cast<const V*>(partial + (lc * 2 + 1) * D)[col];
+                for (int q = 0; q < G; ++q) f4_add(tot, red[q][lir]);
+                V* d = reinterpret_cast<V*>(dW + (int64_t)key * D) + col;
+                if (accumulate) f4_add(tot, *d);
+                *d = tot;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -259,7 +486,7 @@ static ScatterWs scatter_ws_layout(void* ws, int64_t n, int64_t D) {
     w.k1 = (uint32_t*)take((size_t)n * 4);
     w.v0 = (uint32_t*)take((size_t)n * 4);
     w.v1 = (uint32_t*)take((size_t)n * 4);
-    w.hist = (uint32_t*)take((size_t)256 * w.T * 4);
+    w.hist = (uint32_t*)take((size_t)256 * w.T * 4 * 4);   // up to 4 passes of [T x 256] (fused path keeps one per pass)
     w.pflags = (uint32_t*)take((size_t)w.nchunks * 4);
     w.partial = (float*)take((size_t)w.nchunks * 2 * D * 4);
     w.bytes = off;
@@ -279,23 +506,49 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
     if (!dW || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
     if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
-    if (n == 0) return RE_OK;
+    if (n == 0) {
+        if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        return RE_OK;
+    }
     if (!g || !idx || !ws) return RE_EINVAL;
     ScatterWs w = scatter_ws_layout(ws, n, D);
     if (ws_bytes < w.bytes) return RE_EWORKSPACE;
-
-    hipLaunchKernelGGL(scatter_make_keys, dim3(re_grid(n, 256)), dim3(256), 0, s, idx, n, R, padding_idx, w.k0, w.v0);
     int bits = 1;
     while (((int64_t)1 << bits) <= R) ++bits;  // keys take values 0..R
+    const int passes = (bits + 7) / 8;
     uint32_t *ki = w.k0, *vi = w.v0, *ko = w.k1, *vo = w.v1;
-    for (int shift = 0; shift < bits; shift += 8) {
-        hipLaunchKernelGGL(radix_hist, dim3((unsigned)w.T), dim3(64), 0, s, ki, n, shift, w.hist, w.T);
-        hipLaunchKernelGGL(radix_scan, dim3(1), dim3(1024), 0, s, w.hist, (int64_t)256 * w.T);
-        hipLaunchKernelGGL(radix_scatter, dim3((unsigned)w.T), dim3(64), 0, s, ki, vi, n, shift, w.hist, w.T, ko, vo);
-        uint32_t* t;
-        t = ki; ki = ko; ko = t;
-        t = vi; vi = vo; vo = t;
+    if (w.T <= RE_FUSED_MAX_TILES) {
+        const int T = (int)w.T;
+        const int64_t hwords = (int64_t)T * 256;
+        const int64_t zfloats = accumulate ? (int64_t)0 : (int64_t)R * D;
+        int64_t zblocks = re_cdiv(zfloats, 4096);   // >= 16 KB of zero fill per block
+        if (zblocks > 2048) zblocks = 2048;
+        hipLaunchKernelGGL(sc_hist0, dim3((unsigned)(zblocks > T ? zblocks : T)), dim3(256), 0, s, idx, n, R, padding_idx, w.hist,
+                           w.hist + hwords, (int64_t)(passes - 1) * hwords, dW, zfloats,
+                           (reinterpret_cast<uintptr_t>(dW) & 15u) ? (int64_t)0 : zfloats >> 2, T);
+        for (int p = 0; p < passes; ++p) {
+            uint32_t* hn = (p + 1 < passes) ? w.hist + (int64_t)(p + 1) * hwords : (uint32_t*)nullptr;
+            if (p == 0)
+                hipLaunchKernelGGL(sc_scatter<true>, dim3((unsigned)T), dim3(256), 0, s, idx, R, padding_idx, (const uint32_t*)nullptr,
+                                   (const uint32_t*)nullptr, n, 0, w.hist, T, ko, vo, hn, 8);
+            else
+                hipLaunchKernelGGL(sc_scatter<false>, dim3((unsigned)T), dim3(256), 0, s, idx, R, padding_idx, ki, vi, n, 8 * p,
+                                   w.hist + (int64_t)p * hwords, T, ko, vo, hn, 8 * (p + 1));
+            uint32_t* t;
+            t = ki; ki = ko; ko = t;
+            t = vi; vi = vo; vo = t;
+        }
+    } else {
+        if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        hipLaunchKernelGGL(scatter_make_keys, dim3(re_grid(n, 256)), dim3(256), 0, s, idx, n, R, padding_idx, w.k0, w.v0);
+        for (int shift = 0; shift < bits; shift += 8) {
+            hipLaunchKernelGGL(radix_hist, dim3((unsigned)w.T), dim3(64), 0, s, ki, n, shift, w.hist, w.T);
+            hipLaunchKernelGGL(radix_scan, dim3(1), dim3(1024), 0, s, w.hist, (int64_t)256 * w.T);
+            hipLaunchKernelGGL(radix_scatter, dim3((unsigned)w.T), dim3(64), 0, s, ki, vi, n, shift, w.hist, w.T, ko, vo);
+            uint32_t* t;
+            t = ki; ki = ko; ko = t;
+            t = vi; vi = vo; vo = t;
+        }
     }
     const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u) == 0;
 #define SEG_LAUNCH(LPRV, VT)                                                                                                       \

@@ -17,9 +17,9 @@ SIGNATURES = {
     "re_abi_version": (_i32, []),
     "re_error_string": (ctypes.c_char_p, [_i32]),
     "re_gather_rows": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
-    "re_sasrec_embed": (_i32, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _f32, _u32, _vp, _vp]),
+    "re_sasrec_embed": (_i32, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _f32, _u32, _vp, _vp, _vp]),
     "re_sasrec_embed_bwd_workspace_bytes": (_sz, [_i64, _i64]),
-    "re_sasrec_embed_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _f32, _f32, _u32, _vp, _vp, _sz, _vp]),
+    "re_sasrec_embed_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _f32, _f32, _u32, _vp, _vp, _vp, _sz, _vp]),
     "re_scatter_add_rows_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "re_scatter_add_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
     "re_pair_loss_workspace_bytes": (_sz, [_i64]),
@@ -31,9 +31,9 @@ SIGNATURES = {
     "re_score_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_score_topk": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "re_sasrec_tape_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "re_sasrec_encoder_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "re_sasrec_encoder_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "re_sasrec_encoder_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "re_sasrec_encoder_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp,
+    "re_sasrec_encoder_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _sz, _vp, _vp, _vp]),
     "re_spmm_csr": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp, _sz, _vp]),
     "re_rows_sqnorm_workspace_bytes": (_sz, []),
@@ -50,6 +50,8 @@ SIGNATURES = {
     "re_bn_relu_drop_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_colsum": (_i32, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "re_scale_copy": (_i32, [_vp, _vp, _f32, _i64, _vp]),
+    "re_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _f64, _vp]),
+    "re_step_stage": (_i32, [_vp, _vp, _sz, _vp, _u32, _i64, _f64, _f64, _f64, _vp]),
     "re_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _vp]),
 }
 

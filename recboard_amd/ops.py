@@ -46,7 +46,7 @@ def gather_rows(W: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def sasrec_embed(E, P, seq, scale, drop_p=0.0, seed=0, out=None):
+def sasrec_embed(E, P, seq, scale, drop_p=0.0, seed=0, out=None, seed_dev=None):
     """(E[seq]*scale + P[s]) with pad rows zeroed and optional engine dropout (re_sasrec_embed)."""
     _req(E, torch.float32, "E"); _req(P, torch.float32, "P"); _req(seq, torch.int64, "seq")
     B, S = seq.shape
@@ -56,18 +56,18 @@ def sasrec_embed(E, P, seq, scale, drop_p=0.0, seed=0, out=None):
     if out is None:
         out = torch.empty((B, S, D), dtype=torch.float32, device=E.device)
     lib.check(lib.load().re_sasrec_embed(_p(E), R, D, _p(P), _p(seq), B, S, float(scale), float(drop_p),
-                                         int(seed) & 0xFFFFFFFF, _p(out), _stream()), "re_sasrec_embed")
+                                         int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(out), _stream()), "re_sasrec_embed")
     return out
 
 
-def sasrec_embed_bwd(gx, seq, scale, drop_p, seed, dP, ws=None):
+def sasrec_embed_bwd(gx, seq, scale, drop_p, seed, dP, ws=None, seed_dev=None):
     """In place on gx [B,S,D] (gradient w.r.t. x0 -> scatter contribution rows); writes dP [S,D] (re_sasrec_embed_bwd)."""
     _req(gx, torch.float32, "gx"); _req(seq, torch.int64, "seq"); _req(dP, torch.float32, "dP")
     B, S, D = gx.shape
     L = lib.load()
     if ws is None:
         ws = _ws(L.re_sasrec_embed_bwd_workspace_bytes(S, D), gx.device)
-    lib.check(L.re_sasrec_embed_bwd(_p(gx), _p(seq), B, S, D, float(scale), float(drop_p), int(seed) & 0xFFFFFFFF, _p(dP),
+    lib.check(L.re_sasrec_embed_bwd(_p(gx), _p(seq), B, S, D, float(scale), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(dP),
                                     _p(ws), ws.numel(), _stream()), "re_sasrec_embed_bwd")
     return gx
 
@@ -224,7 +224,7 @@ def seq_packing(seq, window=16):
 
 
 def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None, tape=None,
-                       packing=None):
+                       packing=None, seed_dev=None):
     """u = lastLN(blocks(x0)) fused (re_sasrec_encoder_fwd).  -> (u [B,S,D], tape or None)."""
     _req(x0, torch.float32, "x0"); _req(seq, torch.int64, "seq")
     B, S, D = x0.shape
@@ -237,13 +237,13 @@ def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, se
     if order is not None:
         _req(order, torch.int32, "order"); _req(nshort, torch.int32, "nshort")
     lib.check(Lb.re_sasrec_encoder_fwd(_p(x0), _p(seq), B, S, D, L, tbl, _p(last_w), _p(last_b), float(drop_p),
-                                       int(seed) & 0xFFFFFFFF, _p(u), _p(tape), 0 if tape is None else tape.numel() * 4,
+                                       int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(u), _p(tape), 0 if tape is None else tape.numel() * 4,
                                        _p(order), _p(nshort), _stream()), "re_sasrec_encoder_fwd")
     return u, tape
 
 
 def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b,
-                       out=None, ws=None, packing=None):
+                       out=None, ws=None, packing=None, seed_dev=None):
     """-> dx0 [B,S,D]; OVERWRITES the tensors in block_grads / g_last_* with the parameter gradients."""
     _req(dU, torch.float32, "dU"); _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape")
     B, S, D = dU.shape
@@ -255,7 +255,7 @@ def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, 
     tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
     order, nshort = packing if packing is not None else (None, None)
     lib.check(Lb.re_sasrec_encoder_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
-                                       int(seed) & 0xFFFFFFFF, _p(tape), _p(dx0), tg, _p(g_last_w), _p(g_last_b), _p(ws),
+                                       int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(tape), _p(dx0), tg, _p(g_last_w), _p(g_last_b), _p(ws),
                                        ws.numel(), _p(order), _p(nshort), _stream()), "re_sasrec_encoder_bwd")
     return dx0
 
@@ -318,6 +318,23 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
         _req(t, torch.float32, nme)
     lib.check(lib.load().re_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(beta1),
                                       float(beta2), float(eps), float(weight_decay), _stream()), "re_adam_step")
+
+
+def adam_step_dev(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """Adam with the step-dependent scalars in device memory: hyper = [lr/(1-b1^t), 1/sqrt(1-b2^t)]  (re_adam_step_dev)."""
+    for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (hyper, "hyper")):
+        _req(t, torch.float32, nme)
+    lib.check(lib.load().re_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), float(beta1), float(beta2), float(eps),
+                                          float(weight_decay), _stream()), "re_adam_step_dev")
+
+
+def step_stage(dst, src, state, seed, step, lr, beta1=0.9, beta2=0.999):
+    """dst <- src (packed batch blobs, uint8, 16-byte multiples) and state int32[4] <- step scalars  (re_step_stage)."""
+    _req(dst, torch.uint8, "dst"); _req(src, torch.uint8, "src"); _req(state, torch.int32, "state")
+    if dst.numel() != src.numel() or state.numel() < 4:
+        raise ValueError("step_stage: blob sizes differ / state too small")
+    lib.check(lib.load().re_step_stage(_p(dst), _p(src), src.numel(), _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr),
+                                       float(beta1), float(beta2), _stream()), "re_step_stage")
 
 
 def scale_copy(dst, src, alpha):

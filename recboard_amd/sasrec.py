@@ -273,26 +273,22 @@ class SASRecEngine:
                 ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
         return self._bufs[key]
 
-    def train_step_fused(self, seq, pos, neg, aux=None, grad_hook=None):
-        """One training step with every hot-path op a librecengine kernel and no autograd graph:
-        embed -> fused encoder (tape) -> fused pair loss -> loss bwd -> per-block encoder bwd (+ slab reduce)
-        -> embed bwd -> ONE deterministic scatter-add of all 3*B*S item-gradient rows -> fused Adam."""
+    def _step_body(self, seq, pos, neg, aux, sd, seed_dev=None):
+        """Every launch of the fused step up to (not including) the optimizer; gradients land in the gradient arena."""
         A, P, D = self.arena, self.params, self.D
         B, S = seq.shape
-        if aux is None:
-            aux = self.batch_aux_fused(seq, pos, neg)
         valid, rows_all, packing, vidx = aux
         W = self._buffers(B, S)
         G = A.views(A.grad)
         p = self.p_drop if self.training else 0.0
-        sd = self._step_seed()
         E, Ppos = P["Item.embeddings.weight"].detach(), P["Position.weight"].detach()
         lw, lb = P["lastLN.weight"].detach(), P["lastLN.bias"].detach()
         bt = self._block_tensors()
         kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
         n = B * S
-        ops.sasrec_embed(E, Ppos, seq, float(D ** 0.5), p, sd, out=W["x0"])
-        ops.sasrec_encoder_fwd(W["x0"], seq, bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"], packing=packing)
+        ops.sasrec_embed(E, Ppos, seq, float(D ** 0.5), p, sd, out=W["x0"], seed_dev=seed_dev)
+        ops.sasrec_encoder_fwd(W["x0"], seq, bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"], packing=packing,
+                               seed_dev=seed_dev)
         u2 = W["u"].view(n, D)
         posf, negf = pos.reshape(-1), neg.reshape(-1)
         C = W["contrib"]
@@ -309,16 +305,114 @@ class SASRecEngine:
             loss, logits, count = ops.pair_loss_fwd(u2, E, posf, negf, valid, kind, e_off=1)
             ops.pair_loss_bwd(u2, E, posf, negf, valid, kind, logits, count, None, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
         ops.sasrec_encoder_bwd(W["dU"].view(B, S, D), seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad),
-                               G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing)
-        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, G["Position.weight"], ws=W["ws_emb"])
+                               G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing,
+                               seed_dev=seed_dev)
+        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, G["Position.weight"], ws=W["ws_emb"], seed_dev=seed_dev)
         ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])
         if self.loss_kind == "CE":
             ops.gemm(logits, Uv, transA=True, beta=1.0, out=GE[1:])          # dE[1:] += dlogits^T u[valid]
+        return loss
+
+    def train_step_fused(self, seq, pos, neg, aux=None, grad_hook=None):
+        """One training step with every hot-path op a librecengine kernel and no autograd graph:
+        embed -> fused encoder (tape) -> fused pair loss -> loss bwd -> per-block encoder bwd (+ slab reduce)
+        -> embed bwd -> ONE deterministic scatter-add of all 3*B*S item-gradient rows -> fused Adam."""
+        A = self.arena
+        if aux is None:
+            aux = self.batch_aux_fused(seq, pos, neg)
+        loss = self._step_body(seq, pos, neg, aux, self._step_seed())
         if grad_hook is not None:
             grad_hook(A.grad)
         A.step += 1
         ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
         return loss.squeeze(0)
+
+    # ---- the same step as ONE hipGraph replay (the step is ~35 short launches: at B=512 the CPU launch path, not the GPU,
+    #      sets the step time).  Per step: one staging launch (packed batch -> static buffer, step scalars -> device words)
+    #      + one graph launch.  BCE / BPR only: the CE path's shapes depend on the batch's number of valid positions.
+    @staticmethod
+    def _blob_layout(B, S):
+        n, off, o = B * S, {}, 0
+        for name, nbytes in (("seq", 8 * n), ("pos", 8 * n), ("neg", 8 * n), ("rows_all", 24 * n), ("order", 4 * B), ("nshort", 4),
+                             ("valid", n)):
+            off[name] = (o, nbytes)
+            o += (nbytes + 15) // 16 * 16
+        return off, o
+
+    @staticmethod
+    def _blob_views(blob, B, S):
+        off, _ = SASRecEngine._blob_layout(B, S)
+        cut = lambda k, dt: blob[off[k][0]:off[k][0] + off[k][1]].view(dt)  # noqa: E731
+        return dict(seq=cut("seq", torch.int64).view(B, S), pos=cut("pos", torch.int64).view(B, S), neg=cut("neg", torch.int64).view(B, S),
+                    rows_all=cut("rows_all", torch.int64), order=cut("order", torch.int32), nshort=cut("nshort", torch.int32),
+                    valid=cut("valid", torch.uint8))
+
+    @staticmethod
+    def pack_batch(seq, pos, neg):
+        """Batch assembly for `train_step_graph`: (seq, pos, neg) and the index helpers of `batch_aux_fused` laid out in ONE
+        contiguous device buffer, so that a step hands its batch to the captured graph with a single copy launch."""
+        B, S = seq.shape
+        valid, rows_all, (order, nshort), _ = SASRecEngine.batch_aux_fused(seq, pos, neg)
+        _, total = SASRecEngine._blob_layout(B, S)
+        blob = torch.zeros(total, dtype=torch.uint8, device=seq.device)
+        V = SASRecEngine._blob_views(blob, B, S)
+        for k, t in (("seq", seq), ("pos", pos), ("neg", neg), ("rows_all", rows_all), ("order", order), ("nshort", nshort), ("valid", valid)):
+            V[k].copy_(t.view(V[k].shape))
+        return blob
+
+    def _capture(self, B, S, with_adam):
+        A = self.arena
+        _, total = self._blob_layout(B, S)
+        blob = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        V = self._blob_views(blob, B, S)
+        V["nshort"].zero_()
+        V["order"].copy_(torch.arange(B, dtype=torch.int32, device=self.device))
+        state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        hyper = state.view(torch.float32)[2:4]
+        aux = (V["valid"], V["rows_all"], (V["order"], V["nshort"]), None)
+
+        def body():
+            loss = self._step_body(V["seq"], V["pos"], V["neg"], aux, 0, seed_dev=state)
+            if with_adam:
+                ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
+            return loss
+
+        # warm-up on a side stream (one-time kernel attributes, workspace allocation) with an all-padding batch, then restore
+        # everything the warm-up touched; the capture itself only records.
+        keep = [t.clone() for t in (A.data, A.m, A.v, A.grad)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.step_stage(blob, blob.clone(), state, 0, 1, self.lr, *self.betas)
+            body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            loss = body()
+        for t, k in zip((A.data, A.m, A.v, A.grad), keep):
+            t.copy_(k)
+        return dict(graph=graph, blob=blob, state=state, loss=loss)
+
+    def train_step_graph(self, blob, B, S, grad_hook=None):
+        """`train_step_fused` on a batch from `pack_batch`, replayed from a captured hipGraph.  Results are identical to the
+        eager fused step.  The returned loss tensor is overwritten by the next call."""
+        if self.loss_kind == "CE":
+            raise NotImplementedError("graph replay: BCE / BPR only (CE shapes vary with the batch)")
+        A = self.arena
+        key = (B, S, grad_hook is None, self.training)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
+        g = self._graphs[key]
+        ops.step_stage(g["blob"], blob, g["state"], self._step_seed(), A.step + 1, self.lr, *self.betas)
+        g["graph"].replay()
+        A.step += 1
+        if grad_hook is not None:
+            grad_hook(A.grad)
+            ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        return g["loss"].squeeze(0)
 
     # ---- CoachForSASRec.train_per_epoch body (SASRec/main.py:243-250): zero_grad, backward, Adam step
     def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
