@@ -5,9 +5,9 @@
 // 16 GEMMs of 64^3 per sequence per block (2 per linear map: dX = dY W and dW += dY^T X).  Layer-normed operands
 // (LN_a(x), LN_f(x1)) are rebuilt from the saved statistics; dropout masks are regenerated from (seed, stream, index).
 //
-// Parameter gradients: each wave keeps its 16x64 strip of the six 64x64 weight gradients in registers (96 VGPRs)
-// across all the sequences its persistent workgroup processes; bias / LayerNorm gradients are per-thread column
-// partials.  At the end every workgroup writes ONE slab (27 648 floats); sasrec_grad_reduce sums the slabs in a
+// Parameter gradients: each wave keeps its SE_RT 16x16 tiles of the six 64x64 weight gradients in registers (24 VGPRs
+// at 16 waves) across all the work items its persistent workgroup processes; bias / LayerNorm gradients are per-thread
+// column partials.  At the end every workgroup writes ONE slab (SB_SLAB floats); sasrec_grad_reduce sums the slabs in a
 // fixed order straight into the gradient tensors: deterministic, no float atomics (cdna_hip_programming.md G12).
 //
 // MFMA-bound: 16 GEMMs x 2*64^3 = 8.39 MFLOP per sequence per block.
@@ -17,49 +17,51 @@
 
 #define SB_NMAT 6
 #define SB_NVEC 12
-#define SB_SLAB (SB_NMAT * 4096 + SB_NVEC * 256)
+#define SB_SLAB (SB_NMAT * 4096 + SB_NVEC * SE_NT)
 // matrix slots: 0 Wq 1 Wk 2 Wv 3 Wo 4 W1 5 W2;  vector slots: 0 bq 1 bk 2 bv 3 bo 4 b1 5 b2 6 ga 7 ba 8 gf 9 bf 10 glast 11 blast
 
 template <bool A_KC>
-__device__ __forceinline__ void gemm64_acc(const float* A, const float (&bf)[16], int lane, f32x4 (&acc)[4]) {
+__device__ __forceinline__ void gemm64_acc(const float* A, const float (&bf)[16], int lane, int wr, f32x4 (&acc)[SE_RT]) {
     const int g = lane >> 4, c = lane & 15;
-    float af[4][16];
+    float af[SE_RT][16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (A_KC) frag_kc(af[t], A + (16 * t + c) * SE_LS + 16 * g);
-        else frag_ks(af[t], A + (16 * g) * SE_LS + 16 * t + c, SE_LS);
+    for (int t = 0; t < SE_RT; ++t) {
+        const int tt = wr * SE_RT + t;
+        if (A_KC) frag_kc(af[t], A + SE_RO(16 * tt + c) + 16 * g);
+        else frag_ks(af[t], A + SE_RO(16 * g) + 16 * tt + c, SE_LS);
     }
+    __builtin_amdgcn_sched_barrier(0);   // (see gemm64: fragment loads first, then the MFMAs back to back)
 #pragma unroll
     for (int s = 0; s < 16; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
+        for (int t = 0; t < SE_RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// sum over this thread's 16 rows of one column
+// column sums: thread (column tid & 63, row group tid >> 6) covers rows [SE_RPW * (tid >> 6), +SE_RPW)
 __device__ __forceinline__ float colsum16(const float* tile, int tid) {
-    const int c = tid & 63, r0 = (tid >> 6) * 16;
+    const int c = tid & 63, r0 = (tid >> 6) * SE_RPW;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += tile[(r0 + i) * SE_LS + c];
+    for (int i = 0; i < SE_RPW; ++i) s += tile[SE_RO(r0 + i) + c];
     return s;
 }
-// sum over this thread's 16 rows of w[row] * tile[row][col]
+// sum over the thread's rows of w[row] * tile[row][col]
 __device__ __forceinline__ float colsum16_w(const float* tile, const float* w, int tid) {
-    const int c = tid & 63, r0 = (tid >> 6) * 16;
+    const int c = tid & 63, r0 = (tid >> 6) * SE_RPW;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s = fmaf(w[r0 + i], tile[(r0 + i) * SE_LS + c], s);
+    for (int i = 0; i < SE_RPW; ++i) s = fmaf(w[r0 + i], tile[SE_RO(r0 + i) + c], s);
     return s;
 }
-// sum over 16 rows of dy * xhat, xhat = (x - mean[row]) * rstd[row]
+// sum over the thread's rows of dy * xhat, xhat = (x - mean[row]) * rstd[row]
 __device__ __forceinline__ float colsum16_xhat(const float* dy, const float* x, const float* mean, const float* rstd, int tid) {
-    const int c = tid & 63, r0 = (tid >> 6) * 16;
+    const int c = tid & 63, r0 = (tid >> 6) * SE_RPW;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < SE_RPW; ++i) {
         const int r = r0 + i;
-        s = fmaf(dy[r * SE_LS + c], (x[r * SE_LS + c] - mean[r]) * rstd[r], s);
+        s = fmaf(dy[SE_RO(r) + c], (x[SE_RO(r) + c] - mean[r]) * rstd[r], s);
     }
     return s;
 }
@@ -67,34 +69,34 @@ __device__ __forceinline__ float colsum16_xhat(const float* dy, const float* x, 
 template <bool ACCUM>
 __device__ __forceinline__ void ln_bwd_row(const float* dy, const float* x, float* dst, const float* __restrict__ gamma,
                                            const float* mean, const float* rstd, int tid) {
-    const int r = tid >> 2, c0 = (tid & 3) * 16;
-    float d[16], xv[16];
-    frag_kc(d, dy + r * SE_LS + c0);
-    frag_kc(xv, x + r * SE_LS + c0);
+    const int r = tid / SE_TPR, c0 = (tid % SE_TPR) * SE_CPT;
+    float d[SE_CPT], xv[SE_CPT];
+    frag_row(d, dy + SE_RO(r) + c0);
+    frag_row(xv, x + SE_RO(r) + c0);
     const float mu = mean[r], rs = rstd[r];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < SE_CPT; ++i) {
         xv[i] = (xv[i] - mu) * rs;
         d[i] *= gamma[c0 + i];
         s1 += d[i];
         s2 = fmaf(d[i], xv[i], s2);
     }
-    s1 = quad_sum(s1) * (1.0f / SE_D);
-    s2 = quad_sum(s2) * (1.0f / SE_D);
+    s1 = row_sum(s1) * (1.0f / SE_D);
+    s2 = row_sum(s2) * (1.0f / SE_D);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < SE_CPT; ++i) {
         const float v = rs * (d[i] - s1 - xv[i] * s2);
-        if (ACCUM) dst[r * SE_LS + c0 + i] += v; else dst[r * SE_LS + c0 + i] = v;
+        if (ACCUM) dst[SE_RO(r) + c0 + i] += v; else dst[SE_RO(r) + c0 + i] = v;
     }
 }
 // y = (x - mean) * rstd * gamma + beta from saved statistics
 __device__ __forceinline__ void ln_apply_row(const float* x, float* dst, const float* __restrict__ gw, const float* __restrict__ gb,
                                              const float* mean, const float* rstd, int tid) {
-    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    const int r = tid / SE_TPR, c0 = (tid % SE_TPR) * SE_CPT;
     const float mu = mean[r], rs = rstd[r];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dst[r * SE_LS + c0 + i] = (x[r * SE_LS + c0 + i] - mu) * rs * gw[c0 + i] + gb[c0 + i];
+    for (int i = 0; i < SE_CPT; ++i) dst[SE_RO(r) + c0 + i] = (x[SE_RO(r) + c0 + i] - mu) * rs * gw[c0 + i] + gb[c0 + i];
 }
 
 __device__ __forceinline__ void load_stats(float* s_a, float* s_b, const float* __restrict__ st, const int* s_gid, int tid) {
@@ -105,8 +107,14 @@ __device__ __forceinline__ void load_stats(float* s_a, float* s_b, const float* 
     }
 }
 
+#ifdef SE_PROFILE
+extern "C" int re_dbg_encoder_marks_bwd(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_se_marks), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
+}
+#endif
+
 template <bool FIRST>
-__global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restrict__ dIn, const int64_t* __restrict__ seq, int B, int S,
+__global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restrict__ dIn, const int64_t* __restrict__ seq, int B, int S,
                                                           int l, SasrecBlockParams W0, const float* __restrict__ last_w0,
                                                           float drop_scale, uint32_t thresh, uint32_t seed,
                                                           const float* __restrict__ tape, SasrecTape T,
@@ -122,30 +130,36 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
     float* b4 = b3 + SE_BUF;
     float* b5 = b4 + SE_BUF;
     float* b6 = b5 + SE_BUF;
+    float* bW0 = b6 + SE_BUF;   // two staged weight matrices (see wtile_fetch)
+    float* bW1 = bW0 + SE_BUF;
     __shared__ float s_mean[SE_ROWS], s_rstd[SE_ROWS];
     __shared__ float s_ppad[SE_ROWS], s_w[SE_ROWS], s_cpad[SE_ROWS];   // virtual pad key: prob of one copy, total kept weight, dS
     __shared__ int s_gid[SE_ROWS], s_grp[SE_ROWS], s_pad[SE_ROWS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, c = lane & 15, col = 16 * wave + c;
+    const int tid0 = threadIdx.x;
     const float* tp = tape + (int64_t)l * T.per_block;
     const SeWork WK = se_work(B, nshort_ptr);
 
-    f32x4 accW[SB_NMAT][4];
+    f32x4 accW[SB_NMAT][SE_RT];
 #pragma unroll
     for (int m = 0; m < SB_NMAT; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) accW[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < SE_RT; ++t) accW[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float accV[SB_NVEC];
 #pragma unroll
     for (int v = 0; v < SB_NVEC; ++v) accV[v] = 0.f;
 
     for (int wi = blockIdx.x; wi < WK.total; wi += gridDim.x) {
+        SE_THREAD_VARS(tid0);
         const SasrecBlockParams W = se_launder(W0);
         const float* last_w = se_launder(last_w0);
         __syncthreads();
+        SE_MARK(1, 0);
         const int n_out = se_decode(wi, WK, B, S, order, seq, tid, s_gid, s_grp, s_pad);
         __syncthreads();
+        SE_MARK(1, 1);
+        float4 R[SE_WV];                 // the next weight matrix, in flight from global memory
+        wtile_fetch(R, W.w2, tid);
         tile_load(b0, dIn, s_gid, tid);
         if (FIRST) {
             tile_load(b1, tape + T.off_XL, s_gid, tid);
@@ -159,35 +173,42 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
             ln_bwd_row<false>(b0, b1, b0, last_w, s_mean, s_rstd, tid);
             __syncthreads();
         }
+        SE_MARK(1, 2);
         // ---- pad mask of the block output (x'[pad] = 0) and dO2 = dX' * dropout2 mask
         tile_load(b1, tp + T.off_HR, s_gid, tid);
         {
-            const int r = tid >> 2, c0 = (tid & 3) * 16;
+            const int r = r_e, c0 = c0_e;
             const bool dead = s_pad[r] != 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = dead ? 0.f : b0[r * SE_LS + c0 + i];
-                b0[r * SE_LS + c0 + i] = v;
+            for (int i = 0; i < SE_CPT; ++i) {
+                float v = dead ? 0.f : b0[SE_RO(r) + c0 + i];
+                b0[SE_RO(r) + c0 + i] = v;
                 if (thresh) {
                     const uint32_t e = (uint32_t)((int64_t)s_gid[r] * SE_D + c0 + i);
                     v = re_keep(seed, RE_STREAM_FFN2(l), e, thresh) ? v * drop_scale : 0.f;
                 }
-                b2[r * SE_LS + c0 + i] = v;
+                b2[SE_RO(r) + c0 + i] = v;
             }
         }
+        wtile_commit(bW0, R, tid);       // W2
+        wtile_fetch(R, W.w1, tid);
         __syncthreads();
+        SE_MARK(1, 3);
         // ---- A. FFN second map: dW2 += dO2^T hr; db2; dH = (dO2 W2) * (hr > 0) * scale
         {
             float bf[16];
-            frag_ks(bf, b1 + (16 * g) * SE_LS + col, SE_LS);
-            gemm64_acc<false>(b2, bf, lane, accW[5]);
+            wtile_commit(bW1, R, tid);   // W1
+            wtile_fetch(R, W.out_w, tid);
+            frag_ks(bf, b1 + SE_RO(16 * g) + col, SE_LS);
+            gemm64_acc<false>(b2, bf, lane, wr, accW[5]);
             accV[5] += colsum16(b2, tid);
-            wfrag_ks(bf, W.w2, wave, lane);
-            gemm64<true>(b2, bf, lane, [&](int row, float v) {
-                b3[row * SE_LS + col] = (b1[row * SE_LS + col] > 0.f) ? v * drop_scale : 0.f;
+            wtile_frag_n(bf, bW0, wc, lane);
+            gemm64<true>(b2, bf, lane, wr, [&](int row, float v) {
+                b3[SE_RO(row) + col] = (b1[SE_RO(row) + col] > 0.f) ? v * drop_scale : 0.f;
             });
         }
         __syncthreads();
+        SE_MARK(1, 4);
         // ---- B. FFN first map: y = LN_f(x1) rebuilt; dW1 += dH^T y; db1; dY = dH W1 + dX'
         tile_load(b1, tp + T.off_X1, s_gid, tid);
         load_stats(s_mean, s_rstd, tp + T.off_SF, s_gid, tid);
@@ -196,105 +217,118 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
         __syncthreads();
         {
             float bf[16];
-            frag_ks(bf, b2 + (16 * g) * SE_LS + col, SE_LS);
-            gemm64_acc<false>(b3, bf, lane, accW[4]);
+            wtile_commit(bW0, R, tid);   // Wo  (bW0's last reader, GEMM A, finished before phase A's closing barrier)
+            wtile_fetch(R, W.in_w, tid);
+            frag_ks(bf, b2 + SE_RO(16 * g) + col, SE_LS);
+            gemm64_acc<false>(b3, bf, lane, wr, accW[4]);
             accV[4] += colsum16(b3, tid);
-            wfrag_ks(bf, W.w1, wave, lane);
-            gemm64<true>(b3, bf, lane, [&](int row, float v) { b0[row * SE_LS + col] += v; });
+            wtile_frag_n(bf, bW1, wc, lane);
+            gemm64<true>(b3, bf, lane, wr, [&](int row, float v) { b0[SE_RO(row) + col] += v; });
         }
         __syncthreads();
+        SE_MARK(1, 5);
         // ---- C. LN_f backward: dgamma_f, dbeta_f, dX1 (in place in b0)
         accV[8] += colsum16_xhat(b0, b1, s_mean, s_rstd, tid);
         accV[9] += colsum16(b0, tid);
         __syncthreads();
         ln_bwd_row<false>(b0, b1, b0, W.ln_f_w, s_mean, s_rstd, tid);
         __syncthreads();
+        SE_MARK(1, 6);
         // ---- D. out_proj: dWo += dX1^T o; dbo; dO = dX1 Wo
         tile_load(b2, tp + T.off_O, s_gid, tid);
         __syncthreads();
         {
             float bf[16];
-            frag_ks(bf, b2 + (16 * g) * SE_LS + col, SE_LS);
-            gemm64_acc<false>(b0, bf, lane, accW[3]);
+            wtile_commit(bW1, R, tid);   // Wq  (bW1's last reader, GEMM B, finished before phase B's closing barrier)
+            wtile_fetch(R, W.in_w + SE_D * SE_D, tid);
+            frag_ks(bf, b2 + SE_RO(16 * g) + col, SE_LS);
+            gemm64_acc<false>(b0, bf, lane, wr, accW[3]);
             accV[3] += colsum16(b0, tid);
-            wfrag_ks(bf, W.out_w, wave, lane);
-            gemm64<true>(b0, bf, lane, [&](int row, float v) { b3[row * SE_LS + col] = v; });
+            wtile_frag_n(bf, bW0, wc, lane);
+            gemm64<true>(b0, bf, lane, wr, [&](int row, float v) { b3[SE_RO(row) + col] = v; });
         }
         __syncthreads();
+        SE_MARK(1, 7);
         // ---- E. attention: load V, P; Pd = P*mask; dP = (dO V^T)*mask; dV = Pd^T dO; dS = P (dP - rowsum(dP P)) / sqrt(D)
         tile_load(b1, tp + T.off_V, s_gid, tid);
         load_stats(s_ppad, s_w, tp + T.off_PP, s_gid, tid);   // (p_pad, w) of the virtual out-of-window pad key
         {
             const float* Pg = tp + T.off_P;
-            const int i = tid >> 2, j0 = (tid & 3) * 16;
+            const int i = r_e, j0 = c0_e;
             const int gi = s_gid[i], grp = s_grp[i];
             const int sbase = gi >= 0 ? (gi / S) * S : 0;
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
+            for (int jj = 0; jj < SE_CPT; ++jj) {
                 const int j = j0 + jj;
                 const bool ok = gi >= 0 && j <= i && s_gid[j] >= 0 && s_grp[j] == grp;
                 const int sj = ok ? s_gid[j] - sbase : 0;
                 float p = ok ? Pg[(int64_t)gi * S + sj] : 0.f;
                 float m = 1.0f;
                 if (thresh && p != 0.f) m = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? drop_scale : 0.f;
-                b4[i * SE_LS + j] = p;
-                b6[i * SE_LS + j] = p * m;
+                b4[SE_RO(i) + j] = p;
+                b6[SE_RO(i) + j] = p * m;
             }
         }
         __syncthreads();
+        SE_MARK(1, 8);
         {
             float bf[16];
-            frag_kc(bf, b1 + (16 * wave + c) * SE_LS + 16 * g);  // B^T = V (k = d contiguous)
-            gemm64<true>(b3, bf, lane, [&](int row, float v) {
+            frag_kc(bf, b1 + SE_RO(16 * wc + c) + 16 * g);  // B^T = V (k = d contiguous)
+            gemm64<true>(b3, bf, lane, wr, [&](int row, float v) {
                 // grad w.r.t. the pre-dropout probability: scale by the same mask factor Pd/P (0, or 1/(1-p))
-                const float p = b4[row * SE_LS + col];
-                const float pd = b6[row * SE_LS + col];
-                b5[row * SE_LS + col] = (p != 0.f) ? v * (pd / p) : 0.f;
+                const float p = b4[SE_RO(row) + col];
+                const float pd = b6[SE_RO(row) + col];
+                b5[SE_RO(row) + col] = (p != 0.f) ? v * (pd / p) : 0.f;
             });
-            frag_ks(bf, b3 + (16 * g) * SE_LS + col, SE_LS);     // B[k=i][n=d] = dO
-            gemm64<false>(b6, bf, lane, [&](int row, float v) { b2[row * SE_LS + col] = v; });  // dV
+            frag_ks(bf, b3 + SE_RO(16 * g) + col, SE_LS);     // B[k=i][n=d] = dO
+            gemm64<false>(b6, bf, lane, wr, [&](int row, float v) { b2[SE_RO(row) + col] = v; });  // dV
         }
         if (n_out > 0) accV[2] += colsum16_w(b3, s_w, tid);     // d b_v through the virtual pad key: sum_i w_i dO_i
         __syncthreads();
+        SE_MARK(1, 9);
         {
-            const int i = tid >> 2, j0 = (tid & 3) * 16;
-            float dp[16], pp[16];
-            frag_kc(dp, b5 + i * SE_LS + j0);
-            frag_kc(pp, b4 + i * SE_LS + j0);
+            const int i = r_e, j0 = c0_e;
+            float dp[SE_CPT], pp[SE_CPT];
+            frag_row(dp, b5 + SE_RO(i) + j0);
+            frag_row(pp, b4 + SE_RO(i) + j0);
             float s = 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) s = fmaf(dp[jj], pp[jj], s);
-            s = quad_sum(s);
+            for (int jj = 0; jj < SE_CPT; ++jj) s = fmaf(dp[jj], pp[jj], s);
+            s = row_sum(s);
             if (n_out > 0) {
                 // virtual pad key: upstream grad of each copy = (dO_i . b_v) * mask; t = dO_i . b_v
                 float t = 0.f;
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) t = fmaf(b3[i * SE_LS + j0 + jj], W.in_b[2 * SE_D + j0 + jj], t);
-                t = quad_sum(t);
+                for (int jj = 0; jj < SE_CPT; ++jj) t = fmaf(b3[SE_RO(i) + j0 + jj], W.in_b[2 * SE_D + j0 + jj], t);
+                t = row_sum(t);
                 const float wv = s_w[i], ppad = s_ppad[i];
                 s = fmaf(t, wv, s);                                            // rowdot includes the pad copies
-                if ((tid & 3) == 0) s_cpad[i] = (wv * t - (float)n_out * ppad * s) * 0.125f;   // sum of dS over the copies
+                if (row_lead) s_cpad[i] = (wv * t - (float)n_out * ppad * s) * 0.125f;   // sum of dS over the copies
             }
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) b5[i * SE_LS + j0 + jj] = pp[jj] * (dp[jj] - s) * 0.125f;
+            for (int jj = 0; jj < SE_CPT; ++jj) b5[SE_RO(i) + j0 + jj] = pp[jj] * (dp[jj] - s) * 0.125f;
         }
         __syncthreads();   // dS complete; dO (b3), V (b1) and P (b4) no longer needed
+        SE_MARK(1, 10);
         // ---- F. dQ = dS K -> b4 ; dK = dS^T Q -> b6
         tile_load(b3, tp + T.off_Q, s_gid, tid);
         tile_load(b1, tp + T.off_K, s_gid, tid);
         __syncthreads();
         {
             float bf[16];
-            frag_ks(bf, b1 + (16 * g) * SE_LS + col, SE_LS);
+            wtile_commit(bW0, R, tid);   // Wk  (bW0's last reader, GEMM D, is several barriers back)
+            wtile_fetch(R, W.in_w + 2 * SE_D * SE_D, tid);
+            frag_ks(bf, b1 + SE_RO(16 * g) + col, SE_LS);
             const float bkc = (n_out > 0) ? W.in_b[SE_D + col] : 0.f;
-            gemm64<true>(b5, bf, lane, [&](int row, float v) {
-                b4[row * SE_LS + col] = (n_out > 0) ? fmaf(s_cpad[row], bkc, v) : v;   // + dS_pad * b_k
+            gemm64<true>(b5, bf, lane, wr, [&](int row, float v) {
+                b4[SE_RO(row) + col] = (n_out > 0) ? fmaf(s_cpad[row], bkc, v) : v;   // + dS_pad * b_k
             });
-            frag_ks(bf, b3 + (16 * g) * SE_LS + col, SE_LS);
-            gemm64<false>(b5, bf, lane, [&](int row, float v) { b6[row * SE_LS + col] = v; });
+            frag_ks(bf, b3 + SE_RO(16 * g) + col, SE_LS);
+            gemm64<false>(b5, bf, lane, wr, [&](int row, float v) { b6[SE_RO(row) + col] = v; });
             if (n_out > 0) accV[1] += colsum16_w(b3, s_cpad, tid);   // d b_k through the virtual pad key: sum_i dS_pad_i q_i
         }
         __syncthreads();
+        SE_MARK(1, 11);
         // ---- G. projections: x, LN_a(x) rebuilt; dWq/dWk/dWv, biases; dA1 = dQ Wq -> b5; dX (b0) += dK Wk + dV Wv
         tile_load(b1, tp + T.off_X, s_gid, tid);
         load_stats(s_mean, s_rstd, tp + T.off_SA, s_gid, tid);
@@ -303,40 +337,47 @@ __global__ __launch_bounds__(256) void sasrec_block_bwd_k(const float* __restric
         __syncthreads();
         {
             float bf[16];
-            frag_ks(bf, b3 + (16 * g) * SE_LS + col, SE_LS);     // LN_a(x)
-            gemm64_acc<false>(b4, bf, lane, accW[0]);
-            frag_ks(bf, b1 + (16 * g) * SE_LS + col, SE_LS);     // x
-            gemm64_acc<false>(b6, bf, lane, accW[1]);
-            gemm64_acc<false>(b2, bf, lane, accW[2]);
+            frag_ks(bf, b3 + SE_RO(16 * g) + col, SE_LS);     // LN_a(x)
+            gemm64_acc<false>(b4, bf, lane, wr, accW[0]);
+            frag_ks(bf, b1 + SE_RO(16 * g) + col, SE_LS);     // x
+            gemm64_acc<false>(b6, bf, lane, wr, accW[1]);
+            gemm64_acc<false>(b2, bf, lane, wr, accW[2]);
             accV[0] += colsum16(b4, tid);
             accV[1] += colsum16(b6, tid);
             accV[2] += colsum16(b2, tid);
-            wfrag_ks(bf, W.in_w, wave, lane);
-            gemm64<true>(b4, bf, lane, [&](int row, float v) { b5[row * SE_LS + col] = v; });
-            wfrag_ks(bf, W.in_w + SE_D * SE_D, wave, lane);
-            gemm64<true>(b6, bf, lane, [&](int row, float v) { b0[row * SE_LS + col] += v; });
-            wfrag_ks(bf, W.in_w + 2 * SE_D * SE_D, wave, lane);
-            gemm64<true>(b2, bf, lane, [&](int row, float v) { b0[row * SE_LS + col] += v; });
+            wtile_frag_n(bf, bW1, wc, lane);                   // Wq
+            gemm64<true>(b4, bf, lane, wr, [&](int row, float v) { b5[SE_RO(row) + col] = v; });
+            wtile_frag_n(bf, bW0, wc, lane);                   // Wk
+            gemm64<true>(b6, bf, lane, wr, [&](int row, float v) { b0[SE_RO(row) + col] += v; });
+            __syncthreads();                                   // every wave is done with Wq
+            wtile_commit(bW1, R, tid);                         // Wv
+            __syncthreads();
+            wtile_frag_n(bf, bW1, wc, lane);
+            gemm64<true>(b2, bf, lane, wr, [&](int row, float v) { b0[SE_RO(row) + col] += v; });
         }
         __syncthreads();
+        SE_MARK(1, 12);
         // ---- H. LN_a backward: dgamma_a, dbeta_a; dX += LN_a'(dA1)
         accV[6] += colsum16_xhat(b5, b1, s_mean, s_rstd, tid);
         accV[7] += colsum16(b5, tid);
         ln_bwd_row<true>(b5, b1, b0, W.ln_a_w, s_mean, s_rstd, tid);
         __syncthreads();
+        SE_MARK(1, 13);
         tile_store(b0, dOut, s_gid, tid);
+        SE_MARK(1, 14);
     }
 
     // ---- this workgroup's slab
+    SE_THREAD_VARS(tid0);
     float* sl = slab + (int64_t)blockIdx.x * SB_SLAB;
 #pragma unroll
     for (int m = 0; m < SB_NMAT; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < SE_RT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sl[m * 4096 + (16 * t + 4 * g + j) * SE_D + col] = accW[m][t][j];
+            for (int j = 0; j < 4; ++j) sl[m * 4096 + (16 * (wr * SE_RT + t) + 4 * g + j) * SE_D + col] = accW[m][t][j];
 #pragma unroll
-    for (int v = 0; v < SB_NVEC; ++v) sl[SB_NMAT * 4096 + v * 256 + tid] = accV[v];
+    for (int v = 0; v < SB_NVEC; ++v) sl[SB_NMAT * 4096 + v * SE_NT + tid] = accV[v];
 }
 
 struct SasrecGradDst {
@@ -374,8 +415,11 @@ __global__ __launch_bounds__(256) void sasrec_grad_reduce(const float* __restric
         const int v = (e - NM) >> 6, cc = (e - NM) & 63;
         float s = 0.f;
         for (int w = 0; w < ngroups; ++w) {
-            const float* q = part + (int64_t)w * SB_SLAB + NM + v * 256 + cc;
-            s += ((q[0] + q[64]) + q[128]) + q[192];
+            const float* q = part + (int64_t)w * SB_SLAB + NM + v * SE_NT + cc;
+            float t = q[0];
+#pragma unroll
+            for (int i = 1; i < SE_NW; ++i) t += q[64 * i];   // the SE_NW row-group partials of this column, in order
+            s += t;
         }
         float* d;
         switch (v) {
@@ -429,7 +473,7 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     float* part = slab + (size_t)nwg * SB_SLAB;
     float* dxa = part + (size_t)ngroups * SB_SLAB;
     float* dxb = dxa + (size_t)B * S * D;
-    const size_t ldsb = (size_t)7 * SE_BUF * sizeof(float);
+    const size_t ldsb = (size_t)9 * SE_BUF * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     auto kf = sasrec_block_bwd_k<true>;
     auto kn = sasrec_block_bwd_k<false>;
@@ -446,10 +490,10 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
         float* dout = (l == 0) ? dx0 : (((L - 1 - l) & 1) ? dxb : dxa);
         const bool first = (l == L - 1);
         if (first)
-            hipLaunchKernelGGL(kf, dim3(nwg), dim3(256), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
+            hipLaunchKernelGGL(kf, dim3(nwg), dim3(SE_NT), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
                                (const float*)tape, T, dout, slab, order, nshort, seed_dev);
         else
-            hipLaunchKernelGGL(kn, dim3(nwg), dim3(256), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
+            hipLaunchKernelGGL(kn, dim3(nwg), dim3(SE_NT), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
                                (const float*)tape, T, dout, slab, order, nshort, seed_dev);
         SasrecGradDst dst;
         for (int i = 0; i < 12; ++i) dst.p[i] = block_grads[12 * l + i];

@@ -1,9 +1,13 @@
-// Shared device helpers for the fused SASRec encoder kernels (D = 64, S <= 64; one workgroup = one sequence).
+// Shared device helpers for the fused SASRec encoder kernels (D = 64, S <= 64; one workgroup = one work item).
 //
-// All per-sequence activations live in LDS as [64 rows][SE_LS floats] row-major tiles (rows >= S are zero / unused);
-// every product is a 64x64x64 GEMM on v_mfma_f32_16x16x4_f32 (exact fp32), wave w of the 4 waves owning output
-// columns [16w, 16w+16).  The k index of an MFMA step is free as long as A and B agree, so lane group g = lane>>4
-// takes k = 16g + s at step s: a k-contiguous operand fragment is then 16 consecutive floats (4 x ds_read_b128 or
+// All per-item activations live in LDS as [64 rows][SE_LS floats] row-major tiles (rows >= S are zero / unused);
+// every product is a 64x64x64 GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).  A workgroup is SE_NW waves arranged as
+// 4 column strips x SE_WR row groups: wave (wr, wc) owns output columns [16 wc, +16) of the SE_RT 16-row tiles
+// [wr * SE_RT, +SE_RT).  A batch is at most a few hundred work items -- fewer than one per CU -- so a kernel's time is
+// the latency of ONE item; 16 waves (4 per SIMD) cut every per-wave serial section (fragment loads, epilogues, the
+// row-wise phases) by 4 against a 4-wave layout and let the SIMD overlap one wave's LDS / L2 round trips with another
+// wave's MFMAs.  The k index of an MFMA step is free as long as A and B agree, so lane group g = lane>>4 takes
+// k = 16g + s at step s: a k-contiguous operand fragment is then 16 consecutive floats (4 x ds_read_b128 or
 // 4 x global_load_dwordx4), which is how weights W[out][in] (y = x W^T) and row-major activations are consumed
 // without any transposed copies.
 #pragma once
@@ -12,10 +16,33 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Phase timing (debug builds only: make CXXFLAGS+=-DSE_PROFILE): workgroup 0 / thread 0 records the shader clock at phase
+// boundaries of its first work item; scripts/prof_encoder.py reads the marks through re_dbg_encoder_marks.
+#ifdef SE_PROFILE
+static __device__ unsigned long long g_se_marks[64];   // one copy per translation unit (fwd / bwd)
+#define SE_MARK(which, i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && wi == (int)blockIdx.x) g_se_marks[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SE_MARK(which, i) do { } while (0)
+#endif
+
 #define SE_D 64
 #define SE_ROWS 64
+#ifndef SE_NW
+#define SE_NW 16                 // waves per workgroup (4, 8 or 16)
+#endif
+#define SE_NT (64 * SE_NW)       // threads per workgroup
+#define SE_WR (SE_NW / 4)        // wave row groups
+#define SE_RT (4 / SE_WR)        // 16-row output tiles per wave
+#define SE_TPR (SE_NT / SE_ROWS) // row-wise phases: threads per row ...
+#define SE_CPT (SE_D / SE_TPR)   // ... and columns per thread (16 / 8 / 4)
+#define SE_RPW (SE_ROWS / SE_NW) // column-sum phases: rows per thread (thread = (column tid & 63, row group tid >> 6))
 #define SE_LS 68  // LDS row stride in floats (16-B pad: conflict-free b128 fragment reads)
-#define SE_BUF (SE_ROWS * SE_LS)
+// Row r of a tile starts at SE_RO(r): stride SE_LS plus 16 floats per 16-row group.  A k-strided fragment read has lane
+// group g on row 16g + s; with a plain even stride the four groups land on the same banks (16 * SE_LS = 0 mod 32: a 4-way
+// conflict on every ds_read_b32 of a transposed operand); the group offset puts groups g and g+1 on disjoint halves
+// of the 32 banks.  Rows inside one 16-row group keep the constant stride SE_LS.
+#define SE_RO(r) ((r) * SE_LS + (((r) >> 4) << 4))
+#define SE_BUF (SE_ROWS * SE_LS + 64)
 
 struct SasrecBlockParams {
     const float *ln_a_w, *ln_a_b;   // attnLNs.l
@@ -75,11 +102,34 @@ __device__ __forceinline__ SasrecBlockParams se_launder(SasrecBlockParams W) {
     return W;
 }
 
+// Every LDS / tape address in the kernels is a function of the thread index only, i.e. invariant across the work-item loop
+// (and the forward's block loop).  hipcc hoists all of them out of the loops, runs out of registers, spills them, and
+// then reloads each one from scratch memory -- a full memory round trip -- right where it is needed (measured: the
+// epilogue of one 64^3 GEMM cost more than its MFMAs).  Re-deriving the index variables from a laundered thread id at
+// the top of each iteration makes the addresses loop-variant: they are recomputed with a few VALU ops instead.
+#define SE_THREAD_VARS(tid0)                                                                      \
+    int tid = (tid0);                                                                             \
+    asm volatile("" : "+v"(tid));                                                                 \
+    const int lane = tid & 63, wave = tid >> 6;                                                   \
+    const int wc = wave & 3, wr = wave >> 2; /* column strip / row group of this wave */          \
+    const int g = lane >> 4, c = lane & 15, col = 16 * wc + c;                                    \
+    const int r_e = tid / SE_TPR, c0_e = (tid % SE_TPR) * SE_CPT; /* row-wise mapping */          \
+    const bool row_lead = (tid % SE_TPR) == 0;                                                    \
+    (void)lane; (void)wave; (void)wc; (void)wr; (void)g; (void)c; (void)col; (void)r_e; (void)c0_e; (void)row_lead
+
 // ---- fragments ------------------------------------------------------------------------------------------
 // k-contiguous: 16 consecutive floats starting at p (16-B aligned)
 __device__ __forceinline__ void frag_kc(float (&f)[16], const float* p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+        f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+}
+// SE_CPT consecutive floats (row-wise phases)
+__device__ __forceinline__ void frag_row(float (&f)[SE_CPT], const float* p) {
+#pragma unroll
+    for (int q = 0; q < SE_CPT / 4; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
         f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
     }
@@ -90,63 +140,104 @@ __device__ __forceinline__ void frag_ks(float (&f)[16], const float* p, int stri
     for (int s = 0; s < 16; ++s) f[s] = p[s * stride];
 }
 
-// C[m][16w + c] = sum_k A[m][k] * B[k][16w + c] for all 64 rows m.
+// C[m][16 wc + c] = sum_k A[m][k] * B[k][16 wc + c] for the wave's SE_RT row tiles.
 // A_KC: A is an LDS tile [m][k] (k contiguous); otherwise A is given transposed, i.e. the LDS tile is [k][m].
-// bf[s] = B[k = 16g + s][n = 16w + c] is supplied by the caller.  epi(row, value) is called for the lane's column.
+// bf[s] = B[k = 16g + s][n = 16 wc + c] is supplied by the caller.  epi(row, value) is called for the lane's column.
 template <bool A_KC, class Epi>
-__device__ __forceinline__ void gemm64(const float* A, const float (&bf)[16], int lane, Epi epi) {
+__device__ __forceinline__ void gemm64(const float* A, const float (&bf)[16], int lane, int wr, Epi epi) {
     const int g = lane >> 4, c = lane & 15;
-    f32x4 acc[4];
-    float af[4][16];
+    f32x4 acc[SE_RT];
+    float af[SE_RT][16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < SE_RT; ++t) {
+        const int tt = wr * SE_RT + t;
         acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (A_KC) frag_kc(af[t], A + (16 * t + c) * SE_LS + 16 * g);
-        else frag_ks(af[t], A + (16 * g) * SE_LS + 16 * t + c, SE_LS);
+        if (A_KC) frag_kc(af[t], A + SE_RO(16 * tt + c) + 16 * g);
+        else frag_ks(af[t], A + SE_RO(16 * g) + 16 * tt + c, SE_LS);
     }
+    // all fragment loads are issued before the first MFMA: left alone, the scheduler sinks each load next to its use
+    // (lowest register pressure) and the MFMAs then run as (ds_read -> s_waitcnt -> 2 MFMA) groups, one LDS round
+    // trip -- or, for weight fragments, one L2 round trip -- per pair.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 16; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
+        for (int t = 0; t < SE_RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < SE_RT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) epi(16 * t + 4 * g + j, acc[t][j]);
+        for (int j = 0; j < 4; ++j) epi(16 * (wr * SE_RT + t) + 4 * g + j, acc[t][j]);
     __builtin_amdgcn_sched_barrier(0);  // keep consecutive GEMMs from interleaving their fragment loads (VGPR pressure)
 }
 
 // weight fragment for y = x W^T: B[k][n] = W[n][k], W row-major [64][64] in global memory (k contiguous)
-__device__ __forceinline__ void wfrag_kc(float (&bf)[16], const float* W, int wave, int lane) {
-    frag_kc(bf, W + (16 * wave + (lane & 15)) * SE_D + 16 * (lane >> 4));
+__device__ __forceinline__ void wfrag_kc(float (&bf)[16], const float* W, int wc, int lane) {
+    frag_kc(bf, W + (16 * wc + (lane & 15)) * SE_D + 16 * (lane >> 4));
 }
 // weight fragment for dx = dy W: B[k][n] = W[k][n] (k strided)
-__device__ __forceinline__ void wfrag_ks(float (&bf)[16], const float* W, int wave, int lane) {
-    frag_ks(bf, W + (16 * (lane >> 4)) * SE_D + 16 * wave + (lane & 15), SE_D);
+__device__ __forceinline__ void wfrag_ks(float (&bf)[16], const float* W, int wc, int lane) {
+    frag_ks(bf, W + (16 * (lane >> 4)) * SE_D + 16 * wc + (lane & 15), SE_D);
 }
 
-// ---- row-wise helpers: thread tid handles row tid>>2, columns [16*(tid&3), +16) ----------------------------------
-__device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
+// ---- weight staging: a 64x64 weight matrix is fetched ONCE per workgroup (one float4 per thread at 16 waves, requested a
+// phase ahead into registers) and committed to an LDS tile in the activations' layout; the waves then take their
+// B fragments from LDS.  Taking them straight from global memory makes each of the 4 row-group waves of a column strip
+// load the same 4 KB: 64 KB per GEMM through the CU's 64 B/clk vector-memory path, more cycles than the GEMM's MFMAs.
+#define SE_WV (1024 / SE_NT)
+__device__ __forceinline__ void wtile_fetch(float4 (&R)[SE_WV], const float* __restrict__ W, int tid) {
+#pragma unroll
+    for (int q = 0; q < SE_WV; ++q) R[q] = reinterpret_cast<const float4*>(W)[q * SE_NT + tid];
+}
+__device__ __forceinline__ void wtile_commit(float* tile, const float4 (&R)[SE_WV], int tid) {
+#pragma unroll
+    for (int q = 0; q < SE_WV; ++q) {
+        const int f = q * SE_NT + tid;
+        *reinterpret_cast<float4*>(tile + SE_RO(f >> 4) + 4 * (f & 15)) = R[q];
+    }
+}
+// B fragment from a staged weight tile W[64][64]:  y = x W^T  ->  B[k][n] = W[n][k] (k contiguous) ...
+__device__ __forceinline__ void wtile_frag_t(float (&bf)[16], const float* tile, int wc, int lane) {
+    frag_kc(bf, tile + SE_RO(16 * wc + (lane & 15)) + 16 * (lane >> 4));
+}
+// ... and  dx = dy W  ->  B[k][n] = W[k][n] (k strided)
+__device__ __forceinline__ void wtile_frag_n(float (&bf)[16], const float* tile, int wc, int lane) {
+    frag_ks(bf, tile + SE_RO(16 * (lane >> 4)) + 16 * wc + (lane & 15), SE_LS);
+}
+
+// ---- row-wise helpers: thread tid handles row tid / SE_TPR, columns [SE_CPT * (tid % SE_TPR), +SE_CPT) -------------
+// sum / max over the SE_TPR consecutive lanes that share a row
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < SE_TPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float row_max(float v) {
+#pragma unroll
+    for (int o = 1; o < SE_TPR; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int row_sum_i(int v) {
+#pragma unroll
+    for (int o = 1; o < SE_TPR; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
 // LayerNorm of one LDS tile row-slice (eps 1e-8, biased variance -- nn.LayerNorm, SASRec/main.py:89,94,106)
 __device__ __forceinline__ void ln_row(const float* src, float* dst, const float* __restrict__ gw, const float* __restrict__ gb,
                                        int tid, float& mean, float& rstd) {
-    const int r = tid >> 2, c0 = (tid & 3) * 16;
-    float x[16];
-    frag_kc(x, src + r * SE_LS + c0);
+    const int r = tid / SE_TPR, c0 = (tid % SE_TPR) * SE_CPT;
+    float x[SE_CPT];
+    frag_row(x, src + SE_RO(r) + c0);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += x[i];
-    mean = quad_sum(s) * (1.0f / SE_D);
+    for (int i = 0; i < SE_CPT; ++i) s += x[i];
+    mean = row_sum(s) * (1.0f / SE_D);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const float d = x[i] - mean; q = fmaf(d, d, q); }
-    rstd = 1.0f / sqrtf(quad_sum(q) * (1.0f / SE_D) + 1e-8f);
+    for (int i = 0; i < SE_CPT; ++i) { const float d = x[i] - mean; q = fmaf(d, d, q); }
+    rstd = 1.0f / sqrtf(row_sum(q) * (1.0f / SE_D) + 1e-8f);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dst[r * SE_LS + c0 + i] = (x[i] - mean) * rstd * gw[c0 + i] + gb[c0 + i];
+    for (int i = 0; i < SE_CPT; ++i) dst[SE_RO(r) + c0 + i] = (x[i] - mean) * rstd * gw[c0 + i] + gb[c0 + i];
 }
 
 // ---- work items: which (sequence, position) each of the 64 LDS rows holds ------------------------------------------
@@ -197,21 +288,21 @@ __device__ __forceinline__ int se_decode(int wi, const SeWork& W, int B, int S, 
 
 // copy LDS tile rows <-> rows of a [B*S][64] global matrix selected by s_gid (coalesced float4 per row)
 __device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ gdst, const int* s_gid, int tid) {
-    for (int f = tid; f < SE_ROWS * (SE_D / 4); f += 256) {
+    for (int f = tid; f < SE_ROWS * (SE_D / 4); f += SE_NT) {
         const int r = f >> 4, c4 = f & 15;
         const int gid = s_gid[r];
-        if (gid >= 0) reinterpret_cast<float4*>(gdst + (int64_t)gid * SE_D)[c4] = *reinterpret_cast<const float4*>(tile + r * SE_LS + 4 * c4);
+        if (gid >= 0) reinterpret_cast<float4*>(gdst + (int64_t)gid * SE_D)[c4] = *reinterpret_cast<const float4*>(tile + SE_RO(r) + 4 * c4);
     }
 }
 __device__ __forceinline__ void tile_load(float* tile, const float* __restrict__ gsrc, const int* s_gid, int tid) {
     // pin the global loads below this point: hipcc otherwise hoists the loads of EVERY later phase (they do not depend
     // on LDS) to the top of the sequence loop and holds 64 VGPRs per tile until its phase arrives.
     gsrc = se_launder(gsrc);
-    for (int f = tid; f < SE_ROWS * (SE_D / 4); f += 256) {
+    for (int f = tid; f < SE_ROWS * (SE_D / 4); f += SE_NT) {
         const int r = f >> 4, c4 = f & 15;
         const int gid = s_gid[r];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gid >= 0) v = reinterpret_cast<const float4*>(gsrc + (int64_t)gid * SE_D)[c4];
-        *reinterpret_cast<float4*>(tile + r * SE_LS + 4 * c4) = v;
+        *reinterpret_cast<float4*>(tile + SE_RO(r) + 4 * c4) = v;
     }
 }

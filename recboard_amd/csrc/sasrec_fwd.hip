@@ -14,8 +14,14 @@
 
 #include "sasrec_common.h"
 
+#ifdef SE_PROFILE
+extern "C" int re_dbg_encoder_marks_fwd(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_se_marks), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
+}
+#endif
+
 template <bool TRAIN>
-__global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restrict__ x0, const int64_t* __restrict__ seq,
+__global__ __launch_bounds__(SE_NT) void sasrec_encoder_fwd_k(const float* __restrict__ x0, const int64_t* __restrict__ seq,
                                                             int B, int S, int L, SasrecParams P, float drop_scale,
                                                             uint32_t thresh, uint32_t seed, float* __restrict__ u,
                                                             float* __restrict__ tape, SasrecTape T,
@@ -29,50 +35,63 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
     float* bK = bQ + SE_BUF;
     float* bV = bK + SE_BUF;
     float* bP = bV + SE_BUF;
+    float* bW0 = bP + SE_BUF;   // two staged weight matrices (see wtile_fetch)
+    float* bW1 = bW0 + SE_BUF;
     __shared__ int s_gid[SE_ROWS], s_grp[SE_ROWS], s_pad[SE_ROWS];
     __shared__ float s_w[SE_ROWS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, c = lane & 15, col = 16 * wave + c;
-    const int r_e = tid >> 2, c0_e = (tid & 3) * 16;  // element-wise mapping
+    const int tid0 = threadIdx.x;
     const float inv_sqrt_d = 0.125f;                  // 1/sqrt(64)
     const SeWork WK = se_work(B, nshort_ptr);
 
     for (int wi = blockIdx.x; wi < WK.total; wi += gridDim.x) {
+        SE_THREAD_VARS(tid0);
         __syncthreads();
+        SE_MARK(0, 0);
         const int n_out = se_decode(wi, WK, B, S, order, seq, tid, s_gid, s_grp, s_pad);
         __syncthreads();
         tile_load(bX, x0, s_gid, tid);
         __syncthreads();
+        SE_MARK(0, 1);
 
         for (int l = 0; l < L; ++l) {
+            SE_THREAD_VARS(tid0);
             const SasrecBlockParams W = se_launder(P.blk[l]);
             float* tp = TRAIN ? tape + (int64_t)l * T.per_block : nullptr;
+            float4 R[SE_WV];                  // the next weight matrix, in flight from global memory
+            wtile_fetch(R, W.in_w, tid);      // Wq
             // ---- 1. Q-input = LN_a(x)
             {
                 float mean, rstd;
                 ln_row(bX, bA, W.ln_a_w, W.ln_a_b, tid, mean, rstd);
                 if (TRAIN) {
                     tile_store(bX, tp + T.off_X, s_gid, tid);
-                    if ((tid & 3) == 0 && s_gid[r_e] >= 0) {
+                    if (row_lead && s_gid[r_e] >= 0) {
                         float* st = tp + T.off_SA + (int64_t)s_gid[r_e] * 2;
                         st[0] = mean; st[1] = rstd;
                     }
                 }
             }
+            wtile_commit(bW0, R, tid);                              // Wq
+            wtile_fetch(R, W.in_w + SE_D * SE_D, tid);              // Wk
             __syncthreads();
+            if (l == 0) SE_MARK(0, 2);
             // ---- 2. q, k, v projections
             {
+                const float bq = W.in_b[col], bk = W.in_b[SE_D + col], bv = W.in_b[2 * SE_D + col];
                 float bf[16];
-                wfrag_kc(bf, W.in_w, wave, lane);
-                const float bq = W.in_b[col];
-                gemm64<true>(bA, bf, lane, [&](int row, float v) { bQ[row * SE_LS + col] = v + bq; });
-                wfrag_kc(bf, W.in_w + SE_D * SE_D, wave, lane);
-                const float bk = W.in_b[SE_D + col];
-                gemm64<true>(bX, bf, lane, [&](int row, float v) { bK[row * SE_LS + col] = v + bk; });
-                wfrag_kc(bf, W.in_w + 2 * SE_D * SE_D, wave, lane);
-                const float bv = W.in_b[2 * SE_D + col];
-                gemm64<true>(bX, bf, lane, [&](int row, float v) { bV[row * SE_LS + col] = v + bv; });
+                wtile_commit(bW1, R, tid);                          // Wk
+                wtile_fetch(R, W.in_w + 2 * SE_D * SE_D, tid);      // Wv
+                wtile_frag_t(bf, bW0, wc, lane);
+                gemm64<true>(bA, bf, lane, wr, [&](int row, float v) { bQ[SE_RO(row) + col] = v + bq; });
+                __syncthreads();
+                wtile_commit(bW0, R, tid);                          // Wv
+                wtile_fetch(R, W.out_w, tid);                       // Wo
+                wtile_frag_t(bf, bW1, wc, lane);
+                gemm64<true>(bX, bf, lane, wr, [&](int row, float v) { bK[SE_RO(row) + col] = v + bk; });
+                __syncthreads();
+                wtile_frag_t(bf, bW0, wc, lane);
+                gemm64<true>(bX, bf, lane, wr, [&](int row, float v) { bV[SE_RO(row) + col] = v + bv; });
             }
             __syncthreads();
             if (TRAIN) {
@@ -80,73 +99,74 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                 tile_store(bK, tp + T.off_K, s_gid, tid);
                 tile_store(bV, tp + T.off_V, s_gid, tid);
             }
+            if (l == 0) SE_MARK(0, 3);
             // ---- 3. scores = q k^T / sqrt(D)   (B^T = K, k-contiguous in LDS)
             {
                 float bf[16];
-                frag_kc(bf, bK + (16 * wave + c) * SE_LS + 16 * g);
-                gemm64<true>(bQ, bf, lane, [&](int row, float v) { bP[row * SE_LS + col] = v * inv_sqrt_d; });
+                frag_kc(bf, bK + SE_RO(16 * wc + c) + 16 * g);
+                gemm64<true>(bQ, bf, lane, wr, [&](int row, float v) { bP[SE_RO(row) + col] = v * inv_sqrt_d; });
             }
             __syncthreads();
+            if (l == 0) SE_MARK(0, 4);
             // ---- softmax over the keys of the same sequence with j <= i (causal; pads ARE keys), plus the virtual
             //      out-of-window pad key (multiplicity n_out, score q.b_k/sqrt(D), value b_v); dropout on the probabilities
             {
                 const int i = r_e;
                 const int gi = s_gid[i], grp = s_grp[i];
-                float p[16];
+                float p[SE_CPT];
                 float mx = -INFINITY;
                 unsigned okm = 0;
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
+                for (int jj = 0; jj < SE_CPT; ++jj) {
                     const int j = c0_e + jj;
                     const bool ok = gi >= 0 && j <= i && s_gid[j] >= 0 && s_grp[j] == grp;
                     okm |= (ok ? 1u : 0u) << jj;
-                    p[jj] = ok ? bP[i * SE_LS + j] : -INFINITY;
+                    p[jj] = ok ? bP[SE_RO(i) + j] : -INFINITY;
                     mx = fmaxf(mx, p[jj]);
                 }
                 float spad = -INFINITY;
-                if (n_out > 0) {  // wave-uniform
+                if (n_out > 0) {  // workgroup-uniform
                     float d = 0.f;
 #pragma unroll
-                    for (int jj = 0; jj < 16; ++jj) d = fmaf(bQ[i * SE_LS + c0_e + jj], W.in_b[SE_D + c0_e + jj], d);
-                    spad = (gi >= 0) ? quad_sum(d) * inv_sqrt_d : -INFINITY;
+                    for (int jj = 0; jj < SE_CPT; ++jj) d = fmaf(bQ[SE_RO(i) + c0_e + jj], W.in_b[SE_D + c0_e + jj], d);
+                    spad = (gi >= 0) ? row_sum(d) * inv_sqrt_d : -INFINITY;
                     mx = fmaxf(mx, spad);
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+                mx = row_max(mx);
                 float sum = 0.f;
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
+                for (int jj = 0; jj < SE_CPT; ++jj) {
                     p[jj] = (p[jj] == -INFINITY) ? 0.f : expf(p[jj] - mx);
                     sum += p[jj];
                 }
-                sum = quad_sum(sum);
+                sum = row_sum(sum);
                 const float epad = (spad == -INFINITY) ? 0.f : expf(spad - mx);
                 sum += (float)n_out * epad;
                 const float inv = (gi >= 0) ? 1.0f / sum : 0.f;
                 if (n_out > 0) {
                     const float ppad = epad * inv;
                     float kept = (float)n_out;
-                    if (thresh && gi >= 0) {  // each of the n_out pad keys has its own dropout bit (element (b, s_i, jj))
+                    if (thresh) {  // each of the n_out pad keys has its own dropout bit (element (b, s_i, jj))
                         int cnt = 0;
-                        for (int jj = (tid & 3); jj < n_out; jj += 4)
-                            cnt += re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + jj), thresh) ? 1 : 0;
-                        cnt += __shfl_xor(cnt, 1, 64);
-                        cnt += __shfl_xor(cnt, 2, 64);
+                        if (gi >= 0)
+                            for (int jj = (tid % SE_TPR); jj < n_out; jj += SE_TPR)
+                                cnt += re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + jj), thresh) ? 1 : 0;
+                        cnt = row_sum_i(cnt);
                         kept = (float)cnt * drop_scale;
                     }
-                    const float wv = ppad * kept;
-                    if ((tid & 3) == 0) {
+                    const float wv = (gi >= 0) ? ppad * kept : 0.f;
+                    if (row_lead) {
                         s_w[i] = wv;
                         if (TRAIN && gi >= 0) {
                             float* pp = tp + T.off_PP + (int64_t)gi * 2;
                             pp[0] = ppad; pp[1] = wv;
                         }
                     }
-                } else if ((tid & 3) == 0) {
+                } else if (row_lead) {
                     s_w[i] = 0.f;
                 }
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
+                for (int jj = 0; jj < SE_CPT; ++jj) {
                     const int j = c0_e + jj;
                     float pr = p[jj] * inv;
                     if ((okm >> jj) & 1u) {
@@ -155,80 +175,91 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
                         if (thresh && pr != 0.f)
                             pr = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? pr * drop_scale : 0.f;
                     }
-                    bP[i * SE_LS + j] = pr;
+                    bP[SE_RO(i) + j] = pr;
                 }
             }
             __syncthreads();
+            if (l == 0) SE_MARK(0, 5);
             // ---- 4. o = A v + w * b_v   (B[k=j][n=d] = V[j][d]: k strided)
             {
                 float bf[16];
-                frag_ks(bf, bV + (16 * g) * SE_LS + col, SE_LS);
+                wtile_commit(bW1, R, tid);                          // Wo
+                wtile_fetch(R, W.w1, tid);                          // W1
+                frag_ks(bf, bV + SE_RO(16 * g) + col, SE_LS);
                 const float bv = W.in_b[2 * SE_D + col];
-                gemm64<true>(bP, bf, lane, [&](int row, float v) { bA[row * SE_LS + col] = fmaf(s_w[row], bv, v); });
+                gemm64<true>(bP, bf, lane, wr, [&](int row, float v) { bA[SE_RO(row) + col] = fmaf(s_w[row], bv, v); });
             }
             __syncthreads();
             if (TRAIN) tile_store(bA, tp + T.off_O, s_gid, tid);
+            if (l == 0) SE_MARK(0, 6);
             // ---- 5. x1 = o Wo^T + bo + x
             {
                 float bf[16];
-                wfrag_kc(bf, W.out_w, wave, lane);
+                wtile_commit(bW0, R, tid);                          // W1
+                wtile_fetch(R, W.w2, tid);                          // W2
+                wtile_frag_t(bf, bW1, wc, lane);
                 const float bo = W.out_b[col];
-                gemm64<true>(bA, bf, lane, [&](int row, float v) { bQ[row * SE_LS + col] = v + bo + bX[row * SE_LS + col]; });
+                gemm64<true>(bA, bf, lane, wr, [&](int row, float v) { bQ[SE_RO(row) + col] = v + bo + bX[SE_RO(row) + col]; });
             }
             __syncthreads();
+            if (l == 0) SE_MARK(0, 7);
             // ---- 6. y = LN_f(x1)
             {
                 float mean, rstd;
                 ln_row(bQ, bK, W.ln_f_w, W.ln_f_b, tid, mean, rstd);
                 if (TRAIN) {
                     tile_store(bQ, tp + T.off_X1, s_gid, tid);
-                    if ((tid & 3) == 0 && s_gid[r_e] >= 0) {
+                    if (row_lead && s_gid[r_e] >= 0) {
                         float* st = tp + T.off_SF + (int64_t)s_gid[r_e] * 2;
                         st[0] = mean; st[1] = rstd;
                     }
                 }
             }
             __syncthreads();
+            if (l == 0) SE_MARK(0, 8);
             // ---- 7. hr = relu(dropout1(y W1^T + b1))
             {
                 float bf[16];
-                wfrag_kc(bf, W.w1, wave, lane);
+                wtile_commit(bW1, R, tid);                          // W2
+                wtile_frag_t(bf, bW0, wc, lane);
                 const float b1 = W.b1[col];
-                gemm64<true>(bK, bf, lane, [&](int row, float v) {
+                gemm64<true>(bK, bf, lane, wr, [&](int row, float v) {
                     v += b1;
                     if (thresh) {
                         const uint32_t e = (uint32_t)((int64_t)s_gid[row] * SE_D + col);
                         v = re_keep(seed, RE_STREAM_FFN1(l), e, thresh) ? v * drop_scale : 0.f;
                     }
-                    bV[row * SE_LS + col] = fmaxf(v, 0.f);
+                    bV[SE_RO(row) + col] = fmaxf(v, 0.f);
                 });
             }
             __syncthreads();
             if (TRAIN) tile_store(bV, tp + T.off_HR, s_gid, tid);
+            if (l == 0) SE_MARK(0, 9);
             // ---- 8. x' = dropout2(hr W2^T + b2) + y, pad rows zeroed
             {
                 float bf[16];
-                wfrag_kc(bf, W.w2, wave, lane);
+                wtile_frag_t(bf, bW1, wc, lane);
                 const float b2 = W.b2[col];
-                gemm64<true>(bV, bf, lane, [&](int row, float v) {
+                gemm64<true>(bV, bf, lane, wr, [&](int row, float v) {
                     v += b2;
                     if (thresh) {
                         const uint32_t e = (uint32_t)((int64_t)s_gid[row] * SE_D + col);
                         v = re_keep(seed, RE_STREAM_FFN2(l), e, thresh) ? v * drop_scale : 0.f;
                     }
-                    v += bK[row * SE_LS + col];
-                    bX[row * SE_LS + col] = s_pad[row] ? 0.f : v;
+                    v += bK[SE_RO(row) + col];
+                    bX[SE_RO(row) + col] = s_pad[row] ? 0.f : v;
                 });
             }
             __syncthreads();
         }
+        SE_MARK(0, 10);
         // ---- u = LN_last(x_L)
         {
             float mean, rstd;
             ln_row(bX, bA, se_launder(P.last_w), se_launder(P.last_b), tid, mean, rstd);
             if (TRAIN) {
                 tile_store(bX, tape + T.off_XL, s_gid, tid);
-                if ((tid & 3) == 0 && s_gid[r_e] >= 0) {
+                if (row_lead && s_gid[r_e] >= 0) {
                     float* st = tape + T.off_SL + (int64_t)s_gid[r_e] * 2;
                     st[0] = mean; st[1] = rstd;
                 }
@@ -236,9 +267,10 @@ __global__ __launch_bounds__(256) void sasrec_encoder_fwd_k(const float* __restr
         }
         __syncthreads();
         tile_store(bA, u, s_gid, tid);
+        SE_MARK(0, 11);
         if (fill_pads && n_out > 0) {
             // positions in front of the window are pads: u = LN_last(0) = beta_last (what the reference's encode returns there)
-            for (int f = tid; f < 4 * n_out * (SE_D / 4); f += 256) {
+            for (int f = tid; f < 4 * n_out * (SE_D / 4); f += SE_NT) {
                 const int c4 = f & 15, rr = f >> 4;
                 const int t = rr / n_out, s = rr - t * n_out;
                 const int q = 4 * wi + t;
@@ -284,7 +316,7 @@ extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_
     if (tape && tape_bytes < (size_t)T.total * sizeof(float)) return RE_EWORKSPACE;
     const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    const size_t ldsb = (size_t)6 * SE_BUF * sizeof(float);
+    const size_t ldsb = (size_t)8 * SE_BUF * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)(B < 2048 ? B : 2048);  // >= the number of work items (shorts packed 4 per item); idle blocks exit
     if ((order == nullptr) != (nshort == nullptr)) return RE_EINVAL;
@@ -295,14 +327,14 @@ extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_
             if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
             attr_done[1] = true;
         }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, order, nshort, 0, seed_dev);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(SE_NT), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, order, nshort, 0, seed_dev);
     } else {
         auto k = sasrec_encoder_fwd_k<false>;
         if (!attr_done[0]) {
             if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
             attr_done[0] = true;
         }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T, order, nshort, 1, seed_dev);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(SE_NT), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T, order, nshort, 1, seed_dev);
     }
     return re_launch_status();
 }
