@@ -175,68 +175,80 @@ extern "C" int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float
 // re_scatter_add_rows (pad rows zero, dropout mask re-applied, times `scale`).  dP[s,:] = sum_b masked gradient.
 // Deterministic two-stage reduction: EB_WGS workgroups own b = w, w+EB_WGS, ... and keep their [S,D] partial in
 // registers; a second kernel adds the partials in workgroup order.
-#define EB_WGS 64
-#define EB_SLOTS 4  // float4 slots per thread: S*D/4 <= 1024
-
+// One workgroup per 8 consecutive float4 columns (128 B) of the [B][S*D] gradient: thread (tb, cq) walks rows b = tb, tb+32, ...
+// of float4 column cq (4 rows in flight), applies the pad mask / dropout mask / sqrt(D) scale in place and keeps the
+// unscaled column sum; the 32 row-lane partials are then added in lane order through LDS.  No workspace, no second kernel,
+// and a fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void sasrec_embed_bwd_k(float* __restrict__ gx, const int64_t* __restrict__ seq, int B, int S,
                                                           int D, float scale, float drop_scale, uint32_t thresh, uint32_t seed,
-                                                          float* __restrict__ part, const uint32_t* __restrict__ seed_dev) {
+                                                          float* __restrict__ dP, const uint32_t* __restrict__ seed_dev) {
     if (seed_dev) seed ^= seed_dev[0];
+    __shared__ float4 red[32][8];
+    const int cq = threadIdx.x & 7, tb = threadIdx.x >> 3;
     const int nf4 = S * D / 4, d4n = D / 4;
-    float4 acc[EB_SLOTS];
+    const int f = blockIdx.x * 8 + cq;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < nf4) {
+        const int s = f / d4n;
+        float4* col = reinterpret_cast<float4*>(gx) + f;
+        for (int b0 = tb; b0 < B; b0 += 128) {
+            float4 v[4];
+            int64_t sq[4];
 #pragma unroll
-    for (int k = 0; k < EB_SLOTS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        float4* row = reinterpret_cast<float4*>(gx + (int64_t)b * S * D);
-#pragma unroll
-        for (int k = 0; k < EB_SLOTS; ++k) {
-            const int f = k * 256 + threadIdx.x;
-            if (f >= nf4) continue;
-            const int s = f / d4n;
-            float4 v = row[f];
-            if (seq[(int64_t)b * S + s] == 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (thresh) {
-                const uint32_t e = (uint32_t)(((int64_t)b * S * D) + (int64_t)f * 4);
-                v.x = re_keep(seed, RE_STREAM_EMBED, e + 0, thresh) ? v.x * drop_scale : 0.f;
-                v.y = re_keep(seed, RE_STREAM_EMBED, e + 1, thresh) ? v.y * drop_scale : 0.f;
-                v.z = re_keep(seed, RE_STREAM_EMBED, e + 2, thresh) ? v.z * drop_scale : 0.f;
-                v.w = re_keep(seed, RE_STREAM_EMBED, e + 3, thresh) ? v.w * drop_scale : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + 32 * u;
+                const bool ok = b < B;
+                v[u] = ok ? col[(int64_t)b * nf4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                sq[u] = ok ? seq[(int64_t)b * S + s] : 0;
             }
-            acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w;
-            row[f] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + 32 * u;
+                if (b >= B) break;
+                float4 w = v[u];
+                if (sq[u] == 0) w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (thresh) {
+                    const uint32_t e = (uint32_t)(((int64_t)b * nf4 + f) * 4);
+                    w.x = re_keep(seed, RE_STREAM_EMBED, e + 0, thresh) ? w.x * drop_scale : 0.f;
+                    w.y = re_keep(seed, RE_STREAM_EMBED, e + 1, thresh) ? w.y * drop_scale : 0.f;
+                    w.z = re_keep(seed, RE_STREAM_EMBED, e + 2, thresh) ? w.z * drop_scale : 0.f;
+                    w.w = re_keep(seed, RE_STREAM_EMBED, e + 3, thresh) ? w.w * drop_scale : 0.f;
+                }
+                acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+                col[(int64_t)b * nf4] = make_float4(w.x * scale, w.y * scale, w.z * scale, w.w * scale);
+            }
         }
     }
-#pragma unroll
-    for (int k = 0; k < EB_SLOTS; ++k) {
-        const int f = k * 256 + threadIdx.x;
-        if (f < nf4) reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * nf4 * 4)[f] = acc[k];
+    red[tb][cq] = acc;
+    __syncthreads();
+    if (tb == 0 && f < nf4) {
+        float4 t = red[0][cq];
+        for (int i = 1; i < 32; ++i) {
+            const float4 r = red[i][cq];
+            t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+        }
+        reinterpret_cast<float4*>(dP)[f] = t;
     }
 }
 
-__global__ __launch_bounds__(256) void sasrec_embed_bwd_reduce(const float* __restrict__ part, int nwg, int n, float* __restrict__ dP) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += part[(int64_t)w * n + e];
-    dP[e] = s;
+extern "C" size_t re_sasrec_embed_bwd_workspace_bytes(int64_t S, int64_t D) {
+    (void)S; (void)D;
+    return 256;   // (no workspace needed any more; the entry point keeps its ws arguments)
 }
-
-extern "C" size_t re_sasrec_embed_bwd_workspace_bytes(int64_t S, int64_t D) { return (size_t)EB_WGS * S * D * sizeof(float) + 256; }
 
 extern "C" int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int64_t S, int64_t D, float scale, float drop_p,
                                    uint32_t seed, const uint32_t* seed_dev, float* dP, void* ws, size_t ws_bytes, re_stream_t stream) {
     re_clear_error();
-    if (!gx || !seq || !dP || !ws || B < 0 || S <= 0 || D <= 0) return RE_EINVAL;
-    if ((D & 3) || S * D / 4 > 256 * EB_SLOTS || !aligned16(gx) || !aligned16(dP)) return RE_EUNSUPPORTED;
+    (void)ws; (void)ws_bytes;
+    if (!gx || !seq || !dP || B < 0 || S <= 0 || D <= 0) return RE_EINVAL;
+    if ((D & 3) || !aligned16(gx) || !aligned16(dP) || B * S * D >= 0x100000000ll) return RE_EUNSUPPORTED;
     if (drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
-    if (ws_bytes < re_sasrec_embed_bwd_workspace_bytes(S, D)) return RE_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    const int nwg = (int)(B < EB_WGS ? (B > 0 ? B : 1) : EB_WGS);
-    hipLaunchKernelGGL(sasrec_embed_bwd_k, dim3(nwg), dim3(256), 0, s, gx, seq, (int)B, (int)S, (int)D, scale, ds, thresh, seed, (float*)ws, seed_dev);
-    const int n = (int)(S * D);
-    hipLaunchKernelGGL(sasrec_embed_bwd_reduce, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)ws, nwg, n, dP);
+    const int nf4 = (int)(S * D / 4);
+    hipLaunchKernelGGL(sasrec_embed_bwd_k, dim3((nf4 + 7) / 8), dim3(256), 0, s, gx, seq, (int)B, (int)S, (int)D, scale, ds, thresh, seed, dP,
+                       seed_dev);
     return re_launch_status();
 }
 

@@ -17,7 +17,7 @@
 
 #define SB_NMAT 6
 #define SB_NVEC 12
-#define SB_SLAB (SB_NMAT * 4096 + SB_NVEC * SE_NT)
+#define SB_SLAB (SB_NMAT * 4096 + SB_NVEC * 64)
 // matrix slots: 0 Wq 1 Wk 2 Wv 3 Wo 4 W1 5 W2;  vector slots: 0 bq 1 bk 2 bv 3 bo 4 b1 5 b2 6 ga 7 ba 8 gf 9 bf 10 glast 11 blast
 
 template <bool A_KC>
@@ -367,85 +367,103 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         SE_MARK(1, 14);
     }
 
-    // ---- this workgroup's slab
+    // ---- this workgroup's slab (workgroups without a work item write nothing: the reduction only reads the first
+    //      min(work items, gridDim.x) slabs of the block's region)
+    if ((int)blockIdx.x >= WK.total) return;
     SE_THREAD_VARS(tid0);
-    float* sl = slab + (int64_t)blockIdx.x * SB_SLAB;
+    float* sl = slab + ((int64_t)l * gridDim.x + blockIdx.x) * SB_SLAB;
 #pragma unroll
     for (int m = 0; m < SB_NMAT; ++m)
 #pragma unroll
         for (int t = 0; t < SE_RT; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sl[m * 4096 + (16 * (wr * SE_RT + t) + 4 * g + j) * SE_D + col] = accW[m][t][j];
+    // column partials of the SE_NW row groups -> one value per column, added in row-group order
+    __syncthreads();
+    float* red = lds;   // [SB_NVEC][SE_NW][64]
 #pragma unroll
-    for (int v = 0; v < SB_NVEC; ++v) sl[SB_NMAT * 4096 + v * SE_NT + tid] = accV[v];
+    for (int v = 0; v < SB_NVEC; ++v) red[(v * SE_NW + wave) * 64 + lane] = accV[v];
+    __syncthreads();
+    if (tid < SB_NVEC * 64) {
+        const int v = tid >> 6, cc = tid & 63;
+        float s = red[(v * SE_NW) * 64 + cc];
+#pragma unroll
+        for (int i = 1; i < SE_NW; ++i) s += red[(v * SE_NW + i) * 64 + cc];
+        sl[SB_NMAT * 4096 + v * 64 + cc] = s;
+    }
 }
 
 struct SasrecGradDst {
-    float* p[14];  // ABI order of the 12 block gradients, then g_last_w, g_last_b (may be null)
+    float* p[SE_MAX_BLOCKS][14];  // per block: ABI order of the 12 block gradients, then g_last_w, g_last_b (last block only)
 };
 
-// Slab reduction in two fixed-order levels (deterministic): level 1 sums groups of SB_RGROUP slabs with one thread per
-// (group, element) -- SB_RGROUP independent loads in flight per thread, nwg/SB_RGROUP x more threads than elements --
-// level 2 adds the group partials in order and writes the gradient tensors.
+// Slab reduction in two fixed-order levels (deterministic), ONE launch each for all blocks (blockIdx.z / .y = block):
+// level 1 sums groups of SB_RGROUP slabs with one thread per (group, element) -- SB_RGROUP independent loads in flight per
+// thread -- level 2 adds the group partials in order and writes the gradient tensors.  Only the slabs of workgroups that
+// had a work item exist: nact = min(work items, nwg), derived on the device from the packing metadata.
 #define SB_RGROUP 16
-__global__ __launch_bounds__(256) void sasrec_slab_partial(const float* __restrict__ slab, int nwg, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void sasrec_slab_partial(const float* __restrict__ slab, int nwg, int ngroups, float* __restrict__ part,
+                                                           int B, const int* __restrict__ nshort_ptr) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= SB_SLAB) return;
+    const int total = se_work(B, nshort_ptr).total;
+    const int nact = total < nwg ? total : nwg;
     const int w0 = blockIdx.y * SB_RGROUP;
+    if (w0 >= nact) return;
+    const float* sl = slab + (int64_t)blockIdx.z * nwg * SB_SLAB;
     float v[SB_RGROUP];
 #pragma unroll
-    for (int i = 0; i < SB_RGROUP; ++i) v[i] = (w0 + i < nwg) ? slab[(int64_t)(w0 + i) * SB_SLAB + e] : 0.f;
+    for (int i = 0; i < SB_RGROUP; ++i) v[i] = (w0 + i < nact) ? sl[(int64_t)(w0 + i) * SB_SLAB + e] : 0.f;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < SB_RGROUP; ++i) s += v[i];
-    part[(int64_t)blockIdx.y * SB_SLAB + e] = s;
+    part[((int64_t)blockIdx.z * ngroups + blockIdx.y) * SB_SLAB + e] = s;
 }
 
-__global__ __launch_bounds__(256) void sasrec_grad_reduce(const float* __restrict__ part, int ngroups, SasrecGradDst dst, int with_last) {
+__global__ __launch_bounds__(256) void sasrec_grad_reduce(const float* __restrict__ part, int nwg, int ngroups, SasrecGradDst dst, int L,
+                                                          int B, const int* __restrict__ nshort_ptr) {
     const int e = blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
     const int NM = SB_NMAT * 4096;
-    const int nvec = with_last ? SB_NVEC : SB_NVEC - 2;
+    const int nvec = (l == L - 1) ? SB_NVEC : SB_NVEC - 2;
+    if (e >= NM + nvec * 64) return;
+    const int total = se_work(B, nshort_ptr).total;
+    const int nact = total < nwg ? total : nwg;
+    const int ng = (nact + SB_RGROUP - 1) / SB_RGROUP;
+    const float* pl = part + (int64_t)l * ngroups * SB_SLAB;
+    float s = 0.f;
+    for (int w = 0; w < ng; ++w) s += pl[(int64_t)w * SB_SLAB + e];
+    float* const* P = dst.p[l];
+    float* d;
     if (e < NM) {
-        float s = 0.f;
-        for (int w = 0; w < ngroups; ++w) s += part[(int64_t)w * SB_SLAB + e];
         const int m = e >> 12, off = e & 4095;
-        float* d = (m < 3) ? dst.p[2] + m * 4096 : (m == 3 ? dst.p[4] : (m == 4 ? dst.p[8] : dst.p[10]));
-        d[off] = s;
-    } else if (e < NM + nvec * 64) {
+        d = ((m < 3) ? P[2] + m * 4096 : (m == 3 ? P[4] : (m == 4 ? P[8] : P[10]))) + off;
+    } else {
         const int v = (e - NM) >> 6, cc = (e - NM) & 63;
-        float s = 0.f;
-        for (int w = 0; w < ngroups; ++w) {
-            const float* q = part + (int64_t)w * SB_SLAB + NM + v * SE_NT + cc;
-            float t = q[0];
-#pragma unroll
-            for (int i = 1; i < SE_NW; ++i) t += q[64 * i];   // the SE_NW row-group partials of this column, in order
-            s += t;
-        }
-        float* d;
         switch (v) {
-            case 0: case 1: case 2: d = dst.p[3] + v * 64; break;
-            case 3: d = dst.p[5]; break;
-            case 4: d = dst.p[9]; break;
-            case 5: d = dst.p[11]; break;
-            case 6: d = dst.p[0]; break;
-            case 7: d = dst.p[1]; break;
-            case 8: d = dst.p[6]; break;
-            case 9: d = dst.p[7]; break;
-            case 10: d = dst.p[12]; break;
-            default: d = dst.p[13]; break;
+            case 0: case 1: case 2: d = P[3] + v * 64; break;
+            case 3: d = P[5]; break;
+            case 4: d = P[9]; break;
+            case 5: d = P[11]; break;
+            case 6: d = P[0]; break;
+            case 7: d = P[1]; break;
+            case 8: d = P[6]; break;
+            case 9: d = P[7]; break;
+            case 10: d = P[12]; break;
+            default: d = P[13]; break;
         }
-        d[cc] = s;
+        d += cc;
     }
+    *d = s;
 }
 
 #define SB_MAX_WGS 256
 
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L) {
-    (void)L;
     if (B <= 0) return 256;
     const int64_t nwg = B < SB_MAX_WGS ? B : SB_MAX_WGS;
     const int64_t ngroups = (nwg + SB_RGROUP - 1) / SB_RGROUP;
-    return (size_t)((nwg + ngroups) * SB_SLAB + 2 * B * S * D) * sizeof(float) + 512;
+    return (size_t)(L * (nwg + ngroups) * SB_SLAB + 2 * B * S * D) * sizeof(float) + 512;
 }
 
 extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
@@ -470,8 +488,8 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     const int nwg = (int)(B < SB_MAX_WGS ? B : SB_MAX_WGS);
     const int ngroups = (nwg + SB_RGROUP - 1) / SB_RGROUP;
     float* slab = (float*)ws;
-    float* part = slab + (size_t)nwg * SB_SLAB;
-    float* dxa = part + (size_t)ngroups * SB_SLAB;
+    float* part = slab + (size_t)L * nwg * SB_SLAB;
+    float* dxa = part + (size_t)L * ngroups * SB_SLAB;
     float* dxb = dxa + (size_t)B * S * D;
     const size_t ldsb = (size_t)9 * SE_BUF * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
@@ -495,14 +513,15 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
         else
             hipLaunchKernelGGL(kn, dim3(nwg), dim3(SE_NT), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
                                (const float*)tape, T, dout, slab, order, nshort, seed_dev);
-        SasrecGradDst dst;
-        for (int i = 0; i < 12; ++i) dst.p[i] = block_grads[12 * l + i];
-        dst.p[12] = g_last_w;
-        dst.p[13] = g_last_b;
-        const int nelem = SB_NMAT * 4096 + SB_NVEC * 64;
-        hipLaunchKernelGGL(sasrec_slab_partial, dim3((SB_SLAB + 255) / 256, ngroups), dim3(256), 0, s, slab, nwg, part);
-        hipLaunchKernelGGL(sasrec_grad_reduce, dim3((nelem + 255) / 256), dim3(256), 0, s, part, ngroups, dst, first ? 1 : 0);
         din = dout;
     }
+    SasrecGradDst dst;
+    for (int64_t l = 0; l < SE_MAX_BLOCKS; ++l)
+        for (int i = 0; i < 14; ++i) dst.p[l][i] = (l < L && i < 12) ? block_grads[12 * l + i] : (i == 12 ? g_last_w : g_last_b);
+    const int nelem = SB_NMAT * 4096 + SB_NVEC * 64;
+    hipLaunchKernelGGL(sasrec_slab_partial, dim3((SB_SLAB + 255) / 256, ngroups, (unsigned)L), dim3(256), 0, s, slab, nwg, ngroups, part, (int)B,
+                       nshort);
+    hipLaunchKernelGGL(sasrec_grad_reduce, dim3((nelem + 255) / 256, (unsigned)L), dim3(256), 0, s, part, nwg, ngroups, dst, (int)L, (int)B,
+                       nshort);
     return re_launch_status();
 }

@@ -133,13 +133,13 @@ __global__ __launch_bounds__(64) void radix_scatter(const uint32_t* __restrict__
 
 // ------------------------------------------------------------------------------------------------ fused small-n sort
 // n <= RE_FUSED_MAX_TILES * 1024 keys (a training batch: 76 800 contributions at SASRec/Beauty, 160 k at DeepFM/Criteo):
-// the generic pipeline above is 1 + 3 launches per pass, each a latency-bound 64-thread tile walk.  Here a pass is ONE
-// launch.  Tiles are 1024 keys on 256 threads (4 keys per lane, all loaded before the first ranking round); the scan
+// the generic pipeline above is 1 + 3 launches per pass, each a latency-bound 64-thread tile walk.  Here a pass is two
+// launches.  Tiles are 1024 keys on 256 threads (4 keys per lane, all loaded before the first ranking round); the scan
 // kernel is folded into the scatter kernel (thread d sums column d of the [T x 256] tile histogram: everything below its
-// tile, and the column total; one block scan over the totals gives the digit bases); the NEXT pass's tile histogram is
-// built by the scatter itself with integer atomics on the tile its output lands in (integer counts: deterministic).
-// The first pass reads idx directly (no key/val arrays yet) and its histogram kernel also zero-fills dW and the later
-// passes' histograms.  Launches: 1 + passes (+ 2 for the segmented sum), vs 2 + 3 * passes (+ 2).
+// tile, and the column total; one block scan over the totals gives the digit bases).  The first pass reads idx directly
+// (no key/val arrays yet) and its histogram kernel also zero-fills dW.  (Building the next pass's histogram inside the
+// scatter with global integer atomics was measured slower than a separate 256-thread histogram launch: 76 800
+// contended atomics cost 14 us, the launch 4 us.)  Launches: 2 * passes (+ 2 for the segmented sum), vs 2 + 3 * passes (+ 2).
 #define RE_FUSED_MAX_TILES 512
 
 __device__ __forceinline__ uint32_t sc_key(int64_t r, int64_t R, int64_t padding_idx) {
@@ -173,13 +173,31 @@ __global__ __launch_bounds__(256) void sc_hist0(const int64_t* __restrict__ idx,
     hist0[(int64_t)blockIdx.x * 256 + tid] = h[tid];
 }
 
-// FIRST: keys come from idx (vals = position).  hist_next != nullptr: count the next pass's digits per OUTPUT tile.
+__global__ __launch_bounds__(256) void sc_histk(const uint32_t* __restrict__ keys, int64_t n, int shift, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RE_SORT_TILE;
+    uint32_t k[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = base + q * 256 + tid;
+        k[q] = i < n ? keys[i] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (base + q * 256 + tid < n) atomicAdd(&h[(k[q] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist[(int64_t)blockIdx.x * 256 + tid] = h[tid];
+}
+
+// FIRST: keys come from idx (vals = position).
 template <bool FIRST>
 __global__ __launch_bounds__(256) void sc_scatter(const int64_t* __restrict__ idx, int64_t R, int64_t padding_idx,
                                                   const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n,
                                                   int shift, const uint32_t* __restrict__ hist, int T,
-                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                  uint32_t* __restrict__ hist_next, int shift_next) {
+                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
     __shared__ uint32_t base[4][256];   // per wave: running output offset of each digit
     __shared__ uint32_t wcnt[4][256];   // per wave: digit counts of its 256-key strip
     __shared__ uint32_t wtot[4];
@@ -264,7 +282,6 @@ __global__ __launch_bounds__(256) void sc_scatter(const int64_t* __restrict__ id
         if (ok[r]) {
             keys_out[off] = k[r];
             vals_out[off] = v[r];
-            if (hist_next) atomicAdd(&hist_next[(int64_t)(off >> 10) * 256 + ((k[r] >> shift_next) & 255u)], 1u);
         }
     }
 }
@@ -523,17 +540,17 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
         const int64_t zfloats = accumulate ? (int64_t)0 : (int64_t)R * D;
         int64_t zblocks = re_cdiv(zfloats, 4096);   // >= 16 KB of zero fill per block
         if (zblocks > 2048) zblocks = 2048;
+        (void)hwords;
         hipLaunchKernelGGL(sc_hist0, dim3((unsigned)(zblocks > T ? zblocks : T)), dim3(256), 0, s, idx, n, R, padding_idx, w.hist,
-                           w.hist + hwords, (int64_t)(passes - 1) * hwords, dW, zfloats,
-                           (reinterpret_cast<uintptr_t>(dW) & 15u) ? (int64_t)0 : zfloats >> 2, T);
+                           (uint32_t*)nullptr, (int64_t)0, dW, zfloats, (reinterpret_cast<uintptr_t>(dW) & 15u) ? (int64_t)0 : zfloats >> 2, T);
         for (int p = 0; p < passes; ++p) {
-            uint32_t* hn = (p + 1 < passes) ? w.hist + (int64_t)(p + 1) * hwords : (uint32_t*)nullptr;
-            if (p == 0)
+            if (p == 0) {
                 hipLaunchKernelGGL(sc_scatter<true>, dim3((unsigned)T), dim3(256), 0, s, idx, R, padding_idx, (const uint32_t*)nullptr,
-                                   (const uint32_t*)nullptr, n, 0, w.hist, T, ko, vo, hn, 8);
-            else
-                hipLaunchKernelGGL(sc_scatter<false>, dim3((unsigned)T), dim3(256), 0, s, idx, R, padding_idx, ki, vi, n, 8 * p,
-                                   w.hist + (int64_t)p * hwords, T, ko, vo, hn, 8 * (p + 1));
+                                   (const uint32_t*)nullptr, n, 0, w.hist, T, ko, vo);
+            } else {
+                hipLaunchKernelGGL(sc_histk, dim3((unsigned)T), dim3(256), 0, s, ki, n, 8 * p, w.hist);
+                hipLaunchKernelGGL(sc_scatter<false>, dim3((unsigned)T), dim3(256), 0, s, idx, R, padding_idx, ki, vi, n, 8 * p, w.hist, T, ko, vo);
+            }
             uint32_t* t;
             t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
