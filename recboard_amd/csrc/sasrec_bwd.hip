@@ -99,6 +99,17 @@ __device__ __forceinline__ void ln_apply_row(const float* x, float* dst, const f
     for (int i = 0; i < SE_CPT; ++i) dst[SE_RO(r) + c0 + i] = (x[SE_RO(r) + c0 + i] - mu) * rs * gw[c0 + i] + gb[c0 + i];
 }
 
+// (two-step form of load_stats: request early, commit when the arrays are free)
+__device__ __forceinline__ void stats_fetch(float2& r, const float* __restrict__ st, const int* s_gid, int tid) {
+    r = make_float2(0.f, 0.f);
+    if (tid < SE_ROWS) {
+        const int gid = s_gid[tid];
+        if (gid >= 0) r = *reinterpret_cast<const float2*>(st + 2 * (int64_t)gid);
+    }
+}
+__device__ __forceinline__ void stats_commit(float* s_a, float* s_b, const float2& r, int tid) {
+    if (tid < SE_ROWS) { s_a[tid] = r.x; s_b[tid] = r.y; }
+}
 __device__ __forceinline__ void load_stats(float* s_a, float* s_b, const float* __restrict__ st, const int* s_gid, int tid) {
     if (tid < SE_ROWS) {
         const int gid = s_gid[tid];
@@ -159,12 +170,20 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         __syncthreads();
         SE_MARK(1, 1);
         float4 R[SE_WV];                 // the next weight matrix, in flight from global memory
+        TileRegs T0, T1;                 // the next tape tiles, in flight from global memory (requested a phase ahead)
+        float2 ST;                       // ... and the next LayerNorm statistics / pad-key pair
         wtile_fetch(R, W.w2, tid);
-        tile_load(b0, dIn, s_gid, tid);
+        tile_fetch(T0, dIn, s_gid, tid);
+        tile_fetch(T1, FIRST ? tape + T.off_XL : tp + T.off_HR, s_gid, tid);
         if (FIRST) {
-            tile_load(b1, tape + T.off_XL, s_gid, tid);
-            load_stats(s_mean, s_rstd, tape + T.off_SL, s_gid, tid);
+            stats_fetch(ST, tape + T.off_SL, s_gid, tid);
+            stats_commit(s_mean, s_rstd, ST, tid);
         }
+        tile_commit(b0, T0, tid);
+        tile_commit(b1, T1, tid);
+        if (FIRST) tile_fetch(T1, tp + T.off_HR, s_gid, tid);
+        tile_fetch(T0, tp + T.off_X1, s_gid, tid);
+        stats_fetch(ST, tp + T.off_SF, s_gid, tid);
         __syncthreads();
         if (FIRST) {  // u = LN_last(x_L): dgamma/dbeta, then dx_L in place
             accV[10] += colsum16_xhat(b0, b1, s_mean, s_rstd, tid);
@@ -172,10 +191,10 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
             __syncthreads();
             ln_bwd_row<false>(b0, b1, b0, last_w, s_mean, s_rstd, tid);
             __syncthreads();
+            tile_commit(b1, T1, tid);    // HR
         }
         SE_MARK(1, 2);
         // ---- pad mask of the block output (x'[pad] = 0) and dO2 = dX' * dropout2 mask
-        tile_load(b1, tp + T.off_HR, s_gid, tid);
         {
             const int r = r_e, c0 = c0_e;
             const bool dead = s_pad[r] != 0;
@@ -210,8 +229,9 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         __syncthreads();
         SE_MARK(1, 4);
         // ---- B. FFN first map: y = LN_f(x1) rebuilt; dW1 += dH^T y; db1; dY = dH W1 + dX'
-        tile_load(b1, tp + T.off_X1, s_gid, tid);
-        load_stats(s_mean, s_rstd, tp + T.off_SF, s_gid, tid);
+        tile_commit(b1, T0, tid);        // X1
+        stats_commit(s_mean, s_rstd, ST, tid);
+        tile_fetch(T0, tp + T.off_O, s_gid, tid);
         __syncthreads();
         ln_apply_row(b1, b2, W.ln_f_w, W.ln_f_b, s_mean, s_rstd, tid);
         __syncthreads();
@@ -235,7 +255,19 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         __syncthreads();
         SE_MARK(1, 6);
         // ---- D. out_proj: dWo += dX1^T o; dbo; dO = dX1 Wo
-        tile_load(b2, tp + T.off_O, s_gid, tid);
+        tile_commit(b2, T0, tid);        // O
+        tile_fetch(T0, tp + T.off_V, s_gid, tid);
+        stats_fetch(ST, tp + T.off_PP, s_gid, tid);
+        float pq[SE_CPT];                // this thread's slice of the saved probabilities
+        {
+            const int gi = s_gid[r_e];
+#pragma unroll
+            for (int q = 0; q < SE_CPT / 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gi >= 0) v = reinterpret_cast<const float4*>(tp + T.off_P + (int64_t)gi * SE_ROWS + c0_e)[q];
+                pq[4 * q] = v.x; pq[4 * q + 1] = v.y; pq[4 * q + 2] = v.z; pq[4 * q + 3] = v.w;
+            }
+        }
         __syncthreads();
         {
             float bf[16];
@@ -250,21 +282,23 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         __syncthreads();
         SE_MARK(1, 7);
         // ---- E. attention: load V, P; Pd = P*mask; dP = (dO V^T)*mask; dV = Pd^T dO; dS = P (dP - rowsum(dP P)) / sqrt(D)
-        tile_load(b1, tp + T.off_V, s_gid, tid);
-        load_stats(s_ppad, s_w, tp + T.off_PP, s_gid, tid);   // (p_pad, w) of the virtual out-of-window pad key
+        tile_commit(b1, T0, tid);        // V
+        stats_commit(s_ppad, s_w, ST, tid);   // (p_pad, w) of the virtual out-of-window pad key
+        tile_fetch(T0, tp + T.off_Q, s_gid, tid);
+        tile_fetch(T1, tp + T.off_K, s_gid, tid);
         {
-            const float* Pg = tp + T.off_P;
             const int i = r_e, j0 = c0_e;
-            const int gi = s_gid[i], grp = s_grp[i];
+            const int gi = s_gid[i];
             const int sbase = gi >= 0 ? (gi / S) * S : 0;
 #pragma unroll
             for (int jj = 0; jj < SE_CPT; ++jj) {
                 const int j = j0 + jj;
-                const bool ok = gi >= 0 && j <= i && s_gid[j] >= 0 && s_grp[j] == grp;
-                const int sj = ok ? s_gid[j] - sbase : 0;
-                float p = ok ? Pg[(int64_t)gi * S + sj] : 0.f;
+                const float p = pq[jj];          // 0 outside the causal / same-sequence window (the forward stored zeros there)
                 float m = 1.0f;
-                if (thresh && p != 0.f) m = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? drop_scale : 0.f;
+                if (thresh && p != 0.f) {
+                    const int sj = s_gid[j] - sbase;
+                    m = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? drop_scale : 0.f;
+                }
                 b4[SE_RO(i) + j] = p;
                 b6[SE_RO(i) + j] = p * m;
             }
@@ -311,8 +345,10 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         __syncthreads();   // dS complete; dO (b3), V (b1) and P (b4) no longer needed
         SE_MARK(1, 10);
         // ---- F. dQ = dS K -> b4 ; dK = dS^T Q -> b6
-        tile_load(b3, tp + T.off_Q, s_gid, tid);
-        tile_load(b1, tp + T.off_K, s_gid, tid);
+        tile_commit(b3, T0, tid);        // Q
+        tile_commit(b1, T1, tid);        // K
+        tile_fetch(T0, tp + T.off_X, s_gid, tid);
+        stats_fetch(ST, tp + T.off_SA, s_gid, tid);
         __syncthreads();
         {
             float bf[16];
@@ -330,8 +366,8 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         __syncthreads();
         SE_MARK(1, 11);
         // ---- G. projections: x, LN_a(x) rebuilt; dWq/dWk/dWv, biases; dA1 = dQ Wq -> b5; dX (b0) += dK Wk + dV Wv
-        tile_load(b1, tp + T.off_X, s_gid, tid);
-        load_stats(s_mean, s_rstd, tp + T.off_SA, s_gid, tid);
+        tile_commit(b1, T0, tid);        // X
+        stats_commit(s_mean, s_rstd, ST, tid);
         __syncthreads();
         ln_apply_row(b1, b3, W.ln_a_w, W.ln_a_b, s_mean, s_rstd, tid);
         __syncthreads();

@@ -58,14 +58,15 @@ struct SasrecParams {
 };
 
 // ---- tape layout (activations saved by the forward for the backward), all fp32, per block l:
-//   X, Q, K, V, O, X1, HR : [B][S][D]     P : [B][S][S]     stats_a, stats_f : [B][S][2] (mean, rstd)   PP : [B][S][2]
+//   X, Q, K, V, O, X1, HR : [B][S][D]     P : [B][S][64] (tile columns of the work item: one aligned float4 per thread)
+//   stats_a, stats_f : [B][S][2] (mean, rstd)   PP : [B][S][2]
 // then XL [B][S][D] (input of lastLN) and stats_last [B][S][2].
 struct SasrecTape {
     int64_t per_block, off_X, off_Q, off_K, off_V, off_O, off_X1, off_HR, off_P, off_SA, off_SF, off_PP, off_XL, off_SL, total;
 };
 __host__ __device__ inline SasrecTape sasrec_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L) {
     SasrecTape t;
-    const int64_t act = B * S * D, pp = B * S * S, st = B * S * 2;
+    const int64_t act = B * S * D, pp = B * S * SE_ROWS, st = B * S * 2;
     int64_t o = 0;
     t.off_X = o; o += act;
     t.off_Q = o; o += act;
@@ -284,6 +285,29 @@ __device__ __forceinline__ int se_decode(int wi, const SeWork& W, int B, int S, 
         s_pad[tid] = (gid < 0) ? 1 : (seq[gid] == 0);
     }
     return (shortw && S > SE_WIN) ? S - SE_WIN : 0;
+}
+
+// two-step tile load: the global loads are requested a phase ahead into registers (one float4 per thread at 16 waves) and
+// committed to LDS once the destination tile is free -- the tape round trip overlaps the previous phase's GEMMs
+#define SE_TV (SE_ROWS * (SE_D / 4) / SE_NT)
+struct TileRegs {
+    float4 v[SE_TV];
+};
+__device__ __forceinline__ void tile_fetch(TileRegs& R, const float* __restrict__ gsrc, const int* s_gid, int tid) {
+#pragma unroll
+    for (int q = 0; q < SE_TV; ++q) {
+        const int f = q * SE_NT + tid;
+        const int gid = s_gid[f >> 4];
+        R.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gid >= 0) R.v[q] = reinterpret_cast<const float4*>(gsrc + (int64_t)gid * SE_D)[f & 15];
+    }
+}
+__device__ __forceinline__ void tile_commit(float* tile, const TileRegs& R, int tid) {
+#pragma unroll
+    for (int q = 0; q < SE_TV; ++q) {
+        const int f = q * SE_NT + tid;
+        *reinterpret_cast<float4*>(tile + SE_RO(f >> 4) + 4 * (f & 15)) = R.v[q];
+    }
 }
 
 // copy LDS tile rows <-> rows of a [B*S][64] global matrix selected by s_gid (coalesced float4 per row)

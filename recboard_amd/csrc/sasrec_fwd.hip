@@ -165,13 +165,18 @@ __global__ __launch_bounds__(SE_NT) void sasrec_encoder_fwd_k(const float* __res
                 } else if (row_lead) {
                     s_w[i] = 0.f;
                 }
+                if (TRAIN && gi >= 0) {   // pre-dropout probabilities, tile-column layout: one aligned store per SE_CPT columns
+#pragma unroll
+                    for (int q = 0; q < SE_CPT / 4; ++q)
+                        reinterpret_cast<float4*>(tp + T.off_P + (int64_t)gi * SE_ROWS + c0_e)[q] =
+                            make_float4(p[4 * q] * inv, p[4 * q + 1] * inv, p[4 * q + 2] * inv, p[4 * q + 3] * inv);
+                }
 #pragma unroll
                 for (int jj = 0; jj < SE_CPT; ++jj) {
                     const int j = c0_e + jj;
                     float pr = p[jj] * inv;
                     if ((okm >> jj) & 1u) {
                         const int sj = s_gid[j] - (gi / S) * S;   // position of key j inside the sequence
-                        if (TRAIN) tp[T.off_P + (int64_t)gi * S + sj] = pr;
                         if (thresh && pr != 0.f)
                             pr = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? pr * drop_scale : 0.f;
                     }
