@@ -72,6 +72,17 @@ int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int64_t S, int
  * two calls on the same input give bit-identical output.
  * Replaces aten embedding_dense_backward / index_put_(accumulate) reached from `loss.backward()`
  * (SASRec/main.py:249, MF-BPR/main.py:122).  `scale` multiplies every contribution (SASRec: sqrt(D)). */
+/* The two halves of re_scatter_add_rows as separate entry points (same workspace, same sizes):
+ *   re_scatter_plan   -- the index half: stable sort of (destination row, position) into ws; depends on idx only, so a
+ *                        training step can run it on a second stream while the gradient rows are still being produced.
+ *                        Optionally zero-fills `zero_fill[0:zero_floats]` (the table the apply step accumulates into).
+ *   re_scatter_apply  -- the data half: segmented sum of the rows of g in sorted order into dW (accumulate != 0: dW += ...;
+ *                        else dW is zero-filled first).  Must follow a re_scatter_plan with the same (n, D, R, ws).
+ * plan followed by apply(accumulate = 1) on a zero-filled table equals re_scatter_add_rows(accumulate = 0). */
+int re_scatter_plan(const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* zero_fill,
+                    int64_t zero_floats, void* ws, size_t ws_bytes, re_stream_t stream);
+int re_scatter_apply(const float* g, int64_t n, int64_t D, int64_t R, float scale, float* dW, int accumulate, void* ws,
+                     size_t ws_bytes, re_stream_t stream);
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                         int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,

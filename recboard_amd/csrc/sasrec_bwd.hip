@@ -13,6 +13,7 @@
 // MFMA-bound: 16 GEMMs x 2*64^3 = 8.39 MFLOP per sequence per block.
 #include <math.h>
 
+#define SE_NW 8
 #include "sasrec_common.h"
 
 #define SB_NMAT 6
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
 #pragma unroll
     for (int v = 0; v < SB_NVEC; ++v) red[(v * SE_NW + wave) * 64 + lane] = accV[v];
     __syncthreads();
-    if (tid < SB_NVEC * 64) {
-        const int v = tid >> 6, cc = tid & 63;
+    for (int e = tid; e < SB_NVEC * 64; e += SE_NT) {
+        const int v = e >> 6, cc = e & 63;
         float s = red[(v * SE_NW) * 64 + cc];
 #pragma unroll
         for (int i = 1; i < SE_NW; ++i) s += red[(v * SE_NW + i) * 64 + cc];

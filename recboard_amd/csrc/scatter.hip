@@ -320,12 +320,21 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
         for (int64_t j0 = begin; j0 < end; j0 += RE_SEG_CHUNK) {   // (one trip: every load of the chunk is in flight at once)
             uint32_t k[RE_SEG_CHUNK];
             V row[RE_SEG_CHUNK];
+            // two dependent load stages, no branches in between: (keys, positions) of the whole chunk, then every row --
+            // a dropped entry's position is still a valid row of g, so its row is simply loaded and not used
+            uint32_t pos[RE_SEG_CHUNK];
 #pragma unroll
             for (int u = 0; u < RE_SEG_CHUNK; ++u) {
-                const int64_t j = j0 + u;
-                k[u] = j < end ? keys[j] : NONE;
-                row[u] = vzero<V>();
-                if (j < end && k[u] != DROP) row[u] = reinterpret_cast<const V*>(g + (int64_t)vals[j] * D)[col];
+                const int64_t j = (j0 + u < end) ? j0 + u : end - 1;
+                k[u] = keys[j];
+                pos[u] = vals[j];
+            }
+#pragma unroll
+            for (int u = 0; u < RE_SEG_CHUNK; ++u) row[u] = reinterpret_cast<const V*>(g + (int64_t)pos[u] * D)[col];
+#pragma unroll
+            for (int u = 0; u < RE_SEG_CHUNK; ++u) {
+                if (j0 + u >= end) k[u] = NONE;
+                if (k[u] == DROP) row[u] = vzero<V>();
             }
 #pragma unroll
             for (int u = 0; u < RE_SEG_CHUNK; ++u) {
@@ -516,33 +525,25 @@ extern "C" size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int6
     return scatter_ws_layout(nullptr, n, D).bytes;
 }
 
-extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
-                                   int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,
-                                   re_stream_t stream) {
-    re_clear_error();
-    if (!dW || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
-    if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) {
-        if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
-        return RE_OK;
-    }
-    if (!g || !idx || !ws) return RE_EINVAL;
-    ScatterWs w = scatter_ws_layout(ws, n, D);
-    if (ws_bytes < w.bytes) return RE_EWORKSPACE;
+// ---- the index half (sort) and the data half (segmented sum) are separate entry points: the sort depends on idx only,
+//      so a training step can run it on a second stream while the gradients are still being computed.
+static int scatter_passes(int64_t R) {
     int bits = 1;
     while (((int64_t)1 << bits) <= R) ++bits;  // keys take values 0..R
-    const int passes = (bits + 7) / 8;
+    return (bits + 7) / 8;
+}
+
+static int scatter_sort(const int64_t* idx, int64_t n, int64_t R, int64_t padding_idx, float* zero_fill, int64_t zfloats,
+                        const ScatterWs& w, hipStream_t s) {
+    const int passes = scatter_passes(R);
     uint32_t *ki = w.k0, *vi = w.v0, *ko = w.k1, *vo = w.v1;
     if (w.T <= RE_FUSED_MAX_TILES) {
         const int T = (int)w.T;
-        const int64_t hwords = (int64_t)T * 256;
-        const int64_t zfloats = accumulate ? (int64_t)0 : (int64_t)R * D;
         int64_t zblocks = re_cdiv(zfloats, 4096);   // >= 16 KB of zero fill per block
         if (zblocks > 2048) zblocks = 2048;
-        (void)hwords;
         hipLaunchKernelGGL(sc_hist0, dim3((unsigned)(zblocks > T ? zblocks : T)), dim3(256), 0, s, idx, n, R, padding_idx, w.hist,
-                           (uint32_t*)nullptr, (int64_t)0, dW, zfloats, (reinterpret_cast<uintptr_t>(dW) & 15u) ? (int64_t)0 : zfloats >> 2, T);
+                           (uint32_t*)nullptr, (int64_t)0, zero_fill, zfloats,
+                           (reinterpret_cast<uintptr_t>(zero_fill) & 15u) ? (int64_t)0 : zfloats >> 2, T);
         for (int p = 0; p < passes; ++p) {
             if (p == 0) {
                 hipLaunchKernelGGL(sc_scatter<true>, dim3((unsigned)T), dim3(256), 0, s, idx, R, padding_idx, (const uint32_t*)nullptr,
@@ -556,17 +557,25 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
             t = vi; vi = vo; vo = t;
         }
     } else {
-        if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        if (zfloats > 0 && hipMemsetAsync(zero_fill, 0, (size_t)zfloats * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(scatter_make_keys, dim3(re_grid(n, 256)), dim3(256), 0, s, idx, n, R, padding_idx, w.k0, w.v0);
-        for (int shift = 0; shift < bits; shift += 8) {
-            hipLaunchKernelGGL(radix_hist, dim3((unsigned)w.T), dim3(64), 0, s, ki, n, shift, w.hist, w.T);
+        for (int p = 0; p < passes; ++p) {
+            hipLaunchKernelGGL(radix_hist, dim3((unsigned)w.T), dim3(64), 0, s, ki, n, 8 * p, w.hist, w.T);
             hipLaunchKernelGGL(radix_scan, dim3(1), dim3(1024), 0, s, w.hist, (int64_t)256 * w.T);
-            hipLaunchKernelGGL(radix_scatter, dim3((unsigned)w.T), dim3(64), 0, s, ki, vi, n, shift, w.hist, w.T, ko, vo);
+            hipLaunchKernelGGL(radix_scatter, dim3((unsigned)w.T), dim3(64), 0, s, ki, vi, n, 8 * p, w.hist, w.T, ko, vo);
             uint32_t* t;
             t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
         }
     }
+    return RE_OK;
+}
+
+static void scatter_reduce(const float* g, int64_t n, int64_t D, int64_t R, float scale, float* dW, int accumulate, const ScatterWs& w,
+                           hipStream_t s) {
+    const bool odd = scatter_passes(R) & 1;   // every pass ping-pongs the key / value arrays
+    const uint32_t* ki = odd ? w.k1 : w.k0;
+    const uint32_t* vi = odd ? w.v1 : w.v0;
     const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u) == 0;
 #define SEG_LAUNCH(LPRV, VT)                                                                                                       \
     do {                                                                                                                           \
@@ -585,5 +594,59 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
         else SEG_LAUNCH(4, float);
     }
 #undef SEG_LAUNCH
+}
+
+extern "C" int re_scatter_plan(const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* zero_fill,
+                               int64_t zero_floats, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (R <= 0 || D <= 0 || n < 0 || zero_floats < 0 || (zero_floats > 0 && !zero_fill)) return RE_EINVAL;
+    if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (zero_floats > 0 && hipMemsetAsync(zero_fill, 0, (size_t)zero_floats * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        return RE_OK;
+    }
+    if (!idx || !ws) return RE_EINVAL;
+    ScatterWs w = scatter_ws_layout(ws, n, D);
+    if (ws_bytes < w.bytes) return RE_EWORKSPACE;
+    const int rc = scatter_sort(idx, n, R, padding_idx, zero_fill, zero_floats, w, s);
+    return rc != RE_OK ? rc : re_launch_status();
+}
+
+extern "C" int re_scatter_apply(const float* g, int64_t n, int64_t D, int64_t R, float scale, float* dW, int accumulate, void* ws,
+                                size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!dW || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
+    if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        return RE_OK;
+    }
+    if (!g || !ws) return RE_EINVAL;
+    ScatterWs w = scatter_ws_layout(ws, n, D);
+    if (ws_bytes < w.bytes) return RE_EWORKSPACE;
+    if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+    scatter_reduce(g, n, D, R, scale, dW, 1, w, s);
+    return re_launch_status();
+}
+
+extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
+                                   int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,
+                                   re_stream_t stream) {
+    re_clear_error();
+    if (!dW || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
+    if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        return RE_OK;
+    }
+    if (!g || !idx || !ws) return RE_EINVAL;
+    ScatterWs w = scatter_ws_layout(ws, n, D);
+    if (ws_bytes < w.bytes) return RE_EWORKSPACE;
+    const int rc = scatter_sort(idx, n, R, padding_idx, dW, accumulate ? (int64_t)0 : (int64_t)R * D, w, s);
+    if (rc != RE_OK) return rc;
+    scatter_reduce(g, n, D, R, scale, dW, accumulate, w, s);
     return re_launch_status();
 }

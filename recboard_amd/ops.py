@@ -92,6 +92,25 @@ def scatter_add_rows(g: torch.Tensor, idx: torch.Tensor, R: int, padding_idx: in
     return dW
 
 
+def scatter_plan(idx, D, R, ws, padding_idx=-1, zero=None):
+    """Index half of scatter_add_rows (re_scatter_plan): sorts (destination row, position) into `ws`; optionally zero-fills
+    `zero` (the table scatter_apply will accumulate into).  Depends on idx only -- may run on a side stream."""
+    _req(idx, torch.int64, "idx"); _req(ws, torch.uint8, "ws")
+    if zero is not None:
+        _req(zero, torch.float32, "zero")
+    lib.check(lib.load().re_scatter_plan(_p(idx), idx.numel(), int(D), int(R), int(padding_idx), _p(zero),
+                                         0 if zero is None else zero.numel(), _p(ws), ws.numel(), _stream()), "re_scatter_plan")
+
+
+def scatter_apply(g, R, out, ws, scale=1.0, accumulate=True):
+    """Data half of scatter_add_rows (re_scatter_apply): out (+)= segmented sum of g's rows in the order scatter_plan left in ws."""
+    _req(g, torch.float32, "g"); _req(out, torch.float32, "out"); _req(ws, torch.uint8, "ws")
+    n, D = g.shape
+    lib.check(lib.load().re_scatter_apply(_p(g), n, D, int(R), float(scale), _p(out), int(bool(accumulate)), _p(ws), ws.numel(),
+                                          _stream()), "re_scatter_apply")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ K3
 def pair_loss_fwd(U, E, pos, neg, valid, kind, e_off=0):
     """U [n, D] (rows may be strided), E [R, D]; returns (loss[1], logits[n,2], count int32[1])."""

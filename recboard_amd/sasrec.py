@@ -286,13 +286,13 @@ class SASRecEngine:
         bt = self._block_tensors()
         kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
         n = B * S
+        GE = G["Item.embeddings.weight"]
         ops.sasrec_embed(E, Ppos, seq, float(D ** 0.5), p, sd, out=W["x0"], seed_dev=seed_dev)
         ops.sasrec_encoder_fwd(W["x0"], seq, bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"], packing=packing,
                                seed_dev=seed_dev)
         u2 = W["u"].view(n, D)
         posf, negf = pos.reshape(-1), neg.reshape(-1)
         C = W["contrib"]
-        GE = G["Item.embeddings.weight"]
         if self.loss_kind == "CE":
             # SASRec/main.py:216-219: logits = u[valid] E[1:]^T, mean CE against IPos -- three fp32 MFMA GEMMs + one row kernel
             Uv = ops.gather_rows(u2, vidx)                                   # [M, D]
@@ -308,6 +308,8 @@ class SASRecEngine:
                                G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing,
                                seed_dev=seed_dev)
         ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, G["Position.weight"], ws=W["ws_emb"], seed_dev=seed_dev)
+        # (running the index half -- ops.scatter_plan -- on a second stream underneath the encoder was measured: no gain inside
+        #  a hipGraph, and the extra event traffic slows the eager launch path)
         ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])
         if self.loss_kind == "CE":
             ops.gemm(logits, Uv, transA=True, beta=1.0, out=GE[1:])          # dE[1:] += dlogits^T u[valid]

@@ -346,3 +346,22 @@ def test_evaluator_matches_reference_golden_pipeline(ops):
     ref = ranking.metrics_dense(s, tg, (1, 10, 50))
     for k in got:
         np.testing.assert_allclose(got[k], ref[k].mean(), rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_scatter_plan_apply_equals_scatter_add_rows(ops):
+    """re_scatter_plan + re_scatter_apply (the index / data halves as separate entry points) == re_scatter_add_rows, bitwise."""
+    g = torch.Generator().manual_seed(3)
+    n, D, R = 5000, 64, 700
+    idx = torch.randint(0, R, (n,), generator=g).cuda()
+    rows = torch.randn(n, D, generator=g).cuda()
+    ref = ops.scatter_add_rows(rows, idx, R, padding_idx=0)
+    from recboard_amd import lib
+    ws = torch.empty(lib.load().re_scatter_add_rows_workspace_bytes(n, D, R), dtype=torch.uint8, device="cuda")
+    out = torch.full((R, D), 7.0, device="cuda")
+    ops.scatter_plan(idx, D, R, ws, padding_idx=0, zero=out)
+    ops.scatter_apply(rows, R, out, ws, accumulate=True)
+    assert torch.equal(out, ref)
+    out2 = torch.full((R, D), 7.0, device="cuda")
+    ops.scatter_plan(idx, D, R, ws, padding_idx=0)
+    ops.scatter_apply(rows, R, out2, ws, accumulate=False)
+    assert torch.equal(out2, ref)
