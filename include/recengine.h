@@ -114,6 +114,14 @@ int re_pair_loss_bwd(const float* U, int64_t ldu, const float* E, int64_t R, int
                      const float* logits, const int32_t* count, const float* dloss, float* dU, int64_t lddu,
                      float* gpos, float* gneg, re_stream_t stream);
 
+/* Forward + backward in one pass for training steps (upstream gradient of the mean loss = 1): `count` (DEVICE int32[1]) must
+ * hold M, the number of valid positions -- known at batch assembly (sum of `valid`), so no reduction has to finish before
+ * the gradient rows are scaled.  Outputs as re_pair_loss_fwd (loss) and re_pair_loss_bwd (dU, gpos, gneg). */
+int re_pair_loss_fwd_bwd(const float* U, int64_t ldu, const float* E, int64_t R, int64_t D, int64_t e_off,
+                         const int64_t* pos, const int64_t* neg, const uint8_t* valid, int64_t n, int kind,
+                         const int32_t* count, float* loss, float* dU, int64_t lddu, float* gpos, float* gneg,
+                         void* ws, size_t ws_bytes, re_stream_t stream);
+
 /* MF-BPR / LightGCN triplet form (MF-BPR/main.py:81-93): rows gathered from TWO tables inside the kernel.
  *      pl = <Ut[users[i]], It[pos[i]]>, nl = <Ut[users[i]], It[neg[i]]>, loss = mean softplus(nl - pl)
  * bwd writes the three contribution-row sets (for re_scatter_add_rows into dUt / dIt). */
@@ -124,6 +132,10 @@ int re_bpr_triplet_bwd(const float* Ut, int64_t RU, const float* It, int64_t RI,
                        const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                        const float* logits, const float* dloss, float* gu, float* gpos, float* gneg,
                        re_stream_t stream);
+/* forward + backward in one pass (M = n) */
+int re_bpr_triplet_fwd_bwd(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D, const int64_t* users,
+                           const int64_t* pos, const int64_t* neg, int64_t n, float* loss, float* gu, float* gpos,
+                           float* gneg, void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K4  full-catalog scoring.

@@ -140,6 +140,94 @@ __global__ __launch_bounds__(256) void pair_loss_bwd_k(const float* __restrict__
     }
 }
 
+// Forward and backward in ONE pass over the rows (training steps, where the upstream gradient of the mean loss is 1 and
+// the number of valid positions M is known before the launch: a host count, or a device word computed at batch assembly).
+// Reads each of the three rows once, writes the three gradient rows; the loss partials go through the same
+// deterministic per-block reduction as the forward-only kernel.
+template <int LPR>
+__global__ __launch_bounds__(256) void pair_loss_fused_k(const float* __restrict__ Ubase, int64_t ldu, int64_t RU,
+                                                         const int64_t* __restrict__ uidx,
+                                                         const float* __restrict__ E, int64_t R, int64_t D, int64_t e_off,
+                                                         const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                                         const uint8_t* __restrict__ valid, int64_t n, int kind,
+                                                         const int32_t* __restrict__ count, int64_t count_host,
+                                                         float* __restrict__ dU, int64_t lddu, float* __restrict__ gpos,
+                                                         float* __restrict__ gneg, float* __restrict__ bsum, int32_t* __restrict__ bcnt) {
+    __shared__ float s_sum[4];
+    __shared__ int s_cnt[4];
+    const int lir = threadIdx.x % LPR;
+    const int64_t gpb = 256 / LPR;
+    const int64_t D4 = D >> 2;
+    const float gs = 1.0f / (count ? (float)count[0] : (float)count_host);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lsum = 0.f;
+    int lcnt = 0;
+    for (int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR; i < n; i += (int64_t)gridDim.x * gpb) {
+        bool ok = valid ? valid[i] != 0 : true;
+        int64_t ur = uidx ? uidx[i] : i;
+        int64_t pr = pos[i] + e_off, nr = neg[i] + e_off;
+        ok = ok && ur >= 0 && ur < RU && pr >= 0 && pr < R && nr >= 0 && nr < R;
+        float4* du = reinterpret_cast<float4*>(dU + i * lddu);
+        float4* gp = reinterpret_cast<float4*>(gpos + i * D);
+        float4* gn = reinterpret_cast<float4*>(gneg + i * D);
+        if (!ok) {   // (uniform over the lane group)
+            for (int64_t c = lir; c < D4; c += LPR) { du[c] = z; gp[c] = z; gn[c] = z; }
+            continue;
+        }
+        const float4* u = reinterpret_cast<const float4*>(Ubase + ur * ldu);
+        const float4* ep = reinterpret_cast<const float4*>(E + pr * D);
+        const float4* en = reinterpret_cast<const float4*>(E + nr * D);
+        if (D4 <= LPR) {   // the common case (D = 64: 16 lanes x float4): rows stay in registers between the two halves
+            float4 a = z, b = z, d = z;
+            if (lir < D4) { a = u[lir]; b = ep[lir]; d = en[lir]; }
+            const float pl = group_sum<LPR>(dot4(a, b)), nl = group_sum<LPR>(dot4(a, d));
+            float dpl, dnl;
+            if (kind == RE_LOSS_BCE) { dpl = -re_sigmoid(-pl) * gs; dnl = re_sigmoid(nl) * gs; }
+            else { const float sg = re_sigmoid(nl - pl) * gs; dpl = -sg; dnl = sg; }
+            if (lir < D4) {
+                du[lir] = make_float4(fmaf(dpl, b.x, dnl * d.x), fmaf(dpl, b.y, dnl * d.y), fmaf(dpl, b.z, dnl * d.z), fmaf(dpl, b.w, dnl * d.w));
+                gp[lir] = make_float4(dpl * a.x, dpl * a.y, dpl * a.z, dpl * a.w);
+                gn[lir] = make_float4(dnl * a.x, dnl * a.y, dnl * a.z, dnl * a.w);
+            }
+            if (lir == 0) {
+                lsum += (kind == RE_LOSS_BCE) ? re_softplus(-pl) + re_softplus(nl) : re_softplus(nl - pl);
+                lcnt += 1;
+            }
+        } else {
+            float pl = 0.f, nl = 0.f;
+            for (int64_t c = lir; c < D4; c += LPR) {
+                const float4 a = u[c], b = ep[c], d = en[c];
+                pl += dot4(a, b);
+                nl += dot4(a, d);
+            }
+            pl = group_sum<LPR>(pl);
+            nl = group_sum<LPR>(nl);
+            float dpl, dnl;
+            if (kind == RE_LOSS_BCE) { dpl = -re_sigmoid(-pl) * gs; dnl = re_sigmoid(nl) * gs; }
+            else { const float sg = re_sigmoid(nl - pl) * gs; dpl = -sg; dnl = sg; }
+            for (int64_t c = lir; c < D4; c += LPR) {
+                const float4 a = u[c], b = ep[c], d = en[c];
+                du[c] = make_float4(fmaf(dpl, b.x, dnl * d.x), fmaf(dpl, b.y, dnl * d.y), fmaf(dpl, b.z, dnl * d.z), fmaf(dpl, b.w, dnl * d.w));
+                gp[c] = make_float4(dpl * a.x, dpl * a.y, dpl * a.z, dpl * a.w);
+                gn[c] = make_float4(dnl * a.x, dnl * a.y, dnl * a.z, dnl * a.w);
+            }
+            if (lir == 0) {
+                lsum += (kind == RE_LOSS_BCE) ? re_softplus(-pl) + re_softplus(nl) : re_softplus(nl - pl);
+                lcnt += 1;
+            }
+        }
+    }
+    lsum = re_wave_sum(lsum);
+    lcnt = (int)re_wave_sum((float)lcnt);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[wid] = lsum; s_cnt[wid] = lcnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+        bcnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
+}
+
 static bool ok16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 extern "C" size_t re_pair_loss_workspace_bytes(int64_t n) {
@@ -220,4 +308,47 @@ extern "C" int re_bpr_triplet_bwd(const float* Ut, int64_t RU, const float* It, 
     re_clear_error();
     if (!users) return RE_EINVAL;
     return pair_bwd(Ut, D, RU, users, It, RI, D, 0, pos, neg, nullptr, n, RE_LOSS_BPR, logits, nullptr, n, dloss, gu, D, gpos, gneg, (hipStream_t)stream);
+}
+
+static int pair_fused(const float* Ubase, int64_t ldu, int64_t RU, const int64_t* uidx, const float* E, int64_t R, int64_t D,
+                      int64_t e_off, const int64_t* pos, const int64_t* neg, const uint8_t* valid, int64_t n, int kind,
+                      const int32_t* count, int64_t count_host, float* loss, float* dU, int64_t lddu, float* gpos, float* gneg,
+                      void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!Ubase || !E || !pos || !neg || !loss || !dU || !gpos || !gneg || !ws || n < 0 || D <= 0 || R <= 0) return RE_EINVAL;
+    if ((D & 3) || (ldu & 3) || (lddu & 3) || !ok16(Ubase) || !ok16(E) || !ok16(dU) || !ok16(gpos) || !ok16(gneg)) return RE_EUNSUPPORTED;
+    if (kind != RE_LOSS_BCE && kind != RE_LOSS_BPR) return RE_EINVAL;
+    if (ws_bytes < re_pair_loss_workspace_bytes(n)) return RE_EWORKSPACE;
+    float* bsum = (float*)ws;
+    int32_t* bcnt = (int32_t*)((char*)ws + PL_MAX_BLOCKS * 4);
+    int grid;
+    if ((D >> 2) >= 32) {
+        grid = pl_grid(n, 32);
+        hipLaunchKernelGGL(pair_loss_fused_k<32>, dim3(grid), dim3(256), 0, s, Ubase, ldu, RU, uidx, E, R, D, e_off, pos, neg, valid, n, kind,
+                           count, count_host, dU, lddu, gpos, gneg, bsum, bcnt);
+    } else {
+        grid = pl_grid(n, 16);
+        hipLaunchKernelGGL(pair_loss_fused_k<16>, dim3(grid), dim3(256), 0, s, Ubase, ldu, RU, uidx, E, R, D, e_off, pos, neg, valid, n, kind,
+                           count, count_host, dU, lddu, gpos, gneg, bsum, bcnt);
+    }
+    hipLaunchKernelGGL(pair_loss_finalize, dim3(1), dim3(64), 0, s, bsum, bcnt, grid, loss, (int32_t*)nullptr);
+    return re_launch_status();
+}
+
+extern "C" int re_pair_loss_fwd_bwd(const float* U, int64_t ldu, const float* E, int64_t R, int64_t D, int64_t e_off,
+                                    const int64_t* pos, const int64_t* neg, const uint8_t* valid, int64_t n, int kind,
+                                    const int32_t* count, float* loss, float* dU, int64_t lddu, float* gpos, float* gneg, void* ws,
+                                    size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!count) return RE_EINVAL;
+    return pair_fused(U, ldu, n > 0 ? n : 1, nullptr, E, R, D, e_off, pos, neg, valid, n, kind, count, 0, loss, dU, lddu, gpos, gneg, ws,
+                      ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int re_bpr_triplet_fwd_bwd(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D, const int64_t* users,
+                                      const int64_t* pos, const int64_t* neg, int64_t n, float* loss, float* gu, float* gpos,
+                                      float* gneg, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!users) return RE_EINVAL;
+    return pair_fused(Ut, D, RU, users, It, RI, D, 0, pos, neg, nullptr, n, RE_LOSS_BPR, nullptr, n, loss, gu, D, gpos, gneg, ws, ws_bytes,
+                      (hipStream_t)stream);
 }

@@ -52,8 +52,7 @@ class MFEngine:
         A = self.arena
         Ut, It = self.encode()
         u, p, n = users.reshape(-1), pos.reshape(-1), neg.reshape(-1)
-        loss, logits = ops.bpr_triplet_fwd(Ut, It, u, p, n)
-        gu, gp, gn = ops.bpr_triplet_bwd(Ut, It, u, p, n, logits, None)
+        loss, gu, gp, gn = ops.bpr_triplet_fwd_bwd(Ut, It, u, p, n)
         G = A.views(A.grad)
         ops.scatter_add_rows(gu, u, self.U, out=G["User.embeddings.weight"])
         ops.scatter_add_rows(torch.cat([gp, gn]), torch.cat([p, n]), self.N, out=G["Item.embeddings.weight"])
@@ -133,9 +132,8 @@ class LightGCNEngine(MFEngine):
         ue, ie = self.encode()
         u, p, n = users.reshape(-1), pos.reshape(-1), neg.reshape(-1)
         B = u.numel()
-        loss, logits = ops.bpr_triplet_fwd(ue, ie, u, p, n)
+        loss, gu, gp, gn = ops.bpr_triplet_fwd_bwd(ue, ie, u, p, n)
         emb = self._emb_loss(u, p, n)
-        gu, gp, gn = ops.bpr_triplet_bwd(ue, ie, u, p, n, logits, None)
         rows = torch.cat([u, p + U, n + U])
         s = 1.0 / (self.L + 1)
         ops.scatter_add_rows(torch.cat([gu, gp, gn]), rows, self.n, scale=s, out=self.davg)   # d(avg)/(L+1), dense

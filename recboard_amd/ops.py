@@ -151,6 +151,48 @@ def pair_loss_bwd(U, E, pos, neg, valid, kind, logits, count, dloss, e_off=0, ou
     return dU, gpos, gneg
 
 
+def pair_loss_fwd_bwd(U, E, pos, neg, valid, kind, count, e_off=0, out=None):
+    """Training form of the pair criteria: loss and its gradient rows in one pass (re_pair_loss_fwd_bwd).  `count` is the
+    DEVICE int32[1] number of valid positions (batch assembly).  -> (loss[1], dU, gpos, gneg)."""
+    _req(U, torch.float32, "U", contiguous=False); _req(E, torch.float32, "E")
+    _req(pos, torch.int64, "pos"); _req(neg, torch.int64, "neg"); _req(count, torch.int32, "count")
+    if U.dim() != 2 or U.stride(1) != 1:
+        raise ValueError("recengine: U must be [n, D] with unit inner stride")
+    n, D = U.shape
+    if valid is not None:
+        _req(valid, torch.uint8, "valid")
+    dev = U.device
+    if out is not None:
+        dU, gpos, gneg = (_req(t, torch.float32, "out") for t in out)
+    else:
+        dU, gpos, gneg = (torch.empty((n, D), dtype=torch.float32, device=dev) for _ in range(3))
+    L = lib.load()
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    ws = _ws(L.re_pair_loss_workspace_bytes(n), dev)
+    lib.check(L.re_pair_loss_fwd_bwd(_p(U), U.stride(0), _p(E), E.shape[0], D, e_off, _p(pos), _p(neg), _p(valid), n, kind, _p(count),
+                                     _p(loss), _p(dU), D, _p(gpos), _p(gneg), _p(ws), ws.numel(), _stream()), "re_pair_loss_fwd_bwd")
+    return loss, dU, gpos, gneg
+
+
+def bpr_triplet_fwd_bwd(Ut, It, users, pos, neg):
+    """MF-BPR / LightGCN training form: mean BPR loss and the three gradient-row sets in one pass.  -> (loss[1], gu, gp, gn)."""
+    _req(Ut, torch.float32, "Ut"); _req(It, torch.float32, "It")
+    for t, nme in ((users, "users"), (pos, "pos"), (neg, "neg")):
+        _req(t, torch.int64, nme)
+    n = users.numel()
+    if pos.numel() != n or neg.numel() != n:
+        raise ValueError("recengine: one positive and one negative per user row (K = 1)")
+    D = Ut.shape[1]
+    L = lib.load()
+    dev = Ut.device
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    gu, gp, gn = (torch.empty((n, D), dtype=torch.float32, device=dev) for _ in range(3))
+    ws = _ws(L.re_pair_loss_workspace_bytes(n), dev)
+    lib.check(L.re_bpr_triplet_fwd_bwd(_p(Ut), Ut.shape[0], _p(It), It.shape[0], D, _p(users), _p(pos), _p(neg), n, _p(loss), _p(gu),
+                                       _p(gp), _p(gn), _p(ws), ws.numel(), _stream()), "re_bpr_triplet_fwd_bwd")
+    return loss, gu, gp, gn
+
+
 def bpr_triplet_fwd(Ut, It, users, pos, neg):
     _req(Ut, torch.float32, "Ut"); _req(It, torch.float32, "It")
     for t, nme in ((users, "users"), (pos, "pos"), (neg, "neg")):

@@ -253,10 +253,12 @@ class SASRecEngine:
 
     @staticmethod
     def batch_aux_fused(seq, pos, neg):
-        """As batch_aux, for the fused step: (valid uint8 [B*S], destination rows of all 3*B*S gradient contributions)."""
+        """As batch_aux, for the fused step: (valid uint8 [B*S], destination rows of all 3*B*S gradient contributions,
+        length packing, valid positions, number of valid positions int32[1])."""
         v, rp, rn = SASRecEngine.batch_aux(seq, pos, neg)
         vidx = torch.nonzero(v).reshape(-1).contiguous()      # valid positions (CE compacts to them; batch assembly, not the step)
-        return v, torch.cat([seq.reshape(-1), rp, rn]), ops.seq_packing(seq), vidx
+        count = v.sum(dtype=torch.int32).reshape(1)           # M of the mean loss (no host sync)
+        return v, torch.cat([seq.reshape(-1), rp, rn]), ops.seq_packing(seq), vidx, count
 
     def _buffers(self, B, S):
         key = (B, S)
@@ -277,7 +279,7 @@ class SASRecEngine:
         """Every launch of the fused step up to (not including) the optimizer; gradients land in the gradient arena."""
         A, P, D = self.arena, self.params, self.D
         B, S = seq.shape
-        valid, rows_all, packing, vidx = aux
+        valid, rows_all, packing, vidx, count = aux
         W = self._buffers(B, S)
         G = A.views(A.grad)
         p = self.p_drop if self.training else 0.0
@@ -302,8 +304,7 @@ class SASRecEngine:
             ops.scatter_add_rows(dUv, vidx, n, out=W["dU"])                  # back to the [B*S, D] layout (pads zero)
             C[n:].zero_()                                                    # no pos/neg contribution rows in CE mode
         else:
-            loss, logits, count = ops.pair_loss_fwd(u2, E, posf, negf, valid, kind, e_off=1)
-            ops.pair_loss_bwd(u2, E, posf, negf, valid, kind, logits, count, None, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
+            loss, _, _, _ = ops.pair_loss_fwd_bwd(u2, E, posf, negf, valid, kind, count, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
         ops.sasrec_encoder_bwd(W["dU"].view(B, S, D), seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad),
                                G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing,
                                seed_dev=seed_dev)
@@ -336,7 +337,7 @@ class SASRecEngine:
     def _blob_layout(B, S):
         n, off, o = B * S, {}, 0
         for name, nbytes in (("seq", 8 * n), ("pos", 8 * n), ("neg", 8 * n), ("rows_all", 24 * n), ("order", 4 * B), ("nshort", 4),
-                             ("valid", n)):
+                             ("count", 4), ("valid", n)):
             off[name] = (o, nbytes)
             o += (nbytes + 15) // 16 * 16
         return off, o
@@ -347,18 +348,19 @@ class SASRecEngine:
         cut = lambda k, dt: blob[off[k][0]:off[k][0] + off[k][1]].view(dt)  # noqa: E731
         return dict(seq=cut("seq", torch.int64).view(B, S), pos=cut("pos", torch.int64).view(B, S), neg=cut("neg", torch.int64).view(B, S),
                     rows_all=cut("rows_all", torch.int64), order=cut("order", torch.int32), nshort=cut("nshort", torch.int32),
-                    valid=cut("valid", torch.uint8))
+                    count=cut("count", torch.int32), valid=cut("valid", torch.uint8))
 
     @staticmethod
     def pack_batch(seq, pos, neg):
         """Batch assembly for `train_step_graph`: (seq, pos, neg) and the index helpers of `batch_aux_fused` laid out in ONE
         contiguous device buffer, so that a step hands its batch to the captured graph with a single copy launch."""
         B, S = seq.shape
-        valid, rows_all, (order, nshort), _ = SASRecEngine.batch_aux_fused(seq, pos, neg)
+        valid, rows_all, (order, nshort), _, count = SASRecEngine.batch_aux_fused(seq, pos, neg)
         _, total = SASRecEngine._blob_layout(B, S)
         blob = torch.zeros(total, dtype=torch.uint8, device=seq.device)
         V = SASRecEngine._blob_views(blob, B, S)
-        for k, t in (("seq", seq), ("pos", pos), ("neg", neg), ("rows_all", rows_all), ("order", order), ("nshort", nshort), ("valid", valid)):
+        for k, t in (("seq", seq), ("pos", pos), ("neg", neg), ("rows_all", rows_all), ("order", order), ("nshort", nshort), ("count", count),
+                     ("valid", valid)):
             V[k].copy_(t.view(V[k].shape))
         return blob
 
@@ -371,7 +373,7 @@ class SASRecEngine:
         V["order"].copy_(torch.arange(B, dtype=torch.int32, device=self.device))
         state = torch.zeros(4, dtype=torch.int32, device=self.device)
         hyper = state.view(torch.float32)[2:4]
-        aux = (V["valid"], V["rows_all"], (V["order"], V["nshort"]), None)
+        aux = (V["valid"], V["rows_all"], (V["order"], V["nshort"]), None, V["count"])
 
         def body():
             loss = self._step_body(V["seq"], V["pos"], V["neg"], aux, 0, seed_dev=state)

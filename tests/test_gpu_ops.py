@@ -365,3 +365,32 @@ def test_scatter_plan_apply_equals_scatter_add_rows(ops):
     ops.scatter_plan(idx, D, R, ws, padding_idx=0)
     ops.scatter_apply(rows, R, out2, ws, accumulate=False)
     assert torch.equal(out2, ref)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_pair_loss_fwd_bwd_equals_separate_kernels(ops, kind):
+    """re_pair_loss_fwd_bwd (one pass, M from a device word) == re_pair_loss_fwd + re_pair_loss_bwd, bitwise."""
+    g = torch.Generator().manual_seed(11)
+    n, D, R = 3000, 64, 500
+    U = torch.randn(n, D, generator=g).cuda()
+    E = torch.randn(R + 1, D, generator=g).cuda()
+    pos = torch.randint(0, R, (n,), generator=g).cuda()
+    neg = torch.randint(0, R, (n,), generator=g).cuda()
+    valid = (torch.rand(n, generator=g) < 0.4).to(torch.uint8).cuda()
+    loss, logits, count = ops.pair_loss_fwd(U, E, pos, neg, valid, kind, e_off=1)
+    dU, gp, gn = ops.pair_loss_bwd(U, E, pos, neg, valid, kind, logits, count, None, e_off=1)
+    cnt = valid.sum(dtype=torch.int32).reshape(1)
+    loss2, dU2, gp2, gn2 = ops.pair_loss_fwd_bwd(U, E, pos, neg, valid, kind, cnt, e_off=1)
+    assert torch.equal(loss, loss2) and torch.equal(dU, dU2) and torch.equal(gp, gp2) and torch.equal(gn, gn2)
+
+
+def test_bpr_triplet_fwd_bwd_equals_separate_kernels(ops):
+    g = torch.Generator().manual_seed(12)
+    n, D, RU, RI = 2048, 64, 300, 400
+    Ut, It = torch.randn(RU, D, generator=g).cuda(), torch.randn(RI, D, generator=g).cuda()
+    u = torch.randint(0, RU, (n,), generator=g).cuda()
+    p, q = torch.randint(0, RI, (n,), generator=g).cuda(), torch.randint(0, RI, (n,), generator=g).cuda()
+    loss, logits = ops.bpr_triplet_fwd(Ut, It, u, p, q)
+    gu, gp, gn = ops.bpr_triplet_bwd(Ut, It, u, p, q, logits, None)
+    loss2, gu2, gp2, gn2 = ops.bpr_triplet_fwd_bwd(Ut, It, u, p, q)
+    assert torch.equal(loss, loss2) and torch.equal(gu, gu2) and torch.equal(gp, gp2) and torch.equal(gn, gn2)
