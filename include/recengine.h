@@ -185,6 +185,14 @@ int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_
                           const float* const* block_params, const float* last_w, const float* last_b,
                           float drop_p, uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, size_t tape_bytes,
                           const int32_t* order, const int32_t* nshort, re_stream_t stream);
+/* re_sasrec_embed + re_sasrec_encoder_fwd in one launch: the encoder's input rows are built inside the kernel from the item
+ * table E [R, D] (row 0 = padding), the position table P [S, D] and `scale` (= sqrt(D)); same dropout stream as
+ * re_sasrec_embed, so re_sasrec_embed_bwd / re_sasrec_encoder_bwd apply unchanged. */
+int re_sasrec_embed_encoder_fwd(const float* E, int64_t R, const float* P, float scale, const int64_t* seq, int64_t B, int64_t S,
+                                int64_t D, int64_t L, const float* const* block_params, const float* last_w,
+                                const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev, float* u,
+                                void* tape, size_t tape_bytes, const int32_t* order, const int32_t* nshort,
+                                re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b,

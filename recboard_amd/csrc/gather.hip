@@ -173,8 +173,6 @@ extern "C" int re_sasrec_embed(const float* E, int64_t R, int64_t D, const float
 // ---------------------------------------------------------------------------------------------------------
 // backward of the SASRec front end.  In place on gx [B,S,D]: in = gradient w.r.t. x0, out = the contribution rows for
 // re_scatter_add_rows (pad rows zero, dropout mask re-applied, times `scale`).  dP[s,:] = sum_b masked gradient.
-// Deterministic two-stage reduction: EB_WGS workgroups own b = w, w+EB_WGS, ... and keep their [S,D] partial in
-// registers; a second kernel adds the partials in workgroup order.
 // One workgroup per 8 consecutive float4 columns (128 B) of the [B][S*D] gradient: thread (tb, cq) walks rows b = tb, tb+32, ...
 // of float4 column cq (4 rows in flight), applies the pad mask / dropout mask / sqrt(D) scale in place and keeps the
 // unscaled column sum; the 32 row-lane partials are then added in lane order through LDS.  No workspace, no second kernel,

@@ -20,8 +20,42 @@ extern "C" int re_dbg_encoder_marks_fwd(unsigned long long* out64) {
 }
 #endif
 
+// The encoder's input tile straight from the tables (re_sasrec_embed fused in):  x0 = seq == 0 ? 0 : dropout(E[seq] * scale + P[s])
+struct SeEmbed {
+    const float *E, *P;   // item table [R, 64] (row 0 = padding), position table [S, 64]; E == nullptr: x0 is given
+    int64_t R;
+    float scale;
+};
+__device__ __forceinline__ void tile_embed(float* tile, const SeEmbed& em, const int64_t* __restrict__ seq, int S, float drop_scale,
+                                           uint32_t thresh, uint32_t seed, const int* s_gid, int tid) {
+    for (int f = tid; f < SE_ROWS * (SE_D / 4); f += SE_NT) {
+        const int r = f >> 4, c4 = f & 15;
+        const int gid = s_gid[r];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gid >= 0) {
+            const int64_t item = seq[gid];
+            if (item > 0 && item < em.R) {
+                const float4 v = reinterpret_cast<const float4*>(em.E + item * SE_D)[c4];
+                const float4 p = reinterpret_cast<const float4*>(em.P + (int64_t)(gid % S) * SE_D)[c4];
+                o.x = v.x * em.scale + p.x;
+                o.y = v.y * em.scale + p.y;
+                o.z = v.z * em.scale + p.z;
+                o.w = v.w * em.scale + p.w;
+                if (thresh) {
+                    const uint32_t e = (uint32_t)((int64_t)gid * SE_D + c4 * 4);
+                    o.x = re_keep(seed, RE_STREAM_EMBED, e + 0, thresh) ? o.x * drop_scale : 0.f;
+                    o.y = re_keep(seed, RE_STREAM_EMBED, e + 1, thresh) ? o.y * drop_scale : 0.f;
+                    o.z = re_keep(seed, RE_STREAM_EMBED, e + 2, thresh) ? o.z * drop_scale : 0.f;
+                    o.w = re_keep(seed, RE_STREAM_EMBED, e + 3, thresh) ? o.w * drop_scale : 0.f;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(tile + SE_RO(r) + 4 * c4) = o;
+    }
+}
+
 template <bool TRAIN>
-__global__ __launch_bounds__(SE_NT) void sasrec_encoder_fwd_k(const float* __restrict__ x0, const int64_t* __restrict__ seq,
+__global__ __launch_bounds__(SE_NT) void sasrec_encoder_fwd_k(const float* __restrict__ x0, SeEmbed em, const int64_t* __restrict__ seq,
                                                             int B, int S, int L, SasrecParams P, float drop_scale,
                                                             uint32_t thresh, uint32_t seed, float* __restrict__ u,
                                                             float* __restrict__ tape, SasrecTape T,
@@ -50,7 +84,8 @@ __global__ __launch_bounds__(SE_NT) void sasrec_encoder_fwd_k(const float* __res
         SE_MARK(0, 0);
         const int n_out = se_decode(wi, WK, B, S, order, seq, tid, s_gid, s_grp, s_pad);
         __syncthreads();
-        tile_load(bX, x0, s_gid, tid);
+        if (em.E) tile_embed(bX, em, seq, S, drop_scale, thresh, seed, s_gid, tid);
+        else tile_load(bX, x0, s_gid, tid);
         __syncthreads();
         SE_MARK(0, 1);
 
@@ -306,13 +341,12 @@ static bool se_fill_params(SasrecParams& P, const float* const* bp, int64_t L, c
     return true;
 }
 
-extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
-                                     const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
-                                     uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, size_t tape_bytes,
-                                     const int32_t* order, const int32_t* nshort, re_stream_t stream) {
-    re_clear_error();
+static int se_fwd_launch(const float* x0, const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                         const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,
+                         const uint32_t* seed_dev, float* u, void* tape, size_t tape_bytes, const int32_t* order, const int32_t* nshort,
+                         re_stream_t stream) {
     if (B == 0) return RE_OK;
-    if (!x0 || !seq || !u || B < 0) return RE_EINVAL;
+    if ((!x0 && !em.E) || !seq || !u || B < 0) return RE_EINVAL;
     if (D != SE_D || S < 1 || S > SE_ROWS || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
     if (drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
     SasrecParams P;
@@ -332,14 +366,37 @@ extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_
             if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
             attr_done[1] = true;
         }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(SE_NT), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, order, nshort, 0, seed_dev);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(SE_NT), ldsb, s, x0, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, order, nshort, 0, seed_dev);
     } else {
         auto k = sasrec_encoder_fwd_k<false>;
         if (!attr_done[0]) {
             if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
             attr_done[0] = true;
         }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(SE_NT), ldsb, s, x0, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T, order, nshort, 1, seed_dev);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(SE_NT), ldsb, s, x0, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T, order, nshort, 1, seed_dev);
     }
     return re_launch_status();
+}
+
+extern "C" int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                                     const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
+                                     uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, size_t tape_bytes,
+                                     const int32_t* order, const int32_t* nshort, re_stream_t stream) {
+    re_clear_error();
+    if (B != 0 && !x0) return RE_EINVAL;
+    const SeEmbed em{nullptr, nullptr, 0, 0.f};
+    return se_fwd_launch(x0, em, seq, B, S, D, L, block_params, last_w, last_b, drop_p, seed, seed_dev, u, tape, tape_bytes, order, nshort,
+                         stream);
+}
+
+extern "C" int re_sasrec_embed_encoder_fwd(const float* E, int64_t R, const float* P, float scale, const int64_t* seq, int64_t B, int64_t S,
+                                           int64_t D, int64_t L, const float* const* block_params, const float* last_w,
+                                           const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev, float* u, void* tape,
+                                           size_t tape_bytes, const int32_t* order, const int32_t* nshort, re_stream_t stream) {
+    re_clear_error();
+    if (B != 0 && (!E || !P || R <= 0)) return RE_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(P)) & 15u) return RE_EUNSUPPORTED;
+    const SeEmbed em{E, P, R, scale};
+    return se_fwd_launch(nullptr, em, seq, B, S, D, L, block_params, last_w, last_b, drop_p, seed, seed_dev, u, tape, tape_bytes, order, nshort,
+                         stream);
 }

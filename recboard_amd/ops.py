@@ -303,6 +303,27 @@ def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, se
     return u, tape
 
 
+def sasrec_embed_encoder_fwd(E, P, seq, scale, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None,
+                             tape=None, packing=None, seed_dev=None):
+    """sasrec_embed + sasrec_encoder_fwd in one launch (re_sasrec_embed_encoder_fwd).  -> (u [B,S,D], tape or None)."""
+    _req(E, torch.float32, "E"); _req(P, torch.float32, "P"); _req(seq, torch.int64, "seq")
+    B, S = seq.shape
+    D = E.shape[1]
+    Lb = lib.load()
+    u = out if out is not None else torch.empty((B, S, D), dtype=torch.float32, device=E.device)
+    if need_tape and tape is None:
+        tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=E.device)
+    tbl = _ptr_table(block_tensors)
+    order, nshort = packing if packing is not None else (None, None)
+    if order is not None:
+        _req(order, torch.int32, "order"); _req(nshort, torch.int32, "nshort")
+    lib.check(Lb.re_sasrec_embed_encoder_fwd(_p(E), E.shape[0], _p(P), float(scale), _p(seq), B, S, D, L, tbl, _p(last_w), _p(last_b),
+                                             float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(u), _p(tape),
+                                             0 if tape is None else tape.numel() * 4, _p(order), _p(nshort), _stream()),
+              "re_sasrec_embed_encoder_fwd")
+    return u, tape
+
+
 def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b,
                        out=None, ws=None, packing=None, seed_dev=None):
     """-> dx0 [B,S,D]; OVERWRITES the tensors in block_grads / g_last_* with the parameter gradients."""

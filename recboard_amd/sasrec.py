@@ -211,9 +211,9 @@ class SASRecEngine:
             E = P["Item.embeddings.weight"].detach()
             p = self.p_drop if self.training else 0.0
             sd = self._step_seed()
-            x0 = ops.sasrec_embed(E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), p, sd)
-            u, _ = ops.sasrec_encoder_fwd(x0, seq, self._block_tensors(), P["lastLN.weight"].detach(),
-                                          P["lastLN.bias"].detach(), self.L, p, sd, packing=ops.seq_packing(seq))
+            u, _ = ops.sasrec_embed_encoder_fwd(E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), self._block_tensors(),
+                                                P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, sd,
+                                                packing=ops.seq_packing(seq))
             return u, E[1:]
         E = self.params["Item.embeddings.weight"]
         x = _EmbedFn.apply(E, self.params["Position.weight"], seq, float(self.D ** 0.5))
@@ -268,7 +268,7 @@ class SASRecEngine:
             u8 = lambda n: torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)  # noqa: E731
             n3 = 3 * B * S
             self._bufs[key] = dict(
-                x0=f(B, S, D), u=f(B, S, D), dU=f(B * S, D), contrib=f(n3, D),
+                u=f(B, S, D), dU=f(B * S, D), contrib=f(n3, D),
                 tape=f(L.re_sasrec_tape_bytes(B, S, D, self.L) // 4),
                 ws_bwd=u8(L.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, self.L)),
                 ws_emb=u8(L.re_sasrec_embed_bwd_workspace_bytes(S, D)),
@@ -289,9 +289,8 @@ class SASRecEngine:
         kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
         n = B * S
         GE = G["Item.embeddings.weight"]
-        ops.sasrec_embed(E, Ppos, seq, float(D ** 0.5), p, sd, out=W["x0"], seed_dev=seed_dev)
-        ops.sasrec_encoder_fwd(W["x0"], seq, bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"], packing=packing,
-                               seed_dev=seed_dev)
+        ops.sasrec_embed_encoder_fwd(E, Ppos, seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"],
+                                     packing=packing, seed_dev=seed_dev)
         u2 = W["u"].view(n, D)
         posf, negf = pos.reshape(-1), neg.reshape(-1)
         C = W["contrib"]

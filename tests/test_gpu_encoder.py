@@ -123,3 +123,36 @@ def test_encoder_backward_matches_oracle_autograd(ops, B, p, pack):
                            ops.sasrec_block_tensors(G2, L), G2["lastLN.weight"], G2["lastLN.bias"], packing=packing)
     for k in ("attnLayers.0.in_proj_weight", "fwdLayers.1.conv2.weight", "lastLN.weight"):
         assert torch.equal(Gd[k], G2[k])
+
+
+@pytest.mark.parametrize("p,pack,train", [(0.0, False, False), (0.3, True, True), (0.3, False, True)])
+def test_embed_fused_into_encoder_equals_two_launches(ops, p, pack, train):
+    """re_sasrec_embed_encoder_fwd (x0 built inside the encoder kernel) == re_sasrec_embed -> re_sasrec_encoder_fwd, bitwise,
+    for the output and for the tape the backward reads."""
+    L, D, S, N, B = 2, 64, 50, 200, 37
+    P = _params(5, L, D, S, N)
+    Pd = {k: v.cuda() for k, v in P.items()}
+    seq = _seqs(6, B, S, N, beauty=True).cuda()
+    bt = ops.sasrec_block_tensors(Pd, L)
+    packing = ops.seq_packing(seq) if pack else None
+    E, Pp = Pd["Item.embeddings.weight"], Pd["Position.weight"]
+    x0 = ops.sasrec_embed(E, Pp, seq, 8.0, p, 77)
+    u1, t1 = ops.sasrec_encoder_fwd(x0, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, train, packing=packing)
+    if t1 is not None:
+        t1 = t1.clone()
+    u2, t2 = ops.sasrec_embed_encoder_fwd(E, Pp, seq, 8.0, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, train, packing=packing)
+    assert torch.equal(u1, u2)
+    if train:
+        # pad positions of packed items are never written: compare only what the backward can read (rows of real tokens)
+        from recboard_amd import lib
+        assert t1.numel() == t2.numel() == lib.load().re_sasrec_tape_bytes(B, S, D, L) // 4
+        dU = torch.randn(B, S, D, generator=torch.Generator().manual_seed(1)).cuda()
+        outs = []
+        for tape in (t1, t2):
+            g = [torch.zeros_like(t) for t in bt]
+            glw, glb = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+            dx = ops.sasrec_encoder_bwd(dU, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, tape, g, glw, glb, packing=packing)
+            # (dx rows of pads in front of a packed item's window are never written -- and never read: re_sasrec_embed_bwd masks pads)
+            outs.append([dx[seq != 0].clone()] + [t.clone() for t in g] + [glw.clone(), glb.clone()])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
