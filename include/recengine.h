@@ -185,6 +185,15 @@ int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_
                           const float* const* block_params, const float* last_w, const float* last_b,
                           float drop_p, uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, size_t tape_bytes,
                           const int32_t* order, const int32_t* nshort, re_stream_t stream);
+/* re_sasrec_encoder_bwd + re_sasrec_embed_bwd in one pass: block 0's kernel applies the pad mask, the embedding dropout mask
+ * and `scale` itself, so `contrib` [B, S, D] receives the item-gradient contribution rows (what re_sasrec_embed_bwd leaves
+ * in place) and dP [S, D] the position-table gradient.  Rows of pads in front of a packed sequence's window are not written
+ * (they are dropped by the scatter-add: destination row 0 = padding). */
+int re_sasrec_encoder_embed_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                                const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
+                                uint32_t seed, const uint32_t* seed_dev, const void* tape, float scale, float* contrib,
+                                float* dP, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
+                                size_t ws_bytes, const int32_t* order, const int32_t* nshort, re_stream_t stream);
 /* re_sasrec_embed + re_sasrec_encoder_fwd in one launch: the encoder's input rows are built inside the kernel from the item
  * table E [R, D] (row 0 = padding), the position table P [S, D] and `scale` (= sqrt(D)); same dropout stream as
  * re_sasrec_embed, so re_sasrec_embed_bwd / re_sasrec_encoder_bwd apply unchanged. */

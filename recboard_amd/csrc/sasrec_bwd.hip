@@ -18,7 +18,8 @@
 
 #define SB_NMAT 6
 #define SB_NVEC 12
-#define SB_SLAB (SB_NMAT * 4096 + SB_NVEC * 64)
+#define SB_OFFP (SB_NMAT * 4096 + SB_NVEC * 64)   // position-table gradient slots (block 0 with the embedding backward fused in)
+#define SB_SLAB (SB_OFFP + 4096)
 // matrix slots: 0 Wq 1 Wk 2 Wv 3 Wo 4 W1 5 W2;  vector slots: 0 bq 1 bk 2 bv 3 bo 4 b1 5 b2 6 ga 7 ba 8 gf 9 bf 10 glast 11 blast
 
 template <bool A_KC>
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
                                                           const float* __restrict__ tape, SasrecTape T,
                                                           float* __restrict__ dOut, float* __restrict__ slab,
                                                           const int* __restrict__ order, const int* __restrict__ nshort_ptr,
-                                                          const uint32_t* __restrict__ seed_dev) {
+                                                          const uint32_t* __restrict__ seed_dev, int fuse_embed, float emb_scale) {
     if (seed_dev) seed ^= seed_dev[0];   // per-step seed kept in device memory (hipGraph replays)
     extern __shared__ __align__(16) float lds[];
     float* b0 = lds;
@@ -160,6 +161,9 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
     float accV[SB_NVEC];
 #pragma unroll
     for (int v = 0; v < SB_NVEC; ++v) accV[v] = 0.f;
+    float accP[SE_CPT];   // fuse_embed: this thread's slice of the position-table gradient, slot = position + (64 - S)
+#pragma unroll
+    for (int i = 0; i < SE_CPT; ++i) accP[i] = 0.f;
 
     for (int wi = blockIdx.x; wi < WK.total; wi += gridDim.x) {
         SE_THREAD_VARS(tid0);
@@ -400,7 +404,44 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         ln_bwd_row<true>(b5, b1, b0, W.ln_a_w, s_mean, s_rstd, tid);
         __syncthreads();
         SE_MARK(1, 13);
-        tile_store(b0, dOut, s_gid, tid);
+        if (fuse_embed) {
+            // re_sasrec_embed_bwd fused in (block 0): pad rows -> 0, the embedding's dropout mask, position-table gradient
+            // (unscaled sum over the batch), and the rows go out scaled by sqrt(D) as item-gradient contributions
+            {
+                const bool dead = s_pad[r_e] != 0;
+#pragma unroll
+                for (int i = 0; i < SE_CPT; ++i) {
+                    float v = dead ? 0.f : b0[SE_RO(r_e) + c0_e + i];
+                    if (thresh && !dead) {
+                        const uint32_t e = (uint32_t)((int64_t)s_gid[r_e] * SE_D + c0_e + i);
+                        v = re_keep(seed, RE_STREAM_EMBED, e, thresh) ? v * drop_scale : 0.f;
+                    }
+                    b0[SE_RO(r_e) + c0_e + i] = v;
+                }
+            }
+            __syncthreads();
+            if (wi < WK.nsw) {   // packed item: rows 16q + i of the four sequences all sit at position S - 16 + i  (slot 48 + i)
+                if (r_e >= SE_ROWS - SE_WIN) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < SE_CPT; ++i) accP[i] += b0[SE_RO(16 * q + r_e - (SE_ROWS - SE_WIN)) + c0_e + i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SE_CPT; ++i) accP[i] += b0[SE_RO(r_e) + c0_e + i];
+            }
+            for (int f = tid; f < SE_ROWS * (SE_D / 4); f += SE_NT) {
+                const int r = f >> 4, c4 = f & 15;
+                const int gid = s_gid[r];
+                if (gid >= 0) {
+                    const float4 v = *reinterpret_cast<const float4*>(b0 + SE_RO(r) + 4 * c4);
+                    reinterpret_cast<float4*>(dOut + (int64_t)gid * SE_D)[c4] = make_float4(v.x * emb_scale, v.y * emb_scale, v.z * emb_scale, v.w * emb_scale);
+                }
+            }
+        } else {
+            tile_store(b0, dOut, s_gid, tid);
+        }
         SE_MARK(1, 14);
     }
 
@@ -415,6 +456,10 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         for (int t = 0; t < SE_RT; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sl[m * 4096 + (16 * (wr * SE_RT + t) + 4 * g + j) * SE_D + col] = accW[m][t][j];
+    if (fuse_embed) {
+#pragma unroll
+        for (int i = 0; i < SE_CPT; ++i) sl[SB_OFFP + r_e * SE_D + c0_e + i] = accP[i];
+    }
     // column partials of the SE_NW row groups -> one value per column, added in row-group order
     __syncthreads();
     float* red = lds;   // [SB_NVEC][SE_NW][64]
@@ -458,12 +503,18 @@ __global__ __launch_bounds__(256) void sasrec_slab_partial(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void sasrec_grad_reduce(const float* __restrict__ part, int nwg, int ngroups, SasrecGradDst dst, int L,
-                                                          int B, const int* __restrict__ nshort_ptr) {
+                                                          int B, const int* __restrict__ nshort_ptr, float* __restrict__ dP, int S) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int l = blockIdx.y;
     const int NM = SB_NMAT * 4096;
     const int nvec = (l == L - 1) ? SB_NVEC : SB_NVEC - 2;
-    if (e >= NM + nvec * 64) return;
+    if (e >= SB_SLAB) return;
+    const bool is_p = e >= SB_OFFP;
+    if (is_p) {
+        if (l != 0 || !dP || ((e - SB_OFFP) >> 6) < SE_ROWS - S) return;   // slots in front of position 0 are unused
+    } else if (e >= NM + nvec * 64) {
+        return;
+    }
     const int total = se_work(B, nshort_ptr).total;
     const int nact = total < nwg ? total : nwg;
     const int ng = (nact + SB_RGROUP - 1) / SB_RGROUP;
@@ -472,7 +523,9 @@ __global__ __launch_bounds__(256) void sasrec_grad_reduce(const float* __restric
     for (int w = 0; w < ng; ++w) s += pl[(int64_t)w * SB_SLAB + e];
     float* const* P = dst.p[l];
     float* d;
-    if (e < NM) {
+    if (is_p) {
+        d = dP + (e - SB_OFFP) - (SE_ROWS - S) * SE_D;
+    } else if (e < NM) {
         const int m = e >> 12, off = e & 4095;
         d = ((m < 3) ? P[2] + m * 4096 : (m == 3 ? P[4] : (m == 4 ? P[8] : P[10]))) + off;
     } else {
@@ -503,13 +556,11 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
     return (size_t)(L * (nwg + ngroups) * SB_SLAB + 2 * B * S * D) * sizeof(float) + 512;
 }
 
-extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
-                                     const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
-                                     uint32_t seed, const uint32_t* seed_dev, const void* tape, float* dx0, float* const* block_grads,
-                                     float* g_last_w,
-                                     float* g_last_b, void* ws, size_t ws_bytes, const int32_t* order, const int32_t* nshort,
-                                     re_stream_t stream) {
-    re_clear_error();
+static int se_bwd_launch(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                         const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,
+                         const uint32_t* seed_dev, const void* tape, float* dx0, float* const* block_grads, float* g_last_w,
+                         float* g_last_b, void* ws, size_t ws_bytes, const int32_t* order, const int32_t* nshort, float emb_scale,
+                         float* dP, re_stream_t stream) {
     if (B == 0) return RE_OK;
     if (!dU || !seq || !tape || !dx0 || !block_params || !block_grads || !g_last_w || !g_last_b || !last_w || !last_b || !ws || B < 0)
         return RE_EINVAL;
@@ -544,21 +595,43 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
         SasrecBlockParams W{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]};
         float* dout = (l == 0) ? dx0 : (((L - 1 - l) & 1) ? dxb : dxa);
         const bool first = (l == L - 1);
+        const int fuse = (l == 0 && dP) ? 1 : 0;
         if (first)
             hipLaunchKernelGGL(kf, dim3(nwg), dim3(SE_NT), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
-                               (const float*)tape, T, dout, slab, order, nshort, seed_dev);
+                               (const float*)tape, T, dout, slab, order, nshort, seed_dev, fuse, emb_scale);
         else
             hipLaunchKernelGGL(kn, dim3(nwg), dim3(SE_NT), ldsb, s, din, seq, (int)B, (int)S, (int)l, W, last_w, ds, thresh, seed,
-                               (const float*)tape, T, dout, slab, order, nshort, seed_dev);
+                               (const float*)tape, T, dout, slab, order, nshort, seed_dev, fuse, emb_scale);
         din = dout;
     }
     SasrecGradDst dst;
     for (int64_t l = 0; l < SE_MAX_BLOCKS; ++l)
         for (int i = 0; i < 14; ++i) dst.p[l][i] = (l < L && i < 12) ? block_grads[12 * l + i] : (i == 12 ? g_last_w : g_last_b);
-    const int nelem = SB_NMAT * 4096 + SB_NVEC * 64;
     hipLaunchKernelGGL(sasrec_slab_partial, dim3((SB_SLAB + 255) / 256, ngroups, (unsigned)L), dim3(256), 0, s, slab, nwg, ngroups, part, (int)B,
                        nshort);
-    hipLaunchKernelGGL(sasrec_grad_reduce, dim3((nelem + 255) / 256, (unsigned)L), dim3(256), 0, s, part, nwg, ngroups, dst, (int)L, (int)B,
-                       nshort);
+    hipLaunchKernelGGL(sasrec_grad_reduce, dim3((SB_SLAB + 255) / 256, (unsigned)L), dim3(256), 0, s, part, nwg, ngroups, dst, (int)L, (int)B,
+                       nshort, dP, (int)S);
     return re_launch_status();
+}
+
+extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                                     const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
+                                     uint32_t seed, const uint32_t* seed_dev, const void* tape, float* dx0, float* const* block_grads,
+                                     float* g_last_w,
+                                     float* g_last_b, void* ws, size_t ws_bytes, const int32_t* order, const int32_t* nshort,
+                                     re_stream_t stream) {
+    re_clear_error();
+    return se_bwd_launch(dU, seq, B, S, D, L, block_params, last_w, last_b, drop_p, seed, seed_dev, tape, dx0, block_grads, g_last_w, g_last_b,
+                         ws, ws_bytes, order, nshort, 0.f, nullptr, stream);
+}
+
+extern "C" int re_sasrec_encoder_embed_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                                           const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
+                                           uint32_t seed, const uint32_t* seed_dev, const void* tape, float scale, float* contrib,
+                                           float* dP, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
+                                           size_t ws_bytes, const int32_t* order, const int32_t* nshort, re_stream_t stream) {
+    re_clear_error();
+    if (B != 0 && !dP) return RE_EINVAL;
+    return se_bwd_launch(dU, seq, B, S, D, L, block_params, last_w, last_b, drop_p, seed, seed_dev, tape, contrib, block_grads, g_last_w,
+                         g_last_b, ws, ws_bytes, order, nshort, scale, dP, stream);
 }

@@ -36,6 +36,8 @@ SIGNATURES = {
     "re_score_topk": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "re_sasrec_tape_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_sasrec_encoder_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "re_sasrec_encoder_embed_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _sz, _vp, _vp, _vp]),
     "re_sasrec_embed_encoder_fwd": (_i32, [_vp, _i64, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _sz,
                                            _vp, _vp, _vp]),
     "re_sasrec_encoder_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),

@@ -342,6 +342,26 @@ def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, 
     return dx0
 
 
+def sasrec_encoder_embed_bwd(dU, seq, scale, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b, dP,
+                             out=None, ws=None, packing=None, seed_dev=None):
+    """sasrec_encoder_bwd + sasrec_embed_bwd in one pass (re_sasrec_encoder_embed_bwd): -> item-gradient contribution rows
+    [B,S,D]; OVERWRITES block_grads / g_last_* / dP with the parameter gradients."""
+    _req(dU, torch.float32, "dU"); _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape"); _req(dP, torch.float32, "dP")
+    B, S, D = dU.shape
+    Lb = lib.load()
+    contrib = out if out is not None else torch.empty_like(dU)
+    _req(contrib, torch.float32, "out")
+    if ws is None:
+        ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
+    tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
+    order, nshort = packing if packing is not None else (None, None)
+    lib.check(Lb.re_sasrec_encoder_embed_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
+                                             int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(tape), float(scale), _p(contrib), _p(dP), tg,
+                                             _p(g_last_w), _p(g_last_b), _p(ws), ws.numel(), _p(order), _p(nshort), _stream()),
+              "re_sasrec_encoder_embed_bwd")
+    return contrib
+
+
 # ------------------------------------------------------------------------------------------------ K8
 SPMM_LONG, SPMM_CHUNK = 512, 2048
 

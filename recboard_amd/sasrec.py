@@ -271,7 +271,6 @@ class SASRecEngine:
                 u=f(B, S, D), dU=f(B * S, D), contrib=f(n3, D),
                 tape=f(L.re_sasrec_tape_bytes(B, S, D, self.L) // 4),
                 ws_bwd=u8(L.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, self.L)),
-                ws_emb=u8(L.re_sasrec_embed_bwd_workspace_bytes(S, D)),
                 ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
         return self._bufs[key]
 
@@ -304,10 +303,9 @@ class SASRecEngine:
             C[n:].zero_()                                                    # no pos/neg contribution rows in CE mode
         else:
             loss, _, _, _ = ops.pair_loss_fwd_bwd(u2, E, posf, negf, valid, kind, count, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
-        ops.sasrec_encoder_bwd(W["dU"].view(B, S, D), seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad),
-                               G["lastLN.weight"], G["lastLN.bias"], out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing,
-                               seed_dev=seed_dev)
-        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, G["Position.weight"], ws=W["ws_emb"], seed_dev=seed_dev)
+        ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
+                                     self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],
+                                     out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing, seed_dev=seed_dev)
         # (running the index half -- ops.scatter_plan -- on a second stream underneath the encoder was measured: no gain inside
         #  a hipGraph, and the extra event traffic slows the eager launch path)
         ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])

@@ -156,3 +156,32 @@ def test_embed_fused_into_encoder_equals_two_launches(ops, p, pack, train):
             outs.append([dx[seq != 0].clone()] + [t.clone() for t in g] + [glw.clone(), glb.clone()])
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("p,pack", [(0.0, False), (0.3, True), (0.3, False)])
+def test_embed_bwd_fused_into_encoder_bwd_equals_two_launches(ops, p, pack):
+    """re_sasrec_encoder_embed_bwd == re_sasrec_encoder_bwd -> re_sasrec_embed_bwd: identical contribution rows (at real
+    tokens) and block gradients; the position-table gradient is the same sum in a different order (tolerance)."""
+    L, D, S, N, B = 2, 64, 50, 200, 41
+    P = _params(8, L, D, S, N)
+    Pd = {k: v.cuda() for k, v in P.items()}
+    seq = _seqs(9, B, S, N, beauty=True).cuda()
+    bt = ops.sasrec_block_tensors(Pd, L)
+    packing = ops.seq_packing(seq) if pack else None
+    E, Pp = Pd["Item.embeddings.weight"], Pd["Position.weight"]
+    u, tape = ops.sasrec_embed_encoder_fwd(E, Pp, seq, 8.0, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, True, packing=packing)
+    dU = torch.randn(B, S, D, generator=torch.Generator().manual_seed(2)).cuda()
+    g1 = [torch.zeros_like(t) for t in bt]
+    lw1, lb1, dP1 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(S, D, device="cuda")
+    dx = ops.sasrec_encoder_bwd(dU, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, tape, g1, lw1, lb1, packing=packing)
+    dx[seq == 0] = 0.0        # (rows the packed kernels never write)
+    ops.sasrec_embed_bwd(dx, seq, 8.0, p, 99, dP1)
+    g2 = [torch.zeros_like(t) for t in bt]
+    lw2, lb2, dP2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.full((S, D), 5.0, device="cuda")
+    c2 = ops.sasrec_encoder_embed_bwd(dU, seq, 8.0, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, tape, g2, lw2, lb2, dP2,
+                                      packing=packing)
+    m = seq != 0
+    assert torch.equal(dx[m], c2[m])
+    for a, b in zip(g1 + [lw1, lb1], g2 + [lw2, lb2]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(dP2, dP1, rtol=1e-5, atol=1e-5)
