@@ -13,7 +13,10 @@
 // MFMA-bound: 16 GEMMs x 2*64^3 = 8.39 MFLOP per sequence per block.
 #include <math.h>
 
-#define SE_NW 8
+#ifndef SE_NW_BWD
+#define SE_NW_BWD 8
+#endif
+#define SE_NW SE_NW_BWD
 #include "sasrec_common.h"
 
 #define SB_NMAT 6
