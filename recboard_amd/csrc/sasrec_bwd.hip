@@ -175,6 +175,7 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         __syncthreads();
         SE_MARK(1, 0);
         const int n_out = se_decode(wi, WK, B, S, order, seq, tid, s_gid, s_grp, s_pad);
+        const bool packed = wi < WK.nsw;   // four short sequences: attention is block diagonal over the 16-row tiles
         __syncthreads();
         SE_MARK(1, 1);
         float4 R[SE_WV];                 // the next weight matrix, in flight from global memory
@@ -321,9 +322,13 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
                 const float p = b4[SE_RO(row) + col];
                 const float pd = b6[SE_RO(row) + col];
                 b5[SE_RO(row) + col] = (p != 0.f) ? v * (pd / p) : 0.f;
-            });
-            frag_ks(bf, b3 + SE_RO(16 * g) + col, SE_LS);     // B[k=i][n=d] = dO
-            gemm64<false>(b6, bf, lane, wr, [&](int row, float v) { b2[SE_RO(row) + col] = v; });  // dV
+            }, packed ? wc : -1);   // (packed: the off-diagonal tiles of dP are neither computed nor read -- P is 0 there)
+            if (packed) {
+                gemm64_diag<false>(b6, b3, lane, wr, col, [&](int row, float v) { b2[SE_RO(row) + col] = v; });  // dV
+            } else {
+                frag_ks(bf, b3 + SE_RO(16 * g) + col, SE_LS);     // B[k=i][n=d] = dO
+                gemm64<false>(b6, bf, lane, wr, [&](int row, float v) { b2[SE_RO(row) + col] = v; });  // dV
+            }
         }
         if (n_out > 0) accV[2] += colsum16_w(b3, s_w, tid);     // d b_v through the virtual pad key: sum_i w_i dO_i
         __syncthreads();
@@ -335,7 +340,10 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
             frag_row(pp, b4 + SE_RO(i) + j0);
             float s = 0.f;
 #pragma unroll
-            for (int jj = 0; jj < SE_CPT; ++jj) s = fmaf(dp[jj], pp[jj], s);
+            for (int jj = 0; jj < SE_CPT; ++jj) {
+                if (pp[jj] == 0.f) dp[jj] = 0.f;   // (never-written dP entries of a packed item's off-diagonal tiles)
+                s = fmaf(dp[jj], pp[jj], s);
+            }
             s = row_sum(s);
             if (n_out > 0) {
                 // virtual pad key: upstream grad of each copy = (dO_i . b_v) * mask; t = dO_i . b_v
@@ -362,13 +370,20 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
             float bf[16];
             wtile_commit(bW0, R, tid);   // Wk  (bW0's last reader, GEMM D, is several barriers back)
             wtile_fetch(R, W.in_w + 2 * SE_D * SE_D, tid);
-            frag_ks(bf, b1 + SE_RO(16 * g) + col, SE_LS);
             const float bkc = (n_out > 0) ? W.in_b[SE_D + col] : 0.f;
-            gemm64<true>(b5, bf, lane, wr, [&](int row, float v) {
-                b4[SE_RO(row) + col] = (n_out > 0) ? fmaf(s_cpad[row], bkc, v) : v;   // + dS_pad * b_k
-            });
-            frag_ks(bf, b3 + SE_RO(16 * g) + col, SE_LS);
-            gemm64<false>(b5, bf, lane, wr, [&](int row, float v) { b6[SE_RO(row) + col] = v; });
+            if (packed) {
+                gemm64_diag<true>(b5, b1, lane, wr, col, [&](int row, float v) {
+                    b4[SE_RO(row) + col] = (n_out > 0) ? fmaf(s_cpad[row], bkc, v) : v;   // + dS_pad * b_k
+                });
+                gemm64_diag<false>(b5, b3, lane, wr, col, [&](int row, float v) { b6[SE_RO(row) + col] = v; });
+            } else {
+                frag_ks(bf, b1 + SE_RO(16 * g) + col, SE_LS);
+                gemm64<true>(b5, bf, lane, wr, [&](int row, float v) {
+                    b4[SE_RO(row) + col] = (n_out > 0) ? fmaf(s_cpad[row], bkc, v) : v;   // + dS_pad * b_k
+                });
+                frag_ks(bf, b3 + SE_RO(16 * g) + col, SE_LS);
+                gemm64<false>(b5, bf, lane, wr, [&](int row, float v) { b6[SE_RO(row) + col] = v; });
+            }
             if (n_out > 0) accV[1] += colsum16_w(b3, s_cpad, tid);   // d b_k through the virtual pad key: sum_i dS_pad_i q_i
         }
         __syncthreads();

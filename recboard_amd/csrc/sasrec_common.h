@@ -144,8 +144,10 @@ __device__ __forceinline__ void frag_ks(float (&f)[16], const float* p, int stri
 // C[m][16 wc + c] = sum_k A[m][k] * B[k][16 wc + c] for the wave's SE_RT row tiles.
 // A_KC: A is an LDS tile [m][k] (k contiguous); otherwise A is given transposed, i.e. the LDS tile is [k][m].
 // bf[s] = B[k = 16g + s][n = 16 wc + c] is supplied by the caller.  epi(row, value) is called for the lane's column.
+// `only` >= 0: just the 16-row tile `only` is wanted (packed items: attention scores are block diagonal, tile t of the rows
+// only meets column strip t) -- the wave's other tiles are skipped, epilogue included.
 template <bool A_KC, class Epi>
-__device__ __forceinline__ void gemm64(const float* A, const float (&bf)[16], int lane, int wr, Epi epi) {
+__device__ __forceinline__ void gemm64(const float* A, const float (&bf)[16], int lane, int wr, Epi epi, int only = -1) {
     const int g = lane >> 4, c = lane & 15;
     f32x4 acc[SE_RT];
     float af[SE_RT][16];
@@ -153,6 +155,7 @@ __device__ __forceinline__ void gemm64(const float* A, const float (&bf)[16], in
     for (int t = 0; t < SE_RT; ++t) {
         const int tt = wr * SE_RT + t;
         acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (only >= 0 && tt != only) continue;
         if (A_KC) frag_kc(af[t], A + SE_RO(16 * tt + c) + 16 * g);
         else frag_ks(af[t], A + SE_RO(16 * g) + 16 * tt + c, SE_LS);
     }
@@ -161,14 +164,49 @@ __device__ __forceinline__ void gemm64(const float* A, const float (&bf)[16], in
     // trip -- or, for weight fragments, one L2 round trip -- per pair.
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int t = 0; t < SE_RT; ++t) {
+        if (only >= 0 && wr * SE_RT + t != only) continue;   // (wave-uniform)
 #pragma unroll
-        for (int t = 0; t < SE_RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
+        for (int s = 0; s < 16; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < SE_RT; ++t) {
+        if (only >= 0 && wr * SE_RT + t != only) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi(16 * (wr * SE_RT + t) + 4 * g + j, acc[t][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep consecutive GEMMs from interleaving their fragment loads (VGPR pressure)
+}
+
+// Block-diagonal contraction of a packed item: output rows of tile tt only see k in [16 tt, 16 tt + 16) (the tile's own
+// sequence), so 4 MFMA steps replace 16.  The k of a step is again free: lane group g takes k = 16 tt + 4 s + g.
+// A_KC: A is [m][k]; otherwise the tile holds A transposed ([k][m]).  B is an LDS tile [k][n].
+template <bool A_KC, class Epi>
+__device__ __forceinline__ void gemm64_diag(const float* A, const float* B, int lane, int wr, int col, Epi epi) {
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 acc[SE_RT];
+    float af[SE_RT][4], bf[SE_RT][4];
+#pragma unroll
+    for (int t = 0; t < SE_RT; ++t) {
+        const int tt = wr * SE_RT + t;
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * tt + 4 * s + g;
+            af[t][s] = A_KC ? A[SE_RO(16 * tt + c) + k] : A[SE_RO(k) + 16 * tt + c];
+            bf[t][s] = B[SE_RO(k) + col];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < SE_RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[t][s], acc[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < SE_RT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) epi(16 * (wr * SE_RT + t) + 4 * g + j, acc[t][j]);
-    __builtin_amdgcn_sched_barrier(0);  // keep consecutive GEMMs from interleaving their fragment loads (VGPR pressure)
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // weight fragment for y = x W^T: B[k][n] = W[n][k], W row-major [64][64] in global memory (k contiguous)

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(SE_NT) void sasrec_encoder_fwd_k(const float* __res
         __syncthreads();
         SE_MARK(0, 0);
         const int n_out = se_decode(wi, WK, B, S, order, seq, tid, s_gid, s_grp, s_pad);
+        const bool packed = wi < WK.nsw;   // four short sequences: attention is block diagonal over the 16-row tiles
         __syncthreads();
         if (em.E) tile_embed(bX, em, seq, S, drop_scale, thresh, seed, s_gid, tid);
         else tile_load(bX, x0, s_gid, tid);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(SE_NT) void sasrec_encoder_fwd_k(const float* __res
             {
                 float bf[16];
                 frag_kc(bf, bK + SE_RO(16 * wc + c) + 16 * g);
-                gemm64<true>(bQ, bf, lane, wr, [&](int row, float v) { bP[SE_RO(row) + col] = v * inv_sqrt_d; });
+                gemm64<true>(bQ, bf, lane, wr, [&](int row, float v) { bP[SE_RO(row) + col] = v * inv_sqrt_d; }, packed ? wc : -1);
             }
             __syncthreads();
             if (l == 0) SE_MARK(0, 4);
@@ -225,9 +226,13 @@ __global__ __launch_bounds__(SE_NT) void sasrec_encoder_fwd_k(const float* __res
                 float bf[16];
                 wtile_commit(bW1, R, tid);                          // Wo
                 wtile_fetch(R, W.w1, tid);                          // W1
-                frag_ks(bf, bV + SE_RO(16 * g) + col, SE_LS);
                 const float bv = W.in_b[2 * SE_D + col];
-                gemm64<true>(bP, bf, lane, wr, [&](int row, float v) { bA[SE_RO(row) + col] = fmaf(s_w[row], bv, v); });
+                if (packed) {
+                    gemm64_diag<true>(bP, bV, lane, wr, col, [&](int row, float v) { bA[SE_RO(row) + col] = fmaf(s_w[row], bv, v); });
+                } else {
+                    frag_ks(bf, bV + SE_RO(16 * g) + col, SE_LS);
+                    gemm64<true>(bP, bf, lane, wr, [&](int row, float v) { bA[SE_RO(row) + col] = fmaf(s_w[row], bv, v); });
+                }
             }
             __syncthreads();
             if (TRAIN) tile_store(bA, tp + T.off_O, s_gid, tid);

@@ -145,3 +145,30 @@ def test_graph_replayed_step_is_identical_to_eager_step(loss):
         assert torch.equal(le, lg), (i, le, lg)
         assert torch.equal(eager.arena.data, graph.arena.data), i
     assert torch.equal(eager.arena.m, graph.arena.m) and torch.equal(eager.arena.v, graph.arena.v)
+
+
+def test_graph_replayed_step_with_gradient_hook_matches_eager():
+    """Data-parallel form: the captured graph ends before the optimizer, the hook (one all-reduce of the gradient arena in
+    bench.py) runs between the replay and Adam.  A stand-in hook (halve the gradients) must give the eager result."""
+    from recboard_amd.sasrec import SASRecEngine
+    N, B, S = 300, 16, 50
+    rng = np.random.default_rng(9)
+    seq = rng.integers(1, N + 1, (B, S))
+    for b in range(B):
+        seq[b, : rng.integers(0, S - 1)] = 0
+    batch = tuple(torch.from_numpy(a).cuda() for a in (seq, rng.integers(0, N, (B, S)), rng.integers(0, N, (B, S))))
+    calls = []
+
+    def hook(g):
+        calls.append(1)
+        g.mul_(0.5)
+
+    eager = SASRecEngine(N, S, 64, 2, dropout_rate=0.2, loss="BCE", seed=4)
+    graph = SASRecEngine(N, S, 64, 2, dropout_rate=0.2, loss="BCE", seed=4)
+    blob = SASRecEngine.pack_batch(*batch)
+    for i in range(4):
+        le = eager.train_step_fused(*batch, grad_hook=hook).clone()
+        lg = graph.train_step_graph(blob, B, S, grad_hook=hook).clone()
+        assert torch.equal(le, lg), i
+        assert torch.equal(eager.arena.data, graph.arena.data), i
+    assert len(calls) == 8
