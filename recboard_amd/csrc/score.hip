@@ -273,28 +273,42 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------------------------------------
 // Variant R ("register lists"): the same MFMA loop, but every LANE keeps its own best-K list of the items IT sees
-// (lane (c,h) sees 16 of every 32 items of user c) -- sorted, in registers (KR values + KR item ids).  Hits are
-// appended to a per-lane FIFO in LDS with plain stores (no atomics: the queue is private to the lane) and folded into
-// the register list in wave-wide drains: round e processes entry e of every lane's queue with ONE branch-free sorted
-// insertion (1 compare + 4 selects per slot), so the cost of a drain is max-over-lanes(queue length) insertions while
-// all 64 lanes work -- instead of one ~440-cycle LDS heap episode per hit with one or two lanes active (the PMC
-// finding of round 1).  A lane's K-th best is a valid lower bound of its user's K-th best, so filtering on it is exact;
-// the two lanes of a user emit two partial lists per segment and score_topk_merge takes the best K of all of them.
-// VLOG = true ("value lists + log"): the register list holds VALUES only, so an insertion is one v_med3_f32 per slot
-// instead of 1 compare + 4 selects; the (value, item) pairs that passed the lane's threshold are appended to a per-lane
-// log in global memory ([entry][lane] per wave: coalesced), pruned against the current threshold whenever it could
-// overflow (<= KR entries survive a prune, see the tie argument in DESIGN.md), and reduced to the exact best K -- all
-// entries above the lane's K-th value, then the earliest entries equal to it -- at the end of the segment.
+// (lane (c,h) sees 16 of every 32 items of user c) -- sorted, in registers.  Hits are appended to a per-lane FIFO in LDS
+// with plain stores (no atomics: the queue is private to the lane) and folded into the register list in wave-wide drains:
+// round e processes entry e of every lane's queue with ONE branch-free sorted insertion, so the cost of a drain is
+// max-over-lanes(queue length) insertions while all 64 lanes work -- instead of one ~440-cycle LDS heap episode per hit with
+// one or two lanes active (the PMC finding of round 1).  A lane's K-th best is a valid lower bound of its user's K-th best,
+// so filtering on it is exact; the two lanes of a user emit two partial lists per segment and score_topk_merge takes the
+// best K of all of them.
+//
+// List entries are ONE sortable 64-bit key per (score, item): the score widened to double (exact) with the item id in the
+// 29 mantissa bits a float does not have -- 2^29-1-id for scores >= 0, id for negative ones, so that "greater key" is
+// exactly "greater score, or equal score and lower id" (the tie rule).  The sorted insertion of key k into slot j is then
+// clamp(k, list[j], list[j-1]) = v_min_f64 + v_max_f64: no compare, no select, no mask hazards.  The drains are VALU
+// bound (a (value, id) pair of lists costs 1 compare + 4 selects per slot at ~7 cycles per dependent op), and this is
+// what the insertion cost is made of.  (Tried and dropped: value-only lists with the (value, item) pairs logged to global
+// memory -- the end-of-segment selection over the log is latency bound.)
 #define SR_QC 24
-#define SR_LOGCAP 128
+#define SR_TAGBITS 29
+// raw v_min_f64 / v_max_f64: through fmin / fmax the compiler re-canonicalises every loop-carried list element
+// (one extra v_max_f64 v, v, v per slot per insertion); keys are never NaN
+__device__ __forceinline__ double sr_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double sr_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ unsigned long long g_sr_counters[4];   // diagnostics (dbg == 3): drains, rounds, appended hits, tiles with hits
-template <int D, int KR, bool VLOG>
+template <int D, int KR>
 __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
                                                            int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
                                                            const int64_t* __restrict__ seen_idx, int K,
                                                            float* __restrict__ part_vals, int* __restrict__ part_idx,
-                                                           int maxseg, int64_t nub, int64_t nst, int64_t upw,
-                                                           float* __restrict__ logv_all, int* __restrict__ logi_all, int dbg) {
+                                                           int maxseg, int64_t nub, int64_t nst, int64_t upw, int dbg) {
     constexpr int KH = D / 2;
     constexpr int RSF = D + 4;
     constexpr int F4_PER_STAGE = SC_TI * D / 4;
@@ -303,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
     float* tile = reinterpret_cast<float*>(smem);
     float* qv = tile + SC_TI * RSF;                          // [4 waves][SR_QC][64 lanes]
     int* qi = reinterpret_cast<int*>(qv + 4 * SR_QC * 64);
+    __shared__ int vote[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -310,8 +325,23 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
     const int NONE = 0x7FFFFFFF;
     float* myqv = qv + wid * SR_QC * 64 + lane;
     int* myqi = qi + wid * SR_QC * 64 + lane;
-    float* logv = VLOG ? logv_all + ((int64_t)blockIdx.x * 4 + wid) * SR_LOGCAP * 64 + lane : nullptr;
-    int* logi = VLOG ? logi_all + ((int64_t)blockIdx.x * 4 + wid) * SR_LOGCAP * 64 + lane : nullptr;
+    const unsigned long long TAGMASK = (1ull << SR_TAGBITS) - 1ull;
+    // (score, item) -> sortable key; key -> score / item
+    auto make_key = [&](float v, int it) -> double {
+        v += 0.0f;   // -0 -> +0
+        const unsigned long long tag = (v >= 0.0f) ? (TAGMASK - (unsigned long long)it) : (unsigned long long)it;
+        return __longlong_as_double((long long)((unsigned long long)__double_as_longlong((double)v) | tag));
+    };
+    auto key_value = [&](double k) -> float {
+        return (float)__longlong_as_double((long long)((unsigned long long)__double_as_longlong(k) & ~TAGMASK));
+    };
+    auto key_item = [&](double k) -> int {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(k);
+        const unsigned long long tag = b & TAGMASK;
+        return (int)((b >> 63) ? tag : TAGMASK - tag);
+    };
+    // empty slot: below every real entry (a real item id is < 2^29 - 1); decodes to (-FLT_MAX, no item)
+    const double KEMPTY = __longlong_as_double((long long)((unsigned long long)__double_as_longlong((double)-3.402823466e+38f) | TAGMASK));
 
     const int64_t units_total = nub * nst;
     int64_t unit = (int64_t)blockIdx.x * upw;
@@ -330,15 +360,19 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
             const bool uok = user < B;
 #pragma unroll
             for (int s = 0; s < KH; ++s) bq[s] = uok ? qrow[2 * s + h] : 0.0f;
+            // The query fragment is loop invariant.  Left as plain loads, the waitcnt bookkeeping merges "bq may still be in
+            // flight" (first entry) with "the next stage's item prefetch is in flight" (back edge) at the stage loop's header
+            // and puts s_waitcnt vmcnt(0) in front of the first MFMA of every stage.  Waiting once here and passing the
+            // registers through an empty asm detaches them from the loads.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < KH; ++s) asm volatile("" : "+v"(bq[s]));
         }
-        float lv[KR];
-        int li[VLOG ? 1 : KR];
+        double lk[KR];
 #pragma unroll
-        for (int j = 0; j < KR; ++j) lv[j] = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < (VLOG ? 1 : KR); ++j) li[j] = NONE;
-        float thr = (user < B && dbg != 1) ? -INFINITY : INFINITY;
-        int qn = 0, ln = 0;
+        for (int j = 0; j < KR; ++j) lk[j] = KEMPTY;
+        float thr = (user < B && dbg != 1 && dbg < 5) ? -INFINITY : INFINITY;
+        int qn = 0;
         int64_t sc_cur = 0, sc_end = 0;
         int ns0 = NONE, ns1 = NONE;
         if (seen_ptr && user < B) {
@@ -351,23 +385,16 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 if (seen_idx[mid] < first_item) lo = mid + 1; else hi2 = mid;
             }
             sc_cur = lo;
+        }
+        // The seen cursor keeps a window of the next two ids in registers.  It is refilled once per stage, BEFORE the item
+        // prefetch is issued: the memory counter retires in order, so the wait for these two words in the first tile leaves
+        // the prefetch in flight.  A lane that uses up its window inside one stage reloads on the spot (rare).
+        const int NEED = -2;
+        auto refill = [&]() {
             ns0 = sc_cur < sc_end ? (int)seen_idx[sc_cur] : NONE;
             ns1 = sc_cur + 1 < sc_end ? (int)seen_idx[sc_cur + 1] : NONE;
-        }
-
-        // log prune: keep the entries that can still be in the best K (value >= the lane's current KR-th best)
-        auto prune = [&](float keep_from) {
-            int w = 0;
-            for (int e = 0; e < SR_LOGCAP; ++e) {
-                if (__ballot(e < ln) == 0ull) break;
-                if (e < ln) {
-                    const float v = logv[e * 64];
-                    const int it = logi[e * 64];
-                    if (v >= keep_from) { logv[w * 64] = v; logi[w * 64] = it; ++w; }
-                }
-            }
-            ln = w;
         };
+
         // fold every lane's queue into its register list: round e = entry e of every queue
         auto drain = [&]() {
             int rounds = (dbg == 2) ? 0 : qn;
@@ -380,122 +407,110 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
 #pragma unroll 1
             for (int e = 0; e < rounds; ++e) {   // ONE copy of the insertion code: the kernel must stay inside the I-cache
                 const bool act = e < qn;
-                float v = act ? myqv[e * 64] : -INFINITY;
-                const int it = act ? myqi[e * 64] : NONE;
-                if (VLOG) {
-                    const bool take = v > lv[KR - 1];       // strict: a later item with the K-th value loses the tie
-                    if (take) { logv[ln * 64] = v; logi[ln * 64] = it; ++ln; }
-                    if (!take) v = -INFINITY;
+                const double k = act ? make_key(myqv[e * 64], myqi[e * 64]) : KEMPTY;
+                // sorted insertion, best first: slot j takes k clamped into [lk[j], lk[j-1]]
 #pragma unroll
-                    for (int j = KR - 1; j >= 1; --j) lv[j] = __builtin_amdgcn_fmed3f(v, lv[j], lv[j - 1]);
-                    lv[0] = fmaxf(v, lv[0]);
-                } else {
-                    // sorted insertion, best first; ties keep the earlier (lower) item id in front: strict >
-                    bool cprev = v > lv[KR - 1];
-#pragma unroll
-                    for (int j = KR - 1; j >= 1; --j) {
-                        const bool cup = v > lv[j - 1];            // would v also go in front of slot j-1 ?
-                        lv[j] = cprev ? (cup ? lv[j - 1] : v) : lv[j];
-                        li[j] = cprev ? (cup ? li[j - 1] : it) : li[j];
-                        cprev = cup;
-                    }
-                    lv[0] = cprev ? v : lv[0];
-                    li[0] = cprev ? it : li[0];
-                }
+                for (int j = KR - 1; j >= 1; --j) lk[j] = sr_max(lk[j], sr_min(k, lk[j - 1]));
+                lk[0] = sr_max(k, lk[0]);
             }
             qn = 0;
-            if (user < B && (dbg == 0 || dbg == 3)) {
-                thr = lv[KR - 1];
-                if (!VLOG) {
-                    // The user's K-th best is at least (a) either lane's K-th best and (b) min(a, b) where a, b are the
-                    // two lanes' ceil(K/2)-th bests (K/2 items above a in one half + K/2 above b in the other): (b) is
-                    // close to the true K-th value because the halves are statistically alike -> ~40 % fewer hits.
-                    float mid = lv[0], kth = lv[0];
+            if (user < B && (dbg == 0 || dbg == 3 || dbg == 4)) {
+                // The user's K-th best is at least (a) either lane's K-th best and (b) min(a, b) where a, b are the
+                // two lanes' ceil(K/2)-th bests (K/2 items above a in one half + K/2 above b in the other): (b) is
+                // close to the true K-th value because the halves are statistically alike -> ~40 % fewer hits.
+                double kmid = lk[0], kkth = lk[0];
 #pragma unroll
-                    for (int j = 1; j < KR; ++j) {
-                        mid = (j == (K + 1) / 2 - 1) ? lv[j] : mid;
-                        kth = (j == K - 1) ? lv[j] : kth;
-                    }
-                    const float pmid = __shfl_xor(mid, 32, 64), pkth = __shfl_xor(kth, 32, 64);
-                    thr = fmaxf(fmaxf(kth, pkth), fminf(mid, pmid));
+                for (int j = 1; j < KR; ++j) {
+                    kmid = (j == (K + 1) / 2 - 1) ? lk[j] : kmid;
+                    kkth = (j == K - 1) ? lk[j] : kkth;
                 }
+                const float mid = key_value(kmid), kth = key_value(kkth);
+                const float pmid = __shfl_xor(mid, 32, 64), pkth = __shfl_xor(kth, 32, 64);
+                thr = fmaxf(fmaxf(kth, pkth), fminf(mid, pmid));
+                if (thr <= -3.402823466e+38f) thr = -INFINITY;   // lists not full yet
             }
-            if (VLOG && __ballot(ln + SR_QC > SR_LOGCAP) != 0ull) prune(lv[KR - 1]);   // room for the next drain
         };
 
         float4 pf[PF];
         auto prefetch = [&](int64_t st) {
             const int64_t item0 = st * SC_TI;
 #pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                const int f = p * 256 + tid;
-                const int row = f / (D / 4);
-                pf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (item0 + row < N) pf[p] = reinterpret_cast<const float4*>(E + item0 * D)[f];
+            for (int p = 0; p < PF; ++p) {   // always exactly PF loads (rows past N clamp to the last row; their scores are
+                const int f = p * 256 + tid; // masked by index): a fixed count lets the waits in the tile loop leave them in flight
+                const int64_t row = item0 + f / (D / 4);
+                pf[p] = reinterpret_cast<const float4*>(E + (row < N ? row : N - 1) * D)[f % (D / 4)];
             }
         };
         prefetch(st0);
 
-        // the stage loop runs one extra, empty iteration (fin) whose only job is the final drain: the drain code then
-        // exists once in the kernel
-        for (int64_t st = st0; st <= st1; ++st) {
-            const bool fin = st == st1;
-            if (!fin) {
-                __syncthreads();
+        // Drains are WORKGROUP-wide where possible: the four waves share the stage barriers, so a wave draining alone stalls
+        // the other three at the next barrier (measured: drain time x ~3).  The vote rides on the stage's first barrier (each
+        // wave leaves a flag in LDS before it, everybody reads the four flags after it): a drain is called when some queue
+        // is more than half full.  A queue that would still overflow inside a stage (only while the lists fill up, at the
+        // start of a segment) is drained by its wave on the spot.
+        for (int64_t st = st0; st < st1; ++st) {
+            if (lane == 0) vote[wid] = 0;
+            if (qn > SR_QC / 2) vote[wid] = 1;
+            __syncthreads();
+            const bool wg_drain = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
 #pragma unroll
-                for (int p = 0; p < PF; ++p) {
-                    const int f = p * 256 + tid;
-                    const int row = f / (D / 4);
-                    const int k0 = (f % (D / 4)) * 4;
-                    float* dst = tile + row * RSF + (k0 >> 1);
-                    *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);
-                    *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
-                }
-                __syncthreads();
-                if (st + 1 < st1) prefetch(st + 1);
+            for (int p = 0; p < PF; ++p) {
+                const int f = p * 256 + tid;
+                const int row = f / (D / 4);
+                const int k0 = (f % (D / 4)) * 4;
+                float* dst = tile + row * RSF + (k0 >> 1);
+                *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);
+                *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
             }
+            if (wg_drain) drain();
+            __syncthreads();
+            refill();
+            prefetch(st + 1 < st1 ? st + 1 : st);
 #pragma unroll 1
             for (int it = 0; it < SC_TI / 32; ++it) {
                 const int64_t item0 = st * SC_TI + it * 32;
+                if (item0 >= N) break;
                 f32x16 acc;
                 unsigned m = 0;
-                bool need_drain = fin;
-                if (!fin) {
-                    if (item0 >= N) break;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    const float* arow = tile + (it * 32 + c) * RSF + h * KH;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                const float* arow = tile + (it * 32 + c) * RSF + h * KH;
+                if (dbg != 7)
 #pragma unroll
-                    for (int q = 0; q < KH / 4; ++q) {
-                        const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * q + 0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
-                    }
+                for (int q = 0; q < KH / 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * q + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
+                }
+                if (dbg == 6) {   // diagnostics: no filter at all (one use of the accumulators keeps the MFMAs alive)
+                    if (acc[0] == 12345.678f && acc[7] == 1.0f && acc[15] == 2.0f) m = 1;
+                } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
-                    // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with one id prefetched)
-                    while (ns0 < (int)item0 + 32) {
-                        const int d = ns0 - (int)item0;
-                        if (d >= 0 && ((d >> 2) & 1) == h) m &= ~(1u << ((d & 3) + 4 * (d >> 3)));
-                        ++sc_cur;
-                        ns0 = ns1;
-                        ns1 = sc_cur + 1 < sc_end ? (int)seen_idx[sc_cur + 1] : NONE;
-                    }
-                    if (item0 + 32 > N) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if ((int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) m &= ~(1u << r);
-                    }
-                    // Drains are WORKGROUP-wide: the four waves share the stage barriers, so a wave draining alone stalls the
-                    // other three at the next barrier (measured: drain time x ~3); draining together costs one extra barrier
-                    // per tile and keeps the four SIMDs busy at the same time.
-                    need_drain = __syncthreads_or(qn + (int)__popc(m) > SR_QC) != 0;   // some queue cannot take this tile's hits
                 }
-                if (need_drain) {
+                // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with two ids prefetched)
+                while (ns0 < (int)item0 + 32) {
+                    if (ns0 == NEED) {   // window used up inside this stage: reload and wait here, inside the rare branch
+                        refill();
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        asm volatile("" : "+v"(ns0), "+v"(ns1));
+                        continue;
+                    }
+                    const int d = ns0 - (int)item0;
+                    if (d >= 0 && ((d >> 2) & 1) == h) m &= ~(1u << ((d & 3) + 4 * (d >> 3)));
+                    ++sc_cur;
+                    ns0 = ns1;
+                    ns1 = NEED;
+                }
+                if (item0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) m &= ~(1u << r);
+                }
+                if (__ballot(qn + (int)__popc(m) > SR_QC) != 0ull) {   // this wave's queues cannot take the tile's hits
                     drain();
-                    if (fin) break;
                     unsigned m2 = 0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m2 |= (acc[r] > thr ? 1u : 0u) << r;
@@ -511,30 +526,17 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 }
             }
         }
+        drain();
         if (user < B) {
             float* pv = part_vals + ((user * maxseg + seg) * 2 + h) * K;
             int* pi = part_idx + ((user * maxseg + seg) * 2 + h) * K;
-            if (VLOG) {
-                // exact best K of the lane: everything above its K-th value, then the earliest entries equal to it
-                float thrK = lv[0];
 #pragma unroll
-                for (int j = 1; j < KR; ++j) thrK = (j == K - 1) ? lv[j] : thrK;
-                int ngt = 0;
-                for (int e = 0; e < ln; ++e) ngt += logv[e * 64] > thrK ? 1 : 0;
-                int w = 0, neq = K - ngt;
-                for (int e = 0; e < ln && w < K; ++e) {
-                    const float v = logv[e * 64];
-                    if (v > thrK || (v == thrK && neq > 0)) {
-                        if (v == thrK) --neq;
-                        pv[w] = v; pi[w] = logi[e * 64]; ++w;
-                    }
+            for (int j = 0; j < KR; ++j)
+                if (j < K) {
+                    const bool empty = lk[j] == KEMPTY;
+                    pv[j] = empty ? -INFINITY : key_value(lk[j]);
+                    pi[j] = empty ? -1 : key_item(lk[j]);
                 }
-                for (; w < K; ++w) { pv[w] = -INFINITY; pi[w] = -1; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < KR; ++j)
-                    if (j < K) { pv[j] = lv[j]; pi[j] = li[j] == NONE ? -1 : li[j]; }
-            }
         }
         unit += st1 - st0;
         __syncthreads();
@@ -618,14 +620,13 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 static int g_score_pop = 3;      // tuning switches (scripts/tune_score.py); not part of the ABI
 static int64_t g_score_minseg = SC_MIN_SEG;
-static int g_score_vlog = 0;
 static int g_score_dbg = 0;   // diagnostics only (scripts/tune_score.py): 1 = no hits at all, 2 = append but never insert
 extern "C" void re_dbg_score_diag(int mode) { g_score_dbg = mode; }
 extern "C" void re_dbg_score_counters(unsigned long long* out4, int reset) {
     (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sr_counters), 32);
     if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sr_counters), z, 32); }
 }
-extern "C" void re_dbg_score_variant(int pop, int64_t minseg) { g_score_vlog = (pop == 4); g_score_pop = (pop == 4) ? 3 : pop; g_score_minseg = minseg; }
+extern "C" void re_dbg_score_variant(int pop, int64_t minseg) { g_score_pop = pop; g_score_minseg = minseg; }
 
 struct ScorePlan {
     int64_t nub, nst, units, upw;
@@ -661,7 +662,7 @@ extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D,
     if (B <= 0 || N <= 0 || K <= 0) return 256;
     ScorePlan p = score_plan(B, N);
     return re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4) * 2      // up to 2 lists per (user, segment)
-           + (size_t)SC_MAX_WGS * 4 * SR_LOGCAP * 64 * 8 + 256;                    // per-lane candidate logs
+           + 256;
 }
 
 template <int D, bool TOPK, int POP>
@@ -716,21 +717,18 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
     int rc, lps = 1;
     // register-list variant: many users per launch (its two lists per segment double the merge work, which dominates
     // when B is small -- A/B in scripts/tune_score.py)
-    if (g_score_pop == 3 && D == 64 && K <= 52 && p.nub >= 16) {
+    if (g_score_pop == 3 && D == 64 && K <= 52 && p.nub >= 16 && N < (1ll << SR_TAGBITS) - 1) {
         lps = 2;
         const size_t lds = (size_t)SC_TI * (64 + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
-        float* logv = (float*)((char*)ws + 2 * half);
-        int* logi = (int*)(logv + (size_t)SC_MAX_WGS * 4 * SR_LOGCAP * 64);
-#define SR_LAUNCH(KRV, VL) hipLaunchKernelGGL((score_kernel_reg<64, KRV, VL>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, logv, logi, g_score_dbg)
-        if (g_score_vlog) { if (K <= 16) SR_LAUNCH(16, true); else if (K <= 32) SR_LAUNCH(32, true); else SR_LAUNCH(52, true); }
-        else { if (K <= 16) SR_LAUNCH(16, false); else if (K <= 32) SR_LAUNCH(32, false); else SR_LAUNCH(52, false); }
+#define SR_LAUNCH(KRV) hipLaunchKernelGGL((score_kernel_reg<64, KRV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, g_score_dbg)
+        if (K <= 16) SR_LAUNCH(16); else if (K <= 32) SR_LAUNCH(32); else SR_LAUNCH(52);
 #undef SR_LAUNCH
         rc = re_launch_status();
     } else {
         rc = score_dispatch<true>(D, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p, nullptr, s);
     }
     if (rc != RE_OK) return rc;
-    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, p.maxseg, lps, (lps == 2 && !g_score_vlog) ? 1 : 0, B, N, (int)K, p.nst, p.upw,
+    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, p.maxseg, lps, (lps == 2) ? 1 : 0, B, N, (int)K, p.nst, p.upw,
                        seen_ptr, seen_idx, vals, idx);
     return re_launch_status();
 }

@@ -10,3 +10,6 @@ si = torch.sort(torch.randint(0, N, (U, 8), device="cuda", generator=g), 1).valu
 for _ in range(10):
     ops.score_topk(q, E, sp, si, 50)
 torch.cuda.synchronize()
+for _ in range(10):
+    ops.score_topk(q[:512], E, sp[:513], si, 50)
+torch.cuda.synchronize()

@@ -26,7 +26,7 @@ with torch.no_grad():
 E2 = model.params["Item.embeddings.weight"].detach()[1:]
 for rnd in range(2):
     for name, (qq, EE) in {"random-normal": (q, E), "bench (LN-encoded q, xavier E)": (q2, E2)}.items():
-        for pop in (2, 3, 4):
+        for pop in (2, 3):
             for minseg in (1,):
                 L.re_dbg_score_variant(pop, minseg)
                 ms = t(lambda: ops.score_topk(qq, EE, sp, si, 50))
@@ -49,4 +49,10 @@ ops.score_topk(q, E, sp, si, 50); torch.cuda.synchronize()
 L.re_dbg_score_counters(buf, 1)
 nw = 512 * 4
 print(f"one launch: drains/wave {buf[0]/nw:.1f}  rounds/wave {buf[1]/nw:.1f}  hits/lane {buf[2]/nw/64:.1f}  (segments/wave 1; MFMA tiles/wave ~130)")
+L.re_dbg_score_diag(0)
+
+for mode, name in ((5, "no hits"), (6, "no hits, no threshold filter (MFMA + staging only)"), (7, "no hits, no MFMAs (staging + filter only)")):
+    L.re_dbg_score_diag(mode)
+    ms = t(lambda: ops.score_topk(q, E, sp, si, 50))
+    print(f"loop diag {name:55s}: {ms:.3f} ms")
 L.re_dbg_score_diag(0)
