@@ -302,7 +302,8 @@ __device__ __forceinline__ double sr_max(double a, double b) {
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ unsigned long long g_sr_counters[4];   // diagnostics (dbg == 3): drains, rounds, appended hits, tiles with hits
+__device__ unsigned long long g_sr_counters[4];
+__device__ unsigned long long g_sr_counters_x[2];   // diagnostics (dbg == 3): drains, rounds, appended hits, tiles with hits
 template <int D, int KR>
 __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
                                                            int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         double lk[KR];
 #pragma unroll
         for (int j = 0; j < KR; ++j) lk[j] = KEMPTY;
-        float thr = (user < B && dbg != 1 && dbg < 5) ? -INFINITY : INFINITY;
+        float thr = (user < B && dbg != 1 && (dbg < 5 || dbg == 8)) ? -INFINITY : INFINITY;
         int qn = 0;
         int64_t sc_cur = 0, sc_end = 0;
         int ns0 = NONE, ns1 = NONE;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 lk[0] = sr_max(k, lk[0]);
             }
             qn = 0;
-            if (user < B && (dbg == 0 || dbg == 3 || dbg == 4)) {
+            if (user < B && (dbg == 0 || dbg == 3 || dbg == 4 || dbg == 8)) {
                 // The user's K-th best is at least (a) either lane's K-th best and (b) min(a, b) where a, b are the
                 // two lanes' ceil(K/2)-th bests (K/2 items above a in one half + K/2 above b in the other): (b) is
                 // close to the true K-th value because the halves are statistically alike -> ~40 % fewer hits.
@@ -448,10 +449,19 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         // wave leaves a flag in LDS before it, everybody reads the four flags after it): a drain is called when some queue
         // is more than half full.  A queue that would still overflow inside a stage (only while the lists fill up, at the
         // start of a segment) is drained by its wave on the spot.
+#ifdef SC_PROFILE   // cycle accounting of one wave (make CXXFLAGS+=-DSC_PROFILE; scripts/tune_score.py), written out once at the end
+        const bool prof = dbg >= 8 && blockIdx.x == 7 && wid == 0;
+        long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, t0 = 0, t1 = 0;
+#define SC_T(x) x
+#else
+#define SC_T(x)
+#endif
         for (int64_t st = st0; st < st1; ++st) {
+            SC_T(if (prof) t0 = __builtin_readcyclecounter();)
             if (lane == 0) vote[wid] = 0;
             if (qn > SR_QC / 2) vote[wid] = 1;
             __syncthreads();
+            SC_T(if (prof) { t1 = __builtin_readcyclecounter(); ta += t1 - t0; t0 = t1; })
             const bool wg_drain = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
@@ -463,7 +473,9 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
             }
             if (wg_drain) drain();
+            SC_T(if (prof) { t1 = __builtin_readcyclecounter(); tb += t1 - t0; t0 = t1; })
             __syncthreads();
+            SC_T(if (prof) { t1 = __builtin_readcyclecounter(); tc += t1 - t0; t0 = t1; })
             refill();
             prefetch(st + 1 < st1 ? st + 1 : st);
 #pragma unroll 1
@@ -475,7 +487,6 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 const float* arow = tile + (it * 32 + c) * RSF + h * KH;
-                if (dbg != 7)
 #pragma unroll
                 for (int q = 0; q < KH / 4; ++q) {
                     const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
@@ -484,12 +495,9 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
                 }
-                if (dbg == 6) {   // diagnostics: no filter at all (one use of the accumulators keeps the MFMAs alive)
-                    if (acc[0] == 12345.678f && acc[7] == 1.0f && acc[15] == 2.0f) m = 1;
-                } else {
+                SC_T(if (prof) { asm volatile("s_nop 0" :: "v"(acc[0])); t1 = __builtin_readcyclecounter(); td += t1 - t0; t0 = t1; })
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
-                }
+                for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
                 // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with two ids prefetched)
                 while (ns0 < (int)item0 + 32) {
                     if (ns0 == NEED) {   // window used up inside this stage: reload and wait here, inside the rare branch
@@ -524,8 +532,19 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                         ++qn;
                     }
                 }
+                SC_T(if (prof) { t1 = __builtin_readcyclecounter(); te += t1 - t0; t0 = t1; })
             }
         }
+#ifdef SC_PROFILE
+        if (prof && lane == 0) {
+            g_sr_counters[0] = (unsigned long long)ta;   // wait at the stage's first barrier
+            g_sr_counters[1] = (unsigned long long)tb;   // LDS stores of the staged items (+ workgroup drain)
+            g_sr_counters[2] = (unsigned long long)tc;   // wait at the second barrier
+            g_sr_counters[3] = (unsigned long long)td;   // prefetch issue + A-fragment reads + MFMA chain (both tiles)
+            g_sr_counters_x[0] = (unsigned long long)te; // filter, seen-mask, appends (+ wave-local drains)
+            g_sr_counters_x[1] = (unsigned long long)(st1 - st0);
+        }
+#endif
         drain();
         if (user < B) {
             float* pv = part_vals + ((user * maxseg + seg) * 2 + h) * K;
@@ -620,8 +639,13 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 static int g_score_pop = 3;      // tuning switches (scripts/tune_score.py); not part of the ABI
 static int64_t g_score_minseg = SC_MIN_SEG;
+static int64_t g_score_maxwgs = SC_MAX_WGS;
+extern "C" void re_dbg_score_maxwgs(int64_t n) { g_score_maxwgs = n > 0 ? n : SC_MAX_WGS; }
 static int g_score_dbg = 0;   // diagnostics only (scripts/tune_score.py): 1 = no hits at all, 2 = append but never insert
 extern "C" void re_dbg_score_diag(int mode) { g_score_dbg = mode; }
+#ifdef SC_PROFILE
+extern "C" void re_dbg_score_counters_x(unsigned long long* out2) { (void)hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_sr_counters_x), 16); }
+#endif
 extern "C" void re_dbg_score_counters(unsigned long long* out4, int reset) {
     (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sr_counters), 32);
     if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sr_counters), z, 32); }
@@ -642,7 +666,7 @@ static ScorePlan score_plan(int64_t B, int64_t N) {
     // segment: every segment re-warms its users' top-K lists (~K(1+ln(T/K)) heap inserts for T items), so slicing a
     // small catalog over all CUs costs more in warm-ups and list merging than it gains (B=512 x N=12101: 0.58 -> see
     // scripts/tune_score.py).
-    int64_t upw = re_cdiv(p.units, SC_MAX_WGS);
+    int64_t upw = re_cdiv(p.units, g_score_maxwgs);
     const int64_t min_seg = p.nst < g_score_minseg ? p.nst : g_score_minseg;
     if (upw < min_seg) upw = min_seg;
     p.upw = upw;

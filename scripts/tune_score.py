@@ -51,8 +51,26 @@ nw = 512 * 4
 print(f"one launch: drains/wave {buf[0]/nw:.1f}  rounds/wave {buf[1]/nw:.1f}  hits/lane {buf[2]/nw/64:.1f}  (segments/wave 1; MFMA tiles/wave ~130)")
 L.re_dbg_score_diag(0)
 
-for mode, name in ((5, "no hits"), (6, "no hits, no threshold filter (MFMA + staging only)"), (7, "no hits, no MFMAs (staging + filter only)")):
-    L.re_dbg_score_diag(mode)
-    ms = t(lambda: ops.score_topk(q, E, sp, si, 50))
-    print(f"loop diag {name:55s}: {ms:.3f} ms")
-L.re_dbg_score_diag(0)
+L.re_dbg_score_maxwgs.argtypes = [ctypes.c_int64]; L.re_dbg_score_maxwgs.restype = None
+for nw in (256, 512):
+    L.re_dbg_score_maxwgs(nw)
+    for mode, name in ((0, "normal"), (5, "no hits")):
+        L.re_dbg_score_diag(mode)
+        ms = t(lambda: ops.score_topk(q, E, sp, si, 50))
+        print(f"workgroups {nw}: {name:10s} {ms:.3f} ms")
+L.re_dbg_score_diag(0); L.re_dbg_score_maxwgs(0)
+
+if not hasattr(L, "re_dbg_score_counters_x"):
+    sys.exit(0)   # (cycle accounting needs a -DSC_PROFILE build)
+L.re_dbg_score_counters_x.argtypes = [ctypes.c_void_p]; L.re_dbg_score_counters_x.restype = None
+bx = (ctypes.c_ulonglong * 2)()
+for nw in (256, 512):
+    L.re_dbg_score_maxwgs(nw)
+    for mode, name in ((8, "normal"), (9, "no hits")):
+        L.re_dbg_score_diag(mode)
+        ops.score_topk(q, E, sp, si, 50); torch.cuda.synchronize()
+        L.re_dbg_score_counters(buf, 0); L.re_dbg_score_counters_x(bx)
+        n = max(bx[1], 1)
+        print(f"workgroups {nw} {name:8s}: per stage (2 tiles) of one wave, {n} stages: barrier-1 wait {buf[0]/n:.0f}  LDS store(+wg drain) {buf[1]/n:.0f}  "
+              f"barrier-2 wait {buf[2]/n:.0f}  prefetch+MFMA {buf[3]/n:.0f}  filter/append(+local drain) {bx[0]/n:.0f}")
+L.re_dbg_score_diag(0); L.re_dbg_score_maxwgs(0)
