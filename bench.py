@@ -110,6 +110,19 @@ def cpu_baseline(cfg, batches, budget_s=15.0):
                       f"torch {torch.__version__} CPU, {cores} threads"}
 
 
+def pmc_traffic(*kernels):
+    """HBM bytes per launch of the named kernels (summed) from the committed PMC summary -- FETCH_SIZE / WRITE_SIZE cannot be
+    read from inside the process, they come from separate rocprofv3 --pmc passes of this same command (profiles/)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_v5_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+        return {"hbm_bytes_per_launch": int(sum(k[n]["hbm_bytes_per_launch"] for n in kernels) / max(len(kernels), 1)),
+                "source": "profiles/r1_v5_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE)"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,7 +246,8 @@ def main():
             tfb = fl / (t_bwd * 1e-3) / 1e12
             line["roofline"] = {"kernel": "sasrec_block_bwd_k (x%d blocks, + slab reduce)" % Lq, "bound": "mfma",
                                 "achieved": round(tfb, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                "frac": round(tfb / MFMA_F32_PEAK_TF, 4), "traffic": None, "launch_ms": round(t_bwd / Lq, 4),
+                                "frac": round(tfb / MFMA_F32_PEAK_TF, 4),
+                                "traffic": pmc_traffic("sasrec_block_bwd_k<true>", "sasrec_block_bwd_k<false>"), "launch_ms": round(t_bwd / Lq, 4),
                                 "work": f"2 x 62 kFLOP per token per block x {Bq * Sq} token slots = {fl / Lq:.3e} FLOP per block launch "
                                         f"(reference-equivalent work incl. pad positions; the kernel packs 4 short sequences per workgroup)"}
         # ---------------- full-catalog evaluation leg: every user x every item, seen-mask + top-50 fused
@@ -254,7 +268,7 @@ def main():
         line["items_scored_per_sec"] = round(U * N / (t_score * 1e-3), 1)
         line["roofline_score"] = {"kernel": "score_kernel<64,topk> (+merge)", "bound": "mfma", "achieved": round(tf, 2),
                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
-                            "traffic": None, "launch_ms": round(t_score, 4),
+                            "traffic": pmc_traffic("score_kernel_reg<64, 52>"), "launch_ms": round(t_score, 4),
                             "work": f"2*D*B*N = {flops:.3e} FLOP per launch (B={U}, N={N}, D={D}, K={K})"}
         # ---------------- embedding gather leg (HBM-bound): Beauty shape and an HBM-resident 4 GiB table
         idx_small = batches[0][0].reshape(-1)
@@ -270,7 +284,7 @@ def main():
         gbs_big = n_big * bpr / (t_gb * 1e-3) / 1e9
         line["roofline_gather"] = {"kernel": "gather_rows_vec4<16>", "bound": "hbm", "achieved": round(gbs_big, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_big / HBM_PEAK_GBS, 4),
-                                   "traffic": None, "launch_ms": round(t_gb, 4),
+                                   "traffic": pmc_traffic("gather_rows_vec4<16, 4, true>"), "launch_ms": round(t_gb, 4),
                                    "work": f"{bpr} B per looked-up row x {n_big} uniform-random rows of a {R_big}x{D} fp32 table (4 GiB, HBM-resident)",
                                    "beauty_shape": {"rows": int(idx_small.numel()), "launch_ms": round(t_g, 4), "GB/s": round(gbs_small, 1),
                                                     "note": "3.1 MB table is L2/Infinity-Cache resident: launch-latency bound"}}
