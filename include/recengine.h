@@ -83,6 +83,14 @@ int re_scatter_plan(const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t
                     int64_t zero_floats, void* ws, size_t ws_bytes, re_stream_t stream);
 int re_scatter_apply(const float* g, int64_t n, int64_t D, int64_t R, float scale, float* dW, int accumulate, void* ws,
                      size_t ws_bytes, re_stream_t stream);
+/* Row-sparse Adam for tables whose dense gradient does not fit: for every distinct destination row r
+ * of idx (padding_idx / out-of-range entries dropped) G_r = sum of the rows of g pointing at r (position order, deterministic),
+ * then ONE Adam update of row r of (W, m, v) -- torch.optim.SparseAdam's rule (global step count in the bias corrections) plus
+ * coupled weight decay g += wd * w on the touched rows.  Rows without a gradient are not touched.  Workspace as
+ * re_scatter_add_rows (same n, D, R). */
+int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
+                        float* m, float* v, int64_t step, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream);
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                         int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,

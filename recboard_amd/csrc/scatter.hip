@@ -298,11 +298,50 @@ template <class V> __device__ __forceinline__ V vzero();
 template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <> __device__ __forceinline__ float vzero<float>() { return 0.f; }
 
-template <int LPR, class V>
+// What happens to a destination row's complete sum: written / added into the dense gradient table, or -- row-sparse
+// optimizer for tables too large for a dense gradient -- fed straight into an Adam update of that row.
+struct DenseSink {
+    float* dW;
+    int64_t D;
+    int accumulate;
+    template <class V>
+    __device__ __forceinline__ void put(uint32_t row, int64_t col, V acc) const {
+        V* d = reinterpret_cast<V*>(dW + (int64_t)row * D) + col;
+        if (accumulate) f4_add(acc, *d);
+        *d = acc;
+    }
+};
+struct AdamSink {   // torch.optim.SparseAdam semantics on the touched rows (+ coupled weight decay on them), global step count
+    float *W, *m, *v;
+    int64_t D;
+    float b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd;
+    __device__ __forceinline__ void one(float& p, float& mm, float& vv, float g) const {
+        const float gg = g + wd * p;
+        mm = b1 * mm + omb1 * gg;
+        vv = b2 * vv + omb2 * gg * gg;
+        p = p - step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+    }
+    __device__ __forceinline__ void put(uint32_t row, int64_t col, float4 acc) const {
+        float4* pp = reinterpret_cast<float4*>(W + (int64_t)row * D) + col;
+        float4* pm = reinterpret_cast<float4*>(m + (int64_t)row * D) + col;
+        float4* pv = reinterpret_cast<float4*>(v + (int64_t)row * D) + col;
+        float4 P = *pp, M = *pm, Vv = *pv;
+        one(P.x, M.x, Vv.x, acc.x); one(P.y, M.y, Vv.y, acc.y); one(P.z, M.z, Vv.z, acc.z); one(P.w, M.w, Vv.w, acc.w);
+        *pp = P; *pm = M; *pv = Vv;
+    }
+    __device__ __forceinline__ void put(uint32_t row, int64_t col, float acc) const {
+        const int64_t o = (int64_t)row * D + col;
+        float P = W[o], M = m[o], Vv = v[o];
+        one(P, M, Vv, acc);
+        W[o] = P; m[o] = M; v[o] = Vv;
+    }
+};
+
+template <int LPR, class V, class Sink>
 __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                   const float* __restrict__ g, int64_t n, int64_t D, int64_t R,
-                                                  float scale, float* __restrict__ dW, float* __restrict__ partial,
-                                                  uint32_t* __restrict__ pflags, int64_t nchunks, int accumulate) {
+                                                  float scale, Sink sink, float* __restrict__ partial,
+                                                  uint32_t* __restrict__ pflags, int64_t nchunks) {
     const int lir = threadIdx.x % LPR;
     const int64_t c = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (c >= nchunks) return;
@@ -346,9 +385,7 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
                             reinterpret_cast<V*>(partial + (c * 2 + 0) * D)[col] = acc;
                             flags |= RE_FLAG_SLOT0;
                         } else {
-                            V* d = reinterpret_cast<V*>(dW + (int64_t)curKey * D) + col;
-                            if (accumulate) f4_add(acc, *d);
-                            *d = acc;
+                            sink.put(curKey, col, acc);
                         }
                     }
                     curKey = k[u];
@@ -369,9 +406,7 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
                 reinterpret_cast<V*>(partial + (c * 2 + 1) * D)[col] = acc;
                 flags |= RE_FLAG_SLOT1;
             } else {
-                V* d = reinterpret_cast<V*>(dW + (int64_t)curKey * D) + col;
-                if (accumulate) f4_add(acc, *d);
-                *d = acc;
+                sink.put(curKey, col, acc);
             }
         }
     }
@@ -383,10 +418,10 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
 // item, a low-cardinality DeepFM field -- is handed to the whole block: its links are split into G = 256/LPR contiguous
 // ranges summed concurrently (each in link order), and the G range sums are added in range order.  The summation tree is a
 // fixed function of the sorted keys, so the result stays bitwise reproducible.
-template <int LPR, class V>
+template <int LPR, class V, class Sink>
 __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ keys, int64_t n, int64_t D,
-                                                 float* __restrict__ dW, const float* __restrict__ partial,
-                                                 const uint32_t* __restrict__ pflags, int64_t nchunks, int accumulate) {
+                                                 Sink sink, const float* __restrict__ partial,
+                                                 const uint32_t* __restrict__ pflags, int64_t nchunks) {
     constexpr int G = 256 / LPR;
     __shared__ int64_t long_c[G];
     __shared__ int n_long;
@@ -420,9 +455,7 @@ __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ ke
                 if (!(f[u] & RE_FLAG_CONT)) open = false;
             }
             if (open && c + 9 < nchunks) { is_long = true; break; }   // (uniform over the lane group: depends on flags only)
-            V* d = reinterpret_cast<V*>(dW + (int64_t)key * D) + col;
-            if (accumulate) f4_add(acc, *d);
-            *d = acc;
+            sink.put(key, col, acc);
         }
         if (is_long && lir == 0) long_c[atomicAdd(&n_long, 1)] = c;
     }
@@ -484,9 +517,7 @@ __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ ke
             if (grp == 0 && col < D4) {
                 V tot = reinterpret_cast<const V*>(partial + (lc * 2 + 1) * D)[col];
                 for (int q = 0; q < G; ++q) f4_add(tot, red[q][lir]);
-                V* d = reinterpret_cast<V*>(dW + (int64_t)key * D) + col;
-                if (accumulate) f4_add(tot, *d);
-                *d = tot;
+                sink.put(key, col, tot);
             }
             __syncthreads();
         }
@@ -571,17 +602,17 @@ static int scatter_sort(const int64_t* idx, int64_t n, int64_t R, int64_t paddin
     return RE_OK;
 }
 
-static void scatter_reduce(const float* g, int64_t n, int64_t D, int64_t R, float scale, float* dW, int accumulate, const ScatterWs& w,
-                           hipStream_t s) {
+template <class Sink>
+static void scatter_reduce_sink(const float* g, int64_t n, int64_t D, int64_t R, float scale, const Sink& sink, bool vec, const ScatterWs& w,
+                                hipStream_t s) {
     const bool odd = scatter_passes(R) & 1;   // every pass ping-pongs the key / value arrays
     const uint32_t* ki = odd ? w.k1 : w.k0;
     const uint32_t* vi = odd ? w.v1 : w.v0;
-    const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u) == 0;
 #define SEG_LAUNCH(LPRV, VT)                                                                                                       \
     do {                                                                                                                           \
         const unsigned grid = (unsigned)re_cdiv(w.nchunks, 256 / LPRV);                                                            \
-        hipLaunchKernelGGL((seg_reduce<LPRV, VT>), dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, dW, w.partial, w.pflags, w.nchunks, accumulate); \
-        hipLaunchKernelGGL((seg_fixup<LPRV, VT>), dim3(grid), dim3(256), 0, s, ki, n, D, dW, w.partial, w.pflags, w.nchunks, accumulate); \
+        hipLaunchKernelGGL((seg_reduce<LPRV, VT, Sink>), dim3(grid), dim3(256), 0, s, ki, vi, g, n, D, R, scale, sink, w.partial, w.pflags, w.nchunks); \
+        hipLaunchKernelGGL((seg_fixup<LPRV, VT, Sink>), dim3(grid), dim3(256), 0, s, ki, n, D, sink, w.partial, w.pflags, w.nchunks); \
     } while (0)
     if (vec) {
         const int64_t D4 = D >> 2;
@@ -594,6 +625,12 @@ static void scatter_reduce(const float* g, int64_t n, int64_t D, int64_t R, floa
         else SEG_LAUNCH(4, float);
     }
 #undef SEG_LAUNCH
+}
+
+static void scatter_reduce(const float* g, int64_t n, int64_t D, int64_t R, float scale, float* dW, int accumulate, const ScatterWs& w,
+                           hipStream_t s) {
+    const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u) == 0;
+    scatter_reduce_sink(g, n, D, R, scale, DenseSink{dW, D, accumulate}, vec, w, s);
 }
 
 extern "C" int re_scatter_plan(const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* zero_fill,
@@ -648,5 +685,32 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
     const int rc = scatter_sort(idx, n, R, padding_idx, dW, accumulate ? (int64_t)0 : (int64_t)R * D, w, s);
     if (rc != RE_OK) return rc;
     scatter_reduce(g, n, D, R, scale, dW, accumulate, w, s);
+    return re_launch_status();
+}
+
+// Row-sparse Adam: for every distinct destination row r of idx (padding / out-of-range entries dropped), G_r = sum of the rows of g
+// that point at it (position order, deterministic), then one Adam update of row r of (W, m, v) with the GLOBAL step count --
+// torch.optim.SparseAdam's rule plus coupled weight decay on the touched rows.  Rows that receive no gradient are not touched
+// (a dense Adam would keep decaying their moments): the optimizer for tables whose dense gradient does not fit (config 5).
+extern "C" int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
+                                   float* m, float* v, int64_t step, double lr, double beta1, double beta2, double eps,
+                                   double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!W || !m || !v || R <= 0 || D <= 0 || n < 0 || step < 1) return RE_EINVAL;
+    if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
+    if (n == 0) return RE_OK;
+    if (!g || !idx || !ws) return RE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ScatterWs w = scatter_ws_layout(ws, n, D);
+    if (ws_bytes < w.bytes) return RE_EWORKSPACE;
+    const int rc = scatter_sort(idx, n, R, padding_idx, nullptr, 0, w, s);
+    if (rc != RE_OK) return rc;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    AdamSink sink{W, m, v, D, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)(lr / bc1),
+                  (float)(1.0 / sqrt(bc2)), (float)eps, (float)weight_decay};
+    const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(m) |
+                                       reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+    scatter_reduce_sink(g, n, D, R, 1.0f, sink, vec, w, s);
     return re_launch_status();
 }

@@ -92,6 +92,22 @@ def scatter_add_rows(g: torch.Tensor, idx: torch.Tensor, R: int, padding_idx: in
     return dW
 
 
+def sparse_adam_rows(g, idx, W, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, padding_idx=-1, ws=None):
+    """Row-sparse Adam (re_sparse_adam_rows): rows of (W, m, v) hit by idx are updated in place with the summed gradient rows."""
+    _req(g, torch.float32, "g"); _req(idx, torch.int64, "idx")
+    for t, nme in ((W, "W"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nme)
+    R, D = W.shape
+    n = idx.numel()
+    if g.numel() != n * D:
+        raise ValueError("recengine: g must have one row per index")
+    L = lib.load()
+    if ws is None:
+        ws = _ws(L.re_scatter_add_rows_workspace_bytes(n, D, R), g.device)
+    lib.check(L.re_sparse_adam_rows(_p(g), _p(idx), n, D, R, int(padding_idx), _p(W), _p(m), _p(v), int(step), float(lr), float(beta1),
+                                    float(beta2), float(eps), float(weight_decay), _p(ws), ws.numel(), _stream()), "re_sparse_adam_rows")
+
+
 def scatter_plan(idx, D, R, ws, padding_idx=-1, zero=None):
     """Index half of scatter_add_rows (re_scatter_plan): sorts (destination row, position) into `ws`; optionally zero-fills
     `zero` (the table scatter_apply will accumulate into).  Depends on idx only -- may run on a side stream."""

@@ -394,3 +394,33 @@ def test_bpr_triplet_fwd_bwd_equals_separate_kernels(ops):
     gu, gp, gn = ops.bpr_triplet_bwd(Ut, It, u, p, q, logits, None)
     loss2, gu2, gp2, gn2 = ops.bpr_triplet_fwd_bwd(Ut, It, u, p, q)
     assert torch.equal(loss, loss2) and torch.equal(gu, gu2) and torch.equal(gp, gp2) and torch.equal(gn, gn2)
+
+
+@pytest.mark.parametrize("D", [64, 128, 10])
+def test_sparse_adam_rows_matches_oracle(ops, D):
+    """re_sparse_adam_rows: touched rows follow the oracle's sparse Adam (duplicates summed, padding row skipped, weight decay
+    on touched rows), untouched rows keep parameters and moments bit for bit; two identical calls give identical bits."""
+    from oracle import adam as oadam
+    rng = np.random.default_rng(6)
+    R, n = 5000, 3000
+    W0 = rng.standard_normal((R, D)).astype(np.float32)
+    m0 = (0.01 * rng.standard_normal((R, D))).astype(np.float32)
+    v0 = (0.01 * rng.random((R, D))).astype(np.float32)
+    idx = np.minimum(rng.zipf(1.3, n), R - 1).astype(np.int64)
+    idx[::17] = 0                                   # padding row
+    g = rng.standard_normal((n, D)).astype(np.float32)
+    We, me, ve = W0.copy(), m0.copy(), v0.copy()
+    oadam.sparse_adam_rows(We, me, ve, idx, g, 7, 1e-3, wd=1e-2, padding_idx=0)
+    outs = []
+    for _ in range(2):
+        W, m, v = (torch.from_numpy(a.copy()).cuda() for a in (W0, m0, v0))
+        ops.sparse_adam_rows(torch.from_numpy(g).cuda(), torch.from_numpy(idx).cuda(), W, m, v, 7, 1e-3, weight_decay=1e-2, padding_idx=0)
+        outs.append((W.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    W, m, v = outs[0]
+    np.testing.assert_allclose(W, We, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(m, me, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(v, ve, rtol=2e-5, atol=2e-6)
+    untouched = np.setdiff1d(np.arange(R), idx[idx != 0])
+    assert np.array_equal(W[untouched], W0[untouched]) and np.array_equal(m[untouched], m0[untouched]) and np.array_equal(v[untouched], v0[untouched])

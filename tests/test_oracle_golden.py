@@ -212,3 +212,26 @@ def test_adam_matches_torch():
         opt.step()
         adam.adam_step(p, g, m, v, step, 5e-4, 0.9, 0.999, 1e-8, 1e-6)
         np.testing.assert_allclose(p, tp.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_sparse_adam_oracle_matches_torch_sparse_adam():
+    """oracle/adam.py:sparse_adam_rows (the rule re_sparse_adam_rows implements) == torch.optim.SparseAdam over several steps
+    with duplicate indices (weight_decay = 0: SparseAdam has none)."""
+    import torch
+    from oracle import adam as oadam
+    rng = np.random.default_rng(4)
+    R, D = 40, 8
+    W0 = rng.standard_normal((R, D)).astype(np.float32)
+    emb = torch.nn.Embedding(R, D, sparse=True)
+    with torch.no_grad():
+        emb.weight.copy_(torch.from_numpy(W0))
+    opt = torch.optim.SparseAdam(emb.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    W, m, v = W0.copy(), np.zeros_like(W0), np.zeros_like(W0)
+    for step in range(1, 5):
+        idx = rng.integers(0, R, 30)
+        coef = rng.standard_normal((30, D)).astype(np.float32)
+        opt.zero_grad()
+        (emb(torch.from_numpy(idx)) * torch.from_numpy(coef)).sum().backward()
+        opt.step()
+        oadam.sparse_adam_rows(W, m, v, idx, coef, step, 1e-2)
+        np.testing.assert_allclose(W, emb.weight.detach().numpy(), rtol=2e-5, atol=2e-6)

@@ -25,6 +25,10 @@ class OracleLocalOps:
                                   None if seen_idx is None else seen_idx.numpy(), K)
         return torch.from_numpy(v), torch.from_numpy(i)
 
+    def sparse_adam(self, g, idx, W, m, v, step, lr, b1, b2, eps, wd):
+        from oracle import adam
+        adam.sparse_adam_rows(W.numpy(), m.numpy(), v.numpy(), idx.numpy(), g.numpy(), step, lr, b1, b2, eps, wd)   # in place (shared memory)
+
 
 def _free_port():
     s = socket.socket()
@@ -60,6 +64,14 @@ def _worker(rank, world, port, q):
         dist.all_gather(all_grad, grad)
         ref = ranking.scatter_add_rows_c(torch.cat(all_grad).numpy(), torch.cat(all_idx).numpy(), R)
         np.testing.assert_allclose(shard_grad.numpy(), ref[rank::world], rtol=1e-5, atol=1e-5)
+        # sparse optimizer step on the sharded table == sparse Adam on the unsharded table with everybody's gradient rows
+        from oracle import adam as oadam
+        Wref, mref, vref = full.numpy().copy(), np.zeros((R, D), np.float32), np.zeros((R, D), np.float32)
+        oadam.sparse_adam_rows(Wref, mref, vref, torch.cat(all_idx).numpy().reshape(-1), torch.cat(all_grad).numpy().reshape(-1, D), 3, 1e-2, wd=1e-3)
+        tab.backward_sparse_adam(grad, route, 3, 1e-2, weight_decay=1e-3)
+        np.testing.assert_allclose(tab.weight.numpy(), Wref[rank::world], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(tab.m.numpy(), mref[rank::world], rtol=1e-5, atol=1e-6)
+        tab.init_from_full(full)                   # (the scoring checks below use the original table)
         # sharded full-catalog top-K == unsharded oracle (bit-exact indices), with a seen mask
         Q = torch.randn(9, D, generator=g)
         seen = [np.unique(np.random.default_rng(rank * 10 + b).integers(0, R, 7)) for b in range(9)]
