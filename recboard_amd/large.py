@@ -1,0 +1,110 @@
+"""SASRec on an item table too large for dense gradients / dense Adam (BASELINE config 5: 100 M items x D = 128).
+
+Same model as `recboard_amd.sasrec.SASRecEngine` (reference `SASRec/main.py:63-228`), different memory plan:
+
+  * the item table E [N+1, D] and its Adam moments are plain tensors outside the parameter arena (51 GB + 2 x 51 GB at
+    N = 1e8, D = 128: fits one MI355X's 288 GB); no [N+1, D] gradient ever exists;
+  * a step produces the 3*B*S item-gradient CONTRIBUTION ROWS (d x0 through the embedding backward, and the criterion's
+    positive / negative rows) and hands them, with their destination rows, to `re_sparse_adam_rows`: deterministic segmented
+    sums + one Adam update per distinct row (torch.optim.SparseAdam's rule + coupled weight decay on the touched rows) --
+    a dense Adam over the table would move 28 bytes per element, 358 GB per step;
+  * everything else (position table, blocks, lastLN) stays in one dense arena with one fused Adam launch.
+
+Encoder: the fused kernels are D = 64; any other D runs the block stack through torch (`encoder="aten"`), with the engine's
+embedding front end, criterion and optimizer kernels around it -- the D = 128 fused encoder is future work.
+Multi-GPU: `recboard_amd.sharded.ShardedTable.lookup / backward_sparse_adam` is the same step with the table row-sharded
+(one all-to-all per direction); this class is the single-GPU form.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from .sasrec import ParamArena, SASRecEngine, param_shapes
+
+
+class SASRecLargeTableEngine(SASRecEngine):
+    def __init__(self, num_items, maxlen=50, embedding_dim=128, num_blocks=2, dropout_rate=0.0, loss="BCE", lr=1e-3,
+                 weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, table_std=0.02):
+        assert loss in ("BCE", "BPR")
+        self.encoder = "aten"
+        self._bufs = {}
+        self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
+        self.p_drop, self.loss_kind = dropout_rate, loss
+        self.lr, self.wd, self.betas = lr, weight_decay, betas
+        self.device = torch.device(device)
+        shapes = param_shapes(num_items, maxlen, embedding_dim, num_blocks)
+        del shapes["Item.embeddings.weight"]                       # lives outside the arena
+        self.arena = ParamArena(shapes, self.device)
+        self.training = True
+        self.seed = seed
+        self.params = OrderedDict()
+        for k in self.arena.shapes:
+            self.params[k] = self.arena.view(self.arena.data, k).requires_grad_(True)
+        # item table + moments; row 0 = padding.  Filled in place, chunk-wise (no second table-sized temporary).
+        R, D = num_items + 1, embedding_dim
+        self.E = torch.empty((R, D), dtype=torch.float32, device=self.device)
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        step_rows = max(1, (1 << 28) // D)
+        for r0 in range(0, R, step_rows):
+            self.E[r0:r0 + step_rows].normal_(0.0, table_std, generator=g)
+        self.E[0].zero_()
+        self.Em = torch.zeros_like(self.E)
+        self.Ev = torch.zeros_like(self.E)
+        self.reset_parameters(seed)
+
+    def state_dict(self):
+        sd = OrderedDict((k, p.detach().clone()) for k, p in self.params.items())
+        sd["Item.embeddings.weight"] = self.E
+        return sd
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for k, p in self.params.items():
+                p.copy_(torch.as_tensor(sd[k]).to(self.device).view(p.shape))
+            self.E.copy_(torch.as_tensor(sd["Item.embeddings.weight"]).to(self.device))
+
+    # ---- forward pieces
+    def encode(self, seq):
+        """-> (userEmbds [B,S,D], itemEmbds = E[1:]).  SASRec/main.py:178-193 (inference / evaluation)."""
+        with torch.no_grad():
+            x0 = ops.sasrec_embed(self.E, self.params["Position.weight"].detach(), seq, float(self.D ** 0.5),
+                                  self.p_drop if self.training else 0.0, self._step_seed())
+            return self._blocks(x0, (seq == 0).unsqueeze(-1)), self.E[1:]
+
+    def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
+        """One step; gradients of the item table exist only as 3*B*S contribution rows."""
+        A, D = self.arena, self.D
+        B, S = seq.shape
+        n = B * S
+        if aux is None:
+            aux = self.batch_aux_fused(seq, pos, neg)
+        valid, rows_all, _, _, count = aux
+        p = self.p_drop if self.training else 0.0
+        sd = self._step_seed()
+        Ppos = self.params["Position.weight"]
+        # embedding front end (engine kernel, no autograd node: its backward is re_sasrec_embed_bwd below)
+        x0 = ops.sasrec_embed(self.E, Ppos.detach(), seq, float(D ** 0.5), p, sd).requires_grad_(True)
+        A.grad.zero_()
+        for k, q in self.params.items():
+            q.grad = A.view(A.grad, k)
+        u = self._blocks(x0, (seq == 0).unsqueeze(-1))
+        kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
+        C = torch.empty((3 * n, D), dtype=torch.float32, device=self.device)
+        loss, dU, _, _ = ops.pair_loss_fwd_bwd(u.detach().reshape(n, D), self.E, pos.reshape(-1), neg.reshape(-1), valid, kind, count,
+                                              e_off=1, out=(torch.empty((n, D), device=self.device), C[n:2 * n], C[2 * n:]))
+        u.backward(dU.view(B, S, D))                                      # encoder parameter gradients + d x0
+        C[:n].copy_(x0.grad.reshape(n, D))
+        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, A.view(A.grad, "Position.weight"))
+        if grad_hook is not None:
+            grad_hook(A.grad)
+        A.step += 1
+        ops.sparse_adam_rows(C, rows_all, self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
+                             padding_idx=0)
+        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        return loss.squeeze(0)
+
+    def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):
+        u, items = self.encode(seq)
+        return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K)
