@@ -7,6 +7,10 @@ monitored as the mean over batches weighted by batch size); every `eval_freq` ep
 fused score+mask+top-K kernel and the metrics kernel; best epoch tracked on `which4best`.  The per-step `loss.item()`
 host sync of the reference is replaced by one device-side accumulation read at the end of the epoch.
 """
+import datetime
+import json
+import os
+
 import torch
 
 from .evaluate import RankingEvaluator, ragged_to_csr
@@ -14,10 +18,11 @@ from .evaluate import RankingEvaluator, ragged_to_csr
 
 class Coach:
     def __init__(self, model, trainpipe, validpipe=None, testpipe=None, monitors=("LOSS", "HitRate@10", "NDCG@10"),
-                 which4best="NDCG@10", eval_freq=5, kind="seq"):
+                 which4best="NDCG@10", eval_freq=5, kind="seq", checkpoint_path=None):
         self.model, self.trainpipe, self.validpipe, self.testpipe = model, trainpipe, validpipe, testpipe
         self.monitors, self.which4best, self.eval_freq, self.kind = list(monitors), which4best, eval_freq, kind
         self.history, self.best = [], None
+        self.checkpoint_path = checkpoint_path
         self.device = model.device
 
     def dict_to_device(self, data):
@@ -28,7 +33,12 @@ class Coach:
         n = 0
         for data in self.trainpipe:
             data = self.dict_to_device(data)
-            if self.kind == "seq":
+            if self.kind == "seq" and self._graphable():
+                # one staging launch + one hipGraph replay per step (SASRecEngine.train_step_graph); a short last batch
+                # gets its own captured graph
+                seq = data["ISeq"]
+                loss = self.model.train_step_graph(self.model.pack_batch(seq, data["IPos"], data["INeg"]), seq.shape[0], seq.shape[1])
+            elif self.kind == "seq":
                 loss = self.model.train_step(data["ISeq"], data["IPos"], data["INeg"])
             else:
                 loss = self.model.train_step(data["User"], data["IPos"], data["INeg"])
@@ -36,6 +46,54 @@ class Coach:
             tot += loss * bsz
             n += bsz
         return {"LOSS": float(tot / max(n, 1))}
+
+    def _graphable(self):
+        m = self.model
+        return hasattr(m, "train_step_graph") and getattr(m, "encoder", None) == "fused" and getattr(m, "loss_kind", "CE") != "CE"
+
+    # ---- checkpoint / results in the reference's formats: `checkpoint.tar` (model state_dict under the
+    #      reference's parameter names + optimizer state + epoch), `best.pt` (state_dict of the best epoch), and the
+    #      `benchmark/<dataset>/<model>.json` record schema (benchmark/Amazon2014Beauty_550_LOU/SASRec.json:1-304).
+    def save_checkpoint(self, path, epoch):
+        os.makedirs(path, exist_ok=True)
+        m = self.model
+        opt = {}
+        if hasattr(m, "arena"):
+            opt = {"m": m.arena.m.clone(), "v": m.arena.v.clone(), "step": m.arena.step}
+        torch.save({"epoch": epoch, "model": m.state_dict(), "optimizer": opt, "best": self.best, "history": self.history},
+                   os.path.join(path, "checkpoint.tar"))
+
+    def load_checkpoint(self, path):
+        ck = torch.load(os.path.join(path, "checkpoint.tar"), map_location=self.device, weights_only=False)
+        self.model.load_state_dict(ck["model"])
+        if ck["optimizer"] and hasattr(self.model, "arena"):
+            a = self.model.arena
+            a.m.copy_(ck["optimizer"]["m"]); a.v.copy_(ck["optimizer"]["v"]); a.step = ck["optimizer"]["step"]
+        self.best, self.history = ck["best"], ck["history"]
+        return ck["epoch"]
+
+    def save_best(self, path):
+        os.makedirs(path, exist_ok=True)
+        torch.save(self.model.state_dict(), os.path.join(path, "best.pt"))
+
+    def results_record(self, dataset, model_name, out, seed=0, config=None, run_id=None):
+        """-> the list-of-one record the leaderboard's build-data script reads (recboard/scripts/build-data.mjs:95-146)."""
+        last_train = self.history[-1]["train"] if self.history else {}
+        best_valid = {}
+        if self.best is not None:
+            best_valid = next((h["valid"] for h in self.history if h["epoch"] == self.best[0] and "valid" in h), {})
+        now = datetime.datetime.now()
+        return [{
+            "description": "", "dataset": dataset, "tags": [model_name, "recengine", "MI355X"],
+            "runs": [{"id": run_id or now.strftime("%m%d%H%M%S"), "params": {"config": (config or {}).get("config", ""), "seed": seed},
+                      "metrics": {"train": last_train, "valid": best_valid, "test": out.get("test", {}), "best": out.get("test", {})}}],
+            "timestamp": now.strftime("%Y-%m-%dT%H:%M:%S"), "config": config or {},
+        }]
+
+    def save_results(self, path, dataset, model_name, out, **kw):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "results.json"), "w") as f:
+            json.dump(self.results_record(dataset, model_name, out, **kw), f, indent=2)
 
     def evaluate(self, mode="valid"):
         pipe = self.validpipe if mode == "valid" else self.testpipe
@@ -66,7 +124,11 @@ class Coach:
                 score = rec["valid"].get(f"{name.upper()}@{k}")
                 if score is not None and (self.best is None or score > self.best[1]):
                     self.best = (epoch, score)
+                    if self.checkpoint_path:
+                        self.save_best(self.checkpoint_path)
             self.history.append(rec)
+            if self.checkpoint_path:
+                self.save_checkpoint(self.checkpoint_path, epoch)
         out = {"history": self.history, "best": self.best}
         if self.testpipe is not None:
             out["test"] = self.evaluate("test")

@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_sasrec_learns_planted_transitions():
+def test_sasrec_learns_planted_transitions(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from recboard_amd.coach import Coach
@@ -16,7 +16,9 @@ def test_sasrec_learns_planted_transitions():
     ds = SyntheticSeqDataset(3000, 500, mean_len=9, p_follow=0.8, seed=3)
     m = SASRecEngine(500, 50, 64, 2, dropout_rate=0.2, loss="BCE", lr=1e-3, weight_decay=0.0, seed=1)
     coach = Coach(m, SeqTrainSampler(ds, 50, 256, seed=1), EvalSampler(ds, 50, 512, "valid"), EvalSampler(ds, 50, 512, "test"),
-                  monitors=["LOSS", "HitRate@1", "HitRate@10", "NDCG@10"], which4best="NDCG@10", eval_freq=10, kind="seq")
+                  monitors=["LOSS", "HitRate@1", "HitRate@10", "NDCG@10"], which4best="NDCG@10", eval_freq=10, kind="seq",
+                  checkpoint_path=str(tmp_path))
+    assert coach._graphable()                            # the epoch loop replays the captured step
     before = coach.evaluate("valid")
     out = coach.fit(30)
     after = out["history"][-1]["valid"]
@@ -26,6 +28,18 @@ def test_sasrec_learns_planted_transitions():
     assert after["HITRATE@10"] > 0.5                     # 80 % of the targets follow the planted permutation
     assert after["NDCG@10"] <= after["HITRATE@10"] and after["HITRATE@1"] <= after["HITRATE@10"]
     assert out["test"]["HITRATE@10"] > 0.5
+    # checkpoint / best / results in the reference's formats; a restored model evaluates identically
+    import json, os
+    assert os.path.exists(tmp_path / "checkpoint.tar") and os.path.exists(tmp_path / "best.pt")
+    coach.save_results(str(tmp_path), "Synthetic_550_LOU", "SASRec", out, seed=1, config={"config": "synthetic"})
+    rec = json.load(open(tmp_path / "results.json"))
+    assert isinstance(rec, list) and set(rec[0]) >= {"description", "dataset", "tags", "runs", "timestamp", "config"}
+    assert set(rec[0]["runs"][0]["metrics"]) == {"train", "valid", "test", "best"} and "HITRATE@10" in rec[0]["runs"][0]["metrics"]["test"]
+    m2 = SASRecEngine(500, 50, 64, 2, dropout_rate=0.2, loss="BCE", lr=1e-3, weight_decay=0.0, seed=7)
+    coach2 = Coach(m2, None, EvalSampler(ds, 50, 512, "valid"), EvalSampler(ds, 50, 512, "test"),
+                   monitors=["LOSS", "HitRate@1", "HitRate@10", "NDCG@10"], kind="seq")
+    assert coach2.load_checkpoint(str(tmp_path)) == 30
+    assert coach2.evaluate("test") == out["test"]
 
 
 def test_mfbpr_coach_runs():
