@@ -158,8 +158,7 @@ def main():
     hook = None
     if world > 1:
         def hook(garena):  # ONE collective per step: the whole gradient arena is a single bucket
-            dist.all_reduce(garena)
-            garena.mul_(1.0 / world)
+            dist.all_reduce(garena, op=dist.ReduceOp.AVG)   # (RCCL averages in the collective: no separate scaling launch)
 
     use_graph = args.encoder == "fused" and not args.no_graph
     blobs = [model.pack_batch(*b[:3]) for b in batches] if use_graph else None
