@@ -139,7 +139,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("RECBENCH_FORCE_DIST") == "1"   # smoke-test the multi-rank code path (RCCL + graph + hook) on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -156,7 +157,7 @@ def main():
         batches.append(t + ((model.batch_aux_fused(*t) if args.encoder == 'fused' else model.batch_aux(*t)),))
 
     hook = None
-    if world > 1:
+    if world > 1 or force_dist:
         def hook(garena):  # ONE collective per step: the whole gradient arena is a single bucket
             dist.all_reduce(garena, op=dist.ReduceOp.AVG)   # (RCCL averages in the collective: no separate scaling launch)
 
@@ -177,7 +178,7 @@ def main():
             torch.cuda.synchronize()
             step = step_graph
         except Exception as e:  # noqa: BLE001
-            if world == 1:
+            if world == 1 and not force_dist:
                 raise
             print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
             use_graph = False
