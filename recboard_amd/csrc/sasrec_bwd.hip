@@ -156,11 +156,6 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
     const float* tp = tape + (int64_t)l * T.per_block;
     const SeWork WK = se_work(B, nshort_ptr);
 
-    f32x4 accW[SB_NMAT][SE_RT];
-#pragma unroll
-    for (int m = 0; m < SB_NMAT; ++m)
-#pragma unroll
-        for (int t = 0; t < SE_RT; ++t) accW[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float accV[SB_NVEC];
 #pragma unroll
     for (int v = 0; v < SB_NVEC; ++v) accV[v] = 0.f;
@@ -176,6 +171,15 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         SE_MARK(1, 0);
         const int n_out = se_decode(wi, WK, B, S, order, seq, tid, s_gid, s_grp, s_pad);
         const bool packed = wi < WK.nsw;   // four short sequences: attention is block diagonal over the 16-row tiles
+        // weight gradients go straight to this workgroup's slab (overwritten by its first work item, added to by later ones):
+        // keeping the six 64x64 accumulators in registers across the item loop cost 48 VGPRs per wave for a loop that
+        // almost always runs once (work items <= workgroups)
+        float* slw = slab + ((int64_t)l * gridDim.x + blockIdx.x) * SB_SLAB;
+        const bool first_item = wi == (int)blockIdx.x;
+        auto slab_add = [&](int m, int row, float v) {
+            float* p = slw + m * 4096 + row * SE_D + col;
+            *p = first_item ? v : *p + v;
+        };
         __syncthreads();
         SE_MARK(1, 1);
         float4 R[SE_WV];                 // the next weight matrix, in flight from global memory
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
             wtile_commit(bW1, R, tid);   // W1
             wtile_fetch(R, W.out_w, tid);
             frag_ks(bf, b1 + SE_RO(16 * g) + col, SE_LS);
-            gemm64_acc<false>(b2, bf, lane, wr, accW[5]);
+            gemm64<false>(b2, bf, lane, wr, [&](int row, float v) { slab_add(5, row, v); });
             accV[5] += colsum16(b2, tid);
             wtile_frag_n(bf, bW0, wc, lane);
             gemm64<true>(b2, bf, lane, wr, [&](int row, float v) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
             wtile_commit(bW0, R, tid);   // Wo  (bW0's last reader, GEMM A, finished before phase A's closing barrier)
             wtile_fetch(R, W.in_w, tid);
             frag_ks(bf, b2 + SE_RO(16 * g) + col, SE_LS);
-            gemm64_acc<false>(b3, bf, lane, wr, accW[4]);
+            gemm64<false>(b3, bf, lane, wr, [&](int row, float v) { slab_add(4, row, v); });
             accV[4] += colsum16(b3, tid);
             wtile_frag_n(bf, bW1, wc, lane);
             gemm64<true>(b3, bf, lane, wr, [&](int row, float v) { b0[SE_RO(row) + col] += v; });
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
             wtile_commit(bW1, R, tid);   // Wq  (bW1's last reader, GEMM B, finished before phase B's closing barrier)
             wtile_fetch(R, W.in_w + SE_D * SE_D, tid);
             frag_ks(bf, b2 + SE_RO(16 * g) + col, SE_LS);
-            gemm64_acc<false>(b0, bf, lane, wr, accW[3]);
+            gemm64<false>(b0, bf, lane, wr, [&](int row, float v) { slab_add(3, row, v); });
             accV[3] += colsum16(b0, tid);
             wtile_frag_n(bf, bW0, wc, lane);
             gemm64<true>(b0, bf, lane, wr, [&](int row, float v) { b3[SE_RO(row) + col] = v; });
@@ -397,10 +401,10 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
         {
             float bf[16];
             frag_ks(bf, b3 + SE_RO(16 * g) + col, SE_LS);     // LN_a(x)
-            gemm64_acc<false>(b4, bf, lane, wr, accW[0]);
+            gemm64<false>(b4, bf, lane, wr, [&](int row, float v) { slab_add(0, row, v); });
             frag_ks(bf, b1 + SE_RO(16 * g) + col, SE_LS);     // x
-            gemm64_acc<false>(b6, bf, lane, wr, accW[1]);
-            gemm64_acc<false>(b2, bf, lane, wr, accW[2]);
+            gemm64<false>(b6, bf, lane, wr, [&](int row, float v) { slab_add(1, row, v); });
+            gemm64<false>(b2, bf, lane, wr, [&](int row, float v) { slab_add(2, row, v); });
             accV[0] += colsum16(b4, tid);
             accV[1] += colsum16(b6, tid);
             accV[2] += colsum16(b2, tid);
@@ -468,12 +472,6 @@ __global__ __launch_bounds__(SE_NT) void sasrec_block_bwd_k(const float* __restr
     if ((int)blockIdx.x >= WK.total) return;
     SE_THREAD_VARS(tid0);
     float* sl = slab + ((int64_t)l * gridDim.x + blockIdx.x) * SB_SLAB;
-#pragma unroll
-    for (int m = 0; m < SB_NMAT; ++m)
-#pragma unroll
-        for (int t = 0; t < SE_RT; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sl[m * 4096 + (16 * (wr * SE_RT + t) + 4 * g + j) * SE_D + col] = accW[m][t][j];
     if (fuse_embed) {
 #pragma unroll
         for (int i = 0; i < SE_CPT; ++i) sl[SB_OFFP + r_e * SE_D + c0_e + i] = accP[i];
