@@ -432,26 +432,21 @@ __global__ __launch_bounds__(256) void seg_fixup(const uint32_t* __restrict__ ke
     if (threadIdx.x == 0) n_long = 0;
     __syncthreads();
     const int64_t c = (int64_t)blockIdx.x * G + grp;
-    if (c < nchunks) {
-        // ONE load stage: the chunk's own flag, its key, its slot-1 partial and the next 8 links (flags + slot-0 partials) are
-        // all requested before anything is tested -- the kernel's time is launch latency plus dependent memory round trips
+    if (c < nchunks && (pflags[c] & RE_FLAG_SLOT1)) {
         const int64_t end = (c * RE_SEG_CHUNK + RE_SEG_CHUNK < n) ? c * RE_SEG_CHUNK + RE_SEG_CHUNK : n;
-        const uint32_t myflag = pflags[c];
         const uint32_t key = keys[end - 1];
-        uint32_t f[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) f[u] = (c + 1 + u < nchunks) ? pflags[c + 1 + u] : 0u;
         bool is_long = false;
         for (int64_t col = lir; col < D4 && !is_long; col += LPR) {
             V acc = reinterpret_cast<const V*>(partial + (c * 2 + 1) * D)[col];
+            bool open = true;
+            uint32_t f[8];
             V part[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 8; ++u) {   // 8 links of the chain, loads issued together
                 const int64_t cc = (c + 1 + u < nchunks) ? c + 1 + u : nchunks - 1;
+                f[u] = (c + 1 + u < nchunks) ? pflags[cc] : 0u;
                 part[u] = reinterpret_cast<const V*>(partial + (cc * 2 + 0) * D)[col];   // (valid memory; used only on the chain)
             }
-            if (!(myflag & RE_FLAG_SLOT1)) break;   // (uniform over the lane group)
-            bool open = true;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (!open) break;
