@@ -352,6 +352,12 @@ __global__ __launch_bounds__(256) void seg_reduce(const uint32_t* __restrict__ k
     const uint32_t nextKey = end < n ? keys[end] : NONE;
     const int64_t D4 = D / (int64_t)(sizeof(V) / sizeof(float));
     uint32_t flags = 0;
+    // Dropped entries (padding / out of range) sort to the end: a chunk that STARTS with one consists of nothing else, and
+    // its rows are not even read -- in a SASRec batch 88 % of the 3*B*S contribution rows are padding positions.
+    if (keys[begin] == DROP) {
+        if (lir == 0) pflags[c] = 0;
+        return;
+    }
     for (int64_t col = lir; col < D4; col += LPR) {
         uint32_t curKey = keys[begin];
         bool isHead = true;
