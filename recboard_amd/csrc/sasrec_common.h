@@ -244,20 +244,40 @@ __device__ __forceinline__ void wtile_frag_n(float (&bf)[16], const float* tile,
 }
 
 // ---- row-wise helpers: thread tid handles row tid / SE_TPR, columns [SE_CPT * (tid % SE_TPR), +SE_CPT) -------------
-// sum / max over the SE_TPR consecutive lanes that share a row
+// sum / max over the SE_TPR consecutive lanes that share a row, as DPP butterflies inside a 16-lane row (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror): one v_add_f32_dpp per step instead of a ds_bpermute_b32 round trip through the LDS crossbar
+// (__shfl_xor).  Each step still adds the same two partial sums in every lane, so the result equals the xor butterfly's.
+template <int CTRL>
+__device__ __forceinline__ float se_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int se_dpp(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+#define SE_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define SE_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define SE_DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i  inside each group of 8
+#define SE_DPP_MIRROR 0x140       // lane i <-> 15 - i inside each row of 16
 __device__ __forceinline__ float row_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < SE_TPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    v += se_dpp<SE_DPP_XOR1>(v);
+    v += se_dpp<SE_DPP_XOR2>(v);
+    if (SE_TPR >= 8) v += se_dpp<SE_DPP_HALF_MIRROR>(v);
+    if (SE_TPR >= 16) v += se_dpp<SE_DPP_MIRROR>(v);
     return v;
 }
 __device__ __forceinline__ float row_max(float v) {
-#pragma unroll
-    for (int o = 1; o < SE_TPR; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, se_dpp<SE_DPP_XOR1>(v));
+    v = fmaxf(v, se_dpp<SE_DPP_XOR2>(v));
+    if (SE_TPR >= 8) v = fmaxf(v, se_dpp<SE_DPP_HALF_MIRROR>(v));
+    if (SE_TPR >= 16) v = fmaxf(v, se_dpp<SE_DPP_MIRROR>(v));
     return v;
 }
 __device__ __forceinline__ int row_sum_i(int v) {
-#pragma unroll
-    for (int o = 1; o < SE_TPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    v += se_dpp<SE_DPP_XOR1>(v);
+    v += se_dpp<SE_DPP_XOR2>(v);
+    if (SE_TPR >= 8) v += se_dpp<SE_DPP_HALF_MIRROR>(v);
+    if (SE_TPR >= 16) v += se_dpp<SE_DPP_MIRROR>(v);
     return v;
 }
 
