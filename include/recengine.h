@@ -91,6 +91,11 @@ int re_scatter_apply(const float* g, int64_t n, int64_t D, int64_t R, float scal
 int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
                         float* m, float* v, int64_t step, double lr, double beta1, double beta2, double eps,
                         double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream);
+/* hipGraph-friendly form of re_sparse_adam_rows: hyper (DEVICE float[2]) = { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) } as for
+ * re_adam_step_dev. */
+int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
+                            float* m, float* v, const float* hyper, double beta1, double beta2, double eps,
+                            double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream);
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                         int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,

@@ -315,11 +315,13 @@ struct AdamSink {   // torch.optim.SparseAdam semantics on the touched rows (+ c
     float *W, *m, *v;
     int64_t D;
     float b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd;
+    const float* hyper;   // non-null: { lr / (1 - b1^t), 1 / sqrt(1 - b2^t) } in device memory (hipGraph replays)
     __device__ __forceinline__ void one(float& p, float& mm, float& vv, float g) const {
+        const float ss = hyper ? hyper[0] : step_size, ib = hyper ? hyper[1] : inv_sqrt_bc2;
         const float gg = g + wd * p;
         mm = b1 * mm + omb1 * gg;
         vv = b2 * vv + omb2 * gg * gg;
-        p = p - step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+        p = p - ss * (mm / (sqrtf(vv) * ib + eps));
     }
     __device__ __forceinline__ void put(uint32_t row, int64_t col, float4 acc) const {
         float4* pp = reinterpret_cast<float4*>(W + (int64_t)row * D) + col;
@@ -698,11 +700,10 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
 // that point at it (position order, deterministic), then one Adam update of row r of (W, m, v) with the GLOBAL step count --
 // torch.optim.SparseAdam's rule plus coupled weight decay on the touched rows.  Rows that receive no gradient are not touched
 // (a dense Adam would keep decaying their moments): the optimizer for tables whose dense gradient does not fit (config 5).
-extern "C" int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
-                                   float* m, float* v, int64_t step, double lr, double beta1, double beta2, double eps,
-                                   double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream) {
-    re_clear_error();
-    if (!W || !m || !v || R <= 0 || D <= 0 || n < 0 || step < 1) return RE_EINVAL;
+static int sparse_adam_launch(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W, float* m,
+                              float* v, float step_size, float inv_sqrt_bc2, const float* hyper, double beta1, double beta2, double eps,
+                              double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream) {
+    if (!W || !m || !v || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
     if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     if (n == 0) return RE_OK;
     if (!g || !idx || !ws) return RE_EINVAL;
@@ -711,12 +712,30 @@ extern "C" int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n
     if (ws_bytes < w.bytes) return RE_EWORKSPACE;
     const int rc = scatter_sort(idx, n, R, padding_idx, nullptr, 0, w, s);
     if (rc != RE_OK) return rc;
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    AdamSink sink{W, m, v, D, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)(lr / bc1),
-                  (float)(1.0 / sqrt(bc2)), (float)eps, (float)weight_decay};
+    AdamSink sink{W, m, v, D, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), step_size, inv_sqrt_bc2, (float)eps,
+                  (float)weight_decay, hyper};
     const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(m) |
                                        reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
     scatter_reduce_sink(g, n, D, R, 1.0f, sink, vec, w, s);
     return re_launch_status();
+}
+
+extern "C" int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
+                                   float* m, float* v, int64_t step, double lr, double beta1, double beta2, double eps,
+                                   double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (step < 1) return RE_EINVAL;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    return sparse_adam_launch(g, idx, n, D, R, padding_idx, W, m, v, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), nullptr, beta1, beta2, eps,
+                              weight_decay, ws, ws_bytes, stream);
+}
+
+// hipGraph-friendly form: the two step-dependent scalars come from device memory (as re_adam_step_dev; written by re_step_stage)
+extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
+                                       float* m, float* v, const float* hyper, double beta1, double beta2, double eps,
+                                       double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!hyper) return RE_EINVAL;
+    return sparse_adam_launch(g, idx, n, D, R, padding_idx, W, m, v, 0.f, 0.f, hyper, beta1, beta2, eps, weight_decay, ws, ws_bytes, stream);
 }

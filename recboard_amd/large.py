@@ -73,19 +73,16 @@ class SASRecLargeTableEngine(SASRecEngine):
                                   self.p_drop if self.training else 0.0, self._step_seed())
             return self._blocks(x0, (seq == 0).unsqueeze(-1)), self.E[1:]
 
-    def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
-        """One step; gradients of the item table exist only as 3*B*S contribution rows."""
+    def _grads(self, seq, pos, neg, aux, sd, seed_dev=None):
+        """Forward + backward: encoder gradients into the arena, the 3*B*S item-gradient contribution rows into C.  -> (loss, C)."""
         A, D = self.arena, self.D
         B, S = seq.shape
         n = B * S
-        if aux is None:
-            aux = self.batch_aux_fused(seq, pos, neg)
         valid, rows_all, _, _, count = aux
         p = self.p_drop if self.training else 0.0
-        sd = self._step_seed()
         Ppos = self.params["Position.weight"]
         # embedding front end (engine kernel, no autograd node: its backward is re_sasrec_embed_bwd below)
-        x0 = ops.sasrec_embed(self.E, Ppos.detach(), seq, float(D ** 0.5), p, sd).requires_grad_(True)
+        x0 = ops.sasrec_embed(self.E, Ppos.detach(), seq, float(D ** 0.5), p, sd, seed_dev=seed_dev).requires_grad_(True)
         A.grad.zero_()
         for k, q in self.params.items():
             q.grad = A.view(A.grad, k)
@@ -96,14 +93,79 @@ class SASRecLargeTableEngine(SASRecEngine):
                                               e_off=1, out=(torch.empty((n, D), device=self.device), C[n:2 * n], C[2 * n:]))
         u.backward(dU.view(B, S, D))                                      # encoder parameter gradients + d x0
         C[:n].copy_(x0.grad.reshape(n, D))
-        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, A.view(A.grad, "Position.weight"))
+        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, A.view(A.grad, "Position.weight"), seed_dev=seed_dev)
+        return loss, C
+
+    def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
+        """One step; gradients of the item table exist only as 3*B*S contribution rows."""
+        A = self.arena
+        if aux is None:
+            aux = self.batch_aux_fused(seq, pos, neg)
+        loss, C = self._grads(seq, pos, neg, aux, self._step_seed())
         if grad_hook is not None:
             grad_hook(A.grad)
         A.step += 1
-        ops.sparse_adam_rows(C, rows_all, self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
+        ops.sparse_adam_rows(C, aux[1], self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
                              padding_idx=0)
         ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
         return loss.squeeze(0)
+
+    # ---- the same step as one hipGraph replay: at D = 128 the block stack is ~300 torch launches per step and the CPU launch
+    #      path, not the GPU, sets the step time.  (The torch dropout inside the captured blocks draws from torch's graph-safe
+    #      Philox state; the engine's own masks get their per-step seed through the device word, as in SASRecEngine.)
+    def _capture(self, B, S, with_adam):
+        A = self.arena
+        _, total = self._blob_layout(B, S)
+        blob = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        V = self._blob_views(blob, B, S)
+        V["order"].copy_(torch.arange(B, dtype=torch.int32, device=self.device))
+        V["count"].fill_(1)
+        state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        hyper = state.view(torch.float32)[2:4]
+        aux = (V["valid"], V["rows_all"], (V["order"], V["nshort"]), None, V["count"])
+
+        def body():
+            loss, C = self._grads(V["seq"], V["pos"], V["neg"], aux, 0, seed_dev=state)
+            if with_adam:
+                ops.sparse_adam_rows_dev(C, V["rows_all"], self.E, self.Em, self.Ev, hyper, self.betas[0], self.betas[1], 1e-8, self.wd,
+                                         padding_idx=0)
+                ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
+            return loss, C
+
+        # warm-up on a side stream with an all-padding batch (touches no table row; the arena is restored afterwards)
+        keep = [t.clone() for t in (A.data, A.m, A.v, A.grad)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.step_stage(blob, blob.clone(), state, 0, 1, self.lr, *self.betas)
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            loss, C = body()
+        for t, k in zip((A.data, A.m, A.v, A.grad), keep):
+            t.copy_(k)
+        return dict(graph=graph, blob=blob, state=state, loss=loss, C=C, rows=V["rows_all"])
+
+    def train_step_graph(self, blob, B, S, grad_hook=None):
+        A = self.arena
+        key = (B, S, grad_hook is None, self.training)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
+        g = self._graphs[key]
+        ops.step_stage(g["blob"], blob, g["state"], self._step_seed(), A.step + 1, self.lr, *self.betas)
+        g["graph"].replay()
+        A.step += 1
+        if grad_hook is not None:
+            grad_hook(A.grad)
+            ops.sparse_adam_rows(g["C"], g["rows"], self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
+                                 padding_idx=0)
+            ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        return g["loss"].squeeze(0)
 
     def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):
         u, items = self.encode(seq)

@@ -108,6 +108,20 @@ def sparse_adam_rows(g, idx, W, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8
                                     float(beta2), float(eps), float(weight_decay), _p(ws), ws.numel(), _stream()), "re_sparse_adam_rows")
 
 
+def sparse_adam_rows_dev(g, idx, W, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, padding_idx=-1, ws=None):
+    """sparse_adam_rows with the step-dependent scalars in device memory (re_sparse_adam_rows_dev; for captured steps)."""
+    _req(g, torch.float32, "g"); _req(idx, torch.int64, "idx"); _req(hyper, torch.float32, "hyper")
+    for t, nme in ((W, "W"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nme)
+    R, D = W.shape
+    n = idx.numel()
+    L = lib.load()
+    if ws is None:
+        ws = _ws(L.re_scatter_add_rows_workspace_bytes(n, D, R), g.device)
+    lib.check(L.re_sparse_adam_rows_dev(_p(g), _p(idx), n, D, R, int(padding_idx), _p(W), _p(m), _p(v), _p(hyper), float(beta1), float(beta2),
+                                        float(eps), float(weight_decay), _p(ws), ws.numel(), _stream()), "re_sparse_adam_rows_dev")
+
+
 def scatter_plan(idx, D, R, ws, padding_idx=-1, zero=None):
     """Index half of scatter_add_rows (re_scatter_plan): sorts (destination row, position) into `ws`; optionally zero-fills
     `zero` (the table scatter_apply will accumulate into).  Depends on idx only -- may run on a side stream."""

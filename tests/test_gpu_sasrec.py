@@ -198,3 +198,24 @@ def test_large_table_engine_first_step_equals_dense_engine(D):
         torch.testing.assert_close(sl[k], sd[k], rtol=2e-4, atol=2e-5, msg=k)
     # second step runs (moments of untouched rows now differ by design: dense Adam keeps decaying them)
     assert torch.isfinite(large.train_step(*batch))
+
+
+def test_large_table_engine_graph_step_matches_eager_step():
+    """The captured step of SASRecLargeTableEngine (torch block stack + engine kernels in one hipGraph, scalars through device
+    words) reproduces the eager step (dropout 0: torch's RNG plays no part)."""
+    from recboard_amd.large import SASRecLargeTableEngine
+    N, B, S, D = 300, 8, 50, 128
+    rng = np.random.default_rng(31)
+    seq = rng.integers(1, N + 1, (B, S))
+    for b in range(B):
+        seq[b, : rng.integers(0, S - 1)] = 0
+    batch = tuple(torch.from_numpy(a).cuda() for a in (seq, rng.integers(0, N, (B, S)), rng.integers(0, N, (B, S))))
+    eager = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.0, lr=1e-2, weight_decay=1e-4, seed=2)
+    graph = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.0, lr=1e-2, weight_decay=1e-4, seed=2)
+    blob = SASRecLargeTableEngine.pack_batch(*batch)
+    for i in range(3):
+        le = eager.train_step(*batch).clone()
+        lg = graph.train_step_graph(blob, B, S).clone()
+        torch.testing.assert_close(lg, le, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(graph.E, eager.E, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(graph.arena.data, eager.arena.data, rtol=1e-4, atol=1e-6)
