@@ -741,7 +741,7 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
     int rc, lps = 1;
     // register-list variant: many users per launch (its two lists per segment double the merge work, which dominates
     // when B is small -- A/B in scripts/tune_score.py)
-    if (g_score_pop == 3 && D == 64 && K <= 52 && p.nub >= 16 && N < (1ll << SR_TAGBITS) - 1) {
+    if (g_score_pop == 3 && D == 64 && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1) {
         lps = 2;
         const size_t lds = (size_t)SC_TI * (64 + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
 #define SR_LAUNCH(KRV) hipLaunchKernelGGL((score_kernel_reg<64, KRV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, g_score_dbg)
