@@ -304,7 +304,9 @@ __device__ __forceinline__ double sr_max(double a, double b) {
 }
 __device__ unsigned long long g_sr_counters[4];
 __device__ unsigned long long g_sr_counters_x[2];   // diagnostics (dbg == 3): drains, rounds, appended hits, tiles with hits
-template <int D, int KR>
+// KT > 0: K is the compile-time constant KT (= KR): the K-th / (K/2)-th list slots are fixed registers instead of a 2 x KR
+// select chain per drain (the common K = 50 of the evaluation monitors gets its own instantiation)
+template <int D, int KR, int KT>
 __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
                                                            int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
                                                            const int64_t* __restrict__ seen_idx, int K,
@@ -420,10 +422,15 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 // two lanes' ceil(K/2)-th bests (K/2 items above a in one half + K/2 above b in the other): (b) is
                 // close to the true K-th value because the halves are statistically alike -> ~40 % fewer hits.
                 double kmid = lk[0], kkth = lk[0];
+                if constexpr (KT > 0) {
+                    kmid = lk[(KT + 1) / 2 - 1];
+                    kkth = lk[KT - 1];
+                } else {
 #pragma unroll
-                for (int j = 1; j < KR; ++j) {
-                    kmid = (j == (K + 1) / 2 - 1) ? lk[j] : kmid;
-                    kkth = (j == K - 1) ? lk[j] : kkth;
+                    for (int j = 1; j < KR; ++j) {
+                        kmid = (j == (K + 1) / 2 - 1) ? lk[j] : kmid;
+                        kkth = (j == K - 1) ? lk[j] : kkth;
+                    }
                 }
                 const float mid = key_value(kmid), kth = key_value(kkth);
                 const float pmid = __shfl_xor(mid, 32, 64), pkth = __shfl_xor(kth, 32, 64);
@@ -496,8 +503,11 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
                 }
                 SC_T(if (prof) { asm volatile("s_nop 0" :: "v"(acc[0])); t1 = __builtin_readcyclecounter(); td += t1 - t0; t0 = t1; })
+                // threshold filter, 2 vector ops per score and no compare-mask hazards: the sign bit of (thr - score) is shifted
+                // into the mask with v_alignbit.  It is set for score > thr (thr = -inf before the lists fill: every score) and
+                // for the pair (thr = -0, score = +0) -- a harmless extra candidate, the f64 keys order it correctly.
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m |= (acc[r] > thr ? 1u : 0u) << r;
+                for (int r = 15; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(thr - acc[r]), 31);
                 // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with two ids prefetched)
                 while (ns0 < (int)item0 + 32) {
                     if (ns0 == NEED) {   // window used up inside this stage: reload and wait here, inside the rare branch
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                     drain();
                     unsigned m2 = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m2 |= (acc[r] > thr ? 1u : 0u) << r;
+                    for (int r = 15; r >= 0; --r) m2 = __builtin_amdgcn_alignbit(m2, __float_as_uint(thr - acc[r]), 31);
                     m &= m2;
                 }
 #pragma unroll
@@ -744,8 +754,8 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
     if (g_score_pop == 3 && D == 64 && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1) {
         lps = 2;
         const size_t lds = (size_t)SC_TI * (64 + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
-#define SR_LAUNCH(KRV) hipLaunchKernelGGL((score_kernel_reg<64, KRV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, g_score_dbg)
-        if (K <= 16) SR_LAUNCH(16); else if (K <= 32) SR_LAUNCH(32); else SR_LAUNCH(52);
+#define SR_LAUNCH(KRV, KTV) hipLaunchKernelGGL((score_kernel_reg<64, KRV, KTV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, g_score_dbg)
+        if (K == 50) SR_LAUNCH(50, 50); else if (K <= 16) SR_LAUNCH(16, 0); else if (K <= 32) SR_LAUNCH(32, 0); else SR_LAUNCH(52, 0);
 #undef SR_LAUNCH
         rc = re_launch_status();
     } else {
