@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__
 // bound (a (value, id) pair of lists costs 1 compare + 4 selects per slot at ~7 cycles per dependent op), and this is
 // what the insertion cost is made of.  (Tried and dropped: value-only lists with the (value, item) pairs logged to global
 // memory -- the end-of-segment selection over the log is latency bound.)
-#define SR_QC 24
+#define SR_QC 28
 #define SR_TAGBITS 29
 // raw v_min_f64 / v_max_f64: through fmin / fmax the compiler re-canonicalises every loop-carried list element
 // (one extra v_max_f64 v, v, v per slot per insertion); keys are never NaN
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         // Drains are WORKGROUP-wide where possible: the four waves share the stage barriers, so a wave draining alone stalls
         // the other three at the next barrier (measured: drain time x ~3).  The vote rides on the stage's first barrier (each
         // wave leaves a flag in LDS before it, everybody reads the four flags after it): a drain is called when some queue
-        // is more than half full.  A queue that would still overflow inside a stage (only while the lists fill up, at the
+        // is more than two thirds full (fuller queues: fewer rounds lost to the longest lane).  A queue that would still overflow inside a stage (only while the lists fill up, at the
         // start of a segment) is drained by its wave on the spot.
 #ifdef SC_PROFILE   // cycle accounting of one wave (make CXXFLAGS+=-DSC_PROFILE; scripts/tune_score.py), written out once at the end
         const bool prof = dbg >= 8 && blockIdx.x == 7 && wid == 0;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         for (int64_t st = st0; st < st1; ++st) {
             SC_T(if (prof) t0 = __builtin_readcyclecounter();)
             if (lane == 0) vote[wid] = 0;
-            if (qn > SR_QC / 2) vote[wid] = 1;
+            if (qn > (SR_QC * 2) / 3) vote[wid] = 1;
             __syncthreads();
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); ta += t1 - t0; t0 = t1; })
             const bool wg_drain = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
