@@ -297,6 +297,15 @@ __device__ __forceinline__ double sr_min(double a, double b) {
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// order-preserving float <-> uint32 (larger float <-> larger word; 0 is below every float): the shared per-user bound
+__device__ __forceinline__ unsigned sr_enc(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float sr_dec(unsigned e) {
+    if (e == 0u) return -INFINITY;
+    return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e);
+}
 __device__ __forceinline__ double sr_max(double a, double b) {
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -311,7 +320,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                                                            int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
                                                            const int64_t* __restrict__ seen_idx, int K,
                                                            float* __restrict__ part_vals, int* __restrict__ part_idx,
-                                                           int maxseg, int64_t nub, int64_t nst, int64_t upw, int dbg) {
+                                                           int maxseg, int64_t nub, int64_t nst, int64_t upw,
+                                                           unsigned* __restrict__ gthr, int dbg) {
     constexpr int KH = D / 2;
     constexpr int RSF = D + 4;
     constexpr int F4_PER_STAGE = SC_TI * D / 4;
@@ -375,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
 #pragma unroll
         for (int j = 0; j < KR; ++j) lk[j] = KEMPTY;
         float thr = (user < B && dbg != 1 && (dbg < 5 || dbg == 8)) ? -INFINITY : INFINITY;
+        float gbound = -INFINITY;   // the shared bound as last read
         int qn = 0;
         int64_t sc_cur = 0, sc_end = 0;
         int ns0 = NONE, ns1 = NONE;
@@ -436,6 +447,14 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 const float pmid = __shfl_xor(mid, 32, 64), pkth = __shfl_xor(kth, 32, 64);
                 thr = fmaxf(fmaxf(kth, pkth), fminf(mid, pmid));
                 if (thr <= -3.402823466e+38f) thr = -INFINITY;   // lists not full yet
+                // Every workgroup that scores items for this user holds such a lower bound of the user's K-th best: they share
+                // the best one through a word in global memory (device-scope max on an order-preserving encoding; read back,
+                // possibly stale, at the top of every stage).  Each segment then filters almost as if it had seen the whole
+                // catalog: ~K(1+ln(N/K)) list insertions per USER instead of per (segment, lane).
+                if (gthr) {
+                    if (h == 0 && user < B && thr > -INFINITY) atomicMax(gthr + user, sr_enc(thr));
+                    thr = fmaxf(thr, gbound);
+                }
             }
         };
 
@@ -484,6 +503,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
             __syncthreads();
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); tc += t1 - t0; t0 = t1; })
             refill();
+            unsigned genc = 0u;          // (requested before the item prefetch, like the seen window: its wait leaves the prefetch in flight)
+            if (gthr && user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             prefetch(st + 1 < st1 ? st + 1 : st);
 #pragma unroll 1
             for (int it = 0; it < SC_TI / 32; ++it) {
@@ -503,11 +524,18 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
                 }
                 SC_T(if (prof) { asm volatile("s_nop 0" :: "v"(acc[0])); t1 = __builtin_readcyclecounter(); td += t1 - t0; t0 = t1; })
-                // threshold filter, 2 vector ops per score and no compare-mask hazards: the sign bit of (thr - score) is shifted
-                // into the mask with v_alignbit.  It is set for score > thr (thr = -inf before the lists fill: every score) and
-                // for the pair (thr = -0, score = +0) -- a harmless extra candidate, the f64 keys order it correctly.
+                if (gthr && it == 0) {   // fold in the shared bound read at the top of this stage
+                    gbound = fmaxf(gbound, sr_dec(genc));
+                    thr = fmaxf(thr, gbound);
+                }
+                // threshold filter, 2 vector ops per score and no compare-mask hazards: the sign bit of (score - thr) -- set for
+                // score < thr -- is shifted into a mask with v_alignbit; hits are the complement: score >= thr.  ">=" and not ">"
+                // because thr may come from OTHER items (the partner lane, other workgroups): an item that ties the bound with
+                // a lower id can still belong to the top K.  The f64 keys order whatever gets through.  (Neither a score -- an fmaf chain
+                // started at +0 -- nor a bound is ever -0, so equal zeros compare as equal here.)
 #pragma unroll
-                for (int r = 15; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(thr - acc[r]), 31);
+                for (int r = 15; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r] - thr), 31);
+                m = ~m & 0xFFFFu;
                 // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with two ids prefetched)
                 while (ns0 < (int)item0 + 32) {
                     if (ns0 == NEED) {   // window used up inside this stage: reload and wait here, inside the rare branch
@@ -531,8 +559,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                     drain();
                     unsigned m2 = 0;
 #pragma unroll
-                    for (int r = 15; r >= 0; --r) m2 = __builtin_amdgcn_alignbit(m2, __float_as_uint(thr - acc[r]), 31);
-                    m &= m2;
+                    for (int r = 15; r >= 0; --r) m2 = __builtin_amdgcn_alignbit(m2, __float_as_uint(acc[r] - thr), 31);
+                    m &= ~m2;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -651,6 +679,8 @@ static int g_score_pop = 3;      // tuning switches (scripts/tune_score.py); not
 static int64_t g_score_minseg = SC_MIN_SEG;
 static int64_t g_score_maxwgs = SC_MAX_WGS;
 extern "C" void re_dbg_score_maxwgs(int64_t n) { g_score_maxwgs = n > 0 ? n : SC_MAX_WGS; }
+static int g_score_share = 1;   // workgroups share per-user bounds through global memory (0: A/B switch, scripts/tune_score.py)
+extern "C" void re_dbg_score_share(int on) { g_score_share = on; }
 static int g_score_dbg = 0;   // diagnostics only (scripts/tune_score.py): 1 = no hits at all, 2 = append but never insert
 extern "C" void re_dbg_score_diag(int mode) { g_score_dbg = mode; }
 #ifdef SC_PROFILE
@@ -696,7 +726,7 @@ extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D,
     if (B <= 0 || N <= 0 || K <= 0) return 256;
     ScorePlan p = score_plan(B, N);
     return re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4) * 2      // up to 2 lists per (user, segment)
-           + 256;
+           + re_align((size_t)B * 4) + 256;                                     // shared per-user bounds
 }
 
 template <int D, bool TOPK, int POP>
@@ -754,7 +784,9 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
     if (g_score_pop == 3 && D == 64 && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1) {
         lps = 2;
         const size_t lds = (size_t)SC_TI * (64 + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
-#define SR_LAUNCH(KRV, KTV) hipLaunchKernelGGL((score_kernel_reg<64, KRV, KTV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, g_score_dbg)
+        unsigned* gthr = g_score_share ? (unsigned*)((char*)ws + 2 * half) : (unsigned*)nullptr;
+        if (gthr && hipMemsetAsync(gthr, 0, (size_t)B * 4, s) != hipSuccess) return RE_ELAUNCH;
+#define SR_LAUNCH(KRV, KTV) hipLaunchKernelGGL((score_kernel_reg<64, KRV, KTV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, gthr, g_score_dbg)
         if (K == 50) SR_LAUNCH(50, 50); else if (K <= 16) SR_LAUNCH(16, 0); else if (K <= 32) SR_LAUNCH(32, 0); else SR_LAUNCH(52, 0);
 #undef SR_LAUNCH
         rc = re_launch_status();

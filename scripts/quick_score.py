@@ -13,3 +13,11 @@ def t(fn, it=20):
     for _ in range(it): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_time(e1) / it
 print(f"{t(lambda: ops.score_topk(q, E, sp, si, 50)):.3f} ms")
+import ctypes
+from recboard_amd import lib
+L = lib.load()
+if hasattr(L, "re_dbg_score_share"):
+    L.re_dbg_score_share.argtypes = [ctypes.c_int]; L.re_dbg_score_share.restype = None
+    for on in (0, 1):
+        L.re_dbg_score_share(on)
+        print(f"shared bounds {on}: {t(lambda: ops.score_topk(q, E, sp, si, 50)):.3f} ms")

@@ -1,0 +1,21 @@
+"""ISA lint of the compiled gfx950 kernels: every read of an MFMA result is far enough behind the MFMA on every path.
+
+hipcc inserts these wait states itself; one source layout of the score kernel made it emit 9 of the 18 on the taken side of a
+branch ("a compiler hazard"), which showed up as rare, non-deterministic top-K mismatches on the GPU.  The lint
+runs on the CPU (cross-compile to assembly, no GPU needed).
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_mfma_result_reads_wait_long_enough():
+    files = [os.path.join(ROOT, "recboard_amd", "csrc", f) for f in ("score.hip", "sasrec_fwd.hip", "sasrec_bwd.hip", "gemm.hip")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_mfma_hazard.py")] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "findings: 0" in r.stdout
+    for f in files:                                  # the lint saw the MFMA kernels it is meant to check
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith(os.path.basename(f))][0]
+        assert int(line.split()[1]) > 0, line
