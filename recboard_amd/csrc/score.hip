@@ -289,6 +289,18 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const float* __restrict__
 // what the insertion cost is made of.  (Tried and dropped: value-only lists with the (value, item) pairs logged to global
 // memory -- the end-of-segment selection over the log is latency bound.)
 #define SR_QC 28
+#define SR_VOTE 14  // a workgroup drain is called when some queue holds more than this at the top of a stage
+// Filter + append of ONE score in 4 vector instructions: the score and its item id are written to the lane's queue tail
+// unconditionally (one ds_write2st64), the tail advances by the compare bit (v_cmp -> v_addc carry-in); the running item id
+// moves on to the next accumulator register in the two wait states a VALU-written VCC needs before a VALU reads it as carry.
+// Operands: %0 qn, %1 qaddr, %2 id; %3 thr, %4 qbase, then the accumulator registers.  KM: optional "vcc &= ~kill mask".
+#define SR_APPEND1(ACC, KM, DELTA)                                  \
+    "v_cmp_ge_f32 vcc, " ACC ", %3\n"                               \
+    KM                                                              \
+    "ds_write2st64_b32 %1, " ACC ", %2 offset0:0 offset1:%c[qoff]\n" \
+    "v_add_u32 %2, " #DELTA ", %2\n"                                \
+    "v_addc_co_u32 %0, vcc, 0, %0, vcc\n"                           \
+    "v_lshl_add_u32 %1, %0, 8, %4\n"
 #define SR_TAGBITS 29
 // raw v_min_f64 / v_max_f64: through fmin / fmax the compiler re-canonicalises every loop-carried list element
 // (one extra v_max_f64 v, v, v per slot per insertion); keys are never NaN
@@ -336,6 +348,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
     const int c = lane & 31, h = lane >> 5;
     const int ul = wid * 32 + c;
     const int NONE = 0x7FFFFFFF;
+    const int vote_at = (dbg >> 8) ? (dbg >> 8) - 1 : SR_VOTE;   // (tuning override in the upper bits of dbg)
+    dbg &= 0xFF;
     float* myqv = qv + wid * SR_QC * 64 + lane;
     int* myqi = qi + wid * SR_QC * 64 + lane;
     const unsigned long long TAGMASK = (1ull << SR_TAGBITS) - 1ull;
@@ -386,7 +400,12 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         for (int j = 0; j < KR; ++j) lk[j] = KEMPTY;
         float thr = (user < B && dbg != 1 && (dbg < 5 || dbg == 8)) ? -INFINITY : INFINITY;
         float gbound = -INFINITY;   // the shared bound as last read
+        unsigned genc = 0u;         // ... and the word in flight
         int qn = 0;
+        // LDS byte address of the queue tail (= qbase + 256 * qn) and the running item id of the next accumulator register
+        const unsigned qbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)myqv;
+        unsigned qaddr = qbase;
+        int qid = (int)(st0 * SC_TI) + 4 * h;
         int64_t sc_cur = 0, sc_end = 0;
         int ns0 = NONE, ns1 = NONE;
         if (seen_ptr && user < B) {
@@ -420,8 +439,9 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
             }
 #pragma unroll 1
             for (int e = 0; e < rounds; ++e) {   // ONE copy of the insertion code: the kernel must stay inside the I-cache
-                const bool act = e < qn;
-                const double k = act ? make_key(myqv[e * 64], myqi[e * 64]) : KEMPTY;
+                const int qid_e = myqi[e * 64];
+                const bool act = e < qn && qid_e >= 0;   // (a negative id: an entry voided after the fact, see kill_more)
+                const double k = act ? make_key(myqv[e * 64], qid_e) : KEMPTY;
                 // sorted insertion, best first: slot j takes k clamped into [lk[j], lk[j-1]]
 #pragma unroll
                 for (int j = KR - 1; j >= 1; --j) lk[j] = sr_max(lk[j], sr_min(k, lk[j - 1]));
@@ -473,8 +493,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         // Drains are WORKGROUP-wide where possible: the four waves share the stage barriers, so a wave draining alone stalls
         // the other three at the next barrier (measured: drain time x ~3).  The vote rides on the stage's first barrier (each
         // wave leaves a flag in LDS before it, everybody reads the four flags after it): a drain is called when some queue
-        // is more than two thirds full (fuller queues: fewer rounds lost to the longest lane).  A queue that would still overflow inside a stage (only while the lists fill up, at the
-        // start of a segment) is drained by its wave on the spot.
+        // holds more than SR_VOTE entries, which keeps SR_QC - 8 out of reach for the four half tiles of the stage; a wave whose
+        // queues get there anyway (while the lists fill up at the start of a segment) drains on the spot at the top of a half tile.
 #ifdef SC_PROFILE   // cycle accounting of one wave (make CXXFLAGS+=-DSC_PROFILE; scripts/tune_score.py), written out once at the end
         const bool prof = dbg >= 8 && blockIdx.x == 7 && wid == 0;
         long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, t0 = 0, t1 = 0;
@@ -485,8 +505,10 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         for (int64_t st = st0; st < st1; ++st) {
             SC_T(if (prof) t0 = __builtin_readcyclecounter();)
             if (lane == 0) vote[wid] = 0;
-            if (qn > (SR_QC * 2) / 3) vote[wid] = 1;
+            if (qn > vote_at) vote[wid] = 1;
+#ifndef SC_X_NOBARRIER
             __syncthreads();
+#endif
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); ta += t1 - t0; t0 = t1; })
             const bool wg_drain = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
 #pragma unroll
@@ -498,78 +520,155 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);
                 *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
             }
-            if (wg_drain) drain();
+            if (wg_drain) {
+                drain();
+                qaddr = qbase;
+            }
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); tb += t1 - t0; t0 = t1; })
+#ifndef SC_X_NOBARRIER
             __syncthreads();
+#endif
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); tc += t1 - t0; t0 = t1; })
+#ifndef SC_X_NOREFILL
             refill();
-            unsigned genc = 0u;          // (requested before the item prefetch, like the seen window: its wait leaves the prefetch in flight)
-            if (gthr && user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            // the shared bound: fold in the word requested one stage ago (no wait), request the next one -- before the item
+            // prefetch, like the seen window, so that its wait leaves the prefetch in flight
+            if (gthr) {
+                gbound = fmaxf(gbound, sr_dec(genc));
+                thr = fmaxf(thr, gbound);
+                if (user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#ifndef SC_X_NOPREFETCH
             prefetch(st + 1 < st1 ? st + 1 : st);
+#endif
+            // The tile loop, in HALF tiles (16 items = accumulator registers 0-7 / 8-15): one queue-room check -- and the only
+            // in-loop copy of the drain code -- serves both halves; the MFMA chain runs in the even iterations.
+            f32x16 acc;
 #pragma unroll 1
-            for (int it = 0; it < SC_TI / 32; ++it) {
-                const int64_t item0 = st * SC_TI + it * 32;
+            for (int ht = 0; ht < 2 * (SC_TI / 32); ++ht) {
+                const int64_t item0 = st * SC_TI + (ht >> 1) * 32;   // first item of the tile
                 if (item0 >= N) break;
-                f32x16 acc;
-                unsigned m = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                const float* arow = tile + (it * 32 + c) * RSF + h * KH;
-#pragma unroll
-                for (int q = 0; q < KH / 4; ++q) {
-                    const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * q + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
-                }
-                SC_T(if (prof) { asm volatile("s_nop 0" :: "v"(acc[0])); t1 = __builtin_readcyclecounter(); td += t1 - t0; t0 = t1; })
-                if (gthr && it == 0) {   // fold in the shared bound read at the top of this stage
-                    gbound = fmaxf(gbound, sr_dec(genc));
-                    thr = fmaxf(thr, gbound);
-                }
-                // threshold filter, 2 vector ops per score and no compare-mask hazards: the sign bit of (score - thr) -- set for
-                // score < thr -- is shifted into a mask with v_alignbit; hits are the complement: score >= thr.  ">=" and not ">"
-                // because thr may come from OTHER items (the partner lane, other workgroups): an item that ties the bound with
-                // a lower id can still belong to the top K.  The f64 keys order whatever gets through.  (Neither a score -- an fmaf chain
-                // started at +0 -- nor a bound is ever -0, so equal zeros compare as equal here.)
-#pragma unroll
-                for (int r = 15; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r] - thr), 31);
-                m = ~m & 0xFFFFu;
-                // seen-mask: clear the bits of this user's seen ids inside this tile (cursor with two ids prefetched)
-                while (ns0 < (int)item0 + 32) {
-                    if (ns0 == NEED) {   // window used up inside this stage: reload and wait here, inside the rare branch
-                        refill();
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        asm volatile("" : "+v"(ns0), "+v"(ns1));
-                        continue;
-                    }
-                    const int d = ns0 - (int)item0;
-                    if (d >= 0 && ((d >> 2) & 1) == h) m &= ~(1u << ((d & 3) + 4 * (d >> 3)));
-                    ++sc_cur;
-                    ns0 = ns1;
-                    ns1 = NEED;
-                }
-                if (item0 + 32 > N) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if ((int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) m &= ~(1u << r);
-                }
-                if (__ballot(qn + (int)__popc(m) > SR_QC) != 0ull) {   // this wave's queues cannot take the tile's hits
+                // a half tile appends up to 8 entries per lane: make room now (while the lists fill up, or after a burst)
+                if (__ballot(qn > SR_QC - 8) != 0ull) {
                     drain();
-                    unsigned m2 = 0;
-#pragma unroll
-                    for (int r = 15; r >= 0; --r) m2 = __builtin_amdgcn_alignbit(m2, __float_as_uint(acc[r] - thr), 31);
-                    m &= ~m2;
+                    qaddr = qbase;
                 }
+                const int hend = (int)item0 + 16 + 16 * (ht & 1);    // end of this half's item range
+                const bool plain = __ballot(ns0 < hend) == 0ull && (int64_t)hend <= N;
+                // Filter + append.  fp32 MFMA and vector instructions share one pipe on gfx950 (scripts/micro/mfma_valu_samewave.hip:
+                // every vector instruction costs its ~5-6 cycles on top of the MFMA chain, from the same wave or another), so the
+                // vector instruction count per score IS the kernel's efficiency: 4 here (SR_APPEND1), no hit mask, no exec juggling.
+                // ">=" and not ">": thr may come from OTHER items (the partner lane, other workgroups), and an item that ties
+                // the bound with a lower id can still belong to the top K; the f64 keys order whatever gets through.  (Neither a
+                // score -- an fmaf chain started at +0 -- nor a bound is ever -0.)  What must never get through -- the user's seen
+                // items, rows past the end of the catalog -- is rare: such a half tile runs the same sequence with one scalar
+                // "hits &= ~kill[r]" per register, the kill masks built by 8 compares on the lane's (at most one per pass)
+                // killed register.
+#define SR_KM(N) "s_andn2_b64 vcc, vcc, %" #N "\n"
+#define SR_HALF_PLAIN(PRE, A0, A1, A2, A3, A4, A5, A6, A7)                                                                       \
+    asm volatile(PRE SR_APPEND1("%5", "", 1) SR_APPEND1("%6", "", 1) SR_APPEND1("%7", "", 1) SR_APPEND1("%8", "", 5)              \
+                     SR_APPEND1("%9", "", 1) SR_APPEND1("%10", "", 1) SR_APPEND1("%11", "", 1) SR_APPEND1("%12", "", 5)           \
+                 : "+v"(qn), "+v"(qaddr), "+v"(qid)                                                                             \
+                 : "v"(thr), "v"(qbase), "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(A4), "v"(A5), "v"(A6), "v"(A7),                 \
+                   [qoff] "i"(4 * SR_QC)                                                                                        \
+                 : "vcc", "memory")
+#define SR_HALF_KILL(PRE, A0, A1, A2, A3, A4, A5, A6, A7)                                                                        \
+    asm volatile(PRE SR_APPEND1("%5", SR_KM(13), 1) SR_APPEND1("%6", SR_KM(14), 1) SR_APPEND1("%7", SR_KM(15), 1)                 \
+                     SR_APPEND1("%8", SR_KM(16), 5) SR_APPEND1("%9", SR_KM(17), 1) SR_APPEND1("%10", SR_KM(18), 1)                \
+                     SR_APPEND1("%11", SR_KM(19), 1) SR_APPEND1("%12", SR_KM(20), 5)                                            \
+                 : "+v"(qn), "+v"(qaddr), "+v"(qid)                                                                             \
+                 : "v"(thr), "v"(qbase), "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(A4), "v"(A5), "v"(A6), "v"(A7), "s"(km[0]),     \
+                   "s"(km[1]), "s"(km[2]), "s"(km[3]), "s"(km[4]), "s"(km[5]), "s"(km[6]), "s"(km[7]), [qoff] "i"(4 * SR_QC)     \
+                 : "vcc", "memory")
+                // kill masks of this half: seen cursor (two ids prefetched; one id per lane per pass) + catalog end
+                unsigned long long km[8];
+                auto kill_pass = [&]() -> int {   // consume one pending id of this half per lane; -> the register it kills, or -1
+                    int kill = -1;
+                    if (ns0 < hend) {
+                        if (ns0 == NEED) {   // window used up inside this stage: reload and wait here, inside the rare branch
+                            refill();
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            asm volatile("" : "+v"(ns0), "+v"(ns1));
+                        } else {
+                            const int d = ns0 - (hend - 16);   // 0..15 inside this half (< 0: an id before it, skipped)
+                            if (d >= 0 && ((d >> 2) & 1) == h) kill = (d & 3) + 4 * (d >> 3);
+                            ++sc_cur;
+                            ns0 = ns1;
+                            ns1 = NEED;
+                        }
+                    }
+                    return kill;
+                };
+                int qn0 = 0;
+                auto kill_masks = [&]() {
+                    const int k0 = kill_pass();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if ((m >> r) & 1u) {
-                        myqv[qn * 64] = acc[r];
-                        myqi[qn * 64] = (int)item0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        ++qn;
+                    for (int r = 0; r < 8; ++r) km[r] = __builtin_amdgcn_ballot_w64(k0 == r);
+                    if ((int64_t)hend > N) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) km[r] |= __builtin_amdgcn_ballot_w64(qid + (r & 3) + 8 * (r >> 2) >= (int)N);
+                    }
+                    qn0 = qn;
+                };
+                // A second (third ...) seen id of some user inside the same 16 items -- rare: void the entry after the fact (the
+                // drain skips entries whose id is negative) instead of carrying kill masks around a loop.
+                auto kill_more = [&]() {
+                    while (__ballot(ns0 < hend) != 0ull) {
+                        const int k1 = kill_pass();
+                        if (k1 >= 0) {
+                            const int kid = hend - 16 + 4 * h + (k1 & 3) + 8 * (k1 >> 2);
+                            for (int e = qn0; e < qn; ++e)
+                                if (myqi[e * 64] == kid) myqi[e * 64] = -1;
+                        }
+                    }
+                };
+                if ((ht & 1) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    const float* arow = tile + ((ht >> 1) * 32 + c) * RSF + h * KH;
+#ifndef SC_X_NOMFMA
+#pragma unroll
+                    for (int q = 0; q < KH / 4; ++q) {
+#ifdef SC_X_NOAFRAG
+                        float4 a = make_float4(bq[0], bq[1], bq[2], bq[3]); asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+#else
+                        const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+#endif
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * q + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
+                    }
+#endif
+                    SC_T(if (prof) { asm volatile("s_nop 0" :: "v"(acc[0])); t1 = __builtin_readcyclecounter(); td += t1 - t0; t0 = t1; })
+                    // (s_nop: the 18 wait states an fp32 32x32 MFMA result needs before a vector read -- the compiler cannot
+                    // see into the asm; scripts/lint_mfma_hazard.py checks the final ISA)
+#ifdef SC_X_NOAPPEND
+                    if (plain) { asm volatile("" :: "v"(acc)); } else
+#endif
+                    if (plain) {
+                        SR_HALF_PLAIN("s_nop 15\n s_nop 1\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+                    } else {
+                        kill_masks();
+                        SR_HALF_KILL("s_nop 15\n s_nop 1\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+                        kill_more();
+                    }
+                } else {
+#ifdef SC_X_NOAPPEND
+                    if (plain) { asm volatile("" :: "v"(acc)); } else
+#endif
+                    if (plain) {
+                        SR_HALF_PLAIN("", acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
+                    } else {
+                        kill_masks();
+                        SR_HALF_KILL("", acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
+                        kill_more();
                     }
                 }
+#undef SR_HALF_PLAIN
+#undef SR_HALF_KILL
+#undef SR_KM
                 SC_T(if (prof) { t1 = __builtin_readcyclecounter(); te += t1 - t0; t0 = t1; })
             }
         }
@@ -584,7 +683,11 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         }
 #endif
         drain();
+#ifdef SC_X_NOOUTPUT
+        if (user < B && lk[0] == 12345.0) {
+#else
         if (user < B) {
+#endif
             float* pv = part_vals + ((user * maxseg + seg) * 2 + h) * K;
             int* pi = part_idx + ((user * maxseg + seg) * 2 + h) * K;
 #pragma unroll
@@ -682,7 +785,8 @@ extern "C" void re_dbg_score_maxwgs(int64_t n) { g_score_maxwgs = n > 0 ? n : SC
 static int g_score_share = 1;   // workgroups share per-user bounds through global memory (0: A/B switch, scripts/tune_score.py)
 extern "C" void re_dbg_score_share(int on) { g_score_share = on; }
 static int g_score_dbg = 0;   // diagnostics only (scripts/tune_score.py): 1 = no hits at all, 2 = append but never insert
-extern "C" void re_dbg_score_diag(int mode) { g_score_dbg = mode; }
+extern "C" void re_dbg_score_diag(int mode) { g_score_dbg = (g_score_dbg & ~0xFF) | (mode & 0xFF); }
+extern "C" void re_dbg_score_vote(int at) { g_score_dbg = (g_score_dbg & 0xFF) | ((at >= 0 ? at + 1 : 0) << 8); }
 #ifdef SC_PROFILE
 extern "C" void re_dbg_score_counters_x(unsigned long long* out2) { (void)hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_sr_counters_x), 16); }
 #endif

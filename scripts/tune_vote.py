@@ -1,0 +1,31 @@
+"""A/B of the score kernel's workgroup-drain vote threshold (tuning hook re_dbg_score_vote) + drain statistics."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recboard_amd import ops, lib
+L = lib.load()
+L.re_dbg_score_vote.argtypes = [ctypes.c_int]; L.re_dbg_score_vote.restype = None
+L.re_dbg_score_diag.argtypes = [ctypes.c_int]; L.re_dbg_score_diag.restype = None
+L.re_dbg_score_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.re_dbg_score_counters.restype = None
+U, N, D = 22363, 12101, 64
+g = torch.Generator(device="cuda").manual_seed(1)
+q = torch.randn(U, D, device="cuda", generator=g); E = torch.randn(N, D, device="cuda", generator=g)
+sp = torch.arange(0, U + 1, device="cuda") * 8
+si = torch.sort(torch.randint(0, N, (U, 8), device="cuda", generator=g), 1).values.reshape(-1)
+def t(fn, it=20):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True); e0.record()
+    for _ in range(it): fn()
+    e1.record(); e1.synchronize(); return e0.elapsed_time(e1) / it
+buf = (ctypes.c_ulonglong * 4)()
+for at in [int(a) for a in (sys.argv[1:] or "4 6 8 10 12".split())]:
+    L.re_dbg_score_vote(at)
+    ms = t(lambda: ops.score_topk(q, E, sp, si, 50))
+    L.re_dbg_score_diag(1); ms0 = t(lambda: ops.score_topk(q, E, sp, si, 50))
+    L.re_dbg_score_diag(2); ms2 = t(lambda: ops.score_topk(q, E, sp, si, 50))
+    L.re_dbg_score_diag(3); L.re_dbg_score_counters(buf, 1)
+    ops.score_topk(q, E, sp, si, 50); torch.cuda.synchronize(); L.re_dbg_score_counters(buf, 1)
+    L.re_dbg_score_diag(0)
+    nw = 512 * 4
+    print(f"vote at > {at:2d}: {ms:.3f} ms  (no hits {ms0:.3f}, append-only {ms2:.3f})  drains/wave {buf[0]/nw:.1f}  rounds/wave {buf[1]/nw:.1f}  hits/lane {buf[2]/nw/64:.1f}")
+L.re_dbg_score_vote(-1)
