@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         double lk[KR];
 #pragma unroll
         for (int j = 0; j < KR; ++j) lk[j] = KEMPTY;
-        float thr = (user < B && dbg != 1 && (dbg < 5 || dbg == 8)) ? -INFINITY : INFINITY;
+        float thr = (user < B && dbg != 1 && (dbg < 5 || dbg == 7 || dbg == 8)) ? -INFINITY : INFINITY;
         float gbound = -INFINITY;   // the shared bound as last read
         unsigned genc = 0u;         // ... and the word in flight
         int qn = 0;
@@ -433,14 +433,14 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
             int rounds = (dbg == 2) ? 0 : qn;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o, 64));
-            if (dbg == 3) {
+            if (dbg == 3 || dbg == 7) {
                 if (lane == 0) { atomicAdd(&g_sr_counters[0], 1ull); atomicAdd(&g_sr_counters[1], (unsigned long long)rounds); }
                 atomicAdd(&g_sr_counters[2], (unsigned long long)qn);
             }
 #pragma unroll 1
             for (int e = 0; e < rounds; ++e) {   // ONE copy of the insertion code: the kernel must stay inside the I-cache
                 const int qid_e = myqi[e * 64];
-                const bool act = e < qn && qid_e >= 0;   // (a negative id: an entry voided after the fact, see kill_more)
+                const bool act = e < qn && (unsigned)qid_e < (unsigned)N;   // (not a catalog row: voided, or past the end)
                 const double k = act ? make_key(myqv[e * 64], qid_e) : KEMPTY;
                 // sorted insertion, best first: slot j takes k clamped into [lk[j], lk[j-1]]
 #pragma unroll
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 lk[0] = sr_max(k, lk[0]);
             }
             qn = 0;
-            if (user < B && (dbg == 0 || dbg == 3 || dbg == 4 || dbg == 8)) {
+            if (user < B && (dbg == 0 || dbg == 3 || dbg == 4 || dbg == 7 || dbg == 8)) {
                 // The user's K-th best is at least (a) either lane's K-th best and (b) min(a, b) where a, b are the
                 // two lanes' ceil(K/2)-th bests (K/2 items above a in one half + K/2 above b in the other): (b) is
                 // close to the true K-th value because the halves are statistically alike -> ~40 % fewer hits.
@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                 const float pmid = __shfl_xor(mid, 32, 64), pkth = __shfl_xor(kth, 32, 64);
                 thr = fmaxf(fmaxf(kth, pkth), fminf(mid, pmid));
                 if (thr <= -3.402823466e+38f) thr = -INFINITY;   // lists not full yet
+                if (dbg == 7) thr = -INFINITY;                   // (diagnostic: group bound only)
                 // Every workgroup that scores items for this user holds such a lower bound of the user's K-th best: they share
                 // the best one through a word in global memory (device-scope max on an order-preserving encoding; read back,
                 // possibly stale, at the top of every stage).  Each segment then filters almost as if it had seen the whole
@@ -537,7 +538,9 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
             if (gthr) {
                 gbound = fmaxf(gbound, sr_dec(genc));
                 thr = fmaxf(thr, gbound);
-                if (user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (user < B) {
+                    genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
 #ifndef SC_X_NOPREFETCH
             prefetch(st + 1 < st1 ? st + 1 : st);
@@ -555,71 +558,38 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                     qaddr = qbase;
                 }
                 const int hend = (int)item0 + 16 + 16 * (ht & 1);    // end of this half's item range
-                const bool plain = __ballot(ns0 < hend) == 0ull && (int64_t)hend <= N;
                 // Filter + append.  fp32 MFMA and vector instructions share one pipe on gfx950 (scripts/micro/mfma_valu_samewave.hip:
                 // every vector instruction costs its ~5-6 cycles on top of the MFMA chain, from the same wave or another), so the
                 // vector instruction count per score IS the kernel's efficiency: 4 here (SR_APPEND1), no hit mask, no exec juggling.
                 // ">=" and not ">": thr may come from OTHER items (the partner lane, other workgroups), and an item that ties
                 // the bound with a lower id can still belong to the top K; the f64 keys order whatever gets through.  (Neither a
-                // score -- an fmaf chain started at +0 -- nor a bound is ever -0.)  What must never get through -- the user's seen
-                // items, rows past the end of the catalog -- is rare: such a half tile runs the same sequence with one scalar
-                // "hits &= ~kill[r]" per register, the kill masks built by 8 compares on the lane's (at most one per pass)
-                // killed register.
-#define SR_KM(N) "s_andn2_b64 vcc, vcc, %" #N "\n"
-#define SR_HALF_PLAIN(PRE, A0, A1, A2, A3, A4, A5, A6, A7)                                                                       \
+                // score -- an fmaf chain started at +0 -- nor a bound is ever -0.)  What must never get in -- the user's seen
+                // items, rows past the end of the catalog -- is voided AFTER the fact: a lane whose seen cursor points into
+                // these 16 items looks for that id among the entries it has just appended (usually none or one) and negates it;
+                // the drain skips entries whose id is not a catalog row.
+#define SR_HALF(PRE, A0, A1, A2, A3, A4, A5, A6, A7)                                                                             \
     asm volatile(PRE SR_APPEND1("%5", "", 1) SR_APPEND1("%6", "", 1) SR_APPEND1("%7", "", 1) SR_APPEND1("%8", "", 5)              \
                      SR_APPEND1("%9", "", 1) SR_APPEND1("%10", "", 1) SR_APPEND1("%11", "", 1) SR_APPEND1("%12", "", 5)           \
                  : "+v"(qn), "+v"(qaddr), "+v"(qid)                                                                             \
                  : "v"(thr), "v"(qbase), "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(A4), "v"(A5), "v"(A6), "v"(A7),                 \
                    [qoff] "i"(4 * SR_QC)                                                                                        \
                  : "vcc", "memory")
-#define SR_HALF_KILL(PRE, A0, A1, A2, A3, A4, A5, A6, A7)                                                                        \
-    asm volatile(PRE SR_APPEND1("%5", SR_KM(13), 1) SR_APPEND1("%6", SR_KM(14), 1) SR_APPEND1("%7", SR_KM(15), 1)                 \
-                     SR_APPEND1("%8", SR_KM(16), 5) SR_APPEND1("%9", SR_KM(17), 1) SR_APPEND1("%10", SR_KM(18), 1)                \
-                     SR_APPEND1("%11", SR_KM(19), 1) SR_APPEND1("%12", SR_KM(20), 5)                                            \
-                 : "+v"(qn), "+v"(qaddr), "+v"(qid)                                                                             \
-                 : "v"(thr), "v"(qbase), "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(A4), "v"(A5), "v"(A6), "v"(A7), "s"(km[0]),     \
-                   "s"(km[1]), "s"(km[2]), "s"(km[3]), "s"(km[4]), "s"(km[5]), "s"(km[6]), "s"(km[7]), [qoff] "i"(4 * SR_QC)     \
-                 : "vcc", "memory")
-                // kill masks of this half: seen cursor (two ids prefetched; one id per lane per pass) + catalog end
-                unsigned long long km[8];
-                auto kill_pass = [&]() -> int {   // consume one pending id of this half per lane; -> the register it kills, or -1
-                    int kill = -1;
-                    if (ns0 < hend) {
-                        if (ns0 == NEED) {   // window used up inside this stage: reload and wait here, inside the rare branch
-                            refill();
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            asm volatile("" : "+v"(ns0), "+v"(ns1));
-                        } else {
-                            const int d = ns0 - (hend - 16);   // 0..15 inside this half (< 0: an id before it, skipped)
-                            if (d >= 0 && ((d >> 2) & 1) == h) kill = (d & 3) + 4 * (d >> 3);
-                            ++sc_cur;
-                            ns0 = ns1;
-                            ns1 = NEED;
-                        }
-                    }
-                    return kill;
-                };
-                int qn0 = 0;
-                auto kill_masks = [&]() {
-                    const int k0 = kill_pass();
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) km[r] = __builtin_amdgcn_ballot_w64(k0 == r);
-                    if ((int64_t)hend > N) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) km[r] |= __builtin_amdgcn_ballot_w64(qid + (r & 3) + 8 * (r >> 2) >= (int)N);
-                    }
-                    qn0 = qn;
-                };
-                // A second (third ...) seen id of some user inside the same 16 items -- rare: void the entry after the fact (the
-                // drain skips entries whose id is negative) instead of carrying kill masks around a loop.
-                auto kill_more = [&]() {
+                const int qn0 = qn;
+                auto void_seen = [&]() {   // seen cursor: two ids prefetched per stage, one id per lane per pass
                     while (__ballot(ns0 < hend) != 0ull) {
-                        const int k1 = kill_pass();
-                        if (k1 >= 0) {
-                            const int kid = hend - 16 + 4 * h + (k1 & 3) + 8 * (k1 >> 2);
-                            for (int e = qn0; e < qn; ++e)
-                                if (myqi[e * 64] == kid) myqi[e * 64] = -1;
+                        if (ns0 < hend) {
+                            if (ns0 == NEED) {   // window used up inside this stage: reload and wait here, inside the rare branch
+                                refill();
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                asm volatile("" : "+v"(ns0), "+v"(ns1));
+                            } else {
+                                if (ns0 >= hend - 16 && ((ns0 >> 2) & 1) == h)   // (bit 2 of the item id: which lane of the pair)
+                                    for (int e = qn0; e < qn; ++e)
+                                        if (myqi[e * 64] == ns0) myqi[e * 64] = -1;
+                                ++sc_cur;
+                                ns0 = ns1;
+                                ns1 = NEED;
+                            }
                         }
                     }
                 };
@@ -644,31 +614,16 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                     SC_T(if (prof) { asm volatile("s_nop 0" :: "v"(acc[0])); t1 = __builtin_readcyclecounter(); td += t1 - t0; t0 = t1; })
                     // (s_nop: the 18 wait states an fp32 32x32 MFMA result needs before a vector read -- the compiler cannot
                     // see into the asm; scripts/lint_mfma_hazard.py checks the final ISA)
-#ifdef SC_X_NOAPPEND
-                    if (plain) { asm volatile("" :: "v"(acc)); } else
+#ifndef SC_X_NOAPPEND
+                    SR_HALF("s_nop 15\n s_nop 1\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
 #endif
-                    if (plain) {
-                        SR_HALF_PLAIN("s_nop 15\n s_nop 1\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
-                    } else {
-                        kill_masks();
-                        SR_HALF_KILL("s_nop 15\n s_nop 1\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
-                        kill_more();
-                    }
                 } else {
-#ifdef SC_X_NOAPPEND
-                    if (plain) { asm volatile("" :: "v"(acc)); } else
+#ifndef SC_X_NOAPPEND
+                    SR_HALF("", acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
 #endif
-                    if (plain) {
-                        SR_HALF_PLAIN("", acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
-                    } else {
-                        kill_masks();
-                        SR_HALF_KILL("", acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
-                        kill_more();
-                    }
                 }
-#undef SR_HALF_PLAIN
-#undef SR_HALF_KILL
-#undef SR_KM
+                void_seen();
+#undef SR_HALF
                 SC_T(if (prof) { t1 = __builtin_readcyclecounter(); te += t1 - t0; t0 = t1; })
             }
         }
@@ -683,20 +638,53 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         }
 #endif
         drain();
+        // The two partial lists of every user (K values + K ids per lane).  Written lane by lane this is 2K scattered 4-byte
+        // stores per lane (64 cache lines per store instruction: 11 % of the kernel on the Beauty shape, scripts ablation
+        // SC_X_NOOUTPUT); instead the wave transposes them through its (now empty) queue memory and writes each user's
+        // 2K contiguous floats with 16-byte stores.
 #ifdef SC_X_NOOUTPUT
-        if (user < B && lk[0] == 12345.0) {
+        if (lk[0] == 12345.0) {
 #else
-        if (user < B) {
+        {
 #endif
-            float* pv = part_vals + ((user * maxseg + seg) * 2 + h) * K;
-            int* pi = part_idx + ((user * maxseg + seg) * 2 + h) * K;
+            const int K2 = 2 * K;
+            float* ldsA = qv + wid * SR_QC * 64;                                  // 2 x SR_QC*64 floats of wave-private LDS
+            float* ldsB = reinterpret_cast<float*>(qi + wid * SR_QC * 64);
+            const int64_t user0 = ub * SC_USERS + wid * 32;                        // the wave's first user
+            const int64_t ustride = (int64_t)maxseg * K2;                          // floats between consecutive users
+            const int64_t gbase = (user0 * maxseg + seg) * K2;
+            if ((K & 1) == 0 && 64 * K <= 2 * SR_QC * 64) {
+#pragma unroll 1
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int f0 = c * K2 + h * K;
 #pragma unroll
-            for (int j = 0; j < KR; ++j)
-                if (j < K) {
-                    const bool empty = lk[j] == KEMPTY;
-                    pv[j] = empty ? -INFINITY : key_value(lk[j]);
-                    pi[j] = empty ? -1 : key_item(lk[j]);
+                    for (int j = 0; j < KR; ++j)
+                        if (j < K) {
+                            const bool empty = lk[j] == KEMPTY;
+                            const int f = f0 + j;
+                            float* slot = f < SR_QC * 64 ? ldsA + f : ldsB + (f - SR_QC * 64);
+                            if (pass == 0) *slot = empty ? -INFINITY : key_value(lk[j]);
+                            else *reinterpret_cast<int*>(slot) = empty ? -1 : key_item(lk[j]);
+                        }
+                    float* gdst = (pass == 0 ? part_vals : reinterpret_cast<float*>(part_idx)) + gbase;
+                    for (int i = lane; i < 16 * K; i += 64) {      // 32 users x 2K floats = 16K float4
+                        const int f = 4 * i;
+                        const int cc = f / K2, e = f - cc * K2;
+                        const float* slot = f < SR_QC * 64 ? ldsA + f : ldsB + (f - SR_QC * 64);
+                        if (user0 + cc < B) *reinterpret_cast<float4*>(gdst + cc * ustride + e) = *reinterpret_cast<const float4*>(slot);
+                    }
                 }
+            } else if (user < B) {
+                float* pv = part_vals + ((user * maxseg + seg) * 2 + h) * K;
+                int* pi = part_idx + ((user * maxseg + seg) * 2 + h) * K;
+#pragma unroll
+                for (int j = 0; j < KR; ++j)
+                    if (j < K) {
+                        const bool empty = lk[j] == KEMPTY;
+                        pv[j] = empty ? -INFINITY : key_value(lk[j]);
+                        pi[j] = empty ? -1 : key_item(lk[j]);
+                    }
+            }
         }
         unit += st1 - st0;
         __syncthreads();
