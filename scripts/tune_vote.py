@@ -17,6 +17,15 @@ def t(fn, it=20):
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True); e0.record()
     for _ in range(it): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_time(e1) / it
+if os.environ.get("BENCH_DATA"):   # the bench's trained-like state: LayerNorm-encoded queries, xavier item table
+    import bench, numpy as np
+    from recboard_amd.sasrec import SASRecEngine
+    cfg = bench.BEAUTY
+    model = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5).eval()
+    eval_seq = torch.from_numpy(np.concatenate([b[0] for b in bench.synth_batches(cfg, 44, 99)])[:U]).cuda()
+    with torch.no_grad():
+        q = torch.cat([model.encode(eval_seq[i:i + 512])[0][:, -1, :] for i in range(0, U, 512)]).contiguous()
+    E = model.params["Item.embeddings.weight"].detach()[1:]
 buf = (ctypes.c_ulonglong * 4)()
 for at in [int(a) for a in (sys.argv[1:] or "4 6 8 10 12".split())]:
     L.re_dbg_score_vote(at)
