@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
     ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--prefetch", action="store_true", help="sort the next batch's scatter-add destination rows one step ahead on a second stream (SASRecEngine.prefetch_plan)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,13 +164,20 @@ def main():
 
     use_graph = args.encoder == "fused" and not args.no_graph
     blobs = [model.pack_batch(*b[:3]) for b in batches] if use_graph else None
+    torch.cuda.synchronize()   # (the plan prefetch runs on its own stream and does not wait for this one)
 
     def step_eager(i):
         seq, pos, neg, aux = batches[i % len(batches)]
         return model.train_step(seq, pos, neg, aux, grad_hook=hook)
 
     def step_graph(i):
-        return model.train_step_graph(blobs[i % len(blobs)], cfg["B"], cfg["S"], grad_hook=hook)
+        loss = model.train_step_graph(blobs[i % len(blobs)], cfg["B"], cfg["S"], grad_hook=hook)
+        if args.prefetch:
+            # --prefetch: while step i runs, sort batch i+1's scatter-add rows on a second stream (it depends on the batch
+            # only).  Measured at B=512: 0.2138 vs 0.2086 ms/step -- the two cross-stream event dependencies per step cost
+            # more than the ~20 us of sort they take out of the step (scripts/exp_prefetch.py); off by default.
+            model.prefetch_plan(blobs[(i + 1) % len(blobs)], cfg["B"], cfg["S"])
+        return loss
 
     step = step_eager
     if use_graph:

@@ -25,6 +25,28 @@ static inline unsigned re_grid(int64_t work_items, int64_t per_block, int64_t ca
     return (unsigned)g;
 }
 
+// Zero fill as a KERNEL.  hipMemsetAsync turns into a memset node when the stream is being captured, and a graph with such a
+// node has been seen to go wrong from its second replay on (ROCm 7.2, gfx950: garbage in what the following kernels
+// accumulate into the zeroed buffer); every entry point that may run inside a captured training step zeroes this way.
+// `bytes` must be a multiple of 4 and `p` 4-byte aligned (all callers zero float / 32-bit word arrays).
+static __global__ __launch_bounds__(256) void re_zero_k(uint32_t* __restrict__ p, size_t nwords) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+        uint4* p4 = reinterpret_cast<uint4*>(p);
+        const size_t n4 = nwords >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) p[i] = 0u;
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) p[i] = 0u;
+    }
+}
+static inline hipError_t re_zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    const size_t nwords = bytes >> 2;
+    hipLaunchKernelGGL(re_zero_k, dim3(re_grid((int64_t)((nwords + 3) >> 2), 256)), dim3(256), 0, s, (uint32_t*)p, nwords);
+    return hipGetLastError();
+}
+
 __device__ __forceinline__ float re_softplus(float x) {
     // log(1 + exp(x)), stable: max(x,0) + log1p(exp(-|x|))  (torch.nn.functional.softplus, threshold irrelevant in fp32 here)
     return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));

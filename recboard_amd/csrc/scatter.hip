@@ -596,7 +596,7 @@ static int scatter_sort(const int64_t* idx, int64_t n, int64_t R, int64_t paddin
             t = vi; vi = vo; vo = t;
         }
     } else {
-        if (zfloats > 0 && hipMemsetAsync(zero_fill, 0, (size_t)zfloats * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        if (zfloats > 0 && re_zero_async(zero_fill, (size_t)zfloats * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(scatter_make_keys, dim3(re_grid(n, 256)), dim3(256), 0, s, idx, n, R, padding_idx, w.k0, w.v0);
         for (int p = 0; p < passes; ++p) {
             hipLaunchKernelGGL(radix_hist, dim3((unsigned)w.T), dim3(64), 0, s, ki, n, 8 * p, w.hist, w.T);
@@ -648,7 +648,7 @@ extern "C" int re_scatter_plan(const int64_t* idx, int64_t n, int64_t D, int64_t
     if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        if (zero_floats > 0 && hipMemsetAsync(zero_fill, 0, (size_t)zero_floats * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        if (zero_floats > 0 && re_zero_async(zero_fill, (size_t)zero_floats * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
         return RE_OK;
     }
     if (!idx || !ws) return RE_EINVAL;
@@ -665,13 +665,13 @@ extern "C" int re_scatter_apply(const float* g, int64_t n, int64_t D, int64_t R,
     if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        if (!accumulate && re_zero_async(dW, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
         return RE_OK;
     }
     if (!g || !ws) return RE_EINVAL;
     ScatterWs w = scatter_ws_layout(ws, n, D);
     if (ws_bytes < w.bytes) return RE_EWORKSPACE;
-    if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+    if (!accumulate && re_zero_async(dW, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
     scatter_reduce(g, n, D, R, scale, dW, 1, w, s);
     return re_launch_status();
 }
@@ -684,7 +684,7 @@ extern "C" int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n
     if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        if (!accumulate && hipMemsetAsync(dW, 0, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
+        if (!accumulate && re_zero_async(dW, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
         return RE_OK;
     }
     if (!g || !idx || !ws) return RE_EINVAL;

@@ -877,7 +877,7 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
         lps = 2;
         const size_t lds = (size_t)SC_TI * (64 + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
         unsigned* gthr = g_score_share ? (unsigned*)((char*)ws + 2 * half) : (unsigned*)nullptr;
-        if (gthr && hipMemsetAsync(gthr, 0, (size_t)B * 4, s) != hipSuccess) return RE_ELAUNCH;
+        if (gthr && re_zero_async(gthr, (size_t)B * 4, s) != hipSuccess) return RE_ELAUNCH;
 #define SR_LAUNCH(KRV, KTV) hipLaunchKernelGGL((score_kernel_reg<64, KRV, KTV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, gthr, g_score_dbg)
         if (K == 50) SR_LAUNCH(50, 50); else if (K <= 16) SR_LAUNCH(16, 0); else if (K <= 32) SR_LAUNCH(32, 0); else SR_LAUNCH(52, 0);
 #undef SR_LAUNCH

@@ -274,7 +274,7 @@ class SASRecEngine:
                 ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
         return self._bufs[key]
 
-    def _step_body(self, seq, pos, neg, aux, sd, seed_dev=None):
+    def _step_body(self, seq, pos, neg, aux, sd, seed_dev=None, plan_ws=None):
         """Every launch of the fused step up to (not including) the optimizer; gradients land in the gradient arena."""
         A, P, D = self.arena, self.params, self.D
         B, S = seq.shape
@@ -306,9 +306,15 @@ class SASRecEngine:
         ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
                                      self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],
                                      out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing, seed_dev=seed_dev)
-        # (running the index half -- ops.scatter_plan -- on a second stream underneath the encoder was measured: no gain inside
-        #  a hipGraph, and the extra event traffic slows the eager launch path)
-        ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])
+        # The index half of the scatter-add (the stable sort of the 3*B*S destination rows) depends on the batch only: given a
+        # plan that `prefetch_plan` computed on a second stream during the PREVIOUS step, the step runs the data half alone
+        # (scripts/exp_overlap.py: the plan's four launches cost a concurrent step 1 us instead of 20-25 in line -- but the
+        # events that order the two streams cost more than that at B = 512, see prefetch_plan.  Forking the same launches
+        # inside the captured step gains nothing either: the graph's branches do not run concurrently.)
+        if plan_ws is not None:
+            ops.scatter_apply(C, self.N + 1, GE, plan_ws, 1.0, accumulate=False)
+        else:
+            ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])
         if self.loss_kind == "CE":
             ops.gemm(logits, Uv, transA=True, beta=1.0, out=GE[1:])          # dE[1:] += dlogits^T u[valid]
         return loss
@@ -361,7 +367,7 @@ class SASRecEngine:
             V[k].copy_(t.view(V[k].shape))
         return blob
 
-    def _capture(self, B, S, with_adam):
+    def _capture(self, B, S, with_adam, plan_ws=None):
         A = self.arena
         _, total = self._blob_layout(B, S)
         blob = torch.zeros(total, dtype=torch.uint8, device=self.device)
@@ -372,8 +378,8 @@ class SASRecEngine:
         hyper = state.view(torch.float32)[2:4]
         aux = (V["valid"], V["rows_all"], (V["order"], V["nshort"]), None, V["count"])
 
-        def body():
-            loss = self._step_body(V["seq"], V["pos"], V["neg"], aux, 0, seed_dev=state)
+        def body(plan_ws=plan_ws):
+            loss = self._step_body(V["seq"], V["pos"], V["neg"], aux, 0, seed_dev=state, plan_ws=plan_ws)
             if with_adam:
                 ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
             return loss
@@ -385,7 +391,12 @@ class SASRecEngine:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             ops.step_stage(blob, blob.clone(), state, 0, 1, self.lr, *self.betas)
-            body()
+            if plan_ws is not None:   # (the warm-up must not touch the real plan buffer: a prefetched plan may be waiting in it)
+                tmp_ws = torch.empty_like(plan_ws)
+                ops.scatter_plan(V["rows_all"], self.D, self.N + 1, tmp_ws, padding_idx=0)
+                body(tmp_ws)
+            else:
+                body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -395,20 +406,64 @@ class SASRecEngine:
             t.copy_(k)
         return dict(graph=graph, blob=blob, state=state, loss=loss)
 
+    def plan_stream(self):
+        """The second stream `prefetch_plan` works on (assemble the next batch's blob under it to keep that off the step's stream)."""
+        if not hasattr(self, "_plan_stream"):
+            self._plan_stream = torch.cuda.Stream()
+        return self._plan_stream
+
+    def prefetch_plan(self, blob, B, S, after=None):
+        """OPTIONAL pipelining (off in bench.py and Coach: at B = 512 the two cross-stream event dependencies per step cost
+        more than the ~20 us of sort they hide -- 0.2138 vs 0.2086 ms/step, scripts/exp_prefetch.py; the sort grows with the
+        batch, the event cost does not).  Sort the destination rows of `blob`'s item-gradient scatter-add on a second stream, now, so that the
+        `train_step_graph(blob, ...)` that follows finds the plan ready (call it for batch t+1 right after launching step t:
+        the four sort launches then run underneath step t's encoder kernels, which leave ~40 % of the CUs idle).  Two plans can
+        be in flight; `blob` must stay unchanged until its step has been launched.  The sort does NOT wait for the caller's
+        stream (it would queue up behind the step it is meant to run beside): `blob` has to be complete already, or be
+        assembled on `plan_stream()`, or `after` names the event that marks it complete."""
+        if not hasattr(self, "_plans"):
+            nbytes = lib_load().re_scatter_add_rows_workspace_bytes(3 * B * S, self.D, self.N + 1)
+            self._plans = dict(ws=[torch.empty(int(nbytes), dtype=torch.uint8, device=self.device) for _ in range(2)],
+                               ready=[torch.cuda.Event(), torch.cuda.Event()], free=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False],
+                               slot_of={}, next=0,
+                               stream=self.plan_stream())
+        P = self._plans
+        if lib_load().re_scatter_add_rows_workspace_bytes(3 * B * S, self.D, self.N + 1) > P["ws"][0].numel():
+            return                                         # (a batch larger than the first one: that step sorts in line)
+        k = P["next"]
+        P["next"] = 1 - k
+        for key in [key for key, v in P["slot_of"].items() if v == k]:   # the slot's previous (consumed or abandoned) plan
+            del P["slot_of"][key]
+        with torch.cuda.stream(P["stream"]):
+            if P["used"][k]:
+                P["stream"].wait_event(P["free"][k])       # the step that last read this slot has finished
+            if after is not None:
+                P["stream"].wait_event(after)              # (whatever produced `blob` on another stream)
+            ops.scatter_plan(self._blob_views(blob, B, S)["rows_all"], self.D, self.N + 1, P["ws"][k], padding_idx=0)
+            P["ready"][k].record(P["stream"])
+        P["slot_of"][(blob.data_ptr(), B, S)] = k
+
     def train_step_graph(self, blob, B, S, grad_hook=None):
         """`train_step_fused` on a batch from `pack_batch`, replayed from a captured hipGraph.  Results are identical to the
-        eager fused step.  The returned loss tensor is overwritten by the next call."""
+        eager fused step.  The returned loss tensor is overwritten by the next call.  If `prefetch_plan(blob, B, S)` was called
+        for this batch, the step uses that plan and skips the sort."""
         if self.loss_kind == "CE":
             raise NotImplementedError("graph replay: BCE / BPR only (CE shapes vary with the batch)")
         A = self.arena
-        key = (B, S, grad_hook is None, self.training)
+        slot = self._plans["slot_of"].pop((blob.data_ptr(), B, S), None) if hasattr(self, "_plans") else None
+        key = (B, S, grad_hook is None, self.training, slot)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         if key not in self._graphs:
-            self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
+            self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None, plan_ws=None if slot is None else self._plans["ws"][slot])
         g = self._graphs[key]
+        if slot is not None:
+            torch.cuda.current_stream().wait_event(self._plans["ready"][slot])
         ops.step_stage(g["blob"], blob, g["state"], self._step_seed(), A.step + 1, self.lr, *self.betas)
         g["graph"].replay()
+        if slot is not None:
+            self._plans["free"][slot].record(torch.cuda.current_stream())
+            self._plans["used"][slot] = True
         A.step += 1
         if grad_hook is not None:
             grad_hook(A.grad)
