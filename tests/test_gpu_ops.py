@@ -231,6 +231,53 @@ def test_score_topk_bit_exact_vs_oracle(ops, B, N, D, K):
     np.testing.assert_array_equal(idx.cpu().numpy(), ri)
 
 
+def _seen_clustered(rng, B, N, heavy_every=7):
+    """Seen lists that stress the cursor: runs of consecutive ids (several seen ids inside the same 16 items), a few heavy
+    users (hundreds of ids: the two-id window is used up inside a stage), users with none, ids at both ends of the catalog."""
+    lists = []
+    for b in range(B):
+        if b % 5 == 0:
+            ids = np.zeros(0, np.int64)
+        elif b % heavy_every == 0:
+            ids = rng.choice(N, size=min(N - 1, int(rng.integers(100, 400))), replace=False)
+        else:
+            starts = rng.integers(0, N, rng.integers(1, 4))
+            ids = np.concatenate([np.arange(s0, min(N, s0 + rng.integers(1, 9))) for s0 in starts])
+            ids = np.concatenate([ids, [0, N - 1]]) if b % 3 == 0 else ids
+        lists.append(np.unique(ids).astype(np.int64))
+    ptr = np.zeros(B + 1, np.int64)
+    ptr[1:] = np.cumsum([len(x) for x in lists])
+    return ptr, np.concatenate(lists).astype(np.int64)
+
+
+@pytest.mark.parametrize("B,N,K,ties", [(2100, 1500, 50, False), (2050, 1237, 50, True), (2048, 777, 10, True), (2300, 1000, 32, False),
+                                        (2048, 1111, 51, True), (2200, 901, 52, False), (2048, 65, 50, True)])
+def test_score_topk_register_list_kernel_bit_exact(ops, B, N, K, ties):
+    """The variant that serves B >= ~2000 users (per-lane sorted register lists, shared bounds, after-the-fact voiding of seen
+    ids): exact parity with the oracle on catalogs small enough to check every user -- K = 50 (its own instantiation), the
+    generic K <= 16 / 32 / 52 instantiations, an odd K (scalar output path), catalog sizes that are not multiples of the
+    32-item tile, clustered / heavy seen lists, and integer-valued embeddings that make most scores tie."""
+    from oracle import ranking
+    rng = np.random.default_rng(B + N + K)
+    D = 64
+    if ties:
+        Q = rng.integers(-1, 2, (B, D)).astype(np.float32)
+        E = rng.integers(-1, 2, (N, D)).astype(np.float32)
+    else:
+        Q = rng.standard_normal((B, D)).astype(np.float32)
+        E = rng.standard_normal((N, D)).astype(np.float32)
+    sp, si = _seen_clustered(rng, B, N)
+    vals, idx = ops.score_topk(dev(Q), dev(E), dev(sp), dev(si), K)
+    rv, ri = ranking.score_topk(Q, E, sp, si, K)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    np.testing.assert_array_equal(vals.cpu().numpy(), rv)
+    vals2, idx2 = ops.score_topk(dev(Q), dev(E), dev(sp), dev(si), K)       # and again: no dependence on workgroup timing
+    assert torch.equal(idx, idx2) and torch.equal(vals, vals2)
+    vals, idx = ops.score_topk(dev(Q), dev(E), None, None, K)               # retain_seen
+    rv, ri = ranking.score_topk(Q, E, None, None, K)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+
+
 def test_score_topk_ties_and_masked_fill(ops):
     from oracle import ranking
     D = 64
