@@ -402,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
         float gbound = -INFINITY;   // the shared bound as last read
         unsigned genc = 0u;         // ... and the word in flight
         int qn = 0;
+        bool quiet = false;   // the last half tile had no hit in any lane (wave-uniform)
         // LDS byte address of the queue tail (= qbase + 256 * qn) and the running item id of the next accumulator register
         const unsigned qbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)myqv;
         unsigned qaddr = qbase;
@@ -612,14 +613,43 @@ __global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restri
                     }
 #endif
                     SC_T(if (prof) { asm volatile("s_nop 0" :: "v"(acc[0])); t1 = __builtin_readcyclecounter(); td += t1 - t0; t0 = t1; })
-                    // (s_nop: the 18 wait states an fp32 32x32 MFMA result needs before a vector read -- the compiler cannot
-                    // see into the asm; scripts/lint_mfma_hazard.py checks the final ISA)
+                    // The 18 wait states an fp32 32x32 MFMA result needs before a vector instruction touches it: the compiler
+                    // cannot see into the asm blocks below, so they are spent here, once, on every path (tied to acc so that
+                    // the chain cannot sink below them; scripts/lint_mfma_hazard.py checks the final ISA).
+                    asm volatile("s_nop 15\n s_nop 1" : "+v"(acc));
 #ifndef SC_X_NOAPPEND
-                    SR_HALF("s_nop 15\n s_nop 1\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+                    // Long catalogs: once the bounds are warm, most half tiles hold no hit for any of the wave's 64 lanes.  After a
+                    // half tile without hits the next one is screened first -- a v_max3 tree over its 8 scores and one compare,
+                    // 5 instructions instead of 40 -- and skipped if nothing can pass.  (Beauty-sized catalogs never get quiet.)
+                    bool run = true;
+                    if (quiet) {
+                        float mx;   // (raw v_max3: fmaxf would re-canonicalise every operand)
+                        asm volatile("v_max3_f32 %0, %1, %2, %3\n v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %0, %0, %6, %7\n v_max_f32 %0, %0, %8"
+                                     : "=&v"(mx) : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]));
+                        run = __ballot(mx >= thr) != 0ull;
+                    }
+                    if (run) {
+                        SR_HALF("", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+                        quiet = __ballot(qn != qn0) == 0ull;
+                    } else {
+                        qid += 16;
+                    }
 #endif
                 } else {
 #ifndef SC_X_NOAPPEND
-                    SR_HALF("", acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
+                    bool run = true;
+                    if (quiet) {
+                        float mx;
+                        asm volatile("v_max3_f32 %0, %1, %2, %3\n v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %0, %0, %6, %7\n v_max_f32 %0, %0, %8"
+                                     : "=&v"(mx) : "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15]));
+                        run = __ballot(mx >= thr) != 0ull;
+                    }
+                    if (run) {
+                        SR_HALF("", acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
+                        quiet = __ballot(qn != qn0) == 0ull;
+                    } else {
+                        qid += 16;
+                    }
 #endif
                 }
                 void_seen();
