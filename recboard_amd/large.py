@@ -24,9 +24,29 @@ from . import ops
 from .sasrec import ParamArena, SASRecEngine, param_shapes
 
 
+def counter_normal_rows(rows, D, seed, std, device):
+    """Table rows as a pure function of (seed, global row id, column): N(0, std^2) from a 32-bit counter hash, so that a
+    table initialised shard by shard holds the same values for every GPU count.  `rows` int64 [r]."""
+    M = 0xFFFFFFFF
+    idx = (rows.to(torch.int64).unsqueeze(1) * D + torch.arange(D, device=device, dtype=torch.int64)) & 0xFFFFFFFFFFFF
+
+    def mix(h):   # murmur3's finaliser on the low 32 bits (int64 arithmetic, masked)
+        h = h & M
+        h = h ^ (h >> 16)
+        h = (h * 0x85EBCA6B) & M
+        h = h ^ (h >> 13)
+        h = (h * 0xC2B2AE35) & M
+        return h ^ (h >> 16)
+
+    lo = mix((idx & M) * 0x9E3779B1 + (idx >> 32) * 0x7FEB352D + (seed & M))
+    hi = mix(lo * 0x85EBCA77 + 0x165667B1 + (seed & M))
+    u = ((lo << 21) ^ hi).to(torch.float64) * (1.0 / float(1 << 53)) + (0.5 / float(1 << 53))   # (0, 1), 53 bits
+    return (math.sqrt(2.0) * std * torch.erfinv(2.0 * u - 1.0)).to(torch.float32)
+
+
 class SASRecLargeTableEngine(SASRecEngine):
     def __init__(self, num_items, maxlen=50, embedding_dim=128, num_blocks=2, dropout_rate=0.0, loss="BCE", lr=1e-3,
-                 weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, table_std=0.02):
+                 weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, table_std=0.02, table_init="torch"):
         assert loss in ("BCE", "BPR")
         self.encoder = "aten"
         self._bufs = {}
@@ -42,17 +62,25 @@ class SASRecLargeTableEngine(SASRecEngine):
         self.params = OrderedDict()
         for k in self.arena.shapes:
             self.params[k] = self.arena.view(self.arena.data, k).requires_grad_(True)
+        self.table_std, self.table_init = table_std, table_init
+        self._alloc_table(seed)
+        self.reset_parameters(seed)
+
+    def _alloc_table(self, seed):
         # item table + moments; row 0 = padding.  Filled in place, chunk-wise (no second table-sized temporary).
-        R, D = num_items + 1, embedding_dim
+        R, D = self.N + 1, self.D
         self.E = torch.empty((R, D), dtype=torch.float32, device=self.device)
         g = torch.Generator(device=self.device).manual_seed(seed)
-        step_rows = max(1, (1 << 28) // D)
+        step_rows = max(1, (1 << 24) // D)
         for r0 in range(0, R, step_rows):
-            self.E[r0:r0 + step_rows].normal_(0.0, table_std, generator=g)
+            if self.table_init == "counter":   # values depend on (seed, row, column) only: identical for any sharding
+                rows = torch.arange(r0, min(R, r0 + step_rows), device=self.device)
+                self.E[r0:r0 + step_rows] = counter_normal_rows(rows, D, seed, self.table_std, self.device)
+            else:
+                self.E[r0:r0 + step_rows].normal_(0.0, self.table_std, generator=g)
         self.E[0].zero_()
         self.Em = torch.zeros_like(self.E)
         self.Ev = torch.zeros_like(self.E)
-        self.reset_parameters(seed)
 
     def state_dict(self):
         sd = OrderedDict((k, p.detach().clone()) for k, p in self.params.items())
@@ -170,3 +198,117 @@ class SASRecLargeTableEngine(SASRecEngine):
     def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):
         u, items = self.encode(seq)
         return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K)
+
+
+class SASRecShardedEngine(SASRecLargeTableEngine):
+    """The same model with the item table ROW-SHARDED over the process group (BASELINE config 5 at N GPUs: rank r holds rows
+    r, r+G, r+2G, ... of the 100 M x 128 table and their Adam moments), everything else replicated and data-parallel:
+
+      * forward: ONE all-to-all round trip fetches the 3*B*S rows a local batch touches (sequence items, positives, negatives)
+        into a batch-local table; the embedding front end, the encoder and the criterion run on it unchanged;
+      * backward: the 3*B*S item-gradient contribution rows travel to the owners of their table rows (one all-to-all) and each
+        owner applies one row-sparse Adam update per distinct row of its shard -- no table-sized gradient, no all-reduce of
+        the table; the encoder's dense gradient arena is averaged with one all-reduce (`grad_hook` semantics of bench.py).
+
+    With a process group of size 1 the step is `SASRecLargeTableEngine.train_step` on the same numbers (tests/test_gpu_sasrec.py);
+    the exchange itself is covered under gloo with two ranks (tests/test_sharded_gloo.py).  Table values come from
+    `counter_normal_rows`, so every GPU count trains the same table."""
+
+    def __init__(self, *args, group=None, **kw):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        kw["table_init"] = "counter"
+        super().__init__(*args, **kw)
+
+    def _alloc_table(self, seed):
+        from .sharded import ShardedTable
+        self.table = ShardedTable(self.N + 1, self.D, group=self.group, device=self.device)
+        T = self.table
+        step_rows = max(1, (1 << 24) // self.D)
+        for l0 in range(0, T.local_rows, step_rows):
+            local = torch.arange(l0, min(T.local_rows, l0 + step_rows), device=self.device)
+            T.weight[l0:l0 + step_rows] = counter_normal_rows(T.global_index(local), self.D, seed, self.table_std, self.device)
+        if T.rank == 0:
+            T.weight[0].zero_()                      # global row 0 = padding
+        T.m = torch.zeros_like(T.weight)
+        T.v = torch.zeros_like(T.weight)
+        self.E = None                                # no rank holds the table
+
+    def state_dict(self):
+        raise NotImplementedError("sharded table: save `engine.table.weight` per rank (rows rank::world)")
+
+    def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
+        import torch.distributed as dist
+        A, D = self.arena, self.D
+        B, S = seq.shape
+        n = B * S
+        if aux is None:
+            aux = self.batch_aux_fused(seq, pos, neg)
+        valid, rows_all, _, _, count = aux
+        sd = self._step_seed()
+        p = self.p_drop if self.training else 0.0
+        Ppos = self.params["Position.weight"]
+        # the batch-local table: row 0 = padding, row 1 + j = table row rows_all[j]  (one all-to-all round trip)
+        rows, route = self.table.lookup(rows_all)
+        T = torch.cat([torch.zeros((1, D), dtype=torch.float32, device=self.device), rows], 0)
+        ar = torch.arange(1, n + 1, device=self.device)
+        seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
+        x0 = ops.sasrec_embed(T, Ppos.detach(), seq_l, float(D ** 0.5), p, sd).requires_grad_(True)
+        A.grad.zero_()
+        for k, q in self.params.items():
+            q.grad = A.view(A.grad, k)
+        u = self._blocks(x0, (seq == 0).unsqueeze(-1))
+        kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
+        C = torch.empty((3 * n, D), dtype=torch.float32, device=self.device)
+        # positives / negatives are rows n+1.. and 2n+1.. of the batch-local table (pair_loss adds e_off = 1 to the 0-based ids)
+        loss, dU, _, _ = ops.pair_loss_fwd_bwd(u.detach().reshape(n, D), T, ar - 1 + n, ar - 1 + 2 * n, valid, kind, count, e_off=1,
+                                              out=(torch.empty((n, D), device=self.device), C[n:2 * n], C[2 * n:]))
+        u.backward(dU.view(B, S, D))
+        C[:n].copy_(x0.grad.reshape(n, D))
+        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq_l, float(D ** 0.5), p, sd, A.view(A.grad, "Position.weight"))
+        if self.world > 1:
+            C.mul_(1.0 / self.world)                 # the loss of the global batch is the mean of the ranks' losses
+            dist.all_reduce(A.grad, op=dist.ReduceOp.AVG, group=self.group)
+        if grad_hook is not None:
+            grad_hook(A.grad)
+        A.step += 1
+        # contribution rows of pad / invalid positions are zero rows addressed to global row 0 (rank 0 drops them)
+        self.table.backward_sparse_adam(C, route, A.step, self.lr, self.betas, 1e-8, self.wd, padding_global_row=0)
+        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        return loss.squeeze(0)
+
+    def train_step_graph(self, *a, **k):
+        raise NotImplementedError("the exchange's split sizes are host-side: the sharded step runs eagerly")
+
+    def encode(self, seq):
+        with torch.no_grad():
+            B, S = seq.shape
+            rows, _ = self.table.lookup(seq.reshape(-1))
+            T = torch.cat([torch.zeros((1, self.D), dtype=torch.float32, device=self.device), rows], 0)
+            ar = torch.arange(1, B * S + 1, device=self.device)
+            seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
+            x0 = ops.sasrec_embed(T, self.params["Position.weight"].detach(), seq_l, float(self.D ** 0.5),
+                                  self.p_drop if self.training else 0.0, self._step_seed())
+            return self._blocks(x0, (seq == 0).unsqueeze(-1)), None
+
+    def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):
+        """Sharded full-catalog top-K (ShardedTable.score_topk): ids are ITEM ids (table row - 1); the padding row never wins."""
+        u, _ = self.encode(seq)
+        q = u[:, -1, :].contiguous()
+        # the table's row 0 is the padding row: mask it as "seen" for every query, and shift the user's seen item ids by one
+        b = q.shape[0]
+        if seen_ptr is None:
+            sp = torch.arange(0, b + 1, device=self.device, dtype=torch.int64)
+            si = torch.zeros(b, dtype=torch.int64, device=self.device)
+        else:
+            cnt = seen_ptr[1:] - seen_ptr[:-1] + 1
+            sp = torch.zeros(b + 1, dtype=torch.int64, device=self.device)
+            sp[1:] = torch.cumsum(cnt, 0)
+            si = torch.empty(int(sp[-1]), dtype=torch.int64, device=self.device)
+            si[sp[:-1]] = 0
+            body = torch.ones(int(sp[-1]), dtype=torch.bool, device=self.device)
+            body[sp[:-1]] = False
+            si[body] = seen_idx + 1
+        vals, idx = self.table.score_topk(q, sp, si, K)
+        return vals, torch.where(idx >= 0, idx - 1, idx)

@@ -30,9 +30,9 @@ class EngineLocalOps:
         from . import ops
         return ops.score_topk(Q, E, seen_ptr, seen_idx, K)
 
-    def sparse_adam(self, g, idx, W, m, v, step, lr, b1, b2, eps, wd):
+    def sparse_adam(self, g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=-1):
         from . import ops
-        ops.sparse_adam_rows(g, idx, W, m, v, step, lr, b1, b2, eps, wd)
+        ops.sparse_adam_rows(g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=padding_idx)
 
 
 class Route:
@@ -98,7 +98,7 @@ class ShardedTable:
         dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
         return self.ops.scatter_add(recv, route.recv_local, self.local_rows)
 
-    def backward_sparse_adam(self, grad_rows, route, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def backward_sparse_adam(self, grad_rows, route, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, padding_global_row=None):
         """Training form for tables whose dense gradient does not fit: gradient rows go to their owners (the same single
         all-to-all as `backward`) and the owner applies ONE row-sparse Adam update per distinct row of its shard (summed
         duplicates, SparseAdam rule; moments `m`, `v` live next to the shard).  No table-sized gradient ever exists."""
@@ -108,7 +108,11 @@ class ShardedTable:
         g = grad_rows.reshape(-1, self.D)[route.order].contiguous()
         recv = torch.empty((sum(route.recv_counts), self.D), dtype=g.dtype, device=g.device)
         dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
-        self.ops.sparse_adam(recv, route.recv_local, self.weight, self.m, self.v, step, lr, betas[0], betas[1], eps, weight_decay)
+        if padding_global_row is not None and self.owner(padding_global_row) == self.rank:   # the padding row is never updated
+            self.ops.sparse_adam(recv, route.recv_local, self.weight, self.m, self.v, step, lr, betas[0], betas[1], eps, weight_decay,
+                                 padding_idx=self.local_index(padding_global_row))
+        else:
+            self.ops.sparse_adam(recv, route.recv_local, self.weight, self.m, self.v, step, lr, betas[0], betas[1], eps, weight_decay)
 
     # ---- full-catalog scoring over the sharded catalog
     def score_topk(self, Q_local, seen_ptr, seen_idx, K):

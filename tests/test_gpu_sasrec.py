@@ -252,3 +252,40 @@ def test_large_table_engine_graph_step_matches_eager_step():
         torch.testing.assert_close(lg, le, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(graph.E, eager.E, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(graph.arena.data, eager.arena.data, rtol=1e-4, atol=1e-6)
+
+
+def test_sharded_engine_on_one_rank_equals_large_table_engine():
+    """SASRecShardedEngine (row-sharded item table, all-to-all lookups, gradient rows sent to their owners) with a process
+    group of ONE rank over RCCL must take exactly the steps of SASRecLargeTableEngine on the same counter-initialised table;
+    the two-rank exchange itself is covered under gloo (test_sharded_gloo.py)."""
+    import socket
+    import torch.distributed as dist
+    from recboard_amd.large import SASRecLargeTableEngine, SASRecShardedEngine
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        N, B, S, D = 900, 10, 50, 128
+        rng = np.random.default_rng(77)
+        kw = dict(dropout_rate=0.0, lr=1e-2, weight_decay=1e-4, seed=6)
+        large = SASRecLargeTableEngine(N, S, D, 2, table_init="counter", **kw)
+        shard = SASRecShardedEngine(N, S, D, 2, **kw)
+        assert torch.equal(large.E, shard.table.weight)
+        for step in range(3):
+            seq = rng.integers(1, N + 1, (B, S))
+            for b in range(B):
+                seq[b, : rng.integers(0, S - 1)] = 0
+            batch = tuple(torch.from_numpy(a).cuda() for a in (seq, rng.integers(0, N, (B, S)), rng.integers(0, N, (B, S))))
+            ll = large.train_step(*batch)
+            ls = shard.train_step(*batch)
+            assert torch.equal(ll, ls), (step, ll, ls)
+            assert torch.equal(large.arena.data, shard.arena.data), step
+            assert torch.equal(large.E, shard.table.weight), step
+            assert torch.equal(large.Em, shard.table.m) and torch.equal(large.Ev, shard.table.v), step
+        seqs = torch.from_numpy(seq).cuda()
+        sp = torch.arange(0, B + 1, device="cuda") * 3
+        si = torch.sort(torch.from_numpy(rng.integers(0, N, (B, 3))).cuda(), 1).values.reshape(-1)
+        v1, i1 = large.recommend_topk(seqs, sp, si, 20)
+        v2, i2 = shard.recommend_topk(seqs, sp, si, 20)
+        assert torch.equal(i1, i2) and torch.equal(v1, v2)
+    finally:
+        dist.destroy_process_group()

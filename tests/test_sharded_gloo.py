@@ -25,9 +25,10 @@ class OracleLocalOps:
                                   None if seen_idx is None else seen_idx.numpy(), K)
         return torch.from_numpy(v), torch.from_numpy(i)
 
-    def sparse_adam(self, g, idx, W, m, v, step, lr, b1, b2, eps, wd):
+    def sparse_adam(self, g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=-1):
         from oracle import adam
-        adam.sparse_adam_rows(W.numpy(), m.numpy(), v.numpy(), idx.numpy(), g.numpy(), step, lr, b1, b2, eps, wd)   # in place (shared memory)
+        keep = idx.numpy() != padding_idx
+        adam.sparse_adam_rows(W.numpy(), m.numpy(), v.numpy(), idx.numpy()[keep], g.numpy()[keep], step, lr, b1, b2, eps, wd)   # in place (shared memory)
 
 
 def _free_port():
@@ -113,3 +114,17 @@ def test_merge_topk_tie_rule():
     i = torch.tensor([[7, 4, -1, 2, 9, 1]])
     mv, mi = merge_topk(v, i, 4)
     assert mi.tolist() == [[2, 7, 9, 1]] and mv.tolist() == [[3.0, 3.0, 2.0, 1.0]]
+
+
+def test_counter_initialised_table_is_the_same_for_every_sharding():
+    """The config-5 table is generated shard by shard from (seed, global row, column): any rank count sees the same values."""
+    from recboard_amd.large import counter_normal_rows
+    R, D, seed = 1003, 16, 5
+    full = counter_normal_rows(torch.arange(R), D, seed, 0.02, "cpu")
+    assert full.shape == (R, D) and torch.isfinite(full).all()
+    assert abs(float(full.std()) - 0.02) < 1e-3 and abs(float(full.mean())) < 1e-3
+    for G in (2, 3, 8):
+        for r in range(G):
+            rows = torch.arange(r, R, G)
+            assert torch.equal(counter_normal_rows(rows, D, seed, 0.02, "cpu"), full[r::G])
+    assert not torch.equal(counter_normal_rows(torch.arange(R), D, seed + 1, 0.02, "cpu"), full)
