@@ -328,7 +328,7 @@ __device__ unsigned long long g_sr_counters_x[2];   // diagnostics (dbg == 3): d
 // KT > 0: K is the compile-time constant KT (= KR): the K-th / (K/2)-th list slots are fixed registers instead of a 2 x KR
 // select chain per drain (the common K = 50 of the evaluation monitors gets its own instantiation)
 template <int D, int KR, int KT>
-__global__ __launch_bounds__(256, 2) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
                                                            int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
                                                            const int64_t* __restrict__ seen_idx, int K,
                                                            float* __restrict__ part_vals, int* __restrict__ part_idx,
@@ -819,7 +819,7 @@ struct ScorePlan {
     int nwg, maxseg;
 };
 
-static ScorePlan score_plan(int64_t B, int64_t N) {
+static ScorePlan score_plan(int64_t B, int64_t N, int64_t D = 64) {
     ScorePlan p;
     p.nub = re_cdiv(B, SC_USERS);
     p.nst = re_cdiv(N, SC_TI);
@@ -828,7 +828,8 @@ static ScorePlan score_plan(int64_t B, int64_t N) {
     // segment: every segment re-warms its users' top-K lists (~K(1+ln(T/K)) heap inserts for T items), so slicing a
     // small catalog over all CUs costs more in warm-ups and list merging than it gains (B=512 x N=12101: 0.58 -> see
     // scripts/tune_score.py).
-    int64_t upw = re_cdiv(p.units, g_score_maxwgs);
+    // (D = 128: the register-list kernel holds a 64-register query fragment and runs one workgroup per CU)
+    int64_t upw = re_cdiv(p.units, D == 128 && g_score_maxwgs == SC_MAX_WGS ? SC_MAX_WGS / 2 : g_score_maxwgs);
     const int64_t min_seg = p.nst < g_score_minseg ? p.nst : g_score_minseg;
     if (upw < min_seg) upw = min_seg;
     p.upw = upw;
@@ -844,9 +845,8 @@ static size_t score_lds_bytes(int D, int K, bool topk) {
 }
 
 extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K) {
-    (void)D;
     if (B <= 0 || N <= 0 || K <= 0) return 256;
-    ScorePlan p = score_plan(B, N);
+    ScorePlan p = score_plan(B, N, D);
     return re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4) * 2      // up to 2 lists per (user, segment)
            + re_align((size_t)B * 4) + 256;                                     // shared per-user bounds
 }
@@ -896,20 +896,30 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
     if (seen_ptr && !seen_idx) return RE_EINVAL;
     if (ws_bytes < re_score_topk_workspace_bytes(B, N, D, K)) return RE_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    ScorePlan p = score_plan(B, N);
+    ScorePlan p = score_plan(B, N, D);
     const size_t half = re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4);
     float* pv = (float*)ws;
     int* pi = (int*)((char*)ws + half);
     int rc, lps = 1;
     // register-list variant: many users per launch (its two lists per segment double the merge work, which dominates
     // when B is small -- A/B in scripts/tune_score.py)
-    if (g_score_pop == 3 && D == 64 && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1) {
+    if (g_score_pop == 3 && (D == 64 || D == 128) && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1) {
         lps = 2;
-        const size_t lds = (size_t)SC_TI * (64 + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
+        const size_t lds = (size_t)SC_TI * (D + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
         unsigned* gthr = g_score_share ? (unsigned*)((char*)ws + 2 * half) : (unsigned*)nullptr;
         if (gthr && re_zero_async(gthr, (size_t)B * 4, s) != hipSuccess) return RE_ELAUNCH;
-#define SR_LAUNCH(KRV, KTV) hipLaunchKernelGGL((score_kernel_reg<64, KRV, KTV>), dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub, p.nst, p.upw, gthr, g_score_dbg)
-        if (K == 50) SR_LAUNCH(50, 50); else if (K <= 16) SR_LAUNCH(16, 0); else if (K <= 32) SR_LAUNCH(32, 0); else SR_LAUNCH(52, 0);
+#define SR_LAUNCH(DV, KRV, KTV)                                                                                                      \
+    do {                                                                                                                             \
+        auto kern = score_kernel_reg<DV, KRV, KTV>;                                                                                  \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RE_ELAUNCH; \
+        hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub,    \
+                           p.nst, p.upw, gthr, g_score_dbg);                                                                         \
+    } while (0)
+        if (D == 64) {
+            if (K == 50) SR_LAUNCH(64, 50, 50); else if (K <= 16) SR_LAUNCH(64, 16, 0); else if (K <= 32) SR_LAUNCH(64, 32, 0); else SR_LAUNCH(64, 52, 0);
+        } else {   // D = 128 (config 5): one workgroup per CU, 512-register budget
+            if (K == 50) SR_LAUNCH(128, 50, 50); else SR_LAUNCH(128, 52, 0);
+        }
 #undef SR_LAUNCH
         rc = re_launch_status();
     } else {

@@ -250,16 +250,17 @@ def _seen_clustered(rng, B, N, heavy_every=7):
     return ptr, np.concatenate(lists).astype(np.int64)
 
 
-@pytest.mark.parametrize("B,N,K,ties", [(2100, 1500, 50, False), (2050, 1237, 50, True), (2048, 777, 10, True), (2300, 1000, 32, False),
-                                        (2048, 1111, 51, True), (2200, 901, 52, False), (2048, 65, 50, True)])
-def test_score_topk_register_list_kernel_bit_exact(ops, B, N, K, ties):
+@pytest.mark.parametrize("B,N,K,ties,D", [(2100, 1500, 50, False, 64), (2050, 1237, 50, True, 64), (2048, 777, 10, True, 64),
+                                          (2300, 1000, 32, False, 64), (2048, 1111, 51, True, 64), (2200, 901, 52, False, 64),
+                                          (2048, 65, 50, True, 64), (2100, 1300, 50, False, 128), (2048, 999, 50, True, 128),
+                                          (2060, 700, 20, False, 128)])
+def test_score_topk_register_list_kernel_bit_exact(ops, B, N, K, ties, D):
     """The variant that serves B >= ~2000 users (per-lane sorted register lists, shared bounds, after-the-fact voiding of seen
     ids): exact parity with the oracle on catalogs small enough to check every user -- K = 50 (its own instantiation), the
-    generic K <= 16 / 32 / 52 instantiations, an odd K (scalar output path), catalog sizes that are not multiples of the
+    generic K <= 16 / 32 / 52 instantiations, D = 128 (one workgroup per CU), an odd K (scalar output path), catalog sizes that are not multiples of the
     32-item tile, clustered / heavy seen lists, and integer-valued embeddings that make most scores tie."""
     from oracle import ranking
     rng = np.random.default_rng(B + N + K)
-    D = 64
     if ties:
         Q = rng.integers(-1, 2, (B, D)).astype(np.float32)
         E = rng.integers(-1, 2, (N, D)).astype(np.float32)
