@@ -161,14 +161,28 @@ int re_bpr_triplet_fwd_bwd(const float* Ut, int64_t RU, const float* It, int64_t
  *   remaining slots get (-inf, -1).  seen_ptr[B+1]/seen_idx[nnz] is a CSR of int64 item ids, ASCENDING inside
  *   every user's range (duplicates allowed);
  *   seen_ptr == NULL means retain_seen.
- * Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32), i.e. a k-ordered fmaf chain per score -- exact fp32.
- * D must be a multiple of 8 and <= 256; K <= RE_TOPK_MAX. */
+ * Arithmetic: every returned value is the k-ordered fp32 chain acc = fmaf(q[k], e[k], acc) -- exact fp32, and the indices are
+ *   the exact top K under (value, lowest index).  For D = 64 / 128 and K <= 50 the catalog is first screened with bf16 hi/mid
+ *   split products on the XDL matrix pipe (v_mfma_f32_32x32x16_bf16, 3 products per 16 k), the K + 6 best candidates of every
+ *   user are re-scored exactly and the result is certified against a rigorous error bound; users that cannot be certified
+ *   are redone by the exact fp32-MFMA kernel (v_mfma_f32_32x32x2_f32) in the same call.  Same results either way.
+ * D must be a multiple of 8 and <= 256; K <= RE_TOPK_MAX.
+ * re_score_prepare / re_score_topk_prepared: the item table's split planes are built once (prep buffer of
+ *   re_score_prepare_bytes(N, D) bytes, D = 64 or 128) and reused by any number of scoring calls against the same table --
+ *   Coach.evaluate scores every user batch of a split against one table (UniSRec/main.py:400-447).  E must be the same
+ *   table the planes were made from (it is read for the exact re-scoring). */
 int re_score_dense(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, float* out,
                    re_stream_t stream);
 size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K);
 int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t D,
                   const int64_t* seen_ptr, const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx,
                   void* ws, size_t ws_bytes, re_stream_t stream);
+size_t re_score_prepare_bytes(int64_t N, int64_t D);
+int re_score_prepare(const float* E, int64_t N, int64_t D, void* prep, size_t prep_bytes, re_stream_t stream);
+size_t re_score_topk_prepared_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K);
+int re_score_topk_prepared(const float* Q, const float* E, const void* prep, int64_t B, int64_t N, int64_t D,
+                           const int64_t* seen_ptr, const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx,
+                           void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K6/K7  fused SASRec encoder (D = 64, S <= 64, L <= 4, 1 head): one workgroup per sequence, activations in LDS.

@@ -28,6 +28,7 @@
 #include "re_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define SC_USERS 128   // users per workgroup (4 waves x 32)
 #define SC_TI 64       // items per LDS stage (2 MFMA tiles)
@@ -327,15 +328,25 @@ __device__ unsigned long long g_sr_counters[4];
 __device__ unsigned long long g_sr_counters_x[2];   // diagnostics (dbg == 3): drains, rounds, appended hits, tiles with hits
 // KT > 0: K is the compile-time constant KT (= KR): the K-th / (K/2)-th list slots are fixed registers instead of a 2 x KR
 // select chain per drain (the common K = 50 of the evaluation monitors gets its own instantiation)
-template <int D, int KR, int KT>
+//
+// X2 = true ("split" variant, score_topk's fast path): Q and E arrive as bf16 hi/mid planes (score_split_k: row = [D hi | D mid],
+// 4D bytes like the fp32 row) and a score is three v_mfma_f32_32x32x16_bf16 products per 16 k -- hi.hi + hi.mid + mid.hi -- on
+// the XDL matrix pipe, which (unlike the fp32 "SGEMM" MFMA) runs beside the vector ALU and costs 384 instead of 2048 cycles per
+// 32 x 32 tile.  These scores are APPROXIMATE (|s' - s| <= eps_u, see score_topk_merge_x): the kernel selects candidates with
+// them, the merge kernel re-scores the candidates with the exact fmaf chain and certifies the result (or flags the user for
+// the exact kernel).  Everything else -- queues, lists, bounds, seen handling, stream-K split -- is shared with the exact form.
+// blockflag != NULL (exact form as the fallback pass): user blocks whose flag is 0 are skipped.
+template <int D, int KR, int KT, bool X2>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
                                                            int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
                                                            const int64_t* __restrict__ seen_idx, int K,
                                                            float* __restrict__ part_vals, int* __restrict__ part_idx,
                                                            int maxseg, int64_t nub, int64_t nst, int64_t upw,
-                                                           unsigned* __restrict__ gthr, int dbg) {
+                                                           unsigned* __restrict__ gthr, int dbg,
+                                                           const int* __restrict__ blockflag, float* __restrict__ part_T) {
     constexpr int KH = D / 2;
     constexpr int RSF = D + 4;
+    constexpr int NS16 = D / 16;   // X2: MFMA steps of 16 k
     constexpr int F4_PER_STAGE = SC_TI * D / 4;
     constexpr int PF = F4_PER_STAGE / 256;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -380,9 +391,28 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
         const int64_t st1 = (st0 + (unit_end - unit) < nst) ? st0 + (unit_end - unit) : nst;
         const int seg = (int)((int64_t)blockIdx.x - (ub * nst) / upw);
         const int64_t user = ub * SC_USERS + ul;
+        if (blockflag && blockflag[ub] == 0) {   // fallback pass: nobody in this user block asked for it (workgroup-uniform)
+            unit += st1 - st0;
+            continue;
+        }
 
-        float bq[KH];
-        {
+        float bq[X2 ? 1 : KH];
+        float4 bqh[X2 ? NS16 : 1], bqm[X2 ? NS16 : 1];   // X2: 8 bf16 per step and plane, k = 16 s + 8 h + (0..7)
+        if constexpr (X2) {
+            const float4* qrow = reinterpret_cast<const float4*>(Q + user * D);   // [D hi | D mid] bf16 = D floats
+            const bool uok = user < B;
+#pragma unroll
+            for (int s = 0; s < NS16; ++s) {
+                bqh[s] = uok ? qrow[2 * s + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bqm[s] = uok ? qrow[D / 8 + 2 * s + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < NS16; ++s) {
+                asm volatile("" : "+v"(bqh[s].x), "+v"(bqh[s].y), "+v"(bqh[s].z), "+v"(bqh[s].w));
+                asm volatile("" : "+v"(bqm[s].x), "+v"(bqm[s].y), "+v"(bqm[s].z), "+v"(bqm[s].w));
+            }
+        } else {
             const float* qrow = Q + user * D;
             const bool uok = user < B;
 #pragma unroll
@@ -455,7 +485,10 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 // close to the true K-th value because the halves are statistically alike -> ~40 % fewer hits.
                 double kmid = lk[0], kkth = lk[0];
                 if constexpr (KT > 0) {
-                    kmid = lk[(KT + 1) / 2 - 1];
+                    // the m-th of both lanes is a bound on the 2m-th best of the pair: exact form m = ceil(K/2); split form (list
+                    // capacity KT >= K + 6 is what the lists guarantee, see score_x2_capacity) m = KT/2
+                    constexpr int MIDX = X2 ? KT / 2 : (KT + 1) / 2;
+                    kmid = lk[MIDX - 1];
                     kkth = lk[KT - 1];
                 } else {
 #pragma unroll
@@ -518,9 +551,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 const int f = p * 256 + tid;
                 const int row = f / (D / 4);
                 const int k0 = (f % (D / 4)) * 4;
-                float* dst = tile + row * RSF + (k0 >> 1);
-                *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);
-                *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
+                if constexpr (X2) {   // the split row as it is: [D bf16 hi | D bf16 mid], 16-byte pad per row
+                    *reinterpret_cast<float4*>(tile + row * RSF + k0) = pf[p];
+                } else {
+                    float* dst = tile + row * RSF + (k0 >> 1);
+                    *reinterpret_cast<float2*>(dst) = make_float2(pf[p].x, pf[p].z);
+                    *reinterpret_cast<float2*>(dst + KH) = make_float2(pf[p].y, pf[p].w);
+                }
             }
             if (wg_drain) {
                 drain();
@@ -599,6 +636,32 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                     const float* arow = tile + ((ht >> 1) * 32 + c) * RSF + h * KH;
 #ifndef SC_X_NOMFMA
+                    if constexpr (X2) {
+                        // lane (c, h) holds item row c, k = 16 s + 8 h + (0..7): 16 bytes at float offset 8 s + 4 h of a plane
+                        // (rows are 4 D + 16 bytes apart: the 16 lanes of a ds_read_b128 pass hit 16 different 16-byte bank groups)
+                        const float* xrow = tile + ((ht >> 1) * 32 + c) * RSF + 4 * h;
+                        float4 ah[NS16], am[NS16];
+#pragma unroll
+                        for (int s = 0; s < NS16; ++s) {
+                            ah[s] = *reinterpret_cast<const float4*>(xrow + 8 * s);
+                            am[s] = *reinterpret_cast<const float4*>(xrow + KH + 8 * s);
+                        }
+                        // all 2 NS16 fragment reads in flight together, ONE wait: left alone, the register allocator funnels them
+                        // through one register quad and exposes an LDS round trip in front of every other MFMA
+#pragma unroll
+                        for (int s = 0; s < NS16; ++s) {
+                            asm volatile("" : "+v"(ah[s].x), "+v"(ah[s].y), "+v"(ah[s].z), "+v"(ah[s].w));
+                            asm volatile("" : "+v"(am[s].x), "+v"(am[s].y), "+v"(am[s].z), "+v"(am[s].w));
+                        }
+#pragma unroll
+                        for (int s = 0; s < NS16; ++s) {
+                            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[s]), xm = __builtin_bit_cast(bf16x8, am[s]);
+                            const bf16x8 yh = __builtin_bit_cast(bf16x8, bqh[s]), ym = __builtin_bit_cast(bf16x8, bqm[s]);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+                        }
+                    } else {
 #pragma unroll
                     for (int q = 0; q < KH / 4; ++q) {
 #ifdef SC_X_NOAFRAG
@@ -610,6 +673,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * q + 1], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * q + 2], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * q + 3], acc, 0, 0, 0);
+                    }
                     }
 #endif
                     SC_T(if (prof) { asm volatile("s_nop 0" :: "v"(acc[0])); t1 = __builtin_readcyclecounter(); td += t1 - t0; t0 = t1; })
@@ -668,6 +732,10 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
         }
 #endif
         drain();
+        // Split form: the lists are SHORTER than the K the caller wants (capacity K here = c, see score_topk_impl), so what a lane
+        // has dropped matters: everything it filtered out was below its threshold of the moment, everything its list pushed out
+        // is below the list's last entry -- both <= the final threshold, which goes out with the list (score_topk_merge_x).
+        if (part_T && user < B) part_T[(user * maxseg + seg) * 2 + h] = thr;
         // The two partial lists of every user (K values + K ids per lane).  Written lane by lane this is 2K scattered 4-byte
         // stores per lane (64 cache lines per store instruction: 11 % of the kernel on the Beauty shape, scripts ablation
         // SC_X_NOOUTPUT); instead the wave transposes them through its (now empty) queue memory and writes each user's
@@ -742,13 +810,43 @@ __device__ __forceinline__ void bitonic_sort64(float& v, int& i, int lane) {
         }
 }
 
+// write one user's sorted list (lane j = j-th best; PAD = no entry) and apply the K > #unmasked fill
+__device__ __forceinline__ void topk_emit(float bv, int bi, int lane, int64_t user, int64_t N, int K,
+                                          const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
+                                          float* __restrict__ vals, int64_t* __restrict__ idx) {
+    const int PAD = 0x7FFFFFFF;
+    const int nvalid = __popcll(__ballot(bi != PAD && lane < K));
+    if (lane < K && bi != PAD) {
+        vals[user * K + lane] = bv;
+        idx[user * K + lane] = bi;
+    }
+    if (nvalid < K && lane == 0) {
+        // fewer than K unmasked items: torch.topk would continue into the masked (-1e23) entries;
+        // ties -> lowest index, i.e. the user's seen items in ascending order.
+        int o = nvalid;
+        int64_t last = -1;
+        if (seen_ptr)
+            for (int64_t p = seen_ptr[user]; p < seen_ptr[user + 1] && o < K; ++p) {
+                const int64_t it = seen_idx[p];
+                if (it < 0 || it >= N || it == last) continue;
+                last = it;
+                vals[user * K + o] = RE_MASKED_SCORE;
+                idx[user * K + o] = it;
+                ++o;
+            }
+        for (; o < K; ++o) { vals[user * K + o] = -INFINITY; idx[user * K + o] = -1; }
+    }
+}
+
 __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict__ part_vals, const int* __restrict__ part_idx,
                                                         int maxseg, int lps, int presorted, int64_t B, int64_t N, int K, int64_t nst, int64_t upw,
                                                         const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
-                                                        float* __restrict__ vals, int64_t* __restrict__ idx) {
+                                                        float* __restrict__ vals, int64_t* __restrict__ idx,
+                                                        const int* __restrict__ userflag) {
     const int lane = threadIdx.x & 63;
     const int64_t user = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (user >= B) return;
+    if (userflag && userflag[user] == 0) return;   // fallback pass: this user's result is certified already
     const int64_t ub = user / SC_USERS;
     const int64_t w0 = (ub * nst) / upw, w1 = ((ub + 1) * nst - 1) / upw;
     const int nseg = (int)(w1 - w0 + 1) * lps;   // lps partial lists per segment (2 for the register-list variant)
@@ -772,27 +870,216 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
 #pragma unroll
         for (int j = 32; j > 0; j >>= 1) bitonic_step(bv, bi, j, (lane & j) == 0, lane);
     }
-    const int nvalid = __popcll(__ballot(bi != PAD && lane < K));
-    if (lane < K && bi != PAD) {
-        vals[user * K + lane] = bv;
-        idx[user * K + lane] = bi;
+    topk_emit(bv, bi, lane, user, N, K, seen_ptr, seen_idx, vals, idx);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The split form (score_kernel_reg<.., X2 = true>): preparation, candidate re-scoring, certificate.
+//
+// score_split_k: fp32 rows -> two bf16 planes by round-to-nearest-even, hi = bf16(x), mid = bf16(x - hi) (x - hi is exact in
+// fp32), so x = hi + mid + r with |r| <= 2^-18 |x|.  Output row = [D hi | D mid] (4 D bytes, the fp32 row's size); also the
+// row's Euclidean norm (rounded up) -> rownorm[] and/or a device-wide maximum (one atomicMax per wave at the end).
+__device__ __forceinline__ unsigned sx_bf16(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+template <int D>
+__global__ __launch_bounds__(256) void score_split_k(const float* __restrict__ X, int64_t R, unsigned short* __restrict__ Xs,
+                                                     float* __restrict__ rownorm, unsigned* __restrict__ maxnorm) {
+    constexpr int LPR = D / 4;   // lanes per row (16 or 32: a wave holds whole rows)
+    const int64_t total = R * LPR;
+    float wmax = 0.0f;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {
+        const int64_t f = base + threadIdx.x;
+        const bool ok = f < total;
+        const int64_t row = ok ? f / LPR : 0;
+        const int kq = (int)(f % LPR);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) x = reinterpret_cast<const float4*>(X)[f];
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+        unsigned hi[4], mid[4];
+        double ss = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = sx_bf16(xv[j]);
+            mid[j] = sx_bf16(xv[j] - __uint_as_float(hi[j] << 16));
+            ss += (double)xv[j] * (double)xv[j];
+        }
+        if (ok) {
+            unsigned short* dst = Xs + row * (2 * D) + 4 * kq;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+            *reinterpret_cast<uint2*>(dst + D) = make_uint2(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16));
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        float nrm = ss > 1e-30 ? sqrtf((float)ss) : (float)sqrt(ss);   // (fp64 sqrt only for rows that would underflow in fp32)
+        nrm = nrm * 1.000001f;                         // rounded up (sqrt, conversion)
+        if (ss > 0.0 && nrm < 1.2e-38f) nrm = 1.2e-38f;  // never 0 for a non-zero row
+        if (ok && kq == 0 && rownorm) rownorm[row] = nrm;
+        if (ok) wmax = (nrm > wmax || nrm != nrm) ? nrm : wmax;   // (a NaN row poisons the maximum: every user falls back)
     }
-    if (nvalid < K && lane == 0) {
-        // fewer than K unmasked items: torch.topk would continue into the masked (-1e23) entries;
-        // ties -> lowest index, i.e. the user's seen items in ascending order.
-        int o = nvalid;
-        int64_t last = -1;
-        if (seen_ptr)
-            for (int64_t p = seen_ptr[user]; p < seen_ptr[user + 1] && o < K; ++p) {
-                const int64_t it = seen_idx[p];
-                if (it < 0 || it >= N || it == last) continue;
-                last = it;
-                vals[user * K + o] = RE_MASKED_SCORE;
-                idx[user * K + o] = it;
-                ++o;
+    if (maxnorm) {
+        unsigned e = __float_as_uint(wmax);   // non-negative floats (and NaN above them) order as unsigned words
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e = max(e, (unsigned)__shfl_xor((int)e, o, 64));
+        __shared__ unsigned wm[4];
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) {   // one atomic per workgroup: same-address atomics serialise at ~10 ns each
+            e = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+            if (e != 0u) atomicMax(maxnorm, e);
+        }
+    }
+}
+
+// score_topk_merge_x: one wave per user.  The split kernel leaves, per (user, segment, lane half), a list of its C best items
+// by APPROXIMATE score s' and the bound t below which it dropped everything else (its final threshold).
+// (1) Merge the user's lists into the best 64 by (s', lowest id).  Every item of the catalog that is not among them has
+//     s' <= T := max(all t, the 64th merged s' if the lists held more than 64 entries)  (-inf: nothing was ever dropped).
+// (2) Re-score the 64 candidates with the exact chain acc = fmaf(q[k], e[k], acc), k = 0..D-1 (the oracle's and the fp32 MFMA
+//     kernel's arithmetic) and sort them by (s, lowest id).
+// (3) Certificate: with |s' - s| <= eps for every item of this user, an outsider has s <= T + eps; if the K-th best exact
+//     candidate score is strictly above T + eps, the exact top K of the whole catalog are the best K candidates -- written
+//     out, bit-exact.  Otherwise the user is flagged and the exact kernel redoes the user's block (score_kernel_reg<.., false>
+//     with blockflag, score_topk_merge with userflag): correctness never depends on eps being small or on the lists being
+//     long enough, only on eps being an upper bound.
+//   eps = cerr * |q| * max_j |e_j| (+ 1e-36 for flushed denormals), cerr = 1.05 * (3.01 * 2^-18 [dropped mid.mid, split remainders]
+//         + (3 D + 4) * 2^-23 [fp32 accumulation of the 3 D exact bf16 x bf16 products inside the MFMAs, one ulp per addition]
+//         + D * 2^-24 [the exact chain's own distance from the true dot product]), using sum |q_k e_k| <= |q| |e|.
+#define MX_ROWS 16   // candidate rows staged per pass and wave (4 waves x 16 x (D + 4) floats of LDS)
+__device__ float g_sx_info[8];
+__device__ unsigned g_sx_stats[2];   // [0] users sent to the exact fallback so far, [1] diagnostics: max |s' - s| / eps (float bits)
+template <int D>
+__global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restrict__ part_vals, const int* __restrict__ part_idx,
+                                                          const float* __restrict__ part_T,
+                                                          int maxseg, int64_t B, int64_t N, int K, int C, int64_t nst, int64_t upw,
+                                                          const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
+                                                          const float* __restrict__ Q, const float* __restrict__ E,
+                                                          const float* __restrict__ qnorm, const unsigned* __restrict__ emax, float cerr,
+                                                          float* __restrict__ vals, int64_t* __restrict__ idx,
+                                                          int* __restrict__ userflag, int* __restrict__ blockflag,
+                                                          int dbg_maxerr) {
+    constexpr int RS = D + 4, LPR = D / 4;
+    __shared__ __align__(16) float mx_stage[4 * MX_ROWS * RS];
+    const int mxd = dbg_maxerr >> 4;
+    dbg_maxerr &= 15;
+    const int lane = threadIdx.x & 63;
+    const int64_t user = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (user >= B) return;
+    const int64_t ub = user / SC_USERS;
+    const int64_t w0 = (ub * nst) / upw, w1 = ((ub + 1) * nst - 1) / upw;
+    const int nseg = (int)(w1 - w0 + 1) * 2;
+    maxseg *= 2;
+    const int PAD = 0x7FFFFFFF;
+    float bv = -INFINITY;
+    int bi = PAD;
+    float T = -INFINITY;
+    int total = 0;
+    // (four lists per round: their loads are in flight together -- one list per iteration makes the loop a chain of global
+    // memory round trips, and that chain, not the merge network, is this kernel's time)
+    for (int s0 = 0; s0 < ((mxd & 1) ? 1 : nseg); s0 += 4) {
+        float v4[4], t4[4];
+        int i4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u;
+            v4[u] = -INFINITY; i4[u] = -1; t4[u] = -INFINITY;
+            if (s < nseg) {
+                if (lane < C) {
+                    v4[u] = part_vals[(user * maxseg + s) * C + lane];
+                    i4[u] = part_idx[(user * maxseg + s) * C + lane];
+                }
+                t4[u] = part_T[user * maxseg + s];
             }
-        for (; o < K; ++o) { vals[user * K + o] = -INFINITY; idx[user * K + o] = -1; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = v4[u];
+            int i = i4[u];
+            if (i < 0) { i = PAD; v = -INFINITY; }
+            T = fmaxf(T, t4[u]);
+            total += __popcll(__ballot(i != PAD));
+            const float rv = __shfl(v, 63 - lane, 64);
+            const int ri = __shfl(i, 63 - lane, 64);
+            if (sc_before(rv, ri, bv, bi)) { bv = rv; bi = ri; }
+#pragma unroll
+            for (int j = 32; j > 0; j >>= 1) bitonic_step(bv, bi, j, (lane & j) == 0, lane);
+        }
     }
+    const int nvalid = total < 64 ? total : 64;
+    if (total > 64) T = fmaxf(T, __shfl(bv, 63, 64));
+    // exact re-scoring: lane = candidate.  The 64 candidate rows are fetched like a gather -- D/4 lanes per row, whole-row
+    // coalesced float4 loads, ALL of them issued before the first use -- and handed to their lanes through the wave's LDS
+    // slice, MX_ROWS rows per pass (a lane reading its own row from global memory touches 64 cache lines per load
+    // instruction).  LDS rows are D + 4 floats apart (conflict-free float4 reads down a column of rows).
+    float* stage = mx_stage + (threadIdx.x >> 6) * (MX_ROWS * RS);
+    float4 qr[LPR];   // the query row, once (every lane holds it)
+    {
+        const float4* q4 = reinterpret_cast<const float4*>(Q + user * D);
+#pragma unroll
+        for (int k = 0; k < LPR; ++k) qr[k] = q4[k];
+    }
+    constexpr int NLD = 64 * LPR / 64;   // float4 loads per lane for 64 rows
+    float4 rowreg[NLD];
+#pragma unroll
+    for (int t0 = 0; t0 < NLD; ++t0) {
+        const int t = t0 * 64 + lane;
+        const int r = t / LPR, ch = t - r * LPR;
+        const int id = __shfl(bi, r, 64);
+        rowreg[t0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id != PAD) rowreg[t0] = reinterpret_cast<const float4*>(E + (int64_t)id * D)[ch];
+    }
+    float sx = -INFINITY;
+    constexpr int LPP = MX_ROWS * LPR / 64;   // loads per pass
+#pragma unroll
+    for (int ps = 0; ps < 64 / MX_ROWS; ++ps) {
+        const int r0 = ps * MX_ROWS;
+        if (r0 < nvalid && !(mxd & 2)) {   // (wave-uniform)
+#pragma unroll
+            for (int t0 = 0; t0 < LPP; ++t0) {
+                const int t = t0 * 64 + lane;
+                const int r = t / LPR, ch = t - r * LPR;
+                *reinterpret_cast<float4*>(stage + r * RS + 4 * ch) = rowreg[ps * LPP + t0];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= r0 && lane < r0 + MX_ROWS && bi != PAD) {
+                const float4* e4 = reinterpret_cast<const float4*>(stage + (lane - r0) * RS);
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < LPR; ++k) {
+                    const float4 e = e4[k];
+                    acc = fmaf(qr[k].x, e.x, acc);
+                    acc = fmaf(qr[k].y, e.y, acc);
+                    acc = fmaf(qr[k].z, e.z, acc);
+                    acc = fmaf(qr[k].w, e.w, acc);
+                }
+                sx = acc + 0.0f;   // (-0 -> +0, like the list keys of the exact kernel)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    const double eps = (double)cerr * (double)qnorm[user] * (double)__uint_as_float(*emax) + 1e-36;
+    if (dbg_maxerr && bi != PAD) {   // diagnostics: the largest observed |s' - s| / eps (must stay below 1; tests/test_gpu_ops.py)
+        const float ratio = (float)(fabs((double)sx - (double)bv) / eps);
+        atomicMax(&g_sx_stats[1], __float_as_uint(ratio));
+    }
+    if (!(mxd & 4)) bitonic_sort64(sx, bi, lane);
+    const float xk = __shfl(sx, K - 1, 64);
+    const bool validk = __shfl(bi, K - 1, 64) != PAD;
+    const bool pass = T == -INFINITY || (validk && (double)xk > (double)T + eps);   // (T = -inf: nothing was ever dropped)
+    if (!pass) {
+        if (lane == 0) {
+            userflag[user] = 1; blockflag[ub] = 1; atomicAdd(&g_sx_stats[0], 1u);
+            if (dbg_maxerr) {   // diagnostics: the last flagged user's certificate inputs
+                g_sx_info[0] = (float)user; g_sx_info[1] = T; g_sx_info[2] = xk; g_sx_info[3] = (float)eps;
+                g_sx_info[4] = (float)total; g_sx_info[5] = (float)nseg; g_sx_info[6] = validk ? 1.f : 0.f; g_sx_info[7] = __shfl(bv, 63, 64);
+            }
+        }
+        return;
+    }
+    topk_emit(sx, bi, lane, user, N, K, seen_ptr, seen_idx, vals, idx);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -819,7 +1106,7 @@ struct ScorePlan {
     int nwg, maxseg;
 };
 
-static ScorePlan score_plan(int64_t B, int64_t N, int64_t D = 64) {
+static ScorePlan score_plan(int64_t B, int64_t N, int64_t D = 64, int64_t wg_cap = 0) {
     ScorePlan p;
     p.nub = re_cdiv(B, SC_USERS);
     p.nst = re_cdiv(N, SC_TI);
@@ -829,7 +1116,7 @@ static ScorePlan score_plan(int64_t B, int64_t N, int64_t D = 64) {
     // small catalog over all CUs costs more in warm-ups and list merging than it gains (B=512 x N=12101: 0.58 -> see
     // scripts/tune_score.py).
     // (D = 128: the register-list kernel holds a 64-register query fragment and runs one workgroup per CU)
-    int64_t upw = re_cdiv(p.units, D == 128 && g_score_maxwgs == SC_MAX_WGS ? SC_MAX_WGS / 2 : g_score_maxwgs);
+    int64_t upw = re_cdiv(p.units, wg_cap > 0 ? wg_cap : D == 128 && g_score_maxwgs == SC_MAX_WGS ? SC_MAX_WGS / 2 : g_score_maxwgs);
     const int64_t min_seg = p.nst < g_score_minseg ? p.nst : g_score_minseg;
     if (upw < min_seg) upw = min_seg;
     p.upw = upw;
@@ -844,11 +1131,80 @@ static size_t score_lds_bytes(int D, int K, bool topk) {
     return b;
 }
 
+static int g_score_x2 = 1;      // the split (bf16 hi/mid on the XDL pipe + exact re-scoring) fast path; 0 = exact kernel only
+extern "C" void re_dbg_score_x2(int on) { g_score_x2 = on; }
+static int g_score_mxdiag = 0;   // timing-only ablation of score_topk_merge_x (scripts/x2_diag.py): 1 no list merge, 2 no re-scoring, 4 no final sort
+extern "C" void re_dbg_score_mxdiag(int m) { g_score_mxdiag = m; }
+static int g_score_maxerr = 0;   // diagnostics: record max |s' - s| / eps over all re-scored candidates
+extern "C" void re_dbg_score_x2_maxerr(int on) { g_score_maxerr = on; }
+extern "C" void re_dbg_score_x2_info(float* out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sx_info), 32); }
+extern "C" void re_dbg_score_x2_stats(unsigned* out2, int reset) {   // (synchronises; tests and scripts only)
+    (void)hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_sx_stats), 8);
+    if (reset) { unsigned z[2] = {0u, 0u}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sx_stats), z, 8); }
+}
+// List capacity of the split form: the smallest instantiated capacity (16, 24, 32, 56) >= K + 6.  A lane's list must be able to
+// hold MORE than the user's whole top K: the top K of a user routinely sit in one list (popular items have neighbouring ids
+// -- with the bench's Zipf-by-id popularity, the best 50 of every trained user are inside the first 64 ids, i.e. one stage,
+// two lanes), and a list that overflows with them raises its dropped-below bound above the K-th best score, which fails
+// the certificate.  Shorter lists (a lane's statistical share of the top K) were measured: 9 % faster on iid scores, every
+// user in the fallback on the trained state.  Re-ordering the catalog so that id runs spread over the lists would need the
+// seen lists in that order too.
+#define SX_MAX_PREP_BYTES (16ll << 30)   // re_score_topk splits the table into its workspace only up to this size (else: exact path)
+static int score_x2_capacity(const ScorePlan& p, int64_t K) {
+    (void)p;
+    const int64_t need = K + 6;
+    return need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 56;
+}
+static bool score_use_reg(const ScorePlan& p, int64_t N, int64_t D, int64_t K) {
+    return g_score_pop == 3 && (D == 64 || D == 128) && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1;
+}
+static bool score_use_x2(const ScorePlan& p, int64_t N, int64_t D, int64_t K) {
+    // (D = 128: the split kernel's 16 fragment reads + 24 MFMAs per tile run on one wave per SIMD -- one workgroup per CU by LDS --
+    // and nothing overlaps: measured no faster than the exact form, so D = 128 stays on the exact kernel)
+    return g_score_x2 && D == 64 && score_use_reg(p, N, D, K) && K + 6 <= 56;
+}
+static float score_cerr(int64_t D) {
+    const double c = 3.01 * ldexp(1.0, -18) + (3.0 * (double)D + 4.0) * ldexp(1.0, -23) + (double)D * ldexp(1.0, -24);
+    return (float)(1.05 * c);
+}
+
+struct ScoreWs {   // carving of re_score_topk's workspace
+    size_t half, off_pi, off_gthr, off_flags, off_qnorm, off_pt, off_qs, off_prep, total;
+    size_t n_zero;   // bytes from off_gthr that are zeroed per call: gthr[B] gthr2[B] userflag[B] blockflag[nub] emax/dbg[64]
+};
+static ScoreWs score_ws(int64_t B, int64_t N, int64_t D, int64_t K, const ScorePlan& p, bool x2, bool own_prep) {
+    ScoreWs w;
+    const int64_t kk = x2 ? 56 : K;   // (x2: any list capacity, and the exact fallback's K <= 50)
+    int64_t segs = p.maxseg;
+    if (x2) { const ScorePlan pfb = score_plan(B, N, D); if (pfb.maxseg > segs) segs = pfb.maxseg; }
+    w.half = re_align((size_t)p.nub * SC_USERS * segs * 2 * kk * 4);     // up to 2 lists per (user, segment)
+    w.off_pi = w.half;
+    w.off_gthr = 2 * w.half;
+    w.n_zero = re_align((size_t)B * 4 * (x2 ? 3 : 1) + (x2 ? (size_t)p.nub * 4 + 256 : 0));
+    w.off_flags = w.off_gthr + (size_t)B * 8;
+    w.off_qnorm = w.off_gthr + w.n_zero;
+    w.off_pt = w.off_qnorm + (x2 ? re_align((size_t)B * 4) : 0);                     // one dropped-below bound per list
+    w.off_qs = w.off_pt + (x2 ? re_align((size_t)p.nub * SC_USERS * segs * 2 * 4) : 0);
+    w.off_prep = w.off_qs + (x2 ? re_align((size_t)B * D * 4) : 0);
+    w.total = w.off_prep + (x2 && own_prep ? re_align((size_t)N * D * 4) + 256 : 0) + 256;
+    return w;
+}
+
 extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K) {
     if (B <= 0 || N <= 0 || K <= 0) return 256;
     ScorePlan p = score_plan(B, N, D);
-    return re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4) * 2      // up to 2 lists per (user, segment)
-           + re_align((size_t)B * 4) + 256;                                     // shared per-user bounds
+    const bool x2 = score_use_x2(p, N, D, K) && (int64_t)N * D * 4 <= SX_MAX_PREP_BYTES;
+    return score_ws(B, N, D, K, p, x2, true).total;
+}
+// workspace of the prepared form: the item table's split planes live in the caller's `prep` buffer instead
+extern "C" size_t re_score_topk_prepared_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K) {
+    if (B <= 0 || N <= 0 || K <= 0) return 256;
+    ScorePlan p = score_plan(B, N, D);
+    return score_ws(B, N, D, K, p, score_use_x2(p, N, D, K), false).total;
+}
+extern "C" size_t re_score_prepare_bytes(int64_t N, int64_t D) {
+    if (N <= 0 || D <= 0) return 256;
+    return re_align((size_t)N * D * 4) + 256;   // planes + the maximum row norm (last 256 bytes)
 }
 
 template <int D, bool TOPK, int POP>
@@ -886,39 +1242,113 @@ extern "C" int re_score_dense(const float* Q, const float* E, int64_t B, int64_t
     return score_dispatch<false>(D, Q, E, B, N, nullptr, nullptr, 0, nullptr, nullptr, p, out, (hipStream_t)stream);
 }
 
-extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, const int64_t* seen_ptr,
-                             const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx, void* ws, size_t ws_bytes,
-                             re_stream_t stream) {
+template <int D>
+static int score_split_launch(const float* X, int64_t R, void* Xs, float* rownorm, unsigned* maxnorm, hipStream_t s) {
+    // (8 rounds per workgroup where the table allows: the device-wide maximum costs one atomic per workgroup)
+    hipLaunchKernelGGL(score_split_k<D>, dim3(re_grid(R * (D / 4), maxnorm ? 2048 : 256, 2048)), dim3(256), 0, s, X, R, (unsigned short*)Xs, rownorm, maxnorm);
+    return re_launch_status();
+}
+
+// Split the item table once for any number of re_score_topk_prepared calls (Coach.evaluate scores every user batch of a split
+// against the same table).  prep: re_score_prepare_bytes(N, D) bytes, 16-byte aligned.  Unsupported D -> RE_EUNSUPPORTED.
+extern "C" int re_score_prepare(const float* E, int64_t N, int64_t D, void* prep, size_t prep_bytes, re_stream_t stream) {
     re_clear_error();
+    if (!E || !prep || N <= 0) return RE_EINVAL;
+    if (D != 64 && D != 128) return RE_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(E) & 15u) != 0 || (reinterpret_cast<uintptr_t>(prep) & 15u) != 0) return RE_EUNSUPPORTED;
+    if (prep_bytes < re_score_prepare_bytes(N, D)) return RE_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* emax = (unsigned*)((char*)prep + re_align((size_t)N * D * 4));
+    if (re_zero_async(emax, 256, s) != hipSuccess) return RE_ELAUNCH;
+    return D == 64 ? score_split_launch<64>(E, N, prep, nullptr, emax, s) : score_split_launch<128>(E, N, prep, nullptr, emax, s);
+}
+
+// prep == NULL: the table is split into the workspace first (re_score_topk); otherwise prep is re_score_prepare's output for E.
+static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, const int64_t* seen_ptr,
+                           const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx, void* ws, size_t ws_bytes,
+                           const void* prep, hipStream_t s) {
     if (B == 0) return RE_OK;
     if (!Q || !E || !vals || !idx || !ws || B < 0 || N <= 0 || K <= 0 || K > RE_TOPK_MAX) return RE_EINVAL;
     if ((reinterpret_cast<uintptr_t>(E) & 15u) != 0 || N >= 0x7FFFFFFFll) return RE_EUNSUPPORTED;
     if (seen_ptr && !seen_idx) return RE_EINVAL;
-    if (ws_bytes < re_score_topk_workspace_bytes(B, N, D, K)) return RE_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
     ScorePlan p = score_plan(B, N, D);
-    const size_t half = re_align((size_t)p.nub * SC_USERS * p.maxseg * 2 * K * 4);
+    const bool x2 = score_use_x2(p, N, D, K) && (prep || (int64_t)N * D * 4 <= SX_MAX_PREP_BYTES) && (reinterpret_cast<uintptr_t>(Q) & 15u) == 0;
+    const ScoreWs w = score_ws(B, N, D, K, p, x2, prep == nullptr);
+    if (ws_bytes < w.total) return RE_EWORKSPACE;
     float* pv = (float*)ws;
-    int* pi = (int*)((char*)ws + half);
+    int* pi = (int*)((char*)ws + w.off_pi);
+    unsigned* gthr = (unsigned*)((char*)ws + w.off_gthr);
     int rc, lps = 1;
+    const int* userflag = nullptr;
+    // (the fallback pass of the split path has its own plan object: same split today -- a flagged user block is redone by as
+    // many workgroups as scored it the first time; when nobody is flagged, the normal case, what it costs is its dispatch)
+    const ScorePlan pfb = score_plan(B, N, D);
+    const ScorePlan* lp = &p;
+#define SR_LAUNCH(DV, KRV, KTV, X2V, QP, EP, KV, GT, BF, PT)                                                                        \
+    do {                                                                                                                             \
+        auto kern = score_kernel_reg<DV, KRV, KTV, X2V>;                                                                             \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RE_ELAUNCH; \
+        hipLaunchKernelGGL(kern, dim3(lp->nwg), dim3(256), lds, s, QP, EP, B, N, seen_ptr, seen_idx, (int)(KV), pv, pi, lp->maxseg, lp->nub, \
+                           lp->nst, lp->upw, GT, g_score_dbg, BF, PT);                                                                       \
+    } while (0)
     // register-list variant: many users per launch (its two lists per segment double the merge work, which dominates
     // when B is small -- A/B in scripts/tune_score.py)
-    if (g_score_pop == 3 && (D == 64 || D == 128) && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1) {
+    if (score_use_reg(p, N, D, K)) {
         lps = 2;
         const size_t lds = (size_t)SC_TI * (D + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
-        unsigned* gthr = g_score_share ? (unsigned*)((char*)ws + 2 * half) : (unsigned*)nullptr;
-        if (gthr && re_zero_async(gthr, (size_t)B * 4, s) != hipSuccess) return RE_ELAUNCH;
-#define SR_LAUNCH(DV, KRV, KTV)                                                                                                      \
-    do {                                                                                                                             \
-        auto kern = score_kernel_reg<DV, KRV, KTV>;                                                                                  \
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RE_ELAUNCH; \
-        hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(256), lds, s, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p.maxseg, p.nub,    \
-                           p.nst, p.upw, gthr, g_score_dbg);                                                                         \
+        if (re_zero_async(gthr, w.n_zero, s) != hipSuccess) return RE_ELAUNCH;
+        if (!g_score_share) gthr = nullptr;
+        const int* blockflag = nullptr;
+        if (x2) {
+            // ---- fast path: split planes -> approximate scores on the XDL pipe -> exact re-scoring + certificate
+            unsigned* gthr2 = (unsigned*)((char*)ws + w.off_gthr) + B;
+            int* uflag = (int*)((char*)ws + w.off_flags);
+            int* bflag = uflag + B;
+            unsigned* emax_own = (unsigned*)(bflag + p.nub);
+            float* qnorm = (float*)((char*)ws + w.off_qnorm);
+            float* Qs = (float*)((char*)ws + w.off_qs);
+            const float* Es;
+            const unsigned* emax;
+            if (prep) {
+                Es = (const float*)prep;
+                emax = (const unsigned*)((const char*)prep + re_align((size_t)N * D * 4));
+            } else {
+                float* own = (float*)((char*)ws + w.off_prep);
+                rc = D == 64 ? score_split_launch<64>(E, N, own, nullptr, emax_own, s) : score_split_launch<128>(E, N, own, nullptr, emax_own, s);
+                if (rc != RE_OK) return rc;
+                Es = own;
+                emax = emax_own;
+            }
+            rc = D == 64 ? score_split_launch<64>(Q, B, Qs, qnorm, nullptr, s) : score_split_launch<128>(Q, B, Qs, qnorm, nullptr, s);
+            if (rc != RE_OK) return rc;
+            const int C = score_x2_capacity(p, K);
+            float* pt = (float*)((char*)ws + w.off_pt);
+#define SX_LAUNCH(DV)                                                                          \
+    do {                                                                                       \
+        if (C == 16) SR_LAUNCH(DV, 16, 16, true, Qs, Es, 16, gthr, nullptr, pt);               \
+        else if (C == 24) SR_LAUNCH(DV, 24, 24, true, Qs, Es, 24, gthr, nullptr, pt);          \
+        else if (C == 32) SR_LAUNCH(DV, 32, 32, true, Qs, Es, 32, gthr, nullptr, pt);          \
+        else SR_LAUNCH(DV, 56, 56, true, Qs, Es, 56, gthr, nullptr, pt);                       \
     } while (0)
+            SX_LAUNCH(64);
+#undef SX_LAUNCH
+            if ((rc = re_launch_status()) != RE_OK) return rc;
+            hipLaunchKernelGGL(score_topk_merge_x<64>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
+                               p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4));
+            if ((rc = re_launch_status()) != RE_OK) return rc;
+            // ---- fallback pass over flagged user blocks only (normally none: every workgroup returns at once)
+            blockflag = bflag;
+            userflag = uflag;
+            if (gthr) gthr = gthr2;
+            lp = &pfb;
+        }
         if (D == 64) {
-            if (K == 50) SR_LAUNCH(64, 50, 50); else if (K <= 16) SR_LAUNCH(64, 16, 0); else if (K <= 32) SR_LAUNCH(64, 32, 0); else SR_LAUNCH(64, 52, 0);
+            if (K == 50) SR_LAUNCH(64, 50, 50, false, Q, E, K, gthr, blockflag, nullptr);
+            else if (K <= 16) SR_LAUNCH(64, 16, 0, false, Q, E, K, gthr, blockflag, nullptr);
+            else if (K <= 32) SR_LAUNCH(64, 32, 0, false, Q, E, K, gthr, blockflag, nullptr);
+            else SR_LAUNCH(64, 52, 0, false, Q, E, K, gthr, blockflag, nullptr);
         } else {   // D = 128 (config 5): one workgroup per CU, 512-register budget
-            if (K == 50) SR_LAUNCH(128, 50, 50); else SR_LAUNCH(128, 52, 0);
+            if (K == 50) SR_LAUNCH(128, 50, 50, false, Q, E, K, gthr, blockflag, nullptr); else SR_LAUNCH(128, 52, 0, false, Q, E, K, gthr, blockflag, nullptr);
         }
 #undef SR_LAUNCH
         rc = re_launch_status();
@@ -926,7 +1356,22 @@ extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t 
         rc = score_dispatch<true>(D, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p, nullptr, s);
     }
     if (rc != RE_OK) return rc;
-    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, p.maxseg, lps, (lps == 2) ? 1 : 0, B, N, (int)K, p.nst, p.upw,
-                       seen_ptr, seen_idx, vals, idx);
+    hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, lp->maxseg, lps, (lps == 2) ? 1 : 0, B, N, (int)K, lp->nst, lp->upw,
+                       seen_ptr, seen_idx, vals, idx, userflag);
     return re_launch_status();
+}
+
+extern "C" int re_score_topk(const float* Q, const float* E, int64_t B, int64_t N, int64_t D, const int64_t* seen_ptr,
+                             const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx, void* ws, size_t ws_bytes,
+                             re_stream_t stream) {
+    re_clear_error();
+    return score_topk_impl(Q, E, B, N, D, seen_ptr, seen_idx, K, vals, idx, ws, ws_bytes, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int re_score_topk_prepared(const float* Q, const float* E, const void* prep, int64_t B, int64_t N, int64_t D,
+                                      const int64_t* seen_ptr, const int64_t* seen_idx, int64_t K, float* vals, int64_t* idx,
+                                      void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!prep) return RE_EINVAL;
+    return score_topk_impl(Q, E, B, N, D, seen_ptr, seen_idx, K, vals, idx, ws, ws_bytes, prep, (hipStream_t)stream);
 }

@@ -36,6 +36,10 @@ SIGNATURES = {
     "re_score_dense": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "re_score_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_score_topk": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "re_score_prepare_bytes": (_sz, [_i64, _i64]),
+    "re_score_prepare": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp]),
+    "re_score_topk_prepared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "re_score_topk_prepared": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "re_sasrec_tape_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_sasrec_encoder_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "re_sasrec_encoder_embed_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp,

@@ -262,9 +262,22 @@ def score_dense(Q, E):
     return out
 
 
-def score_topk(Q, E, seen_ptr, seen_idx, K):
+def score_prepare(E):
+    """Split the item table once for `score_topk(..., prep=)` (many user batches against one table).  -> opaque uint8 tensor;
+    only D = 64 / 128 have a split form (others: returns None and score_topk takes its exact path)."""
+    _req(E, torch.float32, "E")
+    N, D = E.shape
+    if D not in (64, 128) or N == 0:
+        return None
+    L = lib.load()
+    prep = torch.empty(L.re_score_prepare_bytes(N, D), dtype=torch.uint8, device=E.device)
+    lib.check(L.re_score_prepare(_p(E), N, D, _p(prep), prep.numel(), _stream()), "re_score_prepare")
+    return prep
+
+
+def score_topk(Q, E, seen_ptr, seen_idx, K, prep=None):
     """Fused score + seen-mask + top-K.  seen_ptr int64[B+1], seen_idx int64[nnz] with every user's ids ASCENDING
-    (None/None = retain_seen).  -> (vals f32 [B,K] descending, idx int64 [B,K])."""
+    (None/None = retain_seen).  -> (vals f32 [B,K] descending, idx int64 [B,K]).  prep = score_prepare(E) (optional)."""
     _req(Q, torch.float32, "Q"); _req(E, torch.float32, "E")
     B, D = Q.shape
     N = E.shape[0]
@@ -278,6 +291,11 @@ def score_topk(Q, E, seen_ptr, seen_idx, K):
     dev = Q.device
     vals = torch.empty((B, K), dtype=torch.float32, device=dev)
     idx = torch.empty((B, K), dtype=torch.int64, device=dev)
+    if prep is not None:
+        ws = _ws(L.re_score_topk_prepared_workspace_bytes(B, N, D, K), dev)
+        lib.check(L.re_score_topk_prepared(_p(Q), _p(E), _p(prep), B, N, D, _p(seen_ptr), _p(seen_idx), K, _p(vals), _p(idx),
+                                           _p(ws), ws.numel(), _stream()), "re_score_topk_prepared")
+        return vals, idx
     ws = _ws(L.re_score_topk_workspace_bytes(B, N, D, K), dev)
     lib.check(L.re_score_topk(_p(Q), _p(E), B, N, D, _p(seen_ptr), _p(seen_idx), K, _p(vals), _p(idx), _p(ws),
                               ws.numel(), _stream()), "re_score_topk")

@@ -15,8 +15,10 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = {"32x32x2_f32": 16, "16x16x4_f32": 8, "32x32x1_2b_f32": 16, "16x16x1_4b_f32": 8, "4x4x1_16b_f32": 2,
-          "32x32x8_f16": 16, "16x16x16_f16": 8, "32x32x8_bf16": 16, "16x16x16_bf16": 8, "32x32x16_bf16": 16,
-          "16x16x32_bf16": 8, "32x32x16_f16": 16, "16x16x32_f16": 8}
+          "32x32x8_f16": 16, "16x16x16_f16": 8, "32x32x8_bf16": 16, "16x16x16_bf16": 8, "32x32x16_bf16": 8,
+          "16x16x32_bf16": 4, "32x32x16_f16": 8, "16x16x32_f16": 4}
+# XDL (16-bit input) MFMAs: result -> vector read needs passes + 3 wait states (8 passes: 11); fp32 "SGEMM" MFMAs passes + 2
+XDL = ("_bf16", "_f16")
 REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
 
 
@@ -62,7 +64,7 @@ def lint_function(name, ins):
         if not mn or not mn.startswith("v_mfma"):
             continue
         key = mn[len("v_mfma_f32_"):] if mn.startswith("v_mfma_f32_") else None
-        need = PASSES.get(key, 16) + 2
+        need = PASSES.get(key, 16) + (3 if key and key.endswith(XDL) else 2)
         dst = regs(ops.split(",")[0])
         seen = set()
         stack = [(i + 1, 0)]
