@@ -351,18 +351,24 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
     constexpr int PF = F4_PER_STAGE / 256;
     extern __shared__ __align__(16) unsigned char smem[];
     float* tile = reinterpret_cast<float*>(smem);
-    float* qv = tile + SC_TI * RSF;                          // [4 waves][SR_QC][64 lanes]
-    int* qi = reinterpret_cast<int*>(qv + 4 * SR_QC * 64);
+    // Split form: the item stages go global -> LDS directly (global_load_lds_dwordx4: no staging registers, whose spilling had
+    // put a wait for the prefetch right behind its issue), double buffered, rows unpadded with their 16-byte chunks XOR-swizzled
+    // by the row number (conflict-free fragment reads); the queues give up 8 entries per lane to make room for the second buffer.
+    constexpr int QC = X2 ? 20 : SR_QC;
+    constexpr int TILE_FLOATS = X2 ? 2 * SC_TI * D : SC_TI * RSF;
+    static_assert(!X2 || D == 64, "split form: D = 64");
+    float* qv = tile + TILE_FLOATS;                          // [4 waves][QC][64 lanes]
+    int* qi = reinterpret_cast<int*>(qv + 4 * QC * 64);
     __shared__ int vote[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int ul = wid * 32 + c;
     const int NONE = 0x7FFFFFFF;
-    const int vote_at = (dbg >> 8) ? (dbg >> 8) - 1 : SR_VOTE;   // (tuning override in the upper bits of dbg)
+    const int vote_at = (dbg >> 8) ? (dbg >> 8) - 1 : (X2 ? SR_VOTE - 6 : SR_VOTE);   // (tuning override in the upper bits of dbg)
     dbg &= 0xFF;
-    float* myqv = qv + wid * SR_QC * 64 + lane;
-    int* myqi = qi + wid * SR_QC * 64 + lane;
+    float* myqv = qv + wid * QC * 64 + lane;
+    int* myqi = qi + wid * QC * 64 + lane;
     const unsigned long long TAGMASK = (1ull << SR_TAGBITS) - 1ull;
     // (score, item) -> sortable key; key -> score / item
     auto make_key = [&](float v, int it) -> double {
@@ -430,7 +436,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
         for (int j = 0; j < KR; ++j) lk[j] = KEMPTY;
         float thr = (user < B && dbg != 1 && (dbg < 5 || dbg == 7 || dbg == 8)) ? -INFINITY : INFINITY;
         float gbound = -INFINITY;   // the shared bound as last read
-        unsigned genc = 0u;         // ... and the word in flight
+        unsigned genc = 0u;         // ... and the word in flight (split form: score_bound_k's estimate is there before the first stage)
+        if (X2 && gthr && user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int qn = 0;
         bool quiet = false;   // the last half tile had no hit in any lane (wave-uniform)
         // LDS byte address of the queue tail (= qbase + 256 * qn) and the running item id of the next accumulator register
@@ -468,6 +475,33 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 if (lane == 0) { atomicAdd(&g_sr_counters[0], 1ull); atomicAdd(&g_sr_counters[1], (unsigned long long)rounds); }
                 atomicAdd(&g_sr_counters[2], (unsigned long long)qn);
             }
+            if constexpr (X2) {
+                // Split form: ONE list of 2 KR entries per user and segment, shared by the user's two lanes -- lane h = 0 holds ranks
+                // 0 .. KR-1, lane h = 1 ranks KR .. 2KR-1 (56 f64 keys per lane instead of 112: the kernel stays out of scratch
+                // memory, whose traffic had put a wait in front of every staged item tile).  A round folds in both lanes' queue
+                // entries: the lower lane inserts its own entry and the partner's into its half; what falls off its end (o1, o2)
+                // goes to the upper lane, which inserts it ONE ROUND LATER (same instruction stream for both lanes: "insert a,
+                // insert b" with (a, b) = (own, partner's) below and (o1, o2 of the round before) above), plus one flush round.
+                double o1 = KEMPTY, o2 = KEMPTY;
+#pragma unroll 1
+                for (int e = 0; e <= rounds; ++e) {
+                    const int qid_e = e < QC ? myqi[e * 64] : -1;
+                    const bool act = e < qn && (unsigned)qid_e < (unsigned)N;
+                    const double k = act ? make_key(myqv[e * 64], qid_e) : KEMPTY;
+                    const double kp = __shfl_xor(k, 32, 64), o1p = __shfl_xor(o1, 32, 64), o2p = __shfl_xor(o2, 32, 64);
+                    const double a = h ? o1p : k, b = h ? o2p : kp;
+                    double last = lk[KR - 1];
+#pragma unroll
+                    for (int j = KR - 1; j >= 1; --j) lk[j] = sr_max(lk[j], sr_min(a, lk[j - 1]));
+                    lk[0] = sr_max(a, lk[0]);
+                    o1 = sr_min(last, a);
+                    last = lk[KR - 1];
+#pragma unroll
+                    for (int j = KR - 1; j >= 1; --j) lk[j] = sr_max(lk[j], sr_min(b, lk[j - 1]));
+                    lk[0] = sr_max(b, lk[0]);
+                    o2 = sr_min(last, b);
+                }
+            } else
 #pragma unroll 1
             for (int e = 0; e < rounds; ++e) {   // ONE copy of the insertion code: the kernel must stay inside the I-cache
                 const int qid_e = myqi[e * 64];
@@ -485,8 +519,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 // close to the true K-th value because the halves are statistically alike -> ~40 % fewer hits.
                 double kmid = lk[0], kkth = lk[0];
                 if constexpr (KT > 0) {
-                    // the m-th of both lanes is a bound on the 2m-th best of the pair: exact form m = ceil(K/2); split form (list
-                    // capacity KT >= K + 6 is what the lists guarantee, see score_x2_capacity) m = KT/2
+                    // the m-th of both lanes is a bound on the 2m-th best of the pair: exact form m = ceil(K/2); split form (lists
+                    // of KT >= K + 6 entries, and K + 6 is what the certificate wants the bound to speak of): m = KT/2
                     constexpr int MIDX = X2 ? KT / 2 : (KT + 1) / 2;
                     kmid = lk[MIDX - 1];
                     kkth = lk[KT - 1];
@@ -499,7 +533,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 }
                 const float mid = key_value(kmid), kth = key_value(kkth);
                 const float pmid = __shfl_xor(mid, 32, 64), pkth = __shfl_xor(kth, 32, 64);
-                thr = fmaxf(fmaxf(kth, pkth), fminf(mid, pmid));
+                if constexpr (X2) thr = h ? kth : pkth;   // the pair list's last entry (rank 2 KR, in the upper lane): a USER-level bound
+                else thr = fmaxf(fmaxf(kth, pkth), fminf(mid, pmid));
                 if (thr <= -3.402823466e+38f) thr = -INFINITY;   // lists not full yet
                 if (dbg == 7) thr = -INFINITY;                   // (diagnostic: group bound only)
                 // Every workgroup that scores items for this user holds such a lower bound of the user's K-th best: they share
@@ -513,6 +548,21 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
             }
         };
 
+        // split form: stage st -> LDS buffer buf.  Instruction p of wave wid fills the 1 KB block (4 p + wid) of the buffer, lane l its
+        // 16-byte slot l: rows are 256 bytes, so that is chunk position l & 15 of row 16 p + 4 wid + (l >> 4), which holds the row's
+        // chunk (l & 15) ^ (row & 15).
+        auto issue_stage = [&](int64_t st, int buf) {
+            const int ldrow = 4 * wid + (lane >> 4);
+            const int g = (lane & 15) ^ (ldrow & 15);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int64_t row = st * SC_TI + p * 16 + ldrow;
+                const float* src = E + (row < N ? row : N - 1) * D + 4 * g;
+                __attribute__((address_space(3))) unsigned char* dst =
+                    (__attribute__((address_space(3))) unsigned char*)(__attribute__((address_space(3))) float*)tile + buf * (SC_TI * D * 4) + (4 * p + wid) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, dst, 16, 0, 0);
+            }
+        };
         float4 pf[PF];
         auto prefetch = [&](int64_t st) {
             const int64_t item0 = st * SC_TI;
@@ -523,7 +573,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 pf[p] = reinterpret_cast<const float4*>(E + (row < N ? row : N - 1) * D)[f % (D / 4)];
             }
         };
-        prefetch(st0);
+        if constexpr (X2) issue_stage(st0, 0); else prefetch(st0);
 
         // Drains are WORKGROUP-wide where possible: the four waves share the stage barriers, so a wave draining alone stalls
         // the other three at the next barrier (measured: drain time x ~3).  The vote rides on the stage's first barrier (each
@@ -541,11 +591,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
             SC_T(if (prof) t0 = __builtin_readcyclecounter();)
             if (lane == 0) vote[wid] = 0;
             if (qn > vote_at) vote[wid] = 1;
+            if constexpr (X2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the stage has landed in LDS
 #ifndef SC_X_NOBARRIER
             __syncthreads();
 #endif
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); ta += t1 - t0; t0 = t1; })
             const bool wg_drain = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
+            [[maybe_unused]] const int buf = (int)(st - st0) & 1;
+            if constexpr (!X2)
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
                 const int f = p * 256 + tid;
@@ -565,7 +618,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
             }
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); tb += t1 - t0; t0 = t1; })
 #ifndef SC_X_NOBARRIER
-            __syncthreads();
+            if constexpr (!X2) __syncthreads();   // (split form: one barrier per stage -- the other buffer is being filled, not this one)
 #endif
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); tc += t1 - t0; t0 = t1; })
 #ifndef SC_X_NOREFILL
@@ -581,7 +634,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 }
             }
 #ifndef SC_X_NOPREFETCH
-            prefetch(st + 1 < st1 ? st + 1 : st);
+            if constexpr (X2) { if (st + 1 < st1) issue_stage(st + 1, buf ^ 1); }
+            else prefetch(st + 1 < st1 ? st + 1 : st);
 #endif
             // The tile loop, in HALF tiles (16 items = accumulator registers 0-7 / 8-15): one queue-room check -- and the only
             // in-loop copy of the drain code -- serves both halves; the MFMA chain runs in the even iterations.
@@ -591,7 +645,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 const int64_t item0 = st * SC_TI + (ht >> 1) * 32;   // first item of the tile
                 if (item0 >= N) break;
                 // a half tile appends up to 8 entries per lane: make room now (while the lists fill up, or after a burst)
-                if (__ballot(qn > SR_QC - 8) != 0ull) {
+                if (__ballot(qn > QC - 8) != 0ull) {
                     drain();
                     qaddr = qbase;
                 }
@@ -610,7 +664,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                      SR_APPEND1("%9", "", 1) SR_APPEND1("%10", "", 1) SR_APPEND1("%11", "", 1) SR_APPEND1("%12", "", 5)           \
                  : "+v"(qn), "+v"(qaddr), "+v"(qid)                                                                             \
                  : "v"(thr), "v"(qbase), "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(A4), "v"(A5), "v"(A6), "v"(A7),                 \
-                   [qoff] "i"(4 * SR_QC)                                                                                        \
+                   [qoff] "i"(4 * QC)                                                                                           \
                  : "vcc", "memory")
                 const int qn0 = qn;
                 auto void_seen = [&]() {   // seen cursor: two ids prefetched per stage, one id per lane per pass
@@ -639,28 +693,31 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                     if constexpr (X2) {
                         // lane (c, h) holds item row c, k = 16 s + 8 h + (0..7): 16 bytes at float offset 8 s + 4 h of a plane
                         // (rows are 4 D + 16 bytes apart: the 16 lanes of a ds_read_b128 pass hit 16 different 16-byte bank groups)
-                        const float* xrow = tile + ((ht >> 1) * 32 + c) * RSF + 4 * h;
-                        float4 ah[NS16], am[NS16];
+                        // row (ht >> 1) * 32 + c of buffer buf; chunk j of a row sits at position j ^ (row & 15) = j ^ (c & 15)
+                        const char* xbase = reinterpret_cast<const char*>(tile) + buf * (SC_TI * D * 4) + ((ht >> 1) * 32 + c) * (D * 4);
+                        const int c15 = c & 15;
+                        // Two passes over one set of fragment registers: first the hi plane (products hi.hi and hi.mid), then the mid
+                        // plane (mid.hi).  All NS16 reads of a pass are in flight together (one wait; left alone, the register
+                        // allocator funnels them through one register quad and exposes an LDS round trip in front of every other
+                        // MFMA), and NS16 instead of 2 NS16 quads are live beside the lists.
+                        float4 af[NS16];
+#pragma unroll
+                        for (int s = 0; s < NS16; ++s) af[s] = *reinterpret_cast<const float4*>(xbase + (((2 * s + h) ^ c15) << 4));
+#pragma unroll
+                        for (int s = 0; s < NS16; ++s) asm volatile("" : "+v"(af[s].x), "+v"(af[s].y), "+v"(af[s].z), "+v"(af[s].w));
 #pragma unroll
                         for (int s = 0; s < NS16; ++s) {
-                            ah[s] = *reinterpret_cast<const float4*>(xrow + 8 * s);
-                            am[s] = *reinterpret_cast<const float4*>(xrow + KH + 8 * s);
-                        }
-                        // all 2 NS16 fragment reads in flight together, ONE wait: left alone, the register allocator funnels them
-                        // through one register quad and exposes an LDS round trip in front of every other MFMA
-#pragma unroll
-                        for (int s = 0; s < NS16; ++s) {
-                            asm volatile("" : "+v"(ah[s].x), "+v"(ah[s].y), "+v"(ah[s].z), "+v"(ah[s].w));
-                            asm volatile("" : "+v"(am[s].x), "+v"(am[s].y), "+v"(am[s].z), "+v"(am[s].w));
+                            const bf16x8 xh = __builtin_bit_cast(bf16x8, af[s]);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqm[s]), acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
                         }
 #pragma unroll
-                        for (int s = 0; s < NS16; ++s) {
-                            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[s]), xm = __builtin_bit_cast(bf16x8, am[s]);
-                            const bf16x8 yh = __builtin_bit_cast(bf16x8, bqh[s]), ym = __builtin_bit_cast(bf16x8, bqm[s]);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
-                        }
+                        for (int s = 0; s < NS16; ++s) af[s] = *reinterpret_cast<const float4*>(xbase + (((8 + 2 * s + h) ^ c15) << 4));
+#pragma unroll
+                        for (int s = 0; s < NS16; ++s) asm volatile("" : "+v"(af[s].x), "+v"(af[s].y), "+v"(af[s].z), "+v"(af[s].w));
+#pragma unroll
+                        for (int s = 0; s < NS16; ++s)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
                     } else {
 #pragma unroll
                     for (int q = 0; q < KH / 4; ++q) {
@@ -735,7 +792,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
         // Split form: the lists are SHORTER than the K the caller wants (capacity K here = c, see score_topk_impl), so what a lane
         // has dropped matters: everything it filtered out was below its threshold of the moment, everything its list pushed out
         // is below the list's last entry -- both <= the final threshold, which goes out with the list (score_topk_merge_x).
-        if (part_T && user < B) part_T[(user * maxseg + seg) * 2 + h] = thr;
+        if (part_T && user < B && h == 0) part_T[user * maxseg + seg] = thr;
         // The two partial lists of every user (K values + K ids per lane).  Written lane by lane this is 2K scattered 4-byte
         // stores per lane (64 cache lines per store instruction: 11 % of the kernel on the Beauty shape, scripts ablation
         // SC_X_NOOUTPUT); instead the wave transposes them through its (now empty) queue memory and writes each user's
@@ -746,12 +803,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
         {
 #endif
             const int K2 = 2 * K;
-            float* ldsA = qv + wid * SR_QC * 64;                                  // 2 x SR_QC*64 floats of wave-private LDS
-            float* ldsB = reinterpret_cast<float*>(qi + wid * SR_QC * 64);
+            float* ldsA = qv + wid * QC * 64;                                  // 2 x QC*64 floats of wave-private LDS
+            float* ldsB = reinterpret_cast<float*>(qi + wid * QC * 64);
             const int64_t user0 = ub * SC_USERS + wid * 32;                        // the wave's first user
             const int64_t ustride = (int64_t)maxseg * K2;                          // floats between consecutive users
             const int64_t gbase = (user0 * maxseg + seg) * K2;
-            if ((K & 1) == 0 && 64 * K <= 2 * SR_QC * 64) {
+            if ((K & 1) == 0 && 64 * K <= 2 * QC * 64) {
 #pragma unroll 1
                 for (int pass = 0; pass < 2; ++pass) {
                     const int f0 = c * K2 + h * K;
@@ -760,7 +817,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                         if (j < K) {
                             const bool empty = lk[j] == KEMPTY;
                             const int f = f0 + j;
-                            float* slot = f < SR_QC * 64 ? ldsA + f : ldsB + (f - SR_QC * 64);
+                            float* slot = f < QC * 64 ? ldsA + f : ldsB + (f - QC * 64);
                             if (pass == 0) *slot = empty ? -INFINITY : key_value(lk[j]);
                             else *reinterpret_cast<int*>(slot) = empty ? -1 : key_item(lk[j]);
                         }
@@ -768,7 +825,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                     for (int i = lane; i < 16 * K; i += 64) {      // 32 users x 2K floats = 16K float4
                         const int f = 4 * i;
                         const int cc = f / K2, e = f - cc * K2;
-                        const float* slot = f < SR_QC * 64 ? ldsA + f : ldsB + (f - SR_QC * 64);
+                        const float* slot = f < QC * 64 ? ldsA + f : ldsB + (f - QC * 64);
                         if (user0 + cc < B) *reinterpret_cast<float4*>(gdst + cc * ustride + e) = *reinterpret_cast<const float4*>(slot);
                     }
                 }
@@ -932,6 +989,62 @@ __global__ __launch_bounds__(256) void score_split_k(const float* __restrict__ X
     }
 }
 
+// score_bound_k: a starting threshold for every user from a strided SAMPLE of the catalog (n = 32 n_tiles items, every
+// stride-th row of the split table), before the main kernel runs.  Nearly all list insertions of the main kernel are warm-up:
+// every (segment, lane) list starts empty and lets through ~K ln(n/K) items before its own bound is any good (measured on
+// Beauty: ~1300 insertions per user for 56 final entries).  The r-th best score of a sample that holds a fraction f of the
+// catalog sits near catalog rank r/f; with r = (K + 6) f + 4.5 sqrt((K + 6) f) + 2 fewer than 1 user in 10^4 has r or more
+// of its best K + 6 items inside the sample, i.e. a bound above its (K + 6)-th best score.  The bound need not be valid: it
+// is a filter threshold like any other, it is part of the dropped-below bound T the lists report, and a user for whom it was
+// too high fails the certificate in score_topk_merge_x and is redone exactly.  (Only the split form may do this.)
+// One wave = 32 users; per tile 3 D/16 MFMAs and 16 sorted insertions into the lane's best-8 list (v_med3 per slot); the
+// bound is the smaller of the pair's two rhalf-th bests (2 rhalf items of the sample are at least that good).
+template <int D>
+__global__ __launch_bounds__(256) void score_bound_k(const float* __restrict__ Qs, const float* __restrict__ Es, int64_t B,
+                                                     int n_tiles, int64_t stride, int rhalf, unsigned* __restrict__ gthr) {
+    constexpr int NS16 = D / 16;
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int64_t user = (int64_t)blockIdx.x * SC_USERS + (threadIdx.x >> 6) * 32 + c;
+    float4 bqh[NS16], bqm[NS16];
+    {
+        const float4* qrow = reinterpret_cast<const float4*>(Qs + user * D);
+        const bool uok = user < B;
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) {
+            bqh[s] = uok ? qrow[2 * s + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+            bqm[s] = uok ? qrow[D / 8 + 2 * s + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = -INFINITY;
+    for (int t = 0; t < n_tiles; ++t) {
+        const float4* xr = reinterpret_cast<const float4*>(Es + ((int64_t)(t * 32 + c) * stride) * D);   // the lane's A row
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, xr[2 * s + h]), xm = __builtin_bit_cast(bf16x8, xr[D / 8 + 2 * s + h]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqm[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+#pragma unroll
+            for (int j = 7; j >= 1; --j) l[j] = __builtin_amdgcn_fmed3f(v, l[j], l[j - 1]);   // clamp(v, l[j], l[j-1]): sorted insertion
+            l[0] = fmaxf(v, l[0]);
+        }
+    }
+    float mine = l[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) mine = (j == rhalf - 1) ? l[j] : mine;
+    const float bound = fminf(mine, __shfl_xor(mine, 32, 64));
+    if (h == 0 && user < B && bound > -INFINITY) gthr[user] = sr_enc(bound);
+}
+
 // score_topk_merge_x: one wave per user.  The split kernel leaves, per (user, segment, lane half), a list of its C best items
 // by APPROXIMATE score s' and the bound t below which it dropped everything else (its final threshold).
 // (1) Merge the user's lists into the best 64 by (s', lowest id).  Every item of the catalog that is not among them has
@@ -968,8 +1081,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
     if (user >= B) return;
     const int64_t ub = user / SC_USERS;
     const int64_t w0 = (ub * nst) / upw, w1 = ((ub + 1) * nst - 1) / upw;
-    const int nseg = (int)(w1 - w0 + 1) * 2;
-    maxseg *= 2;
+    const int nseg = (int)(w1 - w0 + 1);   // one pair list per segment
     const int PAD = 0x7FFFFFFF;
     float bv = -INFINITY;
     int bi = PAD;
@@ -1068,7 +1180,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
     if (!(mxd & 4)) bitonic_sort64(sx, bi, lane);
     const float xk = __shfl(sx, K - 1, 64);
     const bool validk = __shfl(bi, K - 1, 64) != PAD;
-    const bool pass = T == -INFINITY || (validk && (double)xk > (double)T + eps);   // (T = -inf: nothing was ever dropped)
+    const bool pass = T == -INFINITY || (validk && (double)xk > (double)T + eps) || mxd != 0;   // (T = -inf: nothing was ever dropped)
     if (!pass) {
         if (lane == 0) {
             userflag[user] = 1; blockflag[ub] = 1; atomicAdd(&g_sx_stats[0], 1u);
@@ -1133,6 +1245,8 @@ static size_t score_lds_bytes(int D, int K, bool topk) {
 
 static int g_score_x2 = 1;      // the split (bf16 hi/mid on the XDL pipe + exact re-scoring) fast path; 0 = exact kernel only
 extern "C" void re_dbg_score_x2(int on) { g_score_x2 = on; }
+static int g_score_sample = 1;   // split form: starting thresholds from a catalog sample (0: A/B switch, scripts/x2_check.py)
+extern "C" void re_dbg_score_sample(int on) { g_score_sample = on; }
 static int g_score_mxdiag = 0;   // timing-only ablation of score_topk_merge_x (scripts/x2_diag.py): 1 no list merge, 2 no re-scoring, 4 no final sort
 extern "C" void re_dbg_score_mxdiag(int m) { g_score_mxdiag = m; }
 static int g_score_maxerr = 0;   // diagnostics: record max |s' - s| / eps over all re-scored candidates
@@ -1142,19 +1256,20 @@ extern "C" void re_dbg_score_x2_stats(unsigned* out2, int reset) {   // (synchro
     (void)hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_sx_stats), 8);
     if (reset) { unsigned z[2] = {0u, 0u}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sx_stats), z, 8); }
 }
-// List capacity of the split form: the smallest instantiated capacity (16, 24, 32, 56) >= K + 6.  A lane's list must be able to
-// hold MORE than the user's whole top K: the top K of a user routinely sit in one list (popular items have neighbouring ids
-// -- with the bench's Zipf-by-id popularity, the best 50 of every trained user are inside the first 64 ids, i.e. one stage,
-// two lanes), and a list that overflows with them raises its dropped-below bound above the K-th best score, which fails
-// the certificate.  Shorter lists (a lane's statistical share of the top K) were measured: 9 % faster on iid scores, every
-// user in the fallback on the trained state.  Re-ordering the catalog so that id runs spread over the lists would need the
-// seen lists in that order too.
-#define SX_MAX_PREP_BYTES (16ll << 30)   // re_score_topk splits the table into its workspace only up to this size (else: exact path)
+// List capacity of the split form: the smallest instantiated capacity (16, 32, 56) >= K + 6.  A lane's list must be able to
+// hold MORE than the user's whole top K: the best K of a user routinely sit in one list (popular items have neighbouring ids
+// -- with the bench's Zipf-by-id popularity the best 50 of every trained user are inside the first 64 ids: one stage, two
+// lanes), and a list that overflows with them raises its dropped-below bound above the K-th best score, which fails the
+// certificate.  Tried on the way: lists as long as a lane's statistical share of the top K (capacity 24: 0.53 ms
+// instead of 0.72 on iid scores, every user in the fallback on the trained state); class-strided stage order to spread id
+// runs over the segments (a run inside one 64-item stage still lands in two lanes, and the seen cursor then walks every id
+// of the user in every segment); 32-entry lists under a pair-level bound with an overflow log for what falls off (the
+// pair's K + 6 best split 28 +- 4 between the lanes: the log floods).
 static int score_x2_capacity(const ScorePlan& p, int64_t K) {
     (void)p;
-    const int64_t need = K + 6;
-    return need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 56;
+    return K + 6 <= 16 ? 16 : K + 6 <= 32 ? 32 : 56;
 }
+#define SX_MAX_PREP_BYTES (16ll << 30)   // re_score_topk splits the table into its workspace only up to this size (else: exact path)
 static bool score_use_reg(const ScorePlan& p, int64_t N, int64_t D, int64_t K) {
     return g_score_pop == 3 && (D == 64 || D == 128) && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1;
 }
@@ -1174,7 +1289,7 @@ struct ScoreWs {   // carving of re_score_topk's workspace
 };
 static ScoreWs score_ws(int64_t B, int64_t N, int64_t D, int64_t K, const ScorePlan& p, bool x2, bool own_prep) {
     ScoreWs w;
-    const int64_t kk = x2 ? 56 : K;   // (x2: any list capacity, and the exact fallback's K <= 50)
+    const int64_t kk = x2 ? 56 : K;   // (x2: list capacity <= 56, and the exact fallback's K <= 50)
     int64_t segs = p.maxseg;
     if (x2) { const ScorePlan pfb = score_plan(B, N, D); if (pfb.maxseg > segs) segs = pfb.maxseg; }
     w.half = re_align((size_t)p.nub * SC_USERS * segs * 2 * kk * 4);     // up to 2 lists per (user, segment)
@@ -1284,11 +1399,12 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
     // many workgroups as scored it the first time; when nobody is flagged, the normal case, what it costs is its dispatch)
     const ScorePlan pfb = score_plan(B, N, D);
     const ScorePlan* lp = &p;
-#define SR_LAUNCH(DV, KRV, KTV, X2V, QP, EP, KV, GT, BF, PT)                                                                        \
+#define SR_LAUNCH(DV, KRV, KTV, X2V, QP, EP, KV, GT, BF, PT)                                                                \
     do {                                                                                                                             \
         auto kern = score_kernel_reg<DV, KRV, KTV, X2V>;                                                                             \
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RE_ELAUNCH; \
-        hipLaunchKernelGGL(kern, dim3(lp->nwg), dim3(256), lds, s, QP, EP, B, N, seen_ptr, seen_idx, (int)(KV), pv, pi, lp->maxseg, lp->nub, \
+        const size_t ldsb = (X2V) ? lds_x2 : lds;                                                                                   \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH; \
+        hipLaunchKernelGGL(kern, dim3(lp->nwg), dim3(256), ldsb, s, QP, EP, B, N, seen_ptr, seen_idx, (int)(KV), pv, pi, lp->maxseg, lp->nub, \
                            lp->nst, lp->upw, GT, g_score_dbg, BF, PT);                                                                       \
     } while (0)
     // register-list variant: many users per launch (its two lists per segment double the merge work, which dominates
@@ -1296,6 +1412,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
     if (score_use_reg(p, N, D, K)) {
         lps = 2;
         const size_t lds = (size_t)SC_TI * (D + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
+        const size_t lds_x2 = (size_t)2 * SC_TI * D * 4 + (size_t)4 * 20 * 64 * 8;   // split form: two unpadded stage buffers, 20-entry queues
         if (re_zero_async(gthr, w.n_zero, s) != hipSuccess) return RE_ELAUNCH;
         if (!g_score_share) gthr = nullptr;
         const int* blockflag = nullptr;
@@ -1321,14 +1438,28 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             }
             rc = D == 64 ? score_split_launch<64>(Q, B, Qs, qnorm, nullptr, s) : score_split_launch<128>(Q, B, Qs, qnorm, nullptr, s);
             if (rc != RE_OK) return rc;
+            // starting thresholds from a sample (score_bound_k): n = N/16 items (512 .. 4096), every stride-th row
+            if (gthr && g_score_sample) {
+                int64_t n = N / 16;
+                n = n < 512 ? 512 : n > 4096 ? 4096 : n;
+                if (n > N) n = N;
+                n &= ~31ll;
+                const int64_t stride = n > 0 ? N / n : 1;
+                const double m = (double)(K + 6) * (double)n / (double)N;
+                int r = (int)ceil(m + 4.5 * sqrt(m) + 2.0);
+                r += r & 1;
+                if (n >= 32 && r <= 16) {
+                    hipLaunchKernelGGL(score_bound_k<64>, dim3((unsigned)p.nub), dim3(256), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
+                    if ((rc = re_launch_status()) != RE_OK) return rc;
+                }
+            }
             const int C = score_x2_capacity(p, K);
             float* pt = (float*)((char*)ws + w.off_pt);
 #define SX_LAUNCH(DV)                                                                          \
-    do {                                                                                       \
-        if (C == 16) SR_LAUNCH(DV, 16, 16, true, Qs, Es, 16, gthr, nullptr, pt);               \
-        else if (C == 24) SR_LAUNCH(DV, 24, 24, true, Qs, Es, 24, gthr, nullptr, pt);          \
-        else if (C == 32) SR_LAUNCH(DV, 32, 32, true, Qs, Es, 32, gthr, nullptr, pt);          \
-        else SR_LAUNCH(DV, 56, 56, true, Qs, Es, 56, gthr, nullptr, pt);                       \
+    do {   /* per-lane length = half the pair list's capacity */                               \
+        if (C == 16) SR_LAUNCH(DV, 8, 8, true, Qs, Es, 8, gthr, nullptr, pt);                  \
+        else if (C == 32) SR_LAUNCH(DV, 16, 16, true, Qs, Es, 16, gthr, nullptr, pt);          \
+        else SR_LAUNCH(DV, 28, 28, true, Qs, Es, 28, gthr, nullptr, pt);                       \
     } while (0)
             SX_LAUNCH(64);
 #undef SX_LAUNCH
