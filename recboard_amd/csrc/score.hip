@@ -997,14 +997,14 @@ __global__ __launch_bounds__(256) void score_split_k(const float* __restrict__ X
 // of its best K + 6 items inside the sample, i.e. a bound above its (K + 6)-th best score.  The bound need not be valid: it
 // is a filter threshold like any other, it is part of the dropped-below bound T the lists report, and a user for whom it was
 // too high fails the certificate in score_topk_merge_x and is redone exactly.  (Only the split form may do this.)
-// One wave = 32 users; per tile 3 D/16 MFMAs and 16 sorted insertions into the lane's best-8 list (v_med3 per slot); the
+// One wave (= one workgroup) = 32 users; per tile 3 D/16 MFMAs and 16 sorted insertions into the lane's best-8 list (v_med3 per slot); the
 // bound is the smaller of the pair's two rhalf-th bests (2 rhalf items of the sample are at least that good).
 template <int D>
-__global__ __launch_bounds__(256) void score_bound_k(const float* __restrict__ Qs, const float* __restrict__ Es, int64_t B,
-                                                     int n_tiles, int64_t stride, int rhalf, unsigned* __restrict__ gthr) {
+__global__ __launch_bounds__(64) void score_bound_k(const float* __restrict__ Qs, const float* __restrict__ Es, int64_t B,
+                                                    int n_tiles, int64_t stride, int rhalf, unsigned* __restrict__ gthr) {
     constexpr int NS16 = D / 16;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const int64_t user = (int64_t)blockIdx.x * SC_USERS + (threadIdx.x >> 6) * 32 + c;
+    const int64_t user = (int64_t)blockIdx.x * 32 + c;   // one wave per workgroup: B/32 workgroups fill the chip
     float4 bqh[NS16], bqm[NS16];
     {
         const float4* qrow = reinterpret_cast<const float4*>(Qs + user * D);
@@ -1018,17 +1018,24 @@ __global__ __launch_bounds__(256) void score_bound_k(const float* __restrict__ Q
     float l[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) l[j] = -INFINITY;
+    float4 xh[NS16], xm[NS16], nh[NS16], nm[NS16];
+    auto fetch = [&](int t, float4* fh, float4* fm) {   // the lane's A row of tile t: item (32 t + c) * stride
+        const float4* xr = reinterpret_cast<const float4*>(Es + ((int64_t)(t * 32 + c) * stride) * D);
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) { fh[s] = xr[2 * s + h]; fm[s] = xr[D / 8 + 2 * s + h]; }
+    };
+    fetch(0, xh, xm);
     for (int t = 0; t < n_tiles; ++t) {
-        const float4* xr = reinterpret_cast<const float4*>(Es + ((int64_t)(t * 32 + c) * stride) * D);   // the lane's A row
+        fetch(t + 1 < n_tiles ? t + 1 : t, nh, nm);   // (in flight under this tile's MFMAs and insertions)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int s = 0; s < NS16; ++s) {
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, xr[2 * s + h]), xm = __builtin_bit_cast(bf16x8, xr[D / 8 + 2 * s + h]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqm[s]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, xh[s]), am = __builtin_bit_cast(bf16x8, xm[s]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bqm[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1037,6 +1044,8 @@ __global__ __launch_bounds__(256) void score_bound_k(const float* __restrict__ Q
             for (int j = 7; j >= 1; --j) l[j] = __builtin_amdgcn_fmed3f(v, l[j], l[j - 1]);   // clamp(v, l[j], l[j-1]): sorted insertion
             l[0] = fmaxf(v, l[0]);
         }
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) { xh[s] = nh[s]; xm[s] = nm[s]; }
     }
     float mine = l[0];
 #pragma unroll
@@ -1125,12 +1134,8 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
     // slice, MX_ROWS rows per pass (a lane reading its own row from global memory touches 64 cache lines per load
     // instruction).  LDS rows are D + 4 floats apart (conflict-free float4 reads down a column of rows).
     float* stage = mx_stage + (threadIdx.x >> 6) * (MX_ROWS * RS);
-    float4 qr[LPR];   // the query row, once (every lane holds it)
-    {
-        const float4* q4 = reinterpret_cast<const float4*>(Q + user * D);
-#pragma unroll
-        for (int k = 0; k < LPR; ++k) qr[k] = q4[k];
-    }
+    // the query row: the user is the wave's, so the row comes in through scalar loads and the chain multiplies by scalar registers
+    const float* qrow = Q + (int64_t)__builtin_amdgcn_readfirstlane((int)user) * D;
     constexpr int NLD = 64 * LPR / 64;   // float4 loads per lane for 64 rows
     float4 rowreg[NLD];
 #pragma unroll
@@ -1161,10 +1166,10 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
 #pragma unroll
                 for (int k = 0; k < LPR; ++k) {
                     const float4 e = e4[k];
-                    acc = fmaf(qr[k].x, e.x, acc);
-                    acc = fmaf(qr[k].y, e.y, acc);
-                    acc = fmaf(qr[k].z, e.z, acc);
-                    acc = fmaf(qr[k].w, e.w, acc);
+                    acc = fmaf(qrow[4 * k + 0], e.x, acc);
+                    acc = fmaf(qrow[4 * k + 1], e.y, acc);
+                    acc = fmaf(qrow[4 * k + 2], e.z, acc);
+                    acc = fmaf(qrow[4 * k + 3], e.w, acc);
                 }
                 sx = acc + 0.0f;   // (-0 -> +0, like the list keys of the exact kernel)
             }
@@ -1177,7 +1182,14 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
         const float ratio = (float)(fabs((double)sx - (double)bv) / eps);
         atomicMax(&g_sx_stats[1], __float_as_uint(ratio));
     }
-    if (!(mxd & 4)) bitonic_sort64(sx, bi, lane);
+    // The candidates arrive in the order of their approximate scores, which is almost always the exact order too: sort only if
+    // some neighbour pair is out of order (a near-tie inside the error bound: a few users in a hundred).
+    {
+        const float nv = __shfl_down(sx, 1, 64);
+        const int ni = __shfl_down(bi, 1, 64);
+        const bool inverted = lane < 63 && sc_before(nv, ni, sx, bi);
+        if (__ballot(inverted) != 0ull && !(mxd & 4)) bitonic_sort64(sx, bi, lane);
+    }
     const float xk = __shfl(sx, K - 1, 64);
     const bool validk = __shfl(bi, K - 1, 64) != PAD;
     const bool pass = T == -INFINITY || (validk && (double)xk > (double)T + eps) || mxd != 0;   // (T = -inf: nothing was ever dropped)
@@ -1449,7 +1461,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
                 int r = (int)ceil(m + 4.5 * sqrt(m) + 2.0);
                 r += r & 1;
                 if (n >= 32 && r <= 16) {
-                    hipLaunchKernelGGL(score_bound_k<64>, dim3((unsigned)p.nub), dim3(256), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
+                    hipLaunchKernelGGL(score_bound_k<64>, dim3((unsigned)re_cdiv(B, 32)), dim3(64), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
                     if ((rc = re_launch_status()) != RE_OK) return rc;
                 }
             }
