@@ -29,6 +29,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SC_USERS 128   // users per workgroup (4 waves x 32)
 #define SC_TI 64       // items per LDS stage (2 MFMA tiles)
@@ -468,9 +469,11 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
 
         // fold every lane's queue into its register list: round e = entry e of every queue
         auto drain = [&]() {
-            int rounds = (dbg == 2) ? 0 : qn;
+            int rounds = 0;   // max over the wave of qn (< 32): bit by bit with ballots -- no cross-lane data movement
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o, 64));
+            for (int bit = 16; bit > 0; bit >>= 1)
+                if (__ballot(qn >= (rounds | bit)) != 0ull) rounds |= bit;
+            if (dbg == 2) rounds = 0;
             if (dbg == 3 || dbg == 7) {
                 if (lane == 0) { atomicAdd(&g_sr_counters[0], 1ull); atomicAdd(&g_sr_counters[1], (unsigned long long)rounds); }
                 atomicAdd(&g_sr_counters[2], (unsigned long long)qn);
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 pf[p] = reinterpret_cast<const float4*>(E + (row < N ? row : N - 1) * D)[f % (D / 4)];
             }
         };
-        if constexpr (X2) issue_stage(st0, 0); else prefetch(st0);
+        if constexpr (X2) { refill(); issue_stage(st0, 0); } else prefetch(st0);
 
         // Drains are WORKGROUP-wide where possible: the four waves share the stage barriers, so a wave draining alone stalls
         // the other three at the next barrier (measured: drain time x ~3).  The vote rides on the stage's first barrier (each
@@ -622,15 +625,18 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
 #endif
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); tc += t1 - t0; t0 = t1; })
 #ifndef SC_X_NOREFILL
-            refill();
+            if constexpr (!X2) refill();
 #endif
             // the shared bound: fold in the word requested one stage ago (no wait), request the next one -- before the item
-            // prefetch, like the seen window, so that its wait leaves the prefetch in flight
+            // prefetch, like the seen window, so that its wait leaves the prefetch in flight.
+            // Split form: the seen window and the bound word of stage s + 1 are requested at the END of stage s (below) and are
+            // first touched after the wait at the top of stage s + 1 -- the memory counter retires in order, and any wait for
+            // them in the middle of a stage would also wait for the stage loads issued just after them.
             if (gthr) {
                 gbound = fmaxf(gbound, sr_dec(genc));
                 thr = fmaxf(thr, gbound);
-                if (user < B) {
-                    genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (!X2) {
+                    if (user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
 #ifndef SC_X_NOPREFETCH
@@ -700,21 +706,27 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                         // plane (mid.hi).  All NS16 reads of a pass are in flight together (one wait; left alone, the register
                         // allocator funnels them through one register quad and exposes an LDS round trip in front of every other
                         // MFMA), and NS16 instead of 2 NS16 quads are live beside the lists.
-                        float4 af[NS16];
-#pragma unroll
-                        for (int s = 0; s < NS16; ++s) af[s] = *reinterpret_cast<const float4*>(xbase + (((2 * s + h) ^ c15) << 4));
-#pragma unroll
-                        for (int s = 0; s < NS16; ++s) asm volatile("" : "+v"(af[s].x), "+v"(af[s].y), "+v"(af[s].z), "+v"(af[s].w));
+                        // The reads are inline asm: the compiler orders every LDS read it knows about behind ALL outstanding
+                        // global->LDS loads (s_waitcnt vmcnt(0) -- it cannot see that the next stage's loads fill the OTHER buffer),
+                        // which would put the whole load latency in front of every tile.
+                        static_assert(NS16 == 4, "split form: D = 64");
+                        f32x4 af[NS16];
+                        const unsigned xb = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)xbase;
+#define SX_FRAGS(J0)                                                                                                              \
+    asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %6\n ds_read_b128 %3, %7\n s_waitcnt lgkmcnt(0)"      \
+                 : "=&v"(af[0]), "=&v"(af[1]), "=&v"(af[2]), "=&v"(af[3])                                                          \
+                 : "v"(xb + ((((J0) + 0 + h) ^ c15) << 4)), "v"(xb + ((((J0) + 2 + h) ^ c15) << 4)),                               \
+                   "v"(xb + ((((J0) + 4 + h) ^ c15) << 4)), "v"(xb + ((((J0) + 6 + h) ^ c15) << 4))                                \
+                 : "memory")
+                        SX_FRAGS(0);   // hi plane: chunks 2 s + h
 #pragma unroll
                         for (int s = 0; s < NS16; ++s) {
                             const bf16x8 xh = __builtin_bit_cast(bf16x8, af[s]);
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqm[s]), acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
                         }
-#pragma unroll
-                        for (int s = 0; s < NS16; ++s) af[s] = *reinterpret_cast<const float4*>(xbase + (((8 + 2 * s + h) ^ c15) << 4));
-#pragma unroll
-                        for (int s = 0; s < NS16; ++s) asm volatile("" : "+v"(af[s].x), "+v"(af[s].y), "+v"(af[s].z), "+v"(af[s].w));
+                        SX_FRAGS(8);   // mid plane: chunks 8 + 2 s + h
+#undef SX_FRAGS
 #pragma unroll
                         for (int s = 0; s < NS16; ++s)
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
@@ -776,6 +788,10 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 void_seen();
 #undef SR_HALF
                 SC_T(if (prof) { t1 = __builtin_readcyclecounter(); te += t1 - t0; t0 = t1; })
+            }
+            if constexpr (X2) {   // requests for the next stage (see above)
+                refill();
+                if (gthr && user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 #ifdef SC_PROFILE
