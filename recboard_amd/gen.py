@@ -66,6 +66,7 @@ class MFEngine:
     def reset_ranking_buffers(self):
         Ut, It = self.encode()
         self.ranking_buffer = (Ut.clone(), It.clone())
+        self._score_prep = ops.score_prepare(self.ranking_buffer[1])   # the item table's split planes, once per evaluation
 
     def recommend_from_full(self, users):
         Ub, Ib = self.ranking_buffer
@@ -73,7 +74,7 @@ class MFEngine:
 
     def recommend_topk(self, users, seen_ptr, seen_idx, K=50):
         Ub, Ib = self.ranking_buffer
-        return ops.score_topk(ops.gather_rows(Ub, users.reshape(-1)), Ib, seen_ptr, seen_idx, K)
+        return ops.score_topk(ops.gather_rows(Ub, users.reshape(-1)), Ib, seen_ptr, seen_idx, K, prep=getattr(self, "_score_prep", None))
 
 
 class LightGCNEngine(MFEngine):
@@ -155,3 +156,4 @@ class LightGCNEngine(MFEngine):
     def reset_ranking_buffers(self):
         ue, ie = self.encode()
         self.ranking_buffer = (ue.clone(), ie.clone())
+        self._score_prep = ops.score_prepare(self.ranking_buffer[1])

@@ -162,13 +162,21 @@ class SASRecEngine:
         with torch.no_grad():
             for k, p in self.params.items():
                 p.copy_(torch.as_tensor(sd[k]).to(self.device).view(p.shape))
+        self._score_prep = None
 
     def state_dict(self):
         return OrderedDict((k, p.detach().clone()) for k, p in self.params.items())
 
     def train(self, mode=True):
         self.training = mode
+        if mode:
+            self._score_prep = None   # the item table is about to change
         return self
+
+    def reset_ranking_buffers(self):
+        """Called by Coach.evaluate before a split's batches (freerec contract; MF-BPR/main.py:95-99 clones its tables here):
+        split the item table once for all of the split's `recommend_topk` calls (re_score_prepare)."""
+        self._score_prep = (ops.score_prepare(self.params["Item.embeddings.weight"].detach()[1:]), self.arena.step)
 
     def eval(self):
         return self.train(False)
@@ -249,7 +257,9 @@ class SASRecEngine:
         """Coach.evaluate contract fused (UniSRec/main.py:408-414): masked top-K without the B x N matrix."""
         with torch.no_grad():
             u, items = self.encode(seq)
-            return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K)
+            prep = None if self.training else getattr(self, "_score_prep", None)
+            prep = prep[0] if prep is not None and prep[1] == self.arena.step else None   # (planes of the table as it is NOW)
+            return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K, prep=prep)
 
     @staticmethod
     def batch_aux_fused(seq, pos, neg):
