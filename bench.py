@@ -123,6 +123,19 @@ def pmc_traffic(*kernels):
         return None
 
 
+def score_call_traffic():
+    """HBM bytes of one whole re_score_topk call (all its launches) from the committed PMC summary of scripts/x2_prof.py."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_v9_score_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)["re_score_topk_call"]
+        return {"hbm_bytes_per_launch": int(c["hbm_bytes_per_call"]), "algorithmic_lower_bound_bytes": int(c["algorithmic_lower_bound_bytes"]),
+                "source": "profiles/r1_v9_score_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
+                          "summed over the launches of one call)"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,7 +291,7 @@ def main():
                                             "pipe), score_topk_merge_x<64> (exact fp32 re-scoring + certificate), fallback pass",
                             "bound": "mfma", "achieved": round(tf, 2),
                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
-                            "traffic": pmc_traffic("score_kernel_reg<64, 52>"), "launch_ms": round(t_score, 4),
+                            "traffic": score_call_traffic(), "launch_ms": round(t_score, 4),
                             "work": f"2*D*B*N = {flops:.3e} FLOP per call (B={U}, N={N}, D={D}, K={K}); algorithmic fp32 FLOPs priced "
                                     f"against the fp32 MFMA peak -- the results are bit-exact fp32; the screening pass executes 3x that "
                                     f"many bf16 FLOPs = {3 * tf:.0f} TFLOP/s of the 2500 TFLOP/s bf16 peak",
