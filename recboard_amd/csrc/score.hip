@@ -958,9 +958,12 @@ __device__ __forceinline__ unsigned sx_bf16(float x) {
 }
 template <int D>
 __global__ __launch_bounds__(256) void score_split_k(const float* __restrict__ X, int64_t R, unsigned short* __restrict__ Xs,
-                                                     float* __restrict__ rownorm, unsigned* __restrict__ maxnorm) {
+                                                     float* __restrict__ rownorm, unsigned* __restrict__ maxnorm,
+                                                     uint4* __restrict__ zfill, size_t zfill_n16) {
     constexpr int LPR = D / 4;   // lanes per row (16 or 32: a wave holds whole rows)
     const int64_t total = R * LPR;
+    // side job of the query split: zero the call's flag / bound words (one launch less than a zero-fill kernel of its own)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zfill_n16; i += (size_t)gridDim.x * 256) zfill[i] = make_uint4(0u, 0u, 0u, 0u);
     float wmax = 0.0f;
     for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {
         const int64_t f = base + threadIdx.x;
@@ -1013,14 +1016,15 @@ __global__ __launch_bounds__(256) void score_split_k(const float* __restrict__ X
 // of its best K + 6 items inside the sample, i.e. a bound above its (K + 6)-th best score.  The bound need not be valid: it
 // is a filter threshold like any other, it is part of the dropped-below bound T the lists report, and a user for whom it was
 // too high fails the certificate in score_topk_merge_x and is redone exactly.  (Only the split form may do this.)
-// One wave (= one workgroup) = 32 users; per tile 3 D/16 MFMAs and 16 sorted insertions into the lane's best-8 list (v_med3 per slot); the
+// One workgroup = 32 users, two waves (even / odd sample tiles, lists joined at the end); per tile 3 D/16 MFMAs and 16 sorted insertions into the lane's best-8 list (v_med3 per slot); the
 // bound is the smaller of the pair's two rhalf-th bests (2 rhalf items of the sample are at least that good).
 template <int D>
-__global__ __launch_bounds__(64) void score_bound_k(const float* __restrict__ Qs, const float* __restrict__ Es, int64_t B,
-                                                    int n_tiles, int64_t stride, int rhalf, unsigned* __restrict__ gthr) {
+__global__ __launch_bounds__(128) void score_bound_k(const float* __restrict__ Qs, const float* __restrict__ Es, int64_t B,
+                                                     int n_tiles, int64_t stride, int rhalf, unsigned* __restrict__ gthr) {
     constexpr int NS16 = D / 16;
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const int64_t user = (int64_t)blockIdx.x * 32 + c;   // one wave per workgroup: B/32 workgroups fill the chip
+    __shared__ float lx[8 * 64];
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int64_t user = (int64_t)blockIdx.x * 32 + c;   // 32 users per workgroup, two waves: even / odd sample tiles
     float4 bqh[NS16], bqm[NS16];
     {
         const float4* qrow = reinterpret_cast<const float4*>(Qs + user * D);
@@ -1040,9 +1044,14 @@ __global__ __launch_bounds__(64) void score_bound_k(const float* __restrict__ Qs
 #pragma unroll
         for (int s = 0; s < NS16; ++s) { fh[s] = xr[2 * s + h]; fm[s] = xr[D / 8 + 2 * s + h]; }
     };
-    fetch(0, xh, xm);
-    for (int t = 0; t < n_tiles; ++t) {
-        fetch(t + 1 < n_tiles ? t + 1 : t, nh, nm);   // (in flight under this tile's MFMAs and insertions)
+    auto insert = [&](float v) {
+#pragma unroll
+        for (int j = 7; j >= 1; --j) l[j] = __builtin_amdgcn_fmed3f(v, l[j], l[j - 1]);   // clamp(v, l[j], l[j-1]): sorted insertion
+        l[0] = fmaxf(v, l[0]);
+    };
+    if (wv < n_tiles) fetch(wv, xh, xm);
+    for (int t = wv; t < n_tiles; t += 2) {
+        fetch(t + 2 < n_tiles ? t + 2 : t, nh, nm);   // (in flight under this tile's MFMAs and insertions)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -1054,20 +1063,25 @@ __global__ __launch_bounds__(64) void score_bound_k(const float* __restrict__ Qs
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = acc[r];
-#pragma unroll
-            for (int j = 7; j >= 1; --j) l[j] = __builtin_amdgcn_fmed3f(v, l[j], l[j - 1]);   // clamp(v, l[j], l[j-1]): sorted insertion
-            l[0] = fmaxf(v, l[0]);
-        }
+        for (int r = 0; r < 16; ++r) insert(acc[r]);
 #pragma unroll
         for (int s = 0; s < NS16; ++s) { xh[s] = nh[s]; xm[s] = nm[s]; }
     }
-    float mine = l[0];
+    // the odd wave hands its lists over; a list that lost entries beyond its 8 only makes the bound lower (safe side)
+    if (wv == 1) {
 #pragma unroll
-    for (int j = 1; j < 8; ++j) mine = (j == rhalf - 1) ? l[j] : mine;
-    const float bound = fminf(mine, __shfl_xor(mine, 32, 64));
-    if (h == 0 && user < B && bound > -INFINITY) gthr[user] = sr_enc(bound);
+        for (int j = 0; j < 8; ++j) lx[j * 64 + lane] = l[j];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) insert(lx[j * 64 + lane]);
+        float mine = l[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mine = (j == rhalf - 1) ? l[j] : mine;
+        const float bound = fminf(mine, __shfl_xor(mine, 32, 64));
+        if (h == 0 && user < B && bound > -INFINITY) gthr[user] = sr_enc(bound);
+    }
 }
 
 // score_topk_merge_x: one wave per user.  The split kernel leaves, per (user, segment, lane half), a list of its C best items
@@ -1386,9 +1400,11 @@ extern "C" int re_score_dense(const float* Q, const float* E, int64_t B, int64_t
 }
 
 template <int D>
-static int score_split_launch(const float* X, int64_t R, void* Xs, float* rownorm, unsigned* maxnorm, hipStream_t s) {
+static int score_split_launch(const float* X, int64_t R, void* Xs, float* rownorm, unsigned* maxnorm, hipStream_t s,
+                              void* zfill = nullptr, size_t zfill_bytes = 0) {
     // (8 rounds per workgroup where the table allows: the device-wide maximum costs one atomic per workgroup)
-    hipLaunchKernelGGL(score_split_k<D>, dim3(re_grid(R * (D / 4), maxnorm ? 2048 : 256, 2048)), dim3(256), 0, s, X, R, (unsigned short*)Xs, rownorm, maxnorm);
+    hipLaunchKernelGGL(score_split_k<D>, dim3(re_grid(R * (D / 4), maxnorm ? 2048 : 256, 2048)), dim3(256), 0, s, X, R, (unsigned short*)Xs, rownorm, maxnorm,
+                       (uint4*)zfill, zfill_bytes >> 4);
     return re_launch_status();
 }
 
@@ -1441,7 +1457,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
         lps = 2;
         const size_t lds = (size_t)SC_TI * (D + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
         const size_t lds_x2 = (size_t)2 * SC_TI * D * 4 + (size_t)4 * 20 * 64 * 8;   // split form: two unpadded stage buffers, 20-entry queues
-        if (re_zero_async(gthr, w.n_zero, s) != hipSuccess) return RE_ELAUNCH;
+        if (!x2 && re_zero_async(gthr, w.n_zero, s) != hipSuccess) return RE_ELAUNCH;   // (split form: zeroed by the query split)
         if (!g_score_share) gthr = nullptr;
         const int* blockflag = nullptr;
         if (x2) {
@@ -1454,18 +1470,20 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             float* Qs = (float*)((char*)ws + w.off_qs);
             const float* Es;
             const unsigned* emax;
+            // the query split zeroes the call's bound / flag words (n_zero is a multiple of 256 bytes) -- it runs FIRST: the item
+            // split's device-wide maximum goes into one of those words
+            rc = score_split_launch<64>(Q, B, Qs, qnorm, nullptr, s, (char*)ws + w.off_gthr, w.n_zero);
+            if (rc != RE_OK) return rc;
             if (prep) {
                 Es = (const float*)prep;
                 emax = (const unsigned*)((const char*)prep + re_align((size_t)N * D * 4));
             } else {
                 float* own = (float*)((char*)ws + w.off_prep);
-                rc = D == 64 ? score_split_launch<64>(E, N, own, nullptr, emax_own, s) : score_split_launch<128>(E, N, own, nullptr, emax_own, s);
+                rc = score_split_launch<64>(E, N, own, nullptr, emax_own, s);
                 if (rc != RE_OK) return rc;
                 Es = own;
                 emax = emax_own;
             }
-            rc = D == 64 ? score_split_launch<64>(Q, B, Qs, qnorm, nullptr, s) : score_split_launch<128>(Q, B, Qs, qnorm, nullptr, s);
-            if (rc != RE_OK) return rc;
             // starting thresholds from a sample (score_bound_k): n = N/16 items (512 .. 4096), every stride-th row
             if (gthr && g_score_sample) {
                 int64_t n = N / 16;
@@ -1477,7 +1495,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
                 int r = (int)ceil(m + 4.5 * sqrt(m) + 2.0);
                 r += r & 1;
                 if (n >= 32 && r <= 16) {
-                    hipLaunchKernelGGL(score_bound_k<64>, dim3((unsigned)re_cdiv(B, 32)), dim3(64), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
+                    hipLaunchKernelGGL(score_bound_k<64>, dim3((unsigned)re_cdiv(B, 32)), dim3(128), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
                     if ((rc = re_launch_status()) != RE_OK) return rc;
                 }
             }
