@@ -162,7 +162,7 @@ int re_bpr_triplet_fwd_bwd(const float* Ut, int64_t RU, const float* It, int64_t
  *   every user's range (duplicates allowed);
  *   seen_ptr == NULL means retain_seen.
  * Arithmetic: every returned value is the k-ordered fp32 chain acc = fmaf(q[k], e[k], acc) -- exact fp32, and the indices are
- *   the exact top K under (value, lowest index).  For D = 64 / 128 and K <= 50 the catalog is first screened with bf16 hi/mid
+ *   the exact top K under (value, lowest index).  For D = 64 / 128 and K <= 50 (many users or a long catalog) the catalog is first screened with bf16 hi/mid
  *   split products on the XDL matrix pipe (v_mfma_f32_32x32x16_bf16, 3 products per 16 k), the K + 6 best candidates of every
  *   user are re-scored exactly and the result is certified against a rigorous error bound; users that cannot be certified
  *   are redone by the exact fp32-MFMA kernel (v_mfma_f32_32x32x2_f32) in the same call.  Same results either way.

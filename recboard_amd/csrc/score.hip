@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
     // by the row number (conflict-free fragment reads); the queues give up 8 entries per lane to make room for the second buffer.
     constexpr int QC = X2 ? 20 : SR_QC;
     constexpr int TILE_FLOATS = X2 ? 2 * SC_TI * D : SC_TI * RSF;
-    static_assert(!X2 || D == 64, "split form: D = 64");
+    static_assert(!X2 || D == 64 || D == 128, "split form: D = 64 or 128");
     float* qv = tile + TILE_FLOATS;                          // [4 waves][QC][64 lanes]
     int* qi = reinterpret_cast<int*>(qv + 4 * QC * 64);
     __shared__ int vote[4];
@@ -552,14 +552,16 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
         };
 
         // split form: stage st -> LDS buffer buf.  Instruction p of wave wid fills the 1 KB block (4 p + wid) of the buffer, lane l its
-        // 16-byte slot l: rows are 256 bytes, so that is chunk position l & 15 of row 16 p + 4 wid + (l >> 4), which holds the row's
-        // chunk (l & 15) ^ (row & 15).
+        // 16-byte slot l: rows are 4 D bytes (CPR = D/4 chunks), so that is chunk position l % CPR of row (4 p + wid) * (64 / CPR) +
+        // l / CPR, which holds the row's chunk (l % CPR) ^ (row & 15)  (D = 64: 4 rows per block; D = 128: 2).
         auto issue_stage = [&](int64_t st, int buf) {
-            const int ldrow = 4 * wid + (lane >> 4);
-            const int g = (lane & 15) ^ (ldrow & 15);
+            constexpr int CPR = D / 4;        // 16-byte chunks per row (16 / 32); a 1 KB block holds 64 / CPR rows
+            constexpr int RPB = 64 / CPR;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int64_t row = st * SC_TI + p * 16 + ldrow;
+            for (int p = 0; p < CPR / 4; ++p) {
+                const int srow = (4 * p + wid) * RPB + lane / CPR;      // row of the stage this lane's slot belongs to
+                const int g = (lane % CPR) ^ (srow & 15);              // ... and the row's chunk that lives in the slot
+                const int64_t row = st * SC_TI + srow;
                 const float* src = E + (row < N ? row : N - 1) * D + 4 * g;
                 __attribute__((address_space(3))) unsigned char* dst =
                     (__attribute__((address_space(3))) unsigned char*)(__attribute__((address_space(3))) float*)tile + buf * (SC_TI * D * 4) + (4 * p + wid) * 1024;
@@ -709,8 +711,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                         // The reads are inline asm: the compiler orders every LDS read it knows about behind ALL outstanding
                         // global->LDS loads (s_waitcnt vmcnt(0) -- it cannot see that the next stage's loads fill the OTHER buffer),
                         // which would put the whole load latency in front of every tile.
-                        static_assert(NS16 == 4, "split form: D = 64");
-                        f32x4 af[NS16];
+                        f32x4 af[4];
                         const unsigned xb = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)xbase;
 #define SX_FRAGS(J0)                                                                                                              \
     asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %6\n ds_read_b128 %3, %7\n s_waitcnt lgkmcnt(0)"      \
@@ -718,18 +719,25 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                  : "v"(xb + ((((J0) + 0 + h) ^ c15) << 4)), "v"(xb + ((((J0) + 2 + h) ^ c15) << 4)),                               \
                    "v"(xb + ((((J0) + 4 + h) ^ c15) << 4)), "v"(xb + ((((J0) + 6 + h) ^ c15) << 4))                                \
                  : "memory")
-                        SX_FRAGS(0);   // hi plane: chunks 2 s + h
+                        // hi plane = chunks 2 s + h (s < NS16), mid plane = chunks D/8 + 2 s + h; four steps (64 k) per pass
 #pragma unroll
-                        for (int s = 0; s < NS16; ++s) {
-                            const bf16x8 xh = __builtin_bit_cast(bf16x8, af[s]);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqm[s]), acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
+                        for (int g4 = 0; g4 < NS16 / 4; ++g4) {
+                            SX_FRAGS(8 * g4);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const bf16x8 xh = __builtin_bit_cast(bf16x8, af[s]);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqm[4 * g4 + s]), acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, bqh[4 * g4 + s]), acc, 0, 0, 0);
+                            }
                         }
-                        SX_FRAGS(8);   // mid plane: chunks 8 + 2 s + h
-#undef SX_FRAGS
 #pragma unroll
-                        for (int s = 0; s < NS16; ++s)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
+                        for (int g4 = 0; g4 < NS16 / 4; ++g4) {
+                            SX_FRAGS(D / 8 + 8 * g4);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, bqh[4 * g4 + s]), acc, 0, 0, 0);
+                        }
+#undef SX_FRAGS
                     } else {
 #pragma unroll
                     for (int q = 0; q < KH / 4; ++q) {
@@ -1098,7 +1106,7 @@ __global__ __launch_bounds__(128) void score_bound_k(const float* __restrict__ Q
 //   eps = cerr * |q| * max_j |e_j| (+ 1e-36 for flushed denormals), cerr = 1.05 * (3.01 * 2^-18 [dropped mid.mid, split remainders]
 //         + (3 D + 4) * 2^-23 [fp32 accumulation of the 3 D exact bf16 x bf16 products inside the MFMAs, one ulp per addition]
 //         + D * 2^-24 [the exact chain's own distance from the true dot product]), using sum |q_k e_k| <= |q| |e|.
-#define MX_ROWS 16   // candidate rows staged per pass and wave (4 waves x 16 x (D + 4) floats of LDS)
+#define MX_ROWS 16   // candidate rows staged per pass and wave (4 waves x 16 x (D + 4) floats of LDS; 32 rows per pass measured slower)
 __device__ float g_sx_info[8];
 __device__ unsigned g_sx_stats[2];   // [0] users sent to the exact fallback so far, [1] diagnostics: max |s' - s| / eps (float bits)
 template <int D>
@@ -1287,6 +1295,8 @@ static size_t score_lds_bytes(int D, int K, bool topk) {
 
 static int g_score_x2 = 1;      // the split (bf16 hi/mid on the XDL pipe + exact re-scoring) fast path; 0 = exact kernel only
 extern "C" void re_dbg_score_x2(int on) { g_score_x2 = on; }
+static int g_score_x2_d128 = 1;  // split form at D = 128 (one workgroup per CU: two 32 KB stage buffers; A/B switch)
+extern "C" void re_dbg_score_x2_d128(int on) { g_score_x2_d128 = on; }
 static int g_score_sample = 1;   // split form: starting thresholds from a catalog sample (0: A/B switch, scripts/x2_check.py)
 extern "C" void re_dbg_score_sample(int on) { g_score_sample = on; }
 static int g_score_mxdiag = 0;   // timing-only ablation of score_topk_merge_x (scripts/x2_diag.py): 1 no list merge, 2 no re-scoring, 4 no final sort
@@ -1316,9 +1326,7 @@ static bool score_use_reg(const ScorePlan& p, int64_t N, int64_t D, int64_t K) {
     return g_score_pop == 3 && (D == 64 || D == 128) && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1;
 }
 static bool score_use_x2(const ScorePlan& p, int64_t N, int64_t D, int64_t K) {
-    // (D = 128: the split kernel's 16 fragment reads + 24 MFMAs per tile run on one wave per SIMD -- one workgroup per CU by LDS --
-    // and nothing overlaps: measured no faster than the exact form, so D = 128 stays on the exact kernel)
-    return g_score_x2 && D == 64 && score_use_reg(p, N, D, K) && K + 6 <= 56;
+    return g_score_x2 && (D == 64 || (D == 128 && g_score_x2_d128)) && score_use_reg(p, N, D, K) && K + 6 <= 56;
 }
 static float score_cerr(int64_t D) {
     const double c = 3.01 * ldexp(1.0, -18) + (3.0 * (double)D + 4.0) * ldexp(1.0, -23) + (double)D * ldexp(1.0, -24);
@@ -1472,14 +1480,15 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             const unsigned* emax;
             // the query split zeroes the call's bound / flag words (n_zero is a multiple of 256 bytes) -- it runs FIRST: the item
             // split's device-wide maximum goes into one of those words
-            rc = score_split_launch<64>(Q, B, Qs, qnorm, nullptr, s, (char*)ws + w.off_gthr, w.n_zero);
+            rc = D == 64 ? score_split_launch<64>(Q, B, Qs, qnorm, nullptr, s, (char*)ws + w.off_gthr, w.n_zero)
+                         : score_split_launch<128>(Q, B, Qs, qnorm, nullptr, s, (char*)ws + w.off_gthr, w.n_zero);
             if (rc != RE_OK) return rc;
             if (prep) {
                 Es = (const float*)prep;
                 emax = (const unsigned*)((const char*)prep + re_align((size_t)N * D * 4));
             } else {
                 float* own = (float*)((char*)ws + w.off_prep);
-                rc = score_split_launch<64>(E, N, own, nullptr, emax_own, s);
+                rc = D == 64 ? score_split_launch<64>(E, N, own, nullptr, emax_own, s) : score_split_launch<128>(E, N, own, nullptr, emax_own, s);
                 if (rc != RE_OK) return rc;
                 Es = own;
                 emax = emax_own;
@@ -1495,7 +1504,8 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
                 int r = (int)ceil(m + 4.5 * sqrt(m) + 2.0);
                 r += r & 1;
                 if (n >= 32 && r <= 16) {
-                    hipLaunchKernelGGL(score_bound_k<64>, dim3((unsigned)re_cdiv(B, 32)), dim3(128), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
+                    if (D == 64) hipLaunchKernelGGL(score_bound_k<64>, dim3((unsigned)re_cdiv(B, 32)), dim3(128), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
+                    else hipLaunchKernelGGL(score_bound_k<128>, dim3((unsigned)re_cdiv(B, 32)), dim3(128), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
                     if ((rc = re_launch_status()) != RE_OK) return rc;
                 }
             }
@@ -1507,11 +1517,15 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
         else if (C == 32) SR_LAUNCH(DV, 16, 16, true, Qs, Es, 16, gthr, nullptr, pt);          \
         else SR_LAUNCH(DV, 28, 28, true, Qs, Es, 28, gthr, nullptr, pt);                       \
     } while (0)
-            SX_LAUNCH(64);
+            if (D == 64) SX_LAUNCH(64); else SX_LAUNCH(128);
 #undef SX_LAUNCH
             if ((rc = re_launch_status()) != RE_OK) return rc;
-            hipLaunchKernelGGL(score_topk_merge_x<64>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                               p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4));
+            if (D == 64)
+                hipLaunchKernelGGL(score_topk_merge_x<64>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4));
+            else
+                hipLaunchKernelGGL(score_topk_merge_x<128>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4));
             if ((rc = re_launch_status()) != RE_OK) return rc;
             // ---- fallback pass over flagged user blocks only (normally none: every workgroup returns at once)
             blockflag = bflag;

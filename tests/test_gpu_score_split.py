@@ -69,6 +69,21 @@ def test_split_equals_exact_kernel_full_beauty(env, K):
     assert 0.0 < ratio < 0.5
 
 
+def test_split_equals_exact_kernel_d128(env):
+    """D = 128 (BASELINE configs[4]: one workgroup per CU, two 32 KB stage buffers): a 4 096-user batch against 50 000 items and a
+    512-user batch against a long shard -- the split form and the exact kernel agree bit for bit."""
+    ops, L = env
+    g = torch.Generator(device="cuda").manual_seed(128)
+    for U, N, n_seen in ((4096, 50000, 16), (512, 1_500_000, 0)):
+        q = torch.randn(U, 128, device="cuda", generator=g)
+        E = torch.randn(N, 128, device="cuda", generator=g)
+        sp, si = seen_csr(g, U, N, n_seen) if n_seen else (None, None)
+        (v0, i0), (v1, i1), flagged, ratio = both_paths(ops, L, q, E, sp, si, 50)
+        assert torch.equal(i0, i1) and torch.equal(v0.view(torch.int32), v1.view(torch.int32))
+        assert flagged == 0
+        assert 0.0 < ratio < 0.5
+
+
 def test_split_on_trained_like_state_with_popular_head(env):
     """Scores dominated by a run of neighbouring ids (popular items sit at the low ids in the bench's synthetic data and in
     many real catalogs): every user's best 50 come from the same 64 items, i.e. one stage of the kernel.  The lists must
