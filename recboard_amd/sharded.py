@@ -26,9 +26,15 @@ class EngineLocalOps:
         from . import ops
         return ops.scatter_add_rows(g, idx, R)
 
-    def score_topk(self, Q, E, seen_ptr, seen_idx, K):
+    def score_topk(self, Q, E, seen_ptr, seen_idx, K, prep=None):
         from . import ops
-        return ops.score_topk(Q, E, seen_ptr, seen_idx, K)
+        return ops.score_topk(Q, E, seen_ptr, seen_idx, K, prep=prep)
+
+    def score_prepare(self, E):
+        """The shard's bf16 planes for the split scoring path (None where there is no split form): built once per
+        ShardedTable.score_topk call -- the shard is scored against every rank's queries."""
+        from . import ops
+        return ops.score_prepare(E)
 
     def sparse_adam(self, g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=-1):
         from . import ops
@@ -124,9 +130,11 @@ class ShardedTable:
         dist.all_gather(Qs, Q_local.contiguous(), group=self.group)
         ptrs, idxs = self._gather_seen(seen_ptr, seen_idx)
         outs_v, outs_i = [], []
+        prep = self.ops.score_prepare(self.weight) if hasattr(self.ops, "score_prepare") else None
+        kw = {} if prep is None else {"prep": prep}
         for src in range(G):                 # score every rank's queries against MY shard
             sp, si = self._seen_for_shard(ptrs[src], idxs[src])
-            v, i = self.ops.score_topk(Qs[src], self.weight, sp, si, min(K, self.local_rows))
+            v, i = self.ops.score_topk(Qs[src], self.weight, sp, si, min(K, self.local_rows), **kw)
             gi = torch.where(i >= 0, self.global_index(i), i)
             if v.shape[1] < K:               # shard smaller than K: pad
                 pad = K - v.shape[1]

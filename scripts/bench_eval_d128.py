@@ -16,4 +16,8 @@ for U, N, D in ((512, 12_500_000, 128), (512, 12_500_000, 64), (4096, 1_000_000,
     ms = t(lambda: ops.score_topk(q, E, sp, si, 50))
     fl = 2 * D * U * N
     print(f"{U} x {N} D={D}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.0f} % of fp32 MFMA peak)  table read {N*D*4/ms/1e6:.0f} GB/s")
+    prep = ops.score_prepare(E)   # the table's bf16 planes built once (an evaluation scores many user batches against one table)
+    ms = t(lambda: ops.score_topk(q, E, sp, si, 50, prep=prep))
+    print(f"   with the table prepared once: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.0f} % of fp32 MFMA peak)")
+    del prep
     del E
