@@ -1266,9 +1266,10 @@ extern "C" void re_dbg_score_variant(int pop, int64_t minseg) { g_score_pop = po
 struct ScorePlan {
     int64_t nub, nst, units, upw;
     int nwg, maxseg;
+    bool small = false;   // few users against a short catalog: register-list kernels on segments of >= 8 stages (score_plan_topk)
 };
 
-static ScorePlan score_plan(int64_t B, int64_t N, int64_t D = 64, int64_t wg_cap = 0) {
+static ScorePlan score_plan(int64_t B, int64_t N, int64_t D = 64, int64_t wg_cap = 0, int64_t seg_floor = 0) {
     ScorePlan p;
     p.nub = re_cdiv(B, SC_USERS);
     p.nst = re_cdiv(N, SC_TI);
@@ -1279,7 +1280,8 @@ static ScorePlan score_plan(int64_t B, int64_t N, int64_t D = 64, int64_t wg_cap
     // scripts/tune_score.py).
     // (D = 128: the register-list kernel holds a 64-register query fragment and runs one workgroup per CU)
     int64_t upw = re_cdiv(p.units, wg_cap > 0 ? wg_cap : D == 128 && g_score_maxwgs == SC_MAX_WGS ? SC_MAX_WGS / 2 : g_score_maxwgs);
-    const int64_t min_seg = p.nst < g_score_minseg ? p.nst : g_score_minseg;
+    const int64_t want_seg = seg_floor > g_score_minseg ? seg_floor : g_score_minseg;
+    const int64_t min_seg = p.nst < want_seg ? p.nst : want_seg;
     if (upw < min_seg) upw = min_seg;
     p.upw = upw;
     p.nwg = (int)re_cdiv(p.units, p.upw);
@@ -1293,6 +1295,10 @@ static size_t score_lds_bytes(int D, int K, bool topk) {
     return b;
 }
 
+static int g_score_small = 1;          // small batches on the register-list kernels (score_plan_topk; 0: A/B switch)
+extern "C" void re_dbg_score_small(int on) { g_score_small = on; }
+static int64_t g_score_reg_nub = 16;   // register-list kernels from this many user blocks on (tuning switch, scripts/x2_small.py)
+extern "C" void re_dbg_score_reg_nub(int64_t n) { g_score_reg_nub = n; }
 static int g_score_x2 = 1;      // the split (bf16 hi/mid on the XDL pipe + exact re-scoring) fast path; 0 = exact kernel only
 extern "C" void re_dbg_score_x2(int on) { g_score_x2 = on; }
 static int g_score_x2_d128 = 1;  // split form at D = 128 (one workgroup per CU: two 32 KB stage buffers; A/B switch)
@@ -1322,8 +1328,23 @@ static int score_x2_capacity(const ScorePlan& p, int64_t K) {
     return K + 6 <= 16 ? 16 : K + 6 <= 32 ? 32 : 56;
 }
 #define SX_MAX_PREP_BYTES (16ll << 30)   // re_score_topk splits the table into its workspace only up to this size (else: exact path)
+static bool score_reg_eligible(int64_t N, int64_t D, int64_t K) {
+    return g_score_pop == 3 && (D == 64 || D == 128) && K <= 52 && N < (1ll << SR_TAGBITS) - 1;
+}
+// The plan of a top-K call.  An evaluation batch of a few hundred users against a short catalog (FreeRec's Coach.evaluate scores
+// one data-loader batch per call) has too few (user block, stage) units for stream-K over 512 workgroups to leave segments of any
+// length: the register-list kernels then run on segments of >= 8 stages -- fewer workgroups, but 113 us instead of the LDS-heap
+// kernel's 859 us at 256 x 12 101, 116 instead of 577 us at 512, 120 instead of 521 us at 1 024 (scripts/x2_small.py).
+static ScorePlan score_plan_topk(int64_t B, int64_t N, int64_t D, int64_t K) {
+    ScorePlan p = score_plan(B, N, D);
+    if (score_reg_eligible(N, D, K) && g_score_small && p.nub < g_score_reg_nub && p.upw < 64) {
+        p = score_plan(B, N, D, 0, 8);
+        p.small = true;
+    }
+    return p;
+}
 static bool score_use_reg(const ScorePlan& p, int64_t N, int64_t D, int64_t K) {
-    return g_score_pop == 3 && (D == 64 || D == 128) && K <= 52 && (p.nub >= 16 || p.upw >= 64) && N < (1ll << SR_TAGBITS) - 1;
+    return score_reg_eligible(N, D, K) && (p.nub >= g_score_reg_nub || p.upw >= 64 || p.small);
 }
 static bool score_use_x2(const ScorePlan& p, int64_t N, int64_t D, int64_t K) {
     return g_score_x2 && (D == 64 || (D == 128 && g_score_x2_d128)) && score_use_reg(p, N, D, K) && K + 6 <= 56;
@@ -1341,7 +1362,7 @@ static ScoreWs score_ws(int64_t B, int64_t N, int64_t D, int64_t K, const ScoreP
     ScoreWs w;
     const int64_t kk = x2 ? 56 : K;   // (x2: list capacity <= 56, and the exact fallback's K <= 50)
     int64_t segs = p.maxseg;
-    if (x2) { const ScorePlan pfb = score_plan(B, N, D); if (pfb.maxseg > segs) segs = pfb.maxseg; }
+    if (x2) { const ScorePlan pfb = score_plan_topk(B, N, D, K); if (pfb.maxseg > segs) segs = pfb.maxseg; }
     w.half = re_align((size_t)p.nub * SC_USERS * segs * 2 * kk * 4);     // up to 2 lists per (user, segment)
     w.off_pi = w.half;
     w.off_gthr = 2 * w.half;
@@ -1357,14 +1378,14 @@ static ScoreWs score_ws(int64_t B, int64_t N, int64_t D, int64_t K, const ScoreP
 
 extern "C" size_t re_score_topk_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K) {
     if (B <= 0 || N <= 0 || K <= 0) return 256;
-    ScorePlan p = score_plan(B, N, D);
+    ScorePlan p = score_plan_topk(B, N, D, K);
     const bool x2 = score_use_x2(p, N, D, K) && (int64_t)N * D * 4 <= SX_MAX_PREP_BYTES;
     return score_ws(B, N, D, K, p, x2, true).total;
 }
 // workspace of the prepared form: the item table's split planes live in the caller's `prep` buffer instead
 extern "C" size_t re_score_topk_prepared_workspace_bytes(int64_t B, int64_t N, int64_t D, int64_t K) {
     if (B <= 0 || N <= 0 || K <= 0) return 256;
-    ScorePlan p = score_plan(B, N, D);
+    ScorePlan p = score_plan_topk(B, N, D, K);
     return score_ws(B, N, D, K, p, score_use_x2(p, N, D, K), false).total;
 }
 extern "C" size_t re_score_prepare_bytes(int64_t N, int64_t D) {
@@ -1438,7 +1459,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
     if (!Q || !E || !vals || !idx || !ws || B < 0 || N <= 0 || K <= 0 || K > RE_TOPK_MAX) return RE_EINVAL;
     if ((reinterpret_cast<uintptr_t>(E) & 15u) != 0 || N >= 0x7FFFFFFFll) return RE_EUNSUPPORTED;
     if (seen_ptr && !seen_idx) return RE_EINVAL;
-    ScorePlan p = score_plan(B, N, D);
+    ScorePlan p = score_plan_topk(B, N, D, K);
     const bool x2 = score_use_x2(p, N, D, K) && (prep || (int64_t)N * D * 4 <= SX_MAX_PREP_BYTES) && (reinterpret_cast<uintptr_t>(Q) & 15u) == 0;
     const ScoreWs w = score_ws(B, N, D, K, p, x2, prep == nullptr);
     if (ws_bytes < w.total) return RE_EWORKSPACE;
@@ -1449,7 +1470,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
     const int* userflag = nullptr;
     // (the fallback pass of the split path has its own plan object: same split today -- a flagged user block is redone by as
     // many workgroups as scored it the first time; when nobody is flagged, the normal case, what it costs is its dispatch)
-    const ScorePlan pfb = score_plan(B, N, D);
+    const ScorePlan pfb = score_plan_topk(B, N, D, K);
     const ScorePlan* lp = &p;
 #define SR_LAUNCH(DV, KRV, KTV, X2V, QP, EP, KV, GT, BF, PT)                                                                \
     do {                                                                                                                             \
