@@ -46,3 +46,12 @@ print(f"identical={torch.equal(i0, i1) and torch.equal(v0, v1)} flagged={out[0]}
 print("last flagged:", [round(float(x), 6) for x in info])
 uq = torch.unique(q, dim=0).shape[0]
 print("distinct query rows:", uq, "of", U, " score sd:", float((q[:64] @ items.T).std()))
+# list-maintenance counters of the main kernel on this state (diagnostic mode 3)
+for n, a in (("re_dbg_score_diag", [ctypes.c_int]), ("re_dbg_score_counters", [ctypes.c_void_p, ctypes.c_int])):
+    getattr(L, n).argtypes = a; getattr(L, n).restype = None
+buf = (ctypes.c_ulonglong * 4)()
+L.re_dbg_score_diag(3); L.re_dbg_score_counters(buf, 1)
+ops.score_topk(q, items, seen_ptr, seen_idx, K); torch.cuda.synchronize()
+L.re_dbg_score_counters(buf, 1); L.re_dbg_score_diag(0)
+nw = 512 * 4
+print(f"split kernel on this state: drains/wave {buf[0]/nw:.1f}  rounds/wave {buf[1]/nw:.1f}  hits/lane {buf[2]/nw/64:.1f}")
