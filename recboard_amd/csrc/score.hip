@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
             userflag[user] = 1; blockflag[ub] = 1; atomicAdd(&g_sx_stats[0], 1u);
             if (dbg_maxerr) {   // diagnostics: the last flagged user's certificate inputs
                 g_sx_info[0] = (float)user; g_sx_info[1] = T; g_sx_info[2] = xk; g_sx_info[3] = (float)eps;
-                g_sx_info[4] = (float)total; g_sx_info[5] = (float)nseg; g_sx_info[6] = validk ? 1.f : 0.f; g_sx_info[7] = __shfl(bv, 63, 64);
+                g_sx_info[4] = (float)total; g_sx_info[5] = (float)nseg; g_sx_info[6] = validk ? 1.f : 0.f; g_sx_info[7] = (float)K;
             }
         }
         return;

@@ -49,8 +49,8 @@ def case(name, q, E, sp, si, K, time_it=True, prep=False):
     if flagged:
         info = (ctypes.c_float * 8)()
         L.re_dbg_score_x2_info(info)
-        print("    last flagged: user %d  T %.6g  x_K %.6g  eps %.3g  entries %d  lists %d  validK %d  64th s' %.6g" % tuple(
-            [int(info[0])] + [info[i] for i in (1, 2, 3)] + [int(info[4]), int(info[5]), int(info[6]), info[7]]))
+        print("    last flagged: user %d  T %.6g  x_K %.6g  eps %.3g  entries %d  lists %d  validK %d" % tuple(
+            [int(info[0])] + [info[i] for i in (1, 2, 3)] + [int(info[4]), int(info[5]), int(info[6])]))
     L.re_dbg_score_x2_maxerr(0)
     t1 = timeit(lambda: ops.score_topk(q, E, sp, si, K, prep=pr)) if time_it else float("nan")
     ok = torch.equal(i0, i1) and torch.equal(v0.view(torch.int32), v1.view(torch.int32))

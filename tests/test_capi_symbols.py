@@ -30,6 +30,13 @@ def test_workspace_queries_are_pure_host_calls():
     assert L.re_scatter_add_rows_workspace_bytes(76800, 64, 12102) > 4 * 76800 * 4
     assert L.re_score_topk_workspace_bytes(22363, 12101, 64, 50) >= 22363 * 50 * 8
     assert L.re_pair_loss_workspace_bytes(1000) >= 8192
+    # split scoring path: the prepared form keeps the item planes outside the workspace
+    N, D = 12101, 64
+    assert L.re_score_prepare_bytes(N, D) >= N * D * 4
+    own = L.re_score_topk_workspace_bytes(22363, N, D, 50)
+    prepared = L.re_score_topk_prepared_workspace_bytes(22363, N, D, 50)
+    assert own >= prepared + N * D * 4 and prepared >= 22363 * 50 * 8
+    assert L.re_score_topk_workspace_bytes(512, N, D, 50) >= 512 * 50 * 8      # small batches have a plan of their own
 
 
 def test_cpu_tensors_are_rejected_loudly():
