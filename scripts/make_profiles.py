@@ -1,0 +1,36 @@
+"""gpurun_out/<dir> (rocprofv3 kernel trace of bench.py + FETCH_SIZE / WRITE_SIZE passes of scripts/x2_prof.py + a plain bench line)
+-> profiles/<tag>_bench.json, <tag>_bench_kernel_stats.csv, <tag>_score_pmc_traffic.json.
+usage: python scripts/make_profiles.py gpurun_out/v10 r1_v10"""
+import csv, glob, json, os, shutil, sqlite3, subprocess, sys
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(root, "profiles")
+db = sqlite3.connect(glob.glob(src + "/trace/**/*.db", recursive=True)[0])
+rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+with open(os.path.join(P, tag + "_bench_kernel_stats.csv"), "w", newline="") as fo:
+    w = csv.writer(fo, quoting=csv.QUOTE_ALL)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for n, c, t, a, mn, mx in rows:
+        w.writerow([n, c, t, round(a, 3), round(100 * t / tot, 2), mn, mx])
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(P, tag + "_bench.json"))
+k = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "scripts", "pmc_traffic.py"), src + "/fetch", src + "/write", "score_", "re_zero"]))
+main = [n for n in k if n.startswith("score_kernel_reg<64, 28")][0]
+exact = [n for n in k if n.startswith("score_kernel_reg<64, 50")][0]
+total = 2 * k["score_split_k<64>"]["hbm_bytes_per_launch"] + sum(k[n]["hbm_bytes_per_launch"] for n in ("score_bound_k<64>", main, "score_topk_merge_x<64>", exact, "score_topk_merge"))
+out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counters): rocprofv3 --pmc FETCH_SIZE -- python3 scripts/x2_prof.py ; same with --pmc WRITE_SIZE  "
+                    "(20 re_score_topk calls, 22 363 users x 12 101 items, D = 64, K = 50, iid scores)",
+       "units": "KB per launch (average over launches)",
+       "correction": "gfx950: FETCH_SIZE tallies the 128-B requests of 16-B-per-lane reads at 64 B (MI355X_MICROARCH.md, HBM): hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE",
+       "kernels": k,
+       "re_score_topk_call": {
+           "launches": "score_split_k x2 (queries -- which also zeroes the call's flag words -- and item table), score_bound_k, score_kernel_reg<64,28,28,split>, "
+                       "score_topk_merge_x, and the fallback pass score_kernel_reg<64,50,50,exact> + score_topk_merge (nobody flagged: both return at once)",
+           "hbm_bytes_per_call": total,
+           "algorithmic_lower_bound_bytes": 4 * 64 * (22363 + 12101) + 12 * 22363 * 50,
+           "note": "above the lower bound: the partial lists (one 56-entry list per user and segment: written by the main kernel, read by the merge), the candidates' "
+                   "rows re-read by the merge, and ~37 MB written by the EMPTY fallback launch (scratch set-up of the exact kernel's 308 B per lane)"}}
+json.dump(out, open(os.path.join(P, tag + "_score_pmc_traffic.json"), "w"), indent=1)
+for n, c, t, a, mn, mx in rows[:12]:
+    print(f"{t/1e3:10.1f} us  calls {c:5d}  avg {a/1e3:8.1f} us  {n[:70]}")
+print("hbm bytes per score call:", total)
