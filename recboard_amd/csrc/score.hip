@@ -345,6 +345,9 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                                                            int maxseg, int64_t nub, int64_t nst, int64_t upw,
                                                            unsigned* __restrict__ gthr, int dbg,
                                                            const int* __restrict__ blockflag, float* __restrict__ part_T) {
+    // Fallback pass with nobody flagged (the normal case): leave before anything else -- the kernel's prologue spills loop
+    // invariants to scratch memory, 37 MB of writes per launch over 512 workgroups that an early exit further down does not avoid.
+    if (blockflag && blockflag[nub + 1] == 0) return;
     constexpr int KH = D / 2;
     constexpr int RSF = D + 4;
     constexpr int NS16 = D / 16;   // X2: MFMA steps of 16 k
@@ -1242,6 +1245,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
     if (!pass) {
         if (lane == 0) {
             userflag[user] = 1; blockflag[ub] = 1; atomicAdd(&g_sx_stats[0], 1u);
+            blockflag[(B + SC_USERS - 1) / SC_USERS + 1] = 1;   // "somebody is flagged": the word the fallback kernel looks at first
             if (dbg_maxerr) {   // diagnostics: the last flagged user's certificate inputs
                 g_sx_info[0] = (float)user; g_sx_info[1] = T; g_sx_info[2] = xk; g_sx_info[3] = (float)eps;
                 g_sx_info[4] = (float)total; g_sx_info[5] = (float)nseg; g_sx_info[6] = validk ? 1.f : 0.f; g_sx_info[7] = (float)K;
