@@ -1122,8 +1122,8 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
                                                           float* __restrict__ vals, int64_t* __restrict__ idx,
                                                           int* __restrict__ userflag, int* __restrict__ blockflag,
                                                           int dbg_maxerr) {
-    constexpr int RS = D + 4, LPR = D / 4;
-    __shared__ __align__(16) float mx_stage[4 * MX_ROWS * RS];
+    constexpr int LPR = D / 4;
+    __shared__ __align__(16) float mx_stage[4 * MX_ROWS * D];
     const int mxd = dbg_maxerr >> 4;
     dbg_maxerr &= 15;
     const int lane = threadIdx.x & 63;
@@ -1178,53 +1178,44 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
     }
     const int nvalid = total < 64 ? total : 64;
     if (total > 64) T = fmaxf(T, __shfl(bv, 63, 64));
-    // exact re-scoring: lane = candidate.  The 64 candidate rows are fetched like a gather -- D/4 lanes per row, whole-row
-    // coalesced float4 loads, ALL of them issued before the first use -- and handed to their lanes through the wave's LDS
-    // slice, MX_ROWS rows per pass (a lane reading its own row from global memory touches 64 cache lines per load
-    // instruction).  LDS rows are D + 4 floats apart (conflict-free float4 reads down a column of rows).
-    float* stage = mx_stage + (threadIdx.x >> 6) * (MX_ROWS * RS);
+    // exact re-scoring: lane = candidate; the candidates' rows come in through the wave's LDS slice, MX_ROWS rows per pass (a lane
+    // reading its own row from global memory would touch 64 cache lines per load instruction).
+    float* stage = mx_stage + (threadIdx.x >> 6) * (MX_ROWS * D);
     // the query row: the user is the wave's, so the row comes in through scalar loads and the chain multiplies by scalar registers
     const float* qrow = Q + (int64_t)__builtin_amdgcn_readfirstlane((int)user) * D;
-    constexpr int NLD = 64 * LPR / 64;   // float4 loads per lane for 64 rows
-    float4 rowreg[NLD];
-#pragma unroll
-    for (int t0 = 0; t0 < NLD; ++t0) {
-        const int t = t0 * 64 + lane;
-        const int r = t / LPR, ch = t - r * LPR;
-        const int id = __shfl(bi, r, 64);
-        rowreg[t0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id != PAD) rowreg[t0] = reinterpret_cast<const float4*>(E + (int64_t)id * D)[ch];
-    }
+    // Rows by LDS-DMA (global_load_lds_dwordx4: no staging registers, no LDS stores): an instruction moves 1 KB = 64 / CPR
+    // whole rows into the wave's slice, lane l the 16-byte slot l; rows are unpadded and slot (l % CPR) of row r holds the row's
+    // chunk (l % CPR) ^ (r & 15), so that MX_ROWS lanes reading chunk k of their own rows hit MX_ROWS different bank groups.
     float sx = -INFINITY;
-    constexpr int LPP = MX_ROWS * LPR / 64;   // loads per pass
+    constexpr int CPR = LPR, RPI = 64 / CPR, IPP = MX_ROWS / RPI;
+#pragma unroll 1
+    for (int r0 = 0; r0 < nvalid && !(mxd & 2); r0 += MX_ROWS) {
 #pragma unroll
-    for (int ps = 0; ps < 64 / MX_ROWS; ++ps) {
-        const int r0 = ps * MX_ROWS;
-        if (r0 < nvalid && !(mxd & 2)) {   // (wave-uniform)
-#pragma unroll
-            for (int t0 = 0; t0 < LPP; ++t0) {
-                const int t = t0 * 64 + lane;
-                const int r = t / LPR, ch = t - r * LPR;
-                *reinterpret_cast<float4*>(stage + r * RS + 4 * ch) = rowreg[ps * LPP + t0];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= r0 && lane < r0 + MX_ROWS && bi != PAD) {
-                const float4* e4 = reinterpret_cast<const float4*>(stage + (lane - r0) * RS);
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < LPR; ++k) {
-                    const float4 e = e4[k];
-                    acc = fmaf(qrow[4 * k + 0], e.x, acc);
-                    acc = fmaf(qrow[4 * k + 1], e.y, acc);
-                    acc = fmaf(qrow[4 * k + 2], e.z, acc);
-                    acc = fmaf(qrow[4 * k + 3], e.w, acc);
-                }
-                sx = acc + 0.0f;   // (-0 -> +0, like the list keys of the exact kernel)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < IPP; ++i) {
+            const int r = i * RPI + lane / CPR;
+            const int id = __shfl(bi, r0 + r, 64);
+            const int g = (lane % CPR) ^ (r & 15);
+            const float* src = E + (int64_t)(id != PAD ? id : 0) * D + 4 * g;
+            __attribute__((address_space(3))) unsigned char* dst =
+                (__attribute__((address_space(3))) unsigned char*)(__attribute__((address_space(3))) float*)stage + i * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, dst, 16, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane >= r0 && lane < r0 + MX_ROWS && bi != PAD) {
+            const int rr = lane - r0;
+            const float* erow = stage + rr * D;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < LPR; ++k) {
+                const float4 e = *reinterpret_cast<const float4*>(erow + 4 * (k ^ (rr & 15)));
+                acc = fmaf(qrow[4 * k + 0], e.x, acc);
+                acc = fmaf(qrow[4 * k + 1], e.y, acc);
+                acc = fmaf(qrow[4 * k + 2], e.z, acc);
+                acc = fmaf(qrow[4 * k + 3], e.w, acc);
+            }
+            sx = acc + 0.0f;   // (-0 -> +0, like the list keys of the exact kernel)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by the next pass
     }
     const double eps = (double)cerr * (double)qnorm[user] * (double)__uint_as_float(*emax) + 1e-36;
     if (dbg_maxerr && bi != PAD) {   // diagnostics: the largest observed |s' - s| / eps (must stay below 1; tests/test_gpu_ops.py)
