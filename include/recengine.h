@@ -167,6 +167,7 @@ int re_bpr_triplet_fwd_bwd(const float* Ut, int64_t RU, const float* It, int64_t
  *   user are re-scored exactly and the result is certified against a rigorous error bound; users that cannot be certified
  *   are redone by the exact fp32-MFMA kernel (v_mfma_f32_32x32x2_f32) in the same call.  Same results either way.
  * D must be a multiple of 8 and <= 256; K <= RE_TOPK_MAX.
+ * The workspace (and a prep buffer) must be 16-byte aligned.
  * re_score_prepare / re_score_topk_prepared: the item table's split planes are built once (prep buffer of
  *   re_score_prepare_bytes(N, D) bytes, D = 64 or 128) and reused by any number of scoring calls against the same table --
  *   Coach.evaluate scores every user batch of a split against one table (UniSRec/main.py:400-447).  E must be the same

@@ -1462,6 +1462,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
     if (!Q || !E || !vals || !idx || !ws || B < 0 || N <= 0 || K <= 0 || K > RE_TOPK_MAX) return RE_EINVAL;
     if ((reinterpret_cast<uintptr_t>(E) & 15u) != 0 || N >= 0x7FFFFFFFll) return RE_EUNSUPPORTED;
     if (seen_ptr && !seen_idx) return RE_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) != 0 || (prep && (reinterpret_cast<uintptr_t>(prep) & 15u) != 0)) return RE_EUNSUPPORTED;
     ScorePlan p = score_plan_topk(B, N, D, K);
     const bool x2 = score_use_x2(p, N, D, K) && (prep || (int64_t)N * D * 4 <= SX_MAX_PREP_BYTES) && (reinterpret_cast<uintptr_t>(Q) & 15u) == 0;
     const ScoreWs w = score_ws(B, N, D, K, p, x2, prep == nullptr);

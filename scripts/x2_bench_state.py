@@ -29,6 +29,8 @@ seen_ptr, seen_idx = torch.from_numpy(sp).cuda(), torch.from_numpy(np.concatenat
 with torch.no_grad():
     q = torch.cat([model.encode(eval_seq[i:i + 512])[0][:, -1, :] for i in range(0, U, 512)]).contiguous()
 items = model.params["Item.embeddings.weight"].detach()[1:]
+if os.environ.get("X2_DUMP"):   # hand the state to scripts/x2_cycles.py
+    torch.save({"q": q.cpu(), "E": items.cpu().clone(), "sp": seen_ptr.cpu(), "si": seen_idx.cpu()}, os.environ["X2_DUMP"])
 def t(fn, it=20):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True); e0.record()

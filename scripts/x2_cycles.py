@@ -15,6 +15,9 @@ g = torch.Generator(device="cuda").manual_seed(1)
 q = torch.randn(U, D, device="cuda", generator=g); E = torch.randn(N, D, device="cuda", generator=g)
 sp = torch.arange(0, U + 1, device="cuda") * 8
 si = torch.sort(torch.randint(0, N, (U, 8), device="cuda", generator=g), 1).values.reshape(-1)
+if os.environ.get("X2_STATE"):   # the bench's trained state, dumped by scripts/x2_bench_state.py (X2_DUMP=...)
+    st = torch.load(os.environ["X2_STATE"])
+    q, E, sp, si = (st[k].cuda().contiguous() for k in ("q", "E", "sp", "si"))
 buf = (ctypes.c_ulonglong * 4)(); bx = (ctypes.c_ulonglong * 2)()
 for x2 in (0, 1):
     L.re_dbg_score_x2(x2)
