@@ -28,8 +28,10 @@ out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counte
                        "score_topk_merge_x, and the fallback pass score_kernel_reg<64,50,50,exact> + score_topk_merge (nobody flagged: both return at once)",
            "hbm_bytes_per_call": total,
            "algorithmic_lower_bound_bytes": 4 * 64 * (22363 + 12101) + 12 * 22363 * 50,
-           "note": "above the lower bound: the partial lists (one 56-entry list per user and segment: written by the main kernel, read by the merge), the candidates' "
-                   "rows re-read by the merge, and ~37 MB written by the EMPTY fallback launch (scratch set-up of the exact kernel's 308 B per lane)"}}
+           "note": "above the lower bound: the partial lists (one 56-entry list per user and segment: 41 MB written by the main kernel, read by the merge), "
+                   "the split item table streamed once per user block (3 MB x 175 blocks; what misses the XCDs' L2s is served by the Infinity Cache and "
+                   "counted here) and the candidates' rows re-read by the merge.  At 0.8 TB/s over the call none of it is what bounds the kernels "
+                   "(vector instruction stream and stage barriers, DESIGN.md section 5a)."}}
 json.dump(out, open(os.path.join(P, tag + "_score_pmc_traffic.json"), "w"), indent=1)
 for n, c, t, a, mn, mx in rows[:12]:
     print(f"{t/1e3:10.1f} us  calls {c:5d}  avg {a/1e3:8.1f} us  {n[:70]}")
