@@ -12,7 +12,9 @@ The second half of BASELINE's metric -- full-catalog items scored per second -- 
 the timed region, over all 22 363 users x 12 101 items with the fused score+mask+top-K kernel, and reported in
 `items_scored_per_sec` and `roofline_score` (MFMA-bound).  `roofline` is the dominant kernel of the timed region (the
 per-block encoder backward, MFMA-bound fp32), `roofline_gather` the HBM-bound
-embedding gather.  `cpu_baseline` times the torch-CPU oracle of the same training step on this box's host cores.
+embedding gather.  `cpu_baseline` times the torch-CPU oracle of the same training step on this box's host cores;
+`eval_baselines` times the evaluation as the reference executes it (dense scores, masked fill, torch.topk) through ROCm aten
+on the same GPU and through torch on the host cores.
 """
 import argparse
 import json
@@ -296,6 +298,41 @@ def main():
                                     f"against the fp32 MFMA peak -- the results are bit-exact fp32; the screening pass executes 3x that "
                                     f"many bf16 FLOPs = {3 * tf:.0f} TFLOP/s of the 2500 TFLOP/s bf16 peak",
                             "whole_call": "all launches of one re_score_topk call, item-table split included"}
+        # ---------------- the same evaluation as the reference executes it (UniSRec/main.py:408-414: dense scores, scores[seen] = -1e23,
+        # torch.topk), through ROCm aten on this GPU and through torch on the host cores -- baselines, reported beside the engine
+        def aten_eval(qq, EE, sp_, si_, rows):
+            sc = qq @ EE.t()
+            sc[rows, si_] = -1e23
+            return torch.topk(sc, K, dim=1)
+        rows_all = torch.repeat_interleave(torch.arange(U, device="cuda"), seen_ptr[1:] - seen_ptr[:-1])
+        t_aten = event_time_ms(lambda: aten_eval(q, items, seen_ptr, seen_idx, rows_all), 5, warmup=2)
+        va, ia = aten_eval(q, items, seen_ptr, seen_idx, rows_all)
+        ve, ie = ops.score_topk(q, items, seen_ptr, seen_idx, K)
+        agree = float((ia == ie).float().mean())       # (aten's GEMM sums in another order: near-ties may swap)
+        line["eval_baselines"] = {"aten_gpu": {"items_per_sec": round(U * N / (t_aten * 1e-3), 1), "ms": round(t_aten, 3),
+                                               "what": "torch (ROCm aten) on the same GPU: q @ E.T, masked fill, torch.topk(50), all users in one batch",
+                                               "topk_index_agreement_with_engine": round(agree, 6)}}
+        del va, ia, ve, ie
+        if not args.no_cpu_baseline:
+            nsub = 2048
+            qc, Ec = q[:nsub].cpu(), items.cpu()
+            spc = seen_ptr[:nsub + 1].cpu()
+            sic = seen_idx[:int(spc[-1])].cpu()
+            rc_ = torch.repeat_interleave(torch.arange(nsub), spc[1:] - spc[:-1])
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
+
+            def cpu_eval():
+                sc = qc @ Ec.t()
+                sc[rc_, sic] = -1e23
+                return torch.topk(sc, K, dim=1)
+            cpu_eval()
+            t0 = time.time()
+            nrep = 0
+            while time.time() - t0 < 3.0:
+                cpu_eval(); nrep += 1
+            dt = (time.time() - t0) / nrep
+            line["eval_baselines"]["torch_cpu"] = {"items_per_sec": round(nsub * N / dt, 1), "cores": torch.get_num_threads(),
+                                                   "sample": f"{nsub} users x {N} items, {nrep} repetitions, {dt * 1e3:.1f} ms each"}
         # ---------------- embedding gather leg (HBM-bound): Beauty shape and an HBM-resident 4 GiB table
         idx_small = batches[0][0].reshape(-1)
         W_small = model.params["Item.embeddings.weight"].detach()
