@@ -14,7 +14,8 @@ the timed region, over all 22 363 users x 12 101 items with the fused score+mask
 per-block encoder backward, MFMA-bound fp32), `roofline_gather` the HBM-bound
 embedding gather.  `cpu_baseline` times the torch-CPU oracle of the same training step on this box's host cores;
 `eval_baselines` times the evaluation as the reference executes it (dense scores, masked fill, torch.topk) through ROCm aten
-on the same GPU and through torch on the host cores.
+on the same GPU and through torch on the host cores; `train_baseline_aten_gpu` a torch.nn SASRec step (eager ROCm aten) on the
+same GPU.
 """
 import argparse
 import json
@@ -123,6 +124,70 @@ def pmc_traffic(*kernels):
                 "source": "profiles/r1_v5_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE)"}
     except Exception:  # noqa: BLE001
         return None
+
+
+def aten_train_baseline(cfg, batches, steps=30):
+    """The training step as the reference runs it on a GPU: a torch.nn SASRec written the way SASRec/main.py:52-221 is (Embedding,
+    nn.MultiheadAttention with a causal mask on LayerNorm'ed queries, Conv1d(k=1) feed-forward, BCE over the non-pad positions),
+    fp32, torch.optim.Adam, eager ROCm aten kernels -- the baseline the engine's step replaces, on the same MI355X."""
+    nn = torch.nn
+    N, S, D, L, p = cfg["items"], cfg["S"], cfg["D"], cfg["L"], cfg["p_drop"]
+
+    class FFN(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.conv2 = nn.Conv1d(D, D, 1), nn.Conv1d(D, D, 1)
+            self.d1, self.d2 = nn.Dropout(p), nn.Dropout(p)
+
+        def forward(self, x):
+            y = self.d2(self.conv2(torch.relu(self.d1(self.conv1(x.transpose(-1, -2)))))).transpose(-1, -2)
+            return y + x
+
+    class Model(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.item, self.pos = nn.Embedding(N + 1, D, padding_idx=0), nn.Embedding(S, D)
+            self.drop = nn.Dropout(p)
+            self.aln = nn.ModuleList(nn.LayerNorm(D, eps=1e-8) for _ in range(L))
+            self.att = nn.ModuleList(nn.MultiheadAttention(D, 1, dropout=p, batch_first=True) for _ in range(L))
+            self.fln = nn.ModuleList(nn.LayerNorm(D, eps=1e-8) for _ in range(L))
+            self.ffn = nn.ModuleList(FFN() for _ in range(L))
+            self.last = nn.LayerNorm(D, eps=1e-8)
+            self.register_buffer("mask", torch.ones(S, S, dtype=torch.bool).triu(1))
+
+        def forward(self, seq, pos, neg):
+            pad = (seq == 0).unsqueeze(-1)
+            x = self.item(seq) * D ** 0.5 + self.pos(torch.arange(S, device=seq.device))
+            x = self.drop(x).masked_fill(pad, 0.0)
+            for l in range(L):
+                qn = self.aln[l](x)
+                x = self.att[l](qn, x, x, attn_mask=self.mask, need_weights=False)[0] + x
+                x = self.ffn[l](self.fln[l](x)).masked_fill(pad, 0.0)
+            u = self.last(x)
+            keep = seq != 0
+            u, E = u[keep], self.item.weight[1:]
+            lp, ln = (u * E[pos[keep]]).sum(-1), (u * E[neg[keep]]).sum(-1)
+            bce = torch.nn.functional.binary_cross_entropy_with_logits
+            return bce(lp, torch.ones_like(lp)) + bce(ln, torch.zeros_like(ln))
+
+    m = Model().cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
+
+    def step(i):
+        seq, pos, neg = batches[i % len(batches)][:3]
+        opt.zero_grad()
+        m(seq, pos, neg).backward()
+        opt.step()
+    for i in range(5):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    return {"samples_per_sec": round(cfg["B"] / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+            "what": f"torch.nn SASRec (same shapes, fp32, eager ROCm aten, torch.optim.Adam), {steps} steps on the same GPU"}
 
 
 def score_call_traffic():
@@ -352,6 +417,7 @@ def main():
                                    "beauty_shape": {"rows": int(idx_small.numel()), "launch_ms": round(t_g, 4), "GB/s": round(gbs_small, 1),
                                                     "note": "3.1 MB table is L2/Infinity-Cache resident: launch-latency bound"}}
         del W_big, idx_big, out_big
+        line["train_baseline_aten_gpu"] = aten_train_baseline(cfg, batches)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, host_batches)
     if rank == 0:
