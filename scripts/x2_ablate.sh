@@ -1,3 +1,6 @@
+# Timing-only ablations of the split score kernel on the bench's trained state (rocprofv3 kernel trace of scripts/x2_prof.py per
+# build).  Build the variants first:  for v in NOMFMA NOAPPEND NOBARRIER NOREFILL NOPREFETCH; do make -C recboard_amd/csrc var V=$v; done
+# then run this script on the GPU box from the repository root ($GRAFT_REPO_ROOT).
 cd /tmp && export TMPDIR=/tmp
 X2_DUMP=/tmp/bs.pt python3 $GRAFT_REPO_ROOT/scripts/x2_bench_state.py 220 > /dev/null 2>&1
 for v in BASE NOMFMA NOAPPEND NOBARRIER NOREFILL NOPREFETCH; do

@@ -1,5 +1,5 @@
 """Cycle accounting of one wave of the score kernel (needs recboard_amd/librecengine_prof.so = a -DSC_PROFILE build of
-score.hip, see csrc/Makefile note): per stage, where the wave's time goes -- exact form vs split form."""
+score.hip: `make -C recboard_amd/csrc prof`): per stage, where the wave's time goes -- exact form vs split form."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
