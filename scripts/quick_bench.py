@@ -1,5 +1,8 @@
 import torch, time, numpy as np, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recboard_amd import lib
+if os.environ.get("RECENGINE_LIB"):   # a diagnostic build of the library
+    lib.LIB_PATH = os.environ["RECENGINE_LIB"]
 from recboard_amd.sasrec import SASRecEngine
 torch.manual_seed(1)
 N,B,S=12101,512,50
