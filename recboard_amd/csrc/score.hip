@@ -557,15 +557,26 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
         // split form: stage st -> LDS buffer buf.  Instruction p of wave wid fills the 1 KB block (4 p + wid) of the buffer, lane l its
         // 16-byte slot l: rows are 4 D bytes (CPR = D/4 chunks), so that is chunk position l % CPR of row (4 p + wid) * (64 / CPR) +
         // l / CPR, which holds the row's chunk (l % CPR) ^ (row & 15)  (D = 64: 4 rows per block; D = 128: 2).
+        // The lane's source address is  E + (64 st + srow_p) D + 4 g_p  with srow_p = (4 p + wid) (64 / CPR) + l / CPR: two base offsets
+        // per lane (p even / odd: at D = 128 the swizzle term 8 p mod 16 alternates; at D = 64 they coincide) plus constants, so a
+        // stage costs two 64-bit additions per instruction instead of a multiply-add and a row clamp each; only the catalog's last
+        // stage (rows past N are clamped to the last row) goes the long way.
+        constexpr int XCPR = D / 4, XRPB = 64 / XCPR;   // 16-byte chunks per row (16 / 32); rows per 1 KB block (4 / 2)
+        [[maybe_unused]] const int xsrow0 = wid * XRPB + lane / XCPR, xsrow1 = (4 + wid) * XRPB + lane / XCPR;
+        [[maybe_unused]] const int64_t xoff0 = (int64_t)xsrow0 * D + 4 * ((lane % XCPR) ^ (xsrow0 & 15));
+        [[maybe_unused]] const int64_t xoff1 = (int64_t)xsrow1 * D + 4 * ((lane % XCPR) ^ (xsrow1 & 15));
         auto issue_stage = [&](int64_t st, int buf) {
-            constexpr int CPR = D / 4;        // 16-byte chunks per row (16 / 32); a 1 KB block holds 64 / CPR rows
-            constexpr int RPB = 64 / CPR;
+            const bool last = (st + 1) * SC_TI > N;   // (wave-uniform)
+            const float* sbase = E + st * (SC_TI * D);
 #pragma unroll
-            for (int p = 0; p < CPR / 4; ++p) {
-                const int srow = (4 * p + wid) * RPB + lane / CPR;      // row of the stage this lane's slot belongs to
-                const int g = (lane % CPR) ^ (srow & 15);              // ... and the row's chunk that lives in the slot
-                const int64_t row = st * SC_TI + srow;
-                const float* src = E + (row < N ? row : N - 1) * D + 4 * g;
+            for (int p = 0; p < XCPR / 4; ++p) {
+                const float* src = sbase + ((p & 1) ? xoff1 : xoff0) + (p >> 1) * (8 * XRPB * D);
+                if (last) {
+                    const int srow = (4 * p + wid) * XRPB + lane / XCPR;      // row of the stage this lane's slot belongs to
+                    const int g = (lane % XCPR) ^ (srow & 15);               // ... and the row's chunk that lives in the slot
+                    const int64_t row = st * SC_TI + srow;
+                    src = E + (row < N ? row : N - 1) * D + 4 * g;
+                }
                 __attribute__((address_space(3))) unsigned char* dst =
                     (__attribute__((address_space(3))) unsigned char*)(__attribute__((address_space(3))) float*)tile + buf * (SC_TI * D * 4) + (4 * p + wid) * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, dst, 16, 0, 0);
