@@ -192,12 +192,12 @@ def aten_train_baseline(cfg, batches, steps=30):
 
 def score_call_traffic():
     """HBM bytes of one whole re_score_topk call (all its launches) from the committed PMC summary of scripts/x2_prof.py."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_v11_score_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_v12_score_pmc_traffic.json")
     try:
         with open(path) as f:
             c = json.load(f)["re_score_topk_call"]
         return {"hbm_bytes_per_launch": int(c["hbm_bytes_per_call"]), "algorithmic_lower_bound_bytes": int(c["algorithmic_lower_bound_bytes"]),
-                "source": "profiles/r1_v11_score_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
+                "source": "profiles/r1_v12_score_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
                           "summed over the launches of one call)"}
     except Exception:  # noqa: BLE001
         return None
@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
+    ap.add_argument("--no-baselines", action="store_true", help="skip the aten-on-GPU baselines (kernel-trace runs: only the engine's kernels)")
     ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
     ap.add_argument("--prefetch", action="store_true", help="sort the next batch's scatter-add destination rows one step ahead on a second stream (SASRecEngine.prefetch_plan)")
@@ -365,19 +366,22 @@ def main():
                             "whole_call": "all launches of one re_score_topk call, item-table split included"}
         # ---------------- the same evaluation as the reference executes it (UniSRec/main.py:408-414: dense scores, scores[seen] = -1e23,
         # torch.topk), through ROCm aten on this GPU and through torch on the host cores -- baselines, reported beside the engine
+        if args.no_baselines:
+            args.no_cpu_baseline = True
         def aten_eval(qq, EE, sp_, si_, rows):
             sc = qq @ EE.t()
             sc[rows, si_] = -1e23
             return torch.topk(sc, K, dim=1)
-        rows_all = torch.repeat_interleave(torch.arange(U, device="cuda"), seen_ptr[1:] - seen_ptr[:-1])
-        t_aten = event_time_ms(lambda: aten_eval(q, items, seen_ptr, seen_idx, rows_all), 5, warmup=2)
-        va, ia = aten_eval(q, items, seen_ptr, seen_idx, rows_all)
-        ve, ie = ops.score_topk(q, items, seen_ptr, seen_idx, K)
-        agree = float((ia == ie).float().mean())       # (aten's GEMM sums in another order: near-ties may swap)
-        line["eval_baselines"] = {"aten_gpu": {"items_per_sec": round(U * N / (t_aten * 1e-3), 1), "ms": round(t_aten, 3),
-                                               "what": "torch (ROCm aten) on the same GPU: q @ E.T, masked fill, torch.topk(50), all users in one batch",
-                                               "topk_index_agreement_with_engine": round(agree, 6)}}
-        del va, ia, ve, ie
+        if not args.no_baselines:
+            rows_all = torch.repeat_interleave(torch.arange(U, device="cuda"), seen_ptr[1:] - seen_ptr[:-1])
+            t_aten = event_time_ms(lambda: aten_eval(q, items, seen_ptr, seen_idx, rows_all), 5, warmup=2)
+            va, ia = aten_eval(q, items, seen_ptr, seen_idx, rows_all)
+            ve, ie = ops.score_topk(q, items, seen_ptr, seen_idx, K)
+            agree = float((ia == ie).float().mean())       # (aten's GEMM sums in another order: near-ties may swap)
+            line["eval_baselines"] = {"aten_gpu": {"items_per_sec": round(U * N / (t_aten * 1e-3), 1), "ms": round(t_aten, 3),
+                                                   "what": "torch (ROCm aten) on the same GPU: q @ E.T, masked fill, torch.topk(50), all users in one batch",
+                                                   "topk_index_agreement_with_engine": round(agree, 6)}}
+            del va, ia, ve, ie
         if not args.no_cpu_baseline:
             nsub = 2048
             qc, Ec = q[:nsub].cpu(), items.cpu()
@@ -417,7 +421,8 @@ def main():
                                    "beauty_shape": {"rows": int(idx_small.numel()), "launch_ms": round(t_g, 4), "GB/s": round(gbs_small, 1),
                                                     "note": "3.1 MB table is L2/Infinity-Cache resident: launch-latency bound"}}
         del W_big, idx_big, out_big
-        line["train_baseline_aten_gpu"] = aten_train_baseline(cfg, batches)
+        if not args.no_baselines:
+            line["train_baseline_aten_gpu"] = aten_train_baseline(cfg, batches)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, host_batches)
     if rank == 0:

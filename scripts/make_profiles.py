@@ -1,10 +1,11 @@
 """gpurun_out/<dir> (rocprofv3 kernel trace of bench.py + FETCH_SIZE / WRITE_SIZE passes of scripts/x2_prof.py + a plain bench line)
 -> profiles/<tag>_bench.json, <tag>_bench_kernel_stats.csv, <tag>_score_pmc_traffic.json.
-usage: python scripts/make_profiles.py gpurun_out/v10 r1_v10"""
+usage: python scripts/make_profiles.py gpurun_out/v10 r1_v10 [output directory, default profiles/]"""
 import csv, glob, json, os, shutil, sqlite3, subprocess, sys
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(root, "profiles")
+P = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")
+os.makedirs(P, exist_ok=True)
 db = sqlite3.connect(glob.glob(src + "/trace/**/*.db", recursive=True)[0])
 rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
 tot = sum(r[2] for r in rows)
