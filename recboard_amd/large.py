@@ -210,20 +210,23 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         owner applies one row-sparse Adam update per distinct row of its shard -- no table-sized gradient, no all-reduce of
         the table; the encoder's dense gradient arena is averaged with one all-reduce (`grad_hook` semantics of bench.py).
 
-    With a process group of size 1 the step is `SASRecLargeTableEngine.train_step` on the same numbers (tests/test_gpu_sasrec.py);
+    With a process group of size 1 and dedup=False the step is `SASRecLargeTableEngine.train_step` on the same numbers, bit for bit
+    (tests/test_gpu_sasrec.py); with dedup (the default: every distinct row travels once, gradient rows pre-summed per sender) the
+    table differs from it in rounding only;
     the exchange itself is covered under gloo with two ranks (tests/test_sharded_gloo.py).  Table values come from
     `counter_normal_rows`, so every GPU count trains the same table."""
 
-    def __init__(self, *args, group=None, **kw):
+    def __init__(self, *args, group=None, dedup=True, **kw):
         import torch.distributed as dist
         self.group = group
+        self.dedup = dedup   # only the distinct rows of a batch cross the fabric (ShardedTable); False: one row per looked-up position
         self.world = dist.get_world_size(group)
         kw["table_init"] = "counter"
         super().__init__(*args, **kw)
 
     def _alloc_table(self, seed):
         from .sharded import ShardedTable
-        self.table = ShardedTable(self.N + 1, self.D, group=self.group, device=self.device)
+        self.table = ShardedTable(self.N + 1, self.D, group=self.group, device=self.device, dedup=self.dedup)
         T = self.table
         step_rows = max(1, (1 << 24) // self.D)
         for l0 in range(0, T.local_rows, step_rows):

@@ -42,12 +42,17 @@ class EngineLocalOps:
 
 
 class Route:
-    """Permutation + split sizes of one lookup, kept for the backward exchange."""
-    __slots__ = ("order", "send_counts", "recv_counts", "recv_local", "n")
+    """Permutation + split sizes of one lookup, kept for the backward exchange.  dedup: `inv` maps every looked-up position to
+    its distinct row among the `n` rows that travel."""
+    __slots__ = ("order", "send_counts", "recv_counts", "recv_local", "n", "inv")
 
 
 class ShardedTable:
-    def __init__(self, num_rows, dim, local_ops=None, group=None, device=None, dtype=torch.float32):
+    def __init__(self, num_rows, dim, local_ops=None, group=None, device=None, dtype=torch.float32, dedup=True):
+        # dedup (SURVEY.md section 8e): every distinct row of a batch crosses the fabric once per direction -- the indices out, the
+        # rows back, and in the backward ONE pre-summed gradient row per distinct index (Zipf-distributed lookups repeat their
+        # hot rows many times: config 2's 76 800 lookups per step hit ~12 000 distinct rows)
+        self.dedup = dedup
         self.group = group
         self.G = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -74,6 +79,9 @@ class ShardedTable:
     # ---- exchange
     def _route(self, idx):
         flat = idx.reshape(-1)
+        inv = None
+        if self.dedup:
+            flat, inv = torch.unique(flat, return_inverse=True)
         own = self.owner(flat)
         order = torch.argsort(own, stable=True)
         send_counts = torch.bincount(own, minlength=self.G)
@@ -84,7 +92,7 @@ class ShardedTable:
         recv_local = torch.empty(sum(rc), dtype=flat.dtype, device=flat.device)
         dist.all_to_all_single(recv_local, send_local, rc, sc, group=self.group)
         r = Route()
-        r.order, r.send_counts, r.recv_counts, r.recv_local, r.n = order, sc, rc, recv_local, flat.numel()
+        r.order, r.send_counts, r.recv_counts, r.recv_local, r.n, r.inv = order, sc, rc, recv_local, flat.numel(), inv
         return r
 
     def lookup(self, idx):
@@ -95,14 +103,22 @@ class ShardedTable:
         dist.all_to_all_single(rows_sorted, rows_for_peers.contiguous(), r.send_counts, r.recv_counts, group=self.group)
         out = torch.empty_like(rows_sorted)
         out[r.order] = rows_sorted
+        if r.inv is not None:
+            out = self.ops.gather(out, r.inv)          # distinct rows -> every looked-up position
         return out.reshape(tuple(idx.shape) + (self.D,)), r
 
     def backward(self, grad_rows, route):
         """Send every gradient row to the owner of its table row; -> dense gradient of THIS rank's shard."""
-        g = grad_rows.reshape(-1, self.D)[route.order].contiguous()
+        g = self._grad_rows_to_send(grad_rows, route)
         recv = torch.empty((sum(route.recv_counts), self.D), dtype=g.dtype, device=g.device)
         dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
         return self.ops.scatter_add(recv, route.recv_local, self.local_rows)
+
+    def _grad_rows_to_send(self, grad_rows, route):
+        g = grad_rows.reshape(-1, self.D)
+        if route.inv is not None:                      # one pre-summed row per distinct index (deterministic segmented sum)
+            g = self.ops.scatter_add(g.contiguous(), route.inv, route.n)
+        return g[route.order].contiguous()
 
     def backward_sparse_adam(self, grad_rows, route, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, padding_global_row=None):
         """Training form for tables whose dense gradient does not fit: gradient rows go to their owners (the same single
@@ -111,7 +127,7 @@ class ShardedTable:
         if not hasattr(self, "m"):
             self.m = torch.zeros_like(self.weight)
             self.v = torch.zeros_like(self.weight)
-        g = grad_rows.reshape(-1, self.D)[route.order].contiguous()
+        g = self._grad_rows_to_send(grad_rows, route)
         recv = torch.empty((sum(route.recv_counts), self.D), dtype=g.dtype, device=g.device)
         dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
         if padding_global_row is not None and self.owner(padding_global_row) == self.rank:   # the padding row is never updated

@@ -268,8 +268,9 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
         rng = np.random.default_rng(77)
         kw = dict(dropout_rate=0.0, lr=1e-2, weight_decay=1e-4, seed=6)
         large = SASRecLargeTableEngine(N, S, D, 2, table_init="counter", **kw)
-        shard = SASRecShardedEngine(N, S, D, 2, **kw)
-        assert torch.equal(large.E, shard.table.weight)
+        shard = SASRecShardedEngine(N, S, D, 2, dedup=False, **kw)
+        dd = SASRecShardedEngine(N, S, D, 2, **kw)        # the default: distinct rows only, gradient rows pre-summed per sender
+        assert torch.equal(large.E, shard.table.weight) and torch.equal(large.E, dd.table.weight)
         for step in range(3):
             seq = rng.integers(1, N + 1, (B, S))
             for b in range(B):
@@ -281,6 +282,14 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
             assert torch.equal(large.arena.data, shard.arena.data), step
             assert torch.equal(large.E, shard.table.weight), step
             assert torch.equal(large.Em, shard.table.m) and torch.equal(large.Ev, shard.table.v), step
+            ld = dd.train_step(*batch)
+            assert abs(float(ld) - float(ll)) <= 1e-6 * abs(float(ll)), step
+            # same sums in another association: Adam turns a last-bit difference of a near-zero gradient sum into a step of up to
+            # lr, so a handful of entries may sit a few lr apart -- everything else agrees to rounding
+            for a, b in ((dd.table.weight, large.E), (dd.arena.data, large.arena.data)):
+                diff = (a - b).abs()
+                assert float(diff.max()) <= 2.5e-2 * (step + 1), step
+                assert float((diff > 1e-5 * (1 + b.abs())).float().mean()) < 2e-3, step
         seqs = torch.from_numpy(seq).cuda()
         sp = torch.arange(0, B + 1, device="cuda") * 3
         si = torch.sort(torch.from_numpy(rng.integers(0, N, (B, 3))).cuda(), 1).values.reshape(-1)

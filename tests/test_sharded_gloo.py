@@ -48,14 +48,24 @@ def _worker(rank, world, port, q):
         torch.manual_seed(0)                       # same "global" table on every rank
         R, D, K = 1001, 64, 20
         full = torch.randn(R, D)
+        w = 1.0 / torch.arange(1, R + 1)
+        # without dedup every looked-up position travels; with it (the default) every DISTINCT row does -- same rows, same gradients
+        plain = ShardedTable(R, D, local_ops=OracleLocalOps(), dedup=False)
+        plain.init_from_full(full)
+        gp = torch.Generator().manual_seed(100 + rank)
+        idx_p = torch.multinomial(w, 300, replacement=True, generator=gp).reshape(6, 50)
+        rows_p, route_p = plain.lookup(idx_p)
+        assert torch.equal(rows_p, full[idx_p]) and route_p.inv is None and route_p.n == 300
+        grad_p = torch.randn(6, 50, D, generator=gp)
+        shard_grad_plain = plain.backward(grad_p, route_p)
         tab = ShardedTable(R, D, local_ops=OracleLocalOps())
         tab.init_from_full(full)
         assert tab.local_rows == len(range(rank, R, world))
         g = torch.Generator().manual_seed(100 + rank)   # different batch on every rank
-        w = 1.0 / torch.arange(1, R + 1)
         idx = torch.multinomial(w, 300, replacement=True, generator=g).reshape(6, 50)   # Zipf: hot rows collide
         rows, route = tab.lookup(idx)
         assert torch.equal(rows, full[idx])                                               # == W[idx], bit exact
+        assert route.n == len(torch.unique(idx)) < 300                                    # only distinct rows travelled
         # backward: every rank contributes gradient rows; owner's dense shard gradient == global scatter restricted
         grad = torch.randn(6, 50, D, generator=g)
         shard_grad = tab.backward(grad, route)
@@ -65,6 +75,7 @@ def _worker(rank, world, port, q):
         dist.all_gather(all_grad, grad)
         ref = ranking.scatter_add_rows_c(torch.cat(all_grad).numpy(), torch.cat(all_idx).numpy(), R)
         np.testing.assert_allclose(shard_grad.numpy(), ref[rank::world], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(shard_grad_plain.numpy(), ref[rank::world], rtol=1e-5, atol=1e-5)
         # sparse optimizer step on the sharded table == sparse Adam on the unsharded table with everybody's gradient rows
         from oracle import adam as oadam
         Wref, mref, vref = full.numpy().copy(), np.zeros((R, D), np.float32), np.zeros((R, D), np.float32)
