@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                                                            float* __restrict__ part_vals, int* __restrict__ part_idx,
                                                            int maxseg, int64_t nub, int64_t nst, int64_t upw,
                                                            unsigned* __restrict__ gthr, int dbg,
-                                                           const int* __restrict__ blockflag, float* __restrict__ part_T) {
+                                                           const int* __restrict__ blockflag, float* __restrict__ part_T, int segs) {
     // Fallback pass with nobody flagged (the normal case): leave before anything else -- the kernel's prologue spills loop
     // invariants to scratch memory, 37 MB of writes per launch over 512 workgroups that an early exit further down does not avoid.
     if (blockflag && blockflag[nub + 1] == 0) return;
@@ -391,15 +391,30 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
     // empty slot: below every real entry (a real item id is < 2^29 - 1); decodes to (-FLT_MAX, no item)
     const double KEMPTY = __longlong_as_double((long long)((unsigned long long)__double_as_longlong((double)-3.402823466e+38f) | TAGMASK));
 
+    // Work split.  segs == 0: stream-K (score_plan) -- the (user block, stage) units in one line, cut into equal ranges.
+    // segs > 0 ("sliced", few user blocks: score_plan_topk): every user block's catalog is cut into the same `segs` slices of
+    // upw stages and workgroup w takes slice 8 (j / nub) + (w mod 8) of user block j mod nub, j = w / 8 -- consecutive workgroup
+    // ids go round the XCDs, so the workgroups of ONE XCD that run together score the SAME slice for different user blocks and
+    // the slice comes out of that XCD's L2 for all but the first of them (512 users x 12.5 M items: the table was streamed from
+    // HBM once per user block, 12.8 GB per call, and the kernel ran at HBM speed).
     const int64_t units_total = nub * nst;
     int64_t unit = (int64_t)blockIdx.x * upw;
-    const int64_t unit_end = (unit + upw < units_total) ? unit + upw : units_total;
+    int64_t unit_end = (unit + upw < units_total) ? unit + upw : units_total;
+    int seg_sliced = -1;
+    if (segs > 0) {
+        const int64_t j = blockIdx.x >> 3;
+        const int64_t ubs = j % nub;
+        seg_sliced = (int)((j / nub) * 8 + (blockIdx.x & 7));
+        if (seg_sliced >= segs) return;
+        unit = ubs * nst + (int64_t)seg_sliced * upw;
+        unit_end = (unit + upw < (ubs + 1) * nst) ? unit + upw : (ubs + 1) * nst;
+    }
 
     while (unit < unit_end) {
         const int64_t ub = unit / nst;
         const int64_t st0 = unit - ub * nst;
         const int64_t st1 = (st0 + (unit_end - unit) < nst) ? st0 + (unit_end - unit) : nst;
-        const int seg = (int)((int64_t)blockIdx.x - (ub * nst) / upw);
+        const int seg = seg_sliced >= 0 ? seg_sliced : (int)((int64_t)blockIdx.x - (ub * nst) / upw);
         const int64_t user = ub * SC_USERS + ul;
         if (blockflag && blockflag[ub] == 0) {   // fallback pass: nobody in this user block asked for it (workgroup-uniform)
             unit += st1 - st0;
@@ -937,14 +952,14 @@ __global__ __launch_bounds__(256) void score_topk_merge(const float* __restrict_
                                                         int maxseg, int lps, int presorted, int64_t B, int64_t N, int K, int64_t nst, int64_t upw,
                                                         const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
                                                         float* __restrict__ vals, int64_t* __restrict__ idx,
-                                                        const int* __restrict__ userflag) {
+                                                        const int* __restrict__ userflag, int segs) {
     const int lane = threadIdx.x & 63;
     const int64_t user = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (user >= B) return;
     if (userflag && userflag[user] == 0) return;   // fallback pass: this user's result is certified already
     const int64_t ub = user / SC_USERS;
     const int64_t w0 = (ub * nst) / upw, w1 = ((ub + 1) * nst - 1) / upw;
-    const int nseg = (int)(w1 - w0 + 1) * lps;   // lps partial lists per segment (2 for the register-list variant)
+    const int nseg = (segs > 0 ? segs : (int)(w1 - w0 + 1)) * lps;   // lps partial lists per segment (2 for the register-list variant)
     maxseg *= lps;
     const int PAD = 0x7FFFFFFF;
     float bv = -INFINITY;
@@ -1132,7 +1147,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
                                                           const float* __restrict__ qnorm, const unsigned* __restrict__ emax, float cerr,
                                                           float* __restrict__ vals, int64_t* __restrict__ idx,
                                                           int* __restrict__ userflag, int* __restrict__ blockflag,
-                                                          int dbg_maxerr) {
+                                                          int dbg_maxerr, int segs) {
     constexpr int LPR = D / 4;
     __shared__ __align__(16) float mx_stage[4 * MX_ROWS * D];
     const int mxd = dbg_maxerr >> 4;
@@ -1142,7 +1157,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
     if (user >= B) return;
     const int64_t ub = user / SC_USERS;
     const int64_t w0 = (ub * nst) / upw, w1 = ((ub + 1) * nst - 1) / upw;
-    const int nseg = (int)(w1 - w0 + 1);   // one pair list per segment
+    const int nseg = segs > 0 ? segs : (int)(w1 - w0 + 1);   // one pair list per segment
     const int PAD = 0x7FFFFFFF;
     float bv = -INFINITY;
     int bi = PAD;
@@ -1281,6 +1296,7 @@ struct ScorePlan {
     int64_t nub, nst, units, upw;
     int nwg, maxseg;
     bool small = false;   // few users against a short catalog: register-list kernels on segments of >= 8 stages (score_plan_topk)
+    int segs = 0;         // > 0: sliced split (score_kernel_reg), `segs` slices of upw stages per user block
 };
 
 static ScorePlan score_plan(int64_t B, int64_t N, int64_t D = 64, int64_t wg_cap = 0, int64_t seg_floor = 0) {
@@ -1309,6 +1325,8 @@ static size_t score_lds_bytes(int D, int K, bool topk) {
     return b;
 }
 
+static int g_score_sliced = 1;         // sliced split for calls with few user blocks (score_plan_topk; 0: A/B switch)
+extern "C" void re_dbg_score_sliced(int on) { g_score_sliced = on; }
 static int g_score_small = 1;          // small batches on the register-list kernels (score_plan_topk; 0: A/B switch)
 extern "C" void re_dbg_score_small(int on) { g_score_small = on; }
 static int64_t g_score_reg_nub = 16;   // register-list kernels from this many user blocks on (tuning switch, scripts/x2_small.py)
@@ -1351,7 +1369,23 @@ static bool score_reg_eligible(int64_t N, int64_t D, int64_t K) {
 // kernel's 859 us at 256 x 12 101, 116 instead of 577 us at 512, 120 instead of 521 us at 1 024 (scripts/x2_small.py).
 static ScorePlan score_plan_topk(int64_t B, int64_t N, int64_t D, int64_t K) {
     ScorePlan p = score_plan(B, N, D);
-    if (score_reg_eligible(N, D, K) && g_score_small && p.nub < g_score_reg_nub && p.upw < 64) {
+    if (!score_reg_eligible(N, D, K)) return p;
+    if (g_score_sliced && p.nub <= 64 && p.nst >= 64) {
+        // few user blocks: the sliced split -- every block's catalog in the same slices (>= 8 stages each), slice-mates of different
+        // blocks on one XCD (see score_kernel_reg)
+        const int64_t wgs = D == 128 ? SC_MAX_WGS / 2 : SC_MAX_WGS;
+        int64_t segs = wgs / p.nub;
+        if (segs > p.nst / 8) segs = p.nst / 8;
+        if (segs >= 8) {
+            p.upw = re_cdiv(p.nst, segs);
+            p.segs = (int)re_cdiv(p.nst, p.upw);
+            p.maxseg = p.segs;
+            p.nwg = (int)(8 * p.nub * re_cdiv(p.segs, 8));
+            p.small = true;
+            return p;
+        }
+    }
+    if (g_score_small && p.nub < g_score_reg_nub && p.upw < 64) {
         p = score_plan(B, N, D, 0, 8);
         p.small = true;
     }
@@ -1493,7 +1527,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
         const size_t ldsb = (X2V) ? lds_x2 : lds;                                                                                   \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH; \
         hipLaunchKernelGGL(kern, dim3(lp->nwg), dim3(256), ldsb, s, QP, EP, B, N, seen_ptr, seen_idx, (int)(KV), pv, pi, lp->maxseg, lp->nub, \
-                           lp->nst, lp->upw, GT, g_score_dbg, BF, PT);                                                                       \
+                           lp->nst, lp->upw, GT, g_score_dbg, BF, PT, lp->segs);                                                                       \
     } while (0)
     // register-list variant: many users per launch (its two lists per segment double the merge work, which dominates
     // when B is small -- A/B in scripts/tune_score.py)
@@ -1558,10 +1592,10 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             if ((rc = re_launch_status()) != RE_OK) return rc;
             if (D == 64)
                 hipLaunchKernelGGL(score_topk_merge_x<64>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4));
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs);
             else
                 hipLaunchKernelGGL(score_topk_merge_x<128>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4));
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs);
             if ((rc = re_launch_status()) != RE_OK) return rc;
             // ---- fallback pass over flagged user blocks only (normally none: every workgroup returns at once)
             blockflag = bflag;
@@ -1584,7 +1618,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
     }
     if (rc != RE_OK) return rc;
     hipLaunchKernelGGL(score_topk_merge, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, lp->maxseg, lps, (lps == 2) ? 1 : 0, B, N, (int)K, lp->nst, lp->upw,
-                       seen_ptr, seen_idx, vals, idx, userflag);
+                       seen_ptr, seen_idx, vals, idx, userflag, lp->segs);
     return re_launch_status();
 }
 
