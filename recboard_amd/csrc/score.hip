@@ -337,7 +337,12 @@ __device__ unsigned long long g_sr_counters_x[2];   // diagnostics (dbg == 3): d
 // them, the merge kernel re-scores the candidates with the exact fmaf chain and certifies the result (or flags the user for
 // the exact kernel).  Everything else -- queues, lists, bounds, seen handling, stream-K split -- is shared with the exact form.
 // blockflag != NULL (exact form as the fallback pass): user blocks whose flag is 0 are skipped.
-template <int D, int KR, int KT, bool X2>
+// NB (split form): LDS stage buffers.  2: the next stage is requested right behind the stage barrier, the seen window and the
+// bound word once per stage.  3 (long catalogs: the rows come from HBM and take longer to arrive than a stage takes to score): stages
+// are requested TWO ahead, and nothing else is loaded per stage -- the memory counter retires in order, so a wait for any other load
+// would drain the stage loads in flight: the seen window is reloaded only when a lane has used it up (blocking, rare: a few ids per
+// user over thousands of stages), the bound word every 16th stage.  The third buffer costs 5 queue entries per lane at D = 64.
+template <int D, int KR, int KT, bool X2, int NB = 2>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const float* __restrict__ Q, const float* __restrict__ E,
                                                            int64_t B, int64_t N, const int64_t* __restrict__ seen_ptr,
                                                            const int64_t* __restrict__ seen_idx, int K,
@@ -358,18 +363,19 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
     // Split form: the item stages go global -> LDS directly (global_load_lds_dwordx4: no staging registers, whose spilling had
     // put a wait for the prefetch right behind its issue), double buffered, rows unpadded with their 16-byte chunks XOR-swizzled
     // by the row number (conflict-free fragment reads); the queues give up 8 entries per lane to make room for the second buffer.
-    constexpr int QC = X2 ? 20 : SR_QC;
-    constexpr int TILE_FLOATS = X2 ? 2 * SC_TI * D : SC_TI * RSF;
+    constexpr int QC = X2 ? (NB == 3 && D == 64 ? 15 : 20) : SR_QC;
+    constexpr int TILE_FLOATS = X2 ? NB * SC_TI * D : SC_TI * RSF;
+    static_assert(NB == 2 || (NB == 3 && X2), "three stage buffers: split form only");
     static_assert(!X2 || D == 64 || D == 128, "split form: D = 64 or 128");
     float* qv = tile + TILE_FLOATS;                          // [4 waves][QC][64 lanes]
     int* qi = reinterpret_cast<int*>(qv + 4 * QC * 64);
-    __shared__ int vote[4];
+    __shared__ __align__(16) int vote[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int ul = wid * 32 + c;
     const int NONE = 0x7FFFFFFF;
-    const int vote_at = (dbg >> 8) ? (dbg >> 8) - 1 : (X2 ? SR_VOTE - 6 : SR_VOTE);   // (tuning override in the upper bits of dbg)
+    const int vote_at = (dbg >> 8) ? (dbg >> 8) - 1 : (X2 ? (QC - 10 < 8 ? QC - 10 : 8) : SR_VOTE);   // (tuning override in the upper bits of dbg)
     dbg &= 0xFF;
     float* myqv = qv + wid * QC * 64 + lane;
     int* myqi = qi + wid * QC * 64 + lane;
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
         float thr = (user < B && dbg != 1 && (dbg < 5 || dbg == 7 || dbg == 8)) ? -INFINITY : INFINITY;
         float gbound = -INFINITY;   // the shared bound as last read
         unsigned genc = 0u;         // ... and the word in flight (split form: score_bound_k's estimate is there before the first stage)
-        if (X2 && gthr && user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (X2 && NB == 2 && gthr && user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (NB == 3: polled in the loop)
         int qn = 0;
         bool quiet = false;   // the last half tile had no hit in any lane (wave-uniform)
         // LDS byte address of the queue tail (= qbase + 256 * qn) and the running item id of the next accumulator register
@@ -607,7 +613,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 pf[p] = reinterpret_cast<const float4*>(E + (row < N ? row : N - 1) * D)[f % (D / 4)];
             }
         };
-        if constexpr (X2) { refill(); issue_stage(st0, 0); } else prefetch(st0);
+        if constexpr (X2) {
+            refill();
+            if constexpr (NB == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ns0), "+v"(ns1) :: "memory");   // (no load pending into the loop)
+            issue_stage(st0, 0);
+            if constexpr (NB == 3) issue_stage(st0 + 1 < st1 ? st0 + 1 : st0, 1);   // (always: the waits below count on it)
+        } else prefetch(st0);
 
         // Drains are WORKGROUP-wide where possible: the four waves share the stage barriers, so a wave draining alone stalls
         // the other three at the next barrier (measured: drain time x ~3).  The vote rides on the stage's first barrier (each
@@ -625,13 +636,31 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
             SC_T(if (prof) t0 = __builtin_readcyclecounter();)
             if (lane == 0) vote[wid] = 0;
             if (qn > vote_at) vote[wid] = 1;
-            if constexpr (X2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the stage has landed in LDS
+            bool wg_drain;
+            if constexpr (X2 && NB == 3) {
+                if (((st - st0) & 15) == 0) {   // the bound word, every 16th stage (wave-uniform; this wait drains the stage in flight)
+                    if (gthr && user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(genc) :: "memory");   // (waited for HERE, not at the merge point below)
+                }
+                // this wave's part of stage st has landed; the stage behind it may still be in flight (the counter retires in order)
+                if constexpr (D == 64) asm volatile("s_waitcnt vmcnt(4)" : "+v"(genc) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" : "+v"(genc) :: "memory");
+                // A bare barrier: __syncthreads() carries a fence, and the fence waits for EVERY outstanding load.  What has to be
+                // ordered is done by hand: the wave's vote and its LDS reads of the previous stage are complete (lgkmcnt(0)); the vote
+                // is read back in the same asm block (an LDS read the compiler knows about would wait for the loads in flight).
+                f32x4 vt;
+                asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier\n ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)"
+                             : "=v"(vt) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) int*)vote) : "memory");
+                wg_drain = (__float_as_uint(vt.x) | __float_as_uint(vt.y) | __float_as_uint(vt.z) | __float_as_uint(vt.w)) != 0u;
+            } else {
+                if constexpr (X2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the stage has landed in LDS
 #ifndef SC_X_NOBARRIER
-            __syncthreads();
+                __syncthreads();
 #endif
+                wg_drain = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
+            }
             SC_T(if (prof) { t1 = __builtin_readcyclecounter(); ta += t1 - t0; t0 = t1; })
-            const bool wg_drain = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
-            [[maybe_unused]] const int buf = (int)(st - st0) & 1;
+            [[maybe_unused]] const int buf = NB == 2 ? (int)(st - st0) & 1 : (int)((st - st0) % 3);
             if constexpr (!X2)
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
@@ -671,7 +700,10 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
                 }
             }
 #ifndef SC_X_NOPREFETCH
-            if constexpr (X2) { if (st + 1 < st1) issue_stage(st + 1, buf ^ 1); }
+            if constexpr (X2) {
+                if constexpr (NB == 2) { if (st + 1 < st1) issue_stage(st + 1, buf ^ 1); }
+                else issue_stage(st + 2 < st1 ? st + 2 : st1 - 1, (buf + 2) % 3);   // every wave is past stage st - 1, the buffer's last reader
+            }
             else prefetch(st + 1 < st1 ? st + 1 : st);
 #endif
             // The tile loop, in HALF tiles (16 items = accumulator registers 0-7 / 8-15): one queue-room check -- and the only
@@ -826,7 +858,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void score_kernel_reg(const f
 #undef SR_HALF
                 SC_T(if (prof) { t1 = __builtin_readcyclecounter(); te += t1 - t0; t0 = t1; })
             }
-            if constexpr (X2) {   // requests for the next stage (see above)
+            if constexpr (X2 && NB == 2) {   // requests for the next stage (see above)
                 refill();
                 if (gthr && user < B) genc = __hip_atomic_load(gthr + user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1057,7 +1089,8 @@ __global__ __launch_bounds__(256) void score_split_k(const float* __restrict__ X
 // bound is the smaller of the pair's two rhalf-th bests (2 rhalf items of the sample are at least that good).
 template <int D>
 __global__ __launch_bounds__(128) void score_bound_k(const float* __restrict__ Qs, const float* __restrict__ Es, int64_t B,
-                                                     int n_tiles, int64_t stride, int rhalf, unsigned* __restrict__ gthr) {
+                                                     int n_tiles, int64_t stride, int rhalf, unsigned* __restrict__ gthr,
+                                                     int chunk_tiles, float* __restrict__ partial) {
     constexpr int NS16 = D / 16;
     __shared__ float lx[8 * 64];
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
@@ -1086,9 +1119,13 @@ __global__ __launch_bounds__(128) void score_bound_k(const float* __restrict__ Q
         for (int j = 7; j >= 1; --j) l[j] = __builtin_amdgcn_fmed3f(v, l[j], l[j - 1]);   // clamp(v, l[j], l[j-1]): sorted insertion
         l[0] = fmaxf(v, l[0]);
     };
-    if (wv < n_tiles) fetch(wv, xh, xm);
-    for (int t = wv; t < n_tiles; t += 2) {
-        fetch(t + 2 < n_tiles ? t + 2 : t, nh, nm);   // (in flight under this tile's MFMAs and insertions)
+    // few users against a long catalog: the sample is cut into gridDim.y chunks of chunk_tiles tiles (one workgroup each, so that
+    // the sample can be large -- N/32 items -- without a few workgroups walking all of it); score_bound_merge_k joins the chunks
+    const int t_beg = blockIdx.y * chunk_tiles;
+    const int t_end = t_beg + chunk_tiles < n_tiles ? t_beg + chunk_tiles : n_tiles;
+    if (t_beg + wv < t_end) fetch(t_beg + wv, xh, xm);
+    for (int t = t_beg + wv; t < t_end; t += 2) {
+        fetch(t + 2 < t_end ? t + 2 : t, nh, nm);   // (in flight under this tile's MFMAs and insertions)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -1113,12 +1150,43 @@ __global__ __launch_bounds__(128) void score_bound_k(const float* __restrict__ Q
     if (wv == 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) insert(lx[j * 64 + lane]);
+        if (partial) {   // one of several chunks: the lane's best 8 of this chunk go to score_bound_merge_k
+#pragma unroll
+            for (int j = 0; j < 8; ++j) partial[(((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + j) * 64 + lane] = l[j];
+            return;
+        }
         float mine = l[0];
 #pragma unroll
         for (int j = 1; j < 8; ++j) mine = (j == rhalf - 1) ? l[j] : mine;
         const float bound = fminf(mine, __shfl_xor(mine, 32, 64));
         if (h == 0 && user < B && bound > -INFINITY) gthr[user] = sr_enc(bound);
     }
+}
+
+// joins the chunks of score_bound_k: one wave per 32 users, lane = (user, half) as there
+__global__ __launch_bounds__(64) void score_bound_merge_k(const float* __restrict__ partial, int nchunks, int64_t B, int rhalf,
+                                                          unsigned* __restrict__ gthr) {
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int64_t user = (int64_t)blockIdx.x * 32 + c;
+    float l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = -INFINITY;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = partial[(((int64_t)blockIdx.x * nchunks + ch) * 8 + j) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int k = 7; k >= 1; --k) l[k] = __builtin_amdgcn_fmed3f(v[j], l[k], l[k - 1]);
+            l[0] = fmaxf(v[j], l[0]);
+        }
+    }
+    float mine = l[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) mine = (j == rhalf - 1) ? l[j] : mine;
+    const float bound = fminf(mine, __shfl_xor(mine, 32, 64));
+    if (h == 0 && user < B && bound > -INFINITY) gthr[user] = sr_enc(bound);
 }
 
 // score_topk_merge_x: one wave per user.  The split kernel leaves, per (user, segment, lane half), a list of its C best items
@@ -1325,6 +1393,8 @@ static size_t score_lds_bytes(int D, int K, bool topk) {
     return b;
 }
 
+static int g_score_nb3 = 1;            // three stage buffers for long slices (0: A/B switch)
+extern "C" void re_dbg_score_nb3(int on) { g_score_nb3 = on; }
 static int g_score_sliced = 1;         // sliced split for calls with few user blocks (score_plan_topk; 0: A/B switch)
 extern "C" void re_dbg_score_sliced(int on) { g_score_sliced = on; }
 static int g_score_small = 1;          // small batches on the register-list kernels (score_plan_topk; 0: A/B switch)
@@ -1403,7 +1473,7 @@ static float score_cerr(int64_t D) {
 }
 
 struct ScoreWs {   // carving of re_score_topk's workspace
-    size_t half, off_pi, off_gthr, off_flags, off_qnorm, off_pt, off_qs, off_prep, total;
+    size_t half, off_pi, off_gthr, off_flags, off_qnorm, off_pt, off_bp, off_qs, off_prep, total;
     size_t n_zero;   // bytes from off_gthr that are zeroed per call: gthr[B] gthr2[B] userflag[B] blockflag[nub] emax/dbg[64]
 };
 static ScoreWs score_ws(int64_t B, int64_t N, int64_t D, int64_t K, const ScorePlan& p, bool x2, bool own_prep) {
@@ -1418,7 +1488,8 @@ static ScoreWs score_ws(int64_t B, int64_t N, int64_t D, int64_t K, const ScoreP
     w.off_flags = w.off_gthr + (size_t)B * 8;
     w.off_qnorm = w.off_gthr + w.n_zero;
     w.off_pt = w.off_qnorm + (x2 ? re_align((size_t)B * 4) : 0);                     // one dropped-below bound per list
-    w.off_qs = w.off_pt + (x2 ? re_align((size_t)p.nub * SC_USERS * segs * 2 * 4) : 0);
+    w.off_bp = w.off_pt + (x2 ? re_align((size_t)p.nub * SC_USERS * segs * 2 * 4) : 0);          // chunk lists of score_bound_k
+    w.off_qs = w.off_bp + (x2 ? re_align((size_t)(re_cdiv(B, 32) + 1024) * 64 * 8 * 4) : 0);
     w.off_prep = w.off_qs + (x2 ? re_align((size_t)B * D * 4) : 0);
     w.total = w.off_prep + (x2 && own_prep ? re_align((size_t)N * D * 4) + 256 : 0) + 256;
     return w;
@@ -1521,10 +1592,11 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
     // many workgroups as scored it the first time; when nobody is flagged, the normal case, what it costs is its dispatch)
     const ScorePlan pfb = score_plan_topk(B, N, D, K);
     const ScorePlan* lp = &p;
-#define SR_LAUNCH(DV, KRV, KTV, X2V, QP, EP, KV, GT, BF, PT)                                                                \
+#define SR_LAUNCH(DV, KRV, KTV, X2V, QP, EP, KV, GT, BF, PT) SR_LAUNCH_NB(DV, KRV, KTV, X2V, 2, QP, EP, KV, GT, BF, PT)
+#define SR_LAUNCH_NB(DV, KRV, KTV, X2V, NBV, QP, EP, KV, GT, BF, PT)                                                       \
     do {                                                                                                                             \
-        auto kern = score_kernel_reg<DV, KRV, KTV, X2V>;                                                                             \
-        const size_t ldsb = (X2V) ? lds_x2 : lds;                                                                                   \
+        auto kern = score_kernel_reg<DV, KRV, KTV, X2V, NBV>;                                                                        \
+        const size_t ldsb = (X2V) ? ((NBV) == 3 ? lds_x3 : lds_x2) : lds;                                                           \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH; \
         hipLaunchKernelGGL(kern, dim3(lp->nwg), dim3(256), ldsb, s, QP, EP, B, N, seen_ptr, seen_idx, (int)(KV), pv, pi, lp->maxseg, lp->nub, \
                            lp->nst, lp->upw, GT, g_score_dbg, BF, PT, lp->segs);                                                                       \
@@ -1535,6 +1607,8 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
         lps = 2;
         const size_t lds = (size_t)SC_TI * (D + 4) * 4 + (size_t)4 * SR_QC * 64 * 8;
         const size_t lds_x2 = (size_t)2 * SC_TI * D * 4 + (size_t)4 * 20 * 64 * 8;   // split form: two unpadded stage buffers, 20-entry queues
+        const size_t lds_x3 = (size_t)3 * SC_TI * D * 4 + (size_t)4 * (D == 64 ? 15 : 20) * 64 * 8;   // ... three, for long slices
+        const bool long_slices = g_score_nb3 && p.segs > 0 && p.upw >= 256;   // rows from HBM: request two stages ahead
         if (!x2 && re_zero_async(gthr, w.n_zero, s) != hipSuccess) return RE_ELAUNCH;   // (split form: zeroed by the query split)
         if (!g_score_share) gthr = nullptr;
         const int* blockflag = nullptr;
@@ -1565,8 +1639,15 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             }
             // starting thresholds from a sample (score_bound_k): n = N/16 items (512 .. 4096), every stride-th row
             if (gthr && g_score_sample) {
+                // every 16th item of a short catalog; every 32nd of a long one when there are few enough users for the sample to be
+                // cut into chunks over >= 1024 workgroups (a 12.5 M-item shard scored for 512 users: the 4 096-item sample of before let
+                // 12 000 items per user through, ~0.5 hits per half tile and wave, so the "quiet" screening rarely applied)
+                const int64_t ugroups = re_cdiv(B, 32);
+                int64_t nchunks = ugroups >= 1024 ? 1 : 1024 / ugroups;
                 int64_t n = N / 16;
-                n = n < 512 ? 512 : n > 4096 ? 4096 : n;
+                if (nchunks == 1) n = n < 512 ? 512 : n > 4096 ? 4096 : n;
+                else n = N / 32 < 4096 ? (N / 16 < 4096 ? N / 16 : 4096) : N / 32;
+                if (n < 512) n = 512;
                 if (n > N) n = N;
                 n &= ~31ll;
                 const int64_t stride = n > 0 ? N / n : 1;
@@ -1574,9 +1655,19 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
                 int r = (int)ceil(m + 4.5 * sqrt(m) + 2.0);
                 r += r & 1;
                 if (n >= 32 && r <= 16) {
-                    if (D == 64) hipLaunchKernelGGL(score_bound_k<64>, dim3((unsigned)re_cdiv(B, 32)), dim3(128), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
-                    else hipLaunchKernelGGL(score_bound_k<128>, dim3((unsigned)re_cdiv(B, 32)), dim3(128), 0, s, Qs, Es, B, (int)(n / 32), stride, r / 2, gthr);
+                    const int n_tiles = (int)(n / 32);
+                    if (nchunks > n_tiles / 8) nchunks = n_tiles / 8 > 0 ? n_tiles / 8 : 1;
+                    const int chunk_tiles = (int)re_cdiv(n_tiles, nchunks);
+                    nchunks = re_cdiv(n_tiles, chunk_tiles);
+                    float* bpart = nchunks > 1 ? (float*)((char*)ws + w.off_bp) : (float*)nullptr;
+                    const dim3 bgrid((unsigned)ugroups, (unsigned)nchunks);
+                    if (D == 64) hipLaunchKernelGGL(score_bound_k<64>, bgrid, dim3(128), 0, s, Qs, Es, B, n_tiles, stride, r / 2, gthr, chunk_tiles, bpart);
+                    else hipLaunchKernelGGL(score_bound_k<128>, bgrid, dim3(128), 0, s, Qs, Es, B, n_tiles, stride, r / 2, gthr, chunk_tiles, bpart);
                     if ((rc = re_launch_status()) != RE_OK) return rc;
+                    if (nchunks > 1) {
+                        hipLaunchKernelGGL(score_bound_merge_k, dim3((unsigned)ugroups), dim3(64), 0, s, bpart, (int)nchunks, B, r / 2, gthr);
+                        if ((rc = re_launch_status()) != RE_OK) return rc;
+                    }
                 }
             }
             const int C = score_x2_capacity(p, K);
@@ -1585,6 +1676,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
     do {   /* per-lane length = half the pair list's capacity */                               \
         if (C == 16) SR_LAUNCH(DV, 8, 8, true, Qs, Es, 8, gthr, nullptr, pt);                  \
         else if (C == 32) SR_LAUNCH(DV, 16, 16, true, Qs, Es, 16, gthr, nullptr, pt);          \
+        else if (long_slices) SR_LAUNCH_NB(DV, 28, 28, true, 3, Qs, Es, 28, gthr, nullptr, pt); \
         else SR_LAUNCH(DV, 28, 28, true, Qs, Es, 28, gthr, nullptr, pt);                       \
     } while (0)
             if (D == 64) SX_LAUNCH(64); else SX_LAUNCH(128);
@@ -1612,6 +1704,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             if (K == 50) SR_LAUNCH(128, 50, 50, false, Q, E, K, gthr, blockflag, nullptr); else SR_LAUNCH(128, 52, 0, false, Q, E, K, gthr, blockflag, nullptr);
         }
 #undef SR_LAUNCH
+#undef SR_LAUNCH_NB
         rc = re_launch_status();
     } else {
         rc = score_dispatch<true>(D, Q, E, B, N, seen_ptr, seen_idx, (int)K, pv, pi, p, nullptr, s);
