@@ -84,6 +84,21 @@ def test_split_equals_exact_kernel_d128(env):
         assert 0.0 < ratio < 0.5
 
 
+def test_split_equals_exact_kernel_long_catalog(env):
+    """Few users against a long catalog (a config-5 shard): the sliced work split, three stage buffers with requests two stages
+    ahead, the sample bound computed in chunks -- the split form and the exact kernel agree bit for bit, with and without a
+    seen mask."""
+    ops, L = env
+    g = torch.Generator(device="cuda").manual_seed(64)
+    U, N = 512, 2_500_000
+    q = torch.randn(U, 64, device="cuda", generator=g)
+    E = torch.randn(N, 64, device="cuda", generator=g)
+    for sp, si in (seen_csr(g, U, N, 40), (None, None)):
+        (v0, i0), (v1, i1), flagged, ratio = both_paths(ops, L, q, E, sp, si, 50)
+        assert torch.equal(i0, i1) and torch.equal(v0.view(torch.int32), v1.view(torch.int32))
+        assert flagged == 0 and 0.0 < ratio < 0.5
+
+
 def test_split_on_trained_like_state_with_popular_head(env):
     """Scores dominated by a run of neighbouring ids (popular items sit at the low ids in the bench's synthetic data and in
     many real catalogs): every user's best 50 come from the same 64 items, i.e. one stage of the kernel.  The lists must
