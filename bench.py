@@ -213,7 +213,6 @@ def main():
     ap.add_argument("--no-baselines", action="store_true", help="skip the aten-on-GPU baselines (kernel-trace runs: only the engine's kernels)")
     ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
-    ap.add_argument("--prefetch", action="store_true", help="sort the next batch's scatter-add destination rows one step ahead on a second stream (SASRecEngine.prefetch_plan)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,7 +235,7 @@ def main():
     batches = []
     for seq, pos, neg in host_batches:
         t = tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg))
-        batches.append(t + ((model.batch_aux_fused(*t) if args.encoder == 'fused' else model.batch_aux(*t)),))
+        batches.append(t + ((None if args.encoder == 'fused' else model.batch_aux(*t)),))
 
     hook = None
     if world > 1 or force_dist:
@@ -244,21 +243,15 @@ def main():
             dist.all_reduce(garena, op=dist.ReduceOp.AVG)   # (RCCL averages in the collective: no separate scaling launch)
 
     use_graph = args.encoder == "fused" and not args.no_graph
-    blobs = [model.pack_batch(*b[:3]) for b in batches] if use_graph else None
-    torch.cuda.synchronize()   # (the plan prefetch runs on its own stream and does not wait for this one)
+    torch.cuda.synchronize()
 
     def step_eager(i):
         seq, pos, neg, aux = batches[i % len(batches)]
         return model.train_step(seq, pos, neg, aux, grad_hook=hook)
 
-    def step_graph(i):
-        loss = model.train_step_graph(blobs[i % len(blobs)], cfg["B"], cfg["S"], grad_hook=hook)
-        if args.prefetch:
-            # --prefetch: while step i runs, sort batch i+1's scatter-add rows on a second stream (it depends on the batch
-            # only).  Measured at B=512: 0.2138 vs 0.2086 ms/step -- the two cross-stream event dependencies per step cost
-            # more than the ~20 us of sort they take out of the step (scripts/exp_prefetch.py); off by default.
-            model.prefetch_plan(blobs[(i + 1) % len(blobs)], cfg["B"], cfg["S"])
-        return loss
+    def step_graph(i):   # RAW batch in: one preparation launch (mask, count, scatter rows, encoder plan, staging) + one graph replay
+        seq, pos, neg, _ = batches[i % len(batches)]
+        return model.train_step_graph(seq, pos, neg, grad_hook=hook)
 
     step = step_eager
     if use_graph:
@@ -312,7 +305,7 @@ def main():
     if rank == 0 and not args.no_extras:
         # ---------------- dominant kernel of the timed region: the per-block encoder backward (MFMA-bound, fp32)
         if args.encoder == "fused":
-            seq, pos, neg, aux = batches[0]
+            seq, pos, neg, _ = batches[0]
             Bq, Sq, Dq, Lq = cfg["B"], cfg["S"], cfg["D"], cfg["L"]
             W = model._buffers(Bq, Sq)
             A = model.arena
@@ -321,24 +314,31 @@ def main():
             lw, lb = model.params["lastLN.weight"].detach(), model.params["lastLN.bias"].detach()
             dU = torch.randn(Bq, Sq, Dq, device="cuda") * 1e-3
             dx = torch.empty_like(dU)
+            pb = model.prepare_batch(seq, pos, neg)
 
-            def run_bwd():   # same launch as in the step: tape of the last training step, same length packing
+            def run_bwd():   # same launches as in the step: tape of the last training step, same plan
                 ops.sasrec_encoder_bwd(dU, seq, bt, lw, lb, Lq, cfg["p_drop"], model._step_seed(), W["tape"], bg,
-                                       G["lastLN.weight"], G["lastLN.bias"], out=dx, ws=W["ws_bwd"], packing=aux[2])
-            model.train_step(seq, pos, neg, aux)          # leaves this batch's tape in W["tape"]
+                                       G["lastLN.weight"], G["lastLN.bias"], out=dx, ws=W["ws_bwd"], plan=pb.plan)
+            model.train_step(seq, pos, neg, pb)           # leaves this batch's tape in W["tape"]
             model.arena.step -= 1                         # keep the seed the tape was produced with
             t_bwd = event_time_ms(run_bwd, 30)
             model.arena.step += 1
-            # algorithmic work: 62 kFLOP per token per block forward, x2 for the backward, over ALL B*S
-            # token slots the reference computes (pads included) -- what the packed kernel is priced against
-            fl = 2 * 62e3 * Bq * Sq * Lq
-            tfb = fl / (t_bwd * 1e-3) / 1e12
-            line["roofline"] = {"kernel": "sasrec_block_bwd_k (x%d blocks, + slab reduce)" % Lq, "bound": "mfma",
+            hdr = pb.plan.view(torch.int32)[:8].cpu().numpy()
+            n_items, n_tiles = int(hdr[0]), int(hdr[1])
+            # algorithmic work: 62 kFLOP per token per block forward, x2 for the backward, over ALL B*S token slots
+            # the reference computes (pads included); executed: 16 products of [16 rows] x D x D per tile and block + attention
+            fl_ref = 2 * 62e3 * Bq * Sq * Lq
+            fl_exec = Lq * n_tiles * (16 * 2 * 16 * Dq * Dq + 4 * 2 * 16 * 16 * Dq)
+            tfb = fl_ref / (t_bwd * 1e-3) / 1e12
+            line["roofline"] = {"kernel": "re_sasrec_encoder_bwd: enc_bwd_k (all blocks) + enc_wgrad_k + enc_grad_reduce_k", "bound": "mfma",
                                 "achieved": round(tfb, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": round(tfb / MFMA_F32_PEAK_TF, 4),
-                                "traffic": pmc_traffic("sasrec_block_bwd_k<true>", "sasrec_block_bwd_k<false>"), "launch_ms": round(t_bwd / Lq, 4),
-                                "work": f"2 x 62 kFLOP per token per block x {Bq * Sq} token slots = {fl / Lq:.3e} FLOP per block launch "
-                                        f"(reference-equivalent work incl. pad positions; the kernel packs 4 short sequences per workgroup)"}
+                                "achieved_executed": round(fl_exec / (t_bwd * 1e-3) / 1e12, 2),
+                                "frac_executed": round(fl_exec / (t_bwd * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                                "traffic": None, "launch_ms": round(t_bwd, 4),
+                                "work": f"reference-equivalent: 2 x 62 kFLOP per token per block x {Bq * Sq} token slots x {Lq} blocks = {fl_ref:.3e} FLOP "
+                                        f"(pad positions included); executed: {fl_exec:.3e} FLOP on {n_tiles} tiles of 16 real-token rows in "
+                                        f"{n_items} work items"}
         # ---------------- full-catalog evaluation leg: every user x every item, seen-mask + top-50 fused
         U, N, D, K = cfg["users"], cfg["items"], cfg["D"], 50
         rng = np.random.default_rng(7)

@@ -186,56 +186,60 @@ int re_score_topk_prepared(const float* Q, const float* E, const void* prep, int
                            void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
- * K6/K7  fused SASRec encoder (D = 64, S <= 64, L <= 4, 1 head): one workgroup per sequence, activations in LDS.
+ * Batch preparation of a SASRec step (what the top of `fit` does, SASRec/main.py:199-204, plus the encoder's work plan), as
+ * ONE device launch with no host sync (capturable):
+ *   valid [B*S] u8 = seq != 0;  count int32[1] = number of valid positions (M of the mean loss);
+ *   rows_all int64 [3*B*S] = seq | (valid ? pos + 1 : 0) | (valid ? neg + 1 : 0): destination rows of the step's item-gradient
+ *   contributions (0 = padding row = dropped by re_scatter_add_rows);
+ *   plan (re_sasrec_plan_bytes(B, S) bytes): the encoder kernels' work items.  Sequences are left-padded (SASRec/main.py:143-157),
+ *   so only the rows from a sequence's first real token on are materialised, in tiles of 16 rows: sequences of <= 16 rows share
+ *   tiles (power-of-two slots), longer ones own 2..4 tiles; a work item is one long sequence or up to `max_tiles` tiles of short
+ *   ones, chosen so that the items just fill `ncu` compute units.  The pad positions in front of a sequence are identical keys
+ *   (k = b_k, v = b_v) and enter the softmax analytically (one virtual key with multiplicity), forward and backward.
+ *   Optional: seq_out / pos_out / neg_out receive copies of the batch (static buffers of a captured step); state (DEVICE
+ *   uint32[4]) = { seed, 0, bits(lr / (1 - beta1^step)), bits(1 / sqrt(1 - beta2^step)) } -- `state` doubles as `seed_dev` of the dropout entry points and, from word 2, as `hyper` of re_adam_step_dev.
+ *   pos / neg may be NULL (evaluation: only the plan is wanted); then valid / count / rows_all rows 1, 2 are not written. */
+size_t re_sasrec_plan_bytes(int64_t B, int64_t S);
+int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
+                         int32_t max_tiles, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid, int32_t* count,
+                         int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
+                         double beta1, double beta2, re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K6/K7  fused SASRec encoder (D = 64, S <= 64, L <= 4, 1 head): one workgroup per work item of the plan, activations in LDS.
  * Replaces the per-block aten chain of SASRec/main.py:163-176 (after_one_block), :31-50 (PointWiseFeedForward),
  * :188-191 (block loop + lastLN): LN -> q/k/v -> causal softmax (pads attended as keys, K/V not layer-normed)
  * -> out_proj + residual -> LN -> Conv1d(k=1) FFN + residual -> pad mask; all five dropout sites in-kernel
  * (counter-based masks, csrc/re_rng.h; drop_p = 0 disables them).
- *   x0 [B,S,D]  = re_sasrec_embed output;  seq [B,S] int64 (0 = pad);  u [B,S,D] = userEmbds (lastLN output).
+ *   x0 [B,S,D] = re_sasrec_embed output, or NULL: the input rows are built inside the kernel from the item table E [R, D]
+ *   (row 0 = padding), the position table Ptab [S, D] and `scale` (= sqrt(D)) -- SASRec/main.py:181-187, same dropout stream as
+ *   re_sasrec_embed.  seq [B,S] int64 (0 = pad);  u [B,S,D] = userEmbds (lastLN output).
  *   block_params: HOST array of 12*L DEVICE pointers, per block in this order:
  *     attnLNs.weight, attnLNs.bias, in_proj_weight [3D,D], in_proj_bias [3D], out_proj.weight [D,D], out_proj.bias,
  *     fwdLNs.weight, fwdLNs.bias, conv1.weight [D,D(,1)], conv1.bias, conv2.weight, conv2.bias
+ *   plan: from re_sasrec_batch_prep for THIS seq.  ncu: the launch grid (compute units to fill; <= 1024).
  *   tape: NULL for inference; otherwise re_sasrec_tape_bytes() bytes that receive the activations the backward
- *   needs (x, q, k, v, P, o, x1, relu(h), LN statistics).
- *   order / nshort (both NULL or both set, DEVICE int32): optional length packing.  order[B] lists the sequence
- *   ids with the `*nshort` "short" ones first -- short = every real token lies in the last 16 positions.  Four short
- *   sequences share one workgroup iteration (block-diagonal attention; the S-16 leading pad positions enter the
- *   softmax analytically as one key of multiplicity S-16), the others take one iteration each.  Results are the
- *   same function of the inputs either way.  In training mode rows of u / dx0 at pad positions in front of a short
- *   sequence's window are not written (nothing on the path reads them); inference fills them with lastLN.bias.
- * re_sasrec_encoder_bwd: given dU [B,S,D] (gradient w.r.t. u) and the tape of the SAME (drop_p, seed) forward,
- *   writes dx0 [B,S,D] (gradient w.r.t. x0, for re_scatter_add_rows / the position table) and OVERWRITES the
- *   parameter gradients: block_grads is a HOST array of 12*L DEVICE pointers in the order above.
- *   Weight gradients are accumulated per workgroup in registers, written as slabs and reduced in a fixed order
- *   (deterministic, no float atomics). */
+ *   needs (x, LN_a(x), q, k, v, P, o, x1, LN_f(x1), relu(h), LN statistics), indexed by the plan's compact rows.
+ *   In training mode rows of u / dx0 at the pad positions in front of a sequence are not written (nothing on the path reads
+ *   them); inference fills them with lastLN.bias (= what the reference's encode returns there).
+ * re_sasrec_encoder_bwd: given dU [B,S,D] (gradient w.r.t. u) and the tape of the SAME (drop_p, seed, plan) forward, ONE launch
+ *   for all blocks writes dx0 [B,S,D] and six dY operands per block; the weight gradients dW = dY^T X are then split-K products
+ *   over all compact rows (second launch) and a fixed-order reduction (third launch) that OVERWRITES the parameter gradients:
+ *   block_grads is a HOST array of 12*L DEVICE pointers in the order above.  Deterministic, no float atomics.
+ *   dPtab == NULL: dx0 = gradient w.r.t. x0 (for re_sasrec_embed_bwd).  dPtab != NULL: re_sasrec_embed_bwd is fused in -- dx0
+ *   receives the item-gradient contribution rows (pad mask, embedding dropout mask, * scale) and dPtab [S, D] the
+ *   position-table gradient. */
 size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
-int re_sasrec_encoder_fwd(const float* x0, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
-                          const float* const* block_params, const float* last_w, const float* last_b,
-                          float drop_p, uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, size_t tape_bytes,
-                          const int32_t* order, const int32_t* nshort, re_stream_t stream);
-/* re_sasrec_encoder_bwd + re_sasrec_embed_bwd in one pass: block 0's kernel applies the pad mask, the embedding dropout mask
- * and `scale` itself, so `contrib` [B, S, D] receives the item-gradient contribution rows (what re_sasrec_embed_bwd leaves
- * in place) and dP [S, D] the position-table gradient.  Rows of pads in front of a packed sequence's window are not written
- * (they are dropped by the scatter-add: destination row 0 = padding). */
-int re_sasrec_encoder_embed_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
-                                const float* const* block_params, const float* last_w, const float* last_b, float drop_p,
-                                uint32_t seed, const uint32_t* seed_dev, const void* tape, float scale, float* contrib,
-                                float* dP, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
-                                size_t ws_bytes, const int32_t* order, const int32_t* nshort, re_stream_t stream);
-/* re_sasrec_embed + re_sasrec_encoder_fwd in one launch: the encoder's input rows are built inside the kernel from the item
- * table E [R, D] (row 0 = padding), the position table P [S, D] and `scale` (= sqrt(D)); same dropout stream as
- * re_sasrec_embed, so re_sasrec_embed_bwd / re_sasrec_encoder_bwd apply unchanged. */
-int re_sasrec_embed_encoder_fwd(const float* E, int64_t R, const float* P, float scale, const int64_t* seq, int64_t B, int64_t S,
-                                int64_t D, int64_t L, const float* const* block_params, const float* last_w,
-                                const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev, float* u,
-                                void* tape, size_t tape_bytes, const int32_t* order, const int32_t* nshort,
-                                re_stream_t stream);
+int re_sasrec_encoder_fwd(const float* x0, const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, int64_t B,
+                          int64_t S, int64_t D, int64_t L, const float* const* block_params, const float* last_w,
+                          const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev, const void* plan, int32_t ncu,
+                          float* u, void* tape, size_t tape_bytes, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
-                          const float* const* block_params, const float* last_w, const float* last_b,
-                          float drop_p, uint32_t seed, const uint32_t* seed_dev, const void* tape, float* dx0,
-                          float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
-                          size_t ws_bytes, const int32_t* order, const int32_t* nshort, re_stream_t stream);
+                          const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,
+                          const uint32_t* seed_dev, const void* tape, const void* plan, int32_t ncu, float scale, float* dx0,
+                          float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
+                          re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Ranking metrics from the sorted top-K list of re_score_topk (freerec.metrics via Coach.evaluate, contract mirrored at
@@ -291,12 +295,6 @@ int re_bce_logits(const float* logits, const float* labels, int64_t n, float* lo
  * n must be a multiple of 4. */
 int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1,
                      double beta2, double eps, double weight_decay, re_stream_t stream);
-/* Prepares a captured step for replay in ONE launch: dst[0:nbytes] = src[0:nbytes] (the step's packed batch -> the static
- * buffer the hipGraph reads; nbytes and both pointers multiples of 16) and state (DEVICE uint32[4]) = { seed, 0,
- * bits(lr / (1 - beta1^step)), bits(1 / sqrt(1 - beta2^step)) } -- state doubles as `seed_dev` of the dropout entry points
- * and, from word 2, as `hyper` of re_adam_step_dev. */
-int re_step_stage(void* dst, const void* src, size_t nbytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
-                  double beta1, double beta2, re_stream_t stream);
 int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
                  double beta1, double beta2, double eps, double weight_decay, re_stream_t stream);
 

@@ -37,7 +37,7 @@ class Coach:
                 # one staging launch + one hipGraph replay per step (SASRecEngine.train_step_graph); a short last batch
                 # gets its own captured graph
                 seq = data["ISeq"]
-                loss = self.model.train_step_graph(self.model.pack_batch(seq, data["IPos"], data["INeg"]), seq.shape[0], seq.shape[1])
+                loss = self.model.train_step_graph(seq, data["IPos"], data["INeg"])
             elif self.kind == "seq":
                 loss = self.model.train_step(data["ISeq"], data["IPos"], data["INeg"])
             else:

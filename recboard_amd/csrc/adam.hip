@@ -95,32 +95,6 @@ extern "C" int re_adam_step(float* p, const float* g, float* m, float* v, int64_
     return re_launch_status();
 }
 
-// One launch that prepares a captured (hipGraph) step for replay: copies the step's packed batch into the static buffer the
-// graph reads (16-byte words) and writes the step scalars { seed, 0, lr/(1-b1^t), 1/sqrt(1-b2^t) } where the captured
-// kernels look for them.  The scalars are computed on the host exactly as in re_adam_step.
-__global__ __launch_bounds__(256) void step_stage_k(uint4* __restrict__ dst, const uint4* __restrict__ src, int64_t n16,
-                                                    uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && state) {
-        state[0] = seed;
-        state[1] = 0u;
-        state[2] = __float_as_uint(step_size);
-        state[3] = __float_as_uint(inv_sqrt_bc2);
-    }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
-}
-extern "C" int re_step_stage(void* dst, const void* src, size_t nbytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
-                             double beta1, double beta2, re_stream_t stream) {
-    re_clear_error();
-    if ((nbytes && (!dst || !src)) || step < 1) return RE_EINVAL;
-    if ((nbytes & 15u) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u)) return RE_EUNSUPPORTED;
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    const int64_t n16 = (int64_t)(nbytes >> 4);
-    hipLaunchKernelGGL(step_stage_k, dim3(re_grid(n16 > 0 ? n16 : 1, 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)dst, (const uint4*)src,
-                       n16, state, seed, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
-    return re_launch_status();
-}
-
 // dst = alpha * src over a flat fp32 range (LightGCN: avgEmbds = allEmbds / (L+1), LightGCN/main.py:80)
 __global__ __launch_bounds__(256) void scale_copy_k(float* __restrict__ dst, const float* __restrict__ src, float alpha, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = alpha * src[i];

@@ -1,0 +1,417 @@
+// K6/K7 backward: ONE launch for all blocks (l = L-1 .. 0), one work item per workgroup iteration, everything in LDS.
+//
+// Gradient of the encoder of enc_fwd.hip (SASRec/main.py:163-176 + :31-50 + lastLN) w.r.t. its input rows, reading the forward's
+// tape (x, q, k, v, P, o, x1, relu(h), LN statistics) instead of recomputing the forward; dropout masks are regenerated from
+// (seed, stream, index).  An item's gradient chain is independent of every other item's, so the block loop runs inside the
+// kernel and dX never leaves LDS between blocks.
+//
+// What this kernel does NOT do is the six weight gradients dW = dY^T X per block: those are contractions over ALL rows of the
+// batch.  The kernel writes its six dY operands per block (dO2, dH, dX1, dQ, dK, dV) to a gradient tape, and
+// enc_wgrad.hip computes the weight gradients as split-K products over the compact rows at full-chip parallelism -- instead
+// of six more MFMA phases on every item's critical path plus one D x D slab per workgroup per matrix to reduce.
+// Bias / LayerNorm gradients are column sums: per-thread partials, one small slab per workgroup and block.
+//
+// MFMA-bound work: 10 products of [16 nt] x D x D per block per item.
+#include <math.h>
+
+#include "enc_common.h"
+
+template <int D>
+__device__ __forceinline__ float colsum(const float* tile, int tid, int nrows) {
+    using C = EC<D>;
+    const int c = tid % D, r0 = (tid / D) * C::RPW;
+    float s = 0.f;
+    if (r0 < nrows) {
+#pragma unroll
+        for (int i = 0; i < C::RPW; ++i) s += tile[(r0 + i) * C::LS + c];
+    }
+    return s;
+}
+// sum over the thread's rows of w[row] * tile[row][col]
+template <int D>
+__device__ __forceinline__ float colsum_w(const float* tile, const float* w, int tid, int nrows) {
+    using C = EC<D>;
+    const int c = tid % D, r0 = (tid / D) * C::RPW;
+    float s = 0.f;
+    if (r0 < nrows) {
+#pragma unroll
+        for (int i = 0; i < C::RPW; ++i) s = fmaf(w[r0 + i], tile[(r0 + i) * C::LS + c], s);
+    }
+    return s;
+}
+// sum over the thread's rows of dy * xhat, xhat = (x - mean[row]) * rstd[row]
+template <int D>
+__device__ __forceinline__ float colsum_xhat(const float* dy, const float* x, const float* mean, const float* rstd, int tid, int nrows) {
+    using C = EC<D>;
+    const int c = tid % D, r0 = (tid / D) * C::RPW;
+    float s = 0.f;
+    if (r0 < nrows) {
+#pragma unroll
+        for (int i = 0; i < C::RPW; ++i) {
+            const int r = r0 + i;
+            s = fmaf(dy[r * C::LS + c], (x[r * C::LS + c] - mean[r]) * rstd[r], s);
+        }
+    }
+    return s;
+}
+// LayerNorm backward for this thread's row slice: dst (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma
+template <int D, bool ACCUM>
+__device__ __forceinline__ void ln_bwd_row(const float* dy, const float* x, float* dst, const float* __restrict__ gamma, const float* mean,
+                                           const float* rstd, int tid) {
+    using C = EC<D>;
+    const int r = tid / C::TPR, c0 = (tid % C::TPR) * C::CPT;
+    float d[C::CPT], xv[C::CPT];
+#pragma unroll
+    for (int q = 0; q < C::CPT / 4; ++q) {
+        ld4(&d[4 * q], dy + r * C::LS + c0 + 4 * q);
+        ld4(&xv[4 * q], x + r * C::LS + c0 + 4 * q);
+    }
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::CPT; ++i) {
+        xv[i] = (xv[i] - mu) * rs;
+        d[i] *= gamma[c0 + i];
+        s1 += d[i];
+        s2 = fmaf(d[i], xv[i], s2);
+    }
+    s1 = row_sum<C::TPR>(s1) * (1.0f / D);
+    s2 = row_sum<C::TPR>(s2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < C::CPT; ++i) {
+        const float v = rs * (d[i] - s1 - xv[i] * s2);
+        if (ACCUM) dst[r * C::LS + c0 + i] += v; else dst[r * C::LS + c0 + i] = v;
+    }
+}
+
+__device__ __forceinline__ void stats_fetch(float2& r, const float* __restrict__ st, int nrows, int tid) {
+    r = make_float2(0.f, 0.f);
+    if (tid < nrows) r = *reinterpret_cast<const float2*>(st + 2 * tid);
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, const int64_t* __restrict__ seq, int B, int S, int L,
+                                                 SasrecParams P, float drop_scale, uint32_t thresh, uint32_t seed,
+                                                 const float* __restrict__ tape, EncTape T, const void* __restrict__ planp,
+                                                 float* __restrict__ dOut, float* __restrict__ gtape, float* __restrict__ slab,
+                                                 const uint32_t* __restrict__ seed_dev, int fuse_embed, float emb_scale) {
+    using C = EC<D>;
+    constexpr int KPT = C::ROWS / C::TPR;
+    if (seed_dev) seed ^= seed_dev[0];   // per-step seed kept in device memory (hipGraph replays)
+    extern __shared__ __align__(16) float lds[];
+    float* b0 = lds;
+    float* b1 = b0 + C::BUF;
+    float* b2 = b1 + C::BUF;
+    float* b3 = b2 + C::BUF;
+    float* b4 = b3 + C::BUF;
+    float* sP = b4 + C::BUF;
+    float* sD = sP + C::PBUF;
+    __shared__ float s_mean[C::ROWS], s_rstd[C::ROWS];
+    __shared__ float s_ppad[C::ROWS], s_w[C::ROWS], s_cpad[C::ROWS];   // virtual pad key: prob of one copy, total kept weight, dS
+    __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS];
+
+    const int tid0 = threadIdx.x;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    const EncPlan PL = enc_plan_view(planp, B, S);
+    const int n_items = PL.hdr[0];
+    const int64_t NR = 16 * enc_plan_max_tiles(B, S);
+
+    for (int k = 0; k * (int)gridDim.x < n_items; ++k) {
+        const int wi = enc_item_of(k, blockIdx.x, gridDim.x);
+        if (wi >= n_items) continue;
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: the wave's tile choices are scalar branches)
+        const int strip = wave % C::NS, wr = wave / C::NS;
+        const int c = lane & 15, col = 16 * strip + c;
+        const int r_e = tid / C::TPR, c0_e = (tid % C::TPR) * C::CPT, j0_e = (tid % C::TPR) * KPT;
+        const bool row_lead = (tid % C::TPR) == 0;
+        const EncItem it = enc_item(PL, wi);
+        const int nt = it.nt, nrows = 16 * nt;
+        const int64_t row0 = (int64_t)it.tile0 * 16;
+        __syncthreads();
+        enc_decode<D>(PL, it, seq, tid, s_gid, s_first, s_pad);
+        __syncthreads();
+        if (tid < C::ROWS) s_sid[tid] = s_gid[tid] >= 0 ? s_gid[tid] / S : -1;
+        TileRegs<D> T0, T1;
+        float2 ST;
+        tile_fetch_gid<D>(T0, dIn, s_gid, nrows, tid);
+        tile_fetch<D>(T1, tape + T.off_XL + row0 * D, nrows, tid);
+        stats_fetch(ST, tape + T.off_SL + row0 * 2, nrows, tid);
+        tile_commit<D>(b0, T0, nrows, tid);
+        tile_commit<D>(b1, T1, nrows, tid);
+        if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
+        __syncthreads();
+        float accV[EG_NVEC];
+#pragma unroll
+        for (int v = 0; v < EG_NVEC; ++v) accV[v] = 0.f;
+        // ---- u = LN_last(x_L): dgamma / dbeta, then dx_L in place
+        accV[10] = colsum_xhat<D>(b0, b1, s_mean, s_rstd, tid, nrows);
+        accV[11] = colsum<D>(b0, tid, nrows);
+        __syncthreads();
+        if (r_e < nrows) ln_bwd_row<D, false>(b0, b1, b0, P.last_w, s_mean, s_rstd, tid);
+        __syncthreads();
+
+        for (int l = L - 1; l >= 0; --l) {
+            const SasrecBlockParams W = P.blk[l];
+            const float* tp = tape + (int64_t)l * T.per_block;
+            float* gp = gtape + (int64_t)l * EG_NMAT * NR * D + row0 * D;
+            float wf[D / 4];
+            if (l != L - 1) {
+                accV[10] = 0.f; accV[11] = 0.f;
+            }
+            tile_fetch<D>(T1, tp + T.off_HR + row0 * D, nrows, tid);
+            tile_fetch<D>(T0, tp + T.off_X1 + row0 * D, nrows, tid);
+            stats_fetch(ST, tp + T.off_SF + row0 * 2, nrows, tid);
+            wfrag_n<D>(wf, W.w2, strip, lane);
+            // ---- pad mask of the block output (x'[pad] = 0) and dO2 = dX' * dropout2 mask
+            if (r_e < nrows) {
+                const bool dead = s_pad[r_e] != 0;
+#pragma unroll
+                for (int i = 0; i < C::CPT; ++i) {
+                    float v = dead ? 0.f : b0[r_e * C::LS + c0_e + i];
+                    b0[r_e * C::LS + c0_e + i] = v;
+                    if (thresh) {
+                        const uint32_t e = (uint32_t)((int64_t)s_gid[r_e] * D + c0_e + i);
+                        v = re_keep(seed, RE_STREAM_FFN2(l), e, thresh) ? v * drop_scale : 0.f;
+                    }
+                    b2[r_e * C::LS + c0_e + i] = v;
+                }
+            }
+            tile_commit<D>(b1, T1, nrows, tid);   // HR
+            __syncthreads();
+            // ---- A. FFN second map: db2; dH = (dO2 W2) * (hr > 0) * scale
+            tile_store<D>(b2, gp + 0 * NR * D, nrows, tid);
+            accV[5] = colsum<D>(b2, tid, nrows);
+            gemm_rows<D>(b2, wf, lane, wr, nt, [&](int row, float v) {
+                b3[row * C::LS + col] = (b1[row * C::LS + col] > 0.f) ? v * drop_scale : 0.f;
+            });
+            wfrag_n<D>(wf, W.w1, strip, lane);
+            __syncthreads();
+            // ---- B. FFN first map: db1; dY = dH W1 + dX'
+            tile_store<D>(b3, gp + 1 * NR * D, nrows, tid);
+            accV[4] = colsum<D>(b3, tid, nrows);
+            tile_commit<D>(b1, T0, nrows, tid);   // X1
+            if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
+            tile_fetch<D>(T0, tp + T.off_V + row0 * D, nrows, tid);
+            stats_fetch(ST, tp + T.off_PP + row0 * 2, nrows, tid);
+            gemm_rows<D>(b3, wf, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
+            wfrag_n<D>(wf, W.out_w, strip, lane);
+            __syncthreads();
+            // ---- C. LN_f backward: dgamma_f, dbeta_f, dX1 (in place in b0)
+            accV[8] = colsum_xhat<D>(b0, b1, s_mean, s_rstd, tid, nrows);
+            accV[9] = colsum<D>(b0, tid, nrows);
+            __syncthreads();
+            if (r_e < nrows) ln_bwd_row<D, false>(b0, b1, b0, W.ln_f_w, s_mean, s_rstd, tid);
+            float pq[KPT];   // this thread's slice of the saved probabilities
+            {
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) pq[q] = 0.f;
+                if (r_e < nrows) {
+                    const float* src = tp + T.off_P + (row0 + r_e) * C::ROWS + j0_e;
+                    if (KPT % 4 == 0) {
+#pragma unroll
+                        for (int q = 0; q < KPT / 4; ++q) ld4(&pq[4 * q], src + 4 * q);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < KPT; ++q) pq[q] = src[q];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- D. out_proj: dbo; dO = dX1 Wo
+            tile_store<D>(b0, gp + 2 * NR * D, nrows, tid);
+            accV[3] = colsum<D>(b0, tid, nrows);
+            gemm_rows<D>(b0, wf, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
+            // ---- E. attention: V, P; Pd = P * mask
+            tile_commit<D>(b1, T0, nrows, tid);   // V  (X1's last readers, phase C, are behind the barrier above)
+            if (tid < C::ROWS) { s_ppad[tid] = ST.x; s_w[tid] = ST.y; }
+            tile_fetch<D>(T0, tp + T.off_K + row0 * D, nrows, tid);
+            tile_fetch<D>(T1, tp + T.off_Q + row0 * D, nrows, tid);
+            if (r_e < nrows) {
+                const int i = r_e;
+                const int gi = s_gid[i];
+                const int sbase = s_sid[i] * S;
+#pragma unroll
+                for (int jj = 0; jj < KPT; ++jj) {
+                    const int j = j0_e + jj;
+                    const float p = pq[jj];          // 0 outside the causal / same-sequence window (the forward stored zeros there)
+                    float m = 1.0f;
+                    if (thresh && p != 0.f) {
+                        const int sj = s_gid[j] - sbase;
+                        m = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? drop_scale : 0.f;
+                    }
+                    sP[i * C::PLS + j] = p;
+                    sD[i * C::PLS + j] = p * m;
+                }
+            }
+            __syncthreads();
+            // dV = Pd^T dO; d b_v through the virtual pad key: sum_i w_i dO_i
+            gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b2[row * C::LS + col] = v; });
+            accV[2] = colsum_w<D>(b3, s_w, tid, nrows);
+            __syncthreads();
+            // dP = (dO V^T) * mask factor Pd / P (0, or 1 / (1 - p)), over the item's tile pairs (P is 0 elsewhere)
+            gemm_pairs<D>(b3, b1, lane, wave, it, [&](int row, int key, float v) {
+                const float p = sP[row * C::PLS + key];
+                const float pd = sD[row * C::PLS + key];
+                sD[row * C::PLS + key] = (p != 0.f) ? v * (pd / p) : 0.f;
+            });
+            tile_store<D>(b2, gp + 5 * NR * D, nrows, tid);
+            accV[2] += colsum<D>(b2, tid, nrows);
+            __syncthreads();
+            // dS = P (dP - rowsum(dP P)) / sqrt(D), the virtual pad key included in the row sum
+            if (r_e < nrows) {
+                const int i = r_e;
+                float dp[KPT], pp[KPT];
+                float s = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < KPT; ++jj) {
+                    dp[jj] = sD[i * C::PLS + j0_e + jj];
+                    pp[jj] = sP[i * C::PLS + j0_e + jj];
+                    if (pp[jj] == 0.f) dp[jj] = 0.f;
+                    s = fmaf(dp[jj], pp[jj], s);
+                }
+                s = row_sum<C::TPR>(s);
+                // virtual pad key: upstream grad of each copy = (dO_i . b_v) * mask; t = dO_i . b_v
+                float t = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < C::CPT; ++jj) t = fmaf(b3[i * C::LS + c0_e + jj], W.in_b[2 * D + c0_e + jj], t);
+                t = row_sum<C::TPR>(t);
+                const float wv = s_w[i], ppad = s_ppad[i];
+                s = fmaf(t, wv, s);                                            // rowdot includes the pad copies
+                if (row_lead) s_cpad[i] = (wv * t - (float)s_first[i] * ppad * s) * inv_sqrt_d;   // sum of dS over the copies
+#pragma unroll
+                for (int jj = 0; jj < KPT; ++jj) sD[i * C::PLS + j0_e + jj] = pp[jj] * (dp[jj] - s) * inv_sqrt_d;
+            }
+            __syncthreads();   // dS complete; dO (b3), V (b1) and P no longer needed
+            // ---- F. dQ = dS K (+ dS_pad b_k) -> b4 ; dK = dS^T Q -> b1
+            tile_commit<D>(b1, T0, nrows, tid);   // K
+            tile_commit<D>(b3, T1, nrows, tid);   // Q
+            tile_fetch<D>(T0, tp + T.off_X + row0 * D, nrows, tid);
+            stats_fetch(ST, tp + T.off_SA + row0 * 2, nrows, tid);
+            __syncthreads();
+            {
+                const float bkc = W.in_b[D + col];
+                gemm_tx<D>(sD, b1, lane, wr, strip, it, [&](int row, float v) { b4[row * C::LS + col] = fmaf(s_cpad[row], bkc, v); });
+            }
+            accV[1] = colsum_w<D>(b3, s_cpad, tid, nrows);   // d b_k through the virtual pad key: sum_i dS_pad_i q_i
+            wfrag_n<D>(wf, W.in_w, strip, lane);             // Wq
+            __syncthreads();
+            gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b1[row * C::LS + col] = v; });
+            tile_store<D>(b4, gp + 3 * NR * D, nrows, tid);
+            accV[0] = colsum<D>(b4, tid, nrows);
+            __syncthreads();
+            // ---- G. projections: dbq/dbk; dA1 = dQ Wq -> b3; dX (b0) += dK Wk + dV Wv
+            tile_store<D>(b1, gp + 4 * NR * D, nrows, tid);
+            accV[1] += colsum<D>(b1, tid, nrows);
+            gemm_rows<D>(b4, wf, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
+            wfrag_n<D>(wf, W.in_w + D * D, strip, lane);     // Wk
+            gemm_rows<D>(b1, wf, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
+            wfrag_n<D>(wf, W.in_w + 2 * D * D, strip, lane); // Wv
+            gemm_rows<D>(b2, wf, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
+            __syncthreads();
+            // ---- H. LN_a backward: dgamma_a, dbeta_a; dX += LN_a'(dA1)
+            tile_commit<D>(b4, T0, nrows, tid);   // X
+            if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
+            __syncthreads();
+            accV[6] = colsum_xhat<D>(b3, b4, s_mean, s_rstd, tid, nrows);
+            accV[7] = colsum<D>(b3, tid, nrows);
+            if (r_e < nrows) ln_bwd_row<D, true>(b3, b4, b0, W.ln_a_w, s_mean, s_rstd, tid);
+            __syncthreads();
+            // ---- this block's vector gradients: row-group partials -> one value per column (fixed order) -> the workgroup's slab
+            {
+                float* red = b1;   // [EG_NVEC][CG][D]  (12 * 512 floats; b1 and b2 are free and adjacent)
+#pragma unroll
+                for (int v = 0; v < EG_NVEC; ++v) red[v * C::NT + tid] = accV[v];
+                __syncthreads();
+                float* sl = slab + ((int64_t)blockIdx.x * L + l) * EG_NVEC * D;
+                for (int e = tid; e < EG_NVEC * D; e += C::NT) {
+                    const int v = e / D, cc = e % D;
+                    float s = red[v * C::NT + cc];
+#pragma unroll
+                    for (int i = 1; i < C::CG; ++i) s += red[v * C::NT + i * D + cc];
+                    sl[e] = (k == 0) ? s : sl[e] + s;
+                }
+                __syncthreads();
+            }
+        }
+        if (fuse_embed) {
+            // re_sasrec_embed_bwd fused in: pad rows -> 0, the embedding's dropout mask; the rows go out scaled by sqrt(D) as
+            // item-gradient contributions (the position-table gradient is summed from them by enc_wgrad.hip)
+            if (r_e < nrows) {
+                const bool dead = s_pad[r_e] != 0;
+#pragma unroll
+                for (int i = 0; i < C::CPT; ++i) {
+                    float v = dead ? 0.f : b0[r_e * C::LS + c0_e + i];
+                    if (thresh && !dead) {
+                        const uint32_t e = (uint32_t)((int64_t)s_gid[r_e] * D + c0_e + i);
+                        v = re_keep(seed, RE_STREAM_EMBED, e, thresh) ? v * drop_scale : 0.f;
+                    }
+                    b0[r_e * C::LS + c0_e + i] = v;
+                }
+            }
+            __syncthreads();
+            tile_store_gid<D>(b0, dOut, s_gid, nrows, tid, emb_scale);
+        } else {
+            tile_store_gid<D>(b0, dOut, s_gid, nrows, tid);
+        }
+    }
+}
+
+// ---- weight gradients (enc_wgrad.hip) ---------------------------------------------------------------------------------------
+int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
+                     int nwg, float* part, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab, float* const* block_grads,
+                     float* g_last_w, float* g_last_b, hipStream_t s);
+size_t enc_wgrad_part_floats(int64_t D, int64_t L);
+
+static inline int enc_bwd_grid(int64_t B, int64_t S, int32_t ncu) {
+    const int64_t mt = enc_plan_max_tiles(B, S);
+    if (ncu < 1) ncu = 256;
+    return (int)(mt < ncu ? mt : ncu);
+}
+
+extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L) {
+    if (B <= 0 || S <= 0 || D <= 0 || L <= 0) return 256;
+    const int64_t NR = 16 * enc_plan_max_tiles(B, S);
+    const int64_t nwg = 1024;   // upper bound of the launch grid (ncu)
+    return (size_t)(nwg * L * EG_NVEC * D + enc_wgrad_part_floats(D, L) + L * EG_NMAT * NR * D) * sizeof(float) + 512;
+}
+
+// dPtab == NULL: dx0 [B,S,D] receives the gradient w.r.t. x0 (rows of real tokens only).  Otherwise re_sasrec_embed_bwd is fused in:
+// dx0 receives the item-gradient contribution rows (pad mask, embedding dropout mask, * scale) and dPtab [S, D] the position-table gradient.
+extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                                     const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,
+                                     const uint32_t* seed_dev, const void* tape, const void* plan, int32_t ncu, float scale, float* dx0,
+                                     float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
+                                     re_stream_t stream) {
+    re_clear_error();
+    if (B == 0) return RE_OK;
+    if (!dU || !seq || !tape || !plan || !dx0 || !block_params || !block_grads || !g_last_w || !g_last_b || !last_w || !last_b || !ws || B < 0)
+        return RE_EINVAL;
+    if (D != 64 || S < 1 || S > 64 || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
+    if (drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
+    if (ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L)) return RE_EWORKSPACE;
+    for (int64_t i = 0; i < 12 * L; ++i)
+        if (!block_grads[i]) return RE_EINVAL;
+    SasrecParams P;
+    if (!se_fill_params(P, block_params, L, last_w, last_b)) return RE_EINVAL;
+    const EncTape T = enc_tape_layout(B, S, D, L);
+    const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
+    const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const int grid = enc_bwd_grid(B, S, ncu);
+    if (grid > 1024) return RE_EUNSUPPORTED;
+    const int64_t NR = 16 * enc_plan_max_tiles(B, S);
+    float* slab = (float*)ws;
+    float* part = slab + (size_t)1024 * L * EG_NVEC * D;
+    float* gtape = part + enc_wgrad_part_floats(D, L);
+    hipStream_t s = (hipStream_t)stream;
+    using C = EC<64>;
+    const size_t ldsb = (size_t)(5 * C::BUF + 2 * C::PBUF) * sizeof(float);
+    auto kf = enc_bwd_k<64>;
+    if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+    hipLaunchKernelGGL(kf, dim3(grid), dim3(C::NT), ldsb, s, dU, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, (const float*)tape, T, plan, dx0,
+                       gtape, slab, seed_dev, dPtab ? 1 : 0, scale);
+    if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
+    (void)NR;
+    return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, part, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
+}

@@ -1,0 +1,435 @@
+// Shared device code of the fused SASRec encoder kernels (enc_fwd.hip, enc_bwd.hip, enc_wgrad.hip, enc_plan.hip).
+//
+// Reference restated: SASRec/main.py:163-176 (after_one_block), :31-50 (PointWiseFeedForward), :178-193 (encode).
+//
+// WORK ITEMS.  Sequences are left-padded (SASRec/main.py:143-157: lpad_), so a sequence's real tokens are its last `span`
+// positions and the `first = S - span` positions in front of them are pads.  Pad positions are attended as keys by the
+// reference, but they are all the SAME key (x = 0 -> k = b_k, v = b_v): they enter the softmax analytically as one virtual
+// key of multiplicity `first`, forward and backward, and get no rows.  Only the rows from the first real token on are
+// materialised, in 16-row TILES (one MFMA tile): sequences of span <= 16 share tiles (power-of-two slots, sorted by size:
+// no slot straddles a tile; attention is restricted to same-sequence rows), a longer sequence owns ceil(span/16) tiles.
+// A work item = 1..MAXT consecutive tiles: one long sequence, or G tiles of short ones (G chosen by the plan kernel so that
+// the items just fill the chip).  On Beauty-shaped batches (88 % of the token slots are padding) that is ~3 600 rows in
+// ~230 tiles instead of 25 600 token slots, spread over every CU.  `re_sasrec_batch_prep` (enc_plan.hip) builds the plan
+// on the device (no host sync, capturable).
+//
+// One workgroup (8 waves) per item; all of an item's activations live in LDS as [ROWS][D + 4] fp32 tiles; every product is
+// v_mfma_f32_16x16x4_f32 (exact fp32).  Wave (wr, strip) owns output columns [16 strip, +16) of the row tiles
+// tt = t * WR + wr.  The k index of an MFMA step is free as long as A and B agree: lane group g = lane >> 4 takes
+// k = 16 q + 4 g + i at step s = 4 q + i, so a k-contiguous operand is read as one 16-byte load per 16 of k, and a
+// k-strided one (rows 16 q + 4 g + i) hits disjoint LDS banks in the two lane groups of a ds_read_b32.
+#pragma once
+#include "re_common.h"
+#include "re_rng.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+struct EC {
+    static constexpr int NS = D / 16;                 // column strips
+    static constexpr int NW = 8;                      // waves per workgroup
+    static constexpr int NT = 64 * NW;                // threads
+    static constexpr int WR = NW / NS;                // wave row groups (2 at D = 64, 1 at D = 128)
+    static constexpr int MAXT = (D == 64) ? 4 : 2;    // tiles per work item (LDS capacity)
+    static constexpr int RT = MAXT / WR;              // row tiles per wave
+    static constexpr int ROWS = 16 * MAXT;
+    static constexpr int TPR = NT / ROWS;             // row-wise phases: threads per row (8 / 16) ...
+    static constexpr int CPT = D / TPR;               // ... columns per thread (8)
+    static constexpr int LS = D + 4;                  // LDS row stride (floats): conflict-free 16-byte row reads
+    static constexpr int PLS = ROWS + 4;              // row stride of the [ROWS][ROWS] probability tiles
+    static constexpr int BUF = ROWS * LS;
+    static constexpr int PBUF = ROWS * PLS;
+    static constexpr int KS = D / 4;                  // MFMA steps of a contraction over D
+    static constexpr int CG = NT / D;                 // column-sum phases: row groups ...
+    static constexpr int RPW = ROWS / CG;             // ... rows per thread (8)
+};
+
+struct SasrecBlockParams {
+    const float *ln_a_w, *ln_a_b;   // attnLNs.l
+    const float *in_w, *in_b;       // attnLayers.l.in_proj_{weight,bias}  [3D, D], [3D]
+    const float *out_w, *out_b;     // attnLayers.l.out_proj
+    const float *ln_f_w, *ln_f_b;   // fwdLNs.l
+    const float *w1, *b1, *w2, *b2; // fwdLayers.l.conv{1,2} ([D, D, 1] == [D, D])
+};
+#define SE_MAX_BLOCKS 4
+struct SasrecParams {
+    SasrecBlockParams blk[SE_MAX_BLOCKS];
+    const float *last_w, *last_b;
+};
+
+// ---- plan (re_sasrec_batch_prep): int32 words
+//   [0] n_items  [1] n_tiles  [2] n_long items  [3] tiles per short item  [4] number of valid (non-pad) positions  [5..7] 0
+//   [8 .. 8 + MT)            item descriptors: tile0 | nt << 24 | kind << 28   (kind 1 = one sequence over nt tiles)
+//   then int2 rowmap[MT * 16]: { gid = b * S + s or -1 (dummy row), first = pads in front of the row's sequence }
+//   then scratch of the plan kernel.   MT = B * ceil(S / 16) bounds the number of tiles.
+#define EP_HDR 8
+struct EncPlan {
+    const int* hdr;
+    const int* items;
+    const int2* rowmap;
+};
+__host__ __device__ inline int64_t enc_plan_max_tiles(int64_t B, int64_t S) { return B * ((S + 15) / 16); }
+__host__ __device__ inline int64_t enc_plan_rowmap_word(int64_t B, int64_t S) { return (EP_HDR + enc_plan_max_tiles(B, S) + 1) / 2 * 2; }
+__host__ __device__ inline size_t enc_plan_bytes(int64_t B, int64_t S) {
+    const int64_t mt = enc_plan_max_tiles(B, S);
+    return (size_t)(enc_plan_rowmap_word(B, S) + 2 * 16 * mt + 2 * B + 64) * 4;   // + span / placement scratch
+}
+__host__ __device__ inline EncPlan enc_plan_view(const void* plan, int64_t B, int64_t S) {
+    const int* w = (const int*)plan;
+    return EncPlan{w, w + EP_HDR, (const int2*)(w + enc_plan_rowmap_word(B, S))};
+}
+
+// ---- tape (activations saved by the forward for the backward), fp32, indexed by COMPACT row (tile * 16 + r): an item's
+// rows are one contiguous block of every array.  Per block l:
+//   X, A = LN_a(x), Q, K, V, O, X1, Y = LN_f(x1), HR : [NR][D]     P : [NR][ROWS] (pre-dropout probabilities, item-local keys)
+//   SA, SF : [NR][2] (mean, rstd)   PP : [NR][2] (probability of one virtual pad key, total kept weight)
+// then XL [NR][D] (input of lastLN) and SL [NR][2].  NR = 16 * MT.
+struct EncTape {
+    int64_t per_block, off_X, off_A, off_Q, off_K, off_V, off_O, off_X1, off_Y, off_HR, off_P, off_SA, off_SF, off_PP, off_XL, off_SL, total;
+};
+__host__ __device__ inline EncTape enc_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L) {
+    EncTape t;
+    const int64_t nr = 16 * enc_plan_max_tiles(B, S), act = nr * D, rows = (D == 64 ? 64 : 32);
+    int64_t o = 0;
+    t.off_X = o; o += act;
+    t.off_A = o; o += act;
+    t.off_Q = o; o += act;
+    t.off_K = o; o += act;
+    t.off_V = o; o += act;
+    t.off_O = o; o += act;
+    t.off_X1 = o; o += act;
+    t.off_Y = o; o += act;
+    t.off_HR = o; o += act;
+    t.off_P = o; o += nr * rows;
+    t.off_SA = o; o += nr * 2;
+    t.off_SF = o; o += nr * 2;
+    t.off_PP = o; o += nr * 2;
+    t.per_block = o;
+    t.off_XL = L * o;
+    t.off_SL = t.off_XL + act;
+    t.total = t.off_SL + nr * 2;
+    return t;
+}
+// ---- gradient tape written by the backward for the weight-gradient kernel: per block six [NR][D] arrays
+//   0 dO2 (-> dW2 with HR)  1 dH (-> dW1 with Y)  2 dX1 (-> dWo with O)  3 dQ (-> dWq with A)  4 dK (-> dWk with X)  5 dV (-> dWv with X)
+#define EG_NMAT 6
+// vector gradients per block: 0 bq 1 bk 2 bv 3 bo 4 b1 5 b2 6 ga 7 ba 8 gf 9 bf 10 glast 11 blast
+#define EG_NVEC 12
+
+template <class T>
+__device__ __forceinline__ const T* se_launder(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// ---- row-wise helpers: thread tid handles row tid / TPR, columns [CPT * (tid % TPR), +CPT) -----------------------------
+// sums over the TPR consecutive lanes that share a row as DPP butterflies inside a 16-lane row
+template <int CTRL>
+__device__ __forceinline__ float se_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int se_dpp(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+#define SE_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define SE_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define SE_DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i  inside each group of 8
+#define SE_DPP_MIRROR 0x140       // lane i <-> 15 - i inside each row of 16
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v) {
+    v += se_dpp<SE_DPP_XOR1>(v);
+    v += se_dpp<SE_DPP_XOR2>(v);
+    if (TPR >= 8) v += se_dpp<SE_DPP_HALF_MIRROR>(v);
+    if (TPR >= 16) v += se_dpp<SE_DPP_MIRROR>(v);
+    return v;
+}
+template <int TPR>
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, se_dpp<SE_DPP_XOR1>(v));
+    v = fmaxf(v, se_dpp<SE_DPP_XOR2>(v));
+    if (TPR >= 8) v = fmaxf(v, se_dpp<SE_DPP_HALF_MIRROR>(v));
+    if (TPR >= 16) v = fmaxf(v, se_dpp<SE_DPP_MIRROR>(v));
+    return v;
+}
+template <int TPR>
+__device__ __forceinline__ int row_sum_i(int v) {
+    v += se_dpp<SE_DPP_XOR1>(v);
+    v += se_dpp<SE_DPP_XOR2>(v);
+    if (TPR >= 8) v += se_dpp<SE_DPP_HALF_MIRROR>(v);
+    if (TPR >= 16) v += se_dpp<SE_DPP_MIRROR>(v);
+    return v;
+}
+
+__device__ __forceinline__ void ld4(float* f, const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+
+// ---- item decode ------------------------------------------------------------------------------------------------------
+struct EncItem {
+    int tile0, nt, kind;
+};
+__device__ __forceinline__ EncItem enc_item(const EncPlan& P, int wi) {
+    const int w = P.items[wi];
+    return EncItem{w & 0xFFFFFF, (w >> 24) & 0xF, (w >> 28) & 0xF};
+}
+// the work items of one workgroup: item k of workgroup b is b + k * grid on even rounds, (k + 1) * grid - 1 - b on odd ones
+// (items are sorted by size, largest first: the snake order pairs a workgroup's large item with a small one)
+__device__ __forceinline__ int enc_item_of(int k, int bid, int grid) { return (k & 1) ? (k + 1) * grid - 1 - bid : k * grid + bid; }
+
+// fills s_gid (b * S + s or -1), s_first (virtual pad keys of the row's sequence), s_pad (1 = pad or dummy row) for the item's rows
+template <int D>
+__device__ __forceinline__ void enc_decode(const EncPlan& P, const EncItem& it, const int64_t* __restrict__ seq, int tid, int* s_gid,
+                                           int* s_first, int* s_pad) {
+    if (tid < EC<D>::ROWS) {
+        int gid = -1, first = 0;
+        if (tid < 16 * it.nt) {
+            const int2 rm = P.rowmap[it.tile0 * 16 + tid];
+            gid = rm.x; first = rm.y;
+        }
+        s_gid[tid] = gid;
+        s_first[tid] = first;
+        s_pad[tid] = (gid < 0) ? 1 : (seq[gid] == 0);
+    }
+}
+// key tiles a row tile attends to: its own tile (short sequences share an item, never a tile's attention) or every tile up to
+// its own (one long sequence, causal)
+__device__ __forceinline__ int enc_kt_lo(const EncItem& it, int tt) { return it.kind ? 0 : tt; }
+
+// ---- GEMM pieces ----------------------------------------------------------------------------------------------------------
+// C[row][16 strip + c] = sum_k A[row][k] B[k][16 strip + c], k over D, for the wave's row tiles tt = t * WR + wr < nt.
+// A: LDS tile [ROWS][LS] (k contiguous).  bf[4 q + i] = B[k = 16 q + 4 g + i][n = 16 strip + c] supplied by the caller.
+// epi(row, value) is called for the lane's column.  Two accumulators per tile (even / odd steps): a lone tile's MFMAs would
+// otherwise wait 40 cycles on each other instead of issuing every 32.
+template <int D, int NTW, class Epi>
+__device__ __forceinline__ void gemm_rows_n(const float* A, const float (&bf)[D / 4], int lane, int wr, Epi epi) {
+    using C = EC<D>;
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 acc[NTW][2];
+    float af[NTW][D / 4];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tt = t * C::WR + wr;
+        acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < D / 16; ++q) ld4(&af[t][4 * q], A + (16 * tt + c) * C::LS + 16 * q + 4 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all fragment loads first, then the MFMAs back to back
+#pragma unroll
+    for (int s = 0; s < D / 4; ++s)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[s], acc[t][s & 1], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tt = t * C::WR + wr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi(16 * tt + 4 * g + j, acc[t][0][j] + acc[t][1][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+// (wr and nt are wave-uniform scalars: the wave's active tiles are t = 0 .. ntw-1, chosen by a scalar branch -- no per-MFMA predicates)
+template <int D, class Epi>
+__device__ __forceinline__ void gemm_rows(const float* A, const float (&bf)[D / 4], int lane, int wr, int nt, Epi epi) {
+    using C = EC<D>;
+    static_assert(C::RT == 2, "two row tiles per wave");
+    const int ntw = (nt - wr + C::WR - 1) / C::WR;
+    if (ntw >= 2) gemm_rows_n<D, 2>(A, bf, lane, wr, epi);
+    else if (ntw == 1) gemm_rows_n<D, 1>(A, bf, lane, wr, epi);
+}
+
+// weight fragment for y = x W^T: B[k][n] = W[n][k], W row-major [D][D] in global memory (k contiguous: 16-byte loads)
+template <int D>
+__device__ __forceinline__ void wfrag_t(float (&bf)[D / 4], const float* __restrict__ W, int strip, int lane) {
+    const float* p = W + (16 * strip + (lane & 15)) * D + 4 * (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) ld4(&bf[4 * q], p + 16 * q);
+}
+// weight fragment for dx = dy W: B[k][n] = W[k][n] (k strided)
+template <int D>
+__device__ __forceinline__ void wfrag_n(float (&bf)[D / 4], const float* __restrict__ W, int strip, int lane) {
+    const float* p = W + (4 * (lane >> 4)) * D + 16 * strip + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[4 * q + i] = p[(16 * q + i) * D];
+}
+
+// Score-type product over the item's (row tile, key tile) pairs: T[i][j] = sum_d A[i][d] B[j][d] for i in tile tt, j in tile kt,
+// both operands LDS tiles [ROWS][LS] with d contiguous.  Pairs are dealt round-robin over the 8 waves.  epi(row, key, value).
+template <int D, class Epi>
+__device__ __forceinline__ void gemm_pairs(const float* A, const float* B, int lane, int wave, const EncItem& it, Epi epi) {
+    using C = EC<D>;
+    const int g = lane >> 4, c = lane & 15;
+    int p = 0;
+    for (int tt = 0; tt < it.nt; ++tt)
+        for (int kt = enc_kt_lo(it, tt); kt <= tt; ++kt, ++p) {
+            if ((p & (C::NW - 1)) != wave) continue;
+            float af[D / 4], bf[D / 4];
+#pragma unroll
+            for (int q = 0; q < D / 16; ++q) {
+                ld4(&af[4 * q], A + (16 * tt + c) * C::LS + 16 * q + 4 * g);
+                ld4(&bf[4 * q], B + (16 * kt + c) * C::LS + 16 * q + 4 * g);
+            }
+            f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < D / 4; s += 2) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s + 1], bf[s + 1], a1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) epi(16 * tt + 4 * g + j, 16 * kt + c, a0[j] + a1[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// O[i][16 strip + c] = sum_j T[i][j] X[j][16 strip + c] over the key tiles of row tile tt (T: [ROWS][PLS] probabilities-type tile,
+// X: [ROWS][LS]) for the wave's row tiles.  epi(row, value).
+template <int D, class Epi>
+__device__ __forceinline__ void gemm_tx(const float* T, const float* X, int lane, int wr, int strip, const EncItem& it, Epi epi) {
+    using C = EC<D>;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < C::RT; ++t) {
+        const int tt = t * C::WR + wr;
+        if (tt >= it.nt) continue;
+        f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        for (int q = enc_kt_lo(it, tt); q <= tt; ++q) {
+            float af[4], bf[4];
+            ld4(af, T + (16 * tt + c) * C::PLS + 16 * q + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = X[(16 * q + 4 * g + i) * C::LS + 16 * strip + c];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi(16 * tt + 4 * g + j, a0[j] + a1[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// O[j][16 strip + c] = sum_i T[i][j] X[i][16 strip + c] for key tile kt = the wave's tiles, i over the row tiles that attend to kt
+// (kt itself, or kt .. nt-1 for a long sequence).  epi(row j, value).
+template <int D, class Epi>
+__device__ __forceinline__ void gemm_ttx(const float* T, const float* X, int lane, int wr, int strip, const EncItem& it, Epi epi) {
+    using C = EC<D>;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < C::RT; ++t) {
+        const int kt = t * C::WR + wr;
+        if (kt >= it.nt) continue;
+        f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        const int qhi = it.kind ? it.nt - 1 : kt;
+        for (int q = kt; q <= qhi; ++q) {
+            float af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = T[(16 * q + 4 * g + i) * C::PLS + 16 * kt + c];
+                bf[i] = X[(16 * q + 4 * g + i) * C::LS + 16 * strip + c];
+            }
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi(16 * kt + 4 * g + j, a0[j] + a1[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- tile <-> global ------------------------------------------------------------------------------------------------------
+// An item's rows are contiguous in the compact (tape) arrays: [16 nt][D] starting at row 16 tile0.
+template <int D>
+struct TileRegs {
+    float4 v[EC<D>::ROWS * (D / 4) / EC<D>::NT];
+};
+template <int D>
+__device__ __forceinline__ void tile_fetch(TileRegs<D>& R, const float* __restrict__ g, int nrows, int tid) {
+    using C = EC<D>;
+#pragma unroll
+    for (int q = 0; q < C::ROWS * (D / 4) / C::NT; ++q) {
+        const int f = q * C::NT + tid;
+        R.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nrows * (D / 4)) R.v[q] = reinterpret_cast<const float4*>(g)[f];
+    }
+}
+template <int D>
+__device__ __forceinline__ void tile_commit(float* tile, const TileRegs<D>& R, int nrows, int tid) {
+    using C = EC<D>;
+#pragma unroll
+    for (int q = 0; q < C::ROWS * (D / 4) / C::NT; ++q) {
+        const int f = q * C::NT + tid;
+        if (f < nrows * (D / 4)) *reinterpret_cast<float4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4))) = R.v[q];
+    }
+}
+template <int D>
+__device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ g, int nrows, int tid) {
+    using C = EC<D>;
+    for (int f = tid; f < nrows * (D / 4); f += C::NT)
+        reinterpret_cast<float4*>(g)[f] = *reinterpret_cast<const float4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4)));
+}
+// rows of a [B*S][D] matrix selected by s_gid (dummy rows read as zero / are not written)
+template <int D>
+__device__ __forceinline__ void tile_fetch_gid(TileRegs<D>& R, const float* __restrict__ g, const int* s_gid, int nrows, int tid) {
+    using C = EC<D>;
+#pragma unroll
+    for (int q = 0; q < C::ROWS * (D / 4) / C::NT; ++q) {
+        const int f = q * C::NT + tid;
+        R.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nrows * (D / 4)) {
+            const int gid = s_gid[f / (D / 4)];
+            if (gid >= 0) R.v[q] = reinterpret_cast<const float4*>(g + (int64_t)gid * D)[f % (D / 4)];
+        }
+    }
+}
+template <int D>
+__device__ __forceinline__ void tile_store_gid(const float* tile, float* __restrict__ g, const int* s_gid, int nrows, int tid, float scale = 1.0f) {
+    using C = EC<D>;
+    for (int f = tid; f < nrows * (D / 4); f += C::NT) {
+        const int r = f / (D / 4), c4 = f % (D / 4);
+        const int gid = s_gid[r];
+        if (gid >= 0) {
+            const float4 v = *reinterpret_cast<const float4*>(tile + r * C::LS + 4 * c4);
+            reinterpret_cast<float4*>(g + (int64_t)gid * D)[c4] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+        }
+    }
+}
+
+// LayerNorm of this thread's row slice (eps 1e-8, biased variance -- nn.LayerNorm, SASRec/main.py:89,94,106)
+template <int D>
+__device__ __forceinline__ void ln_row(const float* src, float* dst, const float* __restrict__ gw, const float* __restrict__ gb, int tid,
+                                       float& mean, float& rstd) {
+    using C = EC<D>;
+    const int r = tid / C::TPR, c0 = (tid % C::TPR) * C::CPT;
+    float x[C::CPT];
+#pragma unroll
+    for (int q = 0; q < C::CPT / 4; ++q) ld4(&x[4 * q], src + r * C::LS + c0 + 4 * q);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::CPT; ++i) s += x[i];
+    mean = row_sum<C::TPR>(s) * (1.0f / D);
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::CPT; ++i) { const float d = x[i] - mean; q2 = fmaf(d, d, q2); }
+    rstd = 1.0f / sqrtf(row_sum<C::TPR>(q2) * (1.0f / D) + 1e-8f);
+#pragma unroll
+    for (int i = 0; i < C::CPT; ++i) dst[r * C::LS + c0 + i] = (x[i] - mean) * rstd * gw[c0 + i] + gb[c0 + i];
+}
+
+static bool se_fill_params(SasrecParams& P, const float* const* bp, int64_t L, const float* last_w, const float* last_b) {
+    if (!bp || !last_w || !last_b || L < 1 || L > SE_MAX_BLOCKS) return false;
+    for (int64_t l = 0; l < L; ++l) {
+        const float* const* q = bp + 12 * l;
+        for (int i = 0; i < 12; ++i)
+            if (!q[i]) return false;
+        P.blk[l] = SasrecBlockParams{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]};
+    }
+    P.last_w = last_w;
+    P.last_b = last_b;
+    return true;
+}

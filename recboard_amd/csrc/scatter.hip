@@ -731,7 +731,7 @@ extern "C" int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n
                               weight_decay, ws, ws_bytes, stream);
 }
 
-// hipGraph-friendly form: the two step-dependent scalars come from device memory (as re_adam_step_dev; written by re_step_stage)
+// hipGraph-friendly form: the two step-dependent scalars come from device memory (as re_adam_step_dev; written by re_sasrec_batch_prep)
 extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
                                        float* m, float* v, const float* hyper, double beta1, double beta2, double eps,
                                        double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream) {

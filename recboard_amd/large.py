@@ -106,7 +106,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         A, D = self.arena, self.D
         B, S = seq.shape
         n = B * S
-        valid, rows_all, _, _, count = aux
+        valid, rows_all, count = aux.valid, aux.rows_all, aux.count
         p = self.p_drop if self.training else 0.0
         Ppos = self.params["Position.weight"]
         # embedding front end (engine kernel, no autograd node: its backward is re_sasrec_embed_bwd below)
@@ -128,12 +128,12 @@ class SASRecLargeTableEngine(SASRecEngine):
         """One step; gradients of the item table exist only as 3*B*S contribution rows."""
         A = self.arena
         if aux is None:
-            aux = self.batch_aux_fused(seq, pos, neg)
+            aux = self.prepare_batch(seq, pos, neg)
         loss, C = self._grads(seq, pos, neg, aux, self._step_seed())
         if grad_hook is not None:
             grad_hook(A.grad)
         A.step += 1
-        ops.sparse_adam_rows(C, aux[1], self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
+        ops.sparse_adam_rows(C, aux.rows_all, self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
                              padding_idx=0)
         ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
         return loss.squeeze(0)
@@ -143,19 +143,15 @@ class SASRecLargeTableEngine(SASRecEngine):
     #      Philox state; the engine's own masks get their per-step seed through the device word, as in SASRecEngine.)
     def _capture(self, B, S, with_adam):
         A = self.arena
-        _, total = self._blob_layout(B, S)
-        blob = torch.zeros(total, dtype=torch.uint8, device=self.device)
-        V = self._blob_views(blob, B, S)
-        V["order"].copy_(torch.arange(B, dtype=torch.int32, device=self.device))
-        V["count"].fill_(1)
+        blob = torch.zeros(ops.prep_layout(B, S)[1], dtype=torch.uint8, device=self.device)
         state = torch.zeros(4, dtype=torch.int32, device=self.device)
         hyper = state.view(torch.float32)[2:4]
-        aux = (V["valid"], V["rows_all"], (V["order"], V["nshort"]), None, V["count"])
+        z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
 
         def body():
-            loss, C = self._grads(V["seq"], V["pos"], V["neg"], aux, 0, seed_dev=state)
+            loss, C = self._grads(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state)
             if with_adam:
-                ops.sparse_adam_rows_dev(C, V["rows_all"], self.E, self.Em, self.Ev, hyper, self.betas[0], self.betas[1], 1e-8, self.wd,
+                ops.sparse_adam_rows_dev(C, pb.rows_all, self.E, self.Em, self.Ev, hyper, self.betas[0], self.betas[1], 1e-8, self.wd,
                                          padding_idx=0)
                 ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
             return loss, C
@@ -165,7 +161,8 @@ class SASRecLargeTableEngine(SASRecEngine):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            ops.step_stage(blob, blob.clone(), state, 0, 1, self.lr, *self.betas)
+            pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1])
+            pb.count.fill_(1)
             for _ in range(3):
                 body()
         torch.cuda.current_stream().wait_stream(side)
@@ -175,17 +172,19 @@ class SASRecLargeTableEngine(SASRecEngine):
             loss, C = body()
         for t, k in zip((A.data, A.m, A.v, A.grad), keep):
             t.copy_(k)
-        return dict(graph=graph, blob=blob, state=state, loss=loss, C=C, rows=V["rows_all"])
+        return dict(graph=graph, blob=blob, state=state, loss=loss, C=C, rows=pb.rows_all)
 
-    def train_step_graph(self, blob, B, S, grad_hook=None):
+    def train_step_graph(self, seq, pos, neg, grad_hook=None):
         A = self.arena
+        B, S = seq.shape
         key = (B, S, grad_hook is None, self.training)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         if key not in self._graphs:
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
-        ops.step_stage(g["blob"], blob, g["state"], self._step_seed(), A.step + 1, self.lr, *self.betas)
+        ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
+                              beta1=self.betas[0], beta2=self.betas[1])
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:
@@ -247,8 +246,8 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         B, S = seq.shape
         n = B * S
         if aux is None:
-            aux = self.batch_aux_fused(seq, pos, neg)
-        valid, rows_all, _, _, count = aux
+            aux = self.prepare_batch(seq, pos, neg)
+        valid, rows_all, count = aux.valid, aux.rows_all, aux.count
         sd = self._step_seed()
         p = self.p_drop if self.training else 0.0
         Ppos = self.params["Position.weight"]

@@ -40,15 +40,15 @@ SIGNATURES = {
     "re_score_prepare": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp]),
     "re_score_topk_prepared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_score_topk_prepared": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "re_sasrec_plan_bytes": (_sz, [_i64, _i64]),
+    "re_sasrec_batch_prep": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32, _i64,
+                                    _f64, _f64, _f64, _vp]),
     "re_sasrec_tape_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "re_sasrec_encoder_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
-    "re_sasrec_encoder_embed_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp,
-                                           _vp, _sz, _vp, _vp, _vp]),
-    "re_sasrec_embed_encoder_fwd": (_i32, [_vp, _i64, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _sz,
-                                           _vp, _vp, _vp]),
+    "re_sasrec_encoder_fwd": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _i32,
+                                     _vp, _vp, _sz, _vp]),
     "re_sasrec_encoder_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "re_sasrec_encoder_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp,
-                                     _vp, _sz, _vp, _vp, _vp]),
+    "re_sasrec_encoder_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _i32, _f32, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_spmm_csr": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp, _sz, _vp]),
     "re_rows_sqnorm_workspace_bytes": (_sz, []),
     "re_rows_sqnorm": (_i32, [_vp, _i64, _i64, _vp, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
@@ -65,7 +65,6 @@ SIGNATURES = {
     "re_colsum": (_i32, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "re_scale_copy": (_i32, [_vp, _vp, _f32, _i64, _vp]),
     "re_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _f64, _vp]),
-    "re_step_stage": (_i32, [_vp, _vp, _sz, _vp, _u32, _i64, _f64, _f64, _f64, _vp]),
     "re_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _vp]),
 }
 

@@ -323,91 +323,140 @@ def sasrec_block_tensors(named, L):
     return [named[k.format(l=l)] for l in range(L) for k in BLOCK_PARAM_ORDER]
 
 
-def seq_packing(seq, window=16):
-    """Length packing for the fused encoder (batch-assembly work, no host sync): -> (order int32[B], nshort int32[1]).
-    `short` = every real token of the left-padded sequence lies in its last `window` positions."""
-    S = seq.shape[1]
-    short = (seq[:, : max(S - window, 0)] != 0).sum(1) == 0
-    order = torch.argsort((~short).to(torch.int8), stable=True).to(torch.int32).contiguous()
-    return order, short.sum().to(torch.int32).reshape(1).contiguous()
+_NCU = {}
+
+
+def num_cus(device=None):
+    """Compute units of the device (the encoder kernels' launch grid: one resident workgroup per CU)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    if dev not in _NCU:
+        _NCU[dev] = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    return _NCU[dev]
+
+
+class PreparedBatch:
+    """What `sasrec_batch_prep` leaves on the device for one (seq, pos, neg) batch: views into ONE uint8 blob."""
+    __slots__ = ("B", "S", "blob", "seq", "pos", "neg", "rows_all", "valid", "count", "plan")
+
+
+def prep_layout(B, S):
+    """Byte offsets of a prepared batch's arrays inside its blob (256-byte aligned).  -> (offsets {name: (off, nbytes)}, total)."""
+    n, off, o = B * S, {}, 0
+    for name, nbytes in (("seq", 8 * n), ("pos", 8 * n), ("neg", 8 * n), ("rows_all", 24 * n), ("valid", n), ("count", 4),
+                         ("plan", int(lib.load().re_sasrec_plan_bytes(B, S)))):
+        off[name] = (o, nbytes)
+        o += (nbytes + 255) // 256 * 256
+    return off, o
+
+
+def prep_views(blob, B, S):
+    off, total = prep_layout(B, S)
+    if blob.numel() < total:
+        raise ValueError("recengine: prepared-batch blob too small")
+    cut = lambda k, dt: blob[off[k][0]:off[k][0] + off[k][1]].view(dt)  # noqa: E731
+    pb = PreparedBatch()
+    pb.B, pb.S, pb.blob = B, S, blob
+    pb.seq, pb.pos, pb.neg = (cut(k, torch.int64).view(B, S) for k in ("seq", "pos", "neg"))
+    pb.rows_all, pb.valid, pb.count, pb.plan = cut("rows_all", torch.int64), cut("valid", torch.uint8), cut("count", torch.int32), cut("plan", torch.uint8)
+    return pb
+
+
+def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4):
+    """Batch preparation as ONE launch (re_sasrec_batch_prep): valid mask, count, scatter destination rows, the encoder's work plan;
+    with `blob` (a static buffer of prep_layout(B, S) bytes) also copies (seq, pos, neg) into it and, with `state` (int32[4]),
+    writes the step scalars -- the staging launch of a captured step.  -> PreparedBatch (views into the blob)."""
+    _req(seq, torch.int64, "seq")
+    B, S = seq.shape
+    if pos is not None:
+        _req(pos, torch.int64, "pos"); _req(neg, torch.int64, "neg")
+    copy = blob is not None
+    if blob is None:
+        blob = torch.empty(prep_layout(B, S)[1], dtype=torch.uint8, device=seq.device)
+    pb = prep_views(_req(blob, torch.uint8, "blob"), B, S)
+    if state is not None:
+        _req(state, torch.int32, "state")
+    have = pos is not None
+    lib.check(lib.load().re_sasrec_batch_prep(_p(seq), _p(pos), _p(neg), B, S, num_cus(seq.device), int(max_tiles),
+                                              _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None,
+                                              _p(pb.neg) if copy and have else None, _p(pb.valid) if have else None,
+                                              _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
+                                              _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2),
+                                              _stream()), "re_sasrec_batch_prep")
+    if not copy:
+        pb.seq, pb.pos, pb.neg = seq, pos, neg
+    return pb
+
+
+def sasrec_plan(seq):
+    """The encoder's work plan alone (evaluation / unit tests).  -> opaque uint8 tensor."""
+    return sasrec_batch_prep(seq).plan
 
 
 def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None, tape=None,
-                       packing=None, seed_dev=None):
-    """u = lastLN(blocks(x0)) fused (re_sasrec_encoder_fwd).  -> (u [B,S,D], tape or None)."""
-    _req(x0, torch.float32, "x0"); _req(seq, torch.int64, "seq")
-    B, S, D = x0.shape
+                       plan=None, seed_dev=None, embed=None):
+    """u = lastLN(blocks(x0)) fused (re_sasrec_encoder_fwd).  embed = (E, P, scale): x0 is built inside the kernel (x0 = None).
+    -> (u [B,S,D], tape or None)."""
+    _req(seq, torch.int64, "seq")
+    B, S = seq.shape
+    if embed is not None:
+        E, Ptab, scale = embed
+        _req(E, torch.float32, "E"); _req(Ptab, torch.float32, "P")
+        D, x0 = E.shape[1], None
+    else:
+        _req(x0, torch.float32, "x0")
+        E, Ptab, scale, D = None, None, 0.0, x0.shape[2]
     Lb = lib.load()
-    u = out if out is not None else torch.empty_like(x0)
+    u = out if out is not None else torch.empty((B, S, D), dtype=torch.float32, device=seq.device)
     if need_tape and tape is None:
-        tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=x0.device)
+        tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=seq.device)
+    if plan is None:
+        plan = sasrec_plan(seq)
     tbl = _ptr_table(block_tensors)
-    order, nshort = packing if packing is not None else (None, None)
-    if order is not None:
-        _req(order, torch.int32, "order"); _req(nshort, torch.int32, "nshort")
-    lib.check(Lb.re_sasrec_encoder_fwd(_p(x0), _p(seq), B, S, D, L, tbl, _p(last_w), _p(last_b), float(drop_p),
-                                       int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(u), _p(tape), 0 if tape is None else tape.numel() * 4,
-                                       _p(order), _p(nshort), _stream()), "re_sasrec_encoder_fwd")
+    lib.check(Lb.re_sasrec_encoder_fwd(_p(x0), _p(E), 0 if E is None else E.shape[0], _p(Ptab), float(scale), _p(seq), B, S, D, L, tbl,
+                                       _p(last_w), _p(last_b), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(plan),
+                                       num_cus(seq.device), _p(u), _p(tape), 0 if tape is None else tape.numel() * 4, _stream()),
+              "re_sasrec_encoder_fwd")
     return u, tape
 
 
 def sasrec_embed_encoder_fwd(E, P, seq, scale, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None,
-                             tape=None, packing=None, seed_dev=None):
-    """sasrec_embed + sasrec_encoder_fwd in one launch (re_sasrec_embed_encoder_fwd).  -> (u [B,S,D], tape or None)."""
-    _req(E, torch.float32, "E"); _req(P, torch.float32, "P"); _req(seq, torch.int64, "seq")
-    B, S = seq.shape
-    D = E.shape[1]
-    Lb = lib.load()
-    u = out if out is not None else torch.empty((B, S, D), dtype=torch.float32, device=E.device)
-    if need_tape and tape is None:
-        tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=E.device)
-    tbl = _ptr_table(block_tensors)
-    order, nshort = packing if packing is not None else (None, None)
-    if order is not None:
-        _req(order, torch.int32, "order"); _req(nshort, torch.int32, "nshort")
-    lib.check(Lb.re_sasrec_embed_encoder_fwd(_p(E), E.shape[0], _p(P), float(scale), _p(seq), B, S, D, L, tbl, _p(last_w), _p(last_b),
-                                             float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(u), _p(tape),
-                                             0 if tape is None else tape.numel() * 4, _p(order), _p(nshort), _stream()),
-              "re_sasrec_embed_encoder_fwd")
-    return u, tape
+                             tape=None, plan=None, seed_dev=None):
+    """sasrec_embed + sasrec_encoder_fwd in one launch.  -> (u [B,S,D], tape or None)."""
+    return sasrec_encoder_fwd(None, seq, block_tensors, last_w, last_b, L, drop_p, seed, need_tape, out, tape, plan, seed_dev,
+                              embed=(E, P, scale))
 
 
 def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b,
-                       out=None, ws=None, packing=None, seed_dev=None):
-    """-> dx0 [B,S,D]; OVERWRITES the tensors in block_grads / g_last_* with the parameter gradients."""
+                       out=None, ws=None, plan=None, seed_dev=None, embed_scale=None, dP=None):
+    """-> dx0 [B,S,D]; OVERWRITES the tensors in block_grads / g_last_* with the parameter gradients.  With dP (and embed_scale)
+    re_sasrec_embed_bwd is fused in: the result is the item-gradient contribution rows and dP [S,D] the position-table gradient."""
     _req(dU, torch.float32, "dU"); _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape")
     B, S, D = dU.shape
     Lb = lib.load()
     dx0 = out if out is not None else torch.empty_like(dU)
     _req(dx0, torch.float32, "out")
+    if dP is not None:
+        _req(dP, torch.float32, "dP")
     if ws is None:
         ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
+    if plan is None:
+        plan = sasrec_plan(seq)
     tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
-    order, nshort = packing if packing is not None else (None, None)
     lib.check(Lb.re_sasrec_encoder_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
-                                       int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(tape), _p(dx0), tg, _p(g_last_w), _p(g_last_b), _p(ws),
-                                       ws.numel(), _p(order), _p(nshort), _stream()), "re_sasrec_encoder_bwd")
+                                       int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(tape), _p(plan), num_cus(dU.device),
+                                       float(embed_scale or 0.0), _p(dx0), _p(dP), tg, _p(g_last_w), _p(g_last_b), _p(ws),
+                                       ws.numel(), _stream()), "re_sasrec_encoder_bwd")
     return dx0
 
 
 def sasrec_encoder_embed_bwd(dU, seq, scale, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b, dP,
-                             out=None, ws=None, packing=None, seed_dev=None):
-    """sasrec_encoder_bwd + sasrec_embed_bwd in one pass (re_sasrec_encoder_embed_bwd): -> item-gradient contribution rows
-    [B,S,D]; OVERWRITES block_grads / g_last_* / dP with the parameter gradients."""
-    _req(dU, torch.float32, "dU"); _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape"); _req(dP, torch.float32, "dP")
-    B, S, D = dU.shape
-    Lb = lib.load()
-    contrib = out if out is not None else torch.empty_like(dU)
-    _req(contrib, torch.float32, "out")
-    if ws is None:
-        ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
-    tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
-    order, nshort = packing if packing is not None else (None, None)
-    lib.check(Lb.re_sasrec_encoder_embed_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
-                                             int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(tape), float(scale), _p(contrib), _p(dP), tg,
-                                             _p(g_last_w), _p(g_last_b), _p(ws), ws.numel(), _p(order), _p(nshort), _stream()),
-              "re_sasrec_encoder_embed_bwd")
-    return contrib
+                             out=None, ws=None, plan=None, seed_dev=None):
+    """sasrec_encoder_bwd + sasrec_embed_bwd in one pass: -> item-gradient contribution rows [B,S,D]; OVERWRITES block_grads /
+    g_last_* / dP with the parameter gradients."""
+    return sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b, out, ws,
+                              plan, seed_dev, embed_scale=scale, dP=dP)
 
 
 # ------------------------------------------------------------------------------------------------ K8
@@ -476,15 +525,6 @@ def adam_step_dev(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
         _req(t, torch.float32, nme)
     lib.check(lib.load().re_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), float(beta1), float(beta2), float(eps),
                                           float(weight_decay), _stream()), "re_adam_step_dev")
-
-
-def step_stage(dst, src, state, seed, step, lr, beta1=0.9, beta2=0.999):
-    """dst <- src (packed batch blobs, uint8, 16-byte multiples) and state int32[4] <- step scalars  (re_step_stage)."""
-    _req(dst, torch.uint8, "dst"); _req(src, torch.uint8, "src"); _req(state, torch.int32, "state")
-    if dst.numel() != src.numel() or state.numel() < 4:
-        raise ValueError("step_stage: blob sizes differ / state too small")
-    lib.check(lib.load().re_step_stage(_p(dst), _p(src), src.numel(), _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr),
-                                       float(beta1), float(beta2), _stream()), "re_step_stage")
 
 
 def scale_copy(dst, src, alpha):

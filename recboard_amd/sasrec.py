@@ -220,8 +220,7 @@ class SASRecEngine:
             p = self.p_drop if self.training else 0.0
             sd = self._step_seed()
             u, _ = ops.sasrec_embed_encoder_fwd(E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), self._block_tensors(),
-                                                P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, sd,
-                                                packing=ops.seq_packing(seq))
+                                                P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, sd)
             return u, E[1:]
         E = self.params["Item.embeddings.weight"]
         x = _EmbedFn.apply(E, self.params["Position.weight"], seq, float(self.D ** 0.5))
@@ -262,13 +261,11 @@ class SASRecEngine:
             return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K, prep=prep)
 
     @staticmethod
-    def batch_aux_fused(seq, pos, neg):
-        """As batch_aux, for the fused step: (valid uint8 [B*S], destination rows of all 3*B*S gradient contributions,
-        length packing, valid positions, number of valid positions int32[1])."""
-        v, rp, rn = SASRecEngine.batch_aux(seq, pos, neg)
-        vidx = torch.nonzero(v).reshape(-1).contiguous()      # valid positions (CE compacts to them; batch assembly, not the step)
-        count = v.sum(dtype=torch.int32).reshape(1)           # M of the mean loss (no host sync)
-        return v, torch.cat([seq.reshape(-1), rp, rn]), ops.seq_packing(seq), vidx, count
+    def prepare_batch(seq, pos, neg):
+        """Per-batch preparation of the fused step as ONE engine launch (re_sasrec_batch_prep; what the reference does at the top of
+        `fit`, SASRec/main.py:199-204, plus the encoder's work plan): valid mask, number of valid positions, destination rows of the
+        3*B*S gradient contributions, work items.  No host sync.  -> ops.PreparedBatch."""
+        return ops.sasrec_batch_prep(seq, pos, neg)
 
     def _buffers(self, B, S):
         key = (B, S)
@@ -284,11 +281,12 @@ class SASRecEngine:
                 ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
         return self._bufs[key]
 
-    def _step_body(self, seq, pos, neg, aux, sd, seed_dev=None, plan_ws=None):
-        """Every launch of the fused step up to (not including) the optimizer; gradients land in the gradient arena."""
+    def _step_body(self, pb, sd, seed_dev=None):
+        """Every launch of the fused step after the batch preparation up to (not including) the optimizer; gradients land in the
+        gradient arena.  pb: ops.PreparedBatch."""
         A, P, D = self.arena, self.params, self.D
+        seq, pos, neg = pb.seq, pb.pos, pb.neg
         B, S = seq.shape
-        valid, rows_all, packing, vidx, count = aux
         W = self._buffers(B, S)
         G = A.views(A.grad)
         p = self.p_drop if self.training else 0.0
@@ -299,12 +297,13 @@ class SASRecEngine:
         n = B * S
         GE = G["Item.embeddings.weight"]
         ops.sasrec_embed_encoder_fwd(E, Ppos, seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"],
-                                     packing=packing, seed_dev=seed_dev)
+                                     plan=pb.plan, seed_dev=seed_dev)
         u2 = W["u"].view(n, D)
         posf, negf = pos.reshape(-1), neg.reshape(-1)
         C = W["contrib"]
         if self.loss_kind == "CE":
             # SASRec/main.py:216-219: logits = u[valid] E[1:]^T, mean CE against IPos -- three fp32 MFMA GEMMs + one row kernel
+            vidx = torch.nonzero(pb.valid).reshape(-1).contiguous()          # (host sync: the CE shapes depend on the batch)
             Uv = ops.gather_rows(u2, vidx)                                   # [M, D]
             logits = ops.gemm(Uv, E[1:], transB=True)                        # [M, N]
             loss = ops.ce_rows_(logits, posf[vidx].contiguous())             # logits <- d loss / d logits
@@ -312,101 +311,54 @@ class SASRecEngine:
             ops.scatter_add_rows(dUv, vidx, n, out=W["dU"])                  # back to the [B*S, D] layout (pads zero)
             C[n:].zero_()                                                    # no pos/neg contribution rows in CE mode
         else:
-            loss, _, _, _ = ops.pair_loss_fwd_bwd(u2, E, posf, negf, valid, kind, count, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
+            loss, _, _, _ = ops.pair_loss_fwd_bwd(u2, E, posf, negf, pb.valid, kind, pb.count, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
         ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
                                      self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],
-                                     out=C[:n].view(B, S, D), ws=W["ws_bwd"], packing=packing, seed_dev=seed_dev)
-        # The index half of the scatter-add (the stable sort of the 3*B*S destination rows) depends on the batch only: given a
-        # plan that `prefetch_plan` computed on a second stream during the PREVIOUS step, the step runs the data half alone
-        # (scripts/exp_overlap.py: the plan's four launches cost a concurrent step 1 us instead of 20-25 in line -- but the
-        # events that order the two streams cost more than that at B = 512, see prefetch_plan.  Forking the same launches
-        # inside the captured step gains nothing either: the graph's branches do not run concurrently.)
-        if plan_ws is not None:
-            ops.scatter_apply(C, self.N + 1, GE, plan_ws, 1.0, accumulate=False)
-        else:
-            ops.scatter_add_rows(C, rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])
+                                     out=C[:n].view(B, S, D), ws=W["ws_bwd"], plan=pb.plan, seed_dev=seed_dev)
+        ops.scatter_add_rows(C, pb.rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])
         if self.loss_kind == "CE":
             ops.gemm(logits, Uv, transA=True, beta=1.0, out=GE[1:])          # dE[1:] += dlogits^T u[valid]
         return loss
 
     def train_step_fused(self, seq, pos, neg, aux=None, grad_hook=None):
         """One training step with every hot-path op a librecengine kernel and no autograd graph:
-        embed -> fused encoder (tape) -> fused pair loss -> loss bwd -> per-block encoder bwd (+ slab reduce)
-        -> embed bwd -> ONE deterministic scatter-add of all 3*B*S item-gradient rows -> fused Adam."""
+        batch prep -> embed + fused encoder (tape) -> fused pair loss (+ backward) -> encoder backward (all blocks, embedding
+        backward fused in) -> weight gradients + reduction -> ONE deterministic scatter-add of all 3*B*S item-gradient rows -> fused Adam.
+        aux: an ops.PreparedBatch of this batch (prepare_batch), or None."""
         A = self.arena
-        if aux is None:
-            aux = self.batch_aux_fused(seq, pos, neg)
-        loss = self._step_body(seq, pos, neg, aux, self._step_seed())
+        pb = aux if aux is not None else self.prepare_batch(seq, pos, neg)
+        loss = self._step_body(pb, self._step_seed())
         if grad_hook is not None:
             grad_hook(A.grad)
         A.step += 1
         ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
         return loss.squeeze(0)
 
-    # ---- the same step as ONE hipGraph replay (the step is ~35 short launches: at B=512 the CPU launch path, not the GPU,
-    #      sets the step time).  Per step: one staging launch (packed batch -> static buffer, step scalars -> device words)
-    #      + one graph launch.  BCE / BPR only: the CE path's shapes depend on the batch's number of valid positions.
-    @staticmethod
-    def _blob_layout(B, S):
-        n, off, o = B * S, {}, 0
-        for name, nbytes in (("seq", 8 * n), ("pos", 8 * n), ("neg", 8 * n), ("rows_all", 24 * n), ("order", 4 * B), ("nshort", 4),
-                             ("count", 4), ("valid", n)):
-            off[name] = (o, nbytes)
-            o += (nbytes + 15) // 16 * 16
-        return off, o
-
-    @staticmethod
-    def _blob_views(blob, B, S):
-        off, _ = SASRecEngine._blob_layout(B, S)
-        cut = lambda k, dt: blob[off[k][0]:off[k][0] + off[k][1]].view(dt)  # noqa: E731
-        return dict(seq=cut("seq", torch.int64).view(B, S), pos=cut("pos", torch.int64).view(B, S), neg=cut("neg", torch.int64).view(B, S),
-                    rows_all=cut("rows_all", torch.int64), order=cut("order", torch.int32), nshort=cut("nshort", torch.int32),
-                    count=cut("count", torch.int32), valid=cut("valid", torch.uint8))
-
-    @staticmethod
-    def pack_batch(seq, pos, neg):
-        """Batch assembly for `train_step_graph`: (seq, pos, neg) and the index helpers of `batch_aux_fused` laid out in ONE
-        contiguous device buffer, so that a step hands its batch to the captured graph with a single copy launch."""
-        B, S = seq.shape
-        valid, rows_all, (order, nshort), _, count = SASRecEngine.batch_aux_fused(seq, pos, neg)
-        _, total = SASRecEngine._blob_layout(B, S)
-        blob = torch.zeros(total, dtype=torch.uint8, device=seq.device)
-        V = SASRecEngine._blob_views(blob, B, S)
-        for k, t in (("seq", seq), ("pos", pos), ("neg", neg), ("rows_all", rows_all), ("order", order), ("nshort", nshort), ("count", count),
-                     ("valid", valid)):
-            V[k].copy_(t.view(V[k].shape))
-        return blob
-
-    def _capture(self, B, S, with_adam, plan_ws=None):
+    # ---- the same step as ONE hipGraph replay (the step is ~15 short launches: at B=512 the CPU launch path, not the GPU,
+    #      sets the step time).  Per step: the batch-preparation launch (raw (seq, pos, neg) -> the static buffers the graph reads:
+    #      copies, valid / count / rows_all, the encoder's plan, per-step seed and Adam scalars as device words) + one graph launch.
+    #      BCE / BPR only: the CE path's shapes depend on the batch's number of valid positions.
+    def _capture(self, B, S, with_adam):
         A = self.arena
-        _, total = self._blob_layout(B, S)
-        blob = torch.zeros(total, dtype=torch.uint8, device=self.device)
-        V = self._blob_views(blob, B, S)
-        V["nshort"].zero_()
-        V["order"].copy_(torch.arange(B, dtype=torch.int32, device=self.device))
+        blob = torch.zeros(ops.prep_layout(B, S)[1], dtype=torch.uint8, device=self.device)
         state = torch.zeros(4, dtype=torch.int32, device=self.device)
         hyper = state.view(torch.float32)[2:4]
-        aux = (V["valid"], V["rows_all"], (V["order"], V["nshort"]), None, V["count"])
+        z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
 
-        def body(plan_ws=plan_ws):
-            loss = self._step_body(V["seq"], V["pos"], V["neg"], aux, 0, seed_dev=state, plan_ws=plan_ws)
+        def body():
+            loss = self._step_body(pb, 0, seed_dev=state)
             if with_adam:
                 ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
             return loss
 
-        # warm-up on a side stream (one-time kernel attributes, workspace allocation) with an all-padding batch, then restore
+        # warm-up on a side stream (workspace allocation, lazy module loads) with an all-padding batch, then restore
         # everything the warm-up touched; the capture itself only records.
         keep = [t.clone() for t in (A.data, A.m, A.v, A.grad)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            ops.step_stage(blob, blob.clone(), state, 0, 1, self.lr, *self.betas)
-            if plan_ws is not None:   # (the warm-up must not touch the real plan buffer: a prefetched plan may be waiting in it)
-                tmp_ws = torch.empty_like(plan_ws)
-                ops.scatter_plan(V["rows_all"], self.D, self.N + 1, tmp_ws, padding_idx=0)
-                body(tmp_ws)
-            else:
-                body()
+            pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1])
+            body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -416,64 +368,23 @@ class SASRecEngine:
             t.copy_(k)
         return dict(graph=graph, blob=blob, state=state, loss=loss)
 
-    def plan_stream(self):
-        """The second stream `prefetch_plan` works on (assemble the next batch's blob under it to keep that off the step's stream)."""
-        if not hasattr(self, "_plan_stream"):
-            self._plan_stream = torch.cuda.Stream()
-        return self._plan_stream
-
-    def prefetch_plan(self, blob, B, S, after=None):
-        """OPTIONAL pipelining (off in bench.py and Coach: at B = 512 the two cross-stream event dependencies per step cost
-        more than the ~20 us of sort they hide -- 0.2138 vs 0.2086 ms/step, scripts/exp_prefetch.py; the sort grows with the
-        batch, the event cost does not).  Sort the destination rows of `blob`'s item-gradient scatter-add on a second stream, now, so that the
-        `train_step_graph(blob, ...)` that follows finds the plan ready (call it for batch t+1 right after launching step t:
-        the four sort launches then run underneath step t's encoder kernels, which leave ~40 % of the CUs idle).  Two plans can
-        be in flight; `blob` must stay unchanged until its step has been launched.  The sort does NOT wait for the caller's
-        stream (it would queue up behind the step it is meant to run beside): `blob` has to be complete already, or be
-        assembled on `plan_stream()`, or `after` names the event that marks it complete."""
-        if not hasattr(self, "_plans"):
-            nbytes = lib_load().re_scatter_add_rows_workspace_bytes(3 * B * S, self.D, self.N + 1)
-            self._plans = dict(ws=[torch.empty(int(nbytes), dtype=torch.uint8, device=self.device) for _ in range(2)],
-                               ready=[torch.cuda.Event(), torch.cuda.Event()], free=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False],
-                               slot_of={}, next=0,
-                               stream=self.plan_stream())
-        P = self._plans
-        if lib_load().re_scatter_add_rows_workspace_bytes(3 * B * S, self.D, self.N + 1) > P["ws"][0].numel():
-            return                                         # (a batch larger than the first one: that step sorts in line)
-        k = P["next"]
-        P["next"] = 1 - k
-        for key in [key for key, v in P["slot_of"].items() if v == k]:   # the slot's previous (consumed or abandoned) plan
-            del P["slot_of"][key]
-        with torch.cuda.stream(P["stream"]):
-            if P["used"][k]:
-                P["stream"].wait_event(P["free"][k])       # the step that last read this slot has finished
-            if after is not None:
-                P["stream"].wait_event(after)              # (whatever produced `blob` on another stream)
-            ops.scatter_plan(self._blob_views(blob, B, S)["rows_all"], self.D, self.N + 1, P["ws"][k], padding_idx=0)
-            P["ready"][k].record(P["stream"])
-        P["slot_of"][(blob.data_ptr(), B, S)] = k
-
-    def train_step_graph(self, blob, B, S, grad_hook=None):
-        """`train_step_fused` on a batch from `pack_batch`, replayed from a captured hipGraph.  Results are identical to the
-        eager fused step.  The returned loss tensor is overwritten by the next call.  If `prefetch_plan(blob, B, S)` was called
-        for this batch, the step uses that plan and skips the sort."""
+    def train_step_graph(self, seq, pos, neg, grad_hook=None):
+        """`train_step_fused` on a RAW batch, replayed from a captured hipGraph: one batch-preparation launch (which also stages the
+        batch and the step scalars into the graph's static buffers) + one graph launch.  Results are identical to the eager fused
+        step.  The returned loss tensor is overwritten by the next call."""
         if self.loss_kind == "CE":
             raise NotImplementedError("graph replay: BCE / BPR only (CE shapes vary with the batch)")
         A = self.arena
-        slot = self._plans["slot_of"].pop((blob.data_ptr(), B, S), None) if hasattr(self, "_plans") else None
-        key = (B, S, grad_hook is None, self.training, slot)
+        B, S = seq.shape
+        key = (B, S, grad_hook is None, self.training)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         if key not in self._graphs:
-            self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None, plan_ws=None if slot is None else self._plans["ws"][slot])
+            self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
-        if slot is not None:
-            torch.cuda.current_stream().wait_event(self._plans["ready"][slot])
-        ops.step_stage(g["blob"], blob, g["state"], self._step_seed(), A.step + 1, self.lr, *self.betas)
+        ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
+                              beta1=self.betas[0], beta2=self.betas[1])
         g["graph"].replay()
-        if slot is not None:
-            self._plans["free"][slot].record(torch.cuda.current_stream())
-            self._plans["used"][slot] = True
         A.step += 1
         if grad_hook is not None:
             grad_hook(A.grad)

@@ -43,14 +43,3 @@ def test_evaluator_helpers():
     assert parse_monitors(["LOSS", "HitRate@10", "ndcg@5"]) == [("HITRATE", 10), ("NDCG", 5)]
     ptr, idx = ragged_to_csr([[5, 1], [], [3]], "cpu")
     assert ptr.tolist() == [0, 2, 2, 3] and idx.tolist() == [1, 5, 3]
-
-
-def test_seq_packing_host_semantics():
-    from recboard_amd.ops import seq_packing
-    seq = torch.zeros(5, 50, dtype=torch.long)
-    seq[0, -3:] = 7          # short
-    seq[1, -16:] = 7         # short (exactly the window)
-    seq[2, -17:] = 7         # long
-    seq[3, :] = 7            # long
-    order, nshort = seq_packing(seq)
-    assert int(nshort) == 3 and sorted(order[:3].tolist()) == [0, 1, 4] and sorted(order[3:].tolist()) == [2, 3]

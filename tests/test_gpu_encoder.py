@@ -67,12 +67,9 @@ def test_encoder_forward_matches_oracle(ops, B, p, pack):
     with torch.no_grad():
         ref = _oracle_blocks(P, x0, seq, L, drop)
     Pd = {k: v.cuda() for k, v in P.items()}
-    packing = ops.seq_packing(seq.cuda()) if pack else None
-    if pack:
-        assert int(packing[1]) > B // 2
     u, tape = ops.sasrec_encoder_fwd(x0.cuda(), seq.cuda(), ops.sasrec_block_tensors(Pd, L), Pd["lastLN.weight"],
-                                     Pd["lastLN.bias"], L, p, 77, need_tape=(p > 0), packing=packing)
-    if pack and p > 0:   # training mode does not write u at pad positions in front of a short sequence's window
+                                     Pd["lastLN.bias"], L, p, 77, need_tape=(p > 0))
+    if p > 0:   # training mode (tape requested) does not write u at the pad positions in front of a sequence
         m = (seq != 0)
         torch.testing.assert_close(u.cpu()[m], ref[m], rtol=1e-4, atol=2e-5)
     else:
@@ -94,7 +91,7 @@ def test_encoder_backward_matches_oracle_autograd(ops, B, p, pack):
     L, D, S, N = 2, 64, 50, 200
     P = {k: v.requires_grad_(True) for k, v in _params(5, L, D, S, N).items()}
     seq = _seqs(6, B, S, N, beauty=pack)
-    packing = ops.seq_packing(seq.cuda()) if pack else None
+    plan = ops.sasrec_plan(seq.cuda())
     g = torch.Generator().manual_seed(7)
     x0 = torch.randn(B, S, D, generator=g).masked_fill((seq == 0).unsqueeze(-1), 0.0).requires_grad_(True)
     dU = torch.randn(B, S, D, generator=g).masked_fill((seq == 0).unsqueeze(-1), 0.0) / B
@@ -104,12 +101,12 @@ def test_encoder_backward_matches_oracle_autograd(ops, B, p, pack):
     Pd = {k: v.detach().cuda() for k, v in P.items()}
     bt = ops.sasrec_block_tensors(Pd, L)
     u, tape = ops.sasrec_encoder_fwd(x0.detach().cuda(), seq.cuda(), bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 4242, True,
-                                     packing=packing)
+                                     plan=plan)
     Gd = {k: torch.full_like(v, float("nan")) for k, v in Pd.items()}
     dx0 = ops.sasrec_encoder_bwd(dU.cuda(), seq.cuda(), bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 4242, tape,
-                                 ops.sasrec_block_tensors(Gd, L), Gd["lastLN.weight"], Gd["lastLN.bias"], packing=packing)
+                                 ops.sasrec_block_tensors(Gd, L), Gd["lastLN.weight"], Gd["lastLN.bias"], plan=plan)
     ref = x0.grad
-    m = (seq != 0) if pack else torch.ones_like(seq, dtype=torch.bool)   # packed: rows in front of the window are not written
+    m = seq != 0   # rows of the pads in front of a sequence are not written
     assert (dx0.cpu()[m] - ref[m]).abs().max() <= 1e-4 * ref.abs().max() + 1e-7
     for k, v in P.items():
         if k.startswith("Item.") or k.startswith("Position."):
@@ -120,7 +117,7 @@ def test_encoder_backward_matches_oracle_autograd(ops, B, p, pack):
     # deterministic: a second backward gives bit-identical parameter gradients
     G2 = {k: torch.zeros_like(v) for k, v in Pd.items()}
     ops.sasrec_encoder_bwd(dU.cuda(), seq.cuda(), bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 4242, tape,
-                           ops.sasrec_block_tensors(G2, L), G2["lastLN.weight"], G2["lastLN.bias"], packing=packing)
+                           ops.sasrec_block_tensors(G2, L), G2["lastLN.weight"], G2["lastLN.bias"], plan=plan)
     for k in ("attnLayers.0.in_proj_weight", "fwdLayers.1.conv2.weight", "lastLN.weight"):
         assert torch.equal(Gd[k], G2[k])
 
@@ -134,14 +131,15 @@ def test_embed_fused_into_encoder_equals_two_launches(ops, p, pack, train):
     Pd = {k: v.cuda() for k, v in P.items()}
     seq = _seqs(6, B, S, N, beauty=True).cuda()
     bt = ops.sasrec_block_tensors(Pd, L)
-    packing = ops.seq_packing(seq) if pack else None
+    plan = ops.sasrec_plan(seq)
     E, Pp = Pd["Item.embeddings.weight"], Pd["Position.weight"]
     x0 = ops.sasrec_embed(E, Pp, seq, 8.0, p, 77)
-    u1, t1 = ops.sasrec_encoder_fwd(x0, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, train, packing=packing)
+    u1, t1 = ops.sasrec_encoder_fwd(x0, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, train, plan=plan)
     if t1 is not None:
         t1 = t1.clone()
-    u2, t2 = ops.sasrec_embed_encoder_fwd(E, Pp, seq, 8.0, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, train, packing=packing)
-    assert torch.equal(u1, u2)
+    u2, t2 = ops.sasrec_embed_encoder_fwd(E, Pp, seq, 8.0, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, train, plan=plan)
+    m = (seq != 0) if train else torch.ones_like(seq, dtype=torch.bool)
+    assert torch.equal(u1[m], u2[m])
     if train:
         # pad positions of packed items are never written: compare only what the backward can read (rows of real tokens)
         from recboard_amd import lib
@@ -151,7 +149,7 @@ def test_embed_fused_into_encoder_equals_two_launches(ops, p, pack, train):
         for tape in (t1, t2):
             g = [torch.zeros_like(t) for t in bt]
             glw, glb = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
-            dx = ops.sasrec_encoder_bwd(dU, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, tape, g, glw, glb, packing=packing)
+            dx = ops.sasrec_encoder_bwd(dU, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 77, tape, g, glw, glb, plan=plan)
             # (dx rows of pads in front of a packed item's window are never written -- and never read: re_sasrec_embed_bwd masks pads)
             outs.append([dx[seq != 0].clone()] + [t.clone() for t in g] + [glw.clone(), glb.clone()])
         for a, b in zip(*outs):
@@ -167,19 +165,19 @@ def test_embed_bwd_fused_into_encoder_bwd_equals_two_launches(ops, p, pack):
     Pd = {k: v.cuda() for k, v in P.items()}
     seq = _seqs(9, B, S, N, beauty=True).cuda()
     bt = ops.sasrec_block_tensors(Pd, L)
-    packing = ops.seq_packing(seq) if pack else None
+    plan = ops.sasrec_plan(seq)
     E, Pp = Pd["Item.embeddings.weight"], Pd["Position.weight"]
-    u, tape = ops.sasrec_embed_encoder_fwd(E, Pp, seq, 8.0, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, True, packing=packing)
+    u, tape = ops.sasrec_embed_encoder_fwd(E, Pp, seq, 8.0, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, True, plan=plan)
     dU = torch.randn(B, S, D, generator=torch.Generator().manual_seed(2)).cuda()
     g1 = [torch.zeros_like(t) for t in bt]
     lw1, lb1, dP1 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(S, D, device="cuda")
-    dx = ops.sasrec_encoder_bwd(dU, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, tape, g1, lw1, lb1, packing=packing)
+    dx = ops.sasrec_encoder_bwd(dU, seq, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, tape, g1, lw1, lb1, plan=plan)
     dx[seq == 0] = 0.0        # (rows the packed kernels never write)
     ops.sasrec_embed_bwd(dx, seq, 8.0, p, 99, dP1)
     g2 = [torch.zeros_like(t) for t in bt]
     lw2, lb2, dP2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.full((S, D), 5.0, device="cuda")
     c2 = ops.sasrec_encoder_embed_bwd(dU, seq, 8.0, bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, tape, g2, lw2, lb2, dP2,
-                                      packing=packing)
+                                      plan=plan)
     m = seq != 0
     assert torch.equal(dx[m], c2[m])
     for a, b in zip(g1 + [lw1, lb1], g2 + [lw2, lb2]):

@@ -54,8 +54,7 @@ def test_encoder_degenerate_batches(ops):
         if B > 3:
             seq[4, :] = 5
         x0 = ops.sasrec_embed(Pd["Item.embeddings.weight"], Pd["Position.weight"], seq.cuda(), 8.0)
-        u, _ = ops.sasrec_encoder_fwd(x0, seq.cuda(), ops.sasrec_block_tensors(Pd, 2), Pd["lastLN.weight"], Pd["lastLN.bias"], 2,
-                                      packing=ops.seq_packing(seq.cuda()))
+        u, _ = ops.sasrec_encoder_fwd(x0, seq.cuda(), ops.sasrec_block_tensors(Pd, 2), Pd["lastLN.weight"], Pd["lastLN.bias"], 2)
         with torch.no_grad():
             ref, _ = osas.encode(P, seq, 2)
         torch.testing.assert_close(u.cpu(), ref, rtol=1e-4, atol=2e-5)

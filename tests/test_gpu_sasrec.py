@@ -141,42 +141,9 @@ def test_graph_replayed_step_is_identical_to_eager_step(loss):
     for i in range(6):
         b = batches[i % 3]
         le = eager.train_step_fused(*b).clone()
-        lg = graph.train_step_graph(SASRecEngine.pack_batch(*b), B, S).clone()
+        lg = graph.train_step_graph(*b).clone()
         assert torch.equal(le, lg), (i, le, lg)
         assert torch.equal(eager.arena.data, graph.arena.data), i
-    assert torch.equal(eager.arena.m, graph.arena.m) and torch.equal(eager.arena.v, graph.arena.v)
-
-
-def test_graph_step_with_prefetched_scatter_plan_is_identical_to_eager_step():
-    """prefetch_plan sorts the NEXT batch's scatter-add rows on a second stream while the current step runs; the step that
-    consumes the plan must still reproduce the eager fused step bit for bit -- also when a prefetched plan is abandoned
-    (a different batch is trained next) and when steps with and without a plan alternate."""
-    from recboard_amd.sasrec import SASRecEngine
-    N, B, S = 700, 32, 50
-    rng = np.random.default_rng(15)
-    batches = []
-    for _ in range(5):
-        seq = rng.integers(1, N + 1, (B, S))
-        for b in range(B):
-            seq[b, : rng.integers(0, S - 1)] = 0
-        batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, rng.integers(0, N, (B, S)), rng.integers(0, N, (B, S)))))
-    blobs = [SASRecEngine.pack_batch(*b) for b in batches]
-    torch.cuda.synchronize()          # (prefetch_plan does not wait for the stream that assembled the blobs)
-    eager = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, loss="BCE", seed=8)
-    graph = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, loss="BCE", seed=8)
-    order = [0, 1, 2, 3, 4, 0, 2, 4, 1, 3, 3, 0]
-    graph.prefetch_plan(blobs[order[0]], B, S)
-    for t, i in enumerate(order):
-        le = eager.train_step_fused(*batches[i]).clone()
-        lg = graph.train_step_graph(blobs[i], B, S)
-        if t + 1 < len(order):
-            nxt = order[t + 1]
-            if t == 4:
-                graph.prefetch_plan(blobs[(nxt + 1) % 5], B, S)      # a plan nobody consumes: the next step sorts in line
-            elif t != 7:                                             # (t == 7: no prefetch at all)
-                graph.prefetch_plan(blobs[nxt], B, S)
-        assert torch.equal(le, lg.clone()), (t, le, lg)
-        assert torch.equal(eager.arena.data, graph.arena.data), t
     assert torch.equal(eager.arena.m, graph.arena.m) and torch.equal(eager.arena.v, graph.arena.v)
 
 
@@ -198,10 +165,9 @@ def test_graph_replayed_step_with_gradient_hook_matches_eager():
 
     eager = SASRecEngine(N, S, 64, 2, dropout_rate=0.2, loss="BCE", seed=4)
     graph = SASRecEngine(N, S, 64, 2, dropout_rate=0.2, loss="BCE", seed=4)
-    blob = SASRecEngine.pack_batch(*batch)
     for i in range(4):
         le = eager.train_step_fused(*batch, grad_hook=hook).clone()
-        lg = graph.train_step_graph(blob, B, S, grad_hook=hook).clone()
+        lg = graph.train_step_graph(*batch, grad_hook=hook).clone()
         assert torch.equal(le, lg), i
         assert torch.equal(eager.arena.data, graph.arena.data), i
     assert len(calls) == 8
@@ -245,10 +211,9 @@ def test_large_table_engine_graph_step_matches_eager_step():
     batch = tuple(torch.from_numpy(a).cuda() for a in (seq, rng.integers(0, N, (B, S)), rng.integers(0, N, (B, S))))
     eager = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.0, lr=1e-2, weight_decay=1e-4, seed=2)
     graph = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.0, lr=1e-2, weight_decay=1e-4, seed=2)
-    blob = SASRecLargeTableEngine.pack_batch(*batch)
     for i in range(3):
         le = eager.train_step(*batch).clone()
-        lg = graph.train_step_graph(blob, B, S).clone()
+        lg = graph.train_step_graph(*batch).clone()
         torch.testing.assert_close(lg, le, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(graph.E, eager.E, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(graph.arena.data, eager.arena.data, rtol=1e-4, atol=1e-6)
