@@ -7,7 +7,7 @@ kernels apply *their own* documented mask consistently in forward and backward: 
 restates that mask generator (recboard_amd/csrc/re_rng.h) so the oracle can be run with the
 very same keep-masks.
 
-    keep(seed, stream, idx) = fmix32(idx*0x9E3779B1 + stream*0x85EBCA77 + seed) >= floor(p * 2^32)
+    keep(seed, stream, idx) = fmix32(idx + stream*0x85EBCA77 + seed) >= floor(p * 2^32)
 """
 import numpy as np
 
@@ -16,7 +16,7 @@ M32 = np.uint64(0xFFFFFFFF)
 
 def rng_u32(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
     idx = np.asarray(idx).astype(np.uint64)
-    h = (idx * np.uint64(0x9E3779B1) + np.uint64((stream * 0x85EBCA77) & 0xFFFFFFFF) + np.uint64(seed & 0xFFFFFFFF)) & M32
+    h = (idx + np.uint64((stream * 0x85EBCA77) & 0xFFFFFFFF) + np.uint64(seed & 0xFFFFFFFF)) & M32
     h ^= h >> np.uint64(16)
     h = (h * np.uint64(0x85EBCA6B)) & M32
     h ^= h >> np.uint64(13)

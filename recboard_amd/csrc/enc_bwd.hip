@@ -84,10 +84,18 @@ __device__ __forceinline__ void ln_bwd_row(const float* dy, const float* x, floa
     }
 }
 
-__device__ __forceinline__ void stats_fetch(float2& r, const float* __restrict__ st, int nrows, int tid) {
+__device__ __forceinline__ void stats_fetch(float2& r, const float* st, int nrows, int tid) {
+    gcf_t sp = g_launder(st);
     r = make_float2(0.f, 0.f);
-    if (tid < nrows) r = *reinterpret_cast<const float2*>(st + 2 * tid);
+    if (tid < nrows) { r.x = sp[2 * tid]; r.y = sp[2 * tid + 1]; }
 }
+
+#ifdef ENC_PROFILE
+__device__ unsigned long long g_bwd_marks[ENC_MARKS];
+extern "C" int re_dbg_enc_marks_bwd(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_marks), sizeof(unsigned long long) * ENC_MARKS) == hipSuccess ? 0 : 1;
+}
+#endif
 
 template <int D>
 __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, const int64_t* __restrict__ seq, int B, int S, int L,
@@ -109,6 +117,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
     __shared__ float s_mean[C::ROWS], s_rstd[C::ROWS];
     __shared__ float s_ppad[C::ROWS], s_w[C::ROWS], s_cpad[C::ROWS];   // virtual pad key: prob of one copy, total kept weight, dS
     __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS];
+    __shared__ float s_par[2 * EP_NPAR * D], s_last[D];
 
     const int tid0 = threadIdx.x;
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
@@ -129,42 +138,61 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
         const EncItem it = enc_item(PL, wi);
         const int nt = it.nt, nrows = 16 * nt;
         const int64_t row0 = (int64_t)it.tile0 * 16;
-        __syncthreads();
+        int mk = 0; (void)mk;
+        // the last block's small parameters and first three weight fragments are requested before anything else of the item
+        ParRegs<D> PR;
+        float wa[D / 4], wb[D / 4], wc[D / 4];
+        par_fetch<D>(PR, P.blk[L - 1], tid);
+        const float lastv = tid < D ? P.last_w[tid] : 0.f;
+        wfrag_n<D>(wa, P.blk[L - 1].w2, strip, lane);
+        wfrag_n<D>(wb, P.blk[L - 1].w1, strip, lane);
+        wfrag_n<D>(wc, P.blk[L - 1].out_w, strip, lane);
+        enc_sync();
+        ENC_MARK(g_bwd_marks, mk); ++mk;
         enc_decode<D>(PL, it, seq, tid, s_gid, s_first, s_pad);
-        __syncthreads();
+        enc_sync();
+        ENC_MARK(g_bwd_marks, mk); ++mk;
         if (tid < C::ROWS) s_sid[tid] = s_gid[tid] >= 0 ? s_gid[tid] / S : -1;
         TileRegs<D> T0, T1;
         float2 ST;
         tile_fetch_gid<D>(T0, dIn, s_gid, nrows, tid);
         tile_fetch<D>(T1, tape + T.off_XL + row0 * D, nrows, tid);
         stats_fetch(ST, tape + T.off_SL + row0 * 2, nrows, tid);
+        par_commit<D>(s_par + ((L - 1) & 1) * EP_NPAR * D, PR, tid);
+        if (tid < D) s_last[tid] = lastv;
         tile_commit<D>(b0, T0, nrows, tid);
         tile_commit<D>(b1, T1, nrows, tid);
         if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
-        __syncthreads();
+        tile_fetch<D>(T1, tape + (int64_t)(L - 1) * T.per_block + T.off_HR + row0 * D, nrows, tid);
+        enc_sync();
+        ENC_MARK(g_bwd_marks, mk); ++mk;
         float accV[EG_NVEC];
 #pragma unroll
         for (int v = 0; v < EG_NVEC; ++v) accV[v] = 0.f;
         // ---- u = LN_last(x_L): dgamma / dbeta, then dx_L in place
         accV[10] = colsum_xhat<D>(b0, b1, s_mean, s_rstd, tid, nrows);
         accV[11] = colsum<D>(b0, tid, nrows);
-        __syncthreads();
-        if (r_e < nrows) ln_bwd_row<D, false>(b0, b1, b0, P.last_w, s_mean, s_rstd, tid);
-        __syncthreads();
+        enc_sync();
+        ENC_MARK(g_bwd_marks, mk); ++mk;
+        if (r_e < nrows) ln_bwd_row<D, false>(b0, b1, b0, s_last, s_mean, s_rstd, tid);
+        enc_sync();
+        ENC_MARK(g_bwd_marks, mk); ++mk;
 
+        // Order inside a phase: commit what was requested earlier -> products -> request what later phases need -> stores.
+        // (The memory counter retires in order: a wait for a request also waits for everything issued before it, so stores go last
+        // and every request is at least one phase older than its first use.)
         for (int l = L - 1; l >= 0; --l) {
             const SasrecBlockParams W = P.blk[l];
+            const SasrecBlockParams Wn = P.blk[l > 0 ? l - 1 : 0];   // the block after this one
+            const bool more = l > 0;
+            const float* par = s_par + (l & 1) * EP_NPAR * D;
             const float* tp = tape + (int64_t)l * T.per_block;
             float* gp = gtape + (int64_t)l * EG_NMAT * NR * D + row0 * D;
-            float wf[D / 4];
             if (l != L - 1) {
                 accV[10] = 0.f; accV[11] = 0.f;
             }
-            tile_fetch<D>(T1, tp + T.off_HR + row0 * D, nrows, tid);
-            tile_fetch<D>(T0, tp + T.off_X1 + row0 * D, nrows, tid);
-            stats_fetch(ST, tp + T.off_SF + row0 * 2, nrows, tid);
-            wfrag_n<D>(wf, W.w2, strip, lane);
-            // ---- pad mask of the block output (x'[pad] = 0) and dO2 = dX' * dropout2 mask
+            if (more) par_fetch<D>(PR, Wn, tid);
+            // ---- pad mask of the block output (x'[pad] = 0) and dO2 = dX' * dropout2 mask      [T1 = HR in flight]
             if (r_e < nrows) {
                 const bool dead = s_pad[r_e] != 0;
 #pragma unroll
@@ -179,30 +207,26 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                 }
             }
             tile_commit<D>(b1, T1, nrows, tid);   // HR
-            __syncthreads();
-            // ---- A. FFN second map: db2; dH = (dO2 W2) * (hr > 0) * scale
-            tile_store<D>(b2, gp + 0 * NR * D, nrows, tid);
-            accV[5] = colsum<D>(b2, tid, nrows);
-            gemm_rows<D>(b2, wf, lane, wr, nt, [&](int row, float v) {
+            tile_fetch<D>(T0, tp + T.off_X1 + row0 * D, nrows, tid);
+            stats_fetch(ST, tp + T.off_SF + row0 * 2, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
+            // ---- A. FFN second map: db2; dH = (dO2 W2) * (hr > 0) * scale        (wa = W2)
+            gemm_rows<D>(b2, wa, lane, wr, nt, [&](int row, float v) {
                 b3[row * C::LS + col] = (b1[row * C::LS + col] > 0.f) ? v * drop_scale : 0.f;
             });
-            wfrag_n<D>(wf, W.w1, strip, lane);
-            __syncthreads();
-            // ---- B. FFN first map: db1; dY = dH W1 + dX'
-            tile_store<D>(b3, gp + 1 * NR * D, nrows, tid);
-            accV[4] = colsum<D>(b3, tid, nrows);
-            tile_commit<D>(b1, T0, nrows, tid);   // X1
+            wfrag_n<D>(wa, W.in_w, strip, lane);                  // Wq
+            accV[5] = colsum<D>(b2, tid, nrows);
+            tile_store<D>(b2, gp + 0 * NR * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
+            // ---- B. FFN first map: db1; dY = dH W1 + dX'        (wb = W1)
+            tile_commit<D>(b1, T0, nrows, tid);   // X1  (HR's last readers are behind the barrier above)
             if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
+            gemm_rows<D>(b3, wb, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
+            wfrag_n<D>(wb, W.in_w + D * D, strip, lane);          // Wk
             tile_fetch<D>(T0, tp + T.off_V + row0 * D, nrows, tid);
             stats_fetch(ST, tp + T.off_PP + row0 * 2, nrows, tid);
-            gemm_rows<D>(b3, wf, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
-            wfrag_n<D>(wf, W.out_w, strip, lane);
-            __syncthreads();
-            // ---- C. LN_f backward: dgamma_f, dbeta_f, dX1 (in place in b0)
-            accV[8] = colsum_xhat<D>(b0, b1, s_mean, s_rstd, tid, nrows);
-            accV[9] = colsum<D>(b0, tid, nrows);
-            __syncthreads();
-            if (r_e < nrows) ln_bwd_row<D, false>(b0, b1, b0, W.ln_f_w, s_mean, s_rstd, tid);
             float pq[KPT];   // this thread's slice of the saved probabilities
             {
 #pragma unroll
@@ -218,11 +242,21 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                     }
                 }
             }
-            __syncthreads();
-            // ---- D. out_proj: dbo; dO = dX1 Wo
-            tile_store<D>(b0, gp + 2 * NR * D, nrows, tid);
-            accV[3] = colsum<D>(b0, tid, nrows);
-            gemm_rows<D>(b0, wf, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
+            accV[4] = colsum<D>(b3, tid, nrows);
+            tile_store<D>(b3, gp + 1 * NR * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
+            // ---- C. LN_f backward: dgamma_f, dbeta_f, dX1 (in place in b0)
+            accV[8] = colsum_xhat<D>(b0, b1, s_mean, s_rstd, tid, nrows);
+            accV[9] = colsum<D>(b0, tid, nrows);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
+            if (r_e < nrows) ln_bwd_row<D, false>(b0, b1, b0, par + 6 * D, s_mean, s_rstd, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
+            // ---- D. out_proj: dbo; dO = dX1 Wo        (wc = Wo)
+            gemm_rows<D>(b0, wc, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
+            wfrag_n<D>(wc, W.in_w + 2 * D * D, strip, lane);      // Wv
             // ---- E. attention: V, P; Pd = P * mask
             tile_commit<D>(b1, T0, nrows, tid);   // V  (X1's last readers, phase C, are behind the barrier above)
             if (tid < C::ROWS) { s_ppad[tid] = ST.x; s_w[tid] = ST.y; }
@@ -245,20 +279,25 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                     sD[i * C::PLS + j] = p * m;
                 }
             }
-            __syncthreads();
+            accV[3] = colsum<D>(b0, tid, nrows);
+            tile_store<D>(b0, gp + 2 * NR * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             // dV = Pd^T dO; d b_v through the virtual pad key: sum_i w_i dO_i
             gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b2[row * C::LS + col] = v; });
             accV[2] = colsum_w<D>(b3, s_w, tid, nrows);
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             // dP = (dO V^T) * mask factor Pd / P (0, or 1 / (1 - p)), over the item's tile pairs (P is 0 elsewhere)
             gemm_pairs<D>(b3, b1, lane, wave, it, [&](int row, int key, float v) {
                 const float p = sP[row * C::PLS + key];
                 const float pd = sD[row * C::PLS + key];
                 sD[row * C::PLS + key] = (p != 0.f) ? v * (pd / p) : 0.f;
             });
-            tile_store<D>(b2, gp + 5 * NR * D, nrows, tid);
             accV[2] += colsum<D>(b2, tid, nrows);
-            __syncthreads();
+            tile_store<D>(b2, gp + 5 * NR * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             // dS = P (dP - rowsum(dP P)) / sqrt(D), the virtual pad key included in the row sum
             if (r_e < nrows) {
                 const int i = r_e;
@@ -275,7 +314,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                 // virtual pad key: upstream grad of each copy = (dO_i . b_v) * mask; t = dO_i . b_v
                 float t = 0.f;
 #pragma unroll
-                for (int jj = 0; jj < C::CPT; ++jj) t = fmaf(b3[i * C::LS + c0_e + jj], W.in_b[2 * D + c0_e + jj], t);
+                for (int jj = 0; jj < C::CPT; ++jj) t = fmaf(b3[i * C::LS + c0_e + jj], par[4 * D + c0_e + jj], t);
                 t = row_sum<C::TPR>(t);
                 const float wv = s_w[i], ppad = s_ppad[i];
                 s = fmaf(t, wv, s);                                            // rowdot includes the pad copies
@@ -283,47 +322,57 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
 #pragma unroll
                 for (int jj = 0; jj < KPT; ++jj) sD[i * C::PLS + j0_e + jj] = pp[jj] * (dp[jj] - s) * inv_sqrt_d;
             }
-            __syncthreads();   // dS complete; dO (b3), V (b1) and P no longer needed
+            enc_sync();   // dS complete; dO (b3), V (b1) and P no longer needed
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             // ---- F. dQ = dS K (+ dS_pad b_k) -> b4 ; dK = dS^T Q -> b1
             tile_commit<D>(b1, T0, nrows, tid);   // K
             tile_commit<D>(b3, T1, nrows, tid);   // Q
             tile_fetch<D>(T0, tp + T.off_X + row0 * D, nrows, tid);
             stats_fetch(ST, tp + T.off_SA + row0 * 2, nrows, tid);
-            __syncthreads();
+            if (more) tile_fetch<D>(T1, tape + (int64_t)(l - 1) * T.per_block + T.off_HR + row0 * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             {
-                const float bkc = W.in_b[D + col];
+                const float bkc = par[3 * D + col];
                 gemm_tx<D>(sD, b1, lane, wr, strip, it, [&](int row, float v) { b4[row * C::LS + col] = fmaf(s_cpad[row], bkc, v); });
             }
             accV[1] = colsum_w<D>(b3, s_cpad, tid, nrows);   // d b_k through the virtual pad key: sum_i dS_pad_i q_i
-            wfrag_n<D>(wf, W.in_w, strip, lane);             // Wq
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b1[row * C::LS + col] = v; });
-            tile_store<D>(b4, gp + 3 * NR * D, nrows, tid);
             accV[0] = colsum<D>(b4, tid, nrows);
-            __syncthreads();
-            // ---- G. projections: dbq/dbk; dA1 = dQ Wq -> b3; dX (b0) += dK Wk + dV Wv
-            tile_store<D>(b1, gp + 4 * NR * D, nrows, tid);
+            tile_store<D>(b4, gp + 3 * NR * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
+            // ---- G. projections: dbq/dbk; dA1 = dQ Wq -> b3; dX (b0) += dK Wk + dV Wv        (wa, wb, wc = Wq, Wk, Wv)
+            gemm_rows<D>(b4, wa, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
+            if (more) wfrag_n<D>(wa, Wn.w2, strip, lane);
+            gemm_rows<D>(b1, wb, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
+            if (more) wfrag_n<D>(wb, Wn.w1, strip, lane);
+            gemm_rows<D>(b2, wc, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
+            if (more) wfrag_n<D>(wc, Wn.out_w, strip, lane);
             accV[1] += colsum<D>(b1, tid, nrows);
-            gemm_rows<D>(b4, wf, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
-            wfrag_n<D>(wf, W.in_w + D * D, strip, lane);     // Wk
-            gemm_rows<D>(b1, wf, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
-            wfrag_n<D>(wf, W.in_w + 2 * D * D, strip, lane); // Wv
-            gemm_rows<D>(b2, wf, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
-            __syncthreads();
+            tile_store<D>(b1, gp + 4 * NR * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             // ---- H. LN_a backward: dgamma_a, dbeta_a; dX += LN_a'(dA1)
             tile_commit<D>(b4, T0, nrows, tid);   // X
             if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             accV[6] = colsum_xhat<D>(b3, b4, s_mean, s_rstd, tid, nrows);
             accV[7] = colsum<D>(b3, tid, nrows);
-            if (r_e < nrows) ln_bwd_row<D, true>(b3, b4, b0, W.ln_a_w, s_mean, s_rstd, tid);
-            __syncthreads();
+            if (r_e < nrows) ln_bwd_row<D, true>(b3, b4, b0, par + 0 * D, s_mean, s_rstd, tid);
+            if (more) par_commit<D>(s_par + ((l - 1) & 1) * EP_NPAR * D, PR, tid);
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             // ---- this block's vector gradients: row-group partials -> one value per column (fixed order) -> the workgroup's slab
             {
                 float* red = b1;   // [EG_NVEC][CG][D]  (12 * 512 floats; b1 and b2 are free and adjacent)
 #pragma unroll
                 for (int v = 0; v < EG_NVEC; ++v) red[v * C::NT + tid] = accV[v];
-                __syncthreads();
+                enc_sync();
+                ENC_MARK(g_bwd_marks, mk); ++mk;
                 float* sl = slab + ((int64_t)blockIdx.x * L + l) * EG_NVEC * D;
                 for (int e = tid; e < EG_NVEC * D; e += C::NT) {
                     const int v = e / D, cc = e % D;
@@ -332,7 +381,8 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                     for (int i = 1; i < C::CG; ++i) s += red[v * C::NT + i * D + cc];
                     sl[e] = (k == 0) ? s : sl[e] + s;
                 }
-                __syncthreads();
+                enc_sync();
+                ENC_MARK(g_bwd_marks, mk); ++mk;
             }
         }
         if (fuse_embed) {
@@ -350,7 +400,8 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                     b0[r_e * C::LS + c0_e + i] = v;
                 }
             }
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_bwd_marks, mk); ++mk;
             tile_store_gid<D>(b0, dOut, s_gid, nrows, tid, emb_scale);
         } else {
             tile_store_gid<D>(b0, dOut, s_gid, nrows, tid);
@@ -360,9 +411,10 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
 
 // ---- weight gradients (enc_wgrad.hip) ---------------------------------------------------------------------------------------
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
-                     int nwg, float* part, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab, float* const* block_grads,
-                     float* g_last_w, float* g_last_b, hipStream_t s);
+                     int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
+                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s);
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
+size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 
 static inline int enc_bwd_grid(int64_t B, int64_t S, int32_t ncu) {
     const int64_t mt = enc_plan_max_tiles(B, S);
@@ -374,7 +426,7 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
     if (B <= 0 || S <= 0 || D <= 0 || L <= 0) return 256;
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
     const int64_t nwg = 1024;   // upper bound of the launch grid (ncu)
-    return (size_t)(nwg * L * EG_NVEC * D + enc_wgrad_part_floats(D, L) + L * EG_NMAT * NR * D) * sizeof(float) + 512;
+    return (size_t)(nwg * L * EG_NVEC * D + enc_wgrad_part_floats(D, L) + enc_wgrad_ppart_floats(B, D) + L * EG_NMAT * NR * D) * sizeof(float) + 512;
 }
 
 // dPtab == NULL: dx0 [B,S,D] receives the gradient w.r.t. x0 (rows of real tokens only).  Otherwise re_sasrec_embed_bwd is fused in:
@@ -403,7 +455,8 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
     float* slab = (float*)ws;
     float* part = slab + (size_t)1024 * L * EG_NVEC * D;
-    float* gtape = part + enc_wgrad_part_floats(D, L);
+    float* ppart = part + enc_wgrad_part_floats(D, L);
+    float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
     hipStream_t s = (hipStream_t)stream;
     using C = EC<64>;
     const size_t ldsb = (size_t)(5 * C::BUF + 2 * C::PBUF) * sizeof(float);
@@ -413,5 +466,5 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
                        gtape, slab, seed_dev, dPtab ? 1 : 0, scale);
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     (void)NR;
-    return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, part, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
+    return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
 }

@@ -116,10 +116,36 @@ __host__ __device__ inline EncTape enc_tape_layout(int64_t B, int64_t S, int64_t
 // vector gradients per block: 0 bq 1 bk 2 bv 3 bo 4 b1 5 b2 6 ga 7 ba 8 gf 9 bf 10 glast 11 blast
 #define EG_NVEC 12
 
-template <class T>
-__device__ __forceinline__ const T* se_launder(const T* p) {
+// Workgroup barrier for LDS hand-offs.  __syncthreads() also fences global memory: hipcc puts `s_waitcnt vmcnt(0)` in front of the
+// barrier, i.e. every phase boundary would wait for the weight fragments / tape tiles requested for LATER phases and for the
+// tape stores issued in this one (a full L2 round trip per barrier, ~10 per block).  Nothing that crosses waves inside these
+// kernels goes through global memory, so the barrier only has to order LDS traffic: the wave's own LDS operations are complete
+// (lgkmcnt(0)), the memory clobber keeps the compiler from moving accesses across it, and vector-memory operations stay in flight.
+__device__ __forceinline__ void enc_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Phase stamps (diagnostic build only: `make -C recboard_amd/csrc encprof` -> librecengine_encprof.so, scripts/enc_phases.py):
+// thread 0 of workgroup 0 records the shader clock at phase boundaries of its first work item (the plan's largest).
+#ifdef ENC_PROFILE
+#define ENC_MARKS 96
+#define ENC_MARK(arr, i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && k == 0 && (i) < ENC_MARKS) arr[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ENC_MARK(arr, i) do { } while (0)
+#endif
+
+// A pointer whose provenance the compiler no longer knows: loads through it are ordinary loads issued where they are written.
+// (Loads from a `const __restrict__` kernel argument are invariant: the compiler re-issues them right in front of their first
+// use -- a full L2 round trip inside a product -- instead of keeping registers live across the phases in between.)  The
+// explicit global address space keeps them global_load (a generic pointer would turn them into flat_load, which counts on
+// both memory counters and retires out of order).
+typedef const __attribute__((address_space(1))) float* gcf_t;
+__device__ __forceinline__ gcf_t g_launder(const float* p) {
     asm volatile("" : "+s"(p));
-    return p;
+    return (gcf_t)p;
+}
+__device__ __forceinline__ void ld4g(float* f, gcf_t p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = *reinterpret_cast<const __attribute__((address_space(1))) f4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
 }
 
 // ---- row-wise helpers: thread tid handles row tid / TPR, columns [CPT * (tid % TPR), +CPT) -----------------------------
@@ -241,15 +267,18 @@ __device__ __forceinline__ void gemm_rows(const float* A, const float (&bf)[D / 
 
 // weight fragment for y = x W^T: B[k][n] = W[n][k], W row-major [D][D] in global memory (k contiguous: 16-byte loads)
 template <int D>
-__device__ __forceinline__ void wfrag_t(float (&bf)[D / 4], const float* __restrict__ W, int strip, int lane) {
-    const float* p = W + (16 * strip + (lane & 15)) * D + 4 * (lane >> 4);
+__device__ __forceinline__ void wfrag_t(float (&bf)[D / 4], const float* W, int strip, int lane) {
+    // (the laundered pointer makes these ordinary loads: as loads from a `const __restrict__` kernel argument they are invariant, and
+    // the compiler re-issues them right in front of their first use -- a full L2 round trip inside every product -- instead of
+    // keeping 16 registers live across the phases in between)
+    gcf_t p = g_launder(W) + (16 * strip + (lane & 15)) * D + 4 * (lane >> 4);
 #pragma unroll
-    for (int q = 0; q < D / 16; ++q) ld4(&bf[4 * q], p + 16 * q);
+    for (int q = 0; q < D / 16; ++q) ld4g(&bf[4 * q], p + 16 * q);
 }
 // weight fragment for dx = dy W: B[k][n] = W[k][n] (k strided)
 template <int D>
-__device__ __forceinline__ void wfrag_n(float (&bf)[D / 4], const float* __restrict__ W, int strip, int lane) {
-    const float* p = W + (4 * (lane >> 4)) * D + 16 * strip + (lane & 15);
+__device__ __forceinline__ void wfrag_n(float (&bf)[D / 4], const float* W, int strip, int lane) {
+    gcf_t p = g_launder(W) + (4 * (lane >> 4)) * D + 16 * strip + (lane & 15);
 #pragma unroll
     for (int q = 0; q < D / 16; ++q)
 #pragma unroll
@@ -349,13 +378,15 @@ struct TileRegs {
     float4 v[EC<D>::ROWS * (D / 4) / EC<D>::NT];
 };
 template <int D>
-__device__ __forceinline__ void tile_fetch(TileRegs<D>& R, const float* __restrict__ g, int nrows, int tid) {
+__device__ __forceinline__ void tile_fetch(TileRegs<D>& R, const float* g, int nrows, int tid) {
     using C = EC<D>;
+    gcf_t gp = g_launder(g);   // (pins the request where it is written)
 #pragma unroll
     for (int q = 0; q < C::ROWS * (D / 4) / C::NT; ++q) {
         const int f = q * C::NT + tid;
-        R.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < nrows * (D / 4)) R.v[q] = reinterpret_cast<const float4*>(g)[f];
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (f < nrows * (D / 4)) ld4g(t, gp + 4 * f);
+        R.v[q] = make_float4(t[0], t[1], t[2], t[3]);
     }
 }
 template <int D>
@@ -375,16 +406,18 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
 }
 // rows of a [B*S][D] matrix selected by s_gid (dummy rows read as zero / are not written)
 template <int D>
-__device__ __forceinline__ void tile_fetch_gid(TileRegs<D>& R, const float* __restrict__ g, const int* s_gid, int nrows, int tid) {
+__device__ __forceinline__ void tile_fetch_gid(TileRegs<D>& R, const float* g, const int* s_gid, int nrows, int tid) {
     using C = EC<D>;
+    gcf_t gp = g_launder(g);
 #pragma unroll
     for (int q = 0; q < C::ROWS * (D / 4) / C::NT; ++q) {
         const int f = q * C::NT + tid;
-        R.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
         if (f < nrows * (D / 4)) {
             const int gid = s_gid[f / (D / 4)];
-            if (gid >= 0) R.v[q] = reinterpret_cast<const float4*>(g + (int64_t)gid * D)[f % (D / 4)];
+            if (gid >= 0) ld4g(t, gp + (int64_t)gid * D + 4 * (f % (D / 4)));
         }
+        R.v[q] = make_float4(t[0], t[1], t[2], t[3]);
     }
 }
 template <int D>
@@ -419,6 +452,38 @@ __device__ __forceinline__ void ln_row(const float* src, float* dst, const float
     rstd = 1.0f / sqrtf(row_sum<C::TPR>(q2) * (1.0f / D) + 1e-8f);
 #pragma unroll
     for (int i = 0; i < C::CPT; ++i) dst[r * C::LS + c0 + i] = (x[i] - mean) * rstd * gw[c0 + i] + gb[c0 + i];
+}
+
+// ---- a block's small parameters (LayerNorm scale / shift, the six biases: 10 vectors of D floats) are staged in LDS one block
+// ahead: read where they are used straight from global memory, every one of them is an exposed L2 round trip on the item's
+// critical path -- and the counter that waits for it (vmcnt, in order) also waits for every older weight-fragment request.
+//   slot: 0 ln_a_w 1 ln_a_b 2 bq 3 bk 4 bv 5 bo 6 ln_f_w 7 ln_f_b 8 b1 9 b2
+#define EP_NPAR 10
+template <int D>
+struct ParRegs {
+    float v[(EP_NPAR * D + EC<D>::NT - 1) / EC<D>::NT];
+};
+template <int D>
+__device__ __forceinline__ void par_fetch(ParRegs<D>& R, const SasrecBlockParams& W, int tid) {
+    using C = EC<D>;
+#pragma unroll
+    for (int q = 0; q < (EP_NPAR * D + C::NT - 1) / C::NT; ++q) {
+        const int e = q * C::NT + tid;
+        const int v = e / D, cc = e % D;
+        const float* p = (v == 0) ? W.ln_a_w : (v == 1) ? W.ln_a_b : (v < 5) ? W.in_b + (v - 2) * D : (v == 5) ? W.out_b
+                       : (v == 6) ? W.ln_f_w : (v == 7) ? W.ln_f_b : (v == 8) ? W.b1 : W.b2;
+        asm volatile("" : "+v"(p));   // (an opaque address: an ordinary load, issued here)
+        R.v[q] = (e < EP_NPAR * D) ? ((gcf_t)p)[cc] : 0.f;
+    }
+}
+template <int D>
+__device__ __forceinline__ void par_commit(float* dst, const ParRegs<D>& R, int tid) {
+    using C = EC<D>;
+#pragma unroll
+    for (int q = 0; q < (EP_NPAR * D + C::NT - 1) / C::NT; ++q) {
+        const int e = q * C::NT + tid;
+        if (e < EP_NPAR * D) dst[e] = R.v[q];
+    }
 }
 
 static bool se_fill_params(SasrecParams& P, const float* const* bp, int64_t L, const float* last_w, const float* last_b) {

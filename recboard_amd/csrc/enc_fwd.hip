@@ -15,6 +15,13 @@
 
 #include "enc_common.h"
 
+#ifdef ENC_PROFILE
+__device__ unsigned long long g_fwd_marks[ENC_MARKS];
+extern "C" int re_dbg_enc_marks_fwd(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_marks), sizeof(unsigned long long) * ENC_MARKS) == hipSuccess ? 0 : 1;
+}
+#endif
+
 struct SeEmbed {
     const float *E, *P;   // item table [R, D] (row 0 = padding), position table [S, D]; E == nullptr: x0 is given
     int64_t R;
@@ -38,6 +45,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
     float* sP = bV + C::BUF;
     __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS];
     __shared__ float s_w[C::ROWS];
+    __shared__ float s_par[2 * EP_NPAR * D], s_last[2 * D];
 
     const int tid0 = threadIdx.x;
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
@@ -58,9 +66,20 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
         const EncItem it = enc_item(PL, wi);
         const int nrows = 16 * it.nt;
         const int64_t row0 = (int64_t)it.tile0 * 16;
-        __syncthreads();
+        int mk = 0; (void)mk;
+        // block 0's small parameters and first three weight fragments are requested before anything else of the item
+        ParRegs<D> PR;
+        float wa[D / 4], wb[D / 4], wc[D / 4];
+        par_fetch<D>(PR, P.blk[0], tid);
+        const float lastv = tid < 2 * D ? (tid < D ? P.last_w[tid] : P.last_b[tid - D]) : 0.f;
+        wfrag_t<D>(wa, P.blk[0].in_w, strip, lane);
+        wfrag_t<D>(wb, P.blk[0].in_w + D * D, strip, lane);
+        wfrag_t<D>(wc, P.blk[0].in_w + 2 * D * D, strip, lane);
+        enc_sync();
+        ENC_MARK(g_fwd_marks, mk); ++mk;
         enc_decode<D>(PL, it, seq, tid, s_gid, s_first, s_pad);
-        __syncthreads();
+        enc_sync();
+        ENC_MARK(g_fwd_marks, mk); ++mk;
         if (tid < C::ROWS) s_sid[tid] = s_gid[tid] >= 0 ? s_gid[tid] / S : -1;
         // ---- x0 rows: from the tables (re_sasrec_embed fused in) or given
         if (em.E) {
@@ -93,44 +112,52 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
             tile_fetch_gid<D>(R, x0, s_gid, nrows, tid);
             tile_commit<D>(bX, R, nrows, tid);
         }
-        __syncthreads();
+        par_commit<D>(s_par, PR, tid);
+        if (tid < 2 * D) s_last[tid] = lastv;
+        enc_sync();
+        ENC_MARK(g_fwd_marks, mk); ++mk;
 
         for (int l = 0; l < L; ++l) {
-            const SasrecBlockParams W = P.blk[l];
             float* tp = TRAIN ? tape + (int64_t)l * T.per_block : nullptr;
-            float wf[D / 4], wg[D / 4];
-            wfrag_t<D>(wf, W.in_w, strip, lane);                      // Wq
+            const float* par = s_par + (l & 1) * EP_NPAR * D;
+            const bool more = l + 1 < L;
+            const SasrecBlockParams Wn = P.blk[more ? l + 1 : l];   // the NEXT block's weights: requested two or more phases before use
+            if (more) par_fetch<D>(PR, Wn, tid);
             // ---- 1. Q-input = LN_a(x)
             if (r_e < nrows) {
                 float mean, rstd;
-                ln_row<D>(bX, bA, W.ln_a_w, W.ln_a_b, tid, mean, rstd);
+                ln_row<D>(bX, bA, par + 0 * D, par + 1 * D, tid, mean, rstd);
                 if (TRAIN && row_lead) {
                     float* st = tp + T.off_SA + (row0 + r_e) * 2;
                     st[0] = mean; st[1] = rstd;
                 }
             }
             if (TRAIN) tile_store<D>(bX, tp + T.off_X + row0 * D, nrows, tid);
-            wfrag_t<D>(wg, W.in_w + D * D, strip, lane);              // Wk
-            __syncthreads();
-            // ---- 2. q, k, v projections
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
+            // ---- 2. q, k, v projections (wa, wb, wc hold Wq, Wk, Wv); each register set is re-requested as soon as its product is done
             {
-                const float bq = W.in_b[col], bk = W.in_b[D + col], bv = W.in_b[2 * D + col];
+                const SasrecBlockParams W = P.blk[l];
+                const float bq = par[2 * D + col], bk = par[3 * D + col], bv = par[4 * D + col];
+                gemm_rows<D>(bA, wa, lane, wr, it.nt, [&](int row, float v) { bQ[row * C::LS + col] = v + bq; });
+                wfrag_t<D>(wa, W.out_w, strip, lane);                 // Wo
+                gemm_rows<D>(bX, wb, lane, wr, it.nt, [&](int row, float v) { bK[row * C::LS + col] = v + bk; });
+                wfrag_t<D>(wb, W.w1, strip, lane);                    // W1
+                gemm_rows<D>(bX, wc, lane, wr, it.nt, [&](int row, float v) { bV[row * C::LS + col] = v + bv; });
+                wfrag_t<D>(wc, W.w2, strip, lane);                    // W2
                 if (TRAIN) tile_store<D>(bA, tp + T.off_A + row0 * D, nrows, tid);
-                gemm_rows<D>(bA, wf, lane, wr, it.nt, [&](int row, float v) { bQ[row * C::LS + col] = v + bq; });
-                wfrag_t<D>(wf, W.in_w + 2 * D * D, strip, lane);      // Wv
-                gemm_rows<D>(bX, wg, lane, wr, it.nt, [&](int row, float v) { bK[row * C::LS + col] = v + bk; });
-                gemm_rows<D>(bX, wf, lane, wr, it.nt, [&](int row, float v) { bV[row * C::LS + col] = v + bv; });
             }
-            wfrag_t<D>(wf, W.out_w, strip, lane);                     // Wo
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
+            // ---- 3. scores = q k^T / sqrt(D) over the item's (row tile, key tile) pairs
+            gemm_pairs<D>(bQ, bK, lane, wave, it, [&](int row, int key, float v) { sP[row * C::PLS + key] = v * inv_sqrt_d; });
             if (TRAIN) {
                 tile_store<D>(bQ, tp + T.off_Q + row0 * D, nrows, tid);
                 tile_store<D>(bK, tp + T.off_K + row0 * D, nrows, tid);
                 tile_store<D>(bV, tp + T.off_V + row0 * D, nrows, tid);
             }
-            // ---- 3. scores = q k^T / sqrt(D) over the item's (row tile, key tile) pairs
-            gemm_pairs<D>(bQ, bK, lane, wave, it, [&](int row, int key, float v) { sP[row * C::PLS + key] = v * inv_sqrt_d; });
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- softmax over the keys of the same sequence with j <= i (causal; explicit pad rows ARE keys), plus the virtual
             //      pad key in front of the sequence (multiplicity first, score q.b_k/sqrt(D), value b_v); dropout on the probabilities
             if (r_e < nrows) {
@@ -151,7 +178,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                 }
                 float d = 0.f;
 #pragma unroll
-                for (int jj = 0; jj < C::CPT; ++jj) d = fmaf(bQ[i * C::LS + c0_e + jj], W.in_b[D + c0_e + jj], d);
+                for (int jj = 0; jj < C::CPT; ++jj) d = fmaf(bQ[i * C::LS + c0_e + jj], par[3 * D + c0_e + jj], d);
                 d = row_sum<C::TPR>(d);
                 const float spad = (gi >= 0 && n_out > 0) ? d * inv_sqrt_d : -INFINITY;
                 mx = row_max<C::TPR>(fmaxf(mx, spad));
@@ -206,38 +233,40 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                     sP[i * C::PLS + j] = pr;
                 }
             }
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- 4. o = A v + w * b_v
             {
-                const float bv = W.in_b[2 * D + col];
+                const float bv = par[4 * D + col];
                 gemm_tx<D>(sP, bV, lane, wr, strip, it, [&](int row, float v) { bA[row * C::LS + col] = fmaf(s_w[row], bv, v); });
             }
-            wfrag_t<D>(wg, W.w1, strip, lane);                        // W1
-            __syncthreads();
-            if (TRAIN) tile_store<D>(bA, tp + T.off_O + row0 * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- 5. x1 = o Wo^T + bo + x
             {
-                const float bo = W.out_b[col];
-                gemm_rows<D>(bA, wf, lane, wr, it.nt, [&](int row, float v) { bQ[row * C::LS + col] = v + bo + bX[row * C::LS + col]; });
+                const float bo = par[5 * D + col];
+                gemm_rows<D>(bA, wa, lane, wr, it.nt, [&](int row, float v) { bQ[row * C::LS + col] = v + bo + bX[row * C::LS + col]; });
+                if (more) wfrag_t<D>(wa, Wn.in_w, strip, lane);                   // next block's Wq
+                if (TRAIN) tile_store<D>(bA, tp + T.off_O + row0 * D, nrows, tid);
             }
-            wfrag_t<D>(wf, W.w2, strip, lane);                        // W2
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- 6. y = LN_f(x1)
             if (r_e < nrows) {
                 float mean, rstd;
-                ln_row<D>(bQ, bK, W.ln_f_w, W.ln_f_b, tid, mean, rstd);
+                ln_row<D>(bQ, bK, par + 6 * D, par + 7 * D, tid, mean, rstd);
                 if (TRAIN && row_lead) {
                     float* st = tp + T.off_SF + (row0 + r_e) * 2;
                     st[0] = mean; st[1] = rstd;
                 }
             }
             if (TRAIN) tile_store<D>(bQ, tp + T.off_X1 + row0 * D, nrows, tid);
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- 7. hr = relu(dropout1(y W1^T + b1))
             {
-                const float b1 = W.b1[col];
-                if (TRAIN) tile_store<D>(bK, tp + T.off_Y + row0 * D, nrows, tid);
-                gemm_rows<D>(bK, wg, lane, wr, it.nt, [&](int row, float v) {
+                const float b1 = par[8 * D + col];
+                gemm_rows<D>(bK, wb, lane, wr, it.nt, [&](int row, float v) {
                     v += b1;
                     if (thresh) {
                         const uint32_t e = (uint32_t)((int64_t)s_gid[row] * D + col);
@@ -245,13 +274,15 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                     }
                     bV[row * C::LS + col] = fmaxf(v, 0.f);
                 });
+                if (more) wfrag_t<D>(wb, Wn.in_w + D * D, strip, lane);           // next block's Wk
+                if (TRAIN) tile_store<D>(bK, tp + T.off_Y + row0 * D, nrows, tid);
             }
-            __syncthreads();
-            if (TRAIN) tile_store<D>(bV, tp + T.off_HR + row0 * D, nrows, tid);
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- 8. x' = dropout2(hr W2^T + b2) + y, pad rows zeroed
             {
-                const float b2 = W.b2[col];
-                gemm_rows<D>(bV, wf, lane, wr, it.nt, [&](int row, float v) {
+                const float b2 = par[9 * D + col];
+                gemm_rows<D>(bV, wc, lane, wr, it.nt, [&](int row, float v) {
                     v += b2;
                     if (thresh) {
                         const uint32_t e = (uint32_t)((int64_t)s_gid[row] * D + col);
@@ -260,20 +291,25 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                     v += bK[row * C::LS + col];
                     bX[row * C::LS + col] = s_pad[row] ? 0.f : v;
                 });
+                if (more) wfrag_t<D>(wc, Wn.in_w + 2 * D * D, strip, lane);       // next block's Wv
+                if (TRAIN) tile_store<D>(bV, tp + T.off_HR + row0 * D, nrows, tid);
+                if (more) par_commit<D>(s_par + ((l + 1) & 1) * EP_NPAR * D, PR, tid);   // (the other half: this block's readers use `par`)
             }
-            __syncthreads();
+            enc_sync();
+            ENC_MARK(g_fwd_marks, mk); ++mk;
         }
         // ---- u = LN_last(x_L)
         if (r_e < nrows) {
             float mean, rstd;
-            ln_row<D>(bX, bA, P.last_w, P.last_b, tid, mean, rstd);
+            ln_row<D>(bX, bA, s_last, s_last + D, tid, mean, rstd);
             if (TRAIN && row_lead) {
                 float* st = tape + T.off_SL + (row0 + r_e) * 2;
                 st[0] = mean; st[1] = rstd;
             }
         }
         if (TRAIN) tile_store<D>(bX, tape + T.off_XL + row0 * D, nrows, tid);
-        __syncthreads();
+        enc_sync();
+        ENC_MARK(g_fwd_marks, mk); ++mk;
         tile_store_gid<D>(bA, u, s_gid, nrows, tid);
         if (fill_pads) {
             // positions in front of a sequence's first row are pads: u = LN_last(0) = beta_last (what the reference's encode returns there)
@@ -281,7 +317,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                 const int gid = s_gid[r], first = s_first[r];
                 if (gid < 0 || first == 0 || gid - s_sid[r] * S != first) continue;   // (workgroup-uniform)
                 for (int f = tid; f < first * (D / 4); f += C::NT)
-                    reinterpret_cast<float4*>(u + (int64_t)(gid - first) * D)[f] = reinterpret_cast<const float4*>(P.last_b)[f % (D / 4)];
+                    reinterpret_cast<float4*>(u + (int64_t)(gid - first) * D)[f] = reinterpret_cast<const float4*>(s_last + D)[f % (D / 4)];
             }
         }
     }

@@ -13,6 +13,7 @@
 
 #define PL_NT 1024
 #define PL_NW (PL_NT / 64)
+#define PL_LDS_B 8192   // sequences whose span / placement fit the plan workgroup's LDS
 #define PL_NCLS 8   // 0..2: long sequences of 4 / 3 / 2 tiles; 3..7: slots of 16 / 8 / 4 / 2 / 1 rows
 
 __device__ __forceinline__ int pl_class(int span) {
@@ -24,6 +25,14 @@ __device__ __forceinline__ int pl_class(int span) {
     if (span > 2) return 5;
     if (span > 1) return 6;
     return 7;
+}
+
+// Barrier of the plan workgroup.  What crosses waves lives in LDS for batches of up to PL_LDS_B sequences: the barrier then only
+// orders LDS traffic and the kernel's global stores stay in flight (__syncthreads() waits for every one of them: a store round
+// trip at each of the ~10 barriers).  Larger batches keep span / placement in global scratch and take the full barrier.
+__device__ __forceinline__ void pl_sync(bool lds_only) {
+    if (lds_only) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
 }
 
 __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
@@ -54,14 +63,25 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
         return;
     }
     // ---- plan (workgroup 0)
+#ifdef ENC_PROFILE
+    unsigned long long pl_t[6];
+    pl_t[0] = __builtin_amdgcn_s_memtime();
+#define PL_STAMP(i) pl_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define PL_STAMP(i) do { } while (0)
+#endif
     __shared__ int s_cnt[PL_NCLS][PL_NW];
-    __shared__ int s_tot[PL_NCLS], s_base[PL_NCLS], s_lay[16], s_red[PL_NW];
+    __shared__ int s_tot[PL_NCLS], s_base[PL_NCLS], s_lay[16], s_red[PL_NW], s_cb[PL_NCLS + 1], s_r0[PL_NCLS + 1];
+    __shared__ unsigned char s_span[PL_LDS_B];
+    __shared__ int s_place[PL_LDS_B];
     const int64_t mt = enc_plan_max_tiles(B, S);
     int* hdr = plan;
     int* items = plan + EP_HDR;
     int2* rowmap = (int2*)(plan + enc_plan_rowmap_word(B, S));
-    int* sc_span = plan + enc_plan_rowmap_word(B, S) + 2 * 16 * mt;   // [B] span
-    int* sc_place = sc_span + B;                                      // [B] first compact row of the sequence
+    // span / first compact row of every sequence: in LDS for batches up to PL_LDS_B sequences, else in the plan's scratch words
+    const bool in_lds = B <= PL_LDS_B;
+    int* g_span = plan + enc_plan_rowmap_word(B, S) + 2 * 16 * mt;
+    int* g_place = g_span + B;
     if (tid == 0 && state) {
         state[0] = seed;
         state[1] = 0u;
@@ -69,19 +89,30 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
         state[3] = __float_as_uint(inv_sqrt_bc2);
     }
     if (tid < PL_NCLS) s_tot[tid] = 0;
-    // 1. span of every sequence (a wave per sequence, lane = position); a sequence without any item is given one explicit pad row
+    // 1. span of every sequence: a wave per sequence, lane = position (one coalesced load, a ballot, two scalar bit counts: ~10
+    //    instructions per sequence -- an element-wise formulation is VALU-bound on this one CU), 16 sequences in flight per wave;
+    //    a sequence without any item is given one explicit pad row
     int nnz = 0;
-    for (int b = wave; b < B; b += PL_NW) {
-        const bool nzl = lane < S && seq[(int64_t)b * S + lane] != 0;
-        const unsigned long long m = __ballot(nzl);
-        const int first = m ? __builtin_ctzll(m) : S - 1;
-        if (lane == 0) {
-            sc_span[b] = S - first;
-            nnz += __builtin_popcountll(m);
+    for (int b0 = wave * 16; b0 < B; b0 += PL_NW * 16) {
+        int64_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {   // (clamped, unconditional: a predicated load is waited for on the spot)
+            const int b = b0 + q < B ? b0 + q : B - 1;
+            v[q] = seq[(int64_t)b * S + (lane < S ? lane : S - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned long long m = __ballot(lane < S && v[q] != 0);
+            const int first = m ? __builtin_ctzll(m) : S - 1;
+            if (lane == 0 && b0 + q < B) {
+                if (in_lds) s_span[b0 + q] = (unsigned char)(S - first); else g_span[b0 + q] = S - first;
+                nnz += __builtin_popcountll(m);
+            }
         }
     }
+    PL_STAMP(1);
     if (lane == 0) s_red[wave] = nnz;
-    __syncthreads();
+    pl_sync(in_lds);
     if (tid == 0) {
         int c = 0;
         for (int w = 0; w < PL_NW; ++w) c += s_red[w];
@@ -91,7 +122,7 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
     // 2. class totals, then ranks (ballot prefix counts: deterministic), in chunks of PL_NT sequences
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
-            __syncthreads();
+            pl_sync(in_lds);
             if (tid == 0) {
                 const int n0 = s_tot[0], n1 = s_tot[1], n2 = s_tot[2];
                 const int nlong = n0 + n1 + n2, tlong = 4 * n0 + 3 * n1 + 2 * n2;
@@ -115,12 +146,20 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 for (int k = 3; k < PL_NCLS; ++k) s_lay[8 + k] = 16 * tlong + ro[k];         // first compact row of the slot classes
                 hdr[0] = nlong + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0;
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;
+                // class k: s_cb[k] sequences in front of it, its rows start at s_r0[k]
+                int cb = 0, r0 = 0;
+                for (int k = 0; k < PL_NCLS; ++k) {
+                    s_cb[k] = cb; s_r0[k] = r0;
+                    cb += s_tot[k];
+                    r0 += s_tot[k] * (k < 3 ? 16 * (4 - k) : (16 >> (k - 3)));
+                }
+                s_cb[PL_NCLS] = cb; s_r0[PL_NCLS] = r0;
             }
-            __syncthreads();
+            pl_sync(in_lds);
         }
         for (int b0 = 0; b0 < B; b0 += PL_NT) {
             const int b = b0 + tid;
-            const int span = b < B ? sc_span[b] : 0;
+            const int span = b < B ? (in_lds ? (int)s_span[b] : g_span[b]) : 0;
             const int cls = b < B ? pl_class(span) : -1;
             int rank = 0;
 #pragma unroll
@@ -129,44 +168,58 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 if (lane == 0) s_cnt[k][wave] = __builtin_popcountll(m);
                 if (cls == k) rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
             }
-            __syncthreads();
+            pl_sync(in_lds);
             if (pass == 1 && cls >= 0) {
                 for (int w = 0; w < wave; ++w) rank += s_cnt[cls][w];
                 rank += s_base[cls];
-                int row0;
                 if (cls < 3) {
                     const int nt = 4 - cls;
-                    const int tile0 = s_lay[5 + cls] + nt * rank;
-                    items[s_lay[8 + cls] + rank] = tile0 | (nt << 24) | (1 << 28);
-                    row0 = 16 * tile0;
-                } else {
-                    row0 = s_lay[8 + cls] + (16 >> (cls - 3)) * rank;
+                    items[s_cb[cls] + rank] = (s_lay[5 + cls] + nt * rank) | (nt << 24) | (1 << 28);
                 }
-                sc_place[b] = row0;
+                // the sequences sorted by class, then rank: sorted index -> sequence (rows are laid out in this order)
+                if (in_lds) s_place[s_cb[cls] + rank] = b; else g_place[s_cb[cls] + rank] = b;
             }
-            __syncthreads();
+            pl_sync(in_lds);
             if (tid < PL_NCLS) {
                 int c = 0;
                 for (int w = 0; w < PL_NW; ++w) c += s_cnt[tid][w];
                 if (pass == 0) s_tot[tid] += c; else s_base[tid] += c;
             }
-            __syncthreads();
+            pl_sync(in_lds);
         }
     }
-    // 3. short items, dummy rows, then the rows of every sequence
+    PL_STAMP(2);
+    // 3. short items, then every compact row exactly once: a sequence's wave writes its whole slot (rows behind the span are
+    //    dummies), the rows behind the last slot of the last short tile are dummies too
     const int nlong = s_lay[0], tlong = s_lay[1], tshort = s_lay[2], G = s_lay[3], nshort = s_lay[4];
     for (int i = tid; i < nshort; i += PL_NT) {
         const int t0 = i * G;
         const int nt = (tshort - t0) < G ? (tshort - t0) : G;
         items[nlong + i] = (tlong + t0) | (nt << 24);
     }
-    const int nrows = 16 * (tlong + tshort);
-    for (int i = tid; i < nrows; i += PL_NT) rowmap[i] = make_int2(-1, 0);
-    __syncthreads();
-    for (int b = wave; b < B; b += PL_NW) {
-        const int span = sc_span[b], row0 = sc_place[b];
-        if (lane < span) rowmap[row0 + lane] = make_int2(b * S + (S - span) + lane, S - span);
+    // (a thread per compact row: coalesced stores.  Row -> class by the class row ranges, -> rank and offset inside the slot,
+    //  -> sequence through the sorted index)
+    const int nrows_all = 16 * (tlong + tshort);
+    for (int r = tid; r < nrows_all; r += PL_NT) {
+        int2 out = make_int2(-1, 0);
+        if (r < s_r0[PL_NCLS]) {
+            int k = 0;
+#pragma unroll
+            for (int q = 1; q < PL_NCLS; ++q) k += (r >= s_r0[q]) ? 1 : 0;
+            const int rel = r - s_r0[k];
+            int rank, off;
+            if (k == 1) { rank = rel / 48; off = rel - 48 * rank; }
+            else { const int sh = (k == 0) ? 6 : (k == 2) ? 5 : 7 - k; rank = rel >> sh; off = rel & ((1 << sh) - 1); }
+            const int b = in_lds ? s_place[s_cb[k] + rank] : g_place[s_cb[k] + rank];
+            const int span = in_lds ? (int)s_span[b] : g_span[b];
+            if (off < span) out = make_int2(b * S + (S - span) + off, S - span);
+        }
+        rowmap[r] = out;
     }
+#ifdef ENC_PROFILE
+    PL_STAMP(3);
+    if (tid == 0) { hdr[5] = (int)(pl_t[1] - pl_t[0]); hdr[6] = (int)(pl_t[2] - pl_t[1]); hdr[7] = (int)(pl_t[3] - pl_t[2]); }
+#endif
 }
 
 extern "C" size_t re_sasrec_plan_bytes(int64_t B, int64_t S) {
@@ -191,7 +244,7 @@ extern "C" int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, cons
         ib = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
     }
     const bool elementwise = seq_out || valid || rows_all || pos_out;
-    const unsigned grid = 1 + (elementwise ? re_grid(B * S, 4 * PL_NT, 64) : 0);
+    const unsigned grid = 1 + (elementwise ? re_grid(B * S, PL_NT, 256) : 0);
     hipLaunchKernelGGL(sasrec_batch_prep_k, dim3(grid), dim3(PL_NT), 0, (hipStream_t)stream, seq, pos, neg, (int)B, (int)S, (int)ncu,
                        (int)max_tiles, seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib);
     return re_launch_status();

@@ -16,36 +16,44 @@ size_t enc_wgrad_part_floats(int64_t D, int64_t L) { return (size_t)L * EG_NMAT 
 template <int D>
 __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tape, EncTape T, const float* __restrict__ gtape, int64_t NR,
                                                    const void* __restrict__ planp, int B, int S, int L, float* __restrict__ part,
-                                                   const int64_t* __restrict__ seq, const float* __restrict__ contrib, float inv_scale,
-                                                   float* __restrict__ dPtab) {
+                                                   const int64_t* __restrict__ seq, const float* __restrict__ contrib, float* __restrict__ ppart,
+                                                   const float* __restrict__ dPtab) {
     using C = EC<D>;
     constexpr int RTW = C::NS / C::WR;   // output row tiles per wave
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int strip = wave % C::NS, wr = wave / C::NS, g = lane >> 4, c = lane & 15;
     if ((int)blockIdx.z == L) {
-        // ---- position-table gradient: dP[p] = sum over the sequences with a real token at p of contrib[b][p] / scale
-        const int p = blockIdx.y * gridDim.x + blockIdx.x;
-        if (p >= S || !dPtab) return;
+        // ---- position-table gradient, partial sums: job (p, chunk of 64 sequences) -> ppart[p][chunk][D] = sum over the chunk's
+        //      sequences with a real token at p of contrib[b][p]  (every load independent: one memory round trip per job)
+        if (!dPtab) return;
+        const int nch = (B + 63) / 64, njobs = S * nch;
         const int col = tid % D, rg = tid / D;
-        float s = 0.f;
-        for (int b0 = rg; b0 < B; b0 += 4 * C::CG) {
-            float v[4];
+        for (int j = blockIdx.y * gridDim.x + blockIdx.x; j < njobs; j += gridDim.x * gridDim.y) {
+            const int p = j / nch, ch = j % nch;
+            int64_t sv[64 / C::CG];
+            float cv[64 / C::CG];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int b = b0 + q * C::CG;
-                v[q] = 0.f;
-                if (b < B && seq[(int64_t)b * S + p] != 0) v[q] = contrib[((int64_t)b * S + p) * D + col];
+            for (int q = 0; q < 64 / C::CG; ++q) {
+                const int b = ch * 64 + rg + C::CG * q;
+                sv[q] = 0; cv[q] = 0.f;
+                if (b < B) {
+                    sv[q] = seq[(int64_t)b * S + p];
+                    cv[q] = contrib[((int64_t)b * S + p) * D + col];
+                }
             }
-            s += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        lds[tid] = s;
-        __syncthreads();
-        if (tid < D) {
-            float t = lds[tid];
+            float s = 0.f;
 #pragma unroll
-            for (int i = 1; i < C::CG; ++i) t += lds[i * D + tid];
-            dPtab[p * D + tid] = t * inv_scale;
+            for (int q = 0; q < 64 / C::CG; ++q) s += (sv[q] != 0) ? cv[q] : 0.f;   // (rows of pad positions are never written: select, not multiply)
+            __syncthreads();
+            lds[tid] = s;
+            __syncthreads();
+            if (tid < D) {
+                float t = lds[tid];
+#pragma unroll
+                for (int i = 1; i < C::CG; ++i) t += lds[i * D + tid];
+                ppart[(int64_t)j * D + tid] = t;
+            }
         }
         return;
     }
@@ -66,13 +74,13 @@ __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tap
     for (int tc = t0; tc < t1; tc += WG_CH) {
         const int ntc = (t1 - tc) < WG_CH ? (t1 - tc) : WG_CH;
         const int nf = 16 * ntc * (D / 4);
-        __syncthreads();
+        enc_sync();
         for (int f = tid; f < nf; f += C::NT) {
             const int r = f / (D / 4), c4 = f % (D / 4);
             *reinterpret_cast<float4*>(bufA + r * C::LS + 4 * c4) = reinterpret_cast<const float4*>(dY + (int64_t)tc * 16 * D)[f];
             *reinterpret_cast<float4*>(bufB + r * C::LS + 4 * c4) = reinterpret_cast<const float4*>(X + (int64_t)tc * 16 * D)[f];
         }
-        __syncthreads();
+        enc_sync();
         for (int q = 0; q < ntc; ++q) {
             float bf[4];
 #pragma unroll
@@ -105,8 +113,19 @@ struct EncGradDst {
 // the rest: 64 columns of one (block, vector) each, summed over the slabs of the workgroups that had work (4 waves x fixed order).
 __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict__ part, const float* __restrict__ slab, int nwg,
                                                          const void* __restrict__ planp, int B, int S, int D, int L, EncGradDst dst,
-                                                         int nmat_blocks) {
+                                                         int nmat_blocks, int nvec_blocks, const float* __restrict__ ppart, float inv_scale,
+                                                         float* __restrict__ dPtab) {
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nmat_blocks + nvec_blocks) {
+        // position-table gradient: the chunk partials of enc_wgrad_k in chunk order, / scale
+        const int e = ((int)blockIdx.x - nmat_blocks - nvec_blocks) * 256 + tid;
+        if (e >= S * D) return;
+        const int p = e / D, cc = e % D, nch = (B + 63) / 64;
+        float s = 0.f;
+        for (int ch = 0; ch < nch; ++ch) s += ppart[((int64_t)p * nch + ch) * D + cc];
+        dPtab[e] = s * inv_scale;
+        return;
+    }
     if ((int)blockIdx.x < nmat_blocks) {
         const int64_t e = (int64_t)blockIdx.x * 256 + tid;
         const int dd = D * D;
@@ -167,23 +186,27 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
     d[cg * 64 + lane] = s;
 }
 
+size_t enc_wgrad_ppart_floats(int64_t B, int64_t D) { return (size_t)64 * ((B + 63) / 64) * D; }
+
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
-                     int nwg, float* part, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab, float* const* block_grads,
-                     float* g_last_w, float* g_last_b, hipStream_t s) {
+                     int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
+                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s) {
     if (D != 64) return RE_EUNSUPPORTED;
     using C = EC<64>;
     const EncTape T = enc_tape_layout(B, S, D, L);
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
     const size_t ldsb = (size_t)2 * 16 * WG_CH * C::LS * sizeof(float);
     hipLaunchKernelGGL(enc_wgrad_k<64>, dim3(WG_NSPLIT, EG_NMAT, (unsigned)(L + (dPtab ? 1 : 0))), dim3(C::NT), ldsb, s, (const float*)tape, T, gtape,
-                       NR, plan, (int)B, (int)S, (int)L, part, seq, contrib, emb_scale != 0.f ? 1.0f / emb_scale : 0.f, dPtab);
+                       NR, plan, (int)B, (int)S, (int)L, part, seq, contrib, ppart, (const float*)dPtab);
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     EncGradDst dst;
     for (int64_t l = 0; l < SE_MAX_BLOCKS; ++l)
         for (int i = 0; i < 14; ++i) dst.p[l][i] = (l < L && i < 12) ? block_grads[12 * l + i] : (i == 12 ? g_last_w : g_last_b);
     const int nmat_blocks = (int)((L * EG_NMAT * D * D + 255) / 256);
     const int nvec_blocks = (int)(L * EG_NVEC * (D / 64));
-    hipLaunchKernelGGL(enc_grad_reduce_k, dim3(nmat_blocks + nvec_blocks), dim3(256), 0, s, (const float*)part, slab, nwg, plan, (int)B, (int)S,
-                       (int)D, (int)L, dst, nmat_blocks);
+    const int npos_blocks = dPtab ? (int)((S * D + 255) / 256) : 0;
+    hipLaunchKernelGGL(enc_grad_reduce_k, dim3(nmat_blocks + nvec_blocks + npos_blocks), dim3(256), 0, s, (const float*)part, slab, nwg, plan,
+                       (int)B, (int)S, (int)D, (int)L, dst, nmat_blocks, nvec_blocks, (const float*)ppart, emb_scale != 0.f ? 1.0f / emb_scale : 0.f,
+                       dPtab);
     return re_launch_status();
 }

@@ -1,5 +1,7 @@
 // Counter-based dropout mask shared by every fused kernel (restated in oracle/rng.py for the tests).
-//   keep(seed, stream, idx) = fmix32(idx*0x9E3779B1 + stream*0x85EBCA77 + seed) >= floor(p * 2^32)
+//   keep(seed, stream, idx) = fmix32(idx + stream*0x85EBCA77 + seed) >= floor(p * 2^32)
+// (murmur3's finaliser over a counter: two 32-bit multiplies per element -- quarter-rate instructions on CDNA, and a mask bit is
+// wanted for every element of five tensors per block; the stream / seed term is wave-uniform and costs nothing per element)
 // Stream ids: 1 = embedding dropout; block l: 16l+2 attention probs, 16l+3 FFN dropout1, 16l+4 FFN dropout2.
 #pragma once
 #include <stdint.h>
@@ -10,7 +12,7 @@
 #define RE_STREAM_FFN2(l) (16u * (l) + 4u)
 
 __host__ __device__ __forceinline__ uint32_t re_rng_u32(uint32_t seed, uint32_t stream, uint32_t idx) {
-    uint32_t h = idx * 0x9E3779B1u + stream * 0x85EBCA77u + seed;
+    uint32_t h = idx + (stream * 0x85EBCA77u + seed);
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
