@@ -250,6 +250,7 @@ extern "C" int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int
     return re_launch_status();
 }
 
+#ifdef RE_DEBUG
 // ---- tuning hook (not part of the ABI): D = 64 gather with a chosen rows-in-flight / store policy / grid cap
 extern "C" int re_dbg_gather64(const float* W, int64_t R, const int64_t* idx, int64_t n, float* out, int variant, int gridcap,
                                re_stream_t stream) {
@@ -269,3 +270,4 @@ extern "C" int re_dbg_gather64(const float* W, int64_t R, const int64_t* idx, in
     }
     return re_launch_status();
 }
+#endif

@@ -1342,23 +1342,46 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static int g_score_pop = 3;      // tuning switches (scripts/tune_score.py); not part of the ABI
-static int64_t g_score_minseg = SC_MIN_SEG;
-static int64_t g_score_maxwgs = SC_MAX_WGS;
+// Tuning / diagnostic switches.  In the product library (librecengine.so) they are compile-time constants and no re_dbg_* symbol
+// exists: the C ABI has no global mutable state (include/recengine.h).  `make dbg` (-DRE_DEBUG) builds librecengine_dbg.so, in
+// which the same switches are variables behind re_dbg_* hooks -- for the A/B tests (tests/test_gpu_score_split.py) and the
+// tuning scripts.
+#ifdef RE_DEBUG
+#define RE_SWITCH static
+#else
+#define RE_SWITCH static const
+#endif
+RE_SWITCH int g_score_pop = 3;      // tuning switches (scripts/tune_score.py); not part of the ABI
+RE_SWITCH int64_t g_score_minseg = SC_MIN_SEG;
+RE_SWITCH int64_t g_score_maxwgs = SC_MAX_WGS;
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_maxwgs(int64_t n) { g_score_maxwgs = n > 0 ? n : SC_MAX_WGS; }
-static int g_score_share = 1;   // workgroups share per-user bounds through global memory (0: A/B switch, scripts/tune_score.py)
+#endif
+RE_SWITCH int g_score_share = 1;   // workgroups share per-user bounds through global memory (0: A/B switch, scripts/tune_score.py)
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_share(int on) { g_score_share = on; }
-static int g_score_dbg = 0;   // diagnostics only (scripts/tune_score.py): 1 = no hits at all, 2 = append but never insert
+#endif
+RE_SWITCH int g_score_dbg = 0;   // diagnostics only (scripts/tune_score.py): 1 = no hits at all, 2 = append but never insert
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_diag(int mode) { g_score_dbg = (g_score_dbg & ~0xFF) | (mode & 0xFF); }
+#endif
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_vote(int at) { g_score_dbg = (g_score_dbg & 0xFF) | ((at >= 0 ? at + 1 : 0) << 8); }
-#ifdef SC_PROFILE
+#endif
+#if defined(SC_PROFILE)
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_counters_x(unsigned long long* out2) { (void)hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_sr_counters_x), 16); }
 #endif
+#endif
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_counters(unsigned long long* out4, int reset) {
     (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sr_counters), 32);
     if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sr_counters), z, 32); }
 }
+#endif
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_variant(int pop, int64_t minseg) { g_score_pop = pop; g_score_minseg = minseg; }
+#endif
 
 struct ScorePlan {
     int64_t nub, nst, units, upw;
@@ -1393,29 +1416,51 @@ static size_t score_lds_bytes(int D, int K, bool topk) {
     return b;
 }
 
-static int g_score_nb3 = 1;            // three stage buffers for long slices (0: A/B switch)
+RE_SWITCH int g_score_nb3 = 1;            // three stage buffers for long slices (0: A/B switch)
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_nb3(int on) { g_score_nb3 = on; }
-static int g_score_sliced = 1;         // sliced split for calls with few user blocks (score_plan_topk; 0: A/B switch)
+#endif
+RE_SWITCH int g_score_sliced = 1;         // sliced split for calls with few user blocks (score_plan_topk; 0: A/B switch)
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_sliced(int on) { g_score_sliced = on; }
-static int g_score_small = 1;          // small batches on the register-list kernels (score_plan_topk; 0: A/B switch)
+#endif
+RE_SWITCH int g_score_small = 1;          // small batches on the register-list kernels (score_plan_topk; 0: A/B switch)
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_small(int on) { g_score_small = on; }
-static int64_t g_score_reg_nub = 16;   // register-list kernels from this many user blocks on (tuning switch, scripts/x2_small.py)
+#endif
+RE_SWITCH int64_t g_score_reg_nub = 16;   // register-list kernels from this many user blocks on (tuning switch, scripts/x2_small.py)
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_reg_nub(int64_t n) { g_score_reg_nub = n; }
-static int g_score_x2 = 1;      // the split (bf16 hi/mid on the XDL pipe + exact re-scoring) fast path; 0 = exact kernel only
+#endif
+RE_SWITCH int g_score_x2 = 1;      // the split (bf16 hi/mid on the XDL pipe + exact re-scoring) fast path; 0 = exact kernel only
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_x2(int on) { g_score_x2 = on; }
-static int g_score_x2_d128 = 1;  // split form at D = 128 (one workgroup per CU: two 32 KB stage buffers; A/B switch)
+#endif
+RE_SWITCH int g_score_x2_d128 = 1;  // split form at D = 128 (one workgroup per CU: two 32 KB stage buffers; A/B switch)
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_x2_d128(int on) { g_score_x2_d128 = on; }
-static int g_score_sample = 1;   // split form: starting thresholds from a catalog sample (0: A/B switch, scripts/x2_check.py)
+#endif
+RE_SWITCH int g_score_sample = 1;   // split form: starting thresholds from a catalog sample (0: A/B switch, scripts/x2_check.py)
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_sample(int on) { g_score_sample = on; }
-static int g_score_mxdiag = 0;   // timing-only ablation of score_topk_merge_x (scripts/x2_diag.py): 1 no list merge, 2 no re-scoring, 4 no final sort
+#endif
+RE_SWITCH int g_score_mxdiag = 0;   // timing-only ablation of score_topk_merge_x (scripts/x2_diag.py): 1 no list merge, 2 no re-scoring, 4 no final sort
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_mxdiag(int m) { g_score_mxdiag = m; }
-static int g_score_maxerr = 0;   // diagnostics: record max |s' - s| / eps over all re-scored candidates
+#endif
+RE_SWITCH int g_score_maxerr = 0;   // diagnostics: record max |s' - s| / eps over all re-scored candidates
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_x2_maxerr(int on) { g_score_maxerr = on; }
+#endif
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_x2_info(float* out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sx_info), 32); }
+#endif
+#ifdef RE_DEBUG
 extern "C" void re_dbg_score_x2_stats(unsigned* out2, int reset) {   // (synchronises; tests and scripts only)
     (void)hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_sx_stats), 8);
     if (reset) { unsigned z[2] = {0u, 0u}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sx_stats), z, 8); }
 }
+#endif
 // List capacity of the split form: the smallest instantiated capacity (16, 32, 56) >= K + 6.  A lane's list must be able to
 // hold MORE than the user's whole top K: the best K of a user routinely sit in one list (popular items have neighbouring ids
 // -- with the bench's Zipf-by-id popularity the best 50 of every trained user are inside the first 64 ids: one stage, two

@@ -13,28 +13,20 @@ in sasrec.py / gen.py / deepfm.py remain the fast path (fused steps, one arena, 
 """
 import torch
 
-from . import ops
+from . import torch_ops  # noqa: F401  (registers torch.ops.recengine.*)
 
-
-class _GatherRows(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, W, idx, padding_idx):
-        idx = idx.contiguous()
-        ctx.save_for_backward(idx)
-        ctx.rows, ctx.padding_idx = W.shape[0], padding_idx
-        return ops.gather_rows(W.contiguous(), idx)
-
-    @staticmethod
-    def backward(ctx, g):
-        (idx,) = ctx.saved_tensors
-        # dense table gradient like aten::embedding_dense_backward, deterministic (sorted segments, no atomics)
-        dW = ops.scatter_add_rows(g.contiguous().view(-1, g.shape[-1]), idx.view(-1), ctx.rows, ctx.padding_idx)
-        return dW, None, None
+_R = torch.ops.recengine
 
 
 def gather_rows(W, idx, padding_idx=-1):
-    """W[idx] with a deterministic dense gradient; rows equal to `padding_idx` receive no gradient (nn.Embedding's rule)."""
-    return _GatherRows.apply(W, idx, padding_idx)
+    """W[idx] with a deterministic dense gradient; rows equal to `padding_idx` receive no gradient (nn.Embedding's rule).
+    = torch.ops.recengine.gather_rows (+ the padding rule applied to the looked-up rows' gradient)."""
+    y = _R.gather_rows(W, idx)
+    if padding_idx >= 0:
+        # a row looked up at the padding index passes its value on but takes no gradient
+        keep = (idx != padding_idx).unsqueeze(-1)
+        y = torch.where(keep, y, y.detach())
+    return y
 
 
 class Embedding(torch.nn.Module):
@@ -56,28 +48,10 @@ class Embedding(torch.nn.Module):
         return gather_rows(self.weight, idx, -1 if self.padding_idx is None else self.padding_idx)
 
 
-class _BprTriplet(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, Ut, It, users, pos, neg):
-        users, pos, neg = (t.reshape(-1).contiguous() for t in (users, pos, neg))
-        Ut, It = Ut.contiguous(), It.contiguous()
-        loss, logits = ops.bpr_triplet_fwd(Ut, It, users, pos, neg)
-        ctx.save_for_backward(Ut, It, users, pos, neg, logits)
-        return loss.squeeze(0)
-
-    @staticmethod
-    def backward(ctx, dloss):
-        Ut, It, users, pos, neg, logits = ctx.saved_tensors
-        gu, gp, gn = ops.bpr_triplet_bwd(Ut, It, users, pos, neg, logits, dloss.reshape(1).contiguous())
-        dU = ops.scatter_add_rows(gu, users, Ut.shape[0])
-        dI = ops.scatter_add_rows(torch.cat([gp, gn]), torch.cat([pos, neg]), It.shape[0])
-        return dU, dI, None, None, None
-
-
 def bpr_triplet(Ut, It, users, pos, neg):
     """mean(softplus(<u, i-> - <u, i+>)) over the triplets, fused (gathers, dots, criterion in one kernel each way):
-    MF.fit (MF-BPR/main.py:81-93) for one negative per positive."""
-    return _BprTriplet.apply(Ut, It, users, pos, neg)
+    MF.fit (MF-BPR/main.py:81-93) for one negative per positive.  = torch.ops.recengine.bpr_triplet(...)[0]."""
+    return _R.bpr_triplet(Ut, It, users, pos, neg)[0]
 
 
 class BPRTripletLoss(torch.nn.Module):
@@ -85,47 +59,16 @@ class BPRTripletLoss(torch.nn.Module):
         return bpr_triplet(Ut, It, users, pos, neg)
 
 
-class _ScoreFull(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, Q, E):
-        Q, E = Q.contiguous(), E.contiguous()
-        ctx.save_for_backward(Q, E)
-        return ops.score_dense(Q, E)
-
-    @staticmethod
-    def backward(ctx, dS):
-        Q, E = ctx.saved_tensors
-        dS = dS.contiguous()
-        dQ = ops.gemm(dS, E) if ctx.needs_input_grad[0] else None                  # [B,N] @ [N,D]
-        dE = ops.gemm(dS, Q, transA=True) if ctx.needs_input_grad[1] else None     # [N,B] @ [B,D]
-        return dQ, dE
-
-
 def score_full(Q, E):
-    """scores[b, n] = <Q[b], E[n]> as exact k-ordered fp32 chains (`recommend_from_full`); differentiable (CE over the catalog)."""
-    return _ScoreFull.apply(Q, E)
-
-
-class _SpmmSym(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, X, crow, col, val, plan):
-        X = X.contiguous()
-        ctx.csr, ctx.plan = (crow, col, val), plan
-        return ops.spmm_csr(crow, col, val, plan, X, torch.empty_like(X))
-
-    @staticmethod
-    def backward(ctx, dY):
-        crow, col, val = ctx.csr
-        dY = dY.contiguous()
-        return ops.spmm_csr(crow, col, val, ctx.plan, dY, torch.empty_like(dY)), None, None, None, None   # A symmetric: A^T dY = A dY
+    """scores[b, n] = <Q[b], E[n]> as exact k-ordered fp32 chains (`recommend_from_full`); differentiable (CE over the catalog).
+    = torch.ops.recengine.score_dense."""
+    return _R.score_dense(Q, E)
 
 
 def spmm_sym(crow, col, val, X, plan=None):
     """A @ X for a SYMMETRIC CSR matrix (LightGCN's normalised bipartite adjacency): the backward is the same kernel.
-    plan = ops.spmm_plan(crow, D) (row order / long-row chunks; build once per matrix)."""
-    if plan is None:
-        plan = ops.spmm_plan(crow, X.shape[1])
-    return _SpmmSym.apply(X, crow, col, val, plan)
+    = torch.ops.recengine.spmm_csr (the row-order plan is built once per adjacency and cached)."""
+    return _R.spmm_csr(crow, col, val, X)
 
 
 class BPRLoss(torch.nn.Module):

@@ -25,6 +25,16 @@ def test_library_exports_every_declared_symbol():
     assert L.re_error_string(0) == b"ok"
 
 
+def test_product_library_has_no_debug_hooks():
+    """include/recengine.h promises "no global mutable state": the tuning switches are compile-time constants in librecengine.so and
+    the re_dbg_* hooks that flip them exist only in the diagnostic twin (make dbg -> librecengine_dbg.so)."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "re_dbg_" not in syms
+    exported = sorted(ln.split()[-1] for ln in syms.splitlines() if " T " in ln and ln.split()[-1].startswith("re_"))
+    assert exported == declared_symbols()        # nothing undeclared is exported either
+
+
 def test_workspace_queries_are_pure_host_calls():
     L = lib.load()
     assert L.re_scatter_add_rows_workspace_bytes(76800, 64, 12102) > 4 * 76800 * 4

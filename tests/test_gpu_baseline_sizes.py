@@ -1,0 +1,149 @@
+"""GPU: parity of the assembled steps at the BASELINE configuration sizes (BASELINE.json configs[1..3]),
+against the CPU oracle on the same seeded inputs.
+
+  C2  SASRec/Beauty   B = 512, N = 12 101, S = 50, D = 64, L = 2, dropout 0.5: ONE graph-replayed fused step from a raw batch vs
+      oracle.sasrec.fit + autograd with the engine's dropout masks (oracle/rng.py): loss and every parameter gradient, 1e-4.
+  C3  LightGCN/Yelp2018 shape: 77 277 users + 45 638 items, ~1.95 M edges (nnz ~3.9 M): SpMM rows and one training step's loss.
+  C4  DeepFM on the Games-context schema (USER 94 762, ITEM 25 612 + 8 context fields), B = 4 096: loss, logits, gradients.
+The oracle finishes each of these in seconds; these are the shapes bench.py / scripts/bench_models.py time.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def test_c2_sasrec_graph_step_at_bench_config_matches_oracle():
+    _need_gpu()
+    from oracle import sasrec as osas
+    from recboard_amd.sasrec import SASRecEngine
+    N, B, S, D, L, p = 12101, 512, 50, 64, 2, 0.5
+    rng = np.random.default_rng(1)
+    w = 1.0 / np.arange(1, N + 1)
+    w /= w.sum()
+    lens = np.clip(rng.geometric(1.0 / 5.9, B) + 1, 1, S - 1)
+    lens[:3] = (49, 33, 17)                                  # every work-item size (4 / 3 / 2 tiles) next to the short ones
+    seq, pos, neg = (np.zeros((B, S), np.int64) for _ in range(3))
+    for b in range(B):
+        n = lens[b]
+        seq[b, S - n:] = rng.choice(N, n, p=w) + 1
+        pos[b, S - n:] = rng.choice(N, n, p=w)
+        neg[b, S - n:] = rng.integers(0, N, n)
+    m = SASRecEngine(N, S, D, L, dropout_rate=p, loss="BCE", lr=0.0, weight_decay=0.0, seed=7)     # lr 0: gradients stay in the arena
+    with torch.no_grad():                                    # non-trivial biases / LayerNorm parameters
+        g = torch.Generator().manual_seed(3)
+        for k, q in m.params.items():
+            if k.endswith("bias"):
+                q.copy_((0.05 * torch.randn(q.shape, generator=g)).cuda())
+            elif "LN" in k:
+                q.copy_((1.0 + 0.1 * torch.randn(q.shape, generator=g)).cuda())
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    m.train_step_graph(dev(seq), dev(pos), dev(neg))                     # capture + first replay (step 1)
+    seed2 = m._step_seed()                                               # the seed of the step that follows
+    loss = m.train_step_graph(dev(seq), dev(pos), dev(neg)).item()       # a pure replay
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = osas.fit(P, torch.from_numpy(seq), torch.from_numpy(pos), torch.from_numpy(neg), "BCE", L, drop=dict(p=p, seed=seed2))
+    ref.backward()
+    np.testing.assert_allclose(loss, ref.item(), rtol=2e-5)
+    Gv = m.arena.views(m.arena.grad)
+    for k, q in P.items():
+        r = q.grad if q.grad is not None else torch.zeros_like(q)
+        err = (Gv[k].cpu() - r).abs().max().item()
+        assert err <= 1e-4 * r.abs().max().item() + 1e-7, (k, err, r.abs().max().item())
+
+
+def _yelp_graph(seed=0):
+    """Yelp2018_10100_LOU shape (benchmark/Yelp2018_10100_LOU/meta.json): lognormal user degrees (mean ~25), Zipf item popularity."""
+    rng = np.random.default_rng(seed)
+    U, N, E = 77277, 45638, 1949342
+    deg = np.maximum(rng.lognormal(2.8, 0.9, U), 1.0)
+    deg = np.maximum((deg * (E / deg.sum())).astype(np.int64), 1)
+    users = np.repeat(np.arange(U), deg)
+    w = 1.0 / np.arange(1, N + 1) ** 0.8
+    items = rng.choice(N, len(users), p=w / w.sum())
+    key = np.unique(users.astype(np.int64) * N + items)
+    return U, N, key // N, key % N
+
+
+def test_c3_lightgcn_yelp_shape_spmm_and_step_match_oracle():
+    _need_gpu()
+    from oracle import lightgcn as olg
+    from recboard_amd import ops
+    from recboard_amd.gen import LightGCNEngine
+    U, N, eu, ei = _yelp_graph()
+    crow, col, val = olg.sym_normalized_adj(U, N, eu, ei)
+    assert len(col) > 3_000_000 and len(crow) == U + N + 1
+    m = LightGCNEngine(U, N, crow, col, val, 64, 3, lr=0.0, weight_decay=1e-3, seed=1)
+    with torch.no_grad():                                    # the reference's 1e-4 init makes every product ~1e-8: use unit-scale rows
+        g = torch.Generator().manual_seed(5)
+        for q in m.params.values():
+            q.copy_((0.1 * torch.randn(q.shape, generator=g)).cuda())
+    Uw, Iw = (m.params[k].cpu() for k in ("User.embeddings.weight", "Item.embeddings.weight"))
+    # one SpMM at full size: every row against the oracle's torch CSR product
+    X = torch.cat([Uw, Iw], 0)
+    cr, co, va = (torch.from_numpy(a).cuda() for a in (crow, col, val))
+    Y = ops.spmm_csr(cr, co, va, ops.spmm_plan(cr, 64), X.cuda(), torch.empty(U + N, 64, device="cuda")).cpu()
+    Yr = olg.spmm_csr(crow, col, val, X)
+    assert (Y - Yr).abs().max() <= 2e-5 * Yr.abs().max()
+    # one training step: loss (rec + wd * emb) and the table gradients
+    rng = np.random.default_rng(2)
+    users = torch.from_numpy(rng.integers(0, U, 2048)); pos = torch.from_numpy(rng.integers(0, N, 2048)); neg = torch.from_numpy(rng.integers(0, N, 2048))
+    loss = m.train_step(users.cuda(), pos.cuda(), neg.cuda()).item()
+    Ur, Ir = Uw.clone().requires_grad_(True), Iw.clone().requires_grad_(True)
+    rec, emb = olg.fit(Ur, Ir, crow, col, val, users, pos, neg, 3)
+    (rec + 1e-3 * emb).backward()
+    np.testing.assert_allclose(loss, (rec + 1e-3 * emb).item(), rtol=2e-5)
+    Gv = m.arena.views(m.arena.grad)
+    for k, r in (("User.embeddings.weight", Ur.grad), ("Item.embeddings.weight", Ir.grad)):
+        assert (Gv[k].cpu() - r).abs().max() <= 1e-4 * r.abs().max() + 1e-9, k
+
+
+def test_c4_deepfm_games_context_schema_matches_oracle():
+    _need_gpu()
+    from oracle import deepfm as odfm
+    from recboard_amd.deepfm import DeepFMEngine
+    counts = [94762, 25612, 7, 24, 12, 5, 50, 500, 5000, 50000]          # SURVEY.md §8d C4 (Games users / items + 8 context fields)
+    B, D = 4096, 10
+    m = DeepFMEngine(counts, D, (400, 400, 400), batch_norm=True, hidden_dropout_rate=0.0, lr=1e-3, seed=1).train()
+    with torch.no_grad():                                    # unit-scale tables (the 1e-4 init leaves the FM term at ~1e-7)
+        g = torch.Generator().manual_seed(9)
+        m.T.copy_((0.1 * torch.randn(m.T.shape, generator=g)).cuda())
+        m.TL.copy_((0.1 * torch.randn(m.TL.shape, generator=g)).cuda())
+    rng = np.random.default_rng(4)
+    x = np.stack([rng.integers(0, c, B) for c in counts], 1)
+    x[:, 1] = np.minimum(rng.zipf(1.3, B), counts[1]) - 1                # popular items: heavy duplicate rows in the scatter-add
+    y = (rng.random(B) < 0.3).astype(np.float32).reshape(B, 1)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    tabs = [t.detach().cpu().clone().requires_grad_(True) for t in m.tables()]
+    tls = [t.detach().cpu().clone().requires_grad_(True) for t in m.tables_lr()]
+    bias = m.bias.detach().cpu().clone().requires_grad_(True)
+    mlp = []
+    for i in range(m.nl):
+        blk = {"linear.weight": m.P[f"dnn.{i}.linear.weight"], "linear.bias": m.P[f"dnn.{i}.linear.bias"],
+               "bn.weight": m.P[f"dnn.{i}.bn.weight"], "bn.bias": m.P[f"dnn.{i}.bn.bias"]}
+        mlp.append({k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.items()})
+    mlp.append({"weight": m.P[f"dnn.{m.nl}.weight"].detach().cpu().clone().requires_grad_(True),
+                "bias": m.P[f"dnn.{m.nl}.bias"].detach().cpu().clone().requires_grad_(True)})
+    ref_logits = odfm.encode(tabs, tls, bias, mlp, xt, True)
+    ref = odfm.criterions.bce_with_logits(ref_logits, yt)
+    ref.backward()
+    logits, _ = m.encode(xt.cuda())
+    assert (logits.cpu() - ref_logits.detach().reshape(-1)).abs().max() <= 1e-4 * ref_logits.abs().max()
+    loss = m.forward_backward(xt.cuda(), yt.cuda()).item()
+    np.testing.assert_allclose(loss, ref.item(), rtol=1e-5)
+    for f, (o, c) in enumerate(zip(m.offsets.tolist(), m.counts)):
+        for got, r in ((m.gT[o:o + c], tabs[f].grad), (m.gTL[o:o + c], tls[f].grad)):
+            assert (got.cpu() - r).abs().max() <= 2e-4 * r.abs().max() + 1e-9, f
+    for i in range(m.nl):
+        for k in ("linear.weight", "bn.weight", "bn.bias"):
+            r = mlp[i][k].grad
+            assert (m.G[f"dnn.{i}.{k}"].cpu() - r).abs().max() <= 2e-4 * r.abs().max() + 1e-8, (i, k)
+    r = mlp[-1]["weight"].grad
+    assert (m.G[f"dnn.{m.nl}.weight"].cpu() - r).abs().max() <= 2e-4 * r.abs().max() + 1e-8

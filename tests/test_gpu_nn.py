@@ -134,3 +134,66 @@ def test_mf_bpr_trains_like_the_aten_model(rnn):
         assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert close(pb, pa)
+
+
+def test_registered_custom_ops_match_aten_and_pass_opcheck(rnn):
+    """torch.ops.recengine.* called directly (SURVEY.md §8b torch-op surface): values and gradients against the aten ops the reference
+    dispatches to, and torch.library.opcheck (schema, fake implementation, autograd registration) on each differentiable op."""
+    R = torch.ops.recengine
+    g = torch.Generator(device="cuda").manual_seed(11)
+    W = torch.randn(300, 64, device="cuda", generator=g, requires_grad=True)
+    idx = torch.randint(0, 300, (40, 7), device="cuda", generator=g)
+    y = R.gather_rows(W, idx)
+    assert torch.equal(y, W[idx])
+    w = torch.randn_like(y)
+    (gW,) = torch.autograd.grad((y * w).sum(), W)
+    (rW,) = torch.autograd.grad((W[idx] * w).sum(), W)
+    assert close(gW, rW, 1e-5)
+    # scatter_add_rows is differentiable too (its gradient is a gather)
+    gsrc = torch.randn(280, 64, device="cuda", generator=g, requires_grad=True)
+    didx = torch.randint(0, 300, (280,), device="cuda", generator=g)
+    dW = R.scatter_add_rows(gsrc, didx, 300, -1)
+    ref = torch.zeros(300, 64, device="cuda").index_add_(0, didx, gsrc.detach())
+    assert close(dW, ref, 1e-5)
+    (gg,) = torch.autograd.grad((dW * W.detach()).sum(), gsrc)
+    assert close(gg, W.detach()[didx], 1e-6)
+    Q = torch.randn(33, 64, device="cuda", generator=g, requires_grad=True)
+    E = torch.randn(500, 64, device="cuda", generator=g, requires_grad=True)
+    S = R.score_dense(Q, E)
+    assert close(S, Q @ E.T, 1e-5)
+    gq, ge = torch.autograd.grad(S.logsumexp(1).sum(), (Q, E))
+    rq, re_ = torch.autograd.grad((Q @ E.T).logsumexp(1).sum(), (Q, E))
+    assert close(gq, rq) and close(ge, re_)
+    sp = torch.arange(0, 34, device="cuda") * 2
+    si = torch.sort(torch.randint(0, 500, (33, 2), device="cuda", generator=g), 1).values.reshape(-1)
+    v, i = R.score_topk(Q.detach(), E.detach(), sp, si, 20)
+    sc = (Q @ E.T).detach()
+    sc[torch.arange(33, device="cuda").repeat_interleave(2), si] = -1e23
+    rv, ri = torch.topk(sc, 20, dim=1)
+    assert close(v, rv, 1e-5) and float((i == ri).float().mean()) > 0.99
+    users, pos, neg = (torch.randint(0, 300, (64,), device="cuda", generator=g) for _ in range(3))
+    for op, args in ((R.gather_rows, (W, idx)), (R.score_dense, (Q, E)), (R.bpr_triplet, (W, W.detach().clone().requires_grad_(), users, pos, neg))):
+        torch.library.opcheck(op, args, test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+
+
+def test_two_streams_call_the_library_concurrently(rnn):
+    """The C ABI is re-entrant (no global mutable state): the same entry points enqueued on two streams at once give the results of
+    serial calls."""
+    from recboard_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Q = [torch.randn(2048, 64, device="cuda", generator=g) for _ in range(2)]
+    E = [torch.randn(9000 + 500 * k, 64, device="cuda", generator=g) for k in range(2)]
+    W = torch.randn(50000, 64, device="cuda", generator=g)
+    idx = [torch.randint(0, 50000, (200000,), device="cuda", generator=g) for _ in range(2)]
+    serial = [(ops.score_topk(Q[k], E[k], None, None, 50), ops.gather_rows(W, idx[k])) for k in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    out = [None, None]
+    for rep in range(3):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                out[k] = (ops.score_topk(Q[k], E[k], None, None, 50), ops.gather_rows(W, idx[k]))
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(out[k][0][1], serial[k][0][1]) and torch.equal(out[k][0][0], serial[k][0][0])
+            assert torch.equal(out[k][1], serial[k][1])

@@ -15,7 +15,12 @@ pytestmark = pytest.mark.gpu
 def env():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    import os
     from recboard_amd import lib, ops
+    # the A/B switches exist only in the diagnostic twin of the library (make dbg: -DRE_DEBUG); the product .so has none.
+    # The same kernels, the same entry points: this module runs `ops` on the twin and puts the product library back afterwards.
+    prod_path, prod_lib = lib.LIB_PATH, lib._LIB
+    lib.LIB_PATH, lib._LIB = os.path.join(os.path.dirname(lib.LIB_PATH), "librecengine_dbg.so"), None
     L = lib.load()
     L.re_dbg_score_x2.argtypes = [ctypes.c_int]; L.re_dbg_score_x2.restype = None
     L.re_dbg_score_x2_maxerr.argtypes = [ctypes.c_int]; L.re_dbg_score_x2_maxerr.restype = None
@@ -23,6 +28,7 @@ def env():
     L.re_dbg_score_sample.argtypes = [ctypes.c_int]; L.re_dbg_score_sample.restype = None
     yield ops, L
     L.re_dbg_score_x2(1); L.re_dbg_score_x2_maxerr(0); L.re_dbg_score_sample(1)
+    lib.LIB_PATH, lib._LIB = prod_path, prod_lib
 
 
 def stats(L):

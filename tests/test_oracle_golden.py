@@ -235,3 +235,32 @@ def test_sparse_adam_oracle_matches_torch_sparse_adam():
         opt.step()
         oadam.sparse_adam_rows(W, m, v, idx, coef, step, 1e-2)
         np.testing.assert_allclose(W, emb.weight.detach().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_published_benchmark_rows_satisfy_the_metric_restatements_identities():
+    """The only fixtures the reference holds for freerec's metric definitions are its published result rows
+    (benchmark/*/{MF-BPR,LightGCN,SASRec}.json -> tests/golden/benchmark_rows.json, made by make_benchmark_fixture.py).  With ONE
+    held-out target per user (leave-one-out) the restated definitions (oracle/ranking.py) imply, for user MEANS too:
+    NDCG@K <= HR@K, NDCG@K >= HR@K / log2(K + 1), both non-decreasing in K, NDCG@5 >= HR@1 (a rank-0 hit counts 1 in both);
+    an untrained BPR / BCE loss is ln 2 / 2 ln 2, a trained one is below it.  Every published row must satisfy them -- and the
+    oracle's metrics on synthetic scores satisfy the same identities (test_metric_known_answers), which is what pins the two together."""
+    import json
+    rows = json.load(open(os.path.join(G, "benchmark_rows.json")))
+    assert len(rows) >= 18 and sum(len(v) for v in rows.values()) >= 90
+    ks = (5, 10, 20, 50)
+    for name, runs in rows.items():
+        for run in runs:
+            for split in ("valid", "test", "best"):
+                m = run[split]
+                hr = {k: m[f"HITRATE@{k}"] for k in (1,) + ks}
+                nd = {k: m[f"NDCG@{k}"] for k in ks}
+                for k in ks:
+                    assert nd[k] <= hr[k] + 1e-12, (name, split, k)
+                    assert nd[k] >= hr[k] / np.log2(k + 1) - 1e-12, (name, split, k)
+                    assert nd[k] >= hr[1] - 1e-12, (name, split, k)
+                seq_k = (1,) + ks
+                assert all(hr[a] <= hr[b] + 1e-12 for a, b in zip(seq_k, seq_k[1:])), (name, split)
+                assert all(nd[a] <= nd[b] + 1e-12 for a, b in zip(ks, ks[1:])), (name, split)
+            loss = run["train"]["LOSS"]
+            bound = 2 * np.log(2) if name.endswith("SASRec") else np.log(2)     # BCE(pos) + BCE(neg)  /  BPR
+            assert 0.0 < loss < bound, (name, loss)
