@@ -206,7 +206,7 @@ int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* 
                          double beta1, double beta2, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
- * K6/K7  fused SASRec encoder (D = 64, S <= 64, L <= 4, 1 head): one workgroup per work item of the plan, activations in LDS.
+ * K6/K7  fused SASRec encoder (D = 64 or 128, S <= 64, L <= 4, 1 head): one workgroup per work item of the plan, activations in LDS.
  * Replaces the per-block aten chain of SASRec/main.py:163-176 (after_one_block), :31-50 (PointWiseFeedForward),
  * :188-191 (block loop + lastLN): LN -> q/k/v -> causal softmax (pads attended as keys, K/V not layer-normed)
  * -> out_proj + residual -> LN -> Conv1d(k=1) FFN + residual -> pad mask; all five dropout sites in-kernel
@@ -220,8 +220,10 @@ int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* 
  *   plan: from re_sasrec_batch_prep for THIS seq.  ncu: the launch grid (compute units to fill; <= 1024).
  *   tape: NULL for inference; otherwise re_sasrec_tape_bytes() bytes that receive the activations the backward
  *   needs (x, LN_a(x), q, k, v, P, o, x1, LN_f(x1), relu(h), LN statistics), indexed by the plan's compact rows.
- *   In training mode rows of u / dx0 at the pad positions in front of a sequence are not written (nothing on the path reads
- *   them); inference fills them with lastLN.bias (= what the reference's encode returns there).
+ *   fill_pads != 0: the rows of u at the pad positions in front of a sequence are set to lastLN.bias (= what the reference's
+ *   encode returns there; inference).  Otherwise they are not written (training: nothing on the path reads them), nor are those of dx0.
+ *   D = 128: a work item holds 32 rows in LDS; a longer sequence is taken in chained parts that hand their k, v over through the
+ *   tape -- which therefore must be given (also for inference) when S > 32.
  * re_sasrec_encoder_bwd: given dU [B,S,D] (gradient w.r.t. u) and the tape of the SAME (drop_p, seed, plan) forward, ONE launch
  *   for all blocks writes dx0 [B,S,D] and six dY operands per block; the weight gradients dW = dY^T X are then split-K products
  *   over all compact rows (second launch) and a fixed-order reduction (third launch) that OVERWRITES the parameter gradients:
@@ -233,7 +235,7 @@ size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_fwd(const float* x0, const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, int64_t B,
                           int64_t S, int64_t D, int64_t L, const float* const* block_params, const float* last_w,
                           const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev, const void* plan, int32_t ncu,
-                          float* u, void* tape, size_t tape_bytes, re_stream_t stream);
+                          float* u, void* tape, size_t tape_bytes, int32_t fill_pads, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,

@@ -90,6 +90,10 @@ __device__ __forceinline__ void stats_fetch(float2& r, const float* st, int nrow
     if (tid < nrows) { r.x = sp[2 * tid]; r.y = sp[2 * tid + 1]; }
 }
 
+// (see enc_fwd.hip: D = 64 keeps three fragment sets in flight, D = 128 loads a fragment where it is used)
+#define WREQ(reg, ptr) do { if (D == 64) wfrag_n<D>(reg, ptr, strip, lane); } while (0)
+#define WUSE(reg, ptr) do { if (D != 64) wfrag_n<D>(reg, ptr, strip, lane); } while (0)
+
 #ifdef ENC_PROFILE
 __device__ unsigned long long g_bwd_marks[ENC_MARKS];
 extern "C" int re_dbg_enc_marks_bwd(unsigned long long* out) {
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                                                  float* __restrict__ dOut, float* __restrict__ gtape, float* __restrict__ slab,
                                                  const uint32_t* __restrict__ seed_dev, int fuse_embed, float emb_scale) {
     using C = EC<D>;
-    constexpr int KPT = C::ROWS / C::TPR;
+    constexpr int KPT = C::KPT;
     if (seed_dev) seed ^= seed_dev[0];   // per-step seed kept in device memory (hipGraph replays)
     extern __shared__ __align__(16) float lds[];
     float* b0 = lds;
@@ -114,6 +118,8 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
     float* b4 = b3 + C::BUF;
     float* sP = b4 + C::BUF;
     float* sD = sP + C::PBUF;
+    float* bK0 = sD + C::PBUF;                 // prefix k / v tiles of a chained part (allocated only where parts can chain: MAXT < 4)
+    float* bV0 = bK0 + C::BUF;
     __shared__ float s_mean[C::ROWS], s_rstd[C::ROWS];
     __shared__ float s_ppad[C::ROWS], s_w[C::ROWS], s_cpad[C::ROWS];   // virtual pad key: prob of one copy, total kept weight, dS
     __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS];
@@ -135,7 +141,18 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
         const int c = lane & 15, col = 16 * strip + c;
         const int r_e = tid / C::TPR, c0_e = (tid % C::TPR) * C::CPT, j0_e = (tid % C::TPR) * KPT;
         const bool row_lead = (tid % C::TPR) == 0;
-        const EncItem it = enc_item(PL, wi);
+        const EncItem whole = enc_item(PL, wi);
+        // chained parts of a sequence with more rows than the LDS holds (D = 128; enc_fwd.hip), LAST part first: the later rows'
+        // queries also attend to the earlier rows (prefix key tiles k, v from the tape), and what they contribute to those rows' dK,
+        // dV is left on the gradient tape for the earlier part to add.
+        const int nsub = C::MAXT < 4 ? (whole.nt + C::MAXT - 1) / C::MAXT : 1;
+        for (int hs = nsub - 1; hs >= 0; --hs) {
+        const EncItem it = EncItem{whole.tile0 + hs * C::MAXT, whole.nt - hs * C::MAXT < C::MAXT ? whole.nt - hs * C::MAXT : C::MAXT, whole.kind};
+        const int npre = C::MAXT < 4 ? hs * C::MAXT : 0;     // prefix key tiles
+        const bool has_succ = C::MAXT < 4 && hs + 1 < nsub;  // a later part left partial dK / dV for these rows
+        const int64_t prow0 = (int64_t)whole.tile0 * 16;     // compact row of the sequence's first row
+        if (hs + 1 < nsub) __syncthreads();                  // (a full barrier: the later part's gradient-tape stores have completed)
+        const bool first_part = k == 0 && hs == nsub - 1;    // the workgroup's first flush of its vector-gradient slab
         const int nt = it.nt, nrows = 16 * nt;
         const int64_t row0 = (int64_t)it.tile0 * 16;
         int mk = 0; (void)mk;
@@ -144,9 +161,9 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
         float wa[D / 4], wb[D / 4], wc[D / 4];
         par_fetch<D>(PR, P.blk[L - 1], tid);
         const float lastv = tid < D ? P.last_w[tid] : 0.f;
-        wfrag_n<D>(wa, P.blk[L - 1].w2, strip, lane);
-        wfrag_n<D>(wb, P.blk[L - 1].w1, strip, lane);
-        wfrag_n<D>(wc, P.blk[L - 1].out_w, strip, lane);
+        WREQ(wa, P.blk[L - 1].w2);
+        WREQ(wb, P.blk[L - 1].w1);
+        WREQ(wc, P.blk[L - 1].out_w);
         enc_sync();
         ENC_MARK(g_bwd_marks, mk); ++mk;
         enc_decode<D>(PL, it, seq, tid, s_gid, s_first, s_pad);
@@ -212,10 +229,11 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
             // ---- A. FFN second map: db2; dH = (dO2 W2) * (hr > 0) * scale        (wa = W2)
+            WUSE(wa, W.w2);
             gemm_rows<D>(b2, wa, lane, wr, nt, [&](int row, float v) {
                 b3[row * C::LS + col] = (b1[row * C::LS + col] > 0.f) ? v * drop_scale : 0.f;
             });
-            wfrag_n<D>(wa, W.in_w, strip, lane);                  // Wq
+            WREQ(wa, W.in_w);                  // Wq
             accV[5] = colsum<D>(b2, tid, nrows);
             tile_store<D>(b2, gp + 0 * NR * D, nrows, tid);
             enc_sync();
@@ -223,8 +241,9 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             // ---- B. FFN first map: db1; dY = dH W1 + dX'        (wb = W1)
             tile_commit<D>(b1, T0, nrows, tid);   // X1  (HR's last readers are behind the barrier above)
             if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
+            WUSE(wb, W.w1);
             gemm_rows<D>(b3, wb, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
-            wfrag_n<D>(wb, W.in_w + D * D, strip, lane);          // Wk
+            WREQ(wb, W.in_w + D * D);          // Wk
             tile_fetch<D>(T0, tp + T.off_V + row0 * D, nrows, tid);
             stats_fetch(ST, tp + T.off_PP + row0 * 2, nrows, tid);
             float pq[KPT];   // this thread's slice of the saved probabilities
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
 #pragma unroll
                 for (int q = 0; q < KPT; ++q) pq[q] = 0.f;
                 if (r_e < nrows) {
-                    const float* src = tp + T.off_P + (row0 + r_e) * C::ROWS + j0_e;
+                    const float* src = tp + T.off_P + (row0 + r_e) * EP_PW + j0_e;
                     if (KPT % 4 == 0) {
 #pragma unroll
                         for (int q = 0; q < KPT / 4; ++q) ld4(&pq[4 * q], src + 4 * q);
@@ -255,10 +274,18 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
             // ---- D. out_proj: dbo; dO = dX1 Wo        (wc = Wo)
+            WUSE(wc, W.out_w);
             gemm_rows<D>(b0, wc, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
-            wfrag_n<D>(wc, W.in_w + 2 * D * D, strip, lane);      // Wv
+            WREQ(wc, W.in_w + 2 * D * D);      // Wv
             // ---- E. attention: V, P; Pd = P * mask
             tile_commit<D>(b1, T0, nrows, tid);   // V  (X1's last readers, phase C, are behind the barrier above)
+            if (C::MAXT < 4 && npre) {            // the prefix rows' k, v of this block (tape; written by the forward)
+                TileRegs<D> TP;
+                tile_fetch<D>(TP, tp + T.off_V + prow0 * D, 16 * npre, tid);
+                tile_commit<D>(bV0, TP, 16 * npre, tid);
+                tile_fetch<D>(TP, tp + T.off_K + prow0 * D, 16 * npre, tid);
+                tile_commit<D>(bK0, TP, 16 * npre, tid);
+            }
             if (tid < C::ROWS) { s_ppad[tid] = ST.x; s_w[tid] = ST.y; }
             tile_fetch<D>(T0, tp + T.off_K + row0 * D, nrows, tid);
             tile_fetch<D>(T1, tp + T.off_Q + row0 * D, nrows, tid);
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                     const float p = pq[jj];          // 0 outside the causal / same-sequence window (the forward stored zeros there)
                     float m = 1.0f;
                     if (thresh && p != 0.f) {
-                        const int sj = s_gid[j] - sbase;
+                        const int sj = it.kind ? s_first[i] + j : s_gid[j & (C::ROWS - 1)] - sbase;   // (one long sequence: consecutive positions)
                         m = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? drop_scale : 0.f;
                     }
                     sP[i * C::PLS + j] = p;
@@ -284,7 +311,9 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
             // dV = Pd^T dO; d b_v through the virtual pad key: sum_i w_i dO_i
-            gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b2[row * C::LS + col] = v; });
+            gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b2[row * C::LS + col] = v; }, npre);
+            if (C::MAXT < 4 && npre)              // what these rows' queries add to the PREFIX rows' dV (-> b4, free until phase F)
+                gemm_ttx_pre<D>(sD, b3, lane, wr, strip, it, npre, [&](int row, float v) { b4[row * C::LS + col] = v; });
             accV[2] = colsum_w<D>(b3, s_w, tid, nrows);
             enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
@@ -293,10 +322,13 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                 const float p = sP[row * C::PLS + key];
                 const float pd = sD[row * C::PLS + key];
                 sD[row * C::PLS + key] = (p != 0.f) ? v * (pd / p) : 0.f;
-            });
+            }, bV0, npre);
+            float* gpre = gtape + (int64_t)l * EG_NMAT * NR * D + prow0 * D;   // the prefix rows of the gradient tape
+            if (C::MAXT < 4 && npre) tile_store<D>(b4, gpre + 5 * NR * D, 16 * npre, tid);          // partial dV of the prefix rows
+            if (has_succ) tile_add_global<D>(b2, gp + 5 * NR * D, nrows, tid);                      // + what the later part left for these rows
+            enc_sync();
             accV[2] += colsum<D>(b2, tid, nrows);
             tile_store<D>(b2, gp + 5 * NR * D, nrows, tid);
-            enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
             // dS = P (dP - rowsum(dP P)) / sqrt(D), the virtual pad key included in the row sum
             if (r_e < nrows) {
@@ -334,23 +366,33 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             ENC_MARK(g_bwd_marks, mk); ++mk;
             {
                 const float bkc = par[3 * D + col];
-                gemm_tx<D>(sD, b1, lane, wr, strip, it, [&](int row, float v) { b4[row * C::LS + col] = fmaf(s_cpad[row], bkc, v); });
+                gemm_tx<D>(sD, b1, lane, wr, strip, it, [&](int row, float v) { b4[row * C::LS + col] = fmaf(s_cpad[row], bkc, v); }, bK0, npre);
             }
             accV[1] = colsum_w<D>(b3, s_cpad, tid, nrows);   // d b_k through the virtual pad key: sum_i dS_pad_i q_i
             enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
-            gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b1[row * C::LS + col] = v; });
+            gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b1[row * C::LS + col] = v; }, npre);
+            if (C::MAXT < 4 && npre)              // ... and to the prefix rows' dK (-> bV0: the prefix v is no longer needed)
+                gemm_ttx_pre<D>(sD, b3, lane, wr, strip, it, npre, [&](int row, float v) { bV0[row * C::LS + col] = v; });
             accV[0] = colsum<D>(b4, tid, nrows);
             tile_store<D>(b4, gp + 3 * NR * D, nrows, tid);
             enc_sync();
+            if (C::MAXT < 4 && npre) tile_store<D>(bV0, gpre + 4 * NR * D, 16 * npre, tid);         // partial dK of the prefix rows
+            if (has_succ) {
+                tile_add_global<D>(b1, gp + 4 * NR * D, nrows, tid);
+                enc_sync();
+            }
             ENC_MARK(g_bwd_marks, mk); ++mk;
             // ---- G. projections: dbq/dbk; dA1 = dQ Wq -> b3; dX (b0) += dK Wk + dV Wv        (wa, wb, wc = Wq, Wk, Wv)
+            WUSE(wa, W.in_w);
             gemm_rows<D>(b4, wa, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
-            if (more) wfrag_n<D>(wa, Wn.w2, strip, lane);
+            if (more) WREQ(wa, Wn.w2);
+            WUSE(wb, W.in_w + D * D);
             gemm_rows<D>(b1, wb, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
-            if (more) wfrag_n<D>(wb, Wn.w1, strip, lane);
+            if (more) WREQ(wb, Wn.w1);
+            WUSE(wc, W.in_w + 2 * D * D);
             gemm_rows<D>(b2, wc, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
-            if (more) wfrag_n<D>(wc, Wn.out_w, strip, lane);
+            if (more) WREQ(wc, Wn.out_w);
             accV[1] += colsum<D>(b1, tid, nrows);
             tile_store<D>(b1, gp + 4 * NR * D, nrows, tid);
             enc_sync();
@@ -379,7 +421,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                     float s = red[v * C::NT + cc];
 #pragma unroll
                     for (int i = 1; i < C::CG; ++i) s += red[v * C::NT + i * D + cc];
-                    sl[e] = (k == 0) ? s : sl[e] + s;
+                    sl[e] = first_part ? s : sl[e] + s;
                 }
                 enc_sync();
                 ENC_MARK(g_bwd_marks, mk); ++mk;
@@ -406,6 +448,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
         } else {
             tile_store_gid<D>(b0, dOut, s_gid, nrows, tid);
         }
+        }   // chained parts
     }
 }
 
@@ -440,7 +483,7 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     if (B == 0) return RE_OK;
     if (!dU || !seq || !tape || !plan || !dx0 || !block_params || !block_grads || !g_last_w || !g_last_b || !last_w || !last_b || !ws || B < 0)
         return RE_EINVAL;
-    if (D != 64 || S < 1 || S > 64 || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
+    if ((D != 64 && D != 128) || S < 1 || S > 64 || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
     if (drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
     if (ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L)) return RE_EWORKSPACE;
     for (int64_t i = 0; i < 12 * L; ++i)
@@ -458,12 +501,21 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     float* ppart = part + enc_wgrad_part_floats(D, L);
     float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
     hipStream_t s = (hipStream_t)stream;
-    using C = EC<64>;
-    const size_t ldsb = (size_t)(5 * C::BUF + 2 * C::PBUF) * sizeof(float);
-    auto kf = enc_bwd_k<64>;
-    if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-    hipLaunchKernelGGL(kf, dim3(grid), dim3(C::NT), ldsb, s, dU, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, (const float*)tape, T, plan, dx0,
-                       gtape, slab, seed_dev, dPtab ? 1 : 0, scale);
+    if (D == 128) {
+        using C = EC<128>;
+        const size_t ldsb = (size_t)(7 * C::BUF + 2 * C::PBUF) * sizeof(float);
+        auto kf = enc_bwd_k<128>;
+        if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(C::NT), ldsb, s, dU, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, (const float*)tape, T, plan, dx0,
+                           gtape, slab, seed_dev, dPtab ? 1 : 0, scale);
+    } else {
+        using C = EC<64>;
+        const size_t ldsb = (size_t)(5 * C::BUF + 2 * C::PBUF) * sizeof(float);
+        auto kf = enc_bwd_k<64>;
+        if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(C::NT), ldsb, s, dU, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, (const float*)tape, T, plan, dx0,
+                           gtape, slab, seed_dev, dPtab ? 1 : 0, scale);
+    }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     (void)NR;
     return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);

@@ -36,7 +36,8 @@ struct EC {
     static constexpr int TPR = NT / ROWS;             // row-wise phases: threads per row (8 / 16) ...
     static constexpr int CPT = D / TPR;               // ... columns per thread (8)
     static constexpr int LS = D + 4;                  // LDS row stride (floats): conflict-free 16-byte row reads
-    static constexpr int PLS = ROWS + 4;              // row stride of the [ROWS][ROWS] probability tiles
+    static constexpr int PLS = 64 + 4;                // row stride of the [ROWS][64] probability tiles (a sequence has at most 64 keys)
+    static constexpr int KPT = 64 / TPR;              // softmax phases: keys per thread
     static constexpr int BUF = ROWS * LS;
     static constexpr int PBUF = ROWS * PLS;
     static constexpr int KS = D / 4;                  // MFMA steps of a contraction over D
@@ -63,6 +64,7 @@ struct SasrecParams {
 //   then int2 rowmap[MT * 16]: { gid = b * S + s or -1 (dummy row), first = pads in front of the row's sequence }
 //   then scratch of the plan kernel.   MT = B * ceil(S / 16) bounds the number of tiles.
 #define EP_HDR 8
+#define EP_PW 64   // row width of the saved probabilities: a sequence has at most 64 keys
 struct EncPlan {
     const int* hdr;
     const int* items;
@@ -89,7 +91,7 @@ struct EncTape {
 };
 __host__ __device__ inline EncTape enc_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L) {
     EncTape t;
-    const int64_t nr = 16 * enc_plan_max_tiles(B, S), act = nr * D, rows = (D == 64 ? 64 : 32);
+    const int64_t nr = 16 * enc_plan_max_tiles(B, S), act = nr * D, rows = EP_PW;
     int64_t o = 0;
     t.off_X = o; o += act;
     t.off_A = o; o += act;
@@ -286,20 +288,24 @@ __device__ __forceinline__ void wfrag_n(float (&bf)[D / 4], const float* W, int 
 }
 
 // Score-type product over the item's (row tile, key tile) pairs: T[i][j] = sum_d A[i][d] B[j][d] for i in tile tt, j in tile kt,
-// both operands LDS tiles [ROWS][LS] with d contiguous.  Pairs are dealt round-robin over the 8 waves.  epi(row, key, value).
+// both operands LDS tiles [.][LS] with d contiguous.  Pairs are dealt round-robin over the 8 waves.  epi(row, key column, value).
+// A CHAINED item (the later rows of a sequence longer than the LDS holds, enc_fwd.hip) has `npre` prefix key tiles in Bpre: key
+// columns [0, 16 npre) are the prefix rows, its own keys follow.
 template <int D, class Epi>
-__device__ __forceinline__ void gemm_pairs(const float* A, const float* B, int lane, int wave, const EncItem& it, Epi epi) {
+__device__ __forceinline__ void gemm_pairs(const float* A, const float* B, int lane, int wave, const EncItem& it, Epi epi,
+                                           const float* Bpre = nullptr, int npre = 0) {
     using C = EC<D>;
     const int g = lane >> 4, c = lane & 15;
     int p = 0;
     for (int tt = 0; tt < it.nt; ++tt)
-        for (int kt = enc_kt_lo(it, tt); kt <= tt; ++kt, ++p) {
+        for (int kk = (npre ? 0 : enc_kt_lo(it, tt)); kk <= npre + tt; ++kk, ++p) {
             if ((p & (C::NW - 1)) != wave) continue;
+            const float* Bt = kk < npre ? Bpre + 16 * kk * C::LS : B + 16 * (kk - npre) * C::LS;
             float af[D / 4], bf[D / 4];
 #pragma unroll
             for (int q = 0; q < D / 16; ++q) {
                 ld4(&af[4 * q], A + (16 * tt + c) * C::LS + 16 * q + 4 * g);
-                ld4(&bf[4 * q], B + (16 * kt + c) * C::LS + 16 * q + 4 * g);
+                ld4(&bf[4 * q], Bt + c * C::LS + 16 * q + 4 * g);
             }
             f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
             __builtin_amdgcn_sched_barrier(0);
@@ -309,15 +315,16 @@ __device__ __forceinline__ void gemm_pairs(const float* A, const float* B, int l
                 a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s + 1], bf[s + 1], a1, 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) epi(16 * tt + 4 * g + j, 16 * kt + c, a0[j] + a1[j]);
+            for (int j = 0; j < 4; ++j) epi(16 * tt + 4 * g + j, 16 * kk + c, a0[j] + a1[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
 }
 
 // O[i][16 strip + c] = sum_j T[i][j] X[j][16 strip + c] over the key tiles of row tile tt (T: [ROWS][PLS] probabilities-type tile,
-// X: [ROWS][LS]) for the wave's row tiles.  epi(row, value).
+// X: [ROWS][LS]) for the wave's row tiles; with prefix tiles (Xpre, npre) the key columns [0, 16 npre) multiply Xpre.  epi(row, value).
 template <int D, class Epi>
-__device__ __forceinline__ void gemm_tx(const float* T, const float* X, int lane, int wr, int strip, const EncItem& it, Epi epi) {
+__device__ __forceinline__ void gemm_tx(const float* T, const float* X, int lane, int wr, int strip, const EncItem& it, Epi epi,
+                                        const float* Xpre = nullptr, int npre = 0) {
     using C = EC<D>;
     const int g = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -325,11 +332,12 @@ __device__ __forceinline__ void gemm_tx(const float* T, const float* X, int lane
         const int tt = t * C::WR + wr;
         if (tt >= it.nt) continue;
         f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-        for (int q = enc_kt_lo(it, tt); q <= tt; ++q) {
+        for (int q = (npre ? 0 : enc_kt_lo(it, tt)); q <= npre + tt; ++q) {
+            const float* Xt = q < npre ? Xpre + 16 * q * C::LS : X + 16 * (q - npre) * C::LS;
             float af[4], bf[4];
             ld4(af, T + (16 * tt + c) * C::PLS + 16 * q + 4 * g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bf[i] = X[(16 * q + 4 * g + i) * C::LS + 16 * strip + c];
+            for (int i = 0; i < 4; ++i) bf[i] = Xt[(4 * g + i) * C::LS + 16 * strip + c];
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], a1, 0, 0, 0);
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], a0, 0, 0, 0);
@@ -342,9 +350,9 @@ __device__ __forceinline__ void gemm_tx(const float* T, const float* X, int lane
 }
 
 // O[j][16 strip + c] = sum_i T[i][j] X[i][16 strip + c] for key tile kt = the wave's tiles, i over the row tiles that attend to kt
-// (kt itself, or kt .. nt-1 for a long sequence).  epi(row j, value).
+// (kt itself, or kt .. nt-1 for a long sequence); the item's own keys sit at key columns 16 npre + ...  epi(row j, value).
 template <int D, class Epi>
-__device__ __forceinline__ void gemm_ttx(const float* T, const float* X, int lane, int wr, int strip, const EncItem& it, Epi epi) {
+__device__ __forceinline__ void gemm_ttx(const float* T, const float* X, int lane, int wr, int strip, const EncItem& it, Epi epi, int npre = 0) {
     using C = EC<D>;
     const int g = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -357,7 +365,7 @@ __device__ __forceinline__ void gemm_ttx(const float* T, const float* X, int lan
             float af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = T[(16 * q + 4 * g + i) * C::PLS + 16 * kt + c];
+                af[i] = T[(16 * q + 4 * g + i) * C::PLS + 16 * (npre + kt) + c];
                 bf[i] = X[(16 * q + 4 * g + i) * C::LS + 16 * strip + c];
             }
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], a0, 0, 0, 0);
@@ -367,6 +375,34 @@ __device__ __forceinline__ void gemm_ttx(const float* T, const float* X, int lan
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) epi(16 * kt + 4 * g + j, a0[j] + a1[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+// The same contraction for the PREFIX key tiles of a chained item: O[j][.] for j in prefix tile pt = the wave's tiles < npre,
+// i over ALL the item's row tiles (every row of the item comes after the prefix).  epi(prefix row j, value).
+template <int D, class Epi>
+__device__ __forceinline__ void gemm_ttx_pre(const float* T, const float* X, int lane, int wr, int strip, const EncItem& it, int npre, Epi epi) {
+    using C = EC<D>;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < C::RT; ++t) {
+        const int pt = t * C::WR + wr;
+        if (pt >= npre) continue;
+        f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        for (int q = 0; q < it.nt; ++q) {
+            float af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = T[(16 * q + 4 * g + i) * C::PLS + 16 * pt + c];
+                bf[i] = X[(16 * q + 4 * g + i) * C::LS + 16 * strip + c];
+            }
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi(16 * pt + 4 * g + j, a0[j] + a1[j]);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -403,6 +439,18 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
     using C = EC<D>;
     for (int f = tid; f < nrows * (D / 4); f += C::NT)
         reinterpret_cast<float4*>(g)[f] = *reinterpret_cast<const float4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4)));
+}
+// tile[r][:] += g[r][:] for nrows contiguous rows (the partial sums a chained item's later rows left for its earlier rows)
+template <int D>
+__device__ __forceinline__ void tile_add_global(float* tile, const float* g, int nrows, int tid) {
+    using C = EC<D>;
+    gcf_t gp = g_launder(g);
+    for (int f = tid; f < nrows * (D / 4); f += C::NT) {
+        float t[4];
+        ld4g(t, gp + 4 * f);
+        float* d = tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4));
+        d[0] += t[0]; d[1] += t[1]; d[2] += t[2]; d[3] += t[3];
+    }
 }
 // rows of a [B*S][D] matrix selected by s_gid (dummy rows read as zero / are not written)
 template <int D>

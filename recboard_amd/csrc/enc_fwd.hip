@@ -22,6 +22,12 @@ extern "C" int re_dbg_enc_marks_fwd(unsigned long long* out) {
 }
 #endif
 
+// Weight fragments.  D = 64: three register sets, each re-requested as soon as its product is done -- two or more phases before
+// its next use (WREQ; WUSE is empty).  D = 128: a fragment is 32 registers and three sets in flight spill; it is loaded where it
+// is used instead (WUSE; WREQ is empty) -- the product behind it is four times longer, the exposed round trip matters less.
+#define WREQ(reg, ptr) do { if (D == 64) wfrag_t<D>(reg, ptr, strip, lane); } while (0)
+#define WUSE(reg, ptr) do { if (D != 64) wfrag_t<D>(reg, ptr, strip, lane); } while (0)
+
 struct SeEmbed {
     const float *E, *P;   // item table [R, D] (row 0 = padding), position table [S, D]; E == nullptr: x0 is given
     int64_t R;
@@ -34,7 +40,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                                                  float* __restrict__ tape, EncTape T, const void* __restrict__ planp, int fill_pads,
                                                  const uint32_t* __restrict__ seed_dev) {
     using C = EC<D>;
-    constexpr int KPT = C::ROWS / C::TPR;   // keys per thread in the softmax phase
+    constexpr int KPT = C::KPT;             // keys per thread in the softmax phase
     if (seed_dev) seed ^= seed_dev[0];      // per-step seed kept in device memory (hipGraph replays)
     extern __shared__ __align__(16) float lds[];
     float* bX = lds;
@@ -43,6 +49,8 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
     float* bK = bQ + C::BUF;
     float* bV = bK + C::BUF;
     float* sP = bV + C::BUF;
+    float* bK0 = sP + C::PBUF;                 // prefix k / v tiles of a chained part (allocated only where parts can chain: MAXT < 4)
+    float* bV0 = bK0 + C::BUF;
     __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS];
     __shared__ float s_w[C::ROWS];
     __shared__ float s_par[2 * EP_NPAR * D], s_last[2 * D];
@@ -63,7 +71,16 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
         const int r_e = tid / C::TPR, c0_e = (tid % C::TPR) * C::CPT, j0_e = (tid % C::TPR) * KPT;
         const bool row_lead = (tid % C::TPR) == 0;
         (void)g;
-        const EncItem it = enc_item(PL, wi);
+        const EncItem whole = enc_item(PL, wi);
+        // A sequence with more rows than the LDS holds (MAXT tiles; only at D = 128) is taken in CHAINED parts: the first MAXT tiles
+        // as an item of their own, then the later rows with the earlier ones as PREFIX key tiles -- their k, v of every block are on
+        // the tape, written by this same workgroup a moment ago (causality: the earlier rows never depend on the later ones).
+        const int nsub = C::MAXT < 4 ? (whole.nt + C::MAXT - 1) / C::MAXT : 1;   // (D = 64 holds every sequence: no chaining code at all)
+        for (int hs = 0; hs < nsub; ++hs) {
+        const EncItem it = EncItem{whole.tile0 + hs * C::MAXT, whole.nt - hs * C::MAXT < C::MAXT ? whole.nt - hs * C::MAXT : C::MAXT, whole.kind};
+        const int npre = C::MAXT < 4 ? hs * C::MAXT : 0;     // prefix key tiles
+        const int64_t prow0 = (int64_t)whole.tile0 * 16;     // compact row of the sequence's first row
+        if (hs > 0) __syncthreads();                         // (a full barrier: the previous part's tape stores have completed)
         const int nrows = 16 * it.nt;
         const int64_t row0 = (int64_t)it.tile0 * 16;
         int mk = 0; (void)mk;
@@ -72,9 +89,9 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
         float wa[D / 4], wb[D / 4], wc[D / 4];
         par_fetch<D>(PR, P.blk[0], tid);
         const float lastv = tid < 2 * D ? (tid < D ? P.last_w[tid] : P.last_b[tid - D]) : 0.f;
-        wfrag_t<D>(wa, P.blk[0].in_w, strip, lane);
-        wfrag_t<D>(wb, P.blk[0].in_w + D * D, strip, lane);
-        wfrag_t<D>(wc, P.blk[0].in_w + 2 * D * D, strip, lane);
+        WREQ(wa, P.blk[0].in_w);
+        WREQ(wb, P.blk[0].in_w + D * D);
+        WREQ(wc, P.blk[0].in_w + 2 * D * D);
         enc_sync();
         ENC_MARK(g_fwd_marks, mk); ++mk;
         enc_decode<D>(PL, it, seq, tid, s_gid, s_first, s_pad);
@@ -123,6 +140,11 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
             const bool more = l + 1 < L;
             const SasrecBlockParams Wn = P.blk[more ? l + 1 : l];   // the NEXT block's weights: requested two or more phases before use
             if (more) par_fetch<D>(PR, Wn, tid);
+            TileRegs<D> TK0, TV0;
+            if (C::MAXT < 4 && npre) {   // this block's k, v of the prefix rows (tape)
+                tile_fetch<D>(TK0, tape + (int64_t)l * T.per_block + T.off_K + prow0 * D, 16 * npre, tid);
+                tile_fetch<D>(TV0, tape + (int64_t)l * T.per_block + T.off_V + prow0 * D, 16 * npre, tid);
+            }
             // ---- 1. Q-input = LN_a(x)
             if (r_e < nrows) {
                 float mean, rstd;
@@ -139,18 +161,25 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
             {
                 const SasrecBlockParams W = P.blk[l];
                 const float bq = par[2 * D + col], bk = par[3 * D + col], bv = par[4 * D + col];
+                WUSE(wa, W.in_w);
                 gemm_rows<D>(bA, wa, lane, wr, it.nt, [&](int row, float v) { bQ[row * C::LS + col] = v + bq; });
-                wfrag_t<D>(wa, W.out_w, strip, lane);                 // Wo
+                WREQ(wa, W.out_w);                 // Wo
+                WUSE(wb, W.in_w + D * D);
                 gemm_rows<D>(bX, wb, lane, wr, it.nt, [&](int row, float v) { bK[row * C::LS + col] = v + bk; });
-                wfrag_t<D>(wb, W.w1, strip, lane);                    // W1
+                WREQ(wb, W.w1);                    // W1
+                WUSE(wc, W.in_w + 2 * D * D);
                 gemm_rows<D>(bX, wc, lane, wr, it.nt, [&](int row, float v) { bV[row * C::LS + col] = v + bv; });
-                wfrag_t<D>(wc, W.w2, strip, lane);                    // W2
+                WREQ(wc, W.w2);                    // W2
                 if (TRAIN) tile_store<D>(bA, tp + T.off_A + row0 * D, nrows, tid);
+                if (C::MAXT < 4 && npre) {
+                    tile_commit<D>(bK0, TK0, 16 * npre, tid);
+                    tile_commit<D>(bV0, TV0, 16 * npre, tid);
+                }
             }
             enc_sync();
             ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- 3. scores = q k^T / sqrt(D) over the item's (row tile, key tile) pairs
-            gemm_pairs<D>(bQ, bK, lane, wave, it, [&](int row, int key, float v) { sP[row * C::PLS + key] = v * inv_sqrt_d; });
+            gemm_pairs<D>(bQ, bK, lane, wave, it, [&](int row, int key, float v) { sP[row * C::PLS + key] = v * inv_sqrt_d; }, bK0, npre);
             if (TRAIN) {
                 tile_store<D>(bQ, tp + T.off_Q + row0 * D, nrows, tid);
                 tile_store<D>(bK, tp + T.off_K + row0 * D, nrows, tid);
@@ -163,14 +192,14 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
             if (r_e < nrows) {
                 const int i = r_e;
                 const int gi = s_gid[i], sid = s_sid[i], n_out = s_first[i];
-                const int klo = 16 * enc_kt_lo(it, i >> 4);
+                const int klo = 16 * enc_kt_lo(it, i >> 4), kpre = 16 * npre;   // key columns [0, kpre): prefix rows; own keys follow
                 float p[KPT];
                 float mx = -INFINITY;
                 unsigned okm = 0;
 #pragma unroll
                 for (int jj = 0; jj < KPT; ++jj) {
-                    const int j = j0_e + jj;
-                    const bool ok = gi >= 0 && j <= i && j >= klo && s_sid[j] == sid;
+                    const int j = j0_e + jj, jo = j - kpre;
+                    const bool ok = gi >= 0 && (jo < 0 || (jo <= i && jo >= klo && s_sid[jo & (C::ROWS - 1)] == sid));
                     okm |= (ok ? 1u : 0u) << jj;
                     const float sv = sP[i * C::PLS + j];
                     p[jj] = ok ? sv : -INFINITY;
@@ -211,7 +240,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                     }
                 }
                 if (TRAIN) {   // pre-dropout probabilities (0 outside the row's window)
-                    float* dst = tp + T.off_P + (row0 + i) * C::ROWS + j0_e;
+                    float* dst = tp + T.off_P + (row0 + i) * EP_PW + j0_e;
                     if (KPT % 4 == 0) {
 #pragma unroll
                         for (int q = 0; q < KPT / 4; ++q)
@@ -227,7 +256,8 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                     const int j = j0_e + jj;
                     float pr = p[jj] * inv;
                     if (((okm >> jj) & 1u) && thresh && pr != 0.f) {
-                        const int sj = s_gid[j] - sbase;   // position of key j inside the sequence
+                        // position of key column j inside the sequence (one long sequence: its rows are consecutive positions)
+                        const int sj = it.kind ? n_out + j : s_gid[j & (C::ROWS - 1)] - sbase;
                         pr = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? pr * drop_scale : 0.f;
                     }
                     sP[i * C::PLS + j] = pr;
@@ -238,15 +268,16 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
             // ---- 4. o = A v + w * b_v
             {
                 const float bv = par[4 * D + col];
-                gemm_tx<D>(sP, bV, lane, wr, strip, it, [&](int row, float v) { bA[row * C::LS + col] = fmaf(s_w[row], bv, v); });
+                gemm_tx<D>(sP, bV, lane, wr, strip, it, [&](int row, float v) { bA[row * C::LS + col] = fmaf(s_w[row], bv, v); }, bV0, npre);
             }
             enc_sync();
             ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- 5. x1 = o Wo^T + bo + x
             {
                 const float bo = par[5 * D + col];
+                WUSE(wa, P.blk[l].out_w);
                 gemm_rows<D>(bA, wa, lane, wr, it.nt, [&](int row, float v) { bQ[row * C::LS + col] = v + bo + bX[row * C::LS + col]; });
-                if (more) wfrag_t<D>(wa, Wn.in_w, strip, lane);                   // next block's Wq
+                if (more) WREQ(wa, Wn.in_w);                   // next block's Wq
                 if (TRAIN) tile_store<D>(bA, tp + T.off_O + row0 * D, nrows, tid);
             }
             enc_sync();
@@ -266,6 +297,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
             // ---- 7. hr = relu(dropout1(y W1^T + b1))
             {
                 const float b1 = par[8 * D + col];
+                WUSE(wb, P.blk[l].w1);
                 gemm_rows<D>(bK, wb, lane, wr, it.nt, [&](int row, float v) {
                     v += b1;
                     if (thresh) {
@@ -274,7 +306,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                     }
                     bV[row * C::LS + col] = fmaxf(v, 0.f);
                 });
-                if (more) wfrag_t<D>(wb, Wn.in_w + D * D, strip, lane);           // next block's Wk
+                if (more) WREQ(wb, Wn.in_w + D * D);           // next block's Wk
                 if (TRAIN) tile_store<D>(bK, tp + T.off_Y + row0 * D, nrows, tid);
             }
             enc_sync();
@@ -282,6 +314,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
             // ---- 8. x' = dropout2(hr W2^T + b2) + y, pad rows zeroed
             {
                 const float b2 = par[9 * D + col];
+                WUSE(wc, P.blk[l].w2);
                 gemm_rows<D>(bV, wc, lane, wr, it.nt, [&](int row, float v) {
                     v += b2;
                     if (thresh) {
@@ -291,7 +324,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                     v += bK[row * C::LS + col];
                     bX[row * C::LS + col] = s_pad[row] ? 0.f : v;
                 });
-                if (more) wfrag_t<D>(wc, Wn.in_w + 2 * D * D, strip, lane);       // next block's Wv
+                if (more) WREQ(wc, Wn.in_w + 2 * D * D);       // next block's Wv
                 if (TRAIN) tile_store<D>(bV, tp + T.off_HR + row0 * D, nrows, tid);
                 if (more) par_commit<D>(s_par + ((l + 1) & 1) * EP_NPAR * D, PR, tid);   // (the other half: this block's readers use `par`)
             }
@@ -320,6 +353,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
                     reinterpret_cast<float4*>(u + (int64_t)(gid - first) * D)[f] = reinterpret_cast<const float4*>(s_last + D)[f % (D / 4)];
             }
         }
+        }   // chained parts
     }
 }
 
@@ -331,20 +365,20 @@ extern "C" size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t 
 template <int D>
 static int enc_fwd_launch_d(const float* x0, const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P,
                             float ds, uint32_t thresh, uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan,
-                            int grid, hipStream_t s) {
+                            int grid, int fill_pads, hipStream_t s) {
     using C = EC<D>;
     const EncTape T = enc_tape_layout(B, S, D, L);
-    const size_t ldsb = (size_t)(5 * C::BUF + C::PBUF) * sizeof(float);
+    const size_t ldsb = (size_t)(5 * C::BUF + C::PBUF + (C::MAXT < 4 ? 2 * C::BUF : 0)) * sizeof(float);
     if (tape) {
         auto k = enc_fwd_k<D, true>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(C::NT), ldsb, s, x0, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, plan, 0,
-                           seed_dev);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(C::NT), ldsb, s, x0, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, plan,
+                           fill_pads, seed_dev);
     } else {
         auto k = enc_fwd_k<D, false>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(k, dim3(grid), dim3(C::NT), ldsb, s, x0, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)nullptr, T, plan,
-                           1, seed_dev);
+                           fill_pads, seed_dev);
     }
     return re_launch_status();
 }
@@ -353,22 +387,24 @@ static int enc_fwd_launch_d(const float* x0, const SeEmbed& em, const int64_t* s
 extern "C" int re_sasrec_encoder_fwd(const float* x0, const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, int64_t B,
                                      int64_t S, int64_t D, int64_t L, const float* const* block_params, const float* last_w,
                                      const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev, const void* plan, int32_t ncu,
-                                     float* u, void* tape, size_t tape_bytes, re_stream_t stream) {
+                                     float* u, void* tape, size_t tape_bytes, int32_t fill_pads, re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
     if (!seq || !u || !plan || B < 0) return RE_EINVAL;
     if (!x0 && (!E || !Ptab || R <= 0)) return RE_EINVAL;
     if (!x0 && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(Ptab)) & 15u)) return RE_EUNSUPPORTED;
-    if (D != 64 || S < 1 || S > 64 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
+    if ((D != 64 && D != 128) || S < 1 || S > 64 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
     if (drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
     SasrecParams P;
     if (!se_fill_params(P, block_params, L, last_w, last_b)) return RE_EINVAL;
     if (tape && tape_bytes < (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float)) return RE_EWORKSPACE;
+    if (D == 128 && !tape && S > 16 * EC<128>::MAXT) return RE_EINVAL;   // parts of a long sequence hand k, v over through the tape
     const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const SeEmbed em{x0 ? nullptr : E, Ptab, R, scale};
     if (ncu < 1) ncu = 256;
     const int64_t mt = enc_plan_max_tiles(B, S);
     const int grid = (int)(mt < ncu ? mt : ncu);   // one resident workgroup per CU; items beyond the grid are taken in further rounds
-    return enc_fwd_launch_d<64>(x0, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, (hipStream_t)stream);
+    if (D == 128) return enc_fwd_launch_d<128>(x0, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, fill_pads, (hipStream_t)stream);
+    return enc_fwd_launch_d<64>(x0, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, fill_pads, (hipStream_t)stream);
 }

@@ -234,7 +234,7 @@ extern "C" int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, cons
     re_clear_error();
     if (!seq || !plan || B <= 0 || S <= 0) return RE_EINVAL;
     if ((pos == nullptr) != (neg == nullptr) || (pos_out == nullptr) != (neg_out == nullptr)) return RE_EINVAL;
-    if (S > 64 || B * S > (int64_t)1 << 30 || max_tiles < 1 || max_tiles > 4 || 16 * max_tiles < S) return RE_EUNSUPPORTED;
+    if (S > 64 || B * S > (int64_t)1 << 30 || max_tiles < 1 || max_tiles > 4) return RE_EUNSUPPORTED;
     if (plan_bytes < enc_plan_bytes(B, S)) return RE_EWORKSPACE;
     if (state && step < 1) return RE_EINVAL;
     if (ncu < 1) ncu = 1;

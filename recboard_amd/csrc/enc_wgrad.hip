@@ -191,13 +191,22 @@ size_t enc_wgrad_ppart_floats(int64_t B, int64_t D) { return (size_t)64 * ((B + 
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
                      int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
                      float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s) {
-    if (D != 64) return RE_EUNSUPPORTED;
-    using C = EC<64>;
+    if (D != 64 && D != 128) return RE_EUNSUPPORTED;
     const EncTape T = enc_tape_layout(B, S, D, L);
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
-    const size_t ldsb = (size_t)2 * 16 * WG_CH * C::LS * sizeof(float);
-    hipLaunchKernelGGL(enc_wgrad_k<64>, dim3(WG_NSPLIT, EG_NMAT, (unsigned)(L + (dPtab ? 1 : 0))), dim3(C::NT), ldsb, s, (const float*)tape, T, gtape,
-                       NR, plan, (int)B, (int)S, (int)L, part, seq, contrib, ppart, (const float*)dPtab);
+    const dim3 grid(WG_NSPLIT, EG_NMAT, (unsigned)(L + (dPtab ? 1 : 0)));
+    if (D == 128) {
+        using C = EC<128>;
+        const size_t ldsb = (size_t)2 * 16 * WG_CH * C::LS * sizeof(float);
+        if (hipFuncSetAttribute((const void*)enc_wgrad_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        hipLaunchKernelGGL(enc_wgrad_k<128>, grid, dim3(C::NT), ldsb, s, (const float*)tape, T, gtape, NR, plan, (int)B, (int)S, (int)L, part, seq, contrib,
+                           ppart, (const float*)dPtab);
+    } else {
+        using C = EC<64>;
+        const size_t ldsb = (size_t)2 * 16 * WG_CH * C::LS * sizeof(float);
+        hipLaunchKernelGGL(enc_wgrad_k<64>, grid, dim3(C::NT), ldsb, s, (const float*)tape, T, gtape, NR, plan, (int)B, (int)S, (int)L, part, seq, contrib,
+                           ppart, (const float*)dPtab);
+    }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     EncGradDst dst;
     for (int64_t l = 0; l < SE_MAX_BLOCKS; ++l)

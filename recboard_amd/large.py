@@ -10,8 +10,9 @@ Same model as `recboard_amd.sasrec.SASRecEngine` (reference `SASRec/main.py:63-2
     a dense Adam over the table would move 28 bytes per element, 358 GB per step;
   * everything else (position table, blocks, lastLN) stays in one dense arena with one fused Adam launch.
 
-Encoder: the fused kernels are D = 64; any other D runs the block stack through torch (`encoder="aten"`), with the engine's
-embedding front end, criterion and optimizer kernels around it -- the D = 128 fused encoder is future work.
+Encoder: the fused kernels (D = 64 and 128; at D = 128 a work item holds 32 rows in LDS and longer sequences are taken in chained
+parts, csrc/enc_fwd.hip) with the embedding front end / backward fused in; any other width runs the block stack through torch
+(`encoder="aten"`) between the engine's embedding, criterion and optimizer kernels.
 Multi-GPU: `recboard_amd.sharded.ShardedTable.lookup / backward_sparse_adam` is the same step with the table row-sharded
 (one all-to-all per direction); this class is the single-GPU form.
 """
@@ -46,9 +47,10 @@ def counter_normal_rows(rows, D, seed, std, device):
 
 class SASRecLargeTableEngine(SASRecEngine):
     def __init__(self, num_items, maxlen=50, embedding_dim=128, num_blocks=2, dropout_rate=0.0, loss="BCE", lr=1e-3,
-                 weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, table_std=0.02, table_init="torch"):
+                 weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, table_std=0.02, table_init="torch", encoder=None):
         assert loss in ("BCE", "BPR")
-        self.encoder = "aten"
+        # the fused encoder kernels cover D = 64 and 128 (BASELINE config 5 is D = 128); any other width runs the block stack on torch
+        self.encoder = encoder or ("fused" if embedding_dim in (64, 128) and maxlen <= 64 and num_blocks <= 4 else "aten")
         self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
         self.p_drop, self.loss_kind = dropout_rate, loss
@@ -97,27 +99,51 @@ class SASRecLargeTableEngine(SASRecEngine):
     def encode(self, seq):
         """-> (userEmbds [B,S,D], itemEmbds = E[1:]).  SASRec/main.py:178-193 (inference / evaluation)."""
         with torch.no_grad():
-            x0 = ops.sasrec_embed(self.E, self.params["Position.weight"].detach(), seq, float(self.D ** 0.5),
-                                  self.p_drop if self.training else 0.0, self._step_seed())
+            P = self.params
+            p = self.p_drop if self.training else 0.0
+            if self.encoder == "fused":
+                u, _ = ops.sasrec_embed_encoder_fwd(self.E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), self._block_tensors(),
+                                                    P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, self._step_seed(),
+                                                    plan=ops.sasrec_plan(seq, self.D))
+                return u, self.E[1:]
+            x0 = ops.sasrec_embed(self.E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), p, self._step_seed())
             return self._blocks(x0, (seq == 0).unsqueeze(-1)), self.E[1:]
 
-    def _grads(self, seq, pos, neg, aux, sd, seed_dev=None):
-        """Forward + backward: encoder gradients into the arena, the 3*B*S item-gradient contribution rows into C.  -> (loss, C)."""
+    def _grads(self, seq, pos, neg, aux, sd, seed_dev=None, table=None):
+        """Forward + backward: encoder gradients into the arena, the 3*B*S item-gradient contribution rows into C.  -> (loss, C).
+        `table` (default: the item table) is what seq / pos / neg index: the sharded engine passes its batch-local table."""
         A, D = self.arena, self.D
         B, S = seq.shape
         n = B * S
-        valid, rows_all, count = aux.valid, aux.rows_all, aux.count
+        valid, count = aux.valid, aux.count
+        E = self.E if table is None else table
         p = self.p_drop if self.training else 0.0
         Ppos = self.params["Position.weight"]
+        kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
+        if self.encoder == "fused":
+            # the same launches as SASRecEngine's fused step, minus the dense scatter-add: fused embedding + encoder forward (tape),
+            # criterion forward + backward, encoder backward with the embedding backward fused in (contribution rows, position gradient)
+            W = self._buffers(B, S)
+            G = A.views(A.grad)
+            lw, lb = self.params["lastLN.weight"].detach(), self.params["lastLN.bias"].detach()
+            bt = self._block_tensors()
+            C = W["contrib"]
+            ops.sasrec_embed_encoder_fwd(E, Ppos.detach(), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"],
+                                         tape=W["tape"], plan=aux.plan, seed_dev=seed_dev)
+            loss, _, _, _ = ops.pair_loss_fwd_bwd(W["u"].view(n, D), E, pos.reshape(-1), neg.reshape(-1), valid, kind, count, e_off=1,
+                                                  out=(W["dU"], C[n:2 * n], C[2 * n:]))
+            ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
+                                         self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],
+                                         out=C[:n].view(B, S, D), ws=W["ws_bwd"], plan=aux.plan, seed_dev=seed_dev)
+            return loss, C
         # embedding front end (engine kernel, no autograd node: its backward is re_sasrec_embed_bwd below)
-        x0 = ops.sasrec_embed(self.E, Ppos.detach(), seq, float(D ** 0.5), p, sd, seed_dev=seed_dev).requires_grad_(True)
+        x0 = ops.sasrec_embed(E, Ppos.detach(), seq, float(D ** 0.5), p, sd, seed_dev=seed_dev).requires_grad_(True)
         A.grad.zero_()
         for k, q in self.params.items():
             q.grad = A.view(A.grad, k)
         u = self._blocks(x0, (seq == 0).unsqueeze(-1))
-        kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
         C = torch.empty((3 * n, D), dtype=torch.float32, device=self.device)
-        loss, dU, _, _ = ops.pair_loss_fwd_bwd(u.detach().reshape(n, D), self.E, pos.reshape(-1), neg.reshape(-1), valid, kind, count,
+        loss, dU, _, _ = ops.pair_loss_fwd_bwd(u.detach().reshape(n, D), E, pos.reshape(-1), neg.reshape(-1), valid, kind, count,
                                               e_off=1, out=(torch.empty((n, D), device=self.device), C[n:2 * n], C[2 * n:]))
         u.backward(dU.view(B, S, D))                                      # encoder parameter gradients + d x0
         C[:n].copy_(x0.grad.reshape(n, D))
@@ -256,19 +282,9 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         T = torch.cat([torch.zeros((1, D), dtype=torch.float32, device=self.device), rows], 0)
         ar = torch.arange(1, n + 1, device=self.device)
         seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
-        x0 = ops.sasrec_embed(T, Ppos.detach(), seq_l, float(D ** 0.5), p, sd).requires_grad_(True)
-        A.grad.zero_()
-        for k, q in self.params.items():
-            q.grad = A.view(A.grad, k)
-        u = self._blocks(x0, (seq == 0).unsqueeze(-1))
-        kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
-        C = torch.empty((3 * n, D), dtype=torch.float32, device=self.device)
-        # positives / negatives are rows n+1.. and 2n+1.. of the batch-local table (pair_loss adds e_off = 1 to the 0-based ids)
-        loss, dU, _, _ = ops.pair_loss_fwd_bwd(u.detach().reshape(n, D), T, ar - 1 + n, ar - 1 + 2 * n, valid, kind, count, e_off=1,
-                                              out=(torch.empty((n, D), device=self.device), C[n:2 * n], C[2 * n:]))
-        u.backward(dU.view(B, S, D))
-        C[:n].copy_(x0.grad.reshape(n, D))
-        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq_l, float(D ** 0.5), p, sd, A.view(A.grad, "Position.weight"))
+        # positives / negatives are rows n+1.. and 2n+1.. of the batch-local table (the criterion adds e_off = 1 to the 0-based ids);
+        # the embedding front end, the encoder and the criterion run on it unchanged (fused kernels or the torch block stack)
+        loss, C = self._grads(seq_l, (ar - 1 + n).view(B, S), (ar - 1 + 2 * n).view(B, S), aux, sd, table=T)
         if self.world > 1:
             C.mul_(1.0 / self.world)                 # the loss of the global batch is the mean of the ranks' losses
             dist.all_reduce(A.grad, op=dist.ReduceOp.AVG, group=self.group)
@@ -290,8 +306,13 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             T = torch.cat([torch.zeros((1, self.D), dtype=torch.float32, device=self.device), rows], 0)
             ar = torch.arange(1, B * S + 1, device=self.device)
             seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
-            x0 = ops.sasrec_embed(T, self.params["Position.weight"].detach(), seq_l, float(self.D ** 0.5),
-                                  self.p_drop if self.training else 0.0, self._step_seed())
+            P, p = self.params, (self.p_drop if self.training else 0.0)
+            if self.encoder == "fused":
+                u, _ = ops.sasrec_embed_encoder_fwd(T, P["Position.weight"].detach(), seq_l, float(self.D ** 0.5), self._block_tensors(),
+                                                    P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, self._step_seed(),
+                                                    plan=ops.sasrec_plan(seq_l, self.D))
+                return u, None
+            x0 = ops.sasrec_embed(T, P["Position.weight"].detach(), seq_l, float(self.D ** 0.5), p, self._step_seed())
             return self._blocks(x0, (seq == 0).unsqueeze(-1)), None
 
     def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):

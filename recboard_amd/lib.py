@@ -45,7 +45,7 @@ SIGNATURES = {
                                     _f64, _f64, _f64, _vp]),
     "re_sasrec_tape_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_sasrec_encoder_fwd": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _i32,
-                                     _vp, _vp, _sz, _vp]),
+                                     _vp, _vp, _sz, _i32, _vp]),
     "re_sasrec_encoder_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_sasrec_encoder_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _i32, _f32, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _sz, _vp]),

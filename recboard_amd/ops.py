@@ -389,9 +389,14 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     return pb
 
 
-def sasrec_plan(seq):
+def max_tiles(D):
+    """Tiles of 16 rows a work item of the encoder kernels holds in LDS (what the plan groups short sequences by)."""
+    return 4 if D == 64 else 2
+
+
+def sasrec_plan(seq, D=64):
     """The encoder's work plan alone (evaluation / unit tests).  -> opaque uint8 tensor."""
-    return sasrec_batch_prep(seq).plan
+    return sasrec_batch_prep(seq, max_tiles=max_tiles(D)).plan
 
 
 def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None, tape=None,
@@ -409,16 +414,18 @@ def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, se
         E, Ptab, scale, D = None, None, 0.0, x0.shape[2]
     Lb = lib.load()
     u = out if out is not None else torch.empty((B, S, D), dtype=torch.float32, device=seq.device)
-    if need_tape and tape is None:
+    fill_pads = 0 if (need_tape or tape is not None) else 1      # inference: pad positions read lastLN.bias; training does not write them
+    if tape is None and (need_tape or (D == 128 and S > 16 * max_tiles(D))):
+        # (D = 128, S > 32: the parts of a long sequence hand k, v over through the tape, inference included)
         tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=seq.device)
     if plan is None:
-        plan = sasrec_plan(seq)
+        plan = sasrec_plan(seq, D)
     tbl = _ptr_table(block_tensors)
     lib.check(Lb.re_sasrec_encoder_fwd(_p(x0), _p(E), 0 if E is None else E.shape[0], _p(Ptab), float(scale), _p(seq), B, S, D, L, tbl,
                                        _p(last_w), _p(last_b), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(plan),
-                                       num_cus(seq.device), _p(u), _p(tape), 0 if tape is None else tape.numel() * 4, _stream()),
-              "re_sasrec_encoder_fwd")
-    return u, tape
+                                       num_cus(seq.device), _p(u), _p(tape), 0 if tape is None else tape.numel() * 4, fill_pads,
+                                       _stream()), "re_sasrec_encoder_fwd")
+    return u, (tape if need_tape or fill_pads == 0 else None)
 
 
 def sasrec_embed_encoder_fwd(E, P, seq, scale, block_tensors, last_w, last_b, L, drop_p=0.0, seed=0, need_tape=False, out=None,
@@ -442,7 +449,7 @@ def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, 
     if ws is None:
         ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
     if plan is None:
-        plan = sasrec_plan(seq)
+        plan = sasrec_plan(seq, D)
     tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
     lib.check(Lb.re_sasrec_encoder_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
                                        int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(tape), _p(plan), num_cus(dU.device),

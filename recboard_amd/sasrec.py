@@ -118,8 +118,8 @@ class SASRecEngine:
         assert encoder in ("fused", "aten")
         if loss == "CE" and encoder != "fused":
             raise NotImplementedError("loss='CE' is implemented on the fused path only")
-        if encoder == "fused" and (embedding_dim != 64 or maxlen > 64 or num_blocks > 4):
-            raise NotImplementedError("fused encoder kernels: D = 64, maxlen <= 64, blocks <= 4 (use encoder='aten')")
+        if encoder == "fused" and (embedding_dim not in (64, 128) or maxlen > 64 or num_blocks > 4):
+            raise NotImplementedError("fused encoder kernels: D = 64 or 128, maxlen <= 64, blocks <= 4 (use encoder='aten')")
         self.encoder = encoder
         self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
@@ -220,7 +220,8 @@ class SASRecEngine:
             p = self.p_drop if self.training else 0.0
             sd = self._step_seed()
             u, _ = ops.sasrec_embed_encoder_fwd(E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), self._block_tensors(),
-                                                P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, sd)
+                                                P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, sd,
+                                                plan=ops.sasrec_batch_prep(seq, max_tiles=self._max_tiles()).plan)
             return u, E[1:]
         E = self.params["Item.embeddings.weight"]
         x = _EmbedFn.apply(E, self.params["Position.weight"], seq, float(self.D ** 0.5))
@@ -260,12 +261,14 @@ class SASRecEngine:
             prep = prep[0] if prep is not None and prep[1] == self.arena.step else None   # (planes of the table as it is NOW)
             return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K, prep=prep)
 
-    @staticmethod
-    def prepare_batch(seq, pos, neg):
+    def _max_tiles(self):
+        return 4 if self.D == 64 else 2     # tiles of 16 rows per work item (LDS capacity of the encoder kernels)
+
+    def prepare_batch(self, seq, pos, neg):
         """Per-batch preparation of the fused step as ONE engine launch (re_sasrec_batch_prep; what the reference does at the top of
         `fit`, SASRec/main.py:199-204, plus the encoder's work plan): valid mask, number of valid positions, destination rows of the
         3*B*S gradient contributions, work items.  No host sync.  -> ops.PreparedBatch."""
-        return ops.sasrec_batch_prep(seq, pos, neg)
+        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles())
 
     def _buffers(self, B, S):
         key = (B, S)
@@ -357,7 +360,8 @@ class SASRecEngine:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1])
+            pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                                       max_tiles=self._max_tiles())
             body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -383,7 +387,7 @@ class SASRecEngine:
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1])
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles())
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:

@@ -183,3 +183,42 @@ def test_embed_bwd_fused_into_encoder_bwd_equals_two_launches(ops, p, pack):
     for a, b in zip(g1 + [lw1, lb1], g2 + [lw2, lb2]):
         assert torch.equal(a, b)
     torch.testing.assert_close(dP2, dP1, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,p,beauty", [(8, 0.0, False), (8, 0.4, False), (70, 0.0, True), (150, 0.3, False)])
+def test_encoder_d128_forward_and_backward_match_oracle(ops, B, p, beauty):
+    """D = 128 (BASELINE configs[4]): a work item holds 32 rows, longer sequences run as CHAINED parts (the later rows attend to the
+    earlier ones through prefix key tiles; their dK / dV contributions travel back through the gradient tape) -- forward values,
+    input gradient and every parameter gradient against the oracle's autograd, with the engine's dropout masks."""
+    L, D, S, N = 2, 128, 50, 300
+    P = {k: v.requires_grad_(True) for k, v in _params(11, L, D, S, N).items()}
+    seq = _seqs(12, B, S, N, beauty=beauty)          # lens[0] = S (4 tiles: two chained parts), lens[3] = 17 (2 tiles), 33..48 -> 3 tiles
+    if B > 5:
+        seq[4, :] = 0
+        seq[4, S - 40:] = torch.randint(1, N + 1, (40,), generator=torch.Generator().manual_seed(1))   # 3 tiles: parts of 2 + 1
+    plan = ops.sasrec_plan(seq.cuda(), D)
+    g = torch.Generator().manual_seed(13)
+    x0 = torch.randn(B, S, D, generator=g).masked_fill((seq == 0).unsqueeze(-1), 0.0).requires_grad_(True)
+    dU = torch.randn(B, S, D, generator=g).masked_fill((seq == 0).unsqueeze(-1), 0.0) / B
+    drop = dict(p=p, seed=99) if p > 0 else None
+    ref = _oracle_blocks(P, x0, seq, L, drop)
+    ref.backward(dU)
+    Pd = {k: v.detach().cuda() for k, v in P.items()}
+    bt = ops.sasrec_block_tensors(Pd, L)
+    # inference form (pad positions filled with lastLN.bias), then the training form with its tape
+    if p == 0:
+        u_eval, _ = ops.sasrec_encoder_fwd(x0.detach().cuda(), seq.cuda(), bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, plan=plan)
+        torch.testing.assert_close(u_eval.cpu(), ref.detach(), rtol=1e-4, atol=2e-5)
+    u, tape = ops.sasrec_encoder_fwd(x0.detach().cuda(), seq.cuda(), bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, True, plan=plan)
+    m = seq != 0
+    torch.testing.assert_close(u.cpu()[m], ref.detach()[m], rtol=1e-4, atol=2e-5)
+    Gd = {k: torch.full_like(v, float("nan")) for k, v in Pd.items()}
+    dx0 = ops.sasrec_encoder_bwd(dU.cuda(), seq.cuda(), bt, Pd["lastLN.weight"], Pd["lastLN.bias"], L, p, 99, tape,
+                                 ops.sasrec_block_tensors(Gd, L), Gd["lastLN.weight"], Gd["lastLN.bias"], plan=plan)
+    r = x0.grad
+    assert (dx0.cpu()[m] - r[m]).abs().max() <= 1e-4 * r.abs().max() + 1e-7
+    for k, v in P.items():
+        if k.startswith("Item.") or k.startswith("Position."):
+            continue
+        err = (Gd[k].cpu() - v.grad).abs().max().item()
+        assert err <= 2e-4 * v.grad.abs().max().item() + 1e-6, (k, err, v.grad.abs().max().item())
