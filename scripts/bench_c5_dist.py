@@ -41,8 +41,7 @@ for _ in range(4):
         seq[b, S - lens[b]:] = np.minimum(rng.zipf(1.05, lens[b]), N)
     pos = np.where(seq > 0, np.minimum(rng.zipf(1.05, (B, S)), N) - 1, 0)
     neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
-    t = tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg))
-    batches.append(t + (model.batch_aux_fused(*t),))
+    batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
 for i in range(args.warmup):
     model.train_step(*batches[i % 4])
 dist.barrier(); torch.cuda.synchronize()
@@ -60,5 +59,5 @@ if rank == 0:
                       "scaling": "weak", "final_loss_rank0": round(float(loss), 5), "rows_per_rank": model.table.local_rows,
                       "table_GB_per_rank": round(3 * model.table.local_rows * D * 4 / 1e9, 1), "table_init_s": round(t_init, 1),
                       "hbm_used_GB_rank0": round((total - free) / 1e9, 1), "launch": "eager (the exchange's split sizes are host-side)",
-                      "encoder": "torch (aten) block stack at D=128; engine kernels for the embedding front end, criterion, optimizers"}))
+                      "world_size": dist.get_world_size(), "backend": dist.get_backend(), "encoder": f"{model.encoder} (D = {D})"}))
 dist.destroy_process_group()

@@ -9,7 +9,7 @@ reference's source enters this repository -- only inputs/outputs (``*.npz``).
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
 
 Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic):
-  sasrec_bce.npz / sasrec_bpr.npz / sasrec_ce.npz : SASRec/main.py  fit loss, every param grad,
+  sasrec_bce.npz / sasrec_bpr.npz / sasrec_ce.npz / sasrec_bce_d128.npz (embedding_dim = 128: BASELINE configs[4]) : SASRec/main.py  fit loss, every param grad,
         recommend_from_full scores, encode() output, masked top-K (Coach.evaluate contract,
         UniSRec/main.py:400-447)
   mfbpr.npz    : MF-BPR/main.py   fit loss + table grads + full scores
@@ -91,9 +91,9 @@ def ragged_np(lists):
     return ptr, flat
 
 
-def gen_sasrec(loss):
+def gen_sasrec(loss, embedding_dim=64):
     torch.manual_seed(1)
-    fr, ref = import_ref("SASRec", f"ref_sasrec_{loss}", dict(dropout_rate=0.0, loss=loss))
+    fr, ref = import_ref("SASRec", f"ref_sasrec_{loss}_{embedding_dim}", dict(dropout_rate=0.0, loss=loss, embedding_dim=embedding_dim))
     N, B, S = 200, 8, ref.cfg.maxlen
     F = fr.data.fields.Field
     ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=40), F("ITEM", "ITEM", "ID", count=N)])
@@ -125,8 +125,9 @@ def gen_sasrec(loss):
     sp, si = ragged_np(seen)
     _, vals, idx = masked_topk(scores, seen, 50)
     out.update({"in/seen_ptr": sp, "in/seen_idx": si, "out/topk_vals": vals.numpy(), "out/topk_idx": idx.numpy()})
-    np.savez_compressed(os.path.join(HERE, f"sasrec_{loss.lower()}.npz"), **out)
-    print(f"sasrec_{loss.lower()}: loss={float(out['out/rec_loss']):.6f}")
+    name = f"sasrec_{loss.lower()}" + ("" if embedding_dim == 64 else f"_d{embedding_dim}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: loss={float(out['out/rec_loss']):.6f}")
 
 
 def gen_mfbpr():
@@ -272,6 +273,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)
     for loss in ("BCE", "BPR", "CE"):
         gen_sasrec(loss)
+    gen_sasrec("BCE", embedding_dim=128)
     gen_mfbpr()
     gen_lightgcn()
     gen_deepfm()

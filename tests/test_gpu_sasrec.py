@@ -42,9 +42,9 @@ def test_fit_loss_and_grads_match_reference_golden(loss):
     assert (m.params["Item.embeddings.weight"].grad[0] == 0).all()   # padding row gets no gradient
 
 
-@pytest.mark.parametrize("encoder", ["aten", "fused"])
-def test_encode_scores_topk_match_reference_golden(encoder):
-    z = np.load(os.path.join(G, "sasrec_bce.npz"))
+@pytest.mark.parametrize("encoder,fixture", [("aten", "sasrec_bce.npz"), ("fused", "sasrec_bce.npz"), ("fused", "sasrec_bce_d128.npz")])
+def test_encode_scores_topk_match_reference_golden(encoder, fixture):
+    z = np.load(os.path.join(G, fixture))
     m = _engine(z, "BCE", encoder=encoder).eval()
     seq = dev(z["in/seq"])
     with torch.no_grad():
@@ -80,9 +80,11 @@ def test_train_step_matches_oracle_adam_trajectory(encoder, loss):
         np.testing.assert_allclose(p.detach().cpu().numpy(), P[k].detach().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)
 
 
-def test_fused_step_grads_match_reference_golden():
-    """fused train step (no autograd): every gradient in the arena vs the reference's loss.backward()."""
-    z = np.load(os.path.join(G, "sasrec_bce.npz"))
+@pytest.mark.parametrize("fixture", ["sasrec_bce.npz", "sasrec_bce_d128.npz"])
+def test_fused_step_grads_match_reference_golden(fixture):
+    """fused train step (no autograd): every gradient in the arena vs the reference's loss.backward() -- embedding_dim 64 (the
+    benchmarked configuration) and 128 (BASELINE configs[4]; one row of the fixture is a full-length sequence: chained parts)."""
+    z = np.load(os.path.join(G, fixture))
     m = _engine(z, "BCE", lr=0.0, encoder="fused")       # lr 0: parameters stay put, gradients stay in the arena
     seq, pos, neg = dev(z["in/seq"]), dev(z["in/pos"]), dev(z["in/neg"])
     L = m.train_step(seq, pos, neg)

@@ -22,9 +22,9 @@ def T(a, grad=False):
 
 
 # ------------------------------------------------------------------ SASRec
-@pytest.mark.parametrize("loss", ["BCE", "BPR", "CE"])
-def test_sasrec_fit_loss_and_grads(loss):
-    z = load(f"sasrec_{loss.lower()}")
+@pytest.mark.parametrize("loss,suffix", [("BCE", ""), ("BPR", ""), ("CE", ""), ("BCE", "_d128")])
+def test_sasrec_fit_loss_and_grads(loss, suffix):
+    z = load(f"sasrec_{loss.lower()}{suffix}")
     P = sasrec.params_from_npz(z, requires_grad=True)
     L = sasrec.fit(P, T(z["in/seq"]), T(z["in/pos"]), T(z["in/neg"]), loss=loss, num_blocks=int(z["cfg/num_blocks"]))
     np.testing.assert_allclose(L.item(), float(z["out/rec_loss"]), rtol=2e-6)
@@ -40,8 +40,9 @@ def test_sasrec_fit_loss_and_grads(loss):
         assert np.abs(g.numpy() - ref).max() <= 2e-5 * scale + 1e-7, name
 
 
-def test_sasrec_encode_scores_topk():
-    z = load("sasrec_bce")
+@pytest.mark.parametrize("fixture", ["sasrec_bce", "sasrec_bce_d128"])
+def test_sasrec_encode_scores_topk(fixture):
+    z = load(fixture)
     P = sasrec.params_from_npz(z)
     seq = T(z["in/seq"])
     with torch.no_grad():
