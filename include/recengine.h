@@ -186,6 +186,18 @@ int re_score_topk_prepared(const float* Q, const float* E, const void* prep, int
                            void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Owner bucketing of a batch's table lookups for a row-sharded table (row r lives on rank r mod G; freerec has no
+ * counterpart -- the reference trains one replicated nn.Embedding, MF-BPR/main.py:36-42): one stable counting-sort pass over the G
+ * owners, no host sync, FIXED capacity per peer -- equal-split all-to-alls, capturable.
+ *   buckets [G * cap] int64: the LOCAL row ids (r div G) wanted from owner g at [g * cap, ...), in order of appearance, -1 in unused slots;
+ *   slot [n] int64: g * cap + rank of lookup j inside its bucket (gather the received rows / scatter the gradient rows by it), -1 if dropped;
+ *   counts [G + 1] int32: lookups per owner (may exceed cap), then the number of DROPPED lookups (index outside [0, R), or bucket
+ *   full) -- the caller checks counts[G] == 0 at its next sync point. */
+size_t re_route_workspace_bytes(int64_t n, int64_t G);
+int re_route_bucket(const int64_t* idx, int64_t n, int64_t R, int64_t G, int64_t cap, int64_t* buckets, int64_t* slot, int32_t* counts,
+                    void* ws, size_t ws_bytes, re_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Batch preparation of a SASRec step (what the top of `fit` does, SASRec/main.py:199-204, plus the encoder's work plan), as
  * ONE device launch with no host sync (capturable):
  *   valid [B*S] u8 = seq != 0;  count int32[1] = number of valid positions (M of the mean loss);
@@ -293,6 +305,11 @@ int re_bce_logits(const float* logits, const float* labels, int64_t n, float* lo
  * parameter arena.  Replaces `self.optimizer.step()` (SASRec/main.py:250; cfg dump
  * benchmark/Amazon2014Beauty_550_LOU/SASRec.json:254-300).  step is 1-based.  Hyper-parameters are doubles because
  * torch derives 1-beta and the bias corrections in double precision before rounding to fp32. */
+/* AUC of a prediction model's scores (DeepFM/configs/Frappe_x1_BARS.yaml:101-102 `monitors: [LOGLOSS, AUC]`; scores =
+ * recommend_from_pool outputs, DeepFM/main.py:217-219; labels > 0.5 = positive): the Mann-Whitney statistic counted pairwise --
+ * no sort, integer counts (exact, deterministic), ties count one half.  auc[0] = 0.5 if a class is empty.  ws: 256 bytes. */
+size_t re_auc_workspace_bytes(void);
+int re_auc(const float* scores, const float* labels, int64_t n, float* auc, void* ws, size_t ws_bytes, re_stream_t stream);
 /* hipGraph-friendly variant of re_adam_step: hyper (DEVICE float[2]) = { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) };
  * n must be a multiple of 4. */
 int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1,

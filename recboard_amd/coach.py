@@ -13,26 +13,39 @@ import os
 
 import torch
 
-from .evaluate import RankingEvaluator, ragged_to_csr
+from .evaluate import PredictionEvaluator, RankingEvaluator, ReduceLROnPlateau, ragged_to_csr  # noqa: F401
 
 
 class Coach:
     def __init__(self, model, trainpipe, validpipe=None, testpipe=None, monitors=("LOSS", "HitRate@10", "NDCG@10"),
-                 which4best="NDCG@10", eval_freq=5, kind="seq", checkpoint_path=None):
+                 which4best="NDCG@10", eval_freq=5, kind="seq", checkpoint_path=None, lr_scheduler=None):
+        """kind: "seq" (SASRec: data ISeq / IPos / INeg), "gen" (MF-BPR / LightGCN: User / IPos / INeg) or "pred" (DeepFM: a field matrix
+        `X` [B, F] and `Label`; monitors LOGLOSS / AUC, DeepFM/configs/Frappe_x1_BARS.yaml:101-102).  lr_scheduler: e.g.
+        `ReduceLROnPlateau(model, mode="max", patience=eval_freq, ...)`, stepped on the best monitored value at the top of every
+        epoch as CoachForDeepFM does (DeepFM/main.py:251-257)."""
         self.model, self.trainpipe, self.validpipe, self.testpipe = model, trainpipe, validpipe, testpipe
         self.monitors, self.which4best, self.eval_freq, self.kind = list(monitors), which4best, eval_freq, kind
         self.history, self.best = [], None
         self.checkpoint_path = checkpoint_path
         self.device = model.device
+        self.lr_scheduler = lr_scheduler
 
     def dict_to_device(self, data):
         return {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
 
     def train_per_epoch(self, epoch):
+        if self.lr_scheduler is not None:            # DeepFM/main.py:256: self.lr_scheduler.step(self._best)
+            self.lr_scheduler.step(self.best[1] if self.best is not None else (-float("inf") if self.lr_scheduler.mode == "max" else float("inf")))
         tot = torch.zeros((), device=self.device)
         n = 0
         for data in self.trainpipe:
             data = self.dict_to_device(data)
+            if self.kind == "pred":                  # DeepFM/main.py:258-268: forward, backward, clip_grad_norm_(.., 10), step
+                loss = self.model.train_step(data["X"], data["Label"])
+                bsz = data["X"].shape[0]
+                tot += loss * bsz
+                n += bsz
+                continue
             if self.kind == "seq" and self._graphable():
                 # one staging launch + one hipGraph replay per step (SASRecEngine.train_step_graph); a short last batch
                 # gets its own captured graph
@@ -54,22 +67,40 @@ class Coach:
     # ---- checkpoint / results in the reference's formats: `checkpoint.tar` (model state_dict under the
     #      reference's parameter names + optimizer state + epoch), `best.pt` (state_dict of the best epoch), and the
     #      `benchmark/<dataset>/<model>.json` record schema (benchmark/Amazon2014Beauty_550_LOU/SASRec.json:1-304).
-    def save_checkpoint(self, path, epoch):
-        os.makedirs(path, exist_ok=True)
+    def _optimizer_state(self):
         m = self.model
-        opt = {}
-        if hasattr(m, "arena"):
-            opt = {"m": m.arena.m.clone(), "v": m.arena.v.clone(), "step": m.arena.step}
-        torch.save({"epoch": epoch, "model": m.state_dict(), "optimizer": opt, "best": self.best, "history": self.history},
+        if hasattr(m, "optimizer_state"):            # engines whose Adam state is more than the arena (large / sharded tables)
+            return m.optimizer_state()
+        if hasattr(m, "arena"):                      # a torch.optim.Adam-shaped state_dict over the reference's parameter names
+            return m.arena.adam_state_dict(m.lr, m.betas, m.wd)
+        if hasattr(m, "adam_state_dict"):
+            return m.adam_state_dict()
+        return {}
+
+    def save_checkpoint(self, path, epoch):
+        """`checkpoint.tar` with the reference's keys (freerec Coach.save_checkpoint, shape evidenced by ETEGRec/train_etegrec.py:549-574
+        and the cfg dump's CHECKPOINT_MODULES): {epoch, model, optimizer, lr_scheduler, monitors}."""
+        os.makedirs(path, exist_ok=True)
+        torch.save({"epoch": epoch, "model": self.model.state_dict(), "optimizer": self._optimizer_state(),
+                    "lr_scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
+                    "monitors": {"best": self.best, "history": self.history}},
                    os.path.join(path, "checkpoint.tar"))
 
     def load_checkpoint(self, path):
         ck = torch.load(os.path.join(path, "checkpoint.tar"), map_location=self.device, weights_only=False)
-        self.model.load_state_dict(ck["model"])
-        if ck["optimizer"] and hasattr(self.model, "arena"):
-            a = self.model.arena
-            a.m.copy_(ck["optimizer"]["m"]); a.v.copy_(ck["optimizer"]["v"]); a.step = ck["optimizer"]["step"]
-        self.best, self.history = ck["best"], ck["history"]
+        m = self.model
+        m.load_state_dict(ck["model"])
+        opt = ck.get("optimizer") or {}
+        if opt:
+            if hasattr(m, "load_optimizer_state"):
+                m.load_optimizer_state(opt)
+            elif hasattr(m, "arena"):
+                m.arena.load_adam_state_dict(opt)
+            elif hasattr(m, "load_adam_state_dict"):
+                m.load_adam_state_dict(opt)
+        if self.lr_scheduler is not None and ck.get("lr_scheduler"):
+            self.lr_scheduler.load_state_dict(ck["lr_scheduler"])
+        self.best, self.history = ck["monitors"]["best"], ck["monitors"]["history"]
         return ck["epoch"]
 
     def save_best(self, path):
@@ -97,6 +128,15 @@ class Coach:
 
     def evaluate(self, mode="valid"):
         pipe = self.validpipe if mode == "valid" else self.testpipe
+        if self.kind == "pred":
+            ev = PredictionEvaluator(self.monitors)
+            was_training = self.model.training
+            self.model.eval()
+            for data in pipe:
+                data = self.dict_to_device(data)
+                ev.update(self.model.encode(data["X"])[0], data["Label"])
+            self.model.train(was_training)
+            return ev.compute()
         ev = RankingEvaluator(self.monitors)
         was_training = getattr(self.model, "training", False)
         if hasattr(self.model, "eval"):
@@ -120,8 +160,11 @@ class Coach:
             rec = {"epoch": epoch, "train": self.train_per_epoch(epoch)}
             if self.validpipe is not None and epoch % self.eval_freq == 0:
                 rec["valid"] = self.evaluate("valid")
-                name, k = self.which4best.split("@")
-                score = rec["valid"].get(f"{name.upper()}@{k}")
+                if "@" in self.which4best:
+                    name, k = self.which4best.split("@")
+                    score = rec["valid"].get(f"{name.upper()}@{k}")
+                else:
+                    score = rec["valid"].get(self.which4best.upper())
                 if score is not None and (self.best is None or score > self.best[1]):
                     self.best = (epoch, score)
                     if self.checkpoint_path:

@@ -76,3 +76,65 @@ extern "C" int re_rank_metrics(const int64_t* topk_idx, int64_t B, int64_t Kmax,
     if (sums) hipLaunchKernelGGL(rank_metrics_sum, dim3(nk * 5), dim3(256), 0, s, (const float*)per_user, B, nk * 5, sums);
     return re_launch_status();
 }
+
+// ---- AUC of a prediction model's scores (DeepFM/configs/Frappe_x1_BARS.yaml:101-102 `monitors: [LOGLOSS, AUC]`, computed by
+// freerec's Coach from `recommend_from_pool` outputs, DeepFM/main.py:217-219).  AUC is the Mann-Whitney statistic
+//     AUC = ( #{(i, j): y_i = 1, y_j = 0, s_i > s_j} + 0.5 #{... s_i == s_j} ) / (P N)
+// counted PAIRWISE: no sort, integer counts (exact, order-free -> deterministic), every (positive, negative) pair compared once.
+// Thread = one sample i against a tile of samples j staged in LDS; grid = (i tiles) x (j tiles).  n = 30 000 evaluation rows are
+// 9e8 comparisons; the count fits 64 bits for any n.  counts = { greater, equal, P, N } (uint64, zeroed by the launcher).
+#define AUC_TILE 2048
+__global__ __launch_bounds__(256) void auc_pairs_k(const float* __restrict__ s, const float* __restrict__ y, int64_t n,
+                                                   unsigned long long* __restrict__ counts) {
+    __shared__ float ls[AUC_TILE];
+    __shared__ unsigned char lneg[AUC_TILE];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool ipos = i < n && y[i] > 0.5f;
+    const float si = i < n ? s[i] : 0.f;
+    const int64_t j0 = (int64_t)blockIdx.y * AUC_TILE;
+    for (int q = tid; q < AUC_TILE; q += 256) {
+        const int64_t j = j0 + q;
+        ls[q] = j < n ? s[j] : 0.f;
+        lneg[q] = (j < n && !(y[j] > 0.5f)) ? 1 : 0;
+    }
+    __syncthreads();
+    unsigned gt = 0, eq = 0;
+    if (ipos) {
+        for (int q = 0; q < AUC_TILE; ++q) {
+            const float sj = ls[q];
+            const unsigned m = lneg[q];
+            gt += (si > sj) ? m : 0u;
+            eq += (si == sj) ? m : 0u;
+        }
+    }
+    // wave totals, one atomic pair per wave; the class counts are taken once (by the first column of j tiles)
+    for (int o = 32; o > 0; o >>= 1) { gt += __shfl_xor(gt, o, 64); eq += __shfl_xor(eq, o, 64); }
+    const unsigned long long mp = __ballot(ipos), mn = __ballot(i < n && !ipos);
+    if ((tid & 63) == 0) {
+        if (gt) atomicAdd(&counts[0], (unsigned long long)gt);
+        if (eq) atomicAdd(&counts[1], (unsigned long long)eq);
+        if (blockIdx.y == 0) {
+            atomicAdd(&counts[2], (unsigned long long)__builtin_popcountll(mp));
+            atomicAdd(&counts[3], (unsigned long long)__builtin_popcountll(mn));
+        }
+    }
+}
+__global__ void auc_final_k(const unsigned long long* __restrict__ counts, float* __restrict__ out) {
+    const double pn = (double)counts[2] * (double)counts[3];
+    out[0] = pn > 0.0 ? (float)(((double)counts[0] + 0.5 * (double)counts[1]) / pn) : 0.5f;
+}
+
+extern "C" size_t re_auc_workspace_bytes(void) { return 256; }
+extern "C" int re_auc(const float* scores, const float* labels, int64_t n, float* auc, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (n < 0 || !auc || !ws || (n && (!scores || !labels))) return RE_EINVAL;
+    if (ws_bytes < 32 || (reinterpret_cast<uintptr_t>(ws) & 7u)) return RE_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (re_zero_async(ws, 32, s) != hipSuccess) return RE_ELAUNCH;
+    if (n > 0)
+        hipLaunchKernelGGL(auc_pairs_k, dim3((unsigned)re_cdiv(n, 256), (unsigned)re_cdiv(n, AUC_TILE)), dim3(256), 0, s, scores, labels, n,
+                           (unsigned long long*)ws);
+    hipLaunchKernelGGL(auc_final_k, dim3(1), dim3(1), 0, s, (const unsigned long long*)ws, auc);
+    return re_launch_status();
+}

@@ -51,6 +51,14 @@ class SyntheticSeqDataset:
         return int(sum(len(s) - 2 for s in self.seqs))
 
 
+class ExplicitSeqDataset(SyntheticSeqDataset):
+    """The same leave-one-out interface over GIVEN per-user item sequences (last item = test target, the one before = valid target)."""
+
+    def __init__(self, seqs, num_items):
+        self.seqs = [np.asarray(s, np.int64) for s in seqs]
+        self.num_users, self.num_items, self.perm = len(self.seqs), num_items, None
+
+
 def _lpad(rows, maxlen, offset=0):
     out = np.zeros((len(rows), maxlen), np.int64)
     for i, r in enumerate(rows):

@@ -98,6 +98,34 @@ class DeepFMEngine:
             self.running[i][0].copy_(torch.as_tensor(sd[f"{i}.bn.running_mean"]).to(self.device))
             self.running[i][1].copy_(torch.as_tensor(sd[f"{i}.bn.running_var"]).to(self.device))
 
+    def state_dict(self):
+        """The reference's state-dict granularity: per-field tables, the LR bias, the MLP incl. BatchNorm running statistics."""
+        sd = OrderedDict()
+        for f, (t, tl) in enumerate(zip(self.tables(), self.tables_lr())):
+            sd[f"fields.{f}.embeddings.weight"] = t.detach().clone()
+            sd[f"fields.{f}.embeddings_lr.weight"] = tl.detach().clone()
+        sd["fm.lr_layer.bias"] = self.bias.detach().clone()
+        for k, p in self.P.items():
+            if k.startswith("dnn."):
+                sd[k] = p.detach().clone()
+        for i, (rm, rv) in self.running.items():
+            sd[f"dnn.{i}.bn.running_mean"], sd[f"dnn.{i}.bn.running_var"] = rm.clone(), rv.clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for f, (t, tl) in enumerate(zip(self.tables(), self.tables_lr())):
+                t.copy_(torch.as_tensor(sd[f"fields.{f}.embeddings.weight"]).to(self.device))
+                tl.copy_(torch.as_tensor(sd[f"fields.{f}.embeddings_lr.weight"]).to(self.device))
+            self.bias.copy_(torch.as_tensor(sd["fm.lr_layer.bias"]).to(self.device))
+            self.load_dnn_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("dnn.")})
+
+    def adam_state_dict(self):
+        return {"m": self.m.clone(), "v": self.v.clone(), "step": self.step, "lr": self.lr}
+
+    def load_adam_state_dict(self, st):
+        self.m.copy_(st["m"]); self.v.copy_(st["v"]); self.step = int(st["step"]); self.lr = float(st.get("lr", self.lr))
+
     def train(self, mode=True):
         self.training = mode
         return self

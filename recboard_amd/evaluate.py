@@ -52,9 +52,77 @@ class RankingEvaluator:
 
     def compute(self):
         """-> {"HITRATE@10": float, ...} for the monitors asked for (mean over users)."""
+        if self.sums is None:                       # an empty split: every metric is 0
+            return {f"{name}@{k}": 0.0 for name, k in self.wanted}
         s = (self.sums / max(self.n, 1)).cpu()
         out = {}
         for name, k in self.wanted:
             j = ops.METRIC_NAMES.index(name)
             out[f"{name}@{k}"] = float(s[self.ks.index(k), j])
         return out
+
+
+class PredictionEvaluator:
+    """LOGLOSS / AUC over the batches of one split of a prediction model (DeepFM/configs/Frappe_x1_BARS.yaml:101-102): the
+    reference's Coach collects `recommend_from_pool` outputs (sigmoid(logits), DeepFM/main.py:217-219) against the labels; here the
+    logits of all batches are kept on the device and the two metrics come from one launch each at the end of the split:
+    LOGLOSS = mean binary cross entropy (re_bce_logits: the stable logits form of -[y log p + (1 - y) log(1 - p)]), AUC = the
+    Mann-Whitney statistic counted pairwise (re_auc: exact, sort-free)."""
+
+    def __init__(self, monitors):
+        self.wanted = [m.upper() for m in monitors if m.upper() in ("LOGLOSS", "AUC")]
+        self.logits, self.labels = [], []
+
+    def update(self, logits, labels):
+        self.logits.append(logits.reshape(-1).to(torch.float32))
+        self.labels.append(labels.reshape(-1).to(torch.float32))
+
+    def compute(self):
+        if not self.logits:
+            return {m: 0.0 for m in self.wanted}
+        z, y = torch.cat(self.logits).contiguous(), torch.cat(self.labels).contiguous()
+        out = {}
+        if "LOGLOSS" in self.wanted:
+            out["LOGLOSS"] = float(ops.bce_logits(z, y)[0])
+        if "AUC" in self.wanted:
+            out["AUC"] = float(ops.auc(torch.sigmoid(z).contiguous(), y))       # (scores as the reference hands them over: probabilities)
+        return out
+
+
+class ReduceLROnPlateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau as CoachForDeepFM uses it (DeepFM/main.py:251-257: mode="max", patience=eval_freq,
+    min_lr / factor / threshold from the yaml, threshold_mode "rel", cooldown 0; `step(self._best)` at the top of every epoch):
+    the same state machine on the engine's own learning-rate attribute."""
+
+    def __init__(self, model, mode="max", factor=0.1, patience=10, threshold=1e-4, min_lr=0.0, eps=1e-8):
+        assert mode in ("max", "min")
+        self.model, self.mode, self.factor, self.patience, self.threshold, self.min_lr, self.eps = model, mode, factor, patience, threshold, min_lr, eps
+        self.best = -float("inf") if mode == "max" else float("inf")
+        self.num_bad_epochs, self.last_epoch = 0, 0
+
+    def _better(self, a):
+        if self.mode == "max":
+            return a > self.best * (1.0 + self.threshold)
+        return a < self.best * (1.0 - self.threshold)
+
+    def step(self, metric):
+        cur = float(metric)
+        self.last_epoch += 1
+        if self._better(cur):
+            self.best, self.num_bad_epochs = cur, 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            new = max(self.model.lr * self.factor, self.min_lr)
+            if self.model.lr - new > self.eps:
+                self.model.lr = new
+            self.num_bad_epochs = 0
+
+    def get_last_lr(self):
+        return [self.model.lr]
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "model"}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)

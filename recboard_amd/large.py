@@ -95,6 +95,19 @@ class SASRecLargeTableEngine(SASRecEngine):
                 p.copy_(torch.as_tensor(sd[k]).to(self.device).view(p.shape))
             self.E.copy_(torch.as_tensor(sd["Item.embeddings.weight"]).to(self.device))
 
+    def reset_ranking_buffers(self):
+        """Coach.evaluate calls this before a split's batches: split the item table once for the split's `recommend_topk` calls."""
+        self._score_prep = (ops.score_prepare(self.E[1:]), self.arena.step)
+
+    def optimizer_state(self):
+        """Adam state incl. the table's moments (Coach.save_checkpoint; the arena alone would lose them on resume)."""
+        return {"m": self.arena.m.clone(), "v": self.arena.v.clone(), "step": self.arena.step, "Em": self.Em, "Ev": self.Ev}
+
+    def load_optimizer_state(self, st):
+        self.arena.m.copy_(st["m"]); self.arena.v.copy_(st["v"]); self.arena.step = int(st["step"])
+        if "Em" in st:
+            self.Em.copy_(st["Em"]); self.Ev.copy_(st["Ev"])
+
     # ---- forward pieces
     def encode(self, seq):
         """-> (userEmbds [B,S,D], itemEmbds = E[1:]).  SASRec/main.py:178-193 (inference / evaluation)."""
@@ -222,7 +235,9 @@ class SASRecLargeTableEngine(SASRecEngine):
 
     def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):
         u, items = self.encode(seq)
-        return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K)
+        prep = None if self.training else getattr(self, "_score_prep", None)
+        prep = prep[0] if prep is not None and prep[1] == self.arena.step else None
+        return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K, prep=prep)
 
 
 class SASRecShardedEngine(SASRecLargeTableEngine):
@@ -241,17 +256,20 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
     the exchange itself is covered under gloo with two ranks (tests/test_sharded_gloo.py).  Table values come from
     `counter_normal_rows`, so every GPU count trains the same table."""
 
-    def __init__(self, *args, group=None, dedup=True, **kw):
+    def __init__(self, *args, group=None, dedup=True, capacity_factor=None, local_ops=None, **kw):
         import torch.distributed as dist
         self.group = group
         self.dedup = dedup   # only the distinct rows of a batch cross the fabric (ShardedTable); False: one row per looked-up position
+        # capacity_factor: the sync-free fixed-capacity exchange (ShardedTable): owner bucketing on the device, equal-split all-to-alls
+        self.capacity_factor, self._local_ops = capacity_factor, local_ops
         self.world = dist.get_world_size(group)
         kw["table_init"] = "counter"
         super().__init__(*args, **kw)
 
     def _alloc_table(self, seed):
         from .sharded import ShardedTable
-        self.table = ShardedTable(self.N + 1, self.D, group=self.group, device=self.device, dedup=self.dedup)
+        self.table = ShardedTable(self.N + 1, self.D, group=self.group, device=self.device, dedup=self.dedup and self.capacity_factor is None,
+                                  capacity_factor=self.capacity_factor, local_ops=self._local_ops)
         T = self.table
         step_rows = max(1, (1 << 24) // self.D)
         for l0 in range(0, T.local_rows, step_rows):
@@ -263,8 +281,42 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         T.v = torch.zeros_like(T.weight)
         self.E = None                                # no rank holds the table
 
-    def state_dict(self):
-        raise NotImplementedError("sharded table: save `engine.table.weight` per rank (rows rank::world)")
+    def state_dict(self, dst=0):
+        """Gather-on-save (every rank must call it): the reference's state_dict holds the whole nn.Embedding
+        (ETEGRec/train_etegrec.py:549-574); here the shards travel to rank `dst` in row chunks.  -> the full state dict on rank
+        `dst` (same keys as SASRecEngine's), the table-less one elsewhere."""
+        sd = OrderedDict((k, p.detach().clone()) for k, p in self.params.items())
+        full = self.table.gather_full(dst)
+        if full is not None:
+            sd["Item.embeddings.weight"] = full
+        return sd
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for k, p in self.params.items():
+                p.copy_(torch.as_tensor(sd[k]).to(self.device).view(p.shape))
+            if "Item.embeddings.weight" in sd:
+                self.table.load_full(sd["Item.embeddings.weight"])
+
+    def optimizer_state(self, dst=0):
+        """Adam state incl. the table's moments, gathered like the table (Coach.save_checkpoint)."""
+        st = {"m": self.arena.m.clone(), "v": self.arena.v.clone(), "step": self.arena.step}
+        Em, Ev = self.table.gather_full(dst, self.table.m), self.table.gather_full(dst, self.table.v)
+        if Em is not None:
+            st["Em"], st["Ev"] = Em, Ev
+        return st
+
+    def load_optimizer_state(self, st):
+        self.arena.m.copy_(st["m"]); self.arena.v.copy_(st["v"]); self.arena.step = int(st["step"])
+        if "Em" in st:
+            self.table.load_full(st["Em"], self.table.m); self.table.load_full(st["Ev"], self.table.v)
+
+    def reset_ranking_buffers(self):
+        """Coach.evaluate calls this before a split's batches: nothing to cache (every rank scores its own shard per call)."""
+
+    def _dense_adam(self):
+        A = self.arena
+        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
 
     def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
         import torch.distributed as dist
@@ -293,7 +345,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         A.step += 1
         # contribution rows of pad / invalid positions are zero rows addressed to global row 0 (rank 0 drops them)
         self.table.backward_sparse_adam(C, route, A.step, self.lr, self.betas, 1e-8, self.wd, padding_global_row=0)
-        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        self._dense_adam()
         return loss.squeeze(0)
 
     def train_step_graph(self, *a, **k):

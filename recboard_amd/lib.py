@@ -40,6 +40,8 @@ SIGNATURES = {
     "re_score_prepare": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp]),
     "re_score_topk_prepared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_score_topk_prepared": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "re_route_workspace_bytes": (_sz, [_i64, _i64]),
+    "re_route_bucket": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_sasrec_plan_bytes": (_sz, [_i64, _i64]),
     "re_sasrec_batch_prep": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32, _i64,
                                     _f64, _f64, _f64, _vp]),
@@ -53,6 +55,8 @@ SIGNATURES = {
     "re_rows_sqnorm_workspace_bytes": (_sz, []),
     "re_rows_sqnorm": (_i32, [_vp, _i64, _i64, _vp, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
     "re_rank_metrics": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "re_auc_workspace_bytes": (_sz, []),
+    "re_auc": (_i32, [_vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "re_fm_bag_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "re_fm_bag_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "re_bce_logits": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),

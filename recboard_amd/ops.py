@@ -323,6 +323,23 @@ def sasrec_block_tensors(named, L):
     return [named[k.format(l=l)] for l in range(L) for k in BLOCK_PARAM_ORDER]
 
 
+def route_bucket(idx, R, G, cap, out=None):
+    """Owner bucketing of lookups into a row-sharded table (re_route_bucket): -> (buckets int64 [G, cap] local row ids, -1 = unused;
+    slot int64 [n]; counts int32 [G + 1], the last word = dropped lookups).  No host sync; fixed capacity per peer."""
+    _req(idx, torch.int64, "idx")
+    n = idx.numel()
+    dev = idx.device
+    if out is None:
+        out = (torch.empty((G, cap), dtype=torch.int64, device=dev), torch.empty(max(n, 1), dtype=torch.int64, device=dev)[:n],
+               torch.empty(G + 1, dtype=torch.int32, device=dev))
+    buckets, slot, counts = out
+    L = lib.load()
+    ws = _ws(L.re_route_workspace_bytes(n, G), dev)
+    lib.check(L.re_route_bucket(_p(idx), n, int(R), int(G), int(cap), _p(buckets), _p(slot) if n else None, _p(counts), _p(ws), ws.numel(),
+                                _stream()), "re_route_bucket")
+    return buckets, slot, counts
+
+
 _NCU = {}
 
 
@@ -554,6 +571,15 @@ def rank_metrics(topk_idx, tgt_ptr, tgt_idx, ks):
     lib.check(lib.load().re_rank_metrics(_p(topk_idx), B, Kmax, _p(tgt_ptr), _p(tgt_idx), arr, len(ks), _p(per_user), _p(sums),
                                          _stream()), "re_rank_metrics")
     return per_user, sums
+
+
+def auc(scores, labels):
+    """AUC (Mann-Whitney, ties one half) of `scores` against 0/1 `labels`, exact and sort-free (re_auc).  -> float32[1]."""
+    _req(scores, torch.float32, "scores"); _req(labels, torch.float32, "labels")
+    out = torch.empty(1, dtype=torch.float32, device=scores.device)
+    ws = _ws(256, scores.device)
+    lib.check(lib.load().re_auc(_p(scores), _p(labels), scores.numel(), _p(out), _p(ws), ws.numel(), _stream()), "re_auc")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ K9

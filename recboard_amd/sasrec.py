@@ -71,6 +71,26 @@ class ParamArena:
     def views(self, buf):
         return OrderedDict((k, self.view(buf, k)) for k in self.shapes)
 
+    def adam_state_dict(self, lr, betas, weight_decay):
+        """The optimizer state in torch.optim.Adam's state_dict shape (what the reference's checkpoint.tar holds under "optimizer"):
+        parameters numbered in state-dict order, per parameter {step, exp_avg, exp_avg_sq} as copies of the arena's views."""
+        names = list(self.shapes)
+        state = {i: {"step": torch.tensor(float(self.step)), "exp_avg": self.view(self.m, k).clone(), "exp_avg_sq": self.view(self.v, k).clone()}
+                 for i, k in enumerate(names)}
+        group = {"lr": lr, "betas": tuple(betas), "eps": 1e-8, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group], "param_names": names}
+
+    def load_adam_state_dict(self, sd):
+        if "state" not in sd:                        # (round-1 checkpoints: flat arena copies)
+            self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step = int(sd["step"])
+            return
+        for i, k in enumerate(self.shapes):
+            st = sd["state"][i]
+            self.view(self.m, k).copy_(st["exp_avg"].to(self.m.device).view(self.shapes[k]))
+            self.view(self.v, k).copy_(st["exp_avg_sq"].to(self.v.device).view(self.shapes[k]))
+            self.step = int(st["step"])
+
 
 class _EmbedFn(torch.autograd.Function):
     """x = E[seq]*sqrt(D) + P[s], pad rows 0 (re_sasrec_embed); backward = deterministic scatter-add into dense dE."""

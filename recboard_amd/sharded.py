@@ -40,19 +40,33 @@ class EngineLocalOps:
         from . import ops
         ops.sparse_adam_rows(g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=padding_idx)
 
+    def route_bucket(self, idx, R, G, cap):
+        """Owner bucketing with a fixed capacity per peer (re_route_bucket): no host sync."""
+        from . import ops
+        return ops.route_bucket(idx, R, G, cap)
+
 
 class Route:
     """Permutation + split sizes of one lookup, kept for the backward exchange.  dedup: `inv` maps every looked-up position to
-    its distinct row among the `n` rows that travel."""
-    __slots__ = ("order", "send_counts", "recv_counts", "recv_local", "n", "inv")
+    its distinct row among the `n` rows that travel.  Fixed-capacity form: `slot` (position of every lookup in the [G, cap] buckets),
+    `cap`, and `recv_local` = the [G * cap] local row ids the peers want from this rank (-1 = unused slot)."""
+    __slots__ = ("order", "send_counts", "recv_counts", "recv_local", "n", "inv", "slot", "cap")
 
 
 class ShardedTable:
-    def __init__(self, num_rows, dim, local_ops=None, group=None, device=None, dtype=torch.float32, dedup=True):
+    def __init__(self, num_rows, dim, local_ops=None, group=None, device=None, dtype=torch.float32, dedup=True, capacity_factor=None):
         # dedup (SURVEY.md section 8e): every distinct row of a batch crosses the fabric once per direction -- the indices out, the
         # rows back, and in the backward ONE pre-summed gradient row per distinct index (Zipf-distributed lookups repeat their
         # hot rows many times: config 2's 76 800 lookups per step hit ~12 000 distinct rows)
         self.dedup = dedup
+        # capacity_factor c: the exchange takes the FIXED-CAPACITY form -- every peer pair moves ceil(c * n / G) slots per
+        # direction (equal-split all-to-alls, sizes known without looking at the data: no host sync, capturable), the lookups are
+        # bucketed by owner on the device (re_route_bucket), unused slots travel as -1 / zero rows.  With mod placement a factor of 2
+        # holds unless one rank owns > 2/G of a batch's lookups; c = G can never overflow.  Lookups that do not fit are counted in
+        # `self.dropped` (device int32, summed over calls): the caller checks it at its next sync point.  None: exact split sizes
+        # through the host (two syncs per lookup), optionally with dedup.
+        self.capacity_factor = capacity_factor
+        self.dropped = None
         self.group = group
         self.G = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -92,11 +106,39 @@ class ShardedTable:
         recv_local = torch.empty(sum(rc), dtype=flat.dtype, device=flat.device)
         dist.all_to_all_single(recv_local, send_local, rc, sc, group=self.group)
         r = Route()
-        r.order, r.send_counts, r.recv_counts, r.recv_local, r.n, r.inv = order, sc, rc, recv_local, flat.numel(), inv
+        r.order, r.send_counts, r.recv_counts, r.recv_local, r.n, r.inv, r.slot, r.cap = order, sc, rc, recv_local, flat.numel(), inv, None, 0
         return r
+
+    def _route_fixed(self, idx):
+        flat = idx.reshape(-1).contiguous()
+        n, G = flat.numel(), self.G
+        cap = max(1, min(n, -(-int(self.capacity_factor * n) // G)))
+        buckets, slot, counts = self.ops.route_bucket(flat, self.R, G, cap)
+        recv_local = torch.empty_like(buckets)
+        dist.all_to_all_single(recv_local.view(-1), buckets.view(-1), group=self.group)      # equal splits: cap ids per pair
+        self.dropped = counts[G:G + 1].clone() if self.dropped is None else self.dropped + counts[G:G + 1]
+        r = Route()
+        r.slot, r.cap, r.recv_local, r.n, r.inv, r.order, r.send_counts, r.recv_counts = slot, cap, recv_local.view(-1), n, None, None, None, None
+        return r
+
+    def check_capacity(self):
+        """Host-side check (one sync) that no lookup since the last check was dropped by the fixed-capacity exchange."""
+        if self.dropped is not None:
+            d = int(self.dropped)
+            self.dropped = None
+            if d:
+                raise RuntimeError(f"ShardedTable: {d} lookups exceeded the exchange capacity (capacity_factor={self.capacity_factor}); "
+                                   f"use capacity_factor={self.G} (never overflows) or None (exact sizes through the host)")
 
     def lookup(self, idx):
         """-> (rows [*idx.shape, D], route).  Global `W[idx]` on a table no rank holds entirely."""
+        if self.capacity_factor is not None:
+            r = self._route_fixed(idx)
+            rows_for_peers = self.ops.gather(self.weight, r.recv_local).reshape(-1, self.D)       # (-1 -> a zero row)
+            rows_recv = torch.empty_like(rows_for_peers)
+            dist.all_to_all_single(rows_recv, rows_for_peers.contiguous(), group=self.group)       # equal splits: cap rows per pair
+            out = self.ops.gather(rows_recv, r.slot)
+            return out.reshape(tuple(idx.shape) + (self.D,)), r
         r = self._route(idx)
         rows_for_peers = self.ops.gather(self.weight, r.recv_local).reshape(-1, self.D)
         rows_sorted = torch.empty((r.n, self.D), dtype=self.weight.dtype, device=self.weight.device)
@@ -110,12 +152,22 @@ class ShardedTable:
     def backward(self, grad_rows, route):
         """Send every gradient row to the owner of its table row; -> dense gradient of THIS rank's shard."""
         g = self._grad_rows_to_send(grad_rows, route)
+        recv = self._exchange_grad_rows(g, route)
+        return self.ops.scatter_add(recv, route.recv_local, self.local_rows)
+
+    def _exchange_grad_rows(self, g, route):
+        if route.slot is not None:
+            recv = torch.empty_like(g)
+            dist.all_to_all_single(recv, g, group=self.group)                                       # equal splits
+            return recv
         recv = torch.empty((sum(route.recv_counts), self.D), dtype=g.dtype, device=g.device)
         dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
-        return self.ops.scatter_add(recv, route.recv_local, self.local_rows)
+        return recv
 
     def _grad_rows_to_send(self, grad_rows, route):
         g = grad_rows.reshape(-1, self.D)
+        if route.slot is not None:                     # fixed capacity: into bucket order (slots are distinct; -1 = dropped)
+            return self.ops.scatter_add(g.contiguous(), route.slot, self.G * route.cap)
         if route.inv is not None:                      # one pre-summed row per distinct index (deterministic segmented sum)
             g = self.ops.scatter_add(g.contiguous(), route.inv, route.n)
         return g[route.order].contiguous()
@@ -128,13 +180,37 @@ class ShardedTable:
             self.m = torch.zeros_like(self.weight)
             self.v = torch.zeros_like(self.weight)
         g = self._grad_rows_to_send(grad_rows, route)
-        recv = torch.empty((sum(route.recv_counts), self.D), dtype=g.dtype, device=g.device)
-        dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
+        recv = self._exchange_grad_rows(g, route)
         if padding_global_row is not None and self.owner(padding_global_row) == self.rank:   # the padding row is never updated
             self.ops.sparse_adam(recv, route.recv_local, self.weight, self.m, self.v, step, lr, betas[0], betas[1], eps, weight_decay,
                                  padding_idx=self.local_index(padding_global_row))
         else:
             self.ops.sparse_adam(recv, route.recv_local, self.weight, self.m, self.v, step, lr, betas[0], betas[1], eps, weight_decay)
+
+    # ---- checkpoints: the full table exists on no rank; gather-on-save / scatter-on-load go through rank `dst` in row chunks
+    def gather_full(self, dst=0, tensor=None, chunk_rows=1 << 20):
+        """-> the whole [R, D] table (or `tensor`, e.g. an Adam moment, laid out like the shard) on rank `dst`, None elsewhere.
+        Every rank must call it.  The reference saves `model.state_dict()` with the whole nn.Embedding (ETEGRec/train_etegrec.py:549-574)."""
+        W = self.weight if tensor is None else tensor
+        full = torch.empty((self.R, self.D), dtype=W.dtype, device=W.device) if self.rank == dst else None
+        maxl = (self.R + self.G - 1) // self.G
+        for l0 in range(0, maxl, chunk_rows):
+            n = min(chunk_rows, maxl - l0)
+            mine = torch.zeros((n, self.D), dtype=W.dtype, device=W.device)
+            k = max(0, min(n, self.local_rows - l0))
+            mine[:k] = W[l0:l0 + k]
+            parts = [torch.empty_like(mine) for _ in range(self.G)] if self.rank == dst else None
+            dist.gather(mine, parts, dst=dist.get_global_rank(self.group, dst) if self.group is not None else dst, group=self.group)
+            if self.rank == dst:
+                for g in range(self.G):
+                    rows = torch.arange(l0, l0 + n, device=W.device) * self.G + g
+                    ok = rows < self.R
+                    full[rows[ok]] = parts[g][: int(ok.sum())]
+        return full
+
+    def load_full(self, full, tensor=None):
+        """Inverse of gather_full for a table every rank can read (e.g. a checkpoint loaded on the host): take this rank's rows."""
+        (self.weight if tensor is None else tensor).copy_(torch.as_tensor(full)[self.rank::self.G].to(self.weight.device))
 
     # ---- full-catalog scoring over the sharded catalog
     def score_topk(self, Q_local, seen_ptr, seen_idx, K):
@@ -142,6 +218,12 @@ class ShardedTable:
         -> (vals [b, K], idx [b, K] global ids), identical to scoring against the unsharded table."""
         G, dev = self.G, Q_local.device
         b = Q_local.shape[0]
+        nb = torch.tensor([b], dtype=torch.int64, device=dev)
+        nbs = [torch.empty_like(nb) for _ in range(G)]
+        dist.all_gather(nbs, nb, group=self.group)
+        if any(int(x) != b for x in nbs):
+            raise ValueError(f"ShardedTable.score_topk: every rank must pass the same number of queries (got {[int(x) for x in nbs]}); "
+                             "pad the last evaluation batch")
         Qs = [torch.empty_like(Q_local) for _ in range(G)]
         dist.all_gather(Qs, Q_local.contiguous(), group=self.group)
         ptrs, idxs = self._gather_seen(seen_ptr, seen_idx)

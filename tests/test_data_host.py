@@ -43,3 +43,29 @@ def test_evaluator_helpers():
     assert parse_monitors(["LOSS", "HitRate@10", "ndcg@5"]) == [("HITRATE", 10), ("NDCG", 5)]
     ptr, idx = ragged_to_csr([[5, 1], [], [3]], "cpu")
     assert ptr.tolist() == [0, 2, 2, 3] and idx.tolist() == [1, 5, 3]
+
+
+def test_sampler_rows_match_the_reference_row_contract_fixture():
+    """tests/golden/sampler_rows.json: rows derived BY HAND from the reference's samplers for a three-user toy data set
+    (HSTU/sampler.py:54-62 train: IPos = seq[1:], ISeq = seq[:-1]; :107-125 valid rows: seq = train items, IUnseen = (valid item,),
+    ISeen = train items; :131-172 test rows: seen = train + valid; SASRec/main.py:143-157: ISeq + NUM_PADS, lprune/lpad to maxlen)."""
+    import json
+    import os
+    from recboard_amd.data import ExplicitSeqDataset
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sampler_rows.json")))
+    ds = ExplicitSeqDataset(fx["seqs"], fx["num_items"])
+    S = fx["maxlen"]
+    got = {}
+    for b in SeqTrainSampler(ds, S, 8, seed=0):
+        for r, u in enumerate(b["User"].tolist()):
+            got[str(u)] = b
+            assert b["ISeq"][r].tolist() == fx["train"][str(u)]["ISeq"] and b["IPos"][r].tolist() == fx["train"][str(u)]["IPos"]
+            neg, seen = b["INeg"][r].tolist(), set(ds.train_seq(u).tolist())
+            assert all((n == 0 and p == 0) or n not in seen for n, p in zip(neg, b["ISeq"][r].tolist()))
+    assert sorted(got) == sorted(fx["train"])            # user 2's train sequence has one item: no (input, target) pair, no row
+    for mode in ("valid", "test"):
+        for b in EvalSampler(ds, S, 8, mode):
+            for r, u in enumerate(b["User"].tolist()):
+                want = fx[mode][str(u)]
+                assert b["ISeq"][r].tolist() == want["ISeq"] and b["IUnseen"][r] == want["IUnseen"]
+                assert sorted(set(b["ISeen"][r])) == want["ISeen"]

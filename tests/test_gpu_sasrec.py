@@ -238,6 +238,7 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
         large = SASRecLargeTableEngine(N, S, D, 2, table_init="counter", **kw)
         shard = SASRecShardedEngine(N, S, D, 2, dedup=False, **kw)
         dd = SASRecShardedEngine(N, S, D, 2, **kw)        # the default: distinct rows only, gradient rows pre-summed per sender
+        fx = SASRecShardedEngine(N, S, D, 2, capacity_factor=1.0, **kw)   # the sync-free form: owner bucketing on the device (re_route_bucket)
         assert torch.equal(large.E, shard.table.weight) and torch.equal(large.E, dd.table.weight)
         for step in range(3):
             seq = rng.integers(1, N + 1, (B, S))
@@ -250,6 +251,9 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
             assert torch.equal(large.arena.data, shard.arena.data), step
             assert torch.equal(large.E, shard.table.weight), step
             assert torch.equal(large.Em, shard.table.m) and torch.equal(large.Ev, shard.table.v), step
+            lf = fx.train_step(*batch)
+            fx.table.check_capacity()
+            assert torch.equal(ll, lf) and torch.equal(large.E, fx.table.weight) and torch.equal(large.arena.data, fx.arena.data), step
             ld = dd.train_step(*batch)
             assert abs(float(ld) - float(ll)) <= 1e-6 * abs(float(ll)), step
             # same sums in another association: Adam turns a last-bit difference of a near-zero gradient sum into a step of up to

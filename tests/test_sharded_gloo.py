@@ -13,11 +13,37 @@ class OracleLocalOps:
 
     def gather(self, W, idx):
         from oracle import embedding
-        return torch.from_numpy(embedding.gather_rows(W.numpy(), idx.numpy()))
+        ix = idx.numpy()
+        ok = (ix >= 0) & (ix < W.shape[0])                       # the engine's rule: an out-of-range index reads a zero row
+        out = embedding.gather_rows(W.numpy(), np.where(ok, ix, 0))
+        out[~ok] = 0.0
+        return torch.from_numpy(out)
 
     def scatter_add(self, g, idx, R):
         from oracle import ranking
-        return torch.from_numpy(ranking.scatter_add_rows_c(g.numpy(), idx.numpy(), R))
+        ix = idx.numpy().reshape(-1)
+        ok = (ix >= 0) & (ix < R)                                # ... and an out-of-range destination is dropped
+        return torch.from_numpy(ranking.scatter_add_rows_c(g.numpy().reshape(ix.size, -1)[ok], ix[ok], R))
+
+    def route_bucket(self, idx, R, G, cap):
+        """numpy restatement of re_route_bucket (csrc/route.hip): stable counting sort by owner, fixed capacity per peer."""
+        ix = idx.numpy().reshape(-1)
+        buckets = np.full((G, cap), -1, np.int64)
+        slot = np.full(ix.size, -1, np.int64)
+        counts = np.zeros(G + 1, np.int32)
+        for j, r in enumerate(ix.tolist()):
+            if r < 0 or r >= R:
+                counts[G] += 1
+                continue
+            g = r % G
+            k = counts[g]
+            counts[g] += 1
+            if k < cap:
+                buckets[g, k] = r // G
+                slot[j] = g * cap + k
+            else:
+                counts[G] += 1
+        return torch.from_numpy(buckets), torch.from_numpy(slot), torch.from_numpy(counts)
 
     def score_topk(self, Q, E, seen_ptr, seen_idx, K):
         from oracle import ranking
@@ -97,6 +123,31 @@ def _worker(rank, world, port, q):
         v, i = tab.score_topk(Q, None, None, K)
         rv, ri = ranking.score_topk(Q.numpy(), full.numpy(), None, None, K)
         np.testing.assert_array_equal(i.numpy(), ri)
+        # ---- the sync-free fixed-capacity exchange (owner bucketing on the device, equal-split all-to-alls): same rows, same step
+        fx = ShardedTable(R, D, local_ops=OracleLocalOps(), capacity_factor=2.0)
+        fx.init_from_full(full)
+        rows_f, route_f = fx.lookup(idx)
+        assert torch.equal(rows_f, full[idx]) and route_f.cap == 300 and route_f.slot.numel() == 300
+        fx.check_capacity()
+        np.testing.assert_allclose(fx.backward(grad, route_f).numpy(), ref[rank::world], rtol=1e-5, atol=1e-5)
+        fx.backward_sparse_adam(grad, route_f, 3, 1e-2, weight_decay=1e-3)
+        np.testing.assert_allclose(fx.weight.numpy(), Wref[rank::world], rtol=1e-5, atol=1e-6)
+        tight = ShardedTable(R, D, local_ops=OracleLocalOps(), capacity_factor=0.5)     # 75 slots per peer: the Zipf batch overflows
+        tight.init_from_full(full)
+        tight.lookup(idx)
+        try:
+            tight.check_capacity()
+            raise AssertionError("the overflow went unnoticed")
+        except RuntimeError as e:
+            assert "capacity" in str(e)
+        # ---- gather-on-save: the whole table on rank 0 from the shards (and back)
+        got = fx.gather_full(0, chunk_rows=200)
+        if rank == 0:
+            np.testing.assert_allclose(got.numpy(), Wref, rtol=1e-5, atol=1e-6)
+        else:
+            assert got is None
+        fx.load_full(full)
+        assert torch.equal(fx.weight, full[rank::world])
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
@@ -139,3 +190,102 @@ def test_counter_initialised_table_is_the_same_for_every_sharding():
             rows = torch.arange(r, R, G)
             assert torch.equal(counter_normal_rows(rows, D, seed, 0.02, "cpu"), full[r::G])
     assert not torch.equal(counter_normal_rows(torch.arange(R), D, seed + 1, 0.02, "cpu"), full)
+
+
+# ---- the whole sharded SASRec training step (recboard_amd/large.py: SASRecShardedEngine.train_step) under gloo with two ranks: the
+#      engine's orchestration (lookup -> batch-local table -> gradients -> contribution rows to their owners -> row-sparse Adam on
+#      the shards, dense gradients averaged) with the ORACLE as compute, against the unsharded oracle step on the global batch.
+def _engine_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import types
+        from oracle import adam as oadam, sasrec as osas
+        from recboard_amd.large import SASRecShardedEngine, counter_normal_rows
+
+        class OracleShardedEngine(SASRecShardedEngine):
+            """Same train_step; prepare_batch / _grads / _dense_adam (HIP kernels in the product) are the CPU oracle here."""
+
+            def prepare_batch(self, seq, pos, neg):
+                v = (seq != 0).reshape(-1)
+                return types.SimpleNamespace(valid=v.to(torch.uint8), count=v.sum().to(torch.int32).reshape(1), plan=None,
+                                             rows_all=torch.cat([seq.reshape(-1), torch.where(v, pos.reshape(-1) + 1, 0), torch.where(v, neg.reshape(-1) + 1, 0)]))
+
+            def _grads(self, seq, pos, neg, aux, sd, seed_dev=None, table=None):
+                P = {k: p.detach().clone().requires_grad_(True) for k, p in self.params.items()}
+                T = table.clone().requires_grad_(True)
+                P["Item.embeddings.weight"] = T
+                loss = osas.fit(P, seq, pos, neg, self.loss_kind, self.L)
+                loss.backward()
+                for k, p in self.params.items():
+                    self.arena.view(self.arena.grad, k).copy_(P[k].grad if P[k].grad is not None else torch.zeros_like(p))
+                return loss.detach().reshape(1), T.grad[1:].clone()          # row 1 + j of the batch-local table = lookup j
+
+            def _dense_adam(self):
+                A = self.arena
+                oadam.adam_step(A.data.numpy(), A.grad.numpy(), A.m.numpy(), A.v.numpy(), A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+
+        N, B, S, D, L, lr, wd = 97, 6, 50, 64, 2, 1e-2, 1e-4
+        from tests.test_sharded_gloo import OracleLocalOps as Ops
+        for factor in (None, 2.0):
+            eng = OracleShardedEngine(N, S, D, L, dropout_rate=0.0, loss="BCE", lr=lr, weight_decay=wd, seed=3, device="cpu", dedup=False,
+                                      capacity_factor=factor, local_ops=Ops())
+            rngs = [np.random.default_rng(50 + r) for r in range(world)]
+            batches = []
+            for r in range(world):
+                seq = rngs[r].integers(1, N + 1, (B, S))
+                for b in range(B):
+                    seq[b, : rngs[r].integers(0, S - 1)] = 0
+                pos, neg = rngs[r].integers(0, N, (B, S)), rngs[r].integers(0, N, (B, S))
+                batches.append(tuple(torch.from_numpy(a) for a in (seq, pos, neg)))
+            # the unsharded reference: full table (same counter-based values), loss = mean of the ranks' losses, dense Adam on the encoder
+            # parameters, row-sparse Adam on the rows the global batch touches
+            full = counter_normal_rows(torch.arange(N + 1), D, 3, 0.02, "cpu")
+            full[0] = 0
+            P = {k: p.detach().clone().requires_grad_(True) for k, p in eng.params.items()}
+            Eref = full.clone().requires_grad_(True)
+            P["Item.embeddings.weight"] = Eref
+            losses = [osas.fit(P, *batches[r], "BCE", L) for r in range(world)]
+            (sum(losses) / world).backward()
+            loss = eng.train_step(*batches[rank])
+            np.testing.assert_allclose(float(loss), float(losses[rank]), rtol=1e-6)
+            if factor is not None:
+                eng.table.check_capacity()
+            A = eng.arena
+            for k in eng.params:
+                ref = P[k].detach().numpy().copy()
+                g = P[k].grad.numpy() if P[k].grad is not None else np.zeros_like(ref)
+                oadam.adam_step(ref, g, np.zeros_like(ref), np.zeros_like(ref), 1, lr, 0.9, 0.999, 1e-8, wd)
+                np.testing.assert_allclose(eng.params[k].detach().numpy(), ref, rtol=1e-5, atol=1e-7, err_msg=k)
+            rows = torch.nonzero(Eref.grad.abs().sum(1)).reshape(-1).numpy()
+            rows = rows[rows != 0]
+            Wref, m, v = full.numpy().copy(), np.zeros((N + 1, D), np.float32), np.zeros((N + 1, D), np.float32)
+            oadam.sparse_adam_rows(Wref, m, v, rows, Eref.grad.numpy()[rows], 1, lr, wd=wd)
+            np.testing.assert_allclose(eng.table.weight.numpy(), Wref[rank::world], rtol=1e-5, atol=1e-7)
+            # gather-on-save through the engine: the reference's state-dict keys incl. the whole item table, on rank 0
+            sd = eng.state_dict(0)
+            if rank == 0:
+                assert set(sd) == set(eng.params) | {"Item.embeddings.weight"}
+                np.testing.assert_allclose(sd["Item.embeddings.weight"].numpy(), Wref, rtol=1e-5, atol=1e-7)
+            else:
+                assert "Item.embeddings.weight" not in sd
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_sharded_engine_step_world2_gloo_matches_unsharded_oracle():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
