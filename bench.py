@@ -6,8 +6,11 @@
 
 Workload (BASELINE.json configs[1]): SASRec d=64, L=2, 1 head, maxlen 50, BCE, dropout 0.5, Adam(lr 5e-4, wd 1e-6),
 B=512 sequences per GPU per step, on synthetic data shaped like Amazon2014Beauty_550_LOU (22 363 users, 12 101 items;
-SURVEY.md §8d C2).  A "step" = one full training step (forward, backward, dense Adam) on one batch already resident
-in HBM.  `value` = training sequences per second over all GPUs (weak scaling: 512 per GPU).
+SURVEY.md §8d C2).  A "step" = one full training step from a RAW (seq, pos, neg) batch already resident in HBM: the batch
+preparation launch (mask of the non-pad positions, their number, scatter destination rows, the encoder's work plan -- what the
+reference does at the top of `fit`, SASRec/main.py:199-204 -- plus staging into the captured step's buffers), then forward,
+backward, dense Adam.  `value` = training sequences per second over all GPUs (weak scaling: 512 per GPU).  `coach_loop` is the
+same step driven by the engine's Coach from HOST batches (H2D copies and the epoch loop's Python included).
 The second half of BASELINE's metric -- full-catalog items scored per second -- is measured in the same run, outside
 the timed region, over all 22 363 users x 12 101 items with the fused score+mask+top-K kernel, and reported in
 `items_scored_per_sec` and `roofline_score` (MFMA-bound).  `roofline` is the dominant kernel of the timed region (the
@@ -109,21 +112,47 @@ def cpu_baseline(cfg, batches, budget_s=15.0):
         n += 1
     dt = time.time() - t0
     return {"value": round(n * cfg["B"] / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} training steps of B={cfg['B']} (same shapes; dropout off on the CPU side), {dt:.1f} s, "
+            "dropout": "off on the CPU side (the GPU step runs dropout 0.5: extra work there, none here)",
+            "sample": f"{n} training steps of B={cfg['B']} (same shapes), {dt:.1f} s, "
                       f"torch {torch.__version__} CPU, {cores} threads"}
 
 
 def pmc_traffic(*kernels):
     """HBM bytes per launch of the named kernels (summed) from the committed PMC summary -- FETCH_SIZE / WRITE_SIZE cannot be
     read from inside the process, they come from separate rocprofv3 --pmc passes of this same command (profiles/)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_v5_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]
-        return {"hbm_bytes_per_launch": int(sum(k[n]["hbm_bytes_per_launch"] for n in kernels) / max(len(kernels), 1)),
-                "source": "profiles/r1_v5_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE)"}
+        return {"hbm_bytes_per_launch": int(sum(k[n]["hbm_bytes_per_launch"] for n in kernels)),
+                "kernels": {n: k[n]["hbm_bytes_per_launch"] for n in kernels},
+                "source": "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this round's kernels, separate passes; 2*FETCH+WRITE)"}
     except Exception:  # noqa: BLE001
         return None
+
+
+def graph_time_ms(fn, reps=20, iters=10):
+    """GPU time of `fn` (a few short launches): `reps` repetitions captured into one hipGraph, replayed `iters` times -- a loop of eager
+    calls is bounded by the CPU launch path at these kernel sizes, not by the GPU."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / (iters * reps)
 
 
 def aten_train_baseline(cfg, batches, steps=30):
@@ -253,21 +282,33 @@ def main():
         seq, pos, neg, _ = batches[i % len(batches)]
         return model.train_step_graph(seq, pos, neg, grad_hook=hook)
 
+    # Graph or eager launches: decided BEFORE any step that contains a collective runs.  Every rank captures and replays one step
+    # with a no-op hook (no collective), the ranks agree with one all-reduce, and the step's effects are rolled back -- a rank whose
+    # capture failed would otherwise skip a collective the others wait in.
     step = step_eager
     if use_graph:
-        try:   # capture happens on the first call; the eager launch path is the same kernels one by one
-            step_graph(0)
+        A = model.arena
+        keep = [t.clone() for t in (A.data, A.m, A.v)] + [A.step]
+        try:
+            seq0, pos0, neg0, _ = batches[0]
+            model.train_step_graph(seq0, pos0, neg0, grad_hook=(None if hook is None else (lambda g: None)))
             torch.cuda.synchronize()
-            step = step_graph
         except Exception as e:  # noqa: BLE001
-            if world == 1 and not force_dist:
+            if dist is None:
                 raise
-            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
             use_graph = False
-    if dist is not None:   # every rank must take the same path (the collectives differ otherwise)
-        flag = torch.tensor([1 if use_graph else 0], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        use_graph = bool(flag.item())
+        for t, k in zip((A.data, A.m, A.v), keep[:3]):
+            t.copy_(k)
+        A.step = keep[3]
+        if dist is not None:
+            flag = torch.tensor([1 if use_graph else 0], device="cuda")
+            lo, hi = flag.clone(), flag.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if int(lo) != int(hi):
+                print(f"[bench] rank {rank}: the ranks disagree on hipGraph capture; aborting", file=sys.stderr)
+                sys.exit(3)
         step = step_graph if use_graph else step_eager
 
     for i in range(args.warmup):
@@ -297,8 +338,10 @@ def main():
         "config": {"workload": "SASRec d=64 L=2 maxlen=50 BCE dropout=0.5 Adam on Amazon2014Beauty_550_LOU shapes "
                                "(12101 items, 22363 users), B=512 per GPU",
                    "global_batch": world * cfg["B"], "seq_len": cfg["S"],
-                   "launch": "one hipGraph replay + one staging launch per step" if use_graph else "eager (one launch per kernel)",
+                   "launch": "one batch-preparation launch + one hipGraph replay per step" if use_graph else "eager (one launch per kernel)",
+                   "timed_region": "raw (seq, pos, neg) in HBM -> batch preparation launch -> forward, backward, Adam (dropout 0.5 on)",
                    "parallelism": f"dp{world} (replicated 3 MB table, one gradient-arena all-reduce per step)"},
+        "world_size": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
         "final_loss": round(float(loss), 5),
     }
 
@@ -321,7 +364,14 @@ def main():
                                        G["lastLN.weight"], G["lastLN.bias"], out=dx, ws=W["ws_bwd"], plan=pb.plan)
             model.train_step(seq, pos, neg, pb)           # leaves this batch's tape in W["tape"]
             model.arena.step -= 1                         # keep the seed the tape was produced with
-            t_bwd = event_time_ms(run_bwd, 30)
+            t_bwd = graph_time_ms(run_bwd)
+
+            def run_fwd():
+                ops.sasrec_embed_encoder_fwd(model.params["Item.embeddings.weight"].detach(), model.params["Position.weight"].detach(), seq,
+                                             float(Dq ** 0.5), bt, lw, lb, Lq, cfg["p_drop"], model._step_seed(), need_tape=True, out=W["u"],
+                                             tape=W["tape"], plan=pb.plan)
+            t_fwd = graph_time_ms(run_fwd)
+            t_prep = graph_time_ms(lambda: ops.sasrec_batch_prep(seq, pos, neg, blob=pb.blob))
             model.arena.step += 1
             hdr = pb.plan.view(torch.int32)[:8].cpu().numpy()
             n_items, n_tiles = int(hdr[0]), int(hdr[1])
@@ -330,12 +380,15 @@ def main():
             fl_ref = 2 * 62e3 * Bq * Sq * Lq
             fl_exec = Lq * n_tiles * (16 * 2 * 16 * Dq * Dq + 4 * 2 * 16 * 16 * Dq)
             tfb = fl_ref / (t_bwd * 1e-3) / 1e12
+            line["encoder_launch_us"] = {"batch_prep": round(t_prep * 1e3, 1), "forward (all blocks, tape)": round(t_fwd * 1e3, 1),
+                                         "backward (enc_bwd_k + enc_wgrad_k + enc_grad_reduce_k)": round(t_bwd * 1e3, 1),
+                                         "how": "each call captured 20x into a hipGraph, replayed 10x (GPU time; an eager loop is CPU-launch-bound)"}
             line["roofline"] = {"kernel": "re_sasrec_encoder_bwd: enc_bwd_k (all blocks) + enc_wgrad_k + enc_grad_reduce_k", "bound": "mfma",
                                 "achieved": round(tfb, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": round(tfb / MFMA_F32_PEAK_TF, 4),
                                 "achieved_executed": round(fl_exec / (t_bwd * 1e-3) / 1e12, 2),
                                 "frac_executed": round(fl_exec / (t_bwd * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
-                                "traffic": None, "launch_ms": round(t_bwd, 4),
+                                "traffic": pmc_traffic("enc_bwd_k<64>", "enc_wgrad_k<64>", "enc_grad_reduce_k"), "launch_ms": round(t_bwd, 4),
                                 "work": f"reference-equivalent: 2 x 62 kFLOP per token per block x {Bq * Sq} token slots x {Lq} blocks = {fl_ref:.3e} FLOP "
                                         f"(pad positions included); executed: {fl_exec:.3e} FLOP on {n_tiles} tiles of 16 real-token rows in "
                                         f"{n_items} work items"}
@@ -354,16 +407,27 @@ def main():
         t_score = event_time_ms(lambda: ops.score_topk(q, items, seen_ptr, seen_idx, K), 20)
         flops = 2.0 * D * U * N
         tf = flops / (t_score * 1e-3) / 1e12
+        # the same call on iid scores (random unit-scale queries and items): the bench's own state after a few hundred steps keeps every
+        # user's best items among the popular ids, which the threshold filter likes -- the iid figure is the data-independent one
+        gq = torch.Generator(device="cuda").manual_seed(11)
+        q_iid = torch.randn(U, D, device="cuda", generator=gq)
+        E_iid = torch.randn(N, D, device="cuda", generator=gq)
+        t_iid = event_time_ms(lambda: ops.score_topk(q_iid, E_iid, seen_ptr, seen_idx, K), 20)
+        tf_iid = flops / (t_iid * 1e-3) / 1e12
         line["items_scored_per_sec"] = round(U * N / (t_score * 1e-3), 1)
-        line["roofline_score"] = {"kernel": "re_score_topk: score_split_k x2, score_kernel_reg<64,24,24,split> (bf16 hi/mid products on the XDL "
+        line["roofline_score"] = {"kernel": "re_score_topk: score_split_k x2, score_kernel_reg<64,28,28,split> (bf16 hi/mid products on the XDL "
                                             "pipe), score_topk_merge_x<64> (exact fp32 re-scoring + certificate), fallback pass",
                             "bound": "mfma", "achieved": round(tf, 2),
                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                            "iid_scores": {"launch_ms": round(t_iid, 4), "achieved": round(tf_iid, 2), "frac": round(tf_iid / MFMA_F32_PEAK_TF, 4)},
+                            "xdl_pipe": {"executed_bf16_TFLOPs": round(3 * tf, 1), "peak": 2500.0, "frac": round(3 * tf / 2500.0, 4),
+                                         "note": "`achieved` is a THROUGHPUT ratio: algorithmic fp32 FLOPs (2*D per pair) per second against the fp32 "
+                                                 "MFMA peak; the arithmetic that runs is 3 bf16 products per pair on the XDL pipe (this entry), the "
+                                                 "returned values are the exact fp32 chains"},
                             "traffic": score_call_traffic(), "launch_ms": round(t_score, 4),
-                            "work": f"2*D*B*N = {flops:.3e} FLOP per call (B={U}, N={N}, D={D}, K={K}); algorithmic fp32 FLOPs priced "
-                                    f"against the fp32 MFMA peak -- the results are bit-exact fp32; the screening pass executes 3x that "
-                                    f"many bf16 FLOPs = {3 * tf:.0f} TFLOP/s of the 2500 TFLOP/s bf16 peak",
+                            "work": f"2*D*B*N = {flops:.3e} FLOP per call (B={U}, N={N}, D={D}, K={K})",
                             "whole_call": "all launches of one re_score_topk call, item-table split included"}
+        del q_iid, E_iid
         # ---------------- the same evaluation as the reference executes it (UniSRec/main.py:408-414: dense scores, scores[seen] = -1e23,
         # torch.topk), through ROCm aten on this GPU and through torch on the host cores -- baselines, reported beside the engine
         if args.no_baselines:
@@ -421,6 +485,25 @@ def main():
                                    "beauty_shape": {"rows": int(idx_small.numel()), "launch_ms": round(t_g, 4), "GB/s": round(gbs_small, 1),
                                                     "note": "3.1 MB table is L2/Infinity-Cache resident: launch-latency bound"}}
         del W_big, idx_big, out_big
+        # ---------------- the step as a USER runs it: the engine's Coach epoch loop over HOST batches (CoachForSASRec.train_per_epoch,
+        # SASRec/main.py:242-258): per batch the H2D copies, the batch-preparation launch and the graph replay; one loss read per epoch
+        if args.encoder == "fused":
+            from recboard_amd.coach import Coach
+            model.train()
+            nb = 100
+            hb = synth_batches(cfg, 10, seed=77)
+            pipe = [{"User": torch.arange(cfg["B"]), "ISeq": torch.from_numpy(hb[i % 10][0]).pin_memory(),
+                     "IPos": torch.from_numpy(hb[i % 10][1]).pin_memory(), "INeg": torch.from_numpy(hb[i % 10][2]).pin_memory()} for i in range(nb)]
+            coach = Coach(model, pipe, monitors=["LOSS"], kind="seq")
+            coach.train_per_epoch(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            coach.train_per_epoch(1)
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t0
+            line["coach_loop"] = {"samples_per_sec": round(nb * cfg["B"] / dtc, 1), "ms_per_step": round(dtc / nb * 1e3, 4),
+                                  "what": f"Coach.train_per_epoch over {nb} HOST batches (pinned): H2D copies + batch preparation + graph replay per "
+                                          "step, the epoch's mean loss read once at the end"}
         if not args.no_baselines:
             line["train_baseline_aten_gpu"] = aten_train_baseline(cfg, batches)
         if not args.no_cpu_baseline:
