@@ -221,12 +221,12 @@ def aten_train_baseline(cfg, batches, steps=30):
 
 def score_call_traffic():
     """HBM bytes of one whole re_score_topk call (all its launches) from the committed PMC summary of scripts/x2_prof.py."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_v12_score_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
     try:
         with open(path) as f:
             c = json.load(f)["re_score_topk_call"]
         return {"hbm_bytes_per_launch": int(c["hbm_bytes_per_call"]), "algorithmic_lower_bound_bytes": int(c["algorithmic_lower_bound_bytes"]),
-                "source": "profiles/r1_v12_score_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
+                "source": "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
                           "summed over the launches of one call)"}
     except Exception:  # noqa: BLE001
         return None

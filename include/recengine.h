@@ -96,6 +96,16 @@ int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n, int64_t D
 int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
                             float* m, float* v, const float* hyper, double beta1, double beta2, double eps,
                             double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream);
+/* Small dense tables (R up to ~100 k rows; D = 64 or 128): the same sum WITHOUT the sort -- every workgroup owns a range of
+ * destination rows, scans all keys and adds the rows that fall into its range; one launch, no workspace, dW [R, D] fully
+ * overwritten (untouched rows and row `padding_idx` zero).  keys are int32: `n_regions` runs of n keys, run q at
+ * keys[q * region_stride], its rows at g[(q * region_stride + i) * D]; n = n_dev[0] * n_mul read on the device (a captured
+ * launch follows the batch: e.g. the tile count of re_sasrec_batch_prep's plan, * 16) or n_host when n_dev is NULL.
+ * Deterministic (fixed summation tree; not the tree of re_scatter_add_rows).  Replaces the same aten
+ * embedding_dense_backward as re_scatter_add_rows, for the three contribution sets of a SASRec step at once. */
+int re_scatter_add_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
+                              int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
+                              re_stream_t stream);
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                         int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,
@@ -242,8 +252,34 @@ int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* 
  *   block_grads is a HOST array of 12*L DEVICE pointers in the order above.  Deterministic, no float atomics.
  *   dPtab == NULL: dx0 = gradient w.r.t. x0 (for re_sasrec_embed_bwd).  dPtab != NULL: re_sasrec_embed_bwd is fused in -- dx0
  *   receives the item-gradient contribution rows (pad mask, embedding dropout mask, * scale) and dPtab [S, D] the
- *   position-table gradient. */
+ *   position-table gradient.
+ *   dU_rows (optional, [re_sasrec_plan_rows, D]): the upstream gradient indexed by the plan's compact rows (re_sasrec_loss_rows);
+ *   replaces dU, which may then be NULL.  dx0_rows (optional): receives the rows of dx0 once more, in compact order (region 0 of
+ *   re_sasrec_loss_rows' g_rows). */
 size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
+/* The pair criteria of re_pair_loss_fwd_bwd on the plan's compact rows only (SASRec/main.py:199-215 without the boolean-mask
+ * compaction and without the padding positions): NR = re_sasrec_plan_rows(B, S) bounds the number of rows; per live row r
+ * (position gid of the plan's row map):  dU_rows [NR, D] row r = d loss / d u[gid] (zero where seq[gid] == 0),
+ * g_rows [3, NR, D]: rows [1][r] = dpl * u, [2][r] = dnl * u (region 0 is re_sasrec_encoder_bwd's dx0_rows),
+ * keys int32 [3, NR] = seq[gid] | e_off + pos[gid] | e_off + neg[gid] (0 = no contribution) -- the operands of
+ * re_scatter_add_rows_small(g_rows, keys, 3, NR, plan + 4 bytes (the tile count), 16, ...).  loss[0] = mean over the `count[0]`
+ * valid positions (count from re_sasrec_batch_prep).  U is userEmbds [B*S, D].  ws: re_sasrec_loss_rows_workspace_bytes() bytes,
+ * zero before the first call (every call leaves it zero).  D = 64 or 128; table row 0 is the padding row. */
+int64_t re_sasrec_plan_rows(int64_t B, int64_t S);
+size_t re_sasrec_loss_rows_workspace_bytes(void);
+int re_sasrec_loss_rows(const float* U, const float* E, int64_t R, int64_t D, int64_t e_off, const int64_t* seq, const int64_t* pos,
+                        const int64_t* neg, int64_t B, int64_t S, const void* plan, int kind, const int32_t* count, float* loss,
+                        float* dU_rows, float* g_rows, int32_t* keys, void* ws, size_t ws_bytes, re_stream_t stream);
+/* Training forward + criterion in ONE launch: re_sasrec_encoder_fwd (x0 == NULL: input rows built from the tables; tape required)
+ * with re_sasrec_loss_rows folded into every work item's tail -- u is still in LDS, and the gathers of E[pos], E[neg] overlap the
+ * last block.  Same outputs as the two calls (u, tape; loss, dU_rows, g_rows[1:3], keys); ws: 256 bytes, zero before the first
+ * call (every call leaves it zero). */
+int re_sasrec_encoder_fwd_loss(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
+                               const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
+                               const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                               const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
+                               const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* ws,
+                               size_t ws_bytes, re_stream_t stream);
 int re_sasrec_encoder_fwd(const float* x0, const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, int64_t B,
                           int64_t S, int64_t D, int64_t L, const float* const* block_params, const float* last_w,
                           const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev, const void* plan, int32_t ncu,
@@ -252,8 +288,8 @@ size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, in
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,
                           const uint32_t* seed_dev, const void* tape, const void* plan, int32_t ncu, float scale, float* dx0,
-                          float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
-                          re_stream_t stream);
+                          float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, const float* dU_rows,
+                          float* dx0_rows, void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Ranking metrics from the sorted top-K list of re_score_topk (freerec.metrics via Coach.evaluate, contract mirrored at

@@ -106,7 +106,9 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
                                                  SasrecParams P, float drop_scale, uint32_t thresh, uint32_t seed,
                                                  const float* __restrict__ tape, EncTape T, const void* __restrict__ planp,
                                                  float* __restrict__ dOut, float* __restrict__ gtape, float* __restrict__ slab,
-                                                 const uint32_t* __restrict__ seed_dev, int fuse_embed, float emb_scale) {
+                                                 const uint32_t* __restrict__ seed_dev, int fuse_embed, float emb_scale, int in_rows,
+                                                 float* __restrict__ dOutRows) {
+    // in_rows: dIn is indexed by the plan's compact rows instead of (b, s).  dOutRows (optional): the output rows once more, in compact order.
     using C = EC<D>;
     constexpr int KPT = C::KPT;
     if (seed_dev) seed ^= seed_dev[0];   // per-step seed kept in device memory (hipGraph replays)
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
         if (tid < C::ROWS) s_sid[tid] = s_gid[tid] >= 0 ? s_gid[tid] / S : -1;
         TileRegs<D> T0, T1;
         float2 ST;
-        tile_fetch_gid<D>(T0, dIn, s_gid, nrows, tid);
+        if (in_rows) tile_fetch<D>(T0, dIn + row0 * D, nrows, tid);
+        else tile_fetch_gid<D>(T0, dIn, s_gid, nrows, tid);
         tile_fetch<D>(T1, tape + T.off_XL + row0 * D, nrows, tid);
         stats_fetch(ST, tape + T.off_SL + row0 * 2, nrows, tid);
         par_commit<D>(s_par + ((L - 1) & 1) * EP_NPAR * D, PR, tid);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             if (l != L - 1) {
                 accV[10] = 0.f; accV[11] = 0.f;
             }
-            if (more) par_fetch<D>(PR, Wn, tid);
+            par_fetch<D>(PR, Wn, tid);   // (unconditional, like every request below: behind a branch the wait counting cannot see them and drains the queue)
             // ---- pad mask of the block output (x'[pad] = 0) and dO2 = dX' * dropout2 mask      [T1 = HR in flight]
             if (r_e < nrows) {
                 const bool dead = s_pad[r_e] != 0;
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             tile_commit<D>(b3, T1, nrows, tid);   // Q
             tile_fetch<D>(T0, tp + T.off_X + row0 * D, nrows, tid);
             stats_fetch(ST, tp + T.off_SA + row0 * 2, nrows, tid);
-            if (more) tile_fetch<D>(T1, tape + (int64_t)(l - 1) * T.per_block + T.off_HR + row0 * D, nrows, tid);
+            tile_fetch<D>(T1, tape + (int64_t)(more ? l - 1 : 0) * T.per_block + T.off_HR + row0 * D, nrows, tid);
             enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
             {
@@ -386,13 +389,13 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             // ---- G. projections: dbq/dbk; dA1 = dQ Wq -> b3; dX (b0) += dK Wk + dV Wv        (wa, wb, wc = Wq, Wk, Wv)
             WUSE(wa, W.in_w);
             gemm_rows<D>(b4, wa, lane, wr, nt, [&](int row, float v) { b3[row * C::LS + col] = v; });
-            if (more) WREQ(wa, Wn.w2);
+            WREQ(wa, Wn.w2);
             WUSE(wb, W.in_w + D * D);
             gemm_rows<D>(b1, wb, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
-            if (more) WREQ(wb, Wn.w1);
+            WREQ(wb, Wn.w1);
             WUSE(wc, W.in_w + 2 * D * D);
             gemm_rows<D>(b2, wc, lane, wr, nt, [&](int row, float v) { b0[row * C::LS + col] += v; });
-            if (more) WREQ(wc, Wn.out_w);
+            WREQ(wc, Wn.out_w);
             accV[1] += colsum<D>(b1, tid, nrows);
             tile_store<D>(b1, gp + 4 * NR * D, nrows, tid);
             enc_sync();
@@ -445,8 +448,10 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
             enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
             tile_store_gid<D>(b0, dOut, s_gid, nrows, tid, emb_scale);
+            if (dOutRows) tile_store<D>(b0, dOutRows + row0 * D, nrows, tid, emb_scale);
         } else {
             tile_store_gid<D>(b0, dOut, s_gid, nrows, tid);
+            if (dOutRows) tile_store<D>(b0, dOutRows + row0 * D, nrows, tid);
         }
         }   // chained parts
     }
@@ -477,10 +482,11 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
 extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                                      const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,
                                      const uint32_t* seed_dev, const void* tape, const void* plan, int32_t ncu, float scale, float* dx0,
-                                     float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
-                                     re_stream_t stream) {
+                                     float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, const float* dU_rows,
+                                     float* dx0_rows, void* ws, size_t ws_bytes, re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
+    if (dU_rows) dU = dU_rows;
     if (!dU || !seq || !tape || !plan || !dx0 || !block_params || !block_grads || !g_last_w || !g_last_b || !last_w || !last_b || !ws || B < 0)
         return RE_EINVAL;
     if ((D != 64 && D != 128) || S < 1 || S > 64 || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
@@ -507,14 +513,14 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
         auto kf = enc_bwd_k<128>;
         if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(kf, dim3(grid), dim3(C::NT), ldsb, s, dU, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, (const float*)tape, T, plan, dx0,
-                           gtape, slab, seed_dev, dPtab ? 1 : 0, scale);
+                           gtape, slab, seed_dev, dPtab ? 1 : 0, scale, dU_rows ? 1 : 0, dx0_rows);
     } else {
         using C = EC<64>;
         const size_t ldsb = (size_t)(5 * C::BUF + 2 * C::PBUF) * sizeof(float);
         auto kf = enc_bwd_k<64>;
         if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(kf, dim3(grid), dim3(C::NT), ldsb, s, dU, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, (const float*)tape, T, plan, dx0,
-                           gtape, slab, seed_dev, dPtab ? 1 : 0, scale);
+                           gtape, slab, seed_dev, dPtab ? 1 : 0, scale, dU_rows ? 1 : 0, dx0_rows);
     }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     (void)NR;

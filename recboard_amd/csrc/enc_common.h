@@ -440,6 +440,14 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
     for (int f = tid; f < nrows * (D / 4); f += C::NT)
         reinterpret_cast<float4*>(g)[f] = *reinterpret_cast<const float4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4)));
 }
+template <int D>
+__device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ g, int nrows, int tid, float scale) {
+    using C = EC<D>;
+    for (int f = tid; f < nrows * (D / 4); f += C::NT) {
+        const float4 v = *reinterpret_cast<const float4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4)));
+        reinterpret_cast<float4*>(g)[f] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    }
+}
 // tile[r][:] += g[r][:] for nrows contiguous rows (the partial sums a chained item's later rows left for its earlier rows)
 template <int D>
 __device__ __forceinline__ void tile_add_global(float* tile, const float* g, int nrows, int tid) {
@@ -465,6 +473,22 @@ __device__ __forceinline__ void tile_fetch_gid(TileRegs<D>& R, const float* g, c
             const int gid = s_gid[f / (D / 4)];
             if (gid >= 0) ld4g(t, gp + (int64_t)gid * D + 4 * (f % (D / 4)));
         }
+        R.v[q] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+// rows of a table by per-row index: the loss head's E[pos], E[neg] (index 0 = the table's padding row; unconditional, clamped loads:
+// a predicated load is waited for where it is issued)
+template <int D>
+__device__ __forceinline__ void tile_fetch_rows(TileRegs<D>& R, const float* table, const int* s_row, int nrows, int tid) {
+    using C = EC<D>;
+    gcf_t gp = g_launder(table);
+    const int last = nrows * (D / 4) - 1;
+#pragma unroll
+    for (int q = 0; q < C::ROWS * (D / 4) / C::NT; ++q) {
+        int f = q * C::NT + tid;
+        f = f < last ? f : last;
+        float t[4];
+        ld4g(t, gp + (int64_t)s_row[f / (D / 4)] * D + 4 * (f % (D / 4)));
         R.v[q] = make_float4(t[0], t[1], t[2], t[3]);
     }
 }

@@ -739,3 +739,166 @@ extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64
     if (!hyper) return RE_EINVAL;
     return sparse_adam_launch(g, idx, n, D, R, padding_idx, W, m, v, 0.f, 0.f, hyper, beta1, beta2, eps, weight_decay, ws, ws_bytes, stream);
 }
+
+// ------------------------------------------------------------------------------------------------ small dense tables: owner computes
+// The sort above costs six dependent launches however few rows there are -- 44 us of a 180 us SASRec step whose batch holds
+// ~13 000 live contribution rows for a 12 102-row table.  For a table that small the inverted index is not worth building: every
+// workgroup OWNS `rpw` destination rows (dealt round-robin), scans ALL keys (int32, L2-resident: 54 KB for the batch above) for the ones
+// that fall into its range, and adds their rows -- one launch, no workspace, and the zero fill of the untouched rows comes with it
+// (every row of dW is written by its owner).
+//   order of summation (bitwise reproducible): matches are numbered in scan order m = 0, 1, ...; lane group m mod 8 adds match m
+//   into ITS OWN accumulator of that row (LDS, [8][rpw][D]), in increasing m; the eight accumulators of a row are added in group
+//   order at the end.  A hot row (Zipf head) is thereby spread over the eight groups, and each group keeps eight row loads in flight.
+//   keys: `n_regions` runs of `n` keys, run q at keys[q * region_stride ...]; row i of run q is g[(q * region_stride + i) * D ...].
+//   n comes from device memory (n_dev[0] * n_mul -- e.g. the batch plan's tile count * 16) so that a captured launch follows the batch.
+#define SO_CAP 4096          // match list (LDS): flushed whenever the next 4096-key tile might not fit
+#define SO_NG 8
+#define SO_INF 32         // row loads a lane group keeps in flight
+
+template <int D>
+__global__ __launch_bounds__(256) void scatter_owner_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
+                                                       const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
+                                                       int64_t padding_idx, float scale, float* __restrict__ dW) {
+    constexpr int VW = D / 32;                       // floats per lane: a lane group is 32 lanes
+    typedef float vt __attribute__((ext_vector_type(VW)));
+    extern __shared__ __align__(16) float so_acc[];  // [SO_NG][rpw][D]
+    __shared__ uint32_t s_idx[SO_CAP];
+    __shared__ uint16_t s_row[SO_CAP];
+    __shared__ int s_wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, grp = tid >> 5, gl = tid & 31;
+    const int64_t n = n_dev ? (int64_t)n_dev[0] * n_mul : n_host;
+    // rows are dealt round-robin: workgroup w owns rows w, w + nwg, w + 2 nwg, ... (popular items tend to have neighbouring ids:
+    // a contiguous range would hand one workgroup most of the batch)
+    // (the grid is a power of two: owner and local row of a key are a mask and a shift)
+    const uint32_t nwg = gridDim.x, me = blockIdx.x, wsh = 31 - __clz((int)nwg);
+    const int rows_here = (int64_t)me < R ? (int)((R - 1 - me) / nwg + 1) : 0;
+    for (int e = tid; e < SO_NG * rpw * D / 4; e += 256) reinterpret_cast<float4*>(so_acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;          // entries in the list (workgroup-uniform)
+    unsigned m0 = 0;      // matches consumed so far
+
+    auto flush = [&]() {
+        // group grp takes the list entries j with (m0 + j) % 8 == grp, in increasing j, SO_INF row loads in flight at a time (a hot
+        // row -- the Zipf head: 10 % of a batch -- is hundreds of entries for one workgroup: the loop is a chain of memory round trips)
+        const int j0 = (int)((grp - m0) & (SO_NG - 1));
+        for (int jb = j0; jb < cnt; jb += SO_NG * SO_INF) {
+            vt v[SO_INF];
+            int rw[SO_INF];
+#pragma unroll
+            for (int u = 0; u < SO_INF; ++u) {
+                const int j = jb + SO_NG * u;
+                const int jj = j < cnt ? j : jb;               // (clamped: a valid entry, its value is not used)
+                rw[u] = j < cnt ? (int)s_row[jj] : -1;
+                v[u] = reinterpret_cast<const vt*>(g + (int64_t)s_idx[jj] * D)[gl];
+            }
+#pragma unroll
+            for (int u = 0; u < SO_INF; ++u) {
+                if (rw[u] >= 0) {
+                    vt* a = reinterpret_cast<vt*>(so_acc + ((int64_t)grp * rpw + rw[u]) * D) + gl;
+                    *a += v[u];
+                }
+            }
+        }
+        m0 += (unsigned)cnt;
+        cnt = 0;
+    };
+
+    __syncthreads();
+    for (int q = 0; q < nreg; ++q) {
+        const int32_t* kq = keys + (int64_t)q * stride;
+        for (int64_t base = 0; base < n; base += 4096) {
+            // ---- 16 keys per thread: four coalesced 16-byte loads
+            int kv[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = base + (int64_t)(u * 256 + tid) * 4;
+                int4 k4 = make_int4(-1, -1, -1, -1);
+                if (i + 3 < n) k4 = *reinterpret_cast<const int4*>(kq + i);
+                else {
+                    if (i < n) k4.x = kq[i];
+                    if (i + 1 < n) k4.y = kq[i + 1];
+                    if (i + 2 < n) k4.z = kq[i + 2];
+                }
+                kv[4 * u] = k4.x; kv[4 * u + 1] = k4.y; kv[4 * u + 2] = k4.z; kv[4 * u + 3] = k4.w;
+            }
+            unsigned mask = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int64_t k = kv[u];
+                const bool hit = k != padding_idx && k >= 0 && k < R && ((uint32_t)k & (nwg - 1)) == me;
+                mask |= (hit ? 1u : 0u) << u;
+            }
+            const int c = __popc(mask);
+            // ---- exclusive scan of the per-thread counts over the workgroup (thread order = match order inside the tile)
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            __syncthreads();                        // (previous tile's s_wsum readers are done)
+            if (lane == 63) s_wsum[wid] = inc;
+            __syncthreads();
+            const int tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+            if (tot == 0) continue;                 // (uniform)
+            if (cnt + tot > SO_CAP) {               // (uniform) make room
+                flush();
+                __syncthreads();
+            }
+            int off = cnt + inc - c;
+            for (int w = 0; w < wid; ++w) off += s_wsum[w];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if ((mask >> u) & 1u) {
+                    const int64_t i = base + (int64_t)((u >> 2) * 256 + tid) * 4 + (u & 3);
+                    s_idx[off] = (uint32_t)(q * stride + i);
+                    s_row[off] = (uint16_t)((uint32_t)kv[u] >> wsh);
+                    ++off;
+                }
+            }
+            cnt += tot;
+        }
+    }
+    __syncthreads();
+    flush();
+    __syncthreads();
+    // ---- the eight accumulators of every owned row, added in group order; untouched rows come out zero
+    for (int e = tid; e < rows_here * (D / 4); e += 256) {
+        const int r = e / (D / 4), c4 = e % (D / 4);
+        float4 s = reinterpret_cast<const float4*>(so_acc + (int64_t)r * D)[c4];
+#pragma unroll
+        for (int gq = 1; gq < SO_NG; ++gq) {
+            const float4 t = reinterpret_cast<const float4*>(so_acc + ((int64_t)gq * rpw + r) * D)[c4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        reinterpret_cast<float4*>(dW + ((int64_t)r * nwg + me) * D)[c4] = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+    }
+}
+
+extern "C" int re_scatter_add_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
+                                         int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
+                                         re_stream_t stream) {
+    re_clear_error();
+    if (!dW || !g || !keys || R <= 0 || n_regions < 1 || region_stride < 0 || n_host < 0 || (n_dev && n_mul < 1)) return RE_EINVAL;
+    if (D != 64 && D != 128) return RE_EUNSUPPORTED;
+    if ((region_stride & 3) || ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u))
+        return RE_EUNSUPPORTED;
+    if ((int64_t)n_regions * region_stride >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
+    const int rpw = D == 64 ? 48 : 24;            // 96 KB of accumulators per workgroup
+    int64_t nwg = 1;
+    while (nwg * rpw < R) nwg *= 2;               // a power of two: rows are dealt round-robin with a mask
+    if (nwg > 2048) return RE_EUNSUPPORTED;       // every workgroup scans all keys: past ~100 k rows the sorted path is the right one
+    const size_t ldsb = (size_t)SO_NG * rpw * D * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 64) {
+        auto k = scatter_owner_k<64>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw,
+                           padding_idx, scale, dW);
+    } else {
+        auto k = scatter_owner_k<128>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw,
+                           padding_idx, scale, dW);
+    }
+    return re_launch_status();
+}

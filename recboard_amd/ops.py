@@ -453,26 +453,106 @@ def sasrec_embed_encoder_fwd(E, P, seq, scale, block_tensors, last_w, last_b, L,
 
 
 def sasrec_encoder_bwd(dU, seq, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b,
-                       out=None, ws=None, plan=None, seed_dev=None, embed_scale=None, dP=None):
+                       out=None, ws=None, plan=None, seed_dev=None, embed_scale=None, dP=None, dU_rows=None, out_rows=None):
     """-> dx0 [B,S,D]; OVERWRITES the tensors in block_grads / g_last_* with the parameter gradients.  With dP (and embed_scale)
-    re_sasrec_embed_bwd is fused in: the result is the item-gradient contribution rows and dP [S,D] the position-table gradient."""
-    _req(dU, torch.float32, "dU"); _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape")
-    B, S, D = dU.shape
+    re_sasrec_embed_bwd is fused in: the result is the item-gradient contribution rows and dP [S,D] the position-table gradient.
+    dU_rows [plan rows, D] (sasrec_loss_rows) replaces dU (pass dU=None and `out`); out_rows receives dx0's rows in compact order."""
+    _req(seq, torch.int64, "seq"); _req(tape, torch.float32, "tape")
+    if dU_rows is not None:
+        _req(dU_rows, torch.float32, "dU_rows")
+        if out is None:
+            raise ValueError("recengine: dU_rows needs `out`")
+        B, S, D = out.shape
+        dev = dU_rows.device
+    else:
+        _req(dU, torch.float32, "dU")
+        B, S, D = dU.shape
+        dev = dU.device
+    if out_rows is not None:
+        _req(out_rows, torch.float32, "out_rows")
     Lb = lib.load()
     dx0 = out if out is not None else torch.empty_like(dU)
     _req(dx0, torch.float32, "out")
     if dP is not None:
         _req(dP, torch.float32, "dP")
     if ws is None:
-        ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dU.device)
+        ws = _ws(Lb.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L), dev)
     if plan is None:
         plan = sasrec_plan(seq, D)
     tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
     lib.check(Lb.re_sasrec_encoder_bwd(_p(dU), _p(seq), B, S, D, L, tp, _p(last_w), _p(last_b), float(drop_p),
-                                       int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(tape), _p(plan), num_cus(dU.device),
-                                       float(embed_scale or 0.0), _p(dx0), _p(dP), tg, _p(g_last_w), _p(g_last_b), _p(ws),
-                                       ws.numel(), _stream()), "re_sasrec_encoder_bwd")
+                                       int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(tape), _p(plan), num_cus(dev),
+                                       float(embed_scale or 0.0), _p(dx0), _p(dP), tg, _p(g_last_w), _p(g_last_b), _p(dU_rows),
+                                       _p(out_rows), _p(ws), ws.numel(), _stream()), "re_sasrec_encoder_bwd")
     return dx0
+
+
+def sasrec_encoder_fwd_loss(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, last_b, L, drop_p, seed, plan, kind, count, u, tape,
+                            dU_rows, g_rows, keys, ws, e_off=1, loss=None, seed_dev=None):
+    """Training forward + pair criterion in one launch (re_sasrec_encoder_fwd_loss): fills u [B,S,D], tape, dU_rows, g_rows[1:3], keys;
+    -> loss[1].  ws: 256 zeroed bytes (kept zero by the kernel)."""
+    _req(E, torch.float32, "E"); _req(Ptab, torch.float32, "Ptab"); _req(seq, torch.int64, "seq"); _req(pos, torch.int64, "pos")
+    _req(neg, torch.int64, "neg"); _req(u, torch.float32, "u"); _req(tape, torch.float32, "tape"); _req(dU_rows, torch.float32, "dU_rows")
+    _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(count, torch.int32, "count"); _req(ws, torch.uint8, "ws")
+    B, S = seq.shape
+    R, D = E.shape
+    NR = sasrec_plan_rows(B, S)
+    if dU_rows.numel() != NR * D or g_rows.numel() != 3 * NR * D or keys.numel() != 3 * NR or u.numel() != B * S * D:
+        raise ValueError("recengine: sasrec_encoder_fwd_loss buffer shapes")
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=E.device)
+    tp = _ptr_table(block_tensors)
+    lib.check(lib.load().re_sasrec_encoder_fwd_loss(_p(E), R, _p(Ptab), float(scale), _p(seq), _p(pos), _p(neg), B, S, D, L, tp, _p(last_w),
+                                                    _p(last_b), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(plan),
+                                                    num_cus(E.device), _p(u), _p(tape), tape.numel() * 4, int(e_off), int(kind), _p(count),
+                                                    _p(loss), _p(dU_rows), _p(g_rows), _p(keys), _p(ws), ws.numel(), _stream()),
+              "re_sasrec_encoder_fwd_loss")
+    return loss
+
+
+def sasrec_plan_rows(B, S):
+    """Upper bound of the number of compact rows of a batch plan (re_sasrec_plan_rows)."""
+    return int(lib.load().re_sasrec_plan_rows(int(B), int(S)))
+
+
+def sasrec_loss_rows(U, E, seq, pos, neg, plan, kind, count, dU_rows, g_rows, keys, e_off=1, loss=None, ws=None):
+    """Pair criteria on the plan's compact rows (re_sasrec_loss_rows) -> loss[1]; fills dU_rows [NR,D], g_rows[1:3] ([3,NR,D]) and
+    keys int32 [3,NR].  ws: zero-filled uint8 tensor of re_sasrec_loss_rows_workspace_bytes() (kept zero by the kernel)."""
+    _req(U, torch.float32, "U"); _req(E, torch.float32, "E"); _req(seq, torch.int64, "seq"); _req(pos, torch.int64, "pos")
+    _req(neg, torch.int64, "neg"); _req(dU_rows, torch.float32, "dU_rows"); _req(g_rows, torch.float32, "g_rows")
+    _req(keys, torch.int32, "keys"); _req(count, torch.int32, "count")
+    B, S = seq.shape
+    R, D = E.shape
+    NR = sasrec_plan_rows(B, S)
+    if dU_rows.numel() != NR * D or g_rows.numel() != 3 * NR * D or keys.numel() != 3 * NR or U.numel() != B * S * D:
+        raise ValueError("recengine: sasrec_loss_rows buffer shapes")
+    Lb = lib.load()
+    if ws is None:
+        ws = torch.zeros(Lb.re_sasrec_loss_rows_workspace_bytes(), dtype=torch.uint8, device=U.device)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=U.device)
+    lib.check(Lb.re_sasrec_loss_rows(_p(U), _p(E), R, D, int(e_off), _p(seq), _p(pos), _p(neg), B, S, _p(plan), int(kind), _p(count),
+                                     _p(loss), _p(dU_rows), _p(g_rows), _p(keys), _p(ws), ws.numel(), _stream()), "re_sasrec_loss_rows")
+    return loss
+
+
+def scatter_add_rows_small(g, keys, R, out, n_regions=1, region_stride=None, n_dev=None, n_mul=1, n=None, padding_idx=0, scale=1.0):
+    """Dense [R, D] sum of contribution rows by int32 destination keys without a sort (re_scatter_add_rows_small): `out` is fully
+    overwritten.  n keys per region: `n` (host) or n_dev[0] * n_mul (device int32)."""
+    _req(g, torch.float32, "g"); _req(keys, torch.int32, "keys"); _req(out, torch.float32, "out")
+    D = g.shape[-1]
+    if region_stride is None:
+        region_stride = keys.numel() // n_regions
+    if n is None and n_dev is None:
+        n = region_stride
+    if n_dev is not None:
+        _req(n_dev, torch.int32, "n_dev")
+    if out.numel() != R * D or g.numel() < n_regions * region_stride * D:
+        raise ValueError("recengine: scatter_add_rows_small buffer shapes")
+    lib.check(lib.load().re_scatter_add_rows_small(_p(g), _p(keys), int(n_regions), int(region_stride), _p(n_dev), int(n_mul),
+                                                   int(n or 0), D, int(R), int(padding_idx), float(scale), _p(out), _stream()),
+              "re_scatter_add_rows_small")
+    return out
 
 
 def sasrec_encoder_embed_bwd(dU, seq, scale, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b, dP,

@@ -141,6 +141,7 @@ class SASRecEngine:
         if encoder == "fused" and (embedding_dim not in (64, 128) or maxlen > 64 or num_blocks > 4):
             raise NotImplementedError("fused encoder kernels: D = 64 or 128, maxlen <= 64, blocks <= 4 (use encoder='aten')")
         self.encoder = encoder
+        self.compact_rows = True     # BCE / BPR fused step on the batch plan's compact rows (False: all B*S positions + sorted scatter-add)
         self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
         self.p_drop, self.loss_kind = dropout_rate, loss
@@ -297,8 +298,12 @@ class SASRecEngine:
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
             u8 = lambda n: torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)  # noqa: E731
             n3 = 3 * B * S
+            NR = ops.sasrec_plan_rows(B, S)
             self._bufs[key] = dict(
                 u=f(B, S, D), dU=f(B * S, D), contrib=f(n3, D),
+                # the step on the plan's compact rows (BCE / BPR): upstream gradient rows, the three contribution-row sets, their keys
+                dU_rows=f(NR, D), g_rows=f(3, NR, D), keys=torch.zeros((3, NR), dtype=torch.int32, device=dev),
+                ws_loss=torch.zeros(L.re_sasrec_loss_rows_workspace_bytes(), dtype=torch.uint8, device=dev),
                 tape=f(L.re_sasrec_tape_bytes(B, S, D, self.L) // 4),
                 ws_bwd=u8(L.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, self.L)),
                 ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
@@ -319,6 +324,17 @@ class SASRecEngine:
         kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
         n = B * S
         GE = G["Item.embeddings.weight"]
+        if self.loss_kind != "CE" and self.compact_rows:
+            # forward + criterion (one launch), encoder backward, weight gradients, item-table gradient -- all on the plan's compact
+            # rows: only rows that exist are read or written, and the table gradient is ONE launch over ~13 k keys (no sort)
+            loss = ops.sasrec_encoder_fwd_loss(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
+                                               W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], e_off=1,
+                                               seed_dev=seed_dev)
+            ops.sasrec_encoder_bwd(None, seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad), G["lastLN.weight"],
+                                   G["lastLN.bias"], out=W["contrib"][:n].view(B, S, D), ws=W["ws_bwd"], plan=pb.plan, seed_dev=seed_dev,
+                                   embed_scale=float(D ** 0.5), dP=G["Position.weight"], dU_rows=W["dU_rows"], out_rows=W["g_rows"][0])
+            ops.scatter_add_rows_small(W["g_rows"], W["keys"], self.N + 1, GE, n_regions=3, n_dev=pb.plan.view(torch.int32)[1:2], n_mul=16)
+            return loss
         ops.sasrec_embed_encoder_fwd(E, Ppos, seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"],
                                      plan=pb.plan, seed_dev=seed_dev)
         u2 = W["u"].view(n, D)
@@ -333,7 +349,7 @@ class SASRecEngine:
             dUv = ops.gemm(logits, E[1:])                                    # [M, D]
             ops.scatter_add_rows(dUv, vidx, n, out=W["dU"])                  # back to the [B*S, D] layout (pads zero)
             C[n:].zero_()                                                    # no pos/neg contribution rows in CE mode
-        else:
+        else:   # (compact_rows = False: the criterion over all B*S positions and the sorted scatter-add -- what the large-table engines run)
             loss, _, _, _ = ops.pair_loss_fwd_bwd(u2, E, posf, negf, pb.valid, kind, pb.count, e_off=1, out=(W["dU"], C[n:2 * n], C[2 * n:]))
         ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
                                      self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],

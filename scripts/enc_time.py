@@ -26,7 +26,7 @@ def batch(kind):
     elif kind == "33-48":
         lens = rng.integers(33, 49, B)
     else:
-        lens = np.full(B, 49)
+        lens = np.full(B, int(kind))     # every sequence this long
     seq = np.zeros((B, S), np.int64)
     for b in range(B):
         seq[b, S - lens[b]:] = rng.integers(1, N + 1, lens[b])

@@ -1,6 +1,7 @@
 """gpurun_out/<dir> (rocprofv3 kernel trace of bench.py + FETCH_SIZE / WRITE_SIZE passes of scripts/x2_prof.py + a plain bench line)
--> profiles/<tag>_bench.json, <tag>_bench_kernel_stats.csv, <tag>_score_pmc_traffic.json.
-usage: python scripts/make_profiles.py gpurun_out/v10 r1_v10 [output directory, default profiles/]"""
+-> profiles/<tag>_bench.json, <tag>_bench_kernel_stats.csv, <tag>_pmc_traffic.json.   The input directory is what
+scripts/prof_round.sh leaves (trace/, fetch/, write/, bench.json).
+usage: python scripts/make_profiles.py gpurun_out/r2 r2 [output directory, default profiles/]"""
 import csv, glob, json, os, shutil, sqlite3, subprocess, sys
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,12 +16,14 @@ with open(os.path.join(P, tag + "_bench_kernel_stats.csv"), "w", newline="") as 
     for n, c, t, a, mn, mx in rows:
         w.writerow([n, c, t, round(a, 3), round(100 * t / tot, 2), mn, mx])
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(P, tag + "_bench.json"))
-k = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "scripts", "pmc_traffic.py"), src + "/fetch", src + "/write", "score_", "re_zero"]))
+k = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "scripts", "pmc_traffic.py"), src + "/fetch", src + "/write"]))
+k = {n: v for n, v in k.items() if not n.startswith(("at::", "void at::", "Cijk", "__amd"))}
 main = [n for n in k if n.startswith("score_kernel_reg<64, 28")][0]
 exact = [n for n in k if n.startswith("score_kernel_reg<64, 50")][0]
 total = 2 * k["score_split_k<64>"]["hbm_bytes_per_launch"] + sum(k[n]["hbm_bytes_per_launch"] for n in ("score_bound_k<64>", main, "score_topk_merge_x<64>", exact, "score_topk_merge"))
-out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counters): rocprofv3 --pmc FETCH_SIZE -- python3 scripts/x2_prof.py ; same with --pmc WRITE_SIZE  "
-                    "(20 re_score_topk calls, 22 363 users x 12 101 items, D = 64, K = 50, iid scores)",
+out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counters): rocprofv3 --pmc FETCH_SIZE -- python3 scripts/pmc_step.py ; same with --pmc WRITE_SIZE  "
+                    "(6 fused SASRec steps at the bench shapes launched eagerly, 3 re_score_topk calls of 22 363 users x 12 101 items, D = 64, K = 50, iid scores, "
+                    "3 gathers of 4 Mi rows from a 16 Mi x 64 table)",
        "units": "KB per launch (average over launches)",
        "correction": "gfx950: FETCH_SIZE tallies the 128-B requests of 16-B-per-lane reads at 64 B (MI355X_MICROARCH.md, HBM): hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE",
        "kernels": k,
@@ -33,7 +36,7 @@ out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counte
                    "the split item table streamed once per user block (3 MB x 175 blocks; what misses the XCDs' L2s is served by the Infinity Cache and "
                    "counted here) and the candidates' rows re-read by the merge.  At 0.8 TB/s over the call none of it is what bounds the kernels "
                    "(vector instruction stream and stage barriers, DESIGN.md section 5a)."}}
-json.dump(out, open(os.path.join(P, tag + "_score_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
 for n, c, t, a, mn, mx in rows[:12]:
     print(f"{t/1e3:10.1f} us  calls {c:5d}  avg {a/1e3:8.1f} us  {n[:70]}")
 print("hbm bytes per score call:", total)

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for k in "$@"; do
   out=$root/gpurun_out/pe_$k
   rm -rf $out; mkdir -p $out
-  rocprofv3 --kernel-trace -d $out -o trace -- python3 $root/scripts/enc_time.py --kinds $k > $out/log.txt 2>&1
+  rocprofv3 --kernel-trace -d $out -o trace -- python3 $root/scripts/enc_time.py --kinds $k --B ${ENC_B:-512} > $out/log.txt 2>&1
   echo "== $k: $(grep items $out/log.txt | cut -c1-60)"
   python3 - $out <<'PY'
 import sqlite3, sys, glob

@@ -1,0 +1,155 @@
+"""GPU: the fused SASRec step's compact-row pieces through the C ABI -- the loss head on the plan's rows (re_sasrec_loss_rows)
+and the sort-free dense table gradient (re_scatter_add_rows_small) -- against the all-positions kernels / torch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(B, S, N, seed, full=False):
+    rng = np.random.default_rng(seed)
+    lens = np.full(B, S) if full else np.clip(rng.geometric(1 / 5.9, B) + 1, 1, S)
+    seq = np.zeros((B, S), np.int64)
+    for b in range(B):
+        seq[b, S - lens[b]:] = rng.integers(1, N + 1, lens[b])
+    pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    return tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg))
+
+
+@pytest.mark.parametrize("D,R,n,hot", [(64, 12102, 13000, False), (64, 50, 9000, True), (128, 3000, 4100, False), (64, 12102, 0, False),
+                                       (64, 90000, 20000, False)])
+def test_scatter_small_matches_index_add(D, R, n, hot):
+    from recboard_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    stride = (max(n, 16) + 15) // 16 * 16 + 32
+    keys = torch.zeros((3, stride), dtype=torch.int32, device="cuda")
+    if n:
+        k = torch.randint(0, R, (3, n), device="cuda", generator=g, dtype=torch.int32)
+        if hot:
+            k[:, ::3] = 7                                     # one row takes a third of everything
+        k[0, :5] = 0                                          # padding entries
+        keys[:, :n] = k
+        keys[:, n:] = 5                                       # beyond n: must not be read as contributions
+    G = torch.randn(3, stride, D, device="cuda", generator=g)
+    out = torch.full((R, D), 7.0, device="cuda")
+    ops.scatter_add_rows_small(G, keys, R, out, n_regions=3, region_stride=stride, n=n, padding_idx=0, scale=0.5)
+    ref = torch.zeros(R, D, device="cuda", dtype=torch.float64)
+    if n:
+        kk = keys[:, :n].reshape(-1).long()
+        rows = G[:, :n].reshape(-1, D).double() * 0.5
+        keep = kk != 0
+        ref.index_add_(0, kk[keep], rows[keep])
+    # (fp32 sums of up to 9 000 terms in the hot case: the bound scales with the number of terms)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=2e-3 if hot else 1e-5)
+    assert float(out[0].abs().max()) == 0.0
+    # n from device memory (tiles * 16), and bitwise reproducible
+    if n and n % 16 == 0:
+        nd = torch.tensor([n // 16], dtype=torch.int32, device="cuda")
+        out2 = torch.empty_like(out)
+        ops.scatter_add_rows_small(G, keys, R, out2, n_regions=3, region_stride=stride, n_dev=nd, n_mul=16, padding_idx=0, scale=0.5)
+        assert torch.equal(out, out2)
+    out3 = torch.empty_like(out)
+    ops.scatter_add_rows_small(G, keys, R, out3, n_regions=3, region_stride=stride, n=n, padding_idx=0, scale=0.5)
+    assert torch.equal(out, out3)
+
+
+def test_scatter_small_rejects_what_it_cannot_do():
+    from recboard_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.scatter_add_rows_small(torch.zeros(16, 32, device="cuda"), torch.zeros(16, dtype=torch.int32, device="cuda"), 10,
+                                   torch.zeros(10, 32, device="cuda"))
+    with pytest.raises(RuntimeError):      # past ~100 k rows the sorted path is the one to use
+        ops.scatter_add_rows_small(torch.zeros(16, 64, device="cuda"), torch.zeros(16, dtype=torch.int32, device="cuda"), 1 << 20,
+                                   torch.zeros(1 << 20, 64, device="cuda"))
+
+
+@pytest.mark.parametrize("D,kind,full", [(64, 0, False), (64, 1, False), (128, 0, False), (64, 0, True)])
+def test_loss_rows_matches_all_positions_kernel(D, kind, full):
+    from recboard_amd import ops
+    B, S, N = 96, 50, 500
+    seq, pos, neg = _batch(B, S, N, 5, full)
+    seq[3, 40] = 0                                            # a pad INSIDE a sequence: a row exists, it is not a valid position
+    pos[3, 40] = 0; neg[3, 40] = 0
+    g = torch.Generator(device="cuda").manual_seed(1)
+    U = torch.randn(B * S, D, device="cuda", generator=g)
+    E = torch.randn(N + 1, D, device="cuda", generator=g) * 0.3
+    pb = ops.sasrec_batch_prep(seq, pos, neg, max_tiles=ops.max_tiles(D))
+    NR = ops.sasrec_plan_rows(B, S)
+    dUr = torch.full((NR, D), 9.0, device="cuda")
+    Gr = torch.full((3, NR, D), 9.0, device="cuda")
+    keys = torch.full((3, NR), -7, dtype=torch.int32, device="cuda")
+    loss = ops.sasrec_loss_rows(U, E, pb.seq, pb.pos, pb.neg, pb.plan, kind, pb.count, dUr, Gr, keys, e_off=1)
+    loss2 = ops.sasrec_loss_rows(U, E, pb.seq, pb.pos, pb.neg, pb.plan, kind, pb.count, dUr, Gr, keys, e_off=1)
+    assert torch.equal(loss, loss2)                           # last-workgroup reduction: fixed order
+    n = B * S
+    ref_loss, dU, gp, gn = ops.pair_loss_fwd_bwd(U, E, pos.reshape(-1), neg.reshape(-1), pb.valid, kind, pb.count, e_off=1)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-6 * abs(float(ref_loss))
+    hdr = pb.plan.view(torch.int32)[:8].cpu().numpy()
+    nr = 16 * int(hdr[1])
+    off = int(lib_rowmap_word(B, S))
+    rm = pb.plan.view(torch.int32)[off: off + 2 * nr].view(nr, 2).cpu().numpy()
+    gid = torch.from_numpy(rm[:, 0].astype(np.int64)).cuda()
+    live = gid >= 0
+    gl = gid[live]
+    seqf, posf, negf = seq.reshape(-1), pos.reshape(-1), neg.reshape(-1)
+    # every valid position has exactly one row
+    assert int((seqf != 0).sum()) == int((seqf[gl] != 0).sum())
+    assert torch.equal(dUr[:nr][live], dU[gl])
+    valid = seqf[gl] != 0
+    assert torch.equal(Gr[1, :nr][live][valid], gp[gl][valid]) and torch.equal(Gr[2, :nr][live][valid], gn[gl][valid])
+    k = keys[:, :nr]
+    assert torch.equal(k[0][live].long(), seqf[gl])
+    assert torch.equal(k[1][live].long(), torch.where(valid, posf[gl] + 1, torch.zeros_like(gl)))
+    assert torch.equal(k[2][live].long(), torch.where(valid, negf[gl] + 1, torch.zeros_like(gl)))
+    assert int(k[:, ~live.cpu().numpy()].abs().sum()) == 0 if (~live).any() else True
+
+
+def lib_rowmap_word(B, S):
+    mt = B * ((S + 15) // 16)
+    return (8 + mt + 1) // 2 * 2
+
+
+@pytest.mark.parametrize("D,kind,p", [(64, 0, 0.0), (64, 1, 0.5), (128, 0, 0.2)])
+def test_forward_with_loss_head_matches_forward_then_loss_rows(D, kind, p):
+    """re_sasrec_encoder_fwd_loss == re_sasrec_encoder_fwd + re_sasrec_loss_rows (u and the tape bitwise; the criterion's dots are
+    reduced in another order inside the item: 1e-6)."""
+    from recboard_amd import ops
+    from recboard_amd.sasrec import SASRecEngine
+    B, S, N, L = 64, 50, 300, 2
+    m = SASRecEngine(N, S, D, L, dropout_rate=p, loss="BCE" if kind == 0 else "BPR", seed=3)
+    seq, pos, neg = _batch(B, S, N, 9)
+    pb = m.prepare_batch(seq, pos, neg)
+    P = m.params
+    E, Pp = P["Item.embeddings.weight"].detach(), P["Position.weight"].detach()
+    lw, lb = P["lastLN.weight"].detach(), P["lastLN.bias"].detach()
+    bt = m._block_tensors()
+    NR = ops.sasrec_plan_rows(B, S)
+    Lb = __import__("recboard_amd.lib", fromlist=["load"]).load()
+    tb = Lb.re_sasrec_tape_bytes(B, S, D, L) // 4
+    outs = []
+    for fused in (False, True):
+        u = torch.zeros(B, S, D, device="cuda")
+        tape = torch.zeros(tb, device="cuda")
+        dUr = torch.zeros(NR, D, device="cuda"); Gr = torch.zeros(3, NR, D, device="cuda")
+        keys = torch.zeros(3, NR, dtype=torch.int32, device="cuda")
+        ws = torch.zeros(256, dtype=torch.uint8, device="cuda")
+        if fused:
+            loss = ops.sasrec_encoder_fwd_loss(E, Pp, pb.seq, pb.pos, pb.neg, float(D ** 0.5), bt, lw, lb, L, p, 77, pb.plan, kind, pb.count,
+                                               u, tape, dUr, Gr, keys, ws)
+            loss_b = ops.sasrec_encoder_fwd_loss(E, Pp, pb.seq, pb.pos, pb.neg, float(D ** 0.5), bt, lw, lb, L, p, 77, pb.plan, kind,
+                                                 pb.count, u, tape, dUr, Gr, keys, ws)
+            assert torch.equal(loss, loss_b) and int(ws.view(torch.int64)[0]) == 0
+        else:
+            ops.sasrec_embed_encoder_fwd(E, Pp, pb.seq, float(D ** 0.5), bt, lw, lb, L, p, 77, need_tape=True, out=u, tape=tape, plan=pb.plan)
+            loss = ops.sasrec_loss_rows(u.view(-1, D), E, pb.seq, pb.pos, pb.neg, pb.plan, kind, pb.count, dUr, Gr, keys, e_off=1)
+        outs.append((u, tape, float(loss), dUr, Gr, keys))
+    a, b = outs
+    nr = 16 * int(pb.plan.view(torch.int32)[1])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert abs(a[2] - b[2]) <= 2e-6 * abs(a[2])
+    assert torch.equal(a[5][:, :nr], b[5][:, :nr])
+    assert torch.allclose(a[3][:nr], b[3][:nr], rtol=2e-5, atol=1e-9)
+    live = (a[5][1, :nr] != 0)
+    assert torch.allclose(a[4][1:, :nr][:, live], b[4][1:, :nr][:, live], rtol=2e-5, atol=1e-9)
