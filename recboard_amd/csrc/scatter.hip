@@ -753,7 +753,7 @@ extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64
 //   n comes from device memory (n_dev[0] * n_mul -- e.g. the batch plan's tile count * 16) so that a captured launch follows the batch.
 #define SO_CAP 4096          // match list (LDS): flushed whenever the next 4096-key tile might not fit
 #define SO_NG 8
-#define SO_INF 32         // row loads a lane group keeps in flight
+#define SO_INF 48         // row loads a lane group keeps in flight (a wave tracks 64)
 
 template <int D>
 __global__ __launch_bounds__(256) void scatter_owner_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
@@ -778,7 +778,9 @@ __global__ __launch_bounds__(256) void scatter_owner_k(const float* __restrict__
 
     auto flush = [&]() {
         // group grp takes the list entries j with (m0 + j) % 8 == grp, in increasing j, SO_INF row loads in flight at a time (a hot
-        // row -- the Zipf head: 10 % of a batch -- is hundreds of entries for one workgroup: the loop is a chain of memory round trips)
+        // row -- the Zipf head is 10 % of a batch -- is hundreds of entries for one workgroup: this loop is a chain of memory round
+        // trips, so each trip carries as many loads as the wave's memory counter can track).  Neighbouring entries of the same row
+        // are added in registers first: the adds into the LDS accumulator are read-modify-writes the compiler must keep in order.
         const int j0 = (int)((grp - m0) & (SO_NG - 1));
         for (int jb = j0; jb < cnt; jb += SO_NG * SO_INF) {
             vt v[SO_INF];
@@ -786,9 +788,15 @@ __global__ __launch_bounds__(256) void scatter_owner_k(const float* __restrict__
 #pragma unroll
             for (int u = 0; u < SO_INF; ++u) {
                 const int j = jb + SO_NG * u;
-                const int jj = j < cnt ? j : jb;               // (clamped: a valid entry, its value is not used)
+                const int jj = j < cnt ? j : j0;               // (clamped: a valid entry, its value is not used)
                 rw[u] = j < cnt ? (int)s_row[jj] : -1;
                 v[u] = reinterpret_cast<const vt*>(g + (int64_t)s_idx[jj] * D)[gl];
+            }
+#pragma unroll
+            for (int u = 0; u + 1 < SO_INF; ++u) {
+                const bool same = rw[u] == rw[u + 1];
+                v[u + 1] += same ? v[u] : vt{};
+                rw[u] = same ? -1 : rw[u];
             }
 #pragma unroll
             for (int u = 0; u < SO_INF; ++u) {
@@ -803,44 +811,52 @@ __global__ __launch_bounds__(256) void scatter_owner_k(const float* __restrict__
     };
 
     __syncthreads();
-    for (int q = 0; q < nreg; ++q) {
-        const int32_t* kq = keys + (int64_t)q * stride;
-        for (int64_t base = 0; base < n; base += 4096) {
-            // ---- 16 keys per thread: four coalesced 16-byte loads
-            int kv[16];
+    // The regions are scanned as ONE run of nreg * n keys (n is a multiple of 4 or the tail is handled by element: a 16-byte load
+    // never straddles two regions), 4096 keys per tile, and the next tile's loads are in flight while this one is ranked: the keys
+    // were written by another XCD a moment ago, every tile is a full memory round trip.
+    const uint32_t n32 = (uint32_t)n, total = (uint32_t)nreg * n32;   // (< 2^32: checked by the entry point)
+    const bool vec = (n32 & 3u) == 0;
+    auto region_of = [&](uint32_t v) { return (uint32_t)(v >= n32) + (uint32_t)(v >= 2 * n32) + (uint32_t)(v >= 3 * n32); };   // (nreg <= 4)
+    auto load_tile = [&](uint32_t base, int (&kv)[16]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t i = base + (int64_t)(u * 256 + tid) * 4;
-                int4 k4 = make_int4(-1, -1, -1, -1);
-                if (i + 3 < n) k4 = *reinterpret_cast<const int4*>(kq + i);
-                else {
-                    if (i < n) k4.x = kq[i];
-                    if (i + 1 < n) k4.y = kq[i + 1];
-                    if (i + 2 < n) k4.z = kq[i + 2];
-                }
-                kv[4 * u] = k4.x; kv[4 * u + 1] = k4.y; kv[4 * u + 2] = k4.z; kv[4 * u + 3] = k4.w;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t v = base + (uint32_t)(u * 256 + tid) * 4;
+            int4 k4 = make_int4(-1, -1, -1, -1);
+            if (vec) {
+                if (v < total) { const uint32_t q = region_of(v); k4 = *reinterpret_cast<const int4*>(keys + (int64_t)q * stride + (v - q * n32)); }
+            } else {
+                int* kk = reinterpret_cast<int*>(&k4);
+                for (int e = 0; e < 4; ++e)
+                    if (v + e < total) { const uint32_t q = region_of(v + e); kk[e] = keys[(int64_t)q * stride + (v + e - q * n32)]; }
             }
-            unsigned mask = 0;
+            kv[4 * u] = k4.x; kv[4 * u + 1] = k4.y; kv[4 * u + 2] = k4.z; kv[4 * u + 3] = k4.w;
+        }
+    };
+    int kv[16], kn[16];
+    if (total > 0) load_tile(0, kv);
+    for (uint32_t base = 0; base < total; base += 4096) {
+        if (base + 4096 < total) load_tile(base + 4096, kn);
+        unsigned mask = 0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int64_t k = kv[u];
-                const bool hit = k != padding_idx && k >= 0 && k < R && ((uint32_t)k & (nwg - 1)) == me;
-                mask |= (hit ? 1u : 0u) << u;
-            }
-            const int c = __popc(mask);
-            // ---- exclusive scan of the per-thread counts over the workgroup (thread order = match order inside the tile)
-            int inc = c;
+        for (int u = 0; u < 16; ++u) {
+            const int64_t k = kv[u];
+            const bool hit = k != padding_idx && k >= 0 && k < R && ((uint32_t)k & (nwg - 1)) == me;
+            mask |= (hit ? 1u : 0u) << u;
+        }
+        const int c = __popc(mask);
+        // ---- exclusive scan of the per-thread counts over the workgroup (thread order = match order inside the tile)
+        int inc = c;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += t;
-            }
-            __syncthreads();                        // (previous tile's s_wsum readers are done)
-            if (lane == 63) s_wsum[wid] = inc;
-            __syncthreads();
-            const int tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-            if (tot == 0) continue;                 // (uniform)
-            if (cnt + tot > SO_CAP) {               // (uniform) make room
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        __syncthreads();                        // (previous tile's s_wsum readers are done)
+        if (lane == 63) s_wsum[wid] = inc;
+        __syncthreads();
+        const int tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        if (tot != 0) {                         // (uniform)
+            if (cnt + tot > SO_CAP) {           // (uniform) make room
                 flush();
                 __syncthreads();
             }
@@ -849,14 +865,17 @@ __global__ __launch_bounds__(256) void scatter_owner_k(const float* __restrict__
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 if ((mask >> u) & 1u) {
-                    const int64_t i = base + (int64_t)((u >> 2) * 256 + tid) * 4 + (u & 3);
-                    s_idx[off] = (uint32_t)(q * stride + i);
+                    const uint32_t v = base + (uint32_t)((u >> 2) * 256 + tid) * 4 + (u & 3);
+                    const uint32_t q = region_of(v);
+                    s_idx[off] = (uint32_t)(q * stride) + (v - q * n32);
                     s_row[off] = (uint16_t)((uint32_t)kv[u] >> wsh);
                     ++off;
                 }
             }
             cnt += tot;
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) kv[u] = kn[u];
     }
     __syncthreads();
     flush();
@@ -878,7 +897,7 @@ extern "C" int re_scatter_add_rows_small(const float* g, const int32_t* keys, in
                                          int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
                                          re_stream_t stream) {
     re_clear_error();
-    if (!dW || !g || !keys || R <= 0 || n_regions < 1 || region_stride < 0 || n_host < 0 || (n_dev && n_mul < 1)) return RE_EINVAL;
+    if (!dW || !g || !keys || R <= 0 || n_regions < 1 || n_regions > 4 || region_stride < 0 || n_host < 0 || (n_dev && n_mul < 1)) return RE_EINVAL;
     if (D != 64 && D != 128) return RE_EUNSUPPORTED;
     if ((region_stride & 3) || ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u))
         return RE_EUNSUPPORTED;

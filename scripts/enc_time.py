@@ -4,6 +4,9 @@ import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
+from recboard_amd import lib
+if os.environ.get("RE_LIB_VARIANT"):   # an experimental build of the library (make var / a hand-linked .so next to librecengine.so)
+    lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), os.environ["RE_LIB_VARIANT"])
 from recboard_amd import ops
 from recboard_amd.sasrec import SASRecEngine
 
