@@ -284,6 +284,17 @@ int re_sasrec_encoder_fwd(const float* x0, const float* E, int64_t R, const floa
                           int64_t S, int64_t D, int64_t L, const float* const* block_params, const float* last_w,
                           const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev, const void* plan, int32_t ncu,
                           float* u, void* tape, size_t tape_bytes, int32_t fill_pads, re_stream_t stream);
+/* The encoder's whole training step: re_sasrec_encoder_fwd_loss followed by re_sasrec_encoder_bwd(dU_rows = the head's rows,
+ * dx0_rows = g_rows region 0, dPtab given), with the two item kernels as ONE launch (per work item: forward, criterion, backward)
+ * + the weight-gradient and reduction launches.  Same results, bit for bit.  ws as re_sasrec_encoder_bwd; loss_ws as
+ * re_sasrec_encoder_fwd_loss. */
+int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
+                           const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
+                           const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                           const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
+                           const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
+                           size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
+                           float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,

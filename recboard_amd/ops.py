@@ -510,6 +510,30 @@ def sasrec_encoder_fwd_loss(E, Ptab, seq, pos, neg, scale, block_tensors, last_w
     return loss
 
 
+def sasrec_encoder_step(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, last_b, L, drop_p, seed, plan, kind, count, u, tape,
+                        dU_rows, g_rows, keys, loss_ws, dx0, dP, block_grads, g_last_w, g_last_b, ws, e_off=1, loss=None, seed_dev=None):
+    """Forward + criterion + backward of the encoder per work item in ONE launch, then the weight gradients (re_sasrec_encoder_step):
+    what sasrec_encoder_fwd_loss + sasrec_encoder_bwd(dU_rows=..., out_rows=g_rows[0], dP=...) compute, bit for bit.  -> loss[1]."""
+    _req(E, torch.float32, "E"); _req(Ptab, torch.float32, "Ptab"); _req(seq, torch.int64, "seq"); _req(pos, torch.int64, "pos")
+    _req(neg, torch.int64, "neg"); _req(u, torch.float32, "u"); _req(tape, torch.float32, "tape"); _req(dU_rows, torch.float32, "dU_rows")
+    _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(count, torch.int32, "count"); _req(loss_ws, torch.uint8, "loss_ws")
+    _req(dx0, torch.float32, "dx0"); _req(dP, torch.float32, "dP"); _req(ws, torch.uint8, "ws")
+    B, S = seq.shape
+    R, D = E.shape
+    NR = sasrec_plan_rows(B, S)
+    if dU_rows.numel() != NR * D or g_rows.numel() != 3 * NR * D or keys.numel() != 3 * NR or u.numel() != B * S * D or dx0.numel() != B * S * D:
+        raise ValueError("recengine: sasrec_encoder_step buffer shapes")
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=E.device)
+    tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
+    lib.check(lib.load().re_sasrec_encoder_step(_p(E), R, _p(Ptab), float(scale), _p(seq), _p(pos), _p(neg), B, S, D, L, tp, _p(last_w),
+                                                _p(last_b), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(plan), num_cus(E.device),
+                                                _p(u), _p(tape), tape.numel() * 4, int(e_off), int(kind), _p(count), _p(loss), _p(dU_rows),
+                                                _p(g_rows), _p(keys), _p(loss_ws), loss_ws.numel(), _p(dx0), _p(dP), tg, _p(g_last_w),
+                                                _p(g_last_b), _p(ws), ws.numel(), _stream()), "re_sasrec_encoder_step")
+    return loss
+
+
 def sasrec_plan_rows(B, S):
     """Upper bound of the number of compact rows of a batch plan (re_sasrec_plan_rows)."""
     return int(lib.load().re_sasrec_plan_rows(int(B), int(S)))

@@ -141,6 +141,7 @@ class SASRecEngine:
         if encoder == "fused" and (embedding_dim not in (64, 128) or maxlen > 64 or num_blocks > 4):
             raise NotImplementedError("fused encoder kernels: D = 64 or 128, maxlen <= 64, blocks <= 4 (use encoder='aten')")
         self.encoder = encoder
+        self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
         self.compact_rows = True     # BCE / BPR fused step on the batch plan's compact rows (False: all B*S positions + sorted scatter-add)
         self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
@@ -327,12 +328,19 @@ class SASRecEngine:
         if self.loss_kind != "CE" and self.compact_rows:
             # forward + criterion (one launch), encoder backward, weight gradients, item-table gradient -- all on the plan's compact
             # rows: only rows that exist are read or written, and the table gradient is ONE launch over ~13 k keys (no sort)
-            loss = ops.sasrec_encoder_fwd_loss(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
-                                               W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], e_off=1,
-                                               seed_dev=seed_dev)
-            ops.sasrec_encoder_bwd(None, seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad), G["lastLN.weight"],
-                                   G["lastLN.bias"], out=W["contrib"][:n].view(B, S, D), ws=W["ws_bwd"], plan=pb.plan, seed_dev=seed_dev,
-                                   embed_scale=float(D ** 0.5), dP=G["Position.weight"], dU_rows=W["dU_rows"], out_rows=W["g_rows"][0])
+            if self.fused_item_kernel:
+                loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
+                                               W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
+                                               W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
+                                               G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev)
+            else:
+                loss = ops.sasrec_encoder_fwd_loss(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind,
+                                                   pb.count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], e_off=1,
+                                                   seed_dev=seed_dev)
+                ops.sasrec_encoder_bwd(None, seq, bt, lw, lb, self.L, p, sd, W["tape"], self._block_tensors(A.grad), G["lastLN.weight"],
+                                       G["lastLN.bias"], out=W["contrib"][:n].view(B, S, D), ws=W["ws_bwd"], plan=pb.plan, seed_dev=seed_dev,
+                                       embed_scale=float(D ** 0.5), dP=G["Position.weight"], dU_rows=W["dU_rows"],
+                                       out_rows=W["g_rows"][0])
             ops.scatter_add_rows_small(W["g_rows"], W["keys"], self.N + 1, GE, n_regions=3, n_dev=pb.plan.view(torch.int32)[1:2], n_mul=16)
             return loss
         ops.sasrec_embed_encoder_fwd(E, Ppos, seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"], tape=W["tape"],

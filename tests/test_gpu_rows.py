@@ -153,3 +153,22 @@ def test_forward_with_loss_head_matches_forward_then_loss_rows(D, kind, p):
     assert torch.allclose(a[3][:nr], b[3][:nr], rtol=2e-5, atol=1e-9)
     live = (a[5][1, :nr] != 0)
     assert torch.allclose(a[4][1:, :nr][:, live], b[4][1:, :nr][:, live], rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("D,p", [(64, 0.5), (128, 0.2)])
+def test_one_launch_item_kernel_equals_two_launches(D, p):
+    """re_sasrec_encoder_step (forward + criterion + backward per work item in one launch) against re_sasrec_encoder_fwd_loss +
+    re_sasrec_encoder_bwd: the same parameters after three Adam steps, bit for bit."""
+    from recboard_amd.sasrec import SASRecEngine
+    B, S, N = 96, 50, 700
+    eng = []
+    for fused in (True, False):
+        m = SASRecEngine(N, S, D, 2, dropout_rate=p, loss="BCE", lr=1e-3, weight_decay=1e-6, seed=4)
+        m.fused_item_kernel = fused
+        losses = []
+        for i in range(3):
+            seq, pos, neg = _batch(B, S, N, 30 + i, full=(i == 2))
+            losses.append(float(m.train_step(seq, pos, neg)))
+        eng.append((m, losses))
+    assert eng[0][1] == eng[1][1]
+    assert torch.equal(eng[0][0].arena.data, eng[1][0].arena.data)
