@@ -92,3 +92,24 @@ class BCELoss4Logits(torch.nn.Module):
 
     def forward(self, logits, targets):
         return torch.nn.functional.binary_cross_entropy_with_logits(logits, targets.to(logits.dtype), reduction=self.reduction)
+
+
+def linear(x, weight, bias=None):
+    """x W^T (+ b) on the engine's fp32 MFMA GEMM (re_gemm_f32), differentiable: torch.nn.functional.linear for 2-D x."""
+    y = _R.gemm(x.contiguous(), weight.contiguous(), False, True)
+    return y if bias is None else y + bias
+
+
+class Linear(torch.nn.Module):
+    """Drop-in for torch.nn.Linear(in_features, out_features, bias) on 2-D inputs; forward and both backward products are
+    recengine::gemm launches (nn.Linear in the reference's MLP blocks: DeepFM/main.py:103-124, DCN/main.py:48-69)."""
+
+    def __init__(self, in_features, out_features, bias=True, device=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = torch.nn.Parameter(torch.empty(out_features, in_features, device=device))
+        self.bias = torch.nn.Parameter(torch.zeros(out_features, device=device)) if bias else None
+        torch.nn.init.xavier_normal_(self.weight)
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)

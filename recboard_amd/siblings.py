@@ -1,0 +1,147 @@
+"""Sibling baselines on the engine's torch custom ops (recboard_amd.nn / torch.ops.recengine): the reference's model code shape --
+an nn.Module with `encode` / `fit` / `recommend_from_*` -- with the hot-path operators swapped for the HIP kernels and autograd
+left to do the bookkeeping.  This is the drop-in path a RecBoard model file takes; SASRec / LightGCN / MF-BPR /
+DeepFM additionally have hand-fused engines (sasrec.py, gen.py, deepfm.py).
+
+  DCN     (DCN/main.py:34-190)     multi-field embedding lookup = recengine::gather_rows on ONE concatenated table (+ scatter-add
+                                   gradient), every Linear (MLP blocks, cross weights, fc) = recengine::gemm forward and backward
+  SimGCL  (SimGCL/main.py:34-160)  K propagations = recengine::spmm_csr (symmetric adjacency: the backward is the same kernel),
+                                   BPR over the propagated tables = recengine::bpr_triplet (gathers + dots + criterion fused),
+                                   the two B x B InfoNCE logit matrices = recengine::score_dense, full ranking = score_dense
+Elementwise glue (BatchNorm / ReLU / dropout, the cross layer's x0 * s + b, L2 normalisation, log-softmax of the B x B logits)
+stays with aten: no table, no catalog and no contraction is touched there.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import nn as rnn
+
+
+# ------------------------------------------------------------------------------------------------ DCN
+class CrossInteraction(torch.nn.Module):
+    """x_{i+1} = (x_i w) * x_0 + b   (DCN/main.py:34-46)."""
+
+    def __init__(self, input_dim, device=None):
+        super().__init__()
+        self.weight = rnn.Linear(input_dim, 1, bias=False, device=device)
+        self.bias = torch.nn.Parameter(torch.zeros(input_dim, device=device))
+
+    def forward(self, X_0, X_i):
+        return self.weight(X_i) * X_0 + self.bias
+
+
+class MLPBlock(torch.nn.Module):
+    """Linear -> BatchNorm1d -> ReLU -> Dropout   (DCN/main.py:48-69; DeepFM/main.py:103-124)."""
+
+    def __init__(self, input_dim, output_dim, batch_norm=False, dropout_rate=0.0, device=None):
+        super().__init__()
+        self.linear = rnn.Linear(input_dim, output_dim, device=device)
+        self.bn = torch.nn.BatchNorm1d(output_dim, device=device) if batch_norm else torch.nn.Identity()
+        self.act = torch.nn.ReLU()
+        self.dropout = torch.nn.Dropout(p=dropout_rate)
+
+    def forward(self, x):
+        return self.dropout(self.act(self.bn(self.linear(x))))
+
+
+class DCN(torch.nn.Module):
+    """Deep & Cross Network over F categorical fields (DCN/main.py:72-190).  The F per-field tables are ONE table: field f, id i is
+    row offsets[f] + i (`tables()` gives the reference's per-field views)."""
+
+    def __init__(self, counts, embedding_dim=10, hidden_dims=(400, 400, 400), num_layers=3, batch_norm=False, hidden_dropout_rate=0.0,
+                 device="cuda"):
+        super().__init__()
+        self.counts = list(counts)
+        off = [0]
+        for c in self.counts[:-1]:
+            off.append(off[-1] + c)
+        self.register_buffer("offsets", torch.tensor(off, dtype=torch.int64, device=device))
+        self.embeddings = rnn.Embedding(sum(self.counts), embedding_dim, device=device)
+        d_in = len(self.counts) * embedding_dim
+        dims = [d_in] + list(hidden_dims)
+        self.dnn = torch.nn.Sequential(*[MLPBlock(a, b, batch_norm, hidden_dropout_rate, device) for a, b in zip(dims[:-1], dims[1:])])
+        self.crossnet = torch.nn.ModuleList([CrossInteraction(d_in, device) for _ in range(num_layers)])
+        self.fc = rnn.Linear(d_in + dims[-1], 1, device=device)
+        self.criterion = rnn.BCELoss4Logits(reduction="mean")
+        with torch.no_grad():                                    # DCN.reset_parameters (DCN/main.py:122-131)
+            torch.nn.init.normal_(self.embeddings.weight, std=1e-4)
+
+    def tables(self):
+        return [self.embeddings.weight[o:o + c] for o, c in zip(self.offsets.tolist(), self.counts)]
+
+    def encode(self, x):
+        """x [B, F] int64 field ids -> logits [B, 1]   (DCN/main.py:153-165)."""
+        B = x.shape[0]
+        emb = self.embeddings((x + self.offsets.unsqueeze(0)).reshape(-1)).reshape(B, -1)      # [B, F*D]
+        deep = self.dnn(emb)
+        cross = emb
+        for layer in self.crossnet:
+            cross = layer(emb, cross)
+        return self.fc(torch.cat((deep, cross), dim=-1))
+
+    def fit(self, x, labels):
+        return {"rec_loss": self.criterion(self.encode(x), labels.to(torch.float32).reshape(-1, 1))}
+
+    def recommend_from_pool(self, x):
+        return self.encode(x).sigmoid()
+
+
+# ------------------------------------------------------------------------------------------------ SimGCL
+class SimGCL(torch.nn.Module):
+    """SimGCL (SimGCL/main.py:34-160): LightGCN-style propagation with the layer-wise mean, BPR + L2 regulariser, and an InfoNCE
+    loss between two noise-perturbed propagation views.  adj = (crow, col, val): the symmetric normalised bipartite adjacency as CSR."""
+
+    def __init__(self, num_users, num_items, adj, embedding_dim=64, num_layers=3, eps=0.1, temperature=0.2, device="cuda"):
+        super().__init__()
+        self.U, self.N, self.num_layers, self.eps, self.temperature = num_users, num_items, num_layers, eps, temperature
+        self.user = rnn.Embedding(num_users, embedding_dim, device=device)
+        self.item = rnn.Embedding(num_items, embedding_dim, device=device)
+        with torch.no_grad():
+            torch.nn.init.xavier_uniform_(self.user.weight)
+            torch.nn.init.xavier_uniform_(self.item.weight)
+        crow, col, val = adj
+        self.register_buffer("crow", crow.to(device)); self.register_buffer("col", col.to(device)); self.register_buffer("val", val.to(device))
+        self.criterion = rnn.BPRLoss(reduction="mean")
+        self.ranking_buffer = None
+
+    def _propagate(self, noisy):
+        x = torch.cat((self.user.weight, self.item.weight), dim=0)
+        avg = 0.0
+        for _ in range(self.num_layers):
+            x = rnn.spmm_sym(self.crow, self.col, self.val, x)
+            if noisy:
+                x = x + self.eps * F.normalize(torch.rand_like(x), dim=-1).mul(x.sign())
+            avg = avg + x / self.num_layers
+        return torch.split(avg, (self.U, self.N))
+
+    def encode(self):
+        return self._propagate(False)
+
+    def encode_(self):
+        u, i = self._propagate(True)
+        return F.normalize(u, dim=-1), F.normalize(i, dim=-1)
+
+    def fit(self, users, positives, negatives):
+        """users, positives, negatives: [B] int64 (one negative per positive, the reference's training pipe)."""
+        users, positives, negatives = users.reshape(-1), positives.reshape(-1), negatives.reshape(-1)
+        ue, ie = self.encode()
+        rec_loss = rnn.bpr_triplet(ue.contiguous(), ie.contiguous(), users, positives, negatives)
+        raw = (self.user(users), self.item(positives), self.item(negatives))
+        emb_loss = sum(t.pow(2).sum() for t in raw) / 2 / users.numel()          # criterion.regularize(rtype="l2") / B
+        u1, i1 = self.encode_()
+        u2, i2 = self.encode_()
+        targets = torch.arange(users.numel(), device=users.device)
+        ssl = 0.0
+        for a, b, idx in ((u1, u2, users), (i1, i2, positives)):
+            logits = rnn.score_full(rnn.gather_rows(a.contiguous(), idx), rnn.gather_rows(b.contiguous(), idx)) / self.temperature
+            ssl = ssl + F.cross_entropy(logits, targets)
+        return {"rec_loss": rec_loss, "emb_loss": emb_loss, "ssl_loss": ssl}
+
+    def reset_ranking_buffers(self):
+        with torch.no_grad():
+            ue, ie = self.encode()
+            self.ranking_buffer = (ue.contiguous(), ie.contiguous())
+
+    def recommend_from_full(self, users):
+        ue, ie = self.ranking_buffer
+        return rnn.score_full(rnn.gather_rows(ue, users.reshape(-1)), ie)

@@ -132,6 +132,28 @@ def _(A, B, transA=False, transB=False):
     return A.new_empty((M, N))
 
 
+def _gemm_setup(ctx, inputs, output):
+    A, B, transA, transB = inputs
+    ctx.save_for_backward(A, B)
+    ctx.tA, ctx.tB = bool(transA), bool(transB)
+
+
+def _gemm_bwd(ctx, dC):
+    """C = op(A) op(B):  d op(A) = dC op(B)^T,  d op(B) = op(A)^T dC -- each again ONE recengine::gemm (no transposed copies)."""
+    A, B = ctx.saved_tensors
+    dC = dC.contiguous()
+    G = torch.ops.recengine.gemm
+    dA = dB = None
+    if ctx.needs_input_grad[0]:
+        dA = G(B, dC, ctx.tB, True) if ctx.tA else G(dC, B, False, not ctx.tB)
+    if ctx.needs_input_grad[1]:
+        dB = G(dC, A, True, ctx.tA) if ctx.tB else G(A, dC, not ctx.tA, False)
+    return dA, dB, None, None
+
+
+gemm.register_autograd(_gemm_bwd, setup_context=_gemm_setup)
+
+
 def _score_setup(ctx, inputs, output):
     ctx.save_for_backward(*inputs)
 

@@ -161,6 +161,10 @@ def build(argv_defaults=None):
                 pass
             self.Size = Field("SIZE", tags.SIZE)
 
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
         def forward(self, data, ranking="train"):
             if self.training:
                 return self.fit(data)
@@ -226,9 +230,13 @@ def build(argv_defaults=None):
         def forward(self, logits, targets):
             return F.cross_entropy(logits, targets, reduction=self.reduction)
 
+    def cross_entropy_with_logits(logits, targets, reduction="mean"):
+        return F.cross_entropy(logits, targets, reduction=reduction)
+
     crit = types.ModuleType("freerec.criterions")
     crit.BaseCriterion, crit.BPRLoss, crit.BCELoss4Logits, crit.CrossEntropy4Logits = (
         BaseCriterion, BPRLoss, BCELoss4Logits, CrossEntropy4Logits)
+    crit.cross_entropy_with_logits = cross_entropy_with_logits
     fr.criterions = crit
 
     # ---------------- launcher ----------------

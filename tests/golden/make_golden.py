@@ -15,6 +15,8 @@ Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic
   mfbpr.npz    : MF-BPR/main.py   fit loss + table grads + full scores
   lightgcn.npz : LightGCN/main.py encode/fit (rec_loss, emb_loss) + grads + full scores
   deepfm.npz   : DeepFM/main.py   logits, loss, grads (train-mode BN), eval sigmoid scores
+  dcn.npz      : DCN/main.py      logits, loss, grads (train-mode BN), eval sigmoid scores
+  simgcl.npz   : SimGCL/main.py   fit (rec_loss, emb_loss, ssl_loss at eps = 0: the noise is torch.rand_like) + grads + full scores
 """
 import importlib.util
 import os
@@ -269,6 +271,91 @@ def gen_deepfm():
     print(f"deepfm: loss={float(loss):.6f}")
 
 
+def gen_dcn():
+    torch.manual_seed(1)
+    fr, ref = import_ref("DCN", "ref_dcn", dict(hidden_dims="32,24", batch_norm=True, hidden_dropout_rate=0.0, num_layers=3, embedding_dim=10))
+    counts = [23, 41, 7, 7, 2, 3, 2, 9, 17, 29]
+    F = fr.data.fields.Field
+    fields = [F(f"F{i}", "EMBED", *(("USER", "ID") if i == 0 else ("ITEM", "ID") if i == 1 else ()), count=c)
+              for i, c in enumerate(counts)]
+    fields.append(F("LABEL", "LABEL"))
+    ds = fr.data.datasets.RecDataSet(fields)
+    model = ref.DCN(ds)
+    g = torch.Generator().manual_seed(13)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "embeddings" in n:
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    B = 32
+    data = {f: torch.randint(0, f.count, (B, 1), generator=g) for f in model.input_fields}
+    labels = torch.randint(0, 2, (B, 1), generator=g)
+    data[model.Label] = labels
+    out = {"in/x": torch.cat([data[f] for f in model.input_fields], 1).numpy(), "in/labels": labels.numpy(),
+           "cfg/counts": np.asarray(counts, np.int64), "cfg/num_layers": np.int64(ref.cfg.num_layers)}
+    out.update(sd_np(model))
+    model.train()
+    logits = model.encode(data)
+    out["out/train_logits"] = logits.detach().numpy().copy()
+    loss = model.criterion(logits, labels)
+    loss.backward()
+    out["out/rec_loss"] = loss.detach().numpy()
+    out.update(grads_np(model))
+    out.update({"post/" + k: v.detach().numpy().copy() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k})
+    out = {k: v for k, v in out.items() if "input_fields" not in k and "/User." not in k and "/Item." not in k and "/fields." not in k}
+    for i, f in enumerate(model.input_fields):
+        out[f"table/{i}"] = f.embeddings.weight.detach().numpy().copy()
+        out[f"gtable/{i}"] = f.embeddings.weight.grad.numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        out["out/eval_scores"] = model(data, ranking="pool").numpy()
+    np.savez_compressed(os.path.join(HERE, "dcn.npz"), **out)
+    print(f"dcn: loss={float(loss):.6f}")
+
+
+def gen_simgcl():
+    torch.manual_seed(1)
+    U, N, B = 30, 40, 16
+    g = torch.Generator().manual_seed(9)
+    edges = set()
+    while len(edges) < 150:
+        edges.add((int(torch.randint(0, U, (1,), generator=g)), int(torch.randint(0, N, (1,), generator=g))))
+    adj = sym_norm_adj(U, N, sorted(edges))
+    fr, ref = import_ref("SimGCL", "ref_simgcl", dict(eps=0.0))      # (the perturbation is torch.rand_like: eps = 0 makes fit deterministic)
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)], adj=adj)
+    model = ref.SimGCL(ds)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(0.3 * torch.randn(p.shape, generator=g))
+    users = torch.randint(0, U, (B, 1), generator=g)
+    ipos = torch.randint(0, N, (B, 1), generator=g)
+    ineg = torch.randint(0, N, (B, 1), generator=g)
+    data = {model.User: users, model.IPos: ipos, model.INeg: ineg}
+    out = {"in/users": users.numpy(), "in/pos": ipos.numpy(), "in/neg": ineg.numpy(),
+           "in/adj_crow": adj.crow_indices().numpy(), "in/adj_col": adj.col_indices().numpy(), "in/adj_val": adj.values().numpy(),
+           "cfg/num_layers": np.int64(ref.cfg.num_layers), "cfg/temperature": np.float64(ref.cfg.temperature),
+           "cfg/weight_decay": np.float64(ref.cfg.weight_decay), "cfg/lambda": np.float64(getattr(ref.cfg, "lambda_", getattr(ref.cfg, "ssl_weight", 0.0)) or 0.0)}
+    out.update({"param/User.embeddings.weight": model.User.embeddings.weight.detach().numpy().copy(),
+                "param/Item.embeddings.weight": model.Item.embeddings.weight.detach().numpy().copy()})
+    model.train()
+    losses = model(data)
+    loss = losses["rec_loss"] + losses["emb_loss"] + losses["ssl_loss"]     # (unit weights: every term's gradient is exercised)
+    loss.backward()
+    for k in ("rec_loss", "emb_loss", "ssl_loss"):
+        out["out/" + k] = losses[k].detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        ue, ie = model.encode()
+        model.reset_ranking_buffers()
+        scores = model(data, ranking="full")
+    out["out/userEmbds"], out["out/itemEmbds"], out["out/scores"] = ue.numpy(), ie.numpy(), scores.numpy()
+    np.savez_compressed(os.path.join(HERE, "simgcl.npz"), **out)
+    print("simgcl: " + " ".join(f"{k}={float(v):.6f}" for k, v in losses.items()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     for loss in ("BCE", "BPR", "CE"):
@@ -277,6 +364,8 @@ if __name__ == "__main__":
     gen_mfbpr()
     gen_lightgcn()
     gen_deepfm()
+    gen_dcn()
+    gen_simgcl()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,96 @@
+"""GPU: sibling baselines on the torch custom ops (recboard_amd.siblings) against golden vectors made by importing the reference's
+DCN/main.py and SimGCL/main.py (tests/golden/make_golden.py): forward values, losses and every parameter gradient."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def test_dcn_matches_reference_forward_and_gradients():
+    from recboard_amd.siblings import DCN
+    g = np.load(os.path.join(GOLD, "dcn.npz"))
+    counts = g["cfg/counts"].tolist()
+    m = DCN(counts, embedding_dim=10, hidden_dims=(32, 24), num_layers=int(g["cfg/num_layers"]), batch_norm=True)
+    sd = m.state_dict()
+    with torch.no_grad():
+        m.embeddings.weight.copy_(torch.cat([_t(g[f"table/{i}"]) for i in range(len(counts))]))
+        for k in sd:
+            if k.startswith(("dnn.", "crossnet.", "fc.")):
+                sd[k].copy_(_t(g["param/" + k]).view(sd[k].shape))
+    x, labels = _t(g["in/x"]), _t(g["in/labels"])
+    m.train()
+    logits = m.encode(x)
+    torch.testing.assert_close(logits, _t(g["out/train_logits"]), rtol=1e-4, atol=1e-6)
+    loss = m.criterion(logits, labels.to(torch.float32))
+    assert abs(float(loss) - float(g["out/rec_loss"])) <= 1e-5 * abs(float(g["out/rec_loss"]))
+    loss.backward()
+    for k, p in m.named_parameters():
+        if k == "embeddings.weight":
+            ref = torch.cat([_t(g[f"gtable/{i}"]) for i in range(len(counts))])
+        else:
+            ref = _t(g["grad/" + k]).view(p.shape)
+        torch.testing.assert_close(p.grad, ref, rtol=2e-4, atol=2e-7, msg=k)
+    # the train-mode forward updated the BatchNorm running statistics as the reference's did
+    for i in range(2):
+        torch.testing.assert_close(m.dnn[i].bn.running_mean, _t(g[f"post/dnn.{i}.bn.running_mean"]), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(m.dnn[i].bn.running_var, _t(g[f"post/dnn.{i}.bn.running_var"]), rtol=1e-5, atol=1e-7)
+    m.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(m.recommend_from_pool(x), _t(g["out/eval_scores"]), rtol=1e-4, atol=1e-6)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DCN(counts, device="cpu").encode(torch.zeros(2, len(counts), dtype=torch.long))
+
+
+def test_simgcl_matches_reference_losses_and_gradients():
+    from recboard_amd.siblings import SimGCL
+    g = np.load(os.path.join(GOLD, "simgcl.npz"))
+    U, N = g["param/User.embeddings.weight"].shape[0], g["param/Item.embeddings.weight"].shape[0]
+    adj = (_t(g["in/adj_crow"]), _t(g["in/adj_col"]), _t(g["in/adj_val"]))
+    m = SimGCL(U, N, adj, embedding_dim=g["param/User.embeddings.weight"].shape[1], num_layers=int(g["cfg/num_layers"]), eps=0.0,
+               temperature=float(g["cfg/temperature"]))
+    with torch.no_grad():
+        m.user.weight.copy_(_t(g["param/User.embeddings.weight"]))
+        m.item.weight.copy_(_t(g["param/Item.embeddings.weight"]))
+    users, pos, neg = (_t(g["in/" + k]).reshape(-1) for k in ("users", "pos", "neg"))
+    m.train()
+    losses = m.fit(users, pos, neg)
+    for k in ("rec_loss", "emb_loss", "ssl_loss"):
+        assert abs(float(losses[k]) - float(g["out/" + k])) <= 2e-5 * abs(float(g["out/" + k])), k
+    (losses["rec_loss"] + losses["emb_loss"] + losses["ssl_loss"]).backward()
+    torch.testing.assert_close(m.user.weight.grad, _t(g["grad/User.embeddings.weight"]), rtol=2e-4, atol=2e-6)
+    torch.testing.assert_close(m.item.weight.grad, _t(g["grad/Item.embeddings.weight"]), rtol=2e-4, atol=2e-6)
+    m.eval()
+    ue, ie = m.encode()
+    torch.testing.assert_close(ue, _t(g["out/userEmbds"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ie, _t(g["out/itemEmbds"]), rtol=1e-5, atol=1e-6)
+    m.reset_ranking_buffers()
+    torch.testing.assert_close(m.recommend_from_full(users), _t(g["out/scores"]), rtol=1e-5, atol=1e-6)
+
+
+def test_linear_on_engine_gemm_matches_torch_linear_both_ways():
+    from recboard_amd import nn as rnn
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(37, 50, device="cuda", generator=g, requires_grad=True)
+    lin = rnn.Linear(50, 24, device="cuda")
+    ref = torch.nn.Linear(50, 24, device="cuda")
+    with torch.no_grad():
+        ref.weight.copy_(lin.weight); ref.bias.copy_(lin.bias.normal_(generator=g))
+    y = lin(x)
+    y.pow(2).sum().backward()
+    gx, gw, gb = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    x.grad = None
+    yr = ref(x)
+    yr.pow(2).sum().backward()
+    torch.testing.assert_close(y, yr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx, x.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gw, ref.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gb, ref.bias.grad, rtol=1e-4, atol=1e-4)

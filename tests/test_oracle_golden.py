@@ -265,3 +265,26 @@ def test_published_benchmark_rows_satisfy_the_metric_restatements_identities():
             loss = run["train"]["LOSS"]
             bound = 2 * np.log(2) if name.endswith("SASRec") else np.log(2)     # BCE(pos) + BCE(neg)  /  BPR
             assert 0.0 < loss < bound, (name, loss)
+
+
+def test_sibling_oracles_reproduce_reference_fixtures():
+    """oracle/siblings.py (DCN logits, SimGCL losses and tables) against the vectors made by the reference's DCN/main.py, SimGCL/main.py."""
+    import torch
+    from oracle import siblings
+    g = np.load(os.path.join(G, "dcn.npz"))
+    nf = len(g["cfg/counts"])
+    T = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    dnn = [(T(f"param/dnn.{i}.linear.weight"), T(f"param/dnn.{i}.linear.bias"), T(f"param/dnn.{i}.bn.weight"), T(f"param/dnn.{i}.bn.bias"))
+           for i in range(2)]
+    cross = [(T(f"param/crossnet.{l}.weight.weight"), T(f"param/crossnet.{l}.bias")) for l in range(int(g["cfg/num_layers"]))]
+    logits = siblings.dcn_logits([T(f"table/{i}") for i in range(nf)], T("in/x"), dnn, cross, (T("param/fc.weight"), T("param/fc.bias")))
+    np.testing.assert_allclose(logits.numpy(), g["out/train_logits"], rtol=1e-5, atol=1e-6)
+    s = np.load(os.path.join(G, "simgcl.npz"))
+    S = lambda k: torch.from_numpy(s[k])  # noqa: E731
+    rec, emb, ssl, ue, ie = siblings.simgcl_losses(S("param/User.embeddings.weight"), S("param/Item.embeddings.weight"), S("in/adj_crow"),
+                                                   S("in/adj_col"), S("in/adj_val"), S("in/users").reshape(-1), S("in/pos").reshape(-1),
+                                                   S("in/neg").reshape(-1), int(s["cfg/num_layers"]), float(s["cfg/temperature"]))
+    for v, k in ((rec, "rec_loss"), (emb, "emb_loss"), (ssl, "ssl_loss")):
+        assert abs(float(v) - float(s["out/" + k])) <= 1e-5 * abs(float(s["out/" + k])), k
+    np.testing.assert_allclose(ue.numpy(), s["out/userEmbds"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ie.numpy(), s["out/itemEmbds"], rtol=1e-5, atol=1e-6)
