@@ -369,6 +369,18 @@ int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_
  * loss[0] = mean(row_loss), and logits <- (softmax(x_m) - onehot(labels[m])) / M, the gradient w.r.t. the logits. */
 int re_ce_rows(float* logits, int64_t M, int64_t N, int64_t ld, const int64_t* labels, float* row_loss, float* loss,
                re_stream_t stream);
+/* The same cross entropy without the [M, N] matrix (K5, SASRec/main.py:217-219 at catalog sizes where M x N does not fit or is not
+ * worth its bytes): the caller walks the catalog in column chunks [col0, col0 + Nc) and materialises ONE chunk of logits at a time.
+ *   re_ce_chunk_stats  folds a chunk into the running row statistics (online log-sum-exp: rowmax, rowsum = sum exp(x - rowmax)) and
+ *                      records tgt[m] = x[m, labels[m] - col0] when the label lies in the chunk; first != 0 starts the statistics.
+ *   re_ce_chunk_loss   after the last chunk: row_loss[m] = log(rowsum) + rowmax - tgt, loss[0] = mean.
+ *   re_ce_chunk_grad   rewrites a RECOMPUTED chunk in place to (softmax - onehot) / M, the gradient w.r.t. that chunk's logits. */
+int re_ce_chunk_stats(const float* logits, int64_t M, int64_t Nc, int64_t ld, int64_t col0, const int64_t* labels, int first,
+                      float* rowmax, float* rowsum, float* tgt, re_stream_t stream);
+int re_ce_chunk_loss(const float* rowmax, const float* rowsum, const float* tgt, const int64_t* labels, int64_t M, int64_t N,
+                     float* row_loss, float* loss, re_stream_t stream);
+int re_ce_chunk_grad(float* logits, int64_t M, int64_t Nc, int64_t ld, int64_t col0, const int64_t* labels, const float* rowmax,
+                     const float* rowsum, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * General fp32 GEMM on the matrix cores: C[M,N] = alpha * op(A)[M,K] op(B)[K,N] + beta * C (+ bias[n]) (+ ReLU).

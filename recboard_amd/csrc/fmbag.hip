@@ -197,3 +197,93 @@ extern "C" int re_ce_rows(float* logits, int64_t M, int64_t N, int64_t ld, const
     hipLaunchKernelGGL(sum_mean_k, dim3(1), dim3(256), 0, s, (const float*)row_loss, M, 1.0f / (float)M, loss);
     return re_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The same cross entropy WITHOUT the [M, N] matrix: the catalog is walked in column chunks, the caller materialises one chunk of
+// logits [M, Nc] at a time (one GEMM), and the row statistics are carried between chunks (online log-sum-exp):
+//   pass 1, per chunk:  (rowmax, rowsum) <- merge with the chunk's (max, sum exp(x - max)); tgt[m] = x[m, y_m] when y_m is in the chunk
+//   finish:             row_loss = log(rowsum) + rowmax - tgt;  loss = mean
+//   pass 2, per chunk (logits recomputed by the same GEMM):  x <- (exp(x - rowmax) / rowsum - [col == y_m]) / M   in place
+// Memory is M x Nc instead of M x N (a 1 M-item catalog at M = 4 000 would be 16 GB of logits); the price is one more GEMM per chunk.
+__global__ __launch_bounds__(256) void ce_chunk_stats_k(const float* __restrict__ logits, int64_t Nc, int64_t ld, int64_t col0,
+                                                        const int64_t* __restrict__ labels, int first, float* __restrict__ rowmax,
+                                                        float* __restrict__ rowsum, float* __restrict__ tgt) {
+    __shared__ float red[4];
+    const float* x = logits + (int64_t)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int64_t i = tid; i < Nc; i += 256) mx = fmaxf(mx, x[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int64_t i = tid; i < Nc; i += 256) s += expf(x[i] - mx);
+    s = re_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        s = ((red[0] + red[1]) + red[2]) + red[3];
+        if (!first) {
+            const float m0 = rowmax[blockIdx.x], s0 = rowsum[blockIdx.x];
+            const float m1 = fmaxf(m0, mx);
+            s = s0 * expf(m0 - m1) + s * expf(mx - m1);
+            mx = m1;
+        }
+        rowmax[blockIdx.x] = mx;
+        rowsum[blockIdx.x] = s;
+        const int64_t y = labels[blockIdx.x] - col0;
+        if (y >= 0 && y < Nc) tgt[blockIdx.x] = x[y];
+        else if (first) tgt[blockIdx.x] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_chunk_loss_k(const float* __restrict__ rowmax, const float* __restrict__ rowsum, const float* __restrict__ tgt,
+                                                       const int64_t* __restrict__ labels, int64_t M, int64_t N, float* __restrict__ row_loss) {
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+        const int64_t y = labels[m];
+        row_loss[m] = (y >= 0 && y < N) ? logf(rowsum[m]) + rowmax[m] - tgt[m] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_chunk_grad_k(float* __restrict__ logits, int64_t Nc, int64_t ld, int64_t col0,
+                                                       const int64_t* __restrict__ labels, const float* __restrict__ rowmax,
+                                                       const float* __restrict__ rowsum, float inv_m) {
+    float* x = logits + (int64_t)blockIdx.x * ld;
+    const float mx = rowmax[blockIdx.x], inv_s = 1.0f / rowsum[blockIdx.x];
+    const int64_t y = labels[blockIdx.x] - col0;
+    for (int64_t i = threadIdx.x; i < Nc; i += 256) {
+        float p = expf(x[i] - mx) * inv_s;
+        if (i == y) p -= 1.0f;
+        x[i] = p * inv_m;
+    }
+}
+
+extern "C" int re_ce_chunk_stats(const float* logits, int64_t M, int64_t Nc, int64_t ld, int64_t col0, const int64_t* labels, int first,
+                                 float* rowmax, float* rowsum, float* tgt, re_stream_t stream) {
+    re_clear_error();
+    if (!logits || !labels || !rowmax || !rowsum || !tgt || M <= 0 || Nc <= 0 || ld < Nc || col0 < 0) return RE_EINVAL;
+    hipLaunchKernelGGL(ce_chunk_stats_k, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, logits, Nc, ld, col0, labels, first, rowmax, rowsum, tgt);
+    return re_launch_status();
+}
+
+extern "C" int re_ce_chunk_loss(const float* rowmax, const float* rowsum, const float* tgt, const int64_t* labels, int64_t M, int64_t N,
+                                float* row_loss, float* loss, re_stream_t stream) {
+    re_clear_error();
+    if (!rowmax || !rowsum || !tgt || !labels || !row_loss || !loss || M <= 0 || N <= 0) return RE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_chunk_loss_k, dim3(re_grid(M, 256)), dim3(256), 0, s, rowmax, rowsum, tgt, labels, M, N, row_loss);
+    hipLaunchKernelGGL(sum_mean_k, dim3(1), dim3(256), 0, s, (const float*)row_loss, M, 1.0f / (float)M, loss);
+    return re_launch_status();
+}
+
+extern "C" int re_ce_chunk_grad(float* logits, int64_t M, int64_t Nc, int64_t ld, int64_t col0, const int64_t* labels, const float* rowmax,
+                                const float* rowsum, re_stream_t stream) {
+    re_clear_error();
+    if (!logits || !labels || !rowmax || !rowsum || M <= 0 || Nc <= 0 || ld < Nc || col0 < 0) return RE_EINVAL;
+    hipLaunchKernelGGL(ce_chunk_grad_k, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, logits, Nc, ld, col0, labels, rowmax, rowsum,
+                       1.0f / (float)M);
+    return re_launch_status();
+}

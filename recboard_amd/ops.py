@@ -750,6 +750,42 @@ def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, bias=N
     return out
 
 
+class CEStats:
+    """Running row statistics of a chunked cross entropy (re_ce_chunk_*): rowmax, rowsum, target logit per row."""
+
+    def __init__(self, M, device):
+        self.rowmax, self.rowsum, self.tgt = (torch.empty(M, dtype=torch.float32, device=device) for _ in range(3))
+        self.first = True
+
+
+def ce_chunk_stats(logits, col0, labels, st):
+    """Fold the logits chunk [M, Nc] (catalog columns [col0, col0 + Nc)) into the running statistics `st` (re_ce_chunk_stats)."""
+    _req(logits, torch.float32, "logits", contiguous=False); _req(labels, torch.int64, "labels")
+    M, Nc = logits.shape
+    lib.check(lib.load().re_ce_chunk_stats(_p(logits), M, Nc, logits.stride(0), int(col0), _p(labels), int(st.first), _p(st.rowmax),
+                                           _p(st.rowsum), _p(st.tgt), _stream()), "re_ce_chunk_stats")
+    st.first = False
+
+
+def ce_chunk_loss(st, labels, N):
+    """mean over the rows of logsumexp - target logit, after the last chunk (re_ce_chunk_loss) -> loss[1]."""
+    M = labels.numel()
+    row_loss = torch.empty(M, dtype=torch.float32, device=labels.device)
+    loss = torch.empty(1, dtype=torch.float32, device=labels.device)
+    lib.check(lib.load().re_ce_chunk_loss(_p(st.rowmax), _p(st.rowsum), _p(st.tgt), _p(labels), M, int(N), _p(row_loss), _p(loss), _stream()),
+              "re_ce_chunk_loss")
+    return loss
+
+
+def ce_chunk_grad_(logits, col0, labels, st):
+    """In place: a recomputed logits chunk -> d(mean CE)/d(that chunk's logits) (re_ce_chunk_grad)."""
+    _req(logits, torch.float32, "logits", contiguous=False)
+    M, Nc = logits.shape
+    lib.check(lib.load().re_ce_chunk_grad(_p(logits), M, Nc, logits.stride(0), int(col0), _p(labels), _p(st.rowmax), _p(st.rowsum), _stream()),
+              "re_ce_chunk_grad")
+    return logits
+
+
 def ce_rows_(logits, labels):
     """In place: logits [M, N] -> d(mean CE)/d(logits); returns loss [1]  (re_ce_rows)."""
     _req(logits, torch.float32, "logits"); _req(labels, torch.int64, "labels")

@@ -142,6 +142,7 @@ class SASRecEngine:
             raise NotImplementedError("fused encoder kernels: D = 64 or 128, maxlen <= 64, blocks <= 4 (use encoder='aten')")
         self.encoder = encoder
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
+        self.ce_logits_bytes = 1 << 28  # loss='CE': at most this many bytes of logits at a time (more: the catalog is walked in chunks)
         self.compact_rows = True     # BCE / BPR fused step on the batch plan's compact rows (False: all B*S positions + sorted scatter-add)
         self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
@@ -349,12 +350,37 @@ class SASRecEngine:
         posf, negf = pos.reshape(-1), neg.reshape(-1)
         C = W["contrib"]
         if self.loss_kind == "CE":
-            # SASRec/main.py:216-219: logits = u[valid] E[1:]^T, mean CE against IPos -- three fp32 MFMA GEMMs + one row kernel
+            # SASRec/main.py:216-219: logits = u[valid] E[1:]^T, mean CE against IPos -- fp32 MFMA GEMMs + row kernels.  The catalog is
+            # walked in column chunks of at most `ce_logits_bytes` of logits: one chunk (the usual case: 190 MB at Beauty's shapes, 0.07 %
+            # of the HBM) is the materialised form; more chunks recompute each chunk's logits in the backward instead of keeping M x N.
             vidx = torch.nonzero(pb.valid).reshape(-1).contiguous()          # (host sync: the CE shapes depend on the batch)
             Uv = ops.gather_rows(u2, vidx)                                   # [M, D]
-            logits = ops.gemm(Uv, E[1:], transB=True)                        # [M, N]
-            loss = ops.ce_rows_(logits, posf[vidx].contiguous())             # logits <- d loss / d logits
-            dUv = ops.gemm(logits, E[1:])                                    # [M, D]
+            M, Nitems = vidx.numel(), self.N
+            labels = posf[vidx].contiguous()
+            Nc = max(1, min(Nitems, self.ce_logits_bytes // (4 * max(M, 1))))
+            if Nc >= Nitems:
+                logits = ops.gemm(Uv, E[1:], transB=True)                    # [M, N]
+                loss = ops.ce_rows_(logits, labels)                          # logits <- d loss / d logits
+                dUv = ops.gemm(logits, E[1:])                                # [M, D]
+                chunks = [(0, logits)]
+            else:
+                st = ops.CEStats(M, self.device)
+                buf = torch.empty((M, Nc), dtype=torch.float32, device=self.device)
+                for c0 in range(0, Nitems, Nc):
+                    lc = ops.gemm(Uv, E[1 + c0:1 + min(c0 + Nc, Nitems)], transB=True, out=buf[:, :min(Nc, Nitems - c0)])
+                    ops.ce_chunk_stats(lc, c0, labels, st)
+                loss = ops.ce_chunk_loss(st, labels, Nitems)
+                # backward, chunk by chunk: logits recomputed, turned into their gradient in place, folded into dU and into the
+                # chunk's rows of the table gradient (the scatter-add below then ACCUMULATES the encoder's contribution rows onto them)
+                dUv = torch.zeros((M, D), dtype=torch.float32, device=self.device)
+                GE[0].zero_()
+                for c0 in range(0, Nitems, Nc):
+                    c1 = min(c0 + Nc, Nitems)
+                    lc = ops.gemm(Uv, E[1 + c0:1 + c1], transB=True, out=buf[:, :c1 - c0])
+                    ops.ce_chunk_grad_(lc, c0, labels, st)
+                    ops.gemm(lc, E[1 + c0:1 + c1], beta=1.0, out=dUv)
+                    ops.gemm(lc, Uv, transA=True, out=GE[1 + c0:1 + c1])
+                chunks = None
             ops.scatter_add_rows(dUv, vidx, n, out=W["dU"])                  # back to the [B*S, D] layout (pads zero)
             C[n:].zero_()                                                    # no pos/neg contribution rows in CE mode
         else:   # (compact_rows = False: the criterion over all B*S positions and the sorted scatter-add -- what the large-table engines run)
@@ -362,8 +388,9 @@ class SASRecEngine:
         ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
                                      self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],
                                      out=C[:n].view(B, S, D), ws=W["ws_bwd"], plan=pb.plan, seed_dev=seed_dev)
-        ops.scatter_add_rows(C, pb.rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"])
-        if self.loss_kind == "CE":
+        chunked = self.loss_kind == "CE" and chunks is None
+        ops.scatter_add_rows(C, pb.rows_all, self.N + 1, 0, 1.0, out=GE, ws=W["ws_sc"], accumulate=chunked)
+        if self.loss_kind == "CE" and not chunked:
             ops.gemm(logits, Uv, transA=True, beta=1.0, out=GE[1:])          # dE[1:] += dlogits^T u[valid]
         return loss
 

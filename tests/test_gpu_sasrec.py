@@ -271,3 +271,27 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
         assert torch.equal(i1, i2) and torch.equal(v1, v2)
     finally:
         dist.destroy_process_group()
+
+
+def test_ce_in_catalog_chunks_equals_materialised_ce():
+    """loss='CE' with the catalog walked in column chunks (re_ce_chunk_*: online log-sum-exp, logits recomputed in the backward)
+    against the single-chunk form that materialises [M, N]: same loss and same parameters after two steps."""
+    from recboard_amd.sasrec import SASRecEngine
+    N, B, S = 700, 24, 50
+    rng = np.random.default_rng(3)
+    seq = rng.integers(1, N + 1, (B, S))
+    for b in range(B):
+        seq[b, : rng.integers(0, S - 1)] = 0
+    pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    batch = tuple(torch.from_numpy(a).cuda() for a in (seq, pos, np.zeros_like(pos)))
+    eng = []
+    for limit in (1 << 28, 4 * 600 * 96):          # one chunk; chunks of ~96 columns (the last one ragged)
+        m = SASRecEngine(N, S, 64, 2, dropout_rate=0.0, loss="CE", lr=1e-3, seed=2)
+        m.ce_logits_bytes = limit
+        eng.append((m, float(m.train_step(*batch))))
+    assert abs(eng[0][1] - eng[1][1]) <= 2e-6 * abs(eng[0][1])
+    # the gradients of the step (compared before Adam: its first step turns the rounding noise of exactly-zero gradients -- the key
+    # bias -- into +-lr)
+    ga, gb = eng[0][0].arena.views(eng[0][0].arena.grad), eng[1][0].arena.views(eng[1][0].arena.grad)
+    for k in ga:
+        torch.testing.assert_close(gb[k], ga[k], rtol=1e-4, atol=1e-7, msg=k)
