@@ -51,6 +51,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         assert loss in ("BCE", "BPR")
         # the fused encoder kernels cover D = 64 and 128 (BASELINE config 5 is D = 128); any other width runs the block stack on torch
         self.encoder = encoder or ("fused" if embedding_dim in (64, 128) and maxlen <= 64 and num_blocks <= 4 else "aten")
+        self.compact_rows = True     # fused encoder: the step on the batch plan's compact rows (criterion in the forward kernel)
         self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
         self.p_drop, self.loss_kind = dropout_rate, loss
@@ -123,7 +124,8 @@ class SASRecLargeTableEngine(SASRecEngine):
             return self._blocks(x0, (seq == 0).unsqueeze(-1)), self.E[1:]
 
     def _grads(self, seq, pos, neg, aux, sd, seed_dev=None, table=None):
-        """Forward + backward: encoder gradients into the arena, the 3*B*S item-gradient contribution rows into C.  -> (loss, C).
+        """Forward + backward: encoder gradients into the arena, the item-gradient contribution rows C with their destination rows
+        (0 = none).  -> (loss, C, rows).
         `table` (default: the item table) is what seq / pos / neg index: the sharded engine passes its batch-local table."""
         A, D = self.arena, self.D
         B, S = seq.shape
@@ -133,6 +135,21 @@ class SASRecLargeTableEngine(SASRecEngine):
         p = self.p_drop if self.training else 0.0
         Ppos = self.params["Position.weight"]
         kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
+        if self.encoder == "fused" and self.compact_rows and table is None:
+            # SASRecEngine's compact-row step minus the dense table gradient: forward + criterion + backward of every work item in one
+            # launch; what comes back are the 3 x NR contribution rows with their destination keys (0 = none) for the row-sparse Adam
+            W = self._buffers(B, S)
+            G = A.views(A.grad)
+            lw, lb = self.params["lastLN.weight"].detach(), self.params["lastLN.bias"].detach()
+            W["keys"].zero_()                                   # rows beyond this batch's plan must read "no contribution"
+            loss = ops.sasrec_encoder_step(E, Ppos.detach(), seq, pos, neg, float(D ** 0.5), self._block_tensors(), lw, lb, self.L, p, sd,
+                                           aux.plan, kind, count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
+                                           W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
+                                           G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev)
+            if "keys64" not in W:
+                W["keys64"] = torch.zeros(W["keys"].numel(), dtype=torch.int64, device=self.device)
+            W["keys64"].copy_(W["keys"].view(-1))
+            return loss, W["g_rows"].view(-1, D), W["keys64"]
         if self.encoder == "fused":
             # the same launches as SASRecEngine's fused step, minus the dense scatter-add: fused embedding + encoder forward (tape),
             # criterion forward + backward, encoder backward with the embedding backward fused in (contribution rows, position gradient)
@@ -148,7 +165,7 @@ class SASRecLargeTableEngine(SASRecEngine):
             ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
                                          self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],
                                          out=C[:n].view(B, S, D), ws=W["ws_bwd"], plan=aux.plan, seed_dev=seed_dev)
-            return loss, C
+            return loss, C, aux.rows_all
         # embedding front end (engine kernel, no autograd node: its backward is re_sasrec_embed_bwd below)
         x0 = ops.sasrec_embed(E, Ppos.detach(), seq, float(D ** 0.5), p, sd, seed_dev=seed_dev).requires_grad_(True)
         A.grad.zero_()
@@ -161,18 +178,18 @@ class SASRecLargeTableEngine(SASRecEngine):
         u.backward(dU.view(B, S, D))                                      # encoder parameter gradients + d x0
         C[:n].copy_(x0.grad.reshape(n, D))
         ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, A.view(A.grad, "Position.weight"), seed_dev=seed_dev)
-        return loss, C
+        return loss, C, aux.rows_all
 
     def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
         """One step; gradients of the item table exist only as 3*B*S contribution rows."""
         A = self.arena
         if aux is None:
             aux = self.prepare_batch(seq, pos, neg)
-        loss, C = self._grads(seq, pos, neg, aux, self._step_seed())
+        loss, C, rows = self._grads(seq, pos, neg, aux, self._step_seed())
         if grad_hook is not None:
             grad_hook(A.grad)
         A.step += 1
-        ops.sparse_adam_rows(C, aux.rows_all, self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
+        ops.sparse_adam_rows(C, rows, self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
                              padding_idx=0)
         ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
         return loss.squeeze(0)
@@ -188,19 +205,20 @@ class SASRecLargeTableEngine(SASRecEngine):
         z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
 
         def body():
-            loss, C = self._grads(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state)
+            loss, C, rows = self._grads(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state)
             if with_adam:
-                ops.sparse_adam_rows_dev(C, pb.rows_all, self.E, self.Em, self.Ev, hyper, self.betas[0], self.betas[1], 1e-8, self.wd,
+                ops.sparse_adam_rows_dev(C, rows, self.E, self.Em, self.Ev, hyper, self.betas[0], self.betas[1], 1e-8, self.wd,
                                          padding_idx=0)
                 ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
-            return loss, C
+            return loss, C, rows
 
         # warm-up on a side stream with an all-padding batch (touches no table row; the arena is restored afterwards)
         keep = [t.clone() for t in (A.data, A.m, A.v, A.grad)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1])
+            pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                                       max_tiles=self._max_tiles())
             pb.count.fill_(1)
             for _ in range(3):
                 body()
@@ -208,10 +226,10 @@ class SASRecLargeTableEngine(SASRecEngine):
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            loss, C = body()
+            loss, C, rows = body()
         for t, k in zip((A.data, A.m, A.v, A.grad), keep):
             t.copy_(k)
-        return dict(graph=graph, blob=blob, state=state, loss=loss, C=C, rows=pb.rows_all)
+        return dict(graph=graph, blob=blob, state=state, loss=loss, C=C, rows=rows)
 
     def train_step_graph(self, seq, pos, neg, grad_hook=None):
         A = self.arena
@@ -223,7 +241,7 @@ class SASRecLargeTableEngine(SASRecEngine):
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1])
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles())
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:
@@ -336,7 +354,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
         # positives / negatives are rows n+1.. and 2n+1.. of the batch-local table (the criterion adds e_off = 1 to the 0-based ids);
         # the embedding front end, the encoder and the criterion run on it unchanged (fused kernels or the torch block stack)
-        loss, C = self._grads(seq_l, (ar - 1 + n).view(B, S), (ar - 1 + 2 * n).view(B, S), aux, sd, table=T)
+        loss, C, _ = self._grads(seq_l, (ar - 1 + n).view(B, S), (ar - 1 + 2 * n).view(B, S), aux, sd, table=T)
         if self.world > 1:
             C.mul_(1.0 / self.world)                 # the loss of the global batch is the mean of the ranks' losses
             dist.all_reduce(A.grad, op=dist.ReduceOp.AVG, group=self.group)

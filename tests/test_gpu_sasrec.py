@@ -191,7 +191,7 @@ def test_large_table_engine_first_step_equals_dense_engine(D):
     dense = SASRecEngine(N, S, D, 2, dropout_rate=0.0, loss="BCE", lr=1e-2, seed=5, encoder="fused")   # (the same encoder kernels: Adam
     large = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.0, loss="BCE", lr=1e-2, seed=5)           #  amplifies rounding differences)
     assert large.encoder == "fused"          # D = 64 and 128 both run the fused encoder kernels
-    dense.compact_rows = False               # the large engine's criterion walks all positions: compare like with like
+    assert large.compact_rows and dense.compact_rows   # both run the compact-row item kernel (criterion inside): the same roundings
     large.load_state_dict(dense.state_dict())
     ld = dense.train_step(*batch)
     ll = large.train_step(*batch)
@@ -237,6 +237,7 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
         rng = np.random.default_rng(77)
         kw = dict(dropout_rate=0.0, lr=1e-2, weight_decay=1e-4, seed=6)
         large = SASRecLargeTableEngine(N, S, D, 2, table_init="counter", **kw)
+        large.compact_rows = False     # the sharded step runs the criterion over all positions of its batch-local table: compare like with like
         shard = SASRecShardedEngine(N, S, D, 2, dedup=False, **kw)
         dd = SASRecShardedEngine(N, S, D, 2, **kw)        # the default: distinct rows only, gradient rows pre-summed per sender
         fx = SASRecShardedEngine(N, S, D, 2, capacity_factor=1.0, **kw)   # the sync-free form: owner bucketing on the device (re_route_bucket)
