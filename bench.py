@@ -327,6 +327,8 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if hasattr(model, "check_handover"):
+        model.check_handover()          # (split long sequences: no hand-over time-out during the timed region)
     ms = dt / args.steps * 1e3
     value = world * cfg["B"] * args.steps / dt
 

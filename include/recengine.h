@@ -220,10 +220,14 @@ int re_route_bucket(const int64_t* idx, int64_t n, int64_t R, int64_t G, int64_t
  *   (k = b_k, v = b_v) and enter the softmax analytically (one virtual key with multiplicity), forward and backward.
  *   Optional: seq_out / pos_out / neg_out receive copies of the batch (static buffers of a captured step); state (DEVICE
  *   uint32[4]) = { seed, 0, bits(lr / (1 - beta1^step)), bits(1 / sqrt(1 - beta2^step)) } -- `state` doubles as `seed_dev` of the dropout entry points and, from word 2, as `hyper` of re_adam_step_dev.
- *   pos / neg may be NULL (evaluation: only the plan is wanted); then valid / count / rows_all rows 1, 2 are not written. */
+ *   pos / neg may be NULL (evaluation: only the plan is wanted); then valid / count / rows_all rows 1, 2 are not written.
+ *   split_long != 0: a sequence of 3 - 4 tiles becomes TWO work items (its first two tiles / the rest) that run in two workgroups at
+ *   once and hand k, v (forward) and the partial dK, dV (backward) over through the tape -- the launch lasts as long as its largest
+ *   item.  Only done when every item of the plan still gets a workgroup of its own (<= ncu items); needs a tape whose flag words
+ *   (the tail of re_sasrec_tape_bytes) are zero before the first launch -- every launch leaves them zero -- i.e. training launches. */
 size_t re_sasrec_plan_bytes(int64_t B, int64_t S);
 int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
-                         int32_t max_tiles, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid, int32_t* count,
+                         int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid, int32_t* count,
                          int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
                          double beta1, double beta2, re_stream_t stream);
 

@@ -58,6 +58,8 @@ class Coach:
             bsz = len(data["User"])
             tot += loss * bsz
             n += bsz
+        if hasattr(self.model, "check_handover"):
+            self.model.check_handover()     # (split long sequences: the halves' hand-over flags; the loss read below syncs anyway)
         return {"LOSS": float(tot / max(n, 1))}
 
     def _graphable(self):

@@ -96,14 +96,14 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {
         using C = EC<128>;
-        const size_t ldsb = (size_t)(7 * C::BUF + 2 * C::PBUF) * sizeof(float);
+        const size_t ldsb = (size_t)(5 * C::BUF + 2 * C::PBUF + 2 * C::PRE) * sizeof(float);
         auto kf = enc_bwd_k<128>;
         if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(kf, dim3(grid), dim3(C::NT), ldsb, s, dU, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, (const float*)tape, T, plan, dx0,
                            gtape, slab, seed_dev, dPtab ? 1 : 0, scale, dU_rows ? 1 : 0, dx0_rows);
     } else {
         using C = EC<64>;
-        const size_t ldsb = (size_t)(5 * C::BUF + 2 * C::PBUF) * sizeof(float);
+        const size_t ldsb = (size_t)(5 * C::BUF + 2 * C::PBUF + 2 * C::PRE) * sizeof(float);
         auto kf = enc_bwd_k<64>;
         if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(kf, dim3(grid), dim3(C::NT), ldsb, s, dU, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, (const float*)tape, T, plan, dx0,

@@ -115,8 +115,8 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
     float* b4 = b3 + C::BUF;
     float* sP = b4 + C::BUF;
     float* sD = sP + C::PBUF;
-    float* bK0 = sD + C::PBUF;                 // prefix k / v tiles of a chained part (allocated only where parts can chain: MAXT < 4)
-    float* bV0 = bK0 + C::BUF;
+    float* bK0 = sD + C::PBUF;                 // prefix k / v tiles (32 rows) of a chained part / the second half of a split sequence
+    float* bV0 = bK0 + C::PRE;
     __shared__ float s_mean[C::ROWS], s_rstd[C::ROWS];
     __shared__ float s_ppad[C::ROWS], s_w[C::ROWS], s_cpad[C::ROWS];   // virtual pad key: prob of one copy, total kept weight, dS
     __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS];
@@ -138,11 +138,14 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
         // queries also attend to the earlier rows (prefix key tiles k, v from the tape), and what they contribute to those rows' dK,
         // dV is left on the gradient tape for the earlier part to add.
         const int nsub = C::MAXT < 4 ? (whole.nt + C::MAXT - 1) / C::MAXT : 1;
+        const bool split_lo = whole.kind == 2, split_hi = whole.kind == 3;   // halves of a sequence split over two workgroups (enc_common.h)
+        float* tflags = const_cast<float*>(tape) + T.off_FLAGS;
+        const int64_t ferr = enc_plan_max_tiles(B, S) * EP_FLAG_WORDS;
         for (int hs = nsub - 1; hs >= 0; --hs) {
         const EncItem it = EncItem{whole.tile0 + hs * C::MAXT, whole.nt - hs * C::MAXT < C::MAXT ? whole.nt - hs * C::MAXT : C::MAXT, whole.kind};
-        const int npre = C::MAXT < 4 ? hs * C::MAXT : 0;     // prefix key tiles
-        const bool has_succ = C::MAXT < 4 && hs + 1 < nsub;  // a later part left partial dK / dV for these rows
-        const int64_t prow0 = (int64_t)whole.tile0 * 16;     // compact row of the sequence's first row
+        const int npre = split_hi ? 2 : (C::MAXT < 4 ? hs * C::MAXT : 0);     // prefix key tiles
+        const bool has_succ = split_lo || (C::MAXT < 4 && hs + 1 < nsub);    // a later part leaves partial dK / dV for these rows
+        const int64_t prow0 = (int64_t)(whole.tile0 - (split_hi ? 2 : 0)) * 16;   // compact row of the sequence's first row
         if (hs + 1 < nsub) __syncthreads();                  // (a full barrier: the later part's gradient-tape stores have completed)
         const bool first_part = k == 0 && hs == nsub - 1;    // the workgroup's first flush of its vector-gradient slab
         const int nt = it.nt, nrows = 16 * nt;
@@ -272,12 +275,17 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
             BWREQ(wc, W.in_w + 2 * D * D);      // Wv
             // ---- E. attention: V, P; Pd = P * mask
             tile_commit<D>(b1, T0, nrows, tid);   // V  (X1's last readers, phase C, are behind the barrier above)
-            if (C::MAXT < 4 && npre) {            // the prefix rows' k, v of this block (tape; written by the forward)
-                TileRegs<D> TP;
-                tile_fetch<D>(TP, tp + T.off_V + prow0 * D, 16 * npre, tid);
-                tile_commit<D>(bV0, TP, 16 * npre, tid);
-                tile_fetch<D>(TP, tp + T.off_K + prow0 * D, 16 * npre, tid);
-                tile_commit<D>(bK0, TP, 16 * npre, tid);
+            if (npre) {                           // the prefix rows' k, v of this block (tape; written by the forward)
+                if (split_hi) {                   // (by the other half's workgroup, with device-scope stores: read the same way)
+                    tile_load_coh<D>(bV0, tp + T.off_V + prow0 * D, 16 * npre, tid);
+                    tile_load_coh<D>(bK0, tp + T.off_K + prow0 * D, 16 * npre, tid);
+                } else {
+                    TileRegs<D> TP;
+                    tile_fetch<D>(TP, tp + T.off_V + prow0 * D, 16 * npre, tid);
+                    tile_commit<D>(bV0, TP, 16 * npre, tid);
+                    tile_fetch<D>(TP, tp + T.off_K + prow0 * D, 16 * npre, tid);
+                    tile_commit<D>(bK0, TP, 16 * npre, tid);
+                }
             }
             if (tid < C::ROWS) { s_ppad[tid] = ST.x; s_w[tid] = ST.y; }
             tile_fetch<D>(T0, tp + T.off_K + row0 * D, nrows, tid);
@@ -305,7 +313,7 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
             ENC_MARK(g_bwd_marks, mk); ++mk;
             // dV = Pd^T dO; d b_v through the virtual pad key: sum_i w_i dO_i
             gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b2[row * C::LS + col] = v; }, npre);
-            if (C::MAXT < 4 && npre)              // what these rows' queries add to the PREFIX rows' dV (-> b4, free until phase F)
+            if (npre)                             // what these rows' queries add to the PREFIX rows' dV (-> b4, free until phase F)
                 gemm_ttx_pre<D>(sD, b3, lane, wr, strip, it, npre, [&](int row, float v) { b4[row * C::LS + col] = v; });
             accV[2] = colsum_w<D>(b3, s_w, tid, nrows);
             enc_sync();
@@ -317,11 +325,16 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
                 sD[row * C::PLS + key] = (p != 0.f) ? v * (pd / p) : 0.f;
             }, bV0, npre);
             float* gpre = gtape + (int64_t)l * EG_NMAT * NR * D + prow0 * D;   // the prefix rows of the gradient tape
-            if (C::MAXT < 4 && npre) tile_store<D>(b4, gpre + 5 * NR * D, 16 * npre, tid);          // partial dV of the prefix rows
-            if (has_succ) tile_add_global<D>(b2, gp + 5 * NR * D, nrows, tid);                      // + what the later part left for these rows
+            if (npre) {                                                                             // partial dV of the prefix rows
+                if (split_hi) tile_store_coh<D>(b4, gpre + 5 * NR * D, 16 * npre, tid);
+                else tile_store<D>(b4, gpre + 5 * NR * D, 16 * npre, tid);
+            }
+            if (has_succ && !split_lo) tile_add_global<D>(b2, gp + 5 * NR * D, nrows, tid);         // + what the later part left for these rows
             enc_sync();
-            accV[2] += colsum<D>(b2, tid, nrows);
-            tile_store<D>(b2, gp + 5 * NR * D, nrows, tid);
+            if (!split_lo) {   // (a split sequence's first half adds the other workgroup's partials after phase F, under the flag)
+                accV[2] += colsum<D>(b2, tid, nrows);
+                tile_store<D>(b2, gp + 5 * NR * D, nrows, tid);
+            }
             ENC_MARK(g_bwd_marks, mk); ++mk;
             // dS = P (dP - rowsum(dP P)) / sqrt(D), the virtual pad key included in the row sum
             if (r_e < nrows) {
@@ -365,13 +378,29 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
             enc_sync();
             ENC_MARK(g_bwd_marks, mk); ++mk;
             gemm_ttx<D>(sD, b3, lane, wr, strip, it, [&](int row, float v) { b1[row * C::LS + col] = v; }, npre);
-            if (C::MAXT < 4 && npre)              // ... and to the prefix rows' dK (-> bV0: the prefix v is no longer needed)
+            if (npre)                             // ... and to the prefix rows' dK (-> bV0: the prefix v is no longer needed)
                 gemm_ttx_pre<D>(sD, b3, lane, wr, strip, it, npre, [&](int row, float v) { bV0[row * C::LS + col] = v; });
             accV[0] = colsum<D>(b4, tid, nrows);
             tile_store<D>(b4, gp + 3 * NR * D, nrows, tid);
             enc_sync();
-            if (C::MAXT < 4 && npre) tile_store<D>(bV0, gpre + 4 * NR * D, 16 * npre, tid);         // partial dK of the prefix rows
-            if (has_succ) {
+            if (npre) {                                                                             // partial dK of the prefix rows
+                if (split_hi) {
+                    tile_store_coh<D>(bV0, gpre + 4 * NR * D, 16 * npre, tid);
+                    __syncthreads();   // (with vmcnt(0): both partial tiles of this block have left this CU)
+                    if (tid == 0) enc_flag_set(tflags, prow0 / 16, 4 + l);
+                } else {
+                    tile_store<D>(bV0, gpre + 4 * NR * D, 16 * npre, tid);
+                }
+            }
+            if (split_lo) {   // the second half's partial dK, dV for these rows: published by its workgroup at the end of ITS phase F
+                if (tid == 0) enc_flag_wait(tflags, row0 / 16, 4 + l, ferr);
+                __syncthreads();
+                tile_add_coh<D>(b1, gp + 4 * NR * D, nrows, tid);
+                tile_add_coh<D>(b2, gp + 5 * NR * D, nrows, tid);
+                enc_sync();
+                accV[2] += colsum<D>(b2, tid, nrows);
+                tile_store<D>(b2, gp + 5 * NR * D, nrows, tid);
+            } else if (has_succ) {
                 tile_add_global<D>(b1, gp + 4 * NR * D, nrows, tid);
                 enc_sync();
             }

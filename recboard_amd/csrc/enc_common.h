@@ -39,6 +39,7 @@ struct EC {
     static constexpr int PLS = 64 + 4;                // row stride of the [ROWS][64] probability tiles (a sequence has at most 64 keys)
     static constexpr int KPT = 64 / TPR;              // softmax phases: keys per thread
     static constexpr int BUF = ROWS * LS;
+    static constexpr int PRE = 32 * LS;               // a prefix key tile pair (the first half of a split / chained sequence: 32 rows)
     static constexpr int PBUF = ROWS * PLS;
     static constexpr int KS = D / 4;                  // MFMA steps of a contraction over D
     static constexpr int CG = NT / D;                 // column-sum phases: row groups ...
@@ -65,6 +66,7 @@ struct SasrecParams {
 //   then scratch of the plan kernel.   MT = B * ceil(S / 16) bounds the number of tiles.
 #define EP_HDR 8
 #define EP_PW 64   // row width of the saved probabilities: a sequence has at most 64 keys
+#define EP_FLAG_WORDS 8   // per tile: [l] forward k, v of block l published, [4 + l] backward dK, dV partials of block l published
 struct EncPlan {
     const int* hdr;
     const int* items;
@@ -87,7 +89,7 @@ __host__ __device__ inline EncPlan enc_plan_view(const void* plan, int64_t B, in
 //   SA, SF : [NR][2] (mean, rstd)   PP : [NR][2] (probability of one virtual pad key, total kept weight)
 // then XL [NR][D] (input of lastLN) and SL [NR][2].  NR = 16 * MT.
 struct EncTape {
-    int64_t per_block, off_X, off_A, off_Q, off_K, off_V, off_O, off_X1, off_Y, off_HR, off_P, off_SA, off_SF, off_PP, off_XL, off_SL, total;
+    int64_t per_block, off_X, off_A, off_Q, off_K, off_V, off_O, off_X1, off_Y, off_HR, off_P, off_SA, off_SF, off_PP, off_XL, off_SL, off_FLAGS, total;
 };
 __host__ __device__ inline EncTape enc_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L) {
     EncTape t;
@@ -109,7 +111,8 @@ __host__ __device__ inline EncTape enc_tape_layout(int64_t B, int64_t S, int64_t
     t.per_block = o;
     t.off_XL = L * o;
     t.off_SL = t.off_XL + act;
-    t.total = t.off_SL + nr * 2;
+    t.off_FLAGS = t.off_SL + nr * 2;                                  // hand-over flags of split sequences (EP_FLAG_WORDS per tile) + one error word
+    t.total = t.off_FLAGS + enc_plan_max_tiles(B, S) * EP_FLAG_WORDS + 16;
     return t;
 }
 // ---- gradient tape written by the backward for the weight-gradient kernel: per block six [NR][D] arrays
@@ -195,6 +198,11 @@ __device__ __forceinline__ void ld4(float* f, const float* p) {
 }
 
 // ---- item decode ------------------------------------------------------------------------------------------------------
+// kind 0: tiles of short sequences (power-of-two slots)   1: one whole long sequence (nt tiles)
+// kind 2 / 3: the FIRST two tiles / the remaining tiles of a long sequence SPLIT over two workgroups (re_sasrec_batch_prep with
+// split_long; only when every item of the plan gets a workgroup of its own, so both halves are resident at once).  The second half
+// attends to the first half's keys: per block, the first half publishes its k, v (forward) and the second half its partial
+// dK, dV for the first half's rows (backward) through the tape, with a flag per block.  Only TWO parts ever exist (S <= 64).
 struct EncItem {
     int tile0, nt, kind;
 };
@@ -205,6 +213,47 @@ __device__ __forceinline__ EncItem enc_item(const EncPlan& P, int wi) {
 // the work items of one workgroup: item k of workgroup b is b + k * grid on even rounds, (k + 1) * grid - 1 - b on odd ones
 // (items are sorted by size, largest first: the snake order pairs a workgroup's large item with a small one)
 __device__ __forceinline__ int enc_item_of(int k, int bid, int grid) { return (k & 1) ? (k + 1) * grid - 1 - bid : k * grid + bid; }
+
+__device__ __forceinline__ int enc_item_npre(const EncItem& it) { return it.kind == 3 ? 2 : 0; }   // prefix key tiles of a second half
+
+// ---- hand-over between the two workgroups of a split sequence.  They may sit on different XCDs, whose L2s are not coherent for
+// ordinary accesses inside a kernel: the handed-over tiles and the flags go through device-scope (sc1) accesses, which are.
+// Producer: tile stores -> workgroup barrier with vmcnt(0) -> one flag store.  Consumer: one thread polls the flag (bounded: a
+// producer that never comes -- it cannot, both are resident -- would otherwise hang the GPU; the error word is set instead),
+// barrier, tile loads.  The consumer clears the flag after use: the tape is reusable by the next launch.
+__device__ __forceinline__ void enc_flag_set(float* tape_flags, int64_t tile, int word) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(tape_flags) + tile * EP_FLAG_WORDS + word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void enc_flag_wait(float* tape_flags, int64_t tile, int word, int64_t err_word) {
+    unsigned* f = reinterpret_cast<unsigned*>(tape_flags) + tile * EP_FLAG_WORDS + word;
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 21)) {   // ~1 s
+            __hip_atomic_store(reinterpret_cast<unsigned*>(tape_flags) + err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int D>
+__device__ __forceinline__ void tile_store_coh(const float* tile, float* g, int nrows, int tid) {
+    using C = EC<D>;
+    for (int f = tid; f < nrows * D; f += C::NT)
+        __hip_atomic_store(g + f, tile[(f / D) * C::LS + (f % D)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int D>
+__device__ __forceinline__ void tile_load_coh(float* tile, const float* g, int nrows, int tid) {
+    using C = EC<D>;
+    for (int f = tid; f < nrows * D; f += C::NT)
+        tile[(f / D) * C::LS + (f % D)] = __hip_atomic_load(g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int D>
+__device__ __forceinline__ void tile_add_coh(float* tile, const float* g, int nrows, int tid) {
+    using C = EC<D>;
+    for (int f = tid; f < nrows * D; f += C::NT)
+        tile[(f / D) * C::LS + (f % D)] += __hip_atomic_load(g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // fills s_gid (b * S + s or -1), s_first (virtual pad keys of the row's sequence), s_pad (1 = pad or dummy row) for the item's rows
 template <int D>

@@ -69,7 +69,7 @@ static int enc_fwd_launch_d(const float* x0, const SeEmbed& em, const int64_t* s
                             int grid, int fill_pads, hipStream_t s) {
     using C = EC<D>;
     const EncTape T = enc_tape_layout(B, S, D, L);
-    const size_t ldsb = (size_t)(5 * C::BUF + C::PBUF + (C::MAXT < 4 ? 2 * C::BUF : 0)) * sizeof(float);
+    const size_t ldsb = (size_t)(5 * C::BUF + C::PBUF + 2 * C::PRE) * sizeof(float);
     if (tape) {
         auto k = enc_fwd_k<D, true>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
@@ -116,7 +116,7 @@ static int enc_fwd_loss_launch_d(const SeEmbed& em, const int64_t* seq, int64_t 
                                  const EncHead& H, hipStream_t s) {
     using C = EC<D>;
     const EncTape T = enc_tape_layout(B, S, D, L);
-    const size_t ldsb = (size_t)(5 * C::BUF + C::PBUF + (C::MAXT < 4 ? 2 * C::BUF : 0)) * sizeof(float);
+    const size_t ldsb = (size_t)(5 * C::BUF + C::PBUF + 2 * C::PRE) * sizeof(float);
     auto k = enc_fwd_loss_k<D>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::NT), ldsb, s, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, plan, H, seed_dev);

@@ -57,8 +57,8 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
     float* bK = bQ + C::BUF;
     float* bV = bK + C::BUF;
     float* sP = bV + C::BUF;
-    float* bK0 = sP + C::PBUF;                 // prefix k / v tiles of a chained part (allocated only where parts can chain: MAXT < 4)
-    float* bV0 = bK0 + C::BUF;
+    float* bK0 = sP + C::PBUF;                 // prefix k / v tiles (32 rows) of a chained part / the second half of a split sequence
+    float* bV0 = bK0 + C::PRE;
     __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS], s_start[C::ROWS];
     __shared__ float s_w[C::ROWS];
     __shared__ int s_item[HEAD ? C::ROWS : 1], s_pos[HEAD ? C::ROWS : 1], s_neg[HEAD ? C::ROWS : 1];   // loss head: table rows of the item's rows (0 = none)
@@ -82,11 +82,16 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
         // A sequence with more rows than the LDS holds (MAXT tiles; only at D = 128) is taken in CHAINED parts: the first MAXT tiles
         // as an item of their own, then the later rows with the earlier ones as PREFIX key tiles -- their k, v of every block are on
         // the tape, written by this same workgroup a moment ago (causality: the earlier rows never depend on the later ones).
-        const int nsub = C::MAXT < 4 ? (whole.nt + C::MAXT - 1) / C::MAXT : 1;   // (D = 64 holds every sequence: no chaining code at all)
+        // (whole long items of more than MAXT tiles exist only at D = 128; the halves of a SPLIT sequence -- kinds 2, 3 -- are items of
+        //  their own in two workgroups and hand k, v over through the tape under flags)
+        const int nsub = C::MAXT < 4 ? (whole.nt + C::MAXT - 1) / C::MAXT : 1;
+        const bool split_lo = whole.kind == 2, split_hi = whole.kind == 3;
+        float* tflags = TRAIN ? tape + T.off_FLAGS : nullptr;
+        const int64_t ferr = enc_plan_max_tiles(B, S) * EP_FLAG_WORDS;
         for (int hs = 0; hs < nsub; ++hs) {
         const EncItem it = EncItem{whole.tile0 + hs * C::MAXT, whole.nt - hs * C::MAXT < C::MAXT ? whole.nt - hs * C::MAXT : C::MAXT, whole.kind};
-        const int npre = C::MAXT < 4 ? hs * C::MAXT : 0;     // prefix key tiles
-        const int64_t prow0 = (int64_t)whole.tile0 * 16;     // compact row of the sequence's first row
+        const int npre = split_hi ? 2 : (C::MAXT < 4 ? hs * C::MAXT : 0);     // prefix key tiles
+        const int64_t prow0 = (int64_t)(whole.tile0 - (split_hi ? 2 : 0)) * 16;   // compact row of the sequence's first row
         if (hs > 0) __syncthreads();                         // (a full barrier: the previous part's tape stores have completed)
         const int nrows = 16 * it.nt;
         const int64_t row0 = (int64_t)it.tile0 * 16;
@@ -163,7 +168,7 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
             const SasrecBlockParams Wn = P.blk[more ? l + 1 : l];   // the NEXT block's weights: requested two or more phases before use
             par_fetch<D>(PR, Wn, tid);                  // (unconditional: the last block re-reads its own -- a branch here hides the loads from the wait counting)
             TileRegs<D> TK0, TV0;
-            if (C::MAXT < 4 && npre) {   // this block's k, v of the prefix rows (tape)
+            if (npre && !split_hi) {   // this block's k, v of the prefix rows (tape; written by this workgroup a moment ago)
                 tile_fetch<D>(TK0, tape + (int64_t)l * T.per_block + T.off_K + prow0 * D, 16 * npre, tid);
                 tile_fetch<D>(TV0, tape + (int64_t)l * T.per_block + T.off_V + prow0 * D, 16 * npre, tid);
             }
@@ -193,21 +198,38 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
                 gemm_rows<D>(bX, wc, lane, wr, it.nt, [&](int row, float v) { bV[row * C::LS + col] = v + bv; });
                 FWREQ(wc, W.w2);                    // W2
                 if (TRAIN) tile_store<D>(bA, tp + T.off_A + row0 * D, nrows, tid);
-                if (C::MAXT < 4 && npre) {
+                if (npre && !split_hi) {
                     tile_commit<D>(bK0, TK0, 16 * npre, tid);
                     tile_commit<D>(bV0, TV0, 16 * npre, tid);
                 }
             }
             enc_sync();
             ENC_MARK(g_fwd_marks, mk); ++mk;
+            if (TRAIN && split_hi) {   // the first half's k, v of this block: published by its workgroup right after ITS projections
+                if (tid == 0) enc_flag_wait(tflags, prow0 / 16, l, ferr);
+                __syncthreads();
+                tile_load_coh<D>(bK0, tp + T.off_K + prow0 * D, 32, tid);
+                tile_load_coh<D>(bV0, tp + T.off_V + prow0 * D, 32, tid);
+                enc_sync();
+            }
             // ---- 3. scores = q k^T / sqrt(D) over the item's (row tile, key tile) pairs
             gemm_pairs<D>(bQ, bK, lane, wave, it, [&](int row, int key, float v) { sP[row * C::PLS + key] = v * inv_sqrt_d; }, bK0, npre);
             if (TRAIN) {
                 tile_store<D>(bQ, tp + T.off_Q + row0 * D, nrows, tid);
-                tile_store<D>(bK, tp + T.off_K + row0 * D, nrows, tid);
-                tile_store<D>(bV, tp + T.off_V + row0 * D, nrows, tid);
+                if (split_lo) {   // (device-scope stores: the second half's workgroup may sit on another XCD)
+                    tile_store_coh<D>(bK, tp + T.off_K + row0 * D, nrows, tid);
+                    tile_store_coh<D>(bV, tp + T.off_V + row0 * D, nrows, tid);
+                } else {
+                    tile_store<D>(bK, tp + T.off_K + row0 * D, nrows, tid);
+                    tile_store<D>(bV, tp + T.off_V + row0 * D, nrows, tid);
+                }
             }
-            enc_sync();
+            if (TRAIN && split_lo) {
+                __syncthreads();   // (with vmcnt(0): the tiles have left this CU)
+                if (tid == 0) enc_flag_set(tflags, row0 / 16, l);
+            } else {
+                enc_sync();
+            }
             ENC_MARK(g_fwd_marks, mk); ++mk;
             // ---- softmax over the keys of the same sequence with j <= i (causal; explicit pad rows ARE keys), plus the virtual
             //      pad key in front of the sequence (multiplicity first, score q.b_k/sqrt(D), value b_v); dropout on the probabilities

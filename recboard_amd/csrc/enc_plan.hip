@@ -36,7 +36,7 @@ __device__ __forceinline__ void pl_sync(bool lds_only) {
 }
 
 __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
-                                                             const int64_t* __restrict__ neg, int B, int S, int ncu, int max_tiles,
+                                                             const int64_t* __restrict__ neg, int B, int S, int ncu, int max_tiles, int split_long,
                                                              int64_t* __restrict__ seq_out, int64_t* __restrict__ pos_out,
                                                              int64_t* __restrict__ neg_out, uint8_t* __restrict__ valid,
                                                              int* __restrict__ count, int64_t* __restrict__ rows_all, int* __restrict__ plan,
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
 #define PL_STAMP(i) do { } while (0)
 #endif
     __shared__ int s_cnt[PL_NCLS][PL_NW];
-    __shared__ int s_tot[PL_NCLS], s_base[PL_NCLS], s_lay[16], s_red[PL_NW], s_cb[PL_NCLS + 1], s_r0[PL_NCLS + 1];
+    __shared__ int s_tot[PL_NCLS], s_base[PL_NCLS], s_lay[16], s_red[PL_NW], s_cb[PL_NCLS + 1], s_r0[PL_NCLS + 1], s_nsplit;
     __shared__ unsigned char s_span[PL_LDS_B];
     __shared__ int s_place[PL_LDS_B];
     const int64_t mt = enc_plan_max_tiles(B, S);
@@ -134,17 +134,26 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 ro[7] = ro[6] + 2 * s_tot[6];
                 const int rs = ro[7] + s_tot[7];
                 const int tshort = (rs + 15) >> 4;
-                int avail = ncu - nlong;
-                if (avail < 1) avail = 1;
-                int G = (tshort + avail - 1) / avail;
-                if (G < 1) G = 1;
-                if (G > max_tiles) G = max_tiles;
-                const int nshort = (tshort + G - 1) / G;
+                // Sequences of 3 - 4 tiles SPLIT over two workgroups (kinds 2 / 3, enc_common.h) -- only if then every item of the
+                // plan still gets a workgroup of its own (the halves wait for each other: both must be resident)
+                int nsplit = split_long ? n0 + n1 : 0;
+                int G = 1, nshort = 0;
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    int avail = ncu - nlong - nsplit;
+                    if (avail < 1) avail = 1;
+                    G = (tshort + avail - 1) / avail;
+                    if (G < 1) G = 1;
+                    if (G > max_tiles) G = max_tiles;
+                    nshort = (tshort + G - 1) / G;
+                    if (nsplit == 0 || nlong + nsplit + nshort <= ncu) break;
+                    nsplit = 0;
+                }
+                s_nsplit = nsplit;
                 s_lay[0] = nlong; s_lay[1] = tlong; s_lay[2] = tshort; s_lay[3] = G; s_lay[4] = nshort;
                 s_lay[5] = 0; s_lay[6] = 4 * n0; s_lay[7] = 4 * n0 + 3 * n1;                 // first tile of the long classes
                 s_lay[8] = 0; s_lay[9] = n0; s_lay[10] = n0 + n1;                            // first item of the long classes
                 for (int k = 3; k < PL_NCLS; ++k) s_lay[8 + k] = 16 * tlong + ro[k];         // first compact row of the slot classes
-                hdr[0] = nlong + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0;
+                hdr[0] = nlong + nsplit + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0;
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;
                 // class k: s_cb[k] sequences in front of it, its rows start at s_r0[k]
                 int cb = 0, r0 = 0;
@@ -173,8 +182,13 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 for (int w = 0; w < wave; ++w) rank += s_cnt[cls][w];
                 rank += s_base[cls];
                 if (cls < 3) {
-                    const int nt = 4 - cls;
-                    items[s_cb[cls] + rank] = (s_lay[5 + cls] + nt * rank) | (nt << 24) | (1 << 28);
+                    const int nt = 4 - cls, t0 = s_lay[5 + cls] + nt * rank;
+                    if (s_nsplit && cls < 2) {   // first half: two tiles; second half: the rest, behind all long items
+                        items[s_cb[cls] + rank] = t0 | (2 << 24) | (2 << 28);
+                        items[s_lay[0] + (cls == 0 ? rank : s_tot[0] + rank)] = (t0 + 2) | ((nt - 2) << 24) | (3 << 28);
+                    } else {
+                        items[s_cb[cls] + rank] = t0 | (nt << 24) | (1 << 28);
+                    }
                 }
                 // the sequences sorted by class, then rank: sorted index -> sequence (rows are laid out in this order)
                 if (in_lds) s_place[s_cb[cls] + rank] = b; else g_place[s_cb[cls] + rank] = b;
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
     for (int i = tid; i < nshort; i += PL_NT) {
         const int t0 = i * G;
         const int nt = (tshort - t0) < G ? (tshort - t0) : G;
-        items[nlong + i] = (tlong + t0) | (nt << 24);
+        items[nlong + s_nsplit + i] = (tlong + t0) | (nt << 24);
     }
     // (a thread per compact row: coalesced stores.  Row -> class by the class row ranges, -> rank and offset inside the slot,
     //  -> sequence through the sorted index)
@@ -228,7 +242,7 @@ extern "C" size_t re_sasrec_plan_bytes(int64_t B, int64_t S) {
 }
 
 extern "C" int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
-                                    int32_t max_tiles, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
+                                    int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
                                     int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
                                     int64_t step, double lr, double beta1, double beta2, re_stream_t stream) {
     re_clear_error();
@@ -246,6 +260,6 @@ extern "C" int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, cons
     const bool elementwise = seq_out || valid || rows_all || pos_out;
     const unsigned grid = 1 + (elementwise ? re_grid(B * S, PL_NT, 256) : 0);
     hipLaunchKernelGGL(sasrec_batch_prep_k, dim3(grid), dim3(PL_NT), 0, (hipStream_t)stream, seq, pos, neg, (int)B, (int)S, (int)ncu,
-                       (int)max_tiles, seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib);
+                       (int)max_tiles, (int)(split_long != 0), seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib);
     return re_launch_status();
 }

@@ -43,8 +43,8 @@ static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, i
                              const EncHead& H, float* dx0, float* gtape, float* slab, float scale, hipStream_t s) {
     using C = EC<D>;
     const EncTape T = enc_tape_layout(B, S, D, L);
-    const size_t lf = (size_t)(5 * C::BUF + C::PBUF + (C::MAXT < 4 ? 2 * C::BUF : 0));
-    const size_t lb = (size_t)((C::MAXT < 4 ? 7 : 5) * C::BUF + 2 * C::PBUF);
+    const size_t lf = (size_t)(5 * C::BUF + C::PBUF + 2 * C::PRE);
+    const size_t lb = (size_t)(5 * C::BUF + 2 * C::PBUF + 2 * C::PRE);
     const size_t ldsb = (lf > lb ? lf : lb) * sizeof(float);
     auto k = enc_step_k<D>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;

@@ -52,6 +52,8 @@ class SASRecLargeTableEngine(SASRecEngine):
         # the fused encoder kernels cover D = 64 and 128 (BASELINE config 5 is D = 128); any other width runs the block stack on torch
         self.encoder = encoder or ("fused" if embedding_dim in (64, 128) and maxlen <= 64 and num_blocks <= 4 else "aten")
         self.compact_rows = True     # fused encoder: the step on the batch plan's compact rows (criterion in the forward kernel)
+        self.split_long = False      # (the large-table engines keep whole long items)
+        self.fused_item_kernel = True
         self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
         self.p_drop, self.loss_kind = dropout_rate, loss

@@ -355,7 +355,7 @@ def num_cus(device=None):
 
 class PreparedBatch:
     """What `sasrec_batch_prep` leaves on the device for one (seq, pos, neg) batch: views into ONE uint8 blob."""
-    __slots__ = ("B", "S", "blob", "seq", "pos", "neg", "rows_all", "valid", "count", "plan")
+    __slots__ = ("B", "S", "blob", "seq", "pos", "neg", "rows_all", "valid", "count", "plan", "split")
 
 
 def prep_layout(B, S):
@@ -380,10 +380,11 @@ def prep_views(blob, B, S):
     return pb
 
 
-def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4):
+def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4, split=False):
     """Batch preparation as ONE launch (re_sasrec_batch_prep): valid mask, count, scatter destination rows, the encoder's work plan;
     with `blob` (a static buffer of prep_layout(B, S) bytes) also copies (seq, pos, neg) into it and, with `state` (int32[4]),
-    writes the step scalars -- the staging launch of a captured step.  -> PreparedBatch (views into the blob)."""
+    writes the step scalars -- the staging launch of a captured step.  -> PreparedBatch (views into the blob).
+    split: sequences of 3 - 4 tiles may become two work items in two workgroups (training launches with a zero-initialised tape only)."""
     _req(seq, torch.int64, "seq")
     B, S = seq.shape
     if pos is not None:
@@ -395,7 +396,7 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     if state is not None:
         _req(state, torch.int32, "state")
     have = pos is not None
-    lib.check(lib.load().re_sasrec_batch_prep(_p(seq), _p(pos), _p(neg), B, S, num_cus(seq.device), int(max_tiles),
+    lib.check(lib.load().re_sasrec_batch_prep(_p(seq), _p(pos), _p(neg), B, S, num_cus(seq.device), int(max_tiles), int(bool(split)),
                                               _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None,
                                               _p(pb.neg) if copy and have else None, _p(pb.valid) if have else None,
                                               _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
@@ -403,6 +404,7 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
                                               _stream()), "re_sasrec_batch_prep")
     if not copy:
         pb.seq, pb.pos, pb.neg = seq, pos, neg
+    pb.split = bool(split)
     return pb
 
 
@@ -434,7 +436,7 @@ def sasrec_encoder_fwd(x0, seq, block_tensors, last_w, last_b, L, drop_p=0.0, se
     fill_pads = 0 if (need_tape or tape is not None) else 1      # inference: pad positions read lastLN.bias; training does not write them
     if tape is None and (need_tape or (D == 128 and S > 16 * max_tiles(D))):
         # (D = 128, S > 32: the parts of a long sequence hand k, v over through the tape, inference included)
-        tape = torch.empty(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=seq.device)
+        tape = torch.zeros(Lb.re_sasrec_tape_bytes(B, S, D, L) // 4, dtype=torch.float32, device=seq.device)
     if plan is None:
         plan = sasrec_plan(seq, D)
     tbl = _ptr_table(block_tensors)
@@ -532,6 +534,12 @@ def sasrec_encoder_step(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, la
                                                 _p(g_rows), _p(keys), _p(loss_ws), loss_ws.numel(), _p(dx0), _p(dP), tg, _p(g_last_w),
                                                 _p(g_last_b), _p(ws), ws.numel(), _stream()), "re_sasrec_encoder_step")
     return loss
+
+
+def sasrec_tape_errors(tape, B, S):
+    """Number of hand-over time-outs recorded in a tape's flag words (split long sequences; 0 in a healthy run).  Host sync."""
+    mt = B * ((S + 15) // 16)
+    return int(tape[-16:].view(torch.int32)[0].item()) if tape.numel() >= mt * 8 + 16 else 0
 
 
 def sasrec_plan_rows(B, S):

@@ -141,6 +141,7 @@ class SASRecEngine:
         if encoder == "fused" and (embedding_dim not in (64, 128) or maxlen > 64 or num_blocks > 4):
             raise NotImplementedError("fused encoder kernels: D = 64 or 128, maxlen <= 64, blocks <= 4 (use encoder='aten')")
         self.encoder = encoder
+        self.split_long = True          # sequences of 3 - 4 tiles as two work items in two workgroups (fused BCE / BPR training step)
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
         self.ce_logits_bytes = 1 << 28  # loss='CE': at most this many bytes of logits at a time (more: the catalog is walked in chunks)
         self.compact_rows = True     # BCE / BPR fused step on the batch plan's compact rows (False: all B*S positions + sorted scatter-add)
@@ -291,7 +292,17 @@ class SASRecEngine:
         """Per-batch preparation of the fused step as ONE engine launch (re_sasrec_batch_prep; what the reference does at the top of
         `fit`, SASRec/main.py:199-204, plus the encoder's work plan): valid mask, number of valid positions, destination rows of the
         3*B*S gradient contributions, work items.  No host sync.  -> ops.PreparedBatch."""
-        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles())
+        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split())
+
+    def check_handover(self):
+        """Raise if a split sequence's halves ever timed out waiting for each other (Coach calls this once per epoch; host sync)."""
+        for (B, S), W in self._bufs.items():
+            if ops.sasrec_tape_errors(W["tape"], B, S):
+                raise RuntimeError("recengine: a split sequence's work items did not meet (hand-over time-out); results of that step are invalid")
+
+    def _split(self):
+        """Long sequences as two work items in two workgroups: the fused training step (its tape carries the hand-over flags)."""
+        return bool(self.split_long and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
 
     def _buffers(self, B, S):
         key = (B, S)
@@ -306,7 +317,7 @@ class SASRecEngine:
                 # the step on the plan's compact rows (BCE / BPR): upstream gradient rows, the three contribution-row sets, their keys
                 dU_rows=f(NR, D), g_rows=f(3, NR, D), keys=torch.zeros((3, NR), dtype=torch.int32, device=dev),
                 ws_loss=torch.zeros(L.re_sasrec_loss_rows_workspace_bytes(), dtype=torch.uint8, device=dev),
-                tape=f(L.re_sasrec_tape_bytes(B, S, D, self.L) // 4),
+                tape=torch.zeros(L.re_sasrec_tape_bytes(B, S, D, self.L) // 4, dtype=torch.float32, device=dev),   # (zero: the hand-over flags)
                 ws_bwd=u8(L.re_sasrec_encoder_bwd_workspace_bytes(B, S, D, self.L)),
                 ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
         return self._bufs[key]
@@ -432,7 +443,7 @@ class SASRecEngine:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles())
+                                       max_tiles=self._max_tiles(), split=self._split())
             body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -458,7 +469,7 @@ class SASRecEngine:
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles())
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split())
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:

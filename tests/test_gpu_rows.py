@@ -172,3 +172,36 @@ def test_one_launch_item_kernel_equals_two_launches(D, p):
         eng.append((m, losses))
     assert eng[0][1] == eng[1][1]
     assert torch.equal(eng[0][0].arena.data, eng[1][0].arena.data)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_long_sequences_split_over_two_workgroups_match_whole_items(D):
+    """split_long: a sequence of 3 - 4 tiles runs as two work items in two workgroups that hand k, v and the partial dK, dV over
+    through the tape under flags.  Same function as the whole-item plan: loss and every gradient within rounding (the attention
+    products see their key tiles in another grouping), twice the same bits, and the flags come back clean."""
+    from recboard_amd import ops
+    from recboard_amd.sasrec import SASRecEngine
+    B, S, N = 48, 50, 400
+    rng = np.random.default_rng(12)
+    lens = np.concatenate([rng.integers(33, 50, 16), rng.integers(17, 33, 8), np.clip(rng.geometric(1 / 5.9, B - 24) + 1, 1, 16)])
+    seq = np.zeros((B, S), np.int64)
+    for b in range(B):
+        seq[b, S - lens[b]:] = rng.integers(1, N + 1, lens[b])
+    pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    batch = tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg))
+    out = []
+    for split in (True, False, True):
+        m = SASRecEngine(N, S, D, 2, dropout_rate=0.3, loss="BCE", lr=1e-3, seed=8)
+        m.split_long = split
+        pb = m.prepare_batch(*batch)
+        kinds = (pb.plan.view(torch.int32)[8:8 + int(pb.plan.view(torch.int32)[0])].cpu().numpy() >> 28) & 15
+        assert (set(kinds.tolist()) >= {2, 3}) == split, kinds
+        loss = float(m.train_step(*batch, aux=pb))
+        W = m._buffers(B, S)
+        flags = W["tape"][-(B * 4 * 8 + 16):].view(torch.int32)
+        assert int(flags.abs().sum()) == 0          # every flag consumed and cleared, no time-out
+        out.append((loss, m.arena.grad.clone()))
+    assert out[0][0] == out[2][0] and torch.equal(out[0][1], out[2][1])
+    assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[1][0])
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=2e-4, atol=1e-7)

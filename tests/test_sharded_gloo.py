@@ -219,7 +219,7 @@ def _engine_worker(rank, world, port, q):
                 loss.backward()
                 for k, p in self.params.items():
                     self.arena.view(self.arena.grad, k).copy_(P[k].grad if P[k].grad is not None else torch.zeros_like(p))
-                return loss.detach().reshape(1), T.grad[1:].clone()          # row 1 + j of the batch-local table = lookup j
+                return loss.detach().reshape(1), T.grad[1:].clone(), None   # row 1 + j of the batch-local table = lookup j (rows: the sharded step has its own)
 
             def _dense_adam(self):
                 A = self.arena
