@@ -69,3 +69,16 @@ def test_sampler_rows_match_the_reference_row_contract_fixture():
                 want = fx[mode][str(u)]
                 assert b["ISeq"][r].tolist() == want["ISeq"] and b["IUnseen"][r] == want["IUnseen"]
                 assert sorted(set(b["ISeen"][r])) == want["ISeen"]
+
+
+def test_scripts_parse_and_cited_scripts_exist():
+    """scripts/ holds the measurement tooling DESIGN.md / README cite: every python file parses, every cited file exists."""
+    import ast, glob, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, "scripts", "*.py")):
+        ast.parse(open(f).read(), f)
+    cited = set()
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+        cited |= set(re.findall(r"scripts/([A-Za-z0-9_]+\.(?:py|sh))", open(os.path.join(root, doc)).read()))
+    missing = sorted(c for c in cited if not os.path.exists(os.path.join(root, "scripts", c)))
+    assert not missing, missing
