@@ -30,16 +30,20 @@ class Coach:
         self.device = model.device
         self.lr_scheduler = lr_scheduler
 
-    def dict_to_device(self, data):
-        return {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+    def dict_to_device(self, data, keys=None):
+        """Coach.dict_to_device: tensors to the model's device (asynchronously when the pipe hands out pinned memory); `keys` limits
+        the copies to what the step reads."""
+        return {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) and (keys is None or k in keys) else v)
+                for k, v in data.items()}
 
     def train_per_epoch(self, epoch):
         if self.lr_scheduler is not None:            # DeepFM/main.py:256: self.lr_scheduler.step(self._best)
             self.lr_scheduler.step(self.best[1] if self.best is not None else (-float("inf") if self.lr_scheduler.mode == "max" else float("inf")))
         tot = torch.zeros((), device=self.device)
         n = 0
+        need = {"seq": ("ISeq", "IPos", "INeg"), "pred": ("X", "Label")}.get(self.kind)
         for data in self.trainpipe:
-            data = self.dict_to_device(data)
+            data = self.dict_to_device(data, need)
             if self.kind == "pred":                  # DeepFM/main.py:258-268: forward, backward, clip_grad_norm_(.., 10), step
                 loss = self.model.train_step(data["X"], data["Label"])
                 bsz = data["X"].shape[0]
@@ -56,7 +60,7 @@ class Coach:
             else:
                 loss = self.model.train_step(data["User"], data["IPos"], data["INeg"])
             bsz = len(data["User"])
-            tot += loss * bsz
+            tot.add_(loss, alpha=bsz)                # (one launch)
             n += bsz
         if hasattr(self.model, "check_handover"):
             self.model.check_handover()     # (split long sequences: the halves' hand-over flags; the loss read below syncs anyway)
