@@ -787,8 +787,10 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
     for (int e = tid; e < SO_NG * rpw * D / 4; e += SO_NT) reinterpret_cast<float4*>(so_acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt = 0;          // entries in the list (workgroup-uniform)
     unsigned m0 = 0;      // matches consumed so far
-    unsigned long long so_t[12] = {}; (void)so_t;
-    int so_i = 2; (void)so_i;
+#ifdef SO_MARKS
+    unsigned long long so_t[12] = {};
+    int so_i = 2;
+#endif
     SO_MARK(0);
 
     auto flush = [&]() {
@@ -874,7 +876,9 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
             mask |= (hit ? 1u : 0u) << u;
         }
         const int c = __popc(mask);
+#ifdef SO_MARKS
         if (so_i < 8) { SO_MARK(so_i); ++so_i; }
+#endif
         // ---- exclusive scan of the per-thread counts over the workgroup
         int inc = c;
 #pragma unroll
