@@ -205,3 +205,27 @@ def test_long_sequences_split_over_two_workgroups_match_whole_items(D):
     assert out[0][0] == out[2][0] and torch.equal(out[0][1], out[2][1])
     assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[1][0])
     torch.testing.assert_close(out[0][1], out[1][1], rtol=2e-4, atol=1e-7)
+
+
+def test_split_is_refused_when_the_halves_could_not_all_be_resident():
+    """More long sequences than compute units: the two halves of a split sequence must be resident at once, so the plan keeps the
+    sequences whole (and the step still equals the split_long = False step bit for bit)."""
+    from recboard_amd.sasrec import SASRecEngine
+    B, S, N = 320, 50, 300
+    rng = np.random.default_rng(4)
+    seq = rng.integers(1, N + 1, (B, S))
+    seq[:, : S - 40] = 0                                   # every sequence has 40 rows = 3 tiles
+    pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    batch = tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg))
+    out = []
+    for split in (True, False):
+        m = SASRecEngine(N, S, 64, 2, dropout_rate=0.2, loss="BPR", lr=1e-3, seed=3)
+        m.split_long = split
+        pb = m.prepare_batch(*batch)
+        w = pb.plan.view(torch.int32)
+        kinds = (w[8:8 + int(w[0])].cpu().numpy() >> 28) & 15
+        assert set(kinds.tolist()) == {1}
+        out.append((float(m.train_step(*batch, aux=pb)), m.arena.grad.clone()))
+        m.check_handover()
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
