@@ -1087,6 +1087,9 @@ __global__ __launch_bounds__(256) void score_split_k(const float* __restrict__ X
 // too high fails the certificate in score_topk_merge_x and is redone exactly.  (Only the split form may do this.)
 // One workgroup = 32 users, two waves (even / odd sample tiles, lists joined at the end); per tile 3 D/16 MFMAs and 16 sorted insertions into the lane's best-8 list (v_med3 per slot); the
 // bound is the smaller of the pair's two rhalf-th bests (2 rhalf items of the sample are at least that good).
+#ifndef SC_BOUND_SIGMAS
+#define SC_BOUND_SIGMAS 4.5
+#endif
 template <int D>
 __global__ __launch_bounds__(128) void score_bound_k(const float* __restrict__ Qs, const float* __restrict__ Es, int64_t B,
                                                      int n_tiles, int64_t stride, int rhalf, unsigned* __restrict__ gthr,
@@ -1697,7 +1700,7 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
                 n &= ~31ll;
                 const int64_t stride = n > 0 ? N / n : 1;
                 const double m = (double)(K + 6) * (double)n / (double)N;
-                int r = (int)ceil(m + 4.5 * sqrt(m) + 2.0);
+                int r = (int)ceil(m + SC_BOUND_SIGMAS * sqrt(m) + 2.0);
                 r += r & 1;
                 if (n >= 32 && r <= 16) {
                     const int n_tiles = (int)(n / 32);

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 import bench
 from recboard_amd import lib, ops
+lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), "librecengine_dbg.so")   # the re_dbg_* switches live in the diagnostic twin (make -C recboard_amd/csrc dbg)
 from recboard_amd.sasrec import SASRecEngine
 L = lib.load()
 for n, a in (("re_dbg_score_x2", [ctypes.c_int]), ("re_dbg_score_x2_maxerr", [ctypes.c_int]), ("re_dbg_score_x2_stats", [ctypes.c_void_p, ctypes.c_int]),

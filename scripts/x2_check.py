@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from recboard_amd import lib, ops  # noqa: E402
+lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), "librecengine_dbg.so")   # the re_dbg_* switches live in the diagnostic twin (make -C recboard_amd/csrc dbg)
 
 L = lib.load()
 L.re_dbg_score_x2.argtypes = [ctypes.c_int]; L.re_dbg_score_x2.restype = None

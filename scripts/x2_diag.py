@@ -4,6 +4,7 @@ import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from recboard_amd import ops, lib
+lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), "librecengine_dbg.so")   # the re_dbg_* switches live in the diagnostic twin (make -C recboard_amd/csrc dbg)
 L = lib.load()
 for n, a in (("re_dbg_score_diag", [ctypes.c_int]), ("re_dbg_score_x2", [ctypes.c_int]), ("re_dbg_score_counters", [ctypes.c_void_p, ctypes.c_int]),
              ("re_dbg_score_vote", [ctypes.c_int])):

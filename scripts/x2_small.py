@@ -4,6 +4,7 @@ import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from recboard_amd import ops, lib
+lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), "librecengine_dbg.so")   # the re_dbg_* switches live in the diagnostic twin (make -C recboard_amd/csrc dbg)
 L = lib.load()
 L.re_dbg_score_x2.argtypes = [ctypes.c_int]; L.re_dbg_score_x2.restype = None
 L.re_dbg_score_reg_nub.argtypes = [ctypes.c_int64]; L.re_dbg_score_reg_nub.restype = None
