@@ -460,7 +460,7 @@ __device__ __forceinline__ void gemm_ttx_pre(const float* T, const float* X, int
 // An item's rows are contiguous in the compact (tape) arrays: [16 nt][D] starting at row 16 tile0.
 template <int D>
 struct TileRegs {
-    float4 v[EC<D>::ROWS * (D / 4) / EC<D>::NT];
+    f32x4 v[EC<D>::ROWS * (D / 4) / EC<D>::NT];   // (native vectors: arrays of HIP's float4 struct tend to end up in scratch memory)
 };
 template <int D>
 __device__ __forceinline__ void tile_fetch(TileRegs<D>& R, const float* g, int nrows, int tid) {
@@ -471,7 +471,7 @@ __device__ __forceinline__ void tile_fetch(TileRegs<D>& R, const float* g, int n
         const int f = q * C::NT + tid;
         float t[4] = {0.f, 0.f, 0.f, 0.f};
         if (f < nrows * (D / 4)) ld4g(t, gp + 4 * f);
-        R.v[q] = make_float4(t[0], t[1], t[2], t[3]);
+        R.v[q] = (f32x4){t[0], t[1], t[2], t[3]};
     }
 }
 template <int D>
@@ -480,7 +480,7 @@ __device__ __forceinline__ void tile_commit(float* tile, const TileRegs<D>& R, i
 #pragma unroll
     for (int q = 0; q < C::ROWS * (D / 4) / C::NT; ++q) {
         const int f = q * C::NT + tid;
-        if (f < nrows * (D / 4)) *reinterpret_cast<float4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4))) = R.v[q];
+        if (f < nrows * (D / 4)) *reinterpret_cast<f32x4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4))) = R.v[q];
     }
 }
 template <int D>
@@ -522,7 +522,7 @@ __device__ __forceinline__ void tile_fetch_gid(TileRegs<D>& R, const float* g, c
             const int gid = s_gid[f / (D / 4)];
             if (gid >= 0) ld4g(t, gp + (int64_t)gid * D + 4 * (f % (D / 4)));
         }
-        R.v[q] = make_float4(t[0], t[1], t[2], t[3]);
+        R.v[q] = (f32x4){t[0], t[1], t[2], t[3]};
     }
 }
 // rows of a table by per-row index: the loss head's E[pos], E[neg] (index 0 = the table's padding row; unconditional, clamped loads:
@@ -538,7 +538,7 @@ __device__ __forceinline__ void tile_fetch_rows(TileRegs<D>& R, const float* tab
         f = f < last ? f : last;
         float t[4];
         ld4g(t, gp + (int64_t)s_row[f / (D / 4)] * D + 4 * (f % (D / 4)));
-        R.v[q] = make_float4(t[0], t[1], t[2], t[3]);
+        R.v[q] = (f32x4){t[0], t[1], t[2], t[3]};
     }
 }
 template <int D>

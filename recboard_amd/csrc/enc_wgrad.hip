@@ -29,22 +29,30 @@ __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tap
         if (!dPtab) return;
         const int nch = (B + 63) / 64, njobs = S * nch;
         const int col = tid % D, rg = tid / D;
-        for (int j = blockIdx.y * gridDim.x + blockIdx.x; j < njobs; j += gridDim.x * gridDim.y) {
-            const int p = j / nch, ch = j % nch;
-            int64_t sv[64 / C::CG];
-            float cv[64 / C::CG];
-#pragma unroll
-            for (int q = 0; q < 64 / C::CG; ++q) {
-                const int b = ch * 64 + rg + C::CG * q;
-                sv[q] = 0; cv[q] = 0.f;
-                if (b < B) {
-                    sv[q] = seq[(int64_t)b * S + p];
-                    cv[q] = contrib[((int64_t)b * S + p) * D + col];
-                }
-            }
+        // (the next job's loads are in flight while this one is reduced: a workgroup has ~3 jobs, each a memory round trip)
+        constexpr int NQP = 64 / C::CG;
+        int64_t sv[NQP], svn[NQP];
+        float cv[NQP], cvn[NQP];
+        const int jstep = gridDim.x * gridDim.y, j0 = blockIdx.y * gridDim.x + blockIdx.x;
+#define WG_PJOB(J, SV, CV)                                                              \
+        do {                                                                            \
+            const int p_ = (J) / nch, ch_ = (J) % nch;                                  \
+            _Pragma("unroll") for (int q = 0; q < NQP; ++q) {                           \
+                int b = ch_ * 64 + rg + C::CG * q;                                      \
+                const bool in_ = b < B;                                                 \
+                b = in_ ? b : B - 1;   /* clamped, unconditional loads */               \
+                const int64_t sx = seq[(int64_t)b * S + p_];                            \
+                const float cx = contrib[((int64_t)b * S + p_) * D + col];              \
+                SV[q] = in_ ? sx : 0;                                                   \
+                CV[q] = cx;                                                             \
+            }                                                                           \
+        } while (0)
+        if (j0 < njobs) WG_PJOB(j0, sv, cv);
+        for (int j = j0; j < njobs; j += jstep) {
+            if (j + jstep < njobs) WG_PJOB(j + jstep, svn, cvn);
             float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < 64 / C::CG; ++q) s += (sv[q] != 0) ? cv[q] : 0.f;   // (rows of pad positions are never written: select, not multiply)
+            for (int q = 0; q < NQP; ++q) s += (sv[q] != 0) ? cv[q] : 0.f;   // (rows of pad positions are never written: select, not multiply)
             __syncthreads();
             lds[tid] = s;
             __syncthreads();
@@ -54,7 +62,10 @@ __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tap
                 for (int i = 1; i < C::CG; ++i) t += lds[i * D + tid];
                 ppart[(int64_t)j * D + tid] = t;
             }
+#pragma unroll
+            for (int q = 0; q < NQP; ++q) { sv[q] = svn[q]; cv[q] = cvn[q]; }
         }
+#undef WG_PJOB
         return;
     }
     const int l = blockIdx.z, m = blockIdx.y, split = blockIdx.x;
@@ -71,15 +82,36 @@ __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tap
     f32x4 acc[RTW];
 #pragma unroll
     for (int t = 0; t < RTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // stages of WG_CH row tiles through LDS; the next stage's rows are requested into registers before this stage's products
+    // (every stage is a memory round trip: four of them in a row were most of the launch)
+    constexpr int NQ = 16 * WG_CH * (D / 4) / C::NT;
+    f32x4 ra[NQ], rb[NQ];   // (native vectors and a macro: HIP's float4 struct arrays / arrays captured by a lambda stay in scratch memory)
+#define WG_FETCH(TC)                                                                                            \
+    do {                                                                                                        \
+        const int ntc_ = (t1 - (TC)) < WG_CH ? (t1 - (TC)) : WG_CH;                                             \
+        const int nf_ = 16 * ntc_ * (D / 4);                                                                    \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                        \
+            int f = q * C::NT + tid;                                                                            \
+            f = f < nf_ ? f : nf_ - 1;   /* clamped, unconditional: a predicated load is waited for on the spot */ \
+            ra[q] = reinterpret_cast<const f32x4*>(dY + (int64_t)(TC) * 16 * D)[f];                             \
+            rb[q] = reinterpret_cast<const f32x4*>(X + (int64_t)(TC) * 16 * D)[f];                              \
+        }                                                                                                       \
+    } while (0)
+    if (t0 < t1) WG_FETCH(t0);
     for (int tc = t0; tc < t1; tc += WG_CH) {
         const int ntc = (t1 - tc) < WG_CH ? (t1 - tc) : WG_CH;
         const int nf = 16 * ntc * (D / 4);
         enc_sync();
-        for (int f = tid; f < nf; f += C::NT) {
-            const int r = f / (D / 4), c4 = f % (D / 4);
-            *reinterpret_cast<float4*>(bufA + r * C::LS + 4 * c4) = reinterpret_cast<const float4*>(dY + (int64_t)tc * 16 * D)[f];
-            *reinterpret_cast<float4*>(bufB + r * C::LS + 4 * c4) = reinterpret_cast<const float4*>(X + (int64_t)tc * 16 * D)[f];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int f = q * C::NT + tid;
+            if (f < nf) {
+                const int r = f / (D / 4), c4 = f % (D / 4);
+                *reinterpret_cast<f32x4*>(bufA + r * C::LS + 4 * c4) = ra[q];
+                *reinterpret_cast<f32x4*>(bufB + r * C::LS + 4 * c4) = rb[q];
+            }
         }
+        if (tc + WG_CH < t1) WG_FETCH(tc + WG_CH);
         enc_sync();
         for (int q = 0; q < ntc; ++q) {
             float bf[4];
@@ -96,6 +128,7 @@ __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tap
             }
         }
     }
+#undef WG_FETCH
     float* out = part + (((int64_t)l * EG_NMAT + m) * WG_NSPLIT + split) * D * D;
 #pragma unroll
     for (int t = 0; t < RTW; ++t) {
