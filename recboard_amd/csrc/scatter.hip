@@ -748,6 +748,8 @@ extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64
 // workgroup OWNS `rpw` destination rows (dealt round-robin), scans ALL keys (int32, L2-resident: 54 KB for the batch above) for the ones
 // that fall into its range, and adds their rows -- one launch, no workspace, and the zero fill of the untouched rows comes with it
 // (every row of dW is written by its owner).
+//   Every table row is owned in TWO column halves by two different workgroups (virtual row 2 r + h): a hot row's contributions are then
+//   pulled through two CUs' memory pipes, one 128-byte line each, instead of 256 bytes through one.
 //   order of summation (bitwise reproducible): matches are numbered in scan order m = 0, 1, ...; lane group m mod 32 loads match m
 //   and adds it into accumulator set (m mod 32) mod 8 of that row (LDS, [8][rpw][D]) -- the four groups of a set one after the
 //   other; the eight sets of a row are added in order at the end.  A hot row (Zipf head) is thereby spread over all 32 lane
@@ -768,23 +770,28 @@ extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64
 #define SO_MARK(i) do { } while (0)
 #endif
 
-template <int D>
+// HS column splits: a table row is owned in HS pieces of DW = D / HS columns by HS DIFFERENT workgroups (virtual row HS * r + h), so
+// a hot row's contributions are pulled through HS memory pipes, DW * 4 bytes each, instead of through one.
+template <int D, int HS>
 __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                                          const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
                                                          int64_t padding_idx, float scale, float* __restrict__ dW) {
-    constexpr int VW = D / 32;                       // floats per lane: a lane group is 32 lanes
+    constexpr int DW = D / HS, VW = DW / 32;         // columns of a piece; floats per lane: a lane group is 32 lanes
+    constexpr int HSH = HS == 1 ? 0 : HS == 2 ? 1 : 2;
     typedef float vt __attribute__((ext_vector_type(VW)));
-    extern __shared__ __align__(16) float so_acc[];  // [SO_NG][rpw][D]
-    __shared__ uint32_t s_ent[SO_CAP];               // local row << 26 | contribution index
+    extern __shared__ __align__(16) float so_acc[];  // [SO_NG][rpw][DW]
+    __shared__ uint32_t s_ent[SO_CAP];               // local row << 25 | contribution index
     __shared__ int s_wsum[SO_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, grp = tid >> 5, gl = tid & 31;
     const int64_t n = n_dev ? (int64_t)n_dev[0] * n_mul : n_host;
     // rows are dealt round-robin: workgroup w owns rows w, w + nwg, w + 2 nwg, ... (popular items tend to have neighbouring ids:
     // a contiguous range would hand one workgroup most of the batch)
     // (the grid is a power of two: owner and local row of a key are a mask and a shift)
-    const uint32_t nwg = gridDim.x, me = blockIdx.x, wsh = 31 - __clz((int)nwg);
-    const int rows_here = (int64_t)me < R ? (int)((R - 1 - me) / nwg + 1) : 0;
-    for (int e = tid; e < SO_NG * rpw * D / 4; e += SO_NT) reinterpret_cast<float4*>(so_acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (virtual rows kk = (r << HSH) | h are dealt round-robin; this workgroup's pieces all have h = me & (HS - 1))
+    const uint32_t nwg = gridDim.x, me = blockIdx.x, wsh = 31 - __clz((int)nwg), h_me = me & (HS - 1);
+    const int64_t VR = R * HS;
+    const int rows_here = (int64_t)me < VR ? (int)((VR - 1 - me) / nwg + 1) : 0;
+    for (int e = tid; e < SO_NG * rpw * DW / 4; e += SO_NT) reinterpret_cast<float4*>(so_acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt = 0;          // entries in the list (workgroup-uniform)
     unsigned m0 = 0;      // matches consumed so far
 #ifdef SO_MARKS
@@ -808,8 +815,8 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
                 for (int u = 0; u < INF; ++u) {
                     const int j = jb + j0 + SO_LG * u;
                     const uint32_t en = s_ent[j < cnt ? j : 0];   // (clamped: a valid entry, its value is not used)
-                    rw[u] = j < cnt ? (int)(en >> 26) : -1;
-                    v[u] = reinterpret_cast<const vt*>(g + (int64_t)(en & 0x3FFFFFFu) * D)[gl];
+                    rw[u] = j < cnt ? (int)(en >> 25) : -1;
+                    v[u] = reinterpret_cast<const vt*>(g + (int64_t)(en & 0x1FFFFFFu) * D + h_me * DW)[gl];
                 }
 #pragma unroll
                 for (int u = 0; u + 1 < INF; ++u) {
@@ -823,7 +830,7 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
 #pragma unroll
                         for (int u = 0; u < INF; ++u) {
                             if (rw[u] >= 0) {
-                                vt* a = reinterpret_cast<vt*>(so_acc + ((int64_t)(grp % SO_NG) * rpw + rw[u]) * D) + gl;
+                                vt* a = reinterpret_cast<vt*>(so_acc + ((int64_t)(grp % SO_NG) * rpw + rw[u]) * DW) + gl;
                                 *a += v[u];
                             }
                         }
@@ -845,7 +852,7 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
     // round trip), counts its matches, ONE workgroup scan places them, and the matches go to the list from registers.
     // Match order = (chunk, thread, key): a fixed function of the keys.  (n is a multiple of 4 or the tail is handled by element:
     // a load never straddles two regions.)
-    const uint32_t n32 = (uint32_t)n, total = (uint32_t)nreg * n32;   // (< 2^26: checked by the entry point)
+    const uint32_t n32 = (uint32_t)n, total = (uint32_t)nreg * n32;   // (< 2^25: checked by the entry point)
     const bool vec = (n32 & 3u) == 0;
     auto region_of = [&](uint32_t v) { return (uint32_t)(v >= n32) + (uint32_t)(v >= 2 * n32) + (uint32_t)(v >= 3 * n32); };   // (nreg <= 4)
     auto load_chunk = [&](uint32_t base, int (&kk)[SO_KPT]) {
@@ -872,7 +879,7 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
 #pragma unroll
         for (int u = 0; u < SO_KPT; ++u) {
             const uint32_t k = (uint32_t)kv[u];   // (a negative key is >= R as unsigned)
-            const bool hit = (k & (nwg - 1)) == me && k < R32 && k != pad32;
+            const bool hit = (k & ((nwg >> HSH) - 1)) == (me >> HSH) && k < R32 && k != pad32;
             mask |= (hit ? 1u : 0u) << u;
         }
         const int c = __popc(mask);
@@ -909,7 +916,7 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
                     if (hit) {
                         const uint32_t v = base + (uint32_t)((u >> 2) * SO_NT + tid) * 4 + (u & 3);
                         const uint32_t q = region_of(v);
-                        s_ent[off] = (((uint32_t)kv[u] >> wsh) << 26) | ((uint32_t)(q * stride) + (v - q * n32));
+                        s_ent[off] = (((uint32_t)kv[u] >> (wsh - HSH)) << 25) | ((uint32_t)(q * stride) + (v - q * n32));
                     }
                     off += hit ? 1 : 0;
                 }
@@ -925,15 +932,16 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
     __syncthreads();
     SO_MARK(9);
     // ---- the eight accumulators of every owned row, added in set order; untouched rows come out zero
-    for (int e = tid; e < rows_here * (D / 4); e += SO_NT) {
-        const int r = e / (D / 4), c4 = e % (D / 4);
-        float4 s = reinterpret_cast<const float4*>(so_acc + (int64_t)r * D)[c4];
+    for (int e = tid; e < rows_here * (DW / 4); e += SO_NT) {
+        const int r = e / (DW / 4), c4 = e % (DW / 4);
+        float4 s = reinterpret_cast<const float4*>(so_acc + (int64_t)r * DW)[c4];
 #pragma unroll
         for (int gq = 1; gq < SO_NG; ++gq) {
-            const float4 t = reinterpret_cast<const float4*>(so_acc + ((int64_t)gq * rpw + r) * D)[c4];
+            const float4 t = reinterpret_cast<const float4*>(so_acc + ((int64_t)gq * rpw + r) * DW)[c4];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
-        reinterpret_cast<float4*>(dW + ((int64_t)r * nwg + me) * D)[c4] = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+        const int64_t kk = (int64_t)r * nwg + me;   // virtual row -> table row kk >> HSH, piece h_me
+        reinterpret_cast<float4*>(dW + (kk >> HSH) * D + h_me * DW)[c4] = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
     }
 #ifdef SO_MARKS
     __syncthreads();
@@ -951,20 +959,21 @@ extern "C" int re_scatter_add_rows_small(const float* g, const int32_t* keys, in
     if (D != 64 && D != 128) return RE_EUNSUPPORTED;
     if ((region_stride & 3) || ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u))
         return RE_EUNSUPPORTED;
-    if ((int64_t)n_regions * region_stride >= (1ll << 26)) return RE_EUNSUPPORTED;   // (a list entry: 6 bits of local row, 26 of index)
-    const int rpw = D == 64 ? 48 : 24;            // 96 KB of accumulators per workgroup
-    int64_t nwg = 1;
-    while (nwg * rpw < R) nwg *= 2;               // a power of two: rows are dealt round-robin with a mask
-    if (nwg > 2048) return RE_EUNSUPPORTED;       // every workgroup scans all keys: past ~100 k rows the sorted path is the right one
-    const size_t ldsb = (size_t)SO_NG * rpw * D * sizeof(float);
+    if ((int64_t)n_regions * region_stride >= (1ll << 25)) return RE_EUNSUPPORTED;   // (a list entry: 7 bits of local row, 25 of index)
+    constexpr int HS = 2;                          // column pieces per row
+    const int rpw = D == 64 ? 96 : 48;            // virtual rows per workgroup: 96 KB of accumulators (8 sets x rpw x D / HS floats)
+    int64_t nwg = HS;
+    while (nwg * rpw < R * HS) nwg *= 2;          // a power of two: virtual rows are dealt round-robin with a mask
+    if (nwg > 4096) return RE_EUNSUPPORTED;       // every workgroup scans all keys: past ~100 k rows the sorted path is the right one
+    const size_t ldsb = (size_t)SO_NG * rpw * (D / HS) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (D == 64) {
-        auto k = scatter_owner_k<64>;
+        auto k = scatter_owner_k<64, HS>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw,
                            padding_idx, scale, dW);
     } else {
-        auto k = scatter_owner_k<128>;
+        auto k = scatter_owner_k<128, HS>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw,
                            padding_idx, scale, dW);
