@@ -517,8 +517,8 @@ def main():
             torch.cuda.synchronize()
             dtc = time.perf_counter() - t0
             line["coach_loop"] = {"samples_per_sec": round(nb * cfg["B"] / dtc, 1), "ms_per_step": round(dtc / nb * 1e3, 4),
-                                  "what": f"Coach.train_per_epoch over {nb} HOST batches (pinned): H2D copies + batch preparation + graph replay per "
-                                          "step, the epoch's mean loss read once at the end"}
+                                  "what": f"Coach.train_per_epoch over {nb} HOST batches (pinned): H2D copies one batch ahead on a copy stream + batch "
+                                          "preparation + graph replay per step, the epoch's mean loss read once at the end"}
         if not args.no_baselines:
             line["train_baseline_aten_gpu"] = aten_train_baseline(cfg, batches)
         if not args.no_cpu_baseline:
