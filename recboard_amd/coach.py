@@ -86,10 +86,10 @@ class Coach:
                 n += bsz
                 continue
             if self.kind == "seq" and self._graphable():
-                # one staging launch + one hipGraph replay per step (SASRecEngine.train_step_graph); a short last batch
-                # gets its own captured graph
-                seq = data["ISeq"]
-                loss = self.model.train_step_graph(seq, data["IPos"], data["INeg"])
+                # one batch-preparation launch + one hipGraph replay per step (SASRecEngine.train_step_graph); a short last batch
+                # gets its own captured graph.  (The preparation launch one batch ahead on the copy stream was measured: 0.305 vs
+                # 0.175 ms per step -- its buffer-reuse wait holds the next copies back.)
+                loss = self.model.train_step_graph(data["ISeq"], data["IPos"], data["INeg"])
             elif self.kind == "seq":
                 loss = self.model.train_step(data["ISeq"], data["IPos"], data["INeg"])
             else:

@@ -229,3 +229,4 @@ def test_split_is_refused_when_the_halves_could_not_all_be_resident():
         out.append((float(m.train_step(*batch, aux=pb)), m.arena.grad.clone()))
         m.check_handover()
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+
