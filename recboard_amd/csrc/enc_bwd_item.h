@@ -119,7 +119,7 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
     float* bV0 = bK0 + C::PRE;
     __shared__ float s_mean[C::ROWS], s_rstd[C::ROWS];
     __shared__ float s_ppad[C::ROWS], s_w[C::ROWS], s_cpad[C::ROWS];   // virtual pad key: prob of one copy, total kept weight, dS
-    __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS];
+    __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS], s_start[C::ROWS];
     __shared__ float s_par[2 * EP_NPAR * D], s_last[D];
 
     const int tid0 = threadIdx.x;
@@ -164,7 +164,11 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
         enc_decode<D>(PL, it, seq, tid, s_gid, s_first, s_pad);
         enc_sync();
         ENC_MARK(g_bwd_marks, mk); ++mk;
-        if (tid < C::ROWS) s_sid[tid] = s_gid[tid] >= 0 ? s_gid[tid] / S : -1;
+        if (tid < C::ROWS) {   // the sequence of a row and the item-local row its first token sits in (as in the forward)
+            const int gid = s_gid[tid], sid = gid >= 0 ? gid / S : -1;
+            s_sid[tid] = sid;
+            s_start[tid] = gid >= 0 ? tid - (gid - sid * S - s_first[tid]) : 0;
+        }
         TileRegs<D> T0, T1;
         float2 ST;
         if (in_rows) tile_fetch<D>(T0, dIn + row0 * D, nrows, tid);
@@ -293,16 +297,14 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
             if (r_e < nrows) {
                 const int i = r_e;
                 const int gi = s_gid[i];
-                const int sbase = s_sid[i] * S;
+                // key column j is position first + j - start - 16 npre of the sequence (enc_fwd_item.h); the probability is 0 outside the
+                // row's window (the forward stored zeros there), so the mask is regenerated for every column without a branch
+                const uint32_t e0 = (uint32_t)((int64_t)gi * S + s_first[i] - s_start[i] - 16 * npre + j0_e);
 #pragma unroll
                 for (int jj = 0; jj < KPT; ++jj) {
                     const int j = j0_e + jj;
-                    const float p = pq[jj];          // 0 outside the causal / same-sequence window (the forward stored zeros there)
-                    float m = 1.0f;
-                    if (thresh && p != 0.f) {
-                        const int sj = it.kind ? s_first[i] + j : s_gid[j & (C::ROWS - 1)] - sbase;   // (one long sequence: consecutive positions)
-                        m = re_keep(seed, RE_STREAM_ATTN(l), (uint32_t)((int64_t)gi * S + sj), thresh) ? drop_scale : 0.f;
-                    }
+                    const float p = pq[jj];
+                    const float m = !thresh ? 1.0f : re_keep(seed, RE_STREAM_ATTN(l), e0 + (uint32_t)jj, thresh) ? drop_scale : 0.f;
                     sP[i * C::PLS + j] = p;
                     sD[i * C::PLS + j] = p * m;
                 }

@@ -15,6 +15,7 @@ ap.add_argument("--B", type=int, default=512)
 args = ap.parse_args()
 B, S, D, L, N = args.B, 50, 64, 2, 12101
 m = SASRecEngine(N, S, D, L, dropout_rate=0.5, loss="BCE", lr=5e-4, weight_decay=1e-6, seed=1)
+m.fused_item_kernel = False   # the stamps live in the forward / backward kernels of their own (the one-launch item kernel has none)
 rng = np.random.default_rng(0)
 if args.kind == "beauty":
     lens = np.clip(rng.geometric(1 / 5.9, B) + 1, 1, S - 1)
