@@ -104,7 +104,7 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
                                              const SasrecParams& P, float drop_scale, uint32_t thresh, uint32_t seed,
                                              const float* __restrict__ tape, const EncTape& T, const EncPlan& PL, float* __restrict__ dOut,
                                              float* __restrict__ gtape, float* __restrict__ slab, int fuse_embed, float emb_scale, int in_rows,
-                                             float* __restrict__ dOutRows, float* lds, int wi, int k) {
+                                             float* __restrict__ dOutRows, float* lds, int wi, int k, const EncHandoff* HO = nullptr) {
     // in_rows: dIn is indexed by the plan's compact rows instead of (b, s).  dOutRows (optional): the output rows once more, in compact order.
     using C = EC<D>;
     constexpr int KPT = C::KPT;
@@ -119,7 +119,9 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
     float* bV0 = bK0 + C::PRE;
     __shared__ float s_mean[C::ROWS], s_rstd[C::ROWS];
     __shared__ float s_ppad[C::ROWS], s_w[C::ROWS], s_cpad[C::ROWS];   // virtual pad key: prob of one copy, total kept weight, dS
-    __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS], s_start[C::ROWS];
+    __shared__ int o_gid[C::ROWS], o_first[C::ROWS], o_pad[C::ROWS], o_sid[C::ROWS], o_start[C::ROWS];
+    int *s_gid = HO ? HO->gid : o_gid, *s_first = HO ? HO->first : o_first, *s_pad = HO ? HO->pad : o_pad, *s_sid = HO ? HO->sid : o_sid,
+        *s_start = HO ? HO->start : o_start;   // (left by the forward of the same launch: enc_step_k)
     __shared__ float s_par[2 * EP_NPAR * D], s_last[D];
 
     const int tid0 = threadIdx.x;
@@ -159,28 +161,46 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
         BWREQ(wa, P.blk[L - 1].w2);
         BWREQ(wb, P.blk[L - 1].w1);
         BWREQ(wc, P.blk[L - 1].out_w);
+        // handed over by the forward of this launch (the item it has just finished: the last part of a chained item): metadata,
+        // lastLN's statistics, x_L (still in the first tile buffer) and the upstream gradient rows -- nothing of the prologue is read back
+        const bool handed = HO != nullptr && hs == nsub - 1;
+        TileRegs<D> T0, T1;
+        float2 ST;
+        if (handed) tile_fetch<D>(T1, tape + (int64_t)(L - 1) * T.per_block + T.off_HR + row0 * D, nrows, tid);
         enc_sync();
         ENC_MARK(g_bwd_marks, mk); ++mk;
-        enc_decode<D>(PL, it, seq, tid, s_gid, s_first, s_pad);
+        if (!handed) enc_decode<D>(PL, it, seq, tid, s_gid, s_first, s_pad);
         enc_sync();
         ENC_MARK(g_bwd_marks, mk); ++mk;
-        if (tid < C::ROWS) {   // the sequence of a row and the item-local row its first token sits in (as in the forward)
+        if (!handed && tid < C::ROWS) {   // the sequence of a row and the item-local row its first token sits in (as in the forward)
             const int gid = s_gid[tid], sid = gid >= 0 ? gid / S : -1;
             s_sid[tid] = sid;
             s_start[tid] = gid >= 0 ? tid - (gid - sid * S - s_first[tid]) : 0;
         }
-        TileRegs<D> T0, T1;
-        float2 ST;
-        if (in_rows) tile_fetch<D>(T0, dIn + row0 * D, nrows, tid);
-        else tile_fetch_gid<D>(T0, dIn, s_gid, nrows, tid);
-        tile_fetch<D>(T1, tape + T.off_XL + row0 * D, nrows, tid);
-        stats_fetch(ST, tape + T.off_SL + row0 * 2, nrows, tid);
         par_commit<D>(s_par + ((L - 1) & 1) * EP_NPAR * D, PR, tid);
         if (tid < D) s_last[tid] = lastv;
-        tile_commit<D>(b0, T0, nrows, tid);
-        tile_commit<D>(b1, T1, nrows, tid);
-        if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
-        tile_fetch<D>(T1, tape + (int64_t)(L - 1) * T.per_block + T.off_HR + row0 * D, nrows, tid);
+        if (handed) {
+            if (r_e < nrows) {   // x_L: first tile buffer -> second; dU: hand-off tile -> first (each thread its own row slice)
+#pragma unroll
+                for (int q = 0; q < C::CPT / 4; ++q) {
+                    float t[4];
+                    ld4(t, b0 + r_e * C::LS + c0_e + 4 * q);
+                    *reinterpret_cast<float4*>(b1 + r_e * C::LS + c0_e + 4 * q) = make_float4(t[0], t[1], t[2], t[3]);
+                    ld4(t, HO->du + r_e * C::LS + c0_e + 4 * q);
+                    *reinterpret_cast<float4*>(b0 + r_e * C::LS + c0_e + 4 * q) = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            if (tid < C::ROWS) { s_mean[tid] = HO->mean[tid]; s_rstd[tid] = HO->rstd[tid]; }
+        } else {
+            if (in_rows) tile_fetch<D>(T0, dIn + row0 * D, nrows, tid);
+            else tile_fetch_gid<D>(T0, dIn, s_gid, nrows, tid);
+            tile_fetch<D>(T1, tape + T.off_XL + row0 * D, nrows, tid);
+            stats_fetch(ST, tape + T.off_SL + row0 * 2, nrows, tid);
+            tile_commit<D>(b0, T0, nrows, tid);
+            tile_commit<D>(b1, T1, nrows, tid);
+            if (tid < C::ROWS) { s_mean[tid] = ST.x; s_rstd[tid] = ST.y; }
+            tile_fetch<D>(T1, tape + (int64_t)(L - 1) * T.per_block + T.off_HR + row0 * D, nrows, tid);
+        }
         enc_sync();
         ENC_MARK(g_bwd_marks, mk); ++mk;
         float accV[EG_NVEC];

@@ -255,6 +255,14 @@ __device__ __forceinline__ void tile_add_coh(float* tile, const float* g, int nr
         tile[(f / D) * C::LS + (f % D)] += __hip_atomic_load(g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Forward -> backward inside ONE launch (enc_step_k): what the backward's prologue would otherwise re-read from memory a moment after
+// the forward produced it -- the item's row metadata, lastLN's statistics and the upstream gradient rows (all LDS).  nullptr: separate launches.
+struct EncHandoff {
+    int *gid, *first, *pad, *sid, *start;
+    float *mean, *rstd;     // [ROWS]
+    float* du;              // [ROWS][LS] tile: d loss / d u of the item's rows
+};
+
 // fills s_gid (b * S + s or -1), s_first (virtual pad keys of the row's sequence), s_pad (1 = pad or dummy row) for the item's rows
 template <int D>
 __device__ __forceinline__ void enc_decode(const EncPlan& P, const EncItem& it, const int64_t* __restrict__ seq, int tid, int* s_gid,

@@ -47,7 +47,7 @@ template <int D, bool TRAIN, bool HEAD>
 __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const SeEmbed& em, const int64_t* __restrict__ seq, int B, int S, int L,
                                              const SasrecParams& P, float drop_scale, uint32_t thresh, uint32_t seed, float* __restrict__ u,
                                              float* __restrict__ tape, const EncTape& T, const EncPlan& PL, int fill_pads, const EncHead& H,
-                                             float* lds, int wi, int k) {
+                                             float* lds, int wi, int k, const EncHandoff* HO = nullptr) {
     using C = EC<D>;
     constexpr int KPT = C::KPT;             // keys per thread in the softmax phase
     (void)k;
@@ -59,7 +59,9 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
     float* sP = bV + C::BUF;
     float* bK0 = sP + C::PBUF;                 // prefix k / v tiles (32 rows) of a chained part / the second half of a split sequence
     float* bV0 = bK0 + C::PRE;
-    __shared__ int s_gid[C::ROWS], s_first[C::ROWS], s_pad[C::ROWS], s_sid[C::ROWS], s_start[C::ROWS];
+    __shared__ int o_gid[C::ROWS], o_first[C::ROWS], o_pad[C::ROWS], o_sid[C::ROWS], o_start[C::ROWS];
+    int *s_gid = HO ? HO->gid : o_gid, *s_first = HO ? HO->first : o_first, *s_pad = HO ? HO->pad : o_pad, *s_sid = HO ? HO->sid : o_sid,
+        *s_start = HO ? HO->start : o_start;   // (handed to the backward of the same launch: enc_step_k)
     __shared__ float s_w[C::ROWS];
     __shared__ int s_item[HEAD ? C::ROWS : 1], s_pos[HEAD ? C::ROWS : 1], s_neg[HEAD ? C::ROWS : 1];   // loss head: table rows of the item's rows (0 = none)
     __shared__ float s_red[HEAD ? C::NW : 1];
@@ -387,6 +389,7 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
             if (TRAIN && row_lead) {
                 float* st = tape + T.off_SL + (row0 + r_e) * 2;
                 st[0] = mean; st[1] = rstd;
+                if (HO) { HO->mean[r_e] = mean; HO->rstd[r_e] = rstd; }
             }
         }
         if (TRAIN) tile_store<D>(bX, tape + T.off_XL + row0 * D, nrows, tid);
@@ -425,8 +428,10 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
             float* gn = H.g_rows + (2 * NRH + r) * D + c0_e;
 #pragma unroll
             for (int q = 0; q < C::CPT / 4; ++q) {
-                reinterpret_cast<float4*>(du)[q] = make_float4(fmaf(dpl, b[4 * q], dnl * d[4 * q]), fmaf(dpl, b[4 * q + 1], dnl * d[4 * q + 1]),
-                                                               fmaf(dpl, b[4 * q + 2], dnl * d[4 * q + 2]), fmaf(dpl, b[4 * q + 3], dnl * d[4 * q + 3]));
+                const float4 dv = make_float4(fmaf(dpl, b[4 * q], dnl * d[4 * q]), fmaf(dpl, b[4 * q + 1], dnl * d[4 * q + 1]),
+                                              fmaf(dpl, b[4 * q + 2], dnl * d[4 * q + 2]), fmaf(dpl, b[4 * q + 3], dnl * d[4 * q + 3]));
+                reinterpret_cast<float4*>(du)[q] = dv;
+                if (HO) *reinterpret_cast<float4*>(HO->du + i * C::LS + c0_e + 4 * q) = dv;
                 if (ok) {
                     reinterpret_cast<float4*>(gp)[q] = make_float4(dpl * a[4 * q], dpl * a[4 * q + 1], dpl * a[4 * q + 2], dpl * a[4 * q + 3]);
                     reinterpret_cast<float4*>(gn)[q] = make_float4(dnl * a[4 * q], dnl * a[4 * q + 1], dnl * a[4 * q + 2], dnl * a[4 * q + 3]);

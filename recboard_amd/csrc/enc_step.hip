@@ -18,13 +18,17 @@ __global__ __launch_bounds__(512) void enc_step_k(SeEmbed em, const int64_t* __r
     extern __shared__ __align__(16) float lds[];
     const EncPlan PL = enc_plan_view(planp, B, S);
     const int n_items = PL.hdr[0];
+    using C = EC<D>;
+    __shared__ int h_gid[C::ROWS], h_first[C::ROWS], h_pad[C::ROWS], h_sid[C::ROWS], h_start[C::ROWS];
+    __shared__ float h_mean[C::ROWS], h_rstd[C::ROWS];
+    const EncHandoff HO{h_gid, h_first, h_pad, h_sid, h_start, h_mean, h_rstd, lds + 4 * C::BUF};   // (the fifth tile buffer is free at both ends)
     for (int k = 0; k * (int)gridDim.x < n_items; ++k) {
         const int wi = enc_item_of(k, blockIdx.x, gridDim.x);
         if (wi >= n_items) continue;
-        enc_fwd_item<D, true, true>(nullptr, em, seq, B, S, L, P, drop_scale, thresh, seed, u, tape, T, PL, 0, H, lds, wi, k);
+        enc_fwd_item<D, true, true>(nullptr, em, seq, B, S, L, P, drop_scale, thresh, seed, u, tape, T, PL, 0, H, lds, wi, k, &HO);
         __syncthreads();   // (a full barrier: the item's tape and upstream-gradient rows are written before they are read back)
         enc_bwd_item<D>(H.dU_rows, seq, B, S, L, P, drop_scale, thresh, seed, tape, T, PL, dOut, gtape, slab, 1, emb_scale, 1,
-                        H.g_rows, lds, wi, k);
+                        H.g_rows, lds, wi, k, &HO);
         __syncthreads();
     }
 }
