@@ -52,7 +52,8 @@ class SASRecLargeTableEngine(SASRecEngine):
         # the fused encoder kernels cover D = 64 and 128 (BASELINE config 5 is D = 128); any other width runs the block stack on torch
         self.encoder = encoder or ("fused" if embedding_dim in (64, 128) and maxlen <= 64 and num_blocks <= 4 else "aten")
         self.compact_rows = True     # fused encoder: the step on the batch plan's compact rows (criterion in the forward kernel)
-        self.split_long = False      # (the large-table engines keep whole long items)
+        self.split_long = True       # sequences of 3 - 4 tiles as two work items in two workgroups (at D = 128 a whole long item is two
+                                     # SEQUENTIAL parts in one workgroup: the launch lasts twice a part)
         self.fused_item_kernel = True
         self._bufs = {}
         self.N, self.S, self.D, self.L = num_items, maxlen, embedding_dim, num_blocks
@@ -220,7 +221,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles())
+                                       max_tiles=self._max_tiles(), split=self._split())
             pb.count.fill_(1)
             for _ in range(3):
                 body()
@@ -243,7 +244,7 @@ class SASRecLargeTableEngine(SASRecEngine):
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles())
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split())
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:
@@ -285,6 +286,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         self.world = dist.get_world_size(group)
         kw["table_init"] = "counter"
         super().__init__(*args, **kw)
+        self.split_long = False      # (the sharded step runs the all-positions criterion on its batch-local table: whole items)
 
     def _alloc_table(self, seed):
         from .sharded import ShardedTable

@@ -192,7 +192,7 @@ def test_large_table_engine_first_step_equals_dense_engine(D):
     large = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.0, loss="BCE", lr=1e-2, seed=5)           #  amplifies rounding differences)
     assert large.encoder == "fused"          # D = 64 and 128 both run the fused encoder kernels
     assert large.compact_rows and dense.compact_rows   # both run the compact-row item kernel (criterion inside): the same roundings
-    dense.split_long = False                           # ... on the same work items (the large-table engine keeps long sequences whole)
+    assert large.split_long and dense.split_long       # ... on the same work items
     large.load_state_dict(dense.state_dict())
     ld = dense.train_step(*batch)
     ll = large.train_step(*batch)
