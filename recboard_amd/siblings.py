@@ -8,8 +8,11 @@ DeepFM additionally have hand-fused engines (sasrec.py, gen.py, deepfm.py).
   SimGCL  (SimGCL/main.py:34-160)  K propagations = recengine::spmm_csr (symmetric adjacency: the backward is the same kernel),
                                    BPR over the propagated tables = recengine::bpr_triplet (gathers + dots + criterion fused),
                                    the two B x B InfoNCE logit matrices = recengine::score_dense, full ranking = score_dense
-Elementwise glue (BatchNorm / ReLU / dropout, the cross layer's x0 * s + b, L2 normalisation, log-softmax of the B x B logits)
-stays with aten: no table, no catalog and no contraction is touched there.
+  GRU4Rec (GRU4Rec/main.py:30-190) item lookup = recengine::gather_rows (padding row without gradient; scatter-add gradient), the dense
+                                   projection = recengine::gemm, the pair criteria = recengine::bpr_triplet (BPR: gathers + dots +
+                                   softplus fused) or gathers + row dots (BCE), CE and full ranking over the catalog = score_dense
+Elementwise glue (BatchNorm / ReLU / dropout, the cross layer's x0 * s + b, L2 normalisation, log-softmax of the B x B logits) and
+the GRU recurrence itself (torch.nn.GRU: MIOpen) stay with aten: no table, no catalog and no catalog-sized contraction is touched there.
 """
 import torch
 import torch.nn.functional as F
@@ -145,3 +148,55 @@ class SimGCL(torch.nn.Module):
     def recommend_from_full(self, users):
         ue, ie = self.ranking_buffer
         return rnn.score_full(rnn.gather_rows(ue, users.reshape(-1)), ie)
+
+
+# ------------------------------------------------------------------------------------------------ GRU4Rec
+class GRU4Rec(torch.nn.Module):
+    """GRU4Rec (GRU4Rec/main.py:30-190): item embeddings (row 0 = padding) -> dropout -> GRU -> dense -> the state at the last real
+    position of the RIGHT-padded sequence -> pair / CE criterion against the item table."""
+
+    def __init__(self, num_items, embedding_dim=64, hidden_size=128, num_blocks=1, emb_dropout_rate=0.2, hidden_dropout_rate=0.2,
+                 loss="BCE", device="cuda"):
+        super().__init__()
+        assert loss in ("BCE", "BPR", "CE")
+        self.N, self.loss_kind = num_items, loss
+        self.item = rnn.Embedding(num_items + 1, embedding_dim, padding_idx=0, device=device)
+        self.emb_dropout = torch.nn.Dropout(emb_dropout_rate)
+        self.gru = torch.nn.GRU(embedding_dim, hidden_size, num_layers=num_blocks, bias=False, batch_first=True,
+                                dropout=hidden_dropout_rate, device=device)
+        self.dense = rnn.Linear(hidden_size, embedding_dim, device=device)
+        with torch.no_grad():                                    # GRU4Rec.reset_parameters (GRU4Rec/main.py:76-82)
+            torch.nn.init.xavier_normal_(self.item.weight)
+            torch.nn.init.xavier_uniform_(self.gru.weight_hh_l0)
+            torch.nn.init.xavier_uniform_(self.gru.weight_ih_l0)
+
+    def encode(self, seqs):
+        """seqs [B, S] int64, ids + 1, right-padded with 0 -> (userEmbds [B, D], itemEmbds [N, D])."""
+        mask = seqs.ne(0)
+        keep = mask.any(dim=0)                                   # shrink_pads: columns that are padding for every row
+        seqs, mask = seqs[:, keep], mask[:, keep]
+        B, S = seqs.shape
+        x = self.emb_dropout(self.item(seqs.reshape(-1)).reshape(B, S, -1))
+        out, _ = self.gru(x)
+        out = self.dense(out.reshape(B * S, -1)).reshape(B, S, -1)
+        last = (mask.sum(1) - 1).clamp_min(0)
+        user = rnn.gather_rows(out.reshape(B * S, -1), torch.arange(B, device=seqs.device) * S + last)
+        return user, self.item.weight[1:]
+
+    def fit(self, seqs, positives, negatives):
+        """positives / negatives [B] int64 (0-based item ids): the last item as the target, one sampled negative."""
+        user, items = self.encode(seqs)
+        pos, neg = positives.reshape(-1), negatives.reshape(-1)
+        if self.loss_kind == "BPR":
+            ar = torch.arange(user.shape[0], device=user.device)
+            return {"rec_loss": rnn.bpr_triplet(user.contiguous(), items.contiguous(), ar, pos, neg)}
+        if self.loss_kind == "BCE":
+            pl = (user * rnn.gather_rows(items.contiguous(), pos)).sum(-1, keepdim=True)
+            nl = (user * rnn.gather_rows(items.contiguous(), neg)).sum(-1, keepdim=True)
+            crit = rnn.BCELoss4Logits(reduction="mean")
+            return {"rec_loss": crit(pl, torch.ones_like(pl)) + crit(nl, torch.zeros_like(nl))}
+        return {"rec_loss": F.cross_entropy(rnn.score_full(user.contiguous(), items.contiguous()), pos)}
+
+    def recommend_from_full(self, seqs):
+        user, items = self.encode(seqs)
+        return rnn.score_full(user.contiguous(), items.contiguous())

@@ -16,6 +16,7 @@ Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic
   lightgcn.npz : LightGCN/main.py encode/fit (rec_loss, emb_loss) + grads + full scores
   deepfm.npz   : DeepFM/main.py   logits, loss, grads (train-mode BN), eval sigmoid scores
   dcn.npz      : DCN/main.py      logits, loss, grads (train-mode BN), eval sigmoid scores
+  gru4rec_{bce,bpr}.npz : GRU4Rec/main.py fit loss + every gradient + full scores (dropouts 0)
   simgcl.npz   : SimGCL/main.py   fit (rec_loss, emb_loss, ssl_loss at eps = 0: the noise is torch.rand_like) + grads + full scores
 """
 import importlib.util
@@ -356,6 +357,38 @@ def gen_simgcl():
     print("simgcl: " + " ".join(f"{k}={float(v):.6f}" for k, v in losses.items()))
 
 
+def gen_gru4rec(loss):
+    torch.manual_seed(1)
+    fr, ref = import_ref("GRU4Rec", f"ref_gru4rec_{loss}", dict(loss=loss, emb_dropout_rate=0.0, hidden_dropout_rate=0.0, hidden_size=48,
+                                                                embedding_dim=64, num_blocks=1))
+    N, B, S = 150, 12, 20
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=30), F("ITEM", "ITEM", "ID", count=N)])
+    model = ref.GRU4Rec(ds)
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        model.dense.bias.add_(0.1 * torch.randn(model.dense.bias.shape, generator=g))
+    lens = torch.randint(1, S - 2, (B,), generator=g)          # (no row reaches S: shrink_pads drops the all-padding columns)
+    seq = torch.zeros(B, S, dtype=torch.long)
+    for b in range(B):
+        seq[b, : int(lens[b])] = torch.randint(0, N, (int(lens[b]),), generator=g) + 1      # RIGHT-padded (GRU4Rec/main.py:93-96)
+    pos = torch.randint(0, N, (B, 1), generator=g)
+    neg = torch.randint(0, N, (B, 1), generator=g)
+    data = {model.ISeq: seq, model.IPos: pos, model.INeg: neg}
+    out = {"in/seq": seq.numpy(), "in/pos": pos.numpy(), "in/neg": neg.numpy(), "cfg/N": np.int64(N), "cfg/hidden": np.int64(48)}
+    out.update(sd_np(model))
+    model.train()
+    losses = model(data)
+    losses["rec_loss"].backward()
+    out["out/rec_loss"] = losses["rec_loss"].detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        out["out/scores"] = model(data, ranking="full").numpy()
+    np.savez_compressed(os.path.join(HERE, f"gru4rec_{loss.lower()}.npz"), **out)
+    print(f"gru4rec {loss}: loss={float(losses['rec_loss'].detach()):.6f}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     for loss in ("BCE", "BPR", "CE"):
@@ -366,6 +399,8 @@ if __name__ == "__main__":
     gen_deepfm()
     gen_dcn()
     gen_simgcl()
+    for loss in ("BCE", "BPR"):
+        gen_gru4rec(loss)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -94,3 +94,27 @@ def test_linear_on_engine_gemm_matches_torch_linear_both_ways():
     torch.testing.assert_close(gx, x.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gw, ref.weight.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gb, ref.bias.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("loss", ["BCE", "BPR"])
+def test_gru4rec_matches_reference_loss_gradients_and_scores(loss):
+    from recboard_amd.siblings import GRU4Rec
+    g = np.load(os.path.join(GOLD, f"gru4rec_{loss.lower()}.npz"))
+    N, H = int(g["cfg/N"]), int(g["cfg/hidden"])
+    m = GRU4Rec(N, embedding_dim=64, hidden_size=H, num_blocks=1, emb_dropout_rate=0.0, hidden_dropout_rate=0.0, loss=loss)
+    with torch.no_grad():
+        m.item.weight.copy_(_t(g["param/Item.embeddings.weight"]))
+        m.gru.weight_ih_l0.copy_(_t(g["param/gru.weight_ih_l0"])); m.gru.weight_hh_l0.copy_(_t(g["param/gru.weight_hh_l0"]))
+        m.dense.weight.copy_(_t(g["param/dense.weight"])); m.dense.bias.copy_(_t(g["param/dense.bias"]))
+    seq, pos, neg = _t(g["in/seq"]), _t(g["in/pos"]).reshape(-1), _t(g["in/neg"]).reshape(-1)
+    m.train()
+    out = m.fit(seq, pos, neg)["rec_loss"]
+    assert abs(float(out.detach()) - float(g["out/rec_loss"])) <= 2e-5 * abs(float(g["out/rec_loss"]))
+    out.backward()
+    for name, p in (("Item.embeddings.weight", m.item.weight), ("gru.weight_ih_l0", m.gru.weight_ih_l0), ("gru.weight_hh_l0", m.gru.weight_hh_l0),
+                    ("dense.weight", m.dense.weight), ("dense.bias", m.dense.bias)):
+        torch.testing.assert_close(p.grad, _t(g["grad/" + name]).view(p.shape), rtol=3e-4, atol=2e-6, msg=name)
+    assert float(m.item.weight.grad[0].abs().max()) == 0.0      # the padding row takes no gradient
+    m.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(m.recommend_from_full(seq), _t(g["out/scores"]), rtol=1e-4, atol=1e-5)
