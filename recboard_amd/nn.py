@@ -113,3 +113,35 @@ class Linear(torch.nn.Module):
 
     def forward(self, x):
         return linear(x, self.weight, self.bias)
+
+
+class _SpmmGeneral(torch.autograd.Function):
+    """Y = A X for a CSR matrix A that is NOT symmetric: the backward is the same kernel on the CSR form of A^T (built once by the
+    caller, e.g. with `csr_transpose`).  NGCF's left-normalised adjacency D^-1 (A + I) (NGCF/main.py:76-87)."""
+
+    @staticmethod
+    def forward(ctx, X, crow, col, val, t_crow, t_col, t_val):
+        ctx.save_for_backward(t_crow, t_col, t_val)
+        return _R.spmm_csr(crow, col, val, X.detach())
+
+    @staticmethod
+    def backward(ctx, dY):
+        t_crow, t_col, t_val = ctx.saved_tensors
+        return _R.spmm_csr(t_crow, t_col, t_val, dY.contiguous()), None, None, None, None, None, None
+
+
+def spmm(A, At, X):
+    """A @ X with A = (crow, col, val) and At = the CSR form of its transpose (`csr_transpose(A, n_cols)`)."""
+    return _SpmmGeneral.apply(X, *A, *At)
+
+
+def csr_transpose(A, n_cols):
+    """(crow, col, val) of A^T, rows sorted, columns ascending inside a row.  Host-side, once per adjacency (like the reference's
+    `to_adjacency`, NGCF/main.py:82-86)."""
+    crow, col, val = A
+    n_rows = crow.numel() - 1
+    rows = torch.repeat_interleave(torch.arange(n_rows, device=crow.device), crow[1:] - crow[:-1])
+    order = torch.argsort(col * n_rows + rows)           # by (column, row)
+    t_crow = torch.zeros(n_cols + 1, dtype=torch.int64, device=crow.device)
+    t_crow[1:] = torch.cumsum(torch.bincount(col, minlength=n_cols), 0)
+    return t_crow, rows[order].contiguous(), val[order].contiguous()

@@ -8,6 +8,9 @@ DeepFM additionally have hand-fused engines (sasrec.py, gen.py, deepfm.py).
   SimGCL  (SimGCL/main.py:34-160)  K propagations = recengine::spmm_csr (symmetric adjacency: the backward is the same kernel),
                                    BPR over the propagated tables = recengine::bpr_triplet (gathers + dots + criterion fused),
                                    the two B x B InfoNCE logit matrices = recengine::score_dense, full ranking = score_dense
+  NGCF    (NGCF/main.py:29-160)    K convolutions on the LEFT-normalised adjacency with self loops (not symmetric: nn.spmm runs the backward on
+                                   the transposed CSR), both Linear maps per layer = recengine::gemm, BPR over the concatenated layer outputs =
+                                   recengine::bpr_triplet, full ranking = recengine::gemm
   GRU4Rec (GRU4Rec/main.py:30-190) item lookup = recengine::gather_rows (padding row without gradient; scatter-add gradient), the dense
                                    projection = recengine::gemm, the pair criteria = recengine::bpr_triplet (BPR: gathers + dots +
                                    softplus fused) or gathers + row dots (BCE), CE and full ranking over the catalog = score_dense
@@ -200,3 +203,63 @@ class GRU4Rec(torch.nn.Module):
     def recommend_from_full(self, seqs):
         user, items = self.encode(seqs)
         return rnn.score_full(user.contiguous(), items.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ NGCF
+class NGCFConv(torch.nn.Module):
+    """normalize(dropout(LeakyReLU(W1 (A x + x)) + LeakyReLU(W2 (A x * x))))   (NGCF/main.py:29-50)."""
+
+    def __init__(self, in_features, out_features, dropout_rate=0.0, device=None):
+        super().__init__()
+        self.linear1 = rnn.Linear(in_features, out_features, device=device)
+        self.linear2 = rnn.Linear(in_features, out_features, device=device)
+        self.act = torch.nn.LeakyReLU()
+        self.dropout = torch.nn.Dropout(p=dropout_rate)
+
+    def forward(self, x, A, At):
+        z = rnn.spmm(A, At, x)
+        return F.normalize(self.dropout(self.act(self.linear1(z + x)) + self.act(self.linear2(z * x))), dim=-1)
+
+
+class NGCF(torch.nn.Module):
+    """NGCF (NGCF/main.py:53-160).  adj = (crow, col, val): D^-1 (A + I) of the bipartite interaction graph as CSR."""
+
+    def __init__(self, num_users, num_items, adj, embedding_dim=64, num_layers=3, dropout_rate=0.0, device="cuda"):
+        super().__init__()
+        self.U, self.N = num_users, num_items
+        self.user = rnn.Embedding(num_users, embedding_dim, device=device)
+        self.item = rnn.Embedding(num_items, embedding_dim, device=device)
+        with torch.no_grad():
+            torch.nn.init.xavier_normal_(self.user.weight)
+            torch.nn.init.xavier_normal_(self.item.weight)
+        self.convs = torch.nn.ModuleList([NGCFConv(embedding_dim, embedding_dim, dropout_rate, device) for _ in range(num_layers)])
+        A = tuple(t.to(device) for t in adj)
+        At = rnn.csr_transpose(A, num_users + num_items)
+        for n, t in zip(("crow", "col", "val", "t_crow", "t_col", "t_val"), A + At):
+            self.register_buffer(n, t)
+        self.ranking_buffer = None
+
+    def encode(self):
+        A, At = (self.crow, self.col, self.val), (self.t_crow, self.t_col, self.t_val)
+        x = torch.cat((self.user.weight, self.item.weight), dim=0)
+        outs = [x]
+        for conv in self.convs:
+            x = conv(x, A, At)
+            outs.append(x)
+        return torch.split(torch.cat(outs, dim=-1), (self.U, self.N))
+
+    def fit(self, users, positives, negatives):
+        users, positives, negatives = users.reshape(-1), positives.reshape(-1), negatives.reshape(-1)
+        ue, ie = self.encode()
+        rec_loss = rnn.bpr_triplet(ue.contiguous(), ie.contiguous(), users, positives, negatives)
+        raw = (self.user(users), self.item(positives), self.item(negatives))
+        return {"rec_loss": rec_loss, "emb_loss": sum(t.pow(2).sum() for t in raw) / 2 / users.numel()}
+
+    def reset_ranking_buffers(self):
+        with torch.no_grad():
+            ue, ie = self.encode()
+            self.ranking_buffer = (ue.contiguous(), ie.contiguous())
+
+    def recommend_from_full(self, users):
+        ue, ie = self.ranking_buffer
+        return rnn.linear(rnn.gather_rows(ue, users.reshape(-1)), ie)

@@ -119,12 +119,17 @@ def build(argv_defaults=None):
         def to_normalized_adj(self, normalization="sym"):
             return self.ds.adj
 
+        def to_graph(self):
+            """The training interactions as an undirected bipartite graph: edge_index [2, 2E] (NGCF/main.py:76)."""
+            return types.SimpleNamespace(edge_index=self.ds.edge_index)
+
     class RecDataSet:
         """Toy dataset: carries fields (+ a prebuilt normalised adjacency for LightGCN)."""
 
-        def __init__(self, fields, adj=None):
+        def __init__(self, fields, adj=None, edge_index=None):
             self.fields = FieldModuleList(fields)
             self.adj = adj
+            self.edge_index = edge_index
 
         def train(self):
             return _Split(self)
@@ -135,6 +140,31 @@ def build(argv_defaults=None):
     ds_mod.PredictionRecDataSet = RecDataSet
     data.datasets = ds_mod
     fr.data = data
+
+    # ---------------- graph (NGCF/main.py:76-87: self loops + "left" normalisation; stated here, parity unpinned like the rest of freerec) ----
+    def add_self_loops(edge_index, num_nodes=None):
+        n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+        loops = torch.arange(n, dtype=edge_index.dtype).repeat(2, 1)
+        return torch.cat((edge_index, loops), dim=1), None
+
+    def to_normalized(edge_index, edge_weight=None, normalization="sym"):
+        n = int(edge_index.max()) + 1
+        w = torch.ones(edge_index.shape[1]) if edge_weight is None else edge_weight
+        deg = torch.zeros(n).index_add_(0, edge_index[0], w)
+        if normalization == "left":        # D^-1 A
+            w = w / deg[edge_index[0]]
+        elif normalization == "right":
+            w = w / deg[edge_index[1]]
+        else:
+            w = w / (deg[edge_index[0]].sqrt() * deg[edge_index[1]].sqrt())
+        return edge_index, w
+
+    def to_adjacency(edge_index, edge_weight, num_nodes):
+        return torch.sparse_coo_tensor(edge_index, edge_weight, (num_nodes, num_nodes)).coalesce().to_sparse_csr()
+
+    graph_mod = types.ModuleType("freerec.graph")
+    graph_mod.add_self_loops, graph_mod.to_normalized, graph_mod.to_adjacency = add_self_loops, to_normalized, to_adjacency
+    fr.graph = graph_mod
 
     # ---------------- models ----------------
     class RecSysArch(nn.Module):
@@ -256,6 +286,6 @@ def build(argv_defaults=None):
         "freerec.data.tags": tags, "freerec.data.fields": fields_mod,
         "freerec.data.datasets": ds_mod, "freerec.models": models,
         "freerec.models.nn": models.nn, "freerec.criterions": crit,
-        "freerec.launcher": launcher, "freerec.utils": fr.utils,
+        "freerec.launcher": launcher, "freerec.utils": fr.utils, "freerec.graph": graph_mod,
     }
     return fr, mods

@@ -17,6 +17,7 @@ Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic
   deepfm.npz   : DeepFM/main.py   logits, loss, grads (train-mode BN), eval sigmoid scores
   dcn.npz      : DCN/main.py      logits, loss, grads (train-mode BN), eval sigmoid scores
   gru4rec_{bce,bpr}.npz : GRU4Rec/main.py fit loss + every gradient + full scores (dropouts 0)
+  ngcf.npz     : NGCF/main.py     fit (rec_loss, emb_loss) + every gradient + full scores on D^-1 (A + I)
   simgcl.npz   : SimGCL/main.py   fit (rec_loss, emb_loss, ssl_loss at eps = 0: the noise is torch.rand_like) + grads + full scores
 """
 import importlib.util
@@ -357,6 +358,49 @@ def gen_simgcl():
     print("simgcl: " + " ".join(f"{k}={float(v):.6f}" for k, v in losses.items()))
 
 
+def gen_ngcf():
+    torch.manual_seed(1)
+    U, N, B = 30, 40, 16
+    g = torch.Generator().manual_seed(23)
+    edges = set()
+    while len(edges) < 150:
+        edges.add((int(torch.randint(0, U, (1,), generator=g)), int(torch.randint(0, N, (1,), generator=g))))
+    e = torch.tensor(sorted(edges), dtype=torch.long)
+    ei = torch.stack((torch.cat((e[:, 0], e[:, 1] + U)), torch.cat((e[:, 1] + U, e[:, 0]))))     # both directions
+    fr, ref = import_ref("NGCF", "ref_ngcf", dict(dropout_rate=0.0))
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)], edge_index=ei)
+    model = ref.NGCF(ds)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif "embeddings" in n:
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+    users = torch.randint(0, U, (B, 1), generator=g)
+    ipos = torch.randint(0, N, (B, 1), generator=g)
+    ineg = torch.randint(0, N, (B, 1), generator=g)
+    data = {model.User: users, model.IPos: ipos, model.INeg: ineg}
+    adj = model.Adj
+    out = {"in/users": users.numpy(), "in/pos": ipos.numpy(), "in/neg": ineg.numpy(),
+           "in/adj_crow": adj.crow_indices().numpy(), "in/adj_col": adj.col_indices().numpy(), "in/adj_val": adj.values().numpy(),
+           "cfg/num_layers": np.int64(ref.cfg.num_layers)}
+    out.update({k: v for k, v in sd_np(model).items() if "Adj" not in k})
+    model.train()
+    losses = model(data)
+    (losses["rec_loss"] + losses["emb_loss"]).backward()
+    out["out/rec_loss"], out["out/emb_loss"] = losses["rec_loss"].detach().numpy(), losses["emb_loss"].detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        ue, ie = model.encode()
+        model.reset_ranking_buffers()
+        scores = model(data, ranking="full")
+    out["out/userEmbds"], out["out/itemEmbds"], out["out/scores"] = ue.numpy(), ie.numpy(), scores.numpy()
+    np.savez_compressed(os.path.join(HERE, "ngcf.npz"), **out)
+    print(f"ngcf: rec={float(losses['rec_loss'].detach()):.6f} emb={float(losses['emb_loss'].detach()):.6f}")
+
+
 def gen_gru4rec(loss):
     torch.manual_seed(1)
     fr, ref = import_ref("GRU4Rec", f"ref_gru4rec_{loss}", dict(loss=loss, emb_dropout_rate=0.0, hidden_dropout_rate=0.0, hidden_size=48,
@@ -399,6 +443,7 @@ if __name__ == "__main__":
     gen_deepfm()
     gen_dcn()
     gen_simgcl()
+    gen_ngcf()
     for loss in ("BCE", "BPR"):
         gen_gru4rec(loss)
     for f in sorted(os.listdir(HERE)):

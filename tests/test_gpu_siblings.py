@@ -118,3 +118,36 @@ def test_gru4rec_matches_reference_loss_gradients_and_scores(loss):
     m.eval()
     with torch.no_grad():
         torch.testing.assert_close(m.recommend_from_full(seq), _t(g["out/scores"]), rtol=1e-4, atol=1e-5)
+
+
+def test_ngcf_matches_reference_losses_gradients_and_scores():
+    """NGCF on the LEFT-normalised adjacency with self loops (not symmetric): nn.spmm's backward runs on the transposed CSR."""
+    from recboard_amd.siblings import NGCF
+    g = np.load(os.path.join(GOLD, "ngcf.npz"))
+    U, N = g["param/User.embeddings.weight"].shape[0], g["param/Item.embeddings.weight"].shape[0]
+    adj = (_t(g["in/adj_crow"]), _t(g["in/adj_col"]), _t(g["in/adj_val"]))
+    m = NGCF(U, N, adj, embedding_dim=g["param/User.embeddings.weight"].shape[1], num_layers=int(g["cfg/num_layers"]), dropout_rate=0.0)
+    sd = m.state_dict()
+    with torch.no_grad():
+        m.user.weight.copy_(_t(g["param/User.embeddings.weight"])); m.item.weight.copy_(_t(g["param/Item.embeddings.weight"]))
+        for k in sd:
+            if k.startswith("convs."):
+                sd[k].copy_(_t(g["param/" + k]).view(sd[k].shape))
+    users, pos, neg = (_t(g["in/" + k]).reshape(-1) for k in ("users", "pos", "neg"))
+    m.train()
+    losses = m.fit(users, pos, neg)
+    for k in ("rec_loss", "emb_loss"):
+        assert abs(float(losses[k].detach()) - float(g["out/" + k])) <= 2e-5 * abs(float(g["out/" + k])), k
+    (losses["rec_loss"] + losses["emb_loss"]).backward()
+    torch.testing.assert_close(m.user.weight.grad, _t(g["grad/User.embeddings.weight"]), rtol=3e-4, atol=2e-6)
+    torch.testing.assert_close(m.item.weight.grad, _t(g["grad/Item.embeddings.weight"]), rtol=3e-4, atol=2e-6)
+    for k, p in m.named_parameters():
+        if k.startswith("convs."):
+            torch.testing.assert_close(p.grad, _t(g["grad/" + k]).view(p.shape), rtol=3e-4, atol=2e-6, msg=k)
+    m.eval()
+    with torch.no_grad():
+        ue, ie = m.encode()
+        torch.testing.assert_close(ue, _t(g["out/userEmbds"]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(ie, _t(g["out/itemEmbds"]), rtol=1e-5, atol=1e-6)
+        m.reset_ranking_buffers()
+        torch.testing.assert_close(m.recommend_from_full(users), _t(g["out/scores"]), rtol=1e-4, atol=1e-5)
