@@ -145,3 +145,48 @@ def csr_transpose(A, n_cols):
     t_crow = torch.zeros(n_cols + 1, dtype=torch.int64, device=crow.device)
     t_crow[1:] = torch.cumsum(torch.bincount(col, minlength=n_cols), 0)
     return t_crow, rows[order].contiguous(), val[order].contiguous()
+
+
+class GraphedStep:
+    """One whole training step -- zero the gradients, `fit`, backward, optimizer step -- captured ONCE as a hipGraph and replayed per
+    batch: a model file on the torch-op surface is a chain of small launches (a DCN step is ~150 of them) and the CPU launch path,
+    not the GPU, sets the eager step time.  The engine's ops are stream-ordered and allocate through torch only, so they capture
+    like aten's; what cannot be captured is a host synchronisation inside `fit` (boolean-mask indexing, `.item()`).
+
+        step = GraphedStep(model, lambda x, y: sum(model.fit(x, y).values()), torch.optim.Adam(model.parameters(), capturable=True), (x0, y0))
+        for x, y in batches: loss = step(x, y)      # `loss` is the graph's static output tensor: read it before the next call
+
+    Batches must have the example's shapes and dtypes (a short last batch takes its own GraphedStep)."""
+
+    def __init__(self, model, loss_fn, optimizer, example_inputs, warmup=3):
+        self.static_in = tuple(t.clone() for t in example_inputs)
+        self.optimizer = optimizer
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        keep = [p.detach().clone() for p in params]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up on a side stream (allocator pools, lazy optimizer state)
+            for _ in range(warmup):
+                optimizer.zero_grad(set_to_none=True)
+                loss_fn(*self.static_in).backward()
+                optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = loss_fn(*self.static_in)
+            self.loss.backward()
+            optimizer.step()
+        with torch.no_grad():                          # the warm-up and capture steps are rolled back (parameters and Adam state)
+            for p, k in zip(params, keep):
+                p.copy_(k)
+            for st in optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+
+    def __call__(self, *inputs):
+        for s, t in zip(self.static_in, inputs):
+            s.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return self.loss

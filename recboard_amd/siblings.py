@@ -14,6 +14,12 @@ DeepFM additionally have hand-fused engines (sasrec.py, gen.py, deepfm.py).
   GRU4Rec (GRU4Rec/main.py:30-190) item lookup = recengine::gather_rows (padding row without gradient; scatter-add gradient), the dense
                                    projection = recengine::gemm, the pair criteria = recengine::bpr_triplet (BPR: gathers + dots +
                                    softplus fused) or gathers + row dots (BCE), CE and full ranking over the catalog = score_dense
+  JGCF    (JGCF/main.py:39-160, modules.py:8-83) the Jacobi-polynomial recurrence = one recengine::spmm_csr per order (symmetric adjacency),
+                                   BPR over the [low-pass | mid-pass] tables = recengine::bpr_triplet, full ranking = recengine::gemm
+  BERT4Rec (BERT4Rec/main.py:33-195) item lookup = recengine::gather_rows (padding row without gradient), the encoder states at the MASKED
+                                   positions = recengine::gather_rows, the projection to the N + 2 logits (`fc`) = recengine::gemm on those
+                                   rows only (the reference projects all B*S rows and then selects), full ranking = recengine::gemm on the
+                                   last position.  The bidirectional encoder itself is torch.nn.TransformerEncoder, as in the reference.
 Elementwise glue (BatchNorm / ReLU / dropout, the cross layer's x0 * s + b, L2 normalisation, log-softmax of the B x B logits) and
 the GRU recurrence itself (torch.nn.GRU: MIOpen) stay with aten: no table, no catalog and no catalog-sized contraction is touched there.
 """
@@ -263,3 +269,117 @@ class NGCF(torch.nn.Module):
     def recommend_from_full(self, users):
         ue, ie = self.ranking_buffer
         return rnn.linear(rnn.gather_rows(ue, users.reshape(-1)), ie)
+
+
+# ------------------------------------------------------------------------------------------------ JGCF
+class JGCF(torch.nn.Module):
+    """JGCF (JGCF/main.py:39-160): z_0 = X, z_l from the Jacobi three-term recurrence on the symmetric normalised adjacency
+    (JGCF/modules.py:8-49), low = mean_l(coef_l z_l) with coef = cumprod(tanh(gamma) * scaling) (modules.py:77-83; gamma is a frozen
+    parameter), mid = weight4mid * X - low, tables = [low | mid]; BPR + L2 regulariser."""
+
+    def __init__(self, num_users, num_items, adj, embedding_dim=64, num_layers=3, scaling_factor=3.0, alpha=1.0, beta=1.0, weight4mid=0.1,
+                 device="cuda"):
+        super().__init__()
+        self.U, self.N, self.L, self.scaling, self.a, self.b, self.weight4mid = num_users, num_items, num_layers, scaling_factor, alpha, beta, weight4mid
+        self.user = rnn.Embedding(num_users, embedding_dim, device=device)
+        self.item = rnn.Embedding(num_items, embedding_dim, device=device)
+        with torch.no_grad():
+            torch.nn.init.normal_(self.user.weight, std=1e-4)
+            torch.nn.init.normal_(self.item.weight, std=1e-4)
+        self.gammas = torch.nn.Parameter(torch.full((num_layers + 1, 1), min(1.0 / scaling_factor, 1.0), device=device), requires_grad=False)
+        for n, t in zip(("crow", "col", "val"), adj):
+            self.register_buffer(n, t.to(device))
+        self.ranking_buffer = None
+
+    def _conv(self, x):
+        a, b = self.a, self.b
+        zs = [x]
+        for l in range(1, self.L + 1):
+            Az = rnn.spmm_sym(self.crow, self.col, self.val, zs[-1].contiguous())
+            if l == 1:
+                z = (a - b) / 2 * zs[-1] + (a + b + 2) / 2 * Az
+            else:
+                c0 = 2 * l * (l + a + b) * (2 * l + a + b - 2)
+                c1 = (2 * l + a + b - 1) * (a ** 2 - b ** 2)
+                c2 = (2 * l + a + b - 1) * (2 * l + a + b) * (2 * l + a + b - 2)
+                c3 = 2 * (l + a - 1) * (l + b - 1) * (2 * l + a + b)
+                z = (c1 * zs[-1] + c2 * Az - c3 * zs[-2]) / c0
+            zs.append(z)
+        coefs = (self.gammas.tanh() * self.scaling).cumprod(dim=0)
+        return (torch.stack(zs, dim=1) * coefs).mean(1)
+
+    def encode(self):
+        x = torch.cat((self.user.weight, self.item.weight), dim=0)
+        low = self._conv(x)
+        return torch.split(torch.cat((low, self.weight4mid * x - low), dim=1), (self.U, self.N))
+
+    def fit(self, users, positives, negatives):
+        users, positives, negatives = users.reshape(-1), positives.reshape(-1), negatives.reshape(-1)
+        ue, ie = self.encode()
+        rec_loss = rnn.bpr_triplet(ue.contiguous(), ie.contiguous(), users, positives, negatives)
+        raw = (self.user(users), self.item(positives), self.item(negatives))
+        return {"rec_loss": rec_loss, "emb_loss": sum(t.pow(2).sum() for t in raw) / 2 / users.numel()}
+
+    def reset_ranking_buffers(self):
+        with torch.no_grad():
+            ue, ie = self.encode()
+            self.ranking_buffer = (ue.contiguous(), ie.contiguous())
+
+    def recommend_from_full(self, users):
+        ue, ie = self.ranking_buffer
+        return rnn.linear(rnn.gather_rows(ue, users.reshape(-1)), ie)
+
+
+# ------------------------------------------------------------------------------------------------ BERT4Rec
+class BERT4Rec(torch.nn.Module):
+    """BERT4Rec (BERT4Rec/main.py:33-195): item + position embeddings -> LayerNorm -> dropout -> bidirectional TransformerEncoder
+    (post-norm, GELU, feed-forward 4 D) -> `fc` to N + NUM_PADS logits -> cross entropy at the masked positions.
+    Ids: 0 = padding, 1 = the mask token, item i = i + 2."""
+
+    NUM_PADS, PADDING_VALUE, MASKING_VALUE = 2, 0, 1
+
+    def __init__(self, num_items, maxlen=50, embedding_dim=64, num_heads=4, num_blocks=2, mask_ratio=0.3, dropout_rate=0.2, device="cuda"):
+        super().__init__()
+        self.N, self.maxlen, self.mask_ratio = num_items, maxlen, mask_ratio
+        self.item = rnn.Embedding(num_items + self.NUM_PADS, embedding_dim, padding_idx=self.PADDING_VALUE, device=device)
+        self.Position = torch.nn.Embedding(maxlen, embedding_dim, device=device)
+        self.layernorm = torch.nn.LayerNorm(embedding_dim, device=device)
+        self.dropout = torch.nn.Dropout(dropout_rate)
+        self.encoder = torch.nn.TransformerEncoder(
+            torch.nn.TransformerEncoderLayer(d_model=embedding_dim, nhead=num_heads, dim_feedforward=embedding_dim * 4, dropout=dropout_rate,
+                                             activation="gelu", batch_first=True, device=device), num_layers=num_blocks)
+        self.fc = rnn.Linear(embedding_dim, num_items + self.NUM_PADS, device=device)
+        with torch.no_grad():                                    # BERT4Rec.reset_parameters (BERT4Rec/main.py:89-98)
+            for m in self.modules():
+                if isinstance(m, (torch.nn.Linear, rnn.Linear, torch.nn.Embedding, rnn.Embedding)):
+                    torch.nn.init.xavier_normal_(m.weight)
+                    m.weight.clamp_(-0.02, 0.02)
+                    if getattr(m, "bias", None) is not None:
+                        m.bias.zero_()
+
+    def random_mask(self, seqs, p, rnds=None):
+        """BERT4Rec.random_mask (BERT4Rec/main.py:155-164); `rnds` [B, S] in [0, 1) stands in for torch.rand (tests)."""
+        pad = seqs == self.PADDING_VALUE
+        if rnds is None:
+            rnds = torch.rand(seqs.shape, device=seqs.device)
+        masked = torch.where(rnds < p, torch.full_like(seqs, self.MASKING_VALUE), seqs).masked_fill(pad, self.PADDING_VALUE)
+        masks = masked == self.MASKING_VALUE
+        return masked, seqs[masks], masks
+
+    def encode(self, seqs):
+        """seqs [B, maxlen] int64 -> states [B, maxlen, D]."""
+        B, S = seqs.shape
+        pad = seqs == self.PADDING_VALUE
+        x = self.item(seqs.reshape(-1)).reshape(B, S, -1) + self.Position.weight[:S].unsqueeze(0)
+        x = self.dropout(self.layernorm(x))
+        return self.encoder(x, src_key_padding_mask=pad)
+
+    def fit(self, seqs, rnds=None):
+        masked, labels, masks = self.random_mask(seqs, self.mask_ratio, rnds)
+        h = self.encode(masked)
+        rows = rnn.gather_rows(h.reshape(-1, h.shape[-1]).contiguous(), masks.reshape(-1).nonzero().squeeze(1))
+        return {"rec_loss": F.cross_entropy(self.fc(rows), labels)}
+
+    def recommend_from_full(self, seqs):
+        """seqs: the evaluation pipe's rows (left-padded history of maxlen - 1, the mask token last)."""
+        return self.fc(self.encode(seqs)[:, -1, :].contiguous())[:, self.NUM_PADS:]

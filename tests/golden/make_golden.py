@@ -17,6 +17,8 @@ Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic
   deepfm.npz   : DeepFM/main.py   logits, loss, grads (train-mode BN), eval sigmoid scores
   dcn.npz      : DCN/main.py      logits, loss, grads (train-mode BN), eval sigmoid scores
   gru4rec_{bce,bpr}.npz : GRU4Rec/main.py fit loss + every gradient + full scores (dropouts 0)
+  jgcf.npz     : JGCF/main.py     fit (rec_loss, emb_loss) + table gradients + [low | mid] tables + full scores
+  bert4rec.npz : BERT4Rec/main.py fit loss (the mask draw recorded) + every gradient + full scores (dropout 0)
   ngcf.npz     : NGCF/main.py     fit (rec_loss, emb_loss) + every gradient + full scores on D^-1 (A + I)
   simgcl.npz   : SimGCL/main.py   fit (rec_loss, emb_loss, ssl_loss at eps = 0: the noise is torch.rand_like) + grads + full scores
 """
@@ -433,6 +435,93 @@ def gen_gru4rec(loss):
     print(f"gru4rec {loss}: loss={float(losses['rec_loss'].detach()):.6f}")
 
 
+def gen_jgcf():
+    torch.manual_seed(1)
+    U, N, B = 30, 40, 16
+    g = torch.Generator().manual_seed(13)
+    edges = set()
+    while len(edges) < 150:
+        edges.add((int(torch.randint(0, U, (1,), generator=g)), int(torch.randint(0, N, (1,), generator=g))))
+    adj = sym_norm_adj(U, N, sorted(edges))
+    sys.path.insert(0, os.path.join(REF, "JGCF"))                 # (JGCF/main.py imports its sibling modules.py)
+    try:
+        fr, ref = import_ref("JGCF", "ref_jgcf", dict(alpha=1.5, beta=0.5))      # (alpha != beta: the c1 term of the recurrence is live)
+    finally:
+        sys.path.pop(0)
+        sys.modules.pop("modules", None)
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)], adj=adj)
+    model = ref.JGCF(ds)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.requires_grad:
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+    users = torch.randint(0, U, (B, 1), generator=g)
+    ipos = torch.randint(0, N, (B, 1), generator=g)
+    ineg = torch.randint(0, N, (B, 1), generator=g)
+    data = {model.User: users, model.IPos: ipos, model.INeg: ineg}
+    out = {"in/users": users.numpy(), "in/pos": ipos.numpy(), "in/neg": ineg.numpy(),
+           "in/adj_crow": adj.crow_indices().numpy(), "in/adj_col": adj.col_indices().numpy(), "in/adj_val": adj.values().numpy(),
+           "cfg/num_layers": np.int64(ref.cfg.num_layers), "cfg/alpha": np.float64(ref.cfg.alpha), "cfg/beta": np.float64(ref.cfg.beta),
+           "cfg/scaling_factor": np.float64(ref.cfg.scaling_factor), "cfg/weight4mid": np.float64(ref.cfg.weight4mid)}
+    out.update(sd_np(model))
+    model.train()
+    losses = model(data)
+    (losses["rec_loss"] + losses["emb_loss"]).backward()
+    for k in ("rec_loss", "emb_loss"):
+        out["out/" + k] = losses[k].detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        ue, ie = model.encode()
+        model.reset_ranking_buffers()
+        scores = model(data, ranking="full")
+    out["out/userEmbds"], out["out/itemEmbds"], out["out/scores"] = ue.numpy(), ie.numpy(), scores.numpy()
+    np.savez_compressed(os.path.join(HERE, "jgcf.npz"), **out)
+    print("jgcf: " + " ".join(f"{k}={float(v):.6f}" for k, v in losses.items()))
+
+
+def gen_bert4rec():
+    torch.manual_seed(1)
+    S = 20
+    fr, ref = import_ref("BERT4Rec", "ref_bert4rec", dict(dropout_rate=0.0, embedding_dim=64, num_heads=4, num_blocks=2, maxlen=S, mask_ratio=0.3))
+    N, B = 150, 12
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=30), F("ITEM", "ITEM", "ID", count=N)])
+    model = ref.BERT4Rec(ds)
+    g = torch.Generator().manual_seed(23)
+    with torch.no_grad():                                       # biases / LayerNorm affine off their initial 0 / 1
+        for k, p in model.named_parameters():
+            if k.endswith("bias") or "norm" in k:
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+    lens = torch.randint(2, S + 1, (B,), generator=g)
+    lens[0] = S
+    seq = torch.zeros(B, S, dtype=torch.long)
+    for b in range(B):
+        seq[b, S - int(lens[b]):] = torch.randint(0, N, (int(lens[b]),), generator=g) + 2      # LEFT-padded, ids + NUM_PADS
+    torch.manual_seed(5)
+    rnds = torch.rand(seq.size())                               # what random_mask will draw (BERT4Rec/main.py:157)
+    out = {"in/seq": seq.numpy(), "in/rnds": rnds.numpy(), "cfg/N": np.int64(N), "cfg/maxlen": np.int64(S)}
+    out.update(sd_np(model))
+    model.train()
+    torch.manual_seed(5)
+    data = {model.ISeq: seq.clone()}
+    losses = model(data)
+    assert torch.equal(data[model.ISeq] == 1, (rnds < 0.3) & (seq != 0))
+    losses["rec_loss"].backward()
+    out["out/rec_loss"] = losses["rec_loss"].detach().numpy()
+    out["out/n_masked"] = np.int64(int((data[model.ISeq] == 1).sum()))
+    out.update(grads_np(model))
+    model.eval()
+    seq_eval = torch.cat((seq[:, 1:], torch.ones(B, 1, dtype=torch.long)), 1)     # lpad_(maxlen - 1) + rpad_(maxlen, MASKING_VALUE)
+    out["in/seq_eval"] = seq_eval.numpy()
+    with torch.no_grad():
+        out["out/states_eval"] = model.encode({model.ISeq: seq_eval}).numpy()
+        out["out/scores"] = model({model.ISeq: seq_eval}, ranking="full").numpy()
+    np.savez_compressed(os.path.join(HERE, "bert4rec.npz"), **out)
+    print(f"bert4rec: loss={float(losses['rec_loss'].detach()):.6f} masked={int(out['out/n_masked'])}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     for loss in ("BCE", "BPR", "CE"):
@@ -446,6 +535,8 @@ if __name__ == "__main__":
     gen_ngcf()
     for loss in ("BCE", "BPR"):
         gen_gru4rec(loss)
+    gen_jgcf()
+    gen_bert4rec()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

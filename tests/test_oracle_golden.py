@@ -288,3 +288,34 @@ def test_sibling_oracles_reproduce_reference_fixtures():
         assert abs(float(v) - float(s["out/" + k])) <= 1e-5 * abs(float(s["out/" + k])), k
     np.testing.assert_allclose(ue.numpy(), s["out/userEmbds"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(ie.numpy(), s["out/itemEmbds"], rtol=1e-5, atol=1e-6)
+
+
+def test_bert4rec_oracle_reproduces_reference_fixture():
+    """oracle/siblings.py's post-norm encoder restatement against BERT4Rec/main.py's own states, loss and scores (bert4rec.npz)."""
+    import torch
+    from oracle import siblings
+    g = np.load(os.path.join(G, "bert4rec.npz"))
+    sd = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}
+    seq_eval = torch.from_numpy(g["in/seq_eval"])
+    h = siblings.bert4rec_states(sd, seq_eval, 2, 4)
+    real = (seq_eval != 0).numpy()          # (eval mode: torch's nested-tensor fast path returns zeros at padded positions)
+    np.testing.assert_allclose(h.numpy()[real], g["out/states_eval"][real], rtol=1e-4, atol=2e-5)
+    scores = (h[:, -1, :] @ sd["fc.weight"].t() + sd["fc.bias"])[:, 2:]
+    np.testing.assert_allclose(scores.numpy(), g["out/scores"], rtol=1e-4, atol=2e-5)
+    loss = siblings.bert4rec_loss(sd, torch.from_numpy(g["in/seq"]), torch.from_numpy(g["in/rnds"]), 0.3, 2, 4)
+    assert abs(float(loss) - float(g["out/rec_loss"])) <= 1e-5 * abs(float(g["out/rec_loss"]))
+
+
+def test_jgcf_oracle_reproduces_reference_fixture():
+    import torch
+    from oracle import siblings
+    g = np.load(os.path.join(G, "jgcf.npz"))
+    T = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    ue, ie = siblings.jgcf_tables(T("param/User.embeddings.weight"), T("param/Item.embeddings.weight"), T("in/adj_crow"), T("in/adj_col"),
+                                  T("in/adj_val"), int(g["cfg/num_layers"]), float(g["cfg/alpha"]), float(g["cfg/beta"]),
+                                  float(g["cfg/scaling_factor"]), float(g["cfg/weight4mid"]), T("param/conv.gammas"))
+    np.testing.assert_allclose(ue.numpy(), g["out/userEmbds"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ie.numpy(), g["out/itemEmbds"], rtol=1e-5, atol=1e-6)
+    u, p, n = (g["in/" + k].reshape(-1) for k in ("users", "pos", "neg"))
+    rec = torch.nn.functional.softplus((ue[u] * ie[n]).sum(-1) - (ue[u] * ie[p]).sum(-1)).mean()
+    assert abs(float(rec) - float(g["out/rec_loss"])) <= 1e-5 * abs(float(g["out/rec_loss"]))
