@@ -114,6 +114,8 @@ def timed_graph(model, lossf, inputs, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--only", default=None, help="substring of the case name (profiling runs)")
+    ap.add_argument("--kinds", default="engine,aten")
     args = ap.parse_args()
     gen = torch.Generator().manual_seed(1)
     U, N, E = 22363, 12101, 153776                  # Beauty's graph size
@@ -146,8 +148,12 @@ def main():
     }
     out = {}
     for name, (make, inputs, graphable) in cases.items():
+        if args.only and args.only not in name:
+            continue
         row = {}
         for kind, table in (("engine", ENGINE), ("aten", ATEN)):
+            if kind not in args.kinds.split(","):
+                continue
             use(table)
             # (aten's operators are measured eagerly only: their captured DCN step ended in a GPU memory fault on this image)
             for mode in ("eager", "graph") if graphable and kind == "engine" else ("eager",):
