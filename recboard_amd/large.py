@@ -138,9 +138,10 @@ class SASRecLargeTableEngine(SASRecEngine):
         p = self.p_drop if self.training else 0.0
         Ppos = self.params["Position.weight"]
         kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
-        if self.encoder == "fused" and self.compact_rows and table is None:
+        if self.encoder == "fused" and self.compact_rows:
             # SASRecEngine's compact-row step minus the dense table gradient: forward + criterion + backward of every work item in one
             # launch; what comes back are the 3 x NR contribution rows with their destination keys (0 = none) for the row-sparse Adam
+            # (keys are rows of `table` when one is given: the sharded engine's batch-local table)
             W = self._buffers(B, S)
             G = A.views(A.grad)
             lw, lb = self.params["lastLN.weight"].detach(), self.params["lastLN.bias"].detach()
@@ -267,9 +268,11 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
 
       * forward: ONE all-to-all round trip fetches the 3*B*S rows a local batch touches (sequence items, positives, negatives)
         into a batch-local table; the embedding front end, the encoder and the criterion run on it unchanged;
-      * backward: the 3*B*S item-gradient contribution rows travel to the owners of their table rows (one all-to-all) and each
-        owner applies one row-sparse Adam update per distinct row of its shard -- no table-sized gradient, no all-reduce of
-        the table; the encoder's dense gradient arena is averaged with one all-reduce (`grad_hook` semantics of bench.py).
+      * forward + criterion + backward of every work item in ONE launch on the batch-local table (SASRecEngine's compact-row step);
+      * the item-gradient contribution rows (3 per real token, each tagged with the lookup it belongs to) travel to the owners of
+        their table rows (one all-to-all) and each owner applies one row-sparse Adam update per distinct row of its shard -- no
+        table-sized gradient, no all-reduce of the table; the encoder's dense gradient arena is averaged with one all-reduce
+        (`grad_hook` semantics of bench.py).
 
     With a process group of size 1 and dedup=False the step is `SASRecLargeTableEngine.train_step` on the same numbers, bit for bit
     (tests/test_gpu_sasrec.py); with dedup (the default: every distinct row travels once, gradient rows pre-summed per sender) the
@@ -286,7 +289,6 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         self.world = dist.get_world_size(group)
         kw["table_init"] = "counter"
         super().__init__(*args, **kw)
-        self.split_long = False      # (the sharded step runs the all-positions criterion on its batch-local table: whole items)
 
     def _alloc_table(self, seed):
         from .sharded import ShardedTable
@@ -340,38 +342,99 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         A = self.arena
         ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
 
-    def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
+    def _sharded_body(self, seq, pos, neg, aux, sd, grad_hook=None, seed_dev=None, hyper=None):
+        """Lookup -> batch-local table -> forward + criterion + backward -> gradient rows to their owners -> both optimizers.
+        hyper (device float32[2]: step size, bias correction): the captured form; otherwise the host's step count."""
         import torch.distributed as dist
         A, D = self.arena, self.D
         B, S = seq.shape
         n = B * S
-        if aux is None:
-            aux = self.prepare_batch(seq, pos, neg)
-        valid, rows_all, count = aux.valid, aux.rows_all, aux.count
-        sd = self._step_seed()
         p = self.p_drop if self.training else 0.0
-        Ppos = self.params["Position.weight"]
         # the batch-local table: row 0 = padding, row 1 + j = table row rows_all[j]  (one all-to-all round trip)
-        rows, route = self.table.lookup(rows_all)
+        rows, route = self.table.lookup(aux.rows_all)
         T = torch.cat([torch.zeros((1, D), dtype=torch.float32, device=self.device), rows], 0)
         ar = torch.arange(1, n + 1, device=self.device)
         seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
-        # positives / negatives are rows n+1.. and 2n+1.. of the batch-local table (the criterion adds e_off = 1 to the 0-based ids);
-        # the embedding front end, the encoder and the criterion run on it unchanged (fused kernels or the torch block stack)
-        loss, C, _ = self._grads(seq_l, (ar - 1 + n).view(B, S), (ar - 1 + 2 * n).view(B, S), aux, sd, table=T)
+        # positives / negatives are rows n+1.. and 2n+1.. of the batch-local table (the criterion adds e_off = 1 to the 0-based ids).
+        # compact-row step: C holds 3 x NR contribution rows, `keys` their rows of T (0 = none); key - 1 = the lookup they belong to.
+        # (all-positions step, compact_rows = False: one row per lookup, keys None)
+        loss, C, keys = self._grads(seq_l, (ar - 1 + n).view(B, S), (ar - 1 + 2 * n).view(B, S), aux, sd, seed_dev=seed_dev, table=T)
+        positions = None if keys is None or keys is aux.rows_all else keys - 1
         if self.world > 1:
             C.mul_(1.0 / self.world)                 # the loss of the global batch is the mean of the ranks' losses
             dist.all_reduce(A.grad, op=dist.ReduceOp.AVG, group=self.group)
         if grad_hook is not None:
             grad_hook(A.grad)
-        A.step += 1
         # contribution rows of pad / invalid positions are zero rows addressed to global row 0 (rank 0 drops them)
-        self.table.backward_sparse_adam(C, route, A.step, self.lr, self.betas, 1e-8, self.wd, padding_global_row=0)
-        self._dense_adam()
-        return loss.squeeze(0)
+        self.table.backward_sparse_adam(C, route, A.step + 1, self.lr, self.betas, 1e-8, self.wd, padding_global_row=0, positions=positions,
+                                        hyper=hyper)
+        if hyper is not None:
+            ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
+        else:
+            A.step += 1
+            self._dense_adam()
+        return loss
 
-    def train_step_graph(self, *a, **k):
-        raise NotImplementedError("the exchange's split sizes are host-side: the sharded step runs eagerly")
+    def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
+        if aux is None:
+            aux = self.prepare_batch(seq, pos, neg)
+        return self._sharded_body(seq, pos, neg, aux, self._step_seed(), grad_hook=grad_hook).squeeze(0)
+
+    # ---- the same step as ONE hipGraph replay.  Needs the fixed-capacity exchange (capacity_factor: equal-split all-to-alls whose sizes
+    #      do not depend on the data -- nothing in the step reads device memory on the host) and RCCL's stream capture; every rank must
+    #      capture and replay in step.  Overflowing lookups are counted on the device: `self.table.check_capacity()` at a sync point.
+    def _capture(self, B, S, with_adam=True):
+        if self.capacity_factor is None:
+            raise NotImplementedError("the exchange's split sizes are host-side: train_step_graph needs capacity_factor (fixed-capacity exchange)")
+        A = self.arena
+        blob = torch.zeros(ops.prep_layout(B, S)[1], dtype=torch.uint8, device=self.device)
+        state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        hyper = state.view(torch.float32)[2:4]
+        z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
+        T = self.table
+        keep = [t.clone() for t in (A.data, A.m, A.v, A.grad)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up with an all-padding batch: every lookup is the padding row, no table row changes
+            pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                                       max_tiles=self._max_tiles(), split=self._split())
+            pb.count.fill_(1)
+            for _ in range(3):
+                self._sharded_body(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, hyper=hyper)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            loss = self._sharded_body(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, hyper=hyper)
+        for t, k in zip((A.data, A.m, A.v, A.grad), keep):
+            t.copy_(k)
+        if T.dropped is not None:
+            T.dropped.zero_()                  # (the all-padding warm-up sends every lookup to the padding row's owner)
+        return dict(graph=graph, blob=blob, state=state, loss=loss)
+
+    def release_graphs(self):
+        """Drop the captured steps.  Call before `dist.destroy_process_group()`: a live hipGraph holds the communicator's captured work
+        and RCCL's teardown waits for it (measured on RCCL 2.26.6: the destroy call never returns otherwise)."""
+        if getattr(self, "_graphs", None):
+            self._graphs.clear()
+            torch.cuda.synchronize()
+
+    def train_step_graph(self, seq, pos, neg, grad_hook=None):
+        if grad_hook is not None:
+            raise NotImplementedError("the captured sharded step averages the dense gradients itself (one all-reduce inside the graph)")
+        A = self.arena
+        B, S = seq.shape
+        key = (B, S, self.training)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(B, S)
+        g = self._graphs[key]
+        ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split())
+        g["graph"].replay()
+        A.step += 1
+        return g["loss"].squeeze(0)
 
     def encode(self, seq):
         with torch.no_grad():

@@ -40,6 +40,11 @@ class EngineLocalOps:
         from . import ops
         ops.sparse_adam_rows(g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=padding_idx)
 
+    def sparse_adam_dev(self, g, idx, W, m, v, hyper, b1, b2, eps, wd, padding_idx=-1):
+        """sparse_adam with the step-dependent scalars in device memory (captured steps)."""
+        from . import ops
+        ops.sparse_adam_rows_dev(g, idx, W, m, v, hyper, b1, b2, eps, wd, padding_idx=padding_idx)
+
     def route_bucket(self, idx, R, G, cap):
         """Owner bucketing with a fixed capacity per peer (re_route_bucket): no host sync."""
         from . import ops
@@ -116,7 +121,9 @@ class ShardedTable:
         buckets, slot, counts = self.ops.route_bucket(flat, self.R, G, cap)
         recv_local = torch.empty_like(buckets)
         dist.all_to_all_single(recv_local.view(-1), buckets.view(-1), group=self.group)      # equal splits: cap ids per pair
-        self.dropped = counts[G:G + 1].clone() if self.dropped is None else self.dropped + counts[G:G + 1]
+        if self.dropped is None:
+            self.dropped = torch.zeros(1, dtype=counts.dtype, device=counts.device)
+        self.dropped.add_(counts[G:G + 1])               # (in place: a captured step keeps counting across replays)
         r = Route()
         r.slot, r.cap, r.recv_local, r.n, r.inv, r.order, r.send_counts, r.recv_counts = slot, cap, recv_local.view(-1), n, None, None, None, None
         return r
@@ -125,7 +132,7 @@ class ShardedTable:
         """Host-side check (one sync) that no lookup since the last check was dropped by the fixed-capacity exchange."""
         if self.dropped is not None:
             d = int(self.dropped)
-            self.dropped = None
+            self.dropped.zero_()
             if d:
                 raise RuntimeError(f"ShardedTable: {d} lookups exceeded the exchange capacity (capacity_factor={self.capacity_factor}); "
                                    f"use capacity_factor={self.G} (never overflows) or None (exact sizes through the host)")
@@ -149,9 +156,9 @@ class ShardedTable:
             out = self.ops.gather(out, r.inv)          # distinct rows -> every looked-up position
         return out.reshape(tuple(idx.shape) + (self.D,)), r
 
-    def backward(self, grad_rows, route):
+    def backward(self, grad_rows, route, positions=None):
         """Send every gradient row to the owner of its table row; -> dense gradient of THIS rank's shard."""
-        g = self._grad_rows_to_send(grad_rows, route)
+        g = self._grad_rows_to_send(grad_rows, route, positions)
         recv = self._exchange_grad_rows(g, route)
         return self.ops.scatter_add(recv, route.recv_local, self.local_rows)
 
@@ -164,28 +171,41 @@ class ShardedTable:
         dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
         return recv
 
-    def _grad_rows_to_send(self, grad_rows, route):
+    def _grad_rows_to_send(self, grad_rows, route, positions=None):
+        """positions (optional, int64 [m]): grad_rows[i] belongs to lookup positions[i] of the routed index list (-1: to nobody);
+        default: one gradient row per lookup, in lookup order."""
         g = grad_rows.reshape(-1, self.D)
+        if positions is not None:
+            positions = positions.reshape(-1)
+            live = positions >= 0
+            at = positions.clamp_min(0)
         if route.slot is not None:                     # fixed capacity: into bucket order (slots are distinct; -1 = dropped)
-            return self.ops.scatter_add(g.contiguous(), route.slot, self.G * route.cap)
+            slot = route.slot if positions is None else torch.where(live, route.slot[at], torch.full_like(at, -1))
+            return self.ops.scatter_add(g.contiguous(), slot, self.G * route.cap)
         if route.inv is not None:                      # one pre-summed row per distinct index (deterministic segmented sum)
-            g = self.ops.scatter_add(g.contiguous(), route.inv, route.n)
+            inv = route.inv if positions is None else torch.where(live, route.inv[at], torch.full_like(at, -1))
+            g = self.ops.scatter_add(g.contiguous(), inv, route.n)
+        elif positions is not None:                    # (no dedup: one row per lookup; lookups nobody contributes to send a zero row)
+            g = self.ops.scatter_add(g.contiguous(), torch.where(live, at, torch.full_like(at, -1)), route.n)
         return g[route.order].contiguous()
 
-    def backward_sparse_adam(self, grad_rows, route, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, padding_global_row=None):
+    def backward_sparse_adam(self, grad_rows, route, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, padding_global_row=None,
+                             positions=None, hyper=None):
         """Training form for tables whose dense gradient does not fit: gradient rows go to their owners (the same single
         all-to-all as `backward`) and the owner applies ONE row-sparse Adam update per distinct row of its shard (summed
         duplicates, SparseAdam rule; moments `m`, `v` live next to the shard).  No table-sized gradient ever exists."""
         if not hasattr(self, "m"):
             self.m = torch.zeros_like(self.weight)
             self.v = torch.zeros_like(self.weight)
-        g = self._grad_rows_to_send(grad_rows, route)
+        g = self._grad_rows_to_send(grad_rows, route, positions)
         recv = self._exchange_grad_rows(g, route)
+        pad = -1
         if padding_global_row is not None and self.owner(padding_global_row) == self.rank:   # the padding row is never updated
-            self.ops.sparse_adam(recv, route.recv_local, self.weight, self.m, self.v, step, lr, betas[0], betas[1], eps, weight_decay,
-                                 padding_idx=self.local_index(padding_global_row))
+            pad = self.local_index(padding_global_row)
+        if hyper is not None:     # (captured step: step size and bias correction come from device memory, `step` / `lr` are ignored)
+            self.ops.sparse_adam_dev(recv, route.recv_local, self.weight, self.m, self.v, hyper, betas[0], betas[1], eps, weight_decay, padding_idx=pad)
         else:
-            self.ops.sparse_adam(recv, route.recv_local, self.weight, self.m, self.v, step, lr, betas[0], betas[1], eps, weight_decay)
+            self.ops.sparse_adam(recv, route.recv_local, self.weight, self.m, self.v, step, lr, betas[0], betas[1], eps, weight_decay, padding_idx=pad)
 
     # ---- checkpoints: the full table exists on no rank; gather-on-save / scatter-on-load go through rank `dst` in row chunks
     def gather_full(self, dst=0, tensor=None, chunk_rows=1 << 20):

@@ -16,6 +16,9 @@ ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--capacity-factor", type=float, default=None, help="fixed-capacity exchange (no host sync); default: exact sizes + dedup")
+ap.add_argument("--graph", action="store_true", help="the whole step (both exchanges included) as one hipGraph replay; needs --capacity-factor")
+ap.add_argument("--all-positions", action="store_true", help="the round-1 step: criterion over all B*S positions, one row per lookup")
 args = ap.parse_args()
 
 rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -29,7 +32,10 @@ from recboard_amd.large import SASRecShardedEngine
 
 N, D, B, S = args.items, args.dim, args.batch, 50
 t0 = time.time()
-model = SASRecShardedEngine(N, S, D, 2, dropout_rate=0.5, loss="BCE", lr=1e-3, weight_decay=1e-6, seed=1, device=f"cuda:{local}")
+model = SASRecShardedEngine(N, S, D, 2, dropout_rate=0.5, loss="BCE", lr=1e-3, weight_decay=1e-6, seed=1, device=f"cuda:{local}",
+                            capacity_factor=args.capacity_factor)
+if args.all_positions:
+    model.compact_rows = False
 torch.cuda.synchronize()
 t_init = time.time() - t0
 rng = np.random.default_rng(1 + rank)
@@ -42,13 +48,16 @@ for _ in range(4):
     pos = np.where(seq > 0, np.minimum(rng.zipf(1.05, (B, S)), N) - 1, 0)
     neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
     batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
+step = model.train_step_graph if args.graph else model.train_step
 for i in range(args.warmup):
-    model.train_step(*batches[i % 4])
+    step(*batches[i % 4])
 dist.barrier(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(args.steps):
-    loss = model.train_step(*batches[i % 4])
+    loss = step(*batches[i % 4])
 torch.cuda.synchronize(); dist.barrier()
+if args.capacity_factor is not None:
+    model.table.check_capacity()
 dt = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
 dt = float(dt.item()) / args.steps
@@ -58,6 +67,9 @@ if rank == 0:
                       "value": round(world * B / dt, 1), "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt * 1e3, 3),
                       "scaling": "weak", "final_loss_rank0": round(float(loss), 5), "rows_per_rank": model.table.local_rows,
                       "table_GB_per_rank": round(3 * model.table.local_rows * D * 4 / 1e9, 1), "table_init_s": round(t_init, 1),
-                      "hbm_used_GB_rank0": round((total - free) / 1e9, 1), "launch": "eager (the exchange's split sizes are host-side)",
+                      "hbm_used_GB_rank0": round((total - free) / 1e9, 1),
+                      "launch": ("one batch-preparation launch + one hipGraph replay" if args.graph else "eager") + (" (the exchange's split sizes are host-side)" if args.capacity_factor is None else f" (fixed-capacity exchange, factor {args.capacity_factor}: no host sync)"),
+                      "step": "all positions" if args.all_positions else "compact rows (one launch for forward + criterion + backward)",
                       "world_size": dist.get_world_size(), "backend": dist.get_backend(), "encoder": f"{model.encoder} (D = {D})"}))
+model.release_graphs()
 dist.destroy_process_group()

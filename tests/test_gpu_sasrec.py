@@ -237,11 +237,21 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
         N, B, S, D = 900, 10, 50, 128
         rng = np.random.default_rng(77)
         kw = dict(dropout_rate=0.0, lr=1e-2, weight_decay=1e-4, seed=6)
+        # (a) the all-positions step (compact_rows = False: one contribution row per lookup, in lookup order) is the large-table engine's,
+        #     bit for bit; (b) the default compact-row step sends the rows that exist, tagged with their lookups: same sums in another order
         large = SASRecLargeTableEngine(N, S, D, 2, table_init="counter", **kw)
-        large.compact_rows = False     # the sharded step runs the criterion over all positions of its batch-local table: compare like with like
         shard = SASRecShardedEngine(N, S, D, 2, dedup=False, **kw)
-        dd = SASRecShardedEngine(N, S, D, 2, **kw)        # the default: distinct rows only, gradient rows pre-summed per sender
         fx = SASRecShardedEngine(N, S, D, 2, capacity_factor=1.0, **kw)   # the sync-free form: owner bucketing on the device (re_route_bucket)
+        for e in (large, shard, fx):
+            e.compact_rows = False
+        dd = SASRecShardedEngine(N, S, D, 2, **kw)        # the default: compact rows, distinct rows only, gradient rows pre-summed per sender
+        cl = SASRecLargeTableEngine(N, S, D, 2, table_init="counter", **kw)                     # compact rows, unsharded
+        cs = SASRecShardedEngine(N, S, D, 2, dedup=False, **kw)                                  # compact rows, one row per lookup on the wire
+        cf = SASRecShardedEngine(N, S, D, 2, capacity_factor=1.0, **kw)                          # compact rows, fixed-capacity exchange
+        cg = SASRecShardedEngine(N, S, D, 2, capacity_factor=1.0, **kw)                          # ... the same step as one hipGraph replay
+        assert dd.compact_rows and cs.compact_rows and cs.split_long
+        with pytest.raises(NotImplementedError, match="capacity_factor"):
+            dd.train_step_graph(*(torch.zeros((B, S), dtype=torch.int64, device="cuda"),) * 3)
         assert torch.equal(large.E, shard.table.weight) and torch.equal(large.E, dd.table.weight)
         for step in range(3):
             seq = rng.integers(1, N + 1, (B, S))
@@ -257,14 +267,25 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
             lf = fx.train_step(*batch)
             fx.table.check_capacity()
             assert torch.equal(ll, lf) and torch.equal(large.E, fx.table.weight) and torch.equal(large.arena.data, fx.arena.data), step
-            ld = dd.train_step(*batch)
-            assert abs(float(ld) - float(ll)) <= 1e-6 * abs(float(ll)), step
-            # same sums in another association: Adam turns a last-bit difference of a near-zero gradient sum into a step of up to
-            # lr, so a handful of entries may sit a few lr apart -- everything else agrees to rounding
-            for a, b in ((dd.table.weight, large.E), (dd.arena.data, large.arena.data)):
-                diff = (a - b).abs()
-                assert float(diff.max()) <= 2.5e-2 * (step + 1), step
-                assert float((diff > 1e-5 * (1 + b.abs())).float().mean()) < 2e-3, step
+            lc = cl.train_step(*batch)
+            assert abs(float(lc) - float(ll)) <= 1e-6 * abs(float(ll)), step
+            for eng in (dd, cs, cf):
+                le = eng.train_step(*batch)
+                assert abs(float(le) - float(lc)) <= 1e-6 * abs(float(lc)), step
+                # same sums in another association: Adam turns a last-bit difference of a near-zero gradient sum into a step of up to
+                # lr, so a handful of entries may sit a few lr apart -- everything else agrees to rounding
+                for a, b in ((eng.table.weight, cl.E), (eng.arena.data, cl.arena.data)):
+                    diff = (a - b).abs()
+                    assert float(diff.max()) <= 2.5e-2 * (step + 1), step
+                    assert float((diff > 1e-5 * (1 + b.abs())).float().mean()) < 2e-3, step
+            cf.table.check_capacity()
+            cs.check_handover()
+            # the captured step (lookup exchange, encoder step, gradient exchange, both optimizers in one graph) replays cf's launches
+            lg = cg.train_step_graph(*batch)
+            assert abs(float(lg) - float(lc)) <= 1e-6 * abs(float(lc)), step
+            torch.testing.assert_close(cg.table.weight, cf.table.weight, rtol=1e-5, atol=1e-7)
+            torch.testing.assert_close(cg.arena.data, cf.arena.data, rtol=1e-5, atol=1e-7)
+            cg.table.check_capacity()
         seqs = torch.from_numpy(seq).cuda()
         sp = torch.arange(0, B + 1, device="cuda") * 3
         si = torch.sort(torch.from_numpy(rng.integers(0, N, (B, 3))).cuda(), 1).values.reshape(-1)
@@ -272,6 +293,8 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
         v2, i2 = shard.recommend_topk(seqs, sp, si, 20)
         assert torch.equal(i1, i2) and torch.equal(v1, v2)
     finally:
+        if "cg" in locals():
+            cg.release_graphs()        # (a live graph holding captured RCCL work blocks the group's teardown)
         dist.destroy_process_group()
 
 

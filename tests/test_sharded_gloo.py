@@ -219,7 +219,16 @@ def _engine_worker(rank, world, port, q):
                 loss.backward()
                 for k, p in self.params.items():
                     self.arena.view(self.arena.grad, k).copy_(P[k].grad if P[k].grad is not None else torch.zeros_like(p))
-                return loss.detach().reshape(1), T.grad[1:].clone(), None   # row 1 + j of the batch-local table = lookup j (rows: the sharded step has its own)
+                C = T.grad[1:].clone()                              # row 1 + j of the batch-local table = lookup j
+                if not self.compact_form:
+                    return loss.detach().reshape(1), C, None        # one contribution row per lookup, in lookup order
+                # the product's compact-row form: only the rows that exist, in any order, tagged with their row of the batch-local
+                # table (0 = belongs to nobody), padded with junk rows under key 0
+                live = torch.nonzero(C.abs().sum(1)).reshape(-1)
+                live = live[torch.randperm(live.numel(), generator=torch.Generator().manual_seed(4))]
+                junk = torch.full((5, C.shape[1]), 7.0)
+                return (loss.detach().reshape(1), torch.cat([C[live[:3]], junk, C[live[3:]]]),
+                        torch.cat([live[:3] + 1, torch.zeros(5, dtype=torch.int64), live[3:] + 1]))
 
             def _dense_adam(self):
                 A = self.arena
@@ -227,9 +236,10 @@ def _engine_worker(rank, world, port, q):
 
         N, B, S, D, L, lr, wd = 97, 6, 50, 64, 2, 1e-2, 1e-4
         from tests.test_sharded_gloo import OracleLocalOps as Ops
-        for factor in (None, 2.0):
-            eng = OracleShardedEngine(N, S, D, L, dropout_rate=0.0, loss="BCE", lr=lr, weight_decay=wd, seed=3, device="cpu", dedup=False,
+        for factor, dedup, compact in ((None, False, False), (2.0, False, False), (None, False, True), (None, True, True), (2.0, False, True)):
+            eng = OracleShardedEngine(N, S, D, L, dropout_rate=0.0, loss="BCE", lr=lr, weight_decay=wd, seed=3, device="cpu", dedup=dedup,
                                       capacity_factor=factor, local_ops=Ops())
+            eng.compact_form = compact
             rngs = [np.random.default_rng(50 + r) for r in range(world)]
             batches = []
             for r in range(world):
