@@ -202,10 +202,12 @@ int re_score_topk_prepared(const float* Q, const float* E, const void* prep, int
  *   buckets [G * cap] int64: the LOCAL row ids (r div G) wanted from owner g at [g * cap, ...), in order of appearance, -1 in unused slots;
  *   slot [n] int64: g * cap + rank of lookup j inside its bucket (gather the received rows / scatter the gradient rows by it), -1 if dropped;
  *   counts [G + 1] int32: lookups per owner (may exceed cap), then the number of DROPPED lookups (index outside [0, R), or bucket
- *   full) -- the caller checks counts[G] == 0 at its next sync point. */
+ *   full) -- the caller checks counts[G] == 0 at its next sync point.
+ *   skip_row >= 0: lookups of that row (the padding row: most of a left-padded batch, SASRec/main.py:143-157) take no slot and are not
+ *   counted as dropped; their slot is -1.  -1: every in-range lookup takes a slot. */
 size_t re_route_workspace_bytes(int64_t n, int64_t G);
-int re_route_bucket(const int64_t* idx, int64_t n, int64_t R, int64_t G, int64_t cap, int64_t* buckets, int64_t* slot, int32_t* counts,
-                    void* ws, size_t ws_bytes, re_stream_t stream);
+int re_route_bucket(const int64_t* idx, int64_t n, int64_t R, int64_t G, int64_t cap, int64_t skip_row, int64_t* buckets, int64_t* slot,
+                    int32_t* counts, void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Batch preparation of a SASRec step (what the top of `fit` does, SASRec/main.py:199-204, plus the encoder's work plan), as

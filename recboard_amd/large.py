@@ -293,7 +293,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
     def _alloc_table(self, seed):
         from .sharded import ShardedTable
         self.table = ShardedTable(self.N + 1, self.D, group=self.group, device=self.device, dedup=self.dedup and self.capacity_factor is None,
-                                  capacity_factor=self.capacity_factor, local_ops=self._local_ops)
+                                  capacity_factor=self.capacity_factor, local_ops=self._local_ops, skip_row=0)
         T = self.table
         step_rows = max(1, (1 << 24) // self.D)
         for l0 in range(0, T.local_rows, step_rows):
@@ -350,16 +350,27 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         B, S = seq.shape
         n = B * S
         p = self.p_drop if self.training else 0.0
-        # the batch-local table: row 0 = padding, row 1 + j = table row rows_all[j]  (one all-to-all round trip)
-        rows, route = self.table.lookup(aux.rows_all)
-        T = torch.cat([torch.zeros((1, D), dtype=torch.float32, device=self.device), rows], 0)
-        ar = torch.arange(1, n + 1, device=self.device)
-        seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
-        # positives / negatives are rows n+1.. and 2n+1.. of the batch-local table (the criterion adds e_off = 1 to the 0-based ids).
-        # compact-row step: C holds 3 x NR contribution rows, `keys` their rows of T (0 = none); key - 1 = the lookup they belong to.
-        # (all-positions step, compact_rows = False: one row per lookup, keys None)
-        loss, C, keys = self._grads(seq_l, (ar - 1 + n).view(B, S), (ar - 1 + 2 * n).view(B, S), aux, sd, seed_dev=seed_dev, table=T)
-        positions = None if keys is None or keys is aux.rows_all else keys - 1
+        slots = positions = None
+        if self.capacity_factor is not None and self.encoder == "fused" and self.compact_rows:
+            # fixed-capacity exchange + compact rows: the batch-local table IS the received bucket (row 0 = padding, row 1 + s = bucket
+            # slot s); the padding row's lookups were never sent (skip_row), a lookup's local id is its slot + 1, and a contribution
+            # row's key - 1 is the bucket slot its gradient travels back in -- nothing is expanded to one row per lookup
+            T, route = self.table.lookup(aux.rows_all, expand=False)
+            loc = route.slot + 1
+            loss, C, keys = self._grads(loc[:n].view(B, S), (loc[n:2 * n] - 1).view(B, S), (loc[2 * n:] - 1).view(B, S), aux, sd,
+                                        seed_dev=seed_dev, table=T)
+            slots = keys - 1 if keys is not None else torch.arange(C.shape[0], device=C.device)     # (None: one row per row of T[1:])
+        else:
+            # the batch-local table: row 0 = padding, row 1 + j = table row rows_all[j]  (one all-to-all round trip)
+            rows, route = self.table.lookup(aux.rows_all)
+            T = torch.cat([torch.zeros((1, D), dtype=torch.float32, device=self.device), rows], 0)
+            ar = torch.arange(1, n + 1, device=self.device)
+            seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
+            # positives / negatives are rows n+1.. and 2n+1.. of the batch-local table (the criterion adds e_off = 1 to the 0-based ids).
+            # compact-row step: C holds 3 x NR contribution rows, `keys` their rows of T (0 = none); key - 1 = the lookup they belong to.
+            # (all-positions step, compact_rows = False: one row per lookup, keys None)
+            loss, C, keys = self._grads(seq_l, (ar - 1 + n).view(B, S), (ar - 1 + 2 * n).view(B, S), aux, sd, seed_dev=seed_dev, table=T)
+            positions = None if keys is None or keys is aux.rows_all else keys - 1
         if self.world > 1:
             C.mul_(1.0 / self.world)                 # the loss of the global batch is the mean of the ranks' losses
             dist.all_reduce(A.grad, op=dist.ReduceOp.AVG, group=self.group)
@@ -367,7 +378,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             grad_hook(A.grad)
         # contribution rows of pad / invalid positions are zero rows addressed to global row 0 (rank 0 drops them)
         self.table.backward_sparse_adam(C, route, A.step + 1, self.lr, self.betas, 1e-8, self.wd, padding_global_row=0, positions=positions,
-                                        hyper=hyper)
+                                        hyper=hyper, slots=slots)
         if hyper is not None:
             ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
         else:

@@ -41,7 +41,7 @@ SIGNATURES = {
     "re_score_topk_prepared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_score_topk_prepared": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "re_route_workspace_bytes": (_sz, [_i64, _i64]),
-    "re_route_bucket": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "re_route_bucket": (_i32, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_sasrec_plan_bytes": (_sz, [_i64, _i64]),
     "re_sasrec_batch_prep": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32, _i64,
                                     _f64, _f64, _f64, _vp]),

@@ -323,9 +323,10 @@ def sasrec_block_tensors(named, L):
     return [named[k.format(l=l)] for l in range(L) for k in BLOCK_PARAM_ORDER]
 
 
-def route_bucket(idx, R, G, cap, out=None):
+def route_bucket(idx, R, G, cap, out=None, skip_row=-1):
     """Owner bucketing of lookups into a row-sharded table (re_route_bucket): -> (buckets int64 [G, cap] local row ids, -1 = unused;
-    slot int64 [n]; counts int32 [G + 1], the last word = dropped lookups).  No host sync; fixed capacity per peer."""
+    slot int64 [n]; counts int32 [G + 1], the last word = dropped lookups).  No host sync; fixed capacity per peer.
+    skip_row >= 0: lookups of that row (the padding row) take no slot (slot -1) and are not counted as dropped."""
     _req(idx, torch.int64, "idx")
     n = idx.numel()
     dev = idx.device
@@ -335,8 +336,8 @@ def route_bucket(idx, R, G, cap, out=None):
     buckets, slot, counts = out
     L = lib.load()
     ws = _ws(L.re_route_workspace_bytes(n, G), dev)
-    lib.check(L.re_route_bucket(_p(idx), n, int(R), int(G), int(cap), _p(buckets), _p(slot) if n else None, _p(counts), _p(ws), ws.numel(),
-                                _stream()), "re_route_bucket")
+    lib.check(L.re_route_bucket(_p(idx), n, int(R), int(G), int(cap), int(skip_row), _p(buckets), _p(slot) if n else None, _p(counts), _p(ws),
+                                ws.numel(), _stream()), "re_route_bucket")
     return buckets, slot, counts
 
 

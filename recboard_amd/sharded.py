@@ -45,10 +45,10 @@ class EngineLocalOps:
         from . import ops
         ops.sparse_adam_rows_dev(g, idx, W, m, v, hyper, b1, b2, eps, wd, padding_idx=padding_idx)
 
-    def route_bucket(self, idx, R, G, cap):
+    def route_bucket(self, idx, R, G, cap, skip_row=-1):
         """Owner bucketing with a fixed capacity per peer (re_route_bucket): no host sync."""
         from . import ops
-        return ops.route_bucket(idx, R, G, cap)
+        return ops.route_bucket(idx, R, G, cap, skip_row=skip_row)
 
 
 class Route:
@@ -59,7 +59,8 @@ class Route:
 
 
 class ShardedTable:
-    def __init__(self, num_rows, dim, local_ops=None, group=None, device=None, dtype=torch.float32, dedup=True, capacity_factor=None):
+    def __init__(self, num_rows, dim, local_ops=None, group=None, device=None, dtype=torch.float32, dedup=True, capacity_factor=None,
+                 skip_row=None):
         # dedup: every distinct row of a batch crosses the fabric once per direction -- the indices out, the
         # rows back, and in the backward ONE pre-summed gradient row per distinct index (Zipf-distributed lookups repeat their
         # hot rows many times: config 2's 76 800 lookups per step hit ~12 000 distinct rows)
@@ -71,6 +72,9 @@ class ShardedTable:
         # `self.dropped` (device int32, summed over calls): the caller checks it at its next sync point.  None: exact split sizes
         # through the host (two syncs per lookup), optionally with dedup.
         self.capacity_factor = capacity_factor
+        # skip_row (fixed-capacity form): lookups of this global row -- the padding row, ~85 % of a left-padded SASRec batch -- are not
+        # exchanged at all (slot -1: a zero row comes back, no gradient row leaves), so the capacity is sized for the real tokens
+        self.skip_row = -1 if skip_row is None else int(skip_row)
         self.dropped = None
         self.group = group
         self.G = dist.get_world_size(group)
@@ -118,7 +122,10 @@ class ShardedTable:
         flat = idx.reshape(-1).contiguous()
         n, G = flat.numel(), self.G
         cap = max(1, min(n, -(-int(self.capacity_factor * n) // G)))
-        buckets, slot, counts = self.ops.route_bucket(flat, self.R, G, cap)
+        if self.skip_row >= 0:
+            buckets, slot, counts = self.ops.route_bucket(flat, self.R, G, cap, self.skip_row)
+        else:
+            buckets, slot, counts = self.ops.route_bucket(flat, self.R, G, cap)
         recv_local = torch.empty_like(buckets)
         dist.all_to_all_single(recv_local.view(-1), buckets.view(-1), group=self.group)      # equal splits: cap ids per pair
         if self.dropped is None:
@@ -137,11 +144,19 @@ class ShardedTable:
                 raise RuntimeError(f"ShardedTable: {d} lookups exceeded the exchange capacity (capacity_factor={self.capacity_factor}); "
                                    f"use capacity_factor={self.G} (never overflows) or None (exact sizes through the host)")
 
-    def lookup(self, idx):
-        """-> (rows [*idx.shape, D], route).  Global `W[idx]` on a table no rank holds entirely."""
+    def lookup(self, idx, expand=True):
+        """-> (rows [*idx.shape, D], route).  Global `W[idx]` on a table no rank holds entirely.
+        expand=False (fixed-capacity form only): -> (table [1 + G * cap, D], route): a zero row followed by the received rows in BUCKET
+        order -- lookup j's row is row `route.slot[j] + 1` (slot -1: the zero row); the caller indexes it instead of asking for a row
+        per lookup."""
         if self.capacity_factor is not None:
             r = self._route_fixed(idx)
             rows_for_peers = self.ops.gather(self.weight, r.recv_local).reshape(-1, self.D)       # (-1 -> a zero row)
+            if not expand:       # (received straight into rows 1.. of the caller's batch-local table; row 0 = the zero / padding row)
+                table = torch.empty((1 + rows_for_peers.shape[0], self.D), dtype=rows_for_peers.dtype, device=rows_for_peers.device)
+                table[0].zero_()
+                dist.all_to_all_single(table[1:], rows_for_peers.contiguous(), group=self.group)
+                return table, r
             rows_recv = torch.empty_like(rows_for_peers)
             dist.all_to_all_single(rows_recv, rows_for_peers.contiguous(), group=self.group)       # equal splits: cap rows per pair
             out = self.ops.gather(rows_recv, r.slot)
@@ -171,10 +186,19 @@ class ShardedTable:
         dist.all_to_all_single(recv, g, route.recv_counts, route.send_counts, group=self.group)
         return recv
 
-    def _grad_rows_to_send(self, grad_rows, route, positions=None):
+    def _grad_rows_to_send(self, grad_rows, route, positions=None, slots=None):
         """positions (optional, int64 [m]): grad_rows[i] belongs to lookup positions[i] of the routed index list (-1: to nobody);
+        slots (optional, fixed-capacity form): grad_rows[i] belongs to bucket slot slots[i] (rows of `lookup(expand=False)`; -1: nobody;
+        every slot at most once);
         default: one gradient row per lookup, in lookup order."""
         g = grad_rows.reshape(-1, self.D)
+        if slots is not None:
+            # every bucket slot belongs to ONE lookup, so at most one row goes into it: no sums to form -- invert the map (integers only)
+            # and gather the rows into bucket order (-1, a slot nobody feeds: a zero row)
+            slots = slots.reshape(-1)
+            src = torch.full((self.G * route.cap + 1,), -1, dtype=torch.int64, device=g.device)
+            src[slots + 1] = torch.arange(slots.numel(), device=g.device)          # (entry 0 collects the slot -1 rows: dropped)
+            return self.ops.gather(g.contiguous(), src[1:]).reshape(-1, self.D)
         if positions is not None:
             positions = positions.reshape(-1)
             live = positions >= 0
@@ -190,14 +214,14 @@ class ShardedTable:
         return g[route.order].contiguous()
 
     def backward_sparse_adam(self, grad_rows, route, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, padding_global_row=None,
-                             positions=None, hyper=None):
+                             positions=None, hyper=None, slots=None):
         """Training form for tables whose dense gradient does not fit: gradient rows go to their owners (the same single
         all-to-all as `backward`) and the owner applies ONE row-sparse Adam update per distinct row of its shard (summed
         duplicates, SparseAdam rule; moments `m`, `v` live next to the shard).  No table-sized gradient ever exists."""
         if not hasattr(self, "m"):
             self.m = torch.zeros_like(self.weight)
             self.v = torch.zeros_like(self.weight)
-        g = self._grad_rows_to_send(grad_rows, route, positions)
+        g = self._grad_rows_to_send(grad_rows, route, positions, slots)
         recv = self._exchange_grad_rows(g, route)
         pad = -1
         if padding_global_row is not None and self.owner(padding_global_row) == self.rank:   # the padding row is never updated

@@ -12,8 +12,9 @@ def _gpu():
         pytest.skip("needs a GPU")
 
 
-@pytest.mark.parametrize("n,R,G,factor", [(76800, 100_000_001, 8, 2.0), (5000, 977, 3, 1.5), (1, 10, 2, 1.0), (3000, 50, 8, 0.5), (0, 10, 4, 1.0)])
-def test_route_bucket_matches_numpy_restatement(n, R, G, factor):
+@pytest.mark.parametrize("n,R,G,factor,skip", [(76800, 100_000_001, 8, 2.0, -1), (5000, 977, 3, 1.5, -1), (1, 10, 2, 1.0, -1), (3000, 50, 8, 0.5, -1),
+                                               (0, 10, 4, 1.0, -1), (76800, 100_000_001, 8, 0.4, 0), (5000, 977, 3, 1.5, 1)])
+def test_route_bucket_matches_numpy_restatement(n, R, G, factor, skip):
     """re_route_bucket (csrc/route.hip): stable counting sort by owner (row mod G) into fixed-capacity buckets; overflow and
     out-of-range lookups are counted, never written."""
     _gpu()
@@ -22,11 +23,15 @@ def test_route_bucket_matches_numpy_restatement(n, R, G, factor):
     idx = np.minimum(rng.zipf(1.05, n), R - 1).astype(np.int64) if n else np.zeros(0, np.int64)
     if n > 10:
         idx[3], idx[7] = -5, R + 2                       # out of range: dropped
+    if skip >= 0 and n > 10:
+        idx[rng.random(n) < 0.8] = skip                  # the padding row: most of a left-padded batch; takes no slot
     cap = max(1, min(max(n, 1), int(np.ceil(factor * max(n, 1) / G))))
     buckets = np.full((G, cap), -1, np.int64)
     slot = np.full(n, -1, np.int64)
     counts = np.zeros(G + 1, np.int64)
     for j, r in enumerate(idx.tolist()):
+        if r == skip:
+            continue
         if r < 0 or r >= R:
             counts[G] += 1
             continue
@@ -37,7 +42,7 @@ def test_route_bucket_matches_numpy_restatement(n, R, G, factor):
             buckets[g, k], slot[j] = r // G, g * cap + k
         else:
             counts[G] += 1
-    b, s, c = ops.route_bucket(torch.from_numpy(idx).cuda(), R, G, cap)
+    b, s, c = ops.route_bucket(torch.from_numpy(idx).cuda(), R, G, cap, skip_row=skip)
     np.testing.assert_array_equal(c.cpu().numpy(), counts)
     np.testing.assert_array_equal(b.cpu().numpy(), buckets)
     np.testing.assert_array_equal(s.cpu().numpy(), slot)
