@@ -16,6 +16,14 @@ DeepFM additionally have hand-fused engines (sasrec.py, gen.py, deepfm.py).
                                    softplus fused) or gathers + row dots (BCE), CE and full ranking over the catalog = score_dense
   JGCF    (JGCF/main.py:39-160, modules.py:8-83) the Jacobi-polynomial recurrence = one recengine::spmm_csr per order (symmetric adjacency),
                                    BPR over the [low-pass | mid-pass] tables = recengine::bpr_triplet, full ranking = recengine::gemm
+  GCN     (GCN/main.py:27-135)     per layer recengine::spmm_csr then the layer's Linear = recengine::gemm (ReLU between layers), BPR =
+                                   recengine::bpr_triplet, full ranking = recengine::gemm
+  STAMP   (STAMP/main.py:28-160)   item lookup = recengine::gather_rows, the trilinear attention's w0..w3 and both MLP branches = recengine::gemm,
+                                   criteria / ranking as GRU4Rec
+  NARM    (NARM/main.py:30-180)    item lookup = recengine::gather_rows, a_1 / a_2 / v_t / b = recengine::gemm, the state at the last real position
+                                   = recengine::gather_rows, BCE on gathered rows; the GRU is torch.nn.GRU (MIOpen)
+  FMLP-Rec (FMLP-Rec/main.py:38-180, modules.py:27-120) item lookup = recengine::gather_rows, dense_1 / dense_2 of every block = recengine::gemm,
+                                   criteria / ranking as GRU4Rec; the frequency-domain filter is torch.fft (rocFFT)
   BERT4Rec (BERT4Rec/main.py:33-195) item lookup = recengine::gather_rows (padding row without gradient), the encoder states at the MASKED
                                    positions = recengine::gather_rows, the projection to the N + 2 logits (`fc`) = recengine::gemm on those
                                    rows only (the reference projects all B*S rows and then selects), full ranking = recengine::gemm on the
@@ -383,3 +391,221 @@ class BERT4Rec(torch.nn.Module):
     def recommend_from_full(self, seqs):
         """seqs: the evaluation pipe's rows (left-padded history of maxlen - 1, the mask token last)."""
         return self.fc(self.encode(seqs)[:, -1, :].contiguous())[:, self.NUM_PADS:]
+
+
+# ------------------------------------------------------------------------------------------------ shared: last-item criteria
+def _last_item_loss(kind, user, items, pos, neg):
+    """BCE / BPR / CE of one user state per sequence against the item table (GRU4Rec/main.py:156-180, STAMP/main.py:128-150,
+    FMLP-Rec/main.py:152-174)."""
+    pos, neg = pos.reshape(-1), neg.reshape(-1)
+    if kind == "BPR":
+        return rnn.bpr_triplet(user.contiguous(), items.contiguous(), torch.arange(user.shape[0], device=user.device), pos, neg)
+    if kind == "BCE":
+        pl = (user * rnn.gather_rows(items.contiguous(), pos)).sum(-1, keepdim=True)
+        nl = (user * rnn.gather_rows(items.contiguous(), neg)).sum(-1, keepdim=True)
+        crit = rnn.BCELoss4Logits(reduction="mean")
+        return crit(pl, torch.ones_like(pl)) + crit(nl, torch.zeros_like(nl))
+    return F.cross_entropy(rnn.score_full(user.contiguous(), items.contiguous()), pos)
+
+
+def _lin3(layer, x):
+    """A 2-D engine Linear over the last dimension of a [B, S, D] tensor."""
+    B, S, D = x.shape
+    return layer(x.reshape(B * S, D)).reshape(B, S, -1)
+
+
+# ------------------------------------------------------------------------------------------------ GCN
+class GCN(torch.nn.Module):
+    """GCN (GCN/main.py:27-135): x <- Linear_l(Adj x), ReLU after all but the last layer; BPR on the propagated tables."""
+
+    def __init__(self, num_users, num_items, adj, embedding_dim=64, num_layers=3, device="cuda"):
+        super().__init__()
+        self.U, self.N = num_users, num_items
+        self.user = rnn.Embedding(num_users, embedding_dim, device=device)
+        self.item = rnn.Embedding(num_items, embedding_dim, device=device)
+        with torch.no_grad():
+            torch.nn.init.normal_(self.user.weight, std=1e-4)
+            torch.nn.init.normal_(self.item.weight, std=1e-4)
+        self.linears = torch.nn.ModuleList([rnn.Linear(embedding_dim, embedding_dim, device=device) for _ in range(num_layers)])
+        for n, t in zip(("crow", "col", "val"), adj):
+            self.register_buffer(n, t.to(device))
+        self.ranking_buffer = None
+
+    def encode(self):
+        x = torch.cat((self.user.weight, self.item.weight), dim=0)
+        for l, lin in enumerate(self.linears):
+            x = lin(rnn.spmm_sym(self.crow, self.col, self.val, x.contiguous()))
+            if l + 1 < len(self.linears):
+                x = torch.relu(x)
+        return torch.split(x, (self.U, self.N))
+
+    def fit(self, users, positives, negatives):
+        ue, ie = self.encode()
+        return {"rec_loss": rnn.bpr_triplet(ue.contiguous(), ie.contiguous(), users.reshape(-1), positives.reshape(-1), negatives.reshape(-1))}
+
+    def reset_ranking_buffers(self):
+        with torch.no_grad():
+            ue, ie = self.encode()
+            self.ranking_buffer = (ue.contiguous(), ie.contiguous())
+
+    def recommend_from_full(self, users):
+        ue, ie = self.ranking_buffer
+        return rnn.linear(rnn.gather_rows(ue, users.reshape(-1)), ie)
+
+
+# ------------------------------------------------------------------------------------------------ STAMP
+class STAMP(torch.nn.Module):
+    """STAMP (STAMP/main.py:28-160): mean of the sequence's embeddings + the last click -> trilinear attention -> two tanh MLP branches,
+    multiplied.  Sequences are LEFT-padded (the last column is the last click); ids + 1, 0 = padding."""
+
+    def __init__(self, num_items, embedding_dim=64, hidden_size=64, loss="BCE", device="cuda"):
+        super().__init__()
+        assert loss in ("BCE", "BPR", "CE")
+        D = embedding_dim
+        self.N, self.loss_kind = num_items, loss
+        self.item = rnn.Embedding(num_items + 1, D, padding_idx=0, device=device)
+        self.w1, self.w2, self.w3 = (rnn.Linear(D, D, bias=False, device=device) for _ in range(3))
+        self.w0 = rnn.Linear(D, 1, bias=False, device=device)
+        self.ba = torch.nn.Parameter(torch.zeros(1, 1, D, device=device))
+        self.mlp_a = rnn.Linear(D, hidden_size, device=device)
+        self.mlp_b = rnn.Linear(D, hidden_size, device=device)
+        with torch.no_grad():                                    # STAMP.reset_parameters (STAMP/main.py:78-84)
+            for m in (self.w0, self.w1, self.w2, self.w3, self.mlp_a, self.mlp_b):
+                torch.nn.init.normal_(m.weight, std=0.05)
+            torch.nn.init.normal_(self.item.weight, std=0.002)
+
+    def encode(self, seqs):
+        B, S = seqs.shape
+        lens = seqs.ne(0).sum(dim=-1, keepdim=True)
+        x = self.item(seqs.reshape(-1)).reshape(B, S, -1)
+        last = x[:, -1, :].contiguous()
+        ms = x.sum(dim=1).div(lens)
+        alphas = _lin3(self.w0, torch.sigmoid(_lin3(self.w1, x) + self.w2(last).unsqueeze(1) + self.w3(ms).unsqueeze(1) + self.ba))
+        ma = alphas.mul(x).sum(1) + last
+        return torch.tanh(self.mlp_a(ma)) * torch.tanh(self.mlp_b(last)), self.item.weight[1:]
+
+    def fit(self, seqs, positives, negatives):
+        user, items = self.encode(seqs)
+        return {"rec_loss": _last_item_loss(self.loss_kind, user, items, positives, negatives)}
+
+    def recommend_from_full(self, seqs):
+        user, items = self.encode(seqs)
+        return rnn.score_full(user.contiguous(), items.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ NARM
+class NARM(torch.nn.Module):
+    """NARM (NARM/main.py:30-180): GRU over the RIGHT-padded sequence; global = the state at the last real position, local = attention
+    over the states (v_t(mask * sigmoid(a_1 h_s + a_2 h_t))); user = b [local | global]; BCE."""
+
+    def __init__(self, num_items, embedding_dim=64, hidden_size=128, num_blocks=1, emb_dropout_rate=0.25, hidden_dropout_rate=0.0,
+                 ct_dropout_rate=0.5, device="cuda"):
+        super().__init__()
+        H = hidden_size
+        self.N = num_items
+        self.item = rnn.Embedding(num_items + 1, embedding_dim, padding_idx=0, device=device)
+        self.emb_dropout = torch.nn.Dropout(emb_dropout_rate)
+        self.gru = torch.nn.GRU(embedding_dim, H, num_layers=num_blocks, bias=False, batch_first=True, dropout=hidden_dropout_rate, device=device)
+        self.a_1 = rnn.Linear(H, H, bias=False, device=device)
+        self.a_2 = rnn.Linear(H, H, bias=False, device=device)
+        self.v_t = rnn.Linear(H, 1, bias=False, device=device)
+        self.ct_dropout = torch.nn.Dropout(ct_dropout_rate)
+        self.b = rnn.Linear(2 * H, embedding_dim, bias=False, device=device)
+        with torch.no_grad():
+            torch.nn.init.xavier_normal_(self.item.weight)
+
+    def encode(self, seqs):
+        mask = seqs.ne(0)
+        keep = mask.any(dim=0)                                   # shrink_pads (NARM/main.py:131-134)
+        seqs, mask = seqs[:, keep], mask[:, keep]
+        B, S = seqs.shape
+        out, _ = self.gru(self.emb_dropout(self.item(seqs.reshape(-1)).reshape(B, S, -1)))
+        last = (mask.sum(1) - 1).clamp_min(0)
+        ht = rnn.gather_rows(out.reshape(B * S, -1).contiguous(), torch.arange(B, device=seqs.device) * S + last)          # [B, H]
+        alpha = _lin3(self.v_t, mask.unsqueeze(-1) * torch.sigmoid(_lin3(self.a_1, out) + self.a_2(ht).unsqueeze(1)))
+        c_t = self.ct_dropout(torch.cat([(alpha * out).sum(1), ht], 1))
+        return self.b(c_t), self.item.weight[1:]
+
+    def fit(self, seqs, positives, negatives):
+        user, items = self.encode(seqs)
+        return {"rec_loss": _last_item_loss("BCE", user, items, positives, negatives)}
+
+    def recommend_from_full(self, seqs):
+        user, items = self.encode(seqs)
+        return rnn.score_full(user.contiguous(), items.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ FMLP-Rec
+class _TFLayerNorm(torch.nn.Module):
+    """LayerNorm with epsilon inside the square root (FMLP-Rec/modules.py:27-40)."""
+
+    def __init__(self, size, eps=1e-12, device=None):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(size, device=device))
+        self.bias = torch.nn.Parameter(torch.zeros(size, device=device))
+        self.eps = eps
+
+    def forward(self, x):
+        u = x.mean(-1, keepdim=True)
+        s = (x - u).pow(2).mean(-1, keepdim=True)
+        return self.weight * ((x - u) / torch.sqrt(s + self.eps)) + self.bias
+
+
+class _FilterBlock(torch.nn.Module):
+    """FilterLayer + Intermediate (FMLP-Rec/modules.py:42-96): rfft over the sequence, a learnable complex filter, irfft, residual
+    LayerNorm; then dense_1 -> GELU -> dense_2, residual LayerNorm."""
+
+    def __init__(self, maxlen, D, dropout_rate, device):
+        super().__init__()
+        self.complex_weight = torch.nn.Parameter(torch.randn(1, maxlen // 2 + 1, D, 2, device=device) * 0.02)
+        self.filter_norm = _TFLayerNorm(D, device=device)
+        self.dense_1 = rnn.Linear(D, 4 * D, device=device)
+        self.dense_2 = rnn.Linear(4 * D, D, device=device)
+        self.out_norm = _TFLayerNorm(D, device=device)
+        self.dropout = torch.nn.Dropout(dropout_rate)
+
+    def forward(self, x):
+        S = x.shape[1]
+        f = torch.fft.irfft(torch.fft.rfft(x, dim=1, norm="ortho") * torch.view_as_complex(self.complex_weight), n=S, dim=1, norm="ortho")
+        h = self.filter_norm(self.dropout(f) + x)
+        z = _lin3(self.dense_1, h)
+        z = z * 0.5 * (1.0 + torch.erf(z / 2.0 ** 0.5))
+        return self.out_norm(self.dropout(_lin3(self.dense_2, z)) + h)
+
+
+class FMLPRec(torch.nn.Module):
+    """FMLP-Rec (FMLP-Rec/main.py:38-180): item + position embeddings -> LayerNorm -> dropout -> filter-enhanced blocks -> the state at
+    the last position of the LEFT-padded sequence -> BPR / BCE / CE against the item table."""
+
+    def __init__(self, num_items, maxlen=50, embedding_dim=64, num_blocks=2, hidden_dropout_rate=0.5, loss="BPR", device="cuda"):
+        super().__init__()
+        assert loss in ("BCE", "BPR", "CE")
+        D = embedding_dim
+        self.N, self.loss_kind = num_items, loss
+        self.item = rnn.Embedding(num_items + 1, D, padding_idx=0, device=device)
+        self.Position = torch.nn.Embedding(maxlen, D, device=device)
+        self.layerNorm = _TFLayerNorm(D, device=device)
+        self.embdDropout = torch.nn.Dropout(hidden_dropout_rate)
+        self.blocks = torch.nn.ModuleList([_FilterBlock(maxlen, D, hidden_dropout_rate, device) for _ in range(num_blocks)])
+        with torch.no_grad():                                    # FMLPRec.reset_parameters (FMLP-Rec/main.py:80-90)
+            for m in self.modules():
+                if isinstance(m, (rnn.Linear, rnn.Embedding, torch.nn.Embedding)):
+                    torch.nn.init.normal_(m.weight, std=0.02)
+                    if getattr(m, "bias", None) is not None:
+                        m.bias.zero_()
+
+    def encode(self, seqs):
+        B, S = seqs.shape
+        x = self.item(seqs.reshape(-1)).reshape(B, S, -1) + self.Position.weight[:S].unsqueeze(0)
+        x = self.embdDropout(self.layerNorm(x))
+        for blk in self.blocks:
+            x = blk(x)
+        return x[:, -1, :].contiguous(), self.item.weight[1:]
+
+    def fit(self, seqs, positives, negatives):
+        user, items = self.encode(seqs)
+        return {"rec_loss": _last_item_loss(self.loss_kind, user, items, positives, negatives)}
+
+    def recommend_from_full(self, seqs):
+        user, items = self.encode(seqs)
+        return rnn.score_full(user.contiguous(), items.contiguous())

@@ -135,6 +135,7 @@ def main():
         seq_r[b, : int(lens[b])] = it + 1
         seq_l[b, S - int(lens[b]):] = it + 2
     seq_r, seq_l = seq_r.cuda(), seq_l.cuda()
+    seq_l1 = (seq_l - 1).clamp_min(0)               # left-padded, ids + 1 (STAMP / FMLP-Rec)
     p1, n1 = (torch.randint(0, N, (Bs,), generator=gen).cuda() for _ in range(2))
 
     tri = (users, pos, neg)
@@ -143,6 +144,10 @@ def main():
         "SimGCL (Beauty graph, B=2048)": (lambda: sib.SimGCL(U, N, A_sym, 64, 3, eps=0.1), tri, True),
         "NGCF (Beauty graph, B=2048)": (lambda: sib.NGCF(U, N, A_left, 64, 3), tri, True),
         "JGCF (Beauty graph, B=2048)": (lambda: sib.JGCF(U, N, A_sym, 64, 3), tri, True),
+        "GCN (Beauty graph, B=2048)": (lambda: sib.GCN(U, N, A_sym, 64, 3), tri, True),
+        "STAMP BCE (N=12101, B=512, S=50)": (lambda: sib.STAMP(N, 64, 64, loss="BCE"), (seq_l1, p1, n1), True),
+        "FMLP-Rec BPR (N=12101, B=512, S=50)": (lambda: sib.FMLPRec(N, S, 64, 2, loss="BPR"), (seq_l1, p1, n1), True),
+        "NARM (N=12101, B=512, S=50)": (lambda: sib.NARM(N, 64, 128), (seq_r, p1, n1), False),
         "GRU4Rec BPR (N=12101, B=512, S=50)": (lambda: sib.GRU4Rec(N, 64, 128, loss="BPR"), (seq_r, p1, n1), False),
         "BERT4Rec (N=12101, B=512, S=50)": (lambda: sib.BERT4Rec(N, S, 64, 4, 2), (seq_l,), False),
     }

@@ -18,6 +18,8 @@ Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic
   dcn.npz      : DCN/main.py      logits, loss, grads (train-mode BN), eval sigmoid scores
   gru4rec_{bce,bpr}.npz : GRU4Rec/main.py fit loss + every gradient + full scores (dropouts 0)
   jgcf.npz     : JGCF/main.py     fit (rec_loss, emb_loss) + table gradients + [low | mid] tables + full scores
+  gcn.npz      : GCN/main.py      fit rec_loss + every gradient + propagated tables + full scores
+  stamp_{bce,ce}.npz, narm.npz, fmlprec_bpr.npz : STAMP / NARM / FMLP-Rec main.py  fit loss + every gradient + full scores (dropouts 0)
   bert4rec.npz : BERT4Rec/main.py fit loss (the mask draw recorded) + every gradient + full scores (dropout 0)
   ngcf.npz     : NGCF/main.py     fit (rec_loss, emb_loss) + every gradient + full scores on D^-1 (A + I)
   simgcl.npz   : SimGCL/main.py   fit (rec_loss, emb_loss, ssl_loss at eps = 0: the noise is torch.rand_like) + grads + full scores
@@ -481,6 +483,92 @@ def gen_jgcf():
     print("jgcf: " + " ".join(f"{k}={float(v):.6f}" for k, v in losses.items()))
 
 
+def gen_gcn():
+    torch.manual_seed(1)
+    U, N, B = 30, 40, 16
+    g = torch.Generator().manual_seed(21)
+    edges = set()
+    while len(edges) < 150:
+        edges.add((int(torch.randint(0, U, (1,), generator=g)), int(torch.randint(0, N, (1,), generator=g))))
+    adj = sym_norm_adj(U, N, sorted(edges))
+    fr, ref = import_ref("GCN", "ref_gcn", dict())
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)], adj=adj)
+    model = ref.GCN(ds)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_((0.3 if "embeddings" in k else 0.2 if k.endswith("weight") else 0.1) * torch.randn(p.shape, generator=g))
+    users = torch.randint(0, U, (B, 1), generator=g)
+    ipos = torch.randint(0, N, (B, 1), generator=g)
+    ineg = torch.randint(0, N, (B, 1), generator=g)
+    data = {model.User: users, model.IPos: ipos, model.INeg: ineg}
+    out = {"in/users": users.numpy(), "in/pos": ipos.numpy(), "in/neg": ineg.numpy(),
+           "in/adj_crow": adj.crow_indices().numpy(), "in/adj_col": adj.col_indices().numpy(), "in/adj_val": adj.values().numpy(),
+           "cfg/num_layers": np.int64(ref.cfg.num_layers)}
+    out.update(sd_np(model))
+    model.train()
+    losses = model(data)
+    losses["rec_loss"].backward()
+    out["out/rec_loss"] = losses["rec_loss"].detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        ue, ie = model.encode()
+        model.reset_ranking_buffers()
+        scores = model(data, ranking="full")
+    out["out/userEmbds"], out["out/itemEmbds"], out["out/scores"] = ue.numpy(), ie.numpy(), scores.numpy()
+    np.savez_compressed(os.path.join(HERE, "gcn.npz"), **out)
+    print(f"gcn: rec_loss={float(losses['rec_loss'].detach()):.6f}")
+
+
+def gen_last_item_model(model_dir, cls, outname, overrides, left_padded, with_modules=False, S=20, emb_scale=1.0):
+    """STAMP / NARM / FMLP-Rec: one user state per sequence against the item table (IPos / INeg [B, 1])."""
+    torch.manual_seed(1)
+    if with_modules:
+        sys.path.insert(0, os.path.join(REF, model_dir))
+    try:
+        fr, ref = import_ref(model_dir, "ref_" + outname, overrides)
+    finally:
+        if with_modules:
+            sys.path.pop(0)
+            sys.modules.pop("modules", None)
+    N, B = 150, 12
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=30), F("ITEM", "ITEM", "ID", count=N)])
+    model = getattr(ref, cls)(ds)
+    g = torch.Generator().manual_seed(31)
+    with torch.no_grad():                                       # biases / LayerNorm affine / STAMP's ba off their initial values
+        for k, p in model.named_parameters():
+            if k.endswith("bias") or k == "ba" or "Norm" in k:
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+            if k == "Item.embeddings.weight":                   # (STAMP's std = 0.002 tables give logits ~ 1e-5: scaled up to exercise the maths)
+                p.mul_(emb_scale)
+    lens = torch.randint(1, S - 2, (B,), generator=g)
+    seq = torch.zeros(B, S, dtype=torch.long)
+    for b in range(B):
+        L = int(lens[b])
+        it = torch.randint(0, N, (L,), generator=g) + 1
+        if left_padded:
+            seq[b, S - L:] = it
+        else:
+            seq[b, :L] = it
+    pos = torch.randint(0, N, (B, 1), generator=g)
+    neg = torch.randint(0, N, (B, 1), generator=g)
+    data = {model.ISeq: seq, model.IPos: pos, model.INeg: neg}
+    out = {"in/seq": seq.numpy(), "in/pos": pos.numpy(), "in/neg": neg.numpy(), "cfg/N": np.int64(N), "cfg/maxlen": np.int64(S)}
+    out.update(sd_np(model))
+    model.train()
+    losses = model(data)
+    losses["rec_loss"].backward()
+    out["out/rec_loss"] = losses["rec_loss"].detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        out["out/scores"] = model(data, ranking="full").numpy()
+    np.savez_compressed(os.path.join(HERE, outname + ".npz"), **out)
+    print(f"{outname}: loss={float(losses['rec_loss'].detach()):.6f}")
+
+
 def gen_bert4rec():
     torch.manual_seed(1)
     S = 20
@@ -536,6 +624,13 @@ if __name__ == "__main__":
     for loss in ("BCE", "BPR"):
         gen_gru4rec(loss)
     gen_jgcf()
+    gen_gcn()
+    gen_last_item_model("STAMP", "STAMP", "stamp_bce", dict(loss="BCE", embedding_dim=64, hidden_size=64), True, emb_scale=200.0)
+    gen_last_item_model("STAMP", "STAMP", "stamp_ce", dict(loss="CE", embedding_dim=64, hidden_size=64), True, emb_scale=200.0)
+    gen_last_item_model("NARM", "NARM", "narm", dict(embedding_dim=64, hidden_size=48, num_blocks=1, emb_dropout_rate=0.0, hidden_dropout_rate=0.0,
+                                                     ct_dropout_rate=0.0), False)
+    gen_last_item_model("FMLP-Rec", "FMLPRec", "fmlprec_bpr", dict(loss="BPR", embedding_dim=64, num_blocks=2, hidden_dropout_rate=0.0, maxlen=20),
+                        True, with_modules=True, emb_scale=10.0)
     gen_bert4rec()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

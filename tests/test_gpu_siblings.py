@@ -238,3 +238,71 @@ def test_graphed_step_replays_the_eager_step():
         assert abs(float(la.detach()) - float(lb)) <= 1e-5 * abs(float(la.detach()))
     for k, p in a.named_parameters():
         torch.testing.assert_close(dict(b.named_parameters())[k], p, rtol=1e-4, atol=1e-6, msg=k)
+
+
+def _load_by_name(m, g, names):
+    """Copy the reference's state-dict entries into the sibling's parameters (names: sibling name -> reference name)."""
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            p.copy_(_t(g["param/" + names.get(k, k)]).view(p.shape))
+
+
+def _check_grads(m, g, names, rtol=5e-4, atol=2e-6):
+    for k, p in m.named_parameters():
+        torch.testing.assert_close(p.grad, _t(g["grad/" + names.get(k, k)]).view(p.shape), rtol=rtol, atol=atol, msg=k)
+
+
+def test_gcn_matches_reference_loss_gradients_and_scores():
+    from recboard_amd.siblings import GCN
+    g = np.load(os.path.join(GOLD, "gcn.npz"))
+    U, N = g["param/User.embeddings.weight"].shape[0], g["param/Item.embeddings.weight"].shape[0]
+    adj = (_t(g["in/adj_crow"]), _t(g["in/adj_col"]), _t(g["in/adj_val"]))
+    m = GCN(U, N, adj, embedding_dim=g["param/User.embeddings.weight"].shape[1], num_layers=int(g["cfg/num_layers"]))
+    names = {"user.weight": "User.embeddings.weight", "item.weight": "Item.embeddings.weight"}
+    _load_by_name(m, g, names)
+    users, pos, neg = (_t(g["in/" + k]).reshape(-1) for k in ("users", "pos", "neg"))
+    m.train()
+    loss = m.fit(users, pos, neg)["rec_loss"]
+    assert abs(float(loss.detach()) - float(g["out/rec_loss"])) <= 2e-5 * abs(float(g["out/rec_loss"]))
+    loss.backward()
+    _check_grads(m, g, names)
+    m.eval()
+    with torch.no_grad():
+        ue, ie = m.encode()
+        torch.testing.assert_close(ue, _t(g["out/userEmbds"]), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(ie, _t(g["out/itemEmbds"]), rtol=1e-4, atol=1e-6)
+        m.reset_ranking_buffers()
+        torch.testing.assert_close(m.recommend_from_full(users), _t(g["out/scores"]), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("which", ["stamp_bce", "stamp_ce", "narm", "fmlprec_bpr"])
+def test_last_item_siblings_match_reference_loss_gradients_and_scores(which):
+    """STAMP, NARM, FMLP-Rec on the engine ops against vectors made from STAMP/main.py, NARM/main.py, FMLP-Rec/main.py + modules.py."""
+    from recboard_amd import siblings as sib
+    g = np.load(os.path.join(GOLD, which + ".npz"))
+    N, S = int(g["cfg/N"]), int(g["cfg/maxlen"])
+    names = {"item.weight": "Item.embeddings.weight"}
+    if which.startswith("stamp"):
+        m = sib.STAMP(N, 64, 64, loss=which[6:].upper())
+    elif which == "narm":
+        m = sib.NARM(N, 64, 48, 1, emb_dropout_rate=0.0, hidden_dropout_rate=0.0, ct_dropout_rate=0.0)
+    else:
+        m = sib.FMLPRec(N, maxlen=S, embedding_dim=64, num_blocks=2, hidden_dropout_rate=0.0, loss="BPR")
+        for l in range(2):
+            pre = f"itemEncoder.layer.{l}."
+            names.update({f"blocks.{l}.complex_weight": pre + "filterlayer.complex_weight",
+                          f"blocks.{l}.filter_norm.weight": pre + "filterlayer.LayerNorm.weight", f"blocks.{l}.filter_norm.bias": pre + "filterlayer.LayerNorm.bias",
+                          f"blocks.{l}.dense_1.weight": pre + "intermediate.dense_1.weight", f"blocks.{l}.dense_1.bias": pre + "intermediate.dense_1.bias",
+                          f"blocks.{l}.dense_2.weight": pre + "intermediate.dense_2.weight", f"blocks.{l}.dense_2.bias": pre + "intermediate.dense_2.bias",
+                          f"blocks.{l}.out_norm.weight": pre + "intermediate.LayerNorm.weight", f"blocks.{l}.out_norm.bias": pre + "intermediate.LayerNorm.bias"})
+    _load_by_name(m, g, names)
+    seq, pos, neg = _t(g["in/seq"]), _t(g["in/pos"]).reshape(-1), _t(g["in/neg"]).reshape(-1)
+    m.train()
+    loss = m.fit(seq, pos, neg)["rec_loss"]
+    assert abs(float(loss.detach()) - float(g["out/rec_loss"])) <= 2e-5 * abs(float(g["out/rec_loss"]))
+    loss.backward()
+    _check_grads(m, g, names)
+    assert float(m.item.weight.grad[0].abs().max()) == 0.0      # the padding row takes no gradient
+    m.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(m.recommend_from_full(seq), _t(g["out/scores"]), rtol=1e-4, atol=1e-5)
