@@ -96,6 +96,17 @@ int re_sparse_adam_rows(const float* g, const int64_t* idx, int64_t n, int64_t D
 int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* W,
                             float* m, float* v, const float* hyper, double beta1, double beta2, double eps,
                             double weight_decay, void* ws, size_t ws_bytes, re_stream_t stream);
+/* The same update for a SMALL key list (a training step's contribution rows: ~15 k at config 5) against a table of any size, in ONE
+ * launch and without a sort or a workspace (csrc/adam_rows.hip: the workgroup a key hashes to collects, orders and sums that key's rows).
+ *   keys: int32 (key_bytes = 4) or int64 (8), n_regions regions of region_stride entries each; of every region the first
+ *   min(n_dev[0] * n_mul, region_stride) entries are read when n_dev (DEVICE int32) is given, else the first n_host;
+ *   g: one row per key entry, [n_regions * region_stride, D]; entries < 0, >= R or == padding_idx are dropped; D = 64 or 128.
+ *   hyper (DEVICE float[2], as re_sparse_adam_rows_dev) or, when null, the host's step / lr.
+ * The sums' association differs from re_sparse_adam_rows' (same values to rounding); deterministic for a given input. */
+int re_sparse_adam_rows_small(const float* g, const void* keys, int32_t key_bytes, int32_t n_regions, int64_t region_stride,
+                              const int32_t* n_dev, int64_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float* W,
+                              float* m, float* v, const float* hyper, int64_t step, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, re_stream_t stream);
 /* Small dense tables (R up to ~100 k rows; D = 64 or 128): the same sum WITHOUT the sort -- every workgroup owns a range of
  * destination rows, scans all keys and adds the rows that fall into its range; one launch, no workspace, dW [R, D] fully
  * overwritten (untouched rows and row `padding_idx` zero).  keys are int32: `n_regions` runs of n keys, run q at

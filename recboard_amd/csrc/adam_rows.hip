@@ -1,0 +1,309 @@
+// Row-sparse Adam for a SMALL key list against a table of any size, in ONE launch and without a sort: what a training step of the
+// large-table engines needs (config 5: ~15 k contribution rows per step against a 100 M x 128 table; the general path,
+// re_sparse_adam_rows, is a 3-pass radix sort + segmented sum + fix-up = 9 launches, ~70 us at this size).
+//
+// Owner computes: SA_NWG workgroups; a key belongs to the workgroup its hash names.  Every workgroup scans the whole key list (60 KB of
+// int32 keys at config 5: it comes from L2) twice: first it counts the contributions of every distinct key it owns (an LDS hash table),
+// then it keeps the entries of the keys with few contributions as (key, position) words in LDS, orders them by all-pairs rank counting
+// (a few dozen entries: no barrier-heavy sorting network) and walks the runs of equal keys -- one wave per distinct row sums the row's
+// contributions in position order and applies ONE Adam update to (W, m, v): re_sparse_adam_rows' rule (torch.optim.SparseAdam on the
+// touched rows + coupled weight decay, the global step count).  A key with many contributions (a Zipf-head item: 8 % of a config-5
+// batch is item 1) never enters the list: all the workgroup's waves sum it straight from the key list, each over a slice of the
+// positions (matches compacted by ballots, eight row loads in flight), the slices combined in order.  Results do not depend on the order
+// in which entries were collected or rows were scheduled.  A workgroup whose share does not fit its LDS structures (adversarial
+// inputs) takes a slow exact path: its distinct keys in ascending order, each summed from the key list the same way.
+#include "re_common.h"
+
+#define SA_NWG 256
+#define SA_NT 1024
+#define SA_NW (SA_NT / 64)
+#define SA_CAP 2048
+#define SA_LONG 48        // keys with more contributions than this are summed by the whole workgroup (<= 64: a listed run fits one ballot)
+
+struct SaParams {
+    const float* g;
+    const void* keys;
+    int n_regions;
+    int64_t region_stride;
+    const int32_t* n_dev;
+    int64_t n_mul, n_host;
+    int64_t R, padding_idx;
+    float *W, *m, *v;
+    float b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd;
+    const float* hyper;
+};
+
+__device__ __forceinline__ uint32_t sa_owner(uint32_t k) { return (k * 0x9E3779B1u) >> 24; }   // 256 owners
+
+template <int VPT>
+struct SaRow {
+    float x[VPT];
+};
+
+template <int VPT>
+__device__ __forceinline__ SaRow<VPT> sa_load(const float* __restrict__ base, int64_t row, int lane) {
+    SaRow<VPT> r;
+    const float* p = base + row * (64 * VPT) + lane * VPT;
+    if (VPT == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        r.x[0] = t.x; r.x[VPT - 1] = t.y;
+    } else {
+        r.x[0] = p[0];
+    }
+    return r;
+}
+
+template <int VPT>
+__device__ __forceinline__ void sa_store(float* __restrict__ base, int64_t row, int lane, const SaRow<VPT>& r) {
+    float* p = base + row * (64 * VPT) + lane * VPT;
+    if (VPT == 2) *reinterpret_cast<float2*>(p) = make_float2(r.x[0], r.x[VPT - 1]);
+    else p[0] = r.x[0];
+}
+
+template <int VPT>
+__device__ __forceinline__ void sa_adam(const SaParams& P, int64_t row, int lane, const SaRow<VPT>& G) {
+    SaRow<VPT> w = sa_load<VPT>(P.W, row, lane), mm = sa_load<VPT>(P.m, row, lane), vv = sa_load<VPT>(P.v, row, lane);
+    const float ss = P.hyper ? P.hyper[0] : P.step_size, ib = P.hyper ? P.hyper[1] : P.inv_sqrt_bc2;
+#pragma unroll
+    for (int c = 0; c < VPT; ++c) {
+        const float gg = G.x[c] + P.wd * w.x[c];
+        mm.x[c] = P.b1 * mm.x[c] + P.omb1 * gg;
+        vv.x[c] = P.b2 * vv.x[c] + P.omb2 * gg * gg;
+        w.x[c] = w.x[c] - ss * (mm.x[c] / (sqrtf(vv.x[c]) * ib + P.eps));
+    }
+    sa_store<VPT>(P.W, row, lane, w);
+    sa_store<VPT>(P.m, row, lane, mm);
+    sa_store<VPT>(P.v, row, lane, vv);
+}
+
+// sum of the contribution rows at positions list[e] (low words), e in [e0, e1), in that order; four loads in flight
+template <int VPT>
+__device__ __forceinline__ SaRow<VPT> sa_sum(const float* __restrict__ g, const unsigned long long* list, int e0, int e1, int lane) {
+    SaRow<VPT> acc;
+#pragma unroll
+    for (int c = 0; c < VPT; ++c) acc.x[c] = 0.f;
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {
+        const SaRow<VPT> a = sa_load<VPT>(g, (int64_t)(uint32_t)list[e], lane), b = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 1], lane),
+                         c2 = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 2], lane), d = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 3], lane);
+#pragma unroll
+        for (int c = 0; c < VPT; ++c) acc.x[c] = (((acc.x[c] + a.x[c]) + b.x[c]) + c2.x[c]) + d.x[c];
+    }
+    for (; e < e1; ++e) {
+        const SaRow<VPT> a = sa_load<VPT>(g, (int64_t)(uint32_t)list[e], lane);
+#pragma unroll
+        for (int c = 0; c < VPT; ++c) acc.x[c] += a.x[c];
+    }
+    return acc;
+}
+
+template <class KeyT>
+__device__ __forceinline__ int64_t sa_key(const SaParams& P, int64_t pos) { return (int64_t)reinterpret_cast<const KeyT*>(P.keys)[pos]; }
+
+#define SA_HT 1024        // slots of the per-workgroup table of owned distinct keys
+#define SA_EMPTY 0xFFFFFFFFu
+#define SA_WQ ((2 * SA_CAP * 2) / SA_NW)   // u32 words of the two list arrays per wave while they serve as position queues (512)
+
+__device__ __forceinline__ uint32_t sa_slot0(uint32_t k) { return ((k * 0x85EBCA6Bu) >> 12) & (SA_HT - 1); }
+
+// Sum of the contribution rows of ONE key over the whole key list, by all waves of the workgroup: wave w takes the w-th slice of every
+// region's positions, first compacts the positions that hold the key into its queue (coalesced key reads, ballots), then sums those rows
+// with eight loads in flight; the waves' partial sums are combined in wave order and the row gets its Adam update.
+// Must be called by every thread of the workgroup (barriers inside).
+template <int VPT, class KeyT>
+__device__ __forceinline__ void sa_heavy(const SaParams& P, uint32_t cur, int64_t rows, uint32_t* queue, float (*part)[64 * VPT], int lane, int wave) {
+    SaRow<VPT> acc;
+#pragma unroll
+    for (int c = 0; c < VPT; ++c) acc.x[c] = 0.f;
+    uint32_t* q = queue + wave * SA_WQ;
+    const int64_t slice = (rows + SA_NW - 1) / SA_NW;
+    const int64_t i0 = (int64_t)wave * slice, i1 = (i0 + slice < rows) ? i0 + slice : rows;
+    for (int r = 0; r < P.n_regions; ++r) {
+        const int64_t base = (int64_t)r * P.region_stride;
+        int64_t i = i0;
+        while (i < i1) {
+            uint32_t nq = 0;                                 // (wave-uniform)
+            for (; i < i1 && nq + 64 <= SA_WQ; i += 64) {
+                const int64_t j = i + lane;
+                const bool hit = j < i1 && sa_key<KeyT>(P, base + j) == (int64_t)cur;
+                const unsigned long long mask = __ballot(hit);
+                if (hit) q[nq + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint32_t)(base + j);
+                nq += (uint32_t)__builtin_popcountll(mask);
+            }
+            uint32_t e = 0;
+            for (; e + 8 <= nq; e += 8) {
+                SaRow<VPT> t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = sa_load<VPT>(P.g, (int64_t)q[e + u], lane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int c = 0; c < VPT; ++c) acc.x[c] += t[u].x[c];
+            }
+            for (; e < nq; ++e) {
+                const SaRow<VPT> t = sa_load<VPT>(P.g, (int64_t)q[e], lane);
+#pragma unroll
+                for (int c = 0; c < VPT; ++c) acc.x[c] += t.x[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < VPT; ++c) part[wave][lane * VPT + c] = acc.x[c];
+    __syncthreads();
+    if (wave == 0) {
+        SaRow<VPT> t;
+#pragma unroll
+        for (int c = 0; c < VPT; ++c) t.x[c] = 0.f;
+        for (int w = 0; w < SA_NW; ++w)
+#pragma unroll
+            for (int c = 0; c < VPT; ++c) t.x[c] += part[w][lane * VPT + c];
+        sa_adam<VPT>(P, (int64_t)cur, lane, t);
+    }
+    __syncthreads();
+}
+
+template <int VPT, class KeyT>
+__global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
+    __shared__ unsigned long long s_lists[2 * SA_CAP];                  // collected entries | ordered entries; the heavy phase's position queues
+    unsigned long long* const s_list = s_lists;
+    unsigned long long* const s_sorted = s_lists + SA_CAP;
+    __shared__ uint32_t s_seg[SA_CAP];
+    __shared__ uint32_t s_hkey[SA_HT], s_hcnt[SA_HT];
+    __shared__ float s_part[SA_NW][64 * VPT];
+    __shared__ uint32_t s_cnt, s_nseg, s_over, s_min, s_nheavy;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t me = blockIdx.x;
+    if (tid == 0) { s_cnt = 0; s_nseg = 0; s_over = 0; s_nheavy = 0; }
+    s_hkey[tid] = SA_EMPTY;                               // (SA_HT == SA_NT)
+    s_hcnt[tid] = 0;
+    __syncthreads();
+    int64_t rows = P.n_host;
+    if (P.n_dev) {
+        rows = (int64_t)P.n_dev[0] * P.n_mul;
+        if (rows > P.region_stride) rows = P.region_stride;
+        if (rows < 0) rows = 0;
+    }
+    // ---- pass A: the distinct keys this workgroup owns, with their number of contributions
+    for (int r = 0; r < P.n_regions; ++r) {
+        const int64_t base = (int64_t)r * P.region_stride;
+        for (int64_t i = tid; i < rows; i += SA_NT) {
+            const int64_t k = sa_key<KeyT>(P, base + i);
+            if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner((uint32_t)k) != me) continue;
+            uint32_t h = sa_slot0((uint32_t)k);
+            int tries = 0;
+            for (; tries < SA_HT; ++tries, h = (h + 1) & (SA_HT - 1)) {
+                const uint32_t old = atomicCAS(&s_hkey[h], SA_EMPTY, (uint32_t)k);
+                if (old == SA_EMPTY || old == (uint32_t)k) { atomicAdd(&s_hcnt[h], 1u); break; }
+            }
+            if (tries == SA_HT) s_over = 1;
+        }
+    }
+    __syncthreads();
+    // ---- pass B: the entries of the keys with few contributions go to the list (key, position)
+    if (!s_over) {
+        for (int r = 0; r < P.n_regions; ++r) {
+            const int64_t base = (int64_t)r * P.region_stride;
+            for (int64_t i = tid; i < rows; i += SA_NT) {
+                const int64_t k = sa_key<KeyT>(P, base + i);
+                if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner((uint32_t)k) != me) continue;
+                uint32_t h = sa_slot0((uint32_t)k);
+                while (s_hkey[h] != (uint32_t)k) h = (h + 1) & (SA_HT - 1);
+                if (s_hcnt[h] > SA_LONG) continue;
+                const uint32_t at = atomicAdd(&s_cnt, 1u);
+                if (at < SA_CAP) s_list[at] = ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)(uint32_t)(base + i);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = s_cnt;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(s_lists);
+    if (s_over || cnt > SA_CAP) {
+        // ---- slow exact path (more distinct keys or short-run entries than the LDS structures hold -- adversarial inputs): every owned
+        //      distinct key in ascending order, each summed over the whole list
+        int64_t lo = -1;
+        for (;;) {
+            if (tid == 0) s_min = SA_EMPTY;
+            __syncthreads();
+            uint32_t mine = SA_EMPTY;
+            for (int r = 0; r < P.n_regions; ++r) {
+                const int64_t base = (int64_t)r * P.region_stride;
+                for (int64_t i = tid; i < rows; i += SA_NT) {
+                    const int64_t k = sa_key<KeyT>(P, base + i);
+                    if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner((uint32_t)k) != me || k <= lo) continue;
+                    if ((uint32_t)k < mine) mine = (uint32_t)k;
+                }
+            }
+            if (mine != SA_EMPTY) atomicMin(&s_min, mine);
+            __syncthreads();
+            const uint32_t cur = s_min;
+            if (cur == SA_EMPTY) break;
+            sa_heavy<VPT, KeyT>(P, cur, rows, queue, s_part, lane, wave);
+            lo = (int64_t)cur;
+        }
+        return;
+    }
+    // ---- order the listed entries: rank = number of smaller words (words are distinct: the position is part of them)
+    for (uint32_t e = tid; e < cnt; e += SA_NT) {
+        const unsigned long long x = s_list[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < cnt; ++j) rank += (s_list[j] < x) ? 1u : 0u;
+        s_sorted[rank] = x;
+    }
+    __syncthreads();
+    // ---- runs of equal keys: one wave per run
+    for (uint32_t e = tid; e < cnt; e += SA_NT)
+        if (e == 0 || (uint32_t)(s_sorted[e] >> 32) != (uint32_t)(s_sorted[e - 1] >> 32)) s_seg[atomicAdd(&s_nseg, 1u)] = e;
+    __syncthreads();
+    const uint32_t nseg = s_nseg;
+    for (uint32_t s = wave; s < nseg; s += SA_NW) {
+        const uint32_t start = s_seg[s];
+        const uint32_t key = (uint32_t)(s_sorted[start] >> 32);
+        const uint32_t e = start + lane;                     // (a listed run has at most SA_LONG <= 64 entries)
+        const bool same = e < cnt && (uint32_t)(s_sorted[e] >> 32) == key;
+        const uint32_t len = (uint32_t)__builtin_ctzll(~__ballot(same));
+        const SaRow<VPT> G = sa_sum<VPT>(P.g, s_sorted, (int)start, (int)(start + len), lane);
+        sa_adam<VPT>(P, (int64_t)key, lane, G);
+    }
+    __syncthreads();
+    // ---- keys with many contributions (a Zipf-head item): summed over the key list by the whole workgroup, one after the other
+    if (s_hkey[tid] != SA_EMPTY && s_hcnt[tid] > SA_LONG) s_seg[atomicAdd(&s_nheavy, 1u)] = s_hkey[tid];     // (s_seg is free again)
+    __syncthreads();
+    const uint32_t nheavy = s_nheavy;
+    for (uint32_t h = 0; h < nheavy; ++h) sa_heavy<VPT, KeyT>(P, s_seg[h], rows, queue, s_part, lane, wave);
+}
+
+extern "C" int re_sparse_adam_rows_small(const float* g, const void* keys, int32_t key_bytes, int32_t n_regions, int64_t region_stride,
+                                         const int32_t* n_dev, int64_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx,
+                                         float* W, float* m, float* v, const float* hyper, int64_t step, double lr, double beta1,
+                                         double beta2, double eps, double weight_decay, re_stream_t stream) {
+    re_clear_error();
+    if (!W || !m || !v || R <= 0 || n_regions < 0 || region_stride < 0 || n_host < 0 || n_mul < 0) return RE_EINVAL;
+    if (D != 64 && D != 128) return RE_EUNSUPPORTED;
+    if (key_bytes != 4 && key_bytes != 8) return RE_EINVAL;
+    if (R >= 0xFFFFFFFEll || (int64_t)n_regions * region_stride >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
+    if (!hyper && step < 1) return RE_EINVAL;
+    if (n_regions == 0 || region_stride == 0 || (!n_dev && n_host == 0)) return RE_OK;
+    if (!g || !keys) return RE_EINVAL;
+    if (n_host > region_stride) return RE_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 7u)
+        return RE_EINVAL;
+    SaParams P;
+    P.g = g; P.keys = keys; P.n_regions = n_regions; P.region_stride = region_stride; P.n_dev = n_dev; P.n_mul = n_mul; P.n_host = n_host;
+    P.R = R; P.padding_idx = padding_idx; P.W = W; P.m = m; P.v = v;
+    P.b1 = (float)beta1; P.b2 = (float)beta2; P.omb1 = (float)(1.0 - beta1); P.omb2 = (float)(1.0 - beta2);
+    P.eps = (float)eps; P.wd = (float)weight_decay; P.hyper = hyper;
+    P.step_size = 0.f; P.inv_sqrt_bc2 = 0.f;
+    if (!hyper) {
+        P.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+        P.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 64) {
+        if (key_bytes == 4) hipLaunchKernelGGL((sparse_adam_owner_k<1, int32_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
+        else hipLaunchKernelGGL((sparse_adam_owner_k<1, int64_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
+    } else {
+        if (key_bytes == 4) hipLaunchKernelGGL((sparse_adam_owner_k<2, int32_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
+        else hipLaunchKernelGGL((sparse_adam_owner_k<2, int64_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
+    }
+    return re_launch_status();
+}

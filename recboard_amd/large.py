@@ -150,10 +150,7 @@ class SASRecLargeTableEngine(SASRecEngine):
                                            aux.plan, kind, count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
                                            W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
                                            G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev)
-            if "keys64" not in W:
-                W["keys64"] = torch.zeros(W["keys"].numel(), dtype=torch.int64, device=self.device)
-            W["keys64"].copy_(W["keys"].view(-1))
-            return loss, W["g_rows"].view(-1, D), W["keys64"]
+            return loss, W["g_rows"].view(-1, D), W["keys"]          # keys: int32 [3, NR], the plan's first rows of every region live
         if self.encoder == "fused":
             # the same launches as SASRecEngine's fused step, minus the dense scatter-add: fused embedding + encoder forward (tape),
             # criterion forward + backward, encoder backward with the embedding backward fused in (contribution rows, position gradient)
@@ -184,6 +181,21 @@ class SASRecLargeTableEngine(SASRecEngine):
         ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, A.view(A.grad, "Position.weight"), seed_dev=seed_dev)
         return loss, C, aux.rows_all
 
+    def _table_adam(self, C, rows, aux, step=0, hyper=None):
+        """Row-sparse Adam of the item table.  Compact-row step (rows: the int32 [3, NR] keys of the plan's rows): ONE launch, no sort
+        (re_sparse_adam_rows_small; the live length of every region comes from the plan on the device); otherwise the sorted general form."""
+        b1, b2 = self.betas
+        if rows.dtype == torch.int32 and self.D in (64, 128):
+            ops.sparse_adam_rows_small(C, rows, self.E, self.Em, self.Ev, step=step, lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, weight_decay=self.wd,
+                                       padding_idx=0, hyper=hyper, n_dev=aux.plan.view(torch.int32)[1:2], n_mul=16)
+        elif ops.sparse_adam_small_ok(rows, self.E):             # (all-positions step: 3*B*S int64 keys, still one launch)
+            ops.sparse_adam_rows_small(C, rows.reshape(-1), self.E, self.Em, self.Ev, step=step, lr=self.lr, beta1=b1, beta2=b2, eps=1e-8,
+                                       weight_decay=self.wd, padding_idx=0, hyper=hyper)
+        elif hyper is not None:
+            ops.sparse_adam_rows_dev(C, rows.view(-1).long(), self.E, self.Em, self.Ev, hyper, b1, b2, 1e-8, self.wd, padding_idx=0)
+        else:
+            ops.sparse_adam_rows(C, rows.view(-1).long(), self.E, self.Em, self.Ev, step, self.lr, b1, b2, 1e-8, self.wd, padding_idx=0)
+
     def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
         """One step; gradients of the item table exist only as 3*B*S contribution rows."""
         A = self.arena
@@ -193,8 +205,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         if grad_hook is not None:
             grad_hook(A.grad)
         A.step += 1
-        ops.sparse_adam_rows(C, rows, self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
-                             padding_idx=0)
+        self._table_adam(C, rows, aux, step=A.step)
         ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
         return loss.squeeze(0)
 
@@ -211,8 +222,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         def body():
             loss, C, rows = self._grads(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state)
             if with_adam:
-                ops.sparse_adam_rows_dev(C, rows, self.E, self.Em, self.Ev, hyper, self.betas[0], self.betas[1], 1e-8, self.wd,
-                                         padding_idx=0)
+                self._table_adam(C, rows, pb, hyper=hyper)
                 ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
             return loss, C, rows
 
@@ -233,7 +243,7 @@ class SASRecLargeTableEngine(SASRecEngine):
             loss, C, rows = body()
         for t, k in zip((A.data, A.m, A.v, A.grad), keep):
             t.copy_(k)
-        return dict(graph=graph, blob=blob, state=state, loss=loss, C=C, rows=rows)
+        return dict(graph=graph, blob=blob, state=state, loss=loss, C=C, rows=rows, pb=pb)
 
     def train_step_graph(self, seq, pos, neg, grad_hook=None):
         A = self.arena
@@ -250,8 +260,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         A.step += 1
         if grad_hook is not None:
             grad_hook(A.grad)
-            ops.sparse_adam_rows(g["C"], g["rows"], self.E, self.Em, self.Ev, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd,
-                                 padding_idx=0)
+            self._table_adam(g["C"], g["rows"], g["pb"], step=A.step)
             ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
         return g["loss"].squeeze(0)
 
@@ -359,7 +368,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             loc = route.slot + 1
             loss, C, keys = self._grads(loc[:n].view(B, S), (loc[n:2 * n] - 1).view(B, S), (loc[2 * n:] - 1).view(B, S), aux, sd,
                                         seed_dev=seed_dev, table=T)
-            slots = keys - 1 if keys is not None else torch.arange(C.shape[0], device=C.device)     # (None: one row per row of T[1:])
+            slots = keys.view(-1).long() - 1 if keys is not None else torch.arange(C.shape[0], device=C.device)   # (None: one row per row of T[1:])
         else:
             # the batch-local table: row 0 = padding, row 1 + j = table row rows_all[j]  (one all-to-all round trip)
             rows, route = self.table.lookup(aux.rows_all)
@@ -370,7 +379,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             # compact-row step: C holds 3 x NR contribution rows, `keys` their rows of T (0 = none); key - 1 = the lookup they belong to.
             # (all-positions step, compact_rows = False: one row per lookup, keys None)
             loss, C, keys = self._grads(seq_l, (ar - 1 + n).view(B, S), (ar - 1 + 2 * n).view(B, S), aux, sd, seed_dev=seed_dev, table=T)
-            positions = None if keys is None or keys is aux.rows_all else keys - 1
+            positions = None if keys is None or keys is aux.rows_all else keys.view(-1).long() - 1
         if self.world > 1:
             C.mul_(1.0 / self.world)                 # the loss of the global batch is the mean of the ranks' losses
             dist.all_reduce(A.grad, op=dist.ReduceOp.AVG, group=self.group)

@@ -24,6 +24,8 @@ SIGNATURES = {
     "re_scatter_plan": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _sz, _vp]),
     "re_scatter_apply": (_i32, [_vp, _i64, _i64, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
     "re_sparse_adam_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _vp, _sz, _vp]),
+    "re_sparse_adam_rows_small": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64,
+                                         _f64, _f64, _vp]),
     "re_sparse_adam_rows_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _sz, _vp]),
     "re_scatter_add_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
     "re_pair_loss_workspace_bytes": (_sz, [_i64]),

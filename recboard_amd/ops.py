@@ -122,6 +122,35 @@ def sparse_adam_rows_dev(g, idx, W, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-
                                         float(eps), float(weight_decay), _p(ws), ws.numel(), _stream()), "re_sparse_adam_rows_dev")
 
 
+def sparse_adam_small_ok(keys, W):
+    """Whether re_sparse_adam_rows_small takes this update: D = 64 / 128 and a key list every workgroup can afford to scan."""
+    return W.shape[1] in (64, 128) and keys.numel() <= (1 << 15) and W.shape[0] < 0xFFFFFFFE
+
+
+def sparse_adam_rows_small(g, keys, W, m, v, step=0, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, padding_idx=-1, hyper=None,
+                          n_dev=None, n_mul=1):
+    """Row-sparse Adam for a small key list in one launch (re_sparse_adam_rows_small).  keys: int32 or int64, [n] or [regions, stride]
+    (one row of g per entry); n_dev (device int32[1]): only the first n_dev * n_mul entries of every region are read; hyper (device
+    float32[2]) replaces the host's step / lr (captured steps)."""
+    _req(g, torch.float32, "g")
+    if keys.dtype not in (torch.int32, torch.int64) or not keys.is_cuda or not keys.is_contiguous():
+        raise TypeError("recengine: `keys` must be a contiguous int32 or int64 tensor on the HIP device")
+    for t, nme in ((W, "W"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nme)
+    R, D = W.shape
+    regions, stride = (1, keys.numel()) if keys.dim() == 1 else (keys.shape[0], keys.shape[1])
+    if g.numel() != keys.numel() * D:
+        raise ValueError("recengine: g must have one row per key entry")
+    if hyper is not None:
+        _req(hyper, torch.float32, "hyper")
+    if n_dev is not None:
+        _req(n_dev, torch.int32, "n_dev")
+    lib.check(lib.load().re_sparse_adam_rows_small(_p(g), _p(keys), keys.element_size(), int(regions), int(stride), _p(n_dev), int(n_mul),
+                                                   int(stride), D, R, int(padding_idx), _p(W), _p(m), _p(v), _p(hyper), int(step), float(lr),
+                                                   float(beta1), float(beta2), float(eps), float(weight_decay), _stream()),
+              "re_sparse_adam_rows_small")
+
+
 def scatter_plan(idx, D, R, ws, padding_idx=-1, zero=None):
     """Index half of scatter_add_rows (re_scatter_plan): sorts (destination row, position) into `ws`; optionally zero-fills
     `zero` (the table scatter_apply will accumulate into).  Depends on idx only -- may run on a side stream."""

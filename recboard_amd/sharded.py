@@ -38,12 +38,18 @@ class EngineLocalOps:
 
     def sparse_adam(self, g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=-1):
         from . import ops
-        ops.sparse_adam_rows(g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=padding_idx)
+        if ops.sparse_adam_small_ok(idx, W):       # a step's worth of rows: one launch, no sort (re_sparse_adam_rows_small)
+            ops.sparse_adam_rows_small(g, idx.reshape(-1), W, m, v, step=step, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, padding_idx=padding_idx)
+        else:
+            ops.sparse_adam_rows(g, idx, W, m, v, step, lr, b1, b2, eps, wd, padding_idx=padding_idx)
 
     def sparse_adam_dev(self, g, idx, W, m, v, hyper, b1, b2, eps, wd, padding_idx=-1):
         """sparse_adam with the step-dependent scalars in device memory (captured steps)."""
         from . import ops
-        ops.sparse_adam_rows_dev(g, idx, W, m, v, hyper, b1, b2, eps, wd, padding_idx=padding_idx)
+        if ops.sparse_adam_small_ok(idx, W):
+            ops.sparse_adam_rows_small(g, idx.reshape(-1), W, m, v, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, padding_idx=padding_idx, hyper=hyper)
+        else:
+            ops.sparse_adam_rows_dev(g, idx, W, m, v, hyper, b1, b2, eps, wd, padding_idx=padding_idx)
 
     def route_bucket(self, idx, R, G, cap, skip_row=-1):
         """Owner bucketing with a fixed capacity per peer (re_route_bucket): no host sync."""

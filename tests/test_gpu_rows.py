@@ -230,3 +230,73 @@ def test_split_is_refused_when_the_halves_could_not_all_be_resident():
         m.check_handover()
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
 
+
+
+@pytest.mark.parametrize("D,case", [(64, "zipf"), (128, "zipf"), (128, "hot"), (64, "one_row"), (128, "regions_dev"), (64, "empty")])
+def test_sparse_adam_rows_small_matches_oracle(D, case):
+    """re_sparse_adam_rows_small (csrc/adam_rows.hip: owner-computes, no sort) against the oracle's sparse Adam: duplicates summed, padding /
+    out-of-range keys dropped, untouched rows bit-identical, two calls identical; `one_row` (every key the same row: more than an LDS
+    list holds) takes the kernel's slow exact path; `regions_dev`: int32 keys in three regions, the live length from device memory."""
+    from oracle import adam as oadam
+    from recboard_amd import ops
+    rng = np.random.default_rng(11)
+    R = 300_000
+    W0 = rng.standard_normal((R, D)).astype(np.float32)
+    m0 = (0.01 * rng.standard_normal((R, D))).astype(np.float32)
+    v0 = (0.01 * rng.random((R, D))).astype(np.float32)
+    kw = {}
+    if case == "zipf":
+        n = 14000
+        keys = np.minimum(rng.zipf(1.05, n), R - 1).astype(np.int64)
+        keys[::17] = 0                                  # padding row
+        keys[5], keys[9] = -3, R + 4                    # out of range
+    elif case == "hot":
+        n = 9000
+        keys = rng.integers(1, R, n).astype(np.int64)
+        keys[rng.random(n) < 0.3] = 777                 # ~2 700 contributions to one row: a long run, summed by the whole workgroup
+        keys[rng.random(n) < 0.01] = 4242               # ~90: a long run next to it
+    elif case == "one_row":
+        n = 5000
+        keys = np.full(n, 123456, np.int64)
+    elif case == "empty":
+        n = 100
+        keys = np.zeros(n, np.int64)
+    else:
+        stride, live = 4096, 16 * 130                   # three regions of 4096 entries, the first 2080 of each live
+        keys = np.zeros((3, stride), np.int32)
+        keys[:, :live] = np.minimum(rng.zipf(1.1, (3, live)), R - 1)
+        keys[:, live:] = 55                             # beyond the live length: must not be read
+        n = 3 * stride
+        kw = dict(n_dev=torch.tensor([130], dtype=torch.int32, device="cuda"), n_mul=16)
+    g = rng.standard_normal((n, D)).astype(np.float32)
+    flat = keys.reshape(-1).astype(np.int64)
+    if case == "regions_dev":
+        use = np.zeros((3, 4096), bool); use[:, :16 * 130] = True
+        flat_used, g_used = flat[use.reshape(-1)], g[use.reshape(-1)]
+    else:
+        flat_used, g_used = flat, g
+    ok = (flat_used > 0) & (flat_used < R)
+    We, me, ve = W0.copy(), m0.copy(), v0.copy()
+    if ok.any():
+        oadam.sparse_adam_rows(We, me, ve, flat_used[ok], g_used[ok], 7, 1e-3, wd=1e-2, padding_idx=0)
+    outs = []
+    for _ in range(2):
+        W, m, v = (torch.from_numpy(a.copy()).cuda() for a in (W0, m0, v0))
+        ops.sparse_adam_rows_small(torch.from_numpy(g).cuda(), torch.from_numpy(keys).cuda(), W, m, v, step=7, lr=1e-3, weight_decay=1e-2,
+                                   padding_idx=0, **kw)
+        outs.append((W.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    W, m, v = outs[0]
+    touched = np.unique(flat_used[ok])
+    tol = dict(rtol=5e-5, atol=5e-5)     # (a Zipf-head row sums thousands of rows: fp32 sums in another association than the oracle's f64-free loop)
+    np.testing.assert_allclose(W[touched], We[touched], **tol)
+    np.testing.assert_allclose(m[touched], me[touched], **tol)
+    np.testing.assert_allclose(v[touched], ve[touched], **tol)
+    untouched = np.setdiff1d(np.arange(R), touched)
+    assert np.array_equal(W[untouched], W0[untouched]) and np.array_equal(m[untouched], m0[untouched]) and np.array_equal(v[untouched], v0[untouched])
+    # the device-scalar form (captured steps) takes the same step
+    hyper = torch.tensor([1e-3 / (1 - 0.9 ** 7), 1 / np.sqrt(1 - 0.999 ** 7)], dtype=torch.float32, device="cuda")
+    W2, m2, v2 = (torch.from_numpy(a.copy()).cuda() for a in (W0, m0, v0))
+    ops.sparse_adam_rows_small(torch.from_numpy(g).cuda(), torch.from_numpy(keys).cuda(), W2, m2, v2, weight_decay=1e-2, padding_idx=0, hyper=hyper, **kw)
+    np.testing.assert_allclose(W2.cpu().numpy(), W, rtol=1e-6, atol=1e-7)
