@@ -101,6 +101,7 @@ template <class KeyT>
 __device__ __forceinline__ int64_t sa_key(const SaParams& P, int64_t pos) { return (int64_t)reinterpret_cast<const KeyT*>(P.keys)[pos]; }
 
 #define SA_HT 1024        // slots of the per-workgroup table of owned distinct keys
+#define SA_KPT 16         // keys a thread loads at a time
 #define SA_EMPTY 0xFFFFFFFFu
 #define SA_WQ ((2 * SA_CAP * 2) / SA_NW)   // u32 words of the two list arrays per wave while they serve as position queues (512)
 
@@ -123,12 +124,17 @@ __device__ __forceinline__ void sa_heavy(const SaParams& P, uint32_t cur, int64_
         int64_t i = i0;
         while (i < i1) {
             uint32_t nq = 0;                                 // (wave-uniform)
-            for (; i < i1 && nq + 64 <= SA_WQ; i += 64) {
-                const int64_t j = i + lane;
-                const bool hit = j < i1 && sa_key<KeyT>(P, base + j) == (int64_t)cur;
-                const unsigned long long mask = __ballot(hit);
-                if (hit) q[nq + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint32_t)(base + j);
-                nq += (uint32_t)__builtin_popcountll(mask);
+            for (; i < i1 && nq + 256 <= SA_WQ; i += 256) {        // four windows of keys in flight
+                int64_t kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kk[u] = (i + 64 * u + lane < i1) ? sa_key<KeyT>(P, base + i + 64 * u + lane) : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool hit = kk[u] == (int64_t)cur;
+                    const unsigned long long mask = __ballot(hit);
+                    if (hit) q[nq + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint32_t)(base + i + 64 * u + lane);
+                    nq += (uint32_t)__builtin_popcountll(mask);
+                }
             }
             uint32_t e = 0;
             for (; e + 8 <= nq; e += 8) {
@@ -183,11 +189,32 @@ __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
         if (rows > P.region_stride) rows = P.region_stride;
         if (rows < 0) rows = 0;
     }
+    // Both passes read the same keys.  A thread's keys are loaded SA_KPT at a time, all loads in flight together (a pass would otherwise
+    // be a chain of L2 round trips: ~15 keys per thread at config 5), over the flattened (region, position) space; a list of at most
+    // SA_KPT * SA_NT entries -- the usual case -- stays in registers for the second pass.
+    const int64_t total = rows * P.n_regions;
+    const bool resident = total <= (int64_t)SA_KPT * SA_NT;
+    int64_t kreg[SA_KPT];
+    uint32_t preg[SA_KPT];
+    auto load_keys = [&](int64_t c0) {
+#pragma unroll
+        for (int u = 0; u < SA_KPT; ++u) {
+            const int64_t f = c0 + tid + (int64_t)u * SA_NT;
+            kreg[u] = -1; preg[u] = 0;
+            if (f < total) {
+                int64_t r = 0, i = f;
+                if (P.n_regions > 1) { r = (int64_t)((uint32_t)f / (uint32_t)rows); i = f - r * rows; }      // (total < 2^32)
+                preg[u] = (uint32_t)(r * P.region_stride + i);
+                kreg[u] = sa_key<KeyT>(P, (int64_t)preg[u]);
+            }
+        }
+    };
     // ---- pass A: the distinct keys this workgroup owns, with their number of contributions
-    for (int r = 0; r < P.n_regions; ++r) {
-        const int64_t base = (int64_t)r * P.region_stride;
-        for (int64_t i = tid; i < rows; i += SA_NT) {
-            const int64_t k = sa_key<KeyT>(P, base + i);
+    for (int64_t c0 = 0; c0 < total; c0 += (int64_t)SA_KPT * SA_NT) {
+        load_keys(c0);
+#pragma unroll
+        for (int u = 0; u < SA_KPT; ++u) {
+            const int64_t k = kreg[u];
             if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner((uint32_t)k) != me) continue;
             uint32_t h = sa_slot0((uint32_t)k);
             int tries = 0;
@@ -201,16 +228,17 @@ __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
     __syncthreads();
     // ---- pass B: the entries of the keys with few contributions go to the list (key, position)
     if (!s_over) {
-        for (int r = 0; r < P.n_regions; ++r) {
-            const int64_t base = (int64_t)r * P.region_stride;
-            for (int64_t i = tid; i < rows; i += SA_NT) {
-                const int64_t k = sa_key<KeyT>(P, base + i);
+        for (int64_t c0 = 0; c0 < total; c0 += (int64_t)SA_KPT * SA_NT) {
+            if (!resident) load_keys(c0);
+#pragma unroll
+            for (int u = 0; u < SA_KPT; ++u) {
+                const int64_t k = kreg[u];
                 if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner((uint32_t)k) != me) continue;
                 uint32_t h = sa_slot0((uint32_t)k);
                 while (s_hkey[h] != (uint32_t)k) h = (h + 1) & (SA_HT - 1);
                 if (s_hcnt[h] > SA_LONG) continue;
                 const uint32_t at = atomicAdd(&s_cnt, 1u);
-                if (at < SA_CAP) s_list[at] = ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)(uint32_t)(base + i);
+                if (at < SA_CAP) s_list[at] = ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)preg[u];
             }
         }
     }
@@ -255,14 +283,42 @@ __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
         if (e == 0 || (uint32_t)(s_sorted[e] >> 32) != (uint32_t)(s_sorted[e - 1] >> 32)) s_seg[atomicAdd(&s_nseg, 1u)] = e;
     __syncthreads();
     const uint32_t nseg = s_nseg;
-    for (uint32_t s = wave; s < nseg; s += SA_NW) {
-        const uint32_t start = s_seg[s];
-        const uint32_t key = (uint32_t)(s_sorted[start] >> 32);
-        const uint32_t e = start + lane;                     // (a listed run has at most SA_LONG <= 64 entries)
-        const bool same = e < cnt && (uint32_t)(s_sorted[e] >> 32) == key;
-        const uint32_t len = (uint32_t)__builtin_ctzll(~__ballot(same));
-        const SaRow<VPT> G = sa_sum<VPT>(P.g, s_sorted, (int)start, (int)(start + len), lane);
-        sa_adam<VPT>(P, (int64_t)key, lane, G);
+    // (four runs per wave at a time: their (W, m, v) rows -- cold HBM lines of a table far larger than the caches -- are requested before
+    //  the contribution rows are summed, so a wave pays one memory round trip per four rows instead of two per row)
+    for (uint32_t s0 = wave; s0 < nseg; s0 += 4 * SA_NW) {
+        uint32_t key[4], start[4], len[4];
+        SaRow<VPT> w[4], mm[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t s = s0 + u * SA_NW;
+            len[u] = 0; key[u] = 0; start[u] = 0;
+            if (s < nseg) {
+                start[u] = s_seg[s];
+                key[u] = (uint32_t)(s_sorted[start[u]] >> 32);
+                const uint32_t e = start[u] + lane;              // (a listed run has at most SA_LONG <= 64 entries)
+                const bool same = e < cnt && (uint32_t)(s_sorted[e] >> 32) == key[u];
+                len[u] = (uint32_t)__builtin_ctzll(~__ballot(same));
+                w[u] = sa_load<VPT>(P.W, (int64_t)key[u], lane);
+                mm[u] = sa_load<VPT>(P.m, (int64_t)key[u], lane);
+                vv[u] = sa_load<VPT>(P.v, (int64_t)key[u], lane);
+            }
+        }
+        const float ss = P.hyper ? P.hyper[0] : P.step_size, ib = P.hyper ? P.hyper[1] : P.inv_sqrt_bc2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (len[u] == 0) continue;
+            const SaRow<VPT> G = sa_sum<VPT>(P.g, s_sorted, (int)start[u], (int)(start[u] + len[u]), lane);
+#pragma unroll
+            for (int c = 0; c < VPT; ++c) {
+                const float gg = G.x[c] + P.wd * w[u].x[c];
+                mm[u].x[c] = P.b1 * mm[u].x[c] + P.omb1 * gg;
+                vv[u].x[c] = P.b2 * vv[u].x[c] + P.omb2 * gg * gg;
+                w[u].x[c] = w[u].x[c] - ss * (mm[u].x[c] / (sqrtf(vv[u].x[c]) * ib + P.eps));
+            }
+            sa_store<VPT>(P.W, (int64_t)key[u], lane, w[u]);
+            sa_store<VPT>(P.m, (int64_t)key[u], lane, mm[u]);
+            sa_store<VPT>(P.v, (int64_t)key[u], lane, vv[u]);
+        }
     }
     __syncthreads();
     // ---- keys with many contributions (a Zipf-head item): summed over the key list by the whole workgroup, one after the other
