@@ -18,8 +18,13 @@ from .evaluate import PredictionEvaluator, RankingEvaluator, ReduceLROnPlateau, 
 
 class Coach:
     def __init__(self, model, trainpipe, validpipe=None, testpipe=None, monitors=("LOSS", "HitRate@10", "NDCG@10"),
-                 which4best="NDCG@10", eval_freq=5, kind="seq", checkpoint_path=None, lr_scheduler=None):
-        """kind: "seq" (SASRec: data ISeq / IPos / INeg), "gen" (MF-BPR / LightGCN: User / IPos / INeg) or "pred" (DeepFM: a field matrix
+                 which4best="NDCG@10", eval_freq=5, kind="seq", checkpoint_path=None, lr_scheduler=None, optimizer=None,
+                 fit_keys=None, loss_fn=None, graph=False):
+        """kind: "seq" (SASRec: data ISeq / IPos / INeg), "gen" (MF-BPR / LightGCN: User / IPos / INeg), "module" (a torch.nn.Module on
+        the custom-op surface, recboard_amd.siblings: `model.fit(*[data[k] for k in fit_keys])` -> dict of losses, `loss_fn(losses)` -> the
+        scalar to differentiate (default: their sum; e.g. CoachForLightGCN's rec + weight_decay * emb, LightGCN/main.py:156-172),
+        `optimizer` a torch optimizer (capturable for graph=True: the step replayed as one hipGraph, nn.GraphedStep); evaluation through
+        `model.recommend_topk(data[fit_keys[0]], seen, K)`) or "pred" (DeepFM: a field matrix
         `X` [B, F] and `Label`; monitors LOGLOSS / AUC, DeepFM/configs/Frappe_x1_BARS.yaml:101-102).  lr_scheduler: e.g.
         `ReduceLROnPlateau(model, mode="max", patience=eval_freq, ...)`, stepped on the best monitored value at the top of every
         epoch as CoachForDeepFM does (DeepFM/main.py:251-257)."""
@@ -27,8 +32,13 @@ class Coach:
         self.monitors, self.which4best, self.eval_freq, self.kind = list(monitors), which4best, eval_freq, kind
         self.history, self.best = [], None
         self.checkpoint_path = checkpoint_path
-        self.device = model.device
+        self.device = model.device if hasattr(model, "device") else next(model.parameters()).device
         self.lr_scheduler = lr_scheduler
+        self.optimizer, self.fit_keys, self.graph = optimizer, tuple(fit_keys) if fit_keys else None, graph
+        self.loss_fn = loss_fn if loss_fn is not None else (lambda losses: sum(losses.values()))
+        self._graphed = {}
+        if kind == "module" and (optimizer is None or not self.fit_keys):
+            raise ValueError("Coach(kind='module') needs `optimizer` and `fit_keys`")
 
     def dict_to_device(self, data, keys=None):
         """Coach.dict_to_device: tensors to the model's device (asynchronously when the pipe hands out pinned memory); `keys` limits
@@ -77,8 +87,14 @@ class Coach:
             self.lr_scheduler.step(self.best[1] if self.best is not None else (-float("inf") if self.lr_scheduler.mode == "max" else float("inf")))
         tot = torch.zeros((), device=self.device)
         n = 0
-        need = {"seq": ("ISeq", "IPos", "INeg"), "pred": ("X", "Label")}.get(self.kind)
+        need = {"seq": ("ISeq", "IPos", "INeg"), "pred": ("X", "Label"), "module": self.fit_keys}.get(self.kind)
         for data in self._device_batches(self.trainpipe, need):
+            if self.kind == "module":
+                loss = self._module_step(tuple(data[k] for k in self.fit_keys))
+                bsz = len(data[self.fit_keys[0]])
+                tot.add_(loss.detach(), alpha=bsz)
+                n += bsz
+                continue
             if self.kind == "pred":                  # DeepFM/main.py:258-268: forward, backward, clip_grad_norm_(.., 10), step
                 loss = self.model.train_step(data["X"], data["Label"])
                 bsz = data["X"].shape[0]
@@ -101,6 +117,21 @@ class Coach:
             self.model.check_handover()     # (split long sequences: the halves' hand-over flags; the loss read below syncs anyway)
         return {"LOSS": float(tot / max(n, 1))}
 
+    def _module_step(self, inputs):
+        """One optimizer step of a torch.nn.Module model: eager, or (graph=True) the whole step replayed as one hipGraph per input shape."""
+        m = self.model
+        if not self.graph:
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = self.loss_fn(m.fit(*inputs))
+            loss.backward()
+            self.optimizer.step()
+            return loss
+        from .nn import GraphedStep
+        key = tuple((tuple(t.shape), t.dtype) for t in inputs)
+        if key not in self._graphed:
+            self._graphed[key] = GraphedStep(m, lambda *a: self.loss_fn(m.fit(*a)), self.optimizer, inputs)
+        return self._graphed[key](*inputs)
+
     def _graphable(self):
         m = self.model
         return hasattr(m, "train_step_graph") and getattr(m, "encoder", None) == "fused" and getattr(m, "loss_kind", "CE") != "CE"
@@ -116,6 +147,8 @@ class Coach:
             return m.arena.adam_state_dict(m.lr, m.betas, m.wd)
         if hasattr(m, "adam_state_dict"):
             return m.adam_state_dict()
+        if self.optimizer is not None:               # kind = "module": the torch optimizer's own state_dict
+            return self.optimizer.state_dict()
         return {}
 
     def save_checkpoint(self, path, epoch):
@@ -139,6 +172,8 @@ class Coach:
                 m.arena.load_adam_state_dict(opt)
             elif hasattr(m, "load_adam_state_dict"):
                 m.load_adam_state_dict(opt)
+            elif self.optimizer is not None:
+                self.optimizer.load_state_dict(opt)
         if self.lr_scheduler is not None and ck.get("lr_scheduler"):
             self.lr_scheduler.load_state_dict(ck["lr_scheduler"])
         self.best, self.history = ck["monitors"]["best"], ck["monitors"]["history"]
@@ -187,7 +222,9 @@ class Coach:
         for data in pipe:
             seen_ptr, seen_idx = ragged_to_csr(data["ISeen"], self.device)
             tgt_ptr, tgt_idx = ragged_to_csr(data["IUnseen"], self.device)
-            if self.kind == "seq":
+            if self.kind == "module":
+                _, idx = self.model.recommend_topk(data[self.fit_keys[0]].to(self.device), seen_ptr, seen_idx, ev.kmax)
+            elif self.kind == "seq":
                 _, idx = self.model.recommend_topk(data["ISeq"].to(self.device), seen_ptr, seen_idx, ev.kmax)
             else:
                 _, idx = self.model.recommend_topk(data["User"].to(self.device), seen_ptr, seen_idx, ev.kmax)

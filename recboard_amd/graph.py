@@ -17,7 +17,8 @@ def to_normalized_adj(num_users, num_items, edges_u, edges_i, normalization="sym
     order = np.lexsort((cols, rows))
     rows, cols = rows[order], cols[order]
     if normalization == "sym":
-        dinv = np.where(deg > 0, deg ** -0.5, 0.0)
+        dinv = np.zeros_like(deg)
+        dinv[deg > 0] = deg[deg > 0] ** -0.5
         val = dinv[rows] * dinv[cols]
     elif normalization == "left":
         val = np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0)[rows]

@@ -37,6 +37,26 @@ import torch.nn.functional as F
 from . import nn as rnn
 
 
+# ------------------------------------------------------------------------------------------------ evaluation contract
+class _BufferRanking:
+    """`recommend_topk` for the graph models: Coach.evaluate's scores -> seen mask -> top-K (UniSRec/main.py:408-414) as ONE fused
+    launch on the ranking buffers (`reset_ranking_buffers` first, as the reference's Coach does)."""
+
+    def recommend_topk(self, users, seen_ptr, seen_idx, K=50):
+        ue, ie = self.ranking_buffer
+        with torch.no_grad():
+            return torch.ops.recengine.score_topk(rnn.gather_rows(ue, users.reshape(-1)), ie, seen_ptr, seen_idx, K)
+
+
+class _EncodeRanking:
+    """`recommend_topk` for the sequence models whose `encode` returns (user states [B, D], item table [N, D])."""
+
+    def recommend_topk(self, seqs, seen_ptr, seen_idx, K=50):
+        with torch.no_grad():
+            user, items = self.encode(seqs)
+            return torch.ops.recengine.score_topk(user.contiguous(), items.contiguous(), seen_ptr, seen_idx, K)
+
+
 # ------------------------------------------------------------------------------------------------ DCN
 class CrossInteraction(torch.nn.Module):
     """x_{i+1} = (x_i w) * x_0 + b   (DCN/main.py:34-46)."""
@@ -107,7 +127,7 @@ class DCN(torch.nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ SimGCL
-class SimGCL(torch.nn.Module):
+class SimGCL(_BufferRanking, torch.nn.Module):
     """SimGCL (SimGCL/main.py:34-160): LightGCN-style propagation with the layer-wise mean, BPR + L2 regulariser, and an InfoNCE
     loss between two noise-perturbed propagation views.  adj = (crow, col, val): the symmetric normalised bipartite adjacency as CSR."""
 
@@ -168,7 +188,7 @@ class SimGCL(torch.nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ GRU4Rec
-class GRU4Rec(torch.nn.Module):
+class GRU4Rec(_EncodeRanking, torch.nn.Module):
     """GRU4Rec (GRU4Rec/main.py:30-190): item embeddings (row 0 = padding) -> dropout -> GRU -> dense -> the state at the last real
     position of the RIGHT-padded sequence -> pair / CE criterion against the item table."""
 
@@ -235,7 +255,7 @@ class NGCFConv(torch.nn.Module):
         return F.normalize(self.dropout(self.act(self.linear1(z + x)) + self.act(self.linear2(z * x))), dim=-1)
 
 
-class NGCF(torch.nn.Module):
+class NGCF(_BufferRanking, torch.nn.Module):
     """NGCF (NGCF/main.py:53-160).  adj = (crow, col, val): D^-1 (A + I) of the bipartite interaction graph as CSR."""
 
     def __init__(self, num_users, num_items, adj, embedding_dim=64, num_layers=3, dropout_rate=0.0, device="cuda"):
@@ -280,7 +300,7 @@ class NGCF(torch.nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ JGCF
-class JGCF(torch.nn.Module):
+class JGCF(_BufferRanking, torch.nn.Module):
     """JGCF (JGCF/main.py:39-160): z_0 = X, z_l from the Jacobi three-term recurrence on the symmetric normalised adjacency
     (JGCF/modules.py:8-49), low = mean_l(coef_l z_l) with coef = cumprod(tanh(gamma) * scaling) (modules.py:77-83; gamma is a frozen
     parameter), mid = weight4mid * X - low, tables = [low | mid]; BPR + L2 regulariser."""
@@ -415,7 +435,7 @@ def _lin3(layer, x):
 
 
 # ------------------------------------------------------------------------------------------------ GCN
-class GCN(torch.nn.Module):
+class GCN(_BufferRanking, torch.nn.Module):
     """GCN (GCN/main.py:27-135): x <- Linear_l(Adj x), ReLU after all but the last layer; BPR on the propagated tables."""
 
     def __init__(self, num_users, num_items, adj, embedding_dim=64, num_layers=3, device="cuda"):
@@ -454,7 +474,7 @@ class GCN(torch.nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ STAMP
-class STAMP(torch.nn.Module):
+class STAMP(_EncodeRanking, torch.nn.Module):
     """STAMP (STAMP/main.py:28-160): mean of the sequence's embeddings + the last click -> trilinear attention -> two tanh MLP branches,
     multiplied.  Sequences are LEFT-padded (the last column is the last click); ids + 1, 0 = padding."""
 
@@ -494,7 +514,7 @@ class STAMP(torch.nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ NARM
-class NARM(torch.nn.Module):
+class NARM(_EncodeRanking, torch.nn.Module):
     """NARM (NARM/main.py:30-180): GRU over the RIGHT-padded sequence; global = the state at the last real position, local = attention
     over the states (v_t(mask * sigmoid(a_1 h_s + a_2 h_t))); user = b [local | global]; BCE."""
 
@@ -573,7 +593,7 @@ class _FilterBlock(torch.nn.Module):
         return self.out_norm(self.dropout(_lin3(self.dense_2, z)) + h)
 
 
-class FMLPRec(torch.nn.Module):
+class FMLPRec(_EncodeRanking, torch.nn.Module):
     """FMLP-Rec (FMLP-Rec/main.py:38-180): item + position embeddings -> LayerNorm -> dropout -> filter-enhanced blocks -> the state at
     the last position of the LEFT-padded sequence -> BPR / BCE / CE against the item table."""
 

@@ -306,3 +306,91 @@ def test_last_item_siblings_match_reference_loss_gradients_and_scores(which):
     m.eval()
     with torch.no_grad():
         torch.testing.assert_close(m.recommend_from_full(seq), _t(g["out/scores"]), rtol=1e-4, atol=1e-5)
+
+
+def _toy_interactions(U, N, per_user, seed):
+    rng = np.random.default_rng(seed)
+    hist = [sorted(rng.choice(N, per_user, replace=False).tolist()) for _ in range(U)]
+    return hist
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_coach_runs_a_graph_sibling_end_to_end(graph):
+    """Coach(kind="module"): GCN on the custom-op surface trained by the Coach's epoch loop (eager and as one hipGraph per step), evaluated
+    through the fused score + seen-mask + top-K; the metrics equal the dense restatement (scores -> -1e23 at seen -> torch.topk)."""
+    from recboard_amd import graph as rgraph
+    from recboard_amd.coach import Coach
+    from recboard_amd.siblings import GCN
+    U, N, B = 60, 90, 32
+    hist = _toy_interactions(U, N, 7, 3)
+    train = [h[:-1] for h in hist]
+    target = [[h[-1]] for h in hist]
+    eu = np.concatenate([[u] * len(t) for u, t in enumerate(train)]); ei = np.concatenate(train)
+    crow, col, val = (torch.from_numpy(a) for a in rgraph.to_normalized_adj(U, N, eu, ei, "sym"))
+    torch.manual_seed(0)
+    m = GCN(U, N, (crow, col, val), embedding_dim=64, num_layers=2)
+    with torch.no_grad():
+        m.user.weight.normal_(std=0.1); m.item.weight.normal_(std=0.1)
+    rng = np.random.default_rng(5)
+    trainpipe = []
+    for _ in range(6):
+        users = rng.integers(0, U, B)
+        pos = np.array([rng.choice(train[u]) for u in users])
+        neg = rng.integers(0, N, B)
+        trainpipe.append({"User": torch.from_numpy(users), "IPos": torch.from_numpy(pos), "INeg": torch.from_numpy(neg)})
+    validpipe = [{"User": torch.arange(u0, min(U, u0 + 25)), "ISeen": train[u0:u0 + 25], "IUnseen": target[u0:u0 + 25]} for u0 in range(0, U, 25)]
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, capturable=graph)
+    coach = Coach(m, trainpipe, validpipe, monitors=("LOSS", "HitRate@10", "NDCG@10"), which4best="NDCG@10", eval_freq=1, kind="module",
+                  optimizer=opt, fit_keys=("User", "IPos", "INeg"), graph=graph)
+    out = coach.fit(3)
+    losses = [h["train"]["LOSS"] for h in out["history"]]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # dense restatement of the last evaluation
+    m.reset_ranking_buffers()
+    ue, ie = m.ranking_buffer
+    scores = (ue @ ie.t()).cpu().numpy()
+    hr = nd = 0.0
+    for u in range(U):
+        s = scores[u].copy(); s[train[u]] = -1e23
+        top = np.argsort(-s, kind="stable")[:10]
+        hit = np.nonzero(top == target[u][0])[0]
+        if hit.size:
+            hr += 1; nd += 1.0 / np.log2(hit[0] + 2)
+    got = out["history"][-1]["valid"]
+    assert abs(got["HITRATE@10"] - hr / U) < 1e-6 and abs(got["NDCG@10"] - nd / U) < 1e-5
+
+
+def test_coach_runs_a_sequence_sibling():
+    """Coach(kind="module") with STAMP: fit on (ISeq, IPos, INeg), evaluation on ISeq through `recommend_topk`."""
+    from recboard_amd.coach import Coach
+    from recboard_amd.siblings import STAMP
+    N, B, S = 80, 16, 12
+    rng = np.random.default_rng(1)
+    torch.manual_seed(1)
+    m = STAMP(N, 64, 64, loss="BPR")
+    with torch.no_grad():
+        m.item.weight.mul_(50.0); m.item.weight[0].zero_()
+
+    def seqs(n):
+        x = np.zeros((n, S), np.int64)
+        for b in range(n):
+            L = rng.integers(2, S)
+            x[b, S - L:] = rng.integers(1, N + 1, L)
+        return x
+    trainpipe = [{"ISeq": torch.from_numpy(seqs(B)), "IPos": torch.from_numpy(rng.integers(0, N, (B, 1))), "INeg": torch.from_numpy(rng.integers(0, N, (B, 1)))}
+                 for _ in range(4)]
+    ev = seqs(20)
+    validpipe = [{"ISeq": torch.from_numpy(ev), "ISeen": [sorted(set((r[r > 0] - 1).tolist())) for r in ev], "IUnseen": [[int(rng.integers(0, N))] for _ in ev]}]
+    coach = Coach(m, trainpipe, validpipe, monitors=("LOSS", "NDCG@10"), eval_freq=1, kind="module",
+                  optimizer=torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True), fit_keys=("ISeq", "IPos", "INeg"), graph=True)
+    out = coach.fit(2)
+    assert np.isfinite(out["history"][-1]["train"]["LOSS"]) and 0.0 <= out["history"][-1]["valid"]["NDCG@10"] <= 1.0
+    # the fused top-K of the evaluation = torch.topk on the masked dense scores
+    x = torch.from_numpy(ev).cuda()
+    sp, si = coach_csr = __import__("recboard_amd.evaluate", fromlist=["ragged_to_csr"]).ragged_to_csr(validpipe[0]["ISeen"], "cuda")
+    _, idx = m.recommend_topk(x, sp, si, 10)
+    with torch.no_grad():
+        dense = m.recommend_from_full(x).clone()
+    for b, seen in enumerate(validpipe[0]["ISeen"]):
+        dense[b, seen] = -1e23
+    assert torch.equal(idx, torch.topk(dense, 10, dim=1).indices)
