@@ -31,9 +31,12 @@ struct SaParams {
     float *W, *m, *v;
     float b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd;
     const float* hyper;
+    int64_t stride;   // floats per table / contribution row (D)
+    int coff;         // first column of the piece this workgroup owns (set in the kernel: 0, or 64 for the upper half at D = 128)
 };
 
-__device__ __forceinline__ uint32_t sa_owner(uint32_t k) { return (k * 0x9E3779B1u) >> 24; }   // 256 owners
+template <int HS>
+__device__ __forceinline__ uint32_t sa_owner(uint32_t k) { return (k * 0x9E3779B1u) >> (HS == 2 ? 25 : 24); }   // 256 owners, or 128 pairs
 
 template <int VPT>
 struct SaRow {
@@ -41,9 +44,9 @@ struct SaRow {
 };
 
 template <int VPT>
-__device__ __forceinline__ SaRow<VPT> sa_load(const float* __restrict__ base, int64_t row, int lane) {
+__device__ __forceinline__ SaRow<VPT> sa_load(const float* __restrict__ base, int64_t row, int lane, int64_t stride, int coff) {
     SaRow<VPT> r;
-    const float* p = base + row * (64 * VPT) + lane * VPT;
+    const float* p = base + row * stride + coff + lane * VPT;
     if (VPT == 2) {
         const float2 t = *reinterpret_cast<const float2*>(p);
         r.x[0] = t.x; r.x[VPT - 1] = t.y;
@@ -54,43 +57,48 @@ __device__ __forceinline__ SaRow<VPT> sa_load(const float* __restrict__ base, in
 }
 
 template <int VPT>
-__device__ __forceinline__ void sa_store(float* __restrict__ base, int64_t row, int lane, const SaRow<VPT>& r) {
-    float* p = base + row * (64 * VPT) + lane * VPT;
+__device__ __forceinline__ void sa_store(float* __restrict__ base, int64_t row, int lane, const SaRow<VPT>& r, int64_t stride, int coff) {
+    float* p = base + row * stride + coff + lane * VPT;
     if (VPT == 2) *reinterpret_cast<float2*>(p) = make_float2(r.x[0], r.x[VPT - 1]);
     else p[0] = r.x[0];
 }
 
+// One element of the update with the operation sequence PINNED (explicit fused / rounded operations): the kernel has several copies of
+// this arithmetic (unrolled row batches, the whole-workgroup path) and which copy a row meets depends on scheduling -- left to the
+// compiler's contraction and packed-math choices the copies differed in the last bit.
+__device__ __forceinline__ void sa_adam_one(const SaParams& P, float ss, float ib, float g, float& w, float& mm, float& vv) {
+    const float gg = __fmaf_rn(P.wd, w, g);
+    mm = __fmaf_rn(P.b1, mm, __fmul_rn(P.omb1, gg));
+    vv = __fmaf_rn(P.b2, vv, __fmul_rn(__fmul_rn(P.omb2, gg), gg));
+    w = __fsub_rn(w, __fmul_rn(ss, __fdiv_rn(mm, __fmaf_rn(__fsqrt_rn(vv), ib, P.eps))));
+}
+
 template <int VPT>
 __device__ __forceinline__ void sa_adam(const SaParams& P, int64_t row, int lane, const SaRow<VPT>& G) {
-    SaRow<VPT> w = sa_load<VPT>(P.W, row, lane), mm = sa_load<VPT>(P.m, row, lane), vv = sa_load<VPT>(P.v, row, lane);
+    SaRow<VPT> w = sa_load<VPT>(P.W, row, lane, P.stride, P.coff), mm = sa_load<VPT>(P.m, row, lane, P.stride, P.coff), vv = sa_load<VPT>(P.v, row, lane, P.stride, P.coff);
     const float ss = P.hyper ? P.hyper[0] : P.step_size, ib = P.hyper ? P.hyper[1] : P.inv_sqrt_bc2;
 #pragma unroll
-    for (int c = 0; c < VPT; ++c) {
-        const float gg = G.x[c] + P.wd * w.x[c];
-        mm.x[c] = P.b1 * mm.x[c] + P.omb1 * gg;
-        vv.x[c] = P.b2 * vv.x[c] + P.omb2 * gg * gg;
-        w.x[c] = w.x[c] - ss * (mm.x[c] / (sqrtf(vv.x[c]) * ib + P.eps));
-    }
-    sa_store<VPT>(P.W, row, lane, w);
-    sa_store<VPT>(P.m, row, lane, mm);
-    sa_store<VPT>(P.v, row, lane, vv);
+    for (int c = 0; c < VPT; ++c) sa_adam_one(P, ss, ib, G.x[c], w.x[c], mm.x[c], vv.x[c]);
+    sa_store<VPT>(P.W, row, lane, w, P.stride, P.coff);
+    sa_store<VPT>(P.m, row, lane, mm, P.stride, P.coff);
+    sa_store<VPT>(P.v, row, lane, vv, P.stride, P.coff);
 }
 
 // sum of the contribution rows at positions list[e] (low words), e in [e0, e1), in that order; four loads in flight
 template <int VPT>
-__device__ __forceinline__ SaRow<VPT> sa_sum(const float* __restrict__ g, const unsigned long long* list, int e0, int e1, int lane) {
+__device__ __forceinline__ SaRow<VPT> sa_sum(const float* __restrict__ g, const unsigned long long* list, int e0, int e1, int lane, int64_t stride, int coff) {
     SaRow<VPT> acc;
 #pragma unroll
     for (int c = 0; c < VPT; ++c) acc.x[c] = 0.f;
     int e = e0;
     for (; e + 4 <= e1; e += 4) {
-        const SaRow<VPT> a = sa_load<VPT>(g, (int64_t)(uint32_t)list[e], lane), b = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 1], lane),
-                         c2 = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 2], lane), d = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 3], lane);
+        const SaRow<VPT> a = sa_load<VPT>(g, (int64_t)(uint32_t)list[e], lane, stride, coff), b = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 1], lane, stride, coff),
+                         c2 = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 2], lane, stride, coff), d = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 3], lane, stride, coff);
 #pragma unroll
-        for (int c = 0; c < VPT; ++c) acc.x[c] = (((acc.x[c] + a.x[c]) + b.x[c]) + c2.x[c]) + d.x[c];
+        for (int c = 0; c < VPT; ++c) acc.x[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.x[c], a.x[c]), b.x[c]), c2.x[c]), d.x[c]);
     }
     for (; e < e1; ++e) {
-        const SaRow<VPT> a = sa_load<VPT>(g, (int64_t)(uint32_t)list[e], lane);
+        const SaRow<VPT> a = sa_load<VPT>(g, (int64_t)(uint32_t)list[e], lane, stride, coff);
 #pragma unroll
         for (int c = 0; c < VPT; ++c) acc.x[c] += a.x[c];
     }
@@ -140,14 +148,14 @@ __device__ __forceinline__ void sa_heavy(const SaParams& P, uint32_t cur, int64_
             for (; e + 8 <= nq; e += 8) {
                 SaRow<VPT> t[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = sa_load<VPT>(P.g, (int64_t)q[e + u], lane);
+                for (int u = 0; u < 8; ++u) t[u] = sa_load<VPT>(P.g, (int64_t)q[e + u], lane, P.stride, P.coff);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
                     for (int c = 0; c < VPT; ++c) acc.x[c] += t[u].x[c];
             }
             for (; e < nq; ++e) {
-                const SaRow<VPT> t = sa_load<VPT>(P.g, (int64_t)q[e], lane);
+                const SaRow<VPT> t = sa_load<VPT>(P.g, (int64_t)q[e], lane, P.stride, P.coff);
 #pragma unroll
                 for (int c = 0; c < VPT; ++c) acc.x[c] += t.x[c];
             }
@@ -168,7 +176,9 @@ __device__ __forceinline__ void sa_heavy(const SaParams& P, uint32_t cur, int64_
     __syncthreads();
 }
 
-template <int VPT, class KeyT>
+// HS = 2 (D = 128): a row is owned in two pieces of 64 columns by two DIFFERENT workgroups (the update is column-wise independent), so a
+// Zipf-head row's contributions are pulled through two compute units' memory pipes; every key is then listed by two workgroups.
+template <int VPT, int HS, class KeyT>
 __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
     __shared__ unsigned long long s_lists[2 * SA_CAP];                  // collected entries | ordered entries; the heavy phase's position queues
     unsigned long long* const s_list = s_lists;
@@ -178,7 +188,8 @@ __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
     __shared__ float s_part[SA_NW][64 * VPT];
     __shared__ uint32_t s_cnt, s_nseg, s_over, s_min, s_nheavy;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t me = blockIdx.x;
+    const uint32_t me = HS == 2 ? blockIdx.x >> 1 : blockIdx.x;      // the owner id keys are matched against
+    P.coff = HS == 2 ? (int)(blockIdx.x & 1) * 64 : 0;
     if (tid == 0) { s_cnt = 0; s_nseg = 0; s_over = 0; s_nheavy = 0; }
     s_hkey[tid] = SA_EMPTY;                               // (SA_HT == SA_NT)
     s_hcnt[tid] = 0;
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
 #pragma unroll
         for (int u = 0; u < SA_KPT; ++u) {
             const int64_t k = kreg[u];
-            if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner((uint32_t)k) != me) continue;
+            if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner<HS>((uint32_t)k) != me) continue;
             uint32_t h = sa_slot0((uint32_t)k);
             int tries = 0;
             for (; tries < SA_HT; ++tries, h = (h + 1) & (SA_HT - 1)) {
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
 #pragma unroll
             for (int u = 0; u < SA_KPT; ++u) {
                 const int64_t k = kreg[u];
-                if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner((uint32_t)k) != me) continue;
+                if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner<HS>((uint32_t)k) != me) continue;
                 uint32_t h = sa_slot0((uint32_t)k);
                 while (s_hkey[h] != (uint32_t)k) h = (h + 1) & (SA_HT - 1);
                 if (s_hcnt[h] > SA_LONG) continue;
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
                 const int64_t base = (int64_t)r * P.region_stride;
                 for (int64_t i = tid; i < rows; i += SA_NT) {
                     const int64_t k = sa_key<KeyT>(P, base + i);
-                    if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner((uint32_t)k) != me || k <= lo) continue;
+                    if (k < 0 || k >= P.R || k == P.padding_idx || sa_owner<HS>((uint32_t)k) != me || k <= lo) continue;
                     if ((uint32_t)k < mine) mine = (uint32_t)k;
                 }
             }
@@ -298,26 +309,21 @@ __global__ __launch_bounds__(SA_NT) void sparse_adam_owner_k(SaParams P) {
                 const uint32_t e = start[u] + lane;              // (a listed run has at most SA_LONG <= 64 entries)
                 const bool same = e < cnt && (uint32_t)(s_sorted[e] >> 32) == key[u];
                 len[u] = (uint32_t)__builtin_ctzll(~__ballot(same));
-                w[u] = sa_load<VPT>(P.W, (int64_t)key[u], lane);
-                mm[u] = sa_load<VPT>(P.m, (int64_t)key[u], lane);
-                vv[u] = sa_load<VPT>(P.v, (int64_t)key[u], lane);
+                w[u] = sa_load<VPT>(P.W, (int64_t)key[u], lane, P.stride, P.coff);
+                mm[u] = sa_load<VPT>(P.m, (int64_t)key[u], lane, P.stride, P.coff);
+                vv[u] = sa_load<VPT>(P.v, (int64_t)key[u], lane, P.stride, P.coff);
             }
         }
         const float ss = P.hyper ? P.hyper[0] : P.step_size, ib = P.hyper ? P.hyper[1] : P.inv_sqrt_bc2;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (len[u] == 0) continue;
-            const SaRow<VPT> G = sa_sum<VPT>(P.g, s_sorted, (int)start[u], (int)(start[u] + len[u]), lane);
+            const SaRow<VPT> G = sa_sum<VPT>(P.g, s_sorted, (int)start[u], (int)(start[u] + len[u]), lane, P.stride, P.coff);
 #pragma unroll
-            for (int c = 0; c < VPT; ++c) {
-                const float gg = G.x[c] + P.wd * w[u].x[c];
-                mm[u].x[c] = P.b1 * mm[u].x[c] + P.omb1 * gg;
-                vv[u].x[c] = P.b2 * vv[u].x[c] + P.omb2 * gg * gg;
-                w[u].x[c] = w[u].x[c] - ss * (mm[u].x[c] / (sqrtf(vv[u].x[c]) * ib + P.eps));
-            }
-            sa_store<VPT>(P.W, (int64_t)key[u], lane, w[u]);
-            sa_store<VPT>(P.m, (int64_t)key[u], lane, mm[u]);
-            sa_store<VPT>(P.v, (int64_t)key[u], lane, vv[u]);
+            for (int c = 0; c < VPT; ++c) sa_adam_one(P, ss, ib, G.x[c], w[u].x[c], mm[u].x[c], vv[u].x[c]);
+            sa_store<VPT>(P.W, (int64_t)key[u], lane, w[u], P.stride, P.coff);
+            sa_store<VPT>(P.m, (int64_t)key[u], lane, mm[u], P.stride, P.coff);
+            sa_store<VPT>(P.v, (int64_t)key[u], lane, vv[u], P.stride, P.coff);
         }
     }
     __syncthreads();
@@ -354,12 +360,13 @@ extern "C" int re_sparse_adam_rows_small(const float* g, const void* keys, int32
         P.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
     }
     hipStream_t s = (hipStream_t)stream;
+    P.stride = D; P.coff = 0;
     if (D == 64) {
-        if (key_bytes == 4) hipLaunchKernelGGL((sparse_adam_owner_k<1, int32_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
-        else hipLaunchKernelGGL((sparse_adam_owner_k<1, int64_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
-    } else {
-        if (key_bytes == 4) hipLaunchKernelGGL((sparse_adam_owner_k<2, int32_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
-        else hipLaunchKernelGGL((sparse_adam_owner_k<2, int64_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
+        if (key_bytes == 4) hipLaunchKernelGGL((sparse_adam_owner_k<1, 1, int32_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
+        else hipLaunchKernelGGL((sparse_adam_owner_k<1, 1, int64_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
+    } else {   // two 64-column pieces per row
+        if (key_bytes == 4) hipLaunchKernelGGL((sparse_adam_owner_k<1, 2, int32_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
+        else hipLaunchKernelGGL((sparse_adam_owner_k<1, 2, int64_t>), dim3(SA_NWG), dim3(SA_NT), 0, s, P);
     }
     return re_launch_status();
 }
