@@ -14,6 +14,10 @@ DeepFM additionally have hand-fused engines (sasrec.py, gen.py, deepfm.py).
   GRU4Rec (GRU4Rec/main.py:30-190) item lookup = recengine::gather_rows (padding row without gradient; scatter-add gradient), the dense
                                    projection = recengine::gemm, the pair criteria = recengine::bpr_triplet (BPR: gathers + dots +
                                    softplus fused) or gathers + row dots (BCE), CE and full ranking over the catalog = score_dense
+  SGL     (SGL/main.py:30-215)     LightGCN-style propagation on the full graph and on two sampled subgraphs (node / edge dropout, random walk):
+                                   a subgraph keeps the full graph's CSR pattern and only re-weights its entries (dropped edge = 0, degrees
+                                   from the kept weights), so every propagation is recengine::spmm_csr on the cached plan; BPR =
+                                   recengine::bpr_triplet, the two B x B InfoNCE logit matrices = recengine::score_dense
   JGCF    (JGCF/main.py:39-160, modules.py:8-83) the Jacobi-polynomial recurrence = one recengine::spmm_csr per order (symmetric adjacency),
                                    BPR over the [low-pass | mid-pass] tables = recengine::bpr_triplet, full ranking = recengine::gemm
   GCN     (GCN/main.py:27-135)     per layer recengine::spmm_csr then the layer's Linear = recengine::gemm (ReLU between layers), BPR =
@@ -297,6 +301,102 @@ class NGCF(_BufferRanking, torch.nn.Module):
     def recommend_from_full(self, users):
         ue, ie = self.ranking_buffer
         return rnn.linear(rnn.gather_rows(ue, users.reshape(-1)), ie)
+
+
+# ------------------------------------------------------------------------------------------------ SGL
+class SGL(_BufferRanking, torch.nn.Module):
+    """SGL (SGL/main.py:30-215).  edges = (users [E], items [E]): the training interactions.  The undirected bipartite graph's CSR
+    pattern is built once; `resample()` (the reference's Coach calls it at the top of every epoch, SGL/main.py:245-246) draws the two
+    subgraphs' edge weights and re-normalises D^-1/2 A_w D^-1/2 on that pattern."""
+
+    def __init__(self, num_users, num_items, edges, embedding_dim=64, num_layers=3, aug_type="ed", ssl_drop_rate=0.1, temperature=0.2,
+                 device="cuda"):
+        super().__init__()
+        assert aug_type in ("nd", "ed", "rw")
+        self.U, self.N, self.num_layers, self.aug_type, self.rate, self.temperature = num_users, num_items, num_layers, aug_type, ssl_drop_rate, temperature
+        self.user = rnn.Embedding(num_users, embedding_dim, device=device)
+        self.item = rnn.Embedding(num_items, embedding_dim, device=device)
+        with torch.no_grad():
+            torch.nn.init.xavier_uniform_(self.user.weight)
+            torch.nn.init.xavier_uniform_(self.item.weight)
+        eu, ei = (torch.as_tensor(t, dtype=torch.int64).reshape(-1) for t in edges)
+        E, n = eu.numel(), num_users + num_items
+        rows = torch.cat((eu, ei + num_users)); cols = torch.cat((ei + num_users, eu))
+        eid = torch.cat((torch.arange(E), torch.arange(E)))                  # CSR entry -> the interaction it comes from
+        order = torch.argsort(rows * n + cols)
+        crow = torch.zeros(n + 1, dtype=torch.int64)
+        crow[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+        for name, t in (("crow", crow), ("col", cols[order].contiguous()), ("row", rows[order].contiguous()), ("eid", eid[order].contiguous()),
+                        ("edge_u", eu), ("edge_i", ei)):
+            self.register_buffer(name, t.to(device))
+        self.register_buffer("val", self._normalised(torch.ones(E, device=device)))
+        self.sub = self.sub_ = None
+        self.ranking_buffer = None
+
+    def _normalised(self, edge_weight):
+        """Per-interaction weights [E] -> the CSR values of D^-1/2 A_w D^-1/2 (a node left without edges keeps zero entries)."""
+        w = edge_weight[self.eid]
+        deg = torch.zeros(self.U + self.N, device=w.device).index_add_(0, self.row, w)
+        dinv = torch.where(deg > 0, deg.rsqrt(), torch.zeros_like(deg))
+        return (w * dinv[self.row] * dinv[self.col]).contiguous()
+
+    def sample_subgraph(self, rnd=None):
+        """SGL.sample_subgraph (SGL/main.py:87-111); rnd: the uniform draws to use instead of torch.rand (tests) -- a [E] tensor for
+        "ed" / "rw", a ([U], [N]) pair for "nd"."""
+        dev = self.val.device
+        if self.aug_type == "nd":
+            ru, ri = rnd if rnd is not None else (torch.rand(self.U, device=dev), torch.rand(self.N, device=dev))
+            w = (ru > self.rate).float()[self.edge_u] * (ri > self.rate).float()[self.edge_i]
+        else:
+            r = rnd if rnd is not None else torch.rand(self.edge_u.numel(), device=dev)
+            w = (r > self.rate).float()
+        return self._normalised(w)
+
+    def resample(self, rnds=None):
+        """Two views; "nd" / "ed": one subgraph per view shared by all layers, "rw": one per layer (SGL/main.py:113-121)."""
+        k = 1 if self.aug_type in ("nd", "ed") else self.num_layers
+        it = iter(rnds) if rnds is not None else None
+        nxt = (lambda: next(it)) if it is not None else (lambda: None)
+        a = [self.sample_subgraph(nxt()) for _ in range(k)]
+        b = [self.sample_subgraph(nxt()) for _ in range(k)]
+        self.sub, self.sub_ = a * (self.num_layers // k), b * (self.num_layers // k)
+
+    def _propagate(self, vals):
+        x = torch.cat((self.user.weight, self.item.weight), dim=0)
+        avg = x / (self.num_layers + 1)
+        for l in range(self.num_layers):
+            x = rnn.spmm_sym(self.crow, self.col, vals[l], x.contiguous())
+            avg = avg + x / (self.num_layers + 1)
+        return torch.split(avg, (self.U, self.N))
+
+    def encode(self):
+        return self._propagate([self.val] * self.num_layers)
+
+    def fit(self, users, positives, negatives):
+        users, positives, negatives = users.reshape(-1), positives.reshape(-1), negatives.reshape(-1)
+        if self.sub is None:
+            self.resample()
+        ue, ie = self.encode()
+        rec_loss = rnn.bpr_triplet(ue.contiguous(), ie.contiguous(), users, positives, negatives)
+        raw = (self.user(users), self.item(positives), self.item(negatives))
+        emb_loss = sum(t.pow(2).sum() for t in raw) / 2 / users.numel()
+        (u1, i1), (u2, i2) = self._propagate(self.sub), self._propagate(self.sub_)
+        targets = torch.arange(users.numel(), device=users.device)
+        ssl = 0.0
+        for a, b, idx in ((u1, u2, users), (i1, i2, positives)):
+            a, b = F.normalize(a, dim=-1), F.normalize(b, dim=-1)
+            logits = rnn.score_full(rnn.gather_rows(a.contiguous(), idx), rnn.gather_rows(b.contiguous(), idx)) / self.temperature
+            ssl = ssl + F.cross_entropy(logits, targets)
+        return {"rec_loss": rec_loss, "emb_loss": emb_loss, "ssl_loss": ssl}
+
+    def reset_ranking_buffers(self):
+        with torch.no_grad():
+            ue, ie = self.encode()
+            self.ranking_buffer = (ue.contiguous(), ie.contiguous())
+
+    def recommend_from_full(self, users):
+        ue, ie = self.ranking_buffer
+        return rnn.score_full(rnn.gather_rows(ue, users.reshape(-1)), ie)
 
 
 # ------------------------------------------------------------------------------------------------ JGCF

@@ -123,13 +123,18 @@ def build(argv_defaults=None):
             """The training interactions as an undirected bipartite graph: edge_index [2, 2E] (NGCF/main.py:76)."""
             return types.SimpleNamespace(edge_index=self.ds.edge_index)
 
+        def to_bigraph(self, edge_type="u2i"):
+            """The training interactions as user -> item edges: {"u2i": edge_index [2, E]} with item ids 0-based (SGL/main.py:55-58)."""
+            return {edge_type: types.SimpleNamespace(edge_index=self.ds.u2i)}
+
     class RecDataSet:
         """Toy dataset: carries fields (+ a prebuilt normalised adjacency for LightGCN)."""
 
-        def __init__(self, fields, adj=None, edge_index=None):
+        def __init__(self, fields, adj=None, edge_index=None, u2i=None):
             self.fields = FieldModuleList(fields)
             self.adj = adj
             self.edge_index = edge_index
+            self.u2i = u2i
 
         def train(self):
             return _Split(self)
@@ -155,15 +160,22 @@ def build(argv_defaults=None):
             w = w / deg[edge_index[0]]
         elif normalization == "right":
             w = w / deg[edge_index[1]]
-        else:
-            w = w / (deg[edge_index[0]].sqrt() * deg[edge_index[1]].sqrt())
+        else:                              # (a node whose edges all carry weight 0 -- SGL's dropped edges -- has degree 0: its entries stay 0)
+            dinv = torch.where(deg > 0, deg.rsqrt(), torch.zeros_like(deg))
+            w = w * dinv[edge_index[0]] * dinv[edge_index[1]]
         return edge_index, w
+
+    def to_undirected(edge_index, edge_weight=None, num_nodes=None):
+        """Both directions of every edge, weights carried along (SGL/main.py:103-105)."""
+        ei = torch.cat((edge_index, edge_index.flip(0)), dim=1)
+        return ei, (None if edge_weight is None else torch.cat((edge_weight, edge_weight)))
 
     def to_adjacency(edge_index, edge_weight, num_nodes):
         return torch.sparse_coo_tensor(edge_index, edge_weight, (num_nodes, num_nodes)).coalesce().to_sparse_csr()
 
     graph_mod = types.ModuleType("freerec.graph")
     graph_mod.add_self_loops, graph_mod.to_normalized, graph_mod.to_adjacency = add_self_loops, to_normalized, to_adjacency
+    graph_mod.to_undirected = to_undirected
     fr.graph = graph_mod
 
     # ---------------- models ----------------

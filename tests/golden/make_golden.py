@@ -17,6 +17,7 @@ Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic
   deepfm.npz   : DeepFM/main.py   logits, loss, grads (train-mode BN), eval sigmoid scores
   dcn.npz      : DCN/main.py      logits, loss, grads (train-mode BN), eval sigmoid scores
   gru4rec_{bce,bpr}.npz : GRU4Rec/main.py fit loss + every gradient + full scores (dropouts 0)
+  sgl.npz      : SGL/main.py      fit (rec_loss, emb_loss, ssl_loss) on two edge-dropout subgraphs (the uniform draws recorded) + grads + scores
   jgcf.npz     : JGCF/main.py     fit (rec_loss, emb_loss) + table gradients + [low | mid] tables + full scores
   gcn.npz      : GCN/main.py      fit rec_loss + every gradient + propagated tables + full scores
   stamp_{bce,ce}.npz, narm.npz, fmlprec_bpr.npz : STAMP / NARM / FMLP-Rec main.py  fit loss + every gradient + full scores (dropouts 0)
@@ -437,6 +438,53 @@ def gen_gru4rec(loss):
     print(f"gru4rec {loss}: loss={float(losses['rec_loss'].detach()):.6f}")
 
 
+def gen_sgl():
+    torch.manual_seed(1)
+    U, N, B, rate = 30, 40, 16, 0.3
+    g = torch.Generator().manual_seed(19)
+    edges = set()
+    while len(edges) < 150:
+        edges.add((int(torch.randint(0, U, (1,), generator=g)), int(torch.randint(0, N, (1,), generator=g))))
+    edges = sorted(edges)
+    adj = sym_norm_adj(U, N, edges)
+    u2i = torch.tensor(edges, dtype=torch.long).t().contiguous()            # [2, E]: (user, item)
+    fr, ref = import_ref("SGL", "ref_sgl", dict(aug_type="ed", ssl_drop_rate=rate))
+    F = fr.data.fields.Field
+    ds = fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)], adj=adj, u2i=u2i)
+    model = ref.SGL(ds)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(0.3 * torch.randn(p.shape, generator=g))
+    users = torch.randint(0, U, (B, 1), generator=g)
+    ipos = torch.randint(0, N, (B, 1), generator=g)
+    ineg = torch.randint(0, N, (B, 1), generator=g)
+    E = u2i.shape[1]
+    torch.manual_seed(5)
+    r1, r2 = torch.rand(E), torch.rand(E)                                   # what resample() will draw (SGL/main.py:98-100, 113-118)
+    torch.manual_seed(5)
+    model.resample()
+    data = {model.User: users, model.IPos: ipos, model.INeg: ineg}
+    out = {"in/users": users.numpy(), "in/pos": ipos.numpy(), "in/neg": ineg.numpy(), "in/edges": u2i.numpy(), "in/rnd1": r1.numpy(), "in/rnd2": r2.numpy(),
+           "cfg/num_layers": np.int64(ref.cfg.num_layers), "cfg/temperature": np.float64(ref.cfg.temperature), "cfg/ssl_drop_rate": np.float64(rate),
+           "out/sub_adj_dense": model.sAdjs[0].to_dense().numpy()}
+    out.update({"param/User.embeddings.weight": model.User.embeddings.weight.detach().numpy().copy(),
+                "param/Item.embeddings.weight": model.Item.embeddings.weight.detach().numpy().copy()})
+    model.train()
+    losses = model(data)
+    (losses["rec_loss"] + losses["emb_loss"] + losses["ssl_loss"]).backward()
+    for k in ("rec_loss", "emb_loss", "ssl_loss"):
+        out["out/" + k] = losses[k].detach().numpy()
+    out.update(grads_np(model))
+    model.eval()
+    with torch.no_grad():
+        ue, ie = model.encode()
+        model.reset_ranking_buffers()
+        scores = model(data, ranking="full")
+    out["out/userEmbds"], out["out/itemEmbds"], out["out/scores"] = ue.numpy(), ie.numpy(), scores.numpy()
+    np.savez_compressed(os.path.join(HERE, "sgl.npz"), **out)
+    print("sgl: " + " ".join(f"{k}={float(v.detach()):.6f}" for k, v in losses.items()))
+
+
 def gen_jgcf():
     torch.manual_seed(1)
     U, N, B = 30, 40, 16
@@ -623,6 +671,7 @@ if __name__ == "__main__":
     gen_ngcf()
     for loss in ("BCE", "BPR"):
         gen_gru4rec(loss)
+    gen_sgl()
     gen_jgcf()
     gen_gcn()
     gen_last_item_model("STAMP", "STAMP", "stamp_bce", dict(loss="BCE", embedding_dim=64, hidden_size=64), True, emb_scale=200.0)

@@ -394,3 +394,39 @@ def test_coach_runs_a_sequence_sibling():
     for b, seen in enumerate(validpipe[0]["ISeen"]):
         dense[b, seen] = -1e23
     assert torch.equal(idx, torch.topk(dense, 10, dim=1).indices)
+
+
+def test_sgl_matches_reference_on_recorded_edge_dropout():
+    """SGL: the two sampled subgraphs are re-weightings of the full graph's CSR pattern; the reference run's uniform draws are replayed."""
+    from recboard_amd.siblings import SGL
+    g = np.load(os.path.join(GOLD, "sgl.npz"))
+    U, N = g["param/User.embeddings.weight"].shape[0], g["param/Item.embeddings.weight"].shape[0]
+    m = SGL(U, N, (g["in/edges"][0], g["in/edges"][1]), embedding_dim=g["param/User.embeddings.weight"].shape[1], num_layers=int(g["cfg/num_layers"]),
+            aug_type="ed", ssl_drop_rate=float(g["cfg/ssl_drop_rate"]), temperature=float(g["cfg/temperature"]))
+    with torch.no_grad():
+        m.user.weight.copy_(_t(g["param/User.embeddings.weight"])); m.item.weight.copy_(_t(g["param/Item.embeddings.weight"]))
+    m.resample(rnds=(_t(g["in/rnd1"]), _t(g["in/rnd2"])))
+    # the first view's adjacency is the reference's sampled one
+    sub = torch.sparse_csr_tensor(m.crow, m.col, m.sub[0], size=(U + N, U + N)).to_dense()
+    torch.testing.assert_close(sub, _t(g["out/sub_adj_dense"]), rtol=1e-5, atol=1e-7)
+    assert float((m.sub[0] == 0).float().mean()) > 0.1          # (edges were dropped)
+    users, pos, neg = (_t(g["in/" + k]).reshape(-1) for k in ("users", "pos", "neg"))
+    m.train()
+    losses = m.fit(users, pos, neg)
+    for k in ("rec_loss", "emb_loss", "ssl_loss"):
+        assert abs(float(losses[k].detach()) - float(g["out/" + k])) <= 2e-5 * abs(float(g["out/" + k])), k
+    (losses["rec_loss"] + losses["emb_loss"] + losses["ssl_loss"]).backward()
+    torch.testing.assert_close(m.user.weight.grad, _t(g["grad/User.embeddings.weight"]), rtol=3e-4, atol=2e-6)
+    torch.testing.assert_close(m.item.weight.grad, _t(g["grad/Item.embeddings.weight"]), rtol=3e-4, atol=2e-6)
+    m.eval()
+    with torch.no_grad():
+        ue, ie = m.encode()
+        torch.testing.assert_close(ue, _t(g["out/userEmbds"]), rtol=1e-5, atol=1e-6)
+        m.reset_ranking_buffers()
+        torch.testing.assert_close(m.recommend_from_full(users), _t(g["out/scores"]), rtol=1e-5, atol=1e-6)
+    # node dropout and random walk draw their own subgraphs
+    for aug in ("nd", "rw"):
+        m2 = SGL(U, N, (g["in/edges"][0], g["in/edges"][1]), embedding_dim=64, num_layers=2, aug_type=aug, ssl_drop_rate=0.2)
+        out = m2.fit(users, pos, neg)
+        assert all(torch.isfinite(v) for v in out.values())
+        assert (m2.sub[0] is m2.sub[1]) == (aug == "nd")
