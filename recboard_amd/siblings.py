@@ -28,6 +28,9 @@ DeepFM additionally have hand-fused engines (sasrec.py, gen.py, deepfm.py).
                                    = recengine::gather_rows, BCE on gathered rows; the GRU is torch.nn.GRU (MIOpen)
   FMLP-Rec (FMLP-Rec/main.py:38-180, modules.py:27-120) item lookup = recengine::gather_rows, dense_1 / dense_2 of every block = recengine::gemm,
                                    criteria / ranking as GRU4Rec; the frequency-domain filter is torch.fft (rocFFT)
+  BSARec  (BSARec/main.py:38-200, modules.py:28-200) item lookup = recengine::gather_rows; query / key / value / dense of the attention branch and
+                                   dense_1 / dense_2 of the feed-forward = recengine::gemm; criteria / ranking as GRU4Rec; the low-pass branch is
+                                   torch.fft (rocFFT), the S x S attention of a 50-item sequence stays with aten
   BERT4Rec (BERT4Rec/main.py:33-195) item lookup = recengine::gather_rows (padding row without gradient), the encoder states at the MASKED
                                    positions = recengine::gather_rows, the projection to the N + 2 logits (`fc`) = recengine::gemm on those
                                    rows only (the reference projects all B*S rows and then selects), full ranking = recengine::gemm on the
@@ -720,6 +723,116 @@ class FMLPRec(_EncodeRanking, torch.nn.Module):
         x = self.embdDropout(self.layerNorm(x))
         for blk in self.blocks:
             x = blk(x)
+        return x[:, -1, :].contiguous(), self.item.weight[1:]
+
+    def fit(self, seqs, positives, negatives):
+        user, items = self.encode(seqs)
+        return {"rec_loss": _last_item_loss(self.loss_kind, user, items, positives, negatives)}
+
+    def recommend_from_full(self, seqs):
+        user, items = self.encode(seqs)
+        return rnn.score_full(user.contiguous(), items.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ BSARec
+class _BSAFrequency(torch.nn.Module):
+    """FrequencyLayer (BSARec/modules.py:146-171): low-pass = the first c // 2 + 1 rfft bins, high-pass = the rest re-weighted by sqrt_beta^2."""
+
+    def __init__(self, D, c, dropout_rate, device):
+        super().__init__()
+        self.c = c // 2 + 1
+        self.sqrt_beta = torch.nn.Parameter(torch.randn(1, 1, D, device=device))
+        self.LayerNorm = _TFLayerNorm(D, device=device)
+        self.out_dropout = torch.nn.Dropout(dropout_rate)
+
+    def forward(self, x):
+        S = x.shape[1]
+        f = torch.fft.rfft(x, dim=1, norm="ortho")
+        f = torch.cat((f[:, :self.c], torch.zeros_like(f[:, self.c:])), dim=1)
+        low = torch.fft.irfft(f, n=S, dim=1, norm="ortho")
+        return self.LayerNorm(self.out_dropout(low + self.sqrt_beta ** 2 * (x - low)) + x)
+
+
+class _BSAAttention(torch.nn.Module):
+    """MultiHeadAttention (BSARec/modules.py:83-143): additive mask (0 / -1e4), softmax, residual nn.LayerNorm(eps = 1e-12)."""
+
+    def __init__(self, D, num_heads, attn_dropout_rate, hidden_dropout_rate, device):
+        super().__init__()
+        self.H, self.dh = num_heads, D // num_heads
+        self.query, self.key, self.value, self.dense = (rnn.Linear(D, D, device=device) for _ in range(4))
+        self.LayerNorm = torch.nn.LayerNorm(D, eps=1e-12, device=device)
+        self.attn_dropout, self.out_dropout = torch.nn.Dropout(attn_dropout_rate), torch.nn.Dropout(hidden_dropout_rate)
+
+    def forward(self, x, mask):
+        B, S, D = x.shape
+        q, k, v = (_lin3(m, x).view(B, S, self.H, self.dh).permute(0, 2, 1, 3) for m in (self.query, self.key, self.value))
+        p = self.attn_dropout(torch.softmax(q @ k.transpose(-1, -2) / self.dh ** 0.5 + mask, dim=-1))
+        ctx = (p @ v).permute(0, 2, 1, 3).reshape(B, S, D)
+        return self.LayerNorm(self.out_dropout(_lin3(self.dense, ctx)) + x)
+
+
+class _BSALayer(torch.nn.Module):
+    def __init__(self, D, num_heads, c, alpha, attn_dropout_rate, hidden_dropout_rate, device):
+        super().__init__()
+        self.alpha = alpha
+        self.filter_layer = _BSAFrequency(D, c, hidden_dropout_rate, device)
+        self.attention_layer = _BSAAttention(D, num_heads, attn_dropout_rate, hidden_dropout_rate, device)
+
+    def forward(self, x, mask):
+        return self.alpha * self.filter_layer(x) + (1 - self.alpha) * self.attention_layer(x, mask)
+
+
+class _BSAFeedForward(torch.nn.Module):
+    def __init__(self, D, dropout_rate, device):
+        super().__init__()
+        self.dense_1, self.dense_2 = rnn.Linear(D, 4 * D, device=device), rnn.Linear(4 * D, D, device=device)
+        self.LayerNorm = _TFLayerNorm(D, device=device)
+        self.dropout = torch.nn.Dropout(dropout_rate)
+
+    def forward(self, x):
+        z = _lin3(self.dense_1, x)
+        z = z * 0.5 * (1.0 + torch.erf(z / 2.0 ** 0.5))
+        return self.LayerNorm(self.dropout(_lin3(self.dense_2, z)) + x)
+
+
+class _BSABlock(torch.nn.Module):
+    def __init__(self, D, num_heads, c, alpha, attn_dropout_rate, hidden_dropout_rate, device):
+        super().__init__()
+        self.layer = _BSALayer(D, num_heads, c, alpha, attn_dropout_rate, hidden_dropout_rate, device)
+        self.feed_forward = _BSAFeedForward(D, hidden_dropout_rate, device)
+
+    def forward(self, x, mask):
+        return self.feed_forward(self.layer(x, mask))
+
+
+class BSARec(_EncodeRanking, torch.nn.Module):
+    """BSARec (BSARec/main.py:38-200): per block alpha * (frequency-domain low-pass branch) + (1 - alpha) * (causal self-attention), then
+    the feed-forward; the state at the last position of the LEFT-padded sequence against the item table (BCE / BPR / CE)."""
+
+    def __init__(self, num_items, maxlen=50, embedding_dim=64, num_heads=1, num_blocks=2, c=5, alpha=0.7, hidden_dropout_rate=0.5,
+                 attn_dropout_rate=0.5, loss="CE", device="cuda"):
+        super().__init__()
+        assert loss in ("BCE", "BPR", "CE")
+        D = embedding_dim
+        self.N, self.loss_kind = num_items, loss
+        self.item = rnn.Embedding(num_items + 1, D, padding_idx=0, device=device)
+        self.Position = torch.nn.Embedding(maxlen, D, device=device)
+        self.layerNorm = torch.nn.LayerNorm(D, eps=1e-12, device=device)
+        self.embdDropout = torch.nn.Dropout(hidden_dropout_rate)
+        self.blocks = torch.nn.ModuleList([_BSABlock(D, num_heads, c, alpha, attn_dropout_rate, hidden_dropout_rate, device) for _ in range(num_blocks)])
+        with torch.no_grad():                                    # BSARec.reset_parameters (BSARec/main.py:88-100)
+            for m in self.modules():
+                if isinstance(m, (rnn.Embedding, torch.nn.Embedding)):
+                    m.weight.normal_(mean=0.0, std=0.02)
+
+    def encode(self, seqs):
+        B, S = seqs.shape
+        keep = (seqs != 0).view(B, 1, 1, S).expand(-1, -1, S, -1).tril()
+        mask = torch.where(keep, 0.0, -1.0e4)
+        x = self.item(seqs.reshape(-1)).reshape(B, S, -1) + self.Position.weight[:S].unsqueeze(0)
+        x = self.embdDropout(self.layerNorm(x))
+        for blk in self.blocks:
+            x = blk(x, mask)
         return x[:, -1, :].contiguous(), self.item.weight[1:]
 
     def fit(self, seqs, positives, negatives):

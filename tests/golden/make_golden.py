@@ -20,7 +20,7 @@ Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic
   sgl.npz      : SGL/main.py      fit (rec_loss, emb_loss, ssl_loss) on two edge-dropout subgraphs (the uniform draws recorded) + grads + scores
   jgcf.npz     : JGCF/main.py     fit (rec_loss, emb_loss) + table gradients + [low | mid] tables + full scores
   gcn.npz      : GCN/main.py      fit rec_loss + every gradient + propagated tables + full scores
-  stamp_{bce,ce}.npz, narm.npz, fmlprec_bpr.npz : STAMP / NARM / FMLP-Rec main.py  fit loss + every gradient + full scores (dropouts 0)
+  stamp_{bce,ce}.npz, narm.npz, fmlprec_bpr.npz, bsarec_ce.npz : STAMP / NARM / FMLP-Rec / BSARec main.py  fit loss + every gradient + full scores (dropouts 0)
   bert4rec.npz : BERT4Rec/main.py fit loss (the mask draw recorded) + every gradient + full scores (dropout 0)
   ngcf.npz     : NGCF/main.py     fit (rec_loss, emb_loss) + every gradient + full scores on D^-1 (A + I)
   simgcl.npz   : SimGCL/main.py   fit (rec_loss, emb_loss, ssl_loss at eps = 0: the noise is torch.rand_like) + grads + full scores
@@ -680,6 +680,8 @@ if __name__ == "__main__":
                                                      ct_dropout_rate=0.0), False)
     gen_last_item_model("FMLP-Rec", "FMLPRec", "fmlprec_bpr", dict(loss="BPR", embedding_dim=64, num_blocks=2, hidden_dropout_rate=0.0, maxlen=20),
                         True, with_modules=True, emb_scale=10.0)
+    gen_last_item_model("BSARec", "BSARec", "bsarec_ce", dict(loss="CE", embedding_dim=64, num_heads=2, num_blocks=2, hidden_dropout_rate=0.0,
+                                                              attn_dropout_rate=0.0, maxlen=20, c=5, alpha=0.7), True, with_modules=True, emb_scale=10.0)
     gen_bert4rec()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

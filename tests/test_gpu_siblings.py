@@ -275,9 +275,10 @@ def test_gcn_matches_reference_loss_gradients_and_scores():
         torch.testing.assert_close(m.recommend_from_full(users), _t(g["out/scores"]), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("which", ["stamp_bce", "stamp_ce", "narm", "fmlprec_bpr"])
+@pytest.mark.parametrize("which", ["stamp_bce", "stamp_ce", "narm", "fmlprec_bpr", "bsarec_ce"])
 def test_last_item_siblings_match_reference_loss_gradients_and_scores(which):
-    """STAMP, NARM, FMLP-Rec on the engine ops against vectors made from STAMP/main.py, NARM/main.py, FMLP-Rec/main.py + modules.py."""
+    """STAMP, NARM, FMLP-Rec, BSARec on the engine ops against vectors made from STAMP/main.py, NARM/main.py, FMLP-Rec/main.py + modules.py,
+    BSARec/main.py + modules.py."""
     from recboard_amd import siblings as sib
     g = np.load(os.path.join(GOLD, which + ".npz"))
     N, S = int(g["cfg/N"]), int(g["cfg/maxlen"])
@@ -286,6 +287,8 @@ def test_last_item_siblings_match_reference_loss_gradients_and_scores(which):
         m = sib.STAMP(N, 64, 64, loss=which[6:].upper())
     elif which == "narm":
         m = sib.NARM(N, 64, 48, 1, emb_dropout_rate=0.0, hidden_dropout_rate=0.0, ct_dropout_rate=0.0)
+    elif which == "bsarec_ce":      # (the sibling mirrors the reference's module tree: only the item table is named differently)
+        m = sib.BSARec(N, maxlen=S, embedding_dim=64, num_heads=2, num_blocks=2, c=5, alpha=0.7, hidden_dropout_rate=0.0, attn_dropout_rate=0.0, loss="CE")
     else:
         m = sib.FMLPRec(N, maxlen=S, embedding_dim=64, num_blocks=2, hidden_dropout_rate=0.0, loss="BPR")
         for l in range(2):
