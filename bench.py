@@ -18,7 +18,8 @@ encoder step: forward + criterion + backward of every work item in one kernel, t
 `roofline_gather` the HBM-bound embedding gather.  `cpu_baseline` times the torch-CPU oracle of the same training step on this box's host cores;
 `eval_baselines` times the evaluation as the reference executes it (dense scores, masked fill, torch.topk) through ROCm aten
 on the same GPU and through torch on the host cores; `train_baseline_aten_gpu` a torch.nn SASRec step (eager ROCm aten) on the
-same GPU.
+same GPU.  `config5` (N = 1 runs only) is BASELINE.json's configs[4] on this GPU: the same step at d = 128 on the synthetic
+100 000 000-item table with the row-sparse Adam (154 GB of HBM; `--no-c5` skips it).
 """
 import argparse
 import json
@@ -232,12 +233,65 @@ def score_call_traffic():
         return None
 
 
+def config5_leg(steps=100, warmup=10):
+    """BASELINE.json configs[4] on this GPU: SASRec d = 128, L = 2, maxlen 50, BCE, on the synthetic 100 000 000-item table (SURVEY.md
+    section 8d C5: item popularity Zipf(1.05), B = 512, one uniform negative, table ~ N(0, 0.02^2) from the counter-based generator).  The table
+    and its two Adam moment tables (154 GB) live in HBM; the step is one batch-preparation launch + one hipGraph replay: fused D = 128
+    item kernel (forward + criterion + backward), weight gradients, the row-sparse Adam of the ~15 k contribution rows, the dense Adam of
+    the encoder.  Skipped (with the reason) when the device does not have the memory free."""
+    import numpy as np
+    N, D, B, S = 100_000_000, 128, 512, 50
+    try:
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
+        need = 3 * (N + 1) * D * 4 + (8 << 30)
+        if free < need:
+            return {"skipped": f"needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} GB free"}
+        from recboard_amd.large import SASRecLargeTableEngine
+        t0 = time.time()
+        eng = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.5, loss="BCE", lr=1e-3, weight_decay=1e-6, seed=1)
+        torch.cuda.synchronize()
+        t_init = time.time() - t0
+        rng = np.random.default_rng(1)
+        bs = []
+        for _ in range(4):
+            lens = np.clip(rng.geometric(1 / 5.9, B) + 1, 1, S - 1)
+            seq = np.zeros((B, S), np.int64)
+            for b in range(B):
+                seq[b, S - lens[b]:] = np.minimum(rng.zipf(1.05, lens[b]), N)
+            pos = np.where(seq > 0, np.minimum(rng.zipf(1.05, (B, S)), N) - 1, 0)
+            neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+            bs.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
+        for i in range(warmup):
+            eng.train_step_graph(*bs[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = eng.train_step_graph(*bs[i % 4])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        eng.check_handover()
+        free2, total = torch.cuda.mem_get_info()
+        out = {"metric": "train samples/sec (SASRec d=128 on the synthetic 100 M-item table, B=512, 1 GPU)", "value": round(B / dt, 1),
+               "unit": "samples/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "warmup": warmup, "final_loss": round(float(loss), 5),
+               "table": f"{N + 1} x {D} fp32 + two Adam moment tables", "hbm_used_GB": round((total - free2) / 1e9, 1),
+               "table_init_s": round(t_init, 1), "launch": "one batch-preparation launch + one hipGraph replay per step",
+               "data": "synthetic: Zipf(1.05) item popularity, lengths ~ clip(Geometric(mean 5.9) + 1, 1, 49)"}
+        del eng, bs
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:  # noqa: BLE001  (the headline line must not depend on this leg)
+        torch.cuda.empty_cache()
+        return {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the config-5 leg (100 M x 128 table: 154 GB of HBM)")
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the aten-on-GPU baselines (kernel-trace runs: only the engine's kernels)")
     ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
@@ -519,6 +573,8 @@ def main():
             line["coach_loop"] = {"samples_per_sec": round(nb * cfg["B"] / dtc, 1), "ms_per_step": round(dtc / nb * 1e3, 4),
                                   "what": f"Coach.train_per_epoch over {nb} HOST batches (pinned): H2D copies one batch ahead on a copy stream + batch "
                                           "preparation + graph replay per step, the epoch's mean loss read once at the end"}
+        if world == 1 and not args.no_c5:
+            line["config5"] = config5_leg()
         if not args.no_baselines:
             line["train_baseline_aten_gpu"] = aten_train_baseline(cfg, batches)
         if not args.no_cpu_baseline:
