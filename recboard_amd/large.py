@@ -283,11 +283,16 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         table-sized gradient, no all-reduce of the table; the encoder's dense gradient arena is averaged with one all-reduce
         (`grad_hook` semantics of bench.py).
 
-    With a process group of size 1 and dedup=False the step is `SASRecLargeTableEngine.train_step` on the same numbers, bit for bit
-    (tests/test_gpu_sasrec.py); with dedup (the default: every distinct row travels once, gradient rows pre-summed per sender) the
-    table differs from it in rounding only;
-    the exchange itself is covered under gloo with two ranks (tests/test_sharded_gloo.py).  Table values come from
-    `counter_normal_rows`, so every GPU count trains the same table."""
+    With a process group of size 1, dedup=False and the all-positions step (`compact_rows = False`) the step is
+    `SASRecLargeTableEngine.train_step` on the same numbers, bit for bit (tests/test_gpu_sasrec.py); the compact-row forms (exact sizes with or
+    without dedup -- every distinct row travels once, gradient rows pre-summed per sender --, the fixed-capacity exchange, the captured step)
+    give the same sums in another association: the table differs from the unsharded compact-row engine's in rounding only.  The exchange itself
+    is covered under gloo with two ranks (tests/test_sharded_gloo.py).  Table values come from `counter_normal_rows`, so every GPU count trains
+    the same table.
+
+    capacity_factor c (fixed-capacity form): every peer pair moves ceil(c * 3 * B * S / G) slots per direction; the padding row's lookups take
+    no slot, so c is sized for the REAL tokens (~15 % of a Beauty-shaped batch: c = 0.3 leaves a factor of two); overflow is counted on the
+    device (`table.check_capacity()`).  `train_step_graph` needs this form; call `release_graphs()` before destroying the process group."""
 
     def __init__(self, *args, group=None, dedup=True, capacity_factor=None, local_ops=None, **kw):
         import torch.distributed as dist
