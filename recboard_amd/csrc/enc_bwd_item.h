@@ -86,6 +86,7 @@ __device__ __forceinline__ void ln_bwd_row(const float* dy, const float* x, floa
 }
 
 __device__ __forceinline__ void stats_fetch(float2& r, const float* st, int nrows, int tid) {
+    tid = enc_opaque(tid);
     gcf_t sp = g_launder(st);
     r = make_float2(0.f, 0.f);
     if (tid < nrows) { r.x = sp[2 * tid]; r.y = sp[2 * tid + 1]; }
@@ -271,7 +272,7 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
 #pragma unroll
                 for (int q = 0; q < KPT; ++q) pq[q] = 0.f;
                 if (r_e < nrows) {
-                    const float* src = tp + T.off_P + (row0 + r_e) * EP_PW + j0_e;
+                    const float* src = tp + T.off_P + (row0 + enc_opaque(r_e)) * EP_PW + enc_opaque(j0_e);
                     if (KPT % 4 == 0) {
 #pragma unroll
                         for (int q = 0; q < KPT / 4; ++q) ld4(&pq[4 * q], src + 4 * q);

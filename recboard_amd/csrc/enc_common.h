@@ -24,6 +24,15 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// A value the compiler must treat as freshly produced here.  The GEMM helpers' epilogue rows go through it: their LDS addresses
+// (row * LS + col for four rows) were otherwise computed once outside the block loop, kept alive across it, spilled to scratch, and each
+// reload's `s_waitcnt vmcnt(0)` -- the memory counter retires in order -- drained the tile prefetches in flight (a full memory round
+// trip in the middle of a phase).  Recomputed at the point of use they cost two vector instructions and the four rows share one register.
+__device__ __forceinline__ int enc_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <int D>
 struct EC {
     static constexpr int NS = D / 16;                 // column strips
@@ -238,18 +247,21 @@ __device__ __forceinline__ void enc_flag_wait(float* tape_flags, int64_t tile, i
 }
 template <int D>
 __device__ __forceinline__ void tile_store_coh(const float* tile, float* g, int nrows, int tid) {
+    tid = enc_opaque(tid);
     using C = EC<D>;
     for (int f = tid; f < nrows * D; f += C::NT)
         __hip_atomic_store(g + f, tile[(f / D) * C::LS + (f % D)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int D>
 __device__ __forceinline__ void tile_load_coh(float* tile, const float* g, int nrows, int tid) {
+    tid = enc_opaque(tid);
     using C = EC<D>;
     for (int f = tid; f < nrows * D; f += C::NT)
         tile[(f / D) * C::LS + (f % D)] = __hip_atomic_load(g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int D>
 __device__ __forceinline__ void tile_add_coh(float* tile, const float* g, int nrows, int tid) {
+    tid = enc_opaque(tid);
     using C = EC<D>;
     for (int f = tid; f < nrows * D; f += C::NT)
         tile[(f / D) * C::LS + (f % D)] += __hip_atomic_load(g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -309,8 +321,9 @@ __device__ __forceinline__ void gemm_rows_n(const float* A, const float (&bf)[D 
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int tt = t * C::WR + wr;
+        { const int rb_ = enc_opaque(16 * tt + 4 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) epi(16 * tt + 4 * g + j, acc[t][0][j] + acc[t][1][j]);
+        for (int j = 0; j < 4; ++j) epi(rb_ + j, acc[t][0][j] + acc[t][1][j]); }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -371,8 +384,9 @@ __device__ __forceinline__ void gemm_pairs(const float* A, const float* B, int l
                 a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s + 1], bf[s + 1], a1, 0, 0, 0);
             }
+            { const int rb_ = enc_opaque(16 * tt + 4 * g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) epi(16 * tt + 4 * g + j, 16 * kk + c, a0[j] + a1[j]);
+            for (int j = 0; j < 4; ++j) epi(rb_ + j, 16 * kk + c, a0[j] + a1[j]); }
             __builtin_amdgcn_sched_barrier(0);
         }
 }
@@ -400,8 +414,9 @@ __device__ __forceinline__ void gemm_tx(const float* T, const float* X, int lane
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], a1, 0, 0, 0);
         }
+        { const int rb_ = enc_opaque(16 * tt + 4 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) epi(16 * tt + 4 * g + j, a0[j] + a1[j]);
+        for (int j = 0; j < 4; ++j) epi(rb_ + j, a0[j] + a1[j]); }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -430,8 +445,9 @@ __device__ __forceinline__ void gemm_ttx(const float* T, const float* X, int lan
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], a1, 0, 0, 0);
         }
+        { const int rb_ = enc_opaque(16 * kt + 4 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) epi(16 * kt + 4 * g + j, a0[j] + a1[j]);
+        for (int j = 0; j < 4; ++j) epi(rb_ + j, a0[j] + a1[j]); }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -458,8 +474,9 @@ __device__ __forceinline__ void gemm_ttx_pre(const float* T, const float* X, int
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], a1, 0, 0, 0);
         }
+        { const int rb_ = enc_opaque(16 * pt + 4 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) epi(16 * pt + 4 * g + j, a0[j] + a1[j]);
+        for (int j = 0; j < 4; ++j) epi(rb_ + j, a0[j] + a1[j]); }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -472,6 +489,7 @@ struct TileRegs {
 };
 template <int D>
 __device__ __forceinline__ void tile_fetch(TileRegs<D>& R, const float* g, int nrows, int tid) {
+    tid = enc_opaque(tid);   // (per-thread addresses recomputed at the call, not carried across the block loop: enc_opaque)
     using C = EC<D>;
     gcf_t gp = g_launder(g);   // (pins the request where it is written)
 #pragma unroll
@@ -484,6 +502,7 @@ __device__ __forceinline__ void tile_fetch(TileRegs<D>& R, const float* g, int n
 }
 template <int D>
 __device__ __forceinline__ void tile_commit(float* tile, const TileRegs<D>& R, int nrows, int tid) {
+    tid = enc_opaque(tid);   // (per-thread addresses recomputed at the call, not carried across the block loop: enc_opaque)
     using C = EC<D>;
 #pragma unroll
     for (int q = 0; q < C::ROWS * (D / 4) / C::NT; ++q) {
@@ -493,12 +512,14 @@ __device__ __forceinline__ void tile_commit(float* tile, const TileRegs<D>& R, i
 }
 template <int D>
 __device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ g, int nrows, int tid) {
+    tid = enc_opaque(tid);   // (per-thread addresses recomputed at the call, not carried across the block loop: enc_opaque)
     using C = EC<D>;
     for (int f = tid; f < nrows * (D / 4); f += C::NT)
         reinterpret_cast<float4*>(g)[f] = *reinterpret_cast<const float4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4)));
 }
 template <int D>
 __device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ g, int nrows, int tid, float scale) {
+    tid = enc_opaque(tid);   // (per-thread addresses recomputed at the call, not carried across the block loop: enc_opaque)
     using C = EC<D>;
     for (int f = tid; f < nrows * (D / 4); f += C::NT) {
         const float4 v = *reinterpret_cast<const float4*>(tile + (f / (D / 4)) * C::LS + 4 * (f % (D / 4)));
@@ -508,6 +529,7 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
 // tile[r][:] += g[r][:] for nrows contiguous rows (the partial sums a chained item's later rows left for its earlier rows)
 template <int D>
 __device__ __forceinline__ void tile_add_global(float* tile, const float* g, int nrows, int tid) {
+    tid = enc_opaque(tid);   // (per-thread addresses recomputed at the call, not carried across the block loop: enc_opaque)
     using C = EC<D>;
     gcf_t gp = g_launder(g);
     for (int f = tid; f < nrows * (D / 4); f += C::NT) {
@@ -520,6 +542,7 @@ __device__ __forceinline__ void tile_add_global(float* tile, const float* g, int
 // rows of a [B*S][D] matrix selected by s_gid (dummy rows read as zero / are not written)
 template <int D>
 __device__ __forceinline__ void tile_fetch_gid(TileRegs<D>& R, const float* g, const int* s_gid, int nrows, int tid) {
+    tid = enc_opaque(tid);   // (per-thread addresses recomputed at the call, not carried across the block loop: enc_opaque)
     using C = EC<D>;
     gcf_t gp = g_launder(g);
 #pragma unroll
@@ -537,6 +560,7 @@ __device__ __forceinline__ void tile_fetch_gid(TileRegs<D>& R, const float* g, c
 // a predicated load is waited for where it is issued)
 template <int D>
 __device__ __forceinline__ void tile_fetch_rows(TileRegs<D>& R, const float* table, const int* s_row, int nrows, int tid) {
+    tid = enc_opaque(tid);   // (per-thread addresses recomputed at the call, not carried across the block loop: enc_opaque)
     using C = EC<D>;
     gcf_t gp = g_launder(table);
     const int last = nrows * (D / 4) - 1;
@@ -551,6 +575,7 @@ __device__ __forceinline__ void tile_fetch_rows(TileRegs<D>& R, const float* tab
 }
 template <int D>
 __device__ __forceinline__ void tile_store_gid(const float* tile, float* __restrict__ g, const int* s_gid, int nrows, int tid, float scale = 1.0f) {
+    tid = enc_opaque(tid);   // (per-thread addresses recomputed at the call, not carried across the block loop: enc_opaque)
     using C = EC<D>;
     for (int f = tid; f < nrows * (D / 4); f += C::NT) {
         const int r = f / (D / 4), c4 = f % (D / 4);
@@ -594,6 +619,7 @@ struct ParRegs {
 };
 template <int D>
 __device__ __forceinline__ void par_fetch(ParRegs<D>& R, const SasrecBlockParams& W, int tid) {
+    tid = enc_opaque(tid);
     using C = EC<D>;
 #pragma unroll
     for (int q = 0; q < (EP_NPAR * D + C::NT - 1) / C::NT; ++q) {
@@ -607,6 +633,7 @@ __device__ __forceinline__ void par_fetch(ParRegs<D>& R, const SasrecBlockParams
 }
 template <int D>
 __device__ __forceinline__ void par_commit(float* dst, const ParRegs<D>& R, int tid) {
+    tid = enc_opaque(tid);
     using C = EC<D>;
 #pragma unroll
     for (int q = 0; q < (EP_NPAR * D + C::NT - 1) / C::NT; ++q) {
