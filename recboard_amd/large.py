@@ -145,7 +145,8 @@ class SASRecLargeTableEngine(SASRecEngine):
             W = self._buffers(B, S)
             G = A.views(A.grad)
             lw, lb = self.params["lastLN.weight"].detach(), self.params["lastLN.bias"].detach()
-            W["keys"].zero_()                                   # rows beyond this batch's plan must read "no contribution"
+            if table is not None:                               # (the sharded step reads every key entry: rows beyond this batch's plan must read
+                W["keys"].zero_()                               #  "no contribution"; the unsharded update stops at the plan's live length)
             loss = ops.sasrec_encoder_step(E, Ppos.detach(), seq, pos, neg, float(D ** 0.5), self._block_tensors(), lw, lb, self.L, p, sd,
                                            aux.plan, kind, count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
                                            W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
