@@ -421,6 +421,18 @@ def main():
         "final_loss": round(float(loss), 5),
     }
 
+    if rank == 0 and not args.no_extras and world == 1:
+        # ---------------- spread of the step time (median + p10 / p90): every step of a second run bracketed by events on
+        # the stream the step runs on, read after the run (nothing synchronises inside it)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(201)]
+        evs[0].record()
+        for i in range(200):
+            step(i)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(200))
+        line["step_ms_percentiles"] = {"p10": round(per[20], 4), "p50": round(per[100], 4), "p90": round(per[180], 4), "steps": 200,
+                                       "how": "hipEvents between consecutive steps of a second run (device-side spacing of the steps)"}
     if rank == 0 and not args.no_extras:
         # ---------------- dominant kernel of the timed region: the per-block encoder backward (MFMA-bound, fp32)
         if args.encoder == "fused":
