@@ -255,7 +255,7 @@ def config5_measure(steps=100, warmup=10):
     item kernel (forward + criterion + backward), weight gradients, the row-sparse Adam of the ~15 k contribution rows, the dense Adam of
     the encoder.  Skipped (with the reason) when the device does not have the memory free."""
     import numpy as np
-    N, D, B, S = 100_000_000, 128, 512, 50
+    N, D, B, S = int(os.environ.get("RECBENCH_C5_ITEMS", 100_000_000)), 128, 512, 50      # (the override: tests/test_gpu_bench.py runs the leg small)
     try:
         torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info()
@@ -287,7 +287,7 @@ def config5_measure(steps=100, warmup=10):
         dt = (time.perf_counter() - t0) / steps
         eng.check_handover()
         free2, total = torch.cuda.mem_get_info()
-        out = {"metric": "train samples/sec (SASRec d=128 on the synthetic 100 M-item table, B=512, 1 GPU)", "value": round(B / dt, 1),
+        out = {"metric": f"train samples/sec (SASRec d=128 on the synthetic {N / 1e6:g} M-item table, B=512, 1 GPU)", "value": round(B / dt, 1),
                "unit": "samples/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "warmup": warmup, "final_loss": round(float(loss), 5),
                "table": f"{N + 1} x {D} fp32 + two Adam moment tables", "hbm_used_GB": round((total - free2) / 1e9, 1),
                "table_init_s": round(t_init, 1), "launch": "one batch-preparation launch + one hipGraph replay per step",
