@@ -115,6 +115,9 @@ class Coach:
             n += bsz
         if hasattr(self.model, "check_handover"):
             self.model.check_handover()     # (split long sequences: the halves' hand-over flags; the loss read below syncs anyway)
+        table = getattr(self.model, "table", None)
+        if table is not None and hasattr(table, "check_capacity"):
+            table.check_capacity()          # (row-sharded tables: a lookup dropped by a full exchange bucket came back as a zero row)
         return {"LOSS": float(tot / max(n, 1))}
 
     def _module_step(self, inputs):
@@ -176,7 +179,8 @@ class Coach:
                 self.optimizer.load_state_dict(opt)
         if self.lr_scheduler is not None and ck.get("lr_scheduler"):
             self.lr_scheduler.load_state_dict(ck["lr_scheduler"])
-        self.best, self.history = ck["monitors"]["best"], ck["monitors"]["history"]
+        mon = ck.get("monitors") or {}           # (checkpoints written before `monitors` existed keep best / history at the top level)
+        self.best, self.history = mon.get("best", ck.get("best")), mon.get("history", ck.get("history", []))
         return ck["epoch"]
 
     def save_best(self, path):
@@ -233,7 +237,21 @@ class Coach:
             self.model.train(was_training)
         return ev.compute()
 
+    #: monitors for which smaller is better (freerec's DEFAULT_BEST_CASTER: min for losses, max for ranking / AUC metrics)
+    MINIMISED = ("LOSS", "LOGLOSS", "MSE", "MAE", "RMSE")
+
+    @property
+    def best_mode(self):
+        return "min" if self.which4best.split("@")[0].upper() in self.MINIMISED else "max"
+
+    def _better(self, score, best):
+        return score < best if self.best_mode == "min" else score > best
+
     def fit(self, epochs):
+        if self.lr_scheduler is not None and getattr(self.lr_scheduler, "mode", self.best_mode) != self.best_mode:
+            import warnings
+            warnings.warn(f"lr_scheduler.mode={self.lr_scheduler.mode!r} but which4best={self.which4best!r} is {self.best_mode}imised: "
+                          "the scheduler will read every improvement as a bad epoch")
         for epoch in range(1, epochs + 1):
             rec = {"epoch": epoch, "train": self.train_per_epoch(epoch)}
             if self.validpipe is not None and epoch % self.eval_freq == 0:
@@ -243,7 +261,7 @@ class Coach:
                     score = rec["valid"].get(f"{name.upper()}@{k}")
                 else:
                     score = rec["valid"].get(self.which4best.upper())
-                if score is not None and (self.best is None or score > self.best[1]):
+                if score is not None and (self.best is None or self._better(score, self.best[1])):
                     self.best = (epoch, score)
                     if self.checkpoint_path:
                         self.save_best(self.checkpoint_path)

@@ -69,7 +69,8 @@ struct SasrecParams {
 };
 
 // ---- plan (re_sasrec_batch_prep): int32 words
-//   [0] n_items  [1] n_tiles  [2] n_long items  [3] tiles per short item  [4] number of valid (non-pad) positions  [5..7] 0
+//   [0] n_items  [1] n_tiles  [2] n_long items  [3] tiles per short item  [4] number of valid (non-pad) positions
+//   [5] number of sequences SPLIT over two work items (kinds 2 / 3; 0 = none)  [6] the workgroup count the plan was made for  [7] 0
 //   [8 .. 8 + MT)            item descriptors: tile0 | nt << 24 | kind << 28   (kind 1 = one sequence over nt tiles)
 //   then int2 rowmap[MT * 16]: { gid = b * S + s or -1 (dummy row), first = pads in front of the row's sequence }
 //   then scratch of the plan kernel.   MT = B * ceil(S / 16) bounds the number of tiles.
@@ -245,6 +246,20 @@ __device__ __forceinline__ void enc_flag_wait(float* tape_flags, int64_t tile, i
     }
     __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A plan with split sequences is only valid for a launch in which EVERY item has a workgroup of its own: the halves wait for each
+// other, so both must be resident (with grid < n_items the snake order can hand one workgroup both halves -- a certain time-out).
+// The plan's workgroup count and the step's grid are independent ABI arguments; this is the check that they agree.  A mismatch
+// sets the tape's error word (re: sasrec_tape_errors / check_handover) and, where the launch has a loss word, makes it NaN; the
+// launch then does nothing (stale gradients are applied by a captured step's optimizer, but the loss and the error word say so).
+__device__ __forceinline__ bool enc_split_plan_rejected(const EncPlan& PL, float* tape_flags, int64_t err_word, float* loss) {
+    if (PL.hdr[5] <= 0 || PL.hdr[0] <= (int)gridDim.x) return false;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (tape_flags) __hip_atomic_store(reinterpret_cast<unsigned*>(tape_flags) + err_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (loss) loss[0] = __builtin_nanf("");
+    }
+    return true;
+}
+
 template <int D>
 __device__ __forceinline__ void tile_store_coh(const float* tile, float* g, int nrows, int tid) {
     tid = enc_opaque(tid);

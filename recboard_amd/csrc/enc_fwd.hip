@@ -33,6 +33,7 @@ __global__ __launch_bounds__(512) void enc_fwd_k(const float* __restrict__ x0, S
     extern __shared__ __align__(16) float lds[];
     const EncPlan PL = enc_plan_view(planp, B, S);
     const int n_items = PL.hdr[0];
+    if (TRAIN && enc_split_plan_rejected(PL, tape + T.off_FLAGS, enc_plan_max_tiles(B, S) * EP_FLAG_WORDS, nullptr)) return;
     const EncHead H{};
     for (int k = 0; k * (int)gridDim.x < n_items; ++k) {
         const int wi = enc_item_of(k, blockIdx.x, gridDim.x);
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(512) void enc_fwd_loss_k(SeEmbed em, const int64_t*
     extern __shared__ __align__(16) float lds[];
     const EncPlan PL = enc_plan_view(planp, B, S);
     const int n_items = PL.hdr[0];
+    if (enc_split_plan_rejected(PL, tape + T.off_FLAGS, enc_plan_max_tiles(B, S) * EP_FLAG_WORDS, H.loss)) return;
     for (int k = 0; k * (int)gridDim.x < n_items; ++k) {
         const int wi = enc_item_of(k, blockIdx.x, gridDim.x);
         if (wi >= n_items) continue;

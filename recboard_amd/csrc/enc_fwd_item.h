@@ -40,7 +40,7 @@ struct EncHead {
     float* dU_rows;               // [NR, D]
     float* g_rows;                // [3, NR, D]: regions 1, 2 written here
     int32_t* keys;                // [3, NR]
-    unsigned long long* acc;      // one zeroed 64-bit word: items arrived << 52 | loss sum in 2^-30 units
+    unsigned long long* acc;      // two zeroed 64-bit words: loss sum in 2^-30 units; arrivals | non-finite partials << 32
 };
 
 template <int D, bool TRAIN, bool HEAD>
@@ -455,9 +455,12 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
         }
         }   // chained parts
         if (HEAD) {
-            // The item's loss goes into ONE 64-bit word: arrivals << 52 | sum in 2^-30 units (integer adds commute: the total does not
-            // depend on the order the items arrive in).  The item that finds all others arrived writes the mean.  One device-scope
-            // atomic, no fence: a release fence here would write back the XCD's whole L2 once per item.
+            // The item's loss goes into a 64-bit fixed-point word (2^-30 units; integer adds commute: the total does not depend on the
+            // order the items arrive in), then the item takes a ticket in the next word: low half = arrivals, high half = how many
+            // partials were NaN / Inf / beyond the fixed-point range -- a diverged model.  Such a partial is NOT converted (llrint of a
+            // NaN is 0 or garbage): the finishing item then writes NaN, as torch's mean would.  Both are device-scope atomics ordered by a
+            // data dependency (the ticket's operand is made from the add's return value); no fence: a release fence here would write
+            // back the XCD's whole L2 once per item.  The finishing item leaves both words zero for the next launch.
             float t = re_wave_sum(head_sum);
             if (lane == 0) s_red[wave] = t;
             __syncthreads();
@@ -465,13 +468,17 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
                 double part = 0.0;
 #pragma unroll
                 for (int w = 0; w < C::NW; ++w) part += (double)s_red[w];
-                const unsigned long long add = (1ull << 52) + (unsigned long long)(long long)llrint(part * 1073741824.0);
+                const bool finite = part == part && fabs(part) < 4294967296.0;
+                const unsigned long long add = finite ? (unsigned long long)(long long)llrint(part * 1073741824.0) : 0ull;
                 const unsigned long long old = __hip_atomic_fetch_add(H.acc, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(old >> 52) == PL.hdr[0] - 1) {
-                    const unsigned long long tot = (old + add) & ((1ull << 52) - 1);
+                const unsigned long long one = 1ull + (finite ? 0ull : (1ull << 32)) + (old & 0ull);
+                const unsigned long long ticket = __hip_atomic_fetch_add(H.acc + 1, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(ticket & 0xFFFFFFFFull) == PL.hdr[0] - 1) {
+                    const unsigned long long tot = __hip_atomic_exchange(H.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool bad = ((ticket + one) >> 32) != 0ull;
                     const int cnt = H.count[0];
-                    H.loss[0] = cnt > 0 ? (float)((double)tot * (1.0 / 1073741824.0) / (double)cnt) : 0.f / 0.f;   // mean over an empty set is NaN, as torch's
-                    __hip_atomic_store(H.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    H.loss[0] = (cnt > 0 && !bad) ? (float)((double)(long long)tot * (1.0 / 1073741824.0) / (double)cnt) : __builtin_nanf("");   // mean over an empty set is NaN, as torch's
+                    __hip_atomic_store(H.acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
                 }
             }
         }

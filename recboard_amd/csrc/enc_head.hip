@@ -78,14 +78,18 @@ __global__ __launch_bounds__(256) void loss_rows_k(const float* __restrict__ U, 
         // total and writes the loss.  Both are device-scope atomics, ordered by a data dependency (the ticket's operand is made from
         // the add's return value) -- no fence: a release fence here writes back this XCD's whole L2, once per workgroup.
         const double part = (double)(((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3]);
-        const unsigned long long add = (unsigned long long)(long long)llrint(part * 1073741824.0);
+        // (a NaN / Inf / out-of-range partial -- a diverged model -- is not converted: it is counted in the ticket word's upper bits
+        //  (grids stay below 2^20 workgroups) and the finishing workgroup writes NaN, as torch's mean would)
+        const bool finite = part == part && fabs(part) < 4294967296.0;
+        const unsigned long long add = finite ? (unsigned long long)(long long)llrint(part * 1073741824.0) : 0ull;
         const unsigned long long old = __hip_atomic_fetch_add(acc, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned one = 1u + (unsigned)(old & 0ull);
+        const unsigned one = 1u + (finite ? 0u : (1u << 20)) + (unsigned)(old & 0ull);
         const unsigned ticket = __hip_atomic_fetch_add(done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == gridDim.x - 1) {
+        if ((ticket & 0xFFFFFu) == gridDim.x - 1) {
             const unsigned long long tot = __hip_atomic_exchange(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool bad = ((ticket + one) >> 20) != 0u;
             const int c = count[0];
-            loss[0] = c > 0 ? (float)((double)(long long)tot * (1.0 / 1073741824.0) / (double)c) : 0.f / 0.f;   // mean over an empty set is NaN, as torch's
+            loss[0] = (c > 0 && !bad) ? (float)((double)(long long)tot * (1.0 / 1073741824.0) / (double)c) : __builtin_nanf("");   // mean over an empty set is NaN, as torch's
             __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
     }

@@ -18,6 +18,7 @@ __global__ __launch_bounds__(512) void enc_step_k(SeEmbed em, const int64_t* __r
     extern __shared__ __align__(16) float lds[];
     const EncPlan PL = enc_plan_view(planp, B, S);
     const int n_items = PL.hdr[0];
+    if (enc_split_plan_rejected(PL, tape + T.off_FLAGS, enc_plan_max_tiles(B, S) * EP_FLAG_WORDS, H.loss)) return;
     using C = EC<D>;
     __shared__ int h_gid[C::ROWS], h_first[C::ROWS], h_pad[C::ROWS], h_sid[C::ROWS], h_start[C::ROWS];
     __shared__ float h_mean[C::ROWS], h_rstd[C::ROWS];

@@ -162,7 +162,16 @@ class GraphedStep:
         self.static_in = tuple(t.clone() for t in example_inputs)
         self.optimizer = optimizer
         params = [p for g in optimizer.param_groups for p in g["params"]]
+        # Everything the warm-up and capture steps change is snapshotted and put back afterwards: the parameters, the optimizer's
+        # state as it stands (a Coach builds one GraphedStep per input shape on a SHARED optimizer -- a short last batch, or the
+        # first step after load_checkpoint, arrives with live Adam moments and step counts), and the module's buffers
+        # (BatchNorm running statistics / num_batches_tracked advance in the warm-up).
         keep = [p.detach().clone() for p in params]
+        had_state = {p: (p in optimizer.state and len(optimizer.state[p]) > 0) for p in params}
+        keep_state = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()}
+                      for p in params if had_state[p]}
+        buffers = [b for b in model.buffers()] if isinstance(model, torch.nn.Module) else []
+        keep_buf = [b.detach().clone() for b in buffers]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up on a side stream (allocator pools, lazy optimizer state)
@@ -177,13 +186,20 @@ class GraphedStep:
             self.loss = loss_fn(*self.static_in)
             self.loss.backward()
             optimizer.step()
-        with torch.no_grad():                          # the warm-up and capture steps are rolled back (parameters and Adam state)
+        with torch.no_grad():                          # roll the warm-up and capture steps back, IN PLACE (the graph holds these tensors)
             for p, k in zip(params, keep):
                 p.copy_(k)
-            for st in optimizer.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            for b, k in zip(buffers, keep_buf):
+                b.copy_(k)
+            for p in params:
+                st = optimizer.state.get(p, {})
+                for name, v in st.items():
+                    if not torch.is_tensor(v):
+                        continue
+                    if had_state[p] and name in keep_state[p] and torch.is_tensor(keep_state[p][name]):
+                        v.copy_(keep_state[p][name])
+                    else:
+                        v.zero_()                      # state the warm-up created: as a fresh optimizer's
 
     def __call__(self, *inputs):
         for s, t in zip(self.static_in, inputs):

@@ -591,6 +591,14 @@ def sasrec_tape_errors(tape, B, S):
     return int(tape[-16:].view(torch.int32)[0].item()) if tape.numel() >= mt * 8 + 16 else 0
 
 
+def sasrec_tape_reset_flags(tape, B, S):
+    """Zero a tape's hand-over flags and error word: after a time-out (or a rejected split plan) a producer's late flag store would
+    otherwise be read by the next replay as "published"."""
+    mt = B * ((S + 15) // 16)
+    if tape.numel() >= mt * 8 + 16:
+        tape[-(mt * 8 + 16):].zero_()
+
+
 def sasrec_plan_rows(B, S):
     """Upper bound of the number of compact rows of a batch plan (re_sasrec_plan_rows)."""
     return int(lib.load().re_sasrec_plan_rows(int(B), int(S)))

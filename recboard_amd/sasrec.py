@@ -297,8 +297,12 @@ class SASRecEngine:
     def check_handover(self):
         """Raise if a split sequence's halves ever timed out waiting for each other (Coach calls this once per epoch; host sync)."""
         for (B, S), W in self._bufs.items():
-            if ops.sasrec_tape_errors(W["tape"], B, S):
-                raise RuntimeError("recengine: a split sequence's work items did not meet (hand-over time-out); results of that step are invalid")
+            err = ops.sasrec_tape_errors(W["tape"], B, S)
+            if err:
+                ops.sasrec_tape_reset_flags(W["tape"], B, S)    # (a late producer store must not read as "published" in the next replay)
+                raise RuntimeError("recengine: a split-sequence plan was launched on fewer workgroups than it has work items (the plan's and the "
+                                   "step's workgroup counts disagree); that step did nothing" if err == 2 else
+                                   "recengine: a split sequence's work items did not meet (hand-over time-out); results of that step are invalid")
 
     def _split(self):
         """Long sequences as two work items in two workgroups: the fused training step (its tape carries the hand-over flags)."""

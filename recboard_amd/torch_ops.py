@@ -5,12 +5,17 @@
     recengine::bpr_triplet(U, I, users, pos, neg) -> (loss, logits)        MF.fit's gathers + row dots + BPRLoss (MF-BPR/main.py:81-93)
     recengine::score_dense(Q, E) -> Tensor                                 einsum("BD,ND->BN") (SASRec/main.py:228)
     recengine::score_topk(Q, E, seen_ptr, seen_idx, K) -> (vals, idx)      Coach.evaluate's masked top-K (UniSRec/main.py:408-414)
-    recengine::spmm_csr(crow, col, val, X) -> Tensor                       Adj @ X (LightGCN/main.py:80-84; Adj symmetric)
+    recengine::spmm_csr(crow, col, val, X) -> Tensor                       Adj @ X (LightGCN/main.py:80-84).  The registered backward is
+                                                                           A dY, i.e. it is right for SYMMETRIC A only (the reference's
+                                                                           to_normalized_adj("sym")); for any other matrix use
+                                                                           recboard_amd.nn.spmm(A, At, X), which takes the transpose explicitly
 
 Each op has a HIP implementation (ctypes -> librecengine.so on the current stream; there is no CPU kernel and CPU tensors raise),
 a fake (meta) implementation so that it traces / exports, and -- where the reference differentiates through it -- a registered
 autograd formula whose backward runs on the engine's kernels too.  `recboard_amd.nn` is the module-level surface over these ops.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -183,12 +188,19 @@ _PLANS = {}
 
 
 def _plan(crow, D):
+    """The row-order / long-row-chunk plan of an adjacency, built once per `crow` TENSOR.  The cache key is the address, but an entry
+    is only valid for the tensor object it was built from at the version it had then: an adjacency rebuilt per epoch (SGL's edge
+    dropout as the reference does it, SGL/main.py) usually gets the freed `crow`'s address back from the caching allocator, and an
+    in-place edit keeps it -- a stale plan would then read col / val past nnz."""
     key = (crow.data_ptr(), crow.numel(), D)
-    if key not in _PLANS:
-        if len(_PLANS) > 16:
-            _PLANS.clear()
-        _PLANS[key] = ops.spmm_plan(crow, D)     # row order / long-row chunks: once per adjacency
-    return _PLANS[key]
+    ent = _PLANS.get(key)
+    if ent is not None and ent[1]() is crow and ent[2] == crow._version:
+        return ent[0]
+    if len(_PLANS) > 16:
+        _PLANS.clear()
+    plan = ops.spmm_plan(crow, D)
+    _PLANS[key] = (plan, weakref.ref(crow), crow._version)
+    return plan
 
 
 @_lib.custom_op("recengine::spmm_csr", mutates_args=(), device_types="cuda")
