@@ -274,6 +274,9 @@ int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* 
  *   replaces dU, which may then be NULL.  dx0_rows (optional): receives the rows of dx0 once more, in compact order (region 0 of
  *   re_sasrec_loss_rows' g_rows). */
 size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
+/* The tape's array offsets in floats (tools / tests that read a tape back; arrays are indexed by the plan's compact rows, those of
+ * block l start at l * per_block): out[0..n) = per_block, X, A, Q, K, V, O, X1, Y, HR, P, SA, SF, PP, MK, XL, SL, FLAGS, total. */
+int re_sasrec_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L, int64_t* out, int64_t n);
 /* The pair criteria of re_pair_loss_fwd_bwd on the plan's compact rows only (SASRec/main.py:199-215 without the boolean-mask
  * compaction and without the padding positions): NR = re_sasrec_plan_rows(B, S) bounds the number of rows; per live row r
  * (position gid of the plan's row map):  dU_rows [NR, D] row r = d loss / d u[gid] (zero where seq[gid] == 0),

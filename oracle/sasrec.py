@@ -47,8 +47,11 @@ def layer_norm(x, w, b, eps=1e-8):
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
-def block(x, pad, P, l, drop=None):
-    """One SASRec block on x [B,S,D]; pad [B,S,1] bool.  SASRec/main.py:163-176."""
+def block(x, pad, P, l, drop=None, gates=None):
+    """One SASRec block on x [B,S,D]; pad [B,S,1] bool.  SASRec/main.py:163-176.
+    gates (optional): {l: (open [B,S,D] bool, eps)} -- where the FFN's pre-activation is within eps of zero (a relu kink) the gate
+    is taken from `open` (the implementation under test) instead of the sign computed here: there the two sides' rounding decides,
+    and a flipped gate changes that element's gradient by its whole upstream value, which no tolerance covers."""
     B, S, D = x.shape
     pre = f"attnLayers.{l}."
     Wi, bi = P[pre + "in_proj_weight"], P[pre + "in_proj_bias"]
@@ -70,14 +73,18 @@ def block(x, pad, P, l, drop=None):
     W2, b2 = P[f"fwdLayers.{l}.conv2.weight"].squeeze(-1), P[f"fwdLayers.{l}.conv2.bias"]
     h = y @ W1.T + b1
     h = _apply(h, _mask(drop, rng.stream_ffn1(l), (B, S, D)))
-    h = torch.relu(h)
+    if gates is not None and l in gates:
+        open_, eps = gates[l]
+        h = h * torch.where(h.detach().abs() < eps, open_, h.detach() > 0).to(h.dtype)
+    else:
+        h = torch.relu(h)
     o = h @ W2.T + b2
     o = _apply(o, _mask(drop, rng.stream_ffn2(l), (B, S, D)))
     x = o + y
     return x.masked_fill(pad, 0.0)
 
 
-def encode(P, seq, num_blocks=2, drop=None):
+def encode(P, seq, num_blocks=2, drop=None, gates=None):
     """-> (userEmbds [B,S,D], itemEmbds = E[1:] [N,D]).  SASRec/main.py:178-193."""
     E = P["Item.embeddings.weight"]
     B, S = seq.shape
@@ -88,14 +95,14 @@ def encode(P, seq, num_blocks=2, drop=None):
     x = _apply(x, _mask(drop, rng.STREAM_EMBED, (B, S, D)))
     x = x.masked_fill(pad, 0.0)
     for l in range(num_blocks):
-        x = block(x, pad, P, l, drop)
+        x = block(x, pad, P, l, drop, gates)
     u = layer_norm(x, P["lastLN.weight"], P["lastLN.bias"])
     return u, E[1:]
 
 
-def fit(P, seq, pos, neg, loss="BCE", num_blocks=2, drop=None):
+def fit(P, seq, pos, neg, loss="BCE", num_blocks=2, drop=None, gates=None):
     """-> rec_loss scalar.  SASRec/main.py:195-221."""
-    u, items = encode(P, seq, num_blocks, drop)
+    u, items = encode(P, seq, num_blocks, drop, gates)
     idx = seq != 0
     u = u[idx]
     if loss in ("BCE", "BPR"):

@@ -65,6 +65,17 @@ extern "C" size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t 
     return (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float);
 }
 
+// The tape's array offsets (floats), for tools and tests that read a tape back: out[0..n) in this order --
+//   per_block, X, A, Q, K, V, O, X1, Y, HR, P, SA, SF, PP, MK, XL, SL, FLAGS, total  (19 values; arrays of block l start at l * per_block)
+extern "C" int re_sasrec_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L, int64_t* out, int64_t n) {
+    if (B <= 0 || S <= 0 || D <= 0 || L <= 0 || !out || n < 0) return RE_EINVAL;
+    const EncTape t = enc_tape_layout(B, S, D, L);
+    const int64_t v[19] = {t.per_block, t.off_X, t.off_A, t.off_Q, t.off_K, t.off_V, t.off_O, t.off_X1, t.off_Y, t.off_HR, t.off_P, t.off_SA,
+                           t.off_SF, t.off_PP, t.off_MK, t.off_XL, t.off_SL, t.off_FLAGS, t.total};
+    for (int64_t i = 0; i < n && i < 19; ++i) out[i] = v[i];
+    return RE_OK;
+}
+
 template <int D>
 static int enc_fwd_launch_d(const float* x0, const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P,
                             float ds, uint32_t thresh, uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan,

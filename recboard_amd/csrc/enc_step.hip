@@ -41,6 +41,11 @@ int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tap
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
+// ---- the wave-per-tile form of the step at D = 64 (enc_wave.hip)
+size_t enc_wave_wfrag_bytes(int64_t L);
+int enc_wave_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
+                         uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
+                         float* gtape, float* slab, float scale, uint32_t* wf, hipStream_t s);
 
 template <int D>
 static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds,
@@ -87,13 +92,22 @@ extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Pt
     const EncHead H{E, R, e_off, pos, neg, kind, count, loss, dU_rows, g_rows, keys, (unsigned long long*)loss_ws};
     if (ncu < 1) ncu = 256;
     const int64_t mt = enc_plan_max_tiles(B, S);
-    const int grid = (int)(mt < ncu ? mt : ncu);
+    // D = 64: one WAVE per tile (enc_wave.hip) -- a workgroup is four tiles at most and many fit a CU, so the grid is not the CU count
+    // but the plan's item bound (the plan should then be made for ~1024 workgroups: one tile per item while the batch allows it)
+    const int grid = (D == 64) ? (int)(mt < 1024 ? mt : 1024) : (int)(mt < ncu ? mt : ncu);
     if (grid > 1024) return RE_EUNSUPPORTED;
     float* slab = (float*)ws;
     float* part = slab + (size_t)1024 * L * EG_NVEC * D;
     float* ppart = part + enc_wgrad_part_floats(D, L);
     float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
     hipStream_t s = (hipStream_t)stream;
+    if (D == 64) {
+        const int64_t NR = 16 * mt;
+        uint32_t* wf = (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * NR * D)) + 255) & ~(uintptr_t)255);
+        const int rcw = enc_wave_step_launch(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, wf, s);
+        if (rcw != RE_OK) return rcw;
+        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
+    }
     const int rc = D == 128 ? enc_step_launch_d<128>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s)
                             : enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s);
     if (rc != RE_OK) return rc;

@@ -429,11 +429,14 @@ def prep_views(blob, B, S, cached=False):
     return pb
 
 
-def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4, split=False):
+def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4, split=False,
+                      ncu=None):
     """Batch preparation as ONE launch (re_sasrec_batch_prep): valid mask, count, scatter destination rows, the encoder's work plan;
     with `blob` (a static buffer of prep_layout(B, S) bytes) also copies (seq, pos, neg) into it and, with `state` (int32[4]),
     writes the step scalars -- the staging launch of a captured step.  -> PreparedBatch (views into the blob).
-    split: sequences of 3 - 4 tiles may become two work items in two workgroups (training launches with a zero-initialised tape only)."""
+    split: sequences of 3 - 4 tiles may become two work items in two workgroups (training launches with a zero-initialised tape only).
+    ncu: the number of workgroups the plan's items should fill (default: the device's CUs, one workgroup per CU; the wave-per-tile
+    step at D = 64 takes 1024 -- one tile per item while the batch allows it)."""
     _req(seq, torch.int64, "seq")
     B, S = seq.shape
     if pos is not None:
@@ -445,7 +448,7 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     if state is not None:
         _req(state, torch.int32, "state")
     have = pos is not None
-    lib.check(lib.load().re_sasrec_batch_prep(_p(seq), _p(pos), _p(neg), B, S, num_cus(seq.device), int(max_tiles), int(bool(split)),
+    lib.check(lib.load().re_sasrec_batch_prep(_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), int(bool(split)),
                                               _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None,
                                               _p(pb.neg) if copy and have else None, _p(pb.valid) if have else None,
                                               _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
@@ -597,6 +600,27 @@ def sasrec_tape_reset_flags(tape, B, S):
     mt = B * ((S + 15) // 16)
     if tape.numel() >= mt * 8 + 16:
         tape[-(mt * 8 + 16):].zero_()
+
+
+TAPE_FIELDS = ("per_block", "X", "A", "Q", "K", "V", "O", "X1", "Y", "HR", "P", "SA", "SF", "PP", "MK", "XL", "SL", "FLAGS", "total")
+
+
+def sasrec_tape_array(tape, plan, B, S, D, L, name, block):
+    """One [NR, D] activation array of a training tape, scattered back to [B, S, D] through the plan's row map (rows without a
+    compact row -- the pads in front of a sequence -- stay zero).  Diagnostics and tests (host syncs)."""
+    import ctypes
+    out = (ctypes.c_int64 * len(TAPE_FIELDS))()
+    lib.check(lib.load().re_sasrec_tape_layout(B, S, D, L, ctypes.cast(out, ctypes.c_void_p), len(TAPE_FIELDS)), "re_sasrec_tape_layout")
+    off = dict(zip(TAPE_FIELDS, out))
+    w = plan.view(torch.int32)
+    mt = B * ((S + 15) // 16)
+    nr = 16 * int(w[1])
+    rm = w[(8 + mt + 1) // 2 * 2:][: 2 * 16 * mt].view(-1, 2)[:nr, 0].long()          # gid of every compact row (-1: dummy)
+    a = tape[block * off["per_block"] + off[name]:][: nr * D].view(nr, D)
+    dense = torch.zeros(B * S, D, dtype=tape.dtype, device=tape.device)
+    live = rm >= 0
+    dense[rm[live]] = a[live]
+    return dense.view(B, S, D)
 
 
 def sasrec_plan_rows(B, S):

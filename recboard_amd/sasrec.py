@@ -292,7 +292,7 @@ class SASRecEngine:
         """Per-batch preparation of the fused step as ONE engine launch (re_sasrec_batch_prep; what the reference does at the top of
         `fit`, SASRec/main.py:199-204, plus the encoder's work plan): valid mask, number of valid positions, destination rows of the
         3*B*S gradient contributions, work items.  No host sync.  -> ops.PreparedBatch."""
-        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split())
+        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu())
 
     def check_handover(self):
         """Raise if a split sequence's halves ever timed out waiting for each other (Coach calls this once per epoch; host sync)."""
@@ -304,9 +304,18 @@ class SASRecEngine:
                                    "step's workgroup counts disagree); that step did nothing" if err == 2 else
                                    "recengine: a split sequence's work items did not meet (hand-over time-out); results of that step are invalid")
 
+    def _wave_step(self):
+        """The training step runs the wave-per-tile kernel (csrc/enc_wave.hip: D = 64, one launch for forward + criterion + backward)."""
+        return bool(self.D == 64 and self.fused_item_kernel and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
+
+    def _plan_ncu(self):
+        """Workgroups the batch plan's items should fill: the wave-per-tile step wants one tile per item (many workgroups per CU)."""
+        return 1024 if self._wave_step() else None
+
     def _split(self):
-        """Long sequences as two work items in two workgroups: the fused training step (its tape carries the hand-over flags)."""
-        return bool(self.split_long and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
+        """Long sequences as two work items in two workgroups: the workgroup-per-item form of the fused training step (its tape carries
+        the hand-over flags).  The wave-per-tile step gives every tile a wave of its own instead."""
+        return bool(self.split_long and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows and not self._wave_step())
 
     def _buffers(self, B, S):
         key = (B, S)
@@ -447,7 +456,7 @@ class SASRecEngine:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split())
+                                       max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu())
             body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -473,7 +482,7 @@ class SASRecEngine:
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split())
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu())
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:

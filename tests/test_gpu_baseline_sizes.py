@@ -49,7 +49,13 @@ def test_c2_sasrec_graph_step_at_bench_config_matches_oracle():
     seed2 = m._step_seed()                                               # the seed of the step that follows
     loss = m.train_step_graph(dev(seq), dev(pos), dev(neg)).item()       # a pure replay
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref = osas.fit(P, torch.from_numpy(seq), torch.from_numpy(pos), torch.from_numpy(neg), "BCE", L, drop=dict(p=p, seed=seed2))
+    # relu kinks: of the ~600 k pre-activations of a batch this size a few lie within rounding of zero, where each side's own rounding
+    # sets the gate -- the oracle takes the engine's gate (the tape's relu(h) > 0) wherever ITS pre-activation is within 2e-5 of zero
+    from recboard_amd import ops
+    W = m._buffers(B, S)
+    plan = ops.prep_views(m._graphs[(B, S, True, True)]["blob"], B, S).plan
+    gates = {l: ((ops.sasrec_tape_array(W["tape"], plan, B, S, D, L, "HR", l) > 0).cpu(), 2e-5) for l in range(L)}
+    ref = osas.fit(P, torch.from_numpy(seq), torch.from_numpy(pos), torch.from_numpy(neg), "BCE", L, drop=dict(p=p, seed=seed2), gates=gates)
     ref.backward()
     np.testing.assert_allclose(loss, ref.item(), rtol=2e-5)
     Gv = m.arena.views(m.arena.grad)

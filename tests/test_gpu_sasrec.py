@@ -66,6 +66,7 @@ def test_train_step_matches_oracle_adam_trajectory(encoder, loss):
     P = osas.params_from_npz(z, requires_grad=True)
     opt = torch.optim.Adam(list(P.values()), lr=5e-4, betas=(0.9, 0.999), weight_decay=1e-6)
     seq, pos, neg = (torch.from_numpy(z[k]) for k in ("in/seq", "in/pos", "in/neg"))
+    g0 = {}
     for step in range(3):
         l_gpu = m.train_step(seq.cuda(), pos.cuda(), neg.cuda())
         opt.zero_grad()
@@ -74,10 +75,22 @@ def test_train_step_matches_oracle_adam_trajectory(encoder, loss):
         for p in P.values():       # params absent from the graph still take the dense L2 + moment update
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
+        if step == 0:
+            g0 = {k: p.grad.detach().abs().numpy().copy() for k, p in P.items()}
         opt.step()
         np.testing.assert_allclose(l_gpu.item(), l_cpu.item(), rtol=2e-5)
+    # Adam's step is lr * m / (sqrt(v) + eps): a RELATIVE error of a gradient element becomes the same relative error of its step.
+    # Gradients are held to 1e-4 of the tensor's largest element (the golden tests), i.e. an element of size |g| may be off by
+    # 1e-4 gmax / |g| relatively -- 100 % for the elements that are zero in exact arithmetic (b_k: softmax is shift-invariant, what
+    # any implementation computes there is its own rounding noise).  So every element is held to what that bound allows over the
+    # three steps: 2e-5 + 1e-3 |theta| + 3 lr min(1, 2e-4 gmax / |g|).
+    lr = 5e-4
     for k, p in m.params.items():
-        np.testing.assert_allclose(p.detach().cpu().numpy(), P[k].detach().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)
+        a, b = p.detach().cpu().numpy(), P[k].detach().numpy()
+        g = g0[k]
+        slack = 3 * lr * np.minimum(1.0, 2e-4 * g.max() / np.maximum(g, 1e-30)) if g.max() > 0 else 0.0
+        bad = np.abs(a - b) > 2e-5 + 1e-3 * np.abs(b) + slack
+        assert not bad.any(), (k, int(bad.sum()), float(np.abs(a - b)[bad].max()))
 
 
 @pytest.mark.parametrize("fixture", ["sasrec_bce.npz", "sasrec_bce_d128.npz"])
