@@ -284,6 +284,19 @@ __global__ __launch_bounds__(256) void enc_wave_prep_k(SasrecParams P, int L, ui
     dst[((s * 2 + q) * 2 + 1) * 64] = (wv_u32x4){md[0], md[1], md[2], md[3]};
 }
 
+// Phase stamps (diagnostic build only: `make -C recboard_amd/csrc encprof`, scripts/wave_phases.py): lane 0 of wave 0 of workgroup 0
+// records the shader clock at the phase boundaries of its first item's tile.
+#ifdef WV_PROFILE
+#define WV_MARKS 96
+__device__ unsigned long long g_wave_marks[WV_MARKS];
+extern "C" int re_dbg_enc_marks_wave(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_marks), sizeof(unsigned long long) * WV_MARKS) == hipSuccess ? 0 : 1;
+}
+#define WV_MARK() do { if (blockIdx.x == 0 && tid == 0 && k == 0 && mk < WV_MARKS) g_wave_marks[mk] = __builtin_amdgcn_s_memtime(); ++mk; } while (0)
+#else
+#define WV_MARK() do { } while (0)
+#endif
+
 // LDS carve-up (floats): parameters | per-wave vector-gradient stage | dK / dV exchange slots | transpose scratch | loss partials
 __host__ __device__ inline size_t wv_lds_floats(int L) {
     return (size_t)(WV_NPAR * L + 2) * WV_D + (size_t)WV_NW * L * EG_NVEC * WV_D + (size_t)WV_XCH_SLOTS * 1024 + WV_NW * WV_TR + 16;
@@ -390,7 +403,16 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             }
         }
         // =================================================== forward ===================================================
-        WFrag w;
+        // Weight fragments: two register sets, each requested one product ahead of its use (a request issued right in front of its
+        // product exposes a whole L2 round trip per product: 26 of them were half of the launch).
+        WFrag wa, wb;
+        int mk = 0; (void)mk;
+        WV_MARK();
+        wv_wload(wa, wf, 0, 0, 0, lane);                  // block 0's Wq
+        // the loss head's indices: requested now, used after the last block
+        int64_t hpr = 0, hng = 0;
+        if (gid >= 0) { hpr = H.pos[gid] + H.e_off; hng = H.neg[gid] + H.e_off; }
+        const float hgs = 1.0f / (float)H.count[0];
         for (int l = 0; l < L; ++l) {
             float* tp = tape + (int64_t)l * T.per_block;
             const float* par = s_par + l * WV_NPAR * WV_D;
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
 #pragma unroll
                 for (int i = 0; i < 16; ++i) a[i] = fmaf((x[i] - mean) * rstd, gw[i], pv[i]);
             }
-            wv_wload(w, wf, l, 0, 0, lane);
+            wv_wload(wb, wf, l, 1, 0, lane);              // Wk
             wv_st_t(tp + T.off_X + row0 * WV_D, c, g, x);
             wv_st_t(tp + T.off_A + row0 * WV_D, c, g, a);
             // ---- q = a Wq^T + bq, k = x Wk^T + bk (T), v = x Wv^T + bv (F)
@@ -412,19 +434,20 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             wv_split64(a, ao);
             wv_split64(x, xo);
             float q[16], kk[16], vf[16];
-            wv_gemm_t(w, ao, q);
-            wv_wload(w, wf, l, 1, 0, lane);
+            WV_MARK();
+            wv_gemm_t(wa, ao, q);
+            wv_wload(wa, wf, l, 2, 0, lane);              // Wv
             wv_par_t(par + 2 * WV_D, g, pv);
 #pragma unroll
             for (int i = 0; i < 16; ++i) q[i] += pv[i];
-            wv_gemm_t(w, xo, kk);
-            wv_wload(w, wf, l, 2, 0, lane);
+            wv_gemm_t(wb, xo, kk);
+            wv_wload(wb, wf, l, 3, 0, lane);              // Wo
             float bk[16];
             wv_par_t(par + 3 * WV_D, g, bk);
 #pragma unroll
             for (int i = 0; i < 16; ++i) kk[i] += bk[i];
-            wv_gemm_f(xo, w, vf);
-            wv_wload(w, wf, l, 3, 0, lane);
+            wv_gemm_f(xo, wa, vf);
+            wv_wload(wa, wf, l, 4, 0, lane);              // W1
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float bvs = par[4 * WV_D + 16 * s + c];
@@ -435,6 +458,7 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             wv_st_t(tp + T.off_K + row0 * WV_D, c, g, kk);
             wv_st_f(tp + T.off_V + row0 * WV_D, c, g, vf);
             if (multi) __syncthreads();                   // (with vmcnt(0): the item's k, v of this block are in L2 for its other waves)
+            WV_MARK();
             // ---- scores Rt(S)[kt] = q k^T / sqrt(D) over the key tiles
             Op64 qo;
             wv_split64(q, qo);
@@ -521,6 +545,7 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
                     }
                 }
             }
+            WV_MARK();
             // ---- o = Pd v + w b_v   (T(o) = sum over key tiles of F(v)-as-A x Rt(Pd)-as-B)
             float o[16];
             {
@@ -558,8 +583,9 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             {
                 Op64 oo;
                 wv_split64(o, oo);
-                wv_gemm_t(w, oo, x1);
-                wv_wload(w, wf, l, 4, 0, lane);
+                WV_MARK();
+                wv_gemm_t(wb, oo, x1);
+                wv_wload(wb, wf, l, 5, 0, lane);          // W2
                 wv_par_t(par + 5 * WV_D, g, pv);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x1[i] += pv[i] + x[i];
@@ -582,8 +608,10 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             {
                 Op64 yo;
                 wv_split64(y, yo);
-                wv_gemm_t(w, yo, hr);
-                wv_wload(w, wf, l, 5, 0, lane);
+                WV_MARK();
+                wv_gemm_t(wa, yo, hr);
+                if (l + 1 < L) wv_wload(wa, wf, l + 1, 0, 0, lane);   // the next block's Wq,
+                else wv_wload(wa, wf, L - 1, 5, 1, lane);            // or the backward's first: W2 of the last block
                 wv_par_t(par + 8 * WV_D, g, pv);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -603,7 +631,8 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
                 Op64 ho;
                 wv_split64(hr, ho);
                 float z[16];
-                wv_gemm_t(w, ho, z);
+                WV_MARK();
+                wv_gemm_t(wb, ho, z);
                 wv_par_t(par + 9 * WV_D, g, pv);
                 if (thresh) m2 = 0u;
 #pragma unroll
@@ -620,11 +649,12 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             }
             // the block's mask bits for the backward: one word per lane ([tile][4][64] words of the tape's mask array)
             {
-                uint32_t* mk = reinterpret_cast<uint32_t*>(tp + T.off_MK) + row0 * 16;
-                mk[lane] = m2 | (hmask << 16);
-                mk[64 + lane] = amask;
+                uint32_t* mkw = reinterpret_cast<uint32_t*>(tp + T.off_MK) + row0 * 16;
+                mkw[lane] = m2 | (hmask << 16);
+                mkw[64 + lane] = amask;
             }
         }
+        WV_MARK();
         // ---- u = LN_last(x_L)
         float mean_l, rstd_l, uu[16], xh[16], glw[16];
         {
@@ -642,8 +672,7 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
         // ---- loss head (SASRec/main.py:199-215): pl = <u, E[pos]>, nl = <u, E[neg]>; the rows' gradient contributions and keys
         float du[16];
         {
-            int64_t pr = 0, ng = 0;
-            if (gid >= 0) { pr = H.pos[gid] + H.e_off; ng = H.neg[gid] + H.e_off; }
+            int64_t pr = hpr, ng = hng;
             const bool realh = item > 0 && item < H.R;
             const bool ok = realh && pr > 0 && pr < H.R && ng > 0 && ng < H.R;
             if (!ok) { pr = 0; ng = 0; }
@@ -655,7 +684,7 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             for (int i = 0; i < 16; ++i) { pl = fmaf(uu[i], ep[i], pl); nl = fmaf(uu[i], en[i], nl); }
             pl = wv_gsum(pl);
             nl = wv_gsum(nl);
-            const float gs = 1.0f / (float)H.count[0];
+            const float gs = hgs;
             float dpl, dnl;
             if (H.kind == RE_LOSS_BCE) { dpl = -re_sigmoid(-pl) * gs; dnl = re_sigmoid(nl) * gs; }
             else { const float sg = re_sigmoid(nl - pl) * gs; dpl = -sg; dnl = sg; }
@@ -681,6 +710,7 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             }
         }
         // =================================================== backward ===================================================
+        WV_MARK();
         float dx[16];
         {
             // lastLN: dgamma, dbeta, dx_L
@@ -698,8 +728,8 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             float* gp = gtape + (int64_t)l * EG_NMAT * NR * WV_D + row0 * WV_D;
             float* ac = acc_w + (size_t)l * EG_NVEC * WV_D;
             if (l != L - 1) { ac[10 * WV_D + lane] = 0.f; ac[11 * WV_D + lane] = 0.f; }
-            const uint32_t* mk = reinterpret_cast<const uint32_t*>(tp + T.off_MK) + row0 * 16;
-            const unsigned mw = mk[lane], amask = mk[64 + lane];
+            const uint32_t* mkw = reinterpret_cast<const uint32_t*>(tp + T.off_MK) + row0 * 16;
+            const unsigned mw = mkw[lane], amask = mkw[64 + lane];
             float pv[16], t1[16];
             // ---- pad mask of the block output, dO2 = dX' * dropout2 mask
             float dz[16];
@@ -708,7 +738,12 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
                 dx[i] = dead ? 0.f : dx[i];
                 dz[i] = !thresh ? dx[i] : ((mw >> i) & 1u) ? dx[i] * drop_scale : 0.f;
             }
-            wv_wload(w, wf, l, 5, 1, lane);
+            wv_wload(wb, wf, l, 4, 1, lane);              // W1 (wa holds W2)
+            // this block's tape rows for the phases below: requested now
+            float x1[16], vt_own[16];
+            wv_ld_t(tp + T.off_X1 + row0 * WV_D, c, g, x1);
+            wv_ld_t(tp + T.off_V + row0 * WV_D, c, g, vt_own);
+            const float2 ppw = *reinterpret_cast<const float2*>(tp + T.off_PP + (row0 + c) * 2);
             wv_st_t(gp + 0 * NR * WV_D, c, g, dz);
             ac[5 * WV_D + lane] = wv_colsum(dz, c);
             // ---- A. dH = (dO2 W2) * (hr > 0) * scale
@@ -716,8 +751,9 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             {
                 Op64 o;
                 wv_split64(dz, o);
-                wv_gemm_t(w, o, dh);
-                wv_wload(w, wf, l, 4, 1, lane);
+                WV_MARK();
+                wv_gemm_t(wa, o, dh);
+                wv_wload(wa, wf, l, 3, 1, lane);          // Wo
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dh[i] = ((mw >> (16 + i)) & 1u) ? dh[i] * drop_scale : 0.f;
             }
@@ -728,16 +764,17 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             {
                 Op64 o;
                 wv_split64(dh, o);
-                wv_gemm_t(w, o, dy);
-                wv_wload(w, wf, l, 3, 1, lane);
+                WV_MARK();
+                wv_gemm_t(wb, o, dy);
+                wv_wload(wb, wf, l, 0, 1, lane);          // Wq
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dy[i] += dx[i];
             }
             // ---- C. LN_f backward: dgamma_f, dbeta_f, dX1
             float dx1[16];
             {
-                float x1[16], mean, rstd;
-                wv_ld_t(tp + T.off_X1 + row0 * WV_D, c, g, x1);
+                float mean, rstd;
+                WV_MARK();
                 wv_ln_stats(x1, mean, rstd);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { x1[i] = (x1[i] - mean) * rstd; t1[i] = dy[i] * x1[i]; }
@@ -753,13 +790,19 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             {
                 Op64 o;
                 wv_split64(dx1, o);
-                wv_gemm_t(w, o, dO);
-                wv_gemm_f(o, w, dOf);
-                wv_wload(w, wf, l, 0, 1, lane);
+                WV_MARK();
+                wv_gemm_t(wa, o, dO);
+                wv_gemm_f(o, wa, dOf);
+                wv_wload(wa, wf, l, 1, 1, lane);          // Wk
             }
             // ---- E. attention backward (enc_bwd_item.h, same arithmetic)
-            const float2 ppw = *reinterpret_cast<const float2*>(tp + T.off_PP + (row0 + c) * 2);
+            WV_MARK();
             const float ppad = ppw.x, wvv = ppw.y;
+            // q and the own tile's k in F layout, x for LN_a's backward: requested here, used behind the score-type products
+            float qf[16], kf_own[16], xx[16];
+            wv_ld_f(tp + T.off_Q + row0 * WV_D, c, g, qf);
+            wv_ld_f(tp + T.off_K + row0 * WV_D, c, g, kf_own);
+            wv_ld_t(tp + T.off_X + row0 * WV_D, c, g, xx);
             float bvt[16], tdot = 0.f;
             wv_par_t(par + 4 * WV_D, g, bvt);
 #pragma unroll
@@ -776,7 +819,12 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
                 if (kt < klo || kt > tt) continue;
                 p[kt] = *reinterpret_cast<const f32x4*>(tp + T.off_P + (row0 + c) * EP_PW + 16 * kt + 4 * g);
                 float vt[16];
-                wv_ld_t(tp + T.off_V + (irow0 + 16 * kt) * WV_D, c, g, vt);
+                if (kt == tt) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) vt[i] = vt_own[i];
+                } else {
+                    wv_ld_t(tp + T.off_V + (irow0 + 16 * kt) * WV_D, c, g, vt);
+                }
                 Op64 vo;
                 wv_split64(vt, vo);
                 const f32x4 raw = wv_mm64(vo, doo, (f32x4){0.f, 0.f, 0.f, 0.f});   // (dO_i . v_j) for token i = c, keys 4 g + j
@@ -797,8 +845,7 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ds[kt][j] = p[kt][j] * (dp[kt][j] - srow) * inv_sqrt_d;
             // dQ = dS K + dS_pad b_k;  per key tile dV_kt = Pd^T dO, dK_kt = dS^T Q
-            float qf[16];
-            wv_ld_f(tp + T.off_Q + row0 * WV_D, c, g, qf);
+            WV_MARK();
             Op16 qo4[4], do4[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -815,7 +862,12 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             for (int kt = 0; kt < 4; ++kt) {
                 if (kt < klo || kt > tt) continue;
                 float kf[16];
-                wv_ld_f(tp + T.off_K + (irow0 + 16 * kt) * WV_D, c, g, kf);
+                if (kt == tt) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) kf[i] = kf_own[i];
+                } else {
+                    wv_ld_f(tp + T.off_K + (irow0 + 16 * kt) * WV_D, c, g, kf);
+                }
                 Op16 dso, pdr, dsr;
                 wv_split16(ds[kt][0], ds[kt][1], ds[kt][2], ds[kt][3], dso);
                 f32x4 tr;
@@ -903,21 +955,22 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
             {
                 Op64 o;
                 wv_split64(dqv, o);
-                wv_gemm_t(w, o, da);
-                wv_wload(w, wf, l, 1, 1, lane);
+                WV_MARK();
+                wv_gemm_t(wb, o, da);
+                wv_wload(wb, wf, l, 2, 1, lane);          // Wv
                 wv_split64(dk, o);
-                wv_gemm_t(w, o, t1);
-                wv_wload(w, wf, l, 2, 1, lane);
+                wv_gemm_t(wa, o, t1);
+                if (l > 0) wv_wload(wa, wf, l - 1, 5, 1, lane);   // the next block's W2
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dx1[i] += t1[i];
                 wv_split64(dv, o);
-                wv_gemm_t(w, o, t1);
+                wv_gemm_t(wb, o, t1);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dx1[i] += t1[i];
             }
             {
-                float xx[16], mean, rstd;
-                wv_ld_t(tp + T.off_X + row0 * WV_D, c, g, xx);
+                float mean, rstd;
+                WV_MARK();
                 wv_ln_stats(xx, mean, rstd);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { xx[i] = (xx[i] - mean) * rstd; t1[i] = da[i] * xx[i]; }
@@ -929,6 +982,7 @@ __global__ __launch_bounds__(WV_NT) void enc_wave_step_k(SeEmbed em, const int64
                 for (int i = 0; i < 16; ++i) dx[i] = dx1[i] + t1[i];
             }
         }
+        WV_MARK();
         // ---- embedding backward (re_sasrec_embed_bwd fused in): pad rows -> 0, the embedding's dropout mask, * sqrt(D)
         {
 #pragma unroll
