@@ -61,7 +61,7 @@ static inline int enc_bwd_grid(int64_t B, int64_t S, int32_t ncu) {
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L) {
     if (B <= 0 || S <= 0 || D <= 0 || L <= 0) return 256;
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
-    const int64_t nwg = 1024;   // upper bound of the launch grid (ncu)
+    const int64_t nwg = enc_slab_rows(B, S);   // upper bound of the launch grid (ncu), or one row per tile
     // (+ the weight-fragment planes of the wave-per-tile step, enc_wave.hip: L x 6 matrices x 2 orientations x 16 KB, 256-byte aligned)
     return (size_t)(nwg * L * EG_NVEC * D + enc_wgrad_part_floats(D, L) + enc_wgrad_ppart_floats(B, D) + L * EG_NMAT * NR * D) * sizeof(float) + 512 +
            (size_t)L * 6 * 2 * 4096 * 4 + 256;
@@ -93,7 +93,7 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     if (grid > 1024) return RE_EUNSUPPORTED;
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
     float* slab = (float*)ws;
-    float* part = slab + (size_t)1024 * L * EG_NVEC * D;
+    float* part = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
     float* ppart = part + enc_wgrad_part_floats(D, L);
     float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
     hipStream_t s = (hipStream_t)stream;

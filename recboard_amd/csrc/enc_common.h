@@ -83,6 +83,8 @@ struct EncPlan {
     const int2* rowmap;
 };
 __host__ __device__ inline int64_t enc_plan_max_tiles(int64_t B, int64_t S) { return B * ((S + 15) / 16); }
+// rows of the vector-gradient slab in the backward's workspace: one per workgroup (<= 1024) or one per tile (enc_tile.hip)
+__host__ __device__ inline int64_t enc_slab_rows(int64_t B, int64_t S) { const int64_t mt = enc_plan_max_tiles(B, S); return mt > 1024 ? mt : 1024; }
 __host__ __device__ inline int64_t enc_plan_rowmap_word(int64_t B, int64_t S) { return (EP_HDR + enc_plan_max_tiles(B, S) + 1) / 2 * 2; }
 __host__ __device__ inline size_t enc_plan_bytes(int64_t B, int64_t S) {
     const int64_t mt = enc_plan_max_tiles(B, S);

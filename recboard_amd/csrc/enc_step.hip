@@ -41,11 +41,11 @@ int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tap
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
-// ---- the wave-per-tile form of the step at D = 64 (enc_wave.hip)
-size_t enc_wave_wfrag_bytes(int64_t L);
-int enc_wave_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
-                         uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
-                         float* gtape, float* slab, float scale, uint32_t* wf, hipStream_t s);
+// ---- the four-waves-per-tile form of the step at D = 64 (enc_tile.hip)
+size_t enc_tile_wfrag_bytes(int64_t L);
+int enc_tile_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
+                         uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, int tpw, const EncHead& H,
+                         float* dx0, float* gtape, float* slab, float scale, uint32_t* wf, hipStream_t s);
 
 template <int D>
 static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds,
@@ -66,8 +66,8 @@ static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, i
 extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
                                       const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
                                       const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
-                                      const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
-                                      const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
+                                      const void* plan, int32_t ncu, int32_t max_tiles, float* u, void* tape, size_t tape_bytes, int64_t e_off,
+                                      int kind, const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
                                       size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
                                       float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream) {
     re_clear_error();
@@ -97,16 +97,16 @@ extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Pt
     const int grid = (D == 64) ? (int)(mt < 1024 ? mt : 1024) : (int)(mt < ncu ? mt : ncu);
     if (grid > 1024) return RE_EUNSUPPORTED;
     float* slab = (float*)ws;
-    float* part = slab + (size_t)1024 * L * EG_NVEC * D;
+    float* part = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
     float* ppart = part + enc_wgrad_part_floats(D, L);
     float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
     hipStream_t s = (hipStream_t)stream;
     if (D == 64) {
         const int64_t NR = 16 * mt;
         uint32_t* wf = (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * NR * D)) + 255) & ~(uintptr_t)255);
-        const int rcw = enc_wave_step_launch(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, wf, s);
+        const int rcw = enc_tile_step_launch(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, max_tiles >= 4 ? 4 : max_tiles == 2 ? 2 : 1, H, dx0, gtape, slab, scale, wf, s);
         if (rcw != RE_OK) return rcw;
-        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
+        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, -1, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
     }
     const int rc = D == 128 ? enc_step_launch_d<128>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s)
                             : enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s);

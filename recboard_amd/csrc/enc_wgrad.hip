@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
     const int cg = job % cgs, v = (job / cgs) % EG_NVEC, l = job / (cgs * EG_NVEC);
     const EncPlan PL = enc_plan_view(planp, B, S);
     const int n_items = PL.hdr[0];
-    const int nact = n_items < nwg ? n_items : nwg;
+    const int nact = nwg < 0 ? PL.hdr[1] : (n_items < nwg ? n_items : nwg);   // nwg < 0: one slab row per TILE (enc_tile.hip)
     const int lane = tid & 63, wave = tid >> 6;
     const float* sl = slab + ((int64_t)l * EG_NVEC + v) * D + cg * 64 + lane;
     const int64_t stride = (int64_t)L * EG_NVEC * D;

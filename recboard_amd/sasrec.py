@@ -286,7 +286,11 @@ class SASRecEngine:
             return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K, prep=prep)
 
     def _max_tiles(self):
-        return 4 if self.D == 64 else 2     # tiles of 16 rows per work item (LDS capacity of the encoder kernels)
+        """Tiles of 16 rows per work item: the LDS capacity of the workgroup-per-item kernels (4 at D = 64, 2 at D = 128), or the tiles
+        per workgroup of the four-waves-per-tile step (`tiles_per_wg`: 1, 2 or 4; 4 covers every sequence of S <= 64)."""
+        if self._wave_step():
+            return int(getattr(self, "tiles_per_wg", 4))
+        return 4 if self.D == 64 else 2
 
     def prepare_batch(self, seq, pos, neg):
         """Per-batch preparation of the fused step as ONE engine launch (re_sasrec_batch_prep; what the reference does at the top of
@@ -357,7 +361,8 @@ class SASRecEngine:
                 loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
                                                W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
                                                W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
-                                               G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev)
+                                               G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev,
+                                               max_tiles=self._max_tiles())
             else:
                 loss = ops.sasrec_encoder_fwd_loss(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind,
                                                    pb.count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], e_off=1,

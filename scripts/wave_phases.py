@@ -11,9 +11,13 @@ from recboard_amd.sasrec import SASRecEngine
 ap = argparse.ArgumentParser()
 ap.add_argument("--kind", default="beauty")
 ap.add_argument("--B", type=int, default=512)
+ap.add_argument("--tpw", type=int, default=4)
+ap.add_argument("--ncu", type=int, default=1024)
 args = ap.parse_args()
 B, S, D, L, N = args.B, 50, 64, 2, 12101
 m = SASRecEngine(N, S, D, L, dropout_rate=0.5, loss="BCE", lr=5e-4, weight_decay=1e-6, seed=1)
+m.tiles_per_wg = args.tpw
+m._plan_ncu = lambda: args.ncu
 rng = np.random.default_rng(0)
 lens = np.clip(rng.geometric(1 / 5.9, B) + 1, 1, S - 1) if args.kind == "beauty" else np.full(B, int(args.kind))
 seq = np.zeros((B, S), np.int64)
@@ -34,8 +38,8 @@ assert Lb.re_dbg_enc_marks_wave(buf) == 0
 t = np.array(list(buf), dtype=np.int64)
 nz = np.nonzero(t)[0]
 t = t[: nz[-1] + 1]
-names = ["x0"] + ["LN_a+splits", "QKV", "scores+softmax", "PV", "Wo+LN_f", "W1", "W2"] * L + ["lastLN+head", "lastLN bwd"] + \
-        ["dz", "W2'", "W1'", "LN_f'", "Wo' x2", "attn dP/dS", "attn dQ/dK/dV", "Wq'Wk'Wv'", "LN_a'"] * L + ["embed'"]
+names = ["x0"] + ["LN_a,put", "QKV", "scores,softmax", "PV,put", "Wo,LN_f,put", "W1,put", "W2"] * L + ["lastLN,head,sync"] + \
+        ["lastLN'"] + ["dz,W2'", "W1',LN_f'", "Wo'", "attn dP/dS", "attn dQ/dK/dV,put", "Wq'Wk'Wv',LN_a'"] * L + ["embed'"]
 d = np.diff(t)
 print("total", int(t[-1] - t[0]), "ticks")
 for i, x in enumerate(d):

@@ -177,7 +177,7 @@ def test_one_launch_item_kernel_equals_two_launches(D, p):
 
 @pytest.mark.parametrize("loss,p,ncu", [("BCE", 0.5, None), ("BPR", 0.0, None), ("BCE", 0.3, 24)])
 def test_wave_per_tile_step_matches_oracle(loss, p, ncu):
-    """D = 64: re_sasrec_encoder_step runs one WAVE per tile (csrc/enc_wave.hip: activations in registers, bf16 hi / mid split products
+    """D = 64: re_sasrec_encoder_step runs four waves per tile (csrc/enc_tile.hip: activations in registers, bf16 hi / mid split products
     on the XDL pipe) -- against the CPU oracle with the same dropout masks: loss to 2e-5, every gradient to the 1e-4 bound; short
     sequences sharing tiles, sequences of 2 - 4 tiles (k, v and the partial dK, dV cross waves), a full-length batch, and (ncu = 24)
     plans whose items hold several tiles.  The oracle takes the engine's relu gates where its own pre-activation is within 2e-5 of
