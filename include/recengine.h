@@ -308,15 +308,16 @@ int re_sasrec_encoder_fwd(const float* x0, const float* E, int64_t R, const floa
  * dx0_rows = g_rows region 0, dPtab given), with the two item kernels as ONE launch (per work item: forward, criterion, backward)
  * + the weight-gradient and reduction launches.  Same results, bit for bit.  ws as re_sasrec_encoder_bwd; loss_ws as
  * re_sasrec_encoder_fwd_loss.
- *   D = 64 runs FOUR WAVES PER TILE (csrc/enc_tile.hip: a tile's activations in registers, one 16-feature strip per wave, bf16
- *   hi / mid split products on the XDL pipe -- results within the 1e-4 bound of the fp32 kernels', not their bits): a workgroup is
- *   `max_tiles` (1, 2 or 4) tiles = the largest work item of the plan, which must have been made with that max_tiles and without
- *   split_long; `ncu` is then ignored (the grid is the plan's item bound).  D = 128 ignores max_tiles. */
+ *   D = 64 runs ONE TILE PER WORKGROUP, four waves per tile (csrc/enc_tile.hip: a tile's activations in registers, one 16-feature
+ *   strip per wave, bf16 hi / mid split products on the XDL pipe -- results within the 1e-4 bound of the fp32 kernels', not their
+ *   bits) whenever the plan says every tile can have a resident workgroup of its own (re_sasrec_batch_prep decides per batch:
+ *   at most 1024 tiles, at most 256 of them tiles of sequences longer than 16 rows, no split_long), and the workgroup-per-item
+ *   kernel otherwise; both are enqueued, one of them returns at once.  The tape's flag words must be zero before the first launch. */
 int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
                            const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
                            const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
-                           const void* plan, int32_t ncu, int32_t max_tiles, float* u, void* tape, size_t tape_bytes, int64_t e_off,
-                           int kind, const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
+                           const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
+                           const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
                            size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
                            float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
 // ---- weight gradients (enc_wgrad.hip) ---------------------------------------------------------------------------------------
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
                      int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
-                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s);
+                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile = 0);
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 
@@ -64,7 +64,7 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
     const int64_t nwg = enc_slab_rows(B, S);   // upper bound of the launch grid (ncu), or one row per tile
     // (+ the weight-fragment planes of the wave-per-tile step, enc_wave.hip: L x 6 matrices x 2 orientations x 16 KB, 256-byte aligned)
     return (size_t)(nwg * L * EG_NVEC * D + enc_wgrad_part_floats(D, L) + enc_wgrad_ppart_floats(B, D) + L * EG_NMAT * NR * D) * sizeof(float) + 512 +
-           (size_t)L * 6 * 2 * 4096 * 4 + 256;
+           (size_t)L * 6 * 2 * 4096 * 4 + 256 + (size_t)enc_plan_max_tiles(B, S) * (3 * 2 * 4 * 256) * 4 + 256;   // (+ the tiles' dK / dV inboxes)
 }
 
 // dPtab == NULL: dx0 [B,S,D] receives the gradient w.r.t. x0 (rows of real tokens only).  Otherwise re_sasrec_embed_bwd is fused in:

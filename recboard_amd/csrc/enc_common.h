@@ -70,7 +70,8 @@ struct SasrecParams {
 
 // ---- plan (re_sasrec_batch_prep): int32 words
 //   [0] n_items  [1] n_tiles  [2] n_long items  [3] tiles per short item  [4] number of valid (non-pad) positions
-//   [5] number of sequences SPLIT over two work items (kinds 2 / 3; 0 = none)  [6] the workgroup count the plan was made for  [7] 0
+//   [5] number of sequences SPLIT over two work items (kinds 2 / 3; 0 = none)  [6] the workgroup count the plan was made for
+//   [7] 1 = every tile can have a resident workgroup of its own (the one-tile-per-workgroup step of enc_tile.hip may run)
 //   [8 .. 8 + MT)            item descriptors: tile0 | nt << 24 | kind << 28   (kind 1 = one sequence over nt tiles)
 //   then int2 rowmap[MT * 16]: { gid = b * S + s or -1 (dummy row), first = pads in front of the row's sequence }
 //   then scratch of the plan kernel.   MT = B * ceil(S / 16) bounds the number of tiles.

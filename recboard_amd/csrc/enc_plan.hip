@@ -153,7 +153,10 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 s_lay[5] = 0; s_lay[6] = 4 * n0; s_lay[7] = 4 * n0 + 3 * n1;                 // first tile of the long classes
                 s_lay[8] = 0; s_lay[9] = n0; s_lay[10] = n0 + n1;                            // first item of the long classes
                 for (int k = 3; k < PL_NCLS; ++k) s_lay[8 + k] = 16 * tlong + ro[k];         // first compact row of the slot classes
-                hdr[0] = nlong + nsplit + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = nsplit; hdr[6] = ncu; hdr[7] = 0;
+                hdr[0] = nlong + nsplit + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = nsplit; hdr[6] = ncu;
+                // [7]: 1 = every tile can have a RESIDENT workgroup of its own (enc_tile.hip: a long sequence's tiles wait for each other
+                // across workgroups; they are laid out first, so they are the first `tlong` blocks of the grid)
+                hdr[7] = (nsplit == 0 && tlong + tshort <= 1024 && tlong <= 256) ? 1 : 0;
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;
                 // class k: s_cb[k] sequences in front of it, its rows start at s_r0[k]
                 int cb = 0, r0 = 0;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
     }
 #ifdef ENC_PROFILE
     PL_STAMP(3);
-    if (tid == 0) hdr[7] = (int)(pl_t[3] - pl_t[0]);   // (diagnostic build: the plan workgroup's ticks)
+    (void)pl_t;
 #endif
 }
 

@@ -18,6 +18,7 @@ __global__ __launch_bounds__(512) void enc_step_k(SeEmbed em, const int64_t* __r
     extern __shared__ __align__(16) float lds[];
     const EncPlan PL = enc_plan_view(planp, B, S);
     const int n_items = PL.hdr[0];
+    if (D == 64 && PL.hdr[7] == 1) return;   // (the one-tile-per-workgroup kernel in front of this launch has run the step: enc_tile.hip)
     if (enc_split_plan_rejected(PL, tape + T.off_FLAGS, enc_plan_max_tiles(B, S) * EP_FLAG_WORDS, H.loss)) return;
     using C = EC<D>;
     __shared__ int h_gid[C::ROWS], h_first[C::ROWS], h_pad[C::ROWS], h_sid[C::ROWS], h_start[C::ROWS];
@@ -37,15 +38,16 @@ __global__ __launch_bounds__(512) void enc_step_k(SeEmbed em, const int64_t* __r
 // ---- weight gradients (enc_wgrad.hip) ---------------------------------------------------------------------------------------
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
                      int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
-                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s);
+                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile = 0);
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 // ---- the four-waves-per-tile form of the step at D = 64 (enc_tile.hip)
 size_t enc_tile_wfrag_bytes(int64_t L);
+size_t enc_tile_xch_bytes(int64_t B, int64_t S);
 int enc_tile_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
-                         uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, int tpw, const EncHead& H,
-                         float* dx0, float* gtape, float* slab, float scale, uint32_t* wf, hipStream_t s);
+                         uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
+                         float* gtape, float* slab, float scale, uint32_t* wf, float* xch, hipStream_t s);
 
 template <int D>
 static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds,
@@ -66,8 +68,8 @@ static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, i
 extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
                                       const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
                                       const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
-                                      const void* plan, int32_t ncu, int32_t max_tiles, float* u, void* tape, size_t tape_bytes, int64_t e_off,
-                                      int kind, const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
+                                      const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
+                                      const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
                                       size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
                                       float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream) {
     re_clear_error();
@@ -92,9 +94,7 @@ extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Pt
     const EncHead H{E, R, e_off, pos, neg, kind, count, loss, dU_rows, g_rows, keys, (unsigned long long*)loss_ws};
     if (ncu < 1) ncu = 256;
     const int64_t mt = enc_plan_max_tiles(B, S);
-    // D = 64: one WAVE per tile (enc_wave.hip) -- a workgroup is four tiles at most and many fit a CU, so the grid is not the CU count
-    // but the plan's item bound (the plan should then be made for ~1024 workgroups: one tile per item while the batch allows it)
-    const int grid = (D == 64) ? (int)(mt < 1024 ? mt : 1024) : (int)(mt < ncu ? mt : ncu);
+    const int grid = (int)(mt < ncu ? mt : ncu);
     if (grid > 1024) return RE_EUNSUPPORTED;
     float* slab = (float*)ws;
     float* part = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
@@ -102,11 +102,18 @@ extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Pt
     float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
     hipStream_t s = (hipStream_t)stream;
     if (D == 64) {
+        // one tile per workgroup (enc_tile.hip) when the plan says every tile can have a resident workgroup (hdr[7]); the workgroup-per-item
+        // kernel is launched behind it and returns at once in that case -- the plan lives in device memory, so both are always enqueued
         const int64_t NR = 16 * mt;
         uint32_t* wf = (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * NR * D)) + 255) & ~(uintptr_t)255);
-        const int rcw = enc_tile_step_launch(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, max_tiles >= 4 ? 4 : max_tiles == 2 ? 2 : 1, H, dx0, gtape, slab, scale, wf, s);
+        float* xch = (float*)(((uintptr_t)wf + enc_tile_wfrag_bytes(L) + 255) & ~(uintptr_t)255);
+        const int tgrid = (int)(mt < 1024 ? mt : 1024);
+        const int rcw = enc_tile_step_launch(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, tgrid, H, dx0, gtape, slab, scale, wf, xch, s);
         if (rcw != RE_OK) return rcw;
-        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, -1, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
+        const int wgrid = (int)(mt < ncu ? mt : ncu);
+        const int rco = enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, wgrid, H, dx0, gtape, slab, scale, s);
+        if (rco != RE_OK) return rco;
+        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, wgrid, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s, 1);
     }
     const int rc = D == 128 ? enc_step_launch_d<128>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s)
                             : enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s);

@@ -24,10 +24,16 @@
 // Arithmetic: operands are split hi = bf16(x), mid = bf16(x - hi); a product is hi.hi + hi.mid + mid.hi with fp32 accumulation
 // (<= 3.01 * 2^-18 of sum |a b| per product: inside the 1e-4 parity bound); all row-wise arithmetic is fp32.
 //
-// WORK.  Workgroup = 16 waves = the up to 4 tiles of one plan item (re_sasrec_batch_prep; kinds 0 / 1 only).  Tiles of short
-// sequences (kind 0) are independent; a long sequence's tile t attends to the keys of tiles 0..t -- k, v (and q, k, v of the
-// backward's transposed reads) travel through the tape behind workgroup barriers, the partial dK, dV a later tile has for an
-// earlier one through LDS slots summed by the owner in tile order.  Everything is deterministic (fixed summation orders).
+// WORK.  Workgroup = 4 waves = ONE tile of the plan (blockIdx = compact tile number; what a tile is -- shared by short sequences,
+// or tile t of a sequence of nt tiles -- is read off the plan's row map), so the ~300 tiles of a batch spread over every CU.
+// Tiles of short sequences are independent.  A long sequence's tile t attends to the keys of tiles 0..t, which other WORKGROUPS
+// compute: per block, a tile publishes its k, v rows (forward) and its partial dK, dV for earlier tiles (backward) with device-scope
+// stores, drains them (s_waitcnt vmcnt(0)), barriers, and one lane stores the launch's EPOCH into the tile's flag word; a consumer
+// polls that word (device-scope load, bounded), barriers, and reads the rows with device-scope loads (MI355X guide: "handoff-flag").
+// A forward wait is for a LOWER block index and a backward wait for tiles of the same sequence; the plan lays the long sequences'
+// tiles first, so all of them are resident from the start as long as there are fewer of them than resident workgroups -- the plan
+// kernel checks exactly that (hdr[7] = 1) and otherwise leaves the step to the workgroup-per-item kernel (enc_step.hip), which is
+// launched right behind this one and returns at once when this one has run.  Sums over tiles are taken in tile order: deterministic.
 // The weight gradients stay in enc_wgrad.hip (tape X, A, O, Y, HR + the six dY arrays); bias / LayerNorm gradients are column
 // sums over a strip's tokens, written per TILE to the slab.
 #include <math.h>
@@ -42,17 +48,18 @@ typedef unsigned tl_u32x2 __attribute__((ext_vector_type(2)));
 #define TL_D 64
 #define TL_FRAG_WORDS 4096      // one (block, matrix, orientation): [strip 4][k step 2][plane 2][lane 64] x 16 bytes
 #define TL_NPAR 10              // per block: 0 ln_a_w 1 ln_a_b 2 bq 3 bk 4 bv 5 bo 6 ln_f_w 7 ln_f_b 8 b1 9 b2
-// per tile, in floats: operand slots [3][2 planes][64 lanes][4 strips] x 8 B | partial score tiles [2][4 waves][64 lanes] x 16 B |
+// per tile, in floats: operand slots [3][2 planes][64 lanes][4 strips] x 8 B | partial score tiles (TL_RED) |
 // per-token partials [2][4 waves][16 tokens] x 16 B | transpose scratch [4 waves][16 x 20]
 #define TL_OB (3 * 2 * 64 * 4 * 2)
-#define TL_RED (2 * 4 * 64 * 4)
+#define TL_RED (2 * 4 * 64 * 16)   // partial score tiles [2][4 waves][64 lanes][4 key tiles] x 16 B
 #define TL_SM (2 * 4 * 16 * 4)
 #define TL_TR (4 * 320)
 #define TL_TILE_LDS (TL_OB + TL_RED + TL_SM + TL_TR)
-#define TL_XCH (6 * 4 * 256)    // dK / dV exchange: (t, kt < t) pairs x strips x [4 registers][64 lanes]
+#define TL_XCH_TILE (3 * 2 * 4 * 256)   // floats of a key tile's inbox of partial dV / dK: [sender t - kt - 1][dV, dK][strip][4 registers][64 lanes]
 
 size_t enc_tile_wfrag_bytes(int64_t L) { return (size_t)L * 6 * 2 * TL_FRAG_WORDS * 4; }
-__host__ __device__ inline size_t tl_lds_floats(int L, int tpw) { return (size_t)(TL_NPAR * L + 2) * TL_D + (size_t)tpw * TL_TILE_LDS + TL_XCH + 32; }
+size_t enc_tile_xch_bytes(int64_t B, int64_t S) { return (size_t)enc_plan_max_tiles(B, S) * TL_XCH_TILE * 4; }
+__host__ __device__ inline size_t tl_lds_floats(int L) { return (size_t)(TL_NPAR * L + 2) * TL_D + (size_t)TL_TILE_LDS + 32; }
 
 // ---- operand splits ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned tl_pk(float a, float b) {   // two fp32 -> packed bf16 (round to nearest even), a in the low half
@@ -149,10 +156,31 @@ __device__ __forceinline__ void tl_tr16(float* scr, int c, int g, const f32x4& i
 }
 __device__ __forceinline__ f32x4 tl_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void tl_st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+// device-scope (sc1) accesses for what crosses workgroups: the XCDs' L2s are not coherent for ordinary accesses inside a kernel
+__device__ __forceinline__ float tl_ldc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tl_stc(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ f32x4 tl_ld4c(const float* p) { return (f32x4){tl_ldc(p), tl_ldc(p + 1), tl_ldc(p + 2), tl_ldc(p + 3)}; }
+__device__ __forceinline__ void tl_st4c(float* p, const f32x4& v) { tl_stc(p, v[0]); tl_stc(p + 1, v[1]); tl_stc(p + 2, v[2]); tl_stc(p + 3, v[3]); }
+// flag word of (tile, slot): slots 0 .. 3 = forward k, v of block l published, 4 .. 7 = backward partial dK, dV of block l published
+__device__ __forceinline__ void tl_flag_set(float* flags, int64_t tile, int word, unsigned epoch) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(flags) + tile * EP_FLAG_WORDS + word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tl_flag_wait(float* flags, int64_t tile, int word, unsigned epoch, int64_t err_word) {
+    unsigned* f = reinterpret_cast<unsigned*>(flags) + tile * EP_FLAG_WORDS + word;
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 21)) {   // ~1 s: the producer never came (it cannot: see the residency rule above) -- say so instead of hanging the GPU
+            __hip_atomic_store(reinterpret_cast<unsigned*>(flags) + err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
 
 // ---- weight preparation: fp32 [64][64] -> bf16 hi / mid fragment planes in the kernel's k order, both orientations ---------------------
-__global__ __launch_bounds__(256) void enc_tile_prep_k(SasrecParams P, int L, uint32_t* __restrict__ wf) {
+__global__ __launch_bounds__(256) void enc_tile_prep_k(SasrecParams P, int L, uint32_t* __restrict__ wf, unsigned* __restrict__ epoch) {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) epoch[0] += 1u;   // the launch's epoch: what this step's hand-over flags are set to (the step kernel runs behind this one)
     const int lane = t & 63, q = (t >> 6) & 1, s = (t >> 7) & 3, o = (t >> 9) & 1, lm = t >> 10;
     if (lm >= 6 * L) return;
     const int l = lm / 6, m = lm % 6, c = lane & 15, g = lane >> 4;
@@ -186,74 +214,46 @@ extern "C" int re_dbg_enc_marks_wave(unsigned long long* out) {
 #define TL_MARK() do { } while (0)
 #endif
 
-// TPW = tiles per workgroup (4 waves each): the plan's items must not hold more tiles than that
-template <int TPW>
-__global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const int64_t* __restrict__ seq, int B, int S, int L, SasrecParams P,
+__global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int64_t* __restrict__ seq, int B, int S, int L, SasrecParams P,
                                                          float drop_scale, uint32_t thresh, uint32_t seed, float* __restrict__ u,
                                                          float* __restrict__ tape, EncTape T, const void* __restrict__ planp, EncHead H,
                                                          float* __restrict__ dOut, float* __restrict__ gtape, float* __restrict__ slab,
                                                          const uint32_t* __restrict__ seed_dev, float emb_scale,
-                                                         const uint32_t* __restrict__ wf) {
+                                                         const uint32_t* __restrict__ wf, float* __restrict__ xch) {
     if (seed_dev) seed ^= seed_dev[0];
     extern __shared__ __align__(16) float lds[];
     const EncPlan PL = enc_plan_view(planp, B, S);
-    const int n_items = PL.hdr[0];
-    if (PL.hdr[5] > 0) {   // a plan with split sequences (kinds 2 / 3) is not for this kernel: say so instead of computing garbage
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            __hip_atomic_store(reinterpret_cast<unsigned*>(tape + T.off_FLAGS) + enc_plan_max_tiles(B, S) * EP_FLAG_WORDS, 2u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            H.loss[0] = __builtin_nanf("");
-        }
-        return;
-    }
+    if (PL.hdr[7] != 1) return;                          // (not a plan for this kernel: the workgroup-per-item kernel behind it runs the step)
+    const int n_tiles = PL.hdr[1];
+    const int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, g = lane >> 4, s = wave & 3, tw = wave >> 2;
+    const int c = lane & 15, g = lane >> 4, s = wave;
     float* s_par = lds;
-    float* tl0 = s_par + (TL_NPAR * L + 2) * TL_D + (size_t)tw * TL_TILE_LDS;   // this tile's LDS
-    float* ob = tl0;
+    float* ob = s_par + (TL_NPAR * L + 2) * TL_D;
     float* red = ob + TL_OB;
     float* sm = red + TL_RED;
     float* scr = sm + TL_SM + s * 320;
-    constexpr int TL_NT = 256 * TPW, TL_NW = 4 * TPW;
-    float* s_xch = s_par + (TL_NPAR * L + 2) * TL_D + (size_t)TPW * TL_TILE_LDS;
-    float* s_red = s_xch + TL_XCH;
+    float* flags = tape + T.off_FLAGS;
+    const int64_t ferr = enc_plan_max_tiles(B, S) * EP_FLAG_WORDS;
+    const unsigned epoch = reinterpret_cast<const unsigned*>(flags)[ferr + 1];
     const float inv_sqrt_d = 0.125f;
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
     const int tofs = c * TL_D + 16 * s + 4 * g;          // T strip: float4 at row c
     const int fofs = 4 * g * TL_D + 16 * s + c;          // F strip: element j at + j * D
 
-    for (int e = tid; e < (TL_NPAR * L + 2) * TL_D; e += TL_NT) {   // the small parameters of every block and lastLN: once per workgroup
-        const int v = e / TL_D, cc = e % TL_D;
-        const float* p;
-        if (v >= TL_NPAR * L) p = (v == TL_NPAR * L) ? P.last_w : P.last_b;
-        else {
-            const SasrecBlockParams& W = P.blk[v / TL_NPAR];
-            const int kk = v % TL_NPAR;
-            p = (kk == 0) ? W.ln_a_w : (kk == 1) ? W.ln_a_b : (kk < 5) ? W.in_b + (kk - 2) * TL_D : (kk == 5) ? W.out_b : (kk == 6) ? W.ln_f_w
-              : (kk == 7) ? W.ln_f_b : (kk == 8) ? W.b1 : W.b2;
-        }
-        s_par[e] = p[cc];
-    }
-    __syncthreads();
-
-    for (int k = 0; k * (int)gridDim.x < n_items; ++k) {
-        const int wi = enc_item_of(k, blockIdx.x, gridDim.x);
-        if (wi >= n_items) continue;                      // (workgroup-uniform)
-        const EncItem it = enc_item(PL, wi);
-        if (it.nt > TPW) {   // (a plan made for larger workgroups: refuse loudly)
-            if (tid == 0) {
-                __hip_atomic_store(reinterpret_cast<unsigned*>(tape + T.off_FLAGS) + enc_plan_max_tiles(B, S) * EP_FLAG_WORDS, 2u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                H.loss[0] = __builtin_nanf("");
-            }
-            continue;
-        }
-        const bool multi = it.kind == 1 && it.nt > 1;     // tiles of ONE sequence: k, v and dK, dV cross tiles
-        const bool live = tw < it.nt;                     // a tile slot without a tile runs the same barriers on tile 0's data, stores nothing
-        const int tt = live ? tw : 0;
-        const int64_t row0 = (int64_t)(it.tile0 + tt) * 16;          // compact row of the tile's first row
-        const int64_t irow0 = (int64_t)it.tile0 * 16;                // ... of the item's
-        const int nkx = multi ? it.nt : 1;                           // score-exchange rounds of the item (key tiles 0 .. tt of a long sequence, else the own tile)
+    {
+        const int k = 0; (void)k;
+        // ---- what this tile is: row 0 of a tile is always a real row; a sequence of more than 16 rows owns whole tiles, in order
+        const int64_t row0 = (int64_t)tile * 16;                     // compact row of the tile's first row
+        const int2 rm0 = PL.rowmap[row0];
+        const int span0 = rm0.x >= 0 ? S - rm0.y : 1;
+        const bool multi = span0 > 16;                               // tile tt of a sequence of nt tiles: k, v and dK, dV cross workgroups
+        const int tt = multi ? (rm0.x % S - rm0.y) / 16 : 0, nt = multi ? (span0 + 15) / 16 : 1;
+        const int64_t irow0 = row0 - 16 * tt;                        // compact row of the sequence's first row
+        const int64_t tile_s0 = tile - tt;                           // the sequence's first tile
+        const int nkx = multi ? tt + 1 : 1;                          // score-exchange rounds (key tiles 0 .. tt of a long sequence, else the own tile)
+        constexpr bool live = true;
         int mk = 0; (void)mk;
         int slot = 0, rp = 0;                                        // operand slot / partial-buffer rotation (uniform over the workgroup)
         TL_MARK();
@@ -274,28 +274,37 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
         int64_t hpr = 0, hng = 0;                                    // the loss head's indices: requested now, used after the last block
         if (gid >= 0) { hpr = H.pos[gid] + H.e_off; hng = H.neg[gid] + H.e_off; }
         const float hgs = 1.0f / (float)H.count[0];
-        // Weight strips: SIX register sets (16 registers each), one per product of a block; a set is reloaded right after its use with
-        // what it holds next -- the same product's weights of the following block, or (last forward block) the backward's -- so every
-        // request is a whole block older than its use (requested one product ahead, every product waited ~1 us for L2).
-        Op64 w0, w1, w2, w3, w4, w5;
-        tl_wload(w0, wf, 0, 0, 0, s, lane);                          // block 0: Wq Wk Wv Wo W1 W2
-        tl_wload(w1, wf, 0, 1, 0, s, lane);
-        tl_wload(w2, wf, 0, 2, 0, s, lane);
-        tl_wload(w3, wf, 0, 3, 0, s, lane);
-        tl_wload(w4, wf, 0, 4, 0, s, lane);
-        tl_wload(w5, wf, 0, 5, 0, s, lane);
+        // Weight strips: two register sets (16 registers each), each requested one product ahead of its use
+        Op64 wa, wb;
+        tl_wload(wa, wf, 0, 0, 0, s, lane);                          // block 0's Wq strip
         // the loss head's table rows: requested now (their indices are known), used after the last block
         const bool hreal = item > 0 && item < H.R;
         const bool hok = hreal && hpr > 0 && hpr < H.R && hng > 0 && hng < H.R;
         if (!hok) { hpr = 0; hng = 0; }
         const f32x4 hep = tl_ld4(H.E + hpr * TL_D + 16 * s + 4 * g), hen = tl_ld4(H.E + hng * TL_D + 16 * s + 4 * g);
-        // ---- x0 = E[item] sqrt(D) + P[position], dropout (SASRec/main.py:181-187)
-        f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // ---- x0 = E[item] sqrt(D) + P[position], dropout (SASRec/main.py:181-187): the rows are requested, the parameters staged meanwhile
+        f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f}, xe = x, xp = x;
         unsigned emask = 0xFu;
         if (real) {
-            const f32x4 e = tl_ld4(em.E + item * TL_D + 16 * s + 4 * g), pp = tl_ld4(em.P + (int64_t)(gid % S) * TL_D + 16 * s + 4 * g);
+            xe = tl_ld4(em.E + item * TL_D + 16 * s + 4 * g);
+            xp = tl_ld4(em.P + (int64_t)(gid % S) * TL_D + 16 * s + 4 * g);
+        }
+        // the small parameters of every block and lastLN into LDS (behind the requests above; a vector per wave and round, uniform pointers)
+        for (int v = wave; v < TL_NPAR * L + 2; v += 4) {
+            const float* pv_;
+            if (v >= TL_NPAR * L) pv_ = (v == TL_NPAR * L) ? P.last_w : P.last_b;
+            else {
+                const SasrecBlockParams& W = P.blk[v / TL_NPAR];
+                const int kk = v % TL_NPAR;
+                pv_ = (kk == 0) ? W.ln_a_w : (kk == 1) ? W.ln_a_b : (kk < 5) ? W.in_b + (kk - 2) * TL_D : (kk == 5) ? W.out_b : (kk == 6) ? W.ln_f_w
+                    : (kk == 7) ? W.ln_f_b : (kk == 8) ? W.b1 : W.b2;
+            }
+            s_par[v * TL_D + lane] = pv_[lane];
+        }
+        __syncthreads();
+        if (real) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = fmaf(e[j], em.scale, pp[j]);
+            for (int j = 0; j < 4; ++j) x[j] = fmaf(xe[j], em.scale, xp[j]);
             if (thresh) {
                 emask = 0u;
                 const uint32_t e0 = (uint32_t)((int64_t)gid * TL_D + 16 * s + 4 * g);
@@ -344,22 +353,26 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             A = (p0_.x + p1_.x) + (p2_.x + p3_.x);                                                                        \
             Bv = (p0_.y + p1_.y) + (p2_.y + p3_.y);                                                                       \
         } while (0)
-// a partial 16 x 16 score tile (+ two per-token scalars) summed over the four strips.  One barrier.
-#define TL_TILE_SUM(PT, A, Bv)                                                                                            \
+// the partial 16 x 16 score tiles of NK key tiles (+ two per-token scalars) summed over the four strips, in strip order.  One barrier.
+#define TL_TILES_SUM(PT, NK, A, Bv)                                                                                       \
         do {                                                                                                              \
-            float* rb_ = red + rp * (4 * 64 * 4);                                                                         \
+            float* rb_ = red + rp * (4 * 64 * 16);                                                                        \
             float* smb_ = sm + rp * (4 * 16 * 4);                                                                         \
-            tl_st4(rb_ + (s * 64 + lane) * 4, PT);                                                                        \
+            _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_)                                                           \
+                if (kt_ < (NK)) tl_st4(rb_ + ((s * 64 + lane) * 4 + kt_) * 4, PT[kt_]);                                   \
             if (g == 0) *reinterpret_cast<float2*>(smb_ + (s * 16 + c) * 4) = make_float2(A, Bv);                         \
             tl_sync();                                                                                                    \
-            const f32x4 t0_ = tl_ld4(rb_ + (0 * 64 + lane) * 4), t1_ = tl_ld4(rb_ + (1 * 64 + lane) * 4);                 \
-            const f32x4 t2_ = tl_ld4(rb_ + (2 * 64 + lane) * 4), t3_ = tl_ld4(rb_ + (3 * 64 + lane) * 4);                 \
+            _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_)                                                           \
+                if (kt_ < (NK)) {                                                                                         \
+                    const f32x4 t0_ = tl_ld4(rb_ + ((0 * 64 + lane) * 4 + kt_) * 4), t1_ = tl_ld4(rb_ + ((1 * 64 + lane) * 4 + kt_) * 4); \
+                    const f32x4 t2_ = tl_ld4(rb_ + ((2 * 64 + lane) * 4 + kt_) * 4), t3_ = tl_ld4(rb_ + ((3 * 64 + lane) * 4 + kt_) * 4); \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) PT[kt_][j] = (t0_[j] + t1_[j]) + (t2_[j] + t3_[j]);     \
+                }                                                                                                         \
             const float2 p0_ = *reinterpret_cast<const float2*>(smb_ + (0 * 16 + c) * 4);                                 \
             const float2 p1_ = *reinterpret_cast<const float2*>(smb_ + (1 * 16 + c) * 4);                                 \
             const float2 p2_ = *reinterpret_cast<const float2*>(smb_ + (2 * 16 + c) * 4);                                 \
             const float2 p3_ = *reinterpret_cast<const float2*>(smb_ + (3 * 16 + c) * 4);                                 \
             rp ^= 1;                                                                                                      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) PT[j] = (t0_[j] + t1_[j]) + (t2_[j] + t3_[j]);                  \
             A = (p0_.x + p1_.x) + (p2_.x + p3_.x);                                                                        \
             Bv = (p0_.y + p1_.y) + (p2_.y + p3_.y);                                                                       \
         } while (0)
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
                 for (int j = 0; j < 4; ++j) a[j] = fmaf((x[j] - mean) * rstd, gw[j], gb[j]);
                 if (live && g == 0) *reinterpret_cast<float2*>(tp + T.off_SA + (row0 + c) * 2) = make_float2(mean, rstd);   // (written four times over: identical values)
             }
+            if (l == 0) tl_wload(wb, wf, 0, 1, 0, s, lane);   // Wk (later blocks: requested at the end of the block before)
             // ---- q = a Wq^T + bq, k = x Wk^T + bk (T strips), v = x Wv^T + bv (F strip)
             const int sa = slot; TL_NEXT_SLOT();
             const int sx = slot; TL_NEXT_SLOT();
@@ -391,24 +405,34 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             Op64 ao, xo;
             tl_get(ob, sa, lane, ao);
             tl_get(ob, sx, lane, xo);
-            const bool lastf = l + 1 == L;
-            f32x4 q = tl_mm64(w0, ao);
-            if (lastf) tl_wload(w0, wf, l, 5, 1, s, lane); else tl_wload(w0, wf, l + 1, 0, 0, s, lane);   // next: Wq, or the backward's W2
+            f32x4 q = tl_mm64(wa, ao);
+            tl_wload(wa, wf, l, 2, 0, s, lane);           // Wv
             const f32x4 bq = tl_ld4(par + 2 * TL_D), bk = tl_ld4(par + 3 * TL_D), bvt = tl_ld4(par + 4 * TL_D);
-            f32x4 kk = tl_mm64(w1, xo);
-            if (lastf) tl_wload(w1, wf, l, 4, 1, s, lane); else tl_wload(w1, wf, l + 1, 1, 0, s, lane);   // Wk, or W1'
-            f32x4 vf = tl_mm64(xo, w2);
-            if (lastf) tl_wload(w2, wf, l, 3, 1, s, lane); else tl_wload(w2, wf, l + 1, 2, 0, s, lane);   // Wv, or Wo'
+            f32x4 kk = tl_mm64(wb, xo);
+            tl_wload(wb, wf, l, 3, 0, s, lane);           // Wo
+            f32x4 vf = tl_mm64(xo, wa);
+            tl_wload(wa, wf, l, 4, 0, s, lane);           // W1
             const float bvs = s_par[l * TL_NPAR * TL_D + 4 * TL_D + 16 * s + c];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { q[j] += bq[j]; kk[j] += bk[j]; vf[j] += bvs; }
-            if (live) {
-                tl_st4(tp + T.off_Q + row0 * TL_D + tofs, q);
+            tl_st4(tp + T.off_Q + row0 * TL_D + tofs, q);
+            if (multi && tt + 1 < nt) {                   // later tiles of the sequence read these rows: device-scope stores, then the flag
+                tl_st4c(tp + T.off_K + row0 * TL_D + tofs, kk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tl_stc(tp + T.off_V + row0 * TL_D + fofs + j * TL_D, vf[j]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) tl_flag_set(flags, tile, l, epoch);
+            } else {
                 tl_st4(tp + T.off_K + row0 * TL_D + tofs, kk);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) tp[T.off_V + row0 * TL_D + fofs + j * TL_D] = vf[j];
             }
-            if (multi) __syncthreads();                   // (with vmcnt(0): the item's k, v of this block are in L2 for its other tiles)
+            if (tt > 0) {                                 // the earlier tiles' k, v of this block
+                if (tid == 0)
+                    for (int kt = 0; kt < tt; ++kt) tl_flag_wait(flags, tile_s0 + kt, l, epoch, ferr);
+                __syncthreads();
+            }
             TL_MARK();
             // ---- scores Rt(S)[kt] = q k^T / sqrt(D): partial over the strip's 16 features, summed over the strips; with them the
             //      pad key's score q.b_k and the count of kept pad keys (each of the n_out pad keys has its own dropout bit)
@@ -432,15 +456,15 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
                 p[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (kt >= nkx) continue;                   // (workgroup-uniform: every wave takes part in every round of the item)
                 const int ktc = multi ? kt : tt;
-                if (ktc <= tt) {
-                    Op16 ko;
-                    if (ktc == tt) tl_split4(kk, ko);
-                    else tl_split4(tl_ld4(tp + T.off_K + (irow0 + 16 * ktc) * TL_D + tofs), ko);
-                    p[kt] = tl_mm16(ko, qo, p[kt]);
-                }
-                float za = (kt == 0) ? dqb : 0.f, zb = (kt == 0) ? cntf : 0.f;
-                TL_TILE_SUM(p[kt], za, zb);
-                if (kt == 0) { dqb = za; cntf = zb; }
+                Op16 ko;
+                if (ktc == tt) tl_split4(kk, ko);
+                else tl_split4(tl_ld4c(tp + T.off_K + (irow0 + 16 * ktc) * TL_D + tofs), ko);
+                p[kt] = tl_mm16(ko, qo, p[kt]);
+            }
+            TL_TILES_SUM(p, nkx, dqb, cntf);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) p[kt][j] *= inv_sqrt_d;
             }
@@ -451,25 +475,29 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             float mx = -INFINITY;
             unsigned okm = 0u;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkx) continue;                   // (uniform: a tile of short sequences has one key tile)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ktc = multi ? kt : tt;
                     const int jo = 16 * ktc + 4 * g + j;
-                    const bool ok = kt < nkx && ktc <= tt && gid >= 0 && (unsigned)(jo - st) <= span;
+                    const bool ok = gid >= 0 && (unsigned)(jo - st) <= span;
                     okm |= (ok ? 1u : 0u) << (4 * kt + j);
                     mx = fmaxf(mx, ok ? p[kt][j] : -INFINITY);
                 }
+            }
             const float spad = (gid >= 0 && n_out > 0) ? dqb * inv_sqrt_d : -INFINITY;
             mx = tl_gmax(fmaxf(mx, spad));
             float sum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     p[kt][j] = ((okm >> (4 * kt + j)) & 1u) ? expf(p[kt][j] - mx) : 0.f;
                     sum += p[kt][j];
                 }
+            }
             sum = tl_gsum(sum);
             const float epad = (spad == -INFINITY) ? 0.f : expf(spad - mx);
             sum += (float)n_out * epad;
@@ -482,11 +510,13 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             f32x4 pd[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
+                pd[kt] = p[kt];
+                if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) p[kt][j] *= inv;
                 pd[kt] = p[kt];
                 const int ktc = multi ? kt : tt;
-                if (live && s == 0 && kt < nkx && ktc <= tt)   // pre-dropout probabilities (0 outside the token's window): row c, key columns 16 kt + 4 g ..
+                if (s == 0)   // pre-dropout probabilities (0 outside the token's window): row c, key columns 16 kt + 4 g ..
                     tl_st4(tp + T.off_P + (row0 + c) * EP_PW + 16 * ktc + 4 * g, p[kt]);
             }
             if (thresh) {
@@ -516,7 +546,7 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
                 f32x4 vt = vf;
                 if (ktc != tt) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) vt[j] = tp[T.off_V + (irow0 + 16 * ktc) * TL_D + fofs + j * TL_D];
+                    for (int j = 0; j < 4; ++j) vt[j] = tl_ldc(tp + T.off_V + (irow0 + 16 * ktc) * TL_D + fofs + j * TL_D);
                 }
                 tl_split4(vt, vo);
                 o = tl_mm16(vo, po, o);
@@ -533,8 +563,8 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             {
                 Op64 oo;
                 tl_get(ob, so, lane, oo);
-                x1 = tl_mm64(w3, oo);
-                if (lastf) tl_wload(w3, wf, l, 0, 1, s, lane); else tl_wload(w3, wf, l + 1, 3, 0, s, lane);   // Wo, or Wq'
+                x1 = tl_mm64(wb, oo);
+                tl_wload(wb, wf, l, 5, 0, s, lane);       // W2
                 const f32x4 bo = tl_ld4(par + 5 * TL_D);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x1[j] += bo[j] + x[j];
@@ -561,8 +591,9 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             {
                 Op64 yo;
                 tl_get(ob, sy, lane, yo);
-                hr = tl_mm64(w4, yo);
-                if (lastf) tl_wload(w4, wf, l, 1, 1, s, lane); else tl_wload(w4, wf, l + 1, 4, 0, s, lane);   // W1, or Wk'
+                hr = tl_mm64(wa, yo);
+                if (l + 1 < L) tl_wload(wa, wf, l + 1, 0, 0, s, lane);   // the next block's Wq,
+                else tl_wload(wa, wf, L - 1, 5, 1, s, lane);            // or the backward's first: W2 of the last block
                 const f32x4 b1 = tl_ld4(par + 8 * TL_D);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -582,8 +613,9 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             {
                 Op64 ho;
                 tl_get(ob, sh, lane, ho);
-                const f32x4 z = tl_mm64(w5, ho);
-                if (lastf) tl_wload(w5, wf, l, 2, 1, s, lane); else tl_wload(w5, wf, l + 1, 5, 0, s, lane);   // W2, or Wv'
+                const f32x4 z = tl_mm64(wb, ho);
+                if (l + 1 < L) tl_wload(wb, wf, l + 1, 1, 0, s, lane);   // the next block's Wk, or the backward's second: W1
+                else tl_wload(wb, wf, L - 1, 4, 1, s, lane);
                 const f32x4 b2 = tl_ld4(par + 9 * TL_D);
                 if (thresh) m2 = 0u;
 #pragma unroll
@@ -656,7 +688,7 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
         __syncthreads();   // (with vmcnt(0): what the forward left on the tape for OTHER waves of the workgroup -- P, the pad-key weights, the
                            //  LayerNorm statistics, a long sequence's k / v rows -- is in L2 before the backward reads it)
         TL_MARK();
-        float* srow = slab + (size_t)(it.tile0 + tt) * L * EG_NVEC * TL_D + 16 * s + 4 * g + ((c >> 3) * 2 + ((c >> 2) & 1));   // the lane's column-sum feature
+        float* srow = slab + (size_t)tile * L * EG_NVEC * TL_D + 16 * s + 4 * g + ((c >> 3) * 2 + ((c >> 2) & 1));   // the lane's column-sum feature
         const bool cs_w = live && (c & 3) == 0;              // one lane of every four holds a column sum to write
 #define TL_COLSUM(V, VAL) do { const float cs_ = tl_colsum(VAL, c); if (cs_w) srow[(size_t)(l * EG_NVEC + (V)) * TL_D] = cs_; } while (0)
         f32x4 dx;
@@ -699,7 +731,6 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
                 sf_n = *reinterpret_cast<const float2*>(tn + T.off_SF + (row0 + c) * 2);
                 ppw_n = *reinterpret_cast<const float2*>(tn + T.off_PP + (row0 + c) * 2);
             }
-            const bool lastb = l == 0;                     // (no block below: the reloads are skipped)
             // ---- pad mask of the block output, dO2 = dX' * dropout2 mask
             f32x4 dz;
 #pragma unroll
@@ -717,8 +748,8 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             {
                 Op64 oo;
                 tl_get(ob, s0, lane, oo);
-                dh = tl_mm64(w0, oo);
-                if (!lastb) tl_wload(w0, wf, l - 1, 5, 1, s, lane);
+                dh = tl_mm64(wa, oo);
+                tl_wload(wa, wf, l, 3, 1, s, lane);       // Wo
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dh[j] = ((mw >> (4 + j)) & 1u) ? dh[j] * drop_scale : 0.f;
             }
@@ -733,8 +764,8 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             {
                 Op64 oo;
                 tl_get(ob, s1s, lane, oo);
-                dy = tl_mm64(w1, oo);
-                if (!lastb) tl_wload(w1, wf, l - 1, 4, 1, s, lane);
+                dy = tl_mm64(wb, oo);
+                tl_wload(wb, wf, l, 0, 1, s, lane);       // Wq
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dy[j] += dx[j];
             }
@@ -782,9 +813,9 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             {
                 Op64 oo;
                 tl_get(ob, s2s, lane, oo);
-                dO = tl_mm64(w2, oo);
-                dOf = tl_mm64(oo, w2);
-                if (!lastb) tl_wload(w2, wf, l - 1, 3, 1, s, lane);
+                dO = tl_mm64(wa, oo);
+                dOf = tl_mm64(oo, wa);
+                tl_wload(wa, wf, l, 1, 1, s, lane);       // Wk
             }
             // ---- E. attention backward (enc_bwd_item.h, same arithmetic): dP = dO v^T as partial tiles per strip
             const float ppad = ppw.x, wvv = ppw.y;
@@ -806,20 +837,22 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
                 p[kt] = ds[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (kt >= nkx) continue;
                 const int ktc = multi ? kt : tt;
-                f32x4 raw = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ktc <= tt) {
-                    p[kt] = tl_ld4(tp + T.off_P + (row0 + c) * EP_PW + 16 * ktc + 4 * g);
-                    Op16 vo;
-                    tl_split4(ktc == tt ? vt_own : tl_ld4(tp + T.off_V + (irow0 + 16 * ktc) * TL_D + tofs), vo);
-                    raw = tl_mm16(vo, doo, raw);           // partial (dO_i . v_j) for token i = c, keys 4 g + j
-                }
-                float za = (kt == 0) ? tdot : 0.f, zb = 0.f;
-                TL_TILE_SUM(raw, za, zb);
-                if (kt == 0) tdot = za;
+                p[kt] = tl_ld4(tp + T.off_P + (row0 + c) * EP_PW + 16 * ktc + 4 * g);
+                Op16 vo;
+                tl_split4(ktc == tt ? vt_own : tl_ld4c(tp + T.off_V + (irow0 + 16 * ktc) * TL_D + tofs), vo);
+                ds[kt] = tl_mm16(vo, doo, ds[kt]);         // partial (dO_i . v_j) for token i = c, keys 4 g + j
+            }
+            {
+                float zb = 0.f;
+                TL_TILES_SUM(ds, nkx, tdot, zb);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float mf = !thresh ? 1.0f : ((amask >> (4 * kt + j)) & 1u) ? drop_scale : 0.f;
-                    ds[kt][j] = (p[kt][j] != 0.f) ? raw[j] * mf : 0.f;
+                    ds[kt][j] = (p[kt][j] != 0.f) ? ds[kt][j] * mf : 0.f;
                     srw = fmaf(ds[kt][j], p[kt][j], srw);
                 }
             }
@@ -827,9 +860,11 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             srw = fmaf(tdot, wvv, srw);                                            // the row dot includes the pad copies
             const float cpad = (wvv * tdot - (float)n_out * ppad * srw) * inv_sqrt_d;   // sum of dS over the pad copies
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ds[kt][j] = p[kt][j] * (ds[kt][j] - srw) * inv_sqrt_d;
+            }
             TL_MARK();
             // dQ = dS K + dS_pad b_k;  per key tile dV_kt = Pd^T dO, dK_kt = dS^T Q  (strip-local: K = tokens)
             Op16 qo4, do4;
@@ -843,7 +878,7 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
                 f32x4 kf = kf_own;
                 if (ktc != tt) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) kf[j] = tp[T.off_K + (irow0 + 16 * ktc) * TL_D + fofs + j * TL_D];
+                    for (int j = 0; j < 4; ++j) kf[j] = tl_ldc(tp + T.off_K + (irow0 + 16 * ktc) * TL_D + fofs + j * TL_D);
                 }
                 Op16 ko, dso, pdr, dsr;
                 tl_split4(kf, ko);
@@ -859,42 +894,29 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
                 const f32x4 pv_ = tl_mm16(do4, pdr, (f32x4){0.f, 0.f, 0.f, 0.f});   // T(dv_kt): features x keys
                 const f32x4 pk_ = tl_mm16(qo4, dsr, (f32x4){0.f, 0.f, 0.f, 0.f});   // T(dk_kt)
                 if (ktc == tt) { dv = pv_; dk = pk_; }
-                else if (live) {
-                    // this tile's contribution to an EARLIER tile's dV, dK: slots (tt, kt), read by their owner behind the barrier below
-                    float* sl = s_xch + ((tt * (tt - 1) / 2 + ktc) * 4 + s) * 256;   // (dK goes through the same slots in a second round)
+                else {
+                    // this tile's contribution to an EARLIER tile's dV, dK: into that tile's inbox, slot tt - kt - 1 (device-scope stores)
+                    float* in = xch + (size_t)(tile_s0 + ktc) * TL_XCH_TILE + (size_t)((tt - ktc - 1) * 2) * 1024 + s * 256 + lane;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sl[j * 64 + lane] = pv_[j];
+                    for (int j = 0; j < 4; ++j) { tl_stc(in + j * 64, pv_[j]); tl_stc(in + 1024 + j * 64, pk_[j]); }
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) dq[j] = fmaf(cpad, bk[j], dq[j]);
-            if (multi) {
-                tl_sync();                                 // round 1: dV partials are in the slots -> owners add them in tile order
-                for (int t = tt + 1; t < it.nt; ++t) {
-                    const float* sl = s_xch + ((t * (t - 1) / 2 + tt) * 4 + s) * 256;
+            if (tt > 0) {                                  // published: drained, then the flag
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) tl_flag_set(flags, tile, 4 + l, epoch);
+            }
+            if (tt + 1 < nt) {                             // the later tiles' partials for these rows, added in tile order
+                if (tid == 0)
+                    for (int t = tt + 1; t < nt; ++t) tl_flag_wait(flags, tile_s0 + t, 4 + l, epoch, ferr);
+                __syncthreads();
+                for (int t = tt + 1; t < nt; ++t) {
+                    const float* in = xch + (size_t)tile * TL_XCH_TILE + (size_t)((t - tt - 1) * 2) * 1024 + s * 256 + lane;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dv[j] += sl[j * 64 + lane];
+                    for (int j = 0; j < 4; ++j) { dv[j] += tl_ldc(in + j * 64); dk[j] += tl_ldc(in + 1024 + j * 64); }
                 }
-                tl_sync();
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt) {           // round 2: dK partials (recomputed: 3 MFMAs, rather than held across the barriers)
-                    if (kt >= tt || !live) continue;
-                    f32x4 tr;
-                    Op16 dsr;
-                    tl_tr16(scr, c, g, ds[kt], tr);
-                    tl_split4(tr, dsr);
-                    const f32x4 pk_ = tl_mm16(qo4, dsr, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    float* sl = s_xch + ((tt * (tt - 1) / 2 + kt) * 4 + s) * 256;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sl[j * 64 + lane] = pk_[j];
-                }
-                tl_sync();
-                for (int t = tt + 1; t < it.nt; ++t) {
-                    const float* sl = s_xch + ((t * (t - 1) / 2 + tt) * 4 + s) * 256;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dk[j] += sl[j * 64 + lane];
-                }
-                tl_sync();
             }
             // ---- G. dA = dQ Wq;  dX = dX1 + dK Wk + dV Wv + LN_a'(dA)
             const int sq = slot; TL_NEXT_SLOT();
@@ -919,14 +941,14 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             {
                 Op64 oo;
                 tl_get(ob, sq, lane, oo);
-                da = tl_mm64(w3, oo);
-                if (!lastb) tl_wload(w3, wf, l - 1, 0, 1, s, lane);
+                da = tl_mm64(wb, oo);
+                tl_wload(wb, wf, l, 2, 1, s, lane);       // Wv
                 tl_get(ob, sk, lane, oo);
-                const f32x4 t1 = tl_mm64(w4, oo);
-                if (!lastb) tl_wload(w4, wf, l - 1, 1, 1, s, lane);
+                const f32x4 t1 = tl_mm64(wa, oo);
+                if (l > 0) tl_wload(wa, wf, l - 1, 5, 1, s, lane);   // the next block's W2
                 tl_get(ob, sv, lane, oo);
-                const f32x4 t2 = tl_mm64(w5, oo);
-                if (!lastb) tl_wload(w5, wf, l - 1, 2, 1, s, lane);
+                const f32x4 t2 = tl_mm64(wb, oo);
+                if (l > 0) tl_wload(wb, wf, l - 1, 4, 1, s, lane);   // ... and W1
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dx1[j] += t1[j] + t2[j];
             }
@@ -963,48 +985,38 @@ __global__ __launch_bounds__(256 * TPW) void enc_tile_step_k(SeEmbed em, const i
             if (gid >= 0) tl_st4(dOut + (int64_t)gid * TL_D + 16 * s + 4 * g, dx);
             tl_st4(H.g_rows + row0 * TL_D + tofs, dx);
         }
-        // ---- the item's loss -> the ticket
-        head_loss = re_wave_sum(head_loss);
-        if (lane == 0) s_red[wave] = head_loss;
-        __syncthreads();
-        if (tid == 0) {
-            double part = 0.0;
-#pragma unroll
-            for (int w = 0; w < TL_NW; w += 4) part += (double)s_red[w];   // (the strip-0 wave of every tile holds the tile's loss)
-            const bool finite = part == part && fabs(part) < 4294967296.0;
-            const unsigned long long add = finite ? (unsigned long long)(long long)llrint(part * 1073741824.0) : 0ull;
-            const unsigned long long old = __hip_atomic_fetch_add(H.acc, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long one = 1ull + (finite ? 0ull : (1ull << 32)) + (old & 0ull);
-            const unsigned long long ticket = __hip_atomic_fetch_add(H.acc + 1, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((int)(ticket & 0xFFFFFFFFull) == n_items - 1) {
-                const unsigned long long tot = __hip_atomic_exchange(H.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool bad = ((ticket + one) >> 32) != 0ull;
-                const int cnt = H.count[0];
-                H.loss[0] = (cnt > 0 && !bad) ? (float)((double)(long long)tot * (1.0 / 1073741824.0) / (double)cnt) : __builtin_nanf("");
-                __hip_atomic_store(H.acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- the tile's loss -> the ticket (strip 0's wave holds it)
+        if (wave == 0) {
+            head_loss = re_wave_sum(head_loss);
+            if (lane == 0) {
+                const double part = (double)head_loss;
+                const bool finite = part == part && fabs(part) < 4294967296.0;
+                const unsigned long long add = finite ? (unsigned long long)(long long)llrint(part * 1073741824.0) : 0ull;
+                const unsigned long long old = __hip_atomic_fetch_add(H.acc, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long one = 1ull + (finite ? 0ull : (1ull << 32)) + (old & 0ull);
+                const unsigned long long ticket = __hip_atomic_fetch_add(H.acc + 1, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(ticket & 0xFFFFFFFFull) == n_tiles - 1) {
+                    const unsigned long long tot = __hip_atomic_exchange(H.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool bad = ((ticket + one) >> 32) != 0ull;
+                    const int cnt = H.count[0];
+                    H.loss[0] = (cnt > 0 && !bad) ? (float)((double)(long long)tot * (1.0 / 1073741824.0) / (double)cnt) : __builtin_nanf("");
+                    __hip_atomic_store(H.acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
-        __syncthreads();   // (the loss partials and every LDS buffer are free for the next item)
     }
 }
 
 int enc_tile_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
-                         uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, int tpw, const EncHead& H,
-                         float* dx0, float* gtape, float* slab, float scale, uint32_t* wf, hipStream_t s) {
+                         uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
+                         float* gtape, float* slab, float scale, uint32_t* wf, float* xch, hipStream_t s) {
     const EncTape T = enc_tape_layout(B, S, TL_D, L);
-    hipLaunchKernelGGL(enc_tile_prep_k, dim3((unsigned)(6 * L * 1024 / 256)), dim3(256), 0, s, P, (int)L, wf);
+    unsigned* epoch = reinterpret_cast<unsigned*>((float*)tape + T.off_FLAGS) + enc_plan_max_tiles(B, S) * EP_FLAG_WORDS + 1;
+    hipLaunchKernelGGL(enc_tile_prep_k, dim3((unsigned)(6 * L * 1024 / 256)), dim3(256), 0, s, P, (int)L, wf, epoch);
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
-    const size_t ldsb = tl_lds_floats((int)L, tpw) * sizeof(float);
-#define TL_LAUNCH(TPW)                                                                                                                  \
-    do {                                                                                                                                \
-        if (hipFuncSetAttribute((const void*)enc_tile_step_k<TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)   \
-            return RE_ELAUNCH;                                                                                                          \
-        hipLaunchKernelGGL(enc_tile_step_k<TPW>, dim3(grid), dim3(256 * TPW), ldsb, s, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, \
-                           (float*)tape, T, plan, H, dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf);                           \
-    } while (0)
-    if (tpw == 1) TL_LAUNCH(1);
-    else if (tpw == 2) TL_LAUNCH(2);
-    else TL_LAUNCH(4);
-#undef TL_LAUNCH
+    const size_t ldsb = tl_lds_floats((int)L) * sizeof(float);
+    if (hipFuncSetAttribute((const void*)enc_tile_step_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+    hipLaunchKernelGGL(enc_tile_step_k, dim3(grid), dim3(256), ldsb, s, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, plan, H,
+                       dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch);
     return hipGetLastError() == hipSuccess ? RE_OK : RE_ELAUNCH;
 }

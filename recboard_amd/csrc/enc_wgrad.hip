@@ -147,7 +147,7 @@ struct EncGradDst {
 __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict__ part, const float* __restrict__ slab, int nwg,
                                                          const void* __restrict__ planp, int B, int S, int D, int L, EncGradDst dst,
                                                          int nmat_blocks, int nvec_blocks, const float* __restrict__ ppart, float inv_scale,
-                                                         float* __restrict__ dPtab) {
+                                                         float* __restrict__ dPtab, int by_tile) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nmat_blocks + nvec_blocks) {
         // position-table gradient: the chunk partials of enc_wgrad_k in chunk order, / scale
@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
     const int cg = job % cgs, v = (job / cgs) % EG_NVEC, l = job / (cgs * EG_NVEC);
     const EncPlan PL = enc_plan_view(planp, B, S);
     const int n_items = PL.hdr[0];
-    const int nact = nwg < 0 ? PL.hdr[1] : (n_items < nwg ? n_items : nwg);   // nwg < 0: one slab row per TILE (enc_tile.hip)
+    // slab rows: one per workgroup that had work, or -- D = 64 steps that ran one tile per workgroup (enc_tile.hip) -- one per tile
+    const int nact = (by_tile && PL.hdr[7] == 1) ? PL.hdr[1] : (n_items < nwg ? n_items : nwg);
     const int lane = tid & 63, wave = tid >> 6;
     const float* sl = slab + ((int64_t)l * EG_NVEC + v) * D + cg * 64 + lane;
     const int64_t stride = (int64_t)L * EG_NVEC * D;
@@ -223,7 +224,7 @@ size_t enc_wgrad_ppart_floats(int64_t B, int64_t D) { return (size_t)64 * ((B + 
 
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
                      int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
-                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s) {
+                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile) {
     if (D != 64 && D != 128) return RE_EUNSUPPORTED;
     const EncTape T = enc_tape_layout(B, S, D, L);
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
@@ -249,6 +250,6 @@ int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tap
     const int npos_blocks = dPtab ? (int)((S * D + 255) / 256) : 0;
     hipLaunchKernelGGL(enc_grad_reduce_k, dim3(nmat_blocks + nvec_blocks + npos_blocks), dim3(256), 0, s, (const float*)part, slab, nwg, plan,
                        (int)B, (int)S, (int)D, (int)L, dst, nmat_blocks, nvec_blocks, (const float*)ppart, emb_scale != 0.f ? 1.0f / emb_scale : 0.f,
-                       dPtab);
+                       dPtab, by_tile);
     return re_launch_status();
 }

@@ -565,7 +565,7 @@ def sasrec_encoder_fwd_loss(E, Ptab, seq, pos, neg, scale, block_tensors, last_w
 
 
 def sasrec_encoder_step(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, last_b, L, drop_p, seed, plan, kind, count, u, tape,
-                        dU_rows, g_rows, keys, loss_ws, dx0, dP, block_grads, g_last_w, g_last_b, ws, e_off=1, loss=None, seed_dev=None, max_tiles=None):
+                        dU_rows, g_rows, keys, loss_ws, dx0, dP, block_grads, g_last_w, g_last_b, ws, e_off=1, loss=None, seed_dev=None):
     """Forward + criterion + backward of the encoder per work item in ONE launch, then the weight gradients (re_sasrec_encoder_step):
     what sasrec_encoder_fwd_loss + sasrec_encoder_bwd(dU_rows=..., out_rows=g_rows[0], dP=...) compute, bit for bit.  -> loss[1]."""
     _req(E, torch.float32, "E"); _req(Ptab, torch.float32, "Ptab"); _req(seq, torch.int64, "seq"); _req(pos, torch.int64, "pos")
@@ -582,7 +582,7 @@ def sasrec_encoder_step(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, la
     tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
     lib.check(lib.load().re_sasrec_encoder_step(_p(E), R, _p(Ptab), float(scale), _p(seq), _p(pos), _p(neg), B, S, D, L, tp, _p(last_w),
                                                 _p(last_b), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(plan), num_cus(E.device),
-                                                int(max_tiles) if max_tiles else globals()["max_tiles"](D), _p(u), _p(tape), tape.numel() * 4, int(e_off), int(kind), _p(count), _p(loss), _p(dU_rows),
+                                                _p(u), _p(tape), tape.numel() * 4, int(e_off), int(kind), _p(count), _p(loss), _p(dU_rows),
                                                 _p(g_rows), _p(keys), _p(loss_ws), loss_ws.numel(), _p(dx0), _p(dP), tg, _p(g_last_w),
                                                 _p(g_last_b), _p(ws), ws.numel(), _stream()), "re_sasrec_encoder_step")
     return loss

@@ -286,11 +286,7 @@ class SASRecEngine:
             return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K, prep=prep)
 
     def _max_tiles(self):
-        """Tiles of 16 rows per work item: the LDS capacity of the workgroup-per-item kernels (4 at D = 64, 2 at D = 128), or the tiles
-        per workgroup of the four-waves-per-tile step (`tiles_per_wg`: 1, 2 or 4; 4 covers every sequence of S <= 64)."""
-        if self._wave_step():
-            return int(getattr(self, "tiles_per_wg", 4))
-        return 4 if self.D == 64 else 2
+        return 4 if self.D == 64 else 2     # tiles of 16 rows per work item (LDS capacity of the workgroup-per-item encoder kernels)
 
     def prepare_batch(self, seq, pos, neg):
         """Per-batch preparation of the fused step as ONE engine launch (re_sasrec_batch_prep; what the reference does at the top of
@@ -309,12 +305,13 @@ class SASRecEngine:
                                    "recengine: a split sequence's work items did not meet (hand-over time-out); results of that step are invalid")
 
     def _wave_step(self):
-        """The training step runs the wave-per-tile kernel (csrc/enc_wave.hip: D = 64, one launch for forward + criterion + backward)."""
+        """The training step may run one tile per workgroup (csrc/enc_tile.hip: D = 64; re_sasrec_encoder_step picks per batch)."""
         return bool(self.D == 64 and self.fused_item_kernel and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
 
     def _plan_ncu(self):
-        """Workgroups the batch plan's items should fill: the wave-per-tile step wants one tile per item (many workgroups per CU)."""
-        return 1024 if self._wave_step() else None
+        """Workgroups the batch plan's items should fill (None: the device's CUs).  The one-tile-per-workgroup step does not read the
+        items at all; its fallback, the workgroup-per-item kernel, wants the default."""
+        return None
 
     def _split(self):
         """Long sequences as two work items in two workgroups: the workgroup-per-item form of the fused training step (its tape carries
@@ -361,8 +358,7 @@ class SASRecEngine:
                 loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
                                                W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
                                                W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
-                                               G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev,
-                                               max_tiles=self._max_tiles())
+                                               G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev)
             else:
                 loss = ops.sasrec_encoder_fwd_loss(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind,
                                                    pb.count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], e_off=1,

@@ -1,13 +1,14 @@
-"""enc_tile_step_k by tiles per workgroup and batch shape (run under rocprofv3 --kernel-trace; diagnostic)."""
+"""The D = 64 encoder step's launches by batch shape (run under rocprofv3 --kernel-trace; diagnostic)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from recboard_amd.sasrec import SASRecEngine
-B, S, N = 512, 50, 12101
+S, N = 50, 12101
 rng = np.random.default_rng(0)
-base = np.clip(rng.geometric(1 / 5.9, B) + 1, 1, S - 1)
-for name, lens, tpw, ncu in (("clip16 tpw1", np.minimum(base, 16), 1, 1024), ("clip16 tpw2", np.minimum(base, 16), 2, 150), ("clip16 tpw4 G1", np.minimum(base, 16), 4, 1024),
-                             ("clip16 tpw4 G4", np.minimum(base, 16), 4, 64), ("beauty tpw4 G1", base, 4, 1024), ("beauty tpw4 G2", base, 4, 180)):
+base = np.clip(rng.geometric(1 / 5.9, 1024) + 1, 1, S - 1)
+for name, lens in (("clip16 B128", np.minimum(base[:128], 16)), ("clip16 B256", np.minimum(base[:256], 16)), ("clip16 B440", np.minimum(base[:440], 16)), ("clip16 B512", np.minimum(base[:512], 16)),
+                   ("clip16 B900", np.minimum(base[:900], 16)), ("beauty B512", base[:512]), ("beauty B400", base[:400])):
+    B = len(lens)
     seq = np.zeros((B, S), np.int64)
     for b in range(B):
         seq[b, S - lens[b]:] = rng.integers(1, N + 1, lens[b])
@@ -15,15 +16,9 @@ for name, lens, tpw, ncu in (("clip16 tpw1", np.minimum(base, 16), 1, 1024), ("c
     neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
     batch = tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg))
     m = SASRecEngine(N, S, 64, 2, dropout_rate=0.5, loss="BCE", lr=5e-4, seed=1)
-    m.tiles_per_wg = tpw
-    m._plan_ncu = lambda ncu=ncu: ncu
+    for _ in range(13):
+        l = m.train_step(*batch)
     torch.cuda.synchronize()
-    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    for _ in range(3):
-        l = m.train_step(*batch)
-    t0.record()
-    for _ in range(10):
-        l = m.train_step(*batch)
-    t1.record(); torch.cuda.synchronize()
-    hdr = m.prepare_batch(*batch).plan.view(torch.int32)[:4].cpu().numpy()
-    print(name, "items", hdr[0], "tiles", hdr[1], "G", hdr[3], "loss", float(l), f"eager step {t0.elapsed_time(t1) / 10 * 1e3:.0f} us")
+    m.check_handover()
+    hdr = m.prepare_batch(*batch).plan.view(torch.int32)[:8].cpu().numpy()
+    print(name, "items", hdr[0], "tiles", hdr[1], "long items", hdr[2], "mode", hdr[7], "loss", float(l))

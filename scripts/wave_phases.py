@@ -16,8 +16,6 @@ ap.add_argument("--ncu", type=int, default=1024)
 args = ap.parse_args()
 B, S, D, L, N = args.B, 50, 64, 2, 12101
 m = SASRecEngine(N, S, D, L, dropout_rate=0.5, loss="BCE", lr=5e-4, weight_decay=1e-6, seed=1)
-m.tiles_per_wg = args.tpw
-m._plan_ncu = lambda: args.ncu
 rng = np.random.default_rng(0)
 lens = np.clip(rng.geometric(1 / 5.9, B) + 1, 1, S - 1) if args.kind == "beauty" else np.full(B, int(args.kind))
 seq = np.zeros((B, S), np.int64)
@@ -31,15 +29,15 @@ for _ in range(5):
     m.train_step(seq, pos, neg)
 torch.cuda.synchronize()
 hdr = m.prepare_batch(seq, pos, neg).plan.view(torch.int32)[:9].cpu().numpy()
-print("items", hdr[0], "tiles", hdr[1], "first item: nt", (int(hdr[8]) >> 24) & 15, "kind", (int(hdr[8]) >> 28) & 15)
+print("items", hdr[0], "tiles", hdr[1], "long items", hdr[2], "mode", hdr[7])
 buf = (ctypes.c_ulonglong * 96)()
 Lb.re_dbg_enc_marks_wave.restype = ctypes.c_int
 assert Lb.re_dbg_enc_marks_wave(buf) == 0
 t = np.array(list(buf), dtype=np.int64)
 nz = np.nonzero(t)[0]
 t = t[: nz[-1] + 1]
-names = ["x0"] + ["LN_a,put", "QKV", "scores,softmax", "PV,put", "Wo,LN_f,put", "W1,put", "W2"] * L + ["lastLN,head,sync"] + \
-        ["lastLN'"] + ["dz,W2'", "W1',LN_f'", "Wo'", "attn dP/dS", "attn dQ/dK/dV,put", "Wq'Wk'Wv',LN_a'"] * L + ["embed'"]
+names = ["x0"] + ["LN_a,put", "QKV,publish/wait", "scores,softmax", "PV,put", "Wo,LN_f,put", "W1,put", "W2"] * L + ["lastLN,head,sync"] + \
+        ["lastLN'"] + ["dz,W2'", "W1',LN_f',put", "Wo'", "attn dP/dS", "attn dQ/dK/dV,xch,put", "Wq'Wk'Wv',LN_a'"] * L + ["embed'"]
 d = np.diff(t)
 print("total", int(t[-1] - t[0]), "ticks")
 for i, x in enumerate(d):
