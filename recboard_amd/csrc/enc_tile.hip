@@ -57,7 +57,8 @@ typedef unsigned tl_u32x2 __attribute__((ext_vector_type(2)));
 #define TL_TILE_LDS (TL_OB + TL_RED + TL_SM + TL_TR)
 #define TL_XCH_TILE (3 * 2 * 4 * 256)   // floats of a key tile's inbox of partial dV / dK: [sender t - kt - 1][dV, dK][strip][4 registers][64 lanes]
 
-size_t enc_tile_wfrag_bytes(int64_t L) { return (size_t)L * 6 * 2 * TL_FRAG_WORDS * 4; }
+// (+ the small parameters of every block and lastLN as one block of (10 L + 2) x 64 floats behind the fragments)
+size_t enc_tile_wfrag_bytes(int64_t L) { return (size_t)L * 6 * 2 * TL_FRAG_WORDS * 4 + (size_t)(TL_NPAR * L + 2) * TL_D * 4; }
 size_t enc_tile_xch_bytes(int64_t B, int64_t S) { return (size_t)enc_plan_max_tiles(B, S) * TL_XCH_TILE * 4; }
 __host__ __device__ inline size_t tl_lds_floats(int L) { return (size_t)(TL_NPAR * L + 2) * TL_D + (size_t)TL_TILE_LDS + 32; }
 
@@ -181,6 +182,18 @@ __device__ __forceinline__ void tl_flag_wait(float* flags, int64_t tile, int wor
 __global__ __launch_bounds__(256) void enc_tile_prep_k(SasrecParams P, int L, uint32_t* __restrict__ wf, unsigned* __restrict__ epoch) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) epoch[0] += 1u;   // the launch's epoch: what this step's hand-over flags are set to (the step kernel runs behind this one)
+    if (t < (TL_NPAR * L + 2) * TL_D) {   // the small parameters, gathered into one block (the step kernel then needs no parameter table)
+        const int v = t / TL_D, cc = t % TL_D;
+        const float* p;
+        if (v >= TL_NPAR * L) p = (v == TL_NPAR * L) ? P.last_w : P.last_b;
+        else {
+            const SasrecBlockParams& Wv = P.blk[v / TL_NPAR];
+            const int kk = v % TL_NPAR;
+            p = (kk == 0) ? Wv.ln_a_w : (kk == 1) ? Wv.ln_a_b : (kk < 5) ? Wv.in_b + (kk - 2) * TL_D : (kk == 5) ? Wv.out_b : (kk == 6) ? Wv.ln_f_w
+              : (kk == 7) ? Wv.ln_f_b : (kk == 8) ? Wv.b1 : Wv.b2;
+        }
+        reinterpret_cast<float*>(wf + (size_t)L * 6 * 2 * TL_FRAG_WORDS)[t] = p[cc];
+    }
     const int lane = t & 63, q = (t >> 6) & 1, s = (t >> 7) & 3, o = (t >> 9) & 1, lm = t >> 10;
     if (lm >= 6 * L) return;
     const int l = lm / 6, m = lm % 6, c = lane & 15, g = lane >> 4;
@@ -214,19 +227,42 @@ extern "C" int re_dbg_enc_marks_wave(unsigned long long* out) {
 #define TL_MARK() do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int64_t* __restrict__ seq, int B, int S, int L, SasrecParams P,
-                                                         float drop_scale, uint32_t thresh, uint32_t seed, float* __restrict__ u,
-                                                         float* __restrict__ tape, EncTape T, const void* __restrict__ planp, EncHead H,
-                                                         float* __restrict__ dOut, float* __restrict__ gtape, float* __restrict__ slab,
-                                                         const uint32_t* __restrict__ seed_dev, float emb_scale,
-                                                         const uint32_t* __restrict__ wf, float* __restrict__ xch) {
-    if (seed_dev) seed ^= seed_dev[0];
-    extern __shared__ __align__(16) float lds[];
-    const EncPlan PL = enc_plan_view(planp, B, S);
-    if (PL.hdr[7] != 1) return;                          // (not a plan for this kernel: the workgroup-per-item kernel behind it runs the step)
-    const int n_tiles = PL.hdr[1];
-    const int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
+struct TlArgs {
+    SeEmbed em;
+    const int64_t* seq;
+    int B, S, L;
+    float drop_scale;
+    uint32_t thresh, seed;
+    float *u, *tape;
+    EncTape T;
+    const void* planp;
+    EncHead H;
+    float *dOut, *gtape, *slab;
+    float emb_scale;
+    const uint32_t* wf;
+    float* xch;
+};
+
+// The work of one tile.  MULTI = a tile of a sequence longer than 16 rows (key tiles 0 .. tt, hand-overs between workgroups); the other
+// instantiation -- a tile shared by short sequences: ONE key tile, nothing crosses workgroups -- is what most tiles of a batch run.
+template <bool MULTI>
+__device__ __forceinline__ void tl_tile(const TlArgs& A, float* lds, const int tile, const int n_tiles, const int2 rm0) {
+    const SeEmbed& em = A.em;
+    const int64_t* __restrict__ seq = A.seq;
+    const int B = A.B, S = A.S, L = A.L;
+    const float drop_scale = A.drop_scale, emb_scale = A.emb_scale;
+    const uint32_t thresh = A.thresh, seed = A.seed;
+    float* __restrict__ u = A.u;
+    float* __restrict__ tape = A.tape;
+    const EncTape& T = A.T;
+    const EncHead& H = A.H;
+    float* __restrict__ dOut = A.dOut;
+    float* __restrict__ gtape = A.gtape;
+    float* __restrict__ slab = A.slab;
+    const uint32_t* __restrict__ wf = A.wf;
+    float* __restrict__ xch = A.xch;
+    const EncPlan PL = enc_plan_view(A.planp, B, S);
+    constexpr int NK = MULTI ? 4 : 1;                    // key tiles a token can attend to
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4, s = wave;
     float* s_par = lds;
@@ -236,22 +272,21 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
     float* scr = sm + TL_SM + s * 320;
     float* flags = tape + T.off_FLAGS;
     const int64_t ferr = enc_plan_max_tiles(B, S) * EP_FLAG_WORDS;
-    const unsigned epoch = reinterpret_cast<const unsigned*>(flags)[ferr + 1];
+    const unsigned epoch = MULTI ? reinterpret_cast<const unsigned*>(flags)[ferr + 1] : 0u;
     const float inv_sqrt_d = 0.125f;
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
     const int tofs = c * TL_D + 16 * s + 4 * g;          // T strip: float4 at row c
     const int fofs = 4 * g * TL_D + 16 * s + c;          // F strip: element j at + j * D
-
     {
         const int k = 0; (void)k;
         // ---- what this tile is: row 0 of a tile is always a real row; a sequence of more than 16 rows owns whole tiles, in order
         const int64_t row0 = (int64_t)tile * 16;                     // compact row of the tile's first row
-        const int2 rm0 = PL.rowmap[row0];
+        constexpr bool multi = MULTI;                                // tile tt of a sequence of nt tiles: k, v and dK, dV cross workgroups
         const int span0 = rm0.x >= 0 ? S - rm0.y : 1;
-        const bool multi = span0 > 16;                               // tile tt of a sequence of nt tiles: k, v and dK, dV cross workgroups
         const int tt = multi ? (rm0.x % S - rm0.y) / 16 : 0, nt = multi ? (span0 + 15) / 16 : 1;
         const int64_t irow0 = row0 - 16 * tt;                        // compact row of the sequence's first row
         const int64_t tile_s0 = tile - tt;                           // the sequence's first tile
+        const int rb = (int)row0 * TL_D, irb = (int)irow0 * TL_D, nrd = (int)(NR * TL_D);   // 32-bit offsets from a block's tape / gradient-tape base
         const int nkx = multi ? tt + 1 : 1;                          // score-exchange rounds (key tiles 0 .. tt of a long sequence, else the own tile)
         constexpr bool live = true;
         int mk = 0; (void)mk;
@@ -289,17 +324,10 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             xe = tl_ld4(em.E + item * TL_D + 16 * s + 4 * g);
             xp = tl_ld4(em.P + (int64_t)(gid % S) * TL_D + 16 * s + 4 * g);
         }
-        // the small parameters of every block and lastLN into LDS (behind the requests above; a vector per wave and round, uniform pointers)
-        for (int v = wave; v < TL_NPAR * L + 2; v += 4) {
-            const float* pv_;
-            if (v >= TL_NPAR * L) pv_ = (v == TL_NPAR * L) ? P.last_w : P.last_b;
-            else {
-                const SasrecBlockParams& W = P.blk[v / TL_NPAR];
-                const int kk = v % TL_NPAR;
-                pv_ = (kk == 0) ? W.ln_a_w : (kk == 1) ? W.ln_a_b : (kk < 5) ? W.in_b + (kk - 2) * TL_D : (kk == 5) ? W.out_b : (kk == 6) ? W.ln_f_w
-                    : (kk == 7) ? W.ln_f_b : (kk == 8) ? W.b1 : W.b2;
-            }
-            s_par[v * TL_D + lane] = pv_[lane];
+        // the small parameters of every block and lastLN into LDS (behind the requests above; enc_tile_prep_k gathered them into one block)
+        {
+            const float* pb = reinterpret_cast<const float*>(wf + (size_t)L * 6 * 2 * TL_FRAG_WORDS);
+            for (int e = tid; e < (TL_NPAR * L + 2) * TL_D; e += 256) s_par[e] = pb[e];
         }
         __syncthreads();
         if (real) {
@@ -358,11 +386,11 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
         do {                                                                                                              \
             float* rb_ = red + rp * (4 * 64 * 16);                                                                        \
             float* smb_ = sm + rp * (4 * 16 * 4);                                                                         \
-            _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_)                                                           \
+            _Pragma("unroll") for (int kt_ = 0; kt_ < NK; ++kt_)                                                           \
                 if (kt_ < (NK)) tl_st4(rb_ + ((s * 64 + lane) * 4 + kt_) * 4, PT[kt_]);                                   \
             if (g == 0) *reinterpret_cast<float2*>(smb_ + (s * 16 + c) * 4) = make_float2(A, Bv);                         \
             tl_sync();                                                                                                    \
-            _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_)                                                           \
+            _Pragma("unroll") for (int kt_ = 0; kt_ < NK; ++kt_)                                                           \
                 if (kt_ < (NK)) {                                                                                         \
                     const f32x4 t0_ = tl_ld4(rb_ + ((0 * 64 + lane) * 4 + kt_) * 4), t1_ = tl_ld4(rb_ + ((1 * 64 + lane) * 4 + kt_) * 4); \
                     const f32x4 t2_ = tl_ld4(rb_ + ((2 * 64 + lane) * 4 + kt_) * 4), t3_ = tl_ld4(rb_ + ((3 * 64 + lane) * 4 + kt_) * 4); \
@@ -391,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
                 const f32x4 gw = tl_ld4(par + 0 * TL_D), gb = tl_ld4(par + 1 * TL_D);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a[j] = fmaf((x[j] - mean) * rstd, gw[j], gb[j]);
-                if (live && g == 0) *reinterpret_cast<float2*>(tp + T.off_SA + (row0 + c) * 2) = make_float2(mean, rstd);   // (written four times over: identical values)
+                if (live && g == 0) *reinterpret_cast<float2*>(tp + ((int)T.off_SA + 2 * ((int)row0 + c))) = make_float2(mean, rstd);   // (written four times over: identical values)
             }
             if (l == 0) tl_wload(wb, wf, 0, 1, 0, s, lane);   // Wk (later blocks: requested at the end of the block before)
             // ---- q = a Wq^T + bq, k = x Wk^T + bk (T strips), v = x Wv^T + bv (F strip)
@@ -399,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             const int sx = slot; TL_NEXT_SLOT();
             tl_put(ob, sa, lane, s, a);
             tl_put(ob, sx, lane, s, x);
-            if (live) { tl_st4(tp + T.off_X + row0 * TL_D + tofs, x); tl_st4(tp + T.off_A + row0 * TL_D + tofs, a); }
+            if (live) { tl_st4(tp + ((int)T.off_X + rb + tofs), x); tl_st4(tp + ((int)T.off_A + rb + tofs), a); }
             tl_sync();
             TL_MARK();
             Op64 ao, xo;
@@ -415,18 +443,18 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             const float bvs = s_par[l * TL_NPAR * TL_D + 4 * TL_D + 16 * s + c];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { q[j] += bq[j]; kk[j] += bk[j]; vf[j] += bvs; }
-            tl_st4(tp + T.off_Q + row0 * TL_D + tofs, q);
+            tl_st4(tp + ((int)T.off_Q + rb + tofs), q);
             if (multi && tt + 1 < nt) {                   // later tiles of the sequence read these rows: device-scope stores, then the flag
-                tl_st4c(tp + T.off_K + row0 * TL_D + tofs, kk);
+                tl_st4c(tp + ((int)T.off_K + rb + tofs), kk);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tl_stc(tp + T.off_V + row0 * TL_D + fofs + j * TL_D, vf[j]);
+                for (int j = 0; j < 4; ++j) tl_stc(tp + ((int)T.off_V + rb + fofs + j * TL_D), vf[j]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) tl_flag_set(flags, tile, l, epoch);
             } else {
-                tl_st4(tp + T.off_K + row0 * TL_D + tofs, kk);
+                tl_st4(tp + ((int)T.off_K + rb + tofs), kk);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tp[T.off_V + row0 * TL_D + fofs + j * TL_D] = vf[j];
+                for (int j = 0; j < 4; ++j) tp[(int)T.off_V + rb + fofs + j * TL_D] = vf[j];
             }
             if (tt > 0) {                                 // the earlier tiles' k, v of this block
                 if (tid == 0)
@@ -450,20 +478,20 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
                 }
                 cntf = tl_gsum((float)cnt);
             }
-            f32x4 p[4];
+            f32x4 p[NK];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 p[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (kt >= nkx) continue;                   // (workgroup-uniform: every wave takes part in every round of the item)
                 const int ktc = multi ? kt : tt;
                 Op16 ko;
                 if (ktc == tt) tl_split4(kk, ko);
-                else tl_split4(tl_ld4c(tp + T.off_K + (irow0 + 16 * ktc) * TL_D + tofs), ko);
+                else tl_split4(tl_ld4c(tp + ((int)T.off_K + irb + 16 * TL_D * ktc + tofs)), ko);
                 p[kt] = tl_mm16(ko, qo, p[kt]);
             }
             TL_TILES_SUM(p, nkx, dqb, cntf);
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) p[kt][j] *= inv_sqrt_d;
@@ -475,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             float mx = -INFINITY;
             unsigned okm = 0u;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 if (kt >= nkx) continue;                   // (uniform: a tile of short sequences has one key tile)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -490,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             mx = tl_gmax(fmaxf(mx, spad));
             float sum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -505,11 +533,11 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             const float ppad = epad * inv;
             const float kept = thresh ? cntf * drop_scale : (float)n_out;
             const float wvv = (gid >= 0) ? ppad * kept : 0.f;
-            if (live && s == 0 && g == 0) *reinterpret_cast<float2*>(tp + T.off_PP + (row0 + c) * 2) = make_float2(ppad, wvv);
+            if (live && s == 0 && g == 0) *reinterpret_cast<float2*>(tp + ((int)T.off_PP + 2 * ((int)row0 + c))) = make_float2(ppad, wvv);
             unsigned amask = 0xFFFFu;
-            f32x4 pd[4];
+            f32x4 pd[NK];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 pd[kt] = p[kt];
                 if (kt >= nkx) continue;
 #pragma unroll
@@ -517,13 +545,13 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
                 pd[kt] = p[kt];
                 const int ktc = multi ? kt : tt;
                 if (s == 0)   // pre-dropout probabilities (0 outside the token's window): row c, key columns 16 kt + 4 g ..
-                    tl_st4(tp + T.off_P + (row0 + c) * EP_PW + 16 * ktc + 4 * g, p[kt]);
+                    tl_st4(tp + ((int)T.off_P + ((int)row0 + c) * EP_PW + 16 * ktc + 4 * g), p[kt]);
             }
             if (thresh) {
                 amask = 0u;
                 const uint32_t e0 = (uint32_t)((int64_t)gid * S + n_out - st);   // + item-local key row: the key's position in the sequence
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
+                for (int kt = 0; kt < NK; ++kt) {
                     const int ktc = multi ? kt : tt;
                     if (kt >= nkx || ktc > tt) continue;
 #pragma unroll
@@ -538,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             // ---- o = Pd v + w b_v   (T strip of o = sum over key tiles of F(v strip)-as-A x Rt(Pd)-as-B)
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 const int ktc = multi ? kt : tt;
                 if (kt >= nkx || ktc > tt) continue;
                 Op16 po, vo;
@@ -546,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
                 f32x4 vt = vf;
                 if (ktc != tt) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) vt[j] = tl_ldc(tp + T.off_V + (irow0 + 16 * ktc) * TL_D + fofs + j * TL_D);
+                    for (int j = 0; j < 4; ++j) vt[j] = tl_ldc(tp + ((int)T.off_V + irb + 16 * TL_D * ktc + fofs + j * TL_D));
                 }
                 tl_split4(vt, vo);
                 o = tl_mm16(vo, po, o);
@@ -556,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             // ---- x1 = o Wo^T + bo + x
             const int so = slot; TL_NEXT_SLOT();
             tl_put(ob, so, lane, s, o);
-            if (live) tl_st4(tp + T.off_O + row0 * TL_D + tofs, o);
+            if (live) tl_st4(tp + ((int)T.off_O + rb + tofs), o);
             tl_sync();
             TL_MARK();
             f32x4 x1;
@@ -569,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x1[j] += bo[j] + x[j];
             }
-            if (live) tl_st4(tp + T.off_X1 + row0 * TL_D + tofs, x1);
+            if (live) tl_st4(tp + ((int)T.off_X1 + rb + tofs), x1);
             // ---- y = LN_f(x1)
             f32x4 y;
             {
@@ -578,12 +606,12 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
                 const f32x4 gw = tl_ld4(par + 6 * TL_D), gb = tl_ld4(par + 7 * TL_D);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = fmaf((x1[j] - mean) * rstd, gw[j], gb[j]);
-                if (live && g == 0) *reinterpret_cast<float2*>(tp + T.off_SF + (row0 + c) * 2) = make_float2(mean, rstd);
+                if (live && g == 0) *reinterpret_cast<float2*>(tp + ((int)T.off_SF + 2 * ((int)row0 + c))) = make_float2(mean, rstd);
             }
             // ---- hr = relu(dropout1(y W1^T + b1))
             const int sy = slot; TL_NEXT_SLOT();
             tl_put(ob, sy, lane, s, y);
-            if (live) tl_st4(tp + T.off_Y + row0 * TL_D + tofs, y);
+            if (live) tl_st4(tp + ((int)T.off_Y + rb + tofs), y);
             tl_sync();
             TL_MARK();
             f32x4 hr;
@@ -606,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             // ---- x' = dropout2(hr W2^T + b2) + y, pad rows zeroed
             const int sh = slot; TL_NEXT_SLOT();
             tl_put(ob, sh, lane, s, hr);
-            if (live) tl_st4(tp + T.off_HR + row0 * TL_D + tofs, hr);
+            if (live) tl_st4(tp + ((int)T.off_HR + rb + tofs), hr);
             tl_sync();
             TL_MARK();
             unsigned m2 = 0xFu;
@@ -630,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
                 }
             }
             // the block's mask bits for the backward: one word per lane and strip ([tile][4 strips][64] words of the tape's mask array)
-            if (live) reinterpret_cast<uint32_t*>(tp + T.off_MK)[row0 * 16 + s * 64 + lane] = m2 | (hmask << 4) | (amask << 8);
+            if (live) reinterpret_cast<uint32_t*>(tp)[(int)T.off_MK + (int)row0 * 16 + s * 64 + lane] = m2 | (hmask << 4) | (amask << 8);
         }
         TL_MARK();
         // ---- u = LN_last(x_L)
@@ -726,10 +754,10 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             const float2 sf = sf_n, ppw = ppw_n;
             if (l > 0) {
                 const float* tn = tp - T.per_block;
-                mw_n = reinterpret_cast<const uint32_t*>(tn + T.off_MK)[row0 * 16 + s * 64 + lane];
-                x1_n = tl_ld4(tn + T.off_X1 + row0 * TL_D + tofs);
-                sf_n = *reinterpret_cast<const float2*>(tn + T.off_SF + (row0 + c) * 2);
-                ppw_n = *reinterpret_cast<const float2*>(tn + T.off_PP + (row0 + c) * 2);
+                mw_n = reinterpret_cast<const uint32_t*>(tn)[(int)T.off_MK + (int)row0 * 16 + s * 64 + lane];
+                x1_n = tl_ld4(tn + ((int)T.off_X1 + rb + tofs));
+                sf_n = *reinterpret_cast<const float2*>(tn + ((int)T.off_SF + 2 * ((int)row0 + c)));
+                ppw_n = *reinterpret_cast<const float2*>(tn + ((int)T.off_PP + 2 * ((int)row0 + c)));
             }
             // ---- pad mask of the block output, dO2 = dX' * dropout2 mask
             f32x4 dz;
@@ -740,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             }
             const int s0 = slot; TL_NEXT_SLOT();
             tl_put(ob, s0, lane, s, dz);
-            if (live) tl_st4(gp + 0 * NR * TL_D, dz);
+            if (live) tl_st4(gp + 0 * nrd, dz);
             TL_COLSUM(5, dz);
             tl_sync();
             // ---- A. dH = (dO2 W2) * (hr > 0) * scale
@@ -755,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             }
             const int s1s = slot; TL_NEXT_SLOT();
             tl_put(ob, s1s, lane, s, dh);
-            if (live) tl_st4(gp + 1 * NR * TL_D, dh);
+            if (live) tl_st4(gp + 1 * nrd, dh);
             TL_COLSUM(4, dh);
             tl_sync();
             TL_MARK();
@@ -793,19 +821,19 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             }
             const int s2s = slot; TL_NEXT_SLOT();
             tl_put(ob, s2s, lane, s, dx1);
-            if (live) tl_st4(gp + 2 * NR * TL_D, dx1);
+            if (live) tl_st4(gp + 2 * nrd, dx1);
             TL_COLSUM(3, dx1);
             // q and the own tile's k in F layout, v in T layout, x and LN_a's statistics: requested here, used behind the products below
             f32x4 qf, kf_own;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                qf[j] = tp[T.off_Q + row0 * TL_D + fofs + j * TL_D];
-                kf_own[j] = tp[T.off_K + row0 * TL_D + fofs + j * TL_D];
+                qf[j] = tp[(int)T.off_Q + rb + fofs + j * TL_D];
+                kf_own[j] = tp[(int)T.off_K + rb + fofs + j * TL_D];
             }
-            const f32x4 vt_own = tl_ld4(tp + T.off_V + row0 * TL_D + tofs);
-            const f32x4 qt = tl_ld4(tp + T.off_Q + row0 * TL_D + tofs);
-            const f32x4 xx = tl_ld4(tp + T.off_X + row0 * TL_D + tofs);
-            const float2 sa_ = *reinterpret_cast<const float2*>(tp + T.off_SA + (row0 + c) * 2);
+            const f32x4 vt_own = tl_ld4(tp + ((int)T.off_V + rb + tofs));
+            const f32x4 qt = tl_ld4(tp + ((int)T.off_Q + rb + tofs));
+            const f32x4 xx = tl_ld4(tp + ((int)T.off_X + rb + tofs));
+            const float2 sa_ = *reinterpret_cast<const float2*>(tp + ((int)T.off_SA + 2 * ((int)row0 + c)));
             tl_sync();
             TL_MARK();
             // ---- D. dO = dX1 Wo, as T strip and as F strip (the same fragments, operands swapped)
@@ -830,16 +858,16 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             }
             Op16 doo;
             tl_split4(dO, doo);
-            f32x4 p[4], ds[4];                             // ds: first dP, then dS (the dropped probabilities are rebuilt from the mask bits where they are used)
+            f32x4 p[NK], ds[NK];                            // ds: first dP, then dS (the dropped probabilities are rebuilt from the mask bits where they are used)
             float srw = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 p[kt] = ds[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (kt >= nkx) continue;
                 const int ktc = multi ? kt : tt;
-                p[kt] = tl_ld4(tp + T.off_P + (row0 + c) * EP_PW + 16 * ktc + 4 * g);
+                p[kt] = tl_ld4(tp + ((int)T.off_P + ((int)row0 + c) * EP_PW + 16 * ktc + 4 * g));
                 Op16 vo;
-                tl_split4(ktc == tt ? vt_own : tl_ld4c(tp + T.off_V + (irow0 + 16 * ktc) * TL_D + tofs), vo);
+                tl_split4(ktc == tt ? vt_own : tl_ld4c(tp + ((int)T.off_V + irb + 16 * TL_D * ktc + tofs)), vo);
                 ds[kt] = tl_mm16(vo, doo, ds[kt]);         // partial (dO_i . v_j) for token i = c, keys 4 g + j
             }
             {
@@ -847,7 +875,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
                 TL_TILES_SUM(ds, nkx, tdot, zb);
             }
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -860,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             srw = fmaf(tdot, wvv, srw);                                            // the row dot includes the pad copies
             const float cpad = (wvv * tdot - (float)n_out * ppad * srw) * inv_sqrt_d;   // sum of dS over the pad copies
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 if (kt >= nkx) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ds[kt][j] = p[kt][j] * (ds[kt][j] - srw) * inv_sqrt_d;
@@ -872,13 +900,13 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             tl_split4(dOf, do4);
             f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f}, dk = dq, dv = dq;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NK; ++kt) {
                 const int ktc = multi ? kt : tt;
                 if (kt >= nkx || ktc > tt) continue;
                 f32x4 kf = kf_own;
                 if (ktc != tt) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) kf[j] = tl_ldc(tp + T.off_K + (irow0 + 16 * ktc) * TL_D + fofs + j * TL_D);
+                    for (int j = 0; j < 4; ++j) kf[j] = tl_ldc(tp + ((int)T.off_K + irb + 16 * TL_D * ktc + fofs + j * TL_D));
                 }
                 Op16 ko, dso, pdr, dsr;
                 tl_split4(kf, ko);
@@ -925,7 +953,7 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
             tl_put(ob, sq, lane, s, dq);
             tl_put(ob, sk, lane, s, dk);
             tl_put(ob, sv, lane, s, dv);
-            if (live) { tl_st4(gp + 3 * NR * TL_D, dq); tl_st4(gp + 4 * NR * TL_D, dk); tl_st4(gp + 5 * NR * TL_D, dv); }
+            if (live) { tl_st4(gp + 3 * nrd, dq); tl_st4(gp + 4 * nrd, dk); tl_st4(gp + 5 * nrd, dv); }
             TL_COLSUM(0, dq);
             {
                 f32x4 t;
@@ -1007,6 +1035,25 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
     }
 }
 
+__global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int64_t* __restrict__ seq, int B, int S, int L,
+                                                         float drop_scale, uint32_t thresh, uint32_t seed, float* __restrict__ u,
+                                                         float* __restrict__ tape, EncTape T, const void* __restrict__ planp, EncHead H,
+                                                         float* __restrict__ dOut, float* __restrict__ gtape, float* __restrict__ slab,
+                                                         const uint32_t* __restrict__ seed_dev, float emb_scale,
+                                                         const uint32_t* __restrict__ wf, float* __restrict__ xch) {
+    extern __shared__ __align__(16) float lds[];
+    const EncPlan PL = enc_plan_view(planp, B, S);
+    if (PL.hdr[7] != 1) return;                          // (not a plan for this kernel: the workgroup-per-item kernel behind it runs the step)
+    const int n_tiles = PL.hdr[1];
+    const int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    if (seed_dev) seed ^= seed_dev[0];
+    const TlArgs A{em, seq, B, S, L, drop_scale, thresh, seed, u, tape, T, planp, H, dOut, gtape, slab, emb_scale, wf, xch};
+    const int2 rm0 = PL.rowmap[(int64_t)tile * 16];
+    if (rm0.x >= 0 && S - rm0.y > 16) tl_tile<true>(A, lds, tile, n_tiles, rm0);
+    else tl_tile<false>(A, lds, tile, n_tiles, rm0);
+}
+
 int enc_tile_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
                          uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
                          float* gtape, float* slab, float scale, uint32_t* wf, float* xch, hipStream_t s) {
@@ -1016,7 +1063,7 @@ int enc_tile_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     const size_t ldsb = tl_lds_floats((int)L) * sizeof(float);
     if (hipFuncSetAttribute((const void*)enc_tile_step_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-    hipLaunchKernelGGL(enc_tile_step_k, dim3(grid), dim3(256), ldsb, s, em, seq, (int)B, (int)S, (int)L, P, ds, thresh, seed, u, (float*)tape, T, plan, H,
+    hipLaunchKernelGGL(enc_tile_step_k, dim3(grid), dim3(256), ldsb, s, em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H,
                        dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch);
     return hipGetLastError() == hipSuccess ? RE_OK : RE_ELAUNCH;
 }
