@@ -1,0 +1,336 @@
+"""`freerec.launcher.Coach`: the training / evaluation loop the scripts drive (`Coach(dataset=, trainpipe=, validpipe=, testpipe=, model=,
+cfg=).fit()`, SASRec/main.py:278-286).  Written from the call sites: overridable `set_optimizer /
+set_lr_scheduler / set_other / train_per_epoch / evaluate`; `self.dataloader`, `dict_to_device`, `monitor(...)`, `register_metric`,
+`self._best`, `self.lr_scheduler`, `self.User / Item / ISeq / ... / Size`, `remove_seen`; evaluate contract mirrored at
+UniSRec/main.py:400-447; fit loop shape evidenced by ETEGRec/train_etegrec.py:625-650; checkpoint.tar keys by :549-574.
+
+ENGINE ROUTING (cfg.engine = "auto", the default): a model the recengine has a fused step for -- a SASRec-shaped module: `Item.embeddings`,
+`Position`, `attnLNs / attnLayers / fwdLNs / fwdLayers`, `lastLN`, BCE / BPR criterion, D in (64, 128), one head, maxlen <= 64, Adam -- is
+trained through `recboard_amd.sasrec.SASRecEngine.train_step_graph` (one batch-preparation launch + one hipGraph replay per step) instead
+of the script's `train_per_epoch`; the module's parameters become views of the engine's arena, so `state_dict()`, the script's own
+`recommend_from_full` and checkpoints see the trained values.  Full-ranking evaluation of dot-product models runs on the fused
+score + seen-mask + top-K kernel and the metrics kernel.  `--engine module` keeps everything on the script's own torch code."""
+import json
+import os
+import time
+from collections import defaultdict
+
+import torch
+
+from . import ddp, metrics, utils
+from .data import tags as T
+
+DEFAULT_METRICS = dict(metrics.DEFAULT_METRICS)
+DEFAULT_FMTS = defaultdict(lambda: ".4f", {"LOSS": ".5f"})
+DEFAULT_BEST_CASTER = defaultdict(lambda: max, {"LOSS": min, "LOGLOSS": min, "MSE": min, "MAE": min, "RMSE": min})
+
+
+class EarlyStopError(Exception):
+    pass
+
+
+class _Meter:
+    def __init__(self, name, func=None, fmt=".4f", best_caster=max):
+        self.name, self.func, self.fmt, self.caster = name, func, fmt, best_caster
+        self.history = []
+        self.reset()
+
+    def reset(self):
+        self.sum, self.n = 0.0, 0
+
+    def update(self, val, n=1, reduction="mean"):
+        val = float(val)
+        self.sum += val * n if reduction == "mean" else val
+        self.n += n
+
+    @property
+    def avg(self):
+        return self.sum / self.n if self.n else 0.0
+
+    def step(self):
+        self.history.append(self.avg if self.n else None)
+        self.reset()
+
+    def best(self):
+        h = [v for v in self.history if v is not None]
+        return self.caster(h) if h else None
+
+
+class Coach:
+    def __init__(self, *, dataset, trainpipe, validpipe, testpipe, model, cfg):
+        self.dataset, self.cfg = dataset, cfg
+        self.trainpipe, self.validpipe, self.testpipe = trainpipe, validpipe, testpipe
+        self.fields = getattr(dataset, "fields", None)
+        for name in ("User", "Item", "ISeq", "IPos", "INeg", "IUnseen", "ISeen", "Label", "Size"):
+            if hasattr(model, name):
+                setattr(self, name, getattr(model, name))
+        self.remove_seen = not bool(cfg.get("retain_seen", False))
+        self.set_device()
+        self.set_model(model)
+        self.set_dataloader()
+        self.set_optimizer()
+        self.set_lr_scheduler()
+        self._meters = {m: {} for m in ("train", "valid", "test")}
+        self._register_default_monitors()
+        self.set_other()
+        self._best, self._best_epoch = (float("inf") if self._best_caster() is min else -float("inf")), 0
+        self._stopping_steps = 0
+        self.path = cfg.get("checkpoint_path") or os.path.join("logs", str(cfg.get("description", "RecSys")), str(cfg.get("dataset")), str(cfg.get("id") or time.strftime("%m%d%H%M%S")))
+        self._engine = self._attach_engine()
+
+    # ---- set-up hooks the scripts override
+    def set_device(self):
+        want = str(self.cfg.get("device", "cuda:0"))
+        if want.startswith("cuda") and not torch.cuda.is_available():
+            want = "cpu"
+        if want.startswith("cuda") and ddp.is_distributed():
+            want = f"cuda:{ddp.get_local_rank()}"
+        self.device = torch.device(want)
+
+    def set_model(self, model):
+        self.model = model.to(self.device)
+
+    def get_res_sys_arch(self):
+        m = self.model
+        return m.module if hasattr(m, "module") and isinstance(m, torch.nn.parallel.DistributedDataParallel) else m
+
+    def set_dataloader(self):
+        # (the pipes are batch iterables themselves: batch assembly is vectorised, there are no worker processes to start)
+        self.dataloader = self.trainpipe
+
+    def set_optimizer(self):
+        cfg, name = self.cfg, str(self.cfg.get("optimizer", "adam")).lower()
+        params = self.model.parameters()
+        if name == "sgd":
+            self.optimizer = torch.optim.SGD(params, lr=cfg.lr, momentum=cfg.get("momentum", 0.9), weight_decay=cfg.weight_decay, nesterov=cfg.get("nesterov", False))
+        elif name == "adam":
+            self.optimizer = torch.optim.Adam(params, lr=cfg.lr, betas=(cfg.get("beta1", 0.9), cfg.get("beta2", 0.999)), weight_decay=cfg.weight_decay)
+        elif name == "adamw":
+            self.optimizer = torch.optim.AdamW(params, lr=cfg.lr, betas=(cfg.get("beta1", 0.9), cfg.get("beta2", 0.999)), weight_decay=cfg.weight_decay)
+        else:
+            raise NotImplementedError(f"Unexpected optimizer {cfg.optimizer} ...")
+
+    def set_lr_scheduler(self):
+        self.lr_scheduler = None
+
+    def set_other(self):
+        pass
+
+    # ---- monitors
+    def _best_caster(self):
+        return DEFAULT_BEST_CASTER[str(self.cfg.get("which4best", "LOSS")).split("@")[0].upper()]
+
+    def register_metric(self, name, func=None, fmt=".4f", best_caster=max, prefix=None):
+        name = name.upper()
+        for mode in self._meters:
+            self._meters[mode][name] = _Meter(name, func, fmt, best_caster)
+
+    def _register_default_monitors(self):
+        for mon in self.cfg.get("monitors", []) or []:
+            fam = mon.split("@")[0].upper()
+            self.register_metric(mon.upper(), DEFAULT_METRICS.get(fam), DEFAULT_FMTS[fam], DEFAULT_BEST_CASTER[fam])
+        if "LOSS" not in self._meters["train"]:
+            self.register_metric("LOSS", None, DEFAULT_FMTS["LOSS"], min)
+
+    def monitor(self, *values, n=1, reduction="mean", mode="train", pool=None):
+        """`monitor(loss.item(), n=, reduction=, mode="train", pool=["LOSS"])` or `monitor(scores, targets, n=, mode=, pool=[families])`:
+        every registered monitor whose family is in `pool` is updated (a "NAME@k" monitor calls its metric with k)."""
+        pool = [p.upper() for p in (pool or [])]
+        for name, meter in self._meters[mode].items():
+            fam = name.split("@")[0]
+            if fam not in pool and name not in pool:
+                continue
+            if meter.func is None or len(values) == 1 and not torch.is_tensor(values[0]):
+                meter.update(values[0], n, reduction)
+            else:
+                kw = {"k": int(name.split("@")[1])} if "@" in name else {}
+                meter.update(meter.func(*values, reduction="mean", **kw), n, "mean")
+
+    def _step_meters(self, mode):
+        out = {}
+        for name, meter in self._meters[mode].items():
+            if meter.n:
+                out[name] = meter.avg
+            meter.step()
+        return out
+
+    # ---- data movement
+    def dict_to_device(self, data):
+        return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in data.items()}
+
+    # ---- the loops
+    def train_per_epoch(self, epoch):
+        raise NotImplementedError("train_per_epoch: the scripts define the step loop (SASRec/main.py:242-258)")
+
+    def train(self, epoch):
+        self.dataloader = self.trainpipe
+        self.get_res_sys_arch().train()
+        if self._engine is not None:
+            self._engine.train_epoch(self, epoch)
+        else:
+            self.train_per_epoch(epoch)
+        return self._step_meters("train")
+
+    @torch.no_grad()
+    def valid(self, epoch, step=-1):
+        self.dataloader = self.validpipe
+        self.get_res_sys_arch().eval()
+        self._evaluate(epoch, step, "valid")
+        return self._step_meters("valid")
+
+    @torch.no_grad()
+    def test(self, epoch, step=-1):
+        self.dataloader = self.testpipe
+        self.get_res_sys_arch().eval()
+        self._evaluate(epoch, step, "test")
+        return self._step_meters("test")
+
+    def _evaluate(self, epoch, step, mode):
+        # a subclass's own `evaluate` wins; otherwise the fused path where it applies, else the reference's dense path
+        if type(self).evaluate is not Coach.evaluate or self.cfg.get("engine", "auto") == "module" or not self._fused_eval(mode):
+            self.evaluate(epoch, step, mode)
+
+    def evaluate(self, epoch, step=-1, mode="valid"):
+        """The reference's dense evaluation (contract: UniSRec/main.py:400-447)."""
+        arch = self.get_res_sys_arch()
+        arch.reset_ranking_buffers()
+        pred = isinstance(arch, __import__("freerec").models.PredRecArch)
+        for data in self.dataloader:
+            bsz = data.get(self.Size, None) if hasattr(self, "Size") else None
+            data = self.dict_to_device(data)
+            if pred:
+                scores = self.model(data, ranking="pool")
+                targets = data[self.Label]
+                self.monitor(scores.reshape(-1), targets.reshape(-1), n=len(targets), mode=mode, pool=["LOGLOSS", "AUC"])
+                continue
+            if self.cfg.ranking == "full":
+                scores = self.model(data, ranking="full")
+                if self.remove_seen:
+                    seen = self.Item.to_csr(data[self.ISeen]).to(self.device).to_dense().bool()
+                    scores[seen] = -1e23
+                targets = self.Item.to_csr(data[self.IUnseen]).to(self.device).to_dense()
+            elif self.cfg.ranking == "pool":
+                scores = self.model(data, ranking="pool")
+                targets = torch.zeros_like(scores)
+                targets[:, 0].fill_(1)
+            else:
+                raise NotImplementedError(f"`ranking` should be 'full' or 'pool' but {self.cfg.ranking} received ...")
+            self.monitor(scores, targets, n=bsz if bsz is not None else scores.shape[0], reduction="mean", mode=mode,
+                         pool=["HITRATE", "PRECISION", "RECALL", "NDCG", "MRR"])
+
+    def _fused_eval(self, mode):
+        """Full ranking on the engine's fused score + mask + top-K and metrics kernels, for models that expose what a dot-product score
+        needs (the engine adapter, or `recommend_topk`).  -> False when it does not apply."""
+        if self.device.type != "cuda" or self.cfg.get("ranking", "full") != "full" or self._engine is None:
+            return False
+        from recboard_amd.evaluate import RankingEvaluator, ragged_to_csr
+        mons = [m for m in self._meters[mode] if "@" in m]
+        if not mons:
+            return True
+        ev = RankingEvaluator(mons)
+        self._engine.reset_ranking_buffers()
+        for data in self.dataloader:
+            empty = [[] for _ in data[self.ISeen]]
+            seen_ptr, seen_idx = ragged_to_csr(data[self.ISeen] if self.remove_seen else empty, self.device)
+            tgt_ptr, tgt_idx = ragged_to_csr(data[self.IUnseen], self.device)
+            _, idx = self._engine.recommend_topk(self, data, seen_ptr, seen_idx, ev.kmax)
+            ev.update(idx, tgt_ptr, tgt_idx)
+        for name, val in ev.compute().items():
+            self._meters[mode][name].update(val, max(ev.n, 1), "mean")
+        return True
+
+    # ---- engine routing
+    def _attach_engine(self):
+        if self.cfg.get("engine", "auto") == "module" or self.device.type != "cuda":
+            return None
+        try:
+            from recboard_amd import bridge
+        except Exception:  # noqa: BLE001  (the engine library is not built: the script's own torch code runs)
+            return None
+        return bridge.attach(self)
+
+    # ---- checkpoints / results (checkpoint.tar {epoch, model, optimizer, lr_scheduler, monitors}, best.pt)
+    def save_checkpoint(self, epoch):
+        utils.mkdirs(self.path)
+        opt = self._engine.optimizer_state() if self._engine is not None else self.optimizer.state_dict()
+        torch.save({"epoch": epoch, "model": self.get_res_sys_arch().state_dict(), "optimizer": opt,
+                    "lr_scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
+                    "monitors": {mode: {k: m.history for k, m in ms.items()} for mode, ms in self._meters.items()}},
+                   os.path.join(self.path, "checkpoint.tar"))
+
+    def load_checkpoint(self):
+        ck = torch.load(os.path.join(self.path, "checkpoint.tar"), map_location=self.device, weights_only=False)
+        self.get_res_sys_arch().load_state_dict(ck["model"])
+        if self._engine is not None:
+            self._engine.load_optimizer_state(ck["optimizer"])
+        else:
+            self.optimizer.load_state_dict(ck["optimizer"])
+        if self.lr_scheduler is not None and ck.get("lr_scheduler"):
+            self.lr_scheduler.load_state_dict(ck["lr_scheduler"])
+        for mode, ms in (ck.get("monitors") or {}).items():
+            for k, h in ms.items():
+                if k in self._meters[mode]:
+                    self._meters[mode][k].history = list(h)
+        return ck["epoch"]
+
+    def save_best(self):
+        utils.mkdirs(self.path)
+        torch.save(self.get_res_sys_arch().state_dict(), os.path.join(self.path, "best.pt"))
+
+    def load_best(self):
+        p = os.path.join(self.path, "best.pt")
+        if os.path.exists(p):
+            self.get_res_sys_arch().load_state_dict(torch.load(p, map_location=self.device))
+
+    def resume(self):
+        if self.cfg.get("resume") and os.path.exists(os.path.join(self.path, "checkpoint.tar")):
+            return self.load_checkpoint() + 1
+        return 0
+
+    def check_best(self, epoch, results):
+        key = str(self.cfg.get("which4best", "LOSS")).upper()
+        if key not in results:
+            return
+        caster = self._best_caster()
+        if caster(results[key], self._best) == results[key] and results[key] != self._best:
+            self._best, self._best_epoch, self._stopping_steps = results[key], epoch, 0
+            self.save_best()
+        else:
+            self._stopping_steps += 1
+            if self._stopping_steps > self.cfg.get("early_stop_patience", 1e23):
+                raise EarlyStopError
+
+    def summary(self):
+        best = {mode: {k: m.best() for k, m in ms.items() if m.best() is not None} for mode, ms in self._meters.items()}
+        utils.mkdirs(self.path)
+        with open(os.path.join(self.path, "results.json"), "w") as f:
+            json.dump({"best": best, "best_epoch": self._best_epoch, "config": {k: v for k, v in self.cfg.to_dict().items() if isinstance(v, (int, float, str, bool, list, dict, type(None)))}}, f, indent=2)
+        return best
+
+    def fit(self):
+        cfg = self.cfg
+        epochs = int(cfg.get("epochs") or 0)
+        start = self.resume()
+        results = {}
+        try:
+            for epoch in range(start, epochs):
+                if epoch % int(cfg.get("eval_freq", 5)) == 0:
+                    if cfg.get("eval_valid", True) and self.validpipe is not None:
+                        results = self.valid(epoch)
+                        self.check_best(epoch, results)
+                    if cfg.get("eval_test", False) and self.testpipe is not None:
+                        self.test(epoch)
+                tr = self.train(epoch)
+                utils.infoLogger(f"[Coach] >>> TRAIN @Epoch: {epoch:<4d} >>> " + " || ".join(f"{k} Avg: {v:.5f}" for k, v in tr.items()))
+                if cfg.get("checkpoint_freq"):
+                    self.save_checkpoint(epoch)
+        except EarlyStopError:
+            utils.infoLogger(f"[Coach] >>> Early Stop @Epoch: {epoch}")
+        if self.validpipe is not None:
+            results = self.valid(epochs)
+            self.check_best(epochs, results)
+        self.save_checkpoint(epochs)
+        self.load_best()
+        out = {"valid": self.valid(epochs) if self.validpipe is not None else {}, "test": self.test(epochs) if self.testpipe is not None else {}}
+        out["best"] = self.summary()
+        return out

@@ -1,0 +1,180 @@
+"""The `freerec`-compatible surface (freerec/: the builder's own package) against the reference's model files IMPORTED IN PLACE from
+/root/reference (never copied; skipped where the reference is absent, i.e. on the GPU box): the scripts import, their models build on
+this package's datasets / fields, load the golden state dicts, and reproduce the golden losses, gradients and scores -- which were
+produced with the test stand-in (tests/golden/_freerec_standin.py), so the two restatements of the FreeRec surface pin each other."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference is not on this machine")
+
+
+def import_script(path, name, argv):
+    """Import a model script under a private module name (its module-level `cfg.compile()` parses sys.argv)."""
+    old_argv, old_path = sys.argv, list(sys.path)
+    sys.argv = ["main.py"] + argv
+    sys.path.insert(0, os.path.dirname(path))
+    sys.path.insert(0, ROOT)
+    for k in [k for k in sys.modules if k == "freerec" or k.startswith("freerec.")]:
+        if "golden" in str(getattr(sys.modules[k], "__file__", "")):
+            del sys.modules[k]
+    try:
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    finally:
+        sys.argv, sys.path[:] = old_argv, old_path
+
+
+def toy_dataset(U, N):
+    import freerec
+    e = np.zeros(0, np.int64)
+    return freerec.data.datasets.RecDataSet.from_splits((e, e), (e, e), (e, e), U, N)
+
+
+def load_golden_state(model, z):
+    sd = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}
+    model.load_state_dict({k: sd[k] for k in model.state_dict() if k in sd}, strict=False)
+    assert set(k for k, _ in model.named_parameters()) <= set(sd)
+
+
+@needs_ref
+@pytest.mark.parametrize("loss,fixture", [("BCE", "sasrec_bce.npz"), ("BPR", "sasrec_bpr.npz"), ("CE", "sasrec_ce.npz")])
+def test_reference_sasrec_runs_unchanged_and_reproduces_the_golden(loss, fixture):
+    ref = import_script(os.path.join(REF, "SASRec", "main.py"), f"_ref_sasrec_{loss}", ["--dropout-rate", "0", "--loss", loss])
+    z = np.load(os.path.join(G, fixture))
+    model = ref.SASRec(toy_dataset(40, int(z["cfg/N"])))
+    load_golden_state(model, z)
+    data = {model.ISeq: torch.from_numpy(z["in/seq"]), model.IPos: torch.from_numpy(z["in/pos"]), model.INeg: torch.from_numpy(z["in/neg"])}
+    model.train()
+    out = model(data)
+    out["rec_loss"].backward()
+    np.testing.assert_allclose(out["rec_loss"].item(), float(z["out/rec_loss"]), rtol=1e-6)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), z["grad/" + k], rtol=1e-5, atol=1e-8, err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(data, ranking="full").numpy(), z["out/scores"], rtol=1e-5, atol=2e-6)
+
+
+@needs_ref
+def test_reference_mfbpr_and_lightgcn_run_unchanged():
+    z = np.load(os.path.join(G, "mfbpr.npz"))
+    ref = import_script(os.path.join(REF, "MF-BPR", "main.py"), "_ref_mfbpr", [])
+    U, N = z["param/User.embeddings.weight"].shape[0], z["param/Item.embeddings.weight"].shape[0]
+    model = ref.MF(toy_dataset(U, N))
+    load_golden_state(model, z)
+    data = {model.User: torch.from_numpy(z["in/users"]), model.IPos: torch.from_numpy(z["in/pos"]), model.INeg: torch.from_numpy(z["in/neg"])}
+    model.train()
+    out = model(data)
+    np.testing.assert_allclose(out["rec_loss"].item(), float(z["out/rec_loss"]), rtol=1e-6)
+    # LightGCN: the script's `dataset.train().to_normalized_adj("sym")` on this package's dataset == the golden's adjacency
+    zl = np.load(os.path.join(G, "lightgcn.npz"))
+    import freerec
+    U, N = zl["param/User.embeddings.weight"].shape[0], zl["param/Item.embeddings.weight"].shape[0]
+    crow, col = zl["in/adj_crow"], zl["in/adj_col"]                       # the golden's adjacency: user rows hold the (user, item) edges
+    rows = np.repeat(np.arange(len(crow) - 1), np.diff(crow))
+    eu, ei = rows[rows < U], col[rows < U] - U
+    e = np.zeros(0, np.int64)
+    ds = freerec.data.datasets.RecDataSet.from_splits((eu, ei), (e, e), (e, e), U, N)
+    refl = import_script(os.path.join(REF, "LightGCN", "main.py"), "_ref_lightgcn", [])
+    model = refl.LightGCN(ds)
+    A = model.Adj.to_dense().numpy()
+    ref_adj = torch.sparse_csr_tensor(torch.from_numpy(zl["in/adj_crow"]), torch.from_numpy(zl["in/adj_col"]), torch.from_numpy(zl["in/adj_val"]),
+                                      size=A.shape).to_dense().numpy()
+    np.testing.assert_allclose(A, ref_adj, rtol=1e-6, atol=1e-8)
+    load_golden_state(model, zl)
+    data = {model.User: torch.from_numpy(zl["in/users"]), model.IPos: torch.from_numpy(zl["in/pos"]), model.INeg: torch.from_numpy(zl["in/neg"])}
+    model.train()
+    out = model(data)
+    np.testing.assert_allclose(out["rec_loss"].item(), float(zl["out/rec_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(out["emb_loss"].item(), float(zl["out/emb_loss"]), rtol=1e-5)
+
+
+@needs_ref
+def test_reference_sasrec_main_fits_end_to_end_on_a_synthetic_dataset(tmp_path):
+    """`main()`'s wiring -- model, the three pipes, CoachForSASRec(...).fit() -- on CPU with this package's Coach (two epochs)."""
+    import freerec
+    ref = import_script(os.path.join(REF, "SASRec", "main.py"), "_ref_sasrec_fit", ["--dropout-rate", "0.2"])
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(300)
+    seqs = []
+    for _ in range(150):
+        s = [int(rng.integers(0, 300))]
+        for _ in range(int(rng.integers(4, 30))):
+            s.append(int(perm[s[-1]]) if rng.random() < 0.8 else int(rng.integers(0, 300)))
+        seqs.append(s)
+    ds = freerec.data.datasets.RecDataSet.from_sequences(seqs, 300)
+    cfg = ref.cfg
+    cfg.epochs, cfg.eval_freq, cfg.device, cfg.batch_size = 2, 1, "cpu", 32
+    cfg.monitors, cfg.which4best, cfg.checkpoint_path = ["LOSS", "HitRate@10", "NDCG@10"], "NDCG@10", str(tmp_path)
+    model = ref.SASRec(ds)
+    pipe = model.sure_trainpipe(cfg.maxlen, cfg.batch_size)
+    b = next(iter(pipe))
+    seq, pos, neg = b[model.ISeq], b[model.IPos], b[model.INeg]
+    assert seq.shape == (32, 50)
+    assert ((seq > 0) | (pos == 0)).all() and ((seq > 0) | (neg == 0)).all()          # pads line up
+    coach = ref.CoachForSASRec(dataset=ds, trainpipe=pipe, validpipe=model.sure_validpipe(cfg.maxlen, ranking="full"),
+                               testpipe=model.sure_testpipe(cfg.maxlen, ranking="full"), model=model, cfg=cfg)
+    out = coach.fit()
+    assert set(out["test"]) == {"HITRATE@10", "NDCG@10"} and 0.0 <= out["test"]["NDCG@10"] <= out["test"]["HITRATE@10"] <= 1.0
+    assert os.path.exists(os.path.join(str(tmp_path), "checkpoint.tar")) and os.path.exists(os.path.join(str(tmp_path), "results.json"))
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint.tar"), weights_only=False)
+    assert set(ck) == {"epoch", "model", "optimizer", "lr_scheduler", "monitors"} and "Item.embeddings.weight" in ck["model"]
+
+
+def test_own_sasrec_script_has_the_reference_state_dict_names():
+    """examples/SASRec/main.py (the builder's model file on this surface) builds the reference's parameter set: the golden state dict
+    loads strictly and the golden loss / scores come out (CPU, the script's own torch code)."""
+    own = import_script(os.path.join(ROOT, "examples", "SASRec", "main.py"), "_own_sasrec", ["--dropout-rate", "0", "--loss", "BCE"])
+    z = np.load(os.path.join(G, "sasrec_bce.npz"))
+    model = own.SASRec(toy_dataset(40, int(z["cfg/N"])))
+    sd = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}
+    model.load_state_dict(sd, strict=True)
+    data = {model.ISeq: torch.from_numpy(z["in/seq"]), model.IPos: torch.from_numpy(z["in/pos"]), model.INeg: torch.from_numpy(z["in/neg"])}
+    model.train()
+    np.testing.assert_allclose(model(data)["rec_loss"].item(), float(z["out/rec_loss"]), rtol=1e-5)
+    model.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(data, ranking="full").numpy(), z["out/scores"], rtol=1e-4, atol=1e-5)
+
+
+def test_pipes_follow_the_row_contract():
+    """tests/golden/sampler_rows.json (rows worked out by hand from HSTU/sampler.py:47-125 / SASRec/main.py:143-157) through the chained
+    pipes of this package: train rows (ISeq = seq[:-1] + 1 left-padded, IPos = seq[1:], negatives unseen), valid / test rows."""
+    import json
+    import freerec
+    fx = json.load(open(os.path.join(G, "sampler_rows.json")))
+    seqs, N, S = fx["seqs"], fx["num_items"], fx["maxlen"]
+    ds = freerec.data.datasets.RecDataSet.from_sequences(seqs, N)
+    own = import_script(os.path.join(ROOT, "examples", "SASRec", "main.py"), "_own_sasrec_pipes", ["--maxlen", str(S)])
+    model = own.SASRec(ds)
+    rows = {}
+    for b in model.sure_trainpipe(S, 4):
+        for i, u in enumerate(b[model.User].tolist()):
+            rows[u] = (b[model.ISeq][i].tolist(), b[model.IPos][i].tolist(), b[model.INeg][i].tolist())
+    for u, want in fx["train"].items():
+        iseq, ipos, ineg = rows[int(u)]
+        assert iseq == want["ISeq"] and ipos == want["IPos"]
+        seen = set(seqs[int(u)][:-2])
+        assert all((n == 0) if s == 0 else (n not in seen and 0 <= n < N) for s, n in zip(iseq, ineg))
+    got = {}
+    for b in model.sure_validpipe(S, ranking="full", batch_size=3):
+        for i, u in enumerate(b[model.User].tolist()):
+            got[u] = (b[model.ISeq][i].tolist(), list(b[model.IUnseen][i]), list(b[model.ISeen][i]))
+    for u, want in fx["valid"].items():
+        assert got[int(u)][0] == want["ISeq"] and got[int(u)][1] == want["IUnseen"] and got[int(u)][2] == want["ISeen"]
+    got = {}
+    for b in model.sure_testpipe(S, ranking="full", batch_size=3):
+        for i, u in enumerate(b[model.User].tolist()):
+            got[u] = (b[model.ISeq][i].tolist(), list(b[model.IUnseen][i]), list(b[model.ISeen][i]))
+    for u, want in fx["test"].items():
+        assert got[int(u)][0] == want["ISeq"] and got[int(u)][1] == want["IUnseen"] and got[int(u)][2] == want["ISeen"]
