@@ -5,6 +5,11 @@
     recengine::bpr_triplet(U, I, users, pos, neg) -> (loss, logits)        MF.fit's gathers + row dots + BPRLoss (MF-BPR/main.py:81-93)
     recengine::score_dense(Q, E) -> Tensor                                 einsum("BD,ND->BN") (SASRec/main.py:228)
     recengine::score_topk(Q, E, seen_ptr, seen_idx, K) -> (vals, idx)      Coach.evaluate's masked top-K (UniSRec/main.py:408-414)
+    recengine::sasrec_encoder(E, P, seq, params, scale, drop_p, seed) -> (u, tape, plan)
+                                                                           SASRec.encode: embedding front end + every block + lastLN fused
+                                                                           (SASRec/main.py:163-193, :31-50); backward = re_sasrec_encoder_bwd
+    recengine::bce_pair(U, E, pos, neg, valid, kind) -> (loss, logits)     the pair criteria on the rows of U (SASRec/main.py:205-215)
+    recengine::fm_bag(T, TL, lr_bias, offsets, x) -> (E, fm_lr)            multi-field bag + FM + LR (DeepFM/main.py:58-62,80-85,204-206)
     recengine::spmm_csr(crow, col, val, X) -> Tensor                       Adj @ X (LightGCN/main.py:80-84).  The registered backward is
                                                                            A dY, i.e. it is right for SYMMETRIC A only (the reference's
                                                                            to_normalized_adj("sym")); for any other matrix use
@@ -229,6 +234,155 @@ def _spmm_bwd(ctx, dY):
 spmm_csr.register_autograd(_spmm_bwd, setup_context=_spmm_setup)
 
 
+# ---- SASRec.encode as ONE op: embedding front end (E[seq] sqrt(D) + P, dropout, pad mask), every block, lastLN (SASRec/main.py:178-193)
+#      params: the 12 * L block tensors in re_sasrec_encoder_fwd's order, then lastLN.weight, lastLN.bias.  tape / plan are what the
+#      backward needs (opaque); u rows at pad positions in front of a sequence are not written (nothing on the path reads them).
+@_lib.custom_op("recengine::sasrec_encoder", mutates_args=(), device_types="cuda")
+def sasrec_encoder(E: torch.Tensor, P: torch.Tensor, seq: torch.Tensor, params: list[torch.Tensor], scale: float, drop_p: float,
+                   seed: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    L = (len(params) - 2) // 12
+    plan = ops.sasrec_plan(seq.contiguous(), E.shape[1]).clone()      # (a tensor of its own: custom-op outputs may not be views)
+    B, S = seq.shape
+    u = torch.zeros((B, S, E.shape[1]), dtype=torch.float32, device=E.device)
+    _, tape = ops.sasrec_embed_encoder_fwd(E.contiguous(), P.contiguous(), seq.contiguous(), scale, [t.contiguous() for t in params[:-2]],
+                                           params[-2].contiguous(), params[-1].contiguous(), L, drop_p, seed, need_tape=True, out=u, plan=plan)
+    return u, tape, plan
+
+
+@sasrec_encoder.register_fake
+def _(E, P, seq, params, scale, drop_p, seed):
+    from . import lib
+    B, S = seq.shape
+    D, L = E.shape[1], (len(params) - 2) // 12
+    Lb = lib.load()                                        # (pure host size queries)
+    return (E.new_empty((B, S, D)), E.new_empty((int(Lb.re_sasrec_tape_bytes(B, S, D, L)) // 4,)),
+            seq.new_empty((int(Lb.re_sasrec_plan_bytes(B, S)),), dtype=torch.uint8))
+
+
+@_lib.custom_op("recengine::sasrec_encoder_backward", mutates_args=(), device_types="cuda")
+def sasrec_encoder_backward(dU: torch.Tensor, E: torch.Tensor, P: torch.Tensor, seq: torch.Tensor, params: list[torch.Tensor], scale: float,
+                            drop_p: float, seed: int, tape: torch.Tensor, plan: torch.Tensor) -> list[torch.Tensor]:
+    L = (len(params) - 2) // 12
+    grads = [torch.zeros_like(t) for t in params]
+    dP = torch.zeros_like(P)
+    contrib = ops.sasrec_encoder_bwd(dU.contiguous(), seq.contiguous(), [t.contiguous() for t in params[:-2]], params[-2].contiguous(),
+                                     params[-1].contiguous(), L, drop_p, seed, tape, grads[:-2], grads[-2], grads[-1], plan=plan,
+                                     embed_scale=scale, dP=dP)
+    dE = ops.scatter_add_rows(contrib.view(-1, E.shape[1]), seq.reshape(-1), E.shape[0], 0)      # (row 0 = the padding row: no gradient)
+    return [dE, dP] + grads
+
+
+@sasrec_encoder_backward.register_fake
+def _(dU, E, P, seq, params, scale, drop_p, seed, tape, plan):
+    return [torch.empty_like(E), torch.empty_like(P)] + [torch.empty_like(t) for t in params]
+
+
+def _enc_setup(ctx, inputs, output):
+    E, P, seq, params, scale, drop_p, seed = inputs
+    ctx.save_for_backward(E, P, seq, output[1], output[2], *params)
+    ctx.scale, ctx.drop_p, ctx.seed = scale, drop_p, seed
+
+
+def _enc_bwd(ctx, dU, dtape, dplan):
+    E, P, seq, tape, plan, *params = ctx.saved_tensors
+    g = torch.ops.recengine.sasrec_encoder_backward(dU, E, P, seq, list(params), ctx.scale, ctx.drop_p, ctx.seed, tape, plan)
+    return g[0], g[1], None, g[2:], None, None, None
+
+
+sasrec_encoder.register_autograd(_enc_bwd, setup_context=_enc_setup)
+
+
+# ---- the pair criteria on rows of U: mean over the valid rows of BCE(<u, E[pos]>, 1) + BCE(<u, E[neg]>, 0) (kind 0) or of
+#      softplus(<u, E[neg]> - <u, E[pos]>) (kind 1: BPR) -- gathers, dots and criterion in one kernel each way (SASRec/main.py:205-215)
+@_lib.custom_op("recengine::bce_pair", mutates_args=(), device_types="cuda")
+def bce_pair(U: torch.Tensor, E: torch.Tensor, pos: torch.Tensor, neg: torch.Tensor, valid: torch.Tensor, kind: int = 0,
+             e_off: int = 0) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    loss, logits, count = ops.pair_loss_fwd(U.contiguous(), E.contiguous(), pos.reshape(-1).contiguous(), neg.reshape(-1).contiguous(),
+                                            valid.reshape(-1).to(torch.uint8).contiguous(), kind, e_off)
+    return loss.squeeze(0), logits, count
+
+
+@bce_pair.register_fake
+def _(U, E, pos, neg, valid, kind=0, e_off=0):
+    return U.new_empty(()), U.new_empty((U.shape[0], 2)), U.new_empty((1,), dtype=torch.int32)
+
+
+@_lib.custom_op("recengine::bce_pair_backward", mutates_args=(), device_types="cuda")
+def bce_pair_backward(U: torch.Tensor, E: torch.Tensor, pos: torch.Tensor, neg: torch.Tensor, valid: torch.Tensor, kind: int, e_off: int,
+                      logits: torch.Tensor, count: torch.Tensor, dloss: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    pos, neg = pos.reshape(-1).contiguous(), neg.reshape(-1).contiguous()
+    v8 = valid.reshape(-1).to(torch.uint8).contiguous()
+    dU, gp, gn = ops.pair_loss_bwd(U.contiguous(), E.contiguous(), pos, neg, v8, kind, logits, count, dloss.reshape(1).contiguous(), e_off)
+    live = v8.bool()
+    rows = torch.cat([torch.where(live, pos + e_off, torch.full_like(pos, -1)), torch.where(live, neg + e_off, torch.full_like(neg, -1))])
+    dE = ops.scatter_add_rows(torch.cat([gp, gn]), rows, E.shape[0], -1)
+    return dU, dE
+
+
+@bce_pair_backward.register_fake
+def _(U, E, pos, neg, valid, kind, e_off, logits, count, dloss):
+    return torch.empty_like(U), torch.empty_like(E)
+
+
+def _pair_setup(ctx, inputs, output):
+    U, E, pos, neg, valid, kind, e_off = inputs
+    ctx.save_for_backward(U, E, pos, neg, valid, output[1], output[2])
+    ctx.kind, ctx.e_off = kind, e_off
+
+
+def _pair_bwd(ctx, dloss, dlogits, dcount):
+    U, E, pos, neg, valid, logits, count = ctx.saved_tensors
+    dU, dE = torch.ops.recengine.bce_pair_backward(U, E, pos, neg, valid, ctx.kind, ctx.e_off, logits, count, dloss)
+    return dU, dE, None, None, None, None, None
+
+
+bce_pair.register_autograd(_pair_bwd, setup_context=_pair_setup)
+
+
+# ---- DeepFM's front end: every field's embedding row, the FM second-order term and the logistic-regression term of a row in one
+#      kernel (DeepFM/main.py:58-62 LogisticRegression, :80-85 InnerProductInteraction, :204-206): the F field tables are ONE table T
+#      [R, D] (+ TL [R]: the LR weights), field f's rows start at offsets[f].  E [B, F * D] feeds the MLP; fm_lr [B] = lr + fm.
+@_lib.custom_op("recengine::fm_bag", mutates_args=(), device_types="cuda")
+def fm_bag(T: torch.Tensor, TL: torch.Tensor, lr_bias: torch.Tensor, offsets: torch.Tensor, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    return ops.fm_bag_fwd(T.contiguous(), TL.reshape(-1).contiguous(), lr_bias.reshape(1).contiguous(), offsets.contiguous(), x.contiguous())
+
+
+@fm_bag.register_fake
+def _(T, TL, lr_bias, offsets, x):
+    return T.new_empty((x.shape[0], x.shape[1] * T.shape[1])), T.new_empty((x.shape[0],))
+
+
+@_lib.custom_op("recengine::fm_bag_backward", mutates_args=(), device_types="cuda")
+def fm_bag_backward(E: torch.Tensor, dE: torch.Tensor, dfm: torch.Tensor, offsets: torch.Tensor, x: torch.Tensor, R: int,
+                    D: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    F = x.shape[1]
+    gE, gL = ops.fm_bag_bwd(E.contiguous(), dE.contiguous(), dfm.contiguous(), F, D)
+    rows = (x + offsets.unsqueeze(0)).reshape(-1).contiguous()
+    dT = ops.scatter_add_rows(gE, rows, R)
+    dTL = ops.scatter_add_rows(gL, rows, R)
+    return dT, dTL.reshape(-1), dfm.sum().reshape(1)
+
+
+@fm_bag_backward.register_fake
+def _(E, dE, dfm, offsets, x, R, D):
+    return E.new_empty((R, D)), E.new_empty((R,)), E.new_empty((1,))
+
+
+def _bag_setup(ctx, inputs, output):
+    T, TL, lr_bias, offsets, x = inputs
+    ctx.save_for_backward(output[0], offsets, x)
+    ctx.R, ctx.D, ctx.tl_shape, ctx.b_shape = T.shape[0], T.shape[1], TL.shape, lr_bias.shape
+
+
+def _bag_bwd(ctx, dE, dfm):
+    E, offsets, x = ctx.saved_tensors
+    dT, dTL, db = torch.ops.recengine.fm_bag_backward(E, dE, dfm, offsets, x, ctx.R, ctx.D)
+    return dT, dTL.view(ctx.tl_shape), db.view(ctx.b_shape), None, None
+
+
+fm_bag.register_autograd(_bag_bwd, setup_context=_bag_setup)
+
+
 def _no_cpu(name):
     def raiser(*a, **k):
         raise RuntimeError(f"recengine::{name}: tensors must be on a HIP device (no CPU fallback exists)")
@@ -237,5 +391,6 @@ def _no_cpu(name):
 
 for _name, _op in (("gather_rows", gather_rows), ("scatter_add_rows", scatter_add_rows), ("bpr_triplet", bpr_triplet),
                    ("bpr_triplet_backward", bpr_triplet_backward), ("score_dense", score_dense), ("gemm", gemm), ("score_topk", score_topk),
-                   ("spmm_csr", spmm_csr)):
+                   ("spmm_csr", spmm_csr), ("sasrec_encoder", sasrec_encoder), ("sasrec_encoder_backward", sasrec_encoder_backward),
+                   ("bce_pair", bce_pair), ("bce_pair_backward", bce_pair_backward), ("fm_bag", fm_bag), ("fm_bag_backward", fm_bag_backward)):
     _op.register_kernel("cpu")(_no_cpu(_name))      # a CPU call fails loudly, with the engine's own message
