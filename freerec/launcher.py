@@ -77,6 +77,8 @@ class Coach:
         self._stopping_steps = 0
         self.path = cfg.get("checkpoint_path") or os.path.join("logs", str(cfg.get("description", "RecSys")), str(cfg.get("dataset")), str(cfg.get("id") or time.strftime("%m%d%H%M%S")))
         self._engine = self._attach_engine()
+        if self._engine is not None and hasattr(self.trainpipe, "to_"):
+            self.trainpipe.to_(self.device)            # (batches sampled on the device where a device sampler exists for the chain)
 
     # ---- set-up hooks the scripts override
     def set_device(self):

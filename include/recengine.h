@@ -277,6 +277,26 @@ size_t re_sasrec_tape_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 /* The tape's array offsets in floats (tools / tests that read a tape back; arrays are indexed by the plan's compact rows, those of
  * block l start at l * per_block): out[0..n) = per_block, X, A, Q, K, V, O, X1, Y, HR, P, SA, SF, PP, MK, XL, SL, FLAGS, total. */
 int re_sasrec_tape_layout(int64_t B, int64_t S, int64_t D, int64_t L, int64_t* out, int64_t n);
+/*
+ * K-S  device-side batch assembly: the reference's datapipe chains as one launch per batch, no host work.
+ *   The training interactions live in HBM as CSR over users: ptr int64[U + 1], items int64[nnz] in chronological order,
+ *   sorted_items int64[nnz] ascending per user (the "seen" probe).  order int64[n_order]: for re_seq_train_sample the epoch's
+ *   shuffled list of users with >= 2 training items (`shuffled_seqs_source`), for re_gen_train_sample the users with >= 1 item.
+ * re_seq_train_sample: `seq_train_yielding_pos_(1, -1) -> seq_train_sampling_neg_(1) -> add_(1, (ISeq,)) -> lpad_(S, ..., 0)`
+ *   (SASRec/main.py:143-157; row contract HSTU/sampler.py:47-125): row b = user order[b0 + b] (rows past n_order are all padding);
+ *   seq [B, S] = the last S inputs + 1, pos [B, S] = the items that follow them, neg [B, S] = one uniform item per real position
+ *   outside the user's training set, all left-padded with 0; users [B] (optional) = the rows' user ids (-1 on padding rows).
+ * re_gen_train_sample: `choiced_user_ids_source -> gen_train_sampling_pos_ -> gen_train_sampling_neg_(1)` (MF-BPR/main.py:60-68):
+ *   users [B] uniform (with replacement) from `order`, pos [B] one of the user's training items, neg [B] one unseen item.
+ *   Draws are a pure function of (seed, step, row, position): counter-based (csrc/re_rng.h), reproducible, capturable.
+ */
+int re_seq_train_sample(const int64_t* ptr, const int64_t* items, const int64_t* sorted_items, const int64_t* order, int64_t n_order,
+                        int64_t b0, int64_t B, int64_t S, int64_t N, uint32_t seed, uint32_t step, int64_t* users, int64_t* seq,
+                        int64_t* pos, int64_t* neg, re_stream_t stream);
+int re_gen_train_sample(const int64_t* ptr, const int64_t* items, const int64_t* sorted_items, const int64_t* order, int64_t n_order,
+                        int64_t B, int64_t N, uint32_t seed, uint32_t step, int64_t* users, int64_t* pos, int64_t* neg,
+                        re_stream_t stream);
+
 /* The pair criteria of re_pair_loss_fwd_bwd on the plan's compact rows only (SASRec/main.py:199-215 without the boolean-mask
  * compaction and without the padding positions): NR = re_sasrec_plan_rows(B, S) bounds the number of rows; per live row r
  * (position gid of the plan's row map):  dU_rows [NR, D] row r = d loss / d u[gid] (zero where seq[gid] == 0),

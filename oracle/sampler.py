@@ -1,0 +1,42 @@
+"""Oracle: the device batch sampler of recboard_amd/csrc/sampler.hip, restated in numpy (TEST INFRASTRUCTURE).
+
+Row contract of the reference's SASRec training chain (SASRec/main.py:143-157; HSTU/sampler.py:47-125): with w = the last maxlen + 1
+items of a user's training sequence, ISeq = w[:-1] + 1, IPos = w[1:], left-padded with 0; INeg = one uniform item per real position
+outside the user's training set.  The draws are the engine's counter-based generator (oracle/rng.py) keyed by
+(seed ^ step * 0x9E3779B1, stream 0x5EED, position * 32 + attempt): the first draw that is not in the user's set stands."""
+import numpy as np
+
+from . import rng
+
+STREAM_NEG = 0x5EED
+MAX_TRIES = 32
+
+
+def seq_train_sample(ptr, items, order, b0, B, S, N, seed, step):
+    """-> (users [B], seq [B,S], pos [B,S], neg [B,S]) exactly as re_seq_train_sample writes them."""
+    users = np.full(B, -1, np.int64)
+    seq, pos, neg = (np.zeros((B, S), np.int64) for _ in range(3))
+    key = (seed ^ ((step * 0x9E3779B1) & 0xFFFFFFFF)) & 0xFFFFFFFF
+    for b in range(B):
+        if b0 + b >= len(order):
+            continue
+        u = int(order[b0 + b])
+        users[b] = u
+        s = items[ptr[u]:ptr[u + 1]]
+        n = len(s)
+        ln = min(n - 1, S)
+        seen = set(s.tolist())
+        base = n - 1 - ln
+        for k in range(ln):
+            col = S - ln + k
+            seq[b, col] = s[base + k] + 1
+            pos[b, col] = s[base + k + 1]
+            i = b * S + col
+            v = 0
+            for t in range(MAX_TRIES):
+                r = int(rng.rng_u32(key, STREAM_NEG, np.asarray([i * MAX_TRIES + t]))[0])
+                v = (r * N) >> 32
+                if v not in seen:
+                    break
+            neg[b, col] = v
+    return users, seq, pos, neg

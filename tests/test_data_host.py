@@ -82,3 +82,20 @@ def test_scripts_parse_and_cited_scripts_exist():
         cited |= set(re.findall(r"scripts/([A-Za-z0-9_]+\.(?:py|sh))", open(os.path.join(root, doc)).read()))
     missing = sorted(c for c in cited if not os.path.exists(os.path.join(root, "scripts", c)))
     assert not missing, missing
+
+
+def test_oracle_device_sampler_restatement_gives_the_hand_derived_rows():
+    """oracle/sampler.py (the numpy restatement the GPU sampler is checked against bit for bit) on tests/golden/sampler_rows.json."""
+    import json
+    import os
+    import numpy as np
+    from oracle import sampler as osm
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampler_rows.json")))
+    train = [np.asarray(s[:-2], np.int64) for s in fx["seqs"]]
+    ptr = np.zeros(len(train) + 1, np.int64)
+    np.cumsum([len(s) for s in train], out=ptr[1:])
+    users, seq, pos, neg = osm.seq_train_sample(ptr, np.concatenate(train), np.arange(len(train)), 0, len(train), fx["maxlen"], fx["num_items"], 5, 3)
+    for u, want in fx["train"].items():
+        assert seq[int(u)].tolist() == want["ISeq"] and pos[int(u)].tolist() == want["IPos"]
+        live = seq[int(u)] > 0
+        assert not np.isin(neg[int(u)][live], train[int(u)]).any() and (neg[int(u)][~live] == 0).all()
