@@ -19,7 +19,10 @@ encoder step: forward + criterion + backward of every work item in one kernel, t
 `eval_baselines` times the evaluation as the reference executes it (dense scores, masked fill, torch.topk) through ROCm aten
 on the same GPU and through torch on the host cores; `train_baseline_aten_gpu` a torch.nn SASRec step (eager ROCm aten) on the
 same GPU.  `config5` (N = 1 runs only) is BASELINE.json's configs[4] on this GPU: the same step at d = 128 on the synthetic
-100 000 000-item table with the row-sparse Adam (154 GB of HBM; `--no-c5` skips it).
+100 000 000-item table with the row-sparse Adam (154 GB of HBM, 64 distinct batches; `--no-c5` skips it); at N > 1 `config5_sharded` is
+that table row-sharded over the ranks.  `config1` / `config3` / `config4` (N = 1) are the other BASELINE configs' steps with their own
+CPU-oracle baselines and the SpMM / field-bag rooflines (bench_legs.py, child processes); `sampler` the device sampler's rate alone
+and feeding the Coach.  `--gpus N` without a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).
 """
 import argparse
 import json
@@ -121,13 +124,14 @@ def cpu_baseline(cfg, batches, budget_s=15.0):
 def pmc_traffic(*kernels):
     """HBM bytes per launch of the named kernels (summed) from the committed PMC summary -- FETCH_SIZE / WRITE_SIZE cannot be
     read from inside the process, they come from separate rocprofv3 --pmc passes of this same command (profiles/)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]
+        kernels = [n for n in kernels if n in k]
         return {"hbm_bytes_per_launch": int(sum(k[n]["hbm_bytes_per_launch"] for n in kernels)),
                 "kernels": {n: k[n]["hbm_bytes_per_launch"] for n in kernels},
-                "source": "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this round's kernels, separate passes; 2*FETCH+WRITE)"}
+                "source": "profiles/r3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this round's kernels, separate passes; 2*FETCH+WRITE)"}
     except Exception:  # noqa: BLE001
         return None
 
@@ -222,82 +226,73 @@ def aten_train_baseline(cfg, batches, steps=30):
 
 def score_call_traffic():
     """HBM bytes of one whole re_score_topk call (all its launches) from the committed PMC summary of scripts/x2_prof.py."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")
     try:
         with open(path) as f:
             c = json.load(f)["re_score_topk_call"]
         return {"hbm_bytes_per_launch": int(c["hbm_bytes_per_call"]), "algorithmic_lower_bound_bytes": int(c["algorithmic_lower_bound_bytes"]),
-                "source": "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
+                "source": "profiles/r3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
                           "summed over the launches of one call)"}
     except Exception:  # noqa: BLE001
         return None
 
 
-def config5_leg():
-    """The config-5 measurement in a CHILD process (this file with --config5-child): it takes 154 GB of HBM, and whatever might go wrong at that
-    size must not take the headline line with it.  -> the child's JSON object, or {"skipped": reason}."""
+def sampler_rates(cfg, model):
+    """The device sampler alone (one re_seq_train_sample launch per batch: shuffled users, last-maxlen window, +1, left pad, one unseen uniform
+    negative per position; SASRec/main.py:143-157) and the same sampler feeding the Coach's epoch loop (sample -> batch preparation -> graph
+    replay, no host batch anywhere), on a synthetic Beauty-shaped training split."""
+    from recboard_amd.coach import Coach
+    from recboard_amd.sampler import DeviceInteractions, DeviceSeqSampler
+    rng = np.random.default_rng(5)
+    U, N, S, B = cfg["users"], cfg["items"], cfg["S"], cfg["B"]
+    w = 1.0 / np.arange(1, N + 1)
+    w /= w.sum()
+    lens = np.clip(rng.geometric(1.0 / 5.9, U) + 2, 2, 200)
+    ptr = np.zeros(U + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    inter = DeviceInteractions(ptr, rng.choice(N, int(ptr[-1]), p=w), N)
+    smp = DeviceSeqSampler(inter, S, B, seed=3)
+    nb = len(smp)
+    for _ in smp:
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        for _ in smp:
+            pass
+    torch.cuda.synchronize()
+    dts = (time.perf_counter() - t0) / 3
+    model.train()
+    coach = Coach(model, smp, monitors=["LOSS"], kind="seq")
+    coach.train_per_epoch(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(3):
+        coach.train_per_epoch(1 + e)
+    torch.cuda.synchronize()
+    dtc = (time.perf_counter() - t0) / 3
+    full = (U // B) * B + (U % B)
+    return {"sampler_samples_per_sec": round(full / dts, 1), "sampler_ms_per_batch": round(dts / nb * 1e3, 4),
+            "sampler_to_coach_samples_per_sec": round(full / dtc, 1), "sampler_to_coach_ms_per_step": round(dtc / nb * 1e3, 4),
+            "what": f"DeviceSeqSampler over {U} users ({int(ptr[-1])} interactions, {nb} batches of {B}; the last one short), 3 epochs each: the sampler alone, "
+                    "then Coach.train_per_epoch fed by it (device batches -> batch preparation -> hipGraph replay; the epoch's loss read once)"}
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started WITHOUT a launcher: start the N ranks here (one process per GPU over RCCL, rendezvous on 127.0.0.1)
+    before this process has touched the GPU, and leave with their exit code -- a failed rank is a failed run, not a silent N = 1 line."""
+    import socket
     import subprocess
-    try:
-        torch.cuda.empty_cache()
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config5-child"], capture_output=True, text=True, timeout=420)
-        for ln in reversed(r.stdout.splitlines()):
-            if ln.startswith("{"):
-                return json.loads(ln)
-        return {"skipped": f"child exited with {r.returncode}: {(r.stderr or r.stdout)[-200:]}"}
-    except Exception as e:  # noqa: BLE001
-        return {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
-
-
-def config5_measure(steps=100, warmup=10):
-    """BASELINE.json configs[4] on this GPU: SASRec d = 128, L = 2, maxlen 50, BCE, on the synthetic 100 000 000-item table (SURVEY.md
-    section 8d C5: item popularity Zipf(1.05), B = 512, one uniform negative, table ~ N(0, 0.02^2) from the counter-based generator).  The table
-    and its two Adam moment tables (154 GB) live in HBM; the step is one batch-preparation launch + one hipGraph replay: fused D = 128
-    item kernel (forward + criterion + backward), weight gradients, the row-sparse Adam of the ~15 k contribution rows, the dense Adam of
-    the encoder.  Skipped (with the reason) when the device does not have the memory free."""
-    import numpy as np
-    N, D, B, S = int(os.environ.get("RECBENCH_C5_ITEMS", 100_000_000)), 128, 512, 50      # (the override: tests/test_gpu_bench.py runs the leg small)
-    try:
-        torch.cuda.empty_cache()
-        free, _ = torch.cuda.mem_get_info()
-        need = 3 * (N + 1) * D * 4 + (8 << 30)
-        if free < need:
-            return {"skipped": f"needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} GB free"}
-        from recboard_amd.large import SASRecLargeTableEngine
-        t0 = time.time()
-        eng = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.5, loss="BCE", lr=1e-3, weight_decay=1e-6, seed=1)
-        torch.cuda.synchronize()
-        t_init = time.time() - t0
-        rng = np.random.default_rng(1)
-        bs = []
-        for _ in range(4):
-            lens = np.clip(rng.geometric(1 / 5.9, B) + 1, 1, S - 1)
-            seq = np.zeros((B, S), np.int64)
-            for b in range(B):
-                seq[b, S - lens[b]:] = np.minimum(rng.zipf(1.05, lens[b]), N)
-            pos = np.where(seq > 0, np.minimum(rng.zipf(1.05, (B, S)), N) - 1, 0)
-            neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
-            bs.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
-        for i in range(warmup):
-            eng.train_step_graph(*bs[i % 4])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            loss = eng.train_step_graph(*bs[i % 4])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        eng.check_handover()
-        free2, total = torch.cuda.mem_get_info()
-        out = {"metric": f"train samples/sec (SASRec d=128 on the synthetic {N / 1e6:g} M-item table, B=512, 1 GPU)", "value": round(B / dt, 1),
-               "unit": "samples/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "warmup": warmup, "final_loss": round(float(loss), 5),
-               "table": f"{N + 1} x {D} fp32 + two Adam moment tables", "hbm_used_GB": round((total - free2) / 1e9, 1),
-               "table_init_s": round(t_init, 1), "launch": "one batch-preparation launch + one hipGraph replay per step",
-               "data": "synthetic: Zipf(1.05) item popularity, lengths ~ clip(Geometric(mean 5.9) + 1, 1, 49)"}
-        del eng, bs
-        torch.cuda.empty_cache()
-        return out
-    except Exception as e:  # noqa: BLE001  (the headline line must not depend on this leg)
-        torch.cuda.empty_cache()
-        return {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
+    if torch.cuda.device_count() < n:
+        print(f"[bench] --gpus {n} asked for, {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=dict(os.environ, RECBENCH_LAUNCHED="1")).returncode
 
 
 def main():
@@ -307,18 +302,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the config-5 leg (100 M x 128 table: 154 GB of HBM)")
-    ap.add_argument("--config5-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-legs", action="store_true", help="skip the config-1 / config-3 / config-4 legs and the sampler rates")
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the aten-on-GPU baselines (kernel-trace runs: only the engine's kernels)")
     ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
     args = ap.parse_args()
-    if args.config5_child:
-        torch.cuda.set_device(0)
-        print(json.dumps(config5_measure()), flush=True)
-        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # (no GPU call has been made in this process)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -328,7 +324,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == world == (args.gpus if not force_dist else world), (dist.get_world_size(), world, args.gpus)
 
+    import bench_legs
     from recboard_amd import ops
     from recboard_amd.sasrec import SASRecEngine
     cfg = BEAUTY
@@ -421,6 +419,14 @@ def main():
         "final_loss": round(float(loss), 5),
     }
 
+    if dist is not None and world > 1 and not args.no_c5:
+        # ---------------- BASELINE.json configs[4] as named: the 100 M-row table row-sharded over the ranks (every rank takes part)
+        c5s = bench_legs.config5_sharded(dist, rank, world, local)
+        bad = torch.tensor([1 if "skipped" in c5s else 0], device="cuda")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad) and "skipped" not in c5s:
+            c5s = {"skipped": "another rank failed in this leg"}
+        line["config5_sharded"] = c5s
     if rank == 0 and not args.no_extras and world == 1:
         # ---------------- spread of the step time (median + p10 / p90): every step of a second run bracketed by events on
         # the stream the step runs on, read after the run (nothing synchronises inside it)
@@ -476,23 +482,31 @@ def main():
             # incl. the weight gradients) + the attention products
             fl_ref = 3 * 62e3 * Bq * Sq * Lq
             fl_exec = Lq * n_tiles * (24 * 2 * 16 * Dq * Dq + 6 * 2 * 16 * 16 * Dq)
-            tfs = fl_ref / (t_step * 1e-3) / 1e12
+            tf_ref = fl_ref / (t_step * 1e-3) / 1e12
+            tf_exec = fl_exec / (t_step * 1e-3) / 1e12
+            tile_mode = int(hdr[7]) == 1
             line["encoder_launch_us"] = {"batch_prep": round(t_prep * 1e3, 1),
-                                         "encoder step (enc_step_k + enc_wgrad_k + enc_grad_reduce_k)": round(t_step * 1e3, 1),
+                                         "encoder step (re_sasrec_encoder_step, all its launches)": round(t_step * 1e3, 1),
                                          "forward alone (enc_fwd_k, tape)": round(t_fwd * 1e3, 1),
                                          "backward alone (enc_bwd_k + enc_wgrad_k + enc_grad_reduce_k)": round(t_bwd * 1e3, 1),
                                          "how": "each call captured 20x into a hipGraph, replayed 10x (GPU time; an eager loop is CPU-launch-bound)"}
-            line["roofline"] = {"kernel": "re_sasrec_encoder_step: enc_step_k (forward + criterion + backward of every work item, all blocks) "
-                                          "+ enc_wgrad_k + enc_grad_reduce_k", "bound": "mfma",
-                                "achieved": round(tfs, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                "frac": round(tfs / MFMA_F32_PEAK_TF, 4),
-                                "achieved_executed": round(fl_exec / (t_step * 1e-3) / 1e12, 2),
-                                "frac_executed": round(fl_exec / (t_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
-                                "traffic": pmc_traffic("enc_step_k<64>", "enc_wgrad_k<64>", "enc_grad_reduce_k"), "launch_ms": round(t_step, 4),
-                                "work": f"reference-equivalent (`achieved`, `frac`): 3 x 62 kFLOP per token per block (forward + backward) x {Bq * Sq} "
-                                        f"token slots x {Lq} blocks = {fl_ref:.3e} FLOP, pad positions included -- what the reference's aten path "
-                                        f"executes; executed (`achieved_executed`): {fl_exec:.3e} FLOP on {n_tiles} tiles of 16 real-token rows "
-                                        f"in {n_items} work items (88 % of the token slots are padding and get no rows)"}
+            names = ("enc_tile_prep_k", "enc_tile_step_k", "enc_step_k<64>", "enc_wgrad_k<64>", "enc_grad_reduce_k")
+            line["roofline"] = {"kernel": "re_sasrec_encoder_step: enc_tile_prep_k (weight fragments) + enc_tile_step_k (forward + criterion + backward of one "
+                                          "16-token tile per workgroup, all blocks) + enc_wgrad_k + enc_grad_reduce_k"
+                                          + ("" if tile_mode else " [this plan took the workgroup-per-item kernel enc_step_k instead]"), "bound": "mfma",
+                                "achieved": round(tf_exec, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": round(tf_exec / MFMA_F32_PEAK_TF, 4),
+                                "achieved_reference_equivalent": round(tf_ref, 2),
+                                "frac_reference_equivalent": round(tf_ref / MFMA_F32_PEAK_TF, 4),
+                                "xdl_pipe": {"executed_bf16_TFLOPs": round(3 * tf_exec, 1), "peak": 2500.0, "frac": round(3 * tf_exec / 2500.0, 4),
+                                             "note": "the tile kernel runs every fp32 product as 3 bf16 products (hi.hi + hi.mid + mid.hi, fp32 accumulate) on the XDL "
+                                                     "pipe; `achieved` prices the algorithmic fp32 FLOPs against the fp32 matrix peak"},
+                                "traffic": pmc_traffic(*names), "launch_ms": round(t_step, 4),
+                                "work": f"executed (`achieved`, `frac`): per 16-token tile and block 8 + 16 products of [16] x D x D (forward; backward incl. the "
+                                        f"weight gradients) + the attention products = {fl_exec:.3e} FLOP on {n_tiles} tiles of real tokens in {n_items} work items; "
+                                        f"reference-equivalent (`frac_reference_equivalent`): 3 x 62 kFLOP per token per block x {Bq * Sq} token slots x {Lq} "
+                                        f"blocks = {fl_ref:.3e} FLOP, pad positions included -- what the reference's aten path executes (88 % of the slots are "
+                                        f"padding and get no rows here)"}
         # ---------------- full-catalog evaluation leg: every user x every item, seen-mask + top-50 fused
         U, N, D, K = cfg["users"], cfg["items"], cfg["D"], 50
         rng = np.random.default_rng(7)
@@ -605,8 +619,13 @@ def main():
             line["coach_loop"] = {"samples_per_sec": round(nb * cfg["B"] / dtc, 1), "ms_per_step": round(dtc / nb * 1e3, 4),
                                   "what": f"Coach.train_per_epoch over {nb} HOST batches (pinned): H2D copies one batch ahead on a copy stream + batch "
                                           "preparation + graph replay per step, the epoch's mean loss read once at the end"}
+        if world == 1 and args.encoder == "fused" and not args.no_legs:
+            line["sampler"] = sampler_rates(cfg, model)
         if world == 1 and not args.no_c5:
-            line["config5"] = config5_leg()
+            line["config5"] = bench_legs.run_child("config5")
+        if world == 1 and not args.no_legs:
+            for leg in ("config1", "config3", "config4"):
+                line[leg] = bench_legs.run_child(leg, timeout=300)
         if not args.no_baselines:
             line["train_baseline_aten_gpu"] = aten_train_baseline(cfg, batches)
         if not args.no_cpu_baseline:

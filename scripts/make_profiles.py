@@ -36,7 +36,37 @@ out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counte
                    "the split item table streamed once per user block (3 MB x 175 blocks; what misses the XCDs' L2s is served by the Infinity Cache and "
                    "counted here) and the candidates' rows re-read by the merge.  At 0.8 TB/s over the call none of it is what bounds the kernels "
                    "(vector instruction stream and stage barriers, DESIGN.md section 5a)."}}
+# config 5: HBM bytes of one step = the engine's kernels of scripts/pmc_c5.py (eager steps over distinct batches; the table's torch init kernels and
+# torch's own small launches are left out), summed over their launches, per step
+if os.path.isdir(src + "/c5fetch") and glob.glob(src + "/c5fetch/**/*.db", recursive=True):
+    k5 = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "scripts", "pmc_traffic.py"), src + "/c5fetch", src + "/c5write"]))
+    k5 = {n: v for n, v in k5.items() if n and not n.startswith(("at::", "void at::", "Cijk", "__amd", "at_cuda", "void at_cuda", "void (anonymous", "(anonymous"))}
+    nsteps = int(open(src + "/c5fetch.log").read().split("steps")[-1].split()[0])
+    tot5 = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in k5.values()) / nsteps
+    out["config5_step"] = {"hbm_bytes_per_step": int(tot5), "steps": nsteps,
+                           "kernels": {n: {"launches_per_step": round(v["launches"] / nsteps, 2), "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for n, v in k5.items()},
+                           "algorithmic_bytes_per_step": "about 3 x 3 600 looked-up rows x (8 + 512 read) + ~10 000 distinct rows x 3 tables x (512 read + 512 written) by the "
+                                                         "row-sparse Adam + the d = 128 encoder's tape: ~45 MB",
+                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/pmc_c5.py (eager steps, each on a batch never seen before: the "
+                                     "uniform negatives' rows come from HBM); 2*FETCH+WRITE"}
 json.dump(out, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
+# SQ counters of the step's kernels (two passes of 7)
+if os.path.isdir(src + "/pmc1") and glob.glob(src + "/pmc1/**/*.db", recursive=True):
+    import collections
+    sq = {}
+    for d in ("pmc1", "pmc2"):
+        acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
+        for f in glob.glob(f"{src}/{d}/**/*.db", recursive=True):
+            for kn, c, v in sqlite3.connect(f).execute("select kernel_name, counter_name, value from counters_collection"):
+                short = kn.split("(")[0].replace("void ", "").strip()
+                acc[(short, c)] += float(v); cnt[(short, c)] += 1
+        for (kn, c), v in acc.items():
+            if kn.startswith(("enc_", "scatter_owner", "sasrec_batch_prep", "adam_vec4")):
+                sq.setdefault(kn, {})[c] = int(v / cnt[(kn, c)])
+    sq = {"what": "rocprofv3 --pmc on scripts/pmc_step.py (SASRec/Beauty B=512 fused step, eager launches; two passes of 7 SQ counters: scripts/prof_round.sh), "
+                  "per launch averages; SQ_WAVE_CYCLES / SQ_WAIT_* are quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES are cycles summed over the 1 024 SIMDs",
+          **sq}
+    json.dump(sq, open(os.path.join(P, tag + "_step_pmc.json"), "w"), indent=1)
 for n, c, t, a, mn, mx in rows[:12]:
     print(f"{t/1e3:10.1f} us  calls {c:5d}  avg {a/1e3:8.1f} us  {n[:70]}")
 print("hbm bytes per score call:", total)
