@@ -115,6 +115,8 @@ class Coach:
             n += bsz
         if hasattr(self.model, "check_handover"):
             self.model.check_handover()     # (split long sequences: the halves' hand-over flags; the loss read below syncs anyway)
+        if hasattr(self.model, "settle_overflow"):
+            self.model.settle_overflow()    # (row-sharded tables: steps whose exchange overflowed were no-ops; they are re-run here at the latest)
         table = getattr(self.model, "table", None)
         if table is not None and hasattr(table, "check_capacity"):
             table.check_capacity()          # (row-sharded tables: a lookup dropped by a full exchange bucket came back as a zero row)

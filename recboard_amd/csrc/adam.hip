@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void adam_vec4_dev(float4* __restrict__ p, con
                                                      float4* __restrict__ v, int64_t n4, float b1, float b2, float omb1, float omb2,
                                                      const float* __restrict__ hyper, float eps, float wd) {
     const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1];
+    if (inv_sqrt_bc2 == 0.f) return;   // {0, 0}: the caller gated this step off (parameters AND moments stay as they are)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 P = p[i], G = g[i], M = m[i], V = v[i];
 #define RE_ADAM1(c)                                        \

@@ -291,25 +291,37 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
     is covered under gloo with two ranks (tests/test_sharded_gloo.py).  Table values come from `counter_normal_rows`, so every GPU count trains
     the same table.
 
-    capacity_factor c (fixed-capacity form): every peer pair moves ceil(c * 3 * B * S / G) slots per direction; the padding row's lookups take
-    no slot, so c is sized for the REAL tokens (~15 % of a Beauty-shaped batch: c = 0.3 leaves a factor of two); overflow is counted on the
-    device (`table.check_capacity()`).  `train_step_graph` needs this form; call `release_graphs()` before destroying the process group."""
+    capacity_factor c (fixed-capacity form, THE DEFAULT: c = 0.3): every peer pair moves ceil(c * 3 * B * S / G) slots per direction; the
+    padding row's lookups take no slot, so c is sized for the REAL tokens (~15 % of a Beauty-shaped batch: c = 0.3 leaves a factor of two).
+    Nothing in such a step reads device memory on the host.  A step in which ANY rank's lookups overflowed a bucket is a NO-OP on every
+    rank (the ranks learn the global count from one extra word per bucket in the id exchange; both optimizers are gated on it on the device),
+    and the host, which reads the count `overflow_lag` steps later, re-runs that batch on the exact-size path (split sizes through the host,
+    distinct rows only) with the step number it had -- so an overflow costs a late step, never a wrong one.  `settle_overflow()` drains the
+    steps still unchecked (Coach calls it at the end of an epoch).  capacity_factor=None: the exact-size exchange on every step.
+    `train_step_graph` needs the fixed-capacity form; call `release_graphs()` before destroying the process group."""
 
-    def __init__(self, *args, group=None, dedup=True, capacity_factor=None, local_ops=None, **kw):
+    DEFAULT_CAPACITY_FACTOR = 0.3
+
+    def __init__(self, *args, group=None, dedup=True, capacity_factor="default", local_ops=None, overflow_lag=2, **kw):
+        import collections
         import torch.distributed as dist
         self.group = group
-        self.dedup = dedup   # only the distinct rows of a batch cross the fabric (ShardedTable); False: one row per looked-up position
+        self.dedup = dedup   # exact-size exchange: only the distinct rows of a batch cross the fabric (ShardedTable); False: one row per lookup
         # capacity_factor: the sync-free fixed-capacity exchange (ShardedTable): owner bucketing on the device, equal-split all-to-alls
-        self.capacity_factor, self._local_ops = capacity_factor, local_ops
+        self.capacity_factor = self.DEFAULT_CAPACITY_FACTOR if isinstance(capacity_factor, str) else capacity_factor
+        self._local_ops = local_ops
+        self.overflow_lag, self.overflow_steps = int(overflow_lag), 0          # (steps re-run on the exact path so far)
+        self._pending = collections.deque()
         self.world = dist.get_world_size(group)
         kw["table_init"] = "counter"
         super().__init__(*args, **kw)
 
     def _alloc_table(self, seed):
         from .sharded import ShardedTable
-        self.table = ShardedTable(self.N + 1, self.D, group=self.group, device=self.device, dedup=self.dedup and self.capacity_factor is None,
+        self.table = ShardedTable(self.N + 1, self.D, group=self.group, device=self.device, dedup=self.dedup,
                                   capacity_factor=self.capacity_factor, local_ops=self._local_ops, skip_row=0)
         T = self.table
+        T.raise_on_overflow = False                  # (overflowing steps are gated on the device and re-run here)
         step_rows = max(1, (1 << 24) // self.D)
         for l0 in range(0, T.local_rows, step_rows):
             local = torch.arange(l0, min(T.local_rows, l0 + step_rows), device=self.device)
@@ -353,20 +365,37 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
     def reset_ranking_buffers(self):
         """Coach.evaluate calls this before a split's batches: nothing to cache (every rank scores its own shard per call)."""
 
-    def _dense_adam(self):
+    def _dense_adam(self, hyper=None):
+        """hyper (device float32[2]): the step size and bias correction from device memory; {0, 0} = leave everything as it is."""
         A = self.arena
-        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        if hyper is not None:
+            ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
+        else:
+            ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
 
-    def _sharded_body(self, seq, pos, neg, aux, sd, grad_hook=None, seed_dev=None, hyper=None):
+    def _hyper(self, step):
+        b1, b2 = self.betas
+        return torch.tensor([self.lr / (1.0 - b1 ** step), 1.0 / math.sqrt(1.0 - b2 ** step)], dtype=torch.float32).to(self.device, non_blocking=True)
+
+    def _sharded_body(self, seq, pos, neg, aux, sd, grad_hook=None, seed_dev=None, hyper=None, exact=False):
         """Lookup -> batch-local table -> forward + criterion + backward -> gradient rows to their owners -> both optimizers.
-        hyper (device float32[2]: step size, bias correction): the captured form; otherwise the host's step count."""
+        hyper (device float32[2]: step size, bias correction): the captured form; otherwise the host's step count.
+        exact: the exact-size exchange for this call (the re-run of a step the fixed-capacity exchange overflowed in).
+        Fixed-capacity form: `self._dropped` (device int [1]) = lookups of this step, over ALL ranks, that found no bucket slot; when it is
+        not zero both optimizers leave their state untouched (the step is re-run by `_settle`)."""
         import torch.distributed as dist
         A, D = self.arena, self.D
         B, S = seq.shape
         n = B * S
         p = self.p_drop if self.training else 0.0
-        slots = positions = None
-        if self.capacity_factor is not None and self.encoder == "fused" and self.compact_rows:
+        slots = positions = gate = None
+        fixed = self.capacity_factor is not None and not exact
+        if fixed and hyper is None:
+            hyper = self._hyper(A.step + 1)        # (the gate below works on the device-side step scalars)
+            host_step = True
+        else:
+            host_step = hyper is None
+        if fixed and self.encoder == "fused" and self.compact_rows:
             # fixed-capacity exchange + compact rows: the batch-local table IS the received bucket (row 0 = padding, row 1 + s = bucket
             # slot s); the padding row's lookups were never sent (skip_row), a lookup's local id is its slot + 1, and a contribution
             # row's key - 1 is the bucket slot its gradient travels back in -- nothing is expanded to one row per lookup
@@ -377,7 +406,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             slots = keys.view(-1).long() - 1 if keys is not None else torch.arange(C.shape[0], device=C.device)   # (None: one row per row of T[1:])
         else:
             # the batch-local table: row 0 = padding, row 1 + j = table row rows_all[j]  (one all-to-all round trip)
-            rows, route = self.table.lookup(aux.rows_all)
+            rows, route = self.table.lookup(aux.rows_all, exact=exact)
             T = torch.cat([torch.zeros((1, D), dtype=torch.float32, device=self.device), rows], 0)
             ar = torch.arange(1, n + 1, device=self.device)
             seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
@@ -391,20 +420,66 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             dist.all_reduce(A.grad, op=dist.ReduceOp.AVG, group=self.group)
         if grad_hook is not None:
             grad_hook(A.grad)
+        if fixed:
+            self._dropped = route.dropped
+            gate = route.dropped > 0
+            hyper = torch.where(gate, torch.zeros_like(hyper), hyper)
         # contribution rows of pad / invalid positions are zero rows addressed to global row 0 (rank 0 drops them)
         self.table.backward_sparse_adam(C, route, A.step + 1, self.lr, self.betas, 1e-8, self.wd, padding_global_row=0, positions=positions,
-                                        hyper=hyper, slots=slots)
-        if hyper is not None:
-            ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
-        else:
+                                        hyper=hyper, slots=slots, gate=gate)
+        if host_step:
             A.step += 1
-            self._dense_adam()
+        self._dense_adam(hyper)
         return loss
+
+    # ---- overflow of the fixed-capacity exchange: the count of step i is read `overflow_lag` steps later (by then the step has long finished:
+    #      the host never waits for the device in the steady state), at the same point of the step sequence on every rank -- the re-run's
+    #      collectives must line up -- and an overflowed step (a no-op on the device) is re-run on the exact-size path
+    def _track(self, batch, step_no, sd):
+        if self.capacity_factor is None:
+            return
+        if self.device.type == "cuda":
+            if not hasattr(self, "_ovf_ring"):
+                self._ovf_ring = torch.zeros(self.overflow_lag + 2, dtype=self._dropped.dtype).pin_memory()
+                self._ovf_i = 0
+            k = self._ovf_i % self._ovf_ring.numel()
+            self._ovf_i += 1
+            self._ovf_ring[k:k + 1].copy_(self._dropped, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((ev, self._ovf_ring[k:k + 1], batch, step_no, sd))
+        else:
+            self._pending.append((None, self._dropped.clone(), batch, step_no, sd))
+        while len(self._pending) > self.overflow_lag:
+            self._settle(self._pending.popleft())
+
+    def _settle(self, item):
+        ev, word, batch, step_no, sd = item
+        if ev is not None:
+            ev.synchronize()
+        if int(word) == 0:
+            return
+        self.overflow_steps += 1
+        A = self.arena
+        now, A.step = A.step, step_no - 1          # the re-run takes the skipped step's number (bias corrections) and dropout seed
+        try:
+            self._sharded_body(*batch, self.prepare_batch(*batch), sd, exact=True)
+        finally:
+            A.step = now
+
+    def settle_overflow(self):
+        """Check (and re-run where needed) every step not checked yet.  Every rank must call it at the same point."""
+        while self._pending:
+            self._settle(self._pending.popleft())
+        return self.overflow_steps
 
     def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
         if aux is None:
             aux = self.prepare_batch(seq, pos, neg)
-        return self._sharded_body(seq, pos, neg, aux, self._step_seed(), grad_hook=grad_hook).squeeze(0)
+        sd = self._step_seed()
+        loss = self._sharded_body(seq, pos, neg, aux, sd, grad_hook=grad_hook).squeeze(0)
+        self._track((seq, pos, neg), self.arena.step, sd)
+        return loss
 
     # ---- the same step as ONE hipGraph replay.  Needs the fixed-capacity exchange (capacity_factor: equal-split all-to-alls whose sizes
     #      do not depend on the data -- nothing in the step reads device memory on the host) and RCCL's stream capture; every rank must
@@ -436,7 +511,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             t.copy_(k)
         if T.dropped is not None:
             T.dropped.zero_()                  # (the all-padding warm-up sends every lookup to the padding row's owner)
-        return dict(graph=graph, blob=blob, state=state, loss=loss)
+        return dict(graph=graph, blob=blob, state=state, loss=loss, dropped=self._dropped)
 
     def release_graphs(self):
         """Drop the captured steps.  Call before `dist.destroy_process_group()`: a live hipGraph holds the communicator's captured work
@@ -458,14 +533,17 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
                               beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split())
+        sd = self._step_seed()
         g["graph"].replay()
         A.step += 1
+        self._dropped = g["dropped"]
+        self._track((seq, pos, neg), A.step, sd)
         return g["loss"].squeeze(0)
 
     def encode(self, seq):
         with torch.no_grad():
             B, S = seq.shape
-            rows, _ = self.table.lookup(seq.reshape(-1))
+            rows, _ = self.table.lookup(seq.reshape(-1), exact=True)
             T = torch.cat([torch.zeros((1, self.D), dtype=torch.float32, device=self.device), rows], 0)
             ar = torch.arange(1, B * S + 1, device=self.device)
             seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)

@@ -61,7 +61,7 @@ class Route:
     """Permutation + split sizes of one lookup, kept for the backward exchange.  dedup: `inv` maps every looked-up position to
     its distinct row among the `n` rows that travel.  Fixed-capacity form: `slot` (position of every lookup in the [G, cap] buckets),
     `cap`, and `recv_local` = the [G * cap] local row ids the peers want from this rank (-1 = unused slot)."""
-    __slots__ = ("order", "send_counts", "recv_counts", "recv_local", "n", "inv", "slot", "cap")
+    __slots__ = ("order", "send_counts", "recv_counts", "recv_local", "n", "inv", "slot", "cap", "dropped")
 
 
 class ShardedTable:
@@ -122,6 +122,7 @@ class ShardedTable:
         dist.all_to_all_single(recv_local, send_local, rc, sc, group=self.group)
         r = Route()
         r.order, r.send_counts, r.recv_counts, r.recv_local, r.n, r.inv, r.slot, r.cap = order, sc, rc, recv_local, flat.numel(), inv, None, 0
+        r.dropped = None
         return r
 
     def _route_fixed(self, idx):
@@ -132,30 +133,36 @@ class ShardedTable:
             buckets, slot, counts = self.ops.route_bucket(flat, self.R, G, cap, self.skip_row)
         else:
             buckets, slot, counts = self.ops.route_bucket(flat, self.R, G, cap)
-        recv_local = torch.empty_like(buckets)
-        dist.all_to_all_single(recv_local.view(-1), buckets.view(-1), group=self.group)      # equal splits: cap ids per pair
+        # every bucket carries one more word: this rank's count of lookups that found no slot -- after the exchange every rank holds
+        # all G counts, so "did ANY rank overflow in this lookup" is known everywhere without a collective of its own (route.dropped)
+        send = torch.cat([buckets, counts[G:G + 1].to(buckets.dtype).expand(G).unsqueeze(1)], 1).contiguous()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)               # equal splits: cap ids + 1 per pair
         if self.dropped is None:
             self.dropped = torch.zeros(1, dtype=counts.dtype, device=counts.device)
         self.dropped.add_(counts[G:G + 1])               # (in place: a captured step keeps counting across replays)
         r = Route()
-        r.slot, r.cap, r.recv_local, r.n, r.inv, r.order, r.send_counts, r.recv_counts = slot, cap, recv_local.view(-1), n, None, None, None, None
+        r.slot, r.cap, r.recv_local, r.n, r.inv, r.order, r.send_counts, r.recv_counts = slot, cap, recv[:, :cap].reshape(-1), n, None, None, None, None
+        r.dropped = recv[:, cap].sum().reshape(1)        # the same number on every rank
         return r
 
     def check_capacity(self):
-        """Host-side check (one sync) that no lookup since the last check was dropped by the fixed-capacity exchange."""
-        if self.dropped is not None:
+        """Host-side check (one sync) that no lookup since the last check was dropped by the fixed-capacity exchange.  (A caller that
+        gates and re-runs overflowing steps itself -- SASRecShardedEngine -- sets `raise_on_overflow = False`.)"""
+        if self.dropped is not None and getattr(self, "raise_on_overflow", True):
             d = int(self.dropped)
             self.dropped.zero_()
             if d:
                 raise RuntimeError(f"ShardedTable: {d} lookups exceeded the exchange capacity (capacity_factor={self.capacity_factor}); "
                                    f"use capacity_factor={self.G} (never overflows) or None (exact sizes through the host)")
 
-    def lookup(self, idx, expand=True):
+    def lookup(self, idx, expand=True, exact=False):
         """-> (rows [*idx.shape, D], route).  Global `W[idx]` on a table no rank holds entirely.
+        exact=True: the exact-size exchange (split sizes through the host) even when the table has a capacity factor.
         expand=False (fixed-capacity form only): -> (table [1 + G * cap, D], route): a zero row followed by the received rows in BUCKET
         order -- lookup j's row is row `route.slot[j] + 1` (slot -1: the zero row); the caller indexes it instead of asking for a row
         per lookup."""
-        if self.capacity_factor is not None:
+        if self.capacity_factor is not None and not exact:
             r = self._route_fixed(idx)
             rows_for_peers = self.ops.gather(self.weight, r.recv_local).reshape(-1, self.D)       # (-1 -> a zero row)
             if not expand:       # (received straight into rows 1.. of the caller's batch-local table; row 0 = the zero / padding row)
@@ -220,10 +227,11 @@ class ShardedTable:
         return g[route.order].contiguous()
 
     def backward_sparse_adam(self, grad_rows, route, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, padding_global_row=None,
-                             positions=None, hyper=None, slots=None):
+                             positions=None, hyper=None, slots=None, gate=None):
         """Training form for tables whose dense gradient does not fit: gradient rows go to their owners (the same single
         all-to-all as `backward`) and the owner applies ONE row-sparse Adam update per distinct row of its shard (summed
-        duplicates, SparseAdam rule; moments `m`, `v` live next to the shard).  No table-sized gradient ever exists."""
+        duplicates, SparseAdam rule; moments `m`, `v` live next to the shard).  No table-sized gradient ever exists.
+        gate (device bool [1], optional): True turns the update into a no-op (every received row id becomes -1: "nobody's")."""
         if not hasattr(self, "m"):
             self.m = torch.zeros_like(self.weight)
             self.v = torch.zeros_like(self.weight)
@@ -232,6 +240,8 @@ class ShardedTable:
         pad = -1
         if padding_global_row is not None and self.owner(padding_global_row) == self.rank:   # the padding row is never updated
             pad = self.local_index(padding_global_row)
+        if gate is not None:
+            route.recv_local = torch.where(gate, torch.full_like(route.recv_local, -1), route.recv_local)
         if hyper is not None:     # (captured step: step size and bias correction come from device memory, `step` / `lr` are ignored)
             self.ops.sparse_adam_dev(recv, route.recv_local, self.weight, self.m, self.v, hyper, betas[0], betas[1], eps, weight_decay, padding_idx=pad)
         else:

@@ -253,13 +253,16 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
         # (a) the all-positions step (compact_rows = False: one contribution row per lookup, in lookup order) is the large-table engine's,
         #     bit for bit; (b) the default compact-row step sends the rows that exist, tagged with their lookups: same sums in another order
         large = SASRecLargeTableEngine(N, S, D, 2, table_init="counter", **kw)
-        shard = SASRecShardedEngine(N, S, D, 2, dedup=False, **kw)
+        shard = SASRecShardedEngine(N, S, D, 2, dedup=False, capacity_factor=None, **kw)
         fx = SASRecShardedEngine(N, S, D, 2, capacity_factor=1.0, **kw)   # the sync-free form: owner bucketing on the device (re_route_bucket)
         for e in (large, shard, fx):
             e.compact_rows = False
-        dd = SASRecShardedEngine(N, S, D, 2, **kw)        # the default: compact rows, distinct rows only, gradient rows pre-summed per sender
+        dd = SASRecShardedEngine(N, S, D, 2, capacity_factor=None, **kw)   # exact sizes: compact rows, distinct rows only, gradient rows pre-summed per sender
         cl = SASRecLargeTableEngine(N, S, D, 2, table_init="counter", **kw)                     # compact rows, unsharded
-        cs = SASRecShardedEngine(N, S, D, 2, dedup=False, **kw)                                  # compact rows, one row per lookup on the wire
+        cs = SASRecShardedEngine(N, S, D, 2, dedup=False, capacity_factor=None, **kw)            # compact rows, one row per lookup on the wire
+        df = SASRecShardedEngine(N, S, D, 2, **kw)     # THE DEFAULT: fixed capacity 0.3 (sized for ~15 % real tokens; these batches are half real:
+        ov = SASRecShardedEngine(N, S, D, 2, capacity_factor=0.02, **kw)   # every step overflows, is a no-op, and is re-run on the exact-size path)
+        assert df.capacity_factor == 0.3
         cf = SASRecShardedEngine(N, S, D, 2, capacity_factor=1.0, **kw)                          # compact rows, fixed-capacity exchange
         cg = SASRecShardedEngine(N, S, D, 2, capacity_factor=1.0, **kw)                          # ... the same step as one hipGraph replay
         assert dd.compact_rows and cs.compact_rows and cs.split_long
@@ -299,6 +302,15 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
             torch.testing.assert_close(cg.table.weight, cf.table.weight, rtol=1e-5, atol=1e-7)
             torch.testing.assert_close(cg.arena.data, cf.arena.data, rtol=1e-5, atol=1e-7)
             cg.table.check_capacity()
+            df.train_step(*batch)
+            ov.train_step_graph(*batch)
+        # overflowing steps: nothing moved when the step ran; the re-runs (exact-size path, the skipped step's number and seed) give dd's table
+        assert ov.overflow_steps == 1 and len(ov._pending) == 2 and ov.settle_overflow() == 3 and df.settle_overflow() == 3
+        for eng in (df, ov):
+            assert eng.arena.step == 3
+            for a, b in ((eng.table.weight, dd.table.weight), (eng.arena.data, dd.arena.data)):
+                diff = (a - b).abs()
+                assert float(diff.max()) <= 7.5e-2 and float((diff > 1e-5 * (1 + b.abs())).float().mean()) < 2e-3
         seqs = torch.from_numpy(seq).cuda()
         sp = torch.arange(0, B + 1, device="cuda") * 3
         si = torch.sort(torch.from_numpy(rng.integers(0, N, (B, 3))).cuda(), 1).values.reshape(-1)
@@ -306,8 +318,9 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
         v2, i2 = shard.recommend_topk(seqs, sp, si, 20)
         assert torch.equal(i1, i2) and torch.equal(v1, v2)
     finally:
-        if "cg" in locals():
-            cg.release_graphs()        # (a live graph holding captured RCCL work blocks the group's teardown)
+        for g_ in ("cg", "ov"):
+            if g_ in locals():
+                locals()[g_].release_graphs()        # (a live graph holding captured RCCL work blocks the group's teardown)
         dist.destroy_process_group()
 
 
