@@ -243,6 +243,15 @@ int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* 
                          int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid, int32_t* count,
                          int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
                          double beta1, double beta2, re_stream_t stream);
+/* The same launch with the weight preparation of the D = 64 one-tile-per-workgroup step in extra workgroups: the encoder's matrices
+ * (block_params / last_w / last_b as for re_sasrec_encoder_step) as bf16 hi / mid fragment planes into that step's workspace `ws`, the
+ * launch epoch in `tape`'s flag area advanced.  The step that follows on the same stream is then called with part + 8
+ * (re_sasrec_encoder_step_part) and launches no preparation kernel of its own. */
+int re_sasrec_batch_prep_w(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
+                           int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid, int32_t* count,
+                           int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
+                           double beta1, double beta2, const float* const* block_params, const float* last_w, const float* last_b,
+                           int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K6/K7  fused SASRec encoder (D = 64 or 128, S <= 64, L <= 4, 1 head): one workgroup per work item of the plan, activations in LDS.
@@ -340,6 +349,19 @@ int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float s
                            const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
                            size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
                            float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream);
+/* The same step in parts.  `part` is a mask of what to launch: 1 = the one-tile-per-workgroup kernels (D = 64), 2 = the
+ * workgroup-per-item kernel (exactly one of the two does the work: the plan decides on the device, the other returns at once),
+ * 4 = the weight gradients (from the tape the item kernels left); 0 = 7 = everything.  + 8: the weight fragments were prepared by
+ * re_sasrec_batch_prep_w for this step.  The two item kernels are independent of each other and the item table's scatter-add
+ * depends on them alone: a caller runs 1 and 2, then 4 and the scatter-add, as parallel branches on two streams
+ * (recboard_amd/sasrec.py does, inside the captured step) and joins them before the optimizer. */
+int re_sasrec_encoder_step_part(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
+                                const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
+                                const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                                const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
+                                const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
+                                size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
+                                float* g_last_b, void* ws, size_t ws_bytes, int32_t part, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,

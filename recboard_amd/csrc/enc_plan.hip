@@ -10,6 +10,7 @@
 #include <math.h>
 
 #include "enc_common.h"
+#include "enc_tile_prep.h"
 
 #define PL_NT 1024
 #define PL_NW (PL_NT / 64)
@@ -35,17 +36,35 @@ __device__ __forceinline__ void pl_sync(bool lds_only) {
     else __syncthreads();
 }
 
+size_t enc_wgrad_part_floats(int64_t D, int64_t L);
+size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
+extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
+
+struct PlWeights {   // optional extra work of the launch: the one-tile-per-workgroup step's weight fragments (enc_tile_prep.h); nblocks = 0: none
+    SasrecParams P;
+    int L, nblocks;
+    uint32_t* wf;
+    unsigned* epoch;
+};
+
 __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
                                                              const int64_t* __restrict__ neg, int B, int S, int ncu, int max_tiles, int split_long,
                                                              int64_t* __restrict__ seq_out, int64_t* __restrict__ pos_out,
                                                              int64_t* __restrict__ neg_out, uint8_t* __restrict__ valid,
                                                              int* __restrict__ count, int64_t* __restrict__ rows_all, int* __restrict__ plan,
-                                                             uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2) {
+                                                             uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2,
+                                                             PlWeights WP) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x >= gridDim.x - WP.nblocks) {
+        // ---- the tile kernel's weight fragments for this step (re_sasrec_batch_prep_w): the last workgroups of the grid
+        const int t = (int)(blockIdx.x - (gridDim.x - WP.nblocks)) * PL_NT + tid;
+        if (t < TL_PREP_THREADS(WP.L)) tl_prep_thread(WP.P, WP.L, WP.wf, WP.epoch, t);
+        return;
+    }
     if (blockIdx.x > 0) {
         // ---- element-wise part: copies, valid mask, scatter destination rows
         const int64_t n = (int64_t)B * S;
-        for (int64_t i = (int64_t)(blockIdx.x - 1) * PL_NT + tid; i < n; i += (int64_t)(gridDim.x - 1) * PL_NT) {
+        for (int64_t i = (int64_t)(blockIdx.x - 1) * PL_NT + tid; i < n; i += (int64_t)(gridDim.x - 1 - WP.nblocks) * PL_NT) {
             const int64_t s = seq[i];
             const bool v = s != 0;
             if (seq_out) seq_out[i] = s;
@@ -244,10 +263,10 @@ extern "C" size_t re_sasrec_plan_bytes(int64_t B, int64_t S) {
     return re_align(enc_plan_bytes(B, S));
 }
 
-extern "C" int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
-                                    int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
-                                    int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
-                                    int64_t step, double lr, double beta1, double beta2, re_stream_t stream) {
+static int batch_prep_launch(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
+                             int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
+                             int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
+                             int64_t step, double lr, double beta1, double beta2, const PlWeights& WP, re_stream_t stream) {
     re_clear_error();
     if (!seq || !plan || B <= 0 || S <= 0) return RE_EINVAL;
     if ((pos == nullptr) != (neg == nullptr) || (pos_out == nullptr) != (neg_out == nullptr)) return RE_EINVAL;
@@ -261,8 +280,44 @@ extern "C" int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, cons
         ib = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
     }
     const bool elementwise = seq_out || valid || rows_all || pos_out;
-    const unsigned grid = 1 + (elementwise ? re_grid(B * S, PL_NT, 256) : 0);
+    const unsigned grid = 1 + (elementwise ? re_grid(B * S, PL_NT, 256) : 0) + (unsigned)WP.nblocks;
     hipLaunchKernelGGL(sasrec_batch_prep_k, dim3(grid), dim3(PL_NT), 0, (hipStream_t)stream, seq, pos, neg, (int)B, (int)S, (int)ncu,
-                       (int)max_tiles, (int)(split_long != 0), seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib);
+                       (int)max_tiles, (int)(split_long != 0), seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib, WP);
     return re_launch_status();
+}
+
+extern "C" int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
+                                    int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
+                                    int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
+                                    int64_t step, double lr, double beta1, double beta2, re_stream_t stream) {
+    PlWeights WP{};
+    WP.nblocks = 0;
+    return batch_prep_launch(seq, pos, neg, B, S, ncu, max_tiles, split_long, seq_out, pos_out, neg_out, valid, count, rows_all, plan, plan_bytes, state,
+                             seed, step, lr, beta1, beta2, WP, stream);
+}
+
+// The same launch + the weight preparation of the D = 64 one-tile-per-workgroup step (re_sasrec_encoder_step_part, part + 8) in extra
+// workgroups: the encoder's matrices as bf16 hi / mid fragment planes into the backward workspace `ws`, the launch epoch in `tape`'s flag
+// area advanced -- the step that follows on the same stream then needs no preparation launch of its own.
+extern "C" int re_sasrec_batch_prep_w(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
+                                      int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
+                                      int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
+                                      int64_t step, double lr, double beta1, double beta2, const float* const* block_params, const float* last_w,
+                                      const float* last_b, int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                                      re_stream_t stream) {
+    if (D != TL_D || !tape || !ws || B <= 0 || S <= 0 || S > 64) return RE_EUNSUPPORTED;
+    PlWeights WP{};
+    if (!se_fill_params(WP.P, block_params, L, last_w, last_b)) return RE_EINVAL;
+    if (tape_bytes < (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float) || ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L))
+        return RE_EWORKSPACE;
+    // (the workspace layout of re_sasrec_encoder_step: slab | weight-gradient partials | gradient tape | fragments | inboxes)
+    float* slab = (float*)ws;
+    float* wpart = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
+    float* gtape = wpart + enc_wgrad_part_floats(D, L) + enc_wgrad_ppart_floats(B, D);
+    WP.L = (int)L;
+    WP.nblocks = (TL_PREP_THREADS((int)L) + PL_NT - 1) / PL_NT;
+    WP.wf = enc_tile_wf(gtape, B, S, L);
+    WP.epoch = enc_tile_epoch(tape, B, S, L);
+    return batch_prep_launch(seq, pos, neg, B, S, ncu, max_tiles, split_long, seq_out, pos_out, neg_out, valid, count, rows_all, plan, plan_bytes, state,
+                             seed, step, lr, beta1, beta2, WP, stream);
 }

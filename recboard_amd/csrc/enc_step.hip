@@ -6,6 +6,7 @@
 #include <math.h>
 
 #include "enc_fwd_item.h"
+#include "enc_tile_prep.h"
 #include "enc_bwd_item.h"
 
 template <int D>
@@ -43,11 +44,9 @@ size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 // ---- the four-waves-per-tile form of the step at D = 64 (enc_tile.hip)
-size_t enc_tile_wfrag_bytes(int64_t L);
-size_t enc_tile_xch_bytes(int64_t B, int64_t S);
 int enc_tile_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
                          uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
-                         float* gtape, float* slab, float scale, uint32_t* wf, float* xch, hipStream_t s);
+                         float* gtape, float* slab, float scale, uint32_t* wf, float* xch, int prep, hipStream_t s);
 
 template <int D>
 static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds,
@@ -65,14 +64,23 @@ static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, i
     return hipGetLastError() == hipSuccess ? RE_OK : RE_ELAUNCH;
 }
 
-extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
-                                      const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
-                                      const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
-                                      const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
-                                      const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
-                                      size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
-                                      float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream) {
+// part: a mask of what to launch -- 1 = the one-tile-per-workgroup kernels (D = 64; runs when the plan allows it), 2 = the workgroup-per-item
+// kernel (D = 128 always; D = 64 when the plan does not allow the tile kernel: exactly one of the two does the work, the other returns at
+// once), 4 = the weight gradients (enc_wgrad_k + enc_grad_reduce_k, from the tape the item kernels left); 0 = 7 = the whole step.
+// + 8: the tile kernel's weight fragments were prepared by re_sasrec_batch_prep_w for this step (no enc_tile_prep_k launch).
+// A caller with other work depending on the item kernels alone (the item table's scatter-add) runs the branches on two streams.
+extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
+                                           const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
+                                           const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                                           const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
+                                           const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
+                                           size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
+                                           float* g_last_b, void* ws, size_t ws_bytes, int32_t part, re_stream_t stream) {
     re_clear_error();
+    if (part < 0 || part > 15) return RE_EINVAL;
+    const bool frag_ready = (part & 8) != 0;
+    part &= 7;
+    if (part == 0) part = 7;
     if (B == 0) return RE_OK;
     if (!seq || !pos || !neg || !u || !plan || !tape || !E || !Ptab || !count || !loss || !dU_rows || !g_rows || !keys || !loss_ws || !dx0 ||
         !dPtab || !block_params || !block_grads || !g_last_w || !g_last_b || !last_w || !last_b || !ws || B < 0 || R <= 0)
@@ -97,26 +105,46 @@ extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Pt
     const int grid = (int)(mt < ncu ? mt : ncu);
     if (grid > 1024) return RE_EUNSUPPORTED;
     float* slab = (float*)ws;
-    float* part = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
-    float* ppart = part + enc_wgrad_part_floats(D, L);
+    float* wpart = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
+    float* ppart = wpart + enc_wgrad_part_floats(D, L);
     float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
     hipStream_t s = (hipStream_t)stream;
     if (D == 64) {
         // one tile per workgroup (enc_tile.hip) when the plan says every tile can have a resident workgroup (hdr[7]); the workgroup-per-item
         // kernel is launched behind it and returns at once in that case -- the plan lives in device memory, so both are always enqueued
-        const int64_t NR = 16 * mt;
-        uint32_t* wf = (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * NR * D)) + 255) & ~(uintptr_t)255);
-        float* xch = (float*)(((uintptr_t)wf + enc_tile_wfrag_bytes(L) + 255) & ~(uintptr_t)255);
+        uint32_t* wf = enc_tile_wf(gtape, B, S, L);
+        float* xch = enc_tile_xch(wf, L);
         const int tgrid = (int)(mt < 1024 ? mt : 1024);
-        const int rcw = enc_tile_step_launch(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, tgrid, H, dx0, gtape, slab, scale, wf, xch, s);
-        if (rcw != RE_OK) return rcw;
         const int wgrid = (int)(mt < ncu ? mt : ncu);
-        const int rco = enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, wgrid, H, dx0, gtape, slab, scale, s);
-        if (rco != RE_OK) return rco;
-        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, wgrid, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s, 1);
+        if (part & 1) {
+            const int rcw = enc_tile_step_launch(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, tgrid, H, dx0, gtape, slab, scale, wf, xch,
+                                                 frag_ready ? 0 : 1, s);
+            if (rcw != RE_OK) return rcw;
+        }
+        if (part & 2) {
+            const int rco = enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, wgrid, H, dx0, gtape, slab, scale, s);
+            if (rco != RE_OK) return rco;
+        }
+        if (!(part & 4)) return RE_OK;
+        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, wgrid, wpart, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s, 1);
     }
-    const int rc = D == 128 ? enc_step_launch_d<128>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s)
-                            : enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s);
-    if (rc != RE_OK) return rc;
-    return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, part, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
+    if (part & 2) {
+        const int rc = D == 128 ? enc_step_launch_d<128>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s)
+                                : enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s);
+        if (rc != RE_OK) return rc;
+    }
+    if (!(part & 4)) return RE_OK;
+    return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, wpart, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
+}
+
+extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
+                                      const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
+                                      const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                                      const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
+                                      const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
+                                      size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
+                                      float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream) {
+    return re_sasrec_encoder_step_part(E, R, Ptab, scale, seq, pos, neg, B, S, D, L, block_params, last_w, last_b, drop_p, seed, seed_dev, plan, ncu, u,
+                                       tape, tape_bytes, e_off, kind, count, loss, dU_rows, g_rows, keys, loss_ws, loss_ws_bytes, dx0, dPtab,
+                                       block_grads, g_last_w, g_last_b, ws, ws_bytes, 0, stream);
 }

@@ -39,39 +39,9 @@
 #include <math.h>
 
 #include "enc_fwd_item.h"
-
-typedef __bf16 tl_bf16x8 __attribute__((ext_vector_type(8)));
-typedef short tl_s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned tl_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned tl_u32x2 __attribute__((ext_vector_type(2)));
-
-#define TL_D 64
-#define TL_FRAG_WORDS 4096      // one (block, matrix, orientation): [strip 4][k step 2][plane 2][lane 64] x 16 bytes
-#define TL_NPAR 10              // per block: 0 ln_a_w 1 ln_a_b 2 bq 3 bk 4 bv 5 bo 6 ln_f_w 7 ln_f_b 8 b1 9 b2
-// per tile, in floats: operand slots [3][2 planes][64 lanes][4 strips] x 8 B | partial score tiles (TL_RED) |
-// per-token partials [2][4 waves][16 tokens] x 16 B | transpose scratch [4 waves][16 x 20]
-#define TL_OB (3 * 2 * 64 * 4 * 2)
-#define TL_RED (2 * 4 * 64 * 16)   // partial score tiles [2][4 waves][64 lanes][4 key tiles] x 16 B
-#define TL_SM (2 * 4 * 16 * 4)
-#define TL_TR (4 * 320)
-#define TL_TILE_LDS (TL_OB + TL_RED + TL_SM + TL_TR)
-#define TL_XCH_TILE (3 * 2 * 4 * 256)   // floats of a key tile's inbox of partial dV / dK: [sender t - kt - 1][dV, dK][strip][4 registers][64 lanes]
-
-// (+ the small parameters of every block and lastLN as one block of (10 L + 2) x 64 floats behind the fragments)
-size_t enc_tile_wfrag_bytes(int64_t L) { return (size_t)L * 6 * 2 * TL_FRAG_WORDS * 4 + (size_t)(TL_NPAR * L + 2) * TL_D * 4; }
-size_t enc_tile_xch_bytes(int64_t B, int64_t S) { return (size_t)enc_plan_max_tiles(B, S) * TL_XCH_TILE * 4; }
-__host__ __device__ inline size_t tl_lds_floats(int L) { return (size_t)(TL_NPAR * L + 2) * TL_D + (size_t)TL_TILE_LDS + 32; }
+#include "enc_tile_prep.h"
 
 // ---- operand splits ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned tl_pk(float a, float b) {   // two fp32 -> packed bf16 (round to nearest even), a in the low half
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    const b2 v = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ void tl_split2(float a, float b, unsigned& h, unsigned& m) {
-    h = tl_pk(a, b);
-    m = tl_pk(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xFFFF0000u));   // (x - hi is exact)
-}
 struct Op64 { tl_u32x4 h[2], m[2]; };   // K = 64 features: 2 steps x 8 bf16, hi and mid planes
 struct Op16 { tl_u32x2 h, m; };         // K = 16: 4 bf16
 __device__ __forceinline__ void tl_split4(const f32x4& x, Op16& o) {
@@ -178,51 +148,21 @@ __device__ __forceinline__ void tl_flag_wait(float* flags, int64_t tile, int wor
     }
 }
 
-// ---- weight preparation: fp32 [64][64] -> bf16 hi / mid fragment planes in the kernel's k order, both orientations ---------------------
 __global__ __launch_bounds__(256) void enc_tile_prep_k(SasrecParams P, int L, uint32_t* __restrict__ wf, unsigned* __restrict__ epoch) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) epoch[0] += 1u;   // the launch's epoch: what this step's hand-over flags are set to (the step kernel runs behind this one)
-    if (t < (TL_NPAR * L + 2) * TL_D) {   // the small parameters, gathered into one block (the step kernel then needs no parameter table)
-        const int v = t / TL_D, cc = t % TL_D;
-        const float* p;
-        if (v >= TL_NPAR * L) p = (v == TL_NPAR * L) ? P.last_w : P.last_b;
-        else {
-            const SasrecBlockParams& Wv = P.blk[v / TL_NPAR];
-            const int kk = v % TL_NPAR;
-            p = (kk == 0) ? Wv.ln_a_w : (kk == 1) ? Wv.ln_a_b : (kk < 5) ? Wv.in_b + (kk - 2) * TL_D : (kk == 5) ? Wv.out_b : (kk == 6) ? Wv.ln_f_w
-              : (kk == 7) ? Wv.ln_f_b : (kk == 8) ? Wv.b1 : Wv.b2;
-        }
-        reinterpret_cast<float*>(wf + (size_t)L * 6 * 2 * TL_FRAG_WORDS)[t] = p[cc];
-    }
-    const int lane = t & 63, q = (t >> 6) & 1, s = (t >> 7) & 3, o = (t >> 9) & 1, lm = t >> 10;
-    if (lm >= 6 * L) return;
-    const int l = lm / 6, m = lm % 6, c = lane & 15, g = lane >> 4;
-    const SasrecBlockParams& W = P.blk[l];
-    const float* w = (m < 3) ? W.in_w + m * TL_D * TL_D : (m == 3) ? W.out_w : (m == 4) ? W.w1 : W.w2;
-    unsigned h[4], md[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        float v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int i = 2 * p + e;
-            const int k = 16 * (2 * q + (i >> 2)) + 4 * g + (i & 3);
-            v[e] = (o == 0) ? w[(16 * s + c) * TL_D + k] : w[k * TL_D + 16 * s + c];   // o = 0: y = x W^T, o = 1: dx = dy W
-        }
-        tl_split2(v[0], v[1], h[p], md[p]);
-    }
-    tl_u32x4* dst = reinterpret_cast<tl_u32x4*>(wf + ((size_t)lm * 2 + o) * TL_FRAG_WORDS) + lane;
-    dst[((s * 2 + q) * 2 + 0) * 64] = (tl_u32x4){h[0], h[1], h[2], h[3]};
-    dst[((s * 2 + q) * 2 + 1) * 64] = (tl_u32x4){md[0], md[1], md[2], md[3]};
+    tl_prep_thread(P, L, wf, epoch, blockIdx.x * 256 + threadIdx.x);
 }
 
 #ifdef TL_PROFILE
 #define TL_MARKS 96
-__device__ unsigned long long g_tile_marks[TL_MARKS];
-extern "C" int re_dbg_enc_marks_wave(unsigned long long* out) {
+#define TL_MARK_BLOCKS 8
+__device__ unsigned long long g_tile_marks[TL_MARK_BLOCKS * TL_MARKS];   // the stamps of workgroups 0 .. 7 (the tiles of the first long sequences)
+extern "C" int re_dbg_enc_marks_wave(unsigned long long* out) {          // (workgroup 0's)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_marks), sizeof(unsigned long long) * TL_MARKS) == hipSuccess ? 0 : 1;
 }
-#define TL_MARK() do { if (blockIdx.x == 0 && tid == 0 && k == 0 && mk < TL_MARKS) g_tile_marks[mk] = __builtin_amdgcn_s_memtime(); ++mk; } while (0)
+extern "C" int re_dbg_enc_marks_blocks(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_marks), sizeof(unsigned long long) * TL_MARK_BLOCKS * TL_MARKS) == hipSuccess ? 0 : 1;
+}
+#define TL_MARK() do { if (blockIdx.x < TL_MARK_BLOCKS && tid == 0 && k == 0 && mk < TL_MARKS) g_tile_marks[blockIdx.x * TL_MARKS + mk] = __builtin_amdgcn_s_memtime(); ++mk; } while (0)
 #else
 #define TL_MARK() do { } while (0)
 #endif
@@ -1056,11 +996,12 @@ __global__ __launch_bounds__(256, 2) void enc_tile_step_k(SeEmbed em, const int6
 
 int enc_tile_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
                          uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
-                         float* gtape, float* slab, float scale, uint32_t* wf, float* xch, hipStream_t s) {
+                         float* gtape, float* slab, float scale, uint32_t* wf, float* xch, int prep, hipStream_t s) {
     const EncTape T = enc_tape_layout(B, S, TL_D, L);
-    unsigned* epoch = reinterpret_cast<unsigned*>((float*)tape + T.off_FLAGS) + enc_plan_max_tiles(B, S) * EP_FLAG_WORDS + 1;
-    hipLaunchKernelGGL(enc_tile_prep_k, dim3((unsigned)(6 * L * 1024 / 256)), dim3(256), 0, s, P, (int)L, wf, epoch);
-    if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
+    if (prep) {   // (0: the batch preparation launch of this step has written the fragments and advanced the epoch)
+        hipLaunchKernelGGL(enc_tile_prep_k, dim3((unsigned)(TL_PREP_THREADS(L) / 256)), dim3(256), 0, s, P, (int)L, wf, enc_tile_epoch(tape, B, S, L));
+        if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
+    }
     const size_t ldsb = tl_lds_floats((int)L) * sizeof(float);
     if (hipFuncSetAttribute((const void*)enc_tile_step_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
     hipLaunchKernelGGL(enc_tile_step_k, dim3(grid), dim3(256), ldsb, s, em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H,

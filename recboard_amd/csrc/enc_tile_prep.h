@@ -1,0 +1,88 @@
+// Weight preparation of the one-tile-per-workgroup SASRec step (enc_tile.hip): constants, the bf16 hi / mid split, and the per-thread body
+// that turns the fp32 [64][64] matrices into fragment planes.  Shared by enc_tile.hip (enc_tile_prep_k) and enc_plan.hip (the batch
+// preparation launch does it in extra workgroups when asked: re_sasrec_batch_prep_w).
+#pragma once
+#include "enc_common.h"
+
+typedef __bf16 tl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short tl_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned tl_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned tl_u32x2 __attribute__((ext_vector_type(2)));
+
+#define TL_D 64
+#define TL_FRAG_WORDS 4096      // one (block, matrix, orientation): [strip 4][k step 2][plane 2][lane 64] x 16 bytes
+#define TL_NPAR 10              // per block: 0 ln_a_w 1 ln_a_b 2 bq 3 bk 4 bv 5 bo 6 ln_f_w 7 ln_f_b 8 b1 9 b2
+// per tile, in floats: operand slots [3][2 planes][64 lanes][4 strips] x 8 B | partial score tiles (TL_RED) |
+// per-token partials [2][4 waves][16 tokens] x 16 B | transpose scratch [4 waves][16 x 20]
+#define TL_OB (3 * 2 * 64 * 4 * 2)
+#define TL_RED (2 * 4 * 64 * 16)   // partial score tiles [2][4 waves][64 lanes][4 key tiles] x 16 B
+#define TL_SM (2 * 4 * 16 * 4)
+#define TL_TR (4 * 320)
+#define TL_TILE_LDS (TL_OB + TL_RED + TL_SM + TL_TR)
+#define TL_XCH_TILE (3 * 2 * 4 * 256)   // floats of a key tile's inbox of partial dV / dK: [sender t - kt - 1][dV, dK][strip][4 registers][64 lanes]
+
+#define TL_PREP_THREADS(L) (6 * (L) * 1024)
+// (+ the small parameters of every block and lastLN as one block of (10 L + 2) x 64 floats behind the fragments)
+inline size_t enc_tile_wfrag_bytes(int64_t L) { return (size_t)L * 6 * 2 * TL_FRAG_WORDS * 4 + (size_t)(TL_NPAR * L + 2) * TL_D * 4; }
+inline size_t enc_tile_xch_bytes(int64_t B, int64_t S) { return (size_t)enc_plan_max_tiles(B, S) * TL_XCH_TILE * 4; }
+// where the fragments, the exchange inboxes and the launch epoch live: behind the gradient tape in the backward workspace / in the tape's flag area
+inline uint32_t* enc_tile_wf(float* gtape, int64_t B, int64_t S, int64_t L) {
+    return (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * 16 * enc_plan_max_tiles(B, S) * TL_D)) + 255) & ~(uintptr_t)255);
+}
+inline float* enc_tile_xch(uint32_t* wf, int64_t L) { return (float*)(((uintptr_t)wf + enc_tile_wfrag_bytes(L) + 255) & ~(uintptr_t)255); }
+inline unsigned* enc_tile_epoch(void* tape, int64_t B, int64_t S, int64_t L) {
+    const EncTape T = enc_tape_layout(B, S, TL_D, L);
+    return reinterpret_cast<unsigned*>((float*)tape + T.off_FLAGS) + enc_plan_max_tiles(B, S) * EP_FLAG_WORDS + 1;
+}
+__host__ __device__ inline size_t tl_lds_floats(int L) { return (size_t)(TL_NPAR * L + 2) * TL_D + (size_t)TL_TILE_LDS + 32; }
+
+
+// ---- operand splits
+__device__ __forceinline__ unsigned tl_pk(float a, float b) {   // two fp32 -> packed bf16 (round to nearest even), a in the low half
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void tl_split2(float a, float b, unsigned& h, unsigned& m) {
+    h = tl_pk(a, b);
+    m = tl_pk(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xFFFF0000u));   // (x - hi is exact)
+}
+
+// ---- weight preparation: fp32 [64][64] -> bf16 hi / mid fragment planes in the kernel's k order, both orientations ---------------------
+// thread t of 6 * L * 1024 (TL_PREP_THREADS): called by enc_tile_prep_k and by the batch preparation kernel's extra workgroups
+__device__ __forceinline__ void tl_prep_thread(const SasrecParams& P, int L, uint32_t* __restrict__ wf, unsigned* __restrict__ epoch, int t) {
+    if (t == 0) epoch[0] += 1u;   // the launch's epoch: what this step's hand-over flags are set to (the step kernel runs behind this one)
+    if (t < (TL_NPAR * L + 2) * TL_D) {   // the small parameters, gathered into one block (the step kernel then needs no parameter table)
+        const int v = t / TL_D, cc = t % TL_D;
+        const float* p;
+        if (v >= TL_NPAR * L) p = (v == TL_NPAR * L) ? P.last_w : P.last_b;
+        else {
+            const SasrecBlockParams& Wv = P.blk[v / TL_NPAR];
+            const int kk = v % TL_NPAR;
+            p = (kk == 0) ? Wv.ln_a_w : (kk == 1) ? Wv.ln_a_b : (kk < 5) ? Wv.in_b + (kk - 2) * TL_D : (kk == 5) ? Wv.out_b : (kk == 6) ? Wv.ln_f_w
+              : (kk == 7) ? Wv.ln_f_b : (kk == 8) ? Wv.b1 : Wv.b2;
+        }
+        reinterpret_cast<float*>(wf + (size_t)L * 6 * 2 * TL_FRAG_WORDS)[t] = p[cc];
+    }
+    const int lane = t & 63, q = (t >> 6) & 1, s = (t >> 7) & 3, o = (t >> 9) & 1, lm = t >> 10;
+    if (lm >= 6 * L) return;
+    const int l = lm / 6, m = lm % 6, c = lane & 15, g = lane >> 4;
+    const SasrecBlockParams& W = P.blk[l];
+    const float* w = (m < 3) ? W.in_w + m * TL_D * TL_D : (m == 3) ? W.out_w : (m == 4) ? W.w1 : W.w2;
+    unsigned h[4], md[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * p + e;
+            const int k = 16 * (2 * q + (i >> 2)) + 4 * g + (i & 3);
+            v[e] = (o == 0) ? w[(16 * s + c) * TL_D + k] : w[k * TL_D + 16 * s + c];   // o = 0: y = x W^T, o = 1: dx = dy W
+        }
+        tl_split2(v[0], v[1], h[p], md[p]);
+    }
+    tl_u32x4* dst = reinterpret_cast<tl_u32x4*>(wf + ((size_t)lm * 2 + o) * TL_FRAG_WORDS) + lane;
+    dst[((s * 2 + q) * 2 + 0) * 64] = (tl_u32x4){h[0], h[1], h[2], h[3]};
+    dst[((s * 2 + q) * 2 + 1) * 64] = (tl_u32x4){md[0], md[1], md[2], md[3]};
+}
+

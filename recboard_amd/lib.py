@@ -47,6 +47,8 @@ SIGNATURES = {
     "re_sasrec_plan_bytes": (_sz, [_i64, _i64]),
     "re_sasrec_batch_prep": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32, _i64,
                                     _f64, _f64, _f64, _vp]),
+    "re_sasrec_batch_prep_w": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32, _i64,
+                                      _f64, _f64, _f64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp]),
     "re_sasrec_tape_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_seq_train_sample": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "re_gen_train_sample": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _u32, _vp, _vp, _vp, _vp]),
@@ -59,6 +61,8 @@ SIGNATURES = {
     "re_sasrec_plan_rows": (_i64, [_i64, _i64]),
     "re_sasrec_encoder_step": (_i32, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _i32,
                                       _vp, _vp, _sz, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "re_sasrec_encoder_step_part": (_i32, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _i32,
+                                           _vp, _vp, _sz, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "re_sasrec_encoder_fwd_loss": (_i32, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _i32,
                                           _vp, _vp, _sz, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_sasrec_loss_rows_workspace_bytes": (_sz, []),

@@ -385,7 +385,7 @@ def num_cus(device=None):
 
 class PreparedBatch:
     """What `sasrec_batch_prep` leaves on the device for one (seq, pos, neg) batch: views into ONE uint8 blob."""
-    __slots__ = ("B", "S", "blob", "seq", "pos", "neg", "rows_all", "valid", "count", "plan", "split")
+    __slots__ = ("B", "S", "blob", "seq", "pos", "neg", "rows_all", "valid", "count", "plan", "split", "weights_ready")
 
 
 _PREP_LAYOUT, _PREP_VIEWS = {}, {}
@@ -430,13 +430,15 @@ def prep_views(blob, B, S, cached=False):
 
 
 def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4, split=False,
-                      ncu=None):
+                      ncu=None, weights=None):
     """Batch preparation as ONE launch (re_sasrec_batch_prep): valid mask, count, scatter destination rows, the encoder's work plan;
     with `blob` (a static buffer of prep_layout(B, S) bytes) also copies (seq, pos, neg) into it and, with `state` (int32[4]),
     writes the step scalars -- the staging launch of a captured step.  -> PreparedBatch (views into the blob).
     split: sequences of 3 - 4 tiles may become two work items in two workgroups (training launches with a zero-initialised tape only).
     ncu: the number of workgroups the plan's items should fill (default: the device's CUs, one workgroup per CU; the wave-per-tile
-    step at D = 64 takes 1024 -- one tile per item while the batch allows it)."""
+    step at D = 64 takes 1024 -- one tile per item while the batch allows it).
+    weights = (block_tensors, last_w, last_b, L, tape, ws) (D = 64): the launch also prepares the one-tile-per-workgroup step's weight
+    fragments in `ws` (re_sasrec_batch_prep_w); the PreparedBatch then says `weights_ready` and sasrec_encoder_step skips its own."""
     _req(seq, torch.int64, "seq")
     B, S = seq.shape
     if pos is not None:
@@ -448,12 +450,17 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     if state is not None:
         _req(state, torch.int32, "state")
     have = pos is not None
-    lib.check(lib.load().re_sasrec_batch_prep(_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), int(bool(split)),
-                                              _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None,
-                                              _p(pb.neg) if copy and have else None, _p(pb.valid) if have else None,
-                                              _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
-                                              _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2),
-                                              _stream()), "re_sasrec_batch_prep")
+    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), int(bool(split)),
+            _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None, _p(pb.neg) if copy and have else None,
+            _p(pb.valid) if have else None, _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
+            _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2))
+    if weights is not None:
+        bt, lw, lb, L, tape, ws = weights
+        lib.check(lib.load().re_sasrec_batch_prep_w(*args, _ptr_table(bt), _p(lw), _p(lb), int(L), int(lw.numel()), _p(tape), tape.numel() * 4, _p(ws),
+                                                    ws.numel(), _stream()), "re_sasrec_batch_prep_w")
+    else:
+        lib.check(lib.load().re_sasrec_batch_prep(*args, _stream()), "re_sasrec_batch_prep")
+    pb.weights_ready = weights is not None
     if not copy:
         pb.seq, pb.pos, pb.neg = seq, pos, neg
     pb.split = bool(split)
@@ -565,9 +572,10 @@ def sasrec_encoder_fwd_loss(E, Ptab, seq, pos, neg, scale, block_tensors, last_w
 
 
 def sasrec_encoder_step(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, last_b, L, drop_p, seed, plan, kind, count, u, tape,
-                        dU_rows, g_rows, keys, loss_ws, dx0, dP, block_grads, g_last_w, g_last_b, ws, e_off=1, loss=None, seed_dev=None):
+                        dU_rows, g_rows, keys, loss_ws, dx0, dP, block_grads, g_last_w, g_last_b, ws, e_off=1, loss=None, seed_dev=None, part=0):
     """Forward + criterion + backward of the encoder per work item in ONE launch, then the weight gradients (re_sasrec_encoder_step):
-    what sasrec_encoder_fwd_loss + sasrec_encoder_bwd(dU_rows=..., out_rows=g_rows[0], dP=...) compute, bit for bit.  -> loss[1]."""
+    what sasrec_encoder_fwd_loss + sasrec_encoder_bwd(dU_rows=..., out_rows=g_rows[0], dP=...) compute, bit for bit.  -> loss[1].
+    part (re_sasrec_encoder_step_part): 1 = the item kernels only, 2 = the weight gradients only (from the tape part 1 left)."""
     _req(E, torch.float32, "E"); _req(Ptab, torch.float32, "Ptab"); _req(seq, torch.int64, "seq"); _req(pos, torch.int64, "pos")
     _req(neg, torch.int64, "neg"); _req(u, torch.float32, "u"); _req(tape, torch.float32, "tape"); _req(dU_rows, torch.float32, "dU_rows")
     _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(count, torch.int32, "count"); _req(loss_ws, torch.uint8, "loss_ws")
@@ -580,11 +588,11 @@ def sasrec_encoder_step(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, la
     if loss is None:
         loss = torch.empty(1, dtype=torch.float32, device=E.device)
     tp, tg = _ptr_table(block_tensors), _ptr_table(block_grads)
-    lib.check(lib.load().re_sasrec_encoder_step(_p(E), R, _p(Ptab), float(scale), _p(seq), _p(pos), _p(neg), B, S, D, L, tp, _p(last_w),
-                                                _p(last_b), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(plan), num_cus(E.device),
-                                                _p(u), _p(tape), tape.numel() * 4, int(e_off), int(kind), _p(count), _p(loss), _p(dU_rows),
-                                                _p(g_rows), _p(keys), _p(loss_ws), loss_ws.numel(), _p(dx0), _p(dP), tg, _p(g_last_w),
-                                                _p(g_last_b), _p(ws), ws.numel(), _stream()), "re_sasrec_encoder_step")
+    lib.check(lib.load().re_sasrec_encoder_step_part(_p(E), R, _p(Ptab), float(scale), _p(seq), _p(pos), _p(neg), B, S, D, L, tp, _p(last_w),
+                                                     _p(last_b), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(plan), num_cus(E.device),
+                                                     _p(u), _p(tape), tape.numel() * 4, int(e_off), int(kind), _p(count), _p(loss), _p(dU_rows),
+                                                     _p(g_rows), _p(keys), _p(loss_ws), loss_ws.numel(), _p(dx0), _p(dP), tg, _p(g_last_w),
+                                                     _p(g_last_b), _p(ws), ws.numel(), int(part), _stream()), "re_sasrec_encoder_step_part")
     return loss
 
 

@@ -143,6 +143,7 @@ class SASRecEngine:
         self.encoder = encoder
         self.split_long = True          # sequences of 3 - 4 tiles as two work items in two workgroups (fused BCE / BPR training step)
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
+        self.fork_wgrad = True          # weight gradients on a side stream beside the item table's scatter-add (same results)
         self.ce_logits_bytes = 1 << 28  # loss='CE': at most this many bytes of logits at a time (more: the catalog is walked in chunks)
         self.compact_rows = True     # BCE / BPR fused step on the batch plan's compact rows (False: all B*S positions + sorted scatter-add)
         self._bufs = {}
@@ -288,11 +289,14 @@ class SASRecEngine:
     def _max_tiles(self):
         return 4 if self.D == 64 else 2     # tiles of 16 rows per work item (LDS capacity of the workgroup-per-item encoder kernels)
 
-    def prepare_batch(self, seq, pos, neg):
+    def prepare_batch(self, seq, pos, neg, for_next_step=False):
         """Per-batch preparation of the fused step as ONE engine launch (re_sasrec_batch_prep; what the reference does at the top of
         `fit`, SASRec/main.py:199-204, plus the encoder's work plan): valid mask, number of valid positions, destination rows of the
-        3*B*S gradient contributions, work items.  No host sync.  -> ops.PreparedBatch."""
-        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu())
+        3*B*S gradient contributions, work items.  No host sync.  -> ops.PreparedBatch.
+        for_next_step: the launch also prepares the weights of the step (re_sasrec_batch_prep_w) -- the batch must then go into the very
+        next step, before anything else changes the parameters."""
+        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(),
+                                     weights=self._prep_weights(*seq.shape) if for_next_step else None)
 
     def check_handover(self):
         """Raise if a split sequence's halves ever timed out waiting for each other (Coach calls this once per epoch; host sync)."""
@@ -307,6 +311,15 @@ class SASRecEngine:
     def _wave_step(self):
         """The training step may run one tile per workgroup (csrc/enc_tile.hip: D = 64; re_sasrec_encoder_step picks per batch)."""
         return bool(self.D == 64 and self.fused_item_kernel and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
+
+    def _prep_weights(self, B, S):
+        """What the batch preparation launch needs to also prepare the tile step's weight fragments (ops.sasrec_batch_prep(weights=));
+        None when the step that follows is not the one-tile-per-workgroup one."""
+        if not (self._wave_step() and self.training and getattr(self, "prep_weights_in_batch_prep", True)):
+            return None
+        W = self._buffers(B, S)
+        P = self.params
+        return (self._block_tensors(), P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, W["tape"], W["ws_bwd"])
 
     def _plan_ncu(self):
         """Workgroups the batch plan's items should fill (None: the device's CUs).  The one-tile-per-workgroup step does not read the
@@ -354,11 +367,31 @@ class SASRecEngine:
         if self.loss_kind != "CE" and self.compact_rows:
             # forward + criterion (one launch), encoder backward, weight gradients, item-table gradient -- all on the plan's compact
             # rows: only rows that exist are read or written, and the table gradient is ONE launch over ~13 k keys (no sort)
+            ready = 8 if getattr(pb, "weights_ready", False) else 0
+            if self.fused_item_kernel and getattr(self, "fork_wgrad", False):
+                # the item kernels, then TWO branches: the weight gradients (enc_wgrad_k + enc_grad_reduce_k) on a side stream beside the
+                # item table's scatter-add on this one -- both depend on the item kernels alone; joined before the optimizer (inside a
+                # captured step the branches are parallel paths of the graph).  (The two item kernels as parallel branches too -- one of
+                # them returns at once -- was measured: 128 vs 110 us per step; a branch at the head of the graph costs more than it hides.)
+                args = (E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count, W["u"], W["tape"], W["dU_rows"],
+                        W["g_rows"], W["keys"], W["ws_loss"], W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
+                        G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"])
+                main = torch.cuda.current_stream()
+                if not hasattr(self, "_side"):
+                    self._side = torch.cuda.Stream()
+                side = self._side
+                loss = ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=3 + ready)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=4, loss=loss)
+                ops.scatter_add_rows_small(W["g_rows"], W["keys"], self.N + 1, GE, n_regions=3, n_dev=pb.plan.view(torch.int32)[1:2], n_mul=16)
+                main.wait_stream(side)
+                return loss
             if self.fused_item_kernel:
                 loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
                                                W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
                                                W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
-                                               G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev)
+                                               G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev, part=ready)
             else:
                 loss = ops.sasrec_encoder_fwd_loss(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind,
                                                    pb.count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], e_off=1,
@@ -425,7 +458,7 @@ class SASRecEngine:
         backward fused in) -> weight gradients + reduction -> ONE deterministic scatter-add of all 3*B*S item-gradient rows -> fused Adam.
         aux: an ops.PreparedBatch of this batch (prepare_batch), or None."""
         A = self.arena
-        pb = aux if aux is not None else self.prepare_batch(seq, pos, neg)
+        pb = aux if aux is not None else self.prepare_batch(seq, pos, neg, for_next_step=True)
         loss = self._step_body(pb, self._step_seed())
         if grad_hook is not None:
             grad_hook(A.grad)
@@ -457,7 +490,7 @@ class SASRecEngine:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu())
+                                       max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(), weights=self._prep_weights(B, S))
             body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -483,7 +516,8 @@ class SASRecEngine:
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu())
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(),
+                              weights=self._prep_weights(B, S))
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:

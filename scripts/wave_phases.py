@@ -42,3 +42,14 @@ d = np.diff(t)
 print("total", int(t[-1] - t[0]), "ticks")
 for i, x in enumerate(d):
     print(f"  {names[i] if i < len(names) else '?':18s} {int(x):7d}")
+
+# the first 8 workgroups side by side (the tiles of the first long sequences: 4-tile sequences first), ticks since the earliest stamp
+big = (ctypes.c_ulonglong * (8 * 96))()
+Lb.re_dbg_enc_marks_blocks.restype = ctypes.c_int
+if Lb.re_dbg_enc_marks_blocks(big) == 0:
+    T = np.array(list(big), dtype=np.int64).reshape(8, 96)
+    n = int((T[0] > 0).sum())
+    print("(the counters of different XCDs are not aligned: ticks since each workgroup's own first stamp)")
+    print(" " * 27 + "".join(f"    wg{b:d} " for b in range(8)))
+    for i in range(n):
+        print(f"{i:3d} {(names[i - 1] if 0 < i <= len(names) else 'start')[:22]:22s}" + "".join(f"{int(T[b, i] - T[b, 0]):8d}" for b in range(8)))
