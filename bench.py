@@ -593,8 +593,20 @@ def main():
         bpr = 8 + 8 * D
         gbs_small = idx_small.numel() * bpr / (t_g * 1e-3) / 1e9
         gbs_big = n_big * bpr / (t_gb * 1e-3) / 1e9
+        # this box's own streaming ceiling for the same bytes: the same kernel over SEQUENTIAL rows (a pure copy + the index stream) and
+        # torch's device-to-device copy of the same 1 GiB (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured with a float4 copy)
+        idx_seq = torch.arange(n_big, device="cuda")
+        t_seq = event_time_ms(lambda: ops.gather_rows(W_big, idx_seq), 20)
+        src_c = W_big[:n_big]
+        dst_c = torch.empty_like(src_c)
+        t_cp = event_time_ms(lambda: dst_c.copy_(src_c), 20)
+        peak_meas = max(n_big * bpr / (t_seq * 1e-3) / 1e9, 2 * n_big * 4 * D / (t_cp * 1e-3) / 1e9)
+        del dst_c, src_c, idx_seq
         line["roofline_gather"] = {"kernel": "gather_rows_vec4<16>", "bound": "hbm", "achieved": round(gbs_big, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_big / HBM_PEAK_GBS, 4),
+                                   "peak_measured": round(peak_meas, 1), "frac_of_peak_measured": round(gbs_big / peak_meas, 4),
+                                   "peak_measured_how": f"best of this box, same run: the same kernel over sequential rows ({n_big * bpr / (t_seq * 1e-3) / 1e9:.0f} GB/s) "
+                                                        f"and torch's device-to-device copy of 1 GiB ({2 * n_big * 4 * D / (t_cp * 1e-3) / 1e9:.0f} GB/s)",
                                    "traffic": pmc_traffic("gather_rows_vec4<16, 4, true>"), "launch_ms": round(t_gb, 4),
                                    "work": f"{bpr} B per looked-up row x {n_big} uniform-random rows of a {R_big}x{D} fp32 table (4 GiB, HBM-resident)",
                                    "beauty_shape": {"rows": int(idx_small.numel()), "launch_ms": round(t_g, 4), "GB/s": round(gbs_small, 1),

@@ -133,6 +133,8 @@ class Coach:
             return loss
         from .nn import GraphedStep
         key = tuple((tuple(t.shape), t.dtype) for t in inputs)
+        if hasattr(m, "static_shapes") or type(m).__name__ in ("GRU4Rec", "NARM", "BERT4Rec"):
+            m.static_shapes = True          # (their reference forms drop all-pad columns / index by a mask: data-dependent shapes, a host sync)
         if key not in self._graphed:
             self._graphed[key] = GraphedStep(m, lambda *a: self.loss_fn(m.fit(*a)), self.optimizer, inputs)
         return self._graphed[key](*inputs)

@@ -13,7 +13,7 @@
 
 #define RE_GATHER_ILP 4
 
-template <int LPR, int ILP = RE_GATHER_ILP, bool NT = false>  // lanes per row; D = 4 * LPR * k
+template <int LPR, int ILP = RE_GATHER_ILP, bool NT = false, bool NTL = false>  // lanes per row; D = 4 * LPR * k
 __global__ __launch_bounds__(256) void gather_rows_vec4(const float* __restrict__ W, int64_t R, int64_t D,
                                                         const int64_t* __restrict__ idx, int64_t n,
                                                         float* __restrict__ out) {
@@ -34,7 +34,12 @@ __global__ __launch_bounds__(256) void gather_rows_vec4(const float* __restrict_
 #pragma unroll
             for (int u = 0; u < ILP; ++u) {
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r[u] >= 0 && r[u] < R) v[u] = reinterpret_cast<const float4*>(W + r[u] * D)[c];
+                if (r[u] >= 0 && r[u] < R) {
+                    const float4* src = reinterpret_cast<const float4*>(W + r[u] * D) + c;
+                    if (NTL) v[u] = make_float4(__builtin_nontemporal_load(&src->x), __builtin_nontemporal_load(&src->y),
+                                                __builtin_nontemporal_load(&src->z), __builtin_nontemporal_load(&src->w));
+                    else v[u] = *src;
+                }
             }
 #pragma unroll
             for (int u = 0; u < ILP; ++u) {
@@ -75,12 +80,13 @@ extern "C" int re_gather_rows(const float* W, int64_t R, int64_t D, const int64_
     if ((D & 3) == 0 && aligned16(W) && aligned16(out)) {
         const int64_t D4 = D >> 2;
         // Outputs larger than the L2s are streamed with non-temporal stores (+9 % on a 4 GiB-table gather: 5.2 -> 5.7 TB/s,
-        // measured with scripts/tune_gather.py); small outputs stay cacheable for the consumer kernel.
+        // measured with scripts/tune_gather.py) and their rows read with non-temporal loads (another +2 %: 5.77 -> 5.88 TB/s);
+        // small outputs stay cacheable for the consumer kernel.
         const bool nt = (size_t)n * D * sizeof(float) > ((size_t)32 << 20);
         const int64_t cap = 65536;
 #define RE_GATHER_LAUNCH(LPRV)                                                                                              \
     do {                                                                                                                    \
-        if (nt) hipLaunchKernelGGL((gather_rows_vec4<LPRV, RE_GATHER_ILP, true>), dim3(re_grid(n, (256 / LPRV) * RE_GATHER_ILP, cap)), dim3(256), 0, s, W, R, D, idx, n, out); \
+        if (nt) hipLaunchKernelGGL((gather_rows_vec4<LPRV, RE_GATHER_ILP, true, true>), dim3(re_grid(n, (256 / LPRV) * RE_GATHER_ILP, cap)), dim3(256), 0, s, W, R, D, idx, n, out); \
         else hipLaunchKernelGGL((gather_rows_vec4<LPRV, RE_GATHER_ILP, false>), dim3(re_grid(n, (256 / LPRV) * RE_GATHER_ILP, cap)), dim3(256), 0, s, W, R, D, idx, n, out); \
     } while (0)
         if (D4 >= 32) RE_GATHER_LAUNCH(32);
@@ -266,6 +272,8 @@ extern "C" int re_dbg_gather64(const float* W, int64_t R, const int64_t* idx, in
         case 3: RE_DBG_LAUNCH(8, true); break;
         case 4: RE_DBG_LAUNCH(2, false); break;
         case 5: RE_DBG_LAUNCH(16, false); break;
+        case 6: hipLaunchKernelGGL((gather_rows_vec4<16, 4, true, true>), dim3(re_grid(n, 16 * 4, gridcap)), dim3(256), 0, s, W, R, D, idx, n, out); break;
+        case 7: hipLaunchKernelGGL((gather_rows_vec4<16, 8, true, true>), dim3(re_grid(n, 16 * 8, gridcap)), dim3(256), 0, s, W, R, D, idx, n, out); break;
         default: return RE_EINVAL;
     }
     return re_launch_status();

@@ -217,8 +217,12 @@ class GRU4Rec(_EncodeRanking, torch.nn.Module):
     def encode(self, seqs):
         """seqs [B, S] int64, ids + 1, right-padded with 0 -> (userEmbds [B, D], itemEmbds [N, D])."""
         mask = seqs.ne(0)
-        keep = mask.any(dim=0)                                   # shrink_pads: columns that are padding for every row
-        seqs, mask = seqs[:, keep], mask[:, keep]
+        if not getattr(self, "static_shapes", False):
+            # shrink_pads: columns that are padding for every row are dropped (GRU4Rec/main.py:121-124).  The state at a row's last real
+            # position does not depend on the pad columns behind it, so keeping them (static_shapes: no data-dependent shape, no host
+            # sync -- what a captured step needs) gives the same user states.
+            keep = mask.any(dim=0)
+            seqs, mask = seqs[:, keep], mask[:, keep]
         B, S = seqs.shape
         x = self.emb_dropout(self.item(seqs.reshape(-1)).reshape(B, S, -1))
         out, _ = self.gru(x)
@@ -506,10 +510,30 @@ class BERT4Rec(torch.nn.Module):
         return self.encoder(x, src_key_padding_mask=pad)
 
     def fit(self, seqs, rnds=None):
+        if getattr(self, "static_shapes", False):
+            return self._fit_static(seqs, rnds)
         masked, labels, masks = self.random_mask(seqs, self.mask_ratio, rnds)
         h = self.encode(masked)
         rows = rnn.gather_rows(h.reshape(-1, h.shape[-1]).contiguous(), masks.reshape(-1).nonzero().squeeze(1))
         return {"rec_loss": F.cross_entropy(self.fc(rows), labels)}
+
+    def _fit_static(self, seqs, rnds=None):
+        """The same loss with no data-dependent shape (no host sync: a captured step).  The masked positions are compacted into a buffer
+        of FIXED capacity (torch.nonzero_static): the mean over n p masked positions plus 8 standard deviations of the binomial count
+        (the count exceeds it with probability < 1e-15; positions beyond it would be left out of the mean), unused slots are zero rows
+        whose label is cross_entropy's ignore_index."""
+        pad = seqs == self.PADDING_VALUE
+        if rnds is None:
+            rnds = torch.rand(seqs.shape, device=seqs.device)
+        masked = torch.where(rnds < self.mask_ratio, torch.full_like(seqs, self.MASKING_VALUE), seqs).masked_fill(pad, self.PADDING_VALUE)
+        masks = (masked == self.MASKING_VALUE).reshape(-1)
+        n, p = masks.numel(), self.mask_ratio
+        cap = min(n, int(n * p + 8.0 * (n * p * (1.0 - p)) ** 0.5) + 16)
+        at = torch.nonzero_static(masks, size=cap, fill_value=-1).squeeze(1)
+        h = self.encode(masked)
+        rows = rnn.gather_rows(h.reshape(-1, h.shape[-1]).contiguous(), at)                    # (-1: a zero row)
+        labels = torch.where(at >= 0, seqs.reshape(-1)[at.clamp_min(0)], torch.full_like(at, -100))
+        return {"rec_loss": F.cross_entropy(self.fc(rows), labels, ignore_index=-100)}
 
     def recommend_from_full(self, seqs):
         """seqs: the evaluation pipe's rows (left-padded history of maxlen - 1, the mask token last)."""
@@ -639,8 +663,9 @@ class NARM(_EncodeRanking, torch.nn.Module):
 
     def encode(self, seqs):
         mask = seqs.ne(0)
-        keep = mask.any(dim=0)                                   # shrink_pads (NARM/main.py:131-134)
-        seqs, mask = seqs[:, keep], mask[:, keep]
+        if not getattr(self, "static_shapes", False):            # shrink_pads (NARM/main.py:131-134); static_shapes: as in GRU4Rec.encode -- the
+            keep = mask.any(dim=0)                               # pad columns carry mask 0 into the attention, the result is the same
+            seqs, mask = seqs[:, keep], mask[:, keep]
         B, S = seqs.shape
         out, _ = self.gru(self.emb_dropout(self.item(seqs.reshape(-1)).reshape(B, S, -1)))
         last = (mask.sum(1) - 1).clamp_min(0)

@@ -18,8 +18,8 @@ def run(v, cap):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / 10
 for rnd in range(2):
-    for v, name in enumerate(["ilp4", "ilp8", "ilp4nt", "ilp8nt", "ilp2", "ilp16"]):
+    for v, name in enumerate(["ilp4", "ilp8", "ilp4nt", "ilp8nt", "ilp2", "ilp16", "ilp4nt+ntload", "ilp8nt+ntload"]):
         for cap in (2048, 4096, 16384, 65536):
             ms = run(v, cap)
-            print(f"{name:7s} cap={cap:6d} {ms:.4f} ms  {n*520/ms/1e6:.0f} GB/s")
+            print(f"{name:14s} cap={cap:6d} {ms:.4f} ms  {n*520/ms/1e6:.0f} GB/s")
 assert torch.equal(out, W[idx])

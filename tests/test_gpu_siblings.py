@@ -433,3 +433,89 @@ def test_sgl_matches_reference_on_recorded_edge_dropout():
         out = m2.fit(users, pos, neg)
         assert all(torch.isfinite(v) for v in out.values())
         assert (m2.sub[0] is m2.sub[1]) == (aug == "nd")
+
+
+def _right_padded(rng, B, S, N, offset=1):
+    seq = np.zeros((B, S), np.int64)
+    for b in range(B):
+        n = int(rng.integers(1, S - 3))                       # (at least three all-pad columns at the right: shrink_pads has something to drop)
+        seq[b, :n] = rng.integers(0, N, n) + offset
+    return seq
+
+
+@pytest.mark.parametrize("name", ["GRU4Rec", "NARM"])
+def test_static_shapes_give_the_reference_form_results(name):
+    """static_shapes (no shrink_pads: no data-dependent shape, no host sync) computes the same loss and gradients as the reference form."""
+    from recboard_amd import siblings
+    N, B, S = 300, 16, 12
+    rng = np.random.default_rng(5)
+    seq = torch.from_numpy(_right_padded(rng, B, S, N)).cuda()
+    pos, neg = (torch.from_numpy(rng.integers(0, N, (B, 1))).cuda() for _ in range(2))
+    kw = dict(emb_dropout_rate=0.0, hidden_dropout_rate=0.0)
+    if name == "NARM":
+        kw["ct_dropout_rate"] = 0.0
+    torch.manual_seed(3)
+    m = getattr(siblings, name)(N, embedding_dim=32, hidden_size=48, **kw).train()
+    out = []
+    for static in (False, True):
+        m.static_shapes = static
+        m.zero_grad(set_to_none=True)
+        loss = m.fit(seq, pos, neg)["rec_loss"]
+        loss.backward()
+        out.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    torch.testing.assert_close(out[1][0], out[0][0], rtol=1e-5, atol=1e-7)
+    for k, g in out[0][1].items():
+        torch.testing.assert_close(out[1][1][k], g, rtol=1e-4, atol=1e-6, msg=k)
+
+
+def test_bert4rec_static_shapes_loss_equals_masked_indexing():
+    from recboard_amd.siblings import BERT4Rec
+    N, B, S = 200, 12, 20
+    rng = np.random.default_rng(9)
+    seq = np.zeros((B, S), np.int64)
+    for b in range(B):
+        n = int(rng.integers(2, S))
+        seq[b, S - n:] = rng.integers(0, N, n) + 2
+    seq = torch.from_numpy(seq).cuda()
+    rnds = torch.from_numpy(rng.random((B, S))).float().cuda()
+    torch.manual_seed(4)
+    m = BERT4Rec(N, maxlen=S, embedding_dim=32, num_heads=2, num_blocks=1, dropout_rate=0.0).train()
+    res = []
+    for static in (False, True):
+        m.static_shapes = static
+        m.zero_grad(set_to_none=True)
+        loss = m.fit(seq, rnds)["rec_loss"]
+        loss.backward()
+        res.append((loss.detach().clone(), m.fc.weight.grad.clone(), m.item.weight.grad.clone()))
+    torch.testing.assert_close(res[1][0], res[0][0], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(res[1][1], res[0][1], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["GRU4Rec", "NARM", "BERT4Rec"])
+def test_sibling_steps_capture_into_a_graph(name):
+    """With static shapes the whole training step of the three models replays from one hipGraph (nn.GraphedStep through the Coach)."""
+    from recboard_amd import siblings
+    from recboard_amd.coach import Coach
+    N, B, S = 300, 32, 12
+    rng = np.random.default_rng(6)
+    torch.manual_seed(8)
+    if name == "BERT4Rec":
+        m = siblings.BERT4Rec(N, maxlen=S, embedding_dim=32, num_heads=2, num_blocks=1, dropout_rate=0.1).train()
+        pipe = [{"ISeq": torch.from_numpy(np.where(rng.random((B, S)) < 0.3, 0, rng.integers(0, N, (B, S)) + 2)).cuda()} for _ in range(6)]
+        keys = ("ISeq",)
+    else:
+        kw = dict(emb_dropout_rate=0.1, hidden_dropout_rate=0.0)
+        m = getattr(siblings, name)(N, embedding_dim=32, hidden_size=48, **kw).train()
+        pipe = [{"ISeq": torch.from_numpy(_right_padded(rng, B, S, N)).cuda(), "IPos": torch.from_numpy(rng.integers(0, N, (B, 1))).cuda(),
+                 "INeg": torch.from_numpy(rng.integers(0, N, (B, 1))).cuda()} for _ in range(6)]
+        keys = ("ISeq", "IPos", "INeg")
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    coach = Coach(m, pipe, monitors=["LOSS"], kind="module", optimizer=torch.optim.Adam(m.parameters(), lr=1e-2, capturable=True), fit_keys=keys,
+                  graph=True)
+    l0 = coach.train_per_epoch(0)["LOSS"]
+    for _ in range(4):
+        l1 = coach.train_per_epoch(1)["LOSS"]
+    assert m.static_shapes and len(coach._graphed) == 1
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0                                # (it trains: 30 replayed steps on 6 batches)
+    assert any(not torch.equal(before[k], p.detach()) for k, p in m.named_parameters())
