@@ -306,6 +306,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the aten-on-GPU baselines (kernel-trace runs: only the engine's kernels)")
     ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
+    ap.add_argument("--prefetch", action="store_true", help="the next batch's preparation launch on a side stream beside the step (measured slower: 115+ vs 106 us)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -352,7 +353,8 @@ def main():
 
     def step_graph(i):   # RAW batch in: one preparation launch (mask, count, scatter rows, encoder plan, staging) + one graph replay
         seq, pos, neg, _ = batches[i % len(batches)]
-        return model.train_step_graph(seq, pos, neg, grad_hook=hook)
+        nxt = batches[(i + 1) % len(batches)][:3] if args.prefetch else None   # (--prefetch: the next batch's preparation beside this step)
+        return model.train_step_graph(seq, pos, neg, grad_hook=hook, next_batch=nxt)
 
     # Graph or eager launches: decided BEFORE any step that contains a collective runs.  Every rank captures and replays one step
     # with a no-op hook (no collective), the ranks agree with one all-reduce, and the step's effects are rolled back -- a rank whose

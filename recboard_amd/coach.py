@@ -16,6 +16,19 @@ import torch
 from .evaluate import PredictionEvaluator, RankingEvaluator, ReduceLROnPlateau, ragged_to_csr  # noqa: F401
 
 
+def _lookahead(it):
+    """(item, next item or None) pairs."""
+    it = iter(it)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 class Coach:
     def __init__(self, model, trainpipe, validpipe=None, testpipe=None, monitors=("LOSS", "HitRate@10", "NDCG@10"),
                  which4best="NDCG@10", eval_freq=5, kind="seq", checkpoint_path=None, lr_scheduler=None, optimizer=None,
@@ -88,7 +101,20 @@ class Coach:
         tot = torch.zeros((), device=self.device)
         n = 0
         need = {"seq": ("ISeq", "IPos", "INeg"), "pred": ("X", "Label"), "module": self.fit_keys}.get(self.kind)
-        for data in self._device_batches(self.trainpipe, need):
+        batches = self._device_batches(self.trainpipe, need)
+        pipelined = self.kind == "seq" and self._graphable() and getattr(self.model, "pipelined_prep", False)
+        if pipelined:
+            batches = _lookahead(batches)
+        for data in batches:
+            if pipelined:
+                # the NEXT batch is already on the device (one batch ahead): its preparation launch runs beside this step
+                data, nxt = data
+                loss = self.model.train_step_graph(data["ISeq"], data["IPos"], data["INeg"],
+                                                   next_batch=None if nxt is None else (nxt["ISeq"], nxt["IPos"], nxt["INeg"]))
+                bsz = len(data["User"])
+                tot.add_(loss, alpha=bsz)
+                n += bsz
+                continue
             if self.kind == "module":
                 loss = self._module_step(tuple(data[k] for k in self.fit_keys))
                 bsz = len(data[self.fit_keys[0]])

@@ -144,6 +144,9 @@ class SASRecEngine:
         self.split_long = True          # sequences of 3 - 4 tiles as two work items in two workgroups (fused BCE / BPR training step)
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
         self.fork_wgrad = True          # weight gradients on a side stream beside the item table's scatter-add (same results)
+        self.pipelined_prep = False     # True: the Coach hands train_step_graph the next batch and its preparation launch runs on a side stream
+                                        # beside this step.  Measured on MI355X: 115 - 137 us per step against 106 in front of the step -- the
+                                        # second queue's launch disturbs the graph's own branches more than the 12 us it hides
         self.ce_logits_bytes = 1 << 28  # loss='CE': at most this many bytes of logits at a time (more: the catalog is walked in chunks)
         self.compact_rows = True     # BCE / BPR fused step on the batch plan's compact rows (False: all B*S positions + sorted scatter-add)
         self._bufs = {}
@@ -470,7 +473,9 @@ class SASRecEngine:
     #      sets the step time).  Per step: the batch-preparation launch (raw (seq, pos, neg) -> the static buffers the graph reads:
     #      copies, valid / count / rows_all, the encoder's plan, per-step seed and Adam scalars as device words) + one graph launch.
     #      BCE / BPR only: the CE path's shapes depend on the batch's number of valid positions.
-    def _capture(self, B, S, with_adam):
+    def _capture(self, B, S, with_adam, in_prep=True):
+        """in_prep: the tile step's weight fragments come from the batch-preparation launch (False: from a launch inside the graph --
+        the pipelined form, whose preparation launch runs before the previous step's optimizer has finished)."""
         A = self.arena
         blob = torch.zeros(ops.prep_layout(B, S)[1], dtype=torch.uint8, device=self.device)
         state = torch.zeros(4, dtype=torch.int32, device=self.device)
@@ -490,7 +495,8 @@ class SASRecEngine:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(), weights=self._prep_weights(B, S))
+                                       max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(),
+                                       weights=self._prep_weights(B, S) if in_prep else None)
             body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -499,27 +505,68 @@ class SASRecEngine:
             loss = body()
         for t, k in zip((A.data, A.m, A.v, A.grad), keep):
             t.copy_(k)
-        return dict(graph=graph, blob=blob, state=state, loss=loss)
+        return dict(graph=graph, blob=blob, state=state, loss=loss, in_prep=in_prep)
 
-    def train_step_graph(self, seq, pos, neg, grad_hook=None):
+    def _stage(self, g, seq, pos, neg, step):
+        """The batch-preparation launch of `step` (1-based) into the static buffers of the captured step `g`."""
+        B, S = seq.shape
+        sd = (self.seed * 0x9E3779B1 + step * 0x85EBCA77) & 0xFFFFFFFF          # (= _step_seed() once arena.step == step - 1)
+        ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=sd, step=step, lr=self.lr,
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(),
+                              weights=self._prep_weights(B, S) if g["in_prep"] else None)
+
+    def train_step_graph(self, seq, pos, neg, grad_hook=None, next_batch=None, next_ready=None):
         """`train_step_fused` on a RAW batch, replayed from a captured hipGraph: one batch-preparation launch (which also stages the
         batch and the step scalars into the graph's static buffers) + one graph launch.  Results are identical to the eager fused
-        step.  The returned loss tensor is overwritten by the next call."""
+        step.  The returned loss tensor is overwritten by the next call (the call after next with `next_batch`).
+        next_batch = (seq, pos, neg) of the FOLLOWING call, if the caller already has it (an epoch loop does): its preparation launch
+        then runs on a side stream BESIDE this step instead of in front of the next one -- it depends on the batch alone -- into the
+        buffers of a second captured copy of the step (two copies alternate).  The following call must pass the same three tensors,
+        unchanged; next_ready: an event after which they are complete (e.g. their host-to-device copies), if they are produced on
+        another stream."""
         if self.loss_kind == "CE":
             raise NotImplementedError("graph replay: BCE / BPR only (CE shapes vary with the batch)")
         A = self.arena
         B, S = seq.shape
-        key = (B, S, grad_hook is None, self.training)
         if not hasattr(self, "_graphs"):
-            self._graphs = {}
-        if key not in self._graphs:
-            self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
-        g = self._graphs[key]
-        ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(),
-                              weights=self._prep_weights(B, S))
+            self._graphs, self._staged, self._pipe_i = {}, None, 0
+        staged, self._staged = self._staged, None
+        hit = staged is not None and staged[0] is seq and staged[1] is pos and staged[2] is neg and staged[5] == (grad_hook is None, self.training)
+        pipelined = hit or next_batch is not None
+        key = (B, S, grad_hook is None, self.training) + (((self._pipe_i & 1),) if pipelined else ())
+        if hit:
+            g = staged[3]
+            torch.cuda.current_stream().wait_event(staged[4])
+        else:
+            if key not in self._graphs:
+                self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None, in_prep=not pipelined)
+            g = self._graphs[key]
+        if next_batch is not None:
+            entry = torch.cuda.Event()
+            entry.record()                      # (everything the caller enqueued so far: the next batch exists, the other copy's last replay is done)
+        if not hit:
+            self._stage(g, seq, pos, neg, A.step + 1)
         g["graph"].replay()
         A.step += 1
+        if pipelined:
+            self._pipe_i += 1
+        if next_batch is not None:
+            nseq, npos, nneg = next_batch
+            k2 = (nseq.shape[0], nseq.shape[1], grad_hook is None, self.training, self._pipe_i & 1)
+            if k2 not in self._graphs:
+                self._graphs[k2] = self._capture(nseq.shape[0], nseq.shape[1], with_adam=grad_hook is None, in_prep=False)
+            g2 = self._graphs[k2]
+            if not hasattr(self, "_prep_stream"):
+                self._prep_stream = torch.cuda.Stream()
+            ps = self._prep_stream
+            ps.wait_event(entry)
+            if next_ready is not None:
+                ps.wait_event(next_ready)
+            with torch.cuda.stream(ps):
+                self._stage(g2, nseq, npos, nneg, A.step + 1)
+                ev = torch.cuda.Event()
+                ev.record(ps)
+            self._staged = (nseq, npos, nneg, g2, ev, (grad_hook is None, self.training))
         if grad_hook is not None:
             grad_hook(A.grad)
             ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)

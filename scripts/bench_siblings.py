@@ -147,9 +147,9 @@ def main():
         "GCN (Beauty graph, B=2048)": (lambda: sib.GCN(U, N, A_sym, 64, 3), tri, True),
         "STAMP BCE (N=12101, B=512, S=50)": (lambda: sib.STAMP(N, 64, 64, loss="BCE"), (seq_l1, p1, n1), True),
         "FMLP-Rec BPR (N=12101, B=512, S=50)": (lambda: sib.FMLPRec(N, S, 64, 2, loss="BPR"), (seq_l1, p1, n1), True),
-        "NARM (N=12101, B=512, S=50)": (lambda: sib.NARM(N, 64, 128), (seq_r, p1, n1), False),
-        "GRU4Rec BPR (N=12101, B=512, S=50)": (lambda: sib.GRU4Rec(N, 64, 128, loss="BPR"), (seq_r, p1, n1), False),
-        "BERT4Rec (N=12101, B=512, S=50)": (lambda: sib.BERT4Rec(N, S, 64, 4, 2), (seq_l,), False),
+        "NARM (N=12101, B=512, S=50)": (lambda: sib.NARM(N, 64, 128), (seq_r, p1, n1), "static"),
+        "GRU4Rec BPR (N=12101, B=512, S=50)": (lambda: sib.GRU4Rec(N, 64, 128, loss="BPR"), (seq_r, p1, n1), "static"),
+        "BERT4Rec (N=12101, B=512, S=50)": (lambda: sib.BERT4Rec(N, S, 64, 4, 2), (seq_l,), "static"),
     }
     out = {}
     for name, (make, inputs, graphable) in cases.items():
@@ -166,6 +166,8 @@ def main():
                 torch.manual_seed(3)
                 m = make().cuda()
                 m.train()
+                if mode == "graph" and graphable == "static":
+                    m.static_shapes = True          # (no shrink_pads / mask indexing: what the Coach sets for a captured step)
                 try:
                     if mode == "eager":
                         row[f"{kind}_ms"] = round(timed(m, (lambda m=m: m.fit(*inputs)), args.steps), 4)

@@ -346,3 +346,29 @@ def test_ce_in_catalog_chunks_equals_materialised_ce():
     ga, gb = eng[0][0].arena.views(eng[0][0].arena.grad), eng[1][0].arena.views(eng[1][0].arena.grad)
     for k in ga:
         torch.testing.assert_close(gb[k], ga[k], rtol=1e-4, atol=1e-7, msg=k)
+
+
+def test_pipelined_preparation_gives_the_same_steps():
+    """train_step_graph(next_batch=...): the next batch's preparation launch on a side stream, two captured copies alternating -- the same
+    losses and parameters as the plain captured step (dropout on: the per-step seeds must line up too)."""
+    from recboard_amd.sasrec import SASRecEngine
+    N, B, S = 500, 48, 50
+    rng = np.random.default_rng(12)
+    batches = []
+    for _ in range(5):
+        seq = np.zeros((B, S), np.int64)
+        for b in range(B):
+            n = int(rng.integers(1, S))
+            seq[b, S - n:] = rng.integers(1, N + 1, n)
+        pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
+    a = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, lr=1e-3, seed=4)
+    b = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, lr=1e-3, seed=4)
+    for i in range(7):
+        la = a.train_step_graph(*batches[i % 5]).clone()
+        lb = b.train_step_graph(*batches[i % 5], next_batch=batches[(i + 1) % 5] if i < 6 else None).clone()
+        torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-7)
+    assert b._staged is None and len([k for k in b._graphs if len(k) == 5]) == 2
+    torch.testing.assert_close(b.arena.data, a.arena.data, rtol=1e-4, atol=1e-6)
+    b.check_handover()
