@@ -263,19 +263,26 @@ def sampler_rates(cfg, model):
     torch.cuda.synchronize()
     dts = (time.perf_counter() - t0) / 3
     model.train()
-    coach = Coach(model, smp, monitors=["LOSS"], kind="seq")
-    coach.train_per_epoch(0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for e in range(3):
-        coach.train_per_epoch(1 + e)
-    torch.cuda.synchronize()
-    dtc = (time.perf_counter() - t0) / 3
+
+    def epoch_rate(sampler):
+        coach = Coach(model, sampler, monitors=["LOSS"], kind="seq")
+        coach.train_per_epoch(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for e in range(3):
+            coach.train_per_epoch(1 + e)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3
+    dtc = epoch_rate(smp)
+    dtf = epoch_rate(DeviceSeqSampler(inter, S, B, seed=3, fused=True))
     full = (U // B) * B + (U % B)
     return {"sampler_samples_per_sec": round(full / dts, 1), "sampler_ms_per_batch": round(dts / nb * 1e3, 4),
-            "sampler_to_coach_samples_per_sec": round(full / dtc, 1), "sampler_to_coach_ms_per_step": round(dtc / nb * 1e3, 4),
-            "what": f"DeviceSeqSampler over {U} users ({int(ptr[-1])} interactions, {nb} batches of {B}; the last one short), 3 epochs each: the sampler alone, "
-                    "then Coach.train_per_epoch fed by it (device batches -> batch preparation -> hipGraph replay; the epoch's loss read once)"}
+            "sampler_to_coach_samples_per_sec": round(full / dtf, 1), "sampler_to_coach_ms_per_step": round(dtf / nb * 1e3, 4),
+            "sampler_to_coach_unfused_samples_per_sec": round(full / dtc, 1), "sampler_to_coach_unfused_ms_per_step": round(dtc / nb * 1e3, 4),
+            "what": f"DeviceSeqSampler over {U} users ({int(ptr[-1])} interactions, {nb} batches of {B}; the last one short), 3 epochs each: the sampler "
+                    "alone (one re_seq_train_sample launch per batch); Coach.train_per_epoch fed by the FUSED sampler (tickets: the step's batch-preparation "
+                    "launch samples the rows itself, re_seq_train_sample_prep -> hipGraph replay; the epoch's loss read once); and fed by the sampler's "
+                    "tensor batches (sampler launch -> batch preparation -> replay: `unfused`)"}
 
 
 def launch_ranks(n, argv):

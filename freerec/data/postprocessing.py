@@ -85,9 +85,10 @@ class Pipe:
         self.rng = np.random.default_rng(seed)
         return self
 
-    def to_(self, device):
-        """recengine extension: sample the epoch on `device` where a device sampler exists for the chain (SASRec training)."""
-        self.device = torch.device(device)
+    def to_(self, device, fused=False):
+        """recengine extension: sample the epoch on `device` where a device sampler exists for the chain (SASRec training).
+        fused: hand out sample tickets instead of tensors -- the engine's batch-preparation launch samples the rows itself."""
+        self.device, self.fused = torch.device(device), bool(fused)
         return self
 
     # ---- an epoch's row seeds
@@ -221,7 +222,7 @@ class Pipe:
     def __iter__(self):
         if self.device is not None and self.device.type == "cuda":
             from recboard_amd import sampler
-            dev = sampler.device_pipe(self)
+            dev = sampler.device_pipe(self, fused=getattr(self, "fused", False))
             if dev is not None:
                 yield from dev
                 return

@@ -78,7 +78,9 @@ class Coach:
         self.path = cfg.get("checkpoint_path") or os.path.join("logs", str(cfg.get("description", "RecSys")), str(cfg.get("dataset")), str(cfg.get("id") or time.strftime("%m%d%H%M%S")))
         self._engine = self._attach_engine()
         if self._engine is not None and hasattr(self.trainpipe, "to_"):
-            self.trainpipe.to_(self.device)            # (batches sampled on the device where a device sampler exists for the chain)
+            # batches sampled on the device where a device sampler exists for the chain; for the fused SASRec step the sampling happens
+            # INSIDE the step's batch-preparation launch (tickets instead of tensors)
+            self.trainpipe.to_(self.device, fused=hasattr(self._engine, "eng") and hasattr(self._engine.eng, "train_step_graph_sampled"))
 
     # ---- set-up hooks the scripts override
     def set_device(self):

@@ -246,12 +246,28 @@ int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, const int64_t* 
 /* The same launch with the weight preparation of the D = 64 one-tile-per-workgroup step in extra workgroups: the encoder's matrices
  * (block_params / last_w / last_b as for re_sasrec_encoder_step) as bf16 hi / mid fragment planes into that step's workspace `ws`, the
  * launch epoch in `tape`'s flag area advanced.  The step that follows on the same stream is then called with part + 8
- * (re_sasrec_encoder_step_part) and launches no preparation kernel of its own. */
+ * (re_sasrec_encoder_step_part) and launches no preparation kernel of its own.  block_params == NULL: no weight preparation.
+ * loss_acc != NULL: loss_acc[0] += prev_loss[0] * loss_weight -- the PREVIOUS step's loss folded into an epoch accumulator by a launch
+ * that runs anyway (the reference reads loss.item() per step, SASRec/main.py:252-256; an accumulation launch per step costs 4 us). */
 int re_sasrec_batch_prep_w(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
                            int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid, int32_t* count,
                            int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed, int64_t step, double lr,
                            double beta1, double beta2, const float* const* block_params, const float* last_w, const float* last_b,
-                           int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, re_stream_t stream);
+                           int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, const float* prev_loss,
+                           float* loss_acc, float loss_weight, re_stream_t stream);
+
+/* SAMPLE + PREPARE in one launch: row b of the batch is user order[b0 + b] of the SASRec training chain -- the rows and draws of
+ * re_seq_train_sample(ptr, items, sorted_items, order, n_order, b0, B, S, N, sample_seed, sample_step, ...) (SASRec/main.py:143-157) --
+ * written straight into seq_out / pos_out / neg_out (the static buffers a captured step reads; required) together with everything
+ * re_sasrec_batch_prep derives from a batch; block_params != NULL: + the tile step's weight fragments as re_sasrec_batch_prep_w.
+ * A sampled training step is then ONE preparation launch + the step, not sampler + preparation + step. */
+int re_seq_train_sample_prep(const int64_t* ptr, const int64_t* items, const int64_t* sorted_items, const int64_t* order, int64_t n_order,
+                             int64_t b0, int64_t N, uint32_t sample_seed, uint32_t sample_step, int64_t* users, int64_t B, int64_t S,
+                             int32_t ncu, int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out,
+                             uint8_t* valid, int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
+                             int64_t step, double lr, double beta1, double beta2, const float* const* block_params, const float* last_w,
+                             const float* last_b, int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                             const float* prev_loss, float* loss_acc, float loss_weight, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K6/K7  fused SASRec encoder (D = 64 or 128, S <= 64, L <= 4, 1 head): one workgroup per work item of the plan, activations in LDS.

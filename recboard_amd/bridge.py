@@ -35,6 +35,11 @@ class SASRecAdapter:
         tot = torch.zeros((), device=coach.device)
         n = 0
         for data in coach.dataloader:
+            if "Sample" in data:          # the device sampler's ticket (freerec pipe -> .to_(device)): the step's preparation launch samples the batch
+                loss = eng.train_step_graph_sampled(data["Sample"])
+                tot.add_(loss, alpha=len(data["Sample"]))
+                n += len(data["Sample"])
+                continue
             seq, pos, neg = (data[f].to(coach.device, non_blocking=True) for f in (coach.ISeq, coach.IPos, coach.INeg))
             loss = eng.train_step_graph(seq, pos.reshape(seq.shape), neg.reshape(seq.shape))
             tot.add_(loss, alpha=seq.shape[0])

@@ -102,6 +102,10 @@ class Coach:
         n = 0
         need = {"seq": ("ISeq", "IPos", "INeg"), "pred": ("X", "Label"), "module": self.fit_keys}.get(self.kind)
         batches = self._device_batches(self.trainpipe, need)
+        # the fused SASRec step sums the epoch's losses itself (each step's loss is folded in by the next step's preparation launch)
+        own_sum = self.kind == "seq" and self._graphable() and hasattr(self.model, "begin_loss_accumulation")
+        if own_sum:
+            self.model.begin_loss_accumulation()
         pipelined = self.kind == "seq" and self._graphable() and getattr(self.model, "pipelined_prep", False)
         if pipelined:
             batches = _lookahead(batches)
@@ -112,7 +116,15 @@ class Coach:
                 loss = self.model.train_step_graph(data["ISeq"], data["IPos"], data["INeg"],
                                                    next_batch=None if nxt is None else (nxt["ISeq"], nxt["IPos"], nxt["INeg"]))
                 bsz = len(data["User"])
-                tot.add_(loss, alpha=bsz)
+                if not own_sum:
+                    tot.add_(loss, alpha=bsz)
+                n += bsz
+                continue
+            if self.kind == "seq" and "Sample" in data:       # a fused device sampler's ticket: the step's preparation launch samples the batch
+                loss = self.model.train_step_graph_sampled(data["Sample"])
+                bsz = len(data["Sample"])
+                if not own_sum:
+                    tot.add_(loss, alpha=bsz)
                 n += bsz
                 continue
             if self.kind == "module":
@@ -137,8 +149,11 @@ class Coach:
             else:
                 loss = self.model.train_step(data["User"], data["IPos"], data["INeg"])
             bsz = len(data["User"])
-            tot.add_(loss, alpha=bsz)                # (one launch)
+            if not (own_sum and self.kind == "seq" and self._graphable()):
+                tot.add_(loss, alpha=bsz)            # (one launch)
             n += bsz
+        if own_sum:
+            tot = self.model.end_loss_accumulation().reshape(())
         if hasattr(self.model, "check_handover"):
             self.model.check_handover()     # (split long sequences: the halves' hand-over flags; the loss read below syncs anyway)
         if hasattr(self.model, "settle_overflow"):

@@ -11,6 +11,7 @@
 
 #include "enc_common.h"
 #include "enc_tile_prep.h"
+#include "re_rng.h"
 
 #define PL_NT 1024
 #define PL_NW (PL_NT / 64)
@@ -40,6 +41,38 @@ size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 
+// optional SOURCE of the batch: instead of reading (seq, pos, neg) the launch SAMPLES them -- the SASRec training chain of csrc/sampler.hip
+// (re_seq_train_sample: same rows, same draws), so a sampled training step is one preparation launch, not a sampler launch + a
+// preparation launch.  ptr == nullptr: the batch is read.
+#define PL_STREAM_NEG 0x5EEDu
+#define PL_MAX_TRIES 32
+struct PlSample {
+    const int64_t *ptr, *items, *sorted_items, *order;
+    int64_t n_order, b0, N;
+    uint32_t seed, step;
+    int64_t* users;
+};
+// row b of the sampled batch: (first item of the window in `items`, number of input positions, the user's CSR start and length)
+__device__ __forceinline__ void pl_sample_row(const PlSample& SP, int b, int S, int64_t& base, int& len, int64_t& p0, int64_t& n, int64_t& u) {
+    u = -1; base = 0; len = 0; p0 = 0; n = 0;
+    if (SP.b0 + b < SP.n_order) {
+        u = SP.order[SP.b0 + b];
+        p0 = SP.ptr[u];
+        n = SP.ptr[u + 1] - p0;
+        len = (int)(n - 1 < S ? n - 1 : S);
+        if (len < 0) len = 0;
+        base = p0 + n - 1 - len;
+    }
+}
+
+// optional: fold the PREVIOUS step's loss into an epoch accumulator (acc[0] += prev[0] * w) -- the epoch loop's "loss.item() per step" of the
+// reference (SASRec/main.py:252-256) as one more word of work in a launch that runs anyway, instead of a launch of its own per step
+struct PlLoss {
+    const float* prev;
+    float* acc;
+    float w;
+};
+
 struct PlWeights {   // optional extra work of the launch: the one-tile-per-workgroup step's weight fragments (enc_tile_prep.h); nblocks = 0: none
     SasrecParams P;
     int L, nblocks;
@@ -53,7 +86,7 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                                                              int64_t* __restrict__ neg_out, uint8_t* __restrict__ valid,
                                                              int* __restrict__ count, int64_t* __restrict__ rows_all, int* __restrict__ plan,
                                                              uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2,
-                                                             PlWeights WP) {
+                                                             PlWeights WP, PlSample SP, PlLoss LA) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.x >= gridDim.x - WP.nblocks) {
         // ---- the tile kernel's weight fragments for this step (re_sasrec_batch_prep_w): the last workgroups of the grid
@@ -65,12 +98,39 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
         // ---- element-wise part: copies, valid mask, scatter destination rows
         const int64_t n = (int64_t)B * S;
         for (int64_t i = (int64_t)(blockIdx.x - 1) * PL_NT + tid; i < n; i += (int64_t)(gridDim.x - 1 - WP.nblocks) * PL_NT) {
-            const int64_t s = seq[i];
+            int64_t s, sp = 0, sq = 0;
+            if (SP.ptr) {   // sample position i = (row b, position k) exactly as seq_train_sample_k does
+                const int b = (int)(i / S), kpos = (int)(i - (int64_t)b * S);
+                int64_t base, p0, nn, u;
+                int len;
+                pl_sample_row(SP, b, S, base, len, p0, nn, u);
+                s = 0;
+                const int k = kpos - (S - len);
+                if (len > 0 && k >= 0) {
+                    s = SP.items[base + k] + 1;
+                    sp = SP.items[base + k + 1];
+                    const int64_t* sl = SP.sorted_items + p0;
+                    const uint32_t ctr = (uint32_t)i * PL_MAX_TRIES;
+                    for (int t = 0; t < PL_MAX_TRIES; ++t) {
+                        const uint32_t r = re_rng_u32(SP.seed ^ (SP.step * 0x9E3779B1u), PL_STREAM_NEG, ctr + t);
+                        sq = (int64_t)(((uint64_t)r * (uint64_t)SP.N) >> 32);
+                        int64_t lo = 0, hi = nn;
+                        while (lo < hi) {
+                            const int64_t mid = (lo + hi) >> 1;
+                            if (sl[mid] < sq) lo = mid + 1; else hi = mid;
+                        }
+                        if (lo >= nn || sl[lo] != sq) break;
+                    }
+                }
+                if (kpos == 0 && SP.users) SP.users[b] = u;
+            } else {
+                s = seq[i];
+            }
             const bool v = s != 0;
             if (seq_out) seq_out[i] = s;
             if (valid) valid[i] = v ? 1 : 0;
-            if (pos) {
-                const int64_t p = pos[i], q = neg[i];
+            if (pos || SP.ptr) {
+                const int64_t p = SP.ptr ? sp : pos[i], q = SP.ptr ? sq : neg[i];
                 if (pos_out) { pos_out[i] = p; neg_out[i] = q; }
                 if (rows_all) {
                     rows_all[i] = s;
@@ -101,6 +161,7 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
     const bool in_lds = B <= PL_LDS_B;
     int* g_span = plan + enc_plan_rowmap_word(B, S) + 2 * 16 * mt;
     int* g_place = g_span + B;
+    if (tid == 0 && LA.acc) LA.acc[0] += LA.prev[0] * LA.w;
     if (tid == 0 && state) {
         state[0] = seed;
         state[1] = 0u;
@@ -112,6 +173,18 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
     //    instructions per sequence -- an element-wise formulation is VALU-bound on this one CU), 16 sequences in flight per wave;
     //    a sequence without any item is given one explicit pad row
     int nnz = 0;
+    if (SP.ptr) {   // sampled batch: a row's span is its window length (every position of the window is a real item) -- no (seq) to read
+        for (int b = tid; b < B; b += PL_NT) {
+            int64_t base, p0, nn, u;
+            int len;
+            pl_sample_row(SP, b, S, base, len, p0, nn, u);
+            const int span = len > 0 ? len : 1;                       // (a row without items: one explicit pad row, as below)
+            if (in_lds) s_span[b] = (unsigned char)span; else g_span[b] = span;
+            nnz += len;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
+    } else
     for (int b0 = wave * 16; b0 < B; b0 += PL_NW * 16) {
         int64_t v[16];
 #pragma unroll
@@ -266,9 +339,10 @@ extern "C" size_t re_sasrec_plan_bytes(int64_t B, int64_t S) {
 static int batch_prep_launch(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
                              int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
                              int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
-                             int64_t step, double lr, double beta1, double beta2, const PlWeights& WP, re_stream_t stream) {
+                             int64_t step, double lr, double beta1, double beta2, const PlWeights& WP, const PlSample& SP, const PlLoss& LA,
+                             re_stream_t stream) {
     re_clear_error();
-    if (!seq || !plan || B <= 0 || S <= 0) return RE_EINVAL;
+    if ((!seq && !SP.ptr) || !plan || B <= 0 || S <= 0) return RE_EINVAL;
     if ((pos == nullptr) != (neg == nullptr) || (pos_out == nullptr) != (neg_out == nullptr)) return RE_EINVAL;
     if (S > 64 || B * S > (int64_t)1 << 30 || max_tiles < 1 || max_tiles > 4) return RE_EUNSUPPORTED;
     if (plan_bytes < enc_plan_bytes(B, S)) return RE_EWORKSPACE;
@@ -282,7 +356,7 @@ static int batch_prep_launch(const int64_t* seq, const int64_t* pos, const int64
     const bool elementwise = seq_out || valid || rows_all || pos_out;
     const unsigned grid = 1 + (elementwise ? re_grid(B * S, PL_NT, 256) : 0) + (unsigned)WP.nblocks;
     hipLaunchKernelGGL(sasrec_batch_prep_k, dim3(grid), dim3(PL_NT), 0, (hipStream_t)stream, seq, pos, neg, (int)B, (int)S, (int)ncu,
-                       (int)max_tiles, (int)(split_long != 0), seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib, WP);
+                       (int)max_tiles, (int)(split_long != 0), seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib, WP, SP, LA);
     return re_launch_status();
 }
 
@@ -292,21 +366,20 @@ extern "C" int re_sasrec_batch_prep(const int64_t* seq, const int64_t* pos, cons
                                     int64_t step, double lr, double beta1, double beta2, re_stream_t stream) {
     PlWeights WP{};
     WP.nblocks = 0;
+    PlSample SP{};
+    PlLoss LA{};
     return batch_prep_launch(seq, pos, neg, B, S, ncu, max_tiles, split_long, seq_out, pos_out, neg_out, valid, count, rows_all, plan, plan_bytes, state,
-                             seed, step, lr, beta1, beta2, WP, stream);
+                             seed, step, lr, beta1, beta2, WP, SP, LA, stream);
 }
 
 // The same launch + the weight preparation of the D = 64 one-tile-per-workgroup step (re_sasrec_encoder_step_part, part + 8) in extra
 // workgroups: the encoder's matrices as bf16 hi / mid fragment planes into the backward workspace `ws`, the launch epoch in `tape`'s flag
 // area advanced -- the step that follows on the same stream then needs no preparation launch of its own.
-extern "C" int re_sasrec_batch_prep_w(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
-                                      int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
-                                      int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
-                                      int64_t step, double lr, double beta1, double beta2, const float* const* block_params, const float* last_w,
-                                      const float* last_b, int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
-                                      re_stream_t stream) {
+static int pl_fill_weights(PlWeights& WP, const float* const* block_params, const float* last_w, const float* last_b, int64_t L, int64_t D, int64_t B,
+                           int64_t S, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes) {
+    WP.nblocks = 0;
+    if (!block_params) return RE_OK;
     if (D != TL_D || !tape || !ws || B <= 0 || S <= 0 || S > 64) return RE_EUNSUPPORTED;
-    PlWeights WP{};
     if (!se_fill_params(WP.P, block_params, L, last_w, last_b)) return RE_EINVAL;
     if (tape_bytes < (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float) || ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L))
         return RE_EWORKSPACE;
@@ -318,6 +391,44 @@ extern "C" int re_sasrec_batch_prep_w(const int64_t* seq, const int64_t* pos, co
     WP.nblocks = (TL_PREP_THREADS((int)L) + PL_NT - 1) / PL_NT;
     WP.wf = enc_tile_wf(gtape, B, S, L);
     WP.epoch = enc_tile_epoch(tape, B, S, L);
+    return RE_OK;
+}
+
+extern "C" int re_sasrec_batch_prep_w(const int64_t* seq, const int64_t* pos, const int64_t* neg, int64_t B, int64_t S, int32_t ncu,
+                                      int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out, uint8_t* valid,
+                                      int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
+                                      int64_t step, double lr, double beta1, double beta2, const float* const* block_params, const float* last_w,
+                                      const float* last_b, int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                                      const float* prev_loss, float* loss_acc, float loss_weight, re_stream_t stream) {
+    PlWeights WP{};
+    const int rc = pl_fill_weights(WP, block_params, last_w, last_b, L, D, B, S, tape, tape_bytes, ws, ws_bytes);
+    if (rc != RE_OK) return rc;
+    if ((prev_loss == nullptr) != (loss_acc == nullptr)) return RE_EINVAL;
+    PlSample SP{};
+    PlLoss LA{prev_loss, loss_acc, loss_weight};
     return batch_prep_launch(seq, pos, neg, B, S, ncu, max_tiles, split_long, seq_out, pos_out, neg_out, valid, count, rows_all, plan, plan_bytes, state,
-                             seed, step, lr, beta1, beta2, WP, stream);
+                             seed, step, lr, beta1, beta2, WP, SP, LA, stream);
+}
+
+// SAMPLE + PREPARE as one launch: the batch is row b = user order[b0 + b] of the SASRec training chain (re_seq_train_sample: the same
+// rows and draws, sample_seed / sample_step as there) written straight into the static buffers a captured step reads (seq_out / pos_out /
+// neg_out must be given), with everything re_sasrec_batch_prep derives from it; block_params != NULL: + the tile step's weight fragments
+// (re_sasrec_batch_prep_w).  users (optional) receives the rows' user ids.
+extern "C" int re_seq_train_sample_prep(const int64_t* ptr, const int64_t* items, const int64_t* sorted_items, const int64_t* order, int64_t n_order,
+                                        int64_t b0, int64_t N, uint32_t sample_seed, uint32_t sample_step, int64_t* users, int64_t B, int64_t S,
+                                        int32_t ncu, int32_t max_tiles, int32_t split_long, int64_t* seq_out, int64_t* pos_out, int64_t* neg_out,
+                                        uint8_t* valid, int32_t* count, int64_t* rows_all, void* plan, size_t plan_bytes, uint32_t* state, uint32_t seed,
+                                        int64_t step, double lr, double beta1, double beta2, const float* const* block_params, const float* last_w,
+                                        const float* last_b, int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                                        const float* prev_loss, float* loss_acc, float loss_weight, re_stream_t stream) {
+    if (!ptr || !items || !sorted_items || !order || !seq_out || !pos_out || !neg_out || n_order < 0 || b0 < 0 || N < 1) return RE_EINVAL;
+    if (B <= 0 || S <= 0 || S > 64 || B * S > (int64_t)1 << 26) return RE_EUNSUPPORTED;            // (32-bit draw counter: position * 32)
+    PlSample SP{ptr, items, sorted_items, order, n_order, b0, N, sample_seed, sample_step, users};
+    PlWeights WP{};
+    const int rc = pl_fill_weights(WP, block_params, last_w, last_b, L, D, B, S, tape, tape_bytes, ws, ws_bytes);
+    if (rc != RE_OK) return rc;
+    if ((prev_loss == nullptr) != (loss_acc == nullptr)) return RE_EINVAL;
+    PlLoss LA{prev_loss, loss_acc, loss_weight};
+    return batch_prep_launch(nullptr, pos_out, neg_out, B, S, ncu, max_tiles, split_long, seq_out, pos_out, neg_out, valid, count, rows_all, plan,
+                             plan_bytes, state, seed, step, lr, beta1, beta2, WP, SP, LA, stream);
 }

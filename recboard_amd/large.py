@@ -256,13 +256,15 @@ class SASRecLargeTableEngine(SASRecEngine):
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split())
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(),
+                              loss_acc=self._take_pending_loss())
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:
             grad_hook(A.grad)
             self._table_adam(g["C"], g["rows"], g["pb"], step=A.step)
             ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
 
     def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):
@@ -532,12 +534,14 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             self._graphs[key] = self._capture(B, S)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split())
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(),
+                              loss_acc=self._take_pending_loss())
         sd = self._step_seed()
         g["graph"].replay()
         A.step += 1
         self._dropped = g["dropped"]
         self._track((seq, pos, neg), A.step, sd)
+        self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
 
     def encode(self, seq):

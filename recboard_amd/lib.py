@@ -48,7 +48,9 @@ SIGNATURES = {
     "re_sasrec_batch_prep": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32, _i64,
                                     _f64, _f64, _f64, _vp]),
     "re_sasrec_batch_prep_w": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u32, _i64,
-                                      _f64, _f64, _f64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp]),
+                                      _f64, _f64, _f64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp, _vp, _f32, _vp]),
+    "re_seq_train_sample_prep": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _u32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _sz, _vp, _u32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp, _vp, _f32, _vp]),
     "re_sasrec_tape_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "re_seq_train_sample": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "re_gen_train_sample": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _u32, _vp, _vp, _vp, _vp]),

@@ -430,7 +430,7 @@ def prep_views(blob, B, S, cached=False):
 
 
 def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4, split=False,
-                      ncu=None, weights=None):
+                      ncu=None, weights=None, loss_acc=None):
     """Batch preparation as ONE launch (re_sasrec_batch_prep): valid mask, count, scatter destination rows, the encoder's work plan;
     with `blob` (a static buffer of prep_layout(B, S) bytes) also copies (seq, pos, neg) into it and, with `state` (int32[4]),
     writes the step scalars -- the staging launch of a captured step.  -> PreparedBatch (views into the blob).
@@ -438,7 +438,8 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     ncu: the number of workgroups the plan's items should fill (default: the device's CUs, one workgroup per CU; the wave-per-tile
     step at D = 64 takes 1024 -- one tile per item while the batch allows it).
     weights = (block_tensors, last_w, last_b, L, tape, ws) (D = 64): the launch also prepares the one-tile-per-workgroup step's weight
-    fragments in `ws` (re_sasrec_batch_prep_w); the PreparedBatch then says `weights_ready` and sasrec_encoder_step skips its own."""
+    fragments in `ws` (re_sasrec_batch_prep_w); the PreparedBatch then says `weights_ready` and sasrec_encoder_step skips its own.
+    loss_acc = (prev_loss[1], acc[1], weight): acc += prev_loss * weight inside this launch (the previous step's loss into an epoch sum)."""
     _req(seq, torch.int64, "seq")
     B, S = seq.shape
     if pos is not None:
@@ -454,16 +455,49 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
             _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None, _p(pb.neg) if copy and have else None,
             _p(pb.valid) if have else None, _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
             _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2))
-    if weights is not None:
-        bt, lw, lb, L, tape, ws = weights
-        lib.check(lib.load().re_sasrec_batch_prep_w(*args, _ptr_table(bt), _p(lw), _p(lb), int(L), int(lw.numel()), _p(tape), tape.numel() * 4, _p(ws),
-                                                    ws.numel(), _stream()), "re_sasrec_batch_prep_w")
+    if weights is not None or loss_acc is not None:
+        lib.check(lib.load().re_sasrec_batch_prep_w(*args, *_weight_args(weights), *_loss_args(loss_acc), _stream()), "re_sasrec_batch_prep_w")
     else:
         lib.check(lib.load().re_sasrec_batch_prep(*args, _stream()), "re_sasrec_batch_prep")
     pb.weights_ready = weights is not None
     if not copy:
         pb.seq, pb.pos, pb.neg = seq, pos, neg
     pb.split = bool(split)
+    return pb
+
+
+def _weight_args(weights):
+    if weights is None:
+        return (None, None, None, 0, 0, None, 0, None, 0)
+    bt, lw, lb, L, tape, ws = weights
+    return (_ptr_table(bt), _p(lw), _p(lb), int(L), int(lw.numel()), _p(tape), tape.numel() * 4, _p(ws), ws.numel())
+
+
+def _loss_args(loss_acc):
+    if loss_acc is None:
+        return (None, None, 0.0)
+    prev, acc, w = loss_acc
+    _req(prev, torch.float32, "prev_loss"); _req(acc, torch.float32, "loss_acc")
+    return (_p(prev), _p(acc), float(w))
+
+
+def sasrec_sample_prep(inter, order, b0, B, S, sample_seed, sample_step, blob, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999,
+                       max_tiles=4, split=False, ncu=None, weights=None, users=None, loss_acc=None):
+    """SAMPLE + PREPARE as one launch (re_seq_train_sample_prep): rows b0 .. b0 + B of the epoch's user order `order`, sampled as
+    recboard_amd.sampler.seq_train_sample would, written straight into the staging `blob` with everything sasrec_batch_prep derives.
+    inter: recboard_amd.sampler.DeviceInteractions.  -> PreparedBatch (views into the blob)."""
+    pb = prep_views(_req(blob, torch.uint8, "blob"), B, S, cached=True)
+    if state is not None:
+        _req(state, torch.int32, "state")
+    wargs = _weight_args(weights) + _loss_args(loss_acc)
+    lib.check(lib.load().re_seq_train_sample_prep(_p(inter.ptr), _p(inter.items), _p(inter.sorted), _p(order), order.numel(), int(b0), inter.num_items,
+                                                  int(sample_seed) & 0xFFFFFFFF, int(sample_step) & 0xFFFFFFFF, _p(users), B, S,
+                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)), _p(pb.seq), _p(pb.pos),
+                                                  _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel(), _p(state),
+                                                  int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), *wargs, _stream()),
+              "re_seq_train_sample_prep")
+    pb.split = bool(split)
+    pb.weights_ready = weights is not None
     return pb
 
 

@@ -67,13 +67,23 @@ def gen_train_sample(inter, B, seed, step):
     return users, pos, neg
 
 
-class DeviceSeqSampler:
-    """An epoch = every user with >= 2 training items once, in a fresh device permutation; batches of {User, ISeq, IPos, INeg}."""
+class SampleTicket:
+    """What a fused sampler hands out instead of tensors: the batch is rows b0 .. b0 + B of `order`, to be sampled by the step's own
+    preparation launch (ops.sasrec_sample_prep) with (seed, step)."""
+    __slots__ = ("inter", "order", "b0", "B", "S", "seed", "step", "users")
 
-    def __init__(self, inter, maxlen, batch_size, seed=1, keys=("User", "ISeq", "IPos", "INeg")):
+    def __len__(self):
+        return self.B
+
+
+class DeviceSeqSampler:
+    """An epoch = every user with >= 2 training items once, in a fresh device permutation; batches of {User, ISeq, IPos, INeg}.
+    fused=True: batches of {"Sample": SampleTicket} -- the engine's preparation launch samples the rows itself (the same rows and draws)."""
+
+    def __init__(self, inter, maxlen, batch_size, seed=1, keys=("User", "ISeq", "IPos", "INeg"), fused=False):
         self.inter, self.S, self.B, self.seed, self.keys = inter, int(maxlen), int(batch_size), int(seed), keys
         self.gen = torch.Generator(device=inter.device).manual_seed(seed)
-        self.step = 0
+        self.step, self.fused = 0, bool(fused)
 
     def __len__(self):
         return (self.inter.users_ge2.numel() + self.B - 1) // self.B
@@ -84,6 +94,11 @@ class DeviceSeqSampler:
         for b0 in range(0, us.numel(), self.B):
             B = min(self.B, us.numel() - b0)
             self.step += 1
+            if self.fused:
+                t = SampleTicket()
+                t.inter, t.order, t.b0, t.B, t.S, t.seed, t.step, t.users = self.inter, order, b0, B, self.S, self.seed, self.step, None
+                yield {"Sample": t}
+                continue
             users, seq, pos, neg = seq_train_sample(self.inter, order, b0, B, self.S, self.seed, self.step)
             yield dict(zip(self.keys, (users, seq, pos, neg)))
 
@@ -103,9 +118,10 @@ class DeviceGenSampler:
             yield dict(zip(self.keys, gen_train_sample(self.inter, self.B, self.seed, self.step)))
 
 
-def device_pipe(pipe):
+def device_pipe(pipe, fused=False):
     """A recorded freerec pipe (freerec/data/postprocessing.py) -> a device sampler yielding the same {Field: tensor} batches, when the
-    chain is one the engine samples on the device; None otherwise (the pipe then runs its vectorised host path)."""
+    chain is one the engine samples on the device; None otherwise (the pipe then runs its vectorised host path).
+    fused (SASRec chain only): {"Sample": ticket} batches for SASRecEngine.train_step_graph_sampled."""
     from freerec.data import tags as T
     from freerec.data.postprocessing import _item_roles
     ds = pipe.ds
@@ -125,11 +141,11 @@ def device_pipe(pipe):
         smp = getattr(pipe, "_device_sampler", None)
         if smp is None:
             smp = pipe._device_sampler = DeviceSeqSampler(inter, d["maxlen"], pipe.batch_size, seed=int(pipe.rng.integers(1 << 31)),
-                                                          keys=(R["User"], R["ISeq"], R["IPos"], R["INeg"]))
+                                                          keys=(R["User"], R["ISeq"], R["IPos"], R["INeg"]), fused=fused)
 
         def batches():
             for bt in smp:
-                bt[R["Size"]] = int(bt[R["User"]].numel())
+                bt[R["Size"]] = len(bt["Sample"]) if "Sample" in bt else int(bt[R["User"]].numel())
                 yield bt
         return batches()
     if pipe.source == "choiced_user_ids" and names == ["gen_pos", "gen_neg"] and pipe.ops[1][1]["k"] == 1:

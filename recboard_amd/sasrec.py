@@ -513,7 +513,36 @@ class SASRecEngine:
         sd = (self.seed * 0x9E3779B1 + step * 0x85EBCA77) & 0xFFFFFFFF          # (= _step_seed() once arena.step == step - 1)
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=sd, step=step, lr=self.lr,
                               beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(),
-                              weights=self._prep_weights(B, S) if g["in_prep"] else None)
+                              weights=self._prep_weights(B, S) if g["in_prep"] else None, loss_acc=self._take_pending_loss())
+
+    # ---- the epoch's loss sum without a launch per step: between begin_ and end_loss_accumulation every captured step's loss is added
+    #      (times its batch size) into one device word by the NEXT step's batch-preparation launch; the last one by end_.
+    def begin_loss_accumulation(self):
+        self._loss_acc = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._loss_pending = None
+        return self._loss_acc
+
+    def _take_pending_loss(self):
+        acc = getattr(self, "_loss_acc", None)
+        pend = getattr(self, "_loss_pending", None)
+        if acc is None or pend is None:
+            return None
+        self._loss_pending = None
+        return (pend[0], acc, pend[1])
+
+    def _note_loss(self, loss, weight):
+        if getattr(self, "_loss_acc", None) is not None:
+            if self._loss_pending is not None:           # (a step whose preparation launch could not carry it: the pipelined form)
+                self._loss_acc.add_(self._loss_pending[0], alpha=self._loss_pending[1])
+            self._loss_pending = (loss, float(weight))
+
+    def end_loss_accumulation(self):
+        """-> the device word holding sum(loss_i * batch size_i) since begin_loss_accumulation."""
+        acc, self._loss_acc = self._loss_acc, None
+        if self._loss_pending is not None:
+            acc.add_(self._loss_pending[0], alpha=self._loss_pending[1])
+        self._loss_pending = None
+        return acc
 
     def train_step_graph(self, seq, pos, neg, grad_hook=None, next_batch=None, next_ready=None):
         """`train_step_fused` on a RAW batch, replayed from a captured hipGraph: one batch-preparation launch (which also stages the
@@ -570,6 +599,27 @@ class SASRecEngine:
         if grad_hook is not None:
             grad_hook(A.grad)
             ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        self._note_loss(g["loss"], B)
+        return g["loss"].squeeze(0)
+
+    def train_step_graph_sampled(self, ticket):
+        """The captured step on a batch the preparation launch SAMPLES itself (recboard_amd.sampler.DeviceSeqSampler(fused=True) hands out
+        tickets instead of tensors): one sample + prepare launch, one graph replay -- no sampler launch, no batch tensors."""
+        A = self.arena
+        B, S = ticket.B, ticket.S
+        key = (B, S, True, self.training)
+        if not hasattr(self, "_graphs"):
+            self._graphs, self._staged, self._pipe_i = {}, None, 0
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(B, S, with_adam=True)
+        g = self._graphs[key]
+        ops.sasrec_sample_prep(ticket.inter, ticket.order, ticket.b0, B, S, ticket.seed, ticket.step, g["blob"], state=g["state"],
+                               seed=self._step_seed(), step=A.step + 1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                               max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(),
+                               weights=self._prep_weights(B, S) if g["in_prep"] else None, users=ticket.users, loss_acc=self._take_pending_loss())
+        g["graph"].replay()
+        A.step += 1
+        self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
 
     # ---- CoachForSASRec.train_per_epoch body (SASRec/main.py:243-250): zero_grad, backward, Adam step

@@ -59,3 +59,27 @@ def test_mfbpr_coach_runs():
     losses = [h["train"]["LOSS"] for h in out["history"]]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     assert 0.0 <= out["history"][-1]["valid"]["NDCG@10"] <= 1.0
+
+
+def test_coach_epoch_loss_is_the_weighted_mean_of_the_step_losses():
+    """The fused SASRec step sums the epoch's losses itself (every step's loss is folded into one device word by the NEXT step's
+    batch-preparation launch, the last one at the end): the Coach's LOSS equals the batch-size-weighted mean of the per-step losses."""
+    from recboard_amd.coach import Coach
+    from recboard_amd.sasrec import SASRecEngine
+    N, S = 300, 50
+    rng = np.random.default_rng(2)
+    pipe = []
+    for B in (40, 40, 40, 17):                                      # (the short last batch replays another captured graph)
+        seq = np.zeros((B, S), np.int64)
+        for b in range(B):
+            n = int(rng.integers(1, S))
+            seq[b, S - n:] = rng.integers(1, N + 1, n)
+        pipe.append({"User": torch.arange(B), "ISeq": torch.from_numpy(seq), "IPos": torch.from_numpy(np.where(seq > 0, rng.integers(0, N, (B, S)), 0)),
+                     "INeg": torch.from_numpy(np.where(seq > 0, rng.integers(0, N, (B, S)), 0))})
+    a = SASRecEngine(N, S, 64, 2, dropout_rate=0.0, lr=1e-3, seed=3)
+    b = SASRecEngine(N, S, 64, 2, dropout_rate=0.0, lr=1e-3, seed=3)
+    got = Coach(a, pipe, monitors=["LOSS"], kind="seq").train_per_epoch(0)["LOSS"]
+    tot = 0.0
+    for d in pipe:
+        tot += float(b.train_step_graph(*(d[k].cuda() for k in ("ISeq", "IPos", "INeg")))) * len(d["User"])
+    assert abs(got - tot / 137) <= 2e-6 * abs(got), (got, tot / 137)

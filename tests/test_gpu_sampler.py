@@ -120,3 +120,43 @@ def test_sampler_to_step_epoch_rate_is_at_least_0p9_of_resident_batches():
         fn()
         best[name] = min(best.get(name, 1e9), time.perf_counter() - t0)
     assert best["resident"] >= 0.9 * best["sampled"], best
+
+
+def test_sample_and_prepare_in_one_launch_equals_sampler_then_prepare():
+    """re_seq_train_sample_prep: the staging blob it leaves (batch, valid mask, count, destination rows, plan) is bit for bit what
+    re_seq_train_sample followed by re_sasrec_batch_prep leave; a training epoch through tickets equals the epoch through tensors."""
+    from recboard_amd import ops
+    from recboard_amd.coach import Coach
+    from recboard_amd.sampler import DeviceInteractions, DeviceSeqSampler, seq_train_sample
+    from recboard_amd.sasrec import SASRecEngine
+    rng = np.random.default_rng(21)
+    U, N, S, B = 700, 400, 50, 96
+    lens = np.concatenate([rng.integers(2, 12, U - 40), rng.integers(30, 120, 40)])
+    ptr = np.zeros(U + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    items = np.concatenate([rng.choice(N, l, replace=False) if l <= N else rng.integers(0, N, l) for l in lens])
+    inter = DeviceInteractions(ptr, items, N)
+    order = inter.users_ge2[torch.randperm(inter.users_ge2.numel(), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))]
+    for b0, Bq in ((0, B), (U - 28, 28)):                                       # a full batch and the epoch's short last one
+        users, seq, pos, neg = seq_train_sample(inter, order, b0, Bq, S, 7, 3)
+        ref = ops.sasrec_batch_prep(seq, pos, neg, blob=torch.zeros(ops.prep_layout(Bq, S)[1], dtype=torch.uint8, device="cuda"))
+        blob = torch.zeros_like(ref.blob)
+        u2 = torch.empty(Bq, dtype=torch.int64, device="cuda")
+        got = ops.sasrec_sample_prep(inter, order, b0, Bq, S, 7, 3, blob, users=u2)
+        torch.cuda.synchronize()
+        assert torch.equal(u2, users)
+        for name in ("seq", "pos", "neg", "rows_all", "valid", "count"):
+            assert torch.equal(getattr(got, name), getattr(ref, name)), name
+        nw = 8 + 2 * int(got.plan.view(torch.int32)[0])                         # header + item words; the row map is compared below
+        assert torch.equal(got.plan.view(torch.int32)[:8], ref.plan.view(torch.int32)[:8])
+        assert torch.equal(got.plan, ref.plan), nw
+    # an epoch either way: the same losses and parameters (tickets carry the same (order, seed, step) the tensor batches were made from)
+    res = []
+    for fused in (False, True):
+        m = SASRecEngine(N, S, 64, 2, dropout_rate=0.2, lr=1e-3, seed=5)
+        smp = DeviceSeqSampler(inter, S, B, seed=9, fused=fused)
+        coach = Coach(m, smp, monitors=["LOSS"], kind="seq")
+        res.append((coach.train_per_epoch(0)["LOSS"], coach.train_per_epoch(1)["LOSS"], m.arena.data.clone()))
+        m.check_handover()
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[0][1])
+    torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-5, atol=1e-7)
