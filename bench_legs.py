@@ -157,6 +157,10 @@ def leg_config3():
                                    "loss = rec + 1e-3 emb, Adam without weight decay (LightGCN/main.py:139-160)"},
             "roofline": {"kernel": "spmm_csr_rows / spmm_csr_long (re_spmm_csr): one propagation X <- A X", "bound": "hbm", "achieved": round(gbs, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(t_sp, 4),
+                         "gathered_rows": {"achieved": round((alg + nnz * 4 * D) / (t_sp * 1e-3) / 1e9, 1), "peak": 8600.0, "unit": "GB/s",
+                                           "frac": round((alg + nnz * 4 * D) / (t_sp * 1e-3) / 1e9 / 8600.0, 4),
+                                           "note": "what bounds the launch: every non-zero gathers a 256-B X row from the 31.5 MB X, which lives in the "
+                                                   "Infinity Cache -- MI355X_MICROARCH.md measures 8.6 TB/s for uniformly random rows of a 38 MB table"},
                          "work": f"algorithmic {alg / 1e6:.1f} MB per launch: {nnz} non-zeros x 12 B + {rows} rows x (8 + {4 * D} written + {4 * D} read once); "
                                  f"with every gathered X row counted ({nnz} x {4 * D} B, served by L2 / Infinity Cache): {(alg + nnz * 4 * D) / (t_sp * 1e-3) / 1e9:.0f} GB/s; "
                                  f"{2 * D * nnz / (t_sp * 1e-3) / 1e9:.0f} GFLOP/s"},

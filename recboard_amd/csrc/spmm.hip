@@ -23,12 +23,48 @@ __device__ __forceinline__ void f4_axpy(float4& a, float s, const float4& x) {
     a.x = fmaf(s, x.x, a.x); a.y = fmaf(s, x.y, a.y); a.z = fmaf(s, x.z, a.z); a.w = fmaf(s, x.w, a.w);
 }
 
+#ifndef SP_ILP
+#define SP_ILP 8
+#endif
+// a row's (or a strided share of a row's) non-zeros SP_ILP at a time; the NEXT group's (col, val) are requested before this group's X rows, so
+// an iteration costs one memory round trip (the X rows), not two (indices, then rows)
 template <int LPR>
 __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col, const float* __restrict__ val,
                                                   const float* __restrict__ X, int64_t ncols, int64_t D, int64_t c4,
                                                   int64_t p0, int64_t p1, int64_t step) {
+    constexpr int U = SP_ILP;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t p = p0;
+    if (p + (U - 1) * step < p1) {
+        int64_t cc[U];
+        float vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { cc[u] = col[p + u * step]; vv[u] = val[p + u * step]; }
+        for (;;) {
+            const int64_t pn = p + U * step;
+            const bool more = pn + (U - 1) * step < p1;
+            int64_t nc[U];
+            float nv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {   // (clamped, unconditional: in flight beside the X rows below.  Padding the last group with
+                const int64_t q = more ? pn + u * step : p;   //  weight-0 slots instead of the tail loops was measured slower: 136 / 156 vs 126 us)
+                nc[u] = col[q]; nv[u] = val[q];
+            }
+            float4 xr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cc[u] >= 0 && cc[u] < ncols) xr[u] = reinterpret_cast<const float4*>(X + cc[u] * D)[c4];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) f4_axpy(acc, vv[u], xr[u]);
+            p = pn;
+            if (!more) break;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cc[u] = nc[u]; vv[u] = nv[u]; }
+        }
+    }
+    // the tail: up to U - 1 non-zeros, four at a time, then one by one
     for (; p + 3 * step < p1; p += 4 * step) {
         int64_t cc[4];
         float vv[4];
