@@ -82,7 +82,8 @@ def leg_config1():
     dev = [tuple(torch.from_numpy(a).cuda() for a in b) for b in bs]
     m = MFEngine(U, N, D, lr=1e-3, weight_decay=1e-6)
     it = iter(range(10 ** 9))
-    ms = wall_ms(lambda: m.train_step(*dev[next(it) % 16]), iters=200, warmup=20)
+    ms_eager = wall_ms(lambda: m.train_step(*dev[next(it) % 16]), iters=100, warmup=20)
+    ms = wall_ms(lambda: m.train_step_graph(*dev[next(it) % 16]), iters=300, warmup=20)
     # CPU oracle: dense tables, autograd, dense Adam with coupled L2 (what the reference's torch path executes)
     g = torch.Generator().manual_seed(1)
     Ut = (torch.randn(U, D, generator=g) * 1e-4).requires_grad_(True)
@@ -98,7 +99,9 @@ def leg_config1():
         opt.step()
     return {"metric": "train triplets/sec (MF-BPR d=64, Beauty shapes, B=2048, 1 GPU)", "value": round(B / (ms * 1e-3), 1), "unit": "triplets/s",
             "ms_per_step": round(ms, 4), "config": {"workload": f"MF-BPR d=64, {U} users x {N} items, B={B}, Adam(lr 1e-3, wd 1e-6); users uniform, positives Zipf(1.0)"},
-            "launch": "eager: fused triplet forward + backward, two scatter-adds, one Adam launch over the table arena",
+            "ms_per_step_eager": round(ms_eager, 4),
+            "launch": "one hipGraph replay per step (three copies into the static batch + one launch for the step's scalars in front of it): fused "
+                      "triplet forward + backward, two scatter-adds, one Adam launch over the table arena",
             "cpu_baseline": cpu_steps(cpu_step, B, "triplets/s", f"B={B} (oracle/mf.py fit + backward + torch.optim.Adam)")}
 
 
@@ -130,7 +133,8 @@ def leg_config3():
     bs = [(rng.integers(0, U, (B, 1)), rng.choice(N, (B, 1), p=wi), rng.integers(0, N, (B, 1))) for _ in range(8)]
     dev = [tuple(torch.from_numpy(a).cuda() for a in b) for b in bs]
     it = iter(range(10 ** 9))
-    ms = wall_ms(lambda: lg.train_step(*dev[next(it) % 8]), iters=30, warmup=5)
+    ms_eager = wall_ms(lambda: lg.train_step(*dev[next(it) % 8]), iters=20, warmup=5)
+    ms = wall_ms(lambda: lg.train_step_graph(*dev[next(it) % 8]), iters=50, warmup=5)
     t_sp = ev_ms(lambda: lg._spmm(lg.X0, lg.Xa))
     rows = U + N
     # per non-zero 4 (val) + 8 (col) B streamed from HBM + one 4 D-byte X row (cache-resident: 31.5 MB < 256 MB Infinity
@@ -152,7 +156,7 @@ def leg_config3():
         (rec + 1e-3 * emb).backward()
         opt.step()
     return {"metric": "train triplets/sec (LightGCN d=64 L=3, Yelp2018 shapes, B=2048, 1 GPU)", "value": round(B / (ms * 1e-3), 1), "unit": "triplets/s",
-            "ms_per_step": round(ms, 4),
+            "ms_per_step": round(ms, 4), "ms_per_step_eager": round(ms_eager, 4), "launch": "one hipGraph replay per step",
             "config": {"workload": f"LightGCN d=64, 3 layers, {U} users x {N} items, {len(eu)} edges (adjacency nnz {nnz}), B={B}: 3 + 3 SpMMs per step, "
                                    "loss = rec + 1e-3 emb, Adam without weight decay (LightGCN/main.py:139-160)"},
             "roofline": {"kernel": "spmm_csr_rows / spmm_csr_long (re_spmm_csr): one propagation X <- A X", "bound": "hbm", "achieved": round(gbs, 1),
@@ -181,7 +185,8 @@ def leg_config4():
     bs = [(np.stack([rng.integers(0, c, B) for c in counts], 1), (rng.random((B, 1)) < 0.3).astype(np.int64)) for _ in range(8)]
     dev = [(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()) for x, y in bs]
     it = iter(range(10 ** 9))
-    ms = wall_ms(lambda: d.train_step(*dev[next(it) % 8]), iters=50, warmup=10)
+    ms_eager = wall_ms(lambda: d.train_step(*dev[next(it) % 8]), iters=30, warmup=10)
+    ms = wall_ms(lambda: d.train_step_graph(*dev[next(it) % 8]), iters=100, warmup=10)
     x0 = dev[0][0]
     t_bag = ev_ms(lambda: ops.fm_bag_fwd(d.T, d.TL.reshape(-1), d.bias, d.offsets, x0), iters=100)
     F = len(counts)
@@ -211,7 +216,7 @@ def leg_config4():
         torch.nn.utils.clip_grad_norm_(emb + other, 10.0)
         opt.step()
     return {"metric": "train rows/sec (DeepFM, synthetic Amazon2023Games context schema, B=4096, 1 GPU)", "value": round(B / (ms * 1e-3), 1), "unit": "rows/s",
-            "ms_per_step": round(ms, 4),
+            "ms_per_step": round(ms, 4), "ms_per_step_eager": round(ms_eager, 4), "launch": "one hipGraph replay per step",
             "config": {"workload": f"DeepFM: {F} embedding fields (cardinalities {counts}), D={D}, MLP {dims}->1 with BatchNorm + dropout 0.1, B={B}, "
                                    "BCE, clip 10, Adam with the reference's two weight-decay groups (DeepFM/main.py:187-199,264-268)"},
             "roofline": {"kernel": "fm_bag_fwd_k (re_fm_bag_fwd): every field's row + FM second-order term + LR term per input row", "bound": "hbm",

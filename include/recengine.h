@@ -442,6 +442,10 @@ size_t re_auc_workspace_bytes(void);
 int re_auc(const float* scores, const float* labels, int64_t n, float* auc, void* ws, size_t ws_bytes, re_stream_t stream);
 /* hipGraph-friendly variant of re_adam_step: hyper (DEVICE float[2]) = { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) };
  * n must be a multiple of 4. */
+/* The per-step device words of a captured step, written by one tiny launch (kernel arguments: no host buffer to keep alive):
+ * state[0] = seed, state[1] = 0, state[2..3] = bits of { lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step) } -- the layout
+ * re_sasrec_batch_prep writes; state doubles as `seed_dev` of the dropout entry points and, from word 2, as `hyper` of re_adam_step_dev. */
+int re_step_state(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, re_stream_t stream);
 int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1,
                      double beta2, double eps, double weight_decay, re_stream_t stream);
 int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
@@ -487,6 +491,7 @@ int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
  * re_colsum: out[n] = sum_m x[m, n] (bias gradients).  All column reductions are fixed-order (deterministic). */
 int re_bn_relu_drop_fwd(const float* z, int64_t M, int64_t N, const float* gamma, const float* beta, float* run_mean,
                         float* run_var, int training, float eps, float momentum, float drop_p, uint32_t seed,
+                        const uint32_t* seed_dev /* non-NULL: the seed is read from this device word (captured steps) */,
                         uint32_t stream_id, float* stats, float* a, void* ws, size_t ws_bytes, re_stream_t stream);
 int re_bn_relu_drop_bwd(const float* da, const float* a, const float* z, int64_t M, int64_t N, const float* gamma,
                         const float* stats, float drop_p, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,

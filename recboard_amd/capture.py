@@ -1,0 +1,50 @@
+"""One hipGraph replay per training step for the engines whose step is a fixed chain of launches (MF-BPR, LightGCN, DeepFM): the
+reference's loop body (`MF-BPR/main.py:116-123`, `LightGCN/main.py:156-164`, `DeepFM/main.py:258-268`) is ~10-40 short launches, and
+issued one by one the CPU launch path, not the GPU, sets the step time.  A captured step reads its batch from static buffers and its
+per-step scalars (dropout seed, Adam's step size and bias correction) from four device words written by one tiny launch (re_step_state);
+everything else is the eager step's launches, recorded once."""
+import torch
+
+from . import ops
+
+
+class CapturedStep:
+    def __init__(self, body, example_inputs, restore):
+        """body(*static_inputs, state) -> loss tensor: the step's launches, reading `state` (int32[4]: seed, 0, Adam scalars) where the
+        eager step takes host scalars.  restore: tensors the warm-up run must leave as it found them (parameters, moments, running
+        statistics)."""
+        dev = example_inputs[0].device
+        self.static = [torch.empty_like(x) for x in example_inputs]
+        for s, x in zip(self.static, example_inputs):
+            s.copy_(x)
+        self.state = torch.zeros(4, dtype=torch.int32, device=dev)
+        ops.step_state(self.state, 0, 1, 1e-3)
+        keep = [t.clone() for t in restore]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up: workspace allocations, lazy module loads
+            body(*self.static, self.state)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.out = body(*self.static, self.state)
+        for t, k in zip(restore, keep):
+            t.copy_(k)
+
+    def __call__(self, inputs, seed, step, lr, beta1, beta2):
+        for s, x in zip(self.static, inputs):
+            s.copy_(x, non_blocking=True)
+        ops.step_state(self.state, seed, step, lr, beta1, beta2)
+        self.graph.replay()
+        return self.out
+
+
+def captured(engine, key, body, inputs, restore):
+    """The engine's captured step for this input signature (captured on first use)."""
+    if not hasattr(engine, "_captured"):
+        engine._captured = {}
+    k = (key,) + tuple((tuple(x.shape), x.dtype) for x in inputs)
+    if k not in engine._captured:
+        engine._captured[k] = CapturedStep(body, inputs, restore)
+    return engine._captured[k]

@@ -59,6 +59,18 @@ __global__ __launch_bounds__(256) void adam_vec4_dev(float4* __restrict__ p, con
     }
 }
 
+__global__ void step_state_k(uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2) {
+    state[0] = seed; state[1] = 0u; state[2] = __float_as_uint(step_size); state[3] = __float_as_uint(inv_sqrt_bc2);
+}
+
+extern "C" int re_step_state(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, re_stream_t stream) {
+    re_clear_error();
+    if (!state || step < 1) return RE_EINVAL;
+    hipLaunchKernelGGL(step_state_k, dim3(1), dim3(1), 0, (hipStream_t)stream, state, seed, (float)(lr / (1.0 - pow(beta1, (double)step))),
+                       (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step))));
+    return re_launch_status();
+}
+
 extern "C" int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1, double beta2,
                                 double eps, double weight_decay, re_stream_t stream) {
     re_clear_error();

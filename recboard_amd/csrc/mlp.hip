@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void bn_stats_eval_k(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_relu_drop_fwd_k(const float* __restrict__ z, int64_t total, int64_t N,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float drop_scale, uint32_t thresh,
-                                                          uint32_t seed, uint32_t stream_id, float* __restrict__ a) {
+                                                          uint32_t seed, uint32_t stream_id, float* __restrict__ a,
+                                                          const uint32_t* __restrict__ seed_dev) {
+    if (seed_dev) seed = seed_dev[0];   // (captured steps: the step's seed is a device word)
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t n = e % N;
         float v = z[e];
@@ -163,7 +165,8 @@ extern "C" size_t re_mlp_workspace_bytes(int64_t N) { return (size_t)ML_CHUNKS *
 
 extern "C" int re_bn_relu_drop_fwd(const float* z, int64_t M, int64_t N, const float* gamma, const float* beta, float* run_mean,
                                    float* run_var, int training, float eps, float momentum, float drop_p, uint32_t seed,
-                                   uint32_t stream_id, float* stats, float* a, void* ws, size_t ws_bytes, re_stream_t stream) {
+                                   const uint32_t* seed_dev, uint32_t stream_id, float* stats, float* a, void* ws, size_t ws_bytes,
+                                   re_stream_t stream) {
     re_clear_error();
     if (!z || !a || M <= 0 || N <= 0) return RE_EINVAL;
     if (gamma && training && (!ws || ws_bytes < re_mlp_workspace_bytes(N))) return RE_EWORKSPACE;
@@ -182,7 +185,7 @@ extern "C" int re_bn_relu_drop_fwd(const float* z, int64_t M, int64_t N, const f
     const uint32_t thresh = (training && drop_p > 0.f) ? re_drop_threshold(drop_p) : 0u;
     const float ds = thresh ? 1.0f / (1.0f - drop_p) : 1.0f;
     hipLaunchKernelGGL(bn_relu_drop_fwd_k, dim3(re_grid(M * N, 1024)), dim3(256), 0, s, z, M * N, N, bn ? (const float*)stats : nullptr, gamma, beta, ds,
-                       thresh, seed, stream_id, a);
+                       thresh, seed, stream_id, a, seed_dev);
     return re_launch_status();
 }
 

@@ -137,8 +137,8 @@ class DeepFMEngine:
         return (self.seed * 0x9E3779B1 + (self.step + 1) * 0x85EBCA77) & 0xFFFFFFFF
 
     # ---- forward: keeps what the backward needs in `tape`
-    def encode(self, x):
-        """-> (logits [B], tape).  DeepFM/main.py:201-209."""
+    def encode(self, x, seed_dev=None):
+        """-> (logits [B], tape).  DeepFM/main.py:201-209.  seed_dev: the dropout seed as a device word (captured steps)."""
         P = self.P
         E, fm_lr = ops.fm_bag_fwd(self.T, self.TL.reshape(-1), self.bias, self.offsets, x)
         tape = {"E": E, "layers": []}
@@ -147,7 +147,7 @@ class DeepFMEngine:
             z = ops.gemm(h, P[f"dnn.{i}.linear.weight"], transB=True, bias=P[f"dnn.{i}.linear.bias"])
             rm, rv = self.running[i] if self.bn else (None, None)
             a, stats = ops.bn_relu_drop_fwd(z, P.get(f"dnn.{i}.bn.weight"), P.get(f"dnn.{i}.bn.bias"), rm, rv, self.training,
-                                            self.p_drop, sd, stream_id=100 + i)
+                                            self.p_drop, sd, stream_id=100 + i, seed_dev=seed_dev)
             tape["layers"].append((h, z, a, stats))
             h = a
         dnn = ops.gemm(h, P[f"dnn.{self.nl}.weight"], transB=True, bias=P[f"dnn.{self.nl}.bias"])   # [B, 1]
@@ -159,10 +159,10 @@ class DeepFMEngine:
         """sigmoid(logits) [B, 1]  (DeepFM/main.py:217-219)."""
         return torch.sigmoid(self.encode(x)[0]).unsqueeze(1)
 
-    def forward_backward(self, x, labels):
+    def forward_backward(self, x, labels, seed_dev=None):
         """loss + every gradient into the gradient arena.  DeepFM/main.py:211-215, 264-266."""
         P, G = self.P, self.G
-        logits, tape = self.encode(x)
+        logits, tape = self.encode(x, seed_dev)
         loss, dlogit, dsum = ops.bce_logits(logits.contiguous(), labels.reshape(-1).to(torch.float32).contiguous())
         dl = dlogit.unsqueeze(1)                                                       # [B, 1]
         nl = self.nl
@@ -185,14 +185,30 @@ class DeepFMEngine:
         self.gbias.copy_(dsum)
         return loss.squeeze(0)
 
-    def train_step(self, x, labels, max_norm=10.0):
+    def train_step(self, x, labels, max_norm=10.0, _state=None):
         """forward, backward, clip_grad_norm_(.., 10), Adam with the reference's two groups (DeepFM/main.py:187-199, 264-268)."""
-        loss = self.forward_backward(x, labels)
+        loss = self.forward_backward(x, labels, seed_dev=_state)
         total = torch.sqrt(self.grad.pow(2).sum())
         self.grad.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
-        self.step += 1
         ne = self.n_emb
         b1, b2 = self.betas
+        if _state is not None:       # captured: seed and Adam scalars are device words; the host counts the step (train_step_graph)
+            hyper = _state.view(torch.float32)[2:4]
+            ops.adam_step_dev(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], hyper, b1, b2, 1e-8, self.emb_decay)
+            ops.adam_step_dev(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], hyper, b1, b2, 1e-8, self.wd)
+            return loss
+        self.step += 1
         ops.adam_step(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], self.step, self.lr, b1, b2, 1e-8, self.emb_decay)
         ops.adam_step(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], self.step, self.lr, b1, b2, 1e-8, self.wd)
         return loss
+
+    def train_step_graph(self, x, labels, max_norm=10.0):
+        """train_step as one hipGraph replay (recboard_amd/capture.py): two copies into the static batch, one launch for the step's seed and
+        Adam scalars, one replay.  Same results as the eager step (same seeds, same launches)."""
+        from .capture import captured
+        labels = labels.reshape(-1).to(torch.float32)
+        restore = [self.data, self.m, self.v] + [t for pair in self.running.values() for t in pair]
+        g = captured(self, ("train", float(max_norm)), lambda xx, yy, st: self.train_step(xx, yy, max_norm, _state=st), (x.contiguous(), labels), restore)
+        sd = self._step_seed()
+        self.step += 1
+        return g((x, labels), sd, self.step, self.lr, self.betas[0], self.betas[1])

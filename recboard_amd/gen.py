@@ -47,7 +47,28 @@ class MFEngine:
         loss, _ = ops.bpr_triplet_fwd(Ut, It, users.reshape(-1), pos.reshape(-1), neg.reshape(-1))
         return {"rec_loss": loss.squeeze(0)}
 
-    def train_step(self, users, pos, neg, grad_hook=None):
+    def train_step_graph(self, users, pos, neg):
+        """train_step as one hipGraph replay (recboard_amd/capture.py): three copies into the static batch, one launch for the step's
+        scalars, one replay."""
+        from .capture import captured
+        A = self.arena
+        users, pos, neg = (t.reshape(-1).contiguous() for t in (users, pos, neg))
+        g = captured(self, "train", lambda u, p, n, st: self.train_step(u, p, n, _state=st), (users, pos, neg), [A.data, A.m, A.v] + self._extra_state())
+        A.step += 1
+        return g((users, pos, neg), 0, A.step, self.lr, self.betas[0], self.betas[1])
+
+    def _extra_state(self):
+        return []
+
+    def _adam(self, wd, state):
+        A = self.arena
+        if state is not None:        # captured: the step's scalars are device words (state[2:4]); the host counts the step
+            ops.adam_step_dev(A.data, A.grad, A.m, A.v, state.view(torch.float32)[2:4], self.betas[0], self.betas[1], 1e-8, wd)
+        else:
+            A.step += 1
+            ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, wd)
+
+    def train_step(self, users, pos, neg, grad_hook=None, _state=None):
         """forward + backward + Adam (MF-BPR/main.py:116-123)."""
         A = self.arena
         Ut, It = self.encode()
@@ -58,8 +79,7 @@ class MFEngine:
         ops.scatter_add_rows(torch.cat([gp, gn]), torch.cat([p, n]), self.N, out=G["Item.embeddings.weight"])
         if grad_hook is not None:
             grad_hook(A.grad)
-        A.step += 1
-        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        self._adam(self.wd, _state)
         return loss.squeeze(0)
 
     # MF-BPR/main.py:95-104
@@ -126,7 +146,7 @@ class LightGCNEngine(MFEngine):
         loss, _ = ops.bpr_triplet_fwd(ue, ie, u, p, n)
         return {"rec_loss": loss.squeeze(0), "emb_loss": self._emb_loss(u, p, n).clone().squeeze(0)}
 
-    def train_step(self, users, pos, neg, grad_hook=None):
+    def train_step(self, users, pos, neg, grad_hook=None, _state=None):
         """loss = rec + weight_decay * emb; backward through the L propagation layers (Adj symmetric); Adam WITHOUT
         weight decay (LightGCN/main.py:139-145,160-164)."""
         A, D, U = self.arena, self.D, self.U
@@ -149,8 +169,7 @@ class LightGCNEngine(MFEngine):
         ops.scatter_add_rows(ops.gather_rows(self.X0, rows), rows, self.n, scale=self.wd / B, out=gX0, accumulate=True)
         if grad_hook is not None:
             grad_hook(A.grad)
-        A.step += 1
-        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, 0.0)
+        self._adam(0.0, _state)
         return (loss + self.wd * emb).squeeze(0)
 
     def reset_ranking_buffers(self):

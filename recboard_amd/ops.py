@@ -928,7 +928,14 @@ def ce_rows_(logits, labels):
 
 
 # ------------------------------------------------------------------------------------------------ MLP pieces
-def bn_relu_drop_fwd(z, gamma, beta, run_mean, run_var, training, drop_p=0.0, seed=0, stream_id=100, eps=1e-5, momentum=0.1):
+def step_state(state, seed, step, lr, beta1=0.9, beta2=0.999):
+    """The per-step device words of a captured step (re_step_state): state int32[4] = {seed, 0, Adam step size, 1 / sqrt(bias correction 2)}."""
+    _req(state, torch.int32, "state")
+    lib.check(lib.load().re_step_state(_p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), _stream()), "re_step_state")
+    return state
+
+
+def bn_relu_drop_fwd(z, gamma, beta, run_mean, run_var, training, drop_p=0.0, seed=0, stream_id=100, eps=1e-5, momentum=0.1, seed_dev=None):
     """-> (a, stats): a = dropout(relu(bn(z)))  (re_bn_relu_drop_fwd); gamma None = no BatchNorm."""
     _req(z, torch.float32, "z")
     M, N = z.shape
@@ -937,7 +944,7 @@ def bn_relu_drop_fwd(z, gamma, beta, run_mean, run_var, training, drop_p=0.0, se
     L = lib.load()
     ws = _ws(L.re_mlp_workspace_bytes(N), z.device)
     lib.check(L.re_bn_relu_drop_fwd(_p(z), M, N, _p(gamma), _p(beta), _p(run_mean), _p(run_var), int(bool(training)),
-                                    float(eps), float(momentum), float(drop_p), int(seed) & 0xFFFFFFFF, int(stream_id),
+                                    float(eps), float(momentum), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), int(stream_id),
                                     _p(stats), _p(a), _p(ws), ws.numel(), _stream()), "re_bn_relu_drop_fwd")
     return a, stats
 

@@ -144,6 +144,7 @@ class SASRecEngine:
         self.split_long = True          # sequences of 3 - 4 tiles as two work items in two workgroups (fused BCE / BPR training step)
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
         self.fork_wgrad = True          # weight gradients on a side stream beside the item table's scatter-add (same results)
+        self.fork_adam = False          # True: the dense Adam as two launches inside the step's two branches (measured: 113 vs 104 us per step)
         self.pipelined_prep = False     # True: the Coach hands train_step_graph the next batch and its preparation launch runs on a side stream
                                         # beside this step.  Measured on MI355X: 115 - 137 us per step against 106 in front of the step -- the
                                         # second queue's launch disturbs the graph's own branches more than the 12 us it hides
@@ -352,9 +353,12 @@ class SASRecEngine:
                 ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
         return self._bufs[key]
 
-    def _step_body(self, pb, sd, seed_dev=None):
+    def _step_body(self, pb, sd, seed_dev=None, adam_hyper=None):
         """Every launch of the fused step after the batch preparation up to (not including) the optimizer; gradients land in the
-        gradient arena.  pb: ops.PreparedBatch."""
+        gradient arena.  pb: ops.PreparedBatch.
+        adam_hyper (device float32[2], captured steps with their own optimizer): the dense Adam too -- in the two-branch form as TWO
+        launches, the item table's slice of the arena behind the scatter-add on one branch and the encoder's slice behind the weight
+        gradients on the other, instead of one launch behind the join.  -> (loss, True) then."""
         A, P, D = self.arena, self.params, self.D
         seq, pos, neg = pb.seq, pb.pos, pb.neg
         B, S = seq.shape
@@ -387,7 +391,16 @@ class SASRecEngine:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=4, loss=loss)
+                ne = A.offsets["Position.weight"]          # the arena's first slice is the item table
+                b1, b2 = self.betas
+                if adam_hyper is not None and getattr(self, "fork_adam", False):
+                    with torch.cuda.stream(side):
+                        ops.adam_step_dev(A.data[ne:], A.grad[ne:], A.m[ne:], A.v[ne:], adam_hyper, b1, b2, 1e-8, self.wd)
                 ops.scatter_add_rows_small(W["g_rows"], W["keys"], self.N + 1, GE, n_regions=3, n_dev=pb.plan.view(torch.int32)[1:2], n_mul=16)
+                if adam_hyper is not None and getattr(self, "fork_adam", False):
+                    ops.adam_step_dev(A.data[:ne], A.grad[:ne], A.m[:ne], A.v[:ne], adam_hyper, b1, b2, 1e-8, self.wd)
+                    main.wait_stream(side)
+                    return loss, True
                 main.wait_stream(side)
                 return loss
             if self.fused_item_kernel:
@@ -483,7 +496,9 @@ class SASRecEngine:
         z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
 
         def body():
-            loss = self._step_body(pb, 0, seed_dev=state)
+            loss = self._step_body(pb, 0, seed_dev=state, adam_hyper=hyper if with_adam else None)
+            if isinstance(loss, tuple):          # (the optimizer ran inside the step's two branches)
+                return loss[0]
             if with_adam:
                 ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
             return loss

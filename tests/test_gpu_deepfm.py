@@ -85,3 +85,23 @@ def test_deepfm_train_step_runs_and_learns():
     x, y = dev(z["in/x"]), dev(z["in/labels"])
     losses = [m.train_step(x, y).item() for _ in range(40)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.05
+
+
+def test_captured_step_replays_the_eager_step():
+    """DeepFMEngine.train_step_graph: the same seeds (device words), the same launches -- identical parameters, moments and running statistics."""
+    from recboard_amd.deepfm import DeepFMEngine
+    counts = [40, 30, 7, 3]
+    rng = np.random.default_rng(6)
+    B = 96
+    batches = [(torch.from_numpy(np.stack([rng.integers(0, c, B) for c in counts], 1)).cuda(), torch.from_numpy((rng.random((B, 1)) < 0.4).astype(np.int64)).cuda())
+               for _ in range(4)]
+    a = DeepFMEngine(counts, 8, (32, 16), batch_norm=True, hidden_dropout_rate=0.2, lr=1e-2, seed=5)
+    b = DeepFMEngine(counts, 8, (32, 16), batch_norm=True, hidden_dropout_rate=0.2, lr=1e-2, seed=5)
+    for x, y in batches:
+        la = a.train_step(x, y).clone()
+        lb = b.train_step_graph(x, y).clone()
+        assert torch.equal(la.reshape(-1), lb.reshape(-1)), (la, lb)
+    assert a.step == b.step == 4
+    assert torch.equal(a.data, b.data) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v)
+    for i in a.running:
+        assert torch.equal(a.running[i][0], b.running[i][0]) and torch.equal(a.running[i][1], b.running[i][1])

@@ -125,3 +125,28 @@ def test_scatter_add_accumulate_mode(ops):
     out = base.clone()
     ops.scatter_add_rows(g, idx, R, out=out, accumulate=True)
     torch.testing.assert_close(out, base + fresh, rtol=1e-6, atol=1e-5)
+
+
+def test_captured_steps_replay_the_eager_steps():
+    """MFEngine / LightGCNEngine.train_step_graph (one hipGraph replay per step, recboard_amd/capture.py) take exactly the eager steps."""
+    from recboard_amd.gen import LightGCNEngine, MFEngine
+    from recboard_amd.graph import to_normalized_adj
+    rng = np.random.default_rng(4)
+    U, N, B = 300, 200, 64
+    eu, ei = rng.integers(0, U, 3000), rng.integers(0, N, 3000)
+    key = np.unique(eu * N + ei)
+    crow, col, val = to_normalized_adj(U, N, key // N, key % N)
+    batches = [tuple(torch.from_numpy(rng.integers(0, m, (B, 1))).cuda() for m in (U, N, N)) for _ in range(4)]
+    for make in (lambda: MFEngine(U, N, 32, lr=1e-2, weight_decay=1e-4, seed=2),
+                 lambda: LightGCNEngine(U, N, crow, col, val, 32, 2, lr=1e-2, weight_decay=1e-3, seed=2)):
+        a, b = make(), make()
+        with torch.no_grad():
+            for e in (a, b):
+                for p in e.params.values():
+                    p.mul_(1e3)
+        for u, p, n in batches:
+            la = a.train_step(u, p, n).clone()
+            lb = b.train_step_graph(u, p, n).clone()
+            assert torch.equal(la, lb), (type(a).__name__, la, lb)
+        assert a.arena.step == b.arena.step == 4
+        assert torch.equal(a.arena.data, b.arena.data) and torch.equal(a.arena.m, b.arena.m) and torch.equal(a.arena.v, b.arena.v)
