@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* __restric
 
 static int gm_nsplit(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = re_cdiv(M, GM_BM) * re_cdiv(N, GM_BN);
-    if (tiles >= 256 || K < 4096) return 1;
+    if (tiles >= 256 || K < 1024) return 1;
     int64_t s = 512 / tiles;
-    const int64_t maxs = K / 1024;
+    const int64_t maxs = K / 256;     // (slices of >= 8 K-steps; K / 1024 left the DeepFM weight-gradient shape 400 x 400 x 4096 at 196 workgroups: 80 -> 3x us)
     if (s > maxs) s = maxs;
     if (s > 64) s = 64;
     return s < 1 ? 1 : (int)s;
