@@ -107,6 +107,16 @@ int re_sparse_adam_rows_small(const float* g, const void* keys, int32_t key_byte
                               const int32_t* n_dev, int64_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float* W,
                               float* m, float* v, const float* hyper, int64_t step, double lr, double beta1, double beta2, double eps,
                               double weight_decay, re_stream_t stream);
+/* Optional: the dense Adam of the parameters whose gradients a launch FINISHES, applied by that launch (no optimizer launch of its
+ * own behind it).  grad_base / param / m / v are arenas of one layout: the gradient written at grad_base + i updates element i.
+ * hyper = device { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) } (re_step_state / re_sasrec_batch_prep); {0, 0} = leave everything as it is. */
+typedef struct re_adam_fuse {
+    const float* grad_base;
+    float *param, *m, *v;
+    const float* hyper;
+    double beta1, beta2, eps, weight_decay;   /* (doubles, as re_adam_step takes them: 1 - beta is formed in double) */
+} re_adam_fuse;
+
 /* Small dense tables (R up to ~100 k rows; D = 64 or 128): the same sum WITHOUT the sort -- every workgroup owns a range of
  * destination rows, scans all keys and adds the rows that fall into its range; one launch, no workspace, dW [R, D] fully
  * overwritten (untouched rows and row `padding_idx` zero).  keys are int32: `n_regions` runs of n keys, run q at
@@ -117,6 +127,12 @@ int re_sparse_adam_rows_small(const float* g, const void* keys, int32_t key_byte
 int re_scatter_add_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
                               int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
                               re_stream_t stream);
+/* The same sum with the table's DENSE Adam update folded in: every row's owner has the row's finished gradient in hand, so it
+ * updates adam->param / m / v rows [0, R) right there (every row moves, as torch.optim.Adam's dense step does) -- the gradient
+ * is not written (dW may be NULL) and no optimizer launch over the table follows.  adam->grad_base is unused here. */
+int re_scatter_adam_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
+                               int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
+                               const re_adam_fuse* adam, re_stream_t stream);
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                         int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,
@@ -370,14 +386,16 @@ int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float s
  * 4 = the weight gradients (from the tape the item kernels left); 0 = 7 = everything.  + 8: the weight fragments were prepared by
  * re_sasrec_batch_prep_w for this step.  The two item kernels are independent of each other and the item table's scatter-add
  * depends on them alone: a caller runs 1 and 2, then 4 and the scatter-add, as parallel branches on two streams
- * (recboard_amd/sasrec.py does, inside the captured step) and joins them before the optimizer. */
+ * (recboard_amd/sasrec.py does, inside the captured step) and joins them before the optimizer.
+ * adam != NULL (with part & 4): the reduction that finishes the encoder's gradients (position table, every block's matrices and vectors,
+ * lastLN) also applies their dense Adam update -- all of them must then be views of one arena (adam->grad_base). */
 int re_sasrec_encoder_step_part(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
                                 const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
                                 const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
                                 const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
                                 const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
                                 size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
-                                float* g_last_b, void* ws, size_t ws_bytes, int32_t part, re_stream_t stream);
+                                float* g_last_b, void* ws, size_t ws_bytes, int32_t part, const re_adam_fuse* adam, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,

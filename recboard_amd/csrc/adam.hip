@@ -10,14 +10,7 @@ __global__ __launch_bounds__(256) void adam_vec4(float4* __restrict__ p, const f
                                                  float step_size, float inv_sqrt_bc2, float eps, float wd) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 P = p[i], G = g[i], M = m[i], V = v[i];
-#define RE_ADAM1(c)                                        \
-    {                                                      \
-        float gg = G.c + wd * P.c;                         \
-        M.c = b1 * M.c + omb1 * gg;                        \
-        V.c = b2 * V.c + omb2 * gg * gg;                   \
-        float denom = sqrtf(V.c) * inv_sqrt_bc2 + eps;     \
-        P.c = P.c - step_size * (M.c / denom);             \
-    }
+#define RE_ADAM1(c) re_adam1(P.c, M.c, V.c, G.c, b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd);
         RE_ADAM1(x) RE_ADAM1(y) RE_ADAM1(z) RE_ADAM1(w)
 #undef RE_ADAM1
         p[i] = P; m[i] = M; v[i] = V;
@@ -29,11 +22,9 @@ __global__ __launch_bounds__(256) void adam_tail(float* __restrict__ p, const fl
                                                  float omb2, float step_size, float inv_sqrt_bc2, float eps, float wd) {
     int64_t i = begin + threadIdx.x;
     if (i >= n) return;
-    float gg = g[i] + wd * p[i];
-    float M = b1 * m[i] + omb1 * gg;
-    float V = b2 * v[i] + omb2 * gg * gg;
-    m[i] = M; v[i] = V;
-    p[i] = p[i] - step_size * (M / (sqrtf(V) * inv_sqrt_bc2 + eps));
+    float P = p[i], M = m[i], V = v[i];
+    re_adam1(P, M, V, g[i], b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd);
+    p[i] = P; m[i] = M; v[i] = V;
 }
 
 // hipGraph-friendly variant: the two step-dependent scalars come from device memory (hyper[0] = lr / (1 - beta1^t),
@@ -45,14 +36,7 @@ __global__ __launch_bounds__(256) void adam_vec4_dev(float4* __restrict__ p, con
     if (inv_sqrt_bc2 == 0.f) return;   // {0, 0}: the caller gated this step off (parameters AND moments stay as they are)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 P = p[i], G = g[i], M = m[i], V = v[i];
-#define RE_ADAM1(c)                                        \
-    {                                                      \
-        float gg = G.c + wd * P.c;                         \
-        M.c = b1 * M.c + omb1 * gg;                        \
-        V.c = b2 * V.c + omb2 * gg * gg;                   \
-        float denom = sqrtf(V.c) * inv_sqrt_bc2 + eps;     \
-        P.c = P.c - step_size * (M.c / denom);             \
-    }
+#define RE_ADAM1(c) re_adam1(P.c, M.c, V.c, G.c, b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd);
         RE_ADAM1(x) RE_ADAM1(y) RE_ADAM1(z) RE_ADAM1(w)
 #undef RE_ADAM1
         p[i] = P; m[i] = M; v[i] = V;

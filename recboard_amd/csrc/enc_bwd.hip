@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, 
 // ---- weight gradients (enc_wgrad.hip) ---------------------------------------------------------------------------------------
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
                      int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
-                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile = 0);
+                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile = 0, const re_adam_fuse* adam = nullptr);
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512) void enc_step_k(SeEmbed em, const int64_t* __r
 // ---- weight gradients (enc_wgrad.hip) ---------------------------------------------------------------------------------------
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
                      int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
-                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile = 0);
+                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile = 0, const re_adam_fuse* adam = nullptr);
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
@@ -75,7 +75,7 @@ extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const floa
                                            const void* plan, int32_t ncu, float* u, void* tape, size_t tape_bytes, int64_t e_off, int kind,
                                            const int32_t* count, float* loss, float* dU_rows, float* g_rows, int32_t* keys, void* loss_ws,
                                            size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
-                                           float* g_last_b, void* ws, size_t ws_bytes, int32_t part, re_stream_t stream) {
+                                           float* g_last_b, void* ws, size_t ws_bytes, int32_t part, const re_adam_fuse* adam, re_stream_t stream) {
     re_clear_error();
     if (part < 0 || part > 15) return RE_EINVAL;
     const bool frag_ready = (part & 8) != 0;
@@ -126,7 +126,7 @@ extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const floa
             if (rco != RE_OK) return rco;
         }
         if (!(part & 4)) return RE_OK;
-        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, wgrid, wpart, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s, 1);
+        return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, wgrid, wpart, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, adam);
     }
     if (part & 2) {
         const int rc = D == 128 ? enc_step_launch_d<128>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s)
@@ -134,7 +134,7 @@ extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const floa
         if (rc != RE_OK) return rc;
     }
     if (!(part & 4)) return RE_OK;
-    return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, wpart, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s);
+    return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, wpart, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s, 0, adam);
 }
 
 extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
@@ -146,5 +146,5 @@ extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Pt
                                       float* g_last_b, void* ws, size_t ws_bytes, re_stream_t stream) {
     return re_sasrec_encoder_step_part(E, R, Ptab, scale, seq, pos, neg, B, S, D, L, block_params, last_w, last_b, drop_p, seed, seed_dev, plan, ncu, u,
                                        tape, tape_bytes, e_off, kind, count, loss, dU_rows, g_rows, keys, loss_ws, loss_ws_bytes, dx0, dPtab,
-                                       block_grads, g_last_w, g_last_b, ws, ws_bytes, 0, stream);
+                                       block_grads, g_last_w, g_last_b, ws, ws_bytes, 0, nullptr, stream);
 }

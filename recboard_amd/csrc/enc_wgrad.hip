@@ -138,6 +138,26 @@ __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tap
     }
 }
 
+// optional: the dense Adam of every gradient element the reduction finishes (re_adam_fuse: arenas of one layout)
+struct EncAdam {
+    const float* gbase;
+    float *p, *m, *v;
+    const float* hyper;
+    float b1, b2, omb1, omb2, eps, wd;
+};
+__device__ __forceinline__ void eg_put(const EncAdam& A, float* d, float g) {
+    *d = g;
+    if (A.p) {
+        const float ss = A.hyper[0], ib = A.hyper[1];
+        if (ib != 0.f) {   // ({0, 0}: the caller gated this step off)
+            const int64_t i = d - A.gbase;
+            float pp = A.p[i], mm = A.m[i], vv = A.v[i];
+            re_adam1(pp, mm, vv, g, A.b1, A.b2, A.omb1, A.omb2, ss, ib, A.eps, A.wd);     // (adam_vec4_dev's arithmetic)
+            A.p[i] = pp; A.m[i] = mm; A.v[i] = vv;
+        }
+    }
+}
+
 struct EncGradDst {
     float* p[SE_MAX_BLOCKS][14];  // per block: ABI order of the 12 block gradients, then g_last_w, g_last_b (last block only)
 };
@@ -147,7 +167,7 @@ struct EncGradDst {
 __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict__ part, const float* __restrict__ slab, int nwg,
                                                          const void* __restrict__ planp, int B, int S, int D, int L, EncGradDst dst,
                                                          int nmat_blocks, int nvec_blocks, const float* __restrict__ ppart, float inv_scale,
-                                                         float* __restrict__ dPtab, int by_tile) {
+                                                         float* __restrict__ dPtab, int by_tile, EncAdam AD) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nmat_blocks + nvec_blocks) {
         // position-table gradient: the chunk partials of enc_wgrad_k in chunk order, / scale
@@ -156,7 +176,7 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
         const int p = e / D, cc = e % D, nch = (B + 63) / 64;
         float s = 0.f;
         for (int ch = 0; ch < nch; ++ch) s += ppart[((int64_t)p * nch + ch) * D + cc];
-        dPtab[e] = s * inv_scale;
+        eg_put(AD, dPtab + e, s * inv_scale);
         return;
     }
     if ((int)blockIdx.x < nmat_blocks) {
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
         const int l = lm / EG_NMAT, m = lm % EG_NMAT;
         float* const* P = dst.p[l];
         float* d = (m == 0) ? P[10] : (m == 1) ? P[8] : (m == 2) ? P[4] : P[2] + (m - 3) * dd;
-        d[off] = s;
+        eg_put(AD, d + off, s);
         return;
     }
     __shared__ float red[4][64];
@@ -217,14 +237,14 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
         case 10: d = P[12]; break;
         default: d = P[13]; break;
     }
-    d[cg * 64 + lane] = s;
+    eg_put(AD, d + cg * 64 + lane, s);
 }
 
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D) { return (size_t)64 * ((B + 63) / 64) * D; }
 
 int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tape, const float* gtape, const void* plan, const float* slab,
                      int nwg, float* part, float* ppart, const int64_t* seq, const float* contrib, float emb_scale, float* dPtab,
-                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile) {
+                     float* const* block_grads, float* g_last_w, float* g_last_b, hipStream_t s, int by_tile, const re_adam_fuse* adam) {
     if (D != 64 && D != 128) return RE_EUNSUPPORTED;
     const EncTape T = enc_tape_layout(B, S, D, L);
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
@@ -248,8 +268,14 @@ int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tap
     const int nmat_blocks = (int)((L * EG_NMAT * D * D + 255) / 256);
     const int nvec_blocks = (int)(L * EG_NVEC * (D / 64));
     const int npos_blocks = dPtab ? (int)((S * D + 255) / 256) : 0;
+    EncAdam AD{};
+    if (adam) {
+        if (!adam->grad_base || !adam->param || !adam->m || !adam->v || !adam->hyper) return RE_EINVAL;
+        AD = EncAdam{adam->grad_base, adam->param, adam->m, adam->v, adam->hyper, (float)adam->beta1, (float)adam->beta2, (float)(1.0 - adam->beta1),
+                     (float)(1.0 - adam->beta2), (float)adam->eps, (float)adam->weight_decay};
+    }
     hipLaunchKernelGGL(enc_grad_reduce_k, dim3(nmat_blocks + nvec_blocks + npos_blocks), dim3(256), 0, s, (const float*)part, slab, nwg, plan,
                        (int)B, (int)S, (int)D, (int)L, dst, nmat_blocks, nvec_blocks, (const float*)ppart, emb_scale != 0.f ? 1.0f / emb_scale : 0.f,
-                       dPtab, by_tile);
+                       dPtab, by_tile, AD);
     return re_launch_status();
 }

@@ -47,6 +47,17 @@ static inline hipError_t re_zero_async(void* p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
+// One element of the dense Adam step with coupled weight decay.  The operation sequence is pinned (explicit fused / rounded operations):
+// the same update is computed by adam_vec4 / adam_vec4_dev, by the scatter-add's row owners and by the gradient reduction's epilogue,
+// and an eager step and a captured step must agree to the bit whichever of them runs.
+__device__ __forceinline__ void re_adam1(float& p, float& m, float& v, float g, float b1, float b2, float omb1, float omb2, float step_size,
+                                         float inv_sqrt_bc2, float eps, float wd) {
+    const float gg = __fmaf_rn(wd, p, g);
+    m = __fmaf_rn(b1, m, __fmul_rn(omb1, gg));
+    v = __fmaf_rn(b2, v, __fmul_rn(__fmul_rn(omb2, gg), gg));
+    p = __fsub_rn(p, __fmul_rn(step_size, __fdiv_rn(m, __fmaf_rn(__fsqrt_rn(v), inv_sqrt_bc2, eps))));
+}
+
 __device__ __forceinline__ float re_softplus(float x) {
     // log(1 + exp(x)), stable: max(x,0) + log1p(exp(-|x|))  (torch.nn.functional.softplus, threshold irrelevant in fp32 here)
     return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));

@@ -772,10 +772,19 @@ extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64
 
 // HS column splits: a table row is owned in HS pieces of DW = D / HS columns by HS DIFFERENT workgroups (virtual row HS * r + h), so
 // a hot row's contributions are pulled through HS memory pipes, DW * 4 bytes each, instead of through one.
+struct SoAdam {   // W != nullptr: the owner applies the dense Adam update of its rows instead of (or besides) writing their gradient
+    float *W, *m, *v;
+    const float* hyper;
+    float b1, b2, omb1, omb2, eps, wd;
+};
+__device__ __forceinline__ void so_adam1(const SoAdam& A, float ss, float ib, float g, float& p, float& m, float& v) {   // (adam_vec4_dev's arithmetic)
+    re_adam1(p, m, v, g, A.b1, A.b2, A.omb1, A.omb2, ss, ib, A.eps, A.wd);
+}
+
 template <int D, int HS>
 __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                                          const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
-                                                         int64_t padding_idx, float scale, float* __restrict__ dW) {
+                                                         int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD) {
     constexpr int DW = D / HS, VW = DW / 32;         // columns of a piece; floats per lane: a lane group is 32 lanes
     constexpr int HSH = HS == 1 ? 0 : HS == 2 ? 1 : 2;
     typedef float vt __attribute__((ext_vector_type(VW)));
@@ -941,7 +950,18 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         const int64_t kk = (int64_t)r * nwg + me;   // virtual row -> table row kk >> HSH, piece h_me
-        reinterpret_cast<float4*>(dW + (kk >> HSH) * D + h_me * DW)[c4] = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+        const float4 gr = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+        const int64_t o = (kk >> HSH) * D + h_me * DW;
+        if (dW) reinterpret_cast<float4*>(dW + o)[c4] = gr;
+        if (AD.W) {
+            const float ss = AD.hyper[0], ib = AD.hyper[1];
+            if (ib != 0.f) {   // ({0, 0}: the caller gated this step off)
+                float4 P = reinterpret_cast<float4*>(AD.W + o)[c4], M = reinterpret_cast<float4*>(AD.m + o)[c4], V = reinterpret_cast<float4*>(AD.v + o)[c4];
+                so_adam1(AD, ss, ib, gr.x, P.x, M.x, V.x); so_adam1(AD, ss, ib, gr.y, P.y, M.y, V.y);
+                so_adam1(AD, ss, ib, gr.z, P.z, M.z, V.z); so_adam1(AD, ss, ib, gr.w, P.w, M.w, V.w);
+                reinterpret_cast<float4*>(AD.W + o)[c4] = P; reinterpret_cast<float4*>(AD.m + o)[c4] = M; reinterpret_cast<float4*>(AD.v + o)[c4] = V;
+            }
+        }
     }
 #ifdef SO_MARKS
     __syncthreads();
@@ -951,13 +971,14 @@ __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict
 #endif
 }
 
-extern "C" int re_scatter_add_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
-                                         int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
-                                         re_stream_t stream) {
+static int scatter_small_launch(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
+                                int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW, const SoAdam& AD,
+                                re_stream_t stream) {
     re_clear_error();
-    if (!dW || !g || !keys || R <= 0 || n_regions < 1 || n_regions > 4 || region_stride < 0 || n_host < 0 || (n_dev && n_mul < 1)) return RE_EINVAL;
+    if ((!dW && !AD.W) || !g || !keys || R <= 0 || n_regions < 1 || n_regions > 4 || region_stride < 0 || n_host < 0 || (n_dev && n_mul < 1)) return RE_EINVAL;
     if (D != 64 && D != 128) return RE_EUNSUPPORTED;
-    if ((region_stride & 3) || ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW)) & 15u))
+    if ((region_stride & 3) || ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW) |
+                                 reinterpret_cast<uintptr_t>(AD.W) | reinterpret_cast<uintptr_t>(AD.m) | reinterpret_cast<uintptr_t>(AD.v)) & 15u))
         return RE_EUNSUPPORTED;
     if ((int64_t)n_regions * region_stride >= (1ll << 25)) return RE_EUNSUPPORTED;   // (a list entry: 7 bits of local row, 25 of index)
     constexpr int HS = 2;                          // column pieces per row
@@ -971,12 +992,29 @@ extern "C" int re_scatter_add_rows_small(const float* g, const int32_t* keys, in
         auto k = scatter_owner_k<64, HS>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw,
-                           padding_idx, scale, dW);
+                           padding_idx, scale, dW, AD);
     } else {
         auto k = scatter_owner_k<128, HS>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw,
-                           padding_idx, scale, dW);
+                           padding_idx, scale, dW, AD);
     }
     return re_launch_status();
+}
+
+extern "C" int re_scatter_add_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
+                                         int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
+                                         re_stream_t stream) {
+    if (!dW) return RE_EINVAL;
+    SoAdam AD{};
+    return scatter_small_launch(g, keys, n_regions, region_stride, n_dev, n_mul, n_host, D, R, padding_idx, scale, dW, AD, stream);
+}
+
+extern "C" int re_scatter_adam_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
+                                          int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
+                                          const re_adam_fuse* adam, re_stream_t stream) {
+    if (!adam || !adam->param || !adam->m || !adam->v || !adam->hyper) return RE_EINVAL;
+    const SoAdam AD{adam->param, adam->m, adam->v, adam->hyper, (float)adam->beta1, (float)adam->beta2, (float)(1.0 - adam->beta1),
+                    (float)(1.0 - adam->beta2), (float)adam->eps, (float)adam->weight_decay};
+    return scatter_small_launch(g, keys, n_regions, region_stride, n_dev, n_mul, n_host, D, R, padding_idx, scale, dW, AD, stream);
 }

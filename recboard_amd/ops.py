@@ -606,10 +606,13 @@ def sasrec_encoder_fwd_loss(E, Ptab, seq, pos, neg, scale, block_tensors, last_w
 
 
 def sasrec_encoder_step(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, last_b, L, drop_p, seed, plan, kind, count, u, tape,
-                        dU_rows, g_rows, keys, loss_ws, dx0, dP, block_grads, g_last_w, g_last_b, ws, e_off=1, loss=None, seed_dev=None, part=0):
+                        dU_rows, g_rows, keys, loss_ws, dx0, dP, block_grads, g_last_w, g_last_b, ws, e_off=1, loss=None, seed_dev=None, part=0,
+                        adam=None):
     """Forward + criterion + backward of the encoder per work item in ONE launch, then the weight gradients (re_sasrec_encoder_step):
     what sasrec_encoder_fwd_loss + sasrec_encoder_bwd(dU_rows=..., out_rows=g_rows[0], dP=...) compute, bit for bit.  -> loss[1].
-    part (re_sasrec_encoder_step_part): 1 = the item kernels only, 2 = the weight gradients only (from the tape part 1 left)."""
+    part (re_sasrec_encoder_step_part): a mask -- 1 tile kernels, 2 workgroup-per-item kernel, 4 weight gradients, + 8 weights prepared.
+    adam (AdamFuse over the arenas the gradient tensors are views of): the reduction that finishes the encoder's gradients applies their
+    dense Adam update too."""
     _req(E, torch.float32, "E"); _req(Ptab, torch.float32, "Ptab"); _req(seq, torch.int64, "seq"); _req(pos, torch.int64, "pos")
     _req(neg, torch.int64, "neg"); _req(u, torch.float32, "u"); _req(tape, torch.float32, "tape"); _req(dU_rows, torch.float32, "dU_rows")
     _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(count, torch.int32, "count"); _req(loss_ws, torch.uint8, "loss_ws")
@@ -626,7 +629,8 @@ def sasrec_encoder_step(E, Ptab, seq, pos, neg, scale, block_tensors, last_w, la
                                                      _p(last_b), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), _p(plan), num_cus(E.device),
                                                      _p(u), _p(tape), tape.numel() * 4, int(e_off), int(kind), _p(count), _p(loss), _p(dU_rows),
                                                      _p(g_rows), _p(keys), _p(loss_ws), loss_ws.numel(), _p(dx0), _p(dP), tg, _p(g_last_w),
-                                                     _p(g_last_b), _p(ws), ws.numel(), int(part), _stream()), "re_sasrec_encoder_step_part")
+                                                     _p(g_last_b), _p(ws), ws.numel(), int(part), ctypes.byref(adam) if adam is not None else None,
+                                                     _stream()), "re_sasrec_encoder_step_part")
     return loss
 
 
@@ -691,10 +695,29 @@ def sasrec_loss_rows(U, E, seq, pos, neg, plan, kind, count, dU_rows, g_rows, ke
     return loss
 
 
-def scatter_add_rows_small(g, keys, R, out, n_regions=1, region_stride=None, n_dev=None, n_mul=1, n=None, padding_idx=0, scale=1.0):
+class AdamFuse(ctypes.Structure):
+    """re_adam_fuse (include/recengine.h): the dense Adam of the gradients a launch finishes, applied by that launch."""
+    _fields_ = [("grad_base", ctypes.c_void_p), ("param", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("hyper", ctypes.c_void_p), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("weight_decay", ctypes.c_double)]
+
+
+def adam_fuse(grad, param, m, v, hyper, beta1, beta2, eps, weight_decay):
+    """-> an AdamFuse over arenas of one layout (keep the tensors alive while it is in use)."""
+    for t, nm in ((grad, "grad"), (param, "param"), (m, "m"), (v, "v"), (hyper, "hyper")):
+        _req(t, torch.float32, nm)
+    return AdamFuse(grad.data_ptr(), param.data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(), float(beta1), float(beta2), float(eps),
+                    float(weight_decay))
+
+
+def scatter_add_rows_small(g, keys, R, out, n_regions=1, region_stride=None, n_dev=None, n_mul=1, n=None, padding_idx=0, scale=1.0, adam=None):
     """Dense [R, D] sum of contribution rows by int32 destination keys without a sort (re_scatter_add_rows_small): `out` is fully
-    overwritten.  n keys per region: `n` (host) or n_dev[0] * n_mul (device int32)."""
-    _req(g, torch.float32, "g"); _req(keys, torch.int32, "keys"); _req(out, torch.float32, "out")
+    overwritten.  n keys per region: `n` (host) or n_dev[0] * n_mul (device int32).
+    adam (AdamFuse over the table's param / m / v rows [0, R)): the table's dense Adam update is applied by the same launch
+    (re_scatter_adam_rows_small); `out` may then be None (the gradient is not written)."""
+    _req(g, torch.float32, "g"); _req(keys, torch.int32, "keys")
+    if out is not None or adam is None:
+        _req(out, torch.float32, "out")
     D = g.shape[-1]
     if region_stride is None:
         region_stride = keys.numel() // n_regions
@@ -702,8 +725,13 @@ def scatter_add_rows_small(g, keys, R, out, n_regions=1, region_stride=None, n_d
         n = region_stride
     if n_dev is not None:
         _req(n_dev, torch.int32, "n_dev")
-    if out.numel() != R * D or g.numel() < n_regions * region_stride * D:
+    if (out is not None and out.numel() != R * D) or g.numel() < n_regions * region_stride * D:
         raise ValueError("recengine: scatter_add_rows_small buffer shapes")
+    if adam is not None:
+        lib.check(lib.load().re_scatter_adam_rows_small(_p(g), _p(keys), int(n_regions), int(region_stride), _p(n_dev), int(n_mul), int(n or 0), D,
+                                                        int(R), int(padding_idx), float(scale), _p(out), ctypes.byref(adam), _stream()),
+                  "re_scatter_adam_rows_small")
+        return out
     lib.check(lib.load().re_scatter_add_rows_small(_p(g), _p(keys), int(n_regions), int(region_stride), _p(n_dev), int(n_mul),
                                                    int(n or 0), D, int(R), int(padding_idx), float(scale), _p(out), _stream()),
               "re_scatter_add_rows_small")

@@ -144,6 +144,7 @@ class SASRecEngine:
         self.split_long = True          # sequences of 3 - 4 tiles as two work items in two workgroups (fused BCE / BPR training step)
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
         self.fork_wgrad = True          # weight gradients on a side stream beside the item table's scatter-add (same results)
+        self.fuse_adam = True           # captured steps: the dense Adam inside the launches that finish the gradients (reduction / scatter-add)
         self.fork_adam = False          # True: the dense Adam as two launches inside the step's two branches (measured: 113 vs 104 us per step)
         self.pipelined_prep = False     # True: the Coach hands train_step_graph the next batch and its preparation launch runs on a side stream
                                         # beside this step.  Measured on MI355X: 115 - 137 us per step against 106 in front of the step -- the
@@ -316,6 +317,11 @@ class SASRecEngine:
         """The training step may run one tile per workgroup (csrc/enc_tile.hip: D = 64; re_sasrec_encoder_step picks per batch)."""
         return bool(self.D == 64 and self.fused_item_kernel and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
 
+    def _tail_word(self):
+        if not hasattr(self, "_tail"):
+            self._tail = torch.zeros(4, dtype=torch.int32, device=self.device)
+        return self._tail
+
     def _prep_weights(self, B, S):
         """What the batch preparation launch needs to also prepare the tile step's weight fragments (ops.sasrec_batch_prep(weights=));
         None when the step that follows is not the one-tile-per-workgroup one."""
@@ -389,19 +395,29 @@ class SASRecEngine:
                 side = self._side
                 loss = ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=3 + ready)
                 side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=4, loss=loss)
                 ne = A.offsets["Position.weight"]          # the arena's first slice is the item table
                 b1, b2 = self.betas
-                if adam_hyper is not None and getattr(self, "fork_adam", False):
-                    with torch.cuda.stream(side):
+                fuse = adam_hyper is not None and getattr(self, "fuse_adam", True)
+                if fuse:
+                    # the optimizer rides in the two launches that FINISH the gradients: the reduction applies the encoder slice's dense
+                    # Adam, the scatter-add's row owners the item table's -- no optimizer launch behind the join
+                    enc_adam = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, b1, b2, 1e-8, self.wd)
+                    tab_adam = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, b1, b2, 1e-8, self.wd)   # (rows [0, N + 1) of the arenas)
+                    self._adam_keep = (enc_adam, tab_adam)
+                with torch.cuda.stream(side):
+                    ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=4, loss=loss, adam=enc_adam if fuse else None)
+                    if adam_hyper is not None and not fuse and getattr(self, "fork_adam", False):
                         ops.adam_step_dev(A.data[ne:], A.grad[ne:], A.m[ne:], A.v[ne:], adam_hyper, b1, b2, 1e-8, self.wd)
-                ops.scatter_add_rows_small(W["g_rows"], W["keys"], self.N + 1, GE, n_regions=3, n_dev=pb.plan.view(torch.int32)[1:2], n_mul=16)
-                if adam_hyper is not None and getattr(self, "fork_adam", False):
+                # (the table gradient is still written in the fused form -- arena.grad stays the step's gradient -- unless keep_table_grad is off)
+                ops.scatter_add_rows_small(W["g_rows"], W["keys"], self.N + 1, GE if (not fuse or getattr(self, "keep_table_grad", True)) else None,
+                                           n_regions=3, n_dev=pb.plan.view(torch.int32)[1:2], n_mul=16, adam=tab_adam if fuse else None)
+                if adam_hyper is not None and not fuse and getattr(self, "fork_adam", False):
                     ops.adam_step_dev(A.data[:ne], A.grad[:ne], A.m[:ne], A.v[:ne], adam_hyper, b1, b2, 1e-8, self.wd)
-                    main.wait_stream(side)
-                    return loss, True
                 main.wait_stream(side)
+                if fuse or (adam_hyper is not None and getattr(self, "fork_adam", False)):
+                    if getattr(self, "tail_node", True):
+                        ops.step_state(self._tail_word(), 0, 1, 1e-3)     # (a graph that ENDS in a join of two branches replays slower: one trivial node behind it)
+                    return loss, True
                 return loss
             if self.fused_item_kernel:
                 loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
