@@ -419,6 +419,18 @@ class SASRecEngine:
                         ops.step_state(self._tail_word(), 0, 1, 1e-3)     # (a graph that ENDS in a join of two branches replays slower: one trivial node behind it)
                     return loss, True
                 return loss
+            if self.fused_item_kernel and adam_hyper is not None and getattr(self, "fuse_adam", True):
+                # one queue: item kernels -> weight gradients -> reduction (+ the encoder slice's Adam) -> scatter-add (+ the table's Adam)
+                b1, b2 = self.betas
+                fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, b1, b2, 1e-8, self.wd)
+                self._adam_keep = (fz,)
+                loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
+                                               W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
+                                               W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
+                                               G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev, part=7 + ready, adam=fz)
+                ops.scatter_add_rows_small(W["g_rows"], W["keys"], self.N + 1, GE if getattr(self, "keep_table_grad", True) else None,
+                                           n_regions=3, n_dev=pb.plan.view(torch.int32)[1:2], n_mul=16, adam=fz)
+                return loss, True
             if self.fused_item_kernel:
                 loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count,
                                                W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
