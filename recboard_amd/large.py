@@ -126,10 +126,13 @@ class SASRecLargeTableEngine(SASRecEngine):
             x0 = ops.sasrec_embed(self.E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), p, self._step_seed())
             return self._blocks(x0, (seq == 0).unsqueeze(-1)), self.E[1:]
 
-    def _grads(self, seq, pos, neg, aux, sd, seed_dev=None, table=None):
+    def _grads(self, seq, pos, neg, aux, sd, seed_dev=None, table=None, adam_hyper=None):
         """Forward + backward: encoder gradients into the arena, the item-gradient contribution rows C with their destination rows
         (0 = none).  -> (loss, C, rows).
-        `table` (default: the item table) is what seq / pos / neg index: the sharded engine passes its batch-local table."""
+        `table` (default: the item table) is what seq / pos / neg index: the sharded engine passes its batch-local table.
+        adam_hyper (captured single-GPU step): BOTH optimizers too, in two branches -- the weight gradients and their reduction (which
+        applies the encoder's dense Adam, re_adam_fuse) on a side stream beside the table's row-sparse Adam on this one; both depend on
+        the item kernel alone.  -> (loss, C, rows, True) then."""
         A, D = self.arena, self.D
         B, S = seq.shape
         n = B * S
@@ -147,6 +150,24 @@ class SASRecLargeTableEngine(SASRecEngine):
             lw, lb = self.params["lastLN.weight"].detach(), self.params["lastLN.bias"].detach()
             if table is not None:                               # (the sharded step reads every key entry: rows beyond this batch's plan must read
                 W["keys"].zero_()                               #  "no contribution"; the unsharded update stops at the plan's live length)
+            if adam_hyper is not None and table is None and self.fused_item_kernel and getattr(self, "fork_wgrad", True):
+                args = (E, Ppos.detach(), seq, pos, neg, float(D ** 0.5), self._block_tensors(), lw, lb, self.L, p, sd, aux.plan, kind, count, W["u"],
+                        W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], W["contrib"][:n].view(B, S, D), G["Position.weight"],
+                        self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"])
+                main = torch.cuda.current_stream()
+                if not hasattr(self, "_side"):
+                    self._side = torch.cuda.Stream()
+                    self._tail = torch.zeros(4, dtype=torch.int32, device=self.device)
+                loss = ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=3)
+                self._side.wait_stream(main)
+                fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
+                self._adam_keep = fz
+                with torch.cuda.stream(self._side):
+                    ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=4, loss=loss, adam=fz)
+                self._table_adam(W["g_rows"].view(-1, D), W["keys"], aux, hyper=adam_hyper)
+                main.wait_stream(self._side)
+                ops.step_state(self._tail, 0, 1, 1e-3)          # (a graph that ends in a join of two branches replays slower: one trivial node behind it)
+                return loss, W["g_rows"].view(-1, D), W["keys"], True
             loss = ops.sasrec_encoder_step(E, Ppos.detach(), seq, pos, neg, float(D ** 0.5), self._block_tensors(), lw, lb, self.L, p, sd,
                                            aux.plan, kind, count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
                                            W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
@@ -221,8 +242,9 @@ class SASRecLargeTableEngine(SASRecEngine):
         z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
 
         def body():
-            loss, C, rows = self._grads(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state)
-            if with_adam:
+            out = self._grads(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, adam_hyper=hyper if with_adam else None)
+            loss, C, rows = out[:3]
+            if with_adam and len(out) == 3:     # (else: both optimizers ran inside the step's two branches)
                 self._table_adam(C, rows, pb, hyper=hyper)
                 ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
             return loss, C, rows

@@ -418,6 +418,8 @@ class SASRecEngine:
                     if getattr(self, "tail_node", True):
                         ops.step_state(self._tail_word(), 0, 1, 1e-3)     # (a graph that ENDS in a join of two branches replays slower: one trivial node behind it)
                     return loss, True
+                if adam_hyper is None and seed_dev is not None:           # (captured without its optimizer -- the data-parallel form: the graph would end in the join)
+                    ops.step_state(self._tail_word(), 0, 1, 1e-3)
                 return loss
             if self.fused_item_kernel and adam_hyper is not None and getattr(self, "fuse_adam", True):
                 # one queue: item kernels -> weight gradients -> reduction (+ the encoder slice's Adam) -> scatter-add (+ the table's Adam)
