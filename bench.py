@@ -429,8 +429,21 @@ def main():
     }
 
     if dist is not None and world > 1 and not args.no_c5:
-        # ---------------- BASELINE.json configs[4] as named: the 100 M-row table row-sharded over the ranks (every rank takes part)
+        # ---------------- BASELINE.json configs[4] as named: the 100 M-row table row-sharded over the ranks (every rank takes part).
+        # This leg's collectives run inside a captured graph on N > 1 ranks for the first time on the driver's node: if it has not come
+        # back after 5 minutes every rank gives it up -- rank 0 prints the line measured so far -- instead of hanging the run.
+        import threading
+        leg_done = threading.Event()
+
+        def give_up():
+            if not leg_done.wait(300.0):
+                if rank == 0:
+                    line["config5_sharded"] = {"skipped": "no result after 300 s: abandoned (the headline above was measured before this leg)"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        threading.Thread(target=give_up, daemon=True).start()
         c5s = bench_legs.config5_sharded(dist, rank, world, local)
+        leg_done.set()
         bad = torch.tensor([1 if "skipped" in c5s else 0], device="cuda")
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if int(bad) and "skipped" not in c5s:
