@@ -24,6 +24,7 @@ extern "C" int re_dbg_enc_marks_bwd(unsigned long long* out) {
 #endif
 
 #include "enc_bwd_item.h"
+#include "enc_tile_prep.h"
 
 template <int D>
 __global__ __launch_bounds__(512) void enc_bwd_k(const float* __restrict__ dIn, const int64_t* __restrict__ seq, int B, int S, int L,
@@ -64,7 +65,7 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
     const int64_t nwg = enc_slab_rows(B, S);   // upper bound of the launch grid (ncu), or one row per tile
     // (+ the weight-fragment planes of the wave-per-tile step, enc_wave.hip: L x 6 matrices x 2 orientations x 16 KB, 256-byte aligned)
     return (size_t)(nwg * L * EG_NVEC * D + enc_wgrad_part_floats(D, L) + enc_wgrad_ppart_floats(B, D) + L * EG_NMAT * NR * D) * sizeof(float) + 512 +
-           (size_t)L * 6 * 2 * 4096 * 4 + (size_t)(10 * L + 2) * 64 * 4 + 512 + (size_t)enc_plan_max_tiles(B, S) * (3 * 2 * 4 * 256) * 4 + 256;   // (+ the tiles' dK / dV inboxes)
+           enc_tile_wfrag_bytes(L, D) + 512 + enc_tile_xch_bytes(B, S, D) + 256;   // (+ the tiles' dK / dV inboxes)
 }
 
 // dPtab == NULL: dx0 [B,S,D] receives the gradient w.r.t. x0 (rows of real tokens only).  Otherwise re_sasrec_embed_bwd is fused in:

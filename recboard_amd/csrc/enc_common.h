@@ -99,7 +99,7 @@ __host__ __device__ inline EncPlan enc_plan_view(const void* plan, int64_t B, in
 // ---- tape (activations saved by the forward for the backward), fp32, indexed by COMPACT row (tile * 16 + r): an item's
 // rows are one contiguous block of every array.  Per block l:
 //   X, A = LN_a(x), Q, K, V, O, X1, Y = LN_f(x1), HR : [NR][D]     P : [NR][ROWS] (pre-dropout probabilities, item-local keys)
-//   SA, SF : [NR][2] (mean, rstd)   PP : [NR][2] (probability of one virtual pad key, total kept weight)   MK : [NR][16] mask words (enc_wave.hip)
+//   SA, SF : [NR][2] (mean, rstd)   PP : [NR][2] (probability of one virtual pad key, total kept weight)   MK : [NR][D / 4] mask words (enc_tile.hip)
 // then XL [NR][D] (input of lastLN) and SL [NR][2].  NR = 16 * MT.
 struct EncTape {
     int64_t per_block, off_X, off_A, off_Q, off_K, off_V, off_O, off_X1, off_Y, off_HR, off_P, off_SA, off_SF, off_PP, off_MK, off_XL, off_SL, off_FLAGS, total;
@@ -121,7 +121,7 @@ __host__ __device__ inline EncTape enc_tape_layout(int64_t B, int64_t S, int64_t
     t.off_SA = o; o += nr * 2;
     t.off_SF = o; o += nr * 2;
     t.off_PP = o; o += nr * 2;
-    t.off_MK = o; o += nr * 16;                                       // dropout / relu mask words of the wave-per-tile step (enc_wave.hip): [tile][4][64]
+    t.off_MK = o; o += nr * (D / 4);                                  // dropout / relu mask words of the one-tile-per-workgroup step (enc_tile.hip): [tile][D / 16 strips][64]
     t.per_block = o;
     t.off_XL = L * o;
     t.off_SL = t.off_XL + act;

@@ -75,7 +75,7 @@ struct PlLoss {
 
 struct PlWeights {   // optional extra work of the launch: the one-tile-per-workgroup step's weight fragments (enc_tile_prep.h); nblocks = 0: none
     SasrecParams P;
-    int L, nblocks;
+    int L, nblocks, ns;   // ns = D / 16
     uint32_t* wf;
     unsigned* epoch;
 };
@@ -91,7 +91,10 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
     if (blockIdx.x >= gridDim.x - WP.nblocks) {
         // ---- the tile kernel's weight fragments for this step (re_sasrec_batch_prep_w): the last workgroups of the grid
         const int t = (int)(blockIdx.x - (gridDim.x - WP.nblocks)) * PL_NT + tid;
-        if (t < TL_PREP_THREADS(WP.L)) tl_prep_thread(WP.P, WP.L, WP.wf, WP.epoch, t);
+        if (t < TLC_PREP_THREADS(WP.L, WP.ns)) {
+            if (WP.ns == 4) tl_prep_thread<4>(WP.P, WP.L, WP.wf, WP.epoch, t);
+            else tl_prep_thread<8>(WP.P, WP.L, WP.wf, WP.epoch, t);
+        }
         return;
     }
     if (blockIdx.x > 0) {
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 const int tshort = (rs + 15) >> 4;
                 // Sequences of 3 - 4 tiles SPLIT over two workgroups (kinds 2 / 3, enc_common.h) -- only if then every item of the
                 // plan still gets a workgroup of its own (the halves wait for each other: both must be resident)
-                int nsplit = split_long ? n0 + n1 : 0;
+                int nsplit = (split_long & 1) ? n0 + n1 : 0;
                 int G = 1, nshort = 0;
                 for (int attempt = 0; attempt < 2; ++attempt) {
                     int avail = ncu - nlong - nsplit;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 hdr[0] = nlong + nsplit + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = nsplit; hdr[6] = ncu;
                 // [7]: 1 = every tile can have a RESIDENT workgroup of its own (enc_tile.hip: a long sequence's tiles wait for each other
                 // across workgroups; they are laid out first, so they are the first `tlong` blocks of the grid)
-                hdr[7] = (nsplit == 0 && tlong + tshort <= 1024 && tlong <= 256) ? 1 : 0;
+                hdr[7] = (nsplit == 0 && tlong + tshort <= 1024 && tlong <= 256 && !(split_long & 2)) ? 1 : 0;   // (split_long & 2: the caller forbids it)
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;
                 // class k: s_cb[k] sequences in front of it, its rows start at s_r0[k]
                 int cb = 0, r0 = 0;
@@ -356,7 +359,7 @@ static int batch_prep_launch(const int64_t* seq, const int64_t* pos, const int64
     const bool elementwise = seq_out || valid || rows_all || pos_out;
     const unsigned grid = 1 + (elementwise ? re_grid(B * S, PL_NT, 256) : 0) + (unsigned)WP.nblocks;
     hipLaunchKernelGGL(sasrec_batch_prep_k, dim3(grid), dim3(PL_NT), 0, (hipStream_t)stream, seq, pos, neg, (int)B, (int)S, (int)ncu,
-                       (int)max_tiles, (int)(split_long != 0), seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib, WP, SP, LA);
+                       (int)max_tiles, (int)split_long, seq_out, pos_out, neg_out, valid, count, rows_all, (int*)plan, state, seed, ss, ib, WP, SP, LA);
     return re_launch_status();
 }
 
@@ -379,7 +382,7 @@ static int pl_fill_weights(PlWeights& WP, const float* const* block_params, cons
                            int64_t S, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes) {
     WP.nblocks = 0;
     if (!block_params) return RE_OK;
-    if (D != TL_D || !tape || !ws || B <= 0 || S <= 0 || S > 64) return RE_EUNSUPPORTED;
+    if (!enc_tile_width_ok(D) || !tape || !ws || B <= 0 || S <= 0 || S > 64) return RE_EUNSUPPORTED;
     if (!se_fill_params(WP.P, block_params, L, last_w, last_b)) return RE_EINVAL;
     if (tape_bytes < (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float) || ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L))
         return RE_EWORKSPACE;
@@ -388,9 +391,10 @@ static int pl_fill_weights(PlWeights& WP, const float* const* block_params, cons
     float* wpart = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
     float* gtape = wpart + enc_wgrad_part_floats(D, L) + enc_wgrad_ppart_floats(B, D);
     WP.L = (int)L;
-    WP.nblocks = (TL_PREP_THREADS((int)L) + PL_NT - 1) / PL_NT;
-    WP.wf = enc_tile_wf(gtape, B, S, L);
-    WP.epoch = enc_tile_epoch(tape, B, S, L);
+    WP.ns = (int)(D / 16);
+    WP.nblocks = (TLC_PREP_THREADS((int)L, WP.ns) + PL_NT - 1) / PL_NT;
+    WP.wf = enc_tile_wf(gtape, B, S, L, D);
+    WP.epoch = enc_tile_epoch(tape, B, S, L, D);
     return RE_OK;
 }
 

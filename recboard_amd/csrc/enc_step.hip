@@ -19,7 +19,7 @@ __global__ __launch_bounds__(512) void enc_step_k(SeEmbed em, const int64_t* __r
     extern __shared__ __align__(16) float lds[];
     const EncPlan PL = enc_plan_view(planp, B, S);
     const int n_items = PL.hdr[0];
-    if (D == 64 && PL.hdr[7] == 1) return;   // (the one-tile-per-workgroup kernel in front of this launch has run the step: enc_tile.hip)
+    if (PL.hdr[7] == 1) return;   // (the one-tile-per-workgroup kernel in front of this launch has run the step: enc_tile.hip)
     if (enc_split_plan_rejected(PL, tape + T.off_FLAGS, enc_plan_max_tiles(B, S) * EP_FLAG_WORDS, H.loss)) return;
     using C = EC<D>;
     __shared__ int h_gid[C::ROWS], h_first[C::ROWS], h_pad[C::ROWS], h_sid[C::ROWS], h_start[C::ROWS];
@@ -43,8 +43,8 @@ int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tap
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
-// ---- the four-waves-per-tile form of the step at D = 64 (enc_tile.hip)
-int enc_tile_step_launch(const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
+// ---- the one-tile-per-workgroup form of the step (enc_tile.hip: four waves per tile at D = 64, eight at D = 128)
+int enc_tile_step_launch(int64_t D, const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
                          uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
                          float* gtape, float* slab, float scale, uint32_t* wf, float* xch, int prep, hipStream_t s);
 
@@ -109,32 +109,26 @@ extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const floa
     float* ppart = wpart + enc_wgrad_part_floats(D, L);
     float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
     hipStream_t s = (hipStream_t)stream;
-    if (D == 64) {
+    {
         // one tile per workgroup (enc_tile.hip) when the plan says every tile can have a resident workgroup (hdr[7]); the workgroup-per-item
         // kernel is launched behind it and returns at once in that case -- the plan lives in device memory, so both are always enqueued
-        uint32_t* wf = enc_tile_wf(gtape, B, S, L);
-        float* xch = enc_tile_xch(wf, L);
+        uint32_t* wf = enc_tile_wf(gtape, B, S, L, D);
+        float* xch = enc_tile_xch(wf, L, D);
         const int tgrid = (int)(mt < 1024 ? mt : 1024);
         const int wgrid = (int)(mt < ncu ? mt : ncu);
         if (part & 1) {
-            const int rcw = enc_tile_step_launch(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, tgrid, H, dx0, gtape, slab, scale, wf, xch,
+            const int rcw = enc_tile_step_launch(D, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, tgrid, H, dx0, gtape, slab, scale, wf, xch,
                                                  frag_ready ? 0 : 1, s);
             if (rcw != RE_OK) return rcw;
         }
         if (part & 2) {
-            const int rco = enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, wgrid, H, dx0, gtape, slab, scale, s);
+            const int rco = D == 128 ? enc_step_launch_d<128>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, wgrid, H, dx0, gtape, slab, scale, s)
+                                     : enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, wgrid, H, dx0, gtape, slab, scale, s);
             if (rco != RE_OK) return rco;
         }
         if (!(part & 4)) return RE_OK;
         return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, wgrid, wpart, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, adam);
     }
-    if (part & 2) {
-        const int rc = D == 128 ? enc_step_launch_d<128>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s)
-                                : enc_step_launch_d<64>(em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape, slab, scale, s);
-        if (rc != RE_OK) return rc;
-    }
-    if (!(part & 4)) return RE_OK;
-    return enc_wgrad_launch(B, S, D, L, tape, gtape, plan, slab, grid, wpart, ppart, seq, dx0, scale, dPtab, block_grads, g_last_w, g_last_b, s, 0, adam);
 }
 
 extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,

@@ -9,32 +9,35 @@ typedef short tl_s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned tl_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned tl_u32x2 __attribute__((ext_vector_type(2)));
 
-#define TL_D 64
-#define TL_FRAG_WORDS 4096      // one (block, matrix, orientation): [strip 4][k step 2][plane 2][lane 64] x 16 bytes
+// sizes as functions of ns = strips of 16 features (D = 16 ns: 4 at D = 64, 8 at D = 128)
 #define TL_NPAR 10              // per block: 0 ln_a_w 1 ln_a_b 2 bq 3 bk 4 bv 5 bo 6 ln_f_w 7 ln_f_b 8 b1 9 b2
-// per tile, in floats: operand slots [3][2 planes][64 lanes][4 strips] x 8 B | partial score tiles (TL_RED) |
-// per-token partials [2][4 waves][16 tokens] x 16 B | transpose scratch [4 waves][16 x 20]
-#define TL_OB (3 * 2 * 64 * 4 * 2)
-#define TL_RED (2 * 4 * 64 * 16)   // partial score tiles [2][4 waves][64 lanes][4 key tiles] x 16 B
-#define TL_SM (2 * 4 * 16 * 4)
-#define TL_TR (4 * 320)
-#define TL_TILE_LDS (TL_OB + TL_RED + TL_SM + TL_TR)
-#define TL_XCH_TILE (3 * 2 * 4 * 256)   // floats of a key tile's inbox of partial dV / dK: [sender t - kt - 1][dV, dK][strip][4 registers][64 lanes]
+#define TLC_D(ns) (16 * (ns))
+#define TLC_NQ(ns) ((ns) / 2)
+#define TLC_FRAG_WORDS(ns) ((ns) * TLC_NQ(ns) * 2 * 64 * 4)   // one (block, matrix, orientation): [strip][k step][plane 2][lane 64] x 16 bytes
+// per tile, in floats: operand slots [3][2 planes][64 lanes][strips] x 8 B | partial score tiles | per-token partials [2][waves][16 tokens] x 16 B |
+// transpose scratch [waves][16 x 20]
+#define TLC_OB(ns) (3 * 2 * 64 * (ns) * 2)
+#define TLC_RED(ns) (2 * (ns) * 64 * 16)   // partial score tiles [2][waves][64 lanes][4 key tiles] x 16 B
+#define TLC_SM(ns) (2 * (ns) * 16 * 4)
+#define TLC_TR(ns) ((ns) * 320)
+#define TLC_TILE_LDS(ns) (TLC_OB(ns) + TLC_RED(ns) + TLC_SM(ns) + TLC_TR(ns))
+#define TLC_XCH_TILE(ns) (3 * 2 * (ns) * 256)   // floats of a key tile's inbox of partial dV / dK: [sender t - kt - 1][dV, dK][strip][4 registers][64 lanes]
+#define TLC_PREP_THREADS(L, ns) (6 * (L) * 2 * (ns) * TLC_NQ(ns) * 64)
 
-#define TL_PREP_THREADS(L) (6 * (L) * 1024)
-// (+ the small parameters of every block and lastLN as one block of (10 L + 2) x 64 floats behind the fragments)
-inline size_t enc_tile_wfrag_bytes(int64_t L) { return (size_t)L * 6 * 2 * TL_FRAG_WORDS * 4 + (size_t)(TL_NPAR * L + 2) * TL_D * 4; }
-inline size_t enc_tile_xch_bytes(int64_t B, int64_t S) { return (size_t)enc_plan_max_tiles(B, S) * TL_XCH_TILE * 4; }
+inline bool enc_tile_width_ok(int64_t D) { return D == 64 || D == 128; }
+// (+ the small parameters of every block and lastLN as one block of (10 L + 2) x D floats behind the fragments)
+inline size_t enc_tile_wfrag_bytes(int64_t L, int64_t D) { return (size_t)L * 6 * 2 * TLC_FRAG_WORDS(D / 16) * 4 + (size_t)(TL_NPAR * L + 2) * D * 4; }
+inline size_t enc_tile_xch_bytes(int64_t B, int64_t S, int64_t D) { return (size_t)enc_plan_max_tiles(B, S) * TLC_XCH_TILE(D / 16) * 4; }
 // where the fragments, the exchange inboxes and the launch epoch live: behind the gradient tape in the backward workspace / in the tape's flag area
-inline uint32_t* enc_tile_wf(float* gtape, int64_t B, int64_t S, int64_t L) {
-    return (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * 16 * enc_plan_max_tiles(B, S) * TL_D)) + 255) & ~(uintptr_t)255);
+inline uint32_t* enc_tile_wf(float* gtape, int64_t B, int64_t S, int64_t L, int64_t D) {
+    return (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * 16 * enc_plan_max_tiles(B, S) * D)) + 255) & ~(uintptr_t)255);
 }
-inline float* enc_tile_xch(uint32_t* wf, int64_t L) { return (float*)(((uintptr_t)wf + enc_tile_wfrag_bytes(L) + 255) & ~(uintptr_t)255); }
-inline unsigned* enc_tile_epoch(void* tape, int64_t B, int64_t S, int64_t L) {
-    const EncTape T = enc_tape_layout(B, S, TL_D, L);
+inline float* enc_tile_xch(uint32_t* wf, int64_t L, int64_t D) { return (float*)(((uintptr_t)wf + enc_tile_wfrag_bytes(L, D) + 255) & ~(uintptr_t)255); }
+inline unsigned* enc_tile_epoch(void* tape, int64_t B, int64_t S, int64_t L, int64_t D) {
+    const EncTape T = enc_tape_layout(B, S, D, L);
     return reinterpret_cast<unsigned*>((float*)tape + T.off_FLAGS) + enc_plan_max_tiles(B, S) * EP_FLAG_WORDS + 1;
 }
-__host__ __device__ inline size_t tl_lds_floats(int L) { return (size_t)(TL_NPAR * L + 2) * TL_D + (size_t)TL_TILE_LDS + 32; }
+__host__ __device__ inline size_t tl_lds_floats(int L, int ns) { return (size_t)(TL_NPAR * L + 2) * 16 * ns + (size_t)TLC_TILE_LDS(ns) + 32; }
 
 
 // ---- operand splits
@@ -49,8 +52,11 @@ __device__ __forceinline__ void tl_split2(float a, float b, unsigned& h, unsigne
 }
 
 // ---- weight preparation: fp32 [64][64] -> bf16 hi / mid fragment planes in the kernel's k order, both orientations ---------------------
-// thread t of 6 * L * 1024 (TL_PREP_THREADS): called by enc_tile_prep_k and by the batch preparation kernel's extra workgroups
+// thread t of TLC_PREP_THREADS(L, NS): called by enc_tile_prep_k and by the batch preparation kernel's extra workgroups
+template <int NS>
 __device__ __forceinline__ void tl_prep_thread(const SasrecParams& P, int L, uint32_t* __restrict__ wf, unsigned* __restrict__ epoch, int t) {
+    constexpr int TL_D = 16 * NS, NQ = NS / 2, LQ = NS == 4 ? 1 : 2, LS = NS == 4 ? 2 : 3;
+    constexpr int TL_FRAG_WORDS = TLC_FRAG_WORDS(NS);
     if (t == 0) epoch[0] += 1u;   // the launch's epoch: what this step's hand-over flags are set to (the step kernel runs behind this one)
     if (t < (TL_NPAR * L + 2) * TL_D) {   // the small parameters, gathered into one block (the step kernel then needs no parameter table)
         const int v = t / TL_D, cc = t % TL_D;
@@ -64,7 +70,7 @@ __device__ __forceinline__ void tl_prep_thread(const SasrecParams& P, int L, uin
         }
         reinterpret_cast<float*>(wf + (size_t)L * 6 * 2 * TL_FRAG_WORDS)[t] = p[cc];
     }
-    const int lane = t & 63, q = (t >> 6) & 1, s = (t >> 7) & 3, o = (t >> 9) & 1, lm = t >> 10;
+    const int lane = t & 63, q = (t >> 6) & (NQ - 1), s = (t >> (6 + LQ)) & (NS - 1), o = (t >> (6 + LQ + LS)) & 1, lm = t >> (7 + LQ + LS);
     if (lm >= 6 * L) return;
     const int l = lm / 6, m = lm % 6, c = lane & 15, g = lane >> 4;
     const SasrecBlockParams& W = P.blk[l];
@@ -82,7 +88,7 @@ __device__ __forceinline__ void tl_prep_thread(const SasrecParams& P, int L, uin
         tl_split2(v[0], v[1], h[p], md[p]);
     }
     tl_u32x4* dst = reinterpret_cast<tl_u32x4*>(wf + ((size_t)lm * 2 + o) * TL_FRAG_WORDS) + lane;
-    dst[((s * 2 + q) * 2 + 0) * 64] = (tl_u32x4){h[0], h[1], h[2], h[3]};
-    dst[((s * 2 + q) * 2 + 1) * 64] = (tl_u32x4){md[0], md[1], md[2], md[3]};
+    dst[((s * NQ + q) * 2 + 0) * 64] = (tl_u32x4){h[0], h[1], h[2], h[3]};
+    dst[((s * NQ + q) * 2 + 1) * 64] = (tl_u32x4){md[0], md[1], md[2], md[3]};
 }
 

@@ -284,7 +284,7 @@ def test_sharded_engine_on_one_rank_equals_large_table_engine():
             fx.table.check_capacity()
             assert torch.equal(ll, lf) and torch.equal(large.E, fx.table.weight) and torch.equal(large.arena.data, fx.arena.data), step
             lc = cl.train_step(*batch)
-            assert abs(float(lc) - float(ll)) <= 1e-6 * abs(float(ll)), step
+            assert abs(float(lc) - float(ll)) <= 5e-5 * abs(float(ll)), step     # (compact rows: the one-tile-per-workgroup kernels' split arithmetic)
             for eng in (dd, cs, cf):
                 le = eng.train_step(*batch)
                 assert abs(float(le) - float(lc)) <= 1e-6 * abs(float(lc)), step
