@@ -158,7 +158,7 @@ class SASRecLargeTableEngine(SASRecEngine):
                 if not hasattr(self, "_side"):
                     self._side = torch.cuda.Stream()
                     self._tail = torch.zeros(4, dtype=torch.int32, device=self.device)
-                loss = ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=3)
+                loss = ops.sasrec_encoder_step(*args, e_off=1, seed_dev=seed_dev, part=3 + (8 if getattr(aux, "weights_ready", False) else 0))
                 self._side.wait_stream(main)
                 fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
                 self._adam_keep = fz
@@ -171,7 +171,8 @@ class SASRecLargeTableEngine(SASRecEngine):
             loss = ops.sasrec_encoder_step(E, Ppos.detach(), seq, pos, neg, float(D ** 0.5), self._block_tensors(), lw, lb, self.L, p, sd,
                                            aux.plan, kind, count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"],
                                            W["contrib"][:n].view(B, S, D), G["Position.weight"], self._block_tensors(A.grad),
-                                           G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev)
+                                           G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev,
+                                           part=8 if getattr(aux, "weights_ready", False) else 0)
             return loss, W["g_rows"].view(-1, D), W["keys"]          # keys: int32 [3, NR], the plan's first rows of every region live
         if self.encoder == "fused":
             # the same launches as SASRecEngine's fused step, minus the dense scatter-add: fused embedding + encoder forward (tape),
@@ -255,7 +256,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step())
+                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), weights=self._prep_weights(B, S))
             pb.count.fill_(1)
             for _ in range(3):
                 body()
@@ -279,7 +280,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
                               beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
-                              loss_acc=self._take_pending_loss())
+                              weights=self._prep_weights(B, S), loss_acc=self._take_pending_loss())
         g["graph"].replay()
         A.step += 1
         if grad_hook is not None:

@@ -176,8 +176,8 @@ def test_one_launch_item_kernel_equals_two_launches(D, p):
     assert torch.equal(eng[0][0].arena.data, eng[1][0].arena.data)
 
 
-@pytest.mark.parametrize("loss,p,ncu", [("BCE", 0.5, None), ("BPR", 0.0, None), ("BCE", 0.3, 24)])
-def test_wave_per_tile_step_matches_oracle(loss, p, ncu):
+@pytest.mark.parametrize("loss,p,ncu,D", [("BCE", 0.5, None, 64), ("BPR", 0.0, None, 64), ("BCE", 0.3, 24, 64), ("BCE", 0.3, None, 128)])
+def test_wave_per_tile_step_matches_oracle(loss, p, ncu, D):
     """D = 64: re_sasrec_encoder_step runs four waves per tile (csrc/enc_tile.hip: activations in registers, bf16 hi / mid split products
     on the XDL pipe) -- against the CPU oracle with the same dropout masks: loss to 2e-5, every gradient to the 1e-4 bound; short
     sequences sharing tiles, sequences of 2 - 4 tiles (k, v and the partial dK, dV cross waves), a full-length batch, and (ncu = 24)
@@ -186,7 +186,7 @@ def test_wave_per_tile_step_matches_oracle(loss, p, ncu):
     from oracle import sasrec as osas
     from recboard_amd import ops
     from recboard_amd.sasrec import SASRecEngine
-    B, S, N, D, L = 96, 50, 700, 64, 2
+    B, S, N, L = 96, 50, 700, 2
     for i in range(3):
         seq, pos, neg = _batch(B, S, N, 30 + i, full=(i == 2))
         if i == 1:                       # a few sequences of every tile count next to the short ones
@@ -361,15 +361,16 @@ def test_sparse_adam_rows_small_matches_oracle(D, case):
     np.testing.assert_allclose(W2.cpu().numpy(), W, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("case", ["long_tiles_at_the_limit", "three_tile_chains", "singles_and_empties", "one_sequence", "maxlen_16", "maxlen_64"])
-def test_tile_kernel_agrees_with_the_fp32_item_kernels(case):
+def test_tile_kernel_agrees_with_the_fp32_item_kernels(case, D):
     """The one-tile-per-workgroup step (bf16 split products, hand-over flags between the workgroups of a long sequence) against the fp32
     workgroup-per-item kernels on batch compositions that stress the hand-over: as many long tiles as may be resident (256), chains of
     three tiles, single-token and empty rows, a batch of one, maxlen 16 (no chains at all) and 64 (four full tiles).  Loss to 2e-5, every
     gradient to 1e-4 of its largest entry; the plan must have chosen the tile kernel; no hand-over time-out."""
     from recboard_amd.sasrec import SASRecEngine
     rng = np.random.default_rng(17)
-    N, D, L, p = 900, 64, 2, 0.25
+    N, L, p = 900, 2, 0.25
     S = {"maxlen_16": 16, "maxlen_64": 64}.get(case, 50)
     if case == "long_tiles_at_the_limit":
         lens = [49] * 64 + list(rng.integers(1, 16, 120))                 # 64 x 4 = 256 long tiles + short ones
@@ -402,7 +403,9 @@ def test_tile_kernel_agrees_with_the_fp32_item_kernels(case):
                     q.copy_((0.05 * torch.randn(q.shape, generator=g)).cuda())
                 elif "LN" in k:
                     q.copy_((1.0 + 0.1 * torch.randn(q.shape, generator=g)).cuda())
-        m.fused_item_kernel = tile
+        m.tile_step = tile               # (off: the fp32 workgroup-per-item kernels, one launch at D = 128, two at D = 64)
+        if D == 64:
+            m.fused_item_kernel = tile
         m.split_long = False
         pb = m.prepare_batch(*batch)
         if tile:
