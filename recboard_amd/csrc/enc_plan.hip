@@ -16,17 +16,62 @@
 #define PL_NT 1024
 #define PL_NW (PL_NT / 64)
 #define PL_LDS_B 8192   // sequences whose span / placement fit the plan workgroup's LDS
-#define PL_NCLS 8   // 0..2: long sequences of 4 / 3 / 2 tiles; 3..7: slots of 16 / 8 / 4 / 2 / 1 rows
+#define PL_NCLS 19  // 0..2: long sequences of 4 / 3 / 2 tiles; 3 + (16 - span): short sequences by their EXACT span 16 .. 1
 
 __device__ __forceinline__ int pl_class(int span) {
     if (span > 48) return 0;
     if (span > 32) return 1;
     if (span > 16) return 2;
-    if (span > 8) return 3;
-    if (span > 4) return 4;
-    if (span > 2) return 5;
-    if (span > 1) return 6;
-    return 7;
+    return 3 + 16 - span;
+}
+
+// Where the short sequences go: COMPLEMENT PAIRING, level by level.  Rows are laid out as units of 16, then 8, then 4, 2, 1 rows.  A unit of
+// 16 holds one sequence of 9 .. 16 rows -- and, while there are any, one sequence of exactly the complement 16 - s behind it; what is
+// left of the sequences of 1 .. 7 rows goes on to the 8-row units (8, 7 + 1, 6 + 2, 5 + 3, or 5 .. 7 alone), then to the 4-row units
+// (4, 3 + 1, 3 alone), 2 and 1.  Power-of-two slots alone (the layout until round 3) waste a fifth of the rows of a Beauty-shaped batch
+// (293 tiles for 512 sequences); this lays the same batch into 244 (a perfect packing: 241), in closed form from the per-span counts.
+struct PlShort {
+    int off16[17], c16[8];   // unit index of the first span-s sequence among the 16-row units (s = 9 .. 16); complements taken at this level (t = 1 .. 7)
+    int off8[9], c8[4];      // the same for the 8-row units (s = 5 .. 8; t = 1 .. 3)
+    int off4[5], c4;         // 4-row units (s = 3, 4; t = 1)
+    int base16, base8, base4, base2, base1, end;   // first compact row of every level
+};
+__device__ __forceinline__ void pl_short_layout(const int* h /* [17]: sequences per span */, int row0, PlShort& P) {
+    int u = 0;
+    for (int s = 16; s >= 9; --s) { P.off16[s] = u; u += h[s]; }
+    const int U16 = u;
+    int h8[9];
+    h8[8] = h[8];
+    for (int t = 1; t <= 7; ++t) { P.c16[t] = h[16 - t] < h[t] ? h[16 - t] : h[t]; h8[t] = h[t] - P.c16[t]; }
+    u = 0;
+    for (int s = 8; s >= 5; --s) { P.off8[s] = u; u += h8[s]; }
+    const int U8 = u;
+    int h4[5];
+    h4[4] = h8[4];
+    for (int t = 1; t <= 3; ++t) { P.c8[t] = h8[8 - t] < h8[t] ? h8[8 - t] : h8[t]; h4[t] = h8[t] - P.c8[t]; }
+    P.off4[4] = 0; P.off4[3] = h4[4];
+    const int U4 = h4[4] + h4[3];
+    P.c4 = h4[3] < h4[1] ? h4[3] : h4[1];
+    P.base16 = row0;
+    P.base8 = P.base16 + 16 * U16;
+    P.base4 = P.base8 + 8 * U8;
+    P.base2 = P.base4 + 4 * U4;
+    P.base1 = P.base2 + 2 * h4[2];
+    P.end = P.base1 + (h4[1] - P.c4);
+}
+// first compact row of the short sequence of span s that is number r among the sequences of its span
+__device__ __forceinline__ int pl_short_row(const PlShort& P, int s, int r) {
+    if (s >= 9) return P.base16 + 16 * (P.off16[s] + r);
+    if (s == 8) return P.base8 + 8 * (P.off8[8] + r);
+    if (r < P.c16[s]) return P.base16 + 16 * (P.off16[16 - s] + r) + (16 - s);
+    r -= P.c16[s];
+    if (s >= 5) return P.base8 + 8 * (P.off8[s] + r);
+    if (s == 4) return P.base4 + 4 * (P.off4[4] + r);
+    if (r < P.c8[s]) return P.base8 + 8 * (P.off8[8 - s] + r) + (8 - s);
+    r -= P.c8[s];
+    if (s == 3) return P.base4 + 4 * (P.off4[3] + r);
+    if (s == 2) return P.base2 + 2 * r;
+    return r < P.c4 ? P.base4 + 4 * (P.off4[3] + r) + 3 : P.base1 + (r - P.c4);
 }
 
 // Barrier of the plan workgroup.  What crosses waves lives in LDS for batches of up to PL_LDS_B sequences: the barrier then only
@@ -153,7 +198,8 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
 #define PL_STAMP(i) do { } while (0)
 #endif
     __shared__ int s_cnt[PL_NCLS][PL_NW];
-    __shared__ int s_tot[PL_NCLS], s_base[PL_NCLS], s_lay[16], s_red[PL_NW], s_cb[PL_NCLS + 1], s_r0[PL_NCLS + 1], s_nsplit;
+    __shared__ int s_tot[PL_NCLS], s_base[PL_NCLS], s_lay[16], s_red[PL_NW], s_cb[4], s_nsplit;
+    __shared__ PlShort s_short;
     __shared__ unsigned char s_span[PL_LDS_B];
     __shared__ int s_place[PL_LDS_B];
     const int64_t mt = enc_plan_max_tiles(B, S);
@@ -221,13 +267,11 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
             if (tid == 0) {
                 const int n0 = s_tot[0], n1 = s_tot[1], n2 = s_tot[2];
                 const int nlong = n0 + n1 + n2, tlong = 4 * n0 + 3 * n1 + 2 * n2;
-                int ro[PL_NCLS];
-                ro[3] = 0;
-                ro[4] = ro[3] + 16 * s_tot[3];
-                ro[5] = ro[4] + 8 * s_tot[4];
-                ro[6] = ro[5] + 4 * s_tot[5];
-                ro[7] = ro[6] + 2 * s_tot[6];
-                const int rs = ro[7] + s_tot[7];
+                int hs[17];
+                hs[0] = 0;
+                for (int sp = 1; sp <= 16; ++sp) hs[sp] = s_tot[3 + 16 - sp];
+                pl_short_layout(hs, 16 * tlong, s_short);
+                const int rs = s_short.end - 16 * tlong;
                 const int tshort = (rs + 15) >> 4;
                 // Sequences of 3 - 4 tiles SPLIT over two workgroups (kinds 2 / 3, enc_common.h) -- only if then every item of the
                 // plan still gets a workgroup of its own (the halves wait for each other: both must be resident)
@@ -247,20 +291,12 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 s_lay[0] = nlong; s_lay[1] = tlong; s_lay[2] = tshort; s_lay[3] = G; s_lay[4] = nshort;
                 s_lay[5] = 0; s_lay[6] = 4 * n0; s_lay[7] = 4 * n0 + 3 * n1;                 // first tile of the long classes
                 s_lay[8] = 0; s_lay[9] = n0; s_lay[10] = n0 + n1;                            // first item of the long classes
-                for (int k = 3; k < PL_NCLS; ++k) s_lay[8 + k] = 16 * tlong + ro[k];         // first compact row of the slot classes
                 hdr[0] = nlong + nsplit + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = nsplit; hdr[6] = ncu;
                 // [7]: 1 = every tile can have a RESIDENT workgroup of its own (enc_tile.hip: a long sequence's tiles wait for each other
                 // across workgroups; they are laid out first, so they are the first `tlong` blocks of the grid)
                 hdr[7] = (nsplit == 0 && tlong + tshort <= 1024 && tlong <= 256 && !(split_long & 2)) ? 1 : 0;   // (split_long & 2: the caller forbids it)
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;
-                // class k: s_cb[k] sequences in front of it, its rows start at s_r0[k]
-                int cb = 0, r0 = 0;
-                for (int k = 0; k < PL_NCLS; ++k) {
-                    s_cb[k] = cb; s_r0[k] = r0;
-                    cb += s_tot[k];
-                    r0 += s_tot[k] * (k < 3 ? 16 * (4 - k) : (16 >> (k - 3)));
-                }
-                s_cb[PL_NCLS] = cb; s_r0[PL_NCLS] = r0;
+                s_cb[0] = 0; s_cb[1] = n0; s_cb[2] = n0 + n1; s_cb[3] = nlong;       // long class k: s_cb[k] long sequences in front of it
             }
             pl_sync(in_lds);
         }
@@ -288,8 +324,9 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                         items[s_cb[cls] + rank] = t0 | (nt << 24) | (1 << 28);
                     }
                 }
-                // the sequences sorted by class, then rank: sorted index -> sequence (rows are laid out in this order)
-                if (in_lds) s_place[s_cb[cls] + rank] = b; else g_place[s_cb[cls] + rank] = b;
+                // the sequence's first compact row: a long sequence owns the tiles of its item, a short one its place among the units
+                const int row = cls < 3 ? 16 * (s_lay[5 + cls] + (4 - cls) * rank) : pl_short_row(s_short, span, rank);
+                if (in_lds) s_place[b] = row; else g_place[b] = row;
             }
             pl_sync(in_lds);
             if (tid < PL_NCLS) {
@@ -309,24 +346,15 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
         const int nt = (tshort - t0) < G ? (tshort - t0) : G;
         items[nlong + s_nsplit + i] = (tlong + t0) | (nt << 24);
     }
-    // (a thread per compact row: coalesced stores.  Row -> class by the class row ranges, -> rank and offset inside the slot,
-    //  -> sequence through the sorted index)
+    // every compact row exactly once: all rows of the plan's tiles are dummies first (coalesced), then every sequence writes the rows of
+    // its span behind the barrier (a lane per row, eight sequences per wave-instruction: the map is 8 bytes per row, ~4 000 rows)
     const int nrows_all = 16 * (tlong + tshort);
-    for (int r = tid; r < nrows_all; r += PL_NT) {
-        int2 out = make_int2(-1, 0);
-        if (r < s_r0[PL_NCLS]) {
-            int k = 0;
-#pragma unroll
-            for (int q = 1; q < PL_NCLS; ++q) k += (r >= s_r0[q]) ? 1 : 0;
-            const int rel = r - s_r0[k];
-            int rank, off;
-            if (k == 1) { rank = rel / 48; off = rel - 48 * rank; }
-            else { const int sh = (k == 0) ? 6 : (k == 2) ? 5 : 7 - k; rank = rel >> sh; off = rel & ((1 << sh) - 1); }
-            const int b = in_lds ? s_place[s_cb[k] + rank] : g_place[s_cb[k] + rank];
-            const int span = in_lds ? (int)s_span[b] : g_span[b];
-            if (off < span) out = make_int2(b * S + (S - span) + off, S - span);
-        }
-        rowmap[r] = out;
+    for (int r = tid; r < nrows_all; r += PL_NT) rowmap[r] = make_int2(-1, 0);
+    __syncthreads();   // (with vmcnt(0): the dummies are in place before the real rows overwrite them)
+    for (int b0 = (tid >> 3); b0 < B; b0 += PL_NT / 8) {
+        const int span = in_lds ? (int)s_span[b0] : g_span[b0];
+        const int row = in_lds ? s_place[b0] : g_place[b0];
+        for (int off = tid & 7; off < span; off += 8) rowmap[row + off] = make_int2(b0 * S + (S - span) + off, S - span);
     }
 #ifdef ENC_PROFILE
     PL_STAMP(3);
