@@ -15,6 +15,7 @@
 
 #define PL_NT 1024
 #define PL_NW (PL_NT / 64)
+#define PL_SIF 16          // sequences a wave of the plan workgroup has in flight while it looks for their first real token
 #define PL_LDS_B 8192   // sequences whose span / placement fit the plan workgroup's LDS
 #define PL_NCLS 19  // 0..2: long sequences of 4 / 3 / 2 tiles; 3 + (16 - span): short sequences by their EXACT span 16 .. 1
 
@@ -234,15 +235,15 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
     } else
-    for (int b0 = wave * 16; b0 < B; b0 += PL_NW * 16) {
-        int64_t v[16];
+    for (int b0 = wave * PL_SIF; b0 < B; b0 += PL_NW * PL_SIF) {   // (PL_SIF sequences in flight per wave: 32 in flight was measured: no faster)
+        int64_t v[PL_SIF];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {   // (clamped, unconditional: a predicated load is waited for on the spot)
+        for (int q = 0; q < PL_SIF; ++q) {   // (clamped, unconditional: a predicated load is waited for on the spot)
             const int b = b0 + q < B ? b0 + q : B - 1;
             v[q] = seq[(int64_t)b * S + (lane < S ? lane : S - 1)];
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < PL_SIF; ++q) {
             const unsigned long long m = __ballot(lane < S && v[q] != 0);
             const int first = m ? __builtin_ctzll(m) : S - 1;
             if (lane == 0 && b0 + q < B) {
