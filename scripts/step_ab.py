@@ -2,6 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from recboard_amd import lib
+if os.environ.get("RECENGINE_LIB"):          # (an experimental build of the library: make a variant .so next to librecengine.so)
+    lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), os.environ["RECENGINE_LIB"])
 import bench
 from recboard_amd.sasrec import SASRecEngine
 cfg = bench.BEAUTY
