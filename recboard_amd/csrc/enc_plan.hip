@@ -295,9 +295,9 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
                 hdr[0] = nlong + nsplit + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = nsplit; hdr[6] = ncu;
                 // [7]: 1 = every tile can have a RESIDENT workgroup of its own (enc_tile.hip: a long sequence's tiles wait for each other
                 // across workgroups; they are laid out first, so they are the first `tlong` blocks of the grid)
-                // (split_long & 2: the caller forbids it; & 4: the kernel holds ONE workgroup per CU -- D = 128 -- so the long tiles get three
-                //  quarters of the CUs at most: a CU busy with somebody else's kernel must not leave a hand-over partner waiting for a slot)
-                const int tl_cap = (split_long & 4) ? (ncu < 256 ? ncu : 256) * 3 / 4 : 256;
+                // (split_long & 2: the caller forbids it.  The tile kernels hold ONE workgroup per CU, so the long tiles get three quarters of
+                //  the CUs at most: a CU busy with somebody else's kernel must not leave a hand-over partner waiting for a slot)
+                const int tl_cap = (ncu < 256 ? ncu : 256) * 3 / 4;
                 hdr[7] = (nsplit == 0 && tlong + tshort <= 1024 && tlong <= tl_cap && !(split_long & 2)) ? 1 : 0;
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;
                 s_cb[0] = 0; s_cb[1] = n0; s_cb[2] = n0 + n1; s_cb[3] = nlong;       // long class k: s_cb[k] long sequences in front of it

@@ -256,7 +256,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), wide=self.D == 128, weights=self._prep_weights(B, S))
+                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), weights=self._prep_weights(B, S))
             pb.count.fill_(1)
             for _ in range(3):
                 body()
@@ -279,7 +279,7 @@ class SASRecLargeTableEngine(SASRecEngine):
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), wide=self.D == 128,
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
                               weights=self._prep_weights(B, S), loss_acc=self._take_pending_loss())
         g["graph"].replay()
         A.step += 1
@@ -523,7 +523,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up with an all-padding batch: every lookup is the padding row, no table row changes
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), wide=self.D == 128)
+                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step())
             pb.count.fill_(1)
             for _ in range(3):
                 self._sharded_body(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, hyper=hyper)
@@ -557,7 +557,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             self._graphs[key] = self._capture(B, S)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), wide=self.D == 128,
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
                               loss_acc=self._take_pending_loss())
         sd = self._step_seed()
         g["graph"].replay()

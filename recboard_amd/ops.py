@@ -430,7 +430,7 @@ def prep_views(blob, B, S, cached=False):
 
 
 def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4, split=False,
-                      ncu=None, weights=None, loss_acc=None, tile=True, wide=False):
+                      ncu=None, weights=None, loss_acc=None, tile=True):
     """Batch preparation as ONE launch (re_sasrec_batch_prep): valid mask, count, scatter destination rows, the encoder's work plan;
     with `blob` (a static buffer of prep_layout(B, S) bytes) also copies (seq, pos, neg) into it and, with `state` (int32[4]),
     writes the step scalars -- the staging launch of a captured step.  -> PreparedBatch (views into the blob).
@@ -441,7 +441,7 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     fragments in `ws` (re_sasrec_batch_prep_w); the PreparedBatch then says `weights_ready` and sasrec_encoder_step skips its own.
     loss_acc = (prev_loss[1], acc[1], weight): acc += prev_loss * weight inside this launch (the previous step's loss into an epoch sum).
     tile=False: the plan never hands the training step to the one-tile-per-workgroup kernels (the workgroup-per-item kernels run it).
-    wide (D = 128: one tile workgroup per CU): fewer tiles of long sequences are allowed before the plan falls back."""
+    (The tile kernels hold one workgroup per CU: more than 3/4 x ncu tiles of long sequences make the plan fall back as well.)"""
     _req(seq, torch.int64, "seq")
     B, S = seq.shape
     if pos is not None:
@@ -453,7 +453,7 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     if state is not None:
         _req(state, torch.int32, "state")
     have = pos is not None
-    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), int(bool(split)) | (0 if tile else 2) | (4 if wide else 0),
+    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), int(bool(split)) | (0 if tile else 2),
             _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None, _p(pb.neg) if copy and have else None,
             _p(pb.valid) if have else None, _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
             _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2))
@@ -484,7 +484,7 @@ def _loss_args(loss_acc):
 
 
 def sasrec_sample_prep(inter, order, b0, B, S, sample_seed, sample_step, blob, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999,
-                       max_tiles=4, split=False, ncu=None, weights=None, users=None, loss_acc=None, tile=True, wide=False):
+                       max_tiles=4, split=False, ncu=None, weights=None, users=None, loss_acc=None, tile=True):
     """SAMPLE + PREPARE as one launch (re_seq_train_sample_prep): rows b0 .. b0 + B of the epoch's user order `order`, sampled as
     recboard_amd.sampler.seq_train_sample would, written straight into the staging `blob` with everything sasrec_batch_prep derives.
     inter: recboard_amd.sampler.DeviceInteractions.  -> PreparedBatch (views into the blob)."""
@@ -494,7 +494,7 @@ def sasrec_sample_prep(inter, order, b0, B, S, sample_seed, sample_step, blob, s
     wargs = _weight_args(weights) + _loss_args(loss_acc)
     lib.check(lib.load().re_seq_train_sample_prep(_p(inter.ptr), _p(inter.items), _p(inter.sorted), _p(order), order.numel(), int(b0), inter.num_items,
                                                   int(sample_seed) & 0xFFFFFFFF, int(sample_step) & 0xFFFFFFFF, _p(users), B, S,
-                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2) | (4 if wide else 0), _p(pb.seq), _p(pb.pos),
+                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2), _p(pb.seq), _p(pb.pos),
                                                   _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel(), _p(state),
                                                   int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), *wargs, _stream()),
               "re_seq_train_sample_prep")

@@ -301,7 +301,7 @@ class SASRecEngine:
         3*B*S gradient contributions, work items.  No host sync.  -> ops.PreparedBatch.
         for_next_step: the launch also prepares the weights of the step (re_sasrec_batch_prep_w) -- the batch must then go into the very
         next step, before anything else changes the parameters."""
-        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), wide=self.D == 128, ncu=self._plan_ncu(),
+        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(),
                                      weights=self._prep_weights(*seq.shape) if for_next_step else None)
 
     def check_handover(self):
@@ -541,7 +541,7 @@ class SASRecEngine:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), wide=self.D == 128, ncu=self._plan_ncu(),
+                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(),
                                        weights=self._prep_weights(B, S) if in_prep else None)
             body()
         torch.cuda.current_stream().wait_stream(side)
@@ -558,7 +558,7 @@ class SASRecEngine:
         B, S = seq.shape
         sd = (self.seed * 0x9E3779B1 + step * 0x85EBCA77) & 0xFFFFFFFF          # (= _step_seed() once arena.step == step - 1)
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=sd, step=step, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), wide=self.D == 128, ncu=self._plan_ncu(),
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(),
                               weights=self._prep_weights(B, S) if g["in_prep"] else None, loss_acc=self._take_pending_loss())
 
     # ---- the epoch's loss sum without a launch per step: between begin_ and end_loss_accumulation every captured step's loss is added
@@ -661,7 +661,7 @@ class SASRecEngine:
         g = self._graphs[key]
         ops.sasrec_sample_prep(ticket.inter, ticket.order, ticket.b0, B, S, ticket.seed, ticket.step, g["blob"], state=g["state"],
                                seed=self._step_seed(), step=A.step + 1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                               max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), wide=self.D == 128, ncu=self._plan_ncu(),
+                               max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(),
                                weights=self._prep_weights(B, S) if g["in_prep"] else None, users=ticket.users, loss_acc=self._take_pending_loss())
         g["graph"].replay()
         A.step += 1

@@ -373,9 +373,9 @@ def test_tile_kernel_agrees_with_the_fp32_item_kernels(case, D):
     N, L, p = 900, 2, 0.25
     S = {"maxlen_16": 16, "maxlen_64": 64}.get(case, 50)
     if case == "long_tiles_at_the_limit":
-        lens = [49] * (64 if D == 64 else 48) + list(rng.integers(1, 16, 120))    # 64 x 4 = 256 long tiles (D = 128: 48 x 4 = 192, its limit) + short ones
+        lens = [49] * 48 + list(rng.integers(1, 16, 120))                 # 48 x 4 = 192 long tiles (the limit: 3/4 of the CUs) + short ones
     elif case == "three_tile_chains":
-        lens = [int(x) for x in rng.integers(33, 49, 85 if D == 64 else 64)] + list(rng.integers(1, 17, 215))   # (255 / 192 long tiles)
+        lens = [int(x) for x in rng.integers(33, 49, 64)] + list(rng.integers(1, 17, 215))   # (192 long tiles)
     elif case == "singles_and_empties":
         lens = [1] * 150 + [0] * 20 + [2] * 30 + [17] * 5
     elif case == "one_sequence":
