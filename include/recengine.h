@@ -133,6 +133,18 @@ int re_scatter_add_rows_small(const float* g, const int32_t* keys, int32_t n_reg
 int re_scatter_adam_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
                                int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
                                const re_adam_fuse* adam, re_stream_t stream);
+/* The tail of a D = 64 SASRec training step as one launch + the reduction: re_scatter_adam_rows_small (or, table_adam NULL,
+ * re_scatter_add_rows_small; scale 1, n from n_dev) over the step's contribution rows, whose 1024-thread workgroups then take the jobs of
+ * re_sasrec_encoder_step_part(part = 4) -- the weight gradients of the encoder from the tape the item kernels left in `tape` / `ws` -- from
+ * a ticket counter; enc_adam (optional) as there.  Both halves depend on the item kernels alone: one queue, no fork and join around them
+ * (csrc/enc_tail.hip).  Results bit-identical to the two calls.  `ticket`: one zero-initialised uint32 of the caller's, left zero.
+ * Replaces: embedding_dense_backward of the item table + the autograd weight gradients of SASRec/main.py:170-197's blocks + the optimizer
+ * step over both (SASRec/main.py:249-252). */
+int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev, int32_t n_mul,
+                        int64_t R, int64_t padding_idx, float* dW, const re_adam_fuse* table_adam, const int64_t* seq, int64_t B, int64_t S,
+                        int64_t D, int64_t L, const void* plan, int32_t ncu, const void* tape, size_t tape_bytes, const float* dx0,
+                        float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
+                        const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream);
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                         int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,

@@ -1,0 +1,109 @@
+// The tail of the D = 64 SASRec training step as ONE launch + the reduction: the item table's scatter-add (+ its Adam) and the encoder's
+// weight-gradient jobs both depend on the item kernels alone.  As two graph branches (round 3's first form) the fork and the join cost more than
+// half of what the overlap saved (timeline of a captured step: the second branch started 13 us behind the item kernels, the node behind the join
+// 10 us behind the branches' end).  Here the scatter-add's 1024-thread workgroups (scatter_owner.h: all but the Zipf head's owner are done in
+// about half the launch) go on with the weight-gradient jobs (enc_wgrad_job.h), two at a time in their two halves, handed out by a ticket counter
+// -- the workgroup with the hot row never gets to take one.  Results: those of re_scatter_adam_rows_small and re_sasrec_encoder_step_part(part =
+// 4), bit for bit (a job's partial does not depend on who computes it; the reduction adds the partials in split order).
+#include "enc_wgrad_job.h"
+#include "scatter_owner.h"
+
+struct TailJobs {
+    const float* tape;
+    EncTape T;
+    const float* gtape;
+    int64_t NR;
+    const void* plan;
+    int B, S, L;
+    float* part;
+    const int64_t* seq;
+    const float* contrib;
+    float* ppart;        // nullptr: no position-table gradient
+    unsigned* ticket;    // zero at launch; enc_grad_reduce_k (the next launch) zeroes it again
+};
+
+template <int D, int HS>
+__global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
+                                                    const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
+                                                    int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J) {
+    extern __shared__ __align__(16) float lds[];
+    so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds);
+    // ---- weight-gradient jobs, two per ticket: matrix jobs q = 2 t + half -> (block, matrix, split) = (q / 144, q / 24 % 6, q % 24), then the
+    //      position-table jobs (144 strides of the (position, chunk) list) -- both halves of a workgroup always run the same kind
+    __shared__ int s_job;
+    const int tid = threadIdx.x, half = tid >> 9, ht = tid & 511;
+    float* jl = lds + half * wg_job_lds_floats<D>();
+    constexpr int PER_PLANE = WG_NSPLIT * EG_NMAT;
+    const int n_mat = J.L * PER_PLANE / 2, n_pos = J.ppart ? PER_PLANE / 2 : 0;
+    const int n_tiles = enc_plan_view(J.plan, J.B, J.S).hdr[1];
+    for (;;) {
+        __syncthreads();   // (the accumulators / the previous job's stages are done with)
+        if (tid == 0) s_job = (int)atomicAdd(J.ticket, 1u);
+        __syncthreads();
+        const int t = s_job;
+        if (t >= n_mat + n_pos) break;
+        if (t < n_mat) {
+            const int q = 2 * t + half;
+            wg_matrix_job<D>(ht, jl, q / PER_PLANE, (q / WG_NSPLIT) % EG_NMAT, q % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
+        } else {
+            wg_pos_job<D>(ht, jl, 2 * (t - n_mat) + half, PER_PLANE, J.B, J.S, J.seq, J.contrib, J.ppart);
+        }
+    }
+}
+
+size_t enc_wgrad_part_floats(int64_t D, int64_t L);
+size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
+extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
+int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
+                           const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
+                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket);
+
+extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev, int32_t n_mul,
+                                   int64_t R, int64_t padding_idx, float* dW, const re_adam_fuse* table_adam, const int64_t* seq, int64_t B,
+                                   int64_t S, int64_t D, int64_t L, const void* plan, int32_t ncu, const void* tape, size_t tape_bytes,
+                                   const float* dx0, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
+                                   void* ws, size_t ws_bytes, const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream) {
+    re_clear_error();
+    if (B == 0) return RE_OK;
+    if (!g || !keys || !n_dev || !seq || !plan || !tape || !dx0 || !block_grads || !g_last_w || !g_last_b || !ws || !ticket || (!dW && !table_adam) ||
+        R <= 0 || B < 0 || n_regions < 1 || n_regions > 4 || region_stride < 0 || n_mul < 1)
+        return RE_EINVAL;
+    if (D != 64 || S < 1 || S > 64 || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
+    if (table_adam && (!table_adam->param || !table_adam->m || !table_adam->v || !table_adam->hyper)) return RE_EINVAL;
+    SoAdam AD{};
+    if (table_adam)
+        AD = SoAdam{table_adam->param, table_adam->m, table_adam->v, table_adam->hyper, (float)table_adam->beta1, (float)table_adam->beta2,
+                    (float)(1.0 - table_adam->beta1), (float)(1.0 - table_adam->beta2), (float)table_adam->eps, (float)table_adam->weight_decay};
+    if ((region_stride & 3) || ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dW) |
+                                 reinterpret_cast<uintptr_t>(AD.W) | reinterpret_cast<uintptr_t>(AD.m) | reinterpret_cast<uintptr_t>(AD.v)) & 15u))
+        return RE_EUNSUPPORTED;
+    if ((int64_t)n_regions * region_stride >= (1ll << 25)) return RE_EUNSUPPORTED;
+    if (tape_bytes < (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float) || ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L))
+        return RE_EWORKSPACE;
+    for (int64_t i = 0; i < 12 * L; ++i)
+        if (!block_grads[i]) return RE_EINVAL;
+    constexpr int HS = 2;
+    const int rpw = 96;                            // (scatter.hip: scatter_small_launch)
+    int64_t nwg = HS;
+    while (nwg * rpw < R * HS) nwg *= 2;
+    if (nwg > 4096) return RE_EUNSUPPORTED;
+    const size_t lds_scatter = (size_t)SO_NG * rpw * (D / HS) * sizeof(float), lds_jobs = (size_t)2 * wg_job_lds_floats<64>() * sizeof(float);
+    const size_t ldsb = lds_scatter > lds_jobs ? lds_scatter : lds_jobs;
+    // the workspace as re_sasrec_encoder_step_part lays it out
+    if (ncu < 1) ncu = 256;
+    const int64_t mt = enc_plan_max_tiles(B, S);
+    const int wgrid = (int)(mt < ncu ? mt : ncu);
+    float* slab = (float*)ws;
+    float* wpart = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
+    float* ppart = wpart + enc_wgrad_part_floats(D, L);
+    float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
+    const TailJobs J{(const float*)tape, enc_tape_layout(B, S, D, L), gtape, 16 * mt, plan, (int)B, (int)S, (int)L, wpart, seq, dx0,
+                     dPtab ? ppart : nullptr, ticket};
+    hipStream_t s = (hipStream_t)stream;
+    auto k = enc_tail_k<64, HS>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, (int64_t)0, R, rpw,
+                       padding_idx, 1.0f, dW, AD, J);
+    if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
+    return enc_grad_reduce_launch(B, S, D, L, plan, slab, wgrid, wpart, ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam, ticket);
+}

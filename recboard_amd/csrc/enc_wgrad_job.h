@@ -1,0 +1,141 @@
+// The two kinds of jobs of the encoder's weight-gradient launch, as device functions of a GROUP of EC<D>::NT = 512 threads: enc_wgrad_k
+// (enc_wgrad.hip) runs one job per workgroup; enc_tail_k (enc_tail.hip) runs them two at a time in the halves of the 1024-thread workgroups
+// that have finished the item table's scatter-add.  Every barrier is workgroup-wide, so a job's barrier count depends on the launch's shapes
+// only (never on the job): groups that run different jobs of one kind side by side stay in step.
+#pragma once
+#include "enc_common.h"
+
+#define WG_NSPLIT 24
+#define WG_CH 4   // row tiles per LDS stage
+
+template <int D>
+__host__ __device__ constexpr int wg_job_lds_floats() { return 2 * 16 * WG_CH * EC<D>::LS; }
+
+// dW partial of (block l, matrix m, row split): out[D][D] = sum over the split's row tiles of dY^T X.   tid: 0 .. 511 within the group.
+//   gradient-tape order: 0 dO2 (x HR -> W2)  1 dH (x Y -> W1)  2 dX1 (x O -> Wo)  3 dQ (x A -> Wq)  4 dK (x X -> Wk)  5 dV (x X -> Wv)
+template <int D>
+__device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m, int split, const float* __restrict__ tape, const EncTape& T,
+                                              const float* __restrict__ gtape, int64_t NR, int n_tiles, float* __restrict__ part) {
+    using C = EC<D>;
+    constexpr int RTW = C::NS / C::WR;   // output row tiles per wave
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = wave % C::NS, wr = wave / C::NS, g = lane >> 4, c = lane & 15;
+    const int per = (n_tiles + WG_NSPLIT - 1) / WG_NSPLIT;
+    const int trips = (per + WG_CH - 1) / WG_CH;      // (the same for every split: the last ones run short or empty stages)
+    const int t0 = split * per;
+    const int t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    const int64_t xoff = (m == 0) ? T.off_HR : (m == 1) ? T.off_Y : (m == 2) ? T.off_O : (m == 3) ? T.off_A : T.off_X;
+    const float* X = tape + (int64_t)l * T.per_block + xoff;
+    const float* dY = gtape + ((int64_t)l * EG_NMAT + m) * NR * D;
+    float* bufA = lds;
+    float* bufB = lds + 16 * WG_CH * C::LS;
+    f32x4 acc[RTW];
+#pragma unroll
+    for (int t = 0; t < RTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // stages of WG_CH row tiles through LDS; the next stage's rows are requested into registers before this stage's products
+    // (every stage is a memory round trip: four of them in a row were most of the launch)
+    constexpr int NQ = 16 * WG_CH * (D / 4) / C::NT;
+    f32x4 ra[NQ], rb[NQ];   // (native vectors and a macro: HIP's float4 struct arrays / arrays captured by a lambda stay in scratch memory)
+#define WG_FETCH(TC)                                                                                            \
+    do {                                                                                                        \
+        const int ntc_ = (t1 - (TC)) < WG_CH ? (t1 - (TC)) : WG_CH;                                             \
+        const int nf_ = 16 * ntc_ * (D / 4);                                                                    \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                        \
+            int f = q * C::NT + tid;                                                                            \
+            f = f < nf_ ? f : nf_ - 1;   /* clamped, unconditional: a predicated load is waited for on the spot */ \
+            ra[q] = reinterpret_cast<const f32x4*>(dY + (int64_t)(TC) * 16 * D)[f];                             \
+            rb[q] = reinterpret_cast<const f32x4*>(X + (int64_t)(TC) * 16 * D)[f];                              \
+        }                                                                                                       \
+    } while (0)
+    if (t0 < t1) WG_FETCH(t0);
+    for (int it = 0; it < trips; ++it) {
+        const int tc = t0 + it * WG_CH;
+        const int left = t1 - tc;
+        const int ntc = left < WG_CH ? (left > 0 ? left : 0) : WG_CH;
+        const int nf = 16 * ntc * (D / 4);
+        enc_sync();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int f = q * C::NT + tid;
+            if (f < nf) {
+                const int r = f / (D / 4), c4 = f % (D / 4);
+                *reinterpret_cast<f32x4*>(bufA + r * C::LS + 4 * c4) = ra[q];
+                *reinterpret_cast<f32x4*>(bufB + r * C::LS + 4 * c4) = rb[q];
+            }
+        }
+        if (tc + WG_CH < t1) WG_FETCH(tc + WG_CH);
+        enc_sync();
+        for (int q = 0; q < ntc; ++q) {
+            float bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = bufB[(16 * q + 4 * g + i) * C::LS + 16 * strip + c];
+#pragma unroll
+            for (int t = 0; t < RTW; ++t) {
+                const int mt = t * C::WR + wr;
+                float af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = bufA[(16 * q + 4 * g + i) * C::LS + 16 * mt + c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#undef WG_FETCH
+    float* out = part + (((int64_t)l * EG_NMAT + m) * WG_NSPLIT + split) * D * D;
+#pragma unroll
+    for (int t = 0; t < RTW; ++t) {
+        const int mt = t * C::WR + wr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(16 * mt + 4 * g + j) * D + 16 * strip + c] = acc[t][j];
+    }
+}
+
+// Position-table gradient, partial sums: job (p, chunk of 64 sequences) -> ppart[p][chunk][D] = sum over the chunk's sequences with a real
+// token at p of contrib[b][p]  (every load independent: one memory round trip per job).  This group takes jobs j0, j0 + jstep, ...
+template <int D>
+__device__ __forceinline__ void wg_pos_job(int tid, float* lds, int j0, int jstep, int B, int S, const int64_t* __restrict__ seq,
+                                           const float* __restrict__ contrib, float* __restrict__ ppart) {
+    using C = EC<D>;
+    const int nch = (B + 63) / 64, njobs = S * nch;
+    const int trips = (njobs + jstep - 1) / jstep;    // (the same for every j0)
+    const int col = tid % D, rg = tid / D;
+    // (the next job's loads are in flight while this one is reduced: a group has ~3 jobs, each a memory round trip)
+    constexpr int NQP = 64 / C::CG;
+    int64_t sv[NQP], svn[NQP];
+    float cv[NQP], cvn[NQP];
+#define WG_PJOB(J, SV, CV)                                                              \
+    do {                                                                                \
+        const int p_ = (J) / nch, ch_ = (J) % nch;                                      \
+        _Pragma("unroll") for (int q = 0; q < NQP; ++q) {                               \
+            int b = ch_ * 64 + rg + C::CG * q;                                          \
+            const bool in_ = b < B;                                                     \
+            b = in_ ? b : B - 1;   /* clamped, unconditional loads */                   \
+            const int64_t sx = seq[(int64_t)b * S + p_];                                \
+            const float cx = contrib[((int64_t)b * S + p_) * D + col];                  \
+            SV[q] = in_ ? sx : 0;                                                       \
+            CV[q] = cx;                                                                 \
+        }                                                                               \
+    } while (0)
+#pragma unroll
+    for (int q = 0; q < NQP; ++q) { sv[q] = 0; cv[q] = 0.f; svn[q] = 0; cvn[q] = 0.f; }
+    if (j0 < njobs) WG_PJOB(j0, sv, cv);
+    for (int it = 0; it < trips; ++it) {
+        const int j = j0 + it * jstep;
+        if (j + jstep < njobs) WG_PJOB(j + jstep, svn, cvn);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQP; ++q) s += (sv[q] != 0) ? cv[q] : 0.f;   // (rows of pad positions are never written: select, not multiply)
+        __syncthreads();
+        lds[tid] = s;
+        __syncthreads();
+        if (tid < D && j < njobs) {
+            float t = lds[tid];
+#pragma unroll
+            for (int i = 1; i < C::CG; ++i) t += lds[i * D + tid];
+            ppart[(int64_t)j * D + tid] = t;
+        }
+#pragma unroll
+        for (int q = 0; q < NQP; ++q) { sv[q] = svn[q]; cv[q] = cvn[q]; }
+    }
+#undef WG_PJOB
+}

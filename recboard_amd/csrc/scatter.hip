@@ -743,232 +743,15 @@ extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64
 }
 
 // ------------------------------------------------------------------------------------------------ small dense tables: owner computes
-// The sort above costs six dependent launches however few rows there are -- 44 us of a 180 us SASRec step whose batch holds
-// ~13 000 live contribution rows for a 12 102-row table.  For a table that small the inverted index is not worth building: every
-// workgroup OWNS `rpw` destination rows (dealt round-robin), scans ALL keys (int32, L2-resident: 54 KB for the batch above) for the ones
-// that fall into its range, and adds their rows -- one launch, no workspace, and the zero fill of the untouched rows comes with it
-// (every row of dW is written by its owner).
-//   Every table row is owned in TWO column halves by two different workgroups (virtual row 2 r + h): a hot row's contributions are then
-//   pulled through two CUs' memory pipes, one 128-byte line each, instead of 256 bytes through one.
-//   order of summation (bitwise reproducible): matches are numbered in scan order m = 0, 1, ...; lane group m mod 32 loads match m
-//   and adds it into accumulator set (m mod 32) mod 8 of that row (LDS, [8][rpw][D]) -- the four groups of a set one after the
-//   other; the eight sets of a row are added in order at the end.  A hot row (Zipf head) is thereby spread over all 32 lane
-//   groups of its workgroup.  What remains serial is the owner's memory pipe: ~20 GB/s of scattered 256-byte rows per CU
-//   (measured), i.e. ~9 us for the 850 rows the Zipf(1.0) head item collects in a 512-sequence batch; the other 255 workgroups
-//   are done in 8 us (scripts/scatter_small_marks.py: clock stamps of a workgroup; build with -DSO_MARKS).
-//   keys: `n_regions` runs of `n` keys, run q at keys[q * region_stride ...]; row i of run q is g[(q * region_stride + i) * D ...].
-//   n comes from device memory (n_dev[0] * n_mul -- e.g. the batch plan's tile count * 16) so that a captured launch follows the batch.
-#define SO_NT 1024           // threads per workgroup: the scan is vector-instruction bound, 4 waves per SIMD hide each other's latencies
-#define SO_CAP 8192          // match list (LDS): flushed whenever the next 8192-key chunk might not fit
-#define SO_NG 8              // accumulator sets
-#define SO_LG (SO_NT / 32)   // lane groups (32 lanes each): 4 per accumulator set
-#define SO_INF 24            // row loads a lane group keeps in flight
-#define SO_KPT 8             // keys per thread and chunk: two 16-byte loads
-#ifdef SO_MARKS   // diagnostic build: workgroup 0 leaves shader-clock stamps in the padding row of dW
-#define SO_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) so_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SO_MARK(i) do { } while (0)
-#endif
-
-// HS column splits: a table row is owned in HS pieces of DW = D / HS columns by HS DIFFERENT workgroups (virtual row HS * r + h), so
-// a hot row's contributions are pulled through HS memory pipes, DW * 4 bytes each, instead of through one.
-struct SoAdam {   // W != nullptr: the owner applies the dense Adam update of its rows instead of (or besides) writing their gradient
-    float *W, *m, *v;
-    const float* hyper;
-    float b1, b2, omb1, omb2, eps, wd;
-};
-__device__ __forceinline__ void so_adam1(const SoAdam& A, float ss, float ib, float g, float& p, float& m, float& v) {   // (adam_vec4_dev's arithmetic)
-    re_adam1(p, m, v, g, A.b1, A.b2, A.omb1, A.omb2, ss, ib, A.eps, A.wd);
-}
+// (the algorithm: scatter_owner.h)
+#include "scatter_owner.h"
 
 template <int D, int HS>
 __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                                          const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
                                                          int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD) {
-    constexpr int DW = D / HS, VW = DW / 32;         // columns of a piece; floats per lane: a lane group is 32 lanes
-    constexpr int HSH = HS == 1 ? 0 : HS == 2 ? 1 : 2;
-    typedef float vt __attribute__((ext_vector_type(VW)));
-    extern __shared__ __align__(16) float so_acc[];  // [SO_NG][rpw][DW]
-    __shared__ uint32_t s_ent[SO_CAP];               // local row << 25 | contribution index
-    __shared__ int s_wsum[SO_NT / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, grp = tid >> 5, gl = tid & 31;
-    const int64_t n = n_dev ? (int64_t)n_dev[0] * n_mul : n_host;
-    // rows are dealt round-robin: workgroup w owns rows w, w + nwg, w + 2 nwg, ... (popular items tend to have neighbouring ids:
-    // a contiguous range would hand one workgroup most of the batch)
-    // (the grid is a power of two: owner and local row of a key are a mask and a shift)
-    // (virtual rows kk = (r << HSH) | h are dealt round-robin; this workgroup's pieces all have h = me & (HS - 1))
-    const uint32_t nwg = gridDim.x, me = blockIdx.x, wsh = 31 - __clz((int)nwg), h_me = me & (HS - 1);
-    const int64_t VR = R * HS;
-    const int rows_here = (int64_t)me < VR ? (int)((VR - 1 - me) / nwg + 1) : 0;
-    for (int e = tid; e < SO_NG * rpw * DW / 4; e += SO_NT) reinterpret_cast<float4*>(so_acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int cnt = 0;          // entries in the list (workgroup-uniform)
-    unsigned m0 = 0;      // matches consumed so far
-#ifdef SO_MARKS
-    unsigned long long so_t[12] = {};
-    int so_i = 2;
-#endif
-    SO_MARK(0);
-
-    auto flush = [&]() {
-        // Lane group grp takes the list entries j with (m0 + j) % 32 == grp, in increasing j, INF row loads in flight at a time; a hot
-        // row (the Zipf head is 10 % of a batch: hundreds of entries for ONE workgroup) is thereby spread over all 32 groups.
-        // Neighbouring entries of the same row are added in registers first; then the four groups that share an accumulator set
-        // (set = grp % 8) add into it one after the other (barriers in between): a fixed order, so the sums are reproducible.
-        const int j0 = (int)((grp - m0) & (SO_LG - 1));
-        auto rounds = [&](auto inf_tag) {
-            constexpr int INF = decltype(inf_tag)::value;
-            for (int jb = 0; jb < cnt; jb += SO_LG * INF) {   // (uniform trip count: the barriers below are workgroup-wide)
-                vt v[INF];
-                int rw[INF];
-#pragma unroll
-                for (int u = 0; u < INF; ++u) {
-                    const int j = jb + j0 + SO_LG * u;
-                    const uint32_t en = s_ent[j < cnt ? j : 0];   // (clamped: a valid entry, its value is not used)
-                    rw[u] = j < cnt ? (int)(en >> 25) : -1;
-                    v[u] = reinterpret_cast<const vt*>(g + (int64_t)(en & 0x1FFFFFFu) * D + h_me * DW)[gl];
-                }
-#pragma unroll
-                for (int u = 0; u + 1 < INF; ++u) {
-                    const bool same = rw[u] == rw[u + 1];
-                    v[u + 1] += same ? v[u] : vt{};
-                    rw[u] = same ? -1 : rw[u];
-                }
-#pragma unroll
-                for (int ph = 0; ph < SO_LG / SO_NG; ++ph) {
-                    if ((grp / SO_NG) == ph) {
-#pragma unroll
-                        for (int u = 0; u < INF; ++u) {
-                            if (rw[u] >= 0) {
-                                vt* a = reinterpret_cast<vt*>(so_acc + ((int64_t)(grp % SO_NG) * rpw + rw[u]) * DW) + gl;
-                                *a += v[u];
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-        };
-        if (cnt <= SO_LG * 4) rounds(std::integral_constant<int, 4>{});   // (uniform) the usual case: a handful of entries per group
-        else rounds(std::integral_constant<int, SO_INF>{});
-        m0 += (unsigned)cnt;
-        cnt = 0;
-    };
-
-    __syncthreads();
-    SO_MARK(1);
-    // The regions are scanned as ONE run of nreg * n keys, 8192 keys per chunk: a thread takes SO_KPT keys as 16-byte loads (the
-    // next chunk's are in flight while this one is ranked: the keys were written by another XCD a moment ago, a chunk is a memory
-    // round trip), counts its matches, ONE workgroup scan places them, and the matches go to the list from registers.
-    // Match order = (chunk, thread, key): a fixed function of the keys.  (n is a multiple of 4 or the tail is handled by element:
-    // a load never straddles two regions.)
-    const uint32_t n32 = (uint32_t)n, total = (uint32_t)nreg * n32;   // (< 2^25: checked by the entry point)
-    const bool vec = (n32 & 3u) == 0;
-    auto region_of = [&](uint32_t v) { return (uint32_t)(v >= n32) + (uint32_t)(v >= 2 * n32) + (uint32_t)(v >= 3 * n32); };   // (nreg <= 4)
-    auto load_chunk = [&](uint32_t base, int (&kk)[SO_KPT]) {
-#pragma unroll
-        for (int u = 0; u < SO_KPT / 4; ++u) {
-            const uint32_t v = base + (uint32_t)(u * SO_NT + tid) * 4;
-            int4 k4 = make_int4(-1, -1, -1, -1);
-            if (vec) {
-                if (v < total) { const uint32_t q = region_of(v); k4 = *reinterpret_cast<const int4*>(keys + (int64_t)q * stride + (v - q * n32)); }
-            } else {
-                int* ke = reinterpret_cast<int*>(&k4);
-                for (int e = 0; e < 4; ++e)
-                    if (v + e < total) { const uint32_t q = region_of(v + e); ke[e] = keys[(int64_t)q * stride + (v + e - q * n32)]; }
-            }
-            kk[4 * u] = k4.x; kk[4 * u + 1] = k4.y; kk[4 * u + 2] = k4.z; kk[4 * u + 3] = k4.w;
-        }
-    };
-    const uint32_t R32 = (uint32_t)R, pad32 = (padding_idx >= 0 && padding_idx < R) ? (uint32_t)padding_idx : 0xFFFFFFFFu;
-    int kv[SO_KPT], kn[SO_KPT];
-    if (total > 0) load_chunk(0, kv);
-    for (uint32_t base = 0; base < total; base += SO_NT * SO_KPT) {
-        if (base + SO_NT * SO_KPT < total) load_chunk(base + SO_NT * SO_KPT, kn);   // (in flight while this chunk is ranked)
-        unsigned mask = 0;
-#pragma unroll
-        for (int u = 0; u < SO_KPT; ++u) {
-            const uint32_t k = (uint32_t)kv[u];   // (a negative key is >= R as unsigned)
-            const bool hit = (k & ((nwg >> HSH) - 1)) == (me >> HSH) && k < R32 && k != pad32;
-            mask |= (hit ? 1u : 0u) << u;
-        }
-        const int c = __popc(mask);
-#ifdef SO_MARKS
-        if (so_i < 8) { SO_MARK(so_i); ++so_i; }
-#endif
-        // ---- exclusive scan of the per-thread counts over the workgroup
-        int inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        __syncthreads();                        // (previous chunk's s_wsum readers are done)
-        if (lane == 63) s_wsum[wid] = inc;
-        __syncthreads();
-        int tot = 0, below = 0;
-#pragma unroll
-        for (int w = 0; w < SO_NT / 64; ++w) {
-            const int x = s_wsum[w];
-            tot += x;
-            below += w < wid ? x : 0;
-        }
-        if (tot != 0) {                         // (uniform)
-            if (cnt + tot > SO_CAP) {           // (uniform) make room
-                flush();
-                __syncthreads();
-            }
-            int off = cnt + below + inc - c;
-            if (c) {
-#pragma unroll
-                for (int u = 0; u < SO_KPT; ++u) {
-                    const bool hit = (mask >> u) & 1u;
-                    if (hit) {
-                        const uint32_t v = base + (uint32_t)((u >> 2) * SO_NT + tid) * 4 + (u & 3);
-                        const uint32_t q = region_of(v);
-                        s_ent[off] = (((uint32_t)kv[u] >> (wsh - HSH)) << 25) | ((uint32_t)(q * stride) + (v - q * n32));
-                    }
-                    off += hit ? 1 : 0;
-                }
-            }
-            cnt += tot;
-        }
-#pragma unroll
-        for (int u = 0; u < SO_KPT; ++u) kv[u] = kn[u];
-    }
-    __syncthreads();
-    SO_MARK(8);
-    flush();
-    __syncthreads();
-    SO_MARK(9);
-    // ---- the eight accumulators of every owned row, added in set order; untouched rows come out zero
-    for (int e = tid; e < rows_here * (DW / 4); e += SO_NT) {
-        const int r = e / (DW / 4), c4 = e % (DW / 4);
-        float4 s = reinterpret_cast<const float4*>(so_acc + (int64_t)r * DW)[c4];
-#pragma unroll
-        for (int gq = 1; gq < SO_NG; ++gq) {
-            const float4 t = reinterpret_cast<const float4*>(so_acc + ((int64_t)gq * rpw + r) * DW)[c4];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-        const int64_t kk = (int64_t)r * nwg + me;   // virtual row -> table row kk >> HSH, piece h_me
-        const float4 gr = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
-        const int64_t o = (kk >> HSH) * D + h_me * DW;
-        if (dW) reinterpret_cast<float4*>(dW + o)[c4] = gr;
-        if (AD.W) {
-            const float ss = AD.hyper[0], ib = AD.hyper[1];
-            if (ib != 0.f) {   // ({0, 0}: the caller gated this step off)
-                float4 P = reinterpret_cast<float4*>(AD.W + o)[c4], M = reinterpret_cast<float4*>(AD.m + o)[c4], V = reinterpret_cast<float4*>(AD.v + o)[c4];
-                so_adam1(AD, ss, ib, gr.x, P.x, M.x, V.x); so_adam1(AD, ss, ib, gr.y, P.y, M.y, V.y);
-                so_adam1(AD, ss, ib, gr.z, P.z, M.z, V.z); so_adam1(AD, ss, ib, gr.w, P.w, M.w, V.w);
-                reinterpret_cast<float4*>(AD.W + o)[c4] = P; reinterpret_cast<float4*>(AD.m + o)[c4] = M; reinterpret_cast<float4*>(AD.v + o)[c4] = V;
-            }
-        }
-    }
-#ifdef SO_MARKS
-    __syncthreads();
-    SO_MARK(10);
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int i = 0; i < 11; ++i) dW[i] = (float)(so_t[i] ? (long long)(so_t[i] - so_t[0]) : -1ll);
-#endif
+    extern __shared__ __align__(16) float so_acc[];
+    so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, so_acc);
 }
 
 static int scatter_small_launch(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,

@@ -71,6 +71,8 @@ SIGNATURES = {
     "re_sasrec_loss_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_scatter_add_rows_small": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _i64, _f32, _vp, _vp]),
     "re_scatter_adam_rows_small": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
+    "re_sasrec_step_tail": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp, _f32, _vp,
+                                    _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "re_spmm_csr": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp, _sz, _vp]),
     "re_rows_sqnorm_workspace_bytes": (_sz, []),
     "re_rows_sqnorm": (_i32, [_vp, _i64, _i64, _vp, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),

@@ -740,6 +740,30 @@ def scatter_add_rows_small(g, keys, R, out, n_regions=1, region_stride=None, n_d
     return out
 
 
+def sasrec_step_tail(g_rows, keys, R, out, n_dev, n_mul, seq, L, plan, tape, dx0, scale, dP, block_grads, g_last_w, g_last_b, ws, ticket,
+                     table_adam=None, enc_adam=None, n_regions=3, padding_idx=0):
+    """scatter_add_rows_small(g_rows, keys, R, out, n_regions, n_dev=, n_mul=, adam=table_adam) and sasrec_encoder_step(part=4, adam=enc_adam)
+    as ONE launch + the reduction (re_sasrec_step_tail; D = 64): the scatter-add's workgroups take the weight-gradient jobs when their rows are
+    done.  Bit-identical to the two calls.  ticket: a zero uint32/int32[1] of the caller's (left zero)."""
+    _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(n_dev, torch.int32, "n_dev"); _req(seq, torch.int64, "seq")
+    _req(tape, torch.float32, "tape"); _req(dx0, torch.float32, "dx0"); _req(dP, torch.float32, "dP"); _req(ws, torch.uint8, "ws")
+    _req(ticket, torch.int32, "ticket")
+    if out is not None or table_adam is None:
+        _req(out, torch.float32, "out")
+    B, S = seq.shape
+    D = g_rows.shape[-1]
+    region_stride = keys.numel() // n_regions
+    if (out is not None and out.numel() != R * D) or g_rows.numel() < n_regions * region_stride * D or dx0.numel() != B * S * D:
+        raise ValueError("recengine: sasrec_step_tail buffer shapes")
+    tg = _ptr_table(block_grads)
+    lib.check(lib.load().re_sasrec_step_tail(_p(g_rows), _p(keys), int(n_regions), int(region_stride), _p(n_dev), int(n_mul), int(R), int(padding_idx),
+                                             _p(out), ctypes.byref(table_adam) if table_adam is not None else None, _p(seq), B, S, D, int(L), _p(plan),
+                                             num_cus(seq.device), _p(tape), tape.numel() * 4, _p(dx0), float(scale), _p(dP), tg, _p(g_last_w),
+                                             _p(g_last_b), _p(ws), ws.numel(), ctypes.byref(enc_adam) if enc_adam is not None else None,
+                                             _p(ticket), _stream()), "re_sasrec_step_tail")
+    return out
+
+
 def sasrec_encoder_embed_bwd(dU, seq, scale, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b, dP,
                              out=None, ws=None, plan=None, seed_dev=None):
     """sasrec_encoder_bwd + sasrec_embed_bwd in one pass: -> item-gradient contribution rows [B,S,D]; OVERWRITES block_grads /

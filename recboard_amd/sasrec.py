@@ -143,7 +143,8 @@ class SASRecEngine:
         self.encoder = encoder
         self.split_long = True          # sequences of 3 - 4 tiles as two work items in two workgroups (fused BCE / BPR training step)
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
-        self.fork_wgrad = True          # weight gradients on a side stream beside the item table's scatter-add (same results)
+        self.fuse_tail = True           # D = 64: scatter-add and weight-gradient jobs in one launch (csrc/enc_tail.hip; same results)
+        self.fork_wgrad = True          # otherwise: weight gradients on a side stream beside the item table's scatter-add (same results)
         self.tile_step = True           # the one-tile-per-workgroup kernels may run the training step (False: always the workgroup-per-item kernels)
         self.fuse_adam = True           # captured steps: the dense Adam inside the launches that finish the gradients (reduction / scatter-add)
         self.fork_adam = False          # True: the dense Adam as two launches inside the step's two branches (measured: 113 vs 104 us per step)
@@ -382,6 +383,24 @@ class SASRecEngine:
             # forward + criterion (one launch), encoder backward, weight gradients, item-table gradient -- all on the plan's compact
             # rows: only rows that exist are read or written, and the table gradient is ONE launch over ~13 k keys (no sort)
             ready = 8 if getattr(pb, "weights_ready", False) else 0
+            if self.fused_item_kernel and D == 64 and getattr(self, "fuse_tail", True):
+                # ONE queue: item kernels, then one launch in which the scatter-add's workgroups (+ the item table's Adam) go on with the
+                # weight-gradient jobs, then the reduction (+ the encoder slice's Adam) -- csrc/enc_tail.hip.  (As two graph branches the
+                # fork and the join cost more than half of what the overlap saved.)
+                loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count, W["u"], W["tape"],
+                                               W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], W["contrib"][:n].view(B, S, D), G["Position.weight"],
+                                               self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev,
+                                               part=3 + ready)
+                fuse = adam_hyper is not None and getattr(self, "fuse_adam", True)
+                fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, self.betas[0], self.betas[1], 1e-8, self.wd) if fuse else None
+                self._adam_keep = (fz,)
+                if not hasattr(self, "_ticket"):
+                    self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
+                ops.sasrec_step_tail(W["g_rows"], W["keys"], self.N + 1, GE if (not fuse or getattr(self, "keep_table_grad", True)) else None,
+                                     pb.plan.view(torch.int32)[1:2], 16, seq, self.L, pb.plan, W["tape"], W["contrib"][:n].view(B, S, D), float(D ** 0.5),
+                                     G["Position.weight"], self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], self._ticket,
+                                     table_adam=fz, enc_adam=fz)
+                return (loss, True) if fuse else loss
             if self.fused_item_kernel and getattr(self, "fork_wgrad", False):
                 # the item kernels, then TWO branches: the weight gradients (enc_wgrad_k + enc_grad_reduce_k) on a side stream beside the
                 # item table's scatter-add on this one -- both depend on the item kernels alone; joined before the optimizer (inside a
@@ -551,7 +570,7 @@ class SASRecEngine:
             loss = body()
         for t, k in zip((A.data, A.m, A.v, A.grad), keep):
             t.copy_(k)
-        return dict(graph=graph, blob=blob, state=state, loss=loss, in_prep=in_prep)
+        return dict(graph=graph, blob=blob, state=state, loss=loss, in_prep=in_prep, pb=pb, hyper=hyper)
 
     def _stage(self, g, seq, pos, neg, step):
         """The batch-preparation launch of `step` (1-based) into the static buffers of the captured step `g`."""
