@@ -126,6 +126,9 @@ struct PlWeights {   // optional extra work of the launch: the one-tile-per-work
     unsigned* epoch;
 };
 
+#ifdef ENC_PROFILE
+__device__ unsigned long long g_plan_marks[4];   // shader-clock stamps of the plan workgroup (100 MHz): spans, ranks, row map
+#endif
 __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
                                                              const int64_t* __restrict__ neg, int B, int S, int ncu, int max_tiles, int split_long,
                                                              int64_t* __restrict__ seq_out, int64_t* __restrict__ pos_out,
@@ -361,10 +364,15 @@ __global__ __launch_bounds__(PL_NT) void sasrec_batch_prep_k(const int64_t* __re
         for (int off = tid & 7; off < span; off += 8) rowmap[row + off] = make_int2(b0 * S + (S - span) + off, S - span);
     }
 #ifdef ENC_PROFILE
+    __syncthreads();
     PL_STAMP(3);
-    (void)pl_t;
+    if (tid == 0)
+        for (int i = 0; i < 4; ++i) g_plan_marks[i] = pl_t[i] - pl_t[0];
 #endif
 }
+#ifdef ENC_PROFILE
+extern "C" void re_dbg_plan_marks(unsigned long long* out4) { (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_plan_marks), 32); }
+#endif
 
 extern "C" size_t re_sasrec_plan_bytes(int64_t B, int64_t S) {
     if (B <= 0 || S <= 0) return 256;

@@ -5,7 +5,9 @@
 #pragma once
 #include "enc_common.h"
 
+#ifndef WG_NSPLIT
 #define WG_NSPLIT 24
+#endif
 #define WG_CH 4   // row tiles per LDS stage
 
 template <int D>
