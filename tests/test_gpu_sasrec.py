@@ -389,3 +389,31 @@ def test_captured_step_is_reproducible_from_process_to_process():
         assert "parameters identical: True" in r.stdout, r.stdout
         out.append(re.search(r"sha1 of the parameters: (\w+)", r.stdout).group(1))
     assert out[0] == out[1], out
+
+
+@pytest.mark.parametrize("captured", [True, False])
+def test_one_launch_tail_equals_the_two_branch_form(captured):
+    """re_sasrec_step_tail (the scatter-add's workgroups take the weight-gradient jobs) against re_scatter_adam_rows_small beside
+    re_sasrec_encoder_step_part(part = 4) on two streams: the same parameters and losses, bit for bit (dropout on, Adam fused or not)."""
+    from recboard_amd.sasrec import SASRecEngine
+    N, B, S = 700, 96, 50
+    rng = np.random.default_rng(21)
+    batches = []
+    for _ in range(3):
+        seq = np.zeros((B, S), np.int64)
+        for b in range(B):
+            n = int(rng.integers(1, S + 1))
+            seq[b, S - n:] = rng.integers(1, N + 1, n)
+        pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
+    eng = []
+    for tail in (True, False):
+        m = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, lr=1e-3, weight_decay=1e-6, seed=9)
+        m.fuse_tail = tail
+        losses = [(m.train_step_graph(*batches[i % 3]) if captured else m.train_step(*batches[i % 3], None)).clone() for i in range(5)]
+        eng.append((m, torch.stack(losses)))
+    assert torch.equal(eng[0][1], eng[1][1])
+    assert torch.equal(eng[0][0].arena.data, eng[1][0].arena.data)
+    assert torch.equal(eng[0][0].arena.grad, eng[1][0].arena.grad)
+    assert int(eng[0][0]._ticket.item()) == 0
