@@ -145,6 +145,14 @@ int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t n_regions, 
                         int64_t D, int64_t L, const void* plan, int32_t ncu, const void* tape, size_t tape_bytes, const float* dx0,
                         float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
                         const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream);
+/* The same tail for a LARGE item table (config 5): re_sparse_adam_rows_small (int32 keys, hyper from device memory) whose workgroups then take
+ * the weight-gradient jobs; D = 64 or 128. */
+int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev, int64_t n_mul,
+                               int64_t R, int64_t padding_idx, float* W, float* m, float* v, const float* hyper, double beta1, double beta2,
+                               double eps, double weight_decay, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L, const void* plan,
+                               int32_t ncu, const void* tape, size_t tape_bytes, const float* dx0, float emb_scale, float* dPtab,
+                               float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
+                               const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream);
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                         int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,

@@ -7,6 +7,7 @@
 // 4), bit for bit (a job's partial does not depend on who computes it; the reduction adds the partials in split order).
 #include "enc_wgrad_job.h"
 #include "scatter_owner.h"
+#include "adam_rows_owner.h"
 
 struct TailJobs {
     const float* tape;
@@ -22,14 +23,10 @@ struct TailJobs {
     unsigned* ticket;    // zero at launch; enc_grad_reduce_k (the next launch) zeroes it again
 };
 
-template <int D, int HS>
-__global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
-                                                    const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
-                                                    int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J) {
-    extern __shared__ __align__(16) float lds[];
-    so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds);
-    // ---- weight-gradient jobs, two per ticket: matrix jobs q = 2 t + half -> (block, matrix, split) = (q / 144, q / 24 % 6, q % 24), then the
-    //      position-table jobs (144 strides of the (position, chunk) list) -- both halves of a workgroup always run the same kind
+// ---- weight-gradient jobs, two per ticket: matrix jobs q = 2 t + half -> (block, matrix, split) = (q / 144, q / 24 % 6, q % 24), then the
+//      position-table jobs (144 strides of the (position, chunk) list) -- both halves of a workgroup always run the same kind
+template <int D>
+__device__ __forceinline__ void tail_jobs(const TailJobs& J, float* lds) {
     __shared__ int s_job;
     const int tid = threadIdx.x, half = tid >> 9, ht = tid & 511;
     float* jl = lds + half * wg_job_lds_floats<D>();
@@ -37,7 +34,7 @@ __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g,
     const int n_mat = J.L * PER_PLANE / 2, n_pos = J.ppart ? PER_PLANE / 2 : 0;
     const int n_tiles = enc_plan_view(J.plan, J.B, J.S).hdr[1];
     for (;;) {
-        __syncthreads();   // (the accumulators / the previous job's stages are done with)
+        __syncthreads();   // (the launch's first part / the previous job's stages are done with the LDS)
         if (tid == 0) s_job = (int)atomicAdd(J.ticket, 1u);
         __syncthreads();
         const int t = s_job;
@@ -51,12 +48,56 @@ __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g,
     }
 }
 
+template <int D, int HS>
+__global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
+                                                    const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
+                                                    int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J) {
+    extern __shared__ __align__(16) float lds[];
+    so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds);
+    tail_jobs<D>(J, lds);
+}
+
+// the same behind the row-sparse Adam of a LARGE table (adam_rows_owner.h; config 5: D = 128, HS = 2)
+template <int D, int HS>
+__global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J) {
+    extern __shared__ __align__(16) float lds[];
+    sa_body<1, HS, int32_t>(P, reinterpret_cast<unsigned char*>(lds));
+    tail_jobs<D>(J, lds);
+}
+
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
                            const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
                            hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket);
+
+// the weight-gradient side of both entry points: checks, and the workspace as re_sasrec_encoder_step_part lays it out
+struct TailSide {
+    TailJobs J;
+    float *slab, *wpart, *ppart;
+    int wgrid;
+};
+static int tail_side(TailSide& T, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, int32_t ncu, const void* tape,
+                     size_t tape_bytes, const float* dx0, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
+                     size_t ws_bytes, uint32_t* ticket) {
+    if (!seq || !plan || !tape || !dx0 || !block_grads || !g_last_w || !g_last_b || !ws || !ticket || B < 0) return RE_EINVAL;
+    if ((D != 64 && D != 128) || S < 1 || S > 64 || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
+    if (tape_bytes < (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float) || ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L))
+        return RE_EWORKSPACE;
+    for (int64_t i = 0; i < 12 * L; ++i)
+        if (!block_grads[i]) return RE_EINVAL;
+    if (ncu < 1) ncu = 256;
+    const int64_t mt = enc_plan_max_tiles(B, S);
+    T.wgrid = (int)(mt < ncu ? mt : ncu);
+    T.slab = (float*)ws;
+    T.wpart = T.slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
+    T.ppart = T.wpart + enc_wgrad_part_floats(D, L);
+    float* gtape = T.ppart + enc_wgrad_ppart_floats(B, D);
+    T.J = TailJobs{(const float*)tape, enc_tape_layout(B, S, D, L), gtape, 16 * mt, plan, (int)B, (int)S, (int)L, T.wpart, seq, dx0,
+                   dPtab ? T.ppart : nullptr, ticket};
+    return RE_OK;
+}
 
 extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev, int32_t n_mul,
                                    int64_t R, int64_t padding_idx, float* dW, const re_adam_fuse* table_adam, const int64_t* seq, int64_t B,
@@ -65,10 +106,8 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
                                    void* ws, size_t ws_bytes, const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
-    if (!g || !keys || !n_dev || !seq || !plan || !tape || !dx0 || !block_grads || !g_last_w || !g_last_b || !ws || !ticket || (!dW && !table_adam) ||
-        R <= 0 || B < 0 || n_regions < 1 || n_regions > 4 || region_stride < 0 || n_mul < 1)
-        return RE_EINVAL;
-    if (D != 64 || S < 1 || S > 64 || L < 1 || L > SE_MAX_BLOCKS) return RE_EUNSUPPORTED;
+    if (!g || !keys || !n_dev || (!dW && !table_adam) || R <= 0 || n_regions < 1 || n_regions > 4 || region_stride < 0 || n_mul < 1) return RE_EINVAL;
+    if (D != 64) return RE_EUNSUPPORTED;
     if (table_adam && (!table_adam->param || !table_adam->m || !table_adam->v || !table_adam->hyper)) return RE_EINVAL;
     SoAdam AD{};
     if (table_adam)
@@ -78,10 +117,9 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
                                  reinterpret_cast<uintptr_t>(AD.W) | reinterpret_cast<uintptr_t>(AD.m) | reinterpret_cast<uintptr_t>(AD.v)) & 15u))
         return RE_EUNSUPPORTED;
     if ((int64_t)n_regions * region_stride >= (1ll << 25)) return RE_EUNSUPPORTED;
-    if (tape_bytes < (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float) || ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L))
-        return RE_EWORKSPACE;
-    for (int64_t i = 0; i < 12 * L; ++i)
-        if (!block_grads[i]) return RE_EINVAL;
+    TailSide T;
+    const int rc = tail_side(T, seq, B, S, D, L, plan, ncu, tape, tape_bytes, dx0, dPtab, block_grads, g_last_w, g_last_b, ws, ws_bytes, ticket);
+    if (rc != RE_OK) return rc;
     constexpr int HS = 2;
     const int rpw = 96;                            // (scatter.hip: scatter_small_launch)
     int64_t nwg = HS;
@@ -89,21 +127,53 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
     if (nwg > 4096) return RE_EUNSUPPORTED;
     const size_t lds_scatter = (size_t)SO_NG * rpw * (D / HS) * sizeof(float), lds_jobs = (size_t)2 * wg_job_lds_floats<64>() * sizeof(float);
     const size_t ldsb = lds_scatter > lds_jobs ? lds_scatter : lds_jobs;
-    // the workspace as re_sasrec_encoder_step_part lays it out
-    if (ncu < 1) ncu = 256;
-    const int64_t mt = enc_plan_max_tiles(B, S);
-    const int wgrid = (int)(mt < ncu ? mt : ncu);
-    float* slab = (float*)ws;
-    float* wpart = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
-    float* ppart = wpart + enc_wgrad_part_floats(D, L);
-    float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
-    const TailJobs J{(const float*)tape, enc_tape_layout(B, S, D, L), gtape, 16 * mt, plan, (int)B, (int)S, (int)L, wpart, seq, dx0,
-                     dPtab ? ppart : nullptr, ticket};
     hipStream_t s = (hipStream_t)stream;
     auto k = enc_tail_k<64, HS>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, (int64_t)0, R, rpw,
-                       padding_idx, 1.0f, dW, AD, J);
+                       padding_idx, 1.0f, dW, AD, T.J);
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
-    return enc_grad_reduce_launch(B, S, D, L, plan, slab, wgrid, wpart, ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam, ticket);
+    return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
+                                  ticket);
+}
+
+// The same behind re_sparse_adam_rows_small (int32 keys, hyper from device memory): the tail of a LARGE-table step (config 5), D = 64 or 128.
+extern "C" int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
+                                          int64_t n_mul, int64_t R, int64_t padding_idx, float* W, float* m, float* v, const float* hyper, double beta1,
+                                          double beta2, double eps, double weight_decay, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
+                                          const void* plan, int32_t ncu, const void* tape, size_t tape_bytes, const float* dx0, float emb_scale,
+                                          float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
+                                          const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream) {
+    re_clear_error();
+    if (B == 0) return RE_OK;
+    if (!g || !keys || !n_dev || !W || !m || !v || !hyper || R <= 0 || n_regions < 1 || region_stride <= 0 || n_mul < 1) return RE_EINVAL;
+    if (R >= 0xFFFFFFFEll || (int64_t)n_regions * region_stride >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 7u) return RE_EINVAL;
+    TailSide T;
+    const int rc = tail_side(T, seq, B, S, D, L, plan, ncu, tape, tape_bytes, dx0, dPtab, block_grads, g_last_w, g_last_b, ws, ws_bytes, ticket);
+    if (rc != RE_OK) return rc;
+    SaParams P;
+    P.g = g; P.keys = keys; P.n_regions = n_regions; P.region_stride = region_stride; P.n_dev = n_dev; P.n_mul = n_mul; P.n_host = 0;
+    P.R = R; P.padding_idx = padding_idx; P.W = W; P.m = m; P.v = v;
+    P.b1 = (float)beta1; P.b2 = (float)beta2; P.omb1 = (float)(1.0 - beta1); P.omb2 = (float)(1.0 - beta2);
+    P.eps = (float)eps; P.wd = (float)weight_decay; P.hyper = hyper;
+    P.step_size = 0.f; P.inv_sqrt_bc2 = 0.f;
+    P.stride = D; P.coff = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 128) {
+        const size_t lds_jobs = (size_t)2 * wg_job_lds_floats<128>() * sizeof(float);
+        const size_t ldsb = lds_jobs > (size_t)SA_LDS_BYTES(1) ? lds_jobs : (size_t)SA_LDS_BYTES(1);
+        auto k = enc_tail_sparse_k<128, 2>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J);
+    } else {
+        const size_t lds_jobs = (size_t)2 * wg_job_lds_floats<64>() * sizeof(float);
+        const size_t ldsb = lds_jobs > (size_t)SA_LDS_BYTES(1) ? lds_jobs : (size_t)SA_LDS_BYTES(1);
+        auto k = enc_tail_sparse_k<64, 1>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J);
+    }
+    if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
+    return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
+                                  ticket);
 }

@@ -150,6 +150,22 @@ class SASRecLargeTableEngine(SASRecEngine):
             lw, lb = self.params["lastLN.weight"].detach(), self.params["lastLN.bias"].detach()
             if table is not None:                               # (the sharded step reads every key entry: rows beyond this batch's plan must read
                 W["keys"].zero_()                               #  "no contribution"; the unsharded update stops at the plan's live length)
+            if adam_hyper is not None and table is None and self.fused_item_kernel and getattr(self, "fuse_tail", True):
+                # ONE queue: item kernels, then one launch in which the row-sparse Adam's workgroups go on with the weight-gradient jobs, then
+                # the reduction (+ the encoder's dense Adam) -- csrc/enc_tail.hip (as two graph branches: fork and join cost ~20 us of a step)
+                loss = ops.sasrec_encoder_step(E, Ppos.detach(), seq, pos, neg, float(D ** 0.5), self._block_tensors(), lw, lb, self.L, p, sd, aux.plan, kind,
+                                               count, W["u"], W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], W["contrib"][:n].view(B, S, D),
+                                               G["Position.weight"], self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"],
+                                               e_off=1, seed_dev=seed_dev, part=3 + (8 if getattr(aux, "weights_ready", False) else 0))
+                fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
+                self._adam_keep = fz
+                if not hasattr(self, "_ticket"):
+                    self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
+                ops.sasrec_step_tail_sparse(W["g_rows"].view(-1, D), W["keys"], self.E, self.Em, self.Ev, adam_hyper, self.betas[0], self.betas[1], 1e-8,
+                                            self.wd, aux.plan.view(torch.int32)[1:2], 16, seq, self.L, aux.plan, W["tape"], W["contrib"][:n].view(B, S, D),
+                                            float(D ** 0.5), G["Position.weight"], self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"],
+                                            W["ws_bwd"], self._ticket, enc_adam=fz)
+                return loss, W["g_rows"].view(-1, D), W["keys"], True
             if adam_hyper is not None and table is None and self.fused_item_kernel and getattr(self, "fork_wgrad", True):
                 args = (E, Ppos.detach(), seq, pos, neg, float(D ** 0.5), self._block_tensors(), lw, lb, self.L, p, sd, aux.plan, kind, count, W["u"],
                         W["tape"], W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], W["contrib"][:n].view(B, S, D), G["Position.weight"],

@@ -764,6 +764,29 @@ def sasrec_step_tail(g_rows, keys, R, out, n_dev, n_mul, seq, L, plan, tape, dx0
     return out
 
 
+def sasrec_step_tail_sparse(g_rows, keys, W, m, v, hyper, beta1, beta2, eps, weight_decay, n_dev, n_mul, seq, L, plan, tape, dx0, scale, dP,
+                            block_grads, g_last_w, g_last_b, ws, ticket, enc_adam=None, padding_idx=0):
+    """sparse_adam_rows_small(g_rows, keys [regions, stride] int32, W, m, v, hyper=, n_dev=, n_mul=) and sasrec_encoder_step(part=4,
+    adam=enc_adam) as ONE launch + the reduction (re_sasrec_step_tail_sparse): the tail of a large-table step.  Bit-identical to the two calls."""
+    _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(n_dev, torch.int32, "n_dev"); _req(seq, torch.int64, "seq")
+    _req(tape, torch.float32, "tape"); _req(dx0, torch.float32, "dx0"); _req(dP, torch.float32, "dP"); _req(ws, torch.uint8, "ws")
+    _req(ticket, torch.int32, "ticket"); _req(hyper, torch.float32, "hyper")
+    for t, nme in ((W, "W"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nme)
+    B, S = seq.shape
+    R, D = W.shape
+    regions, stride = keys.shape
+    if g_rows.numel() != keys.numel() * D or dx0.numel() != B * S * D:
+        raise ValueError("recengine: sasrec_step_tail_sparse buffer shapes")
+    tg = _ptr_table(block_grads)
+    lib.check(lib.load().re_sasrec_step_tail_sparse(_p(g_rows), _p(keys), int(regions), int(stride), _p(n_dev), int(n_mul), R, int(padding_idx), _p(W),
+                                                    _p(m), _p(v), _p(hyper), float(beta1), float(beta2), float(eps), float(weight_decay), _p(seq), B, S, D,
+                                                    int(L), _p(plan), num_cus(seq.device), _p(tape), tape.numel() * 4, _p(dx0), float(scale), _p(dP), tg,
+                                                    _p(g_last_w), _p(g_last_b), _p(ws), ws.numel(),
+                                                    ctypes.byref(enc_adam) if enc_adam is not None else None, _p(ticket), _stream()),
+              "re_sasrec_step_tail_sparse")
+
+
 def sasrec_encoder_embed_bwd(dU, seq, scale, block_tensors, last_w, last_b, L, drop_p, seed, tape, block_grads, g_last_w, g_last_b, dP,
                              out=None, ws=None, plan=None, seed_dev=None):
     """sasrec_encoder_bwd + sasrec_embed_bwd in one pass: -> item-gradient contribution rows [B,S,D]; OVERWRITES block_grads /

@@ -417,3 +417,32 @@ def test_one_launch_tail_equals_the_two_branch_form(captured):
     assert torch.equal(eng[0][0].arena.data, eng[1][0].arena.data)
     assert torch.equal(eng[0][0].arena.grad, eng[1][0].arena.grad)
     assert int(eng[0][0]._ticket.item()) == 0
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_large_table_one_launch_tail_equals_the_two_branch_form(D):
+    """re_sasrec_step_tail_sparse (the row-sparse Adam's workgroups take the weight-gradient jobs) against re_sparse_adam_rows_small beside
+    re_sasrec_encoder_step_part(part = 4) on two streams: the same table, moments, parameters and losses, bit for bit."""
+    from recboard_amd.large import SASRecLargeTableEngine
+    N, B, S = 5000, 64, 50
+    rng = np.random.default_rng(33)
+    batches = []
+    for _ in range(3):
+        seq = np.zeros((B, S), np.int64)
+        for b in range(B):
+            n = int(rng.integers(1, S + 1))
+            seq[b, S - n:] = np.minimum(rng.zipf(1.3, n), N)          # (a heavy head: the whole-workgroup path of the row-sparse Adam)
+        pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
+    eng = []
+    for tail in (True, False):
+        m = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.3, lr=1e-3, weight_decay=1e-6, seed=4)
+        m.fuse_tail = tail
+        losses = [m.train_step_graph(*batches[i % 3]).clone() for i in range(5)]
+        eng.append((m, torch.stack(losses)))
+    assert torch.equal(eng[0][1], eng[1][1])
+    for name in ("E", "Em", "Ev"):
+        assert torch.equal(getattr(eng[0][0], name), getattr(eng[1][0], name)), name
+    assert torch.equal(eng[0][0].arena.data, eng[1][0].arena.data)
+    assert int(eng[0][0]._ticket.item()) == 0
