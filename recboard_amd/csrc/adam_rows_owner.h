@@ -20,6 +20,7 @@
 #define SA_NT 1024
 #define SA_NW (SA_NT / 64)
 #define SA_CAP 2048
+#define SA_RUNS 8         // runs of equal keys a wave works on at a time (their rows are requested together)
 #define SA_LONG 48        // keys with more contributions than this are summed by the whole workgroup (<= 64: a listed run fits one ballot)
 
 struct SaParams {
@@ -88,10 +89,8 @@ __device__ __forceinline__ void sa_adam(const SaParams& P, int64_t row, int lane
 
 // sum of the contribution rows at positions list[e] (low words), e in [e0, e1), in that order; four loads in flight
 template <int VPT>
-__device__ __forceinline__ SaRow<VPT> sa_sum(const float* __restrict__ g, const unsigned long long* list, int e0, int e1, int lane, int64_t stride, int coff) {
-    SaRow<VPT> acc;
-#pragma unroll
-    for (int c = 0; c < VPT; ++c) acc.x[c] = 0.f;
+__device__ __forceinline__ SaRow<VPT> sa_sum(const float* __restrict__ g, const unsigned long long* list, int e0, int e1, int lane, int64_t stride, int coff,
+                                             SaRow<VPT> acc) {
     int e = e0;
     for (; e + 4 <= e1; e += 4) {
         const SaRow<VPT> a = sa_load<VPT>(g, (int64_t)(uint32_t)list[e], lane, stride, coff), b = sa_load<VPT>(g, (int64_t)(uint32_t)list[e + 1], lane, stride, coff),
@@ -241,6 +240,19 @@ __device__ __forceinline__ void sa_body(SaParams P, unsigned char* lds) {
         }
     }
     __syncthreads();
+#ifndef SA_NO_TOUCH
+    // Touch the (W, m, v) rows of the owned keys now (one thread per table slot, one word per row): against a table far beyond the TLBs' reach
+    // every row is a page walk + a cold line, and they are on their way while pass B, the ordering and the run detection go on.  The values are
+    // not used (kept live to the end of the function so that nothing waits for them here).
+    float touch0 = 0.f, touch1 = 0.f, touch2 = 0.f;
+    {
+        const uint32_t hk = s_hkey[tid];
+        if (hk != SA_EMPTY) {
+            const int64_t o = (int64_t)hk * P.stride + P.coff;
+            touch0 = P.W[o]; touch1 = P.m[o]; touch2 = P.v[o];
+        }
+    }
+#endif
     // ---- pass B: the entries of the keys with few contributions go to the list (key, position)
     if (!s_over) {
         for (int64_t c0 = 0; c0 < total; c0 += (int64_t)SA_KPT * SA_NT) {
@@ -298,13 +310,15 @@ __device__ __forceinline__ void sa_body(SaParams P, unsigned char* lds) {
         if (e == 0 || (uint32_t)(s_sorted[e] >> 32) != (uint32_t)(s_sorted[e - 1] >> 32)) s_seg[atomicAdd(&s_nseg, 1u)] = e;
     __syncthreads();
     const uint32_t nseg = s_nseg;
-    // (four runs per wave at a time: their (W, m, v) rows -- cold HBM lines of a table far larger than the caches -- are requested before
-    //  the contribution rows are summed, so a wave pays one memory round trip per four rows instead of two per row)
-    for (uint32_t s0 = wave; s0 < nseg; s0 += 4 * SA_NW) {
-        uint32_t key[4], start[4], len[4];
-        SaRow<VPT> w[4], mm[4], vv[4];
+    // (SA_RUNS runs per wave at a time, every load of the batch requested before anything is used: the runs' (W, m, v) rows -- cold lines of a
+    //  table far larger than the caches and the TLBs' reach -- AND the first four contribution rows of every run (most runs have one or two).
+    //  Run by run, contribution loads behind the previous run's stores, a wave paid a memory round trip per run: 21 us of the launch at config 5's
+    //  shapes with ALL keys distinct.  The order of every sum is unchanged.)
+    for (uint32_t s0 = wave; s0 < nseg; s0 += SA_RUNS * SA_NW) {
+        uint32_t key[SA_RUNS], start[SA_RUNS], len[SA_RUNS];
+        SaRow<VPT> w[SA_RUNS], mm[SA_RUNS], vv[SA_RUNS], g4[SA_RUNS][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SA_RUNS; ++u) {
             const uint32_t s = s0 + u * SA_NW;
             len[u] = 0; key[u] = 0; start[u] = 0;
             if (s < nseg) {
@@ -316,13 +330,31 @@ __device__ __forceinline__ void sa_body(SaParams P, unsigned char* lds) {
                 w[u] = sa_load<VPT>(P.W, (int64_t)key[u], lane, P.stride, P.coff);
                 mm[u] = sa_load<VPT>(P.m, (int64_t)key[u], lane, P.stride, P.coff);
                 vv[u] = sa_load<VPT>(P.v, (int64_t)key[u], lane, P.stride, P.coff);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                    // (clamped to the run's last entry: a valid row, not used)
+                    const uint32_t ej = start[u] + ((uint32_t)j < len[u] ? (uint32_t)j : len[u] - 1);
+                    g4[u][j] = sa_load<VPT>(P.g, (int64_t)(uint32_t)s_sorted[ej], lane, P.stride, P.coff);
+                }
             }
         }
         const float ss = P.hyper ? P.hyper[0] : P.step_size, ib = P.hyper ? P.hyper[1] : P.inv_sqrt_bc2;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SA_RUNS; ++u) {
             if (len[u] == 0) continue;
-            const SaRow<VPT> G = sa_sum<VPT>(P.g, s_sorted, (int)start[u], (int)(start[u] + len[u]), lane, P.stride, P.coff);
+            SaRow<VPT> G;
+            if (len[u] >= 4) {                                   // (sa_sum's order: groups of four with explicit roundings, then singles)
+#pragma unroll
+                for (int c = 0; c < VPT; ++c) G.x[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, g4[u][0].x[c]), g4[u][1].x[c]), g4[u][2].x[c]), g4[u][3].x[c]);
+                if (len[u] > 4) G = sa_sum<VPT>(P.g, s_sorted, (int)start[u] + 4, (int)(start[u] + len[u]), lane, P.stride, P.coff, G);
+            } else {
+#pragma unroll
+                for (int c = 0; c < VPT; ++c) {
+                    G.x[c] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if ((uint32_t)j < len[u]) G.x[c] += g4[u][j].x[c];
+                }
+            }
 #pragma unroll
             for (int c = 0; c < VPT; ++c) sa_adam_one(P, ss, ib, G.x[c], w[u].x[c], mm[u].x[c], vv[u].x[c]);
             sa_store<VPT>(P.W, (int64_t)key[u], lane, w[u], P.stride, P.coff);
@@ -336,5 +368,8 @@ __device__ __forceinline__ void sa_body(SaParams P, unsigned char* lds) {
     __syncthreads();
     const uint32_t nheavy = s_nheavy;
     for (uint32_t h = 0; h < nheavy; ++h) sa_heavy<VPT, KeyT>(P, s_seg[h], rows, queue, s_part, lane, wave);
+#ifndef SA_NO_TOUCH
+    asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));
+#endif
 }
 

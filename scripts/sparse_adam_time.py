@@ -1,52 +1,31 @@
-"""re_sparse_adam_rows (sort + segmented sum) vs re_sparse_adam_rows_small (owner-computes, one launch) on a config-5-shaped step:
-3 regions of compact rows, Zipf(1.05) sequence / positive items, uniform negatives, a table far larger than the caches."""
+"""Time of re_sparse_adam_rows_small on config-5-shaped key lists: Zipf(1.05) items in two of the three regions vs all-uniform keys."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import torch
+import numpy as np, torch
+import bench
 from recboard_amd import ops
-
-R, D = int(os.environ.get("ROWS", 20_000_000)), 128
-NR, live = 32768, 16 * 310
-rng = np.random.default_rng(1)
-W = torch.randn(R, D, device="cuda"); m = torch.zeros_like(W); v = torch.zeros_like(W)
-g = torch.randn(3 * NR, D, device="cuda")
-n_dev = torch.tensor([310], dtype=torch.int32, device="cuda")
-
-
-def keys_for(dist):
-    k = np.zeros((3, NR), np.int32)
-    if dist == "zipf":
-        k[0, :live] = np.minimum(rng.zipf(1.05, live), R - 1)
-        k[1, :live] = np.minimum(rng.zipf(1.05, live), R - 1)
-    else:
-        k[0, :live] = rng.integers(1, R, live)
-        k[1, :live] = rng.integers(1, R, live)
-    k[2, :live] = rng.integers(1, R, live)
-    k[:, :live][rng.random((3, live)) < 0.3] = 0          # slot padding inside the tiles
-    return torch.from_numpy(k).cuda()
-
-
-def timed(f, reps=30):
-    for _ in range(3):
-        f()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        f()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps * 1e3
-
-
-for dist in ("uniform", "zipf"):
-    keys = keys_for(dist)
-    k64 = keys.view(-1).long()
-    ws = torch.empty(ops.lib.load().re_scatter_add_rows_workspace_bytes(k64.numel(), D, R), dtype=torch.uint8, device="cuda")
-    t_old = timed(lambda: ops.sparse_adam_rows(g, k64, W, m, v, 3, 1e-3, padding_idx=0, ws=ws))
-    t_new = timed(lambda: ops.sparse_adam_rows_small(g, keys, W, m, v, step=3, lr=1e-3, padding_idx=0, n_dev=n_dev, n_mul=16))
-    t_new_all = timed(lambda: ops.sparse_adam_rows_small(g, keys, W, m, v, step=3, lr=1e-3, padding_idx=0))
-    u, c = torch.unique(k64[k64 > 0], return_counts=True)
-    print(f"{dist}: sorted {t_old:.1f} us   small (live rows) {t_new:.1f} us   small (all {3 * NR} keys) {t_new_all:.1f} us   distinct {u.numel()} max run {int(c.max())}",
-          flush=True)
+R, D, NR, live = int(os.environ.get("SA_ROWS", "20000001")), 128, 4096, 3616
+NSETS = int(os.environ.get("SA_SETS", "8"))   # distinct key sets cycled through (8: the rows stay in the Infinity Cache; 64+: cold)
+rng = np.random.default_rng(3)
+W = torch.zeros((R, D), device="cuda"); m = torch.zeros_like(W); v = torch.zeros_like(W)
+g = torch.randn((3 * NR, D), device="cuda")
+hyper = torch.tensor([1e-3, 1.0], device="cuda")
+n_dev = torch.tensor([live // 16], dtype=torch.int32, device="cuda")
+w = 1.0 / np.arange(1, 2_000_001) ** 1.05; w /= w.sum()          # (Zipf over the first 2 M ids: the head is what matters here)
+cdf = np.cumsum(w)
+def zipf(n):
+    return (np.searchsorted(cdf, rng.random(n)) + 1).astype(np.int32)
+for name in ("zipf", "uniform", "zipf_top_removed"):
+    ks = []
+    for rep in range(NSETS):
+        k = np.zeros((3, NR), np.int32)
+        for r in range(3):
+            k[r, :live] = rng.integers(1, R, live) if (name == "uniform" or r == 2) else zipf(live)
+        if name == "zipf_top_removed":
+            k[(k > 0) & (k <= 4)] = 17
+        ks.append(torch.from_numpy(k).cuda())
+    i = [0]
+    def f():
+        ops.sparse_adam_rows_small(g, ks[i[0] % NSETS], W, m, v, hyper=hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-6, padding_idx=0, n_dev=n_dev, n_mul=16)
+        i[0] += 1
+    print(name, "%.1f us" % (1e3 * bench.graph_time_ms(f, reps=NSETS, iters=3)), "| contributions of the most frequent key:", int(np.bincount(ks[0].cpu().numpy().ravel())[1:].max()))
