@@ -133,18 +133,37 @@ int re_scatter_add_rows_small(const float* g, const int32_t* keys, int32_t n_reg
 int re_scatter_adam_rows_small(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
                                int32_t n_mul, int64_t n_host, int64_t D, int64_t R, int64_t padding_idx, float scale, float* dW,
                                const re_adam_fuse* adam, re_stream_t stream);
+/* The NEXT batch's preparation riding in a step's tail launch (re_sasrec_step_tail / _sparse): what re_sasrec_batch_prep computes -- mask,
+ * count, destination rows, the encoder's plan, the staged copies -- for the batch whose addresses `mail` holds, into the static buffers of the
+ * captured step that will consume it.  mail: three device words { seq, pos, neg } ([B, S] int64 each), written by re_sasrec_step_stage in front
+ * of the step (seq = 0: no next batch, nothing is prepared).  The outputs are re_sasrec_batch_prep's (seq_out .. rows_all optional). */
+typedef struct {
+    const void* mail;
+    int64_t B, S;
+    int32_t ncu, max_tiles, split_long;
+    void *seq_out, *pos_out, *neg_out, *valid, *count, *rows_all, *plan;
+    size_t plan_bytes;
+} re_next_prep;
+/* The launch in front of a captured step whose batch a previous tail launch prepared: step scalars into `state` (as re_sasrec_batch_prep),
+ * acc += prev_loss * weight (optional), the tile kernels' weight fragments (block_params != NULL: as re_sasrec_batch_prep_w), and the mailbox
+ * for THIS step's tail launch (next_seq = NULL: no next batch). */
+int re_sasrec_step_stage(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, void* mail, const int64_t* next_seq,
+                         const int64_t* next_pos, const int64_t* next_neg, int64_t B, int64_t S, const float* const* block_params,
+                         const float* last_w, const float* last_b, int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                         const float* prev_loss, float* loss_acc, float loss_weight, re_stream_t stream);
 /* The tail of a D = 64 SASRec training step as one launch + the reduction: re_scatter_adam_rows_small (or, table_adam NULL,
  * re_scatter_add_rows_small; scale 1, n from n_dev) over the step's contribution rows, whose 1024-thread workgroups then take the jobs of
  * re_sasrec_encoder_step_part(part = 4) -- the weight gradients of the encoder from the tape the item kernels left in `tape` / `ws` -- from
  * a ticket counter; enc_adam (optional) as there.  Both halves depend on the item kernels alone: one queue, no fork and join around them
  * (csrc/enc_tail.hip).  Results bit-identical to the two calls.  `ticket`: one zero-initialised uint32 of the caller's, left zero.
+ * next (optional, re_next_prep): the launch also prepares the next batch.
  * Replaces: embedding_dense_backward of the item table + the autograd weight gradients of SASRec/main.py:170-197's blocks + the optimizer
  * step over both (SASRec/main.py:249-252). */
 int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev, int32_t n_mul,
                         int64_t R, int64_t padding_idx, float* dW, const re_adam_fuse* table_adam, const int64_t* seq, int64_t B, int64_t S,
                         int64_t D, int64_t L, const void* plan, int32_t ncu, const void* tape, size_t tape_bytes, const float* dx0,
                         float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
-                        const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream);
+                        const re_adam_fuse* enc_adam, uint32_t* ticket, const re_next_prep* next, re_stream_t stream);
 /* The same tail for a LARGE item table (config 5): re_sparse_adam_rows_small (int32 keys, hyper from device memory) whose workgroups then take
  * the weight-gradient jobs; D = 64 or 128. */
 int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev, int64_t n_mul,
@@ -152,7 +171,7 @@ int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, int32_t n_re
                                double eps, double weight_decay, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L, const void* plan,
                                int32_t ncu, const void* tape, size_t tape_bytes, const float* dx0, float emb_scale, float* dPtab,
                                float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
-                               const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream);
+                               const re_adam_fuse* enc_adam, uint32_t* ticket, const re_next_prep* next, re_stream_t stream);
 size_t re_scatter_add_rows_workspace_bytes(int64_t n, int64_t D, int64_t R);
 int re_scatter_add_rows(const float* g, const int64_t* idx, int64_t n, int64_t D, int64_t R,
                         int64_t padding_idx, float scale, float* dW, int accumulate, void* ws, size_t ws_bytes,

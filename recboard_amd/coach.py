@@ -106,15 +106,17 @@ class Coach:
         own_sum = self.kind == "seq" and self._graphable() and hasattr(self.model, "begin_loss_accumulation")
         if own_sum:
             self.model.begin_loss_accumulation()
-        pipelined = self.kind == "seq" and self._graphable() and getattr(self.model, "pipelined_prep", False)
+        pipelined = self.kind == "seq" and self._graphable() and (getattr(self.model, "pipelined_prep", False) or
+                                                                 (getattr(self.model, "_tail_prep_ok", None) is not None and self.model._tail_prep_ok()))
         if pipelined:
             batches = _lookahead(batches)
         for data in batches:
             if pipelined:
-                # the NEXT batch is already on the device (one batch ahead): its preparation launch runs beside this step
                 data, nxt = data
+            if pipelined and "Sample" not in data:
+                # the NEXT batch is already on the device (one batch ahead): it is prepared during this step
                 loss = self.model.train_step_graph(data["ISeq"], data["IPos"], data["INeg"],
-                                                   next_batch=None if nxt is None else (nxt["ISeq"], nxt["IPos"], nxt["INeg"]))
+                                                   next_batch=None if nxt is None or "Sample" in nxt else (nxt["ISeq"], nxt["IPos"], nxt["INeg"]))
                 bsz = len(data["User"])
                 if not own_sum:
                     tot.add_(loss, alpha=bsz)

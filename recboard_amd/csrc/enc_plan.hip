@@ -155,3 +155,48 @@ extern "C" int re_seq_train_sample_prep(const int64_t* ptr, const int64_t* items
     return batch_prep_launch(nullptr, pos_out, neg_out, B, S, ncu, max_tiles, split_long, seq_out, pos_out, neg_out, valid, count, rows_all, plan,
                              plan_bytes, state, seed, step, lr, beta1, beta2, WP, SP, LA, stream);
 }
+
+// ---- the launch in FRONT of a captured step whose batch was prepared by the previous step's tail launch (re_next_prep, enc_tail.hip): what is
+//      left of the preparation launch -- the step scalars, the previous loss into the epoch sum, the tile kernels' weight fragments (they need
+//      the parameters the previous step's optimizer left) -- and the mailbox: where the FOLLOWING batch lives (seq = NULL: there is none).
+__global__ __launch_bounds__(PL_NT) void sasrec_step_stage_k(uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2,
+                                                             PlWeights WP, PlLoss LA, const int64_t** __restrict__ mail, const int64_t* nseq,
+                                                             const int64_t* npos, const int64_t* nneg) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x > 0) {
+        const int t = ((int)blockIdx.x - 1) * PL_NT + tid;
+        if (t < TLC_PREP_THREADS(WP.L, WP.ns)) {
+            if (WP.ns == 4) tl_prep_thread<4>(WP.P, WP.L, WP.wf, WP.epoch, t);
+            else tl_prep_thread<8>(WP.P, WP.L, WP.wf, WP.epoch, t);
+        }
+        return;
+    }
+    if (tid != 0) return;
+    if (LA.acc) LA.acc[0] += LA.prev[0] * LA.w;
+    if (state) {
+        state[0] = seed;
+        state[1] = 0u;
+        state[2] = __float_as_uint(step_size);
+        state[3] = __float_as_uint(inv_sqrt_bc2);
+    }
+    if (mail) { mail[0] = nseq; mail[1] = npos; mail[2] = nneg; }
+}
+
+extern "C" int re_sasrec_step_stage(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, void* mail,
+                                    const int64_t* next_seq, const int64_t* next_pos, const int64_t* next_neg, int64_t B, int64_t S,
+                                    const float* const* block_params, const float* last_w, const float* last_b, int64_t L, int64_t D, void* tape,
+                                    size_t tape_bytes, void* ws, size_t ws_bytes, const float* prev_loss, float* loss_acc, float loss_weight,
+                                    re_stream_t stream) {
+    re_clear_error();
+    if (!state || step < 1) return RE_EINVAL;
+    if (next_seq && (!next_pos || !next_neg || !mail)) return RE_EINVAL;
+    if ((prev_loss == nullptr) != (loss_acc == nullptr)) return RE_EINVAL;
+    PlWeights WP{};
+    const int rc = pl_fill_weights(WP, block_params, last_w, last_b, L, D, B, S, tape, tape_bytes, ws, ws_bytes);
+    if (rc != RE_OK) return rc;
+    const PlLoss LA{prev_loss, loss_acc, loss_weight};
+    const float ss = (float)(lr / (1.0 - pow(beta1, (double)step))), ib = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
+    hipLaunchKernelGGL(sasrec_step_stage_k, dim3(1 + (unsigned)WP.nblocks), dim3(PL_NT), 0, (hipStream_t)stream, state, seed, ss, ib, WP, LA,
+                       (const int64_t**)mail, next_seq, next_pos, next_neg);
+    return re_launch_status();
+}

@@ -8,6 +8,7 @@
 #include "enc_wgrad_job.h"
 #include "scatter_owner.h"
 #include "adam_rows_owner.h"
+#include "enc_plan_body.h"
 
 struct TailJobs {
     const float* tape;
@@ -23,22 +24,48 @@ struct TailJobs {
     unsigned* ticket;    // zero at launch; enc_grad_reduce_k (the next launch) zeroes it again
 };
 
+// The NEXT batch's preparation (enc_plan_body.h: it depends on the batch alone) as the first jobs of the ticket queue: one plan job, n_ew
+// element-wise jobs -- in front of a step it is a 14 us launch (one workgroup's chain of barriers and round trips), here it rides in
+// workgroups that are done with the table while others still work.  mail: device words { seq, pos, neg } of the next batch, written by
+// re_sasrec_step_stage in front of this step (seq = NULL: no next batch); outputs: the OTHER captured copy's static buffers.
+struct TailPrep {
+    const int64_t* const* mail;   // nullptr: this launch prepares nothing
+    int B, S, ncu, max_tiles, split_long, n_ew;
+    int64_t *seq_out, *pos_out, *neg_out;
+    uint8_t* valid;
+    int* count;
+    int64_t* rows_all;
+    int* plan;
+};
+static_assert(PL_NT == SO_NT && PL_NT == SA_NT, "the preparation jobs are written for the tail launches' workgroup size");
+
 // ---- weight-gradient jobs, two per ticket: matrix jobs q = 2 t + half -> (block, matrix, split) = (q / 144, q / 24 % 6, q % 24), then the
 //      position-table jobs (144 strides of the (position, chunk) list) -- both halves of a workgroup always run the same kind
 template <int D>
-__device__ __forceinline__ void tail_jobs(const TailJobs& J, float* lds) {
+__device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP, float* lds) {
     __shared__ int s_job;
     const int tid = threadIdx.x, half = tid >> 9, ht = tid & 511;
     float* jl = lds + half * wg_job_lds_floats<D>();
     constexpr int PER_PLANE = WG_NSPLIT * EG_NMAT;
     const int n_mat = J.L * PER_PLANE / 2, n_pos = J.ppart ? PER_PLANE / 2 : 0;
+    const int n_prep = TP.mail ? 1 + TP.n_ew : 0;
     const int n_tiles = enc_plan_view(J.plan, J.B, J.S).hdr[1];
     for (;;) {
         __syncthreads();   // (the launch's first part / the previous job's stages are done with the LDS)
         if (tid == 0) s_job = (int)atomicAdd(J.ticket, 1u);
         __syncthreads();
-        const int t = s_job;
-        if (t >= n_mat + n_pos) break;
+        int t = s_job;
+        if (t >= n_prep + n_mat + n_pos) break;
+        if (t < n_prep) {
+            const int64_t* nseq = TP.mail[0];
+            if (nseq) {                                        // (uniform)
+                const PlSample SP{};
+                if (t == 0) pl_plan(nseq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, SP, reinterpret_cast<unsigned char*>(lds));
+                else pl_elementwise(t - 1, TP.n_ew, nseq, TP.mail[1], TP.mail[2], TP.B, TP.S, TP.seq_out, TP.pos_out, TP.neg_out, TP.valid, TP.rows_all, SP);
+            }
+            continue;
+        }
+        t -= n_prep;
         if (t < n_mat) {
             const int q = 2 * t + half;
             wg_matrix_job<D>(ht, jl, q / PER_PLANE, (q / WG_NSPLIT) % EG_NMAT, q % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
@@ -51,18 +78,18 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, float* lds) {
 template <int D, int HS>
 __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                                     const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
-                                                    int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J) {
+                                                    int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
     so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds);
-    tail_jobs<D>(J, lds);
+    tail_jobs<D>(J, TP, lds);
 }
 
 // the same behind the row-sparse Adam of a LARGE table (adam_rows_owner.h; config 5: D = 128, HS = 2)
 template <int D, int HS>
-__global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J) {
+__global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
     sa_body<1, HS, int32_t>(P, reinterpret_cast<unsigned char*>(lds));
-    tail_jobs<D>(J, lds);
+    tail_jobs<D>(J, TP, lds);
 }
 
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);
@@ -71,6 +98,21 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
 int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
                            const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
                            hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket);
+
+static int tail_prep(TailPrep& TP, const re_next_prep* next) {
+    TP = TailPrep{};
+    if (!next) return RE_OK;
+    if (!next->mail || !next->plan || next->B <= 0 || next->S <= 0 || next->S > 64) return RE_EINVAL;
+    if (next->plan_bytes < enc_plan_bytes(next->B, next->S)) return RE_EWORKSPACE;
+    if (next->B > PL_LDS_B) return RE_EUNSUPPORTED;          // (the plan job keeps spans and placements in LDS)
+    const bool elementwise = next->seq_out || next->valid || next->rows_all || next->pos_out;
+    TP.mail = (const int64_t* const*)next->mail;
+    TP.B = (int)next->B; TP.S = (int)next->S; TP.ncu = next->ncu < 1 ? 1 : next->ncu; TP.max_tiles = next->max_tiles; TP.split_long = next->split_long;
+    TP.n_ew = elementwise ? (int)re_grid(next->B * next->S, PL_NT, 256) : 0;
+    TP.seq_out = (int64_t*)next->seq_out; TP.pos_out = (int64_t*)next->pos_out; TP.neg_out = (int64_t*)next->neg_out;
+    TP.valid = (uint8_t*)next->valid; TP.count = (int*)next->count; TP.rows_all = (int64_t*)next->rows_all; TP.plan = (int*)next->plan;
+    return RE_OK;
+}
 
 // the weight-gradient side of both entry points: checks, and the workspace as re_sasrec_encoder_step_part lays it out
 struct TailSide {
@@ -103,9 +145,13 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
                                    int64_t R, int64_t padding_idx, float* dW, const re_adam_fuse* table_adam, const int64_t* seq, int64_t B,
                                    int64_t S, int64_t D, int64_t L, const void* plan, int32_t ncu, const void* tape, size_t tape_bytes,
                                    const float* dx0, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
-                                   void* ws, size_t ws_bytes, const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream) {
+                                   void* ws, size_t ws_bytes, const re_adam_fuse* enc_adam, uint32_t* ticket, const re_next_prep* next,
+                                   re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
+    TailPrep TP;
+    const int rcp = tail_prep(TP, next);
+    if (rcp != RE_OK) return rcp;
     if (!g || !keys || !n_dev || (!dW && !table_adam) || R <= 0 || n_regions < 1 || n_regions > 4 || region_stride < 0 || n_mul < 1) return RE_EINVAL;
     if (D != 64) return RE_EUNSUPPORTED;
     if (table_adam && (!table_adam->param || !table_adam->m || !table_adam->v || !table_adam->hyper)) return RE_EINVAL;
@@ -126,12 +172,13 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
     while (nwg * rpw < R * HS) nwg *= 2;
     if (nwg > 4096) return RE_EUNSUPPORTED;
     const size_t lds_scatter = (size_t)SO_NG * rpw * (D / HS) * sizeof(float), lds_jobs = (size_t)2 * wg_job_lds_floats<64>() * sizeof(float);
-    const size_t ldsb = lds_scatter > lds_jobs ? lds_scatter : lds_jobs;
+    size_t ldsb = lds_scatter > lds_jobs ? lds_scatter : lds_jobs;
+    if (ldsb < (size_t)PL_LDS_BYTES) ldsb = PL_LDS_BYTES;
     hipStream_t s = (hipStream_t)stream;
     auto k = enc_tail_k<64, HS>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, (int64_t)0, R, rpw,
-                       padding_idx, 1.0f, dW, AD, T.J);
+                       padding_idx, 1.0f, dW, AD, T.J, TP);
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
                                   ticket);
@@ -143,9 +190,12 @@ extern "C" int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, i
                                           double beta2, double eps, double weight_decay, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                                           const void* plan, int32_t ncu, const void* tape, size_t tape_bytes, const float* dx0, float emb_scale,
                                           float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws, size_t ws_bytes,
-                                          const re_adam_fuse* enc_adam, uint32_t* ticket, re_stream_t stream) {
+                                          const re_adam_fuse* enc_adam, uint32_t* ticket, const re_next_prep* next, re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
+    TailPrep TP;
+    const int rcp = tail_prep(TP, next);
+    if (rcp != RE_OK) return rcp;
     if (!g || !keys || !n_dev || !W || !m || !v || !hyper || R <= 0 || n_regions < 1 || region_stride <= 0 || n_mul < 1) return RE_EINVAL;
     if (R >= 0xFFFFFFFEll || (int64_t)n_regions * region_stride >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 7u) return RE_EINVAL;
@@ -162,16 +212,16 @@ extern "C" int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, i
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {
         const size_t lds_jobs = (size_t)2 * wg_job_lds_floats<128>() * sizeof(float);
-        const size_t ldsb = lds_jobs > (size_t)SA_LDS_BYTES(1) ? lds_jobs : (size_t)SA_LDS_BYTES(1);
+        const size_t ldsb = lds_jobs > (size_t)SA_LDS_BYTES(1) ? lds_jobs : (size_t)SA_LDS_BYTES(1);   // (> PL_LDS_BYTES)
         auto k = enc_tail_sparse_k<128, 2>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J);
+        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J, TP);
     } else {
         const size_t lds_jobs = (size_t)2 * wg_job_lds_floats<64>() * sizeof(float);
         const size_t ldsb = lds_jobs > (size_t)SA_LDS_BYTES(1) ? lds_jobs : (size_t)SA_LDS_BYTES(1);
         auto k = enc_tail_sparse_k<64, 1>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J);
+        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J, TP);
     }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,

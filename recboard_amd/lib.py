@@ -72,9 +72,11 @@ SIGNATURES = {
     "re_scatter_add_rows_small": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _i64, _f32, _vp, _vp]),
     "re_scatter_adam_rows_small": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
     "re_sasrec_step_tail": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp, _f32, _vp,
-                                    _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "re_sasrec_step_tail_sparse": (_i32, [_vp, _vp, _i32, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _i64, _i64,
-                                           _i64, _vp, _i32, _vp, _sz, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+                                           _i64, _vp, _i32, _vp, _sz, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "re_sasrec_step_stage": (_i32, [_vp, _u32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _sz,
+                                     _vp, _vp, _f32, _vp]),
     "re_spmm_csr": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp, _sz, _vp]),
     "re_rows_sqnorm_workspace_bytes": (_sz, []),
     "re_rows_sqnorm": (_i32, [_vp, _i64, _i64, _vp, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),

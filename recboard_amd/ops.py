@@ -740,11 +740,47 @@ def scatter_add_rows_small(g, keys, R, out, n_regions=1, region_stride=None, n_d
     return out
 
 
+class NextPrep(ctypes.Structure):
+    """re_next_prep (include/recengine.h): the next batch's preparation as jobs of a step's tail launch."""
+    _fields_ = [("mail", ctypes.c_void_p), ("B", ctypes.c_int64), ("S", ctypes.c_int64), ("ncu", ctypes.c_int32), ("max_tiles", ctypes.c_int32),
+                ("split_long", ctypes.c_int32), ("seq_out", ctypes.c_void_p), ("pos_out", ctypes.c_void_p), ("neg_out", ctypes.c_void_p),
+                ("valid", ctypes.c_void_p), ("count", ctypes.c_void_p), ("rows_all", ctypes.c_void_p), ("plan", ctypes.c_void_p),
+                ("plan_bytes", ctypes.c_size_t)]
+
+
+def next_prep(mail, blob, B, S, max_tiles=4, split=False, ncu=None, tile=True):
+    """-> NextPrep: the batch whose addresses sasrec_step_stage leaves in `mail` (int64[4], device) is prepared into the staging `blob`
+    (sasrec_batch_prep(..., blob=blob)'s outputs) by the tail launch this is handed to.  Keeps `mail` and `blob` alive."""
+    _req(mail, torch.int64, "mail"); _req(blob, torch.uint8, "blob")
+    pb = prep_views(blob, B, S, cached=True)
+    n = NextPrep(_p(mail), B, S, int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2), _p(pb.seq), _p(pb.pos),
+                 _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel())
+    n._keep = (mail, blob, pb)
+    return n
+
+
+def sasrec_step_stage(state, seed, step, lr, beta1, beta2, B, S, mail=None, next_batch=None, weights=None, loss_acc=None):
+    """The launch in front of a captured step whose batch the previous step's tail launch prepared (re_sasrec_step_stage): the step scalars,
+    the loss fold, the tile kernels' weight fragments, and the addresses of the FOLLOWING batch for this step's tail launch (None: none)."""
+    _req(state, torch.int32, "state")
+    ns = npos = nn = None
+    if next_batch is not None:
+        ns, npos, nn = next_batch
+        _req(ns, torch.int64, "next seq"); _req(npos, torch.int64, "next pos"); _req(nn, torch.int64, "next neg")
+        if tuple(ns.shape) != (B, S) or tuple(npos.shape) != (B, S) or tuple(nn.shape) != (B, S):
+            raise ValueError("recengine: the next batch must have the captured step's shape")
+    if mail is not None:
+        _req(mail, torch.int64, "mail")
+    lib.check(lib.load().re_sasrec_step_stage(_p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), _p(mail), _p(ns),
+                                              _p(npos), _p(nn), B, S, *_weight_args(weights), *_loss_args(loss_acc), _stream()), "re_sasrec_step_stage")
+
+
 def sasrec_step_tail(g_rows, keys, R, out, n_dev, n_mul, seq, L, plan, tape, dx0, scale, dP, block_grads, g_last_w, g_last_b, ws, ticket,
-                     table_adam=None, enc_adam=None, n_regions=3, padding_idx=0):
+                     table_adam=None, enc_adam=None, n_regions=3, padding_idx=0, next=None):
     """scatter_add_rows_small(g_rows, keys, R, out, n_regions, n_dev=, n_mul=, adam=table_adam) and sasrec_encoder_step(part=4, adam=enc_adam)
     as ONE launch + the reduction (re_sasrec_step_tail; D = 64): the scatter-add's workgroups take the weight-gradient jobs when their rows are
-    done.  Bit-identical to the two calls.  ticket: a zero uint32/int32[1] of the caller's (left zero)."""
+    done.  Bit-identical to the two calls.  ticket: a zero uint32/int32[1] of the caller's (left zero).  next (NextPrep): the launch also
+    prepares the next batch (the one sasrec_step_stage named) into the other captured copy's staging buffers."""
     _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(n_dev, torch.int32, "n_dev"); _req(seq, torch.int64, "seq")
     _req(tape, torch.float32, "tape"); _req(dx0, torch.float32, "dx0"); _req(dP, torch.float32, "dP"); _req(ws, torch.uint8, "ws")
     _req(ticket, torch.int32, "ticket")
@@ -760,12 +796,12 @@ def sasrec_step_tail(g_rows, keys, R, out, n_dev, n_mul, seq, L, plan, tape, dx0
                                              _p(out), ctypes.byref(table_adam) if table_adam is not None else None, _p(seq), B, S, D, int(L), _p(plan),
                                              num_cus(seq.device), _p(tape), tape.numel() * 4, _p(dx0), float(scale), _p(dP), tg, _p(g_last_w),
                                              _p(g_last_b), _p(ws), ws.numel(), ctypes.byref(enc_adam) if enc_adam is not None else None,
-                                             _p(ticket), _stream()), "re_sasrec_step_tail")
+                                             _p(ticket), ctypes.byref(next) if next is not None else None, _stream()), "re_sasrec_step_tail")
     return out
 
 
 def sasrec_step_tail_sparse(g_rows, keys, W, m, v, hyper, beta1, beta2, eps, weight_decay, n_dev, n_mul, seq, L, plan, tape, dx0, scale, dP,
-                            block_grads, g_last_w, g_last_b, ws, ticket, enc_adam=None, padding_idx=0):
+                            block_grads, g_last_w, g_last_b, ws, ticket, enc_adam=None, padding_idx=0, next=None):
     """sparse_adam_rows_small(g_rows, keys [regions, stride] int32, W, m, v, hyper=, n_dev=, n_mul=) and sasrec_encoder_step(part=4,
     adam=enc_adam) as ONE launch + the reduction (re_sasrec_step_tail_sparse): the tail of a large-table step.  Bit-identical to the two calls."""
     _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(n_dev, torch.int32, "n_dev"); _req(seq, torch.int64, "seq")
@@ -783,7 +819,8 @@ def sasrec_step_tail_sparse(g_rows, keys, W, m, v, hyper, beta1, beta2, eps, wei
                                                     _p(m), _p(v), _p(hyper), float(beta1), float(beta2), float(eps), float(weight_decay), _p(seq), B, S, D,
                                                     int(L), _p(plan), num_cus(seq.device), _p(tape), tape.numel() * 4, _p(dx0), float(scale), _p(dP), tg,
                                                     _p(g_last_w), _p(g_last_b), _p(ws), ws.numel(),
-                                                    ctypes.byref(enc_adam) if enc_adam is not None else None, _p(ticket), _stream()),
+                                                    ctypes.byref(enc_adam) if enc_adam is not None else None, _p(ticket),
+                                                    ctypes.byref(next) if next is not None else None, _stream()),
               "re_sasrec_step_tail_sparse")
 
 

@@ -144,6 +144,7 @@ class SASRecEngine:
         self.split_long = True          # sequences of 3 - 4 tiles as two work items in two workgroups (fused BCE / BPR training step)
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
         self.fuse_tail = True           # D = 64: scatter-add and weight-gradient jobs in one launch (csrc/enc_tail.hip; same results)
+        self.prep_in_tail = True        # train_step_graph(next_batch=...): the next batch is prepared by jobs of this step's tail launch
         self.fork_wgrad = True          # otherwise: weight gradients on a side stream beside the item table's scatter-add (same results)
         self.tile_step = True           # the one-tile-per-workgroup kernels may run the training step (False: always the workgroup-per-item kernels)
         self.fuse_adam = True           # captured steps: the dense Adam inside the launches that finish the gradients (reduction / scatter-add)
@@ -361,7 +362,7 @@ class SASRecEngine:
                 ws_sc=u8(L.re_scatter_add_rows_workspace_bytes(n3, D, self.N + 1)))
         return self._bufs[key]
 
-    def _step_body(self, pb, sd, seed_dev=None, adam_hyper=None):
+    def _step_body(self, pb, sd, seed_dev=None, adam_hyper=None, next_prep=None):
         """Every launch of the fused step after the batch preparation up to (not including) the optimizer; gradients land in the
         gradient arena.  pb: ops.PreparedBatch.
         adam_hyper (device float32[2], captured steps with their own optimizer): the dense Adam too -- in the two-branch form as TWO
@@ -399,7 +400,7 @@ class SASRecEngine:
                 ops.sasrec_step_tail(W["g_rows"], W["keys"], self.N + 1, GE if (not fuse or getattr(self, "keep_table_grad", True)) else None,
                                      pb.plan.view(torch.int32)[1:2], 16, seq, self.L, pb.plan, W["tape"], W["contrib"][:n].view(B, S, D), float(D ** 0.5),
                                      G["Position.weight"], self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], self._ticket,
-                                     table_adam=fz, enc_adam=fz)
+                                     table_adam=fz, enc_adam=fz, next=next_prep)
                 return (loss, True) if fuse else loss
             if self.fused_item_kernel and getattr(self, "fork_wgrad", False):
                 # the item kernels, then TWO branches: the weight gradients (enc_wgrad_k + enc_grad_reduce_k) on a side stream beside the
@@ -536,17 +537,18 @@ class SASRecEngine:
     #      sets the step time).  Per step: the batch-preparation launch (raw (seq, pos, neg) -> the static buffers the graph reads:
     #      copies, valid / count / rows_all, the encoder's plan, per-step seed and Adam scalars as device words) + one graph launch.
     #      BCE / BPR only: the CE path's shapes depend on the batch's number of valid positions.
-    def _capture(self, B, S, with_adam, in_prep=True):
+    def _capture(self, B, S, with_adam, in_prep=True, blob=None, next_prep=None):
         """in_prep: the tile step's weight fragments come from the batch-preparation launch (False: from a launch inside the graph --
         the pipelined form, whose preparation launch runs before the previous step's optimizer has finished)."""
         A = self.arena
-        blob = torch.zeros(ops.prep_layout(B, S)[1], dtype=torch.uint8, device=self.device)
+        if blob is None:
+            blob = torch.zeros(ops.prep_layout(B, S)[1], dtype=torch.uint8, device=self.device)
         state = torch.zeros(4, dtype=torch.int32, device=self.device)
         hyper = state.view(torch.float32)[2:4]
         z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
 
         def body():
-            loss = self._step_body(pb, 0, seed_dev=state, adam_hyper=hyper if with_adam else None)
+            loss = self._step_body(pb, 0, seed_dev=state, adam_hyper=hyper if with_adam else None, next_prep=next_prep)
             if isinstance(loss, tuple):          # (the optimizer ran inside the step's two branches)
                 return loss[0]
             if with_adam:
@@ -613,17 +615,19 @@ class SASRecEngine:
         """`train_step_fused` on a RAW batch, replayed from a captured hipGraph: one batch-preparation launch (which also stages the
         batch and the step scalars into the graph's static buffers) + one graph launch.  Results are identical to the eager fused
         step.  The returned loss tensor is overwritten by the next call (the call after next with `next_batch`).
-        next_batch = (seq, pos, neg) of the FOLLOWING call, if the caller already has it (an epoch loop does): its preparation launch
-        then runs on a side stream BESIDE this step instead of in front of the next one -- it depends on the batch alone -- into the
-        buffers of a second captured copy of the step (two copies alternate).  The following call must pass the same three tensors,
-        unchanged; next_ready: an event after which they are complete (e.g. their host-to-device copies), if they are produced on
-        another stream."""
+        next_batch = (seq, pos, neg) of the FOLLOWING call, if the caller already has it (an epoch loop does): it is prepared DURING this
+        step instead of in front of the next one -- the preparation depends on the batch alone -- into the buffers of a second captured
+        copy of the step (two copies alternate): by jobs of this step's tail launch (`prep_in_tail`, D = 64 fused steps: _train_step_graph_tail),
+        otherwise by a preparation launch on a side stream.  The following call must pass the same three tensors, unchanged; next_ready: an
+        event after which they are complete (e.g. their host-to-device copies), if they are produced on another stream."""
         if self.loss_kind == "CE":
             raise NotImplementedError("graph replay: BCE / BPR only (CE shapes vary with the batch)")
         A = self.arena
         B, S = seq.shape
         if not hasattr(self, "_graphs"):
             self._graphs, self._staged, self._pipe_i = {}, None, 0
+        if grad_hook is None and self._tail_prep_ok() and (next_batch is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
+            return self._train_step_graph_tail(seq, pos, neg, next_batch, next_ready)
         staged, self._staged = self._staged, None
         hit = staged is not None and staged[0] is seq and staged[1] is pos and staged[2] is neg and staged[5] == (grad_hook is None, self.training)
         pipelined = hit or next_batch is not None
@@ -664,6 +668,56 @@ class SASRecEngine:
         if grad_hook is not None:
             grad_hook(A.grad)
             ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        self._note_loss(g["loss"], B)
+        return g["loss"].squeeze(0)
+
+    # ---- the pipelined form: the NEXT batch is prepared by jobs of THIS step's tail launch (csrc/enc_tail.hip: the preparation depends on the
+    #      batch alone, and most of the tail launch's workgroups are done with the item table long before its last one).  Two captured copies
+    #      of the step alternate; copy p reads the staging buffers p and its tail launch fills the buffers 1 - p from the addresses the stage
+    #      launch in front of it left in a mailbox.  Per step: one stage launch (step scalars, loss fold, weight fragments, mailbox) + one replay.
+    def _tail_prep_ok(self):
+        return bool(getattr(self, "prep_in_tail", False) and self.fused_item_kernel and self.D == 64 and getattr(self, "fuse_tail", True)
+                    and self.encoder == "fused" and self.compact_rows)
+
+    def _tail_pipe(self, B, S):
+        if not hasattr(self, "_tail_pipes"):
+            self._tail_pipes = {}
+        key = (B, S, self.training)
+        tp = self._tail_pipes.get(key)
+        if tp is None:
+            nbytes = ops.prep_layout(B, S)[1]
+            blobs = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            mail = torch.zeros(4, dtype=torch.int64, device=self.device)          # (zero: the captures' warm-up runs prepare nothing)
+            graphs = []
+            for p in range(2):                                                     # both copies now: a capture's warm-up overwrites its staging buffers
+                nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(), tile=self._wave_step())
+                graphs.append(self._capture(B, S, with_adam=True, in_prep=True, blob=blobs[p], next_prep=nxt))
+            tp = self._tail_pipes[key] = dict(blobs=blobs, mail=mail, graphs=graphs, parity=0, staged=None)
+        return tp
+
+    def _train_step_graph_tail(self, seq, pos, neg, next_batch, next_ready):
+        A = self.arena
+        B, S = seq.shape
+        tp = self._tail_pipe(B, S)
+        p = tp["parity"]
+        g = tp["graphs"][p]
+        st, tp["staged"] = tp["staged"], None
+        if not (st is not None and st[0] is seq and st[1] is pos and st[2] is neg):
+            # nobody prepared this batch: the plain preparation launch in front of the step (an epoch's first batch)
+            ops.sasrec_batch_prep(seq, pos, neg, blob=tp["blobs"][p], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
+                                  ncu=self._plan_ncu())
+        if next_batch is not None and tuple(next_batch[0].shape) != (B, S):
+            next_batch = None                                                      # (another shape: its own copies' buffers; prepared in front of its step)
+        if next_batch is not None and next_ready is not None:
+            torch.cuda.current_stream().wait_event(next_ready)
+        step = A.step + 1
+        sd = (self.seed * 0x9E3779B1 + step * 0x85EBCA77) & 0xFFFFFFFF          # (= _step_seed() once arena.step == step - 1)
+        ops.sasrec_step_stage(g["state"], sd, step, self.lr, self.betas[0], self.betas[1], B, S, mail=tp["mail"], next_batch=next_batch,
+                              weights=self._prep_weights(B, S), loss_acc=self._take_pending_loss())
+        g["graph"].replay()
+        A.step += 1
+        tp["parity"] = 1 - p
+        tp["staged"] = next_batch
         self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
 

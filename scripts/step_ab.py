@@ -16,13 +16,13 @@ for attr in [None] + sys.argv[1:]:
         if attr:
             setattr(m, attr, val)
         for i in range(30):
-            m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8] if m.pipelined_prep else None)
+            m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8] if (m.pipelined_prep or os.environ.get('STEP_AB_NEXT')) else None)
         torch.cuda.synchronize()
         best = 1e9
         for rep in range(5):
             t0 = time.perf_counter()
             for i in range(300):
-                loss = m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8] if m.pipelined_prep else None)
+                loss = m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8] if (m.pipelined_prep or os.environ.get('STEP_AB_NEXT')) else None)
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / 300)
         print(f"{attr}={val}: {best * 1e6:.1f} us/step  loss {float(loss):.5f}", flush=True)

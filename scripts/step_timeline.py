@@ -6,7 +6,9 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
 rows = db.execute(f"select name, start, end, {q} from kernels order by start").fetchall()
-prep = [i for i, r in enumerate(rows) if r[0].startswith("sasrec_batch_prep_k")]
+import os
+key = os.environ.get("TL_KEY", "sasrec_batch_prep_k")       # the kernel a step starts with (sasrec_step_stage_k: the pipelined step)
+prep = [i for i, r in enumerate(rows) if r[0].startswith(key)]
 i0, i1 = prep[-back - 1], prep[-back]
 t0 = rows[i0][1]
 last_end = None

@@ -348,9 +348,11 @@ def test_ce_in_catalog_chunks_equals_materialised_ce():
         torch.testing.assert_close(gb[k], ga[k], rtol=1e-4, atol=1e-7, msg=k)
 
 
-def test_pipelined_preparation_gives_the_same_steps():
-    """train_step_graph(next_batch=...): the next batch's preparation launch on a side stream, two captured copies alternating -- the same
-    losses and parameters as the plain captured step (dropout on: the per-step seeds must line up too)."""
+@pytest.mark.parametrize("in_tail", [True, False])
+def test_pipelined_preparation_gives_the_same_steps(in_tail):
+    """train_step_graph(next_batch=...): the next batch prepared during the step -- by jobs of the step's tail launch (in_tail) or by a
+    preparation launch on a side stream --, two captured copies alternating: the same losses and parameters as the plain captured step
+    (dropout on: the per-step seeds must line up too)."""
     from recboard_amd.sasrec import SASRecEngine
     N, B, S = 500, 48, 50
     rng = np.random.default_rng(12)
@@ -365,12 +367,24 @@ def test_pipelined_preparation_gives_the_same_steps():
         batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
     a = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, lr=1e-3, seed=4)
     b = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, lr=1e-3, seed=4)
-    for i in range(7):
+    a.prep_in_tail = False
+    b.prep_in_tail = in_tail
+    for i in range(9):
         la = a.train_step_graph(*batches[i % 5]).clone()
-        lb = b.train_step_graph(*batches[i % 5], next_batch=batches[(i + 1) % 5] if i < 6 else None).clone()
-        torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-7)
-    assert b._staged is None and len([k for k in b._graphs if len(k) == 5]) == 2
-    torch.testing.assert_close(b.arena.data, a.arena.data, rtol=1e-4, atol=1e-6)
+        # (step 4 is called WITHOUT the batch the step before announced, step 5 announces nothing: both must fall back to a preparation in front)
+        nxt = batches[(i + 1) % 5] if i not in (5, 8) else None
+        cur = batches[i % 5] if i != 4 else tuple(t.clone() for t in batches[i % 5])
+        lb = b.train_step_graph(*cur, next_batch=nxt).clone()
+        if in_tail:
+            assert torch.equal(lb, la), i
+        else:
+            torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-7)
+    if in_tail:
+        assert torch.equal(b.arena.data, a.arena.data)
+        assert len(b._tail_pipes) == 1 and int(b._ticket.item()) == 0
+    else:
+        assert b._staged is None and len([k for k in b._graphs if len(k) == 5]) == 2
+        torch.testing.assert_close(b.arena.data, a.arena.data, rtol=1e-4, atol=1e-6)
     b.check_handover()
 
 
