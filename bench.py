@@ -313,7 +313,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the aten-on-GPU baselines (kernel-trace runs: only the engine's kernels)")
     ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
-    ap.add_argument("--prefetch", action="store_true", help="the next batch's preparation launch on a side stream beside the step (measured slower: 115+ vs 106 us)")
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
+                    help="do not hand train_step_graph the next batch (default: an epoch loop has it; it is prepared by jobs of this step's tail launch)")
+    ap.add_argument("--prefetch", dest="prefetch", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(prefetch=True)
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -360,7 +363,7 @@ def main():
 
     def step_graph(i):   # RAW batch in: one preparation launch (mask, count, scatter rows, encoder plan, staging) + one graph replay
         seq, pos, neg, _ = batches[i % len(batches)]
-        nxt = batches[(i + 1) % len(batches)][:3] if args.prefetch else None   # (--prefetch: the next batch's preparation beside this step)
+        nxt = batches[(i + 1) % len(batches)][:3] if args.prefetch and hook is None else None   # (the next batch: prepared during this step)
         return model.train_step_graph(seq, pos, neg, grad_hook=hook, next_batch=nxt)
 
     # Graph or eager launches: decided BEFORE any step that contains a collective runs.  Every rank captures and replays one step
@@ -421,8 +424,12 @@ def main():
         "config": {"workload": "SASRec d=64 L=2 maxlen=50 BCE dropout=0.5 Adam on Amazon2014Beauty_550_LOU shapes "
                                "(12101 items, 22363 users), B=512 per GPU",
                    "global_batch": world * cfg["B"], "seq_len": cfg["S"],
-                   "launch": "one batch-preparation launch + one hipGraph replay per step" if use_graph else "eager (one launch per kernel)",
-                   "timed_region": "raw (seq, pos, neg) in HBM -> batch preparation launch -> forward, backward, Adam (dropout 0.5 on)",
+                   "launch": (("one stage launch (step scalars, weight fragments, the next batch's addresses) + one hipGraph replay per step; every step "
+                               "prepares the NEXT raw batch in jobs of its tail launch (train_step_graph(next_batch=...), as an epoch loop calls it)")
+                              if args.prefetch and hook is None else "one batch-preparation launch + one hipGraph replay per step")
+                   if use_graph else "eager (one launch per kernel)",
+                   "timed_region": "raw (seq, pos, neg) in HBM -> batch preparation (mask, count, rows, plan) -> forward, backward, Adam (dropout 0.5 on): "
+                                   "every timed step does all of it for one batch",
                    "parallelism": f"dp{world} (replicated 3 MB table, one gradient-arena all-reduce per step)"},
         "world_size": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
         "final_loss": round(float(loss), 5),

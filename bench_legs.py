@@ -259,12 +259,13 @@ def leg_config5(steps=128, warmup=16, nbatch=64):
         torch.cuda.synchronize()
         t_init = time.time() - t0
         bs = c5_batches(np.random.default_rng(1), nbatch, N, B, S)
+        # (an epoch loop has the next batch at hand: it is prepared by jobs of this step's tail launch -- SASRecLargeTableEngine._train_step_graph_tail)
         for i in range(warmup):
-            eng.train_step_graph(*bs[i % nbatch])
+            eng.train_step_graph(*bs[i % nbatch], next_batch=bs[(i + 1) % nbatch])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            loss = eng.train_step_graph(*bs[(warmup + i) % nbatch])
+            loss = eng.train_step_graph(*bs[(warmup + i) % nbatch], next_batch=bs[(warmup + i + 1) % nbatch])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         eng.check_handover()
@@ -279,7 +280,7 @@ def leg_config5(steps=128, warmup=16, nbatch=64):
                "unit": "samples/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "warmup": warmup, "distinct_batches": nbatch,
                "final_loss": round(float(loss), 5), "table": f"{N + 1} x {D} fp32 + two Adam moment tables",
                "hbm_used_GB": round((total - free2) / 1e9, 1), "table_init_s": round(t_init, 1), "hbm_traffic_per_step": traffic,
-               "launch": "one batch-preparation launch + one hipGraph replay per step",
+               "launch": "one stage launch + one hipGraph replay per step; the next batch is prepared by jobs of the step's tail launch",
                "data": "synthetic: Zipf(1.05) item popularity, lengths ~ clip(Geometric(mean 5.9) + 1, 1, 49)"}
         del eng, bs
         torch.cuda.empty_cache()

@@ -126,7 +126,7 @@ class SASRecLargeTableEngine(SASRecEngine):
             x0 = ops.sasrec_embed(self.E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), p, self._step_seed())
             return self._blocks(x0, (seq == 0).unsqueeze(-1)), self.E[1:]
 
-    def _grads(self, seq, pos, neg, aux, sd, seed_dev=None, table=None, adam_hyper=None):
+    def _grads(self, seq, pos, neg, aux, sd, seed_dev=None, table=None, adam_hyper=None, next_prep=None):
         """Forward + backward: encoder gradients into the arena, the item-gradient contribution rows C with their destination rows
         (0 = none).  -> (loss, C, rows).
         `table` (default: the item table) is what seq / pos / neg index: the sharded engine passes its batch-local table.
@@ -164,7 +164,7 @@ class SASRecLargeTableEngine(SASRecEngine):
                 ops.sasrec_step_tail_sparse(W["g_rows"].view(-1, D), W["keys"], self.E, self.Em, self.Ev, adam_hyper, self.betas[0], self.betas[1], 1e-8,
                                             self.wd, aux.plan.view(torch.int32)[1:2], 16, seq, self.L, aux.plan, W["tape"], W["contrib"][:n].view(B, S, D),
                                             float(D ** 0.5), G["Position.weight"], self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"],
-                                            W["ws_bwd"], self._ticket, enc_adam=fz)
+                                            W["ws_bwd"], self._ticket, enc_adam=fz, next=next_prep)
                 return loss, W["g_rows"].view(-1, D), W["keys"], True
             if adam_hyper is not None and table is None and self.fused_item_kernel and getattr(self, "fork_wgrad", True):
                 args = (E, Ppos.detach(), seq, pos, neg, float(D ** 0.5), self._block_tensors(), lw, lb, self.L, p, sd, aux.plan, kind, count, W["u"],
@@ -251,15 +251,16 @@ class SASRecLargeTableEngine(SASRecEngine):
     # ---- the same step as one hipGraph replay: at D = 128 the block stack is ~300 torch launches per step and the CPU launch
     #      path, not the GPU, sets the step time.  (The torch dropout inside the captured blocks draws from torch's graph-safe
     #      Philox state; the engine's own masks get their per-step seed through the device word, as in SASRecEngine.)
-    def _capture(self, B, S, with_adam):
+    def _capture(self, B, S, with_adam, blob=None, next_prep=None):
         A = self.arena
-        blob = torch.zeros(ops.prep_layout(B, S)[1], dtype=torch.uint8, device=self.device)
+        if blob is None:
+            blob = torch.zeros(ops.prep_layout(B, S)[1], dtype=torch.uint8, device=self.device)
         state = torch.zeros(4, dtype=torch.int32, device=self.device)
         hyper = state.view(torch.float32)[2:4]
         z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
 
         def body():
-            out = self._grads(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, adam_hyper=hyper if with_adam else None)
+            out = self._grads(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, adam_hyper=hyper if with_adam else None, next_prep=next_prep)
             loss, C, rows = out[:3]
             if with_adam and len(out) == 3:     # (else: both optimizers ran inside the step's two branches)
                 self._table_adam(C, rows, pb, hyper=hyper)
@@ -285,9 +286,55 @@ class SASRecLargeTableEngine(SASRecEngine):
             t.copy_(k)
         return dict(graph=graph, blob=blob, state=state, loss=loss, C=C, rows=rows, pb=pb)
 
-    def train_step_graph(self, seq, pos, neg, grad_hook=None):
+    # ---- the pipelined form (SASRecEngine._train_step_graph_tail): the next batch is prepared by jobs of this step's tail launch
+    def _tail_prep_ok(self):
+        return bool(getattr(self, "prep_in_tail", True) and self.fused_item_kernel and getattr(self, "fuse_tail", True) and self.encoder == "fused"
+                    and self.compact_rows and self.D in (64, 128) and type(self)._grads is SASRecLargeTableEngine._grads
+                    and type(self).train_step_graph is SASRecLargeTableEngine.train_step_graph)
+
+    def _tail_pipe(self, B, S):
+        if not hasattr(self, "_tail_pipes"):
+            self._tail_pipes = {}
+        key = (B, S, self.training)
+        tp = self._tail_pipes.get(key)
+        if tp is None:
+            nbytes = ops.prep_layout(B, S)[1]
+            blobs = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            mail = torch.zeros(4, dtype=torch.int64, device=self.device)
+            graphs = []
+            for p in range(2):
+                nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step())
+                graphs.append(self._capture(B, S, with_adam=True, blob=blobs[p], next_prep=nxt))
+            tp = self._tail_pipes[key] = dict(blobs=blobs, mail=mail, graphs=graphs, parity=0, staged=None)
+        return tp
+
+    def _train_step_graph_tail(self, seq, pos, neg, next_batch, next_ready):
         A = self.arena
         B, S = seq.shape
+        tp = self._tail_pipe(B, S)
+        p = tp["parity"]
+        g = tp["graphs"][p]
+        st, tp["staged"] = tp["staged"], None
+        if not (st is not None and st[0] is seq and st[1] is pos and st[2] is neg):
+            ops.sasrec_batch_prep(seq, pos, neg, blob=tp["blobs"][p], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step())
+        if next_batch is not None and tuple(next_batch[0].shape) != (B, S):
+            next_batch = None
+        if next_batch is not None and next_ready is not None:
+            torch.cuda.current_stream().wait_event(next_ready)
+        ops.sasrec_step_stage(g["state"], self._step_seed(), A.step + 1, self.lr, self.betas[0], self.betas[1], B, S, mail=tp["mail"],
+                              next_batch=next_batch, weights=self._prep_weights(B, S), loss_acc=self._take_pending_loss())
+        g["graph"].replay()
+        A.step += 1
+        tp["parity"] = 1 - p
+        tp["staged"] = next_batch
+        self._note_loss(g["loss"], B)
+        return g["loss"].squeeze(0)
+
+    def train_step_graph(self, seq, pos, neg, grad_hook=None, next_batch=None, next_ready=None):
+        A = self.arena
+        B, S = seq.shape
+        if grad_hook is None and self._tail_prep_ok() and (next_batch is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
+            return self._train_step_graph_tail(seq, pos, neg, next_batch, next_ready)
         key = (B, S, grad_hook is None, self.training)
         if not hasattr(self, "_graphs"):
             self._graphs = {}

@@ -460,3 +460,30 @@ def test_large_table_one_launch_tail_equals_the_two_branch_form(D):
         assert torch.equal(getattr(eng[0][0], name), getattr(eng[1][0], name)), name
     assert torch.equal(eng[0][0].arena.data, eng[1][0].arena.data)
     assert int(eng[0][0]._ticket.item()) == 0
+
+
+def test_large_table_pipelined_preparation_gives_the_same_steps():
+    """SASRecLargeTableEngine.train_step_graph(next_batch=...): the next batch prepared by jobs of the step's tail launch
+    (re_sasrec_step_tail_sparse + re_next_prep) -- the same table, parameters and losses as the plain captured step, bit for bit."""
+    from recboard_amd.large import SASRecLargeTableEngine
+    N, B, S, D = 4000, 64, 50, 128
+    rng = np.random.default_rng(35)
+    batches = []
+    for _ in range(4):
+        seq = np.zeros((B, S), np.int64)
+        for b in range(B):
+            n = int(rng.integers(1, S + 1))
+            seq[b, S - n:] = np.minimum(rng.zipf(1.3, n), N)
+        pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
+    a = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.3, lr=1e-3, weight_decay=1e-6, seed=4)
+    b = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.3, lr=1e-3, weight_decay=1e-6, seed=4)
+    for i in range(7):
+        la = a.train_step_graph(*batches[i % 4]).clone()
+        lb = b.train_step_graph(*batches[i % 4], next_batch=batches[(i + 1) % 4] if i != 3 else None).clone()
+        assert torch.equal(lb, la), i
+    for name in ("E", "Em", "Ev"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.arena.data, b.arena.data)
+    assert len(b._tail_pipes) == 1 and not getattr(a, "_tail_pipes", {})
