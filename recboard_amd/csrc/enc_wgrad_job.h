@@ -4,6 +4,7 @@
 // only (never on the job): groups that run different jobs of one kind side by side stay in step.
 #pragma once
 #include "enc_common.h"
+#include "enc_tile_prep.h"
 
 #ifndef WG_NSPLIT
 #define WG_NSPLIT 24
@@ -15,11 +16,20 @@ __host__ __device__ constexpr int wg_job_lds_floats() { return 2 * 16 * WG_CH * 
 
 // dW partial of (block l, matrix m, row split): out[D][D] = sum over the split's row tiles of dY^T X.   tid: 0 .. 511 within the group.
 //   gradient-tape order: 0 dO2 (x HR -> W2)  1 dH (x Y -> W1)  2 dX1 (x O -> Wo)  3 dQ (x A -> Wq)  4 dK (x X -> Wk)  5 dV (x X -> Wv)
+// The contraction runs over the batch's ROWS, on the XDL pipe as bf16 hi / mid three-product splits (the tile kernels' arithmetic:
+// hi = bf16(x), mid = bf16(x - hi); hi*hi + hi*mid + mid*hi, fp32 accumulation; <= 3.01 * 2^-18 relative per product): sixteen waves of fp32
+// MFMAs per CU were what a job took (7.7 of the ~8 us a stage took at D = 128).  Both operands are split where they are STAGED -- once per
+// element, not once per wave that reads it: a thread fetches the same four columns of two consecutive rows and writes them as four
+// {row 2p, row 2p + 1} bf16 pairs per plane, so that a lane's MFMA operand (eight consecutive rows of one column) is four words of a column.
 template <int D>
 __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m, int split, const float* __restrict__ tape, const EncTape& T,
                                               const float* __restrict__ gtape, int64_t NR, int n_tiles, float* __restrict__ part) {
     using C = EC<D>;
     constexpr int RTW = C::NS / C::WR;   // output row tiles per wave
+    constexpr int RSW = D + 4;           // words of a row pair (+ 4: the four lane groups of a fragment read land in four bank quarters)
+    constexpr int NPAIR = 16 * WG_CH / 2;
+    constexpr int PLANE = NPAIR * RSW;
+    static_assert(4 * PLANE == wg_job_lds_floats<D>(), "four planes (dY hi, mid, X hi, mid) fill the job's LDS");
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int strip = wave % C::NS, wr = wave / C::NS, g = lane >> 4, c = lane & 15;
     const int per = (n_tiles + WG_NSPLIT - 1) / WG_NSPLIT;
@@ -29,24 +39,29 @@ __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m,
     const int64_t xoff = (m == 0) ? T.off_HR : (m == 1) ? T.off_Y : (m == 2) ? T.off_O : (m == 3) ? T.off_A : T.off_X;
     const float* X = tape + (int64_t)l * T.per_block + xoff;
     const float* dY = gtape + ((int64_t)l * EG_NMAT + m) * NR * D;
-    float* bufA = lds;
-    float* bufB = lds + 16 * WG_CH * C::LS;
+    uint32_t* aH = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* aM = aH + PLANE;
+    uint32_t* bH = aM + PLANE;
+    uint32_t* bM = bH + PLANE;
     f32x4 acc[RTW];
 #pragma unroll
     for (int t = 0; t < RTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // stages of WG_CH row tiles through LDS; the next stage's rows are requested into registers before this stage's products
     // (every stage is a memory round trip: four of them in a row were most of the launch)
-    constexpr int NQ = 16 * WG_CH * (D / 4) / C::NT;
-    f32x4 ra[NQ], rb[NQ];   // (native vectors and a macro: HIP's float4 struct arrays / arrays captured by a lambda stay in scratch memory)
+    constexpr int NP = NPAIR * (D / 4) / C::NT;   // (row pair, four columns) units per thread: 1 at D = 64, 2 at D = 128
+    f32x4 ra[NP][2], rb[NP][2];   // (native vectors and a macro: HIP's float4 struct arrays / arrays captured by a lambda stay in scratch memory)
 #define WG_FETCH(TC)                                                                                            \
     do {                                                                                                        \
         const int ntc_ = (t1 - (TC)) < WG_CH ? (t1 - (TC)) : WG_CH;                                             \
         const int nf_ = 16 * ntc_ * (D / 4);                                                                    \
-        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                        \
-            int f = q * C::NT + tid;                                                                            \
-            f = f < nf_ ? f : nf_ - 1;   /* clamped, unconditional: a predicated load is waited for on the spot */ \
-            ra[q] = reinterpret_cast<const f32x4*>(dY + (int64_t)(TC) * 16 * D)[f];                             \
-            rb[q] = reinterpret_cast<const f32x4*>(X + (int64_t)(TC) * 16 * D)[f];                              \
+        _Pragma("unroll") for (int j = 0; j < NP; ++j) {                                                        \
+            const int u_ = j * C::NT + tid, p_ = u_ / (D / 4), c4_ = u_ % (D / 4);                              \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                     \
+                int f = (2 * p_ + e) * (D / 4) + c4_;                                                           \
+                f = f < nf_ ? f : nf_ - 1;   /* clamped, unconditional: a predicated load is waited for on the spot */ \
+                ra[j][e] = reinterpret_cast<const f32x4*>(dY + (int64_t)(TC) * 16 * D)[f];                      \
+                rb[j][e] = reinterpret_cast<const f32x4*>(X + (int64_t)(TC) * 16 * D)[f];                       \
+            }                                                                                                   \
         }                                                                                                       \
     } while (0)
     if (t0 < t1) WG_FETCH(t0);
@@ -54,31 +69,42 @@ __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m,
         const int tc = t0 + it * WG_CH;
         const int left = t1 - tc;
         const int ntc = left < WG_CH ? (left > 0 ? left : 0) : WG_CH;
-        const int nf = 16 * ntc * (D / 4);
         enc_sync();
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int f = q * C::NT + tid;
-            if (f < nf) {
-                const int r = f / (D / 4), c4 = f % (D / 4);
-                *reinterpret_cast<f32x4*>(bufA + r * C::LS + 4 * c4) = ra[q];
-                *reinterpret_cast<f32x4*>(bufB + r * C::LS + 4 * c4) = rb[q];
+        for (int j = 0; j < NP; ++j) {
+            const int u = j * C::NT + tid, p = u / (D / 4), c4 = u % (D / 4);
+            const bool live = 2 * p < 16 * ntc;      // (rows come in pairs: 16 ntc is even; pairs behind the stage's rows are zero)
+            tl_u32x4 h, md, h2, md2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned x, y;
+                tl_split2(live ? ra[j][0][i] : 0.f, live ? ra[j][1][i] : 0.f, x, y);
+                h[i] = x; md[i] = y;
+                tl_split2(live ? rb[j][0][i] : 0.f, live ? rb[j][1][i] : 0.f, x, y);
+                h2[i] = x; md2[i] = y;
             }
+            *reinterpret_cast<tl_u32x4*>(aH + p * RSW + 4 * c4) = h;
+            *reinterpret_cast<tl_u32x4*>(aM + p * RSW + 4 * c4) = md;
+            *reinterpret_cast<tl_u32x4*>(bH + p * RSW + 4 * c4) = h2;
+            *reinterpret_cast<tl_u32x4*>(bM + p * RSW + 4 * c4) = md2;
         }
         if (tc + WG_CH < t1) WG_FETCH(tc + WG_CH);
         enc_sync();
-        for (int q = 0; q < ntc; ++q) {
-            float bf[4];
+        const int ksteps = (ntc + 1) >> 1;           // 32 rows (two row tiles) per MFMA
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int w0 = (16 * ks + 4 * g) * RSW + c;       // the lane's four row pairs: rows 32 ks + 8 g + (0 .. 7)
+            tl_u32x4 bh, bm;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bf[i] = bufB[(16 * q + 4 * g + i) * C::LS + 16 * strip + c];
+            for (int i = 0; i < 4; ++i) { bh[i] = bH[w0 + i * RSW + 16 * strip]; bm[i] = bM[w0 + i * RSW + 16 * strip]; }
 #pragma unroll
             for (int t = 0; t < RTW; ++t) {
                 const int mt = t * C::WR + wr;
-                float af[4];
+                tl_u32x4 ah, am;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = bufA[(16 * q + 4 * g + i) * C::LS + 16 * mt + c];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[t], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) { ah[i] = aH[w0 + i * RSW + 16 * mt]; am[i] = aM[w0 + i * RSW + 16 * mt]; }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, am), __builtin_bit_cast(tl_bf16x8, bh), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, ah), __builtin_bit_cast(tl_bf16x8, bm), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, ah), __builtin_bit_cast(tl_bf16x8, bh), acc[t], 0, 0, 0);
             }
         }
     }
