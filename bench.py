@@ -521,7 +521,8 @@ def main():
                                          "how": "each call captured 20x into a hipGraph, replayed 10x (GPU time; an eager loop is CPU-launch-bound)"}
             names = ("enc_tile_prep_k", "enc_tile_step_k", "enc_step_k<64>", "enc_wgrad_k<64>", "enc_grad_reduce_k")
             line["roofline"] = {"kernel": "re_sasrec_encoder_step: enc_tile_prep_k (weight fragments) + enc_tile_step_k (forward + criterion + backward of one "
-                                          "16-token tile per workgroup, all blocks) + enc_wgrad_k + enc_grad_reduce_k"
+                                          "16-token tile per workgroup, all blocks) + enc_wgrad_k + enc_grad_reduce_k (the launch group of the C-ABI "
+                                          "entry; the captured step runs enc_wgrad_k's jobs inside its tail launch, enc_tail_k)"
                                           + ("" if tile_mode else " [this plan took the workgroup-per-item kernel enc_step_k instead]"), "bound": "mfma",
                                 "achieved": round(tf_exec, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": round(tf_exec / MFMA_F32_PEAK_TF, 4),

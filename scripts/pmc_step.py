@@ -12,6 +12,10 @@ bs = [tuple(torch.from_numpy(a).cuda() for a in b) for b in hb]
 for i in range(6):
     s, p, n = bs[i % 2]
     m.train_step(s, p, n, m.prepare_batch(s, p, n))      # eager launches (batch preparation + the step's kernels), as the graph replays them
+m.fuse_tail = False                                       # ... and with the tail as separate launches (enc_wgrad_k, scatter_owner_k): per-kernel attribution
+for i in range(6):
+    s, p, n = bs[i % 2]
+    m.train_step(s, p, n, m.prepare_batch(s, p, n))
 U, N = 22363, 12101
 gq = torch.Generator(device="cuda").manual_seed(11)
 q = torch.randn(U, 64, device="cuda", generator=gq); E = torch.randn(N, 64, device="cuda", generator=gq)
