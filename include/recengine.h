@@ -135,8 +135,10 @@ int re_scatter_adam_rows_small(const float* g, const int32_t* keys, int32_t n_re
                                const re_adam_fuse* adam, re_stream_t stream);
 /* The NEXT batch's preparation riding in a step's tail launch (re_sasrec_step_tail / _sparse): what re_sasrec_batch_prep computes -- mask,
  * count, destination rows, the encoder's plan, the staged copies -- for the batch whose addresses `mail` holds, into the static buffers of the
- * captured step that will consume it.  mail: three device words { seq, pos, neg } ([B, S] int64 each), written by re_sasrec_step_stage in front
- * of the step (seq = 0: no next batch, nothing is prepared).  The outputs are re_sasrec_batch_prep's (seq_out .. rows_all optional). */
+ * captured step that will consume it.  mail: RE_MAIL_BYTES of device memory, written by re_sasrec_step_stage (the batch's tensors) or
+ * re_sasrec_step_stage_sample (its sampling source: the batch is drawn as re_seq_train_sample_prep draws it) in front of the step; neither
+ * given: no next batch, nothing is prepared.  The outputs are re_sasrec_batch_prep's (a sampled batch needs seq_out / pos_out / neg_out). */
+#define RE_MAIL_BYTES 128
 typedef struct {
     const void* mail;
     int64_t B, S;
@@ -151,6 +153,11 @@ int re_sasrec_step_stage(uint32_t* state, uint32_t seed, int64_t step, double lr
                          const int64_t* next_pos, const int64_t* next_neg, int64_t B, int64_t S, const float* const* block_params,
                          const float* last_w, const float* last_b, int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
                          const float* prev_loss, float* loss_acc, float loss_weight, re_stream_t stream);
+int re_sasrec_step_stage_sample(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, void* mail, const int64_t* ptr,
+                                const int64_t* items, const int64_t* sorted_items, const int64_t* order, int64_t n_order, int64_t b0, int64_t N,
+                                uint32_t sample_seed, uint32_t sample_step, int64_t* users, int64_t B, int64_t S, const float* const* block_params,
+                                const float* last_w, const float* last_b, int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws,
+                                size_t ws_bytes, const float* prev_loss, float* loss_acc, float loss_weight, re_stream_t stream);
 /* The tail of a D = 64 SASRec training step as one launch + the reduction: re_scatter_adam_rows_small (or, table_adam NULL,
  * re_scatter_add_rows_small; scale 1, n from n_dev) over the step's contribution rows, whose 1024-thread workgroups then take the jobs of
  * re_sasrec_encoder_step_part(part = 4) -- the weight gradients of the encoder from the tape the item kernels left in `tape` / `ws` -- from

@@ -123,7 +123,10 @@ class Coach:
                 n += bsz
                 continue
             if self.kind == "seq" and "Sample" in data:       # a fused device sampler's ticket: the step's preparation launch samples the batch
-                loss = self.model.train_step_graph_sampled(data["Sample"])
+                if pipelined and nxt is not None and "Sample" in nxt:   # ... or, one ticket ahead, the PREVIOUS step's tail launch did
+                    loss = self.model.train_step_graph_sampled(data["Sample"], next_ticket=nxt["Sample"])
+                else:
+                    loss = self.model.train_step_graph_sampled(data["Sample"])
                 bsz = len(data["Sample"])
                 if not own_sum:
                     tot.add_(loss, alpha=bsz)

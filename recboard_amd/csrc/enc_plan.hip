@@ -160,8 +160,7 @@ extern "C" int re_seq_train_sample_prep(const int64_t* ptr, const int64_t* items
 //      left of the preparation launch -- the step scalars, the previous loss into the epoch sum, the tile kernels' weight fragments (they need
 //      the parameters the previous step's optimizer left) -- and the mailbox: where the FOLLOWING batch lives (seq = NULL: there is none).
 __global__ __launch_bounds__(PL_NT) void sasrec_step_stage_k(uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2,
-                                                             PlWeights WP, PlLoss LA, const int64_t** __restrict__ mail, const int64_t* nseq,
-                                                             const int64_t* npos, const int64_t* nneg) {
+                                                             PlWeights WP, PlLoss LA, PlMail* __restrict__ mail, PlMail M) {
     const int tid = threadIdx.x;
     if (blockIdx.x > 0) {
         const int t = ((int)blockIdx.x - 1) * PL_NT + tid;
@@ -179,17 +178,16 @@ __global__ __launch_bounds__(PL_NT) void sasrec_step_stage_k(uint32_t* __restric
         state[2] = __float_as_uint(step_size);
         state[3] = __float_as_uint(inv_sqrt_bc2);
     }
-    if (mail) { mail[0] = nseq; mail[1] = npos; mail[2] = nneg; }
+    if (mail) *mail = M;
 }
 
-extern "C" int re_sasrec_step_stage(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, void* mail,
-                                    const int64_t* next_seq, const int64_t* next_pos, const int64_t* next_neg, int64_t B, int64_t S,
-                                    const float* const* block_params, const float* last_w, const float* last_b, int64_t L, int64_t D, void* tape,
-                                    size_t tape_bytes, void* ws, size_t ws_bytes, const float* prev_loss, float* loss_acc, float loss_weight,
-                                    re_stream_t stream) {
+static int step_stage_launch(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, void* mail, const PlMail& M, int64_t B,
+                             int64_t S, const float* const* block_params, const float* last_w, const float* last_b, int64_t L, int64_t D, void* tape,
+                             size_t tape_bytes, void* ws, size_t ws_bytes, const float* prev_loss, float* loss_acc, float loss_weight,
+                             re_stream_t stream) {
     re_clear_error();
     if (!state || step < 1) return RE_EINVAL;
-    if (next_seq && (!next_pos || !next_neg || !mail)) return RE_EINVAL;
+    if ((M.seq || M.SP.ptr) && !mail) return RE_EINVAL;
     if ((prev_loss == nullptr) != (loss_acc == nullptr)) return RE_EINVAL;
     PlWeights WP{};
     const int rc = pl_fill_weights(WP, block_params, last_w, last_b, L, D, B, S, tape, tape_bytes, ws, ws_bytes);
@@ -197,6 +195,36 @@ extern "C" int re_sasrec_step_stage(uint32_t* state, uint32_t seed, int64_t step
     const PlLoss LA{prev_loss, loss_acc, loss_weight};
     const float ss = (float)(lr / (1.0 - pow(beta1, (double)step))), ib = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
     hipLaunchKernelGGL(sasrec_step_stage_k, dim3(1 + (unsigned)WP.nblocks), dim3(PL_NT), 0, (hipStream_t)stream, state, seed, ss, ib, WP, LA,
-                       (const int64_t**)mail, next_seq, next_pos, next_neg);
+                       (PlMail*)mail, M);
     return re_launch_status();
+}
+
+extern "C" int re_sasrec_step_stage(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, void* mail,
+                                    const int64_t* next_seq, const int64_t* next_pos, const int64_t* next_neg, int64_t B, int64_t S,
+                                    const float* const* block_params, const float* last_w, const float* last_b, int64_t L, int64_t D, void* tape,
+                                    size_t tape_bytes, void* ws, size_t ws_bytes, const float* prev_loss, float* loss_acc, float loss_weight,
+                                    re_stream_t stream) {
+    if (next_seq && (!next_pos || !next_neg)) return RE_EINVAL;
+    PlMail M{};
+    M.seq = next_seq; M.pos = next_pos; M.neg = next_neg;
+    return step_stage_launch(state, seed, step, lr, beta1, beta2, mail, M, B, S, block_params, last_w, last_b, L, D, tape, tape_bytes, ws, ws_bytes,
+                             prev_loss, loss_acc, loss_weight, stream);
+}
+
+// The same with a SAMPLING source for the next batch (re_seq_train_sample_prep's: rows b0 .. b0 + B of `order`, sample_seed / sample_step);
+// ptr = NULL: no next batch.
+extern "C" int re_sasrec_step_stage_sample(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, void* mail,
+                                           const int64_t* ptr, const int64_t* items, const int64_t* sorted_items, const int64_t* order,
+                                           int64_t n_order, int64_t b0, int64_t N, uint32_t sample_seed, uint32_t sample_step, int64_t* users,
+                                           int64_t B, int64_t S, const float* const* block_params, const float* last_w, const float* last_b,
+                                           int64_t L, int64_t D, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, const float* prev_loss,
+                                           float* loss_acc, float loss_weight, re_stream_t stream) {
+    PlMail M{};
+    if (ptr) {
+        if (!items || !sorted_items || !order || n_order < 0 || b0 < 0 || N < 1) return RE_EINVAL;
+        if (B <= 0 || S <= 0 || S > 64 || B * S > (int64_t)1 << 26) return RE_EUNSUPPORTED;
+        M.SP = PlSample{ptr, items, sorted_items, order, n_order, b0, N, sample_seed, sample_step, users};
+    }
+    return step_stage_launch(state, seed, step, lr, beta1, beta2, mail, M, B, S, block_params, last_w, last_b, L, D, tape, tape_bytes, ws, ws_bytes,
+                             prev_loss, loss_acc, loss_weight, stream);
 }

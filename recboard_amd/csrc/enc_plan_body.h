@@ -117,6 +117,15 @@ struct PlWeights {   // optional extra work of the launch: the one-tile-per-work
     unsigned* epoch;
 };
 
+// What a step's tail launch prepares the NEXT batch from (enc_tail.hip), left in device memory by the stage launch in front of the step:
+// the batch's tensors, or (SP.ptr != nullptr) the sampling source -- then the batch is drawn, not read.  Neither: nothing to prepare.
+struct PlMail {
+    const int64_t *seq, *pos, *neg;
+    PlSample SP;
+};
+#define PL_MAIL_WORDS 16   // int64 words a mailbox occupies (>= sizeof(PlMail) / 8)
+static_assert(sizeof(PlMail) <= PL_MAIL_WORDS * 8, "mailbox size");
+
 // ---- element-wise part of the preparation: copies, valid mask, scatter destination rows.  Job `job` of `njobs` (PL_NT threads each).
 __device__ __forceinline__ void pl_elementwise(int job, int njobs, const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
                                                const int64_t* __restrict__ neg, int B, int S, int64_t* __restrict__ seq_out,

@@ -26,10 +26,10 @@ struct TailJobs {
 
 // The NEXT batch's preparation (enc_plan_body.h: it depends on the batch alone) as the first jobs of the ticket queue: one plan job, n_ew
 // element-wise jobs -- in front of a step it is a 14 us launch (one workgroup's chain of barriers and round trips), here it rides in
-// workgroups that are done with the table while others still work.  mail: device words { seq, pos, neg } of the next batch, written by
-// re_sasrec_step_stage in front of this step (seq = NULL: no next batch); outputs: the OTHER captured copy's static buffers.
+// workgroups that are done with the table while others still work.  mail: a PlMail in device memory (the next batch's tensors or its sampling
+// source), written by re_sasrec_step_stage[_sample] in front of this step (neither: no next batch); outputs: the OTHER captured copy's buffers.
 struct TailPrep {
-    const int64_t* const* mail;   // nullptr: this launch prepares nothing
+    const PlMail* mail;           // nullptr: this launch prepares nothing
     int B, S, ncu, max_tiles, split_long, n_ew;
     int64_t *seq_out, *pos_out, *neg_out;
     uint8_t* valid;
@@ -57,11 +57,10 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
         int t = s_job;
         if (t >= n_prep + n_mat + n_pos) break;
         if (t < n_prep) {
-            const int64_t* nseq = TP.mail[0];
-            if (nseq) {                                        // (uniform)
-                const PlSample SP{};
-                if (t == 0) pl_plan(nseq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, SP, reinterpret_cast<unsigned char*>(lds));
-                else pl_elementwise(t - 1, TP.n_ew, nseq, TP.mail[1], TP.mail[2], TP.B, TP.S, TP.seq_out, TP.pos_out, TP.neg_out, TP.valid, TP.rows_all, SP);
+            const PlMail M = *TP.mail;
+            if (M.seq || M.SP.ptr) {                           // (uniform)
+                if (t == 0) pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds));
+                else pl_elementwise(t - 1, TP.n_ew, M.seq, M.pos, M.neg, TP.B, TP.S, TP.seq_out, TP.pos_out, TP.neg_out, TP.valid, TP.rows_all, M.SP);
             }
             continue;
         }
@@ -106,7 +105,7 @@ static int tail_prep(TailPrep& TP, const re_next_prep* next) {
     if (next->plan_bytes < enc_plan_bytes(next->B, next->S)) return RE_EWORKSPACE;
     if (next->B > PL_LDS_B) return RE_EUNSUPPORTED;          // (the plan job keeps spans and placements in LDS)
     const bool elementwise = next->seq_out || next->valid || next->rows_all || next->pos_out;
-    TP.mail = (const int64_t* const*)next->mail;
+    TP.mail = (const PlMail*)next->mail;
     TP.B = (int)next->B; TP.S = (int)next->S; TP.ncu = next->ncu < 1 ? 1 : next->ncu; TP.max_tiles = next->max_tiles; TP.split_long = next->split_long;
     TP.n_ew = elementwise ? (int)re_grid(next->B * next->S, PL_NT, 256) : 0;
     TP.seq_out = (int64_t*)next->seq_out; TP.pos_out = (int64_t*)next->pos_out; TP.neg_out = (int64_t*)next->neg_out;

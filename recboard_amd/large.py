@@ -300,7 +300,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         if tp is None:
             nbytes = ops.prep_layout(B, S)[1]
             blobs = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
-            mail = torch.zeros(4, dtype=torch.int64, device=self.device)
+            mail = torch.zeros(ops.MAIL_WORDS, dtype=torch.int64, device=self.device)
             graphs = []
             for p in range(2):
                 nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step())

@@ -75,6 +75,8 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "re_sasrec_step_tail_sparse": (_i32, [_vp, _vp, _i32, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _i64, _i64,
                                            _i64, _vp, _i32, _vp, _sz, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "re_sasrec_step_stage_sample": (_i32, [_vp, _u32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _u32, _vp, _i64, _i64, _vp, _vp,
+                                            _vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp, _vp, _f32, _vp]),
     "re_sasrec_step_stage": (_i32, [_vp, _u32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _sz,
                                      _vp, _vp, _f32, _vp]),
     "re_spmm_csr": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp, _sz, _vp]),

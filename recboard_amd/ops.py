@@ -759,10 +759,26 @@ def next_prep(mail, blob, B, S, max_tiles=4, split=False, ncu=None, tile=True):
     return n
 
 
-def sasrec_step_stage(state, seed, step, lr, beta1, beta2, B, S, mail=None, next_batch=None, weights=None, loss_acc=None):
+MAIL_WORDS = 16      # int64 words of a mailbox (RE_MAIL_BYTES)
+
+
+def sasrec_step_stage(state, seed, step, lr, beta1, beta2, B, S, mail=None, next_batch=None, weights=None, loss_acc=None, next_ticket=None):
     """The launch in front of a captured step whose batch the previous step's tail launch prepared (re_sasrec_step_stage): the step scalars,
-    the loss fold, the tile kernels' weight fragments, and the addresses of the FOLLOWING batch for this step's tail launch (None: none)."""
+    the loss fold, the tile kernels' weight fragments, and -- for this step's tail launch -- where the FOLLOWING batch comes from: its tensors
+    (next_batch) or its sampling source (next_ticket: a recboard_amd.sampler.SampleTicket; re_sasrec_step_stage_sample); neither: none."""
     _req(state, torch.int32, "state")
+    if mail is not None and mail.numel() < MAIL_WORDS:
+        raise ValueError("recengine: a mailbox is MAIL_WORDS int64 words")
+    if next_ticket is not None:
+        t = next_ticket
+        if (t.B, t.S) != (B, S):
+            raise ValueError("recengine: the next ticket must have the captured step's shape")
+        _req(mail, torch.int64, "mail")
+        lib.check(lib.load().re_sasrec_step_stage_sample(_p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), _p(mail),
+                                                         _p(t.inter.ptr), _p(t.inter.items), _p(t.inter.sorted), _p(t.order), t.order.numel(), int(t.b0),
+                                                         t.inter.num_items, int(t.seed) & 0xFFFFFFFF, int(t.step) & 0xFFFFFFFF, _p(t.users), B, S,
+                                                         *_weight_args(weights), *_loss_args(loss_acc), _stream()), "re_sasrec_step_stage_sample")
+        return
     ns = npos = nn = None
     if next_batch is not None:
         ns, npos, nn = next_batch

@@ -687,7 +687,7 @@ class SASRecEngine:
         if tp is None:
             nbytes = ops.prep_layout(B, S)[1]
             blobs = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
-            mail = torch.zeros(4, dtype=torch.int64, device=self.device)          # (zero: the captures' warm-up runs prepare nothing)
+            mail = torch.zeros(ops.MAIL_WORDS, dtype=torch.int64, device=self.device)          # (zero: the captures' warm-up runs prepare nothing)
             graphs = []
             for p in range(2):                                                     # both copies now: a capture's warm-up overwrites its staging buffers
                 nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(), tile=self._wave_step())
@@ -702,7 +702,7 @@ class SASRecEngine:
         p = tp["parity"]
         g = tp["graphs"][p]
         st, tp["staged"] = tp["staged"], None
-        if not (st is not None and st[0] is seq and st[1] is pos and st[2] is neg):
+        if not (isinstance(st, tuple) and st[0] is seq and st[1] is pos and st[2] is neg):
             # nobody prepared this batch: the plain preparation launch in front of the step (an epoch's first batch)
             ops.sasrec_batch_prep(seq, pos, neg, blob=tp["blobs"][p], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
                                   ncu=self._plan_ncu())
@@ -721,11 +721,31 @@ class SASRecEngine:
         self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
 
-    def train_step_graph_sampled(self, ticket):
+    def train_step_graph_sampled(self, ticket, next_ticket=None):
         """The captured step on a batch the preparation launch SAMPLES itself (recboard_amd.sampler.DeviceSeqSampler(fused=True) hands out
-        tickets instead of tensors): one sample + prepare launch, one graph replay -- no sampler launch, no batch tensors."""
+        tickets instead of tensors): one sample + prepare launch, one graph replay -- no sampler launch, no batch tensors.
+        next_ticket (the FOLLOWING call's ticket, if the caller has it): that batch is sampled and prepared by jobs of this step's tail launch
+        (the pipelined form of train_step_graph: _tail_pipe); the following call must pass the same ticket object."""
         A = self.arena
         B, S = ticket.B, ticket.S
+        if self._tail_prep_ok() and (next_ticket is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
+            tp = self._tail_pipe(B, S)
+            p = tp["parity"]
+            g = tp["graphs"][p]
+            st, tp["staged"] = tp["staged"], None
+            if st is not ticket:
+                ops.sasrec_sample_prep(ticket.inter, ticket.order, ticket.b0, B, S, ticket.seed, ticket.step, tp["blobs"][p], max_tiles=self._max_tiles(),
+                                       split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(), users=ticket.users)
+            if next_ticket is not None and (next_ticket.B, next_ticket.S) != (B, S):
+                next_ticket = None
+            ops.sasrec_step_stage(g["state"], self._step_seed(), A.step + 1, self.lr, self.betas[0], self.betas[1], B, S, mail=tp["mail"],
+                                  next_ticket=next_ticket, weights=self._prep_weights(B, S), loss_acc=self._take_pending_loss())
+            g["graph"].replay()
+            A.step += 1
+            tp["parity"] = 1 - p
+            tp["staged"] = next_ticket
+            self._note_loss(g["loss"], B)
+            return g["loss"].squeeze(0)
         key = (B, S, True, self.training)
         if not hasattr(self, "_graphs"):
             self._graphs, self._staged, self._pipe_i = {}, None, 0

@@ -29,15 +29,20 @@ def batch(N, mean_len, p_long):
 
 for name, make in (("SASRecEngine d=64", lambda: SASRecEngine(12101, S, 64, 2, dropout_rate=0.5, loss="BCE", lr=1e-3, seed=1)),
                    ("SASRecLargeTableEngine d=128", lambda: SASRecLargeTableEngine(2_000_000, S, 128, 2, dropout_rate=0.5, loss="BCE", lr=1e-3, seed=1))):
-    eng = make()
+    # eng: every step is told the NEXT batch (prepared by jobs of its tail launch); twin: the same batches, each prepared in front of its step
+    eng, twin = make(), make()
     N = eng.N
     t0 = time.time()
     worst = 0.0
+    nxt = batch(N, 2.0, 0.0)
     for i in range(args.batches):
-        mean_len = (2.0, 5.9, 12.0)[i % 3]
-        p_long = (0.0, 0.05, 0.3, 0.9)[(i // 3) % 4]
-        b = batch(N, mean_len, p_long)
-        loss = eng.train_step_graph(*b)
+        mean_len = (2.0, 5.9, 12.0)[(i + 1) % 3]
+        p_long = (0.0, 0.05, 0.3, 0.9)[((i + 1) // 3) % 4]
+        b, nxt = nxt, batch(N, mean_len, p_long)
+        loss = eng.train_step_graph(*b, next_batch=nxt if i % 37 != 36 else None)      # (now and then nobody announces the next batch)
+        ref = twin.train_step_graph(*b)
+        if i % 20 == 0:
+            assert torch.equal(loss, ref), (name, i, float(loss), float(ref))
         if i % 100 == 0:
             v = float(loss)
             assert np.isfinite(v), (name, i, v)
@@ -45,4 +50,5 @@ for name, make in (("SASRecEngine d=64", lambda: SASRecEngine(12101, S, 64, 2, d
             worst = max(worst, v)
     torch.cuda.synchronize()
     eng.check_handover()
-    print(f"{name}: {args.batches} batches ok, {time.time() - t0:.1f} s, last loss {float(loss):.4f}", flush=True)
+    assert torch.equal(eng.arena.data, twin.arena.data), name
+    print(f"{name}: {args.batches} batches ok (pipelined = unpipelined, bit for bit), {time.time() - t0:.1f} s, last loss {float(loss):.4f}", flush=True)

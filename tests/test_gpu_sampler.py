@@ -160,3 +160,12 @@ def test_sample_and_prepare_in_one_launch_equals_sampler_then_prepare():
         m.check_handover()
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[0][1])
     torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-5, atol=1e-7)
+    # the Coach hands every step the NEXT ticket (sampled + prepared by jobs of the step's tail launch): the same epoch, bit for bit, as with
+    # every ticket sampled by a launch in front of its step
+    m = SASRecEngine(N, S, 64, 2, dropout_rate=0.2, lr=1e-3, seed=5)
+    m.prep_in_tail = False
+    coach = Coach(m, DeviceSeqSampler(inter, S, B, seed=9, fused=True), monitors=["LOSS"], kind="seq")
+    l0, l1 = coach.train_per_epoch(0)["LOSS"], coach.train_per_epoch(1)["LOSS"]
+    assert (l0, l1) == (res[1][0], res[1][1])
+    assert torch.equal(m.arena.data, res[1][2])
+    assert not getattr(m, "_tail_pipes", {})
