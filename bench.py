@@ -280,9 +280,10 @@ def sampler_rates(cfg, model):
             "sampler_to_coach_samples_per_sec": round(full / dtf, 1), "sampler_to_coach_ms_per_step": round(dtf / nb * 1e3, 4),
             "sampler_to_coach_unfused_samples_per_sec": round(full / dtc, 1), "sampler_to_coach_unfused_ms_per_step": round(dtc / nb * 1e3, 4),
             "what": f"DeviceSeqSampler over {U} users ({int(ptr[-1])} interactions, {nb} batches of {B}; the last one short), 3 epochs each: the sampler "
-                    "alone (one re_seq_train_sample launch per batch); Coach.train_per_epoch fed by the FUSED sampler (tickets: the step's batch-preparation "
-                    "launch samples the rows itself, re_seq_train_sample_prep -> hipGraph replay; the epoch's loss read once); and fed by the sampler's "
-                    "tensor batches (sampler launch -> batch preparation -> replay: `unfused`)"}
+                    "alone (one re_seq_train_sample launch per batch); Coach.train_per_epoch fed by the FUSED sampler (tickets, one ahead: every step's tail "
+                    "launch samples and prepares the NEXT batch -- re_sasrec_step_stage_sample + re_next_prep -> one stage launch + one hipGraph replay per "
+                    "step; the epoch's loss read once); and fed by the sampler's tensor batches (sampler launch per batch; the next batch prepared by the "
+                    "tail launch likewise: `unfused`)"}
 
 
 def launch_ranks(n, argv):
