@@ -59,37 +59,96 @@ class Coach:
         return {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) and (keys is None or k in keys) else v)
                 for k, v in data.items()}
 
-    def _device_batches(self, pipe, keys):
-        """The pipe's batches on the device, ONE BATCH AHEAD: the host-to-device copies of batch i+1 run on a copy stream while step i
+    def _device_batches(self, pipe, keys, ahead=1):
+        """The pipe's batches on the device, `ahead` BATCHES AHEAD: the host-to-device copies of batch i+1 run on a copy stream while step i
         computes (three pinned 200 KB copies are ~70 us of DMA latency per step -- half a training step -- when they share the
-        compute stream).  One cross-stream event per step."""
+        compute stream).  One cross-stream event per step.  ahead=2 for a consumer that itself looks one batch ahead (a pipelined step reads
+        batch i+1 during step i: its copies must have been started a step earlier, or the compute stream waits for them)."""
         if self.device.type != "cuda":
             for data in pipe:
                 yield self.dict_to_device(data, keys)
             return
         main = torch.cuda.current_stream()
-        if not hasattr(self, "_copy_stream"):
-            self._copy_stream = torch.cuda.Stream()
+        if not hasattr(self, "_copy_streams"):
+            self._copy_streams = [torch.cuda.Stream() for _ in range(3)]
 
         def stage(data):
-            with torch.cuda.stream(self._copy_stream):
-                d = self.dict_to_device(data, keys)
+            # one copy stream per tensor (round robin): a pinned 200 KB copy is ~40 us of latency, three in a row on ONE stream were 120 us per
+            # batch -- more than a training step, and what an epoch from host batches ran at
+            d, used = {}, []
+            j = 0
+            # same-shape int64 tensors (a sequence batch: ISeq / IPos / INeg) travel as ONE copy: packed into a pinned staging buffer of a
+            # ring (a host memcpy), one transfer, views on the device
+            pack = [k for k, v in data.items() if isinstance(v, torch.Tensor) and (keys is None or k in keys) and v.device.type == "cpu"
+                    and v.dtype == torch.int64 and v.dim() == 2]
+            if getattr(self, "pack_copies", True) and len(pack) >= 2 and len({tuple(data[k].shape) for k in pack}) == 1:
+                shp = tuple(data[pack[0]].shape)
+                ring = self.__dict__.setdefault("_pack_ring", {})
+                slot = ring.get((len(pack),) + shp)
+                if slot is None:
+                    slot = ring[(len(pack),) + shp] = {"bufs": [torch.empty((len(pack),) + shp, dtype=torch.int64).pin_memory()
+                                                                for _ in range(ahead + 3)], "done": [None] * (ahead + 3), "i": 0}
+                bi = slot["i"] % len(slot["bufs"])
+                slot["i"] += 1
+                buf = slot["bufs"][bi]
+                if slot["done"][bi] is not None:
+                    slot["done"][bi].synchronize()             # (the transfer that last read this staging buffer: long done unless the host runs far ahead)
+                for n, k in enumerate(pack):
+                    buf[n].copy_(data[k])
+                st = self._copy_streams[0]
+                with torch.cuda.stream(st):
+                    dev = buf.to(self.device, non_blocking=True)
+                    slot["done"][bi] = torch.cuda.Event()
+                    slot["done"][bi].record(st)
+                used.append(st)
+                for n, k in enumerate(pack):
+                    d[k] = dev[n]
+                data = {k: v for k, v in data.items() if k not in pack}
+            for k, v in data.items():
+                if isinstance(v, torch.Tensor) and (keys is None or k in keys) and v.device != self.device:
+                    st = self._copy_streams[j % len(self._copy_streams)]
+                    j += 1
+                    with torch.cuda.stream(st):
+                        d[k] = v.to(self.device, non_blocking=True)
+                    if st not in used:
+                        used.append(st)
+                else:
+                    d[k] = v
+            evs = []
+            for st in used:
                 ev = torch.cuda.Event()
-                ev.record(self._copy_stream)
-            return d, ev
+                ev.record(st)
+                evs.append(ev)
+            return d, evs
 
+        import collections
         it = iter(pipe)
-        try:
-            nxt = stage(next(it))
-        except StopIteration:
-            return
-        while nxt is not None:
-            cur, ev = nxt
-            try:
-                nxt = stage(next(it))
-            except StopIteration:
-                nxt = None
-            main.wait_event(ev)
+        q = collections.deque()
+
+        def fill():
+            while len(q) < ahead:
+                try:
+                    q.append(stage(next(it)))
+                except StopIteration:
+                    return False
+            return True
+
+        # (a cross-stream wait in front of a step costs ~10 us on this stack: with several batches staged ahead the compute stream waits
+        #  for the NEWEST staged batch's event once per group of `group` batches -- the copy stream is in order, so that covers them all)
+        group = 4 if ahead >= 2 else 1
+        covered = 0
+        more = fill()
+        while q:
+            cur, ev = q.popleft()
+            if covered > 0:
+                covered -= 1
+            else:
+                n_cov = min(group - 1, len(q))
+                for e in (q[n_cov - 1][1] if n_cov > 0 else ev):
+                    main.wait_event(e)
+                covered = n_cov
+            if more:
+                more = fill()
             for v in cur.values():
                 if isinstance(v, torch.Tensor) and v.is_cuda:
                     v.record_stream(main)
@@ -101,13 +160,13 @@ class Coach:
         tot = torch.zeros((), device=self.device)
         n = 0
         need = {"seq": ("ISeq", "IPos", "INeg"), "pred": ("X", "Label"), "module": self.fit_keys}.get(self.kind)
-        batches = self._device_batches(self.trainpipe, need)
+        pipelined = self.kind == "seq" and self._graphable() and (getattr(self.model, "pipelined_prep", False) or
+                                                                 (getattr(self.model, "_tail_prep_ok", None) is not None and self.model._tail_prep_ok()))
+        batches = self._device_batches(self.trainpipe, need, ahead=8 if pipelined else 1)
         # the fused SASRec step sums the epoch's losses itself (each step's loss is folded in by the next step's preparation launch)
         own_sum = self.kind == "seq" and self._graphable() and hasattr(self.model, "begin_loss_accumulation")
         if own_sum:
             self.model.begin_loss_accumulation()
-        pipelined = self.kind == "seq" and self._graphable() and (getattr(self.model, "pipelined_prep", False) or
-                                                                 (getattr(self.model, "_tail_prep_ok", None) is not None and self.model._tail_prep_ok()))
         if pipelined:
             batches = _lookahead(batches)
         for data in batches:

@@ -468,9 +468,26 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     return pb
 
 
+class MarshalledWeights:
+    """`weights` of sasrec_batch_prep / sasrec_step_stage already turned into ABI arguments (the pointer table of the 12 L block tensors and the
+    view constructions were ~50 us of host time per step): make it once per (engine, batch shape) with marshal_weights -- the tensors must stay
+    where they are (parameter arenas do), and are kept alive here."""
+    __slots__ = ("args", "keep")
+
+
+def marshal_weights(weights):
+    if weights is None or isinstance(weights, MarshalledWeights):
+        return weights
+    m = MarshalledWeights()
+    m.args, m.keep = _weight_args(weights), weights
+    return m
+
+
 def _weight_args(weights):
     if weights is None:
         return (None, None, None, 0, 0, None, 0, None, 0)
+    if isinstance(weights, MarshalledWeights):
+        return weights.args
     bt, lw, lb, L, tape, ws = weights
     return (_ptr_table(bt), _p(lw), _p(lb), int(L), int(lw.numel()), _p(tape), tape.numel() * 4, _p(ws), ws.numel())
 

@@ -330,9 +330,14 @@ class SASRecEngine:
         None when the step that follows is not the one-tile-per-workgroup one."""
         if not (self._wave_step() and self.training and getattr(self, "prep_weights_in_batch_prep", True)):
             return None
-        W = self._buffers(B, S)
-        P = self.params
-        return (self._block_tensors(), P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, W["tape"], W["ws_bwd"])
+        cache = self.__dict__.setdefault("_pw_cache", {})
+        mw = cache.get((B, S))
+        if mw is None or mw.keep[4] is not self._buffers(B, S)["tape"] or mw.keep[1].data_ptr() != self.params["lastLN.weight"].data_ptr():
+            W = self._buffers(B, S)
+            P = self.params
+            mw = cache[(B, S)] = ops.marshal_weights((self._block_tensors(), P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L,
+                                                     W["tape"], W["ws_bwd"]))
+        return mw
 
     def _plan_ncu(self):
         """Workgroups the batch plan's items should fill (None: the device's CUs).  The one-tile-per-workgroup step does not read the
