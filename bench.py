@@ -660,8 +660,9 @@ def main():
             torch.cuda.synchronize()
             dtc = time.perf_counter() - t0
             line["coach_loop"] = {"samples_per_sec": round(nb * cfg["B"] / dtc, 1), "ms_per_step": round(dtc / nb * 1e3, 4),
-                                  "what": f"Coach.train_per_epoch over {nb} HOST batches (pinned): H2D copies one batch ahead on a copy stream + batch "
-                                          "preparation + graph replay per step, the epoch's mean loss read once at the end"}
+                                  "what": f"Coach.train_per_epoch over {nb} HOST batches (pinned): one packed H2D copy per batch on a copy stream, several "
+                                          "batches ahead; per step one stage launch + one graph replay (the next batch is prepared by the step's tail "
+                                          "launch); the epoch's mean loss read once at the end"}
         if world == 1 and args.encoder == "fused" and not args.no_legs:
             line["sampler"] = sampler_rates(cfg, model)
         if world == 1 and not args.no_c5:
