@@ -333,7 +333,7 @@ class SASRecLargeTableEngine(SASRecEngine):
     def train_step_graph(self, seq, pos, neg, grad_hook=None, next_batch=None, next_ready=None):
         A = self.arena
         B, S = seq.shape
-        if grad_hook is None and self._tail_prep_ok() and (next_batch is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
+        if grad_hook is None and self._tail_prep_ok() and B <= 8192 and (next_batch is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
             return self._train_step_graph_tail(seq, pos, neg, next_batch, next_ready)
         key = (B, S, grad_hook is None, self.training)
         if not hasattr(self, "_graphs"):

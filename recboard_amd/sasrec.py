@@ -631,7 +631,7 @@ class SASRecEngine:
         B, S = seq.shape
         if not hasattr(self, "_graphs"):
             self._graphs, self._staged, self._pipe_i = {}, None, 0
-        if grad_hook is None and self._tail_prep_ok() and (next_batch is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
+        if grad_hook is None and self._tail_prep_ok() and B <= 8192 and (next_batch is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
             return self._train_step_graph_tail(seq, pos, neg, next_batch, next_ready)
         staged, self._staged = self._staged, None
         hit = staged is not None and staged[0] is seq and staged[1] is pos and staged[2] is neg and staged[5] == (grad_hook is None, self.training)
@@ -733,7 +733,7 @@ class SASRecEngine:
         (the pipelined form of train_step_graph: _tail_pipe); the following call must pass the same ticket object."""
         A = self.arena
         B, S = ticket.B, ticket.S
-        if self._tail_prep_ok() and (next_ticket is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
+        if self._tail_prep_ok() and B <= 8192 and (next_ticket is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
             tp = self._tail_pipe(B, S)
             p = tp["parity"]
             g = tp["graphs"][p]
