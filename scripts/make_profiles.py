@@ -61,7 +61,7 @@ if os.path.isdir(src + "/pmc1") and glob.glob(src + "/pmc1/**/*.db", recursive=T
                 short = kn.split("(")[0].replace("void ", "").strip()
                 acc[(short, c)] += float(v); cnt[(short, c)] += 1
         for (kn, c), v in acc.items():
-            if kn.startswith(("enc_", "scatter_owner", "sasrec_batch_prep", "adam_vec4")):
+            if kn.startswith(("enc_", "tl4::", "tl8::", "scatter_owner", "sasrec_batch_prep", "sasrec_step_stage", "adam_vec4")):
                 sq.setdefault(kn, {})[c] = int(v / cnt[(kn, c)])
     sq = {"what": "rocprofv3 --pmc on scripts/pmc_step.py (SASRec/Beauty B=512 fused step, eager launches; two passes of 7 SQ counters: scripts/prof_round.sh), "
                   "per launch averages; SQ_WAVE_CYCLES / SQ_WAIT_* are quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES are cycles summed over the 1 024 SIMDs",
