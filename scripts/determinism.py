@@ -15,7 +15,8 @@ for rep in range(2):
         setattr(m, k.lstrip("-"), False)
     hist = []
     for i in range(steps):
-        hist.append(m.train_step_graph(*bs[i % 8]).clone())
+        nxt = bs[(i + 1) % 8] if os.environ.get("DET_NEXT") else None      # (DET_NEXT=1: the pipelined step -- the next batch prepared by the tail launch)
+        hist.append(m.train_step_graph(*bs[i % 8], next_batch=nxt).clone())
     torch.cuda.synchronize()
     res.append((torch.stack(hist), m.arena.data.clone()))
 d = (res[0][0] != res[1][0]).nonzero().reshape(-1)

@@ -388,7 +388,8 @@ def test_pipelined_preparation_gives_the_same_steps(in_tail):
     b.check_handover()
 
 
-def test_captured_step_is_reproducible_from_process_to_process():
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_captured_step_is_reproducible_from_process_to_process(pipelined):
     """Two fresh processes, the same seeds and Beauty-shaped batches, 160 captured steps each: the same parameters bit for bit.  (The
     hand-over of long sequences between tile workgroups is only valid at one workgroup per CU -- enc_tile.hip's launch; with two per CU
     about every second pair of runs parted in the last digits by step 80 - 140, while two engines in ONE process always agreed.)"""
@@ -398,7 +399,8 @@ def test_captured_step_is_reproducible_from_process_to_process():
     script = os.path.join(os.path.dirname(G), "..", "scripts", "determinism.py")
     out = []
     for _ in range(2):
-        r = subprocess.run([sys.executable, script, "160", "64"], capture_output=True, text=True, timeout=300)
+        env = dict(os.environ, **({"DET_NEXT": "1"} if pipelined else {}))          # (pipelined: the next batch prepared by the tail launch)
+        r = subprocess.run([sys.executable, script, "160", "64"], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "parameters identical: True" in r.stdout, r.stdout
         out.append(re.search(r"sha1 of the parameters: (\w+)", r.stdout).group(1))
