@@ -586,7 +586,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up with an all-padding batch: every lookup is the padding row, no table row changes
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step())
+                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), weights=self._prep_weights(B, S))
             pb.count.fill_(1)
             for _ in range(3):
                 self._sharded_body(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, hyper=hyper)
@@ -621,7 +621,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
                               beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
-                              loss_acc=self._take_pending_loss())
+                              weights=self._prep_weights(B, S), loss_acc=self._take_pending_loss())
         sd = self._step_seed()
         g["graph"].replay()
         A.step += 1
