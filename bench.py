@@ -364,7 +364,7 @@ def main():
 
     def step_graph(i):   # RAW batch in: one preparation launch (mask, count, scatter rows, encoder plan, staging) + one graph replay
         seq, pos, neg, _ = batches[i % len(batches)]
-        nxt = batches[(i + 1) % len(batches)][:3] if args.prefetch and hook is None else None   # (the next batch: prepared during this step)
+        nxt = batches[(i + 1) % len(batches)][:3] if args.prefetch else None   # (the next batch: prepared during this step)
         return model.train_step_graph(seq, pos, neg, grad_hook=hook, next_batch=nxt)
 
     # Graph or eager launches: decided BEFORE any step that contains a collective runs.  Every rank captures and replays one step
@@ -376,7 +376,8 @@ def main():
         keep = [t.clone() for t in (A.data, A.m, A.v)] + [A.step]
         try:
             seq0, pos0, neg0, _ = batches[0]
-            model.train_step_graph(seq0, pos0, neg0, grad_hook=(None if hook is None else (lambda g: None)))
+            model.train_step_graph(seq0, pos0, neg0, grad_hook=(None if hook is None else (lambda g: None)),
+                                   next_batch=(seq0, pos0, neg0) if args.prefetch else None)      # (the same captured copies the timed steps replay)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             if dist is None:
@@ -427,7 +428,7 @@ def main():
                    "global_batch": world * cfg["B"], "seq_len": cfg["S"],
                    "launch": (("one stage launch (step scalars, weight fragments, the next batch's addresses) + one hipGraph replay per step; every step "
                                "prepares the NEXT raw batch in jobs of its tail launch (train_step_graph(next_batch=...), as an epoch loop calls it)")
-                              if args.prefetch and hook is None else "one batch-preparation launch + one hipGraph replay per step")
+                              if args.prefetch else "one batch-preparation launch + one hipGraph replay per step")
                    if use_graph else "eager (one launch per kernel)",
                    "timed_region": "raw (seq, pos, neg) in HBM -> batch preparation (mask, count, rows, plan) -> forward, backward, Adam (dropout 0.5 on): "
                                    "every timed step does all of it for one batch",

@@ -631,8 +631,9 @@ class SASRecEngine:
         B, S = seq.shape
         if not hasattr(self, "_graphs"):
             self._graphs, self._staged, self._pipe_i = {}, None, 0
-        if grad_hook is None and self._tail_prep_ok() and B <= 8192 and (next_batch is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
-            return self._train_step_graph_tail(seq, pos, neg, next_batch, next_ready)
+        pkey = (B, S, self.training) if grad_hook is None else (B, S, self.training, "grads")
+        if self._tail_prep_ok() and B <= 8192 and (next_batch is not None or pkey in getattr(self, "_tail_pipes", {})):
+            return self._train_step_graph_tail(seq, pos, neg, next_batch, next_ready, grad_hook)
         staged, self._staged = self._staged, None
         hit = staged is not None and staged[0] is seq and staged[1] is pos and staged[2] is neg and staged[5] == (grad_hook is None, self.training)
         pipelined = hit or next_batch is not None
@@ -684,10 +685,11 @@ class SASRecEngine:
         return bool(getattr(self, "prep_in_tail", False) and self.fused_item_kernel and self.D == 64 and getattr(self, "fuse_tail", True)
                     and self.encoder == "fused" and self.compact_rows)
 
-    def _tail_pipe(self, B, S):
+    def _tail_pipe(self, B, S, with_adam=True):
+        """with_adam=False: the step without its optimizer (the data-parallel form: a gradient hook, then Adam, behind the replay)."""
         if not hasattr(self, "_tail_pipes"):
             self._tail_pipes = {}
-        key = (B, S, self.training)
+        key = (B, S, self.training) if with_adam else (B, S, self.training, "grads")
         tp = self._tail_pipes.get(key)
         if tp is None:
             nbytes = ops.prep_layout(B, S)[1]
@@ -696,14 +698,14 @@ class SASRecEngine:
             graphs = []
             for p in range(2):                                                     # both copies now: a capture's warm-up overwrites its staging buffers
                 nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(), tile=self._wave_step())
-                graphs.append(self._capture(B, S, with_adam=True, in_prep=True, blob=blobs[p], next_prep=nxt))
+                graphs.append(self._capture(B, S, with_adam=with_adam, in_prep=True, blob=blobs[p], next_prep=nxt))
             tp = self._tail_pipes[key] = dict(blobs=blobs, mail=mail, graphs=graphs, parity=0, staged=None)
         return tp
 
-    def _train_step_graph_tail(self, seq, pos, neg, next_batch, next_ready):
+    def _train_step_graph_tail(self, seq, pos, neg, next_batch, next_ready, grad_hook=None):
         A = self.arena
         B, S = seq.shape
-        tp = self._tail_pipe(B, S)
+        tp = self._tail_pipe(B, S, with_adam=grad_hook is None)
         p = tp["parity"]
         g = tp["graphs"][p]
         st, tp["staged"] = tp["staged"], None
@@ -723,6 +725,9 @@ class SASRecEngine:
         A.step += 1
         tp["parity"] = 1 - p
         tp["staged"] = next_batch
+        if grad_hook is not None:
+            grad_hook(A.grad)
+            ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
         self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
 

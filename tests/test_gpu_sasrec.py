@@ -489,3 +489,30 @@ def test_large_table_pipelined_preparation_gives_the_same_steps():
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert torch.equal(a.arena.data, b.arena.data)
     assert len(b._tail_pipes) == 1 and not getattr(a, "_tail_pipes", {})
+
+
+def test_pipelined_step_with_a_gradient_hook_matches_the_plain_one():
+    """The data-parallel form (gradient hook, then Adam, behind the replay) through the tail-prepared pipeline: the same losses and parameters
+    as the same steps with every batch prepared in front of its step."""
+    from recboard_amd.sasrec import SASRecEngine
+    N, B, S = 500, 48, 50
+    rng = np.random.default_rng(13)
+    batches = []
+    for _ in range(4):
+        seq = np.zeros((B, S), np.int64)
+        for b in range(B):
+            n = int(rng.integers(1, S))
+            seq[b, S - n:] = rng.integers(1, N + 1, n)
+        pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+        batches.append(tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg)))
+    calls = []
+    hook = lambda g: (calls.append(1), g.mul_(0.5))[0]          # (a stand-in for the all-reduce: something that changes the gradients)
+    a = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, lr=1e-3, seed=4)
+    b = SASRecEngine(N, S, 64, 2, dropout_rate=0.3, lr=1e-3, seed=4)
+    for i in range(6):
+        la = a.train_step_graph(*batches[i % 4], grad_hook=hook).clone()
+        lb = b.train_step_graph(*batches[i % 4], grad_hook=hook, next_batch=batches[(i + 1) % 4]).clone()
+        assert torch.equal(la, lb), i
+    assert torch.equal(a.arena.data, b.arena.data) and len(calls) == 12
+    assert any(len(k) == 4 for k in b._tail_pipes)
