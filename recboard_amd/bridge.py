@@ -31,19 +31,29 @@ class SASRecAdapter:
             named[k].data = view.detach().view(named[k].shape)
 
     def train_epoch(self, coach, epoch):
+        from .coach import _lookahead
         eng = self.eng.train()
-        tot = torch.zeros((), device=coach.device)
         n = 0
-        for data in coach.dataloader:
-            if "Sample" in data:          # the device sampler's ticket (freerec pipe -> .to_(device)): the step's preparation launch samples the batch
-                loss = eng.train_step_graph_sampled(data["Sample"])
-                tot.add_(loss, alpha=len(data["Sample"]))
-                n += len(data["Sample"])
-                continue
-            seq, pos, neg = (data[f].to(coach.device, non_blocking=True) for f in (coach.ISeq, coach.IPos, coach.INeg))
-            loss = eng.train_step_graph(seq, pos.reshape(seq.shape), neg.reshape(seq.shape))
-            tot.add_(loss, alpha=seq.shape[0])
-            n += seq.shape[0]
+        eng.begin_loss_accumulation()       # (every step's loss x its batch size is folded into one device word by the next step's stage launch)
+
+        def batches():
+            for data in coach.dataloader:
+                if "Sample" in data:      # the device sampler's ticket (freerec pipe -> .to_(device)): a step's launches sample the batch
+                    yield data["Sample"]
+                else:
+                    seq, pos, neg = (data[f].to(coach.device, non_blocking=True) for f in (coach.ISeq, coach.IPos, coach.INeg))
+                    yield (seq, pos.reshape(seq.shape), neg.reshape(seq.shape))
+
+        # one batch ahead: every step is told the next batch (or ticket), which its tail launch prepares (SASRecEngine._train_step_graph_tail)
+        for cur, nxt in _lookahead(batches()):
+            if isinstance(cur, tuple):
+                loss = eng.train_step_graph(*cur, next_batch=nxt if isinstance(nxt, tuple) else None)
+                bsz = cur[0].shape[0]
+            else:
+                loss = eng.train_step_graph_sampled(cur, next_ticket=nxt if nxt is not None and not isinstance(nxt, tuple) else None)
+                bsz = len(cur)
+            n += bsz
+        tot = eng.end_loss_accumulation().reshape(())
         eng.check_handover()
         coach.monitor(float(tot / max(n, 1)), n=max(n, 1), reduction="mean", mode="train", pool=["LOSS"])   # (one host read per epoch)
 
