@@ -141,7 +141,7 @@ class Pipe:
             ml = self.kw.get("maxlen")
             seqs = [ds.seq("train", u) for u in seeds]
             row[R["User"]] = seeds
-            row["_seq"] = [s[-(ml + 1):] if ml else s for s in seqs]     # (the input is cut to maxlen further down; one more for the target)
+            row["_seq"] = [s[-ml:] if ml else s for s in seqs]           # to_seqs(maxlen): cut BEFORE the target is split off (HSTU/sampler.py:28-31)
         elif self.source in ("choiced_user_ids", "ordered_user_ids"):
             row[R["User"]] = seeds
         elif self.source == "shuffled_pairs":

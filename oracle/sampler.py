@@ -1,7 +1,7 @@
 """Oracle: the device batch sampler of recboard_amd/csrc/sampler.hip, restated in numpy (TEST INFRASTRUCTURE).
 
-Row contract of the reference's SASRec training chain (SASRec/main.py:143-157; HSTU/sampler.py:47-125): with w = the last maxlen + 1
-items of a user's training sequence, ISeq = w[:-1] + 1, IPos = w[1:], left-padded with 0; INeg = one uniform item per real position
+Row contract of the reference's SASRec training chain (SASRec/main.py:143-157; HSTU/sampler.py:47-125): with w = the last maxlen
+items of a user's training sequence (the source cuts to `items[-maxlen:]` BEFORE the target is split off, HSTU/sampler.py:28-31), ISeq = w[:-1] + 1, IPos = w[1:], left-padded with 0; INeg = one uniform item per real position
 outside the user's training set.  The draws are the engine's counter-based generator (oracle/rng.py) keyed by
 (seed ^ step * 0x9E3779B1, stream 0x5EED, position * 32 + attempt): the first draw that is not in the user's set stands."""
 import numpy as np
@@ -24,7 +24,7 @@ def seq_train_sample(ptr, items, order, b0, B, S, N, seed, step):
         users[b] = u
         s = items[ptr[u]:ptr[u + 1]]
         n = len(s)
-        ln = min(n - 1, S)
+        ln = max(min(n - 1, S - 1), 0)
         seen = set(s.tolist())
         base = n - 1 - ln
         for k in range(ln):

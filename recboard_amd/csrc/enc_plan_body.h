@@ -96,7 +96,7 @@ __device__ __forceinline__ void pl_sample_row(const PlSample& SP, int b, int S, 
         u = SP.order[SP.b0 + b];
         p0 = SP.ptr[u];
         n = SP.ptr[u + 1] - p0;
-        len = (int)(n - 1 < S ? n - 1 : S);
+        len = (int)(n - 1 < S - 1 ? n - 1 : S - 1);             // window = the last min(n, S) items (HSTU/sampler.py:28-31), one of them the last target
         if (len < 0) len = 0;
         base = p0 + n - 1 - len;
     }

@@ -1,7 +1,8 @@
 // Device-side batch assembly of the SASRec training chain:
 //   shuffled_seqs_source(maxlen) -> seq_train_yielding_pos_(1, -1) -> seq_train_sampling_neg_(1) -> add_(1, (ISeq,)) -> lpad_(maxlen, ..., 0)
 // (SASRec/main.py:143-157; row semantics HSTU/sampler.py:47-125): row b of a batch is user order[b0 + b] of the epoch's shuffled user
-// list; with w = the last maxlen + 1 items of its training sequence: ISeq = w[:-1] + 1, IPos = w[1:], both left-padded with 0 to
+// list; with w = the last maxlen items of its training sequence (shuffled_seqs_source(maxlen) cuts the sequence BEFORE the target is split
+// off: HSTU/sampler.py:28-31 `items[-maxlen:]`, so a row has at most maxlen - 1 inputs): ISeq = w[:-1] + 1, IPos = w[1:], both left-padded with 0 to
 // maxlen; INeg = one uniform item per real position that is NOT in the user's training set (0 on pads).
 // The training interactions live in HBM as two CSR arrays over users: `items` chronological, `sorted_items` ascending (the seen
 // probe: a binary search per draw).  Draws come from the counter-based generator of re_rng.h keyed by (seed, step, position,
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void seq_train_sample_k(const int64_t* __restr
     if (b0 + b < n_order) {
         u = order[b0 + b];
         const int64_t p0 = ptr[u], n = ptr[u + 1] - p0;
-        const int64_t len = n - 1 < S ? n - 1 : S;                // input positions of the row (n >= 2 for every user of `order`)
+        const int64_t len = n - 1 < S - 1 ? n - 1 : S - 1;        // input positions of the row: window = the last min(n, S) items, one of them the last target
         const int64_t k = s - (S - len);
         if (len > 0 && k >= 0) {
             const int64_t base = p0 + n - 1 - len;

@@ -77,14 +77,15 @@ class SeqTrainSampler:
         self.rng = np.random.default_rng(seed)
         users = [u for u in range(dataset.num_users) if len(dataset.train_seq(u)) >= 2]
         self.users = np.asarray(users)
-        tr = [dataset.train_seq(u) for u in users]
+        full = [dataset.train_seq(u) for u in users]
+        tr = [s[-maxlen:] for s in full]          # shuffled_seqs_source(maxlen): the sequence is cut BEFORE the target is split off (HSTU/sampler.py:28-31)
         self.iseq = _lpad([s[:-1] for s in tr], maxlen, offset=1)      # NUM_PADS offset on ISeq only
         self.ipos = _lpad([s[1:] for s in tr], maxlen)
         self.mask = self.iseq != 0
         n = dataset.num_items
         self.seen = np.zeros((len(users), n), bool) if len(users) * n <= 4e8 else None
         if self.seen is not None:
-            for i, s in enumerate(tr):
+            for i, s in enumerate(full):
                 self.seen[i, s] = True
 
     def _negatives(self, rows):
