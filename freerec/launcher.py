@@ -4,12 +4,14 @@ set_lr_scheduler / set_other / train_per_epoch / evaluate`; `self.dataloader`, `
 `self._best`, `self.lr_scheduler`, `self.User / Item / ISeq / ... / Size`, `remove_seen`; evaluate contract mirrored at
 UniSRec/main.py:400-447; fit loop shape evidenced by ETEGRec/train_etegrec.py:625-650; checkpoint.tar keys by :549-574.
 
-ENGINE ROUTING (cfg.engine = "auto", the default): a model the recengine has a fused step for -- a SASRec-shaped module: `Item.embeddings`,
-`Position`, `attnLNs / attnLayers / fwdLNs / fwdLayers`, `lastLN`, BCE / BPR criterion, D in (64, 128), one head, maxlen <= 64, Adam -- is
-trained through `recboard_amd.sasrec.SASRecEngine.train_step_graph` (one batch-preparation launch + one hipGraph replay per step) instead
-of the script's `train_per_epoch`; the module's parameters become views of the engine's arena, so `state_dict()`, the script's own
-`recommend_from_full` and checkpoints see the trained values.  Full-ranking evaluation of dot-product models runs on the fused
-score + seen-mask + top-K kernel and the metrics kernel.  `--engine module` keeps everything on the script's own torch code."""
+ENGINE ROUTING (cfg.engine = "auto", the default; recboard_amd/bridge.py): a model the recengine has a step for -- SASRec (BCE / BPR / CE),
+MF-BPR, LightGCN, DeepFM, recognised by structure -- is trained through the engine instead of the script's `train_per_epoch` ONLY AFTER a
+probe has shown, on the first training batch, that the engine's step IS the script's step (same gradients handed to the optimizer, the
+update of the torch.optim.Adam the script built, a call pattern the adapter replays); otherwise a warning names the model and the reason
+and the script's own torch code runs.  After adoption the module's parameters are views of the engine's arena, so `state_dict()`, the
+script's own `recommend_from_full` and checkpoints see the trained values.  Full-ranking evaluation of an adopted model runs on the fused
+score + seen-mask + top-K kernel and the metrics kernel (seen / target lists as device CSR built once per split), DeepFM's pool
+evaluation on the engine's forward + the LOGLOSS / AUC kernels.  `--engine module` keeps everything on the script's own torch code."""
 import json
 import os
 import time
@@ -80,7 +82,7 @@ class Coach:
         if self._engine is not None and hasattr(self.trainpipe, "to_"):
             # batches sampled on the device where a device sampler exists for the chain; for the fused SASRec step the sampling happens
             # INSIDE the step's batch-preparation launch (tickets instead of tensors)
-            self.trainpipe.to_(self.device, fused=hasattr(self._engine, "eng") and hasattr(self._engine.eng, "train_step_graph_sampled"))
+            self.trainpipe.to_(self.device, fused=self._engine.wants_fused_sampler())
 
     # ---- set-up hooks the scripts override
     def set_device(self):
@@ -225,31 +227,68 @@ class Coach:
     def _fused_eval(self, mode):
         """Full ranking on the engine's fused score + mask + top-K and metrics kernels, for models that expose what a dot-product score
         needs (the engine adapter, or `recommend_topk`).  -> False when it does not apply."""
-        if self.device.type != "cuda" or self.cfg.get("ranking", "full") != "full" or self._engine is None:
+        if self.device.type != "cuda" or self._engine is None:
             return False
-        from recboard_amd.evaluate import RankingEvaluator, ragged_to_csr
+        if hasattr(self._engine, "pool_logits"):              # a prediction model (DeepFM): LOGLOSS / AUC over the split's rows
+            from recboard_amd.evaluate import PredictionEvaluator
+            mons = [m for m in self._meters[mode] if m.split("@")[0] in ("LOGLOSS", "AUC")]
+            if not mons:
+                return True
+            ev = PredictionEvaluator(mons)
+            self._engine.reset_ranking_buffers()
+            n = 0
+            for data in self.dataloader:
+                logits, labels = self._engine.pool_logits(self, data)
+                ev.update(logits, labels)
+                n += int(labels.numel())
+            for name, val in ev.compute().items():
+                self._meters[mode][name].update(val, max(n, 1), "mean")
+            return True
+        if self.cfg.get("ranking", "full") != "full":
+            return False
+        from recboard_amd.evaluate import RankingEvaluator
         mons = [m for m in self._meters[mode] if "@" in m]
         if not mons:
             return True
         ev = RankingEvaluator(mons)
         self._engine.reset_ranking_buffers()
-        for data in self.dataloader:
-            empty = [[] for _ in data[self.ISeen]]
-            seen_ptr, seen_idx = ragged_to_csr(data[self.ISeen] if self.remove_seen else empty, self.device)
-            tgt_ptr, tgt_idx = ragged_to_csr(data[self.IUnseen], self.device)
+        for j, data in enumerate(self.dataloader):
+            seen_ptr, seen_idx, tgt_ptr, tgt_idx = self._split_csr(mode, j, data)
             _, idx = self._engine.recommend_topk(self, data, seen_ptr, seen_idx, ev.kmax)
             ev.update(idx, tgt_ptr, tgt_idx)
         for name, val in ev.compute().items():
             self._meters[mode][name].update(val, max(ev.n, 1), "mean")
         return True
 
+    def _split_csr(self, mode, j, data):
+        """The seen / target lists of batch j of a split as device CSR -- built ONCE per split (the evaluation pipes
+        are ordered, every pass hands out the same rows) and kept on the device; a batch whose users are not the cached ones is rebuilt."""
+        from recboard_amd.evaluate import ragged_to_csr
+        cache = self.__dict__.setdefault("_csr_cache", {})
+        users = data.get(self.User) if hasattr(self, "User") else None
+        sig = users.reshape(-1).cpu() if torch.is_tensor(users) else None
+        hit = cache.get((mode, j))
+        if hit is not None and sig is not None and hit[0].shape == sig.shape and bool((hit[0] == sig).all()) and hit[1] == self.remove_seen:
+            return hit[2]
+        empty = [[] for _ in data[self.ISeen]]
+        csr = ragged_to_csr(data[self.ISeen] if self.remove_seen else empty, self.device) + ragged_to_csr(data[self.IUnseen], self.device)
+        if sig is not None:
+            cache[(mode, j)] = (sig, self.remove_seen, csr)
+        return csr
+
     # ---- engine routing
     def _attach_engine(self):
         if self.cfg.get("engine", "auto") == "module" or self.device.type != "cuda":
             return None
         try:
-            from recboard_amd import bridge
-        except Exception:  # noqa: BLE001  (the engine library is not built: the script's own torch code runs)
+            from recboard_amd import bridge, lib
+            lib.load()
+        except Exception as e:  # noqa: BLE001  (the engine library is not built / does not load: say so, loudly -- cfg.engine = "auto" asked for it)
+            import warnings
+            msg = (f"[recengine] >>> librecengine.so is not available ({type(e).__name__}: {e}); the model trains and evaluates on its own torch "
+                   "code.  Build it with `python __graft_entry__.py`, or pass --engine module to silence this.")
+            warnings.warn(msg)
+            utils.warnLogger(msg)
             return None
         return bridge.attach(self)
 

@@ -316,6 +316,8 @@ def score_topk(Q, E, seen_ptr, seen_idx, K, prep=None):
             raise ValueError("recengine: seen_ptr must have B+1 entries")
     if not (0 < K <= TOPK_MAX):
         raise ValueError(f"recengine: K must be in 1..{TOPK_MAX}")
+    if seen_idx is not None and seen_idx.numel() == 0:
+        seen_ptr = seen_idx = None          # (nobody has seen anything: an empty tensor has no address to hand over)
     L = lib.load()
     dev = Q.device
     vals = torch.empty((B, K), dtype=torch.float32, device=dev)

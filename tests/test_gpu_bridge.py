@@ -1,0 +1,263 @@
+"""GPU: the four north-star scripts on the `freerec` surface -- this repo's examples/{SASRec,MF-BPR,LightGCN,DeepFM}/main.py, the builder's
+own model files with the reference's class structure and parameter names -- driven UNCHANGED by `freerec.launcher.Coach`, which adopts them
+onto the HIP engines only after the probe step (recboard_amd/bridge.py): the reference's golden losses come out of `coach.train`, the
+module's parameters ARE the engine's arena, a few epochs through the engine end where the script's own torch loop ends, full-ranking
+evaluation runs on re_score_topk (pool evaluation of DeepFM on the engine's forward + the LOGLOSS / AUC kernels), an epoch through the
+Coach costs at most 1.3x the bare engine loop, and a look-alike with different arithmetic is refused with a warning."""
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_bridge_host import DEEPFM_ARGS, deepfm_dataset, lightgcn_dataset, load_deepfm_golden  # noqa: E402
+from test_freerec_compat import G, ROOT, import_script, toy_dataset  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+EX = os.path.join(ROOT, "examples")
+
+
+def _cfg(mod, **over):
+    cfg = mod.cfg
+    cfg.device, cfg.engine, cfg.epochs, cfg.eval_freq = "cuda:0", "auto", 1, 1
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _gen_batches(model, z):
+    batch = {model.User: torch.from_numpy(z["in/users"]), model.IPos: torch.from_numpy(z["in/pos"]), model.INeg: torch.from_numpy(z["in/neg"]),
+             model.Size: len(z["in/users"])}
+    sc = z["out/scores"]
+    order = np.argsort(-sc, 1, kind="stable")
+    # evaluation rows: nothing seen; the target is the 4th best item of the golden scores
+    vbatch = {model.User: torch.from_numpy(z["in/users"]), model.ISeen: [[] for _ in range(len(sc))],
+              model.IUnseen: [[int(order[b, 3])] for b in range(len(sc))], model.Size: len(sc)}
+    return batch, vbatch
+
+
+def _assert_bound(model, ad):
+    named = dict(model.named_parameters())
+    for k, view in ad.named_views().items():
+        assert named[k].data_ptr() == view.data_ptr() and tuple(named[k].shape) == tuple(view.reshape(named[k].shape).shape), k
+
+
+def _train_both_ways(build, epochs, lr, skip=()):
+    """The same script, the same batches, `epochs` epochs: through the engine and on the script's own torch code (--engine module).
+    skip: name fragments of parameters whose gradient is pure rounding noise in BOTH (Adam turns noise into +-lr steps)."""
+    out = {}
+    for engine in ("auto", "module"):
+        model, coach = build(engine)
+        assert (coach._engine is not None) == (engine == "auto")
+        for e in range(epochs):
+            res = coach.train(e)
+        out[engine] = ({k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}, res["LOSS"])
+    for k, a in out["auto"][0].items():
+        if any(s in k for s in skip):
+            continue
+        b = out["module"][0][k]
+        assert np.abs(a - b).max() <= 0.02 * lr * epochs + 1e-7, (k, float(np.abs(a - b).max()))
+    assert abs(out["auto"][1] - out["module"][1]) <= 1e-4 * abs(out["module"][1])
+
+
+@pytest.mark.parametrize("name,coach_name", [("MF-BPR", "CoachForMF"), ("LightGCN", "CoachForLightGCN")])
+def test_gen_scripts_run_on_their_engines_and_match_the_golden(name, coach_name):
+    fixture = {"MF-BPR": "mfbpr.npz", "LightGCN": "lightgcn.npz"}[name]
+    z = np.load(os.path.join(G, fixture))
+    mod = import_script(os.path.join(EX, name, "main.py"), "_gpu_bridge_" + name.replace("-", ""), [])
+    U, N = z["param/User.embeddings.weight"].shape[0], z["param/Item.embeddings.weight"].shape[0]
+    ds = toy_dataset(U, N) if name == "MF-BPR" else lightgcn_dataset(z)
+    wd = float(z["cfg/weight_decay"]) if name == "LightGCN" else 1e-4
+
+    def build(engine, lr=0.0):
+        model = (mod.MF if name == "MF-BPR" else mod.LightGCN)(ds)
+        model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}, strict=False)
+        batch, vbatch = _gen_batches(model, z)
+        cfg = _cfg(mod, engine=engine, lr=lr, weight_decay=wd, monitors=["LOSS", "HitRate@10", "NDCG@10"], which4best="NDCG@10")
+        coach = getattr(mod, coach_name)(dataset=ds, trainpipe=[batch], validpipe=[vbatch], testpipe=None, model=model, cfg=cfg)
+        return model, coach
+
+    model, coach = build("auto")
+    ad = coach._engine
+    assert ad is not None and ad.kind == name, "the Coach did not adopt the script onto its engine"
+    _assert_bound(model, ad)
+    out = coach.train(0)                                         # lr = 0: the golden loss, the golden gradients, parameters unchanged
+    want = float(z["out/loss"]) if name == "LightGCN" else float(z["out/rec_loss"])
+    assert abs(out["LOSS"] - want) <= 1e-5 * abs(want)
+    for k, g in ad.named_grads().items():
+        ref = z["grad/" + k]
+        assert np.abs(g.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-8, k
+    # full ranking on the fused score + top-K kernel: the 4th best item of the golden scores is the target
+    res = coach.valid(0)
+    assert abs(res["HITRATE@10"] - 1.0) < 1e-6 and abs(res["NDCG@10"] - 1.0 / np.log2(5.0)) < 1e-5
+    # the script's own dense scoring reads the same (engine-owned) parameters
+    model.eval()
+    with torch.no_grad():
+        model.reset_ranking_buffers()
+        sc = model({model.User: torch.from_numpy(z["in/users"]).cuda()}, ranking="full")
+    np.testing.assert_allclose(sc.cpu().numpy(), z["out/scores"], rtol=1e-4, atol=1e-5)
+    # three real epochs: engine == the script's own loop
+    _train_both_ways(lambda engine: build(engine, lr=1e-3), 3, 1e-3)
+
+
+def test_deepfm_script_runs_on_its_engine_and_matches_the_golden(tmp_path):
+    z = np.load(os.path.join(G, "deepfm.npz"))
+    args = [a if a != "0.3" else "0.0" for a in DEEPFM_ARGS]      # (dropout off: the golden's setting)
+    mod = import_script(os.path.join(EX, "DeepFM", "main.py"), "_gpu_bridge_deepfm", args)
+    ds = deepfm_dataset(z)
+
+    def build(engine, lr=0.0):
+        model = mod.DeepFM(ds)
+        load_deepfm_golden(model, z)
+        batch = {f: torch.from_numpy(z["in/x"][:, i:i + 1]) for i, f in enumerate(model.input_fields)}
+        batch[model.Label], batch[model.Size] = torch.from_numpy(z["in/labels"]), len(z["in/labels"])
+        cfg = _cfg(mod, engine=engine, lr=lr, monitors=["LOSS", "LOGLOSS", "AUC"], which4best="AUC", checkpoint_path=str(tmp_path))
+        coach = mod.CoachForDeepFM(dataset=ds, trainpipe=[batch], validpipe=[dict(batch)], testpipe=None, model=model, cfg=cfg)
+        return model, coach
+
+    model, coach = build("auto")
+    ad = coach._engine
+    assert ad is not None and ad.kind == "DeepFM" and ad.sched_mode == "front_best"
+    _assert_bound(model, ad)
+    out = coach.train(0)
+    assert abs(out["LOSS"] - float(z["out/rec_loss"])) <= 1e-5 * abs(float(z["out/rec_loss"]))
+    for i in range(3):      # BatchNorm running statistics are the engine's tensors, updated like nn.BatchNorm1d
+        np.testing.assert_allclose(model.dnn[i].bn.running_mean.cpu().numpy(), z[f"post/dnn.{i}.bn.running_mean"], rtol=1e-4, atol=1e-6)
+        assert int(model.dnn[i].bn.num_batches_tracked) == 1
+    # pool evaluation: the engine's forward + LOGLOSS / AUC kernels == the script's own sigmoid scores through freerec.metrics
+    res = coach.valid(0)
+    model.eval()
+    with torch.no_grad():
+        p = model({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in coach.validpipe[0].items()}, ranking="pool").reshape(-1)
+    np.testing.assert_allclose(p.cpu().numpy(), z["out/eval_scores"].reshape(-1), rtol=1e-4, atol=1e-6)
+    y = torch.from_numpy(z["in/labels"]).reshape(-1).float()
+    logloss = torch.nn.functional.binary_cross_entropy(p.cpu(), y).item()
+    pos, neg = p.cpu()[y > 0], p.cpu()[y == 0]
+    auc = ((pos[:, None] > neg[None, :]).float().sum() + 0.5 * (pos[:, None] == neg[None, :]).float().sum()).item() / (len(pos) * len(neg))
+    assert abs(res["LOGLOSS"] - logloss) <= 1e-5 and abs(res["AUC"] - auc) <= 1e-6
+    coach.save_checkpoint(0)
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint.tar"), weights_only=False)
+    assert set(ck) == {"epoch", "model", "optimizer", "lr_scheduler", "monitors"}
+    # (a Linear bias in front of a BatchNorm has an exactly zero gradient: what both paths hand Adam there is cancellation noise)
+    _train_both_ways(lambda engine: build(engine, lr=1e-3), 3, 1e-3, skip=(".linear.bias",))
+
+
+def test_sasrec_ce_script_runs_on_the_engine():
+    z = np.load(os.path.join(G, "sasrec_ce.npz"))
+    mod = import_script(os.path.join(EX, "SASRec", "main.py"), "_gpu_bridge_sasrec_ce", ["--dropout-rate", "0", "--loss", "CE"])
+    ds = toy_dataset(40, int(z["cfg/N"]))
+    model = mod.SASRec(ds)
+    model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    batch = {model.User: torch.arange(8), model.ISeq: torch.from_numpy(z["in/seq"]), model.IPos: torch.from_numpy(z["in/pos"]),
+             model.INeg: torch.from_numpy(z["in/neg"]), model.Size: 8}
+    cfg = _cfg(mod, lr=0.0, weight_decay=0.0, monitors=["LOSS", "NDCG@10"], which4best="NDCG@10")
+    coach = mod.CoachForSASRec(dataset=ds, trainpipe=[batch], validpipe=None, testpipe=None, model=model, cfg=cfg)
+    ad = coach._engine
+    assert ad is not None and ad.loss == "CE"
+    out = coach.train(0)
+    assert abs(out["LOSS"] - float(z["out/rec_loss"])) <= 1e-5 * abs(float(z["out/rec_loss"]))
+    for k, g in ad.named_grads().items():
+        ref = z["grad/" + k].reshape(g.shape)
+        assert np.abs(g.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, k
+
+
+def test_a_lookalike_with_other_arithmetic_is_refused_with_a_warning():
+    """A SASRec-named module whose attention reads LAYER-NORMED keys and values (the reference's does not: SASRec/main.py:165-169) has every
+    attribute the adapter looks for.  The probe step catches it: the Coach keeps it on its own torch code and says why."""
+    z = np.load(os.path.join(G, "sasrec_bce.npz"))
+    mod = import_script(os.path.join(EX, "SASRec", "main.py"), "_gpu_bridge_sasrec_variant", ["--dropout-rate", "0.2", "--loss", "BCE"])
+
+    class NormedKV(mod.SASRec):
+        def encode(self, data):
+            seq = data[self.ISeq]
+            pad = (seq == self.PADDING_VALUE).unsqueeze(-1)
+            x = self.Item.embeddings(seq) * (mod.cfg.embedding_dim ** 0.5) + self.Position(self.positions)
+            x = self.embdDropout(x).masked_fill(pad, 0.0)
+            for l in range(self.num_blocks):
+                q = self.attnLNs[l](x)
+                x = self.attnLayers[l](q, q, q, attn_mask=self.attnMask, need_weights=False)[0] + x
+                x = self.fwdLayers[l](self.fwdLNs[l](x)).masked_fill(pad, 0.0)
+            return self.lastLN(x), self.Item.embeddings.weight[self.NUM_PADS:]
+
+    ds = toy_dataset(40, int(z["cfg/N"]))
+    model = NormedKV(ds)
+    model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    batch = {model.User: torch.arange(8), model.ISeq: torch.from_numpy(z["in/seq"]), model.IPos: torch.from_numpy(z["in/pos"]),
+             model.INeg: torch.from_numpy(z["in/neg"]), model.Size: 8}
+    cfg = _cfg(mod, lr=1e-3, weight_decay=0.0, monitors=["LOSS"], which4best="LOSS")
+    with pytest.warns(UserWarning, match="NormedKV stays on its own torch code: gradient of"):
+        coach = mod.CoachForSASRec(dataset=ds, trainpipe=[batch], validpipe=None, testpipe=None, model=model, cfg=cfg)
+    assert coach._engine is None
+    before = model.lastLN.weight.detach().clone()
+    out = coach.train(0)                                          # ... and still trains, on aten
+    assert np.isfinite(out["LOSS"]) and not torch.equal(before, model.lastLN.weight.detach())
+    # the unmodified script with the same state IS adopted (dropout on in the model, off in the probe)
+    model2 = mod.SASRec(ds)
+    model2.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        coach2 = mod.CoachForSASRec(dataset=ds, trainpipe=[batch], validpipe=None, testpipe=None, model=model2, cfg=cfg)
+    assert coach2._engine is not None and coach2._engine.eng.p_drop == 0.2
+
+
+def test_gen_and_pred_epochs_through_the_coach_cost_at_most_1p3x_the_bare_engine_loops():
+    from recboard_amd.deepfm import DeepFMEngine
+    from recboard_amd.gen import MFEngine
+    rng = np.random.default_rng(5)
+    # MF-BPR at Beauty's shapes, 75 batches of 2 048 triplets (= one epoch)
+    mod = import_script(os.path.join(EX, "MF-BPR", "main.py"), "_gpu_bridge_mf_speed", [])
+    U, N, B, nb = 22363, 12101, 2048, 75
+    ds = toy_dataset(U, N)
+    model = mod.MF(ds)
+    trip = [tuple(torch.from_numpy(rng.integers(0, n, (B, 1))).cuda() for n in (U, N, N)) for _ in range(10)]
+    pipe = [{model.User: trip[i % 10][0], model.IPos: trip[i % 10][1], model.INeg: trip[i % 10][2], model.Size: B} for i in range(nb)]
+    cfg = _cfg(mod, lr=1e-3, weight_decay=1e-6, monitors=["LOSS"], which4best="LOSS")
+    coach = mod.CoachForMF(dataset=ds, trainpipe=pipe, validpipe=None, testpipe=None, model=model, cfg=cfg)
+    assert coach._engine is not None
+    eng = MFEngine(U, N, 64, lr=1e-3, weight_decay=1e-6)
+
+    def bare_mf():
+        for i in range(nb):
+            eng.train_step(*(t.reshape(-1) for t in trip[i % 10]))
+        torch.cuda.synchronize()
+
+    # DeepFM, ten fields, B = 4 096
+    modd = import_script(os.path.join(EX, "DeepFM", "main.py"), "_gpu_bridge_deepfm_speed", ["--batch-norm", "True"])
+    z = np.load(os.path.join(G, "deepfm.npz"))
+    dsd = deepfm_dataset(z)
+    counts = z["cfg/counts"].tolist()
+    modeld = modd.DeepFM(dsd)
+    Bd, nbd = 4096, 30
+    xs = [torch.from_numpy(np.stack([rng.integers(0, c, Bd) for c in counts], 1)).cuda() for _ in range(5)]
+    ys = [torch.from_numpy(rng.integers(0, 2, (Bd, 1))).cuda() for _ in range(5)]
+    piped = []
+    for i in range(nbd):
+        b = {f: xs[i % 5][:, j:j + 1] for j, f in enumerate(modeld.input_fields)}
+        b[modeld.Label], b[modeld.Size] = ys[i % 5], Bd
+        piped.append(b)
+    cfgd = _cfg(modd, lr=1e-3, monitors=["LOSS", "AUC"], which4best="AUC")
+    coachd = modd.CoachForDeepFM(dataset=dsd, trainpipe=piped, validpipe=None, testpipe=None, model=modeld, cfg=cfgd)
+    assert coachd._engine is not None
+    engd = DeepFMEngine(counts, 10, (400, 400, 400), batch_norm=True, hidden_dropout_rate=0.1, lr=1e-3)
+
+    def bare_deepfm():
+        for i in range(nbd):
+            engd.train_step(xs[i % 5], ys[i % 5].reshape(-1))
+        torch.cuda.synchronize()
+
+    def via(c):
+        def run():
+            c.train(0)
+            torch.cuda.synchronize()
+        return run
+    for bare, coach_run, what in ((bare_mf, via(coach), "MF-BPR"), (bare_deepfm, via(coachd), "DeepFM")):
+        best = {}
+        for name, fn in (("bare", bare), ("coach", coach_run)) * 3:
+            t0 = time.perf_counter()
+            fn()
+            best[name] = min(best.get(name, 1e9), time.perf_counter() - t0)
+        assert best["coach"] <= 1.3 * best["bare"], (what, best)

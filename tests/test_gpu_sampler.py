@@ -81,7 +81,7 @@ def test_freerec_pipe_runs_on_the_device_and_keeps_the_row_contract():
         assert seq.is_cuda and seq.shape[1] == 50 and b[model.Size] == seq.shape[0]
         for r, u in enumerate(users.tolist()):
             tr = np.asarray(seqs[u][:-2])
-            w = tr[-51:]
+            w = tr[-50:]                        # shuffled_seqs_source(maxlen): the last maxlen items, THEN the target is split off
             want_seq = np.zeros(50, np.int64); want_seq[50 - (len(w) - 1):] = w[:-1] + 1
             want_pos = np.zeros(50, np.int64); want_pos[50 - (len(w) - 1):] = w[1:]
             assert np.array_equal(seq[r].cpu().numpy(), want_seq) and np.array_equal(pos[r].cpu().numpy(), want_pos)
