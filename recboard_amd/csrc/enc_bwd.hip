@@ -65,7 +65,7 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
     const int64_t nwg = enc_slab_rows(B, S);   // upper bound of the launch grid (ncu), or one row per tile
     // (+ the weight-fragment planes of the wave-per-tile step, enc_wave.hip: L x 6 matrices x 2 orientations x 16 KB, 256-byte aligned)
     return (size_t)(nwg * L * EG_NVEC * D + enc_wgrad_part_floats(D, L) + enc_wgrad_ppart_floats(B, D) + L * EG_NMAT * NR * D) * sizeof(float) + 512 +
-           enc_tile_wfrag_bytes(L, D) + 512 + enc_tile_xch_bytes(B, S, D) + 256;   // (+ the tiles' dK / dV inboxes)
+           enc_tile_wfrag_bytes(L, D) + 512 + enc_tile_xch_bytes(B, S, D, L) + 256;   // (+ the tiles' dK / dV inboxes)
 }
 
 // dPtab == NULL: dx0 [B,S,D] receives the gradient w.r.t. x0 (rows of real tokens only).  Otherwise re_sasrec_embed_bwd is fused in:

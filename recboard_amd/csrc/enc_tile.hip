@@ -53,6 +53,50 @@ extern "C" int re_dbg_enc_marks_blocks(unsigned long long* out) {
 }
 #endif
 
+#ifdef TL_HANDOVER_DEBUG
+// Hand-over diagnostic build (`make hov` -> librecengine_hov.so; scripts/handover_soak.py): checksums of everything that crosses workgroups,
+// the fenced / sc1-only protocol and the workgroups per CU selectable at run time.
+#define TL_CHK_WORDS 24                                  // per tile: [2 l] k, [2 l + 1] v of block l; [8 + 3 l + slot] the inbox partials of block l
+#define TL_CHK_TILES 65536
+__device__ unsigned g_tl_chk[TL_CHK_TILES * TL_CHK_WORDS];
+__device__ unsigned g_tl_stale[8];                       // [0..2] mismatches: forward k / v, backward k / v, dK / dV inbox; [4..6] checks made
+__device__ int g_tl_fenced;
+__device__ int g_tl_lds_total;                           // floats of LDS the launch requested (the part behind tl_lds_floats is a canary in this build)
+__device__ unsigned g_tl_paranoid;                       // bit 0: a workgroup barrier in front of every operand-slot write; bit 1: ... of every exchange write
+__device__ unsigned g_tl_fill;                           // != 0: every workgroup first fills its LDS with this bit pattern (does anything read LDS it has not written?)
+static int h_tl_lds_kb = 84;
+#define TL_FENCED (::g_tl_fenced != 0)
+#define TL_PARANOID(BIT) do { if (::g_tl_paranoid & (BIT)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+// bit 3: 8 wait states behind every 16-byte global store (is its data still being read when the next instruction overwrites the registers?)
+#define TL_STORE_PAD() do { if (::g_tl_paranoid & 8u) asm volatile("s_nop 7" ::: "memory"); } while (0)
+// bit 2: 16 extra wait states behind the last MFMA of every product, in front of anything that reads its result
+#define TL_MFMA_PAD(ACC) do { if (::g_tl_paranoid & 4u) asm volatile("s_nop 15" : "+v"(ACC)); } while (0)
+extern "C" int re_dbg_tile_handover(int fenced, int lds_kb) {
+    h_tl_lds_kb = lds_kb;
+    const int tot = lds_kb * 256;                        // (floats; D = 64, L <= 2 needs 57 984 bytes: every lds_kb >= 57 is what the launch requests)
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_lds_total), &tot, sizeof(int)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_fenced), &fenced, sizeof(int)) == hipSuccess ? 0 : 1;
+}
+extern "C" int re_dbg_tile_paranoid(unsigned bits) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_paranoid), &bits, sizeof(unsigned)) == hipSuccess ? 0 : 1;
+}
+extern "C" int re_dbg_tile_fill(unsigned pattern) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_fill), &pattern, sizeof(unsigned)) == hipSuccess ? 0 : 1;
+}
+extern "C" int re_dbg_tile_stale(unsigned* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tl_stale), 8 * sizeof(unsigned)) != hipSuccess) return 1;
+    const unsigned z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_tl_stale), z, sizeof(z)) != hipSuccess) ? 1 : 0;
+}
+#else
+#ifndef TL_FENCED
+#define TL_FENCED 0
+#endif
+#define TL_PARANOID(BIT) do { } while (0)
+#define TL_MFMA_PAD(ACC) do { } while (0)
+#define TL_STORE_PAD() do { } while (0)
+#endif
+
 namespace tl4 {
 #define TL_NS 4
 #include "enc_tile_body.inc"
@@ -79,7 +123,13 @@ static int tl_launch(KP prep_k, KS step_k, const SeEmbed& em, const int64_t* seq
     // two per CU (what 256 threads and 60 KB would allow) about one run in two of 300 steps read a stale row somewhere: results that
     // differ from run to run in the last digits (scripts/determinism.py); the step time is the same either way (a batch has ~250 tiles).
     size_t ldsb = tl_lds_floats((int)L, NS) * sizeof(float);
+#ifdef TL_HANDOVER_DEBUG
+    if (ldsb < (size_t)h_tl_lds_kb * 1024) ldsb = (size_t)h_tl_lds_kb * 1024;
+
+    if (grid > TL_CHK_TILES) return RE_EUNSUPPORTED;
+#else
     if (ldsb < (size_t)84 * 1024) ldsb = (size_t)84 * 1024;
+#endif
     if (hipFuncSetAttribute((const void*)step_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
     hipLaunchKernelGGL(step_k, dim3(grid), dim3(64 * NS), ldsb, s, em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H,
                        dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch);

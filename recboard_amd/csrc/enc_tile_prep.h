@@ -21,13 +21,17 @@ typedef unsigned tl_u32x2 __attribute__((ext_vector_type(2)));
 #define TLC_SM(ns) (2 * (ns) * 16 * 4)
 #define TLC_TR(ns) ((ns) * 320)
 #define TLC_TILE_LDS(ns) (TLC_OB(ns) + TLC_RED(ns) + TLC_SM(ns) + TLC_TR(ns))
-#define TLC_XCH_TILE(ns) (3 * 2 * (ns) * 256)   // floats of a key tile's inbox of partial dV / dK: [sender t - kt - 1][dV, dK][strip][4 registers][64 lanes]
+// floats of a key tile's inbox of partial dV / dK for ONE block: [sender t - kt - 1][dV, dK][strip][4 registers][64 lanes].  A tile has an inbox PER
+// BLOCK ([tile][l]): the last tile of a sequence waits for nobody in the backward pass, so it can be a whole block ahead of the tile it sends
+// to -- with one inbox for all blocks its block l - 1 partial could land before the receiver had added the block l one (round 4's finding:
+// results that differed from run to run whenever co-resident workgroups slowed some tiles of a sequence down)
+#define TLC_XCH_TILE(ns) (3 * 2 * (ns) * 256)
 #define TLC_PREP_THREADS(L, ns) (6 * (L) * 2 * (ns) * TLC_NQ(ns) * 64)
 
 inline bool enc_tile_width_ok(int64_t D) { return D == 64 || D == 128; }
 // (+ the small parameters of every block and lastLN as one block of (10 L + 2) x D floats behind the fragments)
 inline size_t enc_tile_wfrag_bytes(int64_t L, int64_t D) { return (size_t)L * 6 * 2 * TLC_FRAG_WORDS(D / 16) * 4 + (size_t)(TL_NPAR * L + 2) * D * 4; }
-inline size_t enc_tile_xch_bytes(int64_t B, int64_t S, int64_t D) { return (size_t)enc_plan_max_tiles(B, S) * TLC_XCH_TILE(D / 16) * 4; }
+inline size_t enc_tile_xch_bytes(int64_t B, int64_t S, int64_t D, int64_t L) { return (size_t)enc_plan_max_tiles(B, S) * L * TLC_XCH_TILE(D / 16) * 4; }
 // where the fragments, the exchange inboxes and the launch epoch live: behind the gradient tape in the backward workspace / in the tape's flag area
 inline uint32_t* enc_tile_wf(float* gtape, int64_t B, int64_t S, int64_t L, int64_t D) {
     return (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * 16 * enc_plan_max_tiles(B, S) * D)) + 255) & ~(uintptr_t)255);

@@ -14,8 +14,11 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# passes on gfx950.  The 16-bit forms CDNA3 already had run at CDNA3's rate there (1 307 TF dense on 304 CUs x 4 SIMDs x 2.1 GHz = 512 FLOP per
+# clock and SIMD: 16x16x16 = 8 192 FLOP = 16 cycles = 4 passes; 32x32x8 = 8 passes) -- half of what gfx90a needed, and what hipcc's own
+# hazard recognizer pads for (7 = 4 + 3 states behind v_mfma_f32_16x16x16_bf16 in csrc/enc_tile.hip); CDNA4's double-K forms take the same passes.
 PASSES = {"32x32x2_f32": 16, "16x16x4_f32": 8, "32x32x1_2b_f32": 16, "16x16x1_4b_f32": 8, "4x4x1_16b_f32": 2,
-          "32x32x8_f16": 16, "16x16x16_f16": 8, "32x32x8_bf16": 16, "16x16x16_bf16": 8, "32x32x16_bf16": 8,
+          "32x32x8_f16": 8, "16x16x16_f16": 4, "32x32x8_bf16": 8, "16x16x16_bf16": 4, "32x32x16_bf16": 8,
           "16x16x32_bf16": 4, "32x32x16_f16": 8, "16x16x32_f16": 4}
 # XDL (16-bit input) MFMAs: result -> vector read needs passes + 3 wait states (8 passes: 11); fp32 "SGEMM" MFMAs passes + 2
 XDL = ("_bf16", "_f16")
