@@ -313,7 +313,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the config-1 / config-3 / config-4 legs and the sampler rates")
     ap.add_argument("--no-extras", action="store_true", help="skip eval / gather legs (profiling runs)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the aten-on-GPU baselines (kernel-trace runs: only the engine's kernels)")
-    ap.add_argument("--encoder", default="fused", choices=("fused", "aten"))
+    ap.add_argument("--encoder", default="fused", choices=("fused",), help="(the engine has one encoder: the HIP kernels; the torch comparator lives in tests/aten_sasrec.py)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="do not hand train_step_graph the next batch (default: an epoch loop has it; it is prepared by jobs of this step's tail launch)")
     ap.add_argument("--prefetch", dest="prefetch", action="store_true", help=argparse.SUPPRESS)

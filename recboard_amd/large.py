@@ -10,9 +10,9 @@ Same model as `recboard_amd.sasrec.SASRecEngine` (reference `SASRec/main.py:63-2
     a dense Adam over the table would move 28 bytes per element, 358 GB per step;
   * everything else (position table, blocks, lastLN) stays in one dense arena with one fused Adam launch.
 
-Encoder: the fused kernels (D = 64 and 128; at D = 128 a work item holds 32 rows in LDS and longer sequences are taken in chained
-parts, csrc/enc_fwd.hip) with the embedding front end / backward fused in; any other width runs the block stack through torch
-(`encoder="aten"`) between the engine's embedding, criterion and optimizer kernels.
+Encoder: the HIP kernels (D = 64 and 128; at D = 128 a work item holds 32 rows in LDS and longer sequences are taken in chained
+parts, csrc/enc_fwd.hip) with the embedding front end / backward fused in; any other shape raises (RE_EUNSUPPORTED) -- the engine has no
+torch encoder (a torch restatement of the block stack is a comparator in tests/aten_sasrec.py).
 Multi-GPU: `recboard_amd.sharded.ShardedTable.lookup / backward_sparse_adam` is the same step with the table row-sharded
 (one all-to-all per direction); this class is the single-GPU form.
 """
@@ -49,8 +49,11 @@ class SASRecLargeTableEngine(SASRecEngine):
     def __init__(self, num_items, maxlen=50, embedding_dim=128, num_blocks=2, dropout_rate=0.0, loss="BCE", lr=1e-3,
                  weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, table_std=0.02, table_init="torch", encoder=None):
         assert loss in ("BCE", "BPR")
-        # the fused encoder kernels cover D = 64 and 128 (BASELINE config 5 is D = 128); any other width runs the block stack on torch
-        self.encoder = encoder or ("fused" if embedding_dim in (64, 128) and maxlen <= 64 and num_blocks <= 4 else "aten")
+        # the encoder kernels cover D = 64 and 128 (BASELINE config 5 is D = 128)
+        if (encoder or "fused") != "fused" or embedding_dim not in (64, 128) or maxlen > 64 or num_blocks > 4:
+            raise NotImplementedError(f"recengine: unsupported shape (RE_EUNSUPPORTED): the encoder kernels cover D = 64 or 128, maxlen <= 64, "
+                                      f"blocks <= 4; got D = {embedding_dim}, maxlen = {maxlen}, blocks = {num_blocks}, encoder = {encoder!r}")
+        self.encoder = "fused"
         self.compact_rows = True     # fused encoder: the step on the batch plan's compact rows (criterion in the forward kernel)
         self.split_long = True       # sequences of 3 - 4 tiles as two work items in two workgroups (at D = 128 a whole long item is two
                                      # SEQUENTIAL parts in one workgroup: the launch lasts twice a part)
@@ -118,13 +121,10 @@ class SASRecLargeTableEngine(SASRecEngine):
         with torch.no_grad():
             P = self.params
             p = self.p_drop if self.training else 0.0
-            if self.encoder == "fused":
-                u, _ = ops.sasrec_embed_encoder_fwd(self.E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), self._block_tensors(),
-                                                    P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, self._step_seed(),
-                                                    plan=ops.sasrec_plan(seq, self.D))
-                return u, self.E[1:]
-            x0 = ops.sasrec_embed(self.E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), p, self._step_seed())
-            return self._blocks(x0, (seq == 0).unsqueeze(-1)), self.E[1:]
+            u, _ = ops.sasrec_embed_encoder_fwd(self.E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), self._block_tensors(),
+                                                P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, self._step_seed(),
+                                                plan=ops.sasrec_plan(seq, self.D))
+            return u, self.E[1:]
 
     def _grads(self, seq, pos, neg, aux, sd, seed_dev=None, table=None, adam_hyper=None, next_prep=None):
         """Forward + backward: encoder gradients into the arena, the item-gradient contribution rows C with their destination rows
@@ -190,34 +190,20 @@ class SASRecLargeTableEngine(SASRecEngine):
                                            G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev,
                                            part=8 if getattr(aux, "weights_ready", False) else 0)
             return loss, W["g_rows"].view(-1, D), W["keys"]          # keys: int32 [3, NR], the plan's first rows of every region live
-        if self.encoder == "fused":
-            # the same launches as SASRecEngine's fused step, minus the dense scatter-add: fused embedding + encoder forward (tape),
-            # criterion forward + backward, encoder backward with the embedding backward fused in (contribution rows, position gradient)
-            W = self._buffers(B, S)
-            G = A.views(A.grad)
-            lw, lb = self.params["lastLN.weight"].detach(), self.params["lastLN.bias"].detach()
-            bt = self._block_tensors()
-            C = W["contrib"]
-            ops.sasrec_embed_encoder_fwd(E, Ppos.detach(), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"],
-                                         tape=W["tape"], plan=aux.plan, seed_dev=seed_dev)
-            loss, _, _, _ = ops.pair_loss_fwd_bwd(W["u"].view(n, D), E, pos.reshape(-1), neg.reshape(-1), valid, kind, count, e_off=1,
-                                                  out=(W["dU"], C[n:2 * n], C[2 * n:]))
-            ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
-                                         self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],
-                                         out=C[:n].view(B, S, D), ws=W["ws_bwd"], plan=aux.plan, seed_dev=seed_dev)
-            return loss, C, aux.rows_all
-        # embedding front end (engine kernel, no autograd node: its backward is re_sasrec_embed_bwd below)
-        x0 = ops.sasrec_embed(E, Ppos.detach(), seq, float(D ** 0.5), p, sd, seed_dev=seed_dev).requires_grad_(True)
-        A.grad.zero_()
-        for k, q in self.params.items():
-            q.grad = A.view(A.grad, k)
-        u = self._blocks(x0, (seq == 0).unsqueeze(-1))
-        C = torch.empty((3 * n, D), dtype=torch.float32, device=self.device)
-        loss, dU, _, _ = ops.pair_loss_fwd_bwd(u.detach().reshape(n, D), E, pos.reshape(-1), neg.reshape(-1), valid, kind, count,
-                                              e_off=1, out=(torch.empty((n, D), device=self.device), C[n:2 * n], C[2 * n:]))
-        u.backward(dU.view(B, S, D))                                      # encoder parameter gradients + d x0
-        C[:n].copy_(x0.grad.reshape(n, D))
-        ops.sasrec_embed_bwd(C[:n].view(B, S, D), seq, float(D ** 0.5), p, sd, A.view(A.grad, "Position.weight"), seed_dev=seed_dev)
+        # the same launches as SASRecEngine's fused step, minus the dense scatter-add: fused embedding + encoder forward (tape),
+        # criterion forward + backward, encoder backward with the embedding backward fused in (contribution rows, position gradient)
+        W = self._buffers(B, S)
+        G = A.views(A.grad)
+        lw, lb = self.params["lastLN.weight"].detach(), self.params["lastLN.bias"].detach()
+        bt = self._block_tensors()
+        C = W["contrib"]
+        ops.sasrec_embed_encoder_fwd(E, Ppos.detach(), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, need_tape=True, out=W["u"],
+                                     tape=W["tape"], plan=aux.plan, seed_dev=seed_dev)
+        loss, _, _, _ = ops.pair_loss_fwd_bwd(W["u"].view(n, D), E, pos.reshape(-1), neg.reshape(-1), valid, kind, count, e_off=1,
+                                              out=(W["dU"], C[n:2 * n], C[2 * n:]))
+        ops.sasrec_encoder_embed_bwd(W["dU"].view(B, S, D), seq, float(D ** 0.5), bt, lw, lb, self.L, p, sd, W["tape"],
+                                     self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], G["Position.weight"],
+                                     out=C[:n].view(B, S, D), ws=W["ws_bwd"], plan=aux.plan, seed_dev=seed_dev)
         return loss, C, aux.rows_all
 
     def _table_adam(self, C, rows, aux, step=0, hyper=None):
@@ -638,13 +624,10 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             ar = torch.arange(1, B * S + 1, device=self.device)
             seq_l = torch.where(seq.reshape(-1) != 0, ar, torch.zeros_like(ar)).view(B, S)
             P, p = self.params, (self.p_drop if self.training else 0.0)
-            if self.encoder == "fused":
-                u, _ = ops.sasrec_embed_encoder_fwd(T, P["Position.weight"].detach(), seq_l, float(self.D ** 0.5), self._block_tensors(),
-                                                    P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, self._step_seed(),
-                                                    plan=ops.sasrec_plan(seq_l, self.D))
-                return u, None
-            x0 = ops.sasrec_embed(T, P["Position.weight"].detach(), seq_l, float(self.D ** 0.5), p, self._step_seed())
-            return self._blocks(x0, (seq == 0).unsqueeze(-1)), None
+            u, _ = ops.sasrec_embed_encoder_fwd(T, P["Position.weight"].detach(), seq_l, float(self.D ** 0.5), self._block_tensors(),
+                                                P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, self._step_seed(),
+                                                plan=ops.sasrec_plan(seq_l, self.D))
+            return u, None
 
     def recommend_topk(self, seq, seen_ptr, seen_idx, K=50):
         """Sharded full-catalog top-K (ShardedTable.score_topk): ids are ITEM ids (table row - 1); the padding row never wins."""

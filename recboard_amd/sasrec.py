@@ -92,54 +92,18 @@ class ParamArena:
             self.step = int(st["step"])
 
 
-class _EmbedFn(torch.autograd.Function):
-    """x = E[seq]*sqrt(D) + P[s], pad rows 0 (re_sasrec_embed); backward = deterministic scatter-add into dense dE."""
-
-    @staticmethod
-    def forward(ctx, E, P, seq, scale):
-        ctx.save_for_backward(seq)
-        ctx.R, ctx.scale, ctx.S = E.shape[0], scale, seq.shape[1]
-        return ops.sasrec_embed(E, P, seq, scale)
-
-    @staticmethod
-    def backward(ctx, gout):
-        (seq,) = ctx.saved_tensors
-        gout = gout.contiguous()
-        dE = ops.scatter_add_rows(gout, seq, ctx.R, 0, ctx.scale)
-        dP = (gout * (seq != 0).unsqueeze(-1)).sum(0)
-        return dE, dP, None, None
-
-
-class _PairLossFn(torch.autograd.Function):
-    """mean BCE(pos,1)+BCE(neg,0) / BPR over the valid positions (re_pair_loss_fwd/bwd), item rows = E[1 + id]."""
-
-    @staticmethod
-    def forward(ctx, U, E, pos, neg, valid, rows_pos, rows_neg, kind):
-        U2 = U.reshape(-1, U.shape[-1])
-        loss, logits, count = ops.pair_loss_fwd(U2, E, pos, neg, valid, kind, e_off=1)
-        ctx.save_for_backward(U2, E, pos, neg, valid, rows_pos, rows_neg, logits, count)
-        ctx.kind, ctx.ushape = kind, U.shape
-        return loss.squeeze(0)
-
-    @staticmethod
-    def backward(ctx, gl):
-        U2, E, pos, neg, valid, rows_pos, rows_neg, logits, count = ctx.saved_tensors
-        dU, gp, gn = ops.pair_loss_bwd(U2, E, pos, neg, valid, ctx.kind, logits, count, gl.reshape(1).contiguous(), e_off=1)
-        dE = ops.scatter_add_rows(torch.cat([gp, gn]), torch.cat([rows_pos, rows_neg]), E.shape[0], 0, 1.0)
-        return dU.view(ctx.ushape), dE, None, None, None, None, None, None
-
-
 class SASRecEngine:
     """SASRec (reference defaults: D=64, 2 blocks, 1 head, maxlen 50) with engine kernels on the hot path."""
 
     def __init__(self, num_items, maxlen=50, embedding_dim=64, num_blocks=2, dropout_rate=0.0, loss="BCE",
                  lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), device="cuda", seed=1, encoder="fused"):
         assert loss in ("BCE", "BPR", "CE")
-        assert encoder in ("fused", "aten")
-        if loss == "CE" and encoder != "fused":
-            raise NotImplementedError("loss='CE' is implemented on the fused path only")
-        if encoder == "fused" and (embedding_dim not in (64, 128) or maxlen > 64 or num_blocks > 4):
-            raise NotImplementedError("fused encoder kernels: D = 64 or 128, maxlen <= 64, blocks <= 4 (use encoder='aten')")
+        if encoder != "fused":
+            raise NotImplementedError("recengine: the engine has ONE encoder, the HIP kernels (a torch restatement of the block stack lives in "
+                                      "tests/aten_sasrec.py as a comparator)")
+        if embedding_dim not in (64, 128) or maxlen > 64 or num_blocks > 4:
+            raise NotImplementedError(f"recengine: unsupported shape (RE_EUNSUPPORTED): the encoder kernels cover D = 64 or 128, maxlen <= 64, "
+                                      f"blocks <= 4; got D = {embedding_dim}, maxlen = {maxlen}, blocks = {num_blocks}")
         self.encoder = encoder
         self.split_long = True          # sequences of 3 - 4 tiles as two work items in two workgroups (fused BCE / BPR training step)
         self.fused_item_kernel = True   # forward + criterion + backward of a work item in one launch (False: two launches; same results)
@@ -214,28 +178,6 @@ class SASRecEngine:
     def eval(self):
         return self.train(False)
 
-    # ---- encoder (aten path; the fused HIP encoder replaces `_blocks`)
-    def _drop(self, x):
-        return torch.nn.functional.dropout(x, self.p_drop, self.training) if self.p_drop > 0 else x
-
-    def _blocks(self, x, pad):
-        P, D, S = self.params, self.D, x.shape[1]
-        F = torch.nn.functional
-        causal = torch.ones(S, S, dtype=torch.bool, device=x.device).triu(1)
-        for l in range(self.L):
-            Wi, bi = P[f"attnLayers.{l}.in_proj_weight"], P[f"attnLayers.{l}.in_proj_bias"]
-            q = F.layer_norm(x, (D,), P[f"attnLNs.{l}.weight"], P[f"attnLNs.{l}.bias"], 1e-8) @ Wi[:D].T + bi[:D]
-            kv = x @ Wi[D:].T + bi[D:]
-            k, v = kv[..., :D], kv[..., D:]
-            att = (q @ k.transpose(1, 2)) / math.sqrt(D)
-            att = self._drop(torch.softmax(att.masked_fill(causal, float("-inf")), -1))
-            x = (att @ v) @ P[f"attnLayers.{l}.out_proj.weight"].T + P[f"attnLayers.{l}.out_proj.bias"] + x
-            y = F.layer_norm(x, (D,), P[f"fwdLNs.{l}.weight"], P[f"fwdLNs.{l}.bias"], 1e-8)
-            h = self._drop(y @ P[f"fwdLayers.{l}.conv1.weight"].squeeze(-1).T + P[f"fwdLayers.{l}.conv1.bias"])
-            o = self._drop(torch.relu(h) @ P[f"fwdLayers.{l}.conv2.weight"].squeeze(-1).T + P[f"fwdLayers.{l}.conv2.bias"])
-            x = (o + y).masked_fill(pad, 0.0)
-        return F.layer_norm(x, (D,), P["lastLN.weight"], P["lastLN.bias"], 1e-8)
-
     def _block_tensors(self, buf=None):
         A = self.arena
         named = self.params if buf is None else A.views(buf)
@@ -246,32 +188,28 @@ class SASRecEngine:
         return (self.seed * 0x9E3779B1 + (self.arena.step + 1) * 0x85EBCA77) & 0xFFFFFFFF
 
     def encode(self, seq):
-        """-> (userEmbds [B,S,D], itemEmbds = E[1:]).  SASRec/main.py:178-193."""
-        if self.encoder == "fused" and not torch.is_grad_enabled():
-            P = self.params
-            E = P["Item.embeddings.weight"].detach()
-            p = self.p_drop if self.training else 0.0
-            sd = self._step_seed()
-            u, _ = ops.sasrec_embed_encoder_fwd(E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), self._block_tensors(),
-                                                P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, sd,
-                                                plan=ops.sasrec_batch_prep(seq, max_tiles=self._max_tiles()).plan)
-            return u, E[1:]
-        E = self.params["Item.embeddings.weight"]
-        x = _EmbedFn.apply(E, self.params["Position.weight"], seq, float(self.D ** 0.5))
-        pad = (seq == 0).unsqueeze(-1)
-        x = self._drop(x)  # pads are zero before and after dropout, as in the reference's order of ops
-        return self._blocks(x, pad), E[1:]
+        """-> (userEmbds [B,S,D], itemEmbds = E[1:]).  SASRec/main.py:178-193.  Forward only (training goes through `train_step*`)."""
+        P = self.params
+        E = P["Item.embeddings.weight"].detach()
+        p = self.p_drop if self.training else 0.0
+        sd = self._step_seed()
+        u, _ = ops.sasrec_embed_encoder_fwd(E, P["Position.weight"].detach(), seq, float(self.D ** 0.5), self._block_tensors(),
+                                            P["lastLN.weight"].detach(), P["lastLN.bias"].detach(), self.L, p, sd,
+                                            plan=ops.sasrec_batch_prep(seq, max_tiles=self._max_tiles()).plan)
+        return u, E[1:]
 
     def fit(self, seq, pos, neg, aux=None):
-        """-> {"rec_loss": scalar}.  SASRec/main.py:195-221 (BCE / BPR)."""
-        u, _ = self.encode(seq)
-        if aux is None:
-            aux = self.batch_aux(seq, pos, neg)
-        valid, rows_pos, rows_neg = aux
+        """-> {"rec_loss": scalar}, forward only.  SASRec/main.py:195-221 (BCE / BPR over the non-pad positions; CE over the catalog)."""
+        u, items = self.encode(seq)
+        valid, _, _ = aux if aux is not None else self.batch_aux(seq, pos, neg)
+        u2 = u.reshape(-1, self.D)
+        if self.loss_kind == "CE":
+            vidx = torch.nonzero(valid).reshape(-1)
+            logits = ops.gemm(ops.gather_rows(u2, vidx), items, transB=True)
+            return {"rec_loss": ops.ce_rows_(logits, pos.reshape(-1)[vidx].contiguous()).squeeze(0)}
         kind = ops.LOSS_BCE if self.loss_kind == "BCE" else ops.LOSS_BPR
-        loss = _PairLossFn.apply(u, self.params["Item.embeddings.weight"], pos.reshape(-1), neg.reshape(-1), valid,
-                                 rows_pos, rows_neg, kind)
-        return {"rec_loss": loss}
+        loss, _, _ = ops.pair_loss_fwd(u2, self.params["Item.embeddings.weight"].detach(), pos.reshape(-1), neg.reshape(-1), valid, kind, e_off=1)
+        return {"rec_loss": loss.squeeze(0)}
 
     @staticmethod
     def batch_aux(seq, pos, neg):
@@ -773,16 +711,4 @@ class SASRecEngine:
 
     # ---- CoachForSASRec.train_per_epoch body (SASRec/main.py:243-250): zero_grad, backward, Adam step
     def train_step(self, seq, pos, neg, aux=None, grad_hook=None):
-        if self.encoder == "fused":
-            return self.train_step_fused(seq, pos, neg, aux, grad_hook)
-        A = self.arena
-        A.grad.zero_()
-        for k, p in self.params.items():
-            p.grad = A.view(A.grad, k)
-        loss = self.fit(seq, pos, neg, aux)["rec_loss"]
-        loss.backward()
-        if grad_hook is not None:
-            grad_hook(A.grad)  # data parallel: one all-reduce over the whole gradient arena
-        A.step += 1
-        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
-        return loss.detach()
+        return self.train_step_fused(seq, pos, neg, aux, grad_hook)

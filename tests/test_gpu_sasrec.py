@@ -1,9 +1,13 @@
 """GPU: SASRec on the engine vs the reference's golden vectors (tests/golden/sasrec_*.npz) and the oracle."""
 import os
 
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -12,9 +16,10 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 def _engine(z, loss, **kw):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    from aten_sasrec import AtenSASRec
     from recboard_amd.sasrec import SASRecEngine
-    kw.setdefault("encoder", "aten")
-    m = SASRecEngine(int(z["cfg/N"]), 50, int(z["cfg/D"]), int(z["cfg/num_blocks"]), dropout_rate=0.0, loss=loss, **kw)
+    cls = AtenSASRec if kw.pop("encoder", "aten") == "aten" else SASRecEngine      # ("aten": the test comparator, tests/aten_sasrec.py)
+    m = cls(int(z["cfg/N"]), 50, int(z["cfg/D"]), int(z["cfg/num_blocks"]), dropout_rate=0.0, loss=loss, **kw)
     m.load_state_dict({k[6:]: z[k] for k in z.files if k.startswith("param/") and z[k].dtype == np.float32})
     return m
 
