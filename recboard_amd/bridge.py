@@ -16,8 +16,10 @@ adapter is returned:
   2. the script's own `train_per_epoch` runs on two copies of the first training batch with dropout switched off, on the module's torch
      code, while the optimizer / scheduler calls are recorded; the gradients it hands to `optimizer.step()` (after any clipping, with any
      extra loss terms) are kept; module, optimizer, scheduler and monitors are restored afterwards;
-  3. the engine takes one step on the same batch from the same parameters: its gradients must equal the script's to 1e-3 of each tensor's
-     largest entry, and its parameter update must equal torch's Adam formula on those gradients with the optimizer's own numbers;
+  3. the engine takes one step on the same batch from the same parameters: its gradients must equal the script's own step in DOUBLE
+     precision, tensor by tensor, to 1e-3 in the L2 sense and 2e-2 of the largest entry for the worst one (or a few times the script's own
+     fp32 rounding where that is larger), and its parameter update must equal torch's Adam formula on those gradients with the
+     optimizer's own numbers;
   4. the recorded call pattern must be one the adapter replays: one `optimizer.step()` per batch; the scheduler not at all, or once per epoch
      (in front of the loop with `coach._best`, as DeepFM/main.py:256, or behind it without arguments).
 Anything else -- and any exception on the way -- logs a warning that names the model and the reason, and the script runs on its own torch
@@ -656,14 +658,21 @@ def _probe(coach, ad):
         ge, gr = grads[k].detach().reshape(-1).double(), g_ref[k].reshape(-1).double()
         scale = float(gr.abs().max())
         err = float((ge - gr).abs().max())
-        # allowed: GRAD_TOL of the tensor's largest entry -- or, where the script's OWN fp32 arithmetic is noisier than that (sums that
-        # cancel: a Linear bias behind a BatchNorm has a zero gradient; ROCm aten's fp32 GEMMs), a few times the script's own distance
-        # from its double-precision self
-        noise = 0.0 if g_f32 is None else float((g_f32[k].reshape(-1).double() - gr).abs().max())
-        tol = max((GRAD_TOL if g_f32 is not None else GRAD_TOL_F32) * scale, 4.0 * noise) + 1e-12
-        if not math.isfinite(err) or err > tol:
-            raise Refused(f"gradient of {k} differs from the script's own step: max |diff| {err:.3e} against max |grad| {scale:.3e} "
-                          f"(the script's own fp32 rounding there: {noise:.1e})")
+        # allowed: GRAD_TOL in the L2 sense and 20 x GRAD_TOL for the worst entry (a relu pre-activation within rounding of zero may fall on the
+        # other side in one of two fp32 arithmetics; that unit's gradient entries then move by its whole contribution -- a handful among
+        # ~10^5 - 10^6 pre-activations of a batch) -- or, where the script's OWN fp32 arithmetic is noisier than that (sums that cancel: a
+        # Linear bias behind a BatchNorm has a zero gradient; ROCm aten's fp32 GEMMs), a few times the script's own distance from its
+        # double-precision self.  Different arithmetic (another mask, another normalisation, a missing term) is off by O(1) in both norms.
+        tol_rel = GRAD_TOL if g_f32 is not None else GRAD_TOL_F32
+        d32 = None if g_f32 is None else (g_f32[k].reshape(-1).double() - gr)
+        noise = 0.0 if d32 is None else float(d32.abs().max())
+        noise2 = 0.0 if d32 is None else float(d32.norm())
+        err2, n2 = float((ge - gr).norm()), float(gr.norm())
+        tol = max(20.0 * tol_rel * scale, 4.0 * noise) + 1e-12
+        tol2 = max(tol_rel * n2, 4.0 * noise2) + 1e-12
+        if not math.isfinite(err) or err > tol or err2 > tol2:
+            raise Refused(f"gradient of {k} differs from the script's own step: |diff| max {err:.3e} / L2 {err2:.3e} against |grad| max {scale:.3e} / L2 "
+                          f"{n2:.3e} (the script's own fp32 rounding there: max {noise:.1e})")
         if scale > 0 and err / scale > worst[1]:
             worst = (k, err / scale)
         # torch.optim.Adam's first step on the ENGINE's gradient with the script's numbers (coupled decay, eps 1e-8)
