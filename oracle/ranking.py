@@ -25,7 +25,7 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "_build", "librecoracle.so")
+        path = os.environ.get("RECORACLE_LIB") or os.path.join(_HERE, "_build", "librecoracle.so")   # (RECORACLE_LIB: the sanitizer build, tests only)
         if not os.path.exists(path):
             import subprocess
             subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)

@@ -189,8 +189,11 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
     unsigned long long pl_t[6];
     pl_t[0] = __builtin_amdgcn_s_memtime();
 #define PL_STAMP(i) pl_t[i] = __builtin_amdgcn_s_memtime()
-#else
+#elif !defined(PL_STAMP)
 #define PL_STAMP(i) do { } while (0)
+#endif
+#ifdef TAIL_PROFILE
+    PL_STAMP(0);
 #endif
     int (*const s_cnt)[PL_NW] = reinterpret_cast<int (*)[PL_NW]>(L);                     // [PL_NCLS][PL_NW]
     int* const s_tot = reinterpret_cast<int*>(L + PL_NCLS * PL_NW * 4);
@@ -352,6 +355,10 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
         const int row = in_lds ? s_place[b0] : g_place[b0];
         for (int off = tid & 7; off < span; off += 8) rowmap[row + off] = make_int2(b0 * S + (S - span) + off, S - span);
     }
+#ifdef TAIL_PROFILE
+    __syncthreads();
+    PL_STAMP(3);
+#endif
 #if defined(ENC_PROFILE) && defined(PL_PLAN_KERNEL)
     __syncthreads();
     PL_STAMP(3);

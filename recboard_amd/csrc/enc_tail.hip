@@ -8,6 +8,23 @@
 #include "enc_wgrad_job.h"
 #include "scatter_owner.h"
 #include "adam_rows_owner.h"
+#ifdef TAIL_PROFILE
+// Diagnostic build (`make encprof`; scripts/tail_phases.py): shader-clock stamps of every workgroup of the last enc_tail_k launch:
+// [0] start, [1] scatter-add done, [2 + 2 i] ticket of its i-th job + 1, [3 + 2 i] that job's end (i < 3), [8 .. 13] the plan job's phases
+// (in the workgroup that ran it), [15] end
+#define TAIL_MARKS 16
+#define TAIL_MARK_WGS 4096
+__device__ unsigned long long g_tail_marks[TAIL_MARK_WGS * TAIL_MARKS];
+extern "C" int re_dbg_tail_marks(unsigned long long* out, int nwg) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_marks), sizeof(unsigned long long) * TAIL_MARKS * (nwg < TAIL_MARK_WGS ? nwg : TAIL_MARK_WGS)) == hipSuccess ? 0 : 1;
+}
+#define TAIL_MARK(i, v) do { if (threadIdx.x == 0 && blockIdx.x < TAIL_MARK_WGS) g_tail_marks[blockIdx.x * TAIL_MARKS + (i)] = (v); } while (0)
+#define TAIL_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#define PL_STAMP(i) TAIL_MARK(8 + (i), TAIL_NOW())
+#else
+#define TAIL_MARK(i, v) do { } while (0)
+#define TAIL_NOW() 0ull
+#endif
 #include "enc_plan_body.h"
 
 struct TailJobs {
@@ -50,12 +67,16 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
     const int n_mat = J.L * PER_PLANE / 2, n_pos = J.ppart ? PER_PLANE / 2 : 0;
     const int n_prep = TP.mail ? 1 + TP.n_ew : 0;
     const int n_tiles = enc_plan_view(J.plan, J.B, J.S).hdr[1];
+    int jn = 0; (void)jn;
     for (;;) {
         __syncthreads();   // (the launch's first part / the previous job's stages are done with the LDS)
+        if (jn > 0 && jn <= 3) TAIL_MARK(1 + 2 * jn, TAIL_NOW());
         if (tid == 0) s_job = (int)atomicAdd(J.ticket, 1u);
         __syncthreads();
         int t = s_job;
         if (t >= n_prep + n_mat + n_pos) break;
+        if (jn < 3) TAIL_MARK(2 + 2 * jn, (unsigned long long)(t + 1));
+        ++jn;
         if (t < n_prep) {
             const PlMail M = *TP.mail;
             if (M.seq || M.SP.ptr) {                           // (uniform)
@@ -79,8 +100,15 @@ __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g,
                                                     const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
                                                     int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
+#ifdef TAIL_PROFILE
+    if (threadIdx.x < TAIL_MARKS && blockIdx.x < TAIL_MARK_WGS) g_tail_marks[blockIdx.x * TAIL_MARKS + threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
+    TAIL_MARK(0, TAIL_NOW());
     so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds);
+    TAIL_MARK(1, TAIL_NOW());
     tail_jobs<D>(J, TP, lds);
+    TAIL_MARK(15, TAIL_NOW());
 }
 
 // the same behind the row-sparse Adam of a LARGE table (adam_rows_owner.h; config 5: D = 128, HS = 2)

@@ -1,0 +1,56 @@
+"""Where the step's tail launch (csrc/enc_tail.hip: scatter-add workgroups that go on with the weight-gradient jobs) spends its time, from the
+per-workgroup shader-clock stamps of the diagnostic build (make -C recboard_amd/csrc encprof).    python scripts/tail_phases.py"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from recboard_amd import lib  # noqa: E402
+lib.LIB_PATH = os.path.join(ROOT, "recboard_amd", "librecengine_encprof.so")
+L = lib.load()
+import bench  # noqa: E402
+from recboard_amd.sasrec import SASRecEngine  # noqa: E402
+cfg = bench.BEAUTY
+bs = [tuple(torch.from_numpy(x).cuda() for x in b) for b in bench.synth_batches(cfg, 8, 1)]
+m = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=1)
+for i in range(40):
+    m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8])
+torch.cuda.synchronize()
+NWG = 256
+buf = (ctypes.c_ulonglong * (16 * NWG))()
+L.re_dbg_tail_marks.argtypes, L.re_dbg_tail_marks.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
+assert L.re_dbg_tail_marks(buf, NWG) == 0
+t = np.array(list(buf), dtype=np.int64).reshape(NWG, 16)
+# (the shader clocks of different XCDs are not aligned: everything below is relative to the workgroup's own start)
+sc = (t[:, 1] - t[:, 0]) / 1e3
+tot = (t[:, 15] - t[:, 0]) / 1e3
+njobs = (t[:, 2:8:2] > 0).sum(1)
+print(f"kilo-cycles of the shader clock, per workgroup, relative to its own start ({NWG} workgroups)")
+print("scatter-add part   min/med/p90/max", sc.min(), np.median(sc), np.percentile(sc, 90), sc.max(), " (slowest: workgroup", int(sc.argmax()), ")")
+print("tickets taken per workgroup: histogram", np.bincount(njobs).tolist())
+durs, tk = [], []
+for w in range(NWG):
+    prev = t[w, 1]
+    for i in range(njobs[w]):
+        e = t[w, 3 + 2 * i]
+        if e > 0:
+            durs.append((e - prev) / 1e3); tk.append(int(t[w, 2 + 2 * i]) - 1)
+            prev = e
+d, tk = np.array(durs), np.array(tk)
+print("ticket duration    min/med/p90/max", d.min(), np.median(d), np.percentile(d, 90), d.max(), " tickets", len(d))
+for lo, hi, name in ((0, 144, "matrix tickets"), (144, 10 ** 9, "position tickets")):
+    sel = (tk >= lo) & (tk < hi)
+    if sel.any():
+        print(f"  {name}: n {int(sel.sum())} med {np.median(d[sel]):.1f} max {d[sel].max():.1f}")
+print("workgroup lifetime min/med/p90/max", tot.min(), np.median(tot), np.percentile(tot, 90), tot.max())
+pw = [w for w in range(NWG) if t[w, 9] > 0]
+for w in pw:
+    st = [int(x) for x in t[w, 8:14]]
+    base = t[w, 1]
+    print("plan job in workgroup", w, ": phase stamps relative to its scatter end (kcycles):", [round((x - base) / 1e3, 1) for x in st if x > 0])
+for w in np.argsort(tot)[-6:]:
+    print("  wg", int(w), "scatter", sc[w], "tickets", int(njobs[w]), [int(t[w, 2 + 2 * i]) - 1 for i in range(njobs[w])], "lifetime", tot[w])

@@ -319,3 +319,27 @@ def test_jgcf_oracle_reproduces_reference_fixture():
     u, p, n = (g["in/" + k].reshape(-1) for k in ("users", "pos", "neg"))
     rec = torch.nn.functional.softplus((ue[u] * ie[n]).sum(-1) - (ue[u] * ie[p]).sum(-1)).mean()
     assert abs(float(rec) - float(g["out/rec_loss"])) <= 1e-5 * abs(float(g["out/rec_loss"]))
+
+
+def test_c_oracle_is_clean_under_asan_ubsan():
+    """SURVEY.md section 5 (sanitizers, host only): the C restatement built with -fsanitize=address,undefined (make -C oracle asan) runs this
+    file's golden checks in a child process with libasan preloaded; any report aborts the child."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("RECORACLE_LIB"):
+        pytest.skip("already inside the sanitizer run")
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "asan"], stdout=subprocess.DEVNULL)
+    asan = subprocess.check_output([gcc, "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(asan):
+        pytest.skip("libasan is not installed")
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               RECORACLE_LIB=os.path.join(root, "oracle", "_build", "librecoracle_asan.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not asan", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
