@@ -97,11 +97,13 @@ def leg_config1():
         opt.zero_grad()
         omf.fit(Ut, It, u, p, n).backward()
         opt.step()
+    ms_graph, ms = ms, min(ms, ms_eager)        # (`value` is the faster form: whichever the Coach would run)
     return {"metric": "train triplets/sec (MF-BPR d=64, Beauty shapes, B=2048, 1 GPU)", "value": round(B / (ms * 1e-3), 1), "unit": "triplets/s",
-            "ms_per_step": round(ms, 4), "config": {"workload": f"MF-BPR d=64, {U} users x {N} items, B={B}, Adam(lr 1e-3, wd 1e-6); users uniform, positives Zipf(1.0)"},
+            "ms_per_step": round(ms, 4), "ms_per_step_graph": round(ms_graph, 4), "config": {"workload": f"MF-BPR d=64, {U} users x {N} items, B={B}, Adam(lr 1e-3, wd 1e-6); users uniform, positives Zipf(1.0)"},
             "ms_per_step_eager": round(ms_eager, 4),
-            "launch": "one hipGraph replay per step (three copies into the static batch + one launch for the step's scalars in front of it): fused "
-                      "triplet forward + backward, two scatter-adds, one Adam launch over the table arena",
+            "launch": "per step: the step's scalars (one tiny launch), the fused triplet forward + backward (gradient rows + their destination rows in the "
+                      "user | item arena), ONE owner-computes launch = scatter-add + dense Adam of all 34 464 rows; eager launches or one hipGraph replay, "
+                      "whichever is faster (`value`)",
             "cpu_baseline": cpu_steps(cpu_step, B, "triplets/s", f"B={B} (oracle/mf.py fit + backward + torch.optim.Adam)")}
 
 
@@ -155,8 +157,9 @@ def leg_config3():
         rec, emb = olg.fit(Ut, It, c_crow, c_col, c_val, torch.from_numpy(u).reshape(-1), torch.from_numpy(p).reshape(-1), torch.from_numpy(n).reshape(-1), Ly)
         (rec + 1e-3 * emb).backward()
         opt.step()
-    return {"metric": "train triplets/sec (LightGCN d=64 L=3, Yelp2018 shapes, B=2048, 1 GPU)", "value": round(B / (ms * 1e-3), 1), "unit": "triplets/s",
-            "ms_per_step": round(ms, 4), "ms_per_step_eager": round(ms_eager, 4), "launch": "one hipGraph replay per step",
+    return {"metric": "train triplets/sec (LightGCN d=64 L=3, Yelp2018 shapes, B=2048, 1 GPU)", "value": round(B / (min(ms, ms_eager) * 1e-3), 1), "unit": "triplets/s",
+            "ms_per_step": round(min(ms, ms_eager), 4), "ms_per_step_graph": round(ms, 4), "ms_per_step_eager": round(ms_eager, 4),
+            "launch": "one hipGraph replay per step, or its launches issued eagerly: `value` is the faster form",
             "config": {"workload": f"LightGCN d=64, 3 layers, {U} users x {N} items, {len(eu)} edges (adjacency nnz {nnz}), B={B}: 3 + 3 SpMMs per step, "
                                    "loss = rec + 1e-3 emb, Adam without weight decay (LightGCN/main.py:139-160)"},
             "roofline": {"kernel": "spmm_csr_rows / spmm_csr_long (re_spmm_csr): one propagation X <- A X", "bound": "hbm", "achieved": round(gbs, 1),
@@ -215,8 +218,9 @@ def leg_config4():
         odf.fit(tables, tables_lr, lr_bias, mlp, torch.from_numpy(x), torch.from_numpy(y).float()).backward()
         torch.nn.utils.clip_grad_norm_(emb + other, 10.0)
         opt.step()
-    return {"metric": "train rows/sec (DeepFM, synthetic Amazon2023Games context schema, B=4096, 1 GPU)", "value": round(B / (ms * 1e-3), 1), "unit": "rows/s",
-            "ms_per_step": round(ms, 4), "ms_per_step_eager": round(ms_eager, 4), "launch": "one hipGraph replay per step",
+    return {"metric": "train rows/sec (DeepFM, synthetic Amazon2023Games context schema, B=4096, 1 GPU)", "value": round(B / (min(ms, ms_eager) * 1e-3), 1), "unit": "rows/s",
+            "ms_per_step": round(min(ms, ms_eager), 4), "ms_per_step_graph": round(ms, 4), "ms_per_step_eager": round(ms_eager, 4),
+            "launch": "one hipGraph replay per step, or its launches issued eagerly: `value` is the faster form",
             "config": {"workload": f"DeepFM: {F} embedding fields (cardinalities {counts}), D={D}, MLP {dims}->1 with BatchNorm + dropout 0.1, B={B}, "
                                    "BCE, clip 10, Adam with the reference's two weight-decay groups (DeepFM/main.py:187-199,264-268)"},
             "roofline": {"kernel": "fm_bag_fwd_k (re_fm_bag_fwd): every field's row + FM second-order term + LR term per input row", "bound": "hbm",

@@ -232,6 +232,12 @@ int re_bpr_triplet_bwd(const float* Ut, int64_t RU, const float* It, int64_t RI,
 int re_bpr_triplet_fwd_bwd(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D, const int64_t* users,
                            const int64_t* pos, const int64_t* neg, int64_t n, float* loss, float* gu, float* gpos,
                            float* gneg, void* ws, size_t ws_bytes, re_stream_t stream);
+/* The same with its outputs laid out for ONE owner-computes update of the user | item arena (re_scatter_adam_rows_small): g [3][n][D] =
+ * the gradient rows of the user / positive / negative lookups, keys int32 [3][n] = their rows in a table of RU user rows followed by RI
+ * item rows (-1: no contribution).  Replaces the three `index` backward scatters + Adam of MF-BPR/main.py:116-123 by two launches. */
+int re_bpr_triplet_step_rows(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D, const int64_t* users,
+                             const int64_t* pos, const int64_t* neg, int64_t n, float* loss, float* g, int32_t* keys, void* ws,
+                             size_t ws_bytes, re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K4  full-catalog scoring.

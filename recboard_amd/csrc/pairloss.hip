@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256) void pair_loss_fused_k(const float* __restrict
                                                          const uint8_t* __restrict__ valid, int64_t n, int kind,
                                                          const int32_t* __restrict__ count, int64_t count_host,
                                                          float* __restrict__ dU, int64_t lddu, float* __restrict__ gpos,
-                                                         float* __restrict__ gneg, float* __restrict__ bsum, int32_t* __restrict__ bcnt) {
+                                                         float* __restrict__ gneg, float* __restrict__ bsum, int32_t* __restrict__ bcnt,
+                                                         int32_t* __restrict__ keys, int32_t key_off) {
+    // keys (optional, int32 [3][n]): the destination rows of the three gradient-row sets in ONE table that holds the user rows first and the
+    // item rows behind them (key_off = number of user rows); -1 for a row that contributes nothing -- what re_scatter_adam_rows_small takes
     __shared__ float s_sum[4];
     __shared__ int s_cnt[4];
     const int lir = threadIdx.x % LPR;
@@ -170,6 +173,11 @@ __global__ __launch_bounds__(256) void pair_loss_fused_k(const float* __restrict
         float4* du = reinterpret_cast<float4*>(dU + i * lddu);
         float4* gp = reinterpret_cast<float4*>(gpos + i * D);
         float4* gn = reinterpret_cast<float4*>(gneg + i * D);
+        if (keys && lir == 0) {
+            keys[i] = ok ? (int32_t)ur : -1;
+            keys[n + i] = ok ? key_off + (int32_t)pr : -1;
+            keys[2 * n + i] = ok ? key_off + (int32_t)nr : -1;
+        }
         if (!ok) {   // (uniform over the lane group)
             for (int64_t c = lir; c < D4; c += LPR) { du[c] = z; gp[c] = z; gn[c] = z; }
             continue;
@@ -313,7 +321,7 @@ extern "C" int re_bpr_triplet_bwd(const float* Ut, int64_t RU, const float* It, 
 static int pair_fused(const float* Ubase, int64_t ldu, int64_t RU, const int64_t* uidx, const float* E, int64_t R, int64_t D,
                       int64_t e_off, const int64_t* pos, const int64_t* neg, const uint8_t* valid, int64_t n, int kind,
                       const int32_t* count, int64_t count_host, float* loss, float* dU, int64_t lddu, float* gpos, float* gneg,
-                      void* ws, size_t ws_bytes, hipStream_t s) {
+                      void* ws, size_t ws_bytes, hipStream_t s, int32_t* keys = nullptr, int32_t key_off = 0) {
     if (!Ubase || !E || !pos || !neg || !loss || !dU || !gpos || !gneg || !ws || n < 0 || D <= 0 || R <= 0) return RE_EINVAL;
     if ((D & 3) || (ldu & 3) || (lddu & 3) || !ok16(Ubase) || !ok16(E) || !ok16(dU) || !ok16(gpos) || !ok16(gneg)) return RE_EUNSUPPORTED;
     if (kind != RE_LOSS_BCE && kind != RE_LOSS_BPR) return RE_EINVAL;
@@ -324,11 +332,11 @@ static int pair_fused(const float* Ubase, int64_t ldu, int64_t RU, const int64_t
     if ((D >> 2) >= 32) {
         grid = pl_grid(n, 32);
         hipLaunchKernelGGL(pair_loss_fused_k<32>, dim3(grid), dim3(256), 0, s, Ubase, ldu, RU, uidx, E, R, D, e_off, pos, neg, valid, n, kind,
-                           count, count_host, dU, lddu, gpos, gneg, bsum, bcnt);
+                           count, count_host, dU, lddu, gpos, gneg, bsum, bcnt, keys, key_off);
     } else {
         grid = pl_grid(n, 16);
         hipLaunchKernelGGL(pair_loss_fused_k<16>, dim3(grid), dim3(256), 0, s, Ubase, ldu, RU, uidx, E, R, D, e_off, pos, neg, valid, n, kind,
-                           count, count_host, dU, lddu, gpos, gneg, bsum, bcnt);
+                           count, count_host, dU, lddu, gpos, gneg, bsum, bcnt, keys, key_off);
     }
     hipLaunchKernelGGL(pair_loss_finalize, dim3(1), dim3(64), 0, s, bsum, bcnt, grid, loss, (int32_t*)nullptr);
     return re_launch_status();
@@ -342,6 +350,19 @@ extern "C" int re_pair_loss_fwd_bwd(const float* U, int64_t ldu, const float* E,
     if (!count) return RE_EINVAL;
     return pair_fused(U, ldu, n > 0 ? n : 1, nullptr, E, R, D, e_off, pos, neg, valid, n, kind, count, 0, loss, dU, lddu, gpos, gneg, ws,
                       ws_bytes, (hipStream_t)stream);
+}
+
+// The same with the gradient rows laid out for ONE owner-computes launch over the user | item arena: g [3][n][D] (user rows' / positives' /
+// negatives' gradients) and keys int32 [3][n] = rows of a table that holds the RU user rows first and the RI item rows behind them
+// (re_scatter_adam_rows_small: scatter-add + the dense Adam of every row in that one launch).  MF-BPR/main.py:81-93,116-123.
+extern "C" int re_bpr_triplet_step_rows(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D, const int64_t* users,
+                                        const int64_t* pos, const int64_t* neg, int64_t n, float* loss, float* g, int32_t* keys, void* ws,
+                                        size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!users || !g || !keys) return RE_EINVAL;
+    if (RU + RI >= 0x7FFFFFFFll) return RE_EUNSUPPORTED;
+    return pair_fused(Ut, D, RU, users, It, RI, D, 0, pos, neg, nullptr, n, RE_LOSS_BPR, nullptr, n, loss, g, D, g + n * D, g + 2 * n * D, ws, ws_bytes,
+                      (hipStream_t)stream, keys, (int32_t)RU);
 }
 
 extern "C" int re_bpr_triplet_fwd_bwd(const float* Ut, int64_t RU, const float* It, int64_t RI, int64_t D, const int64_t* users,

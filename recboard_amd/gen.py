@@ -68,11 +68,37 @@ class MFEngine:
             A.step += 1
             ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, wd)
 
+    def _rows_step_ok(self, grad_hook):
+        """The two-launch step: the user | item arena as ONE table of U + N rows under one owner-computes launch (csrc/scatter_owner.h)."""
+        return grad_hook is None and type(self) is MFEngine and self.D in (64, 128) and (self.U + self.N) * 2 <= 4096 * 96
+
     def train_step(self, users, pos, neg, grad_hook=None, _state=None):
-        """forward + backward + Adam (MF-BPR/main.py:116-123)."""
+        """forward + backward + Adam (MF-BPR/main.py:116-123).  Two launches + the step's scalars: the fused triplet kernel leaves the three
+        gradient-row sets and their destination rows in the user | item arena; ONE owner-computes launch sums them per row and applies the
+        dense Adam update (coupled L2: every row) -- no dense gradient table, no sort."""
         A = self.arena
         Ut, It = self.encode()
         u, p, n = users.reshape(-1), pos.reshape(-1), neg.reshape(-1)
+        if self._rows_step_ok(grad_hook):
+            B = u.numel()
+            W = self.__dict__.setdefault("_rows_bufs", {})
+            if B not in W:
+                W[B] = (torch.empty((3, B, self.D), dtype=torch.float32, device=self.device), torch.empty((3, B), dtype=torch.int32, device=self.device))
+            if not hasattr(self, "_hyper"):
+                self._hyper = torch.zeros(4, dtype=torch.int32, device=self.device)
+            if _state is None:                       # eager: this step's Adam scalars as device words (one tiny launch)
+                A.step += 1
+                ops.step_state(self._hyper, 0, A.step, self.lr, self.betas[0], self.betas[1])
+                hyper = self._hyper.view(torch.float32)[2:4]
+            else:
+                hyper = _state.view(torch.float32)[2:4]
+            loss, g, keys = ops.bpr_triplet_step_rows(Ut, It, u, p, n, *W[B])
+            fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
+            self._adam_keep = fz
+            R = self.U + self.N
+            ops.scatter_add_rows_small(g, keys, R, A.grad[: R * self.D].view(R, self.D) if getattr(self, "keep_table_grad", True) else None,
+                                       n_regions=3, padding_idx=-1, adam=fz)
+            return loss.squeeze(0)
         loss, gu, gp, gn = ops.bpr_triplet_fwd_bwd(Ut, It, u, p, n)
         G = A.views(A.grad)
         ops.scatter_add_rows(gu, u, self.U, out=G["User.embeddings.weight"])

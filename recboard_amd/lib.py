@@ -33,6 +33,7 @@ SIGNATURES = {
     "re_pair_loss_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "re_pair_loss_fwd_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "re_bpr_triplet_fwd_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "re_bpr_triplet_step_rows": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_bpr_triplet_fwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "re_bpr_triplet_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "re_score_dense": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

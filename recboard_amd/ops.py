@@ -252,6 +252,33 @@ def bpr_triplet_fwd_bwd(Ut, It, users, pos, neg):
     return loss, gu, gp, gn
 
 
+def bpr_triplet_step_rows(Ut, It, users, pos, neg, g=None, keys=None):
+    """bpr_triplet_fwd_bwd with the gradient rows as ONE [3, n, D] block and their int32 destination rows in the user | item arena
+    ([3, n]; item rows offset by the number of users; -1 = none): the inputs of scatter_add_rows_small(..., n_regions=3, adam=...).
+    -> (loss[1], g, keys)."""
+    _req(Ut, torch.float32, "Ut"); _req(It, torch.float32, "It")
+    for t, nme in ((users, "users"), (pos, "pos"), (neg, "neg")):
+        _req(t, torch.int64, nme)
+    n = users.numel()
+    if pos.numel() != n or neg.numel() != n:
+        raise ValueError("recengine: one positive and one negative per user row (K = 1)")
+    D = Ut.shape[1]
+    L = lib.load()
+    dev = Ut.device
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    if g is None:
+        g = torch.empty((3, n, D), dtype=torch.float32, device=dev)
+    if keys is None:
+        keys = torch.empty((3, n), dtype=torch.int32, device=dev)
+    _req(g, torch.float32, "g"); _req(keys, torch.int32, "keys")
+    if g.numel() != 3 * n * D or keys.numel() != 3 * n:
+        raise ValueError("recengine: bpr_triplet_step_rows buffer shapes")
+    ws = _ws(L.re_pair_loss_workspace_bytes(n), dev)
+    lib.check(L.re_bpr_triplet_step_rows(_p(Ut), Ut.shape[0], _p(It), It.shape[0], D, _p(users), _p(pos), _p(neg), n, _p(loss), _p(g), _p(keys),
+                                         _p(ws), ws.numel(), _stream()), "re_bpr_triplet_step_rows")
+    return loss, g, keys
+
+
 def bpr_triplet_fwd(Ut, It, users, pos, neg):
     _req(Ut, torch.float32, "Ut"); _req(It, torch.float32, "It")
     for t, nme in ((users, "users"), (pos, "pos"), (neg, "neg")):
