@@ -182,8 +182,15 @@ __device__ __forceinline__ void pl_elementwise(int job, int njobs, const int64_t
 #define PL_OFF_SPAN ((PL_OFF_SHORT + (int)sizeof(PlShort) + 15) & ~15)
 #define PL_OFF_PLACE (PL_OFF_SPAN + PL_LDS_B)
 #define PL_LDS_BYTES (PL_OFF_PLACE + PL_LDS_B * 4)
+// mode 0: the whole plan.  Modes 1 and 2 cut it in two for the step's tail launch (enc_tail.hip), where the plan is the longest job of the
+// queue: 1 = the spans alone (phase 1: the only part that reads the batch -- two memory round trips for 512 sequences), left in the plan
+// buffer's scratch words with a flag behind an agent-scope release; 2 = the rest, by ANOTHER workgroup that waits for that flag (bounded:
+// when it does not come it computes the spans itself) and clears it again.
+#define PL_MODE_ALL 0
+#define PL_MODE_SPANS 1
+#define PL_MODE_REST 2
 __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, int S, int ncu, int max_tiles, int split_long,
-                                        int* __restrict__ count, int* __restrict__ plan, const PlSample& SP, unsigned char* L) {
+                                        int* __restrict__ count, int* __restrict__ plan, const PlSample& SP, unsigned char* L, int mode = PL_MODE_ALL) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if defined(ENC_PROFILE) && defined(PL_PLAN_KERNEL)
     unsigned long long pl_t[6];
@@ -213,18 +220,39 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
     const bool in_lds = B <= PL_LDS_B;
     int* g_span = plan + enc_plan_rowmap_word(B, S) + 2 * 16 * mt;
     int* g_place = g_span + B;
+    unsigned* g_flag = reinterpret_cast<unsigned*>(g_place + B);      // (first of the buffer's 64 spare words; zero in a fresh buffer)
+    const bool to_global = !in_lds || mode == PL_MODE_SPANS;          // where phase 1 leaves the spans
+    bool have_spans = false;
+    if (mode == PL_MODE_REST) {
+        int* const s_got = reinterpret_cast<int*>(L + PL_NCLS * PL_NW * 4) + 2 * PL_NCLS + 16 + PL_NW + 4;     // (= &s_nsplit: written again in phase 2)
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(g_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(4);
+            *s_got = spins < (1 << 16) ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        have_spans = *s_got != 0;
+        __syncthreads();
+        if (have_spans && in_lds)
+            for (int b = tid; b < B; b += PL_NT) s_span[b] = (unsigned char)g_span[b];
+    }
     if (tid < PL_NCLS) s_tot[tid] = 0;
     // 1. span of every sequence: a wave per sequence, lane = position (one coalesced load, a ballot, two scalar bit counts: ~10
     //    instructions per sequence -- an element-wise formulation is VALU-bound on this one CU), 16 sequences in flight per wave;
     //    a sequence without any item is given one explicit pad row
     int nnz = 0;
+    if (have_spans) {
+        // (phase 1 was another workgroup's: spans in place, hdr[4] and count written)
+    } else
     if (SP.ptr) {   // sampled batch: a row's span is its window length (every position of the window is a real item) -- no (seq) to read
         for (int b = tid; b < B; b += PL_NT) {
             int64_t base, p0, nn, u;
             int len;
             pl_sample_row(SP, b, S, base, len, p0, nn, u);
             const int span = len > 0 ? len : 1;                       // (a row without items: one explicit pad row, as below)
-            if (in_lds) s_span[b] = (unsigned char)span; else g_span[b] = span;
+            if (!to_global) s_span[b] = (unsigned char)span; else g_span[b] = span;
             nnz += len;
         }
 #pragma unroll
@@ -242,7 +270,7 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
             const unsigned long long m = __ballot(lane < S && v[q] != 0);
             const int first = m ? __builtin_ctzll(m) : S - 1;
             if (lane == 0 && b0 + q < B) {
-                if (in_lds) s_span[b0 + q] = (unsigned char)(S - first); else g_span[b0 + q] = S - first;
+                if (!to_global) s_span[b0 + q] = (unsigned char)(S - first); else g_span[b0 + q] = S - first;
                 nnz += __builtin_popcountll(m);
             }
         }
@@ -250,11 +278,22 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
     PL_STAMP(1);
     if (lane == 0) s_red[wave] = nnz;
     pl_sync(in_lds);
-    if (tid == 0) {
+    if (tid == 0 && !have_spans) {
         int c = 0;
         for (int w = 0; w < PL_NW; ++w) c += s_red[w];
         hdr[4] = c;
         if (count) count[0] = c;
+    }
+    if (mode == PL_MODE_SPANS) {      // publish: every wave's stores drained, then one release and the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(g_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        return;
     }
     // 2. class totals, then ranks (ballot prefix counts: deterministic), in chunks of PL_NT sequences
     for (int pass = 0; pass < 2; ++pass) {
@@ -355,6 +394,7 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
         const int row = in_lds ? s_place[b0] : g_place[b0];
         for (int off = tid & 7; off < span; off += 8) rowmap[row + off] = make_int2(b0 * S + (S - span) + off, S - span);
     }
+    if (mode == PL_MODE_REST && tid == 0) __hip_atomic_store(g_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the buffer's next use starts from zero)
 #ifdef TAIL_PROFILE
     __syncthreads();
     PL_STAMP(3);

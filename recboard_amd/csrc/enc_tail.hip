@@ -80,7 +80,7 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
         if (t < n_prep) {
             const PlMail M = *TP.mail;
             if (M.seq || M.SP.ptr) {                           // (uniform)
-                if (t == 0) pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds));
+                if (t == 0) pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_REST);
                 else pl_elementwise(t - 1, TP.n_ew, M.seq, M.pos, M.neg, TP.B, TP.S, TP.seq_out, TP.pos_out, TP.neg_out, TP.valid, TP.rows_all, M.SP);
             }
             continue;
@@ -95,6 +95,18 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
     }
 }
 
+// The next batch's spans (the plan's phase 1: the only part that reads the batch) by the launch's LAST workgroup, from the launch's start:
+// the plan job of the queue (PL_MODE_REST) then starts ~23 k cycles in with the spans already there, and ends with the weight-gradient tickets
+// instead of ~17 k cycles behind them (scripts/tail_phases.py).  The last workgroup owns cold rows (popular items have small ids) and, coming
+// late to the queue, takes no ticket: its extra work is hidden.
+__device__ __forceinline__ void tail_spans(const TailPrep& TP, float* lds) {
+    if (!TP.mail || blockIdx.x != gridDim.x - 1) return;
+    const PlMail M = *TP.mail;
+    if (M.seq || M.SP.ptr)
+        pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_SPANS);
+    __syncthreads();
+}
+
 template <int D, int HS>
 __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                                     const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
@@ -105,6 +117,7 @@ __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g,
     __syncthreads();
 #endif
     TAIL_MARK(0, TAIL_NOW());
+    tail_spans(TP, lds);
     so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds);
     TAIL_MARK(1, TAIL_NOW());
     tail_jobs<D>(J, TP, lds);
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g,
 template <int D, int HS>
 __global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
+    tail_spans(TP, lds);
     sa_body<1, HS, int32_t>(P, reinterpret_cast<unsigned char*>(lds));
     tail_jobs<D>(J, TP, lds);
 }
