@@ -62,6 +62,36 @@ def synth_batches(cfg, nbatch, seed):
     return out
 
 
+def large_batch_roofline(cfg, B=8192, steps=40):
+    """The D = 64 step in its THROUGHPUT regime: the same model at B = 8 192 Beauty-shaped sequences per step (~16 tiles of real tokens per
+    CU instead of ~1; what a rank sees when a job scales its batch): samples/s and the executed-FLOP fraction of the fp32 matrix peak.
+    At this size the plan hands the step to the fp32 workgroup-per-item kernels (enc_step_k): the one-tile-per-workgroup kernel needs every
+    tile of the long sequences resident at once (<= 192 of them), a batch of 8 192 has ~1 500."""
+    from recboard_amd.sasrec import SASRecEngine
+    big = dict(cfg, B=B)
+    m = SASRecEngine(cfg["items"], cfg["S"], cfg["D"], cfg["L"], dropout_rate=cfg["p_drop"], loss="BCE", lr=cfg["lr"], weight_decay=cfg["wd"], seed=1)
+    bs = [tuple(torch.from_numpy(a).cuda() for a in b) for b in synth_batches(big, 4, seed=11)]
+    for i in range(6):
+        m.train_step_graph(*bs[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        m.train_step_graph(*bs[i % 4])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    m.check_handover()
+    hdr = m.prepare_batch(*bs[0]).plan.view(torch.int32)[:8].cpu().numpy()
+    n_items, n_tiles, D, L = int(hdr[0]), int(hdr[1]), cfg["D"], cfg["L"]
+    fl_exec = L * n_tiles * (24 * 2 * 16 * D * D + 6 * 2 * 16 * 16 * D)           # (the same count as `roofline.work`: per tile and block)
+    tf = fl_exec / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+            "samples_per_sec": round(B / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "B": B, "tiles": n_tiles, "work_items": n_items,
+            "tiles_per_cu": round(n_tiles / 256.0, 1),
+            "kernel": "the one-tile-per-workgroup step (enc_tile_step_k)" if int(hdr[7]) == 1 else "the fp32 workgroup-per-item step (enc_step_k<64>: the plan's "
+                      "choice whenever the long sequences' tiles cannot all be resident)",
+            "work": f"executed FLOP as in `roofline.work`: {fl_exec:.3e} per step on {n_tiles} tiles; whole step (preparation, encoder, tail, Adam) per replay"}
+
+
 def event_time_ms(fn, iters, warmup=3):
     for _ in range(warmup):
         fn()
@@ -136,7 +166,7 @@ def pmc_traffic(*kernels):
         # a name is matched exactly, or as the prefix of an instantiation ("gather_rows_vec4<16" -> "gather_rows_vec4<16, 4, true, true>")
         hit = []
         for n in kernels:
-            hit += [n] if n in k else [m for m in k if m.startswith(n)]
+            hit += [n] if n in k else [m for m in k if m.startswith(n) or ("::" + n) in m]      # (namespaced: "tl4::enc_tile_step_k")
         if not hit:
             return None
         return {"hbm_bytes_per_launch": int(sum(k[n]["hbm_bytes_per_launch"] for n in hit)),
@@ -676,6 +706,10 @@ def main():
                                           "launch); the epoch's mean loss read once at the end"}
         if world == 1 and args.encoder == "fused" and not args.no_legs:
             line["sampler"] = sampler_rates(cfg, model)
+            try:
+                line["roofline_large_batch"] = large_batch_roofline(cfg)
+            except Exception as e:  # noqa: BLE001  (a leg of its own: the headline stands without it)
+                line["roofline_large_batch"] = {"skipped": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_c5:
             line["config5"] = bench_legs.run_child("config5")
         if world == 1 and not args.no_legs:
