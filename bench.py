@@ -331,7 +331,7 @@ def launch_ranks(n, argv):
     before this process has touched the GPU, and leave with their exit code -- a failed rank is a failed run, not a silent N = 1 line."""
     import socket
     import subprocess
-    if torch.cuda.device_count() < n:
+    if torch.cuda.device_count() < n and "--rendezvous-only" not in argv:
         print(f"[bench] --gpus {n} asked for, {torch.cuda.device_count()} visible", file=sys.stderr)
         return 2
     s = socket.socket()
@@ -359,6 +359,9 @@ def main():
     ap.add_argument("--prefetch", dest="prefetch", action="store_true", help=argparse.SUPPRESS)
     ap.set_defaults(prefetch=True)
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="every rank joins the process group (RCCL; gloo where there is no GPU), all-gathers (rank, world) and prints its own JSON line; "
+                         "no engine work -- the launcher / rendezvous path alone (tests/test_bench_launcher.py runs it with four ranks on the CPU)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # (no GPU call has been made in this process)
@@ -367,6 +370,21 @@ def main():
     if world != args.gpus:
         print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks", file=sys.stderr)
         sys.exit(2)
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        rank = int(os.environ.get("RANK", "0"))
+        gpu = torch.cuda.is_available()
+        if gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl" if gpu else "gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank, dist.get_world_size()], device="cuda" if gpu else "cpu")
+        seen = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(seen, t)
+        print(json.dumps({"rendezvous": "ok", "rank": rank, "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                          "ranks_seen": sorted(int(x[0]) for x in seen), "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(args, env=None):
-    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     e.update(env or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
 
@@ -46,3 +46,16 @@ def test_launch_ranks_builds_a_torchrun_command_on_localhost(monkeypatch):
     c = seen["cmd"]
     assert c[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in c and c[c.index("--master-addr") + 1] == "127.0.0.1"
     assert c[-5] == os.path.join(ROOT, "bench.py") and c[-4:] == ["--gpus", "4", "--steps", "3"]
+
+
+def test_self_launch_starts_four_ranks_that_meet_on_localhost():
+    """`python bench.py --gpus 4 --rendezvous-only` with no launcher around it: bench.py starts the four ranks itself (torch.distributed.run,
+    127.0.0.1), every rank joins the group (gloo here: no GPU), sees all four and prints its OWN line with world_size == 4; exit code 0."""
+    import json
+    r = run(["--gpus", "4", "--rendezvous-only"])
+    import re
+    lines = [json.loads(m) for m in re.findall(r'\{"rendezvous".*?\}', r.stdout)]      # (four processes write to one pipe: lines may share a row)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert sorted(d["rank"] for d in lines) == [0, 1, 2, 3]
+    for d in lines:
+        assert d["world_size"] == 4 and d["ranks_seen"] == [0, 1, 2, 3] and d["master"] == "127.0.0.1"

@@ -284,17 +284,18 @@ def _engine_worker(rank, world, port, q):
                 ref = P[k].detach().numpy().copy()
                 g = P[k].grad.numpy() if P[k].grad is not None else np.zeros_like(ref)
                 oadam.adam_step(ref, g, np.zeros_like(ref), np.zeros_like(ref), 1, lr, 0.9, 0.999, 1e-8, wd)
-                np.testing.assert_allclose(eng.params[k].detach().numpy(), ref, rtol=1e-5, atol=1e-7, err_msg=k)
+                # (Adam's first step is lr g / (|g| + eps): an entry whose gradient is rounding noise of the 4-rank all-reduce moves by a fraction of lr)
+                np.testing.assert_allclose(eng.params[k].detach().numpy(), ref, rtol=1e-5, atol=1e-7 if world == 2 else 2e-4 * lr, err_msg=k)
             rows = torch.nonzero(Eref.grad.abs().sum(1)).reshape(-1).numpy()
             rows = rows[rows != 0]
             Wref, m, v = full.numpy().copy(), np.zeros((N + 1, D), np.float32), np.zeros((N + 1, D), np.float32)
             oadam.sparse_adam_rows(Wref, m, v, rows, Eref.grad.numpy()[rows], 1, lr, wd=wd)
-            np.testing.assert_allclose(eng.table.weight.numpy(), Wref[rank::world], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(eng.table.weight.numpy(), Wref[rank::world], rtol=1e-5, atol=1e-7 if world == 2 else 2e-4 * lr)
             # gather-on-save through the engine: the reference's state-dict keys incl. the whole item table, on rank 0
             sd = eng.state_dict(0)
             if rank == 0:
                 assert set(sd) == set(eng.params) | {"Item.embeddings.weight"}
-                np.testing.assert_allclose(sd["Item.embeddings.weight"].numpy(), Wref, rtol=1e-5, atol=1e-7)
+                np.testing.assert_allclose(sd["Item.embeddings.weight"].numpy(), Wref, rtol=1e-5, atol=1e-7 if world == 2 else 2e-4 * lr)
             else:
                 assert "Item.embeddings.weight" not in sd
         dist.barrier()
@@ -305,8 +306,14 @@ def _engine_worker(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
-def test_sharded_engine_step_world2_gloo_matches_unsharded_oracle():
-    world, port = 2, _free_port()
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_engine_step_gloo_matches_unsharded_oracle(world):
+    """world 2 and 4 (the ranks of `bench.py --gpus 4`'s config5_sharded leg, on a toy table): every exchange form, the overflowing one included
+    -- there EVERY rank asserts that its step was a no-op until the count was read and was then re-run exactly once (settle_overflow() == 1)."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q)) for r in range(world)]
