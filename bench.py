@@ -507,7 +507,7 @@ def main():
                 if rank == 0:
                     line["config5_sharded"] = {"skipped": "no result after 300 s: abandoned (the headline above was measured before this leg)"}
                     print(json.dumps(line), flush=True)
-                os._exit(0)
+                os._exit(3)
         threading.Thread(target=give_up, daemon=True).start()
         c5s = bench_legs.config5_sharded(dist, rank, world, local)
         leg_done.set()

@@ -179,6 +179,17 @@ class Pipe:
                 row[R["ISeq"]] = hist
                 row[R["IUnseen"]] = [ds.seq(kw["mode"], x) for x in u]
                 row[R["ISeen"]] = [np.unique(h) for h in hist]
+                # A NEXT-ITEM pipe (the chain goes on to prune / pad ISeq: SeqRecArch.sure_validpipe) emits one row per HELD-OUT ITEM with a growing
+                # history -- seq = seen + unseen[:k], unseen = (positive,), seen unchanged (HSTU/sampler.py:101-122); a leave-one-out split has
+                # one held-out item per user and nothing changes, a ratio split (*_ROU) gets len(unseen) rows per user
+                seq_pipe = any(n in ("lprune", "lpad", "add") and R["ISeq"] in tuple(k.get("fields", ())) for n, k in self.ops)
+                if seq_pipe and any(len(t) > 1 for t in row[R["IUnseen"]]):
+                    us, hs, ts, ss = [], [], [], []
+                    for x, h, t, s in zip(u.tolist(), hist, row[R["IUnseen"]], row[R["ISeen"]]):
+                        for k in range(len(t)):
+                            us.append(x); hs.append(np.concatenate([h, t[:k]])); ts.append(t[k:k + 1]); ss.append(s)
+                    u = np.asarray(us, np.int64)
+                    row[R["User"]], row[R["ISeq"]], row[R["IUnseen"]], row[R["ISeen"]] = u, hs, ts, ss
                 if kw["ranking"] == "pool":                              # the targets first, then K sampled unseen items
                     neg = self._unseen(u, (len(u), kw["k"]))
                     row[R["IUnseen"]] = [np.concatenate([t, n]) for t, n in zip(row[R["IUnseen"]], neg)]

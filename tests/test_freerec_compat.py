@@ -178,3 +178,24 @@ def test_pipes_follow_the_row_contract():
             got[u] = (b[model.ISeq][i].tolist(), list(b[model.IUnseen][i]), list(b[model.ISeen][i]))
     for u, want in fx["test"].items():
         assert got[int(u)][0] == want["ISeq"] and got[int(u)][1] == want["IUnseen"] and got[int(u)][2] == want["ISeen"]
+
+
+def test_next_item_eval_pipe_emits_one_row_per_held_out_item_on_ratio_splits():
+    """A ratio split (several held-out items per user): the sequence evaluation pipe emits one row per held-out item with a growing history
+    (seq = seen + unseen[:k], one target, `seen` unchanged: HSTU/sampler.py:101-122); the general (user-id) pipe keeps one row per user."""
+    import freerec
+    tr = (np.array([0, 0, 0, 1, 1]), np.array([5, 6, 7, 1, 2]))
+    va = (np.array([0, 0, 1]), np.array([8, 9, 3]))
+    e = np.zeros(0, np.int64)
+    ds = freerec.data.datasets.RecDataSet.from_splits(tr, va, (e, e), 2, 12)
+    own = import_script(os.path.join(ROOT, "examples", "SASRec", "main.py"), "_own_sasrec_rou", ["--maxlen", "6"])
+    model = own.SASRec(ds)
+    rows = []
+    for b in model.sure_validpipe(6, ranking="full", batch_size=8):
+        for i in range(len(b[model.User])):
+            rows.append((int(b[model.User][i]), b[model.ISeq][i].tolist(), list(b[model.IUnseen][i]), sorted(b[model.ISeen][i])))
+    assert rows == [(0, [0, 0, 0, 6, 7, 8], [8], [5, 6, 7]), (0, [0, 0, 6, 7, 8, 9], [9], [5, 6, 7]), (1, [0, 0, 0, 0, 2, 3], [3], [1, 2])]
+    mf = import_script(os.path.join(ROOT, "examples", "MF-BPR", "main.py"), "_own_mf_rou", [])
+    gen = mf.MF(ds)
+    got = [(int(b[gen.User][i]), list(b[gen.IUnseen][i])) for b in gen.sure_validpipe("full") for i in range(len(b[gen.User]))]
+    assert got == [(0, [8, 9]), (1, [3])]
