@@ -129,7 +129,10 @@ template <int D, int HS>
 __global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
     tail_spans(TP, lds);
-    sa_body<1, HS, int32_t>(P, reinterpret_cast<unsigned char*>(lds));
+    // the tape's hand-over error word (a tile waited for a partner's rows in vain: this step's gradients are wrong): the table's rows stay as
+    // they are -- read here, on the device, every step; the epoch's check_handover() reports it
+    const unsigned gated = reinterpret_cast<const unsigned*>(J.tape + J.T.off_FLAGS)[(J.NR / 16) * EP_FLAG_WORDS];
+    if (!gated) sa_body<1, HS, int32_t>(P, reinterpret_cast<unsigned char*>(lds));
     tail_jobs<D>(J, TP, lds);
 }
 
@@ -138,7 +141,7 @@ size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
                            const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
-                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket);
+                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket, const unsigned* gate);
 
 static int tail_prep(TailPrep& TP, const re_next_prep* next) {
     TP = TailPrep{};
@@ -160,6 +163,7 @@ struct TailSide {
     TailJobs J;
     float *slab, *wpart, *ppart;
     int wgrid;
+    const unsigned* gate;   // the tape's hand-over error word (csrc/enc_tile_body.inc: tl_flag_wait): set = this step's gradients are not to be applied
 };
 static int tail_side(TailSide& T, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, int32_t ncu, const void* tape,
                      size_t tape_bytes, const float* dx0, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, void* ws,
@@ -179,6 +183,7 @@ static int tail_side(TailSide& T, const int64_t* seq, int64_t B, int64_t S, int6
     float* gtape = T.ppart + enc_wgrad_ppart_floats(B, D);
     T.J = TailJobs{(const float*)tape, enc_tape_layout(B, S, D, L), gtape, 16 * mt, plan, (int)B, (int)S, (int)L, T.wpart, seq, dx0,
                    dPtab ? T.ppart : nullptr, ticket};
+    T.gate = reinterpret_cast<const unsigned*>((const float*)tape + T.J.T.off_FLAGS) + mt * EP_FLAG_WORDS;
     return RE_OK;
 }
 
@@ -207,6 +212,7 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
     TailSide T;
     const int rc = tail_side(T, seq, B, S, D, L, plan, ncu, tape, tape_bytes, dx0, dPtab, block_grads, g_last_w, g_last_b, ws, ws_bytes, ticket);
     if (rc != RE_OK) return rc;
+    AD.gate = T.gate;      // a hand-over that timed out in this step's tile kernel: gradients are written, neither optimizer moves (read ON THE DEVICE, every step)
     constexpr int HS = 2;
     const int rpw = 96;                            // (scatter.hip: scatter_small_launch)
     int64_t nwg = HS;
@@ -222,7 +228,7 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
                        padding_idx, 1.0f, dW, AD, T.J, TP);
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
-                                  ticket);
+                                  ticket, T.gate);
 }
 
 // The same behind re_sparse_adam_rows_small (int32 keys, hyper from device memory): the tail of a LARGE-table step (config 5), D = 64 or 128.
@@ -266,5 +272,5 @@ extern "C" int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, i
     }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
-                                  ticket);
+                                  ticket, T.gate);
 }

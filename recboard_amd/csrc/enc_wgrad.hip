@@ -31,12 +31,13 @@ struct EncAdam {
     float *p, *m, *v;
     const float* hyper;
     float b1, b2, omb1, omb2, eps, wd;
+    const unsigned* gate;   // optional device word: non-zero = gradients are written, parameters and moments stay (a hand-over of this step timed out)
 };
 __device__ __forceinline__ void eg_put(const EncAdam& A, float* d, float g) {
     *d = g;
     if (A.p) {
         const float ss = A.hyper[0], ib = A.hyper[1];
-        if (ib != 0.f) {   // ({0, 0}: the caller gated this step off)
+        if (ib != 0.f && !(A.gate && A.gate[0] != 0u)) {   // ({0, 0}: the caller gated this step off)
             const int64_t i = d - A.gbase;
             float pp = A.p[i], mm = A.m[i], vv = A.v[i];
             re_adam1(pp, mm, vv, g, A.b1, A.b2, A.omb1, A.omb2, ss, ib, A.eps, A.wd);     // (adam_vec4_dev's arithmetic)
@@ -133,7 +134,7 @@ size_t enc_wgrad_ppart_floats(int64_t B, int64_t D) { return (size_t)64 * ((B + 
 // The reduction launch behind the weight-gradient jobs (enc_wgrad_k here, or enc_tail_k's: enc_tail.hip -- `ticket` is its job counter).
 int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
                            const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
-                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket) {
+                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket, const unsigned* gate) {
     EncGradDst dst;
     for (int64_t l = 0; l < SE_MAX_BLOCKS; ++l)
         for (int i = 0; i < 14; ++i) dst.p[l][i] = (l < L && i < 12) ? block_grads[12 * l + i] : (i == 12 ? g_last_w : g_last_b);
@@ -144,7 +145,7 @@ int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const voi
     if (adam) {
         if (!adam->grad_base || !adam->param || !adam->m || !adam->v || !adam->hyper) return RE_EINVAL;
         AD = EncAdam{adam->grad_base, adam->param, adam->m, adam->v, adam->hyper, (float)adam->beta1, (float)adam->beta2, (float)(1.0 - adam->beta1),
-                     (float)(1.0 - adam->beta2), (float)adam->eps, (float)adam->weight_decay};
+                     (float)(1.0 - adam->beta2), (float)adam->eps, (float)adam->weight_decay, gate};
     }
     hipLaunchKernelGGL(enc_grad_reduce_k, dim3(nmat_blocks + nvec_blocks + npos_blocks), dim3(256), 0, s, part, slab, nwg, plan,
                        (int)B, (int)S, (int)D, (int)L, dst, nmat_blocks, nvec_blocks, ppart, emb_scale != 0.f ? 1.0f / emb_scale : 0.f,
@@ -172,5 +173,5 @@ int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tap
                            ppart, (const float*)dPtab);
     }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
-    return enc_grad_reduce_launch(B, S, D, L, plan, slab, nwg, part, ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, by_tile, adam, nullptr);
+    return enc_grad_reduce_launch(B, S, D, L, plan, slab, nwg, part, ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, by_tile, adam, nullptr, nullptr);
 }

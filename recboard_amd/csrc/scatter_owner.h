@@ -39,6 +39,7 @@ struct SoAdam {   // W != nullptr: the owner applies the dense Adam update of it
     float *W, *m, *v;
     const float* hyper;
     float b1, b2, omb1, omb2, eps, wd;
+    const unsigned* gate;   // optional device word: non-zero = leave the parameters and moments alone (enc_tail_k: the step's hand-over error word)
 };
 __device__ __forceinline__ void so_adam1(const SoAdam& A, float ss, float ib, float g, float& p, float& m, float& v) {   // (adam_vec4_dev's arithmetic)
     re_adam1(p, m, v, g, A.b1, A.b2, A.omb1, A.omb2, ss, ib, A.eps, A.wd);
@@ -219,7 +220,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         if (dW) reinterpret_cast<float4*>(dW + o)[c4] = gr;
         if (AD.W) {
             const float ss = AD.hyper[0], ib = AD.hyper[1];
-            if (ib != 0.f) {   // ({0, 0}: the caller gated this step off)
+            if (ib != 0.f && !(AD.gate && AD.gate[0] != 0u)) {   // ({0, 0}: the caller gated this step off; gate: a hand-over of this step timed out)
                 float4 P = reinterpret_cast<float4*>(AD.W + o)[c4], M = reinterpret_cast<float4*>(AD.m + o)[c4], V = reinterpret_cast<float4*>(AD.v + o)[c4];
                 so_adam1(AD, ss, ib, gr.x, P.x, M.x, V.x); so_adam1(AD, ss, ib, gr.y, P.y, M.y, V.y);
                 so_adam1(AD, ss, ib, gr.z, P.z, M.z, V.z); so_adam1(AD, ss, ib, gr.w, P.w, M.w, V.w);

@@ -36,3 +36,48 @@ def test_every_handed_over_block_arrives_as_it_was_published(fenced):
     assert mism == [0, 0, 0] and canary == 0 and par == 0, (mism, canary, par)
     d = re.search(r": (\d+) of (\d+) repetitions differ from the first", r.stdout)
     assert d and int(d.group(1)) == 0 and int(d.group(2)) == 799, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("engine", ["dense", "large"])
+def test_a_recorded_handover_timeout_gates_both_optimizers_on_the_device(engine):
+    """The tape's error word (a tile waited for its partner's rows in vain: csrc/enc_tile_body.inc tl_flag_wait) is read ON THE DEVICE by the
+    step's tail launches, every step: with it set, the gradients are still written but neither the table's nor the encoder's Adam moves a
+    parameter or a moment -- the damage stops at the step it happened in; the epoch's check_handover() then raises and clears it."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import numpy as np
+    rng = np.random.default_rng(3)
+    N, B, S, D = 900, 64, 50, 64 if engine == "dense" else 128
+    lens = np.clip(rng.geometric(1 / 5.9, B) + 1, 1, S - 1)
+    lens[:4] = (49, 40, 33, 20)
+    seq = np.zeros((B, S), np.int64)
+    for b in range(B):
+        seq[b, S - lens[b]:] = rng.integers(1, N + 1, lens[b])
+    pos = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    neg = np.where(seq > 0, rng.integers(0, N, (B, S)), 0)
+    batch = tuple(torch.from_numpy(a).cuda() for a in (seq, pos, neg))
+    if engine == "dense":
+        from recboard_amd.sasrec import SASRecEngine
+        m = SASRecEngine(N, S, D, 2, dropout_rate=0.2, loss="BCE", lr=1e-2, weight_decay=1e-5, seed=2)
+        state = lambda: [m.arena.data.clone(), m.arena.m.clone(), m.arena.v.clone()]                       # noqa: E731
+    else:
+        from recboard_amd.large import SASRecLargeTableEngine
+        m = SASRecLargeTableEngine(N, S, D, 2, dropout_rate=0.2, loss="BCE", lr=1e-2, weight_decay=1e-5, seed=2)
+        state = lambda: [m.arena.data.clone(), m.arena.m.clone(), m.arena.v.clone(), m.E.clone(), m.Em.clone(), m.Ev.clone()]   # noqa: E731
+    for _ in range(3):
+        m.train_step_graph(*batch, next_batch=batch)
+    torch.cuda.synchronize()
+    m.check_handover()
+    before = state()
+    tape = m._buffers(B, S)["tape"]
+    tape[-16:].view(torch.int32)[0] = 1                                     # what a time-out leaves behind
+    loss = m.train_step_graph(*batch, next_batch=batch)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and float(m.arena.grad.abs().max()) > 0     # the step ran, its gradients are there
+    for a, b in zip(before, state()):
+        assert torch.equal(a, b)                                            # ... and nothing was applied
+    with pytest.raises(RuntimeError, match="hand-over time-out"):
+        m.check_handover()
+    m.train_step_graph(*batch, next_batch=batch)                            # cleared: training goes on
+    torch.cuda.synchronize()
+    assert not torch.equal(before[0], m.arena.data)
