@@ -276,8 +276,12 @@ def leg_config5(steps=128, warmup=16, nbatch=64):
         free2, total = torch.cuda.mem_get_info()
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")) as f:
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=lambda q: int(os.path.basename(q)[1:].split("_")[0]))[-1]
+            with open(latest) as f:
                 traffic = json.load(f).get("config5_step")
+            if traffic is not None:
+                traffic["from"] = "profiles/" + os.path.basename(latest)
         except Exception:  # noqa: BLE001
             pass
         out = {"metric": f"train samples/sec (SASRec d=128 on the synthetic {N / 1e6:g} M-item table, B=512, 1 GPU)", "value": round(B / dt, 1),
