@@ -264,14 +264,21 @@ def aten_train_baseline(cfg, batches, steps=30):
             "what": f"torch.nn SASRec (same shapes, fp32, eager ROCm aten, torch.optim.Adam), {steps} steps on the same GPU"}
 
 
+def _latest_pmc_summary():
+    import glob
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    found = sorted(glob.glob(os.path.join(root, "r*_pmc_traffic.json")), key=lambda p_: int(os.path.basename(p_)[1:].split("_")[0]))
+    return found[-1] if found else None
+
+
 def score_call_traffic():
-    """HBM bytes of one whole re_score_topk call (all its launches) from the committed PMC summary of scripts/x2_prof.py."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")
+    """HBM bytes of one whole re_score_topk call (all its launches) from the latest committed PMC summary (scripts/pmc_step.py)."""
+    path = _latest_pmc_summary()
     try:
         with open(path) as f:
             c = json.load(f)["re_score_topk_call"]
         return {"hbm_bytes_per_launch": int(c["hbm_bytes_per_call"]), "algorithmic_lower_bound_bytes": int(c["algorithmic_lower_bound_bytes"]),
-                "source": "profiles/r3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
+                "source": f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE, "
                           "summed over the launches of one call)"}
     except Exception:  # noqa: BLE001
         return None

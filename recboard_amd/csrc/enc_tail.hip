@@ -5,14 +5,12 @@
 // about half the launch) go on with the weight-gradient jobs (enc_wgrad_job.h), two at a time in their two halves, handed out by a ticket counter
 // -- the workgroup with the hot row never gets to take one.  Results: those of re_scatter_adam_rows_small and re_sasrec_encoder_step_part(part =
 // 4), bit for bit (a job's partial does not depend on who computes it; the reduction adds the partials in split order).
-#include "enc_wgrad_job.h"
-#include "scatter_owner.h"
-#include "adam_rows_owner.h"
+#include <hip/hip_runtime.h>
 #ifdef TAIL_PROFILE
 // Diagnostic build (`make encprof`; scripts/tail_phases.py): shader-clock stamps of every workgroup of the last enc_tail_k launch:
 // [0] start, [1] scatter-add done, [2 + 2 i] ticket of its i-th job + 1, [3 + 2 i] that job's end (i < 3), [8 .. 13] the plan job's phases
 // (in the workgroup that ran it), [15] end
-#define TAIL_MARKS 16
+#define TAIL_MARKS 32
 #define TAIL_MARK_WGS 4096
 __device__ unsigned long long g_tail_marks[TAIL_MARK_WGS * TAIL_MARKS];
 extern "C" int re_dbg_tail_marks(unsigned long long* out, int nwg) {
@@ -21,10 +19,17 @@ extern "C" int re_dbg_tail_marks(unsigned long long* out, int nwg) {
 #define TAIL_MARK(i, v) do { if (threadIdx.x == 0 && blockIdx.x < TAIL_MARK_WGS) g_tail_marks[blockIdx.x * TAIL_MARKS + (i)] = (v); } while (0)
 #define TAIL_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
 #define PL_STAMP(i) TAIL_MARK(8 + (i), TAIL_NOW())
+#define WG_STAMP(i) TAIL_MARK(8 + (i), TAIL_NOW())
+#define SO_STAMP(i) TAIL_MARK(20 + (i), TAIL_NOW())     /* scatter_owner.h: 0 start, 1 key count known, 2 keys scanned, 3 rows added, 4 rows stored */
+#define TJ_STAMP(i) TAIL_MARK(16 + (i), TAIL_NOW())     /* tail_jobs, first pass: 0 first barrier passed, 1 ticket read, 2 job called */
 #else
 #define TAIL_MARK(i, v) do { } while (0)
 #define TAIL_NOW() 0ull
+#define TJ_STAMP(i) do { } while (0)
 #endif
+#include "enc_wgrad_job.h"
+#include "scatter_owner.h"
+#include "adam_rows_owner.h"
 #include "enc_plan_body.h"
 
 struct TailJobs {
@@ -58,22 +63,43 @@ static_assert(PL_NT == SO_NT && PL_NT == SA_NT, "the preparation jobs are writte
 
 // ---- weight-gradient jobs, two per ticket: matrix jobs q = 2 t + half -> (block, matrix, split) = (q / 144, q / 24 % 6, q % 24), then the
 //      position-table jobs (144 strides of the (position, chunk) list) -- both halves of a workgroup always run the same kind
+__shared__ int s_job;   // the workgroup's current ticket
+
+// The queue's counter is one address behind an agent-scope atomic: the first ticket's round trip (and the other 255 workgroups' turns at the
+// counter) runs under this workgroup's last contribution-row loads (scatter_owner.h: issue / collect) -- unless the workgroup owns a hot row
+// (several times its share of the matches): that one comes to the queue when it is done, as before, and normally finds it empty.
+struct TailEarly {
+    unsigned* ticket;
+    int nwg;
+    bool has = false;   // (uniform)
+    int val = -1;       // (thread 0)
+    __device__ __forceinline__ void issue(int matches, int nkeys) {
+        has = matches <= 4 * (nkeys / nwg) + 64;
+        if (has && threadIdx.x == 0) val = (int)atomicAdd(ticket, 1u);
+    }
+    __device__ __forceinline__ void collect() {
+        if (has && threadIdx.x == 0) s_job = val;
+    }
+};
+
+// has_early: s_job already holds this workgroup's first ticket
 template <int D>
-__device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP, float* lds) {
-    __shared__ int s_job;
+__device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP, float* lds, int n_tiles, bool has_early = false) {
     const int tid = threadIdx.x, half = tid >> 9, ht = tid & 511;
     float* jl = lds + half * wg_job_lds_floats<D>();
     constexpr int PER_PLANE = WG_NSPLIT * EG_NMAT;
     const int n_mat = J.L * PER_PLANE / 2, n_pos = J.ppart ? PER_PLANE / 2 : 0;
     const int n_prep = TP.mail ? 1 + TP.n_ew : 0;
-    const int n_tiles = enc_plan_view(J.plan, J.B, J.S).hdr[1];
-    int jn = 0; (void)jn;
+    int jn = 0;
     for (;;) {
+        if (jn == 0) TJ_STAMP(3);
         __syncthreads();   // (the launch's first part / the previous job's stages are done with the LDS)
         if (jn > 0 && jn <= 3) TAIL_MARK(1 + 2 * jn, TAIL_NOW());
-        if (tid == 0) s_job = (int)atomicAdd(J.ticket, 1u);
+        if (jn == 0) TJ_STAMP(0);
+        if (tid == 0 && !(has_early && jn == 0)) s_job = (int)atomicAdd(J.ticket, 1u);
         __syncthreads();
         int t = s_job;
+        if (jn == 0) TJ_STAMP(1);
         if (t >= n_prep + n_mat + n_pos) break;
         if (jn < 3) TAIL_MARK(2 + 2 * jn, (unsigned long long)(t + 1));
         ++jn;
@@ -87,6 +113,7 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
         }
         t -= n_prep;
         if (t < n_mat) {
+            if (jn == 1) TJ_STAMP(2);
             const int q = 2 * t + half;
             wg_matrix_job<D>(ht, jl, q / PER_PLANE, (q / WG_NSPLIT) % EG_NMAT, q % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
         } else {
@@ -112,15 +139,22 @@ __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g,
                                                     const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
                                                     int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
+    re_kernarg_warm<re_kernarg_bytes(&enc_tail_k<D, HS>)>();
 #ifdef TAIL_PROFILE
     if (threadIdx.x < TAIL_MARKS && blockIdx.x < TAIL_MARK_WGS) g_tail_marks[blockIdx.x * TAIL_MARKS + threadIdx.x] = 0ull;
     __syncthreads();
 #endif
     TAIL_MARK(0, TAIL_NOW());
     tail_spans(TP, lds);
-    so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds);
+    // (requested here, first needed by the jobs; the dependence of the key count on it -- tile counts are never negative -- keeps the compiler
+    // from sinking the load to its first use, where it would be a round trip of its own)
+    const int n_tiles = enc_plan_view(J.plan, J.B, J.S).hdr[1];
+    n_host += n_tiles < 0 ? 1 : 0;
+    n_mul += n_tiles < 0 ? 1 : 0;
+    TailEarly early{J.ticket, (int)gridDim.x};
+    so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds, early);
     TAIL_MARK(1, TAIL_NOW());
-    tail_jobs<D>(J, TP, lds);
+    tail_jobs<D>(J, TP, lds, n_tiles, early.has);
     TAIL_MARK(15, TAIL_NOW());
 }
 
@@ -128,12 +162,13 @@ __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g,
 template <int D, int HS>
 __global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
+    re_kernarg_warm<re_kernarg_bytes(&enc_tail_sparse_k<D, HS>)>();
     tail_spans(TP, lds);
     // the tape's hand-over error word (a tile waited for a partner's rows in vain: this step's gradients are wrong): the table's rows stay as
     // they are -- read here, on the device, every step; the epoch's check_handover() reports it
     const unsigned gated = reinterpret_cast<const unsigned*>(J.tape + J.T.off_FLAGS)[(J.NR / 16) * EP_FLAG_WORDS];
     if (!gated) sa_body<1, HS, int32_t>(P, reinterpret_cast<unsigned char*>(lds));
-    tail_jobs<D>(J, TP, lds);
+    tail_jobs<D>(J, TP, lds, enc_plan_view(J.plan, J.B, J.S).hdr[1]);
 }
 
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);

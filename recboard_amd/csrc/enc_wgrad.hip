@@ -33,16 +33,31 @@ struct EncAdam {
     float b1, b2, omb1, omb2, eps, wd;
     const unsigned* gate;   // optional device word: non-zero = gradients are written, parameters and moments stay (a hand-over of this step timed out)
 };
-__device__ __forceinline__ void eg_put(const EncAdam& A, float* d, float g) {
-    *d = g;
+// What the end of an element's chain needs and does not depend on the partial sums -- the step scalars, the gate word, the element's parameter
+// and moments -- is requested FIRST (eg_pre, unconditional loads), together with the partials: the launch is then one memory round trip deep
+// instead of three (partials; scalars, on which a branch depended; parameter and moments).
+struct EgPre {
+    float ss, ib, p, m, v;
+};
+__device__ __forceinline__ EgPre eg_pre(const EncAdam& A, const float* d) {
+    EgPre e{0.f, 0.f, 0.f, 0.f, 0.f};
     if (A.p) {
-        const float ss = A.hyper[0], ib = A.hyper[1];
-        if (ib != 0.f && !(A.gate && A.gate[0] != 0u)) {   // ({0, 0}: the caller gated this step off)
-            const int64_t i = d - A.gbase;
-            float pp = A.p[i], mm = A.m[i], vv = A.v[i];
-            re_adam1(pp, mm, vv, g, A.b1, A.b2, A.omb1, A.omb2, ss, ib, A.eps, A.wd);     // (adam_vec4_dev's arithmetic)
-            A.p[i] = pp; A.m[i] = mm; A.v[i] = vv;
-        }
+        const int64_t i = d - A.gbase;
+        e.p = A.p[i]; e.m = A.m[i]; e.v = A.v[i];
+        const unsigned gate_w = *(A.gate ? A.gate : reinterpret_cast<const unsigned*>(A.hyper));
+        e.ss = A.hyper[0];
+        e.ib = A.hyper[1];
+        e.ib = (A.gate && gate_w != 0u) ? 0.f : e.ib;   // ({0, 0}: the caller gated this step off; gate: a hand-over of this step timed out)
+    }
+    return e;
+}
+__device__ __forceinline__ void eg_put(const EncAdam& A, float* d, float g, const EgPre& e) {
+    *d = g;
+    if (A.p && e.ib != 0.f) {
+        const int64_t i = d - A.gbase;
+        float pp = e.p, mm = e.m, vv = e.v;
+        re_adam1(pp, mm, vv, g, A.b1, A.b2, A.omb1, A.omb2, e.ss, e.ib, A.eps, A.wd);     // (adam_vec4_dev's arithmetic)
+        A.p[i] = pp; A.m[i] = mm; A.v[i] = vv;
     }
 }
 
@@ -56,6 +71,7 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
                                                          const void* __restrict__ planp, int B, int S, int D, int L, EncGradDst dst,
                                                          int nmat_blocks, int nvec_blocks, const float* __restrict__ ppart, float inv_scale,
                                                          float* __restrict__ dPtab, int by_tile, EncAdam AD, unsigned* __restrict__ ticket) {
+    re_kernarg_warm<re_kernarg_bytes(&enc_grad_reduce_k)>();
     const int tid = threadIdx.x;
     if (ticket && blockIdx.x == 0 && tid == 0) ticket[0] = 0u;   // (enc_tail_k's job counter: every job of this step has been taken)
     if ((int)blockIdx.x >= nmat_blocks + nvec_blocks) {
@@ -63,9 +79,10 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
         const int e = ((int)blockIdx.x - nmat_blocks - nvec_blocks) * 256 + tid;
         if (e >= S * D) return;
         const int p = e / D, cc = e % D, nch = (B + 63) / 64;
+        const EgPre pre = eg_pre(AD, dPtab + e);
         float s = 0.f;
         for (int ch = 0; ch < nch; ++ch) s += ppart[((int64_t)p * nch + ch) * D + cc];
-        eg_put(AD, dPtab + e, s * inv_scale);
+        eg_put(AD, dPtab + e, s * inv_scale, pre);
         return;
     }
     if ((int)blockIdx.x < nmat_blocks) {
@@ -74,16 +91,17 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
         if (e >= (int64_t)L * EG_NMAT * dd) return;
         const int lm = (int)(e / dd), off = (int)(e % dd);
         const float* p = part + (int64_t)lm * WG_NSPLIT * dd + off;
+        const int l = lm / EG_NMAT, m = lm % EG_NMAT;
+        float* const* P = dst.p[l];
+        float* d = (m == 0) ? P[10] : (m == 1) ? P[8] : (m == 2) ? P[4] : P[2] + (m - 3) * dd;
+        const EgPre pre = eg_pre(AD, d + off);
         float v[WG_NSPLIT];
 #pragma unroll
         for (int i = 0; i < WG_NSPLIT; ++i) v[i] = p[(int64_t)i * dd];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < WG_NSPLIT; ++i) s += v[i];
-        const int l = lm / EG_NMAT, m = lm % EG_NMAT;
-        float* const* P = dst.p[l];
-        float* d = (m == 0) ? P[10] : (m == 1) ? P[8] : (m == 2) ? P[4] : P[2] + (m - 3) * dd;
-        eg_put(AD, d + off, s);
+        eg_put(AD, d + off, s, pre);
         return;
     }
     __shared__ float red[4][64];
@@ -95,6 +113,24 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
     // slab rows: one per workgroup that had work, or -- D = 64 steps that ran one tile per workgroup (enc_tile.hip) -- one per tile
     const int nact = (by_tile && PL.hdr[7] == 1) ? PL.hdr[1] : (n_items < nwg ? n_items : nwg);
     const int lane = tid & 63, wave = tid >> 6;
+    float* dvec = nullptr;
+    if (!(v >= 10 && l != L - 1)) {
+        float* const* P = dst.p[l];
+        switch (v) {
+            case 0: case 1: case 2: dvec = P[3] + v * D; break;
+            case 3: dvec = P[5]; break;
+            case 4: dvec = P[9]; break;
+            case 5: dvec = P[11]; break;
+            case 6: dvec = P[0]; break;
+            case 7: dvec = P[1]; break;
+            case 8: dvec = P[6]; break;
+            case 9: dvec = P[7]; break;
+            case 10: dvec = P[12]; break;
+            default: dvec = P[13]; break;
+        }
+        dvec += cg * 64 + lane;
+    }
+    const EgPre pre = (dvec && wave == 0) ? eg_pre(AD, dvec) : EgPre{0.f, 0.f, 0.f, 0.f, 0.f};
     const float* sl = slab + ((int64_t)l * EG_NVEC + v) * D + cg * 64 + lane;
     const int64_t stride = (int64_t)L * EG_NVEC * D;
     float s = 0.f;
@@ -111,22 +147,8 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
     __syncthreads();
     if (wave != 0) return;
     s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    if (v >= 10 && l != L - 1) return;
-    float* const* P = dst.p[l];
-    float* d;
-    switch (v) {
-        case 0: case 1: case 2: d = P[3] + v * D; break;
-        case 3: d = P[5]; break;
-        case 4: d = P[9]; break;
-        case 5: d = P[11]; break;
-        case 6: d = P[0]; break;
-        case 7: d = P[1]; break;
-        case 8: d = P[6]; break;
-        case 9: d = P[7]; break;
-        case 10: d = P[12]; break;
-        default: d = P[13]; break;
-    }
-    eg_put(AD, d + cg * 64 + lane, s);
+    if (!dvec) return;
+    eg_put(AD, dvec, s, pre);
 }
 
 size_t enc_wgrad_ppart_floats(int64_t B, int64_t D) { return (size_t)64 * ((B + 63) / 64) * D; }

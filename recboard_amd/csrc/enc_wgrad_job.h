@@ -10,6 +10,9 @@
 #define WG_NSPLIT 24
 #endif
 #define WG_CH 4   // row tiles per LDS stage
+#ifndef WG_STAMP
+#define WG_STAMP(i) do { } while (0)   // (enc_tail.hip's profile build: shader-clock stamps inside a job)
+#endif
 
 template <int D>
 __host__ __device__ constexpr int wg_job_lds_floats() { return 2 * 16 * WG_CH * EC<D>::LS; }
@@ -46,66 +49,84 @@ __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m,
     f32x4 acc[RTW];
 #pragma unroll
     for (int t = 0; t < RTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // stages of WG_CH row tiles through LDS; the next stage's rows are requested into registers before this stage's products
-    // (every stage is a memory round trip: four of them in a row were most of the launch)
+    // Stages of WG_CH row tiles through LDS.  Every stage's rows are a memory round trip (~2 us under the launch's own load) and a job has
+    // ~3 of them: PF stages are requested into registers at once, then staged and multiplied one after the other, a slot's next stage being
+    // requested as soon as its registers are free.  PF = 1 (the next stage in flight under this stage's products) is what the registers of
+    // enc_tail_k allow: PF = 3 at D = 64 -- a Beauty-shaped job as ONE round trip -- pushed 36 registers of the 128 a thread of a
+    // 1024-thread workgroup has into scratch memory, and a job took 38 k cycles instead of 24 k (scripts/tail_phases.py, round 4).
     constexpr int NP = NPAIR * (D / 4) / C::NT;   // (row pair, four columns) units per thread: 1 at D = 64, 2 at D = 128
-    f32x4 ra[NP][2], rb[NP][2];   // (native vectors and a macro: HIP's float4 struct arrays / arrays captured by a lambda stay in scratch memory)
-#define WG_FETCH(TC)                                                                                            \
+    constexpr int PF = 1;
+    f32x4 ra[PF][NP][2], rb[PF][NP][2];   // (native vectors and a macro: HIP's float4 struct arrays / arrays captured by a lambda stay in scratch memory)
+#define WG_FETCH(Q, TC)                                                                                         \
     do {                                                                                                        \
         const int ntc_ = (t1 - (TC)) < WG_CH ? (t1 - (TC)) : WG_CH;                                             \
-        const int nf_ = 16 * ntc_ * (D / 4);                                                                    \
+        const int nf_ = ntc_ > 0 ? 16 * ntc_ * (D / 4) : 1;                                                     \
+        const int tc_ = ntc_ > 0 ? (TC) : t0;   /* (a stage behind the split's rows: any valid address, its values are not used) */ \
         _Pragma("unroll") for (int j = 0; j < NP; ++j) {                                                        \
             const int u_ = j * C::NT + tid, p_ = u_ / (D / 4), c4_ = u_ % (D / 4);                              \
             _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                     \
                 int f = (2 * p_ + e) * (D / 4) + c4_;                                                           \
                 f = f < nf_ ? f : nf_ - 1;   /* clamped, unconditional: a predicated load is waited for on the spot */ \
-                ra[j][e] = reinterpret_cast<const f32x4*>(dY + (int64_t)(TC) * 16 * D)[f];                      \
-                rb[j][e] = reinterpret_cast<const f32x4*>(X + (int64_t)(TC) * 16 * D)[f];                       \
+                ra[Q][j][e] = reinterpret_cast<const f32x4*>(dY + (int64_t)tc_ * 16 * D)[f];                    \
+                rb[Q][j][e] = reinterpret_cast<const f32x4*>(X + (int64_t)tc_ * 16 * D)[f];                     \
             }                                                                                                   \
         }                                                                                                       \
     } while (0)
-    if (t0 < t1) WG_FETCH(t0);
-    for (int it = 0; it < trips; ++it) {
-        const int tc = t0 + it * WG_CH;
-        const int left = t1 - tc;
-        const int ntc = left < WG_CH ? (left > 0 ? left : 0) : WG_CH;
-        enc_sync();
+    WG_STAMP(0);
+    if (t0 < t1) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int u = j * C::NT + tid, p = u / (D / 4), c4 = u % (D / 4);
-            const bool live = 2 * p < 16 * ntc;      // (rows come in pairs: 16 ntc is even; pairs behind the stage's rows are zero)
-            tl_u32x4 h, md, h2, md2;
+        for (int q = 0; q < PF; ++q) WG_FETCH(q, t0 + q * WG_CH);
+    }
+    WG_STAMP(1);
+    for (int it0 = 0; it0 < trips; it0 += PF) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unsigned x, y;
-                tl_split2(live ? ra[j][0][i] : 0.f, live ? ra[j][1][i] : 0.f, x, y);
-                h[i] = x; md[i] = y;
-                tl_split2(live ? rb[j][0][i] : 0.f, live ? rb[j][1][i] : 0.f, x, y);
-                h2[i] = x; md2[i] = y;
+        for (int q = 0; q < PF; ++q) {
+            const int it = it0 + q;
+            if (it >= trips) break;                  // (uniform)
+            const int tc = t0 + it * WG_CH;
+            const int left = t1 - tc;
+            const int ntc = left < WG_CH ? (left > 0 ? left : 0) : WG_CH;
+            enc_sync();
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int u = j * C::NT + tid, p = u / (D / 4), c4 = u % (D / 4);
+                const bool live = 2 * p < 16 * ntc;      // (rows come in pairs: 16 ntc is even; pairs behind the stage's rows are zero)
+                tl_u32x4 h, md, h2, md2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned x, y;
+                    tl_split2(live ? ra[q][j][0][i] : 0.f, live ? ra[q][j][1][i] : 0.f, x, y);
+                    h[i] = x; md[i] = y;
+                    tl_split2(live ? rb[q][j][0][i] : 0.f, live ? rb[q][j][1][i] : 0.f, x, y);
+                    h2[i] = x; md2[i] = y;
+                }
+                *reinterpret_cast<tl_u32x4*>(aH + p * RSW + 4 * c4) = h;
+                *reinterpret_cast<tl_u32x4*>(aM + p * RSW + 4 * c4) = md;
+                *reinterpret_cast<tl_u32x4*>(bH + p * RSW + 4 * c4) = h2;
+                *reinterpret_cast<tl_u32x4*>(bM + p * RSW + 4 * c4) = md2;
             }
-            *reinterpret_cast<tl_u32x4*>(aH + p * RSW + 4 * c4) = h;
-            *reinterpret_cast<tl_u32x4*>(aM + p * RSW + 4 * c4) = md;
-            *reinterpret_cast<tl_u32x4*>(bH + p * RSW + 4 * c4) = h2;
-            *reinterpret_cast<tl_u32x4*>(bM + p * RSW + 4 * c4) = md2;
-        }
-        if (tc + WG_CH < t1) WG_FETCH(tc + WG_CH);
-        enc_sync();
-        const int ksteps = (ntc + 1) >> 1;           // 32 rows (two row tiles) per MFMA
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const int w0 = (16 * ks + 4 * g) * RSW + c;       // the lane's four row pairs: rows 32 ks + 8 g + (0 .. 7)
-            tl_u32x4 bh, bm;
+            // (this slot's registers are free again: the stage PF further on -- none on a Beauty-shaped batch at D = 64)
+            if (tc + PF * WG_CH < t1) WG_FETCH(q, tc + PF * WG_CH);
+            enc_sync();
+            if (it == 0) WG_STAMP(2);
+            const int ksteps = (ntc + 1) >> 1;           // 32 rows (two row tiles) per MFMA
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const int w0 = (16 * ks + 4 * g) * RSW + c;       // the lane's four row pairs: rows 32 ks + 8 g + (0 .. 7)
+                tl_u32x4 bh, bm;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { bh[i] = bH[w0 + i * RSW + 16 * strip]; bm[i] = bM[w0 + i * RSW + 16 * strip]; }
+                for (int i = 0; i < 4; ++i) { bh[i] = bH[w0 + i * RSW + 16 * strip]; bm[i] = bM[w0 + i * RSW + 16 * strip]; }
 #pragma unroll
-            for (int t = 0; t < RTW; ++t) {
-                const int mt = t * C::WR + wr;
-                tl_u32x4 ah, am;
+                for (int t = 0; t < RTW; ++t) {
+                    const int mt = t * C::WR + wr;
+                    tl_u32x4 ah, am;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { ah[i] = aH[w0 + i * RSW + 16 * mt]; am[i] = aM[w0 + i * RSW + 16 * mt]; }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, am), __builtin_bit_cast(tl_bf16x8, bh), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, ah), __builtin_bit_cast(tl_bf16x8, bm), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, ah), __builtin_bit_cast(tl_bf16x8, bh), acc[t], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) { ah[i] = aH[w0 + i * RSW + 16 * mt]; am[i] = aM[w0 + i * RSW + 16 * mt]; }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, am), __builtin_bit_cast(tl_bf16x8, bh), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, ah), __builtin_bit_cast(tl_bf16x8, bm), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, ah), __builtin_bit_cast(tl_bf16x8, bh), acc[t], 0, 0, 0);
+                }
             }
+            if (it < 3) WG_STAMP(3 + it);
         }
     }
 #undef WG_FETCH

@@ -47,6 +47,38 @@ static inline hipError_t re_zero_async(void* p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Kernel arguments are read from the kernarg segment with scalar loads, and under scalar-register pressure the compiler RE-loads them where
+// they are used instead of keeping them (enc_tail_k: 36 such loads all over the kernel): every first touch of a 64-byte line of the segment
+// is then a memory round trip in the middle of a dependent chain (~5 k cycles each in the step's tail launch, scripts/tail_phases.py).
+// re_kernarg_warm touches every line of the explicit arguments once, at the kernel's start, in one batch of scalar loads: the later loads
+// hit the scalar cache.   usage: re_kernarg_warm<re_kernarg_bytes(&kernel<...>)>();
+template <class... A>
+__host__ __device__ constexpr int re_kernarg_bytes(void (*)(A...)) {
+    int o = 0;
+    ((o = (o + (int)alignof(A) - 1) / (int)alignof(A) * (int)alignof(A) + (int)sizeof(A)), ...);
+    return o;
+}
+template <int BYTES>
+__device__ __forceinline__ void re_kernarg_warm() {
+    static_assert(BYTES > 0 && BYTES <= 12 * 64, "twelve lines");
+    constexpr int LAST = (BYTES - 1) / 64 * 64;
+#define RE_KA_OFF(k) ((k) * 64 < LAST ? (k) * 64 : LAST)
+    typedef const uint32_t __attribute__((address_space(4))) ka_word;
+    ka_word* ka = (ka_word*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11;
+    // (one block: the loads' results arrive asynchronously, the wait has to sit in the same statement)
+    asm volatile(
+        "s_load_dword %0, %12, %13\n\ts_load_dword %1, %12, %14\n\ts_load_dword %2, %12, %15\n\ts_load_dword %3, %12, %16\n\t"
+        "s_load_dword %4, %12, %17\n\ts_load_dword %5, %12, %18\n\ts_load_dword %6, %12, %19\n\ts_load_dword %7, %12, %20\n\t"
+        "s_load_dword %8, %12, %21\n\ts_load_dword %9, %12, %22\n\ts_load_dword %10, %12, %23\n\ts_load_dword %11, %12, %24\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(a0), "=&s"(a1), "=&s"(a2), "=&s"(a3), "=&s"(a4), "=&s"(a5), "=&s"(a6), "=&s"(a7), "=&s"(a8), "=&s"(a9), "=&s"(a10), "=&s"(a11)
+        : "s"(ka), "i"(RE_KA_OFF(0)), "i"(RE_KA_OFF(1)), "i"(RE_KA_OFF(2)), "i"(RE_KA_OFF(3)), "i"(RE_KA_OFF(4)), "i"(RE_KA_OFF(5)), "i"(RE_KA_OFF(6)),
+          "i"(RE_KA_OFF(7)), "i"(RE_KA_OFF(8)), "i"(RE_KA_OFF(9)), "i"(RE_KA_OFF(10)), "i"(RE_KA_OFF(11))
+        : "memory");
+#undef RE_KA_OFF
+}
+
 // One element of the dense Adam step with coupled weight decay.  The operation sequence is pinned (explicit fused / rounded operations):
 // the same update is computed by adam_vec4 / adam_vec4_dev, by the scatter-add's row owners and by the gradient reduction's epilogue,
 // and an eager step and a captured step must agree to the bit whichever of them runs.

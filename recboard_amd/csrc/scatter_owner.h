@@ -25,8 +25,11 @@
 #define SO_CAP 8192          // match list (LDS): flushed whenever the next 8192-key chunk might not fit
 #define SO_NG 8              // accumulator sets
 #define SO_LG (SO_NT / 32)   // lane groups (32 lanes each): 4 per accumulator set
-#define SO_INF 24            // row loads a lane group keeps in flight
+#define SO_INF 16            // row loads a lane group keeps in flight (24 was no faster on the Zipf head's 850 rows and cost 22 spilled registers)
 #define SO_KPT 8             // keys per thread and chunk: two 16-byte loads
+#ifndef SO_STAMP
+#define SO_STAMP(i) do { } while (0)   // (enc_tail.hip's profile build)
+#endif
 #ifdef SO_MARKS   // diagnostic build: workgroup 0 leaves shader-clock stamps in the padding row of dW
 #define SO_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) so_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -45,10 +48,19 @@ __device__ __forceinline__ void so_adam1(const SoAdam& A, float ss, float ib, fl
     re_adam1(p, m, v, g, A.b1, A.b2, A.omb1, A.omb2, ss, ib, A.eps, A.wd);
 }
 
-template <int D, int HS>
+struct SoNoHook {
+    __device__ __forceinline__ void issue(int, int) {}
+    __device__ __forceinline__ void collect() {}
+};
+
+// hook.issue(matches, keys): called once by every thread, workgroup-uniformly, when the LAST batch of contribution-row loads has been issued
+// (or there was none); hook.collect(): once, after those rows have been added and BEFORE the owned rows' stores are issued -- enc_tail_k takes
+// its ticket of the job queue in between: the counter's round trip runs under the row loads' own, and nothing waits for a store's.
+template <int D, int HS, class Hook = SoNoHook>
 __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                         const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
-                                        int64_t padding_idx, float scale, float* __restrict__ dW, const SoAdam& AD, float* so_acc) {
+                                        int64_t padding_idx, float scale, float* __restrict__ dW, const SoAdam& AD, float* so_acc,
+                                        Hook&& hook = Hook{}) {
 
     constexpr int DW = D / HS, VW = DW / 32;         // columns of a piece; floats per lane: a lane group is 32 lanes
     constexpr int HSH = HS == 1 ? 0 : HS == 2 ? 1 : 2;
@@ -65,16 +77,37 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
     const uint32_t nwg = gridDim.x, me = blockIdx.x, wsh = 31 - __clz((int)nwg), h_me = me & (HS - 1);
     const int64_t VR = R * HS;
     const int rows_here = (int64_t)me < VR ? (int)((VR - 1 - me) / nwg + 1) : 0;
+    // The launch is a chain of memory round trips (~2 us each under the launch's own load): what the END of the chain needs and does not depend
+    // on the keys is requested here -- the step scalars, the gate word and the thread's own piece of parameter / moment rows (the rows a
+    // workgroup owns are a function of its index; nobody else writes them).
+    float ad_ss = 0.f, ad_ib = 0.f;
+    float4 P0 = make_float4(0.f, 0.f, 0.f, 0.f), M0 = P0, V0 = P0;
+    if (AD.W) {
+        if (tid < rows_here * (DW / 4)) {
+            const int64_t o = ((((int64_t)(tid / (DW / 4)) * nwg + me) >> HSH)) * D + h_me * DW;
+            P0 = reinterpret_cast<const float4*>(AD.W + o)[tid % (DW / 4)];
+            M0 = reinterpret_cast<const float4*>(AD.m + o)[tid % (DW / 4)];
+            V0 = reinterpret_cast<const float4*>(AD.v + o)[tid % (DW / 4)];
+        }
+        // (unconditional loads, selected afterwards: a branch on a loaded word is a round trip of its own)
+        const unsigned gate_w = *(AD.gate ? AD.gate : reinterpret_cast<const unsigned*>(AD.hyper));
+        ad_ss = AD.hyper[0];
+        ad_ib = AD.hyper[1];
+        ad_ib = (AD.gate && gate_w != 0u) ? 0.f : ad_ib;   // ({0, 0}: the caller gated this step off; gate: a hand-over of this step timed out)
+    }
     for (int e = tid; e < SO_NG * rpw * DW / 4; e += SO_NT) reinterpret_cast<float4*>(so_acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt = 0;          // entries in the list (workgroup-uniform)
+    bool hooked = false;  // (uniform)
     unsigned m0 = 0;      // matches consumed so far
 #ifdef SO_MARKS
     unsigned long long so_t[12] = {};
     int so_i = 2;
 #endif
     SO_MARK(0);
+    SO_STAMP(0);
 
-    auto flush = [&]() {
+    const uint32_t n32 = (uint32_t)n, total = (uint32_t)nreg * n32;   // (< 2^25: checked by the entry point)
+    auto flush = [&](bool last) {
         // Lane group grp takes the list entries j with (m0 + j) % 32 == grp, in increasing j, INF row loads in flight at a time; a hot
         // row (the Zipf head is 10 % of a batch: hundreds of entries for ONE workgroup) is thereby spread over all 32 groups.
         // Neighbouring entries of the same row are added in registers first; then the four groups that share an accumulator set
@@ -92,6 +125,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
                     rw[u] = j < cnt ? (int)(en >> 25) : -1;
                     v[u] = reinterpret_cast<const vt*>(g + (int64_t)(en & 0x1FFFFFFu) * D + h_me * DW)[gl];
                 }
+                if (last && jb + SO_LG * INF >= cnt) { hook.issue((int)m0 + cnt, (int)total); hooked = true; }   // (uniform)
 #pragma unroll
                 for (int u = 0; u + 1 < INF; ++u) {
                     const bool same = rw[u] == rw[u + 1];
@@ -126,7 +160,6 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
     // round trip), counts its matches, ONE workgroup scan places them, and the matches go to the list from registers.
     // Match order = (chunk, thread, key): a fixed function of the keys.  (n is a multiple of 4 or the tail is handled by element:
     // a load never straddles two regions.)
-    const uint32_t n32 = (uint32_t)n, total = (uint32_t)nreg * n32;   // (< 2^25: checked by the entry point)
     const bool vec = (n32 & 3u) == 0;
     auto region_of = [&](uint32_t v) { return (uint32_t)(v >= n32) + (uint32_t)(v >= 2 * n32) + (uint32_t)(v >= 3 * n32); };   // (nreg <= 4)
     auto load_chunk = [&](uint32_t base, int (&kk)[SO_KPT]) {
@@ -146,6 +179,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
     };
     const uint32_t R32 = (uint32_t)R, pad32 = (padding_idx >= 0 && padding_idx < R) ? (uint32_t)padding_idx : 0xFFFFFFFFu;
     int kv[SO_KPT], kn[SO_KPT];
+    if (total > 0) SO_STAMP(1);
     if (total > 0) load_chunk(0, kv);
     for (uint32_t base = 0; base < total; base += SO_NT * SO_KPT) {
         if (base + SO_NT * SO_KPT < total) load_chunk(base + SO_NT * SO_KPT, kn);   // (in flight while this chunk is ranked)
@@ -179,7 +213,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         }
         if (tot != 0) {                         // (uniform)
             if (cnt + tot > SO_CAP) {           // (uniform) make room
-                flush();
+                flush(false);
                 __syncthreads();
             }
             int off = cnt + below + inc - c;
@@ -202,9 +236,13 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
     }
     __syncthreads();
     SO_MARK(8);
-    flush();
+    SO_STAMP(2);
+    flush(true);
+    if (!hooked) hook.issue((int)m0, (int)total);
     __syncthreads();
     SO_MARK(9);
+    SO_STAMP(3);
+    hook.collect();
     // ---- the eight accumulators of every owned row, added in set order; untouched rows come out zero
     for (int e = tid; e < rows_here * (DW / 4); e += SO_NT) {
         const int r = e / (DW / 4), c4 = e % (DW / 4);
@@ -219,15 +257,17 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         const int64_t o = (kk >> HSH) * D + h_me * DW;
         if (dW) reinterpret_cast<float4*>(dW + o)[c4] = gr;
         if (AD.W) {
-            const float ss = AD.hyper[0], ib = AD.hyper[1];
-            if (ib != 0.f && !(AD.gate && AD.gate[0] != 0u)) {   // ({0, 0}: the caller gated this step off; gate: a hand-over of this step timed out)
-                float4 P = reinterpret_cast<float4*>(AD.W + o)[c4], M = reinterpret_cast<float4*>(AD.m + o)[c4], V = reinterpret_cast<float4*>(AD.v + o)[c4];
+            if (ad_ib != 0.f) {
+                float4 P = P0, M = M0, V = V0;
+                if (e != tid) { P = reinterpret_cast<float4*>(AD.W + o)[c4]; M = reinterpret_cast<float4*>(AD.m + o)[c4]; V = reinterpret_cast<float4*>(AD.v + o)[c4]; }
+                const float ss = ad_ss, ib = ad_ib;
                 so_adam1(AD, ss, ib, gr.x, P.x, M.x, V.x); so_adam1(AD, ss, ib, gr.y, P.y, M.y, V.y);
                 so_adam1(AD, ss, ib, gr.z, P.z, M.z, V.z); so_adam1(AD, ss, ib, gr.w, P.w, M.w, V.w);
                 reinterpret_cast<float4*>(AD.W + o)[c4] = P; reinterpret_cast<float4*>(AD.m + o)[c4] = M; reinterpret_cast<float4*>(AD.v + o)[c4] = V;
             }
         }
     }
+    SO_STAMP(4);
 #ifdef SO_MARKS
     __syncthreads();
     SO_MARK(10);

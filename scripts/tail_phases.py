@@ -21,10 +21,11 @@ for i in range(40):
     m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8])
 torch.cuda.synchronize()
 NWG = 256
-buf = (ctypes.c_ulonglong * (16 * NWG))()
+NM = 32
+buf = (ctypes.c_ulonglong * (NM * NWG))()
 L.re_dbg_tail_marks.argtypes, L.re_dbg_tail_marks.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
 assert L.re_dbg_tail_marks(buf, NWG) == 0
-t = np.array(list(buf), dtype=np.int64).reshape(NWG, 16)
+t = np.array(list(buf), dtype=np.int64).reshape(NWG, NM)
 # (the shader clocks of different XCDs are not aligned: everything below is relative to the workgroup's own start)
 sc = (t[:, 1] - t[:, 0]) / 1e3
 tot = (t[:, 15] - t[:, 0]) / 1e3
@@ -47,10 +48,24 @@ for lo, hi, name in ((0, 144, "matrix tickets"), (144, 10 ** 9, "position ticket
     if sel.any():
         print(f"  {name}: n {int(sel.sum())} med {np.median(d[sel]):.1f} max {d[sel].max():.1f}")
 print("workgroup lifetime min/med/p90/max", tot.min(), np.median(tot), np.percentile(tot, 90), tot.max())
-pw = [w for w in range(NWG) if t[w, 9] > 0]
+pw = [w for w in range(NWG) if (njobs[w] > 0 and t[w, 2] == 1) or w == NWG - 1]    # (ticket 0: the plan's rest; the last workgroup: its spans)
 for w in pw:
     st = [int(x) for x in t[w, 8:14]]
     base = t[w, 1]
     print("plan job in workgroup", w, ": phase stamps relative to its scatter end (kcycles):", [round((x - base) / 1e3, 1) for x in st if x > 0])
 for w in np.argsort(tot)[-6:]:
     print("  wg", int(w), "scatter", sc[w], "tickets", int(njobs[w]), [int(t[w, 2 + 2 * i]) - 1 for i in range(njobs[w])], "lifetime", tot[w])
+
+# stamps inside the matrix jobs (enc_wgrad_job.h WG_STAMP: 0 entry, 1 first fetch issued, 2 first stage in LDS, 3.. end of each stage's products)
+rows = []
+for w in range(NWG):
+    if w in pw or njobs[w] != 1 or t[w, 8] == 0 or t[w, 10] == 0:
+        continue
+    rows.append([(t[w, 8 + i] - t[w, 1]) / 1e3 if t[w, 8 + i] > 0 else np.nan for i in range(6)] + [(t[w, 3] - t[w, 1]) / 1e3])
+if rows:
+    r = np.array(rows)
+    print("matrix job stamps relative to the scatter end, medians (kcycles): entry, fetch issued, stage 0 staged, products 0, 1, 2 | job end", np.round(np.nanmedian(r, 0), 1).tolist(), " n", len(rows))
+
+rel = lambda i: np.round(np.median([(t[w, i] - t[w, 0]) / 1e3 for w in range(NWG) if t[w, i] > 0 and w not in pw] or [np.nan]), 1)
+print("medians relative to the workgroup's start (kcycles): scatter start", rel(20), "key count known", rel(21), "keys scanned", rel(22), "rows added", rel(23),
+      "rows stored", rel(24), "| scatter end", rel(1), "| at first barrier", rel(19), "passed", rel(16), "ticket read", rel(17), "job called", rel(18), "job entry", rel(8), "| end", rel(15))
