@@ -58,11 +58,12 @@ __host__ __device__ constexpr int re_kernarg_bytes(void (*)(A...)) {
     ((o = (o + (int)alignof(A) - 1) / (int)alignof(A) * (int)alignof(A) + (int)sizeof(A)), ...);
     return o;
 }
-template <int BYTES>
+template <int BYTES, int FROM = 0>
 __device__ __forceinline__ void re_kernarg_warm() {
-    static_assert(BYTES > 0 && BYTES <= 12 * 64, "twelve lines");
+    static_assert(BYTES > 0 && FROM % 64 == 0 && FROM < BYTES, "lines of the explicit arguments");
+    if constexpr (BYTES - FROM > 12 * 64) re_kernarg_warm<BYTES, FROM + 12 * 64>();   // (twelve lines per batch)
     constexpr int LAST = (BYTES - 1) / 64 * 64;
-#define RE_KA_OFF(k) ((k) * 64 < LAST ? (k) * 64 : LAST)
+#define RE_KA_OFF(k) (FROM + (k) * 64 < LAST ? FROM + (k) * 64 : LAST)
     typedef const uint32_t __attribute__((address_space(4))) ka_word;
     ka_word* ka = (ka_word*)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11;
