@@ -65,8 +65,9 @@ def synth_batches(cfg, nbatch, seed):
 def large_batch_roofline(cfg, B=8192, steps=40):
     """The D = 64 step in its THROUGHPUT regime: the same model at B = 8 192 Beauty-shaped sequences per step (~16 tiles of real tokens per
     CU instead of ~1; what a rank sees when a job scales its batch): samples/s and the executed-FLOP fraction of the fp32 matrix peak.
-    At this size the plan hands the step to the fp32 workgroup-per-item kernels (enc_step_k): the one-tile-per-workgroup kernel needs every
-    tile of the long sequences resident at once (<= 192 of them), a batch of 8 192 has ~1 500."""
+    The plan hands a batch to whichever of the two encoder kernels is faster for it (csrc/enc_plan_body.h; scripts/large_batch.py,
+    scripts/long_mix.py): the one-tile-per-workgroup kernel (one workgroup per CU, further tiles from a counter) up to ~10 tiles per CU --
+    B = 2 048 here -- and the fp32 workgroup-per-item kernel beyond -- B = 8 192."""
     from recboard_amd.sasrec import SASRecEngine
     big = dict(cfg, B=B)
     m = SASRecEngine(cfg["items"], cfg["S"], cfg["D"], cfg["L"], dropout_rate=cfg["p_drop"], loss="BCE", lr=cfg["lr"], weight_decay=cfg["wd"], seed=1)
@@ -88,7 +89,7 @@ def large_batch_roofline(cfg, B=8192, steps=40):
             "samples_per_sec": round(B / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "B": B, "tiles": n_tiles, "work_items": n_items,
             "tiles_per_cu": round(n_tiles / 256.0, 1),
             "kernel": "the one-tile-per-workgroup step (enc_tile_step_k)" if int(hdr[7]) == 1 else "the fp32 workgroup-per-item step (enc_step_k<64>: the plan's "
-                      "choice whenever the long sequences' tiles cannot all be resident)",
+                      "choice beyond ~10 tiles or ~1.5 chained tiles per CU)",
             "work": f"executed FLOP as in `roofline.work`: {fl_exec:.3e} per step on {n_tiles} tiles; whole step (preparation, encoder, tail, Adam) per replay"}
 
 
@@ -733,6 +734,7 @@ def main():
             line["sampler"] = sampler_rates(cfg, model)
             try:
                 line["roofline_large_batch"] = large_batch_roofline(cfg)
+                line["roofline_large_batch"]["B_2048"] = large_batch_roofline(cfg, B=2048)
             except Exception as e:  # noqa: BLE001  (a leg of its own: the headline stands without it)
                 line["roofline_large_batch"] = {"skipped": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_c5:

@@ -303,7 +303,9 @@ int re_route_bucket(const int64_t* idx, int64_t n, int64_t R, int64_t G, int64_t
  *   uint32[4]) = { seed, 0, bits(lr / (1 - beta1^step)), bits(1 / sqrt(1 - beta2^step)) } -- `state` doubles as `seed_dev` of the dropout entry points and, from word 2, as `hyper` of re_adam_step_dev.
  *   pos / neg may be NULL (evaluation: only the plan is wanted); then valid / count / rows_all rows 1, 2 are not written.
  *   split_long is a mask.  & 2: the plan must NOT hand the step to the one-tile-per-workgroup kernels (re_sasrec_encoder_step: hdr[7] stays 0).
- *   (The tile kernels hold one workgroup per CU: a plan hands them the step only if at most 3/4 of `ncu` tiles belong to sequences longer than 16 rows.)
+ *   & 4: the plan MUST hand it to them (else it does so where they are the faster of the two: at most 1.5 tiles of sequences longer than 16 rows
+ *   and at most 10 tiles in all per resident workgroup; the tile kernels take any number of tiles -- one workgroup per CU, the tiles beyond the grid
+ *   handed out by a counter).
  *   & 1: a sequence of 3 - 4 tiles becomes TWO work items (its first two tiles / the rest) that run in two workgroups at
  *   once and hand k, v (forward) and the partial dK, dV (backward) over through the tape -- the launch lasts as long as its largest
  *   item.  Only done when every item of the plan still gets a workgroup of its own (<= ncu items); needs a tape whose flag words
@@ -425,9 +427,9 @@ int re_sasrec_encoder_fwd(const float* x0, const float* E, int64_t R, const floa
  * re_sasrec_encoder_fwd_loss.
  *   D = 64 runs ONE TILE PER WORKGROUP, four waves per tile (csrc/enc_tile.hip: a tile's activations in registers, one 16-feature
  *   strip per wave, bf16 hi / mid split products on the XDL pipe -- results within the 1e-4 bound of the fp32 kernels', not their
- *   bits) whenever the plan says every tile can have a resident workgroup of its own (re_sasrec_batch_prep decides per batch:
- *   at most 1024 tiles, at most 256 of them tiles of sequences longer than 16 rows, no split_long), and the workgroup-per-item
- *   kernel otherwise; both are enqueued, one of them returns at once.  The tape's flag words must be zero before the first launch. */
+ *   bits) whenever the plan says so (re_sasrec_batch_prep decides per batch where it is the faster of the two -- see split_long there;
+ *   one workgroup per CU, each taking its block index's tile and then tiles from a counter), and the workgroup-per-item kernel
+ *   otherwise; both are enqueued, one of them returns at once.  The tape's flag words must be zero before the first launch. */
 int re_sasrec_encoder_step(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
                            const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
                            const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,

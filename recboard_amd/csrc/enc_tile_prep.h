@@ -61,7 +61,10 @@ template <int NS>
 __device__ __forceinline__ void tl_prep_thread(const SasrecParams& P, int L, uint32_t* __restrict__ wf, unsigned* __restrict__ epoch, int t) {
     constexpr int TL_D = 16 * NS, NQ = NS / 2, LQ = NS == 4 ? 1 : 2, LS = NS == 4 ? 2 : 3;
     constexpr int TL_FRAG_WORDS = TLC_FRAG_WORDS(NS);
-    if (t == 0) epoch[0] += 1u;   // the launch's epoch: what this step's hand-over flags are set to (the step kernel runs behind this one)
+    if (t == 0) {
+        epoch[0] += 1u;   // the launch's epoch: what this step's hand-over flags are set to (the step kernel runs behind this one)
+        epoch[1] = 0u;    // ... and its counter of tiles handed out beyond the grid (enc_tile_body.inc: the word behind the epoch)
+    }
     if (t < (TL_NPAR * L + 2) * TL_D) {   // the small parameters, gathered into one block (the step kernel then needs no parameter table)
         const int v = t / TL_D, cc = t % TL_D;
         const float* p;

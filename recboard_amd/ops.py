@@ -482,7 +482,7 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     if state is not None:
         _req(state, torch.int32, "state")
     have = pos is not None
-    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), int(bool(split)) | (0 if tile else 2),
+    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), int(bool(split)) | (0 if tile else 2) | (4 if tile == "always" else 0),
             _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None, _p(pb.neg) if copy and have else None,
             _p(pb.valid) if have else None, _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
             _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2))
@@ -540,7 +540,7 @@ def sasrec_sample_prep(inter, order, b0, B, S, sample_seed, sample_step, blob, s
     wargs = _weight_args(weights) + _loss_args(loss_acc)
     lib.check(lib.load().re_seq_train_sample_prep(_p(inter.ptr), _p(inter.items), _p(inter.sorted), _p(order), order.numel(), int(b0), inter.num_items,
                                                   int(sample_seed) & 0xFFFFFFFF, int(sample_step) & 0xFFFFFFFF, _p(users), B, S,
-                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2), _p(pb.seq), _p(pb.pos),
+                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2) | (4 if tile == "always" else 0), _p(pb.seq), _p(pb.pos),
                                                   _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel(), _p(state),
                                                   int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), *wargs, _stream()),
               "re_seq_train_sample_prep")
@@ -799,7 +799,7 @@ def next_prep(mail, blob, B, S, max_tiles=4, split=False, ncu=None, tile=True):
     (sasrec_batch_prep(..., blob=blob)'s outputs) by the tail launch this is handed to.  Keeps `mail` and `blob` alive."""
     _req(mail, torch.int64, "mail"); _req(blob, torch.uint8, "blob")
     pb = prep_views(blob, B, S, cached=True)
-    n = NextPrep(_p(mail), B, S, int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2), _p(pb.seq), _p(pb.pos),
+    n = NextPrep(_p(mail), B, S, int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2) | (4 if tile == "always" else 0), _p(pb.seq), _p(pb.pos),
                  _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel())
     n._keep = (mail, blob, pb)
     return n

@@ -256,7 +256,8 @@ class SASRecEngine:
 
     def _wave_step(self):
         """The training step may run one tile per workgroup (csrc/enc_tile.hip: D = 64 and 128; re_sasrec_encoder_step picks per batch)."""
-        return bool(self.D in (64, 128) and getattr(self, "tile_step", True) and self.fused_item_kernel and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
+        ok = bool(self.D in (64, 128) and getattr(self, "tile_step", True) and self.fused_item_kernel and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
+        return "always" if ok and getattr(self, "tile_step", True) == "always" else ok   # ("always": whatever the batch -- the plan's rule is a matter of speed)
 
     def _tail_word(self):
         if not hasattr(self, "_tail"):

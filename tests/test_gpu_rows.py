@@ -362,11 +362,12 @@ def test_sparse_adam_rows_small_matches_oracle(D, case):
 
 
 @pytest.mark.parametrize("D", [64, 128])
-@pytest.mark.parametrize("case", ["long_tiles_at_the_limit", "three_tile_chains", "singles_and_empties", "one_sequence", "maxlen_16", "maxlen_64"])
+@pytest.mark.parametrize("case", ["long_tiles_at_the_limit", "three_tile_chains", "singles_and_empties", "one_sequence", "maxlen_16", "maxlen_64",
+                                  "more_long_tiles_than_workgroups"])
 def test_tile_kernel_agrees_with_the_fp32_item_kernels(case, D):
     """The one-tile-per-workgroup step (bf16 split products, hand-over flags between the workgroups of a long sequence) on batch compositions
-    that stress the hand-over -- as many long tiles as may be resident (256), chains of three tiles, single-token and empty rows, a batch
-    of one, maxlen 16 (no chains at all) and 64 (four full tiles) -- against the CPU ORACLE with the same masks and pinned relu gates (loss
+    that stress the hand-over -- 192 long tiles, chains of three tiles, single-token and empty rows, a batch of one, maxlen 16 (no chains
+    at all) and 64 (four full tiles), more long tiles than there are resident workgroups (several passes per workgroup) -- against the CPU ORACLE with the same masks and pinned relu gates (loss
     to 2e-5, every gradient entry to 1e-4 of its tensor's largest), and against the fp32 workgroup-per-item kernels (L2).  The plan must
     have chosen the tile kernel; no hand-over time-out."""
     from recboard_amd.sasrec import SASRecEngine
@@ -374,7 +375,11 @@ def test_tile_kernel_agrees_with_the_fp32_item_kernels(case, D):
     N, L, p = 900, 2, 0.25
     S = {"maxlen_16": 16, "maxlen_64": 64}.get(case, 50)
     if case == "long_tiles_at_the_limit":
-        lens = [49] * 48 + list(rng.integers(1, 16, 120))                 # 48 x 4 = 192 long tiles (the limit: 3/4 of the CUs) + short ones
+        lens = [49] * 48 + list(rng.integers(1, 16, 120))                 # 48 x 4 = 192 long tiles + short ones
+    elif case == "more_long_tiles_than_workgroups":
+        # 220 x 4 + 90 x 3 = 1 150 long tiles + short ones for 256 resident workgroups: every workgroup makes several passes, chains cross the
+        # grid's end (tile 255 | 256 of one sequence are the last and the first workgroup, one pass apart)
+        lens = [49] * 220 + [int(x) for x in rng.integers(33, 49, 90)] + list(rng.integers(1, 17, 150))
     elif case == "three_tile_chains":
         lens = [int(x) for x in rng.integers(33, 49, 64)] + list(rng.integers(1, 17, 215))   # (192 long tiles)
     elif case == "singles_and_empties":
@@ -406,7 +411,8 @@ def test_tile_kernel_agrees_with_the_fp32_item_kernels(case, D):
                     q.copy_((0.05 * torch.randn(q.shape, generator=g)).cuda())
                 elif "LN" in k:
                     q.copy_((1.0 + 0.1 * torch.randn(q.shape, generator=g)).cuda())
-        m.tile_step = tile               # (off: the fp32 workgroup-per-item kernels, one launch at D = 128, two at D = 64)
+        m.tile_step = "always" if tile else False   # (off: the fp32 workgroup-per-item kernels, one launch at D = 128, two at D = 64; "always": also
+                                                    #  where the plan would hand the batch to them for speed -- more_long_tiles_than_workgroups)
         if D == 64:
             m.fused_item_kernel = tile
         m.split_long = False
