@@ -303,9 +303,10 @@ int re_route_bucket(const int64_t* idx, int64_t n, int64_t R, int64_t G, int64_t
  *   uint32[4]) = { seed, 0, bits(lr / (1 - beta1^step)), bits(1 / sqrt(1 - beta2^step)) } -- `state` doubles as `seed_dev` of the dropout entry points and, from word 2, as `hyper` of re_adam_step_dev.
  *   pos / neg may be NULL (evaluation: only the plan is wanted); then valid / count / rows_all rows 1, 2 are not written.
  *   split_long is a mask.  & 2: the plan must NOT hand the step to the one-tile-per-workgroup kernels (re_sasrec_encoder_step: hdr[7] stays 0).
- *   & 4: the plan MUST hand it to them (else it does so where they are the faster of the two: at most 1.5 tiles of sequences longer than 16 rows
- *   and at most 10 tiles in all per resident workgroup; the tile kernels take any number of tiles -- one workgroup per CU, the tiles beyond the grid
- *   handed out by a counter).
+ *   & 4: the plan MUST hand it to them where their grid allows.  Otherwise: batches of up to 2048 possible tiles (B <= 512 at S = 50) run a
+ *   workgroup per tile -- at most 1024 tiles, at most 3/4 of the CUs' worth of them tiles of sequences longer than 16 rows; larger batches the
+ *   looped form (one workgroup per CU, the tiles beyond the grid handed out by a counter: any number of tiles) where it is the faster of the
+ *   two: at most 1.5 tiles of long sequences and at most 10 tiles in all per resident workgroup.
  *   & 1: a sequence of 3 - 4 tiles becomes TWO work items (its first two tiles / the rest) that run in two workgroups at
  *   once and hand k, v (forward) and the partial dK, dV (backward) over through the tape -- the launch lasts as long as its largest
  *   item.  Only done when every item of the plan still gets a workgroup of its own (<= ncu items); needs a tape whose flag words

@@ -84,6 +84,9 @@ struct EncPlan {
     const int2* rowmap;
 };
 __host__ __device__ inline int64_t enc_plan_max_tiles(int64_t B, int64_t S) { return B * ((S + 15) / 16); }
+// which form of the tile kernels a launch of this shape uses (enc_tile_body.inc: enc_tile_step_k<LOOP>): batches of more than 2048 possible
+// tiles (B > 512 at S = 50) the looped one -- the plan (enc_plan_body.h) applies the matching rule
+__host__ __device__ inline bool enc_tile_looped(int64_t B, int64_t S) { return enc_plan_max_tiles(B, S) > 2048; }
 // rows of the vector-gradient slab in the backward's workspace: one per workgroup (<= 1024) or one per tile (enc_tile.hip)
 __host__ __device__ inline int64_t enc_slab_rows(int64_t B, int64_t S) { const int64_t mt = enc_plan_max_tiles(B, S); return mt > 1024 ? mt : 1024; }
 __host__ __device__ inline int64_t enc_plan_rowmap_word(int64_t B, int64_t S) { return (EP_HDR + enc_plan_max_tiles(B, S) + 1) / 2 * 2; }

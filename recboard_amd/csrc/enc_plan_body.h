@@ -327,15 +327,19 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
                 s_lay[5] = 0; s_lay[6] = 4 * n0; s_lay[7] = 4 * n0 + 3 * n1;                 // first tile of the long classes
                 s_lay[8] = 0; s_lay[9] = n0; s_lay[10] = n0 + n1;                            // first item of the long classes
                 hdr[0] = nlong + nsplit + nshort; hdr[1] = tlong + tshort; hdr[2] = nlong; hdr[3] = G; hdr[5] = nsplit; hdr[6] = ncu;
-                // [7]: 1 = the tile kernels run the step (enc_tile.hip: one resident workgroup per CU, each taking tiles blockIdx, blockIdx + grid,
-                // ...; a long sequence's tiles wait for each other across workgroups -- neighbours, at the same pass: no limit on their
-                // number).  (split_long & 2: the caller forbids it; & 4: the caller insists; split items are the workgroup-per-item kernels'
-                // device.)  Which of the two is faster was measured (scripts/large_batch.py, scripts/long_mix.py): the tile kernel while the long
-                // sequences' tiles are at most ~1.5 per workgroup (every further pass of chained tiles costs a chain: B = 512 with 20 % full-length
-                // sequences -- 500 long tiles -- is 11 % faster on the workgroup-per-item kernel, with 10 % -- 310 -- 6 % slower) and there are
-                // at most ~10 tiles per workgroup in all (Beauty-shaped batches of 1 024 / 2 048 / 8 192: tile kernel +10 % / +24 % / -6 %).
+                // [7]: 1 = the tile kernels run the step (enc_tile.hip; a long sequence's tiles wait for each other across workgroups).
+                // (split_long & 2: the caller forbids it; & 4: the caller insists; split items are the workgroup-per-item kernels' device.)
+                // One workgroup per CU either way.  The form of batches up to 2048 possible tiles (enc_tile_looped: a workgroup per tile,
+                // the grid covers them): <= 1024 tiles, the long sequences' -- laid out first: the first blocks of the grid -- at most three
+                // quarters of the CUs, so that every hand-over partner is resident from the start.  The looped form (resident workgroups,
+                // further tiles from a counter: any number of tiles) by speed (scripts/large_batch.py, scripts/long_mix.py): while the long
+                // sequences' tiles are at most ~1.5 per workgroup (every further pass of chained tiles costs a chain: 500 long tiles on 256
+                // workgroups are 11 % faster on the workgroup-per-item kernel, 310 are 6 % slower) and there are at most ~10 tiles per
+                // workgroup in all (Beauty-shaped batches of 1 024 / 2 048 / 8 192: tile kernel +10 % / +24 % / -6 %).
                 const int tg = ncu < 256 ? ncu : 256;
-                hdr[7] = (nsplit == 0 && !(split_long & 2) && ((split_long & 4) || (2 * tlong <= 3 * tg && tlong + tshort <= 10 * tg))) ? 1 : 0;
+                const bool fits = enc_tile_looped(B, S) ? ((split_long & 4) || (2 * tlong <= 3 * tg && tlong + tshort <= 10 * tg))
+                                                        : (tlong + tshort <= 1024 && ((split_long & 4) || tlong <= tg * 3 / 4));
+                hdr[7] = (nsplit == 0 && !(split_long & 2) && fits) ? 1 : 0;
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;
                 s_cb[0] = 0; s_cb[1] = n0; s_cb[2] = n0 + n1; s_cb[3] = nlong;       // long class k: s_cb[k] long sequences in front of it
             }

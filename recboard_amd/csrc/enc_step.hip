@@ -114,7 +114,8 @@ extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const floa
         // kernel is launched behind it and returns at once in that case -- the plan lives in device memory, so both are always enqueued
         uint32_t* wf = enc_tile_wf(gtape, B, S, L, D);
         float* xch = enc_tile_xch(wf, L, D);
-        const int tgrid = (int)(mt < ncu ? mt : ncu);   // (the resident workgroups: one per CU; each takes tiles blockIdx, blockIdx + grid, ...)
+        // (looped form: the resident workgroups, one per CU, further tiles from a counter; else a workgroup per tile, <= 1024 tiles by the plan's rule)
+        const int tgrid = enc_tile_looped(B, S) ? (int)(mt < ncu ? mt : ncu) : (int)(mt < 1024 ? mt : 1024);
         const int wgrid = (int)(mt < ncu ? mt : ncu);
         if (part & 1) {
             const int rcw = enc_tile_step_launch(D, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, tgrid, H, dx0, gtape, slab, scale, wf, xch,

@@ -140,11 +140,12 @@ static int tl_launch(KP prep_k, KS step_k, const SeEmbed& em, const int64_t* seq
 int enc_tile_step_launch(int64_t D, const SeEmbed& em, const int64_t* seq, int64_t B, int64_t S, int64_t L, const SasrecParams& P, float ds, uint32_t thresh,
                          uint32_t seed, const uint32_t* seed_dev, float* u, void* tape, const void* plan, int grid, const EncHead& H, float* dx0,
                          float* gtape, float* slab, float scale, uint32_t* wf, float* xch, int prep, hipStream_t s) {
+    const bool loop = enc_tile_looped(B, S);
     if (D == 64)
-        return tl_launch<4>(tl4::enc_tile_prep_k, tl4::enc_tile_step_k, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape,
+        return tl_launch<4>(tl4::enc_tile_prep_k, loop ? tl4::enc_tile_step_k<true> : tl4::enc_tile_step_k<false>, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape,
                             slab, scale, wf, xch, prep, s);
     if (D == 128)
-        return tl_launch<8>(tl8::enc_tile_prep_k, tl8::enc_tile_step_k, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape,
+        return tl_launch<8>(tl8::enc_tile_prep_k, loop ? tl8::enc_tile_step_k<true> : tl8::enc_tile_step_k<false>, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, grid, H, dx0, gtape,
                             slab, scale, wf, xch, prep, s);
     return RE_EUNSUPPORTED;
 }

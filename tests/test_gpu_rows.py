@@ -379,7 +379,8 @@ def test_tile_kernel_agrees_with_the_fp32_item_kernels(case, D):
     elif case == "more_long_tiles_than_workgroups":
         # 220 x 4 + 90 x 3 = 1 150 long tiles + short ones for 256 resident workgroups: every workgroup makes several passes, chains cross the
         # grid's end (tile 255 | 256 of one sequence are the last and the first workgroup, one pass apart)
-        lens = [49] * 220 + [int(x) for x in rng.integers(33, 49, 90)] + list(rng.integers(1, 17, 150))
+        # (+ empty rows: more than 512 sequences -- the looped form of the kernel, enc_common.h: enc_tile_looped)
+        lens = [49] * 220 + [int(x) for x in rng.integers(33, 49, 90)] + list(rng.integers(1, 17, 150)) + [0] * 100
     elif case == "three_tile_chains":
         lens = [int(x) for x in rng.integers(33, 49, 64)] + list(rng.integers(1, 17, 215))   # (192 long tiles)
     elif case == "singles_and_empties":
