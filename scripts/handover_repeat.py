@@ -20,6 +20,7 @@ ap.add_argument("--pipelined", type=int, default=0)
 ap.add_argument("--paranoid", type=int, default=0)
 ap.add_argument("--sync", type=int, default=0, help="1: torch.cuda.synchronize() in front of every step")
 ap.add_argument("--buffers", type=int, default=0, help="1: also compare the tape / contribution-row buffers of every repetition")
+ap.add_argument("--B", type=int, default=0, help="sequences per batch (default: the bench's 512; more than 512: the looped form of the tile kernel)")
 a = ap.parse_args()
 import torch  # noqa: E402
 
@@ -33,7 +34,7 @@ if a.paranoid:
     assert L.re_dbg_tile_paranoid(a.paranoid) == 0
 import bench  # noqa: E402
 from recboard_amd.sasrec import SASRecEngine  # noqa: E402
-cfg = bench.BEAUTY
+cfg = dict(bench.BEAUTY, B=a.B) if a.B else bench.BEAUTY
 bs = [tuple(torch.from_numpy(x).cuda() for x in b) for b in bench.synth_batches(cfg, 8, 1)]
 m = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=0.0, weight_decay=0.0, seed=1)
 A = m.arena

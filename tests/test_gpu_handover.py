@@ -19,14 +19,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("fenced", [0, 1])
-def test_every_handed_over_block_arrives_as_it_was_published(fenced):
+@pytest.mark.parametrize("fenced,B,reps", [(0, 512, 800), (1, 512, 800), (0, 2048, 240)])
+def test_every_handed_over_block_arrives_as_it_was_published(fenced, B, reps):
+    """B = 512: the workgroup-per-tile form of the kernel; B = 2048 (951 tiles on 256 workgroups, ~380 of them chained): the looped form, whose
+    tiles beyond the grid are handed out by a counter."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     lib = os.path.join(ROOT, "recboard_amd", "librecengine_hov.so")
     assert os.path.exists(lib), "librecengine_hov.so is missing: __graft_entry__.build() makes it (make -C recboard_amd/csrc hov)"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "handover_repeat.py"), "--lib", "hov", "--lds-kb", "84", "--fenced", str(fenced),
-                        "--reps", "800", "--cycle", "8"], capture_output=True, text=True, timeout=600)
+                        "--reps", str(reps), "--cycle", "8", "--B", str(B)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     m = re.search(r"checksum mismatches \[forward k/v, backward k/v, inbox\]: \[(\d+), (\d+), (\d+)\] of checks \[(\d+), (\d+), (\d+)\] \| LDS canary words "
                   r"changed: (\d+) \| LDS parameter words changed: (\d+)", r.stdout)
@@ -35,7 +37,7 @@ def test_every_handed_over_block_arrives_as_it_was_published(fenced):
     assert min(checks) > 10000, checks                     # (the eight batches do hand rows over: ~140 checks per step)
     assert mism == [0, 0, 0] and canary == 0 and par == 0, (mism, canary, par)
     d = re.search(r": (\d+) of (\d+) repetitions differ from the first", r.stdout)
-    assert d and int(d.group(1)) == 0 and int(d.group(2)) == 799, r.stdout[-500:]
+    assert d and int(d.group(1)) == 0 and int(d.group(2)) == reps - 1, r.stdout[-500:]
 
 
 @pytest.mark.parametrize("engine", ["dense", "large"])
