@@ -61,8 +61,9 @@ struct TailPrep {
 };
 static_assert(PL_NT == SO_NT && PL_NT == SA_NT, "the preparation jobs are written for the tail launches' workgroup size");
 
-// ---- weight-gradient jobs, two per ticket: matrix jobs q = 2 t + half -> (block, matrix, split) = (q / 144, q / 24 % 6, q % 24), then the
-//      position-table jobs (144 strides of the (position, chunk) list) -- both halves of a workgroup always run the same kind
+// ---- weight-gradient jobs.  D = 64: two per ticket: matrix jobs q = 2 t + half -> (block, matrix, split) = (q / 144, q / 24 % 6, q % 24); D = 128:
+//      one per ticket, run by the whole workgroup: (t / 72, t / 12 % 6, t % 12).  Then the position-table jobs (144 strides of the (position,
+//      chunk) list, two per ticket) -- both halves of a workgroup always run the same kind
 __shared__ int s_job;   // the workgroup's current ticket
 
 // The queue's counter is one address behind an agent-scope atomic: the first ticket's round trip (and the other 255 workgroups' turns at the
@@ -87,8 +88,11 @@ template <int D>
 __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP, float* lds, int n_tiles, bool has_early = false) {
     const int tid = threadIdx.x, half = tid >> 9, ht = tid & 511;
     float* jl = lds + half * wg_job_lds_floats<D>();
-    constexpr int PER_PLANE = WG_NSPLIT * EG_NMAT;
-    const int n_mat = J.L * PER_PLANE / 2, n_pos = J.ppart ? PER_PLANE / 2 : 0;
+    constexpr int WG_NSPLIT = wg_nsplit(D);
+    constexpr int PER_PLANE = WG_NSPLIT * EG_NMAT;      // matrix jobs of a block
+    constexpr bool WHOLE = D == 128;                    // a matrix job is run by the whole workgroup (enc_wgrad_job.h: wg_nsplit), not two by its halves
+    constexpr int POS_GROUPS = 144;                     // the position jobs are dealt to this many 512-thread groups (two per ticket)
+    const int n_mat = WHOLE ? J.L * PER_PLANE : J.L * PER_PLANE / 2, n_pos = J.ppart ? POS_GROUPS / 2 : 0;
     const int n_prep = TP.mail ? 1 + TP.n_ew : 0;
     int jn = 0;
     for (;;) {
@@ -114,10 +118,14 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
         t -= n_prep;
         if (t < n_mat) {
             if (jn == 1) TJ_STAMP(2);
-            const int q = 2 * t + half;
-            wg_matrix_job<D>(ht, jl, q / PER_PLANE, (q / WG_NSPLIT) % EG_NMAT, q % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
+            if constexpr (WHOLE) {
+                wg_matrix_job<D, SO_NT>(tid, lds, t / PER_PLANE, (t / WG_NSPLIT) % EG_NMAT, t % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
+            } else {
+                const int q = 2 * t + half;
+                wg_matrix_job<D>(ht, jl, q / PER_PLANE, (q / WG_NSPLIT) % EG_NMAT, q % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
+            }
         } else {
-            wg_pos_job<D>(ht, jl, 2 * (t - n_mat) + half, PER_PLANE, J.B, J.S, J.seq, J.contrib, J.ppart);
+            wg_pos_job<D>(ht, jl, 2 * (t - n_mat) + half, POS_GROUPS, J.B, J.S, J.seq, J.contrib, J.ppart);
         }
     }
 }
@@ -163,12 +171,19 @@ template <int D, int HS>
 __global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
     re_kernarg_warm<re_kernarg_bytes(&enc_tail_sparse_k<D, HS>)>();
+#ifdef TAIL_PROFILE
+    if (threadIdx.x < TAIL_MARKS && blockIdx.x < TAIL_MARK_WGS) g_tail_marks[blockIdx.x * TAIL_MARKS + threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
+    TAIL_MARK(0, TAIL_NOW());
     tail_spans(TP, lds);
     // the tape's hand-over error word (a tile waited for a partner's rows in vain: this step's gradients are wrong): the table's rows stay as
     // they are -- read here, on the device, every step; the epoch's check_handover() reports it
     const unsigned gated = reinterpret_cast<const unsigned*>(J.tape + J.T.off_FLAGS)[(J.NR / 16) * EP_FLAG_WORDS];
     if (!gated) sa_body<1, HS, int32_t>(P, reinterpret_cast<unsigned char*>(lds));
+    TAIL_MARK(1, TAIL_NOW());
     tail_jobs<D>(J, TP, lds, enc_plan_view(J.plan, J.B, J.S).hdr[1]);
+    TAIL_MARK(15, TAIL_NOW());
 }
 
 size_t enc_wgrad_part_floats(int64_t D, int64_t L);

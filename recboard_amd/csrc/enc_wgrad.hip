@@ -8,7 +8,7 @@
 //   gradient-tape order: 0 dO2 (x HR -> W2)  1 dH (x Y -> W1)  2 dX1 (x O -> Wo)  3 dQ (x A -> Wq)  4 dK (x X -> Wk)  5 dV (x X -> Wv)
 #include "enc_wgrad_job.h"
 
-size_t enc_wgrad_part_floats(int64_t D, int64_t L) { return (size_t)L * EG_NMAT * WG_NSPLIT * D * D; }
+size_t enc_wgrad_part_floats(int64_t D, int64_t L) { return (size_t)L * EG_NMAT * WG_NSPLIT_MAX * D * D; }   // (sized for the most splits any width uses)
 
 template <int D>
 __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tape, EncTape T, const float* __restrict__ gtape, int64_t NR,
@@ -65,7 +65,7 @@ struct EncGradDst {
     float* p[SE_MAX_BLOCKS][14];  // per block: ABI order of the 12 block gradients, then g_last_w, g_last_b (last block only)
 };
 
-// blocks [0, nmat_blocks): 256 elements of the L * 6 * D * D weight gradients each (sum of the WG_NSPLIT partials);
+// blocks [0, nmat_blocks): 256 elements of the L * 6 * D * D weight gradients each (sum of the wg_nsplit(D) partials);
 // the rest: 64 columns of one (block, vector) each, summed over the slabs of the workgroups that had work (4 waves x fixed order).
 __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict__ part, const float* __restrict__ slab, int nwg,
                                                          const void* __restrict__ planp, int B, int S, int D, int L, EncGradDst dst,
@@ -90,17 +90,18 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(const float* __restrict
         const int dd = D * D;
         if (e >= (int64_t)L * EG_NMAT * dd) return;
         const int lm = (int)(e / dd), off = (int)(e % dd);
-        const float* p = part + (int64_t)lm * WG_NSPLIT * dd + off;
+        const int nsplit = wg_nsplit(D);
+        const float* p = part + (int64_t)lm * nsplit * dd + off;
         const int l = lm / EG_NMAT, m = lm % EG_NMAT;
         float* const* P = dst.p[l];
         float* d = (m == 0) ? P[10] : (m == 1) ? P[8] : (m == 2) ? P[4] : P[2] + (m - 3) * dd;
         const EgPre pre = eg_pre(AD, d + off);
-        float v[WG_NSPLIT];
+        float v[WG_NSPLIT_MAX];
 #pragma unroll
-        for (int i = 0; i < WG_NSPLIT; ++i) v[i] = p[(int64_t)i * dd];
+        for (int i = 0; i < WG_NSPLIT_MAX; ++i) v[i] = p[(int64_t)(i < nsplit ? i : 0) * dd];   // (clamped, unconditional)
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < WG_NSPLIT; ++i) s += v[i];
+        for (int i = 0; i < WG_NSPLIT_MAX; ++i) s += i < nsplit ? v[i] : 0.f;                    // (x + 0 = x: the partials in split order)
         eg_put(AD, d + off, s, pre);
         return;
     }
@@ -181,7 +182,7 @@ int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tap
     if (D != 64 && D != 128) return RE_EUNSUPPORTED;
     const EncTape T = enc_tape_layout(B, S, D, L);
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
-    const dim3 grid(WG_NSPLIT, EG_NMAT, (unsigned)(L + (dPtab ? 1 : 0)));
+    const dim3 grid((unsigned)wg_nsplit((int)D), EG_NMAT, (unsigned)(L + (dPtab ? 1 : 0)));
     if (D == 128) {
         using C = EC<128>;
         const size_t ldsb = (size_t)wg_job_lds_floats<128>() * sizeof(float);

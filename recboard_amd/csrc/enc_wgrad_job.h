@@ -6,9 +6,12 @@
 #include "enc_common.h"
 #include "enc_tile_prep.h"
 
-#ifndef WG_NSPLIT
-#define WG_NSPLIT 24
-#endif
+// row splits of a matrix's contraction (partials per matrix): 24 at D = 64; 12 at D = 128 -- there a job of the 1024-thread tail launches is
+// run by the WHOLE workgroup (sixteen waves, 4 accumulator tiles and one staging unit a thread instead of 8 and 2): two 512-thread jobs side by
+// side, as at D = 64, need more than the 128 registers such a thread has and spilled into scratch memory inside the stage loop (a stage 9 - 14 k
+// cycles instead of ~4 k: config 5's tail 47 us, scripts/tail_phases.py large).  Half as many splits of twice the rows keep the ticket count.
+__host__ __device__ constexpr int wg_nsplit(int D) { return D == 128 ? 12 : 24; }
+#define WG_NSPLIT_MAX 24
 #define WG_CH 4   // row tiles per LDS stage
 #ifndef WG_STAMP
 #define WG_STAMP(i) do { } while (0)   // (enc_tail.hip's profile build: shader-clock stamps inside a job)
@@ -24,10 +27,17 @@ __host__ __device__ constexpr int wg_job_lds_floats() { return 2 * 16 * WG_CH * 
 // MFMAs per CU were what a job took (7.7 of the ~8 us a stage took at D = 128).  Both operands are split where they are STAGED -- once per
 // element, not once per wave that reads it: a thread fetches the same four columns of two consecutive rows and writes them as four
 // {row 2p, row 2p + 1} bf16 pairs per plane, so that a lane's MFMA operand (eight consecutive rows of one column) is four words of a column.
-template <int D>
+template <int D, int NT>
+struct WgCfg {
+    static constexpr int NS = EC<D>::NS, WR = (NT / 64) / EC<D>::NS;   // column strips, wave row groups
+};
+// NT: threads of the group that runs the job (tid: 0 .. NT - 1): 512, or 1024 (enc_tail.hip at D = 128)
+template <int D, int NT = EC<D>::NT>
 __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m, int split, const float* __restrict__ tape, const EncTape& T,
                                               const float* __restrict__ gtape, int64_t NR, int n_tiles, float* __restrict__ part) {
-    using C = EC<D>;
+    using C = WgCfg<D, NT>;
+    static_assert(C::WR >= 1 && C::NS % C::WR == 0, "waves = strips x row groups");
+    constexpr int WG_NSPLIT = wg_nsplit(D);
     constexpr int RTW = C::NS / C::WR;   // output row tiles per wave
     constexpr int RSW = D + 4;           // words of a row pair (+ 4: the four lane groups of a fragment read land in four bank quarters)
     constexpr int NPAIR = 16 * WG_CH / 2;
@@ -54,7 +64,7 @@ __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m,
     // requested as soon as its registers are free.  PF = 1 (the next stage in flight under this stage's products) is what the registers of
     // enc_tail_k allow: PF = 3 at D = 64 -- a Beauty-shaped job as ONE round trip -- pushed 36 registers of the 128 a thread of a
     // 1024-thread workgroup has into scratch memory, and a job took 38 k cycles instead of 24 k (scripts/tail_phases.py, round 4).
-    constexpr int NP = NPAIR * (D / 4) / C::NT;   // (row pair, four columns) units per thread: 1 at D = 64, 2 at D = 128
+    constexpr int NP = NPAIR * (D / 4) / NT;      // (row pair, four columns) units per thread: 1 at D = 64, 2 at D = 128 (1 with 1024 threads)
     constexpr int PF = 1;
     f32x4 ra[PF][NP][2], rb[PF][NP][2];   // (native vectors and a macro: HIP's float4 struct arrays / arrays captured by a lambda stay in scratch memory)
 #define WG_FETCH(Q, TC)                                                                                         \
@@ -63,7 +73,7 @@ __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m,
         const int nf_ = ntc_ > 0 ? 16 * ntc_ * (D / 4) : 1;                                                     \
         const int tc_ = ntc_ > 0 ? (TC) : t0;   /* (a stage behind the split's rows: any valid address, its values are not used) */ \
         _Pragma("unroll") for (int j = 0; j < NP; ++j) {                                                        \
-            const int u_ = j * C::NT + tid, p_ = u_ / (D / 4), c4_ = u_ % (D / 4);                              \
+            const int u_ = j * NT + tid, p_ = u_ / (D / 4), c4_ = u_ % (D / 4);                              \
             _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                     \
                 int f = (2 * p_ + e) * (D / 4) + c4_;                                                           \
                 f = f < nf_ ? f : nf_ - 1;   /* clamped, unconditional: a predicated load is waited for on the spot */ \
@@ -89,7 +99,7 @@ __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m,
             enc_sync();
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const int u = j * C::NT + tid, p = u / (D / 4), c4 = u % (D / 4);
+                const int u = j * NT + tid, p = u / (D / 4), c4 = u % (D / 4);
                 const bool live = 2 * p < 16 * ntc;      // (rows come in pairs: 16 ntc is even; pairs behind the stage's rows are zero)
                 tl_u32x4 h, md, h2, md2;
 #pragma unroll
@@ -150,7 +160,10 @@ __device__ __forceinline__ void wg_pos_job(int tid, float* lds, int j0, int jste
     const int col = tid % D, rg = tid / D;
     // (the next job's loads are in flight while this one is reduced: a group has ~3 jobs, each a memory round trip)
     constexpr int NQP = 64 / C::CG;
-    int64_t sv[NQP], svn[NQP];
+    // (an item id's LOW word: ids are < 2^31, and only "is there a token" is asked -- half the registers of the 64-bit ids, which at D = 128,
+    //  16 rows a thread and two jobs in flight, did not fit the tail launches' 128)
+    const int32_t* __restrict__ seq_lo = reinterpret_cast<const int32_t*>(seq);
+    int32_t sv[NQP], svn[NQP];
     float cv[NQP], cvn[NQP];
 #define WG_PJOB(J, SV, CV)                                                              \
     do {                                                                                \
@@ -159,7 +172,7 @@ __device__ __forceinline__ void wg_pos_job(int tid, float* lds, int j0, int jste
             int b = ch_ * 64 + rg + C::CG * q;                                          \
             const bool in_ = b < B;                                                     \
             b = in_ ? b : B - 1;   /* clamped, unconditional loads */                   \
-            const int64_t sx = seq[(int64_t)b * S + p_];                                \
+            const int32_t sx = seq_lo[2 * ((int64_t)b * S + p_)];                       \
             const float cx = contrib[((int64_t)b * S + p_) * D + col];                  \
             SV[q] = in_ ? sx : 0;                                                       \
             CV[q] = cx;                                                                 \

@@ -15,8 +15,13 @@ L = lib.load()
 import bench  # noqa: E402
 from recboard_amd.sasrec import SASRecEngine  # noqa: E402
 cfg = bench.BEAUTY
+LARGE = len(sys.argv) > 1 and sys.argv[1] == "large"      # the sparse tail of a large-table step at D = 128 (config 5's, on a 4 M-row table)
+if LARGE:
+    from recboard_amd.large import SASRecLargeTableEngine
+    cfg = dict(cfg, items=4_000_000, D=128)
 bs = [tuple(torch.from_numpy(x).cuda() for x in b) for b in bench.synth_batches(cfg, 8, 1)]
-m = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=1)
+m = (SASRecLargeTableEngine(cfg["items"], 50, 128, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=1, table_init="counter") if LARGE else
+     SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=1))
 for i in range(40):
     m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8])
 torch.cuda.synchronize()
