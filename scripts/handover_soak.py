@@ -35,7 +35,7 @@ def child(a):
             assert L.re_dbg_tile_fill(int(a.fill, 0)) == 0
     import bench
     from recboard_amd.sasrec import SASRecEngine
-    cfg = bench.BEAUTY
+    cfg = dict(bench.BEAUTY, B=a.B) if a.B else bench.BEAUTY
     bs = [tuple(torch.from_numpy(x).cuda() for x in b) for b in bench.synth_batches(cfg, 8, 1)]
     m = SASRecEngine(cfg["items"], 50, a.dim, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=1)
     for i in range(a.steps):
@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--pipelined", type=int, default=1)
     ap.add_argument("--fill", default="", help="bit pattern every workgroup fills its LDS with first (0x7fc00000 = NaN), diagnostic builds")
     ap.add_argument("--configs", default="0:60,0:84,1:60,1:84")
+    ap.add_argument("--B", type=int, default=0, help="sequences per batch (default: the bench's 512; more: the looped form of the tile kernel)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     if a.child:
@@ -72,7 +73,7 @@ def main():
         runs = []
         for i in range(2 * a.pairs):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--lib", a.lib, "--fenced", str(fenced), "--lds-kb", str(kb),
-                                "--steps", str(a.steps), "--dim", str(a.dim), "--pipelined", str(a.pipelined)] + (["--fill", a.fill] if a.fill else []), capture_output=True, text=True, timeout=600)
+                                "--steps", str(a.steps), "--dim", str(a.dim), "--pipelined", str(a.pipelined), "--B", str(a.B)] + (["--fill", a.fill] if a.fill else []), capture_output=True, text=True, timeout=600)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("SOAK ")]
             if r.returncode != 0 or not line:
                 print(r.stdout[-2000:], r.stderr[-2000:])
@@ -90,7 +91,7 @@ def main():
     if a.out:
         with open(a.out, "w") as f:
             json.dump({"what": "scripts/handover_soak.py: [forward k / v, backward k / v, dK / dV inbox] checks and checksum mismatches summed over all processes",
-                       "lib": a.lib, "dim": a.dim, "configs": report}, f, indent=1)
+                       "lib": a.lib, "dim": a.dim, "B": a.B or 512, "configs": report}, f, indent=1)
 
 
 if __name__ == "__main__":

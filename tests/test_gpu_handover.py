@@ -40,6 +40,32 @@ def test_every_handed_over_block_arrives_as_it_was_published(fenced, B, reps):
     assert d and int(d.group(1)) == 0 and int(d.group(2)) == reps - 1, r.stdout[-500:]
 
 
+def test_looped_tile_kernel_hands_tiles_out_without_deadlock():
+    """Batches of 2 048 Beauty-shaped sequences run the looped form of the tile kernel: 951 tiles, ~380 of them chained, on 256 resident
+    workgroups; whoever is done takes the next tile from a counter.  600 pipelined steps: no hand-over time-out (a version that took the
+    ticket at the START of a tile -- holding a tile it could not start yet -- deadlocked in one 200-step run of three), and a second engine
+    ends in the same state to the bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import hashlib
+    sys.path.insert(0, ROOT)
+    import bench
+    from recboard_amd.sasrec import SASRecEngine
+    cfg = dict(bench.BEAUTY, B=2048)
+    bs = [tuple(torch.from_numpy(x).cuda() for x in b) for b in bench.synth_batches(cfg, 8, 1)]
+    ends = []
+    for _ in range(2):
+        m = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=1)
+        assert int(m.prepare_batch(*bs[0]).plan.view(torch.int32)[7]) == 1
+        for i in range(300):
+            m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8])
+        torch.cuda.synchronize()
+        m.check_handover()
+        ends.append(hashlib.sha1(m.arena.data.cpu().numpy().tobytes()).hexdigest())
+        del m
+    assert ends[0] == ends[1]
+
+
 @pytest.mark.parametrize("engine", ["dense", "large"])
 def test_a_recorded_handover_timeout_gates_both_optimizers_on_the_device(engine):
     """The tape's error word (a tile waited for its partner's rows in vain: csrc/enc_tile_body.inc tl_flag_wait) is read ON THE DEVICE by the
