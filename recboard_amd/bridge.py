@@ -29,6 +29,7 @@ After adoption every module parameter IS the arena view of its name (`p.data = v
 `state_dict()` and checkpoints read what the engine trains; the learning rate of an epoch is read from `coach.optimizer.param_groups`."""
 import copy
 import math
+import os
 import warnings
 
 import torch
@@ -38,7 +39,11 @@ from .deepfm import DeepFMEngine
 from .gen import LightGCNEngine, MFEngine
 from .sasrec import SASRecEngine
 
-GRAD_TOL = 1e-3        # engine gradient vs the script's own step in double precision, relative to the tensor's largest entry
+GRAD_TOL = 2e-2        # engine gradient vs the script's own step in double precision, per tensor in the L2 sense (worst entry: 10 x).  Measured
+                       # (scripts/probe_margin.py, B = 512, twelve random initialisations of the genuine SASRec script: 336 tensors): median 7e-6,
+                       # largest 6.2e-3 (the FFN's first map: a relu unit within rounding of zero falls on the other side in one of the two
+                       # arithmetics and moves its whole row), worst entry 3e-2 of the tensor's largest; a look-alike with other arithmetic
+                       # (layer-normed keys): median 0.26, up to 1.0.  1e-3 refused the genuine script in two fresh processes of ten.
 GRAD_TOL_F32 = 2e-2    # ... vs the script's fp32 step when the module does not run in double (ROCm aten's fp32 GEMMs alone are off by up to 7e-3)
 UPDATE_TOL = 2e-4      # engine update vs torch's Adam formula on the engine's gradient, relative to lr
 
@@ -654,11 +659,16 @@ def _probe(coach, ad):
     lr, (b1, b2) = ad.spec.lr, ad.spec.betas
     views, grads = ad.named_views(), ad.named_grads()
     worst = ("", 0.0)
+    # the model's gradient as a whole: a tensor whose gradient is a millionth of it is rounding residue in BOTH arithmetics (a Linear bias in
+    # front of a BatchNorm: mathematically zero, 1e-19 in double precision, 1e-10 .. 1e-9 in either fp32 form -- and the script's own residue,
+    # measured once, is no bound on the engine's: 6.5e-10 against 4 x 1.5e-10 refused a DeepFM in about one fresh process of six)
+    g_all_max = max(float(g_ref[k].abs().max()) for k in views)
+    g_all_n2 = math.sqrt(sum(float(g_ref[k].double().norm()) ** 2 for k in views))
     for k, v in views.items():
         ge, gr = grads[k].detach().reshape(-1).double(), g_ref[k].reshape(-1).double()
         scale = float(gr.abs().max())
         err = float((ge - gr).abs().max())
-        # allowed: GRAD_TOL in the L2 sense and 20 x GRAD_TOL for the worst entry (a relu pre-activation within rounding of zero may fall on the
+        # allowed: GRAD_TOL in the L2 sense and 10 x GRAD_TOL for the worst entry (a relu pre-activation within rounding of zero may fall on the
         # other side in one of two fp32 arithmetics; that unit's gradient entries then move by its whole contribution -- a handful among
         # ~10^5 - 10^6 pre-activations of a batch) -- or, where the script's OWN fp32 arithmetic is noisier than that (sums that cancel: a
         # Linear bias behind a BatchNorm has a zero gradient; ROCm aten's fp32 GEMMs), a few times the script's own distance from its
@@ -668,8 +678,11 @@ def _probe(coach, ad):
         noise = 0.0 if d32 is None else float(d32.abs().max())
         noise2 = 0.0 if d32 is None else float(d32.norm())
         err2, n2 = float((ge - gr).norm()), float(gr.norm())
-        tol = max(20.0 * tol_rel * scale, 4.0 * noise) + 1e-12
-        tol2 = max(tol_rel * n2, 4.0 * noise2) + 1e-12
+        tol = max(10.0 * tol_rel * scale, 4.0 * noise, 1e-6 * g_all_max) + 1e-12
+        tol2 = max(tol_rel * n2, 4.0 * noise2, 1e-6 * g_all_n2) + 1e-12
+        if os.environ.get("RECENGINE_PROBE_REPORT"):      # (diagnostic: every tensor's distance, scripts/probe_margin.py)
+            print(f"PROBE {type(module).__name__} {k}: L2 {err2 / max(n2, 1e-300):.3e} of the tensor's, worst entry {err / max(scale, 1e-300):.3e} of its largest, "
+                  f"noise x4 L2 {4 * noise2 / max(n2, 1e-300):.1e}", flush=True)
         if not math.isfinite(err) or err > tol or err2 > tol2:
             raise Refused(f"gradient of {k} differs from the script's own step: |diff| max {err:.3e} / L2 {err2:.3e} against |grad| max {scale:.3e} / L2 "
                           f"{n2:.3e} (the script's own fp32 rounding there: max {noise:.1e})")

@@ -263,4 +263,5 @@ def test_gen_and_pred_epochs_through_the_coach_cost_at_most_1p3x_the_bare_engine
                 best[name] = min(best.get(name, 1e9), time.perf_counter() - t0)
             if rnd >= 2 and best["coach"] <= 1.3 * best["bare"]:
                 break
+        print(what, "coach / bare epoch time:", round(best["coach"] / best["bare"], 3), best)
         assert best["coach"] <= 1.3 * best["bare"], (what, best)

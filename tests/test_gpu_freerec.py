@@ -100,4 +100,5 @@ def test_coach_epoch_costs_at_most_1p3x_the_bare_engine_loop():
             best[name] = min(best.get(name, 1e9), time.perf_counter() - t0)
         if rnd >= 2 and best["coach"] <= 1.3 * best["bare"]:
             break
+    print("coach / bare epoch time:", round(best["coach"] / best["bare"], 3), best)
     assert best["coach"] <= 1.3 * best["bare"], best
