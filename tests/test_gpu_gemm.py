@@ -22,8 +22,8 @@ def test_gemm_matches_float64(ops, M, N, K, tA, tB):
     A = torch.randn((K, M) if tA else (M, K), device="cuda", generator=g)
     B = torch.randn((N, K) if tB else (K, N), device="cuda", generator=g)
     out = ops.gemm(A, B, tA, tB)
-    ref = ((A.T if tA else A).double() @ (B.T if tB else B).double())
-    err = (out.double() - ref).abs().max().item()
+    ref = ((A.T if tA else A).cpu().double() @ (B.T if tB else B).cpu().double())     # (on the host: no second GPU GEMM library in the comparison)
+    err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 2e-6 * K ** 0.5 * 10 + 1e-5, err
     assert torch.equal(out, ops.gemm(A, B, tA, tB))      # deterministic (split-K slabs are reduced in order)
 
