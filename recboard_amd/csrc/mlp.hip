@@ -13,20 +13,40 @@
 // Column reductions over [M, N] run on a (N/64) x ML_CHUNKS grid: block (bx, by) reduces rows [by*rpc, (by+1)*rpc) of 64
 // columns (thread (c, rg) takes rows rg, rg+4, ... of the chunk: coalesced over c), the four row groups are combined in
 // LDS in a fixed order, and a finalize kernel merges the ML_CHUNKS partials per column in chunk order -> deterministic.
-#define ML_CHUNKS 32
+#define ML_CHUNKS 64
 
-template <class F>
+struct MlNoPost { __device__ __forceinline__ void operator()(int64_t, int64_t, float) const {} };
+template <class F, class P = MlNoPost>
 __device__ __forceinline__ void col_reduce2(int64_t M, int64_t N, F f, float& o1, float& o2, bool& owner, int64_t& col,
-                                            int64_t& m_begin, int64_t& m_end) {
+                                            int64_t& m_begin, int64_t& m_end, P post = P{}) {
     __shared__ float r1[256], r2[256];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     col = (int64_t)blockIdx.x * 64 + c;
     const int64_t rpc = (M + gridDim.y - 1) / gridDim.y;
     m_begin = (int64_t)blockIdx.y * rpc;
     m_end = (m_begin + rpc < M) ? m_begin + rpc : M;
+    // (four rows a trip, their loads independent of each other -- one row a trip is a memory round trip per row: 29 us for the 13 MB of a
+    //  [4096, 400] backward pass -- added in row order)
     float a = 0.f, b = 0.f;
-    if (col < N)
-        for (int64_t m = m_begin + rg; m < m_end; m += 4) { float x, y; f(m, col, x, y); a += x; b += y; }
+    if (col < N) {
+        int64_t m = m_begin + rg;
+        for (; m + 28 < m_end; m += 32) {     // (eight rows a trip)
+            float x[8], y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f(m + 4 * i, col, x[i], y[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) post(m + 4 * i, col, x[i]);      // (a caller's stores: behind the group's loads)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a += x[i]; b += y[i]; }
+        }
+        for (; m + 12 < m_end; m += 16) {
+            float x0, y0, x1, y1, x2, y2, x3, y3;
+            f(m, col, x0, y0); f(m + 4, col, x1, y1); f(m + 8, col, x2, y2); f(m + 12, col, x3, y3);
+            post(m, col, x0); post(m + 4, col, x1); post(m + 8, col, x2); post(m + 12, col, x3);
+            a += x0; b += y0; a += x1; b += y1; a += x2; b += y2; a += x3; b += y3;
+        }
+        for (; m < m_end; m += 4) { float x, y; f(m, col, x, y); post(m, col, x); a += x; b += y; }
+    }
     r1[threadIdx.x] = a; r2[threadIdx.x] = b;
     __syncthreads();
     owner = rg == 0 && col < N;
@@ -55,24 +75,39 @@ __global__ __launch_bounds__(256) void bn_stats_partial_k(const float* __restric
     }
 }
 
-// Chan's parallel-variance merge of the chunk (mean, M2) pairs, in chunk order; then (mean, rstd) + running statistics
+// Chan's parallel-variance merge of the chunk (mean, M2, count) triples; then (mean, rstd) + running statistics.  One WAVE per column: lane b
+// holds chunk b's triple and the 64 lanes merge in a fixed butterfly (lane ^ 1, ^ 2, ... ^ 32: the same tree for every column and every run) --
+// a thread per column walking the chunks one after the other is a chain of 64 dependent merges with two divisions each (12 - 14 us for 400
+// columns on two workgroups; 0.83 ms step: DeepFM's three BatchNorms call it every step).
+static_assert(ML_CHUNKS <= 64, "one lane per chunk");
 __global__ __launch_bounds__(256) void bn_stats_final_k(const float* __restrict__ partial, int chunks, int64_t M, int64_t N, float eps,
                                                         float momentum, float* __restrict__ stats, float* __restrict__ run_mean,
                                                         float* __restrict__ run_var) {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;                                   // (whole waves)
     const int64_t rpc = (M + chunks - 1) / chunks;
-    float mean = 0.f, m2 = 0.f, cnt = 0.f;
-    for (int b = 0; b < chunks; ++b) {
-        const int64_t mb = (int64_t)b * rpc;
-        if (mb >= M) break;
-        const float nb = (float)(((mb + rpc < M) ? mb + rpc : M) - mb);
-        const float mub = partial[((int64_t)b * 2 + 0) * N + n], m2b = partial[((int64_t)b * 2 + 1) * N + n];
-        const float delta = mub - mean, tot = cnt + nb;
-        mean += delta * (nb / tot);
-        m2 += m2b + delta * delta * (cnt * nb / tot);
+    const int64_t mb = (int64_t)lane * rpc;
+    const bool live = lane < chunks && mb < M;
+    float cnt = live ? (float)(((mb + rpc < M) ? mb + rpc : M) - mb) : 0.f;
+    const int bb = live ? lane : 0;
+    float mean = partial[((int64_t)bb * 2 + 0) * N + n], m2 = partial[((int64_t)bb * 2 + 1) * N + n];
+    if (!live) { mean = 0.f; m2 = 0.f; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float mo = __shfl_xor(mean, o, 64), qo = __shfl_xor(m2, o, 64), co = __shfl_xor(cnt, o, 64);
+        // the pair (lower lane's triple, upper lane's triple), merged the same way in both lanes
+        const bool up = (lane & o) != 0;
+        const float ma = up ? mo : mean, qa = up ? qo : m2, ca = up ? co : cnt;
+        const float mb_ = up ? mean : mo, qb = up ? m2 : qo, cb = up ? cnt : co;
+        const float tot = ca + cb;
+        const float w = tot > 0.f ? cb / tot : 0.f;
+        const float delta = mb_ - ma;
+        mean = ma + delta * w;
+        m2 = qa + qb + delta * delta * (ca * w);
         cnt = tot;
     }
+    if (lane != 0) return;
     const float var = m2 / (float)M;
     stats[n] = mean;
     stats[N + n] = 1.0f / sqrtf(var + eps);
@@ -88,7 +123,16 @@ __global__ __launch_bounds__(256) void col_final_k(const float* __restrict__ par
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     float a = 0.f, b = 0.f;
-    for (int c = 0; c < chunks; ++c) { a += partial[((int64_t)c * 2 + 0) * N + n]; b += partial[((int64_t)c * 2 + 1) * N + n]; }
+    float pa[ML_CHUNKS], pb[ML_CHUNKS];      // (requested together, added in chunk order)
+#pragma unroll
+    for (int c = 0; c < ML_CHUNKS; ++c) {
+        const int cc = c < chunks ? c : chunks - 1;
+        pa[c] = partial[((int64_t)cc * 2 + 0) * N + n];
+        pb[c] = partial[((int64_t)cc * 2 + 1) * N + n];
+    }
+#pragma unroll
+    for (int c = 0; c < ML_CHUNKS; ++c)
+        if (c < chunks) { a += pa[c]; b += pb[c]; }
     if (out1) out1[n] = a;
     if (out2) out2[n] = b;
 }
@@ -124,13 +168,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__
     float sg, sgx;
     bool owner;
     int64_t col, mb, me;
+    // (the thread's column statistics: read once -- behind the stores to dz the compiler has to assume they changed)
+    const int64_t myc = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool bn = stats != nullptr;
+    const float mu = (bn && myc < N) ? stats[myc] : 0.f, rs = (bn && myc < N) ? stats[N + myc] : 0.f;
     col_reduce2(M, N, [&](int64_t m, int64_t n, float& x, float& y) {
         const int64_t e = m * N + n;
-        const float g = (a[e] > 0.f) ? da[e] * drop_scale : 0.f;   // a > 0 <=> relu active and not dropped
-        dz[e] = g;
+        const float av = a[e], dv = da[e], zv = z[e];              // (unconditional loads: a load behind a compare is a round trip of its own)
+        const float g = (av > 0.f) ? dv * drop_scale : 0.f;        // a > 0 <=> relu active and not dropped
         x = g;
-        y = stats ? g * (z[e] - stats[n]) * stats[N + n] : 0.f;
-    }, sg, sgx, owner, col, mb, me);
+        y = bn ? g * (zv - mu) * rs : 0.f;
+    }, sg, sgx, owner, col, mb, me, [&](int64_t m, int64_t n, float g) { dz[m * N + n] = g; });
     if (owner) {
         partial[((int64_t)blockIdx.y * 2 + 0) * N + col] = sg;
         partial[((int64_t)blockIdx.y * 2 + 1) * N + col] = sgx;
@@ -178,7 +226,7 @@ extern "C" int re_bn_relu_drop_fwd(const float* z, int64_t M, int64_t N, const f
         if (training) {
             const int ch = ml_chunks(M);
             hipLaunchKernelGGL(bn_stats_partial_k, dim3((unsigned)re_cdiv(N, 64), ch), dim3(256), 0, s, z, M, N, (float*)ws);
-            hipLaunchKernelGGL(bn_stats_final_k, dim3((unsigned)re_cdiv(N, 256)), dim3(256), 0, s, (const float*)ws, ch, M, N, eps, momentum, stats, run_mean, run_var);
+            hipLaunchKernelGGL(bn_stats_final_k, dim3((unsigned)re_cdiv(N, 4)), dim3(256), 0, s, (const float*)ws, ch, M, N, eps, momentum, stats, run_mean, run_var);
         }
         else hipLaunchKernelGGL(bn_stats_eval_k, dim3((unsigned)re_cdiv(N, 256)), dim3(256), 0, s, (const float*)run_mean, (const float*)run_var, N, eps, stats);
     }
