@@ -11,7 +11,14 @@ update of the torch.optim.Adam the script built, a call pattern the adapter repl
 and the script's own torch code runs.  After adoption the module's parameters are views of the engine's arena, so `state_dict()`, the
 script's own `recommend_from_full` and checkpoints see the trained values.  Full-ranking evaluation of an adopted model runs on the fused
 score + seen-mask + top-K kernel and the metrics kernel (seen / target lists as device CSR built once per split), DeepFM's pool
-evaluation on the engine's forward + the LOGLOSS / AUC kernels.  `--engine module` keeps everything on the script's own torch code."""
+evaluation on the engine's forward + the LOGLOSS / AUC kernels.  `--engine module` keeps everything on the script's own torch code.
+
+ONE Coach.  `recboard_amd.coach.Coach` (engine objects driven without a script: bench, tests) is a constructor shim over this class: the epoch
+loop, evaluation, best tracking, `checkpoint.tar` / `best.pt` and the leaderboard record all live here.  `fit()` ends with `results.json` in
+the schema of `benchmark/<dataset>/<model>.json` (benchmark/Amazon2014Beauty_550_LOU/SASRec.json:1-304: a list of `{description, dataset,
+tags, runs: [{id, params: {config, seed}, metrics: {train, valid, test, best}}], timestamp, config}`), the file
+recboard/scripts/build-data.mjs:95-146 aggregates: a run of an unchanged `main.py` can be dropped into `benchmark/`."""
+import datetime
 import json
 import os
 import time
@@ -77,6 +84,8 @@ class Coach:
         self.set_other()
         self._best, self._best_epoch = (float("inf") if self._best_caster() is min else -float("inf")), 0
         self._stopping_steps = 0
+        self.history = []                   # one record per epoch: {"epoch", "train", ["valid"], ["test"]}; the last one holds the final evaluations
+        self._final = {"train": {}, "valid": {}, "test": {}, "best": {}}
         self.path = cfg.get("checkpoint_path") or os.path.join("logs", str(cfg.get("description", "RecSys")), str(cfg.get("dataset")), str(cfg.get("id") or time.strftime("%m%d%H%M%S")))
         self._engine = self._attach_engine()
         if self._engine is not None and hasattr(self.trainpipe, "to_"):
@@ -168,9 +177,13 @@ class Coach:
     def train_per_epoch(self, epoch):
         raise NotImplementedError("train_per_epoch: the scripts define the step loop (SASRec/main.py:242-258)")
 
+    def _set_training(self, flag):
+        m = self.get_res_sys_arch()
+        m.train() if flag else m.eval()
+
     def train(self, epoch):
         self.dataloader = self.trainpipe
-        self.get_res_sys_arch().train()
+        self._set_training(True)
         if self._engine is not None:
             self._engine.train_epoch(self, epoch)
         else:
@@ -180,14 +193,14 @@ class Coach:
     @torch.no_grad()
     def valid(self, epoch, step=-1):
         self.dataloader = self.validpipe
-        self.get_res_sys_arch().eval()
+        self._set_training(False)
         self._evaluate(epoch, step, "valid")
         return self._step_meters("valid")
 
     @torch.no_grad()
     def test(self, epoch, step=-1):
         self.dataloader = self.testpipe
-        self.get_res_sys_arch().eval()
+        self._set_training(False)
         self._evaluate(epoch, step, "test")
         return self._step_meters("test")
 
@@ -229,27 +242,50 @@ class Coach:
         needs (the engine adapter, or `recommend_topk`).  -> False when it does not apply."""
         if self.device.type != "cuda" or self._engine is None:
             return False
-        if hasattr(self._engine, "pool_logits"):              # a prediction model (DeepFM): LOGLOSS / AUC over the split's rows
-            from recboard_amd.evaluate import PredictionEvaluator
-            mons = [m for m in self._meters[mode] if m.split("@")[0] in ("LOGLOSS", "AUC")]
-            if not mons:
-                return True
-            ev = PredictionEvaluator(mons)
+        if hasattr(self._engine, "pool_logits"):              # a prediction model (DeepFM): LOGLOSS / AUC
+            covered = ("LOGLOSS", "AUC")
+            mons = [m for m in self._meters[mode] if m.split("@")[0] in covered]
+            other = [m for m in self._meters[mode] if m not in mons and m != "LOSS"]
+            if other or not mons:         # a monitor the kernels do not compute (or none at all): the reference's dense path updates what it can
+                return False
             self._engine.reset_ranking_buffers()
+            if str(self.cfg.get("pred_metrics", "batch")) == "global":
+                # ONE value over all rows of the split (the statistically meaningful AUC; NOT what the reference's Coach monitors)
+                from recboard_amd.evaluate import PredictionEvaluator
+                ev, n = PredictionEvaluator(mons), 0
+                for data in self.dataloader:
+                    logits, labels = self._engine.pool_logits(self, data)
+                    ev.update(logits, labels)
+                    n += int(labels.numel())
+                for name, val in ev.compute().items():
+                    self._meters[mode][name].update(val, max(n, 1), "mean")
+                return True
+            # the reference's form (UniSRec/main.py:400-447 with a PredRecArch; DeepFM/main.py:217-219): every batch's LOGLOSS / AUC, weighted by
+            # the batch's rows -- the mean of per-batch AUCs, not the split's AUC.  Computed by the device kernels, summed on the device, one host read.
+            from recboard_amd import ops
+            tot = {m: torch.zeros((), dtype=torch.float64, device=self.device) for m in mons}
             n = 0
             for data in self.dataloader:
                 logits, labels = self._engine.pool_logits(self, data)
-                ev.update(logits, labels)
-                n += int(labels.numel())
-            for name, val in ev.compute().items():
-                self._meters[mode][name].update(val, max(n, 1), "mean")
+                z, y = logits.reshape(-1).to(torch.float32).contiguous(), labels.reshape(-1).to(torch.float32).contiguous()
+                b = int(y.numel())
+                if "LOGLOSS" in tot:
+                    tot["LOGLOSS"] += ops.bce_logits(z, y)[0].reshape(()).double() * b
+                if "AUC" in tot:
+                    tot["AUC"] += ops.auc(torch.sigmoid(z).contiguous(), y).reshape(()).double() * b
+                n += b
+            for name, t in tot.items():
+                self._meters[mode][name].update(float(t) / max(n, 1), max(n, 1), "mean")
             return True
         if self.cfg.get("ranking", "full") != "full":
             return False
+        from recboard_amd import ops
         from recboard_amd.evaluate import RankingEvaluator
         mons = [m for m in self._meters[mode] if "@" in m]
         if not mons:
             return True
+        if any(m.split("@")[0] not in ops.METRIC_NAMES for m in mons):     # a ranking monitor the metrics kernel does not have: the dense path
+            return False
         ev = RankingEvaluator(mons)
         self._engine.reset_ranking_buffers()
         for j, data in enumerate(self.dataloader):
@@ -292,38 +328,64 @@ class Coach:
             return None
         return bridge.attach(self)
 
-    # ---- checkpoints / results (checkpoint.tar {epoch, model, optimizer, lr_scheduler, monitors}, best.pt)
-    def save_checkpoint(self, epoch):
-        utils.mkdirs(self.path)
-        opt = self._engine.optimizer_state() if self._engine is not None else self.optimizer.state_dict()
-        torch.save({"epoch": epoch, "model": self.get_res_sys_arch().state_dict(), "optimizer": opt,
-                    "lr_scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
-                    "monitors": {mode: {k: m.history for k, m in ms.items()} for mode, ms in self._meters.items()}},
-                   os.path.join(self.path, "checkpoint.tar"))
+    # ---- checkpoints / results (checkpoint.tar {epoch, model, optimizer, lr_scheduler, monitors}, best.pt, results.json)
+    def _model_state(self):
+        return self.get_res_sys_arch().state_dict()
 
-    def load_checkpoint(self):
-        ck = torch.load(os.path.join(self.path, "checkpoint.tar"), map_location=self.device, weights_only=False)
-        self.get_res_sys_arch().load_state_dict(ck["model"])
-        if self._engine is not None:
-            self._engine.load_optimizer_state(ck["optimizer"])
-        else:
-            self.optimizer.load_state_dict(ck["optimizer"])
+    def _load_model_state(self, sd):
+        self.get_res_sys_arch().load_state_dict(sd)
+
+    def save_checkpoint(self, epoch, path=None):
+        """`checkpoint.tar` with the reference's keys.  `optimizer` is ALWAYS in torch.optim's state_dict shape over the script's own parameter
+        groups (an adopted engine's moments are written per module parameter), so a checkpoint moves between `--engine auto` and
+        `--engine module`, and to the reference."""
+        path = path or self.path
+        utils.mkdirs(path)
+        opt = self._engine.optimizer_state(self) if self._engine is not None else (self.optimizer.state_dict() if self.optimizer is not None else {})
+        torch.save({"epoch": epoch, "model": self._model_state(), "optimizer": opt,
+                    "lr_scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
+                    "monitors": {"meters": {mode: {k: m.history for k, m in ms.items()} for mode, ms in self._meters.items()},
+                                 "best": self._best, "best_epoch": self._best_epoch, "history": self.history}},
+                   os.path.join(path, "checkpoint.tar"))
+
+    def load_checkpoint(self, path=None):
+        ck = torch.load(os.path.join(path or self.path, "checkpoint.tar"), map_location=self.device, weights_only=False)
+        self._load_model_state(ck["model"])
+        opt = ck.get("optimizer") or {}
+        if opt:
+            if self._engine is not None:
+                # the engine's moments AND the script's optimizer: its param_groups carry the learning rate every epoch starts from
+                # (`_Adapter.begin_epoch` reads it there; a ReduceLROnPlateau has lowered it in a resumed DeepFM run)
+                self._engine.load_optimizer_state(self, opt)
+            elif self.optimizer is not None:
+                self.optimizer.load_state_dict(opt)
         if self.lr_scheduler is not None and ck.get("lr_scheduler"):
             self.lr_scheduler.load_state_dict(ck["lr_scheduler"])
-        for mode, ms in (ck.get("monitors") or {}).items():
-            for k, h in ms.items():
-                if k in self._meters[mode]:
-                    self._meters[mode][k].history = list(h)
+        mon = ck.get("monitors") or {}
+        meters = mon.get("meters", mon if "best" not in mon else {})       # (checkpoints of round 4: the meters' histories at the top level)
+        for mode, ms in meters.items():
+            if mode in self._meters and isinstance(ms, dict):
+                for k, h in ms.items():
+                    if k in self._meters[mode]:
+                        self._meters[mode][k].history = list(h)
+        if "best" in mon and not isinstance(mon["best"], (tuple, list)):
+            self._best, self._best_epoch = mon["best"], mon.get("best_epoch", 0)
+        elif isinstance(mon.get("best"), (tuple, list)):                   # (round-4 engine checkpoints: (epoch, score))
+            self._best_epoch, self._best = mon["best"]
+        self.history = list(mon.get("history", []))
         return ck["epoch"]
 
-    def save_best(self):
-        utils.mkdirs(self.path)
-        torch.save(self.get_res_sys_arch().state_dict(), os.path.join(self.path, "best.pt"))
+    def save_best(self, path=None):
+        path = path or self.path
+        utils.mkdirs(path)
+        torch.save(self._model_state(), os.path.join(path, "best.pt"))
 
-    def load_best(self):
-        p = os.path.join(self.path, "best.pt")
+    def load_best(self, path=None):
+        p = os.path.join(path or self.path, "best.pt")
         if os.path.exists(p):
-            self.get_res_sys_arch().load_state_dict(torch.load(p, map_location=self.device))
+            self._load_model_state(torch.load(p, map_location=self.device))
+            return True
+        return False
 
     def resume(self):
         if self.cfg.get("resume") and os.path.exists(os.path.join(self.path, "checkpoint.tar")):
@@ -337,43 +399,99 @@ class Coach:
         caster = self._best_caster()
         if caster(results[key], self._best) == results[key] and results[key] != self._best:
             self._best, self._best_epoch, self._stopping_steps = results[key], epoch, 0
-            self.save_best()
+            if self._saves_files():
+                self.save_best()
         else:
             self._stopping_steps += 1
             if self._stopping_steps > self.cfg.get("early_stop_patience", 1e23):
                 raise EarlyStopError
 
+    def _saves_files(self):
+        return True
+
+    def results_record(self, dataset=None, model_name=None, metrics=None, seed=None, config=None, run_id=None, tags=None, description=None):
+        """-> the list-of-one record of `benchmark/<dataset>/<model>.json` (benchmark/Amazon2014Beauty_550_LOU/SASRec.json:1-304), what
+        recboard/scripts/build-data.mjs:95-146 reads: per run `metrics.{train, valid, test, best}` (train: the last epoch's monitors;
+        valid / test: the final model; best: the test split under the best checkpoint -- `aggregateRuns` averages `best`)."""
+        cfg = self.cfg
+        m = metrics if metrics is not None else self._final
+        conf = config if config is not None else {k: v for k, v in cfg.to_dict().items() if isinstance(v, (int, float, str, bool, list, dict, type(None)))}
+        now = datetime.datetime.now()
+        arch = self.get_res_sys_arch()
+        name = model_name or type(arch).__name__
+        if tags is None:
+            tags = [t for t in (cfg.get("tasktag"), cfg.get("loss"), cfg.get("embedding_dim")) if t is not None]
+            tags = [str(t) for t in tags] or [name]
+        return [{
+            "description": description if description is not None else (str(cfg.get("description") or "") if cfg.get("description") != "RecSys" else ""),
+            "dataset": str(dataset if dataset is not None else cfg.get("dataset")),
+            "tags": list(tags),
+            "runs": [{"id": str(run_id or cfg.get("id") or now.strftime("%m%d%H%M%S")),
+                      "params": {"config": conf.get("config") or "", "seed": int(seed if seed is not None else (cfg.get("seed") or 0))},
+                      "metrics": {k: {a: float(b) for a, b in (m.get(k) or {}).items()} for k in ("train", "valid", "test", "best")}}],
+            "timestamp": now.strftime("%Y-%m-%dT%H:%M:%S"),
+            "config": conf,
+        }]
+
+    def save_results(self, path=None, **kw):
+        path = path or self.path
+        utils.mkdirs(path)
+        rec = self.results_record(**kw)
+        with open(os.path.join(path, "results.json"), "w") as f:
+            json.dump(rec, f, indent=2)
+        return rec
+
     def summary(self):
+        """Writes `results.json` (the leaderboard record) and returns every monitor's best value per split."""
         best = {mode: {k: m.best() for k, m in ms.items() if m.best() is not None} for mode, ms in self._meters.items()}
-        utils.mkdirs(self.path)
-        with open(os.path.join(self.path, "results.json"), "w") as f:
-            json.dump({"best": best, "best_epoch": self._best_epoch, "config": {k: v for k, v in self.cfg.to_dict().items() if isinstance(v, (int, float, str, bool, list, dict, type(None)))}}, f, indent=2)
+        if self._saves_files():
+            self.save_results()
         return best
 
+    def _eval_round(self, epoch, rec):
+        cfg = self.cfg
+        results = {}
+        if cfg.get("eval_valid", True) and self.validpipe is not None:
+            results = rec["valid"] = self.valid(epoch)
+        if cfg.get("eval_test", False) and self.testpipe is not None:
+            rec["test"] = self.test(epoch)
+        if results:
+            self.check_best(epoch, results)
+
     def fit(self):
+        """Per epoch: every `eval_freq` epochs the evaluation round in FRONT of the epoch (valid -> best checkpoint; test if `eval_test`), then
+        `train`.  After the last epoch: the final model on valid and test, then the best checkpoint on test -> `results.json`."""
         cfg = self.cfg
         epochs = int(cfg.get("epochs") or 0)
         start = self.resume()
-        results = {}
         try:
             for epoch in range(start, epochs):
-                if epoch % int(cfg.get("eval_freq", 5)) == 0:
-                    if cfg.get("eval_valid", True) and self.validpipe is not None:
-                        results = self.valid(epoch)
-                        self.check_best(epoch, results)
-                    if cfg.get("eval_test", False) and self.testpipe is not None:
-                        self.test(epoch)
-                tr = self.train(epoch)
-                utils.infoLogger(f"[Coach] >>> TRAIN @Epoch: {epoch:<4d} >>> " + " || ".join(f"{k} Avg: {v:.5f}" for k, v in tr.items()))
-                if cfg.get("checkpoint_freq"):
+                rec = {"epoch": epoch}
+                if epoch % max(int(cfg.get("eval_freq", 5)), 1) == 0:
+                    self._eval_round(epoch, rec)
+                rec["train"] = self._final["train"] = self.train(epoch)
+                self.history.append(rec)
+                utils.infoLogger(f"[Coach] >>> TRAIN @Epoch: {epoch:<4d} >>> " + " || ".join(f"{k} Avg: {v:.5f}" for k, v in rec["train"].items()))
+                if cfg.get("checkpoint_freq") and self._saves_files():
                     self.save_checkpoint(epoch)
         except EarlyStopError:
             utils.infoLogger(f"[Coach] >>> Early Stop @Epoch: {epoch}")
+        rec = {"epoch": epochs}
         if self.validpipe is not None:
-            results = self.valid(epochs)
-            self.check_best(epochs, results)
-        self.save_checkpoint(epochs)
-        self.load_best()
-        out = {"valid": self.valid(epochs) if self.validpipe is not None else {}, "test": self.test(epochs) if self.testpipe is not None else {}}
+            rec["valid"] = self._final["valid"] = self.valid(epochs)
+            try:
+                self.check_best(epochs, rec["valid"])
+            except EarlyStopError:
+                pass
+        if self.testpipe is not None:
+            rec["test"] = self._final["test"] = self.test(epochs)
+        self.history.append(rec)
+        if self._saves_files():
+            self.save_checkpoint(epochs)
+        self._final["best"] = dict(self._final["test"])
+        if self._saves_files() and self.testpipe is not None and self._best_epoch != epochs and self.load_best():
+            self._final["best"] = self.test(epochs)      # the best checkpoint on the test split: what the leaderboard aggregates
+        out = {"valid": self._final["valid"], "test": self._final["test"], "best_test": self._final["best"], "history": self.history,
+               "best_epoch": self._best_epoch, "best_value": self._best}
         out["best"] = self.summary()
         return out

@@ -149,6 +149,64 @@ class _Adapter:
     def _set_lr(self, lr):
         self.eng.lr = lr
 
+    # ---- optimizer state in torch.optim.Adam's state_dict shape over the SCRIPT's parameter groups: what `checkpoint.tar` holds under
+    #      "optimizer" whichever way the model is trained, so a checkpoint moves between `--engine auto`, `--engine module` and the reference
+    def named_moments(self):
+        """-> (name -> first-moment view, name -> second-moment view) under the module's parameter names."""
+        A = self.eng.arena
+        return A.views(A.m), A.views(A.v)
+
+    def _get_step(self):
+        return int(self.eng.arena.step)
+
+    def _set_step(self, n):
+        self.eng.arena.step = int(n)
+
+    def optimizer_state(self, coach):
+        ids = {id(p): n for n, p in self.module.named_parameters()}
+        m, v = self.named_moments()
+        step = float(self._get_step())
+        state, groups, i = {}, [], 0
+        for g in coach.optimizer.param_groups:
+            gi = {k: val for k, val in g.items() if k != "params"}
+            gi["lr"] = float(getattr(self.eng, "lr", g["lr"]))         # (the engine's current rate: a plateau schedule may have lowered it)
+            gi["params"] = []
+            for p in g["params"]:
+                n = ids[id(p)]
+                if step > 0:
+                    state[i] = {"step": torch.tensor(step), "exp_avg": m[n].detach().clone().reshape(p.shape), "exp_avg_sq": v[n].detach().clone().reshape(p.shape)}
+                gi["params"].append(i)
+                i += 1
+            groups.append(gi)
+        return {"state": state, "param_groups": groups}
+
+    def load_optimizer_state(self, coach, sd):
+        if "param_groups" not in sd:                                   # (round-4 DeepFM checkpoints: {m, v, step, lr} arena copies)
+            self.eng.load_adam_state_dict(sd)
+            lr = float(sd.get("lr", self.eng.lr))
+        else:
+            ids = {id(p): n for n, p in self.module.named_parameters()}
+            m, v = self.named_moments()
+            step, i = 0, 0
+            with torch.no_grad():
+                for g in coach.optimizer.param_groups:
+                    for p in g["params"]:
+                        st = sd["state"].get(i)
+                        n = ids[id(p)]
+                        if st is not None:
+                            m[n].copy_(st["exp_avg"].to(m[n].device).reshape(m[n].shape))
+                            v[n].copy_(st["exp_avg_sq"].to(v[n].device).reshape(v[n].shape))
+                            step = int(st["step"])
+                        else:
+                            m[n].zero_(); v[n].zero_()
+                        i += 1
+            self._set_step(step)
+            lr = float(sd["param_groups"][0]["lr"])
+        # the script's optimizer is where every epoch's learning rate is read from (begin_epoch): the saved rate goes there too
+        for g, gs in zip(coach.optimizer.param_groups, sd.get("param_groups") or [{}] * len(coach.optimizer.param_groups)):
+            g["lr"] = float(gs.get("lr", lr))
+        self._set_lr(lr)
+
 
 class SASRecAdapter(_Adapter):
     kind = "SASRec"
@@ -250,11 +308,6 @@ class SASRecAdapter(_Adapter):
     def recommend_topk(self, coach, data, seen_ptr, seen_idx, K):
         return self.eng.recommend_topk(data[coach.ISeq].to(coach.device), seen_ptr, seen_idx, K)
 
-    def optimizer_state(self):
-        return self.eng.arena.adam_state_dict(self.eng.lr, self.eng.betas, self.eng.wd)
-
-    def load_optimizer_state(self, sd):
-        self.eng.arena.load_adam_state_dict(sd)
 
 
 class MFAdapter(_Adapter):
@@ -340,14 +393,8 @@ class MFAdapter(_Adapter):
     def recommend_topk(self, coach, data, seen_ptr, seen_idx, K):
         return self.eng.recommend_topk(data[coach.User].to(coach.device).reshape(-1), seen_ptr, seen_idx, K)
 
-    def optimizer_state(self):
-        return self.eng.arena.adam_state_dict(self.eng.lr, self.eng.betas, self._adam_wd())
-
     def _adam_wd(self):
         return self.eng.wd
-
-    def load_optimizer_state(self, sd):
-        self.eng.arena.load_adam_state_dict(sd)
 
 
 class LightGCNAdapter(MFAdapter):
@@ -515,11 +562,18 @@ class DeepFMAdapter(_Adapter):
         x, y = self._batch(coach, data)
         return self.eng.encode(x)[0], y
 
-    def optimizer_state(self):
-        return self.eng.adam_state_dict()
+    def named_moments(self):
+        e = self.eng
+        off, cnt = e.offsets.tolist(), e.counts
+        M, V = e._views(e.m), e._views(e.v)
+        per = lambda X: ([X["T"][o:o + c] for o, c in zip(off, cnt)], [X["TL"][o:o + c] for o, c in zip(off, cnt)])   # noqa: E731
+        return self._views(M, *per(M)), self._views(V, *per(V))
 
-    def load_optimizer_state(self, sd):
-        self.eng.load_adam_state_dict(sd)
+    def _get_step(self):
+        return int(self.eng.step)
+
+    def _set_step(self, n):
+        self.eng.step = int(n)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------

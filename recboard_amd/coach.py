@@ -1,17 +1,20 @@
-"""A compact Coach for the engine models: host-side mirror of `freerec.launcher.Coach` as the reference scripts use it
-(`Coach(dataset=, trainpipe=, validpipe=, testpipe=, model=, cfg=).fit()`, SASRec/main.py:278-286; loop shape evidenced by
-ETEGRec/train_etegrec.py:625-650; evaluate contract by UniSRec/main.py:400-447).
+"""The Coach for ENGINE OBJECTS driven without a script (bench.py, tests, scripts): a constructor shim over the one Coach of this repo,
+`freerec.launcher.Coach` (the reference's `Coach(dataset=, trainpipe=, validpipe=, testpipe=, model=, cfg=).fit()`, SASRec/main.py:278-286;
+loop shape evidenced by ETEGRec/train_etegrec.py:625-650; evaluate contract by UniSRec/main.py:400-447).  The epoch loop, the fused
+evaluation, best tracking, `checkpoint.tar` / `best.pt` and the leaderboard record (`results.json`) are the base class's; what is here is
+(a) the keyword constructor (no dataset / cfg objects), (b) `_Direct`: the "engine adapter" the base class drives, stepping the engine object
+itself instead of an adopted script, (c) the host-to-device batch staging of a pipe that hands out CPU tensors.
 
 Per epoch: `train_per_epoch` (SASRec/main.py:242-258 / MF-BPR/main.py:115-131: one engine `train_step` per batch, LOSS
 monitored as the mean over batches weighted by batch size); every `eval_freq` epochs `evaluate("valid")` with the
 fused score+mask+top-K kernel and the metrics kernel; best epoch tracked on `which4best`.  The per-step `loss.item()`
 host sync of the reference is replaced by one device-side accumulation read at the end of the epoch.
 """
-import datetime
-import json
 import os
 
 import torch
+
+from freerec import launcher as _launcher
 
 from .evaluate import PredictionEvaluator, RankingEvaluator, ReduceLROnPlateau, ragged_to_csr  # noqa: F401
 
@@ -29,35 +32,165 @@ def _lookahead(it):
     yield cur, None
 
 
-class Coach:
+class _Cfg(dict):
+    """The few cfg entries the base Coach reads, as attributes and through `get` / `to_dict`."""
+    __getattr__ = dict.get
+
+    def to_dict(self):
+        return dict(self)
+
+
+class _Direct:
+    """What `freerec.launcher.Coach` asks of an engine adapter, for an engine OBJECT (no script, no probe: there is nothing to adopt)."""
+
+    def __init__(self, coach):
+        self.c = coach
+        if coach.kind == "pred":       # (the base class tells a prediction model by this attribute)
+            self.pool_logits = self._pool_logits
+
+    def wants_fused_sampler(self):
+        return False
+
+    def train_epoch(self, coach, epoch):
+        coach.train_per_epoch(epoch)
+
+    def reset_ranking_buffers(self):
+        m = self.c.model
+        if hasattr(m, "eval"):
+            m.eval()
+        if hasattr(m, "reset_ranking_buffers"):
+            m.reset_ranking_buffers()
+
+    def recommend_topk(self, coach, data, seen_ptr, seen_idx, K):
+        key = {"seq": "ISeq", "gen": "User", "module": (coach.fit_keys or ("User",))[0]}[coach.kind]
+        return coach.model.recommend_topk(data[key].to(coach.device), seen_ptr, seen_idx, K)
+
+    def _pool_logits(self, coach, data):
+        data = coach.dict_to_device(data)
+        return coach.model.encode(data["X"])[0], data["Label"]
+
+    def optimizer_state(self, coach):
+        m = coach.model
+        if hasattr(m, "optimizer_state"):            # engines whose Adam state is more than the arena (large / sharded tables)
+            return m.optimizer_state()
+        if hasattr(m, "arena"):                      # a torch.optim.Adam-shaped state_dict over the reference's parameter names
+            return m.arena.adam_state_dict(m.lr, m.betas, m.wd)
+        if hasattr(m, "adam_state_dict"):
+            return m.adam_state_dict()
+        if coach.optimizer is not None:              # kind = "module": the torch optimizer's own state_dict
+            return coach.optimizer.state_dict()
+        return {}
+
+    def load_optimizer_state(self, coach, opt):
+        m = coach.model
+        if hasattr(m, "load_optimizer_state"):
+            m.load_optimizer_state(opt)
+        elif hasattr(m, "arena"):
+            m.arena.load_adam_state_dict(opt)
+        elif hasattr(m, "load_adam_state_dict"):
+            m.load_adam_state_dict(opt)
+        elif coach.optimizer is not None:
+            coach.optimizer.load_state_dict(opt)
+
+
+class Coach(_launcher.Coach):
+    User, Item, ISeq, IPos, INeg, IUnseen, ISeen, Label, Size = "User", "Item", "ISeq", "IPos", "INeg", "IUnseen", "ISeen", "Label", "Size"
+
     def __init__(self, model, trainpipe, validpipe=None, testpipe=None, monitors=("LOSS", "HitRate@10", "NDCG@10"),
                  which4best="NDCG@10", eval_freq=5, kind="seq", checkpoint_path=None, lr_scheduler=None, optimizer=None,
-                 fit_keys=None, loss_fn=None, graph=False):
+                 fit_keys=None, loss_fn=None, graph=False, dataset=None, pred_metrics="global", seed=0):
         """kind: "seq" (SASRec: data ISeq / IPos / INeg), "gen" (MF-BPR / LightGCN: User / IPos / INeg), "module" (a torch.nn.Module on
         the custom-op surface, recboard_amd.siblings: `model.fit(*[data[k] for k in fit_keys])` -> dict of losses, `loss_fn(losses)` -> the
         scalar to differentiate (default: their sum; e.g. CoachForLightGCN's rec + weight_decay * emb, LightGCN/main.py:156-172),
         `optimizer` a torch optimizer (capturable for graph=True: the step replayed as one hipGraph, nn.GraphedStep); evaluation through
-        `model.recommend_topk(data[fit_keys[0]], seen, K)`) or "pred" (DeepFM: a field matrix
-        `X` [B, F] and `Label`; monitors LOGLOSS / AUC, DeepFM/configs/Frappe_x1_BARS.yaml:101-102).  lr_scheduler: e.g.
-        `ReduceLROnPlateau(model, mode="max", patience=eval_freq, ...)`, stepped on the best monitored value at the top of every
-        epoch as CoachForDeepFM does (DeepFM/main.py:251-257)."""
-        self.model, self.trainpipe, self.validpipe, self.testpipe = model, trainpipe, validpipe, testpipe
-        self.monitors, self.which4best, self.eval_freq, self.kind = list(monitors), which4best, eval_freq, kind
-        self.history, self.best = [], None
-        self.checkpoint_path = checkpoint_path
-        self.device = model.device if hasattr(model, "device") else next(model.parameters()).device
-        self.lr_scheduler = lr_scheduler
-        self.optimizer, self.fit_keys, self.graph = optimizer, tuple(fit_keys) if fit_keys else None, graph
+        `model.recommend_topk(data[fit_keys[0]], seen, K)`) or "pred" (DeepFM: a field matrix `X` [B, F] and `Label`; monitors LOGLOSS / AUC,
+        DeepFM/configs/Frappe_x1_BARS.yaml:101-102; pred_metrics = "global": ONE AUC / LOGLOSS over the split's rows -- "batch" is the
+        reference Coach's batch-weighted mean of per-batch values).  lr_scheduler: e.g. `ReduceLROnPlateau(model, mode="max",
+        patience=eval_freq, ...)`, stepped on the best monitored value at the top of every epoch as CoachForDeepFM does (DeepFM/main.py:251-257)."""
+        self.kind, self.checkpoint_path = kind, checkpoint_path
+        self._given = (optimizer, lr_scheduler)
+        self.fit_keys, self.graph = tuple(fit_keys) if fit_keys else None, graph
         self.loss_fn = loss_fn if loss_fn is not None else (lambda losses: sum(losses.values()))
         self._graphed = {}
         if kind == "module" and (optimizer is None or not self.fit_keys):
             raise ValueError("Coach(kind='module') needs `optimizer` and `fit_keys`")
+        mons = list(monitors)
+        # which4best: a monitor that exists for this run (a training-only Coach monitors LOSS alone)
+        has = {m.upper() for m in mons}
+        cfg = _Cfg(monitors=mons, which4best=which4best if which4best.upper() in has else mons[0], eval_freq=eval_freq, epochs=0, ranking="full",
+                   retain_seen=False, eval_valid=True, eval_test=False, checkpoint_path=checkpoint_path or "", engine="direct", seed=seed,
+                   device=str(model.device if hasattr(model, "device") else next(model.parameters()).device), dataset=dataset,
+                   description=type(model).__name__, pred_metrics=pred_metrics, checkpoint_freq=1 if checkpoint_path else 0)
+        super().__init__(dataset=dataset, trainpipe=trainpipe, validpipe=validpipe, testpipe=testpipe, model=model, cfg=cfg)
+
+    # ---- the base class's set-up hooks
+    def set_device(self):
+        self.device = torch.device(self.cfg.device)
+
+    def set_model(self, model):
+        self.model = model
+
+    def set_optimizer(self):
+        self.optimizer = self._given[0]
+
+    def set_lr_scheduler(self):
+        self.lr_scheduler = self._given[1]
+
+    def _attach_engine(self):
+        return _Direct(self)
+
+    def _saves_files(self):
+        return bool(self.checkpoint_path)
+
+    def _set_training(self, flag):
+        m = self.model
+        if flag and hasattr(m, "train"):
+            m.train()
+        elif not flag and hasattr(m, "eval"):
+            m.eval()
+
+    def _evaluate(self, epoch, step, mode):
+        if not self._fused_eval(mode):
+            raise NotImplementedError(f"Coach(kind={self.kind!r}): a monitor of {sorted(self._meters[mode])} is not one the evaluation kernels compute")
 
     def dict_to_device(self, data, keys=None):
         """Coach.dict_to_device: tensors to the model's device (asynchronously when the pipe hands out pinned memory); `keys` limits
         the copies to what the step reads."""
         return {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) and (keys is None or k in keys) else v)
                 for k, v in data.items()}
+
+    # ---- the previous interface of this class (tests, bench, scripts)
+    @property
+    def best(self):
+        return None if self._best in (float("inf"), -float("inf")) else (self._best_epoch, self._best)
+
+    def evaluate(self, mode="valid"):
+        """-> {monitor: value} of one split under the current parameters (no best tracking, no history)."""
+        was = getattr(self.model, "training", False)
+        with torch.no_grad():
+            self.dataloader = self.validpipe if mode == "valid" else self.testpipe
+            self._set_training(False)
+            self._evaluate(0, -1, mode)
+        if hasattr(self.model, "train"):
+            self.model.train(was)
+        out = {}
+        for name, meter in self._meters[mode].items():
+            if meter.n:
+                out[name] = meter.avg
+            meter.reset()
+        return out
+
+    def fit(self, epochs=None):
+        if epochs is not None:
+            self.cfg["epochs"] = int(epochs)
+        sch = self.lr_scheduler
+        if sch is not None and getattr(sch, "mode", None) not in (None, "max" if self._best_caster() is max else "min"):
+            import warnings
+            warnings.warn(f"lr_scheduler.mode={sch.mode!r} but which4best={self.cfg.which4best!r} is {'max' if self._best_caster() is max else 'min'}imised: "
+                          "the scheduler will read every improvement as a bad epoch")
+        out = super().fit()
+        out["best_monitors"], out["best"] = out["best"], self.best
+        return out
 
     def _device_batches(self, pipe, keys, ahead=1):
         """The pipe's batches on the device, `ahead` BATCHES AHEAD: the host-to-device copies of batch i+1 run on a copy stream while step i
@@ -156,7 +289,7 @@ class Coach:
 
     def train_per_epoch(self, epoch):
         if self.lr_scheduler is not None:            # DeepFM/main.py:256: self.lr_scheduler.step(self._best)
-            self.lr_scheduler.step(self.best[1] if self.best is not None else (-float("inf") if self.lr_scheduler.mode == "max" else float("inf")))
+            self.lr_scheduler.step(self._best)
         tot = torch.zeros((), device=self.device)
         n = 0
         need = {"seq": ("ISeq", "IPos", "INeg"), "pred": ("X", "Label"), "module": self.fit_keys}.get(self.kind)
@@ -225,7 +358,9 @@ class Coach:
         table = getattr(self.model, "table", None)
         if table is not None and hasattr(table, "check_capacity"):
             table.check_capacity()          # (row-sharded tables: a lookup dropped by a full exchange bucket came back as a zero row)
-        return {"LOSS": float(tot / max(n, 1))}
+        loss = float(tot / max(n, 1))                # (one host read per epoch)
+        self.monitor(loss, n=max(n, 1), reduction="mean", mode="train", pool=["LOSS"])
+        return {"LOSS": loss}
 
     def _module_step(self, inputs):
         """One optimizer step of a torch.nn.Module model: eager, or (graph=True) the whole step replayed as one hipGraph per input shape."""
@@ -244,140 +379,7 @@ class Coach:
             self._graphed[key] = GraphedStep(m, lambda *a: self.loss_fn(m.fit(*a)), self.optimizer, inputs)
         return self._graphed[key](*inputs)
 
+
     def _graphable(self):
         m = self.model
         return hasattr(m, "train_step_graph") and getattr(m, "encoder", None) == "fused" and getattr(m, "loss_kind", "CE") != "CE"
-
-    # ---- checkpoint / results in the reference's formats: `checkpoint.tar` (model state_dict under the
-    #      reference's parameter names + optimizer state + epoch), `best.pt` (state_dict of the best epoch), and the
-    #      `benchmark/<dataset>/<model>.json` record schema (benchmark/Amazon2014Beauty_550_LOU/SASRec.json:1-304).
-    def _optimizer_state(self):
-        m = self.model
-        if hasattr(m, "optimizer_state"):            # engines whose Adam state is more than the arena (large / sharded tables)
-            return m.optimizer_state()
-        if hasattr(m, "arena"):                      # a torch.optim.Adam-shaped state_dict over the reference's parameter names
-            return m.arena.adam_state_dict(m.lr, m.betas, m.wd)
-        if hasattr(m, "adam_state_dict"):
-            return m.adam_state_dict()
-        if self.optimizer is not None:               # kind = "module": the torch optimizer's own state_dict
-            return self.optimizer.state_dict()
-        return {}
-
-    def save_checkpoint(self, path, epoch):
-        """`checkpoint.tar` with the reference's keys (freerec Coach.save_checkpoint, shape evidenced by ETEGRec/train_etegrec.py:549-574
-        and the cfg dump's CHECKPOINT_MODULES): {epoch, model, optimizer, lr_scheduler, monitors}."""
-        os.makedirs(path, exist_ok=True)
-        torch.save({"epoch": epoch, "model": self.model.state_dict(), "optimizer": self._optimizer_state(),
-                    "lr_scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
-                    "monitors": {"best": self.best, "history": self.history}},
-                   os.path.join(path, "checkpoint.tar"))
-
-    def load_checkpoint(self, path):
-        ck = torch.load(os.path.join(path, "checkpoint.tar"), map_location=self.device, weights_only=False)
-        m = self.model
-        m.load_state_dict(ck["model"])
-        opt = ck.get("optimizer") or {}
-        if opt:
-            if hasattr(m, "load_optimizer_state"):
-                m.load_optimizer_state(opt)
-            elif hasattr(m, "arena"):
-                m.arena.load_adam_state_dict(opt)
-            elif hasattr(m, "load_adam_state_dict"):
-                m.load_adam_state_dict(opt)
-            elif self.optimizer is not None:
-                self.optimizer.load_state_dict(opt)
-        if self.lr_scheduler is not None and ck.get("lr_scheduler"):
-            self.lr_scheduler.load_state_dict(ck["lr_scheduler"])
-        mon = ck.get("monitors") or {}           # (checkpoints written before `monitors` existed keep best / history at the top level)
-        self.best, self.history = mon.get("best", ck.get("best")), mon.get("history", ck.get("history", []))
-        return ck["epoch"]
-
-    def save_best(self, path):
-        os.makedirs(path, exist_ok=True)
-        torch.save(self.model.state_dict(), os.path.join(path, "best.pt"))
-
-    def results_record(self, dataset, model_name, out, seed=0, config=None, run_id=None):
-        """-> the list-of-one record the leaderboard's build-data script reads (recboard/scripts/build-data.mjs:95-146)."""
-        last_train = self.history[-1]["train"] if self.history else {}
-        best_valid = {}
-        if self.best is not None:
-            best_valid = next((h["valid"] for h in self.history if h["epoch"] == self.best[0] and "valid" in h), {})
-        now = datetime.datetime.now()
-        return [{
-            "description": "", "dataset": dataset, "tags": [model_name, "recengine", "MI355X"],
-            "runs": [{"id": run_id or now.strftime("%m%d%H%M%S"), "params": {"config": (config or {}).get("config", ""), "seed": seed},
-                      "metrics": {"train": last_train, "valid": best_valid, "test": out.get("test", {}), "best": out.get("test", {})}}],
-            "timestamp": now.strftime("%Y-%m-%dT%H:%M:%S"), "config": config or {},
-        }]
-
-    def save_results(self, path, dataset, model_name, out, **kw):
-        os.makedirs(path, exist_ok=True)
-        with open(os.path.join(path, "results.json"), "w") as f:
-            json.dump(self.results_record(dataset, model_name, out, **kw), f, indent=2)
-
-    def evaluate(self, mode="valid"):
-        pipe = self.validpipe if mode == "valid" else self.testpipe
-        if self.kind == "pred":
-            ev = PredictionEvaluator(self.monitors)
-            was_training = self.model.training
-            self.model.eval()
-            for data in pipe:
-                data = self.dict_to_device(data)
-                ev.update(self.model.encode(data["X"])[0], data["Label"])
-            self.model.train(was_training)
-            return ev.compute()
-        ev = RankingEvaluator(self.monitors)
-        was_training = getattr(self.model, "training", False)
-        if hasattr(self.model, "eval"):
-            self.model.eval()
-        if hasattr(self.model, "reset_ranking_buffers"):
-            self.model.reset_ranking_buffers()
-        for data in pipe:
-            seen_ptr, seen_idx = ragged_to_csr(data["ISeen"], self.device)
-            tgt_ptr, tgt_idx = ragged_to_csr(data["IUnseen"], self.device)
-            if self.kind == "module":
-                _, idx = self.model.recommend_topk(data[self.fit_keys[0]].to(self.device), seen_ptr, seen_idx, ev.kmax)
-            elif self.kind == "seq":
-                _, idx = self.model.recommend_topk(data["ISeq"].to(self.device), seen_ptr, seen_idx, ev.kmax)
-            else:
-                _, idx = self.model.recommend_topk(data["User"].to(self.device), seen_ptr, seen_idx, ev.kmax)
-            ev.update(idx, tgt_ptr, tgt_idx)
-        if hasattr(self.model, "train"):
-            self.model.train(was_training)
-        return ev.compute()
-
-    #: monitors for which smaller is better (freerec's DEFAULT_BEST_CASTER: min for losses, max for ranking / AUC metrics)
-    MINIMISED = ("LOSS", "LOGLOSS", "MSE", "MAE", "RMSE")
-
-    @property
-    def best_mode(self):
-        return "min" if self.which4best.split("@")[0].upper() in self.MINIMISED else "max"
-
-    def _better(self, score, best):
-        return score < best if self.best_mode == "min" else score > best
-
-    def fit(self, epochs):
-        if self.lr_scheduler is not None and getattr(self.lr_scheduler, "mode", self.best_mode) != self.best_mode:
-            import warnings
-            warnings.warn(f"lr_scheduler.mode={self.lr_scheduler.mode!r} but which4best={self.which4best!r} is {self.best_mode}imised: "
-                          "the scheduler will read every improvement as a bad epoch")
-        for epoch in range(1, epochs + 1):
-            rec = {"epoch": epoch, "train": self.train_per_epoch(epoch)}
-            if self.validpipe is not None and epoch % self.eval_freq == 0:
-                rec["valid"] = self.evaluate("valid")
-                if "@" in self.which4best:
-                    name, k = self.which4best.split("@")
-                    score = rec["valid"].get(f"{name.upper()}@{k}")
-                else:
-                    score = rec["valid"].get(self.which4best.upper())
-                if score is not None and (self.best is None or self._better(score, self.best[1])):
-                    self.best = (epoch, score)
-                    if self.checkpoint_path:
-                        self.save_best(self.checkpoint_path)
-            self.history.append(rec)
-            if self.checkpoint_path:
-                self.save_checkpoint(self.checkpoint_path, epoch)
-        out = {"history": self.history, "best": self.best}
-        if self.testpipe is not None:
-            out["test"] = self.evaluate("test")
-        return out

@@ -97,6 +97,32 @@ extern "C" int re_dbg_tile_stale(unsigned* out8, int reset) {
 #define TL_STORE_PAD() do { } while (0)
 #endif
 
+// The step kernels' ONE argument.  A field the tile uses once, late, is read from the kernel-argument segment where it is used (TL_ARG).
+struct TlArgs {
+    SeEmbed em;
+    const int64_t* seq;
+    int B, S, L;
+    float drop_scale;
+    uint32_t thresh, seed;
+    float *u, *tape;
+    EncTape T;
+    const void* planp;
+    EncHead H;
+    float *dOut, *gtape, *slab;
+    const uint32_t* seed_dev;
+    float emb_scale;
+    const uint32_t* wf;
+    float* xch;
+};
+template <class T>
+__device__ __forceinline__ T tl_arg_at(unsigned off) {
+    asm volatile("" : "+s"(off));
+    typedef const char __attribute__((address_space(4))) ka_byte;
+    typedef const T __attribute__((address_space(4))) ka_T;
+    return *(ka_T*)((ka_byte*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+}
+#define TL_ARG(M) tl_arg_at<decltype(((TlArgs*)nullptr)->M)>((unsigned)offsetof(TlArgs, M))
+
 namespace tl4 {
 #define TL_NS 4
 #include "enc_tile_body.inc"
@@ -131,8 +157,8 @@ static int tl_launch(KP prep_k, KS step_k, const SeEmbed& em, const int64_t* seq
     if (ldsb < (size_t)84 * 1024) ldsb = (size_t)84 * 1024;
 #endif
     if (hipFuncSetAttribute((const void*)step_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-    hipLaunchKernelGGL(step_k, dim3(grid), dim3(64 * NS), ldsb, s, em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H,
-                       dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch);
+    const TlArgs A{em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H, dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch};
+    hipLaunchKernelGGL(step_k, dim3(grid), dim3(64 * NS), ldsb, s, A);
     return hipGetLastError() == hipSuccess ? RE_OK : RE_ELAUNCH;
 }
 

@@ -199,3 +199,75 @@ def test_next_item_eval_pipe_emits_one_row_per_held_out_item_on_ratio_splits():
     gen = mf.MF(ds)
     got = [(int(b[gen.User][i]), list(b[gen.IUnseen][i])) for b in gen.sure_validpipe("full") for i in range(len(b[gen.User]))]
     assert got == [(0, [8, 9]), (1, [3])]
+
+
+def _aggregate_like_build_data(evaluations):
+    """recboard/scripts/build-data.mjs:49-82,116-131 restated: normalizeRun + aggregateRuns over a file's evaluations."""
+    out = []
+    for ev in evaluations if isinstance(evaluations, list) else [evaluations]:
+        runs = [dict(r, metrics={k: (r.get("metrics") or {}).get(k) or {} for k in ("train", "valid", "test", "best")}) for r in ev.get("runs") or []]
+        keys = list(runs[0]["metrics"]["best"]) if runs else []
+        best = {}
+        for k in keys:
+            vals = [r["metrics"]["best"][k] for r in runs if r["metrics"]["best"].get(k) is not None]
+            mean = sum(vals) / len(vals) if vals else 0.0
+            best[k] = {"mean": mean, "std": (sum((v - mean) ** 2 for v in vals) / len(vals)) ** 0.5 if vals else 0.0}
+        out.append({"description": ev.get("description") or "", "tags": ev.get("tags") or [], "bestMetrics": best, "runs": runs,
+                    "config": ev.get("config") or {}, "timestamp": ev.get("timestamp") or ""})
+    return out
+
+
+def test_fit_of_an_unchanged_script_writes_the_leaderboard_record(tmp_path):
+    """`Coach.fit()` of examples/SASRec/main.py (CPU: the script's own torch code) ends with `results.json` in the
+    schema of benchmark/<dataset>/<model>.json (benchmark/Amazon2014Beauty_550_LOU/SASRec.json:1-304), field by field the shape of the
+    published rows (tests/golden/benchmark_rows.json) and readable by the restated aggregation of recboard/scripts/build-data.mjs:95-146."""
+    import datetime
+    import json
+    import re
+    import freerec
+    own = import_script(os.path.join(ROOT, "examples", "SASRec", "main.py"), "_own_sasrec_record", ["--dropout-rate", "0.2", "--seed", "3"])
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(200)
+    seqs = []
+    for _ in range(120):
+        s = [int(rng.integers(0, 200))]
+        for _ in range(int(rng.integers(4, 20))):
+            s.append(int(perm[s[-1]]) if rng.random() < 0.8 else int(rng.integers(0, 200)))
+        seqs.append(s)
+    ds = freerec.data.datasets.RecDataSet.from_sequences(seqs, 200)
+    cfg = own.cfg
+    cfg.epochs, cfg.eval_freq, cfg.device, cfg.batch_size, cfg.dataset = 3, 1, "cpu", 32, "Synthetic_550_LOU"
+    published = json.load(open(os.path.join(G, "benchmark_rows.json")))["Amazon2014Beauty_550_LOU/SASRec"][0]
+    cfg.monitors = ["LOSS"] + sorted(published["valid"])          # the published run's monitors: HITRATE@{1,5,10,20,50}, NDCG@{5,10,20,50}
+    cfg.which4best, cfg.checkpoint_path, cfg.eval_test = "NDCG@10", str(tmp_path), True
+    model = own.SASRec(ds)
+    coach = own.CoachForSASRec(dataset=ds, trainpipe=model.sure_trainpipe(cfg.maxlen, cfg.batch_size), validpipe=model.sure_validpipe(cfg.maxlen, ranking="full"),
+                               testpipe=model.sure_testpipe(cfg.maxlen, ranking="full"), model=model, cfg=cfg)
+    out = coach.fit()
+    rec = json.load(open(tmp_path / "results.json"))
+    assert isinstance(rec, list) and len(rec) == 1
+    ev = rec[0]
+    assert list(ev) == ["description", "dataset", "tags", "runs", "timestamp", "config"]       # the published file's keys, in its order
+    assert ev["dataset"] == "Synthetic_550_LOU" and isinstance(ev["description"], str) and all(isinstance(t, str) for t in ev["tags"]) and ev["tags"]
+    datetime.datetime.strptime(ev["timestamp"], "%Y-%m-%dT%H:%M:%S")
+    assert len(ev["runs"]) == 1
+    run = ev["runs"][0]
+    assert list(run) == ["id", "params", "metrics"] and isinstance(run["id"], str) and set(run["params"]) == {"config", "seed"} and run["params"]["seed"] == 3
+    assert list(run["metrics"]) == ["train", "valid", "test", "best"]
+    # field by field the published row's shape: the same metric names per split, plain floats
+    for split in ("train", "valid", "test", "best"):
+        assert set(run["metrics"][split]) == set(published[split]), (split, sorted(run["metrics"][split]))
+        assert all(isinstance(v, float) and 0.0 <= v for v in run["metrics"][split].values())
+    assert all(re.fullmatch(r"(HITRATE|NDCG)@\d+", k) for k in run["metrics"]["best"])
+    m = run["metrics"]
+    assert m["valid"] == out["valid"] and m["test"] == out["test"] and m["best"] == out["best_test"] and m["train"] == out["history"][-2]["train"]
+    for split in ("valid", "test", "best"):       # the identities the published rows satisfy (one held-out target per user)
+        assert m[split]["HITRATE@1"] <= m[split]["HITRATE@5"] <= m[split]["HITRATE@10"] <= m[split]["HITRATE@50"]
+        assert m[split]["NDCG@10"] <= m[split]["HITRATE@10"] + 1e-12
+    # the config dump: what the script's cfg holds, JSON-clean (build-data.mjs filters its own blacklist)
+    assert ev["config"]["maxlen"] == cfg.maxlen and ev["config"]["which4best"] == "NDCG@10" and ev["config"]["epochs"] == 3
+    agg = _aggregate_like_build_data(rec)[0]
+    assert set(agg["bestMetrics"]) == set(published["best"]) and agg["bestMetrics"]["NDCG@10"]["mean"] == m["best"]["NDCG@10"] and agg["bestMetrics"]["NDCG@10"]["std"] == 0.0
+    # history: one record per epoch (evaluation in front of the epoch) + the final evaluations; the best checkpoint exists
+    assert [h["epoch"] for h in out["history"]] == [0, 1, 2, 3] and all("train" in h for h in out["history"][:-1]) and "valid" in out["history"][-1]
+    assert os.path.exists(tmp_path / "best.pt")

@@ -146,6 +146,82 @@ def test_deepfm_script_runs_on_its_engine_and_matches_the_golden(tmp_path):
     _train_both_ways(lambda engine: build(engine, lr=1e-3), 3, 1e-3, skip=(".linear.bias",))
 
 
+def test_deepfm_resume_keeps_the_reduced_learning_rate_and_checkpoints_move_between_engine_and_module(tmp_path):
+    """(1) `--resume` under an adopted engine starts the next epoch at the learning rate ReduceLROnPlateau had reached (it is
+    pushed into `coach.optimizer.param_groups`, which `begin_epoch` reads), (2) `checkpoint.tar["optimizer"]` is torch.optim.Adam's own
+    state_dict shape over the script's two parameter groups, so a checkpoint written on the engine loads into `--engine module` (and back);
+    (3) the fused evaluation monitors the reference Coach's batch-weighted mean of per-batch AUC / LOGLOSS, equal to `--engine module`'s."""
+    z = np.load(os.path.join(G, "deepfm.npz"))
+    args = [a if a != "0.3" else "0.0" for a in DEEPFM_ARGS]
+    mod = import_script(os.path.join(EX, "DeepFM", "main.py"), "_gpu_bridge_deepfm_resume", args)
+    ds = deepfm_dataset(z)
+    rng = np.random.default_rng(5)
+    counts = z["cfg/counts"].tolist()
+
+    def batches(n, B):
+        out = []
+        for _ in range(n):
+            x = np.stack([rng.integers(0, c, B) for c in counts], 1)
+            y = rng.integers(0, 2, (B, 1)).astype(np.float32)             # (labels independent of the fields: AUC stays ~0.5, the plateau is certain)
+            out.append((x, y))
+        return out
+
+    train, valid = batches(3, 256), batches(3, 200) + batches(1, 57)      # (unequal evaluation batches: per-batch mean != global value)
+
+    def build(engine, path, resume=False):
+        model = mod.DeepFM(ds)
+        load_deepfm_golden(model, z)
+
+        def pipe(bs):
+            out = []
+            for x, y in bs:
+                b = {f: torch.from_numpy(x[:, i:i + 1]) for i, f in enumerate(model.input_fields)}
+                b[model.Label], b[model.Size] = torch.from_numpy(y), len(y)
+                out.append(b)
+            return out
+        cfg = _cfg(mod, engine=engine, lr=1e-2, monitors=["LOSS", "LOGLOSS", "AUC"], which4best="AUC", checkpoint_path=str(path), epochs=4, eval_freq=1,
+                   resume=resume, checkpoint_freq=1)
+        cfg.lr_scheduler = dict(factor=0.1, threshold=10.0, min_lr=1e-6)       # (patience = eval_freq = 1; threshold 10: no epoch "improves")
+        coach = mod.CoachForDeepFM(dataset=ds, trainpipe=pipe(train), validpipe=pipe(valid), testpipe=None, model=model, cfg=cfg)
+        return model, coach
+
+    pa, pm = tmp_path / "auto", tmp_path / "module"
+    model, coach = build("auto", pa)
+    assert coach._engine is not None and coach._engine.sched_mode == "front_best"
+    coach.fit()
+    lr_end = coach.optimizer.param_groups[0]["lr"]
+    assert lr_end < 1e-2 and abs(coach._engine.eng.lr - lr_end) < 1e-15             # (the plateau schedule has reduced the rate)
+    ck = torch.load(pa / "checkpoint.tar", weights_only=False)
+    assert set(ck["optimizer"]) == {"state", "param_groups"} and len(ck["optimizer"]["param_groups"]) == 2
+    assert abs(ck["optimizer"]["param_groups"][0]["lr"] - lr_end) < 1e-15 and len(ck["optimizer"]["state"]) == len(list(model.parameters()))
+    # (3) the monitored evaluation values: the batch-weighted mean of per-batch values, as the script's own torch path monitors them
+    modelm, coachm = build("module", pm)
+    modelm.load_state_dict(model.state_dict())
+    mod.cfg.engine = "auto"                # (the scripts share one cfg object: `coach` evaluates fused, `coachm` has no engine attached)
+    ra, rm = coach.valid(9), coachm.valid(9)
+    assert abs(ra["AUC"] - rm["AUC"]) < 1e-5 and abs(ra["LOGLOSS"] - rm["LOGLOSS"]) < 1e-5
+    # (1) resume on the engine: the reduced rate, the moments, the step count
+    model2, coach2 = build("auto", pa, resume=True)
+    assert coach2.resume() == 5
+    assert abs(coach2.optimizer.param_groups[0]["lr"] - lr_end) < 1e-15 and abs(coach2.optimizer.param_groups[1]["lr"] - lr_end) < 1e-15
+    assert coach2._engine.eng.step == coach._engine.eng.step and torch.equal(coach2._engine.eng.m, coach._engine.eng.m)
+    coach2.train(5)
+    assert abs(coach2._engine.eng.lr - coach2.optimizer.param_groups[0]["lr"]) < 1e-15 and coach2._engine.eng.lr <= lr_end
+    # (2) the engine's checkpoint loads into the script's own torch optimizer (same groups, same per-parameter moments), and back
+    coachm.cfg.checkpoint_path = str(pa)
+    coachm.path = str(pa)
+    assert coachm.load_checkpoint() == 4
+    st = coachm.optimizer.state_dict()
+    assert abs(st["param_groups"][0]["lr"] - lr_end) < 1e-15
+    mom = {id(p): coachm.optimizer.state[p]["exp_avg"] for p in modelm.parameters()}
+    ma, _ = coach._engine.named_moments()
+    for n, p in modelm.named_parameters():
+        torch.testing.assert_close(mom[id(p)].reshape(-1), ma[n].reshape(-1).to(mom[id(p)].device), rtol=0, atol=0)
+    coachm.save_checkpoint(7, str(pm))
+    model3, coach3 = build("auto", pm)
+    assert coach3.load_checkpoint() == 7 and torch.equal(coach3._engine.eng.m, coach._engine.eng.m) and coach3._engine.eng.step == coach._engine.eng.step
+
+
 def test_sasrec_ce_script_runs_on_the_engine():
     z = np.load(os.path.join(G, "sasrec_ce.npz"))
     mod = import_script(os.path.join(EX, "SASRec", "main.py"), "_gpu_bridge_sasrec_ce", ["--dropout-rate", "0", "--loss", "CE"])

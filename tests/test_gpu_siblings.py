@@ -346,7 +346,7 @@ def test_coach_runs_a_graph_sibling_end_to_end(graph):
     coach = Coach(m, trainpipe, validpipe, monitors=("LOSS", "HitRate@10", "NDCG@10"), which4best="NDCG@10", eval_freq=1, kind="module",
                   optimizer=opt, fit_keys=("User", "IPos", "INeg"), graph=graph)
     out = coach.fit(3)
-    losses = [h["train"]["LOSS"] for h in out["history"]]
+    losses = [h["train"]["LOSS"] for h in out["history"] if "train" in h]      # (the last record holds the final evaluations)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     # dense restatement of the last evaluation
     m.reset_ranking_buffers()
@@ -387,7 +387,7 @@ def test_coach_runs_a_sequence_sibling():
     coach = Coach(m, trainpipe, validpipe, monitors=("LOSS", "NDCG@10"), eval_freq=1, kind="module",
                   optimizer=torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True), fit_keys=("ISeq", "IPos", "INeg"), graph=True)
     out = coach.fit(2)
-    assert np.isfinite(out["history"][-1]["train"]["LOSS"]) and 0.0 <= out["history"][-1]["valid"]["NDCG@10"] <= 1.0
+    assert np.isfinite(out["history"][-2]["train"]["LOSS"]) and 0.0 <= out["history"][-1]["valid"]["NDCG@10"] <= 1.0
     # the fused top-K of the evaluation = torch.topk on the masked dense scores
     x = torch.from_numpy(ev).cuda()
     sp, si = coach_csr = __import__("recboard_amd.evaluate", fromlist=["ragged_to_csr"]).ragged_to_csr(validpipe[0]["ISeen"], "cuda")
