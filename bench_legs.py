@@ -98,7 +98,29 @@ def leg_config1():
         omf.fit(Ut, It, u, p, n).backward()
         opt.step()
     ms_graph, ms = ms, min(ms, ms_eager)        # (`value` is the faster form: whichever the Coach would run)
-    return {"metric": "train triplets/sec (MF-BPR d=64, Beauty shapes, B=2048, 1 GPU)", "value": round(B / (ms * 1e-3), 1), "unit": "triplets/s",
+    # the step's dominant launch: scatter-add of the 3 x B gradient rows + the DENSE Adam of all U + N rows (coupled L2 touches every row:
+    # MF-BPR/main.py:115-131 with torch.optim.Adam(weight_decay)) = re_scatter_adam_rows_small.  Algorithmic bytes: per parameter element
+    # 12 B read (p, m, v) + 12 B written, per contribution row 4 (key) + 4 D read.
+    t_own = None
+    try:
+        from recboard_amd import ops
+        u0, p0, n0 = dev[0]
+        m.train_step(u0, p0, n0)
+        own = getattr(m, "_owner_call", None)
+        if own is not None:
+            t_own = ev_ms(own, iters=100)
+    except Exception:  # noqa: BLE001
+        t_own = None
+    own_bytes = (U + N) * D * 24 + 3 * B * (4 + 4 * D)
+    roof1 = None
+    if t_own:
+        roof1 = {"kernel": "scatter_adam_owner_k (re_scatter_adam_rows_small): scatter-add of the step's 3 x B gradient rows + dense Adam of all "
+                           f"{U + N} rows in one launch", "bound": "hbm", "achieved": round(own_bytes / (t_own * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(own_bytes / (t_own * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(t_own, 4),
+                 "work": f"algorithmic {own_bytes / 1e6:.1f} MB per launch: {(U + N) * D} parameter elements x (12 B read + 12 B written) + {3 * B} "
+                         f"contribution rows x (4 + {4 * D}) B (the 26 MB of parameters and moments live in the Infinity Cache between steps: "
+                         "the bound a launch of this size sees is the cache's, not HBM's)"}
+    return {"metric": "train triplets/sec (MF-BPR d=64, Beauty shapes, B=2048, 1 GPU)", **({"roofline": roof1} if roof1 else {}), "value": round(B / (ms * 1e-3), 1), "unit": "triplets/s",
             "ms_per_step": round(ms, 4), "ms_per_step_graph": round(ms_graph, 4), "config": {"workload": f"MF-BPR d=64, {U} users x {N} items, B={B}, Adam(lr 1e-3, wd 1e-6); users uniform, positives Zipf(1.0)"},
             "ms_per_step_eager": round(ms_eager, 4),
             "launch": "per step: the step's scalars (one tiny launch), the fused triplet forward + backward (gradient rows + their destination rows in the "
@@ -192,6 +214,17 @@ def leg_config4():
     ms = wall_ms(lambda: d.train_step_graph(*dev[next(it) % 8]), iters=100, warmup=10)
     x0 = dev[0][0]
     t_bag = ev_ms(lambda: ops.fm_bag_fwd(d.T, d.TL.reshape(-1), d.bias, d.offsets, x0), iters=100)
+    # the step's dominant kernels: the MLP's products (DeepFM/main.py:103-124,151-164) -- the 400 x 400 layer's forward / input-gradient /
+    # weight-gradient forms, timed alone (re_gemm_f32: exact fp32 on v_mfma_f32_16x16x4_f32)
+    gh = torch.randn(B, 400, device="cuda")
+    gw = torch.randn(400, 400, device="cuda")
+    gz = torch.randn(B, 400, device="cuda")
+    gemm_ms = {"forward x W^T [4096 x 400 x 400]": ev_ms(lambda: ops.gemm(gh, gw, transB=True), iters=50),
+               "input gradient dz W [4096 x 400 x 400]": ev_ms(lambda: ops.gemm(gz, gw), iters=50),
+               "weight gradient dz^T x [400 x 400 x 4096]": ev_ms(lambda: ops.gemm(gz, gh, transA=True), iters=50)}
+    gfl = 2.0 * B * 400 * 400
+    t_g = gemm_ms["forward x W^T [4096 x 400 x 400]"]
+    step_fl = 3 * 2.0 * B * (100 * 400 + 400 * 400 + 400 * 400)                     # forward + input gradient + weight gradient of the three layers
     F = len(counts)
     alg = B * F * (8 + 4 * D + 4) + B * (F * D * 4 + 4)                      # F (8 + 40 + 4) B gathered per row, + E [B, F D] and fm_lr [B] written
     gbs = alg / (t_bag * 1e-3) / 1e9
@@ -223,7 +256,18 @@ def leg_config4():
             "launch": "one hipGraph replay per step, or its launches issued eagerly: `value` is the faster form",
             "config": {"workload": f"DeepFM: {F} embedding fields (cardinalities {counts}), D={D}, MLP {dims}->1 with BatchNorm + dropout 0.1, B={B}, "
                                    "BCE, clip 10, Adam with the reference's two weight-decay groups (DeepFM/main.py:187-199,264-268)"},
-            "roofline": {"kernel": "fm_bag_fwd_k (re_fm_bag_fwd): every field's row + FM second-order term + LR term per input row", "bound": "hbm",
+            "roofline": {"kernel": "gemm_wide_k (re_gemm_f32): the MLP's 400 x 400 layer, forward product x W^T at [4096 x 400 x 400] -- the step's dominant "
+                                   "kernel family (9 such products a step: 3 layers x forward / input gradient / weight gradient)", "bound": "mfma",
+                         "achieved": round(gfl / (t_g * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(gfl / (t_g * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None, "launch_ms": round(t_g, 4),
+                         "forms": {k: {"launch_ms": round(v, 4), "TFLOP/s": round(gfl / (v * 1e-3) / 1e12, 2), "frac": round(gfl / (v * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)}
+                                   for k, v in gemm_ms.items()},
+                         "whole_step": {"mlp_FLOP": step_fl, "TFLOP/s": round(step_fl / (min(ms, ms_eager) * 1e-3) / 1e12, 2),
+                                        "frac": round(step_fl / (min(ms, ms_eager) * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                                        "note": "the MLP's FLOP over the WHOLE step time (embedding bag, BatchNorm passes, scatter-add, clip, Adam included)"},
+                         "work": f"2 M N K = {gfl:.3e} FLOP per launch, exact fp32 (v_mfma_f32_16x16x4_f32); 64-row x 112-column workgroup tiles: 256 workgroups, "
+                                 "7 column tiles a wave against 6.25 ideal"},
+            "roofline_fm_bag": {"kernel": "fm_bag_fwd_k (re_fm_bag_fwd): every field's row + FM second-order term + LR term per input row", "bound": "hbm",
                          "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                          "launch_ms": round(t_bag, 4),
                          "work": f"algorithmic {alg / 1e6:.2f} MB per launch: {B} rows x {F} fields x (8 + {4 * D} + 4) B gathered + {F * D * 4 + 4} B written per row "

@@ -277,7 +277,8 @@ class Coach:
             for name, t in tot.items():
                 self._meters[mode][name].update(float(t) / max(n, 1), max(n, 1), "mean")
             return True
-        if self.cfg.get("ranking", "full") != "full":
+        ranking = self.cfg.get("ranking", "full")
+        if ranking not in ("full", "pool") or (ranking == "pool" and not hasattr(self._engine, "recommend_pool")):
             return False
         from recboard_amd import ops
         from recboard_amd.evaluate import RankingEvaluator
@@ -286,6 +287,20 @@ class Coach:
             return True
         if any(m.split("@")[0] not in ops.METRIC_NAMES for m in mons):     # a ranking monitor the metrics kernel does not have: the dense path
             return False
+        if ranking == "pool":
+            # `--ranking=pool` (UniSRec/main.py:415-421: scores [B, 1 + K] of the target and K sampled unseen items, targets[:, 0] = 1): the
+            # pool's rows gathered and dotted by one launch, the exact top-K of the row (ties to the lowest position -- the target's, as in the
+            # full ranking), the metrics kernel against the target list {position 0}
+            ev = RankingEvaluator(mons)
+            self._engine.reset_ranking_buffers()
+            for data in self.dataloader:
+                scores = self._engine.recommend_pool(self, data)
+                B = scores.shape[0]
+                _, idx = ops.pool_topk(scores, ev.kmax)
+                ev.update(idx, torch.arange(B + 1, dtype=torch.int64, device=self.device), torch.zeros(B, dtype=torch.int64, device=self.device))
+            for name, val in ev.compute().items():
+                self._meters[mode][name].update(val, max(ev.n, 1), "mean")
+            return True
         ev = RankingEvaluator(mons)
         self._engine.reset_ranking_buffers()
         for j, data in enumerate(self.dataloader):

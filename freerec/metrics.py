@@ -59,10 +59,10 @@ def auroc(preds, targets, reduction="mean"):
     order = torch.argsort(torch.cat([pos, neg]))
     ranks = torch.empty_like(order, dtype=torch.float64)
     vals = torch.cat([pos, neg])[order]
-    ranks[order] = torch.arange(1, order.numel() + 1, dtype=torch.float64)
+    ranks[order] = torch.arange(1, order.numel() + 1, dtype=torch.float64, device=order.device)
     # average ranks over ties
     uniq, inv, cnt = torch.unique(vals, return_inverse=True, return_counts=True)
-    sums = torch.zeros(uniq.numel(), dtype=torch.float64).index_add_(0, inv, ranks[order])
+    sums = torch.zeros(uniq.numel(), dtype=torch.float64, device=order.device).index_add_(0, inv, ranks[order])
     ranks[order] = (sums / cnt)[inv]
     u = ranks[: pos.numel()].sum() - pos.numel() * (pos.numel() + 1) / 2
     return (u / (pos.numel() * neg.numel())).to(torch.float32)

@@ -305,8 +305,9 @@ int re_route_bucket(const int64_t* idx, int64_t n, int64_t R, int64_t G, int64_t
  *   split_long is a mask.  & 2: the plan must NOT hand the step to the one-tile-per-workgroup kernels (re_sasrec_encoder_step: hdr[7] stays 0).
  *   & 4: the plan MUST hand it to them where their grid allows.  Otherwise: batches of up to 2048 possible tiles (B <= 512 at S = 50) run a
  *   workgroup per tile -- at most 1024 tiles, at most 3/4 of the CUs' worth of them tiles of sequences longer than 16 rows; larger batches the
- *   looped form (one workgroup per CU, the tiles beyond the grid handed out by a counter: any number of tiles) where it is the faster of the
- *   two: at most 1.5 tiles of long sequences and at most 10 tiles in all per resident workgroup.
+ *   looped form (the resident workgroups -- one per CU; two at D = 64, which the caller declares with & 8 -- with the tiles beyond the grid
+ *   handed out by a counter: any number of tiles) where it is the faster of the two: at most 1.5 tiles of long sequences and at most 10 tiles
+ *   in all per resident workgroup.
  *   & 1: a sequence of 3 - 4 tiles becomes TWO work items (its first two tiles / the rest) that run in two workgroups at
  *   once and hand k, v (forward) and the partial dK, dV (backward) over through the tape -- the launch lasts as long as its largest
  *   item.  Only done when every item of the plan still gets a workgroup of its own (<= ncu items); needs a tape whose flag words
@@ -513,6 +514,15 @@ int re_bce_logits(const float* logits, const float* labels, int64_t n, float* lo
 /* AUC of a prediction model's scores (DeepFM/configs/Frappe_x1_BARS.yaml:101-102 `monitors: [LOGLOSS, AUC]`; scores =
  * recommend_from_pool outputs, DeepFM/main.py:217-219; labels > 0.5 = positive): the Mann-Whitney statistic counted pairwise --
  * no sort, integer counts (exact, deterministic), ties count one half.  auc[0] = 0.5 if a class is empty.  ws: 256 bytes. */
+/* Pool ranking (`--ranking=pool`; recommend_from_pool: SASRec/main.py:230-236, MF-BPR/main.py:106-109, LightGCN/main.py:122-125).
+ * re_score_pool: out[b][p] = <Q[b,:], E[pool[b][p],:]> (natural-k fmaf chain: the value re_score_dense gives the pair, bit for bit);
+ *   pool int64 [B, P] item ids; an id outside [0, N) scores -inf.  D a multiple of 4, rows 16-byte aligned.
+ * re_pool_topk: per row of scores [B, P] the exact top-K (vals descending, idx = position in the row, ties -> lowest position; slots
+ *   beyond P get (-inf, -1)); P <= 1024.  With the evaluation pipes' layout (target at position 0) re_rank_metrics on idx against
+ *   the target list {0} gives every NAME@k. */
+int re_score_pool(const float* Q, const float* E, const int64_t* pool, int64_t B, int64_t P, int64_t N, int64_t D, float* out,
+                  re_stream_t stream);
+int re_pool_topk(const float* scores, int64_t B, int64_t P, int64_t K, float* vals, int64_t* idx, re_stream_t stream);
 size_t re_auc_workspace_bytes(void);
 int re_auc(const float* scores, const float* labels, int64_t n, float* auc, void* ws, size_t ws_bytes, re_stream_t stream);
 /* hipGraph-friendly variant of re_adam_step: hyper (DEVICE float[2]) = { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) };
@@ -523,6 +533,14 @@ int re_auc(const float* scores, const float* labels, int64_t n, float* auc, void
 int re_step_state(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, re_stream_t stream);
 int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1,
                      double beta2, double eps, double weight_decay, re_stream_t stream);
+/* clip_grad_norm_ + Adam (DeepFM/main.py:264-268).  re_grad_clip_coef: coef_norm[0] = min(1, max_norm / (||g||_2 + 1e-6)) (torch's
+ * formula), coef_norm[1] = ||g||_2 over the flat gradient, as device words (deterministic two-stage sum).  re_adam_step_scaled: Adam on
+ * gscale[0] * g with the scaled gradient written back to g; step >= 1: the host's bias corrections, step == 0: the device words `hyper`
+ * (re_adam_step_dev's).  n a multiple of 4, 16-byte aligned buffers. */
+size_t re_grad_clip_workspace_bytes(void);
+int re_grad_clip_coef(const float* g, int64_t n, float max_norm, float* coef_norm, void* ws, size_t ws_bytes, re_stream_t stream);
+int re_adam_step_scaled(float* p, float* g, float* m, float* v, int64_t n, int64_t step, double lr, const float* hyper, double beta1,
+                        double beta2, double eps, double weight_decay, const float* gscale, re_stream_t stream);
 int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
                  double beta1, double beta2, double eps, double weight_decay, re_stream_t stream);
 
@@ -554,6 +572,14 @@ size_t re_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
                 const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws,
                 size_t ws_bytes, re_stream_t stream);
+/* C = alpha op(A) op(B) + bias, and in the same launch the BatchNorm batch statistics of C's columns as per-64-row partials:
+ * colstats [M / 64][2][N] = (mean, M2 = sum of squared deviations from it) of rows [64 b, 64 b + 64) -- `bn(linear(x))`
+ * (DeepFM/main.py:119-124) without a second pass over the linear map's output; re_bn_relu_drop_fwd_pre takes them.
+ * M a multiple of 64, operands 16-byte aligned with leading / contiguous dimensions in multiples of 4; otherwise
+ * RE_EUNSUPPORTED (run re_gemm_f32 + re_bn_relu_drop_fwd instead). */
+int re_gemm_f32_colstats(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colstats,
+                         re_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * DeepFM MLPBlock pieces around re_gemm_f32 (DeepFM/main.py:103-124: Linear -> BatchNorm1d -> ReLU -> Dropout):
@@ -571,6 +597,11 @@ int re_bn_relu_drop_fwd(const float* z, int64_t M, int64_t N, const float* gamma
 int re_bn_relu_drop_bwd(const float* da, const float* a, const float* z, int64_t M, int64_t N, const float* gamma,
                         const float* stats, float drop_p, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                         re_stream_t stream);
+/* re_bn_relu_drop_fwd in training mode with BatchNorm, the statistics' partials given: colstats [chunks][2][N] (chunk b = rows
+ * [b ceil(M / chunks), ...): (mean, M2)), chunks <= 64 -- what re_gemm_f32_colstats writes with chunks = M / 64. */
+int re_bn_relu_drop_fwd_pre(const float* z, int64_t M, int64_t N, const float* gamma, const float* beta, float* run_mean,
+                            float* run_var, float eps, float momentum, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                            uint32_t stream_id, float* stats, float* a, const float* colstats, int chunks, re_stream_t stream);
 int re_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, re_stream_t stream);
 size_t re_mlp_workspace_bytes(int64_t N);   /* scratch of the three entry points above (per-chunk column partials) */
 

@@ -71,6 +71,26 @@ def score_topk(Q, E, seen_ptr, seen_idx, K):
     return vals, idx
 
 
+def score_pool(Q: np.ndarray, E: np.ndarray, pool: np.ndarray) -> np.ndarray:
+    """recommend_from_pool (SASRec/main.py:230-236 einsum("BD,BKD->BK"); MF-BPR/main.py:106-109; LightGCN/main.py:122-125): scores [B, P] of
+    every row's candidate pool -- the entries of `score_dense` (the C fmaf chain) at the pool's columns."""
+    full = score_dense(np.ascontiguousarray(Q, np.float32), np.ascontiguousarray(E, np.float32))
+    return np.take_along_axis(full, np.asarray(pool, np.int64), axis=1)
+
+
+def pool_topk(scores: np.ndarray, K: int):
+    """Top-K of every row of a [B, P] pool score matrix, ties to the lowest position (the full ranking's rule; evaluate contract
+    UniSRec/main.py:415-421 puts the target at position 0); slots beyond P: (-inf, -1)."""
+    B, P = scores.shape
+    order = np.argsort(-scores.astype(np.float64), axis=1, kind="stable")
+    vals = np.full((B, K), -np.inf, np.float32)
+    idx = np.full((B, K), -1, np.int64)
+    k = min(K, P)
+    idx[:, :k] = order[:, :k]
+    vals[:, :k] = np.take_along_axis(scores, order[:, :k], axis=1)
+    return vals, idx
+
+
 def gather_rows_c(W, idx):
     W = np.ascontiguousarray(W, np.float32)
     ix = np.ascontiguousarray(idx, np.int64).reshape(-1)

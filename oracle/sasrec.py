@@ -51,7 +51,9 @@ def block(x, pad, P, l, drop=None, gates=None):
     """One SASRec block on x [B,S,D]; pad [B,S,1] bool.  SASRec/main.py:163-176.
     gates (optional): {l: (open [B,S,D] bool, eps)} -- where the FFN's pre-activation is within eps of zero (a relu kink) the gate
     is taken from `open` (the implementation under test) instead of the sign computed here: there the two sides' rounding decides,
-    and a flipped gate changes that element's gradient by its whole upstream value, which no tolerance covers."""
+    and a flipped gate changes that element's gradient by its whole upstream value, which no tolerance covers.  A third tuple element (a
+    dict) receives {window: real-row entries inside the window, total: real-row entries, mismatch_outside: real-row entries OUTSIDE the
+    window where `open` differs from this side's sign} -- the caller asserts a ceiling on the first and zero for the last."""
     B, S, D = x.shape
     pre = f"attnLayers.{l}."
     Wi, bi = P[pre + "in_proj_weight"], P[pre + "in_proj_bias"]
@@ -74,8 +76,14 @@ def block(x, pad, P, l, drop=None, gates=None):
     h = y @ W1.T + b1
     h = _apply(h, _mask(drop, rng.stream_ffn1(l), (B, S, D)))
     if gates is not None and l in gates:
-        open_, eps = gates[l]
-        h = h * torch.where(h.detach().abs() < eps, open_, h.detach() > 0).to(h.dtype)
+        open_, eps = gates[l][0], gates[l][1]
+        near = h.detach().abs() < eps
+        if len(gates[l]) > 2:      # a report for the caller to assert on: how many gates were borrowed, and whether the others agree
+            live = ~pad.expand_as(near)
+            nz = h.detach() != 0           # (an element dropout has zeroed is exactly 0 on both sides: its gate multiplies 0 forward and backward)
+            gates[l][2].update(window=int((near & live & nz).sum()), total=int((live & nz).sum()),
+                               mismatch_outside=int(((open_ != (h.detach() > 0)) & ~near & live).sum()))
+        h = h * torch.where(near, open_, h.detach() > 0).to(h.dtype)
     else:
         h = torch.relu(h)
     o = h @ W2.T + b2

@@ -101,6 +101,12 @@ class OptSpec:
         return w.pop()
 
 
+def _pool_tensor(pool, device):
+    """An evaluation batch's candidate pools (`ranking="pool"`: a [B, P] tensor, or equal-length lists) as int64 [B, P] on the device."""
+    t = pool if torch.is_tensor(pool) else torch.as_tensor(pool, dtype=torch.int64)
+    return t.to(device=device, dtype=torch.int64).reshape(t.shape[0], -1).contiguous()
+
+
 def _current_lr(coach, fallback):
     try:
         return float(coach.optimizer.param_groups[0]["lr"])
@@ -308,6 +314,9 @@ class SASRecAdapter(_Adapter):
     def recommend_topk(self, coach, data, seen_ptr, seen_idx, K):
         return self.eng.recommend_topk(data[coach.ISeq].to(coach.device), seen_ptr, seen_idx, K)
 
+    def recommend_pool(self, coach, data):
+        return self.eng.recommend_from_pool(data[coach.ISeq].to(coach.device), _pool_tensor(data[coach.IUnseen], coach.device))
+
 
 
 class MFAdapter(_Adapter):
@@ -392,6 +401,9 @@ class MFAdapter(_Adapter):
 
     def recommend_topk(self, coach, data, seen_ptr, seen_idx, K):
         return self.eng.recommend_topk(data[coach.User].to(coach.device).reshape(-1), seen_ptr, seen_idx, K)
+
+    def recommend_pool(self, coach, data):
+        return self.eng.recommend_from_pool(data[coach.User].to(coach.device).reshape(-1), _pool_tensor(data[coach.IUnseen], coach.device))
 
     def _adam_wd(self):
         return self.eng.wd

@@ -11,6 +11,7 @@ fused score+mask+top-K kernel and the metrics kernel; best epoch tracked on `whi
 host sync of the reference is replaced by one device-side accumulation read at the end of the epoch.
 """
 import os
+import weakref
 
 import torch
 
@@ -44,9 +45,16 @@ class _Direct:
     """What `freerec.launcher.Coach` asks of an engine adapter, for an engine OBJECT (no script, no probe: there is nothing to adopt)."""
 
     def __init__(self, coach):
-        self.c = coach
-        if coach.kind == "pred":       # (the base class tells a prediction model by this attribute)
-            self.pool_logits = self._pool_logits
+        # (a weak reference: coach -> adapter -> coach would be a cycle, and a Coach -- with its engine's captured hipGraphs -- would then be
+        #  freed by the cyclic collector at an arbitrary later moment, e.g. in the middle of ANOTHER engine's stream capture, which aborts)
+        self.c = weakref.proxy(coach)
+        self.is_pred = coach.kind == "pred"
+
+    def __getattr__(self, name):
+        # the base class tells a prediction model by the presence of `pool_logits`
+        if name == "pool_logits" and self.__dict__.get("is_pred"):
+            return self._pool_logits
+        raise AttributeError(name)
 
     def wants_fused_sampler(self):
         return False
@@ -64,6 +72,13 @@ class _Direct:
     def recommend_topk(self, coach, data, seen_ptr, seen_idx, K):
         key = {"seq": "ISeq", "gen": "User", "module": (coach.fit_keys or ("User",))[0]}[coach.kind]
         return coach.model.recommend_topk(data[key].to(coach.device), seen_ptr, seen_idx, K)
+
+    def recommend_pool(self, coach, data):
+        key = {"seq": "ISeq", "gen": "User", "module": (coach.fit_keys or ("User",))[0]}[coach.kind]
+        pool = data["IUnseen"]
+        pool = pool if torch.is_tensor(pool) else torch.as_tensor(pool, dtype=torch.int64)
+        x = data[key].to(coach.device)
+        return coach.model.recommend_from_pool(x if coach.kind == "seq" else x.reshape(-1), pool.to(coach.device).reshape(pool.shape[0], -1))
 
     def _pool_logits(self, coach, data):
         data = coach.dict_to_device(data)

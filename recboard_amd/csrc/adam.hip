@@ -92,6 +92,94 @@ extern "C" int re_adam_step(float* p, const float* g, float* m, float* v, int64_
     return re_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// clip_grad_norm_(parameters, max_norm) + Adam as two reductions and the optimizer launches (DeepFM/main.py:264-268: backward,
+// nn.utils.clip_grad_norm_(.., 10), optimizer.step()): re_grad_clip_coef leaves coef = min(1, max_norm / (||g|| + 1e-6)) in a device word
+// (torch's formula), re_adam_step_scaled / _dev_scaled multiply the gradient by it on the way in and write the clipped gradient back (what
+// p.grad holds after the reference's step).  The norm: per-block partial sums of squares in a fixed order (thread-sequential over a strided
+// slice, wave butterfly, four waves in order), then one wave over the partials -- deterministic.
+#define SQN_BLOCKS 256
+__global__ __launch_bounds__(256) void sqnorm_partial_k(const float4* __restrict__ g, int64_t n4, const float* __restrict__ tail, int ntail,
+                                                        float* __restrict__ partial) {
+    __shared__ float sw[4];
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = g[i];
+        a = fmaf(v.x, v.x, a); a = fmaf(v.y, v.y, a); a = fmaf(v.z, v.z, a); a = fmaf(v.w, v.w, a);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) a = fmaf(tail[threadIdx.x], tail[threadIdx.x], a);
+    a = re_wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+}
+__global__ __launch_bounds__(64) void clip_coef_k(const float* __restrict__ partial, int nb, float max_norm, float* __restrict__ out) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) a += partial[i];
+    a = re_wave_sum(a);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(a);
+        const float c = max_norm / (norm + 1e-6f);
+        out[0] = c < 1.0f ? c : 1.0f;
+        out[1] = norm;
+    }
+}
+
+extern "C" size_t re_grad_clip_workspace_bytes(void) { return SQN_BLOCKS * sizeof(float); }
+// coef_norm[0] = min(1, max_norm / (||g||_2 + 1e-6)), coef_norm[1] = ||g||_2 over the flat gradient g[0 .. n)
+extern "C" int re_grad_clip_coef(const float* g, int64_t n, float max_norm, float* coef_norm, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!g || !coef_norm || n < 0 || !(max_norm > 0.f)) return RE_EINVAL;
+    if (!ws || ws_bytes < re_grad_clip_workspace_bytes()) return RE_EWORKSPACE;
+    if (reinterpret_cast<uintptr_t>(g) & 15u) return RE_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n4 = n >> 2;
+    int nb = (int)re_cdiv(n4 > 0 ? n4 : 1, 1024);
+    if (nb > SQN_BLOCKS) nb = SQN_BLOCKS;
+    hipLaunchKernelGGL(sqnorm_partial_k, dim3(nb), dim3(256), 0, s, (const float4*)g, n4, g + (n4 << 2), (int)(n & 3), (float*)ws);
+    hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(64), 0, s, (const float*)ws, nb, max_norm, coef_norm);
+    return re_launch_status();
+}
+
+// Adam on gscale[0] * g; the scaled gradient is written back to g.  hyper == NULL: step_size / inv_sqrt_bc2 as given.
+__global__ __launch_bounds__(256) void adam_vec4_scaled(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v,
+                                                        int64_t n4, float b1, float b2, float omb1, float omb2, float step_size, float inv_sqrt_bc2,
+                                                        const float* __restrict__ hyper, float eps, float wd, const float* __restrict__ gscale) {
+    if (hyper) { step_size = hyper[0]; inv_sqrt_bc2 = hyper[1]; }
+    if (inv_sqrt_bc2 == 0.f) return;   // (a gated step: see adam_vec4_dev)
+    const float c = gscale[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = p[i], G = g[i], M = m[i], V = v[i];
+        G.x *= c; G.y *= c; G.z *= c; G.w *= c;
+        g[i] = G;
+#define RE_ADAM1(c_) re_adam1(P.c_, M.c_, V.c_, G.c_, b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd);
+        RE_ADAM1(x) RE_ADAM1(y) RE_ADAM1(z) RE_ADAM1(w)
+#undef RE_ADAM1
+        p[i] = P; m[i] = M; v[i] = V;
+    }
+}
+
+// step >= 1: the host's bias corrections (re_adam_step's); step == 0: `hyper` (device words, re_adam_step_dev's).  n a multiple of 4.
+extern "C" int re_adam_step_scaled(float* p, float* g, float* m, float* v, int64_t n, int64_t step, double lr, const float* hyper, double beta1,
+                                   double beta2, double eps, double weight_decay, const float* gscale, re_stream_t stream) {
+    re_clear_error();
+    if (n == 0) return RE_OK;
+    if (!p || !g || !m || !v || !gscale || n < 0 || (step < 1 && !hyper)) return RE_EINVAL;
+    if ((n & 3) || ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v)) & 15u) != 0)
+        return RE_EUNSUPPORTED;
+    float step_size = 0.f, inv_sqrt_bc2 = 1.f;
+    if (step >= 1) {
+        step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
+        hyper = nullptr;
+    }
+    hipLaunchKernelGGL(adam_vec4_scaled, dim3(re_grid(n >> 2, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
+                       n >> 2, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), step_size, inv_sqrt_bc2, hyper, (float)eps,
+                       (float)weight_decay, gscale);
+    return re_launch_status();
+}
+
 // dst = alpha * src over a flat fp32 range (LightGCN: avgEmbds = allEmbds / (L+1), LightGCN/main.py:80)
 __global__ __launch_bounds__(256) void scale_copy_k(float* __restrict__ dst, const float* __restrict__ src, float alpha, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = alpha * src[i];

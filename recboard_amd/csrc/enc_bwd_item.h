@@ -149,7 +149,7 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
         const int npre = split_hi ? 2 : (C::MAXT < 4 ? hs * C::MAXT : 0);     // prefix key tiles
         const bool has_succ = split_lo || (C::MAXT < 4 && hs + 1 < nsub);    // a later part leaves partial dK / dV for these rows
         const int64_t prow0 = (int64_t)(whole.tile0 - (split_hi ? 2 : 0)) * 16;   // compact row of the sequence's first row
-        if (hs + 1 < nsub) __syncthreads();                  // (a full barrier: the later part's gradient-tape stores have completed)
+        if (hs + 1 < nsub) re_sync_full();                   // (a full barrier: the later part's gradient-tape stores have completed)
         const bool first_part = k == 0 && hs == nsub - 1;    // the workgroup's first flush of its vector-gradient slab
         const int nt = it.nt, nrows = 16 * nt;
         const int64_t row0 = (int64_t)it.tile0 * 16;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void enc_bwd_item(const float* __restrict__ dIn, cons
             if (npre) {                                                                             // partial dK of the prefix rows
                 if (split_hi) {
                     tile_store_coh<D>(bV0, gpre + 4 * NR * D, 16 * npre, tid);
-                    __syncthreads();   // (with vmcnt(0): both partial tiles of this block have left this CU)
+                    re_sync_full();    // (with vmcnt(0): both partial tiles of this block have left this CU)
                     if (tid == 0) enc_flag_set(tflags, prow0 / 16, 4 + l);
                 } else {
                     tile_store<D>(bV0, gpre + 4 * NR * D, 16 * npre, tid);

@@ -87,6 +87,8 @@ __host__ __device__ inline int64_t enc_plan_max_tiles(int64_t B, int64_t S) { re
 // which form of the tile kernels a launch of this shape uses (enc_tile_body.inc: enc_tile_step_k<LOOP>): batches of more than 2048 possible
 // tiles (B > 512 at S = 50) the looped one -- the plan (enc_plan_body.h) applies the matching rule
 __host__ __device__ inline bool enc_tile_looped(int64_t B, int64_t S) { return enc_plan_max_tiles(B, S) > 2048; }
+// resident workgroups per CU of the tile kernels (enc_tile.hip: four waves a workgroup at D = 64 -- two fit; eight at D = 128 -- one)
+__host__ __device__ inline int enc_tile_wg_per_cu(int64_t D) { return D == 64 ? 2 : 1; }
 // rows of the vector-gradient slab in the backward's workspace: one per workgroup (<= 1024) or one per tile (enc_tile.hip)
 __host__ __device__ inline int64_t enc_slab_rows(int64_t B, int64_t S) { const int64_t mt = enc_plan_max_tiles(B, S); return mt > 1024 ? mt : 1024; }
 __host__ __device__ inline int64_t enc_plan_rowmap_word(int64_t B, int64_t S) { return (EP_HDR + enc_plan_max_tiles(B, S) + 1) / 2 * 2; }
@@ -138,10 +140,10 @@ __host__ __device__ inline EncTape enc_tape_layout(int64_t B, int64_t S, int64_t
 // vector gradients per block: 0 bq 1 bk 2 bv 3 bo 4 b1 5 b2 6 ga 7 ba 8 gf 9 bf 10 glast 11 blast
 #define EG_NVEC 12
 
-// Workgroup barrier for LDS hand-offs.  __syncthreads() also fences global memory: hipcc puts `s_waitcnt vmcnt(0)` in front of the
-// barrier, i.e. every phase boundary would wait for the weight fragments / tape tiles requested for LATER phases and for the
-// tape stores issued in this one (a full L2 round trip per barrier, ~10 per block).  Nothing that crosses waves inside these
-// kernels goes through global memory, so the barrier only has to order LDS traffic: the wave's own LDS operations are complete
+// Workgroup barrier for LDS hand-offs.  Nothing that crosses waves inside a phase of these kernels goes through global memory, so the
+// barrier only has to order LDS traffic (where global memory does cross waves or workgroups -- tape rows read back by other threads, flags
+// behind published rows -- the sites use re_sync_full(): a vmcnt(0) drain in front of the barrier; `__syncthreads()` does NOT include
+// one on gfx950, re_common.h): the wave's own LDS operations are complete
 // (lgkmcnt(0)), the memory clobber keeps the compiler from moving accesses across it, and vector-memory operations stay in flight.
 __device__ __forceinline__ void enc_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 

@@ -94,7 +94,7 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
         const EncItem it = EncItem{whole.tile0 + hs * C::MAXT, whole.nt - hs * C::MAXT < C::MAXT ? whole.nt - hs * C::MAXT : C::MAXT, whole.kind};
         const int npre = split_hi ? 2 : (C::MAXT < 4 ? hs * C::MAXT : 0);     // prefix key tiles
         const int64_t prow0 = (int64_t)(whole.tile0 - (split_hi ? 2 : 0)) * 16;   // compact row of the sequence's first row
-        if (hs > 0) __syncthreads();                         // (a full barrier: the previous part's tape stores have completed)
+        if (hs > 0) re_sync_full();                          // (a full barrier: the previous part's tape stores have completed)
         const int nrows = 16 * it.nt;
         const int64_t row0 = (int64_t)it.tile0 * 16;
         int mk = 0; (void)mk;
@@ -227,7 +227,7 @@ __device__ __forceinline__ void enc_fwd_item(const float* __restrict__ x0, const
                 }
             }
             if (TRAIN && split_lo) {
-                __syncthreads();   // (with vmcnt(0): the tiles have left this CU)
+                re_sync_full();    // (with vmcnt(0): the tiles have left this CU)
                 if (tid == 0) enc_flag_set(tflags, row0 / 16, l);
             } else {
                 enc_sync();

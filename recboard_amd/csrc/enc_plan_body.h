@@ -71,11 +71,11 @@ __device__ __forceinline__ int pl_short_row(const PlShort& P, int s, int r) {
 }
 
 // Barrier of the plan workgroup.  What crosses waves lives in LDS for batches of up to PL_LDS_B sequences: the barrier then only
-// orders LDS traffic and the kernel's global stores stay in flight (__syncthreads() waits for every one of them: a store round
-// trip at each of the ~10 barriers).  Larger batches keep span / placement in global scratch and take the full barrier.
+// orders LDS traffic and the kernel's global stores stay in flight.  Larger batches keep span / placement in global scratch, which other
+// waves read behind the barrier: the full barrier (re_sync_full: every wave's stores drained first -- `__syncthreads()` alone does not).
 __device__ __forceinline__ void pl_sync(bool lds_only) {
     if (lds_only) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else __syncthreads();
+    else re_sync_full();
 }
 
 // optional SOURCE of the batch: instead of reading (seq, pos, neg) the launch SAMPLES them -- the SASRec training chain of csrc/sampler.hip
@@ -336,7 +336,7 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
                 // sequences' tiles are at most ~1.5 per workgroup (every further pass of chained tiles costs a chain: 500 long tiles on 256
                 // workgroups are 11 % faster on the workgroup-per-item kernel, 310 are 6 % slower) and there are at most ~10 tiles per
                 // workgroup in all (Beauty-shaped batches of 1 024 / 2 048 / 8 192: tile kernel +10 % / +24 % / -6 %).
-                const int tg = ncu < 256 ? ncu : 256;
+                const int tg = (ncu < 256 ? ncu : 256) * ((split_long & 8) ? 2 : 1);   // resident workgroups (& 8: two per CU)
                 const bool fits = enc_tile_looped(B, S) ? ((split_long & 4) || (2 * tlong <= 3 * tg && tlong + tshort <= 10 * tg))
                                                         : (tlong + tshort <= 1024 && ((split_long & 4) || tlong <= tg * 3 / 4));
                 hdr[7] = (nsplit == 0 && !(split_long & 2) && fits) ? 1 : 0;
@@ -395,7 +395,7 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
     // its span behind the barrier (a lane per row, eight sequences per wave-instruction: the map is 8 bytes per row, ~4 000 rows)
     const int nrows_all = 16 * (tlong + tshort);
     for (int r = tid; r < nrows_all; r += PL_NT) rowmap[r] = make_int2(-1, 0);
-    __syncthreads();   // (with vmcnt(0): the dummies are in place before the real rows overwrite them)
+    re_sync_full();    // (with vmcnt(0): the dummies are in place before the real rows overwrite them)
     for (int b0 = (tid >> 3); b0 < B; b0 += PL_NT / 8) {
         const int span = in_lds ? (int)s_span[b0] : g_span[b0];
         const int row = in_lds ? s_place[b0] : g_place[b0];

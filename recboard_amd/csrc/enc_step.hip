@@ -29,7 +29,7 @@ __global__ __launch_bounds__(512) void enc_step_k(SeEmbed em, const int64_t* __r
         const int wi = enc_item_of(k, blockIdx.x, gridDim.x);
         if (wi >= n_items) continue;
         enc_fwd_item<D, true, true>(nullptr, em, seq, B, S, L, P, drop_scale, thresh, seed, u, tape, T, PL, 0, H, lds, wi, k, &HO);
-        __syncthreads();   // (a full barrier: the item's tape and upstream-gradient rows are written before they are read back)
+        re_sync_full();    // (a full barrier: the item's tape and upstream-gradient rows are written before they are read back)
         enc_bwd_item<D>(H.dU_rows, seq, B, S, L, P, drop_scale, thresh, seed, tape, T, PL, dOut, gtape, slab, 1, emb_scale, 1,
                         H.g_rows, lds, wi, k, &HO);
         __syncthreads();
@@ -69,6 +69,13 @@ static int enc_step_launch_d(const SeEmbed& em, const int64_t* seq, int64_t B, i
 // once), 4 = the weight gradients (enc_wgrad_k + enc_grad_reduce_k, from the tape the item kernels left); 0 = 7 = the whole step.
 // + 8: the tile kernel's weight fragments were prepared by re_sasrec_batch_prep_w for this step (no enc_tile_prep_k launch).
 // A caller with other work depending on the item kernels alone (the item table's scatter-add) runs the branches on two streams.
+// the device's compute units (a constant of the device, asked per launch: no state kept)
+static int enc_device_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) return 256;
+    return n;
+}
+
 extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const float* Ptab, float scale, const int64_t* seq, const int64_t* pos,
                                            const int64_t* neg, int64_t B, int64_t S, int64_t D, int64_t L, const float* const* block_params,
                                            const float* last_w, const float* last_b, float drop_p, uint32_t seed, const uint32_t* seed_dev,
@@ -115,7 +122,10 @@ extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const floa
         uint32_t* wf = enc_tile_wf(gtape, B, S, L, D);
         float* xch = enc_tile_xch(wf, L, D);
         // (looped form: the resident workgroups, one per CU, further tiles from a counter; else a workgroup per tile, <= 1024 tiles by the plan's rule)
-        const int tgrid = enc_tile_looped(B, S) ? (int)(mt < ncu ? mt : ncu) : (int)(mt < 1024 ? mt : 1024);
+        // the looped form's grid = the RESIDENT workgroups (block b owns tile b; the rest come from a counter): CUs x workgroups per CU, the CU
+        // count clamped to the device's (a caller's larger `ncu` would start blocks that cannot be resident while their partners spin)
+        const int64_t res = (int64_t)(ncu < enc_device_cus() ? ncu : enc_device_cus()) * enc_tile_wg_per_cu(D);
+        const int tgrid = enc_tile_looped(B, S) ? (int)(mt < res ? mt : res) : (int)(mt < 1024 ? mt : 1024);
         const int wgrid = (int)(mt < ncu ? mt : ncu);
         if (part & 1) {
             const int rcw = enc_tile_step_launch(D, em, seq, B, S, L, P, ds, thresh, seed, seed_dev, u, tape, plan, tgrid, H, dx0, gtape, slab, scale, wf, xch,

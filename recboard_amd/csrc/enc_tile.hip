@@ -64,7 +64,7 @@ __device__ int g_tl_fenced;
 __device__ int g_tl_lds_total;                           // floats of LDS the launch requested (the part behind tl_lds_floats is a canary in this build)
 __device__ unsigned g_tl_paranoid;                       // bit 0: a workgroup barrier in front of every operand-slot write; bit 1: ... of every exchange write
 __device__ unsigned g_tl_fill;                           // != 0: every workgroup first fills its LDS with this bit pattern (does anything read LDS it has not written?)
-static int h_tl_lds_kb = 84;
+static int h_tl_lds_kb = 0;
 #define TL_FENCED (::g_tl_fenced != 0)
 #define TL_PARANOID(BIT) do { if (::g_tl_paranoid & (BIT)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
 // bit 3: 8 wait states behind every 16-byte global store (is its data still being read when the next instruction overwrites the registers?)
@@ -113,6 +113,7 @@ struct TlArgs {
     float emb_scale;
     const uint32_t* wf;
     float* xch;
+    int grid;                 // workgroups of the launch (the looped form hands out tiles beyond it)
 };
 template <class T>
 __device__ __forceinline__ T tl_arg_at(unsigned off) {
@@ -144,20 +145,19 @@ static int tl_launch(KP prep_k, KS step_k, const SeEmbed& em, const int64_t* seq
         hipLaunchKernelGGL(prep_k, dim3((unsigned)(TLC_PREP_THREADS(L, NS) / 256)), dim3(256), 0, s, P, (int)L, wf, enc_tile_epoch(tape, B, S, L, D));
         if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     }
-    // ONE workgroup per CU (more than half of a CU's 160 KB of LDS is requested): the sc1-store / drained flag / sc1-load hand-over between
-    // the workgroups of a long sequence is valid -- measured -- at one workgroup per CU only (MI355X_MICROARCH.md, hand-off table).  With
-    // two per CU (what 256 threads and 60 KB would allow) about one run in two of 300 steps read a stale row somewhere: results that
-    // differ from run to run in the last digits (scripts/determinism.py); the step time is the same either way (a batch has ~250 tiles).
+    // TWO workgroups per CU at D = 64 (4 waves, <= 232 registers, ~58 KB of LDS each): since round 5.  Rounds 3 - 4 held ONE per CU by requesting
+    // 84 KB: with two, some run in two of 300 steps ended with results that differed in the last digits -- one register of one wave reading
+    // 0 in 16 lanes (profiles/r4_handover_notes.txt), which went away when the kernel's 150 - 245 spilled SGPRs (v_writelane / v_readlane
+    // through vector-register lanes) were spilled to scratch instead.  The kernel now spills 4 (0 at D = 128; profiles/r5_tile_resource_usage.txt)
+    // and the cross-process soak at two per CU ends in ONE state (profiles/r5_handover_soak.json).  D = 128 is 8 waves of ~230 registers: one per CU.
     size_t ldsb = tl_lds_floats((int)L, NS) * sizeof(float);
 #ifdef TL_HANDOVER_DEBUG
     if (ldsb < (size_t)h_tl_lds_kb * 1024) ldsb = (size_t)h_tl_lds_kb * 1024;
 
     if (grid > TL_CHK_TILES) return RE_EUNSUPPORTED;
-#else
-    if (ldsb < (size_t)84 * 1024) ldsb = (size_t)84 * 1024;
 #endif
     if (hipFuncSetAttribute((const void*)step_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-    const TlArgs A{em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H, dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch};
+    const TlArgs A{em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H, dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch, grid};
     hipLaunchKernelGGL(step_k, dim3(grid), dim3(64 * NS), ldsb, s, A);
     return hipGetLastError() == hipSuccess ? RE_OK : RE_ELAUNCH;
 }

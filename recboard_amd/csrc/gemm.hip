@@ -174,6 +174,277 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* __restric
     C[m * ldc + n] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The WIDE form (DeepFM's MLP shapes: 4096 x 400 x {100, 400} forward / input gradient, 400 x {100, 400} x 4096 weight gradient).
+//
+// What the 64 x 64 form above leaves on the table at these shapes (0.32 of the fp32 matrix peak, round 4): N = 400 is 6.25 column blocks of
+// 64 (448 workgroups on 256 CUs: two rounds, the second a quarter full), a wave's 8 MFMAs of a tile run back to back on ONE accumulator
+// (40 dependent cycles each instead of 32 issue cycles), two barriers per k step, and operands that are not k-contiguous are transposed
+// on their way into LDS with 8-way conflicted scalar stores.
+//
+// Here a workgroup owns BM = 16 WM rows and up to TT column tiles of 16 (WM = 4: wave w = row tile w, all TT column tiles, TT accumulators
+// -- the k sub-steps visit them round robin, so no MFMA waits for the one before it; WM = 1: 16 rows, the four waves take two column
+// tiles each: the form for N <= 128, where 64-row blocks would leave most CUs without a workgroup).  The N / 16 column tiles are dealt over
+// the column blocks as evenly as they go (N = 400: 25 tiles = 7 + 6 + 6 + 6 -> 64 x 4 = 256 workgroups, one per CU, 7 tile-times against
+// 6.25 ideal).  K runs in chunks of 64 through DOUBLE-BUFFERED LDS: the next chunk's global loads are issued before the chunk's MFMAs, land
+// in registers meanwhile, are written to the other buffer behind them; one barrier per chunk.  Inside a chunk the fragments of sub-chunk
+// q + 1 are read from LDS into a second register set BEFORE sub-chunk q's MFMAs are issued (one wave per SIMD: nothing else hides an LDS
+// round trip), and sub-chunks beyond K are skipped (K = 400 = 6 chunks + 1 sub-chunk: no padded work).
+// An operand is staged in the orientation it has in memory (16-byte loads and 16-byte LDS stores either way):
+//   k-contiguous  -> Xs[row][36]:      a lane's fragment of a 16-k sub-chunk is ONE ds_read_b128 (k = 16 q + 4 g + i for MFMA i of lane group g)
+//   row-contiguous -> Xs[k][rows + 4]: four ds_read_b32 at rows k = 16 q + 4 g + i (row stride = 4 mod 8 floats: lane groups g land on
+//                                      different bank quarters, conflict-free)
+// -- the same k(g, i) in both, so any pairing of the two orientations multiplies matching k.  Exact fp32 (v_mfma_f32_16x16x4_f32); the
+// order of a dot product's terms is a permutation of the 64 x 64 form's (both fixed: deterministic).
+// Epilogue: alpha / beta / bias / ReLU as above, split-K slabs, and (WM = 4, M a multiple of 64, no split) the BatchNorm batch statistics of
+// the output's columns as per-64-row (mean, M2) partials in re_bn_relu_drop_fwd's workspace format -- bn_stats_partial_k's pass over z
+// (DeepFM/main.py:119-124: bn(linear(x))) is the GEMM's own epilogue.
+#define GW_BK 64
+#define GW_LSK (GW_BK + 4)          // row stride of a k-contiguous tile
+template <bool KMAJ, int ROWS>      // ROWS: rows (or columns) of the tile: a multiple of 16
+struct GwTile {
+    static constexpr int LSR = ROWS + 4;                                  // row stride of a row-contiguous tile ([k][rows])
+    static constexpr int FLOATS = KMAJ ? ROWS * GW_LSK : GW_BK * LSR;
+    static constexpr int SLOTS = ROWS * GW_BK / 4;                        // float4 slots of a chunk
+    static constexpr int PER = (SLOTS + 255) / 256;                       // ... per thread
+    // global -> registers.  mem: the operand's base; (r0, k0): the tile's first row / k; rows [r0, r_end) and k [k0, k_end) exist.
+    // contiguous dimension in multiples of 4 and 16-byte aligned (the launcher checks): a float4 is inside or outside as a whole.
+    static __device__ __forceinline__ void fetch(float4 (&v)[PER], const float* __restrict__ mem, int64_t ld, int64_t r0, int64_t r_end,
+                                                 int64_t k0, int64_t k_end, int tid, bool interior) {
+        if (interior) {            // (uniform: the tile lies wholly inside the operand -- unconditional loads, no per-load branch)
+#pragma unroll
+            for (int p = 0; p < PER; ++p) {
+                const int f = p * 256 + tid;
+                if (SLOTS % 256 != 0 && f >= SLOTS) { v[p] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                if (KMAJ) v[p] = *reinterpret_cast<const float4*>(mem + (r0 + (f / (GW_BK / 4))) * ld + k0 + (f % (GW_BK / 4)) * 4);
+                else v[p] = *reinterpret_cast<const float4*>(mem + (k0 + f / (ROWS / 4)) * ld + r0 + (f % (ROWS / 4)) * 4);
+            }
+            return;
+        }
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int f = p * 256 + tid;
+            v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (SLOTS % 256 != 0 && f >= SLOTS) continue;
+            if (KMAJ) {
+                const int64_t r = r0 + (f / (GW_BK / 4)), k = k0 + (f % (GW_BK / 4)) * 4;
+                if (r < r_end && k < k_end) v[p] = *reinterpret_cast<const float4*>(mem + r * ld + k);
+            } else {
+                const int64_t k = k0 + f / (ROWS / 4), r = r0 + (f % (ROWS / 4)) * 4;
+                if (r < r_end && k < k_end) v[p] = *reinterpret_cast<const float4*>(mem + k * ld + r);
+            }
+        }
+    }
+    static __device__ __forceinline__ void put(float* Xs, const float4 (&v)[PER], int tid) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int f = p * 256 + tid;
+            if (SLOTS % 256 != 0 && f >= SLOTS) continue;
+            if (KMAJ) *reinterpret_cast<float4*>(Xs + (f / (GW_BK / 4)) * GW_LSK + (f % (GW_BK / 4)) * 4) = v[p];
+            else *reinterpret_cast<float4*>(Xs + (f / (ROWS / 4)) * LSR + (f % (ROWS / 4)) * 4) = v[p];
+        }
+    }
+    // the lane's fragment of 16-row tile `t`, sub-chunk q: element i = X(16 t + c, 16 q + 4 g + i)
+    static __device__ __forceinline__ f32x4 frag(const float* Xs, int t, int q, int c, int g) {
+        if (KMAJ) return *reinterpret_cast<const f32x4*>(Xs + (16 * t + c) * GW_LSK + 16 * q + 4 * g);
+        const float* p = Xs + (16 * q + 4 * g) * LSR + 16 * t + c;
+        return (f32x4){p[0], p[LSR], p[2 * LSR], p[3 * LSR]};
+    }
+};
+
+struct GwArgs {
+    int64_t M, N, K;
+    float alpha, beta;
+    const float *A, *B;
+    int64_t lda, ldb, ldc;
+    float* C;
+    const float* bias;
+    int relu;
+    float* slabs;          // split-K: [gridDim.z][M][N] partial products (alpha / beta / bias / relu applied by gemm_splitk_reduce)
+    int64_t kchunk;
+    int nt_base, nt_rem;   // column tiles per column block: base (+ 1 for the first nt_rem blocks)
+    float* colstats;       // [M / 64][2][N]: (mean, M2) of the output's columns over the block's 64 rows, or null
+};
+
+template <bool A_KMAJ, bool B_KMAJ, int WM, int TT>
+__global__ __launch_bounds__(256) void gemm_wide_k(const GwArgs a) {
+    constexpr int BM = 16 * WM;
+    constexpr int WT = (WM == 4) ? TT : 2;           // column tiles a wave multiplies
+    constexpr int BT = (WM == 4) ? TT : 8;           // column tiles of the workgroup's B tile
+    using TA = GwTile<A_KMAJ, BM>;
+    using TB = GwTile<B_KMAJ, 16 * BT>;
+    extern __shared__ __align__(16) float gw_lds[];
+    float* const As0 = gw_lds;
+    float* const Bs0 = gw_lds + 2 * TA::FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int cb = blockIdx.y;
+    const int t_first = cb * a.nt_base + (cb < a.nt_rem ? cb : a.nt_rem), t_cnt = a.nt_base + (cb < a.nt_rem ? 1 : 0);
+    const int64_t n0 = (int64_t)t_first * 16;
+    const int64_t n_end = (n0 + 16 * t_cnt < a.N) ? n0 + 16 * t_cnt : a.N;
+    const int64_t kb = (int64_t)blockIdx.z * a.kchunk;
+    const int64_t ke = (kb + a.kchunk < a.K) ? kb + a.kchunk : a.K;
+    const int arow = (WM == 4) ? wave : 0;           // the wave's row tile
+    const int bcol0 = (WM == 4) ? 0 : 2 * wave;      // ... and its first column tile inside the block
+    const bool in_a = m0 + BM <= a.M, in_b = n0 + 16 * BT <= n_end;     // (uniform) the row / column extent of the tiles is inside the operands
+    f32x4 acc[WT];
+#pragma unroll
+    for (int t = 0; t < WT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 pa[TA::PER], pb[TB::PER];
+    {
+        const bool full = kb + GW_BK <= ke;
+        TA::fetch(pa, a.A, a.lda, m0, a.M, kb, ke, tid, in_a && full);
+        TB::fetch(pb, a.B, a.ldb, n0, n_end, kb, ke, tid, in_b && full);
+    }
+    TA::put(As0, pa, tid);
+    TB::put(Bs0, pb, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k0 = kb; k0 < ke; k0 += GW_BK) {
+        const bool more = k0 + GW_BK < ke;           // (uniform)
+        if (more) {
+            const bool full = k0 + 2 * GW_BK <= ke;
+            TA::fetch(pa, a.A, a.lda, m0, a.M, k0 + GW_BK, ke, tid, in_a && full);
+            TB::fetch(pb, a.B, a.ldb, n0, n_end, k0 + GW_BK, ke, tid, in_b && full);
+        }
+        const float* Asc = As0 + cur * TA::FLOATS;
+        const float* Bsc = Bs0 + cur * TB::FLOATS;
+        const int nq = (int)((ke - k0 + 15) >> 4) < GW_BK / 16 ? (int)((ke - k0 + 15) >> 4) : GW_BK / 16;   // sub-chunks of 16 k with anything in them
+        f32x4 av[2], bv[2][WT];
+        av[0] = TA::frag(Asc, arow, 0, c, g);
+#pragma unroll
+        for (int t = 0; t < WT; ++t) bv[0][t] = TB::frag(Bsc, bcol0 + t, 0, c, g);
+#pragma unroll
+        for (int q = 0; q < GW_BK / 16; ++q) {
+            if (q >= nq) break;                      // (uniform)
+            if (q + 1 < GW_BK / 16 && q + 1 < nq) {  // the next sub-chunk's fragments: requested before this one's MFMAs
+                av[(q + 1) & 1] = TA::frag(Asc, arow, q + 1, c, g);
+#pragma unroll
+                for (int t = 0; t < WT; ++t) bv[(q + 1) & 1][t] = TB::frag(Bsc, bcol0 + t, q + 1, c, g);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < WT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][i], bv[q & 1][t][i], acc[t], 0, 0, 0);
+        }
+        if (more) {
+            TA::put(As0 + (cur ^ 1) * TA::FLOATS, pa, tid);
+            TB::put(Bs0 + (cur ^ 1) * TB::FLOATS, pb, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- epilogue: acc[t][j] = C(m0 + 16 arow + 4 g + j, n0 + 16 (bcol0 + t) + c)
+    float* stat = Bs0;                                              // [4 waves][16 BT columns][2] (the main loop is behind a barrier)
+#pragma unroll
+    for (int t = 0; t < WT; ++t) {
+        const int64_t n = n0 + 16 * (bcol0 + t) + c;
+        const bool n_ok = (bcol0 + t) < t_cnt && n < a.N;
+        const float bv = (a.bias && !a.slabs && n_ok) ? a.bias[n] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + 16 * arow + 4 * g + j;
+            v[j] = acc[t][j];
+            if (!n_ok || m >= a.M) { v[j] = 0.f; continue; }
+            if (a.slabs) { a.slabs[((int64_t)blockIdx.z * a.M + m) * a.N + n] = v[j]; continue; }
+            v[j] = a.alpha * v[j] + bv;
+            if (a.beta != 0.f) v[j] = fmaf(a.beta, a.C[m * a.ldc + n], v[j]);
+            if (a.relu) v[j] = fmaxf(v[j], 0.f);
+            a.C[m * a.ldc + n] = v[j];
+        }
+        if (WM == 4 && a.colstats) {
+            // the column's 16 rows of this wave: mean, then M2 about it (two passes over registers); lane groups g combined by row swaps
+            float s = (v[0] + v[1]) + (v[2] + v[3]);
+            {
+                const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+                s = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+                const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+                s = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+            }
+            const float mu = s * (1.0f / 16);
+            float q2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[j] - mu; q2 = fmaf(d, d, q2); }
+            {
+                const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(q2), __float_as_uint(q2), false, false);
+                q2 = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+                const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(q2), __float_as_uint(q2), false, false);
+                q2 = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+            }
+            if (g == 0) *reinterpret_cast<float2*>(stat + ((wave * BT + t) * 16 + c) * 2) = make_float2(mu, q2);
+        }
+    }
+    if (WM == 4 && a.colstats) {
+        __syncthreads();
+        // Chan's merge of the four waves' (mean, M2, 16 rows), ((0, 1), (2, 3)): equal counts -> mean = average, M2 += delta^2 * n / 2
+        if (tid < 16 * BT) {
+            const int64_t n = n0 + tid;
+            if (tid < 16 * t_cnt && n < a.N) {
+                float2 p[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) p[w] = *reinterpret_cast<const float2*>(stat + (w * BT * 16 + tid) * 2);
+                const float d01 = p[1].x - p[0].x, d23 = p[3].x - p[2].x;
+                const float m01 = p[0].x + 0.5f * d01, m23 = p[2].x + 0.5f * d23;
+                const float q01 = (p[0].y + p[1].y) + d01 * d01 * 8.0f, q23 = (p[2].y + p[3].y) + d23 * d23 * 8.0f;
+                const float d = m23 - m01;
+                a.colstats[((int64_t)blockIdx.x * 2 + 0) * a.N + n] = m01 + 0.5f * d;
+                a.colstats[((int64_t)blockIdx.x * 2 + 1) * a.N + n] = (q01 + q23) + d * d * 16.0f;
+            }
+        }
+    }
+}
+
+// Which form runs a product: the wide one when its 16-byte loads are legal and its grid fills the chip at least as well.
+struct GwPlan { int use, wm, tt, cb, nt_base, nt_rem, nsplit; };
+static GwPlan gw_plan(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                      bool want_stats) {
+    GwPlan p{0, 4, 8, 1, 0, 0, 1};
+    const bool a_kmaj = transA == 0, b_kmaj = transB != 0;
+    // contiguous dimension of each operand: whole float4s, 16-byte aligned
+    const int64_t a_c = a_kmaj ? K : M, b_c = b_kmaj ? K : N;
+    if ((reinterpret_cast<uintptr_t>(A) & 15u) || (reinterpret_cast<uintptr_t>(B) & 15u) || (lda & 3) || (ldb & 3) || (a_c & 3) || (b_c & 3)) return p;
+    if (M < 64 || N < 16 || K < 64) return p;                         // (tiny products: the 64 x 64 form's guards cover them)
+    const int64_t NT = re_cdiv(N, 16);
+    double best = 1e300;
+    const int tts[3] = {4, 7, 8};
+    for (int form = 0; form < 4; ++form) {                            // WM = 4 with TT in {4, 7, 8}; WM = 1 (two tiles a wave)
+        const int wm = form < 3 ? 4 : 1, tt = form < 3 ? tts[form] : 8, per_wave = form < 3 ? tt : 2;
+        if (want_stats && (wm != 4 || (M & 63))) continue;
+        const int64_t cb = re_cdiv(NT, tt), mb = re_cdiv(M, 16 * wm);
+        int ns = 1;
+        if (!want_stats && mb * cb < 192 && K >= 1024) {              // long K, few tiles: split K (slices of >= 8 chunks)
+            int64_t s = 256 / (mb * cb), maxs = K / 256;
+            if (s > maxs) s = maxs;
+            if (s > 64) s = 64;
+            ns = s < 1 ? 1 : (int)s;
+        }
+        const double rounds = (double)re_cdiv(mb * cb * ns, 256);
+        const double cost = rounds * per_wave * (double)re_cdiv(re_cdiv(K, ns), GW_BK) + (ns > 1 ? 3.0 : 0.0) + (wm == 1 ? 0.5 : 0.0);
+        if (cost < best) {
+            best = cost;
+            p = GwPlan{1, wm, tt, (int)cb, (int)(NT / cb), (int)(NT % cb), ns};
+        }
+    }
+    return p;
+}
+
+template <bool AK, bool BK_, int WM, int TT>
+static void gw_launch1(const GwArgs& a, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = 2 * (GwTile<AK, 16 * WM>::FLOATS + GwTile<BK_, 16 * (WM == 4 ? TT : 8)>::FLOATS) * sizeof(float);
+    auto k = gemm_wide_k<AK, BK_, WM, TT>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+}
+template <bool AK, bool BK_>
+static void gw_launch(const GwPlan& p, const GwArgs& a, dim3 grid, hipStream_t s) {
+    if (p.wm == 1) gw_launch1<AK, BK_, 1, 8>(a, grid, s);
+    else if (p.tt == 4) gw_launch1<AK, BK_, 4, 4>(a, grid, s);
+    else if (p.tt == 7) gw_launch1<AK, BK_, 4, 7>(a, grid, s);
+    else gw_launch1<AK, BK_, 4, 8>(a, grid, s);
+}
+
 static int gm_nsplit(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = re_cdiv(M, GM_BM) * re_cdiv(N, GM_BN);
     if (tiles >= 256 || K < 1024) return 1;
@@ -185,19 +456,38 @@ static int gm_nsplit(int64_t M, int64_t N, int64_t K) {
 }
 
 extern "C" size_t re_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-    const int ns = gm_nsplit(M, N, K);
+    // (an upper bound over both forms: the wide form's split is at most 64 slices too, and is only known with the operands' alignment)
+    int ns = gm_nsplit(M, N, K);
+    if (K >= 1024 && ns < 64) {
+        const int64_t s = K / 256;
+        ns = (int)(s > 64 ? 64 : (s > ns ? s : ns));
+    }
     return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 256;
 }
 
-extern "C" int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
-                           const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws,
-                           size_t ws_bytes, re_stream_t stream) {
-    re_clear_error();
-    if (M == 0 || N == 0) return RE_OK;
-    if (!A || !B || !C || M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) return RE_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+static int gemm_run(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
+                    int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws, size_t ws_bytes, float* colstats,
+                    hipStream_t s) {
+    const GwPlan wp = gw_plan(transA, transB, M, N, K, A, lda, B, ldb, colstats != nullptr);
+    if (colstats && !wp.use) return RE_EUNSUPPORTED;
+    if (wp.use) {
+        if (wp.nsplit > 1 && (!ws || ws_bytes < (size_t)wp.nsplit * M * N * sizeof(float))) return RE_EWORKSPACE;
+        int64_t kchunk = re_cdiv(re_cdiv(K, wp.nsplit), GW_BK) * GW_BK;
+        if (kchunk < GW_BK) kchunk = GW_BK;
+        const int ns = (int)re_cdiv(K, kchunk);
+        GwArgs a{M, N, K, alpha, beta, A, B, lda, ldb, ldc, C, bias, relu, ns > 1 ? (float*)ws : nullptr, kchunk, wp.nt_base, wp.nt_rem, colstats};
+        dim3 grid((unsigned)re_cdiv(M, 16 * wp.wm), (unsigned)wp.cb, (unsigned)ns);
+        if (transA == 0 && transB != 0) gw_launch<true, true>(wp, a, grid, s);
+        else if (transA == 0) gw_launch<true, false>(wp, a, grid, s);
+        else if (transB != 0) gw_launch<false, true>(wp, a, grid, s);
+        else gw_launch<false, false>(wp, a, grid, s);
+        if (ns > 1)
+            hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)re_cdiv(M * N, 256)), dim3(256), 0, s, (const float*)ws, ns, M, N, alpha, beta,
+                               C, ldc, bias, relu);
+        return re_launch_status();
+    }
     const int ns = gm_nsplit(M, N, K);
-    if (ns > 1 && (!ws || ws_bytes < re_gemm_f32_workspace_bytes(M, N, K))) return RE_EWORKSPACE;
+    if (ns > 1 && (!ws || ws_bytes < (size_t)ns * M * N * sizeof(float))) return RE_EWORKSPACE;
     int64_t kchunk = re_cdiv(re_cdiv(K, ns), GM_BK) * GM_BK;
     if (kchunk < GM_BK) kchunk = GM_BK;
     const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15u) == 0 && (lda & 3) == 0) ? 1 : 0;
@@ -209,4 +499,26 @@ extern "C" int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
         hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)re_cdiv(M * N, 256)), dim3(256), 0, s, (const float*)ws, ns, M, N, alpha, beta,
                            C, ldc, bias, relu);
     return re_launch_status();
+}
+
+extern "C" int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                           const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws,
+                           size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (M == 0 || N == 0) return RE_OK;
+    if (!A || !B || !C || M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) return RE_EINVAL;
+    return gemm_run(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, relu, ws, ws_bytes, nullptr, (hipStream_t)stream);
+}
+
+// re_gemm_f32 + the BatchNorm batch statistics of C's columns as per-64-row (mean, M2) partials: colstats [M / 64][2][N], the workspace
+// format of re_bn_relu_drop_fwd (pass it as that call's `ws` with `stats_ready` = M / 64: its statistics pass over z is then skipped).
+// M a multiple of 64, operands 16-byte aligned with leading dimensions in multiples of 4; otherwise RE_EUNSUPPORTED (the caller then runs
+// re_gemm_f32 and lets re_bn_relu_drop_fwd take its own statistics).
+extern "C" int re_gemm_f32_colstats(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                                    const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colstats,
+                                    re_stream_t stream) {
+    re_clear_error();
+    if (!A || !B || !C || !colstats || M <= 0 || N <= 0 || K <= 0 || lda < 1 || ldb < 1 || ldc < N) return RE_EINVAL;
+    if (M & 63) return RE_EUNSUPPORTED;
+    return gemm_run(transA, transB, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, bias, 0, nullptr, 0, colstats, (hipStream_t)stream);
 }

@@ -138,3 +138,70 @@ extern "C" int re_auc(const float* scores, const float* labels, int64_t n, float
     hipLaunchKernelGGL(auc_final_k, dim3(1), dim3(1), 0, s, (const unsigned long long*)ws, auc);
     return re_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Pool ranking (`--ranking=pool`: recommend_from_pool, SASRec/main.py:230-236, MF-BPR/main.py:106-109, LightGCN/main.py:122-125; evaluate
+// contract UniSRec/main.py:415-421: the target first, then the sampled unseen items; targets[:, 0] = 1).
+//   re_score_pool: out[b][p] = <Q[b], E[pool[b][p]]> as the natural-k fmaf chain -- the value re_score_dense / re_score_topk give that
+//                  (user, item) pair, bit for bit (einsum("BD,BKD->BK") of the reference).  A thread per pair; the pool's rows are a
+//                  gather of B x P rows of 4 D bytes from a table that lives in L2 / Infinity Cache at these sizes.
+//   re_pool_topk:  the exact top-K of every row of a [B, P] score matrix, ties to the lowest position (the full-ranking kernels' rule):
+//                  one wave per row, a candidate's rank = the number of candidates that beat it (P^2 compares a row: P = 101).
+__global__ __launch_bounds__(256) void score_pool_k(const float* __restrict__ Q, const float* __restrict__ E, const int64_t* __restrict__ pool,
+                                                    int64_t B, int64_t P, int64_t N, int D, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * P) return;
+    const int64_t b = e / P;
+    const int64_t id = pool[e];
+    if (id < 0 || id >= N) { out[e] = -INFINITY; return; }
+    const float4* q = reinterpret_cast<const float4*>(Q + b * D);
+    const float4* r = reinterpret_cast<const float4*>(E + id * D);
+    float acc = 0.f;
+    for (int k = 0; k < D / 4; ++k) {
+        const float4 a = q[k], c = r[k];
+        acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
+    }
+    out[e] = acc;
+}
+
+#define PT_MAXP 1024
+__global__ __launch_bounds__(256) void pool_topk_k(const float* __restrict__ scores, int64_t B, int P, int K, float* __restrict__ vals,
+                                                   int64_t* __restrict__ idx) {
+    __shared__ float s[4][PT_MAXP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 4 + w;
+    if (b >= B) return;                                   // (whole waves; no workgroup barrier below)
+    for (int i = lane; i < P; i += 64) s[w][i] = scores[b * P + i];
+    for (int k = lane; k < K; k += 64)                    // slots beyond the pool: (-inf, -1), as re_score_topk pads K > N
+        if (k >= P) { vals[b * K + k] = -INFINITY; idx[b * K + k] = -1; }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = lane; i < P; i += 64) {
+        const float si = s[w][i];
+        int rank = 0;
+        for (int j = 0; j < P; ++j) {
+            const float sj = s[w][j];
+            rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+        }
+        if (rank < K) { vals[b * K + rank] = si; idx[b * K + rank] = i; }
+    }
+}
+
+extern "C" int re_score_pool(const float* Q, const float* E, const int64_t* pool, int64_t B, int64_t P, int64_t N, int64_t D, float* out,
+                             re_stream_t stream) {
+    re_clear_error();
+    if (B == 0 || P == 0) return RE_OK;
+    if (!Q || !E || !pool || !out || B < 0 || P < 0 || N <= 0 || D <= 0 || (D & 3)) return RE_EINVAL;
+    hipLaunchKernelGGL(score_pool_k, dim3((unsigned)re_cdiv(B * P, 256)), dim3(256), 0, (hipStream_t)stream, Q, E, pool, B, P, N, (int)D, out);
+    return re_launch_status();
+}
+
+extern "C" int re_pool_topk(const float* scores, int64_t B, int64_t P, int64_t K, float* vals, int64_t* idx, re_stream_t stream) {
+    re_clear_error();
+    if (B == 0) return RE_OK;
+    if (!scores || !vals || !idx || B < 0 || P <= 0 || K <= 0) return RE_EINVAL;
+    if (P > PT_MAXP) return RE_EUNSUPPORTED;
+    hipLaunchKernelGGL(pool_topk_k, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, scores, B, (int)P, (int)K, vals, idx);
+    return re_launch_status();
+}

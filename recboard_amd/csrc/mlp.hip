@@ -237,6 +237,24 @@ extern "C" int re_bn_relu_drop_fwd(const float* z, int64_t M, int64_t N, const f
     return re_launch_status();
 }
 
+// re_bn_relu_drop_fwd in training mode with the per-chunk (mean, M2) partials of z's columns ALREADY in `colstats` ([chunks][2][N], chunk b =
+// rows [b rpc, (b + 1) rpc) with rpc = ceil(M / chunks): what re_gemm_f32_colstats leaves, chunks = M / 64): the pass over z that takes the
+// statistics is the producing GEMM's epilogue; here the merge (+ running statistics) and the normalise / ReLU / dropout pass.
+extern "C" int re_bn_relu_drop_fwd_pre(const float* z, int64_t M, int64_t N, const float* gamma, const float* beta, float* run_mean,
+                                       float* run_var, float eps, float momentum, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                                       uint32_t stream_id, float* stats, float* a, const float* colstats, int chunks, re_stream_t stream) {
+    re_clear_error();
+    if (!z || !a || !gamma || !beta || !stats || !run_mean || !run_var || !colstats || M <= 0 || N <= 0) return RE_EINVAL;
+    if (chunks < 1 || chunks > ML_CHUNKS || drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_final_k, dim3((unsigned)re_cdiv(N, 4)), dim3(256), 0, s, colstats, chunks, M, N, eps, momentum, stats, run_mean, run_var);
+    const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
+    const float ds = thresh ? 1.0f / (1.0f - drop_p) : 1.0f;
+    hipLaunchKernelGGL(bn_relu_drop_fwd_k, dim3(re_grid(M * N, 1024)), dim3(256), 0, s, z, M * N, N, (const float*)stats, gamma, beta, ds, thresh, seed,
+                       stream_id, a, seed_dev);
+    return re_launch_status();
+}
+
 extern "C" int re_bn_relu_drop_bwd(const float* da, const float* a, const float* z, int64_t M, int64_t N, const float* gamma,
                                    const float* stats, float drop_p, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                    re_stream_t stream) {

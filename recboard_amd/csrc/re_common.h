@@ -15,6 +15,17 @@ static inline int re_launch_status() {
 }
 
 static inline int64_t re_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+#ifdef __HIPCC__
+// Workgroup barrier that ALSO orders global memory between the workgroup's waves: every wave's vector-memory operations have completed
+// before any wave passes.  `__syncthreads()` alone does not do that on gfx950: hipcc lowers its workgroup-scope release to `s_waitcnt
+// lgkmcnt(0); s_barrier` (not tgsplit; the target's barrier does not drain the counters either), so a load behind the barrier can
+// overtake another wave's store in front of it, and a flag stored behind it can overtake the data (round 5: the tile step's
+// run-to-run differences with two workgroups per CU were exactly that).
+__device__ __forceinline__ void re_sync_full() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+#endif
 static inline size_t re_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // grid size for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, never more than the work

@@ -144,10 +144,12 @@ class DeepFMEngine:
         tape = {"E": E, "layers": []}
         h, sd = E, self._step_seed()
         for i in range(self.nl):
-            z = ops.gemm(h, P[f"dnn.{i}.linear.weight"], transB=True, bias=P[f"dnn.{i}.linear.bias"])
+            # bn(linear(x)) in training mode: the batch statistics' per-64-row partials come out of the GEMM's epilogue (re_gemm_f32_colstats)
+            fused = ops.gemm_colstats(h, P[f"dnn.{i}.linear.weight"], True, P[f"dnn.{i}.linear.bias"]) if (self.bn and self.training) else None
+            z, cs = fused if fused is not None else (ops.gemm(h, P[f"dnn.{i}.linear.weight"], transB=True, bias=P[f"dnn.{i}.linear.bias"]), None)
             rm, rv = self.running[i] if self.bn else (None, None)
             a, stats = ops.bn_relu_drop_fwd(z, P.get(f"dnn.{i}.bn.weight"), P.get(f"dnn.{i}.bn.bias"), rm, rv, self.training,
-                                            self.p_drop, sd, stream_id=100 + i, seed_dev=seed_dev)
+                                            self.p_drop, sd, stream_id=100 + i, seed_dev=seed_dev, colstats=cs)
             tape["layers"].append((h, z, a, stats))
             h = a
         dnn = ops.gemm(h, P[f"dnn.{self.nl}.weight"], transB=True, bias=P[f"dnn.{self.nl}.bias"])   # [B, 1]
@@ -179,27 +181,31 @@ class DeepFMEngine:
                 ops.colsum(dz, out=G[f"dnn.{i}.linear.bias"])                          # (= 0 up to rounding behind a BatchNorm)
             da = ops.gemm(dz, P[f"dnn.{i}.linear.weight"])                             # dx = dz W
         gE, gL = ops.fm_bag_bwd(tape["E"], da, dlogit, self.F, self.D)
+        # both table gradients follow the same destination rows: ONE sort (re_scatter_plan), two segmented sums (re_scatter_apply)
         rows = (x + self.offsets.unsqueeze(0)).reshape(-1)
-        ops.scatter_add_rows(gE, rows, self.rows, out=self.gT)
-        ops.scatter_add_rows(gL, rows, self.rows, out=self.gTL)
+        ws = ops.scatter_workspace(rows.numel(), self.D, self.rows, rows.device)
+        ops.scatter_plan(rows, self.D, self.rows, ws)
+        ops.scatter_apply(gE.reshape(-1, self.D), self.rows, self.gT, ws, accumulate=False)
+        ops.scatter_apply(gL.reshape(-1, 1), self.rows, self.gTL, ws, accumulate=False)
         self.gbias.copy_(dsum)
         return loss.squeeze(0)
 
     def train_step(self, x, labels, max_norm=10.0, _state=None):
         """forward, backward, clip_grad_norm_(.., 10), Adam with the reference's two groups (DeepFM/main.py:187-199, 264-268)."""
         loss = self.forward_backward(x, labels, seed_dev=_state)
-        total = torch.sqrt(self.grad.pow(2).sum())
-        self.grad.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        # clip_grad_norm_(.., max_norm) as a device coefficient (two small launches), applied by the two Adam launches on their way through the
+        # gradient (which they leave clipped in the arena, as p.grad is after the reference's step)
+        coef = ops.grad_clip_coef(self.grad, max_norm, out=self.__dict__.setdefault("_clip", torch.empty(2, dtype=torch.float32, device=self.device)))
         ne = self.n_emb
         b1, b2 = self.betas
         if _state is not None:       # captured: seed and Adam scalars are device words; the host counts the step (train_step_graph)
             hyper = _state.view(torch.float32)[2:4]
-            ops.adam_step_dev(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], hyper, b1, b2, 1e-8, self.emb_decay)
-            ops.adam_step_dev(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], hyper, b1, b2, 1e-8, self.wd)
+            ops.adam_step_scaled(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], coef, hyper=hyper, beta1=b1, beta2=b2, weight_decay=self.emb_decay)
+            ops.adam_step_scaled(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], coef, hyper=hyper, beta1=b1, beta2=b2, weight_decay=self.wd)
             return loss
         self.step += 1
-        ops.adam_step(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], self.step, self.lr, b1, b2, 1e-8, self.emb_decay)
-        ops.adam_step(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], self.step, self.lr, b1, b2, 1e-8, self.wd)
+        ops.adam_step_scaled(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], coef, step=self.step, lr=self.lr, beta1=b1, beta2=b2, weight_decay=self.emb_decay)
+        ops.adam_step_scaled(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], coef, step=self.step, lr=self.lr, beta1=b1, beta2=b2, weight_decay=self.wd)
         return loss
 
     def train_step_graph(self, x, labels, max_norm=10.0):

@@ -96,8 +96,10 @@ class MFEngine:
             fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
             self._adam_keep = fz
             R = self.U + self.N
-            ops.scatter_add_rows_small(g, keys, R, A.grad[: R * self.D].view(R, self.D) if getattr(self, "keep_table_grad", True) else None,
-                                       n_regions=3, padding_idx=-1, adam=fz)
+            out = A.grad[: R * self.D].view(R, self.D) if getattr(self, "keep_table_grad", True) else None
+            ops.scatter_add_rows_small(g, keys, R, out, n_regions=3, padding_idx=-1, adam=fz)
+            # (bench_legs.py times this launch alone for config 1's roofline: the same arguments again)
+            self._owner_call = lambda: ops.scatter_add_rows_small(g, keys, R, out, n_regions=3, padding_idx=-1, adam=fz)
             return loss.squeeze(0)
         loss, gu, gp, gn = ops.bpr_triplet_fwd_bwd(Ut, It, u, p, n)
         G = A.views(A.grad)
@@ -121,6 +123,12 @@ class MFEngine:
     def recommend_topk(self, users, seen_ptr, seen_idx, K=50):
         Ub, Ib = self.ranking_buffer
         return ops.score_topk(ops.gather_rows(Ub, users.reshape(-1)), Ib, seen_ptr, seen_idx, K, prep=getattr(self, "_score_prep", None))
+
+    def recommend_from_pool(self, users, pool):
+        """scores [B, P] of every user's candidate pool (MF-BPR/main.py:106-109, LightGCN/main.py:122-125: einsum("BKD,BKD->BK") on the
+        ranking buffers): one gather-and-dot launch (re_score_pool)."""
+        Ub, Ib = self.ranking_buffer
+        return ops.score_pool(ops.gather_rows(Ub, users.reshape(-1)), Ib, pool.contiguous())
 
 
 class LightGCNEngine(MFEngine):

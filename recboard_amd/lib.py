@@ -84,6 +84,11 @@ SIGNATURES = {
     "re_rows_sqnorm_workspace_bytes": (_sz, []),
     "re_rows_sqnorm": (_i32, [_vp, _i64, _i64, _vp, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
     "re_rank_metrics": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "re_grad_clip_workspace_bytes": (_sz, []),
+    "re_grad_clip_coef": (_i32, [_vp, _i64, _f32, _vp, _vp, _sz, _vp]),
+    "re_adam_step_scaled": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _f64, _f64, _f64, _f64, _vp, _vp]),
+    "re_score_pool": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "re_pool_topk": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "re_auc_workspace_bytes": (_sz, []),
     "re_auc": (_i32, [_vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "re_fm_bag_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
@@ -95,6 +100,8 @@ SIGNATURES = {
     "re_ce_chunk_stats": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "re_ce_chunk_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "re_ce_chunk_grad": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "re_gemm_f32_colstats": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "re_bn_relu_drop_fwd_pre": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "re_bn_relu_drop_fwd": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _u32, _vp, _u32, _vp, _vp, _vp, _sz, _vp]),
     "re_step_state": (_i32, [_vp, _u32, _i64, _f64, _f64, _f64, _vp]),
     "re_mlp_workspace_bytes": (_sz, [_i64]),
@@ -128,6 +135,9 @@ def load():
         fn.argtypes = args
     _LIB = L
     return L
+
+
+RE_EUNSUPPORTED = -4      # (include/recengine.h)
 
 
 def check(code, what):

@@ -190,7 +190,12 @@ class GraphedStep:
             for p, k in zip(params, keep):
                 p.copy_(k)
             for b, k in zip(buffers, keep_buf):
-                b.copy_(k)
+                # only what the warm-up CHANGED (BatchNorm statistics, counters): an in-place write bumps a tensor's version, and the ops' plan
+                # caches are keyed on it (torch_ops._plan: a rewritten adjacency gets a new plan and the old one is freed) -- writing an
+                # unchanged `crow` back here made the next evaluation rebuild the SpMM plan and free the one whose address THIS graph replays
+                # (a memory access fault two epochs later, or silently another tensor's bytes)
+                if not torch.equal(b, k):
+                    b.copy_(k)
             for p in params:
                 st = optimizer.state.get(p, {})
                 for name, v in st.items():

@@ -151,6 +151,11 @@ def sparse_adam_rows_small(g, keys, W, m, v, step=0, lr=0.0, beta1=0.9, beta2=0.
               "re_sparse_adam_rows_small")
 
 
+def scatter_workspace(n, D, R, device):
+    """The workspace of scatter_plan / scatter_apply for n indices and rows of D floats (a plan made with D serves applies of any D' <= D)."""
+    return _ws(lib.load().re_scatter_add_rows_workspace_bytes(int(n), int(D), int(R)), device)
+
+
 def scatter_plan(idx, D, R, ws, padding_idx=-1, zero=None):
     """Index half of scatter_add_rows (re_scatter_plan): sorts (destination row, position) into `ws`; optionally zero-fills
     `zero` (the table scatter_apply will accumulate into).  Depends on idx only -- may run on a side stream."""
@@ -458,8 +463,15 @@ def prep_views(blob, B, S, cached=False):
     return pb
 
 
+def _plan_flags(split, tile, tile_wgs):
+    """re_sasrec_batch_prep's `split_long` mask: & 1 split long sequences over two work items; & 2 never hand the step to the tile kernels;
+    & 4 always; & 8 the tile kernels hold TWO workgroups per CU (D = 64: csrc/enc_common.h enc_tile_wg_per_cu) -- the plan's rule counts
+    resident workgroups."""
+    return int(bool(split)) | (0 if tile else 2) | (4 if tile == "always" else 0) | (8 if tile_wgs == 2 else 0)
+
+
 def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4, split=False,
-                      ncu=None, weights=None, loss_acc=None, tile=True):
+                      ncu=None, weights=None, loss_acc=None, tile=True, tile_wgs=1):
     """Batch preparation as ONE launch (re_sasrec_batch_prep): valid mask, count, scatter destination rows, the encoder's work plan;
     with `blob` (a static buffer of prep_layout(B, S) bytes) also copies (seq, pos, neg) into it and, with `state` (int32[4]),
     writes the step scalars -- the staging launch of a captured step.  -> PreparedBatch (views into the blob).
@@ -482,7 +494,7 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     if state is not None:
         _req(state, torch.int32, "state")
     have = pos is not None
-    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), int(bool(split)) | (0 if tile else 2) | (4 if tile == "always" else 0),
+    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), _plan_flags(split, tile, tile_wgs),
             _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None, _p(pb.neg) if copy and have else None,
             _p(pb.valid) if have else None, _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
             _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2))
@@ -530,7 +542,7 @@ def _loss_args(loss_acc):
 
 
 def sasrec_sample_prep(inter, order, b0, B, S, sample_seed, sample_step, blob, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999,
-                       max_tiles=4, split=False, ncu=None, weights=None, users=None, loss_acc=None, tile=True):
+                       max_tiles=4, split=False, ncu=None, weights=None, users=None, loss_acc=None, tile=True, tile_wgs=1):
     """SAMPLE + PREPARE as one launch (re_seq_train_sample_prep): rows b0 .. b0 + B of the epoch's user order `order`, sampled as
     recboard_amd.sampler.seq_train_sample would, written straight into the staging `blob` with everything sasrec_batch_prep derives.
     inter: recboard_amd.sampler.DeviceInteractions.  -> PreparedBatch (views into the blob)."""
@@ -540,7 +552,7 @@ def sasrec_sample_prep(inter, order, b0, B, S, sample_seed, sample_step, blob, s
     wargs = _weight_args(weights) + _loss_args(loss_acc)
     lib.check(lib.load().re_seq_train_sample_prep(_p(inter.ptr), _p(inter.items), _p(inter.sorted), _p(order), order.numel(), int(b0), inter.num_items,
                                                   int(sample_seed) & 0xFFFFFFFF, int(sample_step) & 0xFFFFFFFF, _p(users), B, S,
-                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2) | (4 if tile == "always" else 0), _p(pb.seq), _p(pb.pos),
+                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), _plan_flags(split, tile, tile_wgs), _p(pb.seq), _p(pb.pos),
                                                   _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel(), _p(state),
                                                   int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), *wargs, _stream()),
               "re_seq_train_sample_prep")
@@ -794,12 +806,12 @@ class NextPrep(ctypes.Structure):
                 ("plan_bytes", ctypes.c_size_t)]
 
 
-def next_prep(mail, blob, B, S, max_tiles=4, split=False, ncu=None, tile=True):
+def next_prep(mail, blob, B, S, max_tiles=4, split=False, ncu=None, tile=True, tile_wgs=1):
     """-> NextPrep: the batch whose addresses sasrec_step_stage leaves in `mail` (int64[4], device) is prepared into the staging `blob`
     (sasrec_batch_prep(..., blob=blob)'s outputs) by the tail launch this is handed to.  Keeps `mail` and `blob` alive."""
     _req(mail, torch.int64, "mail"); _req(blob, torch.uint8, "blob")
     pb = prep_views(blob, B, S, cached=True)
-    n = NextPrep(_p(mail), B, S, int(ncu) if ncu else num_cus(blob.device), int(max_tiles), int(bool(split)) | (0 if tile else 2) | (4 if tile == "always" else 0), _p(pb.seq), _p(pb.pos),
+    n = NextPrep(_p(mail), B, S, int(ncu) if ncu else num_cus(blob.device), int(max_tiles), _plan_flags(split, tile, tile_wgs), _p(pb.seq), _p(pb.pos),
                  _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel())
     n._keep = (mail, blob, pb)
     return n
@@ -962,6 +974,26 @@ def adam_step_dev(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
                                           float(weight_decay), _stream()), "re_adam_step_dev")
 
 
+def grad_clip_coef(g, max_norm, out=None):
+    """-> float32[2] on the device: [min(1, max_norm / (||g|| + 1e-6)), ||g||] over the flat gradient (re_grad_clip_coef: clip_grad_norm_'s
+    coefficient, DeepFM/main.py:267)."""
+    _req(g, torch.float32, "g")
+    out = out if out is not None else torch.empty(2, dtype=torch.float32, device=g.device)
+    L = lib.load()
+    ws = _ws(L.re_grad_clip_workspace_bytes(), g.device)
+    lib.check(L.re_grad_clip_coef(_p(g), g.numel(), float(max_norm), _p(out), _p(ws), ws.numel(), _stream()), "re_grad_clip_coef")
+    return out
+
+
+def adam_step_scaled(p, g, m, v, gscale, step=0, lr=0.0, hyper=None, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """Adam on gscale[0] * g, the scaled gradient written back to g (re_adam_step_scaled).  step >= 1 with lr: host-side bias corrections;
+    step = 0 with `hyper` (device float32[2]): a captured step's."""
+    for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (gscale, "gscale")):
+        _req(t, torch.float32, nme)
+    lib.check(lib.load().re_adam_step_scaled(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), _p(hyper), float(beta1), float(beta2), float(eps),
+                                             float(weight_decay), _p(gscale), _stream()), "re_adam_step_scaled")
+
+
 def scale_copy(dst, src, alpha):
     _req(dst, torch.float32, "dst"); _req(src, torch.float32, "src")
     lib.check(lib.load().re_scale_copy(_p(dst), _p(src), float(alpha), src.numel(), _stream()), "re_scale_copy")
@@ -982,6 +1014,27 @@ def rank_metrics(topk_idx, tgt_ptr, tgt_idx, ks):
     lib.check(lib.load().re_rank_metrics(_p(topk_idx), B, Kmax, _p(tgt_ptr), _p(tgt_idx), arr, len(ks), _p(per_user), _p(sums),
                                          _stream()), "re_rank_metrics")
     return per_user, sums
+
+
+def score_pool(Q, E, pool):
+    """-> scores f32 [B, P]: <Q[b], E[pool[b, p]]> (re_score_pool: the value the full-catalog score gives the pair, bit for bit)."""
+    _req(Q, torch.float32, "Q"); _req(E, torch.float32, "E"); _req(pool, torch.int64, "pool")
+    B, D = Q.shape
+    if pool.dim() != 2 or pool.shape[0] != B:
+        raise ValueError("recengine: `pool` must be [B, P]")
+    out = torch.empty(pool.shape, dtype=torch.float32, device=Q.device)
+    lib.check(lib.load().re_score_pool(_p(Q), _p(E), _p(pool), B, pool.shape[1], E.shape[0], D, _p(out), _stream()), "re_score_pool")
+    return out
+
+
+def pool_topk(scores, K):
+    """-> (vals f32 [B, K] descending, idx int64 [B, K] = positions in the row; ties -> lowest position)  (re_pool_topk)."""
+    _req(scores, torch.float32, "scores")
+    B, P = scores.shape
+    vals = torch.empty((B, K), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((B, K), dtype=torch.int64, device=scores.device)
+    lib.check(lib.load().re_pool_topk(_p(scores), B, P, K, _p(vals), _p(idx), _stream()), "re_pool_topk")
+    return vals, idx
 
 
 def auc(scores, labels):
@@ -1057,6 +1110,31 @@ def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, bias=N
     return out
 
 
+def gemm_colstats(A, B, transB=True, bias=None):
+    """-> (out, colstats) with out = A @ op(B) + bias and colstats [M / 64, 2, N] = per-64-row (mean, M2) of out's columns, from the GEMM's
+    own epilogue (re_gemm_f32_colstats); or None where that form does not apply (M not a multiple of 64, unaligned operands)."""
+    for t, nme in ((A, "A"), (B, "B")):
+        _req(t, torch.float32, nme, contiguous=False)
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"recengine: `{nme}` must be 2-D with unit inner stride")
+    M, K = A.shape
+    Kb, N = (B.shape[1], B.shape[0]) if transB else B.shape
+    if K != Kb:
+        raise ValueError(f"recengine: inner dimensions differ ({K} vs {Kb})")
+    if M % 64:
+        return None
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    cs = torch.empty((M // 64, 2, N), dtype=torch.float32, device=A.device)
+    if bias is not None:
+        _req(bias, torch.float32, "bias")
+    rc = lib.load().re_gemm_f32_colstats(0, int(transB), M, N, K, 1.0, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _p(bias), _p(cs),
+                                         _stream())
+    if rc == lib.RE_EUNSUPPORTED:
+        return None
+    lib.check(rc, "re_gemm_f32_colstats")
+    return out, cs
+
+
 class CEStats:
     """Running row statistics of a chunked cross entropy (re_ce_chunk_*): rowmax, rowsum, target logit per row."""
 
@@ -1111,13 +1189,20 @@ def step_state(state, seed, step, lr, beta1=0.9, beta2=0.999):
     return state
 
 
-def bn_relu_drop_fwd(z, gamma, beta, run_mean, run_var, training, drop_p=0.0, seed=0, stream_id=100, eps=1e-5, momentum=0.1, seed_dev=None):
-    """-> (a, stats): a = dropout(relu(bn(z)))  (re_bn_relu_drop_fwd); gamma None = no BatchNorm."""
+def bn_relu_drop_fwd(z, gamma, beta, run_mean, run_var, training, drop_p=0.0, seed=0, stream_id=100, eps=1e-5, momentum=0.1, seed_dev=None,
+                     colstats=None):
+    """-> (a, stats): a = dropout(relu(bn(z)))  (re_bn_relu_drop_fwd); gamma None = no BatchNorm.  colstats (training, BatchNorm): the
+    per-chunk (mean, M2) partials of z's columns from `gemm_colstats` -- the statistics pass over z is skipped (re_bn_relu_drop_fwd_pre)."""
     _req(z, torch.float32, "z")
     M, N = z.shape
     a = torch.empty_like(z)
     stats = torch.empty(2 * N, dtype=torch.float32, device=z.device) if gamma is not None else None
     L = lib.load()
+    if colstats is not None and training and gamma is not None:
+        lib.check(L.re_bn_relu_drop_fwd_pre(_p(z), M, N, _p(gamma), _p(beta), _p(run_mean), _p(run_var), float(eps), float(momentum), float(drop_p),
+                                            int(seed) & 0xFFFFFFFF, _p(seed_dev), int(stream_id), _p(stats), _p(a), _p(colstats), int(colstats.shape[0]),
+                                            _stream()), "re_bn_relu_drop_fwd_pre")
+        return a, stats
     ws = _ws(L.re_mlp_workspace_bytes(N), z.device)
     lib.check(L.re_bn_relu_drop_fwd(_p(z), M, N, _p(gamma), _p(beta), _p(run_mean), _p(run_var), int(bool(training)),
                                     float(eps), float(momentum), float(drop_p), int(seed) & 0xFFFFFFFF, _p(seed_dev), int(stream_id),

@@ -232,6 +232,13 @@ class SASRecEngine:
             prep = prep[0] if prep is not None and prep[1] == self.arena.step else None   # (planes of the table as it is NOW)
             return ops.score_topk(u[:, -1, :].contiguous(), items, seen_ptr, seen_idx, K, prep=prep)
 
+    def recommend_from_pool(self, seq, pool):
+        """scores [B, P] of every sequence's candidate pool (`pool` int64 [B, P], 0-based item ids: the target first, then the sampled
+        unseen items): SASRec/main.py:230-236, einsum("BD,BKD->BK") on the last position -- one gather-and-dot launch (re_score_pool)."""
+        with torch.no_grad():
+            u, items = self.encode(seq)
+            return ops.score_pool(u[:, -1, :].contiguous(), items, pool.contiguous())
+
     def _max_tiles(self):
         return 4 if self.D == 64 else 2     # tiles of 16 rows per work item (LDS capacity of the workgroup-per-item encoder kernels)
 
@@ -241,7 +248,7 @@ class SASRecEngine:
         3*B*S gradient contributions, work items.  No host sync.  -> ops.PreparedBatch.
         for_next_step: the launch also prepares the weights of the step (re_sasrec_batch_prep_w) -- the batch must then go into the very
         next step, before anything else changes the parameters."""
-        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(),
+        return ops.sasrec_batch_prep(seq, pos, neg, max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(), ncu=self._plan_ncu(),
                                      weights=self._prep_weights(*seq.shape) if for_next_step else None)
 
     def check_handover(self):
@@ -258,6 +265,10 @@ class SASRecEngine:
         """The training step may run one tile per workgroup (csrc/enc_tile.hip: D = 64 and 128; re_sasrec_encoder_step picks per batch)."""
         ok = bool(self.D in (64, 128) and getattr(self, "tile_step", True) and self.fused_item_kernel and self.encoder == "fused" and self.loss_kind != "CE" and self.compact_rows)
         return "always" if ok and getattr(self, "tile_step", True) == "always" else ok   # ("always": whatever the batch -- the plan's rule is a matter of speed)
+
+    def _tile_wgs(self):
+        """Resident workgroups per CU of the tile kernels (csrc/enc_common.h: enc_tile_wg_per_cu): the batch plan's rule counts them."""
+        return 2 if self.D == 64 else 1
 
     def _tail_word(self):
         if not hasattr(self, "_tail"):
@@ -506,7 +517,7 @@ class SASRecEngine:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(),
+                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(), ncu=self._plan_ncu(),
                                        weights=self._prep_weights(B, S) if in_prep else None)
             body()
         torch.cuda.current_stream().wait_stream(side)
@@ -523,7 +534,7 @@ class SASRecEngine:
         B, S = seq.shape
         sd = (self.seed * 0x9E3779B1 + step * 0x85EBCA77) & 0xFFFFFFFF          # (= _step_seed() once arena.step == step - 1)
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=sd, step=step, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(),
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(), ncu=self._plan_ncu(),
                               weights=self._prep_weights(B, S) if g["in_prep"] else None, loss_acc=self._take_pending_loss())
 
     # ---- the epoch's loss sum without a launch per step: between begin_ and end_loss_accumulation every captured step's loss is added
@@ -636,7 +647,7 @@ class SASRecEngine:
             mail = torch.zeros(ops.MAIL_WORDS, dtype=torch.int64, device=self.device)          # (zero: the captures' warm-up runs prepare nothing)
             graphs = []
             for p in range(2):                                                     # both copies now: a capture's warm-up overwrites its staging buffers
-                nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(), tile=self._wave_step())
+                nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), ncu=self._plan_ncu(), tile=self._wave_step(), tile_wgs=self._tile_wgs())
                 graphs.append(self._capture(B, S, with_adam=with_adam, in_prep=True, blob=blobs[p], next_prep=nxt))
             tp = self._tail_pipes[key] = dict(blobs=blobs, mail=mail, graphs=graphs, parity=0, staged=None)
         return tp
@@ -650,7 +661,7 @@ class SASRecEngine:
         st, tp["staged"] = tp["staged"], None
         if not (isinstance(st, tuple) and st[0] is seq and st[1] is pos and st[2] is neg):
             # nobody prepared this batch: the plain preparation launch in front of the step (an epoch's first batch)
-            ops.sasrec_batch_prep(seq, pos, neg, blob=tp["blobs"][p], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
+            ops.sasrec_batch_prep(seq, pos, neg, blob=tp["blobs"][p], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(),
                                   ncu=self._plan_ncu())
         if next_batch is not None and tuple(next_batch[0].shape) != (B, S):
             next_batch = None                                                      # (another shape: its own copies' buffers; prepared in front of its step)
@@ -684,7 +695,7 @@ class SASRecEngine:
             st, tp["staged"] = tp["staged"], None
             if st is not ticket:
                 ops.sasrec_sample_prep(ticket.inter, ticket.order, ticket.b0, B, S, ticket.seed, ticket.step, tp["blobs"][p], max_tiles=self._max_tiles(),
-                                       split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(), users=ticket.users)
+                                       split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(), ncu=self._plan_ncu(), users=ticket.users)
             if next_ticket is not None and (next_ticket.B, next_ticket.S) != (B, S):
                 next_ticket = None
             ops.sasrec_step_stage(g["state"], self._step_seed(), A.step + 1, self.lr, self.betas[0], self.betas[1], B, S, mail=tp["mail"],
@@ -703,7 +714,7 @@ class SASRecEngine:
         g = self._graphs[key]
         ops.sasrec_sample_prep(ticket.inter, ticket.order, ticket.b0, B, S, ticket.seed, ticket.step, g["blob"], state=g["state"],
                                seed=self._step_seed(), step=A.step + 1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                               max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), ncu=self._plan_ncu(),
+                               max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(), ncu=self._plan_ncu(),
                                weights=self._prep_weights(B, S) if g["in_prep"] else None, users=ticket.users, loss_acc=self._take_pending_loss())
         g["graph"].replay()
         A.step += 1

@@ -24,6 +24,7 @@ Fixtures (all fp32, seed fixed, dropout 0 so train-mode forward is deterministic
   bert4rec.npz : BERT4Rec/main.py fit loss (the mask draw recorded) + every gradient + full scores (dropout 0)
   ngcf.npz     : NGCF/main.py     fit (rec_loss, emb_loss) + every gradient + full scores on D^-1 (A + I)
   simgcl.npz   : SimGCL/main.py   fit (rec_loss, emb_loss, ssl_loss at eps = 0: the noise is torch.rand_like) + grads + full scores
+  pool.npz     : SASRec / MF-BPR / LightGCN main.py  recommend_from_pool scores [B, 21] (`python make_golden.py pool`, from the other fixtures' states)
 """
 import importlib.util
 import os
@@ -658,8 +659,66 @@ def gen_bert4rec():
     print(f"bert4rec: loss={float(losses['rec_loss'].detach()):.6f} masked={int(out['out/n_masked'])}")
 
 
+def gen_pool():
+    """pool.npz: `recommend_from_pool` of the reference's SASRec / MF / LightGCN (SASRec/main.py:230-236, MF-BPR/main.py:106-109,
+    LightGCN/main.py:122-125) under the states of sasrec_bce.npz / mfbpr.npz / lightgcn.npz (loaded, not regenerated): per evaluation row a
+    pool of 1 + 20 item ids (the target first, as the evaluation pipes hand it over), with planted duplicates of the target (ties)."""
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # SASRec
+    z = np.load(os.path.join(HERE, "sasrec_bce.npz"))
+    fr, ref = import_ref("SASRec", "ref_sasrec_pool", dict(dropout_rate=0.0, loss="BCE", embedding_dim=64))
+    F = fr.data.fields.Field
+    N = int(z["cfg/N"])
+    model = ref.SASRec(fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=40), F("ITEM", "ITEM", "ID", count=N)]))
+    model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    seq = torch.from_numpy(z["in/seq"])
+    pool = torch.randint(0, N, (seq.shape[0], 21), generator=g)
+    pool[0, 5] = pool[0, 0]; pool[3, 20] = pool[3, 0]                  # the target again further down: a tie the target must win
+    model.eval()
+    with torch.no_grad():
+        sc = model({model.ISeq: seq, model.IUnseen: pool}, ranking="pool")
+    out["sasrec/pool"], out["sasrec/scores"] = pool.numpy(), sc.numpy()
+    # MF-BPR
+    z = np.load(os.path.join(HERE, "mfbpr.npz"))
+    fr, ref = import_ref("MF-BPR", "ref_mfbpr_pool", {})
+    F = fr.data.fields.Field
+    U, N = z["param/User.embeddings.weight"].shape[0], z["param/Item.embeddings.weight"].shape[0]
+    model = ref.MF(fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)]))
+    model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    users = torch.from_numpy(z["in/users"])
+    pool = torch.randint(0, N, (users.shape[0], 21), generator=g)
+    model.eval()
+    with torch.no_grad():
+        model.reset_ranking_buffers()
+        sc = model({model.User: users, model.IUnseen: pool}, ranking="pool")
+    out["mfbpr/pool"], out["mfbpr/scores"] = pool.numpy(), sc.numpy()
+    # LightGCN
+    z = np.load(os.path.join(HERE, "lightgcn.npz"))
+    U, N = z["param/User.embeddings.weight"].shape[0], z["param/Item.embeddings.weight"].shape[0]
+    adj = torch.sparse_csr_tensor(torch.from_numpy(z["in/adj_crow"]), torch.from_numpy(z["in/adj_col"]), torch.from_numpy(z["in/adj_val"]), size=(U + N, U + N))
+    fr, ref = import_ref("LightGCN", "ref_lightgcn_pool", {})
+    F = fr.data.fields.Field
+    model = ref.LightGCN(fr.data.datasets.RecDataSet([F("USER", "USER", "ID", count=U), F("ITEM", "ITEM", "ID", count=N)], adj=adj))
+    with torch.no_grad():
+        model.User.embeddings.weight.copy_(torch.from_numpy(z["param/User.embeddings.weight"]))
+        model.Item.embeddings.weight.copy_(torch.from_numpy(z["param/Item.embeddings.weight"]))
+    users = torch.from_numpy(z["in/users"])
+    pool = torch.randint(0, N, (users.shape[0], 21), generator=g)
+    model.eval()
+    with torch.no_grad():
+        model.reset_ranking_buffers()
+        sc = model({model.User: users, model.IUnseen: pool}, ranking="pool")
+    out["lightgcn/pool"], out["lightgcn/scores"] = pool.numpy(), sc.numpy()
+    np.savez_compressed(os.path.join(HERE, "pool.npz"), **out)
+    print("pool:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["pool"]:          # (the pool fixture alone: it reads the other fixtures' states)
+        gen_pool()
+        sys.exit(0)
     for loss in ("BCE", "BPR", "CE"):
         gen_sasrec(loss)
     gen_sasrec("BCE", embedding_dim=128)
@@ -683,6 +742,7 @@ if __name__ == "__main__":
     gen_last_item_model("BSARec", "BSARec", "bsarec_ce", dict(loss="CE", embedding_dim=64, num_heads=2, num_blocks=2, hidden_dropout_rate=0.0,
                                                               attn_dropout_rate=0.0, maxlen=20, c=5, alpha=0.7), True, with_modules=True, emb_scale=10.0)
     gen_bert4rec()
+    gen_pool()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -54,9 +54,15 @@ def test_c2_sasrec_graph_step_at_bench_config_matches_oracle():
     from recboard_amd import ops
     W = m._buffers(B, S)
     plan = ops.prep_views(m._graphs[(B, S, True, True)]["blob"], B, S).plan
-    gates = {l: ((ops.sasrec_tape_array(W["tape"], plan, B, S, D, L, "HR", l) > 0).cpu(), 2e-5) for l in range(L)}
+    gate_report = {l: {} for l in range(L)}
+    gates = {l: ((ops.sasrec_tape_array(W["tape"], plan, B, S, D, L, "HR", l) > 0).cpu(), 2e-5, gate_report[l]) for l in range(L)}
     ref = osas.fit(P, torch.from_numpy(seq), torch.from_numpy(pos), torch.from_numpy(neg), "BCE", L, drop=dict(p=p, seed=seed2), gates=gates)
     ref.backward()
+    for l, rep in gate_report.items():
+        # the borrowed gates, counted: fewer than 1e-4 of the real rows' pre-activations lie inside the window, and OUTSIDE it the engine's gate
+        # is the oracle's sign exactly -- a broken gate cannot hide in the window
+        assert rep["total"] > 0 and rep["window"] < 1e-4 * rep["total"], (l, rep)
+        assert rep["mismatch_outside"] == 0, (l, rep)
     np.testing.assert_allclose(loss, ref.item(), rtol=2e-5)
     Gv = m.arena.views(m.arena.grad)
     for k, q in P.items():

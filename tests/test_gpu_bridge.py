@@ -154,7 +154,6 @@ def test_deepfm_resume_keeps_the_reduced_learning_rate_and_checkpoints_move_betw
     z = np.load(os.path.join(G, "deepfm.npz"))
     args = [a if a != "0.3" else "0.0" for a in DEEPFM_ARGS]
     mod = import_script(os.path.join(EX, "DeepFM", "main.py"), "_gpu_bridge_deepfm_resume", args)
-    ds = deepfm_dataset(z)
     rng = np.random.default_rng(5)
     counts = z["cfg/counts"].tolist()
 
@@ -169,6 +168,7 @@ def test_deepfm_resume_keeps_the_reduced_learning_rate_and_checkpoints_move_betw
     train, valid = batches(3, 256), batches(3, 200) + batches(1, 57)      # (unequal evaluation batches: per-batch mean != global value)
 
     def build(engine, path, resume=False):
+        ds = deepfm_dataset(z)             # (a dataset of its own: the fields -- nn.Modules that carry the tables -- belong to the dataset)
         model = mod.DeepFM(ds)
         load_deepfm_golden(model, z)
 
@@ -198,8 +198,15 @@ def test_deepfm_resume_keeps_the_reduced_learning_rate_and_checkpoints_move_betw
     modelm, coachm = build("module", pm)
     modelm.load_state_dict(model.state_dict())
     mod.cfg.engine = "auto"                # (the scripts share one cfg object: `coach` evaluates fused, `coachm` has no engine attached)
-    ra, rm = coach.valid(9), coachm.valid(9)
-    assert abs(ra["AUC"] - rm["AUC"]) < 1e-5 and abs(ra["LOGLOSS"] - rm["LOGLOSS"]) < 1e-5
+    modelm.eval()
+    coach._engine.reset_ranking_buffers()  # (evaluation mode: running statistics, no dropout)
+    for vb in coach.validpipe:             # the two paths score the same rows the same way ...
+        z, _ = coach._engine.pool_logits(coach, vb)
+        with torch.no_grad():
+            pm_ = modelm({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in vb.items()}, ranking="pool").reshape(-1)
+        torch.testing.assert_close(torch.sigmoid(z.reshape(-1)), pm_, rtol=1e-4, atol=1e-6)
+    ra, rm = coach.valid(9), coachm.valid(9)   # ... and monitor the same batch-weighted means
+    assert abs(ra["AUC"] - rm["AUC"]) < 1e-5 and abs(ra["LOGLOSS"] - rm["LOGLOSS"]) < 1e-5, (ra, rm)
     # (1) resume on the engine: the reduced rate, the moments, the step count
     model2, coach2 = build("auto", pa, resume=True)
     assert coach2.resume() == 5
@@ -341,3 +348,78 @@ def test_gen_and_pred_epochs_through_the_coach_cost_at_most_1p3x_the_bare_engine
                 break
         print(what, "coach / bare epoch time:", round(best["coach"] / best["bare"], 3), best)
         assert best["coach"] <= 1.3 * best["bare"], (what, best)
+
+
+def test_pool_ranking_runs_on_the_engine_and_matches_the_reference_golden():
+    """`--ranking=pool` (recommend_from_pool: SASRec/main.py:230-236, MF-BPR/main.py:106-109, LightGCN/main.py:122-125; evaluate contract
+    UniSRec/main.py:415-421) for adopted Seq / Gen scripts: the engines' pool scores equal the reference's own (tests/golden/pool.npz) and are,
+    bit for bit, the full-catalog scores at the pool's columns; the Coach's fused evaluation (re_score_pool -> re_pool_topk -> re_rank_metrics)
+    monitors what the script's own torch code monitors (`--engine module`: freerec.metrics on the dense [B, 1 + K] scores)."""
+    from recboard_amd import ops
+    zp = np.load(os.path.join(G, "pool.npz"))
+    for name, coach_name, fixture, key in (("SASRec", "CoachForSASRec", "sasrec_bce.npz", "sasrec"), ("MF-BPR", "CoachForMF", "mfbpr.npz", "mfbpr"),
+                                           ("LightGCN", "CoachForLightGCN", "lightgcn.npz", "lightgcn")):
+        z = np.load(os.path.join(G, fixture))
+        args = ["--dropout-rate", "0", "--loss", "BCE"] if name == "SASRec" else []
+        mod = import_script(os.path.join(EX, name, "main.py"), "_gpu_bridge_pool_" + key, args)
+        pool_g = zp[key + "/pool"]
+        # (the metric comparison on pools WITHOUT repeated items: among equal scores torch.topk's order is its own, the engine's is "lowest position")
+        n_items = int(z["cfg/N"]) if name == "SASRec" else z["param/Item.embeddings.weight"].shape[0]
+        prng = np.random.default_rng(17)
+        pool = np.stack([prng.permutation(n_items)[:21] for _ in range(len(pool_g))]).astype(np.int64)
+        if name == "SASRec":
+            ds = toy_dataset(40, int(z["cfg/N"]))
+            model_cls, wd = mod.SASRec, 0.0
+        else:
+            U, N = z["param/User.embeddings.weight"].shape[0], z["param/Item.embeddings.weight"].shape[0]
+            ds = toy_dataset(U, N) if name == "MF-BPR" else lightgcn_dataset(z)
+            model_cls, wd = (mod.MF if name == "MF-BPR" else mod.LightGCN), (float(z["cfg/weight_decay"]) if name == "LightGCN" else 1e-4)
+        res = {}
+        for engine in ("auto", "module"):
+            model = model_cls(ds)
+            model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/") and z[k].dtype == np.float32}, strict=False)
+            if name == "SASRec":
+                batch = {model.ISeq: torch.from_numpy(z["in/seq"]), model.IPos: torch.from_numpy(z["in/pos"]), model.INeg: torch.from_numpy(z["in/neg"]),
+                         model.User: torch.arange(len(z["in/seq"])), model.Size: len(z["in/seq"])}
+                vbatch = {model.ISeq: torch.from_numpy(z["in/seq"]), model.User: torch.arange(len(z["in/seq"])), model.IUnseen: torch.from_numpy(pool),
+                          model.ISeen: [[] for _ in pool], model.Size: len(pool)}
+            else:
+                batch, _ = _gen_batches(model, z)
+                vbatch = {model.User: torch.from_numpy(z["in/users"]), model.IUnseen: torch.from_numpy(pool), model.ISeen: [[] for _ in pool], model.Size: len(pool)}
+            cfg = _cfg(mod, engine=engine, lr=0.0, weight_decay=wd, ranking="pool", monitors=["LOSS", "HitRate@1", "HitRate@5", "NDCG@5", "NDCG@10", "MRR@10"],
+                       which4best="NDCG@10")
+            coach = getattr(mod, coach_name)(dataset=ds, trainpipe=[batch], validpipe=[vbatch], testpipe=None, model=model, cfg=cfg)
+            assert (coach._engine is not None) == (engine == "auto")
+            res[engine] = coach.valid(0)
+            if engine == "auto":
+                ad = coach._engine
+                ad.reset_ranking_buffers()
+                sc = ad.recommend_pool(coach, {**vbatch, model.IUnseen: torch.from_numpy(pool_g)})
+                np.testing.assert_allclose(sc.cpu().numpy(), zp[key + "/scores"], rtol=1e-4, atol=1e-5)
+                # ... and they are the full-ranking scores at the pool's columns, bit for bit (one definition of a pair's score)
+                with torch.no_grad():
+                    model.eval()
+                    if hasattr(model, "reset_ranking_buffers"):
+                        model.reset_ranking_buffers()
+                if name == "SASRec":
+                    u, items = ad.eng.encode(torch.from_numpy(z["in/seq"]).cuda())
+                    full = ops.score_dense(u[:, -1, :].contiguous(), items)
+                else:
+                    full = ad.eng.recommend_from_full(torch.from_numpy(z["in/users"]).cuda())
+                assert torch.equal(sc, torch.gather(full, 1, torch.from_numpy(pool_g).cuda()))
+        assert set(res["auto"]) == set(res["module"]) and len(res["auto"]) == 5
+        for k in res["auto"]:
+            assert abs(res["auto"][k] - res["module"][k]) <= 1e-6, (name, k, res["auto"][k], res["module"][k])
+    cfg.ranking = "full"
+
+
+def test_pool_topk_is_the_stable_descending_order():
+    from recboard_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(2)
+    s = torch.randn(37, 101, device="cuda", generator=g)
+    s[:, 40] = s[:, 0]; s[5, :] = 1.5; s[6, 7] = float("-inf")
+    vals, idx = ops.pool_topk(s, 50)
+    order = torch.sort(s, dim=1, descending=True, stable=True).indices[:, :50]
+    assert torch.equal(idx, order) and torch.equal(vals, torch.gather(s, 1, order))
+    v2, i2 = ops.pool_topk(s[:, :20].contiguous(), 32)
+    assert (i2[:, 20:] == -1).all() and torch.isinf(v2[:, 20:]).all() and torch.equal(i2[:, :20], torch.sort(s[:, :20], dim=1, descending=True, stable=True).indices)

@@ -51,9 +51,15 @@ def test_one_step_on_the_100m_item_table_matches_the_oracle_on_the_touched_rows(
     P = {k: v.clone().requires_grad_(True) for k, v in dense0.items()}
     P["Item.embeddings.weight"] = E0.clone().requires_grad_(True)
     tape = eng._buffers(B, S)["tape"]
-    gates = {l: ((ops.sasrec_tape_array(tape, pb.plan, B, S, D, L, "HR", l) > 0).cpu(), 2e-5) for l in range(L)}
+    gate_report = {l: {} for l in range(L)}
+    gates = {l: ((ops.sasrec_tape_array(tape, pb.plan, B, S, D, L, "HR", l) > 0).cpu(), 2e-5, gate_report[l]) for l in range(L)}
     ref = osas.fit(P, seq_c, pos_c, neg_c, "BCE", L, gates=gates)
     ref.backward()
+    for l, rep in gate_report.items():
+        # the borrowed gates, counted: fewer than 1e-4 of the real rows' pre-activations lie inside the window, and OUTSIDE it the engine's gate
+        # is the oracle's sign exactly -- a broken gate cannot hide in the window
+        assert rep["total"] > 0 and rep["window"] < 1e-4 * rep["total"], (l, rep)
+        assert rep["mismatch_outside"] == 0, (l, rep)
     assert abs(loss - ref.item()) <= 2e-5 * abs(ref.item()), (loss, ref.item())
     Gv = eng.arena.views(eng.arena.grad)
     for k in dense0:                                                             # every dense gradient, entry by entry

@@ -138,6 +138,35 @@ def _deepfm_params(z, grad):
     return tables, tables_lr, T(z["param/fm.lr_layer.bias"], grad), mlp
 
 
+def test_pool_ranking_restatement_matches_the_reference_recommend_from_pool():
+    """tests/golden/pool.npz (the reference's recommend_from_pool of SASRec / MF / LightGCN under the other fixtures' states): the oracle's
+    pool scores = its full scores at the pool's columns, and the top-K rule puts the target (position 0) in front of its duplicates."""
+    olg, osas = lightgcn, sasrec
+    zp = np.load(os.path.join(G, "pool.npz"))
+    z = np.load(os.path.join(G, "sasrec_bce.npz"))
+    P = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}
+    with torch.no_grad():
+        u, items = osas.encode(P, torch.from_numpy(z["in/seq"]), int(z["cfg/num_blocks"]))
+    sc = ranking.score_pool(u[:, -1, :].numpy(), items.numpy(), zp["sasrec/pool"])
+    np.testing.assert_allclose(sc, zp["sasrec/scores"], rtol=1e-5, atol=1e-5)
+    _, idx = ranking.pool_topk(sc, 21)
+    for b, dup in ((0, 5), (3, 20)):                   # rows with a planted duplicate of the target: the chain gives both the same value (the
+        assert sc[b, 0] == sc[b, dup]                  # reference's batched einsum differs in the last bit between them), position 0 ranks first
+        pos = {int(i): r for r, i in enumerate(idx[b])}
+        assert pos[0] + 1 == pos[dup]
+    z = np.load(os.path.join(G, "mfbpr.npz"))
+    sc = ranking.score_pool(z["param/User.embeddings.weight"][z["in/users"].reshape(-1)], z["param/Item.embeddings.weight"], zp["mfbpr/pool"])
+    np.testing.assert_allclose(sc, zp["mfbpr/scores"], rtol=1e-5, atol=1e-5)
+    z = np.load(os.path.join(G, "lightgcn.npz"))
+    with torch.no_grad():
+        ue, ie = olg.encode(torch.from_numpy(z["param/User.embeddings.weight"]), torch.from_numpy(z["param/Item.embeddings.weight"]), z["in/adj_crow"], z["in/adj_col"],
+                            z["in/adj_val"], int(z["cfg/num_layers"]))
+    sc = ranking.score_pool(ue.numpy()[z["in/users"].reshape(-1)], ie.numpy(), zp["lightgcn/pool"])
+    np.testing.assert_allclose(sc, zp["lightgcn/scores"], rtol=1e-5, atol=1e-5)
+    v, i = ranking.pool_topk(np.array([[1.0, 3.0, 3.0, 2.0]], np.float32), 6)
+    assert i.tolist() == [[1, 2, 3, 0, -1, -1]] and v[0, 4] == -np.inf
+
+
 def test_deepfm():
     z = load("deepfm")
     tables, tables_lr, lrb, mlp = _deepfm_params(z, True)
