@@ -20,6 +20,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+MFMA_F32_PEAK_TF = 157.3      # MI355X fp32 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 

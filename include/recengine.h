@@ -603,7 +603,16 @@ int re_bn_relu_drop_fwd_pre(const float* z, int64_t M, int64_t N, const float* g
                             float* run_var, float eps, float momentum, float drop_p, uint32_t seed, const uint32_t* seed_dev,
                             uint32_t stream_id, float* stats, float* a, const float* colstats, int chunks, re_stream_t stream);
 int re_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, re_stream_t stream);
-size_t re_mlp_workspace_bytes(int64_t N);   /* scratch of the three entry points above (per-chunk column partials) */
+size_t re_mlp_workspace_bytes(int64_t N);
+/* DeepFM's last layer + criterion (DeepFM/main.py:151-164 `dnn` ends in Linear(., 1); :201-215 logits = lr + fm + dnn, BCELoss4Logits):
+ * re_mlp_head_fwd: logits[m] = fm_lr[m] + <h[m, :], w> + b[0] (fm_lr may be NULL); with labels also loss[0] = mean BCE-with-logits,
+ *   dlogit[m] = (sigmoid(logit) - y) / M, dsum[0] = sum dlogit.  re_mlp_head_bwd: da[m, k] = dlogit[m] w[k], dW[k] = sum_m dlogit[m] h[m, k].
+ * h [M, K] contiguous, K a multiple of 4, 16-byte aligned (else RE_EUNSUPPORTED: use re_gemm_f32 + re_bce_logits); fixed-order sums. */
+size_t re_mlp_head_workspace_bytes(int64_t M, int64_t K);
+int re_mlp_head_fwd(const float* h, int64_t M, int64_t K, const float* w, const float* b, const float* fm_lr, const float* labels,
+                    float* logits, float* loss, float* dlogit, float* dsum, void* ws, size_t ws_bytes, re_stream_t stream);
+int re_mlp_head_bwd(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, float* da, float* dW, void* ws,
+                    size_t ws_bytes, re_stream_t stream);   /* scratch of the three entry points above (per-chunk column partials) */
 
 /* dst[i] = alpha * src[i]  (LightGCN/main.py:80 `avgEmbds = allEmbds / (L+1)`) */
 int re_scale_copy(float* dst, const float* src, float alpha, int64_t n, re_stream_t stream);

@@ -87,8 +87,11 @@ __host__ __device__ inline int64_t enc_plan_max_tiles(int64_t B, int64_t S) { re
 // which form of the tile kernels a launch of this shape uses (enc_tile_body.inc: enc_tile_step_k<LOOP>): batches of more than 2048 possible
 // tiles (B > 512 at S = 50) the looped one -- the plan (enc_plan_body.h) applies the matching rule
 __host__ __device__ inline bool enc_tile_looped(int64_t B, int64_t S) { return enc_plan_max_tiles(B, S) > 2048; }
-// resident workgroups per CU of the tile kernels (enc_tile.hip: four waves a workgroup at D = 64 -- two fit; eight at D = 128 -- one)
-__host__ __device__ inline int enc_tile_wg_per_cu(int64_t D) { return D == 64 ? 2 : 1; }
+// resident workgroups per CU of the tile kernels (enc_tile.hip).  ONE: at D = 64 two would fit (four waves, ~190 registers, 58 KB of LDS each) and
+// are 14 - 20 % faster on batches of 1 024 - 4 096 sequences, but with two the results differ from process to process in single registers of single
+// waves -- still unexplained after round 5 ruled out SGPR spills, the barriers' missing vmcnt drain and the transcendental forwarding hazard
+// (profiles/r5_handover_notes.txt).  The launcher, the plan's rule (split_long & 8) and the looped grid all follow this one number.
+__host__ __device__ inline int enc_tile_wg_per_cu(int64_t D) { (void)D; return 1; }
 // rows of the vector-gradient slab in the backward's workspace: one per workgroup (<= 1024) or one per tile (enc_tile.hip)
 __host__ __device__ inline int64_t enc_slab_rows(int64_t B, int64_t S) { const int64_t mt = enc_plan_max_tiles(B, S); return mt > 1024 ? mt : 1024; }
 __host__ __device__ inline int64_t enc_plan_rowmap_word(int64_t B, int64_t S) { return (EP_HDR + enc_plan_max_tiles(B, S) + 1) / 2 * 2; }

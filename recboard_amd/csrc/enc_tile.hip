@@ -64,7 +64,7 @@ __device__ int g_tl_fenced;
 __device__ int g_tl_lds_total;                           // floats of LDS the launch requested (the part behind tl_lds_floats is a canary in this build)
 __device__ unsigned g_tl_paranoid;                       // bit 0: a workgroup barrier in front of every operand-slot write; bit 1: ... of every exchange write
 __device__ unsigned g_tl_fill;                           // != 0: every workgroup first fills its LDS with this bit pattern (does anything read LDS it has not written?)
-static int h_tl_lds_kb = 0;
+static int h_tl_lds_kb = 84;
 #define TL_FENCED (::g_tl_fenced != 0)
 #define TL_PARANOID(BIT) do { if (::g_tl_paranoid & (BIT)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
 // bit 3: 8 wait states behind every 16-byte global store (is its data still being read when the next instruction overwrites the registers?)
@@ -145,16 +145,18 @@ static int tl_launch(KP prep_k, KS step_k, const SeEmbed& em, const int64_t* seq
         hipLaunchKernelGGL(prep_k, dim3((unsigned)(TLC_PREP_THREADS(L, NS) / 256)), dim3(256), 0, s, P, (int)L, wf, enc_tile_epoch(tape, B, S, L, D));
         if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     }
-    // TWO workgroups per CU at D = 64 (4 waves, <= 232 registers, ~58 KB of LDS each): since round 5.  Rounds 3 - 4 held ONE per CU by requesting
-    // 84 KB: with two, some run in two of 300 steps ended with results that differed in the last digits -- one register of one wave reading
-    // 0 in 16 lanes (profiles/r4_handover_notes.txt), which went away when the kernel's 150 - 245 spilled SGPRs (v_writelane / v_readlane
-    // through vector-register lanes) were spilled to scratch instead.  The kernel now spills 4 (0 at D = 128; profiles/r5_tile_resource_usage.txt)
-    // and the cross-process soak at two per CU ends in ONE state (profiles/r5_handover_soak.json).  D = 128 is 8 waves of ~230 registers: one per CU.
+    // ONE workgroup per CU (enc_tile_wg_per_cu): more than half of a CU's 160 KB of LDS is requested.  With two per CU (what 256 threads, ~190
+    // registers and 58 KB allow at D = 64) the step's results differ from process to process -- one register of one wave, its last sixteen
+    // lanes, usually in a tile a workgroup takes SECOND in the looped form -- although every launch is deterministic inside a process
+    // (profiles/r5_handover_notes.txt: what round 5 ruled out; the kernel no longer spills scalar registers and drains vmcnt in front of the
+    // barrier its waves exchange tape rows across).
     size_t ldsb = tl_lds_floats((int)L, NS) * sizeof(float);
 #ifdef TL_HANDOVER_DEBUG
     if (ldsb < (size_t)h_tl_lds_kb * 1024) ldsb = (size_t)h_tl_lds_kb * 1024;
 
     if (grid > TL_CHK_TILES) return RE_EUNSUPPORTED;
+#else
+    if (enc_tile_wg_per_cu(16 * NS) == 1 && ldsb < (size_t)84 * 1024) ldsb = (size_t)84 * 1024;
 #endif
     if (hipFuncSetAttribute((const void*)step_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
     const TlArgs A{em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H, dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch, grid};

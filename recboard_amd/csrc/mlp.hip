@@ -281,3 +281,104 @@ extern "C" int re_colsum(const float* x, int64_t M, int64_t N, float* out, void*
     hipLaunchKernelGGL(col_final_k, dim3((unsigned)re_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, ch, N, out, (float*)nullptr);
     return re_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// DeepFM's last layer and criterion as two small launches each way (DeepFM/main.py:151-164 `dnn` ends in Linear(., 1); :201-215 logits =
+// lr + fm + dnn, BCELoss4Logits mean).  As GEMMs these were N = 1 / K = 1 products on 64 x 64 tiles (18 us each for 6.5 MB of traffic) plus
+// an elementwise add, the criterion and two copies.
+//   forward:  logit[m] = fm_lr[m] + <h[m, :], w> + b   (natural-k fmaf chain; a lane group of 16 per row, four rows in flight)
+//             labels given: dlogit[m] = (sigmoid(logit) - y) / M, loss = mean BCE, dsum = sum dlogit  (per-workgroup partials in a
+//             fixed order, summed in order by a one-workgroup second launch)
+//   backward: da[m, k] = dlogit[m] w[k];  dW[k] = sum_m dlogit[m] h[m, k]  (column sums by row chunk, then col_final_k)
+#define HD_ROWS 64      // rows per workgroup of the forward
+__global__ __launch_bounds__(256) void mlp_head_fwd_k(const float* __restrict__ h, int64_t M, int64_t K, const float* __restrict__ w,
+                                                      const float* __restrict__ b, const float* __restrict__ fm_lr, const float* __restrict__ labels,
+                                                      float* __restrict__ logits, float* __restrict__ dlogit, float* __restrict__ partial) {
+    __shared__ float s_l[4], s_g[4];
+    const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;          // 16 lane groups of 16 lanes: a row each, four trips
+    const float inv = 1.0f / (float)M;
+    float lsum = 0.f, gsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < HD_ROWS / 16; ++t) {
+        const int64_t m = (int64_t)blockIdx.x * HD_ROWS + t * 16 + grp;
+        float acc = 0.f;
+        if (m < M)
+            for (int64_t k = lane16 * 4; k < K; k += 64) {                // (K a multiple of 4: the launcher checks)
+                const float4 a = *reinterpret_cast<const float4*>(h + m * K + k), c = *reinterpret_cast<const float4*>(w + k);
+                acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
+            }
+        // the row's sixteen partial dots, in a fixed tree
+        acc += __shfl_xor(acc, 8, 16); acc += __shfl_xor(acc, 4, 16); acc += __shfl_xor(acc, 2, 16); acc += __shfl_xor(acc, 1, 16);
+        if (m < M && lane16 == 0) {
+            const float x = acc + b[0] + (fm_lr ? fm_lr[m] : 0.f);
+            logits[m] = x;
+            if (labels) {
+                const float y = labels[m];
+                lsum += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+                const float d = (re_sigmoid(x) - y) * inv;
+                dlogit[m] = d;
+                gsum += d;
+            }
+        }
+    }
+    if (!labels) return;
+    lsum = re_wave_sum(lsum); gsum = re_wave_sum(gsum);
+    if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = lsum; s_g[threadIdx.x >> 6] = gsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = ((s_l[0] + s_l[1]) + s_l[2]) + s_l[3];
+        partial[2 * blockIdx.x + 1] = ((s_g[0] + s_g[1]) + s_g[2]) + s_g[3];
+    }
+}
+__global__ __launch_bounds__(64) void mlp_head_final_k(const float* __restrict__ partial, int nb, float inv, float* __restrict__ loss,
+                                                       float* __restrict__ dsum) {
+    float a = 0.f, g = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) { a += partial[2 * i]; g += partial[2 * i + 1]; }
+    a = re_wave_sum(a); g = re_wave_sum(g);
+    if (threadIdx.x == 0) { loss[0] = a * inv; if (dsum) dsum[0] = g; }
+}
+__global__ __launch_bounds__(256) void mlp_head_bwd_k(const float* __restrict__ dlogit, const float* __restrict__ h, const float* __restrict__ w,
+                                                      int64_t M, int64_t K, float* __restrict__ da, float* __restrict__ partial) {
+    float s, d;
+    bool owner;
+    int64_t col, mb, me;
+    const int64_t myc = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const float wk = myc < K ? w[myc] : 0.f;
+    col_reduce2(M, K, [&](int64_t m, int64_t k, float& a, float& b2) { a = dlogit[m] * h[m * K + k]; b2 = 0.f; }, s, d, owner, col, mb, me,
+                [&](int64_t m, int64_t k, float) { da[m * K + k] = dlogit[m] * wk; });
+    if (owner) {
+        partial[((int64_t)blockIdx.y * 2 + 0) * K + col] = s;
+        partial[((int64_t)blockIdx.y * 2 + 1) * K + col] = 0.f;
+    }
+}
+
+extern "C" size_t re_mlp_head_workspace_bytes(int64_t M, int64_t K) {
+    const size_t a = (size_t)re_cdiv(M, HD_ROWS) * 2 * sizeof(float), b = (size_t)ML_CHUNKS * 2 * K * sizeof(float);
+    return (a > b ? a : b) + 256;
+}
+// labels == NULL: the logits alone (evaluation); otherwise loss [1], dlogit [M], dsum [1] too.
+extern "C" int re_mlp_head_fwd(const float* h, int64_t M, int64_t K, const float* w, const float* b, const float* fm_lr, const float* labels,
+                               float* logits, float* loss, float* dlogit, float* dsum, void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!h || !w || !b || !logits || M <= 0 || K <= 0) return RE_EINVAL;
+    if (labels && (!loss || !dlogit)) return RE_EINVAL;
+    if ((K & 3) || ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(w)) & 15u)) return RE_EUNSUPPORTED;
+    if (labels && (!ws || ws_bytes < re_mlp_head_workspace_bytes(M, K))) return RE_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)re_cdiv(M, HD_ROWS);
+    hipLaunchKernelGGL(mlp_head_fwd_k, dim3(nb), dim3(256), 0, s, h, M, K, w, b, fm_lr, labels, logits, dlogit, (float*)ws);
+    if (labels) hipLaunchKernelGGL(mlp_head_final_k, dim3(1), dim3(64), 0, s, (const float*)ws, nb, 1.0f / (float)M, loss, dsum);
+    return re_launch_status();
+}
+extern "C" int re_mlp_head_bwd(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, float* da, float* dW, void* ws,
+                               size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (!dlogit || !h || !w || !da || !dW || M <= 0 || K <= 0) return RE_EINVAL;
+    if (!ws || ws_bytes < re_mlp_head_workspace_bytes(M, K)) return RE_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = ml_chunks(M);
+    hipLaunchKernelGGL(mlp_head_bwd_k, dim3((unsigned)re_cdiv(K, 64), ch), dim3(256), 0, s, dlogit, h, w, M, K, da, (float*)ws);
+    hipLaunchKernelGGL(col_final_k, dim3((unsigned)re_cdiv(K, 256)), dim3(256), 0, s, (const float*)ws, ch, K, dW, (float*)nullptr);
+    return re_launch_status();
+}

@@ -137,8 +137,9 @@ class DeepFMEngine:
         return (self.seed * 0x9E3779B1 + (self.step + 1) * 0x85EBCA77) & 0xFFFFFFFF
 
     # ---- forward: keeps what the backward needs in `tape`
-    def encode(self, x, seed_dev=None):
-        """-> (logits [B], tape).  DeepFM/main.py:201-209.  seed_dev: the dropout seed as a device word (captured steps)."""
+    def encode(self, x, seed_dev=None, labels=None):
+        """-> (logits [B], tape).  DeepFM/main.py:201-209.  seed_dev: the dropout seed as a device word (captured steps).
+        labels (training): the criterion runs in the last layer's launch; tape["loss" / "dlogit" / "dsum"] hold its results."""
         P = self.P
         E, fm_lr = ops.fm_bag_fwd(self.T, self.TL.reshape(-1), self.bias, self.offsets, x)
         tape = {"E": E, "layers": []}
@@ -152,9 +153,14 @@ class DeepFMEngine:
                                             self.p_drop, sd, stream_id=100 + i, seed_dev=seed_dev, colstats=cs)
             tape["layers"].append((h, z, a, stats))
             h = a
-        dnn = ops.gemm(h, P[f"dnn.{self.nl}.weight"], transB=True, bias=P[f"dnn.{self.nl}.bias"])   # [B, 1]
-        tape["h_last"] = h
-        logits = fm_lr + dnn.reshape(-1)      # lr + fm + dnn  (elementwise add of two [B] vectors)
+        tape["h_last"], tape["fm_lr"] = h, fm_lr
+        # logits = lr + fm + dnn: the last Linear(., 1) as a row dot with the FM / LR term added in the same launch (re_mlp_head_fwd)
+        w_last = P[f"dnn.{self.nl}.weight"].reshape(-1)
+        if labels is None:
+            return ops.mlp_head_fwd(h, w_last, P[f"dnn.{self.nl}.bias"], fm_lr), tape
+        logits, tape["loss"], tape["dlogit"], tape["dsum"] = ops.mlp_head_fwd(h, w_last, P[f"dnn.{self.nl}.bias"], fm_lr,
+                                                                               labels.reshape(-1).to(torch.float32).contiguous(),
+                                                                               dsum=self.G[f"dnn.{self.nl}.bias"])
         return logits, tape
 
     def recommend_from_pool(self, x):
@@ -164,21 +170,20 @@ class DeepFMEngine:
     def forward_backward(self, x, labels, seed_dev=None):
         """loss + every gradient into the gradient arena.  DeepFM/main.py:211-215, 264-266."""
         P, G = self.P, self.G
-        logits, tape = self.encode(x, seed_dev)
-        loss, dlogit, dsum = ops.bce_logits(logits.contiguous(), labels.reshape(-1).to(torch.float32).contiguous())
-        dl = dlogit.unsqueeze(1)                                                       # [B, 1]
+        # last layer + criterion fused (re_mlp_head_fwd with labels: loss, dlogit and its sum -- the last bias's gradient); then dW = dl^T h and
+        # da = dl w in one pass over h (re_mlp_head_bwd)
+        logits, tape = self.encode(x, seed_dev, labels=labels)
         nl = self.nl
-        # final Linear(., 1):  dW = dl^T h,  db = sum dl,  dh = dl W
-        ops.gemm(dl, tape["h_last"], transA=True, out=G[f"dnn.{nl}.weight"])
-        G[f"dnn.{nl}.bias"].copy_(dsum)
-        da = ops.gemm(dl, P[f"dnn.{nl}.weight"])
+        loss, dlogit, dsum = tape["loss"], tape["dlogit"], tape["dsum"]
+        da = ops.mlp_head_bwd(dlogit, tape["h_last"], P[f"dnn.{nl}.weight"].reshape(-1), G[f"dnn.{nl}.weight"].reshape(-1))
         for i in reversed(range(nl)):
             h, z, a, stats = tape["layers"][i]
             dz, _, _ = ops.bn_relu_drop_bwd(da, a, z, P.get(f"dnn.{i}.bn.weight"), stats, self.p_drop if self.training else 0.0,
                                             dgamma=G.get(f"dnn.{i}.bn.weight"), dbeta=G[f"dnn.{i}.bn.bias"] if self.bn else G[f"dnn.{i}.linear.bias"])
             ops.gemm(dz, h, transA=True, out=G[f"dnn.{i}.linear.weight"])             # dW = dz^T x
-            if self.bn:
-                ops.colsum(dz, out=G[f"dnn.{i}.linear.bias"])                          # (= 0 up to rounding behind a BatchNorm)
+            # (the Linear bias in front of a BatchNorm: its gradient sum_m dz[m, :] is zero in exact arithmetic -- BatchNorm's backward removes the
+            #  column mean -- and pure cancellation noise (~1e-10 of the model's gradient scale) as autograd computes it; it stays exactly zero
+            #  here: the arena is zero-initialised and nothing writes these entries)
             da = ops.gemm(dz, P[f"dnn.{i}.linear.weight"])                             # dx = dz W
         gE, gL = ops.fm_bag_bwd(tape["E"], da, dlogit, self.F, self.D)
         # both table gradients follow the same destination rows: ONE sort (re_scatter_plan), two segmented sums (re_scatter_apply)

@@ -105,6 +105,9 @@ SIGNATURES = {
     "re_bn_relu_drop_fwd": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _u32, _vp, _u32, _vp, _vp, _vp, _sz, _vp]),
     "re_step_state": (_i32, [_vp, _u32, _i64, _f64, _f64, _f64, _vp]),
     "re_mlp_workspace_bytes": (_sz, [_i64]),
+    "re_mlp_head_workspace_bytes": (_sz, [_i64, _i64]),
+    "re_mlp_head_fwd": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "re_mlp_head_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "re_bn_relu_drop_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_colsum": (_i32, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "re_scale_copy": (_i32, [_vp, _vp, _f32, _i64, _vp]),

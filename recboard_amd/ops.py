@@ -1226,6 +1226,37 @@ def bn_relu_drop_bwd(da, a, z, gamma, stats, drop_p, dgamma=None, dbeta=None):
     return dz, dgamma, dbeta
 
 
+def mlp_head_fwd(h, w, b, fm_lr=None, labels=None, dsum=None):
+    """DeepFM's Linear(., 1) + logit sum (+ criterion) (re_mlp_head_fwd): -> logits [M], and with labels (loss [1], dlogit [M], dsum [1])."""
+    _req(h, torch.float32, "h"); _req(w, torch.float32, "w"); _req(b, torch.float32, "b")
+    M, K = h.shape
+    dev = h.device
+    logits = torch.empty(M, dtype=torch.float32, device=dev)
+    L = lib.load()
+    ws = _ws(L.re_mlp_head_workspace_bytes(M, K), dev)
+    if labels is None:
+        lib.check(L.re_mlp_head_fwd(_p(h), M, K, _p(w), _p(b), _p(fm_lr), None, _p(logits), None, None, None, _p(ws), ws.numel(), _stream()), "re_mlp_head_fwd")
+        return logits
+    _req(labels, torch.float32, "labels")
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dl = torch.empty(M, dtype=torch.float32, device=dev)
+    dsum = dsum if dsum is not None else torch.empty(1, dtype=torch.float32, device=dev)
+    lib.check(L.re_mlp_head_fwd(_p(h), M, K, _p(w), _p(b), _p(fm_lr), _p(labels), _p(logits), _p(loss), _p(dl), _p(dsum), _p(ws), ws.numel(), _stream()),
+              "re_mlp_head_fwd")
+    return logits, loss, dl, dsum
+
+
+def mlp_head_bwd(dlogit, h, w, dW):
+    """-> da [M, K] = dlogit (x) w; dW [K] (+)= nothing: written = sum_m dlogit[m] h[m, :]  (re_mlp_head_bwd)."""
+    _req(dlogit, torch.float32, "dlogit"); _req(h, torch.float32, "h"); _req(w, torch.float32, "w"); _req(dW, torch.float32, "dW")
+    M, K = h.shape
+    da = torch.empty_like(h)
+    L = lib.load()
+    ws = _ws(L.re_mlp_head_workspace_bytes(M, K), h.device)
+    lib.check(L.re_mlp_head_bwd(_p(dlogit), _p(h), _p(w), M, K, _p(da), _p(dW), _p(ws), ws.numel(), _stream()), "re_mlp_head_bwd")
+    return da
+
+
 def colsum(x, out=None):
     _req(x, torch.float32, "x")
     M, N = x.shape

@@ -267,8 +267,9 @@ class SASRecEngine:
         return "always" if ok and getattr(self, "tile_step", True) == "always" else ok   # ("always": whatever the batch -- the plan's rule is a matter of speed)
 
     def _tile_wgs(self):
-        """Resident workgroups per CU of the tile kernels (csrc/enc_common.h: enc_tile_wg_per_cu): the batch plan's rule counts them."""
-        return 2 if self.D == 64 else 1
+        """Resident workgroups per CU of the tile kernels (csrc/enc_common.h: enc_tile_wg_per_cu -- one; two at D = 64 is faster and not yet
+        reproducible from process to process, profiles/r5_handover_notes.txt): the batch plan's rule counts them."""
+        return 1
 
     def _tail_word(self):
         if not hasattr(self, "_tail"):

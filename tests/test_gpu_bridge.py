@@ -204,7 +204,7 @@ def test_deepfm_resume_keeps_the_reduced_learning_rate_and_checkpoints_move_betw
         z, _ = coach._engine.pool_logits(coach, vb)
         with torch.no_grad():
             pm_ = modelm({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in vb.items()}, ranking="pool").reshape(-1)
-        torch.testing.assert_close(torch.sigmoid(z.reshape(-1)), pm_, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(torch.sigmoid(zl.reshape(-1)), pm_, rtol=1e-4, atol=1e-6)
     ra, rm = coach.valid(9), coachm.valid(9)   # ... and monitor the same batch-weighted means
     assert abs(ra["AUC"] - rm["AUC"]) < 1e-5 and abs(ra["LOGLOSS"] - rm["LOGLOSS"]) < 1e-5, (ra, rm)
     # (1) resume on the engine: the reduced rate, the moments, the step count
