@@ -500,7 +500,8 @@ int re_rows_sqnorm(const float* W, int64_t R, int64_t D, const int64_t* idx, int
  * re_bce_logits: loss[0] = mean BCE-with-logits (DeepFM/main.py:214), dlogit[i] = (sigmoid(x_i) - y_i) / n,
  * dsum[0] (optional) = sum_i dlogit[i] (gradient of the LR bias).  labels are fp32 0/1. */
 int re_fm_bag_fwd(const float* T, const float* TL, const float* lr_bias, const int64_t* offsets, int64_t rows_total,
-                  const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, re_stream_t stream);
+                  const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, int64_t* rows_out, re_stream_t stream);
+/* (rows_out [B * F], optional: offsets[f] + x[b, f] -- the destination rows of the backward's scatter-add, re_scatter_plan's `idx`) */
 int re_fm_bag_bwd(const float* E, const float* dE_mlp, const float* dlogit, int64_t B, int64_t F, int64_t D, float* gE,
                   float* gL, re_stream_t stream);
 int re_bce_logits(const float* logits, const float* labels, int64_t n, float* loss, float* dlogit, float* dsum,
@@ -598,7 +599,7 @@ int re_bn_relu_drop_bwd(const float* da, const float* a, const float* z, int64_t
                         const float* stats, float drop_p, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                         re_stream_t stream);
 /* re_bn_relu_drop_fwd in training mode with BatchNorm, the statistics' partials given: colstats [chunks][2][N] (chunk b = rows
- * [b ceil(M / chunks), ...): (mean, M2)), chunks <= 64 -- what re_gemm_f32_colstats writes with chunks = M / 64. */
+ * [b ceil(M / chunks), ...): (mean, M2)) -- what re_gemm_f32_colstats writes with chunks = M / 64.  One launch: every workgroup merges the partials of its 64 columns. */
 int re_bn_relu_drop_fwd_pre(const float* z, int64_t M, int64_t N, const float* gamma, const float* beta, float* run_mean,
                             float* run_var, float eps, float momentum, float drop_p, uint32_t seed, const uint32_t* seed_dev,
                             uint32_t stream_id, float* stats, float* a, const float* colstats, int chunks, re_stream_t stream);
@@ -606,13 +607,28 @@ int re_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t
 size_t re_mlp_workspace_bytes(int64_t N);
 /* DeepFM's last layer + criterion (DeepFM/main.py:151-164 `dnn` ends in Linear(., 1); :201-215 logits = lr + fm + dnn, BCELoss4Logits):
  * re_mlp_head_fwd: logits[m] = fm_lr[m] + <h[m, :], w> + b[0] (fm_lr may be NULL); with labels also loss[0] = mean BCE-with-logits,
- *   dlogit[m] = (sigmoid(logit) - y) / M, dsum[0] = sum dlogit.  re_mlp_head_bwd: da[m, k] = dlogit[m] w[k], dW[k] = sum_m dlogit[m] h[m, k].
+ *   dlogit[m] = (sigmoid(logit) - y) / M, dsum[0] = dsum2[0] = sum dlogit (either may be NULL).  re_mlp_head_bwd: da[m, k] = dlogit[m] w[k], dW[k] = sum_m dlogit[m] h[m, k].
  * h [M, K] contiguous, K a multiple of 4, 16-byte aligned (else RE_EUNSUPPORTED: use re_gemm_f32 + re_bce_logits); fixed-order sums. */
 size_t re_mlp_head_workspace_bytes(int64_t M, int64_t K);
 int re_mlp_head_fwd(const float* h, int64_t M, int64_t K, const float* w, const float* b, const float* fm_lr, const float* labels,
-                    float* logits, float* loss, float* dlogit, float* dsum, void* ws, size_t ws_bytes, re_stream_t stream);
+                    float* logits, float* loss, float* dlogit, float* dsum, float* dsum2, void* ws, size_t ws_bytes, re_stream_t stream);
 int re_mlp_head_bwd(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, float* da, float* dW, void* ws,
                     size_t ws_bytes, re_stream_t stream);   /* scratch of the three entry points above (per-chunk column partials) */
+/* The backward of dropout(relu(bn(z))) (DeepFM/main.py:119-124) split between the launch that PRODUCES the incoming gradient and one pass:
+ *   re_gemm_f32_gated: C = g = act > 0 ? drop_scale alpha op(A) op(B) : 0 (act = the block's output, same leading dimension as C and z) and
+ *     part [M / 64][2][N] = per-64-row (sum g, sum g xhat), xhat = (z - stats[n]) stats[N + n].  M a multiple of 64, operands 16-byte aligned
+ *     with leading dimensions in multiples of 4, else RE_EUNSUPPORTED (then: re_gemm_f32 + re_bn_relu_drop_bwd).
+ *   re_mlp_head_bwd_gated: the same for the gradient that comes from the last Linear(., 1): g [M, K] = h > 0 ? dlogit[m] w[k] / (1 - drop_p) : 0,
+ *     part [*chunks_out][3][K] = (sum g, sum g xhat, sum dlogit h); part >= re_mlp_head_workspace_bytes(M, K).
+ *   re_bn_bwd_apply: dbeta = sum g, dgamma = sum g xhat (the chunks of `part` [chunks][pstride][N] added in a fixed order), g -> dz in place
+ *     = rstd gamma (g - dbeta / M - xhat dgamma / M); extra_out [N] (pstride 3, optional) = the third sums (the last layer's weight gradient). */
+int re_gemm_f32_gated(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* act, const float* z, const float* stats, float drop_scale, float* part,
+                      re_stream_t stream);
+int re_mlp_head_bwd_gated(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, const float* z, const float* stats,
+                          float drop_p, float* g, float* part, size_t part_bytes, int* chunks_out, re_stream_t stream);
+int re_bn_bwd_apply(float* g, const float* z, int64_t M, int64_t N, const float* gamma, const float* stats, const float* part, int chunks,
+                    int pstride, float* dgamma, float* dbeta, float* extra_out, re_stream_t stream);
 
 /* dst[i] = alpha * src[i]  (LightGCN/main.py:80 `avgEmbds = allEmbds / (L+1)`) */
 int re_scale_copy(float* dst, const float* src, float alpha, int64_t n, re_stream_t stream);

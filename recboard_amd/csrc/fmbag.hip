@@ -23,7 +23,7 @@ template <int FP>
 __global__ __launch_bounds__(256) void fm_bag_fwd_k(const float* __restrict__ T, const float* __restrict__ TL,
                                                     const float* __restrict__ lr_bias, const int64_t* __restrict__ offsets,
                                                     int64_t rows_total, const int64_t* __restrict__ x, int64_t B, int F, int D,
-                                                    float* __restrict__ E, float* __restrict__ fm_lr) {
+                                                    float* __restrict__ E, float* __restrict__ fm_lr, int64_t* __restrict__ rows_out) {
     const int f = threadIdx.x % FP;
     const int64_t b = (int64_t)blockIdx.x * (256 / FP) + threadIdx.x / FP;
     float e[FB_MAXD];
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void fm_bag_fwd_k(const float* __restrict__ T,
     for (int d = 0; d < FB_MAXD; ++d) e[d] = 0.f;
     if (act) {
         const int64_t r = x[b * F + f] + offsets[f];
+        if (rows_out) rows_out[b * F + f] = r;
         if (r >= 0 && r < rows_total) {
             for (int d = 0; d < D; ++d) e[d] = T[r * D + d];
             lr = TL[r];
@@ -82,13 +83,13 @@ __global__ __launch_bounds__(256) void fm_bag_bwd_k(const float* __restrict__ E,
 }
 
 extern "C" int re_fm_bag_fwd(const float* T, const float* TL, const float* lr_bias, const int64_t* offsets, int64_t rows_total,
-                             const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, re_stream_t stream) {
+                             const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, int64_t* rows_out, re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
     if (!T || !TL || !lr_bias || !offsets || !x || !E || !fm_lr || B < 0 || rows_total <= 0) return RE_EINVAL;
     if (F < 1 || F > 64 || D < 1 || D > FB_MAXD) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-#define FB_FWD(FPV) hipLaunchKernelGGL(fm_bag_fwd_k<FPV>, dim3((unsigned)re_cdiv(B, 256 / FPV)), dim3(256), 0, s, T, TL, lr_bias, offsets, rows_total, x, B, (int)F, (int)D, E, fm_lr)
+#define FB_FWD(FPV) hipLaunchKernelGGL(fm_bag_fwd_k<FPV>, dim3((unsigned)re_cdiv(B, 256 / FPV)), dim3(256), 0, s, T, TL, lr_bias, offsets, rows_total, x, B, (int)F, (int)D, E, fm_lr, rows_out)
     if (F <= 8) FB_FWD(8); else if (F <= 16) FB_FWD(16); else if (F <= 32) FB_FWD(32); else FB_FWD(64);
 #undef FB_FWD
     return re_launch_status();

@@ -264,6 +264,10 @@ struct GwArgs {
     int64_t kchunk;
     int nt_base, nt_rem;   // column tiles per column block: base (+ 1 for the first nt_rem blocks)
     float* colstats;       // [M / 64][2][N]: (mean, M2) of the output's columns over the block's 64 rows, or null
+    // gated output (the backward of dropout(relu(bn(.))) in the epilogue of the product that makes its incoming gradient): with v the product,
+    // C = g = act > 0 ? gate_scale v : 0 and colstats = the block's (sum g, sum g xhat), xhat = (z - mean) rstd from gate_stats [2][N]
+    const float *gate_act, *gate_z, *gate_stats;
+    float gate_scale;
 };
 
 template <bool A_KMAJ, bool B_KMAJ, int WM, int TT>
@@ -337,6 +341,53 @@ __global__ __launch_bounds__(256) void gemm_wide_k(const GwArgs a) {
     }
     // ---- epilogue: acc[t][j] = C(m0 + 16 arow + 4 g + j, n0 + 16 (bcol0 + t) + c)
     float* stat = Bs0;                                              // [4 waves][16 BT columns][2] (the main loop is behind a barrier)
+    if (WM == 4 && a.gate_act) {
+        // (M a multiple of 64, no split: the launcher's conditions)
+#pragma unroll
+        for (int t = 0; t < WT; ++t) {
+            const int64_t n = n0 + 16 * t + c;
+            const bool n_ok = t < t_cnt && n < a.N;
+            const int64_t nn = n_ok ? n : 0;
+            const float mu = a.gate_stats[nn], rs = a.gate_stats[a.N + nn];
+            float av[4], zv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t e = (m0 + 16 * arow + 4 * g + j) * a.ldc + nn;
+                av[j] = a.gate_act[e]; zv[j] = a.gate_z[e];
+            }
+            float sg = 0.f, sx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gv = (n_ok && av[j] > 0.f) ? a.alpha * acc[t][j] * a.gate_scale : 0.f;
+                if (n_ok) a.C[(m0 + 16 * arow + 4 * g + j) * a.ldc + n] = gv;
+                sg += gv;
+                sx = fmaf(gv, (zv[j] - mu) * rs, sx);
+            }
+            {
+                auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(sg), __float_as_uint(sg), false, false);
+                sg = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+                x = __builtin_amdgcn_permlane32_swap(__float_as_uint(sg), __float_as_uint(sg), false, false);
+                sg = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+                x = __builtin_amdgcn_permlane16_swap(__float_as_uint(sx), __float_as_uint(sx), false, false);
+                sx = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+                x = __builtin_amdgcn_permlane32_swap(__float_as_uint(sx), __float_as_uint(sx), false, false);
+                sx = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+            }
+            if (g == 0) *reinterpret_cast<float2*>(stat + ((wave * BT + t) * 16 + c) * 2) = make_float2(sg, sx);
+        }
+        __syncthreads();
+        if (tid < 16 * BT) {
+            const int64_t n = n0 + tid;
+            if (tid < 16 * t_cnt && n < a.N) {
+                float2 p[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) p[w] = *reinterpret_cast<const float2*>(stat + (w * BT * 16 + tid) * 2);
+                a.colstats[((int64_t)blockIdx.x * 2 + 0) * a.N + n] = (p[0].x + p[1].x) + (p[2].x + p[3].x);
+                a.colstats[((int64_t)blockIdx.x * 2 + 1) * a.N + n] = (p[0].y + p[1].y) + (p[2].y + p[3].y);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < WT; ++t) {
         const int64_t n = n0 + 16 * (bcol0 + t) + c;
@@ -467,7 +518,8 @@ extern "C" size_t re_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 static int gemm_run(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
                     int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws, size_t ws_bytes, float* colstats,
-                    hipStream_t s) {
+                    hipStream_t s, const float* gate_act = nullptr, const float* gate_z = nullptr, const float* gate_stats = nullptr,
+                    float gate_scale = 1.f) {
     const GwPlan wp = gw_plan(transA, transB, M, N, K, A, lda, B, ldb, colstats != nullptr);
     if (colstats && !wp.use) return RE_EUNSUPPORTED;
     if (wp.use) {
@@ -475,7 +527,8 @@ static int gemm_run(int transA, int transB, int64_t M, int64_t N, int64_t K, flo
         int64_t kchunk = re_cdiv(re_cdiv(K, wp.nsplit), GW_BK) * GW_BK;
         if (kchunk < GW_BK) kchunk = GW_BK;
         const int ns = (int)re_cdiv(K, kchunk);
-        GwArgs a{M, N, K, alpha, beta, A, B, lda, ldb, ldc, C, bias, relu, ns > 1 ? (float*)ws : nullptr, kchunk, wp.nt_base, wp.nt_rem, colstats};
+        GwArgs a{M, N, K, alpha, beta, A, B, lda, ldb, ldc, C, bias, relu, ns > 1 ? (float*)ws : nullptr, kchunk, wp.nt_base, wp.nt_rem, colstats,
+                 gate_act, gate_z, gate_stats, gate_scale};
         dim3 grid((unsigned)re_cdiv(M, 16 * wp.wm), (unsigned)wp.cb, (unsigned)ns);
         if (transA == 0 && transB != 0) gw_launch<true, true>(wp, a, grid, s);
         else if (transA == 0) gw_launch<true, false>(wp, a, grid, s);
@@ -521,4 +574,18 @@ extern "C" int re_gemm_f32_colstats(int transA, int transB, int64_t M, int64_t N
     if (!A || !B || !C || !colstats || M <= 0 || N <= 0 || K <= 0 || lda < 1 || ldb < 1 || ldc < N) return RE_EINVAL;
     if (M & 63) return RE_EUNSUPPORTED;
     return gemm_run(transA, transB, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, bias, 0, nullptr, 0, colstats, (hipStream_t)stream);
+}
+
+// The product whose result is the gradient arriving at a dropout(relu(bn(z))) block, with that block's gate and its two column sums in the
+// epilogue (DeepFM/main.py:119-124 backward): C = g = act > 0 ? drop_scale alpha op(A) op(B) : 0 (act: the block's OUTPUT -- positive exactly
+// where relu passed and dropout kept), part [M / 64][2][N] = per-64-row (sum g, sum g xhat), xhat = (z - stats[0][n]) stats[1][n] -- what
+// re_bn_bwd_apply takes.  act and z share C's leading dimension.  M a multiple of 64 and the wide form's alignment, else RE_EUNSUPPORTED.
+extern "C" int re_gemm_f32_gated(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                                 const float* B, int64_t ldb, float* C, int64_t ldc, const float* act, const float* z, const float* stats,
+                                 float drop_scale, float* part, re_stream_t stream) {
+    re_clear_error();
+    if (!A || !B || !C || !act || !z || !stats || !part || M <= 0 || N <= 0 || K <= 0 || lda < 1 || ldb < 1 || ldc < N) return RE_EINVAL;
+    if (M & 63) return RE_EUNSUPPORTED;
+    return gemm_run(transA, transB, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, nullptr, 0, nullptr, 0, part, (hipStream_t)stream, act, z, stats,
+                    drop_scale);
 }

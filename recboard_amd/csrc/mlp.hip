@@ -208,6 +208,148 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int
     }
 }
 
+
+// ---- one-launch forms (the producing GEMM's epilogue left per-chunk partials: re_gemm_f32_colstats / re_gemm_f32_gated)
+// A workgroup = 64 columns x one block of rows.  It first reduces the chunk partials of ITS columns (every row block of a column repeats the
+// same arithmetic on the same numbers: identical results, no second launch, no flag), then streams its rows.
+static int ml_row_blocks(int64_t M) { const int64_t b = re_cdiv(M, 64); return (int)(b < 1 ? 1 : (b > 128 ? 128 : b)); }
+
+// chunk b of `colstats` = (mean, M2) over rows [b rpc, (b + 1) rpc), rpc = ceil(M / chunks).  Thread (c, q) merges chunks [q per, (q + 1) per) one
+// after the other (Chan), the four quarter results are merged ((0, 1), (2, 3)).
+__global__ __launch_bounds__(256) void bn_fwd_fused_k(const float* __restrict__ z, int64_t M, int64_t N, const float* __restrict__ colstats, int chunks,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                      float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ stats,
+                                                      float drop_scale, uint32_t thresh, uint32_t seed, uint32_t stream_id, float* __restrict__ a,
+                                                      const uint32_t* __restrict__ seed_dev) {
+    __shared__ float s_mean[256], s_m2[256], s_cnt[256];
+    if (seed_dev) seed = seed_dev[0];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c;
+    const bool ok = col < N;
+    const int64_t rpc = (M + chunks - 1) / chunks;
+    const int per = (chunks + 3) >> 2;
+    float mean = 0.f, m2 = 0.f, cnt = 0.f;
+    if (ok) {
+        const int lo = q * per, hi = (lo + per < chunks) ? lo + per : chunks;
+#pragma unroll 4
+        for (int b = lo; b < hi; ++b) {
+            const int64_t mb = (int64_t)b * rpc;
+            if (mb >= M) break;
+            const float cb = (float)(((mb + rpc < M) ? mb + rpc : M) - mb);
+            const float mo = colstats[((int64_t)b * 2 + 0) * N + col], qo = colstats[((int64_t)b * 2 + 1) * N + col];
+            const float tot = cnt + cb, w = cb / tot, delta = mo - mean;
+            mean = fmaf(delta, w, mean);
+            m2 = m2 + qo + delta * delta * (cnt * w);
+            cnt = tot;
+        }
+    }
+    s_mean[threadIdx.x] = mean; s_m2[threadIdx.x] = m2; s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    {
+        auto merge = [](float ma, float qa, float ca, float mb_, float qb, float cb, float& mo, float& qo, float& co) {
+            const float tot = ca + cb, w = tot > 0.f ? cb / tot : 0.f, delta = mb_ - ma;
+            mo = fmaf(delta, w, ma); qo = qa + qb + delta * delta * (ca * w); co = tot;
+        };
+        float m01, q01, c01, m23, q23, c23;
+        merge(s_mean[c], s_m2[c], s_cnt[c], s_mean[64 + c], s_m2[64 + c], s_cnt[64 + c], m01, q01, c01);
+        merge(s_mean[128 + c], s_m2[128 + c], s_cnt[128 + c], s_mean[192 + c], s_m2[192 + c], s_cnt[192 + c], m23, q23, c23);
+        merge(m01, q01, c01, m23, q23, c23, mean, m2, cnt);
+    }
+    if (!ok) return;
+    const float var = m2 / (float)M;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (blockIdx.y == 0 && q == 0) {
+        stats[col] = mean;
+        stats[N + col] = rstd;
+        if (run_mean) {
+            run_mean[col] = (1.f - momentum) * run_mean[col] + momentum * mean;
+            run_var[col] = (1.f - momentum) * run_var[col] + momentum * (M > 1 ? m2 / (float)(M - 1) : var);
+        }
+    }
+    const float k1 = gamma[col], k0 = beta[col];
+    const int64_t rpb = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t m_begin = (int64_t)blockIdx.y * rpb, m_end = (m_begin + rpb < M) ? m_begin + rpb : M;
+    auto one = [&](int64_t e, float v) {
+        v = (v - mean) * rstd * k1 + k0;                            // (bn_relu_drop_fwd_k's expression)
+        v = fmaxf(v, 0.f);
+        if (thresh) v = re_keep(seed, stream_id, (uint32_t)e, thresh) ? v * drop_scale : 0.f;
+        a[e] = v;
+    };
+    int64_t m = m_begin + q;
+    for (; m + 28 < m_end; m += 32) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = z[(m + 4 * i) * N + col];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) one((m + 4 * i) * N + col, v[i]);
+    }
+    for (; m + 12 < m_end; m += 16) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = z[(m + 4 * i) * N + col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) one((m + 4 * i) * N + col, v[i]);
+    }
+    for (; m < m_end; m += 4) one(m * N + col, z[m * N + col]);
+}
+
+// part [chunks][ps][N]: thread (c, q) adds chunks [q per, (q + 1) per) in order, the quarters are added ((0 + 1) + 2) + 3
+__global__ __launch_bounds__(256) void bn_bwd_apply2_k(float* __restrict__ dz, const float* __restrict__ z, int64_t M, int64_t N,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ part, int chunks, int ps, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, float* __restrict__ extra_out) {
+    __shared__ float r0[256], r1[256], r2[256];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c;
+    const bool ok = col < N;
+    const bool third = extra_out != nullptr && blockIdx.y == 0;      // (uniform)
+    const int per = (chunks + 3) >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (ok) {
+        const int lo = q * per, hi = (lo + per < chunks) ? lo + per : chunks;
+#pragma unroll 8
+        for (int b = lo; b < hi; ++b) {
+            s0 += part[((int64_t)b * ps + 0) * N + col];
+            s1 += part[((int64_t)b * ps + 1) * N + col];
+            if (third) s2 += part[((int64_t)b * ps + 2) * N + col];
+        }
+    }
+    r0[threadIdx.x] = s0; r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    if (!ok) return;
+    const float db = ((r0[c] + r0[64 + c]) + r0[128 + c]) + r0[192 + c];
+    const float dg = ((r1[c] + r1[64 + c]) + r1[128 + c]) + r1[192 + c];
+    if (blockIdx.y == 0 && q == 0) {
+        dbeta[col] = db;
+        dgamma[col] = dg;
+        if (third) extra_out[col] = ((r2[c] + r2[64 + c]) + r2[128 + c]) + r2[192 + c];
+    }
+    const float invm = 1.0f / (float)M;
+    const float mu = stats[col], rs = stats[N + col], k = rs * gamma[col];
+    const int64_t rpb = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t m_begin = (int64_t)blockIdx.y * rpb, m_end = (m_begin + rpb < M) ? m_begin + rpb : M;
+    auto one = [&](int64_t e, float gv, float zv) {
+        const float xhat = (zv - mu) * rs;
+        dz[e] = k * (gv - db * invm - xhat * dg * invm);             // (bn_bwd_apply_k's expression)
+    };
+    int64_t m = m_begin + q;
+    for (; m + 28 < m_end; m += 32) {
+        float gv[8], zv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gv[i] = dz[(m + 4 * i) * N + col]; zv[i] = z[(m + 4 * i) * N + col]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) one((m + 4 * i) * N + col, gv[i], zv[i]);
+    }
+    for (; m + 12 < m_end; m += 16) {
+        float gv[4], zv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gv[i] = dz[(m + 4 * i) * N + col]; zv[i] = z[(m + 4 * i) * N + col]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) one((m + 4 * i) * N + col, gv[i], zv[i]);
+    }
+    for (; m < m_end; m += 4) one(m * N + col, dz[m * N + col], z[m * N + col]);
+}
+
 static int ml_chunks(int64_t M) { return M >= 4 * ML_CHUNKS ? ML_CHUNKS : 1; }
 extern "C" size_t re_mlp_workspace_bytes(int64_t N) { return (size_t)ML_CHUNKS * 2 * N * sizeof(float) + 256; }
 
@@ -245,13 +387,26 @@ extern "C" int re_bn_relu_drop_fwd_pre(const float* z, int64_t M, int64_t N, con
                                        uint32_t stream_id, float* stats, float* a, const float* colstats, int chunks, re_stream_t stream) {
     re_clear_error();
     if (!z || !a || !gamma || !beta || !stats || !run_mean || !run_var || !colstats || M <= 0 || N <= 0) return RE_EINVAL;
-    if (chunks < 1 || chunks > ML_CHUNKS || drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
+    if (chunks < 1 || drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_final_k, dim3((unsigned)re_cdiv(N, 4)), dim3(256), 0, s, colstats, chunks, M, N, eps, momentum, stats, run_mean, run_var);
     const uint32_t thresh = drop_p > 0.f ? re_drop_threshold(drop_p) : 0u;
     const float ds = thresh ? 1.0f / (1.0f - drop_p) : 1.0f;
-    hipLaunchKernelGGL(bn_relu_drop_fwd_k, dim3(re_grid(M * N, 1024)), dim3(256), 0, s, z, M * N, N, (const float*)stats, gamma, beta, ds, thresh, seed,
-                       stream_id, a, seed_dev);
+    hipLaunchKernelGGL(bn_fwd_fused_k, dim3((unsigned)re_cdiv(N, 64), (unsigned)ml_row_blocks(M)), dim3(256), 0, s, z, M, N, colstats, chunks, gamma, beta,
+                       eps, momentum, run_mean, run_var, stats, ds, thresh, seed, stream_id, a, seed_dev);
+    return re_launch_status();
+}
+
+// The second half of the backward of dropout(relu(bn(z))) when the gate and its column sums came out of the producing launch
+// (re_gemm_f32_gated, re_mlp_head_bwd_gated): g [M, N] in, dz out in place; part [chunks][pstride][N] holds per-row-chunk (sum g, sum g xhat
+// [, a third column sum]); dbeta = sum g, dgamma = sum g xhat (chunks added in a fixed order), dz = rstd gamma (g - dbeta / M - xhat dgamma / M);
+// extra_out [N] (pstride == 3) = the third sums.  One launch: every workgroup adds the chunks of its 64 columns itself.
+extern "C" int re_bn_bwd_apply(float* g, const float* z, int64_t M, int64_t N, const float* gamma, const float* stats, const float* part,
+                               int chunks, int pstride, float* dgamma, float* dbeta, float* extra_out, re_stream_t stream) {
+    re_clear_error();
+    if (!g || !z || !gamma || !stats || !part || !dgamma || !dbeta || M <= 0 || N <= 0 || chunks < 1) return RE_EINVAL;
+    if ((pstride != 2 && pstride != 3) || (extra_out && pstride != 3)) return RE_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply2_k, dim3((unsigned)re_cdiv(N, 64), (unsigned)ml_row_blocks(M)), dim3(256), 0, (hipStream_t)stream, g, z, M, N, stats, gamma,
+                       part, chunks, pstride, dgamma, dbeta, extra_out);
     return re_launch_status();
 }
 
@@ -291,7 +446,7 @@ extern "C" int re_colsum(const float* x, int64_t M, int64_t N, float* out, void*
 //             labels given: dlogit[m] = (sigmoid(logit) - y) / M, loss = mean BCE, dsum = sum dlogit  (per-workgroup partials in a
 //             fixed order, summed in order by a one-workgroup second launch)
 //   backward: da[m, k] = dlogit[m] w[k];  dW[k] = sum_m dlogit[m] h[m, k]  (column sums by row chunk, then col_final_k)
-#define HD_ROWS 64      // rows per workgroup of the forward
+#define HD_ROWS 16      // rows per workgroup of the forward (256 workgroups at M = 4096)
 __global__ __launch_bounds__(256) void mlp_head_fwd_k(const float* __restrict__ h, int64_t M, int64_t K, const float* __restrict__ w,
                                                       const float* __restrict__ b, const float* __restrict__ fm_lr, const float* __restrict__ labels,
                                                       float* __restrict__ logits, float* __restrict__ dlogit, float* __restrict__ partial) {
@@ -332,11 +487,11 @@ __global__ __launch_bounds__(256) void mlp_head_fwd_k(const float* __restrict__ 
     }
 }
 __global__ __launch_bounds__(64) void mlp_head_final_k(const float* __restrict__ partial, int nb, float inv, float* __restrict__ loss,
-                                                       float* __restrict__ dsum) {
+                                                       float* __restrict__ dsum, float* __restrict__ dsum2) {
     float a = 0.f, g = 0.f;
     for (int i = threadIdx.x; i < nb; i += 64) { a += partial[2 * i]; g += partial[2 * i + 1]; }
     a = re_wave_sum(a); g = re_wave_sum(g);
-    if (threadIdx.x == 0) { loss[0] = a * inv; if (dsum) dsum[0] = g; }
+    if (threadIdx.x == 0) { loss[0] = a * inv; if (dsum) dsum[0] = g; if (dsum2) dsum2[0] = g; }
 }
 __global__ __launch_bounds__(256) void mlp_head_bwd_k(const float* __restrict__ dlogit, const float* __restrict__ h, const float* __restrict__ w,
                                                       int64_t M, int64_t K, float* __restrict__ da, float* __restrict__ partial) {
@@ -354,12 +509,14 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_k(const float* __restrict__ 
 }
 
 extern "C" size_t re_mlp_head_workspace_bytes(int64_t M, int64_t K) {
-    const size_t a = (size_t)re_cdiv(M, HD_ROWS) * 2 * sizeof(float), b = (size_t)ML_CHUNKS * 2 * K * sizeof(float);
+    const size_t a = (size_t)re_cdiv(M, HD_ROWS) * 2 * sizeof(float), b = (size_t)ML_CHUNKS * 3 * K * sizeof(float);
     return (a > b ? a : b) + 256;
 }
-// labels == NULL: the logits alone (evaluation); otherwise loss [1], dlogit [M], dsum [1] too.
+// labels == NULL: the logits alone (evaluation); otherwise loss [1], dlogit [M], and sum dlogit into dsum [1] and dsum2 [1] (either may be
+// null: DeepFM has two biases with that gradient, the last layer's and the LR term's) too.
 extern "C" int re_mlp_head_fwd(const float* h, int64_t M, int64_t K, const float* w, const float* b, const float* fm_lr, const float* labels,
-                               float* logits, float* loss, float* dlogit, float* dsum, void* ws, size_t ws_bytes, re_stream_t stream) {
+                               float* logits, float* loss, float* dlogit, float* dsum, float* dsum2, void* ws, size_t ws_bytes,
+                               re_stream_t stream) {
     re_clear_error();
     if (!h || !w || !b || !logits || M <= 0 || K <= 0) return RE_EINVAL;
     if (labels && (!loss || !dlogit)) return RE_EINVAL;
@@ -368,7 +525,7 @@ extern "C" int re_mlp_head_fwd(const float* h, int64_t M, int64_t K, const float
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)re_cdiv(M, HD_ROWS);
     hipLaunchKernelGGL(mlp_head_fwd_k, dim3(nb), dim3(256), 0, s, h, M, K, w, b, fm_lr, labels, logits, dlogit, (float*)ws);
-    if (labels) hipLaunchKernelGGL(mlp_head_final_k, dim3(1), dim3(64), 0, s, (const float*)ws, nb, 1.0f / (float)M, loss, dsum);
+    if (labels) hipLaunchKernelGGL(mlp_head_final_k, dim3(1), dim3(64), 0, s, (const float*)ws, nb, 1.0f / (float)M, loss, dsum, dsum2);
     return re_launch_status();
 }
 extern "C" int re_mlp_head_bwd(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, float* da, float* dW, void* ws,
@@ -380,5 +537,58 @@ extern "C" int re_mlp_head_bwd(const float* dlogit, const float* h, const float*
     const int ch = ml_chunks(M);
     hipLaunchKernelGGL(mlp_head_bwd_k, dim3((unsigned)re_cdiv(K, 64), ch), dim3(256), 0, s, dlogit, h, w, M, K, da, (float*)ws);
     hipLaunchKernelGGL(col_final_k, dim3((unsigned)re_cdiv(K, 256)), dim3(256), 0, s, (const float*)ws, ch, K, dW, (float*)nullptr);
+    return re_launch_status();
+}
+
+// re_mlp_head_bwd with the gate of the block underneath in the same pass (h is that block's output: positive exactly where relu passed and
+// dropout kept): g [M, K] = h > 0 ? drop_scale dlogit[m] w[k] : 0, and per-row-chunk partials part [chunks][3][K] = (sum g, sum g xhat,
+// sum dlogit h) -- re_bn_bwd_apply (pstride 3, extra_out = dW) finishes both.
+__global__ __launch_bounds__(256) void mlp_head_bwd_gated_k(const float* __restrict__ dlogit, const float* __restrict__ h, const float* __restrict__ w,
+                                                            const float* __restrict__ z, const float* __restrict__ stats, float drop_scale,
+                                                            int64_t M, int64_t K, float* __restrict__ g, float* __restrict__ part) {
+    __shared__ float r0[256], r1[256], r2[256];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c;
+    const int64_t rpc = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t m_begin = (int64_t)blockIdx.y * rpc, m_end = (m_begin + rpc < M) ? m_begin + rpc : M;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (col < K) {
+        const float wk = w[col] * drop_scale, mu = stats[col], rs = stats[K + col];
+        auto one = [&](int64_t m, float dl, float hv, float zv) {
+            const float gv = hv > 0.f ? dl * wk : 0.f;
+            g[m * K + col] = gv;
+            s0 += gv;
+            s1 = fmaf(gv, (zv - mu) * rs, s1);
+            s2 = fmaf(dl, hv, s2);
+        };
+        int64_t m = m_begin + rg;
+        for (; m + 28 < m_end; m += 32) {
+            float dl[8], hv[8], zv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { dl[i] = dlogit[m + 4 * i]; hv[i] = h[(m + 4 * i) * K + col]; zv[i] = z[(m + 4 * i) * K + col]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) one(m + 4 * i, dl[i], hv[i], zv[i]);
+        }
+        for (; m < m_end; m += 4) one(m, dlogit[m], h[m * K + col], z[m * K + col]);
+    }
+    r0[threadIdx.x] = s0; r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    if (rg == 0 && col < K) {
+        part[((int64_t)blockIdx.y * 3 + 0) * K + col] = ((r0[c] + r0[64 + c]) + r0[128 + c]) + r0[192 + c];
+        part[((int64_t)blockIdx.y * 3 + 1) * K + col] = ((r1[c] + r1[64 + c]) + r1[128 + c]) + r1[192 + c];
+        part[((int64_t)blockIdx.y * 3 + 2) * K + col] = ((r2[c] + r2[64 + c]) + r2[128 + c]) + r2[192 + c];
+    }
+}
+// -> *chunks_out = the number of row chunks in `part` (part: >= re_mlp_head_workspace_bytes(M, K) bytes)
+extern "C" int re_mlp_head_bwd_gated(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, const float* z,
+                                     const float* stats, float drop_p, float* g, float* part, size_t part_bytes, int* chunks_out,
+                                     re_stream_t stream) {
+    re_clear_error();
+    if (!dlogit || !h || !w || !z || !stats || !g || !part || !chunks_out || M <= 0 || K <= 0 || drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
+    if (part_bytes < re_mlp_head_workspace_bytes(M, K)) return RE_EWORKSPACE;
+    const int ch = ml_chunks(M);
+    hipLaunchKernelGGL(mlp_head_bwd_gated_k, dim3((unsigned)re_cdiv(K, 64), ch), dim3(256), 0, (hipStream_t)stream, dlogit, h, w, z, stats,
+                       drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, M, K, g, part);
+    *chunks_out = ch;
     return re_launch_status();
 }

@@ -141,8 +141,9 @@ class DeepFMEngine:
         """-> (logits [B], tape).  DeepFM/main.py:201-209.  seed_dev: the dropout seed as a device word (captured steps).
         labels (training): the criterion runs in the last layer's launch; tape["loss" / "dlogit" / "dsum"] hold its results."""
         P = self.P
-        E, fm_lr = ops.fm_bag_fwd(self.T, self.TL.reshape(-1), self.bias, self.offsets, x)
-        tape = {"E": E, "layers": []}
+        rows = torch.empty(x.numel(), dtype=torch.int64, device=x.device) if labels is not None else None
+        E, fm_lr = ops.fm_bag_fwd(self.T, self.TL.reshape(-1), self.bias, self.offsets, x, rows_out=rows)
+        tape = {"E": E, "layers": [], "rows": rows}
         h, sd = E, self._step_seed()
         for i in range(self.nl):
             # bn(linear(x)) in training mode: the batch statistics' per-64-row partials come out of the GEMM's epilogue (re_gemm_f32_colstats)
@@ -160,7 +161,7 @@ class DeepFMEngine:
             return ops.mlp_head_fwd(h, w_last, P[f"dnn.{self.nl}.bias"], fm_lr), tape
         logits, tape["loss"], tape["dlogit"], tape["dsum"] = ops.mlp_head_fwd(h, w_last, P[f"dnn.{self.nl}.bias"], fm_lr,
                                                                                labels.reshape(-1).to(torch.float32).contiguous(),
-                                                                               dsum=self.G[f"dnn.{self.nl}.bias"])
+                                                                               dsum=self.G[f"dnn.{self.nl}.bias"], dsum2=self.gbias)
         return logits, tape
 
     def recommend_from_pool(self, x):
@@ -175,24 +176,45 @@ class DeepFMEngine:
         logits, tape = self.encode(x, seed_dev, labels=labels)
         nl = self.nl
         loss, dlogit, dsum = tape["loss"], tape["dlogit"], tape["dsum"]
-        da = ops.mlp_head_bwd(dlogit, tape["h_last"], P[f"dnn.{nl}.weight"].reshape(-1), G[f"dnn.{nl}.weight"].reshape(-1))
+        p_drop = self.p_drop if self.training else 0.0
+        w_last, gw_last = P[f"dnn.{nl}.weight"].reshape(-1), G[f"dnn.{nl}.weight"].reshape(-1)
+        # BatchNorm in training mode: the gate g = dropout'(relu'(.)) x incoming gradient and its column sums (sum g, sum g xhat) come out of the
+        # launch that PRODUCES the incoming gradient (the head's backward for the last block, the dx product's epilogue for the others), and one
+        # pass (re_bn_bwd_apply) finishes dgamma / dbeta and turns g into dz.  Otherwise: da, then re_bn_relu_drop_bwd's three launches.
+        fused = self.bn and self.training and nl > 0
+        da = g = part = None
+        if fused:
+            g, part = ops.mlp_head_bwd_gated(dlogit, tape["h_last"], w_last, tape["layers"][nl - 1][1], tape["layers"][nl - 1][3], p_drop)
+        else:
+            da = ops.mlp_head_bwd(dlogit, tape["h_last"], w_last, gw_last)
         for i in reversed(range(nl)):
             h, z, a, stats = tape["layers"][i]
-            dz, _, _ = ops.bn_relu_drop_bwd(da, a, z, P.get(f"dnn.{i}.bn.weight"), stats, self.p_drop if self.training else 0.0,
-                                            dgamma=G.get(f"dnn.{i}.bn.weight"), dbeta=G[f"dnn.{i}.bn.bias"] if self.bn else G[f"dnn.{i}.linear.bias"])
+            if g is not None:
+                dz = ops.bn_bwd_apply(g, z, P[f"dnn.{i}.bn.weight"], stats, part, G[f"dnn.{i}.bn.weight"], G[f"dnn.{i}.bn.bias"],
+                                      extra_out=gw_last if part.shape[1] == 3 else None)
+            else:
+                dz, _, _ = ops.bn_relu_drop_bwd(da, a, z, P.get(f"dnn.{i}.bn.weight"), stats, p_drop,
+                                                dgamma=G.get(f"dnn.{i}.bn.weight"), dbeta=G[f"dnn.{i}.bn.bias"] if self.bn else G[f"dnn.{i}.linear.bias"])
             ops.gemm(dz, h, transA=True, out=G[f"dnn.{i}.linear.weight"])             # dW = dz^T x
             # (the Linear bias in front of a BatchNorm: its gradient sum_m dz[m, :] is zero in exact arithmetic -- BatchNorm's backward removes the
             #  column mean -- and pure cancellation noise (~1e-10 of the model's gradient scale) as autograd computes it; it stays exactly zero
             #  here: the arena is zero-initialised and nothing writes these entries)
-            da = ops.gemm(dz, P[f"dnn.{i}.linear.weight"])                             # dx = dz W
+            W = P[f"dnn.{i}.linear.weight"]
+            r = None
+            if fused and i > 0:                                                        # dx = dz W, gated for the block underneath
+                hp, zp, ap, sp = tape["layers"][i - 1]
+                r = ops.gemm_gated(dz, W, ap, zp, sp, 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0)
+            if r is not None:
+                g, part = r
+            else:
+                g, da = None, ops.gemm(dz, W)
         gE, gL = ops.fm_bag_bwd(tape["E"], da, dlogit, self.F, self.D)
         # both table gradients follow the same destination rows: ONE sort (re_scatter_plan), two segmented sums (re_scatter_apply)
-        rows = (x + self.offsets.unsqueeze(0)).reshape(-1)
+        rows = tape["rows"]
         ws = ops.scatter_workspace(rows.numel(), self.D, self.rows, rows.device)
         ops.scatter_plan(rows, self.D, self.rows, ws)
         ops.scatter_apply(gE.reshape(-1, self.D), self.rows, self.gT, ws, accumulate=False)
         ops.scatter_apply(gL.reshape(-1, 1), self.rows, self.gTL, ws, accumulate=False)
-        self.gbias.copy_(dsum)
         return loss.squeeze(0)
 
     def train_step(self, x, labels, max_norm=10.0, _state=None):

@@ -1047,8 +1047,8 @@ def auc(scores, labels):
 
 
 # ------------------------------------------------------------------------------------------------ K9
-def fm_bag_fwd(T, TL, lr_bias, offsets, x):
-    """-> (E [B, F*D], fm_lr [B])  (re_fm_bag_fwd)."""
+def fm_bag_fwd(T, TL, lr_bias, offsets, x, rows_out=None):
+    """-> (E [B, F*D], fm_lr [B])  (re_fm_bag_fwd).  rows_out (int64 [B * F], optional) receives offsets[f] + x[b, f]."""
     _req(T, torch.float32, "T"); _req(TL, torch.float32, "TL"); _req(lr_bias, torch.float32, "lr_bias")
     _req(offsets, torch.int64, "offsets"); _req(x, torch.int64, "x")
     B, F = x.shape
@@ -1056,7 +1056,7 @@ def fm_bag_fwd(T, TL, lr_bias, offsets, x):
     E = torch.empty((B, F * D), dtype=torch.float32, device=T.device)
     fm_lr = torch.empty((B,), dtype=torch.float32, device=T.device)
     lib.check(lib.load().re_fm_bag_fwd(_p(T), _p(TL), _p(lr_bias), _p(offsets), T.shape[0], _p(x), B, F, D, _p(E), _p(fm_lr),
-                                       _stream()), "re_fm_bag_fwd")
+                                       _p(rows_out), _stream()), "re_fm_bag_fwd")
     return E, fm_lr
 
 
@@ -1226,8 +1226,9 @@ def bn_relu_drop_bwd(da, a, z, gamma, stats, drop_p, dgamma=None, dbeta=None):
     return dz, dgamma, dbeta
 
 
-def mlp_head_fwd(h, w, b, fm_lr=None, labels=None, dsum=None):
-    """DeepFM's Linear(., 1) + logit sum (+ criterion) (re_mlp_head_fwd): -> logits [M], and with labels (loss [1], dlogit [M], dsum [1])."""
+def mlp_head_fwd(h, w, b, fm_lr=None, labels=None, dsum=None, dsum2=None):
+    """DeepFM's Linear(., 1) + logit sum (+ criterion) (re_mlp_head_fwd): -> logits [M], and with labels (loss [1], dlogit [M], dsum [1]);
+    dsum2: a second place for sum dlogit (DeepFM's LR bias has the same gradient as the last layer's)."""
     _req(h, torch.float32, "h"); _req(w, torch.float32, "w"); _req(b, torch.float32, "b")
     M, K = h.shape
     dev = h.device
@@ -1235,14 +1236,14 @@ def mlp_head_fwd(h, w, b, fm_lr=None, labels=None, dsum=None):
     L = lib.load()
     ws = _ws(L.re_mlp_head_workspace_bytes(M, K), dev)
     if labels is None:
-        lib.check(L.re_mlp_head_fwd(_p(h), M, K, _p(w), _p(b), _p(fm_lr), None, _p(logits), None, None, None, _p(ws), ws.numel(), _stream()), "re_mlp_head_fwd")
+        lib.check(L.re_mlp_head_fwd(_p(h), M, K, _p(w), _p(b), _p(fm_lr), None, _p(logits), None, None, None, None, _p(ws), ws.numel(), _stream()), "re_mlp_head_fwd")
         return logits
     _req(labels, torch.float32, "labels")
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     dl = torch.empty(M, dtype=torch.float32, device=dev)
     dsum = dsum if dsum is not None else torch.empty(1, dtype=torch.float32, device=dev)
-    lib.check(L.re_mlp_head_fwd(_p(h), M, K, _p(w), _p(b), _p(fm_lr), _p(labels), _p(logits), _p(loss), _p(dl), _p(dsum), _p(ws), ws.numel(), _stream()),
-              "re_mlp_head_fwd")
+    lib.check(L.re_mlp_head_fwd(_p(h), M, K, _p(w), _p(b), _p(fm_lr), _p(labels), _p(logits), _p(loss), _p(dl), _p(dsum), _p(dsum2), _p(ws), ws.numel(),
+                                _stream()), "re_mlp_head_fwd")
     return logits, loss, dl, dsum
 
 
@@ -1255,6 +1256,47 @@ def mlp_head_bwd(dlogit, h, w, dW):
     ws = _ws(L.re_mlp_head_workspace_bytes(M, K), h.device)
     lib.check(L.re_mlp_head_bwd(_p(dlogit), _p(h), _p(w), M, K, _p(da), _p(dW), _p(ws), ws.numel(), _stream()), "re_mlp_head_bwd")
     return da
+
+
+def mlp_head_bwd_gated(dlogit, h, w, z, stats, drop_p):
+    """The last Linear(., 1)'s backward with the gate of the block underneath (re_mlp_head_bwd_gated): -> (g [M, K], part [chunks, 3, K])."""
+    _req(dlogit, torch.float32, "dlogit"); _req(h, torch.float32, "h"); _req(w, torch.float32, "w"); _req(z, torch.float32, "z"); _req(stats, torch.float32, "stats")
+    M, K = h.shape
+    g = torch.empty_like(h)
+    L = lib.load()
+    nbytes = L.re_mlp_head_workspace_bytes(M, K)
+    part = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=h.device)
+    ch = ctypes.c_int(0)
+    lib.check(L.re_mlp_head_bwd_gated(_p(dlogit), _p(h), _p(w), M, K, _p(z), _p(stats), float(drop_p), _p(g), _p(part), part.numel() * 4, ctypes.byref(ch),
+                                      _stream()), "re_mlp_head_bwd_gated")
+    return g, part[:ch.value * 3 * K].view(ch.value, 3, K)
+
+
+def gemm_gated(A, B, act, z, stats, drop_scale, transB=False):
+    """g = act > 0 ? drop_scale A op(B) : 0 and its per-64-row column sums (re_gemm_f32_gated) -> (g [M, N], part [M / 64, 2, N]), or None where
+    the form does not apply (M not a multiple of 64, unaligned operands)."""
+    _req(A, torch.float32, "A"); _req(B, torch.float32, "B"); _req(act, torch.float32, "act"); _req(z, torch.float32, "z"); _req(stats, torch.float32, "stats")
+    M, K = A.shape
+    N = B.shape[0] if transB else B.shape[1]
+    if M % 64 or act.shape != (M, N) or z.shape != (M, N):
+        return None
+    g = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    part = torch.empty((M // 64, 2, N), dtype=torch.float32, device=A.device)
+    rc = lib.load().re_gemm_f32_gated(0, int(transB), M, N, K, 1.0, _p(A), A.stride(0), _p(B), B.stride(0), _p(g), N, _p(act), _p(z), _p(stats),
+                                      float(drop_scale), _p(part), _stream())
+    if rc == lib.RE_EUNSUPPORTED:
+        return None
+    lib.check(rc, "re_gemm_f32_gated")
+    return g, part
+
+
+def bn_bwd_apply(g, z, gamma, stats, part, dgamma, dbeta, extra_out=None):
+    """g -> dz in place, dgamma / dbeta (/ extra_out) from the per-chunk partials (re_bn_bwd_apply)."""
+    _req(g, torch.float32, "g"); _req(z, torch.float32, "z"); _req(part, torch.float32, "part")
+    M, N = z.shape
+    lib.check(lib.load().re_bn_bwd_apply(_p(g), _p(z), M, N, _p(gamma), _p(stats), _p(part), int(part.shape[0]), int(part.shape[1]), _p(dgamma), _p(dbeta),
+                                         _p(extra_out), _stream()), "re_bn_bwd_apply")
+    return g
 
 
 def colsum(x, out=None):

@@ -201,7 +201,7 @@ def test_deepfm_resume_keeps_the_reduced_learning_rate_and_checkpoints_move_betw
     modelm.eval()
     coach._engine.reset_ranking_buffers()  # (evaluation mode: running statistics, no dropout)
     for vb in coach.validpipe:             # the two paths score the same rows the same way ...
-        z, _ = coach._engine.pool_logits(coach, vb)
+        zl, _ = coach._engine.pool_logits(coach, vb)
         with torch.no_grad():
             pm_ = modelm({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in vb.items()}, ranking="pool").reshape(-1)
         torch.testing.assert_close(torch.sigmoid(zl.reshape(-1)), pm_, rtol=1e-4, atol=1e-6)
