@@ -9,6 +9,8 @@
 // pass does the transposition (float4 global loads along the operand's contiguous dimension).  Skinny outputs with a
 // long K (dU = dlogits E: 3 000 x 64 x 12 101) are split along K over gridDim.z into partial slabs that a second
 // kernel adds in slice order (deterministic; no float atomics).
+#include <type_traits>
+
 #include "re_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -200,6 +202,27 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* __restric
 // the output's columns as per-64-row (mean, M2) partials in re_bn_relu_drop_fwd's workspace format -- bn_stats_partial_k's pass over z
 // (DeepFM/main.py:119-124: bn(linear(x))) is the GEMM's own epilogue.
 #define GW_BK 64
+// scheduling directions for one stretch of a basic block: NOPS instructions of class MASK (0x100 LDS read, 0x200 LDS write) spread evenly over
+// NMF MFMAs (0x008), in program order of each class
+template <int MASK, int NOPS, int NMF>
+__device__ __forceinline__ void gw_spread() {
+    if constexpr (NOPS <= NMF) {
+        constexpr int per = NMF / NOPS;
+#pragma unroll
+        for (int i = 0; i < NOPS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        }
+        if constexpr (NMF - NOPS * per > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NOPS * per, 0);
+    } else {
+        constexpr int per = (NOPS + NMF - 1) / NMF;
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(MASK, per, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+    }
+}
 #define GW_LSK (GW_BK + 4)          // row stride of a k-contiguous tile
 template <bool KMAJ, int ROWS>      // ROWS: rows (or columns) of the tile: a multiple of 16
 struct GwTile {
@@ -234,6 +257,29 @@ struct GwTile {
                 if (r < r_end && k < k_end) v[p] = *reinterpret_cast<const float4*>(mem + k * ld + r);
             }
         }
+    }
+    // the slots' source pointers at k = k0 with the row clamped into [r0, r_end) (k-contiguous: the last row; row-contiguous: the last whole
+    // float4 of rows) -- for steps that lie wholly inside the operand in k: fetch_at(v, gp, off) loads every slot at gp + off, no guards
+    static __device__ __forceinline__ void ptrs(const float* (&gp)[PER], const float* __restrict__ mem, int64_t ld, int64_t r0, int64_t r_end,
+                                                int64_t k0, int tid) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int f = p * 256 + tid;
+            if (SLOTS % 256 != 0 && f >= SLOTS) f = SLOTS - 1;
+            if (KMAJ) {
+                int64_t r = r0 + (f / (GW_BK / 4));
+                if (r > r_end - 1) r = r_end - 1;
+                gp[p] = mem + r * ld + k0 + (f % (GW_BK / 4)) * 4;
+            } else {
+                int64_t r = r0 + (f % (ROWS / 4)) * 4;
+                if (r > r_end - 4) r = r_end - 4;
+                gp[p] = mem + (k0 + f / (ROWS / 4)) * ld + r;
+            }
+        }
+    }
+    static __device__ __forceinline__ void fetch_at(float4 (&v)[PER], const float* const (&gp)[PER], int64_t off) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) v[p] = *reinterpret_cast<const float4*>(gp[p] + off);
     }
     static __device__ __forceinline__ void put(float* Xs, const float4 (&v)[PER], int tid) {
 #pragma unroll
@@ -296,49 +342,97 @@ __global__ __launch_bounds__(256) void gemm_wide_k(const GwArgs a) {
 #pragma unroll
     for (int t = 0; t < WT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 pa[TA::PER], pb[TB::PER];
-    {
-        const bool full = kb + GW_BK <= ke;
-        TA::fetch(pa, a.A, a.lda, m0, a.M, kb, ke, tid, in_a && full);
-        TB::fetch(pb, a.B, a.ldb, n0, n_end, kb, ke, tid, in_b && full);
-    }
+    // ---- the k loop, software-pipelined for ONE wave per SIMD (93 KB of LDS a workgroup: no second wave hides a barrier or an LDS round trip).
+    // Step s works on LDS buffer s & 1.  Between barrier(s - 1) and barrier(s) a wave issues, in this order,
+    //     global loads of tile s + 2 -> registers;  fragments q0(s) <- LDS;  MFMAs q3(s - 1)            (the MFMAs cover both latencies)
+    //     MFMAs q0(s) | fragments q1(s);  MFMAs q1(s) | fragments q2(s);  MFMAs q2(s) | fragments q3(s) + tile s + 1: registers -> LDS
+    // so the only thing an MFMA ever waits for is the barrier itself.  (The plain loop -- fetch, four sub-chunks, store, barrier -- measured
+    // 54 % MFMA-busy at K = 4 096: 1 300 cycles a step parked at waits, 1 700 issuing everything else with the MFMA pipe idle.)
+    // Steps 0 .. last - 1 are whole (GW_BK of k); the last may be partial and runs guarded.  Rows / columns outside the operand are CLAMPED into
+    // it for the whole steps (unconditional loads; what a clamped slot holds lands in accumulator rows / columns the epilogue never stores);
+    // the partial step's loads are guarded and zero-filled.
+    const int64_t klen = ke - kb;
+    const int nfull = (int)(klen / GW_BK);
+    const int nsteps = nfull + ((klen % GW_BK) ? 1 : 0);
+    const int last = nsteps - 1;
+    const float *gpa[TA::PER], *gpb[TB::PER];
+    TA::ptrs(gpa, a.A, a.lda, m0, a.M, kb, tid);
+    TB::ptrs(gpb, a.B, a.ldb, n0, n_end, kb, tid);
+    const int64_t ska = A_KMAJ ? (int64_t)GW_BK : (int64_t)GW_BK * a.lda, skb = B_KMAJ ? (int64_t)GW_BK : (int64_t)GW_BK * a.ldb;   // a step, in floats
+    auto fetch = [&](int s_) {                        // tile s_ -> registers (s_ <= last; uniform)
+        if (s_ < nfull) {
+            TA::fetch_at(pa, gpa, (int64_t)s_ * ska);
+            TB::fetch_at(pb, gpb, (int64_t)s_ * skb);
+        } else {
+            TA::fetch(pa, a.A, a.lda, m0, a.M, kb + (int64_t)s_ * GW_BK, ke, tid, false);
+            TB::fetch(pb, a.B, a.ldb, n0, n_end, kb + (int64_t)s_ * GW_BK, ke, tid, false);
+        }
+    };
+    f32x4 av[2], bv[2][WT];
+    auto frags = [&](int buf, int q, int slot) {
+        av[slot] = TA::frag(As0 + buf * TA::FLOATS, arow, q, c, g);
+#pragma unroll
+        for (int t = 0; t < WT; ++t) bv[slot][t] = TB::frag(Bs0 + buf * TB::FLOATS, bcol0 + t, q, c, g);
+    };
+    auto mfmas = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < WT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[slot][i], bv[slot][t][i], acc[t], 0, 0, 0);
+    };
+    // LDS reads of a sub-chunk's fragments (k-contiguous: one ds_read_b128 each; else four b32), its MFMAs, the LDS writes of a tile
+    constexpr int RDA = A_KMAJ ? 1 : 4, RDB = B_KMAJ ? 1 : 4, NRDI = RDA + WT * RDB, NMF = 4 * WT, NWR = TA::PER + TB::PER;
+    fetch(0);
     TA::put(As0, pa, tid);
     TB::put(Bs0, pb, tid);
     __syncthreads();
-    int cur = 0;
-    for (int64_t k0 = kb; k0 < ke; k0 += GW_BK) {
-        const bool more = k0 + GW_BK < ke;           // (uniform)
-        if (more) {
-            const bool full = k0 + 2 * GW_BK <= ke;
-            TA::fetch(pa, a.A, a.lda, m0, a.M, k0 + GW_BK, ke, tid, in_a && full);
-            TB::fetch(pb, a.B, a.ldb, n0, n_end, k0 + GW_BK, ke, tid, in_b && full);
+    if (nsteps > 1) fetch(1);
+    frags(0, 0, 0);
+    // a whole step with a successor.  FAST: tile s_ + 2 exists and is whole (its loads unconditional, no branch in the step); otherwise it is
+    // the partial last tile (guarded loads) or there is none -- the two steps in front of the last one
+    auto step = [&](int s_, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const int buf = s_ & 1;
+        frags(buf, 1, 1);
+        mfmas(0);
+        frags(buf, 2, 0);
+        mfmas(1);
+        frags(buf, 3, 1);
+        TA::put(As0 + (buf ^ 1) * TA::FLOATS, pa, tid);
+        TB::put(Bs0 + (buf ^ 1) * TB::FLOATS, pb, tid);
+        mfmas(0);
+        // the order of issue: a sub-chunk's LDS reads spread over the MFMAs of the one before it, the tile's LDS writes over the third's
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        gw_spread<0x100, NRDI, NMF - 1>();
+        gw_spread<0x100, NRDI, NMF>();
+        gw_spread<0x100, NRDI, NMF - NMF / 2>();
+        gw_spread<0x200, NWR, NMF / 2>();
+        __syncthreads();
+        if (FAST) {
+            TA::fetch_at(pa, gpa, (int64_t)(s_ + 2) * ska);
+            TB::fetch_at(pb, gpb, (int64_t)(s_ + 2) * skb);
+        } else if (s_ + 2 <= last) {
+            fetch(s_ + 2);
         }
-        const float* Asc = As0 + cur * TA::FLOATS;
-        const float* Bsc = Bs0 + cur * TB::FLOATS;
-        const int nq = (int)((ke - k0 + 15) >> 4) < GW_BK / 16 ? (int)((ke - k0 + 15) >> 4) : GW_BK / 16;   // sub-chunks of 16 k with anything in them
-        f32x4 av[2], bv[2][WT];
-        av[0] = TA::frag(Asc, arow, 0, c, g);
-#pragma unroll
-        for (int t = 0; t < WT; ++t) bv[0][t] = TB::frag(Bsc, bcol0 + t, 0, c, g);
+        frags(buf ^ 1, 0, 0);
+        mfmas(1);
+    };
+    int s_ = 0;
+    for (; s_ + 2 < nfull && s_ < last; ++s_) step(s_, std::true_type{});
+    for (; s_ < last; ++s_) step(s_, std::false_type{});
+    {                                                 // the last step: whole or partial, no successor (fragments q0 are in slot 0)
+        const int buf = last & 1;
+        const int64_t kl = ke - (kb + (int64_t)last * GW_BK);
+        const int nq = (int)((kl + 15) >> 4) < GW_BK / 16 ? (int)((kl + 15) >> 4) : GW_BK / 16;
 #pragma unroll
         for (int q = 0; q < GW_BK / 16; ++q) {
             if (q >= nq) break;                      // (uniform)
-            if (q + 1 < GW_BK / 16 && q + 1 < nq) {  // the next sub-chunk's fragments: requested before this one's MFMAs
-                av[(q + 1) & 1] = TA::frag(Asc, arow, q + 1, c, g);
-#pragma unroll
-                for (int t = 0; t < WT; ++t) bv[(q + 1) & 1][t] = TB::frag(Bsc, bcol0 + t, q + 1, c, g);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int t = 0; t < WT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][i], bv[q & 1][t][i], acc[t], 0, 0, 0);
+            if (q + 1 < GW_BK / 16 && q + 1 < nq) frags(buf, q + 1, (q + 1) & 1);
+            mfmas(q & 1);
         }
-        if (more) {
-            TA::put(As0 + (cur ^ 1) * TA::FLOATS, pa, tid);
-            TB::put(Bs0 + (cur ^ 1) * TB::FLOATS, pb, tid);
-        }
-        __syncthreads();
-        cur ^= 1;
+        __syncthreads();                             // (the epilogue reuses the tile memory)
     }
+    (void)in_a; (void)in_b;
     // ---- epilogue: acc[t][j] = C(m0 + 16 arow + 4 g + j, n0 + 16 (bcol0 + t) + c)
     float* stat = Bs0;                                              // [4 waves][16 BT columns][2] (the main loop is behind a barrier)
     if (WM == 4 && a.gate_act) {
