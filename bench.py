@@ -393,6 +393,9 @@ def main():
     ap.add_argument("--prefetch", dest="prefetch", action="store_true", help=argparse.SUPPRESS)
     ap.set_defaults(prefetch=True)
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--dp", default="owner", choices=("owner", "allreduce"),
+                    help="N > 1: how the replicas' step is synchronised.  owner (default): all-to-all of the gradient arenas, Adam on each slice's owner, "
+                         "all-gather of the parameters (recboard_amd/dp.py); allreduce: one all-reduce of the gradient arena, dense Adam everywhere")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="every rank joins the process group (RCCL; gloo where there is no GPU), all-gathers (rank, world) and prints its own JSON line; "
                          "no engine work -- the launcher / rendezvous path alone (tests/test_bench_launcher.py runs it with four ranks on the CPU)")
@@ -443,7 +446,10 @@ def main():
         batches.append(t + ((None if args.encoder == 'fused' else model.batch_aux(*t)),))
 
     hook = None
-    if world > 1 or force_dist:
+    if (world > 1 or force_dist) and args.dp == "owner":
+        from recboard_amd.dp import OwnerAdam
+        hook = OwnerAdam(model.arena.numel)   # two one-hop collectives per step; the Adam launch covers 1 / world of the arena
+    elif world > 1 or force_dist:
         def hook(garena):  # ONE collective per step: the whole gradient arena is a single bucket
             dist.all_reduce(garena, op=dist.ReduceOp.AVG)   # (RCCL averages in the collective: no separate scaling launch)
 
@@ -524,7 +530,9 @@ def main():
                    if use_graph else "eager (one launch per kernel)",
                    "timed_region": "raw (seq, pos, neg) in HBM -> batch preparation (mask, count, rows, plan) -> forward, backward, Adam (dropout 0.5 on): "
                                    "every timed step does all of it for one batch",
-                   "parallelism": f"dp{world} (replicated 3 MB table, one gradient-arena all-reduce per step)"},
+                   "parallelism": (f"dp{world} (replicated 3 MB table; per step: all-to-all of the gradient arenas, Adam on each slice's owner, all-gather of the "
+                                   f"parameters: {getattr(hook, 'bytes_per_link_per_step', 0)} B per xGMI link per step)" if getattr(hook, "owns_adam", False)
+                                   else f"dp{world} (replicated 3 MB table, one gradient-arena all-reduce per step)")},
         "world_size": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
         "final_loss": round(float(loss), 5),
     }

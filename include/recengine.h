@@ -542,6 +542,13 @@ size_t re_grad_clip_workspace_bytes(void);
 int re_grad_clip_coef(const float* g, int64_t n, float max_norm, float* coef_norm, void* ws, size_t ws_bytes, re_stream_t stream);
 int re_adam_step_scaled(float* p, float* g, float* m, float* v, int64_t n, int64_t step, double lr, const float* hyper, double beta1,
                         double beta2, double eps, double weight_decay, const float* gscale, re_stream_t stream);
+/* The owner's half of a data-parallel step (N > 1 replicas of one flat parameter arena; the reference trains one replica:
+ * freerec/launcher.py's Coach, SASRec/main.py:264-275): this rank owns p[0 .. n) (a slice of the arena); parts + r * part_stride (r < nparts)
+ * is rank r's gradient for the slice (what an all-to-all of the ranks' gradient arenas delivers).  g = gscale (((part 0 + part 1) + ...)
+ * in rank order); g_out (optional) receives it; then re_adam_step's update on (p, m, v).  n, part_stride multiples of 4, 16-byte aligned. */
+int re_adam_step_reduce(float* p, const float* parts, int nparts, int64_t part_stride, float* g_out, float* m, float* v, int64_t n,
+                        int64_t step, double lr, const float* hyper, double beta1, double beta2, double eps, double weight_decay,
+                        double gscale, re_stream_t stream);
 int re_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
                  double beta1, double beta2, double eps, double weight_decay, re_stream_t stream);
 

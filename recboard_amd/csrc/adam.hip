@@ -180,6 +180,52 @@ extern "C" int re_adam_step_scaled(float* p, float* g, float* m, float* v, int64
     return re_launch_status();
 }
 
+// The owner's half of a data-parallel step (recboard_amd/dp.py): the gradient of this rank's slice of the arena arrives as `nparts` partial
+// slices (one per rank, parts + r * part_stride: what an all-to-all of the ranks' gradient arenas leaves); g = gscale * (((part 0 + part 1) + ...)
+// in rank order) -- every rank computes a slice exactly once, in a fixed order: the replicas stay bit-identical -- then Adam on the slice.
+// g_out (optional): the reduced gradient.  nparts == 1, gscale == 1: re_adam_step's arithmetic on part 0.
+__global__ __launch_bounds__(256) void adam_vec4_reduce(float4* __restrict__ p, const float4* __restrict__ parts, int nparts, int64_t stride4,
+                                                        float4* __restrict__ g_out, float4* __restrict__ m, float4* __restrict__ v, int64_t n4, float b1,
+                                                        float b2, float omb1, float omb2, float step_size, float inv_sqrt_bc2,
+                                                        const float* __restrict__ hyper, float eps, float wd, float gscale) {
+    if (hyper) { step_size = hyper[0]; inv_sqrt_bc2 = hyper[1]; }
+    if (inv_sqrt_bc2 == 0.f) return;   // (a gated step: see adam_vec4_dev)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = p[i], M = m[i], V = v[i], G = parts[i];
+        for (int r = 1; r < nparts; ++r) {
+            const float4 q = parts[(int64_t)r * stride4 + i];
+            G.x += q.x; G.y += q.y; G.z += q.z; G.w += q.w;
+        }
+        if (gscale != 1.0f) { G.x *= gscale; G.y *= gscale; G.z *= gscale; G.w *= gscale; }
+        if (g_out) g_out[i] = G;
+#define RE_ADAM1(c_) re_adam1(P.c_, M.c_, V.c_, G.c_, b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd);
+        RE_ADAM1(x) RE_ADAM1(y) RE_ADAM1(z) RE_ADAM1(w)
+#undef RE_ADAM1
+        p[i] = P; m[i] = M; v[i] = V;
+    }
+}
+extern "C" int re_adam_step_reduce(float* p, const float* parts, int nparts, int64_t part_stride, float* g_out, float* m, float* v, int64_t n,
+                                   int64_t step, double lr, const float* hyper, double beta1, double beta2, double eps, double weight_decay,
+                                   double gscale, re_stream_t stream) {
+    re_clear_error();
+    if (n == 0) return RE_OK;
+    if (!p || !parts || !m || !v || n < 0 || nparts < 1 || part_stride < n || (step < 1 && !hyper)) return RE_EINVAL;
+    if ((n & 3) || (part_stride & 3) ||
+        ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(parts) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+          reinterpret_cast<uintptr_t>(g_out)) & 15u) != 0)
+        return RE_EUNSUPPORTED;
+    float step_size = 0.f, inv_sqrt_bc2 = 1.f;
+    if (step >= 1) {
+        step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
+        hyper = nullptr;
+    }
+    hipLaunchKernelGGL(adam_vec4_reduce, dim3(re_grid(n >> 2, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)parts, nparts,
+                       part_stride >> 2, (float4*)g_out, (float4*)m, (float4*)v, n >> 2, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                       (float)(1.0 - beta2), step_size, inv_sqrt_bc2, hyper, (float)eps, (float)weight_decay, (float)gscale);
+    return re_launch_status();
+}
+
 // dst = alpha * src over a flat fp32 range (LightGCN: avgEmbds = allEmbds / (L+1), LightGCN/main.py:80)
 __global__ __launch_bounds__(256) void scale_copy_k(float* __restrict__ dst, const float* __restrict__ src, float alpha, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = alpha * src[i];

@@ -87,6 +87,7 @@ SIGNATURES = {
     "re_grad_clip_workspace_bytes": (_sz, []),
     "re_grad_clip_coef": (_i32, [_vp, _i64, _f32, _vp, _vp, _sz, _vp]),
     "re_adam_step_scaled": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _f64, _f64, _f64, _f64, _vp, _vp]),
+    "re_adam_step_reduce": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _f64, _f64, _f64, _f64, _f64, _vp]),
     "re_score_pool": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "re_pool_topk": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "re_auc_workspace_bytes": (_sz, []),

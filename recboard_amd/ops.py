@@ -974,6 +974,17 @@ def adam_step_dev(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
                                           float(weight_decay), _stream()), "re_adam_step_dev")
 
 
+def adam_step_reduce(p, parts, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, g_out=None, hyper=None):
+    """Adam on gscale * (parts[0] + parts[1] + ... in order); parts [G, n] (row stride >= n), p / m / v [n]  (re_adam_step_reduce: the owner's
+    half of a data-parallel step, recboard_amd/dp.py).  step >= 1 with lr, or step = 0 with `hyper` (a captured step's device scalars)."""
+    for t, nme in ((p, "p"), (parts, "parts"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nme)
+    assert parts.dim() == 2 and parts.stride(1) == 1 and parts.shape[1] == p.numel()
+    lib.check(lib.load().re_adam_step_reduce(_p(p), _p(parts), int(parts.shape[0]), int(parts.stride(0)), _p(g_out), _p(m), _p(v), p.numel(), int(step),
+                                             float(lr), _p(hyper), float(beta1), float(beta2), float(eps), float(weight_decay), float(gscale), _stream()),
+              "re_adam_step_reduce")
+
+
 def grad_clip_coef(g, max_norm, out=None):
     """-> float32[2] on the device: [min(1, max_norm / (||g|| + 1e-6)), ||g||] over the flat gradient (re_grad_clip_coef: clip_grad_norm_'s
     coefficient, DeepFM/main.py:267)."""

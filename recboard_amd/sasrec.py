@@ -483,10 +483,8 @@ class SASRecEngine:
         A = self.arena
         pb = aux if aux is not None else self.prepare_batch(seq, pos, neg, for_next_step=True)
         loss = self._step_body(pb, self._step_seed())
-        if grad_hook is not None:
-            grad_hook(A.grad)
         A.step += 1
-        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+        self._hook_and_adam(grad_hook)
         return loss.squeeze(0)
 
     # ---- the same step as ONE hipGraph replay (the step is ~15 short launches: at B=512 the CPU launch path, not the GPU,
@@ -567,6 +565,18 @@ class SASRecEngine:
         self._loss_pending = None
         return acc
 
+    def _hook_and_adam(self, grad_hook):
+        """The optimizer step behind a gradient hook (arena.step already advanced).  A hook with `owns_adam` (recboard_amd.dp.OwnerAdam: the
+        data-parallel step whose Adam runs on each slice's owner) performs the update itself; a plain hook (e.g. an all-reduce of the gradient
+        arena) is followed by the dense Adam launch."""
+        A = self.arena
+        if grad_hook is not None and getattr(grad_hook, "owns_adam", False):
+            grad_hook.step_arena(A, self.lr, self.betas, 1e-8, self.wd)
+            return
+        if grad_hook is not None:
+            grad_hook(A.grad)
+        ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+
     def train_step_graph(self, seq, pos, neg, grad_hook=None, next_batch=None, next_ready=None):
         """`train_step_fused` on a RAW batch, replayed from a captured hipGraph: one batch-preparation launch (which also stages the
         batch and the step scalars into the graph's static buffers) + one graph launch.  Results are identical to the eager fused
@@ -623,8 +633,7 @@ class SASRecEngine:
                 ev.record(ps)
             self._staged = (nseq, npos, nneg, g2, ev, (grad_hook is None, self.training))
         if grad_hook is not None:
-            grad_hook(A.grad)
-            ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+            self._hook_and_adam(grad_hook)
         self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
 
@@ -677,8 +686,7 @@ class SASRecEngine:
         tp["parity"] = 1 - p
         tp["staged"] = next_batch
         if grad_hook is not None:
-            grad_hook(A.grad)
-            ops.adam_step(A.data, A.grad, A.m, A.v, A.step, self.lr, self.betas[0], self.betas[1], 1e-8, self.wd)
+            self._hook_and_adam(grad_hook)
         self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
 
