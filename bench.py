@@ -393,6 +393,8 @@ def main():
     ap.add_argument("--prefetch", dest="prefetch", action="store_true", help=argparse.SUPPRESS)
     ap.set_defaults(prefetch=True)
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--dp-outside-graph", action="store_true", help="--dp owner: issue the two collectives and the owner's launch behind the hipGraph replay "
+                                                                    "instead of recording them into it")
     ap.add_argument("--dp", default="owner", choices=("owner", "allreduce"),
                     help="N > 1: how the replicas' step is synchronised.  owner (default): all-to-all of the gradient arenas, Adam on each slice's owner, "
                          "all-gather of the parameters (recboard_amd/dp.py); allreduce: one all-reduce of the gradient arena, dense Adam everywhere")
@@ -449,6 +451,7 @@ def main():
     if (world > 1 or force_dist) and args.dp == "owner":
         from recboard_amd.dp import OwnerAdam
         hook = OwnerAdam(model.arena.numel)   # two one-hop collectives per step; the Adam launch covers 1 / world of the arena
+        hook.in_graph = not args.dp_outside_graph
     elif world > 1 or force_dist:
         def hook(garena):  # ONE collective per step: the whole gradient arena is a single bucket
             dist.all_reduce(garena, op=dist.ReduceOp.AVG)   # (RCCL averages in the collective: no separate scaling launch)
@@ -474,7 +477,9 @@ def main():
         keep = [t.clone() for t in (A.data, A.m, A.v)] + [A.step]
         try:
             seq0, pos0, neg0, _ = batches[0]
-            model.train_step_graph(seq0, pos0, neg0, grad_hook=(None if hook is None else (lambda g: None)),
+            # (an OwnerAdam hook is recorded INTO the graph, collectives included: every rank captures it here, at the same point, and its
+            #  warm-up run is a real exchange; a plain all-reduce hook stays outside the graph and is rehearsed as a no-op)
+            model.train_step_graph(seq0, pos0, neg0, grad_hook=(None if hook is None else (hook if getattr(hook, "owns_adam", False) else (lambda g: None))),
                                    next_batch=(seq0, pos0, neg0) if args.prefetch else None)      # (the same captured copies the timed steps replay)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001

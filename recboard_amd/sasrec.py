@@ -491,8 +491,19 @@ class SASRecEngine:
     #      sets the step time).  Per step: the batch-preparation launch (raw (seq, pos, neg) -> the static buffers the graph reads:
     #      copies, valid / count / rows_all, the encoder's plan, per-step seed and Adam scalars as device words) + one graph launch.
     #      BCE / BPR only: the CE path's shapes depend on the batch's number of valid positions.
+    @staticmethod
+    def _sync_kind(grad_hook):
+        """How a captured step ends: True = the fused / dense Adam inside the graph (one replica); the hook itself = a data-parallel step that
+        can be recorded (OwnerAdam: collectives + the owner's launch, inside the graph); False = gradients only (a plain hook, then Adam,
+        behind the replay)."""
+        if grad_hook is None:
+            return True
+        if getattr(grad_hook, "owns_adam", False) and getattr(grad_hook, "in_graph", True):
+            return grad_hook
+        return False
+
     def _capture(self, B, S, with_adam, in_prep=True, blob=None, next_prep=None):
-        """in_prep: the tile step's weight fragments come from the batch-preparation launch (False: from a launch inside the graph --
+        """with_adam: see _sync_kind.  in_prep: the tile step's weight fragments come from the batch-preparation launch (False: from a launch inside the graph --
         the pipelined form, whose preparation launch runs before the previous step's optimizer has finished)."""
         A = self.arena
         if blob is None:
@@ -502,11 +513,13 @@ class SASRecEngine:
         z = torch.zeros((B, S), dtype=torch.int64, device=self.device)
 
         def body():
-            loss = self._step_body(pb, 0, seed_dev=state, adam_hyper=hyper if with_adam else None, next_prep=next_prep)
+            loss = self._step_body(pb, 0, seed_dev=state, adam_hyper=hyper if with_adam is True else None, next_prep=next_prep)
             if isinstance(loss, tuple):          # (the optimizer ran inside the step's two branches)
                 return loss[0]
-            if with_adam:
+            if with_adam is True:
                 ops.adam_step_dev(A.data, A.grad, A.m, A.v, hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
+            elif with_adam:                      # a recboard_amd.dp.OwnerAdam: the data-parallel step's two collectives + the owner's launch, recorded too
+                with_adam.step(A.data, A.grad, A.m, A.v, 0, 0.0, self.betas, 1e-8, self.wd, hyper=hyper)
             return loss
 
         # warm-up on a side stream (workspace allocation, lazy module loads) with an all-padding batch, then restore
@@ -592,19 +605,21 @@ class SASRecEngine:
         B, S = seq.shape
         if not hasattr(self, "_graphs"):
             self._graphs, self._staged, self._pipe_i = {}, None, 0
-        pkey = (B, S, self.training) if grad_hook is None else (B, S, self.training, "grads")
+        kind = self._sync_kind(grad_hook)
+        ktag = "adam" if kind is True else ("grads" if kind is False else "owner")
+        pkey = (B, S, self.training) if grad_hook is None else (B, S, self.training, ktag)
         if self._tail_prep_ok() and B <= 8192 and (next_batch is not None or pkey in getattr(self, "_tail_pipes", {})):
             return self._train_step_graph_tail(seq, pos, neg, next_batch, next_ready, grad_hook)
         staged, self._staged = self._staged, None
-        hit = staged is not None and staged[0] is seq and staged[1] is pos and staged[2] is neg and staged[5] == (grad_hook is None, self.training)
+        hit = staged is not None and staged[0] is seq and staged[1] is pos and staged[2] is neg and staged[5] == (ktag, self.training)
         pipelined = hit or next_batch is not None
-        key = (B, S, grad_hook is None, self.training) + (((self._pipe_i & 1),) if pipelined else ())
+        key = (B, S, ktag, self.training) + (((self._pipe_i & 1),) if pipelined else ())
         if hit:
             g = staged[3]
             torch.cuda.current_stream().wait_event(staged[4])
         else:
             if key not in self._graphs:
-                self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None, in_prep=not pipelined)
+                self._graphs[key] = self._capture(B, S, with_adam=kind, in_prep=not pipelined)
             g = self._graphs[key]
         if next_batch is not None:
             entry = torch.cuda.Event()
@@ -617,9 +632,9 @@ class SASRecEngine:
             self._pipe_i += 1
         if next_batch is not None:
             nseq, npos, nneg = next_batch
-            k2 = (nseq.shape[0], nseq.shape[1], grad_hook is None, self.training, self._pipe_i & 1)
+            k2 = (nseq.shape[0], nseq.shape[1], ktag, self.training, self._pipe_i & 1)
             if k2 not in self._graphs:
-                self._graphs[k2] = self._capture(nseq.shape[0], nseq.shape[1], with_adam=grad_hook is None, in_prep=False)
+                self._graphs[k2] = self._capture(nseq.shape[0], nseq.shape[1], with_adam=kind, in_prep=False)
             g2 = self._graphs[k2]
             if not hasattr(self, "_prep_stream"):
                 self._prep_stream = torch.cuda.Stream()
@@ -631,8 +646,8 @@ class SASRecEngine:
                 self._stage(g2, nseq, npos, nneg, A.step + 1)
                 ev = torch.cuda.Event()
                 ev.record(ps)
-            self._staged = (nseq, npos, nneg, g2, ev, (grad_hook is None, self.training))
-        if grad_hook is not None:
+            self._staged = (nseq, npos, nneg, g2, ev, (ktag, self.training))
+        if kind is False:
             self._hook_and_adam(grad_hook)
         self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)
@@ -646,10 +661,11 @@ class SASRecEngine:
                     and self.encoder == "fused" and self.compact_rows)
 
     def _tail_pipe(self, B, S, with_adam=True):
-        """with_adam=False: the step without its optimizer (the data-parallel form: a gradient hook, then Adam, behind the replay)."""
+        """with_adam (see _sync_kind): False = the step without its optimizer (a gradient hook, then Adam, behind the replay); an OwnerAdam =
+        the data-parallel step recorded with it."""
         if not hasattr(self, "_tail_pipes"):
             self._tail_pipes = {}
-        key = (B, S, self.training) if with_adam else (B, S, self.training, "grads")
+        key = (B, S, self.training) if with_adam is True else (B, S, self.training, "grads" if with_adam is False else "owner")
         tp = self._tail_pipes.get(key)
         if tp is None:
             nbytes = ops.prep_layout(B, S)[1]
@@ -665,7 +681,8 @@ class SASRecEngine:
     def _train_step_graph_tail(self, seq, pos, neg, next_batch, next_ready, grad_hook=None):
         A = self.arena
         B, S = seq.shape
-        tp = self._tail_pipe(B, S, with_adam=grad_hook is None)
+        kind = self._sync_kind(grad_hook)
+        tp = self._tail_pipe(B, S, with_adam=kind)
         p = tp["parity"]
         g = tp["graphs"][p]
         st, tp["staged"] = tp["staged"], None
@@ -685,7 +702,7 @@ class SASRecEngine:
         A.step += 1
         tp["parity"] = 1 - p
         tp["staged"] = next_batch
-        if grad_hook is not None:
+        if kind is False:
             self._hook_and_adam(grad_hook)
         self._note_loss(g["loss"], B)
         return g["loss"].squeeze(0)

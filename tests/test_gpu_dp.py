@@ -50,7 +50,8 @@ def test_owner_adam_on_one_rank_takes_the_plain_engines_steps():
     from recboard_amd.dp import OwnerAdam
     from recboard_amd.sasrec import SASRecEngine
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    plain = dp_eng = hook = None
     try:
         N, B, S = 500, 16, 50
         rng = np.random.default_rng(5)
@@ -72,4 +73,9 @@ def test_owner_adam_on_one_rank_takes_the_plain_engines_steps():
             torch.testing.assert_close(dp_eng.arena.data, plain.arena.data, rtol=1e-6, atol=1e-8)
             torch.testing.assert_close(dp_eng.arena.m, plain.arena.m, rtol=1e-6, atol=1e-10)
     finally:
+        # (the captured steps hold the communicator's launches: drop them before the group goes)
+        del plain, dp_eng, hook
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
