@@ -416,6 +416,10 @@ __global__ __launch_bounds__(256) void gemm_wide_k(const GwArgs a) {
         }
         frags(buf ^ 1, 0, 0);
         mfmas(1);
+        // (two wait states in front of the back edge: where the compiler rotates accumulators at the loop header -- the 64 x 64 form -- its copies
+        //  read the last MFMA's result one wait state earlier than scripts/lint_mfma_hazard.py's table allows)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1");
     };
     int s_ = 0;
     for (; s_ + 2 < nfull && s_ < last; ++s_) step(s_, std::true_type{});

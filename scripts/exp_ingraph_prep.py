@@ -34,7 +34,7 @@ def run(mode):
         m._step_body = body
     for i in range(30):
         m.train_step_graph(*bs[i % 8])
-    g = m._graphs[(B, S, True, True)]
+    g = m._graphs[(B, S, "adam", True)]
     torch.cuda.synchronize()
     best = 1e9
     for rep in range(5):

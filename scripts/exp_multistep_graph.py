@@ -20,7 +20,7 @@ for k in (0, 1, 2, 4, 8):
                 m.train_step_graph(*bs[i % 8])
         per = 1
     else:
-        g = m._graphs[(B, S, True, True)]
+        g = m._graphs[(B, S, "adam", True)]
 
         def steps():
             for j in range(k):

@@ -53,7 +53,7 @@ def test_c2_sasrec_graph_step_at_bench_config_matches_oracle():
     # sets the gate -- the oracle takes the engine's gate (the tape's relu(h) > 0) wherever ITS pre-activation is within 2e-5 of zero
     from recboard_amd import ops
     W = m._buffers(B, S)
-    plan = ops.prep_views(m._graphs[(B, S, True, True)]["blob"], B, S).plan
+    plan = ops.prep_views(m._graphs[(B, S, "adam", True)]["blob"], B, S).plan
     gate_report = {l: {} for l in range(L)}
     gates = {l: ((ops.sasrec_tape_array(W["tape"], plan, B, S, D, L, "HR", l) > 0).cpu(), 2e-5, gate_report[l]) for l in range(L)}
     ref = osas.fit(P, torch.from_numpy(seq), torch.from_numpy(pos), torch.from_numpy(neg), "BCE", L, drop=dict(p=p, seed=seed2), gates=gates)

@@ -31,6 +31,10 @@ def test_small_config_legs_print_one_json_object(leg, unit):
     assert "skipped" not in d, d
     assert d["unit"] == unit and d["value"] > 0 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     if leg == "config4":
+        # the step's dominant kernel family is the MLP's GEMM (mfma); the field bag (hbm) is reported beside it
+        assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 157.3
+        assert d["roofline_fm_bag"]["bound"] == "hbm" and 0 < d["roofline_fm_bag"]["frac"] < 1
+    if leg == "config1":
         assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
 
 
