@@ -1166,6 +1166,169 @@ __global__ __launch_bounds__(128) void score_bound_k(const float* __restrict__ Q
     }
 }
 
+// score_front_k: the three launches in front of the split form's main kernel -- query split (+ zeroing of the call's words), item-table
+// split, starting thresholds -- as ONE launch of independent workgroups (round 5; 7 + 7 + 21 us in three launches before):
+//   blocks [0, ugroups): score_bound_k's job for 32 users, on the fp32 rows: the users' query rows are split here (score_split_k's arithmetic, bit
+//     for bit: the planes go to Qs for the main kernel, the norms to qnorm) and the sample's item rows are split on the fly by v_cvt_pk_bf16_f32
+//     (same rounding for finite values; a threshold need not be valid, only reported honestly) -- so the job waits for no other launch; four
+//     waves take the sample tiles t = wave, wave + 4, ... and wave 0 joins the four best-8 lists; the bound word is WRITTEN (0 = none), so it
+//     needs no zeroing;
+//   blocks [ugroups, ugroups + nbe): score_split_k's job on the item table, the device-wide maximum norm as one word PER BLOCK (bmax[j]: no
+//     atomic, nothing to zero; score_topk_merge_x takes the maximum of the nbe words);
+//   every block: a share of the words that must be zero when the main kernel starts (second thresholds, user / block flags) -- none of them is
+//     written inside this launch.
+template <int D>
+__global__ __launch_bounds__(256) void score_front_k(const float* __restrict__ Q, const float* __restrict__ E, int64_t B, int64_t N,
+                                                     unsigned short* __restrict__ Qs, float* __restrict__ qnorm, unsigned short* __restrict__ Es,
+                                                     unsigned* __restrict__ bmax, int ugroups, int nbe, int n_tiles, int64_t stride, int rhalf,
+                                                     unsigned* __restrict__ gthr, unsigned* __restrict__ zero_a, size_t zero_a_n,
+                                                     unsigned* __restrict__ zero_b, size_t zero_b_n) {
+    constexpr int NS16 = D / 16;
+    __shared__ float lx[3 * 8 * 64];
+    __shared__ unsigned wm[4];
+    {
+        const size_t nb = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+        for (size_t i = i0; i < zero_a_n; i += nb) zero_a[i] = 0u;
+        for (size_t i = i0; i < zero_b_n; i += nb) zero_b[i] = 0u;
+    }
+    if ((int)blockIdx.x >= ugroups) {
+        // ---- item-table split (score_split_k's loop; rows of this block: a grid-stride share)
+        constexpr int LPR = D / 4;
+        const int64_t total = N * LPR;
+        float wmax = 0.0f;
+        for (int64_t base = (int64_t)((int)blockIdx.x - ugroups) * 256; base < total; base += (int64_t)nbe * 256) {
+            const int64_t f = base + threadIdx.x;
+            const bool ok = f < total;
+            const int64_t row = ok ? f / LPR : 0;
+            const int kq = (int)(f % LPR);
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) x = reinterpret_cast<const float4*>(E)[f];
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+            unsigned hi[4], mid[4];
+            double ss = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = sx_bf16(xv[j]);
+                mid[j] = sx_bf16(xv[j] - __uint_as_float(hi[j] << 16));
+                ss += (double)xv[j] * (double)xv[j];
+            }
+            if (ok) {
+                unsigned short* dst = Es + row * (2 * D) + 4 * kq;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                *reinterpret_cast<uint2*>(dst + D) = make_uint2(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16));
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            float nrm = ss > 1e-30 ? sqrtf((float)ss) : (float)sqrt(ss);
+            nrm = nrm * 1.000001f;
+            if (ss > 0.0 && nrm < 1.2e-38f) nrm = 1.2e-38f;
+            if (ok) wmax = (nrm > wmax || nrm != nrm) ? nrm : wmax;
+        }
+        unsigned e = __float_as_uint(wmax);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e = max(e, (unsigned)__shfl_xor((int)e, o, 64));
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) bmax[(int)blockIdx.x - ugroups] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        return;
+    }
+    // ---- starting thresholds of 32 users (score_bound_k's job)
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int64_t user = (int64_t)blockIdx.x * 32 + c;
+    const bool uok = user < B;
+    float4 bqh[NS16], bqm[NS16];
+    {
+        const float4* qrow = reinterpret_cast<const float4*>(Q + (uok ? user : 0) * D);
+        double ss = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) {
+            const float4 a = uok ? qrow[4 * s + 2 * h] : make_float4(0.f, 0.f, 0.f, 0.f), b = uok ? qrow[4 * s + 2 * h + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            unsigned hi[8], mid[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hi[j] = sx_bf16(xv[j]);
+                mid[j] = sx_bf16(xv[j] - __uint_as_float(hi[j] << 16));
+                ss += (double)xv[j] * (double)xv[j];
+            }
+            const uint4 H = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+            const uint4 M = make_uint4(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16), mid[4] | (mid[5] << 16), mid[6] | (mid[7] << 16));
+            bqh[s] = __builtin_bit_cast(float4, H);
+            bqm[s] = __builtin_bit_cast(float4, M);
+            if (wv == 0 && uok) {
+                unsigned short* dst = Qs + user * (2 * D) + 16 * s + 8 * h;
+                *reinterpret_cast<uint4*>(dst) = H;
+                *reinterpret_cast<uint4*>(dst + D) = M;
+            }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        float nrm = ss > 1e-30 ? sqrtf((float)ss) : (float)sqrt(ss);
+        nrm = nrm * 1.000001f;
+        if (ss > 0.0 && nrm < 1.2e-38f) nrm = 1.2e-38f;
+        if (wv == 0 && h == 0 && uok) qnorm[user] = nrm;
+    }
+    float l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = -INFINITY;
+    float4 xa[NS16], xb[NS16], na[NS16], nb_[NS16];
+    auto fetch = [&](int t, float4* fa, float4* fb) {   // the lane's half of the A row of tile t: item (32 t + c) * stride, fp32
+        const float4* xr = reinterpret_cast<const float4*>(E + ((int64_t)(t * 32 + c) * stride) * D);
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) { fa[s] = xr[4 * s + 2 * h]; fb[s] = xr[4 * s + 2 * h + 1]; }
+    };
+    auto insert = [&](float v) {
+#pragma unroll
+        for (int j = 7; j >= 1; --j) l[j] = __builtin_amdgcn_fmed3f(v, l[j], l[j - 1]);
+        l[0] = fmaxf(v, l[0]);
+    };
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    auto split2 = [](float x, float y, unsigned& hw, unsigned& mw) {
+        const b2 hv = {(__bf16)x, (__bf16)y};
+        hw = __builtin_bit_cast(unsigned, hv);
+        const float hx = __uint_as_float(hw << 16), hy = __uint_as_float(hw & 0xFFFF0000u);
+        const b2 mv = {(__bf16)(x - hx), (__bf16)(y - hy)};
+        mw = __builtin_bit_cast(unsigned, mv);
+    };
+    if (wv < n_tiles) fetch(wv, xa, xb);
+    for (int t = wv; t < n_tiles; t += 4) {
+        fetch(t + 4 < n_tiles ? t + 4 : t, na, nb_);   // (in flight under this tile's MFMAs and insertions)
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) {
+            uint4 H, M;
+            split2(xa[s].x, xa[s].y, H.x, M.x); split2(xa[s].z, xa[s].w, H.y, M.y);
+            split2(xb[s].x, xb[s].y, H.z, M.z); split2(xb[s].z, xb[s].w, H.w, M.w);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, H), am = __builtin_bit_cast(bf16x8, M);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bqm[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) insert(acc[r]);
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) { xa[s] = na[s]; xb[s] = nb_[s]; }
+    }
+    // waves 1 - 3 hand their lists over; a list that lost entries beyond its 8 only makes the bound lower (safe side)
+    if (wv != 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lx[((wv - 1) * 8 + j) * 64 + lane] = l[j];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) insert(lx[(w * 8 + j) * 64 + lane]);
+        float mine = l[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mine = (j == rhalf - 1) ? l[j] : mine;
+        const float bound = fminf(mine, __shfl_xor(mine, 32, 64));
+        if (h == 0 && uok) gthr[user] = bound > -INFINITY ? sr_enc(bound) : 0u;
+    }
+}
+
 // joins the chunks of score_bound_k: one wave per 32 users, lane = (user, half) as there
 __global__ __launch_bounds__(64) void score_bound_merge_k(const float* __restrict__ partial, int nchunks, int64_t B, int rhalf,
                                                           unsigned* __restrict__ gthr) {
@@ -1218,7 +1381,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
                                                           const float* __restrict__ qnorm, const unsigned* __restrict__ emax, float cerr,
                                                           float* __restrict__ vals, int64_t* __restrict__ idx,
                                                           int* __restrict__ userflag, int* __restrict__ blockflag,
-                                                          int dbg_maxerr, int segs) {
+                                                          int dbg_maxerr, int segs, int n_emax) {
     constexpr int LPR = D / 4;
     __shared__ __align__(16) float mx_stage[4 * MX_ROWS * D];
     const int mxd = dbg_maxerr >> 4;
@@ -1314,7 +1477,12 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by the next pass
     }
-    const double eps = (double)cerr * (double)qnorm[user] * (double)__uint_as_float(*emax) + 1e-36;
+    // (the item table's largest row norm: one word, or one word per splitting workgroup of score_front_k -- n_emax <= 64; non-negative floats
+    //  and the NaN above them order as unsigned words)
+    unsigned emw = lane < n_emax ? emax[lane] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) emw = max(emw, (unsigned)__shfl_xor((int)emw, o, 64));
+    const double eps = (double)cerr * (double)qnorm[user] * (double)__uint_as_float(emw) + 1e-36;
     if (dbg_maxerr && bi != PAD) {   // diagnostics: the largest observed |s' - s| / eps (must stay below 1; tests/test_gpu_ops.py)
         const float ratio = (float)(fabs((double)sx - (double)bv) / eps);
         atomicMax(&g_sx_stats[1], __float_as_uint(ratio));
@@ -1446,6 +1614,10 @@ extern "C" void re_dbg_score_x2_d128(int on) { g_score_x2_d128 = on; }
 RE_SWITCH int g_score_sample = 1;   // split form: starting thresholds from a catalog sample (0: A/B switch, scripts/x2_check.py)
 #ifdef RE_DEBUG
 extern "C" void re_dbg_score_sample(int on) { g_score_sample = on; }
+#endif
+RE_SWITCH int g_score_front = 1;    // split form: query split + item split + starting thresholds as ONE launch (score_front_k; 0: the three launches)
+#ifdef RE_DEBUG
+extern "C" void re_dbg_score_front(int on) { g_score_front = on; }
 #endif
 RE_SWITCH int g_score_mxdiag = 0;   // timing-only ablation of score_topk_merge_x (scripts/x2_diag.py): 1 no list merge, 2 no re-scoring, 4 no final sort
 #ifdef RE_DEBUG
@@ -1670,6 +1842,54 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             float* Qs = (float*)((char*)ws + w.off_qs);
             const float* Es;
             const unsigned* emax;
+            // starting thresholds from a sample (score_bound_k / score_front_k): n = N/16 items (512 .. 4096), every stride-th row;
+            // every 16th item of a short catalog; every 32nd of a long one when there are few enough users for the sample to be
+            // cut into chunks over >= 1024 workgroups (a 12.5 M-item shard scored for 512 users: the 4 096-item sample of before let
+            // 12 000 items per user through, ~0.5 hits per half tile and wave, so the "quiet" screening rarely applied)
+            const int64_t ugroups = re_cdiv(B, 32);
+            int64_t nchunks = ugroups >= 1024 ? 1 : 1024 / ugroups;
+            int64_t n = N / 16;
+            if (nchunks == 1) n = n < 512 ? 512 : n > 4096 ? 4096 : n;
+            else n = N / 32 < 4096 ? (N / 16 < 4096 ? N / 16 : 4096) : N / 32;
+            if (n < 512) n = 512;
+            if (n > N) n = N;
+            n &= ~31ll;
+            const int64_t stride = n > 0 ? N / n : 1;
+            const double m = (double)(K + 6) * (double)n / (double)N;
+            int r = (int)ceil(m + SC_BOUND_SIGMAS * sqrt(m) + 2.0);
+            r += r & 1;
+            const bool sample = gthr && g_score_sample && n >= 32 && r <= 16;
+            int n_tiles = (int)(n / 32);
+            if (nchunks > n_tiles / 8) nchunks = n_tiles / 8 > 0 ? n_tiles / 8 : 1;
+            const int chunk_tiles = n_tiles > 0 ? (int)re_cdiv(n_tiles, nchunks) : 1;
+            if (n_tiles > 0) nchunks = re_cdiv(n_tiles, chunk_tiles);
+            int n_emax = 1;
+            // ONE front launch (score_front_k) where the sample is not cut into chunks (many users) and the item table -- if it is split here --
+            // is short enough for <= 64 splitting workgroups of <= 16 rounds each (their maxima: 64 words)
+            const int64_t e_rounds = re_cdiv(N * (D / 4), 256);
+            const int nbe = prep ? 0 : (int)(e_rounds < 64 ? e_rounds : 64);
+            if (sample && g_score_front && nchunks == 1 && (prep || e_rounds <= 64 * 16) && ugroups + nbe < 0x7FFFFFFF) {
+                float* own = (float*)((char*)ws + w.off_prep);
+                unsigned* zero_a = (unsigned*)((char*)ws + w.off_gthr) + B;              // gthr2 [B], userflag [B], blockflag [nub]
+                const size_t zero_a_n = (size_t)2 * B + (size_t)p.nub;
+                unsigned* zero_b = emax_own + nbe;                                         // what is left of the 64 words behind them
+                const size_t zero_b_n = (size_t)(64 - nbe);
+                if (D == 64)
+                    hipLaunchKernelGGL(score_front_k<64>, dim3((unsigned)(ugroups + nbe)), dim3(256), 0, s, Q, E, B, N, (unsigned short*)Qs, qnorm,
+                                       (unsigned short*)own, emax_own, (int)ugroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
+                else
+                    hipLaunchKernelGGL(score_front_k<128>, dim3((unsigned)(ugroups + nbe)), dim3(256), 0, s, Q, E, B, N, (unsigned short*)Qs, qnorm,
+                                       (unsigned short*)own, emax_own, (int)ugroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
+                if ((rc = re_launch_status()) != RE_OK) return rc;
+                if (prep) {
+                    Es = (const float*)prep;
+                    emax = (const unsigned*)((const char*)prep + re_align((size_t)N * D * 4));
+                } else {
+                    Es = own;
+                    emax = emax_own;
+                    n_emax = nbe;
+                }
+            } else {
             // the query split zeroes the call's bound / flag words (n_zero is a multiple of 256 bytes) -- it runs FIRST: the item
             // split's device-wide maximum goes into one of those words
             rc = D == 64 ? score_split_launch<64>(Q, B, Qs, qnorm, nullptr, s, (char*)ws + w.off_gthr, w.n_zero)
@@ -1685,38 +1905,17 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
                 Es = own;
                 emax = emax_own;
             }
-            // starting thresholds from a sample (score_bound_k): n = N/16 items (512 .. 4096), every stride-th row
-            if (gthr && g_score_sample) {
-                // every 16th item of a short catalog; every 32nd of a long one when there are few enough users for the sample to be
-                // cut into chunks over >= 1024 workgroups (a 12.5 M-item shard scored for 512 users: the 4 096-item sample of before let
-                // 12 000 items per user through, ~0.5 hits per half tile and wave, so the "quiet" screening rarely applied)
-                const int64_t ugroups = re_cdiv(B, 32);
-                int64_t nchunks = ugroups >= 1024 ? 1 : 1024 / ugroups;
-                int64_t n = N / 16;
-                if (nchunks == 1) n = n < 512 ? 512 : n > 4096 ? 4096 : n;
-                else n = N / 32 < 4096 ? (N / 16 < 4096 ? N / 16 : 4096) : N / 32;
-                if (n < 512) n = 512;
-                if (n > N) n = N;
-                n &= ~31ll;
-                const int64_t stride = n > 0 ? N / n : 1;
-                const double m = (double)(K + 6) * (double)n / (double)N;
-                int r = (int)ceil(m + SC_BOUND_SIGMAS * sqrt(m) + 2.0);
-                r += r & 1;
-                if (n >= 32 && r <= 16) {
-                    const int n_tiles = (int)(n / 32);
-                    if (nchunks > n_tiles / 8) nchunks = n_tiles / 8 > 0 ? n_tiles / 8 : 1;
-                    const int chunk_tiles = (int)re_cdiv(n_tiles, nchunks);
-                    nchunks = re_cdiv(n_tiles, chunk_tiles);
-                    float* bpart = nchunks > 1 ? (float*)((char*)ws + w.off_bp) : (float*)nullptr;
-                    const dim3 bgrid((unsigned)ugroups, (unsigned)nchunks);
-                    if (D == 64) hipLaunchKernelGGL(score_bound_k<64>, bgrid, dim3(128), 0, s, Qs, Es, B, n_tiles, stride, r / 2, gthr, chunk_tiles, bpart);
-                    else hipLaunchKernelGGL(score_bound_k<128>, bgrid, dim3(128), 0, s, Qs, Es, B, n_tiles, stride, r / 2, gthr, chunk_tiles, bpart);
+            if (sample) {
+                float* bpart = nchunks > 1 ? (float*)((char*)ws + w.off_bp) : (float*)nullptr;
+                const dim3 bgrid((unsigned)ugroups, (unsigned)nchunks);
+                if (D == 64) hipLaunchKernelGGL(score_bound_k<64>, bgrid, dim3(128), 0, s, Qs, Es, B, n_tiles, stride, r / 2, gthr, chunk_tiles, bpart);
+                else hipLaunchKernelGGL(score_bound_k<128>, bgrid, dim3(128), 0, s, Qs, Es, B, n_tiles, stride, r / 2, gthr, chunk_tiles, bpart);
+                if ((rc = re_launch_status()) != RE_OK) return rc;
+                if (nchunks > 1) {
+                    hipLaunchKernelGGL(score_bound_merge_k, dim3((unsigned)ugroups), dim3(64), 0, s, bpart, (int)nchunks, B, r / 2, gthr);
                     if ((rc = re_launch_status()) != RE_OK) return rc;
-                    if (nchunks > 1) {
-                        hipLaunchKernelGGL(score_bound_merge_k, dim3((unsigned)ugroups), dim3(64), 0, s, bpart, (int)nchunks, B, r / 2, gthr);
-                        if ((rc = re_launch_status()) != RE_OK) return rc;
-                    }
                 }
+            }
             }
             const int C = score_x2_capacity(p, K);
             float* pt = (float*)((char*)ws + w.off_pt);
@@ -1732,10 +1931,10 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             if ((rc = re_launch_status()) != RE_OK) return rc;
             if (D == 64)
                 hipLaunchKernelGGL(score_topk_merge_x<64>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs);
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax);
             else
                 hipLaunchKernelGGL(score_topk_merge_x<128>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs);
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax);
             if ((rc = re_launch_status()) != RE_OK) return rc;
             // ---- fallback pass over flagged user blocks only (normally none: every workgroup returns at once)
             blockflag = bflag;
