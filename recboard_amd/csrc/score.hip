@@ -1168,81 +1168,142 @@ __global__ __launch_bounds__(128) void score_bound_k(const float* __restrict__ Q
 
 // score_front_k: the three launches in front of the split form's main kernel -- query split (+ zeroing of the call's words), item-table
 // split, starting thresholds -- as ONE launch of independent workgroups (round 5; 7 + 7 + 21 us in three launches before):
-//   blocks [0, ugroups): score_bound_k's job for 32 users, on the fp32 rows: the users' query rows are split here (score_split_k's arithmetic, bit
-//     for bit: the planes go to Qs for the main kernel, the norms to qnorm) and the sample's item rows are split on the fly by v_cvt_pk_bf16_f32
-//     (same rounding for finite values; a threshold need not be valid, only reported honestly) -- so the job waits for no other launch; four
+//   blocks [nbe, nbe + ugroups): score_bound_k's job for 64 users, on the fp32 rows: the users' query rows are split here (score_split_k's arithmetic, bit
+//     for bit: the planes go to Qs for the main kernel, the norms to qnorm) and the sample's item rows are rounded to bf16 on the fly
+//     (v_cvt_pk_bf16_f32; a threshold need not be valid, only reported honestly) -- so the job waits for no other launch; four
 //     waves take the sample tiles t = wave, wave + 4, ... and wave 0 joins the four best-8 lists; the bound word is WRITTEN (0 = none), so it
 //     needs no zeroing;
-//   blocks [ugroups, ugroups + nbe): score_split_k's job on the item table, the device-wide maximum norm as one word PER BLOCK (bmax[j]: no
+//   blocks [0, nbe): score_split_k's job on the item table, the device-wide maximum norm as one word PER BLOCK (bmax[j]: no
 //     atomic, nothing to zero; score_topk_merge_x takes the maximum of the nbe words);
 //   every block: a share of the words that must be zero when the main kernel starts (second thresholds, user / block flags) -- none of them is
 //     written inside this launch.
+#ifdef RE_DEBUG
+__device__ unsigned long long g_front_stamps[256 * 16];   // [block < 256][16]: wave 0's s_memtime at the phases of score_front_k (scripts/front_stamps.py)
+extern "C" int re_dbg_front_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_front_stamps), sizeof(g_front_stamps)) == hipSuccess ? 0 : 1; }
+__device__ unsigned long long g_front_wall[1024 * 2];     // [block < 1024][start, end]: wall_clock64 (100 MHz, one clock for the whole device)
+extern "C" int re_dbg_front_wall(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_front_wall), sizeof(g_front_wall)) == hipSuccess ? 0 : 1; }
+#define FRONT_STAMP(I) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_front_stamps[blockIdx.x * 16 + (I)] = __builtin_readcyclecounter(); \
+                            if (threadIdx.x == 0 && blockIdx.x < 1024 && ((I) == 0 || (I) == 11)) g_front_wall[blockIdx.x * 2 + ((I) == 11)] = wall_clock64(); } while (0)   // (blocks 0 .. nbe - 1 are the splitting ones)
+#else
+#define FRONT_STAMP(I) do { } while (0)
+#endif
+#define SF_NW 8          // waves of a score_front_k workgroup: the tile phases of its 64 users (a wave takes sample tiles wave, wave + SF_NW, ...)
 template <int D>
-__global__ __launch_bounds__(256) void score_front_k(const float* __restrict__ Q, const float* __restrict__ E, int64_t B, int64_t N,
+__global__ __launch_bounds__(64 * SF_NW) void score_front_k(const float* __restrict__ Q, const float* __restrict__ E, int64_t B, int64_t N,
                                                      unsigned short* __restrict__ Qs, float* __restrict__ qnorm, unsigned short* __restrict__ Es,
                                                      unsigned* __restrict__ bmax, int ugroups, int nbe, int n_tiles, int64_t stride, int rhalf,
                                                      unsigned* __restrict__ gthr, unsigned* __restrict__ zero_a, size_t zero_a_n,
                                                      unsigned* __restrict__ zero_b, size_t zero_b_n) {
     constexpr int NS16 = D / 16;
-    __shared__ float lx[3 * 8 * 64];
-    __shared__ unsigned wm[4];
+    __shared__ __align__(16) float lx2[(64 * (D + 4) > SF_NW * 2 * 8 * 64) ? 64 * (D + 4) : SF_NW * 2 * 8 * 64];   // the 64 users' query rows, then the waves' lists
+    __shared__ unsigned wm[SF_NW];
+    __shared__ uint4 bq[2 * (D / 16) * 64];
+    __shared__ __align__(16) unsigned atile[SF_NW * 32 * (D / 2 + 4)];
+    FRONT_STAMP(0);
     {
-        const size_t nb = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+        const size_t nb = (size_t)gridDim.x * (64 * SF_NW), i0 = (size_t)blockIdx.x * (64 * SF_NW) + threadIdx.x;
         for (size_t i = i0; i < zero_a_n; i += nb) zero_a[i] = 0u;
         for (size_t i = i0; i < zero_b_n; i += nb) zero_b[i] = 0u;
     }
-    if ((int)blockIdx.x >= ugroups) {
+    if ((int)blockIdx.x < nbe) {                     // (the splitting workgroups come FIRST in the grid: theirs is the longest chain of memory round trips)
         // ---- item-table split (score_split_k's loop; rows of this block: a grid-stride share)
         constexpr int LPR = D / 4;
         const int64_t total = N * LPR;
         float wmax = 0.0f;
-        for (int64_t base = (int64_t)((int)blockIdx.x - ugroups) * 256; base < total; base += (int64_t)nbe * 256) {
-            const int64_t f = base + threadIdx.x;
-            const bool ok = f < total;
-            const int64_t row = ok ? f / LPR : 0;
-            const int kq = (int)(f % LPR);
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) x = reinterpret_cast<const float4*>(E)[f];
-            const float xv[4] = {x.x, x.y, x.z, x.w};
-            unsigned hi[4], mid[4];
-            double ss = 0.0;
+        // (four rounds' loads in flight at once: a round is one trip to HBM, ~2 us, and a block has up to 16 of them)
+        constexpr int U = 4;
+        constexpr int NT = 64 * SF_NW;
+        for (int64_t base = (int64_t)blockIdx.x * NT; base < total; base += (int64_t)nbe * NT * U) {
+            float4 xs[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                hi[j] = sx_bf16(xv[j]);
-                mid[j] = sx_bf16(xv[j] - __uint_as_float(hi[j] << 16));
-                ss += (double)xv[j] * (double)xv[j];
-            }
-            if (ok) {
-                unsigned short* dst = Es + row * (2 * D) + 4 * kq;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-                *reinterpret_cast<uint2*>(dst + D) = make_uint2(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16));
+            for (int u = 0; u < U; ++u) {
+                const int64_t f = base + (int64_t)u * nbe * NT + threadIdx.x;
+                xs[u] = f < total ? reinterpret_cast<const float4*>(E)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            float nrm = ss > 1e-30 ? sqrtf((float)ss) : (float)sqrt(ss);
-            nrm = nrm * 1.000001f;
-            if (ss > 0.0 && nrm < 1.2e-38f) nrm = 1.2e-38f;
-            if (ok) wmax = (nrm > wmax || nrm != nrm) ? nrm : wmax;
+            for (int u = 0; u < U; ++u) {
+                const int64_t f = base + (int64_t)u * nbe * NT + threadIdx.x;
+                const bool ok = f < total;
+                const int64_t row = ok ? f / LPR : 0;
+                const int kq = (int)(f % LPR);
+                const float xv[4] = {xs[u].x, xs[u].y, xs[u].z, xs[u].w};
+                unsigned hi[4], mid[4];
+                double ss = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hi[j] = sx_bf16(xv[j]);
+                    mid[j] = sx_bf16(xv[j] - __uint_as_float(hi[j] << 16));
+                    ss += (double)xv[j] * (double)xv[j];
+                }
+                if (ok) {
+                    unsigned short* dst = Es + row * (2 * D) + 4 * kq;
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                    *reinterpret_cast<uint2*>(dst + D) = make_uint2(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16));
+                }
+#pragma unroll
+                for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                float nrm = ss > 1e-30 ? sqrtf((float)ss) : (float)sqrt(ss);
+                nrm = nrm * 1.000001f;
+                if (ss > 0.0 && nrm < 1.2e-38f) nrm = 1.2e-38f;
+                if (ok) wmax = (nrm > wmax || nrm != nrm) ? nrm : wmax;
+            }
         }
         unsigned e = __float_as_uint(wmax);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) e = max(e, (unsigned)__shfl_xor((int)e, o, 64));
         if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = e;
         __syncthreads();
-        if (threadIdx.x == 0) bmax[(int)blockIdx.x - ugroups] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (threadIdx.x == 0) {
+            unsigned em = wm[0];
+#pragma unroll
+            for (int w = 1; w < SF_NW; ++w) em = max(em, wm[w]);
+            bmax[blockIdx.x] = em;
+        }
+        FRONT_STAMP(11);
         return;
     }
-    // ---- starting thresholds of 32 users (score_bound_k's job)
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    const int64_t user = (int64_t)blockIdx.x * 32 + c;
-    const bool uok = user < B;
-    float4 bqh[NS16], bqm[NS16];
+    // ---- starting thresholds of 64 users (score_bound_k's job, two groups of 32 users per wave)
+    // What a workgroup's time goes into is the L1's line rate: a wave-load whose lanes each take 16 bytes of their own row touches 32 cache
+    // lines (32+ cycles in the texture path, x 8 loads a tile x 12 waves a CU = the 3 700 cycles a tile measured with one group per wave).
+    // So: every item tile a wave loads serves TWO groups of users (same A fragments, two B operands), and the 64 users' query rows come in
+    // coalesced once per workgroup through LDS (16-byte pieces, consecutive lanes: 8 lines an instruction) instead of row-per-lane by every wave.
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6, gb = (int)blockIdx.x - nbe;   // gb: the workgroup's 64 users
+    constexpr int QLD = D + 4;                                   // LDS row stride (floats): + 16 bytes, so a row-per-lane b128 read is conflict-free
+    float* const qs = lx2;                                       // [64 users][QLD]
     {
-        const float4* qrow = reinterpret_cast<const float4*>(Q + (uok ? user : 0) * D);
+        const int64_t u0 = (int64_t)gb * 64;
+        constexpr int F4 = D / 4;                                // float4 per row
+        for (int f = threadIdx.x; f < 64 * F4; f += 64 * SF_NW) {
+            const int ur = f / F4, k4 = f % F4;
+            const int64_t u = u0 + ur;
+            const float4 v = u < B ? reinterpret_cast<const float4*>(Q + u * D)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(qs + ur * QLD + 4 * k4) = v;
+        }
+    }
+    __syncthreads();
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    // the B operands (the users' rows rounded to bf16, as MFMA fragments) stay in LDS: [group][s][lane] x 16 bytes, read back per product --
+    // in registers they were 32 of 128, and at 128 registers a second workgroup does not fit a CU beside the first (measured: 256 of the
+    // 414 workgroups started at once, the others when those were done)
+    if (wv < 2) {
+        const float* qrow = qs + (wv * 32 + c) * QLD;
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + 16 * s + 8 * h), b = *reinterpret_cast<const float4*>(qrow + 16 * s + 8 * h + 4);
+            const b2 p0 = {(__bf16)a.x, (__bf16)a.y}, p1 = {(__bf16)a.z, (__bf16)a.w}, p2 = {(__bf16)b.x, (__bf16)b.y}, p3 = {(__bf16)b.z, (__bf16)b.w};
+            bq[(wv * NS16 + s) * 64 + lane] = make_uint4(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1),
+                                                         __builtin_bit_cast(unsigned, p2), __builtin_bit_cast(unsigned, p3));
+        }
+    }
+    if (wv < 2) {
+        // the exact planes and norms of group wv's 32 users (score_split_k's arithmetic, bit for bit): for the main kernel and the certificate
+        const int64_t user = ((int64_t)gb * 2 + wv) * 32 + c;
+        const bool uok = user < B;
+        const float* qrow = qs + (wv * 32 + c) * QLD;
         double ss = 0.0;
 #pragma unroll
         for (int s = 0; s < NS16; ++s) {
-            const float4 a = uok ? qrow[4 * s + 2 * h] : make_float4(0.f, 0.f, 0.f, 0.f), b = uok ? qrow[4 * s + 2 * h + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 a = *reinterpret_cast<const float4*>(qrow + 16 * s + 8 * h), b = *reinterpret_cast<const float4*>(qrow + 16 * s + 8 * h + 4);
             const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             unsigned hi[8], mid[8];
 #pragma unroll
@@ -1251,82 +1312,93 @@ __global__ __launch_bounds__(256) void score_front_k(const float* __restrict__ Q
                 mid[j] = sx_bf16(xv[j] - __uint_as_float(hi[j] << 16));
                 ss += (double)xv[j] * (double)xv[j];
             }
-            const uint4 H = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-            const uint4 M = make_uint4(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16), mid[4] | (mid[5] << 16), mid[6] | (mid[7] << 16));
-            bqh[s] = __builtin_bit_cast(float4, H);
-            bqm[s] = __builtin_bit_cast(float4, M);
-            if (wv == 0 && uok) {
+            if (uok) {
                 unsigned short* dst = Qs + user * (2 * D) + 16 * s + 8 * h;
-                *reinterpret_cast<uint4*>(dst) = H;
-                *reinterpret_cast<uint4*>(dst + D) = M;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+                *reinterpret_cast<uint4*>(dst + D) = make_uint4(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16), mid[4] | (mid[5] << 16), mid[6] | (mid[7] << 16));
             }
         }
         ss += __shfl_xor(ss, 32, 64);
         float nrm = ss > 1e-30 ? sqrtf((float)ss) : (float)sqrt(ss);
         nrm = nrm * 1.000001f;
         if (ss > 0.0 && nrm < 1.2e-38f) nrm = 1.2e-38f;
-        if (wv == 0 && h == 0 && uok) qnorm[user] = nrm;
-    }
-    float l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) l[j] = -INFINITY;
-    float4 xa[NS16], xb[NS16], na[NS16], nb_[NS16];
-    auto fetch = [&](int t, float4* fa, float4* fb) {   // the lane's half of the A row of tile t: item (32 t + c) * stride, fp32
-        const float4* xr = reinterpret_cast<const float4*>(E + ((int64_t)(t * 32 + c) * stride) * D);
-#pragma unroll
-        for (int s = 0; s < NS16; ++s) { fa[s] = xr[4 * s + 2 * h]; fb[s] = xr[4 * s + 2 * h + 1]; }
-    };
-    auto insert = [&](float v) {
-#pragma unroll
-        for (int j = 7; j >= 1; --j) l[j] = __builtin_amdgcn_fmed3f(v, l[j], l[j - 1]);
-        l[0] = fmaxf(v, l[0]);
-    };
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    auto split2 = [](float x, float y, unsigned& hw, unsigned& mw) {
-        const b2 hv = {(__bf16)x, (__bf16)y};
-        hw = __builtin_bit_cast(unsigned, hv);
-        const float hx = __uint_as_float(hw << 16), hy = __uint_as_float(hw & 0xFFFF0000u);
-        const b2 mv = {(__bf16)(x - hx), (__bf16)(y - hy)};
-        mw = __builtin_bit_cast(unsigned, mv);
-    };
-    if (wv < n_tiles) fetch(wv, xa, xb);
-    for (int t = wv; t < n_tiles; t += 4) {
-        fetch(t + 4 < n_tiles ? t + 4 : t, na, nb_);   // (in flight under this tile's MFMAs and insertions)
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < NS16; ++s) {
-            uint4 H, M;
-            split2(xa[s].x, xa[s].y, H.x, M.x); split2(xa[s].z, xa[s].w, H.y, M.y);
-            split2(xb[s].x, xb[s].y, H.z, M.z); split2(xb[s].z, xb[s].w, H.w, M.w);
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, H), am = __builtin_bit_cast(bf16x8, M);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bqm[s]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bqh[s]), acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) insert(acc[r]);
-#pragma unroll
-        for (int s = 0; s < NS16; ++s) { xa[s] = na[s]; xb[s] = nb_[s]; }
-    }
-    // waves 1 - 3 hand their lists over; a list that lost entries beyond its 8 only makes the bound lower (safe side)
-    if (wv != 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lx[((wv - 1) * 8 + j) * 64 + lane] = l[j];
+        if (h == 0 && uok) qnorm[user] = nrm;
     }
     __syncthreads();
-    if (wv == 0) {
+    FRONT_STAMP(1);
+    float l[2][8];
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
+    for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) insert(lx[(w * 8 + j) * 64 + lane]);
-        float mine = l[0];
+        for (int j = 0; j < 8; ++j) l[g2][j] = -INFINITY;
+    // An item tile (32 sample rows) comes in COALESCED -- lane L takes 16 bytes at offset 16 L of a 1 KB piece (4 rows at D = 64): 8 cache lines an
+    // instruction, where a row per lane touched 32 -- is rounded to bf16 and goes through the wave's own LDS buffer ([row][D bf16 + 16 B]) into
+    // the MFMA's A layout (lane (c, h): 8 k of row c).  The wave writes and reads its own buffer: no barrier.
+    constexpr int F4 = D / 4, RPI = 64 / F4, NLD = 32 / RPI;     // float4 per row; rows per load instruction; load instructions per tile
+    constexpr int ARS = D / 2 + 4;                               // the buffer's row stride in dwords (16-byte aligned rows)
+    unsigned* const at = atile + wv * 32 * ARS;
+    const int lrow = lane / F4, lk4 = lane % F4;
+    float4 raw[NLD];
+    const int64_t jstep = (int64_t)RPI * stride * D;             // floats between the rows of two consecutive load instructions (uniform)
+    auto fetch = [&](int t) {
+        const float* base = E + ((int64_t)(t * 32 + lrow) * stride) * D + 4 * lk4;   // sample row r = item r stride
 #pragma unroll
-        for (int j = 1; j < 8; ++j) mine = (j == rhalf - 1) ? l[j] : mine;
-        const float bound = fminf(mine, __shfl_xor(mine, 32, 64));
-        if (h == 0 && uok) gthr[user] = bound > -INFINITY ? sr_enc(bound) : 0u;
+        for (int j = 0; j < NLD; ++j) raw[j] = *reinterpret_cast<const float4*>(base + j * jstep);
+    };
+    auto insert = [&](float (&ll)[8], float v) {
+#pragma unroll
+        for (int j = 7; j >= 1; --j) ll[j] = __builtin_amdgcn_fmed3f(v, ll[j], ll[j - 1]);
+        ll[0] = fmaxf(v, ll[0]);
+    };
+    // A starting threshold is a filter value, not a result (a user whose bound came out too high fails the certificate and is redone exactly):
+    // the sample is scored with the hi planes alone -- one MFMA per 16 k, |error| <= 2^-7 |q| |e|, a few per cent of the gap between the bound's
+    // rank (~ 4 (K + 6)) and the K + 6-th best score it must stay under -- and of every two scores a lane gets only the larger one is inserted
+    // (the r-th best of pair maxima is <= the r-th best: the safe side).
+    if (wv < n_tiles) fetch(wv);
+    for (int t = wv; t < n_tiles; t += SF_NW) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const b2 p0 = {(__bf16)raw[j].x, (__bf16)raw[j].y}, p1 = {(__bf16)raw[j].z, (__bf16)raw[j].w};
+            *reinterpret_cast<uint2*>(at + (j * RPI + lrow) * ARS + 2 * lk4) = make_uint2(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1));
+        }
+        if (t + SF_NW < n_tiles) fetch(t + SF_NW);               // (in flight under this tile's products and insertions)
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) {
+            const bf16x8 H = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(at + c * ARS + 8 * s + 4 * h));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(H, __builtin_bit_cast(bf16x8, bq[s * 64 + lane]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(H, __builtin_bit_cast(bf16x8, bq[(NS16 + s) * 64 + lane]), acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) { insert(l[0], fmaxf(acc0[r], acc0[r + 1])); insert(l[1], fmaxf(acc1[r], acc1[r + 1])); }
+        FRONT_STAMP(2 + ((t / SF_NW) & 7));
     }
+    FRONT_STAMP(10);
+    // the waves' lists of a group are joined by wave `group`; a list that lost entries beyond its 8 only makes the bound lower (safe side)
+    __syncthreads();                                             // (the query rows in LDS are done with: the lists go over them)
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lx2[((wv * 2 + g2) * 8 + j) * 64 + lane] = l[g2][j];
+    __syncthreads();
+    if (wv < 2) {
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < SF_NW; ++w)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) insert(m, lx2[((w * 2 + wv) * 8 + j) * 64 + lane]);
+        float mine = m[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mine = (j == rhalf - 1) ? m[j] : mine;
+        const float bound = fminf(mine, __shfl_xor(mine, 32, 64));
+        const int64_t user = ((int64_t)gb * 2 + wv) * 32 + c;
+        if (h == 0 && user < B) gthr[user] = bound > -INFINITY ? sr_enc(bound) : 0u;
+    }
+    FRONT_STAMP(11);
 }
 
 // joins the chunks of score_bound_k: one wave per 32 users, lane = (user, half) as there
@@ -1866,20 +1938,21 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             int n_emax = 1;
             // ONE front launch (score_front_k) where the sample is not cut into chunks (many users) and the item table -- if it is split here --
             // is short enough for <= 64 splitting workgroups of <= 16 rounds each (their maxima: 64 words)
-            const int64_t e_rounds = re_cdiv(N * (D / 4), 256);
+            const int64_t e_rounds = re_cdiv(N * (D / 4), 64 * SF_NW);
             const int nbe = prep ? 0 : (int)(e_rounds < 64 ? e_rounds : 64);
-            if (sample && g_score_front && nchunks == 1 && (prep || e_rounds <= 64 * 16) && ugroups + nbe < 0x7FFFFFFF) {
+            const int64_t fgroups = re_cdiv(B, 64);                                       // (64 users per workgroup of the front launch)
+            if (sample && g_score_front && nchunks == 1 && (prep || e_rounds <= 64 * 16) && fgroups + nbe < 0x7FFFFFFF) {
                 float* own = (float*)((char*)ws + w.off_prep);
                 unsigned* zero_a = (unsigned*)((char*)ws + w.off_gthr) + B;              // gthr2 [B], userflag [B], blockflag [nub]
                 const size_t zero_a_n = (size_t)2 * B + (size_t)p.nub;
                 unsigned* zero_b = emax_own + nbe;                                         // what is left of the 64 words behind them
                 const size_t zero_b_n = (size_t)(64 - nbe);
                 if (D == 64)
-                    hipLaunchKernelGGL(score_front_k<64>, dim3((unsigned)(ugroups + nbe)), dim3(256), 0, s, Q, E, B, N, (unsigned short*)Qs, qnorm,
-                                       (unsigned short*)own, emax_own, (int)ugroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
+                    hipLaunchKernelGGL(score_front_k<64>, dim3((unsigned)(fgroups + nbe)), dim3(64 * SF_NW), 0, s, Q, E, B, N, (unsigned short*)Qs, qnorm,
+                                       (unsigned short*)own, emax_own, (int)fgroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
                 else
-                    hipLaunchKernelGGL(score_front_k<128>, dim3((unsigned)(ugroups + nbe)), dim3(256), 0, s, Q, E, B, N, (unsigned short*)Qs, qnorm,
-                                       (unsigned short*)own, emax_own, (int)ugroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
+                    hipLaunchKernelGGL(score_front_k<128>, dim3((unsigned)(fgroups + nbe)), dim3(64 * SF_NW), 0, s, Q, E, B, N, (unsigned short*)Qs, qnorm,
+                                       (unsigned short*)own, emax_own, (int)fgroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
                 if ((rc = re_launch_status()) != RE_OK) return rc;
                 if (prep) {
                     Es = (const float*)prep;
