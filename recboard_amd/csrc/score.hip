@@ -1270,9 +1270,23 @@ __global__ __launch_bounds__(64 * SF_NW) void score_front_k(const float* __restr
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6, gb = (int)blockIdx.x - nbe;   // gb: the workgroup's 64 users
     constexpr int QLD = D + 4;                                   // LDS row stride (floats): + 16 bytes, so a row-per-lane b128 read is conflict-free
     float* const qs = lx2;                                       // [64 users][QLD]
+    // An item tile (32 sample rows) comes in COALESCED -- lane L takes 16 bytes at offset 16 L of a 1 KB piece (4 rows at D = 64): 8 cache lines an
+    // instruction, where a row per lane touched 32 -- is rounded to bf16 and goes through the wave's own LDS buffer ([row][D bf16 + 16 B]) into
+    // the MFMA's A layout (lane (c, h): 8 k of row c).  The wave writes and reads its own buffer: no barrier.
+    constexpr int F4 = D / 4, RPI = 64 / F4, NLD = 32 / RPI;     // float4 per row; rows per load instruction; load instructions per tile
+    constexpr int ARS = D / 2 + 4;                               // the buffer's row stride in dwords (16-byte aligned rows)
+    unsigned* const at = atile + wv * 32 * ARS;
+    const int lrow = lane / F4, lk4 = lane % F4;
+    float4 raw[NLD];
+    const int64_t jstep = (int64_t)RPI * stride * D;             // floats between the rows of two consecutive load instructions (uniform)
+    auto fetch = [&](int t) {
+        const float* base = E + ((int64_t)(t * 32 + lrow) * stride) * D + 4 * lk4;   // sample row r = item r stride
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) raw[j] = *reinterpret_cast<const float4*>(base + j * jstep);
+    };
+    if (wv < n_tiles) fetch(wv);                                 // (the first tile's rows: requested before the query rows, two trips to memory overlap)
     {
         const int64_t u0 = (int64_t)gb * 64;
-        constexpr int F4 = D / 4;                                // float4 per row
         for (int f = threadIdx.x; f < 64 * F4; f += 64 * SF_NW) {
             const int ur = f / F4, k4 = f % F4;
             const int64_t u = u0 + ur;
@@ -1331,20 +1345,6 @@ __global__ __launch_bounds__(64 * SF_NW) void score_front_k(const float* __restr
     for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) l[g2][j] = -INFINITY;
-    // An item tile (32 sample rows) comes in COALESCED -- lane L takes 16 bytes at offset 16 L of a 1 KB piece (4 rows at D = 64): 8 cache lines an
-    // instruction, where a row per lane touched 32 -- is rounded to bf16 and goes through the wave's own LDS buffer ([row][D bf16 + 16 B]) into
-    // the MFMA's A layout (lane (c, h): 8 k of row c).  The wave writes and reads its own buffer: no barrier.
-    constexpr int F4 = D / 4, RPI = 64 / F4, NLD = 32 / RPI;     // float4 per row; rows per load instruction; load instructions per tile
-    constexpr int ARS = D / 2 + 4;                               // the buffer's row stride in dwords (16-byte aligned rows)
-    unsigned* const at = atile + wv * 32 * ARS;
-    const int lrow = lane / F4, lk4 = lane % F4;
-    float4 raw[NLD];
-    const int64_t jstep = (int64_t)RPI * stride * D;             // floats between the rows of two consecutive load instructions (uniform)
-    auto fetch = [&](int t) {
-        const float* base = E + ((int64_t)(t * 32 + lrow) * stride) * D + 4 * lk4;   // sample row r = item r stride
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) raw[j] = *reinterpret_cast<const float4*>(base + j * jstep);
-    };
     auto insert = [&](float (&ll)[8], float v) {
 #pragma unroll
         for (int j = 7; j >= 1; --j) ll[j] = __builtin_amdgcn_fmed3f(v, ll[j], ll[j - 1]);
@@ -1354,25 +1354,30 @@ __global__ __launch_bounds__(64 * SF_NW) void score_front_k(const float* __restr
     // the sample is scored with the hi planes alone -- one MFMA per 16 k, |error| <= 2^-7 |q| |e|, a few per cent of the gap between the bound's
     // rank (~ 4 (K + 6)) and the K + 6-th best score it must stay under -- and of every two scores a lane gets only the larger one is inserted
     // (the r-th best of pair maxima is <= the r-th best: the safe side).
-    if (wv < n_tiles) fetch(wv);
     for (int t = wv; t < n_tiles; t += SF_NW) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const b2 p0 = {(__bf16)raw[j].x, (__bf16)raw[j].y}, p1 = {(__bf16)raw[j].z, (__bf16)raw[j].w};
             *reinterpret_cast<uint2*>(at + (j * RPI + lrow) * ARS + 2 * lk4) = make_uint2(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1));
         }
+        __builtin_amdgcn_sched_barrier(0);                       // (phases kept apart: overlapped by the scheduler they cost 16 more registers than a second workgroup per CU allows)
         if (t + SF_NW < n_tiles) fetch(t + SF_NW);               // (in flight under this tile's products and insertions)
-        f32x16 acc0, acc1;
+        __builtin_amdgcn_sched_barrier(0);
+        // (one group after the other: the second accumulator is 16 registers that decide whether two workgroups fit a CU)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        for (int g2 = 0; g2 < 2; ++g2) {
+            f32x16 acc;
 #pragma unroll
-        for (int s = 0; s < NS16; ++s) {
-            const bf16x8 H = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(at + c * ARS + 8 * s + 4 * h));
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(H, __builtin_bit_cast(bf16x8, bq[s * 64 + lane]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(H, __builtin_bit_cast(bf16x8, bq[(NS16 + s) * 64 + lane]), acc1, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < NS16; ++s) {
+                const bf16x8 H = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(at + c * ARS + 8 * s + 4 * h));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(H, __builtin_bit_cast(bf16x8, bq[(g2 * NS16 + s) * 64 + lane]), acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) insert(l[g2], fmaxf(acc[r], acc[r + 1]));
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) { insert(l[0], fmaxf(acc0[r], acc0[r + 1])); insert(l[1], fmaxf(acc1[r], acc1[r + 1])); }
         FRONT_STAMP(2 + ((t / SF_NW) & 7));
     }
     FRONT_STAMP(10);
