@@ -1,0 +1,161 @@
+// The reduction behind the encoder's weight-gradient jobs: the split partials of the L x 6 D x D matrix gradients in split order, the per-tile (or
+// per-workgroup) slabs of the vector gradients in a fixed tree, the position table's chunk partials in chunk order -- and, optionally, the dense
+// Adam of every element it finishes.  As a launch of its own (enc_grad_reduce_k, enc_wgrad.hip) or as the LAST jobs of the step tail's ticket
+// queue (enc_tail.hip, round 5: one launch and its 7 us less per step).  A "virtual block" = 256 threads' worth of the old launch's grid:
+//   [0, nmat_blocks): 256 elements of the matrix gradients each;  then nvec_blocks: 64 columns of one (block, vector);  then npos_blocks.
+#pragma once
+#include "enc_wgrad_job.h"
+
+// optional: the dense Adam of every gradient element the reduction finishes (re_adam_fuse: arenas of one layout)
+struct EncAdam {
+    const float* gbase;
+    float *p, *m, *v;
+    const float* hyper;
+    float b1, b2, omb1, omb2, eps, wd;
+    const unsigned* gate;   // optional device word: non-zero = gradients are written, parameters and moments stay (a hand-over of this step timed out)
+};
+// What the end of an element's chain needs and does not depend on the partial sums -- the step scalars, the gate word, the element's parameter
+// and moments -- is requested FIRST (eg_pre, unconditional loads), together with the partials: the launch is then one memory round trip deep
+// instead of three (partials; scalars, on which a branch depended; parameter and moments).
+struct EgPre {
+    float ss, ib, p, m, v;
+};
+__device__ __forceinline__ EgPre eg_pre(const EncAdam& A, const float* d) {
+    EgPre e{0.f, 0.f, 0.f, 0.f, 0.f};
+    if (A.p) {
+        const int64_t i = d - A.gbase;
+        e.p = A.p[i]; e.m = A.m[i]; e.v = A.v[i];
+        const unsigned gate_w = *(A.gate ? A.gate : reinterpret_cast<const unsigned*>(A.hyper));
+        e.ss = A.hyper[0];
+        e.ib = A.hyper[1];
+        e.ib = (A.gate && gate_w != 0u) ? 0.f : e.ib;   // ({0, 0}: the caller gated this step off; gate: a hand-over of this step timed out)
+    }
+    return e;
+}
+__device__ __forceinline__ void eg_put(const EncAdam& A, float* d, float g, const EgPre& e) {
+    *d = g;
+    if (A.p && e.ib != 0.f) {
+        const int64_t i = d - A.gbase;
+        float pp = e.p, mm = e.m, vv = e.v;
+        re_adam1(pp, mm, vv, g, A.b1, A.b2, A.omb1, A.omb2, e.ss, e.ib, A.eps, A.wd);     // (adam_vec4_dev's arithmetic)
+        A.p[i] = pp; A.m[i] = mm; A.v[i] = vv;
+    }
+}
+
+struct EncGradDst {
+    float* p[SE_MAX_BLOCKS][14];  // per block: ABI order of the 12 block gradients, then g_last_w, g_last_b (last block only)
+};
+
+struct EgReduce {
+    const float *part, *slab;
+    int nwg;
+    const void* planp;
+    int B, S, D, L;
+    EncGradDst dst;
+    int nmat_blocks, nvec_blocks, npos_blocks;
+    const float* ppart;
+    float inv_scale;
+    float* dPtab;
+    int by_tile;
+    EncAdam AD;
+};
+
+// position-table gradient: the chunk partials of the position jobs in chunk order, / scale.  vb in [0, npos_blocks), tid in [0, 256)
+// COHERENT: the partials were written earlier in THIS launch by other workgroups (agent-scope stores, a done count): read them with agent-scope
+// loads, past whatever this XCD's L2 holds
+template <bool COHERENT = false>
+__device__ __forceinline__ float eg_ld(const float* p) {
+    if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COHERENT = false>
+__device__ __forceinline__ void eg_reduce_pos(const EgReduce& R, int vb, int tid) {
+    const int e = vb * 256 + tid;
+    if (e >= R.S * R.D) return;
+    const int p = e / R.D, cc = e % R.D, nch = (R.B + 63) / 64;
+    const EgPre pre = eg_pre(R.AD, R.dPtab + e);
+    float s = 0.f;
+    for (int ch = 0; ch < nch; ++ch) s += eg_ld<COHERENT>(R.ppart + ((int64_t)p * nch + ch) * R.D + cc);
+    eg_put(R.AD, R.dPtab + e, s * R.inv_scale, pre);
+}
+
+// 256 elements of the L * 6 * D * D weight gradients (sum of the wg_nsplit(D) partials).  vb in [0, nmat_blocks)
+template <bool COHERENT = false>
+__device__ __forceinline__ void eg_reduce_mat(const EgReduce& R, int vb, int tid) {
+    const int64_t e = (int64_t)vb * 256 + tid;
+    const int dd = R.D * R.D;
+    if (e >= (int64_t)R.L * EG_NMAT * dd) return;
+    const int lm = (int)(e / dd), off = (int)(e % dd);
+    const int nsplit = wg_nsplit(R.D);
+    const float* p = R.part + (int64_t)lm * nsplit * dd + off;
+    const int l = lm / EG_NMAT, m = lm % EG_NMAT;
+    float* const* P = R.dst.p[l];
+    float* d = (m == 0) ? P[10] : (m == 1) ? P[8] : (m == 2) ? P[4] : P[2] + (m - 3) * dd;
+    const EgPre pre = eg_pre(R.AD, d + off);
+    float v[WG_NSPLIT_MAX];
+#pragma unroll
+    for (int i = 0; i < WG_NSPLIT_MAX; ++i) v[i] = eg_ld<COHERENT>(p + (int64_t)(i < nsplit ? i : 0) * dd);   // (clamped, unconditional)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < WG_NSPLIT_MAX; ++i) s += i < nsplit ? v[i] : 0.f;                    // (x + 0 = x: the partials in split order)
+    eg_put(R.AD, d + off, s, pre);
+}
+
+// 64 columns of one (block, vector), summed over the slabs of the workgroups (tiles) that had work: four waves x a fixed order, joined through
+// `red` ([4][64] floats of LDS) across ONE barrier the caller provides between the two halves.  job in [0, nvec_blocks) (or beyond: no-op halves)
+struct EgVec { float* dvec; EgPre pre; float s; };
+__device__ __forceinline__ EgVec eg_reduce_vec_a(const EgReduce& R, int job, int tid, float (*red)[64]) {
+    EgVec V{nullptr, EgPre{0.f, 0.f, 0.f, 0.f, 0.f}, 0.f};
+    const int lane = tid & 63, wave = tid >> 6;
+    if (job >= R.nvec_blocks) { red[wave][lane] = 0.f; return V; }
+    const int D = R.D, L = R.L;
+    const int cgs = D / 64;
+    const int cg = job % cgs, v = (job / cgs) % EG_NVEC, l = job / (cgs * EG_NVEC);
+    const EncPlan PL = enc_plan_view(R.planp, R.B, R.S);
+    const int n_items = PL.hdr[0];
+    // slab rows: one per workgroup that had work, or -- steps that ran one tile per workgroup (enc_tile.hip) -- one per tile
+    const int nact = (R.by_tile && PL.hdr[7] == 1) ? PL.hdr[1] : (n_items < R.nwg ? n_items : R.nwg);
+    if (!(v >= 10 && l != L - 1)) {
+        float* const* P = R.dst.p[l];
+        switch (v) {
+            case 0: case 1: case 2: V.dvec = P[3] + v * D; break;
+            case 3: V.dvec = P[5]; break;
+            case 4: V.dvec = P[9]; break;
+            case 5: V.dvec = P[11]; break;
+            case 6: V.dvec = P[0]; break;
+            case 7: V.dvec = P[1]; break;
+            case 8: V.dvec = P[6]; break;
+            case 9: V.dvec = P[7]; break;
+            case 10: V.dvec = P[12]; break;
+            default: V.dvec = P[13]; break;
+        }
+        V.dvec += cg * 64 + lane;
+    }
+    if (V.dvec && wave == 0) V.pre = eg_pre(R.AD, V.dvec);
+    const float* sl = R.slab + ((int64_t)l * EG_NVEC + v) * D + cg * 64 + lane;
+    const int64_t stride = (int64_t)L * EG_NVEC * D;
+    float s = 0.f;
+    // (groups of 8 slabs, four groups' loads in flight at once: a group is a memory round trip, a Beauty-shaped batch has eight of them per wave;
+    //  the sums are the one-group-at-a-time ones, bit for bit)
+    for (int w0 = wave; w0 < nact; w0 += 128) {
+        float x[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int w = w0 + 32 * u + 4 * q;
+                x[u][q] = (w < nact) ? sl[(int64_t)w * stride] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (w0 + 32 * u < nact) s += ((x[u][0] + x[u][1]) + (x[u][2] + x[u][3])) + ((x[u][4] + x[u][5]) + (x[u][6] + x[u][7]));
+    }
+    red[wave][lane] = s;
+    return V;
+}
+__device__ __forceinline__ void eg_reduce_vec_b(const EgReduce& R, const EgVec& V, int tid, float (*red)[64]) {
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave != 0 || !V.dvec) return;
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    eg_put(R.AD, V.dvec, s, V.pre);
+}

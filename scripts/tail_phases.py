@@ -74,3 +74,8 @@ if rows:
 rel = lambda i: np.round(np.median([(t[w, i] - t[w, 0]) / 1e3 for w in range(NWG) if t[w, i] > 0 and w not in pw] or [np.nan]), 1)
 print("medians relative to the workgroup's start (kcycles): scatter start", rel(20), "key count known", rel(21), "keys scanned", rel(22), "rows added", rel(23),
       "rows stored", rel(24), "| scatter end", rel(1), "| at first barrier", rel(19), "passed", rel(16), "ticket read", rel(17), "job called", rel(18), "job entry", rel(8), "| end", rel(15))
+rw = [(int(t[w, 26]) - 1, (t[w, 24] - t[w, 0]) / 1e3, (t[w, 25] - t[w, 24]) / 1e3) for w in range(NWG) if t[w, 26] > 0]
+if rw:
+    rw.sort()
+    print("reduction tickets (the LAST one a workgroup ran): ticket, entered at (kcycles after its start), took (kcycles)")
+    print("  ", [(a, round(b, 1), round(c, 1)) for a, b, c in rw][:64])
