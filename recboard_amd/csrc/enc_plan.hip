@@ -188,6 +188,8 @@ static int step_stage_launch(uint32_t* state, uint32_t seed, int64_t step, doubl
     re_clear_error();
     if (!state || step < 1) return RE_EINVAL;
     if ((M.seq || M.SP.ptr) && !mail) return RE_EINVAL;
+    PlMail Me = M;
+    Me.epoch = (unsigned)(step & 0x3FFFFFFF) + 2u;          // (the span hand-over flag's value for this step: never 0, 1 or the value of two steps ago)
     if ((prev_loss == nullptr) != (loss_acc == nullptr)) return RE_EINVAL;
     PlWeights WP{};
     const int rc = pl_fill_weights(WP, block_params, last_w, last_b, L, D, B, S, tape, tape_bytes, ws, ws_bytes);
@@ -195,7 +197,7 @@ static int step_stage_launch(uint32_t* state, uint32_t seed, int64_t step, doubl
     const PlLoss LA{prev_loss, loss_acc, loss_weight};
     const float ss = (float)(lr / (1.0 - pow(beta1, (double)step))), ib = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
     hipLaunchKernelGGL(sasrec_step_stage_k, dim3(1 + (unsigned)WP.nblocks), dim3(PL_NT), 0, (hipStream_t)stream, state, seed, ss, ib, WP, LA,
-                       (PlMail*)mail, M);
+                       (PlMail*)mail, Me);
     return re_launch_status();
 }
 

@@ -122,6 +122,8 @@ struct PlWeights {   // optional extra work of the launch: the one-tile-per-work
 struct PlMail {
     const int64_t *seq, *pos, *neg;
     PlSample SP;
+    unsigned epoch;   // the step's number + 1 (never 0, never the value of two steps ago): what this step's span hand-over flag is set to and waited for
+    unsigned pad_;
 };
 #define PL_MAIL_WORDS 16   // int64 words a mailbox occupies (>= sizeof(PlMail) / 8)
 static_assert(sizeof(PlMail) <= PL_MAIL_WORDS * 8, "mailbox size");
@@ -184,13 +186,14 @@ __device__ __forceinline__ void pl_elementwise(int job, int njobs, const int64_t
 #define PL_LDS_BYTES (PL_OFF_PLACE + PL_LDS_B * 4)
 // mode 0: the whole plan.  Modes 1 and 2 cut it in two for the step's tail launch (enc_tail.hip), where the plan is the longest job of the
 // queue: 1 = the spans alone (phase 1: the only part that reads the batch -- two memory round trips for 512 sequences), left in the plan
-// buffer's scratch words with a flag behind an agent-scope release; 2 = the rest, by ANOTHER workgroup that waits for that flag (bounded:
-// when it does not come it computes the spans itself) and clears it again.
+// buffer's scratch words with a flag -- the step's epoch (PlMail.epoch), never reset -- behind an agent-scope release; 2 = the rest, by ANOTHER
+// workgroup that waits for the flag to show this step's epoch (bounded: when it does not come it computes the spans itself).
 #define PL_MODE_ALL 0
 #define PL_MODE_SPANS 1
 #define PL_MODE_REST 2
 __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, int S, int ncu, int max_tiles, int split_long,
-                                        int* __restrict__ count, int* __restrict__ plan, const PlSample& SP, unsigned char* L, int mode = PL_MODE_ALL) {
+                                        int* __restrict__ count, int* __restrict__ plan, const PlSample& SP, unsigned char* L, int mode = PL_MODE_ALL,
+                                        unsigned epoch = 1u) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if defined(ENC_PROFILE) && defined(PL_PLAN_KERNEL)
     unsigned long long pl_t[6];
@@ -227,7 +230,10 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
         int* const s_got = reinterpret_cast<int*>(L + PL_NCLS * PL_NW * 4) + 2 * PL_NCLS + 16 + PL_NW + 4;     // (= &s_nsplit: written again in phase 2)
         if (tid == 0) {
             int spins = 0;
-            while (__hip_atomic_load(g_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(4);
+            // (the flag is an EPOCH, never reset: a spans workgroup that publishes after this one gave up -- it is the grid's last block and need not
+            //  be resident while this one waits -- leaves a value no later step waits for; with a 0 / 1 flag reset at the end of this job such a
+            //  late publish stayed in the buffer and the buffer's next use read the previous batch's spans)
+            while (__hip_atomic_load(g_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(4);
             *s_got = spins < (1 << 16) ? 1 : 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -290,7 +296,7 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(g_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         return;
@@ -401,7 +407,6 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
         const int row = in_lds ? s_place[b0] : g_place[b0];
         for (int off = tid & 7; off < span; off += 8) rowmap[row + off] = make_int2(b0 * S + (S - span) + off, S - span);
     }
-    if (mode == PL_MODE_REST && tid == 0) __hip_atomic_store(g_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the buffer's next use starts from zero)
 #ifdef TAIL_PROFILE
     __syncthreads();
     PL_STAMP(3);

@@ -176,7 +176,7 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
         if (t < n_prep) {
             const PlMail M = *TP.mail;
             if (M.seq || M.SP.ptr) {                           // (uniform)
-                if (t == 0) pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_REST);
+                if (t == 0) pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_REST, M.epoch);
                 else pl_elementwise(t - 1, TP.n_ew, M.seq, M.pos, M.neg, TP.B, TP.S, TP.seq_out, TP.pos_out, TP.neg_out, TP.valid, TP.rows_all, M.SP);
             }
             continue;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void tail_spans(const TailPrep& TP, float* lds) {
     if (!TP.mail || blockIdx.x != gridDim.x - 1) return;
     const PlMail M = *TP.mail;
     if (M.seq || M.SP.ptr)
-        pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_SPANS);
+        pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_SPANS, M.epoch);
     __syncthreads();
 }
 
