@@ -17,9 +17,14 @@ adapter is returned:
      code, while the optimizer / scheduler calls are recorded; the gradients it hands to `optimizer.step()` (after any clipping, with any
      extra loss terms) are kept; module, optimizer, scheduler and monitors are restored afterwards;
   3. the engine takes one step on the same batch from the same parameters: its gradients must equal the script's own step in DOUBLE
-     precision, tensor by tensor, to 1e-3 in the L2 sense and 2e-2 of the largest entry for the worst one (or a few times the script's own
-     fp32 rounding where that is larger), and its parameter update must equal torch's Adam formula on those gradients with the
-     optimizer's own numbers;
+     precision, tensor by tensor, to GRAD_TOL = 2e-2 in the L2 sense and 10 x that (0.2 of the tensor's largest entry) for the worst one
+     -- or 4 x the script's own fp32 rounding of that tensor, or 1e-6 of the model-wide largest gradient, where those are larger -- and its
+     parameter update must equal torch's Adam formula on those gradients with the optimizer's own numbers.  The bound is wide because a
+     ReLU pre-activation within rounding of zero may fall on the other side in the engine's arithmetic (one flipped gate moves a whole row
+     of the FFN's first map); measured on the four reference scripts the distance is 7e-6 (median) to 3e-3 (worst).  What the bound does
+     NOT catch: a script whose step differs from the engine's by a small extra term (an auxiliary loss scaled by <= 1e-2, light label
+     smoothing) is accepted and then trained WITHOUT that term -- `--engine module` is the answer for such scripts; the probe is one
+     step deep, so a non-default beta pair is read from the optimizer object, not observed;
   4. the recorded call pattern must be one the adapter replays: one `optimizer.step()` per batch; the scheduler not at all, or once per epoch
      (in front of the loop with `coach._best`, as DeepFM/main.py:256, or behind it without arguments).
 Anything else -- and any exception on the way -- logs a warning that names the model and the reason, and the script runs on its own torch
