@@ -668,7 +668,7 @@ def main():
         t_iid = event_time_ms(lambda: ops.score_topk(q_iid, E_iid, seen_ptr, seen_idx, K), 20)
         tf_iid = flops / (t_iid * 1e-3) / 1e12
         line["items_scored_per_sec"] = round(U * N / (t_score * 1e-3), 1)
-        line["roofline_score"] = {"kernel": "re_score_topk: score_split_k x2, score_kernel_reg<64,28,28,split> (bf16 hi/mid products on the XDL "
+        line["roofline_score"] = {"kernel": "re_score_topk: score_front_k (query split + item split + starting thresholds, one launch), score_kernel_reg<64,28,28,split> (bf16 hi/mid products on the XDL "
                                             "pipe), score_topk_merge_x<64> (exact fp32 re-scoring + certificate), fallback pass",
                             "bound": "mfma", "achieved": round(tf, 2),
                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),

@@ -1942,29 +1942,32 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             if (n_tiles > 0) nchunks = re_cdiv(n_tiles, chunk_tiles);
             int n_emax = 1;
             // ONE front launch (score_front_k) where the sample is not cut into chunks (many users) and the item table -- if it is split here --
-            // is short enough for <= 64 splitting workgroups of <= 16 rounds each (their maxima: 64 words)
+            // is short enough for <= 62 splitting workgroups of <= 16 rounds each (their maxima: 62 of the 64 words)
             const int64_t e_rounds = re_cdiv(N * (D / 4), 64 * SF_NW);
-            const int nbe = prep ? 0 : (int)(e_rounds < 64 ? e_rounds : 64);
+            const int nbe = prep ? 0 : (int)(e_rounds < 62 ? e_rounds : 62);
             const int64_t fgroups = re_cdiv(B, 64);                                       // (64 users per workgroup of the front launch)
-            if (sample && g_score_front && nchunks == 1 && (prep || e_rounds <= 64 * 16) && fgroups + nbe < 0x7FFFFFFF) {
+            if (sample && g_score_front && nchunks == 1 && (prep || e_rounds <= 62 * 16) && fgroups + nbe < 0x7FFFFFFF) {
                 float* own = (float*)((char*)ws + w.off_prep);
-                unsigned* zero_a = (unsigned*)((char*)ws + w.off_gthr) + B;              // gthr2 [B], userflag [B], blockflag [nub]
-                const size_t zero_a_n = (size_t)2 * B + (size_t)p.nub;
-                unsigned* zero_b = emax_own + nbe;                                         // what is left of the 64 words behind them
-                const size_t zero_b_n = (size_t)(64 - nbe);
+                // gthr2 [B], userflag [B], blockflag [nub], and the first two of the 64 words behind them: [0] the single-word maximum (unused
+                // here), [1] "somebody is flagged" (what the fallback kernel looks at first); the splitting workgroups' maxima live in [2, 2 + nbe)
+                unsigned* zero_a = (unsigned*)((char*)ws + w.off_gthr) + B;
+                const size_t zero_a_n = (size_t)2 * B + (size_t)p.nub + 2;
+                unsigned* const bmax = emax_own + 2;
+                unsigned* zero_b = bmax + nbe;                                             // what is left of the 64 words
+                const size_t zero_b_n = (size_t)(62 - nbe);
                 if (D == 64)
                     hipLaunchKernelGGL(score_front_k<64>, dim3((unsigned)(fgroups + nbe)), dim3(64 * SF_NW), 0, s, Q, E, B, N, (unsigned short*)Qs, qnorm,
-                                       (unsigned short*)own, emax_own, (int)fgroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
+                                       (unsigned short*)own, bmax, (int)fgroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
                 else
                     hipLaunchKernelGGL(score_front_k<128>, dim3((unsigned)(fgroups + nbe)), dim3(64 * SF_NW), 0, s, Q, E, B, N, (unsigned short*)Qs, qnorm,
-                                       (unsigned short*)own, emax_own, (int)fgroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
+                                       (unsigned short*)own, bmax, (int)fgroups, nbe, n_tiles, stride, r / 2, gthr, zero_a, zero_a_n, zero_b, zero_b_n);
                 if ((rc = re_launch_status()) != RE_OK) return rc;
                 if (prep) {
                     Es = (const float*)prep;
                     emax = (const unsigned*)((const char*)prep + re_align((size_t)N * D * 4));
                 } else {
                     Es = own;
-                    emax = emax_own;
+                    emax = bmax;
                     n_emax = nbe;
                 }
             } else {

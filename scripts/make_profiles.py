@@ -20,7 +20,11 @@ k = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "scri
 k = {n: v for n, v in k.items() if not n.startswith(("at::", "void at::", "Cijk", "__amd"))}
 main = [n for n in k if n.startswith("score_kernel_reg<64, 28")][0]
 exact = [n for n in k if n.startswith("score_kernel_reg<64, 50")][0]
-total = 2 * k["score_split_k<64>"]["hbm_bytes_per_launch"] + sum(k[n]["hbm_bytes_per_launch"] for n in ("score_bound_k<64>", main, "score_topk_merge_x<64>", exact, "score_topk_merge"))
+front = [n for n in k if n.startswith("score_front_k<64>")]      # round 5: query split + item split + starting thresholds in one launch
+if front:
+    total = sum(k[n]["hbm_bytes_per_launch"] for n in (front[0], main, "score_topk_merge_x<64>", exact, "score_topk_merge"))
+else:
+    total = 2 * k["score_split_k<64>"]["hbm_bytes_per_launch"] + sum(k[n]["hbm_bytes_per_launch"] for n in ("score_bound_k<64>", main, "score_topk_merge_x<64>", exact, "score_topk_merge"))
 out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counters): rocprofv3 --pmc FETCH_SIZE -- python3 scripts/pmc_step.py ; same with --pmc WRITE_SIZE  "
                     "(6 fused SASRec steps at the bench shapes launched eagerly, 3 re_score_topk calls of 22 363 users x 12 101 items, D = 64, K = 50, iid scores, "
                     "3 gathers of 4 Mi rows from a 16 Mi x 64 table)",
@@ -28,7 +32,7 @@ out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counte
        "correction": "gfx950: FETCH_SIZE tallies the 128-B requests of 16-B-per-lane reads at 64 B (MI355X_MICROARCH.md, HBM): hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE",
        "kernels": k,
        "re_score_topk_call": {
-           "launches": "score_split_k x2 (queries -- which also zeroes the call's flag words -- and item table), score_bound_k, score_kernel_reg<64,28,28,split>, "
+           "launches": "score_front_k (query split + item-table split + starting thresholds + zeroing of the call's words, one launch), score_kernel_reg<64,28,28,split>, "
                        "score_topk_merge_x, and the fallback pass score_kernel_reg<64,50,50,exact> + score_topk_merge (nobody flagged: both return at once)",
            "hbm_bytes_per_call": total,
            "algorithmic_lower_bound_bytes": 4 * 64 * (22363 + 12101) + 12 * 22363 * 50,
