@@ -162,9 +162,7 @@ int re_sasrec_step_stage_sample(uint32_t* state, uint32_t seed, int64_t step, do
  * re_scatter_add_rows_small; scale 1, n from n_dev) over the step's contribution rows, whose 1024-thread workgroups then take the jobs of
  * re_sasrec_encoder_step_part(part = 4) -- the weight gradients of the encoder from the tape the item kernels left in `tape` / `ws` -- from
  * a ticket counter; enc_adam (optional) as there.  Both halves depend on the item kernels alone: one queue, no fork and join around them
- * (csrc/enc_tail.hip).  Results bit-identical to the two calls.  `ticket`: 128 zero-initialised uint32 of the caller's, left zero (four
- * counters a cache line apart -- the queue's counter, matrix jobs done, position jobs done, workgroups that left: the reduction of the weight gradients runs as the queue's
- * last jobs, behind those counts, instead of as a launch of its own).
+ * (csrc/enc_tail.hip).  Results bit-identical to the two calls.  `ticket`: one zero-initialised uint32 of the caller's, left zero.
  * next (optional, re_next_prep): the launch also prepares the next batch.
  * Replaces: embedding_dense_backward of the item table + the autograd weight gradients of SASRec/main.py:170-197's blocks + the optimizer
  * step over both (SASRec/main.py:249-252). */

@@ -27,14 +27,7 @@ extern "C" int re_dbg_tail_marks(unsigned long long* out, int nwg) {
 #define TAIL_NOW() 0ull
 #define TJ_STAMP(i) do { } while (0)
 #endif
-// 1: the reduction as the queue's last jobs (TailReduce).  Built, bit-identical (tests/test_gpu_sasrec.py run both ways), and NOT faster: the
-// launch ends one reduction (a memory round trip deep) behind its SLOWEST matrix job either way, and with ~50 more workgroups alive the slowest
-// matrix job itself ends later (ticket durations: median 26 k cycles both ways, max 37 k -> 49 k): 37 - 42 us against 25.5 + 6.9 for the two
-// launches (scripts/tail_phases.py, profiles/r5_tail_reduce_in_queue.txt).  So: 0, the reduction is the launch behind the tail.
-#ifndef TAIL_REDUCE_IN_QUEUE
-#define TAIL_REDUCE_IN_QUEUE 0
-#endif
-#include "enc_grad_reduce.h"
+#include "enc_wgrad_job.h"
 #include "scatter_owner.h"
 #include "adam_rows_owner.h"
 #include "enc_plan_body.h"
@@ -50,49 +43,9 @@ struct TailJobs {
     const int64_t* seq;
     const float* contrib;
     float* ppart;        // nullptr: no position-table gradient
-    unsigned* ticket;    // FOUR counters, TK_STRIDE words (a cache line) apart, zero at launch: [0] the queue's ticket counter, [1] matrix jobs done,
-                         // [2] position jobs done, [3] workgroups that left the queue.  With the reduction in the queue (TailReduce.on) the LAST
-                         // workgroup to leave zeroes all four; without it enc_grad_reduce_k (the next launch) zeroes [0].  (A line each: with the four
-                         // in one line the ~50 workgroups polling a done count kept that line busy and every ticket's atomic queued behind them --
-                         // the launch took 68 us instead of 25.)
+    unsigned* ticket;    // zero at launch; enc_grad_reduce_k (the next launch) zeroes it again.  (Round 5 tried the reduction as the queue's LAST jobs,
+                         // behind done counts -- exact, and slower: profiles/r5_tail_reduce_in_queue.txt; that form is commit 4086ee1.)
 };
-
-// The reduction (enc_grad_reduce.h) as the queue's last jobs: 1024-thread workgroups run FOUR of its 256-thread virtual blocks per ticket.  The
-// matrix blocks wait until every matrix job's partial is in memory (word [1] of the ticket area; a ticket is only handed out when all tickets
-// before it have been taken, so the jobs waited for are running on resident workgroups or done: no deadlock), the position blocks likewise
-// (word [2]); the vector blocks read what the step's item / tile kernel left.  One launch, its dispatch and its ~7 us less per step; the sums
-// and their order are the launch's own (bit for bit).
-#define TK_STRIDE 32
-struct TailReduce {
-    EgReduce R;
-    int on;
-};
-
-#if TAIL_REDUCE_IN_QUEUE
-__shared__ TailReduce s_tr;   // the reduction's arguments, copied out of the argument segment once per workgroup (the call below takes a pointer)
-
-__device__ __attribute__((noinline)) void tail_reduce_job(unsigned* ticket, const EgReduce* Rp, int t, int n_mat,
-                                                                                                    int n_pos, int n_rmat, int n_rvec, float* lds) {
-    const EgReduce& R = *Rp;
-    const int tid = threadIdx.x, sub = tid >> 8, t256 = tid & 255;   // sub: the thread's 256-thread virtual block
-    if (t < n_rmat || t >= n_rmat + n_rvec) {
-        const bool pos = t >= n_rmat;
-        const unsigned want = pos ? (unsigned)n_pos : (unsigned)n_mat;
-        if (tid == 0) {
-            const unsigned* w = ticket + (pos ? 2 : 1) * TK_STRIDE;
-            while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(8);
-        }
-        __syncthreads();
-        if (!pos) { if (4 * t + sub < R.nmat_blocks) eg_reduce_mat<true>(R, 4 * t + sub, t256); }
-        else { const int vb = 4 * (t - n_rmat - n_rvec) + sub; if (vb < R.npos_blocks) eg_reduce_pos<true>(R, vb, t256); }
-    } else {
-        float (*red)[64] = reinterpret_cast<float (*)[64]>(lds + sub * 256);
-        const EgVec V = eg_reduce_vec_a(R, 4 * (t - n_rmat) + sub, t256, red);
-        __syncthreads();
-        eg_reduce_vec_b(R, V, t256, red);
-    }
-}
-#endif
 
 // The NEXT batch's preparation (enc_plan_body.h: it depends on the batch alone) as the first jobs of the ticket queue: one plan job, n_ew
 // element-wise jobs -- in front of a step it is a 14 us launch (one workgroup's chain of barriers and round trips), here it rides in
@@ -132,19 +85,8 @@ struct TailEarly {
 };
 
 // has_early: s_job already holds this workgroup's first ticket
-#if TAIL_REDUCE_IN_QUEUE
-#define TR_ON(TR) ((TR).on)
-#define TAIL_TR_PARAM , TailReduce TR
-#define TAIL_TR_LOCAL
-#define TAIL_TR_ARG , TR
-#else
-#define TR_ON(TR) false
-#define TAIL_TR_PARAM                     /* (no argument block for it: 620 bytes more of kernel arguments cost the launch ~2 us) */
-#define TAIL_TR_LOCAL const TailReduce TR{};
-#define TAIL_TR_ARG
-#endif
 template <int D>
-__device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP, const TailReduce& TR, float* lds, int n_tiles, bool has_early = false) {
+__device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP, float* lds, int n_tiles, bool has_early = false) {
     const int tid = threadIdx.x, half = tid >> 9, ht = tid & 511;
     float* jl = lds + half * wg_job_lds_floats<D>();
     constexpr int WG_NSPLIT = wg_nsplit(D);
@@ -153,15 +95,8 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
     constexpr int POS_GROUPS = 144;                     // the position jobs are dealt to this many 512-thread groups (two per ticket)
     const int n_mat = WHOLE ? J.L * PER_PLANE : J.L * PER_PLANE / 2, n_pos = J.ppart ? POS_GROUPS / 2 : 0;
     const int n_prep = TP.mail ? 1 + TP.n_ew : 0;
-    const int n_rmat = TR_ON(TR) ? (TR.R.nmat_blocks + 3) / 4 : 0, n_rvec = TR_ON(TR) ? (TR.R.nvec_blocks + 3) / 4 : 0, n_rpos = TR_ON(TR) ? (TR.R.npos_blocks + 3) / 4 : 0;
     int jn = 0;
-    int done_kind = 0;   // (uniform) the job just finished: 1 a matrix job, 2 a position job -- counted once its stores have drained
     for (;;) {
-        if (TR_ON(TR) && done_kind) {
-            re_sync_full();                                       // every thread's partial stores (agent scope: written through) have completed ...
-            if (tid == 0) atomicAdd(J.ticket + done_kind * TK_STRIDE, 1u);   // ... before the job counts as done
-            done_kind = 0;
-        }
         if (jn == 0) TJ_STAMP(3);
         __syncthreads();   // (the launch's first part / the previous job's stages are done with the LDS)
         if (jn > 0 && jn <= 3) TAIL_MARK(1 + 2 * jn, TAIL_NOW());
@@ -170,7 +105,7 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
         __syncthreads();
         int t = s_job;
         if (jn == 0) TJ_STAMP(1);
-        if (t >= n_prep + n_rvec + n_mat + n_pos + n_rmat + n_rpos) break;
+        if (t >= n_prep + n_mat + n_pos) break;
         if (jn < 3) TAIL_MARK(2 + 2 * jn, (unsigned long long)(t + 1));
         ++jn;
         if (t < n_prep) {
@@ -182,33 +117,8 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
             continue;
         }
         t -= n_prep;
-        // (the vector gradients' reduction depends on the item / tile kernel alone and is a chain of memory round trips: its tickets come FIRST;
-        //  the matrix and position reductions wait for this launch's jobs: LAST)
-#if TAIL_REDUCE_IN_QUEUE
-        if (t < n_rvec) {
-            tail_reduce_job(J.ticket, &s_tr.R, n_rmat + t, n_mat, n_pos, n_rmat, n_rvec, lds);
-            continue;
-        }
-#endif
-        t -= n_rvec;
-        if (t >= n_mat + n_pos) {
-            // ---- the reduction's blocks, four per ticket: a CALL, not inlined -- inlined, its registers (24 partials in flight per thread, the
-            //      argument block's scalars) raised the pressure in the matrix jobs' loops of this 128-register kernel: scratch 28 -> 116 bytes a
-            //      lane, and the launch took 57 us instead of 25 + 7
-            TAIL_MARK(24, TAIL_NOW());
-#if TAIL_REDUCE_IN_QUEUE
-            {
-                const int r = t - n_mat - n_pos;                 // [0, n_rmat): matrices; then the position table's
-                tail_reduce_job(J.ticket, &s_tr.R, r < n_rmat ? r : r + n_rvec, n_mat, n_pos, n_rmat, n_rvec, lds);
-            }
-#endif
-            TAIL_MARK(25, TAIL_NOW());
-            TAIL_MARK(26, (unsigned long long)(t - n_mat - n_pos + 1));
-            continue;
-        }
         if (t < n_mat) {
             if (jn == 1) TJ_STAMP(2);
-            done_kind = 1;
             if constexpr (WHOLE) {
                 wg_matrix_job<D, SO_NT>(tid, lds, t / PER_PLANE, (t / WG_NSPLIT) % EG_NMAT, t % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
             } else {
@@ -217,30 +127,9 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
             }
         } else {
             wg_pos_job<D>(ht, jl, 2 * (t - n_mat) + half, POS_GROUPS, J.B, J.S, J.seq, J.contrib, J.ppart);
-            done_kind = 2;
-        }
-    }
-    if (TR_ON(TR) && tid == 0) {
-        // every workgroup of the grid passes here once; the last one leaves the four words zero for the next step
-        if (atomicAdd(J.ticket + 3 * TK_STRIDE, 1u) == gridDim.x - 1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) __hip_atomic_store(J.ticket + k * TK_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
-
-#if TAIL_REDUCE_IN_QUEUE
-// (a barrier follows before anybody reads it: both kernels' first parts end in one)
-__device__ __forceinline__ void tail_stash_reduce(const TailReduce& TR) {
-    if (!TR_ON(TR)) return;
-    constexpr int NW = (int)(sizeof(TailReduce) / 4);
-    const unsigned* src = reinterpret_cast<const unsigned*>(&TR);
-    unsigned* dst = reinterpret_cast<unsigned*>(&s_tr);
-    for (int i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = src[i];
-}
-#else
-__device__ __forceinline__ void tail_stash_reduce(const TailReduce&) {}
-#endif
 
 // The next batch's spans (the plan's phase 1: the only part that reads the batch) by the launch's LAST workgroup, from the launch's start:
 // the plan job of the queue (PL_MODE_REST) then starts ~23 k cycles in with the spans already there, and ends with the weight-gradient tickets
@@ -257,11 +146,9 @@ __device__ __forceinline__ void tail_spans(const TailPrep& TP, float* lds) {
 template <int D, int HS>
 __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                                     const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
-                                                    int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J, TailPrep TP TAIL_TR_PARAM) {
-    TAIL_TR_LOCAL
+                                                    int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
     re_kernarg_warm<re_kernarg_bytes(&enc_tail_k<D, HS>)>();
-    tail_stash_reduce(TR);
 #ifdef TAIL_PROFILE
     if (threadIdx.x < TAIL_MARKS && blockIdx.x < TAIL_MARK_WGS) g_tail_marks[blockIdx.x * TAIL_MARKS + threadIdx.x] = 0ull;
     __syncthreads();
@@ -276,17 +163,15 @@ __global__ __launch_bounds__(SO_NT) void enc_tail_k(const float* __restrict__ g,
     TailEarly early{J.ticket, (int)gridDim.x};
     so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, lds, early);
     TAIL_MARK(1, TAIL_NOW());
-    tail_jobs<D>(J, TP, TR, lds, n_tiles, early.has);
+    tail_jobs<D>(J, TP, lds, n_tiles, early.has);
     TAIL_MARK(15, TAIL_NOW());
 }
 
 // the same behind the row-sparse Adam of a LARGE table (adam_rows_owner.h; config 5: D = 128, HS = 2)
 template <int D, int HS>
-__global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J, TailPrep TP TAIL_TR_PARAM) {
-    TAIL_TR_LOCAL
+__global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs J, TailPrep TP) {
     extern __shared__ __align__(16) float lds[];
     re_kernarg_warm<re_kernarg_bytes(&enc_tail_sparse_k<D, HS>)>();
-    tail_stash_reduce(TR);
 #ifdef TAIL_PROFILE
     if (threadIdx.x < TAIL_MARKS && blockIdx.x < TAIL_MARK_WGS) g_tail_marks[blockIdx.x * TAIL_MARKS + threadIdx.x] = 0ull;
     __syncthreads();
@@ -298,7 +183,7 @@ __global__ __launch_bounds__(SA_NT) void enc_tail_sparse_k(SaParams P, TailJobs 
     const unsigned gated = reinterpret_cast<const unsigned*>(J.tape + J.T.off_FLAGS)[(J.NR / 16) * EP_FLAG_WORDS];
     if (!gated) sa_body<1, HS, int32_t>(P, reinterpret_cast<unsigned char*>(lds));
     TAIL_MARK(1, TAIL_NOW());
-    tail_jobs<D>(J, TP, TR, lds, enc_plan_view(J.plan, J.B, J.S).hdr[1]);
+    tail_jobs<D>(J, TP, lds, enc_plan_view(J.plan, J.B, J.S).hdr[1]);
     TAIL_MARK(15, TAIL_NOW());
 }
 
@@ -308,10 +193,6 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
 int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
                            const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
                            hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket, const unsigned* gate);
-
-int enc_grad_reduce_args(EgReduce& R, int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
-                         const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, int by_tile,
-                         const re_adam_fuse* adam, const unsigned* gate);
 
 static int tail_prep(TailPrep& TP, const re_next_prep* next) {
     TP = TailPrep{};
@@ -394,17 +275,9 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
     hipStream_t s = (hipStream_t)stream;
     auto k = enc_tail_k<64, HS>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-    TailReduce TR{};
-    TR.on = TAIL_REDUCE_IN_QUEUE;
-    if (TR.on) {
-        const int rcr = enc_grad_reduce_args(TR.R, B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, 1,
-                                             enc_adam, T.gate);
-        if (rcr != RE_OK) return rcr;
-    }
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, (int64_t)0, R, rpw,
-                       padding_idx, 1.0f, dW, AD, T.J, TP TAIL_TR_ARG);
+                       padding_idx, 1.0f, dW, AD, T.J, TP);
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
-    if (TR.on) return RE_OK;
     return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
                                   ticket, T.gate);
 }
@@ -435,28 +308,20 @@ extern "C" int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, i
     P.step_size = 0.f; P.inv_sqrt_bc2 = 0.f;
     P.stride = D; P.coff = 0;
     hipStream_t s = (hipStream_t)stream;
-    TailReduce TR{};
-    TR.on = TAIL_REDUCE_IN_QUEUE;
-    if (TR.on) {
-        const int rcr = enc_grad_reduce_args(TR.R, B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, 1,
-                                             enc_adam, T.gate);
-        if (rcr != RE_OK) return rcr;
-    }
     if (D == 128) {
         const size_t lds_jobs = (size_t)2 * wg_job_lds_floats<128>() * sizeof(float);
         const size_t ldsb = lds_jobs > (size_t)SA_LDS_BYTES(1) ? lds_jobs : (size_t)SA_LDS_BYTES(1);   // (> PL_LDS_BYTES)
         auto k = enc_tail_sparse_k<128, 2>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J, TP TAIL_TR_ARG);
+        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J, TP);
     } else {
         const size_t lds_jobs = (size_t)2 * wg_job_lds_floats<64>() * sizeof(float);
         const size_t ldsb = lds_jobs > (size_t)SA_LDS_BYTES(1) ? lds_jobs : (size_t)SA_LDS_BYTES(1);
         auto k = enc_tail_sparse_k<64, 1>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J, TP TAIL_TR_ARG);
+        hipLaunchKernelGGL(k, dim3(SA_NWG), dim3(SA_NT), ldsb, s, P, T.J, TP);
     }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
-    if (TR.on) return RE_OK;
     return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
                                   ticket, T.gate);
 }

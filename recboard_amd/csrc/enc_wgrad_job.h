@@ -12,15 +12,6 @@
 // cycles instead of ~4 k: config 5's tail 47 us, scripts/tail_phases.py large).  Half as many splits of twice the rows keep the ticket count.
 __host__ __device__ constexpr int wg_nsplit(int D) { return D == 128 ? 12 : 24; }
 #define WG_NSPLIT_MAX 24
-// how a job's partial is stored: plainly -- or, when the reduction runs in the same launch (enc_tail.hip: TAIL_REDUCE_IN_QUEUE), at agent scope
-#ifndef TAIL_REDUCE_IN_QUEUE
-#define TAIL_REDUCE_IN_QUEUE 0
-#endif
-#if TAIL_REDUCE_IN_QUEUE
-#define WG_PART_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#else
-#define WG_PART_STORE(P, V) (*(P) = (V))
-#endif
 #define WG_CH 4   // row tiles per LDS stage
 #ifndef WG_STAMP
 #define WG_STAMP(i) do { } while (0)   // (enc_tail.hip's profile build: shader-clock stamps inside a job)
@@ -154,9 +145,7 @@ __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m,
     for (int t = 0; t < RTW; ++t) {
         const int mt = t * C::WR + wr;
 #pragma unroll
-        // (agent-scope stores: written through to where every XCD reads them -- the reduction may run in this very launch, on another XCD's
-        //  workgroup, behind a done count (enc_tail.hip); a release fence instead writes the whole L2 back: 11 k cycles per job, measured)
-        for (int j = 0; j < 4; ++j) WG_PART_STORE(out + (16 * mt + 4 * g + j) * D + 16 * strip + c, acc[t][j]);
+        for (int j = 0; j < 4; ++j) out[(16 * mt + 4 * g + j) * D + 16 * strip + c] = acc[t][j];
     }
 }
 
@@ -205,7 +194,7 @@ __device__ __forceinline__ void wg_pos_job(int tid, float* lds, int j0, int jste
             float t = lds[tid];
 #pragma unroll
             for (int i = 1; i < C::CG; ++i) t += lds[i * D + tid];
-            WG_PART_STORE(ppart + (int64_t)j * D + tid, t);   // (see wg_matrix_job's stores)
+            ppart[(int64_t)j * D + tid] = t;
         }
 #pragma unroll
         for (int q = 0; q < NQP; ++q) { sv[q] = svn[q]; cv[q] = cvn[q]; }

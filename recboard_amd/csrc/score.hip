@@ -1513,8 +1513,14 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) { v4[u] = nv4[u]; i4[u] = ni4[u]; t4[u] = nt4[u]; }
     }
-    const int nvalid = total < 64 ? total : 64;
-    if (total > 64) T = fmaxf(T, __shfl(bv, 63, 64));
+    // Of the (up to) 64 merged entries the best NC = K + 6 rounded up to a multiple of 8 (56 at K = 50) are re-scored; the rest count as
+    // dropped, the best of them -- lane NC -- into T.  (The pass is bound by the candidates' row gathers from L2, 64 x 4 D bytes per user;
+    // the exact K-th then needs to clear the approximate (NC + 1)-th instead of the 65th: thousands of eps on any scores that are not ties.)
+    const int NC = ((K + 6 + 7) & ~7) < 64 ? ((K + 6 + 7) & ~7) : 64;
+    if (total > NC && NC < 64) T = fmaxf(T, __shfl(bv, NC, 64));
+    else if (total > 64) T = fmaxf(T, __shfl(bv, 63, 64));
+    if (lane >= NC) { bi = PAD; bv = -INFINITY; }
+    const int nvalid = total < NC ? total : NC;
     // exact re-scoring: lane = candidate; the candidates' rows come in through the wave's LDS slice, MX_ROWS rows per pass (a lane
     // reading its own row from global memory would touch 64 cache lines per load instruction).
     float* stage = mx_stage + (threadIdx.x >> 6) * (MX_ROWS * D);

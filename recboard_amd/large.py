@@ -160,7 +160,7 @@ class SASRecLargeTableEngine(SASRecEngine):
                 fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, self.betas[0], self.betas[1], 1e-8, self.wd)
                 self._adam_keep = fz
                 if not hasattr(self, "_ticket"):
-                    self._ticket = torch.zeros(128, dtype=torch.int32, device=self.device)   # (four counters a cache line apart: ticket, matrix jobs done, position jobs done, workgroups that left -- csrc/enc_tail.hip)
+                    self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
                 ops.sasrec_step_tail_sparse(W["g_rows"].view(-1, D), W["keys"], self.E, self.Em, self.Ev, adam_hyper, self.betas[0], self.betas[1], 1e-8,
                                             self.wd, aux.plan.view(torch.int32)[1:2], 16, seq, self.L, aux.plan, W["tape"], W["contrib"][:n].view(B, S, D),
                                             float(D ** 0.5), G["Position.weight"], self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"],

@@ -853,12 +853,11 @@ def sasrec_step_tail(g_rows, keys, R, out, n_dev, n_mul, seq, L, plan, tape, dx0
                      table_adam=None, enc_adam=None, n_regions=3, padding_idx=0, next=None):
     """scatter_add_rows_small(g_rows, keys, R, out, n_regions, n_dev=, n_mul=, adam=table_adam) and sasrec_encoder_step(part=4, adam=enc_adam)
     as ONE launch + the reduction (re_sasrec_step_tail; D = 64): the scatter-add's workgroups take the weight-gradient jobs when their rows are
-    done.  Bit-identical to the two calls.  ticket: zero int32[128] of the caller's (left zero).  next (NextPrep): the launch also
+    done.  Bit-identical to the two calls.  ticket: a zero uint32/int32[1] of the caller's (left zero).  next (NextPrep): the launch also
     prepares the next batch (the one sasrec_step_stage named) into the other captured copy's staging buffers."""
     _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(n_dev, torch.int32, "n_dev"); _req(seq, torch.int64, "seq")
     _req(tape, torch.float32, "tape"); _req(dx0, torch.float32, "dx0"); _req(dP, torch.float32, "dP"); _req(ws, torch.uint8, "ws")
     _req(ticket, torch.int32, "ticket")
-    assert ticket.numel() >= 128, "ticket: 128 zero words -- four counters a cache line apart (csrc/enc_tail.hip)"
     if out is not None or table_adam is None:
         _req(out, torch.float32, "out")
     B, S = seq.shape
@@ -882,7 +881,6 @@ def sasrec_step_tail_sparse(g_rows, keys, W, m, v, hyper, beta1, beta2, eps, wei
     _req(g_rows, torch.float32, "g_rows"); _req(keys, torch.int32, "keys"); _req(n_dev, torch.int32, "n_dev"); _req(seq, torch.int64, "seq")
     _req(tape, torch.float32, "tape"); _req(dx0, torch.float32, "dx0"); _req(dP, torch.float32, "dP"); _req(ws, torch.uint8, "ws")
     _req(ticket, torch.int32, "ticket"); _req(hyper, torch.float32, "hyper")
-    assert ticket.numel() >= 128, "ticket: 128 zero words -- four counters a cache line apart (csrc/enc_tail.hip)"
     for t, nme in ((W, "W"), (m, "m"), (v, "v")):
         _req(t, torch.float32, nme)
     B, S = seq.shape

@@ -352,7 +352,7 @@ class SASRecEngine:
                 fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, self.betas[0], self.betas[1], 1e-8, self.wd) if fuse else None
                 self._adam_keep = (fz,)
                 if not hasattr(self, "_ticket"):
-                    self._ticket = torch.zeros(128, dtype=torch.int32, device=self.device)   # (four counters a cache line apart: ticket, matrix jobs done, position jobs done, workgroups that left -- csrc/enc_tail.hip)
+                    self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
                 ops.sasrec_step_tail(W["g_rows"], W["keys"], self.N + 1, GE if (not fuse or getattr(self, "keep_table_grad", True)) else None,
                                      pb.plan.view(torch.int32)[1:2], 16, seq, self.L, pb.plan, W["tape"], W["contrib"][:n].view(B, S, D), float(D ** 0.5),
                                      G["Position.weight"], self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], self._ticket,
