@@ -91,7 +91,10 @@ __host__ __device__ inline bool enc_tile_looped(int64_t B, int64_t S) { return e
 // are 14 - 20 % faster on batches of 1 024 - 4 096 sequences, but with two the results differ from process to process in single registers of single
 // waves -- still unexplained after round 5 ruled out SGPR spills, the barriers' missing vmcnt drain and the transcendental forwarding hazard
 // (profiles/r5_handover_notes.txt).  The launcher, the plan's rule (split_long & 8) and the looped grid all follow this one number.
-__host__ __device__ inline int enc_tile_wg_per_cu(int64_t D) { (void)D; return 1; }
+#ifndef ENC_TILE_WG_PER_CU
+#define ENC_TILE_WG_PER_CU 1      // (2: the experiment builds `make two` / `make twoinv`, scripts/handover_soak.py --lib two)
+#endif
+__host__ __device__ inline int enc_tile_wg_per_cu(int64_t D) { (void)D; return ENC_TILE_WG_PER_CU; }
 // rows of the vector-gradient slab in the backward's workspace: one per workgroup (<= 1024) or one per tile (enc_tile.hip)
 __host__ __device__ inline int64_t enc_slab_rows(int64_t B, int64_t S) { const int64_t mt = enc_plan_max_tiles(B, S); return mt > 1024 ? mt : 1024; }
 __host__ __device__ inline int64_t enc_plan_rowmap_word(int64_t B, int64_t S) { return (EP_HDR + enc_plan_max_tiles(B, S) + 1) / 2 * 2; }

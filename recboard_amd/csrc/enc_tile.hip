@@ -80,6 +80,11 @@ extern "C" int re_dbg_tile_handover(int fenced, int lds_kb) {
 extern "C" int re_dbg_tile_paranoid(unsigned bits) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_paranoid), &bits, sizeof(unsigned)) == hipSuccess ? 0 : 1;
 }
+__device__ unsigned g_tl_delay;                          // != 0: odd workgroups wait this many shader cycles at their start, every fourth one half of it in front of every
+                                                         // further tile it takes: WHICH workgroup runs which tile after which changes -- do the results? (scripts/tile_order_check.py)
+extern "C" int re_dbg_tile_delay(unsigned cycles) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_delay), &cycles, sizeof(unsigned)) == hipSuccess ? 0 : 1;
+}
 extern "C" int re_dbg_tile_fill(unsigned pattern) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_fill), &pattern, sizeof(unsigned)) == hipSuccess ? 0 : 1;
 }
@@ -126,6 +131,9 @@ __device__ __forceinline__ T tl_arg_at(unsigned off) {
 
 namespace tl4 {
 #define TL_NS 4
+#ifdef TL_L1INV
+#define TL_L1INV_SYNCTHREADS 1
+#endif
 #include "enc_tile_body.inc"
 #undef TL_NS
 }   // namespace tl4

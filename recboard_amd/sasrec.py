@@ -13,6 +13,7 @@ are one tensor.  The arena is padded so every parameter starts 16-byte aligned (
 Hot-path ops are librecengine kernels (recboard_amd/ops.py); there is no CPU fallback.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -268,8 +269,9 @@ class SASRecEngine:
 
     def _tile_wgs(self):
         """Resident workgroups per CU of the tile kernels (csrc/enc_common.h: enc_tile_wg_per_cu -- one; two at D = 64 is faster and not yet
-        reproducible from process to process, profiles/r5_handover_notes.txt): the batch plan's rule counts them."""
-        return 1
+        reproducible from process to process, profiles/r5_handover_notes.txt): the batch plan's rule counts them.  (RE_TILE_WGS=2 with the
+        experiment libraries `make two` / `make twoinv` only: the library's own number must be the same.)"""
+        return int(os.environ.get("RE_TILE_WGS", "1"))
 
     def _tail_word(self):
         if not hasattr(self, "_tail"):

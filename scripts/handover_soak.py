@@ -53,7 +53,7 @@ def child(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--child", action="store_true")
-    ap.add_argument("--lib", default="hov", choices=("hov", "hovn", "hovs", "fenced", "product", "ss"))
+    ap.add_argument("--lib", default="hov", choices=("hov", "hovn", "hovs", "fenced", "product", "ss", "two", "twoinv"))
     ap.add_argument("--fenced", type=int, default=0)
     ap.add_argument("--lds-kb", type=int, default=84)
     ap.add_argument("--steps", type=int, default=300)
