@@ -82,6 +82,11 @@ extern "C" int re_dbg_tile_paranoid(unsigned bits) {
 }
 __device__ unsigned g_tl_delay;                          // != 0: odd workgroups wait this many shader cycles at their start, every fourth one half of it in front of every
                                                          // further tile it takes: WHICH workgroup runs which tile after which changes -- do the results? (scripts/tile_order_check.py)
+__device__ unsigned g_tl_skew;                           // != 0: behind EVERY barrier of the kernel the waves of a workgroup wait 0 .. 3 x this many cycles (which wave waits how long
+                                                         // rotates from barrier to barrier): anything that leans on the waves running in step, not on a barrier, breaks
+extern "C" int re_dbg_tile_skew(unsigned cycles) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_skew), &cycles, sizeof(unsigned)) == hipSuccess ? 0 : 1;
+}
 extern "C" int re_dbg_tile_delay(unsigned cycles) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_delay), &cycles, sizeof(unsigned)) == hipSuccess ? 0 : 1;
 }
