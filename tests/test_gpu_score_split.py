@@ -190,3 +190,35 @@ def test_split_adversarial_scales(env):
         (v0, i0), (v1, i1), flagged, ratio = both_paths(ops, L, qq.contiguous(), EE.contiguous(), sp, si, K)
         assert torch.equal(i0, i1) and torch.equal(v0, v1)
         assert ratio < 1.0
+
+
+@pytest.mark.parametrize("D,N", [(64, 12101), (128, 5000)])
+def test_front_launch_gives_the_three_launches_results_and_few_fallbacks(env, D, N):
+    """score_front_k (query split + item split + starting thresholds in ONE launch, round 5) against the three launches it replaces
+    (re_dbg_score_front(0)): identical values and indices -- the planes it writes are score_split_k's bit for bit, its thresholds are only filter
+    values -- and its cheaper sample arithmetic (hi planes, pair maxima) must not send more than a handful of users to the exact fallback.
+    Enough users for the sample not to be cut into chunks (> 16 384): the shape the front launch takes."""
+    ops, L = env
+    L.re_dbg_score_front.argtypes = [ctypes.c_int]; L.re_dbg_score_front.restype = None
+    g = torch.Generator(device="cuda").manual_seed(21)
+    U, K = 17000, 50
+    q = torch.randn(U, D, device="cuda", generator=g)
+    E = torch.randn(N, D, device="cuda", generator=g)
+    sp, si = seen_csr(g, U, N, 6)
+    try:
+        L.re_dbg_score_front(0)
+        stats(L)
+        v0, i0 = ops.score_topk(q, E, sp, si, K)
+        f0, _ = stats(L)
+        L.re_dbg_score_front(1)
+        v1, i1 = ops.score_topk(q, E, sp, si, K)
+        f1, _ = stats(L)
+    finally:
+        L.re_dbg_score_front(1)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    assert f1 <= f0 + 8, (f0, f1)          # (flagged users cost time, never correctness)
+    # and against the exact kernel
+    L.re_dbg_score_x2(0)
+    ve, ie = ops.score_topk(q, E, sp, si, K)
+    L.re_dbg_score_x2(1)
+    assert torch.equal(ie, i1) and torch.equal(ve, v1)
