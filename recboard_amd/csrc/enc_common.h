@@ -91,6 +91,10 @@ __host__ __device__ inline bool enc_tile_looped(int64_t B, int64_t S) { return e
 // are 14 - 20 % faster on batches of 1 024 - 4 096 sequences, but with two the results differ from process to process in single registers of single
 // waves -- still unexplained after round 5 ruled out SGPR spills, the barriers' missing vmcnt drain and the transcendental forwarding hazard
 // (profiles/r5_handover_notes.txt).  The launcher, the plan's rule (split_long & 8) and the looped grid all follow this one number.
+// the most tiles a batch may have for the tile kernels to run it (the plan's rule, enc_plan_body.h): their dK / dV inboxes (enc_tile_prep.h:
+// enc_tile_xch_bytes) are sized for this many tiles, not for every tile a batch of B sequences could have (B = 8 192: 32 768 tiles = 1.6 GB of
+// inboxes that the plan's speed rule -- at most ~10 tiles per resident workgroup -- never let the kernels use)
+#define ENC_XCH_TILE_CAP 5120
 #ifndef ENC_TILE_WG_PER_CU
 #define ENC_TILE_WG_PER_CU 1      // (2: the experiment builds `make two` / `make twoinv`, scripts/handover_soak.py --lib two)
 #endif

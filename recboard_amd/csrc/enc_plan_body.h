@@ -345,7 +345,7 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
                 const int tg = (ncu < 256 ? ncu : 256) * ((split_long & 8) ? 2 : 1);   // resident workgroups (& 8: two per CU)
                 const bool fits = enc_tile_looped(B, S) ? ((split_long & 4) || (2 * tlong <= 3 * tg && tlong + tshort <= 10 * tg))
                                                         : (tlong + tshort <= 1024 && ((split_long & 4) || tlong <= tg * 3 / 4));
-                hdr[7] = (nsplit == 0 && !(split_long & 2) && fits) ? 1 : 0;
+                hdr[7] = (nsplit == 0 && !(split_long & 2) && fits && tlong + tshort <= ENC_XCH_TILE_CAP) ? 1 : 0;   // (the cap: the inboxes' size, whatever the caller insists on)
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;
                 s_cb[0] = 0; s_cb[1] = n0; s_cb[2] = n0 + n1; s_cb[3] = nlong;       // long class k: s_cb[k] long sequences in front of it
             }

@@ -31,7 +31,10 @@ typedef unsigned tl_u32x2 __attribute__((ext_vector_type(2)));
 inline bool enc_tile_width_ok(int64_t D) { return D == 64 || D == 128; }
 // (+ the small parameters of every block and lastLN as one block of (10 L + 2) x D floats behind the fragments)
 inline size_t enc_tile_wfrag_bytes(int64_t L, int64_t D) { return (size_t)L * 6 * 2 * TLC_FRAG_WORDS(D / 16) * 4 + (size_t)(TL_NPAR * L + 2) * D * 4; }
-inline size_t enc_tile_xch_bytes(int64_t B, int64_t S, int64_t D, int64_t L) { return (size_t)enc_plan_max_tiles(B, S) * L * TLC_XCH_TILE(D / 16) * 4; }
+inline size_t enc_tile_xch_bytes(int64_t B, int64_t S, int64_t D, int64_t L) {
+    const int64_t mt = enc_plan_max_tiles(B, S);
+    return (size_t)(mt < ENC_XCH_TILE_CAP ? mt : ENC_XCH_TILE_CAP) * L * TLC_XCH_TILE(D / 16) * 4;
+}
 // where the fragments, the exchange inboxes and the launch epoch live: behind the gradient tape in the backward workspace / in the tape's flag area
 inline uint32_t* enc_tile_wf(float* gtape, int64_t B, int64_t S, int64_t L, int64_t D) {
     return (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * 16 * enc_plan_max_tiles(B, S) * D)) + 255) & ~(uintptr_t)255);
