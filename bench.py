@@ -214,8 +214,9 @@ def graph_time_ms(fn, reps=20, iters=10):
         fn()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    from recboard_amd.capture import recording
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    with recording(g, capture_error_mode="thread_local"):
         for _ in range(reps):
             fn()
     g.replay()

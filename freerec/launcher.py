@@ -83,6 +83,7 @@ class Coach:
         self._register_default_monitors()
         self.set_other()
         self._best, self._best_epoch = (float("inf") if self._best_caster() is min else -float("inf")), 0
+        self._best_saved = False          # a best.pt written by THIS run (or by the run a checkpoint resumes): only that one is ever loaded back
         self._stopping_steps = 0
         self.history = []                   # one record per epoch: {"epoch", "train", ["valid"], ["test"]}; the last one holds the final evaluations
         self._final = {"train": {}, "valid": {}, "test": {}, "best": {}}
@@ -388,6 +389,7 @@ class Coach:
         elif isinstance(mon.get("best"), (tuple, list)):                   # (round-4 engine checkpoints: (epoch, score))
             self._best_epoch, self._best = mon["best"]
         self.history = list(mon.get("history", []))
+        self._best_saved = self._best not in (float("inf"), -float("inf"))      # (the resumed run's best.pt, if it got as far as writing one)
         return ck["epoch"]
 
     def save_best(self, path=None):
@@ -416,6 +418,7 @@ class Coach:
             self._best, self._best_epoch, self._stopping_steps = results[key], epoch, 0
             if self._saves_files():
                 self.save_best()
+                self._best_saved = True
         else:
             self._stopping_steps += 1
             if self._stopping_steps > self.cfg.get("early_stop_patience", 1e23):
@@ -504,7 +507,9 @@ class Coach:
         if self._saves_files():
             self.save_checkpoint(epochs)
         self._final["best"] = dict(self._final["test"])
-        if self._saves_files() and self.testpipe is not None and self._best_epoch != epochs and self.load_best():
+        # (only a best.pt of this run: `self.path` is reused between runs, and without a validation split `_best_epoch` stays 0 -- a previous
+        #  run's file would otherwise be loaded and its test metrics recorded as this run's `best`)
+        if self._saves_files() and self.testpipe is not None and self._best_saved and self._best_epoch != epochs and self.load_best():
             self._final["best"] = self.test(epochs)      # the best checkpoint on the test split: what the leaderboard aggregates
         out = {"valid": self._final["valid"], "test": self._final["test"], "best_test": self._final["best"], "history": self.history,
                "best_epoch": self._best_epoch, "best_value": self._best}

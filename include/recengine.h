@@ -38,6 +38,9 @@ typedef void* re_stream_t; /* hipStream_t */
 
 int re_abi_version(void);
 const char* re_error_string(int code);
+/* resident workgroups per CU the one-tile-per-workgroup step kernels of this build hold (1): what `split_long & 8` of re_sasrec_batch_prep
+ * must agree with (the plan's residency rule counts them). */
+int re_tile_wgs_per_cu(int64_t D);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K1  embedding row gather.  out[i, :] = W[idx[i], :]   (i < n)

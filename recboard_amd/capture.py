@@ -3,9 +3,46 @@ reference's loop body (`MF-BPR/main.py:116-123`, `LightGCN/main.py:156-164`, `De
 issued one by one the CPU launch path, not the GPU, sets the step time.  A captured step reads its batch from static buffers and its
 per-step scalars (dropout seed, Adam's step size and bias correction) from four device words written by one tiny launch (re_step_state);
 everything else is the eager step's launches, recorded once."""
+import contextlib
+import gc
+
 import torch
 
 from . import ops
+
+
+@contextlib.contextmanager
+def recording(graph, **kw):
+    """`with torch.cuda.graph(graph, **kw)` with the two guards every capture of this package needs:
+
+    * NO CYCLIC GARBAGE COLLECTION WHILE THE STREAM RECORDS.  torch >= 2.9 no longer collects before a capture
+      (`torch.compiler.config.force_cudagraph_gc` is off), and ROCm's `~CUDAGraph` ends in `hipDeviceSynchronize()`: when Python's
+      collector happens to run inside the recording and frees a dead cycle that holds an earlier captured step (an engine of a finished
+      epoch, a previous test's Coach), that call is refused ("operation not permitted when stream is capturing"), the error is thrown
+      out of a destructor and the process dies in `std::terminate` -- SIGABRT from the main thread, "Garbage-collecting" on top of the
+      traceback (gpurun_out/r5c_tests.log; the driver's round-5 GPU run).  So: collect BEFORE the recording, keep the collector off
+      during it.
+    * THE GRAPH OWNS WHAT IT REPLAYS: every storage whose address a launch of the recording was handed (ops._note) is kept on the
+      graph object."""
+    if ops._KEEP is not None:
+        raise RuntimeError("recengine: nested graph captures")
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    keep = ops._KEEP = []
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield keep
+    finally:
+        ops._KEEP = None
+        if was_enabled:
+            gc.enable()
+    seen, owned = set(), []
+    for st in keep:
+        if st.data_ptr() not in seen:
+            seen.add(st.data_ptr())
+            owned.append(st)
+    graph._re_owned = getattr(graph, "_re_owned", []) + owned
 
 
 class CapturedStep:
@@ -27,7 +64,7 @@ class CapturedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with recording(self.graph, capture_error_mode="thread_local"):
             self.out = body(*self.static, self.state)
         for t, k in zip(restore, keep):
             t.copy_(k)

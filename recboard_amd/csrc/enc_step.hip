@@ -153,3 +153,7 @@ extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Pt
                                        tape, tape_bytes, e_off, kind, count, loss, dU_rows, g_rows, keys, loss_ws, loss_ws_bytes, dx0, dPtab,
                                        block_grads, g_last_w, g_last_b, ws, ws_bytes, 0, nullptr, stream);
 }
+
+// Resident workgroups per CU the tile kernels of THIS library are built for (1; 2 in the experiment builds): the batch plan's residency rule
+// (split_long & 8) has to count the same number, so the host asks instead of assuming.
+extern "C" int re_tile_wgs_per_cu(int64_t D) { return enc_tile_wg_per_cu(D); }

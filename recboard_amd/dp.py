@@ -56,8 +56,9 @@ class OwnerAdam:
         self.bytes_per_link_per_step = 2 * self.chunk * 4 if self.G > 1 else 0
 
     def slice(self):
-        lo = self.rank * self.chunk
-        return lo, min(lo + self.chunk, self.numel)
+        """The owned range [lo, hi) of the arena (empty -- lo == hi -- for a rank whose slice lies wholly in the padding)."""
+        lo = min(self.rank * self.chunk, self.numel)
+        return lo, max(lo, min(self.rank * self.chunk + self.chunk, self.numel))
 
     def step(self, data, grad, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, hyper=None):
         """One synchronous data-parallel optimizer step over the flat arenas (data, grad, m, v: [numel] each).  On return `data` holds the
@@ -72,17 +73,19 @@ class OwnerAdam:
         if not self.staged:
             p, mm, vv, gout, full = data[lo:lo + c], m[lo:lo + c], v[lo:lo + c], grad[lo:lo + c], data
         else:
-            hi = min(lo + c, self.numel)
+            # the caller's arenas are the truth for the owner's slice, moments included (a loaded checkpoint, moments accumulated before this
+            # hook existed): they go into the staging slice before the launch and come back behind it
+            slo, hi = self.slice()
             p, mm, vv = self.mine[0], self.mine[1], self.mine[2]
-            p[:hi - lo].copy_(data[lo:hi])
+            p[:hi - slo].copy_(data[slo:hi])
+            mm[:hi - slo].copy_(m[slo:hi]); vv[:hi - slo].copy_(v[slo:hi])
             gout, full = self.gpad[lo:lo + c], self.ppad
         self.ops.reduce_adam(p, parts, mm, vv, step, lr, betas[0], betas[1], eps, weight_decay, 1.0 / G, g_out=gout, hyper=hyper)
         dist.all_gather_into_tensor(full, p if (self.inplace_gather or self.staged) else p.clone(), group=self.group)
         if self.staged:
             data.copy_(self.ppad[:self.numel])
-            hi = min(lo + c, self.numel)
-            grad[lo:hi].copy_(self.gpad[lo:hi])
-            m[lo:hi].copy_(mm[:hi - lo]); v[lo:hi].copy_(vv[:hi - lo])
+            grad[slo:hi].copy_(self.gpad[slo:hi])
+            m[slo:hi].copy_(mm[:hi - slo]); v[slo:hi].copy_(vv[:hi - slo])
 
     def step_arena(self, A, lr, betas, eps, weight_decay):
         """`A`: a ParamArena whose `step` the caller has already advanced (the engines' convention)."""

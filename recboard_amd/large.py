@@ -22,6 +22,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops
+from .capture import recording
 from .sasrec import ParamArena, SASRecEngine, param_shapes
 
 
@@ -266,7 +267,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with recording(graph, capture_error_mode="thread_local"):
             loss, C, rows = body()
         for t, k in zip((A.data, A.m, A.v, A.grad), keep):
             t.copy_(k)
@@ -297,7 +298,7 @@ class SASRecLargeTableEngine(SASRecEngine):
     def _train_step_graph_tail(self, seq, pos, neg, next_batch, next_ready):
         A = self.arena
         B, S = seq.shape
-        tp = self._tail_pipe(B, S)
+        tp = self._fresh_pipe(self._tail_pipe(B, S))
         p = tp["parity"]
         g = tp["graphs"][p]
         st, tp["staged"] = tp["staged"], None
@@ -579,7 +580,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with recording(graph, capture_error_mode="thread_local"):
             loss = self._sharded_body(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, hyper=hyper)
         for t, k in zip((A.data, A.m, A.v, A.grad), keep):
             t.copy_(k)

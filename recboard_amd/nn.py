@@ -14,6 +14,7 @@ in sasrec.py / gen.py / deepfm.py remain the fast path (fused steps, one arena, 
 import torch
 
 from . import torch_ops  # noqa: F401  (registers torch.ops.recengine.*)
+from .capture import recording
 
 _R = torch.ops.recengine
 
@@ -182,7 +183,7 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with recording(self.graph):
             self.loss = loss_fn(*self.static_in)
             self.loss.backward()
             optimizer.step()

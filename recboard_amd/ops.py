@@ -13,8 +13,22 @@ LOSS_BCE, LOSS_BPR = 0, 1
 TOPK_MAX = 64
 
 
+# While one of this package's captures records (recboard_amd.capture.recording), every tensor whose ADDRESS goes into a launch is noted here:
+# a hipGraph replays raw addresses, so the graph has to own what it was handed (the storage, not the tensor: no autograd history is kept
+# alive) -- a workspace, plan or view whose last Python reference goes away after the capture would otherwise be recycled by torch's
+# allocator (silently another tensor's bytes) or, once any later capture's `empty_cache()` has returned its block to the driver, be
+# unmapped under the replay ("Memory access fault by GPU", round 5: DESIGN.md section 8.0).
+_KEEP = None
+
+
+def _note(t):
+    if _KEEP is not None:
+        _KEEP.append(t.untyped_storage())
+    return t.data_ptr()
+
+
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else ctypes.c_void_p(_note(t))
 
 
 def _stream():
@@ -377,7 +391,7 @@ def _ptr_table(tensors):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
         _req(t, torch.float32, f"param[{i}]")
-        arr[i] = t.data_ptr()
+        arr[i] = _note(t)
     return arr
 
 
@@ -766,7 +780,7 @@ def adam_fuse(grad, param, m, v, hyper, beta1, beta2, eps, weight_decay):
     """-> an AdamFuse over arenas of one layout (keep the tensors alive while it is in use)."""
     for t, nm in ((grad, "grad"), (param, "param"), (m, "m"), (v, "v"), (hyper, "hyper")):
         _req(t, torch.float32, nm)
-    return AdamFuse(grad.data_ptr(), param.data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(), float(beta1), float(beta2), float(eps),
+    return AdamFuse(_note(grad), _note(param), _note(m), _note(v), _note(hyper), float(beta1), float(beta2), float(eps),
                     float(weight_decay))
 
 

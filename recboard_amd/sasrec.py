@@ -19,6 +19,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops
+from .capture import recording
 from .lib import load as lib_load
 
 
@@ -63,7 +64,22 @@ class ParamArena:
         self.grad = torch.zeros_like(self.data)
         self.m = torch.zeros_like(self.data)
         self.v = torch.zeros_like(self.data)
-        self.step = 0
+        self._step, self.step_gen = 0, 0
+
+    # the optimizer's step count.  The step loops advance it by one; ANY other write (a loaded checkpoint, a reset, a re-run of a skipped step)
+    # starts a new `step_gen`: the pipelined step's span hand-over flag (csrc/enc_plan_body.h: PlMail.epoch) is derived from the step number
+    # and never reset, so a count that moves back onto a value a staging buffer has already seen would let that buffer's stale flag pass for
+    # this step's -- SASRecEngine._fresh_pipe clears the buffers when the generation changed.
+    @property
+    def step(self):
+        return self._step
+
+    @step.setter
+    def step(self, n):
+        n = int(n)
+        if n != self._step + 1:
+            self.step_gen += 1
+        self._step = n
 
     def view(self, buf, k):
         o = self.offsets[k]
@@ -271,7 +287,11 @@ class SASRecEngine:
         """Resident workgroups per CU of the tile kernels (csrc/enc_common.h: enc_tile_wg_per_cu -- one; two at D = 64 is faster and not yet
         reproducible from process to process, profiles/r5_handover_notes.txt): the batch plan's rule counts them.  (RE_TILE_WGS=2 with the
         experiment libraries `make two` / `make twoinv` only: the library's own number must be the same.)"""
-        return int(os.environ.get("RE_TILE_WGS", "1"))
+        have = int(lib_load().re_tile_wgs_per_cu(self.D))
+        want = os.environ.get("RE_TILE_WGS")
+        if want is not None and int(want) != have:
+            raise RuntimeError(f"recengine: RE_TILE_WGS={want} but the loaded library holds {have} tile workgroup(s) per CU (make two / twoinv build the other)")
+        return have
 
     def _tail_word(self):
         if not hasattr(self, "_tail"):
@@ -537,7 +557,7 @@ class SASRecEngine:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with recording(graph, capture_error_mode="thread_local"):
             loss = body()
         for t, k in zip((A.data, A.m, A.v, A.grad), keep):
             t.copy_(k)
@@ -680,11 +700,22 @@ class SASRecEngine:
             tp = self._tail_pipes[key] = dict(blobs=blobs, mail=mail, graphs=graphs, parity=0, staged=None)
         return tp
 
+    def _fresh_pipe(self, tp):
+        """A pipe whose staging buffers were last used under another step generation (ParamArena.step): flags and staged batch are dropped."""
+        gen = self.arena.step_gen
+        if tp.get("gen") != gen:
+            if "gen" in tp:
+                for b in tp["blobs"]:
+                    b.zero_()
+                tp["staged"] = None
+            tp["gen"] = gen
+        return tp
+
     def _train_step_graph_tail(self, seq, pos, neg, next_batch, next_ready, grad_hook=None):
         A = self.arena
         B, S = seq.shape
         kind = self._sync_kind(grad_hook)
-        tp = self._tail_pipe(B, S, with_adam=kind)
+        tp = self._fresh_pipe(self._tail_pipe(B, S, with_adam=kind))
         p = tp["parity"]
         g = tp["graphs"][p]
         st, tp["staged"] = tp["staged"], None
@@ -717,7 +748,7 @@ class SASRecEngine:
         A = self.arena
         B, S = ticket.B, ticket.S
         if self._tail_prep_ok() and B <= 8192 and (next_ticket is not None or (B, S, self.training) in getattr(self, "_tail_pipes", {})):
-            tp = self._tail_pipe(B, S)
+            tp = self._fresh_pipe(self._tail_pipe(B, S))
             p = tp["parity"]
             g = tp["graphs"][p]
             st, tp["staged"] = tp["staged"], None

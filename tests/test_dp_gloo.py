@@ -34,7 +34,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, numel, q):
+def _worker(rank, world, port, numel, q, preload=False):
     try:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -43,13 +43,16 @@ def _worker(rank, world, port, numel, q):
         g0 = torch.Generator().manual_seed(7)                     # the same replica everywhere
         data = torch.randn(numel, generator=g0)
         grad, m, v = torch.zeros(numel), torch.zeros(numel), torch.zeros(numel)
-        ref_p, ref_m, ref_v = data.numpy().copy(), np.zeros(numel, np.float32), np.zeros(numel, np.float32)
+        if preload:          # moments that exist before the hook does (a checkpoint loaded into the arena): every rank holds all of them
+            m.copy_(torch.randn(numel, generator=g0) * 0.1)
+            v.copy_(torch.rand(numel, generator=g0) * 0.01)
+        ref_p, ref_m, ref_v = data.numpy().copy(), m.numpy().copy(), v.numpy().copy()
         dp = OwnerAdam(numel, local_ops=OracleReduceAdam(), device="cpu")
         assert dp.staged == (numel % (4 * world) != 0)
         assert dp.bytes_per_link_per_step == 2 * dp.chunk * 4
         lo, hi = dp.slice()
         lr, wd = 1e-2, 1e-3
-        for step in (1, 2, 3):
+        for step in ((6, 7, 8) if preload else (1, 2, 3)):
             gens = [torch.Generator().manual_seed(1000 * step + r) for r in range(world)]
             grads = [torch.randn(numel, generator=gg) * (1.0 + r) for r, gg in enumerate(gens)]      # every rank's own batch
             grad.copy_(grads[rank])
@@ -79,12 +82,13 @@ def _worker(rank, world, port, numel, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,numel", [(2, 4096), (4, 4096), (2, 1003), (4, 8 * 999 + 4)])
-def test_owner_adam_step_matches_the_unsharded_oracle(world, numel):
+@pytest.mark.parametrize("world,numel,preload", [(2, 4096, False), (4, 4096, False), (2, 1003, False), (4, 8 * 999 + 4, False),
+                                                 (2, 1003, True), (4, 4096, True), (4, 5, True)])     # (4, 5): ranks 2 and 3 own padding only
+def test_owner_adam_step_matches_the_unsharded_oracle(world, numel, preload):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, numel, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, numel, q, preload)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
