@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TF = 157.3      # MI355X fp32 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+IC_PEAK_GBS = 8600.0          # Infinity Cache, random 1-KB-class rows of a resident table (MI355X_MICROARCH.md "Indexed rows: gather into LDS")
 
 
 def ev_ms(fn, iters=30, warmup=5):
@@ -116,8 +117,10 @@ def leg_config1():
     roof1 = None
     if t_own:
         roof1 = {"kernel": "scatter_adam_owner_k (re_scatter_adam_rows_small): scatter-add of the step's 3 x B gradient rows + dense Adam of all "
-                           f"{U + N} rows in one launch", "bound": "hbm", "achieved": round(own_bytes / (t_own * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": round(own_bytes / (t_own * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(t_own, 4),
+                           f"{U + N} rows in one launch", "bound": "infinity_cache", "achieved": round(own_bytes / (t_own * 1e-3) / 1e9, 1), "peak": IC_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(own_bytes / (t_own * 1e-3) / 1e9 / IC_PEAK_GBS, 4), "traffic": None, "launch_ms": round(t_own, 4),
+                 "frac_of_hbm_peak": round(own_bytes / (t_own * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "peak_source": "MI355X_MICROARCH.md 'Indexed rows': 8.6 TB/s chip-wide from a 38 MB Infinity-Cache-resident table (the guide's one measured Infinity Cache rate)",
                  "work": f"algorithmic {own_bytes / 1e6:.1f} MB per launch: {(U + N) * D} parameter elements x (12 B read + 12 B written) + {3 * B} "
                          f"contribution rows x (4 + {4 * D}) B (the 26 MB of parameters and moments live in the Infinity Cache between steps: "
                          "the bound a launch of this size sees is the cache's, not HBM's)"}
@@ -185,8 +188,13 @@ def leg_config3():
             "launch": "one hipGraph replay per step, or its launches issued eagerly: `value` is the faster form",
             "config": {"workload": f"LightGCN d=64, 3 layers, {U} users x {N} items, {len(eu)} edges (adjacency nnz {nnz}), B={B}: 3 + 3 SpMMs per step, "
                                    "loss = rec + 1e-3 emb, Adam without weight decay (LightGCN/main.py:139-160)"},
-            "roofline": {"kernel": "spmm_csr_rows / spmm_csr_long (re_spmm_csr): one propagation X <- A X", "bound": "hbm", "achieved": round(gbs, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(t_sp, 4),
+            # the bound that binds: every non-zero gathers a 256-B row of the 31.5 MB X out of the Infinity Cache (round-5 verdict: a launch whose
+            # operand lives in a cache is priced against that cache's measured ceiling, not against HBM on bytes that never leave the die)
+            "roofline": {"kernel": "spmm_csr_rows / spmm_csr_long (re_spmm_csr): one propagation X <- A X", "bound": "infinity_cache",
+                         "achieved": round((alg + nnz * 4 * D) / (t_sp * 1e-3) / 1e9, 1), "peak": IC_PEAK_GBS, "unit": "GB/s",
+                         "frac": round((alg + nnz * 4 * D) / (t_sp * 1e-3) / 1e9 / IC_PEAK_GBS, 4), "traffic": None, "launch_ms": round(t_sp, 4),
+                         "algorithmic_hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                             "note": "algorithmic bytes only (CSR stream + each X / Y row once) against the HBM peak"},
                          "gathered_rows": {"achieved": round((alg + nnz * 4 * D) / (t_sp * 1e-3) / 1e9, 1), "peak": 8600.0, "unit": "GB/s",
                                            "frac": round((alg + nnz * 4 * D) / (t_sp * 1e-3) / 1e9 / 8600.0, 4),
                                            "note": "what bounds the launch: every non-zero gathers a 256-B X row from the 31.5 MB X, which lives in the "

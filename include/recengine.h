@@ -488,6 +488,15 @@ int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64
                 const int64_t* row_order, int64_t nlong, const int32_t* chunk_row, const int64_t* chunk_ptr,
                 int64_t nchunks, const float* X, int64_t D, float* Y, const float* Z, float beta, float* ACC,
                 float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream);
+/* re_spmm_csr with the plan's TWO ROW CLASSES kept apart by XCD and / or the once-read streams moved non-temporally.  A bipartite
+ * adjacency's user rows gather item rows and its item rows gather user rows: row_order = [nlong long rows | class 0 | class 1], `split` =
+ * position of class 1's first row in row_order (<= nlong or == nrows: one class, as re_spmm_csr), `xcd_share` (1 .. 7) = how many of the 8
+ * XCD labels (blockIdx % 8) walk class 0 -- each XCD's L2 then holds the hot rows of ONE part of X.  flags & 1: (col, val), Z, Y and ACC
+ * go through the caches with the non-temporal hint.  Bit-identical to re_spmm_csr (a row's sum does not depend on who computes it). */
+int re_spmm_csr_split(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
+                      const int64_t* row_order, int64_t nlong, int64_t split, int32_t xcd_share, int32_t flags,
+                      const int32_t* chunk_row, const int64_t* chunk_ptr, int64_t nchunks, const float* X, int64_t D, float* Y,
+                      const float* Z, float beta, float* ACC, float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream);
 size_t re_rows_sqnorm_workspace_bytes(void);
 int re_rows_sqnorm(const float* W, int64_t R, int64_t D, const int64_t* idx, int64_t n, float scale, float* out,
                    int accumulate, void* ws, size_t ws_bytes, re_stream_t stream);

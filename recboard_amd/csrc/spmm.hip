@@ -28,7 +28,29 @@ __device__ __forceinline__ void f4_axpy(float4& a, float s, const float4& x) {
 #endif
 // a row's (or a strided share of a row's) non-zeros SP_ILP at a time; the NEXT group's (col, val) are requested before this group's X rows, so
 // an iteration costs one memory round trip (the X rows), not two (indices, then rows)
-template <int LPR>
+// NT: the CSR stream (col, val: 12 B per non-zero, each read ONCE per launch) and the output rows are moved with the non-temporal hint, so
+// that what an XCD's 4 MiB L2 keeps are the gathered X rows -- the only bytes of the launch that are ever read twice.
+template <bool NT, typename T>
+__device__ __forceinline__ T sp_ld(const T* p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
+template <bool NT>
+__device__ __forceinline__ void sp_st4(float4* p, const float4& v) {
+    if constexpr (NT) {
+        float* q = reinterpret_cast<float*>(p);
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(q));
+    } else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ float4 sp_ld4(const float4* p) {
+    if constexpr (NT) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v w = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+        return make_float4(w.x, w.y, w.z, w.w);
+    } else return *p;
+}
+
+template <int LPR, bool NT = false>
 __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col, const float* __restrict__ val,
                                                   const float* __restrict__ X, int64_t ncols, int64_t D, int64_t c4,
                                                   int64_t p0, int64_t p1, int64_t step) {
@@ -39,7 +61,7 @@ __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col
         int64_t cc[U];
         float vv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { cc[u] = col[p + u * step]; vv[u] = val[p + u * step]; }
+        for (int u = 0; u < U; ++u) { cc[u] = sp_ld<NT>(col + p + u * step); vv[u] = sp_ld<NT>(val + p + u * step); }
         for (;;) {
             const int64_t pn = p + U * step;
             const bool more = pn + (U - 1) * step < p1;
@@ -48,7 +70,7 @@ __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col
 #pragma unroll
             for (int u = 0; u < U; ++u) {   // (clamped, unconditional: in flight beside the X rows below.  Padding the last group with
                 const int64_t q = more ? pn + u * step : p;   //  weight-0 slots instead of the tail loops was measured slower: 136 / 156 vs 126 us)
-                nc[u] = col[q]; nv[u] = val[q];
+                nc[u] = sp_ld<NT>(col + q); nv[u] = sp_ld<NT>(val + q);
             }
             float4 xr[U];
 #pragma unroll
@@ -70,7 +92,7 @@ __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col
         float vv[4];
         float4 xr[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { cc[u] = col[p + u * step]; vv[u] = val[p + u * step]; }
+        for (int u = 0; u < 4; ++u) { cc[u] = sp_ld<NT>(col + p + u * step); vv[u] = sp_ld<NT>(val + p + u * step); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -80,26 +102,30 @@ __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col
         for (int u = 0; u < 4; ++u) f4_axpy(acc, vv[u], xr[u]);
     }
     for (; p < p1; p += step) {
-        const int64_t cc = col[p];
-        if (cc >= 0 && cc < ncols) f4_axpy(acc, val[p], reinterpret_cast<const float4*>(X + cc * D)[c4]);
+        const int64_t cc = sp_ld<NT>(col + p);
+        if (cc >= 0 && cc < ncols) f4_axpy(acc, sp_ld<NT>(val + p), reinterpret_cast<const float4*>(X + cc * D)[c4]);
     }
     return acc;
 }
 
-template <int LPR>
+template <int LPR, bool NT = false>
 __device__ __forceinline__ void spmm_store(float4 acc, int64_t r, int64_t D, int64_t c4, float* __restrict__ Y,
                                            const float* __restrict__ Z, float beta, float* __restrict__ ACC, float acc_scale) {
-    if (Z) f4_axpy(acc, beta, reinterpret_cast<const float4*>(Z + r * D)[c4]);
-    reinterpret_cast<float4*>(Y + r * D)[c4] = acc;
+    if (Z) f4_axpy(acc, beta, sp_ld4<NT>(reinterpret_cast<const float4*>(Z + r * D) + c4));
+    sp_st4<NT>(reinterpret_cast<float4*>(Y + r * D) + c4, acc);
     if (ACC) {
-        float4 a = reinterpret_cast<float4*>(ACC + r * D)[c4];
+        float4 a = sp_ld4<NT>(reinterpret_cast<const float4*>(ACC + r * D) + c4);
         f4_axpy(a, acc_scale, acc);
-        reinterpret_cast<float4*>(ACC + r * D)[c4] = a;
+        sp_st4<NT>(reinterpret_cast<float4*>(ACC + r * D) + c4, a);
     }
 }
 
-template <int LPR>
-__global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__ row_order, int64_t first,
+// split > first (re_spmm_csr_split; the grid is then a multiple of 8): row_order[first, split) and row_order[split, nrows) are two ROW
+// CLASSES that gather from different parts of X -- a bipartite adjacency's user rows gather item rows and the other way round -- and the
+// blocks that share an XCD (blockIdx % 8 labels them: cdna_hip_programming.md T1) all walk ONE class: labels [0, k0) the first, [k0, 8) the
+// second.  Each L2 then has to hold the hot rows of one part of X instead of both.
+template <int LPR, bool NT>
+__global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__ row_order, int64_t first, int64_t split, int k0,
                                                      const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
                                                      const float* __restrict__ val, int64_t nrows, int64_t ncols,
                                                      const float* __restrict__ X, int64_t D, float* __restrict__ Y,
@@ -108,14 +134,23 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__
     const int lir = threadIdx.x % LPR;
     const int64_t gpb = 256 / LPR;
     const int64_t D4 = D >> 2;
+    int64_t lo = first, hi = nrows, bi = blockIdx.x, nb = gridDim.x;
+    if (split > first) {
+        const int lab = blockIdx.x & 7, cls = lab >= k0;
+        const int k = cls ? 8 - k0 : k0;
+        bi = (int64_t)(blockIdx.x >> 3) * k + (cls ? lab - k0 : lab);
+        nb = (int64_t)(gridDim.x >> 3) * k;
+        lo = cls ? split : first;
+        hi = cls ? nrows : split;
+    }
     // rows are visited in descending-degree order (row_order): the 4 (or 2) rows a wave works on have similar lengths,
     // and the longest rows start first
-    for (int64_t i = first + (int64_t)blockIdx.x * gpb + threadIdx.x / LPR; i < nrows; i += (int64_t)gridDim.x * gpb) {
+    for (int64_t i = lo + bi * gpb + threadIdx.x / LPR; i < hi; i += nb * gpb) {
         const int64_t r = row_order ? row_order[i] : i;
         const int64_t p0 = crow[r], p1 = crow[r + 1];
         for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
-            const float4 acc = spmm_row_range<LPR>(col, val, X, ncols, D, c4, p0, p1, 1);
-            spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
+            const float4 acc = spmm_row_range<LPR, NT>(col, val, X, ncols, D, c4, p0, p1, 1);
+            spmm_store<LPR, NT>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
         }
     }
 }
@@ -176,10 +211,10 @@ __global__ __launch_bounds__(256) void spmm_csr_long_combine(const int64_t* __re
     }
 }
 
-extern "C" int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
-                           const int64_t* row_order, int64_t nlong, const int32_t* chunk_row, const int64_t* chunk_ptr,
-                           int64_t nchunks, const float* X, int64_t D, float* Y, const float* Z, float beta, float* ACC,
-                           float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream) {
+static int spmm_launch(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
+                       const int64_t* row_order, int64_t nlong, int64_t split, int k0, int flags, const int32_t* chunk_row, const int64_t* chunk_ptr,
+                       int64_t nchunks, const float* X, int64_t D, float* Y, const float* Z, float beta, float* ACC,
+                       float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream) {
     re_clear_error();
     if (nrows == 0) return RE_OK;
     if (!crow || !col || !val || !X || !Y || nrows < 0 || ncols <= 0 || D <= 0 || nlong < 0 || nlong > nrows) return RE_EINVAL;
@@ -194,12 +229,38 @@ extern "C" int re_spmm_csr(const int64_t* crow, const int64_t* col, const float*
 #define SP_LAUNCH(LPRV)                                                                                                             \
     do {                                                                                                                            \
         if (nlong) hipLaunchKernelGGL(spmm_csr_long<LPRV>, dim3(re_grid(nchunks, 1, 65536)), dim3(256), 0, s, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial); \
-        if (nrows > nlong) hipLaunchKernelGGL(spmm_csr_rows<LPRV>, dim3(re_grid(nrows - nlong, 256 / LPRV, 65536)), dim3(256), 0, s, row_order, nlong, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
+        if (nrows > nlong) {                                                                                                        \
+            unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536);                                                       \
+            if (split > nlong) g = (g + 7u) & ~7u;                                                                                  \
+            if (flags & 1) hipLaunchKernelGGL((spmm_csr_rows<LPRV, true>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
+            else hipLaunchKernelGGL((spmm_csr_rows<LPRV, false>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
+        }                                                                                                                           \
         if (nlong) hipLaunchKernelGGL(spmm_csr_long_combine<LPRV>, dim3((unsigned)re_cdiv(nlong, 256 / LPRV)), dim3(256), 0, s, row_order, nlong, chunk_ptr, partial, D, Y, Z, beta, ACC, acc_scale); \
     } while (0)
     if ((D >> 2) >= 32) SP_LAUNCH(32); else SP_LAUNCH(16);
 #undef SP_LAUNCH
     return re_launch_status();
+}
+
+extern "C" int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
+                           const int64_t* row_order, int64_t nlong, const int32_t* chunk_row, const int64_t* chunk_ptr,
+                           int64_t nchunks, const float* X, int64_t D, float* Y, const float* Z, float beta, float* ACC,
+                           float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream) {
+    return spmm_launch(crow, col, val, nrows, ncols, row_order, nlong, 0, 0, 0, chunk_row, chunk_ptr, nchunks, X, D, Y, Z, beta, ACC, acc_scale, ws,
+                       ws_bytes, stream);
+}
+
+// The same product with the plan's two row classes kept apart by XCD (spmm_csr_rows) and / or the once-read streams moved non-temporally:
+// row_order = [nlong long rows | class 0 | class 1], split = index of class 1's first row (<= nlong: one class), xcd_share = how many of the
+// 8 XCD labels walk class 0 (1 .. 7), flags & 1 = non-temporal streams.  Results are bit-identical to re_spmm_csr's: a row's sum does not
+// depend on which workgroup computes it.
+extern "C" int re_spmm_csr_split(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
+                                 const int64_t* row_order, int64_t nlong, int64_t split, int32_t xcd_share, int32_t flags,
+                                 const int32_t* chunk_row, const int64_t* chunk_ptr, int64_t nchunks, const float* X, int64_t D, float* Y,
+                                 const float* Z, float beta, float* ACC, float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream) {
+    if (split < 0 || split > nrows || (split > nlong && (!row_order || xcd_share < 1 || xcd_share > 7))) { re_clear_error(); return RE_EINVAL; }
+    return spmm_launch(crow, col, val, nrows, ncols, row_order, nlong, split > nlong && split < nrows ? split : 0, xcd_share, flags, chunk_row,
+                       chunk_ptr, nchunks, X, D, Y, Z, beta, ACC, acc_scale, ws, ws_bytes, stream);
 }
 
 // rows' squared L2 norms: out[0] = scale * sum_i ||W[idx[i], :]||^2   (BaseCriterion.regularize(.., "l2") = sum/2,

@@ -64,6 +64,11 @@ class OwnerAdam:
         """One synchronous data-parallel optimizer step over the flat arenas (data, grad, m, v: [numel] each).  On return `data` holds the
         updated parameters of every slice; grad[own slice] the averaged gradient; m / v[own slice] the owner's moments."""
         G, c, lo = self.G, self.chunk, self.rank * self.chunk
+        if G == 1 and not self.staged:
+            # one replica: there is nobody to exchange with -- the owner's launch over the whole arena IS the step (no collective is issued
+            # or recorded: a world-1 `--dp owner` step costs what the plain step costs; round 5 paid +18 % for two self-copies)
+            self.ops.reduce_adam(data, grad.view(1, c), m, v, step, lr, betas[0], betas[1], eps, weight_decay, 1.0, g_out=None, hyper=hyper)
+            return
         send = grad
         if self.staged:
             self.gpad[:self.numel].copy_(grad)

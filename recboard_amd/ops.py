@@ -928,10 +928,23 @@ class SpmmPlan:
     """Once per adjacency (the only host-visible preprocessing): rows in descending-degree order; the rows with more than
     SPMM_LONG non-zeros are cut into chunks of SPMM_CHUNK non-zeros that get a workgroup each."""
 
-    def __init__(self, crow: torch.Tensor, D: int):
+    def __init__(self, crow: torch.Tensor, D: int, split_row: int = 0, nt: bool = None):
+        """split_row (0: none): rows [0, split_row) and [split_row, n) are two classes that gather from different parts of X (a bipartite
+        adjacency: split_row = number of users); the short rows of each class are then walked by XCDs of their own (re_spmm_csr_split),
+        the XCD labels shared out by the classes' non-zeros.  nt: non-temporal streams (default: with a split)."""
         deg = crow[1:] - crow[:-1]
         self.row_order = torch.argsort(deg, descending=True, stable=True).contiguous()
         self.nlong = int((deg > SPMM_LONG).sum())
+        self.split, self.xcd_share, self.flags = 0, 4, int(bool(nt if nt is not None else split_row))
+        n = deg.numel()
+        if 0 < int(split_row) < n:
+            short = self.row_order[self.nlong:]
+            c0, c1 = short[short < split_row], short[short >= split_row]             # (boolean masks keep the descending-degree order)
+            if c0.numel() and c1.numel():
+                w0, w1 = float(deg[c0].sum()), float(deg[c1].sum())
+                self.row_order = torch.cat([self.row_order[: self.nlong], c0, c1]).contiguous()
+                self.split = self.nlong + int(c0.numel())
+                self.xcd_share = min(7, max(1, int(round(8.0 * w0 / max(w0 + w1, 1.0)))))
         ldeg = deg[self.row_order[: self.nlong]]
         nch = (ldeg + SPMM_CHUNK - 1) // SPMM_CHUNK
         self.chunk_ptr = torch.zeros(self.nlong + 1, dtype=torch.int64, device=crow.device)
@@ -941,8 +954,8 @@ class SpmmPlan:
         self.ws = torch.empty(max(self.nchunks * D, 4), dtype=torch.float32, device=crow.device)
 
 
-def spmm_plan(crow: torch.Tensor, D: int = 64):
-    return SpmmPlan(crow, D)
+def spmm_plan(crow: torch.Tensor, D: int = 64, split_row: int = 0, nt: bool = None):
+    return SpmmPlan(crow, D, split_row, nt)
 
 
 def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0):
@@ -955,6 +968,12 @@ def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale
     D = X.shape[1]
     if plan.ws.numel() < plan.nchunks * D:
         plan.ws = torch.empty(plan.nchunks * D, dtype=torch.float32, device=X.device)
+    if getattr(plan, "split", 0) or getattr(plan, "flags", 0):
+        lib.check(lib.load().re_spmm_csr_split(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(plan.row_order), plan.nlong, int(plan.split),
+                                               int(plan.xcd_share), int(plan.flags), _p(plan.chunk_row), _p(plan.chunk_ptr), plan.nchunks, _p(X), D,
+                                               _p(out), _p(Z), float(beta), _p(acc), float(acc_scale), _p(plan.ws), plan.ws.numel() * 4, _stream()),
+                  "re_spmm_csr_split")
+        return out
     lib.check(lib.load().re_spmm_csr(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(plan.row_order), plan.nlong,
                                      _p(plan.chunk_row), _p(plan.chunk_ptr), plan.nchunks, _p(X), D, _p(out), _p(Z), float(beta),
                                      _p(acc), float(acc_scale), _p(plan.ws), plan.ws.numel() * 4, _stream()), "re_spmm_csr")

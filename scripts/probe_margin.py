@@ -14,7 +14,7 @@ import torch  # noqa: E402
 from test_freerec_compat import import_script, toy_dataset  # noqa: E402
 
 from recboard_amd import bridge  # noqa: E402
-bridge.GRAD_TOL = 1e9          # (report only)
+bridge.GRAD_TOL = bridge.GRAD_TOL_SMOOTH = bridge.GRAD_TOL_UPSTREAM = 1e9          # (report only)
 mod = import_script(os.path.join(ROOT, "examples", "SASRec", "main.py"), "_probe_margin", ["--dropout-rate", "0.5", "--loss", "BCE"])
 
 

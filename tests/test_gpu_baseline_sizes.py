@@ -7,6 +7,8 @@ against the CPU oracle on the same seeded inputs.
   C4  DeepFM on the Games-context schema (USER 94 762, ITEM 25 612 + 8 context fields), B = 4 096: loss, logits, gradients.
 The oracle finishes each of these in seconds; these are the shapes bench.py / scripts/bench_models.py time.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -133,29 +135,41 @@ def test_c4_deepfm_games_context_schema_matches_oracle():
     x[:, 1] = np.minimum(rng.zipf(1.3, B), counts[1]) - 1                # popular items: heavy duplicate rows in the scatter-add
     y = (rng.random(B) < 0.3).astype(np.float32).reshape(B, 1)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
-    tabs = [t.detach().cpu().clone().requires_grad_(True) for t in m.tables()]
-    tls = [t.detach().cpu().clone().requires_grad_(True) for t in m.tables_lr()]
-    bias = m.bias.detach().cpu().clone().requires_grad_(True)
-    mlp = []
-    for i in range(m.nl):
-        blk = {"linear.weight": m.P[f"dnn.{i}.linear.weight"], "linear.bias": m.P[f"dnn.{i}.linear.bias"],
-               "bn.weight": m.P[f"dnn.{i}.bn.weight"], "bn.bias": m.P[f"dnn.{i}.bn.bias"]}
-        mlp.append({k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.items()})
-    mlp.append({"weight": m.P[f"dnn.{m.nl}.weight"].detach().cpu().clone().requires_grad_(True),
-                "bias": m.P[f"dnn.{m.nl}.bias"].detach().cpu().clone().requires_grad_(True)})
+    # The reference is the oracle in DOUBLE precision: at B = 4 096 a weight gradient is a 4 096-term sum and BatchNorm's statistics are
+    # 4 096-term means -- the fp32 oracle is itself up to ~1e-4 of a tensor's scale away from exact arithmetic (measured below and asserted
+    # loosely), so two fp32 implementations can only be held to 2e-4 against EACH OTHER (round 5's bound); against the fp64 result the
+    # engine is held to north_star's 1e-4.
+    def leaves(dt):
+        c = lambda t: t.detach().cpu().to(dt).clone().requires_grad_(True)  # noqa: E731
+        tabs, tls, bias = [c(t) for t in m.tables()], [c(t) for t in m.tables_lr()], c(m.bias)
+        mlp = [{k: c(m.P[f"dnn.{i}.{k}"]) for k in ("linear.weight", "linear.bias", "bn.weight", "bn.bias")} for i in range(m.nl)]
+        mlp.append({"weight": c(m.P[f"dnn.{m.nl}.weight"]), "bias": c(m.P[f"dnn.{m.nl}.bias"])})
+        return tabs, tls, bias, mlp
+    tabs, tls, bias, mlp = leaves(torch.float64)
     ref_logits = odfm.encode(tabs, tls, bias, mlp, xt, True)
-    ref = odfm.criterions.bce_with_logits(ref_logits, yt)
+    ref = odfm.criterions.bce_with_logits(ref_logits, yt.double())
     ref.backward()
+    tabs32, tls32, bias32, mlp32 = leaves(torch.float32)
+    odfm.criterions.bce_with_logits(odfm.encode(tabs32, tls32, bias32, mlp32, xt, True), yt).backward()
+    worst32 = max(float((a.grad.double() - b.grad).abs().max() / b.grad.abs().max())
+                  for a, b in [(mlp32[i][k], mlp[i][k]) for i in range(m.nl) for k in ("linear.weight", "bn.weight", "bn.bias")])
+    os.write(2, f"\n[c4] fp32 oracle vs fp64 oracle, worst MLP tensor: {worst32:.2e} of the tensor's scale\n".encode())
     logits, _ = m.encode(xt.cuda())
-    assert (logits.cpu() - ref_logits.detach().reshape(-1)).abs().max() <= 1e-4 * ref_logits.abs().max()
+    assert (logits.cpu().double() - ref_logits.detach().reshape(-1)).abs().max() <= 1e-4 * ref_logits.abs().max()
     loss = m.forward_backward(xt.cuda(), yt.cuda()).item()
     np.testing.assert_allclose(loss, ref.item(), rtol=1e-5)
     for f, (o, c) in enumerate(zip(m.offsets.tolist(), m.counts)):
         for got, r in ((m.gT[o:o + c], tabs[f].grad), (m.gTL[o:o + c], tls[f].grad)):
-            assert (got.cpu() - r).abs().max() <= 2e-4 * r.abs().max() + 1e-9, f
+            assert (got.cpu().double() - r).abs().max() <= 1e-4 * r.abs().max() + 1e-9, f
+    scale = max(float(mlp[i]["linear.weight"].grad.abs().max()) for i in range(m.nl))
     for i in range(m.nl):
         for k in ("linear.weight", "bn.weight", "bn.bias"):
             r = mlp[i][k].grad
-            assert (m.G[f"dnn.{i}.{k}"].cpu() - r).abs().max() <= 2e-4 * r.abs().max() + 1e-8, (i, k)
+            assert (m.G[f"dnn.{i}.{k}"].cpu().double() - r).abs().max() <= 1e-4 * r.abs().max() + 1e-8, (i, k)
+        # the Linear bias in front of a BatchNorm: its exact gradient is 0 (BatchNorm's backward removes the column mean).  The engine keeps
+        # it EXACTLY zero (nothing writes it: the parameter never moves); autograd hands Adam cancellation residue there (fp32: ~1e-10 of
+        # the model's gradient scale, which torch's Adam then normalises into +-lr steps -- INTEGRATION.md "State-dict differences").
+        assert torch.count_nonzero(m.G[f"dnn.{i}.linear.bias"]).item() == 0
+        assert mlp[i]["linear.bias"].grad.abs().max() <= 1e-9 * scale and mlp32[i]["linear.bias"].grad.abs().max() <= 1e-5 * scale
     r = mlp[-1]["weight"].grad
-    assert (m.G[f"dnn.{m.nl}.weight"].cpu() - r).abs().max() <= 2e-4 * r.abs().max() + 1e-8
+    assert (m.G[f"dnn.{m.nl}.weight"].cpu().double() - r).abs().max() <= 1e-4 * r.abs().max() + 1e-8
