@@ -87,18 +87,20 @@ __host__ __device__ inline int64_t enc_plan_max_tiles(int64_t B, int64_t S) { re
 // which form of the tile kernels a launch of this shape uses (enc_tile_body.inc: enc_tile_step_k<LOOP>): batches of more than 2048 possible
 // tiles (B > 512 at S = 50) the looped one -- the plan (enc_plan_body.h) applies the matching rule
 __host__ __device__ inline bool enc_tile_looped(int64_t B, int64_t S) { return enc_plan_max_tiles(B, S) > 2048; }
-// resident workgroups per CU of the tile kernels (enc_tile.hip).  ONE: at D = 64 two would fit (four waves, ~190 registers, 58 KB of LDS each) and
-// are 14 - 20 % faster on batches of 1 024 - 4 096 sequences, but with two the results differ from process to process in single registers of single
-// waves -- still unexplained after round 5 ruled out SGPR spills, the barriers' missing vmcnt drain and the transcendental forwarding hazard
-// (profiles/r5_handover_notes.txt).  The launcher, the plan's rule (split_long & 8) and the looped grid all follow this one number.
+// resident workgroups per CU of the tile kernels (enc_tile.hip).  TWO at D = 64 since round 6 (four waves, ~206 registers, 58 KB of LDS each: 14 - 20 %
+// faster on batches of 1 024 - 4 096 sequences); ONE at D = 128 (eight waves, 234 registers).  Rounds 3 - 5 shipped one: with two the results differed
+// from replay to replay -- the LOW register of a packed-fp32 result (v_pk_mul / add / fma_f32) wrong in its last sixteen lanes whenever two waves
+// shared a SIMD.  enc_tile.hip is compiled without packed-fp32 instructions now (Makefile: TILE_FLAGS; profiles/r6_handover_notes.txt), which also
+// covers the D = 128 kernels, whose eight waves put two on a SIMD at ONE workgroup per CU.  The launcher, the plan's rule (split_long & 8: the host
+// asks re_tile_wgs_per_cu) and the looped grid all follow this one number.
 // the most tiles a batch may have for the tile kernels to run it (the plan's rule, enc_plan_body.h): their dK / dV inboxes (enc_tile_prep.h:
 // enc_tile_xch_bytes) are sized for this many tiles, not for every tile a batch of B sequences could have (B = 8 192: 32 768 tiles = 1.6 GB of
 // inboxes that the plan's speed rule -- at most ~10 tiles per resident workgroup -- never let the kernels use)
 #define ENC_XCH_TILE_CAP 5120
 #ifndef ENC_TILE_WG_PER_CU
-#define ENC_TILE_WG_PER_CU 1      // (2: the experiment builds `make two` / `make twoinv`, scripts/handover_soak.py --lib two)
+#define ENC_TILE_WG_PER_CU 2      // (D = 64; `make one` builds the one-per-CU library for A/B runs)
 #endif
-__host__ __device__ inline int enc_tile_wg_per_cu(int64_t D) { (void)D; return ENC_TILE_WG_PER_CU; }
+__host__ __device__ inline int enc_tile_wg_per_cu(int64_t D) { return D == 64 ? ENC_TILE_WG_PER_CU : 1; }
 // rows of the vector-gradient slab in the backward's workspace: one per workgroup (<= 1024) or one per tile (enc_tile.hip)
 __host__ __device__ inline int64_t enc_slab_rows(int64_t B, int64_t S) { const int64_t mt = enc_plan_max_tiles(B, S); return mt > 1024 ? mt : 1024; }
 __host__ __device__ inline int64_t enc_plan_rowmap_word(int64_t B, int64_t S) { return (EP_HDR + enc_plan_max_tiles(B, S) + 1) / 2 * 2; }

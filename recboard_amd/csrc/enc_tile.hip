@@ -38,6 +38,15 @@
 // sums over a strip's tokens, written per TILE to the slab.
 #include <math.h>
 
+// NO PACKED-FP32 VECTOR INSTRUCTIONS IN THIS FILE'S DEVICE CODE (round 6; profiles/r6_handover_notes.txt): the Makefile compiles this file with
+// `-Xclang -target-feature -Xclang -packed-fp32-ops`.  With `v_pk_mul_f32` / `v_pk_add_f32` / `v_pk_fma_f32` in the tile kernels (hipcc emits 336 of
+// them at D = 64) and TWO workgroups resident per CU -- two waves per SIMD -- the LOW register of a packed result occasionally comes out wrong
+// in its last sixteen lanes (the lane group of features 12 - 15, register 0 or 2 of the backward's incoming gradient: gradient-tape array dO2,
+// columns 16 s + 12 / 16 s + 14; every later array of the tile follows).  Same code, same data: bit-identical with one workgroup per CU (84 KB
+// of LDS requested), different from replay to replay inside one process with two (58 - 79 KB); not HBM contents, not memory waits
+// (`-amdgpu-waitcnt-forcezero`: still random), not flat atomics, not VGPR-index mode, not the permlane swaps -- and gone (36 / 36 replays
+// identical) once the compiler is told the target has no packed-fp32 operations.  (A `target("no-packed-fp32-ops")` attribute on the kernels
+// does not compile: "illegal VGPR to SGPR copy"; the per-file flag does.)  Cost: +5 % vector instructions on a latency-bound chain.
 #include "enc_fwd_item.h"
 #include "enc_tile_prep.h"
 
@@ -170,6 +179,9 @@ static int tl_launch(KP prep_k, KS step_k, const SeEmbed& em, const int64_t* seq
     if (grid > TL_CHK_TILES) return RE_EUNSUPPORTED;
 #else
     if (enc_tile_wg_per_cu(16 * NS) == 1 && ldsb < (size_t)84 * 1024) ldsb = (size_t)84 * 1024;
+#endif
+#ifdef TL_LDS_KB_ENV   // (round-6 experiment builds only: the LDS request from the environment -- 84: ONE workgroup per CU whatever the grid)
+    if (const char* e = getenv("RE_TILE_LDS_KB")) { const size_t want = (size_t)atoi(e) * 1024; if (want > ldsb) ldsb = want; }
 #endif
     if (hipFuncSetAttribute((const void*)step_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
     const TlArgs A{em, seq, (int)B, (int)S, (int)L, ds, thresh, seed, u, (float*)tape, T, plan, H, dx0, gtape, slab, seed_dev, scale, (const uint32_t*)wf, xch, grid};

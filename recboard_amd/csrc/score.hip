@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
                                                           const float* __restrict__ qnorm, const unsigned* __restrict__ emax, float cerr,
                                                           float* __restrict__ vals, int64_t* __restrict__ idx,
                                                           int* __restrict__ userflag, int* __restrict__ blockflag,
-                                                          int dbg_maxerr, int segs, int n_emax) {
+                                                          int dbg_maxerr, int segs, int n_emax, int* __restrict__ fl_list) {
     constexpr int LPR = D / 4;
     __shared__ __align__(16) float mx_stage[4 * MX_ROWS * D];
     const int mxd = dbg_maxerr >> 4;
@@ -1584,7 +1584,11 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
     if (!pass) {
         if (lane == 0) {
             userflag[user] = 1; blockflag[ub] = 1; atomicAdd(&g_sx_stats[0], 1u);
-            blockflag[(B + SC_USERS - 1) / SC_USERS + 1] = 1;   // "somebody is flagged": the word the fallback kernel looks at first
+            // "somebody is flagged": the word the fallback kernel looks at first -- and, where the call ends in score_rescan_k (fl_list), the
+            // NUMBER of flagged users, each of them listed
+            int* const nfl = &blockflag[(B + SC_USERS - 1) / SC_USERS + 1];
+            if (fl_list) fl_list[atomicAdd(nfl, 1)] = (int)user;
+            else *nfl = 1;
             if (dbg_maxerr) {   // diagnostics: the last flagged user's certificate inputs
                 g_sx_info[0] = (float)user; g_sx_info[1] = T; g_sx_info[2] = xk; g_sx_info[3] = (float)eps;
                 g_sx_info[4] = (float)total; g_sx_info[5] = (float)nseg; g_sx_info[6] = validk ? 1.f : 0.f; g_sx_info[7] = (float)K;
@@ -1593,6 +1597,103 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
         return;
     }
     topk_emit(sx, bi, lane, user, N, K, seen_ptr, seen_idx, vals, idx);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The split path's fallback for catalogs of up to SX_RESCAN_MAX_N items: ONE wave per FLAGGED user (the list score_topk_merge_x wrote)
+// scans the whole catalog with the exact fmaf chain -- 64 items at a time, rows staged through the wave's LDS slice by LDS-DMA as in the
+// merge's re-scoring, seen items dropped by a cursor into the user's sorted list, each chunk that holds anything better than the current
+// K-th merged into the wave's best-64 list by the merge's bitonic networks -- and writes the user's result.  Nobody flagged (the normal case):
+// every wave reads one word and leaves; that replaces the TWO launches (exact kernel over flagged blocks + its merge) whose dispatch was
+// 9 of the call's 387 us.  A flagged user costs ~N / 64 chunk rounds of ~2 000 cycles on one wave (Beauty: ~0.15 ms; every user of a
+// 22 363-user call flagged -- all-zero queries: ~2 ms instead of the exact kernels' 0.6): correctness, as before, never depends on it.
+#define SX_RESCAN_MAX_N (1 << 17)
+template <int D>
+__global__ __launch_bounds__(256) void score_rescan_k(const int* __restrict__ nfl, const int* __restrict__ fl_list, int64_t B, int64_t N, int K,
+                                                      const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
+                                                      const float* __restrict__ Q, const float* __restrict__ E,
+                                                      float* __restrict__ vals, int64_t* __restrict__ idx) {
+    constexpr int LPR = D / 4;
+    __shared__ __align__(16) float mx_stage[4 * MX_ROWS * D];
+    int n = *nfl;
+    if (n <= 0) return;
+    if (n > B) n = (int)B;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int PAD = 0x7FFFFFFF;
+    float* stage = mx_stage + wv * (MX_ROWS * D);
+    constexpr int CPR = LPR, RPI = 64 / CPR, IPP = MX_ROWS / RPI;
+    for (int f = blockIdx.x * 4 + wv; f < n; f += gridDim.x * 4) {
+        const int64_t user = __builtin_amdgcn_readfirstlane(fl_list[f]);
+        const float* qrow = Q + user * D;
+        int64_t sp = seen_ptr ? seen_ptr[user] : 0;
+        const int64_t se = seen_ptr ? seen_ptr[user + 1] : 0;
+        int64_t wbase = -1, w = 0;
+        float bv = -INFINITY;
+        int bi = PAD;
+        for (int64_t c0 = 0; c0 < N; c0 += 64) {
+            float sx = -INFINITY;
+#pragma unroll 1
+            for (int r0 = 0; r0 < 64; r0 += MX_ROWS) {
+                if (c0 + r0 >= N) break;
+#pragma unroll
+                for (int i = 0; i < IPP; ++i) {
+                    const int r = i * RPI + lane / CPR;
+                    int64_t id = c0 + r0 + r;
+                    if (id >= N) id = N - 1;
+                    const int g = (lane % CPR) ^ (r & 15);
+                    const float* src = E + id * D + 4 * g;
+                    __attribute__((address_space(3))) unsigned char* dst =
+                        (__attribute__((address_space(3))) unsigned char*)(__attribute__((address_space(3))) float*)stage + i * 1024;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, dst, 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane >= r0 && lane < r0 + MX_ROWS) {
+                    const int rr = lane - r0;
+                    const float* erow = stage + rr * D;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < LPR; ++k) {
+                        const float4 e = *reinterpret_cast<const float4*>(erow + 4 * (k ^ (rr & 15)));
+                        acc = fmaf(qrow[4 * k + 0], e.x, acc);
+                        acc = fmaf(qrow[4 * k + 1], e.y, acc);
+                        acc = fmaf(qrow[4 * k + 2], e.z, acc);
+                        acc = fmaf(qrow[4 * k + 3], e.w, acc);
+                    }
+                    sx = acc + 0.0f;   // (-0 -> +0, like the list keys of the exact kernel)
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by the next pass
+            }
+            const int64_t item = c0 + lane;
+            bool valid = item < N && sx >= -INFINITY;      // (a NaN score never enters a list: v_cmp_ge in the exact kernel)
+            // the user's seen items inside [c0, c0 + 64): a cursor into the ascending list, 64 entries at a time
+            for (;;) {
+                if (sp >= se) break;
+                if (wbase != sp) { w = sp + lane < se ? seen_idx[sp + lane] : (int64_t)0x7FFFFFFFFFFFFFFFll; wbase = sp; }
+                unsigned long long inr = __ballot(w < c0 + 64);
+                const int cnt = __popcll(inr);
+                while (inr) {
+                    const int b = __ffsll((long long)inr) - 1;
+                    inr &= inr - 1;
+                    const int64_t sid = ((int64_t)__shfl((int)(w >> 32), b, 64) << 32) | (unsigned)__shfl((int)w, b, 64);
+                    if (sid == item) valid = false;
+                }
+                sp += cnt;
+                if (cnt < 64) break;
+            }
+            float v = valid ? sx : -INFINITY;
+            int i = valid ? (int)item : PAD;
+            const float kv = __shfl(bv, K - 1, 64);
+            const int ki = __shfl(bi, K - 1, 64);
+            if (__ballot(valid && (ki == PAD || sc_before(v, i, kv, ki))) == 0ull) continue;
+            bitonic_sort64(v, i, lane);
+            const float rv = __shfl(v, 63 - lane, 64);
+            const int ri = __shfl(i, 63 - lane, 64);
+            if (sc_before(rv, ri, bv, bi)) { bv = rv; bi = ri; }
+#pragma unroll
+            for (int j = 32; j > 0; j >>= 1) bitonic_step(bv, bi, j, (lane & j) == 0, lane);
+        }
+        topk_emit(bv, bi, lane, user, N, K, seen_ptr, seen_idx, vals, idx);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1702,6 +1803,10 @@ RE_SWITCH int g_score_front = 1;    // split form: query split + item split + st
 #ifdef RE_DEBUG
 extern "C" void re_dbg_score_front(int on) { g_score_front = on; }
 #endif
+RE_SWITCH int g_score_rescan = 1;    // the split path's fallback as score_rescan_k (0: the exact kernel over flagged blocks + its merge)
+#ifdef RE_DEBUG
+extern "C" void re_dbg_score_rescan(int on) { g_score_rescan = on; }
+#endif
 RE_SWITCH int g_score_mxdiag = 0;   // timing-only ablation of score_topk_merge_x (scripts/x2_diag.py): 1 no list merge, 2 no re-scoring, 4 no final sort
 #ifdef RE_DEBUG
 extern "C" void re_dbg_score_mxdiag(int m) { g_score_mxdiag = m; }
@@ -1776,7 +1881,7 @@ static float score_cerr(int64_t D) {
 }
 
 struct ScoreWs {   // carving of re_score_topk's workspace
-    size_t half, off_pi, off_gthr, off_flags, off_qnorm, off_pt, off_bp, off_qs, off_prep, total;
+    size_t half, off_pi, off_gthr, off_flags, off_qnorm, off_pt, off_bp, off_qs, off_prep, off_fl, total;
     size_t n_zero;   // bytes from off_gthr that are zeroed per call: gthr[B] gthr2[B] userflag[B] blockflag[nub] emax/dbg[64]
 };
 static ScoreWs score_ws(int64_t B, int64_t N, int64_t D, int64_t K, const ScorePlan& p, bool x2, bool own_prep) {
@@ -1794,7 +1899,8 @@ static ScoreWs score_ws(int64_t B, int64_t N, int64_t D, int64_t K, const ScoreP
     w.off_bp = w.off_pt + (x2 ? re_align((size_t)p.nub * SC_USERS * segs * 2 * 4) : 0);          // chunk lists of score_bound_k
     w.off_qs = w.off_bp + (x2 ? re_align((size_t)(re_cdiv(B, 32) + 1024) * 64 * 8 * 4) : 0);
     w.off_prep = w.off_qs + (x2 ? re_align((size_t)B * D * 4) : 0);
-    w.total = w.off_prep + (x2 && own_prep ? re_align((size_t)N * D * 4) + 256 : 0) + 256;
+    w.off_fl = w.off_prep + (x2 && own_prep ? re_align((size_t)N * D * 4) + 256 : 0);       // the flagged users' list (score_rescan_k)
+    w.total = w.off_fl + (x2 ? re_align((size_t)B * 4) : 0) + 256;
     return w;
 }
 
@@ -2006,6 +2112,8 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             }
             const int C = score_x2_capacity(p, K);
             float* pt = (float*)((char*)ws + w.off_pt);
+            const bool rescan = g_score_rescan && N <= SX_RESCAN_MAX_N;                // the fallback as ONE launch of waves per flagged user
+            int* fl_list = rescan ? (int*)((char*)ws + w.off_fl) : (int*)nullptr;
 #define SX_LAUNCH(DV)                                                                          \
     do {   /* per-lane length = half the pair list's capacity */                               \
         if (C == 16) SR_LAUNCH(DV, 8, 8, true, Qs, Es, 8, gthr, nullptr, pt);                  \
@@ -2018,11 +2126,18 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             if ((rc = re_launch_status()) != RE_OK) return rc;
             if (D == 64)
                 hipLaunchKernelGGL(score_topk_merge_x<64>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax);
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax, fl_list);
             else
                 hipLaunchKernelGGL(score_topk_merge_x<128>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax);
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax, fl_list);
             if ((rc = re_launch_status()) != RE_OK) return rc;
+            if (rescan) {
+                const int* nfl = bflag + p.nub + 1;
+                const unsigned rg = (unsigned)(re_cdiv(B, 4) < 256 ? re_cdiv(B, 4) : 256);
+                if (D == 64) hipLaunchKernelGGL(score_rescan_k<64>, dim3(rg), dim3(256), 0, s, nfl, fl_list, B, N, (int)K, seen_ptr, seen_idx, Q, E, vals, idx);
+                else hipLaunchKernelGGL(score_rescan_k<128>, dim3(rg), dim3(256), 0, s, nfl, fl_list, B, N, (int)K, seen_ptr, seen_idx, Q, E, vals, idx);
+                return re_launch_status();
+            }
             // ---- fallback pass over flagged user blocks only (normally none: every workgroup returns at once)
             blockflag = bflag;
             userflag = uflag;

@@ -142,7 +142,8 @@ class LightGCNEngine(MFEngine):
         self.crow = torch.as_tensor(adj_crow, dtype=torch.int64).to(dev).contiguous()
         self.col = torch.as_tensor(adj_col, dtype=torch.int64).to(dev).contiguous()
         self.val = torch.as_tensor(adj_val, dtype=torch.float32).to(dev).contiguous()
-        self.plan = ops.spmm_plan(self.crow, embedding_dim)
+        # (bipartite: user rows gather item rows and the other way round -- the two row classes get XCDs of their own, ops.SpmmPlan)
+        self.plan = ops.spmm_plan(self.crow, embedding_dim, split_row=num_users)
         n = num_users + num_items
         assert self.crow.numel() == n + 1
         self.n = n

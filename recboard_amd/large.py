@@ -260,7 +260,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), weights=self._prep_weights(B, S))
+                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(), weights=self._prep_weights(B, S))
             pb.count.fill_(1)
             for _ in range(3):
                 body()
@@ -290,7 +290,7 @@ class SASRecLargeTableEngine(SASRecEngine):
             mail = torch.zeros(ops.MAIL_WORDS, dtype=torch.int64, device=self.device)
             graphs = []
             for p in range(2):
-                nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step())
+                nxt = ops.next_prep(mail, blobs[1 - p], B, S, max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs())
                 graphs.append(self._capture(B, S, with_adam=True, blob=blobs[p], next_prep=nxt))
             tp = self._tail_pipes[key] = dict(blobs=blobs, mail=mail, graphs=graphs, parity=0, staged=None)
         return tp
@@ -303,7 +303,7 @@ class SASRecLargeTableEngine(SASRecEngine):
         g = tp["graphs"][p]
         st, tp["staged"] = tp["staged"], None
         if not (st is not None and st[0] is seq and st[1] is pos and st[2] is neg):
-            ops.sasrec_batch_prep(seq, pos, neg, blob=tp["blobs"][p], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step())
+            ops.sasrec_batch_prep(seq, pos, neg, blob=tp["blobs"][p], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs())
         if next_batch is not None and tuple(next_batch[0].shape) != (B, S):
             next_batch = None
         if next_batch is not None and next_ready is not None:
@@ -329,7 +329,7 @@ class SASRecLargeTableEngine(SASRecEngine):
             self._graphs[key] = self._capture(B, S, with_adam=grad_hook is None)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(),
                               weights=self._prep_weights(B, S), loss_acc=self._take_pending_loss())
         g["graph"].replay()
         A.step += 1
@@ -573,7 +573,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up with an all-padding batch: every lookup is the padding row, no table row changes
             pb = ops.sasrec_batch_prep(z, z, z, blob=blob, state=state, seed=0, step=1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), weights=self._prep_weights(B, S))
+                                       max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(), weights=self._prep_weights(B, S))
             pb.count.fill_(1)
             for _ in range(3):
                 self._sharded_body(pb.seq, pb.pos, pb.neg, pb, 0, seed_dev=state, hyper=hyper)
@@ -607,7 +607,7 @@ class SASRecShardedEngine(SASRecLargeTableEngine):
             self._graphs[key] = self._capture(B, S)
         g = self._graphs[key]
         ops.sasrec_batch_prep(seq, pos, neg, blob=g["blob"], state=g["state"], seed=self._step_seed(), step=A.step + 1, lr=self.lr,
-                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(),
+                              beta1=self.betas[0], beta2=self.betas[1], max_tiles=self._max_tiles(), split=self._split(), tile=self._wave_step(), tile_wgs=self._tile_wgs(),
                               weights=self._prep_weights(B, S), loss_acc=self._take_pending_loss())
         sd = self._step_seed()
         g["graph"].replay()

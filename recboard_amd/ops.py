@@ -928,20 +928,24 @@ class SpmmPlan:
     """Once per adjacency (the only host-visible preprocessing): rows in descending-degree order; the rows with more than
     SPMM_LONG non-zeros are cut into chunks of SPMM_CHUNK non-zeros that get a workgroup each."""
 
-    def __init__(self, crow: torch.Tensor, D: int, split_row: int = 0, nt: bool = None):
+    def __init__(self, crow: torch.Tensor, D: int, split_row: int = 0, nt: bool = False):
         """split_row (0: none): rows [0, split_row) and [split_row, n) are two classes that gather from different parts of X (a bipartite
-        adjacency: split_row = number of users); the short rows of each class are then walked by XCDs of their own (re_spmm_csr_split),
-        the XCD labels shared out by the classes' non-zeros.  nt: non-temporal streams (default: with a split)."""
+        adjacency: split_row = number of users); the short rows of each class are then walked by XCDs of their own (re_spmm_csr_split):
+        each XCD's L2 holds the hot rows of ONE part of X.  The 8 XCD labels are shared out by the classes' gather cost -- non-zeros, weighted
+        by the size of the part they gather from (the larger part misses more).  Yelp2018 shapes: 127.4 -> 118.1 us per propagation at 4 : 4
+        (5 : 3: 120.2; 3 : 5: 142.8; profiles/r6_spmm_split.txt).
+        nt: the CSR stream and the output rows with the non-temporal hint -- measured SLOWER (169.5 us: more L2 hits, and yet the stream's
+        own loads get slower); kept as a switch for the record, off."""
         deg = crow[1:] - crow[:-1]
         self.row_order = torch.argsort(deg, descending=True, stable=True).contiguous()
         self.nlong = int((deg > SPMM_LONG).sum())
-        self.split, self.xcd_share, self.flags = 0, 4, int(bool(nt if nt is not None else split_row))
+        self.split, self.xcd_share, self.flags = 0, 4, int(bool(nt))
         n = deg.numel()
         if 0 < int(split_row) < n:
             short = self.row_order[self.nlong:]
             c0, c1 = short[short < split_row], short[short >= split_row]             # (boolean masks keep the descending-degree order)
             if c0.numel() and c1.numel():
-                w0, w1 = float(deg[c0].sum()), float(deg[c1].sum())
+                w0, w1 = float(deg[c0].sum()) * (1.0 + (n - split_row) / n), float(deg[c1].sum()) * (1.0 + split_row / n)
                 self.row_order = torch.cat([self.row_order[: self.nlong], c0, c1]).contiguous()
                 self.split = self.nlong + int(c0.numel())
                 self.xcd_share = min(7, max(1, int(round(8.0 * w0 / max(w0 + w1, 1.0)))))
@@ -954,7 +958,7 @@ class SpmmPlan:
         self.ws = torch.empty(max(self.nchunks * D, 4), dtype=torch.float32, device=crow.device)
 
 
-def spmm_plan(crow: torch.Tensor, D: int = 64, split_row: int = 0, nt: bool = None):
+def spmm_plan(crow: torch.Tensor, D: int = 64, split_row: int = 0, nt: bool = False):
     return SpmmPlan(crow, D, split_row, nt)
 
 

@@ -284,13 +284,13 @@ class SASRecEngine:
         return "always" if ok and getattr(self, "tile_step", True) == "always" else ok   # ("always": whatever the batch -- the plan's rule is a matter of speed)
 
     def _tile_wgs(self):
-        """Resident workgroups per CU of the tile kernels (csrc/enc_common.h: enc_tile_wg_per_cu -- one; two at D = 64 is faster and not yet
-        reproducible from process to process, profiles/r5_handover_notes.txt): the batch plan's rule counts them.  (RE_TILE_WGS=2 with the
-        experiment libraries `make two` / `make twoinv` only: the library's own number must be the same.)"""
+        """Resident workgroups per CU of the tile kernels, as the LOADED library was built (csrc/enc_common.h: enc_tile_wg_per_cu -- two at D = 64
+        since round 6, one at D = 128; `make one` builds the one-per-CU library): the batch plan's residency rule has to count the same number,
+        so the host asks instead of assuming.  RE_TILE_WGS in the environment is checked against it (older scripts set it)."""
         have = int(lib_load().re_tile_wgs_per_cu(self.D))
         want = os.environ.get("RE_TILE_WGS")
         if want is not None and int(want) != have:
-            raise RuntimeError(f"recengine: RE_TILE_WGS={want} but the loaded library holds {have} tile workgroup(s) per CU (make two / twoinv build the other)")
+            raise RuntimeError(f"recengine: RE_TILE_WGS={want} but the loaded library holds {have} tile workgroup(s) per CU (make one builds the other)")
         return have
 
     def _tail_word(self):
