@@ -343,7 +343,10 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
                 // workgroups are 11 % faster on the workgroup-per-item kernel, 310 are 6 % slower) and there are at most ~10 tiles per
                 // workgroup in all (Beauty-shaped batches of 1 024 / 2 048 / 8 192: tile kernel +10 % / +24 % / -6 %).
                 const int tg = (ncu < 256 ? ncu : 256) * ((split_long & 8) ? 2 : 1);   // resident workgroups (& 8: two per CU)
-                const bool fits = enc_tile_looped(B, S) ? ((split_long & 4) || (2 * tlong <= 3 * tg && tlong + tshort <= 10 * tg))
+                // (speed rules, measured: at ONE workgroup per CU long tiles beyond 1.5 x the resident workgroups made the workgroup-per-item kernel the
+                //  faster one; at TWO per CU the tile kernels win up to the inbox cap -- B = 6 144: 0.461 vs 0.517 ms, 8 192: 0.589 vs 0.732, round 6.
+                //  The looped form cannot deadlock on chains: tickets go out in tile order, so whatever a tile waits for is resident or done.)
+                const bool fits = enc_tile_looped(B, S) ? ((split_long & 4) || ((split_long & 8 ? true : 2 * tlong <= 3 * tg) && tlong + tshort <= 10 * tg))
                                                         : (tlong + tshort <= 1024 && ((split_long & 4) || tlong <= tg * 3 / 4));
                 hdr[7] = (nsplit == 0 && !(split_long & 2) && fits && tlong + tshort <= ENC_XCH_TILE_CAP) ? 1 : 0;   // (the cap: the inboxes' size, whatever the caller insists on)
                 for (int k = 0; k < PL_NCLS; ++k) s_base[k] = 0;

@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
             const int s = s0 + u;
             fv[u] = -INFINITY; fi[u] = -1; ft[u] = -INFINITY;
             if (s < nseg) {
-                if (lane < C) {
+                if (lane < C) {   // (round 6: non-temporal loads here -- to leave the L2 to the item rows gathered below -- changed nothing: 59.6 vs 58.8 us)
                     fv[u] = part_vals[(user * maxseg + s) * C + lane];
                     fi[u] = part_idx[(user * maxseg + s) * C + lane];
                 }

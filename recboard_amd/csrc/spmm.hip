@@ -124,22 +124,24 @@ __device__ __forceinline__ void spmm_store(float4 acc, int64_t r, int64_t D, int
 // CLASSES that gather from different parts of X -- a bipartite adjacency's user rows gather item rows and the other way round -- and the
 // blocks that share an XCD (blockIdx % 8 labels them: cdna_hip_programming.md T1) all walk ONE class: labels [0, k0) the first, [k0, 8) the
 // second.  Each L2 then has to hold the hot rows of one part of X instead of both.
+// (blk, nblk: this workgroup's index among the row-walking workgroups of the launch -- the fused launch below puts the long rows' chunk
+//  workgroups in front of them)
 template <int LPR, bool NT>
-__global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__ row_order, int64_t first, int64_t split, int k0,
-                                                     const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
-                                                     const float* __restrict__ val, int64_t nrows, int64_t ncols,
-                                                     const float* __restrict__ X, int64_t D, float* __restrict__ Y,
-                                                     const float* __restrict__ Z, float beta, float* __restrict__ ACC,
-                                                     float acc_scale) {
+__device__ __forceinline__ void spmm_rows_walk(int64_t blk, int64_t nblk, const int64_t* __restrict__ row_order, int64_t first, int64_t split, int k0,
+                                               const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
+                                               const float* __restrict__ val, int64_t nrows, int64_t ncols,
+                                               const float* __restrict__ X, int64_t D, float* __restrict__ Y,
+                                               const float* __restrict__ Z, float beta, float* __restrict__ ACC,
+                                               float acc_scale) {
     const int lir = threadIdx.x % LPR;
     const int64_t gpb = 256 / LPR;
     const int64_t D4 = D >> 2;
-    int64_t lo = first, hi = nrows, bi = blockIdx.x, nb = gridDim.x;
+    int64_t lo = first, hi = nrows, bi = blk, nb = nblk;
     if (split > first) {
-        const int lab = blockIdx.x & 7, cls = lab >= k0;
+        const int lab = (int)(blk & 7), cls = lab >= k0;
         const int k = cls ? 8 - k0 : k0;
-        bi = (int64_t)(blockIdx.x >> 3) * k + (cls ? lab - k0 : lab);
-        nb = (int64_t)(gridDim.x >> 3) * k;
+        bi = (blk >> 3) * k + (cls ? lab - k0 : lab);
+        nb = (nblk >> 3) * k;
         lo = cls ? split : first;
         hi = cls ? nrows : split;
     }
@@ -154,6 +156,15 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__
         }
     }
 }
+template <int LPR, bool NT>
+__global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__ row_order, int64_t first, int64_t split, int k0,
+                                                     const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
+                                                     const float* __restrict__ val, int64_t nrows, int64_t ncols,
+                                                     const float* __restrict__ X, int64_t D, float* __restrict__ Y,
+                                                     const float* __restrict__ Z, float beta, float* __restrict__ ACC,
+                                                     float acc_scale) {
+    spmm_rows_walk<LPR, NT>(blockIdx.x, gridDim.x, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+}
 
 // long rows: one workgroup per CHUNK of SP_CHUNK non-zeros (a popular item can have tens of thousands of non-zeros: one
 // workgroup per row would be the tail of the whole launch).  Lane group j takes non-zeros p0 + j, p0 + j + G, ...; the 16
@@ -161,16 +172,16 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__
 // partials in chunk order and applies the epilogue.  Fixed order everywhere => bitwise reproducible.
 #define SP_CHUNK 2048
 template <int LPR>
-__global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__ row_order, const int32_t* __restrict__ chunk_row,
-                                                     const int64_t* __restrict__ chunk_ptr, int64_t nchunks,
-                                                     const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
-                                                     const float* __restrict__ val, int64_t ncols, const float* __restrict__ X,
-                                                     int64_t D, float* __restrict__ partial) {
-    __shared__ float4 part[256];
+__device__ __forceinline__ void spmm_long_chunks(float4* part, int64_t first_chunk, int64_t chunk_stride,
+                                                 const int64_t* __restrict__ row_order, const int32_t* __restrict__ chunk_row,
+                                                 const int64_t* __restrict__ chunk_ptr, int64_t nchunks,
+                                                 const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
+                                                 const float* __restrict__ val, int64_t ncols, const float* __restrict__ X,
+                                                 int64_t D, float* __restrict__ partial) {
     const int lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     constexpr int G = 256 / LPR;
     const int64_t D4 = D >> 2;
-    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    for (int64_t ch = first_chunk; ch < nchunks; ch += chunk_stride) {
         const int li = chunk_row[ch];
         const int64_t r = row_order[li];
         const int64_t p0 = crow[r] + (ch - chunk_ptr[li]) * SP_CHUNK;
@@ -189,6 +200,37 @@ __global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__
             __syncthreads();
         }
     }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__ row_order, const int32_t* __restrict__ chunk_row,
+                                                     const int64_t* __restrict__ chunk_ptr, int64_t nchunks,
+                                                     const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
+                                                     const float* __restrict__ val, int64_t ncols, const float* __restrict__ X,
+                                                     int64_t D, float* __restrict__ partial) {
+    __shared__ float4 part[256];
+    spmm_long_chunks<LPR>(part, blockIdx.x, gridDim.x, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial);
+}
+
+// ONE launch for the long rows' chunks AND the short rows (round 6): the first nch8 workgroups (nchunks rounded up to a multiple of 8, so that
+// blockIdx % 8 -- the XCD label -- of the row walkers is unchanged) each take a chunk, the rest walk the short rows.  As launches of their own the
+// chunk kernel's 459 workgroups (Yelp2018 shapes: 340 long rows) ran 22 us by themselves in front of the 100 us row walk, six times a step.
+template <int LPR, bool NT>
+__global__ __launch_bounds__(256) void spmm_csr_fused(const int32_t* __restrict__ chunk_row, const int64_t* __restrict__ chunk_ptr, int64_t nchunks,
+                                                      int64_t nch8, float* __restrict__ partial,
+                                                      const int64_t* __restrict__ row_order, int64_t first, int64_t split, int k0,
+                                                      const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
+                                                      const float* __restrict__ val, int64_t nrows, int64_t ncols,
+                                                      const float* __restrict__ X, int64_t D, float* __restrict__ Y,
+                                                      const float* __restrict__ Z, float beta, float* __restrict__ ACC,
+                                                      float acc_scale) {
+    __shared__ float4 part[256];
+    if ((int64_t)blockIdx.x < nch8) {
+        spmm_long_chunks<LPR>(part, blockIdx.x, nch8, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial);
+        return;
+    }
+    spmm_rows_walk<LPR, NT>((int64_t)blockIdx.x - nch8, (int64_t)gridDim.x - nch8, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z,
+                            beta, ACC, acc_scale);
 }
 
 template <int LPR>
@@ -228,8 +270,15 @@ static int spmm_launch(const int64_t* crow, const int64_t* col, const float* val
     float* partial = (float*)ws;
 #define SP_LAUNCH(LPRV)                                                                                                             \
     do {                                                                                                                            \
-        if (nlong) hipLaunchKernelGGL(spmm_csr_long<LPRV>, dim3(re_grid(nchunks, 1, 65536)), dim3(256), 0, s, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial); \
-        if (nrows > nlong) {                                                                                                        \
+        const int64_t nch8 = (nchunks + 7) & ~(int64_t)7;                                                                           \
+        const bool fuse = nlong > 0 && nrows > nlong && nch8 <= 4096;                                                               \
+        if (nlong && !fuse) hipLaunchKernelGGL(spmm_csr_long<LPRV>, dim3(re_grid(nchunks, 1, 65536)), dim3(256), 0, s, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial); \
+        if (fuse) {                                                                                                                 \
+            unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536 - 4096);                                                \
+            g = (g + 7u) & ~7u;                                                                                                     \
+            if (flags & 1) hipLaunchKernelGGL((spmm_csr_fused<LPRV, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
+            else hipLaunchKernelGGL((spmm_csr_fused<LPRV, false>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
+        } else if (nrows > nlong) {                                                                                                 \
             unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536);                                                       \
             if (split > nlong) g = (g + 7u) & ~7u;                                                                                  \
             if (flags & 1) hipLaunchKernelGGL((spmm_csr_rows<LPRV, true>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \

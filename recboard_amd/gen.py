@@ -166,9 +166,11 @@ class LightGCNEngine(MFEngine):
             src = dst
         return self.avg[: self.U], self.avg[self.U:]
 
-    def _emb_loss(self, u, p, n):
+    def _emb_loss(self, u, p, n, rows=None):
         P = self.params
         sc = 0.5 / u.numel()                      # regularize(.., "l2") / len(users)
+        if rows is not None:                      # (the three row sets as rows of X0 = [U; I]: one reduction instead of three)
+            return ops.rows_sqnorm(self.X0, rows, sc, self.emb)
         ops.rows_sqnorm(P["User.embeddings.weight"], u, sc, self.emb)
         ops.rows_sqnorm(P["Item.embeddings.weight"], p, sc, self.emb, accumulate=True)
         ops.rows_sqnorm(P["Item.embeddings.weight"], n, sc, self.emb, accumulate=True)
@@ -188,13 +190,20 @@ class LightGCNEngine(MFEngine):
         ue, ie = self.encode()
         u, p, n = users.reshape(-1), pos.reshape(-1), neg.reshape(-1)
         B = u.numel()
-        loss, gu, gp, gn = ops.bpr_triplet_fwd_bwd(ue, ie, u, p, n)
-        emb = self._emb_loss(u, p, n)
-        rows = torch.cat([u, p + U, n + U])
         s = 1.0 / (self.L + 1)
-        ops.scatter_add_rows(torch.cat([gu, gp, gn]), rows, self.n, scale=s, out=self.davg)   # d(avg)/(L+1), dense
-        # g_L = davg ; g_l = Adj g_{l+1} + davg ; the last product lands in the gradient arena
         gX0 = A.grad[: self.n * D].view(self.n, D)
+        # the triplet kernel leaves its three gradient-row sets as ONE [3, B, D] block with their int32 destination rows in X0 = [U; I] (what
+        # MF-BPR's owner launch takes): no torch.cat of the rows, no index arithmetic launches.  (Round 6 tried both dense scatters as
+        # owner-computes launches (re_scatter_add_rows_small): 82 us each at 122 915 rows against ~45 us for the sorted path -- every one of its
+        # 4 096 workgroups scans all keys; not kept.)
+        W = self.__dict__.setdefault("_rows_bufs", {})
+        if B not in W:
+            W[B] = (torch.empty((3, B, D), dtype=torch.float32, device=self.device), torch.empty((3, B), dtype=torch.int32, device=self.device))
+        loss, g, keys = ops.bpr_triplet_step_rows(ue, ie, u, p, n, *W[B])
+        rows = keys.reshape(-1).to(torch.int64)
+        emb = self._emb_loss(u, p, n, rows)
+        ops.scatter_add_rows(g.view(3 * B, D), rows, self.n, scale=s, out=self.davg)   # d(avg)/(L+1), dense
+        # g_L = davg ; g_l = Adj g_{l+1} + davg ; the last product lands in the gradient arena
         src, bufs = self.davg, (self.Ga, self.Xa)
         for l in range(self.L):
             dst = gX0 if l == self.L - 1 else bufs[l & 1]

@@ -2,6 +2,9 @@
 // the tile kernel's LayerNorm backward has it -- 4-wave workgroups, TWO per CU (58 KB of LDS) against ONE (84 KB) -- compiled twice: with v_pk_*_f32 and
 // (target feature off) without.  Every launch's result is compared with the first launch's and with the other build's.
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/pk_pairs.hip -o /tmp/pk_pairs && /tmp/pk_pairs
+// OUTCOME (round 6, one MI355X, gpurun_out/r6_pk_pairs.txt): NOT reproduced -- 0 differing words in 20 launches of either build at one and at two workgroups
+// per CU.  The instruction pattern alone is not enough; the reproducer that exists is the tile kernel itself: `make -C recboard_amd/csrc twopk` and
+// `RE_TILE_LDS_KB=58 python scripts/hbm_poison_check.py --lib twopk --mode flush` (5 - 6 distinct results in 6 replays; RE_TILE_LDS_KB=84: one).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>

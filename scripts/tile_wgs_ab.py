@@ -19,6 +19,8 @@ for B in [int(x) for x in sys.argv[2:]]:
     cfg = dict(bench.BEAUTY, B=B)
     m = SASRecEngine(cfg["items"], cfg["S"], cfg["D"], cfg["L"], dropout_rate=cfg["p_drop"], loss="BCE", lr=cfg["lr"], weight_decay=cfg["wd"], seed=1)
     m.prep_in_tail = True
+    if os.environ.get("TILE_ALWAYS"):
+        m.tile_step = "always"          # (the plan's speed rule overridden: the tile kernels whatever the batch)
     bs = [tuple(torch.from_numpy(a).cuda() for a in b) for b in bench.synth_batches(cfg, 4, seed=11)]
     out = []
     for nxt in (False, True):
