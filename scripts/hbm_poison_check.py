@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--only", default="", help="comma list of buffer names to poison (default: all)")
     ap.add_argument("--reps", type=int, default=12)
+    ap.add_argument("--item", action="store_true", help="the workgroup-per-item kernels (exact fp32: enc_step_k) instead of the tile kernels")
     ap.add_argument("--mode", default="poison", choices=("poison", "flush", "locate"),
                     help="flush: lr = 0, nothing reset or refilled between repetitions; what runs BETWEEN two repetitions varies instead -- nothing, a "
                          "one-word kernel, a 1 GiB fill (every cache line of the step's buffers evicted), a host synchronisation")
@@ -205,8 +206,10 @@ def main():
     cfg = dict(bench.BEAUTY, B=a.B)
     bs = [tuple(torch.from_numpy(x).cuda() for x in b) for b in bench.synth_batches(cfg, 2, 1)]
     m = SASRecEngine(cfg["items"], 50, a.dim, 2, dropout_rate=0.5, lr=0.0 if a.mode == "flush" else 5e-4, weight_decay=0.0 if a.mode == "flush" else 1e-6, seed=1)
+    if a.item:
+        m.tile_step = False
     A = m.arena
-    print(f"lib {a.lib}: tile workgroups per CU {m._tile_wgs()}, B {a.B}, D {a.dim}", flush=True)
+    print(f"lib {a.lib}: tile workgroups per CU {m._tile_wgs()}, B {a.B}, D {a.dim}, kernels: {'workgroup per item' if a.item else 'tile'}", flush=True)
     init = [t.clone() for t in (A.data, A.m, A.v)]
     S = 50
     m.train_step_graph(*bs[0])                        # captures (the warm-up touches every workspace), runs once

@@ -118,9 +118,19 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         for src in srcs:
             out = os.path.join(td, os.path.basename(src) + ".s")
-            cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+            # enc_tile.hip is built WITHOUT packed-fp32 instructions (csrc/Makefile: TILE_FLAGS; profiles/r6_handover_notes.txt): the lint compiles it
+            # as the product does and checks that none is left -- with them the tile kernels are not reproducible once two waves share a SIMD
+            tile = os.path.basename(src) == "enc_tile.hip"
+            extra = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if tile else []
+            cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only"] + extra + [
                    "-I" + os.path.join(ROOT, "recboard_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), src, "-o", out]
             subprocess.run(cmd, check=True)
+            if tile:
+                n_pk = sum(1 for ln in open(out) if re.match(r"\s+v_pk_(mul|add|fma)_f32\b", ln))
+                print("%-24s %5d packed-fp32 instructions" % (os.path.basename(src), n_pk))
+                if n_pk:
+                    bad += 1
+                    print("HAZARD enc_tile.hip: %d v_pk_*_f32 instructions (the Makefile's TILE_FLAGS must reach this file)" % n_pk)
             n_mfma = 0
             for fn, ins in parse(out).items():
                 n_mfma += sum(1 for _, m, _ in ins if m and m.startswith("v_mfma"))

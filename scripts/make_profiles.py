@@ -19,9 +19,12 @@ shutil.copy(os.path.join(src, "bench.json"), os.path.join(P, tag + "_bench.json"
 k = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "scripts", "pmc_traffic.py"), src + "/fetch", src + "/write"]))
 k = {n: v for n, v in k.items() if not n.startswith(("at::", "void at::", "Cijk", "__amd"))}
 main = [n for n in k if n.startswith("score_kernel_reg<64, 28")][0]
-exact = [n for n in k if n.startswith("score_kernel_reg<64, 50")][0]
+exact = ([n for n in k if n.startswith("score_kernel_reg<64, 50")] or [None])[0]   # (round 6: the fallback is score_rescan_k for catalogs up to 131 072 items)
 front = [n for n in k if n.startswith("score_front_k<64>")]      # round 5: query split + item split + starting thresholds in one launch
-if front:
+rescan = [n for n in k if n.startswith("score_rescan_k<64>")]
+if front and rescan:
+    total = sum(k[n]["hbm_bytes_per_launch"] for n in (front[0], main, "score_topk_merge_x<64>", rescan[0]))
+elif front:
     total = sum(k[n]["hbm_bytes_per_launch"] for n in (front[0], main, "score_topk_merge_x<64>", exact, "score_topk_merge"))
 else:
     total = 2 * k["score_split_k<64>"]["hbm_bytes_per_launch"] + sum(k[n]["hbm_bytes_per_launch"] for n in ("score_bound_k<64>", main, "score_topk_merge_x<64>", exact, "score_topk_merge"))
@@ -33,7 +36,7 @@ out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counte
        "kernels": k,
        "re_score_topk_call": {
            "launches": "score_front_k (query split + item-table split + starting thresholds + zeroing of the call's words, one launch), score_kernel_reg<64,28,28,split>, "
-                       "score_topk_merge_x, and the fallback pass score_kernel_reg<64,50,50,exact> + score_topk_merge (nobody flagged: both return at once)",
+                       "score_topk_merge_x, and the fallback launch score_rescan_k (one wave per flagged user; nobody flagged: it returns at once)",
            "hbm_bytes_per_call": total,
            "algorithmic_lower_bound_bytes": 4 * 64 * (22363 + 12101) + 12 * 22363 * 50,
            "note": "above the lower bound: the partial lists (one 56-entry list per user and segment: 41 MB written by the main kernel, read by the merge), "

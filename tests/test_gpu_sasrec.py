@@ -395,9 +395,10 @@ def test_pipelined_preparation_gives_the_same_steps(in_tail):
 
 @pytest.mark.parametrize("pipelined", [False, True])
 def test_captured_step_is_reproducible_from_process_to_process(pipelined):
-    """Two fresh processes, the same seeds and Beauty-shaped batches, 160 captured steps each: the same parameters bit for bit.  (The
-    hand-over of long sequences between tile workgroups is only valid at one workgroup per CU -- enc_tile.hip's launch; with two per CU
-    about every second pair of runs parted in the last digits by step 80 - 140, while two engines in ONE process always agreed.)"""
+    """Two fresh processes, the same seeds and Beauty-shaped batches, 160 captured steps each: the same parameters bit for bit.  (Rounds 3 - 5
+    ran the tile kernels at one workgroup per CU for this test's sake: with two, about every second pair of runs parted in the last digits.
+    Round 6 traced that to packed-fp32 instructions with two waves on a SIMD -- enc_tile.hip is built without them, two per CU is the
+    product's setting at D = 64: profiles/r6_handover_notes.txt, and the in-process form of this test below.)"""
     import re
     import subprocess
     import sys
@@ -410,6 +411,32 @@ def test_captured_step_is_reproducible_from_process_to_process(pipelined):
         assert "parameters identical: True" in r.stdout, r.stdout
         out.append(re.search(r"sha1 of the parameters: (\w+)", r.stdout).group(1))
     assert out[0] == out[1], out
+
+
+@pytest.mark.parametrize("B", [2048, 4096])
+def test_two_tile_workgroups_per_cu_replay_the_same_bits(B):
+    """The large-batch regime (B >= 1 024: the looped tile kernels, two workgroups resident per CU since round 6): the SAME captured step
+    replayed twelve times -- lr = 0, one batch, one dropout seed -- gives the same loss and gradient arena every time.  With packed-fp32
+    instructions in the tile kernels this failed in five replays of six (one lane group of one register of the backward's incoming
+    gradient; profiles/r6_handover_notes.txt), so the test also pins what the library was built as."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import hashlib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from recboard_amd.lib import load as lib_load
+    from recboard_amd.sasrec import SASRecEngine
+    assert lib_load().re_tile_wgs_per_cu(64) == 2 and lib_load().re_tile_wgs_per_cu(128) == 1
+    cfg = dict(bench.BEAUTY, B=B)
+    seq, pos, neg = (torch.from_numpy(x).cuda() for x in bench.synth_batches(cfg, 1, 1)[0])
+    m = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=0.0, weight_decay=0.0, seed=1)
+    seen = set()
+    for _ in range(12):
+        m.arena.step = 0                                     # (the same dropout seed every time)
+        loss = m.train_step_graph(seq, pos, neg)
+        seen.add(hashlib.sha1(loss.cpu().numpy().tobytes() + m.arena.grad.cpu().numpy().tobytes()).hexdigest())
+    m.check_handover()
+    assert len(seen) == 1, f"{len(seen)} different results in 12 replays"
 
 
 @pytest.mark.parametrize("captured", [True, False])
