@@ -1535,6 +1535,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
     for (int r0 = 0; r0 < nvalid && !(mxd & 2); r0 += MX_ROWS) {
 #pragma unroll
         for (int i = 0; i < IPP; ++i) {
+            if (r0 + i * RPI >= nvalid) break;     // (56 candidates = three and a half passes: the last pass's second half is not fetched)
             const int r = i * RPI + lane / CPR;
             const int id = __shfl(bi, r0 + r, 64);
             const int g = (lane % CPR) ^ (r & 15);

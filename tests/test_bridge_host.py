@@ -204,3 +204,23 @@ def test_missing_engine_library_is_reported_loudly(monkeypatch):
     monkeypatch.setattr(lib, "load", lambda: (_ for _ in ()).throw(OSError("librecengine.so: cannot open shared object file")))
     with pytest.warns(UserWarning, match="librecengine.so is not available"):
         assert freerec.launcher.Coach._attach_engine(coach) is None
+
+
+def test_pointer_marshalling_notes_storages_only_while_a_recording_is_open():
+    """recboard_amd/capture.py: recording() hangs every storage whose address a launch was handed on the graph (a hipGraph replays raw addresses).
+    The host half, no GPU: ops._p / ops._note (what _ptr_table and adam_fuse go through) note storages into ops._KEEP while it is a list and
+    not otherwise; a view notes its BASE storage (what has to stay alive), None is passed through."""
+    from recboard_amd import ops
+    base = torch.zeros(64)
+    view = base[16:32]
+    assert ops._KEEP is None
+    assert ops._p(view).value == view.data_ptr() and ops._p(None) is None and ops._KEEP is None
+    ops._KEEP = keep = []
+    try:
+        ops._p(view)
+        assert ops._note(base) == base.data_ptr() and ops._note(view) == view.data_ptr()
+    finally:
+        ops._KEEP = None
+    assert len(keep) == 3 and all(st.data_ptr() == base.untyped_storage().data_ptr() for st in keep)
+    ops._p(view)
+    assert len(keep) == 3
