@@ -41,6 +41,9 @@ const char* re_error_string(int code);
 /* resident workgroups per CU the one-tile-per-workgroup step kernels of this build hold (1): what `split_long & 8` of re_sasrec_batch_prep
  * must agree with (the plan's residency rule counts them). */
 int re_tile_wgs_per_cu(int64_t D);
+/* 1: every plan of this shape made with split_long = 4 (| 8) -- no splitting, tile kernels forced -- gives the step to the tile kernels
+ * (plan header word 7), so re_sasrec_encoder_step_part may be called without its workgroup-per-item launch (part & 2 clear). */
+int re_sasrec_tile_step_certain(int64_t B, int64_t S, int64_t D);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K1  embedding row gather.  out[i, :] = W[idx[i], :]   (i < n)

@@ -157,3 +157,10 @@ extern "C" int re_sasrec_encoder_step(const float* E, int64_t R, const float* Pt
 // Resident workgroups per CU the tile kernels of THIS library are built for (1; 2 in the experiment builds): the batch plan's residency rule
 // (split_long & 8) has to count the same number, so the host asks instead of assuming.
 extern "C" int re_tile_wgs_per_cu(int64_t D) { return enc_tile_wg_per_cu(D); }
+
+// 1: a plan made for this shape with split_long = 4 (+ 8) -- no splitting, the tile kernels forced -- hands EVERY batch to the tile kernels
+// (hdr[7] = 1 whatever the batch: the looped form takes any number of tiles up to the inbox cap, and tickets in tile order cannot deadlock a
+// chain), so the caller may leave the workgroup-per-item launch out of the step (part & 2: an empty launch costs 5 us of a 90 us step).
+extern "C" int re_sasrec_tile_step_certain(int64_t B, int64_t S, int64_t D) {
+    return (D == 64 && B > 0 && S > 0 && S <= 64 && enc_tile_looped(B, S) && enc_plan_max_tiles(B, S) <= ENC_XCH_TILE_CAP) ? 1 : 0;
+}

@@ -17,6 +17,7 @@ SIGNATURES = {
     "re_abi_version": (_i32, []),
     "re_error_string": (ctypes.c_char_p, [_i32]),
     "re_tile_wgs_per_cu": (_i32, [_i64]),
+    "re_sasrec_tile_step_certain": (_i32, [_i64, _i64, _i64]),
     "re_gather_rows": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "re_sasrec_embed": (_i32, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _f32, _u32, _vp, _vp, _vp]),
     "re_sasrec_embed_bwd_workspace_bytes": (_sz, [_i64, _i64]),

@@ -477,11 +477,18 @@ def prep_views(blob, B, S, cached=False):
     return pb
 
 
-def _plan_flags(split, tile, tile_wgs):
+def tile_step_certain(B, S, D, split, tile, tile_wgs):
+    """The step of this shape ALWAYS runs on the tile kernels when its plans are made with them forced (re_sasrec_tile_step_certain): the
+    preparation calls then force them (_plan_flags) and the step leaves the workgroup-per-item launch out."""
+    return bool(tile) and not split and int(tile_wgs) == 2 and int(D) == 64 and bool(lib.load().re_sasrec_tile_step_certain(int(B), int(S), int(D)))
+
+
+def _plan_flags(split, tile, tile_wgs, B=0, S=0):
     """re_sasrec_batch_prep's `split_long` mask: & 1 split long sequences over two work items; & 2 never hand the step to the tile kernels;
     & 4 always; & 8 the tile kernels hold TWO workgroups per CU (D = 64: csrc/enc_common.h enc_tile_wg_per_cu) -- the plan's rule counts
     resident workgroups."""
-    return int(bool(split)) | (0 if tile else 2) | (4 if tile == "always" else 0) | (8 if tile_wgs == 2 else 0)
+    force = tile == "always" or (B and tile_step_certain(B, S, 64, split, tile, tile_wgs))      # (two per CU: D = 64)
+    return int(bool(split)) | (0 if tile else 2) | (4 if force else 0) | (8 if tile_wgs == 2 else 0)
 
 
 def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, step=1, lr=1e-3, beta1=0.9, beta2=0.999, max_tiles=4, split=False,
@@ -508,7 +515,7 @@ def sasrec_batch_prep(seq, pos=None, neg=None, blob=None, state=None, seed=0, st
     if state is not None:
         _req(state, torch.int32, "state")
     have = pos is not None
-    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), _plan_flags(split, tile, tile_wgs),
+    args = (_p(seq), _p(pos), _p(neg), B, S, int(ncu) if ncu else num_cus(seq.device), int(max_tiles), _plan_flags(split, tile, tile_wgs, B, S),
             _p(pb.seq) if copy else None, _p(pb.pos) if copy and have else None, _p(pb.neg) if copy and have else None,
             _p(pb.valid) if have else None, _p(pb.count), _p(pb.rows_all) if have else None, _p(pb.plan), pb.plan.numel(),
             _p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2))
@@ -566,7 +573,7 @@ def sasrec_sample_prep(inter, order, b0, B, S, sample_seed, sample_step, blob, s
     wargs = _weight_args(weights) + _loss_args(loss_acc)
     lib.check(lib.load().re_seq_train_sample_prep(_p(inter.ptr), _p(inter.items), _p(inter.sorted), _p(order), order.numel(), int(b0), inter.num_items,
                                                   int(sample_seed) & 0xFFFFFFFF, int(sample_step) & 0xFFFFFFFF, _p(users), B, S,
-                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), _plan_flags(split, tile, tile_wgs), _p(pb.seq), _p(pb.pos),
+                                                  int(ncu) if ncu else num_cus(blob.device), int(max_tiles), _plan_flags(split, tile, tile_wgs, B, S), _p(pb.seq), _p(pb.pos),
                                                   _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel(), _p(state),
                                                   int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), *wargs, _stream()),
               "re_seq_train_sample_prep")
@@ -825,7 +832,7 @@ def next_prep(mail, blob, B, S, max_tiles=4, split=False, ncu=None, tile=True, t
     (sasrec_batch_prep(..., blob=blob)'s outputs) by the tail launch this is handed to.  Keeps `mail` and `blob` alive."""
     _req(mail, torch.int64, "mail"); _req(blob, torch.uint8, "blob")
     pb = prep_views(blob, B, S, cached=True)
-    n = NextPrep(_p(mail), B, S, int(ncu) if ncu else num_cus(blob.device), int(max_tiles), _plan_flags(split, tile, tile_wgs), _p(pb.seq), _p(pb.pos),
+    n = NextPrep(_p(mail), B, S, int(ncu) if ncu else num_cus(blob.device), int(max_tiles), _plan_flags(split, tile, tile_wgs, B, S), _p(pb.seq), _p(pb.pos),
                  _p(pb.neg), _p(pb.valid), _p(pb.count), _p(pb.rows_all), _p(pb.plan), pb.plan.numel())
     n._keep = (mail, blob, pb)
     return n

@@ -369,7 +369,7 @@ class SASRecEngine:
                 loss = ops.sasrec_encoder_step(E, Ppos, seq, pos, neg, float(D ** 0.5), bt, lw, lb, self.L, p, sd, pb.plan, kind, pb.count, W["u"], W["tape"],
                                                W["dU_rows"], W["g_rows"], W["keys"], W["ws_loss"], W["contrib"][:n].view(B, S, D), G["Position.weight"],
                                                self._block_tensors(A.grad), G["lastLN.weight"], G["lastLN.bias"], W["ws_bwd"], e_off=1, seed_dev=seed_dev,
-                                               part=3 + ready)
+                                               part=(1 if ops.tile_step_certain(B, S, D, self._split(), self._wave_step(), self._tile_wgs()) else 3) + ready)
                 fuse = adam_hyper is not None and getattr(self, "fuse_adam", True)
                 fz = ops.adam_fuse(A.grad, A.data, A.m, A.v, adam_hyper, self.betas[0], self.betas[1], 1e-8, self.wd) if fuse else None
                 self._adam_keep = (fz,)
