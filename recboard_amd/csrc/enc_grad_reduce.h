@@ -75,7 +75,18 @@ __device__ __forceinline__ void eg_reduce_pos(const EgReduce& R, int vb, int tid
     const int p = e / R.D, cc = e % R.D, nch = (R.B + 63) / 64;
     const EgPre pre = eg_pre(R.AD, R.dPtab + e);
     float s = 0.f;
-    for (int ch = 0; ch < nch; ++ch) s += eg_ld<COHERENT>(R.ppart + ((int64_t)p * nch + ch) * R.D + cc);
+    // (sixteen chunk partials requested together: one at a time a batch of 4 096 sequences was 64 dependent round trips here -- the longest
+    //  chain of the whole reduction launch, 25 us; the sum is the chunk-order one, bit for bit: s + 0 = s behind the last chunk)
+    for (int ch0 = 0; ch0 < nch; ch0 += 16) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int ch = ch0 + u < nch ? ch0 + u : nch - 1;
+            x[u] = eg_ld<COHERENT>(R.ppart + ((int64_t)p * nch + ch) * R.D + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += ch0 + u < nch ? x[u] : 0.f;
+    }
     eg_put(R.AD, R.dPtab + e, s * R.inv_scale, pre);
 }
 
@@ -132,25 +143,37 @@ __device__ __forceinline__ EgVec eg_reduce_vec_a(const EgReduce& R, int job, int
         V.dvec += cg * 64 + lane;
     }
     if (V.dvec && wave == 0) V.pre = eg_pre(R.AD, V.dvec);
-    const float* sl = R.slab + ((int64_t)l * EG_NVEC + v) * D + cg * 64 + lane;
+    // Round 6: a lane loads FOUR columns (16 bytes) of a slab row and the wave's four lane groups walk four different slabs -- 1 KB per load
+    // instruction instead of 256 B.  With one slab per TILE a batch of 4 096 sequences has 1 957 of them and only L x 12 workgroups to sum them:
+    // what a workgroup can keep in flight (4 waves x <= 63 loads) set the launch's 24 us there; 16 of these loads are 16 KB per wave.
+    // Order (fixed, so the sums are reproducible): lane group r of wave w takes slabs 4 w + r, + 16, + 32, ... in ascending order; then the four
+    // groups of a wave pairwise ((r0 + r1) + (r2 + r3)), then the four waves ((w0 + w1) + (w2 + w3)) in eg_reduce_vec_b.
+    const int r = lane >> 4, c4 = lane & 15;
+    const float* sl = R.slab + ((int64_t)l * EG_NVEC + v) * D + cg * 64 + 4 * c4;
     const int64_t stride = (int64_t)L * EG_NVEC * D;
-    float s = 0.f;
-    // (groups of 8 slabs, four groups' loads in flight at once: a group is a memory round trip, a Beauty-shaped batch has eight of them per wave;
-    //  the sums are the one-group-at-a-time ones, bit for bit)
-    for (int w0 = wave; w0 < nact; w0 += 128) {
-        float x[4][8];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int EG_Q = 16;
+    for (int w0 = 4 * wave + r; w0 < nact; w0 += 16 * EG_Q) {
+        float4 x[EG_Q];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int q = 0; q < EG_Q; ++q) {
+            const int w = w0 + 16 * q;
+            x[q] = (w < nact) ? *reinterpret_cast<const float4*>(sl + (int64_t)w * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int w = w0 + 32 * u + 4 * q;
-                x[u][q] = (w < nact) ? sl[(int64_t)w * stride] : 0.f;
-            }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (w0 + 32 * u < nact) s += ((x[u][0] + x[u][1]) + (x[u][2] + x[u][3])) + ((x[u][4] + x[u][5]) + (x[u][6] + x[u][7]));
+        for (int q = 0; q < EG_Q; ++q)
+            if (w0 + 16 * q < nact) { acc.x += x[q].x; acc.y += x[q].y; acc.z += x[q].z; acc.w += x[q].w; }
     }
-    red[wave][lane] = s;
+    float t[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[j] += __shfl_xor(t[j], 16, 64);
+        t[j] += __shfl_xor(t[j], 32, 64);
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave][4 * c4 + j] = t[j];
+    }
     return V;
 }
 __device__ __forceinline__ void eg_reduce_vec_b(const EgReduce& R, const EgVec& V, int tid, float (*red)[64]) {
