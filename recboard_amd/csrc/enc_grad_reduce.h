@@ -60,7 +60,8 @@ struct EgReduce {
     EncAdam AD;
 };
 
-// position-table gradient: the chunk partials of the position jobs in chunk order, / scale.  vb in [0, npos_blocks), tid in [0, 256)
+// position-table gradient: the position jobs' group partials (enc_wgrad_job.h: ppart[p][group][D]) in group order, / scale.
+// vb in [0, npos_blocks), tid in [0, 256)
 // COHERENT: the partials were written earlier in THIS launch by other workgroups (agent-scope stores, a done count): read them with agent-scope
 // loads, past whatever this XCD's L2 holds
 template <bool COHERENT = false>
@@ -69,25 +70,25 @@ __device__ __forceinline__ float eg_ld(const float* p) {
     return *p;
 }
 template <bool COHERENT = false>
-__device__ __forceinline__ void eg_reduce_pos(const EgReduce& R, int vb, int tid) {
-    const int e = vb * 256 + tid;
-    if (e >= R.S * R.D) return;
-    const int p = e / R.D, cc = e % R.D, nch = (R.B + 63) / 64;
-    const EgPre pre = eg_pre(R.AD, R.dPtab + e);
+__device__ __forceinline__ void eg_reduce_pos(const EgReduce& R, int vb, int tid, float (*red)[64]) {
+    // 64 elements a block; wave q sums the partials of groups [36 q, 36 q + 36) (all requested together: one memory round trip), thread (0, c)
+    // adds the four in order
+    constexpr int PER = WG_POS_GROUPS / 4;
+    static_assert(PER * 4 == WG_POS_GROUPS, "four waves share the groups");
+    const int q = tid >> 6, e = vb * 64 + (tid & 63);
+    const bool in = e < R.S * R.D;
+    const int p = in ? e / R.D : 0, cc = in ? e % R.D : 0;
+    float x[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) x[u] = eg_ld<COHERENT>(R.ppart + ((int64_t)p * WG_POS_GROUPS + q * PER + u) * R.D + cc);
+    EgPre pre{0.f, 0.f, 0.f, 0.f, 0.f};
+    if (q == 0) pre = eg_pre(R.AD, R.dPtab + (in ? e : 0));
     float s = 0.f;
-    // (sixteen chunk partials requested together: one at a time a batch of 4 096 sequences was 64 dependent round trips here -- the longest
-    //  chain of the whole reduction launch, 25 us; the sum is the chunk-order one, bit for bit: s + 0 = s behind the last chunk)
-    for (int ch0 = 0; ch0 < nch; ch0 += 16) {
-        float x[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int ch = ch0 + u < nch ? ch0 + u : nch - 1;
-            x[u] = eg_ld<COHERENT>(R.ppart + ((int64_t)p * nch + ch) * R.D + cc);
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += ch0 + u < nch ? x[u] : 0.f;
-    }
-    eg_put(R.AD, R.dPtab + e, s * R.inv_scale, pre);
+    for (int u = 0; u < PER; ++u) s += x[u];
+    red[q][tid & 63] = s;
+    __syncthreads();
+    if (q == 0 && in) eg_put(R.AD, R.dPtab + e, (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) * R.inv_scale, pre);
 }
 
 // 256 elements of the L * 6 * D * D weight gradients (sum of the wg_nsplit(D) partials).  vb in [0, nmat_blocks)

@@ -193,7 +193,7 @@ __device__ __forceinline__ void pl_elementwise(int job, int njobs, const int64_t
 #define PL_MODE_REST 2
 __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, int S, int ncu, int max_tiles, int split_long,
                                         int* __restrict__ count, int* __restrict__ plan, const PlSample& SP, unsigned char* L, int mode = PL_MODE_ALL,
-                                        unsigned epoch = 1u) {
+                                        unsigned epoch = 1u, int part = 0, int nparts = 1) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if defined(ENC_PROFILE) && defined(PL_PLAN_KERNEL)
     unsigned long long pl_t[6];
@@ -248,12 +248,17 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
     // 1. span of every sequence: a wave per sequence, lane = position (one coalesced load, a ballot, two scalar bit counts: ~10
     //    instructions per sequence -- an element-wise formulation is VALU-bound on this one CU), 16 sequences in flight per wave;
     //    a sequence without any item is given one explicit pad row
+    // (PL_MODE_SPANS of a large batch: `nparts` workgroups take a contiguous share of the sequences each -- a wave has sixteen sequences in flight
+    //  and a round is a memory round trip: 4 096 sequences were sixteen rounds, ~140 k cycles, on the one workgroup, and the rest of the plan
+    //  waited for them: the longest chain of the tail launch from B = 2 048 on)
+    const int b_per = nparts > 1 ? ((B + nparts - 1) / nparts + PL_SIF - 1) / PL_SIF * PL_SIF : B;
+    const int b_lo = min(part * b_per, B), b_hi = min(b_lo + b_per, B);
     int nnz = 0;
     if (have_spans) {
         // (phase 1 was another workgroup's: spans in place, hdr[4] and count written)
     } else
     if (SP.ptr) {   // sampled batch: a row's span is its window length (every position of the window is a real item) -- no (seq) to read
-        for (int b = tid; b < B; b += PL_NT) {
+        for (int b = b_lo + tid; b < b_hi; b += PL_NT) {
             int64_t base, p0, nn, u;
             int len;
             pl_sample_row(SP, b, S, base, len, p0, nn, u);
@@ -264,18 +269,18 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
     } else
-    for (int b0 = wave * PL_SIF; b0 < B; b0 += PL_NW * PL_SIF) {   // (PL_SIF sequences in flight per wave: 32 in flight was measured: no faster)
+    for (int b0 = b_lo + wave * PL_SIF; b0 < b_hi; b0 += PL_NW * PL_SIF) {   // (PL_SIF sequences in flight per wave: 32 in flight was measured: no faster)
         int64_t v[PL_SIF];
 #pragma unroll
         for (int q = 0; q < PL_SIF; ++q) {   // (clamped, unconditional: a predicated load is waited for on the spot)
-            const int b = b0 + q < B ? b0 + q : B - 1;
+            const int b = b0 + q < b_hi ? b0 + q : b_hi - 1;
             v[q] = seq[(int64_t)b * S + (lane < S ? lane : S - 1)];
         }
 #pragma unroll
         for (int q = 0; q < PL_SIF; ++q) {
             const unsigned long long m = __ballot(lane < S && v[q] != 0);
             const int first = m ? __builtin_ctzll(m) : S - 1;
-            if (lane == 0 && b0 + q < B) {
+            if (lane == 0 && b0 + q < b_hi) {
                 if (!to_global) s_span[b0 + q] = (unsigned char)(S - first); else g_span[b0 + q] = S - first;
                 nnz += __builtin_popcountll(m);
             }
@@ -284,7 +289,8 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
     PL_STAMP(1);
     if (lane == 0) s_red[wave] = nnz;
     pl_sync(in_lds);
-    if (tid == 0 && !have_spans) {
+    const bool shared_spans = mode == PL_MODE_SPANS && nparts > 1;
+    if (tid == 0 && !have_spans && !shared_spans) {
         int c = 0;
         for (int w = 0; w < PL_NW; ++w) c += s_red[w];
         hdr[4] = c;
@@ -294,9 +300,29 @@ __device__ __forceinline__ void pl_plan(const int64_t* __restrict__ seq, int B, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(g_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool last = true;
+            if (shared_spans) {
+                // (g_flag[1]: how many parts have arrived; g_flag[2]: their token counts -- integer sums, whatever the order.  The LAST part to
+                //  arrive takes both back to zero, writes the totals and publishes; its acquire / release pair orders every part's spans before
+                //  the flag)
+                int c = 0;
+                for (int w = 0; w < PL_NW; ++w) c += s_red[w];
+                __hip_atomic_fetch_add(reinterpret_cast<int*>(g_flag) + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                last = __hip_atomic_fetch_add(g_flag + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nparts - 1);
+                if (last) {
+                    __hip_atomic_store(g_flag + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int tot = __hip_atomic_exchange(reinterpret_cast<int*>(g_flag) + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[4] = tot;
+                    if (count) count[0] = tot;
+                }
+            }
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(g_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
         return;

@@ -53,7 +53,7 @@ struct TailJobs {
 // source), written by re_sasrec_step_stage[_sample] in front of this step (neither: no next batch); outputs: the OTHER captured copy's buffers.
 struct TailPrep {
     const PlMail* mail;           // nullptr: this launch prepares nothing
-    int B, S, ncu, max_tiles, split_long, n_ew;
+    int B, S, ncu, max_tiles, split_long, n_ew, span_parts;
     int64_t *seq_out, *pos_out, *neg_out;
     uint8_t* valid;
     int* count;
@@ -63,8 +63,8 @@ struct TailPrep {
 static_assert(PL_NT == SO_NT && PL_NT == SA_NT, "the preparation jobs are written for the tail launches' workgroup size");
 
 // ---- weight-gradient jobs.  D = 64: two per ticket: matrix jobs q = 2 t + half -> (block, matrix, split) = (q / 144, q / 24 % 6, q % 24); D = 128:
-//      one per ticket, run by the whole workgroup: (t / 72, t / 12 % 6, t % 12).  Then the position-table jobs (144 strides of the (position,
-//      chunk) list, two per ticket) -- both halves of a workgroup always run the same kind
+//      one per ticket, run by the whole workgroup: (t / 72, t / 12 % 6, t % 12).  Then the position-table jobs (WG_POS_GROUPS ranges of the batch's
+//      sequences, two per ticket) -- both halves of a workgroup always run the same kind
 __shared__ int s_job;   // the workgroup's current ticket
 
 // The queue's counter is one address behind an agent-scope atomic: the first ticket's round trip (and the other 255 workgroups' turns at the
@@ -92,7 +92,7 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
     constexpr int WG_NSPLIT = wg_nsplit(D);
     constexpr int PER_PLANE = WG_NSPLIT * EG_NMAT;      // matrix jobs of a block
     constexpr bool WHOLE = D == 128;                    // a matrix job is run by the whole workgroup (enc_wgrad_job.h: wg_nsplit), not two by its halves
-    constexpr int POS_GROUPS = 144;                     // the position jobs are dealt to this many 512-thread groups (two per ticket)
+    constexpr int POS_GROUPS = WG_POS_GROUPS;           // the position jobs: one per 512-thread group (two per ticket)
     const int n_mat = WHOLE ? J.L * PER_PLANE : J.L * PER_PLANE / 2, n_pos = J.ppart ? POS_GROUPS / 2 : 0;
     const int n_prep = TP.mail ? 1 + TP.n_ew : 0;
     int jn = 0;
@@ -108,16 +108,21 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
         if (t >= n_prep + n_mat + n_pos) break;
         if (jn < 3) TAIL_MARK(2 + 2 * jn, (unsigned long long)(t + 1));
         ++jn;
-        if (t < n_prep) {
+        // Queue order: the plan job (the longest single job), the matrix tickets, then the short ones -- the next batch's element-wise jobs and the
+        // position tickets -- for the workgroups that come late (owners of hot rows) or have finished a first ticket: with the element-wise
+        // jobs in front, a batch of 4 096 sequences had 200 workgroups spend their first 15 k cycles on them and start the 110 k-cycle matrix
+        // tickets behind (scripts/tail_phases.py).
+        const int n_plan = n_prep ? 1 : 0;
+        if (t < n_plan || (t >= n_plan + n_mat && t < n_prep + n_mat)) {
             const PlMail M = *TP.mail;
             if (M.seq || M.SP.ptr) {                           // (uniform)
                 if (t == 0) pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_REST, M.epoch);
-                else pl_elementwise(t - 1, TP.n_ew, M.seq, M.pos, M.neg, TP.B, TP.S, TP.seq_out, TP.pos_out, TP.neg_out, TP.valid, TP.rows_all, M.SP);
+                else pl_elementwise(t - n_plan - n_mat, TP.n_ew, M.seq, M.pos, M.neg, TP.B, TP.S, TP.seq_out, TP.pos_out, TP.neg_out, TP.valid, TP.rows_all, M.SP);
             }
             continue;
         }
-        t -= n_prep;
-        if (t < n_mat) {
+        if (t < n_plan + n_mat) {
+            t -= n_plan;
             if (jn == 1) TJ_STAMP(2);
             if constexpr (WHOLE) {
                 wg_matrix_job<D, SO_NT>(tid, lds, t / PER_PLANE, (t / WG_NSPLIT) % EG_NMAT, t % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
@@ -126,7 +131,7 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
                 wg_matrix_job<D>(ht, jl, q / PER_PLANE, (q / WG_NSPLIT) % EG_NMAT, q % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
             }
         } else {
-            wg_pos_job<D>(ht, jl, 2 * (t - n_mat) + half, POS_GROUPS, J.B, J.S, J.seq, J.contrib, J.ppart);
+            wg_pos_job<D>(ht, jl, 2 * (t - n_prep - n_mat) + half, J.B, J.S, J.seq, J.contrib, J.ppart);
         }
     }
 }
@@ -136,10 +141,12 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
 // instead of ~17 k cycles behind them (scripts/tail_phases.py).  The last workgroup owns cold rows (popular items have small ids) and, coming
 // late to the queue, takes no ticket: its extra work is hidden.
 __device__ __forceinline__ void tail_spans(const TailPrep& TP, float* lds) {
-    if (!TP.mail || blockIdx.x != gridDim.x - 1) return;
+    const int parts = TP.span_parts;   // (the launch's LAST workgroups: one up to 512 sequences, one more per 512 from there on, sixteen at most)
+    if (!TP.mail || (int)blockIdx.x < (int)gridDim.x - parts) return;
     const PlMail M = *TP.mail;
     if (M.seq || M.SP.ptr)
-        pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_SPANS, M.epoch);
+        pl_plan(M.seq, TP.B, TP.S, TP.ncu, TP.max_tiles, TP.split_long, TP.count, TP.plan, M.SP, reinterpret_cast<unsigned char*>(lds), PL_MODE_SPANS, M.epoch,
+                (int)blockIdx.x - ((int)gridDim.x - parts), parts);
     __syncthreads();
 }
 
@@ -204,6 +211,7 @@ static int tail_prep(TailPrep& TP, const re_next_prep* next) {
     TP.mail = (const PlMail*)next->mail;
     TP.B = (int)next->B; TP.S = (int)next->S; TP.ncu = next->ncu < 1 ? 1 : next->ncu; TP.max_tiles = next->max_tiles; TP.split_long = next->split_long;
     TP.n_ew = elementwise ? (int)re_grid(next->B * next->S, PL_NT, 256) : 0;
+    TP.span_parts = (int)(next->B <= 512 ? 1 : next->B >= 16 * 512 ? 16 : (next->B + 511) / 512);
     TP.seq_out = (int64_t*)next->seq_out; TP.pos_out = (int64_t*)next->pos_out; TP.neg_out = (int64_t*)next->neg_out;
     TP.valid = (uint8_t*)next->valid; TP.count = (int*)next->count; TP.rows_all = (int64_t*)next->rows_all; TP.plan = (int*)next->plan;
     return RE_OK;

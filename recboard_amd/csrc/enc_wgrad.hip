@@ -18,7 +18,8 @@ __global__ __launch_bounds__(512) void enc_wgrad_k(const float* __restrict__ tap
     extern __shared__ __align__(16) float lds[];
     if ((int)blockIdx.z == L) {
         if (!dPtab) return;
-        wg_pos_job<D>(threadIdx.x, lds, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, B, S, seq, contrib, ppart);
+        for (int g = blockIdx.y * gridDim.x + blockIdx.x; g < WG_POS_GROUPS; g += gridDim.x * gridDim.y)   // (144 workgroups at D = 64, 72 at 128)
+            wg_pos_job<D>(threadIdx.x, lds, g, B, S, seq, contrib, ppart);
         return;
     }
     const EncPlan PL = enc_plan_view(planp, B, S);
@@ -32,21 +33,21 @@ __global__ __launch_bounds__(256) void enc_grad_reduce_k(EgReduce R, unsigned* _
     re_kernarg_warm<re_kernarg_bytes(&enc_grad_reduce_k)>();
     const int tid = threadIdx.x;
     if (ticket && blockIdx.x == 0 && tid == 0) ticket[0] = 0u;   // (enc_tail_k's job counter: every job of this step has been taken)
+    __shared__ float red[4][64];
     if ((int)blockIdx.x >= R.nmat_blocks + R.nvec_blocks) {
-        eg_reduce_pos(R, (int)blockIdx.x - R.nmat_blocks - R.nvec_blocks, tid);
+        eg_reduce_pos(R, (int)blockIdx.x - R.nmat_blocks - R.nvec_blocks, tid, red);
         return;
     }
     if ((int)blockIdx.x < R.nmat_blocks) {
         eg_reduce_mat(R, (int)blockIdx.x, tid);
         return;
     }
-    __shared__ float red[4][64];
     const EgVec V = eg_reduce_vec_a(R, (int)blockIdx.x - R.nmat_blocks, tid, red);
     __syncthreads();
     eg_reduce_vec_b(R, V, tid, red);
 }
 
-size_t enc_wgrad_ppart_floats(int64_t B, int64_t D) { return (size_t)64 * ((B + 63) / 64) * D; }
+size_t enc_wgrad_ppart_floats(int64_t, int64_t D) { return (size_t)64 * WG_POS_GROUPS * D; }   // [S <= 64][groups][D]
 
 // the reduction's arguments (shared by the launch below and the step tail's queue, enc_tail.hip)
 int enc_grad_reduce_args(EgReduce& R, int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
@@ -57,7 +58,7 @@ int enc_grad_reduce_args(EgReduce& R, int64_t B, int64_t S, int64_t D, int64_t L
         for (int i = 0; i < 14; ++i) R.dst.p[l][i] = (l < L && i < 12) ? block_grads[12 * l + i] : (i == 12 ? g_last_w : g_last_b);
     R.nmat_blocks = (int)((L * EG_NMAT * D * D + 255) / 256);
     R.nvec_blocks = (int)(L * EG_NVEC * (D / 64));
-    R.npos_blocks = dPtab ? (int)((S * D + 255) / 256) : 0;
+    R.npos_blocks = dPtab ? (int)((S * D + 63) / 64) : 0;
     if (adam) {
         if (!adam->grad_base || !adam->param || !adam->m || !adam->v || !adam->hyper) return RE_EINVAL;
         R.AD = EncAdam{adam->grad_base, adam->param, adam->m, adam->v, adam->hyper, (float)adam->beta1, (float)adam->beta2, (float)(1.0 - adam->beta1),

@@ -149,55 +149,75 @@ __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m,
     }
 }
 
-// Position-table gradient, partial sums: job (p, chunk of 64 sequences) -> ppart[p][chunk][D] = sum over the chunk's sequences with a real
-// token at p of contrib[b][p]  (every load independent: one memory round trip per job).  This group takes jobs j0, j0 + jstep, ...
+// Position-table gradient, partial sums.  The batch's sequences are dealt to WG_POS_GROUPS groups as contiguous ranges; group g writes
+// ppart[p][g][D] = sum over ITS sequences (ascending) with a real token at p of contrib[b][p], for every position p.  Only rows of real tokens
+// are read (a Beauty-shaped batch is 88 % padding: the round-5 form -- one job per (position, 64 sequences), every row of the dense [B, S, D]
+// array loaded and the pads dropped by a select -- was 52 MB of loads and 22 dependent round trips a group at B = 4 096, ~117 k cycles of the
+// step tail's ~250 k: scripts/tail_phases.py):
+//   1. the range's token flags (the ids' low words != 0) -> LDS, 64 sequences at a time;
+//   2. every row group rg lists the (position, sequence) pairs of ITS positions p = rg (mod CG), position-major, sequences ascending (a ballot
+//      per position);
+//   3. the list's rows, sixteen loads in flight, summed per position in a register and added to acc[p][col] in LDS (one owner per element);
+//   4. acc -> ppart.
+// The order of every sum is fixed by (B, S) alone; barrier counts as well (enc_tail_k runs two groups side by side behind workgroup barriers).
+#define WG_POS_GROUPS 144
 template <int D>
-__device__ __forceinline__ void wg_pos_job(int tid, float* lds, int j0, int jstep, int B, int S, const int64_t* __restrict__ seq,
+__device__ __forceinline__ void wg_pos_job(int tid, float* lds, int g, int B, int S, const int64_t* __restrict__ seq,
                                            const float* __restrict__ contrib, float* __restrict__ ppart) {
     using C = EC<D>;
-    const int nch = (B + 63) / 64, njobs = S * nch;
-    const int trips = (njobs + jstep - 1) / jstep;    // (the same for every j0)
-    const int col = tid % D, rg = tid / D;
-    // (the next job's loads are in flight while this one is reduced: a group has ~3 jobs, each a memory round trip)
-    constexpr int NQP = 64 / C::CG;
-    // (an item id's LOW word: ids are < 2^31, and only "is there a token" is asked -- half the registers of the 64-bit ids, which at D = 128,
-    //  16 rows a thread and two jobs in flight, did not fit the tail launches' 128)
+    constexpr int NT = C::NT, CG = C::CG, G = WG_POS_GROUPS;
+    constexpr int PPG = (64 + CG - 1) / CG;                // positions of a row group, at most (S <= 64)
+    constexpr int LIST = PPG * 64;                         // its list: 64 sequences a pass
+    static_assert((64 * D + 64 * 64 / 4 + CG * LIST / 2) <= wg_job_lds_floats<D>(), "accumulators + flags + lists fit a job's LDS");
+    float* acc = lds;                                                                  // [S][D]
+    unsigned char* tok = reinterpret_cast<unsigned char*>(lds + 64 * D);               // [64][S]
+    unsigned short* list = reinterpret_cast<unsigned short*>(tok + 64 * 64) + (tid / D) * LIST;
+    const int nb = (B + G - 1) / G;                        // sequences of a group
+    const int b_lo = min(g * nb, B), b_hi = min(b_lo + nb, B);
+    const int nsub = (nb + 63) / 64;                       // (uniform: the same for every group)
+    const int col = tid % D, rg = tid / D, lane = tid & 63;
+    // (an item id's LOW word: ids are < 2^31, and only "is there a token" is asked)
     const int32_t* __restrict__ seq_lo = reinterpret_cast<const int32_t*>(seq);
-    int32_t sv[NQP], svn[NQP];
-    float cv[NQP], cvn[NQP];
-#define WG_PJOB(J, SV, CV)                                                              \
-    do {                                                                                \
-        const int p_ = (J) / nch, ch_ = (J) % nch;                                      \
-        _Pragma("unroll") for (int q = 0; q < NQP; ++q) {                               \
-            int b = ch_ * 64 + rg + C::CG * q;                                          \
-            const bool in_ = b < B;                                                     \
-            b = in_ ? b : B - 1;   /* clamped, unconditional loads */                   \
-            const int32_t sx = seq_lo[2 * ((int64_t)b * S + p_)];                       \
-            const float cx = contrib[((int64_t)b * S + p_) * D + col];                  \
-            SV[q] = in_ ? sx : 0;                                                       \
-            CV[q] = cx;                                                                 \
-        }                                                                               \
-    } while (0)
-#pragma unroll
-    for (int q = 0; q < NQP; ++q) { sv[q] = 0; cv[q] = 0.f; svn[q] = 0; cvn[q] = 0.f; }
-    if (j0 < njobs) WG_PJOB(j0, sv, cv);
-    for (int it = 0; it < trips; ++it) {
-        const int j = j0 + it * jstep;
-        if (j + jstep < njobs) WG_PJOB(j + jstep, svn, cvn);
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < NQP; ++q) s += (sv[q] != 0) ? cv[q] : 0.f;   // (rows of pad positions are never written: select, not multiply)
+    __syncthreads();
+    for (int i = tid; i < S * D; i += NT) acc[i] = 0.f;
+    for (int c = 0; c < nsub; ++c) {
+        const int bb = b_lo + 64 * c;
+        const int nbc = max(0, min(64, b_hi - bb));
+        for (int i = tid; i < nbc * S; i += NT) tok[i] = seq_lo[2 * ((int64_t)bb * S + i)] != 0;      // (tok[bl * S + p]: the batch's own layout)
         __syncthreads();
-        lds[tid] = s;
-        __syncthreads();
-        if (tid < D && j < njobs) {
-            float t = lds[tid];
-#pragma unroll
-            for (int i = 1; i < C::CG; ++i) t += lds[i * D + tid];
-            ppart[(int64_t)j * D + tid] = t;
+        int cnt = 0;
+        for (int p = rg; p < S; p += CG) {                 // (at D = 128 both waves of a row group write the same list)
+            const bool f = lane < nbc && tok[lane * S + p];
+            const unsigned long long m = __ballot(f);
+            if (f) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(p << 6 | lane);
+            cnt += __popcll(m);
         }
+        __syncthreads();
+        int pcur = -1;
+        float a = 0.f;
+        for (int k0 = 0; k0 < cnt; k0 += 16) {
+            float x[16];
+            int pe[16];
 #pragma unroll
-        for (int q = 0; q < NQP; ++q) { sv[q] = svn[q]; cv[q] = cvn[q]; }
+            for (int u = 0; u < 16; ++u) {                 // (clamped, unconditional: the loads of a pass are requested together)
+                const int e = __builtin_amdgcn_readfirstlane((int)list[min(k0 + u, cnt - 1)]);
+                pe[u] = e >> 6;
+                x[u] = contrib[((int64_t)(bb + (e & 63)) * S + pe[u]) * D + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (k0 + u < cnt) {                        // (uniform)
+                    if (pe[u] != pcur) {
+                        if (pcur >= 0) acc[pcur * D + col] += a;
+                        pcur = pe[u];
+                        a = 0.f;
+                    }
+                    a += x[u];
+                }
+            }
+        }
+        if (pcur >= 0) acc[pcur * D + col] += a;
+        __syncthreads();
     }
-#undef WG_PJOB
+    for (int i = tid; i < S * D; i += NT) ppart[((int64_t)(i / D) * G + g) * D + i % D] = acc[i];
 }

@@ -22,7 +22,7 @@
 #include "re_common.h"
 
 #define SO_NT 1024           // threads per workgroup: the scan is vector-instruction bound, 4 waves per SIMD hide each other's latencies
-#define SO_CAP 8192          // match list (LDS): flushed whenever the next 8192-key chunk might not fit
+#define SO_CAP 12288         // match list (LDS, 48 KB beside the 96 KB of accumulators): 768 entries a wave; the chunked form flushes it when a chunk might not fit
 #define SO_NG 8              // accumulator sets
 #define SO_LG (SO_NT / 32)   // lane groups (32 lanes each): 4 per accumulator set
 #define SO_INF 16            // row loads a lane group keeps in flight (24 was no faster on the Zipf head's 850 rows and cost 22 spilled registers)
@@ -107,6 +107,10 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
     SO_STAMP(0);
 
     const uint32_t n32 = (uint32_t)n, total = (uint32_t)nreg * n32;   // (< 2^25: checked by the entry point)
+    // The regions are scanned as ONE run of nreg * n keys.  Region q's keys and rows start q * stride in: flat index v -> word / row v + q * dlt;
+    // a list entry holds that row (25 bits) under the key's local row (7 bits).
+    auto region_of = [&](uint32_t v) { return (uint32_t)(v >= n32) + (uint32_t)(v >= 2 * n32) + (uint32_t)(v >= 3 * n32); };   // (nreg <= 4)
+    const uint32_t dlt = (uint32_t)stride - n32;
     auto flush = [&](bool last) {
         // Lane group grp takes the list entries j with (m0 + j) % 32 == grp, in increasing j, INF row loads in flight at a time; a hot
         // row (the Zipf head is 10 % of a batch: hundreds of entries for ONE workgroup) is thereby spread over all 32 groups.
@@ -161,7 +165,6 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
     // Match order = (chunk, thread, key): a fixed function of the keys.  (n is a multiple of 4 or the tail is handled by element:
     // a load never straddles two regions.)
     const bool vec = (n32 & 3u) == 0;
-    auto region_of = [&](uint32_t v) { return (uint32_t)(v >= n32) + (uint32_t)(v >= 2 * n32) + (uint32_t)(v >= 3 * n32); };   // (nreg <= 4)
     auto load_chunk = [&](uint32_t base, int (&kk)[SO_KPT]) {
 #pragma unroll
         for (int u = 0; u < SO_KPT / 4; ++u) {
@@ -178,61 +181,152 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         }
     };
     const uint32_t R32 = (uint32_t)R, pad32 = (padding_idx >= 0 && padding_idx < R) ? (uint32_t)padding_idx : 0xFFFFFFFFu;
-    int kv[SO_KPT], kn[SO_KPT];
-    if (total > 0) SO_STAMP(1);
-    if (total > 0) load_chunk(0, kv);
-    for (uint32_t base = 0; base < total; base += SO_NT * SO_KPT) {
-        if (base + SO_NT * SO_KPT < total) load_chunk(base + SO_NT * SO_KPT, kn);   // (in flight while this chunk is ranked)
-        unsigned mask = 0;
+    auto is_hit = [&](int key) {
+        const uint32_t k = (uint32_t)key;   // (a negative key is >= R as unsigned)
+        return (k & ((nwg >> HSH) - 1)) == (me >> HSH) && k < R32 && k != pad32;
+    };
+    auto entry_of = [&](int key, uint32_t v) { return (((uint32_t)key >> (wsh - HSH)) << 25) | (v + region_of(v) * dlt); };
+    // ---- the usual case: every WAVE ranks its own sixteenth of the keys into its own 512-entry stretch of the list -- ballots and lane counts,
+    // no workgroup barrier inside the scan (the chunked form below, two barriers and a workgroup-wide prefix sum per 8 192 keys, took ~5 k cycles
+    // a chunk whatever the keys were: 13 k of the tail launch's ~50 k at B = 512, 70 k of ~210 k at B = 4 096; scripts/tail_phases.py) -- and the
+    // sixteen stretches are closed up afterwards.  Match order = (wave, chunk of 512 keys, key slot, lane): a fixed function of the keys.  A wave
+    // whose stretch would overflow (the owner of a Zipf head row at a large batch) sends the whole workgroup through the chunked form instead.
+    constexpr int SO_WCAP = SO_CAP / (SO_NT / 64);
+    static_assert(SO_WCAP % 64 == 0 && SO_WCAP / 64 <= 12, "a wave closes up its stretch from twelve registers a lane");
+    const uint32_t per_wave = (total + (SO_NT / 64) * 512u - 1u) / ((SO_NT / 64) * 512u) * 512u;
+    bool slow = !vec;        // (uniform; n is a multiple of 16 wherever a plan's tile count sets it)
+    if (!slow) {
+        const uint32_t w_lo = (uint32_t)wid * per_wave, w_hi = min(w_lo + per_wave, total);
+        // (no branch around a load and none between the loads of a pass: behind a divergent branch hipcc waits for EVERY outstanding load --
+        //  s_waitcnt vmcnt(0) -- and the next chunk's request stopped overlapping anything; addresses are clamped into the wave's range instead,
+        //  and keys past its end never count as matches)
+        auto load_w = [&](uint32_t base, int (&kk)[SO_KPT]) {
 #pragma unroll
-        for (int u = 0; u < SO_KPT; ++u) {
-            const uint32_t k = (uint32_t)kv[u];   // (a negative key is >= R as unsigned)
-            const bool hit = (k & ((nwg >> HSH) - 1)) == (me >> HSH) && k < R32 && k != pad32;
-            mask |= (hit ? 1u : 0u) << u;
-        }
-        const int c = __popc(mask);
-#ifdef SO_MARKS
-        if (so_i < 8) { SO_MARK(so_i); ++so_i; }
-#endif
-        // ---- exclusive scan of the per-thread counts over the workgroup
-        int inc = c;
+            for (int u = 0; u < SO_KPT / 4; ++u) {
+                const uint32_t v = min(base + (uint32_t)(u * 64 + lane) * 4, w_hi - 4u);
+                const int4 k4 = *reinterpret_cast<const int4*>(keys + (v + region_of(v) * dlt));
+                kk[4 * u] = k4.x; kk[4 * u + 1] = k4.y; kk[4 * u + 2] = k4.z; kk[4 * u + 3] = k4.w;
+            }
+        };
+        int wcnt = 0;        // (wave-uniform)
+        bool ovf = false;    // (wave-uniform)
+        if (total > 0) SO_STAMP(1);
+        // (the scan is vector-instruction bound -- sixteen waves of a CU look at every key of the batch.  Per key: an AND, a compare and a scalar
+        //  branch; with 128 owners per row half and 64 lanes, 40 % of the keys have SOME lane that belongs here, so the taken side is kept to a
+        //  dozen instructions as well: two range compares and the ballot; the lane's slot and the entry word only where a lane really has a match)
+        const uint32_t omask = (nwg >> HSH) - 1u, ome = me >> HSH;
+        auto rank = [&](const int (&kk)[SO_KPT], uint32_t base) {
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
+            for (int u = 0; u < SO_KPT; ++u) {
+                const uint32_t k = (uint32_t)kk[u];
+                const bool mine_maybe = (k & omask) == ome;
+                if (__ballot(mine_maybe) != 0ull) {           // (uniform)
+                    const uint32_t v = base + (uint32_t)((u >> 2) * 64 + lane) * 4 + (u & 3);
+                    // (a negative key is >= R as unsigned;  v >= w_hi: a clamped load's repeat of the range's last keys)
+                    const bool hit = mine_maybe && k < R32 && k != pad32 && v < w_hi;
+                    const unsigned long long hm = __ballot(hit);
+                    const int pc = __popcll(hm);
+                    if (wcnt + pc > SO_WCAP) ovf = true;
+                    else {
+                        if (hit) s_ent[wid * SO_WCAP + wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u))] = entry_of(kk[u], v);
+                        wcnt = __builtin_amdgcn_readfirstlane(wcnt + pc);
+                    }
+                }
+            }
+        };
+        if (w_lo < w_hi) {   // (uniform)
+            // (two register sets in turn: a copy at the end of a pass would wait for the chunk just requested)
+            int ka[SO_KPT], kb[SO_KPT];
+            load_w(w_lo, ka);
+            for (uint32_t base = w_lo; base < w_hi; base += 1024u) {
+                load_w(base + 512u, kb);
+                rank(ka, base);
+                if (base == w_lo) SO_STAMP(5);
+                load_w(base + 1024u, ka);
+                rank(kb, base + 512u);
+            }
         }
-        __syncthreads();                        // (previous chunk's s_wsum readers are done)
-        if (lane == 63) s_wsum[wid] = inc;
+        if (lane == 0) s_wsum[wid] = ovf ? -1 : wcnt;
         __syncthreads();
         int tot = 0, below = 0;
 #pragma unroll
         for (int w = 0; w < SO_NT / 64; ++w) {
             const int x = s_wsum[w];
+            slow |= x < 0;
             tot += x;
             below += w < wid ? x : 0;
         }
-        if (tot != 0) {                         // (uniform)
-            if (cnt + tot > SO_CAP) {           // (uniform) make room
-                flush(false);
-                __syncthreads();
-            }
-            int off = cnt + below + inc - c;
-            if (c) {
+        SO_STAMP(6);
+        if (!slow) {                                          // (uniform) close the stretches up, in place: read, barrier, write
+            uint32_t mine[SO_WCAP / 64];
 #pragma unroll
-                for (int u = 0; u < SO_KPT; ++u) {
-                    const bool hit = (mask >> u) & 1u;
-                    if (hit) {
-                        const uint32_t v = base + (uint32_t)((u >> 2) * SO_NT + tid) * 4 + (u & 3);
-                        const uint32_t q = region_of(v);
-                        s_ent[off] = (((uint32_t)kv[u] >> (wsh - HSH)) << 25) | ((uint32_t)(q * stride) + (v - q * n32));
-                    }
-                    off += hit ? 1 : 0;
-                }
-            }
-            cnt += tot;
+            for (int i = 0; i < SO_WCAP / 64; ++i) mine[i] = 64 * i + lane < wcnt ? s_ent[wid * SO_WCAP + 64 * i + lane] : 0u;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SO_WCAP / 64; ++i)
+                if (64 * i + lane < wcnt) s_ent[below + 64 * i + lane] = mine[i];
+            cnt = tot;
         }
+    }
+    if (slow) {                                               // (uniform) the chunked form: flushes the list whenever it might overflow
+        __syncthreads();                                      // (everybody has read s_wsum)
+        int kv[SO_KPT], kn[SO_KPT];
+        if (total > 0) SO_STAMP(1);
+        if (total > 0) load_chunk(0, kv);
+        for (uint32_t base = 0; base < total; base += SO_NT * SO_KPT) {
+            if (base + SO_NT * SO_KPT < total) load_chunk(base + SO_NT * SO_KPT, kn);   // (in flight while this chunk is ranked)
+            unsigned mask = 0;
 #pragma unroll
-        for (int u = 0; u < SO_KPT; ++u) kv[u] = kn[u];
+            for (int u = 0; u < SO_KPT; ++u) {
+                const uint32_t k = (uint32_t)kv[u];   // (a negative key is >= R as unsigned)
+                const bool hit = (k & ((nwg >> HSH) - 1)) == (me >> HSH) && k < R32 && k != pad32;
+                mask |= (hit ? 1u : 0u) << u;
+            }
+            const int c = __popc(mask);
+            if (base == 0) SO_STAMP(5);
+#ifdef SO_MARKS
+            if (so_i < 8) { SO_MARK(so_i); ++so_i; }
+#endif
+            // ---- exclusive scan of the per-thread counts over the workgroup
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            __syncthreads();                        // (previous chunk's s_wsum readers are done)
+            if (lane == 63) s_wsum[wid] = inc;
+            __syncthreads();
+            int tot = 0, below = 0;
+#pragma unroll
+            for (int w = 0; w < SO_NT / 64; ++w) {
+                const int x = s_wsum[w];
+                tot += x;
+                below += w < wid ? x : 0;
+            }
+            if (tot != 0) {                         // (uniform)
+                if (cnt + tot > SO_CAP) {           // (uniform) make room
+                    flush(false);
+                    __syncthreads();
+                }
+                int off = cnt + below + inc - c;
+                if (c) {
+#pragma unroll
+                    for (int u = 0; u < SO_KPT; ++u) {
+                        const bool hit = (mask >> u) & 1u;
+                        if (hit) {
+                            const uint32_t v = base + (uint32_t)((u >> 2) * SO_NT + tid) * 4 + (u & 3);
+                            s_ent[off] = entry_of(kv[u], v);
+                        }
+                        off += hit ? 1 : 0;
+                    }
+                }
+                cnt += tot;
+            }
+            if (base == 0) SO_STAMP(6);
+#pragma unroll
+            for (int u = 0; u < SO_KPT; ++u) kv[u] = kn[u];
+        }
     }
     __syncthreads();
     SO_MARK(8);

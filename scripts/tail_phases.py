@@ -14,7 +14,7 @@ lib.LIB_PATH = os.path.join(ROOT, "recboard_amd", "librecengine_encprof.so")
 L = lib.load()
 import bench  # noqa: E402
 from recboard_amd.sasrec import SASRecEngine  # noqa: E402
-cfg = bench.BEAUTY
+cfg = dict(bench.BEAUTY, B=int(os.environ.get("TAIL_B", "512")))
 LARGE = len(sys.argv) > 1 and sys.argv[1] == "large"      # the sparse tail of a large-table step at D = 128 (config 5's, on a 4 M-row table)
 if LARGE:
     from recboard_amd.large import SASRecLargeTableEngine
@@ -22,6 +22,7 @@ if LARGE:
 bs = [tuple(torch.from_numpy(x).cuda() for x in b) for b in bench.synth_batches(cfg, 8, 1)]
 m = (SASRecLargeTableEngine(cfg["items"], 50, 128, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=1, table_init="counter") if LARGE else
      SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=1))
+m.prep_in_tail = True
 for i in range(40):
     m.train_step_graph(*bs[i % 8], next_batch=bs[(i + 1) % 8])
 torch.cuda.synchronize()
@@ -48,7 +49,13 @@ for w in range(NWG):
             prev = e
 d, tk = np.array(durs), np.array(tk)
 print("ticket duration    min/med/p90/max", d.min(), np.median(d), np.percentile(d, 90), d.max(), " tickets", len(d))
-for lo, hi, name in ((0, 144, "matrix tickets"), (144, 10 ** 9, "position tickets")):
+# queue order (enc_tail.hip: tail_jobs): the next batch's plan job, the matrix tickets, the next batch's element-wise jobs, the position tickets
+n_mat_t = 144
+n_pos_t = 72
+n_prep_t = max(0, int(tk.max()) + 1 - n_mat_t - n_pos_t)
+n_plan_t = 1 if n_prep_t else 0
+for lo, hi, name in ((0, n_plan_t, "plan ticket"), (n_plan_t, n_plan_t + n_mat_t, "matrix tickets"), (n_plan_t + n_mat_t, n_prep_t + n_mat_t, "element-wise tickets"),
+                     (n_prep_t + n_mat_t, 10 ** 9, "position tickets")):
     sel = (tk >= lo) & (tk < hi)
     if sel.any():
         print(f"  {name}: n {int(sel.sum())} med {np.median(d[sel]):.1f} max {d[sel].max():.1f}")
@@ -72,10 +79,8 @@ if rows:
     print("matrix job stamps relative to the scatter end, medians (kcycles): entry, fetch issued, stage 0 staged, products 0, 1, 2 | job end", np.round(np.nanmedian(r, 0), 1).tolist(), " n", len(rows))
 
 rel = lambda i: np.round(np.median([(t[w, i] - t[w, 0]) / 1e3 for w in range(NWG) if t[w, i] > 0 and w not in pw] or [np.nan]), 1)
-print("medians relative to the workgroup's start (kcycles): scatter start", rel(20), "key count known", rel(21), "keys scanned", rel(22), "rows added", rel(23),
+print("medians relative to the workgroup's start (kcycles): scatter start", rel(20), "key count known", rel(21), "first chunk ranked", rel(25), "placed", rel(26), "keys scanned", rel(22), "rows added", rel(23),
       "rows stored", rel(24), "| scatter end", rel(1), "| at first barrier", rel(19), "passed", rel(16), "ticket read", rel(17), "job called", rel(18), "job entry", rel(8), "| end", rel(15))
-rw = [(int(t[w, 26]) - 1, (t[w, 24] - t[w, 0]) / 1e3, (t[w, 25] - t[w, 24]) / 1e3) for w in range(NWG) if t[w, 26] > 0]
-if rw:
-    rw.sort()
-    print("reduction tickets (the LAST one a workgroup ran): ticket, entered at (kcycles after its start), took (kcycles)")
-    print("  ", [(a, round(b, 1), round(c, 1)) for a, b, c in rw][:64])
+for w in np.argsort(sc)[-3:]:      # the owners of the hottest rows: scatter_owner.h stamps (0 start, 1 count known, 5 first chunk, 6 lists placed, 2 scanned, 3 added, 4 stored)
+    print("  slow scatter, workgroup", int(w), {k: round(float((t[w, i] - t[w, 0]) / 1e3), 1) for k, i in
+                                                 (("start", 20), ("count", 21), ("chunk0", 25), ("placed", 26), ("scanned", 22), ("added", 23), ("stored", 24)) if t[w, i] > 0})
