@@ -53,6 +53,7 @@ struct EgReduce {
     int B, S, D, L;
     EncGradDst dst;
     int nmat_blocks, nvec_blocks, npos_blocks;
+    int nsplit;   // partials per matrix (enc_wgrad_job.h: wg_nsplit / wg_nsplit_tail)
     const float* ppart;
     float inv_scale;
     float* dPtab;
@@ -91,25 +92,33 @@ __device__ __forceinline__ void eg_reduce_pos(const EgReduce& R, int vb, int tid
     if (q == 0 && in) eg_put(R.AD, R.dPtab + e, (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) * R.inv_scale, pre);
 }
 
-// 256 elements of the L * 6 * D * D weight gradients (sum of the wg_nsplit(D) partials).  vb in [0, nmat_blocks)
+// 256 elements of the L * 6 * D * D weight gradients (sum of the R.nsplit partials).  vb in [0, nmat_blocks)
 template <bool COHERENT = false>
 __device__ __forceinline__ void eg_reduce_mat(const EgReduce& R, int vb, int tid) {
     const int64_t e = (int64_t)vb * 256 + tid;
     const int dd = R.D * R.D;
     if (e >= (int64_t)R.L * EG_NMAT * dd) return;
     const int lm = (int)(e / dd), off = (int)(e % dd);
-    const int nsplit = wg_nsplit(R.D);
+    const int nsplit = R.nsplit;
     const float* p = R.part + (int64_t)lm * nsplit * dd + off;
     const int l = lm / EG_NMAT, m = lm % EG_NMAT;
     float* const* P = R.dst.p[l];
     float* d = (m == 0) ? P[10] : (m == 1) ? P[8] : (m == 2) ? P[4] : P[2] + (m - 3) * dd;
     const EgPre pre = eg_pre(R.AD, d + off);
-    float v[WG_NSPLIT_MAX];
-#pragma unroll
-    for (int i = 0; i < WG_NSPLIT_MAX; ++i) v[i] = eg_ld<COHERENT>(p + (int64_t)(i < nsplit ? i : 0) * dd);   // (clamped, unconditional)
     float s = 0.f;
+    if (nsplit <= 24) {      // (uniform)
+        float v[24];
 #pragma unroll
-    for (int i = 0; i < WG_NSPLIT_MAX; ++i) s += i < nsplit ? v[i] : 0.f;                    // (x + 0 = x: the partials in split order)
+        for (int i = 0; i < 24; ++i) v[i] = eg_ld<COHERENT>(p + (int64_t)(i < nsplit ? i : 0) * dd);   // (clamped, unconditional)
+#pragma unroll
+        for (int i = 0; i < 24; ++i) s += i < nsplit ? v[i] : 0.f;                    // (x + 0 = x: the partials in split order)
+    } else {
+        float v[WG_NSPLIT_MAX];
+#pragma unroll
+        for (int i = 0; i < WG_NSPLIT_MAX; ++i) v[i] = eg_ld<COHERENT>(p + (int64_t)(i < nsplit ? i : 0) * dd);
+#pragma unroll
+        for (int i = 0; i < WG_NSPLIT_MAX; ++i) s += i < nsplit ? v[i] : 0.f;
+    }
     eg_put(R.AD, d + off, s, pre);
 }
 

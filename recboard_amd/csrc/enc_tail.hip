@@ -43,6 +43,7 @@ struct TailJobs {
     const int64_t* seq;
     const float* contrib;
     float* ppart;        // nullptr: no position-table gradient
+    int nsplit;          // row splits of a matrix's contraction (enc_wgrad_job.h: wg_nsplit_tail)
     unsigned* ticket;    // zero at launch; enc_grad_reduce_k (the next launch) zeroes it again.  (Round 5 tried the reduction as the queue's LAST jobs,
                          // behind done counts -- exact, and slower: profiles/r5_tail_reduce_in_queue.txt; that form is commit 4086ee1.)
 };
@@ -89,8 +90,8 @@ template <int D>
 __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP, float* lds, int n_tiles, bool has_early = false) {
     const int tid = threadIdx.x, half = tid >> 9, ht = tid & 511;
     float* jl = lds + half * wg_job_lds_floats<D>();
-    constexpr int WG_NSPLIT = wg_nsplit(D);
-    constexpr int PER_PLANE = WG_NSPLIT * EG_NMAT;      // matrix jobs of a block
+    const int WG_NSPLIT = J.nsplit;
+    const int PER_PLANE = WG_NSPLIT * EG_NMAT;          // matrix jobs of a block
     constexpr bool WHOLE = D == 128;                    // a matrix job is run by the whole workgroup (enc_wgrad_job.h: wg_nsplit), not two by its halves
     constexpr int POS_GROUPS = WG_POS_GROUPS;           // the position jobs: one per 512-thread group (two per ticket)
     const int n_mat = WHOLE ? J.L * PER_PLANE : J.L * PER_PLANE / 2, n_pos = J.ppart ? POS_GROUPS / 2 : 0;
@@ -125,10 +126,10 @@ __device__ __forceinline__ void tail_jobs(const TailJobs& J, const TailPrep& TP,
             t -= n_plan;
             if (jn == 1) TJ_STAMP(2);
             if constexpr (WHOLE) {
-                wg_matrix_job<D, SO_NT>(tid, lds, t / PER_PLANE, (t / WG_NSPLIT) % EG_NMAT, t % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
+                wg_matrix_job<D, SO_NT>(tid, lds, t / PER_PLANE, (t / WG_NSPLIT) % EG_NMAT, t % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part, WG_NSPLIT);
             } else {
                 const int q = 2 * t + half;
-                wg_matrix_job<D>(ht, jl, q / PER_PLANE, (q / WG_NSPLIT) % EG_NMAT, q % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part);
+                wg_matrix_job<D>(ht, jl, q / PER_PLANE, (q / WG_NSPLIT) % EG_NMAT, q % WG_NSPLIT, J.tape, J.T, J.gtape, J.NR, n_tiles, J.part, WG_NSPLIT);
             }
         } else {
             wg_pos_job<D>(ht, jl, 2 * (t - n_prep - n_mat) + half, J.B, J.S, J.seq, J.contrib, J.ppart);
@@ -199,7 +200,7 @@ size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
 extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
 int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
                            const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
-                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket, const unsigned* gate);
+                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket, const unsigned* gate, int nsplit);
 
 static int tail_prep(TailPrep& TP, const re_next_prep* next) {
     TP = TailPrep{};
@@ -241,7 +242,7 @@ static int tail_side(TailSide& T, const int64_t* seq, int64_t B, int64_t S, int6
     T.ppart = T.wpart + enc_wgrad_part_floats(D, L);
     float* gtape = T.ppart + enc_wgrad_ppart_floats(B, D);
     T.J = TailJobs{(const float*)tape, enc_tape_layout(B, S, D, L), gtape, 16 * mt, plan, (int)B, (int)S, (int)L, T.wpart, seq, dx0,
-                   dPtab ? T.ppart : nullptr, ticket};
+                   dPtab ? T.ppart : nullptr, wg_nsplit_tail((int)D, B), ticket};
     T.gate = reinterpret_cast<const unsigned*>((const float*)tape + T.J.T.off_FLAGS) + mt * EP_FLAG_WORDS;
     return RE_OK;
 }
@@ -287,7 +288,7 @@ extern "C" int re_sasrec_step_tail(const float* g, const int32_t* keys, int32_t 
                        padding_idx, 1.0f, dW, AD, T.J, TP);
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
-                                  ticket, T.gate);
+                                  ticket, T.gate, T.J.nsplit);
 }
 
 // The same behind re_sparse_adam_rows_small (int32 keys, hyper from device memory): the tail of a LARGE-table step (config 5), D = 64 or 128.
@@ -331,5 +332,5 @@ extern "C" int re_sasrec_step_tail_sparse(const float* g, const int32_t* keys, i
     }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
     return enc_grad_reduce_launch(B, S, D, L, plan, T.slab, T.wgrid, T.wpart, T.ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, 1, enc_adam,
-                                  ticket, T.gate);
+                                  ticket, T.gate, T.J.nsplit);
 }

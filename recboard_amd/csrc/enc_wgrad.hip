@@ -52,7 +52,7 @@ size_t enc_wgrad_ppart_floats(int64_t, int64_t D) { return (size_t)64 * WG_POS_G
 // the reduction's arguments (shared by the launch below and the step tail's queue, enc_tail.hip)
 int enc_grad_reduce_args(EgReduce& R, int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
                          const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b, int by_tile,
-                         const re_adam_fuse* adam, const unsigned* gate) {
+                         const re_adam_fuse* adam, const unsigned* gate, int nsplit) {
     R = EgReduce{};
     for (int64_t l = 0; l < SE_MAX_BLOCKS; ++l)
         for (int i = 0; i < 14; ++i) R.dst.p[l][i] = (l < L && i < 12) ? block_grads[12 * l + i] : (i == 12 ? g_last_w : g_last_b);
@@ -65,6 +65,7 @@ int enc_grad_reduce_args(EgReduce& R, int64_t B, int64_t S, int64_t D, int64_t L
                        (float)(1.0 - adam->beta2), (float)adam->eps, (float)adam->weight_decay, gate};
     }
     R.part = part; R.slab = slab; R.nwg = nwg; R.planp = plan; R.B = (int)B; R.S = (int)S; R.D = (int)D; R.L = (int)L;
+    R.nsplit = nsplit > 0 ? nsplit : wg_nsplit((int)D);
     R.ppart = ppart; R.inv_scale = emb_scale != 0.f ? 1.0f / emb_scale : 0.f; R.dPtab = dPtab; R.by_tile = by_tile;
     return RE_OK;
 }
@@ -72,9 +73,9 @@ int enc_grad_reduce_args(EgReduce& R, int64_t B, int64_t S, int64_t D, int64_t L
 // The reduction launch behind the weight-gradient jobs (enc_wgrad_k here, or enc_tail_k's: enc_tail.hip -- `ticket` is its job counter).
 int enc_grad_reduce_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* plan, const float* slab, int nwg, const float* part,
                            const float* ppart, float emb_scale, float* dPtab, float* const* block_grads, float* g_last_w, float* g_last_b,
-                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket, const unsigned* gate) {
+                           hipStream_t s, int by_tile, const re_adam_fuse* adam, unsigned* ticket, const unsigned* gate, int nsplit) {
     EgReduce R;
-    const int rc = enc_grad_reduce_args(R, B, S, D, L, plan, slab, nwg, part, ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, by_tile, adam, gate);
+    const int rc = enc_grad_reduce_args(R, B, S, D, L, plan, slab, nwg, part, ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, by_tile, adam, gate, nsplit);
     if (rc != RE_OK) return rc;
     hipLaunchKernelGGL(enc_grad_reduce_k, dim3(R.nmat_blocks + R.nvec_blocks + R.npos_blocks), dim3(256), 0, s, R, ticket);
     return re_launch_status();
@@ -100,5 +101,5 @@ int enc_wgrad_launch(int64_t B, int64_t S, int64_t D, int64_t L, const void* tap
                            ppart, (const float*)dPtab);
     }
     if (hipGetLastError() != hipSuccess) return RE_ELAUNCH;
-    return enc_grad_reduce_launch(B, S, D, L, plan, slab, nwg, part, ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, by_tile, adam, nullptr, nullptr);
+    return enc_grad_reduce_launch(B, S, D, L, plan, slab, nwg, part, ppart, emb_scale, dPtab, block_grads, g_last_w, g_last_b, s, by_tile, adam, nullptr, nullptr, 0);
 }

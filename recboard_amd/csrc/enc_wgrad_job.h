@@ -11,7 +11,11 @@
 // side, as at D = 64, need more than the 128 registers such a thread has and spilled into scratch memory inside the stage loop (a stage 9 - 14 k
 // cycles instead of ~4 k: config 5's tail 47 us, scripts/tail_phases.py large).  Half as many splits of twice the rows keep the ticket count.
 __host__ __device__ constexpr int wg_nsplit(int D) { return D == 128 ? 12 : 24; }
-#define WG_NSPLIT_MAX 24
+// The step tail's queue at D = 64 cuts finer from 1 024 sequences on: 40 splits = 240 tickets, one for (nearly) every workgroup of the launch --
+// with 144 tickets of a 31 000-row contraction each (B = 4 096) the matrix tickets were 115 k cycles on 144 of the 256 CUs, the longest chain
+// of the launch (scripts/tail_phases.py); below that a ticket is three stages and more of them would only queue behind each other.
+__host__ __device__ constexpr int wg_nsplit_tail(int D, int64_t B) { return D == 64 && B >= 1024 ? 40 : wg_nsplit(D); }
+#define WG_NSPLIT_MAX 40
 #define WG_CH 4   // row tiles per LDS stage
 #ifndef WG_STAMP
 #define WG_STAMP(i) do { } while (0)   // (enc_tail.hip's profile build: shader-clock stamps inside a job)
@@ -34,10 +38,10 @@ struct WgCfg {
 // NT: threads of the group that runs the job (tid: 0 .. NT - 1): 512, or 1024 (enc_tail.hip at D = 128)
 template <int D, int NT = EC<D>::NT>
 __device__ __forceinline__ void wg_matrix_job(int tid, float* lds, int l, int m, int split, const float* __restrict__ tape, const EncTape& T,
-                                              const float* __restrict__ gtape, int64_t NR, int n_tiles, float* __restrict__ part) {
+                                              const float* __restrict__ gtape, int64_t NR, int n_tiles, float* __restrict__ part,
+                                              int WG_NSPLIT = wg_nsplit(D)) {
     using C = WgCfg<D, NT>;
     static_assert(C::WR >= 1 && C::NS % C::WR == 0, "waves = strips x row groups");
-    constexpr int WG_NSPLIT = wg_nsplit(D);
     constexpr int RTW = C::NS / C::WR;   // output row tiles per wave
     constexpr int RSW = D + 4;           // words of a row pair (+ 4: the four lane groups of a fragment read land in four bank quarters)
     constexpr int NPAIR = 16 * WG_CH / 2;

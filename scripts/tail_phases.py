@@ -50,7 +50,7 @@ for w in range(NWG):
 d, tk = np.array(durs), np.array(tk)
 print("ticket duration    min/med/p90/max", d.min(), np.median(d), np.percentile(d, 90), d.max(), " tickets", len(d))
 # queue order (enc_tail.hip: tail_jobs): the next batch's plan job, the matrix tickets, the next batch's element-wise jobs, the position tickets
-n_mat_t = 144
+n_mat_t = 240 if (cfg["B"] >= 1024 and not LARGE) else 144      # (enc_wgrad_job.h: wg_nsplit_tail -- 40 row splits from 1 024 sequences on)
 n_pos_t = 72
 n_prep_t = max(0, int(tk.max()) + 1 - n_mat_t - n_pos_t)
 n_plan_t = 1 if n_prep_t else 0
