@@ -461,6 +461,11 @@ int re_sasrec_encoder_step_part(const float* E, int64_t R, const float* Ptab, fl
                                 size_t loss_ws_bytes, float* dx0, float* dPtab, float* const* block_grads, float* g_last_w,
                                 float* g_last_b, void* ws, size_t ws_bytes, int32_t part, const re_adam_fuse* adam, re_stream_t stream);
 size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t L);
+/* Where the library places the regions of that workspace in a buffer at address `base` (the address is not dereferenced; the two aligned
+ * regions depend on it): out[0..6] = byte offsets of the workgroup slabs, the matrices' split-K partials, the position table's group partials,
+ * the gradient tape, the tile kernels' weight fragments, the tiles' dK / dV inboxes, and the first byte behind the last region
+ * (<= re_sasrec_encoder_bwd_workspace_bytes for every base).  Host only; for layout checks (tests/test_workspace_layout.py). */
+int re_sasrec_encoder_bwd_workspace_layout(int64_t B, int64_t S, int64_t D, int64_t L, uint64_t base, uint64_t* out);
 int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
                           const float* const* block_params, const float* last_w, const float* last_b, float drop_p, uint32_t seed,
                           const uint32_t* seed_dev, const void* tape, const void* plan, int32_t ncu, float scale, float* dx0,

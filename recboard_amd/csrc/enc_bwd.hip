@@ -68,6 +68,18 @@ extern "C" size_t re_sasrec_encoder_bwd_workspace_bytes(int64_t B, int64_t S, in
            enc_tile_wfrag_bytes(L, D) + 512 + enc_tile_xch_bytes(B, S, D, L) + 256;   // (+ the tiles' dK / dV inboxes)
 }
 
+// Where enc_bwd_ws (enc_tile_prep.h) puts the regions of that workspace for a buffer at address `base` (not dereferenced):
+// out[0..6] = byte offsets of slab, matrix partials, position partials, gradient tape, weight fragments, inboxes, end.
+extern "C" int re_sasrec_encoder_bwd_workspace_layout(int64_t B, int64_t S, int64_t D, int64_t L, uint64_t base, uint64_t* out) {
+    if (!out || B <= 0 || S <= 0 || S > 64 || (D != 64 && D != 128) || L < 1 || L > SE_MAX_BLOCKS) return RE_EINVAL;
+    const EncBwdWs W = enc_bwd_ws((void*)(uintptr_t)base, B, S, D, L);
+    const char* b = (const char*)(uintptr_t)base;
+    out[0] = (uint64_t)((const char*)W.slab - b); out[1] = (uint64_t)((const char*)W.wpart - b); out[2] = (uint64_t)((const char*)W.ppart - b);
+    out[3] = (uint64_t)((const char*)W.gtape - b); out[4] = (uint64_t)((const char*)W.wf - b); out[5] = (uint64_t)((const char*)W.xch - b);
+    out[6] = (uint64_t)W.bytes;
+    return RE_OK;
+}
+
 // dPtab == NULL: dx0 [B,S,D] receives the gradient w.r.t. x0 (rows of real tokens only).  Otherwise re_sasrec_embed_bwd is fused in:
 // dx0 receives the item-gradient contribution rows (pad mask, embedding dropout mask, * scale) and dPtab [S, D] the position-table gradient.
 extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_t B, int64_t S, int64_t D, int64_t L,
@@ -93,10 +105,8 @@ extern "C" int re_sasrec_encoder_bwd(const float* dU, const int64_t* seq, int64_
     const int grid = enc_bwd_grid(B, S, ncu);
     if (grid > 1024) return RE_EUNSUPPORTED;
     const int64_t NR = 16 * enc_plan_max_tiles(B, S);
-    float* slab = (float*)ws;
-    float* part = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
-    float* ppart = part + enc_wgrad_part_floats(D, L);
-    float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
+    const EncBwdWs Wk = enc_bwd_ws(ws, B, S, D, L);
+    float *slab = Wk.slab, *part = Wk.wpart, *ppart = Wk.ppart, *gtape = Wk.gtape;
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {
         using C = EC<128>;

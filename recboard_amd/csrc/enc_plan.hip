@@ -106,13 +106,10 @@ static int pl_fill_weights(PlWeights& WP, const float* const* block_params, cons
     if (tape_bytes < (size_t)enc_tape_layout(B, S, D, L).total * sizeof(float) || ws_bytes < re_sasrec_encoder_bwd_workspace_bytes(B, S, D, L))
         return RE_EWORKSPACE;
     // (the workspace layout of re_sasrec_encoder_step: slab | weight-gradient partials | gradient tape | fragments | inboxes)
-    float* slab = (float*)ws;
-    float* wpart = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
-    float* gtape = wpart + enc_wgrad_part_floats(D, L) + enc_wgrad_ppart_floats(B, D);
     WP.L = (int)L;
     WP.ns = (int)(D / 16);
     WP.nblocks = (TLC_PREP_THREADS((int)L, WP.ns) + PL_NT - 1) / PL_NT;
-    WP.wf = enc_tile_wf(gtape, B, S, L, D);
+    WP.wf = enc_bwd_ws(ws, B, S, D, L).wf;
     WP.epoch = enc_tile_epoch(tape, B, S, L, D);
     return RE_OK;
 }

@@ -111,16 +111,14 @@ extern "C" int re_sasrec_encoder_step_part(const float* E, int64_t R, const floa
     const int64_t mt = enc_plan_max_tiles(B, S);
     const int grid = (int)(mt < ncu ? mt : ncu);
     if (grid > 1024) return RE_EUNSUPPORTED;
-    float* slab = (float*)ws;
-    float* wpart = slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
-    float* ppart = wpart + enc_wgrad_part_floats(D, L);
-    float* gtape = ppart + enc_wgrad_ppart_floats(B, D);
+    const EncBwdWs Wk = enc_bwd_ws(ws, B, S, D, L);
+    float *slab = Wk.slab, *wpart = Wk.wpart, *ppart = Wk.ppart, *gtape = Wk.gtape;
     hipStream_t s = (hipStream_t)stream;
     {
         // one tile per workgroup (enc_tile.hip) when the plan says every tile can have a resident workgroup (hdr[7]); the workgroup-per-item
         // kernel is launched behind it and returns at once in that case -- the plan lives in device memory, so both are always enqueued
-        uint32_t* wf = enc_tile_wf(gtape, B, S, L, D);
-        float* xch = enc_tile_xch(wf, L, D);
+        uint32_t* wf = Wk.wf;
+        float* xch = Wk.xch;
         // (looped form: the resident workgroups, one per CU, further tiles from a counter; else a workgroup per tile, <= 1024 tiles by the plan's rule)
         // the looped form's grid = the RESIDENT workgroups (block b owns tile b; the rest come from a counter): CUs x workgroups per CU, the CU
         // count clamped to the device's (a caller's larger `ncu` would start blocks that cannot be resident while their partners spin)

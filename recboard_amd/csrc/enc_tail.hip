@@ -237,10 +237,9 @@ static int tail_side(TailSide& T, const int64_t* seq, int64_t B, int64_t S, int6
     if (ncu < 1) ncu = 256;
     const int64_t mt = enc_plan_max_tiles(B, S);
     T.wgrid = (int)(mt < ncu ? mt : ncu);
-    T.slab = (float*)ws;
-    T.wpart = T.slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
-    T.ppart = T.wpart + enc_wgrad_part_floats(D, L);
-    float* gtape = T.ppart + enc_wgrad_ppart_floats(B, D);
+    const EncBwdWs Wk = enc_bwd_ws(ws, B, S, D, L);
+    T.slab = Wk.slab; T.wpart = Wk.wpart; T.ppart = Wk.ppart;
+    float* gtape = Wk.gtape;
     T.J = TailJobs{(const float*)tape, enc_tape_layout(B, S, D, L), gtape, 16 * mt, plan, (int)B, (int)S, (int)L, T.wpart, seq, dx0,
                    dPtab ? T.ppart : nullptr, wg_nsplit_tail((int)D, B), ticket};
     T.gate = reinterpret_cast<const unsigned*>((const float*)tape + T.J.T.off_FLAGS) + mt * EP_FLAG_WORDS;

@@ -40,6 +40,30 @@ inline uint32_t* enc_tile_wf(float* gtape, int64_t B, int64_t S, int64_t L, int6
     return (uint32_t*)((((uintptr_t)(gtape + (size_t)L * EG_NMAT * 16 * enc_plan_max_tiles(B, S) * D)) + 255) & ~(uintptr_t)255);
 }
 inline float* enc_tile_xch(uint32_t* wf, int64_t L, int64_t D) { return (float*)(((uintptr_t)wf + enc_tile_wfrag_bytes(L, D) + 255) & ~(uintptr_t)255); }
+// The backward workspace (re_sasrec_encoder_bwd_workspace_bytes), carved in ONE place: workgroup slabs of vector gradients | the matrices' split-K
+// partials | the position table's group partials | the gradient tape | (256-byte aligned) the tile kernels' weight fragments + small parameters |
+// (aligned) the tiles' dK / dV inboxes.  `bytes` = the first byte behind the last region, from `ws`.  Every entry point that touches the workspace
+// goes through this (enc_bwd.hip, enc_step.hip, enc_tail.hip, enc_plan.hip); tests/test_workspace_layout.py checks it against the size query and
+// against the largest index each kernel can form (re_sasrec_encoder_bwd_workspace_layout).
+size_t enc_wgrad_part_floats(int64_t D, int64_t L);
+size_t enc_wgrad_ppart_floats(int64_t B, int64_t D);
+struct EncBwdWs {
+    float *slab, *wpart, *ppart, *gtape;
+    uint32_t* wf;
+    float* xch;
+    size_t bytes;
+};
+inline EncBwdWs enc_bwd_ws(void* ws, int64_t B, int64_t S, int64_t D, int64_t L) {
+    EncBwdWs W;
+    W.slab = (float*)ws;
+    W.wpart = W.slab + (size_t)enc_slab_rows(B, S) * L * EG_NVEC * D;
+    W.ppart = W.wpart + enc_wgrad_part_floats(D, L);
+    W.gtape = W.ppart + enc_wgrad_ppart_floats(B, D);
+    W.wf = enc_tile_wf(W.gtape, B, S, L, D);
+    W.xch = enc_tile_xch(W.wf, L, D);
+    W.bytes = (size_t)((char*)W.xch + enc_tile_xch_bytes(B, S, D, L) - (char*)ws);
+    return W;
+}
 inline unsigned* enc_tile_epoch(void* tape, int64_t B, int64_t S, int64_t L, int64_t D) {
     const EncTape T = enc_tape_layout(B, S, D, L);
     return reinterpret_cast<unsigned*>((float*)tape + T.off_FLAGS) + enc_plan_max_tiles(B, S) * EP_FLAG_WORDS + 1;

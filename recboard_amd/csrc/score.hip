@@ -1449,6 +1449,108 @@ __global__ __launch_bounds__(64) void score_bound_merge_k(const float* __restric
 #define MX_ROWS 16   // candidate rows staged per pass and wave (4 waves x 16 x (D + 4) floats of LDS; 32 rows per pass measured slower)
 __device__ float g_sx_info[8];
 __device__ unsigned g_sx_stats[2];   // [0] users sent to the exact fallback so far, [1] diagnostics: max |s' - s| / eps (float bits)
+// The split path's fallback for catalogs of up to SX_RESCAN_MAX_N items: ONE wave per FLAGGED user (the list score_topk_merge_x wrote)
+// scans the whole catalog with the exact fmaf chain -- 64 items at a time, rows staged through the wave's LDS slice by LDS-DMA as in the
+// merge's re-scoring, seen items dropped by a cursor into the user's sorted list, each chunk that holds anything better than the current
+// K-th merged into the wave's best-64 list by the merge's bitonic networks -- and writes the user's result.  Nobody flagged (the normal case):
+// every wave reads one word and leaves; that replaces the TWO launches (exact kernel over flagged blocks + its merge) whose dispatch was
+// 9 of the call's 387 us.  A flagged user costs ~N / 64 chunk rounds of ~2 000 cycles on one wave (Beauty: ~0.15 ms; every user of a
+// 22 363-user call flagged -- all-zero queries: ~2 ms instead of the exact kernels' 0.6): correctness, as before, never depends on it.
+#define SX_RESCAN_MAX_N (1 << 17)
+// one flagged user, by one wave: `stage` = the wave's MX_ROWS x D floats of LDS
+template <int D>
+__device__ __forceinline__ void sx_rescan_user(int64_t user, int64_t N, int K, const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
+                                               const float* __restrict__ Q, const float* __restrict__ E, float* __restrict__ vals,
+                                               int64_t* __restrict__ idx, float* stage, int lane) {
+    constexpr int LPR = D / 4;
+    constexpr int CPR = LPR, RPI = 64 / CPR, IPP = MX_ROWS / RPI;
+    const int PAD = 0x7FFFFFFF;
+    const float* qrow = Q + user * D;
+    int64_t sp = seen_ptr ? seen_ptr[user] : 0;
+    const int64_t se = seen_ptr ? seen_ptr[user + 1] : 0;
+    int64_t wbase = -1, w = 0;
+    float bv = -INFINITY;
+    int bi = PAD;
+    for (int64_t c0 = 0; c0 < N; c0 += 64) {
+        float sx = -INFINITY;
+#pragma unroll 1
+        for (int r0 = 0; r0 < 64; r0 += MX_ROWS) {
+            if (c0 + r0 >= N) break;
+#pragma unroll
+            for (int i = 0; i < IPP; ++i) {
+                const int r = i * RPI + lane / CPR;
+                int64_t id = c0 + r0 + r;
+                if (id >= N) id = N - 1;
+                const int g = (lane % CPR) ^ (r & 15);
+                const float* src = E + id * D + 4 * g;
+                __attribute__((address_space(3))) unsigned char* dst =
+                    (__attribute__((address_space(3))) unsigned char*)(__attribute__((address_space(3))) float*)stage + i * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, dst, 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane >= r0 && lane < r0 + MX_ROWS) {
+                const int rr = lane - r0;
+                const float* erow = stage + rr * D;
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < LPR; ++k) {
+                    const float4 e = *reinterpret_cast<const float4*>(erow + 4 * (k ^ (rr & 15)));
+                    acc = fmaf(qrow[4 * k + 0], e.x, acc);
+                    acc = fmaf(qrow[4 * k + 1], e.y, acc);
+                    acc = fmaf(qrow[4 * k + 2], e.z, acc);
+                    acc = fmaf(qrow[4 * k + 3], e.w, acc);
+                }
+                sx = acc + 0.0f;   // (-0 -> +0, like the list keys of the exact kernel)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by the next pass
+        }
+        const int64_t item = c0 + lane;
+        bool valid = item < N && sx >= -INFINITY;      // (a NaN score never enters a list: v_cmp_ge in the exact kernel)
+        // the user's seen items inside [c0, c0 + 64): a cursor into the ascending list, 64 entries at a time
+        for (;;) {
+            if (sp >= se) break;
+            if (wbase != sp) { w = sp + lane < se ? seen_idx[sp + lane] : (int64_t)0x7FFFFFFFFFFFFFFFll; wbase = sp; }
+            unsigned long long inr = __ballot(w < c0 + 64);
+            const int cnt = __popcll(inr);
+            while (inr) {
+                const int b = __ffsll((long long)inr) - 1;
+                inr &= inr - 1;
+                const int64_t sid = ((int64_t)__shfl((int)(w >> 32), b, 64) << 32) | (unsigned)__shfl((int)w, b, 64);
+                if (sid == item) valid = false;
+            }
+            sp += cnt;
+            if (cnt < 64) break;
+        }
+        float v = valid ? sx : -INFINITY;
+        int i = valid ? (int)item : PAD;
+        const float kv = __shfl(bv, K - 1, 64);
+        const int ki = __shfl(bi, K - 1, 64);
+        if (__ballot(valid && (ki == PAD || sc_before(v, i, kv, ki))) == 0ull) continue;
+        bitonic_sort64(v, i, lane);
+        const float rv = __shfl(v, 63 - lane, 64);
+        const int ri = __shfl(i, 63 - lane, 64);
+        if (sc_before(rv, ri, bv, bi)) { bv = rv; bi = ri; }
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1) bitonic_step(bv, bi, j, (lane & j) == 0, lane);
+    }
+    topk_emit(bv, bi, lane, user, N, K, seen_ptr, seen_idx, vals, idx);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void score_rescan_k(const int* __restrict__ nfl, const int* __restrict__ fl_list, int64_t B, int64_t N, int K,
+                                                      const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
+                                                      const float* __restrict__ Q, const float* __restrict__ E,
+                                                      float* __restrict__ vals, int64_t* __restrict__ idx) {
+    __shared__ __align__(16) float mx_stage[4 * MX_ROWS * D];
+    int n = *nfl;
+    if (n <= 0) return;
+    if (n > B) n = (int)B;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* stage = mx_stage + wv * (MX_ROWS * D);
+    for (int f = blockIdx.x * 4 + wv; f < n; f += gridDim.x * 4)
+        sx_rescan_user<D>(__builtin_amdgcn_readfirstlane(fl_list[f]), N, K, seen_ptr, seen_idx, Q, E, vals, idx, stage, lane);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restrict__ part_vals, const int* __restrict__ part_idx,
                                                           const float* __restrict__ part_T,
@@ -1458,7 +1560,7 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
                                                           const float* __restrict__ qnorm, const unsigned* __restrict__ emax, float cerr,
                                                           float* __restrict__ vals, int64_t* __restrict__ idx,
                                                           int* __restrict__ userflag, int* __restrict__ blockflag,
-                                                          int dbg_maxerr, int segs, int n_emax, int* __restrict__ fl_list) {
+                                                          int dbg_maxerr, int segs, int n_emax, int* __restrict__ fl_list, int rescan_here) {
     constexpr int LPR = D / 4;
     __shared__ __align__(16) float mx_stage[4 * MX_ROWS * D];
     const int mxd = dbg_maxerr >> 4;
@@ -1595,108 +1697,15 @@ __global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restric
                 g_sx_info[4] = (float)total; g_sx_info[5] = (float)nseg; g_sx_info[6] = validk ? 1.f : 0.f; g_sx_info[7] = (float)K;
             }
         }
+        // (the fallback right here, by the wave that found it necessary: the separate launch of waves per flagged user did nothing else, and
+        //  nobody flagged -- the normal case -- was a launch of ~3 us at the end of every call)
+        if (rescan_here) sx_rescan_user<D>(user, N, K, seen_ptr, seen_idx, Q, E, vals, idx, stage, lane);
         return;
     }
     topk_emit(sx, bi, lane, user, N, K, seen_ptr, seen_idx, vals, idx);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The split path's fallback for catalogs of up to SX_RESCAN_MAX_N items: ONE wave per FLAGGED user (the list score_topk_merge_x wrote)
-// scans the whole catalog with the exact fmaf chain -- 64 items at a time, rows staged through the wave's LDS slice by LDS-DMA as in the
-// merge's re-scoring, seen items dropped by a cursor into the user's sorted list, each chunk that holds anything better than the current
-// K-th merged into the wave's best-64 list by the merge's bitonic networks -- and writes the user's result.  Nobody flagged (the normal case):
-// every wave reads one word and leaves; that replaces the TWO launches (exact kernel over flagged blocks + its merge) whose dispatch was
-// 9 of the call's 387 us.  A flagged user costs ~N / 64 chunk rounds of ~2 000 cycles on one wave (Beauty: ~0.15 ms; every user of a
-// 22 363-user call flagged -- all-zero queries: ~2 ms instead of the exact kernels' 0.6): correctness, as before, never depends on it.
-#define SX_RESCAN_MAX_N (1 << 17)
-template <int D>
-__global__ __launch_bounds__(256) void score_rescan_k(const int* __restrict__ nfl, const int* __restrict__ fl_list, int64_t B, int64_t N, int K,
-                                                      const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
-                                                      const float* __restrict__ Q, const float* __restrict__ E,
-                                                      float* __restrict__ vals, int64_t* __restrict__ idx) {
-    constexpr int LPR = D / 4;
-    __shared__ __align__(16) float mx_stage[4 * MX_ROWS * D];
-    int n = *nfl;
-    if (n <= 0) return;
-    if (n > B) n = (int)B;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int PAD = 0x7FFFFFFF;
-    float* stage = mx_stage + wv * (MX_ROWS * D);
-    constexpr int CPR = LPR, RPI = 64 / CPR, IPP = MX_ROWS / RPI;
-    for (int f = blockIdx.x * 4 + wv; f < n; f += gridDim.x * 4) {
-        const int64_t user = __builtin_amdgcn_readfirstlane(fl_list[f]);
-        const float* qrow = Q + user * D;
-        int64_t sp = seen_ptr ? seen_ptr[user] : 0;
-        const int64_t se = seen_ptr ? seen_ptr[user + 1] : 0;
-        int64_t wbase = -1, w = 0;
-        float bv = -INFINITY;
-        int bi = PAD;
-        for (int64_t c0 = 0; c0 < N; c0 += 64) {
-            float sx = -INFINITY;
-#pragma unroll 1
-            for (int r0 = 0; r0 < 64; r0 += MX_ROWS) {
-                if (c0 + r0 >= N) break;
-#pragma unroll
-                for (int i = 0; i < IPP; ++i) {
-                    const int r = i * RPI + lane / CPR;
-                    int64_t id = c0 + r0 + r;
-                    if (id >= N) id = N - 1;
-                    const int g = (lane % CPR) ^ (r & 15);
-                    const float* src = E + id * D + 4 * g;
-                    __attribute__((address_space(3))) unsigned char* dst =
-                        (__attribute__((address_space(3))) unsigned char*)(__attribute__((address_space(3))) float*)stage + i * 1024;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, dst, 16, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane >= r0 && lane < r0 + MX_ROWS) {
-                    const int rr = lane - r0;
-                    const float* erow = stage + rr * D;
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < LPR; ++k) {
-                        const float4 e = *reinterpret_cast<const float4*>(erow + 4 * (k ^ (rr & 15)));
-                        acc = fmaf(qrow[4 * k + 0], e.x, acc);
-                        acc = fmaf(qrow[4 * k + 1], e.y, acc);
-                        acc = fmaf(qrow[4 * k + 2], e.z, acc);
-                        acc = fmaf(qrow[4 * k + 3], e.w, acc);
-                    }
-                    sx = acc + 0.0f;   // (-0 -> +0, like the list keys of the exact kernel)
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by the next pass
-            }
-            const int64_t item = c0 + lane;
-            bool valid = item < N && sx >= -INFINITY;      // (a NaN score never enters a list: v_cmp_ge in the exact kernel)
-            // the user's seen items inside [c0, c0 + 64): a cursor into the ascending list, 64 entries at a time
-            for (;;) {
-                if (sp >= se) break;
-                if (wbase != sp) { w = sp + lane < se ? seen_idx[sp + lane] : (int64_t)0x7FFFFFFFFFFFFFFFll; wbase = sp; }
-                unsigned long long inr = __ballot(w < c0 + 64);
-                const int cnt = __popcll(inr);
-                while (inr) {
-                    const int b = __ffsll((long long)inr) - 1;
-                    inr &= inr - 1;
-                    const int64_t sid = ((int64_t)__shfl((int)(w >> 32), b, 64) << 32) | (unsigned)__shfl((int)w, b, 64);
-                    if (sid == item) valid = false;
-                }
-                sp += cnt;
-                if (cnt < 64) break;
-            }
-            float v = valid ? sx : -INFINITY;
-            int i = valid ? (int)item : PAD;
-            const float kv = __shfl(bv, K - 1, 64);
-            const int ki = __shfl(bi, K - 1, 64);
-            if (__ballot(valid && (ki == PAD || sc_before(v, i, kv, ki))) == 0ull) continue;
-            bitonic_sort64(v, i, lane);
-            const float rv = __shfl(v, 63 - lane, 64);
-            const int ri = __shfl(i, 63 - lane, 64);
-            if (sc_before(rv, ri, bv, bi)) { bv = rv; bi = ri; }
-#pragma unroll
-            for (int j = 32; j > 0; j >>= 1) bitonic_step(bv, bi, j, (lane & j) == 0, lane);
-        }
-        topk_emit(bv, bi, lane, user, N, K, seen_ptr, seen_idx, vals, idx);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Tuning / diagnostic switches.  In the product library (librecengine.so) they are compile-time constants and no re_dbg_* symbol
 // exists: the C ABI has no global mutable state (include/recengine.h).  `make dbg` (-DRE_DEBUG) builds librecengine_dbg.so, in
@@ -1804,7 +1813,7 @@ RE_SWITCH int g_score_front = 1;    // split form: query split + item split + st
 #ifdef RE_DEBUG
 extern "C" void re_dbg_score_front(int on) { g_score_front = on; }
 #endif
-RE_SWITCH int g_score_rescan = 1;    // the split path's fallback as score_rescan_k (0: the exact kernel over flagged blocks + its merge)
+RE_SWITCH int g_score_rescan = 2;    // the split path's fallback: 2 inside the merge (sx_rescan_user), 1 as score_rescan_k behind it, 0 the exact kernel over flagged blocks + its merge
 #ifdef RE_DEBUG
 extern "C" void re_dbg_score_rescan(int on) { g_score_rescan = on; }
 #endif
@@ -2127,11 +2136,12 @@ static int score_topk_impl(const float* Q, const float* E, int64_t B, int64_t N,
             if ((rc = re_launch_status()) != RE_OK) return rc;
             if (D == 64)
                 hipLaunchKernelGGL(score_topk_merge_x<64>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax, fl_list);
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax, fl_list, rescan && g_score_rescan == 2 ? 1 : 0);
             else
                 hipLaunchKernelGGL(score_topk_merge_x<128>, dim3((unsigned)re_cdiv(B, 4)), dim3(256), 0, s, pv, pi, pt, p.maxseg, B, N, (int)K, C,
-                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax, fl_list);
+                                   p.nst, p.upw, seen_ptr, seen_idx, Q, E, qnorm, emax, score_cerr(D), vals, idx, uflag, bflag, g_score_maxerr | (g_score_mxdiag << 4), p.segs, n_emax, fl_list, rescan && g_score_rescan == 2 ? 1 : 0);
             if ((rc = re_launch_status()) != RE_OK) return rc;
+            if (rescan && g_score_rescan == 2) return RE_OK;   // (flagged users were re-scored inside the merge)
             if (rescan) {
                 const int* nfl = bflag + p.nub + 1;
                 const unsigned rg = (unsigned)(re_cdiv(B, 4) < 256 ? re_cdiv(B, 4) : 256);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "re_sasrec_encoder_fwd": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _i32,
                                      _vp, _vp, _sz, _i32, _vp]),
     "re_sasrec_encoder_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "re_sasrec_encoder_bwd_workspace_layout": (_i32, [_i64, _i64, _i64, _i64, ctypes.c_uint64, _vp]),
     "re_sasrec_encoder_bwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _i32, _f32, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_sasrec_plan_rows": (_i64, [_i64, _i64]),
