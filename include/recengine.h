@@ -520,8 +520,20 @@ int re_rows_sqnorm(const float* W, int64_t R, int64_t D, const int64_t* idx, int
  * re_bce_logits: loss[0] = mean BCE-with-logits (DeepFM/main.py:214), dlogit[i] = (sigmoid(x_i) - y_i) / n,
  * dsum[0] (optional) = sum_i dlogit[i] (gradient of the LR bias).  labels are fp32 0/1. */
 int re_fm_bag_fwd(const float* T, const float* TL, const float* lr_bias, const int64_t* offsets, int64_t rows_total,
-                  const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, int64_t* rows_out, re_stream_t stream);
-/* (rows_out [B * F], optional: offsets[f] + x[b, f] -- the destination rows of the backward's scatter-add, re_scatter_plan's `idx`) */
+                  const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, int64_t* rows_out, int32_t* keys_t,
+                  re_stream_t stream);
+/* (rows_out [B * F], optional: offsets[f] + x[b, f] -- the destination rows of the backward's scatter-add, re_scatter_plan's `idx`;
+ *  keys_t [F * B] int32, optional: x[b, f] field-major -- re_fm_table_grad's keys) */
+/* re_fm_table_grad: the two tables' gradients from re_fm_bag_bwd's contribution rows in ONE launch.  keys_t[f * B + b] = x[b, f] (field-major
+ * int32: re_fm_bag_fwd's keys_t); contribution (b, f) goes to row offsets[f] + x[b, f].  The work is cut by destination rows: `slices` (device, int32 [n_slices][4]: field, first row, end row -- both
+ * relative to offsets[field] -- and a spare word) must cover every row that can occur, each exactly once; a workgroup per slice collects the
+ * field's keys that fall into it and sums them per row:
+ *   gT[r, :] = sum over (b, f) with offsets[f] + x[b, f] = r of gE[b, f, :],   gTL[r] = the same of gL[b, f]      (a fixed order: reproducible)
+ * Any slicing gives a correct result; ~40 expected keys a slice (64 or fewer are one wave's work in registers) is the fast one.  Rows nobody
+ * refers to are NOT written: zero-fill gT [rows_total, D] and gTL [rows_total] first.  Keys outside every slice are dropped.
+ * B <= 8192, F <= 64, D <= 15, rows of a field < 2^19 - 1, else RE_EUNSUPPORTED (use re_scatter_add_rows). */
+int re_fm_table_grad(const int32_t* keys_t, int64_t B, int64_t F, const int64_t* offsets, int64_t rows_total, const int32_t* slices,
+                     int64_t n_slices, const float* gE, const float* gL, int64_t D, float* gT, float* gTL, re_stream_t stream);
 int re_fm_bag_bwd(const float* E, const float* dE_mlp, const float* dlogit, int64_t B, int64_t F, int64_t D, float* gE,
                   float* gL, re_stream_t stream);
 int re_bce_logits(const float* logits, const float* labels, int64_t n, float* loss, float* dlogit, float* dsum,
@@ -552,6 +564,11 @@ int re_auc(const float* scores, const float* labels, int64_t n, float* auc, void
  * state[0] = seed, state[1] = 0, state[2..3] = bits of { lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step) } -- the layout
  * re_sasrec_batch_prep writes; state doubles as `seed_dev` of the dropout entry points and, from word 2, as `hyper` of re_adam_step_dev. */
 int re_step_state(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, re_stream_t stream);
+/* re_step_stage_inputs: re_step_state (state may be NULL: no scalars) and up to 8 transfers into a captured step's static buffers in ONE launch:
+ * segment i writes bytes[i] bytes at dst[i] -- kind 0: copied from src[i]; kind 1: four-byte floats converted from the int64 words at src[i]
+ * (labels); kind 2: zeros (src[i] ignored).  Segments must not overlap. */
+int re_step_stage_inputs(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, int32_t n, void* const* dst,
+                         const void* const* src, const int64_t* bytes, const int32_t* kind, re_stream_t stream);
 int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1,
                      double beta2, double eps, double weight_decay, re_stream_t stream);
 /* clip_grad_norm_ + Adam (DeepFM/main.py:264-268).  re_grad_clip_coef: coef_norm[0] = min(1, max_norm / (||g||_2 + 1e-6)) (torch's
@@ -562,6 +579,14 @@ size_t re_grad_clip_workspace_bytes(void);
 int re_grad_clip_coef(const float* g, int64_t n, float max_norm, float* coef_norm, void* ws, size_t ws_bytes, re_stream_t stream);
 int re_adam_step_scaled(float* p, float* g, float* m, float* v, int64_t n, int64_t step, double lr, const float* hyper, double beta1,
                         double beta2, double eps, double weight_decay, const float* gscale, re_stream_t stream);
+/* re_adam_step_clip2: clip_grad_norm_(.., max_norm) and Adam over an arena of two weight-decay groups -- [0, n_first) with wd_first, the rest with
+ * wd_rest (DeepFM/main.py:187-199, 267-268) -- in two launches (square-norm partials; then every workgroup forms the coefficient
+ * min(1, max_norm / (||g|| + 1e-6)) from them, scales g on the way through -- written back -- and updates).  coef_norm (optional) receives
+ * [coefficient, ||g||].  n, n_first multiples of 4, 16-byte aligned pointers; step >= 1: host-side bias corrections, step == 0: hyper (device
+ * float[2]).  ws: re_grad_clip_workspace_bytes(). */
+int re_adam_step_clip2(float* p, float* g, float* m, float* v, int64_t n, int64_t n_first, int64_t step, double lr, const float* hyper,
+                       double beta1, double beta2, double eps, double wd_first, double wd_rest, float max_norm, float* coef_norm, void* ws,
+                       size_t ws_bytes, re_stream_t stream);
 /* The owner's half of a data-parallel step (N > 1 replicas of one flat parameter arena; the reference trains one replica:
  * freerec/launcher.py's Coach, SASRec/main.py:264-275): this rank owns p[0 .. n) (a slice of the arena); parts + r * part_stride (r < nparts)
  * is rank r's gradient for the slice (what an all-to-all of the ranks' gradient arenas delivers).  g = gscale (((part 0 + part 1) + ...)

@@ -46,11 +46,12 @@ def recording(graph, **kw):
 
 
 class CapturedStep:
-    def __init__(self, body, example_inputs, restore):
+    def __init__(self, body, example_inputs, restore, zeros=()):
         """body(*static_inputs, state) -> loss tensor: the step's launches, reading `state` (int32[4]: seed, 0, Adam scalars) where the
         eager step takes host scalars.  restore: tensors the warm-up run must leave as it found them (parameters, moments, running
         statistics)."""
         dev = example_inputs[0].device
+        self.zeros = list(zeros)           # cleared in front of every replay (by the same launch that brings the batch in)
         self.static = [torch.empty_like(x) for x in example_inputs]
         for s, x in zip(self.static, example_inputs):
             s.copy_(x)
@@ -70,18 +71,19 @@ class CapturedStep:
             t.copy_(k)
 
     def __call__(self, inputs, seed, step, lr, beta1, beta2):
-        for s, x in zip(self.static, inputs):
-            s.copy_(x, non_blocking=True)
-        ops.step_state(self.state, seed, step, lr, beta1, beta2)
+        # the batch into the static buffers (int64 labels straight into an fp32 buffer), the step's scalars, the zero fills: ONE launch
+        ops.stage_inputs(self.state, seed, step, lr, beta1, beta2, pairs=list(zip(self.static, inputs)), zeros=self.zeros)
         self.graph.replay()
         return self.out
 
 
-def captured(engine, key, body, inputs, restore):
-    """The engine's captured step for this input signature (captured on first use)."""
+def captured(engine, key, body, inputs, restore, zeros=(), static_dtypes=None):
+    """The engine's captured step for this input signature (captured on first use).  static_dtypes: the dtypes of the graph's static buffers where
+    they differ from the inputs' (fp32 for int64 labels: the staging launch converts on the way in); zeros: tensors that launch clears."""
     if not hasattr(engine, "_captured"):
         engine._captured = {}
     k = (key,) + tuple((tuple(x.shape), x.dtype) for x in inputs)
     if k not in engine._captured:
-        engine._captured[k] = CapturedStep(body, inputs, restore)
+        ex = inputs if static_dtypes is None else tuple(x.to(d) for x, d in zip(inputs, static_dtypes))
+        engine._captured[k] = CapturedStep(body, ex, restore, zeros)
     return engine._captured[k]

@@ -55,6 +55,71 @@ extern "C" int re_step_state(uint32_t* state, uint32_t seed, int64_t step, doubl
     return re_launch_status();
 }
 
+// ---- what stands in FRONT of a captured step, as ONE launch: the step's scalars (re_step_state) and the batch brought into the graph's static
+// buffers -- byte copies, int64 -> fp32 casts (labels), zero fills (a gradient table the step's kernels only write where the batch points).
+// As separate launches -- two or three copy_() calls, a cast, re_step_state, a fill -- they were 4 - 6 dispatches of ~5 us in front of every
+// replay: 20 of DeepFM's 320 us, 15 of MF-BPR's 45.
+#define ST_MAX 8
+#define ST_CHUNK 4096            // bytes of destination a workgroup handles (256 threads x 16 B)
+struct StageSegs {
+    void* dst[ST_MAX];
+    const void* src[ST_MAX];
+    unsigned long long bytes[ST_MAX];      // of the DESTINATION
+    int kind[ST_MAX];                      // 0 copy, 1 int64 -> fp32, 2 zero
+    unsigned first[ST_MAX + 1];            // first workgroup of every segment
+    int n;
+};
+__global__ __launch_bounds__(256) void step_stage_inputs_k(uint32_t* __restrict__ state, uint32_t seed, float step_size, float inv_sqrt_bc2,
+                                                           StageSegs S) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && state) {
+        state[0] = seed; state[1] = 0u; state[2] = __float_as_uint(step_size); state[3] = __float_as_uint(inv_sqrt_bc2);
+    }
+    int sg = 0;
+#pragma unroll
+    for (int i = 1; i < ST_MAX; ++i) sg += (i < S.n && blockIdx.x >= S.first[i]) ? 1 : 0;
+    if (sg >= S.n) return;
+    const unsigned long long off = (unsigned long long)(blockIdx.x - S.first[sg]) * ST_CHUNK + threadIdx.x * 16ull;
+    const unsigned long long nb = S.bytes[sg];
+    if (off >= nb) return;
+    char* d = (char*)S.dst[sg] + off;
+    const int kind = S.kind[sg];
+    const bool whole = off + 16 <= nb && (((uintptr_t)S.dst[sg]) & 15u) == 0;
+    if (kind == 2) {
+        if (whole) *reinterpret_cast<uint4*>(d) = make_uint4(0u, 0u, 0u, 0u);
+        else for (unsigned long long i = off; i < nb && i < off + 16; ++i) ((char*)S.dst[sg])[i] = 0;
+    } else if (kind == 1) {                // four fp32 of destination = four int64 of source
+        const int64_t* s = (const int64_t*)S.src[sg] + off / 4;
+        float* o = (float*)d;
+        for (int i = 0; i < 4 && off + 4 * i < nb; ++i) o[i] = (float)s[i];
+    } else {
+        const char* s = (const char*)S.src[sg] + off;
+        if (whole && (((uintptr_t)S.src[sg]) & 15u) == 0) *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+        else for (unsigned long long i = 0; i < 16 && off + i < nb; ++i) d[i] = s[i];
+    }
+}
+
+extern "C" int re_step_stage_inputs(uint32_t* state, uint32_t seed, int64_t step, double lr, double beta1, double beta2, int32_t n,
+                                    void* const* dst, const void* const* src, const int64_t* bytes, const int32_t* kind, re_stream_t stream) {
+    re_clear_error();
+    if ((state && step < 1) || n < 0 || n > ST_MAX || (n > 0 && (!dst || !src || !bytes || !kind))) return RE_EINVAL;
+    StageSegs S{};
+    S.n = n;
+    unsigned total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!dst[i] || bytes[i] < 0 || kind[i] < 0 || kind[i] > 2 || (kind[i] != 2 && !src[i]) || (kind[i] == 1 && (bytes[i] & 3))) return RE_EINVAL;
+        if (bytes[i] > (1ll << 40)) return RE_EUNSUPPORTED;
+        S.dst[i] = dst[i]; S.src[i] = src[i]; S.bytes[i] = (unsigned long long)bytes[i]; S.kind[i] = kind[i];
+        S.first[i] = total;
+        total += (unsigned)re_cdiv(bytes[i], ST_CHUNK);
+    }
+    S.first[n] = total;
+    if (total == 0) total = 1;
+    const double st = step < 1 ? 1.0 : (double)step;
+    hipLaunchKernelGGL(step_stage_inputs_k, dim3(total), dim3(256), 0, (hipStream_t)stream, state, seed, (float)(lr / (1.0 - pow(beta1, st))),
+                       (float)(1.0 / sqrt(1.0 - pow(beta2, st))), S);
+    return re_launch_status();
+}
+
 extern "C" int re_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1, double beta2,
                                 double eps, double weight_decay, re_stream_t stream) {
     re_clear_error();
@@ -157,6 +222,66 @@ __global__ __launch_bounds__(256) void adam_vec4_scaled(float4* __restrict__ p, 
 #undef RE_ADAM1
         p[i] = P; m[i] = M; v[i] = V;
     }
+}
+
+// clip_grad_norm_(.., max_norm) + Adam over an arena of TWO weight-decay groups ([0, n_first) and the rest) as one launch behind the
+// square-norm partials: every workgroup adds the partials itself (the same fixed order everywhere: the same coefficient), scales the gradient
+// on its way through (written back: p.grad after the reference's step) and updates; workgroup 0 leaves [coefficient, norm] in coef_norm.
+// (As re_grad_clip_coef + two re_adam_step_scaled this was four dispatches.)
+__global__ __launch_bounds__(256) void adam_vec4_clip2(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v,
+                                                       int64_t n4, int64_t n4_first, float b1, float b2, float omb1, float omb2, float step_size,
+                                                       float inv_sqrt_bc2, const float* __restrict__ hyper, float eps, float wd_first, float wd_rest,
+                                                       const float* __restrict__ partial, int nb, float max_norm, float* __restrict__ coef_norm) {
+    __shared__ float sw[4];
+    if (hyper) { step_size = hyper[0]; inv_sqrt_bc2 = hyper[1]; }
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
+    a = re_wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = a;
+    __syncthreads();
+    const float norm = sqrtf(((sw[0] + sw[1]) + sw[2]) + sw[3]);
+    float c = max_norm / (norm + 1e-6f);
+    c = c < 1.0f ? c : 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && coef_norm) { coef_norm[0] = c; coef_norm[1] = norm; }
+    if (inv_sqrt_bc2 == 0.f) return;   // (a gated step: see adam_vec4_dev)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = p[i], G = g[i], M = m[i], V = v[i];
+        G.x *= c; G.y *= c; G.z *= c; G.w *= c;
+        g[i] = G;
+        const float wd = i < n4_first ? wd_first : wd_rest;
+#define RE_ADAM1(c_) re_adam1(P.c_, M.c_, V.c_, G.c_, b1, b2, omb1, omb2, step_size, inv_sqrt_bc2, eps, wd);
+        RE_ADAM1(x) RE_ADAM1(y) RE_ADAM1(z) RE_ADAM1(w)
+#undef RE_ADAM1
+        p[i] = P; m[i] = M; v[i] = V;
+    }
+}
+
+// n and n_first multiples of 4; step >= 1: the host's bias corrections, step == 0: `hyper` (device words).  ws: re_grad_clip_workspace_bytes().
+extern "C" int re_adam_step_clip2(float* p, float* g, float* m, float* v, int64_t n, int64_t n_first, int64_t step, double lr, const float* hyper,
+                                  double beta1, double beta2, double eps, double wd_first, double wd_rest, float max_norm, float* coef_norm,
+                                  void* ws, size_t ws_bytes, re_stream_t stream) {
+    re_clear_error();
+    if (n == 0) return RE_OK;
+    if (!p || !g || !m || !v || n < 0 || n_first < 0 || n_first > n || (step < 1 && !hyper) || !(max_norm > 0.f)) return RE_EINVAL;
+    if (!ws || ws_bytes < re_grad_clip_workspace_bytes()) return RE_EWORKSPACE;
+    if ((n & 3) || (n_first & 3) || ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                                      reinterpret_cast<uintptr_t>(v)) & 15u) != 0)
+        return RE_EUNSUPPORTED;
+    float step_size = 0.f, inv_sqrt_bc2 = 1.f;
+    if (step >= 1) {
+        step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
+        hyper = nullptr;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n4 = n >> 2;
+    int nb = (int)re_cdiv(n4, 1024);
+    if (nb > SQN_BLOCKS) nb = SQN_BLOCKS;
+    hipLaunchKernelGGL(sqnorm_partial_k, dim3(nb), dim3(256), 0, s, (const float4*)g, n4, (const float*)g, 0, (float*)ws);
+    hipLaunchKernelGGL(adam_vec4_clip2, dim3(re_grid(n4, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v, n4, n_first >> 2,
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), step_size, inv_sqrt_bc2, hyper, (float)eps, (float)wd_first,
+                       (float)wd_rest, (const float*)ws, nb, max_norm, coef_norm);
+    return re_launch_status();
 }
 
 // step >= 1: the host's bias corrections (re_adam_step's); step == 0: `hyper` (device words, re_adam_step_dev's).  n a multiple of 4.

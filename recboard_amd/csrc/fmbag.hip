@@ -23,7 +23,8 @@ template <int FP>
 __global__ __launch_bounds__(256) void fm_bag_fwd_k(const float* __restrict__ T, const float* __restrict__ TL,
                                                     const float* __restrict__ lr_bias, const int64_t* __restrict__ offsets,
                                                     int64_t rows_total, const int64_t* __restrict__ x, int64_t B, int F, int D,
-                                                    float* __restrict__ E, float* __restrict__ fm_lr, int64_t* __restrict__ rows_out) {
+                                                    float* __restrict__ E, float* __restrict__ fm_lr, int64_t* __restrict__ rows_out,
+                                                    int32_t* __restrict__ keys_t) {
     const int f = threadIdx.x % FP;
     const int64_t b = (int64_t)blockIdx.x * (256 / FP) + threadIdx.x / FP;
     float e[FB_MAXD];
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void fm_bag_fwd_k(const float* __restrict__ T,
     if (act) {
         const int64_t r = x[b * F + f] + offsets[f];
         if (rows_out) rows_out[b * F + f] = r;
+        if (keys_t) keys_t[(int64_t)f * B + b] = (int32_t)x[b * F + f];     // field-major, relative to the field: re_fm_table_grad's keys
         if (r >= 0 && r < rows_total) {
             for (int d = 0; d < D; ++d) e[d] = T[r * D + d];
             lr = TL[r];
@@ -83,13 +85,14 @@ __global__ __launch_bounds__(256) void fm_bag_bwd_k(const float* __restrict__ E,
 }
 
 extern "C" int re_fm_bag_fwd(const float* T, const float* TL, const float* lr_bias, const int64_t* offsets, int64_t rows_total,
-                             const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, int64_t* rows_out, re_stream_t stream) {
+                             const int64_t* x, int64_t B, int64_t F, int64_t D, float* E, float* fm_lr, int64_t* rows_out, int32_t* keys_t,
+                             re_stream_t stream) {
     re_clear_error();
     if (B == 0) return RE_OK;
     if (!T || !TL || !lr_bias || !offsets || !x || !E || !fm_lr || B < 0 || rows_total <= 0) return RE_EINVAL;
     if (F < 1 || F > 64 || D < 1 || D > FB_MAXD) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-#define FB_FWD(FPV) hipLaunchKernelGGL(fm_bag_fwd_k<FPV>, dim3((unsigned)re_cdiv(B, 256 / FPV)), dim3(256), 0, s, T, TL, lr_bias, offsets, rows_total, x, B, (int)F, (int)D, E, fm_lr, rows_out)
+#define FB_FWD(FPV) hipLaunchKernelGGL(fm_bag_fwd_k<FPV>, dim3((unsigned)re_cdiv(B, 256 / FPV)), dim3(256), 0, s, T, TL, lr_bias, offsets, rows_total, x, B, (int)F, (int)D, E, fm_lr, rows_out, keys_t)
     if (F <= 8) FB_FWD(8); else if (F <= 16) FB_FWD(16); else if (F <= 32) FB_FWD(32); else FB_FWD(64);
 #undef FB_FWD
     return re_launch_status();
@@ -105,6 +108,263 @@ extern "C" int re_fm_bag_bwd(const float* E, const float* dE_mlp, const float* d
 #define FB_BWD(FPV) hipLaunchKernelGGL(fm_bag_bwd_k<FPV>, dim3((unsigned)re_cdiv(B, 256 / FPV)), dim3(256), 0, s, E, dE_mlp, dlogit, B, (int)F, (int)D, gE, gL)
     if (F <= 8) FB_BWD(8); else if (F <= 16) FB_BWD(16); else if (F <= 32) FB_BWD(32); else FB_BWD(64);
 #undef FB_BWD
+    return re_launch_status();
+}
+
+// ---- gradients of the two concatenated tables (T [rows, D], TL [rows]) from the contribution rows of re_fm_bag_bwd, ONE launch.
+// A field's B keys fall into the field's own row range, so the work is cut by ROWS: a workgroup owns a slice [row_lo, row_hi) of one field
+// (slices sized by the caller for ~40 keys each when keys are uniform: ops.fm_table_slices), scans the field's B keys for the ones that fall
+// into it -- waves over contiguous stretches of the batch, ballots, no barrier: the list comes out in batch order -- and sums them per row:
+//   * up to 64 matches (the normal case): ONE wave sorts the (row, b) words in registers (a bitonic network of shuffles) and adds runs of equal
+//     rows with a segmented scan, column by column;
+//   * more (a field of a handful of values: B / count matches on a single row; or skewed keys): the list is sorted in LDS if the slice has
+//     more than one row, cut into FT_GROUPS stretches walked by groups of 16 lanes (lane c < D: column c of gE, lane D: gL; sixteen loads in flight),
+//     runs inside a stretch written directly, the stretches' first and last runs joined in order (16 + FT_GROUPS / 16 steps).
+// Every sum's order is a fixed function of the keys: bitwise reproducible.  Rows nobody refers to are NOT written (the caller zero-fills).
+// The general sorted scatter-add (scatter.hip: re_scatter_plan + two re_scatter_apply) is twelve launches of 5 - 11 us for these 40 960 keys:
+// 80 of the DeepFM step's 375 us (profiles/r5_config4_kstats.txt).
+#define FT_NT 512
+#define FT_NW (FT_NT / 64)
+#define FT_MAXB 8192
+#define FT_BBITS 13
+#define FT_GROUPS (FT_NT / 16)
+#define FT_NONE 0xFFFFFFFFu
+#define FT_INF 16          // contribution rows a lane group keeps in flight
+__global__ __launch_bounds__(FT_NT) void fm_table_grad_k(const int32_t* __restrict__ keys_t, int B, int F, const int64_t* __restrict__ offsets,
+                                                         int64_t rows_total, const int32_t* __restrict__ slices, const float* __restrict__ gE,
+                                                         const float* __restrict__ gL, int D, float* __restrict__ gT, float* __restrict__ gTL, int P2) {
+    extern __shared__ unsigned ft_lds[];
+    const int Bp = (B + FT_NW * 64 - 1) / (FT_NW * 64) * (FT_NW * 64);    // a wave's stretch of the batch: Bp / 16 keys, a multiple of 64
+    unsigned* const k = ft_lds;                                            // [Bp]: the waves' lists | [P2 = 2^n >= Bp]: closed up, padded, sorted
+    float* const firstv = reinterpret_cast<float*>(k + Bp + P2);           // [FT_GROUPS][16]
+    float* const lastv = firstv + FT_GROUPS * 16;                          // [64][16]
+    unsigned* const frow = reinterpret_cast<unsigned*>(lastv + FT_GROUPS * 16);   // [64]  first run's row (FT_NONE: empty stretch)
+    unsigned* const lrow = frow + FT_GROUPS;                               // [64]  last run's row (FT_NONE: the stretch is one run)
+    int* const wcnt = reinterpret_cast<int*>(lrow + FT_GROUPS);            // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = slices[4 * blockIdx.x], row_lo = slices[4 * blockIdx.x + 1], row_hi = slices[4 * blockIdx.x + 2];
+    const int64_t base = offsets[f];
+    auto put = [&](unsigned r, int c, float v) {      // row r of this field is complete
+        if (c < D) gT[(base + r) * D + c] = v;
+        else if (c == D) gTL[base + r] = v;
+    };
+    auto val = [&](unsigned key, int c) {             // column c of the contribution row a list word names (c > D: lane D's word again, unused)
+        // (ONE unconditional load through a selected pointer: behind a branch on c hipcc waits for every load on the spot -- s_waitcnt
+        //  vmcnt(0) at the join -- and the sixteen loads of a pass became sixteen memory round trips)
+        const int64_t cb = (int64_t)(key & (FT_MAXB - 1)) * F + f;
+        const float* p = c < D ? gE + cb * D + c : gL + cb;
+        return *p;
+    };
+    // ---- 1. the slice's keys, in batch order
+    const int per_w = Bp / FT_NW;
+    int n = 0;                                        // (wave-uniform)
+    {
+        int32_t kr[4];
+        const int32_t* __restrict__ kf = keys_t + (int64_t)f * B;             // (field-major: the field's B keys are 4 B of contiguous words)
+        for (int i0 = 0; i0 < per_w; i0 += 256) {     // (four loads in flight)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = wave * per_w + i0 + 64 * u + lane;
+                kr[u] = kf[b < B ? b : B - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = wave * per_w + i0 + 64 * u + lane;
+                const int64_t r = kr[u];
+                const bool hit = i0 + 64 * u < per_w && b < B && r >= row_lo && r < row_hi && r < 0x7FFFF && base + r < rows_total;
+                const unsigned long long hm = __ballot(hit);
+                if (hm != 0ull) {
+                    if (hit) k[wave * per_w + n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u))] =
+                                 ((unsigned)r << FT_BBITS) | (unsigned)b;
+                    n += __popcll(hm);
+                }
+            }
+        }
+    }
+    if (lane == 0) wcnt[wave] = n;
+    __syncthreads();
+    int M = 0, below = 0;
+#pragma unroll
+    for (int w = 0; w < FT_NW; ++w) {
+        const int x = wcnt[w];
+        M += x;
+        below += w < wave ? x : 0;
+    }
+    if (M == 0) return;
+    for (int i = lane; i < n; i += 64) k[Bp + below + i] = k[wave * per_w + i];     // (closed up into the second half)
+    __syncthreads();
+    unsigned* const kl = k + Bp;
+    const bool one_row = row_hi - row_lo == 1;
+    // ---- 2a. up to 64 matches: one wave, registers
+    if (M <= 64) {
+        if (wave != 0) return;
+        // sorted position of the lane's word = how many of the words are smaller (they are all different: 64 broadcasts and compares, no
+        // dependent memory or LDS latency -- the bitonic network this replaces was 21 dependent cross-lane steps, 3 k cycles of a 5 k cycle job);
+        // then ONE cross-lane move puts the words in order
+        const unsigned mine = lane < M ? kl[lane] : FT_NONE;
+        unsigned key = mine;
+        if (!one_row) {
+            int rank = 0;
+            for (int j = 0; j < M; ++j) rank += ((unsigned)__builtin_amdgcn_readlane((int)mine, j) < mine) ? 1 : 0;
+            // lane `rank` takes this lane's word: the inverse permutation through LDS (the list's first half is free by now)
+            if (lane < M) k[rank] = mine;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            key = lane < M ? k[lane] : FT_NONE;
+        }
+        const unsigned r = key >> FT_BBITS;                                   // (FT_NONE >> 13: the padding's "row", behind every real one)
+        const unsigned rn = (unsigned)__shfl_down((int)r, 1, 64);
+        const bool run_end = lane < M && (lane == 63 || rn != r);
+        // (every column requested first: a column at a time was eleven memory round trips)
+        float v[16];
+        const unsigned ka = lane < M ? key : kl[0];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = val(ka, c);
+        bool same[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const unsigned rt = (unsigned)__shfl_up((int)r, 1 << j, 64);      // (by every lane: a shuffle behind `lane >= ..&&` reads switched-off lanes)
+            same[j] = lane >= (1 << j) && rt == r;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = lane < M ? v[c] : 0.f;
+        // (the columns' scans step by step side by side: sixteen independent cross-lane moves a step instead of a chain of six per column)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float t[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[c] = __shfl_up(v[c], 1 << j, 64);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] += same[j] ? t[c] : 0.f;
+        }
+        if (run_end) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c <= D) put(r, c, v[c]);
+        }
+        return;
+    }
+    // ---- 2b. the general form
+    int Mp = FT_GROUPS * 8;
+    while (Mp < M) Mp <<= 1;
+    for (int i = M + tid; i < Mp; i += FT_NT) kl[i] = FT_NONE;                 // (Mp <= P2)
+    if (!one_row) {
+        for (int size = 2; size <= Mp; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                for (int i = tid; i < (Mp >> 1); i += FT_NT) {
+                    const int lo = 2 * i - (i & (stride - 1));
+                    const unsigned a = kl[lo], b = kl[lo + stride];
+                    if ((a > b) == ((lo & size) == 0)) { kl[lo] = b; kl[lo + stride] = a; }
+                }
+            }
+    }
+    __syncthreads();
+    const int grp = tid >> 4, c = tid & 15;
+    const int per = Mp / FT_GROUPS, e0 = grp * per;
+    {
+        unsigned cur = FT_NONE;
+        int nrun = 0;
+        float acc = 0.f;
+        bool ended = false;                    // (the 16 lanes of a group agree on all of these)
+        for (int eb = 0; eb < per && !ended; eb += FT_INF) {
+            unsigned key[FT_INF];
+            float v[FT_INF];
+#pragma unroll
+            for (int u = 0; u < FT_INF; ++u) {
+                key[u] = eb + u < per ? kl[e0 + eb + u] : FT_NONE;
+                v[u] = val(key[u] == FT_NONE ? kl[0] : key[u], c);            // (a valid address: the loads are unconditional)
+            }
+#pragma unroll
+            for (int u = 0; u < FT_INF; ++u) {
+                if (key[u] == FT_NONE) { ended = true; break; }               // (padding sorts to the end)
+                const unsigned r = key[u] >> FT_BBITS;
+                if (r != cur) {
+                    if (cur != FT_NONE) {
+                        if (nrun == 0) { firstv[grp * 16 + c] = acc; if (c == 0) frow[grp] = cur; }
+                        else put(cur, c, acc);
+                        ++nrun;
+                    }
+                    cur = r;
+                    acc = 0.f;
+                }
+                acc += v[u];
+            }
+        }
+        if (cur == FT_NONE) { if (c == 0) { frow[grp] = FT_NONE; lrow[grp] = FT_NONE; } }
+        else if (nrun == 0) { firstv[grp * 16 + c] = acc; if (c == 0) { frow[grp] = cur; lrow[grp] = FT_NONE; } }
+        else { lastv[grp * 16 + c] = acc; if (c == 0) lrow[grp] = cur; }
+    }
+    __syncthreads();
+    // the stretches' open ends, in order: FT_GROUPS / 16 lane groups join sixteen stretches each, then one joins those
+    auto join = [&](int g0, unsigned& hr, float& hv, bool& hopen, unsigned& cr, float& carry) {
+        // walks stretches [g0, g0 + 16): (hr, hv) = the FIRST run met (hopen: nothing has closed it yet), (cr, carry) = the run still open at the
+        // end.  (The sixteen stretches' words come out of LDS together: fetched one at a time they were four dependent LDS trips a step.)
+        unsigned fr[16], lr[16];
+        float fv[16], lv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { fr[i] = frow[g0 + i]; lr[i] = lrow[g0 + i]; fv[i] = firstv[(g0 + i) * 16 + c]; lv[i] = lastv[(g0 + i) * 16 + c]; }
+        hr = FT_NONE; hv = 0.f; hopen = true; cr = FT_NONE; carry = 0.f;
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (fr[i] == FT_NONE) done = true;
+            if (!done) {
+                if (fr[i] == cr) carry += fv[i];
+                else {
+                    if (cr != FT_NONE) { if (hopen && hr == cr) { hv = carry; hopen = false; } else put(cr, c, carry); }
+                    cr = fr[i]; carry = fv[i];
+                    if (hr == FT_NONE) hr = fr[i];
+                }
+                if (lr[i] != FT_NONE) {
+                    if (hopen && hr == cr) { hv = carry; hopen = false; } else put(cr, c, carry);
+                    cr = lr[i]; carry = lv[i];
+                }
+            }
+        }
+    };
+    constexpr int FT_NQ = FT_GROUPS / 16;
+    if (tid < 16 * FT_NQ) {
+        unsigned hr, cr;
+        float hv, carry;
+        bool hopen;
+        join(grp * 16, hr, hv, hopen, cr, carry);
+        // a quarter's summary in the slots of its first stretch: first run (row, value; still open = the quarter is ONE run) and last run
+        // (the four quarters are lanes of one wave: its LDS reads above are done before these writes)
+        if (hr == FT_NONE) { if (c == 0) { frow[grp * 16] = FT_NONE; lrow[grp * 16] = FT_NONE; } }
+        else if (hopen) { firstv[grp * 256 + c] = carry; if (c == 0) { frow[grp * 16] = hr; lrow[grp * 16] = FT_NONE; } }
+        else { firstv[grp * 256 + c] = hv; lastv[grp * 256 + c] = carry; if (c == 0) { frow[grp * 16] = hr; lrow[grp * 16] = cr; } }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        unsigned cr = FT_NONE;
+        float carry = 0.f;
+        for (int q = 0; q < FT_NQ; ++q) {
+            const unsigned fr = frow[q * 16];
+            if (fr == FT_NONE) break;
+            const float fv = firstv[q * 256 + c];
+            if (fr == cr) carry += fv;
+            else { if (cr != FT_NONE) put(cr, c, carry); cr = fr; carry = fv; }
+            const unsigned lr = lrow[q * 16];
+            if (lr != FT_NONE) { put(cr, c, carry); cr = lr; carry = lastv[q * 256 + c]; }
+        }
+        if (cr != FT_NONE) put(cr, c, carry);
+    }
+}
+
+extern "C" int re_fm_table_grad(const int32_t* keys_t, int64_t B, int64_t F, const int64_t* offsets, int64_t rows_total, const int32_t* slices,
+                                int64_t n_slices, const float* gE, const float* gL, int64_t D, float* gT, float* gTL, re_stream_t stream) {
+    re_clear_error();
+    if (B == 0 || n_slices == 0) return RE_OK;
+    if (!keys_t || !offsets || !slices || !gE || !gL || !gT || !gTL || B < 0 || rows_total <= 0 || n_slices < 0) return RE_EINVAL;
+    if (F < 1 || F > 64 || D < 1 || D > 15 || B > FT_MAXB || n_slices > (1 << 20)) return RE_EUNSUPPORTED;
+    const int64_t Bp = re_cdiv(B, FT_NT) * FT_NT;
+    int P2 = FT_GROUPS * 8;
+    while (P2 < Bp) P2 <<= 1;
+    const size_t ldsb = (size_t)(Bp + P2) * 4 + 2 * FT_GROUPS * 16 * 4 + 2 * FT_GROUPS * 4 + FT_NW * 4;
+    if (hipFuncSetAttribute((const void*)fm_table_grad_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
+    hipLaunchKernelGGL(fm_table_grad_k, dim3((unsigned)n_slices), dim3(FT_NT), ldsb, (hipStream_t)stream, keys_t, (int)B, (int)F, offsets, rows_total,
+                       slices, gE, gL, (int)D, gT, gTL, P2);
     return re_launch_status();
 }
 

@@ -181,10 +181,6 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         }
     };
     const uint32_t R32 = (uint32_t)R, pad32 = (padding_idx >= 0 && padding_idx < R) ? (uint32_t)padding_idx : 0xFFFFFFFFu;
-    auto is_hit = [&](int key) {
-        const uint32_t k = (uint32_t)key;   // (a negative key is >= R as unsigned)
-        return (k & ((nwg >> HSH) - 1)) == (me >> HSH) && k < R32 && k != pad32;
-    };
     auto entry_of = [&](int key, uint32_t v) { return (((uint32_t)key >> (wsh - HSH)) << 25) | (v + region_of(v) * dlt); };
     // ---- the usual case: every WAVE ranks its own sixteenth of the keys into its own 512-entry stretch of the list -- ballots and lane counts,
     // no workgroup barrier inside the scan (the chunked form below, two barriers and a workgroup-wide prefix sum per 8 192 keys, took ~5 k cycles

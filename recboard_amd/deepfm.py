@@ -141,9 +141,16 @@ class DeepFMEngine:
         """-> (logits [B], tape).  DeepFM/main.py:201-209.  seed_dev: the dropout seed as a device word (captured steps).
         labels (training): the criterion runs in the last layer's launch; tape["loss" / "dlogit" / "dsum"] hold its results."""
         P = self.P
-        rows = torch.empty(x.numel(), dtype=torch.int64, device=x.device) if labels is not None else None
-        E, fm_lr = ops.fm_bag_fwd(self.T, self.TL.reshape(-1), self.bias, self.offsets, x, rows_out=rows)
-        tape = {"E": E, "layers": [], "rows": rows}
+        # (what the backward's table gradient wants of the batch: the ids field-major for re_fm_table_grad, or the destination rows for the
+        #  general sorted scatter-add where the shapes are beyond it)
+        rows = keys_t = None
+        if labels is not None:
+            if ops.fm_table_grad_ok(x.shape[0], self.F, self.D, max(self.counts)):
+                keys_t = torch.empty(x.numel(), dtype=torch.int32, device=x.device)
+            else:
+                rows = torch.empty(x.numel(), dtype=torch.int64, device=x.device)
+        E, fm_lr = ops.fm_bag_fwd(self.T, self.TL.reshape(-1), self.bias, self.offsets, x, rows_out=rows, keys_t=keys_t)
+        tape = {"E": E, "layers": [], "rows": rows, "keys_t": keys_t}
         h, sd = E, self._step_seed()
         for i in range(self.nl):
             # bn(linear(x)) in training mode: the batch statistics' per-64-row partials come out of the GEMM's epilogue (re_gemm_f32_colstats)
@@ -168,8 +175,9 @@ class DeepFMEngine:
         """sigmoid(logits) [B, 1]  (DeepFM/main.py:217-219)."""
         return torch.sigmoid(self.encode(x)[0]).unsqueeze(1)
 
-    def forward_backward(self, x, labels, seed_dev=None):
-        """loss + every gradient into the gradient arena.  DeepFM/main.py:211-215, 264-266."""
+    def forward_backward(self, x, labels, seed_dev=None, _tables_zeroed=False):
+        """loss + every gradient into the gradient arena.  DeepFM/main.py:211-215, 264-266.
+        _tables_zeroed: the two table gradients were cleared by the caller (the captured step: by the launch that brings the batch in)."""
         P, G = self.P, self.G
         # last layer + criterion fused (re_mlp_head_fwd with labels: loss, dlogit and its sum -- the last bias's gradient); then dW = dl^T h and
         # da = dl w in one pass over h (re_mlp_head_bwd)
@@ -209,8 +217,19 @@ class DeepFMEngine:
             else:
                 g, da = None, ops.gemm(dz, W)
         gE, gL = ops.fm_bag_bwd(tape["E"], da, dlogit, self.F, self.D)
-        # both table gradients follow the same destination rows: ONE sort (re_scatter_plan), two segmented sums (re_scatter_apply)
+        if tape["keys_t"] is not None:
+            # a field's B keys live in the field's own row range: a workgroup per slice of rows collects its keys and sums them per row
+            # (re_fm_table_grad: one launch behind one zero fill, instead of the general sorted scatter-add's twelve)
+            if not _tables_zeroed:
+                self.grad[:self.n_emb].zero_()
+            B = tape["keys_t"].numel() // self.F
+            sl = self.__dict__.setdefault("_slices", {})
+            if B not in sl:
+                sl[B] = ops.fm_table_slices(self.counts, B, self.device)
+            ops.fm_table_grad(tape["keys_t"], self.offsets, sl[B], gE, gL, self.gT, self.gTL.reshape(-1))
+            return loss.squeeze(0)
         rows = tape["rows"]
+        # both table gradients follow the same destination rows: ONE sort (re_scatter_plan), two segmented sums (re_scatter_apply)
         ws = ops.scatter_workspace(rows.numel(), self.D, self.rows, rows.device)
         ops.scatter_plan(rows, self.D, self.rows, ws)
         ops.scatter_apply(gE.reshape(-1, self.D), self.rows, self.gT, ws, accumulate=False)
@@ -219,29 +238,37 @@ class DeepFMEngine:
 
     def train_step(self, x, labels, max_norm=10.0, _state=None):
         """forward, backward, clip_grad_norm_(.., 10), Adam with the reference's two groups (DeepFM/main.py:187-199, 264-268)."""
-        loss = self.forward_backward(x, labels, seed_dev=_state)
-        # clip_grad_norm_(.., max_norm) as a device coefficient (two small launches), applied by the two Adam launches on their way through the
-        # gradient (which they leave clipped in the arena, as p.grad is after the reference's step)
-        coef = ops.grad_clip_coef(self.grad, max_norm, out=self.__dict__.setdefault("_clip", torch.empty(2, dtype=torch.float32, device=self.device)))
-        ne = self.n_emb
+        loss = self.forward_backward(x, labels, seed_dev=_state, _tables_zeroed=_state is not None and self._stage_zeroes(x))
+        # clip_grad_norm_(.., max_norm) + Adam with the reference's two weight-decay groups: the square norm's partials, then ONE launch whose
+        # workgroups form the coefficient from them and apply it on their way through the gradient (which they leave clipped in the arena, as
+        # p.grad is after the reference's step)
+        out = self.__dict__.setdefault("_clip", torch.empty(2, dtype=torch.float32, device=self.device))
         b1, b2 = self.betas
         if _state is not None:       # captured: seed and Adam scalars are device words; the host counts the step (train_step_graph)
-            hyper = _state.view(torch.float32)[2:4]
-            ops.adam_step_scaled(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], coef, hyper=hyper, beta1=b1, beta2=b2, weight_decay=self.emb_decay)
-            ops.adam_step_scaled(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], coef, hyper=hyper, beta1=b1, beta2=b2, weight_decay=self.wd)
+            ops.adam_step_clip2(self.data, self.grad, self.m, self.v, self.n_emb, max_norm, hyper=_state.view(torch.float32)[2:4], beta1=b1, beta2=b2,
+                                wd_first=self.emb_decay, wd_rest=self.wd, out=out)
             return loss
         self.step += 1
-        ops.adam_step_scaled(self.data[:ne], self.grad[:ne], self.m[:ne], self.v[:ne], coef, step=self.step, lr=self.lr, beta1=b1, beta2=b2, weight_decay=self.emb_decay)
-        ops.adam_step_scaled(self.data[ne:], self.grad[ne:], self.m[ne:], self.v[ne:], coef, step=self.step, lr=self.lr, beta1=b1, beta2=b2, weight_decay=self.wd)
+        ops.adam_step_clip2(self.data, self.grad, self.m, self.v, self.n_emb, max_norm, step=self.step, lr=self.lr, beta1=b1, beta2=b2,
+                            wd_first=self.emb_decay, wd_rest=self.wd, out=out)
         return loss
+
+    def _stage_zeroes(self, x):
+        """The captured step's table gradients are cleared in front of the replay (capture.CapturedStep: zeros) when re_fm_table_grad is the
+        kernel that fills them (it writes only the rows the batch points at)."""
+        return ops.fm_table_grad_ok(x.shape[0], self.F, self.D, max(self.counts))
 
     def train_step_graph(self, x, labels, max_norm=10.0):
         """train_step as one hipGraph replay (recboard_amd/capture.py): two copies into the static batch, one launch for the step's seed and
         Adam scalars, one replay.  Same results as the eager step (same seeds, same launches)."""
         from .capture import captured
-        labels = labels.reshape(-1).to(torch.float32)
+        labels = labels.reshape(-1)
         restore = [self.data, self.m, self.v] + [t for pair in self.running.values() for t in pair]
-        g = captured(self, ("train", float(max_norm)), lambda xx, yy, st: self.train_step(xx, yy, max_norm, _state=st), (x.contiguous(), labels), restore)
+        x = x.contiguous()
+        zeros = [self.grad[:self.n_emb]] if self._stage_zeroes(x) else []
+        # (the static label buffer is fp32; int64 labels are converted on their way in by the staging launch)
+        g = captured(self, ("train", float(max_norm)), lambda xx, yy, st: self.train_step(xx, yy, max_norm, _state=st), (x, labels), restore, zeros,
+                     static_dtypes=(x.dtype, torch.float32))
         sd = self._step_seed()
         self.step += 1
         return g((x, labels), sd, self.step, self.lr, self.betas[0], self.betas[1])

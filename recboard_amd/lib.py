@@ -92,13 +92,15 @@ SIGNATURES = {
     "re_grad_clip_workspace_bytes": (_sz, []),
     "re_grad_clip_coef": (_i32, [_vp, _i64, _f32, _vp, _vp, _sz, _vp]),
     "re_adam_step_scaled": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _f64, _f64, _f64, _f64, _vp, _vp]),
+    "re_adam_step_clip2": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp, _f64, _f64, _f64, _f64, _f64, _f32, _vp, _vp, _sz, _vp]),
     "re_adam_step_reduce": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _f64, _f64, _f64, _f64, _f64, _vp]),
     "re_score_pool": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "re_pool_topk": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "re_auc_workspace_bytes": (_sz, []),
     "re_auc": (_i32, [_vp, _vp, _i64, _vp, _vp, _sz, _vp]),
-    "re_fm_bag_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "re_fm_bag_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "re_fm_bag_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "re_fm_table_grad": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "re_bce_logits": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "re_gemm_f32_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "re_gemm_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
@@ -110,6 +112,7 @@ SIGNATURES = {
     "re_bn_relu_drop_fwd_pre": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "re_bn_relu_drop_fwd": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _u32, _vp, _u32, _vp, _vp, _vp, _sz, _vp]),
     "re_step_state": (_i32, [_vp, _u32, _i64, _f64, _f64, _f64, _vp]),
+    "re_step_stage_inputs": (_i32, [_vp, _u32, _i64, _f64, _f64, _f64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "re_mlp_workspace_bytes": (_sz, [_i64]),
     "re_mlp_head_workspace_bytes": (_sz, [_i64, _i64]),
     "re_mlp_head_fwd": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1049,6 +1049,20 @@ def adam_step_scaled(p, g, m, v, gscale, step=0, lr=0.0, hyper=None, beta1=0.9, 
                                              float(weight_decay), _p(gscale), _stream()), "re_adam_step_scaled")
 
 
+def adam_step_clip2(p, g, m, v, n_first, max_norm, step=0, lr=0.0, hyper=None, beta1=0.9, beta2=0.999, eps=1e-8, wd_first=0.0, wd_rest=0.0, out=None):
+    """clip_grad_norm_(.., max_norm) + Adam over an arena whose first n_first entries decay with wd_first and the rest with wd_rest
+    (re_adam_step_clip2: two launches); g is left clipped.  -> float32[2] on the device: [coefficient, ||g||]."""
+    for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nme)
+    out = out if out is not None else torch.empty(2, dtype=torch.float32, device=g.device)
+    L = lib.load()
+    ws = _ws(L.re_grad_clip_workspace_bytes(), g.device)
+    lib.check(L.re_adam_step_clip2(_p(p), _p(g), _p(m), _p(v), p.numel(), int(n_first), int(step), float(lr), _p(hyper), float(beta1), float(beta2),
+                                   float(eps), float(wd_first), float(wd_rest), float(max_norm), _p(out), _p(ws), ws.numel(), _stream()),
+              "re_adam_step_clip2")
+    return out
+
+
 def scale_copy(dst, src, alpha):
     _req(dst, torch.float32, "dst"); _req(src, torch.float32, "src")
     lib.check(lib.load().re_scale_copy(_p(dst), _p(src), float(alpha), src.numel(), _stream()), "re_scale_copy")
@@ -1102,8 +1116,9 @@ def auc(scores, labels):
 
 
 # ------------------------------------------------------------------------------------------------ K9
-def fm_bag_fwd(T, TL, lr_bias, offsets, x, rows_out=None):
-    """-> (E [B, F*D], fm_lr [B])  (re_fm_bag_fwd).  rows_out (int64 [B * F], optional) receives offsets[f] + x[b, f]."""
+def fm_bag_fwd(T, TL, lr_bias, offsets, x, rows_out=None, keys_t=None):
+    """-> (E [B, F*D], fm_lr [B])  (re_fm_bag_fwd).  rows_out (int64 [B * F], optional) receives offsets[f] + x[b, f]; keys_t (int32 [F * B],
+    optional) x[b, f] field-major (fm_table_grad's keys)."""
     _req(T, torch.float32, "T"); _req(TL, torch.float32, "TL"); _req(lr_bias, torch.float32, "lr_bias")
     _req(offsets, torch.int64, "offsets"); _req(x, torch.int64, "x")
     B, F = x.shape
@@ -1111,7 +1126,7 @@ def fm_bag_fwd(T, TL, lr_bias, offsets, x, rows_out=None):
     E = torch.empty((B, F * D), dtype=torch.float32, device=T.device)
     fm_lr = torch.empty((B,), dtype=torch.float32, device=T.device)
     lib.check(lib.load().re_fm_bag_fwd(_p(T), _p(TL), _p(lr_bias), _p(offsets), T.shape[0], _p(x), B, F, D, _p(E), _p(fm_lr),
-                                       _p(rows_out), _stream()), "re_fm_bag_fwd")
+                                       _p(rows_out), _p(keys_t), _stream()), "re_fm_bag_fwd")
     return E, fm_lr
 
 
@@ -1125,6 +1140,37 @@ def fm_bag_bwd(E, dE_mlp, dlogit, F, D):
     gL = torch.empty((B * F, 1), dtype=torch.float32, device=E.device)
     lib.check(lib.load().re_fm_bag_bwd(_p(E), _p(dE_mlp), _p(dlogit), B, F, D, _p(gE), _p(gL), _stream()), "re_fm_bag_bwd")
     return gE, gL
+
+
+def fm_table_grad_ok(B, F, D, max_count):
+    """Shapes re_fm_table_grad takes (else: scatter_plan + scatter_apply)."""
+    return B <= 8192 and F <= 64 and D <= 15 and max_count < (1 << 19) - 1
+
+
+def fm_table_slices(counts, B, device, target=40):
+    """Row slices for fm_table_grad: int32 [n, 4] = (field, first row, end row, 0), rows relative to the field's first; sized for ~`target` keys a
+    slice when a field's B keys are uniform over its rows (a slice of up to 64 keys is one wave's work)."""
+    out = []
+    for f, c in enumerate(counts):
+        rps = max(1, (target * c + B - 1) // max(B, 1))
+        for lo in range(0, c, rps):
+            out.append((f, lo, min(lo + rps, c), 0))
+    return torch.tensor(out, dtype=torch.int32, device=device).reshape(-1, 4)
+
+
+def fm_table_grad(keys_t, offsets, slices, gE, gL, gT, gTL):
+    """gT [R, D], gTL [R] (both ZERO-FILLED by the caller) += the contribution rows of fm_bag_bwd, summed per destination row
+    offsets[f] + keys_t[f, b]  (re_fm_table_grad: one launch, a workgroup per row slice: fm_table_slices; bitwise reproducible).
+    keys_t: int32 [F, B], the batch's ids field-major (fm_bag_fwd's keys_t)."""
+    _req(keys_t, torch.int32, "keys_t"); _req(offsets, torch.int64, "offsets"); _req(gE, torch.float32, "gE"); _req(gL, torch.float32, "gL")
+    _req(gT, torch.float32, "gT"); _req(gTL, torch.float32, "gTL"); _req(slices, torch.int32, "slices")
+    F = offsets.numel()
+    B = keys_t.numel() // F
+    R, D = gT.shape
+    if gE.numel() != B * F * D or gL.numel() != B * F or gTL.numel() != R or slices.dim() != 2 or slices.shape[1] != 4:
+        raise ValueError("fm_table_grad: shapes")
+    lib.check(lib.load().re_fm_table_grad(_p(keys_t), B, F, _p(offsets), R, _p(slices), slices.shape[0], _p(gE), _p(gL), D, _p(gT), _p(gTL),
+                                          _stream()), "re_fm_table_grad")
 
 
 def bce_logits(logits, labels):
@@ -1242,6 +1288,45 @@ def step_state(state, seed, step, lr, beta1=0.9, beta2=0.999):
     _req(state, torch.int32, "state")
     lib.check(lib.load().re_step_state(_p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), _stream()), "re_step_state")
     return state
+
+
+def stage_inputs(state, seed, step, lr, beta1, beta2, pairs=(), zeros=()):
+    """step_state + the batch into a captured step's static buffers + zero fills, ONE launch (re_step_stage_inputs).  pairs: (static, input) with
+    the same dtype (a byte copy) or fp32 <- int64 (a cast); zeros: tensors to clear.  Anything else (another dtype pair, a non-contiguous
+    tensor, more than 8 segments) goes the ordinary way: copy_ / zero_."""
+    import ctypes
+    segs = []
+    for s, x in pairs:
+        if s.is_contiguous() and x.is_contiguous() and x.is_cuda and s.numel() == x.numel() and x.dtype == s.dtype:
+            segs.append((s, x, 0))
+        elif s.is_contiguous() and x.is_contiguous() and x.is_cuda and s.numel() == x.numel() and s.dtype == torch.float32 and x.dtype == torch.int64:
+            segs.append((s, x, 1))
+        else:
+            s.copy_(x, non_blocking=True)
+    for z in zeros:
+        if z.is_contiguous():
+            segs.append((z, None, 2))
+        else:
+            z.zero_()
+    while len(segs) > 8:
+        s, x, kind = segs.pop()
+        if kind == 2:
+            s.zero_()
+        else:
+            s.copy_(x, non_blocking=True)
+    n = len(segs)
+    for s, x, _ in segs:
+        _note(s)
+        if x is not None:
+            _note(x)
+    dst = (ctypes.c_void_p * max(n, 1))(*[s.data_ptr() for s, _, _ in segs])
+    src = (ctypes.c_void_p * max(n, 1))(*[(x.data_ptr() if x is not None else 0) for _, x, _ in segs])
+    nb = (ctypes.c_int64 * max(n, 1))(*[s.numel() * s.element_size() for s, _, _ in segs])
+    kd = (ctypes.c_int32 * max(n, 1))(*[k for _, _, k in segs])
+    if state is not None:
+        _req(state, torch.int32, "state")
+    lib.check(lib.load().re_step_stage_inputs(_p(state), int(seed) & 0xFFFFFFFF, int(step), float(lr), float(beta1), float(beta2), n, dst, src, nb, kd,
+                                              _stream()), "re_step_stage_inputs")
 
 
 def bn_relu_drop_fwd(z, gamma, beta, run_mean, run_var, training, drop_p=0.0, seed=0, stream_id=100, eps=1e-5, momentum=0.1, seed_dev=None,

@@ -105,3 +105,57 @@ def test_captured_step_replays_the_eager_step():
     assert torch.equal(a.data, b.data) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v)
     for i in a.running:
         assert torch.equal(a.running[i][0], b.running[i][0]) and torch.equal(a.running[i][1], b.running[i][1])
+
+
+@pytest.mark.parametrize("B,D,counts", [(4096, 10, [94762, 25612, 7, 24, 12, 5, 50, 500, 5000, 50000]), (1000, 10, [3, 1, 40000]),
+                                        (8192, 15, [2, 300000]), (33, 4, [5, 6, 7, 8, 9]), (1, 10, [10, 10])])
+def test_fm_table_grad_matches_index_add(B, D, counts):
+    """re_fm_table_grad (csrc/fmbag.hip: a workgroup per field sorts the field's keys in LDS and sums the runs) against index_add in fp64:
+    heavy rows (a field of 2 - 7 values takes B / 2 ... B / 7 contributions a row), rows nobody refers to stay as the caller left them (zero),
+    B that is no power of two, one key; and the same bits on a second call."""
+    from recboard_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    F, R = len(counts), sum(counts)
+    off = torch.tensor([sum(counts[:i]) for i in range(F)], dtype=torch.int64, device="cuda")
+    x = torch.stack([torch.randint(0, c, (B,), device="cuda", generator=g) for c in counts], 1)
+    rows = (x + off).contiguous()
+    kt = x.t().contiguous().to(torch.int32)
+    gE = torch.randn(B * F, D, device="cuda", generator=g)
+    gL = torch.randn(B * F, 1, device="cuda", generator=g)
+    assert ops.fm_table_grad_ok(B, F, D, max(counts))
+    gT, gTL = torch.zeros(R, D, device="cuda"), torch.zeros(R, device="cuda")
+    sl = ops.fm_table_slices(counts, B, "cuda")
+    ops.fm_table_grad(kt, off, sl, gE, gL, gT, gTL)
+    refT = torch.zeros(R, D, device="cuda", dtype=torch.float64).index_add_(0, rows.reshape(-1), gE.double())
+    refL = torch.zeros(R, device="cuda", dtype=torch.float64).index_add_(0, rows.reshape(-1), gL.reshape(-1).double())
+    tol = 1e-6 * max(8.0, (B / min(counts)) ** 0.5 * 4)          # fp32 sums of up to B terms
+    assert float((gT.double() - refT).abs().max()) <= tol * float(refT.abs().max() + 1)
+    assert float((gTL.double() - refL).abs().max()) <= tol * float(refL.abs().max() + 1)
+    untouched = torch.ones(R, dtype=torch.bool, device="cuda")
+    untouched[rows.reshape(-1)] = False
+    assert float(gT[untouched].abs().max() if untouched.any() else 0.0) == 0.0
+    gT2, gTL2 = torch.zeros_like(gT), torch.zeros_like(gTL)
+    ops.fm_table_grad(kt, off, sl, gE, gL, gT2, gTL2)
+    assert torch.equal(gT, gT2) and torch.equal(gTL, gTL2)
+    # any slicing is a correct one: one slice per field (every list long: the LDS sort and the stretch walk), and 3-row slices
+    for other in (torch.tensor([(f, 0, c, 0) for f, c in enumerate(counts)], dtype=torch.int32, device="cuda"),
+                  torch.tensor([(f, lo, min(lo + 3, c), 0) for f, c in enumerate(counts) for lo in range(0, c, 3)][:200000], dtype=torch.int32, device="cuda")):
+        if other.shape[0] == 200000:
+            continue
+        gT3, gTL3 = torch.zeros_like(gT), torch.zeros_like(gTL)
+        ops.fm_table_grad(kt, off, other, gE, gL, gT3, gTL3)
+        assert float((gT3.double() - refT).abs().max()) <= tol * float(refT.abs().max() + 1)
+        assert float((gTL3.double() - refL).abs().max()) <= tol * float(refL.abs().max() + 1)
+
+
+def test_fm_table_grad_drops_keys_outside_the_tables():
+    from recboard_amd import ops
+    counts = [4, 6]
+    off = torch.tensor([0, 4], dtype=torch.int64, device="cuda")
+    rows = torch.tensor([[0, 4], [3, 9], [1, 10], [-1, 5]], dtype=torch.int64, device="cuda")      # 10: past the end; -1: in front of field 0
+    kt = (rows - off).t().contiguous().to(torch.int32)
+    gE, gL = torch.ones(8, 3, device="cuda"), torch.ones(8, 1, device="cuda")
+    gT, gTL = torch.zeros(10, 3, device="cuda"), torch.zeros(10, device="cuda")
+    ops.fm_table_grad(kt, off, ops.fm_table_slices(counts, 4, "cuda"), gE, gL, gT, gTL)
+    assert gTL.tolist() == [1, 1, 0, 1, 1, 1, 0, 0, 0, 1]
+    assert not ops.fm_table_grad_ok(8193, 2, 10, 6) and not ops.fm_table_grad_ok(64, 2, 16, 6) and not ops.fm_table_grad_ok(64, 2, 10, 1 << 19)
