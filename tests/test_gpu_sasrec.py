@@ -393,6 +393,29 @@ def test_pipelined_preparation_gives_the_same_steps(in_tail):
     b.check_handover()
 
 
+@pytest.mark.parametrize("B", [1536, 4096])
+def test_tail_preparation_at_large_batches_gives_the_same_steps(B):
+    """From 1 024 sequences on the step's tail launch shares the next plan's spans phase among its last workgroups (csrc/enc_plan_body.h:
+    PL_MODE_SPANS with nparts > 1 -- arrival and token counters, the last to arrive publishes), cuts the weight-gradient contractions 40-way
+    and deals the position jobs by ranges of sequences: the same losses and parameters, bit for bit, as the plain captured step whose batch a
+    preparation launch in front prepares -- over several steps, so that the counters' return to zero is exercised."""
+    import bench
+    from recboard_amd.sasrec import SASRecEngine
+    cfg = dict(bench.BEAUTY, B=B)
+    bs = [tuple(torch.from_numpy(x).cuda() for x in b) for b in bench.synth_batches(cfg, 4, 3)]
+    a = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=2)
+    b = SASRecEngine(cfg["items"], 50, 64, 2, dropout_rate=0.5, lr=5e-4, weight_decay=1e-6, seed=2)
+    a.prep_in_tail = False
+    b.prep_in_tail = True
+    for i in range(7):
+        la = a.train_step_graph(*bs[i % 4]).clone()
+        lb = b.train_step_graph(*bs[i % 4], next_batch=bs[(i + 1) % 4]).clone()
+        assert torch.equal(lb, la), i
+    assert torch.equal(b.arena.data, a.arena.data)
+    b.check_handover()
+    assert int(b._ticket.abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("pipelined", [False, True])
 def test_captured_step_is_reproducible_from_process_to_process(pipelined):
     """Two fresh processes, the same seeds and Beauty-shaped batches, 160 captured steps each: the same parameters bit for bit.  (Rounds 3 - 5
