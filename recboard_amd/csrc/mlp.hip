@@ -231,16 +231,27 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_k(const float* __restrict__ 
     float mean = 0.f, m2 = 0.f, cnt = 0.f;
     if (ok) {
         const int lo = q * per, hi = (lo + per < chunks) ? lo + per : chunks;
-#pragma unroll 4
-        for (int b = lo; b < hi; ++b) {
-            const int64_t mb = (int64_t)b * rpc;
-            if (mb >= M) break;
-            const float cb = (float)(((mb + rpc < M) ? mb + rpc : M) - mb);
-            const float mo = colstats[((int64_t)b * 2 + 0) * N + col], qo = colstats[((int64_t)b * 2 + 1) * N + col];
-            const float tot = cnt + cb, w = cb / tot, delta = mo - mean;
-            mean = fmaf(delta, w, mean);
-            m2 = m2 + qo + delta * delta * (cnt * w);
-            cnt = tot;
+        // (sixteen chunks' partials requested together, through clamped indices: one at a time behind a `break` they were sixteen dependent
+        //  L2 round trips -- 8 of the launch's 11 us at M = 4 096; the merge itself is the same chain of Chan updates, in chunk order)
+        for (int b0 = lo; b0 < hi; b0 += 16) {
+            float mo[16], qo[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = b0 + i < hi ? b0 + i : hi - 1;
+                mo[i] = colstats[((int64_t)b * 2 + 0) * N + col];
+                qo[i] = colstats[((int64_t)b * 2 + 1) * N + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t mb = (int64_t)(b0 + i) * rpc;
+                if (b0 + i < hi && mb < M) {
+                    const float cb = (float)(((mb + rpc < M) ? mb + rpc : M) - mb);
+                    const float tot = cnt + cb, w = cb / tot, delta = mo[i] - mean;
+                    mean = fmaf(delta, w, mean);
+                    m2 = m2 + qo[i] + delta * delta * (cnt * w);
+                    cnt = tot;
+                }
+            }
         }
     }
     s_mean[threadIdx.x] = mean; s_m2[threadIdx.x] = m2; s_cnt[threadIdx.x] = cnt;
@@ -307,11 +318,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_k(float* __restrict__ dz, c
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if (ok) {
         const int lo = q * per, hi = (lo + per < chunks) ? lo + per : chunks;
-#pragma unroll 8
-        for (int b = lo; b < hi; ++b) {
-            s0 += part[((int64_t)b * ps + 0) * N + col];
-            s1 += part[((int64_t)b * ps + 1) * N + col];
-            if (third) s2 += part[((int64_t)b * ps + 2) * N + col];
+        // (sixteen chunks' sums requested together through clamped indices; added in chunk order: x + 0 = x past the end)
+        for (int b0 = lo; b0 < hi; b0 += 16) {
+            float p0[16], p1[16], p2[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = b0 + i < hi ? b0 + i : hi - 1;
+                p0[i] = part[((int64_t)b * ps + 0) * N + col];
+                p1[i] = part[((int64_t)b * ps + 1) * N + col];
+                p2[i] = part[((int64_t)b * ps + (ps > 2 ? 2 : 1)) * N + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool in = b0 + i < hi;
+                s0 += in ? p0[i] : 0.f;
+                s1 += in ? p1[i] : 0.f;
+                s2 += (in && third) ? p2[i] : 0.f;
+            }
         }
     }
     r0[threadIdx.x] = s0; r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
