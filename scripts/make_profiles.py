@@ -24,6 +24,8 @@ front = [n for n in k if n.startswith("score_front_k<64>")]      # round 5: quer
 rescan = [n for n in k if n.startswith("score_rescan_k<64>")]
 if front and rescan:
     total = sum(k[n]["hbm_bytes_per_launch"] for n in (front[0], main, "score_topk_merge_x<64>", rescan[0]))
+elif front and exact is None:     # (round 6, end: a flagged user is re-scored inside the merge launch: three launches a call)
+    total = sum(k[n]["hbm_bytes_per_launch"] for n in (front[0], main, "score_topk_merge_x<64>"))
 elif front:
     total = sum(k[n]["hbm_bytes_per_launch"] for n in (front[0], main, "score_topk_merge_x<64>", exact, "score_topk_merge"))
 else:
@@ -36,7 +38,8 @@ out = {"collected": "two rocprofv3 passes (the TCC block cannot hold both counte
        "kernels": k,
        "re_score_topk_call": {
            "launches": "score_front_k (query split + item-table split + starting thresholds + zeroing of the call's words, one launch), score_kernel_reg<64,28,28,split>, "
-                       "score_topk_merge_x, and the fallback launch score_rescan_k (one wave per flagged user; nobody flagged: it returns at once)",
+                       "score_topk_merge_x (a user whose certificate fails is re-scored against the whole catalog by the merge wave that finds it so: "
+                       "sx_rescan_user; no fallback launch)",
            "hbm_bytes_per_call": total,
            "algorithmic_lower_bound_bytes": 4 * 64 * (22363 + 12101) + 12 * 22363 * 50,
            "note": "above the lower bound: the partial lists (one 56-entry list per user and segment: 41 MB written by the main kernel, read by the merge), "
