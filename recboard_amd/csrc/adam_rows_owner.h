@@ -213,14 +213,16 @@ __device__ __forceinline__ void sa_body(SaParams P, unsigned char* lds) {
     auto load_keys = [&](int64_t c0) {
 #pragma unroll
         for (int u = 0; u < SA_KPT; ++u) {
+            // (clamped and unconditional: behind `if (f < total)` hipcc waits for every load at the branch's join -- s_waitcnt vmcnt(0) -- and
+            //  the SA_KPT loads that were meant to be in flight together were SA_KPT dependent round trips)
             const int64_t f = c0 + tid + (int64_t)u * SA_NT;
-            kreg[u] = -1; preg[u] = 0;
-            if (f < total) {
-                int64_t r = 0, i = f;
-                if (P.n_regions > 1) { r = (int64_t)((uint32_t)f / (uint32_t)rows); i = f - r * rows; }      // (total < 2^32)
-                preg[u] = (uint32_t)(r * P.region_stride + i);
-                kreg[u] = sa_key<KeyT>(P, (int64_t)preg[u]);
-            }
+            const int64_t fc = f < total ? f : total - 1;
+            int64_t r = 0, i = fc;
+            if (P.n_regions > 1) { r = (int64_t)((uint32_t)fc / (uint32_t)rows); i = fc - r * rows; }      // (total < 2^32; uniform branch)
+            const uint32_t pp = (uint32_t)(r * P.region_stride + i);
+            const int64_t kk = sa_key<KeyT>(P, (int64_t)pp);
+            preg[u] = f < total ? pp : 0u;
+            kreg[u] = f < total ? kk : -1;
         }
     };
     // ---- pass A: the distinct keys this workgroup owns, with their number of contributions
@@ -247,10 +249,8 @@ __device__ __forceinline__ void sa_body(SaParams P, unsigned char* lds) {
     float touch0 = 0.f, touch1 = 0.f, touch2 = 0.f;
     {
         const uint32_t hk = s_hkey[tid];
-        if (hk != SA_EMPTY) {
-            const int64_t o = (int64_t)hk * P.stride + P.coff;
-            touch0 = P.W[o]; touch1 = P.m[o]; touch2 = P.v[o];
-        }
+        const int64_t o = (int64_t)(hk != SA_EMPTY ? hk : 0u) * P.stride + P.coff;     // (unconditional: row 0 where the slot is empty)
+        touch0 = P.W[o]; touch1 = P.m[o]; touch2 = P.v[o];
     }
 #endif
     // ---- pass B: the entries of the keys with few contributions go to the list (key, position)

@@ -17,6 +17,11 @@
 #include "re_common.h"
 
 #define FB_MAXD 16
+// The sixteen words of a clamped, unconditional load batch, pinned: without a use that does not depend on the range check hipcc sinks every load
+// into a branch of its own (load, s_waitcnt vmcnt(0), select -- sixteen dependent round trips).
+#define FB_PIN16(t)                                                                                                                         \
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]), \
+                      "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]))
 
 // lanes [0, F) of a group of FP lanes (power of two >= F) handle the F fields of one batch row
 template <int FP>
@@ -36,10 +41,19 @@ __global__ __launch_bounds__(256) void fm_bag_fwd_k(const float* __restrict__ T,
         const int64_t r = x[b * F + f] + offsets[f];
         if (rows_out) rows_out[b * F + f] = r;
         if (keys_t) keys_t[(int64_t)f * B + b] = (int32_t)x[b * F + f];     // field-major, relative to the field: re_fm_table_grad's keys
-        if (r >= 0 && r < rows_total) {
-            for (int d = 0; d < D; ++d) e[d] = T[r * D + d];
-            lr = TL[r];
-        }
+        // (one batch of unconditional loads through a clamped row / column: behind the range check and a run-time loop bound they were D + 1
+        //  dependent round trips)
+        const bool in = r >= 0 && r < rows_total;
+        const int64_t rc = in ? r : 0;
+        float t[FB_MAXD];
+#pragma unroll
+        for (int d = 0; d < FB_MAXD; ++d) t[d] = T[rc * D + (d < D ? d : D - 1)];
+        float tl = TL[rc];
+        FB_PIN16(t);
+        asm volatile("" : "+v"(tl));
+#pragma unroll
+        for (int d = 0; d < FB_MAXD; ++d) e[d] = (in && d < D) ? t[d] : 0.f;
+        lr = in ? tl : 0.f;
         float* dst = E + (b * F + f) * D;
         for (int d = 0; d < D; ++d) dst[d] = e[d];
     }
@@ -68,18 +82,32 @@ __global__ __launch_bounds__(256) void fm_bag_bwd_k(const float* __restrict__ E,
     float e[FB_MAXD];
 #pragma unroll
     for (int d = 0; d < FB_MAXD; ++d) e[d] = 0.f;
-    if (act)
-        for (int d = 0; d < D; ++d) e[d] = E[(b * F + f) * D + d];
+    {
+        const int64_t bc = act ? b * F + f : 0;     // (unconditional, clamped: see fm_bag_fwd_k)
+        float t[FB_MAXD];
+#pragma unroll
+        for (int d = 0; d < FB_MAXD; ++d) t[d] = E[bc * D + (d < D ? d : D - 1)];
+        FB_PIN16(t);
+#pragma unroll
+        for (int d = 0; d < FB_MAXD; ++d) e[d] = (act && d < D) ? t[d] : 0.f;
+    }
     const float dl = (b < B) ? dlogit[b] : 0.f;
+    float dm[FB_MAXD];
+    {
+        const float* dp = dE_mlp ? dE_mlp : E;      // (uniform; E: a valid address, the value is not used)
+        const int64_t bc = act ? b * F + f : 0;
+#pragma unroll
+        for (int d = 0; d < FB_MAXD; ++d) dm[d] = dp[bc * D + (d < D ? d : D - 1)];
+        FB_PIN16(dm);
+#pragma unroll
+        for (int d = 0; d < FB_MAXD; ++d) dm[d] = dE_mlp ? dm[d] : 0.f;
+    }
 #pragma unroll
     for (int d = 0; d < FB_MAXD; ++d) {
         float s = e[d];
 #pragma unroll
         for (int o = FP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (act && d < D) {
-            const int64_t i = (b * F + f) * D + d;
-            gE[i] = (dE_mlp ? dE_mlp[i] : 0.f) + dl * (s - e[d]);
-        }
+        if (act && d < D) gE[(b * F + f) * D + d] = dm[d] + dl * (s - e[d]);
     }
     if (act) gL[b * F + f] = dl;
 }
