@@ -748,12 +748,12 @@ extern "C" int re_sparse_adam_rows_dev(const float* g, const int64_t* idx, int64
 // (the algorithm: scatter_owner.h)
 #include "scatter_owner.h"
 
-template <int D, int HS>
+template <int D, int HS, int NG = SO_NG>
 __global__ __launch_bounds__(SO_NT) void scatter_owner_k(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                                          const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
                                                          int64_t padding_idx, float scale, float* __restrict__ dW, SoAdam AD) {
     extern __shared__ __align__(16) float so_acc[];
-    so_body<D, HS>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, so_acc);
+    so_body<D, HS, SoNoHook, NG>(g, keys, nreg, stride, n_dev, n_mul, n_host, R, rpw, padding_idx, scale, dW, AD, so_acc);
 }
 
 static int scatter_small_launch(const float* g, const int32_t* keys, int32_t n_regions, int64_t region_stride, const int32_t* n_dev,
@@ -767,23 +767,30 @@ static int scatter_small_launch(const float* g, const int32_t* keys, int32_t n_r
         return RE_EUNSUPPORTED;
     if ((int64_t)n_regions * region_stride >= (1ll << 25)) return RE_EUNSUPPORTED;   // (a list entry: 7 bits of local row, 25 of index)
     constexpr int HS = 2;                          // column pieces per row
-    const int rpw = D == 64 ? 96 : 48;            // virtual rows per workgroup: 96 KB of accumulators (8 sets x rpw x D / HS floats)
+    int rpw = D == 64 ? 96 : 48;                   // virtual rows per workgroup: 96 KB of accumulators (8 sets x rpw x D / HS floats)
     int64_t nwg = HS;
     while (nwg * rpw < R * HS) nwg *= 2;          // a power of two: virtual rows are dealt round-robin with a mask
-    if (nwg > 4096) return RE_EUNSUPPORTED;       // every workgroup scans all keys: past ~100 k rows the sorted path is the right one
-    const size_t ldsb = (size_t)SO_NG * rpw * (D / HS) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
-    if (D == 64) {
-        auto k = scatter_owner_k<64, HS>;
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw,
-                           padding_idx, scale, dW, AD);
-    } else {
-        auto k = scatter_owner_k<128, HS>;
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;
-        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw,
-                           padding_idx, scale, dW, AD);
+    // More rows than 256 workgroups hold at eight accumulator sets: two sets and four times the rows per workgroup (a workgroup is 144 KB of
+    // LDS: one per CU, so every further 256 workgroups are another pass over the chip) -- where a list entry's 23 index bits suffice.
+    const bool wide = nwg > 256 && (int64_t)n_regions * region_stride < (1ll << 23);
+    if (wide) {
+        rpw *= 4;
+        nwg = 256;
+        while (nwg * rpw < R * HS) nwg *= 2;
     }
+    if (nwg > 4096) return RE_EUNSUPPORTED;       // every workgroup scans all keys: past ~100 k rows the sorted path is the right one
+    const size_t ldsb = (size_t)(wide ? 2 : SO_NG) * rpw * (D / HS) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define SO_LAUNCH(DV, NGV)                                                                                                                       \
+    do {                                                                                                                                          \
+        auto k = scatter_owner_k<DV, HS, NGV>;                                                                                                    \
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return RE_ELAUNCH;          \
+        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(SO_NT), ldsb, s, g, keys, (int)n_regions, region_stride, n_dev, (int)n_mul, n_host, R, rpw, \
+                           padding_idx, scale, dW, AD);                                                                                           \
+    } while (0)
+    if (D == 64) { if (wide) SO_LAUNCH(64, 2); else SO_LAUNCH(64, SO_NG); }
+    else { if (wide) SO_LAUNCH(128, 2); else SO_LAUNCH(128, SO_NG); }
+#undef SO_LAUNCH
     return re_launch_status();
 }
 

@@ -56,7 +56,11 @@ struct SoNoHook {
 // hook.issue(matches, keys): called once by every thread, workgroup-uniformly, when the LAST batch of contribution-row loads has been issued
 // (or there was none); hook.collect(): once, after those rows have been added and BEFORE the owned rows' stores are issued -- enc_tail_k takes
 // its ticket of the job queue in between: the counter's round trip runs under the row loads' own, and nothing waits for a store's.
-template <int D, int HS, class Hook = SoNoHook>
+// NG accumulator sets per row (SO_NG = 8: the four lane groups of a set add one after the other; a hot row is spread over eight sets) -- or 2
+// for tables whose rows do not fit 256 workgroups at 96 rows each (MF-BPR's 34 464 user + item rows were 1 024 workgroups = four passes over the
+// CUs at one 144 KB workgroup per CU: 30 us; with two sets a workgroup holds 384 rows and ONE pass does: scatter.hip: scatter_small_launch).
+// A list entry is (local row << RSH) | contribution row: 7 + 25 bits at NG = 8, 9 + 23 at NG = 2.
+template <int D, int HS, class Hook = SoNoHook, int NG = SO_NG>
 __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32_t* __restrict__ keys, int nreg, int64_t stride,
                                         const int32_t* __restrict__ n_dev, int n_mul, int64_t n_host, int64_t R, int rpw,
                                         int64_t padding_idx, float scale, float* __restrict__ dW, const SoAdam& AD, float* so_acc,
@@ -65,7 +69,10 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
     constexpr int DW = D / HS, VW = DW / 32;         // columns of a piece; floats per lane: a lane group is 32 lanes
     constexpr int HSH = HS == 1 ? 0 : HS == 2 ? 1 : 2;
     typedef float vt __attribute__((ext_vector_type(VW)));
-    // so_acc: [SO_NG][rpw][DW] floats of (dynamic) LDS
+    // so_acc: [NG][rpw][DW] floats of (dynamic) LDS
+    constexpr int RSH = NG == SO_NG ? 25 : 23;
+    constexpr uint32_t IMASK = (1u << RSH) - 1u;
+    constexpr int PRE = NG == SO_NG ? 1 : 3;         // owned-row elements of a thread whose parameter / moment words are requested at the start
     __shared__ uint32_t s_ent[SO_CAP];               // local row << 25 | contribution index
     __shared__ int s_wsum[SO_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, grp = tid >> 5, gl = tid & 31;
@@ -81,13 +88,20 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
     // on the keys is requested here -- the step scalars, the gate word and the thread's own piece of parameter / moment rows (the rows a
     // workgroup owns are a function of its index; nobody else writes them).
     float ad_ss = 0.f, ad_ib = 0.f;
-    float4 P0 = make_float4(0.f, 0.f, 0.f, 0.f), M0 = P0, V0 = P0;
+    float4 P0[PRE], M0[PRE], V0[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) P0[i] = M0[i] = V0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (AD.W) {
-        if (tid < rows_here * (DW / 4)) {
-            const int64_t o = ((((int64_t)(tid / (DW / 4)) * nwg + me) >> HSH)) * D + h_me * DW;
-            P0 = reinterpret_cast<const float4*>(AD.W + o)[tid % (DW / 4)];
-            M0 = reinterpret_cast<const float4*>(AD.m + o)[tid % (DW / 4)];
-            V0 = reinterpret_cast<const float4*>(AD.v + o)[tid % (DW / 4)];
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int e = tid + i * SO_NT;
+            const int ec = e < rows_here * (DW / 4) ? e : 0;         // (clamped, unconditional; no rows here: row `me` of the table, in range)
+            const int64_t o = ((((int64_t)(ec / (DW / 4)) * nwg + me) >> HSH)) * D + h_me * DW;
+            if (rows_here > 0) {                                     // (uniform)
+                P0[i] = reinterpret_cast<const float4*>(AD.W + o)[ec % (DW / 4)];
+                M0[i] = reinterpret_cast<const float4*>(AD.m + o)[ec % (DW / 4)];
+                V0[i] = reinterpret_cast<const float4*>(AD.v + o)[ec % (DW / 4)];
+            }
         }
         // (unconditional loads, selected afterwards: a branch on a loaded word is a round trip of its own)
         const unsigned gate_w = *(AD.gate ? AD.gate : reinterpret_cast<const unsigned*>(AD.hyper));
@@ -95,7 +109,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         ad_ib = AD.hyper[1];
         ad_ib = (AD.gate && gate_w != 0u) ? 0.f : ad_ib;   // ({0, 0}: the caller gated this step off; gate: a hand-over of this step timed out)
     }
-    for (int e = tid; e < SO_NG * rpw * DW / 4; e += SO_NT) reinterpret_cast<float4*>(so_acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < NG * rpw * DW / 4; e += SO_NT) reinterpret_cast<float4*>(so_acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt = 0;          // entries in the list (workgroup-uniform)
     bool hooked = false;  // (uniform)
     unsigned m0 = 0;      // matches consumed so far
@@ -126,8 +140,8 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
                 for (int u = 0; u < INF; ++u) {
                     const int j = jb + j0 + SO_LG * u;
                     const uint32_t en = s_ent[j < cnt ? j : 0];   // (clamped: a valid entry, its value is not used)
-                    rw[u] = j < cnt ? (int)(en >> 25) : -1;
-                    v[u] = reinterpret_cast<const vt*>(g + (int64_t)(en & 0x1FFFFFFu) * D + h_me * DW)[gl];
+                    rw[u] = j < cnt ? (int)(en >> RSH) : -1;
+                    v[u] = reinterpret_cast<const vt*>(g + (int64_t)(en & IMASK) * D + h_me * DW)[gl];
                 }
                 if (last && jb + SO_LG * INF >= cnt) { hook.issue((int)m0 + cnt, (int)total); hooked = true; }   // (uniform)
 #pragma unroll
@@ -137,12 +151,12 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
                     rw[u] = same ? -1 : rw[u];
                 }
 #pragma unroll
-                for (int ph = 0; ph < SO_LG / SO_NG; ++ph) {
-                    if ((grp / SO_NG) == ph) {
+                for (int ph = 0; ph < SO_LG / NG; ++ph) {
+                    if ((grp / NG) == ph) {
 #pragma unroll
                         for (int u = 0; u < INF; ++u) {
                             if (rw[u] >= 0) {
-                                vt* a = reinterpret_cast<vt*>(so_acc + ((int64_t)(grp % SO_NG) * rpw + rw[u]) * DW) + gl;
+                                vt* a = reinterpret_cast<vt*>(so_acc + ((int64_t)(grp % NG) * rpw + rw[u]) * DW) + gl;
                                 *a += v[u];
                             }
                         }
@@ -181,7 +195,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         }
     };
     const uint32_t R32 = (uint32_t)R, pad32 = (padding_idx >= 0 && padding_idx < R) ? (uint32_t)padding_idx : 0xFFFFFFFFu;
-    auto entry_of = [&](int key, uint32_t v) { return (((uint32_t)key >> (wsh - HSH)) << 25) | (v + region_of(v) * dlt); };
+    auto entry_of = [&](int key, uint32_t v) { return (((uint32_t)key >> (wsh - HSH)) << RSH) | (v + region_of(v) * dlt); };
     // ---- the usual case: every WAVE ranks its own sixteenth of the keys into its own 512-entry stretch of the list -- ballots and lane counts,
     // no workgroup barrier inside the scan (the chunked form below, two barriers and a workgroup-wide prefix sum per 8 192 keys, took ~5 k cycles
     // a chunk whatever the keys were: 13 k of the tail launch's ~50 k at B = 512, 70 k of ~210 k at B = 4 096; scripts/tail_phases.py) -- and the
@@ -338,7 +352,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         const int r = e / (DW / 4), c4 = e % (DW / 4);
         float4 s = reinterpret_cast<const float4*>(so_acc + (int64_t)r * DW)[c4];
 #pragma unroll
-        for (int gq = 1; gq < SO_NG; ++gq) {
+        for (int gq = 1; gq < NG; ++gq) {
             const float4 t = reinterpret_cast<const float4*>(so_acc + ((int64_t)gq * rpw + r) * DW)[c4];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
@@ -348,8 +362,14 @@ __device__ __forceinline__ void so_body(const float* __restrict__ g, const int32
         if (dW) reinterpret_cast<float4*>(dW + o)[c4] = gr;
         if (AD.W) {
             if (ad_ib != 0.f) {
-                float4 P = P0, M = M0, V = V0;
-                if (e != tid) { P = reinterpret_cast<float4*>(AD.W + o)[c4]; M = reinterpret_cast<float4*>(AD.m + o)[c4]; V = reinterpret_cast<float4*>(AD.v + o)[c4]; }
+                const int pi = (e - tid) / SO_NT;               // (uniform)
+                float4 P, M, V;
+                if (pi < PRE) {
+                    P = P0[0]; M = M0[0]; V = V0[0];
+#pragma unroll
+                    for (int i = 1; i < PRE; ++i)
+                        if (pi == i) { P = P0[i]; M = M0[i]; V = V0[i]; }
+                } else { P = reinterpret_cast<float4*>(AD.W + o)[c4]; M = reinterpret_cast<float4*>(AD.m + o)[c4]; V = reinterpret_cast<float4*>(AD.v + o)[c4]; }
                 const float ss = ad_ss, ib = ad_ib;
                 so_adam1(AD, ss, ib, gr.x, P.x, M.x, V.x); so_adam1(AD, ss, ib, gr.y, P.y, M.y, V.y);
                 so_adam1(AD, ss, ib, gr.z, P.z, M.z, V.z); so_adam1(AD, ss, ib, gr.w, P.w, M.w, V.w);

@@ -1,0 +1,7 @@
+"""config 1 alone (bench_legs.leg_config1): python scripts/c1_time.py"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench_legs
+r = bench_legs.leg_config1()
+print(json.dumps({k: r[k] for k in ("value", "ms_per_step", "ms_per_step_graph", "ms_per_step_eager") if k in r}))
+print(json.dumps(r.get("roofline", {}))[:700])
