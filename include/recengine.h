@@ -500,7 +500,12 @@ int re_spmm_csr(const int64_t* crow, const int64_t* col, const float* val, int64
  * adjacency's user rows gather item rows and its item rows gather user rows: row_order = [nlong long rows | class 0 | class 1], `split` =
  * position of class 1's first row in row_order (<= nlong or == nrows: one class, as re_spmm_csr), `xcd_share` (1 .. 7) = how many of the 8
  * XCD labels (blockIdx % 8) walk class 0 -- each XCD's L2 then holds the hot rows of ONE part of X.  flags & 1: (col, val), Z, Y and ACC
- * go through the caches with the non-temporal hint.  Bit-identical to re_spmm_csr (a row's sum does not depend on who computes it). */
+ * go through the caches with the non-temporal hint.  flags & 2: the long rows' chunk partials are added INSIDE the launch (by the workgroup
+ * that brings a row's last chunk, in chunk order) instead of by a second launch: `ws` then holds, behind the partials rounded up to 16 bytes,
+ * nlong int32 arrival counters -- ws_bytes >= align16(nchunks * D * 4) + nlong * 4, the counters ZERO before the first call (every call
+ * leaves them zero).  flags & 4 (nrows == ncols): ACC = acc_scale * (X[row] + Y[row]) instead of ACC += acc_scale * Y[row] -- the running
+ * mean of LightGCN's layers (LightGCN/main.py:77-86) started by the first propagation itself.  Results are bit-identical to re_spmm_csr's (a
+ * row's sum does not depend on who computes it). */
 int re_spmm_csr_split(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
                       const int64_t* row_order, int64_t nlong, int64_t split, int32_t xcd_share, int32_t flags,
                       const int32_t* chunk_row, const int64_t* chunk_ptr, int64_t nchunks, const float* X, int64_t D, float* Y,

@@ -110,11 +110,15 @@ __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col
 
 template <int LPR, bool NT = false>
 __device__ __forceinline__ void spmm_store(float4 acc, int64_t r, int64_t D, int64_t c4, float* __restrict__ Y,
-                                           const float* __restrict__ Z, float beta, float* __restrict__ ACC, float acc_scale) {
+                                           const float* __restrict__ Z, float beta, float* __restrict__ ACC, float acc_scale,
+                                           const float* __restrict__ ainit = nullptr) {
     if (Z) f4_axpy(acc, beta, sp_ld4<NT>(reinterpret_cast<const float4*>(Z + r * D) + c4));
     sp_st4<NT>(reinterpret_cast<float4*>(Y + r * D) + c4, acc);
     if (ACC) {
-        float4 a = sp_ld4<NT>(reinterpret_cast<const float4*>(ACC + r * D) + c4);
+        // (ainit: the running sum STARTS here -- acc_scale x the row of `ainit` (the first propagation's own input: LightGCN's layer-0 term)
+        //  instead of what ACC holds: the launch that filled ACC with acc_scale * X0 beforehand is not needed)
+        float4 a = sp_ld4<NT>(reinterpret_cast<const float4*>((ainit ? ainit : ACC) + r * D) + c4);
+        if (ainit) { a.x *= acc_scale; a.y *= acc_scale; a.z *= acc_scale; a.w *= acc_scale; }
         f4_axpy(a, acc_scale, acc);
         sp_st4<NT>(reinterpret_cast<float4*>(ACC + r * D) + c4, a);
     }
@@ -132,7 +136,7 @@ __device__ __forceinline__ void spmm_rows_walk(int64_t blk, int64_t nblk, const 
                                                const float* __restrict__ val, int64_t nrows, int64_t ncols,
                                                const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                const float* __restrict__ Z, float beta, float* __restrict__ ACC,
-                                               float acc_scale) {
+                                               float acc_scale, const float* __restrict__ ainit = nullptr) {
     const int lir = threadIdx.x % LPR;
     const int64_t gpb = 256 / LPR;
     const int64_t D4 = D >> 2;
@@ -152,7 +156,7 @@ __device__ __forceinline__ void spmm_rows_walk(int64_t blk, int64_t nblk, const 
         const int64_t p0 = crow[r], p1 = crow[r + 1];
         for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
             const float4 acc = spmm_row_range<LPR, NT>(col, val, X, ncols, D, c4, p0, p1, 1);
-            spmm_store<LPR, NT>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
+            spmm_store<LPR, NT>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale, ainit);
         }
     }
 }
@@ -162,8 +166,9 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__
                                                      const float* __restrict__ val, int64_t nrows, int64_t ncols,
                                                      const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                      const float* __restrict__ Z, float beta, float* __restrict__ ACC,
-                                                     float acc_scale) {
-    spmm_rows_walk<LPR, NT>(blockIdx.x, gridDim.x, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale);
+                                                     float acc_scale, int acc_init) {
+    spmm_rows_walk<LPR, NT>(blockIdx.x, gridDim.x, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale,
+                            acc_init ? X : nullptr);
 }
 
 // long rows: one workgroup per CHUNK of SP_CHUNK non-zeros (a popular item can have tens of thousands of non-zeros: one
@@ -223,21 +228,52 @@ __global__ __launch_bounds__(256) void spmm_csr_fused(const int32_t* __restrict_
                                                       const float* __restrict__ val, int64_t nrows, int64_t ncols,
                                                       const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                       const float* __restrict__ Z, float beta, float* __restrict__ ACC,
-                                                      float acc_scale) {
+                                                      float acc_scale, int acc_init, int* __restrict__ arrived) {
     __shared__ float4 part[256];
+    __shared__ int s_last;
     if ((int64_t)blockIdx.x < nch8) {
         spmm_long_chunks<LPR>(part, blockIdx.x, nch8, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial);
+        // `arrived` (a zeroed word per long row): the workgroup that brings a row's LAST chunk adds the row's chunk partials -- in chunk order,
+        // whoever it is: the same sum -- and applies the epilogue; spmm_csr_long_combine, a launch of 6 us behind every propagation (six a
+        // LightGCN step), is then not needed.  The others' partials come through their L2s' write-backs (release) and coherent loads here.
+        if (!arrived || (int64_t)blockIdx.x >= nchunks) return;        // (nch8 <= 4096 <= the grid: one chunk per workgroup)
+        const int li = chunk_row[blockIdx.x];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int n_of_row = (int)(chunk_ptr[li + 1] - chunk_ptr[li]);
+            const int old = __hip_atomic_fetch_add(arrived + li, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == n_of_row - 1;
+            if (s_last) __hip_atomic_store(arrived + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const int64_t r = row_order[li];
+        for (int64_t c = threadIdx.x; c < D; c += 256) {
+            float acc = 0.f;
+            for (int64_t ch = chunk_ptr[li]; ch < chunk_ptr[li + 1]; ++ch)
+                acc += __hip_atomic_load(partial + ch * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (spmm_store's arithmetic, a column at a time)
+            if (Z) acc = fmaf(beta, Z[r * D + c], acc);
+            Y[r * D + c] = acc;
+            if (ACC) {
+                float a = acc_init ? X[r * D + c] * acc_scale : ACC[r * D + c];
+                ACC[r * D + c] = fmaf(acc_scale, acc, a);
+            }
+        }
         return;
     }
     spmm_rows_walk<LPR, NT>((int64_t)blockIdx.x - nch8, (int64_t)gridDim.x - nch8, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z,
-                            beta, ACC, acc_scale);
+                            beta, ACC, acc_scale, acc_init ? X : nullptr);
 }
 
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_csr_long_combine(const int64_t* __restrict__ row_order, int64_t nlong,
                                                              const int64_t* __restrict__ chunk_ptr, const float* __restrict__ partial,
                                                              int64_t D, float* __restrict__ Y, const float* __restrict__ Z, float beta,
-                                                             float* __restrict__ ACC, float acc_scale) {
+                                                             float* __restrict__ ACC, float acc_scale, const float* __restrict__ ainit) {
     const int lir = threadIdx.x % LPR;
     const int64_t li = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (li >= nlong) return;
@@ -249,7 +285,7 @@ __global__ __launch_bounds__(256) void spmm_csr_long_combine(const int64_t* __re
             const float4 q = reinterpret_cast<const float4*>(partial + ch * D)[c4];
             acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
         }
-        spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale);
+        spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale, ainit);
     }
 }
 
@@ -261,13 +297,21 @@ static int spmm_launch(const int64_t* crow, const int64_t* col, const float* val
     if (nrows == 0) return RE_OK;
     if (!crow || !col || !val || !X || !Y || nrows < 0 || ncols <= 0 || D <= 0 || nlong < 0 || nlong > nrows) return RE_EINVAL;
     if (nlong > 0 && (!row_order || !chunk_row || !chunk_ptr || nchunks < nlong || !ws)) return RE_EINVAL;
-    if (nlong > 0 && ws_bytes < (size_t)nchunks * D * sizeof(float)) return RE_EWORKSPACE;
+    // flags: 1 non-temporal streams; 2 the long rows' chunk partials are combined inside the launch -- `ws` then carries nlong int32 counters
+    // behind the partials (zero before the first use; every call leaves them zero); 4 ACC starts at acc_scale * X[row] (square adjacency)
+    const bool in_launch = (flags & 2) && nlong > 0;
+    const int acc_init = (flags & 4) && ACC ? 1 : 0;
+    if (acc_init && nrows != ncols) return RE_EINVAL;
+    const size_t part_bytes = re_align((size_t)nchunks * D * sizeof(float), 16);
+    if (nlong > 0 && ws_bytes < (in_launch ? part_bytes + (size_t)nlong * sizeof(int) : (size_t)nchunks * D * sizeof(float))) return RE_EWORKSPACE;
     if ((D & 3) || ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Z) |
                      reinterpret_cast<uintptr_t>(ACC) | reinterpret_cast<uintptr_t>(ws)) & 15u))
         return RE_EUNSUPPORTED;
     if (X == Y) return RE_EINVAL;  // not in place
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)ws;
+    int* arrived = in_launch ? (int*)((char*)ws + part_bytes) : (int*)nullptr;
+    const float* ainit = acc_init ? X : (const float*)nullptr;
 #define SP_LAUNCH(LPRV)                                                                                                             \
     do {                                                                                                                            \
         const int64_t nch8 = (nchunks + 7) & ~(int64_t)7;                                                                           \
@@ -276,15 +320,15 @@ static int spmm_launch(const int64_t* crow, const int64_t* col, const float* val
         if (fuse) {                                                                                                                 \
             unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536 - 4096);                                                \
             g = (g + 7u) & ~7u;                                                                                                     \
-            if (flags & 1) hipLaunchKernelGGL((spmm_csr_fused<LPRV, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
-            else hipLaunchKernelGGL((spmm_csr_fused<LPRV, false>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
+            if (flags & 1) hipLaunchKernelGGL((spmm_csr_fused<LPRV, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived); \
+            else hipLaunchKernelGGL((spmm_csr_fused<LPRV, false>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived); \
         } else if (nrows > nlong) {                                                                                                 \
             unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536);                                                       \
             if (split > nlong) g = (g + 7u) & ~7u;                                                                                  \
-            if (flags & 1) hipLaunchKernelGGL((spmm_csr_rows<LPRV, true>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
-            else hipLaunchKernelGGL((spmm_csr_rows<LPRV, false>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale); \
+            if (flags & 1) hipLaunchKernelGGL((spmm_csr_rows<LPRV, true>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init); \
+            else hipLaunchKernelGGL((spmm_csr_rows<LPRV, false>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init); \
         }                                                                                                                           \
-        if (nlong) hipLaunchKernelGGL(spmm_csr_long_combine<LPRV>, dim3((unsigned)re_cdiv(nlong, 256 / LPRV)), dim3(256), 0, s, row_order, nlong, chunk_ptr, partial, D, Y, Z, beta, ACC, acc_scale); \
+        if (nlong && !(fuse && arrived)) hipLaunchKernelGGL(spmm_csr_long_combine<LPRV>, dim3((unsigned)re_cdiv(nlong, 256 / LPRV)), dim3(256), 0, s, row_order, nlong, chunk_ptr, partial, D, Y, Z, beta, ACC, acc_scale, ainit); \
     } while (0)
     if ((D >> 2) >= 32) SP_LAUNCH(32); else SP_LAUNCH(16);
 #undef SP_LAUNCH

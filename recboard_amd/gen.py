@@ -158,11 +158,13 @@ class LightGCNEngine(MFEngine):
     def encode(self):
         """-> (userEmbds, itemEmbds) after propagation.  LightGCN/main.py:77-86."""
         s = 1.0 / (self.L + 1)
-        ops.scale_copy(self.avg, self.X0, s)
+        if self.L == 0:
+            ops.scale_copy(self.avg, self.X0, s)
         src, bufs = self.X0, (self.Xa, self.Xb)
         for l in range(self.L):
             dst = bufs[l & 1]
-            self._spmm(src, dst, acc=self.avg, acc_scale=s)
+            # (the first propagation starts the running mean with its own input: avg = s (X0 + A X0) -- no launch that fills avg beforehand)
+            self._spmm(src, dst, acc=self.avg, acc_scale=s, acc_init=(l == 0))
             src = dst
         return self.avg[: self.U], self.avg[self.U:]
 
@@ -202,7 +204,10 @@ class LightGCNEngine(MFEngine):
         loss, g, keys = ops.bpr_triplet_step_rows(ue, ie, u, p, n, *W[B])
         rows = keys.reshape(-1).to(torch.int64)
         emb = self._emb_loss(u, p, n, rows)
-        ops.scatter_add_rows(g.view(3 * B, D), rows, self.n, scale=s, out=self.davg)   # d(avg)/(L+1), dense
+        # both dense scatters of the step go to the same destination rows: ONE sort (re_scatter_plan), two segmented sums (re_scatter_apply)
+        ws = ops.scatter_workspace(rows.numel(), D, self.n, rows.device)
+        ops.scatter_plan(rows, D, self.n, ws)
+        ops.scatter_apply(g.view(3 * B, D), self.n, self.davg, ws, scale=s, accumulate=False)   # d(avg)/(L+1), dense
         # g_L = davg ; g_l = Adj g_{l+1} + davg ; the last product lands in the gradient arena
         src, bufs = self.davg, (self.Ga, self.Xa)
         for l in range(self.L):
@@ -210,7 +215,7 @@ class LightGCNEngine(MFEngine):
             self._spmm(src, dst, Z=self.davg, beta=1.0)
             src = dst
         # + weight_decay * d(emb_loss): rows of the RAW tables, scaled by wd / B
-        ops.scatter_add_rows(ops.gather_rows(self.X0, rows), rows, self.n, scale=self.wd / B, out=gX0, accumulate=True)
+        ops.scatter_apply(ops.gather_rows(self.X0, rows), self.n, gX0, ws, scale=self.wd / B, accumulate=True)
         if grad_hook is not None:
             grad_hook(A.grad)
         self._adam(0.0, _state)

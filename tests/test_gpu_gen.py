@@ -114,6 +114,21 @@ def test_spmm_csr_vs_oracle_with_long_rows(ops, n, D, avg_deg, hot):
     out2 = torch.empty_like(out)
     ops.spmm_csr(cr, co, va, plan, dev(X), out2, Z=dev(Z), beta=0.5)
     assert torch.equal(out, out2)           # bitwise reproducible
+    # acc_init (re_spmm_csr_split flags & 4): the running sum STARTS at acc_scale * X -- the same bits as filling acc with 0.25 X first
+    a1 = (0.25 * dev(X)).contiguous()
+    ops.spmm_csr(cr, co, va, plan, dev(X), out2, acc=a1, acc_scale=0.25)
+    a2 = torch.full((n, D), 7.0, device="cuda")
+    ops.spmm_csr(cr, co, va, plan, dev(X), out2, acc=a2, acc_scale=0.25, acc_init=True)
+    assert torch.equal(a1, a2)
+    # flags & 2 (the long rows' chunks combined inside the launch: measured slower on the LightGCN shape, off by default, kept as a switch):
+    # the same bits, twice in a row (the arrival counters return to zero)
+    if hot:
+        plan2 = ops.spmm_plan(cr, D)
+        plan2.flags |= 2
+        for _ in range(2):
+            out3, a3 = torch.empty_like(out), dev(acc0)
+            ops.spmm_csr(cr, co, va, plan2, dev(X), out3, Z=dev(Z), beta=0.5, acc=a3, acc_scale=0.25)
+            assert torch.equal(out3, out) and torch.equal(a3, acc)
 
 
 def test_scatter_add_accumulate_mode(ops):
