@@ -510,6 +510,18 @@ int re_spmm_csr_split(const int64_t* crow, const int64_t* col, const float* val,
                       const int64_t* row_order, int64_t nlong, int64_t split, int32_t xcd_share, int32_t flags,
                       const int32_t* chunk_row, const int64_t* chunk_ptr, int64_t nchunks, const float* X, int64_t D, float* Y,
                       const float* Z, float beta, float* ACC, float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream);
+/* re_spmm_csr_split with a bit per row of X (src_mask[i >> 5] bit i & 31; NULL: none): 0 = that row of X is all zeros and is not fetched --
+ * the product of a matrix with mostly-zero rows (the first propagation of LightGCN's backward pass: the scatter of 3 B gradient rows into
+ * 122 915) gathers only what can contribute.  Adding exact zeros changes no sum: results are the unmasked ones bit for bit.  The mask is
+ * used where the plan has long rows (nlong > 0: the fused launch), ignored otherwise.  re_row_mask builds it from the scatter's row list.
+ * row_ptrs (optional, [nrows][2]): crow[row_order[i]], crow[row_order[i] + 1] -- the row pointers in WALKING order, fetched beside the row id
+ * instead of behind it (one dependent memory round trip less per row). */
+int re_spmm_csr_masked(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
+                       const int64_t* row_order, int64_t nlong, int64_t split, int32_t xcd_share, int32_t flags,
+                       const int32_t* chunk_row, const int64_t* chunk_ptr, int64_t nchunks, const float* X, int64_t D, float* Y,
+                       const float* Z, float beta, float* ACC, float acc_scale, const uint32_t* src_mask, const int64_t* row_ptrs, void* ws,
+                       size_t ws_bytes, re_stream_t stream);
+int re_row_mask(const int64_t* rows, int64_t n, int64_t nbits, uint32_t* mask, re_stream_t stream);
 size_t re_rows_sqnorm_workspace_bytes(void);
 int re_rows_sqnorm(const float* W, int64_t R, int64_t D, const int64_t* idx, int64_t n, float scale, float* out,
                    int accumulate, void* ws, size_t ws_bytes, re_stream_t stream);

@@ -50,11 +50,18 @@ __device__ __forceinline__ float4 sp_ld4(const float4* p) {
     } else return *p;
 }
 
-template <int LPR, bool NT = false>
+// MASK: `mask` holds one bit per row of X -- 0 = the row is all zeros and is not fetched (the FIRST product of LightGCN's backward pass: its input
+// is the scatter of 3 B gradient rows into a 122 915-row array -- 95 % zero rows, and the launch is bound by the rows it gathers).  Adding an
+// exact zero changes no sum: the result is the unmasked one bit for bit.  The mask words of a group are requested when its column ids
+// arrive (16 KB for the Yelp2018 shape: L1 / L2 hits), in front of the next group's (col, val).
+template <int LPR, bool NT = false, bool MASK = false>
 __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col, const float* __restrict__ val,
                                                   const float* __restrict__ X, int64_t ncols, int64_t D, int64_t c4,
-                                                  int64_t p0, int64_t p1, int64_t step) {
+                                                  int64_t p0, int64_t p1, int64_t step, const uint32_t* __restrict__ mask = nullptr) {
     constexpr int U = SP_ILP;
+    auto in_range = [&](int64_t c) { return c >= 0 && c < ncols; };
+    auto mword = [&](int64_t c) { return MASK ? mask[(in_range(c) ? c : 0) >> 5] : 0xFFFFFFFFu; };      // (clamped, unconditional)
+    auto live = [&](int64_t c, uint32_t w) { return in_range(c) && (!MASK || ((w >> (c & 31)) & 1u)); };
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t p = p0;
     if (p + (U - 1) * step < p1) {
@@ -65,6 +72,9 @@ __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col
         for (;;) {
             const int64_t pn = p + U * step;
             const bool more = pn + (U - 1) * step < p1;
+            uint32_t mw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) mw[u] = mword(cc[u]);
             int64_t nc[U];
             float nv[U];
 #pragma unroll
@@ -76,7 +86,7 @@ __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cc[u] >= 0 && cc[u] < ncols) xr[u] = reinterpret_cast<const float4*>(X + cc[u] * D)[c4];
+                if (live(cc[u], mw[u])) xr[u] = reinterpret_cast<const float4*>(X + cc[u] * D)[c4];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) f4_axpy(acc, vv[u], xr[u]);
@@ -93,17 +103,70 @@ __device__ __forceinline__ float4 spmm_row_range(const int64_t* __restrict__ col
         float4 xr[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { cc[u] = sp_ld<NT>(col + p + u * step); vv[u] = sp_ld<NT>(val + p + u * step); }
+        uint32_t mw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mw[u] = mword(cc[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cc[u] >= 0 && cc[u] < ncols) xr[u] = reinterpret_cast<const float4*>(X + cc[u] * D)[c4];
+            if (live(cc[u], mw[u])) xr[u] = reinterpret_cast<const float4*>(X + cc[u] * D)[c4];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) f4_axpy(acc, vv[u], xr[u]);
     }
     for (; p < p1; p += step) {
         const int64_t cc = sp_ld<NT>(col + p);
-        if (cc >= 0 && cc < ncols) f4_axpy(acc, sp_ld<NT>(val + p), reinterpret_cast<const float4*>(X + cc * D)[c4]);
+        if (live(cc, mword(cc))) f4_axpy(acc, sp_ld<NT>(val + p), reinterpret_cast<const float4*>(X + cc * D)[c4]);
+    }
+    return acc;
+}
+
+// A whole row by ONE lane group, its (col, val) fetched by the group instead of by every lane: lane l of the group loads non-zero p + l
+// (one coalesced 8-byte and one 4-byte load per lane for LPR non-zeros -- the row_range form above issues a (col, val) pair per non-zero in
+// EVERY lane, all lanes of a group the same address: 2 of the 3 memory instructions a non-zero costs, and the launch is bound by the CUs'
+// address units as much as by the rows they fetch: masking 95 % of the gathers away saved 15 %), then hands them round with cross-lane moves.
+// The next block's (col, val) are in flight while this block's X rows are gathered.  Sums in non-zero order: the same bits as spmm_row_range.
+template <int LPR, bool NT = false, bool MASK = false>
+__device__ __forceinline__ float4 spmm_row_contig(const int64_t* __restrict__ col, const float* __restrict__ val,
+                                                   const float* __restrict__ X, int64_t ncols, int64_t D, int64_t c4,
+                                                   int64_t p0, int64_t p1, const uint32_t* __restrict__ mask = nullptr) {
+    const int lir = threadIdx.x % LPR;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p0 >= p1) return acc;
+    auto fetch = [&](int64_t p, int& c, float& v, uint32_t& w) {     // (clamped, unconditional; a slot past the row: column -1 = no row)
+        const int64_t q = p + lir < p1 ? p + lir : p1 - 1;
+        const int64_t cq = sp_ld<NT>(col + q);
+        const float vq = sp_ld<NT>(val + q);
+        const bool ok = p + lir < p1 && cq >= 0 && cq < ncols;
+        c = ok ? (int)cq : -1;
+        v = ok ? vq : 0.f;
+        w = 0xFFFFFFFFu;
+        if (MASK) w = mask[(ok ? cq : 0) >> 5];                   // (behind the column id: an L1 / L2 hit)
+    };
+    int cm, cn = -1;
+    float vm, vn = 0.f;
+    uint32_t wm, wn = 0u;
+    fetch(p0, cm, vm, wm);
+    for (int64_t p = p0; p < p1; p += LPR) {
+        fetch(p + LPR, cn, vn, wn);                                 // (always: past the row every slot is a clamped "no row" -- no branch around the loads)
+#pragma unroll
+        for (int h = 0; h < LPR; h += 8) {
+            if (p + h >= p1) break;                                  // (uniform)
+            int cc[8];
+            float vv[8];
+            float4 xr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                cc[u] = __shfl(cm, h + u, LPR);
+                vv[u] = __shfl(vm, h + u, LPR);
+                const uint32_t w = MASK ? (uint32_t)__shfl((int)wm, h + u, LPR) : 0xFFFFFFFFu;
+                xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cc[u] >= 0 && (!MASK || ((w >> (cc[u] & 31)) & 1u))) xr[u] = reinterpret_cast<const float4*>(X + (int64_t)cc[u] * D)[c4];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f4_axpy(acc, vv[u], xr[u]);
+        }
+        cm = cn; vm = vn; wm = wn;
     }
     return acc;
 }
@@ -130,13 +193,14 @@ __device__ __forceinline__ void spmm_store(float4 acc, int64_t r, int64_t D, int
 // second.  Each L2 then has to hold the hot rows of one part of X instead of both.
 // (blk, nblk: this workgroup's index among the row-walking workgroups of the launch -- the fused launch below puts the long rows' chunk
 //  workgroups in front of them)
-template <int LPR, bool NT>
+template <int LPR, bool NT, bool MASK = false>
 __device__ __forceinline__ void spmm_rows_walk(int64_t blk, int64_t nblk, const int64_t* __restrict__ row_order, int64_t first, int64_t split, int k0,
                                                const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
                                                const float* __restrict__ val, int64_t nrows, int64_t ncols,
                                                const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                const float* __restrict__ Z, float beta, float* __restrict__ ACC,
-                                               float acc_scale, const float* __restrict__ ainit = nullptr) {
+                                               float acc_scale, const float* __restrict__ ainit = nullptr,
+                                               const uint32_t* __restrict__ mask = nullptr, const int64_t* __restrict__ row_ptrs = nullptr) {
     const int lir = threadIdx.x % LPR;
     const int64_t gpb = 256 / LPR;
     const int64_t D4 = D >> 2;
@@ -152,10 +216,14 @@ __device__ __forceinline__ void spmm_rows_walk(int64_t blk, int64_t nblk, const 
     // rows are visited in descending-degree order (row_order): the 4 (or 2) rows a wave works on have similar lengths,
     // and the longest rows start first
     for (int64_t i = lo + bi * gpb + threadIdx.x / LPR; i < hi; i += nb * gpb) {
+        // (row_ptrs: crow[row], crow[row + 1] in WALKING order -- read beside row_order[i] instead of behind it: a short row's chain of memory
+        //  round trips is row id -> row pointers -> (col, val) -> X rows -> store, and a launch is ~7 rounds of such chains)
         const int64_t r = row_order ? row_order[i] : i;
-        const int64_t p0 = crow[r], p1 = crow[r + 1];
+        int64_t p0, p1;
+        if (row_ptrs) { p0 = row_ptrs[2 * i]; p1 = row_ptrs[2 * i + 1]; }     // (uniform)
+        else { p0 = crow[r]; p1 = crow[r + 1]; }
         for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
-            const float4 acc = spmm_row_range<LPR, NT>(col, val, X, ncols, D, c4, p0, p1, 1);
+            const float4 acc = spmm_row_contig<LPR, NT, MASK>(col, val, X, ncols, D, c4, p0, p1, mask);
             spmm_store<LPR, NT>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale, ainit);
         }
     }
@@ -176,13 +244,13 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__
 // group partials are combined in group order -> one partial row per chunk; spmm_csr_long_combine then adds a row's chunk
 // partials in chunk order and applies the epilogue.  Fixed order everywhere => bitwise reproducible.
 #define SP_CHUNK 2048
-template <int LPR>
+template <int LPR, bool MASK = false>
 __device__ __forceinline__ void spmm_long_chunks(float4* part, int64_t first_chunk, int64_t chunk_stride,
                                                  const int64_t* __restrict__ row_order, const int32_t* __restrict__ chunk_row,
                                                  const int64_t* __restrict__ chunk_ptr, int64_t nchunks,
                                                  const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
                                                  const float* __restrict__ val, int64_t ncols, const float* __restrict__ X,
-                                                 int64_t D, float* __restrict__ partial) {
+                                                 int64_t D, float* __restrict__ partial, const uint32_t* __restrict__ mask = nullptr) {
     const int lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     constexpr int G = 256 / LPR;
     const int64_t D4 = D >> 2;
@@ -192,7 +260,7 @@ __device__ __forceinline__ void spmm_long_chunks(float4* part, int64_t first_chu
         const int64_t p0 = crow[r] + (ch - chunk_ptr[li]) * SP_CHUNK;
         const int64_t p1 = (p0 + SP_CHUNK < crow[r + 1]) ? p0 + SP_CHUNK : crow[r + 1];
         for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
-            part[threadIdx.x] = spmm_row_range<LPR>(col, val, X, ncols, D, c4, p0 + grp, p1, G);
+            part[threadIdx.x] = spmm_row_range<LPR, false, MASK>(col, val, X, ncols, D, c4, p0 + grp, p1, G, mask);
             __syncthreads();
             if (grp == 0) {
                 float4 acc = part[lir];
@@ -220,7 +288,7 @@ __global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__
 // ONE launch for the long rows' chunks AND the short rows (round 6): the first nch8 workgroups (nchunks rounded up to a multiple of 8, so that
 // blockIdx % 8 -- the XCD label -- of the row walkers is unchanged) each take a chunk, the rest walk the short rows.  As launches of their own the
 // chunk kernel's 459 workgroups (Yelp2018 shapes: 340 long rows) ran 22 us by themselves in front of the 100 us row walk, six times a step.
-template <int LPR, bool NT>
+template <int LPR, bool NT, bool MASK = false>
 __global__ __launch_bounds__(256) void spmm_csr_fused(const int32_t* __restrict__ chunk_row, const int64_t* __restrict__ chunk_ptr, int64_t nchunks,
                                                       int64_t nch8, float* __restrict__ partial,
                                                       const int64_t* __restrict__ row_order, int64_t first, int64_t split, int k0,
@@ -228,11 +296,12 @@ __global__ __launch_bounds__(256) void spmm_csr_fused(const int32_t* __restrict_
                                                       const float* __restrict__ val, int64_t nrows, int64_t ncols,
                                                       const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                       const float* __restrict__ Z, float beta, float* __restrict__ ACC,
-                                                      float acc_scale, int acc_init, int* __restrict__ arrived) {
+                                                      float acc_scale, int acc_init, int* __restrict__ arrived,
+                                                      const uint32_t* __restrict__ mask, const int64_t* __restrict__ row_ptrs) {
     __shared__ float4 part[256];
     __shared__ int s_last;
     if ((int64_t)blockIdx.x < nch8) {
-        spmm_long_chunks<LPR>(part, blockIdx.x, nch8, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial);
+        spmm_long_chunks<LPR, MASK>(part, blockIdx.x, nch8, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial, mask);
         // `arrived` (a zeroed word per long row): the workgroup that brings a row's LAST chunk adds the row's chunk partials -- in chunk order,
         // whoever it is: the same sum -- and applies the epilogue; spmm_csr_long_combine, a launch of 6 us behind every propagation (six a
         // LightGCN step), is then not needed.  The others' partials come through their L2s' write-backs (release) and coherent loads here.
@@ -265,8 +334,8 @@ __global__ __launch_bounds__(256) void spmm_csr_fused(const int32_t* __restrict_
         }
         return;
     }
-    spmm_rows_walk<LPR, NT>((int64_t)blockIdx.x - nch8, (int64_t)gridDim.x - nch8, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z,
-                            beta, ACC, acc_scale, acc_init ? X : nullptr);
+    spmm_rows_walk<LPR, NT, MASK>((int64_t)blockIdx.x - nch8, (int64_t)gridDim.x - nch8, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D,
+                                  Y, Z, beta, ACC, acc_scale, acc_init ? X : nullptr, mask, row_ptrs);
 }
 
 template <int LPR>
@@ -292,7 +361,8 @@ __global__ __launch_bounds__(256) void spmm_csr_long_combine(const int64_t* __re
 static int spmm_launch(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
                        const int64_t* row_order, int64_t nlong, int64_t split, int k0, int flags, const int32_t* chunk_row, const int64_t* chunk_ptr,
                        int64_t nchunks, const float* X, int64_t D, float* Y, const float* Z, float beta, float* ACC,
-                       float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream) {
+                       float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream, const uint32_t* mask = nullptr,
+                       const int64_t* row_ptrs = nullptr) {
     re_clear_error();
     if (nrows == 0) return RE_OK;
     if (!crow || !col || !val || !X || !Y || nrows < 0 || ncols <= 0 || D <= 0 || nlong < 0 || nlong > nrows) return RE_EINVAL;
@@ -320,8 +390,9 @@ static int spmm_launch(const int64_t* crow, const int64_t* col, const float* val
         if (fuse) {                                                                                                                 \
             unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536 - 4096);                                                \
             g = (g + 7u) & ~7u;                                                                                                     \
-            if (flags & 1) hipLaunchKernelGGL((spmm_csr_fused<LPRV, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived); \
-            else hipLaunchKernelGGL((spmm_csr_fused<LPRV, false>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived); \
+            if (mask) hipLaunchKernelGGL((spmm_csr_fused<LPRV, false, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs); \
+            else if (flags & 1) hipLaunchKernelGGL((spmm_csr_fused<LPRV, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs); \
+            else hipLaunchKernelGGL((spmm_csr_fused<LPRV, false>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs); \
         } else if (nrows > nlong) {                                                                                                 \
             unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536);                                                       \
             if (split > nlong) g = (g + 7u) & ~7u;                                                                                  \
@@ -354,6 +425,38 @@ extern "C" int re_spmm_csr_split(const int64_t* crow, const int64_t* col, const 
     if (split < 0 || split > nrows || (split > nlong && (!row_order || xcd_share < 1 || xcd_share > 7))) { re_clear_error(); return RE_EINVAL; }
     return spmm_launch(crow, col, val, nrows, ncols, row_order, nlong, split > nlong && split < nrows ? split : 0, xcd_share, flags, chunk_row,
                        chunk_ptr, nchunks, X, D, Y, Z, beta, ACC, acc_scale, ws, ws_bytes, stream);
+}
+
+// re_spmm_csr_split with a bit per row of X: 0 = the row is all zeros (it is then not fetched; the result is the unmasked one bit for bit),
+// and / or the rows' (crow[r], crow[r + 1]) pairs in row_order's order (row_ptrs [nrows][2], optional).  Both apply where the plan has long
+// rows (the fused launch); otherwise they are ignored.
+extern "C" int re_spmm_csr_masked(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
+                                  const int64_t* row_order, int64_t nlong, int64_t split, int32_t xcd_share, int32_t flags,
+                                  const int32_t* chunk_row, const int64_t* chunk_ptr, int64_t nchunks, const float* X, int64_t D, float* Y,
+                                  const float* Z, float beta, float* ACC, float acc_scale, const uint32_t* src_mask, const int64_t* row_ptrs,
+                                  void* ws, size_t ws_bytes, re_stream_t stream) {
+    if (split < 0 || split > nrows || (split > nlong && (!row_order || xcd_share < 1 || xcd_share > 7))) { re_clear_error(); return RE_EINVAL; }
+    return spmm_launch(crow, col, val, nrows, ncols, row_order, nlong, split > nlong && split < nrows ? split : 0, xcd_share, flags, chunk_row,
+                       chunk_ptr, nchunks, X, D, Y, Z, beta, ACC, acc_scale, ws, ws_bytes, stream, src_mask, row_ptrs);
+}
+
+// mask[i >> 5] bit (i & 31) = 1 for every i in rows[0 .. n) inside [0, nbits), 0 elsewhere: which rows of a scatter's dense output can be
+// non-zero.  One workgroup (the mask of 122 915 rows is 15 KB): clear, barrier, OR.
+__global__ __launch_bounds__(1024) void row_mask_k(const int64_t* __restrict__ rows, int64_t n, int64_t nbits, uint32_t* __restrict__ mask) {
+    const int64_t nw = (nbits + 31) >> 5;
+    for (int64_t i = threadIdx.x; i < nw; i += 1024) mask[i] = 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t r = rows[i];
+        if (r >= 0 && r < nbits) atomicOr(mask + (r >> 5), 1u << (r & 31));
+    }
+}
+extern "C" int re_row_mask(const int64_t* rows, int64_t n, int64_t nbits, uint32_t* mask, re_stream_t stream) {
+    re_clear_error();
+    if (!mask || nbits <= 0 || n < 0 || (n > 0 && !rows)) return RE_EINVAL;
+    hipLaunchKernelGGL(row_mask_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, rows, n, nbits, mask);
+    return re_launch_status();
 }
 
 // rows' squared L2 norms: out[0] = scale * sum_i ||W[idx[i], :]||^2   (BaseCriterion.regularize(.., "l2") = sum/2,

@@ -209,10 +209,13 @@ class LightGCNEngine(MFEngine):
         ops.scatter_plan(rows, D, self.n, ws)
         ops.scatter_apply(g.view(3 * B, D), self.n, self.davg, ws, scale=s, accumulate=False)   # d(avg)/(L+1), dense
         # g_L = davg ; g_l = Adj g_{l+1} + davg ; the last product lands in the gradient arena
+        # (the first product's input is that scatter: at most 3 B of its U + N rows are non-zero -- 5 % on the Yelp2018 shape -- and a propagation
+        #  is bound by the rows it gathers: the mask of the touched rows lets it skip the others; 109 -> ~25 us, same bits)
+        mask = ops.row_mask(rows, self.n, self.__dict__.setdefault("_mask", torch.empty((self.n + 31) // 32, dtype=torch.int32, device=self.device)))
         src, bufs = self.davg, (self.Ga, self.Xa)
         for l in range(self.L):
             dst = gX0 if l == self.L - 1 else bufs[l & 1]
-            self._spmm(src, dst, Z=self.davg, beta=1.0)
+            self._spmm(src, dst, Z=self.davg, beta=1.0, src_mask=mask if l == 0 else None)
             src = dst
         # + weight_decay * d(emb_loss): rows of the RAW tables, scaled by wd / B
         ops.scatter_apply(ops.gather_rows(self.X0, rows), self.n, gX0, ws, scale=self.wd / B, accumulate=True)

@@ -86,6 +86,9 @@ SIGNATURES = {
     "re_spmm_csr": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp, _sz, _vp]),
     "re_spmm_csr_split": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp, _sz,
                                  _vp]),
+    "re_spmm_csr_masked": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _vp, _vp,
+                                  _vp, _sz, _vp]),
+    "re_row_mask": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "re_rows_sqnorm_workspace_bytes": (_sz, []),
     "re_rows_sqnorm": (_i32, [_vp, _i64, _i64, _vp, _i64, _f32, _vp, _i32, _vp, _sz, _vp]),
     "re_rank_metrics": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

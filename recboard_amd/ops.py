@@ -962,6 +962,8 @@ class SpmmPlan:
         self.chunk_ptr[1:] = torch.cumsum(nch, 0)
         self.nchunks = int(self.chunk_ptr[-1]) if self.nlong else 0
         self.chunk_row = torch.repeat_interleave(torch.arange(self.nlong, device=crow.device, dtype=torch.int32), nch).contiguous()
+        # the rows' (first, end) positions in walking order: read beside the row id instead of behind it (re_spmm_csr_masked: row_ptrs)
+        self.row_ptrs = torch.stack([crow[self.row_order], crow[self.row_order + 1]], 1).contiguous() if self.nlong else None
         # workspace: the long rows' chunk partials [nchunks, D] | (16-byte aligned) one int32 per long row -- how many of its chunks have arrived
         # in the running launch (flags & 2: the workgroup with a row's last chunk adds the partials inside the launch; zero between launches)
         # (flags & 2 is OFF: measured SLOWER on the Yelp2018 shape -- 130 us per propagation against 109: 459 release fences, each a write-back of
@@ -979,9 +981,19 @@ def spmm_plan(crow: torch.Tensor, D: int = 64, split_row: int = 0, nt: bool = Fa
     return SpmmPlan(crow, D, split_row, nt)
 
 
-def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0, acc_init=False):
+def row_mask(rows, nbits, out=None):
+    """-> int32 words, bit i set iff i occurs in rows (re_row_mask): which rows of a scatter's dense output can be non-zero."""
+    _req(rows, torch.int64, "rows")
+    out = out if out is not None else torch.empty((int(nbits) + 31) // 32, dtype=torch.int32, device=rows.device)
+    _req(out, torch.int32, "out")
+    lib.check(lib.load().re_row_mask(_p(rows), rows.numel(), int(nbits), _p(out), _stream()), "re_row_mask")
+    return out
+
+
+def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0, acc_init=False, src_mask=None):
     """out = A @ X (+ beta * Z); acc += acc_scale * out  (re_spmm_csr).  plan = spmm_plan(crow, D).
-    acc_init (square adjacency): acc = acc_scale * (X + out) instead -- the running sum starts with this product's own input."""
+    acc_init (square adjacency): acc = acc_scale * (X + out) instead -- the running sum starts with this product's own input.
+    src_mask (row_mask): a bit per row of X, 0 = the row is all zeros and is skipped."""
     for t, nme in ((crow, "crow"), (col, "col")):
         _req(t, torch.int64, nme)
     for t, nme in ((val, "val"), (X, "X"), (out, "out")):
@@ -991,6 +1003,17 @@ def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale
     if plan.ws.numel() < plan._ws_floats(D):
         plan.ws = torch.zeros(plan._ws_floats(D), dtype=torch.float32, device=X.device)
     flags = int(getattr(plan, "flags", 0)) | (4 if acc_init and acc is not None else 0)
+    row_ptrs = getattr(plan, "row_ptrs", None)
+    if src_mask is not None or row_ptrs is not None:     # (src_mask: rows of X with a zero bit are all zeros: not fetched; same bits as without)
+        if src_mask is not None:
+            _req(src_mask, torch.int32, "src_mask")
+            if src_mask.numel() * 32 < X.shape[0]:
+                raise ValueError("recengine: src_mask needs a bit per row of X")
+        lib.check(lib.load().re_spmm_csr_masked(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(plan.row_order), plan.nlong, int(plan.split),
+                                                int(plan.xcd_share), flags, _p(plan.chunk_row), _p(plan.chunk_ptr), plan.nchunks, _p(X), D,
+                                                _p(out), _p(Z), float(beta), _p(acc), float(acc_scale), _p(src_mask), _p(row_ptrs), _p(plan.ws),
+                                                plan.ws.numel() * 4, _stream()), "re_spmm_csr_masked")
+        return out
     if getattr(plan, "split", 0) or flags:
         lib.check(lib.load().re_spmm_csr_split(_p(crow), _p(col), _p(val), nrows, X.shape[0], _p(plan.row_order), plan.nlong, int(plan.split),
                                                int(plan.xcd_share), flags, _p(plan.chunk_row), _p(plan.chunk_ptr), plan.nchunks, _p(X), D,

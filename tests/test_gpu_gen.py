@@ -120,6 +120,18 @@ def test_spmm_csr_vs_oracle_with_long_rows(ops, n, D, avg_deg, hot):
     a2 = torch.full((n, D), 7.0, device="cuda")
     ops.spmm_csr(cr, co, va, plan, dev(X), out2, acc=a2, acc_scale=0.25, acc_init=True)
     assert torch.equal(a1, a2)
+    # a source-row mask (re_spmm_csr_masked): X with most rows zero, the mask naming the others -- the unmasked result, bit for bit
+    if hot:
+        keep = torch.from_numpy(rng.choice(n, max(n // 20, 3), replace=False)).cuda()
+        Xs = torch.zeros(n, D, device="cuda")
+        Xs[keep] = dev(X)[keep]
+        full, masked = torch.empty_like(out), torch.empty_like(out)
+        ops.spmm_csr(cr, co, va, plan, Xs, full, Z=dev(Z), beta=0.5)
+        ops.spmm_csr(cr, co, va, plan, Xs, masked, Z=dev(Z), beta=0.5, src_mask=ops.row_mask(keep, n))
+        assert torch.equal(full, masked)
+        m = ops.row_mask(torch.tensor([0, 31, 32, n - 1, n + 5, -1], device="cuda"), n).cpu().numpy().view(np.uint32)
+        bits = np.unpackbits(m.view(np.uint8), bitorder="little")[:n]
+        assert bits.sum() == 4 and bits[0] and bits[31] and bits[32] and bits[n - 1]
     # flags & 2 (the long rows' chunks combined inside the launch: measured slower on the LightGCN shape, off by default, kept as a switch):
     # the same bits, twice in a row (the arrival counters return to zero)
     if hot:
