@@ -82,8 +82,9 @@ int re_sasrec_embed_bwd(float* gx, const int64_t* seq, int64_t B, int64_t S, int
  *   re_scatter_plan   -- the index half: stable sort of (destination row, position) into ws; depends on idx only, so a
  *                        training step can run it on a second stream while the gradient rows are still being produced.
  *                        Optionally zero-fills `zero_fill[0:zero_floats]` (the table the apply step accumulates into).
- *   re_scatter_apply  -- the data half: segmented sum of the rows of g in sorted order into dW (accumulate != 0: dW += ...;
- *                        else dW is zero-filled first).  Must follow a re_scatter_plan with the same (n, D, R, ws).
+ *   re_scatter_apply  -- the data half: segmented sum of the rows of g in sorted order into dW (accumulate = 1: dW += ...; 0: dW is
+ *                        zero-filled first; 2: only the rows that occur are written -- assigned -- and the others keep their contents).
+ *                        Must follow a re_scatter_plan with the same (n, D, R, ws).
  * plan followed by apply(accumulate = 1) on a zero-filled table equals re_scatter_add_rows(accumulate = 0). */
 int re_scatter_plan(const int64_t* idx, int64_t n, int64_t D, int64_t R, int64_t padding_idx, float* zero_fill,
                     int64_t zero_floats, void* ws, size_t ws_bytes, re_stream_t stream);
@@ -512,8 +513,10 @@ int re_spmm_csr_split(const int64_t* crow, const int64_t* col, const float* val,
                       const float* Z, float beta, float* ACC, float acc_scale, void* ws, size_t ws_bytes, re_stream_t stream);
 /* re_spmm_csr_split with a bit per row of X (src_mask[i >> 5] bit i & 31; NULL: none): 0 = that row of X is all zeros and is not fetched --
  * the product of a matrix with mostly-zero rows (the first propagation of LightGCN's backward pass: the scatter of 3 B gradient rows into
- * 122 915) gathers only what can contribute.  Adding exact zeros changes no sum: results are the unmasked ones bit for bit.  The mask is
- * used where the plan has long rows (nlong > 0: the fused launch), ignored otherwise.  re_row_mask builds it from the scatter's row list.
+ * 122 915) gathers only what can contribute.  Adding exact zeros changes no sum: results are the unmasked ones bit for bit, and the masked-out
+ * rows are never read: the caller may leave them unwritten (re_scatter_apply accumulate = 2).  re_row_mask builds the mask from the scatter's
+ * row list.
+ * flags & 8: the mask also names Z's non-zero rows (a row of Z with a zero bit is not read); flags & 16: the mask is for Z only.
  * row_ptrs (optional, [nrows][2]): crow[row_order[i]], crow[row_order[i] + 1] -- the row pointers in WALKING order, fetched beside the row id
  * instead of behind it (one dependent memory round trip less per row). */
 int re_spmm_csr_masked(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,

@@ -668,6 +668,7 @@ extern "C" int re_scatter_apply(const float* g, int64_t n, int64_t D, int64_t R,
     if (!dW || R <= 0 || D <= 0 || n < 0) return RE_EINVAL;
     if (R >= 0xFFFFFFFEll || n >= 0xFFFFFFFFll) return RE_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (accumulate < 0 || accumulate > 2) return RE_EINVAL;
     if (n == 0) {
         if (!accumulate && re_zero_async(dW, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
         return RE_OK;
@@ -675,6 +676,9 @@ extern "C" int re_scatter_apply(const float* g, int64_t n, int64_t D, int64_t R,
     if (!g || !ws) return RE_EINVAL;
     ScatterWs w = scatter_ws_layout(ws, n, D);
     if (ws_bytes < w.bytes) return RE_EWORKSPACE;
+    // accumulate: 0 = dW is the scatter's dense result (zero-filled first); 1 = added to dW; 2 = ONLY the rows that occur are written (assigned),
+    // the others keep what they hold -- for a consumer that knows which rows those are (re_row_mask + re_spmm_csr_masked: a 31 MB fill less)
+    if (accumulate == 2) { scatter_reduce(g, n, D, R, scale, dW, 0, w, s); return re_launch_status(); }
     if (!accumulate && re_zero_async(dW, (size_t)R * D * sizeof(float), s) != hipSuccess) return RE_ELAUNCH;
     scatter_reduce(g, n, D, R, scale, dW, 1, w, s);
     return re_launch_status();

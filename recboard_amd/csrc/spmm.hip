@@ -174,8 +174,10 @@ __device__ __forceinline__ float4 spmm_row_contig(const int64_t* __restrict__ co
 template <int LPR, bool NT = false>
 __device__ __forceinline__ void spmm_store(float4 acc, int64_t r, int64_t D, int64_t c4, float* __restrict__ Y,
                                            const float* __restrict__ Z, float beta, float* __restrict__ ACC, float acc_scale,
-                                           const float* __restrict__ ainit = nullptr) {
-    if (Z) f4_axpy(acc, beta, sp_ld4<NT>(reinterpret_cast<const float4*>(Z + r * D) + c4));
+                                           const float* __restrict__ ainit = nullptr, const uint32_t* __restrict__ zmask = nullptr) {
+    // (zmask: a bit per row of Z, 0 = that row is all zeros and is not read -- LightGCN's backward pass adds the SAME 95 %-empty scatter to
+    //  all three products)
+    if (Z && (!zmask || ((zmask[r >> 5] >> (r & 31)) & 1u))) f4_axpy(acc, beta, sp_ld4<NT>(reinterpret_cast<const float4*>(Z + r * D) + c4));
     sp_st4<NT>(reinterpret_cast<float4*>(Y + r * D) + c4, acc);
     if (ACC) {
         // (ainit: the running sum STARTS here -- acc_scale x the row of `ainit` (the first propagation's own input: LightGCN's layer-0 term)
@@ -200,7 +202,8 @@ __device__ __forceinline__ void spmm_rows_walk(int64_t blk, int64_t nblk, const 
                                                const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                const float* __restrict__ Z, float beta, float* __restrict__ ACC,
                                                float acc_scale, const float* __restrict__ ainit = nullptr,
-                                               const uint32_t* __restrict__ mask = nullptr, const int64_t* __restrict__ row_ptrs = nullptr) {
+                                               const uint32_t* __restrict__ mask = nullptr, const int64_t* __restrict__ row_ptrs = nullptr,
+                                               const uint32_t* __restrict__ zmask = nullptr) {
     const int lir = threadIdx.x % LPR;
     const int64_t gpb = 256 / LPR;
     const int64_t D4 = D >> 2;
@@ -224,19 +227,20 @@ __device__ __forceinline__ void spmm_rows_walk(int64_t blk, int64_t nblk, const 
         else { p0 = crow[r]; p1 = crow[r + 1]; }
         for (int64_t c4 = lir; c4 < D4; c4 += LPR) {
             const float4 acc = spmm_row_contig<LPR, NT, MASK>(col, val, X, ncols, D, c4, p0, p1, mask);
-            spmm_store<LPR, NT>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale, ainit);
+            spmm_store<LPR, NT>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale, ainit, zmask);
         }
     }
 }
-template <int LPR, bool NT>
+template <int LPR, bool NT, bool MASK = false>
 __global__ __launch_bounds__(256) void spmm_csr_rows(const int64_t* __restrict__ row_order, int64_t first, int64_t split, int k0,
                                                      const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
                                                      const float* __restrict__ val, int64_t nrows, int64_t ncols,
                                                      const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                      const float* __restrict__ Z, float beta, float* __restrict__ ACC,
-                                                     float acc_scale, int acc_init) {
-    spmm_rows_walk<LPR, NT>(blockIdx.x, gridDim.x, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale,
-                            acc_init ? X : nullptr);
+                                                     float acc_scale, int acc_init, const uint32_t* __restrict__ mask,
+                                                     const uint32_t* __restrict__ zmask) {
+    spmm_rows_walk<LPR, NT, MASK>(blockIdx.x, gridDim.x, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale,
+                                  acc_init ? X : nullptr, mask, nullptr, zmask);
 }
 
 // long rows: one workgroup per CHUNK of SP_CHUNK non-zeros (a popular item can have tens of thousands of non-zeros: one
@@ -275,14 +279,14 @@ __device__ __forceinline__ void spmm_long_chunks(float4* part, int64_t first_chu
     }
 }
 
-template <int LPR>
+template <int LPR, bool MASK = false>
 __global__ __launch_bounds__(256) void spmm_csr_long(const int64_t* __restrict__ row_order, const int32_t* __restrict__ chunk_row,
                                                      const int64_t* __restrict__ chunk_ptr, int64_t nchunks,
                                                      const int64_t* __restrict__ crow, const int64_t* __restrict__ col,
                                                      const float* __restrict__ val, int64_t ncols, const float* __restrict__ X,
-                                                     int64_t D, float* __restrict__ partial) {
+                                                     int64_t D, float* __restrict__ partial, const uint32_t* __restrict__ mask) {
     __shared__ float4 part[256];
-    spmm_long_chunks<LPR>(part, blockIdx.x, gridDim.x, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial);
+    spmm_long_chunks<LPR, MASK>(part, blockIdx.x, gridDim.x, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial, mask);
 }
 
 // ONE launch for the long rows' chunks AND the short rows (round 6): the first nch8 workgroups (nchunks rounded up to a multiple of 8, so that
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(256) void spmm_csr_fused(const int32_t* __restrict_
                                                       const float* __restrict__ X, int64_t D, float* __restrict__ Y,
                                                       const float* __restrict__ Z, float beta, float* __restrict__ ACC,
                                                       float acc_scale, int acc_init, int* __restrict__ arrived,
-                                                      const uint32_t* __restrict__ mask, const int64_t* __restrict__ row_ptrs) {
+                                                      const uint32_t* __restrict__ mask, const int64_t* __restrict__ row_ptrs,
+                                                      const uint32_t* __restrict__ zmask) {
     __shared__ float4 part[256];
     __shared__ int s_last;
     if ((int64_t)blockIdx.x < nch8) {
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void spmm_csr_fused(const int32_t* __restrict_
             for (int64_t ch = chunk_ptr[li]; ch < chunk_ptr[li + 1]; ++ch)
                 acc += __hip_atomic_load(partial + ch * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // (spmm_store's arithmetic, a column at a time)
-            if (Z) acc = fmaf(beta, Z[r * D + c], acc);
+            if (Z && (!zmask || ((zmask[r >> 5] >> (r & 31)) & 1u))) acc = fmaf(beta, Z[r * D + c], acc);
             Y[r * D + c] = acc;
             if (ACC) {
                 float a = acc_init ? X[r * D + c] * acc_scale : ACC[r * D + c];
@@ -335,14 +340,15 @@ __global__ __launch_bounds__(256) void spmm_csr_fused(const int32_t* __restrict_
         return;
     }
     spmm_rows_walk<LPR, NT, MASK>((int64_t)blockIdx.x - nch8, (int64_t)gridDim.x - nch8, row_order, first, split, k0, crow, col, val, nrows, ncols, X, D,
-                                  Y, Z, beta, ACC, acc_scale, acc_init ? X : nullptr, mask, row_ptrs);
+                                  Y, Z, beta, ACC, acc_scale, acc_init ? X : nullptr, mask, row_ptrs, zmask);
 }
 
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_csr_long_combine(const int64_t* __restrict__ row_order, int64_t nlong,
                                                              const int64_t* __restrict__ chunk_ptr, const float* __restrict__ partial,
                                                              int64_t D, float* __restrict__ Y, const float* __restrict__ Z, float beta,
-                                                             float* __restrict__ ACC, float acc_scale, const float* __restrict__ ainit) {
+                                                             float* __restrict__ ACC, float acc_scale, const float* __restrict__ ainit,
+                                                             const uint32_t* __restrict__ zmask) {
     const int lir = threadIdx.x % LPR;
     const int64_t li = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (li >= nlong) return;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void spmm_csr_long_combine(const int64_t* __re
             const float4 q = reinterpret_cast<const float4*>(partial + ch * D)[c4];
             acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
         }
-        spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale, ainit);
+        spmm_store<LPR>(acc, r, D, c4, Y, Z, beta, ACC, acc_scale, ainit, zmask);
     }
 }
 
@@ -371,6 +377,9 @@ static int spmm_launch(const int64_t* crow, const int64_t* col, const float* val
     // behind the partials (zero before the first use; every call leaves them zero); 4 ACC starts at acc_scale * X[row] (square adjacency)
     const bool in_launch = (flags & 2) && nlong > 0;
     const int acc_init = (flags & 4) && ACC ? 1 : 0;
+    // 8: the mask also names Z's non-zero rows (rows with a zero bit are not read); 16: the mask is for Z only (X is fetched in full)
+    const uint32_t* zmask = (flags & 8) && mask && Z ? mask : (const uint32_t*)nullptr;
+    if (flags & 16) mask = nullptr;
     if (acc_init && nrows != ncols) return RE_EINVAL;
     const size_t part_bytes = re_align((size_t)nchunks * D * sizeof(float), 16);
     if (nlong > 0 && ws_bytes < (in_launch ? part_bytes + (size_t)nlong * sizeof(int) : (size_t)nchunks * D * sizeof(float))) return RE_EWORKSPACE;
@@ -386,20 +395,24 @@ static int spmm_launch(const int64_t* crow, const int64_t* col, const float* val
     do {                                                                                                                            \
         const int64_t nch8 = (nchunks + 7) & ~(int64_t)7;                                                                           \
         const bool fuse = nlong > 0 && nrows > nlong && nch8 <= 4096;                                                               \
-        if (nlong && !fuse) hipLaunchKernelGGL(spmm_csr_long<LPRV>, dim3(re_grid(nchunks, 1, 65536)), dim3(256), 0, s, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial); \
+        if (nlong && !fuse) {                                                                                                       \
+            if (mask) hipLaunchKernelGGL((spmm_csr_long<LPRV, true>), dim3(re_grid(nchunks, 1, 65536)), dim3(256), 0, s, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial, mask); \
+            else hipLaunchKernelGGL((spmm_csr_long<LPRV, false>), dim3(re_grid(nchunks, 1, 65536)), dim3(256), 0, s, row_order, chunk_row, chunk_ptr, nchunks, crow, col, val, ncols, X, D, partial, mask); \
+        }                                                                                                                           \
         if (fuse) {                                                                                                                 \
             unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536 - 4096);                                                \
             g = (g + 7u) & ~7u;                                                                                                     \
-            if (mask) hipLaunchKernelGGL((spmm_csr_fused<LPRV, false, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs); \
-            else if (flags & 1) hipLaunchKernelGGL((spmm_csr_fused<LPRV, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs); \
-            else hipLaunchKernelGGL((spmm_csr_fused<LPRV, false>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs); \
+            if (mask) hipLaunchKernelGGL((spmm_csr_fused<LPRV, false, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs, zmask); \
+            else if (flags & 1) hipLaunchKernelGGL((spmm_csr_fused<LPRV, true>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs, zmask); \
+            else hipLaunchKernelGGL((spmm_csr_fused<LPRV, false>), dim3(g + (unsigned)nch8), dim3(256), 0, s, chunk_row, chunk_ptr, nchunks, nch8, partial, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, arrived, mask, row_ptrs, zmask); \
         } else if (nrows > nlong) {                                                                                                 \
             unsigned g = (unsigned)re_grid(nrows - nlong, 256 / LPRV, 65536);                                                       \
             if (split > nlong) g = (g + 7u) & ~7u;                                                                                  \
-            if (flags & 1) hipLaunchKernelGGL((spmm_csr_rows<LPRV, true>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init); \
-            else hipLaunchKernelGGL((spmm_csr_rows<LPRV, false>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init); \
+            if (mask) hipLaunchKernelGGL((spmm_csr_rows<LPRV, false, true>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, mask, zmask); \
+            else if (flags & 1) hipLaunchKernelGGL((spmm_csr_rows<LPRV, true>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, mask, zmask); \
+            else hipLaunchKernelGGL((spmm_csr_rows<LPRV, false>), dim3(g), dim3(256), 0, s, row_order, nlong, split, k0, crow, col, val, nrows, ncols, X, D, Y, Z, beta, ACC, acc_scale, acc_init, mask, zmask); \
         }                                                                                                                           \
-        if (nlong && !(fuse && arrived)) hipLaunchKernelGGL(spmm_csr_long_combine<LPRV>, dim3((unsigned)re_cdiv(nlong, 256 / LPRV)), dim3(256), 0, s, row_order, nlong, chunk_ptr, partial, D, Y, Z, beta, ACC, acc_scale, ainit); \
+        if (nlong && !(fuse && arrived)) hipLaunchKernelGGL(spmm_csr_long_combine<LPRV>, dim3((unsigned)re_cdiv(nlong, 256 / LPRV)), dim3(256), 0, s, row_order, nlong, chunk_ptr, partial, D, Y, Z, beta, ACC, acc_scale, ainit, zmask); \
     } while (0)
     if ((D >> 2) >= 32) SP_LAUNCH(32); else SP_LAUNCH(16);
 #undef SP_LAUNCH
@@ -428,8 +441,8 @@ extern "C" int re_spmm_csr_split(const int64_t* crow, const int64_t* col, const 
 }
 
 // re_spmm_csr_split with a bit per row of X: 0 = the row is all zeros (it is then not fetched; the result is the unmasked one bit for bit),
-// and / or the rows' (crow[r], crow[r + 1]) pairs in row_order's order (row_ptrs [nrows][2], optional).  Both apply where the plan has long
-// rows (the fused launch); otherwise they are ignored.
+// and / or the rows' (crow[r], crow[r + 1]) pairs in row_order's order (row_ptrs [nrows][2], optional: used by the fused launch only).  The masks
+// are honoured by every form of the launch: a caller may leave the masked-out rows of X / Z unwritten.
 extern "C" int re_spmm_csr_masked(const int64_t* crow, const int64_t* col, const float* val, int64_t nrows, int64_t ncols,
                                   const int64_t* row_order, int64_t nlong, int64_t split, int32_t xcd_share, int32_t flags,
                                   const int32_t* chunk_row, const int64_t* chunk_ptr, int64_t nchunks, const float* X, int64_t D, float* Y,

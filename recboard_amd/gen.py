@@ -207,7 +207,9 @@ class LightGCNEngine(MFEngine):
         # both dense scatters of the step go to the same destination rows: ONE sort (re_scatter_plan), two segmented sums (re_scatter_apply)
         ws = ops.scatter_workspace(rows.numel(), D, self.n, rows.device)
         ops.scatter_plan(rows, D, self.n, ws)
-        ops.scatter_apply(g.view(3 * B, D), self.n, self.davg, ws, scale=s, accumulate=False)   # d(avg)/(L+1), dense
+        # d(avg)/(L+1): only the touched rows of davg are written -- every reader below goes by the mask of those rows (the first product's input
+        # rows and the three products' Z), so the other rows' contents never matter and the 31 MB zero fill is not needed
+        ops.scatter_apply(g.view(3 * B, D), self.n, self.davg, ws, scale=s, accumulate="rows")
         # g_L = davg ; g_l = Adj g_{l+1} + davg ; the last product lands in the gradient arena
         # (the first product's input is that scatter: at most 3 B of its U + N rows are non-zero -- 5 % on the Yelp2018 shape -- and a propagation
         #  is bound by the rows it gathers: the mask of the touched rows lets it skip the others; 109 -> ~25 us, same bits)
@@ -215,7 +217,7 @@ class LightGCNEngine(MFEngine):
         src, bufs = self.davg, (self.Ga, self.Xa)
         for l in range(self.L):
             dst = gX0 if l == self.L - 1 else bufs[l & 1]
-            self._spmm(src, dst, Z=self.davg, beta=1.0, src_mask=mask if l == 0 else None)
+            self._spmm(src, dst, Z=self.davg, beta=1.0, src_mask=mask if l == 0 else None, z_mask=mask)
             src = dst
         # + weight_decay * d(emb_loss): rows of the RAW tables, scaled by wd / B
         ops.scatter_apply(ops.gather_rows(self.X0, rows), self.n, gX0, ws, scale=self.wd / B, accumulate=True)

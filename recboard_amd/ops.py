@@ -181,10 +181,11 @@ def scatter_plan(idx, D, R, ws, padding_idx=-1, zero=None):
 
 
 def scatter_apply(g, R, out, ws, scale=1.0, accumulate=True):
-    """Data half of scatter_add_rows (re_scatter_apply): out (+)= segmented sum of g's rows in the order scatter_plan left in ws."""
+    """Data half of scatter_add_rows (re_scatter_apply): out (+)= segmented sum of g's rows in the order scatter_plan left in ws.
+    accumulate="rows": only the rows that occur are written (assigned); the others keep their contents (no zero fill)."""
     _req(g, torch.float32, "g"); _req(out, torch.float32, "out"); _req(ws, torch.uint8, "ws")
     n, D = g.shape
-    lib.check(lib.load().re_scatter_apply(_p(g), n, D, int(R), float(scale), _p(out), int(bool(accumulate)), _p(ws), ws.numel(),
+    lib.check(lib.load().re_scatter_apply(_p(g), n, D, int(R), float(scale), _p(out), 2 if accumulate == "rows" else int(bool(accumulate)), _p(ws), ws.numel(),
                                           _stream()), "re_scatter_apply")
     return out
 
@@ -990,10 +991,11 @@ def row_mask(rows, nbits, out=None):
     return out
 
 
-def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0, acc_init=False, src_mask=None):
+def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale=0.0, acc_init=False, src_mask=None, z_mask=None):
     """out = A @ X (+ beta * Z); acc += acc_scale * out  (re_spmm_csr).  plan = spmm_plan(crow, D).
     acc_init (square adjacency): acc = acc_scale * (X + out) instead -- the running sum starts with this product's own input.
-    src_mask (row_mask): a bit per row of X, 0 = the row is all zeros and is skipped."""
+    src_mask (row_mask): a bit per row of X, 0 = the row is all zeros and is skipped.  z_mask: the same for Z's rows (where both are given
+    they are ONE mask: Z and X the same kind of scatter)."""
     for t, nme in ((crow, "crow"), (col, "col")):
         _req(t, torch.int64, nme)
     for t, nme in ((val, "val"), (X, "X"), (out, "out")):
@@ -1004,6 +1006,11 @@ def spmm_csr(crow, col, val, plan, X, out, Z=None, beta=0.0, acc=None, acc_scale
         plan.ws = torch.zeros(plan._ws_floats(D), dtype=torch.float32, device=X.device)
     flags = int(getattr(plan, "flags", 0)) | (4 if acc_init and acc is not None else 0)
     row_ptrs = getattr(plan, "row_ptrs", None)
+    if z_mask is not None and Z is not None:
+        if src_mask is not None and src_mask.data_ptr() != z_mask.data_ptr():
+            raise ValueError("recengine: src_mask and z_mask must be the same mask")
+        flags |= 8 | (16 if src_mask is None else 0)
+        src_mask = z_mask
     if src_mask is not None or row_ptrs is not None:     # (src_mask: rows of X with a zero bit are all zeros: not fetched; same bits as without)
         if src_mask is not None:
             _req(src_mask, torch.int32, "src_mask")

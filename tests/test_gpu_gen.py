@@ -129,6 +129,15 @@ def test_spmm_csr_vs_oracle_with_long_rows(ops, n, D, avg_deg, hot):
         ops.spmm_csr(cr, co, va, plan, Xs, full, Z=dev(Z), beta=0.5)
         ops.spmm_csr(cr, co, va, plan, Xs, masked, Z=dev(Z), beta=0.5, src_mask=ops.row_mask(keep, n))
         assert torch.equal(full, masked)
+        # ... and the same mask for Z (a Z with the same empty rows), alone (flags 16) and together with X's
+        Zs = torch.zeros(n, D, device="cuda")
+        Zs[keep] = dev(Z)[keep]
+        km = ops.row_mask(keep, n)
+        ref_z, z_only, both = torch.empty_like(out), torch.empty_like(out), torch.empty_like(out)
+        ops.spmm_csr(cr, co, va, plan, Xs, ref_z, Z=Zs, beta=0.5)
+        ops.spmm_csr(cr, co, va, plan, Xs, z_only, Z=Zs, beta=0.5, z_mask=km)
+        ops.spmm_csr(cr, co, va, plan, Xs, both, Z=Zs, beta=0.5, src_mask=km, z_mask=km)
+        assert torch.equal(ref_z, z_only) and torch.equal(ref_z, both)
         m = ops.row_mask(torch.tensor([0, 31, 32, n - 1, n + 5, -1], device="cuda"), n).cpu().numpy().view(np.uint32)
         bits = np.unpackbits(m.view(np.uint8), bitorder="little")[:n]
         assert bits.sum() == 4 and bits[0] and bits[31] and bits[32] and bits[n - 1]
@@ -141,6 +150,23 @@ def test_spmm_csr_vs_oracle_with_long_rows(ops, n, D, avg_deg, hot):
             out3, a3 = torch.empty_like(out), dev(acc0)
             ops.spmm_csr(cr, co, va, plan2, dev(X), out3, Z=dev(Z), beta=0.5, acc=a3, acc_scale=0.25)
             assert torch.equal(out3, out) and torch.equal(a3, acc)
+
+
+def test_scatter_apply_rows_only_mode(ops):
+    """re_scatter_apply accumulate = 2: the rows that occur are assigned their sums (the dense mode's values, bit for bit); the others keep
+    what they held."""
+    rng = np.random.default_rng(9)
+    n, D, R = 6000, 64, 5000
+    g, idx = dev(rng.standard_normal((n, D)).astype(np.float32)), dev(rng.integers(0, R, n))
+    ws = ops.scatter_workspace(n, D, R, g.device)
+    ops.scatter_plan(idx, D, R, ws)
+    dense = torch.empty(R, D, device="cuda")
+    ops.scatter_apply(g, R, dense, ws, scale=0.5, accumulate=False)
+    out = torch.full((R, D), 7.0, device="cuda")
+    ops.scatter_apply(g, R, out, ws, scale=0.5, accumulate="rows")
+    touched = torch.zeros(R, dtype=torch.bool, device="cuda")
+    touched[idx] = True
+    assert torch.equal(out[touched], dense[touched]) and bool((out[~touched] == 7.0).all()) and int((~touched).sum()) > 100
 
 
 def test_scatter_add_accumulate_mode(ops):
