@@ -1552,7 +1552,11 @@ __global__ __launch_bounds__(256) void score_rescan_k(const int* __restrict__ nf
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void score_topk_merge_x(const float* __restrict__ part_vals, const int* __restrict__ part_idx,
+#ifndef MX_WAVES64
+#define MX_WAVES64 8     // waves per SIMD the D = 64 merge is compiled for: 64 registers and 76 B of scratch instead of 86 and none -- 5 -> 8 resident
+                         // waves per SIMD; the launch is a chain of dependent steps per user: 0.4038 -> 0.3998 ms per call (6: 0.4066; scripts/score_ab.py)
+#endif
+__global__ __launch_bounds__(256, D == 64 ? MX_WAVES64 : 4) void score_topk_merge_x(const float* __restrict__ part_vals, const int* __restrict__ part_idx,
                                                           const float* __restrict__ part_T,
                                                           int maxseg, int64_t B, int64_t N, int K, int C, int64_t nst, int64_t upw,
                                                           const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
