@@ -697,8 +697,11 @@ int re_mlp_head_bwd(const float* dlogit, const float* h, const float* w, int64_t
 int re_gemm_f32_gated(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* act, const float* z, const float* stats, float drop_scale, float* part,
                       re_stream_t stream);
+/* (head_ws, loss, dsum, dsum2: optional -- the workspace of a re_mlp_head_fwd call made with labels and loss == NULL, whose per-workgroup
+ *  (loss, sum dlogit) partials this launch then adds in order: the criterion's second launch is saved.  NULL: nothing of the kind.) */
 int re_mlp_head_bwd_gated(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, const float* z, const float* stats,
-                          float drop_p, float* g, float* part, size_t part_bytes, int* chunks_out, re_stream_t stream);
+                          float drop_p, float* g, float* part, size_t part_bytes, int* chunks_out, const void* head_ws, float* loss,
+                          float* dsum, float* dsum2, re_stream_t stream);
 int re_bn_bwd_apply(float* g, const float* z, int64_t M, int64_t N, const float* gamma, const float* stats, const float* part, int chunks,
                     int pstride, float* dgamma, float* dbeta, float* extra_out, re_stream_t stream);
 

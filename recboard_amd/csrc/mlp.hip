@@ -542,13 +542,13 @@ extern "C" int re_mlp_head_fwd(const float* h, int64_t M, int64_t K, const float
                                re_stream_t stream) {
     re_clear_error();
     if (!h || !w || !b || !logits || M <= 0 || K <= 0) return RE_EINVAL;
-    if (labels && (!loss || !dlogit)) return RE_EINVAL;
+    if (labels && !dlogit) return RE_EINVAL;      // (loss == NULL with labels: the per-workgroup partials stay in ws -- re_mlp_head_bwd_gated sums them)
     if ((K & 3) || ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(w)) & 15u)) return RE_EUNSUPPORTED;
     if (labels && (!ws || ws_bytes < re_mlp_head_workspace_bytes(M, K))) return RE_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)re_cdiv(M, HD_ROWS);
     hipLaunchKernelGGL(mlp_head_fwd_k, dim3(nb), dim3(256), 0, s, h, M, K, w, b, fm_lr, labels, logits, dlogit, (float*)ws);
-    if (labels) hipLaunchKernelGGL(mlp_head_final_k, dim3(1), dim3(64), 0, s, (const float*)ws, nb, 1.0f / (float)M, loss, dsum, dsum2);
+    if (labels && loss) hipLaunchKernelGGL(mlp_head_final_k, dim3(1), dim3(64), 0, s, (const float*)ws, nb, 1.0f / (float)M, loss, dsum, dsum2);
     return re_launch_status();
 }
 extern "C" int re_mlp_head_bwd(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, float* da, float* dW, void* ws,
@@ -568,8 +568,18 @@ extern "C" int re_mlp_head_bwd(const float* dlogit, const float* h, const float*
 // sum dlogit h) -- re_bn_bwd_apply (pstride 3, extra_out = dW) finishes both.
 __global__ __launch_bounds__(256) void mlp_head_bwd_gated_k(const float* __restrict__ dlogit, const float* __restrict__ h, const float* __restrict__ w,
                                                             const float* __restrict__ z, const float* __restrict__ stats, float drop_scale,
-                                                            int64_t M, int64_t K, float* __restrict__ g, float* __restrict__ part) {
+                                                            int64_t M, int64_t K, float* __restrict__ g, float* __restrict__ part,
+                                                            const float* __restrict__ fin_partial, int fin_nb, float fin_inv,
+                                                            float* __restrict__ loss, float* __restrict__ dsum, float* __restrict__ dsum2) {
     __shared__ float r0[256], r1[256], r2[256];
+    // (the criterion's second launch -- mlp_head_final_k: the forward's per-workgroup (loss, sum dlogit) partials added in order -- rides here,
+    //  in the first wave of the first workgroup: the same arithmetic, one dispatch less between the forward's head and its backward)
+    if (fin_partial && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        float a = 0.f, gs = 0.f;
+        for (int i = threadIdx.x; i < fin_nb; i += 64) { a += fin_partial[2 * i]; gs += fin_partial[2 * i + 1]; }
+        a = re_wave_sum(a); gs = re_wave_sum(gs);
+        if (threadIdx.x == 0) { loss[0] = a * fin_inv; if (dsum) dsum[0] = gs; if (dsum2) dsum2[0] = gs; }
+    }
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 64 + c;
     const int64_t rpc = (M + gridDim.y - 1) / gridDim.y;
@@ -605,13 +615,15 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_gated_k(const float* __restr
 // -> *chunks_out = the number of row chunks in `part` (part: >= re_mlp_head_workspace_bytes(M, K) bytes)
 extern "C" int re_mlp_head_bwd_gated(const float* dlogit, const float* h, const float* w, int64_t M, int64_t K, const float* z,
                                      const float* stats, float drop_p, float* g, float* part, size_t part_bytes, int* chunks_out,
-                                     re_stream_t stream) {
+                                     const void* head_ws, float* loss, float* dsum, float* dsum2, re_stream_t stream) {
     re_clear_error();
     if (!dlogit || !h || !w || !z || !stats || !g || !part || !chunks_out || M <= 0 || K <= 0 || drop_p < 0.f || drop_p >= 1.f) return RE_EINVAL;
+    if (head_ws && !loss) return RE_EINVAL;     // (head_ws: the workspace a re_mlp_head_fwd call with labels and loss == NULL left its partials in)
     if (part_bytes < re_mlp_head_workspace_bytes(M, K)) return RE_EWORKSPACE;
     const int ch = ml_chunks(M);
     hipLaunchKernelGGL(mlp_head_bwd_gated_k, dim3((unsigned)re_cdiv(K, 64), ch), dim3(256), 0, (hipStream_t)stream, dlogit, h, w, z, stats,
-                       drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, M, K, g, part);
+                       drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, M, K, g, part, (const float*)head_ws, (int)re_cdiv(M, HD_ROWS), 1.0f / (float)M, loss,
+                       dsum, dsum2);
     *chunks_out = ch;
     return re_launch_status();
 }

@@ -137,7 +137,7 @@ class DeepFMEngine:
         return (self.seed * 0x9E3779B1 + (self.step + 1) * 0x85EBCA77) & 0xFFFFFFFF
 
     # ---- forward: keeps what the backward needs in `tape`
-    def encode(self, x, seed_dev=None, labels=None):
+    def encode(self, x, seed_dev=None, labels=None, _defer_final=False):
         """-> (logits [B], tape).  DeepFM/main.py:201-209.  seed_dev: the dropout seed as a device word (captured steps).
         labels (training): the criterion runs in the last layer's launch; tape["loss" / "dlogit" / "dsum"] hold its results."""
         P = self.P
@@ -166,9 +166,12 @@ class DeepFMEngine:
         w_last = P[f"dnn.{self.nl}.weight"].reshape(-1)
         if labels is None:
             return ops.mlp_head_fwd(h, w_last, P[f"dnn.{self.nl}.bias"], fm_lr), tape
-        logits, tape["loss"], tape["dlogit"], tape["dsum"] = ops.mlp_head_fwd(h, w_last, P[f"dnn.{self.nl}.bias"], fm_lr,
-                                                                               labels.reshape(-1).to(torch.float32).contiguous(),
-                                                                               dsum=self.G[f"dnn.{self.nl}.bias"], dsum2=self.gbias)
+        # (_defer_final: the criterion's sums -- loss, the two biases' gradient -- are finished by the head's gated backward launch, which
+        #  forward_backward issues next: tape["final"] is what it needs for that)
+        r = ops.mlp_head_fwd(h, w_last, P[f"dnn.{self.nl}.bias"], fm_lr, labels.reshape(-1).to(torch.float32).contiguous(),
+                             dsum=self.G[f"dnn.{self.nl}.bias"], dsum2=self.gbias, defer_final=_defer_final)
+        logits, tape["loss"], tape["dlogit"], tape["dsum"] = r[:4]
+        tape["final"] = r[4] if _defer_final else None
         return logits, tape
 
     def recommend_from_pool(self, x):
@@ -181,8 +184,8 @@ class DeepFMEngine:
         P, G = self.P, self.G
         # last layer + criterion fused (re_mlp_head_fwd with labels: loss, dlogit and its sum -- the last bias's gradient); then dW = dl^T h and
         # da = dl w in one pass over h (re_mlp_head_bwd)
-        logits, tape = self.encode(x, seed_dev, labels=labels)
         nl = self.nl
+        logits, tape = self.encode(x, seed_dev, labels=labels, _defer_final=self.bn and self.training and nl > 0)
         loss, dlogit, dsum = tape["loss"], tape["dlogit"], tape["dsum"]
         p_drop = self.p_drop if self.training else 0.0
         w_last, gw_last = P[f"dnn.{nl}.weight"].reshape(-1), G[f"dnn.{nl}.weight"].reshape(-1)
@@ -192,7 +195,8 @@ class DeepFMEngine:
         fused = self.bn and self.training and nl > 0
         da = g = part = None
         if fused:
-            g, part = ops.mlp_head_bwd_gated(dlogit, tape["h_last"], w_last, tape["layers"][nl - 1][1], tape["layers"][nl - 1][3], p_drop)
+            g, part = ops.mlp_head_bwd_gated(dlogit, tape["h_last"], w_last, tape["layers"][nl - 1][1], tape["layers"][nl - 1][3], p_drop,
+                                             final=tape["final"])
         else:
             da = ops.mlp_head_bwd(dlogit, tape["h_last"], w_last, gw_last)
         for i in reversed(range(nl)):

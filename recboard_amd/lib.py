@@ -120,7 +120,7 @@ SIGNATURES = {
     "re_mlp_head_workspace_bytes": (_sz, [_i64, _i64]),
     "re_mlp_head_fwd": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "re_gemm_f32_gated": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp]),
-    "re_mlp_head_bwd_gated": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _sz, _vp, _vp]),
+    "re_mlp_head_bwd_gated": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "re_bn_bwd_apply": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "re_mlp_head_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "re_bn_relu_drop_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1408,9 +1408,11 @@ def bn_relu_drop_bwd(da, a, z, gamma, stats, drop_p, dgamma=None, dbeta=None):
     return dz, dgamma, dbeta
 
 
-def mlp_head_fwd(h, w, b, fm_lr=None, labels=None, dsum=None, dsum2=None):
+def mlp_head_fwd(h, w, b, fm_lr=None, labels=None, dsum=None, dsum2=None, defer_final=False):
     """DeepFM's Linear(., 1) + logit sum (+ criterion) (re_mlp_head_fwd): -> logits [M], and with labels (loss [1], dlogit [M], dsum [1]);
-    dsum2: a second place for sum dlogit (DeepFM's LR bias has the same gradient as the last layer's)."""
+    dsum2: a second place for sum dlogit (DeepFM's LR bias has the same gradient as the last layer's).
+    defer_final: loss / dsum / dsum2 are NOT written by this call -- a fifth return value, the workspace with the per-workgroup partials, goes
+    to mlp_head_bwd_gated(final=...), whose launch adds them (one dispatch less)."""
     _req(h, torch.float32, "h"); _req(w, torch.float32, "w"); _req(b, torch.float32, "b")
     M, K = h.shape
     dev = h.device
@@ -1424,8 +1426,10 @@ def mlp_head_fwd(h, w, b, fm_lr=None, labels=None, dsum=None, dsum2=None):
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     dl = torch.empty(M, dtype=torch.float32, device=dev)
     dsum = dsum if dsum is not None else torch.empty(1, dtype=torch.float32, device=dev)
-    lib.check(L.re_mlp_head_fwd(_p(h), M, K, _p(w), _p(b), _p(fm_lr), _p(labels), _p(logits), _p(loss), _p(dl), _p(dsum), _p(dsum2), _p(ws), ws.numel(),
-                                _stream()), "re_mlp_head_fwd")
+    lib.check(L.re_mlp_head_fwd(_p(h), M, K, _p(w), _p(b), _p(fm_lr), _p(labels), _p(logits), None if defer_final else _p(loss), _p(dl), _p(dsum),
+                                _p(dsum2), _p(ws), ws.numel(), _stream()), "re_mlp_head_fwd")
+    if defer_final:
+        return logits, loss, dl, dsum, (ws, loss, dsum, dsum2)
     return logits, loss, dl, dsum
 
 
@@ -1440,8 +1444,9 @@ def mlp_head_bwd(dlogit, h, w, dW):
     return da
 
 
-def mlp_head_bwd_gated(dlogit, h, w, z, stats, drop_p):
-    """The last Linear(., 1)'s backward with the gate of the block underneath (re_mlp_head_bwd_gated): -> (g [M, K], part [chunks, 3, K])."""
+def mlp_head_bwd_gated(dlogit, h, w, z, stats, drop_p, final=None):
+    """The last Linear(., 1)'s backward with the gate of the block underneath (re_mlp_head_bwd_gated): -> (g [M, K], part [chunks, 3, K]).
+    final: mlp_head_fwd(defer_final=True)'s fifth return value -- the criterion's loss / sum dlogit are finished by this launch."""
     _req(dlogit, torch.float32, "dlogit"); _req(h, torch.float32, "h"); _req(w, torch.float32, "w"); _req(z, torch.float32, "z"); _req(stats, torch.float32, "stats")
     M, K = h.shape
     g = torch.empty_like(h)
@@ -1449,8 +1454,9 @@ def mlp_head_bwd_gated(dlogit, h, w, z, stats, drop_p):
     nbytes = L.re_mlp_head_workspace_bytes(M, K)
     part = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=h.device)
     ch = ctypes.c_int(0)
+    fw, fl, fd, fd2 = final if final is not None else (None, None, None, None)
     lib.check(L.re_mlp_head_bwd_gated(_p(dlogit), _p(h), _p(w), M, K, _p(z), _p(stats), float(drop_p), _p(g), _p(part), part.numel() * 4, ctypes.byref(ch),
-                                      _stream()), "re_mlp_head_bwd_gated")
+                                      _p(fw), _p(fl), _p(fd), _p(fd2), _stream()), "re_mlp_head_bwd_gated")
     return g, part[:ch.value * 3 * K].view(ch.value, 3, K)
 
 

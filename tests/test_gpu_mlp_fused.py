@@ -109,6 +109,14 @@ def test_head_forward_backward_and_gated_backward(ops, M, K, p):
     dgm, dbt, dW2 = torch.empty(K).cuda(), torch.empty(K).cuda(), torch.empty(K).cuda()
     dz = ops.bn_bwd_apply(g, z, gamma, stats, part, dgm, dbt, extra_out=dW2)
     close(dz, want_dz); close(dgm, want_dg); close(dbt, want_db); close(dW2, dl.double() @ h.double())
+    # the criterion's sums deferred to the gated backward's launch (defer_final): the same bits as the two-launch forward, and the same g / part
+    ds3, ds4 = torch.full((1,), 9.0).cuda(), torch.full((1,), 9.0).cuda()
+    lg2, loss2, dl2, dsum2_, fin = ops.mlp_head_fwd(h, w, b, fm_lr, y, dsum=ds3, dsum2=ds4, defer_final=True)
+    assert torch.equal(lg2, logits) and torch.equal(dl2, dl) and float(ds3) == 9.0          # (not written yet)
+    g2, part2 = ops.mlp_head_bwd_gated(dl2, h, w, z, stats, p, final=fin)
+    g_ref, part_ref = ops.mlp_head_bwd_gated(dl, h, w, z, stats, p)       # (bn_bwd_apply above turned the first g into dz in place)
+    assert torch.equal(g2, g_ref) and torch.equal(part2, part_ref)
+    assert torch.equal(loss2, loss) and float(ds3) == float(ds1) and float(ds4) == float(ds1)
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 400, 100), (8192, 112, 64)])
