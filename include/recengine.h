@@ -645,6 +645,14 @@ size_t re_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
                 const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws,
                 size_t ws_bytes, re_stream_t stream);
+/* re_gemm_f32_slabs: re_gemm_f32 (beta = 0, no bias / relu) whose split-K reduction is left to the caller -- *nsplit_out > 1: the partial
+ * products are in ws ([nsplit][M][N], alpha not applied) and C is not written yet; == 1: C holds the product.  re_gemm_splitk_reduce_many
+ * finishes up to 8 such products in one launch (the slab-order sums of the one-product path: the same bits): DeepFM's three weight-gradient
+ * products of a step (DeepFM/main.py:103-124 backward). */
+int re_gemm_f32_slabs(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, void* ws, size_t ws_bytes, int32_t* nsplit_out, re_stream_t stream);
+int re_gemm_splitk_reduce_many(int32_t n, const float* const* slabs, const int32_t* nsplit, const int64_t* M, const int64_t* N,
+                               const float* alpha, float* const* C, const int64_t* ldc, re_stream_t stream);
 /* C = alpha op(A) op(B) + bias, and in the same launch the BatchNorm batch statistics of C's columns as per-64-row partials:
  * colstats [M / 64][2][N] = (mean, M2 = sum of squared deviations from it) of rows [64 b, 64 b + 64) -- `bn(linear(x))`
  * (DeepFM/main.py:119-124) without a second pass over the linear map's output; re_bn_relu_drop_fwd_pre takes them.

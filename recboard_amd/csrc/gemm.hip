@@ -614,10 +614,13 @@ extern "C" size_t re_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 256;
 }
 
+// nsplit_out (optional): the split-K partial products are LEFT in ws -- [*nsplit_out][M][N], alpha / beta / bias / relu not applied -- for a
+// later reduction of several products in one launch (re_gemm_splitk_reduce_many); *nsplit_out = 1: no split, C is written as usual.
 static int gemm_run(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
                     int64_t ldb, float beta, float* C, int64_t ldc, const float* bias, int relu, void* ws, size_t ws_bytes, float* colstats,
                     hipStream_t s, const float* gate_act = nullptr, const float* gate_z = nullptr, const float* gate_stats = nullptr,
-                    float gate_scale = 1.f) {
+                    float gate_scale = 1.f, int32_t* nsplit_out = nullptr) {
+    if (nsplit_out) *nsplit_out = 1;
     const GwPlan wp = gw_plan(transA, transB, M, N, K, A, lda, B, ldb, colstats != nullptr);
     if (colstats && !wp.use) return RE_EUNSUPPORTED;
     if (wp.use) {
@@ -632,6 +635,7 @@ static int gemm_run(int transA, int transB, int64_t M, int64_t N, int64_t K, flo
         else if (transA == 0) gw_launch<true, false>(wp, a, grid, s);
         else if (transB != 0) gw_launch<false, true>(wp, a, grid, s);
         else gw_launch<false, false>(wp, a, grid, s);
+        if (ns > 1 && nsplit_out) { *nsplit_out = ns; return re_launch_status(); }
         if (ns > 1)
             hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)re_cdiv(M * N, 256)), dim3(256), 0, s, (const float*)ws, ns, M, N, alpha, beta,
                                C, ldc, bias, relu);
@@ -646,10 +650,68 @@ static int gemm_run(int transA, int transB, int64_t M, int64_t N, int64_t K, flo
     dim3 grid((unsigned)re_cdiv(M, GM_BM), (unsigned)re_cdiv(N, GM_BN), (unsigned)ns);
     hipLaunchKernelGGL(gemm_f32_k, grid, dim3(256), 0, s, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, relu,
                        ns > 1 ? (float*)ws : (float*)nullptr, kchunk, vecA, vecB);
+    if (ns > 1 && nsplit_out) { *nsplit_out = ns; return re_launch_status(); }
     if (ns > 1)
         hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)re_cdiv(M * N, 256)), dim3(256), 0, s, (const float*)ws, ns, M, N, alpha, beta,
                            C, ldc, bias, relu);
     return re_launch_status();
+}
+
+// Several split-K products' reductions as ONE launch (DeepFM's three weight-gradient products of a step: 400 x 400 x 4096 and the like are
+// 16 slabs each; as launches of their own the reductions were three dispatches of ~5 us).  The sum of a product's slabs is the slab-order
+// one of gemm_splitk_reduce: the same bits.
+#define GR_MAX 8
+struct GrMany {
+    const float* slabs[GR_MAX];
+    float* C[GR_MAX];
+    long long MN[GR_MAX], N[GR_MAX], ldc[GR_MAX];
+    float alpha[GR_MAX];
+    int nsplit[GR_MAX];
+    unsigned first[GR_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_many_k(GrMany G) {
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < GR_MAX; ++i) q += (i < G.n && blockIdx.x >= G.first[i]) ? 1 : 0;
+    const long long e = (long long)(blockIdx.x - G.first[q]) * 256 + threadIdx.x;
+    if (e >= G.MN[q]) return;
+    float s = 0.f;
+    for (int z = 0; z < G.nsplit[q]; ++z) s += G.slabs[q][(long long)z * G.MN[q] + e];
+    const long long m = e / G.N[q], n = e - m * G.N[q];
+    G.C[q][m * G.ldc[q] + n] = G.alpha[q] * s;
+}
+extern "C" int re_gemm_splitk_reduce_many(int32_t n, const float* const* slabs, const int32_t* nsplit, const int64_t* M, const int64_t* N,
+                                          const float* alpha, float* const* C, const int64_t* ldc, re_stream_t stream) {
+    re_clear_error();
+    if (n == 0) return RE_OK;
+    if (n < 0 || n > GR_MAX || !slabs || !nsplit || !M || !N || !alpha || !C || !ldc) return RE_EINVAL;
+    GrMany G{};
+    G.n = n;
+    unsigned total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!slabs[i] || !C[i] || nsplit[i] < 1 || M[i] <= 0 || N[i] <= 0 || ldc[i] < N[i]) return RE_EINVAL;
+        G.slabs[i] = slabs[i]; G.C[i] = C[i]; G.MN[i] = M[i] * N[i]; G.N[i] = N[i]; G.ldc[i] = ldc[i]; G.alpha[i] = alpha[i]; G.nsplit[i] = nsplit[i];
+        G.first[i] = total;
+        total += (unsigned)re_cdiv(M[i] * N[i], 256);
+    }
+    G.first[n] = total;
+    hipLaunchKernelGGL(gemm_splitk_reduce_many_k, dim3(total), dim3(256), 0, (hipStream_t)stream, G);
+    return re_launch_status();
+}
+
+// re_gemm_f32 (beta = 0, no bias / relu) whose split-K reduction is left to the caller: *nsplit_out > 1: the partial products are in ws
+// ([nsplit][M][N], alpha not applied) and C is NOT written -- pass them to re_gemm_splitk_reduce_many; *nsplit_out == 1: C holds the product.
+extern "C" int re_gemm_f32_slabs(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                                 const float* B, int64_t ldb, float* C, int64_t ldc, void* ws, size_t ws_bytes, int32_t* nsplit_out,
+                                 re_stream_t stream) {
+    re_clear_error();
+    if (!nsplit_out) return RE_EINVAL;
+    *nsplit_out = 1;
+    if (M == 0 || N == 0) return RE_OK;
+    if (!A || !B || !C || M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) return RE_EINVAL;
+    return gemm_run(transA, transB, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, nullptr, 0, ws, ws_bytes, nullptr, (hipStream_t)stream, nullptr, nullptr,
+                    nullptr, 1.f, nsplit_out);
 }
 
 extern "C" int re_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,

@@ -194,6 +194,7 @@ class DeepFMEngine:
         # pass (re_bn_bwd_apply) finishes dgamma / dbeta and turns g into dz.  Otherwise: da, then re_bn_relu_drop_bwd's three launches.
         fused = self.bn and self.training and nl > 0
         da = g = part = None
+        pending = []
         if fused:
             g, part = ops.mlp_head_bwd_gated(dlogit, tape["h_last"], w_last, tape["layers"][nl - 1][1], tape["layers"][nl - 1][3], p_drop,
                                              final=tape["final"])
@@ -207,7 +208,7 @@ class DeepFMEngine:
             else:
                 dz, _, _ = ops.bn_relu_drop_bwd(da, a, z, P.get(f"dnn.{i}.bn.weight"), stats, p_drop,
                                                 dgamma=G.get(f"dnn.{i}.bn.weight"), dbeta=G[f"dnn.{i}.bn.bias"] if self.bn else G[f"dnn.{i}.linear.bias"])
-            ops.gemm(dz, h, transA=True, out=G[f"dnn.{i}.linear.weight"])             # dW = dz^T x
+            ops.gemm(dz, h, transA=True, out=G[f"dnn.{i}.linear.weight"], defer=pending)   # dW = dz^T x (split-K: reduced with the others below)
             # (the Linear bias in front of a BatchNorm: its gradient sum_m dz[m, :] is zero in exact arithmetic -- BatchNorm's backward removes the
             #  column mean -- and pure cancellation noise (~1e-10 of the model's gradient scale) as autograd computes it; it stays exactly zero
             #  here: the arena is zero-initialised and nothing writes these entries)
@@ -220,6 +221,7 @@ class DeepFMEngine:
                 g, part = r
             else:
                 g, da = None, ops.gemm(dz, W)
+        ops.gemm_reduce_many(pending)        # the weight-gradient products' split-K partials: one reduction launch for all layers
         gE, gL = ops.fm_bag_bwd(tape["E"], da, dlogit, self.F, self.D)
         if tape["keys_t"] is not None:
             # a field's B keys live in the field's own row range: a workgroup per slice of rows collects its keys and sums them per row

@@ -107,6 +107,8 @@ SIGNATURES = {
     "re_bce_logits": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "re_gemm_f32_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "re_gemm_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
+    "re_gemm_f32_slabs": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _sz, _vp, _vp]),
+    "re_gemm_splitk_reduce_many": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "re_ce_rows": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "re_ce_chunk_stats": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "re_ce_chunk_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),

@@ -1228,9 +1228,11 @@ def bce_logits(logits, labels):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, bias=None, relu=False):
+def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, bias=None, relu=False, defer=None):
     """out = alpha * op(A) @ op(B) + beta * out (+ bias) (+ ReLU) on the fp32 matrix cores (re_gemm_f32).
-    A, B: 2-D fp32 with unit inner stride (row stride = leading dimension)."""
+    A, B: 2-D fp32 with unit inner stride (row stride = leading dimension).
+    defer (a list; beta = 0, no bias / relu): a product that is computed split-K leaves its partial products there instead of reducing them --
+    `out` is then NOT complete until gemm_reduce_many(defer) has run (one launch for all the deferred products)."""
     for t, nme in ((A, "A"), (B, "B")):
         _req(t, torch.float32, nme, contiguous=False)
         if t.dim() != 2 or t.stride(1) != 1:
@@ -1248,9 +1250,32 @@ def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, bias=N
         _req(bias, torch.float32, "bias")
     L = lib.load()
     ws = _ws(L.re_gemm_f32_workspace_bytes(M, N, K), A.device)
+    if defer is not None and beta == 0.0 and bias is None and not relu and len(defer) < 8:
+        ns = ctypes.c_int32(1)
+        lib.check(L.re_gemm_f32_slabs(int(transA), int(transB), M, N, K, float(alpha), _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0),
+                                      _p(ws), ws.numel(), ctypes.byref(ns), _stream()), "re_gemm_f32_slabs")
+        if ns.value > 1:
+            defer.append((ws, ns.value, M, N, float(alpha), out))
+        return out
     lib.check(L.re_gemm_f32(int(transA), int(transB), M, N, K, float(alpha), _p(A), A.stride(0), _p(B), B.stride(0), float(beta),
                             _p(out), out.stride(0), _p(bias), int(relu), _p(ws), ws.numel(), _stream()), "re_gemm_f32")
     return out
+
+
+def gemm_reduce_many(pending):
+    """Finishes the products gemm(..., defer=pending) left as split-K partials: one launch (re_gemm_splitk_reduce_many)."""
+    n = len(pending)
+    if n == 0:
+        return
+    slabs = (ctypes.c_void_p * n)(*[_note(p[0]) for p in pending])
+    ns = (ctypes.c_int32 * n)(*[p[1] for p in pending])
+    Ms = (ctypes.c_int64 * n)(*[p[2] for p in pending])
+    Ns = (ctypes.c_int64 * n)(*[p[3] for p in pending])
+    al = (ctypes.c_float * n)(*[p[4] for p in pending])
+    Cs = (ctypes.c_void_p * n)(*[_note(p[5]) for p in pending])
+    ld = (ctypes.c_int64 * n)(*[p[5].stride(0) for p in pending])
+    lib.check(lib.load().re_gemm_splitk_reduce_many(n, slabs, ns, Ms, Ns, al, Cs, ld, _stream()), "re_gemm_splitk_reduce_many")
+    del pending[:]
 
 
 def gemm_colstats(A, B, transB=True, bias=None):

@@ -89,3 +89,19 @@ def test_gemm_colstats_are_the_batchnorm_statistics_of_the_output(ops):
     torch.testing.assert_close(st1[:N].cpu().double(), full.mean(0), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(st1[N:].cpu().double(), 1.0 / torch.sqrt(full.var(0, unbiased=False) + 1e-5), rtol=1e-4, atol=1e-5)
     assert ops.gemm_colstats(x[:100], W, True, b) is None          # (M not a multiple of 64: the caller takes the two-pass form)
+
+
+def test_deferred_split_k_reductions_give_the_same_bits(ops):
+    """gemm(..., defer=pending) + gemm_reduce_many(pending) (re_gemm_f32_slabs + re_gemm_splitk_reduce_many: DeepFM's three weight-gradient
+    products reduced by one launch) against the product that reduces itself: identical; a product that is not split is complete at once."""
+    g = torch.Generator().manual_seed(4)
+    pending, outs, refs = [], [], []
+    for (M, N, K) in ((400, 400, 4096), (400, 100, 4096), (400, 400, 4096), (64, 64, 128)):
+        A, B = torch.randn(K, M, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+        refs.append(ops.gemm(A, B, transA=True, alpha=0.5))
+        out = torch.full((M, N), 7.0).cuda()
+        ops.gemm(A, B, transA=True, alpha=0.5, out=out, defer=pending)
+        outs.append(out)
+    assert len(pending) == 3 and torch.equal(outs[3], refs[3])          # (the small one is not split: complete at once)
+    ops.gemm_reduce_many(pending)
+    assert pending == [] and all(torch.equal(o, r) for o, r in zip(outs, refs))
