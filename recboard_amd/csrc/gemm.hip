@@ -547,6 +547,9 @@ __global__ __launch_bounds__(256) void gemm_wide_k(const GwArgs a) {
 
 // Which form runs a product: the wide one when its 16-byte loads are legal and its grid fills the chip at least as well.
 struct GwPlan { int use, wm, tt, cb, nt_base, nt_rem, nsplit; };
+#ifndef GW_TT4_SLOTS
+#define GW_TT4_SLOTS 512
+#endif
 static GwPlan gw_plan(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                       bool want_stats) {
     GwPlan p{0, 4, 8, 1, 0, 0, 1};
@@ -569,7 +572,8 @@ static GwPlan gw_plan(int transA, int transB, int64_t M, int64_t N, int64_t K, c
             if (s > 64) s = 64;
             ns = s < 1 ? 1 : (int)s;
         }
-        const double rounds = (double)re_cdiv(mb * cb * ns, 256);
+        // (the 64 x 64 tile form -- TT = 4: 140 - 168 registers, 64 KB of LDS -- fits two workgroups on a CU: 512 of them are one round)
+        const double rounds = (double)re_cdiv(mb * cb * ns, (wm == 4 && tt == 4) ? GW_TT4_SLOTS : 256);
         const double cost = rounds * per_wave * (double)re_cdiv(re_cdiv(K, ns), GW_BK) + (ns > 1 ? 3.0 : 0.0) + (wm == 1 ? 0.5 : 0.0);
         if (cost < best) {
             best = cost;
