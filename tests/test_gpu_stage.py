@@ -70,3 +70,32 @@ def test_adam_step_clip2_is_clip_then_two_adam_groups(scale):
     pc, gc, mc, vc = (t.clone() for t in (p0, g0, m0, v0))
     ops.adam_step_clip2(pc, gc, mc, vc, ne, 10.0, hyper=state.view(torch.float32)[2:4], wd_first=0.05, wd_rest=0.0)
     assert torch.equal(pc, pb) and torch.equal(mc, mb) and torch.equal(vc, vb) and torch.equal(gc, gb)
+
+
+def test_captured_deepfm_and_mf_steps_are_reproducible_run_to_run():
+    """Two engines each, the same seeds and batches, a dozen captured steps: parameters identical bit for bit -- through re_fm_table_grad
+    (slices with one row and many keys, slices with many rows and few), the staging launch, the fused clip + Adam, and the owner launch's
+    two-set form (a table beyond 256 x 96 rows)."""
+    import numpy as np
+    from recboard_amd.deepfm import DeepFMEngine
+    from recboard_amd.gen import MFEngine
+    rng = np.random.default_rng(2)
+    counts, B = [30000, 7, 3, 900, 50], 1024
+    bs = [(torch.from_numpy(np.stack([rng.integers(0, c, B) for c in counts], 1)).cuda(), torch.from_numpy((rng.random((B, 1)) < 0.3).astype(np.int64)).cuda())
+          for _ in range(3)]
+    outs = []
+    for _ in range(2):
+        m = DeepFMEngine(counts, 10, (64, 64), batch_norm=True, hidden_dropout_rate=0.1, lr=1e-3, embedding_decay=0.05, seed=1)
+        for i in range(12):
+            m.train_step_graph(*bs[i % 3])
+        outs.append(m.data.clone())
+    assert torch.equal(*outs)
+    U, N, Bm = 20000, 9000, 512                       # 29 000 rows x 2 halves > 256 x 96: the wide owner form
+    tb = [tuple(torch.from_numpy(rng.integers(0, n, Bm)).cuda() for n in (U, N, N)) for _ in range(3)]
+    outs = []
+    for _ in range(2):
+        m = MFEngine(U, N, 64, lr=1e-3, weight_decay=1e-8, seed=1)
+        for i in range(12):
+            m.train_step_graph(*tb[i % 3])
+        outs.append(m.arena.data.clone())
+    assert torch.equal(*outs)
